@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch: a 2^30-sample complex<float> stream already resident in HBM
+-> 256-tap FIR -> 8192-point FFT frames -> |X|^2 (BASELINE.json configs[1]; rectangular window).
+N > 1 (configs[4] shape): every rank owns one SDR channel of the same size (weak scaling) and the per-frame spectra
+are summed over channels by an RCCL reduce_scatter that overlaps the next chunk's compute.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NTAPS, NFFT = 256, 8192
+ALGO_BYTES_PER_SAMPLE = 12.0  # 8 B complex<float> in + 4 B float mag2 out (fused lower bound)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(target_seconds: float = 12.0):
+    """Reference-faithful CPU path (oracle, -O3 -march=native like core/benchmarks/CMakeLists.txt:19-23) on a bounded
+    sample of the same workload.  Single chain == one thread (GR4 never splits one block chain across threads)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+
+    import oracle_lib as O
+    L = O.lib(fast=True)
+    b = O.design_taps_hamming_lowpass(NTAPS, 0.1)
+    x = O.signal_c32(42, 8 * NFFT)
+    t0 = time.perf_counter()
+    O.chain(b, x, NFFT, 0, truth=False, L=L)
+    dt = time.perf_counter() - t0
+    frames = int(max(8, min(4096, target_seconds / (dt / 8))))
+    x = O.signal_c32(42, frames * NFFT)
+    t0 = time.perf_counter()
+    O.chain(b, x, NFFT, 0, truth=False, L=L)
+    dt = time.perf_counter() - t0
+    return {"value": round(frames * NFFT / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{frames} frames x {NFFT} samples (one chain, float32 oracle restatement of fir_filter+FFT+mag2, 1 thread of {os.cpu_count()})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2-samples", type=int, default=30, help="stream length per step and rank (default 2^30 = configs[1])")
+    ap.add_argument("--log2-chunk", type=int, default=26, help="samples per launch")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 unfused, 2 fused time-domain, 3 fused frequency-domain")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import gnuradio4_amd as G
+    from gnuradio4_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+
+    n = 1 << args.log2_samples
+    chunk = min(1 << args.log2_chunk, n)
+    nchunks = n // chunk
+    frames_per_chunk = chunk // NFFT
+
+    # synthetic input, generated on the device (noise seed 42 + channel index, tone at 0.1 fs)
+    x = G.synth_c32(n, seed=42 + rank)
+    out = torch.empty((n // NFFT, NFFT), dtype=torch.float32, device="cuda")
+    rs_out = torch.empty((frames_per_chunk // world) * NFFT, dtype=torch.float32, device="cuda") if world > 1 else None
+    import numpy as np
+    k = np.arange(NTAPS, dtype=np.float64)
+    w = np.empty(NTAPS, np.float32)
+    capi.check(capi.lib().gr4hip_window_create(2, w.ctypes.data, NTAPS, 1.6), "window")
+    taps = (w.astype(np.float64) * 0.2 * np.sinc(0.2 * (k - (NTAPS - 1) / 2.0)))
+    taps = (taps / taps.sum()).astype(np.float32)  # Hamming windowed-sinc, fc = 0.1, DC gain 1
+    chain = G.Chain(taps, NFFT, "None", args.algo)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nchunks)]
+    kernel_ms = []
+
+    def step(record: bool):
+        chain.reset()
+        works = []
+        for c in range(nchunks):
+            xs = x[c * chunk:(c + 1) * chunk]
+            os_ = out[c * frames_per_chunk:(c + 1) * frames_per_chunk]
+            if record:
+                ev[c][0].record()
+            chain.process_bulk(xs, os_)
+            if record:
+                ev[c][1].record()
+            if world > 1:  # fan-in combiner (math::Add over channels) as reduce_scatter, async on RCCL's stream
+                works.append(dist.reduce_scatter_tensor(rs_out, os_.reshape(-1), op=dist.ReduceOp.SUM, async_op=True))
+        for wk in works:
+            wk.wait()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        # event times are read after the timed region
+    fence()
+    dt = time.perf_counter() - t0
+    for a, b_ in ev:  # last step's launches (all steps are identical work)
+        kernel_ms.append(a.elapsed_time(b_))
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        total_samples = float(n) * world * args.steps
+        value = total_samples / dt / 1e6
+        launch_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = chunk * ALGO_BYTES_PER_SAMPLE / (launch_ms * 1e-3) / 1e9
+        algo_names = {1: "fir_poly_kernel + fft_block_kernel (unfused)", 2: "chain_fused_td_kernel", 3: "chain_fused_fd_kernel"}
+        res = {
+            "metric": "Msamples/s through 256-tap cplx FIR->8192-pt FFT chain; %HBM roofline @1/2/4/8 GPU",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, 2^{args.log2_samples}-sample stream per GPU "
+                                   f"(BASELINE.json configs[1]), rectangular window, {nchunks} launches of 2^{args.log2_chunk} samples"
+                                   + (f"; {world} channels, RCCL reduce_scatter fan-in sum (configs[4] shape)" if world > 1 else ""),
+                       "chain_algo": algo_names.get(chain.algo, str(chain.algo)), "parallelism": f"{world} independent channel(s), 1 per GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": algo_names.get(chain.algo, str(chain.algo)),
+                         "algorithmic_bytes_per_launch": chunk * ALGO_BYTES_PER_SAMPLE, "avg_launch_ms": round(launch_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

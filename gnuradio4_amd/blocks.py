@@ -1,0 +1,348 @@
+"""Host-side (Python) mirror of the reference's block interface for the hot path, on top of include/gr4hip.h.
+
+Names, settings and error behaviour follow the reference blocks (citations relative to /root/reference):
+  fir_filter / iir_filter / BasicFilter / BasicDecimatingFilter / Decimator  blocks/filter/.../time_domain_filter.hpp
+  FFT                                                                         blocks/fourier/.../fft.hpp
+  math_const / math_nary (AddConst..Divide)                                   blocks/math/.../Math.hpp
+  Rotator                                                                     blocks/math/.../Rotator.hpp
+  Chain                                                                       the runtime fusion of fir_filter -> FFT -> mag2
+                                                                              (Merge<> analogue, core/.../BlockMerging.hpp:136-320)
+Blocks consume and produce torch tensors that live on the GPU (`process_bulk(x) -> y`); torch only provides the
+device memory and the current HIP stream.  Every block is device-only: without libgr4hip.so or without a GPU the
+constructor / call raises (Gr4HipError / ImportError) -- there is no CPU fallback in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import check, lib
+
+_TORCH_DTYPE = {
+    capi.U8: torch.uint8, capi.U16: torch.uint16, capi.U32: torch.uint32, capi.U64: torch.uint64,
+    capi.I8: torch.int8, capi.I16: torch.int16, capi.I32: torch.int32, capi.I64: torch.int64,
+    capi.F32: torch.float32, capi.F64: torch.float64, capi.C32: torch.complex64, capi.C64: torch.complex128,
+}
+_DTYPE_ID = {v: k for k, v in _TORCH_DTYPE.items()}
+_NP_DTYPE = [np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16, np.int32, np.int64,
+             np.float32, np.float64, np.complex64, np.complex128]
+_OPS = {"Add": capi.ADD, "Subtract": capi.SUB, "Multiply": capi.MUL, "Divide": capi.DIV,
+        "+": capi.ADD, "-": capi.SUB, "*": capi.MUL, "/": capi.DIV}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(x: torch.Tensor, what: str) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise capi.Gr4HipError(capi.INVALID_ARGUMENT, what, "input must be a CUDA/HIP torch tensor (device-only path)")
+    return x.contiguous()
+
+
+def _window_id(window) -> int:
+    if isinstance(window, str):
+        names = [w.lower() for w in capi.WINDOWS]
+        if window.lower() not in names:
+            raise ValueError(f"unknown window '{window}'")
+        return names.index(window.lower())
+    return int(window)
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and self._destroy:
+            getattr(lib(), self._destroy)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class fir_filter(_Handle):
+    """gr::filter::fir_filter<T> (time_domain_filter.hpp:22-48): settings `b`; T in {float32, complex64}."""
+    _destroy = "gr4hip_fir_destroy"
+
+    def __init__(self, b: Sequence[float], dtype=torch.float32, decimate: int = 1):
+        super().__init__()
+        self.b = np.ascontiguousarray(b, np.float32)
+        self.dtype = dtype
+        self.decimate = int(decimate)
+        check(lib().gr4hip_fir_create(C.byref(self._h), _DTYPE_ID[dtype], self.b.ctypes.data, len(self.b), self.decimate), "fir_filter")
+
+    def settings_changed(self, b: Sequence[float]):  # settingsChanged (:38-42)
+        self.b = np.ascontiguousarray(b, np.float32)
+        check(lib().gr4hip_fir_set_taps(self._h, self.b.ctypes.data, len(self.b)), "fir_filter.set_taps")
+
+    def reset(self):
+        check(lib().gr4hip_fir_reset(self._h), "fir_filter.reset")
+
+    def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _dev(x, "fir_filter")
+        if x.dtype != self.dtype:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "fir_filter", f"expected {self.dtype}, got {x.dtype}")
+        n_out = x.numel() // self.decimate
+        if out is None:
+            out = torch.empty(n_out, dtype=self.dtype, device=x.device)
+        check(lib().gr4hip_fir_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), None, _stream()), "fir_filter.process")
+        return out
+
+
+class iir_filter(_Handle):
+    """gr::filter::iir_filter<float, form> (time_domain_filter.hpp:62-122) or a cascade of sections
+    (gr::filter::Filter<float>, FilterTool.hpp:223-247).  b, a: [nsections][n] or 1-D for a single section."""
+    _destroy = "gr4hip_iir_destroy"
+
+    def __init__(self, b, a, form: int = capi.DF_II):
+        super().__init__()
+        b = np.atleast_2d(np.asarray(b, np.float32))
+        a = np.atleast_2d(np.asarray(a, np.float32))
+        if b.shape[0] != a.shape[0]:
+            raise ValueError("b and a need the same number of sections")
+        self.b, self.a, self.form = np.ascontiguousarray(b), np.ascontiguousarray(a), form
+        check(lib().gr4hip_iir_create(C.byref(self._h), form, b.shape[0], self.b.ctypes.data, b.shape[1], self.a.ctypes.data, a.shape[1]), "iir_filter")
+
+    def reset(self):
+        check(lib().gr4hip_iir_reset(self._h), "iir_filter.reset")
+
+    def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _dev(x, "iir_filter")
+        if x.dtype != torch.float32:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "iir_filter", "device path is registered for float32")
+        if out is None:
+            out = torch.empty_like(x)
+        check(lib().gr4hip_iir_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "iir_filter.process")
+        return out
+
+
+def design_fir(filter_response: int, order: int, f_low: float, f_high: float, sample_rate: float, window="Kaiser", gain=1.0,
+               attenuation_db=40.0, beta=1.6) -> np.ndarray:
+    """fir::designFilter<float> (FilterTool.hpp:1006-1071) through the library's host-side restatement."""
+    p = capi.FilterParams()
+    lib().gr4hip_filter_params_default(C.byref(p))
+    p.order, p.f_low, p.f_high, p.fs, p.gain, p.attenuation_db, p.beta = order, f_low, f_high, sample_rate, gain, attenuation_db, beta
+    n = C.c_size_t(0)
+    check(lib().gr4hip_fir_design(filter_response, C.byref(p), _window_id(window), None, 0, C.byref(n)), "fir_design")
+    taps = np.empty(n.value, np.float32)
+    check(lib().gr4hip_fir_design(filter_response, C.byref(p), _window_id(window), taps.ctypes.data, len(taps), C.byref(n)), "fir_design")
+    return taps
+
+
+def design_iir(filter_response: int, order: int, f_low: float, f_high: float, sample_rate: float, design: int = capi.BUTTERWORTH,
+               gain=1.0, ripple_db=0.1, attenuation_db=40.0):
+    """iir::designFilter<float> (FilterTool.hpp:848-917): biquad sections (b[ns][3], a[ns][3])."""
+    p = capi.FilterParams()
+    lib().gr4hip_filter_params_default(C.byref(p))
+    p.order, p.f_low, p.f_high, p.fs, p.gain, p.ripple_db, p.attenuation_db = order, f_low, f_high, sample_rate, gain, ripple_db, attenuation_db
+    b = np.zeros((32, 3), np.float32)
+    a = np.zeros((32, 3), np.float32)
+    ns = C.c_size_t(0)
+    check(lib().gr4hip_iir_design(filter_response, C.byref(p), design, b.ctypes.data, a.ctypes.data, 32, C.byref(ns)), "iir_design")
+    return b[:ns.value].copy(), a[:ns.value].copy()
+
+
+class BasicFilter:
+    """gr::filter::BasicFilterProto<float, Args...> (time_domain_filter.hpp:129-205), defaults :148-157."""
+
+    def __init__(self, filter_type="IIR", filter_response=capi.LOWPASS, filter_order=3, f_low=0.1, f_high=0.2, sample_rate=1.0,
+                 decimate=1, iir_design_method=capi.BUTTERWORTH, fir_design_method="Kaiser"):
+        self.filter_type, self.filter_response, self.filter_order = filter_type, filter_response, filter_order
+        self.f_low, self.f_high, self.sample_rate, self.decimate = f_low, f_high, sample_rate, int(decimate)
+        self.iir_design_method, self.fir_design_method = iir_design_method, fir_design_method
+        self.input_chunk_size = 1
+        self._fir = self._iir = None
+        self.design_filter()
+
+    def design_filter(self):  # designFilter() :163-182
+        self.input_chunk_size = self.decimate
+        if self.filter_type == "FIR":
+            self.taps = design_fir(self.filter_response, self.filter_order, self.f_low, self.f_high, self.sample_rate, self.fir_design_method)
+            self._fir, self._iir = fir_filter(self.taps, torch.float32, self.decimate), None
+        elif self.filter_type == "IIR":
+            self.sections = design_iir(self.filter_response, self.filter_order, self.f_low, self.f_high, self.sample_rate, self.iir_design_method)
+            self._iir, self._fir = iir_filter(*self.sections), None
+        else:
+            raise ValueError("filter_type must be 'FIR' or 'IIR'")
+
+    def process_bulk(self, x: torch.Tensor) -> torch.Tensor:  # :184-204
+        if self._fir is not None:
+            return self._fir.process_bulk(x)
+        y = self._iir.process_bulk(x)
+        return Decimator(self.decimate).process_bulk(y) if self.decimate > 1 else y
+
+
+BasicDecimatingFilter = BasicFilter  # BasicFilterProto<T, Resampling<1,1,false>> (:210-211): same class, decimate > 1
+
+
+class Decimator:
+    """gr::filter::Decimator<T> (time_domain_filter.hpp:215-245): keep every decim-th sample."""
+
+    def __init__(self, decim: int = 1):
+        self.decim = int(decim)
+        self.input_chunk_size = self.decim
+
+    def process_bulk(self, x: torch.Tensor) -> torch.Tensor:
+        x = _dev(x, "Decimator")
+        n_out = (x.numel() + self.decim - 1) // self.decim
+        out = torch.empty(n_out, dtype=x.dtype, device=x.device)
+        check(lib().gr4hip_decimate(_DTYPE_ID[x.dtype], x.data_ptr(), x.numel(), self.decim, out.data_ptr(), None, _stream()), "Decimator")
+        return out
+
+
+class FFT(_Handle):
+    """gr::blocks::fft::FFT<T> (blocks/fourier/.../fft.hpp:31-251): settings fftSize, window, outputInDb, outputInDeg,
+    unwrapPhase.  process_bulk returns a dict per call with the DataSet signals for all frames:
+    magnitude / phase / re / im tensors [frames, n] plus `ranges` [frames, 4, 2] (fft.hpp:173-250)."""
+    _destroy = "gr4hip_fft_destroy"
+
+    def __init__(self, fftSize: int = 1024, window="Hann", outputInDb=False, outputInDeg=False, unwrapPhase=False, dtype=torch.complex64,
+                 sample_rate: float = 1.0):
+        super().__init__()
+        self.fftSize, self.window, self.dtype, self.sample_rate = int(fftSize), window, dtype, sample_rate
+        self.outputInDb, self.outputInDeg, self.unwrapPhase = outputInDb, outputInDeg, unwrapPhase
+        flags = (capi.FFT_OUTPUT_IN_DB if outputInDb else 0) | (capi.FFT_OUTPUT_IN_DEG if outputInDeg else 0) | (capi.FFT_UNWRAP_PHASE if unwrapPhase else 0)
+        check(lib().gr4hip_fft_create(C.byref(self._h), _DTYPE_ID[dtype], self.fftSize, _window_id(window), flags), "FFT")
+        self.input_chunk_size = self.fftSize  # fft.hpp:131-134
+        self.n_out = self.fftSize if dtype == torch.complex64 else self.fftSize // 2
+
+    def _frames(self, x):
+        x = _dev(x, "FFT")
+        if x.dtype != self.dtype:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "FFT", f"expected {self.dtype}, got {x.dtype}")
+        return x, x.numel() // self.fftSize
+
+    def process_bulk(self, x: torch.Tensor, ranges: bool = True) -> dict:
+        x, frames = self._frames(x)
+        mk = lambda: torch.empty((frames, self.n_out), dtype=torch.float32, device=x.device)
+        out = {"magnitude": mk(), "phase": mk(), "re": mk(), "im": mk()}
+        rg = torch.empty((frames, 4, 2), dtype=torch.float32, device=x.device) if ranges else None
+        check(lib().gr4hip_fft_process(self._h, x.data_ptr(), frames, out["magnitude"].data_ptr(), out["phase"].data_ptr(), out["re"].data_ptr(),
+                                       out["im"].data_ptr(), rg.data_ptr() if ranges else None, _stream()), "FFT.process")
+        if ranges:
+            out["ranges"] = rg
+        n = self.n_out
+        fw = self.sample_rate / self.fftSize  # frequency axis (fft.hpp:187-193)
+        out["frequency"] = (np.arange(n) * fw - (n // 2) * fw) if self.dtype == torch.complex64 else np.arange(n) * fw
+        return out
+
+    def spectrum(self, x: torch.Tensor) -> torch.Tensor:
+        x, frames = self._frames(x)
+        out = torch.empty((frames, self.fftSize), dtype=torch.complex64, device=x.device)
+        check(lib().gr4hip_fft_spectrum(self._h, x.data_ptr(), frames, out.data_ptr(), _stream()), "FFT.spectrum")
+        return out
+
+    def mag2(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x, frames = self._frames(x)
+        if out is None:
+            out = torch.empty((frames, self.fftSize), dtype=torch.float32, device=x.device)
+        check(lib().gr4hip_fft_mag2(self._h, x.data_ptr(), frames, out.data_ptr(), _stream()), "FFT.mag2")
+        return out
+
+
+class Chain(_Handle):
+    """complex<float> fir_filter -> FFT frames -> |X|^2, one fused device pipeline (BASELINE.json configs[1])."""
+    _destroy = "gr4hip_chain_destroy"
+
+    def __init__(self, b: Sequence[float], fftSize: int = 8192, window="None", algo: int = capi.CHAIN_AUTO):
+        super().__init__()
+        self.b = np.ascontiguousarray(b, np.float32)
+        self.fftSize = int(fftSize)
+        check(lib().gr4hip_chain_create(C.byref(self._h), self.b.ctypes.data, len(self.b), self.fftSize, _window_id(window), algo), "Chain")
+        a = C.c_int(0)
+        check(lib().gr4hip_chain_get_algo(self._h, C.byref(a)), "Chain.algo")
+        self.algo = a.value
+
+    def reset(self):
+        check(lib().gr4hip_chain_reset(self._h), "Chain.reset")
+
+    def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _dev(x, "Chain")
+        if x.dtype != torch.complex64:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Chain", "input must be complex64")
+        frames = x.numel() // self.fftSize
+        if out is None:
+            out = torch.empty((frames, self.fftSize), dtype=torch.float32, device=x.device)
+        nf = C.c_size_t(0)
+        check(lib().gr4hip_chain_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), C.byref(nf), _stream()), "Chain.process")
+        return out
+
+
+def math_const(op, x: torch.Tensor, value) -> torch.Tensor:
+    """MathOpImpl<T,op>::processOne (Math.hpp:38-56): AddConst / SubtractConst / MultiplyConst / DivideConst."""
+    x = _dev(x, "math_const")
+    did = _DTYPE_ID[x.dtype]
+    v = np.array([value]).astype(_NP_DTYPE[did])
+    out = torch.empty_like(x)
+    check(lib().gr4hip_math_const(_OPS.get(op, op), did, x.data_ptr(), out.data_ptr(), x.numel(), v.ctypes.data, _stream()), "math_const")
+    return out
+
+
+def math_nary(op, inputs: Sequence[torch.Tensor]) -> torch.Tensor:
+    """MathOpMultiPortImpl<T,op>::processBulk (Math.hpp:100-107): Add / Subtract / Multiply / Divide over n_inputs."""
+    ins = [_dev(t, "math_nary") for t in inputs]
+    if not 1 <= len(ins) <= 32:
+        raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "math_nary", "n_inputs must be in [1, 32] (Math.hpp:90)")
+    if any(t.dtype != ins[0].dtype or t.numel() != ins[0].numel() for t in ins):
+        raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "math_nary", "all inputs need the same dtype and length")
+    ptrs = (C.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
+    out = torch.empty_like(ins[0])
+    check(lib().gr4hip_math_nary(_OPS.get(op, op), _DTYPE_ID[ins[0].dtype], ptrs, len(ins), out.data_ptr(), out.numel(), _stream()), "math_nary")
+    return out
+
+
+class Rotator(_Handle):
+    """gr::blocks::math::Rotator<complex<float>> (Rotator.hpp:16-63): XOR settings frequency_shift / phase_increment."""
+    _destroy = "gr4hip_rotator_destroy"
+
+    def __init__(self, phase_increment: Optional[float] = None, frequency_shift: Optional[float] = None, sample_rate: float = 1.0,
+                 initial_phase: float = 0.0):
+        super().__init__()
+        if phase_increment is not None and frequency_shift is not None:  # Rotator.hpp:45-46 throws
+            raise ValueError("cannot set both 'frequency_shift' and 'phase_increment' in new setting (XOR)")
+        self.sample_rate = np.float32(sample_rate)
+        if frequency_shift is not None:  # :41-42 (float arithmetic)
+            self.frequency_shift = np.float32(frequency_shift)
+            self.phase_increment = np.float32(2) * np.float32(np.float32(np.pi) * self.frequency_shift / self.sample_rate)
+        else:
+            self.phase_increment = np.float32(phase_increment or 0.0)
+            self.frequency_shift = np.float32(self.phase_increment / (np.float32(2) * np.float32(np.pi))) * self.sample_rate
+        self.initial_phase = np.float32(initial_phase)
+        check(lib().gr4hip_rotator_create(C.byref(self._h), float(self.phase_increment), float(self.initial_phase)), "Rotator")
+
+    def process_bulk(self, x: torch.Tensor) -> torch.Tensor:
+        x = _dev(x, "Rotator")
+        if x.dtype != torch.complex64:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Rotator", "device path is complex64")
+        out = torch.empty_like(x)
+        check(lib().gr4hip_rotator_process(self._h, x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "Rotator.process")
+        return out
+
+    @property
+    def accumulated_phase(self) -> float:
+        v = C.c_float(0)
+        check(lib().gr4hip_rotator_phase(self._h, C.byref(v), _stream()), "Rotator.phase")
+        return v.value
+
+
+def synth_c32(n: int, seed: int = 42, tone_frel: float = 0.1, tone_amp: float = 1.0, noise_amp: float = 1.0, device="cuda") -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.complex64, device=device)
+    check(lib().gr4hip_synth_c32(out.data_ptr(), n, seed, tone_frel, tone_amp, noise_amp, _stream()), "synth_c32")
+    return out
+
+
+def synth_f32(n: int, seed: int = 42, tone_frel: float = 0.1, tone_amp: float = 1.0, noise_amp: float = 1.0, device="cuda") -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(lib().gr4hip_synth_f32(out.data_ptr(), n, seed, tone_frel, tone_amp, noise_amp, _stream()), "synth_f32")
+    return out

@@ -1,0 +1,20 @@
+#!/bin/bash
+# builds gnuradio4_amd/libgr4hip.so for gfx950 (hipcc cross-compiles without a GPU)
+set -e
+cd "$(dirname "$0")"
+OUT=../libgr4hip.so
+SRCS="runtime.hip fir.hip fft.hip math.hip iir.hip chain.hip chain_fused.hip fir_batched.hip design.hip"
+mkdir -p ../../build/obj
+OBJS=""
+pids=()
+for s in $SRCS; do
+  o=../../build/obj/${s%.hip}.o
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.hpp -nt "$o" ] || [ ../../include/gr4hip.h -nt "$o" ]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+echo "built $(realpath $OUT)"

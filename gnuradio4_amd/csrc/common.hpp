@@ -1,0 +1,74 @@
+// common.hpp -- shared helpers of libgr4hip (gfx950 only; no CUDA/compat paths).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/gr4hip.h"
+
+namespace gr4 {
+
+void set_error(const char* fmt, ...);
+
+#define GR4_HIP_TRY(expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ::gr4::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return GR4HIP_RUNTIME_ERROR;                                                               \
+        }                                                                                              \
+    } while (0)
+
+#define GR4_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            ::gr4::set_error(__VA_ARGS__);    \
+            return GR4HIP_INVALID_ARGUMENT;   \
+        }                                     \
+    } while (0)
+
+#define GR4_LAUNCH_CHECK()                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) {                                                                 \
+            ::gr4::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return GR4HIP_RUNTIME_ERROR;                                                        \
+        }                                                                                       \
+    } while (0)
+
+inline hipStream_t as_stream(gr4hip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline size_t dtype_size(int dtype) {
+    static const size_t s[12] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 8, 16};
+    return (dtype >= 0 && dtype < 12) ? s[dtype] : 0;
+}
+
+inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+inline int  ilog2(size_t n) { int l = 0; while ((size_t(1) << l) < n) ++l; return l; }
+template <typename T> inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+// small RAII device buffer used inside handles (grow-only)
+struct DeviceBuffer {
+    void*  ptr   = nullptr;
+    size_t bytes = 0;
+    int    ensure(size_t need) {
+        if (need <= bytes) return GR4HIP_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr   = nullptr;
+        bytes = 0;
+        GR4_HIP_TRY(hipMalloc(&ptr, need));
+        bytes = need;
+        return GR4HIP_OK;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+    ~DeviceBuffer() { release(); }
+};
+
+// host-side restatement of gr::algorithm::window::create<float> (algorithm/.../fourier/window.hpp:69-183)
+int make_window(int type, float* w, size_t n, float beta);
+
+} // namespace gr4

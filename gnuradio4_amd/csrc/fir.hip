@@ -1,0 +1,314 @@
+// fir.hip -- time-domain FIR / polyphase decimating FIR / Decimator kernels for gfx950.
+//
+// Replaces gr::filter::fir_filter<T>::processOne (blocks/filter/.../time_domain_filter.hpp:44-47; per-sample
+// HistoryBuffer::push_front + K-term transform_reduce driven by Block.hpp:1723-1761) and the decimating
+// BasicFilterProto::processBulk (:190-204) by one launch per work() span:
+//   * the input span (+ the K-1 history samples carried in HBM between launches) is staged once into LDS,
+//     de-interleaved by polyphase branch when decim > 1, so every input sample is read from HBM exactly once;
+//   * each lane owns 8 consecutive output floats and slides a 12-float register window over its LDS row:
+//     one ds_read_b128 of samples + one broadcast ds_read of taps feeds 32 (real) / 16 (complex) FMAs;
+//   * complex<float> data x real taps is the same kernel on the interleaved float view with a tap stride of 2.
+// Bound: FP32 FMA rate (2K flop per real output sample), not HBM -- see DESIGN.md "fir_poly".
+#include "common.hpp"
+
+namespace gr4 {
+
+constexpr int kFirR = 8; // output floats per lane
+
+template <int S, int ROT>
+__device__ __forceinline__ void fir_step(float (&acc)[kFirR], float (&w)[12], const float* __restrict__ tg, const float* __restrict__ xnext, bool load_next) {
+    constexpr int E = 4 / S; // taps consumed per 4-float window advance
+    float         tb[E];
+    if constexpr (S == 1) {
+        const float4 t4 = *reinterpret_cast<const float4*>(tg);
+        tb[0] = t4.x; tb[1] = t4.y; tb[2] = t4.z; tb[3] = t4.w;
+    } else {
+        const float2 t2 = *reinterpret_cast<const float2*>(tg);
+        tb[0] = t2.x; tb[1] = t2.y;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int r = 0; r < kFirR; ++r) acc[r] = fmaf(tb[e], w[((4 + r - S * e) + 4 * ROT) % 12], acc[r]);
+    if (load_next) { // the chunk that just left the window (logical 8..11) is refilled with the next lower chunk
+        const float4 n4 = *reinterpret_cast<const float4*>(xnext);
+        w[(8 + 4 * ROT) % 12 + 0] = n4.x;
+        w[(8 + 4 * ROT) % 12 + 1] = n4.y;
+        w[(8 + 4 * ROT) % 12 + 2] = n4.z;
+        w[(8 + 4 * ROT) % 12 + 3] = n4.w;
+    }
+}
+
+// x: n_in samples; hist: the last `hcap` input samples before x (oldest first); tp: [D][Qpad] phase-major taps
+// (tp[p][q] = b[q*D + p], zero padded); y: n_out samples, y[m] = sum_k b[k] x[m*D - k].
+template <int S, int BS>
+__global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ x, const float* __restrict__ hist, const float* __restrict__ tp,
+                                                       float* __restrict__ y, long n_in, long n_out, int hcap, int D, int G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R  = kFirR;
+    constexpr int E  = 4 / S;
+    const int     Lf = BS * R + 4 * G; // floats per phase row
+    const int     Qp = G * E;          // padded taps per phase
+    float*        xl = smem;           // [D][Lf]
+    float*        bl = smem + (size_t)D * Lf; // [D][Qp]
+    const int     tid   = threadIdx.x;
+    const long    M0    = (long)blockIdx.x * (BS * R / S); // first output sample of this block
+    const long    jbase = M0 - (4 * G) / S;                // first phase-stream sample held in LDS
+    const int     Ls    = Lf / S;                          // samples per phase row
+
+    for (int i = tid; i < D * Qp; i += BS) bl[i] = tp[i];
+
+    // ---- stage inputs: u enumerates input samples i = i_lo + u; sample i belongs to phase p = (-i) mod D at j = ceil(i/D)
+    const long i_lo  = jbase * D - (D - 1);
+    const long total = (long)Ls * D;
+    if (D == 1 && S == 1) {
+        for (long u4 = (long)tid * 4; u4 < total; u4 += (long)BS * 4) { // i_lo is a multiple of 4 here
+            const long i = i_lo + u4;
+            float4     v;
+            if (i >= 0 && i + 3 < n_in) {
+                v = *reinterpret_cast<const float4*>(x + i);
+            } else {
+                float t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const long ii = i + c;
+                    t[c] = (ii >= 0) ? (ii < n_in ? x[ii] : 0.f) : (ii >= -(long)hcap ? hist[hcap + ii] : 0.f);
+                }
+                v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            *reinterpret_cast<float4*>(xl + u4) = v;
+        }
+    } else if (D == 1 && S == 2) {
+        for (long u2 = (long)tid * 2; u2 < total; u2 += (long)BS * 2) { // two complex samples = one float4
+            const long i = i_lo + u2;
+            float4     v;
+            if (i >= 0 && i + 1 < n_in) {
+                v = *reinterpret_cast<const float4*>(x + 2 * i);
+            } else {
+                float t[4];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const long   ii = i + c;
+                    const float* p  = (ii >= 0) ? (ii < n_in ? x + 2 * ii : nullptr) : (ii >= -(long)hcap ? hist + 2 * (hcap + ii) : nullptr);
+                    t[2 * c]     = p ? p[0] : 0.f;
+                    t[2 * c + 1] = p ? p[1] : 0.f;
+                }
+                v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            *reinterpret_cast<float4*>(xl + 2 * u2) = v;
+        }
+    } else {
+        for (long u = tid; u < total; u += BS) {
+            const long   i  = i_lo + u;
+            const int    jl = (int)(u / D);
+            const int    p  = D - 1 - (int)(u % D);
+            const float* src = (i >= 0) ? (i < n_in ? x + S * i : nullptr) : (i >= -(long)hcap ? hist + S * (hcap + i) : nullptr);
+            float*       dst = xl + (size_t)p * Lf + (size_t)jl * S;
+#pragma unroll
+            for (int c = 0; c < S; ++c) dst[c] = src ? src[c] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    const int c0 = tid * R + 4 * G; // local float index of this lane's first output sample's x[m*D] position
+    for (int p = 0; p < D; ++p) {
+        const float* row = xl + (size_t)p * Lf;
+        const float* tg  = bl + (size_t)p * Qp;
+        float        w[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(row + c0 - 4 + 4 * q);
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        int g = 0;
+        for (; g + 3 <= G; g += 3) { // window rotation sequence ROT = 0,2,1 (three steps return to ROT 0)
+            fir_step<S, 0>(acc, w, tg + (g + 0) * E, row + c0 - 4 * (g + 0) - 8, (g + 1) < G);
+            fir_step<S, 2>(acc, w, tg + (g + 1) * E, row + c0 - 4 * (g + 1) - 8, (g + 2) < G);
+            fir_step<S, 1>(acc, w, tg + (g + 2) * E, row + c0 - 4 * (g + 2) - 8, (g + 3) < G);
+        }
+        if (g < G) {
+            fir_step<S, 0>(acc, w, tg + g * E, row + c0 - 4 * g - 8, (g + 1) < G);
+            if (g + 1 < G) fir_step<S, 2>(acc, w, tg + (g + 1) * E, row + c0 - 4 * (g + 1) - 8, false);
+        }
+    }
+
+    const long of    = M0 * S + (long)tid * R; // first output float of this lane
+    const long nf    = n_out * S;
+    if (of + R <= nf) {
+        *reinterpret_cast<float4*>(y + of)     = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(y + of + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (of + r < nf) y[of + r] = acc[r];
+    }
+}
+
+// new_hist[h] = virtual_input[n_in - hcap + h]  (virtual_input(i<0) = old_hist[hcap + i])
+__global__ void fir_hist_update_kernel(const float* __restrict__ x, const float* __restrict__ old_hist, float* __restrict__ new_hist, long n_in,
+                                       int hcap, int S) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)hcap * S) return;
+    const long h = t / S, c = t % S;
+    const long i = n_in - hcap + h;
+    new_hist[t]  = (i >= 0) ? x[i * S + c] : old_hist[(hcap + i) * S + c];
+}
+
+template <typename V>
+__global__ void decimate_kernel(const V* __restrict__ in, V* __restrict__ out, long n_out, long decim) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < n_out; m += stride) out[m] = in[m * decim];
+}
+
+} // namespace gr4
+
+using namespace gr4;
+
+struct gr4hip_fir {
+    int                dtype = GR4HIP_F32;
+    int                S     = 1;
+    size_t             ntaps = 0, decim = 1;
+    size_t             hcap  = 32; // HistoryBuffer capacity (time_domain_filter.hpp:36: inputHistory{32})
+    std::vector<float> taps;
+    int                G = 0;      // tap groups per phase
+    DeviceBuffer       d_taps;     // [D][Qpad]
+    DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
+    int                cur = 0;
+};
+
+static size_t bit_ceil_sz(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
+
+static int fir_upload_taps(gr4hip_fir* f) {
+    const size_t D = f->decim, K = f->ntaps;
+    const int    E = 4 / f->S;
+    const size_t Q = ceil_div(K, D);
+    f->G           = (int)ceil_div(Q, (size_t)E);
+    const size_t Qp = (size_t)f->G * E;
+    std::vector<float> tp(D * Qp, 0.f);
+    for (size_t k = 0; k < K; ++k) tp[(k % D) * Qp + (k / D)] = f->taps[k];
+    int rc = f->d_taps.ensure(tp.size() * sizeof(float));
+    if (rc) return rc;
+    GR4_HIP_TRY(hipMemcpy(f->d_taps.ptr, tp.data(), tp.size() * sizeof(float), hipMemcpyHostToDevice));
+    return GR4HIP_OK;
+}
+
+static int fir_alloc_hist(gr4hip_fir* f) {
+    const size_t bytes = f->hcap * f->S * sizeof(float);
+    for (int k = 0; k < 2; ++k) {
+        int rc = f->d_hist[k].ensure(bytes);
+        if (rc) return rc;
+        GR4_HIP_TRY(hipMemset(f->d_hist[k].ptr, 0, bytes));
+    }
+    f->cur = 0;
+    return GR4HIP_OK;
+}
+
+template <int S, int BS>
+static int fir_launch(const gr4hip_fir* f, const float* x, float* y, long n_in, long n_out, size_t lds, hipStream_t st) {
+    auto kern = fir_poly_kernel<S, BS>;
+    if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long TOs  = BS * kFirR / S;
+    const long grid = ceil_div(n_out, TOs);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, st, x, (const float*)f->d_hist[f->cur].ptr, (const float*)f->d_taps.ptr, y, n_in, n_out,
+                       (int)f->hcap, (int)f->decim, f->G);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+extern "C" {
+
+int gr4hip_fir_create(gr4hip_fir_t** out, int dtype, const float* h_taps, size_t ntaps, size_t decim) {
+    GR4_REQUIRE(out, "fir: null output handle");
+    GR4_REQUIRE(dtype == GR4HIP_F32 || dtype == GR4HIP_C32, "fir: dtype must be F32 or C32 (got %d)", dtype);
+    GR4_REQUIRE(h_taps && ntaps >= 1, "fir: need at least one tap");
+    GR4_REQUIRE(decim >= 1, "fir: decim must be >= 1");
+    auto* f = new (std::nothrow) gr4hip_fir();
+    GR4_REQUIRE(f, "out of host memory");
+    f->dtype = dtype;
+    f->S     = dtype == GR4HIP_C32 ? 2 : 1;
+    f->decim = decim;
+    f->ntaps = ntaps;
+    f->taps.assign(h_taps, h_taps + ntaps);
+    if (ntaps > f->hcap) f->hcap = bit_ceil_sz(ntaps); // time_domain_filter.hpp:38-42
+    int rc = fir_upload_taps(f);
+    if (!rc) rc = fir_alloc_hist(f);
+    if (rc) { delete f; return rc; }
+    *out = f;
+    return GR4HIP_OK;
+}
+
+int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
+    GR4_REQUIRE(f && h_taps && ntaps >= 1, "fir_set_taps: bad arguments");
+    f->taps.assign(h_taps, h_taps + ntaps);
+    f->ntaps = ntaps;
+    int rc   = fir_upload_taps(f);
+    if (rc) return rc;
+    if (ntaps > f->hcap) { // the reference replaces the HistoryBuffer (history is lost) only when it must grow
+        f->hcap = bit_ceil_sz(ntaps);
+        return fir_alloc_hist(f);
+    }
+    return GR4HIP_OK;
+}
+
+int gr4hip_fir_reset(gr4hip_fir_t* f) {
+    GR4_REQUIRE(f, "fir_reset: null handle");
+    return fir_alloc_hist(f);
+}
+
+int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
+    GR4_REQUIRE(f, "fir_process: null handle");
+    GR4_REQUIRE(n_in % f->decim == 0, "fir_process: n_in=%zu is not a multiple of decim=%zu", n_in, f->decim);
+    const size_t n_out = n_in / f->decim;
+    if (n_out_p) *n_out_p = n_out;
+    if (n_in == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out, "fir_process: null device pointer");
+    hipStream_t st = as_stream(stream);
+    const int   E  = 4 / f->S;
+    int         rc = GR4HIP_UNSUPPORTED;
+    for (int bs : {256, 128, 64}) {
+        const size_t Lf  = (size_t)bs * kFirR + 4 * (size_t)f->G;
+        const size_t lds = f->decim * (Lf + (size_t)f->G * E) * sizeof(float);
+        if (lds > 150 * 1024) continue;
+        const float* x = static_cast<const float*>(d_in);
+        float*       y = static_cast<float*>(d_out);
+        if (f->S == 1) rc = bs == 256 ? fir_launch<1, 256>(f, x, y, n_in, n_out, lds, st) : bs == 128 ? fir_launch<1, 128>(f, x, y, n_in, n_out, lds, st) : fir_launch<1, 64>(f, x, y, n_in, n_out, lds, st);
+        else rc = bs == 256 ? fir_launch<2, 256>(f, x, y, n_in, n_out, lds, st) : bs == 128 ? fir_launch<2, 128>(f, x, y, n_in, n_out, lds, st) : fir_launch<2, 64>(f, x, y, n_in, n_out, lds, st);
+        break;
+    }
+    if (rc == GR4HIP_UNSUPPORTED) { set_error("fir_process: ntaps=%zu decim=%zu does not fit the LDS tiling", f->ntaps, f->decim); return rc; }
+    if (rc) return rc;
+    const long tot = (long)f->hcap * f->S;
+    hipLaunchKernelGGL(fir_hist_update_kernel, dim3((unsigned)ceil_div(tot, 256L)), dim3(256), 0, st, static_cast<const float*>(d_in),
+                       (const float*)f->d_hist[f->cur].ptr, (float*)f->d_hist[f->cur ^ 1].ptr, (long)n_in, (int)f->hcap, f->S);
+    GR4_LAUNCH_CHECK();
+    f->cur ^= 1;
+    return GR4HIP_OK;
+}
+
+int gr4hip_fir_destroy(gr4hip_fir_t* f) { delete f; return GR4HIP_OK; }
+
+int gr4hip_decimate(int dtype, const void* d_in, size_t n_in, size_t decim, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
+    const size_t es = dtype_size(dtype);
+    GR4_REQUIRE(es, "decimate: unknown dtype %d", dtype);
+    GR4_REQUIRE(decim >= 1, "decimate: decim must be >= 1");
+    const size_t n_out = ceil_div(n_in, decim); // i % decim == 0 for i in [0, n_in)
+    if (n_out_p) *n_out_p = n_out;
+    if (n_out == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out, "decimate: null device pointer");
+    const unsigned grid = (unsigned)std::min<size_t>(ceil_div(n_out, (size_t)256), 4096);
+    hipStream_t    st   = as_stream(stream);
+    switch (es) {
+    case 1: hipLaunchKernelGGL(decimate_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, (const uint8_t*)d_in, (uint8_t*)d_out, (long)n_out, (long)decim); break;
+    case 2: hipLaunchKernelGGL(decimate_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, (const uint16_t*)d_in, (uint16_t*)d_out, (long)n_out, (long)decim); break;
+    case 4: hipLaunchKernelGGL(decimate_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, (const uint32_t*)d_in, (uint32_t*)d_out, (long)n_out, (long)decim); break;
+    case 8: hipLaunchKernelGGL(decimate_kernel<uint64_t>, dim3(grid), dim3(256), 0, st, (const uint64_t*)d_in, (uint64_t*)d_out, (long)n_out, (long)decim); break;
+    default: hipLaunchKernelGGL(decimate_kernel<ulonglong2>, dim3(grid), dim3(256), 0, st, (const ulonglong2*)d_in, (ulonglong2*)d_out, (long)n_out, (long)decim); break;
+    }
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,327 @@
+// math.hip -- blocks/math kernels (MathOpImpl, MathOpMultiPortImpl, Rotator) and the synthetic-input generator.
+//
+// MathOpImpl<T,op>::processOne (blocks/math/.../Math.hpp:38-56) and MathOpMultiPortImpl::processBulk (:100-107) are
+// pure streaming element-wise work: HBM-bound, 16-byte vector accesses, grid-stride, all n_inputs streams folded in
+// ONE pass (the reference makes n-1 passes over the output).  Integer types keep C++ semantics: operands promoted,
+// result narrowed back to T (wrap-around) -- bit-exact against the oracle.
+#include "common.hpp"
+
+namespace gr4 {
+
+template <typename T> struct Wide { using type = T; };
+template <> struct Wide<uint8_t> { using type = int; };   // integral promotion (Math.hpp:54: op()(a, value) on T operands)
+template <> struct Wide<uint16_t> { using type = int; };
+template <> struct Wide<int8_t> { using type = int; };
+template <> struct Wide<int16_t> { using type = int; };
+template <> struct Wide<int32_t> { using type = uint32_t; }; // wrap-around without signed-overflow UB (+,-,*)
+template <> struct Wide<int64_t> { using type = uint64_t; };
+
+template <typename T, int OP>
+__device__ __forceinline__ T apply_op(T a, T b) {
+    if constexpr (OP == GR4HIP_DIV) {
+        if constexpr (std::is_integral_v<T>) return b == T(0) ? T(0) : (T)(a / b); // x/0 is UB in the reference; defined as 0 here
+        else return a / b;
+    } else {
+        using W = typename Wide<T>::type;
+        const W x = (W)a, y = (W)b;
+        if constexpr (OP == GR4HIP_ADD) return (T)(x + y);
+        else if constexpr (OP == GR4HIP_SUB) return (T)(x - y);
+        else return (T)(x * y);
+    }
+}
+
+// std::complex<T> arithmetic on interleaved pairs
+template <typename F2, int OP>
+__device__ __forceinline__ F2 apply_cop(F2 a, F2 b) {
+    F2 r;
+    if constexpr (OP == GR4HIP_ADD) { r.x = a.x + b.x; r.y = a.y + b.y; }
+    else if constexpr (OP == GR4HIP_SUB) { r.x = a.x - b.x; r.y = a.y - b.y; }
+    else if constexpr (OP == GR4HIP_MUL) { r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; }
+    else {
+        const auto d = b.x * b.x + b.y * b.y;
+        r.x = (a.x * b.x + a.y * b.y) / d;
+        r.y = (a.y * b.x - a.x * b.y) / d;
+    }
+    return r;
+}
+
+template <typename T, int OP>
+__device__ __forceinline__ T apply_any(T a, T b) {
+    if constexpr (std::is_same_v<T, float2> || std::is_same_v<T, double2>) return apply_cop<T, OP>(a, b);
+    else return apply_op<T, OP>(a, b);
+}
+
+constexpr int kMaxInputs = 32; // Math.hpp:90 Limits<1U, 32U>
+struct NaryPtrs { const void* p[kMaxInputs]; };
+
+template <typename T> union Vec16 { uint4 u; T e[16 / sizeof(T)]; };
+
+// out[i] = ((in0[i] op in1[i]) op in2[i]) ...   or, with CONST, out[i] = in0[i] op value
+template <typename T, int OP, bool CONST>
+__global__ void math_kernel(NaryPtrs ins, int n_inputs, T value, T* __restrict__ out, long n) {
+    constexpr int VE     = 16 / sizeof(T);
+    const long    nvec   = n / VE;
+    const long    stride = (long)gridDim.x * blockDim.x;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        Vec16<T> acc;
+        acc.u = reinterpret_cast<const uint4*>(ins.p[0])[v];
+        if constexpr (CONST) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc.e[e] = apply_any<T, OP>(acc.e[e], value);
+        } else {
+            for (int k = 1; k < n_inputs; ++k) {
+                Vec16<T> b;
+                b.u = reinterpret_cast<const uint4*>(ins.p[k])[v];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc.e[e] = apply_any<T, OP>(acc.e[e], b.e[e]);
+            }
+        }
+        reinterpret_cast<uint4*>(out)[v] = acc.u;
+    }
+    for (long i = nvec * VE + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { // tail
+        T a = static_cast<const T*>(ins.p[0])[i];
+        if constexpr (CONST) a = apply_any<T, OP>(a, value);
+        else
+            for (int k = 1; k < n_inputs; ++k) a = apply_any<T, OP>(a, static_cast<const T*>(ins.p[k])[i]);
+        out[i] = a;
+    }
+}
+
+template <typename T, bool CONST>
+static int math_dispatch_op(int op, const NaryPtrs& ins, int n_inputs, T value, void* out, long n, hipStream_t st) {
+    const unsigned grid = (unsigned)std::min<long>(std::max<long>(ceil_div(n / (long)(16 / sizeof(T)) + 1, 256L), 1L), 256L * 8);
+    T*             o    = static_cast<T*>(out);
+    switch (op) {
+    case GR4HIP_ADD: hipLaunchKernelGGL((math_kernel<T, GR4HIP_ADD, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
+    case GR4HIP_SUB: hipLaunchKernelGGL((math_kernel<T, GR4HIP_SUB, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
+    case GR4HIP_MUL: hipLaunchKernelGGL((math_kernel<T, GR4HIP_MUL, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
+    case GR4HIP_DIV: hipLaunchKernelGGL((math_kernel<T, GR4HIP_DIV, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
+    default: set_error("math: unknown op %d", op); return GR4HIP_INVALID_ARGUMENT;
+    }
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+template <bool CONST>
+static int math_dispatch(int op, int dtype, const NaryPtrs& ins, int n_inputs, const void* h_value, void* out, long n, hipStream_t st) {
+#define GR4_CASE(ID, T)                                                              \
+    case ID: {                                                                       \
+        T v{};                                                                       \
+        if (CONST) memcpy(&v, h_value, sizeof(T));                                   \
+        return math_dispatch_op<T, CONST>(op, ins, n_inputs, v, out, n, st);         \
+    }
+    switch (dtype) {
+        GR4_CASE(GR4HIP_U8, uint8_t)
+        GR4_CASE(GR4HIP_U16, uint16_t)
+        GR4_CASE(GR4HIP_U32, uint32_t)
+        GR4_CASE(GR4HIP_U64, uint64_t)
+        GR4_CASE(GR4HIP_I8, int8_t)
+        GR4_CASE(GR4HIP_I16, int16_t)
+        GR4_CASE(GR4HIP_I32, int32_t)
+        GR4_CASE(GR4HIP_I64, int64_t)
+        GR4_CASE(GR4HIP_F32, float)
+        GR4_CASE(GR4HIP_F64, double)
+        GR4_CASE(GR4HIP_C32, float2)
+        GR4_CASE(GR4HIP_C64, double2)
+    default: set_error("math: unknown dtype %d", dtype); return GR4HIP_INVALID_ARGUMENT;
+    }
+#undef GR4_CASE
+}
+
+// ------------------------------------------------------------------------------------------------ rotator
+// Rotator.hpp:51-61.  The float phase recurrence is inherently sequential and is reproduced exactly:
+// one lane walks the recurrence and leaves a checkpoint every kRotChunk samples; the data pass then replays
+// kRotChunk steps per lane into LDS and applies cos/sin with fully coalesced 8-byte accesses.
+constexpr int kRotChunk = 32;
+
+__device__ __forceinline__ float rot_step(float ph, float inc) {
+    const float two_pi = 2.0f * 3.14159265358979323846f;
+    ph += inc;
+    if (ph > two_pi) ph -= two_pi;
+    else if (ph < 0.0f) ph += two_pi;
+    return ph;
+}
+
+__global__ void rotator_checkpoint_kernel(float* __restrict__ state, float inc, float* __restrict__ ckpt, long n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ph = *state;
+    for (long i = 0; i < n; ++i) {
+        if ((i % kRotChunk) == 0) ckpt[i / kRotChunk] = ph;
+        ph = rot_step(ph, inc);
+    }
+    *state = ph;
+}
+
+__global__ __launch_bounds__(256) void rotator_apply_kernel(const float2* __restrict__ x, float2* __restrict__ y, const float* __restrict__ ckpt, float inc, long n) {
+    __shared__ float ph[256 * (kRotChunk + 1)];
+    const long       base  = (long)blockIdx.x * 256 * kRotChunk;
+    const long       chunk = (long)blockIdx.x * 256 + threadIdx.x;
+    if (chunk * kRotChunk < n) {
+        float p = ckpt[chunk];
+#pragma unroll 8
+        for (int i = 0; i < kRotChunk; ++i) {
+            p = rot_step(p, inc);
+            ph[threadIdx.x * (kRotChunk + 1) + i] = p;
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < 256 * kRotChunk; s += 256) {
+        const long i = base + s;
+        if (i >= n) break;
+        const float p = ph[(s / kRotChunk) * (kRotChunk + 1) + (s % kRotChunk)];
+        float       sn, cs;
+        sincosf(p, &sn, &cs);
+        const float2 v = x[i];
+        y[i] = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ synthetic input
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& x) {
+    uint64_t z = (x += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+struct Xo { uint64_t s0, s1, s2, s3; };
+__device__ __forceinline__ uint64_t xo_next(Xo& s) { // Xoshiro256pp.hpp:41-51
+    const uint64_t r = rotl64(s.s0 + s.s3, 23) + s.s0, t = s.s1 << 17;
+    s.s2 ^= s.s0; s.s3 ^= s.s1; s.s1 ^= s.s2; s.s0 ^= s.s3; s.s2 ^= t; s.s3 = rotl64(s.s3, 45);
+    return r;
+}
+__device__ __forceinline__ void polar_pair(Xo& s, float& g1, float& g2) { // GaussianNoise.hpp:101-111
+    float u, v, q;
+    do {
+        u = 2.0f * ((float)(xo_next(s) >> 40) * 0x1.0p-24f) - 1.0f;
+        v = 2.0f * ((float)(xo_next(s) >> 40) * 0x1.0p-24f) - 1.0f;
+        q = u * u + v * v;
+    } while (q >= 1.0f || q == 0.0f);
+    const float f = sqrtf(-2.0f * logf(q) / q);
+    g1 = u * f;
+    g2 = v * f;
+}
+
+template <bool COMPLEX>
+__global__ void synth_kernel(float* __restrict__ out, long n, uint64_t seed, double frel, float tone_amp, float noise_amp) {
+    constexpr int PER    = 8; // samples per lane per visit
+    const long    stride = (long)gridDim.x * blockDim.x * PER;
+    for (long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * PER; i0 < n; i0 += stride) {
+        uint64_t sm = seed ^ (0xd1b54a32d192ed03ULL * (uint64_t)(i0 / PER + 1));
+        Xo       s{splitmix64(sm), splitmix64(sm), splitmix64(sm), splitmix64(sm)};
+        for (int k = 0; k < PER && i0 + k < n; COMPLEX ? ++k : k += 2) {
+            float g1, g2;
+            polar_pair(s, g1, g2);
+            const long i = i0 + k;
+            if constexpr (COMPLEX) {
+                double sn, cs;
+                const double ph = frel * (double)i;
+                sincospi(2.0 * (ph - floor(ph)), &sn, &cs);
+                out[2 * i]     = noise_amp * 0.70710678118654752440f * g1 + (float)(tone_amp * cs);
+                out[2 * i + 1] = noise_amp * 0.70710678118654752440f * g2 + (float)(tone_amp * sn);
+            } else {
+                const double p0 = frel * (double)i, p1 = frel * (double)(i + 1);
+                out[i] = noise_amp * g1 + (float)(tone_amp * sinpi(2.0 * (p0 - floor(p0))));
+                if (i + 1 < n) out[i + 1] = noise_amp * g2 + (float)(tone_amp * sinpi(2.0 * (p1 - floor(p1))));
+            }
+        }
+    }
+}
+
+} // namespace gr4
+
+using namespace gr4;
+
+struct gr4hip_rotator {
+    float        inc = 0.f;
+    DeviceBuffer d_state; // one float: _accumulated_phase
+    DeviceBuffer d_ckpt;
+};
+
+extern "C" {
+
+int gr4hip_math_const(int op, int dtype, const void* d_in, void* d_out, size_t n, const void* h_value, gr4hip_stream_t stream) {
+    GR4_REQUIRE(h_value, "math_const: null value");
+    if (n == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out, "math_const: null device pointer");
+    GR4_REQUIRE(((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 16 == 0), "math_const: device pointers must be 16-byte aligned");
+    NaryPtrs ins{};
+    ins.p[0] = d_in;
+    return math_dispatch<true>(op, dtype, ins, 1, h_value, d_out, (long)n, as_stream(stream));
+}
+
+int gr4hip_math_nary(int op, int dtype, const void* const* h_d_ins, size_t n_inputs, void* d_out, size_t n, gr4hip_stream_t stream) {
+    GR4_REQUIRE(h_d_ins && n_inputs >= 1 && n_inputs <= (size_t)kMaxInputs, "math_nary: n_inputs must be in [1,32] (Math.hpp:90), got %zu", n_inputs);
+    if (n == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_out && ((uintptr_t)d_out % 16 == 0), "math_nary: output must be a 16-byte aligned device pointer");
+    NaryPtrs ins{};
+    for (size_t k = 0; k < n_inputs; ++k) {
+        GR4_REQUIRE(h_d_ins[k] && ((uintptr_t)h_d_ins[k] % 16 == 0), "math_nary: input %zu must be a 16-byte aligned device pointer", k);
+        ins.p[k] = h_d_ins[k];
+    }
+    return math_dispatch<false>(op, dtype, ins, (int)n_inputs, nullptr, d_out, (long)n, as_stream(stream));
+}
+
+int gr4hip_rotator_create(gr4hip_rotator_t** out, float phase_increment, float initial_phase) {
+    GR4_REQUIRE(out, "rotator: null output handle");
+    auto* r = new (std::nothrow) gr4hip_rotator();
+    GR4_REQUIRE(r, "out of host memory");
+    r->inc = phase_increment;
+    int rc = r->d_state.ensure(sizeof(float));
+    if (rc) { delete r; return rc; }
+    rc = gr4hip_rotator_reset(r, initial_phase);
+    if (rc) { delete r; return rc; }
+    *out = r;
+    return GR4HIP_OK;
+}
+
+int gr4hip_rotator_reset(gr4hip_rotator_t* r, float initial_phase) {
+    GR4_REQUIRE(r, "rotator: null handle");
+    GR4_HIP_TRY(hipMemcpy(r->d_state.ptr, &initial_phase, sizeof(float), hipMemcpyHostToDevice));
+    return GR4HIP_OK;
+}
+
+int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, size_t n, gr4hip_stream_t stream) {
+    GR4_REQUIRE(r, "rotator: null handle");
+    if (n == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out, "rotator: null device pointer");
+    hipStream_t  st      = as_stream(stream);
+    const size_t nchunks = ceil_div(n, (size_t)kRotChunk);
+    int          rc      = r->d_ckpt.ensure(nchunks * sizeof(float));
+    if (rc) return rc;
+    hipLaunchKernelGGL(rotator_checkpoint_kernel, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n);
+    GR4_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rotator_apply_kernel, dim3((unsigned)ceil_div(nchunks, (size_t)256)), dim3(256), 0, st, (const float2*)d_in, (float2*)d_out,
+                       (const float*)r->d_ckpt.ptr, r->inc, (long)n);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+int gr4hip_rotator_phase(gr4hip_rotator_t* r, float* phase, gr4hip_stream_t stream) {
+    GR4_REQUIRE(r && phase, "rotator_phase: null argument");
+    GR4_HIP_TRY(hipMemcpyAsync(phase, r->d_state.ptr, sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
+    GR4_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return GR4HIP_OK;
+}
+
+int gr4hip_rotator_destroy(gr4hip_rotator_t* r) { delete r; return GR4HIP_OK; }
+
+int gr4hip_synth_c32(void* d_out, size_t n, uint64_t seed, double tone_frel, float tone_amp, float noise_amp, gr4hip_stream_t stream) {
+    if (n == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_out, "synth: null output");
+    const unsigned grid = (unsigned)std::min<size_t>(ceil_div(n, (size_t)256 * 8), 8192);
+    hipLaunchKernelGGL(synth_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), (float*)d_out, (long)n, seed, tone_frel, tone_amp, noise_amp);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+int gr4hip_synth_f32(float* d_out, size_t n, uint64_t seed, double tone_frel, float tone_amp, float noise_amp, gr4hip_stream_t stream) {
+    if (n == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_out, "synth: null output");
+    const unsigned grid = (unsigned)std::min<size_t>(ceil_div(n, (size_t)256 * 8), 8192);
+    hipLaunchKernelGGL(synth_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), d_out, (long)n, seed, tone_frel, tone_amp, noise_amp);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+} // extern "C"

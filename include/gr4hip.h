@@ -1,0 +1,225 @@
+/*
+ * gr4hip.h -- C-ABI of the MI355X (gfx950) kernel library behind GNU Radio 4's block API.
+ *
+ * This is the drop-in boundary: plain pointers, sizes and opaque handles; no C++ or torch
+ * types; nothing throws across it.  Each entry point replaces the per-block processOne/processBulk arithmetic
+ * that gr::Block<>::dispatchProcessing (core/include/gnuradio-4.0/Block.hpp:1848-1917, device seam :1855-1862)
+ * would run on the CPU.  The reference has no FFI of its own for this path -- the seam is the inert
+ * `compute_domain == "gpu:hip"` hook -- so this header IS the binding a maintainer adds there
+ * (INTEGRATION.md shows the stub).  All citations are relative to /root/reference.
+ *
+ * Conventions
+ *   - every function returns gr4hip_status; values -100..0 are gr::work::Status
+ *     (core/include/gnuradio-4.0/WorkStatus.hpp:12-41), library errors are < -100.
+ *   - `d_*` pointers are device (HBM) pointers on the current device; `stream` is a hipStream_t passed as void*
+ *     (NULL = default stream).  Calls are asynchronous on that stream: spans are borrowed until the stream
+ *     reaches the end of the enqueued work (Block.hpp:1838-1846 publish/consume ordering is the caller's).
+ *   - complex samples are interleaved {re, im}; dtype ids are gr4hip_dtype.
+ *   - state that the reference keeps in block members (HistoryBuffer, _accumulated_phase, twiddles, windows)
+ *     lives in opaque handles created/destroyed by *_create / *_destroy.
+ *   - one handle is driven by one thread at a time (Scheduler.hpp:1938-1951: job lists are disjoint).
+ */
+#ifndef GR4HIP_H
+#define GR4HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR4HIP_ABI_VERSION 1 /* cf. gr_plugin_base::abiVersion() == 1, core/include/gnuradio-4.0/Plugin.hpp:20-33 */
+
+typedef enum {
+    GR4HIP_OK                  = 0,    /* work::Status::OK */
+    GR4HIP_DONE                = -1,   /* work::Status::DONE */
+    GR4HIP_INSUFFICIENT_INPUT  = -2,   /* work::Status::INSUFFICIENT_INPUT_ITEMS */
+    GR4HIP_INSUFFICIENT_OUTPUT = -3,   /* work::Status::INSUFFICIENT_OUTPUT_ITEMS */
+    GR4HIP_ERROR               = -100, /* work::Status::ERROR */
+    GR4HIP_INVALID_ARGUMENT    = -101,
+    GR4HIP_RUNTIME_ERROR       = -102, /* a HIP runtime call failed; see gr4hip_last_error() */
+    GR4HIP_UNSUPPORTED         = -103, /* valid request the device path does not implement (caller keeps the CPU path) */
+    GR4HIP_NO_DEVICE           = -104
+} gr4hip_status;
+
+typedef enum { /* element types of the reference's block registrations (Math.hpp:25-28, time_domain_filter.hpp:20,213) */
+    GR4HIP_U8 = 0, GR4HIP_U16, GR4HIP_U32, GR4HIP_U64, GR4HIP_I8, GR4HIP_I16, GR4HIP_I32, GR4HIP_I64,
+    GR4HIP_F32, GR4HIP_F64, GR4HIP_C32, GR4HIP_C64
+} gr4hip_dtype;
+
+typedef enum { GR4HIP_ADD = 0, GR4HIP_SUB, GR4HIP_MUL, GR4HIP_DIV } gr4hip_op; /* std::plus/minus/multiplies/divides */
+
+typedef enum { /* gr::filter::IIRForm (time_domain_filter.hpp:50-55) == gr::filter::Form (FilterTool.hpp:107-112) */
+    GR4HIP_DF_I = 0, GR4HIP_DF_II, GR4HIP_DF_I_TRANSPOSED, GR4HIP_DF_II_TRANSPOSED
+} gr4hip_iir_form;
+
+typedef enum { /* gr::algorithm::window::Type (algorithm/.../fourier/window.hpp:35) */
+    GR4HIP_WIN_NONE = 0, GR4HIP_WIN_RECTANGULAR, GR4HIP_WIN_HAMMING, GR4HIP_WIN_HANN, GR4HIP_WIN_HANNEXP,
+    GR4HIP_WIN_BLACKMAN, GR4HIP_WIN_NUTTALL, GR4HIP_WIN_BLACKMANHARRIS, GR4HIP_WIN_BLACKMANNUTTALL,
+    GR4HIP_WIN_FLATTOP, GR4HIP_WIN_EXPONENTIAL, GR4HIP_WIN_KAISER
+} gr4hip_window;
+
+enum { /* FFT block output options (blocks/fourier/.../fft.hpp:103-105) */
+    GR4HIP_FFT_OUTPUT_IN_DB  = 1,
+    GR4HIP_FFT_OUTPUT_IN_DEG = 2,
+    GR4HIP_FFT_UNWRAP_PHASE  = 4
+};
+
+typedef enum { /* how the FIR->FFT->mag2 chain is executed */
+    GR4HIP_CHAIN_AUTO = 0,
+    GR4HIP_CHAIN_UNFUSED,  /* fir kernel -> HBM -> fft+mag2 kernel (any window, any power-of-two size) */
+    GR4HIP_CHAIN_FUSED_TD, /* one launch per batch of frames, time-domain FIR in LDS + FFT + mag2 */
+    GR4HIP_CHAIN_FUSED_FD  /* one launch, frequency-domain (overlap-save with tail correction) FIR + FFT + mag2 */
+} gr4hip_chain_algo_t;
+
+typedef void* gr4hip_stream_t; /* hipStream_t */
+typedef void* gr4hip_event_t;  /* hipEvent_t  */
+
+/* ------------------------------------------------------------------------------------------------ runtime */
+int         gr4hip_abi_version(void);
+const char* gr4hip_last_error(void); /* thread-local text of the last failure */
+const char* gr4hip_status_string(int status);
+int         gr4hip_device_count(int* count);
+int         gr4hip_set_device(int index); /* ComputeDomain "gpu:hip:<index>" (ComputeDomain.hpp:47-100) */
+int         gr4hip_get_device(int* index);
+int         gr4hip_device_name(int index, char* buf, size_t buflen);
+
+/* "hip" memory provider (the ComputeRegistry::register_provider("hip", fn) resources, ComputeDomain.hpp:105-173) */
+int gr4hip_malloc(void** d_ptr, size_t bytes);
+int gr4hip_free(void* d_ptr);
+int gr4hip_malloc_host(void** h_ptr, size_t bytes); /* pinned host staging */
+int gr4hip_free_host(void* h_ptr);
+int gr4hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, gr4hip_stream_t stream);
+int gr4hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, gr4hip_stream_t stream);
+int gr4hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, gr4hip_stream_t stream);
+int gr4hip_memset(void* d_dst, int value, size_t bytes, gr4hip_stream_t stream);
+int gr4hip_stream_create(gr4hip_stream_t* stream);
+int gr4hip_stream_destroy(gr4hip_stream_t stream);
+int gr4hip_stream_synchronize(gr4hip_stream_t stream);
+int gr4hip_event_create(gr4hip_event_t* ev);
+int gr4hip_event_destroy(gr4hip_event_t ev);
+int gr4hip_event_record(gr4hip_event_t ev, gr4hip_stream_t stream);
+int gr4hip_event_synchronize(gr4hip_event_t ev);
+int gr4hip_event_query(gr4hip_event_t ev, int* done);
+int gr4hip_event_elapsed_ms(gr4hip_event_t start, gr4hip_event_t stop, float* ms);
+
+/* GPU-resident double-mapped ring: the device analogue of CircularBuffer's memfd_create + 2x mmap
+ * (core/include/gnuradio-4.0/CircularBuffer.hpp:75-172, 191-236): [base, base+size) and [base+size, base+2*size)
+ * alias the same HBM, so a reader/writer span never has to be split at the wrap point. */
+typedef struct gr4hip_ring gr4hip_ring_t;
+int gr4hip_ring_create(gr4hip_ring_t** ring, size_t min_bytes); /* size rounded up to the VMM granularity */
+int gr4hip_ring_destroy(gr4hip_ring_t* ring);
+int gr4hip_ring_base(const gr4hip_ring_t* ring, void** d_base);
+int gr4hip_ring_size(const gr4hip_ring_t* ring, size_t* bytes);
+
+/* ------------------------------------------------------------------------------------------------ a1/a2/a5/a6
+ * gr::filter::fir_filter<T>::processOne (blocks/filter/.../time_domain_filter.hpp:44-47):
+ *   y[n] = sum_k b[k] x[n-k], zero initial history, history carried across calls (HistoryBuffer.hpp:130-139).
+ * dtype F32 (registered) or C32 (complex data x real taps).  decim > 1 gives the
+ * BasicFilterProto decimating processBulk (:190-204): output m == y[m*decim]; n_in must be a multiple of decim
+ * (the reference guarantees it through input_chunk_size = decimate, :166-168). */
+typedef struct gr4hip_fir gr4hip_fir_t;
+int gr4hip_fir_create(gr4hip_fir_t** fir, int dtype, const float* h_taps, size_t ntaps, size_t decim);
+int gr4hip_fir_set_taps(gr4hip_fir_t* fir, const float* h_taps, size_t ntaps); /* settingsChanged (:38-42): history is kept */
+int gr4hip_fir_reset(gr4hip_fir_t* fir);
+int gr4hip_fir_process(gr4hip_fir_t* fir, const void* d_in, size_t n_in, void* d_out, size_t* n_out, gr4hip_stream_t stream);
+int gr4hip_fir_destroy(gr4hip_fir_t* fir);
+
+/* gr::filter::Decimator<T>::processBulk (time_domain_filter.hpp:234-244): keep samples with i % decim == 0. */
+int gr4hip_decimate(int dtype, const void* d_in, size_t n_in, size_t decim, void* d_out, size_t* n_out, gr4hip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ a3/a4
+ * gr::filter::Filter<float>::processOne == cascade of sections through detail::computeFilter
+ * (algorithm/.../filter/FilterTool.hpp:116-158, 244-246), and gr::filter::iir_filter<float, form>::processOne
+ * (time_domain_filter.hpp:89-121) for nsections == 1.  b: [nsections][nb], a: [nsections][na], a[.][0] == 1.
+ * All four forms compute the same transfer function from zero state; `form` is recorded for introspection. */
+typedef struct gr4hip_iir gr4hip_iir_t;
+int gr4hip_iir_create(gr4hip_iir_t** iir, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na);
+int gr4hip_iir_reset(gr4hip_iir_t* iir);
+int gr4hip_iir_process(gr4hip_iir_t* iir, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream);
+int gr4hip_iir_destroy(gr4hip_iir_t* iir);
+
+/* ------------------------------------------------------------------------------------------------ a5 (host-side design)
+ * BasicFilterProto<float>::designFilter (time_domain_filter.hpp:163-182): FIR by window method
+ * (fir::designFilter<float>, FilterTool.hpp:964-1071; tap count from Kaiser's estimate :985-1004) or IIR biquad
+ * sections (iir::designFilter<float>, :476-917).  Pure host code; results feed gr4hip_fir_create / gr4hip_iir_create. */
+typedef struct { /* gr::filter::FilterParameters (FilterTool.hpp:66-75) */
+    size_t order;
+    double f_low, f_high, gain, ripple_db, attenuation_db, beta, fs;
+} gr4hip_filter_params;
+typedef enum { GR4HIP_LOWPASS = 0, GR4HIP_HIGHPASS, GR4HIP_BANDPASS, GR4HIP_BANDSTOP } gr4hip_filter_response; /* filter::Type :64 */
+typedef enum { GR4HIP_BUTTERWORTH = 0, GR4HIP_BESSEL, GR4HIP_CHEBYSHEV1, GR4HIP_CHEBYSHEV2 } gr4hip_iir_design_t; /* iir::Design :425-430 */
+int gr4hip_filter_params_default(gr4hip_filter_params* p);
+/* h_taps == NULL: only *ntaps is returned (size query) */
+int gr4hip_fir_design(int response, const gr4hip_filter_params* p, int window, float* h_taps, size_t cap, size_t* ntaps);
+/* biquads: h_b, h_a are [cap_sections][3] (first-order sections are zero padded) */
+int gr4hip_iir_design(int response, const gr4hip_filter_params* p, int design, float* h_b, float* h_a, size_t cap_sections, size_t* nsections);
+
+/* ------------------------------------------------------------------------------------------------ a7-a10
+ * gr::blocks::fft::FFT<T>::processBulk (blocks/fourier/.../fft.hpp:147-171) per frame of fft_size samples:
+ * window (window.hpp:69-183, default Hann) -> forward DFT (algorithm/.../fourier/fft.hpp:113-153) ->
+ * magnitude hypot*2/N [dB] fft-shifted + phase atan2 [unwrap][deg] fft-shifted (fft_common.hpp:20-123) + Re + Im
+ * (natural order, fft.hpp:217-220).  in_dtype C32: fft_size values per output; F32: fft_size/2 (fft.hpp:140-143, 221-227).
+ * Any output pointer may be NULL.  d_ranges (optional): per frame {min,max} of mag, phase, re, im (fft.hpp:229-232). */
+typedef struct gr4hip_fft gr4hip_fft_t;
+int gr4hip_fft_create(gr4hip_fft_t** fft, int in_dtype, size_t fft_size, int window, int flags);
+int gr4hip_fft_process(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, float* d_mag, float* d_phase, float* d_re, float* d_im,
+                       float* d_ranges, gr4hip_stream_t stream);
+/* raw spectrum of algorithm::FFT::compute (interleaved complex, natural order, window applied if configured) */
+int gr4hip_fft_spectrum(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, float* d_spectrum, gr4hip_stream_t stream);
+/* |X[k]|^2 in natural bin order: mag2[(k + N/2) % N] == (magnitude_block[k] * N/2)^2 */
+int gr4hip_fft_mag2(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, float* d_mag2, gr4hip_stream_t stream);
+int gr4hip_fft_destroy(gr4hip_fft_t* fft);
+/* window::create on the host (float), for callers that need the block's _window member */
+int gr4hip_window_create(int window, float* h_out, size_t n, float beta);
+
+/* ------------------------------------------------------------------------------------------------ headline chain
+ * complex<float> fir_filter -> FFT block frames -> |X|^2 (BASELINE.json configs[1]).  One call consumes
+ * floor(n_samples / fft_size) frames; FIR history (ntaps-1 samples) is carried across calls.
+ * The runtime analogue of Merge<fir,"out",fft,"in"> (core/include/gnuradio-4.0/BlockMerging.hpp:136-320). */
+typedef struct gr4hip_chain gr4hip_chain_t;
+int gr4hip_chain_create(gr4hip_chain_t** chain, const float* h_taps, size_t ntaps, size_t fft_size, int window, int algo);
+int gr4hip_chain_reset(gr4hip_chain_t* chain);
+int gr4hip_chain_process(gr4hip_chain_t* chain, const void* d_in_c32, size_t n_samples, float* d_mag2, size_t* n_frames,
+                         gr4hip_stream_t stream);
+int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
+int gr4hip_chain_destroy(gr4hip_chain_t* chain);
+
+/* ------------------------------------------------------------------------------------------------ a11/a12/a13
+ * MathOpImpl<T,op>::processOne (blocks/math/.../Math.hpp:38-56): out = in (op) value, C++ semantics for T
+ * (integer promotion then narrowing, wrap-around).  h_value points to one host element of `dtype`. */
+int gr4hip_math_const(int op, int dtype, const void* d_in, void* d_out, size_t n, const void* h_value, gr4hip_stream_t stream);
+/* MathOpMultiPortImpl<T,op>::processBulk (Math.hpp:100-107): left fold ((in0 op in1) op in2) ... over 1..32 inputs.
+ * h_d_ins is a HOST array of n_inputs device pointers. */
+int gr4hip_math_nary(int op, int dtype, const void* const* h_d_ins, size_t n_inputs, void* d_out, size_t n, gr4hip_stream_t stream);
+
+/* Rotator<complex<float>>::processOne (blocks/math/.../Rotator.hpp:51-61): phase += inc (before the first sample),
+ * single +-2pi wrap, y = x * (cos, sin); float phase accumulation is reproduced exactly, state carried across calls. */
+typedef struct gr4hip_rotator gr4hip_rotator_t;
+int gr4hip_rotator_create(gr4hip_rotator_t** rot, float phase_increment, float initial_phase);
+int gr4hip_rotator_reset(gr4hip_rotator_t* rot, float initial_phase); /* settingsChanged: _accumulated_phase = initial_phase */
+int gr4hip_rotator_process(gr4hip_rotator_t* rot, const void* d_in_c32, void* d_out_c32, size_t n, gr4hip_stream_t stream);
+int gr4hip_rotator_phase(gr4hip_rotator_t* rot, float* phase, gr4hip_stream_t stream); /* synchronises the stream */
+int gr4hip_rotator_destroy(gr4hip_rotator_t* rot);
+
+/* ------------------------------------------------------------------------------------------------ batched FIR (configs[3])
+ * nchannels independent fir_filter<float> instances, per-channel taps h_taps[c][k], channel-major samples
+ * d_in[c * in_stride + n]; evaluated as a block-Toeplitz contraction on the f32 MFMA units. */
+typedef struct gr4hip_fir_batched gr4hip_fir_batched_t;
+int gr4hip_fir_batched_create(gr4hip_fir_batched_t** fb, size_t nchannels, const float* h_taps, size_t ntaps);
+int gr4hip_fir_batched_reset(gr4hip_fir_batched_t* fb);
+int gr4hip_fir_batched_process(gr4hip_fir_batched_t* fb, const float* d_in, size_t in_stride, size_t n, float* d_out, size_t out_stride,
+                               gr4hip_stream_t stream);
+int gr4hip_fir_batched_destroy(gr4hip_fir_batched_t* fb);
+
+/* ------------------------------------------------------------------------------------------------ a15 (bench input)
+ * device-side synthetic stream of SURVEY.md 8(d): complex Gaussian noise (xoshiro256++ per 4096-sample block,
+ * Marsaglia polar like GaussianNoise.hpp:101-111) + tone; NOT the sequential reference stream (tests upload that). */
+int gr4hip_synth_c32(void* d_out_c32, size_t n, uint64_t seed, double tone_frel, float tone_amp, float noise_amp, gr4hip_stream_t stream);
+int gr4hip_synth_f32(float* d_out, size_t n, uint64_t seed, double tone_frel, float tone_amp, float noise_amp, gr4hip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GR4HIP_H */

@@ -1,0 +1,428 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C-ABI (ctypes -> libgr4hip.so) against the
+CPU oracle on identical seeded inputs.  Bar: bit-exact for integer / byte / copy work; for float32 FIR/IIR/FFT
+max|gpu - truth| <= 1e-5 * rms(truth) against the float64 oracle (BASELINE.json north_star; SURVEY.md section 7
+"Parity definition": point-wise relative error is meaningless near spectral zeros)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _rel(got, truth):
+    got = np.asarray(got).astype(np.complex128 if np.iscomplexobj(got) else np.float64).ravel()
+    truth = np.asarray(truth).ravel()
+    rms = np.sqrt(np.mean(np.abs(truth) ** 2))
+    return float(np.max(np.abs(got - truth)) / (rms if rms > 0 else 1.0))
+
+
+@pytest.fixture(scope="module")
+def G():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import gnuradio4_amd as G
+    G.capi.lib()
+    return G
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------ plumbing
+def test_native_library_is_loaded_and_shares_torch_runtime(G):
+    L = G.capi.lib()
+    n = C.c_int(0)
+    assert L.gr4hip_device_count(C.byref(n)) == 0 and n.value >= 1
+    buf = C.create_string_buffer(256)
+    assert L.gr4hip_device_name(0, buf, 256) == 0
+    assert b"gfx950" in buf.value, buf.value
+    # a torch-allocated tensor is a valid device pointer for the library (same HIP runtime instance)
+    x = torch.arange(1024, dtype=torch.int32, device="cuda")
+    y = G.math_const("Add", x, 5)
+    assert torch.equal(y, x + 5)
+    maps = open("/proc/self/maps").read()
+    assert "libgr4hip.so" in maps
+
+
+def test_ring_is_double_mapped(G):
+    L = G.capi.lib()
+    ring = C.c_void_p()
+    assert L.gr4hip_ring_create(C.byref(ring), 1 << 20) == 0, L.gr4hip_last_error()
+    base, size = C.c_void_p(), C.c_size_t()
+    L.gr4hip_ring_base(ring, C.byref(base))
+    L.gr4hip_ring_size(ring, C.byref(size))
+    n = size.value // 4
+    host = np.arange(n, dtype=np.int32)
+    assert L.gr4hip_memcpy_h2d(base, host.ctypes.data, size.value, None) == 0
+    back = np.empty(n, np.int32)
+    assert L.gr4hip_memcpy_d2h(back.ctypes.data, C.c_void_p(base.value + size.value), size.value, None) == 0  # second mapping
+    L.gr4hip_stream_synchronize(None)
+    assert np.array_equal(back, host)
+    # a span that straddles the wrap point is contiguous: run a kernel across it
+    span = np.empty(1024, np.int32)
+    start = base.value + size.value - 512 * 4
+    one = np.array([1], np.int32)
+    out = torch.empty(1024, dtype=torch.int32, device="cuda")
+    assert L.gr4hip_math_const(0, 6, C.c_void_p(start), out.data_ptr(), 1024, one.ctypes.data, None) == 0
+    L.gr4hip_memcpy_d2h(span.ctypes.data, out.data_ptr(), 4096, None)
+    L.gr4hip_stream_synchronize(None)
+    assert np.array_equal(span, np.concatenate([host[-512:], host[:512]]) + 1)
+    assert L.gr4hip_ring_destroy(ring) == 0
+
+
+# ------------------------------------------------------------------ FIR (a1, a2, a5, a6)
+@pytest.mark.parametrize("ntaps", [1, 2, 10, 64, 91, 256, 1024])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_fir_parity(G, ntaps, cplx):
+    rng = np.random.default_rng(ntaps)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 50_000 + 37
+    x = O.signal_c32(42, n) if cplx else O.signal_f32(42, n)
+    truth, _ = O.fir(b, x)
+    f = G.fir_filter(b, torch.complex64 if cplx else torch.float32)
+    y = f.process_bulk(dev(x)).cpu().numpy()
+    assert _rel(y, truth) <= TOL
+    # not worse than the reference-faithful float CPU path by more than 1e-6 of rms
+    cpu32, _ = O.fir(b, x, acc64=False)
+    assert _rel(y, truth) <= _rel(cpu32, truth) + 1e-6
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_fir_history_across_calls(G, cplx):
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(64).astype(np.float32)
+    x = O.signal_c32(7, 30_000) if cplx else O.signal_f32(7, 30_000)
+    truth, _ = O.fir(b, x)
+    f = G.fir_filter(b, torch.complex64 if cplx else torch.float32)
+    cuts = [0, 1, 2, 33, 63, 64, 65, 4096, 4097, 20_000, 30_000]  # spans shorter and longer than the history
+    parts = [f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])]
+    assert _rel(np.concatenate(parts), truth) <= TOL
+    f.reset()
+    again = f.process_bulk(dev(x[:1000])).cpu().numpy()
+    assert _rel(again, truth[:1000]) <= TOL
+    assert f.process_bulk(dev(x[:0])).numel() == 0  # empty span
+
+
+def test_fir_boxcar_step_golden(G, golden):
+    g = golden["fir_iir_step"]
+    x = np.ones(g["n_steps"], np.float32)
+    x[0] = 0
+    y = G.fir_filter(np.full(g["boxcar_taps"], g["boxcar_value"], np.float32)).process_bulk(dev(x)).cpu().numpy()
+    np.testing.assert_allclose(y[:11], [0, .1, .2, .3, .4, .5, .6, .7, .8, .9, 1.0], atol=1e-6)
+    assert abs(y[-1] - 1.0) < 1e-6
+
+
+def test_fir_settings_changed_keeps_history(G):
+    rng = np.random.default_rng(4)
+    x = O.signal_f32(9, 4000)
+    b1, b2 = rng.standard_normal(20).astype(np.float32), rng.standard_normal(30).astype(np.float32)
+    f = G.fir_filter(b1)
+    y1 = f.process_bulk(dev(x[:2000])).cpu().numpy()
+    f.settings_changed(b2)  # 30 <= capacity 32: history survives (time_domain_filter.hpp:38-42)
+    y2 = f.process_bulk(dev(x[2000:])).cpu().numpy()
+    t1, _ = O.fir(b1, x[:2000])
+    t2, _ = O.fir(b2, x)  # continuing with full history == filtering the whole stream with b2
+    assert _rel(y1, t1) <= TOL and _rel(y2, t2[2000:]) <= TOL
+
+
+@pytest.mark.parametrize("decim,ntaps", [(2, 33), (5, 91), (8, 1024), (10, 64), (64, 512)])
+def test_decimating_fir_parity(G, decim, ntaps):
+    rng = np.random.default_rng(decim)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = decim * 6000
+    x = O.signal_f32(42, n)
+    truth, _ = O.fir_decim(b, x, decim)
+    f = G.fir_filter(b, torch.float32, decimate=decim)
+    half = decim * 2500
+    y = np.concatenate([f.process_bulk(dev(x[:half])).cpu().numpy(), f.process_bulk(dev(x[half:])).cpu().numpy()])
+    assert len(y) == n // decim and _rel(y, truth) <= TOL
+    with pytest.raises(G.capi.Gr4HipError):
+        f.process_bulk(dev(x[: decim + 1]))  # spans must be whole input chunks
+
+
+@pytest.mark.parametrize("dtype_id", range(12))
+def test_decimator_bit_exact(G, dtype_id, golden):
+    g = golden["decimator"]
+    rng = np.random.default_rng(dtype_id)
+    raw = rng.integers(0, 256, size=1003 * O.lib().gr4o_dtype_size(dtype_id), dtype=np.uint8)
+    x = raw.view(O.NP_DTYPES[dtype_id])
+    if dtype_id in (8, 9, 10, 11):
+        x = np.nan_to_num(x, nan=1.0, posinf=2.0, neginf=-2.0)
+    for decim in (1, 3, g["decim"]):
+        y = G.Decimator(decim).process_bulk(dev(x)).cpu().numpy()
+        assert np.array_equal(y.view(np.uint8), np.ascontiguousarray(x[::decim]).view(np.uint8))
+    assert G.Decimator(g["decim"]).process_bulk(dev(np.arange(g["n_in"], dtype=np.float32))).numel() == g["n_out"]
+
+
+# ------------------------------------------------------------------ IIR (a3, a4)
+def test_iir_forms_golden(G, golden):
+    g = golden["fir_iir_step"]
+    x = np.ones(g["n_steps"], np.float32)
+    x[0] = 0
+    truth = O.iir_cascade(O.make_sections([(g["biquad_b"], g["biquad_a"])]), x, O.DF_I)
+    for form in range(4):
+        y = G.iir_filter(g["biquad_b"], g["biquad_a"], form).process_bulk(dev(x)).cpu().numpy()
+        np.testing.assert_allclose(y, truth, atol=g["forms_tolerance"])
+
+
+@pytest.mark.parametrize("order,design", [(1, 0), (2, 0), (8, 0), (4, 2), (5, 3), (6, 1)])
+def test_iir_cascade_parity(G, order, design):
+    import gnuradio4_amd.blocks as B
+    b, a = B.design_iir(0, order, 0.05, float("nan"), 1.0, design)
+    n = 300_000 + 11
+    x = O.signal_f32(42, n)
+    truth = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(b, a)]), x, O.DF_II, f64=True)
+    f = G.iir_filter(b, a)
+    cuts = [0, 5, 8192, 8193, 100_000, n]
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert _rel(y, truth) <= TOL
+    cpu32 = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(b, a)]), x, O.DF_II, f64=False)
+    assert _rel(y, truth) <= 2 * _rel(cpu32, truth) + 2e-6
+
+
+def test_basic_filter_bands(G, golden):
+    g = golden["basic_filter_lowpass"]
+    fs, n = g["sample_rate"], g["num_samples"]
+    for ftype in ("FIR", "IIR"):
+        for decim in (1, g["decimation"]):
+            for f_hz, ok in ((g["pass_hz"], lambda m: m >= g["pass_min"]), (g["stop_hz"], lambda m: m <= g["stop_max"])):
+                flt = G.BasicFilter(filter_type=ftype, filter_response=0, filter_order=g["filter_order"], f_low=g["f_low"], sample_rate=fs,
+                                    decimate=decim, iir_design_method=G.capi.CHEBYSHEV1, fir_design_method="Hamming")
+                assert flt.input_chunk_size == decim
+                x = np.sin(2 * np.pi * f_hz / fs * np.arange(1, 2 * n + 1)).astype(np.float32)
+                y = flt.process_bulk(dev(x)).cpu().numpy()
+                assert len(y) == 2 * n // decim
+                assert ok(np.max(np.abs(y[n // decim:]))), (ftype, decim, f_hz)
+
+
+# ------------------------------------------------------------------ FFT block (a7-a10)
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 64, 256, 1024, 4096, 8192])
+def test_fft_spectrum_parity(G, N):
+    frames = 5
+    x = O.signal_c32(N, frames * N)
+    got = G.FFT(N, "None").spectrum(dev(x)).cpu().numpy()
+    for f in range(frames):
+        truth = O.dft64(x[f * N:(f + 1) * N])
+        assert _rel(got[f], truth) <= TOL
+
+
+def test_fft_n16_patterns_golden(G, golden):
+    g = golden["fft_n16_patterns"]
+    for case in g["cases"]:
+        if case.get("iota"):
+            x = np.arange(1, 17, dtype=np.complex64)
+        elif case.get("alternating"):
+            x = (np.arange(16) % 2).astype(np.complex64)
+        else:
+            x = np.full(16, complex(*case["fill"]), np.complex64)
+        sp = G.FFT(16, "None").spectrum(dev(x)).cpu().numpy()[0]
+        mag = np.abs(sp) * 2 / 16
+        assert int(np.argmax(mag)) == case["peak_index"] and abs(mag.max() - case["peak_amplitude"]) < 1e-4
+        assert abs(sp[0].real - case["fft0"][0]) < 1e-4 and abs(sp[0].imag - case["fft0"][1]) < 1e-4
+
+
+@pytest.mark.parametrize("window", ["None", "Hann", "Hamming", "BlackmanHarris", "Kaiser", "FlatTop"])
+@pytest.mark.parametrize("N", [256, 8192])
+def test_fft_block_outputs_parity(G, window, N):
+    frames = 3
+    x = O.signal_c32(11, frames * N)
+    wid = [w.lower() for w in O.WINDOWS].index(window.lower())
+    out = G.FFT(N, window).process_bulk(dev(x))
+    for f in range(frames):
+        mag, ph, re, im = O.fft_block_truth(x[f * N:(f + 1) * N], wid)
+        assert _rel(out["magnitude"][f].cpu().numpy(), mag) <= TOL
+        assert _rel(out["re"][f].cpu().numpy(), re) <= TOL and _rel(out["im"][f].cpu().numpy(), im) <= TOL
+        # phase: compare where the bin is not numerically empty (atan2 of rounding noise is arbitrary)
+        strong = mag > 1e-3 * mag.max()
+        d = np.angle(np.exp(1j * (out["phase"][f].cpu().numpy() - ph)))
+        assert np.max(np.abs(d[strong])) <= 1e-3
+        rg = out["ranges"][f].cpu().numpy()
+        for s, name in enumerate(("magnitude", "phase", "re", "im")):
+            v = out[name][f].cpu().numpy()
+            assert rg[s, 0] == v.min() and rg[s, 1] == v.max()
+
+
+def test_fft_block_db_deg_unwrap_and_peak(G, golden):
+    g = golden["fft_block"]
+    N = g["N"]
+    x = (np.cos(2 * np.pi * g["tone_frel"] * np.arange(N)) + 0.05 * O.gauss_f32(3, N)).astype(np.complex64)
+    out = G.FFT(N, "Hann", outputInDb=True, outputInDeg=True, unwrapPhase=True).process_bulk(dev(x))
+    mag, ph, _, _ = O.fft_block_truth(x, 3, in_db=True, in_deg=True, unwrap=True)
+    assert abs(abs(out["frequency"][int(np.argmax(out["magnitude"][0].cpu().numpy()))]) - g["tone_frel"]) <= 1.0 / N
+    assert np.max(np.abs(out["magnitude"][0].cpu().numpy() - mag)) < 1e-3  # dB values
+    d = out["phase"][0].cpu().numpy() - ph  # unwrapped degrees: equal up to whole turns at borderline jumps
+    assert np.max(np.abs(d - 360.0 * np.round(d / 360.0))) < 0.05
+    assert np.mean(np.abs(d) < 0.05) > 0.9
+
+
+@pytest.mark.parametrize("N", [64, 1024])
+def test_fft_real_input(G, N):
+    x = O.signal_f32(5, 2 * N)
+    out = G.FFT(N, "Hann", dtype=torch.float32).process_bulk(dev(x))
+    assert out["magnitude"].shape == (2, N // 2)
+    for f in range(2):
+        mag, ph, re, im = O.fft_block_truth(x[f * N:(f + 1) * N], 3)
+        assert _rel(out["magnitude"][f].cpu().numpy(), mag) <= TOL
+        assert _rel(out["re"][f].cpu().numpy(), re) <= TOL and _rel(out["im"][f].cpu().numpy(), im) <= TOL
+
+
+def test_fft_linearity_and_roundtrip_properties(G):
+    N, frames = 8192, 64
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(frames * N) + 1j * rng.standard_normal(frames * N)).astype(np.complex64)
+    y = (rng.standard_normal(frames * N) + 1j * rng.standard_normal(frames * N)).astype(np.complex64)
+    F = G.FFT(N, "None")
+    fx, fy, fs = F.spectrum(dev(x)), F.spectrum(dev(y)), F.spectrum(dev(x + y))
+    assert float((fs - (fx + fy)).abs().max()) < 1e-4 * N  # qa_SimdFFT.cpp:399-424
+    back = torch.conj(F.spectrum(torch.conj(fx).reshape(-1))) / N  # inverse through conjugation
+    assert float((back.reshape(-1) - dev(x)).abs().max()) <= 1e-5 * N  # qa_SimdFFT.cpp:122-185
+    # Parseval: sum |X|^2 == N * sum |x|^2
+    e_t = float((dev(x).abs() ** 2).sum())
+    e_f = float(F.mag2(dev(x)).sum())
+    assert abs(e_f / (N * e_t) - 1) < 1e-5
+
+
+# ------------------------------------------------------------------ headline chain
+@pytest.mark.parametrize("algo", [1, 0])
+@pytest.mark.parametrize("N,ntaps,window", [(8192, 256, "None"), (8192, 256, "Hann"), (1024, 64, "None"), (256, 33, "Hann")])
+def test_chain_parity(G, algo, N, ntaps, window):
+    frames = 6
+    b = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    x = O.signal_c32(42, frames * N)
+    wid = [w.lower() for w in O.WINDOWS].index(window.lower())
+    truth, _ = O.chain(b, x, N, wid, truth=True)
+    ch = G.Chain(b, N, window, algo)
+    half = (frames // 2) * N
+    got = np.concatenate([ch.process_bulk(dev(x[:half])).cpu().numpy().ravel(), ch.process_bulk(dev(x[half:])).cpu().numpy().ravel()])
+    assert _rel(got, truth) <= TOL
+    # noise-only stream (no dominant tone bin in the rms)
+    xn = O.signal_c32(43, 2 * N, tone_amp=0.0)
+    tn, _ = O.chain(b, xn, N, wid, truth=True)
+    ch.reset()
+    assert _rel(ch.process_bulk(dev(xn)).cpu().numpy().ravel(), tn) <= TOL
+    cpu32, _ = O.chain(b, xn, N, wid, truth=False)
+    ch.reset()
+    assert _rel(ch.process_bulk(dev(xn)).cpu().numpy().ravel(), tn) <= _rel(cpu32, tn) + 1e-6
+
+
+def test_chain_matches_reference_block_magnitude(G):
+    """mag2[(k+N/2) mod N] == (magnitude_block[k]*N/2)^2 ties the stream to the FFT block's DataSet output."""
+    N = 1024
+    b = O.design_taps_hamming_lowpass(64, 0.1)
+    x = O.signal_c32(1, 2 * N)
+    m2 = G.Chain(b, N, "Hann").process_bulk(dev(x)).cpu().numpy()
+    y = G.fir_filter(b, torch.complex64).process_bulk(dev(x))
+    mag = G.FFT(N, "Hann").process_bulk(y)["magnitude"].cpu().numpy()
+    np.testing.assert_allclose(np.fft.fftshift(m2, axes=1), (mag.astype(np.float64) * N / 2) ** 2, rtol=1e-4, atol=1e-6 * m2.max())
+
+
+def test_chain_full_size_properties(G):
+    """BASELINE-size frames (N=8192, 256 taps) over a long device-generated stream: size-independent properties."""
+    N, frames = 8192, 512
+    b = O.design_taps_hamming_lowpass(256, 0.1)
+    x = G.synth_c32(frames * N, seed=5)
+    ch = G.Chain(b, N, "None")
+    whole = ch.process_bulk(x)
+    ch.reset()
+    parts = torch.cat([ch.process_bulk(x[: 100 * N]), ch.process_bulk(x[100 * N: 101 * N]), ch.process_bulk(x[101 * N:])])
+    assert float((whole - parts).abs().max()) <= 1e-5 * float(whole.pow(2).mean().sqrt())  # chunking invariance
+    # linearity of the underlying filter+transform: |F(2x)|^2 == 4 |F(x)|^2
+    ch.reset()
+    twice = ch.process_bulk(2 * x)
+    assert float((twice - 4 * whole).abs().max()) <= 1e-5 * float((4 * whole).pow(2).mean().sqrt())
+    # Parseval against the separately filtered stream
+    y = G.fir_filter(b, torch.complex64).process_bulk(x)
+    e_t = float((y.abs().double() ** 2).sum())
+    assert abs(float(whole.double().sum()) / (N * e_t) - 1) < 1e-5
+    # tone at 0.1 fs sits in the passband: its bin dominates every frame
+    assert torch.all(whole.argmax(dim=1) == round(0.1 * N))
+
+
+# ------------------------------------------------------------------ math (a11, a12) + rotator (a13)
+_OPS = {"Add": O.ADD, "Subtract": O.SUB, "Multiply": O.MUL, "Divide": O.DIV}
+
+
+def _rand(dtype_id, n, rng, nonzero=False):
+    dt = O.NP_DTYPES[dtype_id]
+    if np.issubdtype(dt, np.integer):
+        info = np.iinfo(dt)
+        v = rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True)
+        if nonzero:
+            v[v == 0] = 3
+            if info.min < 0:
+                v[v == -1] = 5  # INT_MIN / -1 is UB in the reference
+        return v
+    if np.issubdtype(dt, np.complexfloating):
+        return (rng.uniform(0.5, 4, n) * np.exp(2j * np.pi * rng.uniform(0, 1, n))).astype(dt)
+    return (rng.uniform(0.5, 4, n) * rng.choice([-1, 1], n)).astype(dt)
+
+
+@pytest.mark.parametrize("dtype_id", range(12))
+@pytest.mark.parametrize("opname", list(_OPS))
+def test_math_parity(G, dtype_id, opname):
+    rng = np.random.default_rng(dtype_id * 7 + _OPS[opname])
+    op = _OPS[opname]
+    n = 100_003  # vector body + scalar tail
+    integer = dtype_id < 8
+    ins = [_rand(dtype_id, n, rng, nonzero=(op == O.DIV and k > 0)) for k in range(3)]
+    for k in (1, 2, 3):
+        got = G.math_nary(opname, [dev(a) for a in ins[:k]]).cpu().numpy()
+        want = O.math_nary(op, dtype_id, ins[:k])
+        if integer or op in (O.ADD, O.SUB):
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (opname, k)  # bit-exact
+        else:
+            np.testing.assert_allclose(got, want, rtol=3e-6 if dtype_id in (8, 10) else 1e-14)
+    value = _rand(dtype_id, 1, rng, nonzero=True)[0]
+    got = G.math_const(opname, dev(ins[0]), value).cpu().numpy()
+    want = O.math_const(op, dtype_id, ins[0], value)
+    if integer or op in (O.ADD, O.SUB):
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    else:
+        np.testing.assert_allclose(got, want, rtol=3e-6 if dtype_id in (8, 10) else 1e-14)
+
+
+@pytest.mark.parametrize("dtype_id", range(12))
+def test_math_golden_vectors(G, golden, dtype_id):
+    dt = O.NP_DTYPES[dtype_id]
+    cast = (lambda v: np.array([int(q) for q in v]).astype(dt)) if np.issubdtype(dt, np.integer) else (lambda v: np.array(v).astype(dt))
+    for name in _OPS:
+        for case in golden["math_nary"][name]:
+            if np.issubdtype(dt, np.integer) and not all(float(v).is_integer() for row in case["inputs"] + [case["output"]] for v in row):
+                continue
+            got = G.math_nary(name, [dev(cast(v)) for v in case["inputs"]]).cpu().numpy()
+            np.testing.assert_allclose(got, cast(case["output"]), rtol=1e-6)
+        g = golden["math_const"]
+        assert G.math_const(name, dev(np.array([g["x"]], dt)), g["value"]).cpu().numpy()[0] == dt(g[name])
+    assert G.math_nary("Add", [dev(np.zeros(0, dt))]).numel() == 0
+    with pytest.raises(G.capi.Gr4HipError):
+        G.math_nary("Add", [dev(np.zeros(4, dt))] * 33)
+
+
+def test_rotator_golden_and_parity(G, golden):
+    g = golden["rotator"]
+    inc = np.float32(np.pi * g["phase_increment_over_pi"])
+    r = G.Rotator(phase_increment=float(inc), initial_phase=0.0, sample_rate=1.0)
+    assert abs(r.frequency_shift - 0.25) < 1e-3  # qa_Rotator.cpp:76
+    y = r.process_bulk(dev(np.ones(g["n"], np.complex64))).cpu().numpy()
+    for i in range(g["n"]):
+        want = (i + 1) * float(inc)
+        assert abs(y[i].real - np.cos(want)) < g["tolerance"] and abs(y[i].imag - np.sin(want)) < g["tolerance"]
+    # long stream: the float phase accumulation of the reference (incl. its drift) is reproduced across calls
+    n = 200_000 + 13
+    x = O.signal_c32(3, n)
+    for inc in (0.6283185, -0.01, 3.0):
+        want, ph = O.rotator(x, inc, 0.25)
+        r = G.Rotator(phase_increment=inc, initial_phase=0.25)
+        got = np.concatenate([r.process_bulk(dev(x[:777])).cpu().numpy(), r.process_bulk(dev(x[777:])).cpu().numpy()])
+        assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
+        assert r.accumulated_phase == np.float32(ph)  # bit-identical phase state
+    with pytest.raises(ValueError):
+        G.Rotator(phase_increment=0.1, frequency_shift=0.2)
+    r = G.Rotator(frequency_shift=2.0, sample_rate=100.0)
+    assert abs(r.phase_increment - 2 * np.pi * 0.02) < 1e-6
