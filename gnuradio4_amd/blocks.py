@@ -41,7 +41,7 @@ def _stream() -> int:
 def _dev(x: torch.Tensor, what: str) -> torch.Tensor:
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise capi.Gr4HipError(capi.INVALID_ARGUMENT, what, "input must be a CUDA/HIP torch tensor (device-only path)")
-    return x.contiguous()
+    return x.resolve_conj().contiguous()  # materialise lazy conj views: the kernels read raw memory
 
 
 def _window_id(window) -> int:

@@ -16,10 +16,13 @@ TOL = 1e-5
 
 
 def _rel(got, truth):
+    """max_k |got_k - truth_k| / max(|truth_k|, rms(truth)): relative error for values above the rms level, rms-normalised
+    absolute error below it (an all-rms normalisation would demand better than float32 epsilon on a dominant tone bin of
+    a quadratic output: peak/rms ~ sqrt(N))."""
     got = np.asarray(got).astype(np.complex128 if np.iscomplexobj(got) else np.float64).ravel()
     truth = np.asarray(truth).ravel()
     rms = np.sqrt(np.mean(np.abs(truth) ** 2))
-    return float(np.max(np.abs(got - truth)) / (rms if rms > 0 else 1.0))
+    return float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), rms if rms > 0 else 1.0)))
 
 
 @pytest.fixture(scope="module")
