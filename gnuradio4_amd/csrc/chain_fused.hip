@@ -18,18 +18,23 @@
 // One workgroup (256 lanes) = one frame.  Stockham radix 32 x 16 x 16; every lane holds 32 complex points.
 // LDS exchange layouts are padded (rows of 272 / 513 float2) so all ds_read_b64 / ds_write_b64 are conflict-free.
 #include "common.hpp"
+#include "fir_window.hpp"
 
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 
 namespace gr4 {
 
+#ifndef GR4_FD_WAVES
+#define GR4_FD_WAVES 4
+#endif
 constexpr int kN     = 8192;
-constexpr int kT     = 256;  // lanes per workgroup
+constexpr int kT     = 512;  // lanes per workgroup (8 waves)
 constexpr int kTail  = 255;  // ntaps - 1 (taps are zero-padded to 256)
-constexpr int kRowA  = 272;  // pass-A -> pass-B exchange: S[r'][t], row pitch 272 float2 (544 dwords = 32 mod 64 banks)
-constexpr int kRowB  = 513;  // pass-B -> pass-C exchange: S[c][i3], row pitch 513 float2 (= 1 mod 16 -> 16 lanes spread over 32 banks)
-constexpr int kSLen  = 32 * kRowA; // 8704 float2 >= 16 * 513
+constexpr int kRowA  = 264;  // pass-A -> pass-B exchange: S[r'][n0], row pitch 264 float2 (528 dwords = 16 mod 64; rows k and k+2 are 32 banks apart)
+constexpr int kRowB  = 513;  // pass-B -> pass-C exchange: S[c][i3], row pitch 513 float2 (1026 dwords = 2 mod 32: 16 c-lanes hit 32 distinct banks)
+constexpr int kSLen  = 32 * kRowA + 8; // 8456 float2 (rows 16..31 are shifted by 8) >= 16 * 513
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -109,114 +114,263 @@ struct ChainFdArgs {
     const float*  taps;   // 256 (zero padded)
     float*        out;    // frames * 8192 mag2
     long          n_frames;
+    unsigned long long* dbg; // GR4_FD_TIMING only
 };
 
-// pass B (p = 32, radix 16): butterfly (c, k) gathers S1[k][c + 16 r]
-__device__ __forceinline__ void passB_load(const float2* S, float2 (&w)[16], int c, int k) {
+// multiply v[r] by b^r (r = 1..15) given the four table values b^1, b^2, b^4, b^8: powers are built with 11 multiplies of
+// depth <= 3 and applied as soon as they exist, so that only four intermediate powers stay live
+__device__ __forceinline__ void apply_powers(float2 (&v)[16], float2 b1, float2 b2, float2 b4, float2 b8) {
+    // two interleaved chains (odd / even powers) stepping by b^2: 14 multiplies, only three powers live at any time
+    (void)b4; (void)b8;
+    float2 wo = b1, we = b2;
+    v[1] = cmul(v[1], wo);
+    v[2] = cmul(v[2], we);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = S[k * kRowA + c + 16 * r];
+    for (int r = 3; r < 16; r += 2) {
+        wo   = cmul(wo, b2);
+        v[r] = cmul(v[r], wo);
+        if (r + 1 < 16) {
+            we       = cmul(we, b2);
+            v[r + 1] = cmul(v[r + 1], we);
+        }
+    }
 }
+
+// buffer (SRSRC) accesses: wave-uniform descriptor + one 32-bit lane offset + a scalar offset per access, so no per-access
+// 64-bit address lives in VGPRs (with flat addressing hipcc hoists 40+ lane addresses out of the frame loop and spills them)
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000); }
+__device__ __forceinline__ float2 buf_load_f2(rsrc_t r, int voff, int soff) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
+__device__ __forceinline__ void buf_store_f(rsrc_t r, float v, int voff, int soff) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
+
+// value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS traffic
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+
+// pass-A exchange layout: rows 0..15 at r*kRowA, rows 16..31 shifted by 8 float2 (16 banks) so that the two lanes of a
+// pair (rows k1 and k1+16, same column) never share a bank
+__device__ __forceinline__ int addrA(int row, int col) { return row * kRowA + col + ((row & 16) ? 8 : 0); }
+
+// pass B (p = 32, radix 16): butterfly (c, k) gathers S1[k][c + 16 r], twiddles by W_512^{r k}, scatters to S2[c][32 q + k]
 __device__ __forceinline__ void passB_compute_store(float2* S, float2 (&w)[16], const float2* __restrict__ twB, int c, int k) {
-#pragma unroll
-    for (int r = 1; r < 16; ++r) w[r] = cmul(w[r], twB[r * 32 + k]);
+    apply_powers(w, twB[1 * 32 + k], twB[2 * 32 + k], twB[4 * 32 + k], twB[8 * 32 + k]);
     fft16<1>(w);
 #pragma unroll
     for (int q = 0; q < 16; ++q) S[c * kRowB + 32 * q + k] = w[perm16(q)];
 }
-// pass C (p = 512, radix 16): butterfly i3 gathers S2[r][i3]; result X[i3 + 512 q] at slot perm16(q)
+// pass C (p = 512, radix 16): butterfly i3 gathers S2[r][i3], twiddles by W_8192^{r i3}; X[i3 + 512 q] ends at slot perm16(q)
 __device__ __forceinline__ void passC(const float2* S, float2 (&g)[16], const float2* __restrict__ twC, int i3) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = S[r * kRowB + i3];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) g[r] = cmul(g[r], twC[r * 512 + i3]);
+    apply_powers(g, twC[1 * 512 + i3], twC[2 * 512 + i3], twC[4 * 512 + i3], twC[8 * 512 + i3]);
     fft16<1>(g);
 }
-// FFT(y_f)[k] = H[k] X[k] + E[k];  mag2 = |.|^2   (k = i3 + 512 q)
-__device__ __forceinline__ void combine_store(float* __restrict__ out, const float2* __restrict__ H, const float2 (&X)[16], const float2 (&E)[16], int i3) {
+
+// phase fence: keeps hipcc's scheduler from overlapping independent phases (which costs more registers than the 128 a lane has
+// at 4 waves per SIMD and ends in scratch spills)
+#define GR4_PHASE_FENCE()                      \
+    do {                                       \
+        asm volatile("" ::: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+// developer instrumentation (-DGR4_FD_TIMING): wave 0 of every workgroup stamps s_memtime at phase boundaries into a.dbg
+#ifdef GR4_FD_TIMING
+#define GR4_STAMP(i)                                                                                  \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && a.dbg) a.dbg[((f / gridDim.x) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define GR4_STAMP(i) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(3))) void*       lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+// force 16 complex values into VGPRs at this point (any spill reload happens HERE, i.e. before an LDS-DMA is put in flight:
+// a scratch reload behind the DMA makes hipcc wait vmcnt(0) and serialises the prefetch with the tail of the frame)
+__device__ __forceinline__ void pin16(float2 (&v)[16]) {
+    asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
+                      "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y));
+    asm volatile("" : "+v"(v[8].x), "+v"(v[8].y), "+v"(v[9].x), "+v"(v[9].y), "+v"(v[10].x), "+v"(v[10].y), "+v"(v[11].x), "+v"(v[11].y),
+                      "+v"(v[12].x), "+v"(v[12].y), "+v"(v[13].x), "+v"(v[13].y), "+v"(v[14].x), "+v"(v[14].y), "+v"(v[15].x), "+v"(v[15].y));
+}
+
+// asynchronous HBM -> LDS copy of one frame (64 KB) into the pass-A exchange layout: 64 one-KiB pieces, 8 per wave; no VGPR
+// staging, the data is in flight while the workgroup finishes the previous frame.
+__device__ __forceinline__ void dma_frame(const float2* __restrict__ xf, float2* S, int wave, int lane) {
+    asm volatile("" : "+v"(lane)); // recompute the 8 lane addresses here instead of carrying them (16 VGPRs) around the frame loop
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int    k = i3 + 512 * q;
-        const float2 Y = cadd(cmul(H[k], X[perm16(q)]), E[perm16(q)]);
-        out[k]         = fmaf(Y.x, Y.x, Y.y * Y.y);
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * wave + (i >> 1), half = i & 1;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xf + row * 256 + 128 * half + 2 * lane), (lds_ptr_t)(S + addrA(row, 128 * half)), 16, 0, 0);
     }
 }
 
-__global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    float2* S  = smem;              // kSLen
-    float2* dl = smem + kSLen;      // 256: d[i]
-    float2* el = dl + 256;          // 256: e[n]
-    float*  hl = reinterpret_cast<float*>(el + 256); // 256 taps
+// Persistent workgroups of 512 lanes (8 waves); frame f = blockIdx.x, blockIdx.x + gridDim.x, ...  Every lane owns 16 points.
+__global__ __launch_bounds__(kT, GR4_FD_WAVES) void chain_fd_kernel(ChainFdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
+    float2* S  = smem;                               // kSLen: frame image / exchange buffer
+    float2* D  = smem + kSLen;                       // 512: D[i+1] = d[i] (i < 255), zero elsewhere (zero padding of the e-FIR)
+    float2* el = D + 512;                            // 256: e[n] (tap quarter 0, then the sum)
+    float2* pq = el + 256;                           // 3 x 256: partial e of tap quarters 1..3
+    float*  hl = reinterpret_cast<float*>(pq + 768); // 256 taps
 
-    const int     t = threadIdx.x;
-    const long    f = blockIdx.x;
-    const float2* x = a.x + f * kN;
-
-    // ------------------------------------------------------------------ pass A: 32-point DFT down the 256 columns
-    float2 v[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r] = x[t + 256 * r];
-    hl[t] = a.taps[t];
-    {   // d[t-1] = (previous frame's sample at the same tail position) - (this frame's): only lanes 1..255
-        const float2 prev = (f > 0) ? x[t + 256 * 31 - kN] : a.hist[t];
-        dl[(t + 255) & 255] = (t > 0) ? csub(prev, v[31]) : make_float2(0.f, 0.f); // lane 0 clears slot 255
+    const int t    = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    if (t < 256) {
+        hl[t]      = a.taps[t];
+        D[256 + t] = make_float2(0.f, 0.f);
     }
-    // X[k1 + 16 k2] = E16[k1] + (-1)^k2 W_32^k1 O16[k1]
-    fft16<2>(v);
-    fft16<2>(v + 1);
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-        const float2 e  = v[2 * perm16(k1)];
-        const float2 o  = v[2 * perm16(k1) + 1];
-        const float2 wo = k1 == 0 ? o : cmul(o, w32(k1));
-        S[k1 * kRowA + t]        = cadd(e, wo);
-        S[(k1 + 16) * kRowA + t] = csub(e, wo);
-    }
-    __syncthreads();
+    if (t == 0) D[0] = make_float2(0.f, 0.f);
 
-    // ------------------------------------------------------------------ e[n] = sum_{i=n}^{254} d[i] * b[255 + n - i]
-    {
-        float2 acc = make_float2(0.f, 0.f);
-        for (int i = 0; i < kTail; ++i) {
-            const float2 dv = dl[i];                          // uniform address: LDS broadcast
-            const int    hi = 255 + t - i;
-            const float  hv = (i >= t && hi < 256) ? hl[hi & 255] : 0.f;
-            acc.x = fmaf(dv.x, hv, acc.x);
-            acc.y = fmaf(dv.y, hv, acc.y);
+    long   f  = blockIdx.x;
+    float2 pv = make_float2(0.f, 0.f); // previous frame's sample at this lane's tail position (odd lanes)
+    if (f < a.n_frames) {
+        if (t & 1) pv = (f > 0) ? a.x[f * kN - 256 + (t >> 1)] : a.hist[t >> 1];
+        dma_frame(a.x + f * kN, S, wave, lane);
+    }
+    for (; f < a.n_frames; f += gridDim.x) {
+        // every lane role is re-derived from a laundered copy of the lane id inside the loop: anything lane-dependent that is
+        // loop-invariant gets hoisted by hipcc and then lives (or is spilled) across the whole frame
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        // pass A roles: column n0, parity par (even / odd rows of the column); the pair (2 n0, 2 n0 + 1) are neighbouring lanes
+        const int   n0 = tt >> 1, par = tt & 1;
+        const float sgn = par ? -1.f : 1.f;
+        const float2* twB = a.twB; // laundered: keeps hipcc from hoisting the per-lane table loads out of the frame loop
+        const float2* twC = a.twC;
+        const float2* Hp  = a.H;
+        asm volatile("" : "+s"(twB), "+s"(twC), "+s"(Hp));
+        GR4_STAMP(0);
+        __syncthreads(); // T: this frame's image has landed (vmcnt(0) + barrier); D / el of the previous frame are dead
+
+        GR4_STAMP(1);
+        // ------------------------------------------------------------------ pass A: 32-point DFT down the 256 columns, in place
+        // (a lane pair reads all 32 rows of its column before it writes them back: no barrier needed)
+        {
+            float2 v[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m] = S[addrA(2 * m + par, n0)];
+            if (par && n0 > 0) D[n0] = csub(pv, v[15]); // v[15] is x_f[N - 256 + n0]:  D[n0] = d[n0 - 1]
+            fft16<1>(v); // even lanes: E16[k1], odd lanes: O16[k1], at slot perm16(k1)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) {
+                // X[k1] = E + W O (even lane), X[k1 + 16] = E - W O (odd lane), W = W_32^k1
+                float2       u  = v[perm16(k1)];
+                const float2 uw = k1 == 0 ? u : cmul(u, w32(k1));
+                u.x = par ? uw.x : u.x;
+                u.y = par ? uw.y : u.y;
+                const float2 q = make_float2(lane_xor1(u.x), lane_xor1(u.y));
+                S[addrA(k1 + 16 * par, n0)] = make_float2(fmaf(sgn, u.x, q.x), fmaf(sgn, u.y, q.y));
+            }
         }
-        el[t] = (t < kTail) ? acc : make_float2(0.f, 0.f);
+        GR4_STAMP(2);
+        __syncthreads(); // #1
+        GR4_STAMP(3);
+        GR4_PHASE_FENCE();
+
+        // ------------------------------------------------------------------ e[n] = sum_j b[j] dz[255 + n - j]
+        // wave -> tap quarter tq (taps [64 tq, 64 tq + 64)) and output half oh; lane -> outputs n = 128 oh + 2 lane + {0,1}
+        {
+            const int    tq = wave & 3, oh = wave >> 2;
+            const int    lane = tt & 63;
+            const float* Df = reinterpret_cast<const float*>(D);
+            const float* tg = hl + 64 * tq;
+            const int    c0 = 512 + 256 * oh + 4 * lane - 128 * tq; // float index of (n, tap 64 tq) in the float view of D
+            float        acc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!(oh == 1 && tq < 2)) { // taps j <= 127 never reach outputs n >= 128 (only j > n contributes)
+                float4 hi = *reinterpret_cast<const float4*>(Df + c0);
+                float4 lo = *reinterpret_cast<const float4*>(Df + c0 - 4);
+#pragma unroll 4
+                for (int g = 0; g < 32; ++g) {
+                    const float2 h2 = *reinterpret_cast<const float2*>(tg + 2 * g);
+                    acc[0] = fmaf(h2.x, hi.x, acc[0]); acc[1] = fmaf(h2.x, hi.y, acc[1]);
+                    acc[2] = fmaf(h2.x, hi.z, acc[2]); acc[3] = fmaf(h2.x, hi.w, acc[3]);
+                    acc[0] = fmaf(h2.y, lo.z, acc[0]); acc[1] = fmaf(h2.y, lo.w, acc[1]);
+                    acc[2] = fmaf(h2.y, hi.x, acc[2]); acc[3] = fmaf(h2.y, hi.y, acc[3]);
+                    hi = lo;
+                    if (g < 31) lo = *reinterpret_cast<const float4*>(Df + c0 - 4 * g - 8);
+                }
+            }
+            float2* dst = (tq == 0 ? el : pq + 256 * (tq - 1)) + 128 * oh + 2 * lane;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+
+        GR4_PHASE_FENCE();
+        // ------------------------------------------------------------------ X pass B (p = 32, radix 16)
+        // roles: c = lane & 15, k = 4 wave + {0,2,1,3}[lane >> 4]  (k and k+2 share a 32-lane group: disjoint banks)
+        asm volatile("" : "+v"(tt));
+        const int cb = tt & 15, kq = (tt >> 4) & 3;
+        const int kb = 4 * (tt >> 6) + ((kq & 1) << 1 | (kq >> 1));
+        float2 w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
+        GR4_STAMP(4);
+        __syncthreads(); // #2
+        GR4_STAMP(5);
+        if (tt < 256) {
+            const float2 s0 = el[tt], s1 = pq[tt], s2 = pq[256 + tt], s3 = pq[512 + tt];
+            el[tt] = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+        }
+        passB_compute_store(S, w, twB, cb, kb);
+        GR4_STAMP(6);
+        __syncthreads(); // #3
+        GR4_STAMP(7);
+        // ------------------------------------------------------------------ X pass C (p = 512, radix 16), then H[k] X[k]
+        float2 X[16];
+        asm volatile("" : "+v"(tt));
+        passC(S, X, twC, tt);
+        GR4_PHASE_FENCE();
+        {
+            const rsrc_t rH = make_rsrc(Hp, kN * sizeof(float2));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) X[perm16(q)] = cmul(buf_load_f2(rH, tt * 8, q * 4096), X[perm16(q)]);
+        }
+        GR4_STAMP(8);
+        __syncthreads(); // #4: every lane has consumed S; e[] is complete
+
+        GR4_STAMP(9);
+        // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = el[cb + 16 * r];
+        passB_compute_store(S, w, twB, cb, kb);
+        GR4_STAMP(10);
+        __syncthreads(); // #5
+        GR4_STAMP(11);
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = S[r * kRowB + tt];
+        apply_powers(w, twC[1 * 512 + tt], twC[2 * 512 + tt], twC[4 * 512 + tt], twC[8 * 512 + tt]);
+        const long fn = f + gridDim.x;
+        if ((tt & 1) && fn < a.n_frames) pv = a.x[fn * kN - 256 + (tt >> 1)]; // ordinary load, issued ahead of the DMA, used after barrier T
+        GR4_STAMP(12);
+        __syncthreads(); // #6: S is free -> stream the next frame in while this one is finished from registers
+        pin16(X);
+        pin16(w);
+        GR4_STAMP(13);
+        if (fn < a.n_frames) dma_frame(a.x + fn * kN, S, tt >> 6, tt & 63);
+        GR4_PHASE_FENCE();
+        fft16<1>(w);
+        // ------------------------------------------------------------------ FFT(y_f)[k] = H[k] X[k] + E[k];  mag2 = |.|^2  (k = t + 512 q)
+        const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 Y = cadd(X[perm16(q)], w[perm16(q)]);
+            buf_store_f(ro, fmaf(Y.x, Y.x, Y.y * Y.y), tt * 4, q * 2048); // out[t + 512 q]
+        }
+        GR4_STAMP(14);
     }
-
-    // ------------------------------------------------------------------ X pass B (p = 32, radix 16) and pass C (p = 512, radix 16)
-    // butterfly u = t + 256 h  ->  (c, k) = (u & 15, u >> 4) for pass B;  i3 = u for pass C
-    const int c0 = t & 15, k0 = t >> 4, k1 = k0 + 16;
-    float2    X0[16], X1[16], w0[16], w1[16];
-    passB_load(S, w0, c0, k0);
-    passB_load(S, w1, c0, k1);
-    __syncthreads();
-    passB_compute_store(S, w0, a.twB, c0, k0);
-    passB_compute_store(S, w1, a.twB, c0, k1);
-    __syncthreads();
-    passC(S, X0, a.twC, t);
-    passC(S, X1, a.twC, t + 256);
-    __syncthreads(); // every lane has consumed S; e[] is complete
-
-    // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
-#pragma unroll
-    for (int r = 0; r < 16; ++r) w0[r] = el[c0 + 16 * r];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) w1[r] = w0[r];
-    passB_compute_store(S, w0, a.twB, c0, k0);
-    passB_compute_store(S, w1, a.twB, c0, k1);
-    __syncthreads();
-    float* out = a.out + f * kN;
-    passC(S, w0, a.twC, t);
-    combine_store(out, a.H, X0, w0, t);
-    passC(S, w1, a.twC, t + 256);
-    combine_store(out, a.H, X1, w1, t + 256);
 }
 
 int chain_fused_reset(struct ChainFused* c);
+#ifdef GR4_FD_TIMING
+static unsigned long long* g_dbg = nullptr;
+#endif
 struct ChainFused {
     size_t       ntaps = 0;
     DeviceBuffer d_H, d_twB, d_twC, d_taps, d_hist;
@@ -291,13 +445,21 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
     a.taps     = static_cast<const float*>(c->d_taps.ptr);
     a.out      = d_mag2;
     a.n_frames = (long)n_frames;
-    const size_t lds = (size_t)kSLen * sizeof(float2) + 2 * 256 * sizeof(float2) + 256 * sizeof(float);
-    static bool  attr_set = false;
-    if (!attr_set) {
+    a.dbg      = nullptr;
+#ifdef GR4_FD_TIMING
+    if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
+    if (n_frames * 16 * 8 <= ((size_t)1 << 26)) a.dbg = g_dbg;
+#endif
+    const size_t lds = (size_t)(kSLen + 512 + 256 + 768) * sizeof(float2) + 256 * sizeof(float);
+    static int   n_cu = 0;
+    if (n_cu == 0) {
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        int dev = 0;
+        GR4_HIP_TRY(hipGetDevice(&dev));
+        GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    hipLaunchKernelGGL(chain_fd_kernel, dim3((unsigned)n_frames), dim3(kT), lds, st, a);
+    const unsigned grid = (unsigned)std::min<size_t>(n_frames, (size_t)(GR4_FD_WAVES / 2) * n_cu); // resident workgroups per CU (LDS and VGPR bound)
+    hipLaunchKernelGGL(chain_fd_kernel, dim3(grid), dim3(kT), lds, st, a);
     GR4_LAUNCH_CHECK();
     // carry the last 256 input samples for the next call's first frame (stream-ordered after the kernel's reads)
     GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
@@ -305,5 +467,15 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
 }
 
 void chain_fused_destroy(ChainFused* c) { delete c; }
+
+#ifdef GR4_FD_TIMING
+} // namespace gr4
+extern "C" int gr4hip_dbg_fd_timing(unsigned long long* h_out, size_t n_frames) { // developer-only, not part of the ABI
+    if (!gr4::g_dbg) return GR4HIP_ERROR;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(h_out, gr4::g_dbg, n_frames * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? GR4HIP_OK : GR4HIP_RUNTIME_ERROR;
+}
+namespace gr4 {
+#endif
 
 } // namespace gr4
