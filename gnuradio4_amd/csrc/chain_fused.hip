@@ -26,9 +26,6 @@
 
 namespace gr4 {
 
-#ifndef GR4_FD_WAVES
-#define GR4_FD_WAVES 4
-#endif
 constexpr int kN     = 8192;
 constexpr int kT     = 512;  // lanes per workgroup (8 waves)
 constexpr int kTail  = 255;  // ntaps - 1 (taps are zero-padded to 256)
@@ -117,11 +114,9 @@ struct ChainFdArgs {
     unsigned long long* dbg; // GR4_FD_TIMING only
 };
 
-// multiply v[r] by b^r (r = 1..15) given the four table values b^1, b^2, b^4, b^8: powers are built with 11 multiplies of
-// depth <= 3 and applied as soon as they exist, so that only four intermediate powers stay live
-__device__ __forceinline__ void apply_powers(float2 (&v)[16], float2 b1, float2 b2, float2 b4, float2 b8) {
+// multiply v[r] by b^r (r = 1..15) given the table values b^1 and b^2
+__device__ __forceinline__ void apply_powers(float2 (&v)[16], float2 b1, float2 b2) {
     // two interleaved chains (odd / even powers) stepping by b^2: 14 multiplies, only three powers live at any time
-    (void)b4; (void)b8;
     float2 wo = b1, we = b2;
     v[1] = cmul(v[1], wo);
     v[2] = cmul(v[2], we);
@@ -156,17 +151,17 @@ __device__ __forceinline__ float lane_xor1(float v) {
 __device__ __forceinline__ int addrA(int row, int col) { return row * kRowA + col + ((row & 16) ? 8 : 0); }
 
 // pass B (p = 32, radix 16): butterfly (c, k) gathers S1[k][c + 16 r], twiddles by W_512^{r k}, scatters to S2[c][32 q + k]
-__device__ __forceinline__ void passB_compute_store(float2* S, float2 (&w)[16], const float2* __restrict__ twB, int c, int k) {
-    apply_powers(w, twB[1 * 32 + k], twB[2 * 32 + k], twB[4 * 32 + k], twB[8 * 32 + k]);
+__device__ __forceinline__ void passB_compute_store(float2* S, float2 (&w)[16], float2 b1, float2 b2, int c, int k) {
+    apply_powers(w, b1, b2);
     fft16<1>(w);
 #pragma unroll
     for (int q = 0; q < 16; ++q) S[c * kRowB + 32 * q + k] = w[perm16(q)];
 }
 // pass C (p = 512, radix 16): butterfly i3 gathers S2[r][i3], twiddles by W_8192^{r i3}; X[i3 + 512 q] ends at slot perm16(q)
-__device__ __forceinline__ void passC(const float2* S, float2 (&g)[16], const float2* __restrict__ twC, int i3) {
+__device__ __forceinline__ void passC(const float2* S, float2 (&g)[16], float2 b1, float2 b2, int i3) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = S[r * kRowB + i3];
-    apply_powers(g, twC[1 * 512 + i3], twC[2 * 512 + i3], twC[4 * 512 + i3], twC[8 * 512 + i3]);
+    apply_powers(g, b1, b2);
     fft16<1>(g);
 }
 
@@ -200,63 +195,108 @@ __device__ __forceinline__ void pin16(float2 (&v)[16]) {
                       "+v"(v[12].x), "+v"(v[12].y), "+v"(v[13].x), "+v"(v[13].y), "+v"(v[14].x), "+v"(v[14].y), "+v"(v[15].x), "+v"(v[15].y));
 }
 
+// One LDS-DMA piece: 64 lanes x 16 B = 1 KiB from per-lane global addresses to LDS [lds_byte_addr, +1 KiB) (M0 = wave-uniform LDS
+// address).  Issued from inline asm ON PURPOSE: hipcc's wait insertion does not see it, so it neither drains the copy in front of
+// the next ds_read (it cannot prove that the two frame buffers do not alias) nor in front of a barrier.  The copy is ordered by
+// the explicit s_waitcnt vmcnt(0) + s_barrier at the top of the frame loop (GR4_FULL_BARRIER), nothing else.
+__device__ __forceinline__ void dma_1k(const void* gsrc_lane, unsigned lds_byte_addr) {
+    unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr); // provably wave-uniform for the "s" constraint
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lds_ptr_t)p; }
+
 // asynchronous HBM -> LDS copy of one frame (64 KB) into the pass-A exchange layout: 64 one-KiB pieces, 8 per wave; no VGPR
-// staging, the data is in flight while the workgroup finishes the previous frame.
+// staging, the data is in flight while the workgroup transforms the previous frame.
 __device__ __forceinline__ void dma_frame(const float2* __restrict__ xf, float2* S, int wave, int lane) {
-    asm volatile("" : "+v"(lane)); // recompute the 8 lane addresses here instead of carrying them (16 VGPRs) around the frame loop
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(S));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = 4 * wave + (i >> 1), half = i & 1;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xf + row * 256 + 128 * half + 2 * lane), (lds_ptr_t)(S + addrA(row, 128 * half)), 16, 0, 0);
+        dma_1k(xf + row * 256 + 128 * half + 2 * lane, base + (unsigned)addrA(row, 128 * half) * 8u);
     }
 }
 
-// Persistent workgroups of 512 lanes (8 waves); frame f = blockIdx.x, blockIdx.x + gridDim.x, ...  Every lane owns 16 points.
-__global__ __launch_bounds__(kT, GR4_FD_WAVES) void chain_fd_kernel(ChainFdArgs a) {
+// the 256 samples preceding frame f (previous frame's tail, or the carried history for the first frame of a call): 2 KiB, waves 0/1
+__device__ __forceinline__ void dma_tail(const float2* __restrict__ src, float2* Tl, int wave, int lane) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(Tl));
+    if (wave < 2) dma_1k(src + 128 * wave + 2 * lane, base + 1024u * wave);
+}
+
+// workgroup barriers that do NOT drain the vector-memory counter: an LDS-DMA for the next frame stays in flight across them
+// (__syncthreads() would emit s_waitcnt vmcnt(0) while a DMA is pending and serialise the prefetch with this frame's work)
+#define GR4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define GR4_FULL_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// One persistent workgroup of 512 lanes (8 waves, 2 per SIMD) per CU; frame f = blockIdx.x, blockIdx.x + gridDim.x, ...
+// Every lane owns 16 points.  Two frame buffers alternate: while frame f is transformed in one, the LDS-DMA of frame
+// f + gridDim.x fills the other during the WHOLE frame time (smooth HBM demand instead of chip-wide bursts).  Nothing in the
+// loop issues an ordinary vector load behind the DMA (loads return in order, so waiting for one would wait for the DMA):
+// H[k], the twiddle bases and the FIR taps live in registers / SGPRs for the lifetime of the kernel.
+__global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
-    float2* S  = smem;                               // kSLen: frame image / exchange buffer
-    float2* D  = smem + kSLen;                       // 512: D[i+1] = d[i] (i < 255), zero elsewhere (zero padding of the e-FIR)
+    float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
+    float2* B1 = smem + kSLen;                       // kSLen: (odd frames)
+    float2* D  = B1 + kSLen;                         // 512: D[i+1] = d[i] (i < 255), zero elsewhere (zero padding of the e-FIR)
     float2* el = D + 512;                            // 256: e[n] (tap quarter 0, then the sum)
     float2* pq = el + 256;                           // 3 x 256: partial e of tap quarters 1..3
-    float*  hl = reinterpret_cast<float*>(pq + 768); // 256 taps
+    float2* T0 = pq + 768;                           // 256: tail of the stream before the frame in B0 (x[fN - 256 + j])
+    float2* T1 = T0 + 256;                           // 256: same for B1
+    float*  hl = reinterpret_cast<float*>(T1 + 256); // 256 taps
 
     const int t    = threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     if (t < 256) {
         hl[t]      = a.taps[t];
         D[256 + t] = make_float2(0.f, 0.f);
     }
     if (t == 0) D[0] = make_float2(0.f, 0.f);
 
-    long   f  = blockIdx.x;
-    float2 pv = make_float2(0.f, 0.f); // previous frame's sample at this lane's tail position (odd lanes)
-    if (f < a.n_frames) {
-        if (t & 1) pv = (f > 0) ? a.x[f * kN - 256 + (t >> 1)] : a.hist[t >> 1];
-        dma_frame(a.x + f * kN, S, wave, lane);
-    }
-    for (; f < a.n_frames; f += gridDim.x) {
-        // every lane role is re-derived from a laundered copy of the lane id inside the loop: anything lane-dependent that is
-        // loop-invariant gets hoisted by hipcc and then lives (or is spilled) across the whole frame
-        int tt = t;
-        asm volatile("" : "+v"(tt));
-        // pass A roles: column n0, parity par (even / odd rows of the column); the pair (2 n0, 2 n0 + 1) are neighbouring lanes
-        const int   n0 = tt >> 1, par = tt & 1;
-        const float sgn = par ? -1.f : 1.f;
-        const float2* twB = a.twB; // laundered: keeps hipcc from hoisting the per-lane table loads out of the frame loop
-        const float2* twC = a.twC;
-        const float2* Hp  = a.H;
-        asm volatile("" : "+s"(twB), "+s"(twC), "+s"(Hp));
-        GR4_STAMP(0);
-        __syncthreads(); // T: this frame's image has landed (vmcnt(0) + barrier); D / el of the previous frame are dead
+    // pass A roles: column n0, parity par (even / odd rows of the column); the pair (2 n0, 2 n0 + 1) are neighbouring lanes
+    const int   n0 = t >> 1, par = t & 1;
+    const float sgn = par ? -1.f : 1.f;
+    // pass B roles: c = lane & 15, k = 4 wave + {0,2,1,3}[lane >> 4]  (k and k+2 share a 32-lane group: disjoint banks)
+    const int cb = lane & 15, kq = lane >> 4;
+    const int kb = 4 * wave + ((kq & 1) << 1 | (kq >> 1));
+    // e-FIR roles
+    const int tq = wave & 3, oh = wave >> 2;
 
+    // ---- kernel-lifetime registers: H[t + 512 q], twiddle bases W_512^{kb}, W_512^{2 kb}, W_8192^{t}, W_8192^{2t}
+    float2 Hr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Hr[q] = a.H[t + 512 * q];
+    const float2 bB1 = a.twB[1 * 32 + kb], bB2 = a.twB[2 * 32 + kb];
+    const float2 bC1 = a.twC[1 * 512 + t], bC2 = a.twC[2 * 512 + t];
+
+    long f   = blockIdx.x;
+    int  cur = 0;
+    if (f < a.n_frames) {
+        dma_tail(f > 0 ? a.x + f * kN - 256 : a.hist, T0, wave, lane);
+        dma_frame(a.x + f * kN, B0, wave, lane);
+    }
+    for (; f < a.n_frames; f += gridDim.x, cur ^= 1) {
+        float2* S  = cur ? B1 : B0;
+        float2* Sn = cur ? B0 : B1;
+        const float2* Tc = cur ? T1 : T0;
+        GR4_STAMP(0);
+        GR4_FULL_BARRIER(); // T: this frame's image has landed (vmcnt(0) + barrier); everything of the previous frame is dead
         GR4_STAMP(1);
+        // stream the next frame (and the 256 samples before it) into the other buffers: in flight until the next barrier T.
+        // Unconditional (the last iteration re-reads its own frame): no divergent paths around the DMA for hipcc's wait insertion
+        const long fn = (f + gridDim.x < a.n_frames) ? f + gridDim.x : f;
+        dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
+        dma_frame(a.x + fn * kN, Sn, wave, lane);
+
         // ------------------------------------------------------------------ pass A: 32-point DFT down the 256 columns, in place
         // (a lane pair reads all 32 rows of its column before it writes them back: no barrier needed)
         {
             float2 v[16];
 #pragma unroll
             for (int m = 0; m < 16; ++m) v[m] = S[addrA(2 * m + par, n0)];
-            if (par && n0 > 0) D[n0] = csub(pv, v[15]); // v[15] is x_f[N - 256 + n0]:  D[n0] = d[n0 - 1]
+            if (par && n0 > 0) D[n0] = csub(Tc[n0], v[15]); // v[15] is x_f[N - 256 + n0]:  D[n0] = d[n0 - 1]
             fft16<1>(v); // even lanes: E16[k1], odd lanes: O16[k1], at slot perm16(k1)
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
@@ -270,17 +310,14 @@ __global__ __launch_bounds__(kT, GR4_FD_WAVES) void chain_fd_kernel(ChainFdArgs 
             }
         }
         GR4_STAMP(2);
-        __syncthreads(); // #1
+        GR4_LDS_BARRIER(); // #1
         GR4_STAMP(3);
-        GR4_PHASE_FENCE();
 
         // ------------------------------------------------------------------ e[n] = sum_j b[j] dz[255 + n - j]
-        // wave -> tap quarter tq (taps [64 tq, 64 tq + 64)) and output half oh; lane -> outputs n = 128 oh + 2 lane + {0,1}
+        // wave -> tap quarter tq (taps [64 tq, 64 tq + 64), held in SGPRs) and output half oh; lane -> outputs n = 128 oh + 2 lane + {0,1}
         {
-            const int    tq = wave & 3, oh = wave >> 2;
-            const int    lane = tt & 63;
             const float* Df = reinterpret_cast<const float*>(D);
-            const float* tg = hl + 64 * tq;
+            const float* tg = hl + 64 * tq; // wave-uniform address: LDS broadcast reads
             const int    c0 = 512 + 256 * oh + 4 * lane - 128 * tq; // float index of (n, tap 64 tq) in the float view of D
             float        acc[4] = {0.f, 0.f, 0.f, 0.f};
             if (!(oh == 1 && tq < 2)) { // taps j <= 127 never reach outputs n >= 128 (only j > n contributes)
@@ -289,10 +326,11 @@ __global__ __launch_bounds__(kT, GR4_FD_WAVES) void chain_fd_kernel(ChainFdArgs 
 #pragma unroll 4
                 for (int g = 0; g < 32; ++g) {
                     const float2 h2 = *reinterpret_cast<const float2*>(tg + 2 * g);
-                    acc[0] = fmaf(h2.x, hi.x, acc[0]); acc[1] = fmaf(h2.x, hi.y, acc[1]);
-                    acc[2] = fmaf(h2.x, hi.z, acc[2]); acc[3] = fmaf(h2.x, hi.w, acc[3]);
-                    acc[0] = fmaf(h2.y, lo.z, acc[0]); acc[1] = fmaf(h2.y, lo.w, acc[1]);
-                    acc[2] = fmaf(h2.y, hi.x, acc[2]); acc[3] = fmaf(h2.y, hi.y, acc[3]);
+                    const float  h0 = h2.x, h1 = h2.y;
+                    acc[0] = fmaf(h0, hi.x, acc[0]); acc[1] = fmaf(h0, hi.y, acc[1]);
+                    acc[2] = fmaf(h0, hi.z, acc[2]); acc[3] = fmaf(h0, hi.w, acc[3]);
+                    acc[0] = fmaf(h1, lo.z, acc[0]); acc[1] = fmaf(h1, lo.w, acc[1]);
+                    acc[2] = fmaf(h1, hi.x, acc[2]); acc[3] = fmaf(h1, hi.y, acc[3]);
                     hi = lo;
                     if (g < 31) lo = *reinterpret_cast<const float4*>(Df + c0 - 4 * g - 8);
                 }
@@ -301,68 +339,47 @@ __global__ __launch_bounds__(kT, GR4_FD_WAVES) void chain_fd_kernel(ChainFdArgs 
             *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
 
-        GR4_PHASE_FENCE();
         // ------------------------------------------------------------------ X pass B (p = 32, radix 16)
-        // roles: c = lane & 15, k = 4 wave + {0,2,1,3}[lane >> 4]  (k and k+2 share a 32-lane group: disjoint banks)
-        asm volatile("" : "+v"(tt));
-        const int cb = tt & 15, kq = (tt >> 4) & 3;
-        const int kb = 4 * (tt >> 6) + ((kq & 1) << 1 | (kq >> 1));
         float2 w[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
         GR4_STAMP(4);
-        __syncthreads(); // #2
+        GR4_LDS_BARRIER(); // #2
         GR4_STAMP(5);
-        if (tt < 256) {
-            const float2 s0 = el[tt], s1 = pq[tt], s2 = pq[256 + tt], s3 = pq[512 + tt];
-            el[tt] = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+        if (t < 256) {
+            const float2 s0 = el[t], s1 = pq[t], s2 = pq[256 + t], s3 = pq[512 + t];
+            el[t] = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
         }
-        passB_compute_store(S, w, twB, cb, kb);
+        passB_compute_store(S, w, bB1, bB2, cb, kb);
         GR4_STAMP(6);
-        __syncthreads(); // #3
+        GR4_LDS_BARRIER(); // #3
         GR4_STAMP(7);
         // ------------------------------------------------------------------ X pass C (p = 512, radix 16), then H[k] X[k]
         float2 X[16];
-        asm volatile("" : "+v"(tt));
-        passC(S, X, twC, tt);
-        GR4_PHASE_FENCE();
-        {
-            const rsrc_t rH = make_rsrc(Hp, kN * sizeof(float2));
+        passC(S, X, bC1, bC2, t);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) X[perm16(q)] = cmul(buf_load_f2(rH, tt * 8, q * 4096), X[perm16(q)]);
-        }
+        for (int q = 0; q < 16; ++q) X[perm16(q)] = cmul(Hr[q], X[perm16(q)]);
         GR4_STAMP(8);
-        __syncthreads(); // #4: every lane has consumed S; e[] is complete
-
+        GR4_LDS_BARRIER(); // #4: every lane has consumed S; e[] is complete
         GR4_STAMP(9);
+
         // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
 #pragma unroll
         for (int r = 0; r < 16; ++r) w[r] = el[cb + 16 * r];
-        passB_compute_store(S, w, twB, cb, kb);
+        passB_compute_store(S, w, bB1, bB2, cb, kb);
         GR4_STAMP(10);
-        __syncthreads(); // #5
+        GR4_LDS_BARRIER(); // #5
         GR4_STAMP(11);
-        asm volatile("" : "+v"(tt));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) w[r] = S[r * kRowB + tt];
-        apply_powers(w, twC[1 * 512 + tt], twC[2 * 512 + tt], twC[4 * 512 + tt], twC[8 * 512 + tt]);
-        const long fn = f + gridDim.x;
-        if ((tt & 1) && fn < a.n_frames) pv = a.x[fn * kN - 256 + (tt >> 1)]; // ordinary load, issued ahead of the DMA, used after barrier T
+        passC(S, w, bC1, bC2, t);
         GR4_STAMP(12);
-        __syncthreads(); // #6: S is free -> stream the next frame in while this one is finished from registers
-        pin16(X);
-        pin16(w);
-        GR4_STAMP(13);
-        if (fn < a.n_frames) dma_frame(a.x + fn * kN, S, tt >> 6, tt & 63);
-        GR4_PHASE_FENCE();
-        fft16<1>(w);
         // ------------------------------------------------------------------ FFT(y_f)[k] = H[k] X[k] + E[k];  mag2 = |.|^2  (k = t + 512 q)
         const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float2 Y = cadd(X[perm16(q)], w[perm16(q)]);
-            buf_store_f(ro, fmaf(Y.x, Y.x, Y.y * Y.y), tt * 4, q * 2048); // out[t + 512 q]
+            buf_store_f(ro, fmaf(Y.x, Y.x, Y.y * Y.y), t * 4, q * 2048); // out[t + 512 q]
         }
+        GR4_STAMP(13);
         GR4_STAMP(14);
     }
 }
@@ -450,7 +467,7 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
     if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
     if (n_frames * 16 * 8 <= ((size_t)1 << 26)) a.dbg = g_dbg;
 #endif
-    const size_t lds = (size_t)(kSLen + 512 + 256 + 768) * sizeof(float2) + 256 * sizeof(float);
+    const size_t lds = (size_t)(2 * kSLen + 512 + 256 + 768 + 512) * sizeof(float2) + 256 * sizeof(float);
     static int   n_cu = 0;
     if (n_cu == 0) {
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -458,7 +475,7 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
         GR4_HIP_TRY(hipGetDevice(&dev));
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const unsigned grid = (unsigned)std::min<size_t>(n_frames, (size_t)(GR4_FD_WAVES / 2) * n_cu); // resident workgroups per CU (LDS and VGPR bound)
+    const unsigned grid = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu); // one resident workgroup per CU (148 KB of LDS)
     hipLaunchKernelGGL(chain_fd_kernel, dim3(grid), dim3(kT), lds, st, a);
     GR4_LAUNCH_CHECK();
     // carry the last 256 input samples for the next call's first frame (stream-ordered after the kernel's reads)
