@@ -60,7 +60,7 @@ def main():
     import torch.distributed as dist
 
     import gnuradio4_amd as G
-    from gnuradio4_amd import capi
+    from gnuradio4_amd import capi, fanin
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -78,7 +78,8 @@ def main():
     # synthetic input, generated on the device (noise seed 42 + channel index, tone at 0.1 fs)
     x = G.synth_c32(n, seed=42 + rank)
     out = torch.empty((n // NFFT, NFFT), dtype=torch.float32, device="cuda")
-    rs_out = torch.empty((frames_per_chunk // world) * NFFT, dtype=torch.float32, device="cuda") if world > 1 else None
+    # fan-in result: this rank's shard of the channel-summed spectra, one slab per launch
+    rs_out = torch.empty((nchunks, frames_per_chunk // world, NFFT), dtype=torch.float32, device="cuda") if world > 1 else None
     import numpy as np
     k = np.arange(NTAPS, dtype=np.float64)
     w = np.empty(NTAPS, np.float32)
@@ -102,7 +103,7 @@ def main():
             if record:
                 ev[c][1].record()
             if world > 1:  # fan-in combiner (math::Add over channels) as reduce_scatter, async on RCCL's stream
-                works.append(dist.reduce_scatter_tensor(rs_out, os_.reshape(-1), op=dist.ReduceOp.SUM, async_op=True))
+                works.append(fanin.fan_in_sum(os_, rs_out[c], async_op=True)[1])
         for wk in works:
             wk.wait()
 
@@ -133,6 +134,13 @@ def main():
         launch_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = chunk * ALGO_BYTES_PER_SAMPLE / (launch_ms * 1e-3) / 1e9
         algo_names = {1: "fir_poly_kernel + fft_block_kernel (unfused)", 2: "chain_fused_td_kernel", 3: "chain_fused_fd_kernel"}
+        traffic = None  # HBM bytes per launch from the committed PMC profile of the same kernel + launch size (profiles/), else null
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+            if prof.get("kernel") == algo_names.get(chain.algo) and prof.get("samples_per_launch") == chunk:
+                traffic = prof["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         res = {
             "metric": "Msamples/s through 256-tap cplx FIR->8192-pt FFT chain; %HBM roofline @1/2/4/8 GPU",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -143,7 +151,7 @@ def main():
                                    + (f"; {world} channels, RCCL reduce_scatter fan-in sum (configs[4] shape)" if world > 1 else ""),
                        "chain_algo": algo_names.get(chain.algo, str(chain.algo)), "parallelism": f"{world} independent channel(s), 1 per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": algo_names.get(chain.algo, str(chain.algo)),
+                         "traffic": traffic, "kernel": algo_names.get(chain.algo, str(chain.algo)),
                          "algorithmic_bytes_per_launch": chunk * ALGO_BYTES_PER_SAMPLE, "avg_launch_ms": round(launch_ms, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

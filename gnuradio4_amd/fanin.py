@@ -1,0 +1,53 @@
+"""Multi-GPU host logic: independent SDR-channel sub-graphs (one per rank) and the fan-in combiner edge.
+
+The flowgraph shards only across independent branches: channel c -> rank c mod world.  The one exchange step is the
+combiner `gr::blocks::math::Add<float>` with n_inputs = channels (blocks/math/.../Math.hpp:73-108) that sums frame-aligned |X|^2
+vectors; across GPUs it is an RCCL reduce_scatter (every rank reduces 1/world of the frames, all xGMI links busy both ways) instead
+of a reduce-to-root.  Backend "nccl" is RCCL on ROCm; "gloo" (CPU tests) has no reduce_scatter and takes all_reduce + slice.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def channel_plan(n_channels: int, world: int) -> List[List[int]]:
+    """channels owned by each rank (1/2/4/8 GPUs -> 8/4/2/1 channels per device for the 8-channel graph)."""
+    if n_channels < 1 or world < 1:
+        raise ValueError("n_channels and world must be >= 1")
+    return [[c for c in range(n_channels) if c % world == r] for r in range(world)]
+
+
+def shard_frames(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
+    """[lo, hi) frame range of the reduced spectra that `rank` owns after the reduce_scatter."""
+    if n_frames % world:
+        raise ValueError(f"n_frames={n_frames} must be a multiple of world={world} (launch sizes are chosen accordingly)")
+    per = n_frames // world
+    return rank * per, (rank + 1) * per
+
+
+def local_sum(channels: List[torch.Tensor]) -> torch.Tensor:
+    """left fold over the channels a rank owns -- the order of MathOpMultiPortImpl::processBulk (Math.hpp:100-107)."""
+    acc = channels[0].clone()
+    for c in channels[1:]:
+        acc += c
+    return acc
+
+
+def fan_in_sum(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None, async_op: bool = False):
+    """Sum `local` ([frames, fft_size] mag2 of this rank's channels) over all ranks; every rank keeps its shard of the frames.
+    Returns (shard, work-or-None)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_frames(local.shape[0], world, rank)
+    if out is None:
+        out = torch.empty((hi - lo,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "gloo":  # CPU test path: same result, different collective
+        tmp = local.clone()
+        work = dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group, async_op=False)
+        out.copy_(tmp[lo:hi])
+        return out, None
+    work = dist.reduce_scatter_tensor(out.reshape(-1), local.reshape(-1), op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return out, (work if async_op else None)

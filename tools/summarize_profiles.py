@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/prof_<tag>/ (rocprofv3 outputs) into the committed text summaries under profiles/.
+usage: summarize_profiles.py <tag> <kernel-substring>"""
+import collections
+import csv
+import glob
+import os
+import sqlite3
+import sys
+
+tag, kern = sys.argv[1], sys.argv[2]
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+lines = []
+db = sqlite3.connect(os.path.join(src, "trace_results.db"))
+rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (round tag {tag}; durations in microseconds)")
+lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'%':>6}  kernel")
+for name, calls, total, avg, pct in rows:
+    lines.append(f"{calls:7d} {total:12.1f} {avg:10.2f} {pct:6.2f}  {name}")
+lines.append("")
+lines.append(f"# rocprofv3 --pmc <counters> (separate passes, counters only) -- python bench.py --steps 1 --warmup 1 --log2-samples 28 --no-cpu-baseline")
+lines.append(f"# per-dispatch means for kernels matching '{kern}' (one dispatch = one launch of 2^26 samples)")
+for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if kern in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        lines.append(f"{k:24s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+fetch = [l for l in lines if l.startswith("FETCH_SIZE")]
+write = [l for l in lines if l.startswith("WRITE_SIZE")]
+if fetch and write:
+    fk = float(fetch[0].split("mean=")[1]); wk = float(write[0].split("mean=")[1])
+    lines.append("")
+    lines.append(f"# HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are in KiB): read {fk*1024/1e6:.1f} MB, write {wk*1024/1e6:.1f} MB")
+    lines.append("# (MI355X_MICROARCH.md: FETCH_SIZE under-reports 16-B/lane streaming reads by 2x on gfx950; this kernel's reads are 16-B/lane LDS-DMA)")
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj):
+    lines.append("")
+    lines.append("# python bench.py (un-profiled, same box)")
+    lines.append(open(bj).read().strip().splitlines()[-1])
+out = f"profiles/{tag}_{kern}_rocprof_summary.txt"
+open(out, "w").write("\n".join(lines) + "\n")
+print(open(out).read())
