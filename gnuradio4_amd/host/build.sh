@@ -1,0 +1,11 @@
+#!/bin/bash
+# builds the C++ host-layer test programs (g++ -std=c++20; the device tests link libgr4hip.so)
+set -e
+cd "$(dirname "$0")"
+OUT=../../build/host
+mkdir -p $OUT
+g++ -std=c++20 -O2 -Wall -Wextra -Iinclude tests/test_host_cpu.cpp -o $OUT/test_host_cpu
+if [ -f tests/test_host_device.cpp ]; then
+  g++ -std=c++20 -O2 -Wall -Wextra -Iinclude tests/test_host_device.cpp -o $OUT/test_host_device -L.. -lgr4hip -Wl,-rpath,'$ORIGIN/../../gnuradio4_amd' -Wl,-rpath,/opt/rocm/lib
+fi
+echo "built $(realpath $OUT)"

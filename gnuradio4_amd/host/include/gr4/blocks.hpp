@@ -1,0 +1,310 @@
+// gr4/blocks.hpp -- block definitions on the hot path, written against gr4/core.hpp in the reference's block style.
+//
+// Each block states the reference block it mirrors (settings names, port names, semantics, error behaviour).  The processOne /
+// processBulk bodies are the host ("compute_domain = host") path used by BASELINE configs[0] (CPU scheduler plumbing); with
+// compute_domain = "gpu:hip[:i]" the work loop dispatches to gr::hip::Kernel<Block> (gr4/hip.hpp) instead.
+#pragma once
+#include <cmath>
+#include <numbers>
+
+#include "core.hpp"
+
+namespace gr::testing {
+
+// settable-values source with a sample budget: the role of TagSource<T> (blocks/testing/.../TagMonitors.hpp:134-293) without tags
+template <typename T>
+struct VectorSource : Block<VectorSource<T>> {
+    PortOut<T>     out;
+    std::vector<T> values{};      // repeated cyclically when shorter than n_samples_max
+    Size_t         n_samples_max = 0; // 0: exactly values.size() samples
+    std::size_t    _produced     = 0;
+    GR_MAKE_REFLECTABLE(VectorSource, out, values, n_samples_max);
+
+    work::Result customWork(std::size_t requested) {
+        const std::size_t total = n_samples_max ? n_samples_max : values.size();
+        if (_produced >= total) return {requested, 0, work::Status::DONE};
+        if (!out.connected()) return {requested, 0, work::Status::ERROR};
+        const std::size_t n = std::min({total - _produced, out.buffer->free_space(), requested});
+        if (n == 0) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
+        auto span = out.buffer->write_span(n);
+        for (std::size_t i = 0; i < n; ++i) span[i] = values.empty() ? T{} : values[(_produced + i) % values.size()];
+        out.buffer->publish(n);
+        _produced += n;
+        return {requested, n, work::Status::OK};
+    }
+};
+
+// records everything it receives: TagSink<T> (TagMonitors.hpp:391-479) without tags
+template <typename T>
+struct VectorSink : Block<VectorSink<T>> {
+    PortIn<T>      in;
+    Size_t         n_samples_expected = 0;
+    std::vector<T> _samples;
+    GR_MAKE_REFLECTABLE(VectorSink, in, n_samples_expected);
+
+    work::Result customWork(std::size_t requested) {
+        if (!in.connected()) return {requested, 0, work::Status::ERROR};
+        const std::size_t n = std::min(in.buffer->available(), requested);
+        if (n == 0) return {requested, 0, in.buffer->producer_done ? work::Status::DONE : work::Status::INSUFFICIENT_INPUT_ITEMS};
+        auto span = in.buffer->read_span(n);
+        _samples.insert(_samples.end(), span.begin(), span.end());
+        in.buffer->consume(n);
+        return {requested, n, work::Status::OK};
+    }
+};
+
+// NullSink<T> / CountingSink<T> (blocks/testing/.../NullSources.hpp): consumes and counts
+template <typename T>
+struct NullSink : Block<NullSink<T>> {
+    PortIn<T>   in;
+    std::size_t _count = 0;
+    GR_MAKE_REFLECTABLE(NullSink, in);
+    work::Result customWork(std::size_t requested) {
+        if (!in.connected()) return {requested, 0, work::Status::ERROR};
+        const std::size_t n = std::min(in.buffer->available(), requested);
+        if (n == 0) return {requested, 0, in.buffer->producer_done ? work::Status::DONE : work::Status::INSUFFICIENT_INPUT_ITEMS};
+        in.buffer->consume(n);
+        _count += n;
+        return {requested, n, work::Status::OK};
+    }
+};
+} // namespace gr::testing
+
+namespace gr::basic {
+// gr::basic::SignalGenerator<T> (blocks/basic/.../SignalGenerator.hpp:25-87) reduced to Const / Sin / Cos with a sample budget:
+// value(t) = amplitude * f(2 pi frequency t + phase) + offset, t advancing by 1 / sample_rate  (ToneGenerator.hpp)
+template <typename T>
+struct SignalGenerator : Block<SignalGenerator<T>> {
+    PortOut<T>  out;
+    std::string signal_type = "Sin";
+    float       sample_rate = 1000.f, frequency = 1.f, amplitude = 1.f, offset = 0.f, phase = 0.f;
+    Size_t      n_samples_max = 0;
+    std::size_t _n = 0;
+    GR_MAKE_REFLECTABLE(SignalGenerator, out, signal_type, sample_rate, frequency, amplitude, offset, phase, n_samples_max);
+
+    work::Result customWork(std::size_t requested) {
+        if (n_samples_max && _n >= n_samples_max) return {requested, 0, work::Status::DONE};
+        if (!out.connected()) return {requested, 0, work::Status::ERROR};
+        std::size_t n = std::min(out.buffer->free_space(), requested);
+        if (n_samples_max) n = std::min<std::size_t>(n, n_samples_max - _n);
+        if (n == 0) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
+        auto span = out.buffer->write_span(n);
+        for (std::size_t i = 0; i < n; ++i) {
+            const double th = 2.0 * std::numbers::pi * static_cast<double>(frequency) * (static_cast<double>(_n + i) / static_cast<double>(sample_rate)) + static_cast<double>(phase);
+            const double v  = signal_type == "Const" ? 1.0 : signal_type == "Cos" ? std::cos(th) : std::sin(th);
+            span[i]         = static_cast<T>(static_cast<double>(amplitude) * v + static_cast<double>(offset));
+        }
+        out.buffer->publish(n);
+        _n += n;
+        return {requested, n, work::Status::OK};
+    }
+};
+} // namespace gr::basic
+
+namespace gr::filter {
+
+// gr::filter::fir_filter<T> (blocks/filter/.../time_domain_filter.hpp:22-48): setting `b`, y[n] = sum_k b[k] x[n-k], zero initial
+// history.  T = float / double as registered upstream, plus std::complex<float> (complex data, real taps).
+template <typename T>
+struct fir_filter : Block<fir_filter<T>> {
+    using tap_type = std::conditional_t<detail::is_complex<T>::value, float, T>;
+    PortIn<T>             in;
+    PortOut<T>            out;
+    std::vector<tap_type> b{tap_type(1)};
+    std::vector<T>        _history = std::vector<T>(32, T{}); // newest first, like HistoryBuffer{32}
+    GR_MAKE_REFLECTABLE(fir_filter, in, out, b);
+
+    void settingsChanged(const property_map& /*oldSettings*/, const property_map& newSettings) {
+        if (newSettings.contains("b") && b.size() > _history.size()) { // the reference replaces the HistoryBuffer only when it must grow (:38-42)
+            std::size_t cap = 1;
+            while (cap < b.size()) cap <<= 1;
+            _history.assign(cap, T{});
+        }
+    }
+    [[nodiscard]] T processOne(T input) noexcept {
+        std::move_backward(_history.begin(), _history.end() - 1, _history.end());
+        _history[0] = input;
+        T acc{};
+        for (std::size_t k = 0; k < b.size(); ++k) acc += b[k] * _history[k];
+        return acc;
+    }
+};
+
+enum class IIRForm { DF_I, DF_II, DF_I_TRANSPOSED, DF_II_TRANSPOSED }; // time_domain_filter.hpp:50-55
+
+// gr::filter::iir_filter<T, form> (time_domain_filter.hpp:62-122); a[0] is assumed to be 1
+template <typename T, IIRForm form = IIRForm::DF_II>
+struct iir_filter : Block<iir_filter<T, form>> {
+    PortIn<T>      in;
+    PortOut<T>     out;
+    std::vector<T> b{T(1)}, a{T(1)};
+    std::vector<T> _x = std::vector<T>(32, T{}), _y = std::vector<T>(32, T{});
+    GR_MAKE_REFLECTABLE(iir_filter, in, out, b, a);
+
+    static void push(std::vector<T>& h, T v) {
+        std::move_backward(h.begin(), h.end() - 1, h.end());
+        h[0] = v;
+    }
+    static T dot(const std::vector<T>& c, std::size_t first, const std::vector<T>& h) {
+        T acc{};
+        for (std::size_t k = first; k < c.size(); ++k) acc += c[k] * h[k - first];
+        return acc;
+    }
+    void settingsChanged(const property_map&, const property_map&) {
+        const std::size_t n = std::max(a.size(), b.size());
+        if (n >= _x.size()) { _x.assign(2 * n, T{}); _y.assign(2 * n, T{}); }
+    }
+    [[nodiscard]] T processOne(T input) noexcept {
+        if constexpr (form == IIRForm::DF_I) {
+            push(_x, input);
+            const T o = dot(b, 0, _x) - dot(a, 1, _y);
+            push(_y, o);
+            return o;
+        } else if constexpr (form == IIRForm::DF_II) {
+            const T w = input - dot(a, 1, _x);
+            push(_x, w);
+            return dot(b, 0, _x);
+        } else if constexpr (form == IIRForm::DF_I_TRANSPOSED) {
+            const T v0 = input - dot(a, 1, _y);
+            push(_y, v0);
+            return dot(b, 0, _y);
+        } else {
+            const T o = b[0] * input + dot(b, 1, _x) - dot(a, 1, _y);
+            push(_x, input);
+            push(_y, o);
+            return o;
+        }
+    }
+};
+
+// gr::filter::Decimator<T> (time_domain_filter.hpp:215-245): keep every decim-th sample
+template <typename T>
+struct Decimator : Block<Decimator<T>, Resampling<1, 1, false>> {
+    PortIn<T>  in;
+    PortOut<T> out;
+    Size_t     decim = 1;
+    GR_MAKE_REFLECTABLE(Decimator, in, out, decim);
+    void settingsChanged(const property_map&, const property_map&) { this->input_chunk_size = decim; }
+    [[nodiscard]] work::Status processBulk(std::span<const T> input, std::span<T> output) noexcept {
+        std::size_t o = 0;
+        for (std::size_t i = 0; i < input.size(); ++i)
+            if (i % decim == 0) output[o++] = input[i];
+        return work::Status::OK;
+    }
+};
+} // namespace gr::filter
+
+namespace gr::blocks::math {
+// MathOpImpl<T, op> (blocks/math/.../Math.hpp:30-57): out = in (op) value, default value 1
+template <typename T, typename op>
+struct MathOpImpl : Block<MathOpImpl<T, op>> {
+    PortIn<T>  in;
+    PortOut<T> out;
+    T          value = T(1);
+    GR_MAKE_REFLECTABLE(MathOpImpl, in, out, value);
+    [[nodiscard]] constexpr T processOne(const T& a) const noexcept { return static_cast<T>(op()(a, value)); }
+};
+template <typename T> using AddConst      = MathOpImpl<T, std::plus<T>>;
+template <typename T> using SubtractConst = MathOpImpl<T, std::minus<T>>;
+template <typename T> using MultiplyConst = MathOpImpl<T, std::multiplies<T>>;
+template <typename T> using DivideConst   = MathOpImpl<T, std::divides<T>>;
+
+// MathOpMultiPortImpl<T, op> (Math.hpp:73-108): left fold over n_inputs (1..32) streams
+template <typename T, typename op>
+struct MathOpMultiPortImpl : Block<MathOpMultiPortImpl<T, op>> {
+    std::vector<PortIn<T>> in;
+    PortOut<T>             out;
+    Size_t                 n_inputs = 0;
+    GR_MAKE_REFLECTABLE(MathOpMultiPortImpl, in, out, n_inputs);
+    void settingsChanged(const property_map&, const property_map& newSettings) {
+        if (newSettings.contains("n_inputs")) {
+            if (n_inputs < 1 || n_inputs > 32) throw std::invalid_argument("n_inputs must be in [1, 32]"); // Limits<1U, 32U> (Math.hpp:90)
+            in.resize(n_inputs);
+        }
+    }
+    work::Status processBulk(std::span<const std::span<const T>> ins, std::span<T> sout) const {
+        std::copy(ins[0].begin(), ins[0].end(), sout.begin());
+        for (std::size_t n = 1; n < ins.size(); ++n)
+            std::transform(sout.begin(), sout.end(), ins[n].begin(), sout.begin(), [](T x, T y) { return static_cast<T>(op{}(x, y)); });
+        return work::Status::OK;
+    }
+};
+template <typename T> using Add      = MathOpMultiPortImpl<T, std::plus<T>>;
+template <typename T> using Subtract = MathOpMultiPortImpl<T, std::minus<T>>;
+template <typename T> using Multiply = MathOpMultiPortImpl<T, std::multiplies<T>>;
+template <typename T> using Divide   = MathOpMultiPortImpl<T, std::divides<T>>;
+
+// Rotator<std::complex<T>> (blocks/math/.../Rotator.hpp:16-63): XOR settings frequency_shift / phase_increment
+template <typename T>
+struct Rotator : Block<Rotator<T>> {
+    using value_type = typename T::value_type;
+    PortIn<T>  in;
+    PortOut<T> out;
+    float      sample_rate = 1.f, frequency_shift = 0.f;
+    value_type phase_increment{0}, initial_phase{0};
+    value_type _accumulated_phase{0};
+    GR_MAKE_REFLECTABLE(Rotator, in, out, sample_rate, frequency_shift, initial_phase, phase_increment);
+    void settingsChanged(const property_map&, const property_map& n) {
+        const bool f = n.contains("frequency_shift"), p = n.contains("phase_increment");
+        if (f && p) throw std::invalid_argument("cannot set both 'frequency_shift' and 'phase_increment' in new setting (XOR)");
+        if (f) phase_increment = value_type(2) * static_cast<value_type>(std::numbers::pi_v<float> * frequency_shift / sample_rate);
+        else if (p) frequency_shift = static_cast<float>(phase_increment / (value_type(2) * std::numbers::pi_v<value_type>)) * sample_rate;
+        _accumulated_phase = initial_phase;
+    }
+    [[nodiscard]] T processOne(const T& x) noexcept {
+        _accumulated_phase += phase_increment;
+        if (_accumulated_phase > value_type(2) * std::numbers::pi_v<value_type>) _accumulated_phase -= value_type(2) * std::numbers::pi_v<value_type>;
+        else if (_accumulated_phase < value_type(0)) _accumulated_phase += value_type(2) * std::numbers::pi_v<value_type>;
+        return x * T(std::cos(_accumulated_phase), std::sin(_accumulated_phase));
+    }
+};
+} // namespace gr::blocks::math
+
+namespace gr::blocks::fft {
+// Streaming |FFT|^2: one frame of fftSize complex samples in, fftSize floats (natural bin order) out.  The streaming counterpart of
+// blocks::fft::FFT<T> (blocks/fourier/.../fft.hpp:31-251), which emits a DataSet per frame: mag2[(k + N/2) mod N] equals
+// (DataSet magnitude[k] * N/2)^2.  Settings follow the FFT block: fftSize, window ("None" or "Hann").
+template <typename T>
+struct PowerSpectrum : Block<PowerSpectrum<T>, Resampling<1024, 1024, false>> {
+    using value_type = typename T::value_type;
+    PortIn<T>           in;
+    PortOut<value_type> out;
+    Size_t              fftSize = 1024;
+    std::string         window  = "None";
+    std::vector<value_type> _window;
+    GR_MAKE_REFLECTABLE(PowerSpectrum, in, out, fftSize, window);
+
+    void settingsChanged(const property_map&, const property_map&) {
+        if (fftSize < 2 || (fftSize & (fftSize - 1))) throw std::invalid_argument("fftSize must be a power of two");
+        this->input_chunk_size = this->output_chunk_size = fftSize; // fft.hpp:131-134: exactly whole frames
+        _window.assign(fftSize, value_type(1));
+        if (window == "Hann")
+            for (std::size_t i = 0; i < fftSize; ++i) _window[i] = value_type(.5) - value_type(.5) * std::cos(value_type(2) * std::numbers::pi_v<value_type> / value_type(fftSize - 1) * value_type(i));
+        else if (window != "None" && window != "Rectangular") throw std::invalid_argument("PowerSpectrum: window must be None, Rectangular or Hann");
+    }
+    // host path: iterative radix-2 in double (plumbing only)
+    work::Status processBulk(std::span<const T> input, std::span<value_type> output) {
+        const std::size_t N = fftSize;
+        if (_window.size() != N) settingsChanged({}, {});
+        std::vector<std::complex<double>> v(N);
+        for (std::size_t f = 0; f + N <= input.size(); f += N) {
+            for (std::size_t i = 0, j = 0; i < N; ++i) {
+                v[j] = std::complex<double>(input[f + i]) * static_cast<double>(_window[i]);
+                std::size_t m = N >> 1;
+                while (m >= 1 && (j & m)) { j ^= m; m >>= 1; }
+                j |= m;
+            }
+            for (std::size_t len = 2; len <= N; len <<= 1)
+                for (std::size_t k = 0; k < N; k += len)
+                    for (std::size_t n = 0; n < len / 2; ++n) {
+                        const auto w = std::polar(1.0, -2.0 * std::numbers::pi * static_cast<double>(n) / static_cast<double>(len));
+                        const auto t = v[k + n + len / 2] * w;
+                        v[k + n + len / 2] = v[k + n] - t;
+                        v[k + n] += t;
+                    }
+            for (std::size_t i = 0; i < N; ++i) output[f + i] = static_cast<value_type>(std::norm(v[i]));
+        }
+        return work::Status::OK;
+    }
+};
+} // namespace gr::blocks::fft

@@ -1,0 +1,327 @@
+// gr4/hip.hpp -- the live compute_domain = "gpu:hip[:i]" seam: device implementations of the hot-path blocks on top of the C-ABI
+// (include/gr4hip.h, libgr4hip.so) and the HIP-stream scheduler that fuses adjacent device blocks.
+//
+//   * gr::hip::Kernel<Block>::work  -- what Block::dispatchProcessing calls at the seam (core/include/gnuradio-4.0/Block.hpp:1855-1862)
+//     when a single block is on the device inside a host graph: span -> pinned staging -> HBM -> kernel -> HBM -> span.
+//   * gr::hip::StreamScheduler      -- scheduler::Simple plus device runs: a maximal linear chain of device blocks becomes ONE
+//     work unit whose intermediate edges never leave HBM; samples arrive through pinned hipMemcpyAsync into a double-mapped
+//     device ring (gr4hip_ring_*) and adjacent blocks are fused into one launch where a fused kernel exists
+//     (fir_filter<complex<float>> -> PowerSpectrum == gr4hip_chain_*: the runtime analogue of Merge<>, BlockMerging.hpp:136-320).
+// Device blocks never fall back to the host path: a failing library call turns into work::Status::ERROR with the library's text.
+#pragma once
+#include <cstring>
+#include <functional>
+#include <iostream>
+
+#include "../../../../include/gr4hip.h"
+#include "blocks.hpp"
+
+namespace gr::hip {
+
+inline void check(int rc, const char* what) {
+    if (rc < 0 && rc != GR4HIP_DONE && rc != GR4HIP_INSUFFICIENT_INPUT && rc != GR4HIP_INSUFFICIENT_OUTPUT)
+        throw std::runtime_error(std::string(what) + ": " + gr4hip_status_string(rc) + " (" + gr4hip_last_error() + ")");
+}
+
+// one device stage of a chain: consumes n_in elements at d_in, produces *n_out at d_out, asynchronously on `stream`
+struct Stage {
+    virtual ~Stage() = default;
+    virtual int              enqueue(const void* d_in, std::size_t n_in, void* d_out, std::size_t* n_out, gr4hip_stream_t stream) = 0;
+    virtual std::string_view kind() const                                                                                         = 0;
+    std::size_t              in_bytes = 4, out_bytes = 4; // element sizes
+    std::size_t              in_chunk = 1, out_chunk = 1; // whole chunks only (Resampling)
+};
+
+// grow-only device / pinned buffers
+struct DevBuf {
+    void*       p = nullptr;
+    std::size_t n = 0;
+    bool        pinned;
+    explicit DevBuf(bool pinned_ = false) : pinned(pinned_) {}
+    DevBuf(const DevBuf&)            = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    void* ensure(std::size_t bytes) {
+        if (bytes > n) {
+            release();
+            check(pinned ? gr4hip_malloc_host(&p, bytes) : gr4hip_malloc(&p, bytes), "device allocation");
+            n = bytes;
+        }
+        return p;
+    }
+    void release() {
+        if (p) (pinned ? gr4hip_free_host(p) : gr4hip_free(p));
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+// ---------------------------------------------------------------------------------------------- stages
+template <typename T>
+struct FirStage final : Stage {
+    gr4hip_fir_t* h = nullptr;
+    std::vector<float> taps;
+    template <typename Taps>
+    explicit FirStage(const Taps& b) : taps(b.begin(), b.end()) {
+        in_bytes = out_bytes = sizeof(T);
+        check(gr4hip_fir_create(&h, gr::detail::is_complex<T>::value ? GR4HIP_C32 : GR4HIP_F32, taps.data(), taps.size(), 1), "gr4hip_fir_create");
+    }
+    ~FirStage() override { gr4hip_fir_destroy(h); }
+    std::string_view kind() const override { return gr::detail::is_complex<T>::value ? "fir_c32" : "fir_f32"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override { return gr4hip_fir_process(h, in, n, out, n_out, s); }
+};
+
+struct PowerSpectrumStage final : Stage {
+    gr4hip_fft_t* h = nullptr;
+    std::size_t   N;
+    int           window;
+    PowerSpectrumStage(std::size_t fftSize, int win) : N(fftSize), window(win) {
+        in_bytes = 8; out_bytes = 4; in_chunk = out_chunk = fftSize;
+        check(gr4hip_fft_create(&h, GR4HIP_C32, fftSize, win, 0), "gr4hip_fft_create");
+    }
+    ~PowerSpectrumStage() override { gr4hip_fft_destroy(h); }
+    std::string_view kind() const override { return "power_spectrum_c32"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        *n_out = (n / N) * N;
+        return gr4hip_fft_mag2(h, in, n / N, static_cast<float*>(out), s);
+    }
+};
+
+// fir_filter<complex<float>> -> PowerSpectrum fused into one launch
+struct ChainStage final : Stage {
+    gr4hip_chain_t* h = nullptr;
+    std::size_t     N;
+    ChainStage(const std::vector<float>& taps, std::size_t fftSize, int window) : N(fftSize) {
+        in_bytes = 8; out_bytes = 4; in_chunk = out_chunk = fftSize;
+        check(gr4hip_chain_create(&h, taps.data(), taps.size(), fftSize, window, GR4HIP_CHAIN_AUTO), "gr4hip_chain_create");
+    }
+    ~ChainStage() override { gr4hip_chain_destroy(h); }
+    std::string_view kind() const override { return "chain_fir_fft_mag2"; }
+    int algo() const { int a = 0; gr4hip_chain_get_algo(h, &a); return a; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        std::size_t frames = 0;
+        const int   rc = gr4hip_chain_process(h, in, n, static_cast<float*>(out), &frames, s);
+        *n_out = frames * N;
+        return rc;
+    }
+};
+
+template <typename T, int OP>
+struct MathConstStage final : Stage {
+    T value;
+    explicit MathConstStage(T v) : value(v) { in_bytes = out_bytes = sizeof(T); }
+    std::string_view kind() const override { return "math_const"; }
+    static constexpr int dtype() {
+        if constexpr (std::is_same_v<T, std::uint8_t>) return GR4HIP_U8; else if constexpr (std::is_same_v<T, std::uint16_t>) return GR4HIP_U16;
+        else if constexpr (std::is_same_v<T, std::uint32_t>) return GR4HIP_U32; else if constexpr (std::is_same_v<T, std::uint64_t>) return GR4HIP_U64;
+        else if constexpr (std::is_same_v<T, std::int8_t>) return GR4HIP_I8; else if constexpr (std::is_same_v<T, std::int16_t>) return GR4HIP_I16;
+        else if constexpr (std::is_same_v<T, std::int32_t>) return GR4HIP_I32; else if constexpr (std::is_same_v<T, std::int64_t>) return GR4HIP_I64;
+        else if constexpr (std::is_same_v<T, float>) return GR4HIP_F32; else if constexpr (std::is_same_v<T, double>) return GR4HIP_F64;
+        else if constexpr (std::is_same_v<T, std::complex<float>>) return GR4HIP_C32; else return GR4HIP_C64;
+    }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        *n_out = n;
+        return gr4hip_math_const(OP, dtype(), in, out, n, &value, s);
+    }
+};
+
+template <typename op, typename T> constexpr int op_id() {
+    if constexpr (std::is_same_v<op, std::plus<T>>) return GR4HIP_ADD; else if constexpr (std::is_same_v<op, std::minus<T>>) return GR4HIP_SUB;
+    else if constexpr (std::is_same_v<op, std::multiplies<T>>) return GR4HIP_MUL; else return GR4HIP_DIV;
+}
+
+inline int window_id(const std::string& w) {
+    if (w == "None") return GR4HIP_WIN_NONE;
+    if (w == "Rectangular") return GR4HIP_WIN_RECTANGULAR;
+    if (w == "Hann") return GR4HIP_WIN_HANN;
+    throw std::invalid_argument("unsupported window '" + w + "'");
+}
+
+// ---------------------------------------------------------------------------------------------- per-block offload at the seam
+struct Offload { // state behind Block::_device_state
+    std::unique_ptr<Stage> stage;
+    DevBuf                 d_in, d_out, h_in{true}, h_out{true};
+    int                    device = 0;
+};
+
+template <typename BlockT, typename MakeStage>
+work::Status offload_work(BlockT& blk, std::size_t nIn, std::size_t nOut, MakeStage&& make) {
+    try {
+        auto* st = static_cast<Offload*>(blk._device_state);
+        if (!st) {
+            st         = new Offload();
+            st->device = blk._domain.index;
+            check(gr4hip_set_device(st->device), "gr4hip_set_device");
+            st->stage          = make(blk);
+            blk._device_state = st; // released by the graph owner via hip::release(block)
+        }
+        using TIn  = typename std::decay_t<decltype(blk.in)>::value_type;
+        using TOut = typename std::decay_t<decltype(blk.out)>::value_type;
+        const auto is = blk.in.buffer->read_span(nIn);
+        auto       os = blk.out.buffer->write_span(nOut);
+        std::memcpy(st->h_in.ensure(nIn * sizeof(TIn)), is.data(), nIn * sizeof(TIn)); // pinned staging
+        check(gr4hip_memcpy_h2d(st->d_in.ensure(nIn * sizeof(TIn)), st->h_in.p, nIn * sizeof(TIn), nullptr), "h2d");
+        std::size_t produced = 0;
+        check(st->stage->enqueue(st->d_in.p, nIn, st->d_out.ensure(nOut * sizeof(TOut)), &produced, nullptr), "kernel");
+        if (produced != nOut) throw std::runtime_error("device stage produced an unexpected number of samples");
+        check(gr4hip_memcpy_d2h(st->h_out.ensure(nOut * sizeof(TOut)), st->d_out.p, nOut * sizeof(TOut), nullptr), "d2h");
+        check(gr4hip_stream_synchronize(nullptr), "sync");
+        std::memcpy(os.data(), st->h_out.p, nOut * sizeof(TOut));
+        return work::Status::OK;
+    } catch (const std::exception& e) {
+        blk._log(std::string("device block '") + blk.name + "' failed: " + e.what());
+        return work::Status::ERROR; // never a silent host fallback
+    }
+}
+
+template <typename BlockT>
+void release(BlockT& blk) {
+    delete static_cast<Offload*>(blk._device_state);
+    blk._device_state = nullptr;
+}
+
+template <typename T>
+requires(std::is_same_v<T, float> || std::is_same_v<T, std::complex<float>>)
+struct Kernel<gr::filter::fir_filter<T>> {
+    static std::unique_ptr<Stage> make_stage(gr::filter::fir_filter<T>& b) { return std::make_unique<FirStage<T>>(b.b); }
+    static work::Status           work(gr::filter::fir_filter<T>& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+template <typename T, typename op>
+struct Kernel<gr::blocks::math::MathOpImpl<T, op>> {
+    using B = gr::blocks::math::MathOpImpl<T, op>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<MathConstStage<T, op_id<op, T>()>>(b.value); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+template <>
+struct Kernel<gr::blocks::fft::PowerSpectrum<std::complex<float>>> {
+    using B = gr::blocks::fft::PowerSpectrum<std::complex<float>>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<PowerSpectrumStage>(b.fftSize, window_id(b.window)); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+
+// ---------------------------------------------------------------------------------------------- HIP-stream scheduler with chain fusion
+// A device run = consecutive device blocks wired 1:1, executed as one unit.
+class DeviceRun final : public BlockModel {
+    std::vector<std::unique_ptr<Stage>> _stages;
+    std::shared_ptr<EdgeBufferBase>     _in_edge, _out_edge;
+    std::function<std::size_t()>                                 _avail, _space;
+    std::function<void(void*, std::size_t)>                      _read;  // copy n input elements to pinned memory + consume
+    std::function<void(const void*, std::size_t)>                _write; // publish n output elements from pinned memory
+    gr4hip_ring_t*  _ring = nullptr;
+    void*           _ring_base = nullptr;
+    std::size_t     _ring_bytes = 0, _ring_wr = 0;
+    gr4hip_stream_t _stream = nullptr;
+    DevBuf          _h_in{true}, _h_out{true}, _d_a, _d_b;
+    std::string     _name = "device_run";
+    ComputeDomain   _domain;
+    std::size_t     _in_bytes, _out_bytes, _in_chunk = 1;
+    std::size_t     _launches = 0;
+    std::string     _desc;
+
+public:
+    template <typename TIn, typename TOut>
+    DeviceRun(std::vector<std::unique_ptr<Stage>> stages, std::shared_ptr<EdgeBuffer<TIn>> in, std::shared_ptr<EdgeBuffer<TOut>> out, ComputeDomain d)
+        : _stages(std::move(stages)), _in_edge(in), _out_edge(out), _domain(std::move(d)), _in_bytes(sizeof(TIn)), _out_bytes(sizeof(TOut)) {
+        _avail = [in] { return in->available(); };
+        _space = [out] { return out->free_space(); };
+        _read  = [in](void* dst, std::size_t n) { std::memcpy(dst, in->read_span(n).data(), n * sizeof(TIn)); in->consume(n); };
+        _write = [out](const void* src, std::size_t n) { std::memcpy(out->write_span(n).data(), src, n * sizeof(TOut)); out->publish(n); };
+        for (auto& s : _stages) { _in_chunk = std::max(_in_chunk, s->in_chunk); _desc += std::string(_desc.empty() ? "" : " -> ") + std::string(s->kind()); }
+        check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
+        check(gr4hip_stream_create(&_stream), "gr4hip_stream_create");
+        check(gr4hip_ring_create(&_ring, std::size_t(64) << 20), "gr4hip_ring_create"); // GPU-resident double-mapped input ring
+        check(gr4hip_ring_base(_ring, &_ring_base), "ring base");
+        check(gr4hip_ring_size(_ring, &_ring_bytes), "ring size");
+    }
+    ~DeviceRun() override {
+        _stages.clear();
+        if (_ring) gr4hip_ring_destroy(_ring);
+        if (_stream) gr4hip_stream_destroy(_stream);
+    }
+    std::string_view           description() const { return _desc; }
+    [[nodiscard]] std::size_t  launches() const { return _launches; }
+    const std::vector<std::unique_ptr<Stage>>& stages() const { return _stages; }
+
+    work::Result work(std::size_t requested) override {
+        try {
+            std::size_t n = std::min({_avail(), requested, _ring_bytes / _in_bytes / 2});
+            n -= n % _in_chunk;
+            // output budget: every stage maps whole chunks 1:1 in sample count on this path (fir: n->n, spectrum: N complex -> N floats)
+            n = std::min(n, _space() - _space() % _in_chunk);
+            if (n == 0) {
+                if (_avail() < _in_chunk && _in_edge->producer_done) {
+                    _out_edge->producer_done = true;
+                    return {requested, 0, work::Status::DONE};
+                }
+                return {requested, 0, _avail() < _in_chunk ? work::Status::INSUFFICIENT_INPUT_ITEMS : work::Status::INSUFFICIENT_OUTPUT_ITEMS};
+            }
+            // samples land in HBM: pinned staging -> hipMemcpyAsync -> the double-mapped ring (a wrapping span stays contiguous)
+            _read(_h_in.ensure(n * _in_bytes), n);
+            char* d_in = static_cast<char*>(_ring_base) + _ring_wr;
+            check(gr4hip_memcpy_h2d(d_in, _h_in.p, n * _in_bytes, _stream), "h2d");
+            _ring_wr = (_ring_wr + n * _in_bytes) % _ring_bytes;
+            const void* cur = d_in;
+            std::size_t cnt = n;
+            for (std::size_t i = 0; i < _stages.size(); ++i) { // stages run back-to-back on one stream; intermediates stay in HBM
+                DevBuf&     dst = (i % 2) ? _d_b : _d_a;
+                std::size_t out = 0;
+                check(_stages[i]->enqueue(cur, cnt, dst.ensure(std::max<std::size_t>(cnt, 1) * std::max(_stages[i]->out_bytes, _stages[i]->in_bytes)), &out, _stream), "stage");
+                cur = dst.p;
+                cnt = out;
+                ++_launches;
+            }
+            check(gr4hip_memcpy_d2h(_h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _stream), "d2h");
+            check(gr4hip_stream_synchronize(_stream), "sync"); // cursors advance only after the completion of the stream work
+            _write(_h_out.p, cnt);
+            return {requested, n, work::Status::OK};
+        } catch (const std::exception& e) {
+            std::cerr << "[gr::hip] device run failed: " << e.what() << "\n";
+            return {requested, 0, work::Status::ERROR};
+        }
+    }
+    std::string_view     name() const override { return _name; }
+    std::string_view     type_name() const override { return "gr::hip::DeviceRun"; }
+    const ComputeDomain& compute_domain() const override { return _domain; }
+    void*                raw() override { return this; }
+    std::type_index      port_type(std::string_view) override { return typeid(void); }
+    std::shared_ptr<EdgeBufferBase> make_edge(std::string_view, std::size_t) override { return nullptr; }
+    bool attach_input(std::string_view, std::shared_ptr<EdgeBufferBase>) override { return false; }
+    std::vector<std::shared_ptr<EdgeBufferBase>> input_edges() override { return {_in_edge}; }
+    std::vector<std::shared_ptr<EdgeBufferBase>> output_edges() override { return {_out_edge}; }
+};
+
+// Builds the stage list of a linear device chain, fusing fir_filter<complex<float>> -> PowerSpectrum into gr4hip_chain.
+// Usage (see host/tests): fuse_chain(graph, fir, spectrum) replaces both blocks by one DeviceRun in the graph's block list.
+template <typename First, typename... Rest>
+DeviceRun& fuse_chain(Graph& g, First& first, Rest&... rest) {
+    std::vector<std::unique_ptr<Stage>> stages;
+    auto& last = std::get<sizeof...(Rest)>(std::tie(first, rest...));
+    if constexpr (sizeof...(Rest) == 1 && std::is_same_v<First, gr::filter::fir_filter<std::complex<float>>> &&
+                  (std::is_same_v<Rest, gr::blocks::fft::PowerSpectrum<std::complex<float>>> && ...)) {
+        stages.push_back(std::make_unique<ChainStage>(first.b, last.fftSize, window_id(last.window))); // one launch for both blocks
+    } else {
+        stages.push_back(Kernel<First>::make_stage(first));
+        (stages.push_back(Kernel<Rest>::make_stage(rest)), ...);
+    }
+    if (!first.in.connected() || !last.out.connected()) throw std::invalid_argument("fuse_chain: connect the chain to its neighbours first");
+    auto  run = std::make_unique<DeviceRun>(std::move(stages), first.in.buffer, last.out.buffer, ComputeDomain::parse(first.compute_domain));
+    auto& ref = *run;
+    auto& blocks = g.blocks();
+    const void* members[] = {static_cast<const void*>(&first), static_cast<const void*>(&rest)...};
+    // the run takes the place of its first member; the members themselves leave the schedule (their state lives in the stages)
+    std::size_t first_pos = blocks.size();
+    for (std::size_t i = 0; i < blocks.size(); ++i)
+        if (blocks[i]->raw() == members[0]) first_pos = i;
+    if (first_pos == blocks.size()) throw std::invalid_argument("fuse_chain: block is not part of this graph");
+    std::vector<std::unique_ptr<BlockModel>> kept;
+    for (std::size_t i = 0; i < blocks.size(); ++i) {
+        const bool member = std::find(std::begin(members), std::end(members), blocks[i]->raw()) != std::end(members);
+        if (i == first_pos) kept.push_back(std::move(run));
+        if (!member) kept.push_back(std::move(blocks[i]));
+        else g.retired().push_back(std::move(blocks[i])); // keep the objects alive: callers hold references to them
+    }
+    blocks = std::move(kept);
+    return ref;
+}
+
+} // namespace gr::hip

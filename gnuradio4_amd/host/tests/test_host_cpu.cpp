@@ -1,0 +1,165 @@
+// Host-layer self test (no GPU): the kept gr::Block<>/Port<>/Graph::connect surface and scheduler::Simple, in the style of the
+// reference's own tests (blocks/math/test/qa_Math.cpp:16-41, blocks/filter/test/qa_filter.cpp:267-293, core/test/qa_Block.cpp:1315-1343).
+// Also BASELINE.json configs[0]: SignalSource -> 64-tap float FIR -> sink, 1 000 448 samples, CPU scheduler; the stream is dumped
+// for the python test to compare against the oracle.
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include <gr4/blocks.hpp>
+
+using namespace gr;
+using namespace std::string_literals;
+
+static int failures = 0;
+#define EXPECT(cond)                                                                  \
+    do {                                                                              \
+        if (!(cond)) { ++failures; std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); } \
+    } while (0)
+
+template <typename T, typename BlockUnderTest>
+void math_case(const std::vector<std::vector<T>>& inputs, const std::vector<T>& expected) {
+    Graph graph;
+    auto& block = graph.emplaceBlock<BlockUnderTest>({{"n_inputs", std::int64_t(inputs.size())}});
+    for (std::size_t i = 0; i < inputs.size(); ++i) {
+        std::vector<std::int64_t> vi; std::vector<double> vd;
+        auto& src = graph.emplaceBlock<testing::VectorSource<T>>();
+        src.values = inputs[i];
+        EXPECT(graph.connect(src, "out"s, block, "in#"s + std::to_string(i)).has_value());
+    }
+    auto& sink = graph.emplaceBlock<testing::VectorSink<T>>();
+    EXPECT(graph.connect(block, "out"s, sink, "in"s).has_value());
+    scheduler::Simple sched;
+    EXPECT(sched.exchange(std::move(graph)).has_value());
+    EXPECT(sched.runAndWait().has_value());
+    EXPECT(sink._samples == expected);
+}
+
+template <typename T>
+void math_suite() { // vectors of qa_Math.cpp:59-121 (integer-valued rows)
+    using namespace gr::blocks::math;
+    math_case<T, Add<T>>({{1, 2, 8, 17}}, {1, 2, 8, 17});
+    math_case<T, Add<T>>({{12, 35, 18, 17}, {31, 15, 27, 36}, {83, 46, 37, 41}}, {126, 96, 82, 94});
+    math_case<T, Subtract<T>>({{15, 38, 88, 29}, {3, 12, 26, 18}, {0, 10, 50, 7}}, {12, 16, 12, 4});
+    math_case<T, Multiply<T>>({{0, 1, 2, 3}, {4, 5, 6, 2}, {8, 9, 10, 11}}, {0, 45, 120, 66});
+    math_case<T, Divide<T>>({{0, 10, 40, 80}, {1, 2, 4, 20}, {1, 5, 5, 2}}, {0, 1, 2, 2});
+    AddConst<T> a;      EXPECT(a.processOne(T(4)) == T(5));
+    a.applySettings({{"value", std::int64_t(2)}}); EXPECT(a.processOne(T(4)) == T(6));
+    DivideConst<T> d;   d.applySettings({{"value", std::int64_t(2)}}); EXPECT(d.processOne(T(4)) == T(2));
+}
+
+int main(int argc, char** argv) {
+    // ---- math blocks through Graph + Scheduler for the integer and float types
+    math_suite<std::uint8_t>(); math_suite<std::int16_t>(); math_suite<std::int32_t>(); math_suite<std::uint64_t>(); math_suite<float>(); math_suite<double>();
+
+    // ---- connect(): errors are returned, not thrown (docs/USER_API_Connecting_Blocks.md "Error handling")
+    {
+        Graph g;
+        auto& s = g.emplaceBlock<testing::VectorSource<float>>();
+        auto& k = g.emplaceBlock<testing::VectorSink<double>>();
+        auto& f = g.emplaceBlock<filter::fir_filter<float>>();
+        EXPECT(!(g.connect<"out", "in">(s, k)).has_value());          // value_type mismatch
+        EXPECT(!(g.connect(s, "nope"s, f, "in"s)).has_value());        // unknown port
+        EXPECT(!(g.connect(s, "out"s, f, "out"s)).has_value());        // wrong direction
+        EXPECT((g.connect<"out", "in">(s, f)).has_value());
+        bool threw = false;
+        try { f.applySettings({{"no_such_setting", 1.0}}); } catch (const std::invalid_argument&) { threw = true; }
+        EXPECT(threw);
+    }
+    // ---- Decimator 100 -> 10 samples (qa_filter.cpp:267-293)
+    {
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(100)}});
+        src.values = {1.f, 2.f, 3.f};
+        auto& dec  = g.emplaceBlock<filter::Decimator<float>>({{"decim", std::int64_t(10)}});
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        EXPECT((g.connect<"out", "in">(src, dec)).has_value());
+        EXPECT((g.connect<"out", "in">(dec, sink)).has_value());
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        EXPECT(dec.input_chunk_size == 10u && dec.output_chunk_size == 1u);
+        EXPECT(sink._samples.size() == 10u);
+        EXPECT(sink._samples[1] == src.values[10 % 3]);
+    }
+    // ---- FIR box-car step response settles in 10 samples; IIR forms agree (qa_filter.cpp:53-128)
+    {
+        filter::fir_filter<double> fir;
+        fir.applySettings({{"b", std::vector<double>(10, 0.1)}});
+        double last = 0;
+        for (int i = 0; i < 20; ++i) { last = fir.processOne(i == 0 ? 0.0 : 1.0); if (i == 0) EXPECT(last == 0.0); }
+        EXPECT(std::abs(last - 1.0) < 1e-12);
+        const std::vector<double> b{0.020083365564211, 0.040166731128423, 0.020083365564211}, a{1.0, -1.561018075800718, 0.641351538057563};
+        filter::iir_filter<double, filter::IIRForm::DF_I> f1; filter::iir_filter<double, filter::IIRForm::DF_II> f2;
+        filter::iir_filter<double, filter::IIRForm::DF_I_TRANSPOSED> f3; filter::iir_filter<double, filter::IIRForm::DF_II_TRANSPOSED> f4;
+        for (auto* f : {static_cast<void*>(&f1)}) (void)f;
+        f1.applySettings({{"b", b}, {"a", a}}); f2.applySettings({{"b", b}, {"a", a}}); f3.applySettings({{"b", b}, {"a", a}}); f4.applySettings({{"b", b}, {"a", a}});
+        for (int i = 0; i < 20; ++i) {
+            const double x = i == 0 ? 0.0 : 1.0, y1 = f1.processOne(x);
+            EXPECT(std::abs(f2.processOne(x) - y1) < 1e-5 && std::abs(f3.processOne(x) - y1) < 1e-5 && std::abs(f4.processOne(x) - y1) < 1e-5);
+        }
+    }
+    // ---- rotator: output[i] angle = (i+1) * pi/2 (qa_Rotator.cpp:69-92); XOR settings
+    {
+        blocks::math::Rotator<std::complex<float>> rot;
+        rot.applySettings({{"phase_increment", double(std::numbers::pi / 2)}});
+        EXPECT(std::abs(rot.frequency_shift - 0.25f) < 1e-3f);
+        for (int i = 0; i < 8; ++i) {
+            const auto y = rot.processOne({1.f, 0.f});
+            EXPECT(std::abs(y.real() - std::cos((i + 1) * std::numbers::pi / 2)) < 1e-5 && std::abs(y.imag() - std::sin((i + 1) * std::numbers::pi / 2)) < 1e-5);
+        }
+        bool threw = false;
+        try { rot.applySettings({{"phase_increment", 0.1}, {"frequency_shift", 0.2}}); } catch (const std::invalid_argument&) { threw = true; }
+        EXPECT(threw);
+    }
+    // ---- the inert-seam behaviour the reference pins (qa_Block.cpp:1315-1343): a block without a device kernel warns once, runs on host
+    {
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(5000)}});
+        src.values = {1.f};
+        auto& dec  = g.emplaceBlock<filter::Decimator<float>>({{"decim", std::int64_t(5)}, {"compute_domain", "gpu:hip:0"s}});
+        int   warnings = 0;
+        dec._log = [&](std::string_view) { ++warnings; };
+        auto& sink = g.emplaceBlock<testing::NullSink<float>>();
+        g.connect<"out", "in">(src, dec);
+        g.connect<"out", "in">(dec, sink);
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        EXPECT(sink._count == 1000u && warnings == 1);
+        const auto d = ComputeDomain::parse("gpu:hip:1");
+        EXPECT(d.kind == "gpu" && d.backend == "hip" && d.index == 1 && d.is_device() && !ComputeDomain::parse("host").is_device());
+    }
+    // ---- BASELINE configs[0]: SignalSource -> 64-tap float FIR -> sink, 1 000 448 samples (round_up(1e6, 1024), bm_MergeApi.cpp:20)
+    {
+        constexpr std::size_t N = 1000448, K = 64;
+        std::vector<double> taps(K);
+        double sum = 0;
+        for (std::size_t i = 0; i < K; ++i) { // Hamming windowed-sinc, fc = 0.1, DC gain 1
+            const double w = 0.53836 - 0.46164 * std::cos(2 * std::numbers::pi * double(i) / double(K - 1)), x = 0.2 * (double(i) - (K - 1) / 2.0);
+            taps[i] = w * 0.2 * (x == 0 ? 1.0 : std::sin(std::numbers::pi * x) / (std::numbers::pi * x));
+            sum += taps[i];
+        }
+        for (auto& t : taps) t /= sum;
+        Graph g;
+        auto& src  = g.emplaceBlock<basic::SignalGenerator<float>>({{"signal_type", "Sin"s}, {"frequency", 50.0}, {"sample_rate", 1000.0}, {"n_samples_max", std::int64_t(N)}});
+        auto& fir  = g.emplaceBlock<filter::fir_filter<float>>({{"b", taps}});
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        EXPECT((g.connect<"out", "in">(src, fir)).has_value());
+        EXPECT((g.connect<"out", "in">(fir, sink)).has_value());
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        EXPECT(sink._samples.size() == N); // sample count in == out
+        if (argc > 1) {
+            std::ofstream f(argv[1], std::ios::binary);
+            std::vector<float> tf(taps.begin(), taps.end());
+            const std::uint64_t hdr[2] = {K, sink._samples.size()};
+            f.write(reinterpret_cast<const char*>(hdr), sizeof hdr);
+            f.write(reinterpret_cast<const char*>(tf.data()), K * sizeof(float));
+            f.write(reinterpret_cast<const char*>(sink._samples.data()), sink._samples.size() * sizeof(float));
+        }
+    }
+    std::printf(failures ? "host-cpu: %d FAILURES\n" : "host-cpu: all checks passed\n", failures);
+    return failures ? 1 : 0;
+}

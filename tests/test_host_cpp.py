@@ -1,0 +1,80 @@
+"""The C++ host layer (gnuradio4_amd/host: gr::Block<>/Port<>/Graph::connect surface + compute_domain seam).
+CPU: its self-test program, BASELINE configs[0] plumbing against the oracle, and the loud failure of device blocks without a GPU.
+GPU: device graphs (seam offload and fused device run) through the C++ API against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = O.ROOT
+BIN = os.path.join(ROOT, "build", "host")
+
+
+@pytest.fixture(scope="module")
+def host_bins():
+    subprocess.check_call(["bash", os.path.join(ROOT, "gnuradio4_amd", "host", "build.sh")], stdout=subprocess.DEVNULL)
+    return BIN
+
+
+def test_host_selftest_and_config0_plumbing(host_bins, tmp_path):
+    dump = tmp_path / "c1.bin"
+    r = subprocess.run([os.path.join(host_bins, "test_host_cpu"), str(dump)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
+    raw = open(dump, "rb").read()
+    K, n = np.frombuffer(raw[:16], np.uint64)
+    taps = np.frombuffer(raw[16:16 + 4 * int(K)], np.float32)
+    y = np.frombuffer(raw[16 + 4 * int(K):], np.float32)
+    assert K == 64 and n == 1000448 and len(y) == n  # BASELINE configs[0]: sample count in == out
+    x = np.sin(2 * np.pi * 50.0 * (np.arange(n, dtype=np.float64) / 1000.0)).astype(np.float32)
+    truth, _ = O.fir(taps, x[:65536])
+    assert np.max(np.abs(y[:65536] - truth)) <= 1e-5 * np.sqrt(np.mean(truth ** 2))  # first outputs equal the oracle
+    # steady state: 50 Hz at fs = 1 kHz sits in the passband of the fc = 0.1 low-pass
+    assert abs(np.max(np.abs(y[-2000:])) - 1.0) < 2e-2
+
+
+def _inputs(tmp_path, N, frames, ntaps):
+    x = O.signal_c32(42, frames * N)
+    b = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    x.tofile(tmp_path / "in.bin")
+    b.tofile(tmp_path / "taps.bin")
+    return x, b
+
+
+def test_device_blocks_fail_loudly_without_gpu(host_bins, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _inputs(tmp_path, 1024, 2, 33)
+    r = subprocess.run([os.path.join(host_bins, "test_host_device"), str(tmp_path / "in.bin"), str(tmp_path / "taps.bin"), "1024", str(tmp_path / "o")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)  # work::Status::ERROR from the seam, no host fallback
+    assert "NO_DEVICE" in r.stderr and not os.path.exists(tmp_path / "o_fir.bin")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,ntaps", [(8192, 256), (1024, 64)])
+def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
+    frames = 5
+    x, b = _inputs(tmp_path, N, frames, ntaps)
+    r = subprocess.run([os.path.join(host_bins, "test_host_device"), str(tmp_path / "in.bin"), str(tmp_path / "taps.bin"), str(N), str(tmp_path / "o")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "chain_fir_fft_mag2  (1 stage)" in r.stdout
+
+    def rel(got, truth):
+        rms = np.sqrt(np.mean(np.abs(truth) ** 2))
+        return float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), rms)))
+    fir = np.fromfile(tmp_path / "o_fir.bin", np.complex64)
+    truth, _ = O.fir(b, x)
+    assert len(fir) == len(x) and rel(fir, truth) <= 1e-5
+    for name, wid in (("o_chain.bin", 0), ("o_chain_hann.bin", 3)):
+        got = np.fromfile(tmp_path / name, np.float32)
+        t, _ = O.chain(b, x, N, wid, truth=True)
+        assert len(got) == frames * N and rel(got, t) <= 1e-5, name
+    m = np.fromfile(tmp_path / "o_math.bin", np.int32)
+    src = np.resize(np.array([2147483647, -5, 7, 123456789], np.int32), 100000)
+    assert np.array_equal(m, (src.astype(np.int64) * 3).astype(np.int32))  # wrap-around like the C++ int32 product
