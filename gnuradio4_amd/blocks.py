@@ -279,6 +279,31 @@ class Chain(_Handle):
         return out
 
 
+class FirBatched(_Handle):
+    """nchannels independent fir_filter<float> instances with per-channel taps b[c][k] on channel-major samples x[c][n]
+    (BASELINE.json configs[3]); evaluated as a block-Toeplitz contraction on the f32 MFMA units."""
+    _destroy = "gr4hip_fir_batched_destroy"
+
+    def __init__(self, b):
+        super().__init__()
+        self.b = np.ascontiguousarray(b, np.float32)
+        if self.b.ndim != 2:
+            raise ValueError("taps must be [nchannels][ntaps]")
+        check(lib().gr4hip_fir_batched_create(C.byref(self._h), self.b.shape[0], self.b.ctypes.data, self.b.shape[1]), "FirBatched")
+
+    def reset(self):
+        check(lib().gr4hip_fir_batched_reset(self._h), "FirBatched.reset")
+
+    def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _dev(x, "FirBatched")
+        if x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] != self.b.shape[0]:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "FirBatched", "input must be float32 [nchannels][n]")
+        if out is None:
+            out = torch.empty((x.shape[0], (x.shape[1] + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+        check(lib().gr4hip_fir_batched_process(self._h, x.data_ptr(), x.stride(0), x.shape[1], out.data_ptr(), out.stride(0), _stream()), "FirBatched.process")
+        return out[:, :x.shape[1]]
+
+
 def math_const(op, x: torch.Tensor, value) -> torch.Tensor:
     """MathOpImpl<T,op>::processOne (Math.hpp:38-56): AddConst / SubtractConst / MultiplyConst / DivideConst."""
     x = _dev(x, "math_const")

@@ -1,10 +1,147 @@
-// fir_batched.hip -- many-channel FIR as a block-Toeplitz contraction on the f32 MFMA units (configs[3]).
+// fir_batched.hip -- many-channel FIR as a block-Toeplitz contraction on the f32 MFMA units (BASELINE.json configs[3]).
+//
+// nchannels independent gr::filter::fir_filter<float> instances (blocks/filter/.../time_domain_filter.hpp:22-48), per-channel taps.
+// With Kp = ntaps rounded up to 16 and the output index split as n = 16 i + j:
+//     y_c[16 i + j] = sum_{u=0}^{Kp+15} A_c[j][u] * B_c[u][i],   A_c[j][u] = b_c[Kp + j - u],   B_c[u][i] = x_c[16 i - Kp + u]
+// i.e. per channel a [16 x (Kp+16)] x [(Kp+16) x Nblocks] product whose B operand is just a sliding window of the input: a real dense
+// contraction with (Kp+16)/Kp = 6 % padding waste (instead of the 2x of a naive Toeplitz GEMM).  v_mfma_f32_16x16x4_f32 has no rate
+// advantage over the FP32 VALU on gfx950 (both 64 flop/clk/SIMD, MI355X_MICROARCH.md) but reaches that rate from one wave per SIMD
+// with one VGPR per operand: the A fragments (taps) of a channel live in (Kp+16)/4 registers for the whole workgroup, the B operand
+// is one conflict-free ds_read_b32 per MFMA from the staged (17/16-padded) input segment, D leaves as fully coalesced float4 stores.
+// Bound: MFMA f32 (157.3 TFLOP/s): 2*(Kp+16) flop per output sample.
 #include "common.hpp"
-using namespace gr4;
-struct gr4hip_fir_batched { int dummy; };
-extern "C" {
-int gr4hip_fir_batched_create(gr4hip_fir_batched_t**, size_t, const float*, size_t) { set_error("fir_batched: not implemented yet"); return GR4HIP_UNSUPPORTED; }
-int gr4hip_fir_batched_reset(gr4hip_fir_batched_t*) { return GR4HIP_UNSUPPORTED; }
-int gr4hip_fir_batched_process(gr4hip_fir_batched_t*, const float*, size_t, size_t, float*, size_t, gr4hip_stream_t) { return GR4HIP_UNSUPPORTED; }
-int gr4hip_fir_batched_destroy(gr4hip_fir_batched_t*) { return GR4HIP_OK; }
+
+namespace gr4 {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kSeg = 4096; // output samples per workgroup (4 waves x 4 tiles x 256)
+
+template <int KS> // K-steps of 4: Kp = 4 KS - 16
+__global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__ x, long in_stride, const float* __restrict__ hist, const float* __restrict__ afrag,
+                                                        float* __restrict__ y, long out_stride, long n) {
+    constexpr int Kp   = 4 * KS - 16;
+    constexpr int NPAD = (kSeg + Kp) / 16 * 17;
+    __shared__ float xs[NPAD];
+    const int  c    = blockIdx.y;
+    const long seg0 = (long)blockIdx.x * kSeg;
+    const int  tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xc = x + (long)c * in_stride;
+    const float* hc = hist + (long)c * Kp;
+
+    for (int s = tid; s < kSeg + Kp; s += 256) { // staged index s <-> input index seg0 - Kp + s; one pad float per 16 samples
+        const long i = seg0 - Kp + s;
+        const float v = i >= 0 ? (i < n ? xc[i] : 0.f) : hc[Kp + i];
+        xs[s + (s >> 4)] = v;
+    }
+    float a[KS]; // A fragments: lane l holds A[j = l & 15][u = 4 ks + (l >> 4)] = b[Kp + j - u]
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = afrag[((long)c * KS + ks) * 64 + lane];
+    __syncthreads();
+
+    const int col = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) { // two independent accumulators hide the 40-cycle dependent MFMA latency
+        const int ib0 = 16 * (4 * wave + 2 * pair), ib1 = ib0 + 16; // first 16-sample block of each tile
+        f32x4     acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* p0 = xs + 17 * (ib0 + col) + kq;
+        const float* p1 = xs + 17 * (ib1 + col) + kq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int off = 4 * ks + (ks >> 2); // padded offset of u = 4 ks within the window
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p0[off], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p1[off], acc1, 0, 0, 0);
+        }
+        // D[row = 4 kq + r][col]: y[16 (ib + col) + 4 kq + r]
+        float*     yc = y + (long)c * out_stride;
+        const long o0 = seg0 + 16L * (ib0 + col) + 4 * kq, o1 = seg0 + 16L * (ib1 + col) + 4 * kq;
+        if (o0 + 3 < n) *reinterpret_cast<float4*>(yc + o0) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        else
+            for (int r = 0; r < 4; ++r)
+                if (o0 + r < n) yc[o0 + r] = acc0[r];
+        if (o1 + 3 < n) *reinterpret_cast<float4*>(yc + o1) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+        else
+            for (int r = 0; r < 4; ++r)
+                if (o1 + r < n) yc[o1 + r] = acc1[r];
+    }
 }
+
+// new_hist[c][h] = virtual input of channel c at index n - Kp + h
+__global__ void fir_batched_hist_kernel(const float* __restrict__ x, long in_stride, const float* __restrict__ old_hist, float* __restrict__ new_hist, long n, int Kp) {
+    const int c = blockIdx.y, h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= Kp) return;
+    const long i = n - Kp + h;
+    new_hist[(long)c * Kp + h] = i >= 0 ? x[(long)c * in_stride + i] : old_hist[(long)c * Kp + Kp + i];
+}
+
+} // namespace gr4
+
+using namespace gr4;
+
+struct gr4hip_fir_batched {
+    size_t       nch = 0, ntaps = 0;
+    int          KS = 0, Kp = 0;
+    DeviceBuffer d_afrag, d_hist[2];
+    int          cur = 0;
+};
+
+extern "C" {
+
+int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, const float* h_taps, size_t ntaps) {
+    GR4_REQUIRE(out && h_taps && nchannels >= 1 && ntaps >= 1, "fir_batched: bad arguments");
+    if (ntaps > 256 || nchannels > 65535) { set_error("fir_batched: device path supports ntaps <= 256 and <= 65535 channels (got %zu taps, %zu channels)", ntaps, nchannels); return GR4HIP_UNSUPPORTED; }
+    auto* f = new (std::nothrow) gr4hip_fir_batched();
+    GR4_REQUIRE(f, "out of host memory");
+    f->nch   = nchannels;
+    f->ntaps = ntaps;
+    f->Kp    = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : 256;
+    f->KS    = (f->Kp + 16) / 4;
+    std::vector<float> af(nchannels * f->KS * 64, 0.f);
+    for (size_t c = 0; c < nchannels; ++c)
+        for (int ks = 0; ks < f->KS; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int k = f->Kp + (l & 15) - (4 * ks + (l >> 4)); // tap index b[Kp + j - u]
+                af[(c * f->KS + ks) * 64 + l] = (k >= 0 && (size_t)k < ntaps) ? h_taps[c * ntaps + k] : 0.f;
+            }
+    int rc = f->d_afrag.ensure(af.size() * sizeof(float));
+    if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+    for (int k = 0; k < 2 && !rc; ++k) rc = f->d_hist[k].ensure(nchannels * f->Kp * sizeof(float));
+    if (!rc) rc = gr4hip_fir_batched_reset(f);
+    if (rc) { delete f; return rc; }
+    *out = f;
+    return GR4HIP_OK;
+}
+
+int gr4hip_fir_batched_reset(gr4hip_fir_batched_t* f) {
+    GR4_REQUIRE(f, "fir_batched_reset: null handle");
+    for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(f->d_hist[k].ptr, 0, f->nch * f->Kp * sizeof(float)));
+    f->cur = 0;
+    return GR4HIP_OK;
+}
+
+int gr4hip_fir_batched_process(gr4hip_fir_batched_t* f, const float* d_in, size_t in_stride, size_t n, float* d_out, size_t out_stride, gr4hip_stream_t stream) {
+    GR4_REQUIRE(f, "fir_batched_process: null handle");
+    if (n == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out && in_stride >= n && out_stride >= n, "fir_batched_process: null pointer or stride shorter than n");
+    GR4_REQUIRE(((uintptr_t)d_out % 16 == 0) && (out_stride % 4 == 0), "fir_batched_process: output must be 16-byte aligned with a stride multiple of 4");
+    hipStream_t st = as_stream(stream);
+    const dim3  grid((unsigned)ceil_div(n, (size_t)kSeg), (unsigned)f->nch);
+    const float *hist = (const float*)f->d_hist[f->cur].ptr, *af = (const float*)f->d_afrag.ptr;
+    switch (f->KS) {
+    case 20: hipLaunchKernelGGL(fir_mfma_kernel<20>, grid, dim3(256), 0, st, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n); break;
+    case 36: hipLaunchKernelGGL(fir_mfma_kernel<36>, grid, dim3(256), 0, st, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n); break;
+    default: hipLaunchKernelGGL(fir_mfma_kernel<68>, grid, dim3(256), 0, st, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n); break;
+    }
+    GR4_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fir_batched_hist_kernel, dim3((unsigned)ceil_div(f->Kp, 64), (unsigned)f->nch), dim3(64), 0, st, d_in, (long)in_stride, hist,
+                       (float*)f->d_hist[f->cur ^ 1].ptr, (long)n, f->Kp);
+    GR4_LAUNCH_CHECK();
+    f->cur ^= 1;
+    return GR4HIP_OK;
+}
+
+int gr4hip_fir_batched_destroy(gr4hip_fir_batched_t* f) { delete f; return GR4HIP_OK; }
+
+} // extern "C"

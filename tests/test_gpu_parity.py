@@ -163,6 +163,25 @@ def test_decimator_bit_exact(G, dtype_id, golden):
     assert G.Decimator(g["decim"]).process_bulk(dev(np.arange(g["n_in"], dtype=np.float32))).numel() == g["n_out"]
 
 
+@pytest.mark.parametrize("nch,ntaps", [(64, 256), (3, 33), (8, 100), (1, 1)])
+def test_batched_fir_mfma_parity(G, nch, ntaps):
+    """BASELINE.json configs[3]: many-channel FIR on the f32 MFMA units == nch independent fir_filter<float> instances."""
+    rng = np.random.default_rng(nch * 1000 + ntaps)
+    b = (rng.standard_normal((nch, ntaps)) / np.sqrt(ntaps)).astype(np.float32)
+    n = 9000 + 37
+    x = np.stack([O.signal_f32(42 + c, n) for c in range(nch)])
+    f = G.FirBatched(b)
+    cut = 4100  # spans that are not multiples of the 4096-sample segment, history carried per channel
+    y = np.concatenate([f.process_bulk(dev(x[:, :cut])).cpu().numpy(), f.process_bulk(dev(x[:, cut:])).cpu().numpy()], axis=1)
+    for c in range(nch):
+        truth, _ = O.fir(b[c], x[c])
+        assert _rel(y[c], truth) <= TOL, c
+    f.reset()
+    y0 = f.process_bulk(dev(x[:, :100])).cpu().numpy()
+    t0, _ = O.fir(b[0], x[0, :100])
+    assert _rel(y0[0], t0) <= TOL
+
+
 # ------------------------------------------------------------------ IIR (a3, a4)
 def test_iir_forms_golden(G, golden):
     g = golden["fir_iir_step"]

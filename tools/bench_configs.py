@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""Secondary configurations of BASELINE.json (parity-test cases, not the bench line): timings on one MI355X.
+  configs[2]: polyphase decimating FIR (decim 8, 1024 taps) + IIR biquad x4 cascade      (float stream)
+  configs[3]: batched 64-channel x 256-tap FIR on the f32 MFMA units
+  plus the stand-alone blocks (math, FFT block, fir_filter) for the roofline table in DESIGN.md
+usage: bench_configs.py [--json out.json]"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gnuradio4_amd as G  # noqa: E402
+from gnuradio4_amd import capi  # noqa: E402
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    return float(np.median(ts))
+
+
+def lowpass(ntaps, fc):
+    w = np.empty(ntaps, np.float32)
+    capi.check(capi.lib().gr4hip_window_create(2, w.ctypes.data, ntaps, 1.6), "window")
+    k = np.arange(ntaps, dtype=np.float64)
+    t = w.astype(np.float64) * 2 * fc * np.sinc(2 * fc * (k - (ntaps - 1) / 2.0))
+    return (t / t.sum()).astype(np.float32)
+
+
+res = {}
+# ---- configs[2]
+n = 1 << 27
+x = G.synth_f32(n, seed=42)
+fir = G.fir_filter(lowpass(1024, 0.05), torch.float32, decimate=8)
+b, a = G.blocks.design_iir(capi.LOWPASS, 8, 0.05, float("nan"), 1.0, capi.BUTTERWORTH)  # Butterworth order 8 -> 4 biquads, fc = 0.05 fs (decimated)
+iir = G.iir_filter(b, a)
+yd = torch.empty(n // 8, dtype=torch.float32, device="cuda")
+yo = torch.empty_like(yd)
+t_fir = timeit(lambda: fir.process_bulk(x, yd))
+t_iir = timeit(lambda: iir.process_bulk(yd, yo))
+res["configs[2] decim-8 1024-tap FIR + 4 biquads"] = {
+    "Msamples/s (input rate, both kernels)": round(n / (t_fir + t_iir) / 1e6, 1), "fir_ms": round(t_fir * 1e3, 3), "iir_ms": round(t_iir * 1e3, 3),
+    "alg_GB/s": round(n * 5.5 / (t_fir + t_iir) / 1e9, 1), "fir_TFLOP/s": round(n / 8 * 2048 / t_fir / 1e12, 1),
+    "note": "5.5 B/input sample: 4 in + 0.5 decimated stream written + 0.5 read + 0.5 out; polyphase FIR 256 flop/input sample is FP32-bound"}
+del x, yd, yo
+# ---- configs[3]
+nch, ntaps, n = 64, 256, 1 << 22
+xb = torch.stack([G.synth_f32(n, seed=42 + c) for c in range(nch)])
+rng = np.random.default_rng(0)
+fb = G.FirBatched(np.stack([lowpass(ntaps, 0.05 + 0.005 * c) for c in range(nch)]))
+yb = torch.empty_like(xb)
+t = timeit(lambda: fb.process_bulk(xb, yb))
+res["configs[3] 64 ch x 256-tap FIR (MFMA)"] = {"Msamples/s (all channels)": round(nch * n / t / 1e6, 1), "ms": round(t * 1e3, 3), "alg_GB/s": round(nch * n * 8 / t / 1e9, 1),
+                                               "useful_TFLOP/s": round(nch * n * 512 / t / 1e12, 1), "executed_TFLOP/s": round(nch * n * 544 / t / 1e12, 1),
+                                               "mfma_peak_frac": round(nch * n * 544 / t / 157.3e12, 3)}
+# the same work on the VALU kernel (one fir_filter at a time)
+f1 = G.fir_filter(lowpass(ntaps, 0.05), torch.float32)
+y1 = torch.empty(n, dtype=torch.float32, device="cuda")
+t1 = timeit(lambda: f1.process_bulk(xb[0], y1))
+res["fir_filter<float> 256 taps (VALU kernel)"] = {"Msamples/s": round(n / t1 / 1e6, 1), "TFLOP/s": round(n * 512 / t1 / 1e12, 1)}
+del xb, yb
+# ---- stand-alone blocks
+n = 1 << 28
+xi = torch.randint(-1000, 1000, (n,), dtype=torch.int32, device="cuda")
+t = timeit(lambda: G.math_const("Multiply", xi, 3))
+res["MultiplyConst<int32>"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 8 / t / 1e9, 1), "hbm_frac": round(n * 8 / t / 8e12, 3)}
+ins = [xi, xi + 1, xi + 2, xi + 3]
+t = timeit(lambda: G.math_nary("Add", ins))
+res["Add<int32> n_inputs=4"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 20 / t / 1e9, 1), "hbm_frac": round(n * 20 / t / 8e12, 3)}
+del xi, ins
+n = 1 << 27
+xc = G.synth_c32(n)
+F = G.FFT(8192, "Hann")
+m2 = torch.empty((n // 8192, 8192), dtype=torch.float32, device="cuda")
+t = timeit(lambda: F.mag2(xc, m2))
+res["FFT block 8192 (Hann) -> mag2"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 12 / t / 1e9, 1), "hbm_frac": round(n * 12 / t / 8e12, 3)}
+print(json.dumps(res, indent=1))
+if "--json" in sys.argv:
+    json.dump(res, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
