@@ -151,17 +151,19 @@ __device__ __forceinline__ float lane_xor1(float v) {
 __device__ __forceinline__ int addrA(int row, int col) { return row * kRowA + col + ((row & 16) ? 8 : 0); }
 
 // pass B (p = 32, radix 16): butterfly (c, k) gathers S1[k][c + 16 r], twiddles by W_512^{r k}, scatters to S2[c][32 q + k]
-__device__ __forceinline__ void passB_compute_store(float2* S, float2 (&w)[16], float2 b1, float2 b2, int c, int k) {
-    apply_powers(w, b1, b2);
+__device__ __forceinline__ void passB_compute_store(float2* S, float2 (&w)[16], const float2 (&tw)[16], int c, int k) {
+#pragma unroll
+    for (int r = 1; r < 16; ++r) w[r] = cmul(w[r], tw[r]);
     fft16<1>(w);
 #pragma unroll
     for (int q = 0; q < 16; ++q) S[c * kRowB + 32 * q + k] = w[perm16(q)];
 }
 // pass C (p = 512, radix 16): butterfly i3 gathers S2[r][i3], twiddles by W_8192^{r i3}; X[i3 + 512 q] ends at slot perm16(q)
-__device__ __forceinline__ void passC(const float2* S, float2 (&g)[16], float2 b1, float2 b2, int i3) {
+__device__ __forceinline__ void passC(const float2* S, float2 (&g)[16], const float2 (&tw)[16], int i3) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = S[r * kRowB + i3];
-    apply_powers(g, b1, b2);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) g[r] = cmul(g[r], tw[r]);
     fft16<1>(g);
 }
 
@@ -177,7 +179,11 @@ __device__ __forceinline__ void passC(const float2* S, float2 (&g)[16], float2 b
 #ifdef GR4_FD_TIMING
 #define GR4_STAMP(i)                                                                                  \
     do {                                                                                              \
-        if (threadIdx.x == 0 && a.dbg) a.dbg[((f / gridDim.x) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        if (threadIdx.x == 0 && a.dbg) a.dbg[((f / gridDim.x) * gridDim.x + blockIdx.x) * 16 + (i)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 #else
 #define GR4_STAMP(i) do { } while (0)
@@ -268,8 +274,12 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     float2 Hr[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) Hr[q] = a.H[t + 512 * q];
-    const float2 bB1 = a.twB[1 * 32 + kb], bB2 = a.twB[2 * 32 + kb];
-    const float2 bC1 = a.twC[1 * 512 + t], bC2 = a.twC[2 * 512 + t];
+    float2 twBr[16], twCr[16]; // exact table values, resident for the kernel lifetime (no per-frame twiddle generation)
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+        twBr[r] = a.twB[r * 32 + kb];
+        twCr[r] = a.twC[r * 512 + t];
+    }
 
     long f   = blockIdx.x;
     int  cur = 0;
@@ -350,13 +360,13 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             const float2 s0 = el[t], s1 = pq[t], s2 = pq[256 + t], s3 = pq[512 + t];
             el[t] = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
         }
-        passB_compute_store(S, w, bB1, bB2, cb, kb);
+        passB_compute_store(S, w, twBr, cb, kb);
         GR4_STAMP(6);
         GR4_LDS_BARRIER(); // #3
         GR4_STAMP(7);
         // ------------------------------------------------------------------ X pass C (p = 512, radix 16), then H[k] X[k]
         float2 X[16];
-        passC(S, X, bC1, bC2, t);
+        passC(S, X, twCr, t);
 #pragma unroll
         for (int q = 0; q < 16; ++q) X[perm16(q)] = cmul(Hr[q], X[perm16(q)]);
         GR4_STAMP(8);
@@ -366,11 +376,11 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
 #pragma unroll
         for (int r = 0; r < 16; ++r) w[r] = el[cb + 16 * r];
-        passB_compute_store(S, w, bB1, bB2, cb, kb);
+        passB_compute_store(S, w, twBr, cb, kb);
         GR4_STAMP(10);
         GR4_LDS_BARRIER(); // #5
         GR4_STAMP(11);
-        passC(S, w, bC1, bC2, t);
+        passC(S, w, twCr, t);
         GR4_STAMP(12);
         // ------------------------------------------------------------------ FFT(y_f)[k] = H[k] X[k] + E[k];  mag2 = |.|^2  (k = t + 512 q)
         const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
