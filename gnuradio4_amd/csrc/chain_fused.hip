@@ -31,6 +31,7 @@ constexpr int kT     = 512;  // lanes per workgroup (8 waves)
 constexpr int kTail  = 255;  // ntaps - 1 (taps are zero-padded to 256)
 constexpr int kRowA  = 264;  // pass-A -> pass-B exchange: S[r'][n0], row pitch 264 float2 (528 dwords = 16 mod 64; rows k and k+2 are 32 banks apart)
 constexpr int kRowB  = 513;  // pass-B -> pass-C exchange: S[c][i3], row pitch 513 float2 (1026 dwords = 2 mod 32: 16 c-lanes hit 32 distinct banks)
+constexpr int kDPad  = 544; // >= (16 * 15 + 255) * 17 / 16 + 1
 constexpr int kSLen  = 32 * kRowA + 8; // 8456 float2 (rows 16..31 are shifted by 8) >= 16 * 513
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
@@ -182,11 +183,16 @@ __device__ __forceinline__ void passC(const float2* S, float2 (&g)[16], const fl
         __builtin_amdgcn_sched_barrier(0);                                                            \
         unsigned long long t_;                                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
-        if (threadIdx.x == 0 && a.dbg) a.dbg[((f / gridDim.x) * gridDim.x + blockIdx.x) * 16 + (i)] = t_; \
+        if ((threadIdx.x & 63) == 0 && a.dbg) a.dbg[(((f / gridDim.x) * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_; \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     } while (0)
 #else
 #define GR4_STAMP(i) do { } while (0)
+#endif
+#ifdef GR4_FD_TIMING
+#define GR4_PIN(v) pin16(v)
+#else
+#define GR4_PIN(v) do { } while (0)
 #endif
 
 typedef __attribute__((address_space(3))) void*       lds_ptr_t;
@@ -217,10 +223,11 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 
 // asynchronous HBM -> LDS copy of one frame (64 KB) into the pass-A exchange layout: 64 one-KiB pieces, 8 per wave; no VGPR
 // staging, the data is in flight while the workgroup transforms the previous frame.
+template <int I0 = 0, int I1 = 8>
 __device__ __forceinline__ void dma_frame(const float2* __restrict__ xf, float2* S, int wave, int lane) {
     const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(S));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = I0; i < I1; ++i) {
         const int row = 4 * wave + (i >> 1), half = i & 1;
         dma_1k(xf + row * 256 + 128 * half + 2 * lane, base + (unsigned)addrA(row, 128 * half) * 8u);
     }
@@ -246,48 +253,58 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
     float2* B1 = smem + kSLen;                       // kSLen: (odd frames)
-    float2* D  = B1 + kSLen;                         // 512: D[i+1] = d[i] (i < 255), zero elsewhere (zero padding of the e-FIR)
-    float2* el = D + 512;                            // 256: e[n] (tap quarter 0, then the sum)
-    float2* pq = el + 256;                           // 3 x 256: partial e of tap quarters 1..3
-    float2* T0 = pq + 768;                           // 256: tail of the stream before the frame in B0 (x[fN - 256 + j])
+    float2* T0 = B1 + kSLen;                         // 256: tail of the stream before the frame in B0 (x[fN - 256 + j])
     float2* T1 = T0 + 256;                           // 256: same for B1
-    float*  hl = reinterpret_cast<float*>(T1 + 256); // 256 taps
+    float2* el = T1 + 256;                           // 256: e[n]
+    float*  P  = reinterpret_cast<float*>(el + 256); // [8 waves][re, im][256]: partial e of each wave's 32-tap K range
+    float*  Dre = P + 8 * 2 * 256;                   // kDPad: Dz[s] = d[s - 1] (1 <= s <= 255), zero elsewhere (s <= 511); planar, one pad
+    float*  Dim = Dre + kDPad;                       //        float per 16 samples so that the MFMA B-operand reads are conflict-free
+    float*  hl  = Dim + kDPad;                       // 272: taps, zero from 256 on
 
-    const int t    = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    if (t < 256) {
-        hl[t]      = a.taps[t];
-        D[256 + t] = make_float2(0.f, 0.f);
-    }
-    if (t == 0) D[0] = make_float2(0.f, 0.f);
+    const int t0   = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6), lane0 = t0 & 63;
+
+    for (int i = t0; i < 2 * kDPad; i += kT) Dre[i] = 0.f; // Dre and Dim are adjacent
+    if (t0 < 272) hl[t0] = t0 < 256 ? a.taps[t0] : 0.f;
 
     // pass A roles: column n0, parity par (even / odd rows of the column); the pair (2 n0, 2 n0 + 1) are neighbouring lanes
-    const int   n0 = t >> 1, par = t & 1;
-    const float sgn = par ? -1.f : 1.f;
     // pass B roles: c = lane & 15, k = 4 wave + {0,2,1,3}[lane >> 4]  (k and k+2 share a 32-lane group: disjoint banks)
-    const int cb = lane & 15, kq = lane >> 4;
-    const int kb = 4 * wave + ((kq & 1) << 1 | (kq >> 1));
-    // e-FIR roles
-    const int tq = wave & 3, oh = wave >> 2;
-
+    const int kq0 = lane0 >> 4;
+    const int kb0 = 4 * wave + ((kq0 & 1) << 1 | (kq0 >> 1));
     // ---- kernel-lifetime registers: H[t + 512 q], twiddle bases W_512^{kb}, W_512^{2 kb}, W_8192^{t}, W_8192^{2t}
     float2 Hr[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Hr[q] = a.H[t + 512 * q];
+    for (int q = 0; q < 16; ++q) Hr[q] = a.H[t0 + 512 * q];
     float2 twBr[16], twCr[16]; // exact table values, resident for the kernel lifetime (no per-frame twiddle generation)
 #pragma unroll
     for (int r = 1; r < 16; ++r) {
-        twBr[r] = a.twB[r * 32 + kb];
-        twCr[r] = a.twC[r * 512 + t];
+        twBr[r] = a.twB[r * 32 + kb0];
+        twCr[r] = a.twC[r * 512 + t0];
     }
 
+    // |Y|^2 of the previous frame waits in registers and leaves in four groups of four stores spread over this frame's phases;
+    // likewise the eight DMA pieces per wave of the next frame.  A wave that issues its 16 stores (or 8 DMAs) back to back sits
+    // in VMEM issue for ~4000 cycles behind the other waves' requests and every barrier inherits the skew.
+    float pend[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pend[q] = 0.f;
+    long fprev = -1;
     long f   = blockIdx.x;
     int  cur = 0;
     if (f < a.n_frames) {
-        dma_tail(f > 0 ? a.x + f * kN - 256 : a.hist, T0, wave, lane);
-        dma_frame(a.x + f * kN, B0, wave, lane);
+        dma_tail(f > 0 ? a.x + f * kN - 256 : a.hist, T0, wave, lane0);
+        dma_frame(a.x + f * kN, B0, wave, lane0);
     }
     for (; f < a.n_frames; f += gridDim.x, cur ^= 1) {
+        // per-iteration opaque copy of the lane id: lane-dependent LDS / buffer offsets are recomputed here (a few VALU ops)
+        // instead of being hoisted out of the loop as dozens of loop-invariant VGPRs
+        int tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));
+        const int   lane = tl & 63, t = tl;
+        const int   n0 = tl >> 1, par = tl & 1;
+        const float sgn = par ? -1.f : 1.f;
+        const int   cb = lane & 15, kq = lane >> 4;
+        const int   kb = 4 * wave + ((kq & 1) << 1 | (kq >> 1));
         float2* S  = cur ? B1 : B0;
         float2* Sn = cur ? B0 : B1;
         const float2* Tc = cur ? T1 : T0;
@@ -296,9 +313,15 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(1);
         // stream the next frame (and the 256 samples before it) into the other buffers: in flight until the next barrier T.
         // Unconditional (the last iteration re-reads its own frame): no divergent paths around the DMA for hipcc's wait insertion
-        const long fn = (f + gridDim.x < a.n_frames) ? f + gridDim.x : f;
+        const long   fn = (f + gridDim.x < a.n_frames) ? f + gridDim.x : f;
+        const rsrc_t rq = make_rsrc(a.out + (fprev < 0 ? 0 : fprev) * kN, fprev < 0 ? 0u : (unsigned)(kN * sizeof(float))); // first iteration: nothing pending, stores fall out of range
+#define GR4_DRAIN(g)                                                                                       \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); \
+        dma_frame<(g), (g) + 1>(a.x + fn * kN, Sn, wave, lane);                                            \
+    } while (0)
         dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
-        dma_frame(a.x + fn * kN, Sn, wave, lane);
+        GR4_DRAIN(0);
 
         // ------------------------------------------------------------------ pass A: 32-point DFT down the 256 columns, in place
         // (a lane pair reads all 32 rows of its column before it writes them back: no barrier needed)
@@ -306,8 +329,13 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             float2 v[16];
 #pragma unroll
             for (int m = 0; m < 16; ++m) v[m] = S[addrA(2 * m + par, n0)];
-            if (par && n0 > 0) D[n0] = csub(Tc[n0], v[15]); // v[15] is x_f[N - 256 + n0]:  D[n0] = d[n0 - 1]
+            if (par && n0 > 0) { // v[15] is x_f[N - 256 + n0]:  Dz[n0] = d[n0 - 1]
+                const float2 dd = csub(Tc[n0], v[15]);
+                Dre[n0 + (n0 >> 4)] = dd.x;
+                Dim[n0 + (n0 >> 4)] = dd.y;
+            }
             fft16<1>(v); // even lanes: E16[k1], odd lanes: O16[k1], at slot perm16(k1)
+            GR4_DRAIN(1);
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 // X[k1] = E + W O (even lane), X[k1 + 16] = E - W O (odd lane), W = W_32^k1
@@ -322,56 +350,62 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(2);
         GR4_LDS_BARRIER(); // #1
         GR4_STAMP(3);
+        GR4_DRAIN(2);
 
-        // ------------------------------------------------------------------ e[n] = sum_j b[j] dz[255 + n - j]
-        // wave -> tap quarter tq (taps [64 tq, 64 tq + 64), held in SGPRs) and output half oh; lane -> outputs n = 128 oh + 2 lane + {0,1}
+        // ------------------------------------------------------------------ e[n] = sum_j b[j] Dz[256 + n - j] on the MFMA units
+        // Block-Toeplitz form with n = 16 i + j:  e[16 i + j] = sum_u A[j][u] B[u][i],  A[j][u] = b[256 + j - u],  B[u][i] = Dz[16 i + u],
+        // u < 256 (Dz is zero from 256 on).  [16 x 256] x [256 x 32] (16 blocks x {re, im}) = 128 v_mfma_f32_16x16x4_f32, 16 per wave
+        // (K split over the 8 waves, partial tiles summed after the barrier).  The matrix pipe is otherwise idle in this kernel, the
+        // B operand is ONE conflict-free ds_read_b32 per MFMA, and all eight waves carry the same load.
         {
-            const float* Df = reinterpret_cast<const float*>(D);
-            const float* tg = hl + 64 * tq; // wave-uniform address: LDS broadcast reads
-            const int    c0 = 512 + 256 * oh + 4 * lane - 128 * tq; // float index of (n, tap 64 tq) in the float view of D
-            float        acc[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!(oh == 1 && tq < 2)) { // taps j <= 127 never reach outputs n >= 128 (only j > n contributes)
-                float4 hi = *reinterpret_cast<const float4*>(Df + c0);
-                float4 lo = *reinterpret_cast<const float4*>(Df + c0 - 4);
-#pragma unroll 4
-                for (int g = 0; g < 32; ++g) {
-                    const float2 h2 = *reinterpret_cast<const float2*>(tg + 2 * g);
-                    const float  h0 = h2.x, h1 = h2.y;
-                    acc[0] = fmaf(h0, hi.x, acc[0]); acc[1] = fmaf(h0, hi.y, acc[1]);
-                    acc[2] = fmaf(h0, hi.z, acc[2]); acc[3] = fmaf(h0, hi.w, acc[3]);
-                    acc[0] = fmaf(h1, lo.z, acc[0]); acc[1] = fmaf(h1, lo.w, acc[1]);
-                    acc[2] = fmaf(h1, hi.x, acc[2]); acc[3] = fmaf(h1, hi.y, acc[3]);
-                    hi = lo;
-                    if (g < 31) lo = *reinterpret_cast<const float4*>(Df + c0 - 4 * g - 8);
-                }
+            using f32x4 = __attribute__((ext_vector_type(4))) float;
+            const int    col = lane & 15, kqm = lane >> 4;
+            const float* pr  = Dre + 17 * col + kqm + 34 * wave;
+            const float* pi  = Dim + 17 * col + kqm + 34 * wave;
+            const float* pa  = hl + 256 + col - kqm - 32 * wave; // A[j = col][u] = b[256 + j - u], u = 32 wave + 4 i + kqm
+            f32x4        cr = {0.f, 0.f, 0.f, 0.f}, ci = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int off = 4 * i + (i >> 2); // padded offset of u = 32 wave + 4 i within the window
+                cr = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[-4 * i], pr[off], cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[-4 * i], pi[off], ci, 0, 0, 0);
             }
-            float2* dst = (tq == 0 ? el : pq + 256 * (tq - 1)) + 128 * oh + 2 * lane;
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            // D[row = 4 kqm + r][col] = partial e[16 col + 4 kqm + r]
+            float* dst = P + wave * 512 + 16 * col + 4 * kqm;
+            *reinterpret_cast<float4*>(dst)       = make_float4(cr[0], cr[1], cr[2], cr[3]);
+            *reinterpret_cast<float4*>(dst + 256) = make_float4(ci[0], ci[1], ci[2], ci[3]);
         }
 
+        GR4_DRAIN(3);
         // ------------------------------------------------------------------ X pass B (p = 32, radix 16)
         float2 w[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
+        GR4_PIN(w);
         GR4_STAMP(4);
         GR4_LDS_BARRIER(); // #2
         GR4_STAMP(5);
-        if (t < 256) {
-            const float2 s0 = el[t], s1 = pq[t], s2 = pq[256 + t], s3 = pq[512 + t];
-            el[t] = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+        GR4_DRAIN(4);
+        { // e = sum of the eight partial tiles (fixed order); lane t -> component t >> 8 of e[t & 255]
+            const float* pp = P + t;
+            const float  s01 = pp[0] + pp[512], s23 = pp[1024] + pp[1536], s45 = pp[2048] + pp[2560], s67 = pp[3072] + pp[3584];
+            reinterpret_cast<float*>(el)[2 * (t & 255) + (t >> 8)] = (s01 + s23) + (s45 + s67);
         }
         passB_compute_store(S, w, twBr, cb, kb);
         GR4_STAMP(6);
         GR4_LDS_BARRIER(); // #3
         GR4_STAMP(7);
+        GR4_DRAIN(5);
         // ------------------------------------------------------------------ X pass C (p = 512, radix 16), then H[k] X[k]
         float2 X[16];
         passC(S, X, twCr, t);
+        GR4_DRAIN(6);
 #pragma unroll
         for (int q = 0; q < 16; ++q) X[perm16(q)] = cmul(Hr[q], X[perm16(q)]);
         GR4_STAMP(8);
         GR4_LDS_BARRIER(); // #4: every lane has consumed S; e[] is complete
         GR4_STAMP(9);
+        GR4_DRAIN(7);
 
         // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
 #pragma unroll
@@ -381,18 +415,26 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_LDS_BARRIER(); // #5
         GR4_STAMP(11);
         passC(S, w, twCr, t);
+        GR4_PIN(w);
         GR4_STAMP(12);
         // ------------------------------------------------------------------ FFT(y_f)[k] = H[k] X[k] + E[k];  mag2 = |.|^2  (k = t + 512 q)
-        const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float2 Y = cadd(X[perm16(q)], w[perm16(q)]);
-            buf_store_f(ro, fmaf(Y.x, Y.x, Y.y * Y.y), t * 4, q * 2048); // out[t + 512 q]
+            pend[q] = fmaf(Y.x, Y.x, Y.y * Y.y); // out[t + 512 q], stored during the next frame
         }
+        fprev = f;
         GR4_STAMP(13);
         GR4_STAMP(14);
     }
+    if (fprev >= 0) {
+        const rsrc_t rq = make_rsrc(a.out + fprev * kN, kN * sizeof(float));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) buf_store_f(rq, pend[q], t0 * 4, q * 2048);
+    }
+#undef GR4_DRAIN
 }
+
 
 int chain_fused_reset(struct ChainFused* c);
 #ifdef GR4_FD_TIMING
@@ -475,9 +517,9 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
     a.dbg      = nullptr;
 #ifdef GR4_FD_TIMING
     if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
-    if (n_frames * 16 * 8 <= ((size_t)1 << 26)) a.dbg = g_dbg;
+    if (n_frames * 8 * 16 * 8 <= ((size_t)1 << 26)) a.dbg = g_dbg;
 #endif
-    const size_t lds = (size_t)(2 * kSLen + 512 + 256 + 768 + 512) * sizeof(float2) + 256 * sizeof(float);
+    const size_t lds = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(8 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
     static int   n_cu = 0;
     if (n_cu == 0) {
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -485,7 +527,7 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
         GR4_HIP_TRY(hipGetDevice(&dev));
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const unsigned grid = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu); // one resident workgroup per CU (148 KB of LDS)
+    const unsigned grid = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu); // one resident workgroup per CU
     hipLaunchKernelGGL(chain_fd_kernel, dim3(grid), dim3(kT), lds, st, a);
     GR4_LAUNCH_CHECK();
     // carry the last 256 input samples for the next call's first frame (stream-ordered after the kernel's reads)
@@ -500,7 +542,7 @@ void chain_fused_destroy(ChainFused* c) { delete c; }
 extern "C" int gr4hip_dbg_fd_timing(unsigned long long* h_out, size_t n_frames) { // developer-only, not part of the ABI
     if (!gr4::g_dbg) return GR4HIP_ERROR;
     (void)hipDeviceSynchronize();
-    return hipMemcpy(h_out, gr4::g_dbg, n_frames * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? GR4HIP_OK : GR4HIP_RUNTIME_ERROR;
+    return hipMemcpy(h_out, gr4::g_dbg, n_frames * 8 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? GR4HIP_OK : GR4HIP_RUNTIME_ERROR;
 }
 namespace gr4 {
 #endif
