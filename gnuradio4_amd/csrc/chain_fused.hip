@@ -59,16 +59,19 @@ __device__ __forceinline__ float2 mul_w16(float2 a) {
 // in-place 16-point forward DFT on v[0], v[ST], ..., v[15 ST].  Result order: X[m] sits at slot perm16(m).
 __host__ __device__ constexpr int perm16(int m) { return 4 * (m & 3) + (m >> 2); }
 
+// the three steps of fft16, callable one quarter at a time (the fused pass B interleaves them with MFMA issues)
 template <int ST>
-__device__ __forceinline__ void fft16(float2* v) {
-#pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) bfly4(v[(n2)*ST], v[(n2 + 4) * ST], v[(n2 + 8) * ST], v[(n2 + 12) * ST]);
-    // a[n2][k1] is at slot n2 + 4 k1; twiddle W_16^{n2 k1}
+__device__ __forceinline__ void fft16_s1(float2* v, int n2) { bfly4(v[(n2)*ST], v[(n2 + 4) * ST], v[(n2 + 8) * ST], v[(n2 + 12) * ST]); }
+template <int ST>
+__device__ __forceinline__ void fft16_twa(float2* v) { // a[n2][k1] is at slot n2 + 4 k1; twiddle W_16^{n2 k1}
     v[5 * ST]  = mul_w16<1>(v[5 * ST]);   // n2=1,k1=1
     v[9 * ST]  = mul_w16<2>(v[9 * ST]);   // n2=1,k1=2
     v[13 * ST] = mul_w16<3>(v[13 * ST]);  // n2=1,k1=3
     v[6 * ST]  = mul_w16<2>(v[6 * ST]);   // n2=2,k1=1
     v[10 * ST] = mul_w16<4>(v[10 * ST]);  // n2=2,k1=2
+}
+template <int ST>
+__device__ __forceinline__ void fft16_twb(float2* v) {
     v[14 * ST] = mul_w16<6>(v[14 * ST]);  // n2=2,k1=3
     v[7 * ST]  = mul_w16<3>(v[7 * ST]);   // n2=3,k1=1
     v[11 * ST] = mul_w16<6>(v[11 * ST]);  // n2=3,k1=2
@@ -77,8 +80,18 @@ __device__ __forceinline__ void fft16(float2* v) {
         const float2 a = v[15 * ST];
         v[15 * ST] = make_float2(fmaf(-a.y, s1, -a.x * c1), fmaf(a.x, s1, -a.y * c1));
     }
+}
+template <int ST>
+__device__ __forceinline__ void fft16_s2(float2* v, int k1) { bfly4(v[(4 * k1) * ST], v[(4 * k1 + 1) * ST], v[(4 * k1 + 2) * ST], v[(4 * k1 + 3) * ST]); }
+
+template <int ST>
+__device__ __forceinline__ void fft16(float2* v) {
 #pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) bfly4(v[(4 * k1) * ST], v[(4 * k1 + 1) * ST], v[(4 * k1 + 2) * ST], v[(4 * k1 + 3) * ST]);
+    for (int n2 = 0; n2 < 4; ++n2) fft16_s1<ST>(v, n2);
+    fft16_twa<ST>(v);
+    fft16_twb<ST>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) fft16_s2<ST>(v, k1);
 }
 
 // W_32^k = (cos(2 pi k / 32), -sin(2 pi k / 32)); k is a compile-time constant after unrolling, so the switch folds
@@ -352,6 +365,16 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(3);
         GR4_DRAIN(2);
 
+        GR4_DRAIN(3);
+        // ------------------------------------------------------------------ X pass B (p = 32, radix 16)
+        float2 w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
+        GR4_PIN(w);
+        GR4_STAMP(4);
+        GR4_LDS_BARRIER(); // #2
+        GR4_STAMP(5);
+        GR4_DRAIN(4);
         // ------------------------------------------------------------------ e[n] = sum_j b[j] Dz[256 + n - j] on the MFMA units
         // Block-Toeplitz form with n = 16 i + j:  e[16 i + j] = sum_u A[j][u] B[u][i],  A[j][u] = b[256 + j - u],  B[u][i] = Dz[16 i + u],
         // u < 256 (Dz is zero from 256 on).  [16 x 256] x [256 x 32] (16 blocks x {re, im}) = 128 v_mfma_f32_16x16x4_f32, 16 per wave
@@ -363,39 +386,64 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             const float* pr  = Dre + 17 * col + kqm + 34 * wave;
             const float* pi  = Dim + 17 * col + kqm + 34 * wave;
             const float* pa  = hl + 256 + col - kqm - 32 * wave; // A[j = col][u] = b[256 + j - u], u = 32 wave + 4 i + kqm
-            f32x4        cr = {0.f, 0.f, 0.f, 0.f}, ci = {0.f, 0.f, 0.f, 0.f};
+            float        av[8], br[8], bi[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int off = 4 * i + (i >> 2); // padded offset of u = 32 wave + 4 i within the window
-                cr = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[-4 * i], pr[off], cr, 0, 0, 0);
-                ci = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[-4 * i], pi[off], ci, 0, 0, 0);
+                av[i] = pa[-4 * i];
+                br[i] = pr[off];
+                bi[i] = pi[off];
             }
+            f32x4 cr = {0.f, 0.f, 0.f, 0.f}, ci = {0.f, 0.f, 0.f, 0.f};
+            // One MFMA per ~12-16 butterfly instructions, fenced so that hipcc keeps the order: the wave issues in order, the MFMA
+            // occupies the matrix pipe for 32 cycles while the following VALU instructions of the same wave go to the vector pipe.
+            // (Left alone hipcc emits the 16 MFMAs back to back in front of the butterflies and the interval grows by their 512 cycles.)
+#define GR4_MF(i)                                                                           \
+    do {                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if ((i) & 1) ci = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i) >> 1], bi[(i) >> 1], ci, 0, 0, 0); \
+        else cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i) >> 1], br[(i) >> 1], cr, 0, 0, 0);        \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
+            // ---- X pass B: twiddles W_512^{r k}, 16-point DFT, scatter to S2[c][32 q + k]
+#pragma unroll
+            for (int g = 0; g < 5; ++g) {
+                GR4_MF(g);
+#pragma unroll
+                for (int r = 3 * g + 1; r < 3 * g + 4; ++r) w[r] = cmul(w[r], twBr[r]);
+            }
+#pragma unroll
+            for (int n2 = 0; n2 < 4; ++n2) {
+                GR4_MF(5 + n2);
+                fft16_s1<1>(w, n2);
+            }
+            GR4_MF(9);
+            fft16_twa<1>(w);
+            GR4_MF(10);
+            fft16_twb<1>(w);
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) {
+                GR4_MF(11 + k1);
+                fft16_s2<1>(w, k1);
+            }
+            GR4_MF(15);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) S[cb * kRowB + 32 * q + kb] = w[perm16(q)];
+#undef GR4_MF
             // D[row = 4 kqm + r][col] = partial e[16 col + 4 kqm + r]
             float* dst = P + wave * 512 + 16 * col + 4 * kqm;
             *reinterpret_cast<float4*>(dst)       = make_float4(cr[0], cr[1], cr[2], cr[3]);
             *reinterpret_cast<float4*>(dst + 256) = make_float4(ci[0], ci[1], ci[2], ci[3]);
         }
-
-        GR4_DRAIN(3);
-        // ------------------------------------------------------------------ X pass B (p = 32, radix 16)
-        float2 w[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
-        GR4_PIN(w);
-        GR4_STAMP(4);
-        GR4_LDS_BARRIER(); // #2
-        GR4_STAMP(5);
-        GR4_DRAIN(4);
+        GR4_STAMP(6);
+        GR4_LDS_BARRIER(); // #3
+        GR4_STAMP(7);
+        GR4_DRAIN(5);
         { // e = sum of the eight partial tiles (fixed order); lane t -> component t >> 8 of e[t & 255]
             const float* pp = P + t;
             const float  s01 = pp[0] + pp[512], s23 = pp[1024] + pp[1536], s45 = pp[2048] + pp[2560], s67 = pp[3072] + pp[3584];
             reinterpret_cast<float*>(el)[2 * (t & 255) + (t >> 8)] = (s01 + s23) + (s45 + s67);
         }
-        passB_compute_store(S, w, twBr, cb, kb);
-        GR4_STAMP(6);
-        GR4_LDS_BARRIER(); // #3
-        GR4_STAMP(7);
-        GR4_DRAIN(5);
         // ------------------------------------------------------------------ X pass C (p = 512, radix 16), then H[k] X[k]
         float2 X[16];
         passC(S, X, twCr, t);
