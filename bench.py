@@ -48,10 +48,10 @@ def cpu_baseline(target_seconds: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2-samples", type=int, default=30, help="stream length per step and rank (default 2^30 = configs[1])")
-    ap.add_argument("--log2-chunk", type=int, default=26, help="samples per launch")
+    ap.add_argument("--log2-chunk", type=int, default=28, help="samples per launch")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 unfused, 2 fused time-domain, 3 fused frequency-domain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -28,7 +28,6 @@ namespace gr4 {
 
 constexpr int kN     = 8192;
 constexpr int kT     = 512;  // lanes per workgroup (8 waves)
-constexpr int kTail  = 255;  // ntaps - 1 (taps are zero-padded to 256)
 constexpr int kRowA  = 264;  // pass-A -> pass-B exchange: S[r'][n0], row pitch 264 float2 (528 dwords = 16 mod 64; rows k and k+2 are 32 banks apart)
 constexpr int kRowB  = 513;  // pass-B -> pass-C exchange: S[c][i3], row pitch 513 float2 (1026 dwords = 2 mod 32: 16 c-lanes hit 32 distinct banks)
 constexpr int kDPad  = 544; // >= (16 * 15 + 255) * 17 / 16 + 1
@@ -208,6 +207,21 @@ __device__ __forceinline__ void passC(const float2* S, float2 (&g)[16], const fl
 #define GR4_PIN(v) do { } while (0)
 #endif
 
+// DMA pieces (of 8 per wave) issued at drain point g: [kDmaAt[g], kDmaAt[g + 1]) -- front-loaded, the last piece leaves ~2/3 of a
+// frame time before it is needed
+#ifndef GR4_DMA_SCHED
+#define GR4_DMA_SCHED 0
+#endif
+#if GR4_DMA_SCHED == 0
+constexpr int kDmaAt[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+#elif GR4_DMA_SCHED == 1
+constexpr int kDmaAt[9] = {0, 0, 1, 2, 3, 5, 6, 7, 8};
+#elif GR4_DMA_SCHED == 2
+constexpr int kDmaAt[9] = {0, 1, 1, 3, 4, 5, 6, 7, 8};
+#else
+constexpr int kDmaAt[9] = {0, 0, 0, 2, 4, 5, 6, 7, 8};
+#endif
+
 typedef __attribute__((address_space(3))) void*       lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #define GR4_DRAIN(g)                                                                                       \
     do {                                                                                                   \
         _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); \
-        dma_frame<(g), (g) + 1>(a.x + fn * kN, Sn, wave, lane);                                            \
+        dma_frame<kDmaAt[g], kDmaAt[(g) + 1]>(a.x + fn * kN, Sn, wave, lane);                              \
     } while (0)
         dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
         GR4_DRAIN(0);

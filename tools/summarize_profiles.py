@@ -18,9 +18,17 @@ lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-ba
 lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'%':>6}  kernel")
 for name, calls, total, avg, pct in rows:
     lines.append(f"{calls:7d} {total:12.1f} {avg:10.2f} {pct:6.2f}  {name}")
+durs = [(e - b) / 1e3 for b, e in db.execute("select start, end from kernels where name like ? order by start", (f"%{kern}%",)).fetchall()]
+if durs:
+    sd = sorted(durs)
+    lines.append("")
+    lines.append(f"# per-dispatch durations of '{kern}' in launch order (us): the clocks ramp over the first ~20 launches after the idle gap, the")
+    lines.append(f"# steady-state tail is what bench.py's HIP events report for the last timed step (roofline.avg_launch_ms)")
+    lines.append("#   " + " ".join(f"{d:.0f}" for d in durs))
+    lines.append(f"#   min {sd[0]:.1f}  median {sd[len(sd)//2]:.1f}  max {sd[-1]:.1f}  mean of last 4 {sum(durs[-4:])/4:.1f}")
 lines.append("")
 lines.append(f"# rocprofv3 --pmc <counters> (separate passes, counters only) -- python bench.py --steps 1 --warmup 1 --log2-samples 28 --no-cpu-baseline")
-lines.append(f"# per-dispatch means for kernels matching '{kern}' (one dispatch = one launch of 2^26 samples)")
+lines.append(f"# per-dispatch means for kernels matching '{kern}' (one dispatch = one launch of 2^28 samples)")
 for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
