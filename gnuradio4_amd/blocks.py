@@ -237,9 +237,10 @@ class FFT(_Handle):
         out["frequency"] = (np.arange(n) * fw - (n // 2) * fw) if self.dtype == torch.complex64 else np.arange(n) * fw
         return out
 
-    def spectrum(self, x: torch.Tensor) -> torch.Tensor:
+    def spectrum(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x, frames = self._frames(x)
-        out = torch.empty((frames, self.fftSize), dtype=torch.complex64, device=x.device)
+        if out is None:
+            out = torch.empty((frames, self.fftSize), dtype=torch.complex64, device=x.device)
         check(lib().gr4hip_fft_spectrum(self._h, x.data_ptr(), frames, out.data_ptr(), _stream()), "FFT.spectrum")
         return out
 

@@ -10,7 +10,7 @@ pids=()
 for s in $SRCS; do
   o=../../build/obj/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.hpp -nt "$o" ] || [ fir_window.hpp -nt "$o" ] || [ ../../include/gr4hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.hpp -nt "$o" ] || [ fir_window.hpp -nt "$o" ] || [ fft_radix.hpp -nt "$o" ] || [ buffer_ops.hpp -nt "$o" ] || [ ../../include/gr4hip.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "$s" -o "$o" &
     pids+=($!)
   fi

@@ -224,7 +224,7 @@ def test_basic_filter_bands(G, golden):
 
 
 # ------------------------------------------------------------------ FFT block (a7-a10)
-@pytest.mark.parametrize("N", [2, 4, 8, 16, 64, 256, 1024, 4096, 8192])
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
 def test_fft_spectrum_parity(G, N):
     frames = 5
     x = O.signal_c32(N, frames * N)
@@ -250,7 +250,7 @@ def test_fft_n16_patterns_golden(G, golden):
 
 
 @pytest.mark.parametrize("window", ["None", "Hann", "Hamming", "BlackmanHarris", "Kaiser", "FlatTop"])
-@pytest.mark.parametrize("N", [256, 8192])
+@pytest.mark.parametrize("N", [256, 1024, 8192])
 def test_fft_block_outputs_parity(G, window, N):
     frames = 3
     x = O.signal_c32(11, frames * N)
@@ -283,7 +283,7 @@ def test_fft_block_db_deg_unwrap_and_peak(G, golden):
     assert np.mean(np.abs(d) < 0.05) > 0.9
 
 
-@pytest.mark.parametrize("N", [64, 1024])
+@pytest.mark.parametrize("N", [64, 512, 1024, 2048, 8192])
 def test_fft_real_input(G, N):
     x = O.signal_f32(5, 2 * N)
     out = G.FFT(N, "Hann", dtype=torch.float32).process_bulk(dev(x))
@@ -292,6 +292,20 @@ def test_fft_real_input(G, N):
         mag, ph, re, im = O.fft_block_truth(x[f * N:(f + 1) * N], 3)
         assert _rel(out["magnitude"][f].cpu().numpy(), mag) <= TOL
         assert _rel(out["re"][f].cpu().numpy(), re) <= TOL and _rel(out["im"][f].cpu().numpy(), im) <= TOL
+
+
+@pytest.mark.parametrize("N", [256, 1024, 2048, 8192])
+def test_fft_many_frames_match_small_batches(G, N):
+    """persistent workgroups / several frames per workgroup: a long call equals the same frames processed a few at a time, bit for bit"""
+    frames = 3 * 512 * 16 // N + 5
+    rng = np.random.default_rng(N)
+    x = dev((rng.standard_normal(frames * N) + 1j * rng.standard_normal(frames * N)).astype(np.complex64))
+    F = G.FFT(N, "Hann")
+    whole = F.spectrum(x)
+    for f0 in (0, 7, frames - 3):
+        part = F.spectrum(x[f0 * N:(f0 + 3) * N])
+        assert torch.equal(part, whole[f0:f0 + 3])
+    assert torch.equal(F.mag2(x), whole.real ** 2 + whole.imag ** 2) or float((F.mag2(x) - (whole.real ** 2 + whole.imag ** 2)).abs().max()) <= 1e-6 * float(F.mag2(x).max())
 
 
 def test_fft_linearity_and_roundtrip_properties(G):
