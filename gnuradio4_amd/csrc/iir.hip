@@ -17,171 +17,263 @@
 
 namespace gr4 {
 
-constexpr int kIirL      = 32;  // samples per lane chunk
-constexpr int kIirBS     = 256; // lanes per block
-constexpr int kIirMaxSec = 8;
-constexpr int kIirMaxM   = 16;  // total state floats
-constexpr int kIirRounds = 8;   // log2(kIirBS)
+constexpr int kIirL       = 32;  // samples per lane chunk
+constexpr int kIirBS      = 256; // lanes per block
+constexpr int kIirMaxM    = 16;  // total state floats
+constexpr int kIirRounds  = 8;   // log2(kIirBS)
+constexpr int kIirBB      = 512; // blocks per group of the block-level scan
+constexpr int kIirBRounds = 9;   // log2(kIirBB)
+constexpr int kIirBShift  = 2;   // log2(kIirBK)
+constexpr int kIirBK      = 4;   // blocks chained per lane in the block-level scan
 
-template <int ORD>
+// Kernels are instantiated for (section order, padded section count): the state count MP = ORD * NSEC is a compile-time 4, 8 or 16,
+// so the propagation matrices come in through wide scalar loads and everything unrolls.  A cascade with fewer sections is padded
+// with identity sections (b0 = 1): y = x exactly, no per-section branches in the sample loop.
+template <int ORD, int NSEC>
 struct IirCoef {
-    int   nsec;
-    float b[kIirMaxSec][ORD + 1];
-    float a[kIirMaxSec][ORD + 1]; // a[.][0] unused (== 1)
+    float b[NSEC][ORD + 1];
+    float a[NSEC][ORD + 1]; // a[.][0] unused (== 1)
 };
 
 // one sample through the cascade, direct form II per section (FilterTool.hpp:130-141)
-template <int ORD>
-__device__ __forceinline__ float iir_step(const IirCoef<ORD>& c, float (&st)[kIirMaxSec][ORD], float x) {
+template <int ORD, int NSEC>
+__device__ __forceinline__ float iir_step(const IirCoef<ORD, NSEC>& c, float (&st)[NSEC][ORD], float x) {
 #pragma unroll
-    for (int s = 0; s < kIirMaxSec; ++s) {
-        if (s < c.nsec) {
-            float w = x;
+    for (int s = 0; s < NSEC; ++s) {
+        float w = x;
 #pragma unroll
-            for (int j = 0; j < ORD; ++j) w = fmaf(-c.a[s][j + 1], st[s][j], w);
-            float y = c.b[s][0] * w;
+        for (int j = 0; j < ORD; ++j) w = fmaf(-c.a[s][j + 1], st[s][j], w);
+        float y = c.b[s][0] * w;
 #pragma unroll
-            for (int j = 0; j < ORD; ++j) y = fmaf(c.b[s][j + 1], st[s][j], y);
+        for (int j = 0; j < ORD; ++j) y = fmaf(c.b[s][j + 1], st[s][j], y);
 #pragma unroll
-            for (int j = ORD - 1; j > 0; --j) st[s][j] = st[s][j - 1];
-            st[s][0] = w;
-            x        = y;
-        }
+        for (int j = ORD - 1; j > 0; --j) st[s][j] = st[s][j - 1];
+        st[s][0] = w;
+        x        = y;
     }
     return x;
 }
 
-// inclusive scan over the block's chunks:  sv[c] <- sum_{i<=c} Phi_L^{c-i} sv[i]   (sv holds M floats per lane)
-__device__ __forceinline__ void iir_block_scan(float* sv, const float* __restrict__ phi /*[rounds][M][M]*/, int M) {
+// propagation matrices global -> LDS, transposed ([round][j][i]) so that the scan reads a column of Phi as MP/4 broadcast b128 loads.
+// (Scalar loads straight from global memory cost a cold ~1 us round trip in every scan round of every block.)
+template <int MP, int ROUNDS>
+__device__ __forceinline__ void iir_load_phi(float* pl, const float* __restrict__ phi) {
+    for (int e = threadIdx.x; e < ROUNDS * MP * MP; e += blockDim.x) {
+        const int k = e / (MP * MP), r = e % (MP * MP), i = r / MP, j = r % MP;
+        pl[(k * MP + j) * MP + i] = phi[e];
+    }
+}
+
+// inclusive scan over the block's chunks:  sv[.][c] <- sum_{i<=c} Phi^{c-i} sv[.][i]   (sv is [MP][BS]: lane c owns column c, so every
+// access is lane-contiguous -- a [BS][MP] layout puts 16 lanes on one bank)
+template <int MP, int BS, int ROUNDS>
+__device__ __forceinline__ void iir_block_scan(float* sv, const float* pl /*LDS [ROUNDS][MP(j)][MP(i)]: Phi^(2^k) transposed*/) {
     const int c = threadIdx.x;
-    for (int k = 0; k < kIirRounds; ++k) {
+#pragma unroll 1
+    for (int k = 0; k < ROUNDS; ++k) {
         const int    off = 1 << k;
-        float        tmp[kIirMaxM];
-        const float* P = phi + (size_t)k * M * M;
+        float        tmp[MP];
+        const float* P = pl + k * MP * MP;
         if (c >= off) {
 #pragma unroll
-            for (int i = 0; i < kIirMaxM; ++i) {
-                if (i < M) {
-                    float acc = 0.f;
-                    for (int j = 0; j < M; ++j) acc = fmaf(P[i * M + j], sv[(c - off) * kIirMaxM + j], acc);
-                    tmp[i] = acc;
-                }
+            for (int i = 0; i < MP; ++i) tmp[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < MP; ++j) {
+                const float sj = sv[j * BS + c - off];
+#pragma unroll
+                for (int i = 0; i < MP; ++i) tmp[i] = fmaf(P[j * MP + i], sj, tmp[i]);
             }
         }
         __syncthreads();
         if (c >= off) {
 #pragma unroll
-            for (int i = 0; i < kIirMaxM; ++i)
-                if (i < M) sv[c * kIirMaxM + i] += tmp[i];
+            for (int i = 0; i < MP; ++i) sv[i * BS + c] += tmp[i];
         }
         __syncthreads();
     }
 }
 
-template <int ORD>
+// HBM -> LDS tile [chunk][L + 1]: all eight 16-byte loads of a lane are in flight before the first LDS write (a load-per-iteration
+// loop pays the full memory latency 32 times per block)
 __device__ __forceinline__ void iir_stage_tile(float* tile, const float* __restrict__ x, long base, long n) {
-    for (int s = threadIdx.x; s < kIirBS * kIirL; s += kIirBS) {
-        const long i = base + s;
-        tile[(s / kIirL) * (kIirL + 1) + (s % kIirL)] = i < n ? x[i] : 0.f;
+    constexpr int kV = kIirL / 4; // float4 per lane
+    if (base + (long)kIirBS * kIirL <= n && (reinterpret_cast<uintptr_t>(x + base) & 15) == 0) {
+        float4 v[kV];
+#pragma unroll
+        for (int q = 0; q < kV; ++q) v[q] = reinterpret_cast<const float4*>(x + base)[q * kIirBS + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < kV; ++q) {
+            const int s = 4 * (q * kIirBS + threadIdx.x);
+            float*    d = tile + (s / kIirL) * (kIirL + 1) + (s % kIirL);
+            d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
+        }
+    } else {
+        for (int s = threadIdx.x; s < kIirBS * kIirL; s += kIirBS) {
+            const long i = base + s;
+            tile[(s / kIirL) * (kIirL + 1) + (s % kIirL)] = i < n ? x[i] : 0.f;
+        }
+    }
+}
+__device__ __forceinline__ void iir_unstage_tile(const float* tile, float* __restrict__ y, long base, long n) {
+    constexpr int kV = kIirL / 4;
+    if (base + (long)kIirBS * kIirL <= n && (reinterpret_cast<uintptr_t>(y + base) & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < kV; ++q) {
+            const int    s = 4 * (q * kIirBS + threadIdx.x);
+            const float* d = tile + (s / kIirL) * (kIirL + 1) + (s % kIirL);
+            reinterpret_cast<float4*>(y + base)[q * kIirBS + threadIdx.x] = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    } else {
+        for (int s = threadIdx.x; s < kIirBS * kIirL; s += kIirBS) {
+            const long i = base + s;
+            if (i < n) y[i] = tile[(s / kIirL) * (kIirL + 1) + (s % kIirL)];
+        }
     }
 }
 
-// pass Z: z_c per chunk (global, [chunks][M]) and the block's zero-state end state Zb[block][M]
-template <int ORD>
-__global__ __launch_bounds__(kIirBS) void iir_pass_z(const float* __restrict__ x, long n, IirCoef<ORD> coef, const float* __restrict__ phi, float* __restrict__ zc,
+// pass Z: z_c per chunk (global, [chunks][MP]) and the block's zero-state end state Zb[block][MP]
+template <int ORD, int NSEC>
+__global__ __launch_bounds__(kIirBS) void iir_pass_z(const float* __restrict__ x, long n, IirCoef<ORD, NSEC> coef, const float* __restrict__ phi, float* __restrict__ zc,
                                                       float* __restrict__ zb) {
+    constexpr int    MP = ORD * NSEC;
     __shared__ float tile[kIirBS * (kIirL + 1)];
-    __shared__ float sv[kIirBS * kIirMaxM];
-    const int  M    = coef.nsec * ORD;
-    const long base = (long)blockIdx.x * kIirBS * kIirL;
-    iir_stage_tile<ORD>(tile, x, base, n);
+    __shared__ float sv[MP * kIirBS];
+    __shared__ __attribute__((aligned(16))) float pl[kIirRounds * MP * MP];
+    const long       base = (long)blockIdx.x * kIirBS * kIirL;
+    iir_load_phi<MP, kIirRounds>(pl, phi);
+    iir_stage_tile(tile, x, base, n);
     __syncthreads();
-    float st[kIirMaxSec][ORD];
+    float st[NSEC][ORD];
 #pragma unroll
-    for (int s = 0; s < kIirMaxSec; ++s)
+    for (int s = 0; s < NSEC; ++s)
 #pragma unroll
         for (int j = 0; j < ORD; ++j) st[s][j] = 0.f;
     const float* row = tile + threadIdx.x * (kIirL + 1);
 #pragma unroll 4
-    for (int i = 0; i < kIirL; ++i) (void)iir_step<ORD>(coef, st, row[i]);
+    for (int i = 0; i < kIirL; ++i) (void)iir_step<ORD, NSEC>(coef, st, row[i]);
     const long chunk = (long)blockIdx.x * kIirBS + threadIdx.x;
 #pragma unroll
-    for (int s = 0; s < kIirMaxSec; ++s)
+    for (int s = 0; s < NSEC; ++s)
 #pragma unroll
-        for (int j = 0; j < ORD; ++j)
-            if (s < coef.nsec) {
-                sv[threadIdx.x * kIirMaxM + s * ORD + j] = st[s][j];
-                zc[chunk * kIirMaxM + s * ORD + j]        = st[s][j];
-            }
+        for (int j = 0; j < ORD; ++j) {
+            sv[(s * ORD + j) * kIirBS + threadIdx.x] = st[s][j];
+            zc[chunk * MP + s * ORD + j]              = st[s][j];
+        }
     __syncthreads();
-    iir_block_scan(sv, phi, M);
-    if (threadIdx.x < M) zb[(long)blockIdx.x * kIirMaxM + threadIdx.x] = sv[(kIirBS - 1) * kIirMaxM + threadIdx.x];
+    iir_block_scan<MP, kIirBS, kIirRounds>(sv, pl);
+    if (threadIdx.x < MP) zb[(long)blockIdx.x * MP + threadIdx.x] = sv[threadIdx.x * kIirBS + kIirBS - 1];
 }
 
-// pass B: T_0 = carried state; T_{b+1} = Phi_B T_b + Zb[b].  Writes T_b (state at the START of block b).
-__global__ void iir_pass_b(const float* __restrict__ state0, const float* __restrict__ phiB, const float* __restrict__ zb, float* __restrict__ tb, long nblocks, int M) {
-    __shared__ float T[kIirMaxM];
-    const int        i = threadIdx.x;
-    if (i < M) T[i] = state0[i];
+// pass B: T_0 = carried state; T_{b+1} = Phi_B T_b + Zb[b].  Writes T_b (state at the START of block b).  The same affine scan one
+// level up: every lane chains kIirBK consecutive blocks locally, the workgroup scans the lanes (Kogge-Stone with Phi_B^(kIirBK 2^k)),
+// and only groups of kIirBB * kIirBK blocks (16 M samples) are chained sequentially.
+template <int MP>
+__global__ __launch_bounds__(kIirBB) void iir_pass_b(const float* __restrict__ state0, const float* __restrict__ phiB /*[kIirBShift + kIirBRounds][MP][MP]: Phi_B^(2^k)*/,
+                                                      const float* __restrict__ zb, float* __restrict__ tb, long nblocks) {
+    __shared__ float sv[MP * kIirBB];
+    __shared__ float T[MP];
+    __shared__ __attribute__((aligned(16))) float pl[(kIirBShift + kIirBRounds) * MP * MP];
+    const int        c = threadIdx.x;
+    iir_load_phi<MP, kIirBShift + kIirBRounds>(pl, phiB);
+    if (c < MP) T[c] = state0[c];
     __syncthreads();
-    for (long b = 0; b < nblocks; ++b) {
-        float nv = 0.f;
-        if (i < M) {
-            tb[b * kIirMaxM + i] = T[i];
-            nv = zb[b * kIirMaxM + i];
-            for (int j = 0; j < M; ++j) nv = fmaf(phiB[i * M + j], T[j], nv);
+    const float* PB = pl;                          // Phi_B (transposed)
+    const float* PK = pl + kIirBShift * MP * MP;   // Phi_B^kIirBK and its 2^k powers
+    for (long g0 = 0; g0 < nblocks; g0 += (long)kIirBB * kIirBK) {
+        const long b0 = g0 + (long)c * kIirBK;
+        float      e[MP];
+        // zero-start end state of the lane's kIirBK blocks; lane 0 starts from the carried state instead
+#pragma unroll
+        for (int i = 0; i < MP; ++i) e[i] = c == 0 ? T[i] : 0.f;
+#pragma unroll 1
+        for (int q = 0; q < kIirBK; ++q) {
+            float nv[MP];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) nv[i] = b0 + q < nblocks ? zb[(b0 + q) * MP + i] : 0.f;
+#pragma unroll
+            for (int j = 0; j < MP; ++j)
+#pragma unroll
+                for (int i = 0; i < MP; ++i) nv[i] = fmaf(PB[j * MP + i], e[j], nv[i]);
+#pragma unroll
+            for (int i = 0; i < MP; ++i) e[i] = nv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < MP; ++i) sv[i * kIirBB + c] = e[i];
+        __syncthreads();
+        iir_block_scan<MP, kIirBB, kIirBRounds>(sv, PK); // sv[.][c] = state at the END of the lane's last block
+        // replay the lane's blocks from its true start state
+#pragma unroll
+        for (int i = 0; i < MP; ++i) e[i] = c == 0 ? T[i] : sv[i * kIirBB + c - 1];
+#pragma unroll 1
+        for (int q = 0; q < kIirBK; ++q) {
+            if (b0 + q < nblocks) {
+#pragma unroll
+                for (int i = 0; i < MP; ++i) tb[(b0 + q) * MP + i] = e[i];
+            }
+            float nv[MP];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) nv[i] = b0 + q < nblocks ? zb[(b0 + q) * MP + i] : 0.f; // re-read (L2 hit) rather than held in registers
+#pragma unroll
+            for (int j = 0; j < MP; ++j)
+#pragma unroll
+                for (int i = 0; i < MP; ++i) nv[i] = fmaf(PB[j * MP + i], e[j], nv[i]);
+#pragma unroll
+            for (int i = 0; i < MP; ++i) e[i] = nv[i];
         }
         __syncthreads();
-        if (i < M) T[i] = nv;
+        if (c < MP) T[c] = sv[c * kIirBB + kIirBB - 1];
         __syncthreads();
     }
 }
 
 // pass Y: true start state per chunk, re-run, coalesced store.  The lane owning the last sample stores the carried state.
-template <int ORD>
-__global__ __launch_bounds__(kIirBS) void iir_pass_y(const float* __restrict__ x, float* __restrict__ y, long n, IirCoef<ORD> coef, const float* __restrict__ phi,
+template <int ORD, int NSEC>
+__global__ __launch_bounds__(kIirBS) void iir_pass_y(const float* __restrict__ x, float* __restrict__ y, long n, IirCoef<ORD, NSEC> coef, const float* __restrict__ phi,
                                                       const float* __restrict__ zc, const float* __restrict__ tb, float* __restrict__ state_out) {
+    constexpr int    MP = ORD * NSEC;
     __shared__ float tile[kIirBS * (kIirL + 1)];
-    __shared__ float sv[kIirBS * kIirMaxM];
-    const int  M     = coef.nsec * ORD;
-    const int  c     = threadIdx.x;
-    const long base  = (long)blockIdx.x * kIirBS * kIirL;
-    const long chunk = (long)blockIdx.x * kIirBS + c;
-    iir_stage_tile<ORD>(tile, x, base, n);
+    __shared__ float sv[MP * kIirBS];
+    __shared__ __attribute__((aligned(16))) float pl[kIirRounds * MP * MP];
+    const int        c     = threadIdx.x;
+    const long       base  = (long)blockIdx.x * kIirBS * kIirL;
+    const long       chunk = (long)blockIdx.x * kIirBS + c;
+    iir_load_phi<MP, kIirRounds>(pl, phi);
+    iir_stage_tile(tile, x, base, n);
     // seed: I_0 = Phi_L * T_b + z_0, I_c = z_c
-    const float* Tb = tb + (long)blockIdx.x * kIirMaxM;
+    const float* Tb = tb + (long)blockIdx.x * MP;
 #pragma unroll
-    for (int i = 0; i < kIirMaxM; ++i) {
-        if (i < M) {
-            float v = zc[chunk * kIirMaxM + i];
-            if (c == 0)
-                for (int j = 0; j < M; ++j) v = fmaf(phi[i * M + j], Tb[j], v); // round-0 matrix == Phi_L
-            sv[c * kIirMaxM + i] = v;
+    for (int i = 0; i < MP; ++i) {
+        float v = zc[chunk * MP + i];
+        if (c == 0) {
+#pragma unroll
+            for (int j = 0; j < MP; ++j) v = fmaf(phi[i * MP + j], Tb[j], v); // round-0 matrix == Phi_L
         }
+        sv[i * kIirBS + c] = v;
     }
     __syncthreads();
-    iir_block_scan(sv, phi, M);
-    float st[kIirMaxSec][ORD];
+    iir_block_scan<MP, kIirBS, kIirRounds>(sv, pl);
+    float st[NSEC][ORD];
 #pragma unroll
-    for (int s = 0; s < kIirMaxSec; ++s)
+    for (int s = 0; s < NSEC; ++s)
 #pragma unroll
-        for (int j = 0; j < ORD; ++j) st[s][j] = (s < coef.nsec) ? (c == 0 ? Tb[s * ORD + j] : sv[(c - 1) * kIirMaxM + s * ORD + j]) : 0.f;
+        for (int j = 0; j < ORD; ++j) st[s][j] = c == 0 ? Tb[s * ORD + j] : sv[(s * ORD + j) * kIirBS + c - 1];
     float*     row  = tile + c * (kIirL + 1);
     const long cbeg = base + (long)c * kIirL;
     const int  len  = (int)(n - cbeg < kIirL ? (n - cbeg < 0 ? 0 : n - cbeg) : kIirL);
-    for (int i = 0; i < len; ++i) row[i] = iir_step<ORD>(coef, st, row[i]);
+    if (len == kIirL) {
+#pragma unroll 4
+        for (int i = 0; i < kIirL; ++i) row[i] = iir_step<ORD, NSEC>(coef, st, row[i]);
+    } else {
+        for (int i = 0; i < len; ++i) row[i] = iir_step<ORD, NSEC>(coef, st, row[i]);
+    }
     if (len > 0 && cbeg + len == n) { // this lane consumed the last sample of the span
 #pragma unroll
-        for (int s = 0; s < kIirMaxSec; ++s)
+        for (int s = 0; s < NSEC; ++s)
 #pragma unroll
-            for (int j = 0; j < ORD; ++j)
-                if (s < coef.nsec) state_out[s * ORD + j] = st[s][j];
+            for (int j = 0; j < ORD; ++j) state_out[s * ORD + j] = st[s][j];
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < kIirBS * kIirL; s += kIirBS) {
-        const long i = base + s;
-        if (i < n) y[i] = tile[(s / kIirL) * (kIirL + 1) + (s % kIirL)];
-    }
+    iir_unstage_tile(tile, y, base, n);
 }
 
 } // namespace gr4
@@ -190,9 +282,9 @@ using namespace gr4;
 
 struct gr4hip_iir {
     int                 form = GR4HIP_DF_II;
-    int                 nsec = 0, ord = 2, M = 0;
+    int                 nsec = 0, ord = 2, M = 0; // nsec / M include the identity padding sections
     std::vector<double> b, a; // [nsec][ord+1]
-    DeviceBuffer        d_phi;   // [rounds][M][M] then Phi_B [M][M]
+    DeviceBuffer        d_phi;   // [kIirRounds + kIirBShift + kIirBRounds][M][M]: Phi_{L 2^k}
     DeviceBuffer        d_state[2];
     int                 cur = 0;
     DeviceBuffer        d_zc, d_zb, d_tb;
@@ -212,43 +304,47 @@ static void host_step(const gr4hip_iir* f, std::vector<double>& st, double x) {
     }
 }
 
-static void host_phi(const gr4hip_iir* f, long steps, float* out /*[M][M]*/) {
-    const int M = f->M;
+// Phi_steps in double: column j = state after `steps` zero-input steps from the unit state e_j
+static std::vector<double> host_phi(const gr4hip_iir* f, long steps) {
+    const int           M = f->M;
+    std::vector<double> out((size_t)M * M);
     for (int j = 0; j < M; ++j) {
         std::vector<double> st(M, 0.0);
         st[j] = 1.0;
         for (long t = 0; t < steps; ++t) host_step(f, st, 0.0);
-        for (int i = 0; i < M; ++i) out[i * M + j] = (float)st[i];
+        for (int i = 0; i < M; ++i) out[i * M + j] = st[i];
     }
+    return out;
+}
+static std::vector<double> mat_square(const std::vector<double>& A, int M) {
+    std::vector<double> C((size_t)M * M, 0.0);
+    for (int i = 0; i < M; ++i)
+        for (int k = 0; k < M; ++k)
+            for (int j = 0; j < M; ++j) C[i * M + j] += A[i * M + k] * A[k * M + j];
+    return C;
 }
 
-template <int ORD>
-static IirCoef<ORD> make_coef(const gr4hip_iir* f) {
-    IirCoef<ORD> c{};
-    c.nsec = f->nsec;
-    for (int s = 0; s < f->nsec; ++s)
-        for (int j = 0; j <= ORD; ++j) {
-            c.b[s][j] = (float)f->b[s * (ORD + 1) + j];
-            c.a[s][j] = (float)f->a[s * (ORD + 1) + j];
-        }
-    return c;
-}
-
-template <int ORD>
+template <int ORD, int NSEC>
 static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t st) {
-    const long nblocks = ceil_div(n, (long)kIirBS * kIirL);
-    int        rc      = f->d_zc.ensure((size_t)nblocks * kIirBS * kIirMaxM * sizeof(float));
-    if (!rc) rc = f->d_zb.ensure((size_t)nblocks * kIirMaxM * sizeof(float));
-    if (!rc) rc = f->d_tb.ensure((size_t)nblocks * kIirMaxM * sizeof(float));
+    constexpr int MP      = ORD * NSEC;
+    const long    nblocks = ceil_div(n, (long)kIirBS * kIirL);
+    int           rc      = f->d_zc.ensure((size_t)nblocks * kIirBS * MP * sizeof(float));
+    if (!rc) rc = f->d_zb.ensure((size_t)nblocks * MP * sizeof(float));
+    if (!rc) rc = f->d_tb.ensure((size_t)nblocks * MP * sizeof(float));
     if (rc) return rc;
-    const IirCoef<ORD> coef = make_coef<ORD>(f);
-    const float*       phi  = static_cast<const float*>(f->d_phi.ptr);
-    const float*       phiB = phi + (size_t)kIirRounds * f->M * f->M;
-    hipLaunchKernelGGL(iir_pass_z<ORD>, dim3((unsigned)nblocks), dim3(kIirBS), 0, st, x, n, coef, phi, (float*)f->d_zc.ptr, (float*)f->d_zb.ptr);
+    IirCoef<ORD, NSEC> coef{};
+    for (int s = 0; s < NSEC; ++s)
+        for (int j = 0; j <= ORD; ++j) {
+            coef.b[s][j] = (float)f->b[s * (ORD + 1) + j];
+            coef.a[s][j] = (float)f->a[s * (ORD + 1) + j];
+        }
+    const float* phi  = static_cast<const float*>(f->d_phi.ptr);
+    const float* phiB = phi + (size_t)kIirRounds * MP * MP; // Phi_B^(2^k), k = 0 .. kIirBRounds-1
+    hipLaunchKernelGGL((iir_pass_z<ORD, NSEC>), dim3((unsigned)nblocks), dim3(kIirBS), 0, st, x, n, coef, phi, (float*)f->d_zc.ptr, (float*)f->d_zb.ptr);
     GR4_LAUNCH_CHECK();
-    hipLaunchKernelGGL(iir_pass_b, dim3(1), dim3(64), 0, st, (const float*)f->d_state[f->cur].ptr, phiB, (const float*)f->d_zb.ptr, (float*)f->d_tb.ptr, nblocks, f->M);
+    hipLaunchKernelGGL(iir_pass_b<MP>, dim3(1), dim3(kIirBB), 0, st, (const float*)f->d_state[f->cur].ptr, phiB, (const float*)f->d_zb.ptr, (float*)f->d_tb.ptr, nblocks);
     GR4_LAUNCH_CHECK();
-    hipLaunchKernelGGL(iir_pass_y<ORD>, dim3((unsigned)nblocks), dim3(kIirBS), 0, st, x, y, n, coef, phi, (const float*)f->d_zc.ptr, (const float*)f->d_tb.ptr,
+    hipLaunchKernelGGL((iir_pass_y<ORD, NSEC>), dim3((unsigned)nblocks), dim3(kIirBS), 0, st, x, y, n, coef, phi, (const float*)f->d_zc.ptr, (const float*)f->d_tb.ptr,
                        (float*)f->d_state[f->cur ^ 1].ptr);
     GR4_LAUNCH_CHECK();
     f->cur ^= 1;
@@ -263,27 +359,34 @@ int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const floa
     GR4_REQUIRE(nsections >= 1 && h_b && h_a && nb >= 1 && na >= 1, "iir: need >= 1 section and non-empty b, a");
     const size_t order = std::max(nb, na) - 1;
     const int    ord   = order <= 2 ? 2 : 4;
-    if (order > 4 || nsections > (size_t)kIirMaxSec || nsections * ord > (size_t)kIirMaxM) {
+    if (order > 4 || nsections * ord > (size_t)kIirMaxM) {
         set_error("iir: %zu sections of order %zu exceed the device path (order <= 4, sections*order <= %d)", nsections, order, kIirMaxM);
         return GR4HIP_UNSUPPORTED;
     }
     auto* f = new (std::nothrow) gr4hip_iir();
     GR4_REQUIRE(f, "out of host memory");
     f->form = form;
-    f->nsec = (int)nsections;
     f->ord  = ord;
-    f->M    = f->nsec * ord;
+    const int mp = (int)nsections * ord <= 4 ? 4 : (int)nsections * ord <= 8 ? 8 : 16; // instantiated state counts
+    f->nsec = mp / ord;
+    f->M    = mp;
     f->b.assign((size_t)f->nsec * (ord + 1), 0.0);
     f->a.assign((size_t)f->nsec * (ord + 1), 0.0);
-    for (int s = 0; s < f->nsec; ++s) {
+    for (int s = (int)nsections; s < f->nsec; ++s) f->b[s * (ord + 1)] = 1.0, f->a[s * (ord + 1)] = 1.0; // identity padding sections
+    for (int s = 0; s < (int)nsections; ++s) {
         for (size_t j = 0; j < nb; ++j) f->b[s * (ord + 1) + j] = h_b[s * nb + j];
         for (size_t j = 0; j < na; ++j) f->a[s * (ord + 1) + j] = h_a[s * na + j];
         f->a[s * (ord + 1)] = 1.0; // a[0] is assumed 1 (time_domain_filter.hpp:95,102)
     }
     const size_t       mm = (size_t)f->M * f->M;
-    std::vector<float> phi((kIirRounds + 1) * mm);
-    for (int k = 0; k < kIirRounds; ++k) host_phi(f, (long)kIirL << k, phi.data() + k * mm);
-    host_phi(f, (long)kIirL * kIirBS, phi.data() + kIirRounds * mm);
+    // Phi_{L 2^k}: k < kIirRounds are the in-block rounds, k = kIirRounds is Phi_B (B = L * kIirBS samples), the following ones its
+    // powers for the block-level scan; Phi_L by stepping the recurrence in double, the rest by repeated squaring
+    std::vector<float>  phi((kIirRounds + kIirBShift + kIirBRounds) * mm);
+    std::vector<double> Pk = host_phi(f, kIirL);
+    for (int k = 0; k < kIirRounds + kIirBShift + kIirBRounds; ++k) {
+        for (size_t i = 0; i < mm; ++i) phi[k * mm + i] = (float)Pk[i];
+        Pk = mat_square(Pk, f->M);
+    }
     int rc = f->d_phi.ensure(phi.size() * sizeof(float));
     if (!rc) { hipError_t e = hipMemcpy(f->d_phi.ptr, phi.data(), phi.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     for (int k = 0; k < 2 && !rc; ++k) rc = f->d_state[k].ensure(kIirMaxM * sizeof(float));
@@ -305,7 +408,10 @@ int gr4hip_iir_process(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_ou
     GR4_REQUIRE(f, "iir_process: null handle");
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "iir_process: null device pointer");
-    return f->ord == 2 ? iir_run<2>(f, d_in, d_out, (long)n, as_stream(stream)) : iir_run<4>(f, d_in, d_out, (long)n, as_stream(stream));
+    hipStream_t st = as_stream(stream);
+    const long  ln = (long)n;
+    if (f->ord == 2) return f->nsec == 2 ? iir_run<2, 2>(f, d_in, d_out, ln, st) : f->nsec == 4 ? iir_run<2, 4>(f, d_in, d_out, ln, st) : iir_run<2, 8>(f, d_in, d_out, ln, st);
+    return f->nsec == 1 ? iir_run<4, 1>(f, d_in, d_out, ln, st) : f->nsec == 2 ? iir_run<4, 2>(f, d_in, d_out, ln, st) : iir_run<4, 4>(f, d_in, d_out, ln, st);
 }
 
 int gr4hip_iir_destroy(gr4hip_iir_t* f) { delete f; return GR4HIP_OK; }

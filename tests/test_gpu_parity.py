@@ -208,6 +208,20 @@ def test_iir_cascade_parity(G, order, design):
     assert _rel(y, truth) <= 2 * _rel(cpu32, truth) + 2e-6
 
 
+def test_iir_long_stream_crosses_block_scan_groups(G):
+    """2^24 + 2^22 + 5 samples: more than one 2048-block group of the block-level scan, odd tail; against the float64 oracle"""
+    import gnuradio4_amd.blocks as B
+    b, a = B.design_iir(0, 8, 0.05, float("nan"), 1.0, 0)  # Butterworth order 8 -> 4 biquads (BASELINE configs[2])
+    n = (1 << 24) + (1 << 22) + 5
+    x = O.signal_f32(7, n)
+    truth = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(b, a)]), x, O.DF_II, f64=True)
+    y = G.iir_filter(b, a).process_bulk(dev(x)).cpu().numpy()
+    assert _rel(y, truth) <= TOL
+    f2 = G.iir_filter(b, a)  # the same stream in two calls: state carried across
+    y2 = np.concatenate([f2.process_bulk(dev(x[:n // 3])).cpu().numpy(), f2.process_bulk(dev(x[n // 3:])).cpu().numpy()])
+    assert _rel(y2, truth) <= TOL
+
+
 def test_basic_filter_bands(G, golden):
     g = golden["basic_filter_lowpass"]
     fs, n = g["sample_rate"], g["num_samples"]
