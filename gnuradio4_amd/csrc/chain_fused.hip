@@ -41,6 +41,7 @@ struct ChainFdArgs {
     const float2* twB;    // [16][32]  W_512^{r k}
     const float2* twC;    // [16][512] W_8192^{r i3}
     const float*  taps;   // 256 (zero padded)
+    const float*  win;    // WIN kernels: window[n] / N (8192 floats), else unused
     float*        out;    // frames * 8192 mag2
     long          n_frames;
     unsigned long long* dbg; // GR4_FD_TIMING only
@@ -54,6 +55,14 @@ __device__ __forceinline__ int addrA(int row, int col) { return row * kRowA + co
 __device__ __forceinline__ void passB_compute_store(float2* S, float2 (&w)[16], const float2 (&tw)[16], int c, int k) {
 #pragma unroll
     for (int r = 1; r < 16; ++r) w[r] = cmul(w[r], tw[r]);
+    fft16<1>(w);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) S[c * kRowB + 32 * q + k] = w[perm16(q)];
+}
+// same, twiddles from an LDS table [16][32] (the windowed kernel has no registers left for a resident set)
+__device__ __forceinline__ void passB_table_store(float2* S, float2 (&w)[16], const float2* twl, int c, int k) {
+#pragma unroll
+    for (int r = 1; r < 16; ++r) w[r] = cmul(w[r], twl[r * 32 + k]);
     fft16<1>(w);
 #pragma unroll
     for (int q = 0; q < 16; ++q) S[c * kRowB + 32 * q + k] = w[perm16(q)];
@@ -158,11 +167,33 @@ __device__ __forceinline__ void dma_tail(const float2* __restrict__ src, float2*
 #define GR4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define GR4_FULL_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// pass A on an image already in LDS, in place (the second and third transforms of the windowed kernel)
+__device__ __forceinline__ void passA_inplace(float2* S, int par, int n0, float sgn) {
+    float2 v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = S[addrA(2 * m + par, n0)];
+    fft16<1>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        float2       u  = v[perm16(k1)];
+        const float2 uw = k1 == 0 ? u : cmul(u, w32(k1));
+        u.x = par ? uw.x : u.x;
+        u.y = par ? uw.y : u.y;
+        const float2 q = make_float2(lane_xor1(u.x), lane_xor1(u.y));
+        S[addrA(k1 + 16 * par, n0)] = make_float2(fmaf(sgn, u.x, q.x), fmaf(sgn, u.y, q.y));
+    }
+}
+
 // One persistent workgroup of 512 lanes (8 waves, 2 per SIMD) per CU; frame f = blockIdx.x, blockIdx.x + gridDim.x, ...
 // Every lane owns 16 points.  Two frame buffers alternate: while frame f is transformed in one, the LDS-DMA of frame
 // f + gridDim.x fills the other during the WHOLE frame time (smooth HBM demand instead of chip-wide bursts).  Nothing in the
 // loop issues an ordinary vector load behind the DMA (loads return in order, so waiting for one would wait for the DMA):
 // H[k], the twiddle bases and the FIR taps live in registers / SGPRs for the lifetime of the kernel.
+//
+// WIN = true (any window other than None / Rectangular; the reference FFT block's default is Hann): the window multiplies the FILTERED
+// frame, so y_f has to exist in the time domain: X = FFT(x_f), y_f = IFFT(H X) + e (inverse through conjugation, e added where it
+// lives), then FFT(w y_f): three full transforms instead of 1.65, still without touching HBM in between.
+template <bool WIN>
 __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
@@ -192,8 +223,18 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     float2 twBr[16], twCr[16]; // exact table values, resident for the kernel lifetime (no per-frame twiddle generation)
 #pragma unroll
     for (int r = 1; r < 16; ++r) {
-        twBr[r] = a.twB[r * 32 + kb0];
+        twBr[r] = WIN ? make_float2(0.f, 0.f) : a.twB[r * 32 + kb0]; // WIN: pass-B twiddles come from the LDS table twBl instead
         twCr[r] = a.twC[r * 512 + t0];
+    }
+    // WIN: the correction FIR splits K over 4 wave pairs (one of each pair takes the real tile, the other the imaginary one), so only
+    // half of P is used; the other half holds the pass-B twiddle table
+    float2* twBl = reinterpret_cast<float2*>(P + 4 * 2 * 256);
+    if constexpr (WIN) twBl[t0] = a.twB[t0]; // [16][32] = 512 entries
+
+    float wr[16]; // WIN: window[t + 512 q] / N
+    if constexpr (WIN) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wr[q] = a.win[t0 + 512 * q];
     }
 
     // |Y|^2 of the previous frame waits in registers and leaves in four groups of four stores spread over this frame's phases;
@@ -231,7 +272,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         const rsrc_t rq = make_rsrc(a.out + (fprev < 0 ? 0 : fprev) * kN, fprev < 0 ? 0u : (unsigned)(kN * sizeof(float))); // first iteration: nothing pending, stores fall out of range
 #define GR4_DRAIN(g)                                                                                       \
     do {                                                                                                   \
-        _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); \
+        if constexpr (!WIN) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
         dma_frame<kDmaAt[g], kDmaAt[(g) + 1]>(a.x + fn * kN, Sn, wave, lane);                              \
     } while (0)
         dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
@@ -284,16 +325,20 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         {
             using f32x4 = __attribute__((ext_vector_type(4))) float;
             const int    col = lane & 15, kqm = lane >> 4;
-            const float* pr  = Dre + 17 * col + kqm + 34 * wave;
-            const float* pi  = Dim + 17 * col + kqm + 34 * wave;
-            const float* pa  = hl + 256 + col - kqm - 32 * wave; // A[j = col][u] = b[256 + j - u], u = 32 wave + 4 i + kqm
-            float        av[8], br[8], bi[8];
+            // !WIN: wave w takes K range u in [32 w, 32 w + 32) of both tiles (8 K-steps x {re, im});
+            //  WIN: wave w takes K range [64 (w & 3), +64) of ONE tile (w >> 2: re / im), 16 K-steps -- 16 MFMAs per wave either way
+            constexpr int KSW  = WIN ? 16 : 8;
+            const int     kw   = WIN ? (wave & 3) : wave;
+            const float*  pr   = (WIN && (wave >> 2) ? Dim : Dre) + 17 * col + kqm + (4 * KSW * 17 / 16) * kw;
+            const float*  pi   = Dim + 17 * col + kqm + 34 * wave;
+            const float*  pa   = hl + 256 + col - kqm - 4 * KSW * kw; // A[j = col][u] = b[256 + j - u], u = 4 KSW kw + 4 i + kqm
+            float         av[KSW], br[KSW], bi[WIN ? 1 : 8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int off = 4 * i + (i >> 2); // padded offset of u = 32 wave + 4 i within the window
+            for (int i = 0; i < KSW; ++i) {
+                const int off = 4 * i + (i >> 2); // padded offset of u = 4 KSW kw + 4 i within the window
                 av[i] = pa[-4 * i];
                 br[i] = pr[off];
-                bi[i] = pi[off];
+                if constexpr (!WIN) bi[i] = pi[off];
             }
             f32x4 cr = {0.f, 0.f, 0.f, 0.f}, ci = {0.f, 0.f, 0.f, 0.f};
             // One MFMA per ~12-16 butterfly instructions, fenced so that hipcc keeps the order: the wave issues in order, the MFMA
@@ -302,7 +347,8 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #define GR4_MF(i)                                                                           \
     do {                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                  \
-        if ((i) & 1) ci = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i) >> 1], bi[(i) >> 1], ci, 0, 0, 0); \
+        if constexpr (WIN) cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i)], br[(i)], cr, 0, 0, 0);  \
+        else if ((i) & 1) ci = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i) >> 1], bi[(i) >> 1], ci, 0, 0, 0); \
         else cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i) >> 1], br[(i) >> 1], cr, 0, 0, 0);        \
         __builtin_amdgcn_sched_barrier(0);                                                  \
     } while (0)
@@ -311,7 +357,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             for (int g = 0; g < 5; ++g) {
                 GR4_MF(g);
 #pragma unroll
-                for (int r = 3 * g + 1; r < 3 * g + 4; ++r) w[r] = cmul(w[r], twBr[r]);
+                for (int r = 3 * g + 1; r < 3 * g + 4; ++r) w[r] = cmul(w[r], WIN ? twBl[r * 32 + kb] : twBr[r]);
             }
 #pragma unroll
             for (int n2 = 0; n2 < 4; ++n2) {
@@ -332,9 +378,13 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             for (int q = 0; q < 16; ++q) S[cb * kRowB + 32 * q + kb] = w[perm16(q)];
 #undef GR4_MF
             // D[row = 4 kqm + r][col] = partial e[16 col + 4 kqm + r]
-            float* dst = P + wave * 512 + 16 * col + 4 * kqm;
-            *reinterpret_cast<float4*>(dst)       = make_float4(cr[0], cr[1], cr[2], cr[3]);
-            *reinterpret_cast<float4*>(dst + 256) = make_float4(ci[0], ci[1], ci[2], ci[3]);
+            if constexpr (WIN) { // P[K quarter][re, im][256]
+                *reinterpret_cast<float4*>(P + (wave & 3) * 512 + (wave >> 2) * 256 + 16 * col + 4 * kqm) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+            } else { // P[wave][re, im][256]
+                float* dst = P + wave * 512 + 16 * col + 4 * kqm;
+                *reinterpret_cast<float4*>(dst)       = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                *reinterpret_cast<float4*>(dst + 256) = make_float4(ci[0], ci[1], ci[2], ci[3]);
+            }
         }
         GR4_STAMP(6);
         GR4_LDS_BARRIER(); // #3
@@ -342,8 +392,10 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_DRAIN(5);
         { // e = sum of the eight partial tiles (fixed order); lane t -> component t >> 8 of e[t & 255]
             const float* pp = P + t;
-            const float  s01 = pp[0] + pp[512], s23 = pp[1024] + pp[1536], s45 = pp[2048] + pp[2560], s67 = pp[3072] + pp[3584];
-            reinterpret_cast<float*>(el)[2 * (t & 255) + (t >> 8)] = (s01 + s23) + (s45 + s67);
+            const float  s01 = pp[0] + pp[512], s23 = pp[1024] + pp[1536];
+            float        es  = s01 + s23;
+            if constexpr (!WIN) es += (pp[2048] + pp[2560]) + (pp[3072] + pp[3584]);
+            reinterpret_cast<float*>(el)[2 * (t & 255) + (t >> 8)] = es;
         }
         // ------------------------------------------------------------------ X pass C (p = 512, radix 16), then H[k] X[k]
         float2 X[16];
@@ -356,27 +408,81 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(9);
         GR4_DRAIN(7);
 
-        // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
+        if constexpr (!WIN) {
+            // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = el[cb + 16 * r];
+            passB_compute_store(S, w, twBr, cb, kb);
+            GR4_STAMP(10);
+            GR4_LDS_BARRIER(); // #5
+            GR4_STAMP(11);
+            passC(S, w, twCr, t);
+            GR4_PIN(w);
+            GR4_STAMP(12);
+            // ------------------------------------------------------------------ FFT(y_f)[k] = H[k] X[k] + E[k];  mag2 = |.|^2  (k = t + 512 q)
+    #pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float2 Y = cadd(X[perm16(q)], w[perm16(q)]);
+                pend[q] = fmaf(Y.x, Y.x, Y.y * Y.y); // out[t + 512 q], stored during the next frame
+            }
+        } else {
+            // ------------------------------------------------------------------ y_f = IFFT(H X) + e through conj(FFT(conj(.))) / N
+            // conj(H X) in natural bin order k = t + 512 q IS the pass-A image layout (row k >> 8, column k & 255)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) w[r] = el[cb + 16 * r];
-        passB_compute_store(S, w, twBr, cb, kb);
-        GR4_STAMP(10);
-        GR4_LDS_BARRIER(); // #5
-        GR4_STAMP(11);
-        passC(S, w, twCr, t);
-        GR4_PIN(w);
-        GR4_STAMP(12);
-        // ------------------------------------------------------------------ FFT(y_f)[k] = H[k] X[k] + E[k];  mag2 = |.|^2  (k = t + 512 q)
+            for (int q = 0; q < 16; ++q) S[addrA((t >> 8) + 2 * q, t & 255)] = make_float2(X[perm16(q)].x, -X[perm16(q)].y);
+            GR4_LDS_BARRIER();
+            GR4_PHASE_FENCE();
+            passA_inplace(S, par, n0, sgn);
+            GR4_LDS_BARRIER();
+            GR4_PHASE_FENCE();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float2 Y = cadd(X[perm16(q)], w[perm16(q)]);
-            pend[q] = fmaf(Y.x, Y.x, Y.y * Y.y); // out[t + 512 q], stored during the next frame
+            for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
+            GR4_LDS_BARRIER();
+            GR4_PHASE_FENCE();
+            passB_table_store(S, w, twBl, cb, kb);
+            GR4_LDS_BARRIER();
+            GR4_PHASE_FENCE();
+            passC(S, w, twCr, t); // w[perm16(q)] = N conj(circular y[n]), n = t + 512 q
+            // ------------------------------------------------------------------ window (w[n] / N) (conj(.) + N e[n]), back to the image layout
+            float2 yw[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float2 yv = make_float2(w[perm16(q)].x, -w[perm16(q)].y);
+                if (q == 0 && t < 256) {
+                    const float2 ev = el[t];
+                    yv.x = fmaf((float)kN, ev.x, yv.x);
+                    yv.y = fmaf((float)kN, ev.y, yv.y);
+                }
+                yw[q] = make_float2(yv.x * wr[q], yv.y * wr[q]);
+            }
+            GR4_LDS_BARRIER(); // every lane has consumed S
+            GR4_PHASE_FENCE();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) S[addrA((t >> 8) + 2 * q, t & 255)] = yw[q];
+            GR4_LDS_BARRIER();
+            GR4_PHASE_FENCE();
+            // ------------------------------------------------------------------ FFT(w y_f), |.|^2
+            passA_inplace(S, par, n0, sgn);
+            GR4_LDS_BARRIER();
+            GR4_PHASE_FENCE();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
+            GR4_LDS_BARRIER();
+            GR4_PHASE_FENCE();
+            passB_table_store(S, w, twBl, cb, kb);
+            GR4_LDS_BARRIER();
+            GR4_PHASE_FENCE();
+            passC(S, w, twCr, t);
+            // (no deferred stores here: the 16 registers they would wait in are what this variant does not have)
+            const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) buf_store_f(ro, fmaf(w[perm16(q)].x, w[perm16(q)].x, w[perm16(q)].y * w[perm16(q)].y), t * 4, q * 2048);
         }
         fprev = f;
         GR4_STAMP(13);
         GR4_STAMP(14);
     }
-    if (fprev >= 0) {
+    if (!WIN && fprev >= 0) {
         const rsrc_t rq = make_rsrc(a.out + fprev * kN, kN * sizeof(float));
 #pragma unroll
         for (int q = 0; q < 16; ++q) buf_store_f(rq, pend[q], t0 * 4, q * 2048);
@@ -391,12 +497,13 @@ static unsigned long long* g_dbg = nullptr;
 #endif
 struct ChainFused {
     size_t       ntaps = 0;
-    DeviceBuffer d_H, d_twB, d_twC, d_taps, d_hist;
+    DeviceBuffer d_H, d_twB, d_twC, d_taps, d_hist, d_win;
+    bool         windowed = false;
 };
 
 int chain_fused_supported(size_t ntaps, size_t fft_size, int window, int algo) {
     if (algo != GR4HIP_CHAIN_FUSED_FD) return 0;
-    return fft_size == (size_t)kN && ntaps >= 1 && ntaps <= 256 && (window == GR4HIP_WIN_NONE || window == GR4HIP_WIN_RECTANGULAR);
+    return fft_size == (size_t)kN && ntaps >= 1 && ntaps <= 256 && window >= GR4HIP_WIN_NONE && window <= GR4HIP_WIN_KAISER;
 }
 
 template <typename T>
@@ -441,6 +548,13 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
     if (!rc) rc = upload(c->d_twB, twB);
     if (!rc) rc = upload(c->d_twC, twC);
     if (!rc) rc = upload(c->d_taps, hp);
+    c->windowed = window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR;
+    if (!rc && c->windowed) {
+        std::vector<float> w(kN);
+        rc = make_window(window, w.data(), kN, 1.6f); // fft.hpp:141: create(_window, _windowType) -> default beta
+        for (float& v : w) v *= 1.0f / (float)kN;      // exact (power of two): the 1/N of the inverse transform
+        if (!rc) rc = upload(c->d_win, w);
+    }
     if (!rc) rc = c->d_hist.ensure(256 * sizeof(float2));
     if (!rc) rc = chain_fused_reset(c);
     if (rc) { delete c; return rc; }
@@ -461,6 +575,7 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
     a.twB      = static_cast<const float2*>(c->d_twB.ptr);
     a.twC      = static_cast<const float2*>(c->d_twC.ptr);
     a.taps     = static_cast<const float*>(c->d_taps.ptr);
+    a.win      = static_cast<const float*>(c->d_win.ptr);
     a.out      = d_mag2;
     a.n_frames = (long)n_frames;
     a.dbg      = nullptr;
@@ -471,13 +586,15 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
     const size_t lds = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(8 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
     static int   n_cu = 0;
     if (n_cu == 0) {
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         GR4_HIP_TRY(hipGetDevice(&dev));
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const unsigned grid = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu); // one resident workgroup per CU
-    hipLaunchKernelGGL(chain_fd_kernel, dim3(grid), dim3(kT), lds, st, a);
+    if (c->windowed) hipLaunchKernelGGL(chain_fd_kernel<true>, dim3(grid), dim3(kT), lds, st, a);
+    else hipLaunchKernelGGL(chain_fd_kernel<false>, dim3(grid), dim3(kT), lds, st, a);
     GR4_LAUNCH_CHECK();
     // carry the last 256 input samples for the next call's first frame (stream-ordered after the kernel's reads)
     GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));

@@ -341,6 +341,7 @@ def test_fft_linearity_and_roundtrip_properties(G):
 # ------------------------------------------------------------------ headline chain
 @pytest.mark.parametrize("algo", [1, 0])
 @pytest.mark.parametrize("N,ntaps,window", [(8192, 256, "None"), (8192, 256, "Hann"), (8192, 91, "Rectangular"), (8192, 1, "None"),
+                                            (8192, 200, "BlackmanHarris"), (8192, 256, "Kaiser"), (8192, 17, "FlatTop"),
                                             (1024, 64, "None"), (256, 33, "Hann")])
 def test_chain_parity(G, algo, N, ntaps, window):
     frames = 6
@@ -349,8 +350,8 @@ def test_chain_parity(G, algo, N, ntaps, window):
     wid = [w.lower() for w in O.WINDOWS].index(window.lower())
     truth, _ = O.chain(b, x, N, wid, truth=True)
     ch = G.Chain(b, N, window, algo)
-    if algo == 0 and N == 8192 and window in ("None", "Rectangular"):
-        assert ch.algo == G.capi.CHAIN_FUSED_FD  # the headline configuration must take the fused kernel
+    if algo == 0 and N == 8192:
+        assert ch.algo == G.capi.CHAIN_FUSED_FD  # the headline configuration (any window) must take the fused kernel
     half = (frames // 2) * N
     got = np.concatenate([ch.process_bulk(dev(x[:half])).cpu().numpy().ravel(), ch.process_bulk(dev(x[half:])).cpu().numpy().ravel()])
     assert _rel(got, truth) <= TOL
