@@ -193,8 +193,13 @@ __device__ __forceinline__ void passA_inplace(float2* S, int par, int n0, float 
 // WIN = true (any window other than None / Rectangular; the reference FFT block's default is Hann): the window multiplies the FILTERED
 // frame, so y_f has to exist in the time domain: X = FFT(x_f), y_f = IFFT(H X) + e (inverse through conjugation, e added where it
 // lives), then FFT(w y_f): three full transforms instead of 1.65, still without touching HBM in between.
-template <bool WIN>
+//
+// MODE 2 stops after the inverse transform and writes y_f itself: fir_filter<complex<float>> as a fast convolution (2 transforms
+// per 8192 samples instead of 1024 flop per sample), used by gr4hip_fir_process for long complex inputs.
+enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2 };
+template <int MODE>
 __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
+    constexpr bool WIN = MODE == kModeWinMag2;
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
     float2* B1 = smem + kSLen;                       // kSLen: (odd frames)
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         const rsrc_t rq = make_rsrc(a.out + (fprev < 0 ? 0 : fprev) * kN, fprev < 0 ? 0u : (unsigned)(kN * sizeof(float))); // first iteration: nothing pending, stores fall out of range
 #define GR4_DRAIN(g)                                                                                       \
     do {                                                                                                   \
-        if constexpr (!WIN) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
+        if constexpr (MODE == kModeMag2) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
         dma_frame<kDmaAt[g], kDmaAt[(g) + 1]>(a.x + fn * kN, Sn, wave, lane);                              \
     } while (0)
         dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(9);
         GR4_DRAIN(7);
 
-        if constexpr (!WIN) {
+        if constexpr (MODE == kModeMag2) {
             // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
     #pragma unroll
             for (int r = 0; r < 16; ++r) w[r] = el[cb + 16 * r];
@@ -439,50 +444,61 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
             GR4_LDS_BARRIER();
             GR4_PHASE_FENCE();
-            passB_table_store(S, w, twBl, cb, kb);
+            if constexpr (WIN) passB_table_store(S, w, twBl, cb, kb);
+            else passB_compute_store(S, w, twBr, cb, kb);
             GR4_LDS_BARRIER();
             GR4_PHASE_FENCE();
             passC(S, w, twCr, t); // w[perm16(q)] = N conj(circular y[n]), n = t + 512 q
-            // ------------------------------------------------------------------ window (w[n] / N) (conj(.) + N e[n]), back to the image layout
-            float2 yw[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float2 yv = make_float2(w[perm16(q)].x, -w[perm16(q)].y);
-                if (q == 0 && t < 256) {
-                    const float2 ev = el[t];
-                    yv.x = fmaf((float)kN, ev.x, yv.x);
-                    yv.y = fmaf((float)kN, ev.y, yv.y);
+            if constexpr (WIN) {
+                // ------------------------------------------------------------------ window (w[n] / N) (conj(.) + N e[n]), back to the image layout
+                float2 yw[16];
+    #pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float2 yv = make_float2(w[perm16(q)].x, -w[perm16(q)].y);
+                    if (q == 0 && t < 256) {
+                        const float2 ev = el[t];
+                        yv.x = fmaf((float)kN, ev.x, yv.x);
+                        yv.y = fmaf((float)kN, ev.y, yv.y);
+                    }
+                    yw[q] = make_float2(yv.x * wr[q], yv.y * wr[q]);
                 }
-                yw[q] = make_float2(yv.x * wr[q], yv.y * wr[q]);
+                GR4_LDS_BARRIER(); // every lane has consumed S
+                GR4_PHASE_FENCE();
+    #pragma unroll
+                for (int q = 0; q < 16; ++q) S[addrA((t >> 8) + 2 * q, t & 255)] = yw[q];
+                GR4_LDS_BARRIER();
+                GR4_PHASE_FENCE();
+                // ------------------------------------------------------------------ FFT(w y_f), |.|^2
+                passA_inplace(S, par, n0, sgn);
+                GR4_LDS_BARRIER();
+                GR4_PHASE_FENCE();
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
+                GR4_LDS_BARRIER();
+                GR4_PHASE_FENCE();
+                passB_table_store(S, w, twBl, cb, kb);
+                GR4_LDS_BARRIER();
+                GR4_PHASE_FENCE();
+                passC(S, w, twCr, t);
+                // (no deferred stores here: the 16 registers they would wait in are what this variant does not have)
+                const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
+    #pragma unroll
+                for (int q = 0; q < 16; ++q) buf_store_f(ro, fmaf(w[perm16(q)].x, w[perm16(q)].x, w[perm16(q)].y * w[perm16(q)].y), t * 4, q * 2048);
+            } else { // kModeFir: y_f[n] = conj(.) / N + e[n], complex, straight to HBM
+                const rsrc_t ro = make_rsrc(a.out + f * kN * 2, kN * sizeof(float2));
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float2 yv = make_float2(w[perm16(q)].x * (1.f / kN), -w[perm16(q)].y * (1.f / kN));
+                    if (q == 0 && t < 256) yv = cadd(yv, el[t]);
+                    buf_store_f2(ro, yv, t * 8, q * 4096);
+                }
             }
-            GR4_LDS_BARRIER(); // every lane has consumed S
-            GR4_PHASE_FENCE();
-#pragma unroll
-            for (int q = 0; q < 16; ++q) S[addrA((t >> 8) + 2 * q, t & 255)] = yw[q];
-            GR4_LDS_BARRIER();
-            GR4_PHASE_FENCE();
-            // ------------------------------------------------------------------ FFT(w y_f), |.|^2
-            passA_inplace(S, par, n0, sgn);
-            GR4_LDS_BARRIER();
-            GR4_PHASE_FENCE();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
-            GR4_LDS_BARRIER();
-            GR4_PHASE_FENCE();
-            passB_table_store(S, w, twBl, cb, kb);
-            GR4_LDS_BARRIER();
-            GR4_PHASE_FENCE();
-            passC(S, w, twCr, t);
-            // (no deferred stores here: the 16 registers they would wait in are what this variant does not have)
-            const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
-#pragma unroll
-            for (int q = 0; q < 16; ++q) buf_store_f(ro, fmaf(w[perm16(q)].x, w[perm16(q)].x, w[perm16(q)].y * w[perm16(q)].y), t * 4, q * 2048);
         }
         fprev = f;
         GR4_STAMP(13);
         GR4_STAMP(14);
     }
-    if (!WIN && fprev >= 0) {
+    if (MODE == kModeMag2 && fprev >= 0) {
         const rsrc_t rq = make_rsrc(a.out + fprev * kN, kN * sizeof(float));
 #pragma unroll
         for (int q = 0; q < 16; ++q) buf_store_f(rq, pend[q], t0 * 4, q * 2048);
@@ -567,16 +583,18 @@ int chain_fused_reset(ChainFused* c) {
     return GR4HIP_OK;
 }
 
-int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
+// hist256 == nullptr: the chain's own carried history (updated after the launch); otherwise 256 complex samples preceding d_in, and
+// the output is the filtered stream itself (complex) instead of |FFT|^2
+static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st) {
     ChainFdArgs a{};
     a.x        = reinterpret_cast<const float2*>(d_in);
-    a.hist     = static_cast<const float2*>(c->d_hist.ptr);
+    a.hist     = hist256 ? reinterpret_cast<const float2*>(hist256) : static_cast<const float2*>(c->d_hist.ptr);
     a.H        = static_cast<const float2*>(c->d_H.ptr);
     a.twB      = static_cast<const float2*>(c->d_twB.ptr);
     a.twC      = static_cast<const float2*>(c->d_twC.ptr);
     a.taps     = static_cast<const float*>(c->d_taps.ptr);
     a.win      = static_cast<const float*>(c->d_win.ptr);
-    a.out      = d_mag2;
+    a.out      = d_out;
     a.n_frames = (long)n_frames;
     a.dbg      = nullptr;
 #ifdef GR4_FD_TIMING
@@ -586,19 +604,27 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
     const size_t lds = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(8 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
     static int   n_cu = 0;
     if (n_cu == 0) {
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         GR4_HIP_TRY(hipGetDevice(&dev));
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const unsigned grid = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu); // one resident workgroup per CU
-    if (c->windowed) hipLaunchKernelGGL(chain_fd_kernel<true>, dim3(grid), dim3(kT), lds, st, a);
-    else hipLaunchKernelGGL(chain_fd_kernel<false>, dim3(grid), dim3(kT), lds, st, a);
+    if (hist256) hipLaunchKernelGGL(chain_fd_kernel<kModeFir>, dim3(grid), dim3(kT), lds, st, a);
+    else if (c->windowed) hipLaunchKernelGGL(chain_fd_kernel<kModeWinMag2>, dim3(grid), dim3(kT), lds, st, a);
+    else hipLaunchKernelGGL(chain_fd_kernel<kModeMag2>, dim3(grid), dim3(kT), lds, st, a);
     GR4_LAUNCH_CHECK();
     // carry the last 256 input samples for the next call's first frame (stream-ordered after the kernel's reads)
-    GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    if (!hist256) GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
     return GR4HIP_OK;
+}
+
+int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) { return chain_fused_run(c, d_in, nullptr, n_frames, d_mag2, st); }
+int chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_y, hipStream_t st) {
+    GR4_REQUIRE(!c->windowed && d_hist256, "chain_fused_fir: needs an un-windowed plan and a history");
+    return chain_fused_run(c, d_in, d_hist256, n_frames, d_y, st);
 }
 
 void chain_fused_destroy(ChainFused* c) { delete c; }

@@ -140,7 +140,23 @@ __global__ void decimate_kernel(const V* __restrict__ in, V* __restrict__ out, l
 
 } // namespace gr4
 
+namespace gr4 { // chain_fused.hip: fast-convolution path for long complex inputs
+struct ChainFused;
+int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
+int  chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_y, hipStream_t st);
+void chain_fused_destroy(ChainFused* c);
+
+// hist256[h] = sample at stream position -256 + h, from the hcap-sample history (zeros before it)
+__global__ void fir_hist256_kernel(const float2* __restrict__ hist, int hcap, float2* __restrict__ out) {
+    const int h = threadIdx.x;
+    out[h]      = h >= 256 - hcap ? hist[h - (256 - hcap)] : make_float2(0.f, 0.f);
+}
+} // namespace gr4
+
 using namespace gr4;
+
+constexpr size_t kFdFrame     = 8192;
+constexpr size_t kFdMinFrames = 64; // below this the direct-form kernel is as fast (the persistent FD grid wants >= 1 frame per CU)
 
 struct gr4hip_fir {
     int                dtype = GR4HIP_F32;
@@ -152,6 +168,8 @@ struct gr4hip_fir {
     DeviceBuffer       d_taps;     // [D][Qpad]
     DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
     int                cur = 0;
+    gr4::ChainFused*   fd  = nullptr; // complex, decim 1, ntaps <= 256: frequency-domain plan (created on first use)
+    DeviceBuffer       d_hist256;
 };
 
 static size_t bit_ceil_sz(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
@@ -182,12 +200,12 @@ static int fir_alloc_hist(gr4hip_fir* f) {
 }
 
 template <int S, int BS>
-static int fir_launch(const gr4hip_fir* f, const float* x, float* y, long n_in, long n_out, size_t lds, hipStream_t st) {
+static int fir_launch(const gr4hip_fir* f, const float* x, const float* hist, float* y, long n_in, long n_out, size_t lds, hipStream_t st) {
     auto kern = fir_poly_kernel<S, BS>;
     if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long TOs  = BS * kFirR / S;
     const long grid = ceil_div(n_out, TOs);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, st, x, (const float*)f->d_hist[f->cur].ptr, (const float*)f->d_taps.ptr, y, n_in, n_out,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, st, x, hist, (const float*)f->d_taps.ptr, y, n_in, n_out,
                        (int)f->hcap, (int)f->decim, f->G);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
@@ -219,6 +237,7 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     GR4_REQUIRE(f && h_taps && ntaps >= 1, "fir_set_taps: bad arguments");
     f->taps.assign(h_taps, h_taps + ntaps);
     f->ntaps = ntaps;
+    if (f->fd) { chain_fused_destroy(f->fd); f->fd = nullptr; } // rebuilt from the new taps on next use
     int rc   = fir_upload_taps(f);
     if (rc) return rc;
     if (ntaps > f->hcap) { // the reference replaces the HistoryBuffer (history is lost) only when it must grow
@@ -240,17 +259,38 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     if (n_out_p) *n_out_p = n_out;
     if (n_in == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "fir_process: null device pointer");
-    hipStream_t st = as_stream(stream);
-    const int   E  = 4 / f->S;
-    int         rc = GR4HIP_UNSUPPORTED;
+    hipStream_t  st   = as_stream(stream);
+    const float* x    = static_cast<const float*>(d_in);
+    float*       y    = static_cast<float*>(d_out);
+    const float* hist = (const float*)f->d_hist[f->cur].ptr;
+    size_t       done = 0; // samples already produced by the frequency-domain path
+    // complex<float>, no decimation, <= 256 taps, long input: whole 8192-sample frames go through the fused FFT -> xH -> inverse
+    // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
+    if (f->S == 2 && f->decim == 1 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame) {
+        int rc = GR4HIP_OK;
+        if (!f->fd) rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
+        if (!rc) rc = f->d_hist256.ensure(256 * sizeof(float2));
+        if (rc) return rc;
+        hipLaunchKernelGGL(fir_hist256_kernel, dim3(1), dim3(256), 0, st, (const float2*)hist, (int)f->hcap, (float2*)f->d_hist256.ptr);
+        GR4_LAUNCH_CHECK();
+        const size_t frames = n_in / kFdFrame;
+        rc = chain_fused_fir(f->fd, x, (const float*)f->d_hist256.ptr, frames, y, st);
+        if (rc) return rc;
+        done = frames * kFdFrame;
+        hist = x + (done - f->hcap) * 2; // the hcap samples in front of the remainder are part of the input itself
+    }
+    const int E  = 4 / f->S;
+    int       rc = done == n_in ? GR4HIP_OK : GR4HIP_UNSUPPORTED;
     for (int bs : {256, 128, 64}) {
+        if (done == n_in) break;
         const size_t Lf  = (size_t)bs * kFirR + 4 * (size_t)f->G;
         const size_t lds = f->decim * (Lf + (size_t)f->G * E) * sizeof(float);
         if (lds > 150 * 1024) continue;
-        const float* x = static_cast<const float*>(d_in);
-        float*       y = static_cast<float*>(d_out);
-        if (f->S == 1) rc = bs == 256 ? fir_launch<1, 256>(f, x, y, n_in, n_out, lds, st) : bs == 128 ? fir_launch<1, 128>(f, x, y, n_in, n_out, lds, st) : fir_launch<1, 64>(f, x, y, n_in, n_out, lds, st);
-        else rc = bs == 256 ? fir_launch<2, 256>(f, x, y, n_in, n_out, lds, st) : bs == 128 ? fir_launch<2, 128>(f, x, y, n_in, n_out, lds, st) : fir_launch<2, 64>(f, x, y, n_in, n_out, lds, st);
+        const float* xr = x + done * f->S;
+        float*       yr = y + done * f->S;
+        const long   ni = (long)(n_in - done), no = (long)((n_in - done) / f->decim);
+        if (f->S == 1) rc = bs == 256 ? fir_launch<1, 256>(f, xr, hist, yr, ni, no, lds, st) : bs == 128 ? fir_launch<1, 128>(f, xr, hist, yr, ni, no, lds, st) : fir_launch<1, 64>(f, xr, hist, yr, ni, no, lds, st);
+        else rc = bs == 256 ? fir_launch<2, 256>(f, xr, hist, yr, ni, no, lds, st) : bs == 128 ? fir_launch<2, 128>(f, xr, hist, yr, ni, no, lds, st) : fir_launch<2, 64>(f, xr, hist, yr, ni, no, lds, st);
         break;
     }
     if (rc == GR4HIP_UNSUPPORTED) { set_error("fir_process: ntaps=%zu decim=%zu does not fit the LDS tiling", f->ntaps, f->decim); return rc; }
@@ -263,7 +303,11 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     return GR4HIP_OK;
 }
 
-int gr4hip_fir_destroy(gr4hip_fir_t* f) { delete f; return GR4HIP_OK; }
+int gr4hip_fir_destroy(gr4hip_fir_t* f) {
+    if (f && f->fd) chain_fused_destroy(f->fd);
+    delete f;
+    return GR4HIP_OK;
+}
 
 int gr4hip_decimate(int dtype, const void* d_in, size_t n_in, size_t decim, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
     const size_t es = dtype_size(dtype);

@@ -112,6 +112,31 @@ def test_fir_history_across_calls(G, cplx):
     assert f.process_bulk(dev(x[:0])).numel() == 0  # empty span
 
 
+@pytest.mark.parametrize("ntaps", [256, 91, 33, 2])
+def test_fir_complex_long_input_fast_convolution(G, ntaps):
+    """complex<float>, <= 256 taps, >= 64 frames of 8192: whole frames take the frequency-domain kernel, the rest the direct form;
+    history crosses both boundaries"""
+    rng = np.random.default_rng(ntaps)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 3000 + (70 * 8192 + 77) + 5 + 64 * 8192
+    x = O.signal_c32(5, n)
+    truth, _ = O.fir(b, x)
+    f = G.fir_filter(b, torch.complex64)
+    cuts = [0, 3000, 3000 + 70 * 8192 + 77, 3000 + 70 * 8192 + 77 + 5, n]  # direct | FD + remainder | direct | FD exactly 64 frames
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        xin = torch.empty(hi - lo + 2, dtype=torch.complex64, device="cuda")[2:]  # 16-byte aligned start
+        xin.copy_(torch.from_numpy(x[lo:hi]))
+        parts.append(f.process_bulk(xin).cpu().numpy())
+    y = np.concatenate(parts)
+    assert _rel(y, truth) <= TOL
+    # an input span that is only 8-byte aligned (e.g. an odd ring-buffer position) gives the same answer
+    f2 = G.fir_filter(b, torch.complex64)
+    xin = torch.empty(n + 1, dtype=torch.complex64, device="cuda")[1:]
+    xin.copy_(torch.from_numpy(x))
+    assert _rel(f2.process_bulk(xin).cpu().numpy(), truth) <= TOL
+
+
 def test_fir_boxcar_step_golden(G, golden):
     g = golden["fir_iir_step"]
     x = np.ones(g["n_steps"], np.float32)
@@ -339,6 +364,19 @@ def test_fft_linearity_and_roundtrip_properties(G):
 
 
 # ------------------------------------------------------------------ headline chain
+def test_chain_fused_input_alignment(G):
+    """the fused kernels stage frames with 16-byte LDS-DMA pieces: an 8-byte-aligned span must give the same spectra"""
+    N, frames = 8192, 5
+    b = O.design_taps_hamming_lowpass(256, 0.1)
+    x = O.signal_c32(3, frames * N)
+    buf = torch.empty(frames * N + 1, dtype=torch.complex64, device="cuda")
+    buf[1:].copy_(torch.from_numpy(x))
+    for window in ("None", "Hann"):
+        ref = G.Chain(b, N, window, 0).process_bulk(dev(x))
+        got = G.Chain(b, N, window, 0).process_bulk(buf[1:])
+        assert torch.equal(ref, got)
+
+
 @pytest.mark.parametrize("algo", [1, 0])
 @pytest.mark.parametrize("N,ntaps,window", [(8192, 256, "None"), (8192, 256, "Hann"), (8192, 91, "Rectangular"), (8192, 1, "None"),
                                             (8192, 200, "BlackmanHarris"), (8192, 256, "Kaiser"), (8192, 17, "FlatTop"),
