@@ -146,16 +146,22 @@ int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_
 int  chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_y, hipStream_t st);
 void chain_fused_destroy(ChainFused* c);
 
-// hist256[h] = sample at stream position -256 + h, from the hcap-sample history (zeros before it)
-__global__ void fir_hist256_kernel(const float2* __restrict__ hist, int hcap, float2* __restrict__ out) {
+// fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
+void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out);
+int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st);
+
+// out[h] = sample at stream position -len + h (h < len), from the hcap-sample history (zeros before it)
+template <typename T>
+__global__ void fir_hist_widen_kernel(const T* __restrict__ hist, int hcap, T* __restrict__ out, int len) {
     const int h = threadIdx.x;
-    out[h]      = h >= 256 - hcap ? hist[h - (256 - hcap)] : make_float2(0.f, 0.f);
+    if (h < len) out[h] = h >= len - hcap ? hist[h - (len - hcap)] : T{};
 }
 } // namespace gr4
 
 using namespace gr4;
 
 constexpr size_t kFdFrame     = 8192;
+constexpr size_t kMfmaMinSamples = 1 << 16;
 constexpr size_t kFdMinFrames = 64; // below this the direct-form kernel is as fast (the persistent FD grid wants >= 1 frame per CU)
 
 struct gr4hip_fir {
@@ -170,6 +176,8 @@ struct gr4hip_fir {
     int                cur = 0;
     gr4::ChainFused*   fd  = nullptr; // complex, decim 1, ntaps <= 256: frequency-domain plan (created on first use)
     DeviceBuffer       d_hist256;
+    DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
+    int                mKp = 0, mKS = 0;
 };
 
 static size_t bit_ceil_sz(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
@@ -238,6 +246,7 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     f->taps.assign(h_taps, h_taps + ntaps);
     f->ntaps = ntaps;
     if (f->fd) { chain_fused_destroy(f->fd); f->fd = nullptr; } // rebuilt from the new taps on next use
+    f->mKS = 0;
     int rc   = fir_upload_taps(f);
     if (rc) return rc;
     if (ntaps > f->hcap) { // the reference replaces the HistoryBuffer (history is lost) only when it must grow
@@ -271,13 +280,32 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         if (!f->fd) rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
         if (!rc) rc = f->d_hist256.ensure(256 * sizeof(float2));
         if (rc) return rc;
-        hipLaunchKernelGGL(fir_hist256_kernel, dim3(1), dim3(256), 0, st, (const float2*)hist, (int)f->hcap, (float2*)f->d_hist256.ptr);
+        hipLaunchKernelGGL(fir_hist_widen_kernel<float2>, dim3(1), dim3(256), 0, st, (const float2*)hist, (int)f->hcap, (float2*)f->d_hist256.ptr, 256);
         GR4_LAUNCH_CHECK();
         const size_t frames = n_in / kFdFrame;
         rc = chain_fused_fir(f->fd, x, (const float*)f->d_hist256.ptr, frames, y, st);
         if (rc) return rc;
         done = frames * kFdFrame;
         hist = x + (done - f->hcap) * 2; // the hcap samples in front of the remainder are part of the input itself
+    }
+    // float, no decimation, 33..256 taps, long 16-byte-aligned output: block-Toeplitz product on the f32 MFMA units (about twice the
+    // rate of the register-window VALU kernel, which is FP32-issue bound from ~48 taps on)
+    if (f->S == 1 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in >= kMfmaMinSamples && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
+        int rc = GR4HIP_OK;
+        if (f->mKS == 0) {
+            std::vector<float> af;
+            fir_mfma_make_afrag(f->taps.data(), f->ntaps, 1, &f->mKp, &f->mKS, &af);
+            rc = f->d_afrag.ensure(af.size() * sizeof(float));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (rc) { f->mKS = 0; return rc; }
+        }
+        rc = f->d_hist256.ensure(256 * sizeof(float2));
+        if (rc) return rc;
+        hipLaunchKernelGGL(fir_hist_widen_kernel<float>, dim3(1), dim3(256), 0, st, hist, (int)f->hcap, (float*)f->d_hist256.ptr, f->mKp);
+        GR4_LAUNCH_CHECK();
+        rc = fir_mfma_launch(f->mKS, x, (long)n_in, (const float*)f->d_hist256.ptr, (const float*)f->d_afrag.ptr, y, (long)((n_in + 3) & ~(size_t)3), (long)n_in, 1, st);
+        if (rc) return rc;
+        done = n_in;
     }
     const int E  = 4 / f->S;
     int       rc = done == n_in ? GR4HIP_OK : GR4HIP_UNSUPPORTED;

@@ -76,6 +76,32 @@ __global__ void fir_batched_hist_kernel(const float* __restrict__ x, long in_str
     new_hist[(long)c * Kp + h] = i >= 0 ? x[(long)c * in_stride + i] : old_hist[(long)c * Kp + Kp + i];
 }
 
+// A-fragment table [nch][KS][64] for per-channel taps [nch][ntaps]; Kp = 64 / 128 / 256
+void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out) {
+    const int Kp = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : 256, KS = (Kp + 16) / 4;
+    af_out->assign(nch * KS * 64, 0.f);
+    for (size_t c = 0; c < nch; ++c)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int k = Kp + (l & 15) - (4 * ks + (l >> 4)); // tap index b[Kp + j - u]
+                (*af_out)[(c * KS + ks) * 64 + l] = (k >= 0 && (size_t)k < ntaps) ? taps[c * ntaps + k] : 0.f;
+            }
+    *Kp_out = Kp;
+    *KS_out = KS;
+}
+
+// y[c][i] = sum_k b_c[k] x[c][i - k], i < n; hist[c][Kp] = the Kp samples in front of x[c]; y must be 16-byte aligned, out_stride % 4 == 0
+int fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div(n, (long)kSeg), nch);
+    switch (KS) {
+    case 20: hipLaunchKernelGGL(fir_mfma_kernel<20>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
+    case 36: hipLaunchKernelGGL(fir_mfma_kernel<36>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
+    default: hipLaunchKernelGGL(fir_mfma_kernel<68>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
+    }
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
 } // namespace gr4
 
 using namespace gr4;
@@ -96,15 +122,8 @@ int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, cons
     GR4_REQUIRE(f, "out of host memory");
     f->nch   = nchannels;
     f->ntaps = ntaps;
-    f->Kp    = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : 256;
-    f->KS    = (f->Kp + 16) / 4;
-    std::vector<float> af(nchannels * f->KS * 64, 0.f);
-    for (size_t c = 0; c < nchannels; ++c)
-        for (int ks = 0; ks < f->KS; ++ks)
-            for (int l = 0; l < 64; ++l) {
-                const int k = f->Kp + (l & 15) - (4 * ks + (l >> 4)); // tap index b[Kp + j - u]
-                af[(c * f->KS + ks) * 64 + l] = (k >= 0 && (size_t)k < ntaps) ? h_taps[c * ntaps + k] : 0.f;
-            }
+    std::vector<float> af;
+    fir_mfma_make_afrag(h_taps, ntaps, nchannels, &f->Kp, &f->KS, &af);
     int rc = f->d_afrag.ensure(af.size() * sizeof(float));
     if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     for (int k = 0; k < 2 && !rc; ++k) rc = f->d_hist[k].ensure(nchannels * f->Kp * sizeof(float));
@@ -127,14 +146,9 @@ int gr4hip_fir_batched_process(gr4hip_fir_batched_t* f, const float* d_in, size_
     GR4_REQUIRE(d_in && d_out && in_stride >= n && out_stride >= n, "fir_batched_process: null pointer or stride shorter than n");
     GR4_REQUIRE(((uintptr_t)d_out % 16 == 0) && (out_stride % 4 == 0), "fir_batched_process: output must be 16-byte aligned with a stride multiple of 4");
     hipStream_t st = as_stream(stream);
-    const dim3  grid((unsigned)ceil_div(n, (size_t)kSeg), (unsigned)f->nch);
     const float *hist = (const float*)f->d_hist[f->cur].ptr, *af = (const float*)f->d_afrag.ptr;
-    switch (f->KS) {
-    case 20: hipLaunchKernelGGL(fir_mfma_kernel<20>, grid, dim3(256), 0, st, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n); break;
-    case 36: hipLaunchKernelGGL(fir_mfma_kernel<36>, grid, dim3(256), 0, st, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n); break;
-    default: hipLaunchKernelGGL(fir_mfma_kernel<68>, grid, dim3(256), 0, st, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n); break;
-    }
-    GR4_LAUNCH_CHECK();
+    int          rc   = fir_mfma_launch(f->KS, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n, (unsigned)f->nch, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(fir_batched_hist_kernel, dim3((unsigned)ceil_div(f->Kp, 64), (unsigned)f->nch), dim3(64), 0, st, d_in, (long)in_stride, hist,
                        (float*)f->d_hist[f->cur ^ 1].ptr, (long)n, f->Kp);
     GR4_LAUNCH_CHECK();

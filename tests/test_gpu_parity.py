@@ -112,6 +112,21 @@ def test_fir_history_across_calls(G, cplx):
     assert f.process_bulk(dev(x[:0])).numel() == 0  # empty span
 
 
+@pytest.mark.parametrize("ntaps", [33, 64, 100, 128, 200, 256])
+def test_fir_real_long_input_mfma(G, ntaps):
+    """float, 33..256 taps, >= 2^16 samples: the block-Toeplitz MFMA kernel; history crosses the VALU / MFMA boundaries"""
+    rng = np.random.default_rng(ntaps)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    cuts = [0, 1000, 1000 + 70_001, 1000 + 70_001 + 17, 1000 + 70_001 + 17 + 65_536]
+    x = O.signal_f32(11, cuts[-1])
+    truth, _ = O.fir(b, x)
+    f = G.fir_filter(b, torch.float32)
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert _rel(y, truth) <= TOL
+    cpu32, _ = O.fir(b, x, acc64=False)
+    assert _rel(y, truth) <= _rel(cpu32, truth) + 1e-6
+
+
 @pytest.mark.parametrize("ntaps", [256, 91, 33, 2])
 def test_fir_complex_long_input_fast_convolution(G, ntaps):
     """complex<float>, <= 256 taps, >= 64 frames of 8192: whole frames take the frequency-domain kernel, the rest the direct form;

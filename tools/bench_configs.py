@@ -68,9 +68,17 @@ res["configs[3] 64 ch x 256-tap FIR (MFMA)"] = {"Msamples/s (all channels)": rou
                                                "mfma_peak_frac": round(nch * n * 544 / t / 157.3e12, 3)}
 # the same work on the VALU kernel (one fir_filter at a time)
 f1 = G.fir_filter(lowpass(ntaps, 0.05), torch.float32)
-y1 = torch.empty(n, dtype=torch.float32, device="cuda")
-t1 = timeit(lambda: f1.process_bulk(xb[0], y1))
-res["fir_filter<float> 256 taps (VALU kernel)"] = {"Msamples/s": round(n / t1 / 1e6, 1), "TFLOP/s": round(n * 512 / t1 / 1e12, 1)}
+x1 = xb.reshape(-1)  # one long real stream
+y1 = torch.empty_like(x1)
+t1 = timeit(lambda: f1.process_bulk(x1, y1))
+res["fir_filter<float> 256 taps (single stream, MFMA kernel)"] = {"Msamples/s": round(x1.numel() / t1 / 1e6, 1), "useful_TFLOP/s": round(x1.numel() * 512 / t1 / 1e12, 1)}
+f1 = G.fir_filter(lowpass(64, 0.05), torch.float32)
+t1 = timeit(lambda: f1.process_bulk(x1, y1))
+res["fir_filter<float> 64 taps (single stream, MFMA kernel)"] = {"Msamples/s": round(x1.numel() / t1 / 1e6, 1), "alg_GB/s": round(x1.numel() * 8 / t1 / 1e9, 1), "hbm_frac": round(x1.numel() * 8 / t1 / 8e12, 3)}
+f1 = G.fir_filter(lowpass(32, 0.05), torch.float32)
+t1 = timeit(lambda: f1.process_bulk(x1, y1))
+res["fir_filter<float> 32 taps (VALU register-window kernel)"] = {"Msamples/s": round(x1.numel() / t1 / 1e6, 1), "alg_GB/s": round(x1.numel() * 8 / t1 / 1e9, 1), "hbm_frac": round(x1.numel() * 8 / t1 / 8e12, 3)}
+del x1, y1
 # complex<float> fir_filter, 256 taps, long input: frequency-domain path (2 transforms per 8192-sample frame), 16 B/sample
 nc = 1 << 27
 xcf = G.synth_c32(nc)
