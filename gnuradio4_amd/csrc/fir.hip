@@ -149,11 +149,13 @@ void chain_fused_destroy(ChainFused* c);
 // fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st);
+void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
+int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
 
 // out[h] = sample at stream position -len + h (h < len), from the hcap-sample history (zeros before it)
 template <typename T>
 __global__ void fir_hist_widen_kernel(const T* __restrict__ hist, int hcap, T* __restrict__ out, int len) {
-    const int h = threadIdx.x;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h < len) out[h] = h >= len - hcap ? hist[h - (len - hcap)] : T{};
 }
 } // namespace gr4
@@ -306,6 +308,28 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         rc = fir_mfma_launch(f->mKS, x, (long)n_in, (const float*)f->d_hist256.ptr, (const float*)f->d_afrag.ptr, y, (long)((n_in + 3) & ~(size_t)3), (long)n_in, 1, st);
         if (rc) return rc;
         done = n_in;
+    }
+    // float polyphase decimator with >= 16 taps per phase and a long span: the same contraction with the D phase products summed in
+    // one accumulator tile (BASELINE configs[2]: decim 8, 1024 taps)
+    if (f->S == 1 && f->decim >= 2 && ceil_div(f->ntaps, f->decim) >= 16 && ceil_div(f->ntaps, f->decim) <= 256 && n_out >= (1u << 14) &&
+        (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
+        int rc = GR4HIP_OK;
+        if (f->mKS == 0) {
+            std::vector<float> af;
+            fir_mfma_make_afrag_decim(f->taps.data(), f->ntaps, f->decim, &f->mKp, &f->mKS, &af);
+            rc = f->d_afrag.ensure(af.size() * sizeof(float));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (rc) { f->mKS = 0; return rc; }
+        }
+        const int hl = f->mKp * (int)f->decim; // history the kernel wants: Kp D samples
+        rc = f->d_hist256.ensure((size_t)hl * sizeof(float));
+        if (rc) return rc;
+        const int hu = (int)std::min<size_t>(f->hcap, (size_t)hl); // newest hu samples of the block's history are what the kernel can see
+        hipLaunchKernelGGL(fir_hist_widen_kernel<float>, dim3((unsigned)ceil_div(hl, 256)), dim3(256), 0, st, hist + (f->hcap - hu), hu, (float*)f->d_hist256.ptr, hl);
+        GR4_LAUNCH_CHECK();
+        rc = fir_mfma_decim_launch(f->mKS, (int)f->decim, x, (const float*)f->d_hist256.ptr, (const float*)f->d_afrag.ptr, y, (long)n_out, st);
+        if (rc == GR4HIP_OK) done = n_in;
+        else if (rc != GR4HIP_UNSUPPORTED) return rc; // UNSUPPORTED: the de-interleaved segment does not fit the LDS, keep the VALU kernel
     }
     const int E  = 4 / f->S;
     int       rc = done == n_in ? GR4HIP_OK : GR4HIP_UNSUPPORTED;

@@ -76,6 +76,91 @@ __global__ void fir_batched_hist_kernel(const float* __restrict__ x, long in_str
     new_hist[(long)c * Kp + h] = i >= 0 ? x[(long)c * in_stride + i] : old_hist[(long)c * Kp + Kp + i];
 }
 
+// Polyphase decimating FIR on the same scheme (BASELINE configs[2]: decim 8, 1024 taps).  y[m] = sum_p sum_q b[qD + p] x_p[m - q] with
+// the phase streams x_p[m] = x[mD - p]: D ordinary FIRs of Q = ceil(K / D) taps at the output rate whose products land in the same
+// accumulator tile, i.e. one [16 x D (Kp+16)] x [D (Kp+16) x blocks] contraction.  The input segment is de-interleaved into D padded
+// phase rows while it is staged (every input read from HBM once); the A fragments of one phase at a time are in registers.
+template <int KS, int TPW> // K-steps per phase (Kp = 4 KS - 16), 256-output tiles per wave
+__global__ __launch_bounds__(256) void fir_mfma_decim_kernel(const float* __restrict__ x, const float* __restrict__ hist /*[Kp D] samples in front of x*/,
+                                                              const float* __restrict__ afrag /*[D][KS][64]*/, float* __restrict__ y, long n_out, int D) {
+    constexpr int Kp  = 4 * KS - 16;
+    constexpr int SEG = 1024 * TPW;                  // outputs per workgroup
+    constexpr int ROW = (SEG + Kp) / 16 * 17 + 1;    // padded phase row (odd length: the D rows start on different banks)
+    extern __shared__ float xs[];                    // [D][ROW]
+    const long seg0 = (long)blockIdx.x * SEG;        // first output of this workgroup
+    const int  tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long n_in = n_out * D, H = (long)Kp * D;
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    const int col = lane & 15, kq = lane >> 4;
+    // A fragments of phase 0 are requested before the staging loop and every following phase one phase ahead: their L2 latency hides
+    // under the staging / the previous phase's MFMAs (A does not depend on the wave: four waves share the lines in L1)
+    float a0[KS], a1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a0[ks] = afrag[(long)ks * 64 + lane];
+
+    // stage: phase row p, position m' <-> input index (seg0 - Kp + m') D - p.  Consecutive lanes take consecutive input samples; the
+    // (m', p) pair of a lane's next sample (256 further) follows from the previous one without a division.
+    const long i0  = (seg0 - Kp) * D - (D - 1);      // lowest input index needed (m' = 0, p = D - 1)
+    const int  cnt = (SEG + Kp) * D;
+    {
+        const int q256 = 256 / D, r256 = 256 % D;
+        int       e  = tid - (D - 1);                // = m' D - p for s = tid
+        int       mp = (e + D - 1) / D, pp = mp * D - e;
+        constexpr int U = 8; // loads in flight per lane (a load-per-iteration loop pays the memory latency cnt / 256 times)
+        for (int s0 = tid; s0 < cnt; s0 += 256 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long i = i0 + s0 + 256 * u;
+                v[u] = s0 + 256 * u < cnt ? (i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -H ? hist[H + i] : 0.f)) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (s0 + 256 * u < cnt && mp < SEG + Kp) xs[pp * ROW + mp + (mp >> 4)] = v[u];
+                mp += q256;
+                pp -= r256;
+                if (pp < 0) { pp += D; mp += 1; }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[TPW]; // one 16-block x 16-output tile (256 outputs) each; two tiles per wave hide the dependent-MFMA latency
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* pb[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) pb[t] = xs + kq + 17 * (16 * (wave * TPW + t) + col);
+    auto phase = [&](const float (&a)[KS], int p) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int off = 4 * ks + (ks >> 2);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], pb[t][p * ROW + off], acc[t], 0, 0, 0);
+        }
+    };
+    for (int p = 0; p < D; p += 2) {
+        const int pn = p + 1 < D ? p + 1 : p; // (odd D: the last prefetch re-reads a valid phase and is not used)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a1[ks] = afrag[((long)pn * KS + ks) * 64 + lane];
+        phase(a0, p);
+        if (p + 1 < D) {
+            const int pm = p + 2 < D ? p + 2 : p;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a0[ks] = afrag[((long)pm * KS + ks) * 64 + lane];
+            phase(a1, p + 1);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const long o = seg0 + 16L * (16 * (wave * TPW + t) + col) + 4 * kq;
+        if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        else
+            for (int r = 0; r < 4; ++r)
+                if (o + r < n_out) y[o + r] = acc[t][r];
+    }
+}
+
 // A-fragment table [nch][KS][64] for per-channel taps [nch][ntaps]; Kp = 64 / 128 / 256
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out) {
     const int Kp = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : 256, KS = (Kp + 16) / 4;
@@ -100,6 +185,45 @@ int fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, c
     }
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
+}
+
+// polyphase A fragments [D][KS][64]: phase p holds b[qD + p]
+void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out) {
+    const size_t Q  = ceil_div(ntaps, D);
+    const int    Kp = Q <= 64 ? 64 : Q <= 128 ? 128 : 256, KS = (Kp + 16) / 4;
+    af_out->assign(D * KS * 64, 0.f);
+    for (size_t p = 0; p < D; ++p)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int q = Kp + (l & 15) - (4 * ks + (l >> 4)); // phase-tap index
+                if (q >= 0 && (size_t)q * D + p < ntaps) (*af_out)[(p * KS + ks) * 64 + l] = taps[(size_t)q * D + p];
+            }
+    *Kp_out = Kp;
+    *KS_out = KS;
+}
+
+// y[m] = sum_k b[k] x[mD - k], m < n_out; hist = the Kp D samples in front of x; y 16-byte aligned.  Returns GR4HIP_UNSUPPORTED when the
+// de-interleaved segment does not fit the LDS.
+int fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st) {
+    const int Kp = 4 * KS - 16;
+    for (int tpw : {1, 2}) { // smaller segments first: 39 KB of LDS at D = 8 -> four workgroups per CU cover the staging and A-fragment latencies
+        const int    seg = 1024 * tpw, row = (seg + Kp) / 16 * 17 + 1;
+        const size_t lds = (size_t)D * row * sizeof(float);
+        if (lds > 76 * 1024) continue; // two workgroups per CU
+        const dim3 grid((unsigned)ceil_div(n_out, (long)seg));
+#define GR4_DECIM_CASE(KSV, TPWV)                                                                                                         \
+    do {                                                                                                                                  \
+        auto kern = fir_mfma_decim_kernel<KSV, TPWV>;                                                                                     \
+        if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, afrag, y, n_out, D);                                                  \
+    } while (0)
+        if (tpw == 2) { if (KS == 20) GR4_DECIM_CASE(20, 2); else if (KS == 36) GR4_DECIM_CASE(36, 2); else GR4_DECIM_CASE(68, 2); }
+        else          { if (KS == 20) GR4_DECIM_CASE(20, 1); else if (KS == 36) GR4_DECIM_CASE(36, 1); else GR4_DECIM_CASE(68, 1); }
+#undef GR4_DECIM_CASE
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
+    return GR4HIP_UNSUPPORTED;
 }
 
 } // namespace gr4

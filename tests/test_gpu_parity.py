@@ -127,6 +127,19 @@ def test_fir_real_long_input_mfma(G, ntaps):
     assert _rel(y, truth) <= _rel(cpu32, truth) + 1e-6
 
 
+@pytest.mark.parametrize("decim,ntaps", [(8, 1024), (2, 64), (3, 600), (4, 100), (10, 1000), (5, 91), (16, 4096)])
+def test_fir_decimating_long_input_mfma(G, decim, ntaps):
+    """float polyphase decimator, >= 16 taps per phase, >= 2^14 outputs per span: phase products summed on the MFMA units"""
+    rng = np.random.default_rng(ntaps + decim)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    cuts = [0, 40 * decim, (40 + 20_003) * decim, (40 + 20_003 + 7) * decim, (40 + 20_003 + 7 + 16_384) * decim]
+    x = O.signal_f32(13, cuts[-1])
+    truth, _ = O.fir_decim(b, x, decim)
+    f = G.fir_filter(b, torch.float32, decimate=decim)
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert _rel(y, truth) <= TOL
+
+
 @pytest.mark.parametrize("ntaps", [256, 91, 33, 2])
 def test_fir_complex_long_input_fast_convolution(G, ntaps):
     """complex<float>, <= 256 taps, >= 64 frames of 8192: whole frames take the frequency-domain kernel, the rest the direct form;
