@@ -9,7 +9,10 @@
 //     (fir_filter<complex<float>> -> PowerSpectrum == gr4hip_chain_*: the runtime analogue of Merge<>, BlockMerging.hpp:136-320).
 // Device blocks never fall back to the host path: a failing library call turns into work::Status::ERROR with the library's text.
 #pragma once
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <span>
 #include <functional>
 #include <iostream>
 
@@ -197,6 +200,96 @@ struct Kernel<gr::blocks::fft::PowerSpectrum<std::complex<float>>> {
     using B = gr::blocks::fft::PowerSpectrum<std::complex<float>>;
     static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<PowerSpectrumStage>(b.fftSize, window_id(b.window)); }
     static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+
+// ---------------------------------------------------------------------------------------------- GPU-resident BufferLike ring
+// The device-side analogue of gr::CircularBuffer (core/include/gnuradio-4.0/CircularBuffer.hpp:191-236, BufferLike concept
+// Buffer.hpp:73-103): one writer, any number of readers, capacity rounded up to the VMM granularity; the storage is
+// mapped twice back to back (gr4hip_ring_*), so a span that wraps the physical end is still ONE contiguous device range and kernels
+// never see a split.  Spans hold DEVICE pointers (usable as kernel arguments, not dereferenceable on the host).  Cursor protocol as
+// in the reference: reserve -> (enqueue the producer's stream work) -> publish once its completion event has fired; get -> (enqueue
+// the consumer) -> consume after completion.  Cursors are host-side atomics: the only cross-thread state, like gr::Sequence.
+template <typename T>
+class CircularBuffer {
+    struct State {
+        gr4hip_ring_t*                          ring = nullptr;
+        T*                                      base = nullptr;
+        std::size_t                             cap  = 0; // elements
+        std::atomic<std::size_t>                wr{0};    // monotonically increasing element counts
+        std::mutex                              m;
+        std::vector<std::shared_ptr<std::atomic<std::size_t>>> readers;
+        ~State() { if (ring) gr4hip_ring_destroy(ring); }
+        std::size_t min_read() {
+            std::lock_guard lk(m);
+            std::size_t     r = wr.load(std::memory_order_acquire);
+            for (auto& c : readers) r = std::min(r, c->load(std::memory_order_acquire));
+            return r;
+        }
+    };
+    std::shared_ptr<State> _s;
+
+public:
+    explicit CircularBuffer(std::size_t min_elements) : _s(std::make_shared<State>()) {
+        check(gr4hip_ring_create(&_s->ring, min_elements * sizeof(T)), "gr4hip_ring_create");
+        void*       b = nullptr;
+        std::size_t bytes = 0;
+        check(gr4hip_ring_base(_s->ring, &b), "gr4hip_ring_base");
+        check(gr4hip_ring_size(_s->ring, &bytes), "gr4hip_ring_size");
+        _s->base = static_cast<T*>(b);
+        _s->cap  = bytes / sizeof(T);
+    }
+    [[nodiscard]] std::size_t size() const noexcept { return _s->cap; }
+
+    class Writer {
+        std::shared_ptr<State> _s;
+        std::size_t            _reserved = 0;
+        friend class CircularBuffer;
+        explicit Writer(std::shared_ptr<State> s) : _s(std::move(s)) {}
+
+    public:
+        [[nodiscard]] std::size_t available() const { return _s->cap - (_s->wr.load(std::memory_order_relaxed) - _s->min_read()); }
+        // device span of n elements at the write cursor, contiguous even across the physical end; empty span if the readers are behind
+        [[nodiscard]] std::span<T> tryReserve(std::size_t n) {
+            if (n > available()) return {};
+            _reserved = n;
+            return {_s->base + _s->wr.load(std::memory_order_relaxed) % _s->cap, n};
+        }
+        [[nodiscard]] std::span<T> reserve(std::size_t n) {
+            auto sp = tryReserve(n);
+            if (sp.size() != n) throw std::runtime_error("gr::hip::CircularBuffer: reserve exceeds free space");
+            return sp;
+        }
+        void publish(std::size_t n) {
+            if (n > _reserved) throw std::runtime_error("gr::hip::CircularBuffer: publish exceeds reservation");
+            _reserved = 0;
+            _s->wr.fetch_add(n, std::memory_order_release);
+        }
+    };
+    class Reader {
+        std::shared_ptr<State>                    _s;
+        std::shared_ptr<std::atomic<std::size_t>> _rd;
+        friend class CircularBuffer;
+        Reader(std::shared_ptr<State> s, std::shared_ptr<std::atomic<std::size_t>> rd) : _s(std::move(s)), _rd(std::move(rd)) {}
+
+    public:
+        [[nodiscard]] std::size_t available() const { return _s->wr.load(std::memory_order_acquire) - _rd->load(std::memory_order_relaxed); }
+        [[nodiscard]] std::span<const T> get(std::size_t n) const {
+            n = std::min(n, available());
+            return {_s->base + _rd->load(std::memory_order_relaxed) % _s->cap, n};
+        }
+        [[nodiscard]] bool consume(std::size_t n) {
+            if (n > available()) return false;
+            _rd->fetch_add(n, std::memory_order_release);
+            return true;
+        }
+    };
+    [[nodiscard]] Writer new_writer() { return Writer(_s); }
+    [[nodiscard]] Reader new_reader() { // a new reader starts at the current write position (CircularBuffer.hpp semantics)
+        auto            rd = std::make_shared<std::atomic<std::size_t>>(_s->wr.load(std::memory_order_acquire));
+        std::lock_guard lk(_s->m);
+        _s->readers.push_back(rd);
+        return Reader(_s, rd);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------- HIP-stream scheduler with chain fusion

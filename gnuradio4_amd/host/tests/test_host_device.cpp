@@ -89,6 +89,31 @@ int main(int argc, char** argv) {
         if (sink._samples.size() != (x.size() / N) * N) ++errors;
         dump(out + (fused ? "_chain.bin" : "_chain_hann.bin"), sink._samples);
     }
+    { // 4. the GPU-resident BufferLike ring: spans that wrap the physical end stay contiguous; two readers, back-pressure
+        hip::CircularBuffer<float> ring(1 << 16);
+        auto                       w = ring.new_writer();
+        auto                       r1 = ring.new_reader(), r2 = ring.new_reader();
+        const std::size_t          cap = ring.size(), chunk = cap / 2 + 4096; // the second chunk wraps
+        std::vector<float>         host(chunk), back(chunk);
+        std::size_t                seq = 0;
+        for (int round = 0; round < 5 && !errors; ++round) {
+            for (auto& v : host) v = static_cast<float>(seq++);
+            auto span = w.reserve(chunk);
+            hip::check(gr4hip_memcpy_h2d(span.data(), host.data(), chunk * sizeof(float), nullptr), "ring h2d");
+            hip::check(gr4hip_stream_synchronize(nullptr), "sync");
+            w.publish(chunk);
+            if (!w.tryReserve(chunk).empty()) ++errors; // both readers still hold the chunk: no room for another one
+            for (auto* r : {&r1, &r2}) {
+                auto in = r->get(chunk);
+                if (in.size() != chunk) { ++errors; break; }
+                hip::check(gr4hip_memcpy_d2h(back.data(), in.data(), chunk * sizeof(float), nullptr), "ring d2h"); // ONE copy, also when wrapping
+                hip::check(gr4hip_stream_synchronize(nullptr), "sync");
+                if (back != host) ++errors;
+                if (!r->consume(chunk)) ++errors;
+            }
+        }
+        std::printf("device ring: capacity %zu floats, %s\n", cap, errors ? "FAILED" : "wrapping spans contiguous");
+    }
     std::printf(errors ? "host-device: %d FAILURES\n" : "host-device: all graphs ran\n", errors);
     return errors ? 1 : 0;
 }

@@ -64,6 +64,7 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "chain_fir_fft_mag2  (1 stage)" in r.stdout
+    assert "wrapping spans contiguous" in r.stdout  # gr::hip::CircularBuffer<T>: BufferLike ring in HBM, double-mapped
 
     def rel(got, truth):
         rms = np.sqrt(np.mean(np.abs(truth) ** 2))
