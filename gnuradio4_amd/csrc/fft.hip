@@ -61,6 +61,7 @@ struct FftOutputs {
     float* phase;     // final phase when !unwrap
     float* phase_raw; // natural-order raw atan2 (only when unwrap; finished by unwrap_kernel)
     float* mag2;      // natural order
+    float* ranges;    // fast kernels only: [frames][4][2] {min, max} of magnitude, phase, Re, Im (fft.hpp:229-232); null = not requested
     int    in_db, in_deg, real_input;
 };
 
@@ -317,6 +318,11 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
                 }
             }
         }
+        // per-frame {min, max} of the four DataSet signals, accumulated while the values are in registers (no second pass over HBM)
+        float rmin[4], rmax[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) { rmin[g4] = FLT_MAX; rmax[g4] = -FLT_MAX; }
+        auto track = [&](int sig, float v) { rmin[sig] = fminf(rmin[sig], v); rmax[sig] = fmaxf(rmax[sig], v); };
         // ---- every requested output, straight from registers (fft.hpp:164-166, fft_common.hpp:20-56, 91-123)
         // X[j] is bin eN + j ST of the lane's frame; eS + soff(j) is the same bin after fftshift
         constexpr int ST = R4 == 2 ? 256 : T;
@@ -337,12 +343,12 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
             if (out.re) {
                 const rsrc_t r = make_rsrc(out.re + f0 * N, nlive * N * 4u);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) buf_store_f(r, X[j].x, eN * 4, j * ST * 4);
+                for (int j = 0; j < 16; ++j) { buf_store_f(r, X[j].x, eN * 4, j * ST * 4); track(2, X[j].x); }
             }
             if (out.im) {
                 const rsrc_t r = make_rsrc(out.im + f0 * N, nlive * N * 4u);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) buf_store_f(r, X[j].y, eN * 4, j * ST * 4);
+                for (int j = 0; j < 16; ++j) { buf_store_f(r, X[j].y, eN * 4, j * ST * 4); track(3, X[j].y); }
             }
             if (out.mag) {
                 const rsrc_t r = make_rsrc(out.mag + f0 * N, nlive * N * 4u);
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
                     float m = hypotf(X[j].x, X[j].y) * 2.f / (float)N;
                     if (out.in_db) m = (m > 0.f) ? 20.f * log10f(m) : -FLT_MAX;
                     buf_store_f(r, m, eS * 4, soff(j) * 4);
+                    track(0, m);
                 }
             }
             if (out.phase || out.phase_raw) {
@@ -363,6 +370,7 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
                     } else {
                         if (out.in_deg) ph = ph * 180.f * 0.318309886183790671538f;
                         buf_store_f(r, ph, eS * 4, soff(j) * 4);
+                        track(1, ph);
                     }
                 }
             }
@@ -374,12 +382,12 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
             if (out.re && hi) {
                 const rsrc_t r = make_rsrc(out.re + f0 * HALF, nlive * HALF * 4u);
 #pragma unroll
-                for (int j = J0; j < 16; ++j) buf_store_f(r, X[j].x, eH * 4, (j - J0) * ST * 4);
+                for (int j = J0; j < 16; ++j) { buf_store_f(r, X[j].x, eH * 4, (j - J0) * ST * 4); track(2, X[j].x); }
             }
             if (out.im && hi) {
                 const rsrc_t r = make_rsrc(out.im + f0 * HALF, nlive * HALF * 4u);
 #pragma unroll
-                for (int j = J0; j < 16; ++j) buf_store_f(r, X[j].y, eH * 4, (j - J0) * ST * 4);
+                for (int j = J0; j < 16; ++j) { buf_store_f(r, X[j].y, eH * 4, (j - J0) * ST * 4); track(3, X[j].y); }
             }
             if (out.mag && lo) {
                 const rsrc_t r = make_rsrc(out.mag + f0 * HALF, nlive * HALF * 4u);
@@ -388,6 +396,7 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
                     float m = hypotf(X[j].x, X[j].y) * 2.f / (float)N;
                     if (out.in_db) m = (m > 0.f) ? 20.f * log10f(m) : -FLT_MAX;
                     buf_store_f(r, m, eH * 4, j * ST * 4);
+                    track(0, m);
                 }
             }
             if ((out.phase || out.phase_raw) && lo) {
@@ -397,6 +406,40 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
                     float ph = atan2f(X[j].y, X[j].x);
                     if (!out.phase_raw && out.in_deg) ph = ph * 180.f * 0.318309886183790671538f;
                     buf_store_f(r, ph, eH * 4, j * ST * 4);
+                    if (!out.phase_raw) track(1, ph);
+                }
+            }
+        }
+        if (out.ranges) { // reduce over the T lanes of the frame: butterflies inside the wave, then (T > 64) through LDS
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+                for (int off = (T < 64 ? T : 64) / 2; off > 0; off >>= 1) {
+                    rmin[g4] = fminf(rmin[g4], __shfl_xor(rmin[g4], off));
+                    rmax[g4] = fmaxf(rmax[g4], __shfl_xor(rmax[g4], off));
+                }
+            }
+            if constexpr (T > 64) {
+                __syncthreads(); // everybody is done with buf (the last LDS reads were before the previous barrier, but waves may lag)
+                float* red = reinterpret_cast<float*>(buf);
+                if ((tid & 63) == 0) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) { red[(t >> 6) * 8 + g4] = rmin[g4]; red[(t >> 6) * 8 + 4 + g4] = rmax[g4]; }
+                }
+                __syncthreads();
+                if (t == 0) {
+                    for (int w = 1; w < T / 64; ++w)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) { rmin[g4] = fminf(rmin[g4], red[w * 8 + g4]); rmax[g4] = fmaxf(rmax[g4], red[w * 8 + 4 + g4]); }
+                }
+                __syncthreads(); // red lives in buf: the next iteration writes there
+            }
+            if (t == 0 && f0 + fl < n_frames) {
+                const bool have[4] = {out.mag != nullptr, out.phase != nullptr, out.re != nullptr, out.im != nullptr};
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    out.ranges[((f0 + fl) * 4 + g4) * 2 + 0] = have[g4] ? rmin[g4] : 0.f;
+                    out.ranges[((f0 + fl) * 4 + g4) * 2 + 1] = have[g4] ? rmax[g4] : 0.f;
                 }
             }
         }
@@ -592,6 +635,9 @@ static int fft_run(gr4hip_fft_t* f, const void* d_in, size_t n_frames, FftOutput
         o.phase     = d_phase_final;
         o.phase_raw = nullptr;
     }
+    const bool fast         = f->N >= 256 && f->N <= 8192; // fft_fast_kernel sizes (all powers of two there)
+    const bool fused_ranges = d_ranges && fast && !unwrap;  // the unwrapped phase only exists after unwrap_kernel
+    o.ranges                = fused_ranges ? d_ranges : nullptr;
     int rc = fft_launch(f->plan, static_cast<const float*>(d_in), static_cast<const float*>(f->d_window.ptr), static_cast<const float2*>(f->d_tw.ptr), o,
                         (long)n_frames, st);
     if (rc) return rc;
@@ -601,7 +647,7 @@ static int fft_run(gr4hip_fft_t* f, const void* d_in, size_t n_frames, FftOutput
                            o.real_input ? 0 : 1);
         GR4_LAUNCH_CHECK();
     }
-    if (d_ranges) {
+    if (d_ranges && !fused_ranges) {
         hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)n_frames, 4), dim3(256), 0, st, (const float*)o.mag, (const float*)d_phase_final, (const float*)o.re,
                            (const float*)o.im, nout, d_ranges);
         GR4_LAUNCH_CHECK();
