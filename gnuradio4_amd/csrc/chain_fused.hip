@@ -29,10 +29,10 @@ namespace gr4 {
 
 constexpr int kN     = 8192;
 constexpr int kT     = 512;  // lanes per workgroup (8 waves)
-constexpr int kRowA  = 264;  // pass-A -> pass-B exchange: S[r'][n0], row pitch 264 float2 (528 dwords = 16 mod 64; rows k and k+2 are 32 banks apart)
+constexpr int kRowA  = 272;  // pass-A image / exchange: S[row][col], row pitch 272 float2 = 544 dwords = 32 mod 64 banks: rows of different parity never share a bank
 constexpr int kRowB  = 513;  // pass-B -> pass-C exchange: S[c][i3], row pitch 513 float2 (1026 dwords = 2 mod 32: 16 c-lanes hit 32 distinct banks)
 constexpr int kDPad  = 544; // >= (16 * 15 + 255) * 17 / 16 + 1
-constexpr int kSLen  = 32 * kRowA + 8; // 8456 float2 (rows 16..31 are shifted by 8) >= 16 * 513
+constexpr int kSLen  = 32 * kRowA + 16; // 8720 float2 (rows 16..31 are shifted by 16) >= 16 * 513
 
 struct ChainFdArgs {
     const float2* x;      // frames * 8192 samples
@@ -47,9 +47,12 @@ struct ChainFdArgs {
     unsigned long long* dbg; // GR4_FD_TIMING only
 };
 
-// pass-A exchange layout: rows 0..15 at r*kRowA, rows 16..31 shifted by 8 float2 (16 banks) so that the two lanes of a
-// pair (rows k1 and k1+16, same column) never share a bank
-__device__ __forceinline__ int addrA(int row, int col) { return row * kRowA + col + ((row & 16) ? 8 : 0); }
+// pass-A layout: rows 0..15 at r * kRowA, rows 16..31 shifted by 16 float2 (32 banks).  A ds_read/write_b64 is served in two groups of 32
+// lanes over 64 four-byte banks; every access pattern of the kernel puts the two 16-lane halves of a group 32 banks apart:
+//   pass-A reads   lane pair = rows 2m, 2m+1 of one column (different parity: one pitch = 32 banks)
+//   pass-A writes  lane pair = rows k1, k1+16 (the shift)
+//   pass-B gathers / scatters  the 32-lane group holds rows k and k+16 (gather: the shift; scatter S2[c][32q + k]: 2 * 16 = 32 banks)
+__device__ __forceinline__ int addrA(int row, int col) { return row * kRowA + col + ((row & 16) ? 16 : 0); }
 
 // pass B (p = 32, radix 16): butterfly (c, k) gathers S1[k][c + 16 r], twiddles by W_512^{r k}, scatters to S2[c][32 q + k]
 __device__ __forceinline__ void passB_compute_store(float2* S, float2 (&w)[16], const float2 (&tw)[16], int c, int k) {
@@ -206,8 +209,8 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     float2* T0 = B1 + kSLen;                         // 256: tail of the stream before the frame in B0 (x[fN - 256 + j])
     float2* T1 = T0 + 256;                           // 256: same for B1
     float2* el = T1 + 256;                           // 256: e[n]
-    float*  P  = reinterpret_cast<float*>(el + 256); // [8 waves][re, im][256]: partial e of each wave's 32-tap K range
-    float*  Dre = P + 8 * 2 * 256;                   // kDPad: Dz[s] = d[s - 1] (1 <= s <= 255), zero elsewhere (s <= 511); planar, one pad
+    float*  P  = reinterpret_cast<float*>(el + 256); // [4 K quarters][re, im][256]: partial e; WIN: followed by the pass-B twiddle table [16][32]
+    float*  Dre = P + 4 * 2 * 256 + (WIN ? 1024 : 0);                  // kDPad: Dz[s] = d[s - 1] (1 <= s <= 255), zero elsewhere (s <= 511); planar, one pad
     float*  Dim = Dre + kDPad;                       //        float per 16 samples so that the MFMA B-operand reads are conflict-free
     float*  hl  = Dim + kDPad;                       // 272: taps, zero from 256 on
 
@@ -218,9 +221,9 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     if (t0 < 272) hl[t0] = t0 < 256 ? a.taps[t0] : 0.f;
 
     // pass A roles: column n0, parity par (even / odd rows of the column); the pair (2 n0, 2 n0 + 1) are neighbouring lanes
-    // pass B roles: c = lane & 15, k = 4 wave + {0,2,1,3}[lane >> 4]  (k and k+2 share a 32-lane group: disjoint banks)
+    // pass B roles: c = lane & 15, k = 2 wave + {0, 16, 1, 17}[lane >> 4]  (k and k + 16 share a 32-lane group: disjoint banks)
     const int kq0 = lane0 >> 4;
-    const int kb0 = 4 * wave + ((kq0 & 1) << 1 | (kq0 >> 1));
+    const int kb0 = 2 * wave + (kq0 >> 1) + 16 * (kq0 & 1);
     // ---- kernel-lifetime registers: H[t + 512 q], twiddle bases W_512^{kb}, W_512^{2 kb}, W_8192^{t}, W_8192^{2t}
     float2 Hr[16];
 #pragma unroll
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         const int   n0 = tl >> 1, par = tl & 1;
         const float sgn = par ? -1.f : 1.f;
         const int   cb = lane & 15, kq = lane >> 4;
-        const int   kb = 4 * wave + ((kq & 1) << 1 | (kq >> 1));
+        const int   kb = 2 * wave + (kq >> 1) + 16 * (kq & 1);
         float2* S  = cur ? B1 : B0;
         float2* Sn = cur ? B0 : B1;
         const float2* Tc = cur ? T1 : T0;
@@ -325,36 +328,32 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         // ------------------------------------------------------------------ e[n] = sum_j b[j] Dz[256 + n - j] on the MFMA units
         // Block-Toeplitz form with n = 16 i + j:  e[16 i + j] = sum_u A[j][u] B[u][i],  A[j][u] = b[256 + j - u],  B[u][i] = Dz[16 i + u],
         // u < 256 (Dz is zero from 256 on).  [16 x 256] x [256 x 32] (16 blocks x {re, im}) = 128 v_mfma_f32_16x16x4_f32, 16 per wave
-        // (K split over the 8 waves, partial tiles summed after the barrier).  The matrix pipe is otherwise idle in this kernel, the
+        // (K split over four wave pairs, one wave of a pair per tile; the partial tiles are summed after the barrier).  The matrix pipe is otherwise idle in this kernel, the
         // B operand is ONE conflict-free ds_read_b32 per MFMA, and all eight waves carry the same load.
         {
             using f32x4 = __attribute__((ext_vector_type(4))) float;
             const int    col = lane & 15, kqm = lane >> 4;
             // !WIN: wave w takes K range u in [32 w, 32 w + 32) of both tiles (8 K-steps x {re, im});
             //  WIN: wave w takes K range [64 (w & 3), +64) of ONE tile (w >> 2: re / im), 16 K-steps -- 16 MFMAs per wave either way
-            constexpr int KSW  = WIN ? 16 : 8;
-            const int     kw   = WIN ? (wave & 3) : wave;
-            const float*  pr   = (WIN && (wave >> 2) ? Dim : Dre) + 17 * col + kqm + (4 * KSW * 17 / 16) * kw;
-            const float*  pi   = Dim + 17 * col + kqm + 34 * wave;
+            constexpr int KSW  = 16;
+            const int     kw   = wave & 3;
+            const float*  pr   = ((wave >> 2) ? Dim : Dre) + 17 * col + kqm + (4 * KSW * 17 / 16) * kw;
             const float*  pa   = hl + 256 + col - kqm - 4 * KSW * kw; // A[j = col][u] = b[256 + j - u], u = 4 KSW kw + 4 i + kqm
-            float         av[KSW], br[KSW], bi[WIN ? 1 : 8];
+            float         av[KSW], br[KSW];
 #pragma unroll
             for (int i = 0; i < KSW; ++i) {
                 const int off = 4 * i + (i >> 2); // padded offset of u = 4 KSW kw + 4 i within the window
                 av[i] = pa[-4 * i];
                 br[i] = pr[off];
-                if constexpr (!WIN) bi[i] = pi[off];
             }
-            f32x4 cr = {0.f, 0.f, 0.f, 0.f}, ci = {0.f, 0.f, 0.f, 0.f};
+            f32x4 cr = {0.f, 0.f, 0.f, 0.f};
             // One MFMA per ~12-16 butterfly instructions, fenced so that hipcc keeps the order: the wave issues in order, the MFMA
             // occupies the matrix pipe for 32 cycles while the following VALU instructions of the same wave go to the vector pipe.
             // (Left alone hipcc emits the 16 MFMAs back to back in front of the butterflies and the interval grows by their 512 cycles.)
 #define GR4_MF(i)                                                                           \
     do {                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                  \
-        if constexpr (WIN) cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i)], br[(i)], cr, 0, 0, 0);  \
-        else if ((i) & 1) ci = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i) >> 1], bi[(i) >> 1], ci, 0, 0, 0); \
-        else cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i) >> 1], br[(i) >> 1], cr, 0, 0, 0);        \
+        cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i)], br[(i)], cr, 0, 0, 0);                     \
         __builtin_amdgcn_sched_barrier(0);                                                  \
     } while (0)
             // ---- X pass B: twiddles W_512^{r k}, 16-point DFT, scatter to S2[c][32 q + k]
@@ -383,24 +382,16 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             for (int q = 0; q < 16; ++q) S[cb * kRowB + 32 * q + kb] = w[perm16(q)];
 #undef GR4_MF
             // D[row = 4 kqm + r][col] = partial e[16 col + 4 kqm + r]
-            if constexpr (WIN) { // P[K quarter][re, im][256]
-                *reinterpret_cast<float4*>(P + (wave & 3) * 512 + (wave >> 2) * 256 + 16 * col + 4 * kqm) = make_float4(cr[0], cr[1], cr[2], cr[3]);
-            } else { // P[wave][re, im][256]
-                float* dst = P + wave * 512 + 16 * col + 4 * kqm;
-                *reinterpret_cast<float4*>(dst)       = make_float4(cr[0], cr[1], cr[2], cr[3]);
-                *reinterpret_cast<float4*>(dst + 256) = make_float4(ci[0], ci[1], ci[2], ci[3]);
-            }
+            // P[K quarter][re, im][256]
+            *reinterpret_cast<float4*>(P + (wave & 3) * 512 + (wave >> 2) * 256 + 16 * col + 4 * kqm) = make_float4(cr[0], cr[1], cr[2], cr[3]);
         }
         GR4_STAMP(6);
         GR4_LDS_BARRIER(); // #3
         GR4_STAMP(7);
         GR4_DRAIN(5);
-        { // e = sum of the eight partial tiles (fixed order); lane t -> component t >> 8 of e[t & 255]
+        { // e = sum of the four partial tiles (fixed order); lane t -> component t >> 8 of e[t & 255]
             const float* pp = P + t;
-            const float  s01 = pp[0] + pp[512], s23 = pp[1024] + pp[1536];
-            float        es  = s01 + s23;
-            if constexpr (!WIN) es += (pp[2048] + pp[2560]) + (pp[3072] + pp[3584]);
-            reinterpret_cast<float*>(el)[2 * (t & 255) + (t >> 8)] = es;
+            reinterpret_cast<float*>(el)[2 * (t & 255) + (t >> 8)] = (pp[0] + pp[512]) + (pp[1024] + pp[1536]);
         }
         // ------------------------------------------------------------------ X pass C (p = 512, radix 16), then H[k] X[k]
         float2 X[16];
@@ -601,12 +592,16 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
     if (n_frames * 8 * 16 * 8 <= ((size_t)1 << 26)) a.dbg = g_dbg;
 #endif
-    const size_t lds = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(8 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
+    // two frame buffers, two tails, e | partial tiles (+ WIN: pass-B twiddle table), planar padded d, taps
+    constexpr size_t lds_base = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
+    constexpr size_t lds_win  = lds_base + 1024 * sizeof(float);
+    static_assert(lds_win <= 160 * 1024, "LDS budget of one CU");
+    const size_t lds  = c->windowed ? lds_win : lds_base;
     static int   n_cu = 0;
     if (n_cu == 0) {
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         int dev = 0;
         GR4_HIP_TRY(hipGetDevice(&dev));
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
