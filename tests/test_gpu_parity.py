@@ -536,9 +536,9 @@ def test_rotator_golden_and_parity(G, golden):
     # long stream: the float phase accumulation of the reference (incl. its drift) is reproduced across calls
     n = 200_000 + 13
     x = O.signal_c32(3, n)
-    for inc in (0.6283185, -0.01, 3.0):
-        want, ph = O.rotator(x, inc, 0.25)
-        r = G.Rotator(phase_increment=inc, initial_phase=0.25)
+    for inc, ph0 in ((0.6283185, 0.25), (-0.01, 0.25), (3.0, 0.25), (7.5, 0.25), (-7.5, 0.25), (0.3, -1.0), (-0.3, 9.0), (0.0, 0.25)):  # incl. |inc| > 2 pi, start outside [0, 2 pi]
+        want, ph = O.rotator(x, inc, ph0)
+        r = G.Rotator(phase_increment=inc, initial_phase=ph0)
         got = np.concatenate([r.process_bulk(dev(x[:777])).cpu().numpy(), r.process_bulk(dev(x[777:])).cpu().numpy()])
         assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
         assert r.accumulated_phase == np.float32(ph)  # bit-identical phase state

@@ -112,6 +112,20 @@ F = G.FFT(1024, "Hann")
 t = timeit(lambda: F.process_bulk(xc))
 res["FFT block 1024 (Hann) -> DataSet (mag, phase, re, im, ranges)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 24 / t / 1e9, 1), "hbm_frac": round(n * 24 / t / 8e12, 3),
                                                                          "note": "24 B/sample: 8 in + 4 x 4 out; per-frame min/max ranges reduced inside the kernel; includes torch output allocation"}
+# chain at the FFT block's default size (unfused: fast-convolution FIR -> y in HBM -> FFT kernel), Decimator, Rotator
+ch = G.Chain(lowpass(64, 0.1), 1024, "Hann")
+m2 = torch.empty((n // 1024, 1024), dtype=torch.float32, device="cuda")
+t = timeit(lambda: ch.process_bulk(xc, m2))
+res["chain complex 64-tap FIR -> 1024-pt FFT (Hann) -> mag2 (unfused kernels)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 12 / t / 1e9, 1), "hbm_frac": round(n * 12 / t / 8e12, 3),
+                                                                               "note": "actual traffic 28 B/sample: y is written and re-read"}
+xr = xc.view(torch.float32)
+dec = G.Decimator(10)
+t = timeit(lambda: dec.process_bulk(xr))
+res["Decimator<float> decim 10"] = {"Msamples/s (input)": round(xr.numel() / t / 1e6, 1), "note": "strided 4-byte reads: every input cache line is touched, 1/10 of it used"}
+rot = G.Rotator(0.6283)
+nr = 1 << 24
+t = timeit(lambda: rot.process_bulk(xc[:nr]), reps=2)
+res["Rotator<complex<float>> (bit-exact float phase recurrence)"] = {"Msamples/s": round(nr / t / 1e6, 1), "note": "bounded by the single sequential phase chain of Rotator.hpp:51-61, reproduced exactly"}
 print(json.dumps(res, indent=1))
 if "--json" in sys.argv:
     json.dump(res, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
