@@ -7,7 +7,7 @@
 // contraction with (Kp+16)/Kp = 6 % padding waste (instead of the 2x of a naive Toeplitz GEMM).  v_mfma_f32_16x16x4_f32 has no rate
 // advantage over the FP32 VALU on gfx950 (both 64 flop/clk/SIMD, MI355X_MICROARCH.md) but reaches that rate from one wave per SIMD
 // with one VGPR per operand: the A fragments (taps) of a channel live in (Kp+16)/4 registers for the whole workgroup, the B operand
-// is one conflict-free ds_read_b32 per MFMA from the staged (17/16-padded) input segment, D leaves as fully coalesced float4 stores.
+// is one conflict-free ds_read_b32 per MFMA from the staged (18/16-padded) input segment, D leaves as fully coalesced float4 stores.
 // Bound: MFMA f32 (157.3 TFLOP/s): 2*(Kp+16) flop per output sample.
 #include "common.hpp"
 
@@ -21,7 +21,8 @@ template <int KS> // K-steps of 4: Kp = 4 KS - 16
 __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__ x, long in_stride, const float* __restrict__ hist, const float* __restrict__ afrag,
                                                         float* __restrict__ y, long out_stride, long n) {
     constexpr int Kp   = 4 * KS - 16;
-    constexpr int NPAD = (kSeg + Kp) / 16 * 17;
+    constexpr int NPAD = (kSeg + Kp) / 16 * 18; // two pad floats per 16 samples: block stride 18 = 2 mod 32 banks, so the 32 lanes (16 blocks x 2 K
+                                                // offsets) of a ds_read_b32 group hit 32 different banks (stride 17 puts two of them on one)
     __shared__ float xs[NPAD];
     const int  c    = blockIdx.y;
     const long seg0 = (long)blockIdx.x * kSeg;
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__
     for (int s = tid; s < kSeg + Kp; s += 256) { // staged index s <-> input index seg0 - Kp + s; one pad float per 16 samples
         const long i = seg0 - Kp + s;
         const float v = i >= 0 ? (i < n ? xc[i] : 0.f) : hc[Kp + i];
-        xs[s + (s >> 4)] = v;
+        xs[s + 2 * (s >> 4)] = v;
     }
     float a[KS]; // A fragments: lane l holds A[j = l & 15][u = 4 ks + (l >> 4)] = b[Kp + j - u]
 #pragma unroll
@@ -44,13 +45,13 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__
     for (int pair = 0; pair < 2; ++pair) { // two independent accumulators hide the 40-cycle dependent MFMA latency
         const int ib0 = 16 * (4 * wave + 2 * pair), ib1 = ib0 + 16; // first 16-sample block of each tile
         f32x4     acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float* p0 = xs + 17 * (ib0 + col) + kq;
-        const float* p1 = xs + 17 * (ib1 + col) + kq;
+        const float* p0 = xs + 18 * (ib0 + col) + kq;
+        const float* p1 = xs + 18 * (ib1 + col) + kq;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             constexpr int dummy = 0;
             (void)dummy;
-            const int off = 4 * ks + (ks >> 2); // padded offset of u = 4 ks within the window
+            const int off = 4 * ks + 2 * (ks >> 2); // padded offset of u = 4 ks within the window
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p0[off], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p1[off], acc1, 0, 0, 0);
         }
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void fir_mfma_decim_kernel(const float* __rest
                                                               const float* __restrict__ afrag /*[D][KS][64]*/, float* __restrict__ y, long n_out, int D) {
     constexpr int Kp  = 4 * KS - 16;
     constexpr int SEG = 1024 * TPW;                  // outputs per workgroup
-    constexpr int ROW = (SEG + Kp) / 16 * 17 + 1;    // padded phase row (odd length: the D rows start on different banks)
+    constexpr int ROW = (SEG + Kp) / 16 * 17 + 1;    // padded phase row, one pad per 16 (odd length: the D rows start on different banks).  The
+                                                     // conflict-free stride 18 of fir_mfma_kernel costs the fourth workgroup per CU at D = 8 here (-4 %)
     extern __shared__ float xs[];                    // [D][ROW]
     const long seg0 = (long)blockIdx.x * SEG;        // first output of this workgroup
     const int  tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
