@@ -15,8 +15,14 @@
 // Cost: ~1.7 FFT equivalents (~140 flop/sample) instead of 1024 + 65 flop/sample; HBM traffic = 8 B in + 4 B out
 // (+ 2 KB of the previous frame's tail per 64 KB frame).
 //
-// One workgroup (256 lanes) = one frame.  Stockham radix 32 x 16 x 16; every lane holds 32 complex points.
-// LDS exchange layouts are padded (rows of 272 / 513 float2) so all ds_read_b64 / ds_write_b64 are conflict-free.
+// The same kernel body serves three outputs (template MODE): |FFT(y_f)|^2 with the rectangular window (the formula above), |FFT(w y_f)|^2
+// for any window (y_f recovered by an inverse transform, + e, x w, transformed again), and y_f itself (fir_filter<complex<float>> as a
+// fast convolution).
+//
+// One persistent workgroup of 512 lanes per CU, one frame at a time; Stockham radix 32 x 16 x 16, every lane holds 16 complex points
+// (the radix-32 pass pairs neighbouring lanes through DPP).  The next frame streams into a second LDS buffer by LDS-DMA while the
+// current one is transformed; e comes from the MFMA units.  Exchange layouts are padded (rows of 272 / 513 float2) so that all
+// ds_read_b64 / ds_write_b64 are bank-conflict-free.  DESIGN.md 3.1 has the phase table, the measurements and what was tried.
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fft_radix.hpp"
