@@ -11,6 +11,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <complex>
 
 namespace gr4 {
 
@@ -81,7 +82,7 @@ __device__ __forceinline__ void emit_bin(const FftOutputs& out, long frame, int 
         if (out.im) out.im[frame * N + k] = X.y;
     }
     if (out.real_input && k >= half) return; // computeHalfSpectrum: first N/2 bins, never rotated
-    const int ko = out.real_input ? k : ((k + half) & (N - 1));
+    const int ko = out.real_input ? k : (k + N - half) % N; // shiftSpectrum = std::rotate by N/2: bin N/2 comes first (odd N on the Bluestein path)
     if (out.mag) {
         float m = hypotf(X.x, X.y) * 2.f / (float)N;
         if (out.in_db) m = (m > 0.f) ? 20.f * log10f(m) : -FLT_MAX;
@@ -464,6 +465,85 @@ static int fft_fast_launch(const float* d_in, const float* d_window, const float
     return GR4HIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Sizes beyond one workgroup's LDS and sizes that are not a power of two run as short pipelines of the kernels above through HBM
+// scratch buffers (3 - 5x the traffic of the single-kernel path; these are the rarely used corners of the block, not its hot path).
+//
+// (1) N = N1 * 4096 with N1 in {4, 8, 16} (16384, 32768, 65536), the four-step decomposition n = 4096 n1 + n2, k = k1 + N1 k2:
+//       X[k1 + N1 k2] = sum_{n2} W_4096^{n2 k2} ( W_N^{n2 k1} sum_{n1} x[4096 n1 + n2] W_N1^{n1 k1} )
+//     fft_big_cols_kernel: window, N1-point DFT down the columns in registers, twiddle, A[f][k1][n2]  (lanes over n2: coalesced)
+//     fft_fast_kernel<12>: the N1 rows of every frame as 4096-point frames -> B[f][k1][k2]
+//     fft_emit_kernel:     bin k = k1 + N1 k2 from B, every requested output (LDS-free: consecutive lanes take consecutive k, the
+//                          N1-strided read of B stays inside 64-byte segments)
+template <int N1>
+__global__ __launch_bounds__(256) void fft_big_cols_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ twN /*W_N^j*/,
+                                                            float2* __restrict__ A, long n_frames, int real_input) {
+    constexpr int N2 = 4096, N = N1 * N2;
+    const long    gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long    f   = gid / N2;
+    const int     n2  = (int)(gid % N2);
+    if (f >= n_frames) return;
+    float2 v[N1];
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) {
+        const long i = f * N + (long)N2 * n1 + n2;
+        float2     x = real_input ? make_float2(in[i], 0.f) : reinterpret_cast<const float2*>(in)[i];
+        if (window) { const float w = window[N2 * n1 + n2]; x.x *= w; x.y *= w; }
+        v[n1] = x;
+    }
+    if constexpr (N1 == 16) fft16<1>(v);
+    else dft_small<N1>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < N1; ++k1) {
+        float2 y = v[N1 == 16 ? perm16(k1) : k1];
+        if (k1 > 0) y = cmul(y, twN[(n2 * k1) & (N - 1)]); // n2 k1 < N
+        A[(f * N1 + k1) * N2 + n2] = y;
+    }
+}
+
+// every requested output from a spectrum buffer: bin k of frame f sits at B[f * N + (k % n1) * (N / n1) + k / n1] (n1 = 1: natural order)
+__global__ __launch_bounds__(256) void fft_emit_kernel(const float2* __restrict__ B, FftOutputs out, int N, int n1, long n_frames) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long f   = gid / N;
+    const int  k   = (int)(gid % N);
+    if (f >= n_frames) return;
+    emit_bin(out, f, N, k, B[f * N + (long)(k % n1) * (N / n1) + k / n1]);
+}
+
+// (2) any other N <= 4096 (the reference's Bluestein branch, algorithm/.../fourier/fft.hpp:353-381): X[k] = c*[k] sum_n (x[n] w[n] c*[n]) c[k-n],
+//     c[n] = e^{+i pi n^2 / N}; the convolution is circular of length M = bit_ceil(2N - 1) <= 8192 and runs through the fast kernels:
+//     bluestein_pre -> FFT_M -> x FFT_M(c) and conjugate -> FFT_M (inverse through conjugation) -> bluestein_post (conj, 1/M, c*[k]) + outputs
+__global__ __launch_bounds__(256) void bluestein_pre_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ cconj,
+                                                             float2* __restrict__ a, int N, int M, long n_frames, int real_input) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long f   = gid / M;
+    const int  n   = (int)(gid % M);
+    if (f >= n_frames) return;
+    float2 v = make_float2(0.f, 0.f);
+    if (n < N) {
+        const long i = f * N + n;
+        v            = real_input ? make_float2(in[i], 0.f) : reinterpret_cast<const float2*>(in)[i];
+        if (window) { const float w = window[n]; v.x *= w; v.y *= w; }
+        v = cmul(v, cconj[n]);
+    }
+    a[f * M + n] = v;
+}
+__global__ __launch_bounds__(256) void bluestein_mul_kernel(float2* __restrict__ a, const float2* __restrict__ Bf, int M, long total) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const float2 p = cmul(a[gid], Bf[gid % M]);
+    a[gid]         = make_float2(p.x, -p.y); // conjugate: the next forward transform is the inverse one
+}
+__global__ __launch_bounds__(256) void bluestein_post_kernel(const float2* __restrict__ a, const float2* __restrict__ cconj, FftOutputs out, int N, int M, long n_frames) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long f   = gid / N;
+    const int  k   = (int)(gid % N);
+    if (f >= n_frames) return;
+    const float2 r = a[f * M + k];
+    const float  s = 1.f / (float)M;
+    emit_bin(out, f, N, k, cmul(make_float2(r.x * s, -r.y * s), cconj[k]));
+}
+
 // fft_common.hpp:71-89 unwrapPhase + :113-120 (deg, shift).  One workgroup per frame; wrap counts are integers, so a
 // parallel prefix sum of the per-bin jump decisions reproduces the sequential loop.
 __global__ void unwrap_kernel(const float* __restrict__ raw, float* __restrict__ out, int nout, int in_deg, int shift) {
@@ -496,7 +576,7 @@ __global__ void unwrap_kernel(const float* __restrict__ raw, float* __restrict__
         }
         float ph = (float)((double)r[k] + (double)c * (double)(2.f * pi));
         if (in_deg) ph = ph * 180.f * 0.318309886183790671538f;
-        const int ko = shift ? ((k + nout / 2) % nout) : k;
+        const int ko = shift ? ((k + nout - nout / 2) % nout) : k; // std::rotate by nout/2
         o[ko]        = ph;
     }
 }
@@ -539,6 +619,10 @@ struct gr4hip_fft {
     int          flags    = 0;
     FftPlanDev   plan{};
     DeviceBuffer d_window, d_tw, d_phase_raw;
+    // multi-kernel paths: kind 1 = N1 * 4096 four-step, kind 2 = Bluestein with M-point transforms
+    int          kind = 0, big_n1 = 0;
+    size_t       M    = 0;
+    DeviceBuffer d_twM, d_chirp, d_chirpF, d_scratchA, d_scratchB;
 };
 
 namespace gr4 {
@@ -591,6 +675,8 @@ int fft_launch(const FftPlanDev& plan, const float* d_in, const float* d_window,
 }
 } // namespace gr4
 
+static int fft_upload_bluestein(size_t N, size_t M, DeviceBuffer* d_cconj, DeviceBuffer* d_Bf);
+
 extern "C" {
 
 int gr4hip_fft_create(gr4hip_fft_t** out, int in_dtype, size_t fft_size, int window, int flags) {
@@ -603,8 +689,27 @@ int gr4hip_fft_create(gr4hip_fft_t** out, int in_dtype, size_t fft_size, int win
     f->N        = fft_size;
     f->window   = window;
     f->flags    = flags;
-    int rc      = fft_build_plan(fft_size, &f->plan);
-    if (!rc) rc = fft_upload_twiddles(fft_size, &f->d_tw);
+    int rc = GR4HIP_OK;
+    if (is_pow2(fft_size) && fft_size >= 2 && fft_size <= 8192) {
+        rc = fft_build_plan(fft_size, &f->plan);
+        if (!rc) rc = fft_upload_twiddles(fft_size, &f->d_tw);
+    } else if (is_pow2(fft_size) && fft_size <= 65536) { // 16384, 32768, 65536: four-step with 4096-point rows
+        f->kind   = 1;
+        f->big_n1 = (int)(fft_size / 4096);
+        f->M      = 4096;
+        rc        = fft_upload_twiddles(fft_size, &f->d_tw);       // W_N^j for the inter-step twiddles
+        if (!rc) rc = fft_upload_twiddles(4096, &f->d_twM);        // W_4096^j for the row transforms
+    } else if (fft_size >= 2 && fft_size <= 4096) {                 // Bluestein
+        f->kind = 2;
+        size_t M = 1;
+        while (M < 2 * fft_size - 1) M <<= 1;
+        f->M = M;
+        rc   = fft_upload_twiddles(M, &f->d_twM);
+        if (!rc) rc = fft_upload_bluestein(fft_size, M, &f->d_chirp, &f->d_chirpF);
+    } else {
+        set_error("fft: size %zu is outside the device paths (powers of two <= 65536, any size <= 4096)", fft_size);
+        rc = GR4HIP_UNSUPPORTED;
+    }
     if (!rc && window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR) {
         std::vector<float> w(fft_size);
         rc = make_window(window, w.data(), fft_size, 1.6f); // fft.hpp:141: create(_window, _windowType) -> default beta
@@ -613,6 +718,114 @@ int gr4hip_fft_create(gr4hip_fft_t** out, int in_dtype, size_t fft_size, int win
     }
     if (rc) { delete f; return rc; }
     *out = f;
+    return GR4HIP_OK;
+}
+
+// unwrap and ranges passes behind the transform kernels
+static int fft_finish(gr4hip_fft_t* f, const FftOutputs& o, float* d_phase_final, float* d_ranges, size_t n_frames, int nout, bool unwrap, bool fused_ranges, hipStream_t st) {
+    (void)f;
+    if (unwrap) {
+        const int bs = nout >= 256 ? 256 : 64;
+        hipLaunchKernelGGL(unwrap_kernel, dim3((unsigned)n_frames), dim3(bs), bs * sizeof(int), st, (const float*)o.phase_raw, d_phase_final, nout, o.in_deg,
+                           o.real_input ? 0 : 1);
+        GR4_LAUNCH_CHECK();
+    }
+    if (d_ranges && !fused_ranges) {
+        hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)n_frames, 4), dim3(256), 0, st, (const float*)o.mag, (const float*)d_phase_final, (const float*)o.re,
+                           (const float*)o.im, nout, d_ranges);
+        GR4_LAUNCH_CHECK();
+    }
+    return GR4HIP_OK;
+}
+
+// chirp tables of the Bluestein path: cconj[n] = e^{-i pi n^2 / N} (n < N) and the M-point transform of the wrapped chirp c[+-n]
+static int fft_upload_bluestein(size_t N, size_t M, DeviceBuffer* d_cconj, DeviceBuffer* d_Bf) {
+    std::vector<float>                cc(2 * N);
+    std::vector<std::complex<double>> b(M, {0.0, 0.0});
+    for (size_t n = 0; n < N; ++n) {
+        const double ang = M_PI * (double)((n * n) % (2 * N)) / (double)N; // n^2 mod 2N keeps the argument exact
+        cc[2 * n]        = (float)std::cos(ang);
+        cc[2 * n + 1]    = (float)-std::sin(ang);
+        const std::complex<double> c(std::cos(ang), std::sin(ang));
+        b[n] = c;
+        if (n) b[M - n] = c;
+    }
+    // FFT_M(b) in double: iterative radix-2 (M is a power of two), bit reversal first
+    for (size_t i = 1, j = 0; i < M; ++i) {
+        size_t bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(b[i], b[j]);
+    }
+    for (size_t len = 2; len <= M; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        for (size_t i = 0; i < M; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const std::complex<double> w(std::cos(ang * (double)k), std::sin(ang * (double)k));
+                const std::complex<double> u = b[i + k], v = b[i + k + len / 2] * w;
+                b[i + k]           = u + v;
+                b[i + k + len / 2] = u - v;
+            }
+    }
+    std::vector<float> bf(2 * M);
+    for (size_t k = 0; k < M; ++k) { bf[2 * k] = (float)b[k].real(); bf[2 * k + 1] = (float)b[k].imag(); }
+    int rc = d_cconj->ensure(cc.size() * sizeof(float));
+    if (!rc) rc = d_Bf->ensure(bf.size() * sizeof(float));
+    if (rc) return rc;
+    GR4_HIP_TRY(hipMemcpy(d_cconj->ptr, cc.data(), cc.size() * sizeof(float), hipMemcpyHostToDevice));
+    GR4_HIP_TRY(hipMemcpy(d_Bf->ptr, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+    return GR4HIP_OK;
+}
+
+// the multi-kernel paths (kind 1: four-step, kind 2: Bluestein); `o` already carries the output pointers and flags
+static int fft_run_multi(gr4hip_fft_t* f, const float* d_in, long n_frames, const FftOutputs& o, hipStream_t st) {
+    const long   N   = (long)f->N;
+    const float* win = static_cast<const float*>(f->d_window.ptr);
+    FftOutputs   spec{};
+    if (f->kind == 1) {
+        const int  n1    = f->big_n1;
+        const long total = n_frames * N;
+        int        rc    = f->d_scratchA.ensure((size_t)total * sizeof(float2));
+        if (!rc) rc = f->d_scratchB.ensure((size_t)total * sizeof(float2));
+        if (rc) return rc;
+        float2*    A    = static_cast<float2*>(f->d_scratchA.ptr);
+        const dim3 grid((unsigned)ceil_div(n_frames * 4096L, 256L));
+        const auto twN = static_cast<const float2*>(f->d_tw.ptr);
+        if (n1 == 4) hipLaunchKernelGGL(fft_big_cols_kernel<4>, grid, dim3(256), 0, st, d_in, win, twN, A, n_frames, o.real_input);
+        else if (n1 == 8) hipLaunchKernelGGL(fft_big_cols_kernel<8>, grid, dim3(256), 0, st, d_in, win, twN, A, n_frames, o.real_input);
+        else hipLaunchKernelGGL(fft_big_cols_kernel<16>, grid, dim3(256), 0, st, d_in, win, twN, A, n_frames, o.real_input);
+        GR4_LAUNCH_CHECK();
+        spec.spectrum = static_cast<float*>(f->d_scratchB.ptr);
+        rc            = fft_fast_launch<12>(reinterpret_cast<const float*>(A), nullptr, static_cast<const float2*>(f->d_twM.ptr), spec, n_frames * n1, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fft_emit_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, (const float2*)f->d_scratchB.ptr, o, (int)N, n1, n_frames);
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
+    const long M     = (long)f->M;
+    const long total = n_frames * M;
+    int        rc    = f->d_scratchA.ensure((size_t)total * sizeof(float2));
+    if (!rc) rc = f->d_scratchB.ensure((size_t)total * sizeof(float2));
+    if (rc) return rc;
+    float2*    a  = static_cast<float2*>(f->d_scratchA.ptr);
+    float2*    b  = static_cast<float2*>(f->d_scratchB.ptr);
+    const auto cc = static_cast<const float2*>(f->d_chirp.ptr);
+    const auto tw = static_cast<const float2*>(f->d_twM.ptr);
+    hipLaunchKernelGGL(bluestein_pre_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, d_in, win, cc, a, (int)N, (int)M, n_frames, o.real_input);
+    GR4_LAUNCH_CHECK();
+    FftPlanDev planM{};
+    rc = fft_build_plan((size_t)M, &planM);
+    if (rc) return rc;
+    spec.spectrum = reinterpret_cast<float*>(b);
+    rc            = fft_launch(planM, reinterpret_cast<const float*>(a), nullptr, tw, spec, n_frames, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bluestein_mul_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, b, (const float2*)f->d_chirpF.ptr, (int)M, total);
+    GR4_LAUNCH_CHECK();
+    spec.spectrum = reinterpret_cast<float*>(a);
+    rc            = fft_launch(planM, reinterpret_cast<const float*>(b), nullptr, tw, spec, n_frames, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bluestein_post_kernel, dim3((unsigned)ceil_div(n_frames * N, 256L)), dim3(256), 0, st, (const float2*)a, cc, o, (int)N, (int)M, n_frames);
+    GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
 
@@ -635,24 +848,18 @@ static int fft_run(gr4hip_fft_t* f, const void* d_in, size_t n_frames, FftOutput
         o.phase     = d_phase_final;
         o.phase_raw = nullptr;
     }
+    if (f->kind != 0) {
+        int rc = fft_run_multi(f, static_cast<const float*>(d_in), (long)n_frames, o, st);
+        if (rc) return rc;
+        return fft_finish(f, o, d_phase_final, d_ranges, n_frames, nout, unwrap, false, st);
+    }
     const bool fast         = f->N >= 256 && f->N <= 8192; // fft_fast_kernel sizes (all powers of two there)
     const bool fused_ranges = d_ranges && fast && !unwrap;  // the unwrapped phase only exists after unwrap_kernel
     o.ranges                = fused_ranges ? d_ranges : nullptr;
     int rc = fft_launch(f->plan, static_cast<const float*>(d_in), static_cast<const float*>(f->d_window.ptr), static_cast<const float2*>(f->d_tw.ptr), o,
                         (long)n_frames, st);
     if (rc) return rc;
-    if (unwrap) {
-        const int bs = nout >= 256 ? 256 : 64;
-        hipLaunchKernelGGL(unwrap_kernel, dim3((unsigned)n_frames), dim3(bs), bs * sizeof(int), st, (const float*)o.phase_raw, d_phase_final, nout, o.in_deg,
-                           o.real_input ? 0 : 1);
-        GR4_LAUNCH_CHECK();
-    }
-    if (d_ranges && !fused_ranges) {
-        hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)n_frames, 4), dim3(256), 0, st, (const float*)o.mag, (const float*)d_phase_final, (const float*)o.re,
-                           (const float*)o.im, nout, d_ranges);
-        GR4_LAUNCH_CHECK();
-    }
-    return GR4HIP_OK;
+    return fft_finish(f, o, d_phase_final, d_ranges, n_frames, nout, unwrap, fused_ranges, st);
 }
 
 int gr4hip_fft_process(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float* d_mag, float* d_phase, float* d_re, float* d_im, float* d_ranges,

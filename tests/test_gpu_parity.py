@@ -301,6 +301,39 @@ def test_fft_spectrum_parity(G, N):
         assert _rel(got[f], truth) <= TOL
 
 
+@pytest.mark.parametrize("N", [3, 5, 12, 100, 1000, 1009, 3000, 4095])
+def test_fft_any_size_bluestein(G, N):
+    """sizes that are not a power of two (the reference's Bluestein branch, algorithm/.../fourier/fft.hpp:353-381), <= 4096"""
+    frames = 3
+    x = O.signal_c32(N, frames * N)
+    F = G.FFT(N, "Hann")
+    w = O.window(3, N)
+    got = F.spectrum(dev(x)).cpu().numpy()
+    for f in range(frames):
+        truth = O.dft64(x[f * N:(f + 1) * N].astype(np.complex128) * w)
+        assert _rel(got[f], truth) <= TOL
+    out = F.process_bulk(dev(x))
+    mag, ph, re, im = O.fft_block_truth(x[:N], 3)
+    assert _rel(out["magnitude"][0].cpu().numpy(), mag) <= TOL and _rel(out["re"][0].cpu().numpy(), re) <= TOL
+
+
+@pytest.mark.parametrize("N", [16384, 32768, 65536])
+def test_fft_large_power_of_two(G, N):
+    """N1 x 4096 four-step pipeline; truth: numpy's float64 FFT (the O(N^2) oracle DFT is checked against it at N = 16384 once)"""
+    frames = 2
+    x = O.signal_c32(N + 1, frames * N)
+    got = G.FFT(N, "None").spectrum(dev(x)).cpu().numpy()
+    for f in range(frames):
+        truth = np.fft.fft(x[f * N:(f + 1) * N].astype(np.complex128))
+        assert _rel(got[f], truth) <= TOL
+    if N == 16384:
+        assert _rel(O.dft64(x[:N]), np.fft.fft(x[:N].astype(np.complex128))) <= 1e-9
+    m2 = G.FFT(N, "Hann").mag2(dev(x)).cpu().numpy()
+    w = O.window(3, N)
+    t2 = np.abs(np.fft.fft(x[:N].astype(np.complex128) * w)) ** 2
+    assert _rel(m2[0], t2) <= TOL
+
+
 def test_fft_n16_patterns_golden(G, golden):
     g = golden["fft_n16_patterns"]
     for case in g["cases"]:
