@@ -56,8 +56,9 @@ def test_status_strings_and_errors(L):
     h = C.c_void_p()
     rc = L.gr4hip_fir_create(C.byref(h), 3, None, 0, 1)  # bad dtype
     assert rc == -101 and b"dtype" in L.gr4hip_last_error()
-    rc = L.gr4hip_fft_create(C.byref(h), 10, 1000, 3, 0)  # non power of two -> caller keeps its CPU path
-    assert rc == -103
+    for size in (5000, 131072):  # not a power of two beyond the Bluestein range / beyond the four-step range -> caller keeps its CPU path
+        rc = L.gr4hip_fft_create(C.byref(h), 10, size, 3, 0)
+        assert rc == -103
     rc = L.gr4hip_math_nary(0, 8, None, 33, None, 1, None)
     assert rc == -101 and b"[1,32]" in L.gr4hip_last_error()
 
