@@ -10,6 +10,7 @@
 // Device blocks never fall back to the host path: a failing library call turns into work::Status::ERROR with the library's text.
 #pragma once
 #include <atomic>
+#include <cctype>
 #include <cstring>
 #include <mutex>
 #include <span>
@@ -133,11 +134,14 @@ template <typename op, typename T> constexpr int op_id() {
     else if constexpr (std::is_same_v<op, std::multiplies<T>>) return GR4HIP_MUL; else return GR4HIP_DIV;
 }
 
-inline int window_id(const std::string& w) {
-    if (w == "None") return GR4HIP_WIN_NONE;
-    if (w == "Rectangular") return GR4HIP_WIN_RECTANGULAR;
-    if (w == "Hann") return GR4HIP_WIN_HANN;
-    throw std::invalid_argument("unsupported window '" + w + "'");
+inline int window_id(const std::string& w) { // gr::algorithm::window::TypeNames (window.hpp:22-40), case-insensitive like magic_enum::enum_cast
+    static constexpr const char* names[] = {"none", "rectangular", "hamming", "hann", "hannexp", "blackman", "nuttall", "blackmanharris", "blackmannuttall",
+                                            "flattop", "exponential", "kaiser"};
+    std::string lw(w);
+    for (auto& c : lw) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+    for (int i = 0; i < 12; ++i)
+        if (lw == names[i]) return i; // == GR4HIP_WIN_*
+    throw std::invalid_argument("unknown window '" + w + "'");
 }
 
 // ---------------------------------------------------------------------------------------------- per-block offload at the seam
