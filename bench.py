@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=30, help="stream length per step and rank (default 2^30 = configs[1])")
     ap.add_argument("--log2-chunk", type=int, default=28, help="samples per launch")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 unfused, 2 fused time-domain, 3 fused frequency-domain")
+    ap.add_argument("--fanin-cus", type=int, default=32, help="N > 1: CUs left to the RCCL fan-in kernels (the fused kernel is persistent and fills every CU it gets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -103,6 +104,9 @@ def main():
     taps = (w.astype(np.float64) * 0.2 * np.sinc(0.2 * (k - (NTAPS - 1) / 2.0)))
     taps = (taps / taps.sum()).astype(np.float32)  # Hamming windowed-sinc, fc = 0.1, DC gain 1
     chain = G.Chain(taps, NFFT, "None", args.algo)
+    if world > 1 and args.fanin_cus > 0:  # the collective of chunk c runs beside the transform of chunk c+1 instead of behind it
+        n_cu = torch.cuda.get_device_properties(local).multi_processor_count
+        chain.set_max_workgroups(max(1, n_cu - args.fanin_cus))
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nchunks)]
     kernel_ms = []

@@ -265,6 +265,10 @@ class Chain(_Handle):
         check(lib().gr4hip_chain_get_algo(self._h, C.byref(a)), "Chain.algo")
         self.algo = a.value
 
+    def set_max_workgroups(self, n: int):
+        """cap the persistent grid of the fused kernels (0 = every CU); leaves CUs to kernels on other streams, e.g. an RCCL fan-in"""
+        check(lib().gr4hip_chain_set_max_workgroups(self._h, int(n)), "Chain.set_max_workgroups")
+
     def reset(self):
         check(lib().gr4hip_chain_reset(self._h), "Chain.reset")
 

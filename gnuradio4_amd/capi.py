@@ -80,6 +80,7 @@ SIGNATURES = {
     "gr4hip_chain_reset": (_i, [_vp]),
     "gr4hip_chain_process": (_i, [_vp, _vp, _sz, _vp, _psz, _vp]),
     "gr4hip_chain_get_algo": (_i, [_vp, _pi]),
+    "gr4hip_chain_set_max_workgroups": (_i, [_vp, C.c_uint]),
     "gr4hip_chain_destroy": (_i, [_vp]),
     "gr4hip_math_const": (_i, [_i, _i, _vp, _vp, _sz, _vp, _vp]),
     "gr4hip_math_nary": (_i, [_i, _i, _vp, _sz, _vp, _sz, _vp]),

@@ -11,6 +11,7 @@ int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_
 int  chain_fused_reset(ChainFused* c);
 int  chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st);
 void chain_fused_destroy(ChainFused* c);
+void chain_fused_set_max_workgroups(ChainFused* c, unsigned n);
 } // namespace gr4
 
 using namespace gr4;
@@ -76,6 +77,12 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
     rc = gr4hip_fir_process(c->fir, d_in, n, c->d_y.ptr, nullptr, stream);
     if (rc) return rc;
     return gr4hip_fft_mag2(c->fft, c->d_y.ptr, frames, d_mag2, stream);
+}
+
+int gr4hip_chain_set_max_workgroups(gr4hip_chain_t* c, unsigned n) {
+    GR4_REQUIRE(c, "chain_set_max_workgroups: null handle");
+    if (c->fused) chain_fused_set_max_workgroups(c->fused, n);
+    return GR4HIP_OK;
 }
 
 int gr4hip_chain_get_algo(const gr4hip_chain_t* c, int* algo) { GR4_REQUIRE(c && algo, "chain_algo: null"); *algo = c->algo; return GR4HIP_OK; }

@@ -512,6 +512,7 @@ struct ChainFused {
     size_t       ntaps = 0;
     DeviceBuffer d_H, d_twB, d_twC, d_taps, d_hist, d_win;
     bool         windowed = false;
+    unsigned     max_wg   = 0; // 0 = one workgroup on every CU
 };
 
 int chain_fused_supported(size_t ntaps, size_t fft_size, int window, int algo) {
@@ -612,7 +613,8 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         GR4_HIP_TRY(hipGetDevice(&dev));
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const unsigned grid = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu); // one resident workgroup per CU
+    const size_t   wgs  = c->max_wg ? std::min<size_t>(c->max_wg, (size_t)n_cu) : (size_t)n_cu;
+    const unsigned grid = (unsigned)std::min<size_t>(n_frames, wgs); // one resident workgroup per CU (or fewer: gr4hip_chain_set_max_workgroups)
     if (hist256) hipLaunchKernelGGL(chain_fd_kernel<kModeFir>, dim3(grid), dim3(kT), lds, st, a);
     else if (c->windowed) hipLaunchKernelGGL(chain_fd_kernel<kModeWinMag2>, dim3(grid), dim3(kT), lds, st, a);
     else hipLaunchKernelGGL(chain_fd_kernel<kModeMag2>, dim3(grid), dim3(kT), lds, st, a);
@@ -629,6 +631,7 @@ int chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, si
 }
 
 void chain_fused_destroy(ChainFused* c) { delete c; }
+void chain_fused_set_max_workgroups(ChainFused* c, unsigned n) { c->max_wg = n; }
 
 #ifdef GR4_FD_TIMING
 } // namespace gr4

@@ -186,6 +186,10 @@ int gr4hip_chain_reset(gr4hip_chain_t* chain);
 int gr4hip_chain_process(gr4hip_chain_t* chain, const void* d_in_c32, size_t n_samples, float* d_mag2, size_t* n_frames,
                          gr4hip_stream_t stream);
 int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
+/* The fused kernels are persistent: one workgroup per CU that takes ALL of the CU's registers and LDS, so nothing else (e.g. the RCCL
+ * kernels of a fan-in collective on another stream) runs beside them.  n > 0 caps the grid at n workgroups and leaves the other CUs free;
+ * 0 = all CUs (default).  No effect on the unfused path. */
+int gr4hip_chain_set_max_workgroups(gr4hip_chain_t* chain, unsigned n);
 int gr4hip_chain_destroy(gr4hip_chain_t* chain);
 
 /* ------------------------------------------------------------------------------------------------ a11/a12/a13

@@ -425,6 +425,19 @@ def test_fft_linearity_and_roundtrip_properties(G):
 
 
 # ------------------------------------------------------------------ headline chain
+def test_chain_max_workgroups_is_only_a_schedule(G):
+    """capping the persistent grid (CUs left to an RCCL fan-in on another stream) changes which CU takes which frame, nothing else"""
+    N, frames = 8192, 40
+    b = O.design_taps_hamming_lowpass(256, 0.1)
+    x = dev(O.signal_c32(9, frames * N))
+    for window in ("None", "Hann"):
+        ref = G.Chain(b, N, window).process_bulk(x)
+        for cap in (1, 7, 224):
+            ch = G.Chain(b, N, window)
+            ch.set_max_workgroups(cap)
+            assert torch.equal(ch.process_bulk(x), ref)
+
+
 def test_chain_fused_input_alignment(G):
     """the fused kernels stage frames with 16-byte LDS-DMA pieces: an 8-byte-aligned span must give the same spectra"""
     N, frames = 8192, 5
