@@ -23,6 +23,22 @@ ALGO_BYTES_PER_SAMPLE = 12.0  # 8 B complex<float> in + 4 B float mag2 out (SURV
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _usable_cores() -> int:
+    """hardware threads this process may actually use: affinity mask and cgroup CPU quota, not just os.cpu_count()"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(target_seconds: float = 12.0):
     """Reference-faithful CPU path (oracle, -O3 -march=native like core/benchmarks/CMakeLists.txt:19-23) on a bounded
     sample of the same workload.  Single chain == one thread (GR4 never splits one block chain across threads)."""
@@ -47,7 +63,7 @@ def cpu_baseline(target_seconds: float = 12.0):
     # chain per core.  Same oracle, one chain per hardware thread (ctypes releases the GIL), a few seconds.
     try:
         from concurrent.futures import ThreadPoolExecutor
-        ncore = os.cpu_count() or 1
+        ncore = _usable_cores()
         per = max(8, min(frames, 384, int(3.0 / (dt / frames))))  # <= ~3 s and <= 12 MB of output per thread
         xs = [O.signal_c32(42 + c, per * NFFT) for c in range(min(ncore, 8))]
         t0 = time.perf_counter()
