@@ -280,12 +280,13 @@ struct PowerSpectrum : Block<PowerSpectrum<T>, Resampling<1024, 1024, false>> {
         _window.assign(fftSize, value_type(1));
         if (window == "Hann")
             for (std::size_t i = 0; i < fftSize; ++i) _window[i] = value_type(.5) - value_type(.5) * std::cos(value_type(2) * std::numbers::pi_v<value_type> / value_type(fftSize - 1) * value_type(i));
-        else if (window != "None" && window != "Rectangular") throw std::invalid_argument("PowerSpectrum: window must be None, Rectangular or Hann");
+        else if (window != "None" && window != "Rectangular") _window.clear(); // the other ten windows exist on the device path only (gr4hip_window_create)
     }
     // host path: iterative radix-2 in double (plumbing only)
     work::Status processBulk(std::span<const T> input, std::span<value_type> output) {
         const std::size_t N = fftSize;
         if (_window.size() != N) settingsChanged({}, {});
+        if (_window.size() != N) throw std::invalid_argument("PowerSpectrum: the host path implements None, Rectangular and Hann; window '" + window + "' needs compute_domain gpu:hip");
         std::vector<std::complex<double>> v(N);
         for (std::size_t f = 0; f + N <= input.size(); f += N) {
             for (std::size_t i = 0, j = 0; i < N; ++i) {

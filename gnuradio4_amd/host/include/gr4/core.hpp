@@ -14,6 +14,7 @@
 #include <complex>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <map>
@@ -181,6 +182,12 @@ struct find_resampling<A, R...> {
 struct EdgeBufferBase {
     virtual ~EdgeBufferBase() = default;
     bool producer_done = false; // upstream returned DONE: remaining samples are the last ones
+    // type-erased element IO (used by device runs that replace typed blocks at both ends of an edge)
+    [[nodiscard]] virtual std::size_t elem_bytes() const noexcept           = 0;
+    [[nodiscard]] virtual std::size_t available_items() const noexcept      = 0;
+    [[nodiscard]] virtual std::size_t free_items() const noexcept           = 0;
+    virtual void                      read_items(void* dst, std::size_t n)  = 0; // copy + consume
+    virtual void                      write_items(const void* src, std::size_t n) = 0; // copy + publish
 };
 template <typename T>
 struct EdgeBuffer final : EdgeBufferBase {
@@ -200,6 +207,17 @@ struct EdgeBuffer final : EdgeBufferBase {
     }
     void publish(std::size_t n) noexcept { tail += n; }
     void consume(std::size_t n) noexcept { head += n; }
+    [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
+    [[nodiscard]] std::size_t available_items() const noexcept override { return available(); }
+    [[nodiscard]] std::size_t free_items() const noexcept override { return free_space(); }
+    void read_items(void* dst, std::size_t n) override {
+        std::memcpy(dst, read_span(n).data(), n * sizeof(T));
+        consume(n);
+    }
+    void write_items(const void* src, std::size_t n) override {
+        std::memcpy(write_span(n).data(), src, n * sizeof(T));
+        publish(n);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------- ports (Port.hpp)
@@ -311,6 +329,9 @@ struct BlockModel {
     virtual bool                            attach_input(std::string_view in_port, std::shared_ptr<EdgeBufferBase> edge) = 0;
     virtual std::vector<std::shared_ptr<EdgeBufferBase>> input_edges()                                                   = 0;
     virtual std::vector<std::shared_ptr<EdgeBufferBase>> output_edges()                                                  = 0;
+    // a gr::hip::Stage for this block's current settings, or null when the block type has no device kernel (gr4/hip.hpp; type-erased here
+    // so that this header stays free of the device layer)
+    virtual std::shared_ptr<void> make_device_stage() { return nullptr; }
 };
 
 // ---------------------------------------------------------------------------------------------- Block<Derived, Args...> (Block.hpp)
@@ -522,6 +543,10 @@ struct BlockWrapper final : BlockModel {
             }
         });
         return ok;
+    }
+    std::shared_ptr<void> make_device_stage() override {
+        if constexpr (requires { hip::Kernel<T>::make_stage(block); }) return std::shared_ptr<void>(hip::Kernel<T>::make_stage(block)); // deleter captured here
+        else return nullptr;
     }
     std::vector<std::shared_ptr<EdgeBufferBase>> input_edges() override {
         std::vector<std::shared_ptr<EdgeBufferBase>> v;

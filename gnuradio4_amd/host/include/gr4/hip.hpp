@@ -316,13 +316,13 @@ class DeviceRun final : public BlockModel {
     std::string     _desc;
 
 public:
-    template <typename TIn, typename TOut>
-    DeviceRun(std::vector<std::unique_ptr<Stage>> stages, std::shared_ptr<EdgeBuffer<TIn>> in, std::shared_ptr<EdgeBuffer<TOut>> out, ComputeDomain d)
-        : _stages(std::move(stages)), _in_edge(in), _out_edge(out), _domain(std::move(d)), _in_bytes(sizeof(TIn)), _out_bytes(sizeof(TOut)) {
-        _avail = [in] { return in->available(); };
-        _space = [out] { return out->free_space(); };
-        _read  = [in](void* dst, std::size_t n) { std::memcpy(dst, in->read_span(n).data(), n * sizeof(TIn)); in->consume(n); };
-        _write = [out](const void* src, std::size_t n) { std::memcpy(out->write_span(n).data(), src, n * sizeof(TOut)); out->publish(n); };
+    // the edges at both ends are used through their type-erased element IO: a run does not need to know the sample types
+    DeviceRun(std::vector<std::unique_ptr<Stage>> stages, std::shared_ptr<EdgeBufferBase> in, std::shared_ptr<EdgeBufferBase> out, ComputeDomain d)
+        : _stages(std::move(stages)), _in_edge(in), _out_edge(out), _domain(std::move(d)), _in_bytes(in->elem_bytes()), _out_bytes(out->elem_bytes()) {
+        _avail = [in] { return in->available_items(); };
+        _space = [out] { return out->free_items(); };
+        _read  = [in](void* dst, std::size_t n) { in->read_items(dst, n); };
+        _write = [out](const void* src, std::size_t n) { out->write_items(src, n); };
         for (auto& s : _stages) { _in_chunk = std::max(_in_chunk, s->in_chunk); _desc += std::string(_desc.empty() ? "" : " -> ") + std::string(s->kind()); }
         check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
         check(gr4hip_stream_create(&_stream), "gr4hip_stream_create");
@@ -419,6 +419,95 @@ DeviceRun& fuse_chain(Graph& g, First& first, Rest&... rest) {
     }
     blocks = std::move(kept);
     return ref;
+}
+
+// ---------------------------------------------------------------------------------------------- fusion planner
+// The run-time counterpart of the reference's compile-time Merge<> (BlockMerging.hpp:136-320): every maximal chain of blocks that
+//   * ask for this device (compute_domain "gpu:hip[:i]", all the same),  * have a device kernel (BlockModel::make_device_stage), and
+//   * are wired 1:1 (one input edge, one output edge, the edge between two members has no other reader)
+// is replaced by ONE DeviceRun: samples enter HBM once, the stages run back to back on one stream, and adjacent stages with a fused
+// kernel collapse into it (fir_filter<complex<float>> -> PowerSpectrum = gr4hip_chain, any window).  Returns the runs it created.
+inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2) {
+    auto& blocks = g.blocks();
+    const auto eligible = [](BlockModel& b) {
+        const auto& d = b.compute_domain();
+        return d.is_device() && (d.backend.empty() || d.backend == "hip") && b.input_edges().size() == 1 && b.output_edges().size() == 1 &&
+               b.input_edges()[0] && b.output_edges()[0];
+    };
+    const auto readers = [&](const std::shared_ptr<EdgeBufferBase>& e) {
+        std::size_t n = 0;
+        for (auto& b : blocks)
+            for (auto& in : b->input_edges()) n += in == e;
+        return n;
+    };
+    const auto consumer = [&](const std::shared_ptr<EdgeBufferBase>& e) -> BlockModel* {
+        for (auto& b : blocks)
+            for (auto& in : b->input_edges())
+                if (in == e) return b.get();
+        return nullptr;
+    };
+    const auto producer = [&](const std::shared_ptr<EdgeBufferBase>& e) -> BlockModel* {
+        for (auto& b : blocks)
+            for (auto& out : b->output_edges())
+                if (out == e) return b.get();
+        return nullptr;
+    };
+    std::vector<std::vector<BlockModel*>> chains;
+    std::vector<BlockModel*>              taken;
+    for (auto& bp : blocks) {
+        BlockModel* b = bp.get();
+        if (!eligible(*b) || std::find(taken.begin(), taken.end(), b) != taken.end()) continue;
+        // walk back to the head of the chain this block belongs to
+        const auto joins = [&](BlockModel* up, BlockModel* down) {
+            return up && down && eligible(*up) && eligible(*down) && up->output_edges()[0] == down->input_edges()[0] && readers(up->output_edges()[0]) == 1 &&
+                   up->compute_domain().index == down->compute_domain().index;
+        };
+        BlockModel* head = b;
+        while (BlockModel* up = producer(head->input_edges()[0]))
+            if (joins(up, head)) head = up; else break;
+        std::vector<BlockModel*> chain{head};
+        while (BlockModel* down = consumer(chain.back()->output_edges()[0]))
+            if (joins(chain.back(), down)) chain.push_back(down); else break;
+        for (auto* m : chain) taken.push_back(m);
+        if (chain.size() >= min_blocks) chains.push_back(std::move(chain));
+    }
+    // a stage created through the type-erased hook, owned by the run
+    struct Holder final : Stage {
+        std::shared_ptr<Stage> s;
+        explicit Holder(std::shared_ptr<Stage> p) : s(std::move(p)) { in_bytes = s->in_bytes; out_bytes = s->out_bytes; in_chunk = s->in_chunk; out_chunk = s->out_chunk; }
+        int              enqueue(const void* i, std::size_t n, void* o, std::size_t* no, gr4hip_stream_t st) override { return s->enqueue(i, n, o, no, st); }
+        std::string_view kind() const override { return s->kind(); }
+    };
+    std::vector<DeviceRun*> runs;
+    for (auto& chain : chains) {
+        std::vector<std::shared_ptr<Stage>> made;
+        for (auto* m : chain) made.push_back(std::static_pointer_cast<Stage>(m->make_device_stage()));
+        if (std::find(made.begin(), made.end(), nullptr) != made.end()) continue; // a member without a device kernel: leave the chain to the per-block seam
+        std::vector<std::unique_ptr<Stage>> fused;
+        for (std::size_t i = 0; i < made.size(); ++i) {
+            auto fir  = std::dynamic_pointer_cast<FirStage<std::complex<float>>>(made[i]);
+            auto spec = i + 1 < made.size() ? std::dynamic_pointer_cast<PowerSpectrumStage>(made[i + 1]) : nullptr;
+            if (fir && spec) { // peephole: the pair has a fused kernel
+                fused.push_back(std::make_unique<ChainStage>(fir->taps, spec->N, spec->window));
+                ++i;
+            } else {
+                fused.push_back(std::make_unique<Holder>(made[i]));
+            }
+        }
+        auto  run = std::make_unique<DeviceRun>(std::move(fused), chain.front()->input_edges()[0], chain.back()->output_edges()[0], chain.front()->compute_domain());
+        auto* ref = run.get();
+        std::vector<std::unique_ptr<BlockModel>> kept;
+        bool                                     placed = false;
+        for (auto& bp : blocks) {
+            const bool member = std::find(chain.begin(), chain.end(), bp.get()) != chain.end();
+            if (member && !placed) { kept.push_back(std::move(run)); placed = true; }
+            if (member) g.retired().push_back(std::move(bp)); // keep the objects alive: callers hold references to them
+            else kept.push_back(std::move(bp));
+        }
+        blocks = std::move(kept);
+        runs.push_back(ref);
+    }
+    return runs;
 }
 
 } // namespace gr::hip

@@ -89,6 +89,42 @@ int main(int argc, char** argv) {
         if (sink._samples.size() != (x.size() / N) * N) ++errors;
         dump(out + (fused ? "_chain.bin" : "_chain_hann.bin"), sink._samples);
     }
+    { // 3b. the planner finds the device chains by itself: (a) fir -> PowerSpectrum collapses into the fused kernel, (b) MultiplyConst -> fir_filter<float>
+      //     becomes a two-stage run on one stream, (c) a host block between two device blocks splits the chain
+        Graph g;
+        auto& src  = g.emplaceBlock<testing::VectorSource<std::complex<float>>>();
+        src.values = x;
+        auto& fir  = g.emplaceBlock<filter::fir_filter<std::complex<float>>>({{"b", tapsd}, {"compute_domain", "gpu:hip:0"s}});
+        auto& spec = g.emplaceBlock<blocks::fft::PowerSpectrum<std::complex<float>>>({{"fftSize", std::int64_t(N)}, {"window", "BlackmanHarris"s}, {"compute_domain", "gpu:hip:0"s}});
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        g.connect<"out", "in">(src, fir);
+        g.connect<"out", "in">(fir, spec);
+        g.connect<"out", "in">(spec, sink);
+        auto& fsrc  = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(200000)}});
+        fsrc.values = {1.f, -2.f, 3.f, 0.5f, 0.25f};
+        auto& mul   = g.emplaceBlock<blocks::math::MultiplyConst<float>>({{"value", 2.0}, {"compute_domain", "gpu:hip:0"s}});
+        auto& ffir  = g.emplaceBlock<filter::fir_filter<float>>({{"b", std::vector<double>{0.5, 0.25, 0.25}}, {"compute_domain", "gpu:hip:0"s}});
+        auto& host  = g.emplaceBlock<blocks::math::AddConst<float>>({{"value", 1.0}}); // stays on the host
+        auto& mul2  = g.emplaceBlock<blocks::math::MultiplyConst<float>>({{"value", 3.0}, {"compute_domain", "gpu:hip:0"s}});
+        auto& fsink = g.emplaceBlock<testing::VectorSink<float>>();
+        g.connect<"out", "in">(fsrc, mul);
+        g.connect<"out", "in">(mul, ffir);
+        g.connect<"out", "in">(ffir, host);
+        g.connect<"out", "in">(host, mul2);
+        g.connect<"out", "in">(mul2, fsink);
+        const auto runs = hip::plan(g);
+        std::printf("planner: %zu runs:", runs.size());
+        for (auto* r : runs) std::printf(" [%s]", std::string(r->description()).c_str());
+        std::printf("\n");
+        if (runs.size() != 2 || runs[0]->description() != "chain_fir_fft_mag2" || runs[1]->description() != "math_const -> fir_f32") ++errors;
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        if (const auto r = sched.runAndWait(); !r) { std::cerr << "planned graph: " << r.error().message << "\n"; ++errors; }
+        dump(out + "_chain_planned_bh.bin", sink._samples);
+        dump(out + "_planned_float.bin", fsink._samples);
+        hip::release(mul2);
+    }
+
     { // 4. the GPU-resident BufferLike ring: spans that wrap the physical end stay contiguous; two readers, back-pressure
         hip::CircularBuffer<float> ring(1 << 16);
         auto                       w = ring.new_writer();

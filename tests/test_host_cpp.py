@@ -76,6 +76,15 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
         got = np.fromfile(tmp_path / name, np.float32)
         t, _ = O.chain(b, x, N, wid, truth=True)
         assert len(got) == frames * N and rel(got, t) <= 1e-5, name
+    # the planner's runs: fused chain with a Blackman-Harris window, and MultiplyConst -> fir_filter<float> | host AddConst | MultiplyConst
+    assert "planner: 2 runs: [chain_fir_fft_mag2] [math_const -> fir_f32]" in r.stdout
+    got = np.fromfile(tmp_path / "o_chain_planned_bh.bin", np.float32)
+    t, _ = O.chain(b, x, N, [w.lower() for w in O.WINDOWS].index("blackmanharris"), truth=True)
+    assert len(got) == frames * N and rel(got, t) <= 1e-5
+    pf = np.fromfile(tmp_path / "o_planned_float.bin", np.float32)
+    xin = np.resize(np.array([1.0, -2.0, 3.0, 0.5, 0.25], np.float64), 200000) * 2.0
+    want = (np.convolve(xin, [0.5, 0.25, 0.25])[:200000] + 1.0) * 3.0
+    assert len(pf) == 200000 and np.max(np.abs(pf - want)) <= 1e-5
     m = np.fromfile(tmp_path / "o_math.bin", np.int32)
     src = np.resize(np.array([2147483647, -5, 7, 123456789], np.int32), 100000)
     assert np.array_equal(m, (src.astype(np.int64) * 3).astype(np.int32))  # wrap-around like the C++ int32 product
