@@ -122,6 +122,13 @@ xr = xc.view(torch.float32)
 dec = G.Decimator(10)
 t = timeit(lambda: dec.process_bulk(xr))
 res["Decimator<float> decim 10"] = {"Msamples/s (input)": round(xr.numel() / t / 1e6, 1), "note": "strided 4-byte reads: every input cache line is touched, 1/10 of it used"}
+# the one filter the reference publishes a number for: 1-pole IIR low-pass y[n] = (1 - a) x[n] + a y[n-1] (docs/USER_API_Connecting_Blocks.md:209-222:
+# 994 k/s through a feedback edge, 113 M/s merged, 656 M/s as a constexpr loop, unstated CPU)
+pole = G.iir_filter([[0.05]], [[1.0, -0.95]])
+yp = torch.empty_like(xr)
+t = timeit(lambda: pole.process_bulk(xr, yp))
+res["1-pole IIR low-pass (reference FeedbackMerge benchmark shape)"] = {"Msamples/s": round(xr.numel() / t / 1e6, 1), "alg_GB/s": round(xr.numel() * 8 / t / 1e9, 1),
+                                                                       "reference_published": "113 M/s merged, 656 M/s constexpr (unstated CPU)"}
 rot = G.Rotator(0.6283)
 nr = 1 << 24
 t = timeit(lambda: rot.process_bulk(xc[:nr]), reps=2)
