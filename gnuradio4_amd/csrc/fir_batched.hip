@@ -49,8 +49,6 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__
         const float* p1 = xs + 18 * (ib1 + col) + kq;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int off = 4 * ks + 2 * (ks >> 2); // padded offset of u = 4 ks within the window
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p0[off], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p1[off], acc1, 0, 0, 0);

@@ -493,7 +493,6 @@ template <typename T>
 struct BlockWrapper final : BlockModel {
     T                block{};
     std::string      _type;
-    ComputeDomain    _dummy{};
     explicit BlockWrapper(std::string type) : _type(std::move(type)) {}
     work::Result         work(std::size_t requested) override { return block.work(requested); }
     std::string_view     name() const override { return block.name; }
