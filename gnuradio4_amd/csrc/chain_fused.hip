@@ -177,17 +177,14 @@ __device__ __forceinline__ void dma_tail(const float2* __restrict__ src, float2*
 #define GR4_FULL_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // pass A on an image already in LDS, in place (the second and third transforms of the windowed kernel)
-__device__ __forceinline__ void passA_inplace(float2* S, int par, int n0, float sgn) {
+__device__ __forceinline__ void passA_inplace(float2* S, const float2 (&twA)[16], int par, int n0, float sgn) {
     float2 v[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) v[m] = S[addrA(2 * m + par, n0)];
     fft16<1>(v);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
-        float2       u  = v[perm16(k1)];
-        const float2 uw = k1 == 0 ? u : cmul(u, w32(k1));
-        u.x = par ? uw.x : u.x;
-        u.y = par ? uw.y : u.y;
+        const float2 u = k1 == 0 ? v[perm16(k1)] : cmul(v[perm16(k1)], twA[k1]); // twA: W_32^k1 on the odd lane, 1 on the even lane
         const float2 q = make_float2(lane_xor1(u.x), lane_xor1(u.y));
         S[addrA(k1 + 16 * par, n0)] = make_float2(fmaf(sgn, u.x, q.x), fmaf(sgn, u.y, q.y));
     }
@@ -240,6 +237,11 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         twBr[r] = WIN ? make_float2(0.f, 0.f) : a.twB[r * 32 + kb0]; // WIN: pass-B twiddles come from the LDS table twBl instead
         twCr[r] = a.twC[r * 512 + t0];
     }
+    // pass-A pair twiddle as a per-lane value (W_32^k1 on the odd lane of a pair, 1 on the even one): one multiply for both lanes instead
+    // of multiply + two selects
+    float2 twA[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) twA[k1] = (t0 & 1) ? w32(k1) : make_float2(1.f, 0.f);
     // WIN: the correction FIR splits K over 4 wave pairs (one of each pair takes the real tile, the other the imaginary one), so only
     // half of P is used; the other half holds the pass-B twiddle table
     float2* twBl = reinterpret_cast<float2*>(P + 4 * 2 * 256);
@@ -308,10 +310,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 // X[k1] = E + W O (even lane), X[k1 + 16] = E - W O (odd lane), W = W_32^k1
-                float2       u  = v[perm16(k1)];
-                const float2 uw = k1 == 0 ? u : cmul(u, w32(k1));
-                u.x = par ? uw.x : u.x;
-                u.y = par ? uw.y : u.y;
+                const float2 u = k1 == 0 ? v[perm16(k1)] : cmul(v[perm16(k1)], twA[k1]); // twA: W_32^k1 on the odd lane, 1 on the even lane
                 const float2 q = make_float2(lane_xor1(u.x), lane_xor1(u.y));
                 S[addrA(k1 + 16 * par, n0)] = make_float2(fmaf(sgn, u.x, q.x), fmaf(sgn, u.y, q.y));
             }
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             for (int q = 0; q < 16; ++q) S[addrA((t >> 8) + 2 * q, t & 255)] = make_float2(X[perm16(q)].x, -X[perm16(q)].y);
             GR4_LDS_BARRIER();
             GR4_PHASE_FENCE();
-            passA_inplace(S, par, n0, sgn);
+            passA_inplace(S, twA, par, n0, sgn);
             GR4_LDS_BARRIER();
             GR4_PHASE_FENCE();
 #pragma unroll
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                 GR4_LDS_BARRIER();
                 GR4_PHASE_FENCE();
                 // ------------------------------------------------------------------ FFT(w y_f), |.|^2
-                passA_inplace(S, par, n0, sgn);
+                passA_inplace(S, twA, par, n0, sgn);
                 GR4_LDS_BARRIER();
                 GR4_PHASE_FENCE();
     #pragma unroll
