@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--log2-chunk", type=int, default=28, help="samples per launch")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 unfused, 2 fused time-domain, 3 fused frequency-domain")
     ap.add_argument("--fanin-cus", type=int, default=32, help="N > 1: CUs left to the RCCL fan-in kernels (the fused kernel is persistent and fills every CU it gets)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check of the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -99,9 +100,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % torch.cuda.device_count() if args.dist_backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.dist_backend)
 
     n = 1 << args.log2_samples
     chunk = min(1 << args.log2_chunk, n)
@@ -141,7 +146,8 @@ def main():
             if world > 1:  # fan-in combiner (math::Add over channels) as reduce_scatter, async on RCCL's stream
                 works.append(fanin.fan_in_sum(os_, rs_out[c], async_op=True)[1])
         for wk in works:
-            wk.wait()
+            if wk is not None:
+                wk.wait()
 
     def fence():
         if world > 1:
@@ -184,7 +190,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, 2^{args.log2_samples}-sample stream per GPU "
                                    f"(BASELINE.json configs[1]), rectangular window, {nchunks} launches of 2^{args.log2_chunk} samples"
-                                   + (f"; {world} channels, RCCL reduce_scatter fan-in sum (configs[4] shape)" if world > 1 else ""),
+                                   + (f"; {world} channels, {'RCCL reduce_scatter' if args.dist_backend == 'nccl' else args.dist_backend + ' all_reduce (functional check only)'} fan-in sum (configs[4] shape)" if world > 1 else ""),
                        "chain_algo": algo_names.get(chain.algo, str(chain.algo)), "parallelism": f"{world} independent channel(s), 1 per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": algo_names.get(chain.algo, str(chain.algo)),
