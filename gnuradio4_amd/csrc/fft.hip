@@ -1,10 +1,12 @@
-// fft.hip -- generic power-of-two streaming FFT block kernels for gfx950 (LDS-resident Stockham, radix 8/4/2).
+// fft.hip -- the streaming FFT block on gfx950: C-ABI (gr4hip_fft_*), the generic LDS-resident Stockham kernel (radix 8/4/2, any power of
+// two <= 8192), the multi-kernel paths (four-step for 16384..65536, Bluestein for other sizes <= 4096), phase unwrap and DataSet ranges.
+// The compile-time-plan kernels for N = 256..8192 (the fast path) are in fft_kernels.hpp.
 //
 // Replaces gr::blocks::fft::FFT<T>::processBulk (blocks/fourier/.../fft.hpp:147-171): window -> forward DFT
 // (algorithm/.../fourier/fft.hpp:113-153) -> magnitude / phase / Re / Im (fft_common.hpp:20-123), many frames per
 // launch instead of one frame per work() call.  One workgroup owns whole frames: the frame is read from HBM once
 // (window fused into the load), all passes run in LDS, and every requested output is written once, coalesced.
-// The fused FIR->FFT->mag2 headline kernels live in chain.hip; this file is the any-size / any-window path.
+// The fused FIR->FFT->mag2 kernels live in chain_fused.hip.
 #include "fft_kernels.hpp"
 
 namespace gr4 {

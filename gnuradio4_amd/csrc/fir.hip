@@ -9,6 +9,8 @@
 //     one ds_read_b128 of samples + one broadcast ds_read of taps feeds 32 (real) / 16 (complex) FMAs;
 //   * complex<float> data x real taps is the same kernel on the interleaved float view with a tap stride of 2.
 // Bound: FP32 FMA rate (2K flop per real output sample), not HBM -- see DESIGN.md "fir_poly".
+// Long spans leave this kernel: float 33..256 taps and polyphase decimators go to the MFMA kernels of fir_batched.hip, complex <= 256 taps
+// to the frequency-domain kernel of chain_fused.hip (gr4hip_fir_process below decides).
 #include "common.hpp"
 #include "fir_window.hpp"
 
