@@ -288,6 +288,16 @@ int fft_upload_twiddles(size_t N, DeviceBuffer* buf) {
 }
 
 int fft_launch(const FftPlanDev& plan, const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
+    if (o.real_input && !o.spectrum && !o.mag2) { // real frames of 2N samples as N complex points + split (half the butterflies)
+        switch (plan.N) {
+        case 512: return fft_fast_launch<8, true>(d_in, d_window, d_tw, o, n_frames, st);
+        case 1024: return fft_fast_launch<9, true>(d_in, d_window, d_tw, o, n_frames, st);
+        case 2048: return fft_fast_launch<10, true>(d_in, d_window, d_tw, o, n_frames, st);
+        case 4096: return fft_fast_launch<11, true>(d_in, d_window, d_tw, o, n_frames, st);
+        case 8192: return fft_fast_launch<12, true>(d_in, d_window, d_tw, o, n_frames, st);
+        default: break;
+        }
+    }
     switch (plan.N) { // compile-time plans; everything else takes the generic radix-8/4/2 kernel
     case 256: return fft_fast_launch_256(d_in, d_window, d_tw, o, n_frames, st);
     case 512: return fft_fast_launch<9>(d_in, d_window, d_tw, o, n_frames, st);

@@ -112,10 +112,16 @@ __device__ __forceinline__ void dft_small(float2* v) {
     else { float2(&a)[8] = *reinterpret_cast<float2(*)[8]>(v); fft8(a); }
 }
 
-template <int LOG2N>
+// REAL = true: a frame of 2N REAL samples is transformed as N complex points z[n] = x[2n] + i x[2n+1] (the float array read as float2,
+// window pairs likewise) and split afterwards:  X[k] = (Z[k] + conj Z[N-k]) / 2 + W_2N^k (Z[k] - conj Z[N-k]) / (2i),  k = 0 .. N
+// -- half the butterflies of the "imaginary part = 0" form.  tw is then the table of W_2N^j (every second entry is W_N^j), and the
+// outputs follow the real-input conventions of the block: magnitude / phase = bins 0..N-1, Re / Im = bins N..2N-1 = conj of bins N..1.
+template <int LOG2N, bool REAL = false>
 __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ tw,
                                                           FftOutputs out, long n_frames) {
     constexpr int N = 1 << LOG2N, T = N / 16, FPB = 512 / T, NP = N + N / 32, HALF = N / 2;
+    constexpr int TWS = REAL ? 2 : 1; // stride of W_N^j in the table
+    static_assert(!REAL || LOG2N <= 12, "the real-input split is implemented for the 16 x 16 x R3 plans");
     constexpr int R3  = N >= 4096 ? 16 : N / 256; // 256 -> 1 (no third pass)
     constexpr int R4  = N / (256 * R3);           // 8192 -> 2
     constexpr int B3  = R3 > 1 ? 16 / R3 : 1;     // third-pass butterflies per lane
@@ -125,16 +131,17 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
     const int t0 = threadIdx.x % T;
 
     // per-lane twiddle bases, exact table values (tw[j] = W_N^j)
-    const float2 w2a_ = tw[(t0 & 15) * (N / 256)], w2b_ = tw[2 * (t0 & 15) * (N / 256)]; // W_256^k, W_256^2k
+    const float2 w2a_ = tw[TWS * (t0 & 15) * (N / 256)], w2b_ = tw[TWS * 2 * (t0 & 15) * (N / 256)]; // W_256^k, W_256^2k
     // third pass, butterfly b of the lane: k = t + b T (< 256), W_{256 R3}^k = W_{256 R3}^t W_16^b  (256 R3 = N below 8192)
     float2 w3_ = make_float2(1.f, 0.f), w3sq_ = make_float2(1.f, 0.f);
     // (8192: the lane's third-pass butterfly is i = (t >> 1) + 256 (t & 1), k = t >> 1, see below)
     constexpr int kShift3 = R4 == 2 ? 1 : 0;
-    if constexpr (R3 > 1) w3_ = tw[((t0 >> kShift3) & 255) * (N / (256 * R3))];
-    if constexpr (R3 == 16) w3sq_ = tw[2 * ((t0 >> kShift3) & 255) * (N / 4096)];
+    if constexpr (R3 > 1) w3_ = tw[TWS * ((t0 >> kShift3) & 255) * (N / (256 * R3))];
+    if constexpr (R3 == 16) w3sq_ = tw[TWS * 2 * ((t0 >> kShift3) & 255) * (N / 4096)];
     float2 w4_ = make_float2(1.f, 0.f);
     if constexpr (R4 == 2) w4_ = tw[t0 >> 1]; // W_8192^{t >> 1}
-    const rsrc_t rwin = make_rsrc(window, window ? N * 4u : 0u);
+    const float2 wr_  = REAL ? tw[t0] : make_float2(1.f, 0.f); // REAL: W_2N^t, the split twiddle of bin t + j T is this times W_32^j
+    const rsrc_t rwin = make_rsrc(window, window ? (REAL ? 2 : 1) * N * 4u : 0u);
 
     const long ngroups = (n_frames + FPB - 1) / FPB;
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -156,7 +163,15 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
         const int      vN    = fl * N + t; // element offset of (frame slot, bin t) in an [FPB][N] group (input side)
         float2         v[16];
         // ---- pass 1 (p = 1, radix 16) from global memory; window (fft.hpp:148-162); real input becomes (x*w, 0)
-        if (out.real_input) {
+        if constexpr (REAL) {
+            const rsrc_t rx = make_rsrc(in + f0 * N * 2, nlive * N * 8u); // 2N floats per frame = N float2
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = buf_load_f2(rx, vN * 8, r * T * 8);
+            if (window) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float2 w = buf_load_f2(rwin, t * 8, r * T * 8); v[r].x *= w.x; v[r].y *= w.y; }
+            }
+        } else if (out.real_input) {
             const rsrc_t rx = make_rsrc(in + f0 * N, nlive * N * 4u);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = make_float2(buf_load_f(rx, vN * 4, r * T * 4), 0.f);
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = buf_load_f2(rx, vN * 8, r * T * 8);
         }
-        if (window) {
+        if (!REAL && window) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float w = buf_load_f(rwin, t * 4, r * T * 4); v[r].x *= w; v[r].y *= w; }
         }
@@ -237,6 +252,68 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) { rmin[g4] = FLT_MAX; rmax[g4] = -FLT_MAX; }
         auto track = [&](int sig, float v) { rmin[sig] = fminf(rmin[sig], v); rmax[sig] = fmaxf(rmax[sig], v); };
+        if constexpr (REAL) {
+            // ---- split: X[j] holds Z[k], k = t + j T; the partner Z[(N - k) mod N] lives in another lane -> one more LDS round trip
+            float2 wr = wr_;
+            asm volatile("" : "+v"(wr.x), "+v"(wr.y));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) buf[P(t + j * T)] = X[j];
+            __syncthreads();
+            float2 Zp[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) Zp[j] = buf[P((N - (t + j * T)) & (N - 1))];
+            __syncthreads(); // buf is rewritten by the next iteration
+            const float nyq = X[0].x - X[0].y; // bin N (lane t = 0 only): Re Z[0] - Im Z[0]
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 e  = make_float2(0.5f * (X[j].x + Zp[j].x), 0.5f * (X[j].y - Zp[j].y));
+                const float2 o  = make_float2(0.5f * (X[j].y + Zp[j].y), -0.5f * (X[j].x - Zp[j].x)); // -i (Z - conj Zp) / 2
+                const float2 wk = j == 0 ? wr : cmul(wr, w32(j));
+                X[j]            = cadd(e, cmul(wk, o));
+            }
+            const int vH = fl * N + t; // outputs are [frames][N]
+            if (out.mag) {
+                const rsrc_t r = make_rsrc(out.mag + f0 * N, nlive * N * 4u);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float m = hypotf(X[j].x, X[j].y) * 2.f / (float)(2 * N);
+                    if (out.in_db) m = (m > 0.f) ? 20.f * log10f(m) : -FLT_MAX;
+                    buf_store_f(r, m, vH * 4, j * T * 4);
+                    track(0, m);
+                }
+            }
+            if (out.phase || out.phase_raw) {
+                const rsrc_t r = make_rsrc((out.phase_raw ? out.phase_raw : out.phase) + f0 * N, nlive * N * 4u);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float ph = atan2f(X[j].y, X[j].x);
+                    if (!out.phase_raw && out.in_deg) ph = ph * 180.f * 0.318309886183790671538f;
+                    buf_store_f(r, ph, vH * 4, j * T * 4);
+                    if (!out.phase_raw) track(1, ph);
+                }
+            }
+            // Re / Im: output index m <-> bin N + m = conj(bin N - m); the lane holding bin k = t + j T (k >= 1) owns m = N - k, bin N itself is nyq
+            if (out.re) {
+                const rsrc_t r = make_rsrc(out.re + f0 * N, nlive * N * 4u);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bool  dc = j == 0 && t == 0;
+                    const float v_ = dc ? nyq : X[j].x;
+                    buf_store_f(r, v_, (fl * N + (dc ? 0 : N - t - j * T)) * 4, 0); // (no negative scalar offset: the range check sees the lane offset only)
+                    track(2, v_);
+                }
+            }
+            if (out.im) {
+                const rsrc_t r = make_rsrc(out.im + f0 * N, nlive * N * 4u);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bool  dc = j == 0 && t == 0;
+                    const float v_ = dc ? 0.f : -X[j].y;
+                    buf_store_f(r, v_, (fl * N + (dc ? 0 : N - t - j * T)) * 4, 0);
+                    track(3, v_);
+                }
+            }
+        } else {
         // ---- every requested output, straight from registers (fft.hpp:164-166, fft_common.hpp:20-56, 91-123)
         // X[j] is bin eN + j ST of the lane's frame; eS + soff(j) is the same bin after fftshift
         constexpr int ST = R4 == 2 ? 256 : T;
@@ -324,6 +401,7 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
                 }
             }
         }
+        } // !REAL
         if (out.ranges) { // reduce over the T lanes of the frame: butterflies inside the wave, then (T > 64) through LDS
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -360,20 +438,20 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
     }
 }
 
-template <int LOG2N>
+template <int LOG2N, bool REAL = false>
 static int fft_fast_launch(const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
     constexpr int    N = 1 << LOG2N, FPB = 512 / (N / 16);
     constexpr size_t lds = (size_t)FPB * (N + N / 32) * sizeof(float2);
     static int       n_cu = 0;
     if (n_cu == 0) {
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fft_fast_kernel<LOG2N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fft_fast_kernel<LOG2N, REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0;
         GR4_HIP_TRY(hipGetDevice(&dev));
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const long groups = (n_frames + FPB - 1) / FPB;
     const long grid   = groups < 2L * n_cu ? groups : 2L * n_cu;
-    hipLaunchKernelGGL(fft_fast_kernel<LOG2N>, dim3((unsigned)grid), dim3(512), lds, st, d_in, d_window, d_tw, o, n_frames);
+    hipLaunchKernelGGL((fft_fast_kernel<LOG2N, REAL>), dim3((unsigned)grid), dim3(512), lds, st, d_in, d_window, d_tw, o, n_frames);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

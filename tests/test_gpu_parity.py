@@ -383,15 +383,33 @@ def test_fft_block_db_deg_unwrap_and_peak(G, golden):
     assert np.mean(np.abs(d) < 0.05) > 0.9
 
 
+@pytest.mark.parametrize("window", ["Hann", "None"])
 @pytest.mark.parametrize("N", [64, 512, 1024, 2048, 8192])
-def test_fft_real_input(G, N):
-    x = O.signal_f32(5, 2 * N)
-    out = G.FFT(N, "Hann", dtype=torch.float32).process_bulk(dev(x))
-    assert out["magnitude"].shape == (2, N // 2)
-    for f in range(2):
-        mag, ph, re, im = O.fft_block_truth(x[f * N:(f + 1) * N], 3)
+def test_fft_real_input(G, N, window):
+    """float frames: N >= 512 run as N/2 complex points + split (z[n] = x[2n] + i x[2n+1]); outputs keep the block's real-input conventions"""
+    frames = 5 if N <= 2048 else 3
+    x = O.signal_f32(5, frames * N)
+    wid = [w.lower() for w in O.WINDOWS].index(window.lower())
+    out = G.FFT(N, window, dtype=torch.float32).process_bulk(dev(x))
+    assert out["magnitude"].shape == (frames, N // 2)
+    for f in range(frames):
+        mag, ph, re, im = O.fft_block_truth(x[f * N:(f + 1) * N], wid)
         assert _rel(out["magnitude"][f].cpu().numpy(), mag) <= TOL
         assert _rel(out["re"][f].cpu().numpy(), re) <= TOL and _rel(out["im"][f].cpu().numpy(), im) <= TOL
+        strong = mag > 1e-3 * mag.max()
+        d = np.angle(np.exp(1j * (out["phase"][f].cpu().numpy() - ph)))
+        assert np.max(np.abs(d[strong])) <= 1e-3
+        rg = out["ranges"][f].cpu().numpy()
+        for s_, name in enumerate(("magnitude", "phase", "re", "im")):
+            v = out[name][f].cpu().numpy()
+            assert rg[s_, 0] == v.min() and rg[s_, 1] == v.max()
+    if N == 1024:  # dB / degrees / unwrap take the same kernel
+        o2 = G.FFT(N, "Hann", outputInDb=True, outputInDeg=True, unwrapPhase=True, dtype=torch.float32).process_bulk(dev(x))
+        mag, ph, _, _ = O.fft_block_truth(x[:N], 3, in_db=True, in_deg=True, unwrap=True)
+        finite = mag > -300
+        assert np.max(np.abs(o2["magnitude"][0].cpu().numpy()[finite] - mag[finite])) < 1e-2
+        d = o2["phase"][0].cpu().numpy() - ph
+        assert np.mean(np.abs(d - 360.0 * np.round(d / 360.0)) < 0.05) > 0.9
 
 
 @pytest.mark.parametrize("N", [256, 1024, 2048, 8192])
