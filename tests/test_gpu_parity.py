@@ -140,6 +140,36 @@ def test_fir_decimating_long_input_mfma(G, decim, ntaps):
     assert _rel(y, truth) <= TOL
 
 
+@pytest.mark.parametrize("kind", ["float", "complex", "decim"])
+def test_fir_random_span_sizes_switch_kernels(G, kind):
+    """one stream cut into random spans: every call picks its kernel by size (register-window VALU / MFMA / frequency-domain), the
+    history has to survive every switch"""
+    rng = np.random.default_rng({"float": 1, "complex": 2, "decim": 3}[kind])
+    if kind == "float":
+        b, decim, total, big = (rng.standard_normal(100) / 10).astype(np.float32), 1, 1_200_000, 200_000
+        x = O.signal_f32(21, total)
+        truth, _ = O.fir(b, x)
+        f = G.fir_filter(b, torch.float32)
+    elif kind == "complex":
+        b, decim, total, big = (rng.standard_normal(91) / 9).astype(np.float32), 1, 2_200_000, 700_000
+        x = O.signal_c32(22, total)
+        truth, _ = O.fir(b, x)
+        f = G.fir_filter(b, torch.complex64)
+    else:
+        b, decim, total, big = (rng.standard_normal(1024) / 32).astype(np.float32), 8, 1_600_000, 400_000
+        x = O.signal_f32(23, total)
+        truth, _ = O.fir_decim(b, x, decim)
+        f = G.fir_filter(b, torch.float32, decimate=decim)
+    cuts, pos = [0], 0
+    while pos < total:
+        step = int(rng.choice([rng.integers(1, 300), rng.integers(1000, 70_000), rng.integers(70_000, big)]))
+        step = max(decim, step - step % decim)
+        pos = min(total, pos + step)
+        cuts.append(pos)
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert len(y) == total // decim and _rel(y, truth) <= TOL
+
+
 @pytest.mark.parametrize("ntaps", [256, 91, 33, 2])
 def test_fir_complex_long_input_fast_convolution(G, ntaps):
     """complex<float>, <= 256 taps, >= 64 frames of 8192: whole frames take the frequency-domain kernel, the rest the direct form;
