@@ -1,7 +1,7 @@
 // chain.hip -- the headline chain: complex<float> fir_filter -> FFT block frames -> |X|^2 (BASELINE.json configs[1]).
 //
 // GR4HIP_CHAIN_UNFUSED: gr4hip_fir_process -> y in HBM -> gr4hip_fft_mag2 (any size the FFT block supports).
-// GR4HIP_CHAIN_FUSED_FD (chain_fused.hip): one persistent launch, any window, fft_size 8192, <= 256 taps; AUTO picks it when it applies.
+// GR4HIP_CHAIN_FUSED_FD (chain_fused.hip): one persistent launch, any window, fft_size 256...8192, <= 256 taps; AUTO picks it when it applies.
 #include "common.hpp"
 
 namespace gr4 {

@@ -47,7 +47,8 @@ struct ChainFdArgs {
     const float2* twB;    // [16][32]  W_512^{r k}
     const float2* twC;    // [16][512] W_8192^{r i3}
     const float*  taps;   // 256 (zero padded)
-    const float*  win;    // WIN kernels: window[n] / N (8192 floats), else unused
+    const float*  win;    // WIN kernels: window[n] / N (8192 floats; small-FFT mode: the fftSize-point window tiled over the block), else unused
+    const float2* twS;    // small-FFT mode: W_fftSize^j
     float*        out;    // frames * 8192 mag2
     long          n_frames;
     unsigned long long* dbg; // GR4_FD_TIMING only
@@ -202,10 +203,15 @@ __device__ __forceinline__ void passA_inplace(float2* S, const float2 (&twA)[16]
 //
 // MODE 2 stops after the inverse transform and writes y_f itself: fir_filter<complex<float>> as a fast convolution (2 transforms
 // per 8192 samples instead of 1024 flop per sample), used by gr4hip_fir_process for long complex inputs.
-enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2 };
-template <int MODE>
+//
+// MODE 3 (kModeWinSmall, LOG2NF = 8..12): the FFT block runs at fftSize = 2^LOG2NF < 8192 (its default is 1024).  The FIR part is unchanged --
+// 8192-sample blocks, y recovered in the time domain as in MODE 1 -- and the third transform becomes 8192 / fftSize independent windowed
+// fftSize-point transforms of the block (the compile-time 16 x 16 x R3 plan of the FFT block kernels, fft_radix.hpp, on the LDS image).
+enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2, kModeWinSmall = 3 };
+template <int MODE, int LOG2NF = 13>
 __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
-    constexpr bool WIN = MODE == kModeWinMag2;
+    constexpr bool WIN   = MODE == kModeWinMag2 || MODE == kModeWinSmall; // y_f is needed in the time domain and multiplied by a.win
+    constexpr bool SMALL = MODE == kModeWinSmall;
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
     float2* B1 = smem + kSLen;                       // kSLen: (odd frames)
@@ -251,6 +257,16 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     if constexpr (WIN) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) wr[q] = a.win[t0 + 512 * q];
+    }
+    // SMALL: twiddle bases of the fftSize-point plan for this lane (lane tt of its frame's fftSize / 16 lanes)
+    constexpr int NF = 1 << (SMALL ? LOG2NF : 8), TF = NF / 16, NPF = NF + NF / 32;
+    float2        sw2a = make_float2(1.f, 0.f), sw2b = sw2a, sw3 = sw2a, sw3sq = sw2a;
+    if constexpr (SMALL) {
+        const int tt = t0 % TF;
+        sw2a  = a.twS[(tt & 15) * (NF / 256)];
+        sw2b  = a.twS[2 * (tt & 15) * (NF / 256)];
+        sw3   = a.twS[tt & 255];
+        sw3sq = a.twS[(2 * (tt & 255)) & (NF - 1)];
     }
 
     // |Y|^2 of the previous frame waits in registers and leaves in four groups of four stores spread over this frame's phases;
@@ -460,6 +476,28 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                 }
                 GR4_LDS_BARRIER(); // every lane has consumed S
                 GR4_PHASE_FENCE();
+                if constexpr (SMALL) {
+                    // ---------------------------------------------------------- 8192 / fftSize frames of fftSize points, each in its padded buffer
+                    auto PF = [](int i) { return i + (i >> 5); };
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int n = t + 512 * q;
+                        S[(n >> LOG2NF) * NPF + PF(n & (NF - 1))] = yw[q];
+                    }
+                    GR4_LDS_BARRIER();
+                    const int fl = t / TF, tt = t % TF;
+                    float2*   fb = S + fl * NPF;
+                    float2    v[16], Xs[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fb[PF(tt + r * TF)];
+                    GR4_LDS_BARRIER(); // everybody holds its first-pass inputs: the buffers may be overwritten
+                    float2 b2a = sw2a, b2b = sw2b, b3 = sw3, b3sq = sw3sq; // opaque per iteration (see fft_kernels.hpp: the power chains would be hoisted)
+                    asm volatile("" : "+v"(b2a.x), "+v"(b2a.y), "+v"(b2b.x), "+v"(b2b.y), "+v"(b3.x), "+v"(b3.y), "+v"(b3sq.x), "+v"(b3sq.y));
+                    fft_small_passes<LOG2NF>(v, fb, tt, b2a, b2b, b3, b3sq, Xs, [] { GR4_LDS_BARRIER(); });
+                    const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float)); // frame (8192 / NF) f + fl, bin tt + j TF
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) buf_store_f(ro, fmaf(Xs[j].x, Xs[j].x, Xs[j].y * Xs[j].y), (fl * NF + tt) * 4, j * TF * 4);
+                } else {
     #pragma unroll
                 for (int q = 0; q < 16; ++q) S[addrA((t >> 8) + 2 * q, t & 255)] = yw[q];
                 GR4_LDS_BARRIER();
@@ -480,6 +518,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                 const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
     #pragma unroll
                 for (int q = 0; q < 16; ++q) buf_store_f(ro, fmaf(w[perm16(q)].x, w[perm16(q)].x, w[perm16(q)].y * w[perm16(q)].y), t * 4, q * 2048);
+                }
             } else { // kModeFir: y_f[n] = conj(.) / N + e[n], complex, straight to HBM
                 const rsrc_t ro = make_rsrc(a.out + f * kN * 2, kN * sizeof(float2));
 #pragma unroll
@@ -509,14 +548,17 @@ static unsigned long long* g_dbg = nullptr;
 #endif
 struct ChainFused {
     size_t       ntaps = 0;
-    DeviceBuffer d_H, d_twB, d_twC, d_taps, d_hist, d_win;
+    DeviceBuffer d_H, d_twB, d_twC, d_taps, d_hist, d_win, d_twS;
     bool         windowed = false;
+    int          small_log2n = 0; // 8..12: fftSize = 2^small_log2n < 8192, the launch unit stays an 8192-sample block
+    DeviceBuffer d_stage_in, d_stage_out; // one zero-padded block for the tail of a span that is not a multiple of 8192 samples
     unsigned     max_wg   = 0; // 0 = one workgroup on every CU
 };
 
 int chain_fused_supported(size_t ntaps, size_t fft_size, int window, int algo) {
     if (algo != GR4HIP_CHAIN_FUSED_FD) return 0;
-    return fft_size == (size_t)kN && ntaps >= 1 && ntaps <= 256 && window >= GR4HIP_WIN_NONE && window <= GR4HIP_WIN_KAISER;
+    const bool size_ok = fft_size == (size_t)kN || (is_pow2(fft_size) && fft_size >= 256 && fft_size <= 4096);
+    return size_ok && ntaps >= 1 && ntaps <= 256 && window >= GR4HIP_WIN_NONE && window <= GR4HIP_WIN_KAISER;
 }
 
 template <typename T>
@@ -561,12 +603,24 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
     if (!rc) rc = upload(c->d_twB, twB);
     if (!rc) rc = upload(c->d_twC, twC);
     if (!rc) rc = upload(c->d_taps, hp);
-    c->windowed = window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR;
-    if (!rc && c->windowed) {
-        std::vector<float> w(kN);
-        rc = make_window(window, w.data(), kN, 1.6f); // fft.hpp:141: create(_window, _windowType) -> default beta
-        for (float& v : w) v *= 1.0f / (float)kN;      // exact (power of two): the 1/N of the inverse transform
-        if (!rc) rc = upload(c->d_win, w);
+    c->small_log2n = fft_size == (size_t)kN ? 0 : (int)ilog2(fft_size);
+    c->windowed    = c->small_log2n != 0 || (window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR);
+    if (!rc && c->windowed) { // window[n mod fftSize] / 8192 over the whole block: the 1/N of the inverse 8192-point transform is exact
+        std::vector<float> w(fft_size, 1.f), wt(kN);
+        if (window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR) rc = make_window(window, w.data(), fft_size, 1.6f); // fft.hpp:141: default beta
+        for (int n = 0; n < kN; ++n) wt[n] = w[n % fft_size] * (1.0f / (float)kN);
+        if (!rc) rc = upload(c->d_win, wt);
+    }
+    if (!rc && c->small_log2n) {
+        std::vector<float> ts(2 * fft_size);
+        for (size_t k = 0; k < fft_size; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / (double)fft_size;
+            ts[2 * k] = (float)std::cos(ang);
+            ts[2 * k + 1] = (float)std::sin(ang);
+        }
+        rc = upload(c->d_twS, ts);
+        if (!rc) rc = c->d_stage_in.ensure(kN * sizeof(float2));
+        if (!rc) rc = c->d_stage_out.ensure(kN * sizeof(float));
     }
     if (!rc) rc = c->d_hist.ensure(256 * sizeof(float2));
     if (!rc) rc = chain_fused_reset(c);
@@ -582,7 +636,7 @@ int chain_fused_reset(ChainFused* c) {
 
 // hist256 == nullptr: the chain's own carried history (updated after the launch); otherwise 256 complex samples preceding d_in, and
 // the output is the filtered stream itself (complex) instead of |FFT|^2
-static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st) {
+static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st, bool fir_mode, bool carry_hist) {
     ChainFdArgs a{};
     a.x        = reinterpret_cast<const float2*>(d_in);
     a.hist     = hist256 ? reinterpret_cast<const float2*>(hist256) : static_cast<const float2*>(c->d_hist.ptr);
@@ -591,6 +645,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     a.twC      = static_cast<const float2*>(c->d_twC.ptr);
     a.taps     = static_cast<const float*>(c->d_taps.ptr);
     a.win      = static_cast<const float*>(c->d_win.ptr);
+    a.twS      = static_cast<const float2*>(c->d_twS.ptr);
     a.out      = d_out;
     a.n_frames = (long)n_frames;
     a.dbg      = nullptr;
@@ -602,31 +657,62 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     constexpr size_t lds_base = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
     constexpr size_t lds_win  = lds_base + 1024 * sizeof(float);
     static_assert(lds_win <= 160 * 1024, "LDS budget of one CU");
-    const size_t lds  = c->windowed ? lds_win : lds_base;
+    const size_t lds  = (c->windowed && !fir_mode) ? lds_win : lds_base;
     static int   n_cu = 0;
     if (n_cu == 0) {
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         int dev = 0;
         GR4_HIP_TRY(hipGetDevice(&dev));
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const size_t   wgs  = c->max_wg ? std::min<size_t>(c->max_wg, (size_t)n_cu) : (size_t)n_cu;
     const unsigned grid = (unsigned)std::min<size_t>(n_frames, wgs); // one resident workgroup per CU (or fewer: gr4hip_chain_set_max_workgroups)
-    if (hist256) hipLaunchKernelGGL(chain_fd_kernel<kModeFir>, dim3(grid), dim3(kT), lds, st, a);
+    if (fir_mode) hipLaunchKernelGGL(chain_fd_kernel<kModeFir>, dim3(grid), dim3(kT), lds, st, a);
+    else if (c->small_log2n == 8) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 8>), dim3(grid), dim3(kT), lds, st, a);
+    else if (c->small_log2n == 9) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 9>), dim3(grid), dim3(kT), lds, st, a);
+    else if (c->small_log2n == 10) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 10>), dim3(grid), dim3(kT), lds, st, a);
+    else if (c->small_log2n == 11) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 11>), dim3(grid), dim3(kT), lds, st, a);
+    else if (c->small_log2n == 12) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 12>), dim3(grid), dim3(kT), lds, st, a);
     else if (c->windowed) hipLaunchKernelGGL(chain_fd_kernel<kModeWinMag2>, dim3(grid), dim3(kT), lds, st, a);
     else hipLaunchKernelGGL(chain_fd_kernel<kModeMag2>, dim3(grid), dim3(kT), lds, st, a);
     GR4_LAUNCH_CHECK();
     // carry the last 256 input samples for the next call's first frame (stream-ordered after the kernel's reads)
-    if (!hist256) GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    if (carry_hist) GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
     return GR4HIP_OK;
 }
 
-int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) { return chain_fused_run(c, d_in, nullptr, n_frames, d_mag2, st); }
+// n_frames counts FFT frames of the plan's fftSize.  At fftSize < 8192 whole 8192-sample blocks go through the kernel directly; the frames
+// behind the last whole block (< 8192 samples) are copied into a zero-padded staging block, transformed, and only their spectra copied out.
+int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
+    if (c->small_log2n == 0) return chain_fused_run(c, d_in, nullptr, n_frames, d_mag2, st, false, true);
+    const size_t nf = (size_t)1 << c->small_log2n, per_block = kN / nf;
+    const size_t blocks = n_frames / per_block, rem = n_frames % per_block; // rem fft-frames = rem * nf samples (>= 256 each)
+    if (blocks) {
+        int rc = chain_fused_run(c, d_in, nullptr, blocks, d_mag2, st, false, true);
+        if (rc) return rc;
+    }
+    if (rem) {
+        const float* tail = d_in + blocks * (size_t)kN * 2;
+        GR4_HIP_TRY(hipMemsetAsync(c->d_stage_in.ptr, 0, kN * sizeof(float2), st));
+        GR4_HIP_TRY(hipMemcpyAsync(c->d_stage_in.ptr, tail, rem * nf * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        int rc = chain_fused_run(c, static_cast<const float*>(c->d_stage_in.ptr), nullptr, 1, static_cast<float*>(c->d_stage_out.ptr), st, false, false);
+        if (rc) return rc;
+        GR4_HIP_TRY(hipMemcpyAsync(d_mag2 + blocks * (size_t)kN, c->d_stage_out.ptr, rem * nf * sizeof(float), hipMemcpyDeviceToDevice, st));
+        // history for the next call: the last 256 REAL input samples (rem * nf >= 256)
+        GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, tail + (rem * nf - 256) * 2, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    }
+    return GR4HIP_OK;
+}
 int chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_y, hipStream_t st) {
-    GR4_REQUIRE(!c->windowed && d_hist256, "chain_fused_fir: needs an un-windowed plan and a history");
-    return chain_fused_run(c, d_in, d_hist256, n_frames, d_y, st);
+    GR4_REQUIRE(d_hist256 && c->small_log2n == 0, "chain_fused_fir: needs a history and an 8192-point plan");
+    return chain_fused_run(c, d_in, d_hist256, n_frames, d_y, st, true, false);
 }
 
 void chain_fused_destroy(ChainFused* c) { delete c; }

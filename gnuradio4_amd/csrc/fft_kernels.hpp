@@ -14,37 +14,6 @@
 
 namespace gr4 {
 
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
-__device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); } // * (-i)
-
-__device__ __forceinline__ void fft2(float2& a, float2& b) {
-    const float2 t = a;
-    a = caddf(t, b);
-    b = csubf(t, b);
-}
-__device__ __forceinline__ void fft4(float2& v0, float2& v1, float2& v2, float2& v3) { // natural-order forward DFT-4
-    const float2 t0 = caddf(v0, v2), t1 = csubf(v0, v2), t2 = caddf(v1, v3), t3 = mul_mi(csubf(v1, v3));
-    v0 = caddf(t0, t2);
-    v2 = csubf(t0, t2);
-    v1 = caddf(t1, t3);
-    v3 = csubf(t1, t3);
-}
-__device__ __forceinline__ void fft8(float2 (&v)[8]) { // natural-order forward DFT-8 (decimation in time)
-    constexpr float h = 0.70710678118654752440f;
-    fft4(v[0], v[2], v[4], v[6]);
-    fft4(v[1], v[3], v[5], v[7]);
-    const float2 o1 = make_float2((v[3].x + v[3].y) * h, (v[3].y - v[3].x) * h);   // * W8^1
-    const float2 o2 = mul_mi(v[5]);                                                 // * W8^2
-    const float2 o3 = make_float2((v[7].y - v[7].x) * h, (-v[7].x - v[7].y) * h);  // * W8^3
-    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
-    v[0] = caddf(e0, o0); v[4] = csubf(e0, o0);
-    v[1] = caddf(e1, o1); v[5] = csubf(e1, o1);
-    v[2] = caddf(e2, o2); v[6] = csubf(e2, o2);
-    v[3] = caddf(e3, o3); v[7] = csubf(e3, o3);
-}
-
 struct FftPlanDev {
     int N;
     int npass;
@@ -105,12 +74,6 @@ __device__ __forceinline__ void emit_bin(const FftOutputs& out, long frame, int 
 // t + j N/16: coalesced), so a frame makes 2 (N <= 4096: 16 x 16 x R3) or 3 LDS round trips instead of log8(N) + 1, all of them
 // through a buffer padded by one float2 per 32 (the stride-16 scatter of the first pass is conflict-free).  Twiddles: one or two
 // table values per lane and pass live in registers, the powers b^r come from two interleaved chains (depth <= 7).
-template <int R>
-__device__ __forceinline__ void dft_small(float2* v) {
-    if constexpr (R == 2) fft2(v[0], v[1]);
-    else if constexpr (R == 4) fft4(v[0], v[1], v[2], v[3]);
-    else { float2(&a)[8] = *reinterpret_cast<float2(*)[8]>(v); fft8(a); }
-}
 
 // REAL = true: a frame of 2N REAL samples is transformed as N complex points z[n] = x[2n] + i x[2n+1] (the float array read as float2,
 // window pairs likewise) and split afterwards:  X[k] = (Z[k] + conj Z[N-k]) / 2 + W_2N^k (Z[k] - conj Z[N-k]) / (2i),  k = 0 .. N

@@ -108,4 +108,98 @@ __device__ __forceinline__ float2 w32(int k) {
     }
 }
 
+// natural-order small DFTs (used by the run-time plan kernel and as the third pass of the compile-time plans)
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
+__device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); } // * (-i)
+
+__device__ __forceinline__ void fft2(float2& a, float2& b) {
+    const float2 t = a;
+    a = caddf(t, b);
+    b = csubf(t, b);
+}
+__device__ __forceinline__ void fft4(float2& v0, float2& v1, float2& v2, float2& v3) { // natural-order forward DFT-4
+    const float2 t0 = caddf(v0, v2), t1 = csubf(v0, v2), t2 = caddf(v1, v3), t3 = mul_mi(csubf(v1, v3));
+    v0 = caddf(t0, t2);
+    v2 = csubf(t0, t2);
+    v1 = caddf(t1, t3);
+    v3 = csubf(t1, t3);
+}
+__device__ __forceinline__ void fft8(float2 (&v)[8]) { // natural-order forward DFT-8 (decimation in time)
+    constexpr float h = 0.70710678118654752440f;
+    fft4(v[0], v[2], v[4], v[6]);
+    fft4(v[1], v[3], v[5], v[7]);
+    const float2 o1 = make_float2((v[3].x + v[3].y) * h, (v[3].y - v[3].x) * h);   // * W8^1
+    const float2 o2 = mul_mi(v[5]);                                                 // * W8^2
+    const float2 o3 = make_float2((v[7].y - v[7].x) * h, (-v[7].x - v[7].y) * h);  // * W8^3
+    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+    v[0] = caddf(e0, o0); v[4] = csubf(e0, o0);
+    v[1] = caddf(e1, o1); v[5] = csubf(e1, o1);
+    v[2] = caddf(e2, o2); v[6] = csubf(e2, o2);
+    v[3] = caddf(e3, o3); v[7] = csubf(e3, o3);
+}
+
+template <int R>
+__device__ __forceinline__ void dft_small(float2* v) {
+    if constexpr (R == 2) fft2(v[0], v[1]);
+    else if constexpr (R == 4) fft4(v[0], v[1], v[2], v[3]);
+    else { float2(&a)[8] = *reinterpret_cast<float2(*)[8]>(v); fft8(a); }
+}
+
+// The passes of the compile-time plan 16 x 16 x R3 (N = 256 .. 4096, fft_kernels.hpp) on a frame whose first-pass inputs are already in
+// registers: v[r] = frame[t + r N/16] for lane t of the frame's N/16 lanes.  buf = the frame's exchange buffer of N + N/32 float2 (one pad
+// per 32: the stride-16 scatter of pass 1 is conflict-free).  On return X[j] = bin t + j N/16.  BARRIER() synchronises ALL lanes that share
+// the workgroup (every frame of the group runs the same code); the caller guarantees nobody still reads buf when this starts.
+// w2a/w2b = W_256^{k}, W_256^{2k} (k = t & 15), w3 = W_N^{t & 255}, w3sq = W_N^{2 (t & 255)} (used at N = 4096 only).
+template <int LOG2N, typename Barrier>
+__device__ __forceinline__ void fft_small_passes(float2 (&v)[16], float2* buf, int t, float2 w2a, float2 w2b, float2 w3, float2 w3sq, float2 (&X)[16], Barrier&& BARRIER) {
+    constexpr int N = 1 << LOG2N, T = N / 16;
+    constexpr int R3 = N / 256, B3 = R3 > 1 ? 16 / R3 : 1, NB3 = N / (R3 > 1 ? R3 : 1);
+    static_assert(LOG2N >= 8 && LOG2N <= 12, "16 x 16 x R3 plans");
+    auto P = [](int i) { return i + (i >> 5); };
+    fft16<1>(v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[P(16 * t + r)] = v[perm16(r)];
+    BARRIER();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = buf[P(t + r * T)];
+    BARRIER();
+    apply_powers(v, w2a, w2b);
+    fft16<1>(v);
+    if constexpr (R3 == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) X[q] = v[perm16(q)];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) buf[P((t & ~15) * 16 + (t & 15) + 16 * q)] = v[perm16(q)];
+        BARRIER();
+#pragma unroll
+        for (int b = 0; b < B3; ++b)
+#pragma unroll
+            for (int r = 0; r < R3; ++r) v[b * R3 + r] = buf[P(t + b * T + r * NB3)];
+        BARRIER();
+        if constexpr (R3 == 16) {
+            apply_powers(v, w3, w3sq);
+            fft16<1>(v);
+        } else {
+#pragma unroll
+            for (int b = 0; b < B3; ++b) {
+                const float2 wb = b == 0 ? w3 : cmul(w3, w32(2 * b));
+                float2       pw = wb;
+#pragma unroll
+                for (int r = 1; r < R3; ++r) {
+                    v[b * R3 + r] = cmul(v[b * R3 + r], pw);
+                    if (r + 1 < R3) pw = cmul(pw, wb);
+                }
+                dft_small<R3>(v + b * R3);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < B3; ++b)
+#pragma unroll
+            for (int q = 0; q < R3; ++q) X[b + q * B3] = v[b * R3 + (R3 == 16 ? perm16(q) : q)];
+    }
+}
+
 } // namespace gr4

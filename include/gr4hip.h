@@ -71,7 +71,7 @@ typedef enum { /* how the FIR->FFT->mag2 chain is executed */
     GR4HIP_CHAIN_UNFUSED,  /* fir kernel -> HBM -> fft+mag2 kernel (any window, any size the FFT block supports) */
     GR4HIP_CHAIN_FUSED_TD, /* reserved (time-domain FIR in LDS + FFT + mag2): not implemented, create returns GR4HIP_UNSUPPORTED */
     GR4HIP_CHAIN_FUSED_FD  /* one launch, frequency-domain FIR (circular convolution + exact tail correction) + FFT + mag2;
-                              fft_size 8192, <= 256 taps, any window */
+                              fft_size 256 ... 8192 (power of two), <= 256 taps, any window */
 } gr4hip_chain_algo_t;
 
 typedef void* gr4hip_stream_t; /* hipStream_t */
