@@ -7,6 +7,7 @@
 #include <cmath>
 #include <numbers>
 
+#include "../../../../include/gr4hip.h" // host-side design functions only (gr4hip_fir_design / gr4hip_iir_design / gr4hip_window_create: no device needed)
 #include "core.hpp"
 
 namespace gr::testing {
@@ -192,6 +193,129 @@ struct Decimator : Block<Decimator<T>, Resampling<1, 1, false>> {
         return work::Status::OK;
     }
 };
+
+// ---- BasicFilterProto<T, Args...> (time_domain_filter.hpp:126-210): FIR / IIR by specification, optionally decimating
+enum class FilterType { FIR, IIR };                                   // time_domain_filter.hpp:127
+enum class Type { LOWPASS, HIGHPASS, BANDPASS, BANDSTOP };            // filter::Type (FilterTool.hpp:64) == gr4hip_filter_response
+namespace iir { enum class Design { BUTTERWORTH, BESSEL, CHEBYSHEV1, CHEBYSHEV2 }; // FilterTool.hpp:425-430 == gr4hip_iir_design_t
+inline bool gr_enum_parse(Design& d, std::string_view s) { return gr::detail::enum_from_names(d, s, std::array<std::string_view, 4>{"BUTTERWORTH", "BESSEL", "CHEBYSHEV1", "CHEBYSHEV2"}); }
+}
+inline bool gr_enum_parse(FilterType& d, std::string_view s) { return gr::detail::enum_from_names(d, s, std::array<std::string_view, 2>{"FIR", "IIR"}); }
+inline bool gr_enum_parse(Type& d, std::string_view s) { return gr::detail::enum_from_names(d, s, std::array<std::string_view, 4>{"LOWPASS", "HIGHPASS", "BANDPASS", "BANDSTOP"}); }
+} // namespace gr::filter
+namespace gr::algorithm::window {
+enum class Type : int { None, Rectangular, Hamming, Hann, HannExp, Blackman, Nuttall, BlackmanHarris, BlackmanNuttall, FlatTop, Exponential, Kaiser }; // window.hpp:35 == GR4HIP_WIN_*
+inline constexpr std::array<std::string_view, 12> TypeList{"None", "Rectangular", "Hamming", "Hann", "HannExp", "Blackman", "Nuttall", "BlackmanHarris", "BlackmanNuttall", "FlatTop", "Exponential", "Kaiser"};
+inline bool gr_enum_parse(Type& d, std::string_view s) { return gr::detail::enum_from_names(d, s, TypeList); }
+// window::create (window.hpp:69-183) through the library's host-side restatement
+template <typename T>
+std::vector<T> create(Type type, std::size_t n, float beta = 1.6f) {
+    std::vector<float> w(n);
+    if (n && gr4hip_window_create(static_cast<int>(type), w.data(), n, beta) != GR4HIP_OK) throw std::invalid_argument(std::string("window::create: ") + gr4hip_last_error());
+    return std::vector<T>(w.begin(), w.end());
+}
+} // namespace gr::algorithm::window
+namespace gr::filter {
+
+// designed coefficients: FIR = one section with a = {1}; IIR = biquad (or first-order) sections, applied as a cascade of DF_II sections
+// (Filter<T>::processOne folds over the sections, FilterTool.hpp:223-247; DF_II is the float default :220)
+struct DesignedFilter {
+    bool                            fir = true;
+    std::vector<float>              taps;     // FIR
+    std::vector<std::array<float, 3>> b, a;   // IIR sections (zero padded to order 2)
+};
+inline DesignedFilter designFilter(FilterType ft, Type response, std::size_t order, double fLow, double fHigh, double fs, iir::Design iirDesign, algorithm::window::Type firWindow) {
+    gr4hip_filter_params p;
+    gr4hip_filter_params_default(&p);
+    p.order = order; p.f_low = fLow; p.f_high = fHigh; p.fs = fs;
+    DesignedFilter d;
+    d.fir = ft == FilterType::FIR;
+    const auto fail = [](const char* what) { throw std::invalid_argument(std::string(what) + ": " + gr4hip_last_error()); };
+    if (d.fir) {
+        std::size_t n = 0;
+        if (gr4hip_fir_design(static_cast<int>(response), &p, static_cast<int>(firWindow), nullptr, 0, &n) != GR4HIP_OK) fail("fir::designFilter");
+        d.taps.resize(n);
+        if (gr4hip_fir_design(static_cast<int>(response), &p, static_cast<int>(firWindow), d.taps.data(), n, &n) != GR4HIP_OK) fail("fir::designFilter");
+    } else {
+        std::size_t        cap = 2 * order + 2, n = 0;
+        std::vector<float> fb(3 * cap), fa(3 * cap);
+        if (gr4hip_iir_design(static_cast<int>(response), &p, static_cast<int>(iirDesign), fb.data(), fa.data(), cap, &n) != GR4HIP_OK) fail("iir::designFilter");
+        for (std::size_t s = 0; s < n; ++s) {
+            d.b.push_back({fb[3 * s], fb[3 * s + 1], fb[3 * s + 2]});
+            d.a.push_back({fa[3 * s], fa[3 * s + 1], fa[3 * s + 2]});
+        }
+    }
+    return d;
+}
+
+template <typename T, typename... Args>
+struct BasicFilterProto : Block<BasicFilterProto<T, Args...>, Args...> {
+    using TParent = Block<BasicFilterProto<T, Args...>, Args...>;
+    PortIn<T>  in;
+    PortOut<T> out;
+    Annotated<FilterType, "filter_type">                  filter_type     = FilterType::IIR;
+    Annotated<Type, "filter_response">                    filter_response = Type::LOWPASS;
+    Annotated<Size_t, "filter_order">                     filter_order{3};
+    Annotated<float, "f_low">                             f_low{0.1f};
+    Annotated<float, "f_high">                            f_high{0.2f};
+    Annotated<float, "sample rate">                       sample_rate{1.0f};
+    Annotated<Size_t, "decimation factor">                decimate{1U};
+    Annotated<iir::Design, "iir_design_method">           iir_design_method = iir::Design::BUTTERWORTH;
+    Annotated<algorithm::window::Type, "fir_design_method"> fir_design_method = algorithm::window::Type::Kaiser;
+    GR_MAKE_REFLECTABLE(BasicFilterProto, in, out, filter_type, filter_response, filter_order, f_low, f_high, sample_rate, decimate, iir_design_method, fir_design_method);
+
+    DesignedFilter              _design;
+    std::vector<T>              _fir_hist;             // newest first
+    std::vector<std::array<T, 2>> _w;                  // DF_II state per section
+    bool                        _designed = false;
+
+    void settingsChanged(const property_map&, const property_map&) { designFilter(); }
+    void designFilter() { // time_domain_filter.hpp:163-182
+        if constexpr (!TParent::ResamplingControl::kIsConst) this->input_chunk_size = decimate;
+        _design = gr::filter::designFilter(filter_type, filter_response, filter_order, static_cast<double>(f_low.value), static_cast<double>(f_high.value), static_cast<double>(sample_rate.value), iir_design_method, fir_design_method);
+        _fir_hist.assign(_design.taps.size(), T{});
+        _w.assign(_design.b.size(), std::array<T, 2>{});
+        _designed = true;
+    }
+    [[nodiscard]] T filterOne(T x) noexcept {
+        if (_design.fir) {
+            if (_fir_hist.empty()) return T{};
+            std::move_backward(_fir_hist.begin(), _fir_hist.end() - 1, _fir_hist.end());
+            _fir_hist[0] = x;
+            T acc{};
+            for (std::size_t k = 0; k < _fir_hist.size(); ++k) acc += static_cast<T>(_design.taps[k]) * _fir_hist[k];
+            return acc;
+        }
+        for (std::size_t s = 0; s < _w.size(); ++s) { // DF_II section (FilterTool.hpp:127-135)
+            const auto& b = _design.b[s];
+            const auto& a = _design.a[s];
+            const T w0 = x - static_cast<T>(a[1]) * _w[s][0] - static_cast<T>(a[2]) * _w[s][1];
+            x          = static_cast<T>(b[0]) * w0 + static_cast<T>(b[1]) * _w[s][0] + static_cast<T>(b[2]) * _w[s][1];
+            _w[s][1]   = _w[s][0];
+            _w[s][0]   = w0;
+        }
+        return x;
+    }
+    [[nodiscard]] T processOne(T input) noexcept
+    requires(TParent::ResamplingControl::kIsConst)
+    {
+        if (!_designed) designFilter();
+        return filterOne(input);
+    }
+    [[nodiscard]] work::Status processBulk(std::span<const T> input, std::span<T> output) noexcept
+    requires(!TParent::ResamplingControl::kIsConst)
+    { // full-rate filter, keep the samples with i % decimate == 0 (time_domain_filter.hpp:190-204)
+        if (!_designed) designFilter();
+        std::size_t o = 0;
+        for (std::size_t i = 0; i < input.size(); ++i) {
+            const T y = filterOne(input[i]);
+            if (i % decimate == 0) output[o++] = y;
+        }
+        return work::Status::OK;
+    }
+};
+template <typename T> using BasicFilter           = BasicFilterProto<T>;
+template <typename T> using BasicDecimatingFilter = BasicFilterProto<T, Resampling<1, 1, false>>;
 } // namespace gr::filter
 
 namespace gr::blocks::math {
@@ -306,6 +430,148 @@ struct PowerSpectrum : Block<PowerSpectrum<T>, Resampling<1024, 1024, false>> {
             for (std::size_t i = 0; i < N; ++i) output[f + i] = static_cast<value_type>(std::norm(v[i]));
         }
         return work::Status::OK;
+    }
+};
+
+// ---- gr::blocks::fft::FFT<T> (blocks/fourier/.../fft.hpp:31-251): one DataSet per frame of fftSize samples
+// window (default Hann) -> unnormalised forward DFT -> magnitude (hypot 2/N [dB], fft-shifted) + phase (atan2 [unwrap][deg], shifted) + Re + Im,
+// frequency axis, per-signal min/max.  T = std::complex<float> (N bins) or float (N/2 bins: fft.hpp:140-143, 221-227).
+// The host body is a float64 DFT (radix-2 for powers of two, the defining sum otherwise) -- plumbing; the device path is gr4hip_fft_process.
+template <typename T, typename U = DataSet<float>>
+struct FFT : Block<FFT<T, U>, Resampling<1024, 1, false>> {
+    using value_type                         = typename U::value_type;
+    static constexpr bool computeFullSpectrum = gr::detail::is_complex<T>::value;
+    PortIn<T>                         in;
+    PortOut<U, RequiredSamples<1, 1>> out;
+    Annotated<Size_t, "FFT size">           fftSize{1024U};
+    Annotated<std::string, "window type">   window = std::string("Hann");
+    Annotated<bool, "output in dB">         outputInDb{false};
+    Annotated<bool, "output in deg">        outputInDeg{false};
+    Annotated<bool, "unwrap phase">         unwrapPhase{false};
+    Annotated<float, "sample rate">         sample_rate = 1.f;
+    Annotated<std::string, "signal name">   signal_name = std::string("unknown signal");
+    Annotated<std::string, "signal unit">   signal_unit = std::string("a.u.");
+    Annotated<float, "signal min">          signal_min  = -std::numeric_limits<float>::max();
+    Annotated<float, "signal max">          signal_max  = +std::numeric_limits<float>::max();
+    GR_MAKE_REFLECTABLE(FFT, in, out, fftSize, window, outputInDb, outputInDeg, unwrapPhase, sample_rate, signal_name, signal_unit, signal_min, signal_max);
+
+    gr::algorithm::window::Type       _windowType = gr::algorithm::window::Type::Hann;
+    std::vector<value_type>           _window;
+    std::vector<std::complex<value_type>> _outData;
+    std::vector<value_type>           _magnitudeSpectrum, _phaseSpectrum;
+
+    void settingsChanged(const property_map&, const property_map& newSettings) {
+        if (!newSettings.contains("fftSize") && !newSettings.contains("window") && !_window.empty()) return; // fft.hpp:126-129
+        in.max_samples = in.min_samples = fftSize;
+        this->input_chunk_size          = fftSize;
+        gr::algorithm::window::Type t   = _windowType;
+        if (gr_enum_parse(t, std::string_view(window.value))) _windowType = t; // enum_cast(...).value_or(_windowType) (:138)
+        _window = gr::algorithm::window::create<value_type>(_windowType, fftSize);
+    }
+    [[nodiscard]] std::size_t nBins() const { return computeFullSpectrum ? fftSize.value : fftSize.value / 2; }
+
+    [[nodiscard]] work::Status processBulk(std::span<const T> input, std::span<U> output) {
+        const std::size_t N = fftSize;
+        if (_window.size() != N) settingsChanged({}, {{"fftSize", std::int64_t(N)}});
+        for (std::size_t f = 0; f < output.size(); ++f) {
+            std::vector<std::complex<double>> v(N);
+            for (std::size_t i = 0; i < N; ++i) v[i] = std::complex<double>(input[f * N + i]) * static_cast<double>(_window[i]);
+            dft(v);
+            _outData.assign(N, {});
+            for (std::size_t i = 0; i < N; ++i) _outData[i] = std::complex<value_type>(static_cast<value_type>(v[i].real()), static_cast<value_type>(v[i].imag()));
+            const std::size_t M = nBins();
+            _magnitudeSpectrum.assign(M, 0);
+            _phaseSpectrum.assign(M, 0);
+            for (std::size_t k = 0; k < M; ++k) { // fft_common.hpp:20-56, 91-123
+                const value_type mag = std::hypot(_outData[k].real(), _outData[k].imag()) * value_type(2) / static_cast<value_type>(N);
+                _magnitudeSpectrum[k] = !outputInDb ? mag : mag > value_type(0) ? value_type(20) * std::log10(mag) : std::numeric_limits<value_type>::lowest();
+                _phaseSpectrum[k]     = std::atan2(_outData[k].imag(), _outData[k].real());
+            }
+            if (unwrapPhase) { // fft_common.hpp:71-89
+                const value_type pi = std::numbers::pi_v<value_type>;
+                value_type prev = _phaseSpectrum.front();
+                for (std::size_t k = 1; k < M; ++k) {
+                    value_type& cur = _phaseSpectrum[k];
+                    while (cur - prev > pi) cur -= 2 * pi;
+                    while (cur - prev < -pi) cur += 2 * pi;
+                    prev = cur;
+                }
+            }
+            if (outputInDeg) for (auto& ph : _phaseSpectrum) ph = ph * value_type(180) * std::numbers::inv_pi_v<value_type>;
+            if (computeFullSpectrum) {
+                std::rotate(_magnitudeSpectrum.begin(), _magnitudeSpectrum.begin() + static_cast<std::ptrdiff_t>(M / 2), _magnitudeSpectrum.end());
+                std::rotate(_phaseSpectrum.begin(), _phaseSpectrum.begin() + static_cast<std::ptrdiff_t>(M / 2), _phaseSpectrum.end());
+            }
+            output[f] = createDataset();
+        }
+        return work::Status::OK;
+    }
+
+    // the descriptive part of the DataSet (everything but signal_values / signal_ranges), fft.hpp:173-250
+    [[nodiscard]] U datasetSkeleton() const {
+        U ds{};
+        const std::size_t N = nBins();
+        ds.extents    = {static_cast<std::int32_t>(N)};
+        ds.axis_names = {"Frequency"};
+        ds.axis_units = {"Hz"};
+        ds.axis_values.assign(1, std::vector<value_type>(N));
+        const value_type freqWidth = static_cast<value_type>(sample_rate.value) / static_cast<value_type>(fftSize.value);
+        const value_type freqOffset = computeFullSpectrum ? static_cast<value_type>(N / 2) * freqWidth : value_type(0);
+        for (std::size_t i = 0; i < N; ++i) ds.axis_values[0][i] = static_cast<value_type>(i) * freqWidth - freqOffset;
+        const std::string& n = signal_name.value;
+        ds.signal_names      = {"Magnitude(" + n + ")", "Phase(" + n + ")", "Re(FFT(" + n + "))", "Im(FFT(" + n + "))"};
+        ds.signal_quantities = {"Magnitude(FFT)", "Phase(FFT)", "Re(FFT)", "Im(FFT)"};
+        ds.signal_units      = {signal_unit.value + "/\u221aHz", "rad", "Re" + signal_unit.value, "Im" + signal_unit.value};
+        ds.signal_values.assign(4 * N, 0);
+        ds.signal_ranges.assign(4, {});
+        typename decltype(ds.meta_information)::value_type meta{{"sample_rate", sample_rate.value}, {"window", window.value}, {"output_in_db", outputInDb.value},
+            {"output_in_deg", outputInDeg.value}, {"unwrap_phase", unwrapPhase.value}, {"input_chunk_size", std::uint64_t(this->input_chunk_size)},
+            {"output_chunk_size", std::uint64_t(this->output_chunk_size)}};
+        ds.meta_information.assign(4, meta);
+        return ds;
+    }
+    [[nodiscard]] U createDataset() const {
+        U                 ds = datasetSkeleton();
+        const std::size_t N  = nBins();
+        std::copy_n(_magnitudeSpectrum.begin(), N, ds.signalValues(0).begin());
+        std::copy_n(_phaseSpectrum.begin(), N, ds.signalValues(1).begin());
+        const auto spec = std::span<const std::complex<value_type>>(_outData).last(N); // real input: the upper half (fft.hpp:221-227)
+        for (std::size_t i = 0; i < N; ++i) {
+            ds.signalValues(2)[i] = spec[i].real();
+            ds.signalValues(3)[i] = spec[i].imag();
+        }
+        for (std::size_t i = 0; i < 4; ++i) {
+            const auto sv       = ds.signalValues(i);
+            const auto mm       = std::minmax_element(sv.begin(), sv.end());
+            ds.signal_ranges[i] = {*mm.first, *mm.second};
+        }
+        return ds;
+    }
+
+private:
+    static void dft(std::vector<std::complex<double>>& v) {
+        const std::size_t N = v.size();
+        if (N && !(N & (N - 1))) {
+            for (std::size_t i = 1, j = 0; i < N; ++i) {
+                std::size_t bit = N >> 1;
+                for (; j & bit; bit >>= 1) j ^= bit;
+                j ^= bit;
+                if (i < j) std::swap(v[i], v[j]);
+            }
+            for (std::size_t len = 2; len <= N; len <<= 1)
+                for (std::size_t k = 0; k < N; k += len)
+                    for (std::size_t n = 0; n < len / 2; ++n) {
+                        const auto w = std::polar(1.0, -2.0 * std::numbers::pi * static_cast<double>(n) / static_cast<double>(len));
+                        const auto t = v[k + n + len / 2] * w;
+                        v[k + n + len / 2] = v[k + n] - t;
+                        v[k + n] += t;
+                    }
+            return;
+        }
+        std::vector<std::complex<double>> o(N);
+        for (std::size_t k = 0; k < N; ++k)
+            for (std::size_t n = 0; n < N; ++n) o[k] += v[n] * std::polar(1.0, -2.0 * std::numbers::pi * static_cast<double>((k * n) % N) / static_cast<double>(N));
+        v = std::move(o);
     }
 };
 } // namespace gr::blocks::fft

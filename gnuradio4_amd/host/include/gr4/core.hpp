@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cctype>
 #include <complex>
 #include <cstddef>
 #include <cstdint>
@@ -92,6 +93,11 @@ bool assign_from(T& dst, const pmt& v) {
             } else if constexpr (std::is_enum_v<T> && std::is_arithmetic_v<X>) {
                 dst = static_cast<T>(static_cast<std::underlying_type_t<T>>(x));
                 return true;
+            } else if constexpr (std::is_enum_v<T> && std::is_same_v<X, std::string>) {
+                // enum settings by (case-insensitive) name, the role of magic_enum::enum_cast in the reference; the enum's header provides
+                // bool gr_enum_parse(T&, std::string_view) next to its definition (found by ADL)
+                if constexpr (requires(T& d, std::string_view sv) { { gr_enum_parse(d, sv) } -> std::same_as<bool>; }) return gr_enum_parse(dst, std::string_view(x));
+                else return false;
             } else if constexpr (std::is_arithmetic_v<T> && std::is_arithmetic_v<X>) {
                 dst = static_cast<T>(x);
                 return true;
@@ -116,6 +122,52 @@ bool assign_from(T& dst, const pmt& v) {
         v);
 }
 } // namespace detail
+
+// case-insensitive lookup of `name` in a list of enumerator names (helper for the gr_enum_parse overloads)
+namespace detail {
+template <typename E, std::size_t N>
+bool enum_from_names(E& dst, std::string_view name, const std::array<std::string_view, N>& names) {
+    for (std::size_t i = 0; i < N; ++i) {
+        if (names[i].size() != name.size()) continue;
+        bool eq = true;
+        for (std::size_t c = 0; c < name.size() && eq; ++c) eq = std::tolower(static_cast<unsigned char>(names[i][c])) == std::tolower(static_cast<unsigned char>(name[c]));
+        if (eq) { dst = static_cast<E>(i); return true; }
+    }
+    return false;
+}
+} // namespace detail
+
+// ---------------------------------------------------------------------------------------------- DataSet<T> (core/include/gnuradio-4.0/DataSet.hpp), the fields
+// the FFT block fills (blocks/fourier/.../fft.hpp:173-250): one dependent axis, nSignals x N values stored signal after signal
+template <typename T>
+struct Range {
+    T min{}, max{};
+    bool operator==(const Range&) const = default;
+};
+template <typename T>
+struct DataSet {
+    using value_type = T;
+    std::int64_t                  timestamp = 0;
+    std::vector<std::string>      axis_names, axis_units;
+    std::vector<std::vector<T>>   axis_values;
+    std::vector<std::int32_t>     extents;
+    std::vector<std::string>      signal_names, signal_quantities, signal_units;
+    std::vector<T>                signal_values;
+    std::vector<Range<T>>         signal_ranges;
+    std::vector<std::map<std::string, std::variant<bool, std::int64_t, std::uint64_t, double, float, std::string>, std::less<>>> meta_information;
+    [[nodiscard]] std::size_t nDimensions() const noexcept { return extents.size(); }
+    [[nodiscard]] std::size_t size() const noexcept { return signal_names.size(); } // number of signals
+    [[nodiscard]] std::span<T>       axisValues(std::size_t d) { return axis_values.at(d); }
+    [[nodiscard]] std::span<const T> axisValues(std::size_t d) const { return axis_values.at(d); }
+    [[nodiscard]] std::span<T> signalValues(std::size_t i) {
+        const std::size_t n = size() ? signal_values.size() / size() : 0;
+        return std::span<T>(signal_values).subspan(i * n, n);
+    }
+    [[nodiscard]] std::span<const T> signalValues(std::size_t i) const {
+        const std::size_t n = size() ? signal_values.size() / size() : 0;
+        return std::span<const T>(signal_values).subspan(i * n, n);
+    }
+};
 
 // ---------------------------------------------------------------------------------------------- compile-time strings
 template <std::size_t N>
@@ -211,11 +263,13 @@ struct EdgeBuffer final : EdgeBufferBase {
     [[nodiscard]] std::size_t available_items() const noexcept override { return available(); }
     [[nodiscard]] std::size_t free_items() const noexcept override { return free_space(); }
     void read_items(void* dst, std::size_t n) override {
-        std::memcpy(dst, read_span(n).data(), n * sizeof(T));
+        if constexpr (std::is_trivially_copyable_v<T>) std::memcpy(dst, read_span(n).data(), n * sizeof(T));
+        else throw std::logic_error("type-erased element IO needs a trivially copyable sample type");
         consume(n);
     }
     void write_items(const void* src, std::size_t n) override {
-        std::memcpy(write_span(n).data(), src, n * sizeof(T));
+        if constexpr (std::is_trivially_copyable_v<T>) std::memcpy(write_span(n).data(), src, n * sizeof(T));
+        else throw std::logic_error("type-erased element IO needs a trivially copyable sample type");
         publish(n);
     }
 };

@@ -13,6 +13,7 @@
 #include <cctype>
 #include <cstring>
 #include <mutex>
+#include <numeric>
 #include <span>
 #include <functional>
 #include <iostream>
@@ -110,22 +111,89 @@ struct ChainStage final : Stage {
     }
 };
 
+template <typename T>
+constexpr int dtype_of() { // gr4hip_dtype of a sample type
+    if constexpr (std::is_same_v<T, std::uint8_t>) return GR4HIP_U8; else if constexpr (std::is_same_v<T, std::uint16_t>) return GR4HIP_U16;
+    else if constexpr (std::is_same_v<T, std::uint32_t>) return GR4HIP_U32; else if constexpr (std::is_same_v<T, std::uint64_t>) return GR4HIP_U64;
+    else if constexpr (std::is_same_v<T, std::int8_t>) return GR4HIP_I8; else if constexpr (std::is_same_v<T, std::int16_t>) return GR4HIP_I16;
+    else if constexpr (std::is_same_v<T, std::int32_t>) return GR4HIP_I32; else if constexpr (std::is_same_v<T, std::int64_t>) return GR4HIP_I64;
+    else if constexpr (std::is_same_v<T, float>) return GR4HIP_F32; else if constexpr (std::is_same_v<T, double>) return GR4HIP_F64;
+    else if constexpr (std::is_same_v<T, std::complex<float>>) return GR4HIP_C32; else return GR4HIP_C64;
+}
+
 template <typename T, int OP>
 struct MathConstStage final : Stage {
     T value;
     explicit MathConstStage(T v) : value(v) { in_bytes = out_bytes = sizeof(T); }
     std::string_view kind() const override { return "math_const"; }
-    static constexpr int dtype() {
-        if constexpr (std::is_same_v<T, std::uint8_t>) return GR4HIP_U8; else if constexpr (std::is_same_v<T, std::uint16_t>) return GR4HIP_U16;
-        else if constexpr (std::is_same_v<T, std::uint32_t>) return GR4HIP_U32; else if constexpr (std::is_same_v<T, std::uint64_t>) return GR4HIP_U64;
-        else if constexpr (std::is_same_v<T, std::int8_t>) return GR4HIP_I8; else if constexpr (std::is_same_v<T, std::int16_t>) return GR4HIP_I16;
-        else if constexpr (std::is_same_v<T, std::int32_t>) return GR4HIP_I32; else if constexpr (std::is_same_v<T, std::int64_t>) return GR4HIP_I64;
-        else if constexpr (std::is_same_v<T, float>) return GR4HIP_F32; else if constexpr (std::is_same_v<T, double>) return GR4HIP_F64;
-        else if constexpr (std::is_same_v<T, std::complex<float>>) return GR4HIP_C32; else return GR4HIP_C64;
-    }
+    static constexpr int dtype() { return dtype_of<T>(); }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
         *n_out = n;
         return gr4hip_math_const(OP, dtype(), in, out, n, &value, s);
+    }
+};
+
+// iir_filter<float, form> (one section with the user's b, a) and designed cascades
+struct IirStage final : Stage {
+    gr4hip_iir_t* h = nullptr;
+    IirStage(int form, std::size_t nsections, const std::vector<float>& b, std::size_t nb, const std::vector<float>& a, std::size_t na) {
+        check(gr4hip_iir_create(&h, form, nsections, b.data(), nb, a.data(), na), "gr4hip_iir_create");
+    }
+    ~IirStage() override { gr4hip_iir_destroy(h); }
+    std::string_view kind() const override { return "iir_f32"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        *n_out = n;
+        return gr4hip_iir_process(h, static_cast<const float*>(in), n, static_cast<float*>(out), s);
+    }
+};
+
+template <typename T>
+struct DecimatorStage final : Stage {
+    std::size_t decim;
+    explicit DecimatorStage(std::size_t d) : decim(std::max<std::size_t>(1, d)) { in_bytes = out_bytes = sizeof(T); in_chunk = decim; out_chunk = 1; }
+    std::string_view kind() const override { return "decimator"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override { return gr4hip_decimate(dtype_of<T>(), in, n, decim, out, n_out, s); }
+};
+
+struct RotatorStage final : Stage {
+    gr4hip_rotator_t* h = nullptr;
+    RotatorStage(float phase_increment, float initial_phase) {
+        in_bytes = out_bytes = 8;
+        check(gr4hip_rotator_create(&h, phase_increment, initial_phase), "gr4hip_rotator_create");
+    }
+    ~RotatorStage() override { gr4hip_rotator_destroy(h); }
+    std::string_view kind() const override { return "rotator_c32"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        *n_out = n;
+        return gr4hip_rotator_process(h, in, out, n, s);
+    }
+};
+
+// BasicFilterProto<float, ...>: designed FIR (polyphase when decimating: only the kept outputs are computed) or designed IIR cascade at the
+// full rate followed by the keep-every-D-th step (time_domain_filter.hpp:190-204)
+struct BasicFilterStage final : Stage {
+    gr4hip_fir_t* fir = nullptr;
+    gr4hip_iir_t* iir = nullptr;
+    std::size_t   decim;
+    DevBuf        tmp;
+    BasicFilterStage(const gr::filter::DesignedFilter& d, std::size_t decimate) : decim(std::max<std::size_t>(1, decimate)) {
+        in_chunk = decim; out_chunk = 1;
+        if (d.fir) {
+            check(gr4hip_fir_create(&fir, GR4HIP_F32, d.taps.data(), d.taps.size(), decim), "gr4hip_fir_create");
+        } else {
+            std::vector<float> b, a;
+            for (std::size_t s = 0; s < d.b.size(); ++s) { b.insert(b.end(), d.b[s].begin(), d.b[s].end()); a.insert(a.end(), d.a[s].begin(), d.a[s].end()); }
+            check(gr4hip_iir_create(&iir, GR4HIP_DF_II, d.b.size(), b.data(), 3, a.data(), 3), "gr4hip_iir_create");
+        }
+    }
+    ~BasicFilterStage() override { if (fir) gr4hip_fir_destroy(fir); if (iir) gr4hip_iir_destroy(iir); }
+    std::string_view kind() const override { return fir ? (decim > 1 ? "basic_fir_decim" : "basic_fir") : (decim > 1 ? "basic_iir_decim" : "basic_iir"); }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        if (fir) return gr4hip_fir_process(fir, in, n, out, n_out, s);
+        if (decim == 1) { *n_out = n; return gr4hip_iir_process(iir, static_cast<const float*>(in), n, static_cast<float*>(out), s); }
+        float* y = static_cast<float*>(tmp.ensure(n * sizeof(float)));
+        if (const int rc = gr4hip_iir_process(iir, static_cast<const float*>(in), n, y, s)) return rc;
+        return gr4hip_decimate(GR4HIP_F32, y, n, decim, out, n_out, s);
     }
 };
 
@@ -146,6 +214,7 @@ inline int window_id(const std::string& w) { // gr::algorithm::window::TypeNames
 
 // ---------------------------------------------------------------------------------------------- per-block offload at the seam
 struct Offload { // state behind Block::_device_state
+    virtual ~Offload() = default;
     std::unique_ptr<Stage> stage;
     DevBuf                 d_in, d_out, h_in{true}, h_out{true};
     int                    device = 0;
@@ -204,6 +273,132 @@ struct Kernel<gr::blocks::fft::PowerSpectrum<std::complex<float>>> {
     using B = gr::blocks::fft::PowerSpectrum<std::complex<float>>;
     static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<PowerSpectrumStage>(b.fftSize, window_id(b.window)); }
     static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+
+template <gr::filter::IIRForm form>
+struct Kernel<gr::filter::iir_filter<float, form>> {
+    using B = gr::filter::iir_filter<float, form>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<IirStage>(static_cast<int>(form), 1, b.b, b.b.size(), b.a, b.a.size()); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+template <typename T>
+struct Kernel<gr::filter::Decimator<T>> {
+    using B = gr::filter::Decimator<T>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<DecimatorStage<T>>(b.decim); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+template <typename... Args>
+struct Kernel<gr::filter::BasicFilterProto<float, Args...>> {
+    using B = gr::filter::BasicFilterProto<float, Args...>;
+    static std::unique_ptr<Stage> make_stage(B& b) {
+        if (!b._designed) b.designFilter();
+        return std::make_unique<BasicFilterStage>(b._design, B::TParent::ResamplingControl::kIsConst ? 1 : b.decimate.value);
+    }
+    static work::Status work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+template <>
+struct Kernel<gr::blocks::math::Rotator<std::complex<float>>> {
+    using B = gr::blocks::math::Rotator<std::complex<float>>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<RotatorStage>(b.phase_increment, b._accumulated_phase); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+
+// N inputs -> 1 output at the seam (Math.hpp:100-107): every input span goes to HBM, one fold kernel, one span back.  No Stage: a
+// fan-in is not part of a linear device run, the planner leaves it to this per-block path.
+template <typename T, typename op>
+struct Kernel<gr::blocks::math::MathOpMultiPortImpl<T, op>> {
+    using B = gr::blocks::math::MathOpMultiPortImpl<T, op>;
+    struct State final : Offload {
+        std::vector<std::unique_ptr<DevBuf>> d_ins;
+    };
+    static work::Status work(B& blk, std::size_t nIn, std::size_t nOut) {
+        try {
+            auto* st = static_cast<State*>(static_cast<Offload*>(blk._device_state));
+            if (!st) {
+                st         = new State();
+                st->device = blk._domain.index;
+                check(gr4hip_set_device(st->device), "gr4hip_set_device");
+                blk._device_state = static_cast<Offload*>(st);
+            }
+            while (st->d_ins.size() < blk.in.size()) st->d_ins.push_back(std::make_unique<DevBuf>());
+            const std::size_t        bytes = nIn * sizeof(T);
+            std::vector<const void*> ptrs;
+            char*                    stage = static_cast<char*>(st->h_in.ensure(bytes * blk.in.size()));
+            for (std::size_t i = 0; i < blk.in.size(); ++i) {
+                std::memcpy(stage + i * bytes, blk.in[i].buffer->read_span(nIn).data(), bytes);
+                check(gr4hip_memcpy_h2d(st->d_ins[i]->ensure(bytes), stage + i * bytes, bytes, nullptr), "h2d");
+                ptrs.push_back(st->d_ins[i]->p);
+            }
+            check(gr4hip_math_nary(op_id<op, T>(), dtype_of<T>(), ptrs.data(), ptrs.size(), st->d_out.ensure(bytes), nIn, nullptr), "gr4hip_math_nary");
+            check(gr4hip_memcpy_d2h(st->h_out.ensure(bytes), st->d_out.p, bytes, nullptr), "d2h");
+            check(gr4hip_stream_synchronize(nullptr), "sync");
+            std::memcpy(blk.out.buffer->write_span(nOut).data(), st->h_out.p, nOut * sizeof(T));
+            return work::Status::OK;
+        } catch (const std::exception& e) {
+            blk._log(std::string("device block '") + blk.name + "' failed: " + e.what());
+            return work::Status::ERROR;
+        }
+    }
+};
+
+// FFT block: nOut frames of fftSize samples in, nOut DataSets out.  The four signals and their ranges are computed on the device
+// (gr4hip_fft_process); the host only assembles the descriptive part of the DataSet (axis, names, meta information).
+template <typename T>
+requires(std::is_same_v<T, float> || std::is_same_v<T, std::complex<float>>)
+struct Kernel<gr::blocks::fft::FFT<T, DataSet<float>>> {
+    using B = gr::blocks::fft::FFT<T, DataSet<float>>;
+    struct State final : Offload {
+        gr4hip_fft_t* h = nullptr;
+        std::size_t   N = 0;
+        std::string   window;
+        int           flags = -1;
+        DevBuf        d_sig, d_rng, h_rng{true};
+        ~State() override { if (h) gr4hip_fft_destroy(h); }
+    };
+    static work::Status work(B& blk, std::size_t nIn, std::size_t nOut) {
+        try {
+            auto* st = static_cast<State*>(static_cast<Offload*>(blk._device_state));
+            if (!st) {
+                st         = new State();
+                st->device = blk._domain.index;
+                check(gr4hip_set_device(st->device), "gr4hip_set_device");
+                blk._device_state = static_cast<Offload*>(st);
+            }
+            const int flags = (blk.outputInDb ? GR4HIP_FFT_OUTPUT_IN_DB : 0) | (blk.outputInDeg ? GR4HIP_FFT_OUTPUT_IN_DEG : 0) | (blk.unwrapPhase ? GR4HIP_FFT_UNWRAP_PHASE : 0);
+            if (!st->h || st->N != blk.fftSize || st->window != blk.window.value || st->flags != flags) { // settings changed: new plan
+                if (st->h) gr4hip_fft_destroy(st->h);
+                st->h = nullptr;
+                check(gr4hip_fft_create(&st->h, dtype_of<T>(), blk.fftSize, window_id(blk.window), flags), "gr4hip_fft_create");
+                st->N = blk.fftSize; st->window = blk.window; st->flags = flags;
+            }
+            const std::size_t N = st->N, M = blk.nBins(), frames = nOut;
+            if (nIn != frames * N) throw std::runtime_error("FFT: the work loop must hand over whole frames");
+            std::memcpy(st->h_in.ensure(nIn * sizeof(T)), blk.in.buffer->read_span(nIn).data(), nIn * sizeof(T));
+            check(gr4hip_memcpy_h2d(st->d_in.ensure(nIn * sizeof(T)), st->h_in.p, nIn * sizeof(T), nullptr), "h2d");
+            float* sig = static_cast<float*>(st->d_sig.ensure(4 * frames * M * sizeof(float))); // [mag | phase | re | im], each frames x M
+            float* rng = static_cast<float*>(st->d_rng.ensure(frames * 8 * sizeof(float)));
+            check(gr4hip_fft_process(st->h, st->d_in.p, frames, sig, sig + frames * M, sig + 2 * frames * M, sig + 3 * frames * M, rng, nullptr), "gr4hip_fft_process");
+            check(gr4hip_memcpy_d2h(st->h_out.ensure(4 * frames * M * sizeof(float)), sig, 4 * frames * M * sizeof(float), nullptr), "d2h");
+            check(gr4hip_memcpy_d2h(st->h_rng.ensure(frames * 8 * sizeof(float)), rng, frames * 8 * sizeof(float), nullptr), "d2h");
+            check(gr4hip_stream_synchronize(nullptr), "sync");
+            const float* hs = static_cast<const float*>(st->h_out.p);
+            const float* hr = static_cast<const float*>(st->h_rng.p);
+            auto         os = blk.out.buffer->write_span(nOut);
+            const auto   skeleton = blk.datasetSkeleton();
+            for (std::size_t f = 0; f < frames; ++f) {
+                DataSet<float> ds = skeleton;
+                for (std::size_t i = 0; i < 4; ++i) {
+                    std::memcpy(ds.signalValues(i).data(), hs + (i * frames + f) * M, M * sizeof(float));
+                    ds.signal_ranges[i] = {hr[f * 8 + 2 * i], hr[f * 8 + 2 * i + 1]};
+                }
+                os[f] = std::move(ds);
+            }
+            return work::Status::OK;
+        } catch (const std::exception& e) {
+            blk._log(std::string("device block '") + blk.name + "' failed: " + e.what());
+            return work::Status::ERROR;
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------------- GPU-resident BufferLike ring
@@ -311,7 +506,7 @@ class DeviceRun final : public BlockModel {
     DevBuf          _h_in{true}, _h_out{true}, _d_a, _d_b;
     std::string     _name = "device_run";
     ComputeDomain   _domain;
-    std::size_t     _in_bytes, _out_bytes, _in_chunk = 1;
+    std::size_t     _in_bytes, _out_bytes, _in_chunk = 1, _out_per_chunk = 1; // smallest input count every stage sees as whole chunks, and what it becomes
     std::size_t     _launches = 0;
     std::string     _desc;
 
@@ -323,7 +518,16 @@ public:
         _space = [out] { return out->free_items(); };
         _read  = [in](void* dst, std::size_t n) { in->read_items(dst, n); };
         _write = [out](const void* src, std::size_t n) { out->write_items(src, n); };
-        for (auto& s : _stages) { _in_chunk = std::max(_in_chunk, s->in_chunk); _desc += std::string(_desc.empty() ? "" : " -> ") + std::string(s->kind()); }
+        for (auto& s : _stages) _desc += std::string(_desc.empty() ? "" : " -> ") + std::string(s->kind());
+        // rate bookkeeping (Resampling<>, Block.hpp:1576-1636, across the whole run): walking back from the last stage, `need` is the count a
+        // stage's output must be a multiple of; it produces out_chunk per in_chunk
+        std::size_t need = 1;
+        for (auto it = _stages.rbegin(); it != _stages.rend(); ++it) {
+            const std::size_t k = need / std::gcd(need, (*it)->out_chunk); // chunks so that k * out_chunk is a multiple of need
+            need                = k * (*it)->in_chunk;
+        }
+        _in_chunk      = need;
+        _out_per_chunk = out_count(_in_chunk);
         check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
         check(gr4hip_stream_create(&_stream), "gr4hip_stream_create");
         check(gr4hip_ring_create(&_ring, std::size_t(64) << 20), "gr4hip_ring_create"); // GPU-resident double-mapped input ring
@@ -335,6 +539,10 @@ public:
         if (_ring) gr4hip_ring_destroy(_ring);
         if (_stream) gr4hip_stream_destroy(_stream);
     }
+    [[nodiscard]] std::size_t out_count(std::size_t n_in) const { // elements leaving the last stage for n_in entering the first
+        for (auto& s : _stages) n_in = n_in / s->in_chunk * s->out_chunk;
+        return n_in;
+    }
     std::string_view           description() const { return _desc; }
     [[nodiscard]] std::size_t  launches() const { return _launches; }
     const std::vector<std::unique_ptr<Stage>>& stages() const { return _stages; }
@@ -342,9 +550,7 @@ public:
     work::Result work(std::size_t requested) override {
         try {
             std::size_t n = std::min({_avail(), requested, _ring_bytes / _in_bytes / 2});
-            n -= n % _in_chunk;
-            // output budget: every stage maps whole chunks 1:1 in sample count on this path (fir: n->n, spectrum: N complex -> N floats)
-            n = std::min(n, _space() - _space() % _in_chunk);
+            n = std::min(n / _in_chunk, _space() / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
             if (n == 0) {
                 if (_avail() < _in_chunk && _in_edge->producer_done) {
                     _out_edge->producer_done = true;
@@ -362,7 +568,9 @@ public:
             for (std::size_t i = 0; i < _stages.size(); ++i) { // stages run back-to-back on one stream; intermediates stay in HBM
                 DevBuf&     dst = (i % 2) ? _d_b : _d_a;
                 std::size_t out = 0;
-                check(_stages[i]->enqueue(cur, cnt, dst.ensure(std::max<std::size_t>(cnt, 1) * std::max(_stages[i]->out_bytes, _stages[i]->in_bytes)), &out, _stream), "stage");
+                const std::size_t expect = cnt / _stages[i]->in_chunk * _stages[i]->out_chunk;
+                check(_stages[i]->enqueue(cur, cnt, dst.ensure(std::max<std::size_t>(expect, 1) * _stages[i]->out_bytes), &out, _stream), "stage");
+                if (out != expect) throw std::runtime_error("stage '" + std::string(_stages[i]->kind()) + "' produced an unexpected number of samples");
                 cur = dst.p;
                 cnt = out;
                 ++_launches;

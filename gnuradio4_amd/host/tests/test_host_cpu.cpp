@@ -130,6 +130,81 @@ int main(int argc, char** argv) {
         const auto d = ComputeDomain::parse("gpu:hip:1");
         EXPECT(d.kind == "gpu" && d.backend == "hip" && d.index == 1 && d.is_device() && !ComputeDomain::parse("host").is_device());
     }
+    // ---- BasicFilter / BasicDecimatingFilter: designed low-pass (order 4, f_low 100 Hz, fs 1 kHz; Hamming FIR / Chebyshev-1 IIR) passes 50 Hz >= 0.9,
+    //      attenuates 300 Hz <= 0.2 (qa_filter.cpp:144-265); settings by enumerator name like the reference's property_map strings
+    for (const char* kind : {"FIR", "IIR"}) {
+        const property_map cfg{{"filter_type", std::string(kind)}, {"filter_response", "LOWPASS"s}, {"filter_order", std::int64_t(4)}, {"f_low", 100.0}, {"sample_rate", 1000.0},
+                               {"iir_design_method", "Chebyshev1"s}, {"fir_design_method", "Hamming"s}};
+        for (const double freq : {50.0, 300.0}) {
+            filter::BasicFilter<float> f;
+            f.applySettings(cfg);
+            EXPECT((f.filter_type == (std::string(kind) == "FIR" ? filter::FilterType::FIR : filter::FilterType::IIR)));
+            float  peak = 0.f;
+            double phase = 0;
+            for (int i = 0; i < 2000; ++i) {
+                phase += 2 * std::numbers::pi * freq / 1000.0;
+                const float y = f.processOne(static_cast<float>(std::sin(phase)));
+                if (i >= 1000) peak = std::max(peak, std::abs(y)); // ignore the initial transient
+            }
+            EXPECT(freq < 100 ? peak >= 0.9f : peak <= 0.2f);
+
+            filter::BasicDecimatingFilter<double> d;
+            auto dcfg = cfg;
+            dcfg["decimate"] = std::int64_t(5);
+            d.applySettings(dcfg);
+            EXPECT(d.input_chunk_size == 5u);
+            std::vector<double> in(1000), out(200);
+            double              ph = 0, dpeak = 0;
+            for (int rep = 0; rep < 2; ++rep) {
+                for (auto& v : in) { ph += 2 * std::numbers::pi * freq / 1000.0; v = std::sin(ph); }
+                EXPECT(d.processBulk(in, out) == work::Status::OK);
+            }
+            for (double v : out) dpeak = std::max(dpeak, std::abs(v));
+            EXPECT(freq < 100 ? dpeak >= 0.9 : dpeak <= 0.2);
+        }
+    }
+    {
+        filter::BasicFilter<float> f;
+        bool threw = false;
+        try { f.applySettings({{"filter_type", "NOPE"s}}); } catch (const std::invalid_argument&) { threw = true; }
+        EXPECT(threw); // unknown enumerator name
+    }
+    // ---- FFT block: DataSet per frame; peak at 0.1 fs +- 1/N for N = 256, ranges = min/max of each signal (qa_fourier.cpp:53-109); real input: N/2 bins
+    {
+        constexpr std::size_t N = 256;
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<std::complex<float>>>();
+        for (std::size_t i = 0; i < 3 * N + 17; ++i) src.values.emplace_back(static_cast<float>(std::cos(2 * std::numbers::pi * 0.1 * double(i))), static_cast<float>(std::sin(2 * std::numbers::pi * 0.1 * double(i))));
+        auto& fft  = g.emplaceBlock<blocks::fft::FFT<std::complex<float>>>({{"fftSize", std::int64_t(N)}, {"sample_rate", 1.0}, {"window", "hann"s}});
+        auto& sink = g.emplaceBlock<testing::VectorSink<DataSet<float>>>();
+        EXPECT((g.connect<"out", "in">(src, fft)).has_value());
+        EXPECT((g.connect<"out", "in">(fft, sink)).has_value());
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        EXPECT(sink._samples.size() == 3u); // whole frames only, the 17 trailing samples are dropped
+        EXPECT(fft._windowType == algorithm::window::Type::Hann && fft.input_chunk_size == N && fft.output_chunk_size == 1u);
+        for (const auto& ds : sink._samples) {
+            EXPECT(ds.extents == std::vector<std::int32_t>{std::int32_t(N)} && ds.size() == 4u && ds.signal_values.size() == 4 * N && ds.axis_values[0].size() == N);
+            const auto        mag  = ds.signalValues(0);
+            const std::size_t peak = static_cast<std::size_t>(std::max_element(mag.begin(), mag.end()) - mag.begin());
+            EXPECT(std::abs(ds.axisValues(0)[peak] - 0.1f) <= 1.f / N);
+            EXPECT(ds.axis_values[0].front() == -0.5f);
+            for (std::size_t i = 0; i < 4; ++i) {
+                const auto sv = ds.signalValues(i);
+                EXPECT(ds.signal_ranges[i].min == *std::min_element(sv.begin(), sv.end()) && ds.signal_ranges[i].max == *std::max_element(sv.begin(), sv.end()));
+            }
+            EXPECT(ds.signal_names[0] == "Magnitude(unknown signal)" && ds.signal_quantities[3] == "Im(FFT)" && ds.meta_information.size() == 4u);
+        }
+        blocks::fft::FFT<float> rf;
+        rf.applySettings({{"fftSize", std::int64_t(64)}, {"window", "None"s}, {"sample_rate", 64.0}});
+        std::vector<float> x(64);
+        for (std::size_t i = 0; i < 64; ++i) x[i] = 5.f * static_cast<float>(std::sin(2 * std::numbers::pi * 8.0 * double(i) / 64.0));
+        std::vector<DataSet<float>> o(1);
+        EXPECT(rf.processBulk(x, o) == work::Status::OK);
+        EXPECT(o[0].extents[0] == 32 && o[0].axis_values[0][8] == 8.f);
+        EXPECT(std::abs(o[0].signalValues(0)[8] - 5.f) < 1e-4f); // amplitude of the sine at its bin (qa_algorithm_fourier.cpp:78-94)
+    }
     // ---- BASELINE configs[0]: SignalSource -> 64-tap float FIR -> sink, 1 000 448 samples (round_up(1e6, 1024), bm_MergeApi.cpp:20)
     {
         constexpr std::size_t N = 1000448, K = 64;

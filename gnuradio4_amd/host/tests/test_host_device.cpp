@@ -27,6 +27,34 @@ void dump(const std::string& path, const std::vector<T>& v) {
     f.write(reinterpret_cast<const char*>(v.data()), static_cast<std::streamsize>(v.size() * sizeof(T)));
 }
 
+// one block between a VectorSource and a VectorSink, on the host path or behind the compute_domain seam
+template <typename BlockT, typename TIn, typename TOut>
+std::vector<TOut> run_one(property_map settings, const std::vector<TIn>& input, bool device, int& errors) {
+    Graph g;
+    auto& src  = g.emplaceBlock<testing::VectorSource<TIn>>();
+    src.values = input;
+    if (device) settings["compute_domain"] = "gpu:hip:0"s;
+    auto& blk  = g.emplaceBlock<BlockT>(settings);
+    blk._log   = [](std::string_view m) { std::cerr << "[log] " << m << "\n"; };
+    auto& sink = g.emplaceBlock<testing::VectorSink<TOut>>();
+    if (!g.connect<"out", "in">(src, blk) || !g.connect<"out", "in">(blk, sink)) { ++errors; return {}; }
+    scheduler::Simple sched;
+    sched.exchange(std::move(g));
+    if (const auto r = sched.runAndWait(); !r) { std::cerr << "run_one: " << r.error().message << "\n"; ++errors; }
+    if (device) { if (!blk._device_state) ++errors; hip::release(blk); } // the seam must have been taken
+    return sink._samples;
+}
+template <typename T>
+double max_rel(const std::vector<T>& got, const std::vector<T>& want) { // max |got - want| / max(|want|, rms(want))
+    if (got.size() != want.size() || want.empty()) return 1e30;
+    double rms = 0;
+    for (const auto& v : want) rms += std::norm(std::complex<double>(v));
+    rms = std::sqrt(rms / double(want.size()));
+    double worst = 0;
+    for (std::size_t i = 0; i < want.size(); ++i) worst = std::max(worst, std::abs(std::complex<double>(got[i]) - std::complex<double>(want[i])) / std::max(std::abs(std::complex<double>(want[i])), rms));
+    return worst;
+}
+
 int main(int argc, char** argv) {
     if (argc < 5) { std::fprintf(stderr, "usage: %s in_c32.bin taps.bin fftSize out_prefix\n", argv[0]); return 2; }
     const auto        x    = load<std::complex<float>>(argv[1]);
@@ -149,6 +177,133 @@ int main(int argc, char** argv) {
             }
         }
         std::printf("device ring: capacity %zu floats, %s\n", cap, errors ? "FAILED" : "wrapping spans contiguous");
+    }
+    { // 5. every other hot-path block behind the seam, against the host body of the same block definition (the oracle comparison of the kernels
+      //    themselves is tests/test_gpu_parity.py; this checks the wiring: settings -> handle, chunking, state carried across work() calls)
+        std::vector<float> xf(300000);
+        std::uint32_t      lcg = 12345u;
+        for (auto& v : xf) { lcg = lcg * 1664525u + 1013904223u; v = static_cast<float>(static_cast<std::int32_t>(lcg >> 8) % 2001 - 1000) / 1000.f; }
+        std::vector<std::int32_t> xi(xf.size());
+        for (std::size_t i = 0; i < xi.size(); ++i) xi[i] = static_cast<std::int32_t>(xf[i] * 2.0e9f);
+        const auto report = [&](const char* what, double err, double tol) {
+            std::printf("seam %-34s max rel err %.3g%s\n", what, err, err <= tol ? "" : "  FAILED");
+            if (!(err <= tol)) ++errors;
+        };
+        const std::vector<double> bq_b{0.020083365564211, 0.040166731128423, 0.020083365564211}, bq_a{1.0, -1.561018075800718, 0.641351538057563}; // qa_filter.cpp:86-87
+        {
+            using B = filter::iir_filter<float, filter::IIRForm::DF_II>;
+            const property_map cfg{{"b", bq_b}, {"a", bq_a}};
+            report("iir_filter<float, DF_II>", max_rel(run_one<B, float, float>(cfg, xf, true, errors), run_one<B, float, float>(cfg, xf, false, errors)), 1e-5);
+            using BT = filter::iir_filter<float, filter::IIRForm::DF_I_TRANSPOSED>;
+            report("iir_filter<float, DF_I_TRANSPOSED>", max_rel(run_one<BT, float, float>(cfg, xf, true, errors), run_one<BT, float, float>(cfg, xf, false, errors)), 1e-5);
+        }
+        {
+            using B = filter::Decimator<std::int32_t>;
+            const property_map cfg{{"decim", std::int64_t(7)}};
+            const auto d = run_one<B, std::int32_t, std::int32_t>(cfg, xi, true, errors), h = run_one<B, std::int32_t, std::int32_t>(cfg, xi, false, errors);
+            report("Decimator<int32> decim 7", d == h && d.size() == xi.size() / 7 ? 0.0 : 1.0, 0.0);
+        }
+        {
+            using B = blocks::math::Rotator<std::complex<float>>;
+            std::vector<std::complex<float>> xc(100000);
+            for (std::size_t i = 0; i < xc.size(); ++i) xc[i] = {xf[2 * i], xf[2 * i + 1]};
+            const property_map cfg{{"phase_increment", 0.1}};
+            report("Rotator<complex<float>>", max_rel(run_one<B, std::complex<float>, std::complex<float>>(cfg, xc, true, errors), run_one<B, std::complex<float>, std::complex<float>>(cfg, xc, false, errors)), 1e-5);
+        }
+        for (const char* kind : {"FIR", "IIR"}) {
+            const property_map cfg{{"filter_type", std::string(kind)}, {"filter_response", "LOWPASS"s}, {"filter_order", std::int64_t(4)}, {"f_low", 100.0}, {"sample_rate", 1000.0},
+                                   {"iir_design_method", "CHEBYSHEV1"s}, {"fir_design_method", "Hamming"s}, {"decimate", std::int64_t(5)}};
+            using B = filter::BasicDecimatingFilter<float>;
+            const auto d = run_one<B, float, float>(cfg, xf, true, errors), h = run_one<B, float, float>(cfg, xf, false, errors);
+            report((std::string("BasicDecimatingFilter<float> ") + kind + " /5").c_str(), d.size() == xf.size() / 5 ? max_rel(d, h) : 1e30, 1e-5);
+            dump(out + "_basic_" + (std::string(kind) == "FIR" ? "fir" : "iir") + "5.bin", d);
+            auto cfg1 = cfg;
+            cfg1.erase("decimate");
+            using B1 = filter::BasicFilter<float>;
+            report((std::string("BasicFilter<float> ") + kind).c_str(), max_rel(run_one<B1, float, float>(cfg1, xf, true, errors), run_one<B1, float, float>(cfg1, xf, false, errors)), 1e-5);
+        }
+        dump(out + "_basic_in.bin", xf);
+        { // N inputs -> 1 output: Add<int32> wraps like the C++ sum, Multiply<float>
+            for (int dev = 1; dev >= 0; --dev) {
+                static std::vector<std::int32_t> keep[2];
+                Graph g;
+                auto& add = g.emplaceBlock<blocks::math::Add<std::int32_t>>(dev ? property_map{{"n_inputs", std::int64_t(3)}, {"compute_domain", "gpu:hip:0"s}} : property_map{{"n_inputs", std::int64_t(3)}});
+                for (std::size_t i = 0; i < 3; ++i) {
+                    auto& src  = g.emplaceBlock<testing::VectorSource<std::int32_t>>();
+                    src.values.assign(xi.begin() + static_cast<std::ptrdiff_t>(i * 1000), xi.begin() + static_cast<std::ptrdiff_t>(i * 1000 + 150000));
+                    if (!g.connect(src, "out"s, add, "in#"s + std::to_string(i))) ++errors;
+                }
+                auto& sink = g.emplaceBlock<testing::VectorSink<std::int32_t>>();
+                g.connect<"out", "in">(add, sink);
+                scheduler::Simple sched;
+                sched.exchange(std::move(g));
+                if (!sched.runAndWait()) ++errors;
+                if (dev && !add._device_state) ++errors;
+                if (dev) hip::release(add);
+                keep[dev] = sink._samples;
+                if (!dev) report("Add<int32> n_inputs = 3", keep[0] == keep[1] && keep[0].size() == 150000 ? 0.0 : 1.0, 0.0);
+            }
+        }
+        { // the FFT block: DataSets from the device equal the host body's (values to 1e-5 of the frame scale, identical descriptive part)
+            std::vector<std::complex<float>> xc(1000 * 3 + 5);
+            for (std::size_t i = 0; i < xc.size(); ++i) xc[i] = std::complex<float>(xf[2 * i], xf[2 * i + 1]) + std::polar(1.f, static_cast<float>(2 * std::numbers::pi * 0.1 * double(i % 1000)));
+            const auto compare = [&](const char* what, const std::vector<DataSet<float>>& d, const std::vector<DataSet<float>>& h, std::size_t frames) {
+                double worst = d.size() == frames && h.size() == frames ? 0.0 : 1e30;
+                for (std::size_t f = 0; f < frames && worst < 1e29; ++f) {
+                    if (d[f].axis_values != h[f].axis_values || d[f].signal_names != h[f].signal_names || d[f].signal_units != h[f].signal_units || d[f].extents != h[f].extents ||
+                        d[f].meta_information != h[f].meta_information) worst = 1e30;
+                    for (std::size_t i = 0; i < 4 && worst < 1e29; ++i) {
+                        const auto dv = d[f].signalValues(i), hv = h[f].signalValues(i);
+                        if (i == 1) continue; // phase wraps at +-pi and is noise in empty bins: pinned bin by bin against the oracle in tests/test_gpu_parity.py, by Re / Im here
+                        worst = std::max(worst, max_rel(std::vector<float>(dv.begin(), dv.end()), std::vector<float>(hv.begin(), hv.end())));
+                        const float span = std::max(std::abs(h[f].signal_ranges[i].min), std::abs(h[f].signal_ranges[i].max));
+                        worst = std::max<double>(worst, std::abs(d[f].signal_ranges[i].min - h[f].signal_ranges[i].min) / span);
+                        worst = std::max<double>(worst, std::abs(d[f].signal_ranges[i].max - h[f].signal_ranges[i].max) / span);
+                    }
+                    const auto sv = d[f].signalValues(1); // the device ranges are the min / max of the device's own phase values
+                    if (d[f].signal_ranges[1].min != *std::min_element(sv.begin(), sv.end()) || d[f].signal_ranges[1].max != *std::max_element(sv.begin(), sv.end())) worst = 1e30;
+                }
+                report(what, worst, 2e-5);
+            };
+            for (const std::int64_t N : {std::int64_t(256), std::int64_t(1000)}) { // power of two and Bluestein
+                using B = blocks::fft::FFT<std::complex<float>>;
+                const property_map cfg{{"fftSize", N}, {"window", N == 256 ? "Hann"s : "BlackmanHarris"s}, {"sample_rate", 1000.0}, {"signal_name", "ch0"s}};
+                compare(N == 256 ? "FFT<complex<float>> 256 Hann" : "FFT<complex<float>> 1000 B-Harris", run_one<B, std::complex<float>, DataSet<float>>(cfg, xc, true, errors),
+                        run_one<B, std::complex<float>, DataSet<float>>(cfg, xc, false, errors), xc.size() / static_cast<std::size_t>(N));
+            }
+            using BR = blocks::fft::FFT<float>;
+            const property_map cfg{{"fftSize", std::int64_t(512)}, {"window", "Hamming"s}, {"outputInDb", true}};
+            compare("FFT<float> 512 Hamming dB", run_one<BR, float, DataSet<float>>(cfg, xf, true, errors), run_one<BR, float, DataSet<float>>(cfg, xf, false, errors), xf.size() / 512);
+        }
+        { // planner over resampling stages: MultiplyConst -> BasicDecimatingFilter(FIR, /4) -> Decimator(/3) -> iir_filter, one run, one stream
+            std::vector<float> got[2];
+            for (int dev = 1; dev >= 0; --dev) {
+                Graph g;
+                const auto dom = [&](property_map m) { if (dev) m["compute_domain"] = "gpu:hip:0"s; return m; };
+                auto& src  = g.emplaceBlock<testing::VectorSource<float>>();
+                src.values = xf;
+                auto& mul  = g.emplaceBlock<blocks::math::MultiplyConst<float>>(dom({{"value", 0.5}}));
+                auto& bdf  = g.emplaceBlock<filter::BasicDecimatingFilter<float>>(dom({{"filter_type", "FIR"s}, {"filter_order", std::int64_t(4)}, {"f_low", 50.0}, {"sample_rate", 1000.0}, {"fir_design_method", "Hamming"s}, {"decimate", std::int64_t(4)}}));
+                auto& dec  = g.emplaceBlock<filter::Decimator<float>>(dom({{"decim", std::int64_t(3)}}));
+                auto& iir  = g.emplaceBlock<filter::iir_filter<float>>(dom({{"b", bq_b}, {"a", bq_a}}));
+                auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+                g.connect<"out", "in">(src, mul);
+                g.connect<"out", "in">(mul, bdf);
+                g.connect<"out", "in">(bdf, dec);
+                g.connect<"out", "in">(dec, iir);
+                g.connect<"out", "in">(iir, sink);
+                if (dev) {
+                    const auto runs = hip::plan(g);
+                    std::printf("planner (resampling): %zu run:%s%s\n", runs.size(), runs.empty() ? "" : " ", runs.empty() ? "" : std::string(runs[0]->description()).c_str());
+                    if (runs.size() != 1 || runs[0]->description() != "math_const -> basic_fir_decim -> decimator -> iir_f32" || runs[0]->out_count(12) != 1) ++errors;
+                }
+                scheduler::Simple sched;
+                sched.exchange(std::move(g));
+                if (const auto r = sched.runAndWait(); !r) { std::cerr << "resampling run: " << r.error().message << "\n"; ++errors; }
+                got[dev] = sink._samples;
+            }
+            report("planned run with two rate changes", got[1].size() == xf.size() / 12 ? max_rel(got[1], got[0]) : 1e30, 1e-5);
+        }
     }
     std::printf(errors ? "host-device: %d FAILURES\n" : "host-device: all graphs ran\n", errors);
     return errors ? 1 : 0;

@@ -85,6 +85,22 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     xin = np.resize(np.array([1.0, -2.0, 3.0, 0.5, 0.25], np.float64), 200000) * 2.0
     want = (np.convolve(xin, [0.5, 0.25, 0.25])[:200000] + 1.0) * 3.0
     assert len(pf) == 200000 and np.max(np.abs(pf - want)) <= 1e-5
+    # every other hot-path block behind the seam (device vs the host body of the same block, printed by the program) ...
+    for what in ("iir_filter<float, DF_II>", "Decimator<int32> decim 7", "Rotator<complex<float>>", "BasicDecimatingFilter<float> FIR /5", "BasicFilter<float> IIR",
+                 "Add<int32> n_inputs = 3", "FFT<complex<float>> 256 Hann", "FFT<complex<float>> 1000 B-Harris", "FFT<float> 512 Hamming dB", "planned run with two rate changes"):
+        assert f"seam {what}" in r.stdout, what
+    assert "FAILED" not in r.stdout
+    assert "planner (resampling): 1 run: math_const -> basic_fir_decim -> decimator -> iir_f32" in r.stdout
+    # ... and BasicDecimatingFilter<float> (designed Hamming FIR / Chebyshev-1 IIR low-pass, order 4, 100 Hz at 1 kHz, decimate 5) against the oracle
+    xin = np.fromfile(tmp_path / "o_basic_in.bin", np.float32)
+    par = O.filter_params(order=4, fLow=100.0, fs=1000.0)
+    want, _ = O.fir_decim(O.fir_design(0, par, [w.lower() for w in O.WINDOWS].index("hamming")).astype(np.float32), xin, 5)
+    got = np.fromfile(tmp_path / "o_basic_fir5.bin", np.float32)
+    assert len(got) == len(xin) // 5 and rel(got, want) <= 1e-5
+    secs = O.iir_design(0, par, 2)  # CHEBYSHEV1
+    want = O.iir_cascade(O.make_sections([(np.float32(b), np.float32(a)) for b, a in secs]), xin)[::5]
+    got = np.fromfile(tmp_path / "o_basic_iir5.bin", np.float32)
+    assert len(got) == len(xin) // 5 and rel(got, want) <= 1e-5
     m = np.fromfile(tmp_path / "o_math.bin", np.int32)
     src = np.resize(np.array([2147483647, -5, 7, 123456789], np.int32), 100000)
     assert np.array_equal(m, (src.astype(np.int64) * 3).astype(np.int32))  # wrap-around like the C++ int32 product
