@@ -20,6 +20,8 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <memory_resource>
+#include <mutex>
 #include <optional>
 #include <span>
 #include <stdexcept>
@@ -28,6 +30,7 @@
 #include <tuple>
 #include <type_traits>
 #include <typeindex>
+#include <unordered_map>
 #include <variant>
 #include <vector>
 
@@ -53,7 +56,18 @@ struct unexpected_t {
 };
 inline unexpected_t unexpected(std::string msg) { return {Error{std::move(msg)}}; }
 template <typename T>
-class expected;
+class expected {
+    std::variant<T, Error> _v;
+
+public:
+    expected(T v) : _v(std::move(v)) {}
+    expected(unexpected_t u) : _v(std::move(u.error)) {}
+    [[nodiscard]] bool has_value() const noexcept { return _v.index() == 0; }
+    explicit           operator bool() const noexcept { return has_value(); }
+    [[nodiscard]] T&           value() { return std::get<0>(_v); }
+    [[nodiscard]] const T&     value() const { return std::get<0>(_v); }
+    [[nodiscard]] const Error& error() const { return std::get<1>(_v); }
+};
 template <>
 class expected<void> {
     std::optional<Error> _e;
@@ -243,9 +257,10 @@ struct EdgeBufferBase {
 };
 template <typename T>
 struct EdgeBuffer final : EdgeBufferBase {
-    std::vector<T> data;
-    std::size_t    head = 0, tail = 0, capacity;
-    explicit EdgeBuffer(std::size_t cap = 65536) : data(2 * cap), capacity(cap) {} // default edge size: Graph.hpp:102
+    std::pmr::vector<T> data; // storage from the edge's memory resource (Graph.hpp:738-775): default heap, or e.g. the "hip" provider's pinned pages
+    std::size_t         head = 0, tail = 0, capacity;
+    explicit EdgeBuffer(std::size_t cap = 65536, std::pmr::memory_resource* mr = std::pmr::get_default_resource()) : data(2 * cap, mr), capacity(cap) {} // default edge size: Graph.hpp:102
+    [[nodiscard]] std::pmr::memory_resource* resource() const { return data.get_allocator().resource(); }
     [[nodiscard]] std::size_t available() const noexcept { return tail - head; }
     [[nodiscard]] std::size_t free_space() const noexcept { return capacity - available(); }
     std::span<const T>        read_span(std::size_t n) const { return {data.data() + head, n}; }
@@ -282,13 +297,22 @@ struct RequiredSamples {
     static constexpr std::size_t kMin = Min, kMax = Max;
 };
 
+namespace hip {
+template <typename T>
+struct DeviceEdgeBuffer; // the edge of a GPU-domain port: a double-mapped ring in HBM behind the EdgeBuffer interface (gr4/hip.hpp)
+}
 template <typename T, PortDirection Dir, typename... Attr>
 struct Port {
     using value_type                         = T;
     static constexpr PortDirection direction = Dir;
-    std::size_t                    min_samples = 1, max_samples = std::numeric_limits<std::size_t>::max();
-    std::shared_ptr<EdgeBuffer<T>> buffer; // shared between the connected output and input port
-    [[nodiscard]] bool             connected() const noexcept { return static_cast<bool>(buffer); }
+    // a port belongs to ONE computing domain (core/README.md:87-95); GPU ports carry device spans, and crossing the domains takes an explicit
+    // converter block (gr::hip::H2D / D2H)
+    static constexpr bool kGpu = (std::is_same_v<Attr, GPU> || ...);
+    using buffer_type          = std::conditional_t<kGpu, hip::DeviceEdgeBuffer<T>, EdgeBuffer<T>>;
+    static constexpr std::string_view domain() { return kGpu ? "GPU" : "CPU"; }
+    std::size_t                  min_samples = 1, max_samples = std::numeric_limits<std::size_t>::max();
+    std::shared_ptr<buffer_type> buffer; // shared between the connected output and input port
+    [[nodiscard]] bool           connected() const noexcept { return static_cast<bool>(buffer); }
 };
 template <typename T, typename... Attr>
 using PortIn = Port<T, PortDirection::INPUT, Attr...>;
@@ -370,6 +394,38 @@ struct ComputeDomain {
     [[nodiscard]] bool is_device() const { return kind == "gpu"; }
 };
 
+// ---------------------------------------------------------------------------------------------- memory seam (ComputeDomain.hpp:105-173)
+// Given a domain (+ optional backend context) a provider returns the memory resource edge buffers of that domain are allocated from.
+using ProviderFn = std::pmr::memory_resource* (*)(const ComputeDomain& dom, void* ctx);
+class ComputeRegistry {
+    mutable std::mutex                          _mtx;
+    std::unordered_map<std::string, ProviderFn> _providers;
+
+public:
+    static ComputeRegistry& instance() {
+        static ComputeRegistry r;
+        return r;
+    }
+    void register_provider(std::string_view backend, ProviderFn fn) {
+        std::scoped_lock lk(_mtx);
+        _providers[std::string(backend)] = fn; // replace-or-insert
+    }
+    [[nodiscard]] expected<std::pmr::memory_resource*> resolve(const ComputeDomain& dom, void* ctx = nullptr) const {
+        if (dom.kind == "host" || dom.backend == "none") return std::pmr::new_delete_resource();
+        std::scoped_lock lk(_mtx);
+        const auto       it = _providers.find(dom.backend);
+        if (it == _providers.end()) return unexpected("no provider for backend '" + dom.backend + "'");
+        if (auto* mr = it->second(dom, ctx)) return mr;
+        return unexpected("provider returned null resource for backend '" + dom.backend + "'");
+    }
+    [[nodiscard]] std::pmr::memory_resource* tryResolve(const ComputeDomain& dom, void* ctx = nullptr) const noexcept {
+        try {
+            const auto r = resolve(dom, ctx);
+            return r ? r.value() : nullptr;
+        } catch (...) { return nullptr; }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------- type-erased block (BlockModel.hpp:493, 668-769)
 struct BlockModel {
     virtual ~BlockModel()                                               = default;
@@ -379,7 +435,8 @@ struct BlockModel {
     virtual const ComputeDomain&       compute_domain() const           = 0;
     virtual void*                      raw()                            = 0;
     virtual std::type_index            port_type(std::string_view port) = 0; // typeid(void) if unknown
-    virtual std::shared_ptr<EdgeBufferBase> make_edge(std::string_view out_port, std::size_t min_size)                   = 0;
+    virtual std::string_view           port_domain(std::string_view) { return "CPU"; }
+    virtual std::shared_ptr<EdgeBufferBase> make_edge(std::string_view out_port, std::size_t min_size, std::pmr::memory_resource* mr = nullptr) = 0;
     virtual bool                            attach_input(std::string_view in_port, std::shared_ptr<EdgeBufferBase> edge) = 0;
     virtual std::vector<std::shared_ptr<EdgeBufferBase>> input_edges()                                                   = 0;
     virtual std::vector<std::shared_ptr<EdgeBufferBase>> output_edges()                                                  = 0;
@@ -576,12 +633,20 @@ struct BlockWrapper final : BlockModel {
         with_port(port, [&](auto& p) { t = typeid(typename std::decay_t<decltype(p)>::value_type); });
         return t;
     }
-    std::shared_ptr<EdgeBufferBase> make_edge(std::string_view out_port, std::size_t min_size) override {
+    std::string_view port_domain(std::string_view port) override {
+        std::string_view d = "CPU";
+        with_port(port, [&](auto& p) { d = std::decay_t<decltype(p)>::domain(); });
+        return d;
+    }
+    std::shared_ptr<EdgeBufferBase> make_edge(std::string_view out_port, std::size_t min_size, std::pmr::memory_resource* mr) override {
         std::shared_ptr<EdgeBufferBase> e;
         with_port(out_port, [&](auto& p) {
             using P = std::decay_t<decltype(p)>;
             if constexpr (P::direction == PortDirection::OUTPUT) {
-                if (!p.buffer) p.buffer = std::make_shared<EdgeBuffer<typename P::value_type>>(std::max<std::size_t>(min_size, 65536));
+                if (!p.buffer) {
+                    if constexpr (P::kGpu) p.buffer = std::make_shared<typename P::buffer_type>(std::max<std::size_t>(min_size, 65536)); // HBM ring: its own allocator
+                    else p.buffer = std::make_shared<typename P::buffer_type>(std::max<std::size_t>(min_size, 65536), mr ? mr : std::pmr::get_default_resource());
+                }
                 e = p.buffer;
             }
         });
@@ -592,7 +657,7 @@ struct BlockWrapper final : BlockModel {
         with_port(in_port, [&](auto& p) {
             using P = std::decay_t<decltype(p)>;
             if constexpr (P::direction == PortDirection::INPUT) {
-                if (auto typed = std::dynamic_pointer_cast<EdgeBuffer<typename P::value_type>>(edge)) { p.buffer = typed; ok = true; }
+                if (auto typed = std::dynamic_pointer_cast<typename P::buffer_type>(edge)) { p.buffer = typed; ok = true; }
             }
         });
         return ok;
@@ -625,7 +690,8 @@ struct BlockWrapper final : BlockModel {
 struct EdgeParameters { // BlockModel.hpp:64-72
     std::size_t minBufferSize = 65536;
     std::int32_t weight = 0;
-    std::string name = "unnamed edge", domain;
+    std::string name = "unnamed edge", domain; // domain "gpu:hip[:i]": the edge's storage comes from that backend's provider (ComputeRegistry)
+    std::pmr::memory_resource* dataResource = nullptr; // explicit resource: most specific wins (Graph.hpp:742-765)
 };
 struct Edge {
     BlockModel* src;
@@ -664,7 +730,14 @@ public:
         if (ts == typeid(void)) return unexpected("connect: source port '" + std::string(srcPort) + "' not found");
         if (td == typeid(void)) return unexpected("connect: destination port '" + std::string(dstPort) + "' not found");
         if (ts != td) return unexpected("connect: port value types differ");
-        auto edge = s->make_edge(srcPort, params.minBufferSize);
+        if (s->port_domain(srcPort) != d->port_domain(dstPort))
+            return unexpected("connect: ports belong to different computing domains (" + std::string(s->port_domain(srcPort)) + " -> " + std::string(d->port_domain(dstPort)) +
+                              "): insert an explicit converter block (gr::hip::H2D / gr::hip::D2H)");
+        // resource precedence (Graph.hpp:742-765): EdgeParameters resource > non-host domain provider > default
+        std::pmr::memory_resource* mr = params.dataResource;
+        if (!mr && !params.domain.empty())
+            if (const auto dom = ComputeDomain::parse(params.domain); dom.kind != "host") mr = ComputeRegistry::instance().tryResolve(dom);
+        auto edge = s->make_edge(srcPort, params.minBufferSize, mr);
         if (!edge) return unexpected("connect: '" + std::string(srcPort) + "' is not an output port");
         if (!d->attach_input(dstPort, edge)) return unexpected("connect: '" + std::string(dstPort) + "' is not an input port of the same type");
         _edges.push_back({s, std::string(srcPort), d, std::string(dstPort), std::move(params)});

@@ -17,6 +17,8 @@
 #include <span>
 #include <functional>
 #include <iostream>
+#include <memory_resource>
+#include <new>
 
 #include "../../../../include/gr4hip.h"
 #include "blocks.hpp"
@@ -60,6 +62,31 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
 };
+
+// ---------------------------------------------------------------------------------------------- the "hip" memory provider (ComputeDomain.hpp:105-173)
+// Edge storage for EdgeParameters{.domain = "gpu:hip[:i]"} on CPU-domain ports: page-locked host memory.  The samples stay addressable by the
+// host blocks on both ends of the edge, and the copy engines read them in place -- gr::hip::H2D skips its staging copy for such an edge.
+// (Edges between GPU-domain ports do not go through a memory_resource at all: DeviceEdgeBuffer below owns a VMM double mapping in HBM.)
+class PinnedResource final : public std::pmr::memory_resource {
+    void* do_allocate(std::size_t bytes, std::size_t align) override {
+        void* p = nullptr;
+        if (align > 4096 || gr4hip_malloc_host(&p, std::max<std::size_t>(bytes, 1)) != GR4HIP_OK) throw std::bad_alloc();
+        return p;
+    }
+    void do_deallocate(void* p, std::size_t, std::size_t) override { gr4hip_free_host(p); }
+    bool do_is_equal(const std::pmr::memory_resource& o) const noexcept override { return this == &o; }
+};
+inline std::pmr::memory_resource* pinned_resource() {
+    static PinnedResource r;
+    return &r;
+}
+inline void register_provider() { // idempotent; call once before Graph::connect with a "gpu:hip" edge domain
+    ComputeRegistry::instance().register_provider("hip", [](const ComputeDomain& dom, void*) -> std::pmr::memory_resource* {
+        if (dom.kind != "gpu") return nullptr;
+        if (gr4hip_set_device(dom.index) != GR4HIP_OK) return nullptr; // no such device: the edge falls back to the default resource
+        return pinned_resource();
+    });
+}
 
 // ---------------------------------------------------------------------------------------------- stages
 template <typename T>
@@ -491,6 +518,142 @@ public:
     }
 };
 
+// ---------------------------------------------------------------------------------------------- GPU-domain ports: PortIn<T, GPU> / PortOut<T, GPU>
+// The edge between two GPU-domain ports is a CircularBuffer<T> in HBM behind the EdgeBuffer interface the work loop uses: the spans it
+// hands out hold DEVICE pointers, contiguous across the wrap.  Host code must not dereference them; blocks with GPU ports pass them to
+// kernels.  Crossing between the domains takes an explicit converter block, H2D<T> / D2H<T> below (core/README.md:87-110): the cost of the
+// transfer is a visible node of the graph, and everything between the two converters stays in HBM.
+template <typename T>
+struct DeviceEdgeBuffer final : EdgeBufferBase {
+    CircularBuffer<T>                  ring;
+    typename CircularBuffer<T>::Writer w;
+    typename CircularBuffer<T>::Reader r;
+    explicit DeviceEdgeBuffer(std::size_t min_elements) : ring(min_elements), w(ring.new_writer()), r(ring.new_reader()) {}
+    [[nodiscard]] std::size_t        available() const noexcept { return r.available(); }
+    [[nodiscard]] std::size_t        free_space() const noexcept { return w.available(); }
+    [[nodiscard]] std::span<const T> read_span(std::size_t n) const { return r.get(n); }
+    [[nodiscard]] std::span<T>       write_span(std::size_t n) { return w.reserve(n); }
+    void                             publish(std::size_t n) { w.publish(n); }
+    void                             consume(std::size_t n) { (void)r.consume(n); }
+    [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
+    [[nodiscard]] std::size_t available_items() const noexcept override { return available(); }
+    [[nodiscard]] std::size_t free_items() const noexcept override { return free_space(); }
+    void read_items(void* dst, std::size_t n) override { // type-erased IO of a DeviceRun at this edge: device -> (pinned) host
+        check(gr4hip_memcpy_d2h(dst, read_span(n).data(), n * sizeof(T), nullptr), "d2h");
+        check(gr4hip_stream_synchronize(nullptr), "sync");
+        consume(n);
+    }
+    void write_items(const void* src, std::size_t n) override {
+        check(gr4hip_memcpy_h2d(write_span(n).data(), src, n * sizeof(T), nullptr), "h2d");
+        check(gr4hip_stream_synchronize(nullptr), "sync");
+        publish(n);
+    }
+};
+
+// host -> device converter: CPU-domain input port, GPU-domain output port
+template <typename T>
+struct H2D : Block<H2D<T>> {
+    PortIn<T>       in;
+    PortOut<T, GPU> out;
+    Size_t          device = 0;
+    GR_MAKE_REFLECTABLE(H2D, in, out, device);
+    DevBuf          _staging{true};
+    std::size_t     _bytes = 0, _staged_bytes = 0; // moved in total / of which through the staging buffer
+    work::Status processBulk(std::span<const T> host, std::span<T> dev) {
+        try {
+            check(gr4hip_set_device(static_cast<int>(device)), "gr4hip_set_device");
+            const std::size_t bytes = host.size() * sizeof(T);
+            const void*       src   = host.data();
+            if (in.buffer->resource() != pinned_resource()) { // pageable edge: one staging copy; an edge from the "hip" provider is DMA-able in place
+                std::memcpy(_staging.ensure(bytes), host.data(), bytes);
+                src = _staging.p;
+                _staged_bytes += bytes;
+            }
+            check(gr4hip_memcpy_h2d(dev.data(), src, bytes, nullptr), "h2d");
+            check(gr4hip_stream_synchronize(nullptr), "sync"); // the span is published only once the copy has landed
+            _bytes += bytes;
+            return work::Status::OK;
+        } catch (const std::exception& e) {
+            this->_log(std::string("H2D failed: ") + e.what());
+            return work::Status::ERROR;
+        }
+    }
+};
+// device -> host converter
+template <typename T>
+struct D2H : Block<D2H<T>> {
+    PortIn<T, GPU> in;
+    PortOut<T>     out;
+    Size_t         device = 0;
+    GR_MAKE_REFLECTABLE(D2H, in, out, device);
+    DevBuf         _staging{true};
+    work::Status processBulk(std::span<const T> dev, std::span<T> host) {
+        try {
+            check(gr4hip_set_device(static_cast<int>(device)), "gr4hip_set_device");
+            const std::size_t bytes  = dev.size() * sizeof(T);
+            const bool        direct = out.connected() && out.buffer->resource() == pinned_resource();
+            void*             dst    = direct ? static_cast<void*>(host.data()) : _staging.ensure(bytes);
+            check(gr4hip_memcpy_d2h(dst, dev.data(), bytes, nullptr), "d2h");
+            check(gr4hip_stream_synchronize(nullptr), "sync");
+            if (!direct) std::memcpy(host.data(), dst, bytes);
+            return work::Status::OK;
+        } catch (const std::exception& e) {
+            this->_log(std::string("D2H failed: ") + e.what());
+            return work::Status::ERROR;
+        }
+    }
+};
+
+// A hot-path block with GPU-domain ports: OnDevice<fir_filter<float>> has the settings of fir_filter<float> and the ports
+// PortIn<T, GPU> / PortOut<U, GPU>; its work() enqueues the block's kernel on device spans -- no copies, no staging.
+template <typename BlockT>
+requires requires(BlockT& b) { Kernel<BlockT>::make_stage(b); }
+struct OnDevice : Block<OnDevice<BlockT>, Resampling<1, 1, false>> {
+    using TIn  = typename std::decay_t<decltype(std::declval<BlockT&>().in)>::value_type;
+    using TOut = typename std::decay_t<decltype(std::declval<BlockT&>().out)>::value_type;
+    PortIn<TIn, GPU>   in;
+    PortOut<TOut, GPU> out;
+    Size_t             device = 0;
+    GR_MAKE_REFLECTABLE(OnDevice, in, out, device);
+    BlockT                 block{};  // carries the settings (and is what the stage is built from)
+    std::unique_ptr<Stage> _stage;
+    gr4hip_stream_t        _stream = nullptr;
+    std::size_t            _launches = 0;
+
+    ~OnDevice() {
+        _stage.reset();
+        if (_stream) gr4hip_stream_destroy(_stream);
+    }
+    void applySettings(const property_map& settings) { // everything but the wrapper's own keys goes to the wrapped block
+        property_map inner;
+        for (const auto& [k, v] : settings) {
+            if (k == "name") { gr::detail::assign_from(this->name, v); block.name = this->name; }
+            else if (k == "device") gr::detail::assign_from(device, v);
+            else inner.emplace(k, v);
+        }
+        block.applySettings(inner);
+        _stage.reset(); // rebuilt from the new settings on the next work()
+        this->input_chunk_size  = block.input_chunk_size;
+        this->output_chunk_size = block.output_chunk_size;
+    }
+    work::Status processBulk(std::span<const TIn> dev_in, std::span<TOut> dev_out) {
+        try {
+            check(gr4hip_set_device(static_cast<int>(device)), "gr4hip_set_device");
+            if (!_stream) check(gr4hip_stream_create(&_stream), "gr4hip_stream_create");
+            if (!_stage) _stage = Kernel<BlockT>::make_stage(block);
+            std::size_t produced = 0;
+            check(_stage->enqueue(dev_in.data(), dev_in.size(), dev_out.data(), &produced, _stream), "kernel");
+            if (produced != dev_out.size()) throw std::runtime_error("device stage produced an unexpected number of samples");
+            check(gr4hip_stream_synchronize(_stream), "sync"); // cursors move only after completion (Block.hpp:1989-2026 ordering)
+            ++_launches;
+            return work::Status::OK;
+        } catch (const std::exception& e) {
+            this->_log(std::string("device block '") + this->name + "' failed: " + e.what());
+            return work::Status::ERROR;
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------- HIP-stream scheduler with chain fusion
 // A device run = consecutive device blocks wired 1:1, executed as one unit.
 class DeviceRun final : public BlockModel {
@@ -589,7 +752,7 @@ public:
     const ComputeDomain& compute_domain() const override { return _domain; }
     void*                raw() override { return this; }
     std::type_index      port_type(std::string_view) override { return typeid(void); }
-    std::shared_ptr<EdgeBufferBase> make_edge(std::string_view, std::size_t) override { return nullptr; }
+    std::shared_ptr<EdgeBufferBase> make_edge(std::string_view, std::size_t, std::pmr::memory_resource*) override { return nullptr; }
     bool attach_input(std::string_view, std::shared_ptr<EdgeBufferBase>) override { return false; }
     std::vector<std::shared_ptr<EdgeBufferBase>> input_edges() override { return {_in_edge}; }
     std::vector<std::shared_ptr<EdgeBufferBase>> output_edges() override { return {_out_edge}; }

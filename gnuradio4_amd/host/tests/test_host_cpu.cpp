@@ -66,6 +66,30 @@ int main(int argc, char** argv) {
         try { f.applySettings({{"no_such_setting", 1.0}}); } catch (const std::invalid_argument&) { threw = true; }
         EXPECT(threw);
     }
+    // ---- memory seam: ComputeRegistry providers and per-edge resources (ComputeDomain.hpp:105-173, Graph.hpp:738-775)
+    {
+        struct Counting final : std::pmr::memory_resource {
+            std::size_t bytes = 0;
+            void* do_allocate(std::size_t n, std::size_t a) override { bytes += n; return std::pmr::new_delete_resource()->allocate(n, a); }
+            void  do_deallocate(void* p, std::size_t n, std::size_t a) override { std::pmr::new_delete_resource()->deallocate(p, n, a); }
+            bool  do_is_equal(const std::pmr::memory_resource& o) const noexcept override { return this == &o; }
+        };
+        static Counting counting;
+        auto& reg = ComputeRegistry::instance();
+        EXPECT(reg.resolve(ComputeDomain::parse("host")).value() == std::pmr::new_delete_resource());
+        EXPECT(!reg.resolve(ComputeDomain::parse("gpu:fake:0")).has_value() && reg.tryResolve(ComputeDomain::parse("gpu:fake:0")) == nullptr);
+        reg.register_provider("fake", [](const ComputeDomain& d, void*) -> std::pmr::memory_resource* { return d.index == 0 ? &counting : nullptr; });
+        EXPECT(reg.resolve(ComputeDomain::parse("gpu:fake:0")).value() == &counting);
+        EXPECT(!reg.resolve(ComputeDomain::parse("gpu:fake:1")).has_value()); // provider returned null
+        Graph g;
+        auto& s = g.emplaceBlock<testing::VectorSource<float>>();
+        auto& f = g.emplaceBlock<filter::fir_filter<float>>();
+        auto& k = g.emplaceBlock<testing::NullSink<float>>();
+        EXPECT((g.connect<"out", "in">(s, f, EdgeParameters{.minBufferSize = 1000, .domain = "gpu:fake:0"})).has_value()); // storage from the domain's provider
+        EXPECT(f.in.buffer->resource() == &counting && counting.bytes >= 2 * 65536 * sizeof(float));
+        EXPECT((g.connect<"out", "in">(f, k, EdgeParameters{.domain = "gpu:fake:1"})).has_value());                         // unresolved domain: default resource
+        EXPECT(k.in.buffer->resource() == std::pmr::get_default_resource());
+    }
     // ---- Decimator 100 -> 10 samples (qa_filter.cpp:267-293)
     {
         Graph g;

@@ -64,6 +64,18 @@ int main(int argc, char** argv) {
     const std::vector<double> tapsd(taps.begin(), taps.end());
     int errors = 0;
 
+    { // 0. port domains: a CPU port cannot be wired to a GPU port, the error names the converter blocks (no device needed: nothing is allocated)
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<float>>();
+        auto& dev = g.emplaceBlock<hip::OnDevice<filter::fir_filter<float>>>({{"b", std::vector<double>{1.0}}});
+        auto& d2h = g.emplaceBlock<hip::D2H<float>>();
+        const auto r = g.connect<"out", "in">(src, dev);
+        const bool ok = !r.has_value() && r.error().message.find("different computing domains (CPU -> GPU)") != std::string::npos && r.error().message.find("gr::hip::H2D") != std::string::npos;
+        const auto r2 = g.connect<"out", "in">(d2h, dev); // D2H.out is a CPU port
+        std::printf("port domains: %s\n", ok && !r2.has_value() ? "CPU -> GPU refused, converter required" : "FAILED");
+        if (!ok || r2.has_value()) ++errors;
+    }
+
     { // 1. one device block inside a host graph: the seam in Block::dispatchProcessing offloads fir_filter<complex<float>>
         Graph g;
         auto& src = g.emplaceBlock<testing::VectorSource<std::complex<float>>>();
@@ -151,6 +163,32 @@ int main(int argc, char** argv) {
         dump(out + "_chain_planned_bh.bin", sink._samples);
         dump(out + "_planned_float.bin", fsink._samples);
         hip::release(mul2);
+    }
+
+    { // 3c. GPU-domain ports: src -> H2D -> fir (GPU ports) -> PowerSpectrum (GPU ports) -> D2H -> sink.  The edges between the converters are
+      //     rings in HBM; the edge INTO H2D is allocated from the "hip" provider (pinned pages), so the converter copies without staging
+        hip::register_provider();
+        Graph g;
+        auto& src  = g.emplaceBlock<testing::VectorSource<std::complex<float>>>();
+        src.values = x;
+        auto& h2d  = g.emplaceBlock<hip::H2D<std::complex<float>>>();
+        auto& fir  = g.emplaceBlock<hip::OnDevice<filter::fir_filter<std::complex<float>>>>({{"b", tapsd}, {"name", "fir@gpu"s}});
+        auto& spec = g.emplaceBlock<hip::OnDevice<blocks::fft::PowerSpectrum<std::complex<float>>>>({{"fftSize", std::int64_t(N)}, {"window", "Hann"s}});
+        auto& d2h  = g.emplaceBlock<hip::D2H<float>>();
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        bool  wired = g.connect<"out", "in">(src, h2d, EdgeParameters{.domain = "gpu:hip:0"}).has_value();
+        wired       = wired && g.connect<"out", "in">(h2d, fir).has_value() && g.connect<"out", "in">(fir, spec).has_value() && g.connect<"out", "in">(spec, d2h).has_value() &&
+                g.connect<"out", "in">(d2h, sink).has_value();
+        if (!wired) ++errors;
+        const bool pinned_edge = h2d.in.buffer && h2d.in.buffer->resource() == hip::pinned_resource();
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        if (const auto r = sched.runAndWait(); !r) { std::cerr << "gpu-port graph: " << r.error().message << "\n"; ++errors; }
+        std::printf("gpu ports: %zu launches fir, %zu launches spectrum, H2D moved %zu bytes (%zu staged), input edge %s\n", fir._launches, spec._launches, h2d._bytes, h2d._staged_bytes,
+                    pinned_edge ? "pinned by the hip provider" : "pageable");
+        if (!pinned_edge || h2d._staged_bytes != 0 || h2d._bytes != (x.size() / N) * N * sizeof(std::complex<float>) + (x.size() % N) * sizeof(std::complex<float>)) ++errors;
+        if (sink._samples.size() != (x.size() / N) * N) ++errors;
+        dump(out + "_gpu_ports_hann.bin", sink._samples);
     }
 
     { // 4. the GPU-resident BufferLike ring: spans that wrap the physical end stay contiguous; two readers, back-pressure

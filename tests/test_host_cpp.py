@@ -53,6 +53,7 @@ def test_device_blocks_fail_loudly_without_gpu(host_bins, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)  # work::Status::ERROR from the seam, no host fallback
     assert "NO_DEVICE" in r.stderr and not os.path.exists(tmp_path / "o_fir.bin")
+    assert "port domains: CPU -> GPU refused, converter required" in r.stdout  # checked before anything touches a device
 
 
 @pytest.mark.gpu
@@ -85,6 +86,12 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     xin = np.resize(np.array([1.0, -2.0, 3.0, 0.5, 0.25], np.float64), 200000) * 2.0
     want = (np.convolve(xin, [0.5, 0.25, 0.25])[:200000] + 1.0) * 3.0
     assert len(pf) == 200000 and np.max(np.abs(pf - want)) <= 1e-5
+    # GPU-domain ports with explicit converter blocks: the same spectra as the fused device run, the input edge pinned by the "hip" provider
+    assert "port domains: CPU -> GPU refused, converter required" in r.stdout
+    assert "input edge pinned by the hip provider" in r.stdout and "(0 staged)" in r.stdout
+    got = np.fromfile(tmp_path / "o_gpu_ports_hann.bin", np.float32)
+    t, _ = O.chain(b, x, N, 3, truth=True)
+    assert len(got) == frames * N and rel(got, t) <= 1e-5
     # every other hot-path block behind the seam (device vs the host body of the same block, printed by the program) ...
     for what in ("iir_filter<float, DF_II>", "Decimator<int32> decim 7", "Rotator<complex<float>>", "BasicDecimatingFilter<float> FIR /5", "BasicFilter<float> IIR",
                  "Add<int32> n_inputs = 3", "FFT<complex<float>> 256 Hann", "FFT<complex<float>> 1000 B-Harris", "FFT<float> 512 Hamming dB", "planned run with two rate changes"):
