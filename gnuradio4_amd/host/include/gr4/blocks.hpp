@@ -19,6 +19,7 @@ struct VectorSource : Block<VectorSource<T>> {
     std::vector<T> values{};      // repeated cyclically when shorter than n_samples_max
     Size_t         n_samples_max = 0; // 0: exactly values.size() samples
     std::size_t    _produced     = 0;
+    std::vector<Tag> _tags{};     // tags to emit, ascending index (TagSource::_tags)
     GR_MAKE_REFLECTABLE(VectorSource, out, values, n_samples_max);
 
     work::Result customWork(std::size_t requested) {
@@ -29,6 +30,8 @@ struct VectorSource : Block<VectorSource<T>> {
         if (n == 0) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
         auto span = out.buffer->write_span(n);
         for (std::size_t i = 0; i < n; ++i) span[i] = values.empty() ? T{} : values[(_produced + i) % values.size()];
+        for (const Tag& t : _tags)
+            if (t.index >= _produced && t.index < _produced + n) out.buffer->publishTag(t.map, t.index - _produced);
         out.buffer->publish(n);
         _produced += n;
         return {requested, n, work::Status::OK};
@@ -41,6 +44,7 @@ struct VectorSink : Block<VectorSink<T>> {
     PortIn<T>      in;
     Size_t         n_samples_expected = 0;
     std::vector<T> _samples;
+    std::vector<Tag> _tags; // received tags with their absolute sample index (TagSink::_tags)
     GR_MAKE_REFLECTABLE(VectorSink, in, n_samples_expected);
 
     work::Result customWork(std::size_t requested) {
@@ -48,6 +52,8 @@ struct VectorSink : Block<VectorSink<T>> {
         const std::size_t n = std::min(in.buffer->available(), requested);
         if (n == 0) return {requested, 0, in.buffer->producer_done ? work::Status::DONE : work::Status::INSUFFICIENT_INPUT_ITEMS};
         auto span = in.buffer->read_span(n);
+        for (const Tag& t : in.buffer->tags)
+            if (t.index < in.buffer->read_pos + n) _tags.push_back(t);
         _samples.insert(_samples.end(), span.begin(), span.end());
         in.buffer->consume(n);
         return {requested, n, work::Status::OK};

@@ -5,7 +5,7 @@
 // settingsChanged(old,new), processOne / processBulk(std::span<const T>, std::span<U>), Resampling<>), wires them with
 // Graph::connect<"out","in">(a, b) (Graph.hpp:595-690; errors are returned, not thrown) and runs them with a single-threaded
 // scheduler::Simple (Scheduler.hpp:1916-1952) following the work() chunking rules of Block.hpp:1950-2026.  It is NOT a port of the
-// reference runtime: no tags/messages/settings staging, no thread pool, no lock-free rings (one worker drives every block, so an
+// reference runtime: no messages / settings staging, no thread pool, no lock-free rings (one worker drives every block, so an
 // edge is a plain compacting FIFO).  The compute_domain seam (Block.hpp:713, 1855-1862) is live: see gr4/hip.hpp.
 #pragma once
 
@@ -245,9 +245,46 @@ struct find_resampling<A, R...> {
 } // namespace detail
 
 // ---------------------------------------------------------------------------------------------- edges: a compacting FIFO (one worker thread)
+// ---------------------------------------------------------------------------------------------- tags (Tag.hpp:70-110)
+// (index, map) pairs travelling next to the samples.  Keys of the reference's default tags carry the "gr:" prefix on the wire
+// (GR_TAG_PREFIX, Tag.hpp:112); index is the absolute position in the edge's stream.
+inline constexpr std::string_view GR_TAG_PREFIX = "gr:";
+struct Tag {
+    std::size_t  index = 0;
+    property_map map;
+    bool         operator==(const Tag&) const = default;
+};
+namespace tag {
+inline constexpr std::string_view SAMPLE_RATE = "sample_rate";
+[[nodiscard]] inline std::string_view settingsKey(std::string_view wireKey) { return wireKey.starts_with(GR_TAG_PREFIX) ? wireKey.substr(GR_TAG_PREFIX.size()) : wireKey; } // "gr:x" -> "x"
+[[nodiscard]] inline std::string      wireKey(std::string_view bareKey) { return std::string(GR_TAG_PREFIX) + std::string(bareKey); }
+} // namespace tag
+
 struct EdgeBufferBase {
     virtual ~EdgeBufferBase() = default;
     bool producer_done = false; // upstream returned DONE: remaining samples are the last ones
+    // tag side channel: host-side for every edge type (a device ring moves samples, the few tags stay with the cursors that order them)
+    std::size_t      read_pos = 0, write_pos = 0; // absolute sample counts consumed / published
+    std::vector<Tag> tags;                        // ascending index, index >= read_pos
+    void publishTag(const property_map& map, std::size_t offset = 0) { // at write_pos + offset, i.e. relative to the span being written (Port.hpp publishTag)
+        if (map.empty()) return;
+        const std::size_t idx = write_pos + offset;
+        auto it = std::find_if(tags.begin(), tags.end(), [idx](const Tag& t) { return t.index >= idx; });
+        if (it != tags.end() && it->index == idx) for (const auto& kv : map) it->map.insert_or_assign(kv.first, kv.second);
+        else tags.insert(it, Tag{idx, map});
+    }
+    [[nodiscard]] const Tag* tagAtReadPosition() const { return !tags.empty() && tags.front().index == read_pos ? &tags.front() : nullptr; }
+    // samples until the first tag AFTER the read position (nSamplesUntilNextTag(port, 1), Block.hpp:1525): the chunk limit that keeps tags at chunk starts
+    [[nodiscard]] std::size_t samplesUntilNextTag() const {
+        for (const Tag& t : tags)
+            if (t.index > read_pos) return t.index - read_pos;
+        return std::numeric_limits<std::size_t>::max();
+    }
+    void advanceRead(std::size_t n) {
+        read_pos += n;
+        tags.erase(tags.begin(), std::find_if(tags.begin(), tags.end(), [this](const Tag& t) { return t.index >= read_pos; }));
+    }
+    void advanceWrite(std::size_t n) { write_pos += n; }
     // type-erased element IO (used by device runs that replace typed blocks at both ends of an edge)
     [[nodiscard]] virtual std::size_t elem_bytes() const noexcept           = 0;
     [[nodiscard]] virtual std::size_t available_items() const noexcept      = 0;
@@ -272,8 +309,8 @@ struct EdgeBuffer final : EdgeBufferBase {
         }
         return {data.data() + tail, n};
     }
-    void publish(std::size_t n) noexcept { tail += n; }
-    void consume(std::size_t n) noexcept { head += n; }
+    void publish(std::size_t n) noexcept { tail += n; advanceWrite(n); }
+    void consume(std::size_t n) noexcept { head += n; advanceRead(n); }
     [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
     [[nodiscard]] std::size_t available_items() const noexcept override { return available(); }
     [[nodiscard]] std::size_t free_items() const noexcept override { return free_space(); }
@@ -443,6 +480,8 @@ struct BlockModel {
     // a gr::hip::Stage for this block's current settings, or null when the block type has no device kernel (gr4/hip.hpp; type-erased here
     // so that this header stays free of the device layer)
     virtual std::shared_ptr<void> make_device_stage() { return nullptr; }
+    // settings-by-tag for a block that is driven from outside its own work loop (a member of a fused device run)
+    virtual bool apply_tag_settings(const property_map&) { return false; }
 };
 
 // ---------------------------------------------------------------------------------------------- Block<Derived, Args...> (Block.hpp)
@@ -506,6 +545,53 @@ struct Block {
         }
     }
 
+    // forwarded subset of a tag map: wire keys with the "gr:" prefix; gr:sample_rate (float) is scaled by output_chunk_size / input_chunk_size
+    // on resampling blocks (insertOutputValue, Block.hpp:1088-1099; pinned by qa_filter.cpp:288-292)
+    [[nodiscard]] property_map toOutputTags(const property_map& in) const {
+        property_map out;
+        for (const auto& [key, value] : in) {
+            if (!std::string_view(key).starts_with(GR_TAG_PREFIX)) continue;
+            const bool convert = ResamplingControl::kEnabled && input_chunk_size != output_chunk_size && input_chunk_size != 0 && tag::settingsKey(key) == tag::SAMPLE_RATE;
+            if (const float* rate = convert ? std::get_if<float>(&value) : nullptr) out.insert_or_assign(key, static_cast<float>(output_chunk_size) / static_cast<float>(input_chunk_size) * *rate);
+            else out.insert_or_assign(key, value);
+        }
+        return out;
+    }
+    // settings-by-tag (Settings.hpp:433 autoUpdate): keys that name a reflected setting of this block ("gr:value" or "value") are applied; returns
+    // whether anything was applied
+    bool applyTagSettings(const property_map& tagMap) {
+        property_map matching;
+        for (const auto& [key, value] : tagMap) {
+            const std::string_view field = tag::settingsKey(key);
+            detail::for_each_member(self(), [&](std::string_view mname, auto& member) {
+                using M = std::decay_t<decltype(member)>;
+                if constexpr (!detail::is_port<M>::value && !detail::is_port_vector<M>::value) {
+                    bool match = mname == field;
+                    if constexpr (detail::is_annotated<M>::value) match = match || M::description() == field;
+                    if (match) { // only values that differ from the active setting count as a change
+                        if constexpr (detail::is_annotated<M>::value) {
+                            auto tmp = member.value;
+                            if (detail::assign_from(tmp, value) && !(tmp == member.value)) matching.insert_or_assign(std::string(mname), value);
+                        } else {
+                            auto tmp = member;
+                            if (detail::assign_from(tmp, value) && !(tmp == member)) matching.insert_or_assign(std::string(mname), value);
+                        }
+                    }
+                }
+            });
+        }
+        if (matching.empty()) return false;
+        try {
+            applySettings(matching);
+        } catch (const std::exception& e) { // a tag with an unusable value does not stop the stream
+            _log(std::string("settings-by-tag ignored: ") + e.what());
+            return false;
+        }
+        ++_settings_by_tag;
+        return true;
+    }
+    std::size_t _settings_by_tag = 0;
+
 private:
     template <typename F>
     void each_in(F&& f) {
@@ -538,6 +624,11 @@ private:
         each_out([&](auto& p) { if (p.connected()) space = std::min(space, p.buffer->free_space()); });
         if (!any_in) return {requested, 0, work::Status::ERROR};
         const std::size_t ic = std::max<std::size_t>(1, input_chunk_size), oc = std::max<std::size_t>(1, output_chunk_size);
+        // a chunk ends where the next tag starts, so that every tag sits on the first sample of a chunk (Block.hpp:1511-1530, 1961-1971);
+        // never below one input chunk (ensureMinimalDecimation): a tag inside a forced chunk is consumed without being forwarded
+        std::size_t nextTag = std::numeric_limits<std::size_t>::max();
+        each_in([&](auto& p) { if (p.connected()) nextTag = std::min(nextTag, p.buffer->samplesUntilNextTag()); });
+        avail = std::min(avail, std::max(nextTag, ic));
         std::size_t       k  = std::min({avail / ic, space / oc, std::min(maxIn, requested) / ic});
         if (k == 0) {
             if (avail / ic == 0) {
@@ -551,8 +642,19 @@ private:
             return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
         }
         const std::size_t nIn = k * ic, nOut = k * oc;
+        // tags on the first sample of the chunk: settings-by-tag first (Block.hpp:1979-1985), then the chunk is processed with the new settings
+        property_map chunkTags;
+        each_in([&](auto& p) {
+            if (const Tag* t = p.connected() ? p.buffer->tagAtReadPosition() : nullptr)
+                for (const auto& kv : t->map) chunkTags.insert_or_assign(kv.first, kv.second); // identical tags on several inputs collapse
+        });
+        if (!chunkTags.empty()) applyTagSettings(chunkTags);
         work::Status      st = dispatch(nIn, nOut);
         if (st == work::Status::ERROR) return {requested, 0, st};
+        if (!chunkTags.empty()) { // default forwarding (Block.hpp:1113-1263): "gr:" keys only, at the first output sample of the chunk
+            const property_map fwd = toOutputTags(chunkTags);
+            each_out([&](auto& p) { if (p.connected()) p.buffer->publishTag(fwd, 0); });
+        }
         // finaliseIO (Block.hpp:1989-2026): publish outputs, then consume inputs
         each_out([&](auto& p) { if (p.connected()) p.buffer->publish(nOut); });
         each_in([&](auto& p) { p.buffer->consume(nIn); });
@@ -662,6 +764,7 @@ struct BlockWrapper final : BlockModel {
         });
         return ok;
     }
+    bool apply_tag_settings(const property_map& m) override { return block.applyTagSettings(m); }
     std::shared_ptr<void> make_device_stage() override {
         if constexpr (requires { hip::Kernel<T>::make_stage(block); }) return std::shared_ptr<void>(hip::Kernel<T>::make_stage(block)); // deleter captured here
         else return nullptr;

@@ -533,8 +533,8 @@ struct DeviceEdgeBuffer final : EdgeBufferBase {
     [[nodiscard]] std::size_t        free_space() const noexcept { return w.available(); }
     [[nodiscard]] std::span<const T> read_span(std::size_t n) const { return r.get(n); }
     [[nodiscard]] std::span<T>       write_span(std::size_t n) { return w.reserve(n); }
-    void                             publish(std::size_t n) { w.publish(n); }
-    void                             consume(std::size_t n) { (void)r.consume(n); }
+    void                             publish(std::size_t n) { w.publish(n); advanceWrite(n); }
+    void                             consume(std::size_t n) { (void)r.consume(n); advanceRead(n); }
     [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
     [[nodiscard]] std::size_t available_items() const noexcept override { return available(); }
     [[nodiscard]] std::size_t free_items() const noexcept override { return free_space(); }
@@ -672,8 +672,17 @@ class DeviceRun final : public BlockModel {
     std::size_t     _in_bytes, _out_bytes, _in_chunk = 1, _out_per_chunk = 1; // smallest input count every stage sees as whole chunks, and what it becomes
     std::size_t     _launches = 0;
     std::string     _desc;
+    // the blocks this run stands for (kept alive by Graph::retired) and the stage that realises each: tags address their settings
+    struct Member { BlockModel* block; std::size_t stage; };
+    std::vector<Member>                                  _members;
+    std::function<std::unique_ptr<Stage>(std::size_t)>   _rebuild; // fresh stage i from the members' current settings
+    std::size_t                                          _tags_forwarded = 0, _stages_rebuilt = 0;
 
 public:
+    void set_members(std::vector<Member> members, std::function<std::unique_ptr<Stage>(std::size_t)> rebuild) { _members = std::move(members); _rebuild = std::move(rebuild); }
+    [[nodiscard]] std::size_t tags_forwarded() const { return _tags_forwarded; }
+    [[nodiscard]] std::size_t stages_rebuilt() const { return _stages_rebuilt; }
+    using RunMember = Member;
     // the edges at both ends are used through their type-erased element IO: a run does not need to know the sample types
     DeviceRun(std::vector<std::unique_ptr<Stage>> stages, std::shared_ptr<EdgeBufferBase> in, std::shared_ptr<EdgeBufferBase> out, ComputeDomain d)
         : _stages(std::move(stages)), _in_edge(in), _out_edge(out), _domain(std::move(d)), _in_bytes(in->elem_bytes()), _out_bytes(out->elem_bytes()) {
@@ -682,15 +691,7 @@ public:
         _read  = [in](void* dst, std::size_t n) { in->read_items(dst, n); };
         _write = [out](const void* src, std::size_t n) { out->write_items(src, n); };
         for (auto& s : _stages) _desc += std::string(_desc.empty() ? "" : " -> ") + std::string(s->kind());
-        // rate bookkeeping (Resampling<>, Block.hpp:1576-1636, across the whole run): walking back from the last stage, `need` is the count a
-        // stage's output must be a multiple of; it produces out_chunk per in_chunk
-        std::size_t need = 1;
-        for (auto it = _stages.rbegin(); it != _stages.rend(); ++it) {
-            const std::size_t k = need / std::gcd(need, (*it)->out_chunk); // chunks so that k * out_chunk is a multiple of need
-            need                = k * (*it)->in_chunk;
-        }
-        _in_chunk      = need;
-        _out_per_chunk = out_count(_in_chunk);
+        recompute_rates();
         check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
         check(gr4hip_stream_create(&_stream), "gr4hip_stream_create");
         check(gr4hip_ring_create(&_ring, std::size_t(64) << 20), "gr4hip_ring_create"); // GPU-resident double-mapped input ring
@@ -702,6 +703,17 @@ public:
         if (_ring) gr4hip_ring_destroy(_ring);
         if (_stream) gr4hip_stream_destroy(_stream);
     }
+    // rate bookkeeping (Resampling<>, Block.hpp:1576-1636, across the whole run): walking back from the last stage, `need` is the count a
+    // stage's output must be a multiple of; it produces out_chunk per in_chunk
+    void recompute_rates() {
+        std::size_t need = 1;
+        for (auto it = _stages.rbegin(); it != _stages.rend(); ++it) {
+            const std::size_t k = need / std::gcd(need, (*it)->out_chunk); // chunks so that k * out_chunk is a multiple of need
+            need                = k * (*it)->in_chunk;
+        }
+        _in_chunk      = need;
+        _out_per_chunk = out_count(_in_chunk);
+    }
     [[nodiscard]] std::size_t out_count(std::size_t n_in) const { // elements leaving the last stage for n_in entering the first
         for (auto& s : _stages) n_in = n_in / s->in_chunk * s->out_chunk;
         return n_in;
@@ -712,7 +724,26 @@ public:
 
     work::Result work(std::size_t requested) override {
         try {
+            // a tag on the first sample of the launch: settings-by-tag for the member blocks (only the stages of members that changed are rebuilt, the
+            // others keep their state), then forwarded across the whole run like across one block: "gr:" keys, at the first output sample,
+            // gr:sample_rate scaled by the run's rate change
+            property_map fwd;
+            if (const Tag* t = _in_edge->tagAtReadPosition()) {
+                std::vector<bool> dirty(_stages.size(), false);
+                for (auto& m : _members)
+                    if (m.block->apply_tag_settings(t->map)) dirty[m.stage] = true;
+                for (std::size_t i = 0; i < _stages.size(); ++i)
+                    if (dirty[i] && _rebuild) { _stages[i] = _rebuild(i); ++_stages_rebuilt; }
+                if (std::find(dirty.begin(), dirty.end(), true) != dirty.end()) recompute_rates(); // the launch below is sized with the new chunking
+                for (const auto& [key, value] : t->map) {
+                    if (!std::string_view(key).starts_with(GR_TAG_PREFIX)) continue;
+                    const float* rate = tag::settingsKey(key) == tag::SAMPLE_RATE && _out_per_chunk != _in_chunk ? std::get_if<float>(&value) : nullptr;
+                    if (rate) fwd.insert_or_assign(key, static_cast<float>(_out_per_chunk) / static_cast<float>(_in_chunk) * *rate);
+                    else fwd.insert_or_assign(key, value);
+                }
+            }
             std::size_t n = std::min({_avail(), requested, _ring_bytes / _in_bytes / 2});
+            n = std::min(n, std::max(_in_edge->samplesUntilNextTag(), _in_chunk)); // a launch ends where the next tag starts (Block.hpp:1511-1530): tags sit on launch boundaries
             n = std::min(n / _in_chunk, _space() / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
             if (n == 0) {
                 if (_avail() < _in_chunk && _in_edge->producer_done) {
@@ -740,6 +771,7 @@ public:
             }
             check(gr4hip_memcpy_d2h(_h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _stream), "d2h");
             check(gr4hip_stream_synchronize(_stream), "sync"); // cursors advance only after the completion of the stream work
+            if (!fwd.empty()) { _out_edge->publishTag(fwd, 0); ++_tags_forwarded; }
             _write(_h_out.p, cnt);
             return {requested, n, work::Status::OK};
         } catch (const std::exception& e) {
@@ -851,22 +883,35 @@ inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2) {
     };
     std::vector<DeviceRun*> runs;
     for (auto& chain : chains) {
+        // stage plan: member index -> stage index; adjacent fir_filter<complex<float>> -> PowerSpectrum members share one fused stage (peephole)
         std::vector<std::shared_ptr<Stage>> made;
         for (auto* m : chain) made.push_back(std::static_pointer_cast<Stage>(m->make_device_stage()));
         if (std::find(made.begin(), made.end(), nullptr) != made.end()) continue; // a member without a device kernel: leave the chain to the per-block seam
-        std::vector<std::unique_ptr<Stage>> fused;
+        std::vector<std::size_t>        first_member; // per stage
+        std::vector<DeviceRun::RunMember> members;
         for (std::size_t i = 0; i < made.size(); ++i) {
-            auto fir  = std::dynamic_pointer_cast<FirStage<std::complex<float>>>(made[i]);
-            auto spec = i + 1 < made.size() ? std::dynamic_pointer_cast<PowerSpectrumStage>(made[i + 1]) : nullptr;
-            if (fir && spec) { // peephole: the pair has a fused kernel
-                fused.push_back(std::make_unique<ChainStage>(fir->taps, spec->N, spec->window));
-                ++i;
-            } else {
-                fused.push_back(std::make_unique<Holder>(made[i]));
-            }
+            const bool pair = std::dynamic_pointer_cast<FirStage<std::complex<float>>>(made[i]) && i + 1 < made.size() && std::dynamic_pointer_cast<PowerSpectrumStage>(made[i + 1]);
+            first_member.push_back(i);
+            members.push_back({chain[i], first_member.size() - 1});
+            if (pair) members.push_back({chain[++i], first_member.size() - 1});
         }
+        const auto n_members = [first_member, total = made.size()](std::size_t stage) { return (stage + 1 < first_member.size() ? first_member[stage + 1] : total) - first_member[stage]; };
+        // (re)build stage i from its members' CURRENT settings; `fresh` avoids making the first set twice
+        auto build = [chain, first_member, n_members](std::size_t stage, const std::vector<std::shared_ptr<Stage>>* fresh) -> std::unique_ptr<Stage> {
+            const std::size_t m0 = first_member[stage];
+            const auto get = [&](std::size_t m) { return fresh ? (*fresh)[m] : std::static_pointer_cast<Stage>(chain[m]->make_device_stage()); };
+            if (n_members(stage) == 2) {
+                auto fir  = std::dynamic_pointer_cast<FirStage<std::complex<float>>>(get(m0));
+                auto spec = std::dynamic_pointer_cast<PowerSpectrumStage>(get(m0 + 1));
+                return std::make_unique<ChainStage>(fir->taps, spec->N, spec->window);
+            }
+            return std::make_unique<Holder>(get(m0));
+        };
+        std::vector<std::unique_ptr<Stage>> fused;
+        for (std::size_t st = 0; st < first_member.size(); ++st) fused.push_back(build(st, &made));
         auto  run = std::make_unique<DeviceRun>(std::move(fused), chain.front()->input_edges()[0], chain.back()->output_edges()[0], chain.front()->compute_domain());
         auto* ref = run.get();
+        run->set_members(std::move(members), [build](std::size_t stage) { return build(stage, nullptr); });
         std::vector<std::unique_ptr<BlockModel>> kept;
         bool                                     placed = false;
         for (auto& bp : blocks) {

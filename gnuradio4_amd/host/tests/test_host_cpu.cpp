@@ -106,6 +106,44 @@ int main(int argc, char** argv) {
         EXPECT(sink._samples.size() == 10u);
         EXPECT(sink._samples[1] == src.values[10 % 3]);
     }
+    // ---- tags: forwarded at the first output sample of a chunk, "gr:" keys only, gr:sample_rate scaled by the resampling ratio (qa_filter.cpp:267-293, 318-320);
+    //      chunks split at tags; settings-by-tag (Settings.hpp:433)
+    {
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(100)}});
+        src.values = {1.f, 2.f, 3.f};
+        src._tags  = {{0, {{"gr:sample_rate", 1000.f}}}, {50, {{"gr:sample_rate", 2000.f}, {"custom", std::int64_t(1)}}}};
+        auto& dec  = g.emplaceBlock<filter::Decimator<float>>({{"decim", std::int64_t(10)}});
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        g.connect<"out", "in">(src, dec);
+        g.connect<"out", "in">(dec, sink);
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        EXPECT(sink._samples.size() == 10u && sink._tags.size() == 2u);
+        if (sink._tags.size() == 2) {
+            EXPECT(sink._tags[0].index == 0u && (sink._tags[0].map == property_map{{"gr:sample_rate", 100.f}}));
+            EXPECT(sink._tags[1].index == 5u && (sink._tags[1].map == property_map{{"gr:sample_rate", 200.f}})); // "custom" has no gr: prefix: not forwarded
+        }
+    }
+    {
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(100000)}});
+        src.values = {1.f};
+        src._tags  = {{70001, {{"value", 3.0}, {"gr:trigger_name", "go"s}}}, {70002, {{"gr:value", 5.0}}}};
+        auto& mul  = g.emplaceBlock<blocks::math::MultiplyConst<float>>({{"value", 2.0}});
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        g.connect<"out", "in">(src, mul);
+        g.connect<"out", "in">(mul, sink);
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        bool ok = sink._samples.size() == 100000u;
+        for (std::size_t i = 0; ok && i < sink._samples.size(); ++i) ok = sink._samples[i] == (i < 70001 ? 2.f : i < 70002 ? 3.f : 5.f); // the change lands exactly on the tagged sample
+        EXPECT(ok);
+        EXPECT(mul._settings_by_tag == 2u && mul.value == 5.f);
+        EXPECT(sink._tags.size() == 2u && sink._tags[0].index == 70001u && (sink._tags[0].map == property_map{{"gr:trigger_name", "go"s}}) && sink._tags[1].index == 70002u);
+    }
     // ---- FIR box-car step response settles in 10 samples; IIR forms agree (qa_filter.cpp:53-128)
     {
         filter::fir_filter<double> fir;

@@ -343,6 +343,60 @@ int main(int argc, char** argv) {
             report("planned run with two rate changes", got[1].size() == xf.size() / 12 ? max_rel(got[1], got[0]) : 1e30, 1e-5);
         }
     }
+    { // 6. tags through a fused device run: launches split at tags, "gr:" keys forwarded at the first output sample with gr:sample_rate scaled by the run's rate
+      //    change, settings-by-tag reaches the member block and rebuilds only its stage (the FIR keeps its history)
+        std::vector<float> xs(120000);
+        for (std::size_t i = 0; i < xs.size(); ++i) xs[i] = static_cast<float>(std::sin(0.01 * double(i)));
+        std::vector<float> got[2];
+        std::vector<Tag>   tags[2];
+        for (int dev = 1; dev >= 0; --dev) {
+            Graph g;
+            const auto dom = [&](property_map m) { if (dev) m["compute_domain"] = "gpu:hip:0"s; return m; };
+            auto& src  = g.emplaceBlock<testing::VectorSource<float>>();
+            src.values = xs;
+            src._tags  = {{0, {{"gr:sample_rate", 1000.f}}}, {40000, {{"gr:sample_rate", 1000.f}, {"gr:value", 3.0}, {"note", "dropped"s}}}};
+            auto& mul  = g.emplaceBlock<blocks::math::MultiplyConst<float>>(dom({{"value", 0.5}}));
+            auto& bdf  = g.emplaceBlock<filter::BasicDecimatingFilter<float>>(dom({{"filter_type", "FIR"s}, {"filter_order", std::int64_t(4)}, {"f_low", 50.0}, {"sample_rate", 1000.0}, {"fir_design_method", "Hamming"s}, {"decimate", std::int64_t(4)}}));
+            auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+            g.connect<"out", "in">(src, mul);
+            g.connect<"out", "in">(mul, bdf);
+            g.connect<"out", "in">(bdf, sink);
+            hip::DeviceRun* run = nullptr;
+            if (dev) {
+                const auto runs = hip::plan(g);
+                if (runs.size() != 1) { ++errors; break; }
+                run = runs[0];
+            }
+            scheduler::Simple sched;
+            sched.exchange(std::move(g));
+            if (const auto r = sched.runAndWait(); !r) { std::cerr << "tagged run: " << r.error().message << "\n"; ++errors; }
+            got[dev]  = sink._samples;
+            tags[dev] = sink._tags;
+            if (dev) {
+                std::printf("tags through the device run: %zu forwarded, %zu stage rebuilt, %zu launches\n", run->tags_forwarded(), run->stages_rebuilt(), run->launches());
+                if (run->tags_forwarded() != 2 || run->stages_rebuilt() != 1) ++errors;
+            }
+        }
+        const std::vector<Tag> want{{0, {{"gr:sample_rate", 250.f}}}, {10000, {{"gr:sample_rate", 250.f}, {"gr:value", 3.0}}}};
+        double worst = got[1].size() == xs.size() / 4 && got[0].size() == got[1].size() ? 0.0 : 1e30;
+        for (std::size_t i = 0; i < got[1].size() && worst < 1e29; ++i) worst = std::max(worst, double(std::abs(got[1][i] - got[0][i])));
+        std::printf("tags: device run %s, host graph %s, streams differ by %.3g\n", tags[1] == want ? "forwarded {0: 250 Hz, 10000: 250 Hz + gr:value}" : "WRONG TAGS",
+                    tags[0] == want ? "the same" : "DIFFERENT", worst);
+        if (tags[1] != want || tags[0] != want || !(worst <= 2e-5)) ++errors;
+        // after the tag the run multiplies by 3 instead of 0.5 with the SAME filter state: y_after = FIR(3 x) continues FIR(0.5 x) without a transient
+        // other than the one of the gain step itself; compare against a host rendering of exactly that
+        {
+            filter::BasicDecimatingFilter<float> ref;
+            ref.applySettings({{"filter_type", "FIR"s}, {"filter_order", std::int64_t(4)}, {"f_low", 50.0}, {"sample_rate", 1000.0}, {"fir_design_method", "Hamming"s}, {"decimate", std::int64_t(4)}});
+            std::vector<float> scaled(xs.size()), y(xs.size() / 4);
+            for (std::size_t i = 0; i < xs.size(); ++i) scaled[i] = xs[i] * (i < 40000 ? 0.5f : 3.f);
+            (void)ref.processBulk(scaled, y);
+            double w2 = 0;
+            for (std::size_t i = 0; i < y.size() && i < got[1].size(); ++i) w2 = std::max(w2, double(std::abs(got[1][i] - y[i])));
+            std::printf("tags: gain step at the tagged sample, filter state kept: max diff %.3g\n", w2);
+            if (!(w2 <= 2e-5)) ++errors;
+        }
+    }
     std::printf(errors ? "host-device: %d FAILURES\n" : "host-device: all graphs ran\n", errors);
     return errors ? 1 : 0;
 }

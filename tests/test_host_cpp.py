@@ -92,6 +92,9 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     got = np.fromfile(tmp_path / "o_gpu_ports_hann.bin", np.float32)
     t, _ = O.chain(b, x, N, 3, truth=True)
     assert len(got) == frames * N and rel(got, t) <= 1e-5
+    # tags through a fused device run
+    assert "tags through the device run: 2 forwarded, 1 stage rebuilt" in r.stdout
+    assert "tags: device run forwarded {0: 250 Hz, 10000: 250 Hz + gr:value}, host graph the same" in r.stdout
     # every other hot-path block behind the seam (device vs the host body of the same block, printed by the program) ...
     for what in ("iir_filter<float, DF_II>", "Decimator<int32> decim 7", "Rotator<complex<float>>", "BasicDecimatingFilter<float> FIR /5", "BasicFilter<float> IIR",
                  "Add<int32> n_inputs = 3", "FFT<complex<float>> 256 Hann", "FFT<complex<float>> 1000 B-Harris", "FFT<float> 512 Hamming dB", "planned run with two rate changes"):
