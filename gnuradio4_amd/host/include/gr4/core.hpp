@@ -824,10 +824,20 @@ public:
         return ref;
     }
 
-    // runtime variant (Graph.hpp:564-593): connect(src, "out", dst, "in#0")
+    // a block created elsewhere (plugin registry, PluginLoader::instantiate): Graph::addBlock (Graph.hpp:445-452)
+    BlockModel& addBlock(std::unique_ptr<BlockModel> block) {
+        _blocks.push_back(std::move(block));
+        return *_blocks.back();
+    }
+
+    // runtime variant (Graph.hpp:564-593): connect(src, "out", dst, "in#0"); src / dst are typed blocks or BlockModels of this graph
     template <typename S, typename D>
     expected<void> connect(S& src, std::string_view srcPort, D& dst, std::string_view dstPort, EdgeParameters params = {}) {
-        BlockModel *s = find(&src), *d = find(&dst);
+        const auto model = [this](auto& b) -> BlockModel* {
+            if constexpr (std::is_base_of_v<BlockModel, std::decay_t<decltype(b)>>) return find(b.raw());
+            else return find(&b);
+        };
+        BlockModel *s = model(src), *d = model(dst);
         if (!s || !d) return unexpected("connect: block is not part of this graph");
         const auto ts = s->port_type(srcPort), td = d->port_type(dstPort);
         if (ts == typeid(void)) return unexpected("connect: source port '" + std::string(srcPort) + "' not found");

@@ -56,6 +56,35 @@ def test_device_blocks_fail_loudly_without_gpu(host_bins, tmp_path):
     assert "port domains: CPU -> GPU refused, converter required" in r.stdout  # checked before anything touches a device
 
 
+PLUGIN = os.path.join(ROOT, "gnuradio4_amd", "libgr4hip_blocks.so")
+
+
+def test_plugin_entry_host_domain(host_bins):
+    """gr_plugin_make / gr_plugin_free (Plugin.hpp:82-85): a loader that links nothing finds the blocks under the reference's registry names,
+    builds a graph from property_maps and runs it (host bodies); a library without the entry points is refused with a reason"""
+    r = subprocess.run([os.path.join(host_bins, "test_host_plugin"), PLUGIN, "host", os.path.join(ROOT, "gnuradio4_amd", "libgr4hip.so")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed (compute_domain host)" in r.stdout and "refused:" in r.stdout and "gr_plugin_make / gr_plugin_free missing" in r.stdout
+    exported = subprocess.run(["nm", "-D", "--defined-only", PLUGIN], capture_output=True, text=True).stdout
+    assert " T gr_plugin_make" in exported and " T gr_plugin_free" in exported
+
+
+def test_plugin_device_domain_fails_loudly_without_gpu(host_bins):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([os.path.join(host_bins, "test_host_plugin"), PLUGIN, "gpu:hip:0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_plugin_entry_device_domain(host_bins):
+    """the same registry graph with compute_domain: gpu:hip:0 on every block: the seam is taken (bit-exact int32 wrap, FIR + Decimator, tag rescaled)"""
+    r = subprocess.run([os.path.join(host_bins, "test_host_plugin"), PLUGIN, "gpu:hip:0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed (compute_domain gpu:hip:0)" in r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,ntaps", [(8192, 256), (1024, 64)])
 def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
