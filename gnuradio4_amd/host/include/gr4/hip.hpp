@@ -22,6 +22,7 @@
 
 #include "../../../../include/gr4hip.h"
 #include "blocks.hpp"
+#include "merge.hpp"
 
 namespace gr::hip {
 
@@ -329,6 +330,57 @@ struct Kernel<gr::blocks::math::Rotator<std::complex<float>>> {
     static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<RotatorStage>(b.phase_increment, b._accumulated_phase); }
     static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
 };
+
+// ---- merged blocks (gr4/merge.hpp): the parts of a Merge<> become stages of one block; intermediates stay in HBM
+struct SeqStage final : Stage {
+    std::unique_ptr<Stage> a, b;
+    DevBuf                 mid;
+    std::string            _kind;
+    SeqStage(std::unique_ptr<Stage> a_, std::unique_ptr<Stage> b_) : a(std::move(a_)), b(std::move(b_)), _kind(std::string(a->kind()) + " + " + std::string(b->kind())) {
+        in_bytes = a->in_bytes; out_bytes = b->out_bytes;
+        const std::size_t k = b->in_chunk / std::gcd(b->in_chunk, a->out_chunk); // A chunks so that B sees whole chunks
+        in_chunk  = k * a->in_chunk;
+        out_chunk = k * a->out_chunk / b->in_chunk * b->out_chunk;
+    }
+    std::string_view kind() const override { return _kind; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        std::size_t m = 0;
+        if (const int rc = a->enqueue(in, n, mid.ensure(std::max<std::size_t>(1, n / a->in_chunk * a->out_chunk) * a->out_bytes), &m, s)) return rc;
+        return b->enqueue(mid.p, m, out, n_out, s);
+    }
+};
+template <typename A, fixed_string OutA, typename B, fixed_string InB>
+requires requires(A& a, B& b) { Kernel<A>::make_stage(a); Kernel<B>::make_stage(b); }
+struct Kernel<gr::Merge<A, OutA, B, InB>> {
+    using M = gr::Merge<A, OutA, B, InB>;
+    static std::unique_ptr<Stage> make_stage(M& m);
+    static work::Status           work(M& m, std::size_t nIn, std::size_t nOut) { return offload_work(m, nIn, nOut, make_stage); }
+};
+// an adder whose second input is its own output through a constant gain c, one sample late: y[n] = x[n] + c y[n-1] -- a 1-pole IIR, run by the
+// parallel-in-time scan kernel instead of one sample per scheduler cycle (FeedbackMerge, BlockMerging.hpp:600-800)
+template <fixed_string FO, fixed_string BO, fixed_string FI>
+struct Kernel<gr::FeedbackMerge<gr::Adder<float>, FO, gr::blocks::math::MultiplyConst<float>, BO, FI>> {
+    using M = gr::FeedbackMerge<gr::Adder<float>, FO, gr::blocks::math::MultiplyConst<float>, BO, FI>;
+    static std::unique_ptr<Stage> make_pole(float gain, float c) { // y[n] = gain x[n] + c y[n-1]
+        auto st = std::make_unique<IirStage>(GR4HIP_DF_I, 1, std::vector<float>{gain}, 1, std::vector<float>{1.f, -c}, 2);
+        return st;
+    }
+    static std::unique_ptr<Stage> make_stage(M& m) { return make_pole(1.f, m.feedback.value); }
+    static work::Status           work(M& m, std::size_t nIn, std::size_t nOut) { return offload_work(m, nIn, nOut, make_stage); }
+};
+namespace detail {
+template <typename T>
+struct is_pole_feedback : std::false_type {};
+template <fixed_string FO, fixed_string BO, fixed_string FI>
+struct is_pole_feedback<gr::FeedbackMerge<gr::Adder<float>, FO, gr::blocks::math::MultiplyConst<float>, BO, FI>> : std::true_type {};
+} // namespace detail
+template <typename A, fixed_string OutA, typename B, fixed_string InB>
+requires requires(A& a, B& b) { Kernel<A>::make_stage(a); Kernel<B>::make_stage(b); }
+std::unique_ptr<Stage> Kernel<gr::Merge<A, OutA, B, InB>>::make_stage(M& m) {
+    // peephole: input gain -> pole feedback is still ONE first-order section (bm_MergeApi.cpp:59-60: y[n] = a x[n] + (1 - a) y[n-1])
+    if constexpr (std::is_same_v<A, gr::blocks::math::MultiplyConst<float>> && detail::is_pole_feedback<B>::value) return Kernel<B>::make_pole(m.leftBlock.value, m.rightBlock.feedback.value);
+    else return std::make_unique<SeqStage>(Kernel<A>::make_stage(m.leftBlock), Kernel<B>::make_stage(m.rightBlock));
+}
 
 // N inputs -> 1 output at the seam (Math.hpp:100-107): every input span goes to HBM, one fold kernel, one span back.  No Stage: a
 // fan-in is not part of a linear device run, the planner leaves it to this per-block path.

@@ -7,6 +7,7 @@
 #include <iostream>
 
 #include <gr4/blocks.hpp>
+#include <gr4/merge.hpp>
 
 using namespace gr;
 using namespace std::string_literals;
@@ -143,6 +144,32 @@ int main(int argc, char** argv) {
         EXPECT(ok);
         EXPECT(mul._settings_by_tag == 2u && mul.value == 5.f);
         EXPECT(sink._tags.size() == 2u && sink._tags[0].index == 70001u && (sink._tags[0].map == property_map{{"gr:trigger_name", "go"s}}) && sink._tags[1].index == 70002u);
+    }
+    // ---- merge API: the reference benchmark's IIR low-pass y[n] = a x[n] + (1 - a) y[n-1] as Merge<MultiplyConst, FeedbackMerge<Adder, MultiplyConst>>
+    //      (core/benchmarks/bm_MergeApi.cpp:59-77), type spelled as upstream; sub-block settings by dotted keys
+    {
+        using blocks::math::MultiplyConst;
+        using IIRChain = gr::Merge<MultiplyConst<float>, "out", gr::FeedbackMerge<Adder<>, "out", MultiplyConst<float>, "out", "in2">, "in1">;
+        constexpr float kAlpha = 0.3f;
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(5000)}});
+        src.values = {1.f, -0.5f, 0.25f, 2.f, 0.f, 0.f, -3.f};
+        auto& iir  = g.emplaceBlock<IIRChain>({{"leftBlock.value", double(kAlpha)}, {"rightBlock.feedback.value", double(1.0f - kAlpha)}});
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        EXPECT((g.connect<"out", "in">(src, iir)).has_value() && (g.connect<"out", "in">(iir, sink)).has_value());
+        EXPECT(iir.leftBlock.value == kAlpha && iir.rightBlock.feedback.value == 1.0f - kAlpha);
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        float state = 0.f, worst = 0.f; // IIRReference of the benchmark
+        for (std::size_t i = 0; i < sink._samples.size(); ++i) {
+            state = kAlpha * src.values[i % src.values.size()] + (1.0f - kAlpha) * state;
+            worst = std::max(worst, std::abs(sink._samples[i] - state));
+        }
+        EXPECT(sink._samples.size() == 5000u && worst <= 1e-6f);
+        bool threw = false;
+        try { IIRChain bad; bad.applySettings({{"middleBlock.value", 1.0}}); } catch (const std::invalid_argument&) { threw = true; }
+        EXPECT(threw);
     }
     // ---- FIR box-car step response settles in 10 samples; IIR forms agree (qa_filter.cpp:53-128)
     {

@@ -343,6 +343,29 @@ int main(int argc, char** argv) {
             report("planned run with two rate changes", got[1].size() == xf.size() / 12 ? max_rel(got[1], got[0]) : 1e30, 1e-5);
         }
     }
+    { // 5b. merge API on the device: Merge<MultiplyConst, FeedbackMerge<Adder, MultiplyConst>> (the reference benchmark's IIR low-pass) is ONE first-order
+      //     section for the scan kernel; a Merge of two unrelated blocks is a two-stage block with its intermediate in HBM
+        using blocks::math::MultiplyConst;
+        using IIRChain = gr::Merge<MultiplyConst<float>, "out", gr::FeedbackMerge<Adder<>, "out", MultiplyConst<float>, "out", "in2">, "in1">;
+        std::vector<float> xs(400000);
+        std::uint32_t      lcg = 99u;
+        for (auto& v : xs) { lcg = lcg * 1664525u + 1013904223u; v = static_cast<float>(static_cast<std::int32_t>(lcg >> 8) % 2001 - 1000) / 1000.f; }
+        const property_map cfg{{"leftBlock.value", double(0.3f)}, {"rightBlock.feedback.value", double(1.0f - 0.3f)}};
+        const auto d = run_one<IIRChain, float, float>(cfg, xs, true, errors), h = run_one<IIRChain, float, float>(cfg, xs, false, errors);
+        const double e1 = max_rel(d, h);
+        IIRChain probe;
+        probe.applySettings(cfg);
+        const auto st = hip::Kernel<IIRChain>::make_stage(probe);
+        std::printf("merge IIR low-pass (FeedbackMerge) on the device: stage '%s', max rel err %.3g%s\n", std::string(st->kind()).c_str(), e1, e1 <= 1e-5 ? "" : "  FAILED");
+        if (!(e1 <= 1e-5) || st->kind() != "iir_f32") ++errors;
+        using Two = gr::Merge<MultiplyConst<float>, "out", filter::fir_filter<float>, "in">;
+        const property_map cfg2{{"leftBlock.value", 2.0}, {"rightBlock.b", std::vector<double>{0.5, 0.25, 0.25}}};
+        const double e2 = max_rel(run_one<Two, float, float>(cfg2, xs, true, errors), run_one<Two, float, float>(cfg2, xs, false, errors));
+        Two probe2;
+        probe2.applySettings(cfg2);
+        std::printf("merge MultiplyConst -> fir_filter on the device: stage '%s', max rel err %.3g%s\n", std::string(hip::Kernel<Two>::make_stage(probe2)->kind()).c_str(), e2, e2 <= 1e-5 ? "" : "  FAILED");
+        if (!(e2 <= 1e-5)) ++errors;
+    }
     { // 6. tags through a fused device run: launches split at tags, "gr:" keys forwarded at the first output sample with gr:sample_rate scaled by the run's rate
       //    change, settings-by-tag reaches the member block and rebuilds only its stage (the FIR keeps its history)
         std::vector<float> xs(120000);

@@ -121,6 +121,9 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     got = np.fromfile(tmp_path / "o_gpu_ports_hann.bin", np.float32)
     t, _ = O.chain(b, x, N, 3, truth=True)
     assert len(got) == frames * N and rel(got, t) <= 1e-5
+    # merge API: the reference benchmark's FeedbackMerge IIR collapses into one first-order section of the scan kernel
+    assert "merge IIR low-pass (FeedbackMerge) on the device: stage 'iir_f32'" in r.stdout
+    assert "merge MultiplyConst -> fir_filter on the device: stage 'math_const + fir_f32'" in r.stdout
     # tags through a fused device run
     assert "tags through the device run: 2 forwarded, 1 stage rebuilt" in r.stdout
     assert "tags: device run forwarded {0: 250 Hz, 10000: 250 Hz + gr:value}, host graph the same" in r.stdout
