@@ -54,7 +54,12 @@ __device__ __forceinline__ T apply_any(T a, T b) {
 constexpr int kMaxInputs = 32; // Math.hpp:90 Limits<1U, 32U>
 struct NaryPtrs { const void* p[kMaxInputs]; };
 
-template <typename T> union Vec16 { uint4 u; T e[16 / sizeof(T)]; };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> union Vec16 { u32x4 u; T e[16 / sizeof(T)]; };
+// Launch shape of the streaming kernels (tools/ubench/stream_rate.hip, 2^28 int32 in + out): a workgroup owns ONE contiguous 16 KiB slab
+// (4 x 256 lanes x 16 B) and the accesses are non-temporal -- 5.9 TB/s; a persistent grid-stride loop over 2048 workgroups with the
+// default cache policy reaches 4.8 (hipMemcpyDtoD: 5.2).
+constexpr int kMathSlab = 4; // 16-byte vectors per lane
 
 // out[i] = ((in0[i] op in1[i]) op in2[i]) ...   or, with CONST, out[i] = in0[i] op value
 template <typename T, int OP, bool CONST>
@@ -62,21 +67,25 @@ __global__ void math_kernel(NaryPtrs ins, int n_inputs, T value, T* __restrict__
     constexpr int VE     = 16 / sizeof(T);
     const long    nvec   = n / VE;
     const long    stride = (long)gridDim.x * blockDim.x;
-    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    const long    v0     = (long)blockIdx.x * (blockDim.x * kMathSlab) + threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < kMathSlab; ++s) {
+        const long v = v0 + (long)s * blockDim.x;
+        if (v >= nvec) break;
         Vec16<T> acc;
-        acc.u = reinterpret_cast<const uint4*>(ins.p[0])[v];
+        acc.u = __builtin_nontemporal_load(&reinterpret_cast<const u32x4*>(ins.p[0])[v]);
         if constexpr (CONST) {
 #pragma unroll
             for (int e = 0; e < VE; ++e) acc.e[e] = apply_any<T, OP>(acc.e[e], value);
         } else {
             for (int k = 1; k < n_inputs; ++k) {
                 Vec16<T> b;
-                b.u = reinterpret_cast<const uint4*>(ins.p[k])[v];
+                b.u = __builtin_nontemporal_load(&reinterpret_cast<const u32x4*>(ins.p[k])[v]);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) acc.e[e] = apply_any<T, OP>(acc.e[e], b.e[e]);
             }
         }
-        reinterpret_cast<uint4*>(out)[v] = acc.u;
+        __builtin_nontemporal_store(acc.u, &reinterpret_cast<u32x4*>(out)[v]);
     }
     for (long i = nvec * VE + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { // tail
         T a = static_cast<const T*>(ins.p[0])[i];
@@ -89,7 +98,9 @@ __global__ void math_kernel(NaryPtrs ins, int n_inputs, T value, T* __restrict__
 
 template <typename T, bool CONST>
 static int math_dispatch_op(int op, const NaryPtrs& ins, int n_inputs, T value, void* out, long n, hipStream_t st) {
-    const unsigned grid = (unsigned)std::min<long>(std::max<long>(ceil_div(n / (long)(16 / sizeof(T)) + 1, 256L), 1L), 256L * 8);
+    const long     nvec = n / (long)(16 / sizeof(T));
+    GR4_REQUIRE(ceil_div(nvec + 1, 256L * kMathSlab) < (1L << 31), "math: span too long for one launch");
+    const unsigned grid = (unsigned)std::max<long>(ceil_div(nvec + 1, 256L * kMathSlab), 1L); // one 16 KiB slab per workgroup (the scalar tail loop strides over the grid)
     T*             o    = static_cast<T*>(out);
     switch (op) {
     case GR4HIP_ADD: hipLaunchKernelGGL((math_kernel<T, GR4HIP_ADD, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
