@@ -413,7 +413,9 @@ static int fft_fast_launch(const float* d_in, const float* d_window, const float
         GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const long groups = (n_frames + FPB - 1) / FPB;
-    const long grid   = groups < 2L * n_cu ? groups : 2L * n_cu;
+    // one workgroup per group of frames, not a persistent grid: measured +8 ... 13 % at N <= 1024, +7 % at 8192 (the dispatcher refills a CU as soon as
+    // a workgroup retires, and the per-workgroup set-up is two twiddle loads per lane); the frame loop in the kernel only matters beyond 2^31 groups
+    const long grid   = groups < 0x7fffffffL ? groups : 0x7fffffffL;
     hipLaunchKernelGGL((fft_fast_kernel<LOG2N, REAL>), dim3((unsigned)grid), dim3(512), lds, st, d_in, d_window, d_tw, o, n_frames);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;

@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""gpurun_out/prof_secondary_pmc/*_counter_collection.csv (tools/profile_secondary.sh) -> profiles/r01_secondary_pmc.txt
+Per kernel: mean of every counter over its dispatches; FETCH_SIZE / WRITE_SIZE turned into bytes with the gfx950 correction."""
+import collections, csv, glob, re, sys
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_secondary_pmc"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_secondary_pmc.txt"
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in sorted(glob.glob(f"{src}/*_counter_collection.csv")):
+    for row in csv.DictReader(open(path)):
+        name = re.sub(r"^void ", "", row["Kernel_Name"]).split("(")[0]
+        acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+skip = ("synth_kernel", "at::", "hist", "widen")
+out = ["# rocprofv3 --pmc (counter-only passes: FETCH_SIZE | WRITE_SIZE | SQ/GRBM) -- python tools/secondary_prof.py   (2^26-sample inputs; per-dispatch means)",
+       "# FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts 64 of every 128 read bytes (x2, MI355X_MICROARCH.md HBM section)", ""]
+for name in sorted(acc):
+    if any(s in name for s in skip):
+        continue
+    out.append(name)
+    for c in sorted(acc[name]):
+        v = acc[name][c]
+        m = sum(v) / len(v)
+        extra = ""
+        if c == "FETCH_SIZE":
+            extra = f"   -> {m * 1024 * 2 / 1e6:.1f} MB read (x2 applied)"
+        if c == "WRITE_SIZE":
+            extra = f"   -> {m * 1024 / 1e6:.1f} MB written"
+        out.append(f"    {c:<26} n={len(v):2d} mean={m:.6g}{extra}")
+    out.append("")
+open(dst, "w").write("\n".join(out))
+print(dst, len(acc), "kernels")
