@@ -182,44 +182,61 @@ __global__ __launch_bounds__(kIirBB) void iir_pass_b(const float* __restrict__ s
     for (long g0 = 0; g0 < nblocks; g0 += (long)kIirBB * kIirBK) {
         const long b0 = g0 + (long)c * kIirBK;
         float      e[MP];
-        // zero-start end state of the lane's kIirBK blocks; lane 0 starts from the carried state instead
-#pragma unroll
-        for (int i = 0; i < MP; ++i) e[i] = c == 0 ? T[i] : 0.f;
-#pragma unroll 1
-        for (int q = 0; q < kIirBK; ++q) {
+        // one block step of the lane's chain: e <- Phi_B e + z
+        auto step = [&](const float (&z)[MP]) {
             float nv[MP];
 #pragma unroll
-            for (int i = 0; i < MP; ++i) nv[i] = b0 + q < nblocks ? zb[(b0 + q) * MP + i] : 0.f;
+            for (int i = 0; i < MP; ++i) nv[i] = z[i];
 #pragma unroll
             for (int j = 0; j < MP; ++j)
 #pragma unroll
                 for (int i = 0; i < MP; ++i) nv[i] = fmaf(PB[j * MP + i], e[j], nv[i]);
 #pragma unroll
             for (int i = 0; i < MP; ++i) e[i] = nv[i];
-        }
+        };
+        // Two traversals of the lane's kIirBK blocks: zero-start end state (lane 0: from the carried state), then -- after the workgroup scan --
+        // the replay from the true start state, which writes T_b.  MP <= 8: all block states of a traversal are fetched before the chain starts
+        // (a load inside the chain loop pays the L2 round trip per block, and this pass is nothing but latency); MP = 16 keeps the rolled
+        // loop (64 more live registers spill).
+        auto traverse = [&](bool store) {
+            if constexpr (MP <= 8) {
+                float zq[kIirBK][MP];
+#pragma unroll
+                for (int q = 0; q < kIirBK; ++q)
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) zq[q][i] = b0 + q < nblocks ? zb[(b0 + q) * MP + i] : 0.f;
+#pragma unroll
+                for (int q = 0; q < kIirBK; ++q) {
+                    if (store && b0 + q < nblocks) {
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) tb[(b0 + q) * MP + i] = e[i];
+                    }
+                    step(zq[q]);
+                }
+            } else {
+#pragma unroll 1
+                for (int q = 0; q < kIirBK; ++q) {
+                    if (store && b0 + q < nblocks) {
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) tb[(b0 + q) * MP + i] = e[i];
+                    }
+                    float z[MP];
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) z[i] = b0 + q < nblocks ? zb[(b0 + q) * MP + i] : 0.f;
+                    step(z);
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < MP; ++i) e[i] = c == 0 ? T[i] : 0.f;
+        traverse(false);
 #pragma unroll
         for (int i = 0; i < MP; ++i) sv[i * kIirBB + c] = e[i];
         __syncthreads();
         iir_block_scan<MP, kIirBB, kIirBRounds>(sv, PK); // sv[.][c] = state at the END of the lane's last block
-        // replay the lane's blocks from its true start state
 #pragma unroll
         for (int i = 0; i < MP; ++i) e[i] = c == 0 ? T[i] : sv[i * kIirBB + c - 1];
-#pragma unroll 1
-        for (int q = 0; q < kIirBK; ++q) {
-            if (b0 + q < nblocks) {
-#pragma unroll
-                for (int i = 0; i < MP; ++i) tb[(b0 + q) * MP + i] = e[i];
-            }
-            float nv[MP];
-#pragma unroll
-            for (int i = 0; i < MP; ++i) nv[i] = b0 + q < nblocks ? zb[(b0 + q) * MP + i] : 0.f; // re-read (L2 hit) rather than held in registers
-#pragma unroll
-            for (int j = 0; j < MP; ++j)
-#pragma unroll
-                for (int i = 0; i < MP; ++i) nv[i] = fmaf(PB[j * MP + i], e[j], nv[i]);
-#pragma unroll
-            for (int i = 0; i < MP; ++i) e[i] = nv[i];
-        }
+        traverse(true);
         __syncthreads();
         if (c < MP) T[c] = sv[c * kIirBB + kIirBB - 1];
         __syncthreads();
