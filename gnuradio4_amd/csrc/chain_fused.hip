@@ -658,8 +658,12 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     constexpr size_t lds_win  = lds_base + 1024 * sizeof(float);
     static_assert(lds_win <= 160 * 1024, "LDS budget of one CU");
     const size_t lds  = (c->windowed && !fir_mode) ? lds_win : lds_base;
-    static int   n_cu = 0;
-    if (n_cu == 0) {
+    static PerDevice per_device; // LDS opt-in and CU count, once per device this process uses
+    bool             first = false;
+    int              dev = -1, n_cu = per_device.current(&first, &dev);
+    GR4_REQUIRE(n_cu != 0, "fused chain: cannot query the current device");
+    if (first) {
+        n_cu = -n_cu;
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
@@ -668,9 +672,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-        int dev = 0;
-        GR4_HIP_TRY(hipGetDevice(&dev));
-        GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        per_device.done(dev, n_cu);
     }
     const size_t   wgs  = c->max_wg ? std::min<size_t>(c->max_wg, (size_t)n_cu) : (size_t)n_cu;
     const unsigned grid = (unsigned)std::min<size_t>(n_frames, wgs); // one resident workgroup per CU (or fewer: gr4hip_chain_set_max_workgroups)

@@ -51,6 +51,27 @@ inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline int  ilog2(size_t n) { int l = 0; while ((size_t(1) << l) < n) ++l; return l; }
 template <typename T> inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 
+// Per-device one-time set-up (function attributes are per device; a process may drive several GPUs through gr4hip_set_device).
+// current(&first, &dev): CU count of the calling thread's current device (0: query failed).  The first time a table sees a device it returns
+// the NEGATED count with *first = true: the caller does its one-time set-up for that device and records it with done(dev, count).
+struct PerDevice {
+    static constexpr int kMax = 64;
+    int                  n_cu[kMax] = {};
+    int                  current(bool* first, int* dev_out = nullptr) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMax) { *first = true; return 0; }
+        if (dev_out) *dev_out = dev;
+        *first = n_cu[dev] == 0;
+        if (*first) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+            return -n; // not recorded yet: the caller records it with done() after its own set-up succeeded
+        }
+        return n_cu[dev];
+    }
+    void done(int dev, int n) { if (dev >= 0 && dev < kMax) n_cu[dev] = n; }
+};
+
 // small RAII device buffer used inside handles (grow-only)
 struct DeviceBuffer {
     void*  ptr   = nullptr;

@@ -405,12 +405,14 @@ template <int LOG2N, bool REAL = false>
 static int fft_fast_launch(const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
     constexpr int    N = 1 << LOG2N, FPB = 512 / (N / 16);
     constexpr size_t lds = (size_t)FPB * (N + N / 32) * sizeof(float2);
-    static int       n_cu = 0;
-    if (n_cu == 0) {
+    static PerDevice per_device; // the > 64 KiB LDS opt-in is per device
+    bool             first = false;
+    int              dev = -1;
+    const int        n_cu = per_device.current(&first, &dev);
+    GR4_REQUIRE(n_cu != 0, "fft: cannot query the current device");
+    if (first) {
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fft_fast_kernel<LOG2N, REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int dev = 0;
-        GR4_HIP_TRY(hipGetDevice(&dev));
-        GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        per_device.done(dev, -n_cu);
     }
     const long groups = (n_frames + FPB - 1) / FPB;
     // one workgroup per group of frames, not a persistent grid: measured +8 ... 13 % at N <= 1024, +7 % at 8192 (the dispatcher refills a CU as soon as
