@@ -52,6 +52,7 @@ SIGNATURES = {
     "gr4hip_event_record": (_i, [_vp, _vp]),
     "gr4hip_event_synchronize": (_i, [_vp]),
     "gr4hip_event_query": (_i, [_vp, _pi]),
+    "gr4hip_stream_wait_event": (_i, [_vp, _vp]),
     "gr4hip_event_elapsed_ms": (_i, [_vp, _vp, _pf]),
     "gr4hip_ring_create": (_i, [_pvp, _sz]),
     "gr4hip_ring_destroy": (_i, [_vp]),

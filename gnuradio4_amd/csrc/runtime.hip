@@ -127,6 +127,7 @@ int gr4hip_stream_synchronize(gr4hip_stream_t s) { GR4_HIP_TRY(hipStreamSynchron
 int gr4hip_event_create(gr4hip_event_t* ev) { GR4_REQUIRE(ev, "ev is null"); hipEvent_t e; GR4_HIP_TRY(hipEventCreate(&e)); *ev = e; return GR4HIP_OK; }
 int gr4hip_event_destroy(gr4hip_event_t ev) { if (ev) GR4_HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return GR4HIP_OK; }
 int gr4hip_event_record(gr4hip_event_t ev, gr4hip_stream_t s) { GR4_HIP_TRY(hipEventRecord((hipEvent_t)ev, as_stream(s))); return GR4HIP_OK; }
+int gr4hip_stream_wait_event(gr4hip_stream_t s, gr4hip_event_t ev) { GR4_HIP_TRY(hipStreamWaitEvent(as_stream(s), (hipEvent_t)ev, 0)); return GR4HIP_OK; }
 int gr4hip_event_synchronize(gr4hip_event_t ev) { GR4_HIP_TRY(hipEventSynchronize((hipEvent_t)ev)); return GR4HIP_OK; }
 int gr4hip_event_query(gr4hip_event_t ev, int* done) {
     GR4_REQUIRE(done, "done is null");

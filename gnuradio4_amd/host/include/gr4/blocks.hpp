@@ -29,7 +29,13 @@ struct VectorSource : Block<VectorSource<T>> {
         const std::size_t n = std::min({total - _produced, out.buffer->free_space(), requested});
         if (n == 0) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
         auto span = out.buffer->write_span(n);
-        for (std::size_t i = 0; i < n; ++i) span[i] = values.empty() ? T{} : values[(_produced + i) % values.size()];
+        if (values.empty()) std::fill(span.begin(), span.end(), T{});
+        else
+            for (std::size_t i = 0; i < n;) { // whole runs of the cyclic pattern at a time
+                const std::size_t at = (_produced + i) % values.size(), run = std::min(n - i, values.size() - at);
+                std::copy_n(values.begin() + static_cast<std::ptrdiff_t>(at), run, span.begin() + static_cast<std::ptrdiff_t>(i));
+                i += run;
+            }
         for (const Tag& t : _tags)
             if (t.index >= _produced && t.index < _produced + n) out.buffer->publishTag(t.map, t.index - _produced);
         out.buffer->publish(n);

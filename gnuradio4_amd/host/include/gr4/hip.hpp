@@ -9,6 +9,7 @@
 //     (fir_filter<complex<float>> -> PowerSpectrum == gr4hip_chain_*: the runtime analogue of Merge<>, BlockMerging.hpp:136-320).
 // Device blocks never fall back to the host path: a failing library call turns into work::Status::ERROR with the library's text.
 #pragma once
+#include <array>
 #include <atomic>
 #include <cctype>
 #include <cstring>
@@ -717,8 +718,21 @@ class DeviceRun final : public BlockModel {
     gr4hip_ring_t*  _ring = nullptr;
     void*           _ring_base = nullptr;
     std::size_t     _ring_bytes = 0, _ring_wr = 0;
-    gr4hip_stream_t _stream = nullptr;
-    DevBuf          _h_in{true}, _h_out{true}, _d_a, _d_b;
+    // three HIP streams, one per pipeline step (ingest copy, kernels, result copy), chained by events: the copy-in of chunk c + 1 and the copy-out of
+    // chunk c - 1 run beside the kernels of chunk c.  work() only queues; a chunk's output is published -- and the cursors move -- when its last
+    // event has fired (Block.hpp:1989-2026: publish after the work is done), in queue order.
+    gr4hip_stream_t _s_in = nullptr, _s_k = nullptr, _s_out = nullptr;
+    static constexpr std::size_t kDepth = 3;
+    struct Slot {
+        DevBuf         h_in{true}, h_out{true}, d_out;
+        gr4hip_event_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
+        std::size_t    n_out = 0;
+        bool           busy = false;
+        property_map   fwd; // tags to publish at the first output sample of this chunk
+    };
+    std::array<Slot, kDepth> _slots;
+    std::size_t     _q_head = 0, _q_count = 0, _pending_out = 0, _overlapped = 0; // FIFO of busy slots; output items not yet published; chunks queued while another was in flight
+    DevBuf          _d_a, _d_b;
     std::string     _name = "device_run";
     ComputeDomain   _domain;
     std::size_t     _in_bytes, _out_bytes, _in_chunk = 1, _out_per_chunk = 1; // smallest input count every stage sees as whole chunks, and what it becomes
@@ -745,16 +759,25 @@ public:
         for (auto& s : _stages) _desc += std::string(_desc.empty() ? "" : " -> ") + std::string(s->kind());
         recompute_rates();
         check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
-        check(gr4hip_stream_create(&_stream), "gr4hip_stream_create");
+        for (gr4hip_stream_t* st : {&_s_in, &_s_k, &_s_out}) check(gr4hip_stream_create(st), "gr4hip_stream_create");
+        for (auto& sl : _slots)
+            for (gr4hip_event_t* ev : {&sl.in_done, &sl.k_done, &sl.out_done}) check(gr4hip_event_create(ev), "gr4hip_event_create");
         check(gr4hip_ring_create(&_ring, std::size_t(64) << 20), "gr4hip_ring_create"); // GPU-resident double-mapped input ring
         check(gr4hip_ring_base(_ring, &_ring_base), "ring base");
         check(gr4hip_ring_size(_ring, &_ring_bytes), "ring size");
     }
     ~DeviceRun() override {
+        for (gr4hip_stream_t st : {_s_in, _s_k, _s_out})
+            if (st) gr4hip_stream_synchronize(st); // nothing may be in flight when the stages and buffers go
         _stages.clear();
+        for (auto& sl : _slots)
+            for (gr4hip_event_t ev : {sl.in_done, sl.k_done, sl.out_done})
+                if (ev) gr4hip_event_destroy(ev);
         if (_ring) gr4hip_ring_destroy(_ring);
-        if (_stream) gr4hip_stream_destroy(_stream);
+        for (gr4hip_stream_t st : {_s_in, _s_k, _s_out})
+            if (st) gr4hip_stream_destroy(st);
     }
+    [[nodiscard]] std::size_t overlapped_chunks() const { return _overlapped; }
     // rate bookkeeping (Resampling<>, Block.hpp:1576-1636, across the whole run): walking back from the last stage, `need` is the count a
     // stage's output must be a multiple of; it produces out_chunk per in_chunk
     void recompute_rates() {
@@ -774,8 +797,32 @@ public:
     [[nodiscard]] std::size_t  launches() const { return _launches; }
     const std::vector<std::unique_ptr<Stage>>& stages() const { return _stages; }
 
+    // publish the oldest queued chunk (blocking until its result copy has landed unless only_if_done); returns the items published
+    std::size_t retire(bool only_if_done) {
+        if (_q_count == 0) return 0;
+        Slot& sl = _slots[_q_head];
+        if (only_if_done) {
+            int done = 0;
+            check(gr4hip_event_query(sl.out_done, &done), "event query");
+            if (!done) return 0;
+        } else {
+            check(gr4hip_event_synchronize(sl.out_done), "event sync");
+        }
+        if (!sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
+        _write(sl.h_out.p, sl.n_out);
+        const std::size_t n = sl.n_out;
+        _pending_out -= n;
+        sl.busy = false;
+        sl.fwd.clear();
+        _q_head = (_q_head + 1) % kDepth;
+        --_q_count;
+        return n;
+    }
+
     work::Result work(std::size_t requested) override {
         try {
+            std::size_t published = 0;
+            while (const std::size_t r = retire(true)) published += r; // whatever has finished since the last call
             // a tag on the first sample of the launch: settings-by-tag for the member blocks (only the stages of members that changed are rebuilt, the
             // others keep their state), then forwarded across the whole run like across one block: "gr:" keys, at the first output sample,
             // gr:sample_rate scaled by the run's rate change
@@ -784,9 +831,12 @@ public:
                 std::vector<bool> dirty(_stages.size(), false);
                 for (auto& m : _members)
                     if (m.block->apply_tag_settings(t->map)) dirty[m.stage] = true;
-                for (std::size_t i = 0; i < _stages.size(); ++i)
-                    if (dirty[i] && _rebuild) { _stages[i] = _rebuild(i); ++_stages_rebuilt; }
-                if (std::find(dirty.begin(), dirty.end(), true) != dirty.end()) recompute_rates(); // the launch below is sized with the new chunking
+                if (std::find(dirty.begin(), dirty.end(), true) != dirty.end()) {
+                    while (_q_count) published += retire(false); // a stage is replaced: nothing of the old one may be in flight
+                    for (std::size_t i = 0; i < _stages.size(); ++i)
+                        if (dirty[i] && _rebuild) { _stages[i] = _rebuild(i); ++_stages_rebuilt; }
+                    recompute_rates(); // the launch below is sized with the new chunking
+                }
                 for (const auto& [key, value] : t->map) {
                     if (!std::string_view(key).starts_with(GR_TAG_PREFIX)) continue;
                     const float* rate = tag::settingsKey(key) == tag::SAMPLE_RATE && _out_per_chunk != _in_chunk ? std::get_if<float>(&value) : nullptr;
@@ -794,37 +844,53 @@ public:
                     else fwd.insert_or_assign(key, value);
                 }
             }
-            std::size_t n = std::min({_avail(), requested, _ring_bytes / _in_bytes / 2});
+            if (_q_count == kDepth) published += retire(false); // all slots queued: wait for the oldest
+            std::size_t n = std::min({_avail(), requested, _ring_bytes / _in_bytes / (kDepth + 1)}); // kDepth chunks in flight never wrap onto each other in the ring
             n = std::min(n, std::max(_in_edge->samplesUntilNextTag(), _in_chunk)); // a launch ends where the next tag starts (Block.hpp:1511-1530): tags sit on launch boundaries
-            n = std::min(n / _in_chunk, _space() / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
+            const std::size_t space = _space() - std::min(_space(), _pending_out);  // the output edge minus what queued chunks will publish
+            n = std::min(n / _in_chunk, space / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
             if (n == 0) {
+                if (_q_count) { // nothing new to queue: make room / finish up by publishing the oldest chunk
+                    published += retire(false);
+                    return {requested, published, work::Status::OK};
+                }
+                if (published) return {requested, published, work::Status::OK};
                 if (_avail() < _in_chunk && _in_edge->producer_done) {
                     _out_edge->producer_done = true;
                     return {requested, 0, work::Status::DONE};
                 }
                 return {requested, 0, _avail() < _in_chunk ? work::Status::INSUFFICIENT_INPUT_ITEMS : work::Status::INSUFFICIENT_OUTPUT_ITEMS};
             }
+            Slot& sl = _slots[(_q_head + _q_count) % kDepth];
+            if (_q_count) ++_overlapped;
             // samples land in HBM: pinned staging -> hipMemcpyAsync -> the double-mapped ring (a wrapping span stays contiguous)
-            _read(_h_in.ensure(n * _in_bytes), n);
+            _read(sl.h_in.ensure(n * _in_bytes), n);
             char* d_in = static_cast<char*>(_ring_base) + _ring_wr;
-            check(gr4hip_memcpy_h2d(d_in, _h_in.p, n * _in_bytes, _stream), "h2d");
+            check(gr4hip_memcpy_h2d(d_in, sl.h_in.p, n * _in_bytes, _s_in), "h2d");
+            check(gr4hip_event_record(sl.in_done, _s_in), "event record");
+            check(gr4hip_stream_wait_event(_s_k, sl.in_done), "stream wait");
             _ring_wr = (_ring_wr + n * _in_bytes) % _ring_bytes;
             const void* cur = d_in;
             std::size_t cnt = n;
-            for (std::size_t i = 0; i < _stages.size(); ++i) { // stages run back-to-back on one stream; intermediates stay in HBM
-                DevBuf&     dst = (i % 2) ? _d_b : _d_a;
-                std::size_t out = 0;
+            for (std::size_t i = 0; i < _stages.size(); ++i) { // stages run back-to-back on the kernel stream; intermediates stay in HBM
                 const std::size_t expect = cnt / _stages[i]->in_chunk * _stages[i]->out_chunk;
-                check(_stages[i]->enqueue(cur, cnt, dst.ensure(std::max<std::size_t>(expect, 1) * _stages[i]->out_bytes), &out, _stream), "stage");
+                DevBuf&           dst    = i + 1 == _stages.size() ? sl.d_out : ((i % 2) ? _d_b : _d_a); // the last stage writes the chunk's own result buffer
+                std::size_t       out    = 0;
+                check(_stages[i]->enqueue(cur, cnt, dst.ensure(std::max<std::size_t>(expect, 1) * _stages[i]->out_bytes), &out, _s_k), "stage");
                 if (out != expect) throw std::runtime_error("stage '" + std::string(_stages[i]->kind()) + "' produced an unexpected number of samples");
                 cur = dst.p;
                 cnt = out;
                 ++_launches;
             }
-            check(gr4hip_memcpy_d2h(_h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _stream), "d2h");
-            check(gr4hip_stream_synchronize(_stream), "sync"); // cursors advance only after the completion of the stream work
-            if (!fwd.empty()) { _out_edge->publishTag(fwd, 0); ++_tags_forwarded; }
-            _write(_h_out.p, cnt);
+            check(gr4hip_event_record(sl.k_done, _s_k), "event record");
+            check(gr4hip_stream_wait_event(_s_out, sl.k_done), "stream wait");
+            check(gr4hip_memcpy_d2h(sl.h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _s_out), "d2h");
+            check(gr4hip_event_record(sl.out_done, _s_out), "event record");
+            sl.n_out = cnt;
+            sl.busy  = true;
+            sl.fwd   = std::move(fwd);
+            _pending_out += cnt;
+            ++_q_count;
             return {requested, n, work::Status::OK};
         } catch (const std::exception& e) {
             std::cerr << "[gr::hip] device run failed: " << e.what() << "\n";

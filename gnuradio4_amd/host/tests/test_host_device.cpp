@@ -330,8 +330,10 @@ int main(int argc, char** argv) {
                 g.connect<"out", "in">(bdf, dec);
                 g.connect<"out", "in">(dec, iir);
                 g.connect<"out", "in">(iir, sink);
+                hip::DeviceRun* the_run = nullptr;
                 if (dev) {
                     const auto runs = hip::plan(g);
+                    the_run = runs.empty() ? nullptr : runs[0];
                     std::printf("planner (resampling): %zu run:%s%s\n", runs.size(), runs.empty() ? "" : " ", runs.empty() ? "" : std::string(runs[0]->description()).c_str());
                     if (runs.size() != 1 || runs[0]->description() != "math_const -> basic_fir_decim -> decimator -> iir_f32" || runs[0]->out_count(12) != 1) ++errors;
                 }
@@ -339,6 +341,11 @@ int main(int argc, char** argv) {
                 sched.exchange(std::move(g));
                 if (const auto r = sched.runAndWait(); !r) { std::cerr << "resampling run: " << r.error().message << "\n"; ++errors; }
                 got[dev] = sink._samples;
+                if (dev) { // work() only queues: chunk c + 1 is copied in while chunk c computes and chunk c - 1 is copied out
+                    const std::size_t ov = the_run ? the_run->overlapped_chunks() : 0;
+                    std::printf("pipelined run: %zu of %zu launches queued while an earlier chunk was still in flight\n", ov, the_run ? the_run->launches() / 4 : 0);
+                    if (ov == 0) ++errors;
+                }
             }
             report("planned run with two rate changes", got[1].size() == xf.size() / 12 ? max_rel(got[1], got[0]) : 1e30, 1e-5);
         }

@@ -101,6 +101,7 @@ int gr4hip_stream_synchronize(gr4hip_stream_t stream);
 int gr4hip_event_create(gr4hip_event_t* ev);
 int gr4hip_event_destroy(gr4hip_event_t ev);
 int gr4hip_event_record(gr4hip_event_t ev, gr4hip_stream_t stream);
+int gr4hip_stream_wait_event(gr4hip_stream_t stream, gr4hip_event_t ev); /* work queued on `stream` after this call starts once `ev` has fired */
 int gr4hip_event_synchronize(gr4hip_event_t ev);
 int gr4hip_event_query(gr4hip_event_t ev, int* done);
 int gr4hip_event_elapsed_ms(gr4hip_event_t start, gr4hip_event_t stop, float* ms);
