@@ -526,6 +526,24 @@ def test_chain_parity(G, algo, N, ntaps, window):
     assert _rel(ch.process_bulk(dev(xn)).cpu().numpy().ravel(), tn) <= _rel(cpu32, tn) + 2e-6  # as accurate as the float32 CPU port, to 1/5 of TOL
 
 
+@pytest.mark.parametrize("N,ntaps,window", [(1000, 33, "Hann"), (8192, 300, "None"), (16384, 64, "Hann"), (4096, 1024, "BlackmanHarris"), (128, 16, "None")])
+def test_chain_shapes_outside_the_fused_kernel(G, N, ntaps, window):
+    """AUTO falls back to the FIR kernel + FFT kernel pair for what the fused kernel does not cover (more than 256 taps, sizes that are not a power
+    of two in 256 ... 8192): same contract, same parity bar; asking for the fused kernel explicitly is refused with UNSUPPORTED"""
+    frames = 4
+    b = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    x = O.signal_c32(7, frames * N)
+    wid = [w.lower() for w in O.WINDOWS].index(window.lower())
+    truth, _ = O.chain(b, x, N, wid, truth=True)
+    ch = G.Chain(b, N, window, 0)
+    assert ch.algo == G.capi.CHAIN_UNFUSED
+    got = np.concatenate([ch.process_bulk(dev(x[:N])).cpu().numpy().ravel(), ch.process_bulk(dev(x[N:])).cpu().numpy().ravel()])
+    assert _rel(got, truth) <= TOL
+    with pytest.raises(G.capi.Gr4HipError) as e:
+        G.Chain(b, N, window, G.capi.CHAIN_FUSED_FD)
+    assert e.value.status == G.capi.UNSUPPORTED
+
+
 @pytest.mark.parametrize("N", [256, 1024, 4096])
 def test_chain_small_fft_size_chunking(G, N):
     """fftSize < 8192 runs 8192-sample blocks through the fused kernel and stages the ragged tail: any split of the stream into calls
