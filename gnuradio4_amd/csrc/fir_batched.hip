@@ -10,12 +10,14 @@
 // is one conflict-free ds_read_b32 per MFMA from the staged (18/16-padded) input segment, D leaves as fully coalesced float4 stores.
 // Bound: MFMA f32 (157.3 TFLOP/s): 2*(Kp+16) flop per output sample.
 #include "common.hpp"
+#include "buffer_ops.hpp"
 
 namespace gr4 {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kSeg = 4096; // output samples per workgroup (4 waves x 4 tiles x 256)
+constexpr int kSeg = 4096;    // output samples per segment (4 waves x 4 tiles x 256)
+constexpr int kSegPerWg = 4;  // consecutive segments per workgroup
 
 template <int KS> // K-steps of 4: Kp = 4 KS - 16
 __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__ x, long in_stride, const float* __restrict__ hist, const float* __restrict__ afrag,
@@ -23,47 +25,72 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__
     constexpr int Kp   = 4 * KS - 16;
     constexpr int NPAD = (kSeg + Kp) / 16 * 18; // two pad floats per 16 samples: block stride 18 = 2 mod 32 banks, so the 32 lanes (16 blocks x 2 K
                                                 // offsets) of a ds_read_b32 group hit 32 different banks (stride 17 puts two of them on one)
+    constexpr int NL   = (kSeg + Kp + 255) / 256; // samples a lane holds for the next segment
     __shared__ float xs[NPAD];
     const int  c    = blockIdx.y;
-    const long seg0 = (long)blockIdx.x * kSeg;
     const int  tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xc = x + (long)c * in_stride;
     const float* hc = hist + (long)c * Kp;
+    float*       yc = y + (long)c * out_stride;
 
-    for (int s = tid; s < kSeg + Kp; s += 256) { // staged index s <-> input index seg0 - Kp + s; one pad float per 16 samples
-        const long i = seg0 - Kp + s;
-        const float v = i >= 0 ? (i < n ? xc[i] : 0.f) : hc[Kp + i];
-        xs[s + 2 * (s >> 4)] = v;
-    }
     float a[KS]; // A fragments: lane l holds A[j = l & 15][u = 4 ks + (l >> 4)] = b[Kp + j - u]
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[ks] = afrag[((long)c * KS + ks) * 64 + lane];
-    __syncthreads();
 
+    // A workgroup takes kSegPerWg consecutive segments of its channel; the samples of segment s + 1 are requested (into registers) before the
+    // MFMAs of segment s and written to LDS after them.  The workgroups of a launch start together and stay in step: without the prefetch the
+    // chip alternates between everybody waiting for HBM and everybody on the matrix pipe (the same fix took fir_mfma_decim_kernel from 0.55 to 0.39 ms).
+    float nxt[NL];
+    auto load_next = [&](long seg0) { // seg0 >= kSeg > Kp: no index below 0; past the end of the span / of the segment the range check returns 0
+        const long   i0   = seg0 - Kp;
+        const long   nrec = n - i0 < (long)(kSeg + Kp) ? n - i0 : (long)(kSeg + Kp);
+        const rsrc_t r    = make_rsrc(xc + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
+#pragma unroll
+        for (int u = 0; u < NL; ++u) nxt[u] = buf_load_f(r, tid * 4, 256 * u * 4);
+    };
+    const long nseg = (n + kSeg - 1) / kSeg, sfirst = (long)blockIdx.x * kSegPerWg, slast = sfirst + kSegPerWg < nseg ? sfirst + kSegPerWg : nseg;
+    if (sfirst > 0 && sfirst < slast) load_next(sfirst * kSeg);
     const int col = lane & 15, kq = lane >> 4;
+    for (long sg = sfirst; sg < slast; ++sg) {
+        const long seg0 = sg * kSeg;
+        if (sg > 0) {
 #pragma unroll
-    for (int pair = 0; pair < 2; ++pair) { // two independent accumulators hide the 40-cycle dependent MFMA latency
-        const int ib0 = 16 * (4 * wave + 2 * pair), ib1 = ib0 + 16; // first 16-sample block of each tile
-        f32x4     acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float* p0 = xs + 18 * (ib0 + col) + kq;
-        const float* p1 = xs + 18 * (ib1 + col) + kq;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int off = 4 * ks + 2 * (ks >> 2); // padded offset of u = 4 ks within the window
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p0[off], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p1[off], acc1, 0, 0, 0);
+            for (int u = 0; u < NL; ++u) {
+                const int s_ = tid + 256 * u;
+                if (s_ < kSeg + Kp) xs[s_ + 2 * (s_ >> 4)] = nxt[u];
+            }
+        } else {
+            for (int s_ = tid; s_ < kSeg + Kp; s_ += 256) { // the first segment of the span reads the carried history in front of x
+                const long i = seg0 - Kp + s_;
+                xs[s_ + 2 * (s_ >> 4)] = i >= 0 ? (i < n ? xc[i] : 0.f) : hc[Kp + i];
+            }
         }
-        // D[row = 4 kq + r][col]: y[16 (ib + col) + 4 kq + r]
-        float*     yc = y + (long)c * out_stride;
-        const long o0 = seg0 + 16L * (ib0 + col) + 4 * kq, o1 = seg0 + 16L * (ib1 + col) + 4 * kq;
-        if (o0 + 3 < n) *reinterpret_cast<float4*>(yc + o0) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
-        else
-            for (int r = 0; r < 4; ++r)
-                if (o0 + r < n) yc[o0 + r] = acc0[r];
-        if (o1 + 3 < n) *reinterpret_cast<float4*>(yc + o1) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
-        else
-            for (int r = 0; r < 4; ++r)
-                if (o1 + r < n) yc[o1 + r] = acc1[r];
+        __syncthreads();
+        if (sg + 1 < slast) load_next(seg0 + kSeg); // in flight during the MFMAs below
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) { // two independent accumulators hide the 40-cycle dependent MFMA latency
+            const int ib0 = 16 * (4 * wave + 2 * pair), ib1 = ib0 + 16; // first 16-sample block of each tile
+            f32x4     acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* p0 = xs + 18 * (ib0 + col) + kq;
+            const float* p1 = xs + 18 * (ib1 + col) + kq;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = 4 * ks + 2 * (ks >> 2); // padded offset of u = 4 ks within the window
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p0[off], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], p1[off], acc1, 0, 0, 0);
+            }
+            // D[row = 4 kq + r][col]: y[16 (ib + col) + 4 kq + r]
+            const long o0 = seg0 + 16L * (ib0 + col) + 4 * kq, o1 = seg0 + 16L * (ib1 + col) + 4 * kq;
+            if (o0 + 3 < n) *reinterpret_cast<float4*>(yc + o0) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+            else
+                for (int r = 0; r < 4; ++r)
+                    if (o0 + r < n) yc[o0 + r] = acc0[r];
+            if (o1 + 3 < n) *reinterpret_cast<float4*>(yc + o1) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+            else
+                for (int r = 0; r < 4; ++r)
+                    if (o1 + r < n) yc[o1 + r] = acc1[r];
+        }
+        __syncthreads(); // every wave is done with the staged segment before the next one overwrites it
     }
 }
 
@@ -78,86 +105,111 @@ __global__ void fir_batched_hist_kernel(const float* __restrict__ x, long in_str
 // Polyphase decimating FIR on the same scheme (BASELINE configs[2]: decim 8, 1024 taps).  y[m] = sum_p sum_q b[qD + p] x_p[m - q] with
 // the phase streams x_p[m] = x[mD - p]: D ordinary FIRs of Q = ceil(K / D) taps at the output rate whose products land in the same
 // accumulator tile, i.e. one [16 x D (Kp+16)] x [D (Kp+16) x blocks] contraction.  The input segment is de-interleaved into D padded
-// phase rows while it is staged (every input read from HBM once); the A fragments of one phase at a time are in registers.
+// phase rows while it is staged (every input read from HBM once).  The A operand is Toeplitz -- A[j][u] = b_p[Kp + j - u] -- so it is not stored as
+// fragments at all: the D phase-tap rows (Kp + 32 floats each, zero outside the taps) sit in LDS and lane (j, kq) reads its element of K-step
+// ks at row[16 + Kp + j - kq - 4 ks]: one conflict-free ds_read_b32 (19 consecutive addresses per wave).  Fetching [D][KS][64] fragment tables
+// from L2 instead cost every wave one 256-byte load per MFMA: the MFMA phase alone ran at 53 % of the matrix pipe.
+constexpr int kDecimSPW = 4; // consecutive segments per workgroup (fir_mfma_decim_kernel)
 template <int KS, int TPW> // K-steps per phase (Kp = 4 KS - 16), 256-output tiles per wave
 __global__ __launch_bounds__(256) void fir_mfma_decim_kernel(const float* __restrict__ x, const float* __restrict__ hist /*[Kp D] samples in front of x*/,
-                                                              const float* __restrict__ afrag /*[D][KS][64]*/, float* __restrict__ y, long n_out, int D) {
+                                                              const float* __restrict__ ptaps /*[D][Kp + 32]*/, float* __restrict__ y, long n_out, int D) {
     constexpr int Kp  = 4 * KS - 16;
+    constexpr int TS  = Kp + 32;                     // phase-tap row: index 16 + q holds b[q D + p]
     constexpr int SEG = 1024 * TPW;                  // outputs per workgroup
-    constexpr int ROW = (SEG + Kp) / 16 * 17 + 1;    // padded phase row, one pad per 16 (odd length: the D rows start on different banks).  The
-                                                     // conflict-free stride 18 of fir_mfma_kernel costs the fourth workgroup per CU at D = 8 here (-4 %)
-    extern __shared__ float xs[];                    // [D][ROW]
-    const long seg0 = (long)blockIdx.x * SEG;        // first output of this workgroup
+    constexpr int PAD = 2;                           // floats of padding per 16 samples: stride 18 makes the B-operand reads conflict-free (as in fir_mfma_kernel)
+    constexpr int ROW = (SEG + Kp) / 16 * (16 + PAD) + 1; // padded phase row (odd length: the D rows start on different banks)
+    constexpr int NL  = 40;                          // samples a lane holds for the next segment: (SEG + Kp) D <= 256 NL covers D = 8 at every Kp
+    extern __shared__ float xs[];                    // [D][ROW] samples, then [D][TS] taps
+    float*     tp   = xs + D * ROW;
     const int  tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long n_in = n_out * D, H = (long)Kp * D;
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     const int col = lane & 15, kq = lane >> 4;
-    // A fragments of phase 0 are requested before the staging loop and every following phase one phase ahead: their L2 latency hides
-    // under the staging / the previous phase's MFMAs (A does not depend on the wave: four waves share the lines in L1)
-    float a0[KS], a1[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a0[ks] = afrag[(long)ks * 64 + lane];
+    for (int i = tid; i < D * TS; i += 256) tp[i] = ptaps[i];
 
+    // A workgroup takes kDecimSPW consecutive segments.  The samples of segment s + 1 are requested (into registers) before the MFMA phase of
+    // segment s and written to LDS after it: all workgroups of a launch start together and stay in step, so without this the chip alternates
+    // between everybody waiting for HBM and everybody on the matrix pipe (measured: 0.18 ms of staging + 0.37 ms of MFMAs = the 0.55 ms total).
     // stage: phase row p, position m' <-> input index (seg0 - Kp + m') D - p.  Consecutive lanes take consecutive input samples; the
     // (m', p) pair of a lane's next sample (256 further) follows from the previous one without a division.
-    const long i0  = (seg0 - Kp) * D - (D - 1);      // lowest input index needed (m' = 0, p = D - 1)
-    const int  cnt = (SEG + Kp) * D;
-    {
-        const int q256 = 256 / D, r256 = 256 % D;
-        int       e  = tid - (D - 1);                // = m' D - p for s = tid
-        int       mp = (e + D - 1) / D, pp = mp * D - e;
+    const int  cnt      = (SEG + Kp) * D;
+    const bool prefetch = cnt <= 256 * NL;
+    const int  q256 = 256 / D, r256 = 256 % D;
+    const int  e0 = tid - (D - 1);                   // = m' D - p for s = tid
+    const int  mp0 = (e0 + D - 1) / D, pp0 = mp0 * D - e0;
+    auto sample = [&](long seg0, int s) -> float {
+        const long i = (seg0 - Kp) * D - (D - 1) + s; // lowest input index needed (m' = 0, p = D - 1) + s
+        return s < cnt ? (i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -H ? hist[H + i] : 0.f)) : 0.f;
+    };
+    float nxt[NL];
+    auto load_next = [&](long seg0) { // seg0 >= SEG: no index is negative; SRSRC loads (one lane offset, constant per-load offsets -- no 64-bit address
+                                      // per load in registers), samples past the end of the span or of the segment read as 0 through the range check
+        const long   i0 = (seg0 - Kp) * D - (D - 1);
+        const long   nrec = n_in - i0 < (long)cnt ? n_in - i0 : (long)cnt;
+        const rsrc_t r  = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
+#pragma unroll
+        for (int u = 0; u < NL; ++u) nxt[u] = buf_load_f(r, tid * 4, 256 * u * 4);
+    };
+    auto store_next = [&]() {
+        int mp = mp0, pp = pp0;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            if (tid + 256 * u < cnt && mp < SEG + Kp) xs[pp * ROW + mp + PAD * (mp >> 4)] = nxt[u];
+            mp += q256;
+            pp -= r256;
+            if (pp < 0) { pp += D; mp += 1; }
+        }
+    };
+    auto stage_direct = [&](long seg0) { // segments too long for the register prefetch (large D)
+        int           mp = mp0, pp = pp0;
         constexpr int U = 8; // loads in flight per lane (a load-per-iteration loop pays the memory latency cnt / 256 times)
         for (int s0 = tid; s0 < cnt; s0 += 256 * U) {
             float v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const long i = i0 + s0 + 256 * u;
-                v[u] = s0 + 256 * u < cnt ? (i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -H ? hist[H + i] : 0.f)) : 0.f;
-            }
+            for (int u = 0; u < U; ++u) v[u] = sample(seg0, s0 + 256 * u);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (s0 + 256 * u < cnt && mp < SEG + Kp) xs[pp * ROW + mp + (mp >> 4)] = v[u];
+                if (s0 + 256 * u < cnt && mp < SEG + Kp) xs[pp * ROW + mp + PAD * (mp >> 4)] = v[u];
                 mp += q256;
                 pp -= r256;
                 if (pp < 0) { pp += D; mp += 1; }
             }
         }
-    }
-    __syncthreads();
-
-    f32x4 acc[TPW]; // one 16-block x 16-output tile (256 outputs) each; two tiles per wave hide the dependent-MFMA latency
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    const long nseg = (n_out + SEG - 1) / SEG, sfirst = (long)blockIdx.x * kDecimSPW, slast = sfirst + kDecimSPW < nseg ? sfirst + kDecimSPW : nseg;
+    if (prefetch && sfirst > 0 && sfirst < slast) load_next(sfirst * SEG);
     const float* pb[TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) pb[t] = xs + kq + 17 * (16 * (wave * TPW + t) + col);
-    auto phase = [&](const float (&a)[KS], int p) {
+    for (int t = 0; t < TPW; ++t) pb[t] = xs + kq + (16 + PAD) * (16 * (wave * TPW + t) + col);
+    const float* pa = tp + 16 + Kp + col - kq;
+    for (long sg = sfirst; sg < slast; ++sg) {
+        const long seg0 = sg * SEG; // first output of this segment
+        if (prefetch && sg > 0) store_next();
+        else stage_direct(seg0); // the very first segment of the span reads the carried history in front of x
+        __syncthreads();
+        if (prefetch && sg + 1 < slast) load_next(seg0 + SEG); // in flight during the MFMA phase below
+
+        f32x4 acc[TPW]; // one 16-block x 16-output tile (256 outputs) each
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int off = 4 * ks + (ks >> 2);
+        for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < D; ++p) {
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], pb[t][p * ROW + off], acc[t], 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+                const int   off = 4 * ks + PAD * (ks >> 2);
+                const float a   = pa[p * TS - 4 * ks];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pb[t][p * ROW + off], acc[t], 0, 0, 0);
+            }
         }
-    };
-    for (int p = 0; p < D; p += 2) {
-        const int pn = p + 1 < D ? p + 1 : p; // (odd D: the last prefetch re-reads a valid phase and is not used)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a1[ks] = afrag[((long)pn * KS + ks) * 64 + lane];
-        phase(a0, p);
-        if (p + 1 < D) {
-            const int pm = p + 2 < D ? p + 2 : p;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a0[ks] = afrag[((long)pm * KS + ks) * 64 + lane];
-            phase(a1, p + 1);
+        for (int t = 0; t < TPW; ++t) {
+            const long o = seg0 + 16L * (16 * (wave * TPW + t) + col) + 4 * kq;
+            if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            else
+                for (int r = 0; r < 4; ++r)
+                    if (o + r < n_out) y[o + r] = acc[t][r];
         }
-    }
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const long o = seg0 + 16L * (16 * (wave * TPW + t) + col) + 4 * kq;
-        if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-        else
-            for (int r = 0; r < 4; ++r)
-                if (o + r < n_out) y[o + r] = acc[t][r];
+        __syncthreads(); // every wave is done with the sample rows before the next segment overwrites them
     }
 }
 
@@ -177,7 +229,7 @@ void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_ou
 
 // y[c][i] = sum_k b_c[k] x[c][i - k], i < n; hist[c][Kp] = the Kp samples in front of x[c]; y must be 16-byte aligned, out_stride % 4 == 0
 int fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st) {
-    const dim3 grid((unsigned)ceil_div(n, (long)kSeg), nch);
+    const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kSeg), (long)kSegPerWg), nch);
     switch (KS) {
     case 20: hipLaunchKernelGGL(fir_mfma_kernel<20>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
     case 36: hipLaunchKernelGGL(fir_mfma_kernel<36>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
@@ -187,35 +239,32 @@ int fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, c
     return GR4HIP_OK;
 }
 
-// polyphase A fragments [D][KS][64]: phase p holds b[qD + p]
+// polyphase tap rows [D][Kp + 32]: row p, index 16 + q holds b[q D + p] (zero elsewhere)
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out) {
     const size_t Q  = ceil_div(ntaps, D);
-    const int    Kp = Q <= 64 ? 64 : Q <= 128 ? 128 : 256, KS = (Kp + 16) / 4;
-    af_out->assign(D * KS * 64, 0.f);
+    const int    Kp = Q <= 64 ? 64 : Q <= 128 ? 128 : 256, KS = (Kp + 16) / 4, TS = Kp + 32;
+    af_out->assign(D * TS, 0.f);
     for (size_t p = 0; p < D; ++p)
-        for (int ks = 0; ks < KS; ++ks)
-            for (int l = 0; l < 64; ++l) {
-                const int q = Kp + (l & 15) - (4 * ks + (l >> 4)); // phase-tap index
-                if (q >= 0 && (size_t)q * D + p < ntaps) (*af_out)[(p * KS + ks) * 64 + l] = taps[(size_t)q * D + p];
-            }
+        for (size_t q = 0; q < Q; ++q)
+            if (q * D + p < ntaps) (*af_out)[p * TS + 16 + q] = taps[q * D + p];
     *Kp_out = Kp;
     *KS_out = KS;
 }
 
 // y[m] = sum_k b[k] x[mD - k], m < n_out; hist = the Kp D samples in front of x; y 16-byte aligned.  Returns GR4HIP_UNSUPPORTED when the
 // de-interleaved segment does not fit the LDS.
-int fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st) {
+int fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* ptaps, float* y, long n_out, hipStream_t st) {
     const int Kp = 4 * KS - 16;
     for (int tpw : {1, 2}) { // smaller segments first: 39 KB of LDS at D = 8 -> four workgroups per CU cover the staging and A-fragment latencies
-        const int    seg = 1024 * tpw, row = (seg + Kp) / 16 * 17 + 1;
-        const size_t lds = (size_t)D * row * sizeof(float);
-        if (lds > 76 * 1024) continue; // two workgroups per CU
-        const dim3 grid((unsigned)ceil_div(n_out, (long)seg));
+        const int    seg = 1024 * tpw, row = (seg + Kp) / 16 * 18 + 1;
+        const size_t lds = (size_t)D * (row + Kp + 32) * sizeof(float);
+        if (lds > 78 * 1024) continue; // two workgroups per CU
+        const dim3 grid((unsigned)ceil_div(ceil_div(n_out, (long)seg), (long)kDecimSPW));
 #define GR4_DECIM_CASE(KSV, TPWV)                                                                                                         \
     do {                                                                                                                                  \
         auto kern = fir_mfma_decim_kernel<KSV, TPWV>;                                                                                     \
         if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, afrag, y, n_out, D);                                                  \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, ptaps, y, n_out, D);                                                  \
     } while (0)
         if (tpw == 2) { if (KS == 20) GR4_DECIM_CASE(20, 2); else if (KS == 36) GR4_DECIM_CASE(36, 2); else GR4_DECIM_CASE(68, 2); }
         else          { if (KS == 20) GR4_DECIM_CASE(20, 1); else if (KS == 36) GR4_DECIM_CASE(36, 1); else GR4_DECIM_CASE(68, 1); }
