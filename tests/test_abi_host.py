@@ -113,3 +113,13 @@ def test_device_blocks_fail_loudly_without_gpu():
         G.fir_filter([1.0, 2.0])  # needs device memory for taps/history -> HIP runtime error, no silent CPU path
     with pytest.raises(Gr4HipError):
         G.math_const("Add", torch.zeros(4), 1.0)  # host tensor is rejected, never computed on the CPU
+
+
+def test_missing_library_is_an_import_error_not_a_fallback(monkeypatch, tmp_path):
+    """without libgr4hip.so the package refuses to work (the message says how to build it): nothing computes on the CPU instead"""
+    from gnuradio4_amd import capi
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "libgr4hip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        capi.lib()
+
