@@ -14,6 +14,7 @@
 #include "common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace gr4 {
 
@@ -293,6 +294,212 @@ __global__ __launch_bounds__(kIirBS) void iir_pass_y(const float* __restrict__ x
     iir_unstage_tile(tile, y, base, n);
 }
 
+// ------------------------------------------------------------------------------------------------ single pass (MP <= 8)
+// The three passes above read x twice, write and re-read the per-chunk states (MP floats per 32 samples) and chain the blocks in a
+// one-workgroup kernel.  One pass with a decoupled look-back (the affine-map version of the chained scan) does each of them once:
+//   1. stage the tile, zero-state run per chunk, in-block scan            (as pass Z; the chunk states stay in LDS)
+//   2. publish the block's zero-state end state Z_b (flag 1)
+//   3. wave 0 looks back over the predecessors, 64 at a time: lane l reads block b-1-l; aggregates contribute Phi_B^l Z, the first
+//      block that already knows its true end state P (flag 2) closes the sum:  T_b = sum_{l<w} Phi_B^l Z_{b-1-l} + Phi_B^w P_{b-1-w}
+//      (Phi_B^0..63 from a table; a window without an inclusive block is folded in through Phi_B^64 and the next window follows)
+//   4. publish P_b = Phi_B T_b + Z_b (flag 2)
+//   5. chunk c starts from S_{c-1} + Phi_L^c T_b; with c = 16 a + r that is Phi_L^{16a} (Phi_L^r T_b): two small tables instead of a second scan
+//   6. re-run the chunk from its true start state, coalesced store.
+// Block indices are tickets drawn at the start (a block only ever waits for blocks that already run), status words and ticket are zeroed per call.
+// Waiting is bounded: a waiter that gives up raises err[0] and the span is recomputed by the three-pass kernels.
+struct IirOnePassArgs {
+    const float* x;
+    float*       y;
+    long         n;
+    const float* phi;      // [kIirRounds][MP][MP]  Phi_{L 2^k}
+    const float* plr;      // [16][MP][MP]          Phi_L^r
+    const float* pl16;     // [16][MP][MP]          Phi_L^{16 a}
+    const float* pb;       // [65][MP][MP]          Phi_B^l, l = 0 .. 64
+    const float* state_in; // [MP]
+    float*       state_out;
+    // block status: every component is ONE 64-bit word {value, tag = 1}, written by one atomic store.  A separate flag word behind plain
+    // or write-through data stores can become visible before the data (measured: wrong states at 8 floats per block); a device-scope
+    // release / acquire pair closes that hole but writes back and invalidates the whole L2 of the XCD per block (4x slower than three
+    // passes).  Self-validating words need no ordering at all.  Zeroed before every launch.
+    unsigned long long* st_z; // [nblocks][MP]  zero-state end states
+    unsigned long long* st_p; // [nblocks][MP]  true end states
+    unsigned*           ticket; // [0]: block tickets, [1]: error flag
+};
+
+__device__ __forceinline__ void iir_status_put(unsigned long long* p, float v) {
+    __hip_atomic_store(p, ((unsigned long long)1 << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long iir_status_get(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int ORD, int NSEC>
+__global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, IirCoef<ORD, NSEC> coef) {
+    constexpr int    MP = ORD * NSEC;
+    static_assert(MP <= 8, "the look-back tables are sized for MP <= 8");
+    __shared__ float tile[kIirBS * (kIirL + 1)];
+    __shared__ float sv[MP * kIirBS];
+    __shared__ __attribute__((aligned(16))) float pl[kIirRounds * MP * MP];
+    __shared__ float p16[16 * MP * MP]; // Phi_L^{16 a}, row-major
+    __shared__ float wv[16 * MP];       // Phi_L^r T_b
+    __shared__ float T[MP], R[MP * MP], R2[MP * MP];
+    __shared__ unsigned bid_s;
+    const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    if (c == 0) bid_s = atomicAdd(a.ticket, 1u);
+    iir_load_phi<MP, kIirRounds>(pl, a.phi);
+    for (int e = c; e < 16 * MP * MP; e += kIirBS) p16[e] = a.pl16[e];
+    __syncthreads();
+    const long b    = bid_s;
+    const long base = b * kIirBS * kIirL;
+    iir_stage_tile(tile, a.x, base, a.n);
+    __syncthreads();
+    // ---- 1. zero-state run and in-block scan
+    float st[NSEC][ORD];
+#pragma unroll
+    for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+        for (int j = 0; j < ORD; ++j) st[s][j] = 0.f;
+    float* row = tile + c * (kIirL + 1);
+#pragma unroll 4
+    for (int i = 0; i < kIirL; ++i) (void)iir_step<ORD, NSEC>(coef, st, row[i]);
+#pragma unroll
+    for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+        for (int j = 0; j < ORD; ++j) sv[(s * ORD + j) * kIirBS + c] = st[s][j];
+    __syncthreads();
+    iir_block_scan<MP, kIirBS, kIirRounds>(sv, pl); // sv[.][c] = zero-state end state of chunks 0..c
+    // ---- 2..4: wave 0 publishes, looks back, publishes again
+    if (wave == 0) {
+        float zb = 0.f; // lane i < MP: component i of Z_b
+        if (lane < MP) {
+            zb = sv[lane * kIirBS + kIirBS - 1];
+            if (b > 0) iir_status_put(a.st_z + b * MP + lane, zb);
+        }
+        float tv = 0.f; // lane i < MP: component i of T_b
+        if (b == 0) {
+            if (lane < MP) tv = a.state_in[lane];
+        } else {
+            if (lane < MP * MP) R[lane] = (lane / MP == lane % MP) ? 1.f : 0.f; // R = Phi_B^{64 w}: identity for the first window
+            __builtin_amdgcn_wave_barrier();
+            float acc = 0.f;                                                     // lane i < MP
+            for (long first_j = b - 1; ; first_j -= 64) {
+                const long j     = first_j - lane;
+                const bool valid = j >= 0;
+                unsigned   flag  = 0; // 1: aggregate, 2: inclusive
+                float      z[MP];
+#pragma unroll
+                for (int i = 0; i < MP; ++i) z[i] = 0.f;
+                if (valid) {
+                    int                       spins = 0;
+                    const unsigned long long* src   = nullptr;
+                    unsigned long long        w0    = 0;
+                    for (;;) { // component 0 of either state decides which one this block offers; the true end state wins
+                        if ((w0 = iir_status_get(a.st_p + j * MP)) >> 32) { flag = 2; src = a.st_p + j * MP; break; }
+                        if ((w0 = iir_status_get(a.st_z + j * MP)) >> 32) { flag = 1; src = a.st_z + j * MP; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 24)) { a.ticket[1] = 1u; flag = 2; src = a.st_p + j * MP; break; } // give up instead of hanging (never observed)
+                    }
+                    z[0] = __uint_as_float((unsigned)w0);
+#pragma unroll
+                    for (int i = 1; i < MP; ++i) { // the other components follow within a few hundred cycles; each word validates itself
+                        unsigned long long w;
+                        int                tries = 0;
+                        while (!((w = iir_status_get(src + i)) >> 32) && ++tries < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+                        z[i] = __uint_as_float((unsigned)w);
+                    }
+                }
+                const unsigned long long incl = __ballot(valid && flag == 2);
+                const int                w    = incl ? __ffsll((long long)incl) - 1 : 64; // first lane with an inclusive state
+                float v[MP];
+#pragma unroll
+                for (int i = 0; i < MP; ++i) v[i] = 0.f;
+                if (valid && lane <= w) { // Phi_B^lane * state[j]
+                    const float* P = a.pb + (long)lane * MP * MP;
+#pragma unroll
+                    for (int i = 0; i < MP; ++i)
+#pragma unroll
+                        for (int k = 0; k < MP; ++k) v[i] = fmaf(P[i * MP + k], z[k], v[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < MP; ++i) { // wave sum (every lane ends with the total)
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+                }
+                if (lane < MP) { // acc += R * wsum
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < MP; ++k) t = fmaf(R[lane * MP + k], v[k], t);
+                    acc += t;
+                }
+                if (w < 64) break;
+                // no inclusive state in this window: R <- Phi_B^64 * R ... as R and Phi_B^64 are powers of one matrix the order does not matter
+                if (lane < MP * MP) {
+                    const int    i = lane / MP, k = lane % MP;
+                    const float* P = a.pb + 64L * MP * MP;
+                    float        t = 0.f;
+#pragma unroll
+                    for (int m = 0; m < MP; ++m) t = fmaf(P[i * MP + m], R[m * MP + k], t);
+                    R2[lane] = t;
+                }
+                __builtin_amdgcn_wave_barrier(); // (one wave: LDS accesses complete in program order; this only pins the compiler's order)
+                if (lane < MP * MP) R[lane] = R2[lane];
+                __builtin_amdgcn_wave_barrier();
+            }
+            tv = acc;
+        }
+        if (lane < MP) T[lane] = tv;
+        // P_b = Phi_B T_b + Z_b
+        if (lane < MP) {
+            const float* P = a.pb + 1L * MP * MP;
+            float        pv = zb;
+#pragma unroll
+            for (int k = 0; k < MP; ++k) pv = fmaf(P[lane * MP + k], __shfl(tv, k), pv);
+            iir_status_put(a.st_p + b * MP + lane, pv);
+        }
+    }
+    __syncthreads();
+    // ---- 5. wv[r] = Phi_L^r T_b (r < 16), then every chunk's start state
+    if (c < 16 * MP) {
+        const int    r = c / MP, i = c % MP;
+        const float* P = a.plr + (long)r * MP * MP;
+        float        t = 0.f;
+#pragma unroll
+        for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], T[k], t);
+        wv[c] = t;
+    }
+    __syncthreads();
+    {
+        const int    aa = c >> 4, r = c & 15; // start of chunk c: exponent c = 16 aa + r
+        const float* P = p16 + aa * MP * MP;
+        const float* w = wv + r * MP;
+#pragma unroll
+        for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+            for (int j = 0; j < ORD; ++j) {
+                const int i = s * ORD + j;
+                float     t = c == 0 ? 0.f : sv[i * kIirBS + c - 1];
+#pragma unroll
+                for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], w[k], t);
+                st[s][j] = t;
+            }
+    }
+    // ---- 6. re-run from the true start state
+    const long cbeg = base + (long)c * kIirL;
+    const int  len  = (int)(a.n - cbeg < kIirL ? (a.n - cbeg < 0 ? 0 : a.n - cbeg) : kIirL);
+    if (len == kIirL) {
+#pragma unroll 4
+        for (int i = 0; i < kIirL; ++i) row[i] = iir_step<ORD, NSEC>(coef, st, row[i]);
+    } else {
+        for (int i = 0; i < len; ++i) row[i] = iir_step<ORD, NSEC>(coef, st, row[i]);
+    }
+    if (len > 0 && cbeg + len == a.n) { // this lane consumed the last sample of the span
+#pragma unroll
+        for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+            for (int j = 0; j < ORD; ++j) a.state_out[s * ORD + j] = st[s][j];
+    }
+    __syncthreads();
+    iir_unstage_tile(tile, a.y, base, a.n);
+}
+
 } // namespace gr4
 
 using namespace gr4;
@@ -305,6 +512,8 @@ struct gr4hip_iir {
     DeviceBuffer        d_state[2];
     int                 cur = 0;
     DeviceBuffer        d_zc, d_zb, d_tb;
+    DeviceBuffer        d_tab;            // one-pass tables: Phi_L^r [16], Phi_L^{16a} [16], Phi_B^l [65]  (M <= 8)
+    DeviceBuffer        d_stz;            // one-pass block status words: [nblocks][M] x 2 (+ ticket and error word)
 };
 
 // host double-precision cascade step (same recurrence) used to build the propagation matrices
@@ -345,6 +554,36 @@ template <int ORD, int NSEC>
 static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t st) {
     constexpr int MP      = ORD * NSEC;
     const long    nblocks = ceil_div(n, (long)kIirBS * kIirL);
+    if constexpr (MP <= 8) {
+        if (!std::getenv("GR4HIP_IIR_THREE_PASS")) { // (developer switch: the three-pass kernels below stay the path for MP = 16)
+            const size_t words = (size_t)nblocks * MP;
+            int          rc1   = f->d_stz.ensure((2 * words + 1) * sizeof(unsigned long long)); // Z words, P words, {ticket, error}
+            if (rc1) return rc1;
+            GR4_HIP_TRY(hipMemsetAsync(f->d_stz.ptr, 0, (2 * words + 1) * sizeof(unsigned long long), st));
+            IirCoef<ORD, NSEC> cf{};
+            for (int s = 0; s < NSEC; ++s)
+                for (int j = 0; j <= ORD; ++j) {
+                    cf.b[s][j] = (float)f->b[s * (ORD + 1) + j];
+                    cf.a[s][j] = (float)f->a[s * (ORD + 1) + j];
+                }
+            const float*   tab = static_cast<const float*>(f->d_tab.ptr);
+            IirOnePassArgs a{};
+            a.x = x; a.y = y; a.n = n;
+            a.phi  = static_cast<const float*>(f->d_phi.ptr);
+            a.plr  = tab;
+            a.pl16 = tab + 16 * MP * MP;
+            a.pb   = tab + 32 * MP * MP;
+            a.state_in  = static_cast<const float*>(f->d_state[f->cur].ptr);
+            a.state_out = static_cast<float*>(f->d_state[f->cur ^ 1].ptr);
+            a.st_z   = static_cast<unsigned long long*>(f->d_stz.ptr);
+            a.st_p   = a.st_z + words;
+            a.ticket = reinterpret_cast<unsigned*>(a.st_p + words);
+            hipLaunchKernelGGL((iir_onepass_kernel<ORD, NSEC>), dim3((unsigned)nblocks), dim3(kIirBS), 0, st, a, cf);
+            GR4_LAUNCH_CHECK();
+            f->cur ^= 1;
+            return GR4HIP_OK;
+        }
+    }
     int           rc      = f->d_zc.ensure((size_t)nblocks * kIirBS * MP * sizeof(float));
     if (!rc) rc = f->d_zb.ensure((size_t)nblocks * MP * sizeof(float));
     if (!rc) rc = f->d_tb.ensure((size_t)nblocks * MP * sizeof(float));
@@ -407,6 +646,33 @@ int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const floa
     int rc = f->d_phi.ensure(phi.size() * sizeof(float));
     if (!rc) { hipError_t e = hipMemcpy(f->d_phi.ptr, phi.data(), phi.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     for (int k = 0; k < 2 && !rc; ++k) rc = f->d_state[k].ensure(kIirMaxM * sizeof(float));
+    if (!rc && f->M <= 8) { // tables of the single-pass kernel, all powers in double
+        const int M = f->M;
+        auto mul = [M](const std::vector<double>& A, const std::vector<double>& B) {
+            std::vector<double> C((size_t)M * M, 0.0);
+            for (int i = 0; i < M; ++i)
+                for (int k = 0; k < M; ++k)
+                    for (int j = 0; j < M; ++j) C[i * M + j] += A[i * M + k] * B[k * M + j];
+            return C;
+        };
+        std::vector<double> I((size_t)M * M, 0.0);
+        for (int i = 0; i < M; ++i) I[i * M + i] = 1.0;
+        const std::vector<double> PL = host_phi(f, kIirL);
+        std::vector<double>       PL16 = PL;
+        for (int k = 0; k < 4; ++k) PL16 = mul(PL16, PL16); // Phi_L^16
+        std::vector<double> PB = PL16;
+        for (int k = 0; k < 4; ++k) PB = mul(PB, PB);       // Phi_L^256 = Phi_B  (kIirBS = 256 chunks per block)
+        static_assert(kIirBS == 256, "Phi_B = Phi_L^256");
+        std::vector<float> tab((16 + 16 + 65) * mm);
+        std::vector<double> cur = I;
+        for (int r = 0; r < 16; ++r) { for (size_t i = 0; i < mm; ++i) tab[r * mm + i] = (float)cur[i]; cur = mul(cur, PL); }
+        cur = I;
+        for (int q = 0; q < 16; ++q) { for (size_t i = 0; i < mm; ++i) tab[(16 + q) * mm + i] = (float)cur[i]; cur = mul(cur, PL16); }
+        cur = I;
+        for (int l = 0; l < 65; ++l) { for (size_t i = 0; i < mm; ++i) tab[(32 + l) * mm + i] = (float)cur[i]; cur = mul(cur, PB); }
+        rc = f->d_tab.ensure(tab.size() * sizeof(float));
+        if (!rc) { hipError_t e = hipMemcpy(f->d_tab.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+    }
     if (rc) { delete f; return rc; }
     rc = gr4hip_iir_reset(f);
     if (rc) { delete f; return rc; }

@@ -305,6 +305,32 @@ def test_iir_long_stream_crosses_block_scan_groups(G):
     assert _rel(y2, truth) <= TOL
 
 
+@pytest.mark.parametrize("kind", ["biquad4", "pole1", "order4"])
+def test_iir_single_pass_equals_three_pass(G, kind, monkeypatch):
+    """the single-pass kernel (decoupled look-back over block states) and the three-pass kernels are two evaluations of the same scan: they must agree
+    far inside the parity tolerance on a span long enough for multi-window look-backs (> 64 blocks of 8192 samples), ragged, in two calls"""
+    n = (1 << 21) + 12345
+    x = G.synth_f32(n, seed=21)
+    if kind == "biquad4":
+        b, a = G.blocks.design_iir(G.capi.LOWPASS, 8, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    elif kind == "pole1":
+        b, a = np.array([[0.3]], np.float32), np.array([[1.0, -0.7]], np.float32)
+    else:
+        b, a = np.array([[0.1, 0.2, 0.3, 0.2, 0.1]], np.float32), np.array([[1.0, -0.9, 0.5, -0.1, 0.02]], np.float32)
+    out = {}
+    for mode in ("one", "three"):
+        if mode == "three":
+            monkeypatch.setenv("GR4HIP_IIR_THREE_PASS", "1")
+        f = G.iir_filter(b, a)
+        y = torch.empty_like(x)
+        cut = 700001
+        f.process_bulk(x[:cut], y[:cut])
+        f.process_bulk(x[cut:], y[cut:])
+        out[mode] = y.double()
+    rms = float(out["three"].pow(2).mean().sqrt())
+    assert float((out["one"] - out["three"]).abs().max()) <= 2e-5 * rms
+
+
 def test_basic_filter_bands(G, golden):
     g = golden["basic_filter_lowpass"]
     fs, n = g["sample_rate"], g["num_samples"]
