@@ -6,6 +6,8 @@
 // result narrowed back to T (wrap-around) -- bit-exact against the oracle.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace gr4 {
 
 template <typename T> struct Wide { using type = T; };
@@ -143,7 +145,9 @@ static int math_dispatch(int op, int dtype, const NaryPtrs& ins, int n_inputs, c
 // Rotator.hpp:51-61.  The float phase recurrence is inherently sequential and is reproduced exactly:
 // one lane walks the recurrence and leaves a checkpoint every kRotChunk samples; the data pass then replays
 // kRotChunk steps per lane into LDS and applies cos/sin with fully coalesced 8-byte accesses.
-constexpr int kRotChunk = 32;
+constexpr int   kRotChunk     = 32;
+constexpr float kRotLeapBelow = 0.015f; // |phase_increment| below which the leaping walker is used: one of its segment steps costs ~20 steps of the plain walker
+                                        // (~150 dependent single-wave instructions against 3), and an increment of 0.015 rad averages ~20 samples per segment
 
 __device__ __forceinline__ float rot_step(float ph, float inc) { // same values as the if / else-if of Rotator.hpp:52-58, without branches
     const float two_pi = 2.0f * 3.14159265358979323846f;
@@ -188,6 +192,68 @@ __global__ void rotator_checkpoint_kernel(float* __restrict__ state, float inc, 
         for (; i < n; ++i) ph = rot_step(ph, inc);
     }
     *state = ph;
+}
+
+
+// The leaping walker.  The recurrence is sequential in floating point, but not everywhere: while the phase stays inside one binade
+// [2^e, 2^(e+1)) every state is a multiple of that binade's ulp u, so fl(ph + inc) = ph + c with the CONSTANT c = inc rounded to a multiple of u
+// (round-to-nearest; an increment exactly half-way between two multiples would alternate with the parity of ph -- such steps are taken one at
+// a time).  Inside a binade the states are an exact arithmetic progression, ph_j = ph + j c, evaluated in integers on the 24-bit mantissa; only
+// the steps that change the binade or wrap at 2 pi are genuine float operations.  A 0.01 rad increment meets ~10 binades per turn of 628
+// samples: ~10 sequential segment steps instead of 628 dependent adds, bit-identical states (tests: against the float recurrence of the
+// oracle, 2^20 samples per increment).  One wave: all lanes carry the same walker state (uniform control flow), the lanes only share the
+// checkpoint stores of a segment.
+__global__ __launch_bounds__(64) void rotator_checkpoint_leap_kernel(float* __restrict__ state, float inc, float* __restrict__ ckpt, long n) {
+    const float two_pi = 2.0f * 3.14159265358979323846f;
+    const int   lane   = threadIdx.x;
+    const unsigned Tm  = (__float_as_uint(two_pi) & 0x7fffffu) | 0x800000u; // mantissa of 2 pi in units of the ulp of [4, 8)
+    float       s = *state;
+    long        i = 0; // s is the state after i steps
+    while (i < n) {
+        const float    t    = rot_step(s, inc);
+        const float    raw  = s + inc;
+        const unsigned sb = __float_as_uint(s), tb = __float_as_uint(t);
+        const int      es = (int)((sb >> 23) & 0xff), et = (int)((tb >> 23) & 0xff);
+        long           k    = 1; // states i .. i + k - 1 are s, s + c, ...; the walker moves to state i + k
+        int            C    = 0;
+        const int      S    = (int)((sb & 0x7fffffu) | 0x800000u);
+        const int      sh   = es - 150; // s = S * 2^sh
+        bool           ap   = false;
+        if (t == raw && !(sb >> 31) && es == et && es > 0 && es < 255) { // no wrap, same binade, positive normal: c = t - s is exact
+            const float c = t - s, u = __builtin_amdgcn_ldexpf(1.0f, sh);
+            const float r = inc - c; // exact: |inc - c| <= u / 2 and both are multiples of ulp(inc) or inc is below u
+            C = (int)__builtin_amdgcn_ldexpf(c, -sh);
+            if (fabsf(r) != 0.5f * u) { // not a tie: c is the step for as long as the phase stays in this binade
+                // K = steps for which the progression provably equals the recurrence; all operands are below 2^24, so the quotients come from one float
+                // division each (exact operands, correctly rounded quotient, fixed up by one) instead of 64-bit integer divisions
+                const auto idiv = [](int num, int den) { // floor(num / den), num >= 0, den > 0, both < 2^24
+                    int q = (int)((float)num / (float)den);
+                    if (q * den > num) --q;
+                    return q;
+                };
+                long K;
+                if (C > 0) {
+                    int Ki = idiv(0xffffff - S, C);                    // S + K C <= 2^24 - 1: below the next binade
+                    if (es == 129) { const int K2 = S <= (int)Tm ? idiv((int)Tm - S, C) : 0; Ki = K2 < Ki ? K2 : Ki; } // ... and not above 2 pi (no wrap)
+                    K = Ki;
+                } else if (C < 0) {
+                    K = S > 0x800001 ? idiv(S - 0x800001, -C) : 0;     // S + K C >= 2^23 + 1: strictly inside the binade
+                } else {
+                    K = n;                                             // the increment is below half an ulp here: the phase no longer moves
+                }
+                if (K >= 1) { ap = true; k = K < n - i ? K : n - i; }
+            }
+        }
+        // checkpoints: state index 32 m for every m with i <= 32 m < i + k
+        const long m0 = (i + kRotChunk - 1) / kRotChunk, m1 = (i + k + kRotChunk - 1) / kRotChunk; // [m0, m1)
+        for (long m = m0 + lane; m < m1; m += 64) {
+            const long j = m * kRotChunk - i;
+            ckpt[m] = ap ? __builtin_amdgcn_ldexpf((float)(S + (int)j * C), sh) : s; // !ap: k == 1, j == 0
+        }
+        s = ap ? __builtin_amdgcn_ldexpf((float)(S + (int)k * C), sh) : t;
+        i += k;
+    }
+    if (lane == 0) *state = s;
 }
 
 __global__ __launch_bounds__(256) void rotator_apply_kernel(const float2* __restrict__ x, float2* __restrict__ y, const float* __restrict__ ckpt, float inc, long n) {
@@ -327,7 +393,10 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
     const size_t nchunks = ceil_div(n, (size_t)kRotChunk);
     int          rc      = r->d_ckpt.ensure(nchunks * sizeof(float));
     if (rc) return rc;
-    if (r->inc >= 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<1>, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n);
+    // small increments spend many samples per binade: leap; large ones change binade or wrap every few samples and the plain walker's 27-cycle step wins
+    const bool leap = std::getenv("GR4HIP_ROTATOR_LEAP") ? true : (fabsf(r->inc) < kRotLeapBelow && !std::getenv("GR4HIP_ROTATOR_WALK")); // (developer / test switches)
+    if (leap) hipLaunchKernelGGL(rotator_checkpoint_leap_kernel, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n);
+    else if (r->inc >= 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<1>, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n);
     else if (r->inc < 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<-1>, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n);
     else hipLaunchKernelGGL(rotator_checkpoint_kernel<0>, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n); // NaN increment
     GR4_LAUNCH_CHECK();

@@ -708,3 +708,38 @@ def test_rotator_golden_and_parity(G, golden):
         G.Rotator(phase_increment=0.1, frequency_shift=0.2)
     r = G.Rotator(frequency_shift=2.0, sample_rate=100.0)
     assert abs(r.phase_increment - 2 * np.pi * 0.02) < 1e-6
+
+
+def test_rotator_leaping_walker_is_bit_identical(G, monkeypatch):
+    """small increments take the leaping walker (exact arithmetic progressions inside a binade): every checkpoint, hence every output sample, and
+    the carried phase must equal the plain sample-by-sample walker's, bit for bit -- also for increments that tie between two ulps, that vanish
+    against the phase, that are negative, and across calls"""
+    n = (1 << 20) + 77
+    x = G.synth_c32(n, seed=9)
+    rng = np.random.default_rng(5)
+    incs = [0.01, -0.01, 0.2499, 1e-3, -3.3e-4, 1e-7, 1.5 * 2.0 ** -23, 2.5 * 2.0 ** -22, -1.5 * 2.0 ** -21, 2.0 ** -10, 0.1, 6.1e-5, 1.0, -2.5, 7.0] + list(rng.uniform(-0.25, 0.25, 6))
+    for inc in incs:
+        for ph0 in (0.25, 6.2831, 0.0):
+            res = {}
+            for mode in ("leap", "walk"):
+                if mode == "walk":
+                    monkeypatch.delenv("GR4HIP_ROTATOR_LEAP", raising=False)
+                    monkeypatch.setenv("GR4HIP_ROTATOR_WALK", "1")
+                else:  # force the leaping walker also above the increment where the library would stop using it: short segments stress its boundary logic
+                    monkeypatch.delenv("GR4HIP_ROTATOR_WALK", raising=False)
+                    monkeypatch.setenv("GR4HIP_ROTATOR_LEAP", "1")
+                r = G.Rotator(phase_increment=float(np.float32(inc)), initial_phase=ph0)
+                y = torch.cat([r.process_bulk(x[:100001]), r.process_bulk(x[100001:])])
+                res[mode] = (y, r.accumulated_phase)
+            assert res["leap"][1] == res["walk"][1], (inc, ph0)
+            assert torch.equal(res["leap"][0].view(torch.float32), res["walk"][0].view(torch.float32)), (inc, ph0)
+    monkeypatch.delenv("GR4HIP_ROTATOR_WALK", raising=False)
+    monkeypatch.delenv("GR4HIP_ROTATOR_LEAP", raising=False)
+    # and against the oracle's float recurrence (library defaults: these increments leap)
+    xs = O.signal_c32(3, 300_000)
+    for inc in (0.01, -0.003, 2.0 ** -12):
+        want, ph = O.rotator(xs, inc, 0.5)
+        r = G.Rotator(phase_increment=inc, initial_phase=0.5)
+        got = r.process_bulk(dev(xs)).cpu().numpy()
+        assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want)) and r.accumulated_phase == np.float32(ph)
+
