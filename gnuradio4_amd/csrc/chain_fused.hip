@@ -207,11 +207,15 @@ __device__ __forceinline__ void passA_inplace(float2* S, const float2 (&twA)[16]
 // MODE 3 (kModeWinSmall, LOG2NF = 8..12): the FFT block runs at fftSize = 2^LOG2NF < 8192 (its default is 1024).  The FIR part is unchanged --
 // 8192-sample blocks, y recovered in the time domain as in MODE 1 -- and the third transform becomes 8192 / fftSize independent windowed
 // fftSize-point transforms of the block (the compile-time 16 x 16 x R3 plan of the FFT block kernels, fft_radix.hpp, on the LDS image).
-enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2, kModeWinSmall = 3 };
+// MODE 4 / 5 (kModeFftMag2 / kModeFftWinMag2): no filter at all -- the FFT block's |X|^2 output at fftSize 8192 (gr4hip_fft_mag2) on this kernel's frame pipeline:
+// the next frame streams in by LDS-DMA while this one is transformed, which the load -> transform -> store body of fft_fast_kernel cannot do.
+enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2, kModeWinSmall = 3, kModeFftMag2 = 4, kModeFftWinMag2 = 5 };
 template <int MODE, int LOG2NF = 13>
 __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     constexpr bool WIN   = MODE == kModeWinMag2 || MODE == kModeWinSmall; // y_f is needed in the time domain and multiplied by a.win
     constexpr bool SMALL = MODE == kModeWinSmall;
+    constexpr bool FFTONLY = MODE == kModeFftMag2 || MODE == kModeFftWinMag2; // plain (windowed) transform: no taps, no history, no correction
+    constexpr bool DEFER = MODE == kModeMag2 || FFTONLY;                      // |.|^2 of the previous frame leaves during this frame's phases
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
     float2* B1 = smem + kSLen;                       // kSLen: (odd frames)
@@ -226,8 +230,10 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     const int t0   = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6), lane0 = t0 & 63;
 
-    for (int i = t0; i < 2 * kDPad; i += kT) Dre[i] = 0.f; // Dre and Dim are adjacent
-    if (t0 < 272) hl[t0] = t0 < 256 ? a.taps[t0] : 0.f;
+    if constexpr (!FFTONLY) {
+        for (int i = t0; i < 2 * kDPad; i += kT) Dre[i] = 0.f; // Dre and Dim are adjacent
+        if (t0 < 272) hl[t0] = t0 < 256 ? a.taps[t0] : 0.f;
+    }
 
     // pass A roles: column n0, parity par (even / odd rows of the column); the pair (2 n0, 2 n0 + 1) are neighbouring lanes
     // pass B roles: c = lane & 15, k = 2 wave + {0, 16, 1, 17}[lane >> 4]  (k and k + 16 share a 32-lane group: disjoint banks)
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     // ---- kernel-lifetime registers: H[t + 512 q], twiddle bases W_512^{kb}, W_512^{2 kb}, W_8192^{t}, W_8192^{2t}
     float2 Hr[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Hr[q] = a.H[t0 + 512 * q];
+    for (int q = 0; q < 16; ++q) Hr[q] = FFTONLY ? make_float2(1.f, 0.f) : a.H[t0 + 512 * q];
     float2 twBr[16], twCr[16]; // exact table values, resident for the kernel lifetime (no per-frame twiddle generation)
 #pragma unroll
     for (int r = 1; r < 16; ++r) {
@@ -253,6 +259,11 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     float2* twBl = reinterpret_cast<float2*>(P + 4 * 2 * 256);
     if constexpr (WIN) twBl[t0] = a.twB[t0]; // [16][32] = 512 entries
 
+    float wA[16]; // kModeFftWinMag2: window of the samples pass A reads, row 2 m + par of column n0 = sample (2 m + par) 256 + n0
+    if constexpr (MODE == kModeFftWinMag2) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) wA[m] = a.win[(2 * m + (t0 & 1)) * 256 + (t0 >> 1)];
+    }
     float wr[16]; // WIN: window[t + 512 q] / N
     if constexpr (WIN) {
 #pragma unroll
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     long f   = blockIdx.x;
     int  cur = 0;
     if (f < a.n_frames) {
-        dma_tail(f > 0 ? a.x + f * kN - 256 : a.hist, T0, wave, lane0);
+        if constexpr (!FFTONLY) dma_tail(f > 0 ? a.x + f * kN - 256 : a.hist, T0, wave, lane0);
         dma_frame(a.x + f * kN, B0, wave, lane0);
     }
     for (; f < a.n_frames; f += gridDim.x, cur ^= 1) {
@@ -304,10 +315,10 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         const rsrc_t rq = make_rsrc(a.out + (fprev < 0 ? 0 : fprev) * kN, fprev < 0 ? 0u : (unsigned)(kN * sizeof(float))); // first iteration: nothing pending, stores fall out of range
 #define GR4_DRAIN(g)                                                                                       \
     do {                                                                                                   \
-        if constexpr (MODE == kModeMag2) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
+        if constexpr (DEFER) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
         dma_frame<kDmaAt[g], kDmaAt[(g) + 1]>(a.x + fn * kN, Sn, wave, lane);                              \
     } while (0)
-        dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
+        if constexpr (!FFTONLY) dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
         GR4_DRAIN(0);
 
         // ------------------------------------------------------------------ pass A: 32-point DFT down the 256 columns, in place
@@ -316,10 +327,16 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             float2 v[16];
 #pragma unroll
             for (int m = 0; m < 16; ++m) v[m] = S[addrA(2 * m + par, n0)];
-            if (par && n0 > 0) { // v[15] is x_f[N - 256 + n0]:  Dz[n0] = d[n0 - 1]
-                const float2 dd = csub(Tc[n0], v[15]);
-                Dre[n0 + (n0 >> 4)] = dd.x;
-                Dim[n0 + (n0 >> 4)] = dd.y;
+            if constexpr (MODE == kModeFftWinMag2) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) v[m] = make_float2(v[m].x * wA[m], v[m].y * wA[m]);
+            }
+            if constexpr (!FFTONLY) {
+                if (par && n0 > 0) { // v[15] is x_f[N - 256 + n0]:  Dz[n0] = d[n0 - 1]
+                    const float2 dd = csub(Tc[n0], v[15]);
+                    Dre[n0 + (n0 >> 4)] = dd.x;
+                    Dim[n0 + (n0 >> 4)] = dd.y;
+                }
             }
             fft16<1>(v); // even lanes: E16[k1], odd lanes: O16[k1], at slot perm16(k1)
             GR4_DRAIN(1);
@@ -364,8 +381,8 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #pragma unroll
             for (int i = 0; i < KSW; ++i) {
                 const int off = 4 * i + (i >> 2); // padded offset of u = 4 KSW kw + 4 i within the window
-                av[i] = pa[-4 * i];
-                br[i] = pr[off];
+                av[i] = FFTONLY ? 0.f : pa[-4 * i];
+                br[i] = FFTONLY ? 0.f : pr[off];
             }
             f32x4 cr = {0.f, 0.f, 0.f, 0.f};
             // One MFMA per ~12-16 butterfly instructions, fenced so that hipcc keeps the order: the wave issues in order, the MFMA
@@ -373,9 +390,11 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             // (Left alone hipcc emits the 16 MFMAs back to back in front of the butterflies and the interval grows by their 512 cycles.)
 #define GR4_MF(i)                                                                           \
     do {                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i)], br[(i)], cr, 0, 0, 0);                     \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if constexpr (!FFTONLY) {                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i)], br[(i)], cr, 0, 0, 0);                 \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+        }                                                                                   \
     } while (0)
             // ---- X pass B: twiddles W_512^{r k}, 16-point DFT, scatter to S2[c][32 q + k]
 #pragma unroll
@@ -404,13 +423,13 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #undef GR4_MF
             // D[row = 4 kqm + r][col] = partial e[16 col + 4 kqm + r]
             // P[K quarter][re, im][256]
-            *reinterpret_cast<float4*>(P + (wave & 3) * 512 + (wave >> 2) * 256 + 16 * col + 4 * kqm) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+            if constexpr (!FFTONLY) *reinterpret_cast<float4*>(P + (wave & 3) * 512 + (wave >> 2) * 256 + 16 * col + 4 * kqm) = make_float4(cr[0], cr[1], cr[2], cr[3]);
         }
         GR4_STAMP(6);
         GR4_LDS_BARRIER(); // #3
         GR4_STAMP(7);
         GR4_DRAIN(5);
-        { // e = sum of the four partial tiles (fixed order); lane t -> component t >> 8 of e[t & 255]
+        if constexpr (!FFTONLY) { // e = sum of the four partial tiles (fixed order); lane t -> component t >> 8 of e[t & 255]
             const float* pp = P + t;
             reinterpret_cast<float*>(el)[2 * (t & 255) + (t >> 8)] = (pp[0] + pp[512]) + (pp[1024] + pp[1536]);
         }
@@ -419,13 +438,17 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         passC(S, X, twCr, t);
         GR4_DRAIN(6);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) X[perm16(q)] = cmul(Hr[q], X[perm16(q)]);
+        for (int q = 0; q < 16; ++q)
+            if constexpr (!FFTONLY) X[perm16(q)] = cmul(Hr[q], X[perm16(q)]);
         GR4_STAMP(8);
         GR4_LDS_BARRIER(); // #4: every lane has consumed S; e[] is complete
         GR4_STAMP(9);
         GR4_DRAIN(7);
 
-        if constexpr (MODE == kModeMag2) {
+        if constexpr (FFTONLY) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pend[q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y); // |X[t + 512 q]|^2, stored during the next frame
+        } else if constexpr (MODE == kModeMag2) {
             // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
     #pragma unroll
             for (int r = 0; r < 16; ++r) w[r] = el[cb + 16 * r];
@@ -533,7 +556,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(13);
         GR4_STAMP(14);
     }
-    if (MODE == kModeMag2 && fprev >= 0) {
+    if (DEFER && fprev >= 0) {
         const rsrc_t rq = make_rsrc(a.out + fprev * kN, kN * sizeof(float));
 #pragma unroll
         for (int q = 0; q < 16; ++q) buf_store_f(rq, pend[q], t0 * 4, q * 2048);
@@ -636,7 +659,8 @@ int chain_fused_reset(ChainFused* c) {
 
 // hist256 == nullptr: the chain's own carried history (updated after the launch); otherwise 256 complex samples preceding d_in, and
 // the output is the filtered stream itself (complex) instead of |FFT|^2
-static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st, bool fir_mode, bool carry_hist) {
+static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st, bool fir_mode, bool carry_hist,
+                           bool fft_only = false, const float* fft_window = nullptr) {
     ChainFdArgs a{};
     a.x        = reinterpret_cast<const float2*>(d_in);
     a.hist     = hist256 ? reinterpret_cast<const float2*>(hist256) : static_cast<const float2*>(c->d_hist.ptr);
@@ -644,7 +668,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     a.twB      = static_cast<const float2*>(c->d_twB.ptr);
     a.twC      = static_cast<const float2*>(c->d_twC.ptr);
     a.taps     = static_cast<const float*>(c->d_taps.ptr);
-    a.win      = static_cast<const float*>(c->d_win.ptr);
+    a.win      = fft_only ? fft_window : static_cast<const float*>(c->d_win.ptr);
     a.twS      = static_cast<const float2*>(c->d_twS.ptr);
     a.out      = d_out;
     a.n_frames = (long)n_frames;
@@ -657,7 +681,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     constexpr size_t lds_base = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
     constexpr size_t lds_win  = lds_base + 1024 * sizeof(float);
     static_assert(lds_win <= 160 * 1024, "LDS budget of one CU");
-    const size_t lds  = (c->windowed && !fir_mode) ? lds_win : lds_base;
+    const size_t lds  = (c->windowed && !fir_mode && !fft_only) ? lds_win : lds_base;
     static PerDevice per_device; // LDS opt-in and CU count, once per device this process uses
     bool             first = false;
     int              dev = -1, n_cu = per_device.current(&first, &dev);
@@ -667,6 +691,8 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
@@ -676,7 +702,9 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     }
     const size_t   wgs  = c->max_wg ? std::min<size_t>(c->max_wg, (size_t)n_cu) : (size_t)n_cu;
     const unsigned grid = (unsigned)std::min<size_t>(n_frames, wgs); // one resident workgroup per CU (or fewer: gr4hip_chain_set_max_workgroups)
-    if (fir_mode) hipLaunchKernelGGL(chain_fd_kernel<kModeFir>, dim3(grid), dim3(kT), lds, st, a);
+    if (fft_only && fft_window) hipLaunchKernelGGL(chain_fd_kernel<kModeFftWinMag2>, dim3(grid), dim3(kT), lds, st, a);
+    else if (fft_only) hipLaunchKernelGGL(chain_fd_kernel<kModeFftMag2>, dim3(grid), dim3(kT), lds, st, a);
+    else if (fir_mode) hipLaunchKernelGGL(chain_fd_kernel<kModeFir>, dim3(grid), dim3(kT), lds, st, a);
     else if (c->small_log2n == 8) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 8>), dim3(grid), dim3(kT), lds, st, a);
     else if (c->small_log2n == 9) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 9>), dim3(grid), dim3(kT), lds, st, a);
     else if (c->small_log2n == 10) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 10>), dim3(grid), dim3(kT), lds, st, a);
@@ -711,6 +739,12 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
         GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, tail + (rem * nf - 256) * 2, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
     }
     return GR4HIP_OK;
+}
+// |FFT_8192(window x frame)|^2 for n_frames frames, no filter: the FFT block's mag2 output on the frame pipeline of this kernel (d_window: 8192
+// floats or null for None / Rectangular)
+int chain_fused_fft_mag2(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, const float* d_window, hipStream_t st) {
+    GR4_REQUIRE(c->small_log2n == 0, "chain_fused_fft_mag2: needs an 8192-point plan");
+    return chain_fused_run(c, d_in, nullptr, n_frames, d_mag2, st, false, false, true, d_window);
 }
 int chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_y, hipStream_t st) {
     GR4_REQUIRE(d_hist256 && c->small_log2n == 0, "chain_fused_fir: needs a history and an 8192-point plan");

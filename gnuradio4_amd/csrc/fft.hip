@@ -244,6 +244,13 @@ __global__ void ranges_kernel(const float* __restrict__ s0, const float* __restr
 
 using namespace gr4;
 
+namespace gr4 { // chain_fused.hip
+struct ChainFused;
+int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
+int  chain_fused_fft_mag2(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, const float* d_window, hipStream_t st);
+void chain_fused_destroy(ChainFused* c);
+} // namespace gr4
+
 struct gr4hip_fft {
     int          in_dtype = GR4HIP_C32;
     size_t       N        = 0;
@@ -255,6 +262,8 @@ struct gr4hip_fft {
     int          kind = 0, big_n1 = 0;
     size_t       M    = 0;
     DeviceBuffer d_twM, d_chirp, d_chirpF, d_scratchA, d_scratchB;
+    gr4::ChainFused* pipe = nullptr; // N = 8192 complex, |X|^2 only: the persistent frame pipeline of chain_fused.hip (built on first use)
+    ~gr4hip_fft();
 };
 
 namespace gr4 {
@@ -520,8 +529,22 @@ int gr4hip_fft_spectrum(gr4hip_fft_t* f, const void* d_in, size_t n_frames, floa
     return fft_run(f, d_in, n_frames, o, nullptr, nullptr, stream);
 }
 
+gr4hip_fft::~gr4hip_fft() { if (pipe) gr4::chain_fused_destroy(pipe); }
+
 int gr4hip_fft_mag2(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float* d_mag2, gr4hip_stream_t stream) {
     GR4_REQUIRE(d_mag2 || n_frames == 0, "fft_mag2: null output");
+    GR4_REQUIRE(f, "fft_mag2: null handle");
+    // 8192-point complex frames, >= one frame per CU: the frame pipeline of the fused chain kernel without its filter (LDS-DMA prefetch of the next
+    // frame during the transform of this one); everything else goes to the FFT block kernels
+    if (f->N == 8192 && f->in_dtype == GR4HIP_C32 && f->kind == 0 && n_frames >= 256 && !std::getenv("GR4HIP_FFT_NO_PIPELINE")) {
+        if (!f->pipe) {
+            const float one = 1.f;
+            int rc = gr4::chain_fused_create(&f->pipe, &one, 1, 8192, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
+            if (rc) return rc;
+        }
+        const bool windowed = f->window != GR4HIP_WIN_NONE && f->window != GR4HIP_WIN_RECTANGULAR;
+        return gr4::chain_fused_fft_mag2(f->pipe, static_cast<const float*>(d_in), n_frames, d_mag2, windowed ? static_cast<const float*>(f->d_window.ptr) : nullptr, as_stream(stream));
+    }
     FftOutputs o{};
     o.mag2 = d_mag2;
     return fft_run(f, d_in, n_frames, o, nullptr, nullptr, stream);

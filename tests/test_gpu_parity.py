@@ -357,6 +357,29 @@ def test_fft_spectrum_parity(G, N):
         assert _rel(got[f], truth) <= TOL
 
 
+@pytest.mark.parametrize("window", ["None", "Hann", "Kaiser"])
+def test_fft_mag2_8192_frame_pipeline(G, window, monkeypatch):
+    """|X|^2 of >= 256 frames of 8192 complex samples runs on the fused chain kernel's frame pipeline (no filter): same numbers as the FFT block
+    kernel to float rounding, and the float64 oracle's on sampled frames"""
+    N, frames = 8192, 300
+    x = G.synth_c32(frames * N, seed=17)
+    F = G.FFT(N, window)
+    got = F.mag2(x)
+    monkeypatch.setenv("GR4HIP_FFT_NO_PIPELINE", "1")
+    ref = G.FFT(N, window).mag2(x)
+    monkeypatch.delenv("GR4HIP_FFT_NO_PIPELINE")
+    floor = ref.pow(2).mean(dim=1, keepdim=True).sqrt()
+    assert float(((got - ref).abs() / torch.maximum(ref.abs(), floor)).max()) <= TOL
+    wid = [w.lower() for w in O.WINDOWS].index(window.lower())
+    xs = x.cpu().numpy()
+    for f in (0, 1, 255, 256, 299):
+        fr = xs[f * N:(f + 1) * N].astype(np.complex128)
+        if wid > 1:
+            fr = fr * O.window(wid, N, np.float32).astype(np.float64)  # the block multiplies by its float32 window (fft.hpp:150-157)
+        truth = np.abs(O.dft64(fr)) ** 2
+        assert _rel(got[f].cpu().numpy(), truth) <= TOL, f
+
+
 @pytest.mark.parametrize("N", [3, 5, 12, 100, 1000, 1009, 3000, 4095])
 def test_fft_any_size_bluestein(G, N):
     """sizes that are not a power of two (the reference's Bluestein branch, algorithm/.../fourier/fft.hpp:353-381), <= 4096"""
