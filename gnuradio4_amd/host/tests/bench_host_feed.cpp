@@ -20,7 +20,8 @@ int main(int argc, char** argv) {
     auto& fir  = g.emplaceBlock<filter::fir_filter<std::complex<float>>>({{"b", taps}, {"compute_domain", "gpu:hip:0"s}});
     auto& spec = g.emplaceBlock<blocks::fft::PowerSpectrum<std::complex<float>>>({{"fftSize", std::int64_t(N)}, {"window", "None"s}, {"compute_domain", "gpu:hip:0"s}});
     auto& sink = g.emplaceBlock<testing::NullSink<float>>();
-    const EdgeParameters big{.minBufferSize = std::size_t(1) << 22};
+    EdgeParameters big;
+    big.minBufferSize = std::size_t(1) << 22;
     if (!g.connect<"out", "in">(src, fir, big) || !g.connect<"out", "in">(fir, spec, big) || !g.connect<"out", "in">(spec, sink, big)) return 2;
     const auto runs = hip::plan(g);
     if (runs.size() != 1) { std::fprintf(stderr, "planner: expected one run\n"); return 2; }
