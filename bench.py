@@ -194,7 +194,8 @@ def main():
                        "chain_algo": algo_names.get(chain.algo, str(chain.algo)), "parallelism": f"{world} independent channel(s), 1 per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": algo_names.get(chain.algo, str(chain.algo)),
-                         "algorithmic_bytes_per_launch": chunk * ALGO_BYTES_PER_SAMPLE, "avg_launch_ms": round(launch_ms, 4)},
+                         "algorithmic_bytes_per_launch": chunk * ALGO_BYTES_PER_SAMPLE, "avg_launch_ms": round(launch_ms, 4),
+                         "frac_of_measured_copy_rate": round(achieved / 6290.0, 4)},  # 6.29 TB/s: what a float4 copy reaches on this part (MI355X_MICROARCH.md)
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
