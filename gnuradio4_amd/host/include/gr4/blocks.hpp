@@ -56,7 +56,7 @@ struct VectorSink : Block<VectorSink<T>> {
     work::Result customWork(std::size_t requested) {
         if (!in.connected()) return {requested, 0, work::Status::ERROR};
         const std::size_t n = std::min(in.buffer->available(), requested);
-        if (n == 0) return {requested, 0, in.buffer->producer_done ? work::Status::DONE : work::Status::INSUFFICIENT_INPUT_ITEMS};
+        if (n == 0) return {requested, 0, in.buffer->done() ? work::Status::DONE : work::Status::INSUFFICIENT_INPUT_ITEMS};
         auto span = in.buffer->read_span(n);
         for (const Tag& t : in.buffer->tags)
             if (t.index < in.buffer->read_pos + n) _tags.push_back(t);
@@ -75,7 +75,7 @@ struct NullSink : Block<NullSink<T>> {
     work::Result customWork(std::size_t requested) {
         if (!in.connected()) return {requested, 0, work::Status::ERROR};
         const std::size_t n = std::min(in.buffer->available(), requested);
-        if (n == 0) return {requested, 0, in.buffer->producer_done ? work::Status::DONE : work::Status::INSUFFICIENT_INPUT_ITEMS};
+        if (n == 0) return {requested, 0, in.buffer->done() ? work::Status::DONE : work::Status::INSUFFICIENT_INPUT_ITEMS};
         in.buffer->consume(n);
         _count += n;
         return {requested, n, work::Status::OK};

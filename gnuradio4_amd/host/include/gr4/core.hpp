@@ -263,11 +263,17 @@ inline constexpr std::string_view SAMPLE_RATE = "sample_rate";
 struct EdgeBufferBase {
     virtual ~EdgeBufferBase() = default;
     bool producer_done = false; // upstream returned DONE: remaining samples are the last ones
+    // fan-out (one output port wired to several inputs): every further reader gets its own buffer, a mirror the writer's publish() copies into
+    // -- one worker thread drives every block, so a tee is a copy, not a multi-reader ring.  `upstream` is the writer's own (first) buffer.
+    const EdgeBufferBase*                        upstream = nullptr;
+    std::vector<std::shared_ptr<EdgeBufferBase>> mirror_bases;
+    [[nodiscard]] bool done() const noexcept { return producer_done || (upstream && upstream->producer_done); }
     // tag side channel: host-side for every edge type (a device ring moves samples, the few tags stay with the cursors that order them)
     std::size_t      read_pos = 0, write_pos = 0; // absolute sample counts consumed / published
     std::vector<Tag> tags;                        // ascending index, index >= read_pos
     void publishTag(const property_map& map, std::size_t offset = 0) { // at write_pos + offset, i.e. relative to the span being written (Port.hpp publishTag)
         if (map.empty()) return;
+        for (auto& m : mirror_bases) m->publishTag(map, offset); // the mirrors are written in step with this buffer
         const std::size_t idx = write_pos + offset;
         auto it = std::find_if(tags.begin(), tags.end(), [idx](const Tag& t) { return t.index >= idx; });
         if (it != tags.end() && it->index == idx) for (const auto& kv : map) it->map.insert_or_assign(kv.first, kv.second);
@@ -298,8 +304,20 @@ struct EdgeBuffer final : EdgeBufferBase {
     std::size_t         head = 0, tail = 0, capacity;
     explicit EdgeBuffer(std::size_t cap = 65536, std::pmr::memory_resource* mr = std::pmr::get_default_resource()) : data(2 * cap, mr), capacity(cap) {} // default edge size: Graph.hpp:102
     [[nodiscard]] std::pmr::memory_resource* resource() const { return data.get_allocator().resource(); }
+    std::vector<std::shared_ptr<EdgeBuffer<T>>> mirrors; // see EdgeBufferBase::upstream
+    std::shared_ptr<EdgeBuffer<T>> add_mirror(std::size_t cap, std::pmr::memory_resource* mr) {
+        auto m      = std::make_shared<EdgeBuffer<T>>(cap, mr);
+        m->upstream = this;
+        mirrors.push_back(m);
+        mirror_bases.push_back(m);
+        return m;
+    }
     [[nodiscard]] std::size_t available() const noexcept { return tail - head; }
-    [[nodiscard]] std::size_t free_space() const noexcept { return capacity - available(); }
+    [[nodiscard]] std::size_t free_space() const noexcept {
+        std::size_t f = capacity - available();
+        for (const auto& m : mirrors) f = std::min(f, m->free_space());
+        return f;
+    }
     std::span<const T>        read_span(std::size_t n) const { return {data.data() + head, n}; }
     std::span<T>              write_span(std::size_t n) {
         if (tail + n > data.size()) { // compact: move the unread part to the front (amortised O(1) per sample)
@@ -309,7 +327,15 @@ struct EdgeBuffer final : EdgeBufferBase {
         }
         return {data.data() + tail, n};
     }
-    void publish(std::size_t n) noexcept { tail += n; advanceWrite(n); }
+    void publish(std::size_t n) noexcept {
+        for (auto& m : mirrors) { // the tee: every further reader gets its copy
+            auto dst = m->write_span(n);
+            std::copy_n(data.data() + tail, n, dst.data());
+            m->publish(n);
+        }
+        tail += n;
+        advanceWrite(n);
+    }
     void consume(std::size_t n) noexcept { head += n; advanceRead(n); }
     [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
     [[nodiscard]] std::size_t available_items() const noexcept override { return available(); }
@@ -619,7 +645,7 @@ private:
             if (!p.connected()) { avail = 0; return; }
             avail         = std::min(avail, p.buffer->available());
             maxIn         = std::min(maxIn, p.max_samples);
-            upstream_done = upstream_done && p.buffer->producer_done;
+            upstream_done = upstream_done && p.buffer->done();
         });
         each_out([&](auto& p) { if (p.connected()) space = std::min(space, p.buffer->free_space()); });
         if (!any_in) return {requested, 0, work::Status::ERROR};
@@ -748,8 +774,12 @@ struct BlockWrapper final : BlockModel {
                 if (!p.buffer) {
                     if constexpr (P::kGpu) p.buffer = std::make_shared<typename P::buffer_type>(std::max<std::size_t>(min_size, 65536)); // HBM ring: its own allocator
                     else p.buffer = std::make_shared<typename P::buffer_type>(std::max<std::size_t>(min_size, 65536), mr ? mr : std::pmr::get_default_resource());
+                    e = p.buffer;
+                } else {
+                    // the port already feeds a reader: this connection is a fan-out -- a mirror buffer of its own for the new reader
+                    if constexpr (P::kGpu) e = nullptr; // (GPU-domain edges: one reader per ring in this layer)
+                    else e = p.buffer->add_mirror(std::max<std::size_t>(min_size, 65536), mr ? mr : std::pmr::get_default_resource());
                 }
-                e = p.buffer;
             }
         });
         return e;
@@ -851,7 +881,7 @@ public:
         if (!mr && !params.domain.empty())
             if (const auto dom = ComputeDomain::parse(params.domain); dom.kind != "host") mr = ComputeRegistry::instance().tryResolve(dom);
         auto edge = s->make_edge(srcPort, params.minBufferSize, mr);
-        if (!edge) return unexpected("connect: '" + std::string(srcPort) + "' is not an output port");
+        if (!edge) return unexpected("connect: '" + std::string(srcPort) + "' is not an output port (or a second reader on a GPU-domain edge)");
         if (!d->attach_input(dstPort, edge)) return unexpected("connect: '" + std::string(dstPort) + "' is not an input port of the same type");
         _edges.push_back({s, std::string(srcPort), d, std::string(dstPort), std::move(params)});
         return {};

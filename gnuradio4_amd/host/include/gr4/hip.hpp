@@ -855,7 +855,7 @@ public:
                     return {requested, published, work::Status::OK};
                 }
                 if (published) return {requested, published, work::Status::OK};
-                if (_avail() < _in_chunk && _in_edge->producer_done) {
+                if (_avail() < _in_chunk && _in_edge->done()) {
                     _out_edge->producer_done = true;
                     return {requested, 0, work::Status::DONE};
                 }
@@ -981,6 +981,8 @@ inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2) {
         // walk back to the head of the chain this block belongs to
         const auto joins = [&](BlockModel* up, BlockModel* down) {
             return up && down && eligible(*up) && eligible(*down) && up->output_edges()[0] == down->input_edges()[0] && readers(up->output_edges()[0]) == 1 &&
+                   up->output_edges()[0]->mirror_bases.empty() && // a tee'd output has readers outside the chain: its samples must reach the host edge
+
                    up->compute_domain().index == down->compute_domain().index;
         };
         BlockModel* head = b;

@@ -171,6 +171,36 @@ int main(int argc, char** argv) {
         try { IIRChain bad; bad.applySettings({{"middleBlock.value", 1.0}}); } catch (const std::invalid_argument&) { threw = true; }
         EXPECT(threw);
     }
+    // ---- fan-out: one output port wired to two inputs (Graph.hpp:595-690 allows any number of readers per output); samples and tags reach both
+    {
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(200000)}});
+        src.values = {1.f, 2.f, 3.f};
+        src._tags  = {{70000, {{"gr:trigger_name", "t0"s}}}};
+        auto& dbl  = g.emplaceBlock<blocks::math::MultiplyConst<float>>({{"value", 2.0}});
+        auto& inc  = g.emplaceBlock<blocks::math::AddConst<float>>({{"value", 1.0}});
+        auto& dec  = g.emplaceBlock<filter::Decimator<float>>({{"decim", std::int64_t(4)}});
+        auto& s1 = g.emplaceBlock<testing::VectorSink<float>>();
+        auto& s2 = g.emplaceBlock<testing::VectorSink<float>>();
+        auto& s3 = g.emplaceBlock<testing::VectorSink<float>>();
+        EXPECT((g.connect<"out", "in">(src, dbl)).has_value());
+        EXPECT((g.connect<"out", "in">(dbl, s1)).has_value());  // first reader of dbl.out
+        EXPECT((g.connect<"out", "in">(dbl, inc)).has_value()); // second reader: a mirror buffer
+        EXPECT((g.connect<"out", "in">(dbl, dec)).has_value()); // third reader, at another rate
+        EXPECT((g.connect<"out", "in">(inc, s2)).has_value());
+        EXPECT((g.connect<"out", "in">(dec, s3)).has_value());
+        EXPECT(dbl.out.buffer->mirrors.size() == 2u && s1.in.buffer == dbl.out.buffer && inc.in.buffer == dbl.out.buffer->mirrors[0]);
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        bool ok = s1._samples.size() == 200000u && s2._samples.size() == 200000u && s3._samples.size() == 50000u;
+        for (std::size_t i = 0; ok && i < 200000; ++i) ok = s1._samples[i] == 2.f * src.values[i % 3] && s2._samples[i] == 2.f * src.values[i % 3] + 1.f;
+        for (std::size_t i = 0; ok && i < 50000; ++i) ok = s3._samples[i] == 2.f * src.values[(4 * i) % 3];
+        EXPECT(ok);
+        EXPECT(s1._tags.size() == 1u && s2._tags.size() == 1u && s3._tags.size() == 1u);
+        if (s1._tags.size() == 1 && s2._tags.size() == 1 && s3._tags.size() == 1)
+            EXPECT(s1._tags[0].index == 70000u && s2._tags[0].index == 70000u && s3._tags[0].index == 17500u && s2._tags[0].map == s1._tags[0].map);
+    }
     // ---- FIR box-car step response settles in 10 samples; IIR forms agree (qa_filter.cpp:53-128)
     {
         filter::fir_filter<double> fir;

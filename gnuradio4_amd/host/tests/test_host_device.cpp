@@ -165,6 +165,29 @@ int main(int argc, char** argv) {
         hip::release(mul2);
     }
 
+    { // 3b'. a tee'd device edge: fir.out feeds the spectrum block AND a host sink -> the planner must not fuse across it (the filtered samples have to
+      //      reach the host edge); both readers see every sample
+        Graph g;
+        auto& src  = g.emplaceBlock<testing::VectorSource<std::complex<float>>>();
+        src.values = x;
+        auto& fir  = g.emplaceBlock<filter::fir_filter<std::complex<float>>>({{"b", tapsd}, {"compute_domain", "gpu:hip:0"s}});
+        auto& spec = g.emplaceBlock<blocks::fft::PowerSpectrum<std::complex<float>>>({{"fftSize", std::int64_t(N)}, {"window", "Hann"s}, {"compute_domain", "gpu:hip:0"s}});
+        auto& s1   = g.emplaceBlock<testing::VectorSink<float>>();
+        auto& s2   = g.emplaceBlock<testing::VectorSink<std::complex<float>>>();
+        g.connect<"out", "in">(src, fir);
+        g.connect<"out", "in">(fir, spec);
+        g.connect<"out", "in">(fir, s2); // second reader of fir.out
+        g.connect<"out", "in">(spec, s1);
+        const auto runs = hip::plan(g);
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        if (const auto r = sched.runAndWait(); !r) { std::cerr << "tee graph: " << r.error().message << "\n"; ++errors; }
+        std::printf("tee'd device edge: %zu fused runs, %zu spectra samples, %zu filtered samples\n", runs.size(), s1._samples.size(), s2._samples.size());
+        if (!runs.empty() || s1._samples.size() != (x.size() / N) * N || s2._samples.size() != x.size()) ++errors;
+        dump(out + "_tee_fir.bin", s2._samples);
+        hip::release(fir);
+        hip::release(spec);
+    }
     { // 3c. GPU-domain ports: src -> H2D -> fir (GPU ports) -> PowerSpectrum (GPU ports) -> D2H -> sink.  The edges between the converters are
       //     rings in HBM; the edge INTO H2D is allocated from the "hip" provider (pinned pages), so the converter copies without staging
         hip::register_provider();

@@ -115,6 +115,10 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     xin = np.resize(np.array([1.0, -2.0, 3.0, 0.5, 0.25], np.float64), 200000) * 2.0
     want = (np.convolve(xin, [0.5, 0.25, 0.25])[:200000] + 1.0) * 3.0
     assert len(pf) == 200000 and np.max(np.abs(pf - want)) <= 1e-5
+    # a tee behind a device block: nothing fused across it, both readers complete, the filtered stream equals the oracle's
+    assert "tee'd device edge: 0 fused runs" in r.stdout
+    tee = np.fromfile(tmp_path / "o_tee_fir.bin", np.complex64)
+    assert len(tee) == len(x) and rel(tee, truth) <= 1e-5
     # GPU-domain ports with explicit converter blocks: the same spectra as the fused device run, the input edge pinned by the "hip" provider
     assert "port domains: CPU -> GPU refused, converter required" in r.stdout
     assert "input edge pinned by the hip provider" in r.stdout and "(0 staged)" in r.stdout
