@@ -12,6 +12,7 @@
 #include <array>
 #include <atomic>
 #include <cctype>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -367,11 +368,103 @@ struct Kernel<gr::FeedbackMerge<gr::Adder<float>, FO, gr::blocks::math::Multiply
         return st;
     }
     static std::unique_ptr<Stage> make_stage(M& m) { return make_pole(1.f, m.feedback.value); }
+    static float                  pole(M& m) { return m.feedback.value; }
     static work::Status           work(M& m, std::size_t nIn, std::size_t nOut) { return offload_work(m, nIn, nOut, make_stage); }
+};
+// SplitMergeCombine on the device: every path is a stage fed from the same device span, the signed outputs are folded with the math kernels
+struct SplitStage final : Stage {
+    std::vector<std::unique_ptr<Stage>> paths;
+    std::vector<double>                 signs;
+    std::vector<std::unique_ptr<DevBuf>> tmp;
+    std::string                         _kind = "split(";
+    SplitStage(std::vector<std::unique_ptr<Stage>> p, std::vector<double> s) : paths(std::move(p)), signs(std::move(s)) {
+        for (std::size_t i = 0; i < paths.size(); ++i) {
+            if (paths[i]->in_chunk != 1 || paths[i]->out_chunk != 1 || paths[i]->in_bytes != 4 || paths[i]->out_bytes != 4) throw std::invalid_argument("SplitMergeCombine on the device: float paths at one rate");
+            tmp.push_back(std::make_unique<DevBuf>());
+            _kind += std::string(i ? " | " : "") + std::string(paths[i]->kind());
+        }
+        _kind += ")";
+    }
+    std::string_view kind() const override { return _kind; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        *n_out = n;
+        for (std::size_t i = 0; i < paths.size(); ++i) {
+            void*       dst = i == 0 ? out : tmp[i]->ensure(n * 4);
+            std::size_t m   = 0;
+            if (const int rc = paths[i]->enqueue(in, n, dst, &m, s)) return rc;
+            if (m != n) return GR4HIP_ERROR;
+            const float sg = static_cast<float>(signs[i]);
+            if (i == 0) {
+                if (sg != 1.f) { if (const int rc = gr4hip_math_const(GR4HIP_MUL, GR4HIP_F32, out, out, n, &sg, s)) return rc; }
+            } else {
+                const float mag = std::fabs(sg);
+                if (mag != 1.f) { if (const int rc = gr4hip_math_const(GR4HIP_MUL, GR4HIP_F32, dst, dst, n, &mag, s)) return rc; }
+                const void* ins[2] = {out, dst};
+                if (const int rc = gr4hip_math_nary(sg < 0 ? GR4HIP_SUB : GR4HIP_ADD, GR4HIP_F32, ins, 2, out, n, s)) return rc;
+            }
+        }
+        return GR4HIP_OK;
+    }
+};
+template <typename SignsT, typename... Paths>
+requires(std::is_same_v<gr::detail::in_type_t<std::tuple_element_t<0, std::tuple<Paths...>>>, float> && (requires(Paths& p) { Kernel<Paths>::make_stage(p); } && ...))
+struct Kernel<gr::SplitMergeCombineImpl<SignsT, Paths...>> {
+    using M = gr::SplitMergeCombineImpl<SignsT, Paths...>;
+    static std::unique_ptr<Stage> make_stage(M& m) {
+        std::vector<std::unique_ptr<Stage>> st;
+        std::vector<double>                 sg;
+        [&]<std::size_t... I>(std::index_sequence<I...>) {
+            (st.push_back(Kernel<Paths>::make_stage(m.template path<I>())), ...);
+            (sg.push_back(M::sign(I)), ...);
+        }(std::index_sequence_for<Paths...>{});
+        return std::make_unique<SplitStage>(std::move(st), std::move(sg));
+    }
+    static work::Status work(M& m, std::size_t nIn, std::size_t nOut) { return offload_work(m, nIn, nOut, make_stage); }
+};
+// the gain of a feedback path when the path is nothing but gains: a MultiplyConst, or a SplitMergeCombine of such paths (sum of the signed gains)
+namespace detail {
+inline bool loop_gain(gr::blocks::math::MultiplyConst<float>& b, float* g) { *g = b.value; return true; }
+template <typename SignsT, typename... Paths>
+bool loop_gain(gr::SplitMergeCombineImpl<SignsT, Paths...>& b, float* g);
+template <std::size_t I, typename SM>
+bool loop_gain_path(SM& b, float* sum) { // one path at a time (a fold over a lambda with `if constexpr (requires ...)` inside trips g++ 11)
+    if constexpr (I == std::tuple_size_v<decltype(b._paths)>) {
+        return true;
+    } else {
+        float gi = 0.f;
+        if constexpr (requires { loop_gain(b.template path<I>(), &gi); }) {
+            if (!loop_gain(b.template path<I>(), &gi)) return false;
+            *sum += static_cast<float>(SM::sign(I)) * gi;
+            return loop_gain_path<I + 1>(b, sum);
+        } else {
+            return false;
+        }
+    }
+}
+template <typename SignsT, typename... Paths>
+bool loop_gain(gr::SplitMergeCombineImpl<SignsT, Paths...>& b, float* g) {
+    *g = 0.f;
+    return loop_gain_path<0>(b, g);
+}
+} // namespace detail
+template <fixed_string FO, typename SignsT, typename... Paths, fixed_string BO, fixed_string FI>
+requires requires(gr::SplitMergeCombineImpl<SignsT, Paths...>& b, float* g) { detail::loop_gain(b, g); }
+struct Kernel<gr::FeedbackMerge<gr::Adder<float>, FO, gr::SplitMergeCombineImpl<SignsT, Paths...>, BO, FI>> {
+    using M = gr::FeedbackMerge<gr::Adder<float>, FO, gr::SplitMergeCombineImpl<SignsT, Paths...>, BO, FI>;
+    static std::unique_ptr<Stage> make_pole(float gain, float c) { return std::make_unique<IirStage>(GR4HIP_DF_I, 1, std::vector<float>{gain}, 1, std::vector<float>{1.f, -c}, 2); }
+    static std::unique_ptr<Stage> make_stage(M& m) {
+        float c = 0.f;
+        if (!detail::loop_gain(m.feedback, &c)) throw std::invalid_argument("FeedbackMerge on the device: the feedback path must reduce to a constant gain");
+        return make_pole(1.f, c);
+    }
+    static float        pole(M& m) { float c = 0.f; detail::loop_gain(m.feedback, &c); return c; }
+    static work::Status work(M& m, std::size_t nIn, std::size_t nOut) { return offload_work(m, nIn, nOut, make_stage); }
 };
 namespace detail {
 template <typename T>
 struct is_pole_feedback : std::false_type {};
+template <fixed_string FO, typename SignsT, typename... Paths, fixed_string BO, fixed_string FI>
+struct is_pole_feedback<gr::FeedbackMerge<gr::Adder<float>, FO, gr::SplitMergeCombineImpl<SignsT, Paths...>, BO, FI>> : std::true_type {};
 template <fixed_string FO, fixed_string BO, fixed_string FI>
 struct is_pole_feedback<gr::FeedbackMerge<gr::Adder<float>, FO, gr::blocks::math::MultiplyConst<float>, BO, FI>> : std::true_type {};
 } // namespace detail
@@ -379,7 +472,7 @@ template <typename A, fixed_string OutA, typename B, fixed_string InB>
 requires requires(A& a, B& b) { Kernel<A>::make_stage(a); Kernel<B>::make_stage(b); }
 std::unique_ptr<Stage> Kernel<gr::Merge<A, OutA, B, InB>>::make_stage(M& m) {
     // peephole: input gain -> pole feedback is still ONE first-order section (bm_MergeApi.cpp:59-60: y[n] = a x[n] + (1 - a) y[n-1])
-    if constexpr (std::is_same_v<A, gr::blocks::math::MultiplyConst<float>> && detail::is_pole_feedback<B>::value) return Kernel<B>::make_pole(m.leftBlock.value, m.rightBlock.feedback.value);
+    if constexpr (std::is_same_v<A, gr::blocks::math::MultiplyConst<float>> && detail::is_pole_feedback<B>::value) return Kernel<B>::make_pole(m.leftBlock.value, Kernel<B>::pole(m.rightBlock));
     else return std::make_unique<SeqStage>(Kernel<A>::make_stage(m.leftBlock), Kernel<B>::make_stage(m.rightBlock));
 }
 

@@ -93,4 +93,62 @@ struct FeedbackMerge : Block<FeedbackMerge<Forward, ForwardOut, Feedback, Feedba
     }
 };
 
+// SplitMergeCombine<[OutputSigns<s0, s1, ...>,] Path0, Path1, ...>: the input goes to every path, the (signed) path outputs are summed
+// (BlockMerging.hpp:337-520).  Paths are 1-in / 1-out blocks of one sample type; sub-block settings by "path<I>.<setting>"; block.path<I>().
+template <auto... Signs>
+struct OutputSigns {
+    static constexpr std::size_t size = sizeof...(Signs);
+    static constexpr std::array<double, sizeof...(Signs)> values{static_cast<double>(Signs)...};
+};
+namespace detail {
+template <typename T>
+struct is_output_signs : std::false_type {};
+template <auto... S>
+struct is_output_signs<OutputSigns<S...>> : std::true_type {};
+} // namespace detail
+
+template <typename SignsT, typename... Paths>
+struct SplitMergeCombineImpl : Block<SplitMergeCombineImpl<SignsT, Paths...>> {
+    static_assert(sizeof...(Paths) >= 2, "SplitMergeCombine needs at least two paths");
+    using First = std::tuple_element_t<0, std::tuple<Paths...>>;
+    using T     = detail::in_type_t<First>;
+    static_assert((std::is_same_v<detail::in_type_t<Paths>, T> && ...) && (std::is_same_v<detail::out_type_t<Paths>, T> && ...), "SplitMergeCombine: one sample type on every path");
+    static_assert(SignsT::size == 0 || SignsT::size == sizeof...(Paths), "OutputSigns: one sign per path");
+    PortIn<T>  in;
+    PortOut<T> out;
+    GR_MAKE_REFLECTABLE(SplitMergeCombineImpl, in, out);
+    std::tuple<Paths...> _paths{};
+
+    template <std::size_t I> auto&       path() { return std::get<I>(_paths); }
+    template <std::size_t I> const auto& path() const { return std::get<I>(_paths); }
+    static constexpr double sign(std::size_t i) { return SignsT::size == 0 ? 1.0 : SignsT::values[i]; }
+
+    void applySettings(const property_map& settings) {
+        std::array<property_map, sizeof...(Paths)> per{};
+        property_map                               own;
+        for (const auto& [key, value] : settings) {
+            const auto dot = key.find('.');
+            if (dot == std::string::npos) { own.emplace(key, value); continue; }
+            const std::string prefix = key.substr(0, dot);
+            std::size_t       idx    = sizeof...(Paths);
+            if (prefix.rfind("path", 0) == 0 && prefix.size() > 4) idx = static_cast<std::size_t>(std::stoul(prefix.substr(4)));
+            if (idx >= sizeof...(Paths)) throw std::invalid_argument("unknown sub-block '" + prefix + "' in setting '" + key + "'");
+            per[idx].emplace(key.substr(dot + 1), value);
+        }
+        [&]<std::size_t... I>(std::index_sequence<I...>) { ((per[I].empty() ? void() : std::get<I>(_paths).applySettings(per[I])), ...); }(std::index_sequence_for<Paths...>{});
+        Block<SplitMergeCombineImpl>::applySettings(own);
+    }
+    [[nodiscard]] T processOne(T x) {
+        return [&]<std::size_t... I>(std::index_sequence<I...>) { return ((static_cast<T>(sign(I)) * std::get<I>(_paths).processOne(x)) + ...); }(std::index_sequence_for<Paths...>{});
+    }
+};
+namespace detail {
+template <typename A, typename... Rest>
+struct split_merge_select { using type = SplitMergeCombineImpl<OutputSigns<>, A, Rest...>; };
+template <auto... S, typename... Rest>
+struct split_merge_select<OutputSigns<S...>, Rest...> { using type = SplitMergeCombineImpl<OutputSigns<S...>, Rest...>; };
+} // namespace detail
+template <typename A, typename... Rest>
+using SplitMergeCombine = typename detail::split_merge_select<A, Rest...>::type;
+
 } // namespace gr

@@ -170,6 +170,29 @@ int main(int argc, char** argv) {
         bool threw = false;
         try { IIRChain bad; bad.applySettings({{"middleBlock.value", 1.0}}); } catch (const std::invalid_argument&) { threw = true; }
         EXPECT(threw);
+        // SplitMergeCombine: fan-out to N paths, signed sum (USER_API_Connecting_Blocks.md "SplitMergeCombine"; bm_MergeApi.cpp:62-67)
+        using FanOut = gr::SplitMergeCombine<MultiplyConst<float>, MultiplyConst<float>>;
+        FanOut fan;
+        fan.applySettings({{"path0.value", 2.0}, {"path1.value", 3.0}});
+        EXPECT(fan.processOne(1.5f) == 7.5f && fan.path<1>().value == 3.f);
+        using Diff = gr::SplitMergeCombine<gr::OutputSigns<+1.0f, -1.0f>, MultiplyConst<float>, MultiplyConst<float>>;
+        Diff diff;
+        diff.applySettings({{"path0.value", 2.0}, {"path1.value", 3.0}});
+        EXPECT(diff.processOne(2.f) == -2.f);
+        threw = false;
+        try { diff.applySettings({{"path2.value", 1.0}}); } catch (const std::invalid_argument&) { threw = true; }
+        EXPECT(threw);
+        // the IIR low-pass with its feedback gain decomposed: feedback = y + (-a) y = (1 - a) y
+        using IIRChainSplitMerge = gr::Merge<MultiplyConst<float>, "out", gr::FeedbackMerge<Adder<>, "out", gr::SplitMergeCombine<MultiplyConst<float>, MultiplyConst<float>>, "out", "in2">, "in1">;
+        IIRChainSplitMerge sm;
+        sm.applySettings({{"leftBlock.value", double(kAlpha)}, {"rightBlock.feedback.path0.value", 1.0}, {"rightBlock.feedback.path1.value", double(-kAlpha)}});
+        float st2 = 0.f, w2 = 0.f;
+        for (int i = 0; i < 2000; ++i) {
+            const float xin = src.values[static_cast<std::size_t>(i) % src.values.size()];
+            st2 = kAlpha * xin + (1.0f - kAlpha) * st2;
+            w2  = std::max(w2, std::abs(sm.processOne(xin) - st2));
+        }
+        EXPECT(w2 <= 1e-6f);
     }
     // ---- fan-out: one output port wired to two inputs (Graph.hpp:595-690 allows any number of readers per output); samples and tags reach both
     {

@@ -388,6 +388,23 @@ int main(int argc, char** argv) {
         const auto st = hip::Kernel<IIRChain>::make_stage(probe);
         std::printf("merge IIR low-pass (FeedbackMerge) on the device: stage '%s', max rel err %.3g%s\n", std::string(st->kind()).c_str(), e1, e1 <= 1e-5 ? "" : "  FAILED");
         if (!(e1 <= 1e-5) || st->kind() != "iir_f32") ++errors;
+        // the same low-pass with the feedback gain decomposed into a SplitMergeCombine of two gains (bm_MergeApi.cpp:62-64): still one first-order section
+        using IIRChainSplitMerge = gr::Merge<MultiplyConst<float>, "out", gr::FeedbackMerge<Adder<>, "out", gr::SplitMergeCombine<MultiplyConst<float>, MultiplyConst<float>>, "out", "in2">, "in1">;
+        const property_map cfg_sm{{"leftBlock.value", double(0.3f)}, {"rightBlock.feedback.path0.value", 1.0}, {"rightBlock.feedback.path1.value", double(-0.3f)}};
+        const double e_sm = max_rel(run_one<IIRChainSplitMerge, float, float>(cfg_sm, xs, true, errors), h);
+        IIRChainSplitMerge probe_sm;
+        probe_sm.applySettings(cfg_sm);
+        std::printf("merge IIR low-pass (SplitMergeCombine feedback) on the device: stage '%s', max rel err %.3g%s\n", std::string(hip::Kernel<IIRChainSplitMerge>::make_stage(probe_sm)->kind()).c_str(), e_sm,
+                    e_sm <= 1e-5 ? "" : "  FAILED");
+        if (!(e_sm <= 1e-5) || hip::Kernel<IIRChainSplitMerge>::make_stage(probe_sm)->kind() != "iir_f32") ++errors;
+        // a general SplitMergeCombine: x -> fir(x) - 0.25 x, every path a device stage, the signed sum on the math kernels
+        using Split = gr::SplitMergeCombine<gr::OutputSigns<+1.0f, -1.0f>, filter::fir_filter<float>, MultiplyConst<float>>;
+        const property_map cfg_sp{{"path0.b", std::vector<double>{0.5, 0.25, 0.25}}, {"path1.value", 0.25}};
+        const double e_sp = max_rel(run_one<Split, float, float>(cfg_sp, xs, true, errors), run_one<Split, float, float>(cfg_sp, xs, false, errors));
+        Split probe_sp;
+        probe_sp.applySettings(cfg_sp);
+        std::printf("SplitMergeCombine on the device: stage '%s', max rel err %.3g%s\n", std::string(hip::Kernel<Split>::make_stage(probe_sp)->kind()).c_str(), e_sp, e_sp <= 1e-5 ? "" : "  FAILED");
+        if (!(e_sp <= 1e-5)) ++errors;
         using Two = gr::Merge<MultiplyConst<float>, "out", filter::fir_filter<float>, "in">;
         const property_map cfg2{{"leftBlock.value", 2.0}, {"rightBlock.b", std::vector<double>{0.5, 0.25, 0.25}}};
         const double e2 = max_rel(run_one<Two, float, float>(cfg2, xs, true, errors), run_one<Two, float, float>(cfg2, xs, false, errors));

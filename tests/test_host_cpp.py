@@ -128,6 +128,8 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     # merge API: the reference benchmark's FeedbackMerge IIR collapses into one first-order section of the scan kernel
     assert "merge IIR low-pass (FeedbackMerge) on the device: stage 'iir_f32'" in r.stdout
     assert "merge MultiplyConst -> fir_filter on the device: stage 'math_const + fir_f32'" in r.stdout
+    assert "merge IIR low-pass (SplitMergeCombine feedback) on the device: stage 'iir_f32'" in r.stdout
+    assert "SplitMergeCombine on the device: stage 'split(fir_f32 | math_const)'" in r.stdout
     assert "pipelined run:" in r.stdout and "pipelined run: 0 of" not in r.stdout  # copies and kernels of neighbouring chunks overlap
     # tags through a fused device run
     assert "tags through the device run: 2 forwarded, 1 stage rebuilt" in r.stdout
