@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../../build/host
 mkdir -p $OUT
-HDRS="include/gr4/core.hpp include/gr4/blocks.hpp include/gr4/merge.hpp include/gr4/hip.hpp include/gr4/plugin.hpp ../../include/gr4hip.h"
+HDRS="include/gr4/core.hpp include/gr4/blocks.hpp include/gr4/merge.hpp include/gr4/hip.hpp include/gr4/plugin.hpp include/gr4/grc.hpp ../../include/gr4hip.h"
 CXX="g++ -std=c++20 -Wall -Wextra -Iinclude"
 LINK="-L.. -lgr4hip -Wl,-rpath,\$ORIGIN/../../gnuradio4_amd -Wl,-rpath,/opt/rocm/lib"
 stale() { # target sources...

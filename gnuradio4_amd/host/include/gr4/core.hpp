@@ -499,6 +499,9 @@ struct BlockModel {
     virtual void*                      raw()                            = 0;
     virtual std::type_index            port_type(std::string_view port) = 0; // typeid(void) if unknown
     virtual std::string_view           port_domain(std::string_view) { return "CPU"; }
+    // the index-th reflected input / output port member ("" when there is none) and whether a port member is a vector of ports (GRC wires by index)
+    virtual std::string                port_name(bool /*output*/, std::size_t /*index*/) { return {}; }
+    virtual bool                       port_is_vector(std::string_view) { return false; }
     virtual std::shared_ptr<EdgeBufferBase> make_edge(std::string_view out_port, std::size_t min_size, std::pmr::memory_resource* mr = nullptr) = 0;
     virtual bool                            attach_input(std::string_view in_port, std::shared_ptr<EdgeBufferBase> edge) = 0;
     virtual std::vector<std::shared_ptr<EdgeBufferBase>> input_edges()                                                   = 0;
@@ -760,6 +763,27 @@ struct BlockWrapper final : BlockModel {
         std::type_index t = typeid(void);
         with_port(port, [&](auto& p) { t = typeid(typename std::decay_t<decltype(p)>::value_type); });
         return t;
+    }
+    std::string port_name(bool output, std::size_t index) override {
+        std::string found;
+        std::size_t k = 0;
+        detail::for_each_member(block, [&](std::string_view mname, auto& m) {
+            using M = std::decay_t<decltype(m)>;
+            if constexpr (detail::is_port<M>::value || detail::is_port_vector<M>::value) {
+                if (detail::is_input_v<M> != output) {
+                    if (k == index) found = std::string(mname);
+                    ++k;
+                }
+            }
+        });
+        return found;
+    }
+    bool port_is_vector(std::string_view port) override {
+        bool v = false;
+        detail::for_each_member(block, [&](std::string_view mname, auto& m) {
+            if (mname == port) v = detail::is_port_vector<std::decay_t<decltype(m)>>::value;
+        });
+        return v;
     }
     std::string_view port_domain(std::string_view port) override {
         std::string_view d = "CPU";

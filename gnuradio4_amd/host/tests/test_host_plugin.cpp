@@ -6,6 +6,7 @@
 #include <iostream>
 
 #include <gr4/blocks.hpp>
+#include <gr4/grc.hpp>
 #include <gr4/plugin.hpp>
 
 using namespace gr;
@@ -78,6 +79,73 @@ int main(int argc, char** argv) {
     }
     EXPECT(iok && fok);
     EXPECT(ft.size() == 1u && ft[0].index == 0u && (ft[0].map == property_map{{"gr:sample_rate", 12000.f}})); // through fir (1:1) and Decimator (/4)
+    { // a graph description in the GRC / YAML format (shape of core/test/qa_grc.cpp:132-152): ids from the plugin's registry, compute_domain per block,
+      // connections by port index, [index, sub-index] and name
+        const std::string yaml = R"(
+blocks:
+  - id: gr::testing::VectorSource<float32>
+    parameters:
+      name: ramp                      # comments and blank lines are fine
+
+      values: [1, -2, 3, 0.5, 0.25]
+      n_samples_max: 40000
+  - id: gr::testing::VectorSource<float32>
+    parameters:
+      name: ones
+      values: [1.0]
+      n_samples_max: !!uint32 40000
+  - id: gr::blocks::math::Add<float32>
+    parameters:
+      name: sum
+      n_inputs: 2
+      compute_domain: "DOMAIN"
+  - id: gr::filter::fir_filter<float32>
+    parameters:
+      name: 'smooth'
+      b: [0.5, 0.25, 0.25]
+      compute_domain: "DOMAIN"
+  - id: gr::filter::Decimator<float32>
+    parameters: 
+      name: every4th
+      decim: 4
+      compute_domain: "DOMAIN"
+  - id: gr::testing::VectorSink<float32>
+    parameters:
+      name: sink
+connections:
+  - [ramp, 0, sum, [0, 0]]
+  - [ones, [0, 0], sum, [0, 1]]
+  - [sum, out, smooth, in]
+  - [smooth, 0, every4th, 0]
+  - [every4th, 0, 'sink', 0]
+)";
+        std::string text = yaml;
+        for (std::size_t at; (at = text.find("DOMAIN")) != std::string::npos;) text.replace(at, 6, domain);
+        Graph gg;
+        auto  loaded = loadGrc(loader, gg, text);
+        if (!loaded) std::printf("grc: %s\n", loaded.error().message.c_str());
+        EXPECT(loaded.has_value() && loaded.value().size() == 6u);
+        if (loaded) {
+            auto sched2 = loader.instantiateScheduler("gr::scheduler::Simple");
+            sched2->exchange(std::move(gg));
+            if (const auto r = sched2->runAndWait(); !r) { std::fprintf(stderr, "grc graph: %s\n", r.error().message.c_str()); return 3; }
+            const auto& y = static_cast<testing::VectorSink<float>*>(loaded.value()[5].model->raw())->_samples;
+            const float pat2[] = {1.f, -2.f, 3.f, 0.5f, 0.25f};
+            bool        ok     = y.size() == 10000u;
+            for (std::size_t m = 0; ok && m < y.size(); ++m) {
+                const std::size_t n = 4 * m;
+                const auto        u = [&](std::size_t i) { return double(pat2[i % 5]) + 1.0; };
+                ok = std::abs(y[m] - (0.5 * u(n) + (n >= 1 ? 0.25 * u(n - 1) : 0.0) + (n >= 2 ? 0.25 * u(n - 2) : 0.0))) <= 1e-5;
+            }
+            EXPECT(ok);
+            EXPECT(loaded.value()[3].model->compute_domain().is_device() == (domain != "host"));
+        }
+        Graph bad;
+        EXPECT(!loadGrc(loader, bad, "blocks:\n  - id: gr::nope<float32>\n").has_value());
+        Graph bad2;
+        const auto e2 = loadGrc(loader, bad2, "blocks:\n  - id: gr::testing::NullSink<float32>\n    parameters:\n      name: a\nconnections:\n  - [a, 0, b, 0]\n");
+        EXPECT(!e2.has_value() && e2.error().message.find("unknown block") != std::string::npos);
+    }
     if (failures) std::printf("host-plugin: %d FAILURES\n", failures);
     else std::printf("host-plugin: all checks passed (compute_domain %s)\n", domain.c_str());
     return failures ? 1 : 0;
