@@ -296,6 +296,11 @@ struct EdgeBufferBase {
     [[nodiscard]] virtual std::size_t available_items() const noexcept      = 0;
     [[nodiscard]] virtual std::size_t free_items() const noexcept           = 0;
     virtual void                      read_items(void* dst, std::size_t n)  = 0; // copy + consume
+    // zero-copy variant for consumers that can read the storage in place (a DMA engine, when memory() is page-locked): pointer to the next n
+    // items (valid until consume_items), nullptr when the edge cannot offer that
+    [[nodiscard]] virtual const void*                peek_items(std::size_t /*n*/) { return nullptr; }
+    virtual void                                     consume_items(std::size_t /*n*/) {}
+    [[nodiscard]] virtual std::pmr::memory_resource* memory() const { return nullptr; }
     virtual void                      write_items(const void* src, std::size_t n) = 0; // copy + publish
 };
 template <typename T>
@@ -345,6 +350,9 @@ struct EdgeBuffer final : EdgeBufferBase {
         else throw std::logic_error("type-erased element IO needs a trivially copyable sample type");
         consume(n);
     }
+    [[nodiscard]] const void*                peek_items(std::size_t n) override { return n <= available() ? read_span(n).data() : nullptr; }
+    void                                     consume_items(std::size_t n) override { consume(n); }
+    [[nodiscard]] std::pmr::memory_resource* memory() const override { return resource(); }
     void write_items(const void* src, std::size_t n) override {
         if constexpr (std::is_trivially_copyable_v<T>) std::memcpy(write_span(n).data(), src, n * sizeof(T));
         else throw std::logic_error("type-erased element IO needs a trivially copyable sample type");

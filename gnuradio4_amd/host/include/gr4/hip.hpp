@@ -824,6 +824,7 @@ class DeviceRun final : public BlockModel {
         property_map   fwd; // tags to publish at the first output sample of this chunk
     };
     std::array<Slot, kDepth> _slots;
+    std::size_t     _inplace_chunks = 0; // chunks copied straight out of a page-locked input edge
     std::size_t     _q_head = 0, _q_count = 0, _pending_out = 0, _overlapped = 0; // FIFO of busy slots; output items not yet published; chunks queued while another was in flight
     DevBuf          _d_a, _d_b;
     std::string     _name = "device_run";
@@ -871,6 +872,7 @@ public:
             if (st) gr4hip_stream_destroy(st);
     }
     [[nodiscard]] std::size_t overlapped_chunks() const { return _overlapped; }
+    [[nodiscard]] std::size_t inplace_chunks() const { return _inplace_chunks; }
     // rate bookkeeping (Resampling<>, Block.hpp:1576-1636, across the whole run): walking back from the last stage, `need` is the count a
     // stage's output must be a multiple of; it produces out_chunk per in_chunk
     void recompute_rates() {
@@ -957,10 +959,19 @@ public:
             Slot& sl = _slots[(_q_head + _q_count) % kDepth];
             if (_q_count) ++_overlapped;
             // samples land in HBM: pinned staging -> hipMemcpyAsync -> the double-mapped ring (a wrapping span stays contiguous)
-            _read(sl.h_in.ensure(n * _in_bytes), n);
-            char* d_in = static_cast<char*>(_ring_base) + _ring_wr;
-            check(gr4hip_memcpy_h2d(d_in, sl.h_in.p, n * _in_bytes, _s_in), "h2d");
-            check(gr4hip_event_record(sl.in_done, _s_in), "event record");
+            char*       d_in    = static_cast<char*>(_ring_base) + _ring_wr;
+            const void* inplace = _in_edge->memory() == pinned_resource() ? _in_edge->peek_items(n) : nullptr;
+            if (inplace) { // the edge's storage is page-locked ("hip" provider): the copy engine reads it in place; the span is released once the copy has landed
+                check(gr4hip_memcpy_h2d(d_in, inplace, n * _in_bytes, _s_in), "h2d");
+                check(gr4hip_event_record(sl.in_done, _s_in), "event record");
+                check(gr4hip_event_synchronize(sl.in_done), "event sync");
+                _in_edge->consume_items(n);
+                ++_inplace_chunks;
+            } else {
+                _read(sl.h_in.ensure(n * _in_bytes), n);
+                check(gr4hip_memcpy_h2d(d_in, sl.h_in.p, n * _in_bytes, _s_in), "h2d");
+                check(gr4hip_event_record(sl.in_done, _s_in), "event record");
+            }
             check(gr4hip_stream_wait_event(_s_k, sl.in_done), "stream wait");
             _ring_wr = (_ring_wr + n * _in_bytes) % _ring_bytes;
             const void* cur = d_in;

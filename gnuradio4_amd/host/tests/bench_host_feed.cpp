@@ -1,7 +1,7 @@
 // Host-fed rate of the fused chain through the C++ graph API (developer tool, DESIGN.md "Host feed"):
 //   VectorSource<complex<float>> -> fir_filter (gpu) -> PowerSpectrum (gpu) -> NullSink<float>,  planned into one DeviceRun.
 // Everything a sample goes through is timed: source loop, host edge FIFO, pinned staging, H2D, the fused kernel, D2H, sink.
-//   bench_host_feed [log2_samples = 27] [fftSize = 8192] [ntaps = 256]
+//   bench_host_feed [log2_samples = 27] [fftSize = 8192] [ntaps = 256] [pageable]
 #include <chrono>
 #include <cstdio>
 
@@ -22,7 +22,10 @@ int main(int argc, char** argv) {
     auto& sink = g.emplaceBlock<testing::NullSink<float>>();
     EdgeParameters big;
     big.minBufferSize = std::size_t(1) << 22;
-    if (!g.connect<"out", "in">(src, fir, big) || !g.connect<"out", "in">(fir, spec, big) || !g.connect<"out", "in">(spec, sink, big)) return 2;
+    hip::register_provider();
+    EdgeParameters pinned = big;
+    if (!(argc > 4 && std::string(argv[4]) == "pageable")) pinned.domain = "gpu:hip:0"; // page-locked input edge: the run's copy engine reads it in place
+    if (!g.connect<"out", "in">(src, fir, pinned) || !g.connect<"out", "in">(fir, spec, big) || !g.connect<"out", "in">(spec, sink, big)) return 2;
     const auto runs = hip::plan(g);
     if (runs.size() != 1) { std::fprintf(stderr, "planner: expected one run\n"); return 2; }
     scheduler::Simple sched;
@@ -30,8 +33,8 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     if (const auto r = sched.runAndWait(); !r) { std::fprintf(stderr, "%s\n", r.error().message.c_str()); return 3; }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("host-fed chain (%s): %zu samples in %.3f s = %.1f Msamples/s (%.2f GB/s in + %.2f GB/s out over PCIe); %zu launches, %zu overlapped\n",
+    std::printf("host-fed chain (%s): %zu samples in %.3f s = %.1f Msamples/s (%.2f GB/s in + %.2f GB/s out over PCIe); %zu launches, %zu overlapped, %zu read in place\n",
                 std::string(runs[0]->description()).c_str(), sink._count, dt, double(sink._count) / dt / 1e6, double(sink._count) * 8 / dt / 1e9, double(sink._count) * 4 / dt / 1e9,
-                runs[0]->launches(), runs[0]->overlapped_chunks());
+                runs[0]->launches(), runs[0]->overlapped_chunks(), runs[0]->inplace_chunks());
     return sink._count == (n / N) * N ? 0 : 1;
 }
