@@ -323,7 +323,8 @@ struct IirOnePassArgs {
     // passes).  Self-validating words need no ordering at all.  Zeroed before every launch.
     unsigned long long* st_z; // [nblocks][MP]  zero-state end states
     unsigned long long* st_p; // [nblocks][MP]  true end states
-    unsigned*           ticket; // [0]: block tickets, [1]: error flag
+    unsigned*           ticket; // block tickets
+    unsigned*           err;    // page-locked host word (device view): set when a look-back gave up; the host reports it on the handle's next call
 };
 
 __device__ __forceinline__ void iir_status_put(unsigned long long* p, float v) {
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, I
                         if ((w0 = iir_status_get(a.st_p + j * MP)) >> 32) { flag = 2; src = a.st_p + j * MP; break; }
                         if ((w0 = iir_status_get(a.st_z + j * MP)) >> 32) { flag = 1; src = a.st_z + j * MP; break; }
                         __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1 << 24)) { a.ticket[1] = 1u; flag = 2; src = a.st_p + j * MP; break; } // give up instead of hanging (never observed)
+                        if (++spins > (1 << 24)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); flag = 2; src = a.st_p + j * MP; break; } // give up instead of hanging (never observed)
                     }
                     z[0] = __uint_as_float((unsigned)w0);
 #pragma unroll
@@ -513,7 +514,9 @@ struct gr4hip_iir {
     int                 cur = 0;
     DeviceBuffer        d_zc, d_zb, d_tb;
     DeviceBuffer        d_tab;            // one-pass tables: Phi_L^r [16], Phi_L^{16a} [16], Phi_B^l [65]  (M <= 8)
-    DeviceBuffer        d_stz;            // one-pass block status words: [nblocks][M] x 2 (+ ticket and error word)
+    DeviceBuffer        d_stz;            // one-pass block status words: [nblocks][M] x 2 (+ ticket)
+    unsigned*           h_err = nullptr;  // page-locked, device-visible: a look-back that timed out (never observed) is reported by the next call, loudly
+    ~gr4hip_iir() { if (h_err) (void)hipHostFree(h_err); }
 };
 
 // host double-precision cascade step (same recurrence) used to build the propagation matrices
@@ -556,6 +559,17 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
     const long    nblocks = ceil_div(n, (long)kIirBS * kIirL);
     if constexpr (MP <= 8) {
         if (!std::getenv("GR4HIP_IIR_THREE_PASS")) { // (developer switch: the three-pass kernels below stay the path for MP = 16)
+            if (f->h_err && *f->h_err) { // a previous launch of this handle gave up waiting for a predecessor block: its output was not valid
+                *f->h_err = 0;
+                set_error("iir: the single-pass kernel timed out in its look-back on an earlier call (results of that call are invalid); set GR4HIP_IIR_THREE_PASS=1 to use the three-pass kernels");
+                return GR4HIP_RUNTIME_ERROR;
+            }
+            if (!f->h_err) {
+                GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&f->h_err), sizeof(unsigned), hipHostMallocMapped));
+                *f->h_err = 0;
+            }
+            unsigned* d_err = nullptr;
+            GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_err), f->h_err, 0));
             const size_t words = (size_t)nblocks * MP;
             int          rc1   = f->d_stz.ensure((2 * words + 1) * sizeof(unsigned long long)); // Z words, P words, {ticket, error}
             if (rc1) return rc1;
@@ -578,6 +592,7 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
             a.st_z   = static_cast<unsigned long long*>(f->d_stz.ptr);
             a.st_p   = a.st_z + words;
             a.ticket = reinterpret_cast<unsigned*>(a.st_p + words);
+            a.err    = d_err;
             hipLaunchKernelGGL((iir_onepass_kernel<ORD, NSEC>), dim3((unsigned)nblocks), dim3(kIirBS), 0, st, a, cf);
             GR4_LAUNCH_CHECK();
             f->cur ^= 1;
