@@ -89,6 +89,10 @@ class fir_filter(_Handle):
     def reset(self):
         check(lib().gr4hip_fir_reset(self._h), "fir_filter.reset")
 
+    def set_algo(self, algo: int):
+        """capi.FIR_AUTO / capi.FIR_TIME_DOMAIN (direct form also for long complex spans: error relative to the output, include/gr4hip.h)"""
+        check(lib().gr4hip_fir_set_algo(self._h, int(algo)), "fir_filter.set_algo")
+
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "fir_filter")
         if x.dtype != self.dtype:

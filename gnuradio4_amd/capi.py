@@ -16,7 +16,8 @@ DF_I, DF_II, DF_I_TRANSPOSED, DF_II_TRANSPOSED = range(4)
 WINDOWS = ["None", "Rectangular", "Hamming", "Hann", "HannExp", "Blackman", "Nuttall", "BlackmanHarris",
            "BlackmanNuttall", "FlatTop", "Exponential", "Kaiser"]
 FFT_OUTPUT_IN_DB, FFT_OUTPUT_IN_DEG, FFT_UNWRAP_PHASE = 1, 2, 4
-CHAIN_AUTO, CHAIN_UNFUSED, CHAIN_FUSED_TD, CHAIN_FUSED_FD = range(4)
+CHAIN_AUTO, CHAIN_UNFUSED, CHAIN_FUSED_TD, CHAIN_FUSED_FD, CHAIN_TIME_DOMAIN = range(5)
+FIR_AUTO, FIR_TIME_DOMAIN = range(2)
 
 
 class Gr4HipError(RuntimeError):
@@ -60,6 +61,7 @@ SIGNATURES = {
     "gr4hip_ring_size": (_i, [_vp, _psz]),
     "gr4hip_fir_create": (_i, [_pvp, _i, _vp, _sz, _sz]),
     "gr4hip_fir_set_taps": (_i, [_vp, _vp, _sz]),
+    "gr4hip_fir_set_algo": (_i, [_vp, _i]),
     "gr4hip_fir_reset": (_i, [_vp]),
     "gr4hip_fir_process": (_i, [_vp, _vp, _sz, _vp, _psz, _vp]),
     "gr4hip_fir_destroy": (_i, [_vp]),

@@ -30,7 +30,7 @@ extern "C" {
 int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps, size_t fft_size, int window, int algo) {
     GR4_REQUIRE(out, "chain: null output handle");
     GR4_REQUIRE(h_taps && ntaps >= 1, "chain: need at least one tap");
-    GR4_REQUIRE(algo >= GR4HIP_CHAIN_AUTO && algo <= GR4HIP_CHAIN_FUSED_FD, "chain: unknown algo %d", algo);
+    GR4_REQUIRE(algo >= GR4HIP_CHAIN_AUTO && algo <= GR4HIP_CHAIN_TIME_DOMAIN, "chain: unknown algo %d", algo);
     auto* c = new (std::nothrow) gr4hip_chain();
     GR4_REQUIRE(c, "out of host memory");
     c->ntaps  = ntaps;
@@ -41,15 +41,16 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
         use = GR4HIP_CHAIN_UNFUSED;
         for (int cand : {GR4HIP_CHAIN_FUSED_FD, GR4HIP_CHAIN_FUSED_TD})
             if (chain_fused_supported(ntaps, fft_size, window, cand)) { use = cand; break; }
-    } else if (algo != GR4HIP_CHAIN_UNFUSED && !chain_fused_supported(ntaps, fft_size, window, algo)) {
+    } else if (algo != GR4HIP_CHAIN_UNFUSED && algo != GR4HIP_CHAIN_TIME_DOMAIN && !chain_fused_supported(ntaps, fft_size, window, algo)) {
         set_error("chain: fused algo %d does not support ntaps=%zu fft_size=%zu window=%d", algo, ntaps, fft_size, window);
         delete c;
         return GR4HIP_UNSUPPORTED;
     }
     c->algo = use;
     int rc;
-    if (use == GR4HIP_CHAIN_UNFUSED) {
+    if (use == GR4HIP_CHAIN_UNFUSED || use == GR4HIP_CHAIN_TIME_DOMAIN) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, h_taps, ntaps, 1);
+        if (!rc && use == GR4HIP_CHAIN_TIME_DOMAIN) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN);
         if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, fft_size, window, 0);
     } else {
         rc = chain_fused_create(&c->fused, h_taps, ntaps, fft_size, window, use);

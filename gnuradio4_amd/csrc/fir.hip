@@ -178,6 +178,7 @@ struct gr4hip_fir {
     DeviceBuffer       d_taps;     // [D][Qpad]
     DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
     int                cur = 0;
+    int                algo = GR4HIP_FIR_AUTO; // gr4hip_fir_set_algo
     gr4::ChainFused*   fd  = nullptr; // complex, decim 1, ntaps <= 256: frequency-domain plan (created on first use)
     DeviceBuffer       d_hist256;
     DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
@@ -265,6 +266,13 @@ int gr4hip_fir_reset(gr4hip_fir_t* f) {
     return fir_alloc_hist(f);
 }
 
+int gr4hip_fir_set_algo(gr4hip_fir_t* f, int algo) {
+    GR4_REQUIRE(f, "fir_set_algo: null handle");
+    GR4_REQUIRE(algo == GR4HIP_FIR_AUTO || algo == GR4HIP_FIR_TIME_DOMAIN, "fir_set_algo: unknown algo %d", algo);
+    f->algo = algo;
+    return GR4HIP_OK;
+}
+
 int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
     GR4_REQUIRE(f, "fir_process: null handle");
     GR4_REQUIRE(n_in % f->decim == 0, "fir_process: n_in=%zu is not a multiple of decim=%zu", n_in, f->decim);
@@ -279,7 +287,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     size_t       done = 0; // samples already produced by the frequency-domain path
     // complex<float>, no decimation, <= 256 taps, long input: whole 8192-sample frames go through the fused FFT -> xH -> inverse
     // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
-    if (f->S == 2 && f->decim == 1 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame) {
+    if (f->S == 2 && f->decim == 1 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO) {
         int rc = GR4HIP_OK;
         if (!f->fd) rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
         if (!rc) rc = f->d_hist256.ensure(256 * sizeof(float2));

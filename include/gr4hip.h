@@ -70,8 +70,10 @@ typedef enum { /* how the FIR->FFT->mag2 chain is executed */
     GR4HIP_CHAIN_AUTO = 0,
     GR4HIP_CHAIN_UNFUSED,  /* fir kernel -> HBM -> fft+mag2 kernel (any window, any size the FFT block supports) */
     GR4HIP_CHAIN_FUSED_TD, /* reserved (time-domain FIR in LDS + FFT + mag2): not implemented, create returns GR4HIP_UNSUPPORTED */
-    GR4HIP_CHAIN_FUSED_FD  /* one launch, frequency-domain FIR (circular convolution + exact tail correction) + FFT + mag2;
+    GR4HIP_CHAIN_FUSED_FD, /* one launch, frequency-domain FIR (circular convolution + exact tail correction) + FFT + mag2;
                               fft_size 256 ... 8192 (power of two), <= 256 taps, any window */
+    GR4HIP_CHAIN_TIME_DOMAIN /* direct-form FIR kernel -> HBM -> fft+mag2 kernel: the reference's arithmetic; for inputs whose out-of-band content
+                              dwarfs the filtered output (see gr4hip_fir_set_algo) */
 } gr4hip_chain_algo_t;
 
 typedef void* gr4hip_stream_t; /* hipStream_t */
@@ -127,6 +129,11 @@ typedef struct gr4hip_fir gr4hip_fir_t;
 int gr4hip_fir_create(gr4hip_fir_t** fir, int dtype, const float* h_taps, size_t ntaps, size_t decim);
 int gr4hip_fir_set_taps(gr4hip_fir_t* fir, const float* h_taps, size_t ntaps); /* settingsChanged (:38-42): history is kept */
 int gr4hip_fir_reset(gr4hip_fir_t* fir);
+/* GR4HIP_FIR_AUTO (default): long complex spans take the fast-convolution kernel.  Its float32 error floor is ~2e-6 of the INPUT rms per output sample
+ * (three transforms' worth of rounding), the direct form's ~2e-7: when out-of-band signals that the filter removes are much stronger than what it
+ * passes, GR4HIP_FIR_TIME_DOMAIN keeps the error relative to the OUTPUT inside the 1e-5 parity bar (the reference's own arithmetic, 1024 flop/sample). */
+typedef enum { GR4HIP_FIR_AUTO = 0, GR4HIP_FIR_TIME_DOMAIN = 1 } gr4hip_fir_algo;
+int gr4hip_fir_set_algo(gr4hip_fir_t* fir, int algo);
 int gr4hip_fir_process(gr4hip_fir_t* fir, const void* d_in, size_t n_in, void* d_out, size_t* n_out, gr4hip_stream_t stream);
 int gr4hip_fir_destroy(gr4hip_fir_t* fir);
 

@@ -594,6 +594,54 @@ def test_chain_shapes_outside_the_fused_kernel(G, N, ntaps, window):
     assert e.value.status == G.capi.UNSUPPORTED
 
 
+def test_chain_dynamic_range_and_the_time_domain_algo(G):
+    """a tone 30 dB above the noise, removed by a narrow low-pass: the fast-convolution kernels carry the float32 rounding of their transforms, which scales
+    with the INPUT (error floor ~2e-6 of the input rms per output sample); relative to the much smaller OUTPUT that exceeds 1e-5, and CHAIN_TIME_DOMAIN /
+    FIR_TIME_DOMAIN (the reference's direct-form arithmetic) is what meets the bar there"""
+    N, frames, ntaps = 8192, 80, 64
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    x = O.signal_c32(77, frames * N, tone_frel=0.31, tone_amp=30.0)
+    check = slice(70 * N, 72 * N)  # two frames deep inside the span (the oracle's float64 chain over the whole span is the truth)
+    truth, _ = O.chain(b, x, N, 3, truth=True)
+    truth = truth[check]
+    in_rms = float(np.sqrt(np.mean(np.abs(x) ** 2)))
+    errs = {}
+    for algo in (G.capi.CHAIN_AUTO, G.capi.CHAIN_TIME_DOMAIN):
+        ch = G.Chain(b, N, "Hann", algo)
+        got = ch.process_bulk(dev(x)).cpu().numpy().ravel()[check]
+        errs[algo] = _rel(got, truth)
+    assert errs[G.capi.CHAIN_TIME_DOMAIN] <= TOL
+    assert errs[G.capi.CHAIN_AUTO] > errs[G.capi.CHAIN_TIME_DOMAIN]  # the price of the fused kernel on this input ...
+    # ... and its bound: amplitude errors stay below 4e-6 of the input rms: |d mag2| <= 2 |Y| dY + dY^2 with dY = 4e-6 in_rms sqrt(N sum w^2)
+    y, _ = O.fir(b, x)
+    fir_auto = G.fir_filter(b, torch.complex64)
+    fir_td = G.fir_filter(b, torch.complex64)
+    fir_td.set_algo(G.capi.FIR_TIME_DOMAIN)
+    ya, yt = fir_auto.process_bulk(dev(x)).cpu().numpy(), fir_td.process_bulk(dev(x)).cpu().numpy()
+    assert np.max(np.abs(ya - y)) <= 4e-6 * in_rms    # fast convolution: floor relative to the input
+    assert _rel(yt, y) <= TOL                          # direct form: inside the bar relative to the output
+    assert _rel(ya, y) > _rel(yt, y)
+
+
+def test_chain_random_configurations(G):
+    """seeded random draws over the chain's parameter space (fftSize, tap count, window, frame counts per call): every one against the float64 oracle"""
+    rng = np.random.default_rng(2024)
+    names = [w for w in O.WINDOWS]
+    for case in range(24):
+        N = int(rng.choice([256, 512, 1024, 2048, 4096, 8192]))
+        ntaps = int(rng.integers(1, 257))
+        wid = int(rng.integers(0, len(names)))
+        per = 8192 // N
+        frames = int(rng.integers(1, 3 * per + 4)) if N < 8192 else int(rng.integers(1, 9))
+        b = O.design_taps_hamming_lowpass(ntaps, float(rng.uniform(0.02, 0.4))) if ntaps > 1 else np.array([rng.uniform(0.2, 2.0)], np.float32)
+        x = O.signal_c32(100 + case, frames * N, tone_frel=float(rng.uniform(0.0, 0.5)), tone_amp=float(rng.uniform(0.0, 1.0)))  # (stronger out-of-band tones: the dynamic-range test above)
+        truth, _ = O.chain(b, x, N, wid, truth=True)
+        ch = G.Chain(b, N, names[wid])
+        cuts = sorted(set([0, frames] + [int(c) for c in rng.integers(0, frames + 1, size=2)]))
+        got = np.concatenate([ch.process_bulk(dev(x[a * N: c * N])).cpu().numpy().ravel() for a, c in zip(cuts[:-1], cuts[1:]) if c > a])
+        assert got.shape == truth.shape and _rel(got, truth) <= TOL, (case, N, ntaps, names[wid], frames, cuts)
+
+
 @pytest.mark.parametrize("N", [256, 1024, 4096])
 def test_chain_small_fft_size_chunking(G, N):
     """fftSize < 8192 runs 8192-sample blocks through the fused kernel and stages the ragged tail: any split of the stream into calls
