@@ -450,6 +450,64 @@ def test_fft_block_outputs_parity(G, window, N):
             assert rg[s, 0] == v.min() and rg[s, 1] == v.max()
 
 
+def test_fft_block_random_configurations(G):
+    """seeded random draws over the FFT block's parameter space: size (powers of two up to 65536, Bluestein sizes), window, complex / real input, frames"""
+    rng = np.random.default_rng(77)
+    names = [w for w in O.WINDOWS]
+    sizes = [2, 4, 16, 32, 128, 256, 512, 1024, 4096, 8192, 16384, 3, 7, 60, 100, 1000, 2049, 4095]
+    for case in range(30):
+        N = int(rng.choice(sizes))
+        real = bool(rng.integers(0, 2)) and N % 2 == 0 and N >= 4
+        wid = int(rng.integers(0, len(names)))
+        frames = int(rng.integers(1, 7))
+        x = (O.signal_f32 if real else O.signal_c32)(300 + case, frames * N, tone_frel=float(rng.uniform(0.0, 0.5)), tone_amp=float(rng.uniform(0.0, 1.0)))
+        out = G.FFT(N, names[wid], dtype=torch.float32 if real else torch.complex64).process_bulk(dev(x))
+        for f in range(frames):
+            mag, ph, re, im = O.fft_block_truth(x[f * N:(f + 1) * N], wid)
+            what = (case, N, "real" if real else "complex", names[wid], frames, f)
+            assert out["magnitude"][f].shape[0] == len(mag), what
+            assert _rel(out["magnitude"][f].cpu().numpy(), mag) <= TOL, what
+            assert _rel(out["re"][f].cpu().numpy(), re) <= TOL and _rel(out["im"][f].cpu().numpy(), im) <= TOL, what
+            strong = mag > 1e-3 * mag.max()
+            if strong.any():
+                d = np.angle(np.exp(1j * (out["phase"][f].cpu().numpy() - ph)))
+                assert np.max(np.abs(d[strong])) <= 1e-3, what
+            rg = out["ranges"][f].cpu().numpy()
+            for s_, name in enumerate(("magnitude", "phase", "re", "im")):
+                v = out[name][f].cpu().numpy()
+                assert rg[s_, 0] == v.min() and rg[s_, 1] == v.max(), what
+
+
+def test_iir_random_cascades(G):
+    """seeded random stable cascades (random pole radii / angles, 1 ... 8 biquads and fourth-order sections), random span lengths and chunkings"""
+    rng = np.random.default_rng(31)
+    for case in range(16):
+        order = int(rng.choice([1, 2, 4]))
+        nsec = int(rng.integers(1, (8 if order <= 2 else 4) + 1))
+        b, a = [], []
+        for _ in range(nsec):
+            poles = []
+            while len(poles) < order:
+                r, th = rng.uniform(0.2, 0.97), rng.uniform(0.05, 3.0)
+                if order - len(poles) >= 2:
+                    poles += [r * np.exp(1j * th), r * np.exp(-1j * th)]
+                else:
+                    poles += [rng.uniform(-0.9, 0.9)]
+            a.append(np.real(np.poly(poles)))
+            b.append(rng.uniform(-1, 1, order + 1) * 0.5)
+        b, a = np.array(b, np.float32), np.array(a, np.float32)
+        n = int(rng.integers(1, 400_000))
+        x = O.signal_f32(500 + case, n)
+        truth = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(b, a)]), x, O.DF_II, f64=True)
+        f = G.iir_filter(b, a)
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n, size=2)]))
+        y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo])
+        # lightly damped random cascades are ill-conditioned in float32 whichever way they are evaluated: the bar is the parity tolerance or three times
+        # what the reference's own sequential float32 recurrence loses against float64, whichever is larger
+        seq32 = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(b, a)]), x, O.DF_II, f64=False)
+        assert _rel(y, truth) <= max(TOL, 3 * _rel(seq32, truth)), (case, order, nsec, n, cuts, _rel(seq32, truth))
+
+
 def test_fft_block_db_deg_unwrap_and_peak(G, golden):
     g = golden["fft_block"]
     N = g["N"]
