@@ -65,9 +65,10 @@ constexpr int kMathSlab = 4; // 16-byte vectors per lane
 
 // out[i] = ((in0[i] op in1[i]) op in2[i]) ...   or, with CONST, out[i] = in0[i] op value
 template <typename T, int OP, bool CONST>
-__global__ void math_kernel(NaryPtrs ins, int n_inputs, T value, T* __restrict__ out, long n) {
+__global__ void math_kernel(NaryPtrs ins, int n_inputs, T value, T* __restrict__ out, long n, long head, long nvec) {
+    // elements [head, head + nvec VE) are 16-byte aligned in every stream and go through the vector body; [0, head) and the rest take the scalar loop
+    // (a ring span may start at any element: head = the elements up to the next 16-byte boundary when all streams share one misalignment, else nvec = 0)
     constexpr int VE     = 16 / sizeof(T);
-    const long    nvec   = n / VE;
     const long    stride = (long)gridDim.x * blockDim.x;
     const long    v0     = (long)blockIdx.x * (blockDim.x * kMathSlab) + threadIdx.x;
 #pragma unroll
@@ -75,21 +76,23 @@ __global__ void math_kernel(NaryPtrs ins, int n_inputs, T value, T* __restrict__
         const long v = v0 + (long)s * blockDim.x;
         if (v >= nvec) break;
         Vec16<T> acc;
-        acc.u = __builtin_nontemporal_load(&reinterpret_cast<const u32x4*>(ins.p[0])[v]);
+        acc.u = __builtin_nontemporal_load(&reinterpret_cast<const u32x4*>(static_cast<const T*>(ins.p[0]) + head)[v]);
         if constexpr (CONST) {
 #pragma unroll
             for (int e = 0; e < VE; ++e) acc.e[e] = apply_any<T, OP>(acc.e[e], value);
         } else {
             for (int k = 1; k < n_inputs; ++k) {
                 Vec16<T> b;
-                b.u = __builtin_nontemporal_load(&reinterpret_cast<const u32x4*>(ins.p[k])[v]);
+                b.u = __builtin_nontemporal_load(&reinterpret_cast<const u32x4*>(static_cast<const T*>(ins.p[k]) + head)[v]);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) acc.e[e] = apply_any<T, OP>(acc.e[e], b.e[e]);
             }
         }
-        __builtin_nontemporal_store(acc.u, &reinterpret_cast<u32x4*>(out)[v]);
+        __builtin_nontemporal_store(acc.u, &reinterpret_cast<u32x4*>(out + head)[v]);
     }
-    for (long i = nvec * VE + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { // tail
+    const long body_end = head + nvec * VE, nscalar = head + (n - body_end);
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < nscalar; j += stride) { // head and tail elements
+        const long i = j < head ? j : body_end + (j - head);
         T a = static_cast<const T*>(ins.p[0])[i];
         if constexpr (CONST) a = apply_any<T, OP>(a, value);
         else
@@ -100,15 +103,23 @@ __global__ void math_kernel(NaryPtrs ins, int n_inputs, T value, T* __restrict__
 
 template <typename T, bool CONST>
 static int math_dispatch_op(int op, const NaryPtrs& ins, int n_inputs, T value, void* out, long n, hipStream_t st) {
-    const long     nvec = n / (long)(16 / sizeof(T));
+    constexpr long VE = 16 / sizeof(T);
+    // common misalignment of all streams (in elements up to the next 16-byte boundary), or the all-scalar path when they differ
+    const auto mis = [](const void* p) { return (long)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15); };
+    long head = mis(out);
+    bool same = head % (long)sizeof(T) == 0;
+    for (int k = 0; k < n_inputs; ++k) same = same && mis(ins.p[k]) == head;
+    head = same ? std::min<long>(head / (long)sizeof(T), n) : 0;
+    const long nvec = same ? (n - head) / VE : 0;
     GR4_REQUIRE(ceil_div(nvec + 1, 256L * kMathSlab) < (1L << 31), "math: span too long for one launch");
-    const unsigned grid = (unsigned)std::max<long>(ceil_div(nvec + 1, 256L * kMathSlab), 1L); // one 16 KiB slab per workgroup (the scalar tail loop strides over the grid)
+    const long     nscalar = n - nvec * VE; // head + tail, or everything when the streams are misaligned against each other
+    const unsigned grid = (unsigned)std::max<long>({ceil_div(nvec + 1, 256L * kMathSlab), std::min<long>(ceil_div(nscalar, 1024L), 16384L), 1L}); // one 16 KiB slab per workgroup; the scalar loop strides over the grid
     T*             o    = static_cast<T*>(out);
     switch (op) {
-    case GR4HIP_ADD: hipLaunchKernelGGL((math_kernel<T, GR4HIP_ADD, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
-    case GR4HIP_SUB: hipLaunchKernelGGL((math_kernel<T, GR4HIP_SUB, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
-    case GR4HIP_MUL: hipLaunchKernelGGL((math_kernel<T, GR4HIP_MUL, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
-    case GR4HIP_DIV: hipLaunchKernelGGL((math_kernel<T, GR4HIP_DIV, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n); break;
+    case GR4HIP_ADD: hipLaunchKernelGGL((math_kernel<T, GR4HIP_ADD, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n, head, nvec); break;
+    case GR4HIP_SUB: hipLaunchKernelGGL((math_kernel<T, GR4HIP_SUB, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n, head, nvec); break;
+    case GR4HIP_MUL: hipLaunchKernelGGL((math_kernel<T, GR4HIP_MUL, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n, head, nvec); break;
+    case GR4HIP_DIV: hipLaunchKernelGGL((math_kernel<T, GR4HIP_DIV, CONST>), dim3(grid), dim3(256), 0, st, ins, n_inputs, value, o, n, head, nvec); break;
     default: set_error("math: unknown op %d", op); return GR4HIP_INVALID_ARGUMENT;
     }
     GR4_LAUNCH_CHECK();
@@ -348,7 +359,6 @@ int gr4hip_math_const(int op, int dtype, const void* d_in, void* d_out, size_t n
     GR4_REQUIRE(h_value, "math_const: null value");
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "math_const: null device pointer");
-    GR4_REQUIRE(((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 16 == 0), "math_const: device pointers must be 16-byte aligned");
     NaryPtrs ins{};
     ins.p[0] = d_in;
     return math_dispatch<true>(op, dtype, ins, 1, h_value, d_out, (long)n, as_stream(stream));
@@ -357,10 +367,10 @@ int gr4hip_math_const(int op, int dtype, const void* d_in, void* d_out, size_t n
 int gr4hip_math_nary(int op, int dtype, const void* const* h_d_ins, size_t n_inputs, void* d_out, size_t n, gr4hip_stream_t stream) {
     GR4_REQUIRE(h_d_ins && n_inputs >= 1 && n_inputs <= (size_t)kMaxInputs, "math_nary: n_inputs must be in [1,32] (Math.hpp:90), got %zu", n_inputs);
     if (n == 0) return GR4HIP_OK;
-    GR4_REQUIRE(d_out && ((uintptr_t)d_out % 16 == 0), "math_nary: output must be a 16-byte aligned device pointer");
+    GR4_REQUIRE(d_out, "math_nary: null output pointer");
     NaryPtrs ins{};
     for (size_t k = 0; k < n_inputs; ++k) {
-        GR4_REQUIRE(h_d_ins[k] && ((uintptr_t)h_d_ins[k] % 16 == 0), "math_nary: input %zu must be a 16-byte aligned device pointer", k);
+        GR4_REQUIRE(h_d_ins[k], "math_nary: input %zu is a null device pointer", k);
         ins.p[k] = h_d_ins[k];
     }
     return math_dispatch<false>(op, dtype, ins, (int)n_inputs, nullptr, d_out, (long)n, as_stream(stream));

@@ -205,7 +205,8 @@ int gr4hip_chain_destroy(gr4hip_chain_t* chain);
 
 /* ------------------------------------------------------------------------------------------------ a11/a12/a13
  * MathOpImpl<T,op>::processOne (blocks/math/.../Math.hpp:38-56): out = in (op) value, C++ semantics for T
- * (integer promotion then narrowing, wrap-around).  h_value points to one host element of `dtype`. */
+ * (integer promotion then narrowing, wrap-around).  h_value points to one host element of `dtype`.
+ * Spans need only their element's natural alignment (a ring span starts at any element); 16-byte aligned spans are fastest. */
 int gr4hip_math_const(int op, int dtype, const void* d_in, void* d_out, size_t n, const void* h_value, gr4hip_stream_t stream);
 /* MathOpMultiPortImpl<T,op>::processBulk (Math.hpp:100-107): left fold ((in0 op in1) op in2) ... over 1..32 inputs.
  * h_d_ins is a HOST array of n_inputs device pointers. */

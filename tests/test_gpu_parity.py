@@ -799,6 +799,65 @@ def test_math_parity(G, dtype_id, opname):
         np.testing.assert_allclose(got, want, rtol=3e-6 if dtype_id in (8, 10) else 1e-14)
 
 
+def test_float_blocks_any_span_alignment(G):
+    """float streams whose spans start 4 bytes past a 16-byte boundary (an odd ring position): fir_filter (VALU and MFMA sizes, decimating), iir_filter,
+    Decimator and the real-input FFT block give exactly what they give on aligned spans"""
+    n = 1 << 17
+    x0 = G.synth_f32(n, seed=4)
+
+    def shifted(off):  # the same samples, starting `off` floats into a fresh aligned allocation
+        t = torch.empty(n + 8, dtype=torch.float32, device="cuda")[off:off + n]
+        t.copy_(x0)
+        return t
+    b32, b200 = O.design_taps_hamming_lowpass(32, 0.1), O.design_taps_hamming_lowpass(200, 0.1)
+    bi, ai = G.blocks.design_iir(G.capi.LOWPASS, 4, 0.1, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    makers = {"fir32": lambda: G.fir_filter(b32, torch.float32), "fir200": lambda: G.fir_filter(b200, torch.float32),
+              "fir_decim4": lambda: G.fir_filter(b200, torch.float32, decimate=4), "iir": lambda: G.iir_filter(bi, ai), "decimator": lambda: G.Decimator(4)}
+    for name, make in makers.items():
+        ref = make().process_bulk(x0)
+        for off in (1, 2, 3):
+            xin = shifted(off)
+            out = torch.empty(ref.numel() + 8, dtype=torch.float32, device="cuda")[off:off + ref.numel()]
+            blk = make()
+            got = blk.process_bulk(xin, out) if name != "decimator" else blk.process_bulk(xin)
+            if name in ("fir200", "fir_decim4"):  # an unaligned output takes the VALU kernel instead of the MFMA one: same filter, different summation order
+                assert float((got - ref).abs().max()) <= TOL * float(ref.pow(2).mean().sqrt()), (name, off)
+            else:
+                assert torch.equal(got, ref), (name, off)
+    fr = G.FFT(1024, "Hann", dtype=torch.float32)
+    ref = fr.process_bulk(x0)
+    got = G.FFT(1024, "Hann", dtype=torch.float32).process_bulk(shifted(1))
+    for k in ("magnitude", "phase", "re", "im"):
+        assert torch.equal(got[k], ref[k]), k
+
+
+@pytest.mark.parametrize("dtype_id", [0, 5, 6, 8, 10, 11])
+def test_math_any_span_alignment(G, dtype_id):
+    """a ring span starts at any element: inputs and output sharing one misalignment keep the 16-byte vector body (scalar head and tail), spans misaligned
+    against each other take the element loop -- bit-identical to the aligned call in both cases"""
+    rng = np.random.default_rng(dtype_id)
+    n = 70_001
+    a, b = _rand(dtype_id, n, rng), _rand(dtype_id, n, rng, nonzero=True)
+    ref_nary = G.math_nary("Multiply", [dev(a), dev(b)])
+    ref_const = G.math_const("Add", dev(a), a[3])
+    tdt = ref_nary.dtype
+    val = np.array([a[3]], O.NP_DTYPES[dtype_id])
+
+    def view(src, off):  # a device copy of src that starts `off` elements into an aligned allocation
+        t = torch.empty(n + 8, dtype=tdt, device="cuda")[off:off + n]
+        if src is not None:
+            t.copy_(dev(src))
+        return t
+    for off_a, off_b, off_o in ((1, 1, 1), (3, 3, 3), (1, 2, 0), (0, 0, 5), (7, 0, 3)):
+        xa, xb, out = view(a, off_a), view(b, off_b), view(None, off_o)
+        G.capi.check(G.capi.lib().gr4hip_math_nary(2, dtype_id, (C.c_void_p * 2)(xa.data_ptr(), xb.data_ptr()), 2, out.data_ptr(), n, None), "nary")
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.uint8), ref_nary.view(torch.uint8)), (off_a, off_b, off_o)
+        G.capi.check(G.capi.lib().gr4hip_math_const(0, dtype_id, xa.data_ptr(), out.data_ptr(), n, val.ctypes.data, None), "const")
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.uint8), ref_const.view(torch.uint8)), (off_a, off_o)
+
+
 @pytest.mark.parametrize("dtype_id", range(12))
 def test_math_golden_vectors(G, golden, dtype_id):
     dt = O.NP_DTYPES[dtype_id]
