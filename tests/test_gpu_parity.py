@@ -799,6 +799,32 @@ def test_math_parity(G, dtype_id, opname):
         np.testing.assert_allclose(got, want, rtol=3e-6 if dtype_id in (8, 10) else 1e-14)
 
 
+def test_tiny_and_empty_spans_every_block(G):
+    """work() hands a block whatever the upstream produced: 0, 1, 2 ... samples per call must stream exactly like one long call (state carried)"""
+    sizes = [0, 1, 2, 3, 7, 0, 31, 33, 255, 257, 1, 1000]
+    n = sum(sizes)
+    xf, xc = O.signal_f32(8, n), O.signal_c32(9, n)
+    b = O.design_taps_hamming_lowpass(45, 0.1)
+    bi, ai = G.blocks.design_iir(G.capi.LOWPASS, 4, 0.1, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    cases = [("fir f32", lambda: G.fir_filter(b, torch.float32), xf, O.fir(b, xf)[0]),
+             ("fir c32", lambda: G.fir_filter(b, torch.complex64), xc, O.fir(b, xc)[0]),
+             ("iir", lambda: G.iir_filter(bi, ai), xf, O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)]), xf, O.DF_II, f64=True)),
+             ("rotator", lambda: G.Rotator(phase_increment=0.37, initial_phase=0.1), xc, O.rotator(xc, 0.37, 0.1)[0])]
+    for name, make, x, truth in cases:
+        blk, parts, at = make(), [], 0
+        for k in sizes:
+            parts.append(blk.process_bulk(dev(x[at:at + k])).cpu().numpy())
+            assert parts[-1].shape == (k,), (name, k)
+            at += k
+        assert _rel(np.concatenate(parts), truth) <= TOL, name
+    assert G.math_const("Add", dev(np.zeros(0, np.int16)), 3).numel() == 0 and G.math_const("Multiply", dev(np.array([7], np.int16)), 3).cpu().numpy()[0] == 21
+    assert G.Decimator(4).process_bulk(dev(np.zeros(0, np.float32))).numel() == 0
+    f = G.FFT(64, "Hann")
+    assert f.mag2(dev(np.zeros(0, np.complex64))).shape == (0, 64)
+    ch = G.Chain(b, 1024, "Hann")
+    assert ch.process_bulk(dev(np.zeros(0, np.complex64))).shape == (0, 1024)
+
+
 def test_float_blocks_any_span_alignment(G):
     """float streams whose spans start 4 bytes past a 16-byte boundary (an odd ring position): fir_filter (VALU and MFMA sizes, decimating), iir_filter,
     Decimator and the real-input FFT block give exactly what they give on aligned spans"""
