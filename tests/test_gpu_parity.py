@@ -825,6 +825,35 @@ def test_tiny_and_empty_spans_every_block(G):
     assert ch.process_bulk(dev(np.zeros(0, np.complex64))).shape == (0, 1024)
 
 
+def test_independent_handles_on_concurrent_streams(G):
+    """one HIP stream per fused chain (SURVEY 8b "Threading"): handles driven from different streams at the same time do not share mutable state"""
+    N, frames = 8192, 300
+    b = O.design_taps_hamming_lowpass(256, 0.1)
+    xs = [G.synth_c32(frames * N, seed=60 + i) for i in range(3)]
+    bi, ai = G.blocks.design_iir(G.capi.LOWPASS, 8, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    xr = G.synth_f32(1 << 22, seed=70)
+    ref = [G.Chain(b, N, w).process_bulk(x) for x, w in zip(xs, ("None", "Hann", "None"))]
+    ref_iir = G.iir_filter(bi, ai).process_bulk(xr)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    chains = [G.Chain(b, N, w) for w in ("None", "Hann", "None")]
+    iir = G.iir_filter(bi, ai)
+    outs = [None] * 4
+    for rep in range(3):  # interleaved submission, nothing synchronised in between
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                if i < 3:
+                    chains[i].reset()
+                    outs[i] = chains[i].process_bulk(xs[i])
+                else:
+                    iir.reset()
+                    outs[3] = iir.process_bulk(xr)
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(outs[i], ref[i]), i
+    assert torch.equal(outs[3], ref_iir)
+
+
 def test_float_blocks_any_span_alignment(G):
     """float streams whose spans start 4 bytes past a 16-byte boundary (an odd ring position): fir_filter (VALU and MFMA sizes, decimating), iir_filter,
     Decimator and the real-input FFT block give exactly what they give on aligned spans"""
