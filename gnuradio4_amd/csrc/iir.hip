@@ -297,14 +297,22 @@ __global__ __launch_bounds__(kIirBS) void iir_pass_y(const float* __restrict__ x
 // ------------------------------------------------------------------------------------------------ single pass (MP <= 8)
 // The three passes above read x twice, write and re-read the per-chunk states (MP floats per 32 samples) and chain the blocks in a
 // one-workgroup kernel.  One pass with a decoupled look-back (the affine-map version of the chained scan) does each of them once:
-//   1. stage the tile, zero-state run per chunk, in-block scan            (as pass Z; the chunk states stay in LDS)
+//   1. stage the tile, zero-state run per chunk, scan over the 64 chunks of every wave IN REGISTERS (no barriers; the four waves are
+//      stitched together in step 5)
 //   2. publish the block's zero-state end state Z_b (flag 1)
 //   3. wave 0 looks back over the predecessors, 64 at a time: lane l reads block b-1-l; aggregates contribute Phi_B^l Z, the first
 //      block that already knows its true end state P (flag 2) closes the sum:  T_b = sum_{l<w} Phi_B^l Z_{b-1-l} + Phi_B^w P_{b-1-w}
 //      (Phi_B^0..63 from a table; a window without an inclusive block is folded in through Phi_B^64 and the next window follows)
 //   4. publish P_b = Phi_B T_b + Z_b (flag 2)
-//   5. chunk c starts from S_{c-1} + Phi_L^c T_b; with c = 16 a + r that is Phi_L^{16a} (Phi_L^r T_b): two small tables instead of a second scan
+//   5. wave w starts from T^w = Phi_L^{64 w} T_b + (the waves before it); its chunk l = 16 a + r starts from S_{l-1} + Phi_L^{16a} (Phi_L^r T^w):
+//      two small tables instead of a second scan
 //   6. re-run the chunk from its true start state, coalesced store.
+// Where a block's ~19 us go (s_memrealtime stamps, -DGR4_IIR_TIMING + tools/iir_stamps.py, 4 biquads): stage 1.8, run 1.9, scan 3.1,
+// LOOK-BACK 7.6, start states 1.4, re-run 2.1, store 0.6.  A poll of the status words is a ~2 us round trip while the streaming
+// tiles saturate the memory system, and a block needs 3.8 of them (2.2 windows; the nearest predecessors publish Z within +-2 us of
+// this block).  Wider look-backs (2 or 4 waves polling 128 / 256 predecessors per round trip, partial sums handed over through LDS)
+// were built and measured SLOWER (212 / 173 vs 255 Gsamples/s): the extra polling traffic lengthens every round trip by more than
+// the saved windows are worth.
 // Block indices are tickets drawn at the start (a block only ever waits for blocks that already run), status words and ticket are zeroed per call.
 // Waiting is bounded: a waiter that gives up raises err[0] and the span is recomputed by the three-pass kernels.
 struct IirOnePassArgs {
@@ -324,6 +332,9 @@ struct IirOnePassArgs {
     unsigned long long* st_z; // [nblocks][MP]  zero-state end states
     unsigned long long* st_p; // [nblocks][MP]  true end states
     unsigned*           ticket; // block tickets
+#ifdef GR4_IIR_TIMING
+    unsigned long long* dbgc; // [nblocks][16] stamps
+#endif
     unsigned*           err;    // page-locked host word (device view): set when a look-back gave up; the host reports it on the handle's next call
 };
 
@@ -332,26 +343,63 @@ __device__ __forceinline__ void iir_status_put(unsigned long long* p, float v) {
 }
 __device__ __forceinline__ unsigned long long iir_status_get(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// inclusive scan over the 64 chunks of one wave, in registers:  e(lane) <- sum_{i<=lane} Phi_L^{lane-i} e(i).  No LDS state and no
+// barriers (the block-wide LDS scan above cost 16 barriers and 4.9 us of a 20 us block in the single-pass kernel); the four waves of a
+// block are stitched together afterwards with the same two-table trick that applies T_b.
+template <int MP>
+__device__ __forceinline__ void iir_wave_scan(float (&e)[MP], const float* pl /*LDS [round][MP(j)][MP(i)]: Phi_L^(2^k) transposed*/, int lane) {
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {
+        const int    off = 1 << k;
+        const float* P   = pl + k * MP * MP;
+        float        p[MP];
+#pragma unroll
+        for (int j = 0; j < MP; ++j) p[j] = __shfl_up(e[j], off);
+        if (lane >= off) {
+#pragma unroll
+            for (int j = 0; j < MP; ++j)
+#pragma unroll
+                for (int i = 0; i < MP; ++i) e[i] = fmaf(P[j * MP + i], p[j], e[i]);
+        }
+    }
+}
+
+// developer instrumentation (-DGR4_IIR_TIMING): lane 0 of every block stamps s_memrealtime (100 MHz) at phase boundaries; the host dumps
+// them to /tmp/iir_stamps.txt after every launch (tools/iir_stamps.py reads that)
+#ifdef GR4_IIR_TIMING
+#define IIR_STAMP(k) do { if (c == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); a.dbgc[bid_s * 16 + (k)] = t_; } } while (0)
+#define IIR_COUNT(k, v) do { if (c == 0) a.dbgc[bid_s * 16 + (k)] = (v); } while (0)
+#else
+#define IIR_STAMP(k) do { } while (0)
+#define IIR_COUNT(k, v) do { } while (0)
+#endif
 template <int ORD, int NSEC>
 __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, IirCoef<ORD, NSEC> coef) {
     constexpr int    MP = ORD * NSEC;
     static_assert(MP <= 8, "the look-back tables are sized for MP <= 8");
     __shared__ float tile[kIirBS * (kIirL + 1)];
-    __shared__ float sv[MP * kIirBS];
     __shared__ __attribute__((aligned(16))) float pl[kIirRounds * MP * MP];
     __shared__ float p16[16 * MP * MP]; // Phi_L^{16 a}, row-major
-    __shared__ float wv[16 * MP];       // Phi_L^r T_b
-    __shared__ float T[MP], R[MP * MP], R2[MP * MP];
+    __shared__ float plr[16 * MP * MP]; // Phi_L^r (needed the moment T_b is known: a global read there is a cold round trip on the block's critical path)
+    __shared__ float wv[4 * 16 * MP];   // Phi_L^r T^w (T^w: state at the start of wave w's first chunk)
+    __shared__ float wz[4 * MP], Tw[4 * MP]; // zero-state end state of every wave's 64 chunks; T^w
+    __shared__ float R[MP * MP], R2[MP * MP];
     __shared__ unsigned bid_s;
     const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    __builtin_amdgcn_s_setprio(3); // until Z_b is out (every successor waits for it) this block goes first on its SIMDs: +1 .. 2 %
     if (c == 0) bid_s = atomicAdd(a.ticket, 1u);
     iir_load_phi<MP, kIirRounds>(pl, a.phi);
-    for (int e = c; e < 16 * MP * MP; e += kIirBS) p16[e] = a.pl16[e];
+    for (int e = c; e < 16 * MP * MP; e += kIirBS) {
+        p16[e] = a.pl16[e];
+        plr[e] = a.plr[e];
+    }
     __syncthreads();
     const long b    = bid_s;
     const long base = b * kIirBS * kIirL;
+    IIR_STAMP(0);
     iir_stage_tile(tile, a.x, base, a.n);
     __syncthreads();
+    IIR_STAMP(1);
     // ---- 1. zero-state run and in-block scan
     float st[NSEC][ORD];
 #pragma unroll
@@ -361,127 +409,189 @@ __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, I
     float* row = tile + c * (kIirL + 1);
 #pragma unroll 4
     for (int i = 0; i < kIirL; ++i) (void)iir_step<ORD, NSEC>(coef, st, row[i]);
+    float e[MP], ex[MP]; // zero-state end state of the wave's chunks 0..lane (inclusive / exclusive)
 #pragma unroll
     for (int s = 0; s < NSEC; ++s)
 #pragma unroll
-        for (int j = 0; j < ORD; ++j) sv[(s * ORD + j) * kIirBS + c] = st[s][j];
+        for (int j = 0; j < ORD; ++j) e[s * ORD + j] = st[s][j];
+    IIR_STAMP(2);
+    iir_wave_scan<MP>(e, pl, lane);
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        ex[i] = __shfl_up(e[i], 1);
+        if (lane == 0) ex[i] = 0.f;
+        if (lane == 63) wz[wave * MP + i] = e[i];
+    }
     __syncthreads();
-    iir_block_scan<MP, kIirBS, kIirRounds>(sv, pl); // sv[.][c] = zero-state end state of chunks 0..c
+    IIR_STAMP(3);
+    if (wave != 0) __builtin_amdgcn_s_setprio(0);
     // ---- 2..4: wave 0 publishes, looks back, publishes again
+    float zb = 0.f; // wave 0, lane i < MP: component i of Z_b
+    float p1[MP];   // wave 0: row `lane` of Phi_B (for P_b below; requested here, used after the look-back)
     if (wave == 0) {
-        float zb = 0.f; // lane i < MP: component i of Z_b
         if (lane < MP) {
-            zb = sv[lane * kIirBS + kIirBS - 1];
+            zb = wz[3 * MP + lane]; // Z_b = sum_w Phi_L^{64 (3 - w)} wz[w]
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float* P = p16 + 4 * (3 - w) * MP * MP;
+#pragma unroll
+                for (int k = 0; k < MP; ++k) zb = fmaf(P[lane * MP + k], wz[w * MP + k], zb);
+            }
             if (b > 0) iir_status_put(a.st_z + b * MP + lane, zb);
         }
-        float tv = 0.f; // lane i < MP: component i of T_b
-        if (b == 0) {
-            if (lane < MP) tv = a.state_in[lane];
-        } else {
-            if (lane < MP * MP) R[lane] = (lane / MP == lane % MP) ? 1.f : 0.f; // R = Phi_B^{64 w}: identity for the first window
-            __builtin_amdgcn_wave_barrier();
-            float acc = 0.f;                                                     // lane i < MP
-            for (long first_j = b - 1; ; first_j -= 64) {
-                const long j     = first_j - lane;
-                const bool valid = j >= 0;
-                unsigned   flag  = 0; // 1: aggregate, 2: inclusive
-                float      z[MP];
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-                for (int i = 0; i < MP; ++i) z[i] = 0.f;
-                if (valid) {
-                    int                       spins = 0;
-                    const unsigned long long* src   = nullptr;
-                    unsigned long long        w0    = 0;
-                    for (;;) { // component 0 of either state decides which one this block offers; the true end state wins
-                        if ((w0 = iir_status_get(a.st_p + j * MP)) >> 32) { flag = 2; src = a.st_p + j * MP; break; }
-                        if ((w0 = iir_status_get(a.st_z + j * MP)) >> 32) { flag = 1; src = a.st_z + j * MP; break; }
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1 << 24)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); flag = 2; src = a.st_p + j * MP; break; } // give up instead of hanging (never observed)
-                    }
-                    z[0] = __uint_as_float((unsigned)w0);
+        for (int k = 0; k < MP; ++k) p1[k] = lane < MP ? a.pb[1L * MP * MP + lane * MP + k] : 0.f;
+    }
+    float tv = 0.f; // wave 0, lane i < MP: component i of T_b
+    if (b == 0) {
+        if (wave == 0 && lane < MP) tv = a.state_in[lane];
+    } else if (wave == 0) {
+        if (lane < MP * MP) R[lane] = (lane / MP == lane % MP) ? 1.f : 0.f; // R = Phi_B^{64 it}: identity for the first window
+        float acc = 0.f;   // wave 0, lane i < MP
+        float Pl[MP * MP]; // Phi_B^lane: requested before the polling starts, so its L2 round trip overlaps the first poll
+        {
+            const float* P = a.pb + (long)lane * MP * MP;
 #pragma unroll
-                    for (int i = 1; i < MP; ++i) { // the other components follow within a few hundred cycles; each word validates itself
-                        unsigned long long w;
-                        int                tries = 0;
-                        while (!((w = iir_status_get(src + i)) >> 32) && ++tries < (1 << 24)) __builtin_amdgcn_s_sleep(1);
-                        z[i] = __uint_as_float((unsigned)w);
-                    }
-                }
-                const unsigned long long incl = __ballot(valid && flag == 2);
-                const int                w    = incl ? __ffsll((long long)incl) - 1 : 64; // first lane with an inclusive state
-                float v[MP];
-#pragma unroll
-                for (int i = 0; i < MP; ++i) v[i] = 0.f;
-                if (valid && lane <= w) { // Phi_B^lane * state[j]
-                    const float* P = a.pb + (long)lane * MP * MP;
-#pragma unroll
-                    for (int i = 0; i < MP; ++i)
-#pragma unroll
-                        for (int k = 0; k < MP; ++k) v[i] = fmaf(P[i * MP + k], z[k], v[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < MP; ++i) { // wave sum (every lane ends with the total)
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
-                }
-                if (lane < MP) { // acc += R * wsum
-                    float t = 0.f;
-#pragma unroll
-                    for (int k = 0; k < MP; ++k) t = fmaf(R[lane * MP + k], v[k], t);
-                    acc += t;
-                }
-                if (w < 64) break;
-                // no inclusive state in this window: R <- Phi_B^64 * R ... as R and Phi_B^64 are powers of one matrix the order does not matter
-                if (lane < MP * MP) {
-                    const int    i = lane / MP, k = lane % MP;
-                    const float* P = a.pb + 64L * MP * MP;
-                    float        t = 0.f;
-#pragma unroll
-                    for (int m = 0; m < MP; ++m) t = fmaf(P[i * MP + m], R[m * MP + k], t);
-                    R2[lane] = t;
-                }
-                __builtin_amdgcn_wave_barrier(); // (one wave: LDS accesses complete in program order; this only pins the compiler's order)
-                if (lane < MP * MP) R[lane] = R2[lane];
-                __builtin_amdgcn_wave_barrier();
-            }
-            tv = acc;
+            for (int e = 0; e < MP * MP; ++e) Pl[e] = P[e];
         }
-        if (lane < MP) T[lane] = tv;
+        int nround = 0, it = 0;
+        for (;; ++it) {
+            const long j     = b - 1 - 64L * it - lane;
+            const bool valid = j >= 0;
+            unsigned   flag  = 0; // 1: aggregate, 2: inclusive
+            float      z[MP];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) z[i] = 0.f;
+            // Polling rounds are wave-synchronous: all 2 MP status words of block j in ONE round trip (word after word cost 2 + MP - 1
+            // dependent latencies), a state is taken only when every word of it validates, and the window is complete as soon as
+            // every lane IN FRONT OF the first inclusive state has data -- a late block behind that point is not waited for.
+            const unsigned long long* sp = a.st_p + j * MP;
+            const unsigned long long* sz = a.st_z + j * MP;
+            int                       w  = 64; // first lane with an inclusive state
+            for (int spins = 0;; ++spins) {
+                if (valid && flag == 0) {
+                    unsigned long long wp[MP], wq[MP];
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) wp[i] = iir_status_get(sp + i);
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) wq[i] = iir_status_get(sz + i);
+                    unsigned long long okp = wp[0], okz = wq[0];
+#pragma unroll
+                    for (int i = 1; i < MP; ++i) { okp &= wp[i]; okz &= wq[i]; }
+                    if (okp >> 32) { // the true end state wins
+                        flag = 2;
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) z[i] = __uint_as_float((unsigned)wp[i]);
+                    } else if (okz >> 32) {
+                        flag = 1;
+#pragma unroll
+                        for (int i = 0; i < MP; ++i) z[i] = __uint_as_float((unsigned)wq[i]);
+                    }
+                }
+                if (nround == 0) IIR_STAMP(8);
+                ++nround;
+                const unsigned long long incl = __ballot(valid && flag == 2);
+                w = incl ? __ffsll((long long)incl) - 1 : 64;
+                if (!__ballot(valid && flag == 0 && lane < w)) break;
+                if (spins > (1 << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; } // give up instead of hanging (never observed)
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (it == 0) IIR_STAMP(9);
+            float v[MP];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) v[i] = 0.f;
+            if (valid && lane <= w) { // Phi_B^lane * state[j]
+#pragma unroll
+                for (int i = 0; i < MP; ++i)
+#pragma unroll
+                    for (int k = 0; k < MP; ++k) v[i] = fmaf(Pl[i * MP + k], z[k], v[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < MP; ++i) { // wave sum (every lane ends with the total)
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+            }
+            if (lane < MP) { // acc += R * sum
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < MP; ++k) t = fmaf(R[lane * MP + k], v[k], t);
+                acc += t;
+            }
+            if (w < 64) break;
+            // no inclusive state in this iteration: R <- Phi_B^64 * R ... as both are powers of one matrix the order does not matter
+            if (lane < MP * MP) {
+                const int    i = lane / MP, k = lane % MP;
+                const float* P = a.pb + 64L * MP * MP;
+                float        t = 0.f;
+#pragma unroll
+                for (int m = 0; m < MP; ++m) t = fmaf(P[i * MP + m], R[m * MP + k], t);
+                R2[lane] = t;
+            }
+            __builtin_amdgcn_wave_barrier(); // (one wave: LDS accesses complete in program order; this only pins the compiler's order)
+            if (lane < MP * MP) R[lane] = R2[lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+        tv = acc;
+        IIR_COUNT(10, it + 1);
+        IIR_COUNT(11, nround);
+    }
+    if (wave == 0) {
+        IIR_STAMP(4);
+        float tvk[MP];
+#pragma unroll
+        for (int k = 0; k < MP; ++k) tvk[k] = __shfl(tv, k);
         // P_b = Phi_B T_b + Z_b
         if (lane < MP) {
-            const float* P = a.pb + 1L * MP * MP;
-            float        pv = zb;
+            float pv = zb;
 #pragma unroll
-            for (int k = 0; k < MP; ++k) pv = fmaf(P[lane * MP + k], __shfl(tv, k), pv);
+            for (int k = 0; k < MP; ++k) pv = fmaf(p1[k], tvk[k], pv);
             iir_status_put(a.st_p + b * MP + lane, pv);
+        }
+        // T^w = Phi_L^{64 w} T_b + sum_{w' < w} Phi_L^{64 (w - 1 - w')} wz[w']
+        if (lane < 4 * MP) {
+            const int w = lane / MP, i = lane % MP;
+            float     t = 0.f;
+            {
+                const float* P = p16 + 4 * w * MP * MP;
+#pragma unroll
+                for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], tvk[k], t);
+            }
+            for (int wp = 0; wp < w; ++wp) {
+                const float* P = p16 + 4 * (w - 1 - wp) * MP * MP;
+#pragma unroll
+                for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], wz[wp * MP + k], t);
+            }
+            Tw[lane] = t;
         }
     }
     __syncthreads();
-    // ---- 5. wv[r] = Phi_L^r T_b (r < 16), then every chunk's start state
-    if (c < 16 * MP) {
-        const int    r = c / MP, i = c % MP;
-        const float* P = a.plr + (long)r * MP * MP;
+    // ---- 5. wv[w][r] = Phi_L^r T^w (r < 16), then every chunk's start state
+    for (int q = c; q < 4 * 16 * MP; q += kIirBS) {
+        const int    w = q / (16 * MP), r = (q / MP) % 16, i = q % MP;
+        const float* P = plr + r * MP * MP;
         float        t = 0.f;
 #pragma unroll
-        for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], T[k], t);
-        wv[c] = t;
+        for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], Tw[w * MP + k], t);
+        wv[q] = t;
     }
     __syncthreads();
     {
-        const int    aa = c >> 4, r = c & 15; // start of chunk c: exponent c = 16 aa + r
+        const int    aa = lane >> 4, r = lane & 15; // start of the wave's chunk `lane`: exponent 16 aa + r
         const float* P = p16 + aa * MP * MP;
-        const float* w = wv + r * MP;
+        const float* w = wv + (wave * 16 + r) * MP;
 #pragma unroll
         for (int s = 0; s < NSEC; ++s)
 #pragma unroll
             for (int j = 0; j < ORD; ++j) {
                 const int i = s * ORD + j;
-                float     t = c == 0 ? 0.f : sv[i * kIirBS + c - 1];
+                float     t = ex[i];
 #pragma unroll
                 for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], w[k], t);
                 st[s][j] = t;
             }
     }
+    IIR_STAMP(5);
     // ---- 6. re-run from the true start state
     const long cbeg = base + (long)c * kIirL;
     const int  len  = (int)(a.n - cbeg < kIirL ? (a.n - cbeg < 0 ? 0 : a.n - cbeg) : kIirL);
@@ -498,7 +608,9 @@ __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, I
             for (int j = 0; j < ORD; ++j) a.state_out[s * ORD + j] = st[s][j];
     }
     __syncthreads();
+    IIR_STAMP(6);
     iir_unstage_tile(tile, a.y, base, a.n);
+    IIR_STAMP(7);
 }
 
 } // namespace gr4
@@ -571,7 +683,12 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
             unsigned* d_err = nullptr;
             GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_err), f->h_err, 0));
             const size_t words = (size_t)nblocks * MP;
-            int          rc1   = f->d_stz.ensure((2 * words + 1) * sizeof(unsigned long long)); // Z words, P words, {ticket, error}
+#ifdef GR4_IIR_TIMING
+            constexpr size_t kTimingWords = 16;
+#else
+            constexpr size_t kTimingWords = 0;
+#endif
+            int          rc1   = f->d_stz.ensure((2 * words + 1 + kTimingWords * nblocks) * sizeof(unsigned long long)); // Z words, P words, {ticket, error}
             if (rc1) return rc1;
             GR4_HIP_TRY(hipMemsetAsync(f->d_stz.ptr, 0, (2 * words + 1) * sizeof(unsigned long long), st));
             IirCoef<ORD, NSEC> cf{};
@@ -593,8 +710,21 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
             a.st_p   = a.st_z + words;
             a.ticket = reinterpret_cast<unsigned*>(a.st_p + words);
             a.err    = d_err;
+#ifdef GR4_IIR_TIMING
+            a.dbgc = a.st_p + words + 1;
+#endif
             hipLaunchKernelGGL((iir_onepass_kernel<ORD, NSEC>), dim3((unsigned)nblocks), dim3(kIirBS), 0, st, a, cf);
             GR4_LAUNCH_CHECK();
+#ifdef GR4_IIR_TIMING
+            {
+                std::vector<unsigned long long> h(16 * nblocks);
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(h.data(), a.dbgc, h.size() * 8, hipMemcpyDeviceToHost);
+                FILE* fp = fopen("/tmp/iir_stamps.txt", "w");
+                for (long i = 0; i < nblocks; ++i) { for (int k = 0; k < 16; ++k) fprintf(fp, "%llu ", h[i * 16 + k]); fprintf(fp, "\n"); }
+                fclose(fp);
+            }
+#endif
             f->cur ^= 1;
             return GR4HIP_OK;
         }
