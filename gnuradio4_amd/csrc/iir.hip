@@ -312,7 +312,10 @@ __global__ __launch_bounds__(kIirBS) void iir_pass_y(const float* __restrict__ x
 // tiles saturate the memory system, and a block needs 3.8 of them (2.2 windows; the nearest predecessors publish Z within +-2 us of
 // this block).  Wider look-backs (2 or 4 waves polling 128 / 256 predecessors per round trip, partial sums handed over through LDS)
 // were built and measured SLOWER (212 / 173 vs 255 Gsamples/s): the extra polling traffic lengthens every round trip by more than
-// the saved windows are worth.
+// the saved windows are worth.  Persistent workgroups (tables loaded once, the next tile's ticket and samples prefetched into registers during
+// the re-run) were built too: stage 1.8 -> 0.7 us, but no gain in throughput (253 / 396 vs 260 / 392 Gsamples/s): the ticket must not be
+// drawn before the look-back is over (a ticket held by a block that is still busy makes every successor wait for its Z: 192), and at
+// 168 VGPRs the loop spills around the look-back.
 // Block indices are tickets drawn at the start (a block only ever waits for blocks that already run), status words and ticket are zeroed per call.
 // Waiting is bounded: a waiter that gives up raises err[0] and the span is recomputed by the three-pass kernels.
 struct IirOnePassArgs {
@@ -348,7 +351,7 @@ __device__ __forceinline__ unsigned long long iir_status_get(const unsigned long
 // block are stitched together afterwards with the same two-table trick that applies T_b.
 template <int MP>
 __device__ __forceinline__ void iir_wave_scan(float (&e)[MP], const float* pl /*LDS [round][MP(j)][MP(i)]: Phi_L^(2^k) transposed*/, int lane) {
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int    off = 1 << k;
         const float* P   = pl + k * MP * MP;
@@ -455,6 +458,9 @@ __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, I
 #pragma unroll
             for (int e = 0; e < MP * MP; ++e) Pl[e] = P[e];
         }
+        // Ticket order is start order only to +-2 us: polled at once, half of the nearest predecessors have not published their Z yet and the
+        // round trip is spent on a retry.  A short nap first (0.8 / 1.5 us) is cheaper: +2 % (MP = 8), +8 % (MP = 4).
+        if constexpr (MP <= 4) __builtin_amdgcn_s_sleep(50); else __builtin_amdgcn_s_sleep(25);
         int nround = 0, it = 0;
         for (;; ++it) {
             const long j     = b - 1 - 64L * it - lane;
