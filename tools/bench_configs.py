@@ -112,12 +112,12 @@ F = G.FFT(1024, "Hann")
 t = timeit(lambda: F.process_bulk(xc))
 res["FFT block 1024 (Hann) -> DataSet (mag, phase, re, im, ranges)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 24 / t / 1e9, 1), "hbm_frac": round(n * 24 / t / 8e12, 3),
                                                                          "note": "24 B/sample: 8 in + 4 x 4 out; per-frame min/max ranges reduced inside the kernel; includes torch output allocation"}
-# chain at the FFT block's default size (unfused: fast-convolution FIR -> y in HBM -> FFT kernel), Decimator, Rotator
+# chain at the FFT block's default size (fused: 8192-sample fast-convolution blocks, fftSize-point transforms on the LDS image), Decimator, Rotator
 ch = G.Chain(lowpass(64, 0.1), 1024, "Hann")
 m2 = torch.empty((n // 1024, 1024), dtype=torch.float32, device="cuda")
 t = timeit(lambda: ch.process_bulk(xc, m2))
 res["chain complex 64-tap FIR -> 1024-pt FFT (Hann) -> mag2 (fused, fftSize < 8192)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 12 / t / 1e9, 1), "hbm_frac": round(n * 12 / t / 8e12, 3),
-                                                                               "note": "actual traffic 28 B/sample: y is written and re-read"}
+                                                                               "note": "one launch, traffic = algorithmic (the unfused pair moved 28 B/sample: y written and re-read)"}
 xr = xc.view(torch.float32)
 dec = G.Decimator(10)
 t = timeit(lambda: dec.process_bulk(xr))
