@@ -313,9 +313,8 @@ __global__ __launch_bounds__(kIirBS) void iir_pass_y(const float* __restrict__ x
 // this block).  Wider look-backs (2 or 4 waves polling 128 / 256 predecessors per round trip, partial sums handed over through LDS)
 // were built and measured SLOWER (212 / 173 vs 255 Gsamples/s): the extra polling traffic lengthens every round trip by more than
 // the saved windows are worth.  Persistent workgroups (tables loaded once, the next tile's ticket and samples prefetched into registers during
-// the re-run) were built too: stage 1.8 -> 0.7 us, but no gain in throughput (253 / 396 vs 260 / 392 Gsamples/s): the ticket must not be
-// drawn before the look-back is over (a ticket held by a block that is still busy makes every successor wait for its Z: 192), and at
-// 168 VGPRs the loop spills around the look-back.
+// the re-run) were built too: stage 1.8 -> 0.7 us, but no gain in throughput (272 / 429 vs 275 / 423 Gsamples/s, spill-free); the ticket must
+// not be drawn before the look-back is over (a ticket held by a block that is still busy makes every successor wait for its Z: 192).
 // Block indices are tickets drawn at the start (a block only ever waits for blocks that already run), status words and ticket are zeroed per call.
 // Waiting is bounded: a waiter that gives up raises err[0] and the span is recomputed by the three-pass kernels.
 struct IirOnePassArgs {
@@ -349,7 +348,9 @@ __device__ __forceinline__ unsigned long long iir_status_get(const unsigned long
 // inclusive scan over the 64 chunks of one wave, in registers:  e(lane) <- sum_{i<=lane} Phi_L^{lane-i} e(i).  No LDS state and no
 // barriers (the block-wide LDS scan above cost 16 barriers and 4.9 us of a 20 us block in the single-pass kernel); the four waves of a
 // block are stitched together afterwards with the same two-table trick that applies T_b.
-template <int MP>
+// A cascade is block lower triangular in its sections (section s sees the states of sections <= s only), and so is every power of Phi:
+// the matrix-vector products of the single-pass kernel skip the structural zeros (40 instead of 64 multiply-adds for four biquads).
+template <int MP, int ORD>
 __device__ __forceinline__ void iir_wave_scan(float (&e)[MP], const float* pl /*LDS [round][MP(j)][MP(i)]: Phi_L^(2^k) transposed*/, int lane) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -362,7 +363,7 @@ __device__ __forceinline__ void iir_wave_scan(float (&e)[MP], const float* pl /*
 #pragma unroll
             for (int j = 0; j < MP; ++j)
 #pragma unroll
-                for (int i = 0; i < MP; ++i) e[i] = fmaf(P[j * MP + i], p[j], e[i]);
+                for (int i = (j / ORD) * ORD; i < MP; ++i) e[i] = fmaf(P[j * MP + i], p[j], e[i]);
         }
     }
 }
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, I
 #pragma unroll
         for (int j = 0; j < ORD; ++j) e[s * ORD + j] = st[s][j];
     IIR_STAMP(2);
-    iir_wave_scan<MP>(e, pl, lane);
+    iir_wave_scan<MP, ORD>(e, pl, lane);
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
         ex[i] = __shfl_up(e[i], 1);
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, I
 #pragma unroll
                 for (int i = 0; i < MP; ++i)
 #pragma unroll
-                    for (int k = 0; k < MP; ++k) v[i] = fmaf(Pl[i * MP + k], z[k], v[i]);
+                    for (int k = 0; k < (i / ORD + 1) * ORD; ++k) v[i] = fmaf(Pl[i * MP + k], z[k], v[i]);
             }
 #pragma unroll
             for (int i = 0; i < MP; ++i) { // wave sum (every lane ends with the total)
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, I
                 const int i = s * ORD + j;
                 float     t = ex[i];
 #pragma unroll
-                for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], w[k], t);
+                for (int k = 0; k < (s + 1) * ORD; ++k) t = fmaf(P[i * MP + k], w[k], t);
                 st[s][j] = t;
             }
     }
