@@ -215,7 +215,8 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     constexpr bool WIN   = MODE == kModeWinMag2 || MODE == kModeWinSmall; // y_f is needed in the time domain and multiplied by a.win
     constexpr bool SMALL = MODE == kModeWinSmall;
     constexpr bool FFTONLY = MODE == kModeFftMag2 || MODE == kModeFftWinMag2; // plain (windowed) transform: no taps, no history, no correction
-    constexpr bool DEFER = MODE == kModeMag2 || FFTONLY;                      // |.|^2 of the previous frame leaves during this frame's phases
+    constexpr bool FIR   = MODE == kModeFir;
+    constexpr bool DEFER = !SMALL;                                           // the previous frame's results leave during this frame's phases
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
     float2* B1 = smem + kSLen;                       // kSLen: (odd frames)
@@ -283,9 +284,9 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     // |Y|^2 of the previous frame waits in registers and leaves in four groups of four stores spread over this frame's phases;
     // likewise the eight DMA pieces per wave of the next frame.  A wave that issues its 16 stores (or 8 DMAs) back to back sits
     // in VMEM issue for ~4000 cycles behind the other waves' requests and every barrier inherits the skew.
-    float pend[16];
+    float pend[16], pendi[16]; // (pendi: imaginary parts, kModeFir only -- y_f is complex)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) pend[q] = 0.f;
+    for (int q = 0; q < 16; ++q) pend[q] = pendi[q] = 0.f;
     long fprev = -1;
     long f   = blockIdx.x;
     int  cur = 0;
@@ -312,10 +313,11 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         // stream the next frame (and the 256 samples before it) into the other buffers: in flight until the next barrier T.
         // Unconditional (the last iteration re-reads its own frame): no divergent paths around the DMA for hipcc's wait insertion
         const long   fn = (f + gridDim.x < a.n_frames) ? f + gridDim.x : f;
-        const rsrc_t rq = make_rsrc(a.out + (fprev < 0 ? 0 : fprev) * kN, fprev < 0 ? 0u : (unsigned)(kN * sizeof(float))); // first iteration: nothing pending, stores fall out of range
+        const rsrc_t rq = make_rsrc(a.out + (fprev < 0 ? 0 : fprev) * kN * (FIR ? 2 : 1), fprev < 0 ? 0u : (unsigned)(kN * sizeof(float) * (FIR ? 2 : 1))); // first iteration: nothing pending, stores fall out of range
 #define GR4_DRAIN(g)                                                                                       \
     do {                                                                                                   \
-        if constexpr (DEFER) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
+        if constexpr (DEFER && FIR) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f2(rq, make_float2(pend[q], pendi[q]), t * 8, q * 4096); } \
+        else if constexpr (DEFER) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
         dma_frame<kDmaAt[g], kDmaAt[(g) + 1]>(a.x + fn * kN, Sn, wave, lane);                              \
     } while (0)
         if constexpr (!FFTONLY) dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
@@ -537,18 +539,16 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                 GR4_LDS_BARRIER();
                 GR4_PHASE_FENCE();
                 passC(S, w, twCr, t);
-                // (no deferred stores here: the 16 registers they would wait in are what this variant does not have)
-                const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float));
     #pragma unroll
-                for (int q = 0; q < 16; ++q) buf_store_f(ro, fmaf(w[perm16(q)].x, w[perm16(q)].x, w[perm16(q)].y * w[perm16(q)].y), t * 4, q * 2048);
+                for (int q = 0; q < 16; ++q) pend[q] = fmaf(w[perm16(q)].x, w[perm16(q)].x, w[perm16(q)].y * w[perm16(q)].y); // stored during the next frame
                 }
             } else { // kModeFir: y_f[n] = conj(.) / N + e[n], complex, straight to HBM
-                const rsrc_t ro = make_rsrc(a.out + f * kN * 2, kN * sizeof(float2));
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     float2 yv = make_float2(w[perm16(q)].x * (1.f / kN), -w[perm16(q)].y * (1.f / kN));
                     if (q == 0 && t < 256) yv = cadd(yv, el[t]);
-                    buf_store_f2(ro, yv, t * 8, q * 4096);
+                    pend[q]  = yv.x; // y_f[t + 512 q], stored during the next frame
+                    pendi[q] = yv.y;
                 }
             }
         }
@@ -557,9 +557,12 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(14);
     }
     if (DEFER && fprev >= 0) {
-        const rsrc_t rq = make_rsrc(a.out + fprev * kN, kN * sizeof(float));
+        const rsrc_t rq = make_rsrc(a.out + fprev * kN * (FIR ? 2 : 1), kN * sizeof(float) * (FIR ? 2 : 1));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) buf_store_f(rq, pend[q], t0 * 4, q * 2048);
+        for (int q = 0; q < 16; ++q) {
+            if constexpr (FIR) buf_store_f2(rq, make_float2(pend[q], pendi[q]), t0 * 8, q * 4096);
+            else buf_store_f(rq, pend[q], t0 * 4, q * 2048);
+        }
     }
 #undef GR4_DRAIN
 }
