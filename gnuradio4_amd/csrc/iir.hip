@@ -316,7 +316,9 @@ __global__ __launch_bounds__(kIirBS) void iir_pass_y(const float* __restrict__ x
 // load covers whole records: 64 memory requests per round instead of 1024, words handed to the owning lane through LDS) and the window sum as a
 // six-level tree with Phi_B^(2^k) from LDS (no per-lane Phi_B^l, 106 VGPRs) left the raw round trip at ~2.5 us -- it is latency, not
 // request count -- while the LDS transposes and the tree lengthen every window; a longer look-back puts the nearest true end state
-// further back (2.3 -> 3.0 windows), which lengthens it again: 256 and 224 instead of 275 Gsamples/s.  Persistent workgroups (tables loaded once, the next tile's ticket and samples prefetched into registers during
+// further back (2.3 -> 3.0 windows), which lengthens it again: 256 and 224 instead of 275 Gsamples/s.  Requesting the NEXT window's words together
+// with this window's first poll (its round trip would be over when the walk gets there): 235 / 374.  Everything that makes a block poll more
+// per round trip has measured slower than the plain 64-lane walk.  Persistent workgroups (tables loaded once, the next tile's ticket and samples prefetched into registers during
 // the re-run) were built too: stage 1.8 -> 0.7 us, but no gain in throughput (272 / 429 vs 275 / 423 Gsamples/s, spill-free); the ticket must
 // not be drawn before the look-back is over (a ticket held by a block that is still busy makes every successor wait for its Z: 192).
 // Block indices are tickets drawn at the start (a block only ever waits for blocks that already run), status words and ticket are zeroed per call.
