@@ -3,7 +3,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import gnuradio4_amd as G
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 n = 1 << 27
 x = G.synth_c32(n, seed=5)
 taps = (np.hamming(256) / np.hamming(256).sum()).astype(np.float32)
@@ -18,6 +17,6 @@ ch = G.Chain(taps, 8192, "Hann"); m2 = torch.empty((n // 8192, 8192), dtype=torc
 print("chain 256 taps -> 8192 Hann -> mag2: %.1f Gsamples/s" % rate(lambda: ch.process_bulk(x, m2)))
 ch0 = G.Chain(taps, 8192, "None")
 print("chain 256 taps -> 8192 None -> mag2: %.1f Gsamples/s" % rate(lambda: ch0.process_bulk(x, m2)))
-f = G.fir_filter(taps, dtype=torch.complex64) if "dtype" in G.fir_filter.__init__.__code__.co_varnames else G.fir_filter(taps)
+f = G.fir_filter(taps, dtype=torch.complex64)
 y = torch.empty_like(x)
 print("fir_filter<complex<float>> 256 taps: %.1f Gsamples/s" % rate(lambda: f.process_bulk(x, y)))
