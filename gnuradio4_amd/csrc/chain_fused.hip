@@ -209,13 +209,16 @@ __device__ __forceinline__ void passA_inplace(float2* S, const float2 (&twA)[16]
 // fftSize-point transforms of the block (the compile-time 16 x 16 x R3 plan of the FFT block kernels, fft_radix.hpp, on the LDS image).
 // MODE 4 / 5 (kModeFftMag2 / kModeFftWinMag2): no filter at all -- the FFT block's |X|^2 output at fftSize 8192 (gr4hip_fft_mag2) on this kernel's frame pipeline:
 // the next frame streams in by LDS-DMA while this one is transformed, which the load -> transform -> store body of fft_fast_kernel cannot do.
-enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2, kModeWinSmall = 3, kModeFftMag2 = 4, kModeFftWinMag2 = 5 };
+// MODE 6 / 7 (kModeFftSpec / kModeFftWinSpec): the same plain transform, the complex spectrum itself as output (gr4hip_fft_spectrum).
+enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2, kModeWinSmall = 3, kModeFftMag2 = 4, kModeFftWinMag2 = 5, kModeFftSpec = 6, kModeFftWinSpec = 7 };
 template <int MODE, int LOG2NF = 13>
 __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     constexpr bool WIN   = MODE == kModeWinMag2 || MODE == kModeWinSmall; // y_f is needed in the time domain and multiplied by a.win
     constexpr bool SMALL = MODE == kModeWinSmall;
-    constexpr bool FFTONLY = MODE == kModeFftMag2 || MODE == kModeFftWinMag2; // plain (windowed) transform: no taps, no history, no correction
-    constexpr bool FIR   = MODE == kModeFir;
+    constexpr bool FFTONLY = MODE == kModeFftMag2 || MODE == kModeFftWinMag2 || MODE == kModeFftSpec || MODE == kModeFftWinSpec; // plain (windowed) transform: no taps, no history, no correction
+    constexpr bool FFTWIN  = MODE == kModeFftWinMag2 || MODE == kModeFftWinSpec;
+    constexpr bool SPEC    = MODE == kModeFftSpec || MODE == kModeFftWinSpec;
+    constexpr bool FIR   = MODE == kModeFir || SPEC;                           // complex output (y_f, or the spectrum): 8 bytes per sample
     constexpr bool DEFER = !SMALL;                                           // the previous frame's results leave during this frame's phases
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     if constexpr (WIN) twBl[t0] = a.twB[t0]; // [16][32] = 512 entries
 
     float wA[16]; // kModeFftWinMag2: window of the samples pass A reads, row 2 m + par of column n0 = sample (2 m + par) 256 + n0
-    if constexpr (MODE == kModeFftWinMag2) {
+    if constexpr (FFTWIN) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) wA[m] = a.win[(2 * m + (t0 & 1)) * 256 + (t0 >> 1)];
     }
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             float2 v[16];
 #pragma unroll
             for (int m = 0; m < 16; ++m) v[m] = S[addrA(2 * m + par, n0)];
-            if constexpr (MODE == kModeFftWinMag2) {
+            if constexpr (FFTWIN) {
 #pragma unroll
                 for (int m = 0; m < 16; ++m) v[m] = make_float2(v[m].x * wA[m], v[m].y * wA[m]);
             }
@@ -447,7 +450,10 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(9);
         GR4_DRAIN(7);
 
-        if constexpr (FFTONLY) {
+        if constexpr (SPEC) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { pend[q] = X[perm16(q)].x; pendi[q] = X[perm16(q)].y; } // X[t + 512 q], stored during the next frame
+        } else if constexpr (FFTONLY) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) pend[q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y); // |X[t + 512 q]|^2, stored during the next frame
         } else if constexpr (MODE == kModeMag2) {
@@ -663,7 +669,7 @@ int chain_fused_reset(ChainFused* c) {
 // hist256 == nullptr: the chain's own carried history (updated after the launch); otherwise 256 complex samples preceding d_in, and
 // the output is the filtered stream itself (complex) instead of |FFT|^2
 static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st, bool fir_mode, bool carry_hist,
-                           bool fft_only = false, const float* fft_window = nullptr) {
+                           bool fft_only = false, const float* fft_window = nullptr, bool fft_spectrum = false) {
     ChainFdArgs a{};
     a.x        = reinterpret_cast<const float2*>(d_in);
     a.hist     = hist256 ? reinterpret_cast<const float2*>(hist256) : static_cast<const float2*>(c->d_hist.ptr);
@@ -696,6 +702,8 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftSpec>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftWinSpec>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
@@ -705,7 +713,9 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     }
     const size_t   wgs  = c->max_wg ? std::min<size_t>(c->max_wg, (size_t)n_cu) : (size_t)n_cu;
     const unsigned grid = (unsigned)std::min<size_t>(n_frames, wgs); // one resident workgroup per CU (or fewer: gr4hip_chain_set_max_workgroups)
-    if (fft_only && fft_window) hipLaunchKernelGGL(chain_fd_kernel<kModeFftWinMag2>, dim3(grid), dim3(kT), lds, st, a);
+    if (fft_only && fft_spectrum && fft_window) hipLaunchKernelGGL(chain_fd_kernel<kModeFftWinSpec>, dim3(grid), dim3(kT), lds, st, a);
+    else if (fft_only && fft_spectrum) hipLaunchKernelGGL(chain_fd_kernel<kModeFftSpec>, dim3(grid), dim3(kT), lds, st, a);
+    else if (fft_only && fft_window) hipLaunchKernelGGL(chain_fd_kernel<kModeFftWinMag2>, dim3(grid), dim3(kT), lds, st, a);
     else if (fft_only) hipLaunchKernelGGL(chain_fd_kernel<kModeFftMag2>, dim3(grid), dim3(kT), lds, st, a);
     else if (fir_mode) hipLaunchKernelGGL(chain_fd_kernel<kModeFir>, dim3(grid), dim3(kT), lds, st, a);
     else if (c->small_log2n == 8) hipLaunchKernelGGL((chain_fd_kernel<kModeWinSmall, 8>), dim3(grid), dim3(kT), lds, st, a);
@@ -748,6 +758,11 @@ int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float
 int chain_fused_fft_mag2(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, const float* d_window, hipStream_t st) {
     GR4_REQUIRE(c->small_log2n == 0, "chain_fused_fft_mag2: needs an 8192-point plan");
     return chain_fused_run(c, d_in, nullptr, n_frames, d_mag2, st, false, false, true, d_window);
+}
+// FFT_8192(window x frame) itself (interleaved re, im) on the same pipeline
+int chain_fused_fft_spectrum(ChainFused* c, const float* d_in, size_t n_frames, float* d_spectrum, const float* d_window, hipStream_t st) {
+    GR4_REQUIRE(c->small_log2n == 0, "chain_fused_fft_spectrum: needs an 8192-point plan");
+    return chain_fused_run(c, d_in, nullptr, n_frames, d_spectrum, st, false, false, true, d_window, true);
 }
 int chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_y, hipStream_t st) {
     GR4_REQUIRE(d_hist256 && c->small_log2n == 0, "chain_fused_fir: needs a history and an 8192-point plan");

@@ -248,6 +248,7 @@ namespace gr4 { // chain_fused.hip
 struct ChainFused;
 int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
 int  chain_fused_fft_mag2(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, const float* d_window, hipStream_t st);
+int  chain_fused_fft_spectrum(ChainFused* c, const float* d_in, size_t n_frames, float* d_spectrum, const float* d_window, hipStream_t st);
 void chain_fused_destroy(ChainFused* c);
 } // namespace gr4
 
@@ -522,8 +523,26 @@ int gr4hip_fft_process(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float
     return fft_run(f, d_in, n_frames, o, d_phase, d_ranges, stream);
 }
 
+// 8192-point complex frames, >= one frame per CU: |X|^2 and the raw spectrum run on the frame pipeline of the fused chain kernel without its filter
+// (LDS-DMA prefetch of the next frame during the transform of this one); everything else goes to the FFT block kernels
+static bool fft_on_frame_pipeline(const gr4hip_fft_t* f, size_t n_frames) {
+    return f->N == 8192 && f->in_dtype == GR4HIP_C32 && f->kind == 0 && n_frames >= 256 && !std::getenv("GR4HIP_FFT_NO_PIPELINE");
+}
+static int fft_pipe(gr4hip_fft_t* f) {
+    if (f->pipe) return GR4HIP_OK;
+    const float one = 1.f;
+    return gr4::chain_fused_create(&f->pipe, &one, 1, 8192, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
+}
+
 int gr4hip_fft_spectrum(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float* d_spectrum, gr4hip_stream_t stream) {
     GR4_REQUIRE(d_spectrum || n_frames == 0, "fft_spectrum: null output");
+    GR4_REQUIRE(f, "fft_spectrum: null handle");
+    if (fft_on_frame_pipeline(f, n_frames)) {
+        int rc = fft_pipe(f);
+        if (rc) return rc;
+        const bool windowed = f->window != GR4HIP_WIN_NONE && f->window != GR4HIP_WIN_RECTANGULAR;
+        return gr4::chain_fused_fft_spectrum(f->pipe, static_cast<const float*>(d_in), n_frames, d_spectrum, windowed ? static_cast<const float*>(f->d_window.ptr) : nullptr, as_stream(stream));
+    }
     FftOutputs o{};
     o.spectrum = d_spectrum;
     return fft_run(f, d_in, n_frames, o, nullptr, nullptr, stream);
@@ -536,12 +555,9 @@ int gr4hip_fft_mag2(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float* d
     GR4_REQUIRE(f, "fft_mag2: null handle");
     // 8192-point complex frames, >= one frame per CU: the frame pipeline of the fused chain kernel without its filter (LDS-DMA prefetch of the next
     // frame during the transform of this one); everything else goes to the FFT block kernels
-    if (f->N == 8192 && f->in_dtype == GR4HIP_C32 && f->kind == 0 && n_frames >= 256 && !std::getenv("GR4HIP_FFT_NO_PIPELINE")) {
-        if (!f->pipe) {
-            const float one = 1.f;
-            int rc = gr4::chain_fused_create(&f->pipe, &one, 1, 8192, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
-            if (rc) return rc;
-        }
+    if (fft_on_frame_pipeline(f, n_frames)) {
+        int rc = fft_pipe(f);
+        if (rc) return rc;
         const bool windowed = f->window != GR4HIP_WIN_NONE && f->window != GR4HIP_WIN_RECTANGULAR;
         return gr4::chain_fused_fft_mag2(f->pipe, static_cast<const float*>(d_in), n_frames, d_mag2, windowed ? static_cast<const float*>(f->d_window.ptr) : nullptr, as_stream(stream));
     }

@@ -381,6 +381,29 @@ def test_fft_mag2_frame_pipeline(G, N, window, monkeypatch):
         assert _rel(got[f].cpu().numpy(), truth) <= TOL, f
 
 
+@pytest.mark.parametrize("window", ["None", "Hann"])
+def test_fft_spectrum_frame_pipeline(G, window, monkeypatch):
+    """the raw spectrum of >= 256 frames of 8192 complex samples takes the same frame pipeline (complex output): same numbers as the FFT block
+    kernel to float rounding, and the float64 oracle's on sampled frames; 255 frames stay on the block kernel"""
+    N, frames = 8192, 301
+    x = G.synth_c32(frames * N, seed=23)
+    got = G.FFT(N, window).spectrum(x)
+    monkeypatch.setenv("GR4HIP_FFT_NO_PIPELINE", "1")
+    ref = G.FFT(N, window).spectrum(x)
+    monkeypatch.delenv("GR4HIP_FFT_NO_PIPELINE")
+    floor = ref.abs().pow(2).mean(dim=1, keepdim=True).sqrt()
+    assert float(((got - ref).abs() / torch.maximum(ref.abs(), floor)).max()) <= TOL
+    few = G.FFT(N, window).spectrum(x[: 255 * N])
+    assert torch.equal(few, ref[:255])
+    wid = [w.lower() for w in O.WINDOWS].index(window.lower())
+    xs = x.cpu().numpy()
+    for f in (0, 255, 256, frames - 1):
+        fr = xs[f * N:(f + 1) * N].astype(np.complex128)
+        if wid > 1:
+            fr = fr * O.window(wid, N, np.float32).astype(np.float64)
+        assert _rel(got[f].cpu().numpy(), O.dft64(fr)) <= TOL, f
+
+
 @pytest.mark.parametrize("N", [3, 5, 12, 100, 1000, 1009, 3000, 4095])
 def test_fft_any_size_bluestein(G, N):
     """sizes that are not a power of two (the reference's Bluestein branch, algorithm/.../fourier/fft.hpp:353-381), <= 4096"""

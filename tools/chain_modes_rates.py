@@ -20,3 +20,7 @@ print("chain 256 taps -> 8192 None -> mag2: %.1f Gsamples/s" % rate(lambda: ch0.
 f = G.fir_filter(taps, dtype=torch.complex64)
 y = torch.empty_like(x)
 print("fir_filter<complex<float>> 256 taps: %.1f Gsamples/s" % rate(lambda: f.process_bulk(x, y)))
+F = G.FFT(8192, "Hann"); sp = torch.empty((n // 8192, 8192), dtype=torch.complex64, device="cuda")
+print("FFT block 8192 Hann -> complex spectrum: %.1f Gsamples/s" % rate(lambda: F.spectrum(x, sp)))
+os.environ["GR4HIP_FFT_NO_PIPELINE"] = "1"
+print("   block kernel (GR4HIP_FFT_NO_PIPELINE): %.1f Gsamples/s" % rate(lambda: F.spectrum(x, sp)))
