@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     constexpr bool FFTWIN  = MODE == kModeFftWinMag2 || MODE == kModeFftWinSpec;
     constexpr bool SPEC    = MODE == kModeFftSpec || MODE == kModeFftWinSpec;
     constexpr bool FIR   = MODE == kModeFir || SPEC;                           // complex output (y_f, or the spectrum): 8 bytes per sample
-    constexpr bool DEFER = !SMALL;                                           // the previous frame's results leave during this frame's phases
+    constexpr bool DEFER = true;                                             // the previous frame's results leave during this frame's phases
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
     float2* B1 = smem + kSLen;                       // kSLen: (odd frames)
@@ -320,6 +320,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #define GR4_DRAIN(g)                                                                                       \
     do {                                                                                                   \
         if constexpr (DEFER && FIR) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f2(rq, make_float2(pend[q], pendi[q]), t * 8, q * 4096); } \
+        else if constexpr (DEFER && SMALL) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], ((t / TF) * NF + t % TF) * 4, q * TF * 4); } \
         else if constexpr (DEFER) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
         dma_frame<kDmaAt[g], kDmaAt[(g) + 1]>(a.x + fn * kN, Sn, wave, lane);                              \
     } while (0)
@@ -525,9 +526,8 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                     float2 b2a = sw2a, b2b = sw2b, b3 = sw3, b3sq = sw3sq; // opaque per iteration (see fft_kernels.hpp: the power chains would be hoisted)
                     asm volatile("" : "+v"(b2a.x), "+v"(b2a.y), "+v"(b2b.x), "+v"(b2b.y), "+v"(b3.x), "+v"(b3.y), "+v"(b3sq.x), "+v"(b3sq.y));
                     fft_small_passes<LOG2NF>(v, fb, tt, b2a, b2b, b3, b3sq, Xs, [] { GR4_LDS_BARRIER(); });
-                    const rsrc_t ro = make_rsrc(a.out + f * kN, kN * sizeof(float)); // frame (8192 / NF) f + fl, bin tt + j TF
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) buf_store_f(ro, fmaf(Xs[j].x, Xs[j].x, Xs[j].y * Xs[j].y), (fl * NF + tt) * 4, j * TF * 4);
+                    for (int j = 0; j < 16; ++j) pend[j] = fmaf(Xs[j].x, Xs[j].x, Xs[j].y * Xs[j].y); // frame (8192 / NF) f + fl, bin tt + j TF: stored during the next block
                 } else {
     #pragma unroll
                 for (int q = 0; q < 16; ++q) S[addrA((t >> 8) + 2 * q, t & 255)] = yw[q];
@@ -567,6 +567,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if constexpr (FIR) buf_store_f2(rq, make_float2(pend[q], pendi[q]), t0 * 8, q * 4096);
+            else if constexpr (SMALL) buf_store_f(rq, pend[q], ((t0 / TF) * NF + t0 % TF) * 4, q * TF * 4);
             else buf_store_f(rq, pend[q], t0 * 4, q * 2048);
         }
     }
