@@ -3,11 +3,18 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one batch: a 2^30-sample complex<float> stream already resident in HBM
--> 256-tap FIR -> 8192-point FFT frames -> |X|^2 (BASELINE.json configs[1]; rectangular window).
-N > 1 (configs[4] shape): every rank owns one SDR channel of the same size (weak scaling) and the per-frame spectra
-are summed over channels by an RCCL reduce_scatter that overlaps the next chunk's compute.
-Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM.
+
+  N = 1 (BASELINE.json configs[1]): ONE 2^30-sample complex<float> stream -> 256-tap FIR -> 8192-point FFT frames -> |X|^2
+        (rectangular window), 4 launches of 2^28 samples, FIR history carried between launches.
+  N > 1 (configs[4]): the 8-channel graph.  8 independent SDR channels of 2^30 samples each, channel c on
+        rank c mod N (8/N channels per GPU, each with its own chain handle and HIP stream), the combiner math::Add<float> with
+        n_inputs = 8 (blocks/math/.../Math.hpp:73-108) as a local n-ary fold on every GPU followed by ONE exchange step per launch:
+        an RCCL reduce_scatter(sum) of the per-frame spectra, asynchronous, overlapping the next chunk's transforms.
+        Total work is fixed (8 channels) whatever N: strong scaling.  `--channels 8` runs the same graph on one GPU.
+
+After the timed region a self-check pulls sampled output frames back and compares them with the float64 oracle on the same
+device-generated input (checker only; exit code 3 above 1e-5).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -21,6 +28,10 @@ sys.path.insert(0, ROOT)
 NTAPS, NFFT = 256, 8192
 ALGO_BYTES_PER_SAMPLE = 12.0  # 8 B complex<float> in + 4 B float mag2 out (fused lower bound)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_LINK_GBS = 153.0         # per link and direction (7 links per GPU), nominal
+PARITY_TOL = 1e-5             # BASELINE.json north_star: <= 1e-5 rel for float32 FIR/FFT
+KERNEL_SYMBOLS = {1: "gr4::fir_poly_kernel + gr4::fft_fast_kernel (unfused)", 3: "gr4::chain_fd_kernel<0, 13>",
+                  4: "gr4::fir_poly_kernel + gr4::fft_fast_kernel (time domain)"}
 
 
 def _usable_cores() -> int:
@@ -39,13 +50,16 @@ def _usable_cores() -> int:
     return n
 
 
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    return O
+
+
 def cpu_baseline(target_seconds: float = 12.0):
     """Reference-faithful CPU path (oracle, -O3 -march=native like core/benchmarks/CMakeLists.txt:19-23) on a bounded
     sample of the same workload.  Single chain == one thread (GR4 never splits one block chain across threads)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-
-    import oracle_lib as O
+    O = _oracle()
     L = O.lib(fast=True)
     b = O.design_taps_hamming_lowpass(NTAPS, 0.1)
     x = O.signal_c32(42, 8 * NFFT)
@@ -77,19 +91,39 @@ def cpu_baseline(target_seconds: float = 12.0):
     return res
 
 
+def _rel_err(got, truth):
+    """the parity metric of tests/test_gpu_parity.py::_rel: relative above the rms level, rms-normalised below it"""
+    import numpy as np
+    truth = np.asarray(truth, np.float64)
+    scale = np.maximum(np.abs(truth), np.sqrt(np.mean(truth ** 2)))
+    return float(np.max(np.abs(np.asarray(got, np.float64) - truth) / scale))
+
+
+def oracle_frame(O, taps, x_dev, f):
+    """float64 oracle |FFT(fir(x))|^2 of frame f of one channel: frames f-1 and f go through the oracle chain (255 samples of
+    history are all a 256-tap FIR needs; frame 0 starts from the zero history the bench resets to)."""
+    lo = max(f - 1, 0)
+    xs = x_dev[lo * NFFT:(f + 1) * NFFT].cpu().numpy()
+    out, _ = O.chain(taps, xs, NFFT, 0, truth=True)
+    return out.reshape(-1, NFFT)[f - lo]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--log2-samples", type=int, default=30, help="stream length per step and rank (default 2^30 = configs[1])")
+    ap.add_argument("--channels", type=int, default=0, help="SDR channels in the graph: 0 = 1 at --gpus 1 (configs[1]) and 8 at --gpus N > 1 (configs[4])")
+    ap.add_argument("--log2-samples", type=int, default=30, help="stream length per step and channel (default 2^30 = configs[1])")
     ap.add_argument("--log2-chunk", type=int, default=28, help="samples per launch")
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 unfused, 2 fused time-domain, 3 fused frequency-domain")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 unfused, 3 fused frequency-domain, 4 time domain")
     ap.add_argument("--fanin-cus", type=int, default=32, help="N > 1: CUs left to the RCCL fan-in kernels (the fused kernel is persistent and fills every CU it gets)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check of the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of sampled output frames")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -108,46 +142,78 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
+    n_channels = args.channels or (1 if world == 1 else 8)
+    plan = fanin.channel_plan(n_channels, world)
+    mine = plan[rank]  # channels this rank owns
+    combine = n_channels > 1
     n = 1 << args.log2_samples
     chunk = min(1 << args.log2_chunk, n)
     nchunks = n // chunk
     frames_per_chunk = chunk // NFFT
+    assert frames_per_chunk % world == 0, "frames per launch must split evenly over the ranks (reduce_scatter shards)"
 
     # synthetic input, generated on the device (noise seed 42 + channel index, tone at 0.1 fs)
-    x = G.synth_c32(n, seed=42 + rank)
-    out = torch.empty((n // NFFT, NFFT), dtype=torch.float32, device="cuda")
-    # fan-in result: this rank's shard of the channel-summed spectra, one slab per launch
+    xs = [G.synth_c32(n, seed=42 + c) for c in mine]
+    outs = [torch.empty((n // NFFT, NFFT), dtype=torch.float32, device="cuda") for _ in mine]
+    # combiner output of this rank: the local fold of its channels per launch (double-buffered: the collective of launch c reads
+    # slab c & 1 while the fold of launch c + 1 writes the other) and its shard of the all-channel sum of every launch
+    acc = torch.empty((2, frames_per_chunk, NFFT), dtype=torch.float32, device="cuda") if combine and len(mine) > 1 else None
     rs_out = torch.empty((nchunks, frames_per_chunk // world, NFFT), dtype=torch.float32, device="cuda") if world > 1 else None
-    import numpy as np
-    k = np.arange(NTAPS, dtype=np.float64)
+    sum_out = torch.empty((n // NFFT, NFFT), dtype=torch.float32, device="cuda") if combine and world == 1 else None
+
     w = np.empty(NTAPS, np.float32)
     capi.check(capi.lib().gr4hip_window_create(2, w.ctypes.data, NTAPS, 1.6), "window")
+    k = np.arange(NTAPS, dtype=np.float64)
     taps = (w.astype(np.float64) * 0.2 * np.sinc(0.2 * (k - (NTAPS - 1) / 2.0)))
     taps = (taps / taps.sum()).astype(np.float32)  # Hamming windowed-sinc, fc = 0.1, DC gain 1
-    chain = G.Chain(taps, NFFT, "None", args.algo)
-    if world > 1 and args.fanin_cus > 0:  # the collective of chunk c runs beside the transform of chunk c+1 instead of behind it
-        n_cu = torch.cuda.get_device_properties(local).multi_processor_count
-        chain.set_max_workgroups(max(1, n_cu - args.fanin_cus))
+    chains = [G.Chain(taps, NFFT, "None", args.algo) for _ in mine]
+    streams = [torch.cuda.Stream() for _ in mine] if len(mine) > 1 else [torch.cuda.current_stream()]
+    n_cu = torch.cuda.get_device_properties(local).multi_processor_count
+    if world > 1 and args.fanin_cus > 0:  # the collective of chunk c runs beside the transforms of chunk c+1 instead of behind them
+        for ch in chains:
+            ch.set_max_workgroups(max(1, n_cu - args.fanin_cus))
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nchunks)]
-    kernel_ms = []
+    done = [[torch.cuda.Event() for _ in mine] for _ in range(2)]
+    main_stream = torch.cuda.current_stream()
 
     def step(record: bool):
-        chain.reset()
+        for ch in chains:
+            ch.reset()
+        if len(mine) > 1:  # a channel stream must not overwrite a slice the previous step's fold still reads
+            for s in streams:
+                s.wait_stream(main_stream)
         works = []
         for c in range(nchunks):
-            xs = x[c * chunk:(c + 1) * chunk]
-            os_ = out[c * frames_per_chunk:(c + 1) * frames_per_chunk]
-            if record:
-                ev[c][0].record()
-            chain.process_bulk(xs, os_)
-            if record:
-                ev[c][1].record()
-            if world > 1:  # fan-in combiner (math::Add over channels) as reduce_scatter, async on RCCL's stream
-                works.append(fanin.fan_in_sum(os_, rs_out[c], async_op=True)[1])
+            fr = slice(c * frames_per_chunk, (c + 1) * frames_per_chunk)
+            for i, ch in enumerate(chains):  # every channel on its own stream
+                with torch.cuda.stream(streams[i]):
+                    if record and i == 0:
+                        ev[c][0].record()  # on the stream the kernel is launched on
+                    ch.process_bulk(xs[i][c * chunk:(c + 1) * chunk], outs[i][fr])
+                    if record and i == 0:
+                        ev[c][1].record()
+                    if len(mine) > 1:
+                        done[c & 1][i].record()
+            if not combine:
+                continue
+            if len(mine) > 1:  # local part of math::Add over the channels: ONE n-ary fold (left fold order, Math.hpp:100-107)
+                for e in done[c & 1]:
+                    main_stream.wait_event(e)
+                if world > 1 and c >= 2 and works[c - 2] is not None:
+                    works[c - 2].wait()  # the collective that read this slab two launches ago
+                dst = sum_out[fr] if world == 1 else acc[c & 1]
+                G.math_nary("Add", [o[fr] for o in outs], out=dst)
+            else:
+                dst = outs[0][fr]
+            if world > 1:  # the one exchange step: reduce_scatter(sum) of this launch's spectra, async on RCCL's stream
+                works.append(fanin.fan_in_sum(dst, rs_out[c], async_op=True)[1])
         for wk in works:
             if wk is not None:
                 wk.wait()
+        if len(mine) > 1:
+            for s in streams:
+                main_stream.wait_stream(s)
 
     def fence():
         if world > 1:
@@ -163,45 +229,92 @@ def main():
         # event times are read after the timed region
     fence()
     dt = time.perf_counter() - t0
-    for a, b_ in ev:  # last step's launches (all steps are identical work)
-        kernel_ms.append(a.elapsed_time(b_))
+    kernel_ms = [a.elapsed_time(b_) for a, b_ in ev]  # last step's launches of this rank's first channel (all steps are identical work)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- self-check (outside the timed region): sampled frames of the last step against the float64 oracle on the same input
+    verify = None
+    if not args.no_verify:
+        O = _oracle()
+        errs = []
+        lastf = n // NFFT - 1
+        cand = sorted({0, 1, 255, 256, frames_per_chunk - 1, frames_per_chunk, min(lastf, 3 * frames_per_chunk + 4097), lastf} & set(range(lastf + 1)))
+        if not combine or world == 1:  # per-channel spectra of this rank (and, for the one-GPU graph, their sum)
+            for i in range(len(mine)):
+                for f in (cand if i == 0 else cand[:2]):
+                    errs.append(_rel_err(outs[i][f].cpu().numpy(), oracle_frame(O, taps, xs[i], f)))
+            if combine:
+                for f in cand[:3]:
+                    truth = sum(oracle_frame(O, taps, xs[i], f) for i in range(len(mine)))
+                    errs.append(_rel_err(sum_out[f].cpu().numpy(), truth))
+        elif rank == 0:  # the reduced shard of rank 0: regenerate every channel's stream (deterministic by seed), sum the oracle spectra
+            per = frames_per_chunk // world
+            picks = sorted({(0, 0), (0, 1), (0, per - 1), (nchunks - 1, per // 2)})
+            truth = {p: 0.0 for p in picks}
+            for c in range(n_channels):
+                xc = xs[mine.index(c)] if c in mine else G.synth_c32(n, seed=42 + c)
+                for (ck, j) in picks:
+                    truth[(ck, j)] = truth[(ck, j)] + oracle_frame(O, taps, xc, ck * frames_per_chunk + j)  # rank 0 owns frames [0, per) of every launch
+                del xc
+            for (ck, j) in picks:
+                errs.append(_rel_err(rs_out[ck, j].cpu().numpy(), truth[(ck, j)]))
+        if errs:
+            verify = {"verified_frames": len(errs), "max_rel_err": float(f"{max(errs):.3e}"), "tolerance": PARITY_TOL,
+                      "metric": "max |gpu - f64 oracle| / max(|oracle|, rms(oracle)) per frame (tests/test_gpu_parity.py::_rel)"}
+
+    rc = 0
     if rank == 0:
-        total_samples = float(n) * world * args.steps
+        total_samples = float(n) * n_channels * args.steps
         value = total_samples / dt / 1e6
         launch_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = chunk * ALGO_BYTES_PER_SAMPLE / (launch_ms * 1e-3) / 1e9
-        algo_names = {1: "fir_poly_kernel + fft_block_kernel (unfused)", 2: "chain_fused_td_kernel", 3: "chain_fused_fd_kernel"}
-        traffic = None  # HBM bytes per launch from the committed PMC profile of the same kernel + launch size (profiles/), else null
+        algo = chains[0].algo
+        committed = None  # HBM bytes per launch from the committed PMC profile of the same kernel + launch size (profiles/); this run does not measure it
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-            if prof.get("kernel") == algo_names.get(chain.algo) and prof.get("samples_per_launch") == chunk:
-                traffic = prof["hbm_bytes_per_launch"]
+            if prof.get("kernel") == KERNEL_SYMBOLS.get(algo) and prof.get("samples_per_launch") == chunk:
+                committed = prof["hbm_bytes_per_launch"]
         except Exception:
             pass
+        per_gpu = len(mine)
+        graph = (f"; {n_channels}-channel graph: {per_gpu} channel(s) per GPU on own streams, math::Add fold on device"
+                 + (f", {'RCCL reduce_scatter' if args.dist_backend == 'nccl' else args.dist_backend + ' all_reduce (functional check only)'} fan-in per launch (configs[4])" if world > 1 else " (one GPU, no collective)")) if combine else ""
         res = {
             "metric": "Msamples/s through 256-tap cplx FIR->8192-pt FFT chain; %HBM roofline @1/2/4/8 GPU",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if combine else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, 2^{args.log2_samples}-sample stream per GPU "
-                                   f"(BASELINE.json configs[1]), rectangular window, {nchunks} launches of 2^{args.log2_chunk} samples"
-                                   + (f"; {world} channels, {'RCCL reduce_scatter' if args.dist_backend == 'nccl' else args.dist_backend + ' all_reduce (functional check only)'} fan-in sum (configs[4] shape)" if world > 1 else ""),
-                       "chain_algo": algo_names.get(chain.algo, str(chain.algo)), "parallelism": f"{world} independent channel(s), 1 per GPU"},
+            "config": {"workload": f"complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, 2^{args.log2_samples}-sample stream per channel "
+                                   f"(BASELINE.json configs[{4 if combine else 1}]), rectangular window, {nchunks} launches of 2^{args.log2_chunk} samples per channel" + graph,
+                       "chain_algo": KERNEL_SYMBOLS.get(algo, str(algo)), "channels": n_channels,
+                       "parallelism": f"{n_channels} independent channel(s), {per_gpu} per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": algo_names.get(chain.algo, str(chain.algo)),
+                         "traffic": None, "traffic_from_committed_profile": committed, "kernel": KERNEL_SYMBOLS.get(algo, str(algo)),
                          "algorithmic_bytes_per_launch": chunk * ALGO_BYTES_PER_SAMPLE, "avg_launch_ms": round(launch_ms, 4),
-                         "frac_of_measured_copy_rate": round(achieved / 6290.0, 4)},  # 6.29 TB/s: what a float4 copy reaches on this part (MI355X_MICROARCH.md)
+                         "frac_of_measured_copy_rate": round(achieved / 6290.0, 4),  # 6.29 TB/s: what a float4 copy reaches on this part (MI355X_MICROARCH.md)
+                         "whole_job_frac_per_gpu": round(value * 1e6 * ALGO_BYTES_PER_SAMPLE / world / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world > 1:  # SURVEY.md 8(e) / DESIGN.md 5: what the fan-in allows at the nominal link rate
+            # after the local fold a GPU holds ONE partial-sum stream for its per_gpu channels; the reduce_scatter sends (N-1)/N of it
+            # out, 1/N to each peer over that peer's link: 4 B x (N-1)/N per frame bin = per per_gpu input samples
+            egress = 4.0 * (world - 1) / world / per_gpu
+            res["fanin"] = {"collective": "reduce_scatter(sum, f32)" if args.dist_backend == "nccl" else f"{args.dist_backend} all_reduce + slice (functional check)",
+                            "xgmi_egress_bytes_per_input_sample": round(egress, 4),
+                            "xgmi_ceiling_msamples": round(world * (world - 1) * XGMI_LINK_GBS * 1e9 / egress / 1e6, 1),
+                            "note": "ceiling = N GPUs x (N-1) links x 153 GB/s nominal per direction / egress bytes per input sample; the collective of launch c overlaps the transforms of launch c+1"}
+        if verify:
+            res["verify"] = verify
+            if not (verify["max_rel_err"] <= PARITY_TOL):
+                rc = 3
+        if world == 1 and not combine and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

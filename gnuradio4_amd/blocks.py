@@ -323,15 +323,19 @@ def math_const(op, x: torch.Tensor, value) -> torch.Tensor:
     return out
 
 
-def math_nary(op, inputs: Sequence[torch.Tensor]) -> torch.Tensor:
-    """MathOpMultiPortImpl<T,op>::processBulk (Math.hpp:100-107): Add / Subtract / Multiply / Divide over n_inputs."""
+def math_nary(op, inputs: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MathOpMultiPortImpl<T,op>::processBulk (Math.hpp:100-107): Add / Subtract / Multiply / Divide over n_inputs.
+    `out` (optional): a contiguous device tensor of the inputs' dtype and length that receives the result."""
     ins = [_dev(t, "math_nary") for t in inputs]
     if not 1 <= len(ins) <= 32:
         raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "math_nary", "n_inputs must be in [1, 32] (Math.hpp:90)")
     if any(t.dtype != ins[0].dtype or t.numel() != ins[0].numel() for t in ins):
         raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "math_nary", "all inputs need the same dtype and length")
     ptrs = (C.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
-    out = torch.empty_like(ins[0])
+    if out is None:
+        out = torch.empty_like(ins[0])
+    elif not out.is_cuda or not out.is_contiguous() or out.dtype != ins[0].dtype or out.numel() != ins[0].numel():
+        raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "math_nary", "out must be a contiguous device tensor of the inputs' dtype and length")
     check(lib().gr4hip_math_nary(_OPS.get(op, op), _DTYPE_ID[ins[0].dtype], ptrs, len(ins), out.data_ptr(), out.numel(), _stream()), "math_nary")
     return out
 

@@ -28,9 +28,13 @@ def shard_frames(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def local_sum(channels: List[torch.Tensor]) -> torch.Tensor:
-    """left fold over the channels a rank owns -- the order of MathOpMultiPortImpl::processBulk (Math.hpp:100-107)."""
-    acc = channels[0].clone()
+def local_sum(channels: List[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """left fold over the channels a rank owns -- the order of MathOpMultiPortImpl::processBulk (Math.hpp:100-107).
+    Device tensors take the library's one-pass n-ary kernel (gr4hip_math_nary); host tensors (CPU tests) the same fold in torch."""
+    if channels[0].is_cuda:
+        from .blocks import math_nary
+        return math_nary("Add", channels, out=out)
+    acc = channels[0].clone() if out is None else out.copy_(channels[0])
     for c in channels[1:]:
         acc += c
     return acc
@@ -44,9 +48,9 @@ def fan_in_sum(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=No
     lo, hi = shard_frames(local.shape[0], world, rank)
     if out is None:
         out = torch.empty((hi - lo,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if dist.get_backend(group) == "gloo":  # CPU test path: same result, different collective
-        tmp = local.clone()
-        work = dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group, async_op=False)
+    if dist.get_backend(group) == "gloo":  # functional path (CPU tests, several ranks on one GPU): same result, staged through the host
+        tmp = local.detach().to("cpu", copy=True)
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group, async_op=False)
         out.copy_(tmp[lo:hi])
         return out, None
     work = dist.reduce_scatter_tensor(out.reshape(-1), local.reshape(-1), op=dist.ReduceOp.SUM, group=group, async_op=async_op)

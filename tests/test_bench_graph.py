@@ -1,0 +1,54 @@
+"""bench.py end to end on the GPU box: the N = 1 headline line with its oracle self-check, the 8-channel graph (BASELINE.json
+configs[4]) on one GPU, and the N > 1 code path executed for real -- two ranks (4 channels each) sharing the one
+GPU of the box, gloo carrying the fan-in -- with rank 0's shard of the channel sum checked against the float64 oracle inside
+bench.py (exit code 3 if any sampled frame is off by more than 1e-5)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, f"{' '.join(cmd)}\nrc={p.returncode}\n{p.stdout[-3000:]}\n{p.stderr[-3000:]}"
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_single_channel_self_check():
+    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline"])
+    assert r["n_gpus"] == 1 and r["config"]["channels"] == 1 and r["scaling"] == "weak"
+    assert r["roofline"]["kernel"] == "gr4::chain_fd_kernel<0, 13>"
+    v = r["verify"]
+    assert v["verified_frames"] >= 6 and v["max_rel_err"] <= 1e-5
+
+
+def test_bench_eight_channel_graph_one_gpu():
+    r = _run([sys.executable, "bench.py", "--channels", "8", "--steps", "2", "--warmup", "1", "--log2-samples", "24"])
+    assert r["config"]["channels"] == 8 and r["scaling"] == "strong" and "cpu_baseline" not in r
+    assert r["verify"]["verified_frames"] >= 8 and r["verify"]["max_rel_err"] <= 1e-5
+
+
+def test_bench_two_ranks_share_the_gpu_gloo_fanin():
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--log2-samples", "24",
+              "--steps", "2", "--warmup", "1"])
+    assert r["n_gpus"] == 2 and r["config"]["channels"] == 8 and r["scaling"] == "strong"
+    assert "4 per GPU" in r["config"]["parallelism"]
+    assert r["fanin"]["xgmi_ceiling_msamples"] > 0
+    v = r["verify"]  # rank 0's shard of the 8-channel sum vs the oracle's sum of the eight channels' spectra
+    assert v["verified_frames"] >= 3 and v["max_rel_err"] <= 1e-5

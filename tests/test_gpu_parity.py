@@ -757,6 +757,26 @@ def test_chain_matches_reference_block_magnitude(G):
     np.testing.assert_allclose(np.fft.fftshift(m2, axes=1), (mag.astype(np.float64) * N / 2) ** 2, rtol=1e-4, atol=1e-6 * m2.max())
 
 
+@pytest.mark.parametrize("window", ["None", "Hann"])
+def test_chain_parity_many_frames_per_workgroup(G, window):
+    """the persistent grid at bench scale: more frames than CUs, so every workgroup loops (double-buffered LDS-DMA, deferred stores,
+    carried tail) -- sampled frames straight against the float64 oracle on the same device-generated stream, in two calls so that the
+    history crosses a call boundary in the middle of a workgroup's share"""
+    N, frames, ntaps = 8192, 1400, 256  # > 5 frames per workgroup on 256 CUs
+    wid = [w.lower() for w in O.WINDOWS].index(window.lower())
+    b = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    x = G.synth_c32(frames * N, seed=17)
+    ch = G.Chain(b, N, window)
+    assert ch.algo == G.capi.CHAIN_FUSED_FD
+    cut = 777
+    got = torch.cat([ch.process_bulk(x[: cut * N]), ch.process_bulk(x[cut * N:])])
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    for f in sorted({0, 1, n_cu - 1, n_cu, n_cu + 1, 2 * n_cu, 599, 600, cut - 1, cut, cut + 1, 1024, frames - 2, frames - 1}):
+        lo = max(f - 1, 0)
+        truth, _ = O.chain(b, x[lo * N:(f + 1) * N].cpu().numpy(), N, wid, truth=True)
+        assert _rel(got[f].cpu().numpy(), truth.reshape(-1, N)[f - lo]) <= TOL, (window, f)
+
+
 def test_chain_full_size_properties(G):
     """BASELINE-size frames (N=8192, 256 taps) over a long device-generated stream: size-independent properties."""
     N, frames = 8192, 512

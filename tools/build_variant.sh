@@ -1,0 +1,14 @@
+#!/bin/bash
+# developer tool: gnuradio4_amd/libgr4hip_<tag>.so = the current objects with ONE source recompiled under extra flags
+#   tools/build_variant.sh timing chain_fused.hip -DGR4_FD_TIMING
+set -e
+TAG=$1; SRC=$2; shift 2
+cd "$(dirname "$0")/../gnuradio4_amd/csrc"
+O=../../build/obj
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wall -Wno-unused-function "$@" -c $SRC -o $O/${SRC%.hip}_$TAG.o
+OBJS=""
+for s in runtime fir fft fft_fast_pk math iir chain chain_fused fir_batched design; do
+  if [ "$s.hip" = "$SRC" ]; then OBJS="$OBJS $O/${s}_$TAG.o"; else OBJS="$OBJS $O/$s.o"; fi
+done
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libgr4hip_$TAG.so $OBJS
+echo "built libgr4hip_$TAG.so"
