@@ -154,6 +154,9 @@ def main():
 
     # synthetic input, generated on the device (noise seed 42 + channel index, tone at 0.1 fs)
     xs = [G.synth_c32(n, seed=42 + c) for c in mine]
+    if os.environ.get("GR4HIP_BENCH_ZERO_INPUT") == "1":  # developer experiment (DVFS: how far the clocks rise when the datapaths stop toggling); never a reported number
+        for x_ in xs:
+            x_.zero_()
     outs = [torch.empty((n // NFFT, NFFT), dtype=torch.float32, device="cuda") for _ in mine]
     # combiner output of this rank: the local fold of its channels per launch (double-buffered: the collective of launch c reads
     # slab c & 1 while the fold of launch c + 1 writes the other) and its shard of the all-channel sum of every launch

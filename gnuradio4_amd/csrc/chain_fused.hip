@@ -576,6 +576,11 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 
 
 int chain_fused_reset(struct ChainFused* c);
+// chain16.hip: the 16-wave kernel for the rectangular-window modes (|FFT(fir(x))|^2 and |FFT(x)|^2 at 8192 points)
+struct Chain16;
+int  chain16_create(Chain16** out, const float* H, const float* taps256);
+void chain16_destroy(Chain16* c);
+int  chain16_run(Chain16* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_out, unsigned max_wg, bool fft_only, hipStream_t st);
 #ifdef GR4_FD_TIMING
 static unsigned long long* g_dbg = nullptr;
 #endif
@@ -586,6 +591,8 @@ struct ChainFused {
     int          small_log2n = 0; // 8..12: fftSize = 2^small_log2n < 8192, the launch unit stays an 8192-sample block
     DeviceBuffer d_stage_in, d_stage_out; // one zero-padded block for the tail of a span that is not a multiple of 8192 samples
     unsigned     max_wg   = 0; // 0 = one workgroup on every CU
+    Chain16*     c16      = nullptr; // 8192-point plans: tables of the 16-wave kernel
+    ~ChainFused() { if (c16) chain16_destroy(c16); }
 };
 
 int chain_fused_supported(size_t ntaps, size_t fft_size, int window, int algo) {
@@ -636,6 +643,7 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
     if (!rc) rc = upload(c->d_twB, twB);
     if (!rc) rc = upload(c->d_twC, twC);
     if (!rc) rc = upload(c->d_taps, hp);
+    if (!rc && fft_size == (size_t)kN) rc = chain16_create(&c->c16, H.data(), hp.data());
     c->small_log2n = fft_size == (size_t)kN ? 0 : (int)ilog2(fft_size);
     c->windowed    = c->small_log2n != 0 || (window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR);
     if (!rc && c->windowed) { // window[n mod fftSize] / 8192 over the whole block: the 1/N of the inverse 8192-point transform is exact
@@ -671,6 +679,18 @@ int chain_fused_reset(ChainFused* c) {
 // the output is the filtered stream itself (complex) instead of |FFT|^2
 static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st, bool fir_mode, bool carry_hist,
                            bool fft_only = false, const float* fft_window = nullptr, bool fft_spectrum = false) {
+    {
+        static const int use16 = [] { const char* e = std::getenv("GR4HIP_CHAIN16"); return e ? std::atoi(e) : 0; }();
+        const bool plain_chain = !fir_mode && !fft_only && !c->windowed && c->small_log2n == 0;
+        const bool plain_fft   = fft_only && !fft_window && !fft_spectrum;
+        if (use16 && c->c16 && (plain_chain || plain_fft)) {
+            const float* hist = hist256 ? hist256 : static_cast<const float*>(c->d_hist.ptr);
+            int rc = chain16_run(c->c16, d_in, hist, n_frames, d_out, c->max_wg, plain_fft, st);
+            if (rc) return rc;
+            if (carry_hist) GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, reinterpret_cast<const float2*>(d_in) + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            return GR4HIP_OK;
+        }
+    }
     ChainFdArgs a{};
     a.x        = reinterpret_cast<const float2*>(d_in);
     a.hist     = hist256 ? reinterpret_cast<const float2*>(hist256) : static_cast<const float2*>(c->d_hist.ptr);

@@ -1030,3 +1030,45 @@ def test_rotator_leaping_walker_is_bit_identical(G, monkeypatch):
         got = r.process_bulk(dev(xs)).cpu().numpy()
         assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want)) and r.accumulated_phase == np.float32(ph)
 
+
+
+def test_chain16_kernel_matches_oracle_and_the_eight_wave_kernel():
+    """the 16-wave kernel (csrc/chain16.hip, selected per process with GR4HIP_CHAIN16=1) on the headline configuration: sampled frames against the
+    float64 oracle, every frame against the 8-wave kernel's output of this process, history across calls, the filter-less |FFT|^2 mode"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+import gnuradio4_amd as G, oracle_lib as O
+N, frames = 8192, 700
+b = O.design_taps_hamming_lowpass(256, 0.1)
+x = G.synth_c32(frames * N, seed=23)
+ch = G.Chain(b, N, "None")
+got = torch.cat([ch.process_bulk(x[: 301 * N]), ch.process_bulk(x[301 * N:])])
+F = G.FFT(N, "None")
+np.savez(OUT, chain=got.cpu().numpy(), fft=F.mag2(x[: 300 * N]).cpu().numpy())
+'''
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            out = os.path.join(td, f"k{flag}.npz")
+            env = dict(os.environ, GR4HIP_CHAIN16=flag)
+            p = subprocess.run([sys.executable, "-c", code.replace("ROOT", repr(root)).replace("OUT", repr(out))], env=env, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            outs[flag] = dict(np.load(out))
+    N = 8192
+    for key in ("chain", "fft"):
+        a, c = outs["0"][key].astype(np.float64), outs["1"][key].astype(np.float64)
+        rms = np.sqrt(np.mean(a ** 2, axis=1, keepdims=True))
+        assert np.max(np.abs(a - c) / np.maximum(np.abs(a), rms)) <= 2e-6, key  # two float32 evaluations of the same spectra
+    import gnuradio4_amd as G2
+    x = G2.synth_c32(700 * N, seed=23)
+    b = O.design_taps_hamming_lowpass(256, 0.1)
+    for f in (0, 1, 255, 256, 300, 301, 302, 699):
+        lo = max(f - 1, 0)
+        truth, _ = O.chain(b, x[lo * N:(f + 1) * N].cpu().numpy(), N, 0, truth=True)
+        assert _rel(outs["1"]["chain"][f], truth.reshape(-1, N)[f - lo]) <= TOL, f
