@@ -341,11 +341,13 @@ def math_nary(op, inputs: Sequence[torch.Tensor], out: Optional[torch.Tensor] = 
 
 
 class Rotator(_Handle):
-    """gr::blocks::math::Rotator<complex<float>> (Rotator.hpp:16-63): XOR settings frequency_shift / phase_increment."""
+    """gr::blocks::math::Rotator<complex<float>> (Rotator.hpp:16-63): XOR settings frequency_shift / phase_increment.
+    algo: "closed_form" (default: float64 phase of sample i = carried + (i+1) inc, HBM-bound) or "recurrence" (the reference's float
+    accumulator bit for bit, sequential); the carried phase is the same float member either way (include/gr4hip.h)."""
     _destroy = "gr4hip_rotator_destroy"
 
     def __init__(self, phase_increment: Optional[float] = None, frequency_shift: Optional[float] = None, sample_rate: float = 1.0,
-                 initial_phase: float = 0.0):
+                 initial_phase: float = 0.0, algo: str = "closed_form"):
         super().__init__()
         if phase_increment is not None and frequency_shift is not None:  # Rotator.hpp:45-46 throws
             raise ValueError("cannot set both 'frequency_shift' and 'phase_increment' in new setting (XOR)")
@@ -358,6 +360,14 @@ class Rotator(_Handle):
             self.frequency_shift = np.float32(self.phase_increment / (np.float32(2) * np.float32(np.pi))) * self.sample_rate
         self.initial_phase = np.float32(initial_phase)
         check(lib().gr4hip_rotator_create(C.byref(self._h), float(self.phase_increment), float(self.initial_phase)), "Rotator")
+        self.set_algo(algo)
+
+    def set_algo(self, algo: str):
+        ids = {"closed_form": capi.ROTATOR_CLOSED_FORM, "recurrence": capi.ROTATOR_RECURRENCE}
+        if algo not in ids:
+            raise ValueError(f"unknown rotator algo '{algo}'")
+        check(lib().gr4hip_rotator_set_algo(self._h, ids[algo]), "Rotator.set_algo")
+        self.algo = algo
 
     def process_bulk(self, x: torch.Tensor) -> torch.Tensor:
         x = _dev(x, "Rotator")

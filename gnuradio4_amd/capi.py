@@ -18,6 +18,7 @@ WINDOWS = ["None", "Rectangular", "Hamming", "Hann", "HannExp", "Blackman", "Nut
 FFT_OUTPUT_IN_DB, FFT_OUTPUT_IN_DEG, FFT_UNWRAP_PHASE = 1, 2, 4
 CHAIN_AUTO, CHAIN_UNFUSED, CHAIN_FUSED_TD, CHAIN_FUSED_FD, CHAIN_TIME_DOMAIN = range(5)
 FIR_AUTO, FIR_TIME_DOMAIN = range(2)
+ROTATOR_CLOSED_FORM, ROTATOR_RECURRENCE = range(2)
 
 
 class Gr4HipError(RuntimeError):
@@ -88,6 +89,7 @@ SIGNATURES = {
     "gr4hip_math_const": (_i, [_i, _i, _vp, _vp, _sz, _vp, _vp]),
     "gr4hip_math_nary": (_i, [_i, _i, _vp, _sz, _vp, _sz, _vp]),
     "gr4hip_rotator_create": (_i, [_pvp, _f, _f]),
+    "gr4hip_rotator_set_algo": (_i, [_vp, _i]),
     "gr4hip_rotator_reset": (_i, [_vp, _f]),
     "gr4hip_rotator_process": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "gr4hip_rotator_phase": (_i, [_vp, _pf, _vp]),

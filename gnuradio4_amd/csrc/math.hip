@@ -291,6 +291,58 @@ __global__ __launch_bounds__(256) void rotator_apply_kernel(const float2* __rest
     }
 }
 
+// Closed-form phase (GR4HIP_ROTATOR_CLOSED_FORM): sample i of a call sees phase = carried + (i + 1) inc, evaluated in float64 turns and reduced
+// exactly: k inc = (k >> 20) (2^20 inc) + (k & 0xfffff) inc with both factors' fractional parts taken first, so the argument of the final fract() stays
+// below 2^21 turns (2^-32 turn resolution) however long the span.  One pass, 16 B per sample: HBM-bound.  The float recurrence of the reference
+// drifts ~1e-7 rad per step away from this value (the walker above reproduces that drift bit for bit); this one is the float64 oracle's phase.
+template <bool V4> // V4: 16-byte accesses (both spans 16-byte aligned); otherwise one 8-byte sample per lane (a ring span may start at any element)
+__global__ __launch_bounds__(256) void rotator_closed_kernel(const float4* __restrict__ x, float4* __restrict__ y, const float* __restrict__ state_in,
+                                                             float* __restrict__ state_out, double inc_t, double inc_t20, long n) {
+    const double two_pi = 6.283185307179586476925286766559;
+    const double ph0_t  = (double)*state_in * (1.0 / two_pi);
+    const long   pairs  = (n + 1) / 2;
+    auto         rot    = [&](long k, float re, float im, float& ore, float& oim) { // k = sample index + 1
+        double t = fma((double)(k & 0xfffff), inc_t, ph0_t);
+        t        = fma((double)(k >> 20), inc_t20, t);
+        t -= rint(t); // [-0.5, 0.5] turns
+        float sn, cs;
+        sincosf((float)(t * two_pi), &sn, &cs);
+        ore = re * cs - im * sn;
+        oim = re * sn + im * cs;
+    };
+    if constexpr (!V4) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+            const float2 v = reinterpret_cast<const float2*>(x)[i];
+            float2       o;
+            rot(i + 1, v.x, v.y, o.x, o.y);
+            reinterpret_cast<float2*>(y)[i] = o;
+        }
+    } else
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (long)gridDim.x * blockDim.x) {
+        if (2 * p + 1 < n) {
+            using f32x4 = __attribute__((ext_vector_type(4))) float;
+            const f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + p);
+            const float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            float4       o;
+            rot(2 * p + 1, v.x, v.y, o.x, o.y);
+            rot(2 * p + 2, v.z, v.w, o.z, o.w);
+            const f32x4 oo = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(oo, reinterpret_cast<f32x4*>(y) + p);
+        } else { // odd tail
+            const float2 v = reinterpret_cast<const float2*>(x)[2 * p];
+            float2       o;
+            rot(2 * p + 1, v.x, v.y, o.x, o.y);
+            reinterpret_cast<float2*>(y)[2 * p] = o;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // carried phase in [0, 2 pi), into the OTHER state slot (every workgroup reads state_in)
+        double t = fma((double)(n & 0xfffff), inc_t, ph0_t);
+        t        = fma((double)(n >> 20), inc_t20, t);
+        t -= floor(t);
+        *state_out = (float)(t * two_pi);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ synthetic input
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 __device__ __forceinline__ uint64_t splitmix64(uint64_t& x) {
@@ -348,9 +400,12 @@ __global__ void synth_kernel(float* __restrict__ out, long n, uint64_t seed, dou
 using namespace gr4;
 
 struct gr4hip_rotator {
-    float        inc = 0.f;
-    DeviceBuffer d_state; // one float: _accumulated_phase
+    float        inc  = 0.f;
+    int          algo = GR4HIP_ROTATOR_CLOSED_FORM;
+    int          cur  = 0; // which of the two state slots holds _accumulated_phase (the closed-form kernel writes the other one: no read/write race)
+    DeviceBuffer d_state; // two floats
     DeviceBuffer d_ckpt;
+    float*       state() const { return static_cast<float*>(d_state.ptr) + cur; }
 };
 
 extern "C" {
@@ -381,7 +436,7 @@ int gr4hip_rotator_create(gr4hip_rotator_t** out, float phase_increment, float i
     auto* r = new (std::nothrow) gr4hip_rotator();
     GR4_REQUIRE(r, "out of host memory");
     r->inc = phase_increment;
-    int rc = r->d_state.ensure(sizeof(float));
+    int rc = r->d_state.ensure(2 * sizeof(float));
     if (rc) { delete r; return rc; }
     rc = gr4hip_rotator_reset(r, initial_phase);
     if (rc) { delete r; return rc; }
@@ -391,7 +446,14 @@ int gr4hip_rotator_create(gr4hip_rotator_t** out, float phase_increment, float i
 
 int gr4hip_rotator_reset(gr4hip_rotator_t* r, float initial_phase) {
     GR4_REQUIRE(r, "rotator: null handle");
-    GR4_HIP_TRY(hipMemcpy(r->d_state.ptr, &initial_phase, sizeof(float), hipMemcpyHostToDevice));
+    GR4_HIP_TRY(hipMemcpy(r->state(), &initial_phase, sizeof(float), hipMemcpyHostToDevice));
+    return GR4HIP_OK;
+}
+
+int gr4hip_rotator_set_algo(gr4hip_rotator_t* r, int algo) {
+    GR4_REQUIRE(r, "rotator: null handle");
+    GR4_REQUIRE(algo == GR4HIP_ROTATOR_CLOSED_FORM || algo == GR4HIP_ROTATOR_RECURRENCE, "rotator_set_algo: unknown algo %d", algo);
+    r->algo = algo; // the carried phase is one float whichever algorithm advances it
     return GR4HIP_OK;
 }
 
@@ -400,15 +462,28 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "rotator: null device pointer");
     hipStream_t  st      = as_stream(stream);
+    if (r->algo == GR4HIP_ROTATOR_CLOSED_FORM && r->inc == r->inc) { // (a NaN increment takes the recurrence: NaN in, NaN out, like the reference)
+        const double inc_t = (double)r->inc / 6.283185307179586476925286766559, inc20 = inc_t * 1048576.0;
+        const bool   v4    = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+        const size_t items = v4 ? (n + 1) / 2 : n;
+        const unsigned grid = (unsigned)std::min<size_t>(ceil_div(items, (size_t)256), (size_t)1 << 20);
+        float* nxt = static_cast<float*>(r->d_state.ptr) + (r->cur ^ 1);
+        if (v4) hipLaunchKernelGGL(rotator_closed_kernel<true>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->state(), nxt, inc_t - std::floor(inc_t), inc20 - std::floor(inc20), (long)n);
+        else hipLaunchKernelGGL(rotator_closed_kernel<false>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->state(), nxt, inc_t - std::floor(inc_t), inc20 - std::floor(inc20), (long)n);
+        GR4_LAUNCH_CHECK();
+        r->cur ^= 1;
+        return GR4HIP_OK;
+    }
+    // the reference's float recurrence, bit for bit
     const size_t nchunks = ceil_div(n, (size_t)kRotChunk);
     int          rc      = r->d_ckpt.ensure(nchunks * sizeof(float));
     if (rc) return rc;
     // small increments spend many samples per binade: leap; large ones change binade or wrap every few samples and the plain walker's 27-cycle step wins
     const bool leap = std::getenv("GR4HIP_ROTATOR_LEAP") ? true : (fabsf(r->inc) < kRotLeapBelow && !std::getenv("GR4HIP_ROTATOR_WALK")); // (developer / test switches)
-    if (leap) hipLaunchKernelGGL(rotator_checkpoint_leap_kernel, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n);
-    else if (r->inc >= 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<1>, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n);
-    else if (r->inc < 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<-1>, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n);
-    else hipLaunchKernelGGL(rotator_checkpoint_kernel<0>, dim3(1), dim3(64), 0, st, (float*)r->d_state.ptr, r->inc, (float*)r->d_ckpt.ptr, (long)n); // NaN increment
+    if (leap) hipLaunchKernelGGL(rotator_checkpoint_leap_kernel, dim3(1), dim3(64), 0, st, r->state(), r->inc, (float*)r->d_ckpt.ptr, (long)n);
+    else if (r->inc >= 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<1>, dim3(1), dim3(64), 0, st, r->state(), r->inc, (float*)r->d_ckpt.ptr, (long)n);
+    else if (r->inc < 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<-1>, dim3(1), dim3(64), 0, st, r->state(), r->inc, (float*)r->d_ckpt.ptr, (long)n);
+    else hipLaunchKernelGGL(rotator_checkpoint_kernel<0>, dim3(1), dim3(64), 0, st, r->state(), r->inc, (float*)r->d_ckpt.ptr, (long)n); // NaN increment
     GR4_LAUNCH_CHECK();
     hipLaunchKernelGGL(rotator_apply_kernel, dim3((unsigned)ceil_div(nchunks, (size_t)256)), dim3(256), 0, st, (const float2*)d_in, (float2*)d_out,
                        (const float*)r->d_ckpt.ptr, r->inc, (long)n);
@@ -418,7 +493,7 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
 
 int gr4hip_rotator_phase(gr4hip_rotator_t* r, float* phase, gr4hip_stream_t stream) {
     GR4_REQUIRE(r && phase, "rotator_phase: null argument");
-    GR4_HIP_TRY(hipMemcpyAsync(phase, r->d_state.ptr, sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
+    GR4_HIP_TRY(hipMemcpyAsync(phase, r->state(), sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
     GR4_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     return GR4HIP_OK;
 }

@@ -852,7 +852,8 @@ def test_tiny_and_empty_spans_every_block(G):
     cases = [("fir f32", lambda: G.fir_filter(b, torch.float32), xf, O.fir(b, xf)[0]),
              ("fir c32", lambda: G.fir_filter(b, torch.complex64), xc, O.fir(b, xc)[0]),
              ("iir", lambda: G.iir_filter(bi, ai), xf, O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)]), xf, O.DF_II, f64=True)),
-             ("rotator", lambda: G.Rotator(phase_increment=0.37, initial_phase=0.1), xc, O.rotator(xc, 0.37, 0.1)[0])]
+             ("rotator", lambda: G.Rotator(phase_increment=0.37, initial_phase=0.1), xc, O.rotator(xc.astype(np.complex128), float(np.float32(0.37)), float(np.float32(0.1)))[0]),
+             ("rotator (float recurrence)", lambda: G.Rotator(phase_increment=0.37, initial_phase=0.1, algo="recurrence"), xc, O.rotator(xc, 0.37, 0.1)[0])]
     for name, make, x, truth in cases:
         blk, parts, at = make(), [], 0
         for k in sizes:
@@ -982,15 +983,41 @@ def test_rotator_golden_and_parity(G, golden):
     for i in range(g["n"]):
         want = (i + 1) * float(inc)
         assert abs(y[i].real - np.cos(want)) < g["tolerance"] and abs(y[i].imag - np.sin(want)) < g["tolerance"]
-    # long stream: the float phase accumulation of the reference (incl. its drift) is reproduced across calls
+    # long stream, algo "recurrence": the float phase accumulation of the reference (incl. its drift) is reproduced across calls
     n = 200_000 + 13
     x = O.signal_c32(3, n)
-    for inc, ph0 in ((0.6283185, 0.25), (-0.01, 0.25), (3.0, 0.25), (7.5, 0.25), (-7.5, 0.25), (0.3, -1.0), (-0.3, 9.0), (0.0, 0.25)):  # incl. |inc| > 2 pi, start outside [0, 2 pi]
+    cases = ((0.6283185, 0.25), (-0.01, 0.25), (3.0, 0.25), (7.5, 0.25), (-7.5, 0.25), (0.3, -1.0), (-0.3, 9.0), (0.0, 0.25))  # incl. |inc| > 2 pi, start outside [0, 2 pi]
+    for inc, ph0 in cases:
         want, ph = O.rotator(x, inc, ph0)
-        r = G.Rotator(phase_increment=inc, initial_phase=ph0)
+        r = G.Rotator(phase_increment=inc, initial_phase=ph0, algo="recurrence")
         got = np.concatenate([r.process_bulk(dev(x[:777])).cpu().numpy(), r.process_bulk(dev(x[777:])).cpu().numpy()])
         assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
         assert r.accumulated_phase == np.float32(ph)  # bit-identical phase state
+    # default algo "closed_form": the float64 oracle's phase (gr4o_rotator_c64), one HBM-bound pass; ragged calls, an 8-byte-aligned span, hand-over
+    # of the carried phase to the recurrence and back
+    x64 = x.astype(np.complex128)
+    for inc, ph0 in cases:
+        want, ph = O.rotator(x64, float(np.float32(inc)), float(np.float32(ph0)))
+        r = G.Rotator(phase_increment=inc, initial_phase=ph0)
+        assert r.algo == "closed_form"
+        xd = dev(x)
+        buf = torch.empty(n + 1, dtype=torch.complex64, device="cuda")
+        buf[1:].copy_(xd)
+        got = np.concatenate([r.process_bulk(xd[:777]).cpu().numpy(), r.process_bulk(buf[1:][777:100_000]).cpu().numpy(), r.process_bulk(xd[100_000:]).cpu().numpy()])
+        assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want)), (inc, ph0)
+        two_pi = 2 * np.pi
+        dphi = (r.accumulated_phase - ph) % two_pi
+        assert min(dphi, two_pi - dphi) <= 2e-6  # the carried float phase: same angle modulo 2 pi, float rounding per call
+        # switch algorithms on the live handle: the carried float phase is the hand-over, exactly
+        st0 = r.accumulated_phase
+        r.set_algo("recurrence")
+        a = r.process_bulk(xd[:1000]).cpu().numpy()
+        wa, st1 = O.rotator(x[:1000], inc, st0)  # the reference's float recurrence from the carried state
+        assert np.max(np.abs(a - wa)) <= 1e-5 * np.max(np.abs(wa)) and r.accumulated_phase == np.float32(st1)
+        r.set_algo("closed_form")
+        b2 = r.process_bulk(xd[1000:3000]).cpu().numpy()
+        wb, _ = O.rotator(x64[1000:3000], float(np.float32(inc)), float(np.float32(st1)))
+        assert np.max(np.abs(b2 - wb)) <= 1e-5 * np.max(np.abs(wb))
     with pytest.raises(ValueError):
         G.Rotator(phase_increment=0.1, frequency_shift=0.2)
     r = G.Rotator(frequency_shift=2.0, sample_rate=100.0)
@@ -1015,7 +1042,7 @@ def test_rotator_leaping_walker_is_bit_identical(G, monkeypatch):
                 else:  # force the leaping walker also above the increment where the library would stop using it: short segments stress its boundary logic
                     monkeypatch.delenv("GR4HIP_ROTATOR_WALK", raising=False)
                     monkeypatch.setenv("GR4HIP_ROTATOR_LEAP", "1")
-                r = G.Rotator(phase_increment=float(np.float32(inc)), initial_phase=ph0)
+                r = G.Rotator(phase_increment=float(np.float32(inc)), initial_phase=ph0, algo="recurrence")
                 y = torch.cat([r.process_bulk(x[:100001]), r.process_bulk(x[100001:])])
                 res[mode] = (y, r.accumulated_phase)
             assert res["leap"][1] == res["walk"][1], (inc, ph0)
@@ -1026,7 +1053,7 @@ def test_rotator_leaping_walker_is_bit_identical(G, monkeypatch):
     xs = O.signal_c32(3, 300_000)
     for inc in (0.01, -0.003, 2.0 ** -12):
         want, ph = O.rotator(xs, inc, 0.5)
-        r = G.Rotator(phase_increment=inc, initial_phase=0.5)
+        r = G.Rotator(phase_increment=inc, initial_phase=0.5, algo="recurrence")
         got = r.process_bulk(dev(xs)).cpu().numpy()
         assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want)) and r.accumulated_phase == np.float32(ph)
 
