@@ -104,6 +104,36 @@ class fir_filter(_Handle):
         return out
 
 
+class fir_interpolator(_Handle):
+    """Interpolating FIR (north_star "decimating / interpolating FIR"; the reference only has the rate declaration Resampling<1, L>,
+    annotated.hpp:121-128): zero-stuff by `interpolate`, fir_filter's sum at the output rate, gain `interpolate`,
+    evaluated as a polyphase bank.  settings `b`, `interpolate`; T in {float32, complex64}; n_out = n_in * interpolate."""
+    _destroy = "gr4hip_fir_interp_destroy"
+
+    def __init__(self, b: Sequence[float], interpolate: int, dtype=torch.float32):
+        super().__init__()
+        self.b = np.ascontiguousarray(b, np.float32)
+        self.dtype = dtype
+        self.interpolate = int(interpolate)
+        check(lib().gr4hip_fir_interp_create(C.byref(self._h), _DTYPE_ID[dtype], self.b.ctypes.data, len(self.b), self.interpolate), "fir_interpolator")
+
+    def settings_changed(self, b: Sequence[float]):
+        self.b = np.ascontiguousarray(b, np.float32)
+        check(lib().gr4hip_fir_interp_set_taps(self._h, self.b.ctypes.data, len(self.b)), "fir_interpolator.set_taps")
+
+    def reset(self):
+        check(lib().gr4hip_fir_interp_reset(self._h), "fir_interpolator.reset")
+
+    def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _dev(x, "fir_interpolator")
+        if x.dtype != self.dtype:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "fir_interpolator", f"expected {self.dtype}, got {x.dtype}")
+        if out is None:
+            out = torch.empty(x.numel() * self.interpolate, dtype=self.dtype, device=x.device)
+        check(lib().gr4hip_fir_interp_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), None, _stream()), "fir_interpolator.process")
+        return out
+
+
 class iir_filter(_Handle):
     """gr::filter::iir_filter<float, form> (time_domain_filter.hpp:62-122) or a cascade of sections
     (gr::filter::Filter<float>, FilterTool.hpp:223-247).  b, a: [nsections][n] or 1-D for a single section."""

@@ -66,6 +66,11 @@ SIGNATURES = {
     "gr4hip_fir_reset": (_i, [_vp]),
     "gr4hip_fir_process": (_i, [_vp, _vp, _sz, _vp, _psz, _vp]),
     "gr4hip_fir_destroy": (_i, [_vp]),
+    "gr4hip_fir_interp_create": (_i, [_pvp, _i, _vp, _sz, _sz]),
+    "gr4hip_fir_interp_set_taps": (_i, [_vp, _vp, _sz]),
+    "gr4hip_fir_interp_reset": (_i, [_vp]),
+    "gr4hip_fir_interp_process": (_i, [_vp, _vp, _sz, _vp, _psz, _vp]),
+    "gr4hip_fir_interp_destroy": (_i, [_vp]),
     "gr4hip_decimate": (_i, [_i, _vp, _sz, _sz, _vp, _psz, _vp]),
     "gr4hip_iir_create": (_i, [_pvp, _i, _sz, _vp, _sz, _vp, _sz]),
     "gr4hip_iir_reset": (_i, [_vp]),

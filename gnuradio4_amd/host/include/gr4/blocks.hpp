@@ -328,6 +328,41 @@ struct BasicFilterProto : Block<BasicFilterProto<T, Args...>, Args...> {
 };
 template <typename T> using BasicFilter           = BasicFilterProto<T>;
 template <typename T> using BasicDecimatingFilter = BasicFilterProto<T, Resampling<1, 1, false>>;
+
+// ---- interpolating FIR (BASELINE.json north_star).  The reference has no such block, only the rate declaration it would carry --
+// Resampling<1, L> (annotated.hpp:121-128; chunk bookkeeping Block.hpp:1576-1636) -- so this follows fir_filter's shape (settings `b`, plus `interpolate`)
+// and SURVEY.md Appendix A's definition: zero-stuff by L, fir_filter's sum at the output rate, gain L.  Host body: the polyphase form
+// y[m L + p] = L sum_q b[q L + p] x[m - q]; output_chunk_size = interpolate, so gr:sample_rate is forwarded times L (Block.hpp:1088-1099).
+template <typename T>
+struct fir_interpolator : Block<fir_interpolator<T>, Resampling<1, 1, false>> {
+    PortIn<T>          in;
+    PortOut<T>         out;
+    std::vector<float> b{1.f};
+    Size_t             interpolate = 1;
+    GR_MAKE_REFLECTABLE(fir_interpolator, in, out, b, interpolate);
+    std::vector<T> _hist; // newest first, ceil(K / L) input samples
+
+    void settingsChanged(const property_map&, const property_map&) {
+        if (interpolate == 0) throw std::invalid_argument("fir_interpolator: interpolate must be >= 1");
+        this->output_chunk_size = interpolate;
+        const std::size_t kp = (b.size() + interpolate - 1) / interpolate;
+        if (kp > _hist.size()) _hist.assign(kp, T{}); // like fir_filter: the history is replaced only when it must grow
+    }
+    [[nodiscard]] work::Status processBulk(std::span<const T> input, std::span<T> output) noexcept {
+        const std::size_t L = interpolate, K = b.size(), kp = (K + L - 1) / L;
+        if (_hist.size() < kp) _hist.assign(kp, T{});
+        for (std::size_t m = 0; m < input.size(); ++m) {
+            std::move_backward(_hist.begin(), _hist.end() - 1, _hist.end());
+            _hist[0] = input[m];
+            for (std::size_t p = 0; p < L; ++p) {
+                T acc{};
+                for (std::size_t q = 0; q * L + p < K; ++q) acc += static_cast<T>(b[q * L + p]) * _hist[q];
+                output[m * L + p] = static_cast<T>(static_cast<float>(L)) * acc;
+            }
+        }
+        return work::Status::OK;
+    }
+};
 } // namespace gr::filter
 
 namespace gr::blocks::math {

@@ -185,6 +185,20 @@ struct DecimatorStage final : Stage {
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override { return gr4hip_decimate(dtype_of<T>(), in, n, decim, out, n_out, s); }
 };
 
+// interpolating FIR: polyphase kernel, n_out = n L
+template <typename T>
+struct InterpStage final : Stage {
+    gr4hip_fir_interp_t* h = nullptr;
+    std::size_t          L;
+    InterpStage(const std::vector<float>& b, std::size_t interp) : L(std::max<std::size_t>(1, interp)) {
+        in_bytes = out_bytes = sizeof(T); in_chunk = 1; out_chunk = L;
+        check(gr4hip_fir_interp_create(&h, dtype_of<T>(), b.data(), b.size(), L), "gr4hip_fir_interp_create");
+    }
+    ~InterpStage() override { gr4hip_fir_interp_destroy(h); }
+    std::string_view kind() const override { return "fir_interp"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override { return gr4hip_fir_interp_process(h, in, n, out, n_out, s); }
+};
+
 struct RotatorStage final : Stage {
     gr4hip_rotator_t* h = nullptr;
     RotatorStage(float phase_increment, float initial_phase) {
@@ -315,6 +329,13 @@ template <typename T>
 struct Kernel<gr::filter::Decimator<T>> {
     using B = gr::filter::Decimator<T>;
     static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<DecimatorStage<T>>(b.decim); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+template <typename T>
+    requires(std::is_same_v<T, float> || std::is_same_v<T, std::complex<float>>)
+struct Kernel<gr::filter::fir_interpolator<T>> {
+    using B = gr::filter::fir_interpolator<T>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<InterpStage<T>>(b.b, b.interpolate); }
     static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
 };
 template <typename... Args>

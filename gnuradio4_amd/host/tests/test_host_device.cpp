@@ -264,6 +264,15 @@ int main(int argc, char** argv) {
             const auto d = run_one<B, std::int32_t, std::int32_t>(cfg, xi, true, errors), h = run_one<B, std::int32_t, std::int32_t>(cfg, xi, false, errors);
             report("Decimator<int32> decim 7", d == h && d.size() == xi.size() / 7 ? 0.0 : 1.0, 0.0);
         }
+        for (const std::size_t L : {std::size_t(2), std::size_t(3), std::size_t(8), std::size_t(7)}) { // interpolating FIR (north_star; Resampling<1, L>): device polyphase kernel vs the host body
+            using B = filter::fir_interpolator<float>;
+            std::vector<float> bt(91);
+            for (std::size_t k = 0; k < bt.size(); ++k) bt[k] = static_cast<float>((0.54 - 0.46 * std::cos(2 * std::numbers::pi * double(k) / 90.0)) / 49.0);
+            const property_map cfg{{"b", bt}, {"interpolate", std::int64_t(L)}};
+            std::vector<float> xs(xf.begin(), xf.begin() + 20000);
+            const auto d = run_one<B, float, float>(cfg, xs, true, errors), h = run_one<B, float, float>(cfg, xs, false, errors);
+            report(("fir_interpolator<float> x" + std::to_string(L)).c_str(), d.size() == xs.size() * L && h.size() == d.size() ? max_rel(d, h) : 1e30, 1e-5);
+        }
         {
             using B = blocks::math::Rotator<std::complex<float>>;
             std::vector<std::complex<float>> xc(100000);

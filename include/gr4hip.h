@@ -137,6 +137,19 @@ int gr4hip_fir_set_algo(gr4hip_fir_t* fir, int algo);
 int gr4hip_fir_process(gr4hip_fir_t* fir, const void* d_in, size_t n_in, void* d_out, size_t* n_out, gr4hip_stream_t stream);
 int gr4hip_fir_destroy(gr4hip_fir_t* fir);
 
+/* Interpolating FIR (BASELINE.json north_star "decimating / interpolating FIR").  The reference has no such block, only the rate declaration
+ * it would carry, Resampling<1, L> (core/include/gnuradio-4.0/annotated.hpp:121-128; chunk bookkeeping Block.hpp:1576-1636), so the definition is
+ * SURVEY.md Appendix A's: zero-stuff by `interp`, then fir_filter's sum at the output rate, gain `interp`:
+ *   u[n] = x[n / L] if n % L == 0 else 0,   y[n] = L sum_k b[k] u[n - k]   ==   y[m L + p] = sum_q (L b[q L + p]) x[m - q]   (polyphase, evaluated)
+ * n_out = n_in * interp; zero initial history, ceil(ntaps / interp) - 1 input samples carried across calls; dtype F32 or C32 (real taps).
+ * Parity is pinned by the project's own float64 oracle (gr4o_fir_interp_*: literal zero-stuffing + the a1 sum), not by the reference. */
+typedef struct gr4hip_fir_interp gr4hip_fir_interp_t;
+int gr4hip_fir_interp_create(gr4hip_fir_interp_t** fir, int dtype, const float* h_taps, size_t ntaps, size_t interp);
+int gr4hip_fir_interp_set_taps(gr4hip_fir_interp_t* fir, const float* h_taps, size_t ntaps); /* history kept unless it must grow (like fir_filter) */
+int gr4hip_fir_interp_reset(gr4hip_fir_interp_t* fir);
+int gr4hip_fir_interp_process(gr4hip_fir_interp_t* fir, const void* d_in, size_t n_in, void* d_out, size_t* n_out, gr4hip_stream_t stream);
+int gr4hip_fir_interp_destroy(gr4hip_fir_interp_t* fir);
+
 /* gr::filter::Decimator<T>::processBulk (time_domain_filter.hpp:234-244): keep samples with i % decim == 0. */
 int gr4hip_decimate(int dtype, const void* d_in, size_t n_in, size_t decim, void* d_out, size_t* n_out, gr4hip_stream_t stream);
 

@@ -205,6 +205,29 @@ void gr4o_fir_decim_f32_acc64(const float* b, size_t ntaps, float* hist, const f
     fir_update_hist(hist, x, ntaps, n, 1);
 }
 
+/* Interpolating FIR -- PARITY UNPINNED BY THE REFERENCE (it has no such block; only the rate declaration Resampling<1, L>,
+ * core/include/gnuradio-4.0/annotated.hpp:121-128).  Definition of SURVEY.md Appendix A, stated literally: zero-stuff the input by L,
+ * run the a1 sum (fir_filter::processOne, time_domain_filter.hpp:44-47) at the OUTPUT rate in float64, gain L.  `hist_up` is the a1
+ * history at the output rate (ntaps - 1 zero-stuffed samples, oldest first), chained across calls like successive work() calls. */
+void gr4o_fir_interp_f32_acc64(const float* b, size_t ntaps, size_t L, float* hist_up, const float* x, double* y, size_t n_in) {
+    const size_t n_out = n_in * L;
+    float*       u     = (float*)calloc(n_out ? n_out : 1, sizeof(float));
+    size_t       i;
+    for (i = 0; i < n_in; ++i) u[i * L] = x[i];
+    gr4o_fir_f32_acc64(b, ntaps, hist_up, u, y, n_out);
+    for (i = 0; i < n_out; ++i) y[i] *= (double)L;
+    free(u);
+}
+void gr4o_fir_interp_c32_acc64(const float* b, size_t ntaps, size_t L, float* hist_up, const float* x, double* y, size_t n_in) {
+    const size_t n_out = n_in * L;
+    float*       u     = (float*)calloc(n_out ? 2 * n_out : 2, sizeof(float));
+    size_t       i;
+    for (i = 0; i < n_in; ++i) { u[2 * i * L] = x[2 * i]; u[2 * i * L + 1] = x[2 * i + 1]; }
+    gr4o_fir_c32_acc64(b, ntaps, hist_up, u, y, n_out);
+    for (i = 0; i < 2 * n_out; ++i) y[i] *= (double)L;
+    free(u);
+}
+
 /* Decimator<T>::processBulk (time_domain_filter.hpp:234-244) */
 size_t gr4o_decimate_bytes(const void* in, void* out, size_t n, size_t elem_size, size_t decim) {
     size_t i, o = 0;

@@ -52,6 +52,10 @@ void gr4o_fir_c32_acc64(const float* b, size_t ntaps, float* hist_interleaved, c
 /* decimating variant: BasicFilterProto::processBulk (time_domain_filter.hpp:190-204): filter every
  * input, keep outputs with i % decim == 0 (i restarts per call; n must be a multiple of decim). */
 void gr4o_fir_decim_f32_acc64(const float* b, size_t ntaps, float* hist, const float* x, double* y, size_t n, size_t decim);
+/* interpolating FIR: PARITY UNPINNED BY THE REFERENCE (no such block upstream; SURVEY.md Appendix A definition): zero-stuff by L, the a1 sum at
+ * the output rate in float64, gain L.  hist_up: ntaps - 1 samples at the OUTPUT rate (zero-stuffed), chained across calls. */
+void gr4o_fir_interp_f32_acc64(const float* b, size_t ntaps, size_t L, float* hist_up, const float* x, double* y, size_t n_in);
+void gr4o_fir_interp_c32_acc64(const float* b, size_t ntaps, size_t L, float* hist_up_interleaved, const float* x, double* y, size_t n_in);
 /* Decimator<T>::processBulk (time_domain_filter.hpp:234-244): keep i % decim == 0; bytes-exact copy */
 size_t gr4o_decimate_bytes(const void* in, void* out, size_t n, size_t elem_size, size_t decim);
 

@@ -82,6 +82,8 @@ def _declare(L):
     for n in ("gr4o_fir_f32", "gr4o_fir_f32_acc64", "gr4o_fir_c32", "gr4o_fir_c32_acc64"):
         getattr(L, n).argtypes = [vp, sz, vp, vp, vp, sz]
     L.gr4o_fir_decim_f32_acc64.argtypes = [vp, sz, vp, vp, vp, sz, sz]
+    L.gr4o_fir_interp_f32_acc64.argtypes = [vp, sz, sz, vp, vp, vp, sz]
+    L.gr4o_fir_interp_c32_acc64.argtypes = [vp, sz, sz, vp, vp, vp, sz]
     L.gr4o_decimate_bytes.argtypes = [vp, vp, sz, sz, sz]
     L.gr4o_decimate_bytes.restype = sz
     L.gr4o_section_init.argtypes = [vp, vp, i, vp, i]
@@ -184,6 +186,20 @@ def fir_decim(b, x, decim, hist=None):
     y = np.empty(len(x) // decim, np.float64)
     lib().gr4o_fir_decim_f32_acc64(_p(b), len(b), _p(hist), _p(x), _p(y), len(x), decim)
     return y, hist
+
+
+def fir_interp(b, x, interp, hist_up=None):
+    """interpolating FIR (parity unpinned by the reference): zero-stuff by `interp`, a1 sum at the output rate in float64, gain `interp`.
+    returns (y float64 / complex128, hist_up)."""
+    b = np.ascontiguousarray(b, np.float32)
+    x = np.ascontiguousarray(x)
+    cplx = np.iscomplexobj(x)
+    x = x.astype(np.complex64 if cplx else np.float32, copy=False)
+    H = max(len(b) - 1, 1)
+    hist_up = np.zeros(H, x.dtype) if hist_up is None else np.ascontiguousarray(hist_up, x.dtype).copy()
+    y = np.empty(len(x) * interp, np.complex128 if cplx else np.float64)
+    (lib().gr4o_fir_interp_c32_acc64 if cplx else lib().gr4o_fir_interp_f32_acc64)(_p(b), len(b), interp, _p(hist_up), _p(x), _p(y), len(x))
+    return y, hist_up
 
 
 def make_sections(coeffs):

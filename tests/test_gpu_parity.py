@@ -232,6 +232,47 @@ def test_decimating_fir_parity(G, decim, ntaps):
         f.process_bulk(dev(x[: decim + 1]))  # spans must be whole input chunks
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("interp,ntaps", [(2, 33), (3, 91), (8, 1024), (2, 256), (4, 64), (5, 100), (6, 7), (8, 33), (7, 50), (16, 256), (3, 1), (1, 45)])
+def test_interpolating_fir_parity(G, interp, ntaps, cplx):
+    """north_star "interpolating FIR" (no reference block: SURVEY.md Appendix A definition, own float64 oracle = literal zero-stuffing + the a1 sum, gain L):
+    polyphase kernels for L in {2,3,4,5,6,8}, the generic kernel otherwise; ragged calls carry ceil(K/L) - 1 input samples of history"""
+    n = 30_011
+    b = O.design_taps_hamming_lowpass(ntaps, 0.4 / interp) if ntaps > 1 else np.array([0.75], np.float32)
+    x = O.signal_c32(21, n) if cplx else O.signal_f32(21, n)
+    truth, _ = O.fir_interp(b, x, interp)
+    f = G.fir_interpolator(b, interp, torch.complex64 if cplx else torch.float32)
+    cuts = [0, 1, 2, 500, 501, 7000, 7000, 20_001, n]  # incl. an empty call, one-sample calls, spans shorter than the history
+    got = np.concatenate([f.process_bulk(dev(x[a:c])).cpu().numpy() for a, c in zip(cuts[:-1], cuts[1:])])
+    assert got.shape == truth.shape and _rel(got, truth) <= TOL
+    # the same stream in one call, after a reset; and new taps on the live block keep the history (like fir_filter::settingsChanged)
+    f.reset()
+    assert _rel(f.process_bulk(dev(x)).cpu().numpy(), truth) <= TOL
+    if ntaps > 1:
+        f.reset()
+        y1 = f.process_bulk(dev(x[:5000])).cpu().numpy()
+        b2 = (0.5 * b).astype(np.float32)
+        f.settings_changed(b2)
+        y2 = f.process_bulk(dev(x[5000:9000])).cpu().numpy()
+        t1, h = O.fir_interp(b, x[:5000], interp)
+        t2, _ = O.fir_interp(b2, x[5000:9000], interp, h)
+        assert _rel(np.concatenate([y1, y2]), np.concatenate([t1, t2])) <= TOL
+    with pytest.raises(G.capi.Gr4HipError):
+        G.fir_interpolator(b, 0)
+
+
+def test_interpolating_fir_is_the_gain_L_inverse_of_decimation(G):
+    """size-independent property at a long device-generated stream: interpolate by L with a 1/L-band low-pass, keep every L-th output of the
+    branch-0 phase -> the input delayed by the filter's group delay, to the filter's pass-band ripple"""
+    L, ntaps, n = 4, 255, 1 << 20
+    b = O.design_taps_hamming_lowpass(ntaps, 0.5 / L)
+    x = G.synth_f32(n, seed=3, tone_frel=0.01, noise_amp=0.0)  # a slow tone: well inside the pass band
+    y = G.fir_interpolator(b, L).process_bulk(x)
+    d = (ntaps - 1) // 2
+    back = y[d::L][: n - 1000]  # output sample m L + d is x[m] through the centre tap's phase (unit DC gain after the gain L)
+    assert float((back - x[: n - 1000]).abs().max()) <= 2e-3
+
+
 @pytest.mark.parametrize("dtype_id", range(12))
 def test_decimator_bit_exact(G, dtype_id, golden):
     g = golden["decimator"]

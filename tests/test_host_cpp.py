@@ -136,7 +136,8 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     assert "tags: device run forwarded {0: 250 Hz, 10000: 250 Hz + gr:value}, host graph the same" in r.stdout
     # every other hot-path block behind the seam (device vs the host body of the same block, printed by the program) ...
     for what in ("iir_filter<float, DF_II>", "Decimator<int32> decim 7", "Rotator<complex<float>>", "BasicDecimatingFilter<float> FIR /5", "BasicFilter<float> IIR",
-                 "Add<int32> n_inputs = 3", "FFT<complex<float>> 256 Hann", "FFT<complex<float>> 1000 B-Harris", "FFT<float> 512 Hamming dB", "planned run with two rate changes"):
+                 "Add<int32> n_inputs = 3", "FFT<complex<float>> 256 Hann", "FFT<complex<float>> 1000 B-Harris", "FFT<float> 512 Hamming dB", "planned run with two rate changes",
+                 "fir_interpolator<float> x2", "fir_interpolator<float> x3", "fir_interpolator<float> x8", "fir_interpolator<float> x7", "Rotator<complex<float>> vs host body (first 64)"):
         assert f"seam {what}" in r.stdout, what
     assert "FAILED" not in r.stdout
     assert "planner (resampling): 1 run: math_const -> basic_fir_decim -> decimator -> iir_f32" in r.stdout

@@ -395,3 +395,23 @@ def test_chain_f32_vs_truth():
     t, _ = O.chain(b, x, N, 0, truth=True)
     f, _ = O.chain(b, x, N, 0, truth=False)
     assert np.max(np.abs(f - t)) / np.sqrt(np.mean(t ** 2)) < 1e-5
+
+
+def test_interpolating_fir_oracle_matches_its_polyphase_form():
+    """the interpolating FIR has no reference block (parity unpinned upstream): the oracle states SURVEY.md Appendix A literally (zero-stuff, a1 sum,
+    gain L); here it is checked against the independent polyphase identity y[m L + p] = L sum_q b[q L + p] x[m - q] in numpy float64, across calls"""
+    rng = np.random.default_rng(11)
+    for L, K, cplx in ((2, 33, False), (3, 10, True), (8, 64, False), (5, 1, True), (1, 7, False)):
+        b = rng.standard_normal(K).astype(np.float32)
+        x = (rng.standard_normal(300) + 1j * rng.standard_normal(300)).astype(np.complex64) if cplx else rng.standard_normal(300).astype(np.float32)
+        y1, h = O.fir_interp(b, x[:101], L)
+        y2, _ = O.fir_interp(b, x[101:], L, h)
+        got = np.concatenate([y1, y2])
+        xx = x.astype(np.complex128 if cplx else np.float64)
+        want = np.zeros(len(x) * L, got.dtype)
+        for n in range(len(want)):
+            m, p = divmod(n, L)
+            q = np.arange((K - p + L - 1) // L)
+            q = q[m - q >= 0]
+            want[n] = L * np.sum(b[q * L + p].astype(np.float64) * xx[m - q])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
