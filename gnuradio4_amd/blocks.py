@@ -420,6 +420,13 @@ def synth_c32(n: int, seed: int = 42, tone_frel: float = 0.1, tone_amp: float = 
     return out
 
 
+def synth_draws(n_draws: int, seed: int, group: int) -> torch.Tensor:
+    """raw 64-bit draws of the generator behind 8-sample group `group` of a synth stream (int64 tensor holding the uint64 bit patterns)"""
+    out = torch.empty(n_draws, dtype=torch.int64, device="cuda")
+    check(lib().gr4hip_synth_draws(out.data_ptr(), n_draws, seed & (2 ** 64 - 1), group, _stream()), "synth_draws")
+    return out
+
+
 def synth_f32(n: int, seed: int = 42, tone_frel: float = 0.1, tone_amp: float = 1.0, noise_amp: float = 1.0, device="cuda") -> torch.Tensor:
     out = torch.empty(n, dtype=torch.float32, device=device)
     check(lib().gr4hip_synth_f32(out.data_ptr(), n, seed, tone_frel, tone_amp, noise_amp, _stream()), "synth_f32")

@@ -19,6 +19,7 @@ FFT_OUTPUT_IN_DB, FFT_OUTPUT_IN_DEG, FFT_UNWRAP_PHASE = 1, 2, 4
 CHAIN_AUTO, CHAIN_UNFUSED, CHAIN_FUSED_TD, CHAIN_FUSED_FD, CHAIN_TIME_DOMAIN = range(5)
 FIR_AUTO, FIR_TIME_DOMAIN = range(2)
 ROTATOR_CLOSED_FORM, ROTATOR_RECURRENCE = range(2)
+SYNTH_MIX = 0xd1b54a32d192ed03  # group g of a synth stream: Xoshiro256pp(seed ^ SYNTH_MIX * (g + 1)) (include/gr4hip.h)
 
 
 class Gr4HipError(RuntimeError):
@@ -103,6 +104,7 @@ SIGNATURES = {
     "gr4hip_fir_batched_reset": (_i, [_vp]),
     "gr4hip_fir_batched_process": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _vp]),
     "gr4hip_fir_batched_destroy": (_i, [_vp]),
+    "gr4hip_synth_draws": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),
     "gr4hip_synth_c32": (_i, [_vp, _sz, C.c_uint64, _d, _f, _f, _vp]),
     "gr4hip_synth_f32": (_i, [_vp, _sz, C.c_uint64, _d, _f, _f, _vp]),
 }

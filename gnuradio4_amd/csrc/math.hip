@@ -369,13 +369,24 @@ __device__ __forceinline__ void polar_pair(Xo& s, float& g1, float& g2) { // Gau
     g2 = v * f;
 }
 
+// the generator of 8-sample group g of a stream with seed `seed`: Xoshiro256pp(seed ^ kSynthMix (g + 1)) (constructor: Xoshiro256pp.hpp:33-39)
+constexpr uint64_t kSynthMix = 0xd1b54a32d192ed03ULL;
+__device__ __forceinline__ Xo synth_group_rng(uint64_t seed, uint64_t group) {
+    uint64_t sm = seed ^ (kSynthMix * (group + 1));
+    return Xo{splitmix64(sm), splitmix64(sm), splitmix64(sm), splitmix64(sm)};
+}
+__global__ void synth_draws_kernel(uint64_t* __restrict__ out, int n, uint64_t seed, uint64_t group) {
+    if (threadIdx.x || blockIdx.x) return;
+    Xo s = synth_group_rng(seed, group);
+    for (int i = 0; i < n; ++i) out[i] = xo_next(s);
+}
+
 template <bool COMPLEX>
 __global__ void synth_kernel(float* __restrict__ out, long n, uint64_t seed, double frel, float tone_amp, float noise_amp) {
     constexpr int PER    = 8; // samples per lane per visit
     const long    stride = (long)gridDim.x * blockDim.x * PER;
     for (long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * PER; i0 < n; i0 += stride) {
-        uint64_t sm = seed ^ (0xd1b54a32d192ed03ULL * (uint64_t)(i0 / PER + 1));
-        Xo       s{splitmix64(sm), splitmix64(sm), splitmix64(sm), splitmix64(sm)};
+        Xo s = synth_group_rng(seed, (uint64_t)(i0 / PER));
         for (int k = 0; k < PER && i0 + k < n; COMPLEX ? ++k : k += 2) {
             float g1, g2;
             polar_pair(s, g1, g2);
@@ -505,6 +516,14 @@ int gr4hip_synth_c32(void* d_out, size_t n, uint64_t seed, double tone_frel, flo
     GR4_REQUIRE(d_out, "synth: null output");
     const unsigned grid = (unsigned)std::min<size_t>(ceil_div(n, (size_t)256 * 8), 8192);
     hipLaunchKernelGGL(synth_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), (float*)d_out, (long)n, seed, tone_frel, tone_amp, noise_amp);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+int gr4hip_synth_draws(uint64_t* d_out, size_t n_draws, uint64_t seed, uint64_t group, gr4hip_stream_t stream) {
+    if (n_draws == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_out && n_draws <= (1u << 20), "synth_draws: null output or more than 2^20 draws");
+    hipLaunchKernelGGL(synth_draws_kernel, dim3(1), dim3(64), 0, as_stream(stream), d_out, (int)n_draws, seed, group);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

@@ -253,8 +253,13 @@ int gr4hip_fir_batched_process(gr4hip_fir_batched_t* fb, const float* d_in, size
 int gr4hip_fir_batched_destroy(gr4hip_fir_batched_t* fb);
 
 /* ------------------------------------------------------------------------------------------------ a15 (bench input)
- * device-side synthetic stream of SURVEY.md 8(d): complex Gaussian noise (xoshiro256++ per 4096-sample block,
- * Marsaglia polar like GaussianNoise.hpp:101-111) + tone; NOT the sequential reference stream (tests upload that). */
+ * device-side synthetic stream of SURVEY.md 8(d): unit-power Gaussian noise + tone.  The stream is cut into groups of 8 samples; group g has its own
+ * generator Xoshiro256pp(seed ^ 0xd1b54a32d192ed03 (g + 1)) (algorithm/.../rng/Xoshiro256pp.hpp:22-96, constructor :33-39) and fills its 8 samples with
+ * GaussianNoise<float>::fill / fillComplex (GaussianNoise.hpp:59-111: Marsaglia polar, amplitude / sqrt2 per component for complex), so every group
+ * is the reference's own recipe and the groups are independent (any lane can generate any group).  It is NOT the single sequential reference stream
+ * (tests that need that one upload it).  gr4hip_synth_draws returns the raw 64-bit draws of group g's generator: with seed = 0xd1b54a32d192ed03, g = 0
+ * that generator is Xoshiro256pp(0), whose first draws are the reference's known answer (algorithm/test/qa_Xoshiro256pp.cpp:55-69). */
+int gr4hip_synth_draws(uint64_t* d_out_u64, size_t n_draws, uint64_t seed, uint64_t group, gr4hip_stream_t stream);
 int gr4hip_synth_c32(void* d_out_c32, size_t n, uint64_t seed, double tone_frel, float tone_amp, float noise_amp, gr4hip_stream_t stream);
 int gr4hip_synth_f32(float* d_out, size_t n, uint64_t seed, double tone_frel, float tone_amp, float noise_amp, gr4hip_stream_t stream);
 

@@ -1140,3 +1140,41 @@ np.savez(OUT, chain=got.cpu().numpy(), fft=F.mag2(x[: 300 * N]).cpu().numpy())
         lo = max(f - 1, 0)
         truth, _ = O.chain(b, x[lo * N:(f + 1) * N].cpu().numpy(), N, 0, truth=True)
         assert _rel(outs["1"]["chain"][f], truth.reshape(-1, N)[f - lo]) <= TOL, f
+
+
+# ------------------------------------------------------------------ a15: the device-side generator behind the bench input and the long-stream tests
+def test_device_generator_is_the_reference_prng(G, golden):
+    """gr4hip_synth_*: group g of 8 samples has its own Xoshiro256pp(seed ^ MIX (g + 1)) and is filled with the reference's GaussianNoise recipe.
+    The integer core is pinned by the reference's seed-0 known answer (qa_Xoshiro256pp.cpp:55-69) and bit for bit by the oracle (itself bit-exact
+    against the reference's own header, oracle/_ref); the float samples by the oracle's fill / fillComplex for the same generator; plus statistics."""
+    MIX, M64 = G.capi.SYNTH_MIX, 2 ** 64 - 1
+    want0 = [int(h, 16) for h in golden["xoshiro_seed0_first5"]["draws_hex"]]
+    got0 = [int(v) & M64 for v in G.synth_draws(5, MIX, 0).cpu().numpy()]  # seed ^ MIX * 1 == 0: the generator is Xoshiro256pp(0)
+    assert got0 == want0
+    for seed, g in ((42, 0), (42, 7), (43, 123456789), (0, 2 ** 40)):
+        sg = (seed ^ (MIX * (g + 1))) & M64
+        got = G.synth_draws(64, seed, g).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, O.xoshiro_draws(sg, 64)), (seed, g)
+    # samples: every 8-sample group is fillComplex / fill of its own generator (float log / sqrt differ by an ulp or two between libm and the device)
+    n, seed = 1 << 16, 42
+    xc = G.synth_c32(n, seed=seed, tone_frel=0.1, tone_amp=1.0, noise_amp=1.0).cpu().numpy()
+    xf = G.synth_f32(n, seed=seed, tone_frel=0.1, tone_amp=1.0, noise_amp=1.0).cpu().numpy()
+    for g in (0, 1, 2, 777, n // 8 - 1):
+        sg = (seed ^ (MIX * (g + 1))) & M64
+        i = np.arange(8 * g, 8 * g + 8, dtype=np.float64)
+        ph = 2 * np.pi * np.mod(0.1 * i, 1.0)
+        wc = O.gauss_c32(sg, 8).astype(np.complex128) + np.exp(1j * ph)
+        wf = O.gauss_f32(sg, 8).astype(np.float64) + np.sin(ph)
+        assert np.max(np.abs(xc[8 * g: 8 * g + 8] - wc)) <= 4e-6, g
+        assert np.max(np.abs(xf[8 * g: 8 * g + 8] - wf)) <= 4e-6, g
+    # statistics of the bench input (2^22 samples): unit noise power, zero mean, independent components, the tone on its bin
+    n = 1 << 22
+    z = G.synth_c32(n, seed=42, tone_frel=0.0, tone_amp=0.0, noise_amp=1.0)
+    p = float((z.abs().double() ** 2).mean())
+    assert abs(p - 1.0) < 5e-3 and abs(complex(z.mean())) < 3e-3
+    assert abs(float((z.real.double() * z.imag.double()).mean())) < 3e-3 and abs(float((z.real.double() ** 2).mean()) - 0.5) < 3e-3
+    assert abs(float((z[1:].real.double() * z[:-1].real.double()).mean())) < 3e-3  # neighbours (same group and across groups) uncorrelated
+    zt = G.synth_c32(n, seed=42, tone_frel=0.1, tone_amp=1.0, noise_amp=1.0)
+    m2 = G.FFT(8192, "None").mag2(zt[: 64 * 8192]).double().mean(dim=0)
+    assert int(m2.argmax()) == 819  # 0.1 fs * 8192 = 819.2
+    assert abs(float((zt.abs().double() ** 2).mean()) - 2.0) < 1e-2  # unit tone + unit noise
