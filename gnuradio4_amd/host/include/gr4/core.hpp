@@ -539,7 +539,8 @@ struct Block {
     ComputeDomain _domain{};
     bool          _warned_device_fallback = false;
     std::function<void(std::string_view)> _log = [](std::string_view) {};
-    void*         _device_state = nullptr; // owned by hip::Kernel<Derived>
+    std::shared_ptr<void> _device_state;  // hip::Offload of this block (type-erased with its deleter: released with the block, i.e. with the graph)
+    std::size_t   _settings_generation = 0; // bumped by every applySettings(): a device stage built from older settings is stale
 
     Derived&       self() { return *static_cast<Derived*>(this); }
     const Derived& self() const { return *static_cast<const Derived*>(this); }
@@ -570,6 +571,7 @@ struct Block {
             });
             if (!found) throw std::invalid_argument("unknown setting '" + key + "' for block " + name);
         }
+        if (!applied.empty()) ++_settings_generation;
         if constexpr (requires(Derived& d, const property_map& m) { d.settingsChanged(m, m); }) self().settingsChanged(property_map{}, applied);
     }
 

@@ -102,6 +102,11 @@ struct FirStage final : Stage {
         check(gr4hip_fir_create(&h, gr::detail::is_complex<T>::value ? GR4HIP_C32 : GR4HIP_F32, taps.data(), taps.size(), 1), "gr4hip_fir_create");
     }
     ~FirStage() override { gr4hip_fir_destroy(h); }
+    template <typename Taps>
+    void set_taps(const Taps& b) { // fir_filter::settingsChanged (time_domain_filter.hpp:38-42): new taps, the history survives
+        taps.assign(b.begin(), b.end());
+        check(gr4hip_fir_set_taps(h, taps.data(), taps.size()), "gr4hip_fir_set_taps");
+    }
     std::string_view kind() const override { return gr::detail::is_complex<T>::value ? "fir_c32" : "fir_f32"; }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override { return gr4hip_fir_process(h, in, n, out, n_out, s); }
 };
@@ -257,23 +262,43 @@ inline int window_id(const std::string& w) { // gr::algorithm::window::TypeNames
 }
 
 // ---------------------------------------------------------------------------------------------- per-block offload at the seam
-struct Offload { // state behind Block::_device_state
+struct Offload { // state behind Block::_device_state (owned by the block through a shared_ptr<void> with this type's deleter)
     virtual ~Offload() = default;
     std::unique_ptr<Stage> stage;
     DevBuf                 d_in, d_out, h_in{true}, h_out{true};
     int                    device = 0;
+    std::size_t            settings_generation = 0; // Block::_settings_generation the stage was built (or refreshed) for
 };
+// the block's Offload (created on first use, on the block's device); every call makes the block's device the calling thread's current device:
+// one scheduler thread drives blocks of several "gpu:hip:<i>" domains, and allocations, attributes and launches follow the CURRENT device
+template <typename State = Offload, typename BlockT>
+State* offload_state(BlockT& blk) {
+    auto* st = static_cast<State*>(static_cast<Offload*>(blk._device_state.get()));
+    if (!st) {
+        check(gr4hip_set_device(blk._domain.index), "gr4hip_set_device");
+        st         = new State();
+        st->device = blk._domain.index;
+        blk._device_state = std::shared_ptr<void>(static_cast<Offload*>(st), [](void* p) { delete static_cast<Offload*>(p); });
+    }
+    check(gr4hip_set_device(st->device), "gr4hip_set_device");
+    return st;
+}
 
-template <typename BlockT, typename MakeStage>
-work::Status offload_work(BlockT& blk, std::size_t nIn, std::size_t nOut, MakeStage&& make) {
+// make(blk): a fresh stage from the block's CURRENT settings.  update(stage, blk) (optional): bring a live stage up to date and return true when that
+// is possible without losing its state (fir_filter keeps its history across new taps); otherwise the stage is rebuilt.  A settings change is seen
+// through Block::_settings_generation (applySettings and settings-by-tag bump it): a stage is never used with stale taps or constants.
+template <typename BlockT, typename MakeStage, typename UpdateStage = std::nullptr_t>
+work::Status offload_work(BlockT& blk, std::size_t nIn, std::size_t nOut, MakeStage&& make, UpdateStage&& update = nullptr) {
     try {
-        auto* st = static_cast<Offload*>(blk._device_state);
-        if (!st) {
-            st         = new Offload();
-            st->device = blk._domain.index;
-            check(gr4hip_set_device(st->device), "gr4hip_set_device");
-            st->stage          = make(blk);
-            blk._device_state = st; // released by the graph owner via hip::release(block)
+        Offload* st = offload_state(blk);
+        if (!st->stage) {
+            st->stage               = make(blk);
+            st->settings_generation = blk._settings_generation;
+        } else if (st->settings_generation != blk._settings_generation) {
+            bool kept = false;
+            if constexpr (!std::is_same_v<std::decay_t<UpdateStage>, std::nullptr_t>) kept = update(*st->stage, blk);
+            if (!kept) st->stage = make(blk);
+            st->settings_generation = blk._settings_generation;
         }
         using TIn  = typename std::decay_t<decltype(blk.in)>::value_type;
         using TOut = typename std::decay_t<decltype(blk.out)>::value_type;
@@ -295,16 +320,17 @@ work::Status offload_work(BlockT& blk, std::size_t nIn, std::size_t nOut, MakeSt
 }
 
 template <typename BlockT>
-void release(BlockT& blk) {
-    delete static_cast<Offload*>(blk._device_state);
-    blk._device_state = nullptr;
+void release(BlockT& blk) { // early release (the state also goes with the block)
+    blk._device_state.reset();
 }
 
 template <typename T>
 requires(std::is_same_v<T, float> || std::is_same_v<T, std::complex<float>>)
 struct Kernel<gr::filter::fir_filter<T>> {
     static std::unique_ptr<Stage> make_stage(gr::filter::fir_filter<T>& b) { return std::make_unique<FirStage<T>>(b.b); }
-    static work::Status           work(gr::filter::fir_filter<T>& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+    static work::Status           work(gr::filter::fir_filter<T>& b, std::size_t nIn, std::size_t nOut) {
+        return offload_work(b, nIn, nOut, make_stage, [](Stage& st, gr::filter::fir_filter<T>& blk) { static_cast<FirStage<T>&>(st).set_taps(blk.b); return true; });
+    }
 };
 template <typename T, typename op>
 struct Kernel<gr::blocks::math::MathOpImpl<T, op>> {
@@ -507,13 +533,7 @@ struct Kernel<gr::blocks::math::MathOpMultiPortImpl<T, op>> {
     };
     static work::Status work(B& blk, std::size_t nIn, std::size_t nOut) {
         try {
-            auto* st = static_cast<State*>(static_cast<Offload*>(blk._device_state));
-            if (!st) {
-                st         = new State();
-                st->device = blk._domain.index;
-                check(gr4hip_set_device(st->device), "gr4hip_set_device");
-                blk._device_state = static_cast<Offload*>(st);
-            }
+            State* st = offload_state<State>(blk);
             while (st->d_ins.size() < blk.in.size()) st->d_ins.push_back(std::make_unique<DevBuf>());
             const std::size_t        bytes = nIn * sizeof(T);
             std::vector<const void*> ptrs;
@@ -551,13 +571,7 @@ struct Kernel<gr::blocks::fft::FFT<T, DataSet<float>>> {
     };
     static work::Status work(B& blk, std::size_t nIn, std::size_t nOut) {
         try {
-            auto* st = static_cast<State*>(static_cast<Offload*>(blk._device_state));
-            if (!st) {
-                st         = new State();
-                st->device = blk._domain.index;
-                check(gr4hip_set_device(st->device), "gr4hip_set_device");
-                blk._device_state = static_cast<Offload*>(st);
-            }
+            State* st = offload_state<State>(blk);
             const int flags = (blk.outputInDb ? GR4HIP_FFT_OUTPUT_IN_DB : 0) | (blk.outputInDeg ? GR4HIP_FFT_OUTPUT_IN_DEG : 0) | (blk.unwrapPhase ? GR4HIP_FFT_UNWRAP_PHASE : 0);
             if (!st->h || st->N != blk.fftSize || st->window != blk.window.value || st->flags != flags) { // settings changed: new plan
                 if (st->h) gr4hip_fft_destroy(st->h);
@@ -937,6 +951,7 @@ public:
 
     work::Result work(std::size_t requested) override {
         try {
+            check(gr4hip_set_device(_domain.index), "gr4hip_set_device"); // runs on several devices share the scheduler thread: the current device is per call
             std::size_t published = 0;
             while (const std::size_t r = retire(true)) published += r; // whatever has finished since the last call
             // a tag on the first sample of the launch: settings-by-tag for the member blocks (only the stages of members that changed are rebuilt, the

@@ -41,7 +41,7 @@ std::vector<TOut> run_one(property_map settings, const std::vector<TIn>& input, 
     scheduler::Simple sched;
     sched.exchange(std::move(g));
     if (const auto r = sched.runAndWait(); !r) { std::cerr << "run_one: " << r.error().message << "\n"; ++errors; }
-    if (device) { if (!blk._device_state) ++errors; hip::release(blk); } // the seam must have been taken
+    if (device && !blk._device_state) ++errors; // the seam must have been taken (the state goes with the block)
     return sink._samples;
 }
 template <typename T>
@@ -482,6 +482,54 @@ int main(int argc, char** argv) {
             for (std::size_t i = 0; i < y.size() && i < got[1].size(); ++i) w2 = std::max(w2, double(std::abs(got[1][i] - y[i])));
             std::printf("tags: gain step at the tagged sample, filter state kept: max diff %.3g\n", w2);
             if (!(w2 <= 2e-5)) ++errors;
+        }
+    }
+    // ------------------------------------------------------------------ settings-by-tag on a LONE device block (no DeviceRun: the per-block seam)
+    // a stage is built once and must follow the block's settings: a gain step by tag on MultiplyConst, new taps by tag on fir_filter (history kept)
+    {
+        const std::size_t   n = 60000, at = 23456;
+        std::vector<float> xs(n);
+        for (std::size_t i = 0; i < n; ++i) xs[i] = static_cast<float>(std::sin(0.013 * double(i)) + 0.25 * std::cos(0.4 * double(i)));
+        std::vector<float> b1(33, 1.f / 33.f), b2(33);
+        for (std::size_t k = 0; k < b2.size(); ++k) b2[k] = (k % 2 ? -1.f : 1.f) / 33.f;
+        for (int which = 0; which < 2; ++which) {
+            std::vector<float> got[2];
+            for (int dev = 0; dev < 2; ++dev) {
+                Graph g;
+                auto& src  = g.emplaceBlock<testing::VectorSource<float>>();
+                src.values = xs;
+                auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+                bool  ok   = true;
+                void* took = nullptr;
+                scheduler::Simple sched; // owns the graph from exchange() on: must outlive the reads of the sink below
+                if (which == 0) {
+                    src._tags = {{at, {{"value", 3.0}}}};
+                    property_map m{{"value", 0.5}};
+                    if (dev) m["compute_domain"] = "gpu:hip:0"s;
+                    auto& blk = g.emplaceBlock<blocks::math::MultiplyConst<float>>(m);
+                    ok        = bool(g.connect<"out", "in">(src, blk)) && bool(g.connect<"out", "in">(blk, sink));
+                    sched.exchange(std::move(g));
+                    if (const auto r = sched.runAndWait(); !r) ok = false;
+                    took = blk._device_state.get();
+                } else {
+                    src._tags = {{at, {{"b", b2}}}};
+                    property_map m{{"b", b1}};
+                    if (dev) m["compute_domain"] = "gpu:hip:0"s;
+                    auto& blk = g.emplaceBlock<filter::fir_filter<float>>(m);
+                    ok        = bool(g.connect<"out", "in">(src, blk)) && bool(g.connect<"out", "in">(blk, sink));
+                    sched.exchange(std::move(g));
+                    if (const auto r = sched.runAndWait(); !r) ok = false;
+                    took = blk._device_state.get();
+                }
+                if (!ok || (dev && !took)) ++errors;
+                got[dev] = sink._samples;
+            }
+            double worst = got[0].size() == n && got[1].size() == n ? 0.0 : 1e30;
+            for (std::size_t i = 0; i < n && worst < 1e29; ++i) worst = std::max(worst, double(std::abs(got[1][i] - got[0][i])));
+            const bool stepped = got[0].size() == n && (which == 1 || (got[0][at - 1] == xs[at - 1] * 0.5f && got[0][at] == xs[at] * 3.f));
+            std::printf("settings-by-tag on a lone device block (%s): device vs host max diff %.3g%s\n", which == 0 ? "MultiplyConst value" : "fir_filter taps, history kept", worst,
+                        stepped ? "" : "  (host step missing)");
+            if (!(worst <= 2e-6) || !stepped) ++errors;
         }
     }
     std::printf(errors ? "host-device: %d FAILURES\n" : "host-device: all graphs ran\n", errors);

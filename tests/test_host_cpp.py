@@ -140,6 +140,7 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
                  "fir_interpolator<float> x2", "fir_interpolator<float> x3", "fir_interpolator<float> x8", "fir_interpolator<float> x7", "Rotator<complex<float>> vs host body (first 64)"):
         assert f"seam {what}" in r.stdout, what
     assert "FAILED" not in r.stdout
+    assert "settings-by-tag on a lone device block (MultiplyConst value)" in r.stdout and "settings-by-tag on a lone device block (fir_filter taps, history kept)" in r.stdout
     assert "planner (resampling): 1 run: math_const -> basic_fir_decim -> decimator -> iir_f32" in r.stdout
     # ... and BasicDecimatingFilter<float> (designed Hamming FIR / Chebyshev-1 IIR low-pass, order 4, 100 Hz at 1 kHz, decimate 5) against the oracle
     xin = np.fromfile(tmp_path / "o_basic_in.bin", np.float32)
