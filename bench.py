@@ -100,12 +100,15 @@ def _rel_err(got, truth):
 
 
 def oracle_frame(O, taps, x_dev, f):
-    """float64 oracle |FFT(fir(x))|^2 of frame f of one channel: frames f-1 and f go through the oracle chain (255 samples of
-    history are all a 256-tap FIR needs; frame 0 starts from the zero history the bench resets to)."""
-    lo = max(f - 1, 0)
-    xs = x_dev[lo * NFFT:(f + 1) * NFFT].cpu().numpy()
-    out, _ = O.chain(taps, xs, NFFT, 0, truth=True)
-    return out.reshape(-1, NFFT)[f - lo]
+    """float64 oracle |FFT(fir(x))|^2 of frame f of one channel: the frame before it and frame f go through the oracle chain (255 samples
+    of history are all a 256-tap FIR needs).  The bench streams the same buffer step after step without resetting the chain, so the
+    frame in front of frame 0 is the LAST frame of the buffer (the previous step's tail is the carried history)."""
+    import numpy as np
+    nfr = x_dev.numel() // NFFT
+    prev = x_dev[((f - 1) % nfr) * NFFT:((f - 1) % nfr + 1) * NFFT].cpu().numpy()
+    cur = x_dev[f * NFFT:(f + 1) * NFFT].cpu().numpy()
+    out, _ = O.chain(taps, np.concatenate([prev, cur]), NFFT, 0, truth=True)
+    return out.reshape(-1, NFFT)[1]
 
 
 def main():
@@ -181,8 +184,7 @@ def main():
     main_stream = torch.cuda.current_stream()
 
     def step(record: bool):
-        for ch in chains:
-            ch.reset()
+        # (no reset between steps: the stream simply continues, the FIR history of a step's first frame is the previous step's tail)
         if len(mine) > 1:  # a channel stream must not overwrite a slice the previous step's fold still reads
             for s in streams:
                 s.wait_stream(main_stream)

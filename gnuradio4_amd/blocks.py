@@ -151,6 +151,10 @@ class iir_filter(_Handle):
     def reset(self):
         check(lib().gr4hip_iir_reset(self._h), "iir_filter.reset")
 
+    def status(self):
+        """synchronise the current stream and raise if an earlier launch of this handle reported a look-back time-out (include/gr4hip.h)"""
+        check(lib().gr4hip_iir_status(self._h, _stream()), "iir_filter.status")
+
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "iir_filter")
         if x.dtype != torch.float32:
@@ -305,6 +309,12 @@ class Chain(_Handle):
 
     def reset(self):
         check(lib().gr4hip_chain_reset(self._h), "Chain.reset")
+
+    def last_power_ratio(self):
+        """(output / input power of the last measured fused launch or -1, chain now in the time domain?) -- the dynamic-range guard of CHAIN_AUTO (include/gr4hip.h)"""
+        r, td = C.c_float(0), C.c_int(0)
+        check(lib().gr4hip_chain_last_power_ratio(self._h, C.byref(r), C.byref(td), _stream()), "Chain.last_power_ratio")
+        return r.value, bool(td.value)
 
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "Chain")

@@ -76,6 +76,7 @@ SIGNATURES = {
     "gr4hip_iir_create": (_i, [_pvp, _i, _sz, _vp, _sz, _vp, _sz]),
     "gr4hip_iir_reset": (_i, [_vp]),
     "gr4hip_iir_process": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "gr4hip_iir_status": (_i, [_vp, _vp]),
     "gr4hip_iir_destroy": (_i, [_vp]),
     "gr4hip_filter_params_default": (_i, [_vp]),
     "gr4hip_fir_design": (_i, [_i, _vp, _i, _vp, _sz, _psz]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "gr4hip_chain_reset": (_i, [_vp]),
     "gr4hip_chain_process": (_i, [_vp, _vp, _sz, _vp, _psz, _vp]),
     "gr4hip_chain_get_algo": (_i, [_vp, _pi]),
+    "gr4hip_chain_last_power_ratio": (_i, [_vp, _pf, _pi, _vp]),
     "gr4hip_chain_set_max_workgroups": (_i, [_vp, C.c_uint]),
     "gr4hip_chain_destroy": (_i, [_vp]),
     "gr4hip_math_const": (_i, [_i, _i, _vp, _vp, _sz, _vp, _vp]),

@@ -12,18 +12,34 @@ int  chain_fused_reset(ChainFused* c);
 int  chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st);
 void chain_fused_destroy(ChainFused* c);
 void chain_fused_set_max_workgroups(ChainFused* c, unsigned n);
+void chain_fused_set_measure(ChainFused* c, bool on);
+int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio);
+const float* chain_fused_history(const ChainFused* c);
+int  chain_fused_set_history(ChainFused* c, const float* d_hist256, hipStream_t st);
 } // namespace gr4
+int gr4hip_internal_fir_load_history(gr4hip_fir_t* f, const float* d_last256, hipStream_t st); // fir.hip
 
 using namespace gr4;
 
 struct gr4hip_chain {
     size_t          ntaps = 0, N = 0;
+    std::vector<float> taps;
     int             window = 0, algo = GR4HIP_CHAIN_UNFUSED;
     gr4hip_fir_t*   fir = nullptr;
     gr4hip_fft_t*   fft = nullptr;
     gr4::ChainFused* fused = nullptr;
     DeviceBuffer    d_y;
+    // dynamic-range guard (GR4HIP_CHAIN_AUTO on the fused kernel).  The fast-convolution kernels carry the float32 rounding of their transforms, ~2e-6 of the
+    // INPUT rms per output sample; the parity bar is 1e-5 of the OUTPUT, so they meet it while out_rms / in_rms >= 0.2, i.e. power ratio >= 0.04 (-14 dB).
+    // Every fused launch samples both powers (one frame in sixteen).  The first call after create / reset probes its first frames synchronously; later calls
+    // read the finished measurements of earlier ones without waiting.  Below the threshold the handle switches to the direct-form kernels (the
+    // reference's own arithmetic) from the call that finds out onwards, until reset.
+    bool            guard = false, probed = false, use_td = false;
+    float           last_ratio = -1.f; // most recent measured power ratio (< 0: none yet)
+    DeviceBuffer    d_hist_save;
 };
+constexpr float  kGuardMinPowerRatio = 0.04f;
+constexpr size_t kGuardProbeFrames   = 8; // in units of 8192-sample blocks
 
 extern "C" {
 
@@ -34,6 +50,7 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
     auto* c = new (std::nothrow) gr4hip_chain();
     GR4_REQUIRE(c, "out of host memory");
     c->ntaps  = ntaps;
+    c->taps.assign(h_taps, h_taps + ntaps);
     c->N      = fft_size;
     c->window = window;
     int use   = algo;
@@ -46,7 +63,8 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
         delete c;
         return GR4HIP_UNSUPPORTED;
     }
-    c->algo = use;
+    c->algo  = use;
+    c->guard = algo == GR4HIP_CHAIN_AUTO && use == GR4HIP_CHAIN_FUSED_FD && ntaps > 1;
     int rc;
     if (use == GR4HIP_CHAIN_UNFUSED || use == GR4HIP_CHAIN_TIME_DOMAIN) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, h_taps, ntaps, 1);
@@ -54,6 +72,7 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
         if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, fft_size, window, 0);
     } else {
         rc = chain_fused_create(&c->fused, h_taps, ntaps, fft_size, window, use);
+        if (!rc && c->guard) chain_fused_set_measure(c->fused, true);
     }
     if (rc) { gr4hip_chain_destroy(c); return rc; }
     *out = c;
@@ -62,7 +81,34 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
 
 int gr4hip_chain_reset(gr4hip_chain_t* c) {
     GR4_REQUIRE(c, "chain_reset: null handle");
+    c->probed = c->use_td = false;
+    c->last_ratio = -1.f;
+    if (c->fused && c->fir) { int rc = gr4hip_fir_reset(c->fir); if (rc) return rc; }
     return c->fused ? chain_fused_reset(c->fused) : gr4hip_fir_reset(c->fir);
+}
+
+// direct-form FIR kernel -> y in HBM -> FFT kernel (the GR4HIP_CHAIN_TIME_DOMAIN path; also where the guard sends a fused AUTO chain)
+static int chain_time_domain(gr4hip_chain* c, const void* d_in, size_t frames, float* d_mag2, gr4hip_stream_t stream) {
+    const size_t n  = frames * c->N;
+    int          rc = c->d_y.ensure(n * 2 * sizeof(float));
+    if (rc) return rc;
+    rc = gr4hip_fir_process(c->fir, d_in, n, c->d_y.ptr, nullptr, stream);
+    if (rc) return rc;
+    return gr4hip_fft_mag2(c->fft, c->d_y.ptr, frames, d_mag2, stream);
+}
+
+// the guard found the filter removing most of the input: from here on the stream runs through the direct-form kernels, starting from `d_hist256`
+static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, hipStream_t st) {
+    std::vector<float>& taps = c->taps;
+    int rc = GR4HIP_OK;
+    if (!c->fir) {
+        rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, taps.data(), taps.size(), 1);
+        if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN);
+        if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, c->N, c->window, 0);
+    }
+    if (!rc) rc = gr4hip_internal_fir_load_history(c->fir, d_hist256, st);
+    if (!rc) c->use_td = true;
+    return rc;
 }
 
 int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, float* d_mag2, size_t* n_frames_p, gr4hip_stream_t stream) {
@@ -71,13 +117,49 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
     if (n_frames_p) *n_frames_p = frames;
     if (frames == 0) return n_samples ? GR4HIP_INSUFFICIENT_INPUT : GR4HIP_OK;
     GR4_REQUIRE(d_in && d_mag2, "chain_process: null device pointer");
-    const size_t n = frames * c->N;
-    if (c->fused) return chain_fused_process(c->fused, static_cast<const float*>(d_in), frames, d_mag2, as_stream(stream));
-    int rc = c->d_y.ensure(n * 2 * sizeof(float));
-    if (rc) return rc;
-    rc = gr4hip_fir_process(c->fir, d_in, n, c->d_y.ptr, nullptr, stream);
-    if (rc) return rc;
-    return gr4hip_fft_mag2(c->fft, c->d_y.ptr, frames, d_mag2, stream);
+    if (c->fused && !c->guard) return chain_fused_process(c->fused, static_cast<const float*>(d_in), frames, d_mag2, as_stream(stream));
+    if (c->fused) { // GR4HIP_CHAIN_AUTO on the fused kernel: dynamic-range guard
+        hipStream_t  st  = as_stream(stream);
+        const float* x   = static_cast<const float*>(d_in);
+        const size_t per = c->N < 8192 ? 8192 / c->N : 1; // fft frames per 8192-sample block
+        if (c->use_td) return chain_time_domain(c, d_in, frames, d_mag2, stream);
+        float ratio;
+        if (chain_fused_power_ratio(c->fused, false, false, &ratio)) c->last_ratio = ratio; // an earlier launch has finished: no waiting
+        size_t done = 0;
+        if (!c->probed) { // first call after create / reset: the first blocks synchronously, before the rest of the span is committed to an algorithm
+            int rc = c->d_hist_save.ensure(256 * 2 * sizeof(float));
+            if (rc) return rc;
+            GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            const size_t probe = std::min(frames, kGuardProbeFrames * per);
+            rc = chain_fused_process(c->fused, x, probe, d_mag2, st);
+            if (rc) return rc;
+            if (chain_fused_power_ratio(c->fused, true, false, &ratio)) c->last_ratio = ratio;
+            c->probed = true;
+            done      = probe;
+            if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) { // redo the probed frames too, from the history the call started with
+                rc = chain_switch_to_time_domain(c, static_cast<const float*>(c->d_hist_save.ptr), st);
+                if (rc) return rc;
+                return chain_time_domain(c, d_in, frames, d_mag2, stream);
+            }
+        } else if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) { // an earlier call ran into the regime: switch before this one
+            int rc = chain_switch_to_time_domain(c, chain_fused_history(c->fused), st);
+            if (rc) return rc;
+            return chain_time_domain(c, d_in, frames, d_mag2, stream);
+        }
+        if (done == frames) return GR4HIP_OK;
+        return chain_fused_process(c->fused, x + done * c->N * 2, frames - done, d_mag2 + done * c->N, st);
+    }
+    return chain_time_domain(c, d_in, frames, d_mag2, stream);
+}
+
+int gr4hip_chain_last_power_ratio(gr4hip_chain_t* c, float* ratio, int* time_domain, gr4hip_stream_t stream) {
+    GR4_REQUIRE(c && ratio, "chain_last_power_ratio: null argument");
+    (void)stream;
+    float r;
+    if (c->fused && c->guard && chain_fused_power_ratio(c->fused, true, false, &r)) c->last_ratio = r; // waits for the last measured launch
+    *ratio = c->last_ratio;
+    if (time_domain) *time_domain = c->use_td ? 1 : 0;
+    return GR4HIP_OK;
 }
 
 int gr4hip_chain_set_max_workgroups(gr4hip_chain_t* c, unsigned n) {

@@ -51,6 +51,9 @@ struct ChainFdArgs {
     const float2* twS;    // small-FFT mode: W_fftSize^j
     float*        out;    // frames * 8192 mag2
     long          n_frames;
+    float*        pw;     // optional 16 x {sum |x|^2, sum of the outputs' power} + workgroups done, over every 16th frame of every workgroup (dynamic-range guard), else null
+    float*        pw_host; // page-locked {in, out}: written with one 8-byte store by the last workgroup to finish (no extra stream operation per launch)
+    unsigned      pw_seq;
     unsigned long long* dbg; // GR4_FD_TIMING only
 };
 
@@ -288,6 +291,8 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     // likewise the eight DMA pieces per wave of the next frame.  A wave that issues its 16 stores (or 8 DMAs) back to back sits
     // in VMEM issue for ~4000 cycles behind the other waves' requests and every barrier inherits the skew.
     float pend[16], pendi[16]; // (pendi: imaginary parts, kModeFir only -- y_f is complex)
+    float pw_in = 0.f, pw_out = 0.f; // dynamic-range guard: input and output power of the sampled frames
+    int   iter = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) pend[q] = pendi[q] = 0.f;
     long fprev = -1;
@@ -297,7 +302,8 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         if constexpr (!FFTONLY) dma_tail(f > 0 ? a.x + f * kN - 256 : a.hist, T0, wave, lane0);
         dma_frame(a.x + f * kN, B0, wave, lane0);
     }
-    for (; f < a.n_frames; f += gridDim.x, cur ^= 1) {
+    for (; f < a.n_frames; f += gridDim.x, cur ^= 1, ++iter) {
+        const bool measure = !FFTONLY && a.pw != nullptr && (iter & 15) == 0; // wave-uniform: one frame in sixteen pays ~50 extra VALU instructions
         // per-iteration opaque copy of the lane id: lane-dependent LDS / buffer offsets are recomputed here (a few VALU ops)
         // instead of being hoisted out of the loop as dozens of loop-invariant VGPRs
         int tl = threadIdx.x;
@@ -338,6 +344,10 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                 for (int m = 0; m < 16; ++m) v[m] = make_float2(v[m].x * wA[m], v[m].y * wA[m]);
             }
             if constexpr (!FFTONLY) {
+                if (measure) {
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) pw_in = fmaf(v[m].x, v[m].x, fmaf(v[m].y, v[m].y, pw_in));
+                }
                 if (par && n0 > 0) { // v[15] is x_f[N - 256 + n0]:  Dz[n0] = d[n0 - 1]
                     const float2 dd = csub(Tc[n0], v[15]);
                     Dre[n0 + (n0 >> 4)] = dd.x;
@@ -558,9 +568,50 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                 }
             }
         }
+        if constexpr (!FFTONLY) {
+            if (measure) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pw_out += MODE == kModeFir ? fmaf(pend[q], pend[q], pendi[q] * pendi[q]) : pend[q];
+            }
+        }
         fprev = f;
         GR4_STAMP(13);
         GR4_STAMP(14);
+    }
+    if constexpr (!FFTONLY) {
+        if (a.pw != nullptr) { // one pair of atomics per WORKGROUP, spread over 16 slots (4096 atomics on two addresses cost ~15 us at the end of every launch);
+                               // the last workgroup to finish folds the slots, hands the totals to the host and re-arms the accumulators
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                pw_in += __shfl_xor(pw_in, off);
+                pw_out += __shfl_xor(pw_out, off);
+            }
+            __syncthreads(); // (P below is not a DMA target; every lane is past its last use of it)
+            if ((threadIdx.x & 63) == 0) {
+                P[2 * (threadIdx.x >> 6)]     = pw_in;
+                P[2 * (threadIdx.x >> 6) + 1] = pw_out;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float si = 0.f, so = 0.f;
+#pragma unroll
+                for (int w = 0; w < kT / 64; ++w) { si += P[2 * w]; so += P[2 * w + 1]; }
+                float* slot = a.pw + 2 * (blockIdx.x & 15);
+                atomicAdd(slot, si);
+                atomicAdd(slot + 1, so);
+                __threadfence();
+                unsigned* done = reinterpret_cast<unsigned*>(a.pw + 32);
+                if (atomicAdd(done, 1u) == gridDim.x - 1) {
+                    __threadfence();
+                    float tin = 0.f, tout = 0.f;
+                    for (int k = 0; k < 16; ++k) { tin += atomicExch(a.pw + 2 * k, 0.f); tout += atomicExch(a.pw + 2 * k + 1, 0.f); }
+                    atomicExch(done, 0u);
+                    // ONE 8-byte store: the pair arrives whole, and a pair that differs from the last one seen is a new measurement
+                    (void)a.pw_seq;
+                    *reinterpret_cast<volatile unsigned long long*>(a.pw_host) = (unsigned long long)__float_as_uint(tin) | ((unsigned long long)__float_as_uint(tout) << 32);
+                }
+            }
+        }
     }
     if (DEFER && fprev >= 0) {
         const rsrc_t rq = make_rsrc(a.out + fprev * kN * (FIR ? 2 : 1), kN * sizeof(float) * (FIR ? 2 : 1));
@@ -592,7 +643,20 @@ struct ChainFused {
     DeviceBuffer d_stage_in, d_stage_out; // one zero-padded block for the tail of a span that is not a multiple of 8192 samples
     unsigned     max_wg   = 0; // 0 = one workgroup on every CU
     Chain16*     c16      = nullptr; // 8192-point plans: tables of the 16-wave kernel
-    ~ChainFused() { if (c16) chain16_destroy(c16); }
+    // dynamic-range guard (chain.hip / fir.hip decide with it): sampled input / output power of the last measured launch
+    bool         measure  = false;
+    DeviceBuffer d_pw;                 // {sum |x|^2, sum out, workgroups done}: accumulated by the kernel, re-armed by its last workgroup
+    float*       h_pw     = nullptr;   // page-locked, device-mapped {in, out, sequence number of the launch that wrote them}
+    float*       d_hpw    = nullptr;   // device view of h_pw
+    unsigned     pw_seq   = 0;         // measured launches so far
+    unsigned     pw_read  = 0;         // launches accounted for by the measurements handed out
+    unsigned long long pw_word = 0;    // the last {in, out} pair seen
+    hipStream_t  pw_stream = nullptr;  // stream of the last measured launch
+    float        win_gain = 1.f;       // mean w[n]^2 of the window the measured output carries (1: none)
+    ~ChainFused() {
+        if (c16) chain16_destroy(c16);
+        if (h_pw) (void)hipHostFree(h_pw);
+    }
 };
 
 int chain_fused_supported(size_t ntaps, size_t fft_size, int window, int algo) {
@@ -650,6 +714,9 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
         std::vector<float> w(fft_size, 1.f), wt(kN);
         if (window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR) rc = make_window(window, w.data(), fft_size, 1.6f); // fft.hpp:141: default beta
         for (int n = 0; n < kN; ++n) wt[n] = w[n % fft_size] * (1.0f / (float)kN);
+        double g = 0;
+        for (size_t n = 0; n < fft_size; ++n) g += (double)w[n] * w[n];
+        c->win_gain = (float)(g / (double)fft_size);
         if (!rc) rc = upload(c->d_win, wt);
     }
     if (!rc && c->small_log2n) {
@@ -683,7 +750,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         static const int use16 = [] { const char* e = std::getenv("GR4HIP_CHAIN16"); return e ? std::atoi(e) : 0; }();
         const bool plain_chain = !fir_mode && !fft_only && !c->windowed && c->small_log2n == 0;
         const bool plain_fft   = fft_only && !fft_window && !fft_spectrum;
-        if (use16 && c->c16 && (plain_chain || plain_fft)) {
+        if (use16 && c->c16 && (plain_chain || plain_fft) && !(c->measure && !fft_only)) { // (the dynamic-range guard samples its powers in the 8-wave kernel)
             const float* hist = hist256 ? hist256 : static_cast<const float*>(c->d_hist.ptr);
             int rc = chain16_run(c->c16, d_in, hist, n_frames, d_out, c->max_wg, plain_fft, st);
             if (rc) return rc;
@@ -703,6 +770,22 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     a.out      = d_out;
     a.n_frames = (long)n_frames;
     a.dbg      = nullptr;
+    a.pw       = nullptr;
+    const bool measure = c->measure && !fft_only;
+    if (measure) {
+        if (!c->h_pw) {
+            int rc = c->d_pw.ensure(36 * sizeof(float)); // 16 {in, out} slots, the done counter
+            if (rc) return rc;
+            GR4_HIP_TRY(hipMemset(c->d_pw.ptr, 0, 36 * sizeof(float)));
+            GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 4 * sizeof(float), hipHostMallocMapped));
+            std::memset(c->h_pw, 0, 4 * sizeof(float));
+            GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_hpw), c->h_pw, 0));
+        }
+        a.pw        = static_cast<float*>(c->d_pw.ptr);
+        a.pw_host   = c->d_hpw;
+        a.pw_seq    = ++c->pw_seq;
+        c->pw_stream = st;
+    }
 #ifdef GR4_FD_TIMING
     if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
     if (n_frames * 8 * 16 * 8 <= ((size_t)1 << 26)) a.dbg = g_dbg;
@@ -791,6 +874,28 @@ int chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, si
 }
 
 void chain_fused_destroy(ChainFused* c) { delete c; }
+// dynamic-range guard: sampled power ratio (output / input, window gain taken out) of the most recent measured launch.
+// wait: synchronise on that launch; otherwise only report it when it has already finished.  Returns 1 with *ratio set, 0 if nothing (new) is available.
+void chain_fused_set_measure(ChainFused* c, bool on) { c->measure = on; }
+int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio) {
+    if (!c->h_pw || c->pw_seq == c->pw_read) return 0;
+    if (wait && hipStreamSynchronize(c->pw_stream) != hipSuccess) return 0;
+    const unsigned long long word = *reinterpret_cast<volatile unsigned long long*>(c->h_pw); // {in, out} of the most recent finished launch, stored whole
+    if (!wait && word == c->pw_word) return 0;                                                  // nothing new has arrived
+    c->pw_word = word;
+    c->pw_read = c->pw_seq; // (with wait: exactly; without: at least one newer launch has reported)
+    float pair[2];
+    std::memcpy(pair, &word, sizeof(pair));
+    const double in = pair[0], out = pair[1];
+    // spectra: sum_k |Y_k|^2 = N sum_n |w_n y_n|^2 ~ N mean(w^2) sum |y|^2; the complex FIR output is y itself
+    *ratio = in > 0 ? (float)(out / (in * (fir_output ? 1.0 : (double)kN * c->win_gain))) : 1.f;
+    return 1;
+}
+const float* chain_fused_history(const ChainFused* c) { return static_cast<const float*>(c->d_hist.ptr); } // the 256 samples before the next call's first frame
+int chain_fused_set_history(ChainFused* c, const float* d_hist256, hipStream_t st) {
+    GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, d_hist256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    return GR4HIP_OK;
+}
 void chain_fused_set_max_workgroups(ChainFused* c, unsigned n) { c->max_wg = n; }
 
 #ifdef GR4_FD_TIMING

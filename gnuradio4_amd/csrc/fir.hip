@@ -365,6 +365,18 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     return GR4HIP_OK;
 }
 
+} // extern "C"
+
+// (library-internal, chain.hip) make `d_last256` -- the 256 complex samples in front of the next input sample -- this filter's history: the fused chain
+// hands its stream over to the direct-form kernels when the dynamic-range guard switches algorithms
+int gr4hip_internal_fir_load_history(gr4hip_fir_t* f, const float* d_last256, hipStream_t st) {
+    GR4_REQUIRE(f && f->S == 2 && f->hcap <= 256, "fir_load_history: complex filter with <= 256 samples of history expected");
+    GR4_HIP_TRY(hipMemcpyAsync(f->d_hist[f->cur].ptr, d_last256 + (256 - f->hcap) * 2, f->hcap * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return GR4HIP_OK;
+}
+
+extern "C" {
+
 int gr4hip_fir_destroy(gr4hip_fir_t* f) {
     if (f && f->fd) chain_fused_destroy(f->fd);
     delete f;

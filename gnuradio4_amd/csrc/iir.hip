@@ -322,7 +322,9 @@ __global__ __launch_bounds__(kIirBS) void iir_pass_y(const float* __restrict__ x
 // the re-run) were built too: stage 1.8 -> 0.7 us, but no gain in throughput (272 / 429 vs 275 / 423 Gsamples/s, spill-free); the ticket must
 // not be drawn before the look-back is over (a ticket held by a block that is still busy makes every successor wait for its Z: 192).
 // Block indices are tickets drawn at the start (a block only ever waits for blocks that already run), status words and ticket are zeroed per call.
-// Waiting is bounded: a waiter that gives up raises err[0] and the span is recomputed by the three-pass kernels.
+// Waiting is bounded: a waiter that gives up (never observed) raises a page-locked error word; the span's output is then INVALID and the handle says so:
+// gr4hip_iir_status() after the caller's own stream synchronisation, or at the latest the next process / reset call, returns GR4HIP_RUNTIME_ERROR
+// (nothing is recomputed behind the caller's back; GR4HIP_IIR_THREE_PASS=1 selects the three-pass kernels, which cannot time out).
 struct IirOnePassArgs {
     const float* x;
     float*       y;
@@ -678,17 +680,15 @@ static std::vector<double> mat_square(const std::vector<double>& A, int M) {
     return C;
 }
 
+static int iir_take_error(gr4hip_iir* f, const char* where);
+
 template <int ORD, int NSEC>
 static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t st) {
     constexpr int MP      = ORD * NSEC;
     const long    nblocks = ceil_div(n, (long)kIirBS * kIirL);
     if constexpr (MP <= 8) {
         if (!std::getenv("GR4HIP_IIR_THREE_PASS")) { // (developer switch: the three-pass kernels below stay the path for MP = 16)
-            if (f->h_err && *f->h_err) { // a previous launch of this handle gave up waiting for a predecessor block: its output was not valid
-                *f->h_err = 0;
-                set_error("iir: the single-pass kernel timed out in its look-back on an earlier call (results of that call are invalid); set GR4HIP_IIR_THREE_PASS=1 to use the three-pass kernels");
-                return GR4HIP_RUNTIME_ERROR;
-            }
+            if (const int e = iir_take_error(f, "iir_process")) return e; // a previous launch of this handle gave up waiting for a predecessor block
             if (!f->h_err) {
                 GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&f->h_err), sizeof(unsigned), hipHostMallocMapped));
                 *f->h_err = 0;
@@ -838,11 +838,27 @@ int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const floa
     return GR4HIP_OK;
 }
 
+static int iir_take_error(gr4hip_iir* f, const char* where) {
+    if (f->h_err && *f->h_err) {
+        *f->h_err = 0;
+        set_error("%s: the single-pass IIR kernel timed out in its look-back on an earlier call of this handle (the output of that call is invalid); "
+                  "GR4HIP_IIR_THREE_PASS=1 selects the three-pass kernels", where);
+        return GR4HIP_RUNTIME_ERROR;
+    }
+    return GR4HIP_OK;
+}
+
 int gr4hip_iir_reset(gr4hip_iir_t* f) {
     GR4_REQUIRE(f, "iir_reset: null handle");
-    for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(f->d_state[k].ptr, 0, kIirMaxM * sizeof(float)));
+    for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(f->d_state[k].ptr, 0, kIirMaxM * sizeof(float))); // (hipMemset synchronises: every earlier launch has finished)
     f->cur = 0;
-    return GR4HIP_OK;
+    return iir_take_error(f, "iir_reset");
+}
+
+int gr4hip_iir_status(gr4hip_iir_t* f, gr4hip_stream_t stream) {
+    GR4_REQUIRE(f, "iir_status: null handle");
+    GR4_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return iir_take_error(f, "iir_status");
 }
 
 int gr4hip_iir_process(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream) {

@@ -157,11 +157,16 @@ int gr4hip_decimate(int dtype, const void* d_in, size_t n_in, size_t decim, void
  * gr::filter::Filter<float>::processOne == cascade of sections through detail::computeFilter
  * (algorithm/.../filter/FilterTool.hpp:116-158, 244-246), and gr::filter::iir_filter<float, form>::processOne
  * (time_domain_filter.hpp:89-121) for nsections == 1.  b: [nsections][nb], a: [nsections][na], a[.][0] == 1.
- * All four forms compute the same transfer function from zero state; `form` is recorded for introspection. */
+ * All four forms compute the same transfer function from zero state and are EVALUATED as direct form II (the parallel-in-time scan works on the DF-II
+ * state); `form` is recorded for introspection only, so rounding can differ from the reference's DF_I / transposed forms in the last bits (the four forms
+ * agree to 1e-5 upstream too, qa_filter.cpp:53-128).
+ * gr4hip_iir_status: synchronises `stream` and reports a look-back time-out of an earlier launch of this handle (a bounded wait gave up: never observed,
+ * but then that call's output is invalid) as GR4HIP_RUNTIME_ERROR; the next process / reset call reports it too. */
 typedef struct gr4hip_iir gr4hip_iir_t;
 int gr4hip_iir_create(gr4hip_iir_t** iir, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na);
 int gr4hip_iir_reset(gr4hip_iir_t* iir);
 int gr4hip_iir_process(gr4hip_iir_t* iir, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream);
+int gr4hip_iir_status(gr4hip_iir_t* iir, gr4hip_stream_t stream);
 int gr4hip_iir_destroy(gr4hip_iir_t* iir);
 
 /* ------------------------------------------------------------------------------------------------ a5 (host-side design)
@@ -210,6 +215,15 @@ int gr4hip_chain_reset(gr4hip_chain_t* chain);
 int gr4hip_chain_process(gr4hip_chain_t* chain, const void* d_in_c32, size_t n_samples, float* d_mag2, size_t* n_frames,
                          gr4hip_stream_t stream);
 int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
+/* Dynamic-range guard of GR4HIP_CHAIN_AUTO.  The fused kernels filter in the frequency domain and carry the float32 rounding of their transforms: an error
+ * floor of ~2e-6 of the INPUT rms per output sample.  The parity bar is 1e-5 of the OUTPUT, so they meet it while the filter passes at least -14 dB of the
+ * input power (power ratio >= 0.04) and miss it when a strong out-of-band signal is removed.  Every fused launch of an AUTO chain therefore samples input and
+ * output power (one frame in sixteen); the first call after create / reset probes its first 8 blocks synchronously, later calls
+ * read the finished measurements of earlier ones without waiting; when the ratio falls below 0.04 the chain continues with the direct-form kernels (the
+ * reference's arithmetic, history handed over) -- on the first call before anything is published, otherwise from the call after the one that ran into it --
+ * until gr4hip_chain_reset.  Explicit GR4HIP_CHAIN_FUSED_FD never switches.  This call waits for the last measured launch and returns its ratio
+ * (< 0: nothing measured yet) and whether the chain now runs in the time domain. */
+int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time_domain, gr4hip_stream_t stream);
 /* The fused kernels are persistent: one workgroup per CU that takes ALL of the CU's registers and LDS, so nothing else (e.g. the RCCL
  * kernels of a fan-in collective on another stream) runs beside them.  n > 0 caps the grid at n workgroups and leaves the other CUs free;
  * 0 = all CUs (default).  No effect on the unfused path. */

@@ -332,6 +332,17 @@ def test_iir_cascade_parity(G, order, design):
     assert _rel(y, truth) <= 2 * _rel(cpu32, truth) + 2e-6
 
 
+def test_iir_status_is_clean_after_long_streams(G):
+    """gr4hip_iir_status: where a caller synchronises anyway; a look-back time-out (never observed) would surface here instead of on the next call"""
+    bi, ai = G.blocks.design_iir(G.capi.LOWPASS, 8, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    f = G.iir_filter(bi, ai)
+    x = G.synth_f32(1 << 24, seed=2)
+    for _ in range(3):
+        f.process_bulk(x)
+    f.status()
+    f.reset()
+
+
 def test_iir_long_stream_crosses_block_scan_groups(G):
     """2^24 + 2^22 + 5 samples: more than one 2048-block group of the block-level scan, odd tail; against the float64 oracle"""
     import gnuradio4_amd.blocks as B
@@ -718,22 +729,29 @@ def test_chain_shapes_outside_the_fused_kernel(G, N, ntaps, window):
 
 def test_chain_dynamic_range_and_the_time_domain_algo(G):
     """a tone 30 dB above the noise, removed by a narrow low-pass: the fast-convolution kernels carry the float32 rounding of their transforms, which scales
-    with the INPUT (error floor ~2e-6 of the input rms per output sample); relative to the much smaller OUTPUT that exceeds 1e-5, and CHAIN_TIME_DOMAIN /
-    FIR_TIME_DOMAIN (the reference's direct-form arithmetic) is what meets the bar there"""
+    with the INPUT (error floor ~2e-6 of the input rms per output sample); relative to the much smaller OUTPUT that exceeds 1e-5.  CHAIN_AUTO measures the
+    power ratio and hands such a stream to the direct-form kernels (the reference's arithmetic) before anything is published; an explicit CHAIN_FUSED_FD does not"""
     N, frames, ntaps = 8192, 80, 64
     b = O.design_taps_hamming_lowpass(ntaps, 0.02)
     x = O.signal_c32(77, frames * N, tone_frel=0.31, tone_amp=30.0)
     check = slice(70 * N, 72 * N)  # two frames deep inside the span (the oracle's float64 chain over the whole span is the truth)
     truth, _ = O.chain(b, x, N, 3, truth=True)
-    truth = truth[check]
     in_rms = float(np.sqrt(np.mean(np.abs(x) ** 2)))
     errs = {}
-    for algo in (G.capi.CHAIN_AUTO, G.capi.CHAIN_TIME_DOMAIN):
+    for algo in (G.capi.CHAIN_AUTO, G.capi.CHAIN_FUSED_FD, G.capi.CHAIN_TIME_DOMAIN):
         ch = G.Chain(b, N, "Hann", algo)
-        got = ch.process_bulk(dev(x)).cpu().numpy().ravel()[check]
-        errs[algo] = _rel(got, truth)
-    assert errs[G.capi.CHAIN_TIME_DOMAIN] <= TOL
-    assert errs[G.capi.CHAIN_AUTO] > errs[G.capi.CHAIN_TIME_DOMAIN]  # the price of the fused kernel on this input ...
+        got = ch.process_bulk(dev(x)).cpu().numpy().ravel()
+        errs[algo] = _rel(got[check], truth[check])
+        if algo == G.capi.CHAIN_AUTO:
+            assert _rel(got, truth) <= TOL  # every frame, the probed first ones included
+            ratio, td = ch.last_power_ratio()
+            assert td and 0 <= ratio < 0.04, (ratio, td)
+            # ... and it stays there across calls (history handed over), until reset
+            x2 = O.signal_c32(78, 4 * N, tone_frel=0.31, tone_amp=30.0)
+            t2, _ = O.chain(b, np.concatenate([x, x2]), N, 3, truth=True)
+            assert _rel(ch.process_bulk(dev(x2)).cpu().numpy().ravel(), t2[frames * N:]) <= TOL
+    assert errs[G.capi.CHAIN_TIME_DOMAIN] <= TOL and errs[G.capi.CHAIN_AUTO] <= TOL
+    assert errs[G.capi.CHAIN_FUSED_FD] > TOL > errs[G.capi.CHAIN_TIME_DOMAIN]  # the price of the fused kernel on this input ...
     # ... and its bound: amplitude errors stay below 4e-6 of the input rms: |d mag2| <= 2 |Y| dY + dY^2 with dY = 4e-6 in_rms sqrt(N sum w^2)
     y, _ = O.fir(b, x)
     fir_auto = G.fir_filter(b, torch.complex64)
@@ -743,6 +761,30 @@ def test_chain_dynamic_range_and_the_time_domain_algo(G):
     assert np.max(np.abs(ya - y)) <= 4e-6 * in_rms    # fast convolution: floor relative to the input
     assert _rel(yt, y) <= TOL                          # direct form: inside the bar relative to the output
     assert _rel(ya, y) > _rel(yt, y)
+
+
+def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
+    """the guard of CHAIN_AUTO: pass-band input never leaves the fused kernel; an interferer that appears in a LATER call is found by that call's own
+    measurement and the following calls run in the time domain (the one call in between carries the fused kernel's floor: 4e-6 of the input rms)"""
+    N, ntaps = 8192, 64
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    clean = O.signal_c32(5, 40 * N, tone_frel=0.01, tone_amp=1.0)        # tone in the pass band
+    loud = O.signal_c32(6, 40 * N, tone_frel=0.31, tone_amp=30.0)        # interferer far outside
+    ch = G.Chain(b, N, "None")
+    assert ch.algo == G.capi.CHAIN_FUSED_FD
+    parts = [ch.process_bulk(dev(clean)).cpu().numpy().ravel()]
+    r, td = ch.last_power_ratio()
+    assert not td and r > 0.04
+    parts.append(ch.process_bulk(dev(loud)).cpu().numpy().ravel())     # still fused: this call is the one that measures the drop
+    r, td = ch.last_power_ratio()
+    assert 0 <= r < 0.04
+    parts.append(ch.process_bulk(dev(loud)).cpu().numpy().ravel())     # switched before this call, history carried over
+    assert ch.last_power_ratio()[1]
+    truth, _ = O.chain(b, np.concatenate([clean, loud, loud]), N, 0, truth=True)
+    t = truth.reshape(3, -1)
+    assert _rel(parts[0], t[0]) <= TOL and _rel(parts[2], t[2]) <= TOL
+    ch.reset()
+    assert _rel(ch.process_bulk(dev(clean)).cpu().numpy().ravel(), t[0]) <= TOL and not ch.last_power_ratio()[1]  # a reset re-arms the fused kernel
 
 
 def test_chain_random_configurations(G):
