@@ -146,6 +146,8 @@ namespace gr4 { // chain_fused.hip: fast-convolution path for long complex input
 struct ChainFused;
 int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
 int  chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_y, hipStream_t st);
+void chain_fused_set_measure(ChainFused* c, bool on);
+int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio);
 void chain_fused_destroy(ChainFused* c);
 
 // fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
@@ -180,6 +182,10 @@ struct gr4hip_fir {
     int                cur = 0;
     int                algo = GR4HIP_FIR_AUTO; // gr4hip_fir_set_algo
     gr4::ChainFused*   fd  = nullptr; // complex, decim 1, ntaps <= 256: frequency-domain plan (created on first use)
+    // dynamic-range guard of GR4HIP_FIR_AUTO (same policy as the chain's, include/gr4hip.h): the fast convolution's error floor is ~2e-6 of the INPUT rms;
+    // below an output / input power ratio of 0.04 the direct form takes over (first use: probed synchronously; later: from finished measurements)
+    bool               fd_probed = false, fd_blocked = false;
+    float              fd_ratio  = -1.f;
     DeviceBuffer       d_hist256;
     DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
     int                mKp = 0, mKS = 0;
@@ -251,6 +257,8 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     f->taps.assign(h_taps, h_taps + ntaps);
     f->ntaps = ntaps;
     if (f->fd) { chain_fused_destroy(f->fd); f->fd = nullptr; } // rebuilt from the new taps on next use
+    f->fd_probed = f->fd_blocked = false;
+    f->fd_ratio  = -1.f;
     f->mKS = 0;
     int rc   = fir_upload_taps(f);
     if (rc) return rc;
@@ -263,6 +271,8 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
 
 int gr4hip_fir_reset(gr4hip_fir_t* f) {
     GR4_REQUIRE(f, "fir_reset: null handle");
+    f->fd_probed = f->fd_blocked = false;
+    f->fd_ratio  = -1.f;
     return fir_alloc_hist(f);
 }
 
@@ -287,18 +297,37 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     size_t       done = 0; // samples already produced by the frequency-domain path
     // complex<float>, no decimation, <= 256 taps, long input: whole 8192-sample frames go through the fused FFT -> xH -> inverse
     // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
-    if (f->S == 2 && f->decim == 1 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO) {
+    if (f->S == 2 && f->decim == 1 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
         int rc = GR4HIP_OK;
-        if (!f->fd) rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
+        if (!f->fd) {
+            rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
+            if (!rc && f->ntaps > 1) chain_fused_set_measure(f->fd, true);
+        }
         if (!rc) rc = f->d_hist256.ensure(256 * sizeof(float2));
         if (rc) return rc;
         hipLaunchKernelGGL(fir_hist_widen_kernel<float2>, dim3(1), dim3(256), 0, st, (const float2*)hist, (int)f->hcap, (float2*)f->d_hist256.ptr, 256);
         GR4_LAUNCH_CHECK();
         const size_t frames = n_in / kFdFrame;
-        rc = chain_fused_fir(f->fd, x, (const float*)f->d_hist256.ptr, frames, y, st);
-        if (rc) return rc;
-        done = frames * kFdFrame;
-        hist = x + (done - f->hcap) * 2; // the hcap samples in front of the remainder are part of the input itself
+        float        ratio;
+        if (chain_fused_power_ratio(f->fd, false, true, &ratio)) f->fd_ratio = ratio; // a finished earlier launch: no waiting
+        size_t probe = 0;
+        if (!f->fd_probed && f->ntaps > 1) { // first fast convolution of this stream: eight frames, synchronously, before the span is committed to it
+            probe = std::min<size_t>(frames, 8);
+            rc    = chain_fused_fir(f->fd, x, (const float*)f->d_hist256.ptr, probe, y, st);
+            if (rc) return rc;
+            if (chain_fused_power_ratio(f->fd, true, true, &ratio)) f->fd_ratio = ratio;
+            f->fd_probed = true;
+        }
+        if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) {
+            f->fd_blocked = true; // the direct form below redoes the probed frames too
+        } else {
+            if (probe < frames) {
+                rc = chain_fused_fir(f->fd, x + probe * kFdFrame * 2, probe ? x + (probe * kFdFrame - 256) * 2 : (const float*)f->d_hist256.ptr, frames - probe, y + probe * kFdFrame * 2, st);
+                if (rc) return rc;
+            }
+            done = frames * kFdFrame;
+            hist = x + (done - f->hcap) * 2; // the hcap samples in front of the remainder are part of the input itself
+        }
     }
     // float, no decimation, 33..256 taps, long 16-byte-aligned output: block-Toeplitz product on the f32 MFMA units (about twice the
     // rate of the register-window VALU kernel, which is FP32-issue bound from ~48 taps on)

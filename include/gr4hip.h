@@ -132,6 +132,8 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
 /* GR4HIP_FIR_AUTO (default): long complex spans take the fast-convolution kernel.  Its float32 error floor is ~2e-6 of the INPUT rms per output sample
  * (three transforms' worth of rounding), the direct form's ~2e-7: when out-of-band signals that the filter removes are much stronger than what it
  * passes, GR4HIP_FIR_TIME_DOMAIN keeps the error relative to the OUTPUT inside the 1e-5 parity bar (the reference's own arithmetic, 1024 flop/sample). */
+/* FIR_AUTO carries the same dynamic-range guard as GR4HIP_CHAIN_AUTO (gr4hip_chain_last_power_ratio below): the first fast convolution of a stream is probed
+ * on eight frames, later ones are watched through the powers every launch samples, and below an output / input power ratio of 0.04 the direct form takes over. */
 typedef enum { GR4HIP_FIR_AUTO = 0, GR4HIP_FIR_TIME_DOMAIN = 1 } gr4hip_fir_algo;
 int gr4hip_fir_set_algo(gr4hip_fir_t* fir, int algo);
 int gr4hip_fir_process(gr4hip_fir_t* fir, const void* d_in, size_t n_in, void* d_out, size_t* n_out, gr4hip_stream_t stream);
