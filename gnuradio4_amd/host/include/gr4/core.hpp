@@ -83,7 +83,16 @@ public:
 // ---------------------------------------------------------------------------------------------- property_map (settings payload)
 using pmt = std::variant<bool, std::int64_t, std::uint64_t, double, float, std::string, std::complex<float>, std::complex<double>, std::vector<float>,
                          std::vector<double>, std::vector<std::int64_t>>;
-using property_map = std::map<std::string, pmt, std::less<>>;
+// (the reference's property_map is pmt::Value::Map; block code uses the std::map surface plus find_value(), ValueMap.hpp:1811-1830)
+struct property_map : std::map<std::string, pmt, std::less<>> {
+    using base_t = std::map<std::string, pmt, std::less<>>;
+    using base_t::base_t;
+    property_map() = default;
+    [[nodiscard]] std::optional<pmt> find_value(std::string_view key) const {
+        const auto it = this->find(key);
+        return it == this->end() ? std::nullopt : std::optional<pmt>(it->second);
+    }
+};
 
 namespace detail {
 template <typename T>

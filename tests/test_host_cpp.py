@@ -36,6 +36,28 @@ def test_host_selftest_and_config0_plumbing(host_bins, tmp_path):
     assert abs(np.max(np.abs(y[-2000:])) - 1.0) < 2e-2
 
 
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="container-only: needs the reference tree where it lies (nothing of it travels)")
+def test_reference_block_headers_compile_unmodified(tmp_path):
+    """SURVEY.md 8(b) row 1, "existing block source must compile unchanged against the new headers": the reference's own
+    blocks/math/include/gnuradio-4.0/math/{Math,Rotator}.hpp, included from /root/reference as they are, compiled against this host layer's
+    gnuradio-4.0/ forwarding headers, instantiated in a Graph and run on the host path against the vectors of qa_Math.cpp:59-149 and
+    qa_Rotator.cpp:69-92 (gnuradio4_amd/host/tests/test_reference_dropin.cpp).  The only include paths: this layer, and the reference's blocks/math."""
+    exe = tmp_path / "test_reference_dropin"
+    cmd = ["g++", "-std=c++20", "-Wall", "-Wextra", "-O1", "-I" + os.path.join(ROOT, "gnuradio4_amd", "host", "include"),
+           "-I" + os.path.join(REFERENCE, "blocks", "math", "include"), os.path.join(ROOT, "gnuradio4_amd", "host", "tests", "test_reference_dropin.cpp"), "-o", str(exe)]
+    c = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stderr[-4000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "reference drop-in: all checks passed" in r.stdout, r.stdout + r.stderr
+    assert "(Math.hpp unmodified)" in r.stdout and "(MathOpMultiPortImpl unmodified)" in r.stdout and "(Rotator.hpp unmodified)" in r.stdout
+    # nothing of the reference's text is kept in the repository: the test program only #includes it
+    src = open(os.path.join(ROOT, "gnuradio4_amd", "host", "tests", "test_reference_dropin.cpp")).read()
+    assert "#include <gnuradio-4.0/math/Math.hpp>" in src and "struct MathOpImpl" not in src
+
+
 def _inputs(tmp_path, N, frames, ntaps):
     x = O.signal_c32(42, frames * N)
     b = O.design_taps_hamming_lowpass(ntaps, 0.1)
