@@ -888,7 +888,8 @@ int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* r
     std::memcpy(pair, &word, sizeof(pair));
     const double in = pair[0], out = pair[1];
     // spectra: sum_k |Y_k|^2 = N sum_n |w_n y_n|^2 ~ N mean(w^2) sum |y|^2; the complex FIR output is y itself
-    *ratio = in > 0 ? (float)(out / (in * (fir_output ? 1.0 : (double)kN * c->win_gain))) : 1.f;
+    const double nfft = c->small_log2n ? (double)(1 << c->small_log2n) : (double)kN; // the spectra summed are fftSize-point ones
+    *ratio = in > 0 ? (float)(out / (in * (fir_output ? 1.0 : nfft * c->win_gain))) : 1.f;
     return 1;
 }
 const float* chain_fused_history(const ChainFused* c) { return static_cast<const float*>(c->d_hist.ptr); } // the 256 samples before the next call's first frame

@@ -150,6 +150,13 @@ void chain_fused_set_measure(ChainFused* c, bool on);
 int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio);
 void chain_fused_destroy(ChainFused* c);
 
+// fir_decim_fd.hip: decimate-by-8 real FIR (<= 1024 taps) as overlap-save blocks in the frequency domain
+struct FirDecimFd;
+int  fir_decim_fd_supported(size_t ntaps, size_t decim);
+int  fir_decim_fd_create(FirDecimFd** out, const float* taps, size_t ntaps);
+void fir_decim_fd_destroy(FirDecimFd* c);
+int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, const float* d_hist1024, size_t n_blocks, float* d_out, hipStream_t st);
+
 // fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st);
@@ -186,6 +193,7 @@ struct gr4hip_fir {
     // below an output / input power ratio of 0.04 the direct form takes over (first use: probed synchronously; later: from finished measurements)
     bool               fd_probed = false, fd_blocked = false;
     float              fd_ratio  = -1.f;
+    gr4::FirDecimFd*   dfd = nullptr; // float, decim 8, <= 1024 taps: frequency-domain decimator (created on first use)
     DeviceBuffer       d_hist256;
     DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
     int                mKp = 0, mKS = 0;
@@ -257,6 +265,7 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     f->taps.assign(h_taps, h_taps + ntaps);
     f->ntaps = ntaps;
     if (f->fd) { chain_fused_destroy(f->fd); f->fd = nullptr; } // rebuilt from the new taps on next use
+    if (f->dfd) { fir_decim_fd_destroy(f->dfd); f->dfd = nullptr; }
     f->fd_probed = f->fd_blocked = false;
     f->fd_ratio  = -1.f;
     f->mKS = 0;
@@ -348,9 +357,27 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         if (rc) return rc;
         done = n_in;
     }
+    // float, decimate by 8, <= 1024 taps, long 16-byte-aligned span: overlap-save blocks of 8192 samples in the frequency domain (~35 lane-operations per
+    // input sample instead of 2 K / 8 flop: HBM / power-bound instead of FP32-bound); the remainder (< 7168 samples) takes the kernels below
+    constexpr size_t kDfHopS = 7168, kDfMinBlocks = 64;
+    if (f->S == 1 && f->algo == GR4HIP_FIR_AUTO && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 && n_in >= kDfMinBlocks * kDfHopS &&
+        (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && !std::getenv("GR4HIP_FIR_NO_DECIM_FD")) {
+        int rc = GR4HIP_OK;
+        if (!f->dfd) rc = fir_decim_fd_create(&f->dfd, f->taps.data(), f->ntaps);
+        if (!rc) rc = f->d_hist256.ensure(1024 * sizeof(float));
+        if (rc) return rc;
+        const int hu = (int)std::min<size_t>(f->hcap, 1024);
+        hipLaunchKernelGGL(fir_hist_widen_kernel<float>, dim3(4), dim3(256), 0, st, hist + (f->hcap - hu), hu, (float*)f->d_hist256.ptr, 1024);
+        GR4_LAUNCH_CHECK();
+        const size_t blocks = n_in / kDfHopS;
+        rc = fir_decim_fd_run(f->dfd, x, (const float*)f->d_hist256.ptr, blocks, y, st);
+        if (rc) return rc;
+        done = blocks * kDfHopS;
+        hist = x + (done - f->hcap); // the hcap samples in front of the remainder are part of the input itself
+    }
     // float polyphase decimator with >= 16 taps per phase and a long span: the same contraction with the D phase products summed in
     // one accumulator tile (BASELINE configs[2]: decim 8, 1024 taps)
-    if (f->S == 1 && f->decim >= 2 && ceil_div(f->ntaps, f->decim) >= 16 && ceil_div(f->ntaps, f->decim) <= 256 && n_out >= (1u << 14) &&
+    if (done == 0 && f->S == 1 && f->decim >= 2 && ceil_div(f->ntaps, f->decim) >= 16 && ceil_div(f->ntaps, f->decim) <= 256 && n_out >= (1u << 14) &&
         (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
         int rc = GR4HIP_OK;
         if (f->mKS == 0) {
@@ -378,7 +405,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         const size_t lds = f->decim * (Lf + (size_t)f->G * E) * sizeof(float);
         if (lds > 150 * 1024) continue;
         const float* xr = x + done * f->S;
-        float*       yr = y + done * f->S;
+        float*       yr = y + (done / f->decim) * f->S;
         const long   ni = (long)(n_in - done), no = (long)((n_in - done) / f->decim);
         if (f->S == 1) rc = bs == 256 ? fir_launch<1, 256>(f, xr, hist, yr, ni, no, lds, st) : bs == 128 ? fir_launch<1, 128>(f, xr, hist, yr, ni, no, lds, st) : fir_launch<1, 64>(f, xr, hist, yr, ni, no, lds, st);
         else rc = bs == 256 ? fir_launch<2, 256>(f, xr, hist, yr, ni, no, lds, st) : bs == 128 ? fir_launch<2, 128>(f, xr, hist, yr, ni, no, lds, st) : fir_launch<2, 64>(f, xr, hist, yr, ni, no, lds, st);
@@ -408,6 +435,7 @@ extern "C" {
 
 int gr4hip_fir_destroy(gr4hip_fir_t* f) {
     if (f && f->fd) chain_fused_destroy(f->fd);
+    if (f && f->dfd) fir_decim_fd_destroy(f->dfd);
     delete f;
     return GR4HIP_OK;
 }

@@ -1,0 +1,299 @@
+// fir_decim_fd.hip -- decimate-by-8 real FIR (<= 1025 taps) in the frequency domain for gfx950: BASELINE.json configs[2]'s filter.
+//
+// BasicFilterProto's decimating processBulk (blocks/filter/.../time_domain_filter.hpp:190-204) keeps y[8 m] of y[n] = sum_k b[k] x[n - k].  In direct
+// (polyphase) form that is 2 K / 8 = 256 flop per input sample at 1024 taps -- FP32-bound at ~340 G input samples/s on the matrix pipe (fir_batched.hip).
+// Here the kept outputs come from overlap-save blocks of N = 8192 real samples (overlap V = 1024, hop 7168 = 896 outputs):
+//
+//   z[n] = xb[2 n] + i xb[2 n + 1]                       the real block as 4096 complex points
+//   Z    = FFT_4096(z)                                     decimation in frequency 8 x 512: cross pass + wave-private 512-point transforms (chain16.hip)
+//   G[r] = sum_{j<4} R[r + 1024 j] Z[r + 1024 j]          r < 1024: real-FFT untangling, times H, and the alias sum of the decimation in ONE table:
+//          R[k] = H[k] (1 - i W_8192^k)/2 + conj( H[4096-k] (1 + i W_8192^{4096-k})/2 ),  R[0] := (R[0] + R[4096])/2;  all four terms sit in ONE lane
+//   y[8 i] = Re( IFFT_1024(G) )[i] / 4                    valid for i >= 128: wave-private 128-point inverse transforms + one radix-8 pass across the waves
+//
+// (derivation and a float64 check of the identity: tools/proto_decim_fd.py).  ~35 VALU lane-operations per input sample instead of 256 flop; HBM 4 B in
+// (+ 14 % overlap re-read) + 0.5 B out per sample.  One workgroup of 512 lanes (8 waves, <= 128 VGPRs) per block, two workgroups per CU, persistent,
+// the next block streams into the landing buffer by LDS-DMA while this one is transformed.
+#include "common.hpp"
+#include "buffer_ops.hpp"
+#include "fft_radix.hpp"
+#include "wave16_common.hpp"
+
+#include <cmath>
+#include <complex>
+
+namespace gr4 {
+
+constexpr int kDfN   = 8192;            // real samples per block
+constexpr int kDfV   = 1024;            // overlap (history) samples
+constexpr int kDfHop = kDfN - kDfV;     // 7168 new samples = 896 outputs per block
+constexpr int kDfT   = 512;             // lanes per workgroup
+constexpr int kDfRS  = 4552;            // bytes per wave-private region (568 float2 + 8)
+constexpr int kDfOffW = 32768;          // landing buffer: 8192 floats at 0
+constexpr int kDfOffF = kDfOffW + 8 * kDfRS; // F_q[i''] of the inverse transforms: 8 x 128 float2 (pitch 129: the final pass reads 8 rows per lane)
+constexpr int kDfLds  = kDfOffF + 8 * 129 * 8;
+static_assert(2 * kDfLds <= 160 * 1024, "two workgroups per CU");
+
+struct DecimFdArgs {
+    const float*  x;       // input samples (the span); block j covers positions j * 7168 - 1024 .. + 8191
+    const float*  hist;    // 1024 samples in front of the span
+    const float2* twX;     // [512][8]  W_4096^{m q}
+    const float2* tw1;     // [64][8]   W_512^{l k}
+    const float2* tw2;     // [8][8]    W_64^{l0 k}
+    const float2* R;       // [8][64][8] R[8 k' + q] (normalisation folded in), k' = c16_out_bin(lane, reg)
+    const float2* twI1;    // [16]   W_128^{-k_lo}   (the inverse passes build their few powers from one exact base per lane: 4 registers instead of 32)
+    const float2* twI2;    // [128]  W_1024^{-i''}
+    float*        y;       // 896 outputs per block
+    long          n_blocks;
+};
+
+__device__ __forceinline__ void ifft8(float2 (&v)[8]) { // inverse DFT-8: the forward butterfly on (im, re)
+    float2 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = make_float2(v[i].y, v[i].x);
+    fft8(t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = make_float2(t[i].y, t[i].x);
+}
+
+// v[k] *= w^k, k = 1..7, powers by products of depth <= 3
+__device__ __forceinline__ void mul_powers(float2 (&v)[8], float2 w) {
+    const float2 w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
+    v[1] = cmul(v[1], w);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    v[4] = cmul(v[4], w4);
+    v[5] = cmul(v[5], cmul(w4, w));
+    v[6] = cmul(v[6], cmul(w4, w2));
+    v[7] = cmul(v[7], cmul(w4, w3));
+}
+
+// landing: 32 one-KiB pieces per block, 4 per wave; the first 4 pieces of the span's first block come from the history
+__device__ __forceinline__ void decim_dma(const DecimFdArgs& a, long blk, unsigned lds_L, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int    p   = 4 * wave + i;                       // piece: floats [256 p, 256 p + 256) of the block
+        const long   pos = blk * kDfHop - kDfV + 256L * p;     // stream position of its first sample
+        const float* src = pos < 0 ? a.hist + (kDfV + pos) : a.x + pos; // (pieces never straddle position 0: 1024 = 4 pieces)
+        dma16_1k(src + 4 * lane, lds_L + 1024u * (unsigned)p);
+    }
+}
+
+__global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_df[]; // the ONLY LDS object
+    const int t0   = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6), lane0 = t0 & 63;
+    // ---- kernel-lifetime registers
+    float2 twX[8], tw1[8], tw2[8], Rr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        twX[k] = a.twX[t0 * 8 + k];
+        tw1[k] = a.tw1[lane0 * 8 + k];
+        tw2[k] = a.tw2[(lane0 & 7) * 8 + k];
+        Rr[k]  = a.R[(wave * 64 + lane0) * 8 + k];
+    }
+    const float2 bI1 = a.twI1[lane0 & 15], bI2 = a.twI2[t0 & 127];
+    const unsigned lds_L = __builtin_amdgcn_readfirstlane(lds_off(smem_df));
+    long blk = blockIdx.x;
+    if (blk < a.n_blocks) decim_dma(a, blk, lds_L, wave, lane0);
+    for (; blk < a.n_blocks; blk += gridDim.x) {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        const int l = t & 63;
+        float2*   R = reinterpret_cast<float2*>(smem_df + kDfOffW + wave * kDfRS);
+        G16_FULL_BARRIER(); // T: the block has landed; everybody is done with the previous one
+        // ---- phase 0: radix-8 across the block's eight 512-point segments
+        float2 u[8];
+        {
+            f2v            d[8];
+            const unsigned la = lds_L + 8u * (unsigned)t;
+            G16_RD8(d, la, 4096);
+            lds_wait8(d);
+            unpack8(u, d);
+        }
+        fft8(u);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) u[q] = cmul(u[q], twX[q]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float2*>(smem_df + kDfOffW + q * kDfRS + 8 * t) = u[q];
+        G16_LDS_BARRIER(); // #1: the landing buffer is free
+        const long bn = (blk + gridDim.x < a.n_blocks) ? blk + gridDim.x : blk; // (last iteration re-reads its own block: no divergent paths around the DMA)
+        decim_dma(a, bn, lds_L, wave, l);
+        // ---- phase 1: wave q: Z[8 k' + q], 512 points on its own
+        float2 v[8];
+        {
+            f2v            d[8];
+            const unsigned a0 = lds_off(R) + 8u * (unsigned)l;
+            G16_RD8(d, a0, 512);
+            lds_wait8(d);
+            unpack8(v, d);
+        }
+        fft8(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw1[k]);
+        private_tail(v, R, l, tw2);
+        // ---- G[r] = sum_j R[r + 1024 j] Z[r + 1024 j]: r = 8 k'_r + q, k'_r = bin(lane, kb1 in {0, 1}); + 1024 j <-> register kb1 + 2 j
+        float2 g0 = cmul(Rr[0], v[0]), g1 = cmul(Rr[1], v[1]);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            g0 = cadd(g0, cmul(Rr[2 * j], v[2 * j]));
+            g1 = cadd(g1, cmul(Rr[2 * j + 1], v[2 * j + 1]));
+        }
+        // ---- G_q[k'], k' = (l >> 3) + 8 (l & 7) + 64 kb1, into row q of the shared G / F buffer
+        float2* GF = reinterpret_cast<float2*>(smem_df + kDfOffF);
+        {
+            const int kk = 129 * wave + (l >> 3) + 8 * (l & 7);
+            GF[kk]      = g0;
+            GF[kk + 64] = g1;
+        }
+        G16_LDS_BARRIER(); // #2: all eight G_q are in place
+        // ---- the eight 128-point inverse transforms F_q[i''] = sum_k' G_q[k'] W_128^{-k' i''}: waves 0 and 1, one transform per 16-lane group (8 points a lane),
+        //      so that every lane of the two waves works (one transform per wave on 16 of its 64 lanes cost four times the issue slots)
+        if (wave < 2) {
+            const int      grp = l >> 4, kl = l & 15;            // transform q = 4 wave + grp, lane kl of its sixteen
+            float2*        Gq  = GF + 129 * (4 * wave + grp);
+            float2*        X   = R + 136 * grp;                  // exchange scratch of this group inside the wave's (now idle) private region: 8 rows of 17
+            f2v            d[8];
+            const unsigned a1 = lds_off(Gq) + 8u * (unsigned)kl;
+            G16_RD8(d, a1, 128); // G_q[kl + 16 k_hi]
+            lds_wait8(d);
+            unpack8(v, d);
+            ifft8(v);            // -> a1 = 0..7
+            mul_powers(v, bI1);  // W_128^{-k_lo a1}
+            // exchange inside the 16 lanes: lane (a1', hh) takes k_lo = j + 8 hh, j = 0..7
+#pragma unroll
+            for (int k = 0; k < 8; ++k) X[17 * k + kl] = v[k]; // [a1][k_lo], pitch 17
+            const int      a1p = kl & 7, hh = kl >> 3;
+            const unsigned a2  = lds_off(X) + 8u * (unsigned)(17 * a1p + 8 * hh);
+            G16_RD8(d, a2, 8);
+            lds_wait8(d);
+            unpack8(v, d);
+            // radix-2 over hh between lanes l and l ^ 8 (row rotate by 8), then W_16^{-j} on the difference lanes, then radix-8 over j
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float px = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[j].x), 0x128, 0xF, 0xF, false)); // row_ror:8
+                const float py = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[j].y), 0x128, 0xF, 0xF, false));
+                v[j] = hh ? make_float2(px - v[j].x, py - v[j].y) : make_float2(v[j].x + px, v[j].y + py); // hh = 0: A[j] + A[j + 8];  hh = 1: A[j] - A[j + 8]
+            }
+            if (hh) { // times W_16^{-j} = conj(W_16^j)
+                constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, hq = 0.70710678118654752440f;
+                v[1] = cmul(v[1], make_float2(c1, s1));
+                v[2] = make_float2((v[2].x - v[2].y) * hq, (v[2].y + v[2].x) * hq);
+                v[3] = cmul(v[3], make_float2(s1, c1));
+                v[4] = make_float2(-v[4].y, v[4].x);
+                v[5] = cmul(v[5], make_float2(-s1, c1));
+                v[6] = make_float2((-v[6].x - v[6].y) * hq, (v[6].x - v[6].y) * hq);
+                v[7] = cmul(v[7], make_float2(-c1, s1));
+            }
+            ifft8(v); // -> b' : i'' = a1' + 8 (2 b' + hh); F_q overwrites G_q (every lane of the group has read its inputs: one wave, in order)
+#pragma unroll
+            for (int bp = 0; bp < 8; ++bp) Gq[a1p + 8 * (2 * bp + hh)] = v[bp];
+        }
+        G16_LDS_BARRIER(); // #3: every F_q is in place
+        // ---- final pass across the waves: y[i'' + 128 a] = Re( sum_q W_1024^{-q i''} F_q[i''] W_8^{-q a} ), lanes 0..127
+        if (t < 128) {
+            const float2* F = reinterpret_cast<const float2*>(smem_df + kDfOffF) + t;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = F[129 * q];
+            mul_powers(v, bI2); // W_1024^{-q i''}
+            ifft8(v);
+            // valid outputs: i' = i'' + 128 a >= 128, i.e. a = 1..7 -> y[blk * 896 + i' - 128]
+            float* yo = a.y + blk * (kDfHop / 8) + t;
+#pragma unroll
+            for (int aa = 1; aa < 8; ++aa) yo[128 * (aa - 1)] = v[aa].x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct FirDecimFd {
+    DeviceBuffer d_twX, d_tw1, d_tw2, d_R, d_twI1, d_twI2;
+};
+
+static void put_wd(std::vector<float>& v, size_t idx, long num, long den) { // exp(-2 pi i num / den)
+    const double ang = -2.0 * M_PI * (double)(((num % den) + den) % den) / (double)den;
+    v[2 * idx]     = (float)std::cos(ang);
+    v[2 * idx + 1] = (float)std::sin(ang);
+}
+template <typename T>
+static int upload_df(DeviceBuffer& b, const std::vector<T>& h) {
+    int rc = b.ensure(h.size() * sizeof(T));
+    if (rc) return rc;
+    GR4_HIP_TRY(hipMemcpy(b.ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GR4HIP_OK;
+}
+
+int fir_decim_fd_supported(size_t ntaps, size_t decim) { return decim == 8 && ntaps >= 1 && ntaps <= (size_t)kDfV + 1; }
+
+int fir_decim_fd_create(FirDecimFd** out, const float* taps, size_t ntaps) {
+    auto* c = new (std::nothrow) FirDecimFd();
+    GR4_REQUIRE(c, "out of host memory");
+    using cd = std::complex<double>;
+    const int NC = kDfN / 2;
+    std::vector<cd> H(NC + 1), Rt(NC);
+    for (int k = 0; k <= NC; ++k) { // H[k] = sum_j b[j] e^{-2 pi i j k / 8192}, float64, exact angle reduction
+        cd s = 0;
+        for (size_t j = 0; j < ntaps; ++j) {
+            const double ang = -2.0 * M_PI * (double)((j * (size_t)k) % kDfN) / kDfN;
+            s += (double)taps[j] * cd(std::cos(ang), std::sin(ang));
+        }
+        H[k] = s;
+    }
+    auto W = [](int k) { const double ang = -2.0 * M_PI * (double)k / kDfN; return cd(std::cos(ang), std::sin(ang)); };
+    const cd I(0, 1);
+    auto P = [&](int k) { return H[k] * (1.0 - I * W(k)) * 0.5; };
+    auto Q = [&](int k) { return H[k] * (1.0 + I * W(k)) * 0.5; };
+    for (int k = 0; k < NC; ++k) Rt[k] = P(k) + std::conj(Q(NC - k));
+    Rt[0] = (Rt[0] + (P(NC) + std::conj(Q(0)))) * 0.5;
+    const double norm = 1.0 / (4.0 * 1024.0); // Re(.) / 4 and the 1 / 1024 of the inverse transform
+    std::vector<float> twX(2 * 512 * 8), tw1(2 * 64 * 8), tw2(2 * 8 * 8), Rq(2 * 8 * 64 * 8), tI1(2 * 16), tI2(2 * 128);
+    for (int m = 0; m < 512; ++m)
+        for (int q = 0; q < 8; ++q) put_wd(twX, (size_t)m * 8 + q, (long)m * q, 4096);
+    for (int l = 0; l < 64; ++l)
+        for (int k = 0; k < 8; ++k) put_wd(tw1, (size_t)l * 8 + k, (long)l * k, 512);
+    for (int l0 = 0; l0 < 8; ++l0)
+        for (int k = 0; k < 8; ++k) put_wd(tw2, (size_t)l0 * 8 + k, (long)l0 * k, 64);
+    for (int q = 0; q < 8; ++q)
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 8; ++r) {
+                const cd     val = Rt[8 * c16_out_bin(l, r) + q] * norm;
+                const size_t i   = ((size_t)q * 64 + l) * 8 + r;
+                Rq[2 * i]     = (float)val.real();
+                Rq[2 * i + 1] = (float)val.imag();
+            }
+    for (int kl = 0; kl < 16; ++kl) put_wd(tI1, (size_t)kl, -(long)kl, 128);
+    for (int i = 0; i < 128; ++i) put_wd(tI2, (size_t)i, -(long)i, 1024);
+    int rc = upload_df(c->d_twX, twX);
+    if (!rc) rc = upload_df(c->d_tw1, tw1);
+    if (!rc) rc = upload_df(c->d_tw2, tw2);
+    if (!rc) rc = upload_df(c->d_R, Rq);
+    if (!rc) rc = upload_df(c->d_twI1, tI1);
+    if (!rc) rc = upload_df(c->d_twI2, tI2);
+    if (rc) { delete c; return rc; }
+    *out = c;
+    return GR4HIP_OK;
+}
+void fir_decim_fd_destroy(FirDecimFd* c) { delete c; }
+
+// n_blocks blocks of 7168 input samples -> 896 outputs each; d_hist1024: the 1024 samples in front of d_in
+int fir_decim_fd_run(FirDecimFd* c, const float* d_in, const float* d_hist1024, size_t n_blocks, float* d_out, hipStream_t st) {
+    DecimFdArgs a{};
+    a.x = d_in; a.hist = d_hist1024;
+    a.twX = static_cast<const float2*>(c->d_twX.ptr); a.tw1 = static_cast<const float2*>(c->d_tw1.ptr); a.tw2 = static_cast<const float2*>(c->d_tw2.ptr);
+    a.R = static_cast<const float2*>(c->d_R.ptr); a.twI1 = static_cast<const float2*>(c->d_twI1.ptr); a.twI2 = static_cast<const float2*>(c->d_twI2.ptr);
+    a.y = d_out; a.n_blocks = (long)n_blocks;
+    static PerDevice per_device;
+    bool             first = false;
+    int              dev = -1, n_cu = per_device.current(&first, &dev);
+    GR4_REQUIRE(n_cu != 0, "fir_decim_fd: cannot query the current device");
+    if (first) {
+        n_cu = -n_cu;
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_fd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDfLds));
+        per_device.done(dev, n_cu);
+    }
+    const unsigned grid = (unsigned)std::min<size_t>(n_blocks, (size_t)2 * n_cu);
+    hipLaunchKernelGGL(fir_decim_fd_kernel, dim3(grid), dim3(kDfT), kDfLds, st, a);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+} // namespace gr4

@@ -140,6 +140,28 @@ def test_fir_decimating_long_input_mfma(G, decim, ntaps):
     assert _rel(y, truth) <= TOL
 
 
+@pytest.mark.parametrize("ntaps", [1024, 1000, 513, 129, 8, 1])
+def test_fir_decimate_by_8_frequency_domain(G, ntaps, monkeypatch):
+    """BASELINE configs[2]'s filter: decimate by 8, <= 1024 taps, spans of >= 64 blocks of 7168 samples take the overlap-save kernel (csrc/fir_decim_fd.hip:
+    4096-point complex transform, one table product, 1024-point inverse per block); against the float64 oracle, across calls (history from the handle, then
+    from the previous span), with ragged remainders going to the polyphase kernels, and against the polyphase path on the same input"""
+    rng = np.random.default_rng(ntaps)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32) if ntaps > 1 else np.array([0.7], np.float32)
+    blk = 7168
+    cuts = [0, 64 * blk + 8 * 37, 64 * blk + 8 * 37 + 8 * 5, 2 * (64 * blk) + 8 * 100, 2 * (64 * blk) + 8 * 100 + 70 * blk]
+    x = O.signal_f32(31, cuts[-1])
+    truth, _ = O.fir_decim(b, x, 8)
+    f = G.fir_filter(b, torch.float32, decimate=8)
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert y.shape == truth.shape and _rel(y, truth) <= TOL
+    monkeypatch.setenv("GR4HIP_FIR_NO_DECIM_FD", "1")  # developer switch: the polyphase (MFMA / VALU) kernels on the same stream
+    f2 = G.fir_filter(b, torch.float32, decimate=8)
+    y2 = np.concatenate([f2.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    monkeypatch.delenv("GR4HIP_FIR_NO_DECIM_FD")
+    assert _rel(y2, truth) <= TOL
+    assert _rel(y, truth) <= _rel(y2, truth) + 2e-6  # as accurate as the direct form, to 1/5 of the tolerance
+
+
 @pytest.mark.parametrize("kind", ["float", "complex", "decim"])
 def test_fir_random_span_sizes_switch_kernels(G, kind):
     """one stream cut into random spans: every call picks its kernel by size (register-window VALU / MFMA / frequency-domain), the
@@ -790,6 +812,14 @@ def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
     assert _rel(parts[0], t[0]) <= TOL and _rel(parts[2], t[2]) <= TOL
     ch.reset()
     assert _rel(ch.process_bulk(dev(clean)).cpu().numpy().ravel(), t[0]) <= TOL and not ch.last_power_ratio()[1]  # a reset re-arms the fused kernel
+    # the measured ratio is the filter's power gain whatever the fftSize and window: white noise through a DC-gain-1 low-pass passes sum b^2 of its power
+    noise = O.signal_c32(8, 64 * N, tone_amp=0.0)
+    want = float(np.sum(b.astype(np.float64) ** 2))
+    for fft_size, window in ((8192, "None"), (8192, "Hann"), (1024, "Hann"), (256, "None")):
+        c2 = G.Chain(b, fft_size, window)
+        c2.process_bulk(dev(noise))
+        r, _ = c2.last_power_ratio()
+        assert 0.7 * want < r < 1.4 * want, (fft_size, window, r, want)
 
 
 def test_chain_random_configurations(G):

@@ -53,8 +53,16 @@ t_fir = timeit(lambda: fir.process_bulk(x, yd))
 t_iir = timeit(lambda: iir.process_bulk(yd, yo))
 res["configs[2] decim-8 1024-tap FIR + 4 biquads"] = {
     "Msamples/s (input rate, both kernels)": round(n / (t_fir + t_iir) / 1e6, 1), "fir_ms": round(t_fir * 1e3, 3), "iir_ms": round(t_iir * 1e3, 3),
-    "alg_GB/s": round(n * 5.5 / (t_fir + t_iir) / 1e9, 1), "fir_TFLOP/s": round(n / 8 * 2048 / t_fir / 1e12, 1),
-    "note": "5.5 B/input sample: 4 in + 0.5 decimated stream written + 0.5 read + 0.5 out; polyphase FIR 256 flop/input sample is FP32-bound"}
+    "fir_Msamples/s (input)": round(n / t_fir / 1e6, 1), "alg_GB/s": round(n * 5.5 / (t_fir + t_iir) / 1e9, 1), "hbm_frac": round(n * 5.5 / (t_fir + t_iir) / 8e12, 3),
+    "fir_direct_form_equivalent_TFLOP/s": round(n / 8 * 2048 / t_fir / 1e12, 1),
+    "note": "5.5 B/input sample: 4 in + 0.5 decimated stream written + 0.5 read + 0.5 out; the FIR runs as 8192-sample overlap-save blocks in the frequency domain "
+            "(csrc/fir_decim_fd.hip), the polyphase MFMA kernel it replaces is FP32-bound at 256 flop/input sample"}
+os.environ["GR4HIP_FIR_NO_DECIM_FD"] = "1"
+fir_p = G.fir_filter(lowpass(1024, 0.05), torch.float32, decimate=8)
+t_firp = timeit(lambda: fir_p.process_bulk(x, yd))
+del os.environ["GR4HIP_FIR_NO_DECIM_FD"]
+res["configs[2] with the polyphase MFMA decimator (round-1 path)"] = {"Msamples/s (input rate, both kernels)": round(n / (t_firp + t_iir) / 1e6, 1), "fir_ms": round(t_firp * 1e3, 3),
+                                                                      "fir_TFLOP/s": round(n / 8 * 2048 / t_firp / 1e12, 1)}
 del x, yd, yo
 # ---- configs[3]
 nch, ntaps, n = 64, 256, 1 << 22
@@ -130,6 +138,11 @@ t = timeit(lambda: pole.process_bulk(xr, yp))
 res["1-pole IIR low-pass (reference FeedbackMerge benchmark shape)"] = {"Msamples/s": round(xr.numel() / t / 1e6, 1), "alg_GB/s": round(xr.numel() * 8 / t / 1e9, 1),
                                                                        "reference_published": "113 M/s merged, 656 M/s constexpr (unstated CPU)"}
 rot = G.Rotator(0.6283)
+yr = torch.empty_like(xc)
+t = timeit(lambda: rot.process_bulk(xc))
+res["Rotator<complex<float>> (closed-form float64 phase, default)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 16 / t / 1e9, 1), "hbm_frac": round(n * 16 / t / 8e12, 3),
+                                                                       "note": "includes torch output allocation"}
+rot = G.Rotator(0.6283, algo="recurrence")
 nr = 1 << 24
 t = timeit(lambda: rot.process_bulk(xc[:nr]), reps=2)
 res["Rotator<complex<float>> (bit-exact float phase recurrence)"] = {"Msamples/s": round(nr / t / 1e6, 1), "note": "bounded by the single sequential phase chain of Rotator.hpp:51-61, reproduced exactly"}
