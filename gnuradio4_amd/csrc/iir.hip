@@ -628,6 +628,163 @@ __global__ __launch_bounds__(kIirBS) void iir_onepass_kernel(IirOnePassArgs a, I
     IIR_STAMP(7);
 }
 
+
+// ------------------------------------------------------------------------------------------------ segment-sequential kernel (long spans, fading memory)
+// The look-back above is ~45 % of a block's residence and every cheaper-poll variant measured slower.  For a long span there is a way around the
+// dependency chain altogether: a workgroup takes a CONTIGUOUS run of tiles and walks it in order, the state at a tile's start is simply what the previous
+// tile left (kept in LDS) -- no tickets, no status words, no polling, nothing that can time out.  Only the state at the START of a workgroup's run is
+// unknown; a stable filter forgets: after W samples an error in the start state has shrunk by ||Phi^W||.  The host picks the smallest warm-up of 1, 2 or 4
+// tiles with ||Phi_B^w||_inf <= 1e-8 (below float32 resolution of the state; the parity bar is 1e-5) and every run but the first starts w tiles early from
+// the zero state with stores and the second recurrence pass switched off (a warm-up tile costs the zero-state pass and the scan only).  Filters whose memory
+// does not fade within 4 tiles = 32768 samples (poles within ~6e-4 of the unit circle) keep the look-back kernel, and so do short spans.
+struct IirSeqArgs {
+    const float* x;
+    float*       y;
+    long         n;
+    const float* phi;  // [kIirRounds][MP][MP]  Phi_{L 2^k}
+    const float* plr;  // [16][MP][MP]          Phi_L^r
+    const float* pl16; // [16][MP][MP]          Phi_L^{16 a}
+    const float* pb;   // [65][MP][MP]          Phi_B^l
+    const float* state_in;
+    float*       state_out;
+    long         tiles_per_wg;
+    int          warm_tiles;
+};
+
+template <int ORD, int NSEC>
+__global__ __launch_bounds__(kIirBS) void iir_seq_kernel(IirSeqArgs a, IirCoef<ORD, NSEC> coef) {
+    constexpr int MP = ORD * NSEC;
+    static_assert(MP <= 8, "tables are sized for MP <= 8");
+    __shared__ float tile[kIirBS * (kIirL + 1)];
+    __shared__ __attribute__((aligned(16))) float pl[kIirRounds * MP * MP];
+    __shared__ float p16[16 * MP * MP], plr[16 * MP * MP];
+    __shared__ float wv[4 * 16 * MP];
+    __shared__ float wz[4 * MP], Tw[4 * MP], Tcar[MP];
+    const int  c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const long ntiles = (a.n + (long)kIirBS * kIirL - 1) / ((long)kIirBS * kIirL);
+    const long t0 = (long)blockIdx.x * a.tiles_per_wg, t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
+    if (t0 >= ntiles) return;
+    iir_load_phi<MP, kIirRounds>(pl, a.phi);
+    for (int e = c; e < 16 * MP * MP; e += kIirBS) {
+        p16[e] = a.pl16[e];
+        plr[e] = a.plr[e];
+    }
+    long tb = t0 - a.warm_tiles;
+    if (c < MP) Tcar[c] = tb <= 0 ? a.state_in[c] : 0.f; // the first run starts from the handle's carried state, exactly
+    if (tb < 0) tb = 0;
+    float p1[MP]; // wave 0, lane < MP: row `lane` of Phi_B
+#pragma unroll
+    for (int k = 0; k < MP; ++k) p1[k] = (wave == 0 && lane < MP) ? a.pb[1L * MP * MP + lane * MP + k] : 0.f;
+    __syncthreads();
+    for (long b = tb; b < t1; ++b) {
+        const bool emit = b >= t0; // warm-up tiles only advance the state
+        const long base = b * kIirBS * kIirL;
+        iir_stage_tile(tile, a.x, base, a.n);
+        __syncthreads();
+        // ---- 1. zero-state run and in-wave scan
+        float st[NSEC][ORD];
+#pragma unroll
+        for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+            for (int j = 0; j < ORD; ++j) st[s][j] = 0.f;
+        float* row = tile + c * (kIirL + 1);
+#pragma unroll 4
+        for (int i = 0; i < kIirL; ++i) (void)iir_step<ORD, NSEC>(coef, st, row[i]);
+        float e[MP], ex[MP];
+#pragma unroll
+        for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+            for (int j = 0; j < ORD; ++j) e[s * ORD + j] = st[s][j];
+        iir_wave_scan<MP, ORD>(e, pl, lane);
+#pragma unroll
+        for (int i = 0; i < MP; ++i) {
+            ex[i] = __shfl_up(e[i], 1);
+            if (lane == 0) ex[i] = 0.f;
+            if (lane == 63) wz[wave * MP + i] = e[i];
+        }
+        __syncthreads();
+        // ---- 2. wave 0: Z_b, the next tile's start state P_b = Phi_B T_b + Z_b, and the four waves' start states T^w
+        if (wave == 0) {
+            float tvk[MP];
+#pragma unroll
+            for (int k = 0; k < MP; ++k) tvk[k] = Tcar[k];
+            if (lane < MP) {
+                float zb = wz[3 * MP + lane]; // Z_b = sum_w Phi_L^{64 (3 - w)} wz[w]
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const float* P = p16 + 4 * (3 - w) * MP * MP;
+#pragma unroll
+                    for (int k = 0; k < MP; ++k) zb = fmaf(P[lane * MP + k], wz[w * MP + k], zb);
+                }
+                float pv = zb;
+#pragma unroll
+                for (int k = 0; k < MP; ++k) pv = fmaf(p1[k], tvk[k], pv);
+                Tcar[lane] = pv; // (every lane of the wave has read Tcar above: one wave, LDS in program order)
+            }
+            if (emit && lane < 4 * MP) { // T^w = Phi_L^{64 w} T_b + sum_{w' < w} Phi_L^{64 (w - 1 - w')} wz[w']
+                const int w = lane / MP, i = lane % MP;
+                float     t = 0.f;
+                {
+                    const float* P = p16 + 4 * w * MP * MP;
+#pragma unroll
+                    for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], tvk[k], t);
+                }
+                for (int wp = 0; wp < w; ++wp) {
+                    const float* P = p16 + 4 * (w - 1 - wp) * MP * MP;
+#pragma unroll
+                    for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], wz[wp * MP + k], t);
+                }
+                Tw[lane] = t;
+            }
+        }
+        __syncthreads();
+        if (!emit) continue; // (uniform)
+        // ---- 3. wv[w][r] = Phi_L^r T^w (r < 16), then every chunk's start state
+        for (int q = c; q < 4 * 16 * MP; q += kIirBS) {
+            const int    w = q / (16 * MP), r = (q / MP) % 16, i = q % MP;
+            const float* P = plr + r * MP * MP;
+            float        t = 0.f;
+#pragma unroll
+            for (int k = 0; k < MP; ++k) t = fmaf(P[i * MP + k], Tw[w * MP + k], t);
+            wv[q] = t;
+        }
+        __syncthreads();
+        {
+            const int    aa = lane >> 4, r = lane & 15;
+            const float* P = p16 + aa * MP * MP;
+            const float* w = wv + (wave * 16 + r) * MP;
+#pragma unroll
+            for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+                for (int j = 0; j < ORD; ++j) {
+                    const int i = s * ORD + j;
+                    float     t = ex[i];
+#pragma unroll
+                    for (int k = 0; k < (s + 1) * ORD; ++k) t = fmaf(P[i * MP + k], w[k], t);
+                    st[s][j] = t;
+                }
+        }
+        // ---- 4. re-run from the true start state
+        const long cbeg = base + (long)c * kIirL;
+        const int  len  = (int)(a.n - cbeg < kIirL ? (a.n - cbeg < 0 ? 0 : a.n - cbeg) : kIirL);
+        if (len == kIirL) {
+#pragma unroll 4
+            for (int i = 0; i < kIirL; ++i) row[i] = iir_step<ORD, NSEC>(coef, st, row[i]);
+        } else {
+            for (int i = 0; i < len; ++i) row[i] = iir_step<ORD, NSEC>(coef, st, row[i]);
+        }
+        if (len > 0 && cbeg + len == a.n) { // this lane consumed the last sample of the span
+#pragma unroll
+            for (int s = 0; s < NSEC; ++s)
+#pragma unroll
+                for (int j = 0; j < ORD; ++j) a.state_out[s * ORD + j] = st[s][j];
+        }
+        __syncthreads();
+        iir_unstage_tile(tile, a.y, base, a.n);
+        __syncthreads(); // the tile is staged again at the top
+    }
+}
+
 } // namespace gr4
 
 using namespace gr4;
@@ -642,6 +799,7 @@ struct gr4hip_iir {
     DeviceBuffer        d_zc, d_zb, d_tb;
     DeviceBuffer        d_tab;            // one-pass tables: Phi_L^r [16], Phi_L^{16a} [16], Phi_B^l [65]  (M <= 8)
     DeviceBuffer        d_stz;            // one-pass block status words: [nblocks][M] x 2 (+ ticket)
+    int                 warm_tiles = 0;   // segment-sequential kernel: warm-up tiles that make a run's unknown start state irrelevant (0: memory does not fade fast enough)
     unsigned*           h_err = nullptr;  // page-locked, device-visible: a look-back that timed out (never observed) is reported by the next call, loudly
     ~gr4hip_iir() { if (h_err) (void)hipHostFree(h_err); }
 };
@@ -687,6 +845,35 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
     constexpr int MP      = ORD * NSEC;
     const long    nblocks = ceil_div(n, (long)kIirBS * kIirL);
     if constexpr (MP <= 8) {
+        // long span + fading memory: contiguous runs of tiles per workgroup, state carried from tile to tile, warm-up instead of look-back
+        if (f->warm_tiles > 0 && nblocks >= 256 && !std::getenv("GR4HIP_IIR_THREE_PASS") && !std::getenv("GR4HIP_IIR_LOOKBACK")) {
+            static PerDevice per_device;
+            bool             first = false;
+            int              dev = -1, n_cu = per_device.current(&first, &dev);
+            GR4_REQUIRE(n_cu != 0, "iir: cannot query the current device");
+            if (first) { n_cu = -n_cu; per_device.done(dev, n_cu); }
+            const long slots = 3L * n_cu; // three resident workgroups per CU (LDS)
+            long       per   = std::max<long>(8L * f->warm_tiles, ceil_div(nblocks, slots));
+            IirCoef<ORD, NSEC> cf{};
+            for (int s = 0; s < NSEC; ++s)
+                for (int j = 0; j <= ORD; ++j) {
+                    cf.b[s][j] = (float)f->b[s * (ORD + 1) + j];
+                    cf.a[s][j] = (float)f->a[s * (ORD + 1) + j];
+                }
+            const float* tab = static_cast<const float*>(f->d_tab.ptr);
+            IirSeqArgs   a{};
+            a.x = x; a.y = y; a.n = n;
+            a.phi = static_cast<const float*>(f->d_phi.ptr);
+            a.plr = tab; a.pl16 = tab + 16 * MP * MP; a.pb = tab + 32 * MP * MP;
+            a.state_in  = static_cast<const float*>(f->d_state[f->cur].ptr);
+            a.state_out = static_cast<float*>(f->d_state[f->cur ^ 1].ptr);
+            a.tiles_per_wg = per;
+            a.warm_tiles   = f->warm_tiles;
+            hipLaunchKernelGGL((iir_seq_kernel<ORD, NSEC>), dim3((unsigned)ceil_div(nblocks, per)), dim3(kIirBS), 0, st, a, cf);
+            GR4_LAUNCH_CHECK();
+            f->cur ^= 1;
+            return GR4HIP_OK;
+        }
         if (!std::getenv("GR4HIP_IIR_THREE_PASS")) { // (developer switch: the three-pass kernels below stay the path for MP = 16)
             if (const int e = iir_take_error(f, "iir_process")) return e; // a previous launch of this handle gave up waiting for a predecessor block
             if (!f->h_err) {
@@ -828,6 +1015,16 @@ int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const floa
         for (int q = 0; q < 16; ++q) { for (size_t i = 0; i < mm; ++i) tab[(16 + q) * mm + i] = (float)cur[i]; cur = mul(cur, PL16); }
         cur = I;
         for (int l = 0; l < 65; ++l) { for (size_t i = 0; i < mm; ++i) tab[(32 + l) * mm + i] = (float)cur[i]; cur = mul(cur, PB); }
+        { // warm-up length of the segment-sequential kernel: smallest w in {1, 2, 4} tiles with ||Phi_B^w||_inf <= 1e-8
+            std::vector<double> Pw = PB;
+            f->warm_tiles = 0;
+            for (int w = 1; w <= 4; w *= 2) {
+                double nrm = 0;
+                for (int i = 0; i < M; ++i) { double r = 0; for (int j = 0; j < M; ++j) r += std::fabs(Pw[i * M + j]); nrm = std::max(nrm, r); }
+                if (nrm <= 1e-8) { f->warm_tiles = w; break; }
+                Pw = mul(Pw, Pw);
+            }
+        }
         rc = f->d_tab.ensure(tab.size() * sizeof(float));
         if (!rc) { hipError_t e = hipMemcpy(f->d_tab.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     }

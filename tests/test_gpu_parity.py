@@ -405,6 +405,28 @@ def test_iir_single_pass_equals_three_pass(G, kind, monkeypatch):
     assert float((out["one"] - out["three"]).abs().max()) <= 2e-5 * rms
 
 
+@pytest.mark.parametrize("pole", [0.7, 0.998, 0.999, 0.99999])
+def test_iir_segment_sequential_runs_match_the_lookback_and_the_oracle(G, pole, monkeypatch):
+    """spans of >= 256 tiles take the segment-sequential kernel when the filter's memory fades inside 1, 2 or 4 tiles (poles 0.7 / 0.998 / 0.999 here;
+    0.99999 does not and stays on the look-back): same answers as the look-back kernel and the float64 oracle, in two calls so that run 0 of the second
+    call starts from the carried state and not from a warm-up"""
+    n = (1 << 22) + (1 << 20) + 4321
+    x = O.signal_f32(31, n)
+    b, a = np.array([[1.0 - pole, 0.0, 0.0], [0.2, 0.3, 0.2]], np.float32), np.array([[1.0, -pole, 0.0], [1.0, -0.4, 0.2]], np.float32)
+    truth = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(b, a)]), x, O.DF_II, f64=True)
+    out = {}
+    for mode in ("runs", "lookback"):
+        if mode == "lookback":
+            monkeypatch.setenv("GR4HIP_IIR_LOOKBACK", "1")
+        f = G.iir_filter(b, a)
+        cut = (1 << 21) + 777  # both calls are >= 256 tiles
+        out[mode] = np.concatenate([f.process_bulk(dev(x[:cut])).cpu().numpy(), f.process_bulk(dev(x[cut:])).cpu().numpy()])
+        f.status()
+        assert _rel(out[mode], truth) <= TOL, mode
+    rms = float(np.sqrt(np.mean(truth ** 2)))
+    assert float(np.abs(out["runs"].astype(np.float64) - out["lookback"]).max()) <= 2e-5 * rms
+
+
 def test_basic_filter_bands(G, golden):
     g = golden["basic_filter_lowpass"]
     fs, n = g["sample_rate"], g["num_samples"]

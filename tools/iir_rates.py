@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""developer tool: IIR cascade rates -- segment-sequential kernel (default for long spans) vs the decoupled look-back kernel (GR4HIP_IIR_LOOKBACK=1)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import gnuradio4_amd as G
+from gnuradio4_amd import capi
+def rate(f, x, y, reps=10):
+    for _ in range(3): f.process_bulk(x, y)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): f.process_bulk(x, y)
+    b.record(); b.synchronize()
+    return x.numel() * reps / a.elapsed_time(b) / 1e6
+for log2n in (24, 26, 27):
+    n = 1 << log2n
+    x = G.synth_f32(n, seed=1); y = torch.empty_like(x)
+    b4, a4 = G.blocks.design_iir(capi.LOWPASS, 8, 0.05, float("nan"), 1.0, capi.BUTTERWORTH)
+    for name, mk in (("4 biquads (Butterworth-8, fc 0.05)", lambda: G.iir_filter(b4, a4)), ("1-pole low-pass a = 0.95", lambda: G.iir_filter([[0.05]], [[1.0, -0.95]]))):
+        out = []
+        for env in (None, "1"):
+            if env: os.environ["GR4HIP_IIR_LOOKBACK"] = env
+            else: os.environ.pop("GR4HIP_IIR_LOOKBACK", None)
+            out.append(rate(mk(), x, y))
+        os.environ.pop("GR4HIP_IIR_LOOKBACK", None)
+        print("2^%d %-38s sequential runs %7.1f Gsamples/s (%.2f TB/s) | look-back %7.1f Gsamples/s" % (log2n, name, out[0], out[0] * 8 / 1e3, out[1]))
