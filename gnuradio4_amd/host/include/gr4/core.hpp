@@ -305,10 +305,16 @@ struct EdgeBufferBase {
     [[nodiscard]] virtual std::size_t available_items() const noexcept      = 0;
     [[nodiscard]] virtual std::size_t free_items() const noexcept           = 0;
     virtual void                      read_items(void* dst, std::size_t n)  = 0; // copy + consume
-    // zero-copy variant for consumers that can read the storage in place (a DMA engine, when memory() is page-locked): pointer to the next n
-    // items (valid until consume_items), nullptr when the edge cannot offer that
-    [[nodiscard]] virtual const void*                peek_items(std::size_t /*n*/) { return nullptr; }
+    // zero-copy variants for a neighbour that moves the samples itself (a copy engine when memory() is page-locked, or a pool of copy threads):
+    //   lend_items(n): pointer to the next n items that are not yet lent, or nullptr; they stay in the buffer -- and available_items() stops counting
+    //                  them -- until consume_items() releases them in order.  Several lent spans may be outstanding (chunks in flight).
+    //   reserve_items(n) / publish_reserved(n): the same on the writing side: storage for n items behind everything already reserved; readers see
+    //                  them once published, in order.
+    // While anything is lent or reserved the storage does not move (no compaction): free_items() shrinks to the contiguous room that is left.
+    [[nodiscard]] virtual const void*                lend_items(std::size_t /*n*/) { return nullptr; }
     virtual void                                     consume_items(std::size_t /*n*/) {}
+    [[nodiscard]] virtual void*                      reserve_items(std::size_t /*n*/) { return nullptr; }
+    virtual void                                     publish_reserved(std::size_t /*n*/) {}
     [[nodiscard]] virtual std::pmr::memory_resource* memory() const { return nullptr; }
     virtual void                      write_items(const void* src, std::size_t n) = 0; // copy + publish
 };
@@ -316,6 +322,7 @@ template <typename T>
 struct EdgeBuffer final : EdgeBufferBase {
     std::pmr::vector<T> data; // storage from the edge's memory resource (Graph.hpp:738-775): default heap, or e.g. the "hip" provider's pinned pages
     std::size_t         head = 0, tail = 0, capacity;
+    std::size_t         lent = 0, reserved = 0; // items handed out for in-place reading (from head) / writing (from tail) that are still in flight
     explicit EdgeBuffer(std::size_t cap = 65536, std::pmr::memory_resource* mr = std::pmr::get_default_resource()) : data(2 * cap, mr), capacity(cap) {} // default edge size: Graph.hpp:102
     [[nodiscard]] std::pmr::memory_resource* resource() const { return data.get_allocator().resource(); }
     std::vector<std::shared_ptr<EdgeBuffer<T>>> mirrors; // see EdgeBufferBase::upstream
@@ -328,18 +335,23 @@ struct EdgeBuffer final : EdgeBufferBase {
     }
     [[nodiscard]] std::size_t available() const noexcept { return tail - head; }
     [[nodiscard]] std::size_t free_space() const noexcept {
-        std::size_t f = capacity - available();
+        std::size_t f = capacity - std::min(capacity, available() + reserved);
+        if (lent || reserved) f = std::min(f, data.size() - tail - reserved); // the storage stays where it is while a neighbour reads or writes it in place
         for (const auto& m : mirrors) f = std::min(f, m->free_space());
         return f;
     }
     std::span<const T>        read_span(std::size_t n) const { return {data.data() + head, n}; }
+    void compact() { // move the unread part to the front (amortised O(1) per sample)
+        std::move(data.begin() + static_cast<std::ptrdiff_t>(head), data.begin() + static_cast<std::ptrdiff_t>(tail), data.begin());
+        tail -= head;
+        head = 0;
+    }
     std::span<T>              write_span(std::size_t n) {
-        if (tail + n > data.size()) { // compact: move the unread part to the front (amortised O(1) per sample)
-            std::move(data.begin() + static_cast<std::ptrdiff_t>(head), data.begin() + static_cast<std::ptrdiff_t>(tail), data.begin());
-            tail -= head;
-            head = 0;
+        if (tail + reserved + n > data.size()) {
+            if (lent || reserved) throw std::logic_error("EdgeBuffer::write_span: beyond free_space() while spans are lent or reserved");
+            compact();
         }
-        return {data.data() + tail, n};
+        return {data.data() + tail + reserved, n};
     }
     void publish(std::size_t n) noexcept {
         for (auto& m : mirrors) { // the tee: every further reader gets its copy
@@ -352,15 +364,33 @@ struct EdgeBuffer final : EdgeBufferBase {
     }
     void consume(std::size_t n) noexcept { head += n; advanceRead(n); }
     [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
-    [[nodiscard]] std::size_t available_items() const noexcept override { return available(); }
+    [[nodiscard]] std::size_t available_items() const noexcept override { return available() - lent; }
     [[nodiscard]] std::size_t free_items() const noexcept override { return free_space(); }
     void read_items(void* dst, std::size_t n) override {
         if constexpr (std::is_trivially_copyable_v<T>) std::memcpy(dst, read_span(n).data(), n * sizeof(T));
         else throw std::logic_error("type-erased element IO needs a trivially copyable sample type");
         consume(n);
     }
-    [[nodiscard]] const void*                peek_items(std::size_t n) override { return n <= available() ? read_span(n).data() : nullptr; }
-    void                                     consume_items(std::size_t n) override { consume(n); }
+    [[nodiscard]] const void* lend_items(std::size_t n) override {
+        if (lent + n > available()) return nullptr;
+        const T* p = data.data() + head + lent;
+        lent += n;
+        return p;
+    }
+    void consume_items(std::size_t n) override {
+        consume(n);
+        lent -= std::min(lent, n);
+    }
+    [[nodiscard]] void* reserve_items(std::size_t n) override {
+        if (n > free_space()) return nullptr;
+        T* p = write_span(n).data(); // compacts only when nothing is lent or reserved (free_space() has bounded n otherwise)
+        reserved += n;
+        return p;
+    }
+    void publish_reserved(std::size_t n) override {
+        reserved -= std::min(reserved, n);
+        publish(n);
+    }
     [[nodiscard]] std::pmr::memory_resource* memory() const override { return resource(); }
     void write_items(const void* src, std::size_t n) override {
         if constexpr (std::is_trivially_copyable_v<T>) std::memcpy(write_span(n).data(), src, n * sizeof(T));

@@ -9,14 +9,18 @@
 //     (fir_filter<complex<float>> -> PowerSpectrum == gr4hip_chain_*: the runtime analogue of Merge<>, BlockMerging.hpp:136-320).
 // Device blocks never fall back to the host path: a failing library call turns into work::Status::ERROR with the library's text.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <atomic>
+#include <condition_variable>
+#include <cstdlib>
 #include <cctype>
 #include <cmath>
 #include <cstring>
 #include <mutex>
 #include <numeric>
 #include <span>
+#include <thread>
 #include <functional>
 #include <iostream>
 #include <memory_resource>
@@ -90,6 +94,67 @@ inline void register_provider() { // idempotent; call once before Graph::connect
         return pinned_resource();
     });
 }
+
+// ---------------------------------------------------------------------------------------------- copy threads
+// A pageable edge has to be staged through page-locked memory before the copy engine can take it, and one host thread's memcpy (10-15 GB/s)
+// is far below what the link moves (DESIGN.md "Host feed"): large staging copies are cut into slices for a few helper threads.
+// GR4HIP_COPY_THREADS sets the helper count (default 3, 0: the calling thread copies alone).
+class CopyPool {
+    struct Slice { char* d; const char* s; std::size_t n; };
+    std::vector<std::thread>  _threads;
+    std::mutex                _m;
+    std::condition_variable   _cv, _cv_done;
+    std::vector<Slice>        _work;
+    std::size_t               _pending = 0;
+    bool                      _stop    = false;
+    void run() {
+        for (;;) {
+            Slice sl;
+            {
+                std::unique_lock lk(_m);
+                _cv.wait(lk, [&] { return _stop || !_work.empty(); });
+                if (_stop) return;
+                sl = _work.back();
+                _work.pop_back();
+            }
+            std::memcpy(sl.d, sl.s, sl.n);
+            std::lock_guard lk(_m);
+            if (--_pending == 0) _cv_done.notify_all();
+        }
+    }
+    CopyPool() {
+        const char* e = std::getenv("GR4HIP_COPY_THREADS");
+        const long  k = e ? std::strtol(e, nullptr, 10) : 3;
+        for (long i = 0; i < std::clamp(k, 0L, 16L); ++i) _threads.emplace_back([this] { run(); });
+    }
+    ~CopyPool() {
+        { std::lock_guard lk(_m); _stop = true; }
+        _cv.notify_all();
+        for (auto& t : _threads) t.join();
+    }
+
+public:
+    static CopyPool& instance() { static CopyPool p; return p; }
+    [[nodiscard]] std::size_t helpers() const { return _threads.size(); }
+    void copy(void* dst, const void* src, std::size_t bytes) {
+        constexpr std::size_t kMin = std::size_t(1) << 20; // below this a slice is not worth a wake-up
+        const std::size_t parts = std::min(_threads.size() + 1, bytes / kMin);
+        if (parts < 2) { std::memcpy(dst, src, bytes); return; }
+        const std::size_t per = (bytes / parts + 63) & ~std::size_t(63);
+        {
+            std::lock_guard lk(_m);
+            for (std::size_t i = 1; i < parts; ++i) {
+                const std::size_t at = i * per;
+                _work.push_back({static_cast<char*>(dst) + at, static_cast<const char*>(src) + at, std::min(per, bytes - at)});
+            }
+            _pending += parts - 1;
+        }
+        _cv.notify_all();
+        std::memcpy(dst, src, per); // the caller's share
+        std::unique_lock lk(_m);
+        _cv_done.wait(lk, [&] { return _pending == 0; });
+    }
+};
 
 // ---------------------------------------------------------------------------------------------- stages
 template <typename T>
@@ -854,12 +919,13 @@ class DeviceRun final : public BlockModel {
     struct Slot {
         DevBuf         h_in{true}, h_out{true}, d_out;
         gr4hip_event_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
-        std::size_t    n_out = 0;
+        std::size_t    n_out = 0, n_lent = 0; // n_lent: input items the copy engine reads in the edge's own storage, released when in_done has fired
+        void*          direct = nullptr;      // the result copy lands in the output edge's own (page-locked) storage: published in place
         bool           busy = false;
         property_map   fwd; // tags to publish at the first output sample of this chunk
     };
     std::array<Slot, kDepth> _slots;
-    std::size_t     _inplace_chunks = 0; // chunks copied straight out of a page-locked input edge
+    std::size_t     _inplace_chunks = 0, _direct_chunks = 0; // chunks copied straight out of a page-locked input edge / straight into a page-locked output edge
     std::size_t     _q_head = 0, _q_count = 0, _pending_out = 0, _overlapped = 0; // FIFO of busy slots; output items not yet published; chunks queued while another was in flight
     DevBuf          _d_a, _d_b;
     std::string     _name = "device_run";
@@ -908,6 +974,22 @@ public:
     }
     [[nodiscard]] std::size_t overlapped_chunks() const { return _overlapped; }
     [[nodiscard]] std::size_t inplace_chunks() const { return _inplace_chunks; }
+    [[nodiscard]] std::size_t direct_chunks() const { return _direct_chunks; }
+    // input spans lent to the copy engine go back to the edge, oldest first, as their copies land (wait: block until all have)
+    void release_inputs(bool wait) {
+        for (std::size_t i = 0; i < _q_count; ++i) {
+            Slot& sl = _slots[(_q_head + i) % kDepth];
+            if (sl.n_lent == 0) continue;
+            if (wait) check(gr4hip_event_synchronize(sl.in_done), "event sync");
+            else {
+                int done = 0;
+                check(gr4hip_event_query(sl.in_done, &done), "event query");
+                if (!done) return;
+            }
+            _in_edge->consume_items(sl.n_lent);
+            sl.n_lent = 0;
+        }
+    }
     // rate bookkeeping (Resampling<>, Block.hpp:1576-1636, across the whole run): walking back from the last stage, `need` is the count a
     // stage's output must be a multiple of; it produces out_chunk per in_chunk
     void recompute_rates() {
@@ -938,10 +1020,17 @@ public:
         } else {
             check(gr4hip_event_synchronize(sl.out_done), "event sync");
         }
+        if (sl.n_lent) { _in_edge->consume_items(sl.n_lent); sl.n_lent = 0; } // the result has landed, so has the input (slots retire oldest first)
         if (!sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
-        _write(sl.h_out.p, sl.n_out);
         const std::size_t n = sl.n_out;
-        _pending_out -= n;
+        if (sl.direct) _out_edge->publish_reserved(n);
+        else {
+            void* dst = n * _out_bytes >= (std::size_t(2) << 20) ? _out_edge->reserve_items(n) : nullptr; // large chunk into a pageable edge: the copy threads share it
+            if (dst) { CopyPool::instance().copy(dst, sl.h_out.p, n * _out_bytes); _out_edge->publish_reserved(n); }
+            else _write(sl.h_out.p, n);
+            _pending_out -= n;
+        }
+        sl.direct = nullptr;
         sl.busy = false;
         sl.fwd.clear();
         _q_head = (_q_head + 1) % kDepth;
@@ -954,6 +1043,7 @@ public:
             check(gr4hip_set_device(_domain.index), "gr4hip_set_device"); // runs on several devices share the scheduler thread: the current device is per call
             std::size_t published = 0;
             while (const std::size_t r = retire(true)) published += r; // whatever has finished since the last call
+            release_inputs(!_in_edge->tags.empty()); // tags are addressed relative to the read position: with tags around, every lent span is returned first
             // a tag on the first sample of the launch: settings-by-tag for the member blocks (only the stages of members that changed are rebuilt, the
             // others keep their state), then forwarded across the whole run like across one block: "gr:" keys, at the first output sample,
             // gr:sample_rate scaled by the run's rate change
@@ -978,7 +1068,7 @@ public:
             if (_q_count == kDepth) published += retire(false); // all slots queued: wait for the oldest
             std::size_t n = std::min({_avail(), requested, _ring_bytes / _in_bytes / (kDepth + 1)}); // kDepth chunks in flight never wrap onto each other in the ring
             n = std::min(n, std::max(_in_edge->samplesUntilNextTag(), _in_chunk)); // a launch ends where the next tag starts (Block.hpp:1511-1530): tags sit on launch boundaries
-            const std::size_t space = _space() - std::min(_space(), _pending_out);  // the output edge minus what queued chunks will publish
+            const std::size_t space = _space() - std::min(_space(), _pending_out);  // the output edge minus what queued chunks will publish (reserved spans are already off it)
             n = std::min(n / _in_chunk, space / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
             if (n == 0) {
                 if (_q_count) { // nothing new to queue: make room / finish up by publishing the oldest chunk
@@ -992,19 +1082,34 @@ public:
                 }
                 return {requested, 0, _avail() < _in_chunk ? work::Status::INSUFFICIENT_INPUT_ITEMS : work::Status::INSUFFICIENT_OUTPUT_ITEMS};
             }
+            // a page-locked output edge ("hip" provider) takes the result copy in its own storage; at the end of the storage the edge must compact
+            // first, which it only does with nothing in flight
+            void* direct = nullptr;
+            if (_out_edge->memory() == pinned_resource()) {
+                const std::size_t n_res = out_count(n);
+                direct = _out_edge->reserve_items(n_res);
+                if (!direct && _q_count) {
+                    while (_q_count) published += retire(false);
+                    direct = _out_edge->reserve_items(n_res);
+                }
+            }
             Slot& sl = _slots[(_q_head + _q_count) % kDepth];
             if (_q_count) ++_overlapped;
             // samples land in HBM: pinned staging -> hipMemcpyAsync -> the double-mapped ring (a wrapping span stays contiguous)
             char*       d_in    = static_cast<char*>(_ring_base) + _ring_wr;
-            const void* inplace = _in_edge->memory() == pinned_resource() ? _in_edge->peek_items(n) : nullptr;
-            if (inplace) { // the edge's storage is page-locked ("hip" provider): the copy engine reads it in place; the span is released once the copy has landed
-                check(gr4hip_memcpy_h2d(d_in, inplace, n * _in_bytes, _s_in), "h2d");
+            const void* lent = _in_edge->lend_items(n);
+            if (lent && _in_edge->memory() == pinned_resource()) { // page-locked storage ("hip" provider): the copy engine reads the edge in place;
+                check(gr4hip_memcpy_h2d(d_in, lent, n * _in_bytes, _s_in), "h2d"); // the span goes back to the edge once the copy has landed (release_inputs)
                 check(gr4hip_event_record(sl.in_done, _s_in), "event record");
-                check(gr4hip_event_synchronize(sl.in_done), "event sync");
-                _in_edge->consume_items(n);
+                sl.n_lent = n;
                 ++_inplace_chunks;
             } else {
-                _read(sl.h_in.ensure(n * _in_bytes), n);
+                if (lent) { // pageable edge: staged through page-locked memory by the copy threads
+                    CopyPool::instance().copy(sl.h_in.ensure(n * _in_bytes), lent, n * _in_bytes);
+                    _in_edge->consume_items(n);
+                } else {
+                    _read(sl.h_in.ensure(n * _in_bytes), n);
+                }
                 check(gr4hip_memcpy_h2d(d_in, sl.h_in.p, n * _in_bytes, _s_in), "h2d");
                 check(gr4hip_event_record(sl.in_done, _s_in), "event record");
             }
@@ -1024,12 +1129,14 @@ public:
             }
             check(gr4hip_event_record(sl.k_done, _s_k), "event record");
             check(gr4hip_stream_wait_event(_s_out, sl.k_done), "stream wait");
-            check(gr4hip_memcpy_d2h(sl.h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _s_out), "d2h");
+            check(gr4hip_memcpy_d2h(direct ? direct : sl.h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _s_out), "d2h");
             check(gr4hip_event_record(sl.out_done, _s_out), "event record");
-            sl.n_out = cnt;
-            sl.busy  = true;
-            sl.fwd   = std::move(fwd);
-            _pending_out += cnt;
+            sl.n_out  = cnt;
+            sl.busy   = true;
+            sl.direct = direct;
+            sl.fwd    = std::move(fwd);
+            if (direct) ++_direct_chunks;
+            else _pending_out += cnt;
             ++_q_count;
             return {requested, n, work::Status::OK};
         } catch (const std::exception& e) {

@@ -67,6 +67,44 @@ int main(int argc, char** argv) {
         try { f.applySettings({{"no_such_setting", 1.0}}); } catch (const std::invalid_argument&) { threw = true; }
         EXPECT(threw);
     }
+    // ---- edge storage handed to a neighbour that moves the samples itself (a copy engine, copy threads): lend / consume on the reading side,
+    //      reserve / publish on the writing side; the storage must not move while spans are out, and readers only see published items
+    {
+        EdgeBuffer<int> e(8); // capacity 8, storage 16
+        EdgeBufferBase& b = e;
+        for (int i = 0; i < 8; ++i) e.write_span(1)[0] = i, e.publish(1);
+        const int* a = static_cast<const int*>(b.lend_items(3));
+        const int* c = static_cast<const int*>(b.lend_items(4));
+        EXPECT(a && c && a[0] == 0 && c[0] == 3 && c == a + 3);
+        EXPECT(b.available_items() == 1 && b.lend_items(2) == nullptr); // lent items are spoken for; only one is left
+        EXPECT(e.free_space() == 0);                                     // still 8 unread items in a capacity of 8
+        b.consume_items(3);                                              // the oldest span comes back
+        EXPECT(e.read_pos == 3 && e.free_space() == 3 && b.available_items() == 1);
+        for (int i = 8; i < 11; ++i) e.write_span(1)[0] = i, e.publish(1);
+        EXPECT(c[0] == 3 && c[3] == 6);                                  // the span still out has not moved
+        EXPECT(e.free_space() == 0);
+        b.consume_items(4);
+        EXPECT(e.free_space() == 4 && e.lent == 0);
+        // the tail has reached 11 of 16: with a span lent the writer only gets the contiguous room that is left, afterwards the storage compacts again
+        const int* d = static_cast<const int*>(b.lend_items(4));
+        EXPECT(d && d[0] == 7 && e.free_space() == 4);
+        for (int i = 11; i < 15; ++i) e.write_span(1)[0] = i, e.publish(1);
+        EXPECT(e.tail == 15 && e.free_space() == 0);
+        b.consume_items(4);
+        EXPECT(e.free_space() == 4);
+        e.write_span(4)[0] = 15; // compacts: 4 unread items move to the front
+        EXPECT(e.head == 0 && e.tail == 4 && e.read_span(4)[0] == 11 && e.data[4] == 15);
+        e.publish(1);
+        // writing side
+        int* r1 = static_cast<int*>(b.reserve_items(2));
+        int* r2 = static_cast<int*>(b.reserve_items(1));
+        EXPECT(r1 && r2 == r1 + 2 && e.available() == 5 && e.free_space() == 0 && b.reserve_items(1) == nullptr);
+        r1[0] = 100; r1[1] = 101; r2[0] = 102;
+        b.publish_reserved(2);
+        EXPECT(e.available() == 7 && e.read_span(7)[5] == 100 && e.reserved == 1);
+        b.publish_reserved(1);
+        EXPECT(e.available() == 8 && e.read_span(8)[7] == 102 && e.write_pos == 19);
+    }
     // ---- memory seam: ComputeRegistry providers and per-edge resources (ComputeDomain.hpp:105-173, Graph.hpp:738-775)
     {
         struct Counting final : std::pmr::memory_resource {

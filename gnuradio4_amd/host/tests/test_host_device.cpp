@@ -164,7 +164,37 @@ int main(int argc, char** argv) {
         dump(out + "_planned_float.bin", fsink._samples);
         hip::release(mul2);
     }
-
+    { // 3b''. the chain between page-locked edges ("hip" provider) at both ends: the run's copy engine reads the input edge and writes the output edge in
+      //       place, several chunks in flight, the edges small enough (4 frames) that their storage fills and compacts many times on the way.
+      //       Sample for sample the result of the same graph with ordinary edges (staged through the run's own page-locked buffers).
+        hip::register_provider();
+        std::size_t launches = 0, inplace = 0, direct = 0, overlapped = 0;
+        const auto run_chain = [&](bool locked_edges) {
+            Graph g;
+            auto& src  = g.emplaceBlock<testing::VectorSource<std::complex<float>>>({{"n_samples_max", std::int64_t(96 * N + 77)}});
+            src.values = x; // repeated cyclically
+            auto& fir  = g.emplaceBlock<filter::fir_filter<std::complex<float>>>({{"b", tapsd}, {"compute_domain", "gpu:hip:0"s}});
+            auto& spec = g.emplaceBlock<blocks::fft::PowerSpectrum<std::complex<float>>>({{"fftSize", std::int64_t(N)}, {"window", "BlackmanHarris"s}, {"compute_domain", "gpu:hip:0"s}});
+            auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+            EdgeParameters e;
+            e.minBufferSize = 4 * N;
+            if (locked_edges) e.domain = "gpu:hip:0";
+            if (!g.connect<"out", "in">(src, fir, e) || !g.connect<"out", "in">(fir, spec) || !g.connect<"out", "in">(spec, sink, e)) ++errors;
+            const auto runs = hip::plan(g);
+            scheduler::Simple sched;
+            sched.exchange(std::move(g));
+            if (const auto r = sched.runAndWait(); !r) { std::cerr << "page-locked graph: " << r.error().message << "\n"; ++errors; }
+            if (runs.size() != 1) { ++errors; return std::vector<float>{}; }
+            if (locked_edges) { launches = runs[0]->launches(); inplace = runs[0]->inplace_chunks(); direct = runs[0]->direct_chunks(); overlapped = runs[0]->overlapped_chunks(); }
+            else if (runs[0]->inplace_chunks() || runs[0]->direct_chunks()) ++errors;
+            return sink._samples;
+        };
+        const auto staged = run_chain(false), in_place = run_chain(true);
+        const bool same   = staged.size() == 96 * N && in_place == staged;
+        std::printf("page-locked edges: %zu launches, %zu chunks read in place, %zu written in place, %zu overlapped, output %s the staged run\n", launches, inplace, direct, overlapped,
+                    same ? "equals" : "DIFFERS from");
+        if (!same || launches < 2 || inplace != launches || direct != launches) ++errors; // (chunks this small finish before the next one is queued: overlap is bench_host_feed's subject)
+    }
     { // 3b'. a tee'd device edge: fir.out feeds the spectrum block AND a host sink -> the planner must not fuse across it (the filtered samples have to
       //      reach the host edge); both readers see every sample
         Graph g;
