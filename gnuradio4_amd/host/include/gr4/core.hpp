@@ -289,6 +289,16 @@ struct EdgeBufferBase {
         else tags.insert(it, Tag{idx, map});
     }
     [[nodiscard]] const Tag* tagAtReadPosition() const { return !tags.empty() && tags.front().index == read_pos ? &tags.front() : nullptr; }
+    // every tag on the next n samples merged into one map, later tags overriding earlier ones key by key: what a chunk that had to span tags (a whole
+    // frame, a decimation group) sees and forwards at its first output sample (mergedInputTag, Block.hpp:1511-1530)
+    [[nodiscard]] property_map mergedTags(std::size_t n) const {
+        property_map merged;
+        for (const Tag& t : tags) {
+            if (t.index >= read_pos + n) break;
+            for (const auto& kv : t.map) merged.insert_or_assign(kv.first, kv.second);
+        }
+        return merged;
+    }
     // samples until the first tag AFTER the read position (nSamplesUntilNextTag(port, 1), Block.hpp:1525): the chunk limit that keeps tags at chunk starts
     [[nodiscard]] std::size_t samplesUntilNextTag() const {
         for (const Tag& t : tags)
@@ -703,7 +713,7 @@ private:
         if (!any_in) return {requested, 0, work::Status::ERROR};
         const std::size_t ic = std::max<std::size_t>(1, input_chunk_size), oc = std::max<std::size_t>(1, output_chunk_size);
         // a chunk ends where the next tag starts, so that every tag sits on the first sample of a chunk (Block.hpp:1511-1530, 1961-1971);
-        // never below one input chunk (ensureMinimalDecimation): a tag inside a forced chunk is consumed without being forwarded
+        // never below one input chunk (ensureMinimalDecimation): tags inside such a forced chunk are merged into the chunk's own tag below
         std::size_t nextTag = std::numeric_limits<std::size_t>::max();
         each_in([&](auto& p) { if (p.connected()) nextTag = std::min(nextTag, p.buffer->samplesUntilNextTag()); });
         avail = std::min(avail, std::max(nextTag, ic));
@@ -720,11 +730,12 @@ private:
             return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
         }
         const std::size_t nIn = k * ic, nOut = k * oc;
-        // tags on the first sample of the chunk: settings-by-tag first (Block.hpp:1979-1985), then the chunk is processed with the new settings
+        // the chunk's tag: normally the one on its first sample; every tag of the chunk when it had to span some.  Settings-by-tag first
+        // (Block.hpp:1979-1985), then the chunk is processed with the new settings
         property_map chunkTags;
         each_in([&](auto& p) {
-            if (const Tag* t = p.connected() ? p.buffer->tagAtReadPosition() : nullptr)
-                for (const auto& kv : t->map) chunkTags.insert_or_assign(kv.first, kv.second); // identical tags on several inputs collapse
+            if (!p.connected()) return;
+            for (auto& kv : p.buffer->mergedTags(nIn)) chunkTags.insert_or_assign(kv.first, std::move(kv.second)); // identical tags on several inputs collapse
         });
         if (!chunkTags.empty()) applyTagSettings(chunkTags);
         work::Status      st = dispatch(nIn, nOut);

@@ -1044,21 +1044,29 @@ public:
             std::size_t published = 0;
             while (const std::size_t r = retire(true)) published += r; // whatever has finished since the last call
             release_inputs(!_in_edge->tags.empty()); // tags are addressed relative to the read position: with tags around, every lent span is returned first
-            // a tag on the first sample of the launch: settings-by-tag for the member blocks (only the stages of members that changed are rebuilt, the
-            // others keep their state), then forwarded across the whole run like across one block: "gr:" keys, at the first output sample,
-            // gr:sample_rate scaled by the run's rate change
+            // the launch's tag: the one on its first sample -- launches end where the next tag starts -- or, when a whole input chunk (a frame, a
+            // decimation group) has to span tags, all of them merged (Block.hpp:1511-1530).  Settings-by-tag for the member blocks first (only the
+            // stages of members that changed are rebuilt, the others keep their state), then forwarded across the whole run like across one block:
+            // "gr:" keys, at the first output sample, gr:sample_rate scaled by the run's rate change
             property_map fwd;
-            if (const Tag* t = _in_edge->tagAtReadPosition()) {
-                std::vector<bool> dirty(_stages.size(), false);
-                for (auto& m : _members)
-                    if (m.block->apply_tag_settings(t->map)) dirty[m.stage] = true;
-                if (std::find(dirty.begin(), dirty.end(), true) != dirty.end()) {
+            if (!_in_edge->tags.empty()) {
+                const auto apply = [&](const property_map& map) {
+                    std::vector<bool> dirty(_stages.size(), false);
+                    for (auto& m : _members)
+                        if (m.block->apply_tag_settings(map)) dirty[m.stage] = true;
+                    if (std::find(dirty.begin(), dirty.end(), true) == dirty.end()) return;
                     while (_q_count) published += retire(false); // a stage is replaced: nothing of the old one may be in flight
                     for (std::size_t i = 0; i < _stages.size(); ++i)
                         if (dirty[i] && _rebuild) { _stages[i] = _rebuild(i); ++_stages_rebuilt; }
                     recompute_rates(); // the launch below is sized with the new chunking
+                };
+                property_map merged;
+                if (const Tag* t = _in_edge->tagAtReadPosition()) { merged = t->map; apply(merged); }
+                if (_in_edge->samplesUntilNextTag() < _in_chunk && _avail() >= _in_chunk) { // tags inside the one chunk this launch cannot be shorter than
+                    merged = _in_edge->mergedTags(_in_chunk);
+                    apply(merged);
                 }
-                for (const auto& [key, value] : t->map) {
+                for (const auto& [key, value] : merged) {
                     if (!std::string_view(key).starts_with(GR_TAG_PREFIX)) continue;
                     const float* rate = tag::settingsKey(key) == tag::SAMPLE_RATE && _out_per_chunk != _in_chunk ? std::get_if<float>(&value) : nullptr;
                     if (rate) fwd.insert_or_assign(key, static_cast<float>(_out_per_chunk) / static_cast<float>(_in_chunk) * *rate);

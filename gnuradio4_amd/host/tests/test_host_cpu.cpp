@@ -165,6 +165,26 @@ int main(int argc, char** argv) {
             EXPECT(sink._tags[1].index == 5u && (sink._tags[1].map == property_map{{"gr:sample_rate", 200.f}})); // "custom" has no gr: prefix: not forwarded
         }
     }
+    { // tags INSIDE a chunk that cannot be split (a decimation group of 100): all tags of the chunk are merged, later ones overriding earlier ones,
+      // and forwarded at the chunk's first output sample -- none is lost (mergedInputTag, Block.hpp:1511-1530)
+        Graph g;
+        auto& src = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(500)}});
+        src.values = {1.f, 2.f, 3.f};
+        src._tags  = {{0, {{"gr:sample_rate", 1000.f}}}, {250, {{"gr:sample_rate", 2000.f}, {"gr:trigger_name", "a"s}}}, {260, {{"gr:trigger_name", "b"s}}}, {400, {{"gr:trigger_name", "c"s}}}};
+        auto& dec  = g.emplaceBlock<filter::Decimator<float>>({{"decim", std::int64_t(100)}});
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        g.connect<"out", "in">(src, dec);
+        g.connect<"out", "in">(dec, sink);
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        EXPECT(sched.runAndWait().has_value());
+        EXPECT(sink._samples.size() == 5u && sink._tags.size() == 3u);
+        if (sink._tags.size() == 3) {
+            EXPECT(sink._tags[0].index == 0u && (sink._tags[0].map == property_map{{"gr:sample_rate", 10.f}}));
+            EXPECT(sink._tags[1].index == 2u && (sink._tags[1].map == property_map{{"gr:sample_rate", 20.f}, {"gr:trigger_name", "b"s}})); // samples 200..299: tags at 250 and 260
+            EXPECT(sink._tags[2].index == 4u && (sink._tags[2].map == property_map{{"gr:trigger_name", "c"s}}));
+        }
+    }
     {
         Graph g;
         auto& src = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(100000)}});

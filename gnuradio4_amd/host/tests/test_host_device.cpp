@@ -514,6 +514,36 @@ int main(int argc, char** argv) {
             if (!(w2 <= 2e-5)) ++errors;
         }
     }
+    { // 6b. tags INSIDE a chunk the run cannot split (a decimation group of 100 samples): every tag of the chunk is merged and forwarded at the chunk's
+      //     first output sample, and a setting among them is applied -- on the device run exactly as in the host graph
+        std::vector<Tag>   tags[2];
+        std::vector<float> got[2];
+        for (int dev = 1; dev >= 0; --dev) {
+            Graph g;
+            const auto dom = [&](property_map m) { if (dev) m["compute_domain"] = "gpu:hip:0"s; return m; };
+            auto& src  = g.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(500)}});
+            src.values = {1.f, 2.f, 3.f};
+            src._tags  = {{0, {{"gr:sample_rate", 1000.f}}}, {250, {{"gr:sample_rate", 2000.f}, {"gr:trigger_name", "a"s}}}, {260, {{"gr:trigger_name", "b"s}, {"gr:value", 4.0}}}, {400, {{"gr:trigger_name", "c"s}}}};
+            auto& mul  = g.emplaceBlock<blocks::math::MultiplyConst<float>>(dom({{"value", 0.5}}));
+            auto& dec  = g.emplaceBlock<filter::Decimator<float>>(dom({{"decim", std::int64_t(100)}}));
+            auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+            g.connect<"out", "in">(src, mul);
+            g.connect<"out", "in">(mul, dec);
+            g.connect<"out", "in">(dec, sink);
+            if (dev && hip::plan(g).size() != 1) { ++errors; break; }
+            scheduler::Simple sched;
+            sched.exchange(std::move(g));
+            if (const auto r = sched.runAndWait(); !r) { std::cerr << "inner-tag run: " << r.error().message << "\n"; ++errors; }
+            tags[dev] = sink._tags;
+            got[dev]  = sink._samples;
+        }
+        // the host graph splits MultiplyConst's chunks at every tag, so it sees 250 and 260 separately and the Decimator merges them; the run sees them merged
+        const std::vector<Tag> want{{0, {{"gr:sample_rate", 10.f}}}, {2, {{"gr:sample_rate", 20.f}, {"gr:trigger_name", "b"s}, {"gr:value", 4.0}}}, {4, {{"gr:trigger_name", "c"s}}}};
+        std::printf("tags inside a decimation group: device run %s, host graph %s\n", tags[1] == want ? "forwarded all of them merged" : "WRONG TAGS", tags[0] == want ? "the same" : "DIFFERENT");
+        if (tags[1] != want || tags[0] != want || got[1].size() != 5 || got[0].size() != 5) ++errors;
+        // samples 0 and 100 carry the old gain in both; from the chunk that holds the tag on, the run applies the new value to the whole chunk
+        if (got[1].size() == 5 && !(got[1][0] == 0.5f && got[1][1] == 1.f && got[1][3] == 4.f && got[1][4] == 8.f)) ++errors; // x[0]=1, x[100]=2, x[300]=1, x[400]=2
+    }
     // ------------------------------------------------------------------ settings-by-tag on a LONE device block (no DeviceRun: the per-block seam)
     // a stage is built once and must follow the block's settings: a gain step by tag on MultiplyConst, new taps by tag on fir_filter (history kept)
     {
