@@ -8,6 +8,8 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import steady
 import numpy as np
 import torch
 
@@ -17,19 +19,8 @@ import gnuradio4_amd as G  # noqa: E402
 from gnuradio4_amd import capi  # noqa: E402
 
 
-def timeit(fn, reps=5, warm=2):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        fn()
-        b.record()
-        b.synchronize()
-        ts.append(a.elapsed_time(b) * 1e-3)
-    return float(np.median(ts))
+def timeit(fn, reps=None, warm=None):
+    return steady(fn)  # back to back at settled clocks (tools/_timing.py)
 
 
 def lowpass(ntaps, fc):

@@ -3,15 +3,12 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import steady
 import gnuradio4_amd as G
 from gnuradio4_amd import capi
-def timeit(fn, reps=7, warm=3):
-    for _ in range(warm): fn()
-    torch.cuda.synchronize(); ts = []
-    for _ in range(reps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b) * 1e-3)
-    return float(np.median(ts))
+def timeit(fn):
+    return steady(fn)  # back to back at settled clocks (tools/_timing.py)
 n = 7168 * int(os.environ.get("C2_BLOCKS", "18432"))  # whole blocks: ~2^27 samples (C2_BLOCKS=147456: ~2^30)
 x = G.synth_f32(n, seed=42)
 k = np.arange(1024); w = np.hamming(1024); t = w * 0.1 * np.sinc(0.1 * (k - 511.5)); taps = (t / t.sum()).astype(np.float32)

@@ -3,15 +3,12 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import steady
 import gnuradio4_amd as G
 from gnuradio4_amd import capi
-def rate(f, x, y, reps=10):
-    for _ in range(3): f.process_bulk(x, y)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps): f.process_bulk(x, y)
-    b.record(); b.synchronize()
-    return x.numel() * reps / a.elapsed_time(b) / 1e6
+def rate(f, x, y):
+    return x.numel() / steady(lambda: f.process_bulk(x, y)) / 1e9  # back to back at settled clocks (tools/_timing.py)
 for log2n in (24, 26, 27):
     n = 1 << log2n
     x = G.synth_f32(n, seed=1); y = torch.empty_like(x)
