@@ -114,7 +114,7 @@ def oracle_frame(O, taps, x_dev, f):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=0, help="SDR channels in the graph: 0 = 1 at --gpus 1 (configs[1]) and 8 at --gpus N > 1 (configs[4])")
     ap.add_argument("--log2-samples", type=int, default=30, help="stream length per step and channel (default 2^30 = configs[1])")

@@ -1,5 +1,5 @@
 // fft.hip -- the streaming FFT block on gfx950: C-ABI (gr4hip_fft_*), the generic LDS-resident Stockham kernel (radix 8/4/2, any power of
-// two <= 8192), the multi-kernel paths (four-step for 16384..65536, Bluestein for other sizes <= 4096), phase unwrap and DataSet ranges.
+// two <= 8192), the multi-kernel paths (four-step for powers of two 16384..2^20, Bluestein for every other size <= 2^19), phase unwrap and DataSet ranges.
 // The compile-time-plan kernels for N = 256..8192 (the fast path) are in fft_kernels.hpp.
 //
 // Replaces gr::blocks::fft::FFT<T>::processBulk (blocks/fourier/.../fft.hpp:147-171): window -> forward DFT
@@ -133,17 +133,73 @@ __global__ __launch_bounds__(256) void fft_big_cols_kernel(const float* __restri
     }
 }
 
-// every requested output from a spectrum buffer: bin k of frame f sits at B[f * N + (k % n1) * (N / n1) + k / n1] (n1 = 1: natural order)
-__global__ __launch_bounds__(256) void fft_emit_kernel(const float2* __restrict__ B, FftOutputs out, int N, int n1, long n_frames) {
+// every requested output from a spectrum buffer: bin k of frame f sits at B[f * N + (k % n1) * (N / n1) + k / n1] (n1 = 1: natural order);
+// frame0: index of the buffer's first frame in the outputs (long inputs run in batches of frames through bounded scratch buffers)
+__global__ __launch_bounds__(256) void fft_emit_kernel(const float2* __restrict__ B, FftOutputs out, int N, int n1, long n_frames, long frame0) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long f   = gid / N;
     const int  k   = (int)(gid % N);
     if (f >= n_frames) return;
-    emit_bin(out, f, N, k, B[f * N + (long)(k % n1) * (N / n1) + k / n1]);
+    emit_bin(out, frame0 + f, N, k, B[f * N + (long)(k % n1) * (N / n1) + k / n1]);
 }
 
-// (2) any other N <= 4096 (the reference's Bluestein branch, algorithm/.../fourier/fft.hpp:353-381): X[k] = c*[k] sum_n (x[n] w[n] c*[n]) c[k-n],
-//     c[n] = e^{+i pi n^2 / N}; the convolution is circular of length M = bit_ceil(2N - 1) <= 8192 and runs through the fast kernels:
+// N1 = 32 .. 256 (N = 2^17 .. 2^20): the column transforms no longer fit a lane's registers.  They run as ordinary N1-point frames of the block
+// kernels, between two transpositions done in 32 x 32 tiles through LDS (reads and writes both in 256-byte rows):
+//   gather:  x[f][n1][n2] (window applied) -> Xt[f][n2][n1]        cols: N1-point transforms of the 4096 rows of Xt -> Yt[f][n2][k1]
+//   scatter: Yt[f][n2][k1] W_N^{n2 k1} -> A[f][k1][n2]              rows: as above                    emit: B[f][k1][k2] -> bin k1 + N1 k2, tiled
+struct BigTile { // this block's tile: rows a0 .. a0 + 31 of the N1 axis, columns b0 .. b0 + 31 of the 4096 axis, of frame f
+    long f;
+    int  a0, b0, tx, ty;
+    __device__ BigTile(int n1) {
+        const long per = 128L * (n1 / 32);
+        f              = blockIdx.x / per;
+        const int tl   = (int)(blockIdx.x % per);
+        a0             = (tl / 128) * 32;
+        b0             = (tl % 128) * 32;
+        tx             = threadIdx.x & 31;
+        ty             = threadIdx.x >> 5;
+    }
+};
+__global__ __launch_bounds__(256) void fft_big_gather_kernel(const float* __restrict__ in, const float* __restrict__ window, float2* __restrict__ Xt, int n1, int real_input) {
+    __shared__ float2 tile[32][33];
+    const BigTile     t(n1);
+    const long        N = 4096L * n1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int  a = t.a0 + t.ty + 8 * r, b = t.b0 + t.tx;
+        const long i = t.f * N + 4096L * a + b;
+        float2     x = real_input ? make_float2(in[i], 0.f) : reinterpret_cast<const float2*>(in)[i];
+        if (window) { const float w = window[4096L * a + b]; x.x *= w; x.y *= w; }
+        tile[t.ty + 8 * r][t.tx] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xt[(t.f * 4096 + t.b0 + t.ty + 8 * r) * n1 + t.a0 + t.tx] = tile[t.tx][t.ty + 8 * r];
+}
+__global__ __launch_bounds__(256) void fft_big_scatter_kernel(const float2* __restrict__ Yt, const float2* __restrict__ twN, float2* __restrict__ A, int n1) {
+    __shared__ float2 tile[32][33];
+    const BigTile     t(n1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = t.b0 + t.ty + 8 * r, k = t.a0 + t.tx; // b k < 4096 N1 = N
+        tile[t.ty + 8 * r][t.tx] = cmul(Yt[(t.f * 4096 + b) * n1 + k], twN[(long)b * k]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A[(t.f * n1 + t.a0 + t.ty + 8 * r) * 4096 + t.b0 + t.tx] = tile[t.tx][t.ty + 8 * r];
+}
+__global__ __launch_bounds__(256) void fft_big_emit_kernel(const float2* __restrict__ B, FftOutputs out, int n1, long frame0) {
+    __shared__ float2 tile[32][33];
+    const BigTile     t(n1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[t.ty + 8 * r][t.tx] = B[(t.f * n1 + t.a0 + t.ty + 8 * r) * 4096 + t.b0 + t.tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) emit_bin(out, frame0 + t.f, 4096 * n1, (t.a0 + t.tx) + n1 * (t.b0 + t.ty + 8 * r), tile[t.tx][t.ty + 8 * r]);
+}
+
+// (2) any other N <= 2^19 (the reference's Bluestein branch, algorithm/.../fourier/fft.hpp:353-381): X[k] = c*[k] sum_n (x[n] w[n] c*[n]) c[k-n],
+//     c[n] = e^{+i pi n^2 / N}; the convolution is circular of length M = bit_ceil(2N - 1) <= 2^20 and runs through the power-of-two paths:
 //     bluestein_pre -> FFT_M -> x FFT_M(c) and conjugate -> FFT_M (inverse through conjugation) -> bluestein_post (conj, 1/M, c*[k]) + outputs
 __global__ __launch_bounds__(256) void bluestein_pre_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ cconj,
                                                              float2* __restrict__ a, int N, int M, long n_frames, int real_input) {
@@ -153,12 +209,12 @@ __global__ __launch_bounds__(256) void bluestein_pre_kernel(const float* __restr
     if (f >= n_frames) return;
     float2 v = make_float2(0.f, 0.f);
     if (n < N) {
-        const long i = f * N + n;
+        const long i = f * (long)N + n;
         v            = real_input ? make_float2(in[i], 0.f) : reinterpret_cast<const float2*>(in)[i];
         if (window) { const float w = window[n]; v.x *= w; v.y *= w; }
         v = cmul(v, cconj[n]);
     }
-    a[f * M + n] = v;
+    a[f * (long)M + n] = v;
 }
 __global__ __launch_bounds__(256) void bluestein_mul_kernel(float2* __restrict__ a, const float2* __restrict__ Bf, int M, long total) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -166,14 +222,14 @@ __global__ __launch_bounds__(256) void bluestein_mul_kernel(float2* __restrict__
     const float2 p = cmul(a[gid], Bf[gid % M]);
     a[gid]         = make_float2(p.x, -p.y); // conjugate: the next forward transform is the inverse one
 }
-__global__ __launch_bounds__(256) void bluestein_post_kernel(const float2* __restrict__ a, const float2* __restrict__ cconj, FftOutputs out, int N, int M, long n_frames) {
+__global__ __launch_bounds__(256) void bluestein_post_kernel(const float2* __restrict__ a, const float2* __restrict__ cconj, FftOutputs out, int N, int M, long n_frames, long frame0) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long f   = gid / N;
     const int  k   = (int)(gid % N);
     if (f >= n_frames) return;
-    const float2 r = a[f * M + k];
+    const float2 r = a[f * (long)M + k];
     const float  s = 1.f / (float)M;
-    emit_bin(out, f, N, k, cmul(make_float2(r.x * s, -r.y * s), cconj[k]));
+    emit_bin(out, frame0 + f, N, k, cmul(make_float2(r.x * s, -r.y * s), cconj[k]));
 }
 
 // fft_common.hpp:71-89 unwrapPhase + :113-120 (deg, shift).  One workgroup per frame; wrap counts are integers, so a
@@ -252,6 +308,18 @@ int  chain_fused_fft_spectrum(ChainFused* c, const float* d_in, size_t n_frames,
 void chain_fused_destroy(ChainFused* c);
 } // namespace gr4
 
+// A power-of-two transform of any supported length as a building block: frames in, every requested output of the natural-order spectrum out.
+//   M <= 8192:            one launch of the block kernels
+//   M = N1 * 4096 <= 2^20: the four-step pipeline above through the engine's own scratch buffers (N1 <= 16: column transforms in registers)
+struct Pow2Engine {
+    size_t       M  = 0;
+    int          n1 = 0; // 0: single launch
+    FftPlanDev   plan{}, plan_cols{};
+    DeviceBuffer tw /*W_M^j*/, tw_rows /*W_4096^j*/, tw_cols /*W_N1^j, N1 > 16*/, s0, s1;
+};
+constexpr size_t kFftMaxPow2 = size_t(1) << 20;      // largest power-of-two transform (N1 = 256)
+constexpr long   kFftBatchElems = 1L << 25;          // multi-kernel paths: complex elements per scratch buffer (256 MiB); longer inputs run in batches of frames
+
 struct gr4hip_fft {
     int          in_dtype = GR4HIP_C32;
     size_t       N        = 0;
@@ -260,9 +328,10 @@ struct gr4hip_fft {
     FftPlanDev   plan{};
     DeviceBuffer d_window, d_tw, d_phase_raw;
     // multi-kernel paths: kind 1 = N1 * 4096 four-step, kind 2 = Bluestein with M-point transforms
-    int          kind = 0, big_n1 = 0;
+    int          kind = 0;
     size_t       M    = 0;
-    DeviceBuffer d_twM, d_chirp, d_chirpF, d_scratchA, d_scratchB;
+    Pow2Engine   eng;  // the power-of-two transform both are built on (kind 1: of N points, kind 2: of M points)
+    DeviceBuffer d_chirp, d_chirpF, d_scratchA, d_scratchB;
     gr4::ChainFused* pipe = nullptr; // N = 8192 complex, |X|^2 only: the persistent frame pipeline of chain_fused.hip (built on first use)
     ~gr4hip_fft();
 };
@@ -327,6 +396,61 @@ int fft_launch(const FftPlanDev& plan, const float* d_in, const float* d_window,
 }
 } // namespace gr4
 
+static int engine_create(Pow2Engine* e, size_t M) {
+    e->M   = M;
+    int rc = fft_upload_twiddles(M, &e->tw);
+    if (rc) return rc;
+    if (M <= 8192) return fft_build_plan(M, &e->plan);
+    e->n1 = (int)(M / 4096);
+    rc    = fft_upload_twiddles(4096, &e->tw_rows);
+    if (!rc && e->n1 > 16) {
+        rc = fft_build_plan((size_t)e->n1, &e->plan_cols);
+        if (!rc) rc = fft_upload_twiddles((size_t)e->n1, &e->tw_cols);
+    }
+    return rc;
+}
+
+// n_frames frames of M points (complex, or real when fin.real_input; `window` may be null) -> the outputs named in `fin`, written from frame index frame0 on
+static int engine_run(Pow2Engine* e, const float* d_in, const float* window, const FftOutputs& fin, long n_frames, long frame0, hipStream_t st) {
+    const long M = (long)e->M;
+    if (e->n1 == 0) {
+        if (frame0 != 0) { set_error("fft: internal: a single-launch transform has no frame offset"); return GR4HIP_RUNTIME_ERROR; }
+        return fft_launch(e->plan, d_in, window, static_cast<const float2*>(e->tw.ptr), fin, n_frames, st);
+    }
+    const int  n1    = e->n1;
+    const long total = n_frames * M;
+    int        rc    = e->s0.ensure((size_t)total * sizeof(float2));
+    if (!rc) rc = e->s1.ensure((size_t)total * sizeof(float2));
+    if (rc) return rc;
+    float2*    s0  = static_cast<float2*>(e->s0.ptr);
+    float2*    s1  = static_cast<float2*>(e->s1.ptr);
+    const auto twN = static_cast<const float2*>(e->tw.ptr);
+    FftOutputs spec{};
+    if (n1 <= 16) {
+        const dim3 grid((unsigned)ceil_div(n_frames * 4096L, 256L));
+        if (n1 == 4) hipLaunchKernelGGL(fft_big_cols_kernel<4>, grid, dim3(256), 0, st, d_in, window, twN, s0, n_frames, fin.real_input);
+        else if (n1 == 8) hipLaunchKernelGGL(fft_big_cols_kernel<8>, grid, dim3(256), 0, st, d_in, window, twN, s0, n_frames, fin.real_input);
+        else hipLaunchKernelGGL(fft_big_cols_kernel<16>, grid, dim3(256), 0, st, d_in, window, twN, s0, n_frames, fin.real_input);
+        GR4_LAUNCH_CHECK();
+    } else {
+        const dim3 tiles((unsigned)(n_frames * 128L * (n1 / 32)));
+        hipLaunchKernelGGL(fft_big_gather_kernel, tiles, dim3(256), 0, st, d_in, window, s0, n1, fin.real_input);
+        GR4_LAUNCH_CHECK();
+        spec.spectrum = reinterpret_cast<float*>(s1);
+        rc            = fft_launch(e->plan_cols, reinterpret_cast<const float*>(s0), nullptr, static_cast<const float2*>(e->tw_cols.ptr), spec, n_frames * 4096L, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fft_big_scatter_kernel, tiles, dim3(256), 0, st, (const float2*)s1, twN, s0, n1);
+        GR4_LAUNCH_CHECK();
+    }
+    spec.spectrum = reinterpret_cast<float*>(s1);
+    rc            = fft_fast_launch<12>(reinterpret_cast<const float*>(s0), nullptr, static_cast<const float2*>(e->tw_rows.ptr), spec, n_frames * n1, st);
+    if (rc) return rc;
+    if (n1 <= 16) hipLaunchKernelGGL(fft_emit_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, (const float2*)s1, fin, (int)M, n1, n_frames, frame0);
+    else hipLaunchKernelGGL(fft_big_emit_kernel, dim3((unsigned)(n_frames * 128L * (n1 / 32))), dim3(256), 0, st, (const float2*)s1, fin, n1, frame0);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
 static int fft_upload_bluestein(size_t N, size_t M, DeviceBuffer* d_cconj, DeviceBuffer* d_Bf);
 
 extern "C" {
@@ -345,21 +469,19 @@ int gr4hip_fft_create(gr4hip_fft_t** out, int in_dtype, size_t fft_size, int win
     if (is_pow2(fft_size) && fft_size >= 2 && fft_size <= 8192) {
         rc = fft_build_plan(fft_size, &f->plan);
         if (!rc) rc = fft_upload_twiddles(fft_size, &f->d_tw);
-    } else if (is_pow2(fft_size) && fft_size <= 65536) { // 16384, 32768, 65536: four-step with 4096-point rows
-        f->kind   = 1;
-        f->big_n1 = (int)(fft_size / 4096);
-        f->M      = 4096;
-        rc        = fft_upload_twiddles(fft_size, &f->d_tw);       // W_N^j for the inter-step twiddles
-        if (!rc) rc = fft_upload_twiddles(4096, &f->d_twM);        // W_4096^j for the row transforms
-    } else if (fft_size >= 2 && fft_size <= 4096) {                 // Bluestein
+    } else if (is_pow2(fft_size) && fft_size <= kFftMaxPow2) { // 16384 .. 2^20: four-step with 4096-point rows
+        f->kind = 1;
+        f->M    = fft_size;
+        rc      = engine_create(&f->eng, fft_size);
+    } else if (fft_size >= 2 && 2 * fft_size - 1 <= kFftMaxPow2) { // every other size (SimdFFT's radix-3/5 sizes included): Bluestein
         f->kind = 2;
         size_t M = 1;
         while (M < 2 * fft_size - 1) M <<= 1;
         f->M = M;
-        rc   = fft_upload_twiddles(M, &f->d_twM);
+        rc   = engine_create(&f->eng, M);
         if (!rc) rc = fft_upload_bluestein(fft_size, M, &f->d_chirp, &f->d_chirpF);
     } else {
-        set_error("fft: size %zu is outside the device paths (powers of two <= 65536, any size <= 4096)", fft_size);
+        set_error("fft: size %zu is outside the device paths (powers of two <= %zu, any size <= %zu)", fft_size, kFftMaxPow2, kFftMaxPow2 / 2);
         rc = GR4HIP_UNSUPPORTED;
     }
     if (!rc && window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR) {
@@ -429,55 +551,42 @@ static int fft_upload_bluestein(size_t N, size_t M, DeviceBuffer* d_cconj, Devic
     return GR4HIP_OK;
 }
 
-// the multi-kernel paths (kind 1: four-step, kind 2: Bluestein); `o` already carries the output pointers and flags
+// the multi-kernel paths (kind 1: four-step, kind 2: Bluestein); `o` already carries the output pointers and flags.  The scratch buffers are bounded:
+// long inputs run in batches of frames (the emitting kernels address the outputs with the absolute frame index)
 static int fft_run_multi(gr4hip_fft_t* f, const float* d_in, long n_frames, const FftOutputs& o, hipStream_t st) {
-    const long   N   = (long)f->N;
-    const float* win = static_cast<const float*>(f->d_window.ptr);
-    FftOutputs   spec{};
-    if (f->kind == 1) {
-        const int  n1    = f->big_n1;
-        const long total = n_frames * N;
+    const long   N      = (long)f->N, M = (long)f->M;
+    const float* win    = static_cast<const float*>(f->d_window.ptr);
+    const long   batch  = std::max(1L, kFftBatchElems / M);
+    const long   in_per = o.real_input ? N : 2 * N; // floats per input frame
+    for (long f0 = 0; f0 < n_frames; f0 += batch) {
+        const long   nf = std::min(batch, n_frames - f0);
+        const float* in = d_in + f0 * in_per;
+        if (f->kind == 1) {
+            int rc = engine_run(&f->eng, in, win, o, nf, f0, st);
+            if (rc) return rc;
+            continue;
+        }
+        const long total = nf * M;
         int        rc    = f->d_scratchA.ensure((size_t)total * sizeof(float2));
         if (!rc) rc = f->d_scratchB.ensure((size_t)total * sizeof(float2));
         if (rc) return rc;
-        float2*    A    = static_cast<float2*>(f->d_scratchA.ptr);
-        const dim3 grid((unsigned)ceil_div(n_frames * 4096L, 256L));
-        const auto twN = static_cast<const float2*>(f->d_tw.ptr);
-        if (n1 == 4) hipLaunchKernelGGL(fft_big_cols_kernel<4>, grid, dim3(256), 0, st, d_in, win, twN, A, n_frames, o.real_input);
-        else if (n1 == 8) hipLaunchKernelGGL(fft_big_cols_kernel<8>, grid, dim3(256), 0, st, d_in, win, twN, A, n_frames, o.real_input);
-        else hipLaunchKernelGGL(fft_big_cols_kernel<16>, grid, dim3(256), 0, st, d_in, win, twN, A, n_frames, o.real_input);
+        float2*    a  = static_cast<float2*>(f->d_scratchA.ptr);
+        float2*    b  = static_cast<float2*>(f->d_scratchB.ptr);
+        const auto cc = static_cast<const float2*>(f->d_chirp.ptr);
+        hipLaunchKernelGGL(bluestein_pre_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, in, win, cc, a, (int)N, (int)M, nf, o.real_input);
         GR4_LAUNCH_CHECK();
-        spec.spectrum = static_cast<float*>(f->d_scratchB.ptr);
-        rc            = fft_fast_launch<12>(reinterpret_cast<const float*>(A), nullptr, static_cast<const float2*>(f->d_twM.ptr), spec, n_frames * n1, st);
+        FftOutputs spec{};
+        spec.spectrum = reinterpret_cast<float*>(b);
+        rc            = engine_run(&f->eng, reinterpret_cast<const float*>(a), nullptr, spec, nf, 0, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(fft_emit_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, (const float2*)f->d_scratchB.ptr, o, (int)N, n1, n_frames);
+        hipLaunchKernelGGL(bluestein_mul_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, b, (const float2*)f->d_chirpF.ptr, (int)M, total);
         GR4_LAUNCH_CHECK();
-        return GR4HIP_OK;
+        spec.spectrum = reinterpret_cast<float*>(a);
+        rc            = engine_run(&f->eng, reinterpret_cast<const float*>(b), nullptr, spec, nf, 0, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bluestein_post_kernel, dim3((unsigned)ceil_div(nf * N, 256L)), dim3(256), 0, st, (const float2*)a, cc, o, (int)N, (int)M, nf, f0);
+        GR4_LAUNCH_CHECK();
     }
-    const long M     = (long)f->M;
-    const long total = n_frames * M;
-    int        rc    = f->d_scratchA.ensure((size_t)total * sizeof(float2));
-    if (!rc) rc = f->d_scratchB.ensure((size_t)total * sizeof(float2));
-    if (rc) return rc;
-    float2*    a  = static_cast<float2*>(f->d_scratchA.ptr);
-    float2*    b  = static_cast<float2*>(f->d_scratchB.ptr);
-    const auto cc = static_cast<const float2*>(f->d_chirp.ptr);
-    const auto tw = static_cast<const float2*>(f->d_twM.ptr);
-    hipLaunchKernelGGL(bluestein_pre_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, d_in, win, cc, a, (int)N, (int)M, n_frames, o.real_input);
-    GR4_LAUNCH_CHECK();
-    FftPlanDev planM{};
-    rc = fft_build_plan((size_t)M, &planM);
-    if (rc) return rc;
-    spec.spectrum = reinterpret_cast<float*>(b);
-    rc            = fft_launch(planM, reinterpret_cast<const float*>(a), nullptr, tw, spec, n_frames, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bluestein_mul_kernel, dim3((unsigned)ceil_div(total, 256L)), dim3(256), 0, st, b, (const float2*)f->d_chirpF.ptr, (int)M, total);
-    GR4_LAUNCH_CHECK();
-    spec.spectrum = reinterpret_cast<float*>(a);
-    rc            = fft_launch(planM, reinterpret_cast<const float*>(b), nullptr, tw, spec, n_frames, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bluestein_post_kernel, dim3((unsigned)ceil_div(n_frames * N, 256L)), dim3(256), 0, st, (const float2*)a, cc, o, (int)N, (int)M, n_frames);
-    GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
 

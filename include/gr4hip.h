@@ -193,8 +193,10 @@ int gr4hip_iir_design(int response, const gr4hip_filter_params* p, int design, f
  * magnitude hypot*2/N [dB] fft-shifted + phase atan2 [unwrap][deg] fft-shifted (fft_common.hpp:20-123) + Re + Im
  * (natural order, fft.hpp:217-220).  in_dtype C32: fft_size values per output; F32: fft_size/2 (fft.hpp:140-143, 221-227).
  * Any output pointer may be NULL.  d_ranges (optional): per frame {min,max} of mag, phase, re, im (fft.hpp:229-232).
- * fft_size: any power of two up to 65536 and any other size up to 4096 (Bluestein, algorithm/.../fourier/fft.hpp:353-381);
- * everything else returns GR4HIP_UNSUPPORTED from create (the caller keeps its CPU path). */
+ * fft_size: any power of two up to 2^20 (one kernel up to 8192, a four-step pipeline above) and every other size up to 2^19 -- the
+ * sizes SimdFFT takes with radix-3/5 passes (SimdFFT.hpp:348-375) and the ones the reference sends to Bluestein
+ * (algorithm/.../fourier/fft.hpp:353-381) alike run as a chirp convolution over the power-of-two transforms; larger sizes return
+ * GR4HIP_UNSUPPORTED from create (the caller keeps its CPU path). */
 typedef struct gr4hip_fft gr4hip_fft_t;
 int gr4hip_fft_create(gr4hip_fft_t** fft, int in_dtype, size_t fft_size, int window, int flags);
 int gr4hip_fft_process(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, float* d_mag, float* d_phase, float* d_re, float* d_im,
