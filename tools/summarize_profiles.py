@@ -31,8 +31,10 @@ lines.append(f"# rocprofv3 --pmc <counters> (separate passes, counters only) -- 
 lines.append(f"# per-dispatch means for kernels matching '{kern}' (one dispatch = one launch of 2^28 samples)")
 for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if kern in r["Kernel_Name"]:
+    rows_k = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+    full = max((int(r["Grid_Size"]) for r in rows_k), default=0)  # the guard's probe launch (first call of a stream: 8 frames) is a dispatch too: full-size launches only
+    for r in rows_k:
+        if int(r["Grid_Size"]) == full:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         lines.append(f"{k:24s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
@@ -43,6 +45,13 @@ if fetch and write:
     lines.append("")
     lines.append(f"# HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are in KiB): read {fk*1024/1e6:.1f} MB, write {wk*1024/1e6:.1f} MB")
     lines.append("# (MI355X_MICROARCH.md: FETCH_SIZE under-reports 16-B/lane streaming reads by 2x on gfx950; this kernel's reads are 16-B/lane LDS-DMA)")
+    lines.append(f"# corrected: {2*fk*1024/1e6:.1f} MB read + {wk*1024/1e6:.1f} MB written = {(2*fk+wk)*1024/1e6:.1f} MB per launch of 2^28 samples (algorithmic: 3221.2 MB)")
+    if kern == "chain_fd_kernel":
+        import json
+        json.dump({"kernel": "gr4::chain_fd_kernel<0, 13>", "samples_per_launch": 1 << 28, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
+                   "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate counter-only passes (profiles/{tag}_{kern}_rocprof_summary.txt): FETCH_SIZE {fk:.0f} KiB x2 "
+                          "(gfx950 under-reports 16-B/lane streaming reads by 2x, MI355X_MICROARCH.md HBM section) + WRITE_SIZE " f"{wk:.0f} KiB",
+                   "algorithmic_bytes_per_launch": 12 << 28}, open("profiles/latest_pmc.json", "w"), indent=1)
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj):
     lines.append("")
