@@ -56,7 +56,7 @@ def test_status_strings_and_errors(L):
     h = C.c_void_p()
     rc = L.gr4hip_fir_create(C.byref(h), 3, None, 0, 1)  # bad dtype
     assert rc == -101 and b"dtype" in L.gr4hip_last_error()
-    for size in (5000, 131072):  # not a power of two beyond the Bluestein range / beyond the four-step range -> caller keeps its CPU path
+    for size in (600000, 1 << 21):  # beyond the chirp-convolution range (2^19) / beyond the four-step range (2^20) -> caller keeps its CPU path
         rc = L.gr4hip_fft_create(C.byref(h), 10, size, 3, 0)
         assert rc == -103
     rc = L.gr4hip_math_nary(0, 8, None, 33, None, 1, None)
