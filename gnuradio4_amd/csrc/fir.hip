@@ -160,6 +160,7 @@ int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, const float* d_hist1024,
 // fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st);
+int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
 
@@ -194,7 +195,7 @@ struct gr4hip_fir {
     bool               fd_probed = false, fd_blocked = false;
     float              fd_ratio  = -1.f;
     gr4::FirDecimFd*   dfd = nullptr; // float, decim 8, <= 1024 taps: frequency-domain decimator (created on first use)
-    DeviceBuffer       d_hist256;
+    DeviceBuffer       d_hist256, d_histc;
     DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
     int                mKp = 0, mKS = 0;
 };
@@ -337,6 +338,25 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
             done = frames * kFdFrame;
             hist = x + (done - f->hcap) * 2; // the hcap samples in front of the remainder are part of the input itself
         }
+    }
+    // complex<float>, no decimation, 33..256 taps, whatever the fast convolution did not take (GR4HIP_FIR_TIME_DOMAIN, a stream the dynamic-range guard has
+    // moved to the direct form, or both): the same block-Toeplitz product on the re and im planes of the interleaved samples (fir_mfma_c32_kernel)
+    if (f->S == 2 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && (reinterpret_cast<uintptr_t>(y + done * 2) & 15) == 0) {
+        int rc = GR4HIP_OK;
+        if (f->mKS == 0) {
+            std::vector<float> af;
+            fir_mfma_make_afrag(f->taps.data(), f->ntaps, 1, &f->mKp, &f->mKS, &af);
+            rc = f->d_afrag.ensure(af.size() * sizeof(float));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (rc) { f->mKS = 0; return rc; }
+        }
+        rc = f->d_histc.ensure(256 * sizeof(float2));
+        if (rc) return rc;
+        hipLaunchKernelGGL(fir_hist_widen_kernel<float2>, dim3(1), dim3(256), 0, st, (const float2*)hist, (int)f->hcap, (float2*)f->d_histc.ptr, f->mKp);
+        GR4_LAUNCH_CHECK();
+        rc = fir_mfma_c32_launch(f->mKS, x + done * 2, (long)(n_in - done), (const float*)f->d_histc.ptr, (const float*)f->d_afrag.ptr, y + done * 2, st);
+        if (rc) return rc;
+        done = n_in;
     }
     // float, no decimation, 33..256 taps, long 16-byte-aligned output: block-Toeplitz product on the f32 MFMA units (about twice the
     // rate of the register-window VALU kernel, which is FP32-issue bound from ~48 taps on)

@@ -94,6 +94,79 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__
     }
 }
 
+// fir_filter<complex<float>> (real taps on interleaved {re, im} samples) on the same scheme: the two components are two real streams under the same
+// taps.  The segment is de-interleaved into a re plane and an im plane while it is staged; a wave's two accumulators are the re and the im tile of the
+// same 256 outputs (same A fragment, B operand from the two planes), so D leaves re-interleaved as two 16-byte stores per lane.  2048 complex outputs
+// per segment (the same 4096 real outputs and the same LDS footprint as fir_mfma_kernel).  hist: the Kp complex samples in front of x.
+constexpr int kSegC = 2048;
+template <int KS>
+__global__ __launch_bounds__(256) void fir_mfma_c32_kernel(const float2* __restrict__ x, const float2* __restrict__ hist, const float* __restrict__ afrag, float2* __restrict__ y, long n) {
+    constexpr int Kp   = 4 * KS - 16;
+    constexpr int NPAD = (kSegC + Kp) / 16 * 18 + 16; // per plane; + 16: the two planes sit 16 banks apart, so the re / im halves of a staged lane pair do not collide
+    constexpr int NL   = (kSegC + Kp + 255) / 256;    // complex samples a lane holds for the next segment
+    __shared__ float xs[2 * NPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float     a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = afrag[ks * 64 + lane];
+    float2 nxt[NL];
+    auto   load_next = [&](long seg0) {
+        const long   i0   = seg0 - Kp;
+        const long   nrec = n - i0 < (long)(kSegC + Kp) ? n - i0 : (long)(kSegC + Kp);
+        const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 8 : 0));
+#pragma unroll
+        for (int u = 0; u < NL; ++u) nxt[u] = buf_load_f2(r, tid * 8, 256 * u * 8);
+    };
+    const long nseg = (n + kSegC - 1) / kSegC, sfirst = (long)blockIdx.x * kSegPerWg, slast = sfirst + kSegPerWg < nseg ? sfirst + kSegPerWg : nseg;
+    if (sfirst > 0 && sfirst < slast) load_next(sfirst * kSegC);
+    const int col = lane & 15, kq = lane >> 4;
+    for (long sg = sfirst; sg < slast; ++sg) {
+        const long seg0 = sg * kSegC;
+        if (sg > 0) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int s_ = tid + 256 * u;
+                if (s_ < kSegC + Kp) {
+                    xs[s_ + 2 * (s_ >> 4)]        = nxt[u].x;
+                    xs[NPAD + s_ + 2 * (s_ >> 4)] = nxt[u].y;
+                }
+            }
+        } else {
+            for (int s_ = tid; s_ < kSegC + Kp; s_ += 256) { // the first segment of the span reads the carried history in front of x
+                const long   i = seg0 - Kp + s_;
+                const float2 v = i >= 0 ? (i < n ? x[i] : make_float2(0.f, 0.f)) : hist[Kp + i];
+                xs[s_ + 2 * (s_ >> 4)]        = v.x;
+                xs[NPAD + s_ + 2 * (s_ >> 4)] = v.y;
+            }
+        }
+        __syncthreads();
+        if (sg + 1 < slast) load_next(seg0 + kSegC); // in flight during the MFMAs below
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            const int    ib  = 16 * (2 * wave + pair); // first 16-sample block of this wave's tile
+            f32x4        acr = {0.f, 0.f, 0.f, 0.f}, aci = {0.f, 0.f, 0.f, 0.f};
+            const float* pr  = xs + 18 * (ib + col) + kq;
+            const float* pi  = pr + NPAD;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = 4 * ks + 2 * (ks >> 2);
+                acr = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], pr[off], acr, 0, 0, 0);
+                aci = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], pi[off], aci, 0, 0, 0);
+            }
+            const long o = seg0 + 16L * (ib + col) + 4 * kq; // D[row = 4 kq + r][col]: y[16 (ib + col) + 4 kq + r]
+            if (o + 3 < n) {
+                float4* d = reinterpret_cast<float4*>(y + o);
+                d[0]      = make_float4(acr[0], aci[0], acr[1], aci[1]);
+                d[1]      = make_float4(acr[2], aci[2], acr[3], aci[3]);
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (o + r < n) y[o + r] = make_float2(acr[r], aci[r]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // new_hist[c][h] = virtual input of channel c at index n - Kp + h
 __global__ void fir_batched_hist_kernel(const float* __restrict__ x, long in_stride, const float* __restrict__ old_hist, float* __restrict__ new_hist, long n, int Kp) {
     const int c = blockIdx.y, h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,6 +307,20 @@ int fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, c
     case 20: hipLaunchKernelGGL(fir_mfma_kernel<20>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
     case 36: hipLaunchKernelGGL(fir_mfma_kernel<36>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
     default: hipLaunchKernelGGL(fir_mfma_kernel<68>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
+    }
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+// y[i] = sum_k b[k] x[i - k] on complex samples; hist = the Kp complex samples in front of x; y must be 16-byte aligned
+int fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kSegC), (long)kSegPerWg));
+    const auto xc = reinterpret_cast<const float2*>(x), hc = reinterpret_cast<const float2*>(hist);
+    const auto yc = reinterpret_cast<float2*>(y);
+    switch (KS) {
+    case 20: hipLaunchKernelGGL(fir_mfma_c32_kernel<20>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n); break;
+    case 36: hipLaunchKernelGGL(fir_mfma_c32_kernel<36>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n); break;
+    default: hipLaunchKernelGGL(fir_mfma_c32_kernel<68>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n); break;
     }
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;

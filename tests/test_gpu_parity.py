@@ -217,6 +217,28 @@ def test_fir_complex_long_input_fast_convolution(G, ntaps):
     assert _rel(f2.process_bulk(xin).cpu().numpy(), truth) <= TOL
 
 
+@pytest.mark.parametrize("ntaps", [256, 129, 64, 40])
+def test_fir_complex_time_domain_on_the_matrix_pipe(G, ntaps):
+    """complex<float> direct form (GR4HIP_FIR_TIME_DOMAIN: the regime the dynamic-range guard moves a stream to), 33 .. 256 taps, spans >= 2^15 samples: the
+    re and im planes as a block-Toeplitz product on the f32 MFMA units; ragged spans, history across the kernel switches, an output that is only 8-byte
+    aligned (-> the VALU kernel) gives the same stream"""
+    rng = np.random.default_rng(ntaps)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    cuts = [0, 50_001, 50_001 + 300_003, 50_001 + 300_003 + 700, 50_001 + 300_003 + 700 + 40_000, 50_001 + 300_003 + 700 + 40_000 + 150_000]
+    x = O.signal_c32(6, cuts[-1])
+    truth, _ = O.fir(b, x)
+    f = G.fir_filter(b, torch.complex64)
+    f.set_algo(G.capi.FIR_TIME_DOMAIN)
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert _rel(y, truth) <= TOL
+    f2 = G.fir_filter(b, torch.complex64)
+    f2.set_algo(G.capi.FIR_TIME_DOMAIN)
+    out = torch.empty(cuts[-1] + 1, dtype=torch.complex64, device="cuda")[1:]
+    f2.process_bulk(dev(x), out)
+    assert _rel(out.cpu().numpy(), truth) <= TOL
+    assert float(np.abs(out.cpu().numpy() - y).max()) <= TOL * float(np.sqrt(np.mean(np.abs(truth) ** 2)))  # two float32 summation orders
+
+
 def test_fir_boxcar_step_golden(G, golden):
     g = golden["fir_iir_step"]
     x = np.ones(g["n_steps"], np.float32)

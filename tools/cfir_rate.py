@@ -18,3 +18,14 @@ for log2n in (28, 27, 28):
     tc = timeit(lambda: c.process_bulk(x, m))
     print("2^%d: complex FIR %.3f ms = %6.1f Gsamples/s (%.2f TB/s at 16 B) | chain -> mag2 %.3f ms = %6.1f Gsamples/s (%.2f TB/s at 12 B)" % (log2n, t * 1e3, n / t / 1e9, n * 16 / t / 1e12, tc * 1e3, n / tc / 1e9, n * 12 / tc / 1e12))
     del x, y, m
+from gnuradio4_amd import capi
+for ntaps in (256, 64):
+    n = 1 << 27
+    kk = np.arange(ntaps); t = np.hamming(ntaps) * 0.2 * np.sinc(0.2 * (kk - (ntaps - 1) / 2)); t = (t / t.sum()).astype(np.float32)
+    x = G.synth_c32(n); y = torch.empty(n, dtype=torch.complex64, device="cuda"); m = torch.empty(n, dtype=torch.float32, device="cuda")
+    f = G.fir_filter(t, torch.complex64); f.set_algo(capi.FIR_TIME_DOMAIN)
+    tt = timeit(lambda: f.process_bulk(x, y))
+    c = G.Chain(t, 8192, "None", capi.CHAIN_TIME_DOMAIN)
+    tc = timeit(lambda: c.process_bulk(x, m))
+    print("time domain, %3d taps: complex FIR %.3f ms = %6.1f Gsamples/s (%.1f TFLOP/s) | chain (FIR kernel + FFT kernel) %.3f ms = %6.1f Gsamples/s" % (ntaps, tt * 1e3, n / tt / 1e9, n * 4 * ntaps / tt / 1e12, tc * 1e3, n / tc / 1e9))
+    del x, y, m
