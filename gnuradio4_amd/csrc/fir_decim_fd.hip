@@ -13,6 +13,12 @@
 // (derivation and a float64 check of the identity: tools/proto_decim_fd.py).  ~35 VALU lane-operations per input sample instead of 256 flop; HBM 4 B in
 // (+ 14 % overlap re-read) + 0.5 B out per sample.  One workgroup of 512 lanes (8 waves, <= 128 VGPRs) per block, two workgroups per CU, persistent,
 // the next block streams into the landing buffer by LDS-DMA while this one is transformed.
+//
+// Where the time goes (timing-only builds, 2^27 input samples, tools/abdf.sh; the full kernel: 0.216-0.224 ms): without the landing DMA 0.158-0.162, with the
+// DMA re-reading a block that sits in the L2 0.175, without the wave-private 512-point transforms 0.149, without the inverse transforms 0.194, neither (DMA,
+// cross pass, product, final pass: the memory skeleton) 0.128.  Memory and arithmetic do not hide behind each other -- as for the fused chain
+// the sum behaves like an energy budget, not like max(compute, memory).  Warming the L2 one, two or three blocks ahead with 4-byte LDS-DMA touches measured
+// 0 / -5 / -8 %: the traffic itself costs, not its latency.
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fft_radix.hpp"
