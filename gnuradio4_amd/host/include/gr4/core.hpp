@@ -81,8 +81,22 @@ public:
 };
 
 // ---------------------------------------------------------------------------------------------- property_map (settings payload)
-using pmt = std::variant<bool, std::int64_t, std::uint64_t, double, float, std::string, std::complex<float>, std::complex<double>, std::vector<float>,
-                         std::vector<double>, std::vector<std::int64_t>>;
+struct property_map;
+using pmt_base = std::variant<bool, std::int64_t, std::uint64_t, double, float, std::string, std::complex<float>, std::complex<double>, std::vector<float>,
+                              std::vector<double>, std::vector<std::int64_t>, std::shared_ptr<const property_map>>;
+// a property value; the last alternative is a nested map ({"leftBlock", property_map{{"value", 2.0}}}: the settings of a merged block's parts,
+// BlockMerging.hpp:103-110 forwardNestedSettings)
+struct pmt : pmt_base {
+    using pmt_base::pmt_base;
+    pmt() = default;
+    pmt(const property_map& nested);
+    pmt(property_map&& nested);
+    [[nodiscard]] const property_map* get_if_map() const noexcept {
+        const auto* p = std::get_if<std::shared_ptr<const property_map>>(static_cast<const pmt_base*>(this));
+        return p ? p->get() : nullptr;
+    }
+    [[nodiscard]] friend bool operator==(const pmt& a, const pmt& b);
+};
 // (the reference's property_map is pmt::Value::Map; block code uses the std::map surface plus find_value(), ValueMap.hpp:1811-1830)
 struct property_map : std::map<std::string, pmt, std::less<>> {
     using base_t = std::map<std::string, pmt, std::less<>>;
@@ -93,6 +107,13 @@ struct property_map : std::map<std::string, pmt, std::less<>> {
         return it == this->end() ? std::nullopt : std::optional<pmt>(it->second);
     }
 };
+inline pmt::pmt(const property_map& nested) : pmt_base(std::make_shared<const property_map>(nested)) {}
+inline pmt::pmt(property_map&& nested) : pmt_base(std::make_shared<const property_map>(std::move(nested))) {}
+[[nodiscard]] inline bool operator==(const pmt& a, const pmt& b) { // nested maps compare by content
+    const property_map *ma = a.get_if_map(), *mb = b.get_if_map();
+    if (ma || mb) return ma && mb && static_cast<const property_map::base_t&>(*ma) == static_cast<const property_map::base_t&>(*mb);
+    return static_cast<const pmt_base&>(a) == static_cast<const pmt_base&>(b);
+}
 
 namespace detail {
 template <typename T>
@@ -142,7 +163,7 @@ bool assign_from(T& dst, const pmt& v) {
                 return false;
             }
         },
-        v);
+        static_cast<const pmt_base&>(v));
 }
 } // namespace detail
 
@@ -594,6 +615,22 @@ struct Block {
     Derived&       self() { return *static_cast<Derived*>(this); }
     const Derived& self() const { return *static_cast<const Derived*>(this); }
 
+    // does `key` name one of this block's settings?  (merged blocks hand a flat key to every part that has it, BlockMerging.hpp:206-210)
+    [[nodiscard]] bool hasSetting(std::string_view key) {
+        if constexpr (requires(Derived& d) { d.hasSettingOverride(key); }) {
+            if (self().hasSettingOverride(key)) return true;
+        }
+        bool found = false;
+        detail::for_each_member(self(), [&](std::string_view mname, auto& member) {
+            using M = std::decay_t<decltype(member)>;
+            if constexpr (!detail::is_port<M>::value && !detail::is_port_vector<M>::value) {
+                bool match = (mname == key);
+                if constexpr (detail::is_annotated<M>::value) match = match || (M::description() == key);
+                found = found || match;
+            }
+        });
+        return found;
+    }
     // apply a property_map to the reflected members and call settingsChanged(old, new) like Block::init / applyChangedSettings
     void applySettings(const property_map& newSettings) {
         property_map applied;
@@ -810,6 +847,7 @@ struct BlockWrapper final : BlockModel {
             base = port.substr(0, h);
             idx  = static_cast<std::size_t>(std::stoul(std::string(port.substr(h + 1))));
         }
+        if constexpr (requires { T::port_alias(base); }) base = T::port_alias(base); // e.g. a merged block's ports under the names its parts gave them
         bool done = false;
         detail::for_each_member(block, [&](std::string_view mname, auto& m) {
             using M = std::decay_t<decltype(m)>;

@@ -8,8 +8,10 @@
 // feedback path closed over a one-sample state.  With compute_domain = "gpu:hip" the parts become device stages of ONE block, and
 // affine feedback loops (adder + constant gain) collapse into the parallel-in-time IIR kernel (gr4/hip.hpp): the run-time fusion the
 // reference does at compile time.
-// Deviation: a merged block always names its remaining ports `in` and `out` (upstream keeps the forward block's names, e.g. `in1`).
-// Sub-block settings use dotted keys ("leftBlock.value", "feedback.value") instead of nested property_maps.
+// Settings reach the parts as upstream (BlockMerging.hpp:93-110, 206-210, 641-649): a flat key goes to every part that has a setting of that name, and a
+// nested map under the part's name -- {"leftBlock", property_map{{"value", 2.0}}}, "rightBlock", "forward", "feedback", "path<I>" -- goes to that part;
+// dotted keys ("leftBlock.value") are accepted as a shorthand for the nested form.  The exposed ports are `in` / `out`; the names the parts gave them
+// (a FeedbackMerge over Adder<> exposes the adder's free input: `in1`) resolve to the same ports in Graph::connect.
 #pragma once
 #include "blocks.hpp"
 
@@ -30,16 +32,35 @@ using in_type_t = typename std::decay_t<decltype(std::declval<B&>().in)>::value_
 template <typename B>
 using out_type_t = typename std::decay_t<decltype(std::declval<B&>().out)>::value_type;
 
-// split {"leftBlock.value": v, ...} into per-part maps; unknown prefixes throw like an unknown setting
-inline void route_settings(const property_map& all, std::initializer_list<std::pair<std::string_view, property_map*>> parts, property_map& own) {
+// settings of a merged block -> its parts.  `has(i, key)`: does part i have a setting of that name.  Returns per-part maps; what belongs to the merged
+// block itself (name, compute_domain, ...) lands in `own`; a key nobody knows throws like an unknown setting
+inline std::vector<property_map> route_settings(const property_map& all, const std::vector<std::string>& part_names, const std::function<bool(std::size_t, std::string_view)>& has,
+                                                property_map& own) {
+    std::vector<property_map> per(part_names.size());
+    const auto part_index = [&](std::string_view name) {
+        for (std::size_t i = 0; i < part_names.size(); ++i)
+            if (part_names[i] == name) return i;
+        return part_names.size();
+    };
     for (const auto& [key, value] : all) {
-        const auto dot = key.find('.');
-        if (dot == std::string::npos) { own.emplace(key, value); continue; }
-        bool routed = false;
-        for (auto& [prefix, dst] : parts)
-            if (std::string_view(key).substr(0, dot) == prefix) { dst->emplace(key.substr(dot + 1), value); routed = true; }
-        if (!routed) throw std::invalid_argument("unknown sub-block '" + key.substr(0, dot) + "' in setting '" + key + "'");
+        if (const property_map* nested = value.get_if_map()) { // {"leftBlock", property_map{...}}
+            const std::size_t i = part_index(key);
+            if (i == part_names.size()) throw std::invalid_argument("unknown sub-block '" + key + "'");
+            for (const auto& kv : *nested) per[i].insert_or_assign(kv.first, kv.second);
+            continue;
+        }
+        if (const auto dot = key.find('.'); dot != std::string::npos) { // "leftBlock.value"
+            const std::size_t i = part_index(std::string_view(key).substr(0, dot));
+            if (i == part_names.size()) throw std::invalid_argument("unknown sub-block '" + key.substr(0, dot) + "' in setting '" + key + "'");
+            per[i].insert_or_assign(key.substr(dot + 1), value);
+            continue;
+        }
+        bool taken = false; // flat key: every part that has such a setting takes it (forwardSettings to both parts)
+        for (std::size_t i = 0; i < part_names.size(); ++i)
+            if (has(i, key)) { per[i].insert_or_assign(key, value); taken = true; }
+        if (!taken) own.emplace(key, value);
     }
+    return per;
 }
 } // namespace detail
 
@@ -55,12 +76,19 @@ struct Merge : Block<Merge<A, OutA, B, InB>> {
     A leftBlock{};
     B rightBlock{};
 
-    void applySettings(const property_map& settings) { // keys "leftBlock.<setting>" / "rightBlock.<setting>" (Settings forwarding, USER_API_Connecting_Blocks.md)
-        property_map l, r, own;
-        detail::route_settings(settings, {{"leftBlock", &l}, {"rightBlock", &r}}, own);
-        if (!l.empty()) leftBlock.applySettings(l);
-        if (!r.empty()) rightBlock.applySettings(r);
+    void applySettings(const property_map& settings) { // flat keys, {"leftBlock", map} / {"rightBlock", map}, "leftBlock.<setting>" (see the file header)
+        property_map own;
+        const auto   per = detail::route_settings(settings, {"leftBlock", "rightBlock"}, [this](std::size_t i, std::string_view k) { return i == 0 ? leftBlock.hasSetting(k) : rightBlock.hasSetting(k); }, own);
+        if (!per[0].empty()) leftBlock.applySettings(per[0]);
+        if (!per[1].empty()) rightBlock.applySettings(per[1]);
         Block<Merge>::applySettings(own); // name, compute_domain
+    }
+    [[nodiscard]] bool hasSettingOverride(std::string_view k) { return leftBlock.hasSetting(k) || rightBlock.hasSetting(k); } // (a Merge inside a Merge)
+    // the exposed ports under the names the parts gave them: A's input port, B's output port (whatever they are called there)
+    static constexpr std::string_view port_alias(std::string_view p) {
+        if constexpr (requires { A::port_alias(p); }) { if (A::port_alias(p) == "in") return "in"; }
+        if constexpr (requires { B::port_alias(p); }) { if (B::port_alias(p) == "out") return "out"; }
+        return p;
     }
     [[nodiscard]] TOut processOne(TIn x) { return rightBlock.processOne(leftBlock.processOne(x)); }
 };
@@ -79,13 +107,16 @@ struct FeedbackMerge : Block<FeedbackMerge<Forward, ForwardOut, Feedback, Feedba
     Feedback feedback{};
     T        _state{}; // what the feedback path delivered for the previous sample
 
-    void applySettings(const property_map& settings) { // keys "forward.<setting>" / "feedback.<setting>"
-        property_map f, b, own;
-        detail::route_settings(settings, {{"forward", &f}, {"feedback", &b}}, own);
-        if (!f.empty()) forward.applySettings(f);
-        if (!b.empty()) feedback.applySettings(b);
+    void applySettings(const property_map& settings) { // flat keys, {"forward", map} / {"feedback", map}, "feedback.<setting>"
+        property_map own;
+        const auto   per = detail::route_settings(settings, {"forward", "feedback"}, [this](std::size_t i, std::string_view k) { return i == 0 ? forward.hasSetting(k) : feedback.hasSetting(k); }, own);
+        if (!per[0].empty()) forward.applySettings(per[0]);
+        if (!per[1].empty()) feedback.applySettings(per[1]);
         Block<FeedbackMerge>::applySettings(own);
     }
+    [[nodiscard]] bool hasSettingOverride(std::string_view k) { return forward.hasSetting(k) || feedback.hasSetting(k); }
+    // upstream keeps the forward block's name for its free input (the adder's `in1` when the feedback enters at `in2`)
+    static constexpr std::string_view port_alias(std::string_view p) { return p == (kFeedbackIntoSecond ? "in1" : "in2") ? std::string_view("in") : p; }
     [[nodiscard]] T processOne(T x) noexcept {
         const T y = kFeedbackIntoSecond ? forward.processOne(x, _state) : forward.processOne(_state, x);
         _state    = feedback.processOne(y);
@@ -123,20 +154,21 @@ struct SplitMergeCombineImpl : Block<SplitMergeCombineImpl<SignsT, Paths...>> {
     template <std::size_t I> const auto& path() const { return std::get<I>(_paths); }
     static constexpr double sign(std::size_t i) { return SignsT::size == 0 ? 1.0 : SignsT::values[i]; }
 
-    void applySettings(const property_map& settings) {
-        std::array<property_map, sizeof...(Paths)> per{};
-        property_map                               own;
-        for (const auto& [key, value] : settings) {
-            const auto dot = key.find('.');
-            if (dot == std::string::npos) { own.emplace(key, value); continue; }
-            const std::string prefix = key.substr(0, dot);
-            std::size_t       idx    = sizeof...(Paths);
-            if (prefix.rfind("path", 0) == 0 && prefix.size() > 4) idx = static_cast<std::size_t>(std::stoul(prefix.substr(4)));
-            if (idx >= sizeof...(Paths)) throw std::invalid_argument("unknown sub-block '" + prefix + "' in setting '" + key + "'");
-            per[idx].emplace(key.substr(dot + 1), value);
-        }
+    void applySettings(const property_map& settings) { // flat keys (every path that has the setting), {"path<I>", map}, "path<I>.<setting>"
+        std::vector<std::string> names;
+        for (std::size_t i = 0; i < sizeof...(Paths); ++i) names.push_back("path" + std::to_string(i));
+        property_map own;
+        const auto   has = [this](std::size_t i, std::string_view k) {
+            bool h = false;
+            [&]<std::size_t... I>(std::index_sequence<I...>) { ((I == i ? void(h = std::get<I>(_paths).hasSetting(k)) : void()), ...); }(std::index_sequence_for<Paths...>{});
+            return h;
+        };
+        const auto per = detail::route_settings(settings, names, has, own);
         [&]<std::size_t... I>(std::index_sequence<I...>) { ((per[I].empty() ? void() : std::get<I>(_paths).applySettings(per[I])), ...); }(std::index_sequence_for<Paths...>{});
         Block<SplitMergeCombineImpl>::applySettings(own);
+    }
+    [[nodiscard]] bool hasSettingOverride(std::string_view k) {
+        return [&]<std::size_t... I>(std::index_sequence<I...>) { return (std::get<I>(_paths).hasSetting(k) || ...); }(std::index_sequence_for<Paths...>{});
     }
     [[nodiscard]] T processOne(T x) {
         return [&]<std::size_t... I>(std::index_sequence<I...>) { return ((static_cast<T>(sign(I)) * std::get<I>(_paths).processOne(x)) + ...); }(std::index_sequence_for<Paths...>{});

@@ -204,7 +204,7 @@ int main(int argc, char** argv) {
         EXPECT(sink._tags.size() == 2u && sink._tags[0].index == 70001u && (sink._tags[0].map == property_map{{"gr:trigger_name", "go"s}}) && sink._tags[1].index == 70002u);
     }
     // ---- merge API: the reference benchmark's IIR low-pass y[n] = a x[n] + (1 - a) y[n-1] as Merge<MultiplyConst, FeedbackMerge<Adder, MultiplyConst>>
-    //      (core/benchmarks/bm_MergeApi.cpp:59-77), type spelled as upstream; sub-block settings by dotted keys
+    //      (core/benchmarks/bm_MergeApi.cpp:59-77), type spelled as upstream; sub-block settings by dotted keys (shorthand) and as upstream's nested maps
     {
         using blocks::math::MultiplyConst;
         using IIRChain = gr::Merge<MultiplyConst<float>, "out", gr::FeedbackMerge<Adder<>, "out", MultiplyConst<float>, "out", "in2">, "in1">;
@@ -228,6 +228,31 @@ int main(int argc, char** argv) {
         bool threw = false;
         try { IIRChain bad; bad.applySettings({{"middleBlock.value", 1.0}}); } catch (const std::invalid_argument&) { threw = true; }
         EXPECT(threw);
+        // settings as upstream spells them (BlockMerging.hpp:93-110, 206-210, 641-649): nested maps under the part's name; a flat key goes to every part that has it
+        {
+            IIRChain nested;
+            nested.applySettings({{"leftBlock", property_map{{"value", double(kAlpha)}}}, {"rightBlock", property_map{{"feedback", property_map{{"value", double(1.0f - kAlpha)}}}}}});
+            EXPECT(nested.leftBlock.value == kAlpha && nested.rightBlock.feedback.value == 1.0f - kAlpha);
+            IIRChain flat;
+            flat.applySettings({{"value", 0.5}, {"name", "lp"s}}); // both MultiplyConst parts have `value`; the name is the merged block's own
+            EXPECT(flat.leftBlock.value == 0.5f && flat.rightBlock.feedback.value == 0.5f && flat.name == "lp");
+            bool bad_part = false;
+            try { flat.applySettings({{"middleBlock", property_map{{"value", 1.0}}}}); } catch (const std::invalid_argument&) { bad_part = true; }
+            EXPECT(bad_part);
+            // the exposed input of a FeedbackMerge under the name the forward block gave it (the adder's free `in1`), as upstream's graphs address it
+            using Loop = gr::FeedbackMerge<Adder<>, "out", MultiplyConst<float>, "out", "in2">;
+            Graph g2;
+            auto& s2 = g2.emplaceBlock<testing::VectorSource<float>>({{"n_samples_max", std::int64_t(4)}});
+            s2.values = {1.f, 1.f, 1.f, 1.f};
+            auto& lp  = g2.emplaceBlock<Loop>({{"feedback", property_map{{"value", 0.5}}}});
+            auto& k2  = g2.emplaceBlock<testing::VectorSink<float>>();
+            EXPECT((g2.connect<"out", "in1">(s2, lp)).has_value() && (g2.connect<"out", "in">(lp, k2)).has_value());
+            EXPECT(!(g2.connect<"out", "in2">(s2, lp)).has_value()); // the feedback input is closed inside the block
+            scheduler::Simple sc2;
+            sc2.exchange(std::move(g2));
+            EXPECT(sc2.runAndWait().has_value());
+            EXPECT((k2._samples == std::vector<float>{1.f, 1.5f, 1.75f, 1.875f}));
+        }
         // SplitMergeCombine: fan-out to N paths, signed sum (USER_API_Connecting_Blocks.md "SplitMergeCombine"; bm_MergeApi.cpp:62-67)
         using FanOut = gr::SplitMergeCombine<MultiplyConst<float>, MultiplyConst<float>>;
         FanOut fan;
