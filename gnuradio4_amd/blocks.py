@@ -72,22 +72,33 @@ class _Handle:
 
 
 class fir_filter(_Handle):
-    """gr::filter::fir_filter<T> (time_domain_filter.hpp:22-48): settings `b`; T in {float32, complex64}."""
+    """gr::filter::fir_filter<T> (time_domain_filter.hpp:22-48): settings `b`; T in {float32, complex64} and the second registered type float64
+    (double taps, the plain FP64 kernel of csrc/f64.hip)."""
     _destroy = "gr4hip_fir_destroy"
 
     def __init__(self, b: Sequence[float], dtype=torch.float32, decimate: int = 1):
         super().__init__()
-        self.b = np.ascontiguousarray(b, np.float32)
         self.dtype = dtype
         self.decimate = int(decimate)
+        self._f64 = dtype == torch.float64
+        if self._f64:
+            self._destroy = "gr4hip_fir64_destroy"
+            self.b = np.ascontiguousarray(b, np.float64)
+            check(lib().gr4hip_fir64_create(C.byref(self._h), self.b.ctypes.data, len(self.b), self.decimate), "fir_filter<float64>")
+            return
+        self.b = np.ascontiguousarray(b, np.float32)
         check(lib().gr4hip_fir_create(C.byref(self._h), _DTYPE_ID[dtype], self.b.ctypes.data, len(self.b), self.decimate), "fir_filter")
 
     def settings_changed(self, b: Sequence[float]):  # settingsChanged (:38-42)
+        if self._f64:
+            self.b = np.ascontiguousarray(b, np.float64)
+            check(lib().gr4hip_fir64_set_taps(self._h, self.b.ctypes.data, len(self.b)), "fir_filter.set_taps")
+            return
         self.b = np.ascontiguousarray(b, np.float32)
         check(lib().gr4hip_fir_set_taps(self._h, self.b.ctypes.data, len(self.b)), "fir_filter.set_taps")
 
     def reset(self):
-        check(lib().gr4hip_fir_reset(self._h), "fir_filter.reset")
+        check((lib().gr4hip_fir64_reset if self._f64 else lib().gr4hip_fir_reset)(self._h), "fir_filter.reset")
 
     def set_algo(self, algo: int):
         """capi.FIR_AUTO / capi.FIR_TIME_DOMAIN (direct form also for long complex spans: error relative to the output, include/gr4hip.h)"""
@@ -100,7 +111,8 @@ class fir_filter(_Handle):
         n_out = x.numel() // self.decimate
         if out is None:
             out = torch.empty(n_out, dtype=self.dtype, device=x.device)
-        check(lib().gr4hip_fir_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), None, _stream()), "fir_filter.process")
+        fn = lib().gr4hip_fir64_process if self._f64 else lib().gr4hip_fir_process
+        check(fn(self._h, x.data_ptr(), x.numel(), out.data_ptr(), None, _stream()), "fir_filter.process")
         return out
 
 
@@ -139,29 +151,38 @@ class iir_filter(_Handle):
     (gr::filter::Filter<float>, FilterTool.hpp:223-247).  b, a: [nsections][n] or 1-D for a single section."""
     _destroy = "gr4hip_iir_destroy"
 
-    def __init__(self, b, a, form: int = capi.DF_II):
+    def __init__(self, b, a, form: int = capi.DF_II, dtype=torch.float32):
         super().__init__()
-        b = np.atleast_2d(np.asarray(b, np.float32))
-        a = np.atleast_2d(np.asarray(a, np.float32))
+        self.dtype = dtype
+        self._f64 = dtype == torch.float64  # iir_filter<double, form> (time_domain_filter.hpp:57-60): csrc/f64.hip
+        npt = np.float64 if self._f64 else np.float32
+        b = np.atleast_2d(np.asarray(b, npt))
+        a = np.atleast_2d(np.asarray(a, npt))
         if b.shape[0] != a.shape[0]:
             raise ValueError("b and a need the same number of sections")
         self.b, self.a, self.form = np.ascontiguousarray(b), np.ascontiguousarray(a), form
+        if self._f64:
+            self._destroy = "gr4hip_iir64_destroy"
+            check(lib().gr4hip_iir64_create(C.byref(self._h), form, b.shape[0], self.b.ctypes.data, b.shape[1], self.a.ctypes.data, a.shape[1]), "iir_filter<float64>")
+            return
         check(lib().gr4hip_iir_create(C.byref(self._h), form, b.shape[0], self.b.ctypes.data, b.shape[1], self.a.ctypes.data, a.shape[1]), "iir_filter")
 
     def reset(self):
-        check(lib().gr4hip_iir_reset(self._h), "iir_filter.reset")
+        check((lib().gr4hip_iir64_reset if self._f64 else lib().gr4hip_iir_reset)(self._h), "iir_filter.reset")
 
     def status(self):
         """synchronise the current stream and raise if an earlier launch of this handle reported a look-back time-out (include/gr4hip.h)"""
-        check(lib().gr4hip_iir_status(self._h, _stream()), "iir_filter.status")
+        if not self._f64:
+            check(lib().gr4hip_iir_status(self._h, _stream()), "iir_filter.status")
 
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "iir_filter")
-        if x.dtype != torch.float32:
-            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "iir_filter", "device path is registered for float32")
+        if x.dtype != self.dtype:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "iir_filter", f"expected {self.dtype}, got {x.dtype}")
         if out is None:
             out = torch.empty_like(x)
-        check(lib().gr4hip_iir_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "iir_filter.process")
+        fn = lib().gr4hip_iir64_process if self._f64 else lib().gr4hip_iir_process
+        check(fn(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "iir_filter.process")
         return out
 
 
@@ -251,9 +272,14 @@ class FFT(_Handle):
         self.fftSize, self.window, self.dtype, self.sample_rate = int(fftSize), window, dtype, sample_rate
         self.outputInDb, self.outputInDeg, self.unwrapPhase = outputInDb, outputInDeg, unwrapPhase
         flags = (capi.FFT_OUTPUT_IN_DB if outputInDb else 0) | (capi.FFT_OUTPUT_IN_DEG if outputInDeg else 0) | (capi.FFT_UNWRAP_PHASE if unwrapPhase else 0)
-        check(lib().gr4hip_fft_create(C.byref(self._h), _DTYPE_ID[dtype], self.fftSize, _window_id(window), flags), "FFT")
+        self._f64 = dtype == torch.float64  # FFT<double> (fourier/fft.hpp:29): real double frames, outputs in double (csrc/f64.hip)
         self.input_chunk_size = self.fftSize  # fft.hpp:131-134
         self.n_out = self.fftSize if dtype == torch.complex64 else self.fftSize // 2
+        if self._f64:
+            self._destroy = "gr4hip_fft64_destroy"
+            check(lib().gr4hip_fft64_create(C.byref(self._h), self.fftSize, _window_id(window), flags), "FFT<float64>")
+            return
+        check(lib().gr4hip_fft_create(C.byref(self._h), _DTYPE_ID[dtype], self.fftSize, _window_id(window), flags), "FFT")
 
     def _frames(self, x):
         x = _dev(x, "FFT")
@@ -263,6 +289,14 @@ class FFT(_Handle):
 
     def process_bulk(self, x: torch.Tensor, ranges: bool = True) -> dict:
         x, frames = self._frames(x)
+        if self._f64:
+            mk64 = lambda: torch.empty((frames, self.n_out), dtype=torch.float64, device=x.device)
+            out = {"magnitude": mk64(), "phase": mk64(), "re": mk64(), "im": mk64()}
+            check(lib().gr4hip_fft64_process(self._h, x.data_ptr(), frames, out["magnitude"].data_ptr(), out["phase"].data_ptr(), out["re"].data_ptr(), out["im"].data_ptr(),
+                                             _stream()), "FFT.process")
+            if ranges:  # fft.hpp:229-232: min / max of the four signals per frame (host-side glue for the float64 corner)
+                out["ranges"] = torch.stack([torch.stack([out[k].amin(dim=1), out[k].amax(dim=1)], dim=1) for k in ("magnitude", "phase", "re", "im")], dim=1)
+            return out
         mk = lambda: torch.empty((frames, self.n_out), dtype=torch.float32, device=x.device)
         out = {"magnitude": mk(), "phase": mk(), "re": mk(), "im": mk()}
         rg = torch.empty((frames, 4, 2), dtype=torch.float32, device=x.device) if ranges else None
@@ -387,10 +421,24 @@ class Rotator(_Handle):
     _destroy = "gr4hip_rotator_destroy"
 
     def __init__(self, phase_increment: Optional[float] = None, frequency_shift: Optional[float] = None, sample_rate: float = 1.0,
-                 initial_phase: float = 0.0, algo: str = "closed_form"):
+                 initial_phase: float = 0.0, algo: str = "closed_form", dtype=torch.complex64):
         super().__init__()
         if phase_increment is not None and frequency_shift is not None:  # Rotator.hpp:45-46 throws
             raise ValueError("cannot set both 'frequency_shift' and 'phase_increment' in new setting (XOR)")
+        self.dtype = dtype
+        self._f64 = dtype == torch.complex128  # Rotator<complex<double>> (Rotator.hpp:15): closed form in float64 (csrc/f64.hip)
+        if self._f64:
+            self._destroy = "gr4hip_rotator64_destroy"
+            self.sample_rate = float(sample_rate)
+            if frequency_shift is not None:
+                self.frequency_shift = float(frequency_shift)
+                self.phase_increment = 2.0 * np.pi * self.frequency_shift / self.sample_rate
+            else:
+                self.phase_increment = float(phase_increment or 0.0)
+                self.frequency_shift = self.phase_increment / (2.0 * np.pi) * self.sample_rate
+            self.initial_phase, self.algo = float(initial_phase), "closed_form"
+            check(lib().gr4hip_rotator64_create(C.byref(self._h), self.phase_increment, self.initial_phase), "Rotator<complex128>")
+            return
         self.sample_rate = np.float32(sample_rate)
         if frequency_shift is not None:  # :41-42 (float arithmetic)
             self.frequency_shift = np.float32(frequency_shift)
@@ -406,19 +454,28 @@ class Rotator(_Handle):
         ids = {"closed_form": capi.ROTATOR_CLOSED_FORM, "recurrence": capi.ROTATOR_RECURRENCE}
         if algo not in ids:
             raise ValueError(f"unknown rotator algo '{algo}'")
+        if self._f64:
+            if algo != "closed_form":
+                raise capi.Gr4HipError(capi.UNSUPPORTED, "Rotator", "the float64 rotator has the closed form only")
+            return
         check(lib().gr4hip_rotator_set_algo(self._h, ids[algo]), "Rotator.set_algo")
         self.algo = algo
 
     def process_bulk(self, x: torch.Tensor) -> torch.Tensor:
         x = _dev(x, "Rotator")
-        if x.dtype != torch.complex64:
-            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Rotator", "device path is complex64")
+        if x.dtype != self.dtype:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Rotator", f"expected {self.dtype}, got {x.dtype}")
         out = torch.empty_like(x)
-        check(lib().gr4hip_rotator_process(self._h, x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "Rotator.process")
+        fn = lib().gr4hip_rotator64_process if self._f64 else lib().gr4hip_rotator_process
+        check(fn(self._h, x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "Rotator.process")
         return out
 
     @property
     def accumulated_phase(self) -> float:
+        if self._f64:
+            d = C.c_double(0)
+            check(lib().gr4hip_rotator64_phase(self._h, C.byref(d)), "Rotator.phase")
+            return d.value
         v = C.c_float(0)
         check(lib().gr4hip_rotator_phase(self._h, C.byref(v), _stream()), "Rotator.phase")
         return v.value

@@ -61,6 +61,23 @@ SIGNATURES = {
     "gr4hip_ring_destroy": (_i, [_vp]),
     "gr4hip_ring_base": (_i, [_vp, _pvp]),
     "gr4hip_ring_size": (_i, [_vp, _psz]),
+    "gr4hip_fir64_create": (_i, [_pvp, _vp, _sz, _sz]),
+    "gr4hip_fir64_set_taps": (_i, [_vp, _vp, _sz]),
+    "gr4hip_fir64_reset": (_i, [_vp]),
+    "gr4hip_fir64_process": (_i, [_vp, _vp, _sz, _vp, _psz, _vp]),
+    "gr4hip_fir64_destroy": (_i, [_vp]),
+    "gr4hip_iir64_create": (_i, [_pvp, _i, _sz, _vp, _sz, _vp, _sz]),
+    "gr4hip_iir64_reset": (_i, [_vp]),
+    "gr4hip_iir64_process": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "gr4hip_iir64_destroy": (_i, [_vp]),
+    "gr4hip_fft64_create": (_i, [_pvp, _sz, _i, _i]),
+    "gr4hip_fft64_process": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "gr4hip_fft64_destroy": (_i, [_vp]),
+    "gr4hip_rotator64_create": (_i, [_pvp, _d, _d]),
+    "gr4hip_rotator64_reset": (_i, [_vp, _d]),
+    "gr4hip_rotator64_process": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "gr4hip_rotator64_phase": (_i, [_vp, C.POINTER(C.c_double)]),
+    "gr4hip_rotator64_destroy": (_i, [_vp]),
     "gr4hip_fir_create": (_i, [_pvp, _i, _vp, _sz, _sz]),
     "gr4hip_fir_set_taps": (_i, [_vp, _vp, _sz]),
     "gr4hip_fir_set_algo": (_i, [_vp, _i]),
@@ -87,6 +104,7 @@ SIGNATURES = {
     "gr4hip_fft_mag2": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "gr4hip_fft_destroy": (_i, [_vp]),
     "gr4hip_window_create": (_i, [_i, _vp, _sz, _f]),
+    "gr4hip_window_create_f64": (_i, [_i, _vp, _sz, _d]),
     "gr4hip_chain_create": (_i, [_pvp, _vp, _sz, _sz, _i, _i]),
     "gr4hip_chain_reset": (_i, [_vp]),
     "gr4hip_chain_process": (_i, [_vp, _vp, _sz, _vp, _psz, _vp]),

@@ -91,5 +91,6 @@ struct DeviceBuffer {
 
 // host-side restatement of gr::algorithm::window::create<float> (algorithm/.../fourier/window.hpp:69-183)
 int make_window(int type, float* w, size_t n, float beta);
+int make_window64(int type, double* w, size_t n, double beta); // create<double>
 
 } // namespace gr4

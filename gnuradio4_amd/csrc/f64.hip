@@ -1,0 +1,596 @@
+// f64.hip -- the float64 instantiations the reference registers for the hot-path blocks: fir_filter<double> and iir_filter<double, form>
+// (blocks/filter/.../time_domain_filter.hpp:20, 57-60), FFT<double> (blocks/fourier/.../fft.hpp:29) and Rotator<complex<double>>
+// (blocks/math/.../Rotator.hpp:15).  north_star is float32; these are the second registered type of each block, so that a graph that asks for it keeps
+// running on the device.  Plain FP64 vector code (78 TFLOP/s peak), one straightforward kernel per block -- not the tuned float32 paths:
+//   FIR        direct form, segment + history staged in LDS as doubles, R outputs per lane from a strided window
+//   IIR        exact parallel-in-time in three passes (per-tile zero-state chunk runs + in-tile scan, one sequential walk over the tile states,
+//              re-run from the true start states); every matrix power is host-precomputed in float64
+//   FFT        real frames: window, in-place radix-2 passes in LDS (power-of-two N <= 8192), the block's outputs in double
+//   Rotator    closed-form phase per sample (the float64 oracle's definition up to the rounding of the accumulated sum)
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace gr4 {
+
+// ------------------------------------------------------------------------------------------------ FIR
+constexpr int kF64BS = 256;
+
+// y[m] = sum_k b[k] x[m D - k], m < n_out; xin = x with the hcap samples of history in front (virtual index -hcap .. -1 from hist).
+// A lane owns R outputs 256 apart (lane-consecutive LDS reads) and walks the taps once for all of them: one broadcast tap read per R multiply-adds
+template <int R>
+__global__ __launch_bounds__(kF64BS) void fir64_kernel(const double* __restrict__ x, const double* __restrict__ hist, int hcap, const double* __restrict__ taps, int K, int D,
+                                                       double* __restrict__ y, long n_out, long n_in) {
+    extern __shared__ double smem64[];
+    double*    tl  = smem64;      // [K]
+    double*    xs  = smem64 + K;  // [(BS R - 1) D + K]: samples (o0 D - (K - 1)) ..
+    const long o0  = (long)blockIdx.x * kF64BS * R;
+    const int  len = (kF64BS * R - 1) * D + K;
+    const long i0  = o0 * D - (K - 1);
+    for (int i = threadIdx.x; i < K; i += kF64BS) tl[i] = taps[i];
+    for (int i = threadIdx.x; i < len; i += kF64BS) {
+        const long g = i0 + i;
+        xs[i]        = g >= 0 ? (g < n_in ? x[g] : 0.0) : (g >= -(long)hcap ? hist[hcap + g] : 0.0);
+    }
+    __syncthreads();
+    const double* w[R];
+    double        acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        w[r]   = xs + (long)(r * kF64BS + threadIdx.x) * D + (K - 1);
+        acc[r] = 0.0;
+    }
+    for (int k = 0; k < K; ++k) {
+        const double t = tl[k];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fma(t, w[r][-k], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long o = o0 + (long)r * kF64BS + threadIdx.x;
+        if (o < n_out) y[o] = acc[r];
+    }
+}
+
+// new_hist[h] = virtual sample n_in - hcap + h of (old_hist ++ x)
+__global__ void hist64_kernel(const double* __restrict__ x, const double* __restrict__ old_hist, double* __restrict__ new_hist, long n_in, int hcap) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= hcap) return;
+    const long g = n_in - hcap + h;
+    new_hist[h]  = g >= 0 ? x[g] : old_hist[hcap + g];
+}
+
+// ------------------------------------------------------------------------------------------------ IIR
+constexpr int kI64L  = 32;  // samples per lane chunk
+constexpr int kI64BS = 256; // chunks per tile
+constexpr int kI64MP = 8;   // state dimension the kernels are built for (up to 4 biquads, or one section of order <= 8)
+
+struct Iir64Desc {
+    int    nsec, ord;              // sections of order `ord` (state: ord values per section, direct form II)
+    double b[kI64MP / 1][9];       // [section][ord + 1]   (at most 8 sections of order 1)
+    double a[kI64MP / 1][9];
+};
+
+// one sample through the cascade (computeFilter, time_domain_filter.hpp / FilterTool.hpp DF-II): s = [section][ord] delay lines.  The section count and
+// order are template parameters: every loop unrolls and the state stays in registers (as run-time loops the state arrays lived in scratch memory: 8x slower)
+template <int NSEC, int ORD>
+__device__ __forceinline__ double iir64_step(const Iir64Desc& d, double (&s)[NSEC * ORD], double x) {
+#pragma unroll
+    for (int c = 0; c < NSEC; ++c) {
+        double w = x;
+#pragma unroll
+        for (int k = 1; k <= ORD; ++k) w = fma(-d.a[c][k], s[c * ORD + k - 1], w);
+        double yv = d.b[c][0] * w;
+#pragma unroll
+        for (int k = 1; k <= ORD; ++k) yv = fma(d.b[c][k], s[c * ORD + k - 1], yv);
+#pragma unroll
+        for (int k = ORD - 1; k > 0; --k) s[c * ORD + k] = s[c * ORD + k - 1];
+        s[c * ORD] = w;
+        x          = yv;
+    }
+    return x;
+}
+template <int MP>
+__device__ __forceinline__ void matvec64(const double* __restrict__ M, const double (&v)[MP], double (&out)[MP]) { // out = M v (row-major MP x MP)
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < MP; ++j) acc = fma(M[i * MP + j], v[j], acc);
+        out[i] = acc;
+    }
+}
+
+// pass Z: per tile of 256 chunks: zero-state end state of every chunk, inclusive scan over the chunks (P_l = state at the end of chunk l when the tile
+// starts from zero), all P_l to scratch, the tile's own end state Z_t = P_255
+template <int NSEC, int ORD>
+__global__ __launch_bounds__(kI64BS) void iir64_pass_z(Iir64Desc d, const double* __restrict__ x, long n, const double* __restrict__ phiPow /*[8][MP][MP]: Phi_L^(2^k)*/,
+                                                       double* __restrict__ P /*[tiles][256][MP]*/, double* __restrict__ Z /*[tiles][MP]*/) {
+    constexpr int MP = NSEC * ORD;
+    __shared__ double sc[2][MP][kI64BS]; // lane-contiguous
+    const long tile = blockIdx.x;
+    const int  l    = threadIdx.x;
+    const long i0   = (tile * kI64BS + l) * kI64L;
+    double     s[MP];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) s[i] = 0.0;
+    if (i0 + kI64L <= n) {
+#pragma unroll 8
+        for (int i = 0; i < kI64L; ++i) (void)iir64_step<NSEC, ORD>(d, s, x[i0 + i]);
+    } else {
+        for (int i = 0; i < kI64L; ++i) (void)iir64_step<NSEC, ORD>(d, s, i0 + i < n ? x[i0 + i] : 0.0); // (padding the last tile with zeros only moves states nobody reads)
+    }
+    int cur = 0;
+#pragma unroll
+    for (int i = 0; i < MP; ++i) sc[0][i][l] = s[i];
+    __syncthreads();
+    for (int k = 0, off = 1; off < kI64BS; ++k, off <<= 1) { // Hillis-Steele: P_l <- Phi_L^off P_{l - off} + P_l
+        double v[MP];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) v[i] = sc[cur][i][l];
+        if (l >= off) {
+            double u[MP], t[MP];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) u[i] = sc[cur][i][l - off];
+            matvec64<MP>(phiPow + (long)k * MP * MP, u, t);
+#pragma unroll
+            for (int i = 0; i < MP; ++i) v[i] += t[i];
+        }
+#pragma unroll
+        for (int i = 0; i < MP; ++i) sc[cur ^ 1][i][l] = v[i];
+        cur ^= 1;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MP; ++i) P[(tile * kI64BS + l) * MP + i] = sc[cur][i][l];
+    if (l == kI64BS - 1) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i) Z[tile * MP + i] = sc[cur][i][l];
+    }
+}
+
+// pass B: the tiles in order, T_{t+1} = Phi_B T_t + Z_t; T_0 = the carried state.  One lane walks the dependent chain; the workgroup stages the Z_t of
+// 256 tiles at a time in LDS so that the walker never waits for global memory
+template <int MP>
+__global__ __launch_bounds__(256) void iir64_pass_b(const double* __restrict__ phiB, const double* __restrict__ Z, long tiles, const double* __restrict__ state0, double* __restrict__ T /*[tiles][MP]*/) {
+    constexpr int    kStage = 256;
+    __shared__ double zs[kStage * MP], ts[kStage * MP], M[MP * MP], carry[MP];
+    for (int i = threadIdx.x; i < MP * MP; i += 256) M[i] = phiB[i];
+    if (threadIdx.x < MP) carry[threadIdx.x] = state0[threadIdx.x];
+    for (long t0 = 0; t0 < tiles; t0 += kStage) {
+        const int cnt = (int)(tiles - t0 < kStage ? tiles - t0 : kStage);
+        for (int i = threadIdx.x; i < cnt * MP; i += 256) zs[i] = Z[t0 * MP + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s[MP], t[MP];
+#pragma unroll
+            for (int i = 0; i < MP; ++i) s[i] = carry[i];
+            for (int c = 0; c < cnt; ++c) {
+#pragma unroll
+                for (int i = 0; i < MP; ++i) ts[c * MP + i] = s[i];
+                matvec64<MP>(M, s, t);
+#pragma unroll
+                for (int i = 0; i < MP; ++i) s[i] = t[i] + zs[c * MP + i];
+            }
+#pragma unroll
+            for (int i = 0; i < MP; ++i) carry[i] = s[i];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt * MP; i += 256) T[t0 * MP + i] = ts[i];
+        __syncthreads();
+    }
+}
+
+// pass Y: chunk l of tile t starts from P_{l-1} + Phi_L^l T_t; re-run, write y; the lane that holds the last sample of the span writes the state after it
+template <int NSEC, int ORD>
+__global__ __launch_bounds__(kI64BS) void iir64_pass_y(Iir64Desc d, const double* __restrict__ x, long n, const double* __restrict__ phiL /*[256][MP][MP]: Phi_L^l*/,
+                                                       const double* __restrict__ P, const double* __restrict__ T, double* __restrict__ y, double* __restrict__ state_out) {
+    constexpr int MP = NSEC * ORD;
+    const long tile = blockIdx.x;
+    const int  l    = threadIdx.x;
+    const long i0   = (tile * kI64BS + l) * kI64L;
+    if (i0 >= n) return;
+    double s[MP], tt[MP], t0[MP];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) t0[i] = T[tile * MP + i];
+    matvec64<MP>(phiL + (long)l * MP * MP, t0, tt);
+#pragma unroll
+    for (int i = 0; i < MP; ++i) s[i] = tt[i] + (l > 0 ? P[(tile * kI64BS + l - 1) * MP + i] : 0.0);
+    if (i0 + kI64L <= n) {
+#pragma unroll 8
+        for (int i = 0; i < kI64L; ++i) y[i0 + i] = iir64_step<NSEC, ORD>(d, s, x[i0 + i]);
+    } else {
+        for (int i = 0; i < kI64L && i0 + i < n; ++i) y[i0 + i] = iir64_step<NSEC, ORD>(d, s, x[i0 + i]);
+    }
+    if (i0 + kI64L >= n) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i) state_out[i] = s[i];
+    }
+}
+
+// the three passes for one (section count, order) shape
+template <int NSEC, int ORD>
+static int iir64_run(const Iir64Desc& d, const double* x, long n, long tiles, const double* phiPow, const double* phiL, const double* phiB, const double* state_in, double* state_out, double* P,
+                     double* Z, double* T, double* y, hipStream_t st) {
+    hipLaunchKernelGGL((iir64_pass_z<NSEC, ORD>), dim3((unsigned)tiles), dim3(kI64BS), 0, st, d, x, n, phiPow, P, Z);
+    GR4_LAUNCH_CHECK();
+    hipLaunchKernelGGL((iir64_pass_b<NSEC * ORD>), dim3(1), dim3(256), 0, st, phiB, (const double*)Z, tiles, state_in, T);
+    GR4_LAUNCH_CHECK();
+    hipLaunchKernelGGL((iir64_pass_y<NSEC, ORD>), dim3((unsigned)tiles), dim3(kI64BS), 0, st, d, x, n, phiL, (const double*)P, (const double*)T, y, state_out);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ FFT (real double frames)
+struct Fft64Out {
+    double *mag, *phase, *re, *im;
+    int     in_db, in_deg, unwrap;
+};
+// one workgroup per frame: x w -> complex points in LDS (bit-reversed), in-place radix-2 passes, outputs as FFT<T>::processBulk
+// for real input (fft.hpp:147-171, 221-227: magnitude / phase of bins 0 .. N/2-1, Re / Im of bins N/2 .. N-1)
+__global__ __launch_bounds__(256) void fft64_kernel(const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw /*[N/2]: W_N^j*/, int log2n, long n_frames,
+                                                    Fft64Out o) {
+    extern __shared__ double2 sm2[];
+    const int  N = 1 << log2n, half = N >> 1;
+    double2*   A = sm2; // the whole frame as complex points, in place: 8192 x 16 B = 128 KiB
+    const long f = blockIdx.x;
+    for (int i = threadIdx.x; i < N; i += 256) { // bit-reversed load, then in-place decimation-in-time butterflies
+        const double v                      = x[f * N + i] * (win ? win[i] : 1.0);
+        A[__brev((unsigned)i) >> (32 - log2n)] = make_double2(v, 0.0);
+    }
+    __syncthreads();
+    for (int s = 1, hm = 1; s <= log2n; ++s, hm <<= 1) { // hm = half the butterfly span of this pass
+        for (int j = threadIdx.x; j < half; j += 256) {
+            const int     k    = j & (hm - 1);
+            const int     base = ((j - k) << 1) + k;
+            const double2 w    = tw[k * (half / hm)]; // W_{2 hm}^k
+            const double2 u    = A[base], b = A[base + hm];
+            const double2 t    = make_double2(fma(b.x, w.x, -b.y * w.y), fma(b.x, w.y, b.y * w.x));
+            A[base]            = make_double2(u.x + t.x, u.y + t.y);
+            A[base + hm]       = make_double2(u.x - t.x, u.y - t.y);
+        }
+        __syncthreads();
+    }
+    const double pi = 3.14159265358979323846;
+    for (int k = threadIdx.x; k < half; k += 256) {
+        const double2 X = A[k], Xh = A[k + half];
+        if (o.re) o.re[f * half + k] = Xh.x;
+        if (o.im) o.im[f * half + k] = Xh.y;
+        if (o.mag) {
+            double m = hypot(X.x, X.y) * 2.0 / (double)N;
+            if (o.in_db) m = m > 0.0 ? 20.0 * log10(m) : -1.7976931348623157e308;
+            o.mag[f * half + k] = m;
+        }
+        if (o.phase) {
+            double ph = atan2(X.y, X.x);
+            if (o.in_deg && !o.unwrap) ph = ph * 180.0 / pi;
+            o.phase[f * half + k] = ph;
+        }
+    }
+    if (o.phase && o.unwrap) { // fft_common.hpp:71-89 unwrapPhase: sequential over the half spectrum (one lane; the frame's phases are in global memory)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* ph   = o.phase + f * half;
+            double  corr = 0.0, prev = ph[0];
+            for (int k = 1; k < half; ++k) {
+                const double raw = ph[k], diff = raw - prev;
+                if (diff > pi) corr -= 2.0 * pi;
+                else if (diff < -pi) corr += 2.0 * pi;
+                prev  = raw;
+                ph[k] = raw + corr;
+            }
+            if (o.in_deg)
+                for (int k = 0; k < half; ++k) ph[k] = ph[k] * 180.0 / pi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Rotator<complex<double>>
+// y[i] = x[i] e^{i (phase0 + (i + 1) inc)} (Rotator.hpp:51-61 with the accumulated phase in closed form); the index is split so that both products are exact
+__global__ __launch_bounds__(256) void rotator64_kernel(const double2* __restrict__ x, double2* __restrict__ y, long n, double phase0, double inc) {
+    const double two_pi = 6.283185307179586476925286766559;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long   k  = i + 1;
+        const double hi = (double)(k >> 20) * 1048576.0, lo = (double)(k & 1048575);
+        double       ph = fma(hi, inc, phase0);
+        ph              = ph - two_pi * floor(ph / two_pi);
+        ph              = fma(lo, inc, ph);
+        double s, c;
+        sincos(ph, &s, &c);
+        const double2 v = x[i];
+        y[i]            = make_double2(fma(v.x, c, -v.y * s), fma(v.x, s, v.y * c));
+    }
+}
+
+} // namespace gr4
+
+using namespace gr4;
+
+// ================================================================================================ handles
+struct gr4hip_fir64 {
+    std::vector<double> taps;
+    size_t              decim = 1, hcap = 32;
+    DeviceBuffer        d_taps, d_hist[2];
+    int                 cur = 0;
+};
+struct gr4hip_iir64 {
+    Iir64Desc    d{};
+    int          mp = 0;
+    DeviceBuffer d_phiPow, d_phiL, d_phiB, d_state[2], d_P, d_Z, d_T;
+    int          cur = 0;
+};
+struct gr4hip_fft64 {
+    size_t       N = 0;
+    int          log2n = 0, flags = 0;
+    DeviceBuffer d_win, d_tw;
+    bool         windowed = false;
+};
+struct gr4hip_rotator64 {
+    double inc = 0.0, phase = 0.0, initial = 0.0;
+};
+
+static size_t bit_ceil_sz(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
+
+static int fir64_upload(gr4hip_fir64* f, const double* taps, size_t ntaps, bool keep_history) {
+    const size_t hcap = std::max<size_t>(32, bit_ceil_sz(ntaps)); // HistoryBuffer{32}, grown by settingsChanged (time_domain_filter.hpp:36-42)
+    int          rc   = f->d_taps.ensure(ntaps * sizeof(double));
+    if (rc) return rc;
+    GR4_HIP_TRY(hipMemcpy(f->d_taps.ptr, taps, ntaps * sizeof(double), hipMemcpyHostToDevice));
+    if (!keep_history || hcap != f->hcap || !f->d_hist[0].ptr) { // a history that has to grow starts empty, as upstream's replaced HistoryBuffer does
+        for (auto& h : f->d_hist) {
+            rc = h.ensure(hcap * sizeof(double));
+            if (rc) return rc;
+            GR4_HIP_TRY(hipMemset(h.ptr, 0, hcap * sizeof(double)));
+        }
+        f->cur = 0;
+    }
+    f->hcap = hcap;
+    f->taps.assign(taps, taps + ntaps);
+    return GR4HIP_OK;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------- fir_filter<double>
+int gr4hip_fir64_create(gr4hip_fir64_t** out, const double* h_taps, size_t ntaps, size_t decim) {
+    GR4_REQUIRE(out && h_taps && ntaps >= 1, "fir64: taps required");
+    GR4_REQUIRE(decim >= 1, "fir64: decim must be >= 1");
+    if (ntaps > 2048 || decim > 32) { set_error("fir64: ntaps=%zu decim=%zu is outside the float64 kernel (<= 2048 taps, decim <= 32)", ntaps, decim); return GR4HIP_UNSUPPORTED; }
+    auto* f = new (std::nothrow) gr4hip_fir64();
+    GR4_REQUIRE(f, "out of host memory");
+    f->decim = decim;
+    int rc   = fir64_upload(f, h_taps, ntaps, false);
+    if (rc) { delete f; return rc; }
+    *out = f;
+    return GR4HIP_OK;
+}
+int gr4hip_fir64_set_taps(gr4hip_fir64_t* f, const double* h_taps, size_t ntaps) {
+    GR4_REQUIRE(f && h_taps && ntaps >= 1, "fir64_set_taps: taps required");
+    if (ntaps > 2048) { set_error("fir64: ntaps=%zu is outside the float64 kernel", ntaps); return GR4HIP_UNSUPPORTED; }
+    return fir64_upload(f, h_taps, ntaps, true);
+}
+int gr4hip_fir64_reset(gr4hip_fir64_t* f) {
+    GR4_REQUIRE(f, "fir64_reset: null handle");
+    for (auto& h : f->d_hist) GR4_HIP_TRY(hipMemset(h.ptr, 0, f->hcap * sizeof(double)));
+    return GR4HIP_OK;
+}
+int gr4hip_fir64_process(gr4hip_fir64_t* f, const double* d_in, size_t n_in, double* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
+    GR4_REQUIRE(f, "fir64_process: null handle");
+    GR4_REQUIRE(n_in % f->decim == 0, "fir64_process: n_in=%zu is not a multiple of decim=%zu", n_in, f->decim);
+    const size_t n_out = n_in / f->decim;
+    if (n_out_p) *n_out_p = n_out;
+    if (n_in == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out, "fir64_process: null device pointer");
+    hipStream_t st = as_stream(stream);
+    const int   K = (int)f->taps.size(), D = (int)f->decim;
+    const int   R = D <= 8 ? 4 : D <= 16 ? 2 : 1;
+    const size_t lds = ((size_t)K + (size_t)(kF64BS * R - 1) * D + K) * sizeof(double);
+    const auto  kern = R == 4 ? fir64_kernel<4> : R == 2 ? fir64_kernel<2> : fir64_kernel<1>;
+    if (lds > 64 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)ceil_div(n_out, (size_t)kF64BS * R);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kF64BS), lds, st, d_in, (const double*)f->d_hist[f->cur].ptr, (int)f->hcap, (const double*)f->d_taps.ptr, K, D, d_out, (long)n_out, (long)n_in);
+    GR4_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hist64_kernel, dim3((unsigned)ceil_div(f->hcap, (size_t)256)), dim3(256), 0, st, d_in, (const double*)f->d_hist[f->cur].ptr, (double*)f->d_hist[f->cur ^ 1].ptr,
+                       (long)n_in, (int)f->hcap);
+    GR4_LAUNCH_CHECK();
+    f->cur ^= 1;
+    return GR4HIP_OK;
+}
+int gr4hip_fir64_destroy(gr4hip_fir64_t* f) { delete f; return GR4HIP_OK; }
+
+// ---------------------------------------------------------------- iir_filter<double, form>
+int gr4hip_iir64_create(gr4hip_iir64_t** out, int form, size_t nsections, const double* h_b, size_t nb, const double* h_a, size_t na) {
+    GR4_REQUIRE(out && h_b && h_a && nsections >= 1, "iir64: coefficients required");
+    GR4_REQUIRE(form >= 0 && form <= 3, "iir64: unknown form %d", form); // all four forms realise the same transfer function; evaluated as DF-II (like the float kernels)
+    GR4_REQUIRE(nb >= 1 && na >= 1, "iir64: empty coefficient rows");
+    const size_t ord = std::max(nb, na) - 1;
+    if (ord == 0 || ord > 8 || nsections * ord > (size_t)kI64MP) {
+        set_error("iir64: %zu sections of order %zu: the float64 kernels hold up to %d state values (4 biquads, or one section of order <= 8)", nsections, ord, kI64MP);
+        return GR4HIP_UNSUPPORTED;
+    }
+    auto* f = new (std::nothrow) gr4hip_iir64();
+    GR4_REQUIRE(f, "out of host memory");
+    f->d.nsec = (int)nsections;
+    f->d.ord  = (int)ord;
+    for (size_t c = 0; c < nsections; ++c) {
+        const double a0 = h_a[c * na];
+        if (a0 == 0.0) { delete f; set_error("iir64: a[0] = 0 in section %zu", c); return GR4HIP_INVALID_ARGUMENT; }
+        for (size_t k = 0; k <= ord; ++k) { // normalised by a[0] (FilterTool.hpp Section)
+            f->d.b[c][k] = k < nb ? h_b[c * nb + k] / a0 : 0.0;
+            f->d.a[c][k] = k < na ? h_a[c * na + k] / a0 : 0.0;
+        }
+    }
+    const int mp = f->mp = (int)(nsections * ord);
+    // Phi_L: the zero-input state transition over L samples, column j = the state after L steps from the unit state e_j (host restatement of iir64_step)
+    auto step = [&](std::vector<double>& s, double x) {
+        for (int c = 0; c < f->d.nsec; ++c) {
+            double* sc = s.data() + c * f->d.ord;
+            double  w  = x;
+            for (int k = 1; k <= f->d.ord; ++k) w -= f->d.a[c][k] * sc[k - 1];
+            double yv = f->d.b[c][0] * w;
+            for (int k = 1; k <= f->d.ord; ++k) yv += f->d.b[c][k] * sc[k - 1];
+            for (int k = f->d.ord - 1; k > 0; --k) sc[k] = sc[k - 1];
+            sc[0] = w;
+            x     = yv;
+        }
+    };
+    std::vector<long double> PL((size_t)mp * mp);
+    for (int j = 0; j < mp; ++j) {
+        std::vector<double> s(mp, 0.0);
+        s[j] = 1.0;
+        for (int i = 0; i < kI64L; ++i) step(s, 0.0);
+        for (int i = 0; i < mp; ++i) PL[(size_t)i * mp + j] = s[i];
+    }
+    auto mul = [mp](const std::vector<long double>& A, const std::vector<long double>& B) {
+        std::vector<long double> C((size_t)mp * mp, 0.0L);
+        for (int i = 0; i < mp; ++i)
+            for (int k = 0; k < mp; ++k)
+                for (int j = 0; j < mp; ++j) C[(size_t)i * mp + j] += A[(size_t)i * mp + k] * B[(size_t)k * mp + j];
+        return C;
+    };
+    std::vector<double> pow2((size_t)8 * mp * mp), powl((size_t)kI64BS * mp * mp), phiB((size_t)mp * mp);
+    {
+        std::vector<long double> M = PL;
+        for (int k = 0; k < 8; ++k) { // Phi_L^(2^k)
+            for (size_t i = 0; i < M.size(); ++i) pow2[(size_t)k * mp * mp + i] = (double)M[i];
+            M = mul(M, M);
+        }
+        for (size_t i = 0; i < M.size(); ++i) phiB[i] = (double)M[i]; // Phi_L^256 = one tile
+        std::vector<long double> Q((size_t)mp * mp, 0.0L);
+        for (int i = 0; i < mp; ++i) Q[(size_t)i * mp + i] = 1.0L;
+        for (int l = 0; l < kI64BS; ++l) { // Phi_L^l
+            for (size_t i = 0; i < Q.size(); ++i) powl[(size_t)l * mp * mp + i] = (double)Q[i];
+            Q = mul(Q, PL);
+        }
+    }
+    int rc = f->d_phiPow.ensure(pow2.size() * sizeof(double));
+    if (!rc) rc = f->d_phiL.ensure(powl.size() * sizeof(double));
+    if (!rc) rc = f->d_phiB.ensure(phiB.size() * sizeof(double));
+    for (auto& s : f->d_state)
+        if (!rc) rc = s.ensure(kI64MP * sizeof(double));
+    if (rc) { delete f; return rc; }
+    hipError_t e = hipMemcpy(f->d_phiPow.ptr, pow2.data(), pow2.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(f->d_phiL.ptr, powl.data(), powl.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(f->d_phiB.ptr, phiB.data(), phiB.size() * sizeof(double), hipMemcpyHostToDevice);
+    for (auto& s : f->d_state)
+        if (e == hipSuccess) e = hipMemset(s.ptr, 0, kI64MP * sizeof(double));
+    if (e != hipSuccess) { delete f; set_error("iir64: upload failed: %s", hipGetErrorString(e)); return GR4HIP_RUNTIME_ERROR; }
+    *out = f;
+    return GR4HIP_OK;
+}
+int gr4hip_iir64_reset(gr4hip_iir64_t* f) {
+    GR4_REQUIRE(f, "iir64_reset: null handle");
+    for (auto& s : f->d_state) GR4_HIP_TRY(hipMemset(s.ptr, 0, kI64MP * sizeof(double)));
+    return GR4HIP_OK;
+}
+int gr4hip_iir64_process(gr4hip_iir64_t* f, const double* d_in, size_t n, double* d_out, gr4hip_stream_t stream) {
+    GR4_REQUIRE(f, "iir64_process: null handle");
+    if (n == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out, "iir64_process: null device pointer");
+    hipStream_t st    = as_stream(stream);
+    const long  tiles = (long)ceil_div(n, (size_t)kI64BS * kI64L);
+    const int   mp    = f->mp;
+    int         rc    = f->d_P.ensure((size_t)tiles * kI64BS * mp * sizeof(double));
+    if (!rc) rc = f->d_Z.ensure((size_t)tiles * mp * sizeof(double));
+    if (!rc) rc = f->d_T.ensure((size_t)tiles * mp * sizeof(double));
+    if (rc) return rc;
+    const double *pp = (const double*)f->d_phiPow.ptr, *pl = (const double*)f->d_phiL.ptr, *pb = (const double*)f->d_phiB.ptr, *s_in = (const double*)f->d_state[f->cur].ptr;
+    double *     s_out = (double*)f->d_state[f->cur ^ 1].ptr, *P = (double*)f->d_P.ptr, *Z = (double*)f->d_Z.ptr, *T = (double*)f->d_T.ptr;
+#define GR4_IIR64_CASE(NS, OR) \
+    if (f->d.nsec == NS && f->d.ord == OR) rc = iir64_run<NS, OR>(f->d, d_in, (long)n, tiles, pp, pl, pb, s_in, s_out, P, Z, T, d_out, st); else
+    GR4_IIR64_CASE(1, 1) GR4_IIR64_CASE(2, 1) GR4_IIR64_CASE(3, 1) GR4_IIR64_CASE(4, 1) GR4_IIR64_CASE(5, 1) GR4_IIR64_CASE(6, 1) GR4_IIR64_CASE(7, 1) GR4_IIR64_CASE(8, 1)
+    GR4_IIR64_CASE(1, 2) GR4_IIR64_CASE(2, 2) GR4_IIR64_CASE(3, 2) GR4_IIR64_CASE(4, 2) GR4_IIR64_CASE(1, 3) GR4_IIR64_CASE(2, 3) GR4_IIR64_CASE(1, 4) GR4_IIR64_CASE(2, 4)
+    GR4_IIR64_CASE(1, 5) GR4_IIR64_CASE(1, 6) GR4_IIR64_CASE(1, 7) GR4_IIR64_CASE(1, 8)
+    { set_error("iir64: no kernel for %d sections of order %d", f->d.nsec, f->d.ord); rc = GR4HIP_UNSUPPORTED; }
+#undef GR4_IIR64_CASE
+    if (rc) return rc;
+    f->cur ^= 1;
+    return GR4HIP_OK;
+}
+int gr4hip_iir64_destroy(gr4hip_iir64_t* f) { delete f; return GR4HIP_OK; }
+
+// ---------------------------------------------------------------- FFT<double>
+int gr4hip_fft64_create(gr4hip_fft64_t** out, size_t fft_size, int window, int flags) {
+    GR4_REQUIRE(out, "fft64: null output handle");
+    GR4_REQUIRE(window >= GR4HIP_WIN_NONE && window <= GR4HIP_WIN_KAISER, "fft64: unknown window %d", window);
+    if (!is_pow2(fft_size) || fft_size < 2 || fft_size > 8192) {
+        set_error("fft64: size %zu is outside the float64 kernel (powers of two 2 .. 8192)", fft_size);
+        return GR4HIP_UNSUPPORTED;
+    }
+    auto* f = new (std::nothrow) gr4hip_fft64();
+    GR4_REQUIRE(f, "out of host memory");
+    f->N     = fft_size;
+    f->log2n = ilog2(fft_size);
+    f->flags = flags;
+    std::vector<double> tw(fft_size); // W_N^j, j < N/2, interleaved
+    for (size_t j = 0; j < fft_size / 2; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)fft_size;
+        tw[2 * j]     = std::cos(a);
+        tw[2 * j + 1] = std::sin(a);
+    }
+    int rc = f->d_tw.ensure(std::max<size_t>(tw.size(), 2) * sizeof(double));
+    if (!rc && window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR) {
+        std::vector<double> w(fft_size);
+        rc = make_window64(window, w.data(), fft_size, 1.6);
+        if (!rc) rc = f->d_win.ensure(fft_size * sizeof(double));
+        if (!rc && hipMemcpy(f->d_win.ptr, w.data(), fft_size * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("fft64: window upload failed"); rc = GR4HIP_RUNTIME_ERROR; }
+        f->windowed = true;
+    }
+    if (!rc && hipMemcpy(f->d_tw.ptr, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("fft64: twiddle upload failed"); rc = GR4HIP_RUNTIME_ERROR; }
+    if (rc) { delete f; return rc; }
+    *out = f;
+    return GR4HIP_OK;
+}
+int gr4hip_fft64_process(gr4hip_fft64_t* f, const double* d_in, size_t n_frames, double* d_mag, double* d_phase, double* d_re, double* d_im, gr4hip_stream_t stream) {
+    GR4_REQUIRE(f, "fft64_process: null handle");
+    if (n_frames == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in, "fft64_process: null input");
+    hipStream_t  st  = as_stream(stream);
+    const size_t lds = f->N * sizeof(double2);
+    if (lds > 64 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fft64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Fft64Out o{d_mag, d_phase, d_re, d_im, (f->flags & GR4HIP_FFT_OUTPUT_IN_DB) != 0, (f->flags & GR4HIP_FFT_OUTPUT_IN_DEG) != 0, (f->flags & GR4HIP_FFT_UNWRAP_PHASE) != 0};
+    hipLaunchKernelGGL(fft64_kernel, dim3((unsigned)n_frames), dim3(256), lds, st, d_in, f->windowed ? (const double*)f->d_win.ptr : nullptr, (const double2*)f->d_tw.ptr, f->log2n,
+                       (long)n_frames, o);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+int gr4hip_fft64_destroy(gr4hip_fft64_t* f) { delete f; return GR4HIP_OK; }
+
+// ---------------------------------------------------------------- Rotator<complex<double>>
+int gr4hip_rotator64_create(gr4hip_rotator64_t** out, double phase_increment, double initial_phase) {
+    GR4_REQUIRE(out, "rotator64: null output handle");
+    auto* r = new (std::nothrow) gr4hip_rotator64();
+    GR4_REQUIRE(r, "out of host memory");
+    r->inc = phase_increment;
+    r->phase = r->initial = initial_phase;
+    *out = r;
+    return GR4HIP_OK;
+}
+int gr4hip_rotator64_reset(gr4hip_rotator64_t* r, double initial_phase) {
+    GR4_REQUIRE(r, "rotator64_reset: null handle");
+    r->phase = r->initial = initial_phase;
+    return GR4HIP_OK;
+}
+int gr4hip_rotator64_process(gr4hip_rotator64_t* r, const void* d_in_c64, void* d_out_c64, size_t n, gr4hip_stream_t stream) {
+    GR4_REQUIRE(r, "rotator64_process: null handle");
+    if (n == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in_c64 && d_out_c64, "rotator64_process: null device pointer");
+    const unsigned grid = (unsigned)std::min<size_t>(ceil_div(n, (size_t)256), 1u << 16);
+    hipLaunchKernelGGL(rotator64_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const double2*)d_in_c64, (double2*)d_out_c64, (long)n, r->phase, r->inc);
+    GR4_LAUNCH_CHECK();
+    const double two_pi = 6.283185307179586476925286766559;
+    double       ph     = std::fma((double)n, r->inc, r->phase); // the accumulated phase after n samples, kept in [0, 2 pi) like the block's wrap (Rotator.hpp:55-60)
+    ph -= two_pi * std::floor(ph / two_pi);
+    r->phase = ph;
+    return GR4HIP_OK;
+}
+int gr4hip_rotator64_phase(gr4hip_rotator64_t* r, double* phase) {
+    GR4_REQUIRE(r && phase, "rotator64_phase: null argument");
+    *phase = r->phase;
+    return GR4HIP_OK;
+}
+int gr4hip_rotator64_destroy(gr4hip_rotator64_t* r) { delete r; return GR4HIP_OK; }
+
+} // extern "C"

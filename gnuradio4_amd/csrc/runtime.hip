@@ -15,22 +15,23 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static float bessel_i0f(float x) { // window.hpp:42-56
-    float sum = 1, term = 1;
-    int   k = 1;
-    const float x_half = x / 2;
+template <typename T>
+static T bessel_i0f(T x) { // window.hpp:42-56
+    T       sum = 1, term = 1;
+    int     k = 1;
+    const T x_half = x / 2;
     do {
-        term *= (x_half / static_cast<float>(k));
+        term *= (x_half / static_cast<T>(k));
         sum += term * term;
         ++k;
-    } while (term * term > sum * std::numeric_limits<float>::epsilon());
+    } while (term * term > sum * std::numeric_limits<T>::epsilon());
     return sum;
 }
 
-int make_window(int type, float* w, size_t n, float beta) {
-    using T = float;
+template <typename T>
+static int make_window_t(int type, T* w, size_t n, T beta) { // gr::algorithm::window::create<T> (window.hpp:69-183), T = float | double
     if (n == 0) return GR4HIP_OK; // window.hpp:72-74
-    const T pi2 = 2 * 3.14159265358979323846f;
+    const T pi2 = 2 * static_cast<T>(3.14159265358979323846);
     const T a   = pi2 / static_cast<T>(n - 1);
     auto    fill = [&](auto&& f) { for (size_t i = 0; i < n; ++i) w[i] = f(i); };
     switch (type) {
@@ -55,6 +56,8 @@ int make_window(int type, float* w, size_t n, float beta) {
     }
     return GR4HIP_OK;
 }
+int make_window(int type, float* w, size_t n, float beta) { return make_window_t<float>(type, w, n, beta); }
+int make_window64(int type, double* w, size_t n, double beta) { return make_window_t<double>(type, w, n, beta); }
 
 } // namespace gr4
 
@@ -195,6 +198,10 @@ int gr4hip_ring_size(const gr4hip_ring_t* r, size_t* bytes) { GR4_REQUIRE(r && b
 int gr4hip_window_create(int window, float* h_out, size_t n, float beta) {
     GR4_REQUIRE(h_out || n == 0, "window: null output");
     return make_window(window, h_out, n, beta);
+}
+int gr4hip_window_create_f64(int window, double* h_out, size_t n, double beta) {
+    GR4_REQUIRE(h_out || n == 0, "window: null output");
+    return make_window64(window, h_out, n, beta);
 }
 
 } // extern "C"

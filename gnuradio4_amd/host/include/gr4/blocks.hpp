@@ -222,9 +222,15 @@ inline bool gr_enum_parse(Type& d, std::string_view s) { return gr::detail::enum
 // window::create (window.hpp:69-183) through the library's host-side restatement
 template <typename T>
 std::vector<T> create(Type type, std::size_t n, float beta = 1.6f) {
-    std::vector<float> w(n);
-    if (n && gr4hip_window_create(static_cast<int>(type), w.data(), n, beta) != GR4HIP_OK) throw std::invalid_argument(std::string("window::create: ") + gr4hip_last_error());
-    return std::vector<T>(w.begin(), w.end());
+    if constexpr (std::is_same_v<T, double>) { // create<double>: evaluated in double
+        std::vector<double> w(n);
+        if (n && gr4hip_window_create_f64(static_cast<int>(type), w.data(), n, static_cast<double>(beta)) != GR4HIP_OK) throw std::invalid_argument(std::string("window::create: ") + gr4hip_last_error());
+        return w;
+    } else {
+        std::vector<float> w(n);
+        if (n && gr4hip_window_create(static_cast<int>(type), w.data(), n, beta) != GR4HIP_OK) throw std::invalid_argument(std::string("window::create: ") + gr4hip_last_error());
+        return std::vector<T>(w.begin(), w.end());
+    }
 }
 } // namespace gr::algorithm::window
 namespace gr::filter {

@@ -283,6 +283,47 @@ struct RotatorStage final : Stage {
     }
 };
 
+// ---- the float64 instantiations the reference registers (time_domain_filter.hpp:20, 57-60; Rotator.hpp:15; fourier/fft.hpp:29): plain FP64 kernels
+struct Fir64Stage final : Stage {
+    gr4hip_fir64_t* h = nullptr;
+    explicit Fir64Stage(const std::vector<double>& b) {
+        in_bytes = out_bytes = sizeof(double);
+        check(gr4hip_fir64_create(&h, b.data(), b.size(), 1), "gr4hip_fir64_create");
+    }
+    ~Fir64Stage() override { gr4hip_fir64_destroy(h); }
+    void set_taps(const std::vector<double>& b) { check(gr4hip_fir64_set_taps(h, b.data(), b.size()), "gr4hip_fir64_set_taps"); }
+    std::string_view kind() const override { return "fir_f64"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        return gr4hip_fir64_process(h, static_cast<const double*>(in), n, static_cast<double*>(out), n_out, s);
+    }
+};
+struct Iir64Stage final : Stage {
+    gr4hip_iir64_t* h = nullptr;
+    Iir64Stage(int form, const std::vector<double>& b, const std::vector<double>& a) {
+        in_bytes = out_bytes = sizeof(double);
+        check(gr4hip_iir64_create(&h, form, 1, b.data(), b.size(), a.data(), a.size()), "gr4hip_iir64_create");
+    }
+    ~Iir64Stage() override { gr4hip_iir64_destroy(h); }
+    std::string_view kind() const override { return "iir_f64"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        *n_out = n;
+        return gr4hip_iir64_process(h, static_cast<const double*>(in), n, static_cast<double*>(out), s);
+    }
+};
+struct Rotator64Stage final : Stage {
+    gr4hip_rotator64_t* h = nullptr;
+    Rotator64Stage(double phase_increment, double initial_phase) {
+        in_bytes = out_bytes = 16;
+        check(gr4hip_rotator64_create(&h, phase_increment, initial_phase), "gr4hip_rotator64_create");
+    }
+    ~Rotator64Stage() override { gr4hip_rotator64_destroy(h); }
+    std::string_view kind() const override { return "rotator_c64"; }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        *n_out = n;
+        return gr4hip_rotator64_process(h, in, out, n, s);
+    }
+};
+
 // BasicFilterProto<float, ...>: designed FIR (polyphase when decimating: only the kept outputs are computed) or designed IIR cascade at the
 // full rate followed by the keep-every-D-th step (time_domain_filter.hpp:190-204)
 struct BasicFilterStage final : Stage {
@@ -396,6 +437,26 @@ struct Kernel<gr::filter::fir_filter<T>> {
     static work::Status           work(gr::filter::fir_filter<T>& b, std::size_t nIn, std::size_t nOut) {
         return offload_work(b, nIn, nOut, make_stage, [](Stage& st, gr::filter::fir_filter<T>& blk) { static_cast<FirStage<T>&>(st).set_taps(blk.b); return true; });
     }
+};
+template <>
+struct Kernel<gr::filter::fir_filter<double>> {
+    using B = gr::filter::fir_filter<double>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<Fir64Stage>(b.b); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) {
+        return offload_work(b, nIn, nOut, make_stage, [](Stage& st, B& blk) { static_cast<Fir64Stage&>(st).set_taps(blk.b); return true; });
+    }
+};
+template <gr::filter::IIRForm form>
+struct Kernel<gr::filter::iir_filter<double, form>> {
+    using B = gr::filter::iir_filter<double, form>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<Iir64Stage>(static_cast<int>(form), b.b, b.a); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
+};
+template <>
+struct Kernel<gr::blocks::math::Rotator<std::complex<double>>> {
+    using B = gr::blocks::math::Rotator<std::complex<double>>;
+    static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<Rotator64Stage>(b.phase_increment, b._accumulated_phase); }
+    static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
 };
 template <typename T, typename op>
 struct Kernel<gr::blocks::math::MathOpImpl<T, op>> {
@@ -663,6 +724,57 @@ struct Kernel<gr::blocks::fft::FFT<T, DataSet<float>>> {
                 for (std::size_t i = 0; i < 4; ++i) {
                     std::memcpy(ds.signalValues(i).data(), hs + (i * frames + f) * M, M * sizeof(float));
                     ds.signal_ranges[i] = {hr[f * 8 + 2 * i], hr[f * 8 + 2 * i + 1]};
+                }
+                os[f] = std::move(ds);
+            }
+            return work::Status::OK;
+        } catch (const std::exception& e) {
+            blk._log(std::string("device block '") + blk.name + "' failed: " + e.what());
+            return work::Status::ERROR;
+        }
+    }
+};
+
+// FFT<double>: real double frames -> DataSet<double> (gr4hip_fft64_process; the per-signal ranges of fft.hpp:229-232 are taken on the host from the copied signals)
+template <>
+struct Kernel<gr::blocks::fft::FFT<double, DataSet<double>>> {
+    using B = gr::blocks::fft::FFT<double, DataSet<double>>;
+    struct State final : Offload {
+        gr4hip_fft64_t* h = nullptr;
+        std::size_t     N = 0;
+        std::string     window;
+        int             flags = -1;
+        DevBuf          d_sig;
+        ~State() override { if (h) gr4hip_fft64_destroy(h); }
+    };
+    static work::Status work(B& blk, std::size_t nIn, std::size_t nOut) {
+        try {
+            State* st = offload_state<State>(blk);
+            const int flags = (blk.outputInDb ? GR4HIP_FFT_OUTPUT_IN_DB : 0) | (blk.outputInDeg ? GR4HIP_FFT_OUTPUT_IN_DEG : 0) | (blk.unwrapPhase ? GR4HIP_FFT_UNWRAP_PHASE : 0);
+            if (!st->h || st->N != blk.fftSize || st->window != blk.window.value || st->flags != flags) {
+                if (st->h) gr4hip_fft64_destroy(st->h);
+                st->h = nullptr;
+                check(gr4hip_fft64_create(&st->h, blk.fftSize, window_id(blk.window), flags), "gr4hip_fft64_create");
+                st->N = blk.fftSize; st->window = blk.window; st->flags = flags;
+            }
+            const std::size_t N = st->N, M = blk.nBins(), frames = nOut;
+            if (nIn != frames * N) throw std::runtime_error("FFT: the work loop must hand over whole frames");
+            std::memcpy(st->h_in.ensure(nIn * sizeof(double)), blk.in.buffer->read_span(nIn).data(), nIn * sizeof(double));
+            check(gr4hip_memcpy_h2d(st->d_in.ensure(nIn * sizeof(double)), st->h_in.p, nIn * sizeof(double), nullptr), "h2d");
+            double* sig = static_cast<double*>(st->d_sig.ensure(4 * frames * M * sizeof(double))); // [mag | phase | re | im], each frames x M
+            check(gr4hip_fft64_process(st->h, static_cast<const double*>(st->d_in.p), frames, sig, sig + frames * M, sig + 2 * frames * M, sig + 3 * frames * M, nullptr), "gr4hip_fft64_process");
+            check(gr4hip_memcpy_d2h(st->h_out.ensure(4 * frames * M * sizeof(double)), sig, 4 * frames * M * sizeof(double), nullptr), "d2h");
+            check(gr4hip_stream_synchronize(nullptr), "sync");
+            const double* hs = static_cast<const double*>(st->h_out.p);
+            auto          os = blk.out.buffer->write_span(nOut);
+            const auto    skeleton = blk.datasetSkeleton();
+            for (std::size_t f = 0; f < frames; ++f) {
+                DataSet<double> ds = skeleton;
+                for (std::size_t i = 0; i < 4; ++i) {
+                    const double* v = hs + (i * frames + f) * M;
+                    std::memcpy(ds.signalValues(i).data(), v, M * sizeof(double));
+                    const auto [mn, mx] = std::minmax_element(v, v + M);
+                    ds.signal_ranges[i] = {*mn, *mx};
                 }
                 os[f] = std::move(ds);
             }

@@ -54,15 +54,21 @@ const bool registered = [] {
     register_math<float>(r); register_math<double>(r); register_math<std::complex<float>>(r); register_math<std::complex<double>>(r);
     register_io<float>(r); register_io<std::complex<float>>(r); register_io<std::int32_t>(r);
     r.insert<fir_filter<float>>(named<float>("gr::filter::fir_filter"));
-    r.insert<fir_filter<double>>(named<double>("gr::filter::fir_filter")); // host body only (no float64 kernel: warn-once fallback as the reference pins)
+    r.insert<fir_filter<double>>(named<double>("gr::filter::fir_filter")); // FP64 kernel behind the seam (csrc/f64.hip)
     r.insert<fir_filter<std::complex<float>>>(named<std::complex<float>>("gr::filter::fir_filter"));
     r.insert<iir_filter<float, IIRForm::DF_I>>(named<float>("gr::filter::iir_filter", ", gr::filter::IIRForm::DF_I"));
     r.insert<iir_filter<float, IIRForm::DF_II>>(named<float>("gr::filter::iir_filter", ", gr::filter::IIRForm::DF_II"));
     r.insert<iir_filter<float, IIRForm::DF_I_TRANSPOSED>>(named<float>("gr::filter::iir_filter", ", gr::filter::IIRForm::DF_I_TRANSPOSED"));
     r.insert<iir_filter<float, IIRForm::DF_II_TRANSPOSED>>(named<float>("gr::filter::iir_filter", ", gr::filter::IIRForm::DF_II_TRANSPOSED"));
+    r.insert<iir_filter<double, IIRForm::DF_I>>(named<double>("gr::filter::iir_filter", ", gr::filter::IIRForm::DF_I"));
+    r.insert<iir_filter<double, IIRForm::DF_II>>(named<double>("gr::filter::iir_filter", ", gr::filter::IIRForm::DF_II"));
+    r.insert<iir_filter<double, IIRForm::DF_I_TRANSPOSED>>(named<double>("gr::filter::iir_filter", ", gr::filter::IIRForm::DF_I_TRANSPOSED"));
+    r.insert<iir_filter<double, IIRForm::DF_II_TRANSPOSED>>(named<double>("gr::filter::iir_filter", ", gr::filter::IIRForm::DF_II_TRANSPOSED"));
     r.insert<BasicFilter<float>>(named<float>("gr::filter::BasicFilter"));
     r.insert<BasicDecimatingFilter<float>>(named<float>("gr::filter::BasicFilterProto", ", gr::Resampling<1, 1, false>"));
     r.insert<gr::blocks::math::Rotator<std::complex<float>>>(named<std::complex<float>>("gr::blocks::math::Rotator"));
+    r.insert<gr::blocks::math::Rotator<std::complex<double>>>(named<std::complex<double>>("gr::blocks::math::Rotator"));
+    r.insert<gr::blocks::fft::FFT<double, gr::DataSet<double>>>(named<double>("gr::blocks::fft::FFT"));
     r.insert<gr::blocks::fft::FFT<float>>(named<float>("gr::blocks::fft::FFT"));
     r.insert<gr::blocks::fft::FFT<std::complex<float>>>(named<std::complex<float>>("gr::blocks::fft::FFT"));
     r.insert<gr::blocks::fft::PowerSpectrum<std::complex<float>>>(named<std::complex<float>>("gr::blocks::fft::PowerSpectrum"));

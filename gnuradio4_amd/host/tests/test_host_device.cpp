@@ -318,6 +318,33 @@ int main(int argc, char** argv) {
             // (with inc = 0.1f the float accumulator is already 6e-5 rad off after 1000 steps: same rounding direction inside a binade)
             report("Rotator<complex<float>> vs host body (first 64)", max_rel(std::vector<std::complex<float>>(dv.begin(), dv.begin() + 64), std::vector<std::complex<float>>(hv.begin(), hv.begin() + 64)), 1e-5);
         }
+        { // the float64 instantiations the reference registers (fir_filter / iir_filter<double>, Rotator<complex<double>>, FFT<double>): FP64 kernels behind the same seam;
+          // the device differs from the host body of the same block only by the order of its float64 sums
+            std::vector<double> xd(xf.begin(), xf.begin() + 100000);
+            for (std::size_t i = 0; i < xd.size(); ++i) xd[i] += 1e-9 * static_cast<double>(i % 977); // not float-representable
+            std::vector<double> bt(77);
+            for (std::size_t k = 0; k < bt.size(); ++k) bt[k] = (0.54 - 0.46 * std::cos(2 * std::numbers::pi * double(k) / 76.0)) / 41.0;
+            using F = filter::fir_filter<double>;
+            report("fir_filter<double> 77 taps", max_rel(run_one<F, double, double>({{"b", bt}}, xd, true, errors), run_one<F, double, double>({{"b", bt}}, xd, false, errors)), 1e-12);
+            using I = filter::iir_filter<double, filter::IIRForm::DF_I>;
+            const property_map icfg{{"b", bq_b}, {"a", bq_a}};
+            report("iir_filter<double, DF_I>", max_rel(run_one<I, double, double>(icfg, xd, true, errors), run_one<I, double, double>(icfg, xd, false, errors)), 1e-11);
+            using R = blocks::math::Rotator<std::complex<double>>;
+            std::vector<std::complex<double>> xc(50000);
+            for (std::size_t i = 0; i < xc.size(); ++i) xc[i] = {xd[2 * i], xd[2 * i + 1]};
+            const property_map rcfg{{"phase_increment", 0.1}};
+            report("Rotator<complex<double>>", max_rel(run_one<R, std::complex<double>, std::complex<double>>(rcfg, xc, true, errors), run_one<R, std::complex<double>, std::complex<double>>(rcfg, xc, false, errors)), 1e-10);
+            using FF = blocks::fft::FFT<double, DataSet<double>>;
+            const property_map fcfg{{"fftSize", std::int64_t(1024)}, {"window", "Hann"s}};
+            const auto dd = run_one<FF, double, DataSet<double>>(fcfg, xd, true, errors), dh = run_one<FF, double, DataSet<double>>(fcfg, xd, false, errors);
+            double worst = dd.size() == xd.size() / 1024 && dh.size() == dd.size() ? 0.0 : 1e30;
+            for (std::size_t f = 0; f < dd.size() && worst < 1e29; ++f)
+                for (std::size_t i : {std::size_t(0), std::size_t(2), std::size_t(3)}) { // magnitude, Re, Im (phase is noise in empty bins; pinned bin by bin in tests/test_gpu_parity.py)
+                    const auto a = dd[f].signalValues(i), b = dh[f].signalValues(i);
+                    worst = std::max(worst, max_rel(std::vector<double>(a.begin(), a.end()), std::vector<double>(b.begin(), b.end())));
+                }
+            report("FFT<double> 1024 Hann -> DataSet<double>", worst, 1e-11);
+        }
         for (const char* kind : {"FIR", "IIR"}) {
             const property_map cfg{{"filter_type", std::string(kind)}, {"filter_response", "LOWPASS"s}, {"filter_order", std::int64_t(4)}, {"f_low", 100.0}, {"sample_rate", 1000.0},
                                    {"iir_design_method", "CHEBYSHEV1"s}, {"fir_design_method", "Hamming"s}, {"decimate", std::int64_t(5)}};

@@ -208,6 +208,7 @@ int gr4hip_fft_mag2(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, float*
 int gr4hip_fft_destroy(gr4hip_fft_t* fft);
 /* window::create on the host (float), for callers that need the block's _window member */
 int gr4hip_window_create(int window, float* h_out, size_t n, float beta);
+int gr4hip_window_create_f64(int window, double* h_out, size_t n, double beta); /* create<double> */
 
 /* ------------------------------------------------------------------------------------------------ headline chain
  * complex<float> fir_filter -> FFT block frames -> |X|^2 (BASELINE.json configs[1]).  One call consumes
@@ -259,6 +260,34 @@ int gr4hip_rotator_reset(gr4hip_rotator_t* rot, float initial_phase); /* setting
 int gr4hip_rotator_process(gr4hip_rotator_t* rot, const void* d_in_c32, void* d_out_c32, size_t n, gr4hip_stream_t stream);
 int gr4hip_rotator_phase(gr4hip_rotator_t* rot, float* phase, gr4hip_stream_t stream); /* synchronises the stream */
 int gr4hip_rotator_destroy(gr4hip_rotator_t* rot);
+
+/* ------------------------------------------------------------------------------------------------ float64 instantiations
+ * The second registered type of the hot-path blocks: fir_filter<double> / iir_filter<double, form> (time_domain_filter.hpp:20, 57-60), FFT<double>
+ * (fourier/fft.hpp:29: real double frames -> DataSet<double>) and Rotator<complex<double>> (Rotator.hpp:15).  Same semantics as the float32 entry points
+ * above (history / state carried between calls, decimation = y[m D], all IIR forms evaluated as DF-II, FFT outputs of a real-input block: magnitude and
+ * phase of bins 0 .. N/2-1, Re / Im of bins N/2 .. N-1), plain FP64 kernels.  Envelope: FIR <= 2048 taps, decim <= 32; IIR <= 8 state values (4 biquads,
+ * or one section of order <= 8); FFT powers of two 2 .. 8192; anything else returns GR4HIP_UNSUPPORTED from create (the caller keeps its CPU path). */
+typedef struct gr4hip_fir64 gr4hip_fir64_t;
+int gr4hip_fir64_create(gr4hip_fir64_t** fir, const double* h_taps, size_t ntaps, size_t decim);
+int gr4hip_fir64_set_taps(gr4hip_fir64_t* fir, const double* h_taps, size_t ntaps); /* history kept unless it has to grow */
+int gr4hip_fir64_reset(gr4hip_fir64_t* fir);
+int gr4hip_fir64_process(gr4hip_fir64_t* fir, const double* d_in, size_t n_in, double* d_out, size_t* n_out, gr4hip_stream_t stream);
+int gr4hip_fir64_destroy(gr4hip_fir64_t* fir);
+typedef struct gr4hip_iir64 gr4hip_iir64_t;
+int gr4hip_iir64_create(gr4hip_iir64_t** iir, int form, size_t nsections, const double* h_b, size_t nb, const double* h_a, size_t na);
+int gr4hip_iir64_reset(gr4hip_iir64_t* iir);
+int gr4hip_iir64_process(gr4hip_iir64_t* iir, const double* d_in, size_t n, double* d_out, gr4hip_stream_t stream);
+int gr4hip_iir64_destroy(gr4hip_iir64_t* iir);
+typedef struct gr4hip_fft64 gr4hip_fft64_t;
+int gr4hip_fft64_create(gr4hip_fft64_t** fft, size_t fft_size, int window, int flags);
+int gr4hip_fft64_process(gr4hip_fft64_t* fft, const double* d_in, size_t n_frames, double* d_mag, double* d_phase, double* d_re, double* d_im, gr4hip_stream_t stream);
+int gr4hip_fft64_destroy(gr4hip_fft64_t* fft);
+typedef struct gr4hip_rotator64 gr4hip_rotator64_t;
+int gr4hip_rotator64_create(gr4hip_rotator64_t** rot, double phase_increment, double initial_phase);
+int gr4hip_rotator64_reset(gr4hip_rotator64_t* rot, double initial_phase);
+int gr4hip_rotator64_process(gr4hip_rotator64_t* rot, const void* d_in_c64, void* d_out_c64, size_t n, gr4hip_stream_t stream);
+int gr4hip_rotator64_phase(gr4hip_rotator64_t* rot, double* phase);
+int gr4hip_rotator64_destroy(gr4hip_rotator64_t* rot);
 
 /* ------------------------------------------------------------------------------------------------ batched FIR (configs[3])
  * nchannels independent fir_filter<float> instances, per-channel taps h_taps[c][k], channel-major samples

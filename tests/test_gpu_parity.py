@@ -1347,3 +1347,115 @@ def test_device_generator_is_the_reference_prng(G, golden):
     m2 = G.FFT(8192, "None").mag2(zt[: 64 * 8192]).double().mean(dim=0)
     assert int(m2.argmax()) == 819  # 0.1 fs * 8192 = 819.2
     assert abs(float((zt.abs().double() ** 2).mean()) - 2.0) < 1e-2  # unit tone + unit noise
+
+
+# ---------------------------------------------------------------------------------------------------------------- float64 instantiations
+# the second registered type of the filter / fourier / rotator blocks (time_domain_filter.hpp:20, 57-60; fourier/fft.hpp:29; Rotator.hpp:15).  Truth: the
+# same formulas in float64 (numpy / the oracle's double sections); the device differs only by the order of its float64 sums, so the bar is 1e-12, not 1e-5
+TOL64 = 1e-12
+
+
+@pytest.mark.parametrize("ntaps,decim", [(1, 1), (7, 1), (64, 1), (300, 1), (1024, 8), (33, 3), (2048, 1)])
+def test_fir_filter_float64(G, ntaps, decim):
+    rng = np.random.default_rng(ntaps + decim)
+    b = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+    n = 60_000 - 60_000 % decim
+    x = rng.standard_normal(n)
+    full = np.convolve(x, b)[:n]  # y[i] = sum_k b[k] x[i - k], zero history
+    truth = full[::decim]
+    f = G.fir_filter(b, torch.float64, decimate=decim)
+    cuts = [0, 3 * decim, 3 * decim + 7000 * decim - (7000 * decim) % decim, n]
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])  # history across calls
+    assert y.dtype == np.float64 and y.shape == truth.shape and _rel(y, truth) <= TOL64
+    f.reset()
+    assert _rel(f.process_bulk(dev(x[:999 * decim])).cpu().numpy(), truth[:999]) <= TOL64
+    if ntaps >= 7 and ntaps <= 64:  # settingsChanged keeps the history while it fits (time_domain_filter.hpp:38-42)
+        f2 = G.fir_filter(b, torch.float64, decimate=decim)
+        y1 = f2.process_bulk(dev(x[:3000 * decim])).cpu().numpy()
+        b2 = b[::-1].copy()
+        f2.settings_changed(b2)
+        y2 = f2.process_bulk(dev(x[3000 * decim:6000 * decim])).cpu().numpy()
+        t2 = np.convolve(x[:6000 * decim], b2)[:6000 * decim][::decim][3000:]
+        assert _rel(y1, truth[:3000]) <= TOL64 and _rel(y2, t2) <= TOL64
+    with pytest.raises(G.capi.Gr4HipError) as e:
+        G.fir_filter(np.ones(4096), torch.float64)
+    assert e.value.status == G.capi.UNSUPPORTED
+
+
+@pytest.mark.parametrize("kind", ["biquad4", "pole1", "order4", "narrow"])
+def test_iir_filter_float64(G, kind):
+    import scipy.signal as sps
+    rng = np.random.default_rng(3)
+    if kind == "biquad4":
+        sos = sps.butter(8, 0.1, output="sos")  # 4 biquads
+        b, a = sos[:, :3], sos[:, 3:]
+    elif kind == "pole1":
+        b, a = np.array([[0.3, 0.0]]), np.array([[1.0, -0.7]])
+    elif kind == "order4":
+        b, a = np.array([[0.1, 0.2, 0.3, 0.2, 0.1]]), np.array([[1.0, -0.9, 0.5, -0.1, 0.02]])
+    else:
+        sos = sps.butter(4, 0.0005, output="sos")  # poles within 1e-3 of the unit circle: the scan must carry long memory exactly
+        b, a = sos[:, :3], sos[:, 3:]
+    n = 3 * 8192 * 17 + 1234
+    x = rng.standard_normal(n)
+    truth = x.copy()
+    for bb, aa in zip(b, a):
+        truth = sps.lfilter(bb, aa, truth)
+    f = G.iir_filter(b, a, dtype=torch.float64)
+    cut = 8192 * 5 + 77
+    y = np.concatenate([f.process_bulk(dev(x[:cut])).cpu().numpy(), f.process_bulk(dev(x[cut:])).cpu().numpy()])  # state across calls, ragged tiles
+    assert y.dtype == np.float64 and _rel(y, truth) <= (1e-9 if kind == "narrow" else TOL64)  # (narrow: condition of the filter itself, ~1e3 / (1 - |p|))
+    sec = O.make_sections([(bb, aa) for bb, aa in zip(b, a)])  # and the oracle's own double sections on the (float32-representable) head of the stream
+    x32 = x[:50_000].astype(np.float32)
+    f.reset()
+    assert _rel(f.process_bulk(dev(x32.astype(np.float64))).cpu().numpy(), O.iir_cascade(sec, x32, O.DF_II, f64=True)) <= (1e-9 if kind == "narrow" else TOL64)
+    with pytest.raises(G.capi.Gr4HipError) as e:
+        G.iir_filter(np.ones((5, 3)), np.ones((5, 3)), dtype=torch.float64)  # 10 state values
+    assert e.value.status == G.capi.UNSUPPORTED
+
+
+@pytest.mark.parametrize("N", [2, 16, 1024, 8192])
+@pytest.mark.parametrize("window", ["None", "Hann", "BlackmanHarris"])
+def test_fft_block_float64(G, N, window):
+    """FFT<double>: real double frames; magnitude / phase = bins 0 .. N/2-1, Re / Im = bins N/2 .. N-1 (fft.hpp:221-227), all in double"""
+    rng = np.random.default_rng(N)
+    frames = 5
+    x = rng.standard_normal(frames * N) + np.cos(0.3 * np.arange(frames * N))
+    w = np.ones(N) if window == "None" else O.window(O.WINDOWS.index(window), N, np.float64)
+    X = np.fft.fft(x.reshape(frames, N) * w, axis=1)
+    out = G.FFT(N, window, dtype=torch.float64).process_bulk(dev(x))
+    h = N // 2
+    assert out["magnitude"].dtype == torch.float64
+    assert _rel(out["magnitude"].cpu().numpy(), np.abs(X[:, :h]) * 2 / N) <= TOL64
+    assert _rel(out["re"].cpu().numpy(), X[:, h:].real) <= TOL64 and _rel(out["im"].cpu().numpy(), X[:, h:].imag) <= TOL64
+    ph, tp = out["phase"].cpu().numpy(), np.angle(X[:, :h])
+    d = np.abs(ph - tp)
+    d = np.minimum(d, 2 * np.pi - d)  # +-pi is one point
+    big = np.abs(X[:, :h]) > 1e-6 * np.abs(X).max()
+    assert not big.any() or d[big].max() <= 1e-9  # (N = 2 under a window that is zero at both ends: nothing to compare)
+    if N >= 16:
+        o2 = G.FFT(N, window, outputInDb=True, outputInDeg=True, unwrapPhase=True, dtype=torch.float64).process_bulk(dev(x))
+        assert _rel(o2["magnitude"].cpu().numpy(), 20 * np.log10(np.abs(X[:, :h]) * 2 / N)) <= 1e-9
+        tph = np.degrees(np.unwrap(np.angle(X[:, :h]), axis=1))
+        if big.all():
+            assert np.abs(o2["phase"].cpu().numpy() - tph).max() <= 1e-6
+        assert o2["ranges"].shape == (frames, 4, 2)
+    with pytest.raises(G.capi.Gr4HipError) as e:
+        G.FFT(1000, "None", dtype=torch.float64)
+    assert e.value.status == G.capi.UNSUPPORTED
+
+
+@pytest.mark.parametrize("inc", [1e-3, 0.37, -2.5, 7.0])
+def test_rotator_complex128(G, inc):
+    rng = np.random.default_rng(5)
+    n = (1 << 21) + 333
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    r = G.Rotator(phase_increment=inc, initial_phase=0.25, dtype=torch.complex128)
+    cut = 700_001
+    y = np.concatenate([r.process_bulk(dev(x[:cut])).cpu().numpy(), r.process_bulk(dev(x[cut:])).cpu().numpy()])
+    truth = x * np.exp(1j * (0.25 + inc * np.arange(1, n + 1)))
+    assert y.dtype == np.complex128 and np.abs(y - truth).max() <= 1e-9 * np.abs(truth).max()
+    yo, _ = O.rotator(x[:4096], inc, 0.25)  # the oracle's float64 recurrence (gr4o_rotator_c64)
+    # (beyond 2 pi per sample the recurrence wraps once per step and its accumulator grows without bound: 6.5e-10 of drift in 4096 steps at inc = 7, all its own)
+    assert np.abs(y[:4096] - yo).max() <= (1e-10 if abs(inc) < 2 * np.pi else 5e-9)
+    assert abs(np.exp(1j * r.accumulated_phase) - np.exp(1j * (0.25 + inc * n))) <= 1e-7
