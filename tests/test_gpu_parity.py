@@ -1064,13 +1064,31 @@ def test_tiny_and_empty_spans_every_block(G):
              ("iir", lambda: G.iir_filter(bi, ai), xf, O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)]), xf, O.DF_II, f64=True)),
              ("rotator", lambda: G.Rotator(phase_increment=0.37, initial_phase=0.1), xc, O.rotator(xc.astype(np.complex128), float(np.float32(0.37)), float(np.float32(0.1)))[0]),
              ("rotator (float recurrence)", lambda: G.Rotator(phase_increment=0.37, initial_phase=0.1, algo="recurrence"), xc, O.rotator(xc, 0.37, 0.1)[0])]
+    # the float64 instantiations and the interpolator stream the same way
+    b64, x64 = b.astype(np.float64) * 1.000000123, xf.astype(np.float64) + 1e-9
+    bi64, ai64 = bi.astype(np.float64), ai.astype(np.float64)
+    import scipy.signal as sps
+    t_iir64 = x64.copy()
+    for bb, aa in zip(bi64, ai64):
+        t_iir64 = sps.lfilter(bb, aa, t_iir64)
+    xc64 = xc.astype(np.complex128)
+    cases += [("fir f64", lambda: G.fir_filter(b64, torch.float64), x64, np.convolve(x64, b64)[:n]),
+              ("iir f64", lambda: G.iir_filter(bi64, ai64, dtype=torch.float64), x64, t_iir64),
+              ("rotator c128", lambda: G.Rotator(phase_increment=0.37, initial_phase=0.1, dtype=torch.complex128), xc64, xc64 * np.exp(1j * (0.1 + 0.37 * np.arange(1, n + 1))))]
     for name, make, x, truth in cases:
         blk, parts, at = make(), [], 0
         for k in sizes:
             parts.append(blk.process_bulk(dev(x[at:at + k])).cpu().numpy())
             assert parts[-1].shape == (k,), (name, k)
             at += k
-        assert _rel(np.concatenate(parts), truth) <= TOL, name
+        assert _rel(np.concatenate(parts), truth) <= (1e-11 if "64" in name or "128" in name else TOL), name
+    itp, parts, at = G.fir_interpolator(b, 3, torch.float32), [], 0
+    for k in sizes:
+        parts.append(itp.process_bulk(dev(xf[at:at + k])).cpu().numpy())
+        assert parts[-1].shape == (3 * k,)
+        at += k
+    assert _rel(np.concatenate(parts), O.fir_interp(b, xf, 3)[0]) <= TOL
+    assert G.FFT(64, "Hann", dtype=torch.float64).process_bulk(dev(np.zeros(0, np.float64)))["magnitude"].shape == (0, 32)
     assert G.math_const("Add", dev(np.zeros(0, np.int16)), 3).numel() == 0 and G.math_const("Multiply", dev(np.array([7], np.int16)), 3).cpu().numpy()[0] == 21
     assert G.Decimator(4).process_bulk(dev(np.zeros(0, np.float32))).numel() == 0
     f = G.FFT(64, "Hann")
