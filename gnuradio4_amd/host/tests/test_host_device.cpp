@@ -487,6 +487,39 @@ int main(int argc, char** argv) {
         std::printf("merge MultiplyConst -> fir_filter on the device: stage '%s', max rel err %.3g%s\n", std::string(hip::Kernel<Two>::make_stage(probe2)->kind()).c_str(), e2, e2 <= 1e-5 ? "" : "  FAILED");
         if (!(e2 <= 1e-5)) ++errors;
     }
+    { // 5b. the multi-channel graph of BASELINE configs[4] in the C++ API: every channel its own planned device run (fir_filter -> PowerSpectrum fused), channel c on
+      //     device c mod <devices> (one here; the runs set their device on every work() call), the fan-in combiner math::Add<float> with n_inputs = channels
+      //     (Math.hpp:73-108) on device 0.  Against the same graph on the host.
+        int n_dev = 1;
+        (void)gr4hip_device_count(&n_dev);
+        constexpr std::size_t kCh = 4;
+        std::vector<float> sums[2];
+        std::size_t        n_runs = 0;
+        for (int dev = 1; dev >= 0; --dev) {
+            Graph g;
+            auto& add = g.emplaceBlock<blocks::math::Add<float>>(dev ? property_map{{"n_inputs", std::int64_t(kCh)}, {"compute_domain", "gpu:hip:0"s}} : property_map{{"n_inputs", std::int64_t(kCh)}});
+            for (std::size_t c = 0; c < kCh; ++c) {
+                const std::string dom = "gpu:hip:" + std::to_string(c % static_cast<std::size_t>(std::max(1, n_dev)));
+                auto& src  = g.emplaceBlock<testing::VectorSource<std::complex<float>>>({{"n_samples_max", std::int64_t(6 * N)}});
+                src.values.assign(x.begin() + static_cast<std::ptrdiff_t>(37 * c), x.end()); // the channels see different streams
+                auto& fir  = g.emplaceBlock<filter::fir_filter<std::complex<float>>>(dev ? property_map{{"b", tapsd}, {"compute_domain", dom}} : property_map{{"b", tapsd}});
+                auto& spec = g.emplaceBlock<blocks::fft::PowerSpectrum<std::complex<float>>>(
+                    dev ? property_map{{"fftSize", std::int64_t(N)}, {"window", "Hann"s}, {"compute_domain", dom}} : property_map{{"fftSize", std::int64_t(N)}, {"window", "Hann"s}});
+                if (!g.connect<"out", "in">(src, fir) || !g.connect<"out", "in">(fir, spec) || !g.connect(spec, "out"s, add, "in#"s + std::to_string(c))) ++errors;
+            }
+            auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+            if (!g.connect<"out", "in">(add, sink)) ++errors;
+            if (dev) n_runs = hip::plan(g).size();
+            scheduler::Simple sched;
+            sched.exchange(std::move(g));
+            if (const auto r = sched.runAndWait(); !r) { std::cerr << "fan-in graph: " << r.error().message << "\n"; ++errors; }
+            sums[dev] = sink._samples;
+        }
+        const double e = sums[1].size() == 6 * N && sums[0].size() == sums[1].size() ? max_rel(sums[1], sums[0]) : 1e30;
+        std::printf("fan-in graph: %zu channels, %zu fused runs on %d device(s), Add<float> n_inputs = %zu on the device: max rel err vs the host graph %.3g%s\n", kCh, n_runs, n_dev, kCh, e,
+                    e <= 1e-5 ? "" : "  FAILED");
+        if (n_runs != kCh || !(e <= 1e-5)) ++errors;
+    }
     { // 6. tags through a fused device run: launches split at tags, "gr:" keys forwarded at the first output sample with gr:sample_rate scaled by the run's rate
       //    change, settings-by-tag reaches the member block and rebuilds only its stage (the FIR keeps its history)
         std::vector<float> xs(120000);
