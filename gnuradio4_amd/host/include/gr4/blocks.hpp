@@ -84,16 +84,165 @@ struct NullSink : Block<NullSink<T>> {
 } // namespace gr::testing
 
 namespace gr::basic {
-// gr::basic::SignalGenerator<T> (blocks/basic/.../SignalGenerator.hpp:25-87) reduced to Const / Sin / Cos with a sample budget:
-// value(t) = amplitude * f(2 pi frequency t + phase) + offset, t advancing by 1 / sample_rate  (ToneGenerator.hpp)
+namespace signal_generator {
+enum class Type : int { Const, Sin, Cos, Square, Saw, Triangle, FastSin, FastCos, UniformNoise, TriangularNoise, GaussianNoise }; // SignalGeneratorCore.hpp:16
+inline bool gr_enum_parse(Type& d, std::string_view s) {
+    return gr::detail::enum_from_names(d, s, std::array<std::string_view, 11>{"Const", "Sin", "Cos", "Square", "Saw", "Triangle", "FastSin", "FastCos", "UniformNoise", "TriangularNoise", "GaussianNoise"});
+}
+
+// xoshiro256++ with the reference's float conversions (algorithm/.../rng/Xoshiro256pp.hpp:22-96: splitmix64 seeding :33-39, next :41-52, 24 / 53 mantissa
+// bits -> [0, 1) :55-61) and its Marsaglia-polar Gaussian with the cached second variate (GaussianNoise.hpp:33-55)
+template <typename F>
+struct Noise {
+    std::uint64_t s[4]{};
+    F             spare{};
+    bool          has_spare = false;
+    void          seed(std::uint64_t v) {
+        for (auto& w : s) { // splitmix64
+            v += 0x9e3779b97f4a7c15ULL;
+            std::uint64_t z = v;
+            z               = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+            z               = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+            w               = z ^ (z >> 31);
+        }
+        has_spare = false;
+    }
+    static constexpr std::uint64_t rotl(std::uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    std::uint64_t next() {
+        const std::uint64_t r = rotl(s[0] + s[3], 23) + s[0], t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return r;
+    }
+    F u01() {
+        if constexpr (std::is_same_v<F, float>) return static_cast<F>(next() >> 40) * F(0x1.0p-24);
+        else return static_cast<F>(next() >> 11) * F(0x1.0p-53);
+    }
+    F um11() { return F(2) * u01() - F(1); }
+    F triangular() { const F a = u01(), b = u01(); return a + b - F(1); }
+    F gauss() {
+        if (has_spare) { has_spare = false; return spare; }
+        F u, v, q;
+        do { u = um11(); v = um11(); q = u * u + v * v; } while (q >= F(1) || q == F(0));
+        const F f = std::sqrt(F(-2) * std::log(q) / q);
+        spare     = v * f;
+        has_spare = true;
+        return u * f;
+    }
+};
+} // namespace signal_generator
+
+// gr::basic::SignalGenerator<T> (blocks/basic/.../SignalGenerator.hpp:25-87) over SignalGeneratorCore<T> (algorithm/.../signal/SignalGeneratorCore.hpp:72-147),
+// free-running with a sample budget instead of the wall-clock pacing.  All eleven signal types, sample by sample as the block does (generateSample):
+//   tones (ToneGenerator.hpp): time accumulates by 1 / sample_rate in the compute type F (double for scalar T, the base type for complex T); Sin / Cos by
+//   std::sin / std::cos of 2 pi f t + phase, FastSin / FastCos by a phasor rotated once per sample and renormalised every 65536 samples, Square / Saw /
+//   Triangle from the cycle count f t + phase / 2 pi; frequency <= 0 turns every tone into Const; complex output = the analytic signal for the four
+//   sinusoids (offset on the real part), {value, 0} otherwise
+//   noise (NoiseGenerator.hpp): xoshiro256++ seeded with `seed`; Uniform [-1, 1), Triangular u1 + u2 - 1, Gaussian by Marsaglia's polar method; complex:
+//   independent components (offset on the real part), Gaussian components scaled by 1 / sqrt 2
+//   integer T: truncation, clamped to the type's range (clampToInt, SignalGeneratorCore.hpp:47-58)
 template <typename T>
 struct SignalGenerator : Block<SignalGenerator<T>> {
-    PortOut<T>  out;
-    std::string signal_type = "Sin";
-    float       sample_rate = 1000.f, frequency = 1.f, amplitude = 1.f, offset = 0.f, phase = 0.f;
-    Size_t      n_samples_max = 0;
-    std::size_t _n = 0;
-    GR_MAKE_REFLECTABLE(SignalGenerator, out, signal_type, sample_rate, frequency, amplitude, offset, phase, n_samples_max);
+    using F = std::conditional_t<std::is_same_v<T, std::complex<float>>, float, double>;
+    PortOut<T>             out;
+    signal_generator::Type signal_type = signal_generator::Type::Sin;
+    float                  sample_rate = 1000.f, frequency = 1.f, amplitude = 1.f, offset = 0.f, phase = 0.f;
+    std::uint64_t          seed          = 0;
+    Size_t                 n_samples_max = 0;
+    std::size_t            _n            = 0;
+    GR_MAKE_REFLECTABLE(SignalGenerator, out, signal_type, sample_rate, frequency, amplitude, offset, phase, seed, n_samples_max);
+
+    // ---- the core's state
+    signal_generator::Type     _type = signal_generator::Type::Sin;
+    F                          _t = 0, _tick = 0, _omega = 0, _cycles0 = 0, _f = 1, _a = 1, _o = 0, _ph = 0;
+    std::complex<F>            _phasor{1, 0}, _rot{1, 0};
+    std::size_t                _count = 0;
+    signal_generator::Noise<F> _noise;
+    bool                       _configured = false;
+
+    void configure() {
+        using signal_generator::Type;
+        constexpr F pi2 = F(2) * std::numbers::pi_v<F>;
+        _f = static_cast<F>(frequency); _a = static_cast<F>(amplitude); _o = static_cast<F>(offset); _ph = static_cast<F>(phase);
+        _tick    = F(1) / static_cast<F>(sample_rate);
+        _type    = signal_type;
+        if (static_cast<int>(_type) <= static_cast<int>(Type::FastCos) && _f <= F(0)) _type = Type::Const;
+        _omega   = pi2 * _f;
+        _cycles0 = _ph / pi2;
+        _rot     = {std::cos(pi2 * _f * _tick), std::sin(pi2 * _f * _tick)};
+        _phasor  = {std::cos(_ph), std::sin(_ph)};
+        _count   = 0;
+        _noise.seed(seed);
+        _configured = true;
+    }
+    void settingsChanged(const property_map&, const property_map&) { configure(); } // (the time base keeps running across a settings change, as upstream)
+    void reset() { _t = 0; configure(); }
+
+    [[nodiscard]] F tone() const {
+        using signal_generator::Type;
+        const F theta = _omega * _t + _ph, cycle = _f * _t + _cycles0;
+        switch (_type) {
+        case Type::Sin: return _a * std::sin(theta) + _o;
+        case Type::Cos: return _a * std::cos(theta) + _o;
+        case Type::FastSin: return _a * _phasor.imag() + _o;
+        case Type::FastCos: return _a * _phasor.real() + _o;
+        case Type::Square: return (cycle - std::floor(cycle) < F(0.5)) ? _a + _o : -_a + _o;
+        case Type::Saw: return _a * (F(2) * (cycle - std::floor(cycle + F(0.5)))) + _o;
+        case Type::Triangle: return _a * (F(4) * std::abs(cycle - std::floor(cycle + F(0.75)) + F(0.25)) - F(1)) + _o;
+        default: return _a + _o;
+        }
+    }
+    void advance() {
+        using signal_generator::Type;
+        _t += _tick;
+        if (_type == Type::FastSin || _type == Type::FastCos) {
+            _phasor *= _rot;
+            if ((++_count & 0xFFFF) == 0) { const F inv = F(1) / std::abs(_phasor); _phasor = {_phasor.real() * inv, _phasor.imag() * inv}; }
+        }
+    }
+    [[nodiscard]] F noise() {
+        using signal_generator::Type;
+        return _type == Type::UniformNoise ? _noise.um11() : _type == Type::TriangularNoise ? _noise.triangular() : _noise.gauss();
+    }
+    [[nodiscard]] T generateSample() {
+        using signal_generator::Type;
+        if (!_configured) configure();
+        const bool is_tone = static_cast<int>(_type) <= static_cast<int>(Type::FastCos);
+        if constexpr (gr::detail::is_complex<T>::value) {
+            T r;
+            if (is_tone) {
+                const F theta = _omega * _t + _ph;
+                switch (_type) {
+                case Type::Sin: r = T(_a * std::sin(theta) + _o, -_a * std::cos(theta)); break;
+                case Type::Cos: r = T(_a * std::cos(theta) + _o, _a * std::sin(theta)); break;
+                case Type::FastSin: r = T(_a * _phasor.imag() + _o, -_a * _phasor.real()); break;
+                case Type::FastCos: r = T(_a * _phasor.real() + _o, _a * _phasor.imag()); break;
+                default: r = T(tone(), F(0)); break;
+                }
+                advance();
+            } else if (_type == Type::GaussianNoise) {
+                constexpr F scale = F(1) / std::numbers::sqrt2_v<F>;
+                const F     g1 = _noise.gauss() * scale, g2 = _noise.gauss() * scale;
+                r = T(_a * g1 + _o, _a * g2);
+            } else {
+                const F n1 = noise(), n2 = noise();
+                r = T(_a * n1 + _o, _a * n2);
+            }
+            return r;
+        } else {
+            F raw;
+            if (is_tone) { raw = tone(); advance(); }
+            else raw = _a * noise() + _o;
+            if constexpr (std::is_integral_v<T>) {
+                if (raw >= static_cast<F>(std::numeric_limits<T>::max())) return std::numeric_limits<T>::max();
+                if (raw <= static_cast<F>(std::numeric_limits<T>::min())) return std::numeric_limits<T>::min();
+                return static_cast<T>(raw);
+            } else {
+                return static_cast<T>(raw);
+            }
+        }
+    }
 
     work::Result customWork(std::size_t requested) {
         if (n_samples_max && _n >= n_samples_max) return {requested, 0, work::Status::DONE};
@@ -102,11 +251,7 @@ struct SignalGenerator : Block<SignalGenerator<T>> {
         if (n_samples_max) n = std::min<std::size_t>(n, n_samples_max - _n);
         if (n == 0) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
         auto span = out.buffer->write_span(n);
-        for (std::size_t i = 0; i < n; ++i) {
-            const double th = 2.0 * std::numbers::pi * static_cast<double>(frequency) * (static_cast<double>(_n + i) / static_cast<double>(sample_rate)) + static_cast<double>(phase);
-            const double v  = signal_type == "Const" ? 1.0 : signal_type == "Cos" ? std::cos(th) : std::sin(th);
-            span[i]         = static_cast<T>(static_cast<double>(amplitude) * v + static_cast<double>(offset));
-        }
+        for (std::size_t i = 0; i < n; ++i) span[i] = generateSample();
         out.buffer->publish(n);
         _n += n;
         return {requested, n, work::Status::OK};

@@ -177,3 +177,34 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     m = np.fromfile(tmp_path / "o_math.bin", np.int32)
     src = np.resize(np.array([2147483647, -5, 7, 123456789], np.int32), 100000)
     assert np.array_equal(m, (src.astype(np.int64) * 3).astype(np.int32))  # wrap-around like the C++ int32 product
+
+
+def test_signal_generator_is_the_reference_core(host_bins, tmp_path):
+    """gr::basic::SignalGenerator<T> of the host mirror (all eleven signal types; float / double / int16 / complex<float>) against the reference's OWN
+    SignalGeneratorCore<T> -- oracle/_ref/libgr4ref.so is compiled from algorithm/.../signal/{Tone,Noise,SignalGeneratorCore}.hpp and the rng headers where they
+    lie under /root/reference (oracle/Makefile; no stand-ins).  200 000 samples: past the phasor renormalisation at 65 536.  Same arithmetic, same compiler:
+    bit for bit, except where libm's sin / cos are evaluated in a different context (a few ulp allowed there)."""
+    import ctypes as C
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libgr4ref.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref not built (no reference tree here)")
+    R = C.CDLL(ref_path)
+    if not hasattr(R, "gr4ref_signal_f32"):
+        pytest.skip("oracle/_ref predates the signal-generator harness")
+    n = 200_000
+    r = subprocess.run([os.path.join(host_bins, "dump_signal_generator"), str(tmp_path / "sg"), str(n)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cases = {"f32": (np.float32, R.gr4ref_signal_f32, 1.5, 0.25), "f64": (np.float64, R.gr4ref_signal_f64, 1.5, 0.25), "i16": (np.int16, R.gr4ref_signal_i16, 30000.0, 9000.0),
+             "c32": (np.complex64, R.gr4ref_signal_c32, 1.5, 0.25)}
+    for tname, (dt, fn, amp, off) in cases.items():
+        fn.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t]
+        fn.restype = None
+        for t in range(11):
+            want = np.empty(n, dt)
+            fn(t, 37.5, 1000.0, 0.3, amp, off, 12345, want.ctypes.data, n)
+            got = np.fromfile(tmp_path / f"sg_{tname}_{t}.bin", dt)
+            assert got.shape == want.shape, (tname, t)
+            if np.array_equal(got, want):
+                continue
+            err = np.abs(got.astype(np.complex128) - want.astype(np.complex128)).max()
+            assert t not in (0, 3, 8, 9) and err <= (1 if dt == np.int16 else 4e-6 if dt in (np.float32, np.complex64) else 1e-12), (tname, t, err)
