@@ -812,6 +812,8 @@ class CircularBuffer {
     };
     std::shared_ptr<State> _s;
 
+    explicit CircularBuffer(std::shared_ptr<State> s) : _s(std::move(s)) {} // another handle on the same ring (Reader / Writer::buffer())
+
 public:
     explicit CircularBuffer(std::size_t min_elements) : _s(std::make_shared<State>()) {
         check(gr4hip_ring_create(&_s->ring, min_elements * sizeof(T)), "gr4hip_ring_create");
@@ -826,11 +828,13 @@ public:
 
     class Writer {
         std::shared_ptr<State> _s;
-        std::size_t            _reserved = 0;
+        std::size_t            _reserved = 0, _published = 0;
         friend class CircularBuffer;
         explicit Writer(std::shared_ptr<State> s) : _s(std::move(s)) {}
 
     public:
+        [[nodiscard]] CircularBuffer buffer() const { return CircularBuffer(_s); }                       // BufferWriterLike (Buffer.hpp:88-95)
+        [[nodiscard]] std::size_t    nRequestedSamplesToPublish() const noexcept { return _published; } // what the last publish() handed to the readers
         [[nodiscard]] std::size_t available() const { return _s->cap - (_s->wr.load(std::memory_order_relaxed) - _s->min_read()); }
         // device span of n elements at the write cursor, contiguous even across the physical end; empty span if the readers are behind
         [[nodiscard]] std::span<T> tryReserve(std::size_t n) {
@@ -845,25 +849,35 @@ public:
         }
         void publish(std::size_t n) {
             if (n > _reserved) throw std::runtime_error("gr::hip::CircularBuffer: publish exceeds reservation");
-            _reserved = 0;
+            _reserved  = 0;
+            _published = n;
             _s->wr.fetch_add(n, std::memory_order_release);
         }
     };
     class Reader {
         std::shared_ptr<State>                    _s;
         std::shared_ptr<std::atomic<std::size_t>> _rd;
+        mutable bool                              _consume_requested = false; // since the last get()
+        std::size_t                               _consumed = 0;              // by the last consume()
         friend class CircularBuffer;
         Reader(std::shared_ptr<State> s, std::shared_ptr<std::atomic<std::size_t>> rd) : _s(std::move(s)), _rd(std::move(rd)) {}
 
     public:
+        [[nodiscard]] CircularBuffer buffer() const { return CircularBuffer(_s); }                                    // BufferReaderLike (Buffer.hpp:78-86)
+        [[nodiscard]] std::size_t    position() const noexcept { return _rd->load(std::memory_order_relaxed); }       // absolute read cursor (elements)
+        [[nodiscard]] std::size_t    nSamplesConsumed() const noexcept { return _consumed; }
+        [[nodiscard]] bool           isConsumeRequested() const noexcept { return _consume_requested; }
         [[nodiscard]] std::size_t available() const { return _s->wr.load(std::memory_order_acquire) - _rd->load(std::memory_order_relaxed); }
         [[nodiscard]] std::span<const T> get(std::size_t n) const {
-            n = std::min(n, available());
+            n                  = std::min(n, available());
+            _consume_requested = false;
             return {_s->base + _rd->load(std::memory_order_relaxed) % _s->cap, n};
         }
         [[nodiscard]] bool consume(std::size_t n) {
             if (n > available()) return false;
             _rd->fetch_add(n, std::memory_order_release);
+            _consumed          = n;
+            _consume_requested = true;
             return true;
         }
     };

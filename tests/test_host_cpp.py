@@ -58,6 +58,16 @@ def test_reference_block_headers_compile_unmodified(tmp_path):
     assert "#include <gnuradio-4.0/math/Math.hpp>" in src and "struct MathOpImpl" not in src
 
 
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="container-only: needs the reference tree where it lies (nothing of it travels)")
+def test_hbm_ring_models_the_reference_bufferlike_concept():
+    """the reference's own BufferLike / BufferReaderLike / BufferWriterLike concepts (core/include/gnuradio-4.0/Buffer.hpp:78-102, included
+    unmodified from /root/reference; std-only header) hold for gr::hip::CircularBuffer<T> (static_asserts in host/tests/test_reference_bufferlike.cpp)"""
+    cmd = ["g++", "-std=c++20", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "gnuradio4_amd", "host", "include"), "-I" + os.path.join(REFERENCE, "core", "include"),
+           os.path.join(ROOT, "gnuradio4_amd", "host", "tests", "test_reference_bufferlike.cpp")]
+    c = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stderr[-4000:]
+
+
 def _inputs(tmp_path, N, frames, ntaps):
     x = O.signal_c32(42, frames * N)
     b = O.design_taps_hamming_lowpass(ntaps, 0.1)
