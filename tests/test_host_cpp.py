@@ -66,6 +66,10 @@ def test_hbm_ring_models_the_reference_bufferlike_concept():
            os.path.join(ROOT, "gnuradio4_amd", "host", "tests", "test_reference_bufferlike.cpp")]
     c = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert c.returncode == 0, c.stderr[-4000:]
+    # and the C-ABI's status codes against the reference's own WorkStatus.hpp (include/gr4hip.h: "status codes reuse gr::work::Status values")
+    c = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-w", "-I" + os.path.join(REFERENCE, "core", "include"),
+                        os.path.join(ROOT, "gnuradio4_amd", "host", "tests", "test_reference_workstatus.cpp")], capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stderr[-4000:]
 
 
 def _inputs(tmp_path, N, frames, ntaps):
