@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--log2-chunk", type=int, default=28, help="samples per launch")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 unfused, 3 fused frequency-domain, 4 time domain")
     ap.add_argument("--fanin-cus", type=int, default=32, help="N > 1: CUs left to the RCCL fan-in kernels (the fused kernel is persistent and fills every CU it gets)")
+    ap.add_argument("--fanin-algo", default="auto", choices=["auto", "reduce_scatter", "all_to_all"],
+                    help="N > 1: how the partial sums cross xGMI (gnuradio4_amd/fanin.py); auto = both are timed before the warm-up, the faster one runs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check of the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of sampled output frames")
@@ -182,13 +184,35 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nchunks)]
     done = [[torch.cuda.Event() for _ in mine] for _ in range(2)]
     main_stream = torch.cuda.current_stream()
+    # the fan-in of launch c runs on its own stream beside the chains of launch c + 1; slab c & 1 is free again when its fan-in has finished
+    fan_stream = torch.cuda.Stream() if world > 1 else None
+    fan_done = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
+    recv = torch.empty((frames_per_chunk, NFFT), dtype=torch.float32, device="cuda") if world > 1 else None  # all_to_all landing area
+    fanin_algo = args.fanin_algo if args.fanin_algo != "auto" else "reduce_scatter"
+    fanin_probe = None
+    if world > 1 and args.fanin_algo == "auto":
+        # which collective the node's RCCL moves faster is measured, not assumed: three fan-ins of a launch-sized slab each, max over ranks
+        probe_src = torch.zeros((frames_per_chunk, NFFT), dtype=torch.float32, device="cuda")
+        fanin_probe = {}
+        for algo in ("reduce_scatter", "all_to_all"):
+            fanin.fan_in_sum(probe_src, rs_out[0], algo=algo, recv=recv)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fanin.fan_in_sum(probe_src, rs_out[0], algo=algo, recv=recv)
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fanin_probe[algo] = float(t.item())
+        fanin_algo = min(fanin_probe, key=fanin_probe.get)  # the same numbers on every rank: the same choice
+        del probe_src
 
     def step(record: bool):
         # (no reset between steps: the stream simply continues, the FIR history of a step's first frame is the previous step's tail)
         if len(mine) > 1:  # a channel stream must not overwrite a slice the previous step's fold still reads
             for s in streams:
                 s.wait_stream(main_stream)
-        works = []
         for c in range(nchunks):
             fr = slice(c * frames_per_chunk, (c + 1) * frames_per_chunk)
             for i, ch in enumerate(chains):  # every channel on its own stream
@@ -205,17 +229,19 @@ def main():
             if len(mine) > 1:  # local part of math::Add over the channels: ONE n-ary fold (left fold order, Math.hpp:100-107)
                 for e in done[c & 1]:
                     main_stream.wait_event(e)
-                if world > 1 and c >= 2 and works[c - 2] is not None:
-                    works[c - 2].wait()  # the collective that read this slab two launches ago
+                if world > 1 and c >= 2:
+                    main_stream.wait_event(fan_done[c & 1])  # the fan-in that read this slab two launches ago
                 dst = sum_out[fr] if world == 1 else acc[c & 1]
                 G.math_nary("Add", [o[fr] for o in outs], out=dst)
             else:
                 dst = outs[0][fr]
-            if world > 1:  # the one exchange step: reduce_scatter(sum) of this launch's spectra, async on RCCL's stream
-                works.append(fanin.fan_in_sum(dst, rs_out[c], async_op=True)[1])
-        for wk in works:
-            if wk is not None:
-                wk.wait()
+            if world > 1:  # the one exchange step: this launch's partial sums cross xGMI while the next launch computes
+                fan_stream.wait_stream(main_stream)
+                with torch.cuda.stream(fan_stream):
+                    fanin.fan_in_sum(dst, rs_out[c], algo=fanin_algo, recv=recv)
+                    fan_done[c & 1].record()
+        if world > 1:
+            main_stream.wait_stream(fan_stream)
         if len(mine) > 1:
             for s in streams:
                 main_stream.wait_stream(s)
@@ -306,7 +332,8 @@ def main():
             # after the local fold a GPU holds ONE partial-sum stream for its per_gpu channels; the reduce_scatter sends (N-1)/N of it
             # out, 1/N to each peer over that peer's link: 4 B x (N-1)/N per frame bin = per per_gpu input samples
             egress = 4.0 * (world - 1) / world / per_gpu
-            res["fanin"] = {"collective": "reduce_scatter(sum, f32)" if args.dist_backend == "nccl" else f"{args.dist_backend} all_reduce + slice (functional check)",
+            res["fanin"] = {"collective": (fanin_algo + "(f32)" if args.dist_backend == "nccl" else f"{fanin_algo} on {args.dist_backend}, staged through the host (functional check)"),
+                            "probe_seconds_per_launch": fanin_probe,
                             "xgmi_egress_bytes_per_input_sample": round(egress, 4),
                             "xgmi_ceiling_msamples": round(world * (world - 1) * XGMI_LINK_GBS * 1e9 / egress / 1e6, 1),
                             "note": "ceiling = N GPUs x (N-1) links x 153 GB/s nominal per direction / egress bytes per input sample; the collective of launch c overlaps the transforms of launch c+1"}

@@ -2,8 +2,9 @@
 
 The flowgraph shards only across independent branches: channel c -> rank c mod world.  The one exchange step is the
 combiner `gr::blocks::math::Add<float>` with n_inputs = channels (blocks/math/.../Math.hpp:73-108) that sums frame-aligned |X|^2
-vectors; across GPUs it is an RCCL reduce_scatter (every rank reduces 1/world of the frames, all xGMI links busy both ways) instead
-of a reduce-to-root.  Backend "nccl" is RCCL on ROCm; "gloo" (CPU tests) has no reduce_scatter and takes all_reduce + slice.
+vectors; across GPUs every rank ends up with 1/world of the frames of the sum (never a reduce-to-root): an RCCL reduce_scatter, or an
+all_to_all of the shards (one xGMI link per peer) folded in rank order -- see fan_in_sum.  Backend "nccl" is RCCL on ROCm; "gloo" (CPU tests,
+several ranks on one GPU) is the functional stand-in, staged through the host.
 """
 from __future__ import annotations
 
@@ -40,15 +41,36 @@ def local_sum(channels: List[torch.Tensor], out: Optional[torch.Tensor] = None) 
     return acc
 
 
-def fan_in_sum(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None, async_op: bool = False):
+def fan_in_sum(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None, async_op: bool = False, algo: str = "reduce_scatter",
+               recv: Optional[torch.Tensor] = None):
     """Sum `local` ([frames, fft_size] mag2 of this rank's channels) over all ranks; every rank keeps its shard of the frames.
-    Returns (shard, work-or-None)."""
+    Returns (shard, work-or-None).  Two ways to move the same (N-1)/N of every rank's partial sum:
+      "reduce_scatter"  one RCCL reduce_scatter(sum)
+      "all_to_all"      every rank sends shard j of its partial sum straight to rank j (all_to_all_single: one xGMI link per peer, all of them busy at once --
+                        xGMI is point-to-point, not a switch) and folds the `world` shards it received in RANK ORDER with the library's n-ary Add: the same
+                        left fold on every rank, so the result does not depend on the collective's internal reduction order.  `recv`: scratch of local's shape.
+    Which one is faster is a property of the node's RCCL; bench.py measures both before the timed region and keeps the faster (--fanin-algo auto)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = shard_frames(local.shape[0], world, rank)
     if out is None:
         out = torch.empty((hi - lo,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if dist.get_backend(group) == "gloo":  # functional path (CPU tests, several ranks on one GPU): same result, staged through the host
+    gloo = dist.get_backend(group) == "gloo"  # functional path (CPU tests, several ranks on one GPU): same result, staged through the host
+    if algo == "all_to_all":
+        if recv is None:
+            recv = torch.empty_like(local)
+        if gloo:
+            src, dst = local.detach().to("cpu", copy=True).contiguous(), torch.empty(local.shape, dtype=local.dtype)
+            dist.all_to_all_single(dst.reshape(-1), src.reshape(-1), group=group)
+            recv.copy_(dst)
+        else:
+            dist.all_to_all_single(recv.reshape(-1), local.reshape(-1), group=group)
+        per = hi - lo
+        local_sum([recv[j * per:(j + 1) * per] for j in range(world)], out=out)
+        return out, None
+    if algo != "reduce_scatter":
+        raise ValueError(f"unknown fan-in algorithm '{algo}'")
+    if gloo:
         tmp = local.detach().to("cpu", copy=True)
         dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group, async_op=False)
         out.copy_(tmp[lo:hi])

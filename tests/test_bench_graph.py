@@ -43,12 +43,18 @@ def test_bench_eight_channel_graph_one_gpu():
     assert r["verify"]["verified_frames"] >= 8 and r["verify"]["max_rel_err"] <= 1e-5
 
 
-def test_bench_two_ranks_share_the_gpu_gloo_fanin():
+@pytest.mark.parametrize("algo", ["auto", "reduce_scatter", "all_to_all"])
+def test_bench_two_ranks_share_the_gpu_gloo_fanin(algo):
+    """auto: both fan-in algorithms are timed before the warm-up and the faster one runs (the choice is the same on every rank)"""
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
               "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--log2-samples", "24",
-              "--steps", "2", "--warmup", "1"])
+              "--steps", "2", "--warmup", "1", "--fanin-algo", algo])
     assert r["n_gpus"] == 2 and r["config"]["channels"] == 8 and r["scaling"] == "strong"
     assert "4 per GPU" in r["config"]["parallelism"]
     assert r["fanin"]["xgmi_ceiling_msamples"] > 0
+    if algo == "auto":
+        assert set(r["fanin"]["probe_seconds_per_launch"]) == {"reduce_scatter", "all_to_all"} and r["fanin"]["collective"].split(" ")[0] in ("reduce_scatter", "all_to_all")
+    else:
+        assert r["fanin"]["collective"].startswith(algo)
     v = r["verify"]  # rank 0's shard of the 8-channel sum vs the oracle's sum of the eight channels' spectra
     assert v["verified_frames"] >= 3 and v["max_rel_err"] <= 1e-5

@@ -30,6 +30,8 @@ def _worker(rank, world, port, frames, n, q):
         assert work is None
         lo, hi = fanin.shard_frames(frames, world, rank)
         want = allch.sum(dim=0)[lo:hi]
+        shard2, _ = fanin.fan_in_sum(mine, algo="all_to_all")  # shards sent peer to peer, folded in rank order: the same sums
+        assert float((shard2 - want).abs().max()) <= 1e-5 * float(want.abs().max()) and shard2.shape == shard.shape
         q.put((rank, float((shard - want).abs().max()), float(want.abs().max()), plan[rank], (lo, hi)))
     finally:
         dist.destroy_process_group()
