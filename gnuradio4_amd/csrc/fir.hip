@@ -155,7 +155,7 @@ struct FirDecimFd;
 int  fir_decim_fd_supported(size_t ntaps, size_t decim);
 int  fir_decim_fd_create(FirDecimFd** out, const float* taps, size_t ntaps);
 void fir_decim_fd_destroy(FirDecimFd* c);
-int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, const float* d_hist1024, size_t n_blocks, float* d_out, hipStream_t st);
+int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st);
 
 // fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out);
@@ -378,22 +378,18 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         done = n_in;
     }
     // float, decimate by 8, <= 1024 taps, long 16-byte-aligned span: overlap-save blocks of 8192 samples in the frequency domain (~35 lane-operations per
-    // input sample instead of 2 K / 8 flop: HBM / power-bound instead of FP32-bound); the remainder (< 7168 samples) takes the kernels below
+    // input sample instead of 2 K / 8 flop: HBM / power-bound instead of FP32-bound); a partial last block rides in the same launch
     constexpr size_t kDfHopS = 7168, kDfMinBlocks = 64;
     if (f->S == 1 && f->algo == GR4HIP_FIR_AUTO && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 && n_in >= kDfMinBlocks * kDfHopS &&
         (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && !std::getenv("GR4HIP_FIR_NO_DECIM_FD")) {
         int rc = GR4HIP_OK;
         if (!f->dfd) rc = fir_decim_fd_create(&f->dfd, f->taps.data(), f->ntaps);
-        if (!rc) rc = f->d_hist256.ensure(1024 * sizeof(float));
         if (rc) return rc;
-        const int hu = (int)std::min<size_t>(f->hcap, 1024);
-        hipLaunchKernelGGL(fir_hist_widen_kernel<float>, dim3(4), dim3(256), 0, st, hist + (f->hcap - hu), hu, (float*)f->d_hist256.ptr, 1024);
-        GR4_LAUNCH_CHECK();
-        const size_t blocks = n_in / kDfHopS;
-        rc = fir_decim_fd_run(f->dfd, x, (const float*)f->d_hist256.ptr, blocks, y, st);
+        // whole blocks and the span's partial last block in ONE launch (+ one small launch in front that widens the history and stages the partial block):
+        // sending the < 7168 leftover samples through the polyphase kernel cost a 44 us single-workgroup launch behind a 164 us transform kernel
+        rc = fir_decim_fd_run(f->dfd, x, n_in, hist, (int)f->hcap, y, st);
         if (rc) return rc;
-        done = blocks * kDfHopS;
-        hist = x + (done - f->hcap); // the hcap samples in front of the remainder are part of the input itself
+        done = n_in;
     }
     // float polyphase decimator with >= 16 taps per phase and a long span: the same contraction with the D phase products summed in
     // one accumulator tile (BASELINE configs[2]: decim 8, 1024 taps)

@@ -50,6 +50,11 @@ struct DecimFdArgs {
     const float2* twI2;    // [128]  W_1024^{-i''}
     float*        y;       // 896 outputs per block
     long          n_blocks;
+    // a span that is not a whole number of hops: its last, partial block (index tail_blk = n_blocks - 1) is read from a zero-padded staging image of 8192 samples
+    // (FIR causality: the padding cannot reach the valid outputs) and only its first tail_out outputs are stored.  tail_blk < 0: no such block
+    const float*  x_tail;
+    long          tail_blk;
+    int           tail_out;
 };
 
 __device__ __forceinline__ void ifft8(float2 (&v)[8]) { // inverse DFT-8: the forward butterfly on (im, re)
@@ -79,7 +84,7 @@ __device__ __forceinline__ void decim_dma(const DecimFdArgs& a, long blk, unsign
     for (int i = 0; i < 4; ++i) {
         const int    p   = 4 * wave + i;                       // piece: floats [256 p, 256 p + 256) of the block
         const long   pos = blk * kDfHop - kDfV + 256L * p;     // stream position of its first sample
-        const float* src = pos < 0 ? a.hist + (kDfV + pos) : a.x + pos; // (pieces never straddle position 0: 1024 = 4 pieces)
+        const float* src = blk == a.tail_blk ? a.x_tail + 256 * p : pos < 0 ? a.hist + (kDfV + pos) : a.x + pos; // (pieces never straddle position 0: 1024 = 4 pieces)
         dma16_1k(src + 4 * lane, lds_L + 1024u * (unsigned)p);
     }
 }
@@ -203,16 +208,18 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
             mul_powers(v, bI2); // W_1024^{-q i''}
             ifft8(v);
             // valid outputs: i' = i'' + 128 a >= 128, i.e. a = 1..7 -> y[blk * 896 + i' - 128]
-            float* yo = a.y + blk * (kDfHop / 8) + t;
+            float*    yo    = a.y + blk * (kDfHop / 8) + t;
+            const int valid = blk == a.tail_blk ? a.tail_out : kDfHop / 8;
 #pragma unroll
-            for (int aa = 1; aa < 8; ++aa) yo[128 * (aa - 1)] = v[aa].x;
+            for (int aa = 1; aa < 8; ++aa)
+                if (t + 128 * (aa - 1) < valid) yo[128 * (aa - 1)] = v[aa].x;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 struct FirDecimFd {
-    DeviceBuffer d_twX, d_tw1, d_tw2, d_R, d_twI1, d_twI2;
+    DeviceBuffer d_twX, d_tw1, d_tw2, d_R, d_twI1, d_twI2, d_hist1024, d_stage;
 };
 
 static void put_wd(std::vector<float>& v, size_t idx, long num, long den) { // exp(-2 pi i num / den)
@@ -281,9 +288,29 @@ int fir_decim_fd_create(FirDecimFd** out, const float* taps, size_t ntaps) {
 void fir_decim_fd_destroy(FirDecimFd* c) { delete c; }
 
 // n_blocks blocks of 7168 input samples -> 896 outputs each; d_hist1024: the 1024 samples in front of d_in
-int fir_decim_fd_run(FirDecimFd* c, const float* d_in, const float* d_hist1024, size_t n_blocks, float* d_out, hipStream_t st) {
+// ONE small launch in front of the transform kernel: the block's history widened to the 1024 samples the first block reads, and (tail_n > 0) the staging image of
+// the span's last, partial block: stream positions full_blocks * 7168 - 1024 .. + 8191, zeros from n_in on
+__global__ __launch_bounds__(256) void decim_fd_prepare_kernel(const float* __restrict__ hist, int hcap, const float* __restrict__ x, long n_in, long full_blocks, float* __restrict__ hist1024,
+                                                               float* __restrict__ stage, int with_tail) {
+    const int  i   = blockIdx.x * 256 + threadIdx.x; // 0 .. 1023: history; 1024 .. 9215: staging image
+    const auto at  = [&](long pos) -> float { return pos >= n_in ? 0.f : pos >= 0 ? x[pos] : pos >= -(long)hcap ? hist[hcap + pos] : 0.f; };
+    if (i < kDfV) hist1024[i] = at((long)i - kDfV);
+    else if (with_tail && i < kDfV + kDfN) stage[i - kDfV] = at(full_blocks * kDfHop - kDfV + (i - kDfV));
+}
+
+// d_hist: the filter's history (hcap samples in front of d_in); n_in input samples (a multiple of 8): floor(n_in / 7168) whole blocks and, if anything is left, one partial block
+int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st) {
+    const size_t full = n_in / kDfHop, rest = n_in - full * kDfHop;
+    int          rc   = c->d_hist1024.ensure(kDfV * sizeof(float));
+    if (!rc && rest) rc = c->d_stage.ensure(kDfN * sizeof(float));
+    if (rc) return rc;
+    hipLaunchKernelGGL(decim_fd_prepare_kernel, dim3((kDfV + (rest ? kDfN : 0)) / 256), dim3(256), 0, st, d_hist, hcap, d_in, (long)n_in, (long)full, (float*)c->d_hist1024.ptr,
+                       (float*)c->d_stage.ptr, rest ? 1 : 0);
+    GR4_LAUNCH_CHECK();
+    const size_t n_blocks = full + (rest ? 1 : 0);
     DecimFdArgs a{};
-    a.x = d_in; a.hist = d_hist1024;
+    a.x = d_in; a.hist = (const float*)c->d_hist1024.ptr;
+    a.x_tail = (const float*)c->d_stage.ptr; a.tail_blk = rest ? (long)full : -1; a.tail_out = (int)(rest / 8);
     a.twX = static_cast<const float2*>(c->d_twX.ptr); a.tw1 = static_cast<const float2*>(c->d_tw1.ptr); a.tw2 = static_cast<const float2*>(c->d_tw2.ptr);
     a.R = static_cast<const float2*>(c->d_R.ptr); a.twI1 = static_cast<const float2*>(c->d_twI1.ptr); a.twI2 = static_cast<const float2*>(c->d_twI2.ptr);
     a.y = d_out; a.n_blocks = (long)n_blocks;

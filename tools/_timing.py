@@ -8,6 +8,7 @@ import torch
 
 
 def steady(fn, warm_s=0.06, time_s=0.12, min_reps=5):
+    fn()  # set-up (plans, tables, first-use allocations) is not part of the rate, and must not shorten the warm-up below
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 0

@@ -31,4 +31,20 @@ for _ in range(2):
 ch = G.Chain(taps[:256], 8192, "Hann")
 for _ in range(2):
     ch.process_bulk(xc, m2.view(n // 8192, 8192))
+# round 2: interpolating FIR, closed-form rotator, the complex direct form on the matrix pipe, float64 FIR
+it = G.fir_interpolator(taps[:256], 8, torch.float32)
+yi = torch.empty(n, dtype=torch.float32, device="cuda")
+for _ in range(2):
+    it.process_bulk(xr[: n // 8], yi)
+rot = G.Rotator(phase_increment=0.37)
+for _ in range(2):
+    rot.process_bulk(xc)
+ft = G.fir_filter(taps[:256], torch.complex64)
+ft.set_algo(capi.FIR_TIME_DOMAIN)
+for _ in range(2):
+    ft.process_bulk(xc, yc)
+x64 = xr[: n // 4].double()
+f64 = G.fir_filter(taps[:256].astype(np.float64), torch.float64)
+for _ in range(2):
+    f64.process_bulk(x64)
 torch.cuda.synchronize()

@@ -3,7 +3,7 @@
 Per kernel: mean of every counter over its dispatches; FETCH_SIZE / WRITE_SIZE turned into bytes with the gfx950 correction."""
 import collections, csv, glob, re, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_secondary_pmc"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_secondary_pmc.txt"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_secondary_pmc.txt"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sorted(glob.glob(f"{src}/*_counter_collection.csv")):
     for row in csv.DictReader(open(path)):
