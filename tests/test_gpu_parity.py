@@ -601,6 +601,11 @@ def test_fft_large_power_of_two(G, N):
     w = O.window(3, N)
     t2 = np.abs(np.fft.fft(x[:N].astype(np.complex128) * w)) ** 2
     assert _rel(m2[0], t2) <= TOL
+    if N in (16384, 1 << 17):  # float frames through both column-transform variants: the block's real-input outputs
+        xr = np.ascontiguousarray(x.real[:2 * N])
+        out = G.FFT(N, "Hann", dtype=torch.float32).process_bulk(dev(xr))
+        X = np.fft.fft(xr.reshape(2, N).astype(np.float64) * w, axis=1)
+        assert _rel(out["magnitude"].cpu().numpy(), np.abs(X[:, :N // 2]) * 2 / N) <= TOL and _rel(out["re"].cpu().numpy(), X[:, N // 2:].real) <= TOL
 
 
 def test_fft_n16_patterns_golden(G, golden):
