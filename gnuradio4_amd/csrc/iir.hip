@@ -846,14 +846,17 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
     const long    nblocks = ceil_div(n, (long)kIirBS * kIirL);
     if constexpr (MP <= 8) {
         // long span + fading memory: contiguous runs of tiles per workgroup, state carried from tile to tile, warm-up instead of look-back
-        if (f->warm_tiles > 0 && nblocks >= 256 && !std::getenv("GR4HIP_IIR_THREE_PASS") && !std::getenv("GR4HIP_IIR_LOOKBACK")) {
+        // (from 16 tiles on the sequential runs beat the look-back at every span length measured: 2^17 .. 2^27 samples, profiles/r02_iir_rates.txt)
+        if (f->warm_tiles > 0 && nblocks >= 16 && !std::getenv("GR4HIP_IIR_THREE_PASS") && !std::getenv("GR4HIP_IIR_LOOKBACK")) {
             static PerDevice per_device;
             bool             first = false;
             int              dev = -1, n_cu = per_device.current(&first, &dev);
             GR4_REQUIRE(n_cu != 0, "iir: cannot query the current device");
             if (first) { n_cu = -n_cu; per_device.done(dev, n_cu); }
             const long slots = 3L * n_cu; // three resident workgroups per CU (LDS)
-            long       per   = std::max<long>(8L * f->warm_tiles, ceil_div(nblocks, slots));
+            // runs as short as the warm-up itself when the span has fewer tiles than the chip has workgroup slots: half of such a run is warm-up, but every slot
+            // works (measured, 4 biquads: 2^22 / 2^23 / 2^24 samples 207 / 278 / 358 Gsamples/s against 67 / 130 / 248 with runs of >= 8 warm-ups)
+            long       per   = std::max<long>(f->warm_tiles, ceil_div(nblocks, slots));
             IirCoef<ORD, NSEC> cf{};
             for (int s = 0; s < NSEC; ++s)
                 for (int j = 0; j <= ORD; ++j) {

@@ -429,7 +429,7 @@ def test_iir_single_pass_equals_three_pass(G, kind, monkeypatch):
 
 @pytest.mark.parametrize("pole", [0.7, 0.998, 0.999, 0.99999])
 def test_iir_segment_sequential_runs_match_the_lookback_and_the_oracle(G, pole, monkeypatch):
-    """spans of >= 256 tiles take the segment-sequential kernel when the filter's memory fades inside 1, 2 or 4 tiles (poles 0.7 / 0.998 / 0.999 here;
+    """spans of >= 16 tiles take the segment-sequential kernel when the filter's memory fades inside 1, 2 or 4 tiles (poles 0.7 / 0.998 / 0.999 here;
     0.99999 does not and stays on the look-back): same answers as the look-back kernel and the float64 oracle, in two calls so that run 0 of the second
     call starts from the carried state and not from a warm-up"""
     n = (1 << 22) + (1 << 20) + 4321
@@ -441,7 +441,7 @@ def test_iir_segment_sequential_runs_match_the_lookback_and_the_oracle(G, pole, 
         if mode == "lookback":
             monkeypatch.setenv("GR4HIP_IIR_LOOKBACK", "1")
         f = G.iir_filter(b, a)
-        cut = (1 << 21) + 777  # both calls are >= 256 tiles
+        cut = (1 << 21) + 777  # both calls are hundreds of tiles: runs of several tiles behind a warm-up
         out[mode] = np.concatenate([f.process_bulk(dev(x[:cut])).cpu().numpy(), f.process_bulk(dev(x[cut:])).cpu().numpy()])
         f.status()
         assert _rel(out[mode], truth) <= TOL, mode

@@ -9,7 +9,7 @@ import gnuradio4_amd as G
 from gnuradio4_amd import capi
 def rate(f, x, y):
     return x.numel() / steady(lambda: f.process_bulk(x, y)) / 1e9  # back to back at settled clocks (tools/_timing.py)
-for log2n in (24, 26, 27):
+for log2n in [int(v) for v in os.environ.get('IIR_LOG2N', '24,26,27').split(',')]:
     n = 1 << log2n
     x = G.synth_f32(n, seed=1); y = torch.empty_like(x)
     b4, a4 = G.blocks.design_iir(capi.LOWPASS, 8, 0.05, float("nan"), 1.0, capi.BUTTERWORTH)
