@@ -20,7 +20,7 @@ namespace gr4 {
 // (tp[p][q] = b[q*D + p], zero padded); y: n_out samples, y[m] = sum_k b[k] x[m*D - k].
 template <int S, int BS>
 __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ x, const float* __restrict__ hist, const float* __restrict__ tp,
-                                                       float* __restrict__ y, long n_in, long n_out, int hcap, int D, int G) {
+                                                       float* __restrict__ y, long n_in, long n_out, int hcap, int D, int G, float* __restrict__ new_hist) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R  = kFirR;
     constexpr int E  = 4 / S;
@@ -122,6 +122,14 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
         for (int r = 0; r < R; ++r)
             if (of + r < nf) y[of + r] = acc[r];
     }
+    // a span served by this launch alone: workgroup 0 also writes the block's next history (the other half of the ping-pong pair; nobody reads it in this
+    // launch), which saves the separate update launch -- a scheduler's 4 Ki .. 64 Ki-sample work() chunks cost launches, not arithmetic
+    if (new_hist != nullptr && blockIdx.x == 0) {
+        for (int t = tid; t < hcap * S; t += BS) {
+            const long h = t / S, c = t % S, i = n_in - hcap + h;
+            new_hist[t]  = (i >= 0) ? x[i * S + c] : hist[(hcap + i) * S + c];
+        }
+    }
 }
 
 // new_hist[h] = virtual_input[n_in - hcap + h]  (virtual_input(i<0) = old_hist[hcap + i])
@@ -159,8 +167,8 @@ int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float
 
 // fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out);
-int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st);
-int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st);
+int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st, float* new_hist);
+int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
 
@@ -228,13 +236,13 @@ static int fir_alloc_hist(gr4hip_fir* f) {
 }
 
 template <int S, int BS>
-static int fir_launch(const gr4hip_fir* f, const float* x, const float* hist, float* y, long n_in, long n_out, size_t lds, hipStream_t st) {
+static int fir_launch(const gr4hip_fir* f, const float* x, const float* hist, float* y, long n_in, long n_out, size_t lds, hipStream_t st, float* new_hist) {
     auto kern = fir_poly_kernel<S, BS>;
     if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long TOs  = BS * kFirR / S;
     const long grid = ceil_div(n_out, TOs);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, st, x, hist, (const float*)f->d_taps.ptr, y, n_in, n_out,
-                       (int)f->hcap, (int)f->decim, f->G);
+                       (int)f->hcap, (int)f->decim, f->G, new_hist);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
@@ -305,6 +313,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     float*       y    = static_cast<float*>(d_out);
     const float* hist = (const float*)f->d_hist[f->cur].ptr;
     size_t       done = 0; // samples already produced by the frequency-domain path
+    bool         mfma_wrote_hist = false;
     // complex<float>, no decimation, <= 256 taps, long input: whole 8192-sample frames go through the fused FFT -> xH -> inverse
     // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
     if (f->S == 2 && f->decim == 1 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
@@ -350,13 +359,19 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
             if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->mKS = 0; return rc; }
         }
-        rc = f->d_histc.ensure(256 * sizeof(float2));
-        if (rc) return rc;
-        hipLaunchKernelGGL(fir_hist_widen_kernel<float2>, dim3(1), dim3(256), 0, st, (const float2*)hist, (int)f->hcap, (float2*)f->d_histc.ptr, f->mKp);
-        GR4_LAUNCH_CHECK();
-        rc = fir_mfma_c32_launch(f->mKS, x + done * 2, (long)(n_in - done), (const float*)f->d_histc.ptr, (const float*)f->d_afrag.ptr, y + done * 2, st);
+        const float* hk = hist; // (hcap = bit_ceil(ntaps) is Kp for 33 .. 256 taps: read in place; a span served by this launch alone also gets its next history from it)
+        if ((int)f->hcap != f->mKp) {
+            rc = f->d_histc.ensure(256 * sizeof(float2));
+            if (rc) return rc;
+            hipLaunchKernelGGL(fir_hist_widen_kernel<float2>, dim3(1), dim3(256), 0, st, (const float2*)hist, (int)f->hcap, (float2*)f->d_histc.ptr, f->mKp);
+            GR4_LAUNCH_CHECK();
+            hk = (const float*)f->d_histc.ptr;
+        }
+        float* nh = (done == 0 && (int)f->hcap == f->mKp) ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
+        rc = fir_mfma_c32_launch(f->mKS, x + done * 2, (long)(n_in - done), hk, (const float*)f->d_afrag.ptr, y + done * 2, st, nh);
         if (rc) return rc;
         done = n_in;
+        mfma_wrote_hist = nh != nullptr;
     }
     // float, no decimation, 33..256 taps, long 16-byte-aligned output: block-Toeplitz product on the f32 MFMA units (about twice the
     // rate of the register-window VALU kernel, which is FP32-issue bound from ~48 taps on)
@@ -369,13 +384,21 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
             if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->mKS = 0; return rc; }
         }
-        rc = f->d_hist256.ensure(256 * sizeof(float2));
-        if (rc) return rc;
-        hipLaunchKernelGGL(fir_hist_widen_kernel<float>, dim3(1), dim3(256), 0, st, hist, (int)f->hcap, (float*)f->d_hist256.ptr, f->mKp);
-        GR4_LAUNCH_CHECK();
-        rc = fir_mfma_launch(f->mKS, x, (long)n_in, (const float*)f->d_hist256.ptr, (const float*)f->d_afrag.ptr, y, (long)((n_in + 3) & ~(size_t)3), (long)n_in, 1, st);
+        // hcap = bit_ceil(ntaps) IS Kp for 33 .. 256 taps: the block's history is read as it lies, and the launch writes the next one (one launch per call
+        // instead of three: what a scheduler's 64 Ki-sample chunks cost is launches)
+        const float* hk = hist;
+        if ((int)f->hcap != f->mKp) {
+            rc = f->d_hist256.ensure(256 * sizeof(float2));
+            if (rc) return rc;
+            hipLaunchKernelGGL(fir_hist_widen_kernel<float>, dim3(1), dim3(256), 0, st, hist, (int)f->hcap, (float*)f->d_hist256.ptr, f->mKp);
+            GR4_LAUNCH_CHECK();
+            hk = (const float*)f->d_hist256.ptr;
+        }
+        float* nh = (int)f->hcap == f->mKp ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
+        rc = fir_mfma_launch(f->mKS, x, (long)n_in, hk, (const float*)f->d_afrag.ptr, y, (long)((n_in + 3) & ~(size_t)3), (long)n_in, 1, st, nh);
         if (rc) return rc;
         done = n_in;
+        mfma_wrote_hist = nh != nullptr;
     }
     // float, decimate by 8, <= 1024 taps, long 16-byte-aligned span: overlap-save blocks of 8192 samples in the frequency domain (~35 lane-operations per
     // input sample instead of 2 K / 8 flop: HBM / power-bound instead of FP32-bound); a partial last block rides in the same launch
@@ -415,6 +438,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     }
     const int E  = 4 / f->S;
     int       rc = done == n_in ? GR4HIP_OK : GR4HIP_UNSUPPORTED;
+    bool      hist_written = mfma_wrote_hist;
     for (int bs : {256, 128, 64}) {
         if (done == n_in) break;
         const size_t Lf  = (size_t)bs * kFirR + 4 * (size_t)f->G;
@@ -423,16 +447,20 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         const float* xr = x + done * f->S;
         float*       yr = y + (done / f->decim) * f->S;
         const long   ni = (long)(n_in - done), no = (long)((n_in - done) / f->decim);
-        if (f->S == 1) rc = bs == 256 ? fir_launch<1, 256>(f, xr, hist, yr, ni, no, lds, st) : bs == 128 ? fir_launch<1, 128>(f, xr, hist, yr, ni, no, lds, st) : fir_launch<1, 64>(f, xr, hist, yr, ni, no, lds, st);
-        else rc = bs == 256 ? fir_launch<2, 256>(f, xr, hist, yr, ni, no, lds, st) : bs == 128 ? fir_launch<2, 128>(f, xr, hist, yr, ni, no, lds, st) : fir_launch<2, 64>(f, xr, hist, yr, ni, no, lds, st);
+        float*       nh = done == 0 ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr; // the whole span in this launch: it writes the next history itself
+        if (f->S == 1) rc = bs == 256 ? fir_launch<1, 256>(f, xr, hist, yr, ni, no, lds, st, nh) : bs == 128 ? fir_launch<1, 128>(f, xr, hist, yr, ni, no, lds, st, nh) : fir_launch<1, 64>(f, xr, hist, yr, ni, no, lds, st, nh);
+        else rc = bs == 256 ? fir_launch<2, 256>(f, xr, hist, yr, ni, no, lds, st, nh) : bs == 128 ? fir_launch<2, 128>(f, xr, hist, yr, ni, no, lds, st, nh) : fir_launch<2, 64>(f, xr, hist, yr, ni, no, lds, st, nh);
+        hist_written = nh != nullptr && rc == GR4HIP_OK;
         break;
     }
     if (rc == GR4HIP_UNSUPPORTED) { set_error("fir_process: ntaps=%zu decim=%zu does not fit the LDS tiling", f->ntaps, f->decim); return rc; }
     if (rc) return rc;
-    const long tot = (long)f->hcap * f->S;
-    hipLaunchKernelGGL(fir_hist_update_kernel, dim3((unsigned)ceil_div(tot, 256L)), dim3(256), 0, st, static_cast<const float*>(d_in),
-                       (const float*)f->d_hist[f->cur].ptr, (float*)f->d_hist[f->cur ^ 1].ptr, (long)n_in, (int)f->hcap, f->S);
-    GR4_LAUNCH_CHECK();
+    if (!hist_written) {
+        const long tot = (long)f->hcap * f->S;
+        hipLaunchKernelGGL(fir_hist_update_kernel, dim3((unsigned)ceil_div(tot, 256L)), dim3(256), 0, st, static_cast<const float*>(d_in),
+                           (const float*)f->d_hist[f->cur].ptr, (float*)f->d_hist[f->cur ^ 1].ptr, (long)n_in, (int)f->hcap, f->S);
+        GR4_LAUNCH_CHECK();
+    }
     f->cur ^= 1;
     return GR4HIP_OK;
 }

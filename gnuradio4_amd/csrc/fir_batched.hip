@@ -21,7 +21,7 @@ constexpr int kSegPerWg = 4;  // consecutive segments per workgroup
 
 template <int KS> // K-steps of 4: Kp = 4 KS - 16
 __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__ x, long in_stride, const float* __restrict__ hist, const float* __restrict__ afrag,
-                                                        float* __restrict__ y, long out_stride, long n) {
+                                                        float* __restrict__ y, long out_stride, long n, float* __restrict__ new_hist /*single stream: the next Kp-sample history, or null*/) {
     constexpr int Kp   = 4 * KS - 16;
     constexpr int NPAD = (kSeg + Kp) / 16 * 18; // two pad floats per 16 samples: block stride 18 = 2 mod 32 banks, so the 32 lanes (16 blocks x 2 K
                                                 // offsets) of a ds_read_b32 group hit 32 different banks (stride 17 puts two of them on one)
@@ -92,6 +92,12 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__
         }
         __syncthreads(); // every wave is done with the staged segment before the next one overwrites it
     }
+    if (new_hist != nullptr && blockIdx.x == 0 && blockIdx.y == 0) { // (the other half of the caller's ping-pong pair: nobody reads it in this launch)
+        for (int h = tid; h < Kp; h += 256) {
+            const long i = n - Kp + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kp + i];
+        }
+    }
 }
 
 // fir_filter<complex<float>> (real taps on interleaved {re, im} samples) on the same scheme: the two components are two real streams under the same
@@ -100,7 +106,8 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const float* __restrict__
 // per segment (the same 4096 real outputs and the same LDS footprint as fir_mfma_kernel).  hist: the Kp complex samples in front of x.
 constexpr int kSegC = 2048;
 template <int KS>
-__global__ __launch_bounds__(256) void fir_mfma_c32_kernel(const float2* __restrict__ x, const float2* __restrict__ hist, const float* __restrict__ afrag, float2* __restrict__ y, long n) {
+__global__ __launch_bounds__(256) void fir_mfma_c32_kernel(const float2* __restrict__ x, const float2* __restrict__ hist, const float* __restrict__ afrag, float2* __restrict__ y, long n,
+                                                            float2* __restrict__ new_hist /*the next Kp-sample history, or null*/) {
     constexpr int Kp   = 4 * KS - 16;
     constexpr int NPAD = (kSegC + Kp) / 16 * 18 + 16; // per plane; + 16: the two planes sit 16 banks apart, so the re / im halves of a staged lane pair do not collide
     constexpr int NL   = (kSegC + Kp + 255) / 256;    // complex samples a lane holds for the next segment
@@ -164,6 +171,12 @@ __global__ __launch_bounds__(256) void fir_mfma_c32_kernel(const float2* __restr
             }
         }
         __syncthreads();
+    }
+    if (new_hist != nullptr && blockIdx.x == 0) {
+        for (int h = tid; h < Kp; h += 256) {
+            const long i = n - Kp + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kp + i];
+        }
     }
 }
 
@@ -301,26 +314,27 @@ void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_ou
 }
 
 // y[c][i] = sum_k b_c[k] x[c][i - k], i < n; hist[c][Kp] = the Kp samples in front of x[c]; y must be 16-byte aligned, out_stride % 4 == 0
-int fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st) {
+int fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st, float* new_hist) {
     const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kSeg), (long)kSegPerWg), nch);
     switch (KS) {
-    case 20: hipLaunchKernelGGL(fir_mfma_kernel<20>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
-    case 36: hipLaunchKernelGGL(fir_mfma_kernel<36>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
-    default: hipLaunchKernelGGL(fir_mfma_kernel<68>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n); break;
+    case 20: hipLaunchKernelGGL(fir_mfma_kernel<20>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n, new_hist); break;
+    case 36: hipLaunchKernelGGL(fir_mfma_kernel<36>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n, new_hist); break;
+    default: hipLaunchKernelGGL(fir_mfma_kernel<68>, grid, dim3(256), 0, st, x, in_stride, hist, afrag, y, out_stride, n, new_hist); break;
     }
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
 
 // y[i] = sum_k b[k] x[i - k] on complex samples; hist = the Kp complex samples in front of x; y must be 16-byte aligned
-int fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st) {
+int fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st, float* new_hist) {
     const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kSegC), (long)kSegPerWg));
     const auto xc = reinterpret_cast<const float2*>(x), hc = reinterpret_cast<const float2*>(hist);
     const auto yc = reinterpret_cast<float2*>(y);
+    const auto nh = reinterpret_cast<float2*>(new_hist);
     switch (KS) {
-    case 20: hipLaunchKernelGGL(fir_mfma_c32_kernel<20>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n); break;
-    case 36: hipLaunchKernelGGL(fir_mfma_c32_kernel<36>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n); break;
-    default: hipLaunchKernelGGL(fir_mfma_c32_kernel<68>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n); break;
+    case 20: hipLaunchKernelGGL(fir_mfma_c32_kernel<20>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n, nh); break;
+    case 36: hipLaunchKernelGGL(fir_mfma_c32_kernel<36>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n, nh); break;
+    default: hipLaunchKernelGGL(fir_mfma_c32_kernel<68>, grid, dim3(256), 0, st, xc, hc, afrag, yc, n, nh); break;
     }
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
@@ -407,7 +421,7 @@ int gr4hip_fir_batched_process(gr4hip_fir_batched_t* f, const float* d_in, size_
     GR4_REQUIRE(((uintptr_t)d_out % 16 == 0) && (out_stride % 4 == 0), "fir_batched_process: output must be 16-byte aligned with a stride multiple of 4");
     hipStream_t st = as_stream(stream);
     const float *hist = (const float*)f->d_hist[f->cur].ptr, *af = (const float*)f->d_afrag.ptr;
-    int          rc   = fir_mfma_launch(f->KS, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n, (unsigned)f->nch, st);
+    int          rc   = fir_mfma_launch(f->KS, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n, (unsigned)f->nch, st, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(fir_batched_hist_kernel, dim3((unsigned)ceil_div(f->Kp, 64), (unsigned)f->nch), dim3(64), 0, st, d_in, (long)in_stride, hist,
                        (float*)f->d_hist[f->cur ^ 1].ptr, (long)n, f->Kp);

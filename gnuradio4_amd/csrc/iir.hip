@@ -847,7 +847,7 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
     if constexpr (MP <= 8) {
         // long span + fading memory: contiguous runs of tiles per workgroup, state carried from tile to tile, warm-up instead of look-back
         // (from 16 tiles on the sequential runs beat the look-back at every span length measured: 2^17 .. 2^27 samples, profiles/r02_iir_rates.txt)
-        if (f->warm_tiles > 0 && nblocks >= 16 && !std::getenv("GR4HIP_IIR_THREE_PASS") && !std::getenv("GR4HIP_IIR_LOOKBACK")) {
+        if (f->warm_tiles > 0 && nblocks >= 1 && !std::getenv("GR4HIP_IIR_THREE_PASS") && !std::getenv("GR4HIP_IIR_LOOKBACK")) {
             static PerDevice per_device;
             bool             first = false;
             int              dev = -1, n_cu = per_device.current(&first, &dev);
