@@ -652,12 +652,13 @@ struct IirSeqArgs {
 };
 
 template <int ORD, int NSEC>
-__global__ __launch_bounds__(kIirBS) void iir_seq_kernel(IirSeqArgs a, IirCoef<ORD, NSEC> coef) {
+__global__ __launch_bounds__(kIirBS, 4) void iir_seq_kernel(IirSeqArgs a, IirCoef<ORD, NSEC> coef) {
     constexpr int MP = ORD * NSEC;
     static_assert(MP <= 8, "tables are sized for MP <= 8");
     __shared__ float tile[kIirBS * (kIirL + 1)];
     __shared__ __attribute__((aligned(16))) float pl[kIirRounds * MP * MP];
-    __shared__ float p16[16 * MP * MP], plr[16 * MP * MP];
+    const float* __restrict__ p16 = a.pl16; // Phi_L^{16 a} and Phi_L^r stay in global memory (L1 / L2 resident, read a few times per tile): the 8 KiB they took
+    const float* __restrict__ plr = a.plr;  // in LDS were what kept a fourth workgroup off the CU
     __shared__ float wv[4 * 16 * MP];
     __shared__ float wz[4 * MP], Tw[4 * MP], Tcar[MP];
     const int  c = threadIdx.x, lane = c & 63, wave = c >> 6;
@@ -665,10 +666,6 @@ __global__ __launch_bounds__(kIirBS) void iir_seq_kernel(IirSeqArgs a, IirCoef<O
     const long t0 = (long)blockIdx.x * a.tiles_per_wg, t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
     if (t0 >= ntiles) return;
     iir_load_phi<MP, kIirRounds>(pl, a.phi);
-    for (int e = c; e < 16 * MP * MP; e += kIirBS) {
-        p16[e] = a.pl16[e];
-        plr[e] = a.plr[e];
-    }
     long tb = t0 - a.warm_tiles;
     if (c < MP) Tcar[c] = tb <= 0 ? a.state_in[c] : 0.f; // the first run starts from the handle's carried state, exactly
     if (tb < 0) tb = 0;
@@ -853,7 +850,7 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
             int              dev = -1, n_cu = per_device.current(&first, &dev);
             GR4_REQUIRE(n_cu != 0, "iir: cannot query the current device");
             if (first) { n_cu = -n_cu; per_device.done(dev, n_cu); }
-            const long slots = 3L * n_cu; // three resident workgroups per CU (LDS)
+            const long slots = 4L * n_cu; // four resident workgroups per CU (LDS 38.7 KB, <= 128 VGPRs)
             // runs as short as the warm-up itself when the span has fewer tiles than the chip has workgroup slots: half of such a run is warm-up, but every slot
             // works (measured, 4 biquads: 2^22 / 2^23 / 2^24 samples 207 / 278 / 358 Gsamples/s against 67 / 130 / 248 with runs of >= 8 warm-ups)
             long       per   = std::max<long>(f->warm_tiles, ceil_div(nblocks, slots));
