@@ -761,7 +761,9 @@ __global__ __launch_bounds__(kIirBS, 4) void iir_seq_kernel(IirSeqArgs a, IirCoe
                     st[s][j] = t;
                 }
         }
-        // ---- 4. re-run from the true start state
+        // ---- 4. re-run from the true start state.  (Tried instead: keep the zero-state outputs of pass 1 and add the homogeneous response y[k] += sum_j C[k][j] s0[j],
+        //      MP multiply-adds per sample with C from scalar loads: 13 % SLOWER at 4 biquads, 3 % at one pole -- the 32 extra LDS writes of pass 1 and the
+        //      scalar-load waits in the loop cost more than the second cascade run.)
         const long cbeg = base + (long)c * kIirL;
         const int  len  = (int)(a.n - cbeg < kIirL ? (a.n - cbeg < 0 ? 0 : a.n - cbeg) : kIirL);
         if (len == kIirL) {
