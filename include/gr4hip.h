@@ -162,6 +162,10 @@ int gr4hip_decimate(int dtype, const void* d_in, size_t n_in, size_t decim, void
  * All four forms compute the same transfer function from zero state and are EVALUATED as direct form II (the parallel-in-time scan works on the DF-II
  * state); `form` is recorded for introspection only, so rounding can differ from the reference's DF_I / transposed forms in the last bits (the four forms
  * agree to 1e-5 upstream too, qa_filter.cpp:53-128).
+ * Evaluation: when the cascade's memory fades within 1, 2 or 4 tiles of 8192 samples (||Phi^tiles||_inf <= 1e-8, checked in float64 at create), a span is cut
+ * into contiguous runs of tiles that start from a warm-up over the preceding tiles instead of the exact state: the state a run starts from is within 1e-8
+ * (relative to the state that far back) of the exact one -- three orders below the float32 parity tolerance; the first run of every call starts from the
+ * handle's carried state exactly.  Filters that fade more slowly (poles within ~5e-4 of the unit circle) take the exact look-back scan.
  * gr4hip_iir_status: synchronises `stream` and reports a look-back time-out of an earlier launch of this handle (a bounded wait gave up: never observed,
  * but then that call's output is invalid) as GR4HIP_RUNTIME_ERROR; the next process / reset call reports it too. */
 typedef struct gr4hip_iir gr4hip_iir_t;
