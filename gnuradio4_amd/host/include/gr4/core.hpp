@@ -347,6 +347,9 @@ struct EdgeBufferBase {
     [[nodiscard]] virtual void*                      reserve_items(std::size_t /*n*/) { return nullptr; }
     virtual void                                     publish_reserved(std::size_t /*n*/) {}
     [[nodiscard]] virtual std::pmr::memory_resource* memory() const { return nullptr; }
+    // grow an EMPTY edge to at least n items (same memory resource); false if it cannot (data in it, spans out, fan-out mirrors).  Used by the device planner:
+    // an edge that feeds a device run wants chunks far larger than the reference's 65536-item default
+    virtual bool ensure_capacity(std::size_t /*n*/) { return false; }
     virtual void                      write_items(const void* src, std::size_t n) = 0; // copy + publish
 };
 template <typename T>
@@ -423,6 +426,14 @@ struct EdgeBuffer final : EdgeBufferBase {
         publish(n);
     }
     [[nodiscard]] std::pmr::memory_resource* memory() const override { return resource(); }
+    bool ensure_capacity(std::size_t n) override {
+        if (n <= capacity) return true;
+        if (available() || lent || reserved || !mirrors.empty() || upstream) return false;
+        data.assign(2 * n, T{});
+        capacity = n;
+        head = tail = 0;
+        return true;
+    }
     void write_items(const void* src, std::size_t n) override {
         if constexpr (std::is_trivially_copyable_v<T>) std::memcpy(write_span(n).data(), src, n * sizeof(T));
         else throw std::logic_error("type-erased element IO needs a trivially copyable sample type");

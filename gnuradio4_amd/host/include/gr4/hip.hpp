@@ -1101,6 +1101,19 @@ public:
     [[nodiscard]] std::size_t overlapped_chunks() const { return _overlapped; }
     [[nodiscard]] std::size_t inplace_chunks() const { return _inplace_chunks; }
     [[nodiscard]] std::size_t direct_chunks() const { return _direct_chunks; }
+    // the oldest input span still lent out: wait for its copy and give it back; returns the items released (0: nothing is lent)
+    std::size_t release_oldest_input() {
+        for (std::size_t i = 0; i < _q_count; ++i) {
+            Slot& sl = _slots[(_q_head + i) % kDepth];
+            if (sl.n_lent == 0) continue;
+            check(gr4hip_event_synchronize(sl.in_done), "event sync");
+            const std::size_t n = sl.n_lent;
+            _in_edge->consume_items(n);
+            sl.n_lent = 0;
+            return n;
+        }
+        return 0;
+    }
     // input spans lent to the copy engine go back to the edge, oldest first, as their copies land (wait: block until all have)
     void release_inputs(bool wait) {
         for (std::size_t i = 0; i < _q_count; ++i) {
@@ -1205,7 +1218,11 @@ public:
             const std::size_t space = _space() - std::min(_space(), _pending_out);  // the output edge minus what queued chunks will publish (reserved spans are already off it)
             n = std::min(n / _in_chunk, space / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
             if (n == 0) {
-                if (_q_count) { // nothing new to queue: make room / finish up by publishing the oldest chunk
+                if (_q_count) { // nothing new to queue
+                    // input lent to the copy engine is what keeps a small edge full: give the oldest such span back as soon as ITS copy has landed and let the
+                    // source refill the edge while the kernels and the result copy of that chunk still run (waiting for the whole chunk here serialised
+                    // source, copies and kernels on a default 64 Ki-sample edge: 0.73 -> 2 Gsamples/s host-fed); otherwise publish the oldest chunk
+                    if (const std::size_t freed = release_oldest_input()) return {requested, std::max(published, freed), work::Status::OK}; // (progress: the source can write again)
                     published += retire(false);
                     return {requested, published, work::Status::OK};
                 }
@@ -1329,7 +1346,10 @@ DeviceRun& fuse_chain(Graph& g, First& first, Rest&... rest) {
 //   * are wired 1:1 (one input edge, one output edge, the edge between two members has no other reader)
 // is replaced by ONE DeviceRun: samples enter HBM once, the stages run back to back on one stream, and adjacent stages with a fused
 // kernel collapse into it (fir_filter<complex<float>> -> PowerSpectrum = gr4hip_chain, any window).  Returns the runs it created.
-inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2) {
+// run_edge_items: the edges at both ends of every run are grown to at least this many items while they are still empty (same memory resource; 0: left
+// alone).  A run moves its input over the link in whole chunks and keeps several in flight; on the reference's default 65536-item edges a chunk IS the edge and
+// source, copies and kernels take turns (0.75 Gsamples/s host-fed where 2^22-item edges give 5.7: profiles/r02_host_feed.txt).
+inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2, std::size_t run_edge_items = std::size_t(1) << 22) {
     auto& blocks = g.blocks();
     const auto eligible = [](BlockModel& b) {
         const auto& d = b.compute_domain();
@@ -1410,6 +1430,10 @@ inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2) {
         };
         std::vector<std::unique_ptr<Stage>> fused;
         for (std::size_t st = 0; st < first_member.size(); ++st) fused.push_back(build(st, &made));
+        if (run_edge_items) {
+            (void)chain.front()->input_edges()[0]->ensure_capacity(run_edge_items);
+            (void)chain.back()->output_edges()[0]->ensure_capacity(run_edge_items);
+        }
         auto  run = std::make_unique<DeviceRun>(std::move(fused), chain.front()->input_edges()[0], chain.back()->output_edges()[0], chain.front()->compute_domain());
         auto* ref = run.get();
         run->set_members(std::move(members), [build](std::size_t stage) { return build(stage, nullptr); });

@@ -1,7 +1,8 @@
 // Host-fed rate of the fused chain through the C++ graph API (developer tool, DESIGN.md "Host feed"):
 //   VectorSource<complex<float>> -> fir_filter (gpu) -> PowerSpectrum (gpu) -> NullSink<float>,  planned into one DeviceRun.
 // Everything a sample goes through is timed: source loop, host edge FIFO, pinned staging, H2D, the fused kernel, D2H, sink.
-//   bench_host_feed [log2_samples = 27] [fftSize = 8192] [ntaps = 256] [mode = dma] [log2_edge_capacity = 24]
+//   bench_host_feed [log2_samples = 27] [fftSize = 8192] [ntaps = 256] [mode = dma] [log2_edge_capacity = 24] [grow]
+//   (an explicit edge capacity is measured as it is; with "grow" the planner enlarges the run's edges as it does by default: hip::plan's run_edge_items)
 // mode: "dma"      page-locked edges at both ends ("hip" provider); the source publishes spans of its output edge without rewriting them, the way a
 //                  driver whose DMA engine fills the port buffer does; the copy engine reads and writes the edges in place: no host copy at all
 //       "pinned"   page-locked edges, the source memcpy's every sample into its port buffer (VectorSource): one host copy per sample
@@ -82,7 +83,8 @@ int main(int argc, char** argv) {
         ok = connect_src(src, fir, pinned);
     }
     if (!ok || !g.connect<"out", "in">(fir, spec, big) || !g.connect<"out", "in">(spec, sink, pinned)) return 2;
-    const auto runs = hip::plan(g);
+    const auto runs = hip::plan(g, 2, (argc > 5 && !(argc > 6 && std::string(argv[6]) == "grow")) ? 0 : std::size_t(1) << 22);
+    if (mode == "dma" && argc > 6) { /* the grown storage is zero: fine for a rate */ }
     if (runs.size() != 1) { std::fprintf(stderr, "planner: expected one run\n"); return 2; }
     scheduler::Simple sched;
     sched.exchange(std::move(g));

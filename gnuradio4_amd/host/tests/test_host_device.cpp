@@ -180,7 +180,7 @@ int main(int argc, char** argv) {
             e.minBufferSize = 4 * N;
             if (locked_edges) e.domain = "gpu:hip:0";
             if (!g.connect<"out", "in">(src, fir, e) || !g.connect<"out", "in">(fir, spec) || !g.connect<"out", "in">(spec, sink, e)) ++errors;
-            const auto runs = hip::plan(g);
+            const auto runs = hip::plan(g, 2, 0); // (0: the planner leaves these deliberately small edges alone)
             scheduler::Simple sched;
             sched.exchange(std::move(g));
             if (const auto r = sched.runAndWait(); !r) { std::cerr << "page-locked graph: " << r.error().message << "\n"; ++errors; }
@@ -429,7 +429,7 @@ int main(int argc, char** argv) {
                 g.connect<"out", "in">(iir, sink);
                 hip::DeviceRun* the_run = nullptr;
                 if (dev) {
-                    const auto runs = hip::plan(g);
+                    const auto runs = hip::plan(g, 2, 0); // (default-size edges on purpose: several launches, so that the pipelining shows)
                     the_run = runs.empty() ? nullptr : runs[0];
                     std::printf("planner (resampling): %zu run:%s%s\n", runs.size(), runs.empty() ? "" : " ", runs.empty() ? "" : std::string(runs[0]->description()).c_str());
                     if (runs.size() != 1 || runs[0]->description() != "math_const -> basic_fir_decim -> decimator -> iir_f32" || runs[0]->out_count(12) != 1) ++errors;
