@@ -83,8 +83,16 @@ int main(int argc, char** argv) {
         ok = connect_src(src, fir, pinned);
     }
     if (!ok || !g.connect<"out", "in">(fir, spec, big) || !g.connect<"out", "in">(spec, sink, pinned)) return 2;
+    if (argc > 6 && std::string(argv[6]) == "seam") { // no planner: every device block on the per-block seam (synchronous copy-in, kernel, copy-out per work() call)
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        const auto t0 = std::chrono::steady_clock::now();
+        if (const auto r = sched.runAndWait(); !r) { std::fprintf(stderr, "%s\n", r.error().message.c_str()); return 3; }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("host-fed, per-block seam (no planner, %s): %zu samples in %.3f s = %.1f Msamples/s\n", mode.c_str(), sink._count, dt, double(sink._count) / dt / 1e6);
+        return sink._count == (n / N) * N ? 0 : 1;
+    }
     const auto runs = hip::plan(g, 2, (argc > 5 && !(argc > 6 && std::string(argv[6]) == "grow")) ? 0 : std::size_t(1) << 22);
-    if (mode == "dma" && argc > 6) { /* the grown storage is zero: fine for a rate */ }
     if (runs.size() != 1) { std::fprintf(stderr, "planner: expected one run\n"); return 2; }
     scheduler::Simple sched;
     sched.exchange(std::move(g));
