@@ -98,7 +98,7 @@ inline void register_provider() { // idempotent; call once before Graph::connect
 // ---------------------------------------------------------------------------------------------- copy threads
 // A pageable edge has to be staged through page-locked memory before the copy engine can take it, and one host thread's memcpy (10-15 GB/s)
 // is far below what the link moves (DESIGN.md "Host feed"): large staging copies are cut into slices for a few helper threads.
-// GR4HIP_COPY_THREADS sets the helper count (default 3, 0: the calling thread copies alone).
+// GR4HIP_COPY_THREADS sets the helper count (default: an eighth of the host's hardware threads, 1 .. 7; 0: the calling thread copies alone).
 class CopyPool {
     struct Slice { char* d; const char* s; std::size_t n; };
     std::vector<std::thread>  _threads;
@@ -124,7 +124,7 @@ class CopyPool {
     }
     CopyPool() {
         const char* e = std::getenv("GR4HIP_COPY_THREADS");
-        const long  k = e ? std::strtol(e, nullptr, 10) : 3;
+        const long  k = e ? std::strtol(e, nullptr, 10) : std::clamp<long>(static_cast<long>(std::thread::hardware_concurrency()) / 8, 1, 7); // (7 on the 256-core boxes)
         for (long i = 0; i < std::clamp(k, 0L, 16L); ++i) _threads.emplace_back([this] { run(); });
     }
     ~CopyPool() {
