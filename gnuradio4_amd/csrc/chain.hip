@@ -88,6 +88,8 @@ int gr4hip_chain_reset(gr4hip_chain_t* c) {
 }
 
 // direct-form FIR kernel -> y in HBM -> FFT kernel (the GR4HIP_CHAIN_TIME_DOMAIN path; also where the guard sends a fused AUTO chain)
+// (Measured and dropped: four batches on two internal streams so that the FIR of batch b + 1 -- matrix pipe -- runs beside the FFT of batch b: 93 instead of 98
+// Gsamples/s at 256 taps, 167 instead of 179 at 64: two grids that each fill the chip take turns anyway, and the extra launches cost.)
 static int chain_time_domain(gr4hip_chain* c, const void* d_in, size_t frames, float* d_mag2, gr4hip_stream_t stream) {
     const size_t n  = frames * c->N;
     int          rc = c->d_y.ensure(n * 2 * sizeof(float));
