@@ -1014,6 +1014,88 @@ def test_chain_full_size_properties(G):
     assert torch.all(whole.argmax(dim=1) == round(0.1 * N))
 
 
+def test_bench_size_launch_properties(G):
+    """one launch of the bench's size (2^28 samples = 32768 frames, 128 per workgroup) on a device-generated stream: chunking invariance against 2^26-sample calls,
+    Parseval against the separately filtered stream, and the float64 oracle on frames from every region of the launch (first, across a call seam of the
+    chunked run, deep inside a workgroup's share, last)"""
+    N, frames = 8192, 1 << 15
+    b = O.design_taps_hamming_lowpass(256, 0.1)
+    x = G.synth_c32(frames * N, seed=11)
+    ch = G.Chain(b, N, "None")
+    whole = ch.process_bulk(x)
+    ch.reset()
+    q = frames // 4
+    parts = torch.cat([ch.process_bulk(x[i * q * N:(i + 1) * q * N]) for i in range(4)])
+    rms = float(whole.double().pow(2).mean().sqrt())
+    assert float((whole - parts).abs().max()) <= 1e-5 * rms
+    del parts
+    y = G.fir_filter(b, torch.complex64).process_bulk(x)
+    assert abs(float(whole.double().sum()) / (N * float((y.abs().double() ** 2).sum())) - 1) < 1e-5
+    del y
+    for f in (0, q - 1, q, 12345, frames - 1):
+        lo = max(f - 1, 0)
+        truth, _ = O.chain(b, x[lo * N:(f + 1) * N].cpu().numpy(), N, 0, truth=True)
+        assert _rel(whole[f].cpu().numpy(), truth.reshape(-1, N)[f - lo]) <= TOL, f
+
+
+def test_configs2_full_size_properties(G):
+    """BASELINE configs[2] at bench size (2^27 input samples: frequency-domain decimator + sequential-run IIR): chunking invariance over calls that take
+    different kernels, linearity, DC gain of the decimated stream, and the float64 oracle on a slice deep inside the span"""
+    n = (1 << 27) + 8 * 1234  # not a whole number of decimator hops: the partial last block rides in the launch
+    k = np.arange(1024) - 511.5
+    t = np.hamming(1024) * 0.1 * np.sinc(0.1 * k)
+    taps = (t / t.sum()).astype(np.float32)
+    bi, ai = G.blocks.design_iir(G.capi.LOWPASS, 8, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    x = G.synth_f32(n, seed=12)
+    fir, iir = G.fir_filter(taps, torch.float32, decimate=8), G.iir_filter(bi, ai)
+    yd = fir.process_bulk(x)
+    yo = iir.process_bulk(yd)
+    assert yd.numel() == n // 8
+    fir.reset(); iir.reset()
+    cuts = [0, 8 * 1000, 8 * 1000 + 7168 * 64 * 3 + 8 * 77, 1 << 26, n]  # polyphase VALU | FD + partial block | FD | FD + partial block
+    yd2 = torch.cat([fir.process_bulk(x[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])])
+    yo2 = torch.cat([iir.process_bulk(yd2[lo // 8:hi // 8]) for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert float((yd - yd2).abs().max()) <= 1e-5 * float(yd.double().pow(2).mean().sqrt())
+    # (two float32 evaluations of the cascade with different run boundaries: each is within 1e-5 of the float64 oracle, so they may differ by up to 2e-5)
+    assert float((yo - yo2).abs().max()) <= 2e-5 * float(yo.double().pow(2).mean().sqrt()), float((yo - yo2).abs().max()) / float(yo.double().pow(2).mean().sqrt())
+    del yd2, yo2
+    fir.reset(); iir.reset()
+    y3 = iir.process_bulk(fir.process_bulk(-4 * x))  # linearity of the pair (a power of two: every product and sum scales exactly)
+    assert float((y3 + 4 * yo).abs().max()) <= 1e-6 * float((4 * yo).double().pow(2).mean().sqrt())
+    del y3
+    ones = torch.ones(1 << 22, dtype=torch.float32, device="cuda")  # DC gain 1 x Butterworth DC gain 1
+    fir.reset(); iir.reset()
+    dc = iir.process_bulk(fir.process_bulk(ones))
+    assert abs(float(dc[-1000:].mean()) - 1.0) <= 1e-5
+    m0 = (1 << 26) + 8 * 5000  # oracle on 40000 decimated samples behind 2^26 inputs: the FIR needs 1023 inputs of history, the IIR is warmed up over 30000 outputs
+    seg = x[m0 - 8 * 30000 - 1024:m0 + 8 * 40000].cpu().numpy()
+    tf, _ = O.fir_decim(taps, seg, 8)
+    ti = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)]), tf.astype(np.float32), O.DF_II, f64=True)
+    got = yo[m0 // 8:m0 // 8 + 40000].cpu().numpy()
+    assert _rel(got, ti[-40000:]) <= TOL
+
+
+def test_configs3_full_size_properties(G):
+    """BASELINE configs[3] at bench size (64 channels x 256 taps x 2^22 samples): every channel equals the single-stream kernel on its row, linearity, and the
+    float64 oracle on slices of three channels"""
+    nch, ntaps, n = 64, 256, 1 << 22
+    rng = np.random.default_rng(7)
+    taps = (rng.standard_normal((nch, ntaps)) / 16).astype(np.float32)
+    x = torch.stack([G.synth_f32(n, seed=100 + c) for c in range(nch)])
+    fb = G.FirBatched(taps)
+    y = fb.process_bulk(x)
+    fb2 = G.FirBatched(taps)
+    y2 = fb2.process_bulk(2 * x)
+    assert float((y2 - 2 * y).abs().max()) <= 1e-5 * float((2 * y).double().pow(2).mean().sqrt())
+    del y2
+    for c in (0, 31, 63):
+        one = G.fir_filter(taps[c], torch.float32).process_bulk(x[c])
+        assert float((one - y[c]).abs().max()) <= 1e-5 * float(one.double().pow(2).mean().sqrt())
+        seg = x[c, 1_000_000 - 255:1_000_000 + 5000].cpu().numpy()
+        truth, _ = O.fir(taps[c], seg)
+        assert _rel(y[c, 1_000_000:1_000_000 + 5000].cpu().numpy(), truth[255:]) <= TOL
+
+
 # ------------------------------------------------------------------ math (a11, a12) + rotator (a13)
 _OPS = {"Add": O.ADD, "Subtract": O.SUB, "Multiply": O.MUL, "Divide": O.DIV}
 
