@@ -2,6 +2,7 @@
 // reference's own tests (blocks/math/test/qa_Math.cpp:16-41, blocks/filter/test/qa_filter.cpp:267-293, core/test/qa_Block.cpp:1315-1343).
 // Also BASELINE.json configs[0]: SignalSource -> 64-tap float FIR -> sink, 1 000 448 samples, CPU scheduler; the stream is dumped
 // for the python test to compare against the oracle.
+#include <deque>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -104,6 +105,84 @@ int main(int argc, char** argv) {
         EXPECT(e.available() == 7 && e.read_span(7)[5] == 100 && e.reserved == 1);
         b.publish_reserved(1);
         EXPECT(e.available() == 8 && e.read_span(8)[7] == 102 && e.write_pos == 19);
+    }
+    // ---- the same edge under 200 000 random operations against a plain queue: typed writes, lends / releases in order, reservations / publications in order;
+    //      spans handed out must stay where they are and hold the right items until they come back
+    {
+        EdgeBuffer<int>  e(64);
+        EdgeBufferBase&  b = e;
+        std::deque<int>  model;                                    // published and not yet consumed
+        std::deque<std::pair<const int*, std::size_t>> lent;       // outstanding lent spans (pointer, n) with their first value = model index base
+        std::deque<std::pair<int*, std::size_t>>       reserved;   // outstanding reservations
+        std::deque<int>                                reserved_first; // first value each reservation will hold
+        std::size_t   lent_items = 0;
+        int           next = 0;
+        std::uint32_t rng = 2463534242u;
+        const auto    rnd = [&](std::uint32_t m) { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng % m; };
+        bool ok = true;
+        for (int step = 0; step < 200000 && ok; ++step) {
+            switch (rnd(6)) {
+            case 0: { // typed write (only while nothing is reserved: one writer per edge)
+                if (!reserved.empty()) break;
+                const std::size_t n = std::min<std::size_t>(e.free_space(), rnd(40));
+                if (n == 0) break;
+                auto sp = e.write_span(n);
+                for (std::size_t i = 0; i < n; ++i) { sp[i] = next; model.push_back(next++); }
+                e.publish(n);
+                break;
+            }
+            case 1: { // lend
+                const std::size_t n = rnd(30) + 1;
+                const int* p = static_cast<const int*>(b.lend_items(n));
+                if (n > model.size() - lent_items) { ok = ok && p == nullptr; break; }
+                ok = ok && p != nullptr && p[0] == model[lent_items] && p[n - 1] == model[lent_items + n - 1];
+                lent.emplace_back(p, n);
+                lent_items += n;
+                break;
+            }
+            case 2: { // give the oldest lent span back: it still holds what it held
+                if (lent.empty()) break;
+                auto [p, n] = lent.front();
+                ok = ok && p[0] == model.front() && p[n - 1] == model[n - 1];
+                b.consume_items(n);
+                model.erase(model.begin(), model.begin() + static_cast<std::ptrdiff_t>(n));
+                lent.pop_front();
+                lent_items -= n;
+                break;
+            }
+            case 3: { // typed consume (only while nothing is lent)
+                if (!lent.empty() || model.empty()) break;
+                const std::size_t n = rnd(static_cast<std::uint32_t>(model.size())) + 1;
+                auto sp = e.read_span(n);
+                ok = ok && sp[0] == model.front() && sp[n - 1] == model[n - 1];
+                e.consume(n);
+                model.erase(model.begin(), model.begin() + static_cast<std::ptrdiff_t>(n));
+                break;
+            }
+            case 4: { // reserve
+                const std::size_t n = rnd(30) + 1;
+                int* p = static_cast<int*>(b.reserve_items(n));
+                if (!p) break;
+                for (std::size_t i = 0; i < n; ++i) p[i] = next + static_cast<int>(i);
+                reserved.emplace_back(p, n);
+                reserved_first.push_back(next);
+                next += static_cast<int>(n);
+                break;
+            }
+            case 5: { // publish the oldest reservation: it has not moved
+                if (reserved.empty()) break;
+                auto [p, n] = reserved.front();
+                ok = ok && p[0] == reserved_first.front() && p[n - 1] == reserved_first.front() + static_cast<int>(n) - 1;
+                b.publish_reserved(n);
+                for (std::size_t i = 0; i < n; ++i) model.push_back(reserved_first.front() + static_cast<int>(i));
+                reserved.pop_front();
+                reserved_first.pop_front();
+                break;
+            }
+            }
+            ok = ok && e.available() == model.size() && b.available_items() == model.size() - lent_items && e.available() + e.reserved <= e.capacity;
+        }
+        EXPECT(ok);
     }
     // ---- memory seam: ComputeRegistry providers and per-edge resources (ComputeDomain.hpp:105-173, Graph.hpp:738-775)
     {
