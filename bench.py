@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check of the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of sampled output frames")
+    ap.add_argument("--no-graph8", action="store_true", help="N = 1: skip the extra measurement of the 8-channel graph on this one GPU (the 1-GPU point of the strong-scaling curve)")
     args = ap.parse_args()
 
     import numpy as np
@@ -347,6 +348,20 @@ def main():
                 rc = 3
         if world == 1 and not combine and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not combine and not args.no_graph8 and os.environ.get("GR4HIP_BENCH_CHILD") != "1":
+            # the N > 1 runs shard the 8-channel graph of configs[4] (total work fixed); its 1-GPU point -- all eight channels on this GPU -- is measured here,
+            # after the headline (its own process, shorter streams: the rate is a steady-state one), so that the scaling curve has its origin in the same file
+            del xs, outs
+            torch.cuda.empty_cache()
+            import subprocess
+            try:
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--channels", "8", "--log2-samples", "28", "--steps", "12", "--warmup", "4", "--no-cpu-baseline"],
+                                       capture_output=True, text=True, timeout=600, env={**os.environ, "GR4HIP_BENCH_CHILD": "1"})
+                g8 = json.loads(child.stdout.strip().splitlines()[-1])
+                res["eight_channel_graph_on_one_gpu"] = {"value": g8["value"], "unit": g8["unit"], "ms_per_step": g8["ms_per_step"], "samples_per_channel_and_step": 1 << 28,
+                                                         "steps": g8["steps"], "verify": g8.get("verify"), "workload": g8["config"]["workload"]}
+            except Exception as e:  # never at the price of the headline line
+                res["eight_channel_graph_on_one_gpu"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -30,11 +30,18 @@ def _run(cmd, timeout=900):
 
 
 def test_bench_single_channel_self_check():
-    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline"])
+    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline", "--no-graph8"])
     assert r["n_gpus"] == 1 and r["config"]["channels"] == 1 and r["scaling"] == "weak"
     assert r["roofline"]["kernel"] == "gr4::chain_fd_kernel<0, 13>"
     v = r["verify"]
     assert v["verified_frames"] >= 6 and v["max_rel_err"] <= 1e-5
+
+
+def test_bench_single_channel_line_carries_the_one_gpu_point_of_the_graph():
+    """the N = 1 line also reports the 8-channel graph on this one GPU (own process, after the headline): the origin of the strong-scaling curve"""
+    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline"])
+    g8 = r["eight_channel_graph_on_one_gpu"]
+    assert "error" not in g8 and g8["value"] > 0 and g8["verify"]["max_rel_err"] <= 1e-5 and r["config"]["channels"] == 1
 
 
 def test_bench_eight_channel_graph_one_gpu():
