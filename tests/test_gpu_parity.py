@@ -305,6 +305,37 @@ def test_interpolating_fir_parity(G, interp, ntaps, cplx):
         G.fir_interpolator(b, 0)
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("interp,ntaps", [(2, 64), (2, 530), (4, 256), (4, 37), (8, 256), (8, 1024), (8, 2168), (16, 256), (16, 5), (7, 128), (12, 100), (20, 333), (48, 96), (100, 1000), (9, 2400)])
+def test_interpolating_fir_matrix_pipe_long_streams(G, interp, ntaps, cplx):
+    """spans of >= 32768 outputs at L in {2, 4, 8, 16} (G = 16 / L input positions per 16-row tile) and at any other L except 3, 5, 6 (one input
+    position per tile, rows = 16 phases at a time): the block-Toeplitz contraction on the f32 matrix pipe (fir_interp_mfma_kernel) -- many segments
+    per call, ragged ends, history handed between the matrix-pipe and the register-window / generic kernel"""
+    n = 150_003 if interp <= 16 else 40_003
+    b = O.design_taps_hamming_lowpass(ntaps, 0.4 / interp)
+    x = O.signal_c32(33, n) if cplx else O.signal_f32(33, n)
+    truth, _ = O.fir_interp(b, x, interp)
+    f = G.fir_interpolator(b, interp, torch.complex64 if cplx else torch.float32)
+    assert _rel(f.process_bulk(dev(x)).cpu().numpy(), truth) <= TOL
+    f.reset()
+    cuts = [0, 70_001, 70_004, 74_100, 140_000, 140_900, n] if interp <= 16 else [0, 20_001, 20_004, 21_000, n]  # long spans (matrix pipe), short ones in between
+    got = np.concatenate([f.process_bulk(dev(x[a:c])).cpu().numpy() for a, c in zip(cuts[:-1], cuts[1:])])
+    assert got.shape == truth.shape and _rel(got, truth) <= TOL
+
+
+def test_interpolating_fir_matrix_pipe_many_workgroups(G):
+    """a device-generated stream long enough that every workgroup takes 4 segments: against the register-window kernel's definition through the
+    polyphase identity -- branch p of the output is an ordinary FIR of the input with taps L b[p::L] (fir_filter, itself oracle-checked)"""
+    L, ntaps, n = 8, 256, 1 << 25
+    b = O.design_taps_hamming_lowpass(ntaps, 0.4 / L)
+    x = G.synth_f32(n, seed=5)
+    y = G.fir_interpolator(b, L).process_bulk(x)
+    for p in (0, 5):
+        ref = G.fir_filter((L * b[p::L]).astype(np.float32)).process_bulk(x)
+        d = (y[p::L] - ref).abs().max() / ref.abs().max()
+        assert float(d) <= 2e-6
+
+
 def test_interpolating_fir_is_the_gain_L_inverse_of_decimation(G):
     """size-independent property at a long device-generated stream: interpolate by L with a 1/L-band low-pass, keep every L-th output of the
     branch-0 phase -> the input delayed by the filter's group delay, to the filter's pass-band ripple"""
