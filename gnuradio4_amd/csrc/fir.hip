@@ -316,7 +316,9 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     bool         mfma_wrote_hist = false;
     // complex<float>, no decimation, <= 256 taps, long input: whole 8192-sample frames go through the fused FFT -> xH -> inverse
     // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
-    if (f->S == 2 && f->decim == 1 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
+    // (<= 64 taps: the direct form is write-bound, not FP32-bound -- 306 .. 356 Gsamples/s against the fast convolution's 256 at every tap count,
+    // tools/cfir_taps_sweep.py -- and has no dynamic-range floor; 65 .. 128 taps on the matrix pipe run at 215 .. 229)
+    if (f->S == 2 && f->decim == 1 && f->ntaps > 64 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
         int rc = GR4HIP_OK;
         if (!f->fd) {
             rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
