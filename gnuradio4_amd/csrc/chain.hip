@@ -2,6 +2,8 @@
 //
 // GR4HIP_CHAIN_UNFUSED: gr4hip_fir_process -> y in HBM -> gr4hip_fft_mag2 (any size the FFT block supports).
 // GR4HIP_CHAIN_FUSED_FD (chain_fused.hip): one persistent launch, any window, fft_size 256...8192, <= 256 taps; AUTO picks it when it applies.
+// GR4HIP_CHAIN_FUSED_TD (chain_td.hip): one launch, direct-form filter on the matrix pipe + one transform per frame, fft_size 256...4096, <= 256 taps;
+//   AUTO picks it for <= 64 taps (faster than the fast convolution there), and it is where the dynamic-range guard sends a stream when the size allows.
 #include "common.hpp"
 
 namespace gr4 {
@@ -16,6 +18,13 @@ void chain_fused_set_measure(ChainFused* c, bool on);
 int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio);
 const float* chain_fused_history(const ChainFused* c);
 int  chain_fused_set_history(ChainFused* c, const float* d_hist256, hipStream_t st);
+struct ChainTd;
+int  chain_td_supported(size_t ntaps, size_t fft_size, int window);
+int  chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_size, int window);
+int  chain_td_reset(ChainTd* c);
+int  chain_td_process(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st);
+int  chain_td_set_history256(ChainTd* c, const float* d_hist256, hipStream_t st);
+void chain_td_destroy(ChainTd* c);
 } // namespace gr4
 int gr4hip_internal_fir_load_history(gr4hip_fir_t* f, const float* d_last256, hipStream_t st); // fir.hip
 
@@ -28,6 +37,7 @@ struct gr4hip_chain {
     gr4hip_fir_t*   fir = nullptr;
     gr4hip_fft_t*   fft = nullptr;
     gr4::ChainFused* fused = nullptr;
+    gr4::ChainTd*   td = nullptr; // GR4HIP_CHAIN_FUSED_TD, or the guard's destination when the fft size allows
     DeviceBuffer    d_y;
     // dynamic-range guard (GR4HIP_CHAIN_AUTO on the fused kernel).  The fast-convolution kernels carry the float32 rounding of their transforms, ~2e-6 of the
     // INPUT rms per output sample; the parity bar is 1e-5 of the OUTPUT, so they meet it while out_rms / in_rms >= 0.2, i.e. power ratio >= 0.04 (-14 dB).
@@ -40,6 +50,7 @@ struct gr4hip_chain {
 };
 constexpr float  kGuardMinPowerRatio = 0.04f;
 constexpr size_t kGuardProbeFrames   = 8; // in units of 8192-sample blocks
+constexpr size_t kTdAutoMaxTaps      = 64; // AUTO: up to here the fused time-domain kernel beats the fused fast convolution (tools/chain_modes_rates.py)
 
 extern "C" {
 
@@ -56,9 +67,10 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
     int use   = algo;
     if (algo == GR4HIP_CHAIN_AUTO) {
         use = GR4HIP_CHAIN_UNFUSED;
-        for (int cand : {GR4HIP_CHAIN_FUSED_FD, GR4HIP_CHAIN_FUSED_TD})
-            if (chain_fused_supported(ntaps, fft_size, window, cand)) { use = cand; break; }
-    } else if (algo != GR4HIP_CHAIN_UNFUSED && algo != GR4HIP_CHAIN_TIME_DOMAIN && !chain_fused_supported(ntaps, fft_size, window, algo)) {
+        if (ntaps <= kTdAutoMaxTaps && chain_td_supported(ntaps, fft_size, window)) use = GR4HIP_CHAIN_FUSED_TD;
+        else if (chain_fused_supported(ntaps, fft_size, window, GR4HIP_CHAIN_FUSED_FD)) use = GR4HIP_CHAIN_FUSED_FD;
+    } else if (algo == GR4HIP_CHAIN_FUSED_TD ? !chain_td_supported(ntaps, fft_size, window)
+                                             : (algo != GR4HIP_CHAIN_UNFUSED && algo != GR4HIP_CHAIN_TIME_DOMAIN && !chain_fused_supported(ntaps, fft_size, window, algo))) {
         set_error("chain: fused algo %d does not support ntaps=%zu fft_size=%zu window=%d", algo, ntaps, fft_size, window);
         delete c;
         return GR4HIP_UNSUPPORTED;
@@ -70,6 +82,8 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, h_taps, ntaps, 1);
         if (!rc && use == GR4HIP_CHAIN_TIME_DOMAIN) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN);
         if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, fft_size, window, 0);
+    } else if (use == GR4HIP_CHAIN_FUSED_TD) {
+        rc = chain_td_create(&c->td, h_taps, ntaps, fft_size, window);
     } else {
         rc = chain_fused_create(&c->fused, h_taps, ntaps, fft_size, window, use);
         if (!rc && c->guard) chain_fused_set_measure(c->fused, true);
@@ -84,6 +98,7 @@ int gr4hip_chain_reset(gr4hip_chain_t* c) {
     c->probed = c->use_td = false;
     c->last_ratio = -1.f;
     if (c->fused && c->fir) { int rc = gr4hip_fir_reset(c->fir); if (rc) return rc; }
+    if (c->td) { int rc = chain_td_reset(c->td); if (rc || !c->fused) return rc; }
     return c->fused ? chain_fused_reset(c->fused) : gr4hip_fir_reset(c->fir);
 }
 
@@ -91,6 +106,7 @@ int gr4hip_chain_reset(gr4hip_chain_t* c) {
 // (Measured and dropped: four batches on two internal streams so that the FIR of batch b + 1 -- matrix pipe -- runs beside the FFT of batch b: 93 instead of 98
 // Gsamples/s at 256 taps, 167 instead of 179 at 64: two grids that each fill the chip take turns anyway, and the extra launches cost.)
 static int chain_time_domain(gr4hip_chain* c, const void* d_in, size_t frames, float* d_mag2, gr4hip_stream_t stream) {
+    if (c->td) return chain_td_process(c->td, static_cast<const float*>(d_in), frames, d_mag2, as_stream(stream)); // one launch where the size allows
     const size_t n  = frames * c->N;
     int          rc = c->d_y.ensure(n * 2 * sizeof(float));
     if (rc) return rc;
@@ -103,6 +119,12 @@ static int chain_time_domain(gr4hip_chain* c, const void* d_in, size_t frames, f
 static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, hipStream_t st) {
     std::vector<float>& taps = c->taps;
     int rc = GR4HIP_OK;
+    if (chain_td_supported(taps.size(), c->N, c->window)) {
+        if (!c->td) rc = chain_td_create(&c->td, taps.data(), taps.size(), c->N, c->window);
+        if (!rc) rc = chain_td_set_history256(c->td, d_hist256, st);
+        if (!rc) c->use_td = true;
+        return rc;
+    }
     if (!c->fir) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, taps.data(), taps.size(), 1);
         if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN);
@@ -119,6 +141,7 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
     if (n_frames_p) *n_frames_p = frames;
     if (frames == 0) return n_samples ? GR4HIP_INSUFFICIENT_INPUT : GR4HIP_OK;
     GR4_REQUIRE(d_in && d_mag2, "chain_process: null device pointer");
+    if (c->td && !c->fused) return chain_td_process(c->td, static_cast<const float*>(d_in), frames, d_mag2, as_stream(stream));
     if (c->fused && !c->guard) return chain_fused_process(c->fused, static_cast<const float*>(d_in), frames, d_mag2, as_stream(stream));
     if (c->fused) { // GR4HIP_CHAIN_AUTO on the fused kernel: dynamic-range guard
         hipStream_t  st  = as_stream(stream);
@@ -177,6 +200,7 @@ int gr4hip_chain_destroy(gr4hip_chain_t* c) {
     if (c->fir) gr4hip_fir_destroy(c->fir);
     if (c->fft) gr4hip_fft_destroy(c->fft);
     if (c->fused) chain_fused_destroy(c->fused);
+    if (c->td) chain_td_destroy(c->td);
     delete c;
     return GR4HIP_OK;
 }

@@ -1,0 +1,338 @@
+// chain_td.hip -- fused complex<float> FIR -> fftSize-point FFT -> |X|^2 with the filter in the TIME domain (GR4HIP_CHAIN_FUSED_TD), fftSize 256 .. 4096.
+//
+// The same runtime fusion as chain_fused.hip -- fir_filter (blocks/filter/.../time_domain_filter.hpp:44-47) + FFT block (blocks/fourier/.../fft.hpp:147-171)
+// + mag2, the analogue of Merge<fir,"out",fft,"in"> (core/include/gnuradio-4.0/BlockMerging.hpp:136-320) -- but with the reference's own arithmetic for the
+// filter: the direct-form sum, as the block-Toeplitz contraction of fir_batched.hip on the f32 matrix pipe.  Two reasons to have it beside the fast
+// convolution:
+//  * short filters.  At <= 64 taps the direct form costs 320 executed flop per complex sample on the MATRIX pipe, which the frame transform (VALU) does not
+//    use: one workgroup's MFMA phase runs beside another workgroup's transform, and the chain needs ONE transform per frame instead of the fast
+//    convolution's three (forward, inverse, windowed forward).
+//  * dynamic range.  The fast convolution carries the rounding of its transforms (~2e-6 of the INPUT rms); this kernel has the error of a
+//    float32 dot product relative to the OUTPUT, so it is where the guard of chain.hip sends a stream whose filter removes most of the input.
+//
+// One workgroup (256 lanes) per segment of 4096 complex samples = 4096 / fftSize frames:
+//   stage    the segment + Kp samples in front of it, de-interleaved into a re and an im plane (18 / 16-padded, planes 16 banks apart) -- requested into
+//            registers at once (17 loads in flight per lane)
+//   MFMA     wave w: tiles of 256 outputs, re and im accumulators under the same A operand (Toeplitz: read from the tap row in LDS); D x window -> the frame
+//            buffer in LDS (natural order, one pad float2 per 32)
+//   FFT      16 points per lane, fftSize / 16 lanes per frame: Stockham 16 x 16 x (fftSize / 256), the plan of fft_fast_kernel with its first pass fed
+//            from LDS instead of HBM; |X|^2 straight from registers (lane t holds bins t + j fftSize / 16: coalesced)
+// The frame buffer takes the place of the staged samples: LDS 38 KB -> four workgroups per CU, whose phases interleave on the two pipes.  HBM traffic: 8 B in + 4 B out per sample.  Bound: MFMA f32 (2 * 2 * (Kp + 16) flop per sample).
+#include "common.hpp"
+#include "buffer_ops.hpp"
+#include "fft_radix.hpp"
+
+#include <cmath>
+
+namespace gr4 {
+
+void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out); // fir_batched.hip
+int  make_window(int window, float* w, size_t n, float beta);                                                               // runtime.hip
+
+using td_f32x4 = __attribute__((ext_vector_type(4))) float;
+// every barrier of the kernel orders LDS accesses only.  __syncthreads() also waits for the global stores in flight (vmcnt(0)): the |X|^2 stores of a
+// segment would have to land before its workgroup may stage the next one -- measured 245 instead of 3xx Gsamples/s at 64 taps
+#define GR4_TD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+constexpr int kTdSeg = 4096; // complex samples per segment
+
+// waves per SIMD the kernel is compiled for (512 / W registers per lane): the most that needs no scratch -- 16 x 16 transforms fit 128 registers,
+// a third pass of radix >= 4 wants ~140 .. 165, 256 taps at 1024 points and beyond ~230
+template <int KS, int LOG2N>
+constexpr int td_waves() {
+#ifdef GR4_TD_W
+    return GR4_TD_W;
+#else
+    return (LOG2N <= 9 && KS <= 36) || LOG2N == 8 ? 4 : (KS == 68 ? 2 : 3);
+#endif
+}
+
+template <int KS, int LOG2N>
+__global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(const float2* __restrict__ x, const float2* __restrict__ hist /*the Kp samples in front of x*/, const float* __restrict__ trow /*[Kp + 32]: index 16 + q = b[q]*/,
+                                                        const float* __restrict__ win /*[N] or null*/, const float2* __restrict__ tw /*W_N^j*/, float* __restrict__ out,
+                                                        long n /*samples: whole frames*/, float2* __restrict__ new_hist) {
+    constexpr int Kp = 4 * KS - 16, N = 1 << LOG2N, T = N / 16, NP = N + N / 32;
+    constexpr int NPL = (kTdSeg + Kp) / 16 * 18 + 16; // floats per plane; + 16: the two planes sit 16 banks apart
+    constexpr int NL  = (kTdSeg + Kp + 255) / 256;    // complex samples a lane holds for the next segment
+    constexpr int R3  = N / 256;                      // third pass radix (1: none)
+    constexpr int B3  = R3 > 1 ? 16 / R3 : 1, NB3 = N / (R3 > 1 ? R3 : 1);
+    extern __shared__ __attribute__((aligned(16))) float td_sm[];
+    float*  xs = td_sm;                              // [2][NPL] staged samples ...
+    float2* fb = reinterpret_cast<float2*>(td_sm);   // ... then, in the same place, the segment's frames [4096 / N][NP]
+    constexpr int DATA = 2 * NPL > 2 * (kTdSeg + kTdSeg / 32) ? 2 * NPL : 2 * (kTdSeg + kTdSeg / 32);
+    float*  tp = td_sm + DATA;                       // tap row: A[j][u] = b[Kp + j - u] is Toeplitz, lane (j, kq) reads tp[16 + Kp + j - kq - 4 ks]
+    auto    P  = [](int i) { return i + (i >> 5); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int fl = tid / T, t = tid % T; // FFT phase: frame slot, lane of the frame
+
+    for (int i = tid; i < Kp + 32; i += 256) tp[i] = trow[i];
+    const float* pa = tp + 16 + Kp + col - kq;
+    // per-lane twiddle bases, exact table values
+    const float2 w2a_ = tw[(t & 15) * (N / 256)], w2b_ = tw[2 * (t & 15) * (N / 256)]; // W_256^k, W_256^2k
+    float2       w3_ = make_float2(1.f, 0.f), w3sq_ = make_float2(1.f, 0.f);
+    if constexpr (R3 > 1) w3_ = tw[t & 255];         // W_N^t  (256 R3 = N)
+    if constexpr (R3 == 16) w3sq_ = tw[2 * (t & 255)];
+
+    // Persistent grid: as many workgroups per CU as the kernel is compiled for, segments dealt round-robin.  (Tried: a different wave priority for each of
+    // the workgroups that share a CU, so that they would not fall into step on the matrix pipe -- no change, 245 Gsamples/s with and without.)
+    const long nseg = (n + kTdSeg - 1) / kTdSeg;
+    const long n_frames = n >> LOG2N;
+    for (long sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+        const long seg0 = sg * kTdSeg;
+        if (sg > 0) { // (no register prefetch of the next segment: with four workgroups per CU another one always has work, and the registers buy the fourth)
+            const long   i0   = seg0 - Kp; // seg0 >= kTdSeg > Kp: nothing below 0; past the end of the span / of the segment the range check returns 0
+            const long   nrec = n - i0 < (long)(kTdSeg + Kp) ? n - i0 : (long)(kTdSeg + Kp);
+            const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 8 : 0));
+            float2       nxt[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) nxt[u] = buf_load_f2(r, tid * 8, 256 * u * 8);
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int s_ = tid + 256 * u;
+                if (s_ < kTdSeg + Kp) {
+                    xs[s_ + 2 * (s_ >> 4)]       = nxt[u].x;
+                    xs[NPL + s_ + 2 * (s_ >> 4)] = nxt[u].y;
+                }
+            }
+        } else {
+            for (int s_ = tid; s_ < kTdSeg + Kp; s_ += 256) { // the first segment of the span reads the carried history in front of x
+                const long   i = s_ - Kp;
+                const float2 v = i >= 0 ? (i < n ? x[i] : make_float2(0.f, 0.f)) : hist[Kp + i];
+                xs[s_ + 2 * (s_ >> 4)]       = v.x;
+                xs[NPL + s_ + 2 * (s_ >> 4)] = v.y;
+            }
+        }
+        GR4_TD_BARRIER();
+
+        // ---- direct-form FIR on the matrix pipe: this wave's four tiles of 256 outputs, re and im accumulators under the same A fragment
+        td_f32x4 acr[4], aci[4];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) { // two tiles (four accumulators) at a time hide the dependent-MFMA latency
+            const int    ib0 = 16 * (4 * wave + 2 * pp), ib1 = ib0 + 16; // first 16-sample block of each tile
+            td_f32x4     ar0 = {0.f, 0.f, 0.f, 0.f}, ai0 = ar0, ar1 = ar0, ai1 = ar0;
+            const float* p0  = xs + 18 * (ib0 + col) + kq;
+            const float* p1  = xs + 18 * (ib1 + col) + kq;
+#ifndef GR4_TD_NO_MFMA // (developer builds: one phase removed, tools/build_variant.sh)
+#pragma unroll
+#else
+            ar0[0] = p0[0]; ai0[0] = p0[NPL]; ar1[0] = p1[0]; ai1[0] = p1[NPL];
+#pragma unroll
+            for (int ks = 0; ks < 0; ++ks)
+#endif
+            for (int ks = 0; ks < KS; ++ks) {
+                const int   off = 4 * ks + 2 * (ks >> 2);
+                const float a   = pa[-4 * ks];
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p0[off], ar0, 0, 0, 0);
+                ai0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p0[NPL + off], ai0, 0, 0, 0);
+                ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p1[off], ar1, 0, 0, 0);
+                ai1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p1[NPL + off], ai1, 0, 0, 0);
+            }
+            acr[2 * pp] = ar0; aci[2 * pp] = ai0; acr[2 * pp + 1] = ar1; aci[2 * pp + 1] = ai1;
+        }
+        GR4_TD_BARRIER(); // every wave is done with the staged samples: the frame buffer takes their place
+        // D[row = 4 kq + r][col] of tile q: sample 16 (16 (4 wave + q) + col) + 4 kq + r of the segment; x window -> frame buffer (natural order)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = 16 * (16 * (4 * wave + q) + col) + 4 * kq, f = o >> LOG2N, pos = o & (N - 1);
+            float4    w = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (win) w = *reinterpret_cast<const float4*>(win + pos);
+            float2* d = fb + f * NP + P(pos); // pos % 4 == 0: the four samples share a 32-block
+            d[0]      = make_float2(acr[q][0] * w.x, aci[q][0] * w.x);
+            d[1]      = make_float2(acr[q][1] * w.y, aci[q][1] * w.y);
+            d[2]      = make_float2(acr[q][2] * w.z, aci[q][2] * w.z);
+            d[3]      = make_float2(acr[q][3] * w.w, aci[q][3] * w.w);
+        }
+        GR4_TD_BARRIER();
+
+        // ---- the segment's frames: 16 x 16 x R3
+        float2* buf = fb + fl * NP;
+        float2  v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = buf[P(t + r * T)];
+#ifdef GR4_TD_NO_FFT
+        {
+            const long frame = (seg0 >> LOG2N) + fl;
+            if (frame < n_frames)
+                for (int j = 0; j < 16; ++j) out[frame * N + t + j * T] = fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
+            GR4_TD_BARRIER(); continue;
+        }
+#endif
+        GR4_TD_BARRIER();
+        fft16<1>(v);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[P(16 * t + r)] = v[perm16(r)];
+        GR4_TD_BARRIER();
+        // pass 2 (p = 16, radix 16): butterfly i = t, k = t & 15
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = buf[P(t + r * T)];
+        float2 w2a = w2a_, w2b = w2b_, w3 = w3_, w3sq = w3sq_; // (laundered: their power chains are loop-invariant and would be kept as ~35 registers)
+        asm volatile("" : "+v"(w2a.x), "+v"(w2a.y), "+v"(w2b.x), "+v"(w2b.y), "+v"(w3.x), "+v"(w3.y), "+v"(w3sq.x), "+v"(w3sq.y));
+        apply_powers(v, w2a, w2b);
+        fft16<1>(v);
+        float2 X[16]; // X[j] = bin t + j T
+        if constexpr (R3 == 1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) X[q] = v[perm16(q)];
+        } else {
+            GR4_TD_BARRIER();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) buf[P((t & ~15) * 16 + (t & 15) + 16 * q)] = v[perm16(q)];
+            GR4_TD_BARRIER();
+            // pass 3 (p = 256, radix R3): butterflies i_b = t + b T, k = i_b & 255
+#pragma unroll
+            for (int b = 0; b < B3; ++b)
+#pragma unroll
+                for (int r = 0; r < R3; ++r) v[b * R3 + r] = buf[P(t + b * T + r * NB3)];
+            if constexpr (R3 == 16) {
+                apply_powers(v, w3, w3sq);
+                fft16<1>(v);
+            } else {
+#pragma unroll
+                for (int b = 0; b < B3; ++b) {
+                    const float2 wb = b == 0 ? w3 : cmul(w3, w32(2 * b));
+                    float2       pw = wb;
+#pragma unroll
+                    for (int r = 1; r < R3; ++r) {
+                        v[b * R3 + r] = cmul(v[b * R3 + r], pw);
+                        if (r + 1 < R3) pw = cmul(pw, wb);
+                    }
+                    dft_small<R3>(v + b * R3);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < B3; ++b)
+#pragma unroll
+                for (int q = 0; q < R3; ++q) X[b + q * B3] = v[b * R3 + (R3 == 16 ? perm16(q) : q)];
+        }
+        const long frame = (seg0 >> LOG2N) + fl;
+        if (frame < n_frames) {
+            float* o = out + frame * N + t;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j * T] = fmaf(X[j].x, X[j].x, X[j].y * X[j].y);
+        }
+        GR4_TD_BARRIER(); // every lane is done with the frame buffer before the next segment is staged over it
+    }
+    if (new_hist != nullptr && blockIdx.x == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
+        for (int h = tid; h < Kp; h += 256) {
+            const long i = n - Kp + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kp + i];
+        }
+    }
+}
+
+struct ChainTd {
+    size_t       ntaps = 0, N = 0;
+    int          KS = 0, Kp = 0, log2n = 0;
+    bool         windowed = false;
+    DeviceBuffer d_afrag, d_win, d_tw, d_hist[2];
+    int          cur = 0, dev = 0;
+};
+
+int chain_td_supported(size_t ntaps, size_t fft_size, int window) {
+    return is_pow2(fft_size) && fft_size >= 256 && fft_size <= 4096 && ntaps >= 1 && ntaps <= 256 && window >= GR4HIP_WIN_NONE && window <= GR4HIP_WIN_KAISER;
+}
+
+int chain_td_reset(ChainTd* c) {
+    for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(c->d_hist[k].ptr, 0, (size_t)c->Kp * sizeof(float2)));
+    c->cur = 0;
+    return GR4HIP_OK;
+}
+
+int chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_size, int window) {
+    if (!chain_td_supported(ntaps, fft_size, window)) { set_error("fused time-domain chain: unsupported configuration (fft_size 256 .. 4096, <= 256 taps)"); return GR4HIP_UNSUPPORTED; }
+    auto* c = new (std::nothrow) ChainTd();
+    GR4_REQUIRE(c, "out of host memory");
+    c->ntaps = ntaps;
+    c->N     = fft_size;
+    (void)hipGetDevice(&c->dev);
+    c->log2n = (int)ilog2(fft_size);
+    std::vector<float> af;
+    fir_mfma_make_afrag_decim(taps, ntaps, 1, &c->Kp, &c->KS, &af); // D = 1: the tap row [Kp + 32], index 16 + q = b[q]
+    auto up = [](DeviceBuffer& b, const void* p, size_t bytes) -> int {
+        int rc = b.ensure(bytes);
+        if (rc) return rc;
+        GR4_HIP_TRY(hipMemcpy(b.ptr, p, bytes, hipMemcpyHostToDevice));
+        return GR4HIP_OK;
+    };
+    int rc = up(c->d_afrag, af.data(), af.size() * sizeof(float));
+    c->windowed = window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR;
+    if (!rc && c->windowed) {
+        std::vector<float> w(fft_size);
+        rc = make_window(window, w.data(), fft_size, 1.6f); // fft.hpp:141: default beta
+        if (!rc) rc = up(c->d_win, w.data(), w.size() * sizeof(float));
+    }
+    if (!rc) {
+        std::vector<float> ts(2 * fft_size);
+        for (size_t k = 0; k < fft_size; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / (double)fft_size;
+            ts[2 * k]     = (float)std::cos(ang);
+            ts[2 * k + 1] = (float)std::sin(ang);
+        }
+        rc = up(c->d_tw, ts.data(), ts.size() * sizeof(float));
+    }
+    for (int k = 0; k < 2 && !rc; ++k) rc = c->d_hist[k].ensure((size_t)c->Kp * sizeof(float2));
+    if (!rc) rc = chain_td_reset(c);
+    if (rc) { delete c; return rc; }
+    *out = c;
+    return GR4HIP_OK;
+}
+
+void chain_td_destroy(ChainTd* c) { delete c; }
+
+// the carried history: the last Kp complex samples of the stream, hist[h] = x[-Kp + h] of the next call
+const float* chain_td_history(const ChainTd* c, int* Kp) {
+    if (Kp) *Kp = c->Kp;
+    return static_cast<const float*>(c->d_hist[c->cur].ptr);
+}
+// start from the 256 complex samples in front of the next call (the fused frequency-domain kernel's convention)
+int chain_td_set_history256(ChainTd* c, const float* d_hist256, hipStream_t st) {
+    GR4_HIP_TRY(hipMemcpyAsync(c->d_hist[c->cur].ptr, d_hist256 + 2 * (256 - c->Kp), (size_t)c->Kp * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    return GR4HIP_OK;
+}
+
+template <int KS>
+static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
+    constexpr int Kp  = 4 * KS - 16, NPL = (kTdSeg + Kp) / 16 * 18 + 16;
+    const size_t  lds = std::max((size_t)2 * NPL * sizeof(float), (size_t)(kTdSeg + kTdSeg / 32) * sizeof(float2)) + (Kp + 32) * sizeof(float); // staged samples, then the frames; tap row
+    const long    n   = (long)(n_frames * c->N), nseg = ceil_div(n, (long)kTdSeg);
+    int           n_cu = 0;
+    GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->dev));
+
+    const auto    xc = reinterpret_cast<const float2*>(d_in);
+    const auto    hc = static_cast<const float2*>(c->d_hist[c->cur].ptr);
+    const auto    nh = static_cast<float2*>(c->d_hist[c->cur ^ 1].ptr);
+    const float*  af = static_cast<const float*>(c->d_afrag.ptr);
+    const float*  wn = c->windowed ? static_cast<const float*>(c->d_win.ptr) : nullptr;
+    const auto    tw = static_cast<const float2*>(c->d_tw.ptr);
+#define GR4_TD_CASE(L2)                                                                                                                    \
+    case L2: {                                                                                                                             \
+        auto kern = chain_td_kernel<KS, L2>;                                                                                               \
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+        const dim3 grid((unsigned)std::min<long>(nseg, (long)n_cu * td_waves<KS, L2>()));                          \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, xc, hc, af, wn, tw, d_mag2, n, nh);                                        \
+    } break
+    switch (c->log2n) {
+        GR4_TD_CASE(8);
+        GR4_TD_CASE(9);
+        GR4_TD_CASE(10);
+        GR4_TD_CASE(11);
+        GR4_TD_CASE(12);
+    default: return GR4HIP_UNSUPPORTED;
+    }
+#undef GR4_TD_CASE
+    GR4_LAUNCH_CHECK();
+    c->cur ^= 1;
+    return GR4HIP_OK;
+}
+
+int chain_td_process(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
+    if (n_frames == 0) return GR4HIP_OK;
+    GR4_REQUIRE((uintptr_t)d_in % 8 == 0 && (uintptr_t)d_mag2 % 4 == 0, "fused time-domain chain: misaligned device pointer");
+    switch (c->KS) {
+    case 20: return td_launch<20>(c, d_in, n_frames, d_mag2, st);
+    case 36: return td_launch<36>(c, d_in, n_frames, d_mag2, st);
+    default: return td_launch<68>(c, d_in, n_frames, d_mag2, st);
+    }
+}
+
+} // namespace gr4

@@ -69,7 +69,7 @@ enum { /* FFT block output options (blocks/fourier/.../fft.hpp:103-105) */
 typedef enum { /* how the FIR->FFT->mag2 chain is executed */
     GR4HIP_CHAIN_AUTO = 0,
     GR4HIP_CHAIN_UNFUSED,  /* fir kernel -> HBM -> fft+mag2 kernel (any window, any size the FFT block supports) */
-    GR4HIP_CHAIN_FUSED_TD, /* reserved (time-domain FIR in LDS + FFT + mag2): not implemented, create returns GR4HIP_UNSUPPORTED */
+    GR4HIP_CHAIN_FUSED_TD, /* one launch: direct-form FIR on the matrix pipe -> window -> FFT -> mag2 (fft_size 256 .. 4096, <= 256 taps); AUTO takes it for <= 64 taps */
     GR4HIP_CHAIN_FUSED_FD, /* one launch, frequency-domain FIR (circular convolution + exact tail correction) + FFT + mag2;
                               fft_size 256 ... 8192 (power of two), <= 256 taps, any window */
     GR4HIP_CHAIN_TIME_DOMAIN /* direct-form FIR kernel -> HBM -> fft+mag2 kernel: the reference's arithmetic; for inputs whose out-of-band content

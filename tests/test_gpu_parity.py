@@ -832,7 +832,7 @@ def test_chain_fused_input_alignment(G):
         assert torch.equal(ref, got)
 
 
-@pytest.mark.parametrize("algo", [1, 0])
+@pytest.mark.parametrize("algo", [1, 0, 3, 2])
 @pytest.mark.parametrize("N,ntaps,window", [(8192, 256, "None"), (8192, 256, "Hann"), (8192, 91, "Rectangular"), (8192, 1, "None"),
                                             (8192, 200, "BlackmanHarris"), (8192, 256, "Kaiser"), (8192, 17, "FlatTop"),
                                             (1024, 64, "None"), (256, 33, "Hann"), (1024, 64, "Hann"), (512, 256, "BlackmanHarris"),
@@ -843,9 +843,13 @@ def test_chain_parity(G, algo, N, ntaps, window):
     x = O.signal_c32(42, frames * N)
     wid = [w.lower() for w in O.WINDOWS].index(window.lower())
     truth, _ = O.chain(b, x, N, wid, truth=True)
+    if algo == G.capi.CHAIN_FUSED_TD and N > 4096:
+        with pytest.raises(G.capi.Gr4HipError):  # the fused time-domain kernel covers fftSize 256 .. 4096
+            G.Chain(b, N, window, algo)
+        return
     ch = G.Chain(b, N, window, algo)
-    if algo == 0:
-        assert ch.algo == G.capi.CHAIN_FUSED_FD  # the headline configuration and the FFT block's default sizes must take the fused kernel
+    if algo == 0:  # the headline configuration and the FFT block's default sizes must take a fused kernel: the time-domain one up to 64 taps
+        assert ch.algo == (G.capi.CHAIN_FUSED_TD if ntaps <= 64 and N <= 4096 else G.capi.CHAIN_FUSED_FD)
     half = (frames // 2) * N
     got = np.concatenate([ch.process_bulk(dev(x[:half])).cpu().numpy().ravel(), ch.process_bulk(dev(x[half:])).cpu().numpy().ravel()])
     assert _rel(got, truth) <= TOL
@@ -857,6 +861,29 @@ def test_chain_parity(G, algo, N, ntaps, window):
     cpu32, _ = O.chain(b, xn, N, wid, truth=False)
     ch.reset()
     assert _rel(ch.process_bulk(dev(xn)).cpu().numpy().ravel(), tn) <= _rel(cpu32, tn) + 2e-6  # as accurate as the float32 CPU port, to 1/5 of TOL
+
+
+@pytest.mark.parametrize("window", ["None", "Hann"])
+@pytest.mark.parametrize("N,ntaps", [(256, 64), (512, 17), (1024, 64), (1024, 200), (2048, 128), (4096, 64), (4096, 256), (1024, 1)])
+def test_chain_fused_time_domain_many_segments(G, N, ntaps, window):
+    """GR4HIP_CHAIN_FUSED_TD at a device-generated stream of many 4096-sample segments (every workgroup takes several, registers prefetch the next
+    one), in ragged calls whose frame counts are not whole segments: sampled frames against the float64 oracle, and the whole output against the
+    FIR kernel + FFT kernel pair"""
+    frames = (1 << 22) // N + 3
+    wid = [w.lower() for w in O.WINDOWS].index(window.lower())
+    b = O.design_taps_hamming_lowpass(ntaps, 0.1) if ntaps > 1 else np.array([0.5], np.float32)
+    x = G.synth_c32(frames * N, seed=23)
+    ch = G.Chain(b, N, window, G.capi.CHAIN_FUSED_TD)
+    assert ch.algo == G.capi.CHAIN_FUSED_TD
+    cuts = [0, 1, 1 + (4096 // N) * 5 + 1, frames // 2, frames]
+    got = torch.cat([ch.process_bulk(x[a * N: c * N]) for a, c in zip(cuts[:-1], cuts[1:])])
+    ref = G.Chain(b, N, window, G.capi.CHAIN_TIME_DOMAIN).process_bulk(x)
+    assert float((got - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    fps = max(4096 // N, 1)
+    for f in sorted({0, 1, 2, fps - 1, fps, 4 * fps, 4 * fps + 1, cuts[2] - 1, cuts[2], cuts[3] - 1, cuts[3], frames - 1}):
+        lo = max(f - (256 + N - 1) // N, 0)
+        truth, _ = O.chain(b, x[lo * N:(f + 1) * N].cpu().numpy(), N, wid, truth=True)
+        assert _rel(got[f].cpu().numpy(), truth.reshape(-1, N)[f - lo]) <= TOL, (f,)
 
 
 @pytest.mark.parametrize("N,ntaps,window", [(1000, 33, "Hann"), (8192, 300, "None"), (16384, 64, "Hann"), (4096, 1024, "BlackmanHarris"), (128, 16, "None")])
@@ -918,6 +945,24 @@ def test_chain_dynamic_range_and_the_time_domain_algo(G):
     assert np.max(np.abs(got - yp)) <= 4e-6 * float(np.sqrt(np.mean(np.abs(xp) ** 2))) and _rel(got, yp) <= TOL
 
 
+def test_chain_guard_hands_small_fft_sizes_to_the_fused_time_domain_kernel(G):
+    """fftSize <= 4096 with more than 64 taps: CHAIN_AUTO starts on the fused fast convolution; a stream whose filter removes most of the input is handed
+    (history included) to the fused time-domain kernel -- one launch, the reference's arithmetic -- and meets the bar relative to the OUTPUT"""
+    N, frames, ntaps = 1024, 700, 200
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    x = O.signal_c32(81, frames * N, tone_frel=0.31, tone_amp=30.0)
+    truth, _ = O.chain(b, x, N, 3, truth=True)
+    ch = G.Chain(b, N, "Hann")
+    assert ch.algo == G.capi.CHAIN_FUSED_FD
+    cut = 650 * N
+    got = np.concatenate([ch.process_bulk(dev(x[:cut])).cpu().numpy().ravel(), ch.process_bulk(dev(x[cut:])).cpu().numpy().ravel()])
+    ratio, td = ch.last_power_ratio()
+    assert td and 0 <= ratio < 0.04, (ratio, td)
+    assert _rel(got, truth) <= TOL
+    fd = G.Chain(b, N, "Hann", G.capi.CHAIN_FUSED_FD).process_bulk(dev(x)).cpu().numpy().ravel()
+    assert _rel(fd, truth) > TOL  # what the guard is for
+
+
 def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
     """the guard of CHAIN_AUTO: pass-band input never leaves the fused kernel; an interferer that appears in a LATER call is found by that call's own
     measurement and the following calls run in the time domain (the one call in between carries the fused kernel's floor: 4e-6 of the input rms)"""
@@ -942,12 +987,16 @@ def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
     assert _rel(ch.process_bulk(dev(clean)).cpu().numpy().ravel(), t[0]) <= TOL and not ch.last_power_ratio()[1]  # a reset re-arms the fused kernel
     # the measured ratio is the filter's power gain whatever the fftSize and window: white noise through a DC-gain-1 low-pass passes sum b^2 of its power
     noise = O.signal_c32(8, 64 * N, tone_amp=0.0)
-    want = float(np.sum(b.astype(np.float64) ** 2))
-    for fft_size, window in ((8192, "None"), (8192, "Hann"), (1024, "Hann"), (256, "None")):
-        c2 = G.Chain(b, fft_size, window)
+    b100 = O.design_taps_hamming_lowpass(100, 0.02)  # (up to 64 taps the small sizes take the fused time-domain kernel: nothing to guard)
+    for fft_size, window, taps in ((8192, "None", b), (8192, "Hann", b), (1024, "Hann", b100), (256, "None", b100)):
+        want = float(np.sum(taps.astype(np.float64) ** 2))
+        c2 = G.Chain(taps, fft_size, window)
+        assert c2.algo == G.capi.CHAIN_FUSED_FD
         c2.process_bulk(dev(noise))
         r, _ = c2.last_power_ratio()
         assert 0.7 * want < r < 1.4 * want, (fft_size, window, r, want)
+    c3 = G.Chain(b, 1024, "Hann")
+    assert c3.algo == G.capi.CHAIN_FUSED_TD and c3.last_power_ratio() == (-1.0, False)
 
 
 def test_chain_random_configurations(G):
@@ -978,7 +1027,7 @@ def test_chain_small_fft_size_chunking(G, N):
     frames = 5 * per + 3
     x = dev(O.signal_c32(11, frames * N))
     ref = G.Chain(b, N, "Hann", 1).process_bulk(x)
-    ch = G.Chain(b, N, "Hann", 0)
+    ch = G.Chain(b, N, "Hann", G.capi.CHAIN_FUSED_FD)
     assert ch.algo == G.capi.CHAIN_FUSED_FD
     cuts = [0, 1, per, 2 * per + 1, 4 * per + 1, frames]  # 1 frame (tail only), per-1, per+1 (block + tail), 2 blocks, rest
     got = torch.cat([ch.process_bulk(x[a * N: c * N]) for a, c in zip(cuts[:-1], cuts[1:])])
