@@ -36,13 +36,13 @@ using td_f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kTdSeg = 4096; // complex samples per segment
 
 // waves per SIMD the kernel is compiled for (512 / W registers per lane): the most that needs no scratch -- 16 x 16 transforms fit 128 registers,
-// a third pass of radix >= 4 wants ~140 .. 165, 256 taps at 1024 points and beyond ~230
+// a third pass of radix >= 4 wants ~146 .. 153
 template <int KS, int LOG2N>
 constexpr int td_waves() {
 #ifdef GR4_TD_W
     return GR4_TD_W;
 #else
-    return (LOG2N <= 9 && KS <= 36) || LOG2N == 8 ? 4 : (KS == 68 ? 2 : 3);
+    return LOG2N == 8 || (LOG2N == 9 && KS == 20) ? 4 : (KS == 68 ? 2 : 3); // (256 taps under the 168-register cap with the pinned MFMA order: the compiler does not finish)
 #endif
 }
 
@@ -104,6 +104,12 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
         }
         GR4_TD_BARRIER();
 
+        float4 wq[4]; // this lane's window values, requested before the MFMAs (the frame-buffer writes behind them would otherwise wait for the L2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pos = (16 * (16 * (4 * wave + q) + col) + 4 * kq) & (N - 1);
+            wq[q]         = win ? *reinterpret_cast<const float4*>(win + pos) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
         // ---- direct-form FIR on the matrix pipe: this wave's four tiles of 256 outputs, re and im accumulators under the same A fragment
         td_f32x4 acr[4], aci[4];
 #pragma unroll
@@ -128,14 +134,14 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
                 ai1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p1[NPL + off], ai1, 0, 0, 0);
             }
             acr[2 * pp] = ar0; aci[2 * pp] = ai0; acr[2 * pp + 1] = ar1; aci[2 * pp + 1] = ai1;
+            // (pinning the MFMA / LDS-read order with sched_group_barrier changes nothing here -- other waves hide the operand latency -- and costs minutes of compile time)
         }
         GR4_TD_BARRIER(); // every wave is done with the staged samples: the frame buffer takes their place
         // D[row = 4 kq + r][col] of tile q: sample 16 (16 (4 wave + q) + col) + 4 kq + r of the segment; x window -> frame buffer (natural order)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int o = 16 * (16 * (4 * wave + q) + col) + 4 * kq, f = o >> LOG2N, pos = o & (N - 1);
-            float4    w = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (win) w = *reinterpret_cast<const float4*>(win + pos);
+            const float4 w = wq[q];
             float2* d = fb + f * NP + P(pos); // pos % 4 == 0: the four samples share a 32-block
             d[0]      = make_float2(acr[q][0] * w.x, aci[q][0] * w.x);
             d[1]      = make_float2(acr[q][1] * w.y, aci[q][1] * w.y);
@@ -219,6 +225,18 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Why the kernel above alternates and does not pipeline.  Two pipelined forms were built and measured against it (64 taps -> 1024-pt Hann, 251 Gsamples/s):
+//  * 512 lanes, waves 0..3 multiply segment i while waves 4..7 transform segment i - 1, six workgroup barriers per segment: 177;
+//  * producer / consumer wave pairs (wave w multiplies blocks of 1024 samples, wave w + 4 transforms them; frame slots and two LDS counters per pair, no
+//    workgroup barrier at all, MFMA / LDS-read order pinned with sched_group_barrier): 230.
+// In every form the time is the SUM of the filter's and the transform's: the M role alone runs the matrix pipe at 84 % (396 Gsamples/s), the F role alone
+// at 298 .. 438, both together never beat the alternating kernel; counters of the latter: v_mfma_f32 busy 53 % + other VALU 29 %.  The f32 MFMA has the
+// FP32 VALU's rate (64 flop / clk / SIMD) and, by these measurements, its issue slot: a SIMD does one or the other.  "Matrix pipe beside the VALU" holds
+// for the reduced-precision MFMAs, not for this one -- so 2.33 ps (filter) + ~0.7 ps (transform) + staging per sample bound this chain at ~300 Gsamples/s.
+// (Also measured: pinning the order in the alternating kernel changes nothing -- other waves hide the operand latency -- and the solver behind
+// sched_group_barrier does not finish on a 272-MFMA region.)
 
 struct ChainTd {
     size_t       ntaps = 0, N = 0;
