@@ -111,12 +111,25 @@ F = G.FFT(1024, "Hann")
 t = timeit(lambda: F.process_bulk(xc))
 res["FFT block 1024 (Hann) -> DataSet (mag, phase, re, im, ranges)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 24 / t / 1e9, 1), "hbm_frac": round(n * 24 / t / 8e12, 3),
                                                                          "note": "24 B/sample: 8 in + 4 x 4 out; per-frame min/max ranges reduced inside the kernel; includes torch output allocation"}
-# chain at the FFT block's default size (fused: 8192-sample fast-convolution blocks, fftSize-point transforms on the LDS image), Decimator, Rotator
+# chain at the FFT block's default size (<= 64 taps: fused time-domain kernel -- direct-form filter + one transform per frame in one launch), Decimator, Rotator
 ch = G.Chain(lowpass(64, 0.1), 1024, "Hann")
 m2 = torch.empty((n // 1024, 1024), dtype=torch.float32, device="cuda")
 t = timeit(lambda: ch.process_bulk(xc, m2))
-res["chain complex 64-tap FIR -> 1024-pt FFT (Hann) -> mag2 (fused, fftSize < 8192)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 12 / t / 1e9, 1), "hbm_frac": round(n * 12 / t / 8e12, 3),
+res["chain complex 64-tap FIR -> 1024-pt FFT (Hann) -> mag2 (fused time domain, AUTO)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 12 / t / 1e9, 1), "hbm_frac": round(n * 12 / t / 8e12, 3),
                                                                                "note": "one launch, traffic = algorithmic (the unfused pair moved 28 B/sample: y written and re-read)"}
+chf = G.Chain(lowpass(64, 0.1), 1024, "Hann", G.capi.CHAIN_FUSED_FD)
+t = timeit(lambda: chf.process_bulk(xc, m2))
+res["chain complex 64-tap FIR -> 1024-pt FFT (Hann) -> mag2 (fused fast convolution, fftSize < 8192)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 12 / t / 1e9, 1), "hbm_frac": round(n * 12 / t / 8e12, 3)}
+# interpolating FIR: x8 with 256 taps (block-Toeplitz on the f32 matrix pipe), outputs per second
+itp = G.fir_interpolator(lowpass(256, 0.05), 8)
+xi8 = xc.view(torch.float32)[: 1 << 23]
+yi8 = torch.empty(xi8.numel() * 8, dtype=torch.float32, device="cuda")
+t = timeit(lambda: itp.process_bulk(xi8, yi8))
+res["fir_interpolator<float> x8, 256 taps"] = {"Moutputs/s": round(yi8.numel() / t / 1e6, 1), "alg_GB/s": round(yi8.numel() * 4.5 / t / 1e9, 1), "hbm_frac": round(yi8.numel() * 4.5 / t / 8e12, 3)}
+del yi8
+cf64 = G.fir_filter(lowpass(64, 0.1), torch.complex64)
+t = timeit(lambda: cf64.process_bulk(xc, sp))
+res["fir_filter<complex<float>> 64 taps (direct form on the matrix pipe)"] = {"Msamples/s": round(n / t / 1e6, 1), "alg_GB/s": round(n * 16 / t / 1e9, 1), "hbm_frac": round(n * 16 / t / 8e12, 3)}
 xr = xc.view(torch.float32)
 dec = G.Decimator(10)
 t = timeit(lambda: dec.process_bulk(xr))
