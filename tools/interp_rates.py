@@ -8,7 +8,7 @@ import numpy as np, torch
 import gnuradio4_amd as G
 from _timing import steady
 for dtype, S in ((torch.float32, 1), (torch.complex64, 2)):
-    for L, K in ((2, 64), (2, 256), (3, 91), (4, 256), (8, 256), (8, 1024), (16, 256), (7, 128), (12, 256), (32, 512)):
+    for L, K in ((2, 64), (2, 256), (3, 91), (3, 256), (5, 100), (5, 320), (6, 96), (6, 384), (4, 256), (8, 256), (8, 1024), (16, 256), (7, 128), (12, 256), (32, 512)):
         n = (1 << 26) // (L * S)
         x = G.synth_f32(n) if S == 1 else G.synth_c32(n)
         b = (np.hamming(K) / K).astype(np.float32)
