@@ -54,6 +54,96 @@ __global__ __launch_bounds__(kF64BS) void fir64_kernel(const double* __restrict_
     }
 }
 
+// fir_filter<double>, no decimation, 17 .. 2048 taps, long spans: the block-Toeplitz contraction of fir_batched.hip on v_mfma_f64_16x16x4_f64 (the FP64 VALU's
+// rate, reached from one wave per SIMD with one operand read per 2048 flop instead of one LDS read per fma).  With Kp = taps rounded up to 64 / 128 / 256 (compile-time K-loop) or to the next multiple of 64 (run-time K-loop):
+//     y[16 i + j] = sum_{u < Kp + 16} A[j][u] B[u][i],   A[j][u] = b[Kp + j - u]  (Toeplitz: read from the tap row in LDS),   B[u][i] = x[16 i - Kp + u]
+// 4096 outputs per segment (4 waves x 4 tiles of 256), the segment + Kp samples staged 18 / 16-padded (8-byte elements: a K-step's 32 lanes hit 64 different
+// banks), the next segment requested into registers before the MFMAs of this one, workgroup 0 writes the next history.  Bound: MFMA f64, 2 (Kp + 16) flop per sample.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+constexpr int kF64Seg = 4096, kF64SegPerWg = 4;
+template <int KSC> // K-steps of 4 (Kp = 4 KS - 16); 0: given at run time (Kp = 320 .. 2048 in steps of 64)
+__global__ __launch_bounds__(256) void fir64_mfma_kernel(const double* __restrict__ x, const double* __restrict__ hist, int hcap, const double* __restrict__ trow /*[Kp + 32]: index 16 + q = b[q]*/,
+                                                          double* __restrict__ y, long n, double* __restrict__ new_hist, int ks_rt) {
+    const int     KS = KSC ? KSC : ks_rt, Kp = 4 * KS - 16, NPAD = (kF64Seg + Kp) / 16 * 18;
+    constexpr int NL = KSC ? (kF64Seg + 4 * KSC - 16 + 255) / 256 : (kF64Seg + 2048 + 255) / 256;
+    extern __shared__ double smem64[];
+    double*   xs = smem64;        // [NPAD]
+    double*   tp = smem64 + NPAD; // [Kp + 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < Kp + 32; i += 256) tp[i] = trow[i];
+    // v_mfma_f64_16x16x4_f64 returns D[4 r + kq][col] in register r of lane (col, kq) (the f32 form: D[4 kq + r][col]).  A's row i' therefore carries the
+    // taps of output j = 4 (i' & 3) + (i' >> 2): register r of a lane is then output 4 kq + r of its block, and a lane's four results are contiguous
+    const double* pa = tp + 16 + Kp + (4 * (col & 3) + (col >> 2)) - kq;
+    double        nxt[NL];
+    auto          load_next = [&](long seg0) { // seg0 >= kF64Seg > Kp: nothing below 0; past the end of the span / of the segment: 0
+        const long i0 = seg0 - Kp;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const long i = i0 + tid + 256 * u;
+            nxt[u]       = (tid + 256 * u < kF64Seg + Kp && i < n) ? x[i] : 0.0;
+        }
+    };
+    const long nseg = (n + kF64Seg - 1) / kF64Seg, sfirst = (long)blockIdx.x * kF64SegPerWg, slast = sfirst + kF64SegPerWg < nseg ? sfirst + kF64SegPerWg : nseg;
+    if (sfirst > 0 && sfirst < slast) load_next(sfirst * kF64Seg);
+    for (long sg = sfirst; sg < slast; ++sg) {
+        const long seg0 = sg * kF64Seg;
+        if (sg > 0) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int s_ = tid + 256 * u;
+                if (s_ < kF64Seg + Kp) xs[s_ + 2 * (s_ >> 4)] = nxt[u];
+            }
+        } else {
+            for (int s_ = tid; s_ < kF64Seg + Kp; s_ += 256) { // the first segment of the span reads the carried history in front of x
+                const long i           = s_ - Kp;
+                xs[s_ + 2 * (s_ >> 4)] = i >= 0 ? (i < n ? x[i] : 0.0) : (i >= -(long)hcap ? hist[hcap + i] : 0.0);
+            }
+        }
+        __syncthreads();
+        if (sg + 1 < slast) load_next(seg0 + kF64Seg); // in flight during the MFMAs below
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) { // two independent accumulators per round
+            const int     ib0 = 16 * (4 * wave + 2 * pair), ib1 = ib0 + 16;
+            f64x4         acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+            const double* p0 = xs + 18 * (ib0 + col) + kq;
+            const double* p1 = xs + 18 * (ib1 + col) + kq;
+            auto kstep = [&](int ks) {
+                const int    off = 4 * ks + 2 * (ks >> 2);
+                const double a   = pa[-4 * ks];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, p0[off], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, p1[off], acc1, 0, 0, 0);
+            };
+            if constexpr (KSC != 0) {
+#pragma unroll
+                for (int ks = 0; ks < KSC; ++ks) kstep(ks);
+            } else {
+                for (int ks = 0; ks < KS; ks += 4) { kstep(ks); kstep(ks + 1); kstep(ks + 2); kstep(ks + 3); } // KS = Kp / 4 + 4 with 64 | Kp: a multiple of 4
+            }
+            // D[row = 4 kq + r][col]: y[16 (ib + col) + 4 kq + r]
+            const long o0 = seg0 + 16L * (ib0 + col) + 4 * kq, o1 = seg0 + 16L * (ib1 + col) + 4 * kq;
+            if (o0 + 3 < n) {
+                *reinterpret_cast<double2*>(y + o0)     = make_double2(acc0[0], acc0[1]);
+                *reinterpret_cast<double2*>(y + o0 + 2) = make_double2(acc0[2], acc0[3]);
+            } else
+                for (int r = 0; r < 4; ++r)
+                    if (o0 + r < n) y[o0 + r] = acc0[r];
+            if (o1 + 3 < n) {
+                *reinterpret_cast<double2*>(y + o1)     = make_double2(acc1[0], acc1[1]);
+                *reinterpret_cast<double2*>(y + o1 + 2) = make_double2(acc1[2], acc1[3]);
+            } else
+                for (int r = 0; r < 4; ++r)
+                    if (o1 + r < n) y[o1 + r] = acc1[r];
+        }
+        __syncthreads(); // every wave is done with the staged segment before the next one overwrites it
+    }
+    if (blockIdx.x == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
+        for (int h = tid; h < hcap; h += 256) {
+            const long g = n - hcap + h;
+            new_hist[h]  = g >= 0 ? x[g] : hist[hcap + g];
+        }
+    }
+}
+
 // new_hist[h] = virtual sample n_in - hcap + h of (old_hist ++ x)
 __global__ void hist64_kernel(const double* __restrict__ x, const double* __restrict__ old_hist, double* __restrict__ new_hist, long n_in, int hcap) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,7 +402,7 @@ using namespace gr4;
 struct gr4hip_fir64 {
     std::vector<double> taps;
     size_t              decim = 1, hcap = 32;
-    DeviceBuffer        d_taps, d_hist[2];
+    DeviceBuffer        d_taps, d_hist[2], d_trow; // d_trow: zero-padded tap row of the matrix-pipe kernel
     int                 cur = 0;
 };
 struct gr4hip_iir64 {
@@ -338,6 +428,14 @@ static int fir64_upload(gr4hip_fir64* f, const double* taps, size_t ntaps, bool 
     int          rc   = f->d_taps.ensure(ntaps * sizeof(double));
     if (rc) return rc;
     GR4_HIP_TRY(hipMemcpy(f->d_taps.ptr, taps, ntaps * sizeof(double), hipMemcpyHostToDevice));
+    { // fir64_mfma_kernel: row[16 + q] = b[q], zero elsewhere
+        const size_t        Kp = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : ntaps <= 256 ? 256 : (ntaps + 63) / 64 * 64;
+        std::vector<double> row(Kp + 32, 0.0);
+        for (size_t q = 0; q < ntaps; ++q) row[16 + q] = taps[q];
+        rc = f->d_trow.ensure(row.size() * sizeof(double));
+        if (rc) return rc;
+        GR4_HIP_TRY(hipMemcpy(f->d_trow.ptr, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (!keep_history || hcap != f->hcap || !f->d_hist[0].ptr) { // a history that has to grow starts empty, as upstream's replaced HistoryBuffer does
         for (auto& h : f->d_hist) {
             rc = h.ensure(hcap * sizeof(double));
@@ -385,6 +483,25 @@ int gr4hip_fir64_process(gr4hip_fir64_t* f, const double* d_in, size_t n_in, dou
     GR4_REQUIRE(d_in && d_out, "fir64_process: null device pointer");
     hipStream_t st = as_stream(stream);
     const int   K = (int)f->taps.size(), D = (int)f->decim;
+    if (D == 1 && K > 16 && n_in >= 32768 && (uintptr_t)d_out % 16 == 0 && f->d_trow.ptr) { // matrix-pipe form; writes the next history itself
+        const int    Kp = K <= 64 ? 64 : K <= 128 ? 128 : K <= 256 ? 256 : (K + 63) / 64 * 64, NPAD = (kF64Seg + Kp) / 16 * 18;
+        const size_t lds = ((size_t)NPAD + Kp + 32) * sizeof(double);
+        const dim3   grid((unsigned)ceil_div(ceil_div((long)n_in, (long)kF64Seg), (long)kF64SegPerWg));
+        const auto   hp = (const double*)f->d_hist[f->cur].ptr;
+        auto         nh = (double*)f->d_hist[f->cur ^ 1].ptr;
+        const auto   tr = (const double*)f->d_trow.ptr;
+#define GR4_F64_MFMA(KSV)                                                                                                                   \
+    do {                                                                                                                                    \
+        auto kern = fir64_mfma_kernel<KSV>;                                                                                                 \
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d_in, hp, (int)f->hcap, tr, d_out, (long)n_in, nh, (Kp + 16) / 4);               \
+    } while (0)
+        if (Kp == 64) GR4_F64_MFMA(20); else if (Kp == 128) GR4_F64_MFMA(36); else if (Kp == 256) GR4_F64_MFMA(68); else GR4_F64_MFMA(0);
+#undef GR4_F64_MFMA
+        GR4_LAUNCH_CHECK();
+        f->cur ^= 1;
+        return GR4HIP_OK;
+    }
     const int   R = D <= 8 ? 4 : D <= 16 ? 2 : 1;
     const size_t lds = ((size_t)K + (size_t)(kF64BS * R - 1) * D + K) * sizeof(double);
     const auto  kern = R == 4 ? fir64_kernel<4> : R == 2 ? fir64_kernel<2> : fir64_kernel<1>;

@@ -1567,6 +1567,23 @@ def test_fir_filter_float64(G, ntaps, decim):
     assert e.value.status == G.capi.UNSUPPORTED
 
 
+@pytest.mark.parametrize("ntaps", [17, 64, 65, 100, 129, 256, 257, 700, 1024, 2048])
+def test_fir_filter_float64_matrix_pipe(G, ntaps):
+    """fir_filter<double>, 17 .. 2048 taps, spans of >= 32768 samples: the block-Toeplitz contraction on v_mfma_f64_16x16x4_f64 (fir64_mfma_kernel) -- many
+    segments per workgroup, ragged ends, history handed between the matrix-pipe and the plain kernel across calls"""
+    rng = np.random.default_rng(ntaps)
+    b = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+    n = 400_003
+    x = rng.standard_normal(n)
+    truth = np.convolve(x, b)[:n]
+    f = G.fir_filter(b, torch.float64)
+    cuts = [0, 100_001, 100_004, 105_000, 370_000, 371_000, n]  # long spans (matrix pipe), short ones (plain kernel) in between
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert y.dtype == np.float64 and _rel(y, truth) <= TOL64
+    f.reset()
+    assert _rel(f.process_bulk(dev(x)).cpu().numpy(), truth) <= TOL64
+
+
 @pytest.mark.parametrize("kind", ["biquad4", "pole1", "order4", "narrow"])
 def test_iir_filter_float64(G, kind):
     import scipy.signal as sps

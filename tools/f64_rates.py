@@ -8,7 +8,7 @@ from _timing import steady
 import gnuradio4_amd as G
 n = 1 << 24
 x = torch.randn(n, dtype=torch.float64, device="cuda"); y = torch.empty_like(x)
-for K in (32, 256, 1024):
+for K in (32, 64, 128, 256, 1024):
     f = G.fir_filter(np.hanning(K) / K, torch.float64)
     t = steady(lambda: f.process_bulk(x, y))
     print("fir_filter<double> %4d taps: %7.2f Gsamples/s  %.2f TFLOP/s (FP64)" % (K, n / t / 1e9, 2.0 * K * n / t / 1e12))
