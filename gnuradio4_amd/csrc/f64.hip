@@ -156,6 +156,8 @@ __global__ void hist64_kernel(const double* __restrict__ x, const double* __rest
 constexpr int kI64L  = 32;  // samples per lane chunk
 constexpr int kI64BS = 256; // chunks per tile
 constexpr int kI64MP = 8;   // state dimension the kernels are built for (up to 4 biquads, or one section of order <= 8)
+constexpr int kI64P  = kI64L + 1; // pitch of a lane's chunk in the staged tile: 33 doubles = 66 dwords, a lane group's 8-byte accesses hit 64 different banks
+static_assert(kI64L == 32, "the staging index arithmetic below uses idx >> 5, idx & 31");
 
 struct Iir64Desc {
     int    nsec, ord;              // sections of order `ord` (state: ord values per section, direct form II)
@@ -193,25 +195,35 @@ __device__ __forceinline__ void matvec64(const double* __restrict__ M, const dou
     }
 }
 
+// The tile's 8192 samples go through LDS: consecutive lanes load consecutive samples (a lane reading its own 256-byte chunk straight from global memory
+// touches 64 cache lines per load instruction -- the first version ran 4 biquads at 26 Gsamples/s), then every lane walks its chunk at pitch 33.
+__device__ __forceinline__ void iir64_stage_tile(double* sm, const double* __restrict__ x, long tile, long n, int l) {
+    const long t0 = tile * (long)(kI64BS * kI64L);
+#pragma unroll 8
+    for (int j = 0; j < kI64L; ++j) {
+        const int idx = j * kI64BS + l;
+        sm[(idx >> 5) * kI64P + (idx & 31)] = t0 + idx < n ? x[t0 + idx] : 0.0;
+    }
+}
+
 // pass Z: per tile of 256 chunks: zero-state end state of every chunk, inclusive scan over the chunks (P_l = state at the end of chunk l when the tile
 // starts from zero), all P_l to scratch, the tile's own end state Z_t = P_255
 template <int NSEC, int ORD>
 __global__ __launch_bounds__(kI64BS) void iir64_pass_z(Iir64Desc d, const double* __restrict__ x, long n, const double* __restrict__ phiPow /*[8][MP][MP]: Phi_L^(2^k)*/,
                                                        double* __restrict__ P /*[tiles][256][MP]*/, double* __restrict__ Z /*[tiles][MP]*/) {
     constexpr int MP = NSEC * ORD;
-    __shared__ double sc[2][MP][kI64BS]; // lane-contiguous
+    extern __shared__ double smem64[];
+    double (*sc)[MP][kI64BS] = reinterpret_cast<double (*)[MP][kI64BS]>(smem64 + kI64BS * kI64P); // [2][MP][256], lane-contiguous
     const long tile = blockIdx.x;
     const int  l    = threadIdx.x;
-    const long i0   = (tile * kI64BS + l) * kI64L;
-    double     s[MP];
+    iir64_stage_tile(smem64, x, tile, n, l);
+    __syncthreads();
+    double        s[MP];
+    const double* xc = smem64 + l * kI64P;
 #pragma unroll
     for (int i = 0; i < MP; ++i) s[i] = 0.0;
-    if (i0 + kI64L <= n) {
 #pragma unroll 8
-        for (int i = 0; i < kI64L; ++i) (void)iir64_step<NSEC, ORD>(d, s, x[i0 + i]);
-    } else {
-        for (int i = 0; i < kI64L; ++i) (void)iir64_step<NSEC, ORD>(d, s, i0 + i < n ? x[i0 + i] : 0.0); // (padding the last tile with zeros only moves states nobody reads)
-    }
+    for (int i = 0; i < kI64L; ++i) (void)iir64_step<NSEC, ORD>(d, s, xc[i]); // (the zero padding of the last tile only moves states nobody reads)
     int cur = 0;
 #pragma unroll
     for (int i = 0; i < MP; ++i) sc[0][i][l] = s[i];
@@ -241,34 +253,63 @@ __global__ __launch_bounds__(kI64BS) void iir64_pass_z(Iir64Desc d, const double
     }
 }
 
-// pass B: the tiles in order, T_{t+1} = Phi_B T_t + Z_t; T_0 = the carried state.  One lane walks the dependent chain; the workgroup stages the Z_t of
-// 256 tiles at a time in LDS so that the walker never waits for global memory
+// pass B: the tiles in order, T_{t+1} = Phi_B T_t + Z_t; T_0 = the carried state -- the same recurrence one level up, evaluated the same way: lane l owns
+// kI64G consecutive tiles, runs them from zero (lane 0: from the carry), a Hillis-Steele scan over the 256 lanes with Phi_B^(G 2^k) gives every lane the state
+// its group starts from, and a second run writes the T_t.  4096 tiles (2^25 samples) per round; longer spans take further rounds from the carried state.
+// (One lane walking all tiles in order was 68 % of the cascade's time at 2^24 samples: 0.52 of 0.76 ms.)
+constexpr int kI64G = 16; // tiles per lane
 template <int MP>
-__global__ __launch_bounds__(256) void iir64_pass_b(const double* __restrict__ phiB, const double* __restrict__ Z, long tiles, const double* __restrict__ state0, double* __restrict__ T /*[tiles][MP]*/) {
-    constexpr int    kStage = 256;
-    __shared__ double zs[kStage * MP], ts[kStage * MP], M[MP * MP], carry[MP];
-    for (int i = threadIdx.x; i < MP * MP; i += 256) M[i] = phiB[i];
-    if (threadIdx.x < MP) carry[threadIdx.x] = state0[threadIdx.x];
-    for (long t0 = 0; t0 < tiles; t0 += kStage) {
-        const int cnt = (int)(tiles - t0 < kStage ? tiles - t0 : kStage);
-        for (int i = threadIdx.x; i < cnt * MP; i += 256) zs[i] = Z[t0 * MP + i];
+__global__ __launch_bounds__(256) void iir64_pass_b(const double* __restrict__ phiB /*[9][MP][MP]: Phi_B, then Phi_B^(G 2^k), k < 8*/, const double* __restrict__ Z, long tiles,
+                                                     const double* __restrict__ state0, double* __restrict__ T /*[tiles][MP]*/) {
+    __shared__ double sc[2][MP][256], carry[MP];
+    const int l = threadIdx.x;
+    if (l < MP) carry[l] = state0[l];
+    __syncthreads();
+    for (long t0 = 0; t0 < tiles; t0 += 256 * kI64G) {
+        const long g0 = t0 + (long)l * kI64G;
+        double     s[MP], t[MP];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) s[i] = l == 0 ? carry[i] : 0.0;
+        for (int c = 0; c < kI64G; ++c) { // end state of the group (tiles past the end contribute nothing: nobody reads what follows them)
+            matvec64<MP>(phiB, s, t);
+#pragma unroll
+            for (int i = 0; i < MP; ++i) s[i] = t[i] + (g0 + c < tiles ? Z[(g0 + c) * MP + i] : 0.0);
+        }
+        int cur = 0;
+#pragma unroll
+        for (int i = 0; i < MP; ++i) sc[0][i][l] = s[i];
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double s[MP], t[MP];
+        for (int k = 0, off = 1; off < 256; ++k, off <<= 1) { // P_l <- Phi_B^(G off) P_{l - off} + P_l
+            double v[MP];
 #pragma unroll
-            for (int i = 0; i < MP; ++i) s[i] = carry[i];
-            for (int c = 0; c < cnt; ++c) {
+            for (int i = 0; i < MP; ++i) v[i] = sc[cur][i][l];
+            if (l >= off) {
+                double u[MP];
 #pragma unroll
-                for (int i = 0; i < MP; ++i) ts[c * MP + i] = s[i];
-                matvec64<MP>(M, s, t);
+                for (int i = 0; i < MP; ++i) u[i] = sc[cur][i][l - off];
+                matvec64<MP>(phiB + (long)(1 + k) * MP * MP, u, t);
 #pragma unroll
-                for (int i = 0; i < MP; ++i) s[i] = t[i] + zs[c * MP + i];
+                for (int i = 0; i < MP; ++i) v[i] += t[i];
             }
 #pragma unroll
-            for (int i = 0; i < MP; ++i) carry[i] = s[i];
+            for (int i = 0; i < MP; ++i) sc[cur ^ 1][i][l] = v[i];
+            cur ^= 1;
+            __syncthreads();
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt * MP; i += 256) T[t0 * MP + i] = ts[i];
+#pragma unroll
+        for (int i = 0; i < MP; ++i) s[i] = l == 0 ? carry[i] : sc[cur][i][l - 1]; // the state this lane's group starts from
+        __syncthreads(); // (lane 0 has read the carry)
+        if (l == 255) {
+#pragma unroll
+            for (int i = 0; i < MP; ++i) carry[i] = sc[cur][i][255]; // only read when another round follows, i.e. when every group was full
+        }
+        for (int c = 0; c < kI64G && g0 + c < tiles; ++c) {
+#pragma unroll
+            for (int i = 0; i < MP; ++i) T[(g0 + c) * MP + i] = s[i];
+            matvec64<MP>(phiB, s, t);
+#pragma unroll
+            for (int i = 0; i < MP; ++i) s[i] = t[i] + Z[(g0 + c) * MP + i];
+        }
         __syncthreads();
     }
 }
@@ -278,11 +319,14 @@ template <int NSEC, int ORD>
 __global__ __launch_bounds__(kI64BS) void iir64_pass_y(Iir64Desc d, const double* __restrict__ x, long n, const double* __restrict__ phiL /*[256][MP][MP]: Phi_L^l*/,
                                                        const double* __restrict__ P, const double* __restrict__ T, double* __restrict__ y, double* __restrict__ state_out) {
     constexpr int MP = NSEC * ORD;
+    extern __shared__ double smem64[];
     const long tile = blockIdx.x;
     const int  l    = threadIdx.x;
     const long i0   = (tile * kI64BS + l) * kI64L;
-    if (i0 >= n) return;
-    double s[MP], tt[MP], t0[MP];
+    iir64_stage_tile(smem64, x, tile, n, l);
+    __syncthreads();
+    double* xc = smem64 + l * kI64P; // y takes the place of x, sample by sample
+    double  s[MP], tt[MP], t0[MP];
 #pragma unroll
     for (int i = 0; i < MP; ++i) t0[i] = T[tile * MP + i];
     matvec64<MP>(phiL + (long)l * MP * MP, t0, tt);
@@ -290,13 +334,20 @@ __global__ __launch_bounds__(kI64BS) void iir64_pass_y(Iir64Desc d, const double
     for (int i = 0; i < MP; ++i) s[i] = tt[i] + (l > 0 ? P[(tile * kI64BS + l - 1) * MP + i] : 0.0);
     if (i0 + kI64L <= n) {
 #pragma unroll 8
-        for (int i = 0; i < kI64L; ++i) y[i0 + i] = iir64_step<NSEC, ORD>(d, s, x[i0 + i]);
+        for (int i = 0; i < kI64L; ++i) xc[i] = iir64_step<NSEC, ORD>(d, s, xc[i]);
     } else {
-        for (int i = 0; i < kI64L && i0 + i < n; ++i) y[i0 + i] = iir64_step<NSEC, ORD>(d, s, x[i0 + i]);
+        for (int i = 0; i < kI64L && i0 + i < n; ++i) xc[i] = iir64_step<NSEC, ORD>(d, s, xc[i]);
     }
-    if (i0 + kI64L >= n) {
+    if (i0 < n && i0 + kI64L >= n) { // the lane that holds the last sample of the span: the state after it
 #pragma unroll
         for (int i = 0; i < MP; ++i) state_out[i] = s[i];
+    }
+    __syncthreads();
+    const long t0s = tile * (long)(kI64BS * kI64L);
+#pragma unroll 4
+    for (int j = 0; j < kI64L; ++j) { // coalesced: consecutive lanes store consecutive samples
+        const int idx = j * kI64BS + l;
+        if (t0s + idx < n) y[t0s + idx] = smem64[(idx >> 5) * kI64P + (idx & 31)];
     }
 }
 
@@ -304,11 +355,14 @@ __global__ __launch_bounds__(kI64BS) void iir64_pass_y(Iir64Desc d, const double
 template <int NSEC, int ORD>
 static int iir64_run(const Iir64Desc& d, const double* x, long n, long tiles, const double* phiPow, const double* phiL, const double* phiB, const double* state_in, double* state_out, double* P,
                      double* Z, double* T, double* y, hipStream_t st) {
-    hipLaunchKernelGGL((iir64_pass_z<NSEC, ORD>), dim3((unsigned)tiles), dim3(kI64BS), 0, st, d, x, n, phiPow, P, Z);
+    constexpr size_t ldsY = (size_t)kI64BS * kI64P * sizeof(double), ldsZ = ldsY + (size_t)2 * NSEC * ORD * kI64BS * sizeof(double);
+    GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(iir64_pass_z<NSEC, ORD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsZ));
+    GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(iir64_pass_y<NSEC, ORD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsY));
+    hipLaunchKernelGGL((iir64_pass_z<NSEC, ORD>), dim3((unsigned)tiles), dim3(kI64BS), ldsZ, st, d, x, n, phiPow, P, Z);
     GR4_LAUNCH_CHECK();
     hipLaunchKernelGGL((iir64_pass_b<NSEC * ORD>), dim3(1), dim3(256), 0, st, phiB, (const double*)Z, tiles, state_in, T);
     GR4_LAUNCH_CHECK();
-    hipLaunchKernelGGL((iir64_pass_y<NSEC, ORD>), dim3((unsigned)tiles), dim3(kI64BS), 0, st, d, x, n, phiL, (const double*)P, (const double*)T, y, state_out);
+    hipLaunchKernelGGL((iir64_pass_y<NSEC, ORD>), dim3((unsigned)tiles), dim3(kI64BS), ldsY, st, d, x, n, phiL, (const double*)P, (const double*)T, y, state_out);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
@@ -567,7 +621,7 @@ int gr4hip_iir64_create(gr4hip_iir64_t** out, int form, size_t nsections, const 
                 for (int j = 0; j < mp; ++j) C[(size_t)i * mp + j] += A[(size_t)i * mp + k] * B[(size_t)k * mp + j];
         return C;
     };
-    std::vector<double> pow2((size_t)8 * mp * mp), powl((size_t)kI64BS * mp * mp), phiB((size_t)mp * mp);
+    std::vector<double> pow2((size_t)8 * mp * mp), powl((size_t)kI64BS * mp * mp), phiB((size_t)9 * mp * mp); // phiB: Phi_B, then Phi_B^(G 2^k), k < 8 (pass B's scan)
     {
         std::vector<long double> M = PL;
         for (int k = 0; k < 8; ++k) { // Phi_L^(2^k)
@@ -575,6 +629,14 @@ int gr4hip_iir64_create(gr4hip_iir64_t** out, int form, size_t nsections, const 
             M = mul(M, M);
         }
         for (size_t i = 0; i < M.size(); ++i) phiB[i] = (double)M[i]; // Phi_L^256 = one tile
+        {
+            std::vector<long double> B = M;
+            for (int q = 1; q < kI64G; q <<= 1) B = mul(B, B); // Phi_B^G (G = 16)
+            for (int k = 0; k < 8; ++k) {
+                for (size_t i = 0; i < B.size(); ++i) phiB[(size_t)(1 + k) * mp * mp + i] = (double)B[i];
+                B = mul(B, B);
+            }
+        }
         std::vector<long double> Q((size_t)mp * mp, 0.0L);
         for (int i = 0; i < mp; ++i) Q[(size_t)i * mp + i] = 1.0L;
         for (int l = 0; l < kI64BS; ++l) { // Phi_L^l

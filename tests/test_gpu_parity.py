@@ -1616,6 +1616,26 @@ def test_iir_filter_float64(G, kind):
     assert e.value.status == G.capi.UNSUPPORTED
 
 
+@pytest.mark.parametrize("kind", ["biquad4", "narrow"])
+def test_iir_filter_float64_more_tiles_than_one_scan_round(G, kind):
+    """the tile-level scan of the float64 cascade (iir64_pass_b) covers 4096 tiles = 2^25 samples per round: a span beyond that carries the state into a
+    second round, and a span that ends inside the first groups leaves most lanes of the scan idle"""
+    import scipy.signal as sps
+    sos = sps.butter(8, 0.1, output="sos") if kind == "biquad4" else sps.butter(4, 0.0005, output="sos")
+    b, a = sos[:, :3], sos[:, 3:]
+    n = (1 << 25) + 8192 * 9 + 321
+    x = np.random.default_rng(11).standard_normal(n)
+    truth = sps.sosfilt(sos, x)
+    f = G.iir_filter(b, a, dtype=torch.float64)
+    y = f.process_bulk(dev(x)).cpu().numpy()
+    bar = 1e-9 if kind == "narrow" else TOL64
+    assert _rel(y, truth) <= bar
+    f.reset()
+    cut = 8192 * 3 + 5  # four tiles in the first call: lanes 1 .. 255 of the scan idle
+    y2 = np.concatenate([f.process_bulk(dev(x[:cut])).cpu().numpy(), f.process_bulk(dev(x[cut:1_000_000])).cpu().numpy()])
+    assert _rel(y2, truth[:1_000_000]) <= bar
+
+
 @pytest.mark.parametrize("N", [2, 16, 1024, 8192])
 @pytest.mark.parametrize("window", ["None", "Hann", "BlackmanHarris"])
 def test_fft_block_float64(G, N, window):
