@@ -336,6 +336,24 @@ def test_interpolating_fir_matrix_pipe_many_workgroups(G):
         assert float(d) <= 2e-6
 
 
+def test_interpolating_fir_random_configurations(G):
+    """seeded random draws over the interpolator's parameter space (factor, tap count, real / complex, call lengths on both sides of the matrix-pipe
+    threshold): every one against the zero-stuffing oracle"""
+    rng = np.random.default_rng(4242)
+    for case in range(24):
+        L = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 24, 33]))
+        ntaps = int(rng.integers(1, min(40 * L, 700)))
+        cplx = bool(rng.integers(0, 2))
+        n = int(rng.integers(1, 120_000 if L <= 8 else 30_000))
+        b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        x = O.signal_c32(200 + case, n) if cplx else O.signal_f32(200 + case, n)
+        truth, _ = O.fir_interp(b, x, L)
+        f = G.fir_interpolator(b, L, torch.complex64 if cplx else torch.float32)
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=3)]))
+        got = np.concatenate([f.process_bulk(dev(x[a:c])).cpu().numpy() for a, c in zip(cuts[:-1], cuts[1:])])
+        assert got.shape == truth.shape and _rel(got, truth) <= TOL, (case, L, ntaps, cplx, n, cuts)
+
+
 def test_interpolating_fir_is_the_gain_L_inverse_of_decimation(G):
     """size-independent property at a long device-generated stream: interpolate by L with a 1/L-band low-pass, keep every L-th output of the
     branch-0 phase -> the input delayed by the filter's group delay, to the filter's pass-band ripple"""
