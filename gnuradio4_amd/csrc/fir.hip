@@ -169,6 +169,8 @@ int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st, float* new_hist);
 int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st, float* new_hist);
+void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_out, std::vector<float>* row);
+int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
 
@@ -203,6 +205,8 @@ struct gr4hip_fir {
     bool               fd_probed = false, fd_blocked = false;
     float              fd_ratio  = -1.f;
     gr4::FirDecimFd*   dfd = nullptr; // float, decim 8, <= 1024 taps: frequency-domain decimator (created on first use)
+    DeviceBuffer       d_band;        // float, decim 16 / 32 / 64: tap row of fir_decim_band_kernel (built on first use)
+    int                bandKp = 0;
     DeviceBuffer       d_hist256, d_histc;
     DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
     int                mKp = 0, mKS = 0;
@@ -278,6 +282,7 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     f->fd_probed = f->fd_blocked = false;
     f->fd_ratio  = -1.f;
     f->mKS = 0;
+    f->bandKp = 0;
     int rc   = fir_upload_taps(f);
     if (rc) return rc;
     if (ntaps > f->hcap) { // the reference replaces the HistoryBuffer (history is lost) only when it must grow
@@ -415,6 +420,20 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         rc = fir_decim_fd_run(f->dfd, x, n_in, hist, (int)f->hcap, y, st);
         if (rc) return rc;
         done = n_in;
+    }
+    // float, decimate by 16 / 32 / 64, long span: the band form of the contraction (samples in stream order, the decimation in the A operand)
+    if (done == 0 && f->S == 1 && (f->decim == 16 || f->decim == 32 || f->decim == 64) && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO) {
+        int rc = GR4HIP_OK;
+        if (f->bandKp == 0) {
+            std::vector<float> row;
+            fir_decim_band_make_row(f->taps.data(), f->ntaps, f->decim, &f->bandKp, &row);
+            rc = f->d_band.ensure(row.size() * sizeof(float));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_band.ptr, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (rc) { f->bandKp = 0; return rc; }
+        }
+        rc = fir_decim_band_launch((int)f->decim, f->bandKp, x, hist, (int)f->hcap, (const float*)f->d_band.ptr, y, (long)n_out, (long)n_in, st);
+        if (rc == GR4HIP_OK) done = n_in;
+        else if (rc != GR4HIP_UNSUPPORTED) return rc; // UNSUPPORTED: the tile does not fit the LDS, keep the kernels below
     }
     // float polyphase decimator with >= 16 taps per phase and a long span: the same contraction with the D phase products summed in
     // one accumulator tile (BASELINE configs[2]: decim 8, 1024 taps)

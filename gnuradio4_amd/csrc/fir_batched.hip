@@ -299,6 +299,97 @@ __global__ __launch_bounds__(256) void fir_mfma_decim_kernel(const float* __rest
     }
 }
 
+// Decimation by a large power of two (16, 32, 64): the polyphase form above de-interleaves the segment into D phase rows, which stops fitting the LDS at
+// D = 16, and the register-window kernel behind it spends its time on that de-interleave (D = 16: 104 G input samples/s, 64: 27).  Here the samples stay
+// in stream order and the decimation sits in the A operand: with W_i[u] = x[16 i D - Kp + u], u < Kp + 16 D,
+//     y[16 i + j] = sum_u A[j][u] W_i[u],   A[j][u] = b[Kp + j D - u]
+// -- a band of Kp taps that moves D columns per row, Kp / (Kp + 15 D) of the products non-zero (68 % at K = 32 D), 2 (Kp + 16 D) / D executed flop per input
+// sample: HBM-bound.  One tile of 256 outputs (256 D inputs + Kp) per workgroup; the four waves SPLIT the K-steps and their partial tiles are summed
+// through LDS.  Bank layout: the 16 columns of a K-step are 16 D floats apart -- two pad floats per 16 D samples put them on different banks (offset of a
+// K-step: lane base + wave-uniform part); A's lanes are D floats apart in the tap row -- two pad floats per D taps.
+template <int LOGD>
+__global__ __launch_bounds__(256) void fir_decim_band_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-hcap + h]*/, int hcap,
+                                                              const float* __restrict__ tb /*[Kp + 32 D]: index 16 D + t holds b[t]*/, int Kp, float* __restrict__ y, long n_out, long n_in) {
+    constexpr int D = 1 << LOGD, BLK = 16 * D;
+    extern __shared__ float bsm[];
+    auto      padx = [](int s_) { return s_ + 2 * (s_ >> (LOGD + 4)); };
+    auto      padt = [](int q) { return q + 2 * (q >> LOGD); };
+    const int KS = (Kp + BLK) / 4, NS = 256 * D + Kp, NT = Kp + 32 * D;
+    float*    xs   = bsm;                       // padx(NS) + 2
+    float*    tl   = xs + padx(NS) + 2;         // padt(NT) + 2
+    float*    part = tl + padt(NT) + 2;         // [4 waves][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    const long tile = blockIdx.x, p0 = tile * 256 * D - Kp; // stream position of staged sample 0
+    for (int q = tid; q < NT; q += 256) tl[padt(q)] = tb[q];
+    constexpr int NB = 24; // loads in flight per lane (D = 16: the whole tile in one round)
+    for (int s0 = tid; s0 < NS; s0 += 256 * NB) {
+        float v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int  s_ = s0 + 256 * u;
+            const long i  = p0 + s_;
+            v[u]          = s_ < NS ? (i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -(long)hcap ? hist[hcap + i] : 0.f)) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int s_ = s0 + 256 * u;
+            if (s_ < NS) xs[padx(s_)] = v[u];
+        }
+    }
+    __syncthreads();
+    using f32x4b = __attribute__((ext_vector_type(4))) float;
+    f32x4b      acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const int   KSw = (KS + 3) / 4, k0 = wave * KSw, k1 = k0 + KSw < KS ? k0 + KSw : KS; // this wave's K-steps
+    const float* pb = xs + (BLK + 2) * col + kq;            // B: sample 16 D col + u, u = 4 ks + kq
+    const int    qa = Kp + col * D + BLK - kq;              // A: tap-row index of u = kq
+    auto step = [&](f32x4b& acc, int ks) {
+        const int u = 4 * ks;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[padt(qa - u)], pb[u + 2 * (u >> (LOGD + 4))], acc, 0, 0, 0);
+    };
+    int ks = k0;
+    for (; ks + 8 <= k1; ks += 8) { // four accumulators, eight K-steps per round: the operand reads of a round are issued ahead of its MFMAs
+        step(acc0, ks); step(acc1, ks + 1); step(acc2, ks + 2); step(acc3, ks + 3);
+        step(acc0, ks + 4); step(acc1, ks + 5); step(acc2, ks + 6); step(acc3, ks + 7);
+    }
+    for (; ks < k1; ++ks) step(acc0, ks);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc0[r] += acc2[r]; acc1[r] += acc3[r]; }
+    *reinterpret_cast<float4*>(part + (wave * 64 + lane) * 4) = make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+    __syncthreads();
+    // D[row = 4 kq + r][col]: output 16 col + 4 kq + r of the tile; thread o sums the four waves' partial sums of output o
+    const int  o = tid, ln = (o >> 4) + 16 * ((o & 15) >> 2), r = o & 3;
+    const long m = tile * 256 + o;
+    if (m < n_out) y[m] = (part[(0 * 64 + ln) * 4 + r] + part[(1 * 64 + ln) * 4 + r]) + (part[(2 * 64 + ln) * 4 + r] + part[(3 * 64 + ln) * 4 + r]);
+}
+
+// tap row of fir_decim_band_kernel: [Kp + 32 D], index 16 D + t holds b[t]; Kp = taps rounded up to a multiple of 4
+void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_out, std::vector<float>* row) {
+    const int Kp = (int)((ntaps + 3) / 4 * 4);
+    row->assign((size_t)Kp + 32 * D, 0.f);
+    for (size_t t = 0; t < ntaps; ++t) (*row)[16 * D + t] = taps[t];
+    *Kp_out = Kp;
+}
+
+// y[m] = sum_k b[k] x[m D - k], m < n_out, D in {16, 32, 64}; GR4HIP_UNSUPPORTED when the tile does not fit the LDS
+int fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st) {
+    const int    logd = D == 16 ? 4 : D == 32 ? 5 : D == 64 ? 6 : 0;
+    if (!logd) return GR4HIP_UNSUPPORTED;
+    const int    NS = 256 * D + Kp, NT = Kp + 32 * D;
+    const size_t lds = ((size_t)(NS + 2 * (NS >> (logd + 4)) + 2) + (size_t)(NT + 2 * (NT >> logd) + 2) + 4 * 64 * 4) * sizeof(float);
+    if (lds > 150 * 1024) return GR4HIP_UNSUPPORTED;
+    const dim3 grid((unsigned)ceil_div(n_out, 256L));
+#define GR4_BAND_CASE(LD)                                                                                                                   \
+    do {                                                                                                                                    \
+        auto kern = fir_decim_band_kernel<LD>;                                                                                              \
+        if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, hcap, row, Kp, y, n_out, n_in);                                         \
+    } while (0)
+    if (logd == 4) GR4_BAND_CASE(4); else if (logd == 5) GR4_BAND_CASE(5); else GR4_BAND_CASE(6);
+#undef GR4_BAND_CASE
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
 // A-fragment table [nch][KS][64] for per-channel taps [nch][ntaps]; Kp = 64 / 128 / 256
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out) {
     const int Kp = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : 256, KS = (Kp + 16) / 4;
