@@ -800,7 +800,16 @@ struct gr4hip_iir {
     DeviceBuffer        d_stz;            // one-pass block status words: [nblocks][M] x 2 (+ ticket)
     int                 warm_tiles = 0;   // segment-sequential kernel: warm-up tiles that make a run's unknown start state irrelevant (0: memory does not fade fast enough)
     unsigned*           h_err = nullptr;  // page-locked, device-visible: a look-back that timed out (never observed) is reported by the next call, loudly
-    ~gr4hip_iir() { if (h_err) (void)hipHostFree(h_err); }
+    // more than 8 state values (5 .. 8 biquads, 3 .. 4 sections of order 4): two cascades of <= 8 state values run one behind the other through a scratch
+    // stream -- the section order and the float32 rounding between sections are the cascade's own, and each half takes the fast kernels (measured: 8 biquads
+    // as one 16-state scan 69 Gsamples/s, as 4 + 4 biquads 230)
+    gr4hip_iir*         part[2] = {nullptr, nullptr};
+    DeviceBuffer        d_mid;
+    ~gr4hip_iir() {
+        if (h_err) (void)hipHostFree(h_err);
+        delete part[0];
+        delete part[1];
+    }
 };
 
 // host double-precision cascade step (same recurrence) used to build the propagation matrices
@@ -970,6 +979,14 @@ int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const floa
     GR4_REQUIRE(f, "out of host memory");
     f->form = form;
     f->ord  = ord;
+    if (nsections * ord > 8 && !std::getenv("GR4HIP_IIR_NO_SPLIT")) { // two cascades of <= 8 state values (GR4HIP_IIR_NO_SPLIT: the 16-state kernels, which the tests compare)
+        const size_t k = 8 / ord;
+        int rc = gr4hip_iir_create(&f->part[0], form, k, h_b, nb, h_a, na);
+        if (!rc) rc = gr4hip_iir_create(&f->part[1], form, nsections - k, h_b + k * nb, nb, h_a + k * na, na);
+        if (rc) { delete f; return rc; }
+        *out = f;
+        return GR4HIP_OK;
+    }
     const int mp = (int)nsections * ord <= 4 ? 4 : (int)nsections * ord <= 8 ? 8 : 16; // instantiated state counts
     f->nsec = mp / ord;
     f->M    = mp;
@@ -1049,6 +1066,7 @@ static int iir_take_error(gr4hip_iir* f, const char* where) {
 
 int gr4hip_iir_reset(gr4hip_iir_t* f) {
     GR4_REQUIRE(f, "iir_reset: null handle");
+    if (f->part[0]) { int rc = gr4hip_iir_reset(f->part[0]); return rc ? rc : gr4hip_iir_reset(f->part[1]); }
     for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(f->d_state[k].ptr, 0, kIirMaxM * sizeof(float))); // (hipMemset synchronises: every earlier launch has finished)
     f->cur = 0;
     return iir_take_error(f, "iir_reset");
@@ -1056,6 +1074,7 @@ int gr4hip_iir_reset(gr4hip_iir_t* f) {
 
 int gr4hip_iir_status(gr4hip_iir_t* f, gr4hip_stream_t stream) {
     GR4_REQUIRE(f, "iir_status: null handle");
+    if (f->part[0]) { int rc = gr4hip_iir_status(f->part[0], stream); return rc ? rc : gr4hip_iir_status(f->part[1], stream); }
     GR4_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     return iir_take_error(f, "iir_status");
 }
@@ -1064,6 +1083,11 @@ int gr4hip_iir_process(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_ou
     GR4_REQUIRE(f, "iir_process: null handle");
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "iir_process: null device pointer");
+    if (f->part[0]) {
+        int rc = f->d_mid.ensure(n * sizeof(float));
+        if (!rc) rc = gr4hip_iir_process(f->part[0], d_in, n, static_cast<float*>(f->d_mid.ptr), stream);
+        return rc ? rc : gr4hip_iir_process(f->part[1], static_cast<const float*>(f->d_mid.ptr), n, d_out, stream);
+    }
     hipStream_t st = as_stream(stream);
     const long  ln = (long)n;
     if (f->ord == 2) return f->nsec == 2 ? iir_run<2, 2>(f, d_in, d_out, ln, st) : f->nsec == 4 ? iir_run<2, 4>(f, d_in, d_out, ln, st) : iir_run<2, 8>(f, d_in, d_out, ln, st);

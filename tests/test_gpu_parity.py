@@ -722,6 +722,33 @@ def test_fft_block_random_configurations(G):
                 assert rg[s_, 0] == v.min() and rg[s_, 1] == v.max(), what
 
 
+@pytest.mark.parametrize("nsec,order", [(5, 2), (8, 2), (3, 4), (4, 4)])
+def test_iir_more_than_eight_state_values_runs_as_two_cascades(G, nsec, order):
+    """5 .. 8 biquads / 3 .. 4 fourth-order sections: the first 8 state values' worth of sections and the rest as two cascades one behind the other (each on
+    the fast kernels) -- the section order and the float32 stream between sections are the cascade's own; long ragged calls, state across calls, reset"""
+    import scipy.signal as sps
+    sos = sps.butter(2 * nsec, 0.12, output="sos")
+    if order == 2:
+        b, a = sos[:, :3], sos[:, 3:]
+    else:  # pairs of biquads multiplied out into fourth-order sections
+        sos = sps.butter(4 * nsec, 0.12, output="sos")
+        b = np.array([np.convolve(sos[2 * i, :3], sos[2 * i + 1, :3]) for i in range(nsec)])
+        a = np.array([np.convolve(sos[2 * i, 3:], sos[2 * i + 1, 3:]) for i in range(nsec)])
+    b, a = b.astype(np.float32), a.astype(np.float32)
+    n = 700_001
+    x = O.signal_f32(77, n)
+    sec = O.make_sections([(bb, aa) for bb, aa in zip(b, a)])
+    truth = O.iir_cascade(sec, x, O.DF_II, f64=True)
+    seq32 = O.iir_cascade(sec, x, O.DF_II, f64=False)
+    bar = max(TOL, 3 * _rel(seq32, truth))
+    f = G.iir_filter(b, a)
+    cuts = [0, 5, 300_000, 300_077, n]
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert _rel(y, truth) <= bar
+    f.reset()
+    assert _rel(f.process_bulk(dev(x[:100_000])).cpu().numpy(), truth[:100_000]) <= bar
+
+
 def test_iir_random_cascades(G):
     """seeded random stable cascades (random pole radii / angles, 1 ... 8 biquads and fourth-order sections), random span lengths and chunkings"""
     rng = np.random.default_rng(31)
