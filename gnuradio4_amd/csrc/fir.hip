@@ -421,8 +421,9 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         if (rc) return rc;
         done = n_in;
     }
-    // float, decimate by 16 / 32 / 64, long span: the band form of the contraction (samples in stream order, the decimation in the A operand)
-    if (done == 0 && f->S == 1 && (f->decim == 16 || f->decim == 32 || f->decim == 64) && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO) {
+    // float, decimate by kBandMinDecim .. 128, long span: the band form of the contraction (samples in stream order, the decimation in the A operand)
+    static const size_t kBandMinDecim = [] { const char* e = std::getenv("GR4HIP_FIR_BAND_MIN_DECIM"); return e ? (size_t)std::atoi(e) : (size_t)10; }(); // (developer switch: where the band form takes over from the polyphase form)
+    if (done == 0 && f->S == 1 && f->decim >= kBandMinDecim && f->decim <= 128 && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO) {
         int rc = GR4HIP_OK;
         if (f->bandKp == 0) {
             std::vector<float> row;
@@ -473,6 +474,16 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         else rc = bs == 256 ? fir_launch<2, 256>(f, xr, hist, yr, ni, no, lds, st, nh) : bs == 128 ? fir_launch<2, 128>(f, xr, hist, yr, ni, no, lds, st, nh) : fir_launch<2, 64>(f, xr, hist, yr, ni, no, lds, st, nh);
         hist_written = nh != nullptr && rc == GR4HIP_OK;
         break;
+    }
+    if (rc == GR4HIP_UNSUPPORTED && done == 0 && f->S == 1 && f->decim >= 2) { // D phase rows do not fit the LDS at any workgroup size: the band form at any span length
+        if (f->bandKp == 0) {
+            std::vector<float> row;
+            fir_decim_band_make_row(f->taps.data(), f->ntaps, f->decim, &f->bandKp, &row);
+            int rb = f->d_band.ensure(row.size() * sizeof(float));
+            if (!rb) { hipError_t e = hipMemcpy(f->d_band.ptr, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rb = GR4HIP_RUNTIME_ERROR; } }
+            if (rb) { f->bandKp = 0; return rb; }
+        }
+        rc = fir_decim_band_launch((int)f->decim, f->bandKp, x, hist, (int)f->hcap, (const float*)f->d_band.ptr, y, (long)n_out, (long)n_in, st);
     }
     if (rc == GR4HIP_UNSUPPORTED) { set_error("fir_process: ntaps=%zu decim=%zu does not fit the LDS tiling", f->ntaps, f->decim); return rc; }
     if (rc) return rc;

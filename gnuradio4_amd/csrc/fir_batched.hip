@@ -299,27 +299,29 @@ __global__ __launch_bounds__(256) void fir_mfma_decim_kernel(const float* __rest
     }
 }
 
-// Decimation by a large power of two (16, 32, 64): the polyphase form above de-interleaves the segment into D phase rows, which stops fitting the LDS at
-// D = 16, and the register-window kernel behind it spends its time on that de-interleave (D = 16: 104 G input samples/s, 64: 27).  Here the samples stay
+// Decimation by 9 and more: the polyphase form above de-interleaves the segment into D phase rows, which stops fitting the LDS at
+// D = 11 .. 16, and the register-window kernel behind it spends its time on that de-interleave (D = 16: 104 G input samples/s, 64: 27).  Here the samples stay
 // in stream order and the decimation sits in the A operand: with W_i[u] = x[16 i D - Kp + u], u < Kp + 16 D,
 //     y[16 i + j] = sum_u A[j][u] W_i[u],   A[j][u] = b[Kp + j D - u]
 // -- a band of Kp taps that moves D columns per row, Kp / (Kp + 15 D) of the products non-zero (68 % at K = 32 D), 2 (Kp + 16 D) / D executed flop per input
 // sample: HBM-bound.  One tile of 256 outputs (256 D inputs + Kp) per workgroup; the four waves SPLIT the K-steps and their partial tiles are summed
 // through LDS.  Bank layout: the 16 columns of a K-step are 16 D floats apart -- two pad floats per 16 D samples put them on different banks (offset of a
 // K-step: lane base + wave-uniform part); A's lanes are D floats apart in the tap row -- two pad floats per D taps.
-template <int LOGD>
+// D = 2^a m with m odd: the pads go in per 2^(a+4) samples and per 2^a taps (shifts, no divisions); the column stride becomes 2 m (2^(a+3) + 1) and the row
+// stride 2 m (2^(a-1) + 1) floats -- an odd multiple of 2 either way (a < 2: the tap row needs no padding), so 16 lanes always hit 16 different even banks.
 __global__ __launch_bounds__(256) void fir_decim_band_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-hcap + h]*/, int hcap,
-                                                              const float* __restrict__ tb /*[Kp + 32 D]: index 16 D + t holds b[t]*/, int Kp, float* __restrict__ y, long n_out, long n_in) {
-    constexpr int D = 1 << LOGD, BLK = 16 * D;
+                                                              const float* __restrict__ tb /*[Kp + 32 D]: index 16 D + t holds b[t]*/, int Kp, float* __restrict__ y, long n_out, long n_in,
+                                                              int D, int sha /*ctz(D) + 4*/, int sht /*ctz(D), or 31: no padding*/) {
+    const int BLK = 16 * D;
     extern __shared__ float bsm[];
-    auto      padx = [](int s_) { return s_ + 2 * (s_ >> (LOGD + 4)); };
-    auto      padt = [](int q) { return q + 2 * (q >> LOGD); };
+    auto      padx = [sha](int s_) { return s_ + 2 * (s_ >> sha); };
+    auto      padt = [sht](int q) { return q + 2 * (q >> sht); };
     const int KS = (Kp + BLK) / 4, NS = 256 * D + Kp, NT = Kp + 32 * D;
     float*    xs   = bsm;                       // padx(NS) + 2
     float*    tl   = xs + padx(NS) + 2;         // padt(NT) + 2
     float*    part = tl + padt(NT) + 2;         // [4 waves][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
-    const long tile = blockIdx.x, p0 = tile * 256 * D - Kp; // stream position of staged sample 0
+    const long tile = blockIdx.x, p0 = tile * 256L * D - Kp; // stream position of staged sample 0
     for (int q = tid; q < NT; q += 256) tl[padt(q)] = tb[q];
     constexpr int NB = 24; // loads in flight per lane (D = 16: the whole tile in one round)
     for (int s0 = tid; s0 < NS; s0 += 256 * NB) {
@@ -340,11 +342,11 @@ __global__ __launch_bounds__(256) void fir_decim_band_kernel(const float* __rest
     using f32x4b = __attribute__((ext_vector_type(4))) float;
     f32x4b      acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     const int   KSw = (KS + 3) / 4, k0 = wave * KSw, k1 = k0 + KSw < KS ? k0 + KSw : KS; // this wave's K-steps
-    const float* pb = xs + (BLK + 2) * col + kq;            // B: sample 16 D col + u, u = 4 ks + kq
+    const float* pb = xs + padx(BLK) * col + kq;            // B: sample 16 D col + u, u = 4 ks + kq  (16 D col has no low bits: the pad count splits exactly)
     const int    qa = Kp + col * D + BLK - kq;              // A: tap-row index of u = kq
     auto step = [&](f32x4b& acc, int ks) {
         const int u = 4 * ks;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[padt(qa - u)], pb[u + 2 * (u >> (LOGD + 4))], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[padt(qa - u)], pb[u + 2 * (u >> sha)], acc, 0, 0, 0);
     };
     int ks = k0;
     for (; ks + 8 <= k1; ks += 8) { // four accumulators, eight K-steps per round: the operand reads of a round are issued ahead of its MFMAs
@@ -370,22 +372,19 @@ void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_
     *Kp_out = Kp;
 }
 
-// y[m] = sum_k b[k] x[m D - k], m < n_out, D in {16, 32, 64}; GR4HIP_UNSUPPORTED when the tile does not fit the LDS
+// y[m] = sum_k b[k] x[m D - k], m < n_out; GR4HIP_UNSUPPORTED when the tile does not fit the LDS
 int fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st) {
-    const int    logd = D == 16 ? 4 : D == 32 ? 5 : D == 64 ? 6 : 0;
-    if (!logd) return GR4HIP_UNSUPPORTED;
+    if (D < 2) return GR4HIP_UNSUPPORTED;
+    int a = 0;
+    while (((D >> a) & 1) == 0) ++a;
+    const int    sha = a + 4, sht = a >= 2 ? a : 31;
     const int    NS = 256 * D + Kp, NT = Kp + 32 * D;
-    const size_t lds = ((size_t)(NS + 2 * (NS >> (logd + 4)) + 2) + (size_t)(NT + 2 * (NT >> logd) + 2) + 4 * 64 * 4) * sizeof(float);
+    const size_t lds = ((size_t)(NS + 2 * (NS >> sha) + 2) + (size_t)(NT + 2 * (NT >> sht) + 2) + 4 * 64 * 4) * sizeof(float);
     if (lds > 150 * 1024) return GR4HIP_UNSUPPORTED;
     const dim3 grid((unsigned)ceil_div(n_out, 256L));
-#define GR4_BAND_CASE(LD)                                                                                                                   \
-    do {                                                                                                                                    \
-        auto kern = fir_decim_band_kernel<LD>;                                                                                              \
-        if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, hcap, row, Kp, y, n_out, n_in);                                         \
-    } while (0)
-    if (logd == 4) GR4_BAND_CASE(4); else if (logd == 5) GR4_BAND_CASE(5); else GR4_BAND_CASE(6);
-#undef GR4_BAND_CASE
+    auto       kern = fir_decim_band_kernel;
+    if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, hcap, row, Kp, y, n_out, n_in, D, sha, sht);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

@@ -127,9 +127,10 @@ def test_fir_real_long_input_mfma(G, ntaps):
     assert _rel(y, truth) <= _rel(cpu32, truth) + 1e-6
 
 
-@pytest.mark.parametrize("decim,ntaps", [(8, 1024), (2, 64), (3, 600), (4, 100), (10, 1000), (5, 91), (16, 4096), (16, 512), (16, 33), (32, 1024), (32, 7), (64, 2048), (64, 100), (64, 1)])
+@pytest.mark.parametrize("decim,ntaps", [(8, 1024), (2, 64), (3, 600), (4, 100), (10, 1000), (5, 91), (16, 4096), (16, 512), (16, 33), (32, 1024), (32, 7), (64, 2048), (64, 100), (64, 1),
+                                         (11, 352), (12, 384), (20, 333), (24, 100), (25, 800), (48, 1536), (100, 1000), (96, 1536)])
 def test_fir_decimating_long_input_mfma(G, decim, ntaps):
-    """float polyphase decimator, >= 16 taps per phase, >= 2^14 outputs per span: phase products summed on the MFMA units; decimation by 16 / 32 / 64:
+    """float polyphase decimator, >= 16 taps per phase, >= 2^14 outputs per span: phase products summed on the MFMA units; decimation by 11 .. 128:
     the band form (samples in stream order, the decimation in the A operand, the four waves of a tile splitting the K-steps)"""
     rng = np.random.default_rng(ntaps + decim)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
