@@ -30,34 +30,9 @@ __device__ __forceinline__ void store_bfly(const float2* v, float2* dst, int i, 
     for (int r = 0; r < R; ++r) dst[base + r * p] = v[r];
 }
 
-// One workgroup = fpb frames; tf = max(1, N/8) lanes per frame, 8 points per lane.
-__global__ void fft_block_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ tw, FftPlanDev plan, FftOutputs out,
-                                 long n_frames) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int  N     = plan.N;
-    const int  tf    = plan.tf;
-    const int  fl    = threadIdx.x / tf; // frame slot in block
-    const int  t     = threadIdx.x - fl * tf;
-    const long frame = (long)blockIdx.x * plan.fpb + fl;
-    const bool live  = frame < n_frames;
-    float2*    buf   = lds + (size_t)fl * N;
-
-    // ---- load + window (fft.hpp:148-162); real input becomes (x*w, 0)
-    if (live) {
-        if (out.real_input) {
-            const float* x = in + frame * N;
-            for (int i = t; i < N; i += tf) buf[i] = make_float2(x[i] * (window ? window[i] : 1.f), 0.f);
-        } else {
-            const float2* x = reinterpret_cast<const float2*>(in) + frame * N;
-            for (int i = t; i < N; i += tf) {
-                float2 s = x[i];
-                if (window) { const float w = window[i]; s.x *= w; s.y *= w; }
-                buf[i] = s;
-            }
-        }
-    }
-    __syncthreads();
-
+// the Stockham passes of one frame that sits in LDS (natural order in, natural order out); every lane of the workgroup calls it (it synchronises)
+__device__ __forceinline__ void lds_passes(float2* buf, int t, int tf, const FftPlanDev& plan, const float2* __restrict__ tw) {
+    const int N = plan.N;
     int p = 1;
     for (int pass = 0; pass < plan.npass; ++pass) {
         const int R  = plan.radix[pass];
@@ -91,6 +66,37 @@ __global__ void fft_block_kernel(const float* __restrict__ in, const float* __re
         __syncthreads();
         p *= R;
     }
+}
+
+// One workgroup = fpb frames; tf = max(1, N/8) lanes per frame, 8 points per lane.
+__global__ void fft_block_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ tw, FftPlanDev plan, FftOutputs out,
+                                 long n_frames) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int  N     = plan.N;
+    const int  tf    = plan.tf;
+    const int  fl    = threadIdx.x / tf; // frame slot in block
+    const int  t     = threadIdx.x - fl * tf;
+    const long frame = (long)blockIdx.x * plan.fpb + fl;
+    const bool live  = frame < n_frames;
+    float2*    buf   = lds + (size_t)fl * N;
+
+    // ---- load + window (fft.hpp:148-162); real input becomes (x*w, 0)
+    if (live) {
+        if (out.real_input) {
+            const float* x = in + frame * N;
+            for (int i = t; i < N; i += tf) buf[i] = make_float2(x[i] * (window ? window[i] : 1.f), 0.f);
+        } else {
+            const float2* x = reinterpret_cast<const float2*>(in) + frame * N;
+            for (int i = t; i < N; i += tf) {
+                float2 s = x[i];
+                if (window) { const float w = window[i]; s.x *= w; s.y *= w; }
+                buf[i] = s;
+            }
+        }
+    }
+    __syncthreads();
+
+    lds_passes(buf, t, tf, plan, tw);
     if (!live) return;
 
     // ---- epilogue over natural-order bins
@@ -230,6 +236,42 @@ __global__ __launch_bounds__(256) void bluestein_post_kernel(const float2* __res
     const float2 r = a[f * (long)M + k];
     const float  s = 1.f / (float)M;
     emit_bin(out, frame0 + f, N, k, cmul(make_float2(r.x * s, -r.y * s), cconj[k]));
+}
+
+// N <= 4096 (M <= 8192): the whole chirp convolution of a frame in LDS -- chirp x window x input, FFT_M, x FFT_M(c) and conjugate, FFT_M again (the inverse through
+// conjugation), conj / M x chirp, outputs.  12 .. 24 B of HBM traffic per sample instead of the ~160 B of the five-kernel pipeline above.
+__global__ void bluestein_fused_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ cconj, const float2* __restrict__ Bf,
+                                       const float2* __restrict__ tw /*W_M^j*/, FftPlanDev plan /*of M*/, FftOutputs out, int N, long n_frames) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int  M = plan.N, tf = plan.tf;
+    const int  fl = threadIdx.x / tf, t = threadIdx.x - fl * tf;
+    const long frame = (long)blockIdx.x * plan.fpb + fl;
+    const bool live  = frame < n_frames;
+    float2*    buf   = lds + (size_t)fl * M;
+    for (int i = t; i < M; i += tf) {
+        float2 v = make_float2(0.f, 0.f);
+        if (live && i < N) {
+            const long g = frame * (long)N + i;
+            v            = out.real_input ? make_float2(in[g], 0.f) : reinterpret_cast<const float2*>(in)[g];
+            if (window) { const float w = window[i]; v.x *= w; v.y *= w; }
+            v = cmulf(v, cconj[i]);
+        }
+        buf[i] = v;
+    }
+    __syncthreads();
+    lds_passes(buf, t, tf, plan, tw);
+    for (int i = t; i < M; i += tf) {
+        const float2 p = cmulf(buf[i], Bf[i]);
+        buf[i]         = make_float2(p.x, -p.y);
+    }
+    __syncthreads();
+    lds_passes(buf, t, tf, plan, tw);
+    if (!live) return;
+    const float sc = 1.f / (float)M;
+    for (int k = t; k < N; k += tf) {
+        const float2 r = buf[k];
+        emit_bin(out, frame, N, k, cmulf(make_float2(r.x * sc, -r.y * sc), cconj[k]));
+    }
 }
 
 // fft_common.hpp:71-89 unwrapPhase + :113-120 (deg, shift).  One workgroup per frame; wrap counts are integers, so a
@@ -480,6 +522,10 @@ int gr4hip_fft_create(gr4hip_fft_t** out, int in_dtype, size_t fft_size, int win
         f->M = M;
         rc   = engine_create(&f->eng, M);
         if (!rc) rc = fft_upload_bluestein(fft_size, M, &f->d_chirp, &f->d_chirpF);
+        if (!rc && M <= 8192) { // the fused single-launch form
+            rc = fft_build_plan(M, &f->plan);
+            if (!rc) rc = fft_upload_twiddles(M, &f->d_tw);
+        }
     } else {
         set_error("fft: size %zu is outside the device paths (powers of two <= %zu, any size <= %zu)", fft_size, kFftMaxPow2, kFftMaxPow2 / 2);
         rc = GR4HIP_UNSUPPORTED;
@@ -558,6 +604,14 @@ static int fft_run_multi(gr4hip_fft_t* f, const float* d_in, long n_frames, cons
     const float* win    = static_cast<const float*>(f->d_window.ptr);
     const long   batch  = std::max(1L, kFftBatchElems / M);
     const long   in_per = o.real_input ? N : 2 * N; // floats per input frame
+    if (f->kind == 2 && M <= 8192 && !std::getenv("GR4HIP_FFT_BLUESTEIN_PIPELINE")) { // (developer switch: the five-kernel pipeline, which the tests compare)
+        const size_t lds = (size_t)f->plan.fpb * M * sizeof(float2);
+        if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bluestein_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bluestein_fused_kernel, dim3((unsigned)ceil_div(n_frames, (long)f->plan.fpb)), dim3(f->plan.tf * f->plan.fpb), lds, st, d_in, win,
+                           static_cast<const float2*>(f->d_chirp.ptr), static_cast<const float2*>(f->d_chirpF.ptr), static_cast<const float2*>(f->d_tw.ptr), f->plan, o, (int)N, n_frames);
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
     for (long f0 = 0; f0 < n_frames; f0 += batch) {
         const long   nf = std::min(batch, n_frames - f0);
         const float* in = d_in + f0 * in_per;
