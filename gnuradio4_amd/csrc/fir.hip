@@ -170,6 +170,8 @@ void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_ou
 int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st, float* new_hist);
 int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_out, std::vector<float>* row);
+void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af);
+int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
@@ -205,8 +207,10 @@ struct gr4hip_fir {
     bool               fd_probed = false, fd_blocked = false;
     float              fd_ratio  = -1.f;
     gr4::FirDecimFd*   dfd = nullptr; // float, decim 8, <= 1024 taps: frequency-domain decimator (created on first use)
-    DeviceBuffer       d_band;        // float, decim 16 / 32 / 64: tap row of fir_decim_band_kernel (built on first use)
+    DeviceBuffer       d_band;        // float, decim >= 10: tap row of fir_decim_band_kernel (built on first use)
     int                bandKp = 0;
+    DeviceBuffer       d_bfrag;       // float, 65 .. 256 taps: the three bf16 tap-fragment tables of fir_mfma_bf16x3_kernel (built on first use)
+    int                bfKS = 0;
     DeviceBuffer       d_hist256, d_histc;
     DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
     int                mKp = 0, mKS = 0;
@@ -283,6 +287,7 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     f->fd_ratio  = -1.f;
     f->mKS = 0;
     f->bandKp = 0;
+    f->bfKS = 0;
     int rc   = fir_upload_taps(f);
     if (rc) return rc;
     if (ntaps > f->hcap) { // the reference replaces the HistoryBuffer (history is lost) only when it must grow
@@ -380,9 +385,27 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
+    // float, no decimation, 65 .. 256 taps, long 16-byte-aligned span: the same product on the bf16 matrix pipe with three-term splits of samples and taps
+    // (fir_bf16.hip: float32 accuracy, 2.4 times less matrix-pipe time than the f32 MFMA -- HBM-bound instead of MFMA-bound)
+    if (f->S == 1 && f->decim == 1 && f->ntaps > 64 && f->ntaps <= 256 && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+        f->algo == GR4HIP_FIR_AUTO && !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
+        int rc = GR4HIP_OK;
+        if (f->bfKS == 0) {
+            std::vector<unsigned short> af;
+            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af);
+            rc = f->d_bfrag.ensure(af.size() * sizeof(unsigned short));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (rc) { f->bfKS = 0; return rc; }
+        }
+        float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
+        rc = fir_bf16_launch(f->bfKS, x, (long)n_in, hist, (int)f->hcap, f->d_bfrag.ptr, y, st, nh);
+        if (rc) return rc;
+        done = n_in;
+        mfma_wrote_hist = true;
+    }
     // float, no decimation, 33..256 taps, long 16-byte-aligned output: block-Toeplitz product on the f32 MFMA units (about twice the
     // rate of the register-window VALU kernel, which is FP32-issue bound from ~48 taps on)
-    if (f->S == 1 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in >= kMfmaMinSamples && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
+    if (done == 0 && f->S == 1 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in >= kMfmaMinSamples && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
         int rc = GR4HIP_OK;
         if (f->mKS == 0) {
             std::vector<float> af;

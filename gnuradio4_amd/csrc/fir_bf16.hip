@@ -1,0 +1,210 @@
+// fir_bf16.hip -- fir_filter<float>, 65 .. 256 taps, on the bf16 matrix pipe with float32 accuracy (three-term splits).
+//
+// The block-Toeplitz contraction of fir_batched.hip is bound by v_mfma_f32_16x16x4_f32, which runs at the FP32 VALU's rate (and, measured in chain_td.hip, on
+// its issue slot): 256 taps = 251 Gsamples/s = 2 TB/s, a quarter of the HBM roofline.  The bf16 MFMA is 15x faster per flop.  A float32 value is the exact sum
+// of three bf16 values (8 significant bits each: x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); the residual is <= 2^-25 |x|), bf16 x
+// bf16 products are exact in float32, and the MFMA accumulates in float32.  With samples AND taps split, x b = sum_{i,j} x_i b_j; the six terms with
+// i + j <= 2 (hh, hm, mh, hl, lh, mm) carry everything above 2^-23 |x b| -- the size of float32's own rounding of that product.  Six bf16 MFMAs replace the
+// 8 f32 MFMAs of the same K range (16x16x32 against 16x16x4): 102 against 256 matrix-pipe cycles.
+//
+//     y[16 i + j] = sum_u A[j][u] B[u][i],   B[u][i] = x[16 i - Hb + u],   A[j][u] = b[Hb + j - u],   u < Kw = 32 KS,   Hb = Kw - 16 >= taps - 1
+//
+// The samples are split once, while they are staged (three bf16 planes in LDS; a lane's B operand is 8 consecutive samples = one ds_read_b128 per plane),
+// the taps on the host (three fragment tables, resident in registers).  4096 outputs per segment, two tiles (four accumulators) in flight per wave, the
+// next segment requested into registers before the MFMAs, workgroup 0 writes the next history.  Bound: HBM (8 B per sample) once the matrix pipe is out of
+// the way.  Parity: the same 1e-5 bar as every float32 path; measured error against the float64 oracle ~2e-7, like the f32 MFMA kernel's.
+#include "common.hpp"
+#include "buffer_ops.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace gr4 {
+
+using bf16x8  = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4_b = __attribute__((ext_vector_type(4))) float;
+using u32x4_b = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int kBfSeg = 4096, kBfSegPerWg = 4;
+
+using bf16x2_b = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2_b  = __attribute__((ext_vector_type(2))) float;
+// two samples -> their three bf16 terms h, m, l, each pair packed in one dword (v_cvt_pk_bf16_f32: round to nearest even; the residuals are exact in float32)
+__device__ __forceinline__ void bf_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2_b  v  = {x0, x1};
+    const bf16x2_b hh = __builtin_convertvector(v, bf16x2_b);
+    const f32x2_b  r1 = v - __builtin_convertvector(hh, f32x2_b);
+    const bf16x2_b mm = __builtin_convertvector(r1, bf16x2_b);
+    const f32x2_b  r2 = r1 - __builtin_convertvector(mm, f32x2_b);
+    const bf16x2_b ll = __builtin_convertvector(r2, bf16x2_b);
+    h = __builtin_bit_cast(unsigned, hh);
+    m = __builtin_bit_cast(unsigned, mm);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+template <int KS> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block
+__global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ hist /*the Kh samples in front of x*/, int Kh,
+                                                               const u32x4_b* __restrict__ afrag /*[3 planes][KS][64 lanes]: 8 bf16 each*/, float* __restrict__ y, long n,
+                                                               float* __restrict__ new_hist) {
+    constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kBfSeg + Hb; // staged samples per segment (a multiple of 16)
+    constexpr int PL  = NS + 8 * (NS >> 7) + 8;                 // bf16 elements per plane: 8 pad elements per 128 (the 16 columns of a K-step are 16 elements apart)
+    constexpr int NL4 = (NS / 4 + 255) / 256;                   // float4 loads a lane holds for the next segment
+    __shared__ __attribute__((aligned(16))) unsigned short pl[3 * PL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    auto      P   = [](int s_) { return s_ + 8 * (s_ >> 7); };
+
+    u32x4_b a[3][KS]; // A fragments of the three tap planes
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[p][ks] = afrag[(p * KS + ks) * 64 + lane];
+
+    float4 nxt[NL4];
+    auto   load_next = [&](long seg0) { // seg0 >= kBfSeg > Hb: nothing below 0; past the end of the span / of the segment the range check returns 0
+        const long   i0   = seg0 - Hb;
+        const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
+        const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto put4 = [&](int q, float4 v) { // samples 4 q .. 4 q + 3 of the staged range -> the three planes
+        unsigned h0, m0, l0, h1, m1, l1;
+        bf_split2(v.x, v.y, h0, m0, l0);
+        bf_split2(v.z, v.w, h1, m1, l1);
+        const int e = P(4 * q); // 4 consecutive elements never straddle a pad (pads sit at multiples of 128)
+        *reinterpret_cast<uint2*>(pl + e)          = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(pl + PL + e)     = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(pl + 2 * PL + e) = make_uint2(l0, l1);
+    };
+    const long nseg = (n + kBfSeg - 1) / kBfSeg, sfirst = (long)blockIdx.x * kBfSegPerWg, slast = sfirst + kBfSegPerWg < nseg ? sfirst + kBfSegPerWg : nseg;
+    if (sfirst > 0 && sfirst < slast) load_next(sfirst * kBfSeg);
+    for (long sg = sfirst; sg < slast; ++sg) {
+        const long seg0 = sg * kBfSeg;
+        if (sg > 0) {
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) {
+                const int q = tid + 256 * u;
+                if (q < NS / 4) put4(q, nxt[u]);
+            }
+        } else {
+            for (int q = tid; q < NS / 4; q += 256) { // the first segment of the span reads the carried history in front of x
+                float t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const long i = 4L * q + c - Hb;
+                    t[c]         = i >= 0 ? (i < n ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f);
+                }
+                put4(q, make_float4(t[0], t[1], t[2], t[3]));
+            }
+        }
+        __syncthreads();
+        if (sg + 1 < slast) load_next(seg0 + kBfSeg); // in flight during the MFMAs below
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            const int ib0 = 16 * (4 * wave + 2 * pair), ib1 = ib0 + 16; // first 16-sample block of each tile
+            f32x4_b   c0 = {0.f, 0.f, 0.f, 0.f}, d0 = c0, c1 = c0, d1 = c0; // per tile: hh + hm + mh, and hl + lh + mm
+            const int s0 = 16 * (ib0 + col) + 8 * kq, s1 = 16 * (ib1 + col) + 8 * kq;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const unsigned short* q0 = pl + P(s0 + 32 * ks);
+                const unsigned short* q1 = pl + P(s1 + 32 * ks);
+                const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(q0), bm0 = *reinterpret_cast<const bf16x8*>(q0 + PL), bl0 = *reinterpret_cast<const bf16x8*>(q0 + 2 * PL);
+                const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(q1), bm1 = *reinterpret_cast<const bf16x8*>(q1 + PL), bl1 = *reinterpret_cast<const bf16x8*>(q1 + 2 * PL);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0][ks]), am = __builtin_bit_cast(bf16x8, a[1][ks]), al = __builtin_bit_cast(bf16x8, a[2][ks]);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh1, c1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl0, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl1, d1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm1, c1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh0, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh1, d1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh1, c1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm0, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm1, d1, 0, 0, 0);
+            }
+            // D[row = 4 kq + r][col]: y[16 (ib + col) + 4 kq + r]; the small terms are added to the large ones last
+            const long o0 = seg0 + 16L * (ib0 + col) + 4 * kq, o1 = seg0 + 16L * (ib1 + col) + 4 * kq;
+            if (o0 + 3 < n) *reinterpret_cast<float4*>(y + o0) = make_float4(c0[0] + d0[0], c0[1] + d0[1], c0[2] + d0[2], c0[3] + d0[3]);
+            else
+                for (int r = 0; r < 4; ++r)
+                    if (o0 + r < n) y[o0 + r] = c0[r] + d0[r];
+            if (o1 + 3 < n) *reinterpret_cast<float4*>(y + o1) = make_float4(c1[0] + d1[0], c1[1] + d1[1], c1[2] + d1[2], c1[3] + d1[3]);
+            else
+                for (int r = 0; r < 4; ++r)
+                    if (o1 + r < n) y[o1 + r] = c1[r] + d1[r];
+        }
+        __syncthreads(); // every wave is done with the staged segment before the next one overwrites it
+    }
+    if (new_hist != nullptr && blockIdx.x == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+        }
+    }
+}
+
+static unsigned short host_bf_rne(float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float host_bf_to_f(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float          f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// fragment tables [3][KS][64][8] of bf16: plane p, K-step ks, lane l, element t = tap-plane value b_p[Hb + (l & 15) - (32 ks + 8 (l >> 4) + t)]
+void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af) {
+    const int KS = std::max(3, (int)((ntaps - 1 + 16 + 31) / 32)), Hb = 32 * KS - 16; // the smallest window of 32 KS samples with Hb = 32 KS - 16 >= taps - 1 (KS = 3 .. 9)
+    std::vector<unsigned short> pl[3];
+    for (auto& v : pl) v.assign(ntaps, 0);
+    for (size_t k = 0; k < ntaps; ++k) {
+        const float          b = taps[k];
+        const unsigned short h = host_bf_rne(b);
+        const float          r1 = b - host_bf_to_f(h);
+        const unsigned short m = host_bf_rne(r1);
+        const float          r2 = r1 - host_bf_to_f(m);
+        pl[0][k] = h;
+        pl[1][k] = m;
+        pl[2][k] = host_bf_rne(r2);
+    }
+    af->assign((size_t)3 * KS * 64 * 8, 0);
+    for (int p = 0; p < 3; ++p)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int t = 0; t < 8; ++t) {
+                    const int k = Hb + (l & 15) - (32 * ks + 8 * (l >> 4) + t);
+                    if (k >= 0 && (size_t)k < ntaps) (*af)[(((size_t)p * KS + ks) * 64 + l) * 8 + t] = pl[p][k];
+                }
+    *KS_out = KS;
+}
+
+// y[i] = sum_k b[k] x[i - k], i < n; hist = the Kh samples in front of x; x and y 16-byte aligned
+int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist) {
+    const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kBfSeg), (long)kBfSegPerWg));
+    const auto af = static_cast<const u32x4_b*>(afrag);
+#define GR4_BF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_bf16x3_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist); break
+    switch (KS) {
+        GR4_BF_CASE(3);
+        GR4_BF_CASE(4);
+        GR4_BF_CASE(5);
+        GR4_BF_CASE(6);
+        GR4_BF_CASE(7);
+        GR4_BF_CASE(8);
+        GR4_BF_CASE(9);
+    default: return GR4HIP_UNSUPPORTED;
+    }
+#undef GR4_BF_CASE
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+} // namespace gr4

@@ -127,6 +127,46 @@ def test_fir_real_long_input_mfma(G, ntaps):
     assert _rel(y, truth) <= _rel(cpu32, truth) + 1e-6
 
 
+@pytest.mark.parametrize("ntaps", [65, 81, 113, 146, 200, 256])
+def test_fir_float_bf16_three_term_kernel(G, ntaps, monkeypatch):
+    """fir_filter<float>, 65 .. 256 taps, long aligned spans: samples and taps as three bf16 terms each on the bf16 matrix pipe (fir_bf16.hip) -- float32
+    accuracy: against the float64 oracle at the same bar as the f32 MFMA kernel, also when the filter removes a tone 30 dB above what passes (the error is
+    relative to the products, like float32's own rounding, so the bar is checked relative to the OUTPUT), across ragged calls, and against the f32 kernel"""
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    n = 300_000
+    x = (O.signal_f32(91, n, tone_frel=0.31, tone_amp=30.0)).astype(np.float32)
+    truth, _ = O.fir(b, x)
+    f = G.fir_filter(b, torch.float32)
+    cuts = [0, 120_000, 120_004, 121_000, n]
+
+    def run(flt):
+        parts = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            xin = torch.empty(hi - lo + 4, dtype=torch.float32, device="cuda")[4:]  # 16-byte aligned start
+            xin.copy_(torch.from_numpy(x[lo:hi]))
+            parts.append(flt.process_bulk(xin).cpu().numpy())
+        return np.concatenate(parts)
+    y = run(f)
+    assert _rel(y, truth) <= TOL
+    monkeypatch.setenv("GR4HIP_FIR_NO_BF16X3", "1")
+    y32 = run(G.fir_filter(b, torch.float32))
+    monkeypatch.delenv("GR4HIP_FIR_NO_BF16X3")
+    assert _rel(y32, truth) <= TOL
+    assert _rel(y, truth) <= 3 * _rel(y32, truth) + 1e-7  # as accurate as the float32 kernel, to a small factor
+    # white noise through a random filter: no structure for the dropped 2^-24 terms to hide behind
+    rng = np.random.default_rng(ntaps)
+    br = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    xr = O.signal_f32(92, 100_000, tone_amp=0.0)
+    tr, _ = O.fir(br, xr)
+    xin = torch.empty(100_004, dtype=torch.float32, device="cuda")[4:]
+    xin.copy_(torch.from_numpy(xr))
+    e_bf = _rel(G.fir_filter(br, torch.float32).process_bulk(xin).cpu().numpy(), tr)
+    monkeypatch.setenv("GR4HIP_FIR_NO_BF16X3", "1")
+    e_32 = _rel(G.fir_filter(br, torch.float32).process_bulk(xin).cpu().numpy(), tr)
+    monkeypatch.delenv("GR4HIP_FIR_NO_BF16X3")
+    assert e_bf <= 3e-6 and e_bf <= 3 * e_32 + 1e-7, (e_bf, e_32)
+
+
 @pytest.mark.parametrize("decim,ntaps", [(8, 1024), (2, 64), (3, 600), (4, 100), (10, 1000), (5, 91), (16, 4096), (16, 512), (16, 33), (32, 1024), (32, 7), (64, 2048), (64, 100), (64, 1),
                                          (11, 352), (12, 384), (20, 333), (24, 100), (25, 800), (48, 1536), (100, 1000), (96, 1536)])
 def test_fir_decimating_long_input_mfma(G, decim, ntaps):
