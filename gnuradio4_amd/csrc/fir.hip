@@ -170,8 +170,8 @@ void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_ou
 int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st, float* new_hist);
 int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_out, std::vector<float>* row);
-void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af);
-int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
+void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch);
+int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch);
 int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
@@ -392,13 +392,13 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         int rc = GR4HIP_OK;
         if (f->bfKS == 0) {
             std::vector<unsigned short> af;
-            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af);
+            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af, 1);
             rc = f->d_bfrag.ensure(af.size() * sizeof(unsigned short));
             if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->bfKS = 0; return rc; }
         }
         float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
-        rc = fir_bf16_launch(f->bfKS, x, (long)n_in, hist, (int)f->hcap, f->d_bfrag.ptr, y, st, nh);
+        rc = fir_bf16_launch(f->bfKS, x, (long)n_in, hist, (int)f->hcap, f->d_bfrag.ptr, y, st, nh, 0, 0, 1);
         if (rc) return rc;
         done = n_in;
         mfma_wrote_hist = true;

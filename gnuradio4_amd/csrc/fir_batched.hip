@@ -12,6 +12,8 @@
 #include "common.hpp"
 #include "buffer_ops.hpp"
 
+#include <cstdlib>
+
 namespace gr4 {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -470,11 +472,17 @@ int fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, cons
 
 using namespace gr4;
 
+namespace gr4 {
+void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch); // fir_bf16.hip
+int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch);
+}
 struct gr4hip_fir_batched {
     size_t       nch = 0, ntaps = 0;
     int          KS = 0, Kp = 0;
     DeviceBuffer d_afrag, d_hist[2];
     int          cur = 0;
+    DeviceBuffer d_bfrag; // > 64 taps: per-channel three-term bf16 tap fragments (fir_bf16.hip)
+    int          bfKS = 0;
 };
 
 extern "C" {
@@ -490,6 +498,12 @@ int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, cons
     fir_mfma_make_afrag(h_taps, ntaps, nchannels, &f->Kp, &f->KS, &af);
     int rc = f->d_afrag.ensure(af.size() * sizeof(float));
     if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+    if (!rc && ntaps > 64) {
+        std::vector<unsigned short> bf;
+        fir_bf16_make_afrag(h_taps, ntaps, &f->bfKS, &bf, nchannels);
+        rc = f->d_bfrag.ensure(bf.size() * sizeof(unsigned short));
+        if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, bf.data(), bf.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+    }
     for (int k = 0; k < 2 && !rc; ++k) rc = f->d_hist[k].ensure(nchannels * f->Kp * sizeof(float));
     if (!rc) rc = gr4hip_fir_batched_reset(f);
     if (rc) { delete f; return rc; }
@@ -511,7 +525,11 @@ int gr4hip_fir_batched_process(gr4hip_fir_batched_t* f, const float* d_in, size_
     GR4_REQUIRE(((uintptr_t)d_out % 16 == 0) && (out_stride % 4 == 0), "fir_batched_process: output must be 16-byte aligned with a stride multiple of 4");
     hipStream_t st = as_stream(stream);
     const float *hist = (const float*)f->d_hist[f->cur].ptr, *af = (const float*)f->d_afrag.ptr;
-    int          rc   = fir_mfma_launch(f->KS, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n, (unsigned)f->nch, st, nullptr);
+    int rc;
+    if (f->bfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !std::getenv("GR4HIP_FIR_NO_BF16X3")) // three-term bf16 form (fir_bf16.hip): same history layout
+        rc = fir_bf16_launch(f->bfKS, d_in, (long)n, hist, f->Kp, f->d_bfrag.ptr, d_out, st, nullptr, (long)in_stride, (long)out_stride, (unsigned)f->nch);
+    else
+        rc = fir_mfma_launch(f->KS, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n, (unsigned)f->nch, st, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(fir_batched_hist_kernel, dim3((unsigned)ceil_div(f->Kp, 64), (unsigned)f->nch), dim3(64), 0, st, d_in, (long)in_stride, hist,
                        (float*)f->d_hist[f->cur ^ 1].ptr, (long)n, f->Kp);

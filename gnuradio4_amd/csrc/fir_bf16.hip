@@ -43,9 +43,13 @@ __device__ __forceinline__ void bf_split2(float x0, float x1, unsigned& h, unsig
 }
 
 template <int KS> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block
-__global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ hist /*the Kh samples in front of x*/, int Kh,
-                                                               const u32x4_b* __restrict__ afrag /*[3 planes][KS][64 lanes]: 8 bf16 each*/, float* __restrict__ y, long n,
-                                                               float* __restrict__ new_hist) {
+__global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __restrict__ x0, const float* __restrict__ hist0 /*the Kh samples in front of x*/, int Kh,
+                                                               const u32x4_b* __restrict__ afrag0 /*[3 planes][KS][64 lanes]: 8 bf16 each*/, float* __restrict__ y0, long n,
+                                                               float* __restrict__ new_hist, long in_stride, long out_stride /*channel blockIdx.y: x0 + c in_stride, hist0 + c Kh, afrag0 + c 3 KS 64, y0 + c out_stride*/) {
+    const float*   x     = x0 + (long)blockIdx.y * in_stride;
+    const float*   hist  = hist0 + (long)blockIdx.y * Kh;
+    const u32x4_b* afrag = afrag0 + (long)blockIdx.y * 3 * KS * 64;
+    float*         y     = y0 + (long)blockIdx.y * out_stride;
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kBfSeg + Hb; // staged samples per segment (a multiple of 16)
     constexpr int PL  = NS + 8 * (NS >> 7) + 8;                 // bf16 elements per plane: 8 pad elements per 128 (the 16 columns of a K-step are 16 elements apart)
     constexpr int NL4 = (NS / 4 + 255) / 256;                   // float4 loads a lane holds for the next segment
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __res
         }
         __syncthreads(); // every wave is done with the staged segment before the next one overwrites it
     }
-    if (new_hist != nullptr && blockIdx.x == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
+    if (new_hist != nullptr && blockIdx.x == 0 && blockIdx.y == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
         for (int h = tid; h < Kh; h += 256) {
             const long i = n - Kh + h;
             new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
@@ -162,8 +166,12 @@ static float host_bf_to_f(unsigned short h) {
 }
 
 // fragment tables [3][KS][64][8] of bf16: plane p, K-step ks, lane l, element t = tap-plane value b_p[Hb + (l & 15) - (32 ks + 8 (l >> 4) + t)]
-void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af) {
+// (nch channels with their own taps [nch][ntaps]: the tables follow each other)
+void fir_bf16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch) {
     const int KS = std::max(3, (int)((ntaps - 1 + 16 + 31) / 32)), Hb = 32 * KS - 16; // the smallest window of 32 KS samples with Hb = 32 KS - 16 >= taps - 1 (KS = 3 .. 9)
+    af->assign((size_t)nch * 3 * KS * 64 * 8, 0);
+    for (size_t c = 0; c < nch; ++c) {
+    const float* taps = taps_all + c * ntaps;
     std::vector<unsigned short> pl[3];
     for (auto& v : pl) v.assign(ntaps, 0);
     for (size_t k = 0; k < ntaps; ++k) {
@@ -176,22 +184,22 @@ void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vect
         pl[1][k] = m;
         pl[2][k] = host_bf_rne(r2);
     }
-    af->assign((size_t)3 * KS * 64 * 8, 0);
     for (int p = 0; p < 3; ++p)
         for (int ks = 0; ks < KS; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int t = 0; t < 8; ++t) {
                     const int k = Hb + (l & 15) - (32 * ks + 8 * (l >> 4) + t);
-                    if (k >= 0 && (size_t)k < ntaps) (*af)[(((size_t)p * KS + ks) * 64 + l) * 8 + t] = pl[p][k];
+                    if (k >= 0 && (size_t)k < ntaps) (*af)[((((size_t)c * 3 + p) * KS + ks) * 64 + l) * 8 + t] = pl[p][k];
                 }
+    }
     *KS_out = KS;
 }
 
 // y[i] = sum_k b[k] x[i - k], i < n; hist = the Kh samples in front of x; x and y 16-byte aligned
-int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist) {
-    const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kBfSeg), (long)kBfSegPerWg));
+int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch) {
+    const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kBfSeg), (long)kBfSegPerWg), nch);
     const auto af = static_cast<const u32x4_b*>(afrag);
-#define GR4_BF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_bf16x3_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist); break
+#define GR4_BF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_bf16x3_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist, in_stride, out_stride); break
     switch (KS) {
         GR4_BF_CASE(3);
         GR4_BF_CASE(4);

@@ -441,6 +441,22 @@ def test_batched_fir_mfma_parity(G, nch, ntaps):
     assert _rel(y0[0], t0) <= TOL
 
 
+@pytest.mark.parametrize("nch,ntaps", [(5, 256), (3, 65), (2, 130)])
+def test_batched_fir_long_spans_take_the_bf16_three_term_kernel(G, nch, ntaps):
+    """configs[3] at spans of >= 32768 samples per channel and more than 64 taps: per-channel taps as three bf16 planes each (fir_bf16.hip), the channels in
+    grid.y; ragged ends, per-channel history handed between the bf16 kernel (long spans) and the f32 kernel (short ones)"""
+    rng = np.random.default_rng(nch * 1000 + ntaps)
+    b = (rng.standard_normal((nch, ntaps)) / np.sqrt(ntaps)).astype(np.float32)
+    n = 90_000 + 36
+    x = np.stack([O.signal_f32(142 + c, n) for c in range(nch)])
+    f = G.FirBatched(b)
+    cuts = [0, 40_004, 41_000, n]
+    y = np.concatenate([f.process_bulk(dev(np.ascontiguousarray(x[:, lo:hi]))).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])], axis=1)
+    for c in range(nch):
+        truth, _ = O.fir(b[c], x[c])
+        assert _rel(y[c], truth) <= TOL, c
+
+
 # ------------------------------------------------------------------ IIR (a3, a4)
 def test_iir_forms_golden(G, golden):
     g = golden["fir_iir_step"]
