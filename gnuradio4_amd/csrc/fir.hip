@@ -172,6 +172,7 @@ int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, cons
 void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_out, std::vector<float>* row);
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch);
+int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
@@ -326,9 +327,9 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     bool         mfma_wrote_hist = false;
     // complex<float>, no decimation, <= 256 taps, long input: whole 8192-sample frames go through the fused FFT -> xH -> inverse
     // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
-    // (<= 64 taps: the direct form is write-bound, not FP32-bound -- 306 .. 356 Gsamples/s against the fast convolution's 256 at every tap count,
-    // tools/cfir_taps_sweep.py -- and has no dynamic-range floor; 65 .. 128 taps on the matrix pipe run at 215 .. 229)
-    if (f->S == 2 && f->decim == 1 && f->ntaps > 64 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
+    // (<= 96 taps: the direct form is faster -- write-bound 300 .. 356 Gsamples/s up to 64 taps, 311 .. 275 at 65 .. 96 taps on the bf16 matrix pipe, against
+    // the fast convolution's 248 at every tap count, tools/cfir_taps_sweep.py -- and has no dynamic-range floor; 128 taps: 220, 256 taps: 151)
+    if (f->S == 2 && f->decim == 1 && f->ntaps > 96 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
         int rc = GR4HIP_OK;
         if (!f->fd) {
             rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
@@ -362,7 +363,24 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     }
     // complex<float>, no decimation, 33..256 taps, whatever the fast convolution did not take (GR4HIP_FIR_TIME_DOMAIN, a stream the dynamic-range guard has
     // moved to the direct form, or both): the same block-Toeplitz product on the re and im planes of the interleaved samples (fir_mfma_c32_kernel)
-    if (f->S == 2 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && (reinterpret_cast<uintptr_t>(y + done * 2) & 15) == 0) {
+    // (more than 64 taps, 16-byte-aligned input too: the three-term bf16 form of the same product, fir_bf16.hip)
+    if (f->S == 2 && f->decim == 1 && f->ntaps > 64 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y + done * 2) | reinterpret_cast<uintptr_t>(x + done * 2)) & 15) == 0 &&
+        !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
+        int rc = GR4HIP_OK;
+        if (f->bfKS == 0) {
+            std::vector<unsigned short> af;
+            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af, 1);
+            rc = f->d_bfrag.ensure(af.size() * sizeof(unsigned short));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (rc) { f->bfKS = 0; return rc; }
+        }
+        float* nh = done == 0 ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
+        rc = fir_bf16_c32_launch(f->bfKS, x + done * 2, (long)(n_in - done), hist, (int)f->hcap, f->d_bfrag.ptr, y + done * 2, st, nh);
+        if (rc) return rc;
+        done = n_in;
+        mfma_wrote_hist = nh != nullptr;
+    }
+    if (done < n_in && f->S == 2 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && (reinterpret_cast<uintptr_t>(y + done * 2) & 15) == 0) {
         int rc = GR4HIP_OK;
         if (f->mKS == 0) {
             std::vector<float> af;

@@ -152,6 +152,117 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __res
     }
 }
 
+// fir_filter<complex<float>> (real taps on interleaved {re, im} samples) on the same scheme: the two components are two real streams under the same taps -- six
+// planes (re / im x h / m / l), 2048 complex outputs per segment, a wave's two tiles with re and im accumulators each (eight accumulators in flight), D leaves
+// re-interleaved as two 16-byte stores per lane.  hist: the Kh complex samples in front of x.
+constexpr int kBfSegC = 2048;
+template <int KS>
+__global__ __launch_bounds__(256) void fir_mfma_bf16x3_c32_kernel(const float2* __restrict__ x, const float2* __restrict__ hist, int Kh, const u32x4_b* __restrict__ afrag,
+                                                                   float2* __restrict__ y, long n, float2* __restrict__ new_hist) {
+    constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kBfSegC + Hb;
+    constexpr int PL  = NS + 8 * (NS >> 7) + 8;
+    constexpr int NL4 = (NS / 2 + 255) / 256; // float4 loads (two complex samples each) a lane holds for the next segment
+    __shared__ __attribute__((aligned(16))) unsigned short pl[6 * PL]; // re h, m, l, then im h, m, l
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    auto      P   = [](int s_) { return s_ + 8 * (s_ >> 7); };
+    u32x4_b   a[3][KS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[p][ks] = afrag[(p * KS + ks) * 64 + lane];
+    float4 nxt[NL4];
+    auto   load_next = [&](long seg0) {
+        const long   i0   = seg0 - Hb;
+        const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
+        const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 8 : 0));
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto put2 = [&](int q, float4 v) { // complex samples 2 q, 2 q + 1 of the staged range -> the six planes
+        unsigned h, m, l;
+        const int e = P(2 * q);
+        bf_split2(v.x, v.z, h, m, l);
+        *reinterpret_cast<unsigned*>(pl + e)          = h;
+        *reinterpret_cast<unsigned*>(pl + PL + e)     = m;
+        *reinterpret_cast<unsigned*>(pl + 2 * PL + e) = l;
+        bf_split2(v.y, v.w, h, m, l);
+        *reinterpret_cast<unsigned*>(pl + 3 * PL + e) = h;
+        *reinterpret_cast<unsigned*>(pl + 4 * PL + e) = m;
+        *reinterpret_cast<unsigned*>(pl + 5 * PL + e) = l;
+    };
+    const long nseg = (n + kBfSegC - 1) / kBfSegC, sfirst = (long)blockIdx.x * kBfSegPerWg, slast = sfirst + kBfSegPerWg < nseg ? sfirst + kBfSegPerWg : nseg;
+    if (sfirst > 0 && sfirst < slast) load_next(sfirst * kBfSegC);
+    for (long sg = sfirst; sg < slast; ++sg) {
+        const long seg0 = sg * kBfSegC;
+        if (sg > 0) {
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) {
+                const int q = tid + 256 * u;
+                if (q < NS / 2) put2(q, nxt[u]);
+            }
+        } else {
+            for (int q = tid; q < NS / 2; q += 256) { // the first segment of the span reads the carried history in front of x
+                float2 t[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const long i = 2L * q + c - Hb;
+                    t[c]         = i >= 0 ? (i < n ? x[i] : make_float2(0.f, 0.f)) : (i >= -(long)Kh ? hist[Kh + i] : make_float2(0.f, 0.f));
+                }
+                put2(q, make_float4(t[0].x, t[0].y, t[1].x, t[1].y));
+            }
+        }
+        __syncthreads();
+        if (sg + 1 < slast) load_next(seg0 + kBfSegC);
+        {
+            const int ib0 = 16 * (2 * wave), ib1 = ib0 + 16; // this wave's two tiles
+            f32x4_b   cr0 = {0.f, 0.f, 0.f, 0.f}, dr0 = cr0, ci0 = cr0, di0 = cr0, cr1 = cr0, dr1 = cr0, ci1 = cr0, di1 = cr0;
+            const int s0 = 16 * (ib0 + col) + 8 * kq, s1 = 16 * (ib1 + col) + 8 * kq;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const unsigned short* q0 = pl + P(s0 + 32 * ks);
+                const unsigned short* q1 = pl + P(s1 + 32 * ks);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0][ks]), am = __builtin_bit_cast(bf16x8, a[1][ks]), al = __builtin_bit_cast(bf16x8, a[2][ks]);
+                auto six = [&](const unsigned short* qp, f32x4_b& c, f32x4_b& d) { // hh, hm, mh -> c; hl, lh, mm -> d
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(qp), bm = *reinterpret_cast<const bf16x8*>(qp + PL), bl = *reinterpret_cast<const bf16x8*>(qp + 2 * PL);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
+                };
+                six(q0, cr0, dr0);
+                six(q0 + 3 * PL, ci0, di0);
+                six(q1, cr1, dr1);
+                six(q1 + 3 * PL, ci1, di1);
+            }
+            auto out2 = [&](int ib, const f32x4_b& cr, const f32x4_b& dr, const f32x4_b& ci, const f32x4_b& di) { // D[row = 4 kq + r][col]: y[16 (ib + col) + 4 kq + r]
+                const long o = seg0 + 16L * (ib + col) + 4 * kq;
+                if (o + 3 < n) {
+                    float4* d = reinterpret_cast<float4*>(y + o);
+                    d[0]      = make_float4(cr[0] + dr[0], ci[0] + di[0], cr[1] + dr[1], ci[1] + di[1]);
+                    d[1]      = make_float4(cr[2] + dr[2], ci[2] + di[2], cr[3] + dr[3], ci[3] + di[3]);
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (o + r < n) y[o + r] = make_float2(cr[r] + dr[r], ci[r] + di[r]);
+                }
+            };
+            out2(ib0, cr0, dr0, ci0, di0);
+            out2(ib1, cr1, dr1, ci1, di1);
+        }
+        __syncthreads();
+    }
+    if (new_hist != nullptr && blockIdx.x == 0) {
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+        }
+    }
+}
+
 static unsigned short host_bf_rne(float f) {
     unsigned u;
     std::memcpy(&u, &f, 4);
@@ -211,6 +322,28 @@ int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, c
     default: return GR4HIP_UNSUPPORTED;
     }
 #undef GR4_BF_CASE
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+// the same on complex samples; hist = the Kh complex samples in front of x; x and y 16-byte aligned
+int fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist) {
+    const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kBfSegC), (long)kBfSegPerWg));
+    const auto af = static_cast<const u32x4_b*>(afrag);
+    const auto xc = reinterpret_cast<const float2*>(x), hc = reinterpret_cast<const float2*>(hist);
+    const auto yc = reinterpret_cast<float2*>(y), nh = reinterpret_cast<float2*>(new_hist);
+#define GR4_BFC_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_bf16x3_c32_kernel<K>, grid, dim3(256), 0, st, xc, hc, Kh, af, yc, n, nh); break
+    switch (KS) {
+        GR4_BFC_CASE(3);
+        GR4_BFC_CASE(4);
+        GR4_BFC_CASE(5);
+        GR4_BFC_CASE(6);
+        GR4_BFC_CASE(7);
+        GR4_BFC_CASE(8);
+        GR4_BFC_CASE(9);
+    default: return GR4HIP_UNSUPPORTED;
+    }
+#undef GR4_BFC_CASE
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

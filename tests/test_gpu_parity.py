@@ -234,10 +234,10 @@ def test_fir_random_span_sizes_switch_kernels(G, kind):
     assert len(y) == total // decim and _rel(y, truth) <= TOL
 
 
-@pytest.mark.parametrize("ntaps", [256, 91, 65, 33, 2])
+@pytest.mark.parametrize("ntaps", [256, 129, 97, 91, 65, 33, 2])
 def test_fir_complex_long_input_fast_convolution(G, ntaps):
-    """complex<float>, 65 .. 256 taps, >= 64 frames of 8192: whole frames take the frequency-domain kernel, the rest the direct form;
-    history crosses both boundaries (<= 64 taps: the same spans stay on the write-bound direct form, which is faster there)"""
+    """complex<float>, 97 .. 256 taps, >= 64 frames of 8192: whole frames take the frequency-domain kernel, the rest the direct form;
+    history crosses both boundaries (<= 96 taps: the same spans stay on the direct form -- write-bound up to 64 taps, bf16 matrix pipe above -- which is faster there)"""
     rng = np.random.default_rng(ntaps)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
     n = 3000 + (70 * 8192 + 77) + 5 + 64 * 8192
