@@ -2,7 +2,8 @@
 //
 // The same runtime fusion as chain_fused.hip -- fir_filter (blocks/filter/.../time_domain_filter.hpp:44-47) + FFT block (blocks/fourier/.../fft.hpp:147-171)
 // + mag2, the analogue of Merge<fir,"out",fft,"in"> (core/include/gnuradio-4.0/BlockMerging.hpp:136-320) -- but with the reference's own arithmetic for the
-// filter: the direct-form sum, as the block-Toeplitz contraction of fir_batched.hip on the f32 matrix pipe.  Two reasons to have it beside the fast
+// filter: the direct-form sum, as the block-Toeplitz contraction of fir_batched.hip -- on the bf16 matrix pipe with three-term splits of samples and taps
+// (fir_bf16.hip: float32 accuracy; the first version used the f32 MFMA, whose measurements the notes below refer to).  Two reasons to have it beside the fast
 // convolution:
 //  * short filters.  At <= 64 taps the direct form costs 320 executed flop per complex sample on the MATRIX pipe, which the frame transform (VALU) does not
 //    use: one workgroup's MFMA phase runs beside another workgroup's transform, and the chain needs ONE transform per frame instead of the fast
@@ -26,47 +27,72 @@
 
 namespace gr4 {
 
-void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out); // fir_batched.hip
+void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_bf16.hip
 int  make_window(int window, float* w, size_t n, float beta);                                                               // runtime.hip
 
 using td_f32x4 = __attribute__((ext_vector_type(4))) float;
+using td_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using td_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using td_f32x2  = __attribute__((ext_vector_type(2))) float;
+using td_u32x4  = __attribute__((ext_vector_type(4))) unsigned;
+// two samples -> their three bf16 terms, each pair packed in one dword (fir_bf16.hip: x = h + m + l to 2^-25 |x|, residuals exact in float32)
+__device__ __forceinline__ void td_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const td_f32x2  v  = {x0, x1};
+    const td_bf16x2 hh = __builtin_convertvector(v, td_bf16x2);
+    const td_f32x2  r1 = v - __builtin_convertvector(hh, td_f32x2);
+    const td_bf16x2 mm = __builtin_convertvector(r1, td_bf16x2);
+    const td_f32x2  r2 = r1 - __builtin_convertvector(mm, td_f32x2);
+    const td_bf16x2 ll = __builtin_convertvector(r2, td_bf16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    m = __builtin_bit_cast(unsigned, mm);
+    l = __builtin_bit_cast(unsigned, ll);
+}
 // every barrier of the kernel orders LDS accesses only.  __syncthreads() also waits for the global stores in flight (vmcnt(0)): the |X|^2 stores of a
 // segment would have to land before its workgroup may stage the next one -- measured 245 instead of 3xx Gsamples/s at 64 taps
 #define GR4_TD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 constexpr int kTdSeg = 4096; // complex samples per segment
 
-// waves per SIMD the kernel is compiled for (512 / W registers per lane): the most that needs no scratch -- 16 x 16 transforms fit 128 registers,
-// a third pass of radix >= 4 wants ~146 .. 153
+// waves per SIMD the kernel is compiled for (512 / W registers per lane)
 template <int KS, int LOG2N>
 constexpr int td_waves() {
 #ifdef GR4_TD_W
     return GR4_TD_W;
 #else
-    return LOG2N == 8 || (LOG2N == 9 && KS == 20) ? 4 : (KS == 68 ? 2 : 3); // (256 taps under the 168-register cap with the pinned MFMA order: the compiler does not finish)
+    return 2; // (eight accumulators, twelve B operands and the tap fragments of a K-step want ~180 .. 230 registers; 2 / 3 / 4 waves per SIMD measured alike on the f32 form)
 #endif
 }
 
-template <int KS, int LOG2N>
-__global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(const float2* __restrict__ x, const float2* __restrict__ hist /*the Kp samples in front of x*/, const float* __restrict__ trow /*[Kp + 32]: index 16 + q = b[q]*/,
+template <int KS /*K-steps of 32: window 32 KS, Hb = 32 KS - 16 samples in front of a block*/, int LOG2N>
+__global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(const float2* __restrict__ x, const float2* __restrict__ hist /*the Kh samples in front of x*/, int Kh,
+                                                        const td_u32x4* __restrict__ afrag /*[3 planes][KS][64 lanes]: 8 bf16 each (fir_bf16_make_afrag)*/,
                                                         const float* __restrict__ win /*[N] or null*/, const float2* __restrict__ tw /*W_N^j*/, float* __restrict__ out,
                                                         long n /*samples: whole frames*/, float2* __restrict__ new_hist) {
-    constexpr int Kp = 4 * KS - 16, N = 1 << LOG2N, T = N / 16, NP = N + N / 32;
-    constexpr int NPL = (kTdSeg + Kp) / 16 * 18 + 16; // floats per plane; + 16: the two planes sit 16 banks apart
-    constexpr int NL  = (kTdSeg + Kp + 255) / 256;    // complex samples a lane holds for the next segment
-    constexpr int R3  = N / 256;                      // third pass radix (1: none)
+    constexpr int Hb = 32 * KS - 16, NS = kTdSeg + Hb, N = 1 << LOG2N, T = N / 16, NP = N + N / 32;
+    constexpr int PL  = NS + 8 * (NS >> 7) + 8;        // bf16 elements per plane (8 pad elements per 128)
+    constexpr int NL4 = (NS / 2 + 255) / 256;          // float4 loads (two complex samples each) per lane and segment
+    constexpr int R3  = N / 256;                       // third pass radix (1: none)
     constexpr int B3  = R3 > 1 ? 16 / R3 : 1, NB3 = N / (R3 > 1 ? R3 : 1);
     extern __shared__ __attribute__((aligned(16))) float td_sm[];
-    float*  xs = td_sm;                              // [2][NPL] staged samples ...
-    float2* fb = reinterpret_cast<float2*>(td_sm);   // ... then, in the same place, the segment's frames [4096 / N][NP]
-    constexpr int DATA = 2 * NPL > 2 * (kTdSeg + kTdSeg / 32) ? 2 * NPL : 2 * (kTdSeg + kTdSeg / 32);
-    float*  tp = td_sm + DATA;                       // tap row: A[j][u] = b[Kp + j - u] is Toeplitz, lane (j, kq) reads tp[16 + Kp + j - kq - 4 ks]
+    unsigned short* pl = reinterpret_cast<unsigned short*>(td_sm); // [6][PL] staged samples: re h, m, l, im h, m, l ...
+    float2*         fb = reinterpret_cast<float2*>(td_sm);         // ... then, in the same place, the segment's frames [4096 / N][NP]
     auto    P  = [](int i) { return i + (i >> 5); };
+    auto    PB = [](int s_) { return s_ + 8 * (s_ >> 7); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int fl = tid / T, t = tid % T; // FFT phase: frame slot, lane of the frame
 
-    for (int i = tid; i < Kp + 32; i += 256) tp[i] = trow[i];
-    const float* pa = tp + 16 + Kp + col - kq;
+    auto put2 = [&](int q, float4 v) { // complex samples 2 q, 2 q + 1 of the staged range -> the six planes
+        unsigned h, m, l;
+        const int e = PB(2 * q);
+        td_split2(v.x, v.z, h, m, l);
+        *reinterpret_cast<unsigned*>(pl + e)          = h;
+        *reinterpret_cast<unsigned*>(pl + PL + e)     = m;
+        *reinterpret_cast<unsigned*>(pl + 2 * PL + e) = l;
+        td_split2(v.y, v.w, h, m, l);
+        *reinterpret_cast<unsigned*>(pl + 3 * PL + e) = h;
+        *reinterpret_cast<unsigned*>(pl + 4 * PL + e) = m;
+        *reinterpret_cast<unsigned*>(pl + 5 * PL + e) = l;
+    };
     // per-lane twiddle bases, exact table values
     const float2 w2a_ = tw[(t & 15) * (N / 256)], w2b_ = tw[2 * (t & 15) * (N / 256)]; // W_256^k, W_256^2k
     float2       w3_ = make_float2(1.f, 0.f), w3sq_ = make_float2(1.f, 0.f);
@@ -79,27 +105,30 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
     const long n_frames = n >> LOG2N;
     for (long sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
         const long seg0 = sg * kTdSeg;
-        if (sg > 0) { // (no register prefetch of the next segment: with four workgroups per CU another one always has work, and the registers buy the fourth)
-            const long   i0   = seg0 - Kp; // seg0 >= kTdSeg > Kp: nothing below 0; past the end of the span / of the segment the range check returns 0
-            const long   nrec = n - i0 < (long)(kTdSeg + Kp) ? n - i0 : (long)(kTdSeg + Kp);
+        if (sg > 0) { // (no register prefetch of the next segment: with several workgroups per CU another one always has work)
+            const long   i0   = seg0 - Hb; // seg0 >= kTdSeg > Hb: nothing below 0; past the end of the span / of the segment the range check returns 0
+            const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
             const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 8 : 0));
-            float2       nxt[NL];
+            float4       nxt[NL4];
 #pragma unroll
-            for (int u = 0; u < NL; ++u) nxt[u] = buf_load_f2(r, tid * 8, 256 * u * 8);
+            for (int u = 0; u < NL4; ++u) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+                nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
 #pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                const int s_ = tid + 256 * u;
-                if (s_ < kTdSeg + Kp) {
-                    xs[s_ + 2 * (s_ >> 4)]       = nxt[u].x;
-                    xs[NPL + s_ + 2 * (s_ >> 4)] = nxt[u].y;
-                }
+            for (int u = 0; u < NL4; ++u) {
+                const int q = tid + 256 * u;
+                if (q < NS / 2) put2(q, nxt[u]);
             }
         } else {
-            for (int s_ = tid; s_ < kTdSeg + Kp; s_ += 256) { // the first segment of the span reads the carried history in front of x
-                const long   i = s_ - Kp;
-                const float2 v = i >= 0 ? (i < n ? x[i] : make_float2(0.f, 0.f)) : hist[Kp + i];
-                xs[s_ + 2 * (s_ >> 4)]       = v.x;
-                xs[NPL + s_ + 2 * (s_ >> 4)] = v.y;
+            for (int q = tid; q < NS / 2; q += 256) { // the first segment of the span reads the carried history in front of x
+                float2 t2[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const long i = 2L * q + c - Hb;
+                    t2[c]        = i >= 0 ? (i < n ? x[i] : make_float2(0.f, 0.f)) : (i >= -(long)Kh ? hist[Kh + i] : make_float2(0.f, 0.f));
+                }
+                put2(q, make_float4(t2[0].x, t2[0].y, t2[1].x, t2[1].y));
             }
         }
         GR4_TD_BARRIER();
@@ -110,31 +139,48 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
             const int pos = (16 * (16 * (4 * wave + q) + col) + 4 * kq) & (N - 1);
             wq[q]         = win ? *reinterpret_cast<const float4*>(win + pos) : make_float4(1.f, 1.f, 1.f, 1.f);
         }
-        // ---- direct-form FIR on the matrix pipe: this wave's four tiles of 256 outputs, re and im accumulators under the same A fragment
+        // ---- direct-form FIR on the bf16 matrix pipe with three-term splits (fir_bf16.hip): this wave's four tiles of 256 outputs, re and im under the same A
         td_f32x4 acr[4], aci[4];
+        const td_u32x4* afl = afrag + lane; // (laundered: the loads are loop-invariant and would be hoisted out of the segment loop, registers and all)
+        asm volatile("" : "+v"(afl));
+        td_u32x4 a[3][KS]; // A fragments of the three tap planes: fetched (L2) per segment, so that they do not occupy registers through the transform phase
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) { // two tiles (four accumulators) at a time hide the dependent-MFMA latency
-            const int    ib0 = 16 * (4 * wave + 2 * pp), ib1 = ib0 + 16; // first 16-sample block of each tile
-            td_f32x4     ar0 = {0.f, 0.f, 0.f, 0.f}, ai0 = ar0, ar1 = ar0, ai1 = ar0;
-            const float* p0  = xs + 18 * (ib0 + col) + kq;
-            const float* p1  = xs + 18 * (ib1 + col) + kq;
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[p][ks] = afl[(p * KS + ks) * 64];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) { // two tiles (eight accumulators) at a time
+            const int ib0 = 16 * (4 * wave + 2 * pp), ib1 = ib0 + 16; // first 16-sample block of each tile
+            td_f32x4  cr0 = {0.f, 0.f, 0.f, 0.f}, dr0 = cr0, ci0 = cr0, di0 = cr0, cr1 = cr0, dr1 = cr0, ci1 = cr0, di1 = cr0;
+            const int s0 = 16 * (ib0 + col) + 8 * kq, s1 = 16 * (ib1 + col) + 8 * kq;
 #ifndef GR4_TD_NO_MFMA // (developer builds: one phase removed, tools/build_variant.sh)
 #pragma unroll
-#else
-            ar0[0] = p0[0]; ai0[0] = p0[NPL]; ar1[0] = p1[0]; ai1[0] = p1[NPL];
-#pragma unroll
-            for (int ks = 0; ks < 0; ++ks)
-#endif
             for (int ks = 0; ks < KS; ++ks) {
-                const int   off = 4 * ks + 2 * (ks >> 2);
-                const float a   = pa[-4 * ks];
-                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p0[off], ar0, 0, 0, 0);
-                ai0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p0[NPL + off], ai0, 0, 0, 0);
-                ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p1[off], ar1, 0, 0, 0);
-                ai1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p1[NPL + off], ai1, 0, 0, 0);
+                const unsigned short* q0 = pl + PB(s0 + 32 * ks);
+                const unsigned short* q1 = pl + PB(s1 + 32 * ks);
+                const td_bf16x8 ah = __builtin_bit_cast(td_bf16x8, a[0][ks]), am = __builtin_bit_cast(td_bf16x8, a[1][ks]), al = __builtin_bit_cast(td_bf16x8, a[2][ks]);
+                auto six = [&](const unsigned short* qp, td_f32x4& c, td_f32x4& d) { // hh, hm, mh -> c; hl, lh, mm -> d
+                    const td_bf16x8 bh = *reinterpret_cast<const td_bf16x8*>(qp), bm = *reinterpret_cast<const td_bf16x8*>(qp + PL), bl = *reinterpret_cast<const td_bf16x8*>(qp + 2 * PL);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
+                };
+                six(q0, cr0, dr0);
+                six(q0 + 3 * PL, ci0, di0);
+                six(q1, cr1, dr1);
+                six(q1 + 3 * PL, ci1, di1);
             }
-            acr[2 * pp] = ar0; aci[2 * pp] = ai0; acr[2 * pp + 1] = ar1; aci[2 * pp + 1] = ai1;
-            // (pinning the MFMA / LDS-read order with sched_group_barrier changes nothing here -- other waves hide the operand latency -- and costs minutes of compile time)
+#else
+            cr0[0] = (float)pl[PB(s0)]; ci0[0] = (float)pl[3 * PL + PB(s0)]; cr1[0] = (float)pl[PB(s1)]; ci1[0] = (float)pl[3 * PL + PB(s1)];
+#endif
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acr[2 * pp][r] = cr0[r] + dr0[r]; aci[2 * pp][r] = ci0[r] + di0[r];
+                acr[2 * pp + 1][r] = cr1[r] + dr1[r]; aci[2 * pp + 1][r] = ci1[r] + di1[r];
+            }
         }
         GR4_TD_BARRIER(); // every wave is done with the staged samples: the frame buffer takes their place
         // D[row = 4 kq + r][col] of tile q: sample 16 (16 (4 wave + q) + col) + 4 kq + r of the segment; x window -> frame buffer (natural order)
@@ -219,9 +265,9 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
         GR4_TD_BARRIER(); // every lane is done with the frame buffer before the next segment is staged over it
     }
     if (new_hist != nullptr && blockIdx.x == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
-        for (int h = tid; h < Kp; h += 256) {
-            const long i = n - Kp + h;
-            new_hist[h]  = i >= 0 ? x[i] : hist[Kp + i];
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
         }
     }
 }
@@ -264,15 +310,17 @@ int chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_s
     c->N     = fft_size;
     (void)hipGetDevice(&c->dev);
     c->log2n = (int)ilog2(fft_size);
-    std::vector<float> af;
-    fir_mfma_make_afrag_decim(taps, ntaps, 1, &c->Kp, &c->KS, &af); // D = 1: the tap row [Kp + 32], index 16 + q = b[q]
+    std::vector<unsigned short> af;
+    c->Kp = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : 256;             // carried history: Kp complex samples
+    c->KS = ntaps <= 81 ? 3 : ntaps <= 145 ? 5 : 9;                   // window of 32 KS samples, Hb = 32 KS - 16 >= taps - 1
+    fir_bf16_make_afrag(taps, ntaps, &c->KS, &af, 1, c->KS);
     auto up = [](DeviceBuffer& b, const void* p, size_t bytes) -> int {
         int rc = b.ensure(bytes);
         if (rc) return rc;
         GR4_HIP_TRY(hipMemcpy(b.ptr, p, bytes, hipMemcpyHostToDevice));
         return GR4HIP_OK;
     };
-    int rc = up(c->d_afrag, af.data(), af.size() * sizeof(float));
+    int rc = up(c->d_afrag, af.data(), af.size() * sizeof(unsigned short));
     c->windowed = window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR;
     if (!rc && c->windowed) {
         std::vector<float> w(fft_size);
@@ -310,8 +358,8 @@ int chain_td_set_history256(ChainTd* c, const float* d_hist256, hipStream_t st) 
 
 template <int KS>
 static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
-    constexpr int Kp  = 4 * KS - 16, NPL = (kTdSeg + Kp) / 16 * 18 + 16;
-    const size_t  lds = std::max((size_t)2 * NPL * sizeof(float), (size_t)(kTdSeg + kTdSeg / 32) * sizeof(float2)) + (Kp + 32) * sizeof(float); // staged samples, then the frames; tap row
+    constexpr int NS = kTdSeg + 32 * KS - 16, PL = NS + 8 * (NS >> 7) + 8;
+    const size_t  lds = std::max((size_t)6 * PL * sizeof(unsigned short), (size_t)(kTdSeg + kTdSeg / 32) * sizeof(float2)); // six bf16 planes of staged samples, then the frames
     const long    n   = (long)(n_frames * c->N), nseg = ceil_div(n, (long)kTdSeg);
     int           n_cu = 0;
     GR4_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->dev));
@@ -319,7 +367,7 @@ static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_ma
     const auto    xc = reinterpret_cast<const float2*>(d_in);
     const auto    hc = static_cast<const float2*>(c->d_hist[c->cur].ptr);
     const auto    nh = static_cast<float2*>(c->d_hist[c->cur ^ 1].ptr);
-    const float*  af = static_cast<const float*>(c->d_afrag.ptr);
+    const auto    af = static_cast<const td_u32x4*>(c->d_afrag.ptr);
     const float*  wn = c->windowed ? static_cast<const float*>(c->d_win.ptr) : nullptr;
     const auto    tw = static_cast<const float2*>(c->d_tw.ptr);
 #define GR4_TD_CASE(L2)                                                                                                                    \
@@ -327,7 +375,7 @@ static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_ma
         auto kern = chain_td_kernel<KS, L2>;                                                                                               \
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
         const dim3 grid((unsigned)std::min<long>(nseg, (long)n_cu * td_waves<KS, L2>()));                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, xc, hc, af, wn, tw, d_mag2, n, nh);                                        \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, xc, hc, c->Kp, af, wn, tw, d_mag2, n, nh);                                 \
     } break
     switch (c->log2n) {
         GR4_TD_CASE(8);
@@ -347,9 +395,9 @@ int chain_td_process(ChainTd* c, const float* d_in, size_t n_frames, float* d_ma
     if (n_frames == 0) return GR4HIP_OK;
     GR4_REQUIRE((uintptr_t)d_in % 8 == 0 && (uintptr_t)d_mag2 % 4 == 0, "fused time-domain chain: misaligned device pointer");
     switch (c->KS) {
-    case 20: return td_launch<20>(c, d_in, n_frames, d_mag2, st);
-    case 36: return td_launch<36>(c, d_in, n_frames, d_mag2, st);
-    default: return td_launch<68>(c, d_in, n_frames, d_mag2, st);
+    case 3: return td_launch<3>(c, d_in, n_frames, d_mag2, st);
+    case 5: return td_launch<5>(c, d_in, n_frames, d_mag2, st);
+    default: return td_launch<9>(c, d_in, n_frames, d_mag2, st);
     }
 }
 

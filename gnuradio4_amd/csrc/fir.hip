@@ -170,7 +170,7 @@ void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_ou
 int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, const float* afrag, float* y, long out_stride, long n, unsigned nch, hipStream_t st, float* new_hist);
 int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_out, std::vector<float>* row);
-void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch);
+void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
@@ -369,7 +369,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         int rc = GR4HIP_OK;
         if (f->bfKS == 0) {
             std::vector<unsigned short> af;
-            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af, 1);
+            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af, 1, 0);
             rc = f->d_bfrag.ensure(af.size() * sizeof(unsigned short));
             if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->bfKS = 0; return rc; }
@@ -410,7 +410,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         int rc = GR4HIP_OK;
         if (f->bfKS == 0) {
             std::vector<unsigned short> af;
-            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af, 1);
+            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af, 1, 0);
             rc = f->d_bfrag.ensure(af.size() * sizeof(unsigned short));
             if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->bfKS = 0; return rc; }

@@ -473,7 +473,7 @@ int fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, cons
 using namespace gr4;
 
 namespace gr4 {
-void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch); // fir_bf16.hip
+void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_bf16.hip
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch);
 }
 struct gr4hip_fir_batched {
@@ -500,7 +500,7 @@ int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, cons
     if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     if (!rc && ntaps > 64) {
         std::vector<unsigned short> bf;
-        fir_bf16_make_afrag(h_taps, ntaps, &f->bfKS, &bf, nchannels);
+        fir_bf16_make_afrag(h_taps, ntaps, &f->bfKS, &bf, nchannels, 0);
         rc = f->d_bfrag.ensure(bf.size() * sizeof(unsigned short));
         if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, bf.data(), bf.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     }

@@ -278,8 +278,8 @@ static float host_bf_to_f(unsigned short h) {
 
 // fragment tables [3][KS][64][8] of bf16: plane p, K-step ks, lane l, element t = tap-plane value b_p[Hb + (l & 15) - (32 ks + 8 (l >> 4) + t)]
 // (nch channels with their own taps [nch][ntaps]: the tables follow each other)
-void fir_bf16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch) {
-    const int KS = std::max(3, (int)((ntaps - 1 + 16 + 31) / 32)), Hb = 32 * KS - 16; // the smallest window of 32 KS samples with Hb = 32 KS - 16 >= taps - 1 (KS = 3 .. 9)
+void fir_bf16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks) {
+    const int KS = force_ks ? force_ks : std::max(3, (int)((ntaps - 1 + 16 + 31) / 32)), Hb = 32 * KS - 16; // the smallest window of 32 KS samples with Hb = 32 KS - 16 >= taps - 1 (KS = 3 .. 9)
     af->assign((size_t)nch * 3 * KS * 64 * 8, 0);
     for (size_t c = 0; c < nch; ++c) {
     const float* taps = taps_all + c * ntaps;
