@@ -13,6 +13,9 @@
 // the taps on the host (three fragment tables, resident in registers).  4096 outputs per segment, two tiles (four accumulators) in flight per wave, the
 // next segment requested into registers before the MFMAs, workgroup 0 writes the next history.  Bound: HBM (8 B per sample) once the matrix pipe is out of
 // the way.  Parity: the same 1e-5 bar as every float32 path; measured error against the float64 oracle ~2e-7, like the f32 MFMA kernel's.
+// (Measured and dropped: the m and l tap planes' fragments in LDS instead of registers -- 180 instead of 228 registers at 256 taps, one more LDS read per K-step and
+// tile pair: 303 instead of 326 Gsamples/s.  With all three planes resident the compiler re-uses one B register quad and waits for the LDS three times per K-step;
+// the extra reads cost more than those waits.)
 #include "common.hpp"
 #include "buffer_ops.hpp"
 
