@@ -171,7 +171,7 @@ int  fir_mfma_launch(int KS, const float* x, long in_stride, const float* hist, 
 int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, const float* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_out, std::vector<float>* row);
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
-int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch);
+int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
@@ -210,8 +210,10 @@ struct gr4hip_fir {
     gr4::FirDecimFd*   dfd = nullptr; // float, decim 8, <= 1024 taps: frequency-domain decimator (created on first use)
     DeviceBuffer       d_band;        // float, decim >= 10: tap row of fir_decim_band_kernel (built on first use)
     int                bandKp = 0;
-    DeviceBuffer       d_bfrag;       // float, 65 .. 256 taps: the three bf16 tap-fragment tables of fir_mfma_bf16x3_kernel (built on first use)
+    DeviceBuffer       d_bfrag;       // float / complex, 65 .. 256 taps (float: slices of 256 up to 2048): the three bf16 tap-fragment tables of fir_mfma_bf16x3_kernel (built on first use)
     int                bfKS = 0;
+    std::vector<size_t> bf_off;       // per slice: offset into d_bfrag (in bf16 elements) ...
+    std::vector<int>    bf_ks;        // ... and window size
     DeviceBuffer       d_hist256, d_histc;
     DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
     int                mKp = 0, mKS = 0;
@@ -405,18 +407,31 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     }
     // float, no decimation, 65 .. 256 taps, long 16-byte-aligned span: the same product on the bf16 matrix pipe with three-term splits of samples and taps
     // (fir_bf16.hip: float32 accuracy, 2.4 times less matrix-pipe time than the f32 MFMA -- HBM-bound instead of MFMA-bound)
-    if (f->S == 1 && f->decim == 1 && f->ntaps > 64 && f->ntaps <= 256 && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+    // (384 .. 1024 taps: slices of 256 taps, each a pass over the input delayed by 256 p samples that adds to y: 512 taps 115 instead of 90 Gsamples/s on the
+    // register-window kernel, 1024 taps 50.5 instead of 47; below 384 and above 1024 taps the extra passes cost more than they save -- measured)
+    if (f->S == 1 && f->decim == 1 && f->ntaps > 64 && (f->ntaps <= 256 || (f->ntaps >= 384 && f->ntaps <= 1024)) && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
         f->algo == GR4HIP_FIR_AUTO && !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
-        int rc = GR4HIP_OK;
+        int          rc = GR4HIP_OK;
+        const size_t nslice = ceil_div(f->ntaps, (size_t)256);
         if (f->bfKS == 0) {
-            std::vector<unsigned short> af;
-            fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af, 1, 0);
-            rc = f->d_bfrag.ensure(af.size() * sizeof(unsigned short));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
-            if (rc) { f->bfKS = 0; return rc; }
+            std::vector<unsigned short> all;
+            f->bf_off.assign(nslice, 0);
+            f->bf_ks.assign(nslice, 0);
+            for (size_t p = 0; p < nslice; ++p) {
+                std::vector<unsigned short> af;
+                const size_t                len = std::min<size_t>(256, f->ntaps - 256 * p);
+                fir_bf16_make_afrag(f->taps.data() + 256 * p, len, &f->bf_ks[p], &af, 1, 0);
+                f->bf_off[p] = all.size();
+                all.insert(all.end(), af.begin(), af.end());
+            }
+            rc = f->d_bfrag.ensure(all.size() * sizeof(unsigned short));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (rc) return rc;
+            f->bfKS = f->bf_ks[0];
         }
         float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
-        rc = fir_bf16_launch(f->bfKS, x, (long)n_in, hist, (int)f->hcap, f->d_bfrag.ptr, y, st, nh, 0, 0, 1);
+        for (size_t p = 0; p < nslice && !rc; ++p)
+            rc = fir_bf16_launch(f->bf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_bfrag.ptr + f->bf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0);
         if (rc) return rc;
         done = n_in;
         mfma_wrote_hist = true;

@@ -48,7 +48,8 @@ __device__ __forceinline__ void bf_split2(float x0, float x1, unsigned& h, unsig
 template <int KS> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block
 __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __restrict__ x0, const float* __restrict__ hist0 /*the Kh samples in front of x*/, int Kh,
                                                                const u32x4_b* __restrict__ afrag0 /*[3 planes][KS][64 lanes]: 8 bf16 each*/, float* __restrict__ y0, long n,
-                                                               float* __restrict__ new_hist, long in_stride, long out_stride /*channel blockIdx.y: x0 + c in_stride, hist0 + c Kh, afrag0 + c 3 KS 64, y0 + c out_stride*/) {
+                                                               float* __restrict__ new_hist, long in_stride, long out_stride /*channel blockIdx.y: x0 + c in_stride, hist0 + c Kh, afrag0 + c 3 KS 64, y0 + c out_stride*/,
+                                                               int delay /*this pass filters x delayed by `delay` samples (a multiple of 16) ...*/, int accum /*... and adds to y: filters longer than 256 taps run as slices*/) {
     const float*   x     = x0 + (long)blockIdx.y * in_stride;
     const float*   hist  = hist0 + (long)blockIdx.y * Kh;
     const u32x4_b* afrag = afrag0 + (long)blockIdx.y * 3 * KS * 64;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __res
 
     float4 nxt[NL4];
     auto   load_next = [&](long seg0) { // seg0 >= kBfSeg > Hb: nothing below 0; past the end of the span / of the segment the range check returns 0
-        const long   i0   = seg0 - Hb;
+        const long   i0   = seg0 - Hb - delay; // (seg0 >= kBfSeg > Hb + delay is NOT guaranteed for delayed passes: they stage every segment through the general path below)
         const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
         const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
 #pragma unroll
@@ -87,10 +88,11 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __res
         *reinterpret_cast<uint2*>(pl + 2 * PL + e) = make_uint2(l0, l1);
     };
     const long nseg = (n + kBfSeg - 1) / kBfSeg, sfirst = (long)blockIdx.x * kBfSegPerWg, slast = sfirst + kBfSegPerWg < nseg ? sfirst + kBfSegPerWg : nseg;
-    if (sfirst > 0 && sfirst < slast) load_next(sfirst * kBfSeg);
+    const bool pre = delay == 0; // register prefetch of the next segment
+    if (pre && sfirst > 0 && sfirst < slast) load_next(sfirst * kBfSeg);
     for (long sg = sfirst; sg < slast; ++sg) {
         const long seg0 = sg * kBfSeg;
-        if (sg > 0) {
+        if (pre && sg > 0) {
 #pragma unroll
             for (int u = 0; u < NL4; ++u) {
                 const int q = tid + 256 * u;
@@ -101,14 +103,14 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __res
                 float t[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const long i = 4L * q + c - Hb;
+                    const long i = seg0 + 4L * q + c - Hb - delay;
                     t[c]         = i >= 0 ? (i < n ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f);
                 }
                 put4(q, make_float4(t[0], t[1], t[2], t[3]));
             }
         }
         __syncthreads();
-        if (sg + 1 < slast) load_next(seg0 + kBfSeg); // in flight during the MFMAs below
+        if (pre && sg + 1 < slast) load_next(seg0 + kBfSeg); // in flight during the MFMAs below
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair) {
             const int ib0 = 16 * (4 * wave + 2 * pair), ib1 = ib0 + 16; // first 16-sample block of each tile
@@ -136,14 +138,18 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __res
             }
             // D[row = 4 kq + r][col]: y[16 (ib + col) + 4 kq + r]; the small terms are added to the large ones last
             const long o0 = seg0 + 16L * (ib0 + col) + 4 * kq, o1 = seg0 + 16L * (ib1 + col) + 4 * kq;
-            if (o0 + 3 < n) *reinterpret_cast<float4*>(y + o0) = make_float4(c0[0] + d0[0], c0[1] + d0[1], c0[2] + d0[2], c0[3] + d0[3]);
-            else
-                for (int r = 0; r < 4; ++r)
-                    if (o0 + r < n) y[o0 + r] = c0[r] + d0[r];
-            if (o1 + 3 < n) *reinterpret_cast<float4*>(y + o1) = make_float4(c1[0] + d1[0], c1[1] + d1[1], c1[2] + d1[2], c1[3] + d1[3]);
-            else
-                for (int r = 0; r < 4; ++r)
-                    if (o1 + r < n) y[o1 + r] = c1[r] + d1[r];
+            auto outp = [&](long o, const f32x4_b& c, const f32x4_b& d) {
+                if (o + 3 < n) {
+                    float4 v = make_float4(c[0] + d[0], c[1] + d[1], c[2] + d[2], c[3] + d[3]);
+                    if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+                    *reinterpret_cast<float4*>(y + o) = v;
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + (c[r] + d[r]);
+                }
+            };
+            outp(o0, c0, d0);
+            outp(o1, c1, d1);
         }
         __syncthreads(); // every wave is done with the staged segment before the next one overwrites it
     }
@@ -310,10 +316,11 @@ void fir_bf16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::
 }
 
 // y[i] = sum_k b[k] x[i - k], i < n; hist = the Kh samples in front of x; x and y 16-byte aligned
-int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch) {
+int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay,
+                    int accum) {
     const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kBfSeg), (long)kBfSegPerWg), nch);
     const auto af = static_cast<const u32x4_b*>(afrag);
-#define GR4_BF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_bf16x3_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist, in_stride, out_stride); break
+#define GR4_BF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_bf16x3_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist, in_stride, out_stride, delay, accum); break
     switch (KS) {
         GR4_BF_CASE(3);
         GR4_BF_CASE(4);

@@ -127,6 +127,25 @@ def test_fir_real_long_input_mfma(G, ntaps):
     assert _rel(y, truth) <= _rel(cpu32, truth) + 1e-6
 
 
+@pytest.mark.parametrize("ntaps", [257, 384, 512, 1000, 1024, 2048])
+def test_fir_float_more_than_256_taps_in_slices(G, ntaps):
+    """fir_filter<float>, 384 .. 1024 taps, long aligned spans (257 and 2048 taps: the register-window kernel, same contract): slices of 256 taps, each a pass of the three-term bf16 kernel over the input delayed by 256 p
+    samples that adds to the output; history deeper than one slice, ragged calls alternating with the register-window kernel"""
+    rng = np.random.default_rng(ntaps)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 200_000
+    x = O.signal_f32(95, n)
+    truth, _ = O.fir(b, x)
+    f = G.fir_filter(b, torch.float32)
+    cuts = [0, 60_000, 60_004, 63_000, 150_000, n]
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        xin = torch.empty(hi - lo + 4, dtype=torch.float32, device="cuda")[4:]  # 16-byte aligned start
+        xin.copy_(torch.from_numpy(x[lo:hi]))
+        parts.append(f.process_bulk(xin).cpu().numpy())
+    assert _rel(np.concatenate(parts), truth) <= TOL
+
+
 @pytest.mark.parametrize("ntaps", [65, 81, 113, 146, 200, 256])
 def test_fir_float_bf16_three_term_kernel(G, ntaps, monkeypatch):
     """fir_filter<float>, 65 .. 256 taps, long aligned spans: samples and taps as three bf16 terms each on the bf16 matrix pipe (fir_bf16.hip) -- float32
