@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
                                                         const float* __restrict__ win /*[N] or null*/, const float2* __restrict__ tw /*W_N^j*/, float* __restrict__ out,
                                                         long n /*samples: whole frames*/, float2* __restrict__ new_hist) {
     constexpr int Hb = 32 * KS - 16, NS = kTdSeg + Hb, N = 1 << LOG2N, T = N / 16, NP = N + N / 32;
-    constexpr int PL  = NS + 8 * (NS >> 7) + 8;        // bf16 elements per plane (8 pad elements per 128)
+    constexpr int PL  = NS + 8;                         // bf16 elements per plane
     constexpr int NL4 = (NS / 2 + 255) / 256;          // float4 loads (two complex samples each) per lane and segment
     constexpr int R3  = N / 256;                       // third pass radix (1: none)
     constexpr int B3  = R3 > 1 ? 16 / R3 : 1, NB3 = N / (R3 > 1 ? R3 : 1);
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
     unsigned short* pl = reinterpret_cast<unsigned short*>(td_sm); // [6][PL] staged samples: re h, m, l, im h, m, l ...
     float2*         fb = reinterpret_cast<float2*>(td_sm);         // ... then, in the same place, the segment's frames [4096 / N][NP]
     auto    P  = [](int i) { return i + (i >> 5); };
-    auto    PB = [](int s_) { return s_ + 8 * (s_ >> 7); };
+    auto    PB = [](int s_) { return s_; }; // (no padding: see fir_bf16.hip)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int fl = tid / T, t = tid % T; // FFT phase: frame slot, lane of the frame
@@ -358,7 +358,7 @@ int chain_td_set_history256(ChainTd* c, const float* d_hist256, hipStream_t st) 
 
 template <int KS>
 static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
-    constexpr int NS = kTdSeg + 32 * KS - 16, PL = NS + 8 * (NS >> 7) + 8;
+    constexpr int NS = kTdSeg + 32 * KS - 16, PL = NS + 8;
     const size_t  lds = std::max((size_t)6 * PL * sizeof(unsigned short), (size_t)(kTdSeg + kTdSeg / 32) * sizeof(float2)); // six bf16 planes of staged samples, then the frames
     const long    n   = (long)(n_frames * c->N), nseg = ceil_div(n, (long)kTdSeg);
     int           n_cu = 0;

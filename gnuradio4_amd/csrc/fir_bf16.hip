@@ -10,7 +10,9 @@
 //     y[16 i + j] = sum_u A[j][u] B[u][i],   B[u][i] = x[16 i - Hb + u],   A[j][u] = b[Hb + j - u],   u < Kw = 32 KS,   Hb = Kw - 16 >= taps - 1
 //
 // The samples are split once, while they are staged (three bf16 planes in LDS; a lane's B operand is 8 consecutive samples = one ds_read_b128 per plane),
-// the taps on the host (three fragment tables, resident in registers).  4096 outputs per segment, two tiles (four accumulators) in flight per wave, the
+// the taps on the host (three fragment tables, resident in registers).  The planes are NOT padded: ds_read_b128 serves a wave in four fixed groups of 16 lanes, and
+// with lane (col, kq) reading chunk 2 col + kq every group covers 16 different chunks mod 16 -- the first version padded 8 elements per 128 "against" conflicts and
+// had 62 % of its LDS cycles in conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, LDS 77 % busy).  4096 outputs per segment, two tiles (four accumulators) in flight per wave, the
 // next segment requested into registers before the MFMAs, workgroup 0 writes the next history.  Bound: HBM (8 B per sample) once the matrix pipe is out of
 // the way.  Parity: the same 1e-5 bar as every float32 path; measured error against the float64 oracle ~2e-7, like the f32 MFMA kernel's.
 // (Measured and dropped: the m and l tap planes' fragments in LDS instead of registers -- 180 instead of 228 registers at 256 taps, one more LDS read per K-step and
@@ -55,11 +57,11 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __res
     const u32x4_b* afrag = afrag0 + (long)blockIdx.y * 3 * KS * 64;
     float*         y     = y0 + (long)blockIdx.y * out_stride;
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kBfSeg + Hb; // staged samples per segment (a multiple of 16)
-    constexpr int PL  = NS + 8 * (NS >> 7) + 8;                 // bf16 elements per plane: 8 pad elements per 128 (the 16 columns of a K-step are 16 elements apart)
+    constexpr int PL  = NS + 8;                                   // bf16 elements per plane
     constexpr int NL4 = (NS / 4 + 255) / 256;                   // float4 loads a lane holds for the next segment
     __shared__ __attribute__((aligned(16))) unsigned short pl[3 * PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
-    auto      P   = [](int s_) { return s_ + 8 * (s_ >> 7); };
+    auto      P   = [](int s_) { return s_; }; // no padding: lane (col, kq) reads the 16-byte chunk 2 col + kq (+ 4 ks) -- ds_read_b128's four lane groups each cover 16 different chunks mod 16
 
     u32x4_b a[3][KS]; // A fragments of the three tap planes
 #pragma unroll
@@ -169,11 +171,11 @@ template <int KS>
 __global__ __launch_bounds__(256) void fir_mfma_bf16x3_c32_kernel(const float2* __restrict__ x, const float2* __restrict__ hist, int Kh, const u32x4_b* __restrict__ afrag,
                                                                    float2* __restrict__ y, long n, float2* __restrict__ new_hist) {
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kBfSegC + Hb;
-    constexpr int PL  = NS + 8 * (NS >> 7) + 8;
+    constexpr int PL  = NS + 8;
     constexpr int NL4 = (NS / 2 + 255) / 256; // float4 loads (two complex samples each) a lane holds for the next segment
     __shared__ __attribute__((aligned(16))) unsigned short pl[6 * PL]; // re h, m, l, then im h, m, l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
-    auto      P   = [](int s_) { return s_ + 8 * (s_ >> 7); };
+    auto      P   = [](int s_) { return s_; }; // no padding: lane (col, kq) reads the 16-byte chunk 2 col + kq (+ 4 ks) -- ds_read_b128's four lane groups each cover 16 different chunks mod 16
     u32x4_b   a[3][KS];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
