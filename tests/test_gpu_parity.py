@@ -127,6 +127,19 @@ def test_fir_real_long_input_mfma(G, ntaps):
     assert _rel(y, truth) <= _rel(cpu32, truth) + 1e-6
 
 
+@pytest.mark.parametrize("scale", [1e-25, 1e25])
+def test_fir_float_bf16_three_term_kernel_keeps_its_accuracy_across_the_exponent_range(G, scale):
+    """the three bf16 terms share float32's exponent range: a stream 25 decades above or below unity loses nothing (no scaling step, no fp16-style range limit)"""
+    ntaps, n = 200, 120_000
+    b = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    x = (O.signal_f32(97, n) * np.float32(scale)).astype(np.float32)
+    truth, _ = O.fir(b, x)
+    xin = torch.empty(n + 4, dtype=torch.float32, device="cuda")[4:]
+    xin.copy_(torch.from_numpy(x))
+    y = G.fir_filter(b, torch.float32).process_bulk(xin).cpu().numpy()
+    assert np.all(np.isfinite(y)) and _rel(y, truth) <= TOL
+
+
 @pytest.mark.parametrize("ntaps", [257, 384, 512, 1000, 1024, 2048])
 def test_fir_float_more_than_256_taps_in_slices(G, ntaps):
     """fir_filter<float>, 384 .. 1024 taps, long aligned spans (257 and 2048 taps: the register-window kernel, same contract): slices of 256 taps, each a pass of the three-term bf16 kernel over the input delayed by 256 p
