@@ -405,11 +405,11 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
-    // float, no decimation, 65 .. 256 taps, long 16-byte-aligned span: the same product on the bf16 matrix pipe with three-term splits of samples and taps
+    // float, no decimation, 33 .. 256 taps, long 16-byte-aligned span: the same product on the bf16 matrix pipe with three-term splits of samples and taps
     // (fir_bf16.hip: float32 accuracy, 2.4 times less matrix-pipe time than the f32 MFMA -- HBM-bound instead of MFMA-bound)
     // (384 .. 1024 taps: slices of 256 taps, each a pass over the input delayed by 256 p samples that adds to y: 512 taps 115 instead of 90 Gsamples/s on the
     // register-window kernel, 1024 taps 50.5 instead of 47; below 384 and above 1024 taps the extra passes cost more than they save -- measured)
-    if (f->S == 1 && f->decim == 1 && f->ntaps > 64 && (f->ntaps <= 256 || (f->ntaps >= 384 && f->ntaps <= 1024)) && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+    if (f->S == 1 && f->decim == 1 && f->ntaps > 32 && (f->ntaps <= 256 || (f->ntaps >= 384 && f->ntaps <= 1024)) && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
         f->algo == GR4HIP_FIR_AUTO && !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
         int          rc = GR4HIP_OK;
         const size_t nslice = ceil_div(f->ntaps, (size_t)256);

@@ -8,7 +8,7 @@ from _timing import steady
 import gnuradio4_amd as G
 n = 1 << 27
 x = G.synth_f32(n); y = torch.empty_like(x)
-for K in (64, 65, 81, 82, 128, 145, 146, 200, 256):
+for K in (32, 33, 48, 64, 65, 81, 82, 128, 145, 146, 200, 256):
     b = (np.hamming(K) / K).astype(np.float32)
     f = G.fir_filter(b, torch.float32)
     t = steady(lambda: f.process_bulk(x, y))
