@@ -173,6 +173,8 @@ void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
+void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af);
+int  fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist);
 int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
@@ -212,6 +214,8 @@ struct gr4hip_fir {
     int                bandKp = 0;
     DeviceBuffer       d_bfrag;       // float / complex, 65 .. 256 taps (float: slices of 256 up to 2048): the three bf16 tap-fragment tables of fir_mfma_bf16x3_kernel (built on first use)
     int                bfKS = 0;
+    DeviceBuffer       d_bdfrag;      // float, decim 2 .. 9, short branches: band-form bf16 fragments (fir_decim_bf16x3_kernel)
+    int                bdKS = 0, bdHb = 0; // bdKS < 0: the window does not fit that kernel
     std::vector<size_t> bf_off;       // per slice: offset into d_bfrag (in bf16 elements) ...
     std::vector<int>    bf_ks;        // ... and window size
     DeviceBuffer       d_hist256, d_histc;
@@ -291,6 +295,7 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     f->mKS = 0;
     f->bandKp = 0;
     f->bfKS = 0;
+    f->bdKS = 0;
     int rc   = fir_upload_taps(f);
     if (rc) return rc;
     if (ntaps > f->hcap) { // the reference replaces the HistoryBuffer (history is lost) only when it must grow
@@ -463,10 +468,33 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
+    // float, decimate by 2 .. 9 with a window of <= 288 samples (taps - 1 + 15 D), long 16-byte-aligned span: the band form with three-term bf16 products (fir_bf16.hip)
+    if (done == 0 && f->S == 1 && f->decim >= 2 && f->decim <= 9 && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
+        ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
+        int rc = GR4HIP_OK;
+        if (f->bdKS == 0) {
+            std::vector<unsigned short> af;
+            int                         ks = 0;
+            fir_decim_bf16_make_afrag(f->taps.data(), f->ntaps, f->decim, &ks, &f->bdHb, &af);
+            if (ks == 0) f->bdKS = -1; // the window does not fit: the kernels below
+            else {
+                rc = f->d_bdfrag.ensure(af.size() * sizeof(unsigned short));
+                if (!rc) { hipError_t e = hipMemcpy(f->d_bdfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (rc) return rc;
+                f->bdKS = ks;
+            }
+        }
+        if (f->bdKS > 0) {
+            float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
+            rc = fir_decim_bf16_launch(f->bdKS, (int)f->decim, f->bdHb, x, (long)n_in, hist, (int)f->hcap, f->d_bdfrag.ptr, y, (long)n_out, st, nh);
+            if (rc == GR4HIP_OK) { done = n_in; mfma_wrote_hist = true; }
+            else if (rc != GR4HIP_UNSUPPORTED) return rc;
+        }
+    }
     // float, decimate by 8, <= 1024 taps, long 16-byte-aligned span: overlap-save blocks of 8192 samples in the frequency domain (~35 lane-operations per
     // input sample instead of 2 K / 8 flop: HBM / power-bound instead of FP32-bound); a partial last block rides in the same launch
     constexpr size_t kDfHopS = 7168, kDfMinBlocks = 64;
-    if (f->S == 1 && f->algo == GR4HIP_FIR_AUTO && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 && n_in >= kDfMinBlocks * kDfHopS &&
+    if (done == 0 && f->S == 1 && f->algo == GR4HIP_FIR_AUTO && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 && n_in >= kDfMinBlocks * kDfHopS &&
         (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && !std::getenv("GR4HIP_FIR_NO_DECIM_FD")) {
         int rc = GR4HIP_OK;
         if (!f->dfd) rc = fir_decim_fd_create(&f->dfd, f->taps.data(), f->ntaps);

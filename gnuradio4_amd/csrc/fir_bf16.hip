@@ -274,6 +274,96 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_c32_kernel(const float2* 
     }
 }
 
+// Decimating fir_filter<float> with short polyphase branches (decimation 2 .. 9, window Hb + 15 D + 1 <= 288 samples): the band form of fir_decim_band_kernel
+// (samples in stream order, A[j][u] = b[Hb + j D - u]: the decimation sits in the A operand) with the three-term products -- the polyphase kernel on the f32 MFMA
+// is bound by that instruction (D = 2, 256 taps: 306 G input samples/s).  1024 outputs (1024 D inputs) per segment, one tile per wave, one accumulator per term.
+constexpr int kBdSegOut = 1024, kBdMaxNL4 = 10;
+template <int KS>
+__global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh, const u32x4_b* __restrict__ afrag,
+                                                                float* __restrict__ y, long n_out, long n_in, int D, int Hb /*a multiple of 4: samples in front of a block*/,
+                                                                float* __restrict__ new_hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short bpl[]; // [3][PL]
+    const int NS = 16 * D * 63 + 32 * KS, PL = NS + 8; // staged samples per segment: the last block's window ends 16 D 63 + 32 KS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    u32x4_b   a[3][KS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[p][ks] = afrag[(p * KS + ks) * 64 + lane];
+    float4 nxt[kBdMaxNL4];
+    auto   load_next = [&](long in0) { // in0 = first staged stream position (>= 0 here)
+        const long   nrec = n_in - in0 < (long)NS ? n_in - in0 : (long)NS;
+        const rsrc_t r    = make_rsrc(x + in0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
+#pragma unroll
+        for (int u = 0; u < kBdMaxNL4; ++u) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto put4 = [&](int q, float4 v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        bf_split2(v.x, v.y, h0, m0, l0);
+        bf_split2(v.z, v.w, h1, m1, l1);
+        *reinterpret_cast<uint2*>(bpl + 4 * q)          = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(bpl + PL + 4 * q)     = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(bpl + 2 * PL + 4 * q) = make_uint2(l0, l1);
+    };
+    const long nseg = (n_out + kBdSegOut - 1) / kBdSegOut, sfirst = (long)blockIdx.x * kBfSegPerWg, slast = sfirst + kBfSegPerWg < nseg ? sfirst + kBfSegPerWg : nseg;
+    auto in_start = [&](long sg) { return sg * kBdSegOut * D - Hb; };
+    if (sfirst < slast && in_start(sfirst) >= 0) load_next(in_start(sfirst));
+    for (long sg = sfirst; sg < slast; ++sg) {
+        const long in0 = in_start(sg);
+        if (in0 >= 0) {
+#pragma unroll
+            for (int u = 0; u < kBdMaxNL4; ++u) {
+                const int q = tid + 256 * u;
+                if (q < NS / 4) put4(q, nxt[u]);
+            }
+        } else { // the first segment of the span reads the carried history in front of x
+            for (int q = tid; q < NS / 4; q += 256) {
+                float t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const long i = in0 + 4L * q + c;
+                    t[c]         = i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f);
+                }
+                put4(q, make_float4(t[0], t[1], t[2], t[3]));
+            }
+        }
+        __syncthreads();
+        if (sg + 1 < slast) load_next(in_start(sg + 1)); // (>= 0: sg + 1 >= 1)
+        f32x4_b c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0; // one accumulator per term: hh, hm, mh, hl, lh, mm
+        const int s0 = 16 * D * (16 * wave + col) + 8 * kq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned short* q0 = bpl + s0 + 32 * ks;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(q0), bm = *reinterpret_cast<const bf16x8*>(q0 + PL), bl = *reinterpret_cast<const bf16x8*>(q0 + 2 * PL);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0][ks]), am = __builtin_bit_cast(bf16x8, a[1][ks]), al = __builtin_bit_cast(bf16x8, a[2][ks]);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c3, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c4, 0, 0, 0);
+            c5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c5, 0, 0, 0);
+        }
+        const long o = sg * kBdSegOut + 16L * (16 * wave + col) + 4 * kq; // D[row = 4 kq + r][col]
+        float      v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (c0[r] + (c1[r] + c2[r])) + ((c3[r] + c4[r]) + c5[r]);
+        if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int r = 0; r < 4; ++r)
+                if (o + r < n_out) y[o + r] = v[r];
+        __syncthreads();
+    }
+    if (new_hist != nullptr && blockIdx.x == 0) {
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n_in - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+        }
+    }
+}
+
 static unsigned short host_bf_rne(float f) {
     unsigned u;
     std::memcpy(&u, &f, 4);
@@ -356,6 +446,65 @@ int fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int K
     default: return GR4HIP_UNSUPPORTED;
     }
 #undef GR4_BFC_CASE
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+// band-form fragments of a decimator: [3][KS][64][8], element t of lane l at K-step ks = tap-plane value b_p[Hb + (l & 15) D - (32 ks + 8 (l >> 4) + t)]
+// Returns KS = 0 when the window Hb + 15 D + 1 does not fit 288 samples.
+void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af) {
+    const int Hb = (int)((ntaps - 1 + 3) / 4 * 4), Kw = (Hb + 15 * (int)D + 1 + 31) / 32 * 32, KS = Kw / 32;
+    *KS_out = 0;
+    *Hb_out = Hb;
+    if (KS < 1 || KS > 9) return;
+    std::vector<unsigned short> pl[3];
+    for (auto& v : pl) v.assign(ntaps, 0);
+    for (size_t k = 0; k < ntaps; ++k) {
+        const float          b = taps[k];
+        const unsigned short h = host_bf_rne(b);
+        const float          r1 = b - host_bf_to_f(h);
+        const unsigned short m = host_bf_rne(r1);
+        pl[0][k] = h;
+        pl[1][k] = m;
+        pl[2][k] = host_bf_rne(r1 - host_bf_to_f(m));
+    }
+    af->assign((size_t)3 * KS * 64 * 8, 0);
+    for (int p = 0; p < 3; ++p)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int t = 0; t < 8; ++t) {
+                    const long k = (long)Hb + (long)(l & 15) * (long)D - (32 * ks + 8 * (l >> 4) + t);
+                    if (k >= 0 && (size_t)k < ntaps) (*af)[(((size_t)p * KS + ks) * 64 + l) * 8 + t] = pl[p][(size_t)k];
+                }
+    *KS_out = KS;
+}
+
+// y[m] = sum_k b[k] x[m D - k], m < n_out; hist[h] = x[-Kh + h]; x and y 16-byte aligned
+int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist) {
+    const int    NS  = 16 * D * 63 + 32 * KS;
+    const size_t lds = (size_t)3 * (NS + 8) * sizeof(unsigned short);
+    if (lds > 64 * 1024 || (NS / 4 + 255) / 256 > kBdMaxNL4) return GR4HIP_UNSUPPORTED;
+    const dim3 grid((unsigned)ceil_div(ceil_div(n_out, (long)kBdSegOut), (long)kBfSegPerWg));
+    const auto af = static_cast<const u32x4_b*>(afrag);
+#define GR4_BD_CASE(K)                                                                                                                     \
+    case K: {                                                                                                                              \
+        auto kern = fir_decim_bf16x3_kernel<K>;                                                                                            \
+        if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, af, y, n_out, n_in, D, Hb, new_hist);                              \
+    } break
+    switch (KS) {
+        GR4_BD_CASE(1);
+        GR4_BD_CASE(2);
+        GR4_BD_CASE(3);
+        GR4_BD_CASE(4);
+        GR4_BD_CASE(5);
+        GR4_BD_CASE(6);
+        GR4_BD_CASE(7);
+        GR4_BD_CASE(8);
+        GR4_BD_CASE(9);
+    default: return GR4HIP_UNSUPPORTED;
+    }
+#undef GR4_BD_CASE
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

@@ -200,10 +200,11 @@ def test_fir_float_bf16_three_term_kernel(G, ntaps, monkeypatch):
 
 
 @pytest.mark.parametrize("decim,ntaps", [(8, 1024), (2, 64), (3, 600), (4, 100), (10, 1000), (5, 91), (16, 4096), (16, 512), (16, 33), (32, 1024), (32, 7), (64, 2048), (64, 100), (64, 1),
-                                         (11, 352), (12, 384), (20, 333), (24, 100), (25, 800), (48, 1536), (100, 1000), (96, 1536)])
+                                         (11, 352), (12, 384), (20, 333), (24, 100), (25, 800), (48, 1536), (100, 1000), (96, 1536),
+                                         (2, 256), (2, 258), (2, 17), (3, 243), (4, 228), (5, 213), (7, 100), (9, 152), (9, 153), (6, 1)])
 def test_fir_decimating_long_input_mfma(G, decim, ntaps):
-    """float polyphase decimator, >= 16 taps per phase, >= 2^14 outputs per span: phase products summed on the MFMA units; decimation by 11 .. 128:
-    the band form (samples in stream order, the decimation in the A operand, the four waves of a tile splitting the K-steps)"""
+    """float polyphase decimator, >= 16 taps per phase, >= 2^14 outputs per span: phase products summed on the MFMA units; decimation by 2 .. 9 with short branches:
+    the band form with three-term bf16 products; decimation by 10 .. 128: the band form (samples in stream order, the decimation in the A operand, the four waves of a tile splitting the K-steps)"""
     rng = np.random.default_rng(ntaps + decim)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
     cuts = [0, 40 * decim, (40 + 20_003) * decim, (40 + 20_003 + 7) * decim, (40 + 20_003 + 7 + 16_384) * decim]

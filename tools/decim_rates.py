@@ -8,7 +8,7 @@ from _timing import steady
 import gnuradio4_amd as G
 n = 1 << 27
 x = G.synth_f32(n)
-for D, K in ((2, 64), (2, 256), (3, 96), (4, 128), (4, 512), (5, 160), (8, 256), (8, 1024), (9, 288), (10, 320), (11, 352), (12, 384), (16, 512), (20, 640), (25, 800), (48, 1536), (100, 1600), (16, 2048), (32, 1024), (64, 2048)):
+for D, K in ((2, 64), (2, 128), (2, 256), (3, 240), (4, 220), (5, 210), (9, 150), (8, 128), (8, 167), (3, 96), (4, 128), (4, 512), (5, 160), (8, 256), (8, 1024), (9, 288), (10, 320), (11, 352), (12, 384), (16, 512), (20, 640), (25, 800), (48, 1536), (100, 1600), (16, 2048), (32, 1024), (64, 2048)):
     b = (np.hamming(K) / K).astype(np.float32)
     try:
         f = G.fir_filter(b, torch.float32, decimate=D)
