@@ -468,15 +468,17 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
-    // float, decimate by 2 .. 9 with a window of <= 288 samples (taps - 1 + 15 D), long 16-byte-aligned span: the band form with three-term bf16 products (fir_bf16.hip)
-    if (done == 0 && f->S == 1 && f->decim >= 2 && f->decim <= 9 && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
+    // float, decimate by 2 .. 12 with a window of <= 1152 samples (taps - 1 + 15 D), long 16-byte-aligned span: the band form with three-term bf16 products
+    // (fir_bf16.hip; windows beyond 288 samples with the K-steps split over the four waves)
+    if (done == 0 && f->S == 1 && f->decim >= 2 && f->decim <= 12 && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
         ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
         int rc = GR4HIP_OK;
         if (f->bdKS == 0) {
             std::vector<unsigned short> af;
             int                         ks = 0;
             fir_decim_bf16_make_afrag(f->taps.data(), f->ntaps, f->decim, &ks, &f->bdHb, &af);
-            if (ks == 0) f->bdKS = -1; // the window does not fit: the kernels below
+            if (ks == 0 || (f->decim == 8 && ks > 9 && f->ntaps <= 1024)) f->bdKS = -1; // the window does not fit -- or decimate-by-8 with a long window, where the
+                                                                                          // frequency-domain kernel is faster (762 against 305 G input samples/s at 1024 taps): the kernels below
             else {
                 rc = f->d_bdfrag.ensure(af.size() * sizeof(unsigned short));
                 if (!rc) { hipError_t e = hipMemcpy(f->d_bdfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }

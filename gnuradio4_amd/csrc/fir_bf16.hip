@@ -364,6 +364,108 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
     }
 }
 
+// The same with LONG windows (taps - 1 + 15 D + 1 <= 1152 samples: BASELINE configs[2]'s decimate-by-8 1024-tap filter, decimation 10 .. 32 with K ~ 32 D): the four
+// waves of a workgroup split the K-steps -- each holds the fragments of its quarter (<= 9 steps) -- and their partial tiles are summed through LDS.  Two tiles
+// (512 outputs, 512 D inputs + the window) per segment, twelve accumulators per wave.
+constexpr int kBsTiles = 2, kBsSegOut = 256 * kBsTiles, kBsMaxNL4 = 20;
+template <int KSW, int NL4> // K-steps of 32 per wave (the window is 128 KSW samples); float4 loads a lane holds for the next segment
+__global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh, const u32x4_b* __restrict__ afrag /*[3][4 KSW][64]*/,
+                                                                       float* __restrict__ y, long n_out, long n_in, int D, int Hb, float* __restrict__ new_hist, int spw /*segments per workgroup*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short bpl[]; // [3][PL] bf16 planes, then the partial tiles [4 waves][kBsTiles][64 lanes][4] floats
+    constexpr int KS = 4 * KSW;
+    const int NS = 16 * D * (16 * kBsTiles - 1) + 32 * KS, PL = NS + 8;
+    float*    part = reinterpret_cast<float*>(bpl + 3 * PL + (3 * PL & 1));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    u32x4_b   a[3][KSW];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) a[p][ks] = afrag[(p * KS + wave * KSW + ks) * 64 + lane];
+    float4 nxt[NL4];
+    auto   load_next = [&](long in0) {
+        const long   nrec = n_in - in0 < (long)NS ? n_in - in0 : (long)NS;
+        const rsrc_t r    = make_rsrc(x + in0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto put4 = [&](int q, float4 v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        bf_split2(v.x, v.y, h0, m0, l0);
+        bf_split2(v.z, v.w, h1, m1, l1);
+        *reinterpret_cast<uint2*>(bpl + 4 * q)          = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(bpl + PL + 4 * q)     = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(bpl + 2 * PL + 4 * q) = make_uint2(l0, l1);
+    };
+    const long nseg = (n_out + kBsSegOut - 1) / kBsSegOut, sfirst = (long)blockIdx.x * spw, slast = sfirst + spw < nseg ? sfirst + spw : nseg;
+    auto in_start = [&](long sg) { return sg * kBsSegOut * D - Hb; };
+    if (sfirst < slast && in_start(sfirst) >= 0) load_next(in_start(sfirst));
+    for (long sg = sfirst; sg < slast; ++sg) {
+        const long in0 = in_start(sg);
+        if (in0 >= 0) {
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) {
+                const int q = tid + 256 * u;
+                if (q < NS / 4) put4(q, nxt[u]);
+            }
+        } else {
+            for (int q = tid; q < NS / 4; q += 256) {
+                float t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const long i = in0 + 4L * q + c;
+                    t[c]         = i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f);
+                }
+                put4(q, make_float4(t[0], t[1], t[2], t[3]));
+            }
+        }
+        __syncthreads();
+        if (sg + 1 < slast) load_next(in_start(sg + 1));
+#pragma unroll
+        for (int tl = 0; tl < kBsTiles; ++tl) {
+            f32x4_b   c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
+            const int s0 = 16 * D * (16 * tl + col) + 32 * (wave * KSW) + 8 * kq; // this wave's quarter of the window
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                const unsigned short* q0 = bpl + s0 + 32 * ks;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(q0), bm = *reinterpret_cast<const bf16x8*>(q0 + PL), bl = *reinterpret_cast<const bf16x8*>(q0 + 2 * PL);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0][ks]), am = __builtin_bit_cast(bf16x8, a[1][ks]), al = __builtin_bit_cast(bf16x8, a[2][ks]);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c3, 0, 0, 0);
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c4, 0, 0, 0);
+                c5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c5, 0, 0, 0);
+            }
+            float4 v;
+            v.x = (c0[0] + (c1[0] + c2[0])) + ((c3[0] + c4[0]) + c5[0]);
+            v.y = (c0[1] + (c1[1] + c2[1])) + ((c3[1] + c4[1]) + c5[1]);
+            v.z = (c0[2] + (c1[2] + c2[2])) + ((c3[2] + c4[2]) + c5[2]);
+            v.w = (c0[3] + (c1[3] + c2[3])) + ((c3[3] + c4[3]) + c5[3]);
+            *reinterpret_cast<float4*>(part + ((wave * kBsTiles + tl) * 64 + lane) * 4) = v;
+        }
+        __syncthreads();
+        // D[row = 4 kq + r][col] of tile tl: output 256 tl + 16 col + 4 kq + r of the segment; thread t sums the four waves' partial sums of outputs t and t + 256
+#pragma unroll
+        for (int tl = 0; tl < kBsTiles; ++tl) {
+            const int  o = tid, ln = (o >> 4) + 16 * ((o & 15) >> 2), r = o & 3;
+            const long m = sg * kBsSegOut + 256 * tl + o;
+            if (m < n_out)
+                y[m] = (part[((0 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((1 * kBsTiles + tl) * 64 + ln) * 4 + r]) +
+                       (part[((2 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((3 * kBsTiles + tl) * 64 + ln) * 4 + r]);
+        }
+        __syncthreads(); // (the partial tiles and the planes are reused by the next segment)
+    }
+    if (new_hist != nullptr && blockIdx.x == 0) {
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n_in - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+        }
+    }
+}
+
 static unsigned short host_bf_rne(float f) {
     unsigned u;
     std::memcpy(&u, &f, 4);
@@ -451,12 +553,14 @@ int fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int K
 }
 
 // band-form fragments of a decimator: [3][KS][64][8], element t of lane l at K-step ks = tap-plane value b_p[Hb + (l & 15) D - (32 ks + 8 (l >> 4) + t)]
-// Returns KS = 0 when the window Hb + 15 D + 1 does not fit 288 samples.
+// Returns KS = 0 when the window Hb + 15 D + 1 does not fit 1152 samples (KS <= 9: one wave holds all fragments; 12 .. 36: split over the four waves).
 void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af) {
-    const int Hb = (int)((ntaps - 1 + 3) / 4 * 4), Kw = (Hb + 15 * (int)D + 1 + 31) / 32 * 32, KS = Kw / 32;
+    const int Hb = (int)((ntaps - 1 + 3) / 4 * 4);
+    int       KS = ((Hb + 15 * (int)D + 1 + 31) / 32 * 32) / 32;
     *KS_out = 0;
     *Hb_out = Hb;
-    if (KS < 1 || KS > 9) return;
+    if (KS > 9) KS = (KS + 3) / 4 * 4; // split over the four waves (fir_decim_bf16x3_splitk_kernel): a multiple of 4, <= 36
+    if (KS < 1 || KS > 36) return;
     std::vector<unsigned short> pl[3];
     for (auto& v : pl) v.assign(ntaps, 0);
     for (size_t k = 0; k < ntaps; ++k) {
@@ -481,6 +585,35 @@ void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* K
 
 // y[m] = sum_k b[k] x[m D - k], m < n_out; hist[h] = x[-Kh + h]; x and y 16-byte aligned
 int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist) {
+    if (KS > 9) { // long window: the waves split the K-steps
+        const int    NS   = 16 * D * (16 * kBsTiles - 1) + 32 * KS, PL = NS + 8;
+        const size_t lds  = (size_t)(3 * PL + (3 * PL & 1)) * sizeof(unsigned short) + (size_t)4 * kBsTiles * 64 * 4 * sizeof(float);
+        if (lds > 72 * 1024 || (NS / 4 + 255) / 256 > kBsMaxNL4 || KS % 4) return GR4HIP_UNSUPPORTED;
+        const bool small = (NS / 4 + 255) / 256 <= 6; // (fewer prefetch registers: one more wave per SIMD)
+        const long nseg = ceil_div(n_out, (long)kBsSegOut);
+        const int  spw  = (int)std::min<long>(std::max<long>(nseg / 2048, 1), 8);
+        const dim3 grid((unsigned)ceil_div(nseg, (long)spw));
+        const auto af   = static_cast<const u32x4_b*>(afrag);
+#define GR4_BS_CASE(K)                                                                                                                     \
+    case K: {                                                                                                                              \
+        auto kern = small ? fir_decim_bf16x3_splitk_kernel<K, 6> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4>;                           \
+        if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, af, y, n_out, n_in, D, Hb, new_hist, spw);                         \
+    } break
+        switch (KS / 4) {
+            GR4_BS_CASE(3);
+            GR4_BS_CASE(4);
+            GR4_BS_CASE(5);
+            GR4_BS_CASE(6);
+            GR4_BS_CASE(7);
+            GR4_BS_CASE(8);
+            GR4_BS_CASE(9);
+        default: return GR4HIP_UNSUPPORTED;
+        }
+#undef GR4_BS_CASE
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
     const int    NS  = 16 * D * 63 + 32 * KS;
     const size_t lds = (size_t)3 * (NS + 8) * sizeof(unsigned short);
     if (lds > 64 * 1024 || (NS / 4 + 255) / 256 > kBdMaxNL4) return GR4HIP_UNSUPPORTED;
