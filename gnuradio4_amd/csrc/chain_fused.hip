@@ -30,6 +30,11 @@
 #include <cmath>
 #include <complex>
 #include <cstdlib>
+#include <cstring>
+
+#ifndef GR4_E_BF16
+#define GR4_E_BF16 1 // the correction e on the bf16 matrix pipe (three-term splits); 0: on v_mfma_f32_16x16x4_f32 as before
+#endif
 
 namespace gr4 {
 
@@ -47,6 +52,7 @@ struct ChainFdArgs {
     const float2* twB;    // [16][32]  W_512^{r k}
     const float2* twC;    // [16][512] W_8192^{r i3}
     const float*  taps;   // 256 (zero padded)
+    const void*   efrag;  // e on the bf16 matrix pipe (non-windowed modes): [4 K quarters][2 K-steps][3 tap planes][64 lanes] x 8 bf16, A[j][u] = b_p[256 + j - u]
     const float*  win;    // WIN kernels: window[n] / N (8192 floats; small-FFT mode: the fftSize-point window tiled over the block), else unused
     const float2* twS;    // small-FFT mode: W_fftSize^j
     float*        out;    // frames * 8192 mag2
@@ -233,13 +239,28 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     float*  Dre = P + 4 * 2 * 256 + (WIN ? 1024 : 0);                  // kDPad: Dz[s] = d[s - 1] (1 <= s <= 255), zero elsewhere (s <= 511); planar, one pad
     float*  Dim = Dre + kDPad;                       //        float per 16 samples so that the MFMA B-operand reads are conflict-free
     float*  hl  = Dim + kDPad;                       // 272: taps, zero from 256 on
+    // EBF (non-windowed modes): e on the bf16 matrix pipe with three-term splits (fir_bf16.hip) -- the f32 MFMA shares the VALU's issue slot, and this
+    // kernel is VALU-bound.  The same LDS bytes then hold six bf16 planes of Dz (re h, m, l, im h, m, l; 512 elements each, zero outside 1 .. 255) instead of Dre / Dim / hl.
+    constexpr bool EBF = GR4_E_BF16 && !WIN && !FFTONLY;
+    unsigned short* Dp = reinterpret_cast<unsigned short*>(Dre);
 
     const int t0   = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6), lane0 = t0 & 63;
 
-    if constexpr (!FFTONLY) {
+    if constexpr (EBF) {
+        for (int i = t0; i < 6 * 512 / 2; i += kT) reinterpret_cast<unsigned*>(Dp)[i] = 0u;
+    } else if constexpr (!FFTONLY) {
         for (int i = t0; i < 2 * kDPad; i += kT) Dre[i] = 0.f; // Dre and Dim are adjacent
         if (t0 < 272) hl[t0] = t0 < 256 ? a.taps[t0] : 0.f;
+    }
+    using e_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    e_u32x4 ea[2][3]; // EBF: this wave's tap fragments (K quarter wave & 3), kernel-lifetime registers
+    if constexpr (EBF) {
+        const e_u32x4* ef = static_cast<const e_u32x4*>(a.efrag) + (size_t)(wave & 3) * 2 * 3 * 64 + lane0;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ea[s_][p] = ef[(s_ * 3 + p) * 64];
     }
 
     // pass A roles: column n0, parity par (even / odd rows of the column); the pair (2 n0, 2 n0 + 1) are neighbouring lanes
@@ -350,8 +371,21 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                 }
                 if (par && n0 > 0) { // v[15] is x_f[N - 256 + n0]:  Dz[n0] = d[n0 - 1]
                     const float2 dd = csub(Tc[n0], v[15]);
-                    Dre[n0 + (n0 >> 4)] = dd.x;
-                    Dim[n0 + (n0 >> 4)] = dd.y;
+                    if constexpr (EBF) {
+                        const __bf16 rh = (__bf16)dd.x, ih = (__bf16)dd.y;
+                        const float  r1 = dd.x - (float)rh, i1 = dd.y - (float)ih;
+                        const __bf16 rm = (__bf16)r1, im = (__bf16)i1;
+                        const __bf16 rl = (__bf16)(r1 - (float)rm), il = (__bf16)(i1 - (float)im);
+                        Dp[n0]           = __builtin_bit_cast(unsigned short, rh);
+                        Dp[512 + n0]     = __builtin_bit_cast(unsigned short, rm);
+                        Dp[2 * 512 + n0] = __builtin_bit_cast(unsigned short, rl);
+                        Dp[3 * 512 + n0] = __builtin_bit_cast(unsigned short, ih);
+                        Dp[4 * 512 + n0] = __builtin_bit_cast(unsigned short, im);
+                        Dp[5 * 512 + n0] = __builtin_bit_cast(unsigned short, il);
+                    } else {
+                        Dre[n0 + (n0 >> 4)] = dd.x;
+                        Dim[n0 + (n0 >> 4)] = dd.y;
+                    }
                 }
             }
             fft16<1>(v); // even lanes: E16[k1], odd lanes: O16[k1], at slot perm16(k1)
@@ -394,19 +428,40 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             const float*  pr   = ((wave >> 2) ? Dim : Dre) + 17 * col + kqm + (4 * KSW * 17 / 16) * kw;
             const float*  pa   = hl + 256 + col - kqm - 4 * KSW * kw; // A[j = col][u] = b[256 + j - u], u = 4 KSW kw + 4 i + kqm
             float         av[KSW], br[KSW];
+            using e_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+            e_bf16x8 eb[2][3]; // EBF: B operands: lane (col, kqm) reads Dz[16 col + 64 kw + 32 s + 8 kqm + 0 .. 7] of the re or im planes (tile wave >> 2)
+            if constexpr (EBF) {
+                const unsigned short* q0 = Dp + (wave >> 2) * 3 * 512 + 16 * col + 64 * kw + 8 * kqm;
 #pragma unroll
-            for (int i = 0; i < KSW; ++i) {
-                const int off = 4 * i + (i >> 2); // padded offset of u = 4 KSW kw + 4 i within the window
-                av[i] = FFTONLY ? 0.f : pa[-4 * i];
-                br[i] = FFTONLY ? 0.f : pr[off];
+                for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) eb[s_][p] = *reinterpret_cast<const e_bf16x8*>(q0 + p * 512 + 32 * s_);
+            } else {
+#pragma unroll
+                for (int i = 0; i < KSW; ++i) {
+                    const int off = 4 * i + (i >> 2); // padded offset of u = 4 KSW kw + 4 i within the window
+                    av[i] = FFTONLY ? 0.f : pa[-4 * i];
+                    br[i] = FFTONLY ? 0.f : pr[off];
+                }
             }
-            f32x4 cr = {0.f, 0.f, 0.f, 0.f};
+            f32x4 cr = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
             // One MFMA per ~12-16 butterfly instructions, fenced so that hipcc keeps the order: the wave issues in order, the MFMA
             // occupies the matrix pipe for 32 cycles while the following VALU instructions of the same wave go to the vector pipe.
             // (Left alone hipcc emits the 16 MFMAs back to back in front of the butterflies and the interval grows by their 512 cycles.)
+    // EBF: slots 0 .. 11 carry the twelve bf16 MFMAs (two K-steps x {hh, hm, mh -> cr; hl, lh, mm -> cs}), slots 12 .. 15 nothing
 #define GR4_MF(i)                                                                           \
     do {                                                                                    \
-        if constexpr (!FFTONLY) {                                                           \
+        if constexpr (EBF) {                                                                \
+            if ((i) < 12) { /* (i is a literal or the counter of an unrolled loop: resolved at compile time) */ \
+                const int s_ = ((i) / 6) & 1, m_ = (i) % 6;                                 \
+                const int pa_ = m_ == 0 || m_ == 1 || m_ == 3 ? 0 : (m_ == 2 || m_ == 5 ? 1 : 2); /* tap plane: hh hm mh hl lh mm */ \
+                const int pb_ = m_ == 0 || m_ == 2 || m_ == 4 ? 0 : (m_ == 1 || m_ == 5 ? 1 : 2); /* sample plane */                   \
+                __builtin_amdgcn_sched_barrier(0);                                          \
+                if (m_ < 3) cr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(e_bf16x8, ea[s_][pa_]), eb[s_][pb_], cr, 0, 0, 0); \
+                else cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(e_bf16x8, ea[s_][pa_]), eb[s_][pb_], cs, 0, 0, 0);        \
+                __builtin_amdgcn_sched_barrier(0);                                          \
+            }                                                                               \
+        } else if constexpr (!FFTONLY) {                                                    \
             __builtin_amdgcn_sched_barrier(0);                                              \
             cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(i)], br[(i)], cr, 0, 0, 0);                 \
             __builtin_amdgcn_sched_barrier(0);                                              \
@@ -439,7 +494,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #undef GR4_MF
             // D[row = 4 kqm + r][col] = partial e[16 col + 4 kqm + r]
             // P[K quarter][re, im][256]
-            if constexpr (!FFTONLY) *reinterpret_cast<float4*>(P + (wave & 3) * 512 + (wave >> 2) * 256 + 16 * col + 4 * kqm) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+            if constexpr (!FFTONLY) *reinterpret_cast<float4*>(P + (wave & 3) * 512 + (wave >> 2) * 256 + 16 * col + 4 * kqm) = make_float4(cr[0] + cs[0], cr[1] + cs[1], cr[2] + cs[2], cr[3] + cs[3]);
         }
         GR4_STAMP(6);
         GR4_LDS_BARRIER(); // #3
@@ -637,7 +692,7 @@ static unsigned long long* g_dbg = nullptr;
 #endif
 struct ChainFused {
     size_t       ntaps = 0;
-    DeviceBuffer d_H, d_twB, d_twC, d_taps, d_hist, d_win, d_twS;
+    DeviceBuffer d_H, d_twB, d_twC, d_taps, d_hist, d_win, d_twS, d_efrag;
     bool         windowed = false;
     int          small_log2n = 0; // 8..12: fftSize = 2^small_log2n < 8192, the launch unit stays an 8192-sample block
     DeviceBuffer d_stage_in, d_stage_out; // one zero-padded block for the tail of a span that is not a multiple of 8192 samples
@@ -707,6 +762,28 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
     if (!rc) rc = upload(c->d_twB, twB);
     if (!rc) rc = upload(c->d_twC, twC);
     if (!rc) rc = upload(c->d_taps, hp);
+    if (!rc) { // tap fragments of the correction e on the bf16 matrix pipe: [4 K quarters][2 K-steps][3 planes][64 lanes][8], A[j][u] = b_p[256 + j - u], b = h + m + l in bf16
+        auto rne = [](float f) { unsigned u; std::memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); };
+        auto tof = [](unsigned short h) { const unsigned u = (unsigned)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        std::vector<unsigned short> pl[3];
+        for (auto& v : pl) v.assign(256, 0);
+        for (int k = 0; k < 256; ++k) {
+            const unsigned short h = rne(hp[k]);
+            const float          r1 = hp[k] - tof(h);
+            const unsigned short m = rne(r1);
+            pl[0][k] = h; pl[1][k] = m; pl[2][k] = rne(r1 - tof(m));
+        }
+        std::vector<unsigned short> ef((size_t)4 * 2 * 3 * 64 * 8, 0);
+        for (int kw = 0; kw < 4; ++kw)
+            for (int s_ = 0; s_ < 2; ++s_)
+                for (int p = 0; p < 3; ++p)
+                    for (int l = 0; l < 64; ++l)
+                        for (int t = 0; t < 8; ++t) {
+                            const int k = 256 + (l & 15) - (64 * kw + 32 * s_ + 8 * (l >> 4) + t);
+                            if (k >= 0 && k < 256) ef[((((size_t)kw * 2 + s_) * 3 + p) * 64 + l) * 8 + t] = pl[p][k];
+                        }
+        rc = upload(c->d_efrag, ef);
+    }
     if (!rc && fft_size == (size_t)kN) rc = chain16_create(&c->c16, H.data(), hp.data());
     c->small_log2n = fft_size == (size_t)kN ? 0 : (int)ilog2(fft_size);
     c->windowed    = c->small_log2n != 0 || (window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR);
@@ -765,6 +842,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     a.twB      = static_cast<const float2*>(c->d_twB.ptr);
     a.twC      = static_cast<const float2*>(c->d_twC.ptr);
     a.taps     = static_cast<const float*>(c->d_taps.ptr);
+    a.efrag    = c->d_efrag.ptr;
     a.win      = fft_only ? fft_window : static_cast<const float*>(c->d_win.ptr);
     a.twS      = static_cast<const float2*>(c->d_twS.ptr);
     a.out      = d_out;
@@ -793,17 +871,18 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     // two frame buffers, two tails, e | partial tiles (+ WIN: pass-B twiddle table), planar padded d, taps
     constexpr size_t lds_base = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
     constexpr size_t lds_win  = lds_base + 1024 * sizeof(float);
-    static_assert(lds_win <= 160 * 1024, "LDS budget of one CU");
-    const size_t lds  = (c->windowed && !fir_mode && !fft_only) ? lds_win : lds_base;
+    constexpr size_t lds_ebf  = lds_base + (GR4_E_BF16 ? 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 0); // non-windowed filter modes: six bf16 planes of Dz instead of Dre / Dim / hl
+    static_assert(lds_win <= 160 * 1024 && lds_ebf <= 160 * 1024, "LDS budget of one CU");
+    const size_t lds  = (c->windowed && !fir_mode && !fft_only) ? lds_win : (fft_only ? lds_base : lds_ebf);
     static PerDevice per_device; // LDS opt-in and CU count, once per device this process uses
     bool             first = false;
     int              dev = -1, n_cu = per_device.current(&first, &dev);
     GR4_REQUIRE(n_cu != 0, "fused chain: cannot query the current device");
     if (first) {
         n_cu = -n_cu;
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ebf));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFir>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ebf));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeFftSpec>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
