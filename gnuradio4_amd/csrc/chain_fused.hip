@@ -35,6 +35,9 @@
 #ifndef GR4_E_BF16
 #define GR4_E_BF16 1 // the correction e on the bf16 matrix pipe (three-term splits); 0: on v_mfma_f32_16x16x4_f32 as before
 #endif
+#ifndef GR4_E_BF16_WIN
+#define GR4_E_BF16_WIN 1 // the same in the windowed modes (their LDS image is 160 KiB to the byte with it)
+#endif
 
 namespace gr4 {
 
@@ -52,7 +55,7 @@ struct ChainFdArgs {
     const float2* twB;    // [16][32]  W_512^{r k}
     const float2* twC;    // [16][512] W_8192^{r i3}
     const float*  taps;   // 256 (zero padded)
-    const void*   efrag;  // e on the bf16 matrix pipe (non-windowed modes): [4 K quarters][2 K-steps][3 tap planes][64 lanes] x 8 bf16, A[j][u] = b_p[256 + j - u]
+    const void*   efrag;  // e on the bf16 matrix pipe: [4 K quarters][2 K-steps][3 tap planes][64 lanes] x 8 bf16, A[j][u] = b_p[256 + j - u]
     const float*  win;    // WIN kernels: window[n] / N (8192 floats; small-FFT mode: the fftSize-point window tiled over the block), else unused
     const float2* twS;    // small-FFT mode: W_fftSize^j
     float*        out;    // frames * 8192 mag2
@@ -236,12 +239,13 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     float2* T1 = T0 + 256;                           // 256: same for B1
     float2* el = T1 + 256;                           // 256: e[n]
     float*  P  = reinterpret_cast<float*>(el + 256); // [4 K quarters][re, im][256]: partial e; WIN: followed by the pass-B twiddle table [16][32]
-    float*  Dre = P + 4 * 2 * 256 + (WIN ? 1024 : 0);                  // kDPad: Dz[s] = d[s - 1] (1 <= s <= 255), zero elsewhere (s <= 511); planar, one pad
+    constexpr bool EBFW = GR4_E_BF16 && GR4_E_BF16_WIN && WIN;                  // windowed modes: the table keeps rows 1 .. 15 only (row 0 is never read), which is the 256 bytes the bf16 planes need
+    float*  Dre = P + 4 * 2 * 256 + (WIN ? (EBFW ? 960 : 1024) : 0);                  // kDPad: Dz[s] = d[s - 1] (1 <= s <= 255), zero elsewhere (s <= 511); planar, one pad
     float*  Dim = Dre + kDPad;                       //        float per 16 samples so that the MFMA B-operand reads are conflict-free
     float*  hl  = Dim + kDPad;                       // 272: taps, zero from 256 on
-    // EBF (non-windowed modes): e on the bf16 matrix pipe with three-term splits (fir_bf16.hip) -- the f32 MFMA shares the VALU's issue slot, and this
+    // EBF: e on the bf16 matrix pipe with three-term splits (fir_bf16.hip) -- the f32 MFMA shares the VALU's issue slot, and this
     // kernel is VALU-bound.  The same LDS bytes then hold six bf16 planes of Dz (re h, m, l, im h, m, l; 512 elements each, zero outside 1 .. 255) instead of Dre / Dim / hl.
-    constexpr bool EBF = GR4_E_BF16 && !WIN && !FFTONLY;
+    constexpr bool EBF = GR4_E_BF16 && (!WIN || EBFW) && !FFTONLY;
     unsigned short* Dp = reinterpret_cast<unsigned short*>(Dre);
 
     const int t0   = threadIdx.x;
@@ -284,8 +288,8 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     for (int k1 = 0; k1 < 16; ++k1) twA[k1] = (t0 & 1) ? w32(k1) : make_float2(1.f, 0.f);
     // WIN: the correction FIR splits K over 4 wave pairs (one of each pair takes the real tile, the other the imaginary one), so only
     // half of P is used; the other half holds the pass-B twiddle table
-    float2* twBl = reinterpret_cast<float2*>(P + 4 * 2 * 256);
-    if constexpr (WIN) twBl[t0] = a.twB[t0]; // [16][32] = 512 entries
+    float2* twBl = reinterpret_cast<float2*>(P + 4 * 2 * 256) - (EBFW ? 32 : 0);
+    if constexpr (WIN) { if (!EBFW || t0 >= 32) twBl[t0] = a.twB[t0]; } // [16][32] = 512 entries (EBFW: rows 1 .. 15)
 
     float wA[16]; // kModeFftWinMag2: window of the samples pass A reads, row 2 m + par of column n0 = sample (2 m + par) 256 + n0
     if constexpr (FFTWIN) {
@@ -870,7 +874,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
 #endif
     // two frame buffers, two tails, e | partial tiles (+ WIN: pass-B twiddle table), planar padded d, taps
     constexpr size_t lds_base = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
-    constexpr size_t lds_win  = lds_base + 1024 * sizeof(float);
+    constexpr size_t lds_win  = lds_base + ((GR4_E_BF16 && GR4_E_BF16_WIN) ? 960 * sizeof(float) + 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 1024 * sizeof(float)); // = 160 KiB exactly with the bf16 planes
     constexpr size_t lds_ebf  = lds_base + (GR4_E_BF16 ? 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 0); // non-windowed filter modes: six bf16 planes of Dz instead of Dre / Dim / hl
     static_assert(lds_win <= 160 * 1024 && lds_ebf <= 160 * 1024, "LDS budget of one CU");
     const size_t lds  = (c->windowed && !fir_mode && !fft_only) ? lds_win : (fft_only ? lds_base : lds_ebf);
