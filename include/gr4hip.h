@@ -124,7 +124,7 @@ int gr4hip_ring_size(const gr4hip_ring_t* ring, size_t* bytes);
  * BasicFilterProto decimating processBulk (:190-204): output m == y[m*decim]; n_in must be a multiple of decim
  * (the reference guarantees it through input_chunk_size = decimate, :166-168). */
 /* (complex data, 97 .. 256 taps, spans of >= 64 x 8192 samples take a fast-convolution kernel: a non-finite input sample then reaches every output of
- * its 8192-sample block instead of the next ntaps outputs.  33 .. 256 taps (complex: 65 .. 256) on long 16-byte-aligned spans evaluate the products with samples and taps split into
+ * its 8192-sample block instead of the next ntaps outputs.  33 .. 256 taps (complex too) on long 16-byte-aligned spans evaluate the products with samples and taps split into
  * three bf16 terms each (float32 accuracy, same 1e-5 parity bar): an infinite sample gives NaN -- not +-Inf -- in the outputs it reaches, and a finite sample
  * above bf16's largest value, 3.39e38, counts as infinite.  GR4HIP_FIR_NO_BF16X3 in the environment keeps the float32 multiply-add kernels.) */
 typedef struct gr4hip_fir gr4hip_fir_t;

@@ -292,10 +292,10 @@ def test_fir_complex_long_input_fast_convolution(G, ntaps):
     assert _rel(f2.process_bulk(xin).cpu().numpy(), truth) <= TOL
 
 
-@pytest.mark.parametrize("ntaps", [256, 129, 64, 40])
+@pytest.mark.parametrize("ntaps", [256, 129, 64, 40, 33])
 def test_fir_complex_time_domain_on_the_matrix_pipe(G, ntaps):
     """complex<float> direct form (GR4HIP_FIR_TIME_DOMAIN: the regime the dynamic-range guard moves a stream to), 33 .. 256 taps, spans >= 2^15 samples: the
-    re and im planes as a block-Toeplitz product on the f32 MFMA units; ragged spans, history across the kernel switches, an output that is only 8-byte
+    re and im planes as a block-Toeplitz product on the matrix pipe (bf16 three-term products on 16-byte-aligned spans, the f32 MFMA otherwise); ragged spans, history across the kernel switches, an output that is only 8-byte
     aligned (-> the VALU kernel) gives the same stream"""
     rng = np.random.default_rng(ntaps)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
