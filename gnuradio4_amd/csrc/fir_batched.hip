@@ -498,7 +498,8 @@ int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, cons
     fir_mfma_make_afrag(h_taps, ntaps, nchannels, &f->Kp, &f->KS, &af);
     int rc = f->d_afrag.ensure(af.size() * sizeof(float));
     if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
-    if (!rc && ntaps > 64) {
+    static const size_t kBfMinTaps = [] { const char* e = std::getenv("GR4HIP_FIR_BATCHED_BF16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // developer knob
+    if (!rc && ntaps >= kBfMinTaps && ntaps > 32) {
         std::vector<unsigned short> bf;
         fir_bf16_make_afrag(h_taps, ntaps, &f->bfKS, &bf, nchannels, 0);
         rc = f->d_bfrag.ensure(bf.size() * sizeof(unsigned short));

@@ -474,9 +474,9 @@ def test_batched_fir_mfma_parity(G, nch, ntaps):
     assert _rel(y0[0], t0) <= TOL
 
 
-@pytest.mark.parametrize("nch,ntaps", [(5, 256), (3, 65), (2, 130)])
+@pytest.mark.parametrize("nch,ntaps", [(5, 256), (3, 65), (2, 130), (4, 33), (3, 48), (2, 64)])
 def test_batched_fir_long_spans_take_the_bf16_three_term_kernel(G, nch, ntaps):
-    """configs[3] at spans of >= 32768 samples per channel and more than 64 taps: per-channel taps as three bf16 planes each (fir_bf16.hip), the channels in
+    """configs[3] at spans of >= 32768 samples per channel and more than 32 taps: per-channel taps as three bf16 planes each (fir_bf16.hip), the channels in
     grid.y; ragged ends, per-channel history handed between the bf16 kernel (long spans) and the f32 kernel (short ones)"""
     rng = np.random.default_rng(nch * 1000 + ntaps)
     b = (rng.standard_normal((nch, ntaps)) / np.sqrt(ntaps)).astype(np.float32)
