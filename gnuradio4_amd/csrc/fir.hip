@@ -371,8 +371,8 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     // complex<float>, no decimation, 33..256 taps, whatever the fast convolution did not take (GR4HIP_FIR_TIME_DOMAIN, a stream the dynamic-range guard has
     // moved to the direct form, or both): the same block-Toeplitz product on the re and im planes of the interleaved samples (fir_mfma_c32_kernel)
     // (16-byte-aligned input too: the three-term bf16 form of the same product, fir_bf16.hip)
-    static const size_t kCBfMinTaps = [] { const char* e = std::getenv("GR4HIP_CFIR_BF16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // developer knob: 65 puts 33..64 taps back on the f32 MFMA (measured 5-8 % slower: 299-316 against 322-333 Gsamples/s)
-    if (f->S == 2 && f->decim == 1 && f->ntaps >= kCBfMinTaps && f->ntaps > 32 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y + done * 2) | reinterpret_cast<uintptr_t>(x + done * 2)) & 15) == 0 &&
+    static const size_t kCBfMinTaps = [] { const char* e = std::getenv("GR4HIP_CFIR_BF16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // developer knob: 65 puts 33..64 taps back on the f32 MFMA (measured 5-8 % slower: 299-316 against 322-333 Gsamples/s); below 33 taps the register-window kernel is ahead up to 27 taps and within 3 % from there (tools/cfir_bf16_threshold.py)
+    if (f->S == 2 && f->decim == 1 && f->ntaps >= kCBfMinTaps && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y + done * 2) | reinterpret_cast<uintptr_t>(x + done * 2)) & 15) == 0 &&
         !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
         int rc = GR4HIP_OK;
         if (f->bfKS == 0) {

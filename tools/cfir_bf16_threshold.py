@@ -9,7 +9,7 @@ import gnuradio4_amd as G
 from gnuradio4_amd import capi
 n = 1 << 27
 x = G.synth_c32(n); y = torch.empty(n, dtype=torch.complex64, device="cuda")
-for ntaps in (33, 40, 48, 56, 64, 65):
+for ntaps in (8, 12, 16, 20, 24, 28, 32, 33, 48, 64):
     kk = np.arange(ntaps); t = np.hamming(ntaps) * 0.2 * np.sinc(0.2 * (kk - (ntaps - 1) / 2)); t = (t / t.sum()).astype(np.float32)
     g = G.fir_filter(t, torch.complex64); g.set_algo(capi.FIR_TIME_DOMAIN)
     tt = steady(lambda: g.process_bulk(x, y))
