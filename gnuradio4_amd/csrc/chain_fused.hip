@@ -35,6 +35,9 @@
 #ifndef GR4_E_BF16
 #define GR4_E_BF16 1 // the correction e on the bf16 matrix pipe (three-term splits); 0: on v_mfma_f32_16x16x4_f32 as before
 #endif
+#ifndef GR4_FMA_COMBINE
+#define GR4_FMA_COMBINE 1
+#endif
 #ifndef GR4_E_BF16_WIN
 #define GR4_E_BF16_WIN 1 // the same in the windowed modes (their LDS image is 160 KiB to the byte with it)
 #endif
@@ -323,6 +326,9 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     long fprev = -1;
     long f   = blockIdx.x;
     int  cur = 0;
+#if defined(GR4_PRIO_YOUNG)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1); // the second-dispatched half loses every age arbitration on its SIMD otherwise
+#endif
     if (f < a.n_frames) {
         if constexpr (!FFTONLY) dma_tail(f > 0 ? a.x + f * kN - 256 : a.hist, T0, wave, lane0);
         dma_frame(a.x + f * kN, B0, wave, lane0);
@@ -346,8 +352,13 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_STAMP(1);
         // stream the next frame (and the 256 samples before it) into the other buffers: in flight until the next barrier T.
         // Unconditional (the last iteration re-reads its own frame): no divergent paths around the DMA for hipcc's wait insertion
+#if defined(GR4_T_L2ONLY) // developer timing build (results are wrong): every workgroup re-reads and re-writes ITS FIRST frame -- the same instructions with the traffic held in L2
+        const long   fn = blockIdx.x;
+        const rsrc_t rq = make_rsrc(a.out + (long)blockIdx.x * kN * (FIR ? 2 : 1), fprev < 0 ? 0u : (unsigned)(kN * sizeof(float) * (FIR ? 2 : 1)));
+#else
         const long   fn = (f + gridDim.x < a.n_frames) ? f + gridDim.x : f;
         const rsrc_t rq = make_rsrc(a.out + (fprev < 0 ? 0 : fprev) * kN * (FIR ? 2 : 1), fprev < 0 ? 0u : (unsigned)(kN * sizeof(float) * (FIR ? 2 : 1))); // first iteration: nothing pending, stores fall out of range
+#endif
 #define GR4_DRAIN(g)                                                                                       \
     do {                                                                                                   \
         if constexpr (DEFER && FIR) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f2(rq, make_float2(pend[q], pendi[q]), t * 8, q * 4096); } \
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         GR4_DRAIN(6);
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-            if constexpr (!FFTONLY) X[perm16(q)] = cmul(Hr[q], X[perm16(q)]);
+            if constexpr (!FFTONLY && !(GR4_FMA_COMBINE && MODE == kModeMag2)) X[perm16(q)] = cmul(Hr[q], X[perm16(q)]); // (headline mode: H enters in the combine, as one fma chain onto E)
         GR4_STAMP(8);
         GR4_LDS_BARRIER(); // #4: every lane has consumed S; e[] is complete
         GR4_STAMP(9);
@@ -528,9 +539,21 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             for (int q = 0; q < 16; ++q) pend[q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y); // |X[t + 512 q]|^2, stored during the next frame
         } else if constexpr (MODE == kModeMag2) {
             // ------------------------------------------------------------------ E: pass A is a broadcast, then the same passes B and C
+#if defined(GR4_T_NOE) // developer timing build (results are wrong): no E transform at all = the bound of 1.0 transforms per frame
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pend[q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y);
+            if (false) {
+#else
+            {
+#endif
     #pragma unroll
             for (int r = 0; r < 16; ++r) w[r] = el[cb + 16 * r];
+#if defined(GR4_T_NOEB) // developer timing build (results are wrong): E's pass B without its arithmetic = the bound of moving it off the VALU
+#pragma unroll
+            for (int q = 0; q < 16; ++q) S[cb * kRowB + 32 * q + kb] = w[perm16(q)];
+#else
             passB_compute_store(S, w, twBr, cb, kb);
+#endif
             GR4_STAMP(10);
             GR4_LDS_BARRIER(); // #5
             GR4_STAMP(11);
@@ -540,8 +563,14 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
             // ------------------------------------------------------------------ FFT(y_f)[k] = H[k] X[k] + E[k];  mag2 = |.|^2  (k = t + 512 q)
     #pragma unroll
             for (int q = 0; q < 16; ++q) {
+#if GR4_FMA_COMBINE
+                const float2 Xq = X[perm16(q)], Eq = w[perm16(q)]; // H X + E as two fma chains per component (4 instructions instead of 4 + 2)
+                const float2 Y  = make_float2(fmaf(Hr[q].x, Xq.x, fmaf(-Hr[q].y, Xq.y, Eq.x)), fmaf(Hr[q].x, Xq.y, fmaf(Hr[q].y, Xq.x, Eq.y)));
+#else
                 const float2 Y = cadd(X[perm16(q)], w[perm16(q)]);
+#endif
                 pend[q] = fmaf(Y.x, Y.x, Y.y * Y.y); // out[t + 512 q], stored during the next frame
+            }
             }
         } else {
             // ------------------------------------------------------------------ y_f = IFFT(H X) + e through conj(FFT(conj(.))) / N
