@@ -118,7 +118,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=0, help="SDR channels in the graph: 0 = 1 at --gpus 1 (configs[1]) and 8 at --gpus N > 1 (configs[4])")
     ap.add_argument("--log2-samples", type=int, default=30, help="stream length per step and channel (default 2^30 = configs[1])")
-    ap.add_argument("--log2-chunk", type=int, default=28, help="samples per launch")
+    ap.add_argument("--log2-chunk", type=int, default=0, help="samples per launch (default: 2^30 = the whole 1G-sample stream in one call at one channel on one GPU -- a strict-guard "
+                    "chain call returns when its launch has finished, so launches are as long as the stream allows; 2^28 when the graph has a fan-in to overlap with the next launch)")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 unfused, 3 fused frequency-domain, 4 time domain")
     ap.add_argument("--fanin-cus", type=int, default=32, help="N > 1: CUs left to the RCCL fan-in kernels (the fused kernel is persistent and fills every CU it gets)")
     ap.add_argument("--fanin-algo", default="auto", choices=["auto", "reduce_scatter", "all_to_all"],
@@ -126,6 +127,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check of the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of sampled output frames")
+    ap.add_argument("--no-multi", action="store_true", help="several channels per GPU: one kernel per channel on its own stream + a separate math::Add fold (round 2's shape) "
+                    "instead of ONE launch with the fold in registers (gr4hip_chain_process_multi)")
+    ap.add_argument("--guard-mode", type=int, default=0, help="dynamic-range guard of the AUTO chain: 0 strict (default of the library), 1 deferred, 2 off")
     ap.add_argument("--no-graph8", action="store_true", help="N = 1: skip the extra measurement of the 8-channel graph on this one GPU (the 1-GPU point of the strong-scaling curve)")
     args = ap.parse_args()
 
@@ -135,6 +139,7 @@ def main():
 
     import gnuradio4_amd as G
     from gnuradio4_amd import capi, fanin
+    from gnuradio4_amd.blocks import chain_process_multi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -153,7 +158,8 @@ def main():
     mine = plan[rank]  # channels this rank owns
     combine = n_channels > 1
     n = 1 << args.log2_samples
-    chunk = min(1 << args.log2_chunk, n)
+    log2_chunk = args.log2_chunk or (28 if (combine or world > 1) else 30)
+    chunk = min(1 << log2_chunk, n)
     nchunks = n // chunk
     frames_per_chunk = chunk // NFFT
     assert frames_per_chunk % world == 0, "frames per launch must split evenly over the ranks (reduce_scatter shards)"
@@ -163,7 +169,8 @@ def main():
     if os.environ.get("GR4HIP_BENCH_ZERO_INPUT") == "1":  # developer experiment (DVFS: how far the clocks rise when the datapaths stop toggling); never a reported number
         for x_ in xs:
             x_.zero_()
-    outs = [torch.empty((n // NFFT, NFFT), dtype=torch.float32, device="cuda") for _ in mine]
+    multi = len(mine) > 1 and not args.no_multi  # this rank's channels in ONE launch, their math::Add fold kept in registers: only the sum reaches HBM
+    outs = [torch.empty((n // NFFT, NFFT), dtype=torch.float32, device="cuda") for _ in mine] if not multi else []
     # combiner output of this rank: the local fold of its channels per launch (double-buffered: the collective of launch c reads
     # slab c & 1 while the fold of launch c + 1 writes the other) and its shard of the all-channel sum of every launch
     acc = torch.empty((2, frames_per_chunk, NFFT), dtype=torch.float32, device="cuda") if combine and len(mine) > 1 else None
@@ -176,7 +183,10 @@ def main():
     taps = (w.astype(np.float64) * 0.2 * np.sinc(0.2 * (k - (NTAPS - 1) / 2.0)))
     taps = (taps / taps.sum()).astype(np.float32)  # Hamming windowed-sinc, fc = 0.1, DC gain 1
     chains = [G.Chain(taps, NFFT, "None", args.algo) for _ in mine]
-    streams = [torch.cuda.Stream() for _ in mine] if len(mine) > 1 else [torch.cuda.current_stream()]
+    if args.guard_mode:
+        for ch in chains:
+            ch.set_guard_mode(args.guard_mode)
+    streams = [torch.cuda.Stream() for _ in mine] if len(mine) > 1 and not multi else [torch.cuda.current_stream()]
     n_cu = torch.cuda.get_device_properties(local).multi_processor_count
     if world > 1 and args.fanin_cus > 0:  # the collective of chunk c runs beside the transforms of chunk c+1 instead of behind them
         for ch in chains:
@@ -215,11 +225,26 @@ def main():
 
     def step(record: bool):
         # (no reset between steps: the stream simply continues, the FIR history of a step's first frame is the previous step's tail)
-        if len(mine) > 1:  # a channel stream must not overwrite a slice the previous step's fold still reads
+        if len(mine) > 1 and not multi:  # a channel stream must not overwrite a slice the previous step's fold still reads
             for s in streams:
                 s.wait_stream(main_stream)
         for c in range(nchunks):
             fr = slice(c * frames_per_chunk, (c + 1) * frames_per_chunk)
+            if multi:
+                if world > 1 and c >= 2:
+                    main_stream.wait_event(fan_done[c & 1])  # the fan-in that read this slab two launches ago
+                dst = sum_out[fr] if world == 1 else acc[c & 1]
+                if record:
+                    ev[c][0].record()
+                chain_process_multi(chains, [x_[c * chunk:(c + 1) * chunk] for x_ in xs], want_outs=False, sum_out=dst)
+                if record:
+                    ev[c][1].record()
+                if world > 1:
+                    fan_stream.wait_stream(main_stream)
+                    with torch.cuda.stream(fan_stream):
+                        fanin.fan_in_sum(dst, rs_out[c], algo=fanin_algo, recv=recv)
+                        fan_done[c & 1].record()
+                continue
             for i, ch in enumerate(chains):  # every channel on its own stream
                 with torch.cuda.stream(streams[i]):
                     if record and i == 0:
@@ -247,7 +272,7 @@ def main():
                     fan_done[c & 1].record()
         if world > 1:
             main_stream.wait_stream(fan_stream)
-        if len(mine) > 1:
+        if len(mine) > 1 and not multi:
             for s in streams:
                 main_stream.wait_stream(s)
 
@@ -279,11 +304,11 @@ def main():
         lastf = n // NFFT - 1
         cand = sorted({0, 1, 255, 256, frames_per_chunk - 1, frames_per_chunk, min(lastf, 3 * frames_per_chunk + 4097), lastf} & set(range(lastf + 1)))
         if not combine or world == 1:  # per-channel spectra of this rank (and, for the one-GPU graph, their sum)
-            for i in range(len(mine)):
+            for i in range(len(outs)):
                 for f in (cand if i == 0 else cand[:2]):
                     errs.append(_rel_err(outs[i][f].cpu().numpy(), oracle_frame(O, taps, xs[i], f)))
             if combine:
-                for f in cand[:3]:
+                for f in (cand if multi else cand[:3]):
                     truth = sum(oracle_frame(O, taps, xs[i], f) for i in range(len(mine)))
                     errs.append(_rel_err(sum_out[f].cpu().numpy(), truth))
         elif rank == 0:  # the reduced shard of rank 0: regenerate every channel's stream (deterministic by seed), sum the oracle spectra
@@ -316,7 +341,7 @@ def main():
         except Exception:
             pass
         per_gpu = len(mine)
-        graph = (f"; {n_channels}-channel graph: {per_gpu} channel(s) per GPU on own streams, math::Add fold on device"
+        graph = (f"; {n_channels}-channel graph: {per_gpu} channel(s) per GPU " + ("in ONE launch, math::Add fold in its registers" if multi else "on own streams, math::Add fold on device")
                  + (f", {'RCCL reduce_scatter' if args.dist_backend == 'nccl' else args.dist_backend + ' all_reduce (functional check only)'} fan-in per launch (configs[4])" if world > 1 else " (one GPU, no collective)")) if combine else ""
         res = {
             "metric": "Msamples/s through 256-tap cplx FIR->8192-pt FFT chain; %HBM roofline @1/2/4/8 GPU",
@@ -324,7 +349,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if combine else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, 2^{args.log2_samples}-sample stream per channel "
-                                   f"(BASELINE.json configs[{4 if combine else 1}]), rectangular window, {nchunks} launches of 2^{args.log2_chunk} samples per channel" + graph,
+                                   f"(BASELINE.json configs[{4 if combine else 1}]), rectangular window, {nchunks} launch(es) of 2^{log2_chunk} samples per channel" + graph,
                        "chain_algo": KERNEL_SYMBOLS.get(algo, str(algo)), "channels": n_channels,
                        "parallelism": f"{n_channels} independent channel(s), {per_gpu} per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

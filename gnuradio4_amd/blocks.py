@@ -361,6 +361,39 @@ class Chain(_Handle):
         check(lib().gr4hip_chain_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), C.byref(nf), _stream()), "Chain.process")
         return out
 
+    def set_guard_mode(self, mode: int):
+        """capi.GUARD_STRICT (default: a span below the power-ratio threshold is redone in the time domain before the call returns; the call is
+        synchronous), GUARD_DEFERRED (asynchronous calls, the switch lags one call) or GUARD_OFF (include/gr4hip.h)"""
+        check(lib().gr4hip_chain_set_guard_mode(self._h, int(mode)), "Chain.set_guard_mode")
+
+
+def chain_process_multi(chains: Sequence[Chain], xs: Sequence[torch.Tensor], outs: Optional[Sequence[torch.Tensor]] = None,
+                        sum_out: Optional[torch.Tensor] = None, want_outs: bool = True):
+    """n chains fed the same number of samples in ONE call (gr4hip_chain_process_multi): the parallel SDR channels of a flowgraph that share
+    this device.  Returns (outs or None, sum_out or None).  want_outs=False with sum_out given: only the combiner output sum_i |FFT(fir(x_i))|^2
+    (math::Add over the channels) is produced -- one launch with the fold in registers when all chains have the same taps."""
+    n = len(chains)
+    assert n >= 1 and len(xs) == n
+    xs = [_dev(x, "chain_process_multi") for x in xs]
+    N = chains[0].fftSize
+    frames = xs[0].numel() // N
+    for x in xs:
+        if x.dtype != torch.complex64 or x.numel() != xs[0].numel():
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "chain_process_multi", "inputs must be complex64 spans of one length")
+    if want_outs and outs is None:
+        outs = [torch.empty((frames, N), dtype=torch.float32, device=xs[0].device) for _ in range(n)]
+    if not want_outs:
+        outs = None
+        if sum_out is None:
+            sum_out = torch.empty((frames, N), dtype=torch.float32, device=xs[0].device)
+    hs = (C.c_void_p * n)(*[c._h for c in chains])
+    ins = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    os_ = (C.c_void_p * n)(*[o.data_ptr() for o in outs]) if outs is not None else None
+    nf = C.c_size_t(0)
+    check(lib().gr4hip_chain_process_multi(hs, n, ins, xs[0].numel(), os_, sum_out.data_ptr() if sum_out is not None else None, C.byref(nf), _stream()),
+          "chain_process_multi")
+    return outs, sum_out
+
 
 class FirBatched(_Handle):
     """nchannels independent fir_filter<float> instances with per-channel taps b[c][k] on channel-major samples x[c][n]

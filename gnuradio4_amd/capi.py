@@ -17,6 +17,7 @@ WINDOWS = ["None", "Rectangular", "Hamming", "Hann", "HannExp", "Blackman", "Nut
            "BlackmanNuttall", "FlatTop", "Exponential", "Kaiser"]
 FFT_OUTPUT_IN_DB, FFT_OUTPUT_IN_DEG, FFT_UNWRAP_PHASE = 1, 2, 4
 CHAIN_AUTO, CHAIN_UNFUSED, CHAIN_FUSED_TD, CHAIN_FUSED_FD, CHAIN_TIME_DOMAIN = range(5)
+GUARD_STRICT, GUARD_DEFERRED, GUARD_OFF = range(3)
 FIR_AUTO, FIR_TIME_DOMAIN = range(2)
 ROTATOR_CLOSED_FORM, ROTATOR_RECURRENCE = range(2)
 SYNTH_MIX = 0xd1b54a32d192ed03  # group g of a synth stream: Xoshiro256pp(seed ^ SYNTH_MIX * (g + 1)) (include/gr4hip.h)
@@ -111,6 +112,8 @@ SIGNATURES = {
     "gr4hip_chain_get_algo": (_i, [_vp, _pi]),
     "gr4hip_chain_last_power_ratio": (_i, [_vp, _pf, _pi, _vp]),
     "gr4hip_chain_set_max_workgroups": (_i, [_vp, C.c_uint]),
+    "gr4hip_chain_set_guard_mode": (_i, [_vp, _i]),
+    "gr4hip_chain_process_multi": (_i, [_vp, _sz, _vp, _sz, _vp, _vp, _psz, _vp]),
     "gr4hip_chain_destroy": (_i, [_vp]),
     "gr4hip_math_const": (_i, [_i, _i, _vp, _vp, _sz, _vp, _vp]),
     "gr4hip_math_nary": (_i, [_i, _i, _vp, _sz, _vp, _sz, _vp]),

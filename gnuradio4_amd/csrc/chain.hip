@@ -12,6 +12,8 @@ struct ChainFused;
 int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
 int  chain_fused_reset(ChainFused* c);
 int  chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st);
+int  chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps, const float* const* d_in, size_t n_frames, float* const* d_out, float* d_sum, hipStream_t st);
+bool chain_fused_multi_capable(const ChainFused* c);
 void chain_fused_destroy(ChainFused* c);
 void chain_fused_set_max_workgroups(ChainFused* c, unsigned n);
 void chain_fused_set_measure(ChainFused* c, bool on);
@@ -34,6 +36,7 @@ struct gr4hip_chain {
     size_t          ntaps = 0, N = 0;
     std::vector<float> taps;
     int             window = 0, algo = GR4HIP_CHAIN_UNFUSED;
+    bool            auto_algo = false; // created with GR4HIP_CHAIN_AUTO (the guard belongs to AUTO only)
     gr4hip_fir_t*   fir = nullptr;
     gr4hip_fft_t*   fft = nullptr;
     gr4::ChainFused* fused = nullptr;
@@ -45,8 +48,10 @@ struct gr4hip_chain {
     // read the finished measurements of earlier ones without waiting.  Below the threshold the handle switches to the direct-form kernels (the
     // reference's own arithmetic) from the call that finds out onwards, until reset.
     bool            guard = false, probed = false, use_td = false;
+    int             guard_mode = GR4HIP_GUARD_STRICT;
     float           last_ratio = -1.f; // most recent measured power ratio (< 0: none yet)
     DeviceBuffer    d_hist_save;
+    DeviceBuffer    d_multi;           // gr4hip_chain_process_multi on handles[0]: per-chain spectra when only their sum was asked for and one launch cannot fold them
 };
 constexpr float  kGuardMinPowerRatio = 0.04f;
 constexpr size_t kGuardProbeFrames   = 8; // in units of 8192-sample blocks
@@ -76,6 +81,7 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
         return GR4HIP_UNSUPPORTED;
     }
     c->algo  = use;
+    c->auto_algo = algo == GR4HIP_CHAIN_AUTO;
     c->guard = algo == GR4HIP_CHAIN_AUTO && use == GR4HIP_CHAIN_FUSED_FD && ntaps > 1;
     int rc;
     if (use == GR4HIP_CHAIN_UNFUSED || use == GR4HIP_CHAIN_TIME_DOMAIN) {
@@ -149,6 +155,24 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
         const size_t per = c->N < 8192 ? 8192 / c->N : 1; // fft frames per 8192-sample block
         if (c->use_td) return chain_time_domain(c, d_in, frames, d_mag2, stream);
         float ratio;
+        if (c->guard_mode == GR4HIP_GUARD_STRICT) {
+            // nothing out of tolerance is ever published: the span runs on the fused kernel, its measurement is awaited, and a span that fell below the
+            // threshold is redone by the direct-form kernels from the history the call started with -- before the call returns.  (The call therefore
+            // returns when the launch has finished; GR4HIP_GUARD_DEFERRED keeps it asynchronous at the price of one call of latency in the switch.)
+            int rc = c->d_hist_save.ensure(256 * 2 * sizeof(float));
+            if (rc) return rc;
+            GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            rc = chain_fused_process(c->fused, x, frames, d_mag2, st);
+            if (rc) return rc;
+            if (chain_fused_power_ratio(c->fused, true, false, &ratio)) c->last_ratio = ratio;
+            c->probed = true;
+            if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) {
+                rc = chain_switch_to_time_domain(c, static_cast<const float*>(c->d_hist_save.ptr), st);
+                if (rc) return rc;
+                return chain_time_domain(c, d_in, frames, d_mag2, stream);
+            }
+            return GR4HIP_OK;
+        }
         if (chain_fused_power_ratio(c->fused, false, false, &ratio)) c->last_ratio = ratio; // an earlier launch has finished: no waiting
         size_t done = 0;
         if (!c->probed) { // first call after create / reset: the first blocks synchronously, before the rest of the span is committed to an algorithm
@@ -175,6 +199,121 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
         return chain_fused_process(c->fused, x + done * c->N * 2, frames - done, d_mag2 + done * c->N, st);
     }
     return chain_time_domain(c, d_in, frames, d_mag2, stream);
+}
+
+int gr4hip_chain_set_guard_mode(gr4hip_chain_t* c, int mode) {
+    GR4_REQUIRE(c, "chain_set_guard_mode: null handle");
+    GR4_REQUIRE(mode >= GR4HIP_GUARD_STRICT && mode <= GR4HIP_GUARD_OFF, "chain_set_guard_mode: unknown mode %d", mode);
+    c->guard_mode = mode;
+    if (c->fused) {
+        const bool was = c->guard;
+        c->guard = mode != GR4HIP_GUARD_OFF && c->algo == GR4HIP_CHAIN_FUSED_FD && c->auto_algo && c->ntaps > 1;
+        if (was != c->guard) chain_fused_set_measure(c->fused, c->guard);
+    }
+    return GR4HIP_OK;
+}
+
+// Several chains, one launch (include/gr4hip.h).  The single launch applies when every chain runs the fused frequency-domain kernel at 8192 points with the
+// rectangular window and none has been moved to the time domain by its guard; anything else is served chain by chain (+ math::Add) with the same results.
+int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, const void* const* d_in, size_t n_samples, float* const* d_mag2, float* d_sum,
+                               size_t* n_frames_p, gr4hip_stream_t stream) {
+    GR4_REQUIRE(chains && n_chains >= 1 && n_chains <= 16, "chain_process_multi: 1 .. 16 chains");
+    GR4_REQUIRE(d_in && (d_mag2 || d_sum), "chain_process_multi: null argument");
+    for (size_t i = 0; i < n_chains; ++i) GR4_REQUIRE(chains[i] && chains[i]->N == chains[0]->N, "chain_process_multi: null handle or differing fft sizes");
+    gr4hip_chain* c0     = chains[0];
+    const size_t  frames = n_samples / c0->N;
+    if (n_frames_p) *n_frames_p = frames;
+    if (frames == 0) return n_samples ? GR4HIP_INSUFFICIENT_INPUT : GR4HIP_OK;
+    for (size_t i = 0; i < n_chains; ++i) GR4_REQUIRE(d_in[i] && (!d_mag2 || d_mag2[i]), "chain_process_multi: null device pointer");
+    hipStream_t st = as_stream(stream);
+    bool one_launch = c0->N == 8192, shared = true, any_guard = false;
+    for (size_t i = 0; i < n_chains; ++i) {
+        gr4hip_chain* c = chains[i];
+        one_launch = one_launch && c->fused && !c->use_td && chain_fused_multi_capable(c->fused);
+        shared     = shared && c->taps == c0->taps;
+        any_guard  = any_guard || c->guard;
+    }
+    const bool fold = d_sum && !d_mag2 && shared && n_chains > 1; // the combiner in registers; otherwise per-chain spectra (+ the n-ary Add below)
+    // per-chain spectra nobody asked for but the fold needs: scratch on handles[0]
+    std::vector<float*> outs(n_chains, nullptr);
+    if (!fold) {
+        if (d_mag2) for (size_t i = 0; i < n_chains; ++i) outs[i] = d_mag2[i];
+        else {
+            int rc = c0->d_multi.ensure(n_chains * frames * c0->N * sizeof(float));
+            if (rc) return rc;
+            for (size_t i = 0; i < n_chains; ++i) outs[i] = static_cast<float*>(c0->d_multi.ptr) + i * frames * c0->N;
+        }
+    }
+    auto chain_by_chain = [&]() -> int {
+        std::vector<float*> o = outs;
+        if (fold) { // the fold needs the spectra after all
+            int rc = c0->d_multi.ensure(n_chains * frames * c0->N * sizeof(float));
+            if (rc) return rc;
+            for (size_t i = 0; i < n_chains; ++i) o[i] = static_cast<float*>(c0->d_multi.ptr) + i * frames * c0->N;
+        }
+        for (size_t i = 0; i < n_chains; ++i) {
+            int rc = gr4hip_chain_process(chains[i], d_in[i], n_samples, o[i], nullptr, stream);
+            if (rc) return rc;
+        }
+        if (!d_sum) return GR4HIP_OK;
+        std::vector<const void*> ins(o.begin(), o.end());
+        return gr4hip_math_nary(GR4HIP_ADD, GR4HIP_F32, ins.data(), n_chains, d_sum, frames * c0->N, stream);
+    };
+    if (!one_launch) return chain_by_chain();
+
+    std::vector<gr4::ChainFused*> fs(n_chains);
+    std::vector<const float*>     xs(n_chains);
+    for (size_t i = 0; i < n_chains; ++i) { fs[i] = chains[i]->fused; xs[i] = static_cast<const float*>(d_in[i]); }
+    const bool strict = any_guard && c0->guard_mode == GR4HIP_GUARD_STRICT;
+    if (any_guard) { // the histories the call starts with (a span the guard rejects is redone from them)
+        for (size_t i = 0; i < n_chains; ++i) {
+            gr4hip_chain* c = chains[i];
+            int rc = c->d_hist_save.ensure(256 * 2 * sizeof(float));
+            if (rc) return rc;
+            GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        if (!strict) { // deferred: a finished earlier launch decides for this one
+            bool bad = false;
+            for (size_t i = 0; i < n_chains; ++i) {
+                float r;
+                gr4hip_chain* c = chains[fold ? 0 : i];
+                if (chain_fused_power_ratio(c->fused, false, false, &r)) c->last_ratio = r;
+                bad = bad || (chains[i]->guard && c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio);
+            }
+            if (bad) {
+                for (size_t i = 0; i < n_chains; ++i) {
+                    int rc = chain_switch_to_time_domain(chains[i], static_cast<const float*>(chains[i]->d_hist_save.ptr), st);
+                    if (rc) return rc;
+                }
+                return chain_by_chain();
+            }
+        }
+    }
+    int rc = chain_fused_process_multi(fs.data(), n_chains, shared, xs.data(), frames, fold ? nullptr : outs.data(), fold ? d_sum : nullptr, st);
+    if (rc) return rc;
+    if (strict) { // await the measurement(s) of this launch; redo the span in the time domain if it fell below the threshold
+        bool bad = false;
+        for (size_t i = 0; i < n_chains; ++i) {
+            gr4hip_chain* c = chains[fold ? 0 : i]; // (the fold measures all channels together, into chain 0's slots: the ratio that matters for the delivered sum)
+            float r;
+            if (chain_fused_power_ratio(c->fused, true, false, &r)) c->last_ratio = r;
+            chains[i]->probed = true;
+            chains[i]->last_ratio = c->last_ratio;
+            bad = bad || (chains[i]->guard && c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio);
+        }
+        if (bad) {
+            for (size_t i = 0; i < n_chains; ++i) {
+                rc = chain_switch_to_time_domain(chains[i], static_cast<const float*>(chains[i]->d_hist_save.ptr), st);
+                if (rc) return rc;
+            }
+            return chain_by_chain();
+        }
+    }
+    if (!fold && d_sum) {
+        std::vector<const void*> ins(outs.begin(), outs.end());
+        return gr4hip_math_nary(GR4HIP_ADD, GR4HIP_F32, ins.data(), n_chains, d_sum, frames * c0->N, stream);
+    }
+    return GR4HIP_OK;
 }
 
 int gr4hip_chain_last_power_ratio(gr4hip_chain_t* c, float* ratio, int* time_domain, gr4hip_stream_t stream) {

@@ -68,6 +68,21 @@ struct ChainFdArgs {
     unsigned      pw_seq;
     unsigned long long* dbg; // GR4_FD_TIMING only
 };
+// several channels in ONE launch (gr4hip_chain_process_multi, kModeMag2 only).  fold_ch > 1: every workgroup takes frame f of ALL channels in turn (same taps:
+// H and the tap fragments are shared) and keeps sum_c |FFT(fir(x_c))|^2 in registers -- the combiner math::Add<float> (blocks/math/.../Math.hpp:73-108, left fold over
+// the inputs) as the store epilogue: 8 + 4 / n B per sample instead of 12 + the fold's traffic.  fold_ch == 1: workgroup b belongs to channel b mod n_ch
+// (its own taps, history, output and power slots), frames b / n_ch + i gridDim / n_ch: one resident workgroup per CU instead of n persistent kernels that contend for them.
+constexpr int kMaxMulti = 16;
+struct ChainFdMulti {
+    int           n_ch, fold_ch;
+    const float2* xs[kMaxMulti];
+    const float2* hists[kMaxMulti];
+    const float2* Hs[kMaxMulti];    // fold_ch == 1 only (else ChainFdArgs::H of the shared taps)
+    const void*   efrags[kMaxMulti];
+    float*        outs[kMaxMulti];
+    float*        pws[kMaxMulti];
+    float*        pw_hosts[kMaxMulti];
+};
 
 // pass-A layout: rows 0..15 at r * kRowA, rows 16..31 shifted by 16 float2 (32 banks).  A ds_read/write_b64 is served in two groups of 32
 // lanes over 64 four-byte banks; every access pattern of the kernel puts the two 16-lane halves of a group 32 banks apart:
@@ -226,8 +241,8 @@ __device__ __forceinline__ void passA_inplace(float2* S, const float2 (&twA)[16]
 // the next frame streams in by LDS-DMA while this one is transformed, which the load -> transform -> store body of fft_fast_kernel cannot do.
 // MODE 6 / 7 (kModeFftSpec / kModeFftWinSpec): the same plain transform, the complex spectrum itself as output (gr4hip_fft_spectrum).
 enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2, kModeWinSmall = 3, kModeFftMag2 = 4, kModeFftWinMag2 = 5, kModeFftSpec = 6, kModeFftWinSpec = 7 };
-template <int MODE, int LOG2NF = 13>
-__global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
+template <int MODE, int LOG2NF, bool MULTI>
+__device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti* mc) {
     constexpr bool WIN   = MODE == kModeWinMag2 || MODE == kModeWinSmall; // y_f is needed in the time domain and multiplied by a.win
     constexpr bool SMALL = MODE == kModeWinSmall;
     constexpr bool FFTONLY = MODE == kModeFftMag2 || MODE == kModeFftWinMag2 || MODE == kModeFftSpec || MODE == kModeFftWinSpec; // plain (windowed) transform: no taps, no history, no correction
@@ -235,6 +250,24 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     constexpr bool SPEC    = MODE == kModeFftSpec || MODE == kModeFftWinSpec;
     constexpr bool FIR   = MODE == kModeFir || SPEC;                           // complex output (y_f, or the spectrum): 8 bytes per sample
     constexpr bool DEFER = true;                                             // the previous frame's results leave during this frame's phases
+    static_assert(!MULTI || MODE == kModeMag2, "several channels per launch: headline mode only");
+    // frames of this workgroup: fstart, fstart + fstride, ...; gslot / gcount: its place among the workgroups that report to a.pw
+    long     fstart = blockIdx.x, fstride = gridDim.x;
+    unsigned gslot = blockIdx.x, gcount = gridDim.x;
+    int      C = 1; // channels folded by this workgroup (MULTI with shared taps), else 1
+    if constexpr (MULTI) {
+        if (mc->fold_ch > 1) {
+            C = mc->fold_ch;
+        } else { // this workgroup belongs to ONE channel: its pointers take the place of the single-channel arguments
+            const int c = (int)(blockIdx.x % (unsigned)mc->n_ch);
+            a.x = mc->xs[c]; a.hist = mc->hists[c]; a.H = mc->Hs[c]; a.efrag = mc->efrags[c]; a.out = mc->outs[c]; a.pw = mc->pws[c]; a.pw_host = mc->pw_hosts[c];
+            fstart = blockIdx.x / (unsigned)mc->n_ch;
+            fstride = gridDim.x / (unsigned)mc->n_ch;
+            gslot = (unsigned)fstart; gcount = (unsigned)fstride;
+        }
+    }
+    auto xof    = [&](int c) -> const float2* { if constexpr (MULTI) { if (C > 1) return mc->xs[c]; } return a.x; };
+    auto histof = [&](int c) -> const float2* { if constexpr (MULTI) { if (C > 1) return mc->hists[c]; } return a.hist; };
     extern __shared__ __attribute__((aligned(16))) float2 smem[]; // the ONLY LDS object (a second one would make hipcc drain the DMA early)
     float2* B0 = smem;                               // kSLen: frame image / exchange buffer (even frames of this workgroup)
     float2* B1 = smem + kSLen;                       // kSLen: (odd frames)
@@ -321,20 +354,21 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     float pend[16], pendi[16]; // (pendi: imaginary parts, kModeFir only -- y_f is complex)
     float pw_in = 0.f, pw_out = 0.f; // dynamic-range guard: input and output power of the sampled frames
     int   iter = 0;
+    [[maybe_unused]] int fiter = 0; // frames this workgroup has finished (MULTI: an item is one channel of a frame)
 #pragma unroll
     for (int q = 0; q < 16; ++q) pend[q] = pendi[q] = 0.f;
     long fprev = -1;
-    long f   = blockIdx.x;
-    int  cur = 0;
+    long f   = fstart;
+    int  cur = 0, ch = 0; // ch: channel of the current work item (MULTI with shared taps: frame f of channels 0 .. C - 1 in turn)
 #if defined(GR4_PRIO_YOUNG)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1); // the second-dispatched half loses every age arbitration on its SIMD otherwise
 #endif
     if (f < a.n_frames) {
-        if constexpr (!FFTONLY) dma_tail(f > 0 ? a.x + f * kN - 256 : a.hist, T0, wave, lane0);
-        dma_frame(a.x + f * kN, B0, wave, lane0);
+        if constexpr (!FFTONLY) dma_tail(f > 0 ? xof(0) + f * kN - 256 : histof(0), T0, wave, lane0);
+        dma_frame(xof(0) + f * kN, B0, wave, lane0);
     }
-    for (; f < a.n_frames; f += gridDim.x, cur ^= 1, ++iter) {
-        const bool measure = !FFTONLY && a.pw != nullptr && (iter & 15) == 0; // wave-uniform: one frame in sixteen pays ~50 extra VALU instructions
+    for (; f < a.n_frames; cur ^= 1, ++iter) {
+        const bool measure = !FFTONLY && a.pw != nullptr && ((MULTI ? fiter : iter) & 15) == 0; // wave-uniform: one frame in sixteen pays ~50 extra VALU instructions (MULTI: that frame of every channel)
         // per-iteration opaque copy of the lane id: lane-dependent LDS / buffer offsets are recomputed here (a few VALU ops)
         // instead of being hoisted out of the loop as dozens of loop-invariant VGPRs
         int tl = threadIdx.x;
@@ -346,6 +380,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         const int   kb = 2 * wave + (kq >> 1) + 16 * (kq & 1);
         float2* S  = cur ? B1 : B0;
         float2* Sn = cur ? B0 : B1;
+        [[maybe_unused]] float m2sum = 0.f;
         const float2* Tc = cur ? T1 : T0;
         GR4_STAMP(0);
         GR4_FULL_BARRIER(); // T: this frame's image has landed (vmcnt(0) + barrier); everything of the previous frame is dead
@@ -356,7 +391,15 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         const long   fn = blockIdx.x;
         const rsrc_t rq = make_rsrc(a.out + (long)blockIdx.x * kN * (FIR ? 2 : 1), fprev < 0 ? 0u : (unsigned)(kN * sizeof(float) * (FIR ? 2 : 1)));
 #else
-        const long   fn = (f + gridDim.x < a.n_frames) ? f + gridDim.x : f;
+        long fn  = (f + fstride < a.n_frames) ? f + fstride : f;
+        int  chn = 0;
+        if constexpr (MULTI) { // next work item: the same frame of the next channel, then the workgroup's next frame of channel 0
+            chn = ch + 1;
+            fn  = f;
+            if (chn >= C) { chn = 0; fn = f + fstride; }
+            if (fn >= a.n_frames) { fn = f; chn = ch; }
+        }
+        const float2* xn = xof(chn);
         const rsrc_t rq = make_rsrc(a.out + (fprev < 0 ? 0 : fprev) * kN * (FIR ? 2 : 1), fprev < 0 ? 0u : (unsigned)(kN * sizeof(float) * (FIR ? 2 : 1))); // first iteration: nothing pending, stores fall out of range
 #endif
 #define GR4_DRAIN(g)                                                                                       \
@@ -364,9 +407,9 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         if constexpr (DEFER && FIR) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f2(rq, make_float2(pend[q], pendi[q]), t * 8, q * 4096); } \
         else if constexpr (DEFER && SMALL) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], ((t / TF) * NF + t % TF) * 4, q * TF * 4); } \
         else if constexpr (DEFER) { _Pragma("unroll") for (int q = 2 * (g); q < 2 * (g) + 2; ++q) buf_store_f(rq, pend[q], t * 4, q * 2048); } \
-        dma_frame<kDmaAt[g], kDmaAt[(g) + 1]>(a.x + fn * kN, Sn, wave, lane);                              \
+        dma_frame<kDmaAt[g], kDmaAt[(g) + 1]>(xn + fn * kN, Sn, wave, lane);                               \
     } while (0)
-        if constexpr (!FFTONLY) dma_tail(fn > 0 ? a.x + fn * kN - 256 : a.hist, cur ? T0 : T1, wave, lane);
+        if constexpr (!FFTONLY) dma_tail(fn > 0 ? xn + fn * kN - 256 : histof(chn), cur ? T0 : T1, wave, lane);
         GR4_DRAIN(0);
 
         // ------------------------------------------------------------------ pass A: 32-point DFT down the 256 columns, in place
@@ -569,7 +612,9 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
 #else
                 const float2 Y = cadd(X[perm16(q)], w[perm16(q)]);
 #endif
-                pend[q] = fmaf(Y.x, Y.x, Y.y * Y.y); // out[t + 512 q], stored during the next frame
+                const float m2 = fmaf(Y.x, Y.x, Y.y * Y.y);
+                if constexpr (MULTI) m2sum += m2; // (the guard's output power of THIS work item: pend carries the running fold)
+                pend[q] = (MULTI && ch > 0) ? pend[q] + m2 : m2; // out[t + 512 q], stored during the next frame (MULTI: math::Add's left fold over the channels)
             }
             }
         } else {
@@ -659,10 +704,17 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
         if constexpr (!FFTONLY) {
             if (measure) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) pw_out += MODE == kModeFir ? fmaf(pend[q], pend[q], pendi[q] * pendi[q]) : pend[q];
+                for (int q = 0; q < 16; ++q) pw_out += MULTI ? 0.f : (MODE == kModeFir ? fmaf(pend[q], pend[q], pendi[q] * pendi[q]) : pend[q]);
+                if constexpr (MULTI) pw_out += m2sum;
             }
         }
         fprev = f;
+        if constexpr (MULTI) { // the fold is complete after the last channel; the other work items store nothing
+            if (ch != C - 1) fprev = -1;
+            if (++ch >= C) { ch = 0; f += fstride; ++fiter; }
+        } else {
+            f += fstride;
+        }
         GR4_STAMP(13);
         GR4_STAMP(14);
     }
@@ -684,12 +736,12 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
                 float si = 0.f, so = 0.f;
 #pragma unroll
                 for (int w = 0; w < kT / 64; ++w) { si += P[2 * w]; so += P[2 * w + 1]; }
-                float* slot = a.pw + 2 * (blockIdx.x & 15);
+                float* slot = a.pw + 2 * (gslot & 15);
                 atomicAdd(slot, si);
                 atomicAdd(slot + 1, so);
                 __threadfence();
                 unsigned* done = reinterpret_cast<unsigned*>(a.pw + 32);
-                if (atomicAdd(done, 1u) == gridDim.x - 1) {
+                if (atomicAdd(done, 1u) == gcount - 1) {
                     __threadfence();
                     float tin = 0.f, tout = 0.f;
                     for (int k = 0; k < 16; ++k) { tin += atomicExch(a.pw + 2 * k, 0.f); tout += atomicExch(a.pw + 2 * k + 1, 0.f); }
@@ -712,6 +764,9 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) {
     }
 #undef GR4_DRAIN
 }
+template <int MODE, int LOG2NF = 13>
+__global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) { chain_fd_body<MODE, LOG2NF, false>(a, nullptr); }
+__global__ __launch_bounds__(kT, 2) void chain_fd_multi_kernel(ChainFdArgs a, ChainFdMulti m) { chain_fd_body<kModeMag2, 13, true>(a, &m); }
 
 
 int chain_fused_reset(struct ChainFused* c);
@@ -852,6 +907,21 @@ int chain_fused_reset(ChainFused* c) {
     return GR4HIP_OK;
 }
 
+// dynamic-range guard: this launch of `c` is a measured one (accumulators and the mapped result word exist from the first time on)
+static int arm_measure(ChainFused* c, hipStream_t st) {
+    if (!c->h_pw) {
+        int rc = c->d_pw.ensure(36 * sizeof(float)); // 16 {in, out} slots, the done counter
+        if (rc) return rc;
+        GR4_HIP_TRY(hipMemset(c->d_pw.ptr, 0, 36 * sizeof(float)));
+        GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 4 * sizeof(float), hipHostMallocMapped));
+        std::memset(c->h_pw, 0, 4 * sizeof(float));
+        GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_hpw), c->h_pw, 0));
+    }
+    ++c->pw_seq;
+    c->pw_stream = st;
+    return GR4HIP_OK;
+}
+
 // hist256 == nullptr: the chain's own carried history (updated after the launch); otherwise 256 complex samples preceding d_in, and
 // the output is the filtered stream itself (complex) instead of |FFT|^2
 static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st, bool fir_mode, bool carry_hist,
@@ -884,18 +954,11 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     a.pw       = nullptr;
     const bool measure = c->measure && !fft_only;
     if (measure) {
-        if (!c->h_pw) {
-            int rc = c->d_pw.ensure(36 * sizeof(float)); // 16 {in, out} slots, the done counter
-            if (rc) return rc;
-            GR4_HIP_TRY(hipMemset(c->d_pw.ptr, 0, 36 * sizeof(float)));
-            GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 4 * sizeof(float), hipHostMallocMapped));
-            std::memset(c->h_pw, 0, 4 * sizeof(float));
-            GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_hpw), c->h_pw, 0));
-        }
-        a.pw        = static_cast<float*>(c->d_pw.ptr);
-        a.pw_host   = c->d_hpw;
-        a.pw_seq    = ++c->pw_seq;
-        c->pw_stream = st;
+        int rc = arm_measure(c, st);
+        if (rc) return rc;
+        a.pw      = static_cast<float*>(c->d_pw.ptr);
+        a.pw_host = c->d_hpw;
+        a.pw_seq  = c->pw_seq;
     }
 #ifdef GR4_FD_TIMING
     if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
@@ -985,6 +1048,72 @@ int chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, si
     return chain_fused_run(c, d_in, d_hist256, n_frames, d_y, st, true, false);
 }
 
+// n fused chains (8192-point plans, rectangular window) in ONE launch: n_frames frames of every d_in[i].
+//   d_sum != nullptr (needs shared_taps): only the combiner output sum_i |FFT(fir(x_i))|^2 is written (math::Add's left fold, kept in registers);
+//   otherwise d_out[i] receives chain i's spectra and workgroup b works for chain b mod n.
+// The guard's powers: with the fold, of all channels together into chain 0's slots (the ratio that matters for the delivered sum); otherwise per chain.
+int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps, const float* const* d_in, size_t n_frames, float* const* d_out, float* d_sum, hipStream_t st) {
+    GR4_REQUIRE(n >= 1 && n <= (size_t)kMaxMulti, "chain multi: 1 .. %d chains per launch", kMaxMulti);
+    const bool fold = d_sum != nullptr;
+    GR4_REQUIRE(!fold || shared_taps, "chain multi: the in-register fold needs identical taps on every chain");
+    GR4_REQUIRE(fold || d_out, "chain multi: no output");
+    for (size_t i = 0; i < n; ++i) GR4_REQUIRE(cs[i] && cs[i]->small_log2n == 0 && !cs[i]->windowed, "chain multi: 8192-point rectangular-window fused chains only");
+    ChainFdArgs  a{};
+    ChainFdMulti m{};
+    ChainFused*  c0 = cs[0];
+    a.x = reinterpret_cast<const float2*>(d_in[0]);
+    a.hist = static_cast<const float2*>(c0->d_hist.ptr);
+    a.H = static_cast<const float2*>(c0->d_H.ptr);
+    a.twB = static_cast<const float2*>(c0->d_twB.ptr);
+    a.twC = static_cast<const float2*>(c0->d_twC.ptr);
+    a.taps = static_cast<const float*>(c0->d_taps.ptr);
+    a.efrag = c0->d_efrag.ptr;
+    a.out = fold ? d_sum : d_out[0];
+    a.n_frames = (long)n_frames;
+    m.n_ch = (int)n;
+    m.fold_ch = fold ? (int)n : 1;
+    for (size_t i = 0; i < n; ++i) {
+        ChainFused* c = cs[i];
+        m.xs[i] = reinterpret_cast<const float2*>(d_in[i]);
+        m.hists[i] = static_cast<const float2*>(c->d_hist.ptr);
+        m.Hs[i] = static_cast<const float2*>(c->d_H.ptr);
+        m.efrags[i] = c->d_efrag.ptr;
+        m.outs[i] = fold ? d_sum : d_out[i];
+        const bool measure = c->measure && (!fold || i == 0);
+        if (measure) {
+            int rc = arm_measure(c, st);
+            if (rc) return rc;
+            m.pws[i] = static_cast<float*>(c->d_pw.ptr);
+            m.pw_hosts[i] = c->d_hpw;
+        }
+    }
+    if (fold) { a.pw = m.pws[0]; a.pw_host = m.pw_hosts[0]; }
+    constexpr size_t lds = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256) * sizeof(float) + 6 * 512 * sizeof(unsigned short); // = lds_ebf of chain_fused_run
+    static PerDevice per_device;
+    bool             first = false;
+    int              dev = -1, n_cu = per_device.current(&first, &dev);
+    GR4_REQUIRE(n_cu != 0, "chain multi: cannot query the current device");
+    if (first) {
+        n_cu = -n_cu;
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        per_device.done(dev, n_cu);
+    }
+    size_t wgs = c0->max_wg ? std::min<size_t>(c0->max_wg, (size_t)n_cu) : (size_t)n_cu;
+    unsigned grid;
+    if (fold) {
+        grid = (unsigned)std::min<size_t>(n_frames, wgs);
+    } else { // the same number of workgroups for every chain
+        const size_t per = std::min<size_t>(std::max<size_t>(wgs / n, 1), n_frames);
+        grid = (unsigned)(per * n);
+    }
+    hipLaunchKernelGGL(chain_fd_multi_kernel, dim3(grid), dim3(kT), lds, st, a, m);
+    GR4_LAUNCH_CHECK();
+    for (size_t i = 0; i < n; ++i) // carry every chain's last 256 input samples (stream-ordered after the kernel's reads)
+        GR4_HIP_TRY(hipMemcpyAsync(cs[i]->d_hist.ptr, m.xs[i] + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    return GR4HIP_OK;
+}
+
+bool chain_fused_multi_capable(const ChainFused* c) { return c->small_log2n == 0 && !c->windowed; }
 void chain_fused_destroy(ChainFused* c) { delete c; }
 // dynamic-range guard: sampled power ratio (output / input, window gain taken out) of the most recent measured launch.
 // wait: synchronise on that launch; otherwise only report it when it has already finished.  Returns 1 with *ratio set, 0 if nothing (new) is available.

@@ -235,6 +235,27 @@ int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
  * until gr4hip_chain_reset.  Explicit GR4HIP_CHAIN_FUSED_FD never switches.  This call waits for the last measured launch and returns its ratio
  * (< 0: nothing measured yet) and whether the chain now runs in the time domain. */
 int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time_domain, gr4hip_stream_t stream);
+/* What the guard does with its measurement (per handle; GR4HIP_CHAIN_AUTO chains on the fused frequency-domain kernel only, a no-op elsewhere):
+ *   GR4HIP_GUARD_STRICT (default): every call awaits the measurement of its OWN launch and redoes a span that fell below the threshold with the direct-form
+ *     kernels, from the history the call started with, before it returns: nothing out of tolerance is ever handed out.  The price: gr4hip_chain_process
+ *     returns when its launch has finished (one host synchronisation per call) instead of when it is queued.
+ *   GR4HIP_GUARD_DEFERRED: calls stay asynchronous.  The first call after create / reset probes its first 8 blocks synchronously; later calls read the finished
+ *     measurements of EARLIER launches, so the call in which a strong out-of-band signal first appears is published from the fused kernel (error floor
+ *     ~2e-6 of the input rms) and the switch happens from the next call on.
+ *   GR4HIP_GUARD_OFF: no measurement, never switches (what an explicit GR4HIP_CHAIN_FUSED_FD chain does). */
+typedef enum { GR4HIP_GUARD_STRICT = 0, GR4HIP_GUARD_DEFERRED = 1, GR4HIP_GUARD_OFF = 2 } gr4hip_guard_mode;
+int gr4hip_chain_set_guard_mode(gr4hip_chain_t* chain, int mode);
+/* n_chains (<= 16) chains of the same fft size fed n_samples each in ONE call -- the branches of a flowgraph with parallel SDR channels that share a device
+ * (BASELINE.json configs[4] at fewer GPUs than channels).  d_in_c32 / d_mag2 are HOST arrays of device pointers.
+ *   d_mag2 != NULL: chain i's spectra go to d_mag2[i];  d_sum != NULL: sum_i |FFT(fir(x_i))|^2, the combiner MathOpMultiPortImpl<float, std::plus>
+ *   (blocks/math/.../Math.hpp:73-108, left fold over the inputs) -- both may be given.
+ * When every chain runs the fused frequency-domain kernel at 8192 points with the rectangular window, the call is ONE persistent launch (one workgroup per
+ * CU) instead of n kernels contending for every CU; with d_mag2 == NULL and identical taps on all chains the fold is kept in registers and only d_sum is
+ * written (8 + 4 / n bytes of HBM traffic per sample).  Any other combination is served chain by chain followed by gr4hip_math_nary, with the same results.
+ * History, guard state and measurements stay per chain (with the in-register fold the guard measures all channels together: the ratio that matters for
+ * the delivered sum).  Do not mix this call with calls on the same handles from other streams. */
+int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, const void* const* d_in_c32, size_t n_samples, float* const* d_mag2,
+                               float* d_sum, size_t* n_frames, gr4hip_stream_t stream);
 /* The fused kernels are persistent: one workgroup per CU that takes ALL of the CU's registers and LDS, so nothing else (e.g. the RCCL
  * kernels of a fan-in collective on another stream) runs beside them.  n > 0 caps the grid at n workgroups and leaves the other CUs free;
  * 0 = all CUs (default).  No effect on the unfused path. */
