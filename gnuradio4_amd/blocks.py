@@ -101,7 +101,8 @@ class fir_filter(_Handle):
         check((lib().gr4hip_fir64_reset if self._f64 else lib().gr4hip_fir_reset)(self._h), "fir_filter.reset")
 
     def set_algo(self, algo: int):
-        """capi.FIR_AUTO / capi.FIR_TIME_DOMAIN (direct form also for long complex spans: error relative to the output, include/gr4hip.h)"""
+        """capi.FIR_AUTO / capi.FIR_TIME_DOMAIN (direct form also for long complex spans: error relative to the output) / capi.FIR_EXACT_F32 (IEEE float32
+        multiply-add only: the reference's Inf / NaN behaviour) -- include/gr4hip.h"""
         check(lib().gr4hip_fir_set_algo(self._h, int(algo)), "fir_filter.set_algo")
 
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -18,7 +18,7 @@ WINDOWS = ["None", "Rectangular", "Hamming", "Hann", "HannExp", "Blackman", "Nut
 FFT_OUTPUT_IN_DB, FFT_OUTPUT_IN_DEG, FFT_UNWRAP_PHASE = 1, 2, 4
 CHAIN_AUTO, CHAIN_UNFUSED, CHAIN_FUSED_TD, CHAIN_FUSED_FD, CHAIN_TIME_DOMAIN = range(5)
 GUARD_STRICT, GUARD_DEFERRED, GUARD_OFF = range(3)
-FIR_AUTO, FIR_TIME_DOMAIN = range(2)
+FIR_AUTO, FIR_TIME_DOMAIN, FIR_EXACT_F32 = range(3)
 ROTATOR_CLOSED_FORM, ROTATOR_RECURRENCE = range(2)
 SYNTH_MIX = 0xd1b54a32d192ed03  # group g of a synth stream: Xoshiro256pp(seed ^ SYNTH_MIX * (g + 1)) (include/gr4hip.h)
 
@@ -113,6 +113,8 @@ SIGNATURES = {
     "gr4hip_chain_last_power_ratio": (_i, [_vp, _pf, _pi, _vp]),
     "gr4hip_chain_set_max_workgroups": (_i, [_vp, C.c_uint]),
     "gr4hip_chain_set_guard_mode": (_i, [_vp, _i]),
+    "gr4hip_fir_set_guard_mode": (_i, [_vp, _i]),
+    "gr4hip_developer_switch": (_i, [C.c_char_p, _i]),
     "gr4hip_chain_process_multi": (_i, [_vp, _sz, _vp, _sz, _vp, _vp, _psz, _vp]),
     "gr4hip_chain_destroy": (_i, [_vp]),
     "gr4hip_math_const": (_i, [_i, _i, _vp, _vp, _sz, _vp, _vp]),
@@ -173,3 +175,8 @@ def device_count() -> int:
     n = C.c_int(0)
     check(lib().gr4hip_device_count(C.byref(n)), "device_count")
     return n.value
+
+
+def developer_switch(name: str, value: int = 1) -> None:
+    """kernel A/B switches of the library (include/gr4hip.h: gr4hip_developer_switch); the tests use it where they compare two kernels"""
+    check(lib().gr4hip_developer_switch(name.encode(), int(value)), "developer_switch")

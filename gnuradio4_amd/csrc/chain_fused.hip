@@ -927,7 +927,7 @@ static int arm_measure(ChainFused* c, hipStream_t st) {
 static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st, bool fir_mode, bool carry_hist,
                            bool fft_only = false, const float* fft_window = nullptr, bool fft_spectrum = false) {
     {
-        static const int use16 = [] { const char* e = std::getenv("GR4HIP_CHAIN16"); return e ? std::atoi(e) : 0; }();
+        const int use16 = dev_switch(kDevChain16);
         const bool plain_chain = !fir_mode && !fft_only && !c->windowed && c->small_log2n == 0;
         const bool plain_fft   = fft_only && !fft_window && !fft_spectrum;
         if (use16 && c->c16 && (plain_chain || plain_fft) && !(c->measure && !fft_only)) { // (the dynamic-range guard samples its powers in the 8-wave kernel)

@@ -14,6 +14,23 @@ namespace gr4 {
 
 void set_error(const char* fmt, ...);
 
+// Developer switches (kernel A/B comparisons in the tests and tools; none of them changes what a call computes beyond rounding): read from the environment
+// ONCE, when the library is loaded, and settable afterwards through gr4hip_developer_switch (atomic: no getenv on the call path, no race against setenv).
+enum DevSwitch {
+    kDevFirNoBf16x3 = 0,      // GR4HIP_FIR_NO_BF16X3: float32 multiply-add FIR kernels instead of the three-term bf16 ones (per handle: GR4HIP_FIR_EXACT_F32)
+    kDevFirNoDecimFd,         // GR4HIP_FIR_NO_DECIM_FD: polyphase decimators instead of the frequency-domain decimate-by-8 kernel
+    kDevIirThreePass,         // GR4HIP_IIR_THREE_PASS
+    kDevIirLookback,          // GR4HIP_IIR_LOOKBACK
+    kDevIirNoSplit,           // GR4HIP_IIR_NO_SPLIT
+    kDevFftBluesteinPipeline, // GR4HIP_FFT_BLUESTEIN_PIPELINE
+    kDevFftNoPipeline,        // GR4HIP_FFT_NO_PIPELINE
+    kDevRotatorLeap,          // GR4HIP_ROTATOR_LEAP
+    kDevRotatorWalk,          // GR4HIP_ROTATOR_WALK
+    kDevChain16,              // GR4HIP_CHAIN16
+    kDevSwitchCount
+};
+int dev_switch(DevSwitch s);
+
 #define GR4_HIP_TRY(expr)                                                                              \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \

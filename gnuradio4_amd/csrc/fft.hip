@@ -604,7 +604,7 @@ static int fft_run_multi(gr4hip_fft_t* f, const float* d_in, long n_frames, cons
     const float* win    = static_cast<const float*>(f->d_window.ptr);
     const long   batch  = std::max(1L, kFftBatchElems / M);
     const long   in_per = o.real_input ? N : 2 * N; // floats per input frame
-    if (f->kind == 2 && M <= 8192 && !std::getenv("GR4HIP_FFT_BLUESTEIN_PIPELINE")) { // (developer switch: the five-kernel pipeline, which the tests compare)
+    if (f->kind == 2 && M <= 8192 && !dev_switch(kDevFftBluesteinPipeline)) { // (developer switch: the five-kernel pipeline, which the tests compare)
         const size_t lds = (size_t)f->plan.fpb * M * sizeof(float2);
         if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bluestein_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bluestein_fused_kernel, dim3((unsigned)ceil_div(n_frames, (long)f->plan.fpb)), dim3(f->plan.tf * f->plan.fpb), lds, st, d_in, win,
@@ -689,7 +689,7 @@ int gr4hip_fft_process(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float
 // 8192-point complex frames, >= one frame per CU: |X|^2 and the raw spectrum run on the frame pipeline of the fused chain kernel without its filter
 // (LDS-DMA prefetch of the next frame during the transform of this one); everything else goes to the FFT block kernels
 static bool fft_on_frame_pipeline(const gr4hip_fft_t* f, size_t n_frames) {
-    return f->N == 8192 && f->in_dtype == GR4HIP_C32 && f->kind == 0 && n_frames >= 256 && !std::getenv("GR4HIP_FFT_NO_PIPELINE");
+    return f->N == 8192 && f->in_dtype == GR4HIP_C32 && f->kind == 0 && n_frames >= 256 && !dev_switch(kDevFftNoPipeline);
 }
 static int fft_pipe(gr4hip_fft_t* f) {
     if (f->pipe) return GR4HIP_OK;

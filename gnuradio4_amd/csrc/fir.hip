@@ -163,7 +163,8 @@ struct FirDecimFd;
 int  fir_decim_fd_supported(size_t ntaps, size_t decim);
 int  fir_decim_fd_create(FirDecimFd** out, const float* taps, size_t ntaps);
 void fir_decim_fd_destroy(FirDecimFd* c);
-int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st);
+int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st, bool measure);
+int  fir_decim_fd_power_ratio(FirDecimFd* c, bool wait, float* ratio);
 
 // fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
 void fir_mfma_make_afrag(const float* taps, size_t ntaps, size_t nch, int* Kp_out, int* KS_out, std::vector<float>* af_out);
@@ -204,6 +205,7 @@ struct gr4hip_fir {
     DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
     int                cur = 0;
     int                algo = GR4HIP_FIR_AUTO; // gr4hip_fir_set_algo
+    int                guard_mode = GR4HIP_GUARD_STRICT; // gr4hip_fir_set_guard_mode
     gr4::ChainFused*   fd  = nullptr; // complex, decim 1, ntaps <= 256: frequency-domain plan (created on first use)
     // dynamic-range guard of GR4HIP_FIR_AUTO (same policy as the chain's, include/gr4hip.h): the fast convolution's error floor is ~2e-6 of the INPUT rms;
     // below an output / input power ratio of 0.04 the direct form takes over (first use: probed synchronously; later: from finished measurements)
@@ -314,10 +316,19 @@ int gr4hip_fir_reset(gr4hip_fir_t* f) {
 
 int gr4hip_fir_set_algo(gr4hip_fir_t* f, int algo) {
     GR4_REQUIRE(f, "fir_set_algo: null handle");
-    GR4_REQUIRE(algo == GR4HIP_FIR_AUTO || algo == GR4HIP_FIR_TIME_DOMAIN, "fir_set_algo: unknown algo %d", algo);
+    GR4_REQUIRE(algo == GR4HIP_FIR_AUTO || algo == GR4HIP_FIR_TIME_DOMAIN || algo == GR4HIP_FIR_EXACT_F32, "fir_set_algo: unknown algo %d", algo);
     f->algo = algo;
     return GR4HIP_OK;
 }
+int gr4hip_fir_set_guard_mode(gr4hip_fir_t* f, int mode) {
+    GR4_REQUIRE(f, "fir_set_guard_mode: null handle");
+    GR4_REQUIRE(mode >= GR4HIP_GUARD_STRICT && mode <= GR4HIP_GUARD_OFF, "fir_set_guard_mode: unknown mode %d", mode);
+    f->guard_mode = mode;
+    if (f->fd) chain_fused_set_measure(f->fd, mode != GR4HIP_GUARD_OFF && f->ntaps > 1);
+    return GR4HIP_OK;
+}
+// the three-term bf16 kernels are off for this handle (GR4HIP_FIR_EXACT_F32: IEEE float32 multiply-add, the reference's Inf / NaN behaviour) or for the process (developer switch)
+static bool no_bf16x3(const gr4hip_fir_t* f) { return f->algo == GR4HIP_FIR_EXACT_F32 || dev_switch(kDevFirNoBf16x3); }
 
 int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
     GR4_REQUIRE(f, "fir_process: null handle");
@@ -340,7 +351,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         int rc = GR4HIP_OK;
         if (!f->fd) {
             rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
-            if (!rc && f->ntaps > 1) chain_fused_set_measure(f->fd, true);
+            if (!rc && f->ntaps > 1 && f->guard_mode != GR4HIP_GUARD_OFF) chain_fused_set_measure(f->fd, true);
         }
         if (!rc) rc = f->d_hist256.ensure(256 * sizeof(float2));
         if (rc) return rc;
@@ -348,16 +359,29 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         GR4_LAUNCH_CHECK();
         const size_t frames = n_in / kFdFrame;
         float        ratio;
+        const bool   guarded = f->ntaps > 1 && f->guard_mode != GR4HIP_GUARD_OFF;
+        if (guarded && f->guard_mode == GR4HIP_GUARD_STRICT) {
+            // the whole span on the fast convolution, its own measurement awaited: below the threshold the direct form redoes it before the call returns
+            rc = chain_fused_fir(f->fd, x, (const float*)f->d_hist256.ptr, frames, y, st);
+            if (rc) return rc;
+            if (chain_fused_power_ratio(f->fd, true, true, &ratio)) f->fd_ratio = ratio;
+            f->fd_probed = true;
+            if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) f->fd_blocked = true;
+            else {
+                done = frames * kFdFrame;
+                hist = x + (done - f->hcap) * 2;
+            }
+        } else {
         if (chain_fused_power_ratio(f->fd, false, true, &ratio)) f->fd_ratio = ratio; // a finished earlier launch: no waiting
         size_t probe = 0;
-        if (!f->fd_probed && f->ntaps > 1) { // first fast convolution of this stream: eight frames, synchronously, before the span is committed to it
+        if (!f->fd_probed && guarded) { // first fast convolution of this stream: eight frames, synchronously, before the span is committed to it
             probe = std::min<size_t>(frames, 8);
             rc    = chain_fused_fir(f->fd, x, (const float*)f->d_hist256.ptr, probe, y, st);
             if (rc) return rc;
             if (chain_fused_power_ratio(f->fd, true, true, &ratio)) f->fd_ratio = ratio;
             f->fd_probed = true;
         }
-        if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) {
+        if (guarded && f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) {
             f->fd_blocked = true; // the direct form below redoes the probed frames too
         } else {
             if (probe < frames) {
@@ -367,13 +391,14 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
             done = frames * kFdFrame;
             hist = x + (done - f->hcap) * 2; // the hcap samples in front of the remainder are part of the input itself
         }
+        }
     }
     // complex<float>, no decimation, 33..256 taps, whatever the fast convolution did not take (GR4HIP_FIR_TIME_DOMAIN, a stream the dynamic-range guard has
     // moved to the direct form, or both): the same block-Toeplitz product on the re and im planes of the interleaved samples (fir_mfma_c32_kernel)
     // (16-byte-aligned input too: the three-term bf16 form of the same product, fir_bf16.hip)
     static const size_t kCBfMinTaps = [] { const char* e = std::getenv("GR4HIP_CFIR_BF16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // developer knob: 65 puts 33..64 taps back on the f32 MFMA (measured 5-8 % slower: 299-316 against 322-333 Gsamples/s); below 33 taps the register-window kernel is ahead up to 27 taps and within 3 % from there (tools/cfir_bf16_threshold.py)
     if (f->S == 2 && f->decim == 1 && f->ntaps >= kCBfMinTaps && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y + done * 2) | reinterpret_cast<uintptr_t>(x + done * 2)) & 15) == 0 &&
-        !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
+        !no_bf16x3(f)) {
         int rc = GR4HIP_OK;
         if (f->bfKS == 0) {
             std::vector<unsigned short> af;
@@ -388,7 +413,8 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
-    if (done < n_in && f->S == 2 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && (reinterpret_cast<uintptr_t>(y + done * 2) & 15) == 0) {
+    const bool exact = f->algo == GR4HIP_FIR_EXACT_F32; // only the register-window kernel: its products are the taps' (padded to a multiple of 4 per phase), nothing wider
+    if (!exact && done < n_in && f->S == 2 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && (reinterpret_cast<uintptr_t>(y + done * 2) & 15) == 0) {
         int rc = GR4HIP_OK;
         if (f->mKS == 0) {
             std::vector<float> af;
@@ -416,7 +442,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     // (384 .. 1024 taps: slices of 256 taps, each a pass over the input delayed by 256 p samples that adds to y: 512 taps 115 instead of 90 Gsamples/s on the
     // register-window kernel, 1024 taps 50.5 instead of 47; below 384 and above 1024 taps the extra passes cost more than they save -- measured)
     if (f->S == 1 && f->decim == 1 && f->ntaps > 32 && (f->ntaps <= 256 || (f->ntaps >= 384 && f->ntaps <= 1024)) && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
-        f->algo == GR4HIP_FIR_AUTO && !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
+        f->algo == GR4HIP_FIR_AUTO && !no_bf16x3(f)) {
         int          rc = GR4HIP_OK;
         const size_t nslice = ceil_div(f->ntaps, (size_t)256);
         if (f->bfKS == 0) {
@@ -444,7 +470,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     }
     // float, no decimation, 33..256 taps, long 16-byte-aligned output: block-Toeplitz product on the f32 MFMA units (about twice the
     // rate of the register-window VALU kernel, which is FP32-issue bound from ~48 taps on)
-    if (done == 0 && f->S == 1 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in >= kMfmaMinSamples && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
+    if (!exact && done == 0 && f->S == 1 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in >= kMfmaMinSamples && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
         int rc = GR4HIP_OK;
         if (f->mKS == 0) {
             std::vector<float> af;
@@ -472,7 +498,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     // float, decimate by 2 .. 12 with a window of <= 1152 samples (taps - 1 + 15 D), long 16-byte-aligned span: the band form with three-term bf16 products
     // (fir_bf16.hip; windows beyond 288 samples with the K-steps split over the four waves)
     if (done == 0 && f->S == 1 && f->decim >= 2 && f->decim <= 12 && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
-        ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !std::getenv("GR4HIP_FIR_NO_BF16X3")) {
+        ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !no_bf16x3(f)) {
         int rc = GR4HIP_OK;
         if (f->bdKS == 0) {
             std::vector<unsigned short> af;
@@ -497,16 +523,29 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     // float, decimate by 8, <= 1024 taps, long 16-byte-aligned span: overlap-save blocks of 8192 samples in the frequency domain (~35 lane-operations per
     // input sample instead of 2 K / 8 flop: HBM / power-bound instead of FP32-bound); a partial last block rides in the same launch
     constexpr size_t kDfHopS = 7168, kDfMinBlocks = 64;
-    if (done == 0 && f->S == 1 && f->algo == GR4HIP_FIR_AUTO && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 && n_in >= kDfMinBlocks * kDfHopS &&
-        (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && !std::getenv("GR4HIP_FIR_NO_DECIM_FD")) {
+    if (done == 0 && f->S == 1 && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 && n_in >= kDfMinBlocks * kDfHopS &&
+        (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && !dev_switch(kDevFirNoDecimFd)) {
         int rc = GR4HIP_OK;
         if (!f->dfd) rc = fir_decim_fd_create(&f->dfd, f->taps.data(), f->ntaps);
         if (rc) return rc;
         // whole blocks and the span's partial last block in ONE launch (+ one small launch in front that widens the history and stages the partial block):
         // sending the < 7168 leftover samples through the polyphase kernel cost a 44 us single-workgroup launch behind a 164 us transform kernel
-        rc = fir_decim_fd_run(f->dfd, x, n_in, hist, (int)f->hcap, y, st);
-        if (rc) return rc;
-        done = n_in;
+        // the same dynamic-range guard as the complex fast convolution above: the error floor of the transforms is ~2e-6 of the INPUT rms, and an anti-alias
+        // filter is exactly where strong out-of-band power is removed.  Strict: this launch's own measurement decides before the call returns (the polyphase
+        // kernels below redo the span); deferred: a finished earlier launch decides; from the first rejection on the stream stays on the polyphase kernels
+        const bool guarded = f->guard_mode != GR4HIP_GUARD_OFF && f->ntaps > 1;
+        float      ratio;
+        if (guarded && fir_decim_fd_power_ratio(f->dfd, false, &ratio)) f->fd_ratio = ratio;
+        if (guarded && f->guard_mode == GR4HIP_GUARD_DEFERRED && f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) f->fd_blocked = true;
+        if (!f->fd_blocked) {
+            rc = fir_decim_fd_run(f->dfd, x, n_in, hist, (int)f->hcap, y, st, guarded);
+            if (rc) return rc;
+            done = n_in;
+            if (guarded && f->guard_mode == GR4HIP_GUARD_STRICT) {
+                if (fir_decim_fd_power_ratio(f->dfd, true, &ratio)) f->fd_ratio = ratio;
+                if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) { f->fd_blocked = true; done = 0; }
+            }
+        }
     }
     // float, decimate by kBandMinDecim .. 128, long span: the band form of the contraction (samples in stream order, the decimation in the A operand)
     static const size_t kBandMinDecim = [] { const char* e = std::getenv("GR4HIP_FIR_BAND_MIN_DECIM"); return e ? (size_t)std::atoi(e) : (size_t)10; }(); // (developer switch: where the band form takes over from the polyphase form)
@@ -525,7 +564,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     }
     // float polyphase decimator with >= 16 taps per phase and a long span: the same contraction with the D phase products summed in
     // one accumulator tile (BASELINE configs[2]: decim 8, 1024 taps)
-    if (done == 0 && f->S == 1 && f->decim >= 2 && ceil_div(f->ntaps, f->decim) >= 16 && ceil_div(f->ntaps, f->decim) <= 256 && n_out >= (1u << 14) &&
+    if (!exact && done == 0 && f->S == 1 && f->decim >= 2 && ceil_div(f->ntaps, f->decim) >= 16 && ceil_div(f->ntaps, f->decim) <= 256 && n_out >= (1u << 14) &&
         (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
         int rc = GR4HIP_OK;
         if (f->mKS == 0) {

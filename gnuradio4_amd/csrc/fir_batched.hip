@@ -527,7 +527,7 @@ int gr4hip_fir_batched_process(gr4hip_fir_batched_t* f, const float* d_in, size_
     hipStream_t st = as_stream(stream);
     const float *hist = (const float*)f->d_hist[f->cur].ptr, *af = (const float*)f->d_afrag.ptr;
     int rc;
-    if (f->bfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !std::getenv("GR4HIP_FIR_NO_BF16X3")) // three-term bf16 form (fir_bf16.hip): same history layout
+    if (f->bfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3)) // three-term bf16 form (fir_bf16.hip): same history layout
         rc = fir_bf16_launch(f->bfKS, d_in, (long)n, hist, f->Kp, f->d_bfrag.ptr, d_out, st, nullptr, (long)in_stride, (long)out_stride, (unsigned)f->nch, 0, 0);
     else
         rc = fir_mfma_launch(f->KS, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n, (unsigned)f->nch, st, nullptr);

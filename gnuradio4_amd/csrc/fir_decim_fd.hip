@@ -55,6 +55,7 @@ struct DecimFdArgs {
     const float*  x_tail;
     long          tail_blk;
     int           tail_out;
+    float*        pw;      // dynamic-range guard (optional): 16 slots of {sum x^2, sum y^2} over every 16th block of every workgroup (8192 inputs / <= 896 outputs each)
 };
 
 __device__ __forceinline__ void ifft8(float2 (&v)[8]) { // inverse DFT-8: the forward butterfly on (im, re)
@@ -105,8 +106,11 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
     const float2 bI1 = a.twI1[lane0 & 15], bI2 = a.twI2[t0 & 127];
     const unsigned lds_L = __builtin_amdgcn_readfirstlane(lds_off(smem_df));
     long blk = blockIdx.x;
+    float pw_in = 0.f, pw_out = 0.f;
+    int   iter  = 0;
     if (blk < a.n_blocks) decim_dma(a, blk, lds_L, wave, lane0);
-    for (; blk < a.n_blocks; blk += gridDim.x) {
+    for (; blk < a.n_blocks; blk += gridDim.x, ++iter) {
+        const bool measure = a.pw != nullptr && (iter & 15) == 0 && blk != a.tail_blk; // wave-uniform
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
         const int l = t & 63;
@@ -120,6 +124,10 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
             G16_RD8(d, la, 4096);
             lds_wait8(d);
             unpack8(u, d);
+        }
+        if (measure) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pw_in = fmaf(u[q].x, u[q].x, fmaf(u[q].y, u[q].y, pw_in));
         }
         fft8(u);
 #pragma unroll
@@ -213,13 +221,36 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
 #pragma unroll
             for (int aa = 1; aa < 8; ++aa)
                 if (t + 128 * (aa - 1) < valid) yo[128 * (aa - 1)] = v[aa].x;
+            if (measure) {
+#pragma unroll
+                for (int aa = 1; aa < 8; ++aa) pw_out = fmaf(v[aa].x, v[aa].x, pw_out);
+            }
+        }
+    }
+    if (a.pw != nullptr) { // one pair of atomics per wave, spread over 16 slots
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            pw_in += __shfl_xor(pw_in, off);
+            pw_out += __shfl_xor(pw_out, off);
+        }
+        if ((threadIdx.x & 63) == 0 && (pw_in != 0.f || pw_out != 0.f)) {
+            float* slot = a.pw + 2 * ((blockIdx.x * 8 + (threadIdx.x >> 6)) & 15);
+            atomicAdd(slot, pw_in);
+            atomicAdd(slot + 1, pw_out);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 struct FirDecimFd {
-    DeviceBuffer d_twX, d_tw1, d_tw2, d_R, d_twI1, d_twI2, d_hist1024, d_stage;
+    DeviceBuffer d_twX, d_tw1, d_tw2, d_R, d_twI1, d_twI2, d_hist1024, d_stage, d_pw;
+    float*       h_pw = nullptr;     // page-locked copy of the 16 power slots of the last measured launch
+    hipEvent_t   pw_ev = nullptr;    // fires when h_pw holds them
+    bool         pw_pending = false;
+    ~FirDecimFd() {
+        if (h_pw) (void)hipHostFree(h_pw);
+        if (pw_ev) (void)hipEventDestroy(pw_ev);
+    }
 };
 
 static void put_wd(std::vector<float>& v, size_t idx, long num, long den) { // exp(-2 pi i num / den)
@@ -299,7 +330,8 @@ __global__ __launch_bounds__(256) void decim_fd_prepare_kernel(const float* __re
 }
 
 // d_hist: the filter's history (hcap samples in front of d_in); n_in input samples (a multiple of 8): floor(n_in / 7168) whole blocks and, if anything is left, one partial block
-int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st) {
+// measure: this launch samples input and output power (dynamic-range guard, fir.hip); fir_decim_fd_power_ratio hands the result out
+int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st, bool measure) {
     const size_t full = n_in / kDfHop, rest = n_in - full * kDfHop;
     int          rc   = c->d_hist1024.ensure(kDfV * sizeof(float));
     if (!rc && rest) rc = c->d_stage.ensure(kDfN * sizeof(float));
@@ -314,6 +346,16 @@ int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float*
     a.twX = static_cast<const float2*>(c->d_twX.ptr); a.tw1 = static_cast<const float2*>(c->d_tw1.ptr); a.tw2 = static_cast<const float2*>(c->d_tw2.ptr);
     a.R = static_cast<const float2*>(c->d_R.ptr); a.twI1 = static_cast<const float2*>(c->d_twI1.ptr); a.twI2 = static_cast<const float2*>(c->d_twI2.ptr);
     a.y = d_out; a.n_blocks = (long)n_blocks;
+    if (measure) {
+        rc = c->d_pw.ensure(32 * sizeof(float));
+        if (rc) return rc;
+        if (!c->h_pw) {
+            GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 32 * sizeof(float), hipHostMallocDefault));
+            GR4_HIP_TRY(hipEventCreateWithFlags(&c->pw_ev, hipEventDisableTiming));
+        }
+        GR4_HIP_TRY(hipMemsetAsync(c->d_pw.ptr, 0, 32 * sizeof(float), st));
+        a.pw = static_cast<float*>(c->d_pw.ptr);
+    }
     static PerDevice per_device;
     bool             first = false;
     int              dev = -1, n_cu = per_device.current(&first, &dev);
@@ -326,7 +368,25 @@ int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float*
     const unsigned grid = (unsigned)std::min<size_t>(n_blocks, (size_t)2 * n_cu);
     hipLaunchKernelGGL(fir_decim_fd_kernel, dim3(grid), dim3(kDfT), kDfLds, st, a);
     GR4_LAUNCH_CHECK();
+    if (measure) {
+        GR4_HIP_TRY(hipMemcpyAsync(c->h_pw, c->d_pw.ptr, 32 * sizeof(float), hipMemcpyDeviceToHost, st));
+        GR4_HIP_TRY(hipEventRecord(c->pw_ev, st));
+        c->pw_pending = true;
+    }
     return GR4HIP_OK;
+}
+// mean output power / mean input power of the last measured launch's sampled blocks.  wait: synchronise on it; otherwise only when it has finished.
+// Returns 1 with *ratio set, 0 if nothing (new) is available.
+int fir_decim_fd_power_ratio(FirDecimFd* c, bool wait, float* ratio) {
+    if (!c->pw_pending) return 0;
+    if (wait) { if (hipEventSynchronize(c->pw_ev) != hipSuccess) return 0; }
+    else if (hipEventQuery(c->pw_ev) != hipSuccess) return 0;
+    c->pw_pending = false;
+    double in = 0, out = 0;
+    for (int k = 0; k < 16; ++k) { in += c->h_pw[2 * k]; out += c->h_pw[2 * k + 1]; }
+    // per sampled block: 8192 input samples (the overlap counted twice: statistics only), 896 outputs
+    *ratio = in > 0 ? (float)((out / (kDfHop / 8)) / (in / kDfN)) : 1.f;
+    return 1;
 }
 
 } // namespace gr4

@@ -855,7 +855,7 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
     if constexpr (MP <= 8) {
         // long span + fading memory: contiguous runs of tiles per workgroup, state carried from tile to tile, warm-up instead of look-back
         // (from 16 tiles on the sequential runs beat the look-back at every span length measured: 2^17 .. 2^27 samples, profiles/r02_iir_rates.txt)
-        if (f->warm_tiles > 0 && nblocks >= 1 && !std::getenv("GR4HIP_IIR_THREE_PASS") && !std::getenv("GR4HIP_IIR_LOOKBACK")) {
+        if (f->warm_tiles > 0 && nblocks >= 1 && !dev_switch(kDevIirThreePass) && !dev_switch(kDevIirLookback)) {
             static PerDevice per_device;
             bool             first = false;
             int              dev = -1, n_cu = per_device.current(&first, &dev);
@@ -885,7 +885,7 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
             f->cur ^= 1;
             return GR4HIP_OK;
         }
-        if (!std::getenv("GR4HIP_IIR_THREE_PASS")) { // (developer switch: the three-pass kernels below stay the path for MP = 16)
+        if (!dev_switch(kDevIirThreePass)) { // (developer switch: the three-pass kernels below stay the path for MP = 16)
             if (const int e = iir_take_error(f, "iir_process")) return e; // a previous launch of this handle gave up waiting for a predecessor block
             if (!f->h_err) {
                 GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&f->h_err), sizeof(unsigned), hipHostMallocMapped));
@@ -979,7 +979,7 @@ int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const floa
     GR4_REQUIRE(f, "out of host memory");
     f->form = form;
     f->ord  = ord;
-    if (nsections * ord > 8 && !std::getenv("GR4HIP_IIR_NO_SPLIT")) { // two cascades of <= 8 state values (GR4HIP_IIR_NO_SPLIT: the 16-state kernels, which the tests compare)
+    if (nsections * ord > 8 && !dev_switch(kDevIirNoSplit)) { // two cascades of <= 8 state values (GR4HIP_IIR_NO_SPLIT: the 16-state kernels, which the tests compare)
         const size_t k = 8 / ord;
         int rc = gr4hip_iir_create(&f->part[0], form, k, h_b, nb, h_a, na);
         if (!rc) rc = gr4hip_iir_create(&f->part[1], form, nsections - k, h_b + k * nb, nb, h_a + k * na, na);

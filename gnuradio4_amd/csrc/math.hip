@@ -490,7 +490,7 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
     int          rc      = r->d_ckpt.ensure(nchunks * sizeof(float));
     if (rc) return rc;
     // small increments spend many samples per binade: leap; large ones change binade or wrap every few samples and the plain walker's 27-cycle step wins
-    const bool leap = std::getenv("GR4HIP_ROTATOR_LEAP") ? true : (fabsf(r->inc) < kRotLeapBelow && !std::getenv("GR4HIP_ROTATOR_WALK")); // (developer / test switches)
+    const bool leap = dev_switch(kDevRotatorLeap) ? true : (fabsf(r->inc) < kRotLeapBelow && !dev_switch(kDevRotatorWalk)); // (developer / test switches)
     if (leap) hipLaunchKernelGGL(rotator_checkpoint_leap_kernel, dim3(1), dim3(64), 0, st, r->state(), r->inc, (float*)r->d_ckpt.ptr, (long)n);
     else if (r->inc >= 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<1>, dim3(1), dim3(64), 0, st, r->state(), r->inc, (float*)r->d_ckpt.ptr, (long)n);
     else if (r->inc < 0.f) hipLaunchKernelGGL(rotator_checkpoint_kernel<-1>, dim3(1), dim3(64), 0, st, r->state(), r->inc, (float*)r->d_ckpt.ptr, (long)n);

@@ -1,12 +1,29 @@
 // runtime.hip -- error state, device/memory/stream/event helpers and the VMM double-mapped ring of libgr4hip.
 #include "common.hpp"
 
+#include <atomic>
+#include <cstdlib>
+
 #include <cmath>
 #include <limits>
 
 namespace gr4 {
 
 static thread_local char g_err[512] = "";
+
+static const char* const kDevNames[kDevSwitchCount] = {"GR4HIP_FIR_NO_BF16X3", "GR4HIP_FIR_NO_DECIM_FD", "GR4HIP_IIR_THREE_PASS", "GR4HIP_IIR_LOOKBACK", "GR4HIP_IIR_NO_SPLIT",
+                                                       "GR4HIP_FFT_BLUESTEIN_PIPELINE", "GR4HIP_FFT_NO_PIPELINE", "GR4HIP_ROTATOR_LEAP", "GR4HIP_ROTATOR_WALK", "GR4HIP_CHAIN16"};
+struct DevTable {
+    std::atomic<int> v[kDevSwitchCount];
+    DevTable() {
+        for (int i = 0; i < kDevSwitchCount; ++i) {
+            const char* e = std::getenv(kDevNames[i]);
+            v[i].store(e ? (e[0] >= '0' && e[0] <= '9' ? std::atoi(e) : 1) : 0, std::memory_order_relaxed);
+        }
+    }
+};
+static DevTable& dev_table() { static DevTable t; return t; } // (initialised on first use: thread-safe, and independent of static-initialisation order)
+int dev_switch(DevSwitch s) { return dev_table().v[s].load(std::memory_order_relaxed); }
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -75,6 +92,14 @@ extern "C" {
 
 int gr4hip_abi_version(void) { return GR4HIP_ABI_VERSION; }
 const char* gr4hip_last_error(void) { return g_err; }
+
+int gr4hip_developer_switch(const char* name, int value) {
+    GR4_REQUIRE(name, "developer_switch: null name");
+    for (int i = 0; i < gr4::kDevSwitchCount; ++i)
+        if (std::strcmp(name, gr4::kDevNames[i]) == 0) { gr4::dev_table().v[i].store(value, std::memory_order_relaxed); return GR4HIP_OK; }
+    gr4::set_error("developer_switch: unknown switch %s", name);
+    return GR4HIP_INVALID_ARGUMENT;
+}
 
 const char* gr4hip_status_string(int s) {
     switch (s) {

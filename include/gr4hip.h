@@ -50,6 +50,8 @@ typedef enum { /* element types of the reference's block registrations (Math.hpp
 
 typedef enum { GR4HIP_ADD = 0, GR4HIP_SUB, GR4HIP_MUL, GR4HIP_DIV } gr4hip_op; /* std::plus/minus/multiplies/divides */
 
+typedef enum { GR4HIP_GUARD_STRICT = 0, GR4HIP_GUARD_DEFERRED = 1, GR4HIP_GUARD_OFF = 2 } gr4hip_guard_mode; /* dynamic-range guard: gr4hip_chain_set_guard_mode */
+
 typedef enum { /* gr::filter::IIRForm (time_domain_filter.hpp:50-55) == gr::filter::Form (FilterTool.hpp:107-112) */
     GR4HIP_DF_I = 0, GR4HIP_DF_II, GR4HIP_DF_I_TRANSPOSED, GR4HIP_DF_II_TRANSPOSED
 } gr4hip_iir_form;
@@ -82,6 +84,13 @@ typedef void* gr4hip_event_t;  /* hipEvent_t  */
 /* ------------------------------------------------------------------------------------------------ runtime */
 int         gr4hip_abi_version(void);
 const char* gr4hip_last_error(void); /* thread-local text of the last failure */
+/* Developer switches: which of two kernels that compute the same thing serves a call (the tests compare them; tools/ time them).  Each is read from the
+ * environment variable of the same name ONCE, when the library is first used, and can be changed afterwards with this call (atomic; process-wide).
+ * Nothing here changes the meaning of a call -- choices that do (exact float32 FIR arithmetic, the rotator's phase recurrence, the chain's algorithm and
+ * guard) are per-handle settings: gr4hip_fir_set_algo, gr4hip_rotator_set_algo, gr4hip_chain_create / gr4hip_chain_set_guard_mode.
+ * Names: GR4HIP_FIR_NO_BF16X3, GR4HIP_FIR_NO_DECIM_FD, GR4HIP_IIR_THREE_PASS, GR4HIP_IIR_LOOKBACK, GR4HIP_IIR_NO_SPLIT, GR4HIP_FFT_BLUESTEIN_PIPELINE,
+ * GR4HIP_FFT_NO_PIPELINE, GR4HIP_ROTATOR_LEAP, GR4HIP_ROTATOR_WALK, GR4HIP_CHAIN16. */
+int gr4hip_developer_switch(const char* name, int value);
 const char* gr4hip_status_string(int status);
 int         gr4hip_device_count(int* count);
 int         gr4hip_set_device(int index); /* ComputeDomain "gpu:hip:<index>" (ComputeDomain.hpp:47-100) */
@@ -123,10 +132,15 @@ int gr4hip_ring_size(const gr4hip_ring_t* ring, size_t* bytes);
  * dtype F32 (registered) or C32 (complex data x real taps).  decim > 1 gives the
  * BasicFilterProto decimating processBulk (:190-204): output m == y[m*decim]; n_in must be a multiple of decim
  * (the reference guarantees it through input_chunk_size = decimate, :166-168). */
-/* (complex data, 97 .. 256 taps, spans of >= 64 x 8192 samples take a fast-convolution kernel: a non-finite input sample then reaches every output of
- * its 8192-sample block instead of the next ntaps outputs.  33 .. 256 taps (complex too) on long 16-byte-aligned spans evaluate the products with samples and taps split into
- * three bf16 terms each (float32 accuracy, same 1e-5 parity bar): an infinite sample gives NaN -- not +-Inf -- in the outputs it reaches, and a finite sample
- * above bf16's largest value, 3.39e38, counts as infinite.  GR4HIP_FIR_NO_BF16X3 in the environment keeps the float32 multiply-add kernels.) */
+/* Non-finite and near-FLT_MAX samples (pinned by tests/test_gpu_parity.py::test_fir_non_finite_samples / test_chain_non_finite_samples).  The reference's
+ * transform_reduce gives +-Inf / NaN on exactly the ntaps outputs whose window contains such a sample.  With the default algorithm:
+ *  - 33 .. 256 taps (float and complex; float also 384 .. 1024) on long 16-byte-aligned spans evaluate the products with samples and taps split into three
+ *    bf16 terms each (float32 accuracy, same 1e-5 parity bar): every output the reference makes non-finite is non-finite here too, as NaN (not +-Inf); the
+ *    reach is the kernel's 32-sample-granular window -- at most 15 outputs earlier and 46 later than the reference's; a finite sample above bf16's largest
+ *    value, 3.39e38, counts as infinite;
+ *  - complex data, 97 .. 256 taps, spans of >= 64 x 8192 samples take a fast-convolution kernel: a non-finite sample reaches every output of its 8192-sample
+ *    block (and of the next block when it lies within the block's last 255 samples) instead of the next ntaps outputs.
+ * gr4hip_fir_set_algo(GR4HIP_FIR_EXACT_F32) selects, per handle, kernels whose classes (+Inf, -Inf, NaN) and reach are the reference's exactly. */
 typedef struct gr4hip_fir gr4hip_fir_t;
 int gr4hip_fir_create(gr4hip_fir_t** fir, int dtype, const float* h_taps, size_t ntaps, size_t decim);
 int gr4hip_fir_set_taps(gr4hip_fir_t* fir, const float* h_taps, size_t ntaps); /* settingsChanged (:38-42): history is kept */
@@ -136,8 +150,13 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
  * passes, GR4HIP_FIR_TIME_DOMAIN keeps the error relative to the OUTPUT inside the 1e-5 parity bar (the reference's own arithmetic, 1024 flop/sample). */
 /* FIR_AUTO carries the same dynamic-range guard as GR4HIP_CHAIN_AUTO (gr4hip_chain_last_power_ratio below): the first fast convolution of a stream is probed
  * on eight frames, later ones are watched through the powers every launch samples, and below an output / input power ratio of 0.04 the direct form takes over. */
-typedef enum { GR4HIP_FIR_AUTO = 0, GR4HIP_FIR_TIME_DOMAIN = 1 } gr4hip_fir_algo;
+/* GR4HIP_FIR_EXACT_F32: every product and sum in IEEE float32 (no frequency-domain kernels, no bf16 splits): the kernels whose arithmetic is the reference's
+ * transform_reduce (time_domain_filter.hpp:44-47) term for term up to the order of the additions -- an infinite or NaN input sample reaches exactly the
+ * ntaps outputs whose window contains it, as +-Inf / NaN (tests/test_gpu_parity.py::test_fir_non_finite_samples pins this and what the default algorithm
+ * does instead).  Slower for 33 .. 1024 taps (the f32 MFMA / register-window kernels: DESIGN.md 3.2, 3.6). */
+typedef enum { GR4HIP_FIR_AUTO = 0, GR4HIP_FIR_TIME_DOMAIN = 1, GR4HIP_FIR_EXACT_F32 = 2 } gr4hip_fir_algo;
 int gr4hip_fir_set_algo(gr4hip_fir_t* fir, int algo);
+int gr4hip_fir_set_guard_mode(gr4hip_fir_t* fir, int mode); /* gr4hip_guard_mode (below), for FIR_AUTO's fast convolution of long complex spans; default GR4HIP_GUARD_STRICT */
 int gr4hip_fir_process(gr4hip_fir_t* fir, const void* d_in, size_t n_in, void* d_out, size_t* n_out, gr4hip_stream_t stream);
 int gr4hip_fir_destroy(gr4hip_fir_t* fir);
 
@@ -243,7 +262,6 @@ int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time
  *     measurements of EARLIER launches, so the call in which a strong out-of-band signal first appears is published from the fused kernel (error floor
  *     ~2e-6 of the input rms) and the switch happens from the next call on.
  *   GR4HIP_GUARD_OFF: no measurement, never switches (what an explicit GR4HIP_CHAIN_FUSED_FD chain does). */
-typedef enum { GR4HIP_GUARD_STRICT = 0, GR4HIP_GUARD_DEFERRED = 1, GR4HIP_GUARD_OFF = 2 } gr4hip_guard_mode;
 int gr4hip_chain_set_guard_mode(gr4hip_chain_t* chain, int mode);
 /* n_chains (<= 16) chains of the same fft size fed n_samples each in ONE call -- the branches of a flowgraph with parallel SDR channels that share a device
  * (BASELINE.json configs[4] at fewer GPUs than channels).  d_in_c32 / d_mag2 are HOST arrays of device pointers.
