@@ -495,11 +495,12 @@ class Rotator(_Handle):
         check(lib().gr4hip_rotator_set_algo(self._h, ids[algo]), "Rotator.set_algo")
         self.algo = algo
 
-    def process_bulk(self, x: torch.Tensor) -> torch.Tensor:
+    def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "Rotator")
         if x.dtype != self.dtype:
             raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Rotator", f"expected {self.dtype}, got {x.dtype}")
-        out = torch.empty_like(x)
+        if out is None:
+            out = torch.empty_like(x)
         fn = lib().gr4hip_rotator64_process if self._f64 else lib().gr4hip_rotator_process
         check(fn(self._h, x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "Rotator.process")
         return out

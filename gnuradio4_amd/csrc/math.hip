@@ -296,10 +296,9 @@ __global__ __launch_bounds__(256) void rotator_apply_kernel(const float2* __rest
 // below 2^21 turns (2^-32 turn resolution) however long the span.  One pass, 16 B per sample: HBM-bound.  The float recurrence of the reference
 // drifts ~1e-7 rad per step away from this value (the walker above reproduces that drift bit for bit); this one is the float64 oracle's phase.
 template <bool V4> // V4: 16-byte accesses (both spans 16-byte aligned); otherwise one 8-byte sample per lane (a ring span may start at any element)
-__global__ __launch_bounds__(256) void rotator_closed_kernel(const float4* __restrict__ x, float4* __restrict__ y, const float* __restrict__ state_in,
-                                                             float* __restrict__ state_out, double inc_t, double inc_t20, long n) {
+__global__ __launch_bounds__(256) void rotator_closed_kernel(const float4* __restrict__ x, float4* __restrict__ y, double ph0_t /*carried phase in turns: float64, kept by the handle*/,
+                                                             double inc_t, double inc_t20, long n) {
     const double two_pi = 6.283185307179586476925286766559;
-    const double ph0_t  = (double)*state_in * (1.0 / two_pi);
     const long   pairs  = (n + 1) / 2;
     auto         rot    = [&](long k, float re, float im, float& ore, float& oim) { // k = sample index + 1
         double t = fma((double)(k & 0xfffff), inc_t, ph0_t);
@@ -334,12 +333,6 @@ __global__ __launch_bounds__(256) void rotator_closed_kernel(const float4* __res
             rot(2 * p + 1, v.x, v.y, o.x, o.y);
             reinterpret_cast<float2*>(y)[2 * p] = o;
         }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { // carried phase in [0, 2 pi), into the OTHER state slot (every workgroup reads state_in)
-        double t = fma((double)(n & 0xfffff), inc_t, ph0_t);
-        t        = fma((double)(n >> 20), inc_t20, t);
-        t -= floor(t);
-        *state_out = (float)(t * two_pi);
     }
 }
 
@@ -413,8 +406,10 @@ using namespace gr4;
 struct gr4hip_rotator {
     float        inc  = 0.f;
     int          algo = GR4HIP_ROTATOR_CLOSED_FORM;
-    int          cur  = 0; // which of the two state slots holds _accumulated_phase (the closed-form kernel writes the other one: no read/write race)
-    DeviceBuffer d_state; // two floats
+    int          cur  = 0; // state slot in use
+    double       ph_t = 0.0; // closed form: the carried phase in TURNS, float64, advanced on the host (inc is a host constant: nothing to read back, and no
+                             // rounding to float between calls -- one float per call is a 2.4e-7 rad random walk, beyond 1e-5 after a few thousand small calls)
+    DeviceBuffer d_state; // recurrence: _accumulated_phase as the reference's float
     DeviceBuffer d_ckpt;
     float*       state() const { return static_cast<float*>(d_state.ptr) + cur; }
 };
@@ -458,13 +453,25 @@ int gr4hip_rotator_create(gr4hip_rotator_t** out, float phase_increment, float i
 int gr4hip_rotator_reset(gr4hip_rotator_t* r, float initial_phase) {
     GR4_REQUIRE(r, "rotator: null handle");
     GR4_HIP_TRY(hipMemcpy(r->state(), &initial_phase, sizeof(float), hipMemcpyHostToDevice));
+    r->ph_t = (double)initial_phase / 6.283185307179586476925286766559;
     return GR4HIP_OK;
 }
 
 int gr4hip_rotator_set_algo(gr4hip_rotator_t* r, int algo) {
     GR4_REQUIRE(r, "rotator: null handle");
     GR4_REQUIRE(algo == GR4HIP_ROTATOR_CLOSED_FORM || algo == GR4HIP_ROTATOR_RECURRENCE, "rotator_set_algo: unknown algo %d", algo);
-    r->algo = algo; // the carried phase is one float whichever algorithm advances it
+    if (algo == r->algo) return GR4HIP_OK;
+    // the carried phase changes hands (rare: a settings change, not a per-call operation): everything queued on the handle finishes first
+    GR4_HIP_TRY(hipDeviceSynchronize());
+    if (algo == GR4HIP_ROTATOR_RECURRENCE) {
+        const float ph = (float)((r->ph_t - std::floor(r->ph_t)) * 6.283185307179586476925286766559);
+        GR4_HIP_TRY(hipMemcpy(r->state(), &ph, sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        float ph = 0.f;
+        GR4_HIP_TRY(hipMemcpy(&ph, r->state(), sizeof(float), hipMemcpyDeviceToHost));
+        r->ph_t = (double)ph / 6.283185307179586476925286766559;
+    }
+    r->algo = algo;
     return GR4HIP_OK;
 }
 
@@ -478,11 +485,13 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
         const bool   v4    = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
         const size_t items = v4 ? (n + 1) / 2 : n;
         const unsigned grid = (unsigned)std::min<size_t>(ceil_div(items, (size_t)256), (size_t)1 << 20);
-        float* nxt = static_cast<float*>(r->d_state.ptr) + (r->cur ^ 1);
-        if (v4) hipLaunchKernelGGL(rotator_closed_kernel<true>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->state(), nxt, inc_t - std::floor(inc_t), inc20 - std::floor(inc20), (long)n);
-        else hipLaunchKernelGGL(rotator_closed_kernel<false>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->state(), nxt, inc_t - std::floor(inc_t), inc20 - std::floor(inc20), (long)n);
+        const double f1 = inc_t - std::floor(inc_t), f20 = inc20 - std::floor(inc20);
+        if (v4) hipLaunchKernelGGL(rotator_closed_kernel<true>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->ph_t, f1, f20, (long)n);
+        else hipLaunchKernelGGL(rotator_closed_kernel<false>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->ph_t, f1, f20, (long)n);
         GR4_LAUNCH_CHECK();
-        r->cur ^= 1;
+        double t = std::fma((double)(n & 0xfffff), f1, r->ph_t); // the phase the next call starts from, in [0, 1) turns
+        t        = std::fma((double)(n >> 20), f20, t);
+        r->ph_t  = t - std::floor(t);
         return GR4HIP_OK;
     }
     // the reference's float recurrence, bit for bit
@@ -504,6 +513,10 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
 
 int gr4hip_rotator_phase(gr4hip_rotator_t* r, float* phase, gr4hip_stream_t stream) {
     GR4_REQUIRE(r && phase, "rotator_phase: null argument");
+    if (r->algo == GR4HIP_ROTATOR_CLOSED_FORM && r->inc == r->inc) { // known on the host: the phase behind everything queued so far
+        *phase = (float)((r->ph_t - std::floor(r->ph_t)) * 6.283185307179586476925286766559);
+        return GR4HIP_OK;
+    }
     GR4_HIP_TRY(hipMemcpyAsync(phase, r->state(), sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
     GR4_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     return GR4HIP_OK;

@@ -37,6 +37,16 @@ inline void check(int rc, const char* what) {
         throw std::runtime_error(std::string(what) + ": " + gr4hip_status_string(rc) + " (" + gr4hip_last_error() + ")");
 }
 
+// Process-wide choices of the device implementations that a block's reflected settings do not carry (the block definitions are the reference's: no extra
+// members).  Set before the graph is initialised.
+struct Options {
+    // Rotator<complex<float>> on a device: false (default) = closed-form float64 phase -- the float64 oracle's output, one HBM-bound pass; it does NOT reproduce
+    // the drift of the reference's float accumulator (beyond 1e-5 of the CPU block's own output after ~10^3 .. 10^5 samples).  true = the reference's float
+    // recurrence itself, bit-identical to the block on the host (a sequential walk: far slower; include/gr4hip.h, gr4hip_rotator_set_algo).
+    bool rotator_reference_recurrence = false;
+};
+inline Options& options() { static Options o; return o; }
+
 // one device stage of a chain: consumes n_in elements at d_in, produces *n_out at d_out, asynchronously on `stream`
 struct Stage {
     virtual ~Stage() = default;
@@ -274,6 +284,7 @@ struct RotatorStage final : Stage {
     RotatorStage(float phase_increment, float initial_phase) {
         in_bytes = out_bytes = 8;
         check(gr4hip_rotator_create(&h, phase_increment, initial_phase), "gr4hip_rotator_create");
+        if (options().rotator_reference_recurrence) check(gr4hip_rotator_set_algo(h, GR4HIP_ROTATOR_RECURRENCE), "gr4hip_rotator_set_algo");
     }
     ~RotatorStage() override { gr4hip_rotator_destroy(h); }
     std::string_view kind() const override { return "rotator_c32"; }

@@ -290,11 +290,14 @@ int gr4hip_math_const(int op, int dtype, const void* d_in, void* d_out, size_t n
 int gr4hip_math_nary(int op, int dtype, const void* const* h_d_ins, size_t n_inputs, void* d_out, size_t n, gr4hip_stream_t stream);
 
 /* Rotator<complex<float>>::processOne (blocks/math/.../Rotator.hpp:51-61): phase += inc (before the first sample),
- * single +-2pi wrap, y = x * (cos, sin); the accumulated phase (one float, like the block's member) is carried across calls.
+ * single +-2pi wrap, y = x * (cos, sin); the accumulated phase is carried across calls.
  * Two evaluations of the phase (gr4hip_rotator_set_algo; both keep the same carried state, so they may be switched between calls):
  *   GR4HIP_ROTATOR_CLOSED_FORM (default): sample i of a call sees carried + (i + 1) inc, computed in float64 and reduced exactly -- the float64
- *     oracle's phase (<= 1e-5 against it however long the stream), one HBM-bound pass.  It does NOT reproduce the drift of the reference's float
- *     accumulator (~1e-7 rad per step, i.e. beyond 1e-5 after ~10^3..10^5 samples).
+ *     oracle's phase (<= 1e-5 against it however long the stream and however many calls it is cut into: the carried phase is kept in float64 by the
+ *     handle, gr4hip_rotator_phase reports it rounded to float), one HBM-bound pass.  The default is MORE ACCURATE THAN, not identical to, the
+ *     reference block: it does NOT reproduce the drift of the reference's float accumulator (~1e-7 rad per step), so against the reference's own output
+ *     it is beyond 1e-5 after ~10^3..10^5 samples.  A caller who needs the CPU block's output bit for bit selects the recurrence (below; the host
+ *     engine: gr::hip::options().rotator_reference_recurrence).
  *   GR4HIP_ROTATOR_RECURRENCE: the reference's float recurrence itself, bit-identical phase sequence and carried phase (a sequential walk: ~10^2..10^4
  *     times slower, for callers that need the reference's exact output). */
 typedef struct gr4hip_rotator gr4hip_rotator_t;

@@ -1779,6 +1779,24 @@ def test_rotator_golden_and_parity(G, golden):
     assert abs(r.phase_increment - 2 * np.pi * 0.02) < 1e-6
 
 
+def test_rotator_closed_form_phase_survives_many_small_calls(G):
+    """scheduler-sized chunks: 20 000 calls of 37 samples.  The closed form's carried phase lives in float64 on the host, so the last call is as close to
+    the float64 oracle as the first (a float carried between calls would random-walk 2.4e-7 rad per call: beyond 1e-5 after a few thousand calls)"""
+    calls, per = 20_000, 37
+    inc, ph0 = 0.6283185, 0.25
+    x = O.signal_c32(12, calls * per)
+    want, _ = O.rotator(x.astype(np.complex128), float(np.float32(inc)), float(np.float32(ph0)))
+    r = G.Rotator(phase_increment=inc, initial_phase=ph0)
+    xd = dev(x)
+    out = torch.empty_like(xd)
+    for c in range(calls):
+        r.process_bulk(xd[c * per:(c + 1) * per], out[c * per:(c + 1) * per])
+    got = out.cpu().numpy()
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(got[-10 * per:] - want[-10 * per:])) <= 1e-5 * scale
+    assert np.max(np.abs(got - want)) <= 1e-5 * scale
+
+
 def test_rotator_leaping_walker_is_bit_identical(G, devsw):
     """small increments take the leaping walker (exact arithmetic progressions inside a binade): every checkpoint, hence every output sample, and
     the carried phase must equal the plain sample-by-sample walker's, bit for bit -- also for increments that tie between two ulps, that vanish
