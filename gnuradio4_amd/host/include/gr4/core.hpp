@@ -346,6 +346,9 @@ struct EdgeBufferBase {
     virtual void                                     consume_items(std::size_t /*n*/) {}
     [[nodiscard]] virtual void*                      reserve_items(std::size_t /*n*/) { return nullptr; }
     virtual void                                     publish_reserved(std::size_t /*n*/) {}
+    // hand the most recently lent / reserved n items back untouched (a launch that failed before anything was queued for them)
+    virtual void                                     unlend_items(std::size_t /*n*/) {}
+    virtual void                                     unreserve_items(std::size_t /*n*/) {}
     [[nodiscard]] virtual std::pmr::memory_resource* memory() const { return nullptr; }
     // grow an EMPTY edge to at least n items (same memory resource); false if it cannot (data in it, spans out, fan-out mirrors).  Used by the device planner:
     // an edge that feeds a device run wants chunks far larger than the reference's 65536-item default
@@ -425,6 +428,8 @@ struct EdgeBuffer final : EdgeBufferBase {
         reserved -= std::min(reserved, n);
         publish(n);
     }
+    void unlend_items(std::size_t n) override { lent -= std::min(lent, n); }
+    void unreserve_items(std::size_t n) override { reserved -= std::min(reserved, n); }
     [[nodiscard]] std::pmr::memory_resource* memory() const override { return resource(); }
     bool ensure_capacity(std::size_t n) override {
         if (n <= capacity) return true;

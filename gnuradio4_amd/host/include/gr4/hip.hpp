@@ -110,12 +110,11 @@ inline void register_provider() { // idempotent; call once before Graph::connect
 // is far below what the link moves (DESIGN.md "Host feed"): large staging copies are cut into slices for a few helper threads.
 // GR4HIP_COPY_THREADS sets the helper count (default: an eighth of the host's hardware threads, 1 .. 7; 0: the calling thread copies alone).
 class CopyPool {
-    struct Slice { char* d; const char* s; std::size_t n; };
+    struct Slice { char* d; const char* s; std::size_t n; std::size_t* pending; }; // pending: the slice counter of the copy() call it belongs to
     std::vector<std::thread>  _threads;
     std::mutex                _m;
     std::condition_variable   _cv, _cv_done;
     std::vector<Slice>        _work;
-    std::size_t               _pending = 0;
     bool                      _stop    = false;
     void run() {
         for (;;) {
@@ -129,7 +128,7 @@ class CopyPool {
             }
             std::memcpy(sl.d, sl.s, sl.n);
             std::lock_guard lk(_m);
-            if (--_pending == 0) _cv_done.notify_all();
+            if (--*sl.pending == 0) _cv_done.notify_all();
         }
     }
     CopyPool() {
@@ -151,18 +150,18 @@ public:
         const std::size_t parts = std::min(_threads.size() + 1, bytes / kMin);
         if (parts < 2) { std::memcpy(dst, src, bytes); return; }
         const std::size_t per = (bytes / parts + 63) & ~std::size_t(63);
+        std::size_t       pending = parts - 1; // this call's own slices: concurrent callers (several scheduler threads, several graphs) do not wait for each other's
         {
             std::lock_guard lk(_m);
             for (std::size_t i = 1; i < parts; ++i) {
                 const std::size_t at = i * per;
-                _work.push_back({static_cast<char*>(dst) + at, static_cast<const char*>(src) + at, std::min(per, bytes - at)});
+                _work.push_back({static_cast<char*>(dst) + at, static_cast<const char*>(src) + at, std::min(per, bytes - at), &pending});
             }
-            _pending += parts - 1;
         }
         _cv.notify_all();
         std::memcpy(dst, src, per); // the caller's share
         std::unique_lock lk(_m);
-        _cv_done.wait(lk, [&] { return _pending == 0; });
+        _cv_done.wait(lk, [&] { return pending == 0; });
     }
 };
 
@@ -1197,6 +1196,7 @@ public:
     }
 
     work::Result work(std::size_t requested) override {
+        std::size_t held_lent = 0, held_reserved = 0; // spans taken from the edges for a chunk that is not queued yet (given back if the launch fails)
         try {
             check(gr4hip_set_device(_domain.index), "gr4hip_set_device"); // runs on several devices share the scheduler thread: the current device is per call
             std::size_t published = 0;
@@ -1262,12 +1262,14 @@ public:
                     while (_q_count) published += retire(false);
                     direct = _out_edge->reserve_items(n_res);
                 }
+                if (direct) held_reserved = n_res;
             }
             Slot& sl = _slots[(_q_head + _q_count) % kDepth];
             if (_q_count) ++_overlapped;
             // samples land in HBM: pinned staging -> hipMemcpyAsync -> the double-mapped ring (a wrapping span stays contiguous)
             char*       d_in    = static_cast<char*>(_ring_base) + _ring_wr;
             const void* lent = _in_edge->lend_items(n);
+            if (lent) held_lent = n;
             if (lent && _in_edge->memory() == pinned_resource()) { // page-locked storage ("hip" provider): the copy engine reads the edge in place;
                 check(gr4hip_memcpy_h2d(d_in, lent, n * _in_bytes, _s_in), "h2d"); // the span goes back to the edge once the copy has landed (release_inputs)
                 check(gr4hip_event_record(sl.in_done, _s_in), "event record");
@@ -1277,6 +1279,7 @@ public:
                 if (lent) { // pageable edge: staged through page-locked memory by the copy threads
                     CopyPool::instance().copy(sl.h_in.ensure(n * _in_bytes), lent, n * _in_bytes);
                     _in_edge->consume_items(n);
+                    held_lent = 0;
                 } else {
                     _read(sl.h_in.ensure(n * _in_bytes), n);
                 }
@@ -1308,9 +1311,18 @@ public:
             if (direct) ++_direct_chunks;
             else _pending_out += cnt;
             ++_q_count;
-            return {requested, n, work::Status::OK};
+            return {requested, n, work::Status::OK}; // (the slot owns the spans from here on)
         } catch (const std::exception& e) {
             std::cerr << "[gr::hip] device run failed: " << e.what() << "\n";
+            // the failed chunk's spans go back to their edges untouched (a graph that tolerates ERROR must not find free_items() / available_items() shrunk
+            // for good) -- once nothing queued on the streams can still read or write them
+            if (held_lent || held_reserved) {
+                (void)gr4hip_stream_synchronize(_s_in);
+                (void)gr4hip_stream_synchronize(_s_k);
+                (void)gr4hip_stream_synchronize(_s_out);
+                if (held_lent) _in_edge->unlend_items(held_lent);
+                if (held_reserved) _out_edge->unreserve_items(held_reserved);
+            }
             return {requested, 0, work::Status::ERROR};
         }
     }
