@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--fanin-cus", type=int, default=32, help="N > 1: CUs left to the RCCL fan-in kernels (the fused kernel is persistent and fills every CU it gets)")
     ap.add_argument("--fanin-algo", default="auto", choices=["auto", "reduce_scatter", "all_to_all"],
                     help="N > 1: how the partial sums cross xGMI (gnuradio4_amd/fanin.py); auto = both are timed before the warm-up, the faster one runs")
+    ap.add_argument("--fanin-impl", default="capi", choices=["capi", "torch"], help="N > 1 over RCCL: the collectives through the library's C entry points (gr4hip_fanin_*: the "
+                    "communicator the C++ engine uses; torch.distributed only ships its id) or through torch.distributed's own communicator")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check of the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of sampled output frames")
@@ -199,6 +201,18 @@ def main():
     fan_stream = torch.cuda.Stream() if world > 1 else None
     fan_done = [torch.cuda.Event() for _ in range(2)] if world > 1 else None
     recv = torch.empty((frames_per_chunk, NFFT), dtype=torch.float32, device="cuda") if world > 1 else None  # all_to_all landing area
+    comm = None
+    if world > 1 and args.dist_backend == "nccl" and args.fanin_impl == "capi":
+        try:
+            comm = fanin.Communicator()
+            ok = 1
+        except Exception as e:  # e.g. no librccl the library can open: every rank must take the same path
+            print(f"[bench] rank {rank}: gr4hip_fanin communicator unavailable ({e}); falling back to torch.distributed", file=sys.stderr, flush=True)
+            ok = 0
+        agree = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0:
+            comm = None
     fanin_algo = args.fanin_algo if args.fanin_algo != "auto" else "reduce_scatter"
     fanin_probe = None
     if world > 1 and args.fanin_algo == "auto":
@@ -207,12 +221,12 @@ def main():
         fanin_probe = {}
         for algo in ("reduce_scatter", "all_to_all"):
             try:
-                fanin.fan_in_sum(probe_src, rs_out[0], algo=algo, recv=recv)
+                fanin.fan_in_sum(probe_src, rs_out[0], algo=algo, recv=recv, comm=comm)
                 torch.cuda.synchronize()
                 dist.barrier()
                 t0 = time.perf_counter()
                 for _ in range(3):
-                    fanin.fan_in_sum(probe_src, rs_out[0], algo=algo, recv=recv)
+                    fanin.fan_in_sum(probe_src, rs_out[0], algo=algo, recv=recv, comm=comm)
                 torch.cuda.synchronize()
                 t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device="cuda")
             except RuntimeError as e:  # a collective this RCCL build refuses: the other one runs (an error on one rank is an error on all: same outcome everywhere)
@@ -242,7 +256,7 @@ def main():
                 if world > 1:
                     fan_stream.wait_stream(main_stream)
                     with torch.cuda.stream(fan_stream):
-                        fanin.fan_in_sum(dst, rs_out[c], algo=fanin_algo, recv=recv)
+                        fanin.fan_in_sum(dst, rs_out[c], algo=fanin_algo, recv=recv, comm=comm)
                         fan_done[c & 1].record()
                 continue
             for i, ch in enumerate(chains):  # every channel on its own stream
@@ -268,7 +282,7 @@ def main():
             if world > 1:  # the one exchange step: this launch's partial sums cross xGMI while the next launch computes
                 fan_stream.wait_stream(main_stream)
                 with torch.cuda.stream(fan_stream):
-                    fanin.fan_in_sum(dst, rs_out[c], algo=fanin_algo, recv=recv)
+                    fanin.fan_in_sum(dst, rs_out[c], algo=fanin_algo, recv=recv, comm=comm)
                     fan_done[c & 1].record()
         if world > 1:
             main_stream.wait_stream(fan_stream)
@@ -342,7 +356,7 @@ def main():
             pass
         per_gpu = len(mine)
         graph = (f"; {n_channels}-channel graph: {per_gpu} channel(s) per GPU " + ("in ONE launch, math::Add fold in its registers" if multi else "on own streams, math::Add fold on device")
-                 + (f", {'RCCL reduce_scatter' if args.dist_backend == 'nccl' else args.dist_backend + ' all_reduce (functional check only)'} fan-in per launch (configs[4])" if world > 1 else " (one GPU, no collective)")) if combine else ""
+                 + (f", {('RCCL ' + fanin_algo + (' through gr4hip_fanin_*' if comm is not None else ' through torch.distributed')) if args.dist_backend == 'nccl' else args.dist_backend + ' all_reduce (functional check only)'} fan-in per launch (configs[4])" if world > 1 else " (one GPU, no collective)")) if combine else ""
         res = {
             "metric": "Msamples/s through 256-tap cplx FIR->8192-pt FFT chain; %HBM roofline @1/2/4/8 GPU",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -117,6 +117,13 @@ SIGNATURES = {
     "gr4hip_developer_switch": (_i, [C.c_char_p, _i]),
     "gr4hip_chain_process_multi": (_i, [_vp, _sz, _vp, _sz, _vp, _vp, _psz, _vp]),
     "gr4hip_chain_destroy": (_i, [_vp]),
+    "gr4hip_fanin_unique_id": (_i, [_vp]),
+    "gr4hip_fanin_create": (_i, [_pvp, _vp, _i, _i]),
+    "gr4hip_fanin_rank": (_i, [_vp, _pi, _pi]),
+    "gr4hip_fanin_reduce_scatter_sum_f32": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "gr4hip_fanin_all_to_all_sum_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "gr4hip_fanin_all_reduce_sum_f32": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "gr4hip_fanin_destroy": (_i, [_vp]),
     "gr4hip_math_const": (_i, [_i, _i, _vp, _vp, _sz, _vp, _vp]),
     "gr4hip_math_nary": (_i, [_i, _i, _vp, _sz, _vp, _sz, _vp]),
     "gr4hip_rotator_create": (_i, [_pvp, _f, _f]),

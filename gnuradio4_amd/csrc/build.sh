@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libgr4hip.so
-SRCS="runtime.hip fir.hip fir_interp.hip fir_decim_fd.hip fft.hip fft_fast_pk.hip math.hip iir.hip chain.hip chain_fused.hip chain_td.hip chain16.hip fir_batched.hip fir_bf16.hip design.hip f64.hip"
+SRCS="runtime.hip fir.hip fir_interp.hip fir_decim_fd.hip fft.hip fft_fast_pk.hip math.hip iir.hip chain.hip chain_fused.hip chain_td.hip chain16.hip fir_batched.hip fir_bf16.hip design.hip f64.hip fanin.hip"
 mkdir -p ../../build/obj
 OBJS=""
 pids=()
@@ -20,5 +20,5 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS -ldl
 echo "built $(realpath $OUT)"

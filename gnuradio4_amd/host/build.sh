@@ -16,6 +16,7 @@ stale() { # target sources...
 pids=()
 # the CPU program links the library too: the filter-design and window functions behind BasicFilter / FFT are host code in libgr4hip.so
 if stale $OUT/test_host_cpu tests/test_host_cpu.cpp; then $CXX -O2 tests/test_host_cpu.cpp -o $OUT/test_host_cpu $LINK & pids+=($!); fi
+if stale $OUT/test_host_fanin tests/test_host_fanin.cpp; then $CXX -O2 tests/test_host_fanin.cpp -o $OUT/test_host_fanin $LINK & pids+=($!); fi
 if stale $OUT/test_host_device tests/test_host_device.cpp; then $CXX -O2 tests/test_host_device.cpp -o $OUT/test_host_device $LINK & pids+=($!); fi
 # the plugin (gr_plugin_make / gr_plugin_free) next to libgr4hip.so, and a loader test that links neither
 if stale ../libgr4hip_blocks.so plugin/gr4hip_blocks.cpp; then

@@ -17,12 +17,14 @@
 #include <cctype>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <numeric>
 #include <span>
 #include <thread>
 #include <functional>
 #include <iostream>
+#include <limits>
 #include <memory_resource>
 #include <new>
 
@@ -1478,6 +1480,203 @@ inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2, std::s
         }
         blocks = std::move(kept);
         runs.push_back(ref);
+    }
+    return runs;
+}
+
+// ---------------------------------------------------------------------------------------------- sharded graphs: the cross-device combiner edge
+// A flowgraph shards across the GPUs of a node only along independent branches -- one SDR channel per GPU -- and the placement is what the
+// graph already says: every block of a branch carries compute_domain "gpu:hip:i" (ComputeDomain.hpp:47-100; EdgeParameters.domain, BlockModel.hpp:64-72).  One
+// process per GPU: Shard is this process' place among them.  plan_sharded() rewrites
+//     source_c -> fir_filter<complex<float>> -> PowerSpectrum -> Add<float>.in[c]   (c = 0 .. n-1, branch c on gpu:hip:d_c)   Add.out -> ...
+// into ONE FanInRun per combiner: the branches with d_c mod n_ranks == rank stay (their samples enter THIS device, all of them in one launch whose store
+// epilogue is the local part of math::Add: gr4hip_chain_process_multi), the other branches leave this process' schedule together with their sources, and the
+// edge between the devices -- the combiner's inputs that live elsewhere -- is an RCCL collective over xGMI queued on the run's stream (gr4hip_fanin_*): every
+// rank publishes the all-channel sum on the combiner's output edge (all_reduce), or its shard of the frames (reduce_scatter).
+// All ranks run the same graph description on streams of the same length; an exchange covers `frames_per_exchange` frames (the last one what is left).
+struct Shard {
+    int             rank = 0, n_ranks = 1;
+    gr4hip_fanin_t* comm = nullptr;      // null with n_ranks == 1: no collective at all; non-null: the collective runs even on one rank
+    bool            scatter = false;     // true: every rank publishes only its 1 / n_ranks of each exchange's frames (reduce_scatter) instead of the whole sum
+    std::size_t     frames_per_exchange = 64;
+};
+
+class FanInRun final : public BlockModel {
+    struct Branch {
+        std::shared_ptr<EdgeBufferBase> in;
+        gr4hip_chain_t*                 chain = nullptr;
+        DevBuf                          d_in{false}, h_in{true};
+    };
+    std::deque<Branch>              _branches; // (a Branch owns device buffers: it never moves)
+    std::shared_ptr<EdgeBufferBase> _out;
+    Shard                           _shard;
+    std::size_t                     _N, _n_total;
+    ComputeDomain                   _domain;
+    gr4hip_stream_t                 _s = nullptr;
+    DevBuf                          _d_partial{false}, _d_sum{false}, _h_out{true};
+    std::string                     _name;
+    std::size_t                     _launches = 0, _exchanges = 0;
+
+public:
+    FanInRun(std::vector<std::pair<std::shared_ptr<EdgeBufferBase>, std::vector<float>>> local_branches, std::shared_ptr<EdgeBufferBase> out, std::size_t fftSize, int window,
+             std::size_t n_total, Shard shard, ComputeDomain domain)
+        : _out(std::move(out)), _shard(shard), _N(fftSize), _n_total(n_total), _domain(std::move(domain)) {
+        check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
+        check(gr4hip_stream_create(&_s), "gr4hip_stream_create");
+        for (auto& [edge, taps] : local_branches) {
+            _branches.emplace_back();
+            _branches.back().in = std::move(edge);
+            check(gr4hip_chain_create(&_branches.back().chain, taps.data(), taps.size(), fftSize, window, GR4HIP_CHAIN_AUTO), "gr4hip_chain_create");
+        }
+        _name = "fan_in[" + std::to_string(_branches.size()) + " of " + std::to_string(n_total) + " channels on gpu:hip:" + std::to_string(_domain.index) + "]";
+    }
+    ~FanInRun() override {
+        for (auto& b : _branches) gr4hip_chain_destroy(b.chain);
+        if (_s) gr4hip_stream_destroy(_s);
+    }
+    [[nodiscard]] std::size_t local_channels() const { return _branches.size(); }
+    [[nodiscard]] std::size_t launches() const { return _launches; }   // device launches of the branch kernels: ONE per exchange whatever the channel count
+    [[nodiscard]] std::size_t exchanges() const { return _exchanges; } // collectives queued
+
+    work::Result work(std::size_t requested) override {
+        try {
+            check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
+            bool        all_done = true;
+            std::size_t avail    = std::numeric_limits<std::size_t>::max();
+            for (auto& b : _branches) {
+                avail    = std::min(avail, b.in->available_items());
+                all_done = all_done && b.in->done();
+            }
+            if (_branches.empty()) { avail = 0; all_done = true; }
+            std::size_t frames = std::min(avail / _N, _shard.frames_per_exchange);
+            if (frames < _shard.frames_per_exchange && !all_done) return {requested, 0, work::Status::INSUFFICIENT_INPUT_ITEMS}; // every rank exchanges the same frame counts
+            if (frames == 0) {
+                if (all_done) { _out->producer_done = true; return {requested, 0, work::Status::DONE}; }
+                return {requested, 0, work::Status::INSUFFICIENT_INPUT_ITEMS};
+            }
+            const std::size_t n_out = _shard.scatter ? frames / static_cast<std::size_t>(_shard.n_ranks) * _N : frames * _N;
+            if (_shard.scatter && frames % static_cast<std::size_t>(_shard.n_ranks)) throw std::runtime_error("reduce_scatter fan-in: the exchange's frame count is not a multiple of the rank count");
+            if (_out->free_items() < n_out) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
+            const std::size_t n = frames * _N;
+            // samples of every local branch land in HBM (pinned staging, one stream: the copies of branch c + 1 run behind those of branch c)
+            std::vector<gr4hip_chain_t*> chains;
+            std::vector<const void*>     ins;
+            for (auto& b : _branches) {
+                b.in->read_items(b.h_in.ensure(n * 8), n);
+                check(gr4hip_memcpy_h2d(b.d_in.ensure(n * 8), b.h_in.p, n * 8, _s), "h2d");
+                chains.push_back(b.chain);
+                ins.push_back(b.d_in.p);
+            }
+            // ONE launch for all local channels, the local part of math::Add as its store epilogue
+            std::size_t got = 0;
+            check(gr4hip_chain_process_multi(chains.data(), chains.size(), ins.data(), n, nullptr, static_cast<float*>(_d_partial.ensure(n * 4)), &got, _s), "gr4hip_chain_process_multi");
+            ++_launches;
+            const float* result = static_cast<const float*>(_d_partial.p);
+            if (_shard.comm) { // the combiner's inputs that live on other devices: one collective per exchange
+                float* sum = static_cast<float*>(_d_sum.ensure(n_out * 4));
+                if (_shard.scatter) check(gr4hip_fanin_reduce_scatter_sum_f32(_shard.comm, result, sum, n_out, _s), "gr4hip_fanin_reduce_scatter_sum_f32");
+                else check(gr4hip_fanin_all_reduce_sum_f32(_shard.comm, result, sum, n_out, _s), "gr4hip_fanin_all_reduce_sum_f32");
+                result = sum;
+                ++_exchanges;
+            } else if (_shard.n_ranks != 1) {
+                throw std::runtime_error("sharded graph without a communicator");
+            }
+            check(gr4hip_memcpy_d2h(_h_out.ensure(n_out * 4), result, n_out * 4, _s), "d2h");
+            check(gr4hip_stream_synchronize(_s), "stream synchronize");
+            _out->write_items(_h_out.p, n_out);
+            return {requested, n_out, work::Status::OK};
+        } catch (const std::exception& e) {
+            std::cerr << "[gr::hip] fan-in run failed: " << e.what() << "\n";
+            return {requested, 0, work::Status::ERROR};
+        }
+    }
+    std::string_view     name() const override { return _name; }
+    std::string_view     type_name() const override { return "gr::hip::FanInRun"; }
+    const ComputeDomain& compute_domain() const override { return _domain; }
+    void*                raw() override { return this; }
+    std::type_index      port_type(std::string_view) override { return typeid(void); }
+    std::shared_ptr<EdgeBufferBase> make_edge(std::string_view, std::size_t, std::pmr::memory_resource*) override { return nullptr; }
+    bool attach_input(std::string_view, std::shared_ptr<EdgeBufferBase>) override { return false; }
+    std::vector<std::shared_ptr<EdgeBufferBase>> input_edges() override {
+        std::vector<std::shared_ptr<EdgeBufferBase>> v;
+        for (auto& b : _branches) v.push_back(b.in);
+        return v;
+    }
+    std::vector<std::shared_ptr<EdgeBufferBase>> output_edges() override { return {_out}; }
+};
+
+// Finds every combiner  Add<float>(n inputs)  all of whose inputs are  fir_filter<complex<float>> -> PowerSpectrum  branches on "gpu:hip:i" domains and replaces
+// combiner + branches by one FanInRun for this rank (see above).  Returns the runs it created; graphs without such a combiner are left alone.
+inline std::vector<FanInRun*> plan_sharded(Graph& g, const Shard& shard, std::size_t run_edge_items = std::size_t(1) << 22) {
+    auto& blocks = g.blocks();
+    const auto producer = [&](const std::shared_ptr<EdgeBufferBase>& e) -> BlockModel* {
+        for (auto& b : blocks)
+            for (auto& out : b->output_edges())
+                if (out == e) return b.get();
+        return nullptr;
+    };
+    const auto hip_device = [](BlockModel& b) { const auto& d = b.compute_domain(); return d.is_device() && (d.backend.empty() || d.backend == "hip"); };
+    std::vector<FanInRun*> runs;
+    for (std::size_t pos = 0; pos < blocks.size(); ++pos) {
+        BlockModel* add = blocks[pos].get();
+        const std::string_view tn = add->type_name();
+        if (tn.find("MathOpMultiPortImpl") == std::string_view::npos && tn.find("math::Add") == std::string_view::npos) continue;
+        if (add->port_type("out") != typeid(float)) continue;
+        const auto ins = add->input_edges();
+        if (ins.size() < 1 || add->output_edges().size() != 1) continue;
+        struct Found { BlockModel *fir, *spec; std::vector<BlockModel*> upstream; std::vector<float> taps; std::size_t N; int window; int device; };
+        std::vector<Found> found;
+        bool               ok = true;
+        for (auto& e : ins) {
+            BlockModel* spec = e ? producer(e) : nullptr;
+            BlockModel* fir  = spec && spec->input_edges().size() == 1 ? producer(spec->input_edges()[0]) : nullptr;
+            if (!spec || !fir || !hip_device(*spec) || !hip_device(*fir) || fir->input_edges().size() != 1) { ok = false; break; }
+            auto ss = std::dynamic_pointer_cast<PowerSpectrumStage>(std::static_pointer_cast<Stage>(spec->make_device_stage()));
+            auto fs = std::dynamic_pointer_cast<FirStage<std::complex<float>>>(std::static_pointer_cast<Stage>(fir->make_device_stage()));
+            if (!ss || !fs) { ok = false; break; }
+            Found f{fir, spec, {}, fs->taps, ss->N, ss->window, fir->compute_domain().index};
+            // everything upstream of the branch feeds only this branch: it leaves the schedule with it when the branch lives on another rank
+            std::vector<BlockModel*> todo{fir};
+            while (!todo.empty()) {
+                BlockModel* b = todo.back();
+                todo.pop_back();
+                for (auto& ie : b->input_edges())
+                    if (BlockModel* up = ie ? producer(ie) : nullptr) { f.upstream.push_back(up); todo.push_back(up); }
+            }
+            found.push_back(std::move(f));
+        }
+        if (!ok || found.empty()) continue;
+        for (auto& f : found) ok = ok && f.N == found[0].N && f.window == found[0].window;
+        if (!ok) continue;
+        std::vector<std::pair<std::shared_ptr<EdgeBufferBase>, std::vector<float>>> local;
+        std::vector<BlockModel*> retire;
+        int                      device = -1;
+        for (auto& f : found) {
+            const bool mine = f.device % shard.n_ranks == shard.rank;
+            if (mine) {
+                if (run_edge_items) (void)f.fir->input_edges()[0]->ensure_capacity(run_edge_items);
+                local.emplace_back(f.fir->input_edges()[0], f.taps);
+                if (device < 0) device = f.device;
+            } else {
+                for (auto* up : f.upstream) retire.push_back(up); // the other ranks' sources are not this process' business
+            }
+            retire.push_back(f.fir);
+            retire.push_back(f.spec);
+        }
+        retire.push_back(add);
+        ComputeDomain dom = found[0].fir->compute_domain();
+        if (device >= 0) dom.index = device;
+        auto  run = std::make_unique<FanInRun>(std::move(local), add->output_edges()[0], found[0].N, found[0].window, found.size(), shard, dom);
+        auto* ref = run.get();
+        std::vector<std::unique_ptr<BlockModel>> kept;
+        for (auto& bp : blocks) {
+            if (bp.get() == add) kept.push_back(std::move(run));
+            if (std::find(retire.begin(), retire.end(), bp.get()) != retire.end()) g.retired().push_back(std::move(bp)); // (callers hold references to the blocks)
+            else kept.push_back(std::move(bp));
+        }
+        blocks = std::move(kept);
+        runs.push_back(ref);
+        pos = static_cast<std::size_t>(-1); // the block list changed: start over (combiners already replaced are FanInRuns now)
     }
     return runs;
 }

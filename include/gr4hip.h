@@ -280,6 +280,30 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
 int gr4hip_chain_set_max_workgroups(gr4hip_chain_t* chain, unsigned n);
 int gr4hip_chain_destroy(gr4hip_chain_t* chain);
 
+/* ------------------------------------------------------------------------------------------------ e: the cross-device combiner edge
+ * A flowgraph shards across the GPUs of a node only along independent branches (one SDR channel per GPU); the one exchange step is the
+ * combiner MathOpMultiPortImpl<float, std::plus> (blocks/math/.../Math.hpp:73-108) whose inputs sit on different "gpu:hip:i" compute domains
+ * (ComputeDomain.hpp:47-100; EdgeParameters.domain, BlockModel.hpp:64-72).  Every rank folds its own channels (gr4hip_chain_process_multi /
+ * gr4hip_math_nary) and these calls add the partial sums over RCCL (xGMI): one process per GPU, one communicator rank per process, the collective
+ * queued on a caller stream like every other call here.  librccl is opened at run time (an RCCL the process already carries is reused; GR4HIP_RCCL_LIBRARY
+ * names one explicitly) -- GR4HIP_UNSUPPORTED with the reason in gr4hip_last_error() when there is none.
+ *   gr4hip_fanin_unique_id   rank 0 draws the 128-byte id; the caller ships it to the other ranks (file, socket, MPI, a torch.distributed store ...)
+ *   gr4hip_fanin_create      collective over all ranks; binds the communicator to the calling thread's current device (gr4hip_set_device)
+ *   ..._reduce_scatter_sum   d_partial: n_ranks shards of shard_count floats (this rank's partial sum of every shard); d_shard: the all-rank sum of shard `rank`
+ *   ..._all_to_all_sum       the same result as point-to-point sends (one xGMI link per peer, all busy at once) + a left fold in RANK order: the reduction
+ *                            order does not depend on RCCL's ring; d_scratch: n_ranks * shard_count floats
+ *   ..._all_reduce_sum       every rank gets the whole sum (a sink that lives on every rank, or on one)
+ * In-place operation (d_shard inside d_partial etc.) follows RCCL's rules. */
+typedef struct gr4hip_fanin gr4hip_fanin_t;
+#define GR4HIP_FANIN_ID_BYTES 128
+int gr4hip_fanin_unique_id(void* id128);
+int gr4hip_fanin_create(gr4hip_fanin_t** fanin, const void* id128, int rank, int n_ranks);
+int gr4hip_fanin_rank(const gr4hip_fanin_t* fanin, int* rank, int* n_ranks);
+int gr4hip_fanin_reduce_scatter_sum_f32(gr4hip_fanin_t* fanin, const float* d_partial, float* d_shard, size_t shard_count, gr4hip_stream_t stream);
+int gr4hip_fanin_all_to_all_sum_f32(gr4hip_fanin_t* fanin, const float* d_partial, float* d_scratch, float* d_shard, size_t shard_count, gr4hip_stream_t stream);
+int gr4hip_fanin_all_reduce_sum_f32(gr4hip_fanin_t* fanin, const float* d_partial, float* d_sum, size_t count, gr4hip_stream_t stream);
+int gr4hip_fanin_destroy(gr4hip_fanin_t* fanin);
+
 /* ------------------------------------------------------------------------------------------------ a11/a12/a13
  * MathOpImpl<T,op>::processOne (blocks/math/.../Math.hpp:38-56): out = in (op) value, C++ semantics for T
  * (integer promotion then narrowing, wrap-around).  h_value points to one host element of `dtype`.

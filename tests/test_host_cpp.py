@@ -222,3 +222,58 @@ def test_signal_generator_is_the_reference_core(host_bins, tmp_path):
                 continue
             err = np.abs(got.astype(np.complex128) - want.astype(np.complex128)).max()
             assert t not in (0, 3, 8, 9) and err <= (1 if dt == np.int16 else 4e-6 if dt in (np.float32, np.complex64) else 1e-12), (tname, t, err)
+
+
+@pytest.mark.gpu
+def test_sharded_graph_one_rank_communicator(host_bins, tmp_path):
+    """the 8-channel graph of BASELINE configs[4] written with compute_domain: gpu:hip:{c mod N} per branch and planned by gr::hip::plan_sharded for one rank:
+    all channels in ONE launch per exchange (gr4hip_chain_process_multi, the local part of math::Add as its store epilogue), the cross-device edge as an RCCL
+    collective on a one-rank communicator (ncclCommInitRank / ncclAllReduce / ncclReduceScatter execute; the transport does not).  Against the oracle sum."""
+    N, frames, ntaps, C = 8192, 10, 256, 8
+    x, b = _inputs(tmp_path, N, frames, ntaps)
+    r = subprocess.run([os.path.join(host_bins, "test_host_fanin"), str(tmp_path / "in.bin"), str(tmp_path / "taps.bin"), str(N), str(tmp_path / "o"), str(C)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "communicator: rank 0 of 1" in r.stdout and "all sharded-graph checks passed" in r.stdout
+    assert "plan for rank 0 of 2: ok (4 local channels, 6 blocks)" in r.stdout
+
+    def rel(got, truth):
+        rms = np.sqrt(np.mean(np.abs(truth) ** 2))
+        return float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), rms)))
+    for variant, gains in ((0, [1.0] * C), (1, [1.0 + 0.125 * c for c in range(C)]), (2, [1.0] * C)):
+        want = 0.0
+        for c in range(C):
+            t, _ = O.chain((b.astype(np.float64) * gains[c]).astype(np.float32), np.roll(x, -977 * c), N, 0, truth=True)
+            want = want + t
+        got = np.fromfile(tmp_path / f"o_fanin{variant}.bin", np.float32)
+        assert len(got) == frames * N and rel(got, want) <= 1e-5, variant
+
+
+@pytest.mark.gpu
+def test_fanin_entry_points_one_rank():
+    """gr4hip_fanin_* straight through the C-ABI on a one-rank communicator: reduce_scatter, all_to_all + rank-order fold and all_reduce all return the input"""
+    import ctypes as C
+    import torch
+    import gnuradio4_amd as G
+    L = G.capi.lib()
+    ident = (C.c_char * 128)()
+    G.capi.check(L.gr4hip_fanin_unique_id(ident), "unique_id")
+    h = C.c_void_p()
+    G.capi.check(L.gr4hip_fanin_create(C.byref(h), ident, 0, 1), "create")
+    rk, nr = C.c_int(-1), C.c_int(-1)
+    G.capi.check(L.gr4hip_fanin_rank(h, C.byref(rk), C.byref(nr)), "rank")
+    assert (rk.value, nr.value) == (0, 1)
+    x = torch.randn(4 * 8192, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for name in ("reduce_scatter", "all_to_all", "all_reduce"):
+        out = torch.zeros_like(x)
+        if name == "reduce_scatter":
+            G.capi.check(L.gr4hip_fanin_reduce_scatter_sum_f32(h, x.data_ptr(), out.data_ptr(), x.numel(), st), name)
+        elif name == "all_to_all":
+            scratch = torch.empty_like(x)
+            G.capi.check(L.gr4hip_fanin_all_to_all_sum_f32(h, x.data_ptr(), scratch.data_ptr(), out.data_ptr(), x.numel(), st), name)
+        else:
+            G.capi.check(L.gr4hip_fanin_all_reduce_sum_f32(h, x.data_ptr(), out.data_ptr(), x.numel(), st), name)
+        torch.cuda.synchronize()
+        assert torch.equal(out, x), name
+    G.capi.check(L.gr4hip_fanin_destroy(h), "destroy")
