@@ -317,6 +317,8 @@ def main():
         errs = []
         lastf = n // NFFT - 1
         cand = sorted({0, 1, 255, 256, frames_per_chunk - 1, frames_per_chunk, min(lastf, 3 * frames_per_chunk + 4097), lastf} & set(range(lastf + 1)))
+        if multi:  # only the sum exists: more of its frames
+            cand = sorted(set(cand) | ({2, 3, 127, 257, 511, 512, lastf // 2, lastf - 1} & set(range(lastf + 1))))
         if not combine or world == 1:  # per-channel spectra of this rank (and, for the one-GPU graph, their sum)
             for i in range(len(outs)):
                 for f in (cand if i == 0 else cand[:2]):

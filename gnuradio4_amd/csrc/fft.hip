@@ -8,6 +8,7 @@
 // (window fused into the load), all passes run in LDS, and every requested output is written once, coalesced.
 // The fused FIR->FFT->mag2 kernels live in chain_fused.hip.
 #include "fft_kernels.hpp"
+#include "fft_smooth.hpp"
 
 namespace gr4 {
 
@@ -381,6 +382,11 @@ struct gr4hip_fft {
 namespace gr4 {
 // shared with chain.hip
 int fft_build_plan(size_t N, FftPlanDev* plan) {
+    plan->smooth = 0;
+    if (!is_pow2(N) && fft_is_smooth235(N) && N <= 8192) { // SimdFFT's radix-3 / radix-5 sizes (SimdFFT.hpp:348-375): mixed-radix passes, one launch
+        plan->smooth = 1;
+        return fft_build_smooth_plan(N, plan);
+    }
     if (!is_pow2(N) || N < 2) { set_error("fft: size %zu is not a power of two >= 2 (device path)", N); return GR4HIP_UNSUPPORTED; }
     if (N > 8192) { set_error("fft: size %zu exceeds the single-workgroup LDS path (max 8192)", N); return GR4HIP_UNSUPPORTED; }
     plan->N  = (int)N;
@@ -409,6 +415,7 @@ int fft_upload_twiddles(size_t N, DeviceBuffer* buf) {
 }
 
 int fft_launch(const FftPlanDev& plan, const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
+    if (plan.smooth) return fft_smooth_launch(plan, d_in, d_window, d_tw, o, n_frames, st);
     if (o.real_input && !o.spectrum && !o.mag2) { // real frames of 2N samples as N complex points + split (half the butterflies)
         switch (plan.N) {
         case 512: return fft_fast_launch<8, true>(d_in, d_window, d_tw, o, n_frames, st);
@@ -508,7 +515,7 @@ int gr4hip_fft_create(gr4hip_fft_t** out, int in_dtype, size_t fft_size, int win
     f->window   = window;
     f->flags    = flags;
     int rc = GR4HIP_OK;
-    if (is_pow2(fft_size) && fft_size >= 2 && fft_size <= 8192) {
+    if ((is_pow2(fft_size) || fft_is_smooth235(fft_size)) && fft_size >= 2 && fft_size <= 8192) {
         rc = fft_build_plan(fft_size, &f->plan);
         if (!rc) rc = fft_upload_twiddles(fft_size, &f->d_tw);
     } else if (is_pow2(fft_size) && fft_size <= kFftMaxPow2) { // 16384 .. 2^20: four-step with 4096-point rows
@@ -668,7 +675,7 @@ static int fft_run(gr4hip_fft_t* f, const void* d_in, size_t n_frames, FftOutput
         if (rc) return rc;
         return fft_finish(f, o, d_phase_final, d_ranges, n_frames, nout, unwrap, false, st);
     }
-    const bool fast         = f->N >= 256 && f->N <= 8192; // fft_fast_kernel sizes (all powers of two there)
+    const bool fast         = f->N >= 256 && f->N <= 8192 && !f->plan.smooth; // fft_fast_kernel sizes (powers of two; the mixed-radix kernel leaves the ranges to ranges_kernel)
     const bool fused_ranges = d_ranges && fast && !unwrap;  // the unwrapped phase only exists after unwrap_kernel
     o.ranges                = fused_ranges ? d_ranges : nullptr;
     int rc = fft_launch(f->plan, static_cast<const float*>(d_in), static_cast<const float*>(f->d_window.ptr), static_cast<const float2*>(f->d_tw.ptr), o,

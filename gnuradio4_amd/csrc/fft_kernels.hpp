@@ -20,6 +20,7 @@ struct FftPlanDev {
     int radix[16];
     int tf;  // threads per frame
     int fpb; // frames per block
+    int smooth; // 1: mixed-radix plan of fft_smooth.hpp (radices 2 .. 16, N not a power of two)
 };
 
 struct FftOutputs {

@@ -691,6 +691,33 @@ def test_fft_any_size_bluestein(G, N):
     assert _rel(out["magnitude"][0].cpu().numpy(), mag) <= TOL and _rel(out["re"][0].cpu().numpy(), re) <= TOL
 
 
+@pytest.mark.parametrize("N", [6, 12, 15, 45, 100, 243, 360, 1000, 1536, 1920, 3000, 3125, 3750, 4000, 6000, 6561, 7680, 7776, 8000])
+def test_fft_smooth_sizes_mixed_radix(G, N):
+    """{2,3,5}-smooth sizes that are not powers of two -- the sizes SimdFFT::canProcessSize takes with radix-3 / radix-5 passes (SimdFFT.hpp:348-375, the
+    reference benchmark sweeps one: bm_fft.cpp:44-58) -- run as mixed-radix Stockham passes in ONE launch (fft_smooth.hpp: radices 2 .. 16, prime-factor 6 / 10 /
+    12 / 15), every output of the block, complex and real input, odd sizes included; truth: the float64 DFT"""
+    frames = 7
+    x = O.signal_c32(N, frames * N + 3)
+    F = G.FFT(N, "Hann")
+    w = O.window(3, N)
+    got = F.spectrum(dev(x)).cpu().numpy()
+    assert got.shape == (frames, N)
+    for f in range(frames):
+        truth = O.dft64(x[f * N:(f + 1) * N].astype(np.complex128) * w)
+        assert _rel(got[f], truth) <= TOL, f
+    out = F.process_bulk(dev(x))
+    mag, ph, re, im = O.fft_block_truth(x[:N], 3)
+    assert _rel(out["magnitude"][0].cpu().numpy(), mag) <= TOL and _rel(out["re"][0].cpu().numpy(), re) <= TOL and _rel(out["im"][0].cpu().numpy(), im) <= TOL
+    m2 = F.mag2(dev(x[: frames * N])).cpu().numpy()
+    assert _rel(m2, np.abs(got.astype(np.complex128)) ** 2) <= TOL
+    if N % 2 == 0:  # real input (computeHalfSpectrum): first N / 2 bins of magnitude / phase
+        xr = O.signal_f32(N + 1, frames * N)
+        Fr = G.FFT(N, "Hamming", dtype=torch.float32)
+        o2 = Fr.process_bulk(dev(xr))
+        tm = np.abs(O.dft64(xr[:N].astype(np.complex128) * O.window(2, N)))[: N // 2] * 2.0 / N
+        assert _rel(o2["magnitude"][0].cpu().numpy(), tm) <= TOL
+
+
 @pytest.mark.parametrize("N", [6000, 10000, 30000, 48000, 65535, 100003, 3 ** 7 * 5 ** 3, 1 << 19])
 def test_fft_any_size_beyond_one_workgroup(G, N):
     """sizes SimdFFT takes with radix-3/5 passes (SimdFFT.hpp:348-375: 6000, 10000, 30000, 48000, 3^7 5^3) and sizes the reference sends to Bluestein
