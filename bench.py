@@ -352,8 +352,9 @@ def main():
         committed = None  # HBM bytes per launch from the committed PMC profile of the same kernel + launch size (profiles/); this run does not measure it
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-            if prof.get("kernel") == KERNEL_SYMBOLS.get(algo) and prof.get("samples_per_launch") == chunk:
-                committed = prof["hbm_bytes_per_launch"]
+            if prof.get("kernel") == KERNEL_SYMBOLS.get(algo) and prof.get("samples_per_launch"):
+                # the PMC passes profile one 2^28-sample launch; traffic is proportional to the frames a launch covers (every frame is read and written once)
+                committed = int(round(prof["hbm_bytes_per_launch"] * (chunk / prof["samples_per_launch"])))
         except Exception:
             pass
         per_gpu = len(mine)

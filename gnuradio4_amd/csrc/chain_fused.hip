@@ -82,6 +82,7 @@ struct ChainFdMulti {
     float*        outs[kMaxMulti];
     float*        pws[kMaxMulti];
     float*        pw_hosts[kMaxMulti];
+    unsigned      pw_seqs[kMaxMulti];
 };
 
 // pass-A layout: rows 0..15 at r * kRowA, rows 16..31 shifted by 16 float2 (32 banks).  A ds_read/write_b64 is served in two groups of 32
@@ -260,7 +261,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
             C = mc->fold_ch;
         } else { // this workgroup belongs to ONE channel: its pointers take the place of the single-channel arguments
             const int c = (int)(blockIdx.x % (unsigned)mc->n_ch);
-            a.x = mc->xs[c]; a.hist = mc->hists[c]; a.H = mc->Hs[c]; a.efrag = mc->efrags[c]; a.out = mc->outs[c]; a.pw = mc->pws[c]; a.pw_host = mc->pw_hosts[c];
+            a.x = mc->xs[c]; a.hist = mc->hists[c]; a.H = mc->Hs[c]; a.efrag = mc->efrags[c]; a.out = mc->outs[c]; a.pw = mc->pws[c]; a.pw_host = mc->pw_hosts[c]; a.pw_seq = mc->pw_seqs[c];
             fstart = blockIdx.x / (unsigned)mc->n_ch;
             fstride = gridDim.x / (unsigned)mc->n_ch;
             gslot = (unsigned)fstart; gcount = (unsigned)fstride;
@@ -746,9 +747,11 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                     float tin = 0.f, tout = 0.f;
                     for (int k = 0; k < 16; ++k) { tin += atomicExch(a.pw + 2 * k, 0.f); tout += atomicExch(a.pw + 2 * k + 1, 0.f); }
                     atomicExch(done, 0u);
-                    // ONE 8-byte store: the pair arrives whole, and a pair that differs from the last one seen is a new measurement
-                    (void)a.pw_seq;
+                    // ONE 8-byte store: the pair arrives whole; then, behind a system-scope fence, the launch's sequence number -- what a waiting host spins on
+                    // (a few microseconds after the last workgroup instead of a stream synchronisation's wake-up)
                     *reinterpret_cast<volatile unsigned long long*>(a.pw_host) = (unsigned long long)__float_as_uint(tin) | ((unsigned long long)__float_as_uint(tout) << 32);
+                    __threadfence_system();
+                    reinterpret_cast<volatile unsigned*>(a.pw_host)[2] = a.pw_seq;
                 }
             }
         }
@@ -794,6 +797,7 @@ struct ChainFused {
     unsigned     pw_seq   = 0;         // measured launches so far
     unsigned     pw_read  = 0;         // launches accounted for by the measurements handed out
     unsigned long long pw_word = 0;    // the last {in, out} pair seen
+    unsigned     pw_seen  = 0;         // sequence number of the last measurement handed out
     hipStream_t  pw_stream = nullptr;  // stream of the last measured launch
     float        win_gain = 1.f;       // mean w[n]^2 of the window the measured output carries (1: none)
     ~ChainFused() {
@@ -1085,9 +1089,10 @@ int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps,
             if (rc) return rc;
             m.pws[i] = static_cast<float*>(c->d_pw.ptr);
             m.pw_hosts[i] = c->d_hpw;
+            m.pw_seqs[i] = c->pw_seq;
         }
     }
-    if (fold) { a.pw = m.pws[0]; a.pw_host = m.pw_hosts[0]; }
+    if (fold) { a.pw = m.pws[0]; a.pw_host = m.pw_hosts[0]; a.pw_seq = m.pw_seqs[0]; }
     constexpr size_t lds = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256) * sizeof(float) + 6 * 512 * sizeof(unsigned short); // = lds_ebf of chain_fused_run
     static PerDevice per_device;
     bool             first = false;
@@ -1120,9 +1125,20 @@ void chain_fused_destroy(ChainFused* c) { delete c; }
 void chain_fused_set_measure(ChainFused* c, bool on) { c->measure = on; }
 int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio) {
     if (!c->h_pw || c->pw_seq == c->pw_read) return 0;
-    if (wait && hipStreamSynchronize(c->pw_stream) != hipSuccess) return 0;
+    volatile unsigned* seqw = reinterpret_cast<volatile unsigned*>(c->h_pw) + 2; // sequence number of the launch whose pair the word holds
+    if (wait) { // spin on the mapped word the launch's last workgroup writes; every 4096 polls check that the stream has not simply failed / finished without it
+        for (unsigned long spins = 1; *seqw != c->pw_seq; ++spins) {
+            if ((spins & 4095) == 0 && hipStreamQuery(c->pw_stream) != hipErrorNotReady) {
+                if (hipStreamSynchronize(c->pw_stream) != hipSuccess) return 0;
+                if (*seqw != c->pw_seq) return 0; // (a launch that measured nothing)
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+    }
     const unsigned long long word = *reinterpret_cast<volatile unsigned long long*>(c->h_pw); // {in, out} of the most recent finished launch, stored whole
-    if (!wait && word == c->pw_word) return 0;                                                  // nothing new has arrived
+    if (!wait && *seqw == c->pw_seen) return 0;                                                 // nothing new has arrived
+    c->pw_seen = *seqw;
     c->pw_word = word;
     c->pw_read = c->pw_seq; // (with wait: exactly; without: at least one newer launch has reported)
     float pair[2];

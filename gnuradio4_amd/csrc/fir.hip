@@ -536,14 +536,18 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         const bool guarded = f->guard_mode != GR4HIP_GUARD_OFF && f->ntaps > 1;
         float      ratio;
         if (guarded && fir_decim_fd_power_ratio(f->dfd, false, &ratio)) f->fd_ratio = ratio;
-        if (guarded && f->guard_mode == GR4HIP_GUARD_DEFERRED && f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) f->fd_blocked = true;
+        // threshold: this kernel's floor is one forward 4096-point and one inverse 1024-point transform -- measured (tools/decim_fd_floor.py) max 2.5e-7 .. 3.7e-7, rms 7e-8 of
+        // the INPUT rms per output sample, six times below the fused chain's -- so 1e-5 of the OUTPUT rms holds down to a power ratio of (4e-7 / 1e-5)^2 = 1.6e-3; 2.5e-3
+        // (-26 dB) with margin.  White noise through a DC-gain-1 low-pass of cut-off fc passes 2 fc of its power: every anti-alias filter down to fc = 0.00125 stays here.
+        constexpr float kDecimFdMinPowerRatio = 2.5e-3f;
+        if (guarded && f->guard_mode == GR4HIP_GUARD_DEFERRED && f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) f->fd_blocked = true;
         if (!f->fd_blocked) {
             rc = fir_decim_fd_run(f->dfd, x, n_in, hist, (int)f->hcap, y, st, guarded);
             if (rc) return rc;
             done = n_in;
             if (guarded && f->guard_mode == GR4HIP_GUARD_STRICT) {
                 if (fir_decim_fd_power_ratio(f->dfd, true, &ratio)) f->fd_ratio = ratio;
-                if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) { f->fd_blocked = true; done = 0; }
+                if (f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) { f->fd_blocked = true; done = 0; }
             }
         }
     }

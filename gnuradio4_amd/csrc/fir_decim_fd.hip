@@ -25,6 +25,7 @@
 #include "wave16_common.hpp"
 
 #include <cmath>
+#include <cstring>
 #include <complex>
 
 namespace gr4 {
@@ -55,7 +56,9 @@ struct DecimFdArgs {
     const float*  x_tail;
     long          tail_blk;
     int           tail_out;
-    float*        pw;      // dynamic-range guard (optional): 16 slots of {sum x^2, sum y^2} over every 16th block of every workgroup (8192 inputs / <= 896 outputs each)
+    float*        pw;      // dynamic-range guard (optional): 16 slots of {sum x^2, sum y^2} over every 16th block of every workgroup (8192 inputs / <= 896 outputs each), then the workgroups-done counter
+    float*        pw_host; // page-locked, device-mapped {in, out, sequence number}: written by the last workgroup to finish
+    unsigned      pw_seq;
 };
 
 __device__ __forceinline__ void ifft8(float2 (&v)[8]) { // inverse DFT-8: the forward butterfly on (im, re)
@@ -233,10 +236,29 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
             pw_in += __shfl_xor(pw_in, off);
             pw_out += __shfl_xor(pw_out, off);
         }
-        if ((threadIdx.x & 63) == 0 && (pw_in != 0.f || pw_out != 0.f)) {
-            float* slot = a.pw + 2 * ((blockIdx.x * 8 + (threadIdx.x >> 6)) & 15);
-            atomicAdd(slot, pw_in);
-            atomicAdd(slot + 1, pw_out);
+        // one pair of atomics per WORKGROUP, spread over 16 slots (a pair per wave -- 8192 atomics on 32 addresses -- cost ~35 us at the end of a 176 us launch)
+        __syncthreads(); // every lane is past the final pass: the G / F buffer is free (the landing buffer is not: the last block's re-read may still be in flight)
+        float* red = reinterpret_cast<float*>(smem_df + kDfOffF);
+        if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = pw_in; red[2 * (threadIdx.x >> 6) + 1] = pw_out; }
+        __syncthreads();
+        if (threadIdx.x == 0) { // the last workgroup to finish folds the slots, re-arms them and hands the totals to the host (chain_fused.hip: same scheme)
+            float si = 0.f, so = 0.f;
+#pragma unroll
+            for (int w = 0; w < kDfT / 64; ++w) { si += red[2 * w]; so += red[2 * w + 1]; }
+            float* slot = a.pw + 2 * (blockIdx.x & 15);
+            atomicAdd(slot, si);
+            atomicAdd(slot + 1, so);
+            __threadfence();
+            unsigned* done = reinterpret_cast<unsigned*>(a.pw + 32);
+            if (atomicAdd(done, 1u) == gridDim.x - 1) {
+                __threadfence();
+                float tin = 0.f, tout = 0.f;
+                for (int k = 0; k < 16; ++k) { tin += atomicExch(a.pw + 2 * k, 0.f); tout += atomicExch(a.pw + 2 * k + 1, 0.f); }
+                atomicExch(done, 0u);
+                *reinterpret_cast<volatile unsigned long long*>(a.pw_host) = (unsigned long long)__float_as_uint(tin) | ((unsigned long long)__float_as_uint(tout) << 32);
+                __threadfence_system();
+                reinterpret_cast<volatile unsigned*>(a.pw_host)[2] = a.pw_seq;
+            }
         }
     }
 }
@@ -244,12 +266,12 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
 // ------------------------------------------------------------------------------------------------ host side
 struct FirDecimFd {
     DeviceBuffer d_twX, d_tw1, d_tw2, d_R, d_twI1, d_twI2, d_hist1024, d_stage, d_pw;
-    float*       h_pw = nullptr;     // page-locked copy of the 16 power slots of the last measured launch
-    hipEvent_t   pw_ev = nullptr;    // fires when h_pw holds them
-    bool         pw_pending = false;
+    float*       h_pw = nullptr;     // page-locked, device-mapped {in, out, sequence number} of the last measured launch that has finished
+    float*       d_hpw = nullptr;    // its device view
+    unsigned     pw_seq = 0, pw_seen = 0;
+    hipStream_t  pw_stream = nullptr;
     ~FirDecimFd() {
         if (h_pw) (void)hipHostFree(h_pw);
-        if (pw_ev) (void)hipEventDestroy(pw_ev);
     }
 };
 
@@ -347,14 +369,18 @@ int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float*
     a.R = static_cast<const float2*>(c->d_R.ptr); a.twI1 = static_cast<const float2*>(c->d_twI1.ptr); a.twI2 = static_cast<const float2*>(c->d_twI2.ptr);
     a.y = d_out; a.n_blocks = (long)n_blocks;
     if (measure) {
-        rc = c->d_pw.ensure(32 * sizeof(float));
-        if (rc) return rc;
         if (!c->h_pw) {
-            GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 32 * sizeof(float), hipHostMallocDefault));
-            GR4_HIP_TRY(hipEventCreateWithFlags(&c->pw_ev, hipEventDisableTiming));
+            rc = c->d_pw.ensure(36 * sizeof(float));
+            if (rc) return rc;
+            GR4_HIP_TRY(hipMemset(c->d_pw.ptr, 0, 36 * sizeof(float)));
+            GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 4 * sizeof(float), hipHostMallocMapped));
+            std::memset(c->h_pw, 0, 4 * sizeof(float));
+            GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_hpw), c->h_pw, 0));
         }
-        GR4_HIP_TRY(hipMemsetAsync(c->d_pw.ptr, 0, 32 * sizeof(float), st));
-        a.pw = static_cast<float*>(c->d_pw.ptr);
+        a.pw        = static_cast<float*>(c->d_pw.ptr);
+        a.pw_host   = c->d_hpw;
+        a.pw_seq    = ++c->pw_seq;
+        c->pw_stream = st;
     }
     static PerDevice per_device;
     bool             first = false;
@@ -368,22 +394,29 @@ int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float*
     const unsigned grid = (unsigned)std::min<size_t>(n_blocks, (size_t)2 * n_cu);
     hipLaunchKernelGGL(fir_decim_fd_kernel, dim3(grid), dim3(kDfT), kDfLds, st, a);
     GR4_LAUNCH_CHECK();
-    if (measure) {
-        GR4_HIP_TRY(hipMemcpyAsync(c->h_pw, c->d_pw.ptr, 32 * sizeof(float), hipMemcpyDeviceToHost, st));
-        GR4_HIP_TRY(hipEventRecord(c->pw_ev, st));
-        c->pw_pending = true;
-    }
     return GR4HIP_OK;
 }
 // mean output power / mean input power of the last measured launch's sampled blocks.  wait: synchronise on it; otherwise only when it has finished.
 // Returns 1 with *ratio set, 0 if nothing (new) is available.
 int fir_decim_fd_power_ratio(FirDecimFd* c, bool wait, float* ratio) {
-    if (!c->pw_pending) return 0;
-    if (wait) { if (hipEventSynchronize(c->pw_ev) != hipSuccess) return 0; }
-    else if (hipEventQuery(c->pw_ev) != hipSuccess) return 0;
-    c->pw_pending = false;
-    double in = 0, out = 0;
-    for (int k = 0; k < 16; ++k) { in += c->h_pw[2 * k]; out += c->h_pw[2 * k + 1]; }
+    if (!c->h_pw || c->pw_seq == c->pw_seen) return 0;
+    volatile unsigned* seqw = reinterpret_cast<volatile unsigned*>(c->h_pw) + 2;
+    if (wait) { // spin on the mapped word (a few microseconds behind the last workgroup); a stream that has finished without writing it ends the wait
+        for (unsigned long spins = 1; *seqw != c->pw_seq; ++spins) {
+            if ((spins & 4095) == 0 && hipStreamQuery(c->pw_stream) != hipErrorNotReady) {
+                if (hipStreamSynchronize(c->pw_stream) != hipSuccess || *seqw != c->pw_seq) return 0;
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+    } else if (*seqw == c->pw_seen) {
+        return 0;
+    }
+    const unsigned long long word = *reinterpret_cast<volatile unsigned long long*>(c->h_pw);
+    c->pw_seen = *seqw;
+    float pair[2];
+    std::memcpy(pair, &word, sizeof(pair));
+    const double in = pair[0], out = pair[1];
     // per sampled block: 8192 input samples (the overlap counted twice: statistics only), 896 outputs
     *ratio = in > 0 ? (float)((out / (kDfHop / 8)) / (in / kDfN)) : 1.f;
     return 1;

@@ -48,10 +48,10 @@ res["configs[2] decim-8 1024-tap FIR + 4 biquads"] = {
     "fir_direct_form_equivalent_TFLOP/s": round(n / 8 * 2048 / t_fir / 1e12, 1),
     "note": "5.5 B/input sample: 4 in + 0.5 decimated stream written + 0.5 read + 0.5 out; the FIR runs as 8192-sample overlap-save blocks in the frequency domain "
             "(csrc/fir_decim_fd.hip), the polyphase MFMA kernel it replaces is FP32-bound at 256 flop/input sample"}
-os.environ["GR4HIP_FIR_NO_DECIM_FD"] = "1"
+capi.developer_switch("GR4HIP_FIR_NO_DECIM_FD", 1)
 fir_p = G.fir_filter(lowpass(1024, 0.05), torch.float32, decimate=8)
 t_firp = timeit(lambda: fir_p.process_bulk(x, yd))
-del os.environ["GR4HIP_FIR_NO_DECIM_FD"]
+capi.developer_switch("GR4HIP_FIR_NO_DECIM_FD", 0)
 res["configs[2] with the polyphase MFMA decimator (round-1 path)"] = {"Msamples/s (input rate, both kernels)": round(n / (t_firp + t_iir) / 1e6, 1), "fir_ms": round(t_firp * 1e3, 3),
                                                                       "fir_TFLOP/s": round(n / 8 * 2048 / t_firp / 1e12, 1)}
 del x, yd, yo

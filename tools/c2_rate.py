@@ -17,7 +17,7 @@ yd = torch.empty(n // 8, dtype=torch.float32, device="cuda"); yo = torch.empty_l
 iir = G.iir_filter(b, a)
 t_iir = timeit(lambda: iir.process_bulk(yd, yo))
 for tag, env in (("frequency domain", None), ("polyphase MFMA", "1")):
-    if env: os.environ["GR4HIP_FIR_NO_DECIM_FD"] = env
+    capi.developer_switch("GR4HIP_FIR_NO_DECIM_FD", 1 if env else 0)
     fir = G.fir_filter(taps, torch.float32, decimate=8)
     t_fir = timeit(lambda: fir.process_bulk(x, yd))
     print("%-18s FIR %.3f ms = %6.1f G input samples/s (%.2f TB/s at 4.5 B/sample) | + IIR %.3f ms -> configs[2] %6.1f G input samples/s" % (tag, t_fir * 1e3, n / t_fir / 1e9, n * 4.5 / t_fir / 1e12, t_iir * 1e3, n / (t_fir + t_iir) / 1e9))

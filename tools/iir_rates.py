@@ -16,8 +16,7 @@ for log2n in [int(v) for v in os.environ.get('IIR_LOG2N', '24,26,27').split(',')
     for name, mk in (("4 biquads (Butterworth-8, fc 0.05)", lambda: G.iir_filter(b4, a4)), ("1-pole low-pass a = 0.95", lambda: G.iir_filter([[0.05]], [[1.0, -0.95]]))):
         out = []
         for env in (None, "1"):
-            if env: os.environ["GR4HIP_IIR_LOOKBACK"] = env
-            else: os.environ.pop("GR4HIP_IIR_LOOKBACK", None)
+            capi.developer_switch("GR4HIP_IIR_LOOKBACK", 1 if env else 0)
             out.append(rate(mk(), x, y))
-        os.environ.pop("GR4HIP_IIR_LOOKBACK", None)
+        capi.developer_switch("GR4HIP_IIR_LOOKBACK", 0)
         print("2^%d %-38s sequential runs %7.1f Gsamples/s (%.2f TB/s) | look-back %7.1f Gsamples/s" % (log2n, name, out[0], out[0] * 8 / 1e3, out[1]))

@@ -19,9 +19,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     ys = {}
     for mode in ("one", "three"):
         if mode == "three":
-            os.environ["GR4HIP_IIR_THREE_PASS"] = "1"
+            capi.developer_switch("GR4HIP_IIR_THREE_PASS", 1)
         else:
-            os.environ.pop("GR4HIP_IIR_THREE_PASS", None)
+            capi.developer_switch("GR4HIP_IIR_THREE_PASS", 0)
         f = G.iir_filter(b, a)
         y = torch.empty_like(x)
         for lo, hi in zip(cuts[:-1], cuts[1:]):
