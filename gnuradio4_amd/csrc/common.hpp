@@ -27,6 +27,7 @@ enum DevSwitch {
     kDevRotatorLeap,          // GR4HIP_ROTATOR_LEAP
     kDevRotatorWalk,          // GR4HIP_ROTATOR_WALK
     kDevChain16,              // GR4HIP_CHAIN16
+    kDevFftSmoothRuntime,     // GR4HIP_FFT_SMOOTH_RUNTIME: the run-time mixed-radix kernel also for sizes that have a compile-time plan
     kDevSwitchCount
 };
 int dev_switch(DevSwitch s);

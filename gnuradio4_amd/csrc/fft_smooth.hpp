@@ -210,6 +210,183 @@ __global__ __launch_bounds__(BS, 4) void fft_smooth_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ compile-time plans for the common sizes
+// The run-time kernel above pays for its generality: a call per pass, an integer division per butterfly, run-time strides.  The sizes an SDR chain actually
+// asks for (1000, 1200, 1536, 1920, 2000, 3000, 3072, 4000, 5000, 6000, 6144, 8000, ...) get the same passes with everything known at compile time -- as the
+// power-of-two kernels do: the first pass reads its inputs straight from global memory (window fused, coalesced), the last emits every output straight from
+// registers, a frame makes npass - 1 LDS round trips, twiddles from the LDS table + two power chains.
+template <int N, int R0, int R1, int R2, int R3>
+struct SmoothCT {
+    static constexpr int kR[4] = {R0, R1, R2, R3};
+    static constexpr int NP    = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    static constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+    static constexpr int tf_of(int R) { return R > 1 ? cdiv(N, R * (16 / R)) : 1; }
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int TF  = cmax(cmax(tf_of(R0), tf_of(R1)), cmax(tf_of(R2), tf_of(R3)));
+    static constexpr int FPB = cmax(1, (512 / TF) < (int)(40 * 1024 / (N * 8)) ? (512 / TF) : (int)(40 * 1024 / (N * 8)));
+    static constexpr int BS  = cdiv(TF * FPB, 64) * 64;
+    // twiddle table: a pass of radix R reads W_N^j for j = k SU and 2 k SU < 2 N / R only, and the first pass none: 2 N / (smallest later radix) entries instead
+    // of N (at N = 6000 the difference between one and two workgroups per CU)
+    static constexpr int need(int R) { return R > 2 ? (2 * N) / R : (R == 2 ? N / 2 : 0); } // (radix 2 multiplies by W^k only)
+    static constexpr int TW  = cmax(cmax(need(R1), need(R2)), need(R3)) + 2;
+    static constexpr size_t LDS = ((size_t)FPB * N + TW) * sizeof(float2);
+    static_assert(R0 * R1 * R2 * R3 == N && BS <= 1024, "plan");
+};
+
+template <int N, int R, int P /*product of the radices before this pass*/, bool FIRST, bool LAST, int TF>
+__device__ __forceinline__ void smooth_ct_pass(float2* buf, int t, const float2* twl, const float* __restrict__ x, const float* __restrict__ window, const FftOutputs& out, long frame, bool live) {
+    constexpr int NBL = 16 / R, NB = N / R, SU = N / (P * R);
+    float2        v[NBL][R];
+    int           kk[NBL];
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) {
+        const int i = t + b * TF;
+        kk[b] = 0;
+        if (i < NB) {
+            if constexpr (FIRST) {
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int   n = i + r * NB;
+                        const float w = window ? window[n] : 1.f;
+                        if (out.real_input) v[b][r] = make_float2(x[n] * w, 0.f);
+                        else { const float2 s_ = reinterpret_cast<const float2*>(x)[n]; v[b][r] = make_float2(s_.x * w, s_.y * w); }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[b][r] = make_float2(0.f, 0.f);
+                }
+            } else {
+                const int k = i % P;
+                kk[b] = k;
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[b][r] = buf[i + r * NB];
+                if (k > 0) { // W_{PR}^{r k} = tw[r k SU]
+                    const float2 w1 = twl[k * SU];
+                    v[b][1] = cmulf(v[b][1], w1);
+                    if constexpr (R > 2) {
+                        const float2 w2 = twl[2 * k * SU];
+                        float2       wo = w1, we = w2;
+                        v[b][2] = cmulf(v[b][2], we);
+#pragma unroll
+                        for (int r = 3; r < R; r += 2) {
+                            wo      = cmulf(wo, w2);
+                            v[b][r] = cmulf(v[b][r], wo);
+                            if (r + 1 < R) {
+                                we          = cmulf(we, w2);
+                                v[b][r + 1] = cmulf(v[b][r + 1], we);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (!FIRST && !LAST) __syncthreads(); // in place: everybody has read before anybody writes
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) {
+        const int i = t + b * TF;
+        if (i < NB) {
+            dft_any<R>(v[b]);
+            if constexpr (LAST) {
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) emit_bin(out, frame, N, i + r * NB, v[b][r]); // P R = N: k = i, the outputs are i + r N / R
+                }
+            } else {
+                const int base = (i - kk[b]) * R + kk[b];
+#pragma unroll
+                for (int r = 0; r < R; ++r) buf[base + r * P] = v[b][r];
+            }
+        }
+    }
+    if constexpr (!LAST) __syncthreads();
+}
+
+template <int N, int R0, int R1, int R2, int R3>
+__global__ __launch_bounds__((SmoothCT<N, R0, R1, R2, R3>::BS), 2) void fft_smooth_ct_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ tw, FftOutputs out,
+                                                                                               long n_frames) {
+    using PL = SmoothCT<N, R0, R1, R2, R3>;
+    constexpr int TF = PL::TF, FPB = PL::FPB;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float2* twl = lds;
+    for (int i = threadIdx.x; i < PL::TW && i < N; i += blockDim.x) twl[i] = tw[i];
+    __syncthreads();
+    const long ngroups = (n_frames + FPB - 1) / FPB;
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid)); // (lane-dependent offsets recomputed per iteration instead of hoisted into dozens of registers)
+        const int  fl = tid / TF, t = fl < FPB ? tid - fl * TF : N;
+        float2*    buf = lds + PL::TW + (size_t)(fl < FPB ? fl : 0) * N;
+        const long frame = g * FPB + fl;
+        const bool live = frame < n_frames && fl < FPB;
+        const float* xf = in + (live ? frame : 0) * N * (out.real_input ? 1 : 2);
+        constexpr bool two = PL::NP == 2, three = PL::NP == 3, four = PL::NP == 4;
+        static_assert(two || three || four, "two to four passes");
+        smooth_ct_pass<N, R0, 1, true, false, TF>(buf, t, twl, xf, window, out, frame, live);
+        if constexpr (two) {
+            smooth_ct_pass<N, R1, R0, false, true, TF>(buf, t, twl, xf, window, out, frame, live);
+        } else {
+            smooth_ct_pass<N, R1, R0, false, false, TF>(buf, t, twl, xf, window, out, frame, live);
+            if constexpr (three) {
+                smooth_ct_pass<N, R2, R0 * R1, false, true, TF>(buf, t, twl, xf, window, out, frame, live);
+            } else {
+                smooth_ct_pass<N, R2, R0 * R1, false, false, TF>(buf, t, twl, xf, window, out, frame, live);
+                smooth_ct_pass<N, R3, R0 * R1 * R2, false, true, TF>(buf, t, twl, xf, window, out, frame, live);
+            }
+        }
+        __syncthreads(); // every lane is done with the frame before the next one lands on it
+    }
+}
+
+// the sizes with a compile-time plan: X(N, R0, R1, R2, R3), radices in pass order (1 = no such pass)
+// Pass order (measured, tools/ab_smooth.sh: 1536 as 12-16-8 / 8-12-16 / 16-12-8: 177 / 153 / 144 Gsamples/s; 3000 as 10-15-10-2 / 15-10-10-2 / 2-10-10-15: 190 / 163 /
+// 149; 6000: 223 / 191 / 121): the first pass stores R0 consecutive float2 per lane, so R0 should not be a power of two (stride R0: 16 -> 16-way, 8 -> 8-way bank
+// conflicts, 10 -> 2-way); the largest radix second; the smallest last (one twiddle multiply per point there, and it sets the table size only through N / 2).
+#ifdef GR4_SMOOTH_ORDER_ALT // developer experiment: other pass orders for a few sizes (tools/ab_smooth.sh)
+#define GR4_SMOOTH_CT_SIZES(X) X(1000, 10, 10, 10, 1) X(1536, 12, 8, 16, 1) X(3000, 10, 15, 10, 2) X(6000, 10, 15, 10, 4) X(8000, 5, 16, 10, 10) X(2000, 10, 10, 10, 2)
+#elif defined(GR4_SMOOTH_ORDER_ALT2)
+#define GR4_SMOOTH_CT_SIZES(X) X(1000, 10, 10, 10, 1) X(1536, 6, 16, 16, 1) X(3000, 10, 15, 10, 2) X(6000, 15, 10, 10, 4) X(8000, 10, 10, 16, 5) X(2000, 10, 10, 10, 2)
+#else
+#define GR4_SMOOTH_CT_SIZES(X)                                                                                              \
+    X(1000, 10, 10, 10, 1) X(1200, 10, 12, 10, 1) X(1280, 10, 16, 8, 1) X(1500, 10, 15, 10, 1) X(1536, 12, 16, 8, 1)        \
+    X(1600, 10, 16, 10, 1) X(1800, 10, 15, 12, 1) X(1920, 10, 16, 12, 1) X(2000, 10, 10, 10, 2) X(2400, 10, 16, 15, 1)      \
+    X(2560, 10, 16, 16, 1) X(3000, 10, 15, 10, 2) X(3072, 12, 16, 16, 1) X(3200, 10, 16, 10, 2) X(3600, 15, 16, 15, 1)      \
+    X(3840, 15, 16, 16, 1) X(4000, 10, 10, 10, 4) X(4800, 10, 16, 15, 2) X(5000, 10, 10, 10, 5) X(5120, 10, 16, 16, 2)      \
+    X(6000, 10, 15, 10, 4) X(6144, 12, 16, 16, 2) X(6400, 10, 16, 10, 4) X(7200, 15, 16, 15, 2) X(7680, 15, 16, 16, 2)      \
+    X(8000, 10, 16, 10, 5) X(640, 10, 8, 8, 1) X(768, 12, 8, 8, 1) X(800, 10, 10, 8, 1) X(960, 10, 12, 8, 1)                \
+    X(500, 10, 10, 5, 1) X(600, 10, 12, 5, 1) X(720, 10, 12, 6, 1) X(360, 10, 6, 6, 1) X(480, 10, 12, 4, 1)
+#endif
+
+template <int N, int R0, int R1, int R2, int R3>
+inline int fft_smooth_ct_launch(const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
+    using PL = SmoothCT<N, R0, R1, R2, R3>;
+    auto kern = fft_smooth_ct_kernel<N, R0, R1, R2, R3>;
+    static PerDevice per_device;
+    bool             first = false;
+    int              dev = -1, n_cu = per_device.current(&first, &dev);
+    GR4_REQUIRE(n_cu != 0, "fft: cannot query the current device");
+    if (first) {
+        n_cu = -n_cu;
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS));
+        per_device.done(dev, n_cu);
+    }
+    const long groups = ceil_div(n_frames, (long)PL::FPB);
+    const long per_cu = std::max<long>(1, std::min<long>(2048 / PL::BS, (long)(160 * 1024 / PL::LDS)));
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long>(groups, (long)n_cu * per_cu)), dim3(PL::BS), PL::LDS, st, d_in, d_window, d_tw, o, n_frames);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+// GR4HIP_UNSUPPORTED: no compile-time plan for this size (the run-time kernel takes it)
+inline int fft_smooth_ct_dispatch(int N, const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
+    switch (N) {
+#define GR4_X(N_, A, B, C, D) case N_: return fft_smooth_ct_launch<N_, A, B, C, D>(d_in, d_window, d_tw, o, n_frames, st);
+        GR4_SMOOTH_CT_SIZES(GR4_X)
+#undef GR4_X
+    default: return GR4HIP_UNSUPPORTED;
+    }
+}
+
 // {2,3,5}-smooth and not a power of two?
 inline bool fft_is_smooth235(size_t N) {
     if (N < 2) return false;
@@ -245,6 +422,10 @@ inline int fft_build_smooth_plan(size_t N, FftPlanDev* plan) {
 }
 
 inline int fft_smooth_launch(const FftPlanDev& plan, const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
+    if (!dev_switch(kDevFftSmoothRuntime)) { // (developer switch: the run-time plan kernel for every size; the tests compare the two)
+        const int rc = fft_smooth_ct_dispatch(plan.N, d_in, d_window, d_tw, o, n_frames, st);
+        if (rc != GR4HIP_UNSUPPORTED) return rc;
+    }
     const size_t lds = (size_t)(plan.fpb + 1) * plan.N * sizeof(float2); // frames + the twiddle table
     const int    bs  = ((plan.tf * plan.fpb + 63) / 64) * 64;
     static PerDevice per_device;

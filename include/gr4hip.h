@@ -89,7 +89,7 @@ const char* gr4hip_last_error(void); /* thread-local text of the last failure */
  * Nothing here changes the meaning of a call -- choices that do (exact float32 FIR arithmetic, the rotator's phase recurrence, the chain's algorithm and
  * guard) are per-handle settings: gr4hip_fir_set_algo, gr4hip_rotator_set_algo, gr4hip_chain_create / gr4hip_chain_set_guard_mode.
  * Names: GR4HIP_FIR_NO_BF16X3, GR4HIP_FIR_NO_DECIM_FD, GR4HIP_IIR_THREE_PASS, GR4HIP_IIR_LOOKBACK, GR4HIP_IIR_NO_SPLIT, GR4HIP_FFT_BLUESTEIN_PIPELINE,
- * GR4HIP_FFT_NO_PIPELINE, GR4HIP_ROTATOR_LEAP, GR4HIP_ROTATOR_WALK, GR4HIP_CHAIN16. */
+ * GR4HIP_FFT_NO_PIPELINE, GR4HIP_ROTATOR_LEAP, GR4HIP_ROTATOR_WALK, GR4HIP_CHAIN16, GR4HIP_FFT_SMOOTH_RUNTIME. */
 int gr4hip_developer_switch(const char* name, int value);
 const char* gr4hip_status_string(int status);
 int         gr4hip_device_count(int* count);

@@ -718,6 +718,23 @@ def test_fft_smooth_sizes_mixed_radix(G, N):
         assert _rel(o2["magnitude"][0].cpu().numpy(), tm) <= TOL
 
 
+@pytest.mark.parametrize("N", [360, 500, 1000, 1200, 1536, 2000, 3000, 3072, 4800, 5000, 6144, 7680, 8000])
+def test_fft_smooth_compile_time_plans_match_the_run_time_kernel(G, N, devsw):
+    """the common {2,3,5}-smooth sizes have compile-time plans (fft_smooth.hpp: first pass from global memory, last pass emits from registers); the run-time
+    mixed-radix kernel computes the same passes -- both against the float64 DFT, and against each other to float32 rounding"""
+    frames = 11
+    x = O.signal_c32(3 * N + 1, frames * N)
+    w = O.window(7, N)  # Blackman-Harris
+    outs = {}
+    for which in ("compile_time", "run_time"):
+        devsw("GR4HIP_FFT_SMOOTH_RUNTIME", 1 if which == "run_time" else 0)
+        outs[which] = G.FFT(N, "BlackmanHarris").spectrum(dev(x)).cpu().numpy()
+    for f in (0, frames // 2, frames - 1):
+        truth = O.dft64(x[f * N:(f + 1) * N].astype(np.complex128) * w)
+        assert _rel(outs["compile_time"][f], truth) <= TOL and _rel(outs["run_time"][f], truth) <= TOL, f
+    assert _rel(outs["compile_time"], outs["run_time"].astype(np.complex128)) <= 5e-6  # (the two plans take their radices in different orders)
+
+
 @pytest.mark.parametrize("N", [6000, 10000, 30000, 48000, 65535, 100003, 3 ** 7 * 5 ** 3, 1 << 19])
 def test_fft_any_size_beyond_one_workgroup(G, N):
     """sizes SimdFFT takes with radix-3/5 passes (SimdFFT.hpp:348-375: 6000, 10000, 30000, 48000, 3^7 5^3) and sizes the reference sends to Bluestein

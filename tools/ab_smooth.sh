@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+cp gnuradio4_amd/libgr4hip.so /tmp/orig.so
+for tag in base salt salt2 base; do
+  if [ $tag = base ]; then cp /tmp/orig.so gnuradio4_amd/libgr4hip.so; else cp gnuradio4_amd/libgr4hip_$tag.so gnuradio4_amd/libgr4hip.so; fi
+  echo -n "$tag: "; python tools/fft_smooth_rates.py 2>&1 | tail -1
+done
+cp /tmp/orig.so gnuradio4_amd/libgr4hip.so
