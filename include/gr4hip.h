@@ -248,11 +248,10 @@ int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
 /* Dynamic-range guard of GR4HIP_CHAIN_AUTO.  The fused kernels filter in the frequency domain and carry the float32 rounding of their transforms: an error
  * floor of ~2e-6 of the INPUT rms per output sample.  The parity bar is 1e-5 of the OUTPUT, so they meet it while the filter passes at least -14 dB of the
  * input power (power ratio >= 0.04) and miss it when a strong out-of-band signal is removed.  Every fused launch of an AUTO chain therefore samples input and
- * output power (one frame in sixteen); the first call after create / reset probes its first 8 blocks synchronously, later calls
- * read the finished measurements of earlier ones without waiting; when the ratio falls below 0.04 the chain continues with the direct-form kernels (the
- * reference's arithmetic, history handed over) -- on the first call before anything is published, otherwise from the call after the one that ran into it --
- * until gr4hip_chain_reset.  Explicit GR4HIP_CHAIN_FUSED_FD never switches.  This call waits for the last measured launch and returns its ratio
- * (< 0: nothing measured yet) and whether the chain now runs in the time domain. */
+ * output power (one frame in sixteen); what happens with the measurement is the handle's guard mode (gr4hip_chain_set_guard_mode below; default STRICT: the
+ * call that measures a ratio below 0.04 redoes its span with the direct-form kernels -- the reference's arithmetic, history handed over -- before it returns,
+ * and the chain stays there until gr4hip_chain_reset).  Explicit GR4HIP_CHAIN_FUSED_FD never measures nor switches.  This call waits for the last measured
+ * launch and returns its ratio (< 0: nothing measured yet) and whether the chain now runs in the time domain. */
 int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time_domain, gr4hip_stream_t stream);
 /* What the guard does with its measurement (per handle; GR4HIP_CHAIN_AUTO chains on the fused frequency-domain kernel only, a no-op elsewhere):
  *   GR4HIP_GUARD_STRICT (default): every call awaits the measurement of its OWN launch and redoes a span that fell below the threshold with the direct-form
