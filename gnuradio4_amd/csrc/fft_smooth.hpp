@@ -215,12 +215,15 @@ __global__ __launch_bounds__(BS, 4) void fft_smooth_kernel(const float* __restri
 // asks for (1000, 1200, 1536, 1920, 2000, 3000, 3072, 4000, 5000, 6000, 6144, 8000, ...) get the same passes with everything known at compile time -- as the
 // power-of-two kernels do: the first pass reads its inputs straight from global memory (window fused, coalesced), the last emits every output straight from
 // registers, a frame makes npass - 1 LDS round trips, twiddles from the LDS table + two power chains.
+#ifndef GR4_SMOOTH_PTS
+#define GR4_SMOOTH_PTS 16 // points a lane holds between the barriers of a pass (compile-time plans)
+#endif
 template <int N, int R0, int R1, int R2, int R3>
 struct SmoothCT {
     static constexpr int kR[4] = {R0, R1, R2, R3};
     static constexpr int NP    = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
     static constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
-    static constexpr int tf_of(int R) { return R > 1 ? cdiv(N, R * (16 / R)) : 1; }
+    static constexpr int tf_of(int R) { return R > 1 ? cdiv(N, R * (GR4_SMOOTH_PTS / R)) : 1; }
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int TF  = cmax(cmax(tf_of(R0), tf_of(R1)), cmax(tf_of(R2), tf_of(R3)));
     static constexpr int FPB = cmax(1, (512 / TF) < (int)(40 * 1024 / (N * 8)) ? (512 / TF) : (int)(40 * 1024 / (N * 8)));
@@ -235,7 +238,7 @@ struct SmoothCT {
 
 template <int N, int R, int P /*product of the radices before this pass*/, bool FIRST, bool LAST, int TF>
 __device__ __forceinline__ void smooth_ct_pass(float2* buf, int t, const float2* twl, const float* __restrict__ x, const float* __restrict__ window, const FftOutputs& out, long frame, bool live) {
-    constexpr int NBL = 16 / R, NB = N / R, SU = N / (P * R);
+    constexpr int NBL = GR4_SMOOTH_PTS / R, NB = N / R, SU = N / (P * R);
     float2        v[NBL][R];
     int           kk[NBL];
 #pragma unroll
