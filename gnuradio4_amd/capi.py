@@ -104,6 +104,7 @@ SIGNATURES = {
     "gr4hip_fft_spectrum": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "gr4hip_fft_mag2": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "gr4hip_fft_destroy": (_i, [_vp]),
+    "gr4hip_fft_plan": (_i, [_sz, _pi, _vp, _pi]),
     "gr4hip_window_create": (_i, [_i, _vp, _sz, _f]),
     "gr4hip_window_create_f64": (_i, [_i, _vp, _sz, _d]),
     "gr4hip_chain_create": (_i, [_pvp, _vp, _sz, _sz, _i, _i]),

@@ -738,5 +738,24 @@ int gr4hip_fft_mag2(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float* d
 
 int gr4hip_fft_destroy(gr4hip_fft_t* f) { delete f; return GR4HIP_OK; }
 
+int gr4hip_fft_plan(size_t fft_size, int* kind, int* radices, int* n_passes) {
+    GR4_REQUIRE(kind && radices && n_passes, "fft_plan: null argument");
+    *n_passes = 0;
+    if (is_pow2(fft_size) && fft_size >= 2 && fft_size <= 8192) { *kind = 0; return GR4HIP_OK; }
+    if (fft_is_smooth235(fft_size) && fft_size <= 8192) {
+        FftPlanDev plan{};
+        int rc = fft_build_smooth_plan(fft_size, &plan);
+        if (rc) return rc;
+        *kind = 3;
+        *n_passes = plan.npass;
+        for (int i = 0; i < plan.npass; ++i) radices[i] = plan.radix[i];
+        return GR4HIP_OK;
+    }
+    if (is_pow2(fft_size) && fft_size <= kFftMaxPow2) { *kind = 1; return GR4HIP_OK; }
+    if (fft_size >= 2 && 2 * fft_size - 1 <= kFftMaxPow2) { *kind = 2; return GR4HIP_OK; }
+    set_error("fft: size %zu is outside the device paths", fft_size);
+    return GR4HIP_UNSUPPORTED;
+}
+
 } // extern "C"
 

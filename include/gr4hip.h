@@ -231,6 +231,10 @@ int gr4hip_fft_spectrum(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, fl
 /* |X[k]|^2 in natural bin order: mag2[(k + N/2) % N] == (magnitude_block[k] * N/2)^2 */
 int gr4hip_fft_mag2(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, float* d_mag2, gr4hip_stream_t stream);
 int gr4hip_fft_destroy(gr4hip_fft_t* fft);
+/* Which device path a size takes (host-only, no device needed): kind 0 = power of two <= 8192 (one kernel), 3 = {2,3,5}-smooth <= 8192 (mixed-radix passes in one
+ * launch: the sizes SimdFFT::canProcessSize takes with radix-3 / radix-5 passes, SimdFFT.hpp:348-375; radices[0 .. n_passes) is the run-time plan, <= 15 passes of
+ * radix 2 .. 16), 1 = power of two up to 2^20 (four-step), 2 = any other size up to 2^19 (chirp convolution); GR4HIP_UNSUPPORTED beyond. */
+int gr4hip_fft_plan(size_t fft_size, int* kind, int* radices16, int* n_passes);
 /* window::create on the host (float), for callers that need the block's _window member */
 int gr4hip_window_create(int window, float* h_out, size_t n, float beta);
 int gr4hip_window_create_f64(int window, double* h_out, size_t n, double beta); /* create<double> */

@@ -123,3 +123,44 @@ def test_missing_library_is_an_import_error_not_a_fallback(monkeypatch, tmp_path
     with pytest.raises(ImportError, match="no CPU fallback"):
         capi.lib()
 
+
+
+def test_fft_plan_of_every_smooth_size():
+    """gr4hip_fft_plan (host-only): every {2,3,5}-smooth size up to 8192 that is not a power of two gets a mixed-radix plan whose radices (2 .. 16) multiply to the
+    size in the fewest passes; powers of two, larger and non-smooth sizes name their paths"""
+    import ctypes as C
+    from gnuradio4_amd import capi
+    L = capi.lib()
+    rad = (C.c_int * 16)()
+    kind, npass = C.c_int(-1), C.c_int(-1)
+    smooth = sorted({2 ** a * 3 ** b * 5 ** c for a in range(14) for b in range(9) for c in range(6)} - {2 ** a for a in range(14)})
+    n_checked = 0
+    radset = (2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16)
+    memo = {1: 0}
+
+    def fewest(n):  # the fewest passes over the radix set (what the planner's dynamic programme must find)
+        if n not in memo:
+            memo[n] = min((fewest(n // r) + 1 for r in radset if n % r == 0), default=10 ** 6)
+        return memo[n]
+    for N in [n for n in smooth if 2 <= n <= 8192]:
+        capi.check(L.gr4hip_fft_plan(N, C.byref(kind), rad, C.byref(npass)), "fft_plan")
+        assert kind.value == 3 and 1 <= npass.value <= 15, N
+        prod = 1
+        for i in range(npass.value):
+            assert rad[i] in (2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16), (N, rad[i])
+            prod *= rad[i]
+        assert prod == N
+        assert npass.value == fewest(N), (N, npass.value)
+        n_checked += 1
+    assert n_checked > 200
+    for N, want in ((1024, 0), (8192, 0), (16384, 1), (1 << 20, 1), (1009, 2), (10000, 2), (3 ** 7 * 5 ** 3, 2)):
+        capi.check(L.gr4hip_fft_plan(N, C.byref(kind), rad, C.byref(npass)), "fft_plan")
+        assert kind.value == want, N
+    assert L.gr4hip_fft_plan(1 << 21, C.byref(kind), rad, C.byref(npass)) == capi.UNSUPPORTED if hasattr(capi, "UNSUPPORTED") else True
+
+
+def test_developer_switch_names():
+    from gnuradio4_amd import capi
+    L = capi.lib()
+    assert L.gr4hip_developer_switch(b"GR4HIP_FFT_SMOOTH_RUNTIME", 1) == 0 and L.gr4hip_developer_switch(b"GR4HIP_FFT_SMOOTH_RUNTIME", 0) == 0
+    assert L.gr4hip_developer_switch(b"GR4HIP_NO_SUCH_SWITCH", 1) < 0 and b"unknown switch" in L.gr4hip_last_error()
