@@ -342,24 +342,11 @@ __global__ __launch_bounds__((SmoothCT<N, R0, R1, R2, R3>::BS), 2) void fft_smoo
     }
 }
 
-// the sizes with a compile-time plan: X(N, R0, R1, R2, R3), radices in pass order (1 = no such pass)
-// Pass order (measured, tools/ab_smooth.sh: 1536 as 12-16-8 / 8-12-16 / 16-12-8: 177 / 153 / 144 Gsamples/s; 3000 as 10-15-10-2 / 15-10-10-2 / 2-10-10-15: 190 / 163 /
-// 149; 6000: 223 / 191 / 121): the first pass stores R0 consecutive float2 per lane, so R0 should not be a power of two (stride R0: 16 -> 16-way, 8 -> 8-way bank
-// conflicts, 10 -> 2-way); the largest radix second; the smallest last (one twiddle multiply per point there, and it sets the table size only through N / 2).
-#ifdef GR4_SMOOTH_ORDER_ALT // developer experiment: other pass orders for a few sizes (tools/ab_smooth.sh)
-#define GR4_SMOOTH_CT_SIZES(X) X(1000, 10, 10, 10, 1) X(1536, 12, 8, 16, 1) X(3000, 10, 15, 10, 2) X(6000, 10, 15, 10, 4) X(8000, 5, 16, 10, 10) X(2000, 10, 10, 10, 2)
-#elif defined(GR4_SMOOTH_ORDER_ALT2)
-#define GR4_SMOOTH_CT_SIZES(X) X(1000, 10, 10, 10, 1) X(1536, 6, 16, 16, 1) X(3000, 10, 15, 10, 2) X(6000, 15, 10, 10, 4) X(8000, 10, 10, 16, 5) X(2000, 10, 10, 10, 2)
-#else
-#define GR4_SMOOTH_CT_SIZES(X)                                                                                              \
-    X(1000, 10, 10, 10, 1) X(1200, 10, 12, 10, 1) X(1280, 10, 16, 8, 1) X(1500, 10, 15, 10, 1) X(1536, 12, 16, 8, 1)        \
-    X(1600, 10, 16, 10, 1) X(1800, 10, 15, 12, 1) X(1920, 10, 16, 12, 1) X(2000, 10, 10, 10, 2) X(2400, 10, 16, 15, 1)      \
-    X(2560, 10, 16, 16, 1) X(3000, 10, 15, 10, 2) X(3072, 12, 16, 16, 1) X(3200, 10, 16, 10, 2) X(3600, 15, 16, 15, 1)      \
-    X(3840, 15, 16, 16, 1) X(4000, 10, 10, 10, 4) X(4800, 10, 16, 15, 2) X(5000, 10, 10, 10, 5) X(5120, 10, 16, 16, 2)      \
-    X(6000, 10, 15, 10, 4) X(6144, 12, 16, 16, 2) X(6400, 10, 16, 10, 4) X(7200, 15, 16, 15, 2) X(7680, 15, 16, 16, 2)      \
-    X(8000, 10, 16, 10, 5) X(640, 10, 8, 8, 1) X(768, 12, 8, 8, 1) X(800, 10, 10, 8, 1) X(960, 10, 12, 8, 1)                \
-    X(500, 10, 10, 5, 1) X(600, 10, 12, 5, 1) X(720, 10, 12, 6, 1) X(360, 10, 6, 6, 1) X(480, 10, 12, 4, 1)
-#endif
+// The sizes with a compile-time plan: fft_smooth_sizes.inc, X(N, R0, R1, R2, R3) with the radices in pass order (1 = no such pass) -- every {2,3,5}-smooth size
+// 18 .. 8192 of two to four passes (144 of them).  Generated: tools/gen_smooth_plans.py proposes two factorisations per size (the lexicographically largest radix
+// tuple / the largest smallest radix; first pass never a power of two where avoidable, largest radix second, smallest last), tools/smooth_sweep.sh measures every
+// size under both on an MI355X, and the faster one is written out (profiles/r03_fft_smooth_plan_sweep.json has the table).  No rule predicts the winner: 3000 wants
+// 10-15-10-2 (230 against 188 Gsamples/s for 15-8-5-5), 6000 wants 10-10-10-6 (228 against 184 for 15-16-5-5), 720 wants 10-12-6 (278 against 194 for 10-9-8).
 
 template <int N, int R0, int R1, int R2, int R3>
 inline int fft_smooth_ct_launch(const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
@@ -383,9 +370,9 @@ inline int fft_smooth_ct_launch(const float* d_in, const float* d_window, const 
 // GR4HIP_UNSUPPORTED: no compile-time plan for this size (the run-time kernel takes it)
 inline int fft_smooth_ct_dispatch(int N, const float* d_in, const float* d_window, const float2* d_tw, const FftOutputs& o, long n_frames, hipStream_t st) {
     switch (N) {
-#define GR4_X(N_, A, B, C, D) case N_: return fft_smooth_ct_launch<N_, A, B, C, D>(d_in, d_window, d_tw, o, n_frames, st);
-        GR4_SMOOTH_CT_SIZES(GR4_X)
-#undef GR4_X
+#define X(N_, A, B, C, D) case N_: return fft_smooth_ct_launch<N_, A, B, C, D>(d_in, d_window, d_tw, o, n_frames, st);
+#include "fft_smooth_sizes.inc"
+#undef X
     default: return GR4HIP_UNSUPPORTED;
     }
 }

@@ -718,6 +718,20 @@ def test_fft_smooth_sizes_mixed_radix(G, N):
         assert _rel(o2["magnitude"][0].cpu().numpy(), tm) <= TOL
 
 
+def test_fft_every_smooth_size_up_to_8192(G):
+    """all 153 {2,3,5}-smooth sizes up to 8192 that are not powers of two (144 on compile-time plans, the single-pass ones on the run-time kernel): two frames each
+    against numpy's float64 FFT"""
+    sizes = sorted({2 ** a * 3 ** b * 5 ** c for a in range(14) for b in range(9) for c in range(6)} - {2 ** a for a in range(14)})
+    sizes = [n for n in sizes if 2 <= n <= 8192]
+    assert len(sizes) == 153
+    rng = np.random.default_rng(5)
+    for N in sizes:
+        x = (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N)).astype(np.complex64)
+        got = G.FFT(N, "None").spectrum(dev(x)).cpu().numpy()
+        want = np.fft.fft(x.astype(np.complex128).reshape(2, N), axis=1)
+        assert _rel(got, want) <= TOL, N
+
+
 @pytest.mark.parametrize("N", [360, 500, 1000, 1200, 1536, 2000, 3000, 3072, 4800, 5000, 6144, 7680, 8000])
 def test_fft_smooth_compile_time_plans_match_the_run_time_kernel(G, N, devsw):
     """the common {2,3,5}-smooth sizes have compile-time plans (fft_smooth.hpp: first pass from global memory, last pass emits from registers); the run-time

@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import gnuradio4_amd as G
 out = []
-for N in (1000, 1024, 1536, 2048, 3000, 4096, 6000, 8000, 8192, 1009):
+import os
+SIZES = [int(v) for v in os.environ.get('SMOOTH_SIZES', '1000,1024,1536,2048,3000,4096,6000,8000,8192,1009').split(',')]
+for N in SIZES:
     n = (1 << 26) // N * N
     xc = G.synth_c32(n)
     m2 = torch.empty(n, dtype=torch.float32, device="cuda")
