@@ -215,6 +215,9 @@ __global__ __launch_bounds__(BS, 4) void fft_smooth_kernel(const float* __restri
 // asks for (1000, 1200, 1536, 1920, 2000, 3000, 3072, 4000, 5000, 6000, 6144, 8000, ...) get the same passes with everything known at compile time -- as the
 // power-of-two kernels do: the first pass reads its inputs straight from global memory (window fused, coalesced), the last emits every output straight from
 // registers, a frame makes npass - 1 LDS round trips, twiddles from the LDS table + two power chains.
+#ifndef GR4_SMOOTH_GRID_MULT
+#define GR4_SMOOTH_GRID_MULT 1 // persistent grid = resident workgroups x this
+#endif
 #ifndef GR4_SMOOTH_PTS
 #define GR4_SMOOTH_PTS 16 // points a lane holds between the barriers of a pass (compile-time plans)
 #endif
@@ -363,7 +366,12 @@ inline int fft_smooth_ct_launch(const float* d_in, const float* d_window, const 
     }
     const long groups = ceil_div(n_frames, (long)PL::FPB);
     const long per_cu = std::max<long>(1, std::min<long>(2048 / PL::BS, (long)(160 * 1024 / PL::LDS)));
-    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long>(groups, (long)n_cu * per_cu)), dim3(PL::BS), PL::LDS, st, d_in, d_window, d_tw, o, n_frames);
+#ifdef GR4_SMOOTH_ONESHOT // developer experiment: one workgroup per frame group instead of a persistent grid
+    (void)per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long>(groups, 1L << 30)), dim3(PL::BS), PL::LDS, st, d_in, d_window, d_tw, o, n_frames);
+#else
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long>(groups, (long)n_cu * per_cu * GR4_SMOOTH_GRID_MULT)), dim3(PL::BS), PL::LDS, st, d_in, d_window, d_tw, o, n_frames);
+#endif
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
