@@ -60,6 +60,7 @@ def cpu_baseline(target_seconds: float = 12.0):
     """Reference-faithful CPU path (oracle, -O3 -march=native like core/benchmarks/CMakeLists.txt:19-23) on a bounded
     sample of the same workload.  Single chain == one thread (GR4 never splits one block chain across threads)."""
     O = _oracle()
+    provenance = O.build_fast_for_this_host()  # -march=native must mean THIS box's cores, not the container the binary was first built in
     L = O.lib(fast=True)
     b = O.design_taps_hamming_lowpass(NTAPS, 0.1)
     x = O.signal_c32(42, 8 * NFFT)
@@ -72,7 +73,8 @@ def cpu_baseline(target_seconds: float = 12.0):
     O.chain(b, x, NFFT, 0, truth=False, L=L)
     dt = time.perf_counter() - t0
     res = {"value": round(frames * NFFT / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-           "sample": f"{frames} frames x {NFFT} samples (one chain, float32 oracle restatement of fir_filter+FFT+mag2, 1 thread of {os.cpu_count()})"}
+           "sample": f"{frames} frames x {NFFT} samples (one chain, float32 oracle restatement of fir_filter+FFT+mag2, 1 thread of {os.cpu_count()})",
+           "binary": "oracle/liboracle_fast.so, gcc -O3 -march=native: " + provenance}
     # GR4's multiThreaded policy never splits one chain across threads, so the host's best case is one independent
     # chain per core.  Same oracle, one chain per hardware thread (ctypes releases the GIL), a few seconds.
     try:

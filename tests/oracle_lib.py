@@ -48,6 +48,37 @@ def build(force: bool = False) -> None:
 _lib = None
 
 
+def _cpu_signature() -> str:
+    """model name + ISA flags of the host this process runs on (what -march=native resolves against)"""
+    try:
+        txt = open("/proc/cpuinfo").read()
+        model = next((l.split(":", 1)[1].strip() for l in txt.splitlines() if l.startswith("model name")), "?")
+        flags = next((l.split(":", 1)[1].strip() for l in txt.splitlines() if l.startswith("flags")), "")
+        import hashlib
+        return model + " / " + hashlib.sha1(flags.encode()).hexdigest()[:12]
+    except Exception:
+        return "unknown"
+
+
+def build_fast_for_this_host() -> str:
+    """liboracle_fast.so is compiled with -march=native (the reference benchmarks' flags): a binary built in one container and shipped to another box carries the
+    BUILD host's ISA.  The signature of the host it was built on is kept beside it; on a different host it is rebuilt here (gcc is part of the image) before the
+    cpu_baseline is timed.  Returns what happened, for the bench line."""
+    so, tag = os.path.join(ORACLE_DIR, "liboracle_fast.so"), os.path.join(ORACLE_DIR, "liboracle_fast.so.host")
+    sig = _cpu_signature()
+    have = open(tag).read().strip() if os.path.exists(tag) else None
+    if os.path.exists(so) and have == sig:
+        return "built on this host (" + sig.split(" / ")[0] + ")"
+    try:
+        if os.path.exists(so):
+            os.remove(so)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "liboracle_fast.so"], stdout=subprocess.DEVNULL)
+        open(tag, "w").write(sig + "\n")
+        return "rebuilt -march=native on this host (" + sig.split(" / ")[0] + ")"
+    except Exception as e:  # no compiler here: the shipped binary is what there is
+        return "shipped binary (built elsewhere: " + str(have) + "); rebuild failed: " + str(e)[:80]
+
+
 def lib(fast: bool = False):
     global _lib
     build()
