@@ -389,8 +389,10 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
         // stream the next frame (and the 256 samples before it) into the other buffers: in flight until the next barrier T.
         // Unconditional (the last iteration re-reads its own frame): no divergent paths around the DMA for hipcc's wait insertion
 #if defined(GR4_T_L2ONLY) // developer timing build (results are wrong): every workgroup re-reads and re-writes ITS FIRST frame -- the same instructions with the traffic held in L2
-        const long   fn = blockIdx.x;
-        const rsrc_t rq = make_rsrc(a.out + (long)blockIdx.x * kN * (FIR ? 2 : 1), fprev < 0 ? 0u : (unsigned)(kN * sizeof(float) * (FIR ? 2 : 1)));
+        const long    fn  = blockIdx.x;
+        const int     chn = 0;
+        const float2* xn  = a.x;
+        const rsrc_t  rq  = make_rsrc(a.out + (long)blockIdx.x * kN * (FIR ? 2 : 1), fprev < 0 ? 0u : (unsigned)(kN * sizeof(float) * (FIR ? 2 : 1)));
 #else
         long fn  = (f + fstride < a.n_frames) ? f + fstride : f;
         int  chn = 0;
