@@ -46,6 +46,10 @@ struct Options {
     // the drift of the reference's float accumulator (beyond 1e-5 of the CPU block's own output after ~10^3 .. 10^5 samples).  true = the reference's float
     // recurrence itself, bit-identical to the block on the host (a sequential walk: far slower; include/gr4hip.h, gr4hip_rotator_set_algo).
     bool rotator_reference_recurrence = false;
+    // Dynamic-range guard of the frequency-domain kernels (fused chain, long complex FIR spans, decimate-by-8 FIR): GR4HIP_GUARD_STRICT (default: a span whose
+    // measured output / input power falls below the threshold is redone in the time domain before the stage's enqueue returns -- the enqueue then waits for its own
+    // launch), GR4HIP_GUARD_DEFERRED (enqueues stay asynchronous, the switch lags by one chunk) or GR4HIP_GUARD_OFF (include/gr4hip.h)
+    int guard_mode = GR4HIP_GUARD_STRICT;
 };
 inline Options& options() { static Options o; return o; }
 
@@ -176,6 +180,7 @@ struct FirStage final : Stage {
     explicit FirStage(const Taps& b) : taps(b.begin(), b.end()) {
         in_bytes = out_bytes = sizeof(T);
         check(gr4hip_fir_create(&h, gr::detail::is_complex<T>::value ? GR4HIP_C32 : GR4HIP_F32, taps.data(), taps.size(), 1), "gr4hip_fir_create");
+        check(gr4hip_fir_set_guard_mode(h, options().guard_mode), "gr4hip_fir_set_guard_mode");
     }
     ~FirStage() override { gr4hip_fir_destroy(h); }
     template <typename Taps>
@@ -210,6 +215,7 @@ struct ChainStage final : Stage {
     ChainStage(const std::vector<float>& taps, std::size_t fftSize, int window) : N(fftSize) {
         in_bytes = 8; out_bytes = 4; in_chunk = out_chunk = fftSize;
         check(gr4hip_chain_create(&h, taps.data(), taps.size(), fftSize, window, GR4HIP_CHAIN_AUTO), "gr4hip_chain_create");
+        check(gr4hip_chain_set_guard_mode(h, options().guard_mode), "gr4hip_chain_set_guard_mode");
     }
     ~ChainStage() override { gr4hip_chain_destroy(h); }
     std::string_view kind() const override { return "chain_fir_fft_mag2"; }
@@ -1527,6 +1533,7 @@ public:
             _branches.emplace_back();
             _branches.back().in = std::move(edge);
             check(gr4hip_chain_create(&_branches.back().chain, taps.data(), taps.size(), fftSize, window, GR4HIP_CHAIN_AUTO), "gr4hip_chain_create");
+            check(gr4hip_chain_set_guard_mode(_branches.back().chain, options().guard_mode), "gr4hip_chain_set_guard_mode");
         }
         _name = "fan_in[" + std::to_string(_branches.size()) + " of " + std::to_string(n_total) + " channels on gpu:hip:" + std::to_string(_domain.index) + "]";
     }

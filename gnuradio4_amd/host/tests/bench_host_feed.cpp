@@ -9,6 +9,7 @@
 //       "pageable" ordinary edges: source copy + staging copies through page-locked memory by the copy threads (GR4HIP_COPY_THREADS)
 //       "link"     no graph: the same chunk sizes copied host -> device and device -> host on two streams at once, nothing else: what the link gives
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 
 #include <gr4/hip.hpp>
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
     const std::size_t n = std::size_t(1) << (argc > 1 ? std::stoul(argv[1]) : 27), N = argc > 2 ? std::stoul(argv[2]) : 8192, K = argc > 3 ? std::stoul(argv[3]) : 256;
     std::vector<double> taps(K, 1.0 / double(K));
     const std::string mode = argc > 4 ? argv[4] : "dma";
+    if (const char* g = std::getenv("GR4HIP_BENCH_GUARD_MODE")) gr::hip::options().guard_mode = std::atoi(g); // 0 strict (default), 1 deferred, 2 off
     if (mode == "link") {
         const std::size_t chunk = std::size_t(2) << 20, chunks = n / chunk; // 2 Mi samples: 16 MiB in, 8 MiB out per chunk (what the run moves)
         void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
