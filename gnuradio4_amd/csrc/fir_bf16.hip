@@ -18,6 +18,14 @@
 // (Measured and dropped: the m and l tap planes' fragments in LDS instead of registers -- 180 instead of 228 registers at 256 taps, one more LDS read per K-step and
 // tile pair: 303 instead of 326 Gsamples/s.  With all three planes resident the compiler re-uses one B register quad and waits for the LDS three times per K-step;
 // the extra reads cost more than those waits.)
+//
+// Round 3, windows of 256 / 288 samples (KS = 8, 9: 210 .. 256 taps, and the 256-tap slices of longer filters): fir_mfma_bf16x3_shared_kernel.  At KS = 9 the kernel
+// above reads 0.5 KB of B operand from LDS per MFMA -- as many LDS cycles as matrix-pipe cycles -- and holds the package at its 1400 W cap with the shader clock at
+// 1.77 GHz (tools/fir_power_probe.sh).  The second kernel maps outputs to tiles so that four tiles of a wave walk ONE fragment stream (a third of the operand
+// reads), double-buffers the planes so that the next segment is split beside the MFMAs, and keeps two segments of loads in flight: 256 taps 360 -> 389 Gsamples/s,
+// BASELINE configs[3] (64 channels x 256 taps) 357 -> 387, 512 taps 134 -> 173, 1024 taps 56 -> 81 (same box, tools/ab_run.sh tools/fir_ab.py).  Narrower windows
+// are HBM- and power-bound, not operand-bound, and run 0 .. 15 % FASTER on the first kernel (its stores are whole 256-byte rows; the tile map of the second one
+// leaves 64-byte pieces: +7 % when timed with row stores, -DGR4_T_COALESCED_STORE), so they stay there (kBfSharedMinKS).
 #include "common.hpp"
 #include "buffer_ops.hpp"
 
@@ -30,7 +38,11 @@ using bf16x8  = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4_b = __attribute__((ext_vector_type(4))) float;
 using u32x4_b = __attribute__((ext_vector_type(4))) unsigned;
 
+#ifndef GR4_BF16_WG_PER_CU
+#define GR4_BF16_WG_PER_CU 2
+#endif
 constexpr int kBfSeg = 4096, kBfSegPerWg = 4;
+constexpr int kBfSharedMinKS = 8; // measured: 8 % faster at 256 taps, equal at 200, slower below (those windows are HBM- and power-bound, not operand-bound)
 
 using bf16x2_b = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2_b  = __attribute__((ext_vector_type(2))) float;
@@ -154,6 +166,144 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_kernel(const float* __res
             outp(o1, c1, d1);
         }
         __syncthreads(); // every wave is done with the staged segment before the next one overwrites it
+    }
+    if (new_hist != nullptr && blockIdx.x == 0 && blockIdx.y == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+        }
+    }
+}
+
+// Output (column i, tile t, row j) of a segment = y[seg0 + 256 i + 16 t + j]: the 16 columns of a tile are 256 samples apart, and tile t + 2 sits 32 samples = one
+// K-step behind tile t, so B_{t+2}(ks - 1) IS B_t(ks), lane for lane.  A wave owns four tiles tb, tb + 2, tb + 4, tb + 6 and walks ONE fragment stream
+// F(m) = staged[256 col + 16 tb + 32 m + 8 kq ..+8), m < KS + 3; tile j uses F(m) as its K-step m - j: KS + 3 fragment reads feed 4 KS K-steps (a third of the
+// LDS operand traffic of a read per tile and K-step at KS = 9).  The planes are double-buffered: the next segment is split and written BESIDE the MFMAs
+// (its VALU and ds_write instructions fill the matrix pipe's issue gaps), one barrier per segment.
+template <int KS> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block
+__global__ __launch_bounds__(256, GR4_BF16_WG_PER_CU) void fir_mfma_bf16x3_shared_kernel(const float* __restrict__ x0, const float* __restrict__ hist0 /*the Kh samples in front of x*/, int Kh,
+                                                               const u32x4_b* __restrict__ afrag0 /*[3 planes][KS][64 lanes]: 8 bf16 each*/, float* __restrict__ y0, long n,
+                                                               float* __restrict__ new_hist, long in_stride, long out_stride /*channel blockIdx.y: x0 + c in_stride, hist0 + c Kh, afrag0 + c 3 KS 64, y0 + c out_stride*/,
+                                                               int delay /*this pass filters x delayed by `delay` samples (a multiple of 16) ...*/, int accum /*... and adds to y: filters longer than 256 taps run as slices*/,
+                                                               int seg_per_wg) {
+    const float*   x     = x0 + (long)blockIdx.y * in_stride;
+    const float*   hist  = hist0 + (long)blockIdx.y * Kh;
+    const u32x4_b* afrag = afrag0 + (long)blockIdx.y * 3 * KS * 64;
+    float*         y     = y0 + (long)blockIdx.y * out_stride;
+    constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kBfSeg + Hb; // staged samples per segment (a multiple of 16)
+    constexpr int PL  = NS + 8 * (NS / 256) + 16;               // bf16 elements per plane: one 16-byte chunk of padding per 256 samples (see P below)
+    constexpr int NL4 = (NS / 4 + 255) / 256;                   // float4 loads a lane holds for the next segment
+    constexpr int NM  = KS + 3;                                 // fragments of a wave's stream
+    __shared__ __attribute__((aligned(16))) unsigned short pls[2][3 * PL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    // lane (col, kq) reads the 16-byte chunk 32 col + kq (+ 4 m): columns are 256 samples apart, so one chunk of padding per 256 samples puts the 16 columns of a
+    // ds_read_b128 lane group on 16 different chunks mod 16
+    auto P = [](int s_) { return s_ + 8 * (s_ >> 8); };
+
+    u32x4_b a[3][KS]; // A fragments of the three tap planes
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[p][ks] = afrag[(p * KS + ks) * 64 + lane];
+
+    float4 nxa[NL4], nxb[NL4]; // two segments ahead: one set is being split into the other plane buffer while the loads of the other are in flight
+    auto   load_next = [&](float4 (&nxt)[NL4], long seg0) { // seg0 >= kBfSeg > Hb: nothing below 0; past the end of the span / of the segment the range check returns 0
+        const long   i0   = seg0 - Hb - delay; // >= 0 from the second segment on (Hb + delay <= kBfSeg: the launcher checks)
+        const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
+        const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto put4e = [&](unsigned short* pl, int e, float4 v) { // four samples -> elements e .. e + 3 of the three planes
+        unsigned h0, m0, l0, h1, m1, l1;
+        bf_split2(v.x, v.y, h0, m0, l0);
+        bf_split2(v.z, v.w, h1, m1, l1);
+        *reinterpret_cast<uint2*>(pl + e)          = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(pl + PL + e)     = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(pl + 2 * PL + e) = make_uint2(l0, l1);
+    };
+    auto put4 = [&](unsigned short* pl, int q, float4 v) { put4e(pl, P(4 * q), v); }; // samples 4 q .. 4 q + 3 of the staged range (4 consecutive elements never straddle a pad: pads sit at multiples of 256)
+    auto put_next = [&](unsigned short* pl, int u, const float4& v) { // branch-free (it sits between MFMAs): lanes past the staged range write into the spare elements behind each plane
+        const int q = tid + 256 * u;
+        put4e(pl, (256 * (u + 1) <= NS / 4 || q < NS / 4) ? P(4 * q) : PL - 16 + 4 * (lane & 3), v);
+    };
+    auto stage_general = [&](unsigned short* pl, long seg0) { // any segment, sample by sample: the carried history in front of x, delayed passes, zeros past the end
+        for (int q = tid; q < NS / 4; q += 256) {
+            float t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long i = seg0 + 4L * q + c - Hb - delay;
+                t[c]         = i >= 0 ? (i < n ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f);
+            }
+            put4(pl, q, make_float4(t[0], t[1], t[2], t[3]));
+        }
+    };
+    const long nseg = (n + kBfSeg - 1) / kBfSeg, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
+    if (sfirst < slast) {
+        if (sfirst > 0) {
+            load_next(nxa, sfirst * kBfSeg);
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) put_next(pls[0], u, nxa[u]);
+        } else {
+            stage_general(pls[0], sfirst * kBfSeg);
+        }
+        load_next(nxa, (sfirst + 1) * kBfSeg); // (past the end of the span: empty loads)
+    }
+    __syncthreads();
+    const int tb = (wave >> 1) + 8 * (wave & 1); // waves 0, 1: the even tiles from 0 / 8; waves 2, 3: the odd tiles from 1 / 9
+    const int sb = 256 * col + 16 * tb + 8 * kq;
+    // one segment: MFMAs on `pl`; `cur` (the segment behind it, requested a segment ago) goes into `plo` meanwhile; the segment behind THAT is requested into `oth` first
+    auto segment = [&](long sg, const unsigned short* pl, unsigned short* plo, float4 (&cur)[NL4], float4 (&oth)[NL4]) {
+        const long seg0 = sg * kBfSeg;
+        load_next(oth, seg0 + 2 * kBfSeg);
+        f32x4_b c[4], d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = d[j] = f32x4_b{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const unsigned short* q = pl + P(sb + 32 * m);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(q), bm = *reinterpret_cast<const bf16x8*>(q + PL), bl = *reinterpret_cast<const bf16x8*>(q + 2 * PL);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ks = m - j;
+                if (ks < 0 || ks >= KS) continue;
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0][ks]), am = __builtin_bit_cast(bf16x8, a[1][ks]), al = __builtin_bit_cast(bf16x8, a[2][ks]);
+                c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c[j], 0, 0, 0);
+                d[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d[j], 0, 0, 0);
+                c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c[j], 0, 0, 0);
+                d[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d[j], 0, 0, 0);
+                c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c[j], 0, 0, 0);
+                d[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) // the next segment's samples are split and written into the other buffer beside the MFMAs, spread over the stream
+                if (u * NM / NL4 == m) put_next(plo, u, cur[u]);
+        }
+        // D[row = 4 kq + r][col]: y[seg0 + 256 col + 16 t + 4 kq + r]; the small terms are added to the large ones last
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#ifdef GR4_T_COALESCED_STORE // timing only (wrong positions): what the 64-byte store pieces cost
+            const long o = seg0 + (wave * 4 + j) * 256 + lane * 4;
+#else
+            const long o = seg0 + 256L * col + 16 * (tb + 2 * j) + 4 * kq;
+#endif
+            if (o + 3 < n) {
+                float4 v = make_float4(c[j][0] + d[j][0], c[j][1] + d[j][1], c[j][2] + d[j][2], c[j][3] + d[j][3]);
+                if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+                *reinterpret_cast<float4*>(y + o) = v;
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + (c[j][r] + d[j][r]);
+            }
+        }
+        __syncthreads(); // the other buffer is complete, and every wave is done with this one before the segment after the next overwrites it
+    };
+    for (long sg = sfirst; sg < slast; sg += 2) {
+        segment(sg, pls[0], pls[1], nxa, nxb);
+        if (sg + 1 < slast) segment(sg + 1, pls[1], pls[0], nxb, nxa);
     }
     if (new_hist != nullptr && blockIdx.x == 0 && blockIdx.y == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
         for (int h = tid; h < Kh; h += 256) {
@@ -512,8 +662,17 @@ void fir_bf16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::
 // y[i] = sum_k b[k] x[i - k], i < n; hist = the Kh samples in front of x; x and y 16-byte aligned
 int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay,
                     int accum) {
-    const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kBfSeg), (long)kBfSegPerWg), nch);
     const auto af = static_cast<const u32x4_b*>(afrag);
+    if (KS >= kBfSharedMinKS && 32 * KS - 16 + delay <= kBfSeg) { // the wide windows: shared fragment stream, double-buffered planes (fir_mfma_bf16x3_shared_kernel)
+        const long nseg = ceil_div(n, (long)kBfSeg);
+        const int  spw  = (int)std::min<long>(std::max<long>(nseg * (long)nch / 2048, 1), 32); // segments per workgroup: >= 2048 workgroups when the span has them, the prologue (tap fragments, first staging) once per run
+        const dim3 grid((unsigned)ceil_div(nseg, (long)spw), nch);
+        if (KS == 8) hipLaunchKernelGGL(fir_mfma_bf16x3_shared_kernel<8>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist, in_stride, out_stride, delay, accum, spw);
+        else hipLaunchKernelGGL(fir_mfma_bf16x3_shared_kernel<9>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist, in_stride, out_stride, delay, accum, spw);
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
+    const dim3 grid((unsigned)ceil_div(ceil_div(n, (long)kBfSeg), (long)kBfSegPerWg), nch);
 #define GR4_BF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_bf16x3_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist, in_stride, out_stride, delay, accum); break
     switch (KS) {
         GR4_BF_CASE(3);
