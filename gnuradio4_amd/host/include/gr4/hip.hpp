@@ -1671,6 +1671,7 @@ inline std::vector<FanInRun*> plan_sharded(Graph& g, const Shard& shard, std::si
             retire.push_back(f.spec);
         }
         retire.push_back(add);
+        if (local.empty()) throw std::runtime_error("plan_sharded: rank " + std::to_string(shard.rank) + " of " + std::to_string(shard.n_ranks) + " owns no branch of the combiner (more ranks than gpu:hip devices in the graph): it could not take part in the exchanges");
         ComputeDomain dom = found[0].fir->compute_domain();
         if (device >= 0) dom.index = device;
         auto  run = std::make_unique<FanInRun>(std::move(local), add->output_edges()[0], found[0].N, found[0].window, found.size(), shard, dom);

@@ -98,6 +98,14 @@ int main(int argc, char** argv) {
         std::printf("plan for rank 0 of 2: %s (%zu local channels, %zu blocks)\n", ok ? "ok" : "FAILED", runs.empty() ? std::size_t(0) : runs[0]->local_channels(), b.g.blocks().size());
         if (!ok) ++errors;
     }
+    { // a rank that owns no branch could never take part in the exchanges: planning refuses instead of leaving its partners waiting in a collective
+        Built b;
+        build(b, x, tapsd, N, C, 1, false);
+        bool refused = false;
+        try { (void)hip::plan_sharded(b.g, hip::Shard{1, 2, nullptr, false, 4}); } catch (const std::exception& e) { refused = std::string(e.what()).find("owns no branch") != std::string::npos; }
+        std::printf("plan for a rank without branches: %s\n", refused ? "refused" : "FAILED");
+        if (!refused) ++errors;
+    }
     gr4hip_fanin_destroy(comm);
     std::printf(errors ? "FAILED (%d)\n" : "all sharded-graph checks passed\n", errors);
     return errors ? 3 : 0;
