@@ -26,6 +26,8 @@
 // BASELINE configs[3] (64 channels x 256 taps) 357 -> 387, 512 taps 134 -> 173, 1024 taps 56 -> 81 (same box, tools/ab_run.sh tools/fir_ab.py).  Narrower windows
 // are HBM- and power-bound, not operand-bound, and run 0 .. 15 % FASTER on the first kernel (its stores are whole 256-byte rows; the tile map of the second one
 // leaves 64-byte pieces: +7 % when timed with row stores, -DGR4_T_COALESCED_STORE), so they stay there (kBfSharedMinKS).
+// (The complex kernel below was rebuilt the same way -- 4096 complex outputs per segment, six planes double-buffered, sixteen accumulators per wave -- and measured
+// 163-164 against 168 Gsamples/s at 256 taps, 175 against 179 at 224: it is at the same power cap with two streams' worth of MFMAs per sample, and stays as it is.)
 #include "common.hpp"
 #include "buffer_ops.hpp"
 

@@ -23,3 +23,17 @@ fb = G.FirBatched(np.stack([lowpass(256, 0.05 + 0.005 * c) for c in range(nch)])
 yb = torch.empty_like(xb)
 t = steady(lambda: fb.process_bulk(xb, yb))
 print(f"configs[3] {nch * n2 / t / 1e9:.0f} G")
+nc = 1 << 27
+xc = G.synth_c32(nc)
+yc = torch.empty(nc, dtype=torch.complex64, device="cuda")
+out = []
+for nt in (128, 200, 224, 256):
+    f = G.fir_filter(lowpass(nt, 0.05), torch.complex64)
+    f.set_algo(capi.FIR_TIME_DOMAIN)
+    t = steady(lambda: f.process_bulk(xc, yc))
+    out.append(f"{nt}: {nc / t / 1e9:.0f}")
+print("complex direct-form FIR Gsamples/s ", "  ".join(out))
+ch = G.Chain(lowpass(256, 0.05), 8192, "None", capi.CHAIN_TIME_DOMAIN)
+m2 = torch.empty((nc // 8192, 8192), dtype=torch.float32, device="cuda")
+t = steady(lambda: ch.process_bulk(xc, m2))
+print(f"chain 256 taps -> 8192 -> mag2, time-domain pair (where the guard sends the headline stream): {nc / t / 1e9:.0f} G")
