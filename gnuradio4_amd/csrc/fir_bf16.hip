@@ -21,7 +21,7 @@
 //
 // Round 3, windows of 256 / 288 samples (KS = 8, 9: 210 .. 256 taps, and the 256-tap slices of longer filters): fir_mfma_bf16x3_shared_kernel.  At KS = 9 the kernel
 // above reads 0.5 KB of B operand from LDS per MFMA -- as many LDS cycles as matrix-pipe cycles -- and holds the package at its 1400 W cap with the shader clock at
-// 1.77 GHz (tools/fir_power_probe.sh).  The second kernel maps outputs to tiles so that four tiles of a wave walk ONE fragment stream (a third of the operand
+// 1.77 GHz (tools/power_probe.sh).  The second kernel maps outputs to tiles so that four tiles of a wave walk ONE fragment stream (a third of the operand
 // reads), double-buffers the planes so that the next segment is split beside the MFMAs, and keeps two segments of loads in flight: 256 taps 360 -> 389 Gsamples/s,
 // BASELINE configs[3] (64 channels x 256 taps) 357 -> 387, 512 taps 134 -> 173, 1024 taps 56 -> 81 (same box, tools/ab_run.sh tools/fir_ab.py).  Narrower windows
 // are HBM- and power-bound, not operand-bound, and run 0 .. 15 % FASTER on the first kernel (its stores are whole 256-byte rows; the tile map of the second one
