@@ -19,6 +19,9 @@ elif cfg.startswith("cfir"):
     x = G.synth_c32(n); y = torch.empty_like(x); f = G.fir_filter(lowpass(int(cfg[4:])), torch.complex64); f.set_algo(capi.FIR_TIME_DOMAIN); run = lambda: f.process_bulk(x, y); units = n
 elif cfg.startswith("fft"):
     N = int(cfg[3:]); x = G.synth_c32(n); y = torch.empty((n // N, N), dtype=torch.float32, device="cuda"); f = G.FFT(N, "None"); run = lambda: f.mag2(x, y); units = n
+elif cfg.startswith("chain"):  # chain<taps>_<fftSize>_<window>[_fd]: GR4HIP_CHAIN_AUTO (or the fused fast convolution with _fd)
+    p = cfg[5:].split("_"); N = int(p[1])
+    x = G.synth_c32(n); y = torch.empty((n // N, N), dtype=torch.float32, device="cuda"); f = G.Chain(lowpass(int(p[0])), N, p[2], capi.CHAIN_FUSED_FD if len(p) > 3 else capi.CHAIN_AUTO); run = lambda: f.process_bulk(x, y); units = n
 else:
     algo = {"headline": capi.CHAIN_AUTO, "pair": capi.CHAIN_TIME_DOMAIN}[cfg]
     x = G.synth_c32(n); y = torch.empty((n // 8192, 8192), dtype=torch.float32, device="cuda"); f = G.Chain(lowpass(256), 8192, "None", algo); run = lambda: f.process_bulk(x, y); units = n
