@@ -5,7 +5,8 @@
 //   FIR        direct form, segment + history staged in LDS as doubles, R outputs per lane from a strided window
 //   IIR        exact parallel-in-time in three passes (per-tile zero-state chunk runs + in-tile scan, one sequential walk over the tile states,
 //              re-run from the true start states); every matrix power is host-precomputed in float64
-//   FFT        real frames: window, in-place radix-2 passes in LDS (power-of-two N <= 8192), the block's outputs in double
+//   FFT        real frames (power-of-two N <= 8192): window, half-size complex transform as radix-4 Stockham passes in LDS, 8192 / N frames per workgroup,
+//              untangled into the block's outputs in double (N < 16: one frame per workgroup, radix-2 passes)
 //   Rotator    closed-form phase per sample (the float64 oracle's definition up to the rounding of the accumulated sum)
 #include "common.hpp"
 
@@ -431,6 +432,125 @@ __global__ __launch_bounds__(256) void fft64_kernel(const double* __restrict__ x
     }
 }
 
+// The same block for N >= 16, the way the float kernels do it: a real frame of N points is HALF a complex transform -- z[n] = x[2n] + i x[2n+1], Z = FFT_M(z), M = N/2,
+// X[k] = (Z[k] + conj Z[M-k]) / 2 - i W_N^k (Z[k] - conj Z[M-k]) / 2 -- and the transform runs as Stockham autosort passes of radix 4 (one radix-2 pass in front when
+// log2 M is odd) on 4096 complex points per workgroup = 8192 / N frames side by side: every lane does four butterflies per pass whatever N is, reads at the constant
+// stride M / 4, scatters into natural order (no bit reversal), two LDS barriers per pass.  One 64 KiB buffer, two workgroups per CU.
+constexpr int kF64Pts = 4096; // complex points per workgroup
+__device__ __forceinline__ double2 c64_mul(double2 a, double2 b) { return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x)); }
+__device__ __forceinline__ double2 c64_tw(const double2* __restrict__ tw, int j, int M) { // W_{2M}^j for j < 2M from the half-period table
+    const double2 w = tw[j & (M - 1)];
+    return (j & M) ? make_double2(-w.x, -w.y) : w;
+}
+__global__ __launch_bounds__(256, 2) void fft64_r2c_kernel(const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw /*[N/2]: W_N^j*/, int log2n, long n_frames,
+                                                           Fft64Out o) {
+    extern __shared__ double2 sm2[];
+    const int  N = 1 << log2n, M = N >> 1, log2m = log2n - 1;
+    const int  fpb = kF64Pts / M;                 // frames per workgroup
+    const long f0  = (long)blockIdx.x * fpb;
+    const int  tid = threadIdx.x;
+    double2*   A   = sm2;
+    // load: complex point p of the workgroup = real samples 2p, 2p + 1 of the frames' concatenation (16-byte loads, lane-contiguous)
+    for (int p = tid; p < kF64Pts; p += 256) {
+        const long g = f0 * N + 2L * p;
+        double2    v = make_double2(0.0, 0.0);
+        if (g < n_frames * N) {
+            v = *reinterpret_cast<const double2*>(x + g);
+            if (win) { const int i = (2 * p) & (N - 1); v.x *= win[i]; v.y *= win[i + 1]; }
+        }
+        A[p] = v;
+    }
+    __syncthreads();
+    const int Mq = M >> 2;
+    int       Ns = 1;
+    if (log2m & 1) { // radix 2 first: butterflies (j, j + M/2) of every frame, no twiddles
+        double2 u[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int bj = tid + 256 * i, fr = bj / (M >> 1), j = bj % (M >> 1); u[i] = A[fr * M + j]; b[i] = A[fr * M + j + (M >> 1)]; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int bj = tid + 256 * i, fr = bj / (M >> 1), j = bj % (M >> 1);
+            A[fr * M + 2 * j]     = make_double2(u[i].x + b[i].x, u[i].y + b[i].y);
+            A[fr * M + 2 * j + 1] = make_double2(u[i].x - b[i].x, u[i].y - b[i].y);
+        }
+        __syncthreads();
+        Ns = 2;
+    }
+    for (; Ns < M; Ns <<= 2) {
+        double2 v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bj = tid + 256 * i, fr = bj / Mq, j = bj % Mq, k = j & (Ns - 1);
+            const int step = M / (2 * Ns) * k; // W_{4 Ns}^k = W_{2M}^{k 2M / (4 Ns)}
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 a = A[fr * M + j + r * Mq];
+                v[i][r]         = r == 0 ? a : c64_mul(a, c64_tw(tw, step * r, M));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int     bj = tid + 256 * i, fr = bj / Mq, j = bj % Mq, k = j & (Ns - 1);
+            const int     j0 = ((j - k) << 2) + k; // (j / Ns) 4 Ns + k
+            const double2 t0 = make_double2(v[i][0].x + v[i][2].x, v[i][0].y + v[i][2].y), t1 = make_double2(v[i][0].x - v[i][2].x, v[i][0].y - v[i][2].y);
+            const double2 t2 = make_double2(v[i][1].x + v[i][3].x, v[i][1].y + v[i][3].y), t3 = make_double2(v[i][1].y - v[i][3].y, v[i][3].x - v[i][1].x); // -i (v1 - v3)
+            double2*      d  = A + fr * M + j0;
+            d[0]             = make_double2(t0.x + t2.x, t0.y + t2.y);
+            d[Ns]            = make_double2(t1.x + t3.x, t1.y + t3.y);
+            d[2 * Ns]        = make_double2(t0.x - t2.x, t0.y - t2.y);
+            d[3 * Ns]        = make_double2(t1.x - t3.x, t1.y - t3.y);
+        }
+        __syncthreads();
+    }
+    // untangle + the block's outputs (fft.hpp:147-171, 221-227): magnitude / phase of bins 0 .. N/2-1, Re / Im of bins N/2 .. N-1 (= conj X[N - k])
+    const double pi = 3.14159265358979323846;
+    for (int p = tid; p < kF64Pts; p += 256) {
+        const int  fr = p / M, k = p % M;
+        const long f  = f0 + fr;
+        if (f >= n_frames) continue;
+        const double2 Z = A[fr * M + k], Zc = A[fr * M + ((M - k) & (M - 1))];
+        const double2 e = make_double2(0.5 * (Z.x + Zc.x), 0.5 * (Z.y - Zc.y)), dd = make_double2(0.5 * (Z.x - Zc.x), 0.5 * (Z.y + Zc.y)); // (Z + conj Zc) / 2, (Z - conj Zc) / 2
+        const double2 w = tw[k];                                                                                                           // W_N^k
+        const double2 t = c64_mul(dd, w);
+        const double2 X = make_double2(e.x + t.y, e.y - t.x); // e - i t
+        if (k == 0) { // bin N/2 = Re Z0 - Im Z0 (real)
+            if (o.re) o.re[f * M] = Z.x - Z.y;
+            if (o.im) o.im[f * M] = 0.0;
+        } else { // bin N - k = conj X[k]
+            if (o.re) o.re[f * M + (M - k)] = X.x;
+            if (o.im) o.im[f * M + (M - k)] = -X.y;
+        }
+        if (o.mag) {
+            double m = hypot(X.x, X.y) * 2.0 / (double)N;
+            if (o.in_db) m = m > 0.0 ? 20.0 * log10(m) : -1.7976931348623157e308;
+            o.mag[f * M + k] = m;
+        }
+        if (o.phase) {
+            double ph = atan2(X.y, X.x);
+            if (o.in_deg && !o.unwrap) ph = ph * 180.0 / pi;
+            o.phase[f * M + k] = ph;
+        }
+    }
+    if (o.phase && o.unwrap) { // fft_common.hpp:71-89 unwrapPhase: sequential over the half spectrum (one lane per frame; the phases are in global memory)
+        __syncthreads();
+        for (int fr = tid; fr < fpb && f0 + fr < n_frames; fr += 256) {
+            double* ph   = o.phase + (f0 + fr) * M;
+            double  corr = 0.0, prev = ph[0];
+            for (int k = 1; k < M; ++k) {
+                const double raw = ph[k], diff = raw - prev;
+                if (diff > pi) corr -= 2.0 * pi;
+                else if (diff < -pi) corr += 2.0 * pi;
+                prev  = raw;
+                ph[k] = raw + corr;
+            }
+            if (o.in_deg)
+                for (int k = 0; k < M; ++k) ph[k] = ph[k] * 180.0 / pi;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Rotator<complex<double>>
 // y[i] = x[i] e^{i (phase0 + (i + 1) inc)} (Rotator.hpp:51-61 with the accumulated phase in closed form); the index is split so that both products are exact
 __global__ __launch_bounds__(256) void rotator64_kernel(const double2* __restrict__ x, double2* __restrict__ y, long n, double phase0, double inc) {
@@ -727,6 +847,16 @@ int gr4hip_fft64_process(gr4hip_fft64_t* f, const double* d_in, size_t n_frames,
     if (n_frames == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in, "fft64_process: null input");
     hipStream_t  st  = as_stream(stream);
+    if (f->N >= 16 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0) { // half-size complex transform, radix-4 Stockham passes, 8192 / N frames per workgroup
+        const size_t lds = (size_t)kF64Pts * sizeof(double2);
+        const size_t fpb = kF64Pts / (f->N / 2);
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fft64_r2c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Fft64Out o{d_mag, d_phase, d_re, d_im, (f->flags & GR4HIP_FFT_OUTPUT_IN_DB) != 0, (f->flags & GR4HIP_FFT_OUTPUT_IN_DEG) != 0, (f->flags & GR4HIP_FFT_UNWRAP_PHASE) != 0};
+        hipLaunchKernelGGL(fft64_r2c_kernel, dim3((unsigned)ceil_div(n_frames, fpb)), dim3(256), lds, st, d_in, f->windowed ? (const double*)f->d_win.ptr : nullptr, (const double2*)f->d_tw.ptr,
+                           f->log2n, (long)n_frames, o);
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
     const size_t lds = f->N * sizeof(double2);
     if (lds > 64 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fft64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     Fft64Out o{d_mag, d_phase, d_re, d_im, (f->flags & GR4HIP_FFT_OUTPUT_IN_DB) != 0, (f->flags & GR4HIP_FFT_OUTPUT_IN_DEG) != 0, (f->flags & GR4HIP_FFT_UNWRAP_PHASE) != 0};

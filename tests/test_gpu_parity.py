@@ -2072,12 +2072,12 @@ def test_iir_filter_float64_more_tiles_than_one_scan_round(G, kind):
     assert _rel(y2, truth[:1_000_000]) <= bar
 
 
-@pytest.mark.parametrize("N", [2, 16, 1024, 8192])
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 32, 64, 512, 1024, 2048, 4096, 8192])
 @pytest.mark.parametrize("window", ["None", "Hann", "BlackmanHarris"])
 def test_fft_block_float64(G, N, window):
     """FFT<double>: real double frames; magnitude / phase = bins 0 .. N/2-1, Re / Im = bins N/2 .. N-1 (fft.hpp:221-227), all in double"""
     rng = np.random.default_rng(N)
-    frames = 5
+    frames = 700 if N <= 64 else 5  # (N >= 16: 8192 / N frames share a workgroup -- several workgroups with a partial last one, or one partial workgroup)
     x = rng.standard_normal(frames * N) + np.cos(0.3 * np.arange(frames * N))
     w = np.ones(N) if window == "None" else O.window(O.WINDOWS.index(window), N, np.float64)
     X = np.fft.fft(x.reshape(frames, N) * w, axis=1)
