@@ -1521,7 +1521,7 @@ class FanInRun final : public BlockModel {
     gr4hip_stream_t                 _s = nullptr;
     DevBuf                          _d_partial{false}, _d_sum{false}, _h_out{true};
     std::string                     _name;
-    std::size_t                     _launches = 0, _exchanges = 0;
+    std::size_t                     _launches = 0, _exchanges = 0, _tags_forwarded = 0;
 
 public:
     FanInRun(std::vector<std::pair<std::shared_ptr<EdgeBufferBase>, std::vector<float>>> local_branches, std::shared_ptr<EdgeBufferBase> out, std::size_t fftSize, int window,
@@ -1544,6 +1544,7 @@ public:
     [[nodiscard]] std::size_t local_channels() const { return _branches.size(); }
     [[nodiscard]] std::size_t launches() const { return _launches; }   // device launches of the branch kernels: ONE per exchange whatever the channel count
     [[nodiscard]] std::size_t exchanges() const { return _exchanges; } // collectives queued
+    [[nodiscard]] std::size_t tags_forwarded() const { return _tags_forwarded; }
 
     work::Result work(std::size_t requested) override {
         try {
@@ -1565,6 +1566,17 @@ public:
             if (_shard.scatter && frames % static_cast<std::size_t>(_shard.n_ranks)) throw std::runtime_error("reduce_scatter fan-in: the exchange's frame count is not a multiple of the rank count");
             if (_out->free_items() < n_out) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
             const std::size_t n = frames * _N;
+            // the exchange's tag: every tag on the exchange's samples of every LOCAL branch merged ("gr:" keys; identical tags on several branches collapse, like
+            // the merged input tag of an n-ary block, Block.hpp:1511-1530), published on the first output sample; gr:sample_rate follows the run's rate change
+            // (1 : 1, or 1 / n_ranks of the frames in scatter mode).  Tags of branches that live on other ranks stay on those ranks.
+            property_map fwd;
+            for (auto& b : _branches)
+                for (const auto& [key, value] : b.in->mergedTags(n)) {
+                    if (!std::string_view(key).starts_with(GR_TAG_PREFIX)) continue;
+                    const float* rate = _shard.scatter && tag::settingsKey(key) == tag::SAMPLE_RATE ? std::get_if<float>(&value) : nullptr;
+                    if (rate) fwd.insert_or_assign(key, *rate / static_cast<float>(_shard.n_ranks));
+                    else fwd.insert_or_assign(key, value);
+                }
             // samples of every local branch land in HBM (pinned staging, one stream: the copies of branch c + 1 run behind those of branch c)
             std::vector<gr4hip_chain_t*> chains;
             std::vector<const void*>     ins;
@@ -1590,6 +1602,7 @@ public:
             }
             check(gr4hip_memcpy_d2h(_h_out.ensure(n_out * 4), result, n_out * 4, _s), "d2h");
             check(gr4hip_stream_synchronize(_s), "stream synchronize");
+            if (!fwd.empty()) { _out->publishTag(fwd, 0); ++_tags_forwarded; }
             _out->write_items(_h_out.p, n_out);
             return {requested, n_out, work::Status::OK};
         } catch (const std::exception& e) {

@@ -39,6 +39,8 @@ static void build(Built& b, const std::vector<std::complex<float>>& x, const std
     for (std::size_t c = 0; c < channels; ++c) {
         const std::string dom = "gpu:hip:" + std::to_string(static_cast<int>(c) % n_devices);
         auto& src  = b.g.emplaceBlock<testing::VectorSource<std::complex<float>>>();
+        if (c == 1) src._tags.push_back(Tag{5 * N + 17, property_map{{"gr:trigger_name", "burst"s}, {"private_key", 1.f}}}); // inside the second exchange of four frames
+        if (c == 2) src._tags.push_back(Tag{0, property_map{{"gr:sample_rate", 2.0e6f}}});
         src.values.resize(x.size());
         for (std::size_t i = 0; i < x.size(); ++i) src.values[i] = x[(i + 977 * c) % x.size()];
         std::vector<double> t = taps;
@@ -87,6 +89,13 @@ int main(int argc, char** argv) {
         const std::size_t frames = x.size() / N, want_launches = (frames + 3) / 4;
         std::printf("run (variant %d): %zu outputs, %zu launches, %zu collectives\n", variant, b.sink->_samples.size(), run->launches(), run->exchanges());
         if (b.sink->_samples.size() != frames * N || run->launches() != want_launches || run->exchanges() != want_launches) ++errors;
+        { // tags cross the run like one n-ary block: channel 2's rate tag on sample 0, channel 1's trigger at the start of the exchange it fell into, "gr:" keys only
+            const auto& tg = b.sink->_tags;
+            const bool ok = C < 3 || (run->tags_forwarded() == 2 && tg.size() == 2 && tg[0].index == 0 && tg[0].map.count("gr:sample_rate") && std::get<float>(tg[0].map.at("gr:sample_rate")) == 2.0e6f &&
+                                      tg[1].index == 4 * N && tg[1].map.count("gr:trigger_name") && !tg[1].map.count("private_key"));
+            std::printf("tags (variant %d): %s (%zu forwarded, %zu received)\n", variant, ok ? "ok" : "FAILED", run->tags_forwarded(), tg.size());
+            if (!ok) ++errors;
+        }
         dump(out + "_fanin" + std::to_string(variant) + ".bin", b.sink->_samples);
     }
     { // the same graph placed on TWO devices, planned for rank 0 (not run: its partner would sit on gpu:hip:1): half of the branches stay, the others leave with their sources
