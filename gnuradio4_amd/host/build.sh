@@ -23,6 +23,7 @@ if stale ../libgr4hip_blocks.so plugin/gr4hip_blocks.cpp; then
   $CXX -O1 -fPIC -shared -fvisibility=hidden plugin/gr4hip_blocks.cpp -o ../libgr4hip_blocks.so -L.. -lgr4hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib & pids+=($!)
 fi
 if stale $OUT/bench_host_feed tests/bench_host_feed.cpp; then $CXX -O2 tests/bench_host_feed.cpp -o $OUT/bench_host_feed $LINK & pids+=($!); fi
+if stale $OUT/bench_host_fanin tests/bench_host_fanin.cpp; then $CXX -O2 tests/bench_host_fanin.cpp -o $OUT/bench_host_fanin $LINK & pids+=($!); fi
 if stale $OUT/dump_signal_generator tests/dump_signal_generator.cpp; then $CXX -O2 tests/dump_signal_generator.cpp -o $OUT/dump_signal_generator $LINK & pids+=($!); fi
 if stale $OUT/test_host_plugin tests/test_host_plugin.cpp; then $CXX -O2 tests/test_host_plugin.cpp -o $OUT/test_host_plugin -ldl & pids+=($!); fi
 for p in "${pids[@]}"; do wait $p; done

@@ -353,6 +353,7 @@ struct EdgeBufferBase {
     // grow an EMPTY edge to at least n items (same memory resource); false if it cannot (data in it, spans out, fan-out mirrors).  Used by the device planner:
     // an edge that feeds a device run wants chunks far larger than the reference's 65536-item default
     virtual bool ensure_capacity(std::size_t /*n*/) { return false; }
+    [[nodiscard]] virtual std::size_t capacity_items() const noexcept { return 0; }
     virtual void                      write_items(const void* src, std::size_t n) = 0; // copy + publish
 };
 template <typename T>
@@ -399,7 +400,11 @@ struct EdgeBuffer final : EdgeBufferBase {
         tail += n;
         advanceWrite(n);
     }
-    void consume(std::size_t n) noexcept { head += n; advanceRead(n); }
+    void consume(std::size_t n) noexcept {
+        head += n;
+        advanceRead(n);
+        if (head == tail && !lent && !reserved) head = tail = 0; // drained: the next span starts at the front again, nothing to move
+    }
     [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
     [[nodiscard]] std::size_t available_items() const noexcept override { return available() - lent; }
     [[nodiscard]] std::size_t free_items() const noexcept override { return free_space(); }
@@ -415,8 +420,8 @@ struct EdgeBuffer final : EdgeBufferBase {
         return p;
     }
     void consume_items(std::size_t n) override {
-        consume(n);
         lent -= std::min(lent, n);
+        consume(n);
     }
     [[nodiscard]] void* reserve_items(std::size_t n) override {
         if (n > free_space()) return nullptr;
@@ -431,6 +436,7 @@ struct EdgeBuffer final : EdgeBufferBase {
     void unlend_items(std::size_t n) override { lent -= std::min(lent, n); }
     void unreserve_items(std::size_t n) override { reserved -= std::min(reserved, n); }
     [[nodiscard]] std::pmr::memory_resource* memory() const override { return resource(); }
+    [[nodiscard]] std::size_t capacity_items() const noexcept override { return capacity; }
     bool ensure_capacity(std::size_t n) override {
         if (n <= capacity) return true;
         if (available() || lent || reserved || !mirrors.empty() || upstream) return false;

@@ -1504,7 +1504,8 @@ struct Shard {
     int             rank = 0, n_ranks = 1;
     gr4hip_fanin_t* comm = nullptr;      // null with n_ranks == 1: no collective at all; non-null: the collective runs even on one rank
     bool            scatter = false;     // true: every rank publishes only its 1 / n_ranks of each exchange's frames (reduce_scatter) instead of the whole sum
-    std::size_t     frames_per_exchange = 64;
+    std::size_t     frames_per_exchange = 0; // 0: as many frames as the branches' input edges hold (plan_sharded's run_edge_items / fftSize): an exchange then drains the edges,
+                                             // which never have to move unread samples to make room (64-frame exchanges on 4 Mi-sample edges: 2.5 instead of 6.4 Gsamples/s host-fed)
 };
 
 class FanInRun final : public BlockModel {
@@ -1512,6 +1513,7 @@ class FanInRun final : public BlockModel {
         std::shared_ptr<EdgeBufferBase> in;
         gr4hip_chain_t*                 chain = nullptr;
         DevBuf                          d_in{false}, h_in{true};
+        std::size_t                     n_lent = 0; // items of the input edge the copy engine is reading in place
     };
     std::deque<Branch>              _branches; // (a Branch owns device buffers: it never moves)
     std::shared_ptr<EdgeBufferBase> _out;
@@ -1545,8 +1547,10 @@ public:
     [[nodiscard]] std::size_t launches() const { return _launches; }   // device launches of the branch kernels: ONE per exchange whatever the channel count
     [[nodiscard]] std::size_t exchanges() const { return _exchanges; } // collectives queued
     [[nodiscard]] std::size_t tags_forwarded() const { return _tags_forwarded; }
+    [[nodiscard]] std::size_t frames_per_exchange() const { return _shard.frames_per_exchange; }
 
     work::Result work(std::size_t requested) override {
+        std::size_t held_reserved = 0;
         try {
             check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
             bool        all_done = true;
@@ -1581,8 +1585,19 @@ public:
             std::vector<gr4hip_chain_t*> chains;
             std::vector<const void*>     ins;
             for (auto& b : _branches) {
-                b.in->read_items(b.h_in.ensure(n * 8), n);
-                check(gr4hip_memcpy_h2d(b.d_in.ensure(n * 8), b.h_in.p, n * 8, _s), "h2d");
+                const void* lent = b.in->lend_items(n);
+                if (lent && b.in->memory() == pinned_resource()) { // page-locked edge ("hip" provider): the copy engine reads the edge in place; the span goes back below
+                    check(gr4hip_memcpy_h2d(b.d_in.ensure(n * 8), lent, n * 8, _s), "h2d");
+                    b.n_lent = n;
+                } else {
+                    if (lent) { // pageable edge: staged through page-locked memory by the copy threads
+                        CopyPool::instance().copy(b.h_in.ensure(n * 8), lent, n * 8);
+                        b.in->consume_items(n);
+                    } else {
+                        b.in->read_items(b.h_in.ensure(n * 8), n);
+                    }
+                    check(gr4hip_memcpy_h2d(b.d_in.ensure(n * 8), b.h_in.p, n * 8, _s), "h2d");
+                }
                 chains.push_back(b.chain);
                 ins.push_back(b.d_in.p);
             }
@@ -1600,13 +1615,23 @@ public:
             } else if (_shard.n_ranks != 1) {
                 throw std::runtime_error("sharded graph without a communicator");
             }
-            check(gr4hip_memcpy_d2h(_h_out.ensure(n_out * 4), result, n_out * 4, _s), "d2h");
+            void* direct = _out->memory() == pinned_resource() ? _out->reserve_items(n_out) : nullptr; // a page-locked output edge takes the result copy in its own storage
+            held_reserved = direct ? n_out : 0;
+            check(gr4hip_memcpy_d2h(direct ? direct : _h_out.ensure(n_out * 4), result, n_out * 4, _s), "d2h");
             check(gr4hip_stream_synchronize(_s), "stream synchronize");
+            for (auto& b : _branches)
+                if (b.n_lent) { b.in->consume_items(b.n_lent); b.n_lent = 0; }
             if (!fwd.empty()) { _out->publishTag(fwd, 0); ++_tags_forwarded; }
-            _out->write_items(_h_out.p, n_out);
+            if (direct) { _out->publish_reserved(n_out); held_reserved = 0; }
+            else if (void* dst = n_out * 4 >= (std::size_t(2) << 20) ? _out->reserve_items(n_out) : nullptr) { CopyPool::instance().copy(dst, _h_out.p, n_out * 4); _out->publish_reserved(n_out); } // large exchange into a pageable edge: the copy threads share it
+            else _out->write_items(_h_out.p, n_out);
             return {requested, n_out, work::Status::OK};
         } catch (const std::exception& e) {
             std::cerr << "[gr::hip] fan-in run failed: " << e.what() << "\n";
+            (void)gr4hip_stream_synchronize(_s); // nothing of the failed exchange may still read a lent span
+            for (auto& b : _branches)
+                if (b.n_lent) { b.in->unlend_items(b.n_lent); b.n_lent = 0; }
+            if (held_reserved) _out->unreserve_items(held_reserved);
             return {requested, 0, work::Status::ERROR};
         }
     }
@@ -1687,7 +1712,20 @@ inline std::vector<FanInRun*> plan_sharded(Graph& g, const Shard& shard, std::si
         if (local.empty()) throw std::runtime_error("plan_sharded: rank " + std::to_string(shard.rank) + " of " + std::to_string(shard.n_ranks) + " owns no branch of the combiner (more ranks than gpu:hip devices in the graph): it could not take part in the exchanges");
         ComputeDomain dom = found[0].fir->compute_domain();
         if (device >= 0) dom.index = device;
-        auto  run = std::make_unique<FanInRun>(std::move(local), add->output_edges()[0], found[0].N, found[0].window, found.size(), shard, dom);
+        Shard sh = shard;
+        if (sh.frames_per_exchange == 0) { // as much as the edges around the run hold (the same graph, hence the same number, on every rank)
+            std::size_t cap = std::numeric_limits<std::size_t>::max();
+            for (auto& [edge, taps] : local) cap = std::min(cap, edge->capacity_items());
+            sh.frames_per_exchange = std::max<std::size_t>(1, cap / found[0].N);
+        }
+        {   // the combiner's output edge takes a whole exchange
+            auto              out  = add->output_edges()[0];
+            const std::size_t need = sh.frames_per_exchange * found[0].N / (sh.scatter ? static_cast<std::size_t>(sh.n_ranks) : 1);
+            if (!out->ensure_capacity(need) && out->capacity_items() < need)
+                sh.frames_per_exchange = std::max<std::size_t>(1, out->capacity_items() * (sh.scatter ? static_cast<std::size_t>(sh.n_ranks) : 1) / found[0].N);
+        }
+        if (sh.scatter) sh.frames_per_exchange = std::max<std::size_t>(1, sh.frames_per_exchange / static_cast<std::size_t>(sh.n_ranks)) * static_cast<std::size_t>(sh.n_ranks);
+        auto  run = std::make_unique<FanInRun>(std::move(local), add->output_edges()[0], found[0].N, found[0].window, found.size(), sh, dom);
         auto* ref = run.get();
         std::vector<std::unique_ptr<BlockModel>> kept;
         for (auto& bp : blocks) {
