@@ -1074,6 +1074,9 @@ class DeviceRun final : public BlockModel {
         std::size_t    n_out = 0, n_lent = 0; // n_lent: input items the copy engine reads in the edge's own storage, released when in_done has fired
         void*          direct = nullptr;      // the result copy lands in the output edge's own (page-locked) storage: published in place
         bool           busy = false;
+        bool           launched = false;      // false: the chunk's samples are on their way into the ring (or there), its kernels are not queued yet
+        const void*    d_src = nullptr;       // where the chunk sits in the ring
+        std::size_t    n_in = 0;
         property_map   fwd; // tags to publish at the first output sample of this chunk
     };
     std::array<Slot, kDepth> _slots;
@@ -1109,7 +1112,10 @@ public:
         for (gr4hip_stream_t* st : {&_s_in, &_s_k, &_s_out}) check(gr4hip_stream_create(st), "gr4hip_stream_create");
         for (auto& sl : _slots)
             for (gr4hip_event_t* ev : {&sl.in_done, &sl.k_done, &sl.out_done}) check(gr4hip_event_create(ev), "gr4hip_event_create");
-        check(gr4hip_ring_create(&_ring, std::size_t(64) << 20), "gr4hip_ring_create"); // GPU-resident double-mapped input ring
+        // GPU-resident double-mapped input ring: kDepth + 1 chunks.  A chunk is a quarter of what the input edge holds (so that the source refills the edge while
+        // chunks are in flight), between 2^21 and 2^23 items: fewer, larger copies and launches per sample
+        const std::size_t chunk_items = in->memory() == pinned_resource() ? std::clamp<std::size_t>(in->capacity_items() / 4, std::size_t(1) << 21, std::size_t(1) << 23) : std::size_t(1) << 21; // (edges that are staged by host copies overlap better in small chunks)
+        check(gr4hip_ring_create(&_ring, (kDepth + 1) * chunk_items * _in_bytes), "gr4hip_ring_create");
         check(gr4hip_ring_base(_ring, &_ring_base), "ring base");
         check(gr4hip_ring_size(_ring, &_ring_bytes), "ring size");
     }
@@ -1174,10 +1180,47 @@ public:
     [[nodiscard]] std::size_t  launches() const { return _launches; }
     const std::vector<std::unique_ptr<Stage>>& stages() const { return _stages; }
 
+    // the kernels and the result copy of a chunk whose samples are on their way into the ring.  Ingest and launch are separate steps: work() queues the copy of
+    // chunk c + 1 BEFORE it launches chunk c, so that the link stays busy while a stage's enqueue waits for its own launch (the strict dynamic-range guard of the
+    // chain: the call returns when the launch has finished) -- with both in one step the copy engine idled for a kernel time per chunk (host-fed 5.4 Gsamples/s
+    // under the strict guard where the deferred one gave 6.1)
+    void launch(Slot& sl) {
+        check(gr4hip_stream_wait_event(_s_k, sl.in_done), "stream wait");
+        const void* cur = sl.d_src;
+        std::size_t cnt = sl.n_in;
+        for (std::size_t i = 0; i < _stages.size(); ++i) { // stages run back-to-back on the kernel stream; intermediates stay in HBM
+            const std::size_t expect = cnt / _stages[i]->in_chunk * _stages[i]->out_chunk;
+            DevBuf&           dst    = i + 1 == _stages.size() ? sl.d_out : ((i % 2) ? _d_b : _d_a); // the last stage writes the chunk's own result buffer
+            std::size_t       out    = 0;
+            check(_stages[i]->enqueue(cur, cnt, dst.ensure(std::max<std::size_t>(expect, 1) * _stages[i]->out_bytes), &out, _s_k), "stage");
+            if (out != expect) throw std::runtime_error("stage '" + std::string(_stages[i]->kind()) + "' produced an unexpected number of samples");
+            cur = dst.p;
+            cnt = out;
+            ++_launches;
+        }
+        if (cnt != sl.n_out) throw std::runtime_error("device run: a chunk produced an unexpected number of samples");
+        check(gr4hip_event_record(sl.k_done, _s_k), "event record");
+        check(gr4hip_stream_wait_event(_s_out, sl.k_done), "stream wait");
+        check(gr4hip_memcpy_d2h(sl.direct ? sl.direct : sl.h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _s_out), "d2h");
+        check(gr4hip_event_record(sl.out_done, _s_out), "event record");
+        sl.launched = true;
+    }
+    // launches every ingested chunk except the newest `keep` ones, oldest first
+    void launch_pending(std::size_t keep) {
+        for (std::size_t i = 0; i + keep < _q_count; ++i) {
+            Slot& sl = _slots[(_q_head + i) % kDepth];
+            if (!sl.launched) launch(sl);
+        }
+    }
+
     // publish the oldest queued chunk (blocking until its result copy has landed unless only_if_done); returns the items published
     std::size_t retire(bool only_if_done) {
         if (_q_count == 0) return 0;
         Slot& sl = _slots[_q_head];
+        if (!sl.launched) {
+            if (only_if_done) return 0;
+            launch(sl);
+        }
         if (only_if_done) {
             int done = 0;
             check(gr4hip_event_query(sl.out_done, &done), "event query");
@@ -1196,7 +1239,7 @@ public:
             _pending_out -= n;
         }
         sl.direct = nullptr;
-        sl.busy = false;
+        sl.busy = sl.launched = false;
         sl.fwd.clear();
         _q_head = (_q_head + 1) % kDepth;
         --_q_count;
@@ -1245,6 +1288,7 @@ public:
             const std::size_t space = _space() - std::min(_space(), _pending_out);  // the output edge minus what queued chunks will publish (reserved spans are already off it)
             n = std::min(n / _in_chunk, space / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
             if (n == 0) {
+                launch_pending(0); // nothing new to copy: whatever has been ingested runs now
                 if (_q_count) { // nothing new to queue
                     // input lent to the copy engine is what keeps a small edge full: give the oldest such span back as soon as ITS copy has landed and let the
                     // source refill the edge while the kernels and the result copy of that chunk still run (waiting for the whole chunk here serialised
@@ -1294,42 +1338,42 @@ public:
                 check(gr4hip_memcpy_h2d(d_in, sl.h_in.p, n * _in_bytes, _s_in), "h2d");
                 check(gr4hip_event_record(sl.in_done, _s_in), "event record");
             }
-            check(gr4hip_stream_wait_event(_s_k, sl.in_done), "stream wait");
             _ring_wr = (_ring_wr + n * _in_bytes) % _ring_bytes;
-            const void* cur = d_in;
-            std::size_t cnt = n;
-            for (std::size_t i = 0; i < _stages.size(); ++i) { // stages run back-to-back on the kernel stream; intermediates stay in HBM
-                const std::size_t expect = cnt / _stages[i]->in_chunk * _stages[i]->out_chunk;
-                DevBuf&           dst    = i + 1 == _stages.size() ? sl.d_out : ((i % 2) ? _d_b : _d_a); // the last stage writes the chunk's own result buffer
-                std::size_t       out    = 0;
-                check(_stages[i]->enqueue(cur, cnt, dst.ensure(std::max<std::size_t>(expect, 1) * _stages[i]->out_bytes), &out, _s_k), "stage");
-                if (out != expect) throw std::runtime_error("stage '" + std::string(_stages[i]->kind()) + "' produced an unexpected number of samples");
-                cur = dst.p;
-                cnt = out;
-                ++_launches;
-            }
-            check(gr4hip_event_record(sl.k_done, _s_k), "event record");
-            check(gr4hip_stream_wait_event(_s_out, sl.k_done), "stream wait");
-            check(gr4hip_memcpy_d2h(direct ? direct : sl.h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _s_out), "d2h");
-            check(gr4hip_event_record(sl.out_done, _s_out), "event record");
-            sl.n_out  = cnt;
-            sl.busy   = true;
-            sl.direct = direct;
-            sl.fwd    = std::move(fwd);
+            sl.d_src    = d_in;
+            sl.n_in     = n;
+            sl.n_out    = out_count(n);
+            sl.busy     = true;
+            sl.launched = false;
+            sl.direct   = direct;
+            sl.fwd      = std::move(fwd);
             if (direct) ++_direct_chunks;
-            else _pending_out += cnt;
+            else _pending_out += sl.n_out;
             ++_q_count;
-            return {requested, n, work::Status::OK}; // (the slot owns the spans from here on)
+            held_lent = held_reserved = 0; // (the slot owns the spans from here on)
+            launch_pending(1);             // the chunk before this one: its kernels go out while this chunk's copy is on the link
+            return {requested, n, work::Status::OK};
         } catch (const std::exception& e) {
             std::cerr << "[gr::hip] device run failed: " << e.what() << "\n";
             // the failed chunk's spans go back to their edges untouched (a graph that tolerates ERROR must not find free_items() / available_items() shrunk
             // for good) -- once nothing queued on the streams can still read or write them
-            if (held_lent || held_reserved) {
+            bool unlaunched = false;
+            for (std::size_t i = 0; i < _q_count; ++i) unlaunched = unlaunched || !_slots[(_q_head + i) % kDepth].launched;
+            if (held_lent || held_reserved || unlaunched) {
                 (void)gr4hip_stream_synchronize(_s_in);
                 (void)gr4hip_stream_synchronize(_s_k);
                 (void)gr4hip_stream_synchronize(_s_out);
                 if (held_lent) _in_edge->unlend_items(held_lent);
                 if (held_reserved) _out_edge->unreserve_items(held_reserved);
+                while (_q_count && !_slots[(_q_head + _q_count - 1) % kDepth].launched) { // ingested chunks whose launch failed (or never happened): the newest entries of the queue
+                    Slot& sl = _slots[(_q_head + _q_count - 1) % kDepth];
+                    if (sl.n_lent) { _in_edge->unlend_items(sl.n_lent); sl.n_lent = 0; }
+                    if (sl.direct) _out_edge->unreserve_items(sl.n_out);
+                    else _pending_out -= std::min(_pending_out, sl.n_out);
+                    sl.direct = nullptr;
+                    sl.busy   = false;
+                    sl.fwd.clear();
+                    --_q_count;
+                }
             }
             return {requested, 0, work::Status::ERROR};
         }
@@ -1387,7 +1431,9 @@ DeviceRun& fuse_chain(Graph& g, First& first, Rest&... rest) {
 // kernel collapse into it (fir_filter<complex<float>> -> PowerSpectrum = gr4hip_chain, any window).  Returns the runs it created.
 // run_edge_items: the edges at both ends of every run are grown to at least this many items while they are still empty (same memory resource; 0: left
 // alone).  A run moves its input over the link in whole chunks and keeps several in flight; on the reference's default 65536-item edges a chunk IS the edge and
-// source, copies and kernels take turns (0.75 Gsamples/s host-fed where 2^22-item edges give 5.7: profiles/r02_host_feed.txt).
+// source, copies and kernels take turns (0.75 Gsamples/s host-fed where 2^22-item edges give 5.7: profiles/r02_host_feed.txt).  Larger page-locked edges that a
+// driver fills by DMA are worth having (a run moves a quarter of such an edge per chunk, up to 64 MiB: 4.8 / 6.2 Gsamples/s on 2^22 / 2^24-item edges); edges the
+// CPU writes sample by sample are not (cache footprint: 3.4 -> 2.6 with a copying source): profiles/r03_host_feed.txt.
 inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2, std::size_t run_edge_items = std::size_t(1) << 22) {
     auto& blocks = g.blocks();
     const auto eligible = [](BlockModel& b) {
