@@ -1137,6 +1137,7 @@ public:
     std::size_t release_oldest_input() {
         for (std::size_t i = 0; i < _q_count; ++i) {
             Slot& sl = _slots[(_q_head + i) % kDepth];
+            if (!sl.launched) break; // a chunk keeps its input until its kernels are queued: one whose launch fails goes back to the edge whole
             if (sl.n_lent == 0) continue;
             check(gr4hip_event_synchronize(sl.in_done), "event sync");
             const std::size_t n = sl.n_lent;
@@ -1148,8 +1149,10 @@ public:
     }
     // input spans lent to the copy engine go back to the edge, oldest first, as their copies land (wait: block until all have)
     void release_inputs(bool wait) {
+        if (wait) launch_pending(0); // (everything lent is to go back: the chunks that hold spans run first)
         for (std::size_t i = 0; i < _q_count; ++i) {
             Slot& sl = _slots[(_q_head + i) % kDepth];
+            if (!sl.launched) break;
             if (sl.n_lent == 0) continue;
             if (wait) check(gr4hip_event_synchronize(sl.in_done), "event sync");
             else {
@@ -1328,10 +1331,9 @@ public:
                 sl.n_lent = n;
                 ++_inplace_chunks;
             } else {
-                if (lent) { // pageable edge: staged through page-locked memory by the copy threads
-                    CopyPool::instance().copy(sl.h_in.ensure(n * _in_bytes), lent, n * _in_bytes);
-                    _in_edge->consume_items(n);
-                    held_lent = 0;
+                if (lent) { // pageable edge: staged through page-locked memory by the copy threads; the span stays lent until the chunk's copy has landed, like an
+                    CopyPool::instance().copy(sl.h_in.ensure(n * _in_bytes), lent, n * _in_bytes); // in-place one -- a chunk whose launch fails goes back to the edge whole
+                    sl.n_lent = n;
                 } else {
                     _read(sl.h_in.ensure(n * _in_bytes), n);
                 }

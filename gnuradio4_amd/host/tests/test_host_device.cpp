@@ -653,6 +653,51 @@ int main(int argc, char** argv) {
             if (!(worst <= 2e-6) || !stepped) ++errors;
         }
     }
+    { // a stage that fails in the middle of the stream: the run reports ERROR, the chunk whose launch failed and the chunk whose copy was already on its way go back
+      // to the input edge untouched, nothing is published twice or lost, and the stream completes once the stage works again (page-locked and ordinary edges)
+        struct FlakyStage final : hip::Stage {
+            hip::MathConstStage<float, GR4HIP_MUL> inner{3.f};
+            int calls = 0, fail_at;
+            explicit FlakyStage(int fail_at_) : fail_at(fail_at_) { in_bytes = out_bytes = 4; }
+            std::string_view kind() const override { return "flaky"; }
+            int enqueue(const void* in, std::size_t n, void* o, std::size_t* n_out, gr4hip_stream_t st) override {
+                if (++calls == fail_at) return GR4HIP_RUNTIME_ERROR;
+                return inner.enqueue(in, n, o, n_out, st);
+            }
+        };
+        for (int pinned = 0; pinned < 2; ++pinned) {
+            hip::register_provider();
+            std::pmr::memory_resource* mr = pinned ? hip::pinned_resource() : std::pmr::get_default_resource();
+            const std::size_t cap = std::size_t(1) << 23, total = std::size_t(5) << 22;
+            auto in  = std::make_shared<EdgeBuffer<float>>(cap, mr);
+            auto outb = std::make_shared<EdgeBuffer<float>>(cap, mr);
+            std::vector<std::unique_ptr<hip::Stage>> st;
+            st.push_back(std::make_unique<FlakyStage>(3));
+            hip::DeviceRun run(std::move(st), in, outb, ComputeDomain::parse("gpu:hip:0"));
+            std::size_t fed = 0, got = 0, n_err = 0, bad = 0;
+            for (int iter = 0; iter < 10000 && got < total; ++iter) {
+                const std::size_t room = std::min(in->free_space(), total - fed);
+                if (room) {
+                    auto span = in->write_span(room);
+                    for (std::size_t i = 0; i < room; ++i) span[i] = static_cast<float>((fed + i) % 1021);
+                    in->publish(room);
+                    fed += room;
+                }
+                if (fed == total) in->producer_done = true;
+                const auto r = run.work(std::numeric_limits<std::size_t>::max());
+                if (r.status == work::Status::ERROR) ++n_err;
+                const std::size_t avail = outb->available();
+                auto rs = outb->read_span(avail);
+                for (std::size_t i = 0; i < avail; ++i) bad += rs[i] != 3.f * static_cast<float>((got + i) % 1021);
+                outb->consume(avail);
+                got += avail;
+                if (r.status == work::Status::DONE) break;
+            }
+            const bool ok = n_err == 1 && got == total && bad == 0 && in->available() == 0;
+            std::printf("a failing launch in mid-stream (%s edges): %s (%zu errors, %zu of %zu samples, %zu wrong)\n", pinned ? "page-locked" : "ordinary", ok ? "recovered" : "FAILED", n_err, got, total, bad);
+            if (!ok) ++errors;
+        }
+    }
     std::printf(errors ? "host-device: %d FAILURES\n" : "host-device: all graphs ran\n", errors);
     return errors ? 1 : 0;
 }
