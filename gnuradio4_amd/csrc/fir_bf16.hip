@@ -43,6 +43,10 @@ using u32x4_b = __attribute__((ext_vector_type(4))) unsigned;
 #ifndef GR4_BF16_WG_PER_CU
 #define GR4_BF16_WG_PER_CU 2
 #endif
+#ifndef GR4_BF16_TARGET_WGS
+#define GR4_BF16_TARGET_WGS 512 // two workgroups per CU, each walking up to 128 segments (measured against 1024 x 64, 2048 x 32, 4096 x 16: 387 / 386 / 380 / 371 Gsamples/s at 256 taps)
+#define GR4_BF16_MAX_SPW 128
+#endif
 constexpr int kBfSeg = 4096, kBfSegPerWg = 4;
 constexpr int kBfSharedMinKS = 8; // measured: 8 % faster at 256 taps, equal at 200, slower below (those windows are HBM- and power-bound, not operand-bound)
 
@@ -667,7 +671,7 @@ int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, c
     const auto af = static_cast<const u32x4_b*>(afrag);
     if (KS >= kBfSharedMinKS && 32 * KS - 16 + delay <= kBfSeg) { // the wide windows: shared fragment stream, double-buffered planes (fir_mfma_bf16x3_shared_kernel)
         const long nseg = ceil_div(n, (long)kBfSeg);
-        const int  spw  = (int)std::min<long>(std::max<long>(nseg * (long)nch / 2048, 1), 32); // segments per workgroup: >= 2048 workgroups when the span has them, the prologue (tap fragments, first staging) once per run
+        const int  spw  = (int)std::min<long>(std::max<long>(nseg * (long)nch / GR4_BF16_TARGET_WGS, 1), GR4_BF16_MAX_SPW); // segments per workgroup: the prologue (tap fragments, first staging) once per run
         const dim3 grid((unsigned)ceil_div(nseg, (long)spw), nch);
         if (KS == 8) hipLaunchKernelGGL(fir_mfma_bf16x3_shared_kernel<8>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist, in_stride, out_stride, delay, accum, spw);
         else hipLaunchKernelGGL(fir_mfma_bf16x3_shared_kernel<9>, grid, dim3(256), 0, st, x, hist, Kh, af, y, n, new_hist, in_stride, out_stride, delay, accum, spw);
