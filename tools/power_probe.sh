@@ -19,6 +19,13 @@ elif cfg.startswith("cfir"):
     x = G.synth_c32(n); y = torch.empty_like(x); f = G.fir_filter(lowpass(int(cfg[4:])), torch.complex64); f.set_algo(capi.FIR_TIME_DOMAIN); run = lambda: f.process_bulk(x, y); units = n
 elif cfg.startswith("fft"):
     N = int(cfg[3:]); x = G.synth_c32(n); y = torch.empty((n // N, N), dtype=torch.float32, device="cuda"); f = G.FFT(N, "None"); run = lambda: f.mag2(x, y); units = n
+elif cfg == "iir4":
+    b, a = G.blocks.design_iir(capi.LOWPASS, 8, 0.05, float("nan"), 1.0, capi.BUTTERWORTH)
+    x = G.synth_f32(2 * n, seed=42); y = torch.empty_like(x); f = G.iir_filter(b, a); run = lambda: f.process_bulk(x, y); units = 2 * n
+elif cfg == "decim8":
+    x = G.synth_f32(2 * n, seed=42); y = torch.empty(2 * n // 8, dtype=torch.float32, device="cuda"); f = G.fir_filter(lowpass(1024), torch.float32, decimate=8); run = lambda: f.process_bulk(x, y); units = 2 * n
+elif cfg == "rotator":
+    x = G.synth_c32(n); y = torch.empty_like(x); f = G.Rotator(phase_increment=0.37); run = lambda: f.process_bulk(x, out=y); units = n
 elif cfg.startswith("chain"):  # chain<taps>_<fftSize>_<window>[_fd]: GR4HIP_CHAIN_AUTO (or the fused fast convolution with _fd)
     p = cfg[5:].split("_"); N = int(p[1])
     x = G.synth_c32(n); y = torch.empty((n // N, N), dtype=torch.float32, device="cuda"); f = G.Chain(lowpass(int(p[0])), N, p[2], capi.CHAIN_FUSED_FD if len(p) > 3 else capi.CHAIN_AUTO); run = lambda: f.process_bulk(x, y); units = n
