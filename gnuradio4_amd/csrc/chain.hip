@@ -44,7 +44,7 @@ struct gr4hip_chain {
     DeviceBuffer    d_y;
     // dynamic-range guard (GR4HIP_CHAIN_AUTO on the fused kernel).  The fast-convolution kernels carry the float32 rounding of their transforms, ~2e-6 of the
     // INPUT rms per output sample; the parity bar is 1e-5 of the OUTPUT, so they meet it while out_rms / in_rms >= 0.2, i.e. power ratio >= 0.04 (-14 dB).
-    // Every fused launch samples both powers (one frame in sixteen).  The first call after create / reset probes its first frames synchronously; later calls
+    // Every fused launch measures both powers of every frame (a frame below the threshold by itself marks the launch: chain_fused.hip).  The first call after create / reset probes its first frames synchronously; later calls
     // read the finished measurements of earlier ones without waiting.  Below the threshold the handle switches to the direct-form kernels (the
     // reference's own arithmetic) from the call that finds out onwards, until reset.
     bool            guard = false, probed = false, use_td = false;

@@ -63,15 +63,23 @@ struct ChainFdArgs {
     const float2* twS;    // small-FFT mode: W_fftSize^j
     float*        out;    // frames * 8192 mag2
     long          n_frames;
-    float*        pw;     // optional 16 x {sum |x|^2, sum of the outputs' power} + workgroups done, over every 16th frame of every workgroup (dynamic-range guard), else null
+    float*        pw;     // optional 16 x {sum |x|^2, sum of the outputs' power} + workgroups done + a flag word, over a quarter of every frame's points (dynamic-range guard), else null
     float*        pw_host; // page-locked {in, out}: written with one 8-byte store by the last workgroup to finish (no extra stream operation per launch)
     unsigned      pw_seq;
+    unsigned      pw_mask; // 0: every frame is measured
+    float         pw_thr; // a frame whose sampled output power is below pw_thr x its sampled input power marks the launch (word 33 of pw, word 3 of pw_host)
     unsigned long long* dbg; // GR4_FD_TIMING only
 };
 // several channels in ONE launch (gr4hip_chain_process_multi, kModeMag2 only).  fold_ch > 1: every workgroup takes frame f of ALL channels in turn (same taps:
 // H and the tap fragments are shared) and keeps sum_c |FFT(fir(x_c))|^2 in registers -- the combiner math::Add<float> (blocks/math/.../Math.hpp:73-108, left fold over
 // the inputs) as the store epilogue: 8 + 4 / n B per sample instead of 12 + the fold's traffic.  fold_ch == 1: workgroup b belongs to channel b mod n_ch
 // (its own taps, history, output and power slots), frames b / n_ch + i gridDim / n_ch: one resident workgroup per CU instead of n persistent kernels that contend for them.
+#ifndef GR4_PW_IN_STEP
+#define GR4_PW_IN_STEP 1 // every input sample of every frame (a lane's samples t + 512 m are 512-sample stripes of the frame: a subset of m is blind to a burst in the others)
+#endif
+constexpr int   kLdsEbfBytes = (2 * kSLen + 512 + 256) * 8 + 4 * 2 * 256 * 4 + 6 * 512 * 2; // LDS of the non-windowed filter modes (= lds_ebf of chain_fused_run); the 16 verdict words follow it
+constexpr int   kPwFrameSlots = 40, kPwMaxWorkgroups = 2048; // ChainFdArgs::pw: words 0 .. 35 as before, then two words per workgroup for the frames' verdicts
+constexpr float kGuardFrameThreshold = 0.04f; // the guard's output / input power threshold (chain.hip, fir.hip), applied to every frame by itself inside the kernel
 constexpr int kMaxMulti = 16;
 struct ChainFdMulti {
     int           n_ch, fold_ch;
@@ -242,6 +250,17 @@ __device__ __forceinline__ void passA_inplace(float2* S, const float2 (&twA)[16]
 // the next frame streams in by LDS-DMA while this one is transformed, which the load -> transform -> store body of fft_fast_kernel cannot do.
 // MODE 6 / 7 (kModeFftSpec / kModeFftWinSpec): the same plain transform, the complex spectrum itself as output (gr4hip_fft_spectrum).
 enum { kModeMag2 = 0, kModeWinMag2 = 1, kModeFir = 2, kModeWinSmall = 3, kModeFftMag2 = 4, kModeFftWinMag2 = 5, kModeFftSpec = 6, kModeFftWinSpec = 7 };
+// sum of v over the wave on the DPP network (row shifts, then the two row broadcasts): the total lands in lane 63
+__device__ __forceinline__ float wave_total_lane63(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)); // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true)); // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)); // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true)); // row_shr:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true)); // row_bcast:15 into rows 1, 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true)); // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 template <int MODE, int LOG2NF, bool MULTI>
 __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti* mc) {
     constexpr bool WIN   = MODE == kModeWinMag2 || MODE == kModeWinSmall; // y_f is needed in the time domain and multiplied by a.win
@@ -276,6 +295,9 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
     float2* T1 = T0 + 256;                           // 256: same for B1
     float2* el = T1 + 256;                           // 256: e[n]
     float*  P  = reinterpret_cast<float*>(el + 256); // [4 K quarters][re, im][256]: partial e; WIN: followed by the pass-B twiddle table [16][32]
+    if constexpr (!WIN && !FFTONLY) { // the frames' verdict words (dynamic-range guard) start at zero; the first frame's top barrier comes before anyone reads them
+        if (threadIdx.x < 16) reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + kLdsEbfBytes)[threadIdx.x] = 0.f;
+    }
     constexpr bool EBFW = GR4_E_BF16 && GR4_E_BF16_WIN && WIN;                  // windowed modes: the table keeps rows 1 .. 15 only (row 0 is never read), which is the 256 bytes the bf16 planes need
     float*  Dre = P + 4 * 2 * 256 + (WIN ? (EBFW ? 960 : 1024) : 0);                  // kDPad: Dz[s] = d[s - 1] (1 <= s <= 255), zero elsewhere (s <= 511); planar, one pad
     float*  Dim = Dre + kDPad;                       //        float per 16 samples so that the MFMA B-operand reads are conflict-free
@@ -353,7 +375,14 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
     // likewise the eight DMA pieces per wave of the next frame.  A wave that issues its 16 stores (or 8 DMAs) back to back sits
     // in VMEM issue for ~4000 cycles behind the other waves' requests and every barrier inherits the skew.
     float pend[16], pendi[16]; // (pendi: imaginary parts, kModeFir only -- y_f is complex)
-    float pw_in = 0.f, pw_out = 0.f; // dynamic-range guard: input and output power of the sampled frames
+    float pw_in = 0.f, pw_out = 0.f; // dynamic-range guard: sampled input and output power of this workgroup's frames
+    // ... and every frame's own verdict: the sum over the WORKGROUP of out - thr * in (a wave alone will not do: its bins are 64-bin windows 2048 apart, and a narrow
+    // pass band lands in the windows of two or three waves).  Each wave adds its total into one of two words of global scratch (L2 atomics, no LDS: the windowed
+    // kernels have none to spare, and no barrier of their own: the frame's top barrier orders them), thread 0 collects the sum of the frame before two iterations later.
+    float  pw_dprev = 0.f;  // this lane's out - thr * in of the frame before
+    float  pw_pend = 0.f;   // thread 0: the workgroup sum requested an iteration ago
+    float  pw_dmin = 0.f;   // thread 0: the smallest workgroup sum so far (negative: a frame fell below the threshold by itself)
+    float* pw_slot = a.pw != nullptr ? a.pw + kPwFrameSlots + 2 * blockIdx.x : nullptr;
     int   iter = 0;
     [[maybe_unused]] int fiter = 0; // frames this workgroup has finished (MULTI: an item is one channel of a frame)
 #pragma unroll
@@ -369,7 +398,10 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
         dma_frame(xof(0) + f * kN, B0, wave, lane0);
     }
     for (; f < a.n_frames; cur ^= 1, ++iter) {
-        const bool measure = !FFTONLY && a.pw != nullptr && ((MULTI ? fiter : iter) & 15) == 0; // wave-uniform: one frame in sixteen pays ~50 extra VALU instructions (MULTI: that frame of every channel)
+        // EVERY frame: an eighth of its input samples, all of its output bins (about 35 VALU instructions per lane and frame): a frame the guard does not look at is a frame it cannot vouch for.
+        // (pw_mask is 0; as a run-time value it keeps the branch a branch -- with a loop-invariant condition the compiler builds two loops and the measured one spills)
+        const bool measure = !FFTONLY && a.pw != nullptr && ((unsigned)iter & a.pw_mask) == 0u;
+        [[maybe_unused]] float fr_in = 0.f; // this work item's sampled input power
         // per-iteration opaque copy of the lane id: lane-dependent LDS / buffer offsets are recomputed here (a few VALU ops)
         // instead of being hoisted out of the loop as dozens of loop-invariant VGPRs
         int tl = threadIdx.x;
@@ -386,6 +418,23 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
         GR4_STAMP(0);
         GR4_FULL_BARRIER(); // T: this frame's image has landed (vmcnt(0) + barrier); everything of the previous frame is dead
         GR4_STAMP(1);
+        if constexpr (!FFTONLY) {
+            if (a.pw != nullptr) {
+                const float wt = wave_total_lane63(pw_dprev); // the frame before this one
+                if constexpr (!WIN) { // 64 bytes of LDS behind the image: wave totals of frame i - 1 in, the sum of frame i - 2 out (wave 0); the frame's own barriers order them
+                    float* Gv = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + kLdsEbfBytes);
+                    if ((threadIdx.x & 63) == 63) Gv[8 * (iter & 1) + (threadIdx.x >> 6)] = wt;
+                    if (threadIdx.x < 64) {
+                        const float4 g0 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1)), g1 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1) + 4);
+                        pw_dmin = fminf(pw_dmin, ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w)));
+                    }
+                } else { // the windowed kernels fill their 160 KiB to the byte: two words of global scratch per workgroup, L2 atomics
+                    pw_dmin = fminf(pw_dmin, pw_pend);
+                    if ((threadIdx.x & 63) == 63) atomicAdd(pw_slot + (iter & 1), wt);
+                    if (threadIdx.x == 0) pw_pend = atomicExch(pw_slot + ((iter + 1) & 1), 0.f); // the frame before that: every wave's share arrived before the barrier above
+                }
+            }
+        }
         // stream the next frame (and the 256 samples before it) into the other buffers: in flight until the next barrier T.
         // Unconditional (the last iteration re-reads its own frame): no divergent paths around the DMA for hipcc's wait insertion
 #if defined(GR4_T_L2ONLY) // developer timing build (results are wrong): every workgroup re-reads and re-writes ITS FIRST frame -- the same instructions with the traffic held in L2
@@ -426,9 +475,12 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                 for (int m = 0; m < 16; ++m) v[m] = make_float2(v[m].x * wA[m], v[m].y * wA[m]);
             }
             if constexpr (!FFTONLY) {
-                if (measure) {
+                if (measure) { // x[t + 512 m], m = 0, 8: an eighth of the frame's samples, spread over all of it (1024 per workgroup)
+                    float s = 0.f;
 #pragma unroll
-                    for (int m = 0; m < 16; ++m) pw_in = fmaf(v[m].x, v[m].x, fmaf(v[m].y, v[m].y, pw_in));
+                    for (int m = 0; m < 16; m += GR4_PW_IN_STEP) s = fmaf(v[m].x, v[m].x, fmaf(v[m].y, v[m].y, s));
+                    fr_in = (float)GR4_PW_IN_STEP * s;
+                    pw_in += fr_in;
                 }
                 if (par && n0 > 0) { // v[15] is x_f[N - 256 + n0]:  Dz[n0] = d[n0 - 1]
                     const float2 dd = csub(Tc[n0], v[15]);
@@ -705,10 +757,16 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
             }
         }
         if constexpr (!FFTONLY) {
-            if (measure) {
+            if (measure) { // ALL of the lane's outputs: its sixteen bins t + 512 q are a comb over the whole spectrum, any subset of q is not (a low-pass sits in q = 0 and 15)
+                float fr_out = MULTI ? m2sum : 0.f;
+                if constexpr (!MULTI) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) pw_out += MULTI ? 0.f : (MODE == kModeFir ? fmaf(pend[q], pend[q], pendi[q] * pendi[q]) : pend[q]);
-                if constexpr (MULTI) pw_out += m2sum;
+                    for (int q = 0; q < 16; ++q) fr_out += MODE == kModeFir ? fmaf(pend[q], pend[q], pendi[q] * pendi[q]) : pend[q];
+                }
+                pw_out += fr_out;
+                // the frame's own verdict, per wave (1024 of its points): the wave's sum of out - thr * in on the DPP network (it lands in lane 63; the other lanes keep
+                // partial sums nobody reads), its minimum over the frames kept per lane -- no LDS, no barrier, no branch
+                pw_dprev = fmaf(-a.pw_thr, fr_in, fr_out); // (summed over the wave at the top of the next iteration: the DPP sequence here costs the compiler ten spills)
             }
         }
         fprev = f;
@@ -729,6 +787,14 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                 pw_in += __shfl_xor(pw_in, off);
                 pw_out += __shfl_xor(pw_out, off);
             }
+            {   // the last two frames' verdicts
+                const float wt = wave_total_lane63(pw_dprev);
+                if constexpr (!WIN) {
+                    if ((threadIdx.x & 63) == 63) reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + kLdsEbfBytes)[8 * (iter & 1) + (threadIdx.x >> 6)] = wt;
+                } else {
+                    if ((threadIdx.x & 63) == 63) atomicAdd(pw_slot + (iter & 1), wt);
+                }
+            }
             __syncthreads(); // (P below is not a DMA target; every lane is past its last use of it)
             if ((threadIdx.x & 63) == 0) {
                 P[2 * (threadIdx.x >> 6)]     = pw_in;
@@ -736,6 +802,16 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
             }
             __syncthreads();
             if (threadIdx.x == 0) {
+                if constexpr (!WIN) {
+                    const float* Gv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + kLdsEbfBytes);
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) { s0 += Gv[w]; s1 += Gv[8 + w]; }
+                    pw_dmin = fminf(pw_dmin, fminf(s0, s1));
+                } else {
+                    pw_dmin = fminf(fminf(pw_dmin, pw_pend), fminf(atomicExch(pw_slot, 0.f), atomicExch(pw_slot + 1, 0.f))); // (the slots are zero again for the next launch)
+                }
+                if (pw_dmin < 0.f) atomicOr(reinterpret_cast<unsigned*>(a.pw + 33), 1u);
                 float si = 0.f, so = 0.f;
 #pragma unroll
                 for (int w = 0; w < kT / 64; ++w) { si += P[2 * w]; so += P[2 * w + 1]; }
@@ -749,6 +825,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                     float tin = 0.f, tout = 0.f;
                     for (int k = 0; k < 16; ++k) { tin += atomicExch(a.pw + 2 * k, 0.f); tout += atomicExch(a.pw + 2 * k + 1, 0.f); }
                     atomicExch(done, 0u);
+                    reinterpret_cast<volatile unsigned*>(a.pw_host)[3] = atomicExch(reinterpret_cast<unsigned*>(a.pw + 33), 0u); // a frame of this launch fell below the threshold
                     // ONE 8-byte store: the pair arrives whole; then, behind a system-scope fence, the launch's sequence number -- what a waiting host spins on
                     // (a few microseconds after the last workgroup instead of a stream synchronisation's wake-up)
                     *reinterpret_cast<volatile unsigned long long*>(a.pw_host) = (unsigned long long)__float_as_uint(tin) | ((unsigned long long)__float_as_uint(tout) << 32);
@@ -916,9 +993,10 @@ int chain_fused_reset(ChainFused* c) {
 // dynamic-range guard: this launch of `c` is a measured one (accumulators and the mapped result word exist from the first time on)
 static int arm_measure(ChainFused* c, hipStream_t st) {
     if (!c->h_pw) {
-        int rc = c->d_pw.ensure(36 * sizeof(float)); // 16 {in, out} slots, the done counter
+        constexpr size_t words = kPwFrameSlots + 2 * kPwMaxWorkgroups; // 16 {in, out} slots, the done counter, the flag word, two verdict words per workgroup
+        int rc = c->d_pw.ensure(words * sizeof(float));
         if (rc) return rc;
-        GR4_HIP_TRY(hipMemset(c->d_pw.ptr, 0, 36 * sizeof(float)));
+        GR4_HIP_TRY(hipMemset(c->d_pw.ptr, 0, words * sizeof(float)));
         GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 4 * sizeof(float), hipHostMallocMapped));
         std::memset(c->h_pw, 0, 4 * sizeof(float));
         GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_hpw), c->h_pw, 0));
@@ -965,6 +1043,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         a.pw      = static_cast<float*>(c->d_pw.ptr);
         a.pw_host = c->d_hpw;
         a.pw_seq  = c->pw_seq;
+        a.pw_thr  = kGuardFrameThreshold * (fir_mode ? 1.f : (float)(c->small_log2n ? (1 << c->small_log2n) : kN) * c->win_gain); // (the scale chain_fused_power_ratio takes out)
     }
 #ifdef GR4_FD_TIMING
     if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
@@ -973,7 +1052,8 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     // two frame buffers, two tails, e | partial tiles (+ WIN: pass-B twiddle table), planar padded d, taps
     constexpr size_t lds_base = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
     constexpr size_t lds_win  = lds_base + ((GR4_E_BF16 && GR4_E_BF16_WIN) ? 960 * sizeof(float) + 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 1024 * sizeof(float)); // = 160 KiB exactly with the bf16 planes
-    constexpr size_t lds_ebf  = lds_base + (GR4_E_BF16 ? 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 0); // non-windowed filter modes: six bf16 planes of Dz instead of Dre / Dim / hl
+    constexpr size_t lds_ebf  = lds_base + (GR4_E_BF16 ? 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 0) + 64; // non-windowed filter modes: six bf16 planes of Dz instead of Dre / Dim / hl, + the 16 verdict words
+    static_assert(!GR4_E_BF16 || lds_ebf == (size_t)kLdsEbfBytes + 64, "the kernel's verdict words sit behind the image");
     static_assert(lds_win <= 160 * 1024 && lds_ebf <= 160 * 1024, "LDS budget of one CU");
     const size_t lds  = (c->windowed && !fir_mode && !fft_only) ? lds_win : (fft_only ? lds_base : lds_ebf);
     static PerDevice per_device; // LDS opt-in and CU count, once per device this process uses
@@ -1095,7 +1175,8 @@ int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps,
         }
     }
     if (fold) { a.pw = m.pws[0]; a.pw_host = m.pw_hosts[0]; a.pw_seq = m.pw_seqs[0]; }
-    constexpr size_t lds = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256) * sizeof(float) + 6 * 512 * sizeof(unsigned short); // = lds_ebf of chain_fused_run
+    a.pw_thr = kGuardFrameThreshold * (float)kN; // (8192-point rectangular-window chains only: window gain 1)
+    constexpr size_t lds = (size_t)kLdsEbfBytes + 64; // = lds_ebf of chain_fused_run
     static PerDevice per_device;
     bool             first = false;
     int              dev = -1, n_cu = per_device.current(&first, &dev);
@@ -1149,6 +1230,9 @@ int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* r
     // spectra: sum_k |Y_k|^2 = N sum_n |w_n y_n|^2 ~ N mean(w^2) sum |y|^2; the complex FIR output is y itself
     const double nfft = c->small_log2n ? (double)(1 << c->small_log2n) : (double)kN; // the spectra summed are fftSize-point ones
     *ratio = in > 0 ? (float)(out / (in * (fir_output ? 1.0 : nfft * c->win_gain))) : 1.f;
+    // the launch-wide ratio can hide a frame: an interferer that arrives late in a long span barely moves the sums.  Every frame is judged by itself in the kernel
+    // (a quarter of its points, per wave); a launch with ONE frame below the threshold reports below the threshold
+    if (reinterpret_cast<volatile unsigned*>(c->h_pw)[3] != 0u && *ratio >= kGuardFrameThreshold) *ratio = 0.5f * kGuardFrameThreshold;
     return 1;
 }
 const float* chain_fused_history(const ChainFused* c) { return static_cast<const float*>(c->d_hist.ptr); } // the 256 samples before the next call's first frame

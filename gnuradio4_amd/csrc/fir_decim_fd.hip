@@ -38,7 +38,9 @@ constexpr int kDfRS  = 4552;            // bytes per wave-private region (568 fl
 constexpr int kDfOffW = 32768;          // landing buffer: 8192 floats at 0
 constexpr int kDfOffF = kDfOffW + 8 * kDfRS; // F_q[i''] of the inverse transforms: 8 x 128 float2 (pitch 129: the final pass reads 8 rows per lane)
 constexpr int kDfLds  = kDfOffF + 8 * 129 * 8;
-static_assert(2 * kDfLds <= 160 * 1024, "two workgroups per CU");
+constexpr int kDfLdsAll = kDfLds + 64; // + the 16 verdict words of the dynamic-range guard (two slots x 8 waves)
+static_assert(2 * kDfLdsAll <= 160 * 1024, "two workgroups per CU");
+constexpr float kDecimFdBlockThreshold = 2.5e-3f; // = kDecimFdMinPowerRatio of fir.hip: the guard's output / input power threshold, applied to every block by itself
 
 struct DecimFdArgs {
     const float*  x;       // input samples (the span); block j covers positions j * 7168 - 1024 .. + 8191
@@ -56,9 +58,10 @@ struct DecimFdArgs {
     const float*  x_tail;
     long          tail_blk;
     int           tail_out;
-    float*        pw;      // dynamic-range guard (optional): 16 slots of {sum x^2, sum y^2} over every 16th block of every workgroup (8192 inputs / <= 896 outputs each), then the workgroups-done counter
+    float*        pw;      // dynamic-range guard (optional): 16 slots of {sum x^2, sum y^2} over EVERY block (8192 inputs / <= 896 outputs each), then the workgroups-done counter and the flag word
     float*        pw_host; // page-locked, device-mapped {in, out, sequence number}: written by the last workgroup to finish
     unsigned      pw_seq;
+    float         pw_thr;  // a block whose output power is below pw_thr x its input power marks the launch (word 33 of pw, word 3 of pw_host)
 };
 
 __device__ __forceinline__ void ifft8(float2 (&v)[8]) { // inverse DFT-8: the forward butterfly on (im, re)
@@ -93,6 +96,17 @@ __device__ __forceinline__ void decim_dma(const DecimFdArgs& a, long blk, unsign
     }
 }
 
+// sum of v over the wave on the DPP network (row shifts, then the two row broadcasts): the total lands in lane 63
+__device__ __forceinline__ float decim_wave_total_lane63(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)); // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true)); // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)); // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true)); // row_shr:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true)); // row_bcast:15 into rows 1, 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true)); // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_df[]; // the ONLY LDS object
     const int t0   = threadIdx.x;
@@ -110,15 +124,30 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
     const unsigned lds_L = __builtin_amdgcn_readfirstlane(lds_off(smem_df));
     long blk = blockIdx.x;
     float pw_in = 0.f, pw_out = 0.f;
+    // every block's own verdict: the workgroup's sum of out - thr * in.  A lane keeps the block's share until the next block's top barrier, the waves' totals (DPP network)
+    // meet in 16 words of LDS behind the image, wave 0 collects the sum of the block before -- no barrier of its own
+    float  pw_dprev = 0.f, pw_dmin = 0.f;
+    float* Gv = reinterpret_cast<float*>(smem_df + kDfLds);
+    if (threadIdx.x < 16) Gv[threadIdx.x] = 0.f;
     int   iter  = 0;
     if (blk < a.n_blocks) decim_dma(a, blk, lds_L, wave, lane0);
     for (; blk < a.n_blocks; blk += gridDim.x, ++iter) {
-        const bool measure = a.pw != nullptr && (iter & 15) == 0 && blk != a.tail_blk; // wave-uniform
+        const bool measure = a.pw != nullptr && blk != a.tail_blk; // wave-uniform; EVERY block: one the guard does not look at is one it cannot vouch for
+        float      blk_in  = 0.f;
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
         const int l = t & 63;
         float2*   R = reinterpret_cast<float2*>(smem_df + kDfOffW + wave * kDfRS);
         G16_FULL_BARRIER(); // T: the block has landed; everybody is done with the previous one
+        if (a.pw != nullptr) {
+            const float wt = decim_wave_total_lane63(pw_dprev); // the block before this one
+            if ((threadIdx.x & 63) == 63) Gv[8 * (iter & 1) + wave] = wt;
+            if (wave == 0) {
+                const float4 g0 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1)), g1 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1) + 4);
+                pw_dmin = fminf(pw_dmin, ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w)));
+            }
+            pw_dprev = 0.f;
+        }
         // ---- phase 0: radix-8 across the block's eight 512-point segments
         float2 u[8];
         {
@@ -130,7 +159,8 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
         }
         if (measure) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) pw_in = fmaf(u[q].x, u[q].x, fmaf(u[q].y, u[q].y, pw_in));
+            for (int q = 0; q < 8; ++q) blk_in = fmaf(u[q].x, u[q].x, fmaf(u[q].y, u[q].y, blk_in));
+            pw_in += blk_in;
         }
         fft8(u);
 #pragma unroll
@@ -225,8 +255,11 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
             for (int aa = 1; aa < 8; ++aa)
                 if (t + 128 * (aa - 1) < valid) yo[128 * (aa - 1)] = v[aa].x;
             if (measure) {
+                float blk_out = 0.f;
 #pragma unroll
-                for (int aa = 1; aa < 8; ++aa) pw_out = fmaf(v[aa].x, v[aa].x, pw_out);
+                for (int aa = 1; aa < 8; ++aa) blk_out = fmaf(v[aa].x, v[aa].x, blk_out);
+                pw_out += blk_out;
+                pw_dprev = fmaf(-a.pw_thr, blk_in, blk_out);
             }
         }
     }
@@ -236,15 +269,20 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
             pw_in += __shfl_xor(pw_in, off);
             pw_out += __shfl_xor(pw_out, off);
         }
+        {   // the last two blocks' verdicts
+            const float wt = decim_wave_total_lane63(pw_dprev);
+            if ((threadIdx.x & 63) == 63) Gv[8 * (iter & 1) + wave] = wt;
+        }
         // one pair of atomics per WORKGROUP, spread over 16 slots (a pair per wave -- 8192 atomics on 32 addresses -- cost ~35 us at the end of a 176 us launch)
         __syncthreads(); // every lane is past the final pass: the G / F buffer is free (the landing buffer is not: the last block's re-read may still be in flight)
         float* red = reinterpret_cast<float*>(smem_df + kDfOffF);
         if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = pw_in; red[2 * (threadIdx.x >> 6) + 1] = pw_out; }
         __syncthreads();
         if (threadIdx.x == 0) { // the last workgroup to finish folds the slots, re-arms them and hands the totals to the host (chain_fused.hip: same scheme)
-            float si = 0.f, so = 0.f;
+            float si = 0.f, so = 0.f, s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int w = 0; w < kDfT / 64; ++w) { si += red[2 * w]; so += red[2 * w + 1]; }
+            for (int w = 0; w < kDfT / 64; ++w) { si += red[2 * w]; so += red[2 * w + 1]; s0 += Gv[w]; s1 += Gv[8 + w]; }
+            if (fminf(pw_dmin, fminf(s0, s1)) < 0.f) atomicOr(reinterpret_cast<unsigned*>(a.pw + 33), 1u);
             float* slot = a.pw + 2 * (blockIdx.x & 15);
             atomicAdd(slot, si);
             atomicAdd(slot + 1, so);
@@ -255,6 +293,7 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
                 float tin = 0.f, tout = 0.f;
                 for (int k = 0; k < 16; ++k) { tin += atomicExch(a.pw + 2 * k, 0.f); tout += atomicExch(a.pw + 2 * k + 1, 0.f); }
                 atomicExch(done, 0u);
+                reinterpret_cast<volatile unsigned*>(a.pw_host)[3] = atomicExch(reinterpret_cast<unsigned*>(a.pw + 33), 0u); // a block of this launch fell below the threshold
                 *reinterpret_cast<volatile unsigned long long*>(a.pw_host) = (unsigned long long)__float_as_uint(tin) | ((unsigned long long)__float_as_uint(tout) << 32);
                 __threadfence_system();
                 reinterpret_cast<volatile unsigned*>(a.pw_host)[2] = a.pw_seq;
@@ -380,6 +419,7 @@ int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float*
         a.pw        = static_cast<float*>(c->d_pw.ptr);
         a.pw_host   = c->d_hpw;
         a.pw_seq    = ++c->pw_seq;
+        a.pw_thr    = kDecimFdBlockThreshold * (float)(kDfHop / 8) / (float)kDfN; // (the scale fir_decim_fd_power_ratio takes out)
         c->pw_stream = st;
     }
     static PerDevice per_device;
@@ -388,11 +428,11 @@ int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float*
     GR4_REQUIRE(n_cu != 0, "fir_decim_fd: cannot query the current device");
     if (first) {
         n_cu = -n_cu;
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_fd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDfLds));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_fd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDfLdsAll));
         per_device.done(dev, n_cu);
     }
     const unsigned grid = (unsigned)std::min<size_t>(n_blocks, (size_t)2 * n_cu);
-    hipLaunchKernelGGL(fir_decim_fd_kernel, dim3(grid), dim3(kDfT), kDfLds, st, a);
+    hipLaunchKernelGGL(fir_decim_fd_kernel, dim3(grid), dim3(kDfT), kDfLdsAll, st, a);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
@@ -419,6 +459,7 @@ int fir_decim_fd_power_ratio(FirDecimFd* c, bool wait, float* ratio) {
     const double in = pair[0], out = pair[1];
     // per sampled block: 8192 input samples (the overlap counted twice: statistics only), 896 outputs
     *ratio = in > 0 ? (float)((out / (kDfHop / 8)) / (in / kDfN)) : 1.f;
+    if (reinterpret_cast<volatile unsigned*>(c->h_pw)[3] != 0u && *ratio >= kDecimFdBlockThreshold) *ratio = 0.5f * kDecimFdBlockThreshold; // one block below the threshold is enough
     return 1;
 }
 

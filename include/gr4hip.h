@@ -251,8 +251,9 @@ int gr4hip_chain_process(gr4hip_chain_t* chain, const void* d_in_c32, size_t n_s
 int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
 /* Dynamic-range guard of GR4HIP_CHAIN_AUTO.  The fused kernels filter in the frequency domain and carry the float32 rounding of their transforms: an error
  * floor of ~2e-6 of the INPUT rms per output sample.  The parity bar is 1e-5 of the OUTPUT, so they meet it while the filter passes at least -14 dB of the
- * input power (power ratio >= 0.04) and miss it when a strong out-of-band signal is removed.  Every fused launch of an AUTO chain therefore samples input and
- * output power (one frame in sixteen); what happens with the measurement is the handle's guard mode (gr4hip_chain_set_guard_mode below; default STRICT: the
+ * input power (power ratio >= 0.04) and miss it when a strong out-of-band signal is removed.  Every fused launch of an AUTO chain therefore measures input and
+ * output power of EVERY frame (all of its samples and bins; a frame whose own ratio is below the threshold marks the launch, whatever the launch's totals say:
+ * an interferer that sets in for the last few frames of a long span is seen); what happens with the measurement is the handle's guard mode (gr4hip_chain_set_guard_mode below; default STRICT: the
  * call that measures a ratio below 0.04 redoes its span with the direct-form kernels -- the reference's arithmetic, history handed over -- before it returns,
  * and the chain stays there until gr4hip_chain_reset).  Explicit GR4HIP_CHAIN_FUSED_FD never measures nor switches.  This call waits for the last measured
  * launch and returns its ratio (< 0: nothing measured yet) and whether the chain now runs in the time domain. */

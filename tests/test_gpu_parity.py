@@ -1252,6 +1252,38 @@ def test_fir_decimate_by_8_dynamic_range_guard(G, devsw):
         assert (e_fd > TOL) == expect_switch, (name, e_fd)
 
 
+def test_guard_sees_every_frame_and_block(G):
+    """an interferer that sets in near the END of a long call -- where one workgroup has long left its first frame behind -- or only for a few frames is seen:
+    the kernels judge every frame / block by itself (workgroup-wide sums of output - threshold x input power), not a sample of them, and not the launch's totals,
+    which such a short event barely moves.  Strict guard: the span is redone before the call returns, every output inside the bar."""
+    N, ntaps = 8192, 100
+    b = O.design_taps_hamming_lowpass(ntaps, 0.05)
+    frames = 700                                                  # 256 workgroups: frames 512 .. 699 are every workgroup's third iteration
+    x = O.signal_c32(9, frames * N, tone_frel=0.01, tone_amp=1.0)
+    k = np.arange(5 * N)
+    for first, count in ((frames - 5, 5), (600, 2)):
+        xi = x.copy()
+        xi[first * N:(first + count) * N] += (60.0 * np.exp(2j * np.pi * 0.31 * k[: count * N])).astype(np.complex64)
+        truth, _ = O.chain(b, xi, N, 0, truth=True)
+        ch = G.Chain(b, N, "None")
+        assert ch.algo == G.capi.CHAIN_FUSED_FD
+        got = ch.process_bulk(dev(xi)).cpu().numpy().ravel()
+        r, td = ch.last_power_ratio()
+        assert td and r < 0.04, (first, count, r)                 # the launch-wide ratio alone is ~0.3: one frame below the threshold marks the launch
+        assert _rel(got, truth) <= TOL, (first, count)
+    # the frequency-domain decimator: a blocker in the last 3 of 700 blocks
+    D, nt = 8, 1024
+    bd = O.design_taps_hamming_lowpass(nt, 0.05)
+    n = 700 * 7168
+    xq = O.signal_f32(41, n, tone_frel=0.01, tone_amp=1.0, noise_amp=0.05)
+    xq[-3 * 7168:] += (100.0 * np.cos(2 * np.pi * 0.31 * np.arange(3 * 7168))).astype(np.float32)
+    truth, _ = O.fir_decim(bd, xq, D)
+    assert _rel(G.fir_filter(bd, torch.float32, decimate=D).process_bulk(dev(xq)).cpu().numpy(), truth) <= TOL
+    f2 = G.fir_filter(bd, torch.float32, decimate=D)
+    G.capi.check(G.capi.lib().gr4hip_fir_set_guard_mode(f2._h, G.capi.GUARD_OFF), "guard off")
+    assert _rel(f2.process_bulk(dev(xq)).cpu().numpy(), truth) > TOL  # (what the guard was for)
+
+
 def _aligned16(x):
     """a device copy of x whose first element sits on a 16-byte boundary (what the matrix-pipe FIR kernels ask of a span)"""
     pad = 4 if x.dtype == np.float32 else 2
