@@ -370,7 +370,9 @@ def main():
             "config": {"workload": f"complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, 2^{args.log2_samples}-sample stream per channel "
                                    f"(BASELINE.json configs[{4 if combine else 1}]), rectangular window, {nchunks} launch(es) of 2^{log2_chunk} samples per channel" + graph,
                        "chain_algo": KERNEL_SYMBOLS.get(algo, str(algo)), "channels": n_channels,
-                       "parallelism": f"{n_channels} independent channel(s), {per_gpu} per GPU"},
+                       "parallelism": f"{n_channels} independent channel(s), {per_gpu} per GPU",
+                       "dynamic_range_guard": ["strict: every frame measured and judged inside the kernel, a span below the threshold redone before the call returns (library default)",
+                                               "deferred", "off"][args.guard_mode]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None, "traffic_from_committed_profile": committed, "kernel": KERNEL_SYMBOLS.get(algo, str(algo)),
                          "algorithmic_bytes_per_launch": chunk * ALGO_BYTES_PER_SAMPLE, "avg_launch_ms": round(launch_ms, 4),
