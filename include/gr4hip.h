@@ -149,7 +149,12 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
  * (three transforms' worth of rounding), the direct form's ~2e-7: when out-of-band signals that the filter removes are much stronger than what it
  * passes, GR4HIP_FIR_TIME_DOMAIN keeps the error relative to the OUTPUT inside the 1e-5 parity bar (the reference's own arithmetic, 1024 flop/sample). */
 /* FIR_AUTO carries the same dynamic-range guard as GR4HIP_CHAIN_AUTO (gr4hip_chain_last_power_ratio below): the first fast convolution of a stream is probed
- * on eight frames, later ones are watched through the powers every launch samples, and below an output / input power ratio of 0.04 the direct form takes over. */
+ * on eight frames, later ones are watched through the powers every launch measures (every frame judged by itself), and below an output / input power ratio of
+ * 0.04 the direct form takes over. */
+/* Accuracy of the bf16 three-term direct form (GR4HIP_FIR_TIME_DOMAIN and the default for 33 .. 256 taps): the six products kept carry everything above 2^-23 of
+ * a product, a correctly rounded float32 product 2^-25.  On ordinary input the error against float64 is that of a float32 sum (~2e-7); when a rejected
+ * out-of-band signal 50 dB above the output dominates the partial sums it measures 3 .. 12 x the float32 CPU form's (profiles/r03_fuzz_summary.txt) -- both are
+ * then above 1e-5 of the output.  GR4HIP_FIR_EXACT_F32 is the float32 arithmetic itself. */
 /* GR4HIP_FIR_EXACT_F32: every product and sum in IEEE float32 (no frequency-domain kernels, no bf16 splits): the kernels whose arithmetic is the reference's
  * transform_reduce (time_domain_filter.hpp:44-47) term for term up to the order of the additions -- an infinite or NaN input sample reaches exactly the
  * ntaps outputs whose window contains it, as +-Inf / NaN (tests/test_gpu_parity.py::test_fir_non_finite_samples pins this and what the default algorithm
