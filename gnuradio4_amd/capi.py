@@ -18,7 +18,7 @@ WINDOWS = ["None", "Rectangular", "Hamming", "Hann", "HannExp", "Blackman", "Nut
 FFT_OUTPUT_IN_DB, FFT_OUTPUT_IN_DEG, FFT_UNWRAP_PHASE = 1, 2, 4
 CHAIN_AUTO, CHAIN_UNFUSED, CHAIN_FUSED_TD, CHAIN_FUSED_FD, CHAIN_TIME_DOMAIN = range(5)
 GUARD_STRICT, GUARD_DEFERRED, GUARD_OFF = range(3)
-FIR_AUTO, FIR_TIME_DOMAIN, FIR_EXACT_F32 = range(3)
+FIR_AUTO, FIR_TIME_DOMAIN, FIR_EXACT_F32, FIR_TIME_DOMAIN_F32 = range(4)
 ROTATOR_CLOSED_FORM, ROTATOR_RECURRENCE = range(2)
 SYNTH_MIX = 0xd1b54a32d192ed03  # group g of a synth stream: Xoshiro256pp(seed ^ SYNTH_MIX * (g + 1)) (include/gr4hip.h)
 

@@ -3,7 +3,7 @@
 // GR4HIP_CHAIN_UNFUSED: gr4hip_fir_process -> y in HBM -> gr4hip_fft_mag2 (any size the FFT block supports).
 // GR4HIP_CHAIN_FUSED_FD (chain_fused.hip): one persistent launch, any window, fft_size 256...8192, <= 256 taps; AUTO picks it when it applies.
 // GR4HIP_CHAIN_FUSED_TD (chain_td.hip): one launch, direct-form filter on the matrix pipe + one transform per frame, fft_size 256...4096, <= 256 taps;
-//   AUTO picks it for <= 64 taps (faster than the fast convolution there), and it is where the dynamic-range guard sends a stream when the size allows.
+//   AUTO picks it for <= 64 taps (faster than the fast convolution there).  The dynamic-range guard sends a stream to the kernel pair with float32 products.
 #include "common.hpp"
 
 namespace gr4 {
@@ -86,7 +86,7 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
     int rc;
     if (use == GR4HIP_CHAIN_UNFUSED || use == GR4HIP_CHAIN_TIME_DOMAIN) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, h_taps, ntaps, 1);
-        if (!rc && use == GR4HIP_CHAIN_TIME_DOMAIN) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN);
+        if (!rc && use == GR4HIP_CHAIN_TIME_DOMAIN) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN_F32); // "the reference's own arithmetic": float32 products
         if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, fft_size, window, 0);
     } else if (use == GR4HIP_CHAIN_FUSED_TD) {
         rc = chain_td_create(&c->td, h_taps, ntaps, fft_size, window);
@@ -125,15 +125,11 @@ static int chain_time_domain(gr4hip_chain* c, const void* d_in, size_t frames, f
 static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, hipStream_t st) {
     std::vector<float>& taps = c->taps;
     int rc = GR4HIP_OK;
-    if (chain_td_supported(taps.size(), c->N, c->window)) {
-        if (!c->td) rc = chain_td_create(&c->td, taps.data(), taps.size(), c->N, c->window);
-        if (!rc) rc = chain_td_set_history256(c->td, d_hist256, st);
-        if (!rc) c->use_td = true;
-        return rc;
-    }
+    // the kernel pair with float32 products (GR4HIP_FIR_TIME_DOMAIN_F32), at every fft size: the regime that trips the guard -- a rejected signal far above the
+    // output -- is the one in which the three-term bf16 products of chain_td_kernel / the default direct form measure 3 .. 16 x a float32 sum's error
     if (!c->fir) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, taps.data(), taps.size(), 1);
-        if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN);
+        if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN_F32);
         if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, c->N, c->window, 0);
     }
     if (!rc) rc = gr4hip_internal_fir_load_history(c->fir, d_hist256, st);

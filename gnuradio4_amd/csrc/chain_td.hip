@@ -9,7 +9,8 @@
 //    use: one workgroup's MFMA phase runs beside another workgroup's transform, and the chain needs ONE transform per frame instead of the fast
 //    convolution's three (forward, inverse, windowed forward).
 //  * dynamic range.  The fast convolution carries the rounding of its transforms (~2e-6 of the INPUT rms); this kernel has the error of a
-//    float32 dot product relative to the OUTPUT, so it is where the guard of chain.hip sends a stream whose filter removes most of the input.
+//    float32 dot product relative to the OUTPUT.  (The guard of chain.hip sent its streams here until late round 3; under a rejected signal 50 dB above the output the
+//    three-term bf16 products measure 3 .. 16 x a float32 sum's error, so the guard's destination is now the kernel pair with float32 products, chain.hip.)
 //
 // One workgroup (256 lanes) per segment of 4096 complex samples = 4096 / fftSize frames:
 //   stage    the segment + Kp samples in front of it, de-interleaved into a re and an im plane (18 / 16-padded, planes 16 banks apart) -- requested into

@@ -205,6 +205,8 @@ struct gr4hip_fir {
     DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
     int                cur = 0;
     int                algo = GR4HIP_FIR_AUTO; // gr4hip_fir_set_algo
+    bool               f32_user = false;       // (what gr4hip_fir_set_algo asked for: a reset re-arms the guard and goes back to it)
+    bool               f32_products = false;   // GR4HIP_FIR_TIME_DOMAIN_F32, or a stream the dynamic-range guard has moved: no three-term bf16 products (the f32 matrix-pipe kernels instead)
     int                guard_mode = GR4HIP_GUARD_STRICT; // gr4hip_fir_set_guard_mode
     gr4::ChainFused*   fd  = nullptr; // complex, decim 1, ntaps <= 256: frequency-domain plan (created on first use)
     // dynamic-range guard of GR4HIP_FIR_AUTO (same policy as the chain's, include/gr4hip.h): the fast convolution's error floor is ~2e-6 of the INPUT rms;
@@ -293,6 +295,7 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     if (f->fd) { chain_fused_destroy(f->fd); f->fd = nullptr; } // rebuilt from the new taps on next use
     if (f->dfd) { fir_decim_fd_destroy(f->dfd); f->dfd = nullptr; }
     f->fd_probed = f->fd_blocked = false;
+    f->f32_products = f->f32_user;
     f->fd_ratio  = -1.f;
     f->mKS = 0;
     f->bandKp = 0;
@@ -310,14 +313,16 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
 int gr4hip_fir_reset(gr4hip_fir_t* f) {
     GR4_REQUIRE(f, "fir_reset: null handle");
     f->fd_probed = f->fd_blocked = false;
+    f->f32_products = f->f32_user;
     f->fd_ratio  = -1.f;
     return fir_alloc_hist(f);
 }
 
 int gr4hip_fir_set_algo(gr4hip_fir_t* f, int algo) {
     GR4_REQUIRE(f, "fir_set_algo: null handle");
-    GR4_REQUIRE(algo == GR4HIP_FIR_AUTO || algo == GR4HIP_FIR_TIME_DOMAIN || algo == GR4HIP_FIR_EXACT_F32, "fir_set_algo: unknown algo %d", algo);
-    f->algo = algo;
+    GR4_REQUIRE(algo >= GR4HIP_FIR_AUTO && algo <= GR4HIP_FIR_TIME_DOMAIN_F32, "fir_set_algo: unknown algo %d", algo);
+    f->algo         = algo == GR4HIP_FIR_TIME_DOMAIN_F32 ? (int)GR4HIP_FIR_TIME_DOMAIN : algo;
+    f->f32_products = f->f32_user = algo == GR4HIP_FIR_TIME_DOMAIN_F32;
     return GR4HIP_OK;
 }
 int gr4hip_fir_set_guard_mode(gr4hip_fir_t* f, int mode) {
@@ -328,7 +333,7 @@ int gr4hip_fir_set_guard_mode(gr4hip_fir_t* f, int mode) {
     return GR4HIP_OK;
 }
 // the three-term bf16 kernels are off for this handle (GR4HIP_FIR_EXACT_F32: IEEE float32 multiply-add, the reference's Inf / NaN behaviour) or for the process (developer switch)
-static bool no_bf16x3(const gr4hip_fir_t* f) { return f->algo == GR4HIP_FIR_EXACT_F32 || dev_switch(kDevFirNoBf16x3); }
+static bool no_bf16x3(const gr4hip_fir_t* f) { return f->algo == GR4HIP_FIR_EXACT_F32 || f->f32_products || dev_switch(kDevFirNoBf16x3); }
 
 int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
     GR4_REQUIRE(f, "fir_process: null handle");
@@ -366,7 +371,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
             if (rc) return rc;
             if (chain_fused_power_ratio(f->fd, true, true, &ratio)) f->fd_ratio = ratio;
             f->fd_probed = true;
-            if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) f->fd_blocked = true;
+            if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) f->fd_blocked = f->f32_products = true; // (the direct form the guard falls back to multiplies in float32: under the rejected signal that made it fall back the three-term bf16 products measure 3 .. 16 x a float32 sum's error)
             else {
                 done = frames * kFdFrame;
                 hist = x + (done - f->hcap) * 2;
@@ -382,7 +387,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
             f->fd_probed = true;
         }
         if (guarded && f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) {
-            f->fd_blocked = true; // the direct form below redoes the probed frames too
+            f->fd_blocked = f->f32_products = true; // the direct form below redoes the probed frames too (float32 products from here on)
         } else {
             if (probe < frames) {
                 rc = chain_fused_fir(f->fd, x + probe * kFdFrame * 2, probe ? x + (probe * kFdFrame - 256) * 2 : (const float*)f->d_hist256.ptr, frames - probe, y + probe * kFdFrame * 2, st);

@@ -1284,6 +1284,28 @@ def test_guard_sees_every_frame_and_block(G):
     assert _rel(f2.process_bulk(dev(xq)).cpu().numpy(), truth) > TOL  # (what the guard was for)
 
 
+def test_guard_destination_multiplies_in_float32(G):
+    """where the guard sends a stream -- a rejected signal far above the output -- is where product precision shows: the three-term bf16 products keep everything
+    above 2^-23 of a product (3 .. 16 x the error of a float32 sum there), so the guard's destination and GR4HIP_CHAIN_TIME_DOMAIN run the direct form with
+    float32 products on the f32 matrix pipe (GR4HIP_FIR_TIME_DOMAIN_F32): inside the bar with an interferer 50 dB above the noise, where the default direct form
+    (and the float32 CPU form) are not"""
+    N, ntaps, frames = 8192, 100, 64
+    b = O.design_taps_hamming_lowpass(ntaps, 0.05)
+    x = O.signal_c32(12, frames * N, tone_frel=0.01, tone_amp=1.0)
+    x += (316.0 * np.exp(2j * np.pi * 0.41 * np.arange(frames * N))).astype(np.complex64)
+    truth, _ = O.chain(b, x, N, 0, truth=True)
+    ch = G.Chain(b, N, "None")                                   # AUTO: the guard trips on the first call and redoes it
+    got = ch.process_bulk(dev(x)).cpu().numpy().ravel()
+    assert ch.last_power_ratio()[1] and _rel(got, truth) <= TOL
+    assert _rel(G.Chain(b, N, "None", G.capi.CHAIN_TIME_DOMAIN).process_bulk(dev(x)).cpu().numpy().ravel(), truth) <= TOL
+    # the FIR alone: float32 products against the default three-term bf16 ones, both against float64
+    yt, _ = O.fir(b, x)                                           # (float64 accumulation)
+    f32 = G.fir_filter(b, torch.complex64); f32.set_algo(G.capi.FIR_TIME_DOMAIN_F32)
+    fbf = G.fir_filter(b, torch.complex64); fbf.set_algo(G.capi.FIR_TIME_DOMAIN)
+    e32, ebf = _rel(f32.process_bulk(dev(x)).cpu().numpy(), yt), _rel(fbf.process_bulk(dev(x)).cpu().numpy(), yt)
+    assert e32 <= TOL and e32 < 0.5 * ebf, (e32, ebf)
+
+
 def _aligned16(x):
     """a device copy of x whose first element sits on a 16-byte boundary (what the matrix-pipe FIR kernels ask of a span)"""
     pad = 4 if x.dtype == np.float32 else 2
@@ -1364,8 +1386,8 @@ def test_chain_non_finite_samples(G, ntaps):
         assert want <= marked, (algo, marked)
         extra = marked - want
         assert extra <= ({5, 8} if algo != G.capi.CHAIN_TIME_DOMAIN else set()), (algo, extra)
-        for f in marked:
-            assert not np.any(np.isfinite(y[f]))                          # a marked frame is marked in every bin
+        for f in marked:                                                  # a marked frame is marked in every bin -- but for a bin where the filter has a ZERO: an even-length
+            assert np.count_nonzero(np.isfinite(y[f])) <= 1, (algo, f)    # symmetric low-pass cancels the 3.4e38 sample exactly at fs / 2 when the products are float32
         for f in set(range(12)) - marked:
             assert _rel(y[f], t2[f]) <= TOL, (algo, f)
 
