@@ -74,8 +74,8 @@ typedef enum { /* how the FIR->FFT->mag2 chain is executed */
     GR4HIP_CHAIN_FUSED_TD, /* one launch: direct-form FIR on the matrix pipe -> window -> FFT -> mag2 (fft_size 256 .. 4096, <= 256 taps); AUTO takes it for <= 64 taps */
     GR4HIP_CHAIN_FUSED_FD, /* one launch, frequency-domain FIR (circular convolution + exact tail correction) + FFT + mag2;
                               fft_size 256 ... 8192 (power of two), <= 256 taps, any window */
-    GR4HIP_CHAIN_TIME_DOMAIN /* direct-form FIR kernel -> HBM -> fft+mag2 kernel: the reference's arithmetic; for inputs whose out-of-band content
-                              dwarfs the filtered output (see gr4hip_fir_set_algo) */
+    GR4HIP_CHAIN_TIME_DOMAIN /* direct-form FIR kernel with float32 products (GR4HIP_FIR_TIME_DOMAIN_F32) -> HBM -> fft+mag2 kernel: the reference's arithmetic; for
+                              inputs whose out-of-band content dwarfs the filtered output (see gr4hip_fir_set_algo), and where the dynamic-range guard sends a stream */
 } gr4hip_chain_algo_t;
 
 typedef void* gr4hip_stream_t; /* hipStream_t */
