@@ -1,3 +1,5 @@
+"""developer tool: windowed 8192-point chains with and without a strong passed / rejected tone: fused fast convolution, time-domain pair and unfused kernels against
+float64 and a float32 CPU chain (where the worst bin sits and how large the truth is there)"""
 import sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
