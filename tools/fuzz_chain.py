@@ -30,10 +30,11 @@ while time.time() - t0 < secs:
     y = lfilter(taps.astype(np.float64), [1.0], x.astype(np.complex128)).reshape(frames, N)
     w = 1.0
     if win != "None":
-        # the reference's symmetric windows (denominator N - 1); Hamming with its 0.53836 / 0.46164 coefficients
-        k = np.arange(N) / (N - 1)
-        w = {"Hann": 0.5 - 0.5 * np.cos(2 * np.pi * k), "Hamming": 0.53836 - 0.46164 * np.cos(2 * np.pi * k),
-             "BlackmanHarris": 0.35875 - 0.48829 * np.cos(2 * np.pi * k) + 0.14128 * np.cos(4 * np.pi * k) - 0.01168 * np.cos(6 * np.pi * k)}[win]
+        # the window table the chain multiplies with: the library's host-side window::create in float32 (pinned against the reference's golden N = 8 arrays by the CPU
+        # tests) -- a float64 window differs by ~3e-8 where the window is ~1e-4, which a strong tone that sets in at the edge of a frame turns into 1e-5 of the frame's rms
+        w32 = np.empty(N, np.float32)
+        capi.check(capi.lib().gr4hip_window_create({"Hann": 3, "Hamming": 2, "BlackmanHarris": 7}[win], w32.ctypes.data, N, 1.6), "window")
+        w = w32.astype(np.float64)
         y = y * w
     truth = np.abs(np.fft.fft(y, axis=1)) ** 2
     rms = np.sqrt(np.mean(truth ** 2, axis=1, keepdims=True)) + 1e-300
