@@ -265,7 +265,8 @@ int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
  * an interferer that sets in for the last few frames of a long span is seen); what happens with the measurement is the handle's guard mode (gr4hip_chain_set_guard_mode below; default STRICT: the
  * call that measures a ratio below 0.04 redoes its span with the direct-form kernels -- the reference's arithmetic, history handed over -- before it returns,
  * and the chain stays there until gr4hip_chain_reset).  Explicit GR4HIP_CHAIN_FUSED_FD never measures nor switches.  This call waits for the last measured
- * launch and returns its ratio (< 0: nothing measured yet) and whether the chain now runs in the time domain. */
+ * launch and returns its ratio (< 0: nothing measured yet; the launch's totals -- or half the threshold when they are above it but one frame by itself was not)
+ * and whether the chain now runs in the time domain. */
 int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time_domain, gr4hip_stream_t stream);
 /* What the guard does with its measurement (per handle; GR4HIP_CHAIN_AUTO chains on the fused frequency-domain kernel only, a no-op elsewhere):
  *   GR4HIP_GUARD_STRICT (default): every call awaits the measurement of its OWN launch and redoes a span that fell below the threshold with the direct-form
