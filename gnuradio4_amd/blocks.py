@@ -100,6 +100,14 @@ class fir_filter(_Handle):
     def reset(self):
         check((lib().gr4hip_fir64_reset if self._f64 else lib().gr4hip_fir_reset)(self._h), "fir_filter.reset")
 
+    def set_prologue(self, prog: Optional["Merged"]):
+        """per-sample blocks in FRONT of the filter, executed in its launch (gr4hip_fir_set_prologue): gains fold into the taps, anything else is a load hook"""
+        check(lib().gr4hip_fir_set_prologue(self._h, prog._h if prog is not None else None), "fir_filter.set_prologue")
+
+    def set_epilogue(self, prog: Optional["Merged"]):
+        """per-sample blocks BEHIND the filter, executed in its launch (gr4hip_fir_set_epilogue)"""
+        check(lib().gr4hip_fir_set_epilogue(self._h, prog._h if prog is not None else None), "fir_filter.set_epilogue")
+
     def set_algo(self, algo: int):
         """capi.FIR_AUTO / capi.FIR_TIME_DOMAIN (direct form also for long complex spans: error relative to the output) / capi.FIR_EXACT_F32 (IEEE float32
         multiply-add only: the reference's Inf / NaN behaviour) -- include/gr4hip.h"""
@@ -446,6 +454,53 @@ def math_nary(op, inputs: Sequence[torch.Tensor], out: Optional[torch.Tensor] = 
         raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "math_nary", "out must be a contiguous device tensor of the inputs' dtype and length")
     check(lib().gr4hip_math_nary(_OPS.get(op, op), _DTYPE_ID[ins[0].dtype], ptrs, len(ins), out.data_ptr(), out.numel(), _stream()), "math_nary")
     return out
+
+
+class Merged(_Handle):
+    """A run of per-sample blocks as ONE launch: the run-time counterpart of Merge<A, "out", B, "in"> (core/.../BlockMerging.hpp:126-240) for chains of
+    MathOpImpl<T, op> (Math.hpp:38-56) and Rotator<complex<float>> (Rotator.hpp:51-61; closed-form phase).  `ops`: a sequence of
+    ("Add" | "Subtract" | "Multiply" | "Divide", value) and ("Rotator", phase_increment[, initial_phase]) in stream order.  2 sizeof(T) bytes of HBM traffic per
+    sample whatever the length; integer types bit-exact, float ops single IEEE operations in program order (include/gr4hip.h, gr4hip_ewise_*).
+    The same object is what fir_filter.set_prologue / set_epilogue take."""
+    _destroy = "gr4hip_ewise_destroy"
+
+    def __init__(self, dtype, ops=()):
+        super().__init__()
+        self.dtype = dtype
+        self._did = _DTYPE_ID[dtype]
+        check(lib().gr4hip_ewise_create(C.byref(self._h), self._did), "Merged")
+        self.ops = []
+        for op in ops:
+            self.append(*op)
+
+    def append(self, op, *args):
+        if op == "Rotator":
+            inc = float(np.float32(args[0]))
+            ph0 = float(np.float32(args[1])) if len(args) > 1 else 0.0
+            check(lib().gr4hip_ewise_append_rotator(self._h, inc, ph0), "Merged.append_rotator")
+        else:
+            v = np.array([args[0]]).astype(_NP_DTYPE[self._did])
+            check(lib().gr4hip_ewise_append_const(self._h, _OPS[op], v.ctypes.data), "Merged.append_const")
+        self.ops.append((op,) + tuple(args))
+        return self
+
+    def reset(self):
+        check(lib().gr4hip_ewise_reset(self._h), "Merged.reset")
+
+    @property
+    def position(self) -> int:
+        v = C.c_uint64(0)
+        check(lib().gr4hip_ewise_position(self._h, C.byref(v)), "Merged.position")
+        return v.value
+
+    def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _dev(x, "Merged")
+        if x.dtype != self.dtype:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Merged", f"expected {self.dtype}, got {x.dtype}")
+        if out is None:
+            out = torch.empty_like(x)
+        check(lib().gr4hip_ewise_process(self._h, x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "Merged.process")
+        return out
 
 
 class Rotator(_Handle):

@@ -127,6 +127,16 @@ SIGNATURES = {
     "gr4hip_fanin_destroy": (_i, [_vp]),
     "gr4hip_math_const": (_i, [_i, _i, _vp, _vp, _sz, _vp, _vp]),
     "gr4hip_math_nary": (_i, [_i, _i, _vp, _sz, _vp, _sz, _vp]),
+    "gr4hip_ewise_create": (_i, [_pvp, _i]),
+    "gr4hip_ewise_append_const": (_i, [_vp, _i, _vp]),
+    "gr4hip_ewise_append_rotator": (_i, [_vp, _f, _f]),
+    "gr4hip_ewise_length": (_i, [_vp, _psz]),
+    "gr4hip_ewise_reset": (_i, [_vp]),
+    "gr4hip_ewise_position": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "gr4hip_ewise_process": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "gr4hip_ewise_destroy": (_i, [_vp]),
+    "gr4hip_fir_set_prologue": (_i, [_vp, _vp]),
+    "gr4hip_fir_set_epilogue": (_i, [_vp, _vp]),
     "gr4hip_rotator_create": (_i, [_pvp, _f, _f]),
     "gr4hip_rotator_set_algo": (_i, [_vp, _i]),
     "gr4hip_rotator_reset": (_i, [_vp, _f]),

@@ -12,15 +12,20 @@
 // Long spans leave this kernel: float 33..256 taps and polyphase decimators go to the MFMA kernels of fir_batched.hip, complex <= 256 taps
 // to the frequency-domain kernel of chain_fused.hip (gr4hip_fir_process below decides).
 #include "common.hpp"
+#include "ewise.hpp"
 #include "fir_window.hpp"
 
 namespace gr4 {
 
 // x: n_in samples; hist: the last `hcap` input samples before x (oldest first); tp: [D][Qpad] phase-major taps
 // (tp[p][q] = b[q*D + p], zero padded); y: n_out samples, y[m] = sum_k b[k] x[m*D - k].
-template <int S, int BS>
+// HOOK: the filter's per-sample neighbours ride in this launch (ewise.hpp).  `pre` is applied to every input sample on its way into LDS -- x and the history
+// alike are RAW samples; a sample with absolute stream index pre.pos + i below pre_origin entered the history under an earlier prologue (or is the zero initial
+// history) and is taken as it lies -- `post` to every output sample before its store (post.pos = absolute index of y[0]).
+template <int S, int BS, bool HOOK>
 __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ x, const float* __restrict__ hist, const float* __restrict__ tp,
-                                                       float* __restrict__ y, long n_in, long n_out, int hcap, int D, int G, float* __restrict__ new_hist) {
+                                                       float* __restrict__ y, long n_in, long n_out, int hcap, int D, int G, float* __restrict__ new_hist,
+                                                       EwiseHook pre, long pre_origin, EwiseHook post) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R  = kFirR;
     constexpr int E  = 4 / S;
@@ -44,12 +49,19 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
             float4     v;
             if (i >= 0 && i + 3 < n_in) {
                 v = *reinterpret_cast<const float4*>(x + i);
+                if constexpr (HOOK) {
+                    float e[4] = {v.x, v.y, v.z, v.w};
+                    ewise_hook<float, 4>(e, pre, i);
+                    v = make_float4(e[0], e[1], e[2], e[3]);
+                }
             } else {
                 float t[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const long ii = i + c;
                     t[c] = (ii >= 0) ? (ii < n_in ? x[ii] : 0.f) : (ii >= -(long)hcap ? hist[hcap + ii] : 0.f);
+                    if constexpr (HOOK)
+                        if (ii < n_in && ii >= -(long)hcap && pre.pos + ii >= pre_origin) t[c] = ewise_hook1<float>(t[c], pre, ii);
                 }
                 v = make_float4(t[0], t[1], t[2], t[3]);
             }
@@ -61,14 +73,22 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
             float4     v;
             if (i >= 0 && i + 1 < n_in) {
                 v = *reinterpret_cast<const float4*>(x + 2 * i);
+                if constexpr (HOOK) {
+                    float2 e[2] = {make_float2(v.x, v.y), make_float2(v.z, v.w)};
+                    ewise_hook<float2, 2>(e, pre, i);
+                    v = make_float4(e[0].x, e[0].y, e[1].x, e[1].y);
+                }
             } else {
                 float t[4];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const long   ii = i + c;
                     const float* p  = (ii >= 0) ? (ii < n_in ? x + 2 * ii : nullptr) : (ii >= -(long)hcap ? hist + 2 * (hcap + ii) : nullptr);
-                    t[2 * c]     = p ? p[0] : 0.f;
-                    t[2 * c + 1] = p ? p[1] : 0.f;
+                    float2       q  = p ? make_float2(p[0], p[1]) : make_float2(0.f, 0.f);
+                    if constexpr (HOOK)
+                        if (p && pre.pos + ii >= pre_origin) q = ewise_hook1<float2>(q, pre, ii);
+                    t[2 * c]     = q.x;
+                    t[2 * c + 1] = q.y;
                 }
                 v = make_float4(t[0], t[1], t[2], t[3]);
             }
@@ -81,6 +101,13 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
             const int    p  = D - 1 - (int)(u % D);
             const float* src = (i >= 0) ? (i < n_in ? x + S * i : nullptr) : (i >= -(long)hcap ? hist + S * (hcap + i) : nullptr);
             float*       dst = xl + (size_t)p * Lf + (size_t)jl * S;
+            if constexpr (HOOK) {
+                if (src && pre.pos + i >= pre_origin) {
+                    if constexpr (S == 1) dst[0] = ewise_hook1<float>(src[0], pre, i);
+                    else { const float2 q = ewise_hook1<float2>(make_float2(src[0], src[1]), pre, i); dst[0] = q.x; dst[S - 1] = q.y; }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < S; ++c) dst[c] = src ? src[c] : 0.f;
         }
@@ -114,6 +141,19 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
 
     const long of    = M0 * S + (long)tid * R; // first output float of this lane
     const long nf    = n_out * S;
+    if constexpr (HOOK) {
+        if (post.n_ops > 0) {
+            if constexpr (S == 1) ewise_hook<float, R>(acc, post, of);
+            else {
+                float2 e[R / 2];
+#pragma unroll
+                for (int r = 0; r < R / 2; ++r) e[r] = make_float2(acc[2 * r], acc[2 * r + 1]);
+                ewise_hook<float2, R / 2>(e, post, of / 2);
+#pragma unroll
+                for (int r = 0; r < R / 2; ++r) { acc[2 * r] = e[r].x; acc[2 * r + 1] = e[r].y; }
+            }
+        }
+    }
     if (of + R <= nf) {
         *reinterpret_cast<float4*>(y + of)     = make_float4(acc[0], acc[1], acc[2], acc[3]);
         *reinterpret_cast<float4*>(y + of + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
@@ -140,6 +180,15 @@ __global__ void fir_hist_update_kernel(const float* __restrict__ x, const float*
     const long h = t / S, c = t % S;
     const long i = n_in - hcap + h;
     new_hist[t]  = (i >= 0) ? x[i * S + c] : old_hist[(hcap + i) * S + c];
+}
+
+// a prologue is replaced in mid-stream: the samples already in the history become what the OLD prologue made of them (hist[h] has absolute index pos - hcap + h)
+template <typename V>
+__global__ void fir_hist_cook_kernel(V* __restrict__ hist, int hcap, EwiseHook pre /*pos = index of the next input sample*/, long pre_origin) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= hcap) return;
+    const long i = (long)h - hcap;
+    if (pre.pos + i >= pre_origin && pre.pos + i >= 0) hist[h] = ewise_hook1<V>(hist[h], pre, i);
 }
 
 template <typename V>
@@ -225,6 +274,15 @@ struct gr4hip_fir {
     DeviceBuffer       d_hist256, d_histc;
     DeviceBuffer       d_afrag;       // real, decim 1, 32 < ntaps <= 256: MFMA A fragments (built on first use)
     int                mKp = 0, mKS = 0;
+    // per-sample neighbours executed in this filter's launch (gr4hip_fir_set_prologue / _epilogue): private copies of the programs
+    gr4hip_ewise*      pre = nullptr, *post = nullptr;
+    bool               pre_is_gain = false, post_is_gain = false; // nothing but real gains: folded into the taps (a FIR filter is linear)
+    double             pre_gain = 1.0, post_gain = 1.0;
+    double             folded = 1.0;   // the gain the device tap tables currently carry: `taps` = folded x `user_taps`
+    std::vector<float> user_taps;      // the block's setting `b` as given
+    long               pos = 0;        // input samples consumed since create / reset / a history replacement
+    long               pre_origin = 0; // history samples with an absolute index below this are what an EARLIER prologue produced (or the zero initial history)
+    ~gr4hip_fir() { delete pre; delete post; }
 };
 
 static size_t bit_ceil_sz(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
@@ -254,15 +312,94 @@ static int fir_alloc_hist(gr4hip_fir* f) {
     return GR4HIP_OK;
 }
 
-template <int S, int BS>
-static int fir_launch(const gr4hip_fir* f, const float* x, const float* hist, float* y, long n_in, long n_out, size_t lds, hipStream_t st, float* new_hist) {
-    auto kern = fir_poly_kernel<S, BS>;
+struct FirHooks { EwiseHook pre, post; long pre_origin = 0; bool any = false; };
+
+template <int S, int BS, bool HOOK>
+static int fir_launch_h(const gr4hip_fir* f, const float* x, const float* hist, float* y, long n_in, long n_out, size_t lds, hipStream_t st, float* new_hist, const FirHooks& hk) {
+    auto kern = fir_poly_kernel<S, BS, HOOK>;
     if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long TOs  = BS * kFirR / S;
     const long grid = ceil_div(n_out, TOs);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, st, x, hist, (const float*)f->d_taps.ptr, y, n_in, n_out,
-                       (int)f->hcap, (int)f->decim, f->G, new_hist);
+                       (int)f->hcap, (int)f->decim, f->G, new_hist, hk.pre, hk.pre_origin, hk.post);
     GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+template <int S, int BS>
+static int fir_launch(const gr4hip_fir* f, const float* x, const float* hist, float* y, long n_in, long n_out, size_t lds, hipStream_t st, float* new_hist, const FirHooks& hk) {
+    return hk.any ? fir_launch_h<S, BS, true>(f, x, hist, y, n_in, n_out, lds, st, new_hist, hk) : fir_launch_h<S, BS, false>(f, x, hist, y, n_in, n_out, lds, st, new_hist, hk);
+}
+
+// every device table derived from the taps is rebuilt on next use
+static void fir_invalidate_tables(gr4hip_fir* f) {
+    if (f->fd) { chain_fused_destroy(f->fd); f->fd = nullptr; }
+    if (f->dfd) { fir_decim_fd_destroy(f->dfd); f->dfd = nullptr; }
+    f->mKS = 0;
+    f->bandKp = 0;
+    f->bfKS = 0;
+    f->bdKS = 0;
+}
+// `taps` = gain x `user_taps` (float64 product, rounded once), uploaded
+static int fir_apply_gain(gr4hip_fir* f, double gain) {
+    f->taps.resize(f->user_taps.size());
+    for (size_t k = 0; k < f->taps.size(); ++k) f->taps[k] = (float)(gain * (double)f->user_taps[k]);
+    f->folded = gain;
+    fir_invalidate_tables(f);
+    return fir_upload_taps(f);
+}
+// what this call does with the neighbours: gains ride in the taps (a prologue's only once no sample an earlier prologue produced is left in the history), the
+// rest as hooks of the register-window kernel
+static int fir_prepare_hooks(gr4hip_fir* f, FirHooks* hk) {
+    const bool fold_pre  = f->pre && f->pre_is_gain && (f->pre_origin == 0 || f->pos - f->pre_origin >= (long)f->hcap);
+    const bool fold_post = f->post && f->post_is_gain;
+    const double want    = (fold_pre ? f->pre_gain : 1.0) * (fold_post ? f->post_gain : 1.0);
+    if (want != f->folded) { if (const int rc = fir_apply_gain(f, want)) return rc; }
+    hk->pre_origin = f->pre_origin;
+    if (f->pre && !fold_pre) {
+        f->pre->pos = f->pos;
+        if (const int rc = ewise_device_ops(f->pre, &hk->pre)) return rc;
+    }
+    if (f->post && !fold_post) {
+        f->post->pos = f->pos / (long)f->decim;
+        if (const int rc = ewise_device_ops(f->post, &hk->post)) return rc;
+    }
+    hk->any = hk->pre.n_ops > 0 || hk->post.n_ops > 0;
+    return GR4HIP_OK;
+}
+// (set_prologue in mid-stream) the history becomes what the outgoing prologue made of it
+static int fir_cook_history(gr4hip_fir* f) {
+    if (!f->pre || f->pos == 0) return GR4HIP_OK;
+    EwiseHook h;
+    f->pre->pos = f->pos;
+    if (const int rc = ewise_device_ops(f->pre, &h)) return rc;
+    if (h.n_ops == 0) return GR4HIP_OK;
+    GR4_HIP_TRY(hipDeviceSynchronize()); // (a settings change, not a per-call operation: everything queued on the handle finishes first)
+    const unsigned grid = (unsigned)ceil_div(f->hcap, (size_t)256);
+    if (f->S == 2) hipLaunchKernelGGL(fir_hist_cook_kernel<float2>, dim3(grid), dim3(256), 0, nullptr, (float2*)f->d_hist[f->cur].ptr, (int)f->hcap, h, f->pre_origin);
+    else hipLaunchKernelGGL(fir_hist_cook_kernel<float>, dim3(grid), dim3(256), 0, nullptr, (float*)f->d_hist[f->cur].ptr, (int)f->hcap, h, f->pre_origin);
+    GR4_LAUNCH_CHECK();
+    GR4_HIP_TRY(hipDeviceSynchronize());
+    return GR4HIP_OK;
+}
+static int fir_set_hook(gr4hip_fir* f, const gr4hip_ewise_t* prog, bool prologue) {
+    GR4_REQUIRE(f, "fir_set_%s: null handle", prologue ? "prologue" : "epilogue");
+    if (prog && prog->dtype != f->dtype) { set_error("fir_set_%s: the program's dtype %d is not the filter's (%d)", prologue ? "prologue" : "epilogue", prog->dtype, f->dtype); return GR4HIP_UNSUPPORTED; }
+    gr4hip_ewise* copy = nullptr;
+    if (prog && !prog->user.empty()) {
+        copy = ewise_clone(prog);
+        GR4_REQUIRE(copy, "out of host memory");
+    }
+    if (prologue) {
+        if (const int rc = fir_cook_history(f)) { delete copy; return rc; }
+        delete f->pre;
+        f->pre         = copy;
+        f->pre_origin  = f->pos;
+        f->pre_is_gain = copy && ewise_as_real_gain(copy, &f->pre_gain);
+    } else {
+        delete f->post;
+        f->post         = copy;
+        f->post_is_gain = copy && ewise_as_real_gain(copy, &f->post_gain);
+    }
     return GR4HIP_OK;
 }
 
@@ -280,6 +417,7 @@ int gr4hip_fir_create(gr4hip_fir_t** out, int dtype, const float* h_taps, size_t
     f->decim = decim;
     f->ntaps = ntaps;
     f->taps.assign(h_taps, h_taps + ntaps);
+    f->user_taps = f->taps;
     if (ntaps > f->hcap) f->hcap = bit_ceil_sz(ntaps); // time_domain_filter.hpp:38-42
     int rc = fir_upload_taps(f);
     if (!rc) rc = fir_alloc_hist(f);
@@ -290,21 +428,16 @@ int gr4hip_fir_create(gr4hip_fir_t** out, int dtype, const float* h_taps, size_t
 
 int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     GR4_REQUIRE(f && h_taps && ntaps >= 1, "fir_set_taps: bad arguments");
-    f->taps.assign(h_taps, h_taps + ntaps);
+    f->user_taps.assign(h_taps, h_taps + ntaps);
     f->ntaps = ntaps;
-    if (f->fd) { chain_fused_destroy(f->fd); f->fd = nullptr; } // rebuilt from the new taps on next use
-    if (f->dfd) { fir_decim_fd_destroy(f->dfd); f->dfd = nullptr; }
     f->fd_probed = f->fd_blocked = false;
     f->f32_products = f->f32_user;
     f->fd_ratio  = -1.f;
-    f->mKS = 0;
-    f->bandKp = 0;
-    f->bfKS = 0;
-    f->bdKS = 0;
-    int rc   = fir_upload_taps(f);
+    int rc   = fir_apply_gain(f, f->folded); // every table derived from the taps is rebuilt on next use
     if (rc) return rc;
     if (ntaps > f->hcap) { // the reference replaces the HistoryBuffer (history is lost) only when it must grow
         f->hcap = bit_ceil_sz(ntaps);
+        f->pre_origin = f->pos; // (the new history is all zeros: nothing in it is a raw sample)
         return fir_alloc_hist(f);
     }
     return GR4HIP_OK;
@@ -315,8 +448,12 @@ int gr4hip_fir_reset(gr4hip_fir_t* f) {
     f->fd_probed = f->fd_blocked = false;
     f->f32_products = f->f32_user;
     f->fd_ratio  = -1.f;
+    f->pos = f->pre_origin = 0;
     return fir_alloc_hist(f);
 }
+
+int gr4hip_fir_set_prologue(gr4hip_fir_t* f, const gr4hip_ewise_t* prog) { return fir_set_hook(f, prog, true); }
+int gr4hip_fir_set_epilogue(gr4hip_fir_t* f, const gr4hip_ewise_t* prog) { return fir_set_hook(f, prog, false); }
 
 int gr4hip_fir_set_algo(gr4hip_fir_t* f, int algo) {
     GR4_REQUIRE(f, "fir_set_algo: null handle");
@@ -345,6 +482,10 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     hipStream_t  st   = as_stream(stream);
     const float* x    = static_cast<const float*>(d_in);
     float*       y    = static_cast<float*>(d_out);
+    FirHooks     hk;
+    if (f->pre || f->post || f->folded != 1.0) { if (const int rc = fir_prepare_hooks(f, &hk)) return rc; }
+    const bool   plain = !hk.any;
+    const int    algo  = plain ? f->algo : (int)GR4HIP_FIR_EXACT_F32; // (EXACT_F32 == "the register-window kernel only") // hooks run in the register-window kernel only: the matrix-pipe and frequency-domain kernels below are for plain filters
     const float* hist = (const float*)f->d_hist[f->cur].ptr;
     size_t       done = 0; // samples already produced by the frequency-domain path
     bool         mfma_wrote_hist = false;
@@ -352,7 +493,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
     // (<= 96 taps: the direct form is faster -- write-bound 300 .. 356 Gsamples/s up to 64 taps, 311 .. 275 at 65 .. 96 taps on the bf16 matrix pipe, against
     // the fast convolution's 248 at every tap count, tools/cfir_taps_sweep.py -- and has no dynamic-range floor; 128 taps: 220, 256 taps: 151)
-    if (f->S == 2 && f->decim == 1 && f->ntaps > 96 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
+    if (f->S == 2 && f->decim == 1 && f->ntaps > 96 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
         int rc = GR4HIP_OK;
         if (!f->fd) {
             rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);
@@ -403,7 +544,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     // (16-byte-aligned input too: the three-term bf16 form of the same product, fir_bf16.hip)
     static const size_t kCBfMinTaps = [] { const char* e = std::getenv("GR4HIP_CFIR_BF16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // developer knob: 65 puts 33..64 taps back on the f32 MFMA (measured 5-8 % slower: 299-316 against 322-333 Gsamples/s); below 33 taps the register-window kernel is ahead up to 27 taps and within 3 % from there (tools/cfir_bf16_threshold.py)
     if (f->S == 2 && f->decim == 1 && f->ntaps >= kCBfMinTaps && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y + done * 2) | reinterpret_cast<uintptr_t>(x + done * 2)) & 15) == 0 &&
-        !no_bf16x3(f)) {
+        !no_bf16x3(f) && plain) {
         int rc = GR4HIP_OK;
         if (f->bfKS == 0) {
             std::vector<unsigned short> af;
@@ -418,7 +559,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
-    const bool exact = f->algo == GR4HIP_FIR_EXACT_F32; // only the register-window kernel: its products are the taps' (padded to a multiple of 4 per phase), nothing wider
+    const bool exact = algo == GR4HIP_FIR_EXACT_F32; // only the register-window kernel: its products are the taps' (padded to a multiple of 4 per phase), nothing wider
     if (!exact && done < n_in && f->S == 2 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && (reinterpret_cast<uintptr_t>(y + done * 2) & 15) == 0) {
         int rc = GR4HIP_OK;
         if (f->mKS == 0) {
@@ -447,7 +588,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     // (384 .. 1024 taps: slices of 256 taps, each a pass over the input delayed by 256 p samples that adds to y: 512 taps 115 instead of 90 Gsamples/s on the
     // register-window kernel, 1024 taps 50.5 instead of 47; below 384 and above 1024 taps the extra passes cost more than they save -- measured)
     if (f->S == 1 && f->decim == 1 && f->ntaps > 32 && (f->ntaps <= 256 || (f->ntaps >= 384 && f->ntaps <= 1024)) && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
-        f->algo == GR4HIP_FIR_AUTO && !no_bf16x3(f)) {
+        algo == GR4HIP_FIR_AUTO && !no_bf16x3(f) && plain) {
         int          rc = GR4HIP_OK;
         const size_t nslice = ceil_div(f->ntaps, (size_t)256);
         if (f->bfKS == 0) {
@@ -502,8 +643,8 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     }
     // float, decimate by 2 .. 12 with a window of <= 1152 samples (taps - 1 + 15 D), long 16-byte-aligned span: the band form with three-term bf16 products
     // (fir_bf16.hip; windows beyond 288 samples with the K-steps split over the four waves)
-    if (done == 0 && f->S == 1 && f->decim >= 2 && f->decim <= 12 && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
-        ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !no_bf16x3(f)) {
+    if (done == 0 && f->S == 1 && f->decim >= 2 && f->decim <= 12 && n_out >= (1u << 14) && algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
+        ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !no_bf16x3(f) && plain) {
         int rc = GR4HIP_OK;
         if (f->bdKS == 0) {
             std::vector<unsigned short> af;
@@ -528,7 +669,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     // float, decimate by 8, <= 1024 taps, long 16-byte-aligned span: overlap-save blocks of 8192 samples in the frequency domain (~35 lane-operations per
     // input sample instead of 2 K / 8 flop: HBM / power-bound instead of FP32-bound); a partial last block rides in the same launch
     constexpr size_t kDfHopS = 7168, kDfMinBlocks = 64;
-    if (done == 0 && f->S == 1 && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 && n_in >= kDfMinBlocks * kDfHopS &&
+    if (done == 0 && f->S == 1 && algo == GR4HIP_FIR_AUTO && !f->fd_blocked && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 && n_in >= kDfMinBlocks * kDfHopS &&
         (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && !dev_switch(kDevFirNoDecimFd)) {
         int rc = GR4HIP_OK;
         if (!f->dfd) rc = fir_decim_fd_create(&f->dfd, f->taps.data(), f->ntaps);
@@ -558,7 +699,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     }
     // float, decimate by kBandMinDecim .. 128, long span: the band form of the contraction (samples in stream order, the decimation in the A operand)
     static const size_t kBandMinDecim = [] { const char* e = std::getenv("GR4HIP_FIR_BAND_MIN_DECIM"); return e ? (size_t)std::atoi(e) : (size_t)10; }(); // (developer switch: where the band form takes over from the polyphase form)
-    if (done == 0 && f->S == 1 && f->decim >= kBandMinDecim && f->decim <= 128 && n_out >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO) {
+    if (done == 0 && f->S == 1 && f->decim >= kBandMinDecim && f->decim <= 128 && n_out >= (1u << 14) && algo == GR4HIP_FIR_AUTO) {
         int rc = GR4HIP_OK;
         if (f->bandKp == 0) {
             std::vector<float> row;
@@ -605,12 +746,12 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         float*       yr = y + (done / f->decim) * f->S;
         const long   ni = (long)(n_in - done), no = (long)((n_in - done) / f->decim);
         float*       nh = done == 0 ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr; // the whole span in this launch: it writes the next history itself
-        if (f->S == 1) rc = bs == 256 ? fir_launch<1, 256>(f, xr, hist, yr, ni, no, lds, st, nh) : bs == 128 ? fir_launch<1, 128>(f, xr, hist, yr, ni, no, lds, st, nh) : fir_launch<1, 64>(f, xr, hist, yr, ni, no, lds, st, nh);
-        else rc = bs == 256 ? fir_launch<2, 256>(f, xr, hist, yr, ni, no, lds, st, nh) : bs == 128 ? fir_launch<2, 128>(f, xr, hist, yr, ni, no, lds, st, nh) : fir_launch<2, 64>(f, xr, hist, yr, ni, no, lds, st, nh);
+        if (f->S == 1) rc = bs == 256 ? fir_launch<1, 256>(f, xr, hist, yr, ni, no, lds, st, nh, hk) : bs == 128 ? fir_launch<1, 128>(f, xr, hist, yr, ni, no, lds, st, nh, hk) : fir_launch<1, 64>(f, xr, hist, yr, ni, no, lds, st, nh, hk);
+        else rc = bs == 256 ? fir_launch<2, 256>(f, xr, hist, yr, ni, no, lds, st, nh, hk) : bs == 128 ? fir_launch<2, 128>(f, xr, hist, yr, ni, no, lds, st, nh, hk) : fir_launch<2, 64>(f, xr, hist, yr, ni, no, lds, st, nh, hk);
         hist_written = nh != nullptr && rc == GR4HIP_OK;
         break;
     }
-    if (rc == GR4HIP_UNSUPPORTED && done == 0 && f->S == 1 && f->decim >= 2) { // D phase rows do not fit the LDS at any workgroup size: the band form at any span length
+    if (rc == GR4HIP_UNSUPPORTED && done == 0 && f->S == 1 && f->decim >= 2 && plain) { // D phase rows do not fit the LDS at any workgroup size: the band form at any span length
         if (f->bandKp == 0) {
             std::vector<float> row;
             fir_decim_band_make_row(f->taps.data(), f->ntaps, f->decim, &f->bandKp, &row);
@@ -629,6 +770,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         GR4_LAUNCH_CHECK();
     }
     f->cur ^= 1;
+    f->pos += (long)n_in;
     return GR4HIP_OK;
 }
 

@@ -53,6 +53,73 @@ struct Options {
 };
 inline Options& options() { static Options o; return o; }
 
+// A run of per-sample blocks -- MathOpImpl<T, op> (Math.hpp:38-56), Rotator<complex<float>> (Rotator.hpp:51-61) -- as data: what Merge<A, "out", B, "in">
+// (BlockMerging.hpp:126-240) is at compile time upstream.  One program = one launch (gr4hip_ewise_*), or no launch at all when a neighbouring filter takes it
+// as its load / store hook (Stage::absorb).
+struct EwiseProgram {
+    struct Op {
+        int                           kind = GR4HIP_ADD; // gr4hip_op, or kRotator
+        std::array<unsigned char, 16> value{};           // the constant, one element of the program's dtype
+        float                         inc = 0.f, ph0 = 0.f; // kRotator
+    };
+    static constexpr int kRotator = 4;
+    int                  dtype = GR4HIP_F32;
+    std::vector<Op>      ops;
+    [[nodiscard]] bool empty() const { return ops.empty(); }
+    void append(const EwiseProgram& o) { ops.insert(ops.end(), o.ops.begin(), o.ops.end()); }
+    void prepend(const EwiseProgram& o) { ops.insert(ops.begin(), o.ops.begin(), o.ops.end()); }
+    [[nodiscard]] std::string describe() const {
+        static constexpr const char* names[] = {"add", "sub", "mul", "div", "rot"};
+        std::string d;
+        if (ops.size() > 6) return std::to_string(ops.size()) + " ops";
+        for (const auto& o : ops) d += std::string(d.empty() ? "" : ",") + names[std::clamp(o.kind, 0, 4)];
+        return d;
+    }
+    // a fresh library handle (the caller destroys it; a filter that takes the program as a hook copies it)
+    [[nodiscard]] gr4hip_ewise_t* make() const {
+        gr4hip_ewise_t* h = nullptr;
+        if (const int rc = gr4hip_ewise_create(&h, dtype); rc < 0) throw std::runtime_error(std::string("gr4hip_ewise_create: ") + gr4hip_last_error());
+        for (const auto& o : ops) {
+            const int rc = o.kind == kRotator ? gr4hip_ewise_append_rotator(h, o.inc, o.ph0) : gr4hip_ewise_append_const(h, o.kind, o.value.data());
+            if (rc < 0) { gr4hip_ewise_destroy(h); throw std::runtime_error(std::string("gr4hip_ewise_append: ") + gr4hip_last_error()); }
+        }
+        return h;
+    }
+};
+
+// the hooks of a stage that runs its neighbours' per-sample ops inside its own launch
+struct AbsorbedPrograms {
+    EwiseProgram pre, post;
+    bool take(const EwiseProgram& p, bool before, int dtype) {
+        if (p.dtype != dtype) return false;
+        pre.dtype = post.dtype = dtype;
+        if (before) pre.prepend(p); else post.append(p);
+        return true;
+    }
+    void clear() { pre.ops.clear(); post.ops.clear(); }
+    [[nodiscard]] std::string suffix() const {
+        std::string s;
+        if (!pre.empty()) s += "pre: " + pre.describe();
+        if (!post.empty()) s += std::string(s.empty() ? "" : "; ") + "post: " + post.describe();
+        return s.empty() ? s : "[" + s + "]";
+    }
+    // the product of a program that is nothing but real gains (what a linear stage folds into its coefficients); false otherwise
+    static bool real_gain(const EwiseProgram& p, double* g) {
+        double acc = 1.0;
+        for (const auto& o : p.ops) {
+            if (o.kind != GR4HIP_MUL && o.kind != GR4HIP_DIV) return false;
+            float v[2] = {0.f, 0.f};
+            if (p.dtype == GR4HIP_F32) std::memcpy(v, o.value.data(), 4);
+            else if (p.dtype == GR4HIP_C32) std::memcpy(v, o.value.data(), 8);
+            else return false;
+            if (v[1] != 0.f || v[0] == 0.f || !std::isfinite(v[0])) return false;
+            acc = o.kind == GR4HIP_MUL ? acc * double(v[0]) : acc / double(v[0]);
+        }
+        *g = acc;
+        return true;
+    }
+};
+
 // one device stage of a chain: consumes n_in elements at d_in, produces *n_out at d_out, asynchronously on `stream`
 struct Stage {
     virtual ~Stage() = default;
@@ -60,6 +127,12 @@ struct Stage {
     virtual std::string_view kind() const                                                                                         = 0;
     std::size_t              in_bytes = 4, out_bytes = 4; // element sizes
     std::size_t              in_chunk = 1, out_chunk = 1; // whole chunks only (Resampling)
+    // ---- kernel-level fusion (the run-time Merge<>): a stage that is nothing but per-sample ops says so; a stage that can run a neighbour's ops inside its own
+    // launch takes them.  before: the program works on this stage's INPUT (in front of whatever it already does there), otherwise on its output (behind).
+    [[nodiscard]] virtual const EwiseProgram* program() const { return nullptr; }
+    virtual bool absorb(const EwiseProgram& /*p*/, bool /*before*/) { return false; }
+    virtual void clear_absorbed() {}
+    virtual Stage* self() { return this; } // (a wrapper that only owns a stage answers with the stage: fusion looks at concrete types)
 };
 
 // grow-only device / pinned buffers
@@ -172,23 +245,54 @@ public:
 };
 
 // ---------------------------------------------------------------------------------------------- stages
+// the hooks of a gr4hip_fir handle follow `ab` (gr4hip_fir_set_prologue / _epilogue: the library copies the programs)
+inline void apply_fir_hooks(gr4hip_fir_t* h, const AbsorbedPrograms& ab) {
+    for (int pro = 1; pro >= 0; --pro) {
+        const EwiseProgram& p    = pro ? ab.pre : ab.post;
+        gr4hip_ewise_t*     prog = p.empty() ? nullptr : p.make();
+        const int           rc   = pro ? gr4hip_fir_set_prologue(h, prog) : gr4hip_fir_set_epilogue(h, prog);
+        if (prog) gr4hip_ewise_destroy(prog);
+        check(rc, pro ? "gr4hip_fir_set_prologue" : "gr4hip_fir_set_epilogue");
+    }
+}
+
 template <typename T>
 struct FirStage final : Stage {
     gr4hip_fir_t* h = nullptr;
     std::vector<float> taps;
+    std::size_t        decim = 1;
+    AbsorbedPrograms   absorbed;
+    std::string        _kind;
+    static constexpr int kDtype = gr::detail::is_complex<T>::value ? GR4HIP_C32 : GR4HIP_F32;
     template <typename Taps>
-    explicit FirStage(const Taps& b) : taps(b.begin(), b.end()) {
+    explicit FirStage(const Taps& b, std::size_t decimate = 1) : taps(b.begin(), b.end()), decim(std::max<std::size_t>(1, decimate)) {
         in_bytes = out_bytes = sizeof(T);
-        check(gr4hip_fir_create(&h, gr::detail::is_complex<T>::value ? GR4HIP_C32 : GR4HIP_F32, taps.data(), taps.size(), 1), "gr4hip_fir_create");
+        in_chunk = decim;
+        check(gr4hip_fir_create(&h, kDtype, taps.data(), taps.size(), decim), "gr4hip_fir_create");
         check(gr4hip_fir_set_guard_mode(h, options().guard_mode), "gr4hip_fir_set_guard_mode");
+        name();
     }
     ~FirStage() override { gr4hip_fir_destroy(h); }
+    void name() { _kind = std::string(gr::detail::is_complex<T>::value ? "fir_c32" : "fir_f32") + (decim > 1 ? "/" + std::to_string(decim) : std::string()) + absorbed.suffix(); }
+    // the neighbours' per-sample ops in this filter's launch: gains fold into the taps, the rest are load / store hooks (include/gr4hip.h)
+    bool absorb(const EwiseProgram& p, bool before) override {
+        if (!absorbed.take(p, before, kDtype)) return false;
+        apply_fir_hooks(h, absorbed);
+        name();
+        return true;
+    }
+    void clear_absorbed() override {
+        if (absorbed.pre.empty() && absorbed.post.empty()) return;
+        absorbed.clear();
+        apply_fir_hooks(h, absorbed);
+        name();
+    }
     template <typename Taps>
     void set_taps(const Taps& b) { // fir_filter::settingsChanged (time_domain_filter.hpp:38-42): new taps, the history survives
         taps.assign(b.begin(), b.end());
         check(gr4hip_fir_set_taps(h, taps.data(), taps.size()), "gr4hip_fir_set_taps");
     }
-    std::string_view kind() const override { return gr::detail::is_complex<T>::value ? "fir_c32" : "fir_f32"; }
+    std::string_view kind() const override { return _kind; }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override { return gr4hip_fir_process(h, in, n, out, n_out, s); }
 };
 
@@ -240,24 +344,87 @@ constexpr int dtype_of() { // gr4hip_dtype of a sample type
 
 template <typename T, int OP>
 struct MathConstStage final : Stage {
-    T value;
-    explicit MathConstStage(T v) : value(v) { in_bytes = out_bytes = sizeof(T); }
+    T            value;
+    EwiseProgram prog;
+    explicit MathConstStage(T v) : value(v) {
+        in_bytes = out_bytes = sizeof(T);
+        prog.dtype = dtype();
+        EwiseProgram::Op op;
+        op.kind = OP;
+        std::memcpy(op.value.data(), &value, sizeof(T));
+        prog.ops.push_back(op);
+    }
     std::string_view kind() const override { return "math_const"; }
     static constexpr int dtype() { return dtype_of<T>(); }
+    const EwiseProgram*  program() const override { return &prog; }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
         *n_out = n;
         return gr4hip_math_const(OP, dtype(), in, out, n, &value, s);
     }
 };
 
+// a run of per-sample blocks: ONE launch, the values in registers between the ops (gr4hip_ewise_process)
+struct EwiseStage final : Stage {
+    EwiseProgram    prog;
+    gr4hip_ewise_t* h = nullptr;
+    std::string     _kind;
+    explicit EwiseStage(EwiseProgram p) : prog(std::move(p)) {
+        static constexpr std::size_t bytes[12] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 8, 16};
+        in_bytes = out_bytes = bytes[std::clamp(prog.dtype, 0, 11)];
+        rebuild();
+    }
+    ~EwiseStage() override { if (h) gr4hip_ewise_destroy(h); }
+    void rebuild() {
+        gr4hip_ewise_t* fresh = prog.make();
+        if (h) gr4hip_ewise_destroy(h);
+        h     = fresh;
+        _kind = "ewise[" + prog.describe() + "]";
+    }
+    std::string_view    kind() const override { return _kind; }
+    const EwiseProgram* program() const override { return &prog; }
+    bool absorb(const EwiseProgram& p, bool before) override { // program + program = program
+        if (p.dtype != prog.dtype) return false;
+        if (before) prog.prepend(p); else prog.append(p);
+        rebuild();
+        return true;
+    }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        *n_out = n;
+        return gr4hip_ewise_process(h, in, out, n, s);
+    }
+};
+
 // iir_filter<float, form> (one section with the user's b, a) and designed cascades
 struct IirStage final : Stage {
-    gr4hip_iir_t* h = nullptr;
-    IirStage(int form, std::size_t nsections, const std::vector<float>& b, std::size_t nb, const std::vector<float>& a, std::size_t na) {
+    gr4hip_iir_t*      h = nullptr;
+    int                form;
+    std::size_t        nsections, nb, na;
+    std::vector<float> b, a;
+    double             gain = 1.0; // neighbouring gains folded into the first section's numerator (the cascade is linear)
+    std::string        _kind = "iir_f32";
+    IirStage(int form_, std::size_t nsections_, const std::vector<float>& b_, std::size_t nb_, const std::vector<float>& a_, std::size_t na_)
+        : form(form_), nsections(nsections_), nb(nb_), na(na_), b(b_), a(a_) {
         check(gr4hip_iir_create(&h, form, nsections, b.data(), nb, a.data(), na), "gr4hip_iir_create");
     }
     ~IirStage() override { gr4hip_iir_destroy(h); }
-    std::string_view kind() const override { return "iir_f32"; }
+    void regain(double g) { // a new handle with the first section's numerator scaled (plan time: no state yet; a live stage restarts from zero state)
+        std::vector<float> bs = b;
+        for (std::size_t k = 0; k < nb; ++k) bs[k] = static_cast<float>(g * double(b[k]));
+        gr4hip_iir_t* fresh = nullptr;
+        check(gr4hip_iir_create(&fresh, form, nsections, bs.data(), nb, a.data(), na), "gr4hip_iir_create");
+        gr4hip_iir_destroy(h);
+        h     = fresh;
+        gain  = g;
+        _kind = g == 1.0 ? "iir_f32" : "iir_f32[gain folded]";
+    }
+    bool absorb(const EwiseProgram& p, bool /*before*/) override { // a gain commutes with the filter: in front or behind, it scales the numerator
+        double g = 1.0;
+        if (p.dtype != GR4HIP_F32 || !AbsorbedPrograms::real_gain(p, &g)) return false;
+        regain(gain * g);
+        return true;
+    }
+    void clear_absorbed() override { if (gain != 1.0) regain(1.0); }
+    std::string_view kind() const override { return _kind; }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
         *n_out = n;
         return gr4hip_iir_process(h, static_cast<const float*>(in), n, static_cast<float*>(out), s);
@@ -277,23 +444,48 @@ template <typename T>
 struct InterpStage final : Stage {
     gr4hip_fir_interp_t* h = nullptr;
     std::size_t          L;
-    InterpStage(const std::vector<float>& b, std::size_t interp) : L(std::max<std::size_t>(1, interp)) {
+    std::vector<float>   taps;
+    double               gain = 1.0; // neighbouring gains folded into the taps (linear)
+    InterpStage(const std::vector<float>& b, std::size_t interp) : L(std::max<std::size_t>(1, interp)), taps(b) {
         in_bytes = out_bytes = sizeof(T); in_chunk = 1; out_chunk = L;
         check(gr4hip_fir_interp_create(&h, dtype_of<T>(), b.data(), b.size(), L), "gr4hip_fir_interp_create");
     }
     ~InterpStage() override { gr4hip_fir_interp_destroy(h); }
-    std::string_view kind() const override { return "fir_interp"; }
+    void regain(double g) {
+        std::vector<float> bs(taps.size());
+        for (std::size_t k = 0; k < taps.size(); ++k) bs[k] = static_cast<float>(g * double(taps[k]));
+        check(gr4hip_fir_interp_set_taps(h, bs.data(), bs.size()), "gr4hip_fir_interp_set_taps"); // (the history is kept)
+        gain = g;
+    }
+    bool absorb(const EwiseProgram& p, bool /*before*/) override {
+        double g = 1.0;
+        if (p.dtype != dtype_of<T>() || !AbsorbedPrograms::real_gain(p, &g)) return false;
+        regain(gain * g);
+        return true;
+    }
+    void clear_absorbed() override { if (gain != 1.0) regain(1.0); }
+    std::string_view kind() const override { return gain == 1.0 ? "fir_interp" : "fir_interp[gain folded]"; }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override { return gr4hip_fir_interp_process(h, in, n, out, n_out, s); }
 };
 
 struct RotatorStage final : Stage {
     gr4hip_rotator_t* h = nullptr;
+    EwiseProgram      prog; // the closed-form rotator as a per-sample op (empty with the reference's recurrence: that one is sequential and stays a stage of its own)
     RotatorStage(float phase_increment, float initial_phase) {
         in_bytes = out_bytes = 8;
         check(gr4hip_rotator_create(&h, phase_increment, initial_phase), "gr4hip_rotator_create");
         if (options().rotator_reference_recurrence) check(gr4hip_rotator_set_algo(h, GR4HIP_ROTATOR_RECURRENCE), "gr4hip_rotator_set_algo");
+        else if (std::isfinite(phase_increment) && std::isfinite(initial_phase)) {
+            prog.dtype = GR4HIP_C32;
+            EwiseProgram::Op op;
+            op.kind = EwiseProgram::kRotator;
+            op.inc  = phase_increment;
+            op.ph0  = initial_phase;
+            prog.ops.push_back(op);
+        }
     }
     ~RotatorStage() override { gr4hip_rotator_destroy(h); }
+    const EwiseProgram* program() const override { return prog.empty() ? nullptr : &prog; }
     std::string_view kind() const override { return "rotator_c32"; }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
         *n_out = n;
@@ -345,22 +537,41 @@ struct Rotator64Stage final : Stage {
 // BasicFilterProto<float, ...>: designed FIR (polyphase when decimating: only the kept outputs are computed) or designed IIR cascade at the
 // full rate followed by the keep-every-D-th step (time_domain_filter.hpp:190-204)
 struct BasicFilterStage final : Stage {
-    gr4hip_fir_t* fir = nullptr;
-    gr4hip_iir_t* iir = nullptr;
-    std::size_t   decim;
-    DevBuf        tmp;
-    BasicFilterStage(const gr::filter::DesignedFilter& d, std::size_t decimate) : decim(std::max<std::size_t>(1, decimate)) {
+    gr4hip_fir_t*    fir = nullptr;
+    gr4hip_iir_t*    iir = nullptr;
+    std::size_t      decim;
+    int              dtype; // GR4HIP_F32 as registered upstream, or GR4HIP_C32 (complex data, the designed real taps: FIR designs only)
+    DevBuf           tmp;
+    AbsorbedPrograms absorbed;
+    std::string      _kind;
+    BasicFilterStage(const gr::filter::DesignedFilter& d, std::size_t decimate, int dtype_ = GR4HIP_F32) : decim(std::max<std::size_t>(1, decimate)), dtype(dtype_) {
         in_chunk = decim; out_chunk = 1;
+        in_bytes = out_bytes = dtype == GR4HIP_C32 ? 8 : 4;
         if (d.fir) {
-            check(gr4hip_fir_create(&fir, GR4HIP_F32, d.taps.data(), d.taps.size(), decim), "gr4hip_fir_create");
+            check(gr4hip_fir_create(&fir, dtype, d.taps.data(), d.taps.size(), decim), "gr4hip_fir_create");
         } else {
+            if (dtype != GR4HIP_F32) throw std::invalid_argument("BasicFilter<complex<float>> on the device: FIR designs only");
             std::vector<float> b, a;
             for (std::size_t s = 0; s < d.b.size(); ++s) { b.insert(b.end(), d.b[s].begin(), d.b[s].end()); a.insert(a.end(), d.a[s].begin(), d.a[s].end()); }
             check(gr4hip_iir_create(&iir, GR4HIP_DF_II, d.b.size(), b.data(), 3, a.data(), 3), "gr4hip_iir_create");
         }
+        name();
     }
     ~BasicFilterStage() override { if (fir) gr4hip_fir_destroy(fir); if (iir) gr4hip_iir_destroy(iir); }
-    std::string_view kind() const override { return fir ? (decim > 1 ? "basic_fir_decim" : "basic_fir") : (decim > 1 ? "basic_iir_decim" : "basic_iir"); }
+    void name() { _kind = std::string(fir ? (decim > 1 ? "basic_fir_decim" : "basic_fir") : (decim > 1 ? "basic_iir_decim" : "basic_iir")) + absorbed.suffix(); }
+    bool absorb(const EwiseProgram& p, bool before) override { // designed FIR: the neighbours ride in the filter's launch (gains in the taps, the rest as hooks)
+        if (!fir || !absorbed.take(p, before, dtype)) return false;
+        apply_fir_hooks(fir, absorbed);
+        name();
+        return true;
+    }
+    void clear_absorbed() override {
+        if (!fir || (absorbed.pre.empty() && absorbed.post.empty())) return;
+        absorbed.clear();
+        apply_fir_hooks(fir, absorbed);
+        name();
+    }
+    std::string_view kind() const override { return _kind; }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
         if (fir) return gr4hip_fir_process(fir, in, n, out, n_out, s);
         if (decim == 1) { *n_out = n; return gr4hip_iir_process(iir, static_cast<const float*>(in), n, static_cast<float*>(out), s); }
@@ -516,12 +727,13 @@ struct Kernel<gr::filter::fir_interpolator<T>> {
     static std::unique_ptr<Stage> make_stage(B& b) { return std::make_unique<InterpStage<T>>(b.b, b.interpolate); }
     static work::Status           work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
 };
-template <typename... Args>
-struct Kernel<gr::filter::BasicFilterProto<float, Args...>> {
-    using B = gr::filter::BasicFilterProto<float, Args...>;
+template <typename T, typename... Args>
+requires(std::is_same_v<T, float> || std::is_same_v<T, std::complex<float>>)
+struct Kernel<gr::filter::BasicFilterProto<T, Args...>> {
+    using B = gr::filter::BasicFilterProto<T, Args...>;
     static std::unique_ptr<Stage> make_stage(B& b) {
         if (!b._designed) b.designFilter();
-        return std::make_unique<BasicFilterStage>(b._design, B::TParent::ResamplingControl::kIsConst ? 1 : b.decimate.value);
+        return std::make_unique<BasicFilterStage>(b._design, B::TParent::ResamplingControl::kIsConst ? 1 : b.decimate.value, dtype_of<T>());
     }
     static work::Status work(B& b, std::size_t nIn, std::size_t nOut) { return offload_work(b, nIn, nOut, make_stage); }
 };
@@ -550,6 +762,85 @@ struct SeqStage final : Stage {
         return b->enqueue(mid.p, m, out, n_out, s);
     }
 };
+// ---- kernel-level fusion of adjacent stages: the run-time Merge<> (BlockMerging.hpp:126-240: "one processOne through both blocks, bypassing runtime buffers")
+//   * per-sample stage + per-sample stage (MathOpImpl, closed-form Rotator)      -> ONE element-wise program: one launch, values in registers
+//   * per-sample stage next to a filter that can take it (Stage::absorb)         -> the filter's launch: gains fold into its coefficients, anything else is its
+//                                                                                   load / store hook.  Behind a filter first (its output rate is the lower one)
+//   * fir_filter<T> -> Decimator<T>                                              -> the polyphase decimating FIR (only the kept outputs are computed)
+//   * fir_filter<complex<float>> -> PowerSpectrum                                -> the fused FIR -> FFT -> |.|^2 kernel (gr4hip_chain_*)
+// A group keeps the members it stands for; `anchor` is the member whose stage survived with the others absorbed into it (npos: the group's stage was made anew).
+struct FusedGroup {
+    std::unique_ptr<Stage>   stage;
+    std::vector<std::size_t> members;
+    std::size_t              anchor = static_cast<std::size_t>(-1);
+};
+namespace detail {
+template <typename T>
+inline std::unique_ptr<Stage> fuse_fir_decimator(Stage& a, Stage& b) {
+    auto* fir = dynamic_cast<FirStage<T>*>(a.self());
+    auto* dec = dynamic_cast<DecimatorStage<T>*>(b.self());
+    if (!fir || !dec || fir->decim != 1 || dec->decim < 2 || !fir->absorbed.post.empty()) return nullptr;
+    auto fused = std::make_unique<FirStage<T>>(fir->taps, dec->decim);
+    if (!fir->absorbed.pre.empty() && !fused->absorb(fir->absorbed.pre, true)) return nullptr;
+    return fused;
+}
+inline std::unique_ptr<Stage> fuse_pair(Stage& a, Stage& b); // defined below ChainStage's users
+} // namespace detail
+inline std::vector<FusedGroup> fuse_stages(std::vector<std::unique_ptr<Stage>> made) {
+    std::vector<FusedGroup> g;
+    for (std::size_t i = 0; i < made.size(); ++i) {
+        FusedGroup f;
+        f.stage   = std::move(made[i]);
+        f.members = {i};
+        f.anchor  = i;
+        g.push_back(std::move(f));
+    }
+    const auto merge_into = [&](std::size_t keep, std::size_t drop, std::unique_ptr<Stage> replacement) { // groups keep and drop are neighbours
+        FusedGroup& k = g[keep];
+        FusedGroup& d = g[drop];
+        if (replacement) { k.stage = std::move(replacement); k.anchor = static_cast<std::size_t>(-1); }
+        if (drop < keep) k.members.insert(k.members.begin(), d.members.begin(), d.members.end());
+        else k.members.insert(k.members.end(), d.members.begin(), d.members.end());
+        g.erase(g.begin() + static_cast<std::ptrdiff_t>(drop));
+    };
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (std::size_t i = 0; i + 1 < g.size() && !changed; ++i) {
+            Stage&              a  = *g[i].stage;
+            Stage&              b  = *g[i + 1].stage;
+            const EwiseProgram* pa = a.program();
+            const EwiseProgram* pb = b.program();
+            if (pa && pb && pa->dtype == pb->dtype) { // program + program
+                if (dynamic_cast<EwiseStage*>(a.self())) { a.absorb(*pb, false); merge_into(i, i + 1, nullptr); g[i].anchor = static_cast<std::size_t>(-1); }
+                else if (dynamic_cast<EwiseStage*>(b.self())) { b.absorb(*pa, true); merge_into(i + 1, i, nullptr); g[i].anchor = static_cast<std::size_t>(-1); }
+                else {
+                    auto e = std::make_unique<EwiseStage>(*pa);
+                    e->absorb(*pb, false);
+                    merge_into(i, i + 1, std::move(e));
+                }
+                changed = true;
+            } else if (pb && !pa && a.absorb(*pb, false)) { // behind a filter: its store hook
+                merge_into(i, i + 1, nullptr);
+                changed = true;
+            } else if (pa && !pb && b.absorb(*pa, true)) { // in front of a filter: its load hook
+                merge_into(i + 1, i, nullptr);
+                changed = true;
+            } else if (auto fused = detail::fuse_pair(a, b)) {
+                merge_into(i, i + 1, std::move(fused));
+                changed = true;
+            }
+        }
+    }
+    return g;
+}
+// the stages of `made` as ONE stage: fused where kernels exist for it, back to back with the intermediates in HBM where not
+inline std::unique_ptr<Stage> fuse_to_one(std::vector<std::unique_ptr<Stage>> made) {
+    auto                   groups = fuse_stages(std::move(made));
+    std::unique_ptr<Stage> acc    = std::move(groups.front().stage);
+    for (std::size_t i = 1; i < groups.size(); ++i) acc = std::make_unique<SeqStage>(std::move(acc), std::move(groups[i].stage));
+    return acc;
+}
+
 template <typename A, fixed_string OutA, typename B, fixed_string InB>
 requires requires(A& a, B& b) { Kernel<A>::make_stage(a); Kernel<B>::make_stage(b); }
 struct Kernel<gr::Merge<A, OutA, B, InB>> {
@@ -672,8 +963,29 @@ requires requires(A& a, B& b) { Kernel<A>::make_stage(a); Kernel<B>::make_stage(
 std::unique_ptr<Stage> Kernel<gr::Merge<A, OutA, B, InB>>::make_stage(M& m) {
     // peephole: input gain -> pole feedback is still ONE first-order section (bm_MergeApi.cpp:59-60: y[n] = a x[n] + (1 - a) y[n-1])
     if constexpr (std::is_same_v<A, gr::blocks::math::MultiplyConst<float>> && detail::is_pole_feedback<B>::value) return Kernel<B>::make_pole(m.leftBlock.value, Kernel<B>::pole(m.rightBlock));
-    else return std::make_unique<SeqStage>(Kernel<A>::make_stage(m.leftBlock), Kernel<B>::make_stage(m.rightBlock));
+    else { // one launch where the parts fuse (per-sample parts into one program or into the neighbouring filter's launch), two with the intermediate in HBM where not
+        std::vector<std::unique_ptr<Stage>> parts;
+        parts.push_back(Kernel<A>::make_stage(m.leftBlock));
+        parts.push_back(Kernel<B>::make_stage(m.rightBlock));
+        return fuse_to_one(std::move(parts));
+    }
 }
+namespace detail {
+inline std::unique_ptr<Stage> fuse_pair(Stage& a, Stage& b) {
+    if (auto f = fuse_fir_decimator<float>(a, b)) return f;
+    if (auto f = fuse_fir_decimator<std::complex<float>>(a, b)) return f;
+    auto* fir  = dynamic_cast<FirStage<std::complex<float>>*>(a.self());
+    auto* spec = dynamic_cast<PowerSpectrumStage*>(b.self());
+    if (fir && spec && fir->decim == 1 && fir->absorbed.post.empty()) { // the fused FIR -> FFT -> |.|^2 kernel; a gain in front of the filter rides in its taps
+        double g = 1.0;
+        if (!fir->absorbed.pre.empty() && !AbsorbedPrograms::real_gain(fir->absorbed.pre, &g)) return nullptr;
+        std::vector<float> taps(fir->taps.size());
+        for (std::size_t k = 0; k < taps.size(); ++k) taps[k] = static_cast<float>(g * double(fir->taps[k]));
+        return std::make_unique<ChainStage>(taps, spec->N, spec->window);
+    }
+    return nullptr;
+}
+} // namespace detail
 
 // N inputs -> 1 output at the seam (Math.hpp:100-107): every input span goes to HBM, one fold kernel, one span back.  No Stage: a
 // fan-in is not part of a linear device run, the planner leaves it to this per-block path.
@@ -1091,11 +1403,14 @@ class DeviceRun final : public BlockModel {
     // the blocks this run stands for (kept alive by Graph::retired) and the stage that realises each: tags address their settings
     struct Member { BlockModel* block; std::size_t stage; };
     std::vector<Member>                                  _members;
-    std::function<std::unique_ptr<Stage>(std::size_t)>   _rebuild; // fresh stage i from the members' current settings
+    // stage i follows its members' CURRENT settings: `dirty` marks the members that changed; the callee either updates `live` in place (a filter whose absorbed
+    // neighbours changed keeps its history) and returns null, or returns a fresh stage
+    using Rebuild = std::function<std::unique_ptr<Stage>(std::size_t stage, const std::vector<bool>& dirty, Stage* live)>;
+    Rebuild                                              _rebuild;
     std::size_t                                          _tags_forwarded = 0, _stages_rebuilt = 0;
 
 public:
-    void set_members(std::vector<Member> members, std::function<std::unique_ptr<Stage>(std::size_t)> rebuild) { _members = std::move(members); _rebuild = std::move(rebuild); }
+    void set_members(std::vector<Member> members, Rebuild rebuild) { _members = std::move(members); _rebuild = std::move(rebuild); }
     [[nodiscard]] std::size_t tags_forwarded() const { return _tags_forwarded; }
     [[nodiscard]] std::size_t stages_rebuilt() const { return _stages_rebuilt; }
     using RunMember = Member;
@@ -1263,13 +1578,18 @@ public:
             property_map fwd;
             if (!_in_edge->tags.empty()) {
                 const auto apply = [&](const property_map& map) {
-                    std::vector<bool> dirty(_stages.size(), false);
-                    for (auto& m : _members)
-                        if (m.block->apply_tag_settings(map)) dirty[m.stage] = true;
+                    std::vector<bool> dirty(_stages.size(), false), changed(_members.size(), false);
+                    for (std::size_t m = 0; m < _members.size(); ++m)
+                        if (_members[m].block->apply_tag_settings(map)) dirty[_members[m].stage] = changed[m] = true;
                     if (std::find(dirty.begin(), dirty.end(), true) == dirty.end()) return;
                     while (_q_count) published += retire(false); // a stage is replaced: nothing of the old one may be in flight
                     for (std::size_t i = 0; i < _stages.size(); ++i)
-                        if (dirty[i] && _rebuild) { _stages[i] = _rebuild(i); ++_stages_rebuilt; }
+                        if (dirty[i] && _rebuild) {
+                            if (auto fresh = _rebuild(i, changed, _stages[i].get())) _stages[i] = std::move(fresh);
+                            ++_stages_rebuilt;
+                        }
+                    _desc.clear();
+                    for (auto& st : _stages) _desc += std::string(_desc.empty() ? "" : " -> ") + std::string(st->kind());
                     recompute_rates(); // the launch below is sized with the new chunking
                 };
                 property_map merged;
@@ -1397,12 +1717,11 @@ template <typename First, typename... Rest>
 DeviceRun& fuse_chain(Graph& g, First& first, Rest&... rest) {
     std::vector<std::unique_ptr<Stage>> stages;
     auto& last = std::get<sizeof...(Rest)>(std::tie(first, rest...));
-    if constexpr (sizeof...(Rest) == 1 && std::is_same_v<First, gr::filter::fir_filter<std::complex<float>>> &&
-                  (std::is_same_v<Rest, gr::blocks::fft::PowerSpectrum<std::complex<float>>> && ...)) {
-        stages.push_back(std::make_unique<ChainStage>(first.b, last.fftSize, window_id(last.window))); // one launch for both blocks
-    } else {
-        stages.push_back(Kernel<First>::make_stage(first));
-        (stages.push_back(Kernel<Rest>::make_stage(rest)), ...);
+    {
+        std::vector<std::unique_ptr<Stage>> made;
+        made.push_back(Kernel<First>::make_stage(first));
+        (made.push_back(Kernel<Rest>::make_stage(rest)), ...);
+        for (auto& grp : fuse_stages(std::move(made))) stages.push_back(std::move(grp.stage)); // neighbours with a fused kernel share one launch
     }
     if (!first.in.connected() || !last.out.connected()) throw std::invalid_argument("fuse_chain: connect the chain to its neighbours first");
     auto  run = std::make_unique<DeviceRun>(std::move(stages), first.in.buffer, last.out.buffer, ComputeDomain::parse(first.compute_domain));
@@ -1482,48 +1801,68 @@ inline std::vector<DeviceRun*> plan(Graph& g, std::size_t min_blocks = 2, std::s
         for (auto* m : chain) taken.push_back(m);
         if (chain.size() >= min_blocks) chains.push_back(std::move(chain));
     }
-    // a stage created through the type-erased hook, owned by the run
+    // a stage created through the type-erased hook (the deleter travels with the shared_ptr), owned by the run
     struct Holder final : Stage {
         std::shared_ptr<Stage> s;
-        explicit Holder(std::shared_ptr<Stage> p) : s(std::move(p)) { in_bytes = s->in_bytes; out_bytes = s->out_bytes; in_chunk = s->in_chunk; out_chunk = s->out_chunk; }
+        explicit Holder(std::shared_ptr<Stage> p) : s(std::move(p)) { sync(); }
+        void sync() { in_bytes = s->in_bytes; out_bytes = s->out_bytes; in_chunk = s->in_chunk; out_chunk = s->out_chunk; }
         int              enqueue(const void* i, std::size_t n, void* o, std::size_t* no, gr4hip_stream_t st) override { return s->enqueue(i, n, o, no, st); }
         std::string_view kind() const override { return s->kind(); }
+        const EwiseProgram* program() const override { return s->program(); }
+        bool absorb(const EwiseProgram& p, bool before) override { return s->absorb(p, before); }
+        void clear_absorbed() override { s->clear_absorbed(); }
+        Stage* self() override { return s->self(); }
     };
     std::vector<DeviceRun*> runs;
     for (auto& chain : chains) {
-        // stage plan: member index -> stage index; adjacent fir_filter<complex<float>> -> PowerSpectrum members share one fused stage (peephole)
-        std::vector<std::shared_ptr<Stage>> made;
-        for (auto* m : chain) made.push_back(std::static_pointer_cast<Stage>(m->make_device_stage()));
-        if (std::find(made.begin(), made.end(), nullptr) != made.end()) continue; // a member without a device kernel: leave the chain to the per-block seam
-        std::vector<std::size_t>        first_member; // per stage
-        std::vector<DeviceRun::RunMember> members;
-        for (std::size_t i = 0; i < made.size(); ++i) {
-            const bool pair = std::dynamic_pointer_cast<FirStage<std::complex<float>>>(made[i]) && i + 1 < made.size() && std::dynamic_pointer_cast<PowerSpectrumStage>(made[i + 1]);
-            first_member.push_back(i);
-            members.push_back({chain[i], first_member.size() - 1});
-            if (pair) members.push_back({chain[++i], first_member.size() - 1});
-        }
-        const auto n_members = [first_member, total = made.size()](std::size_t stage) { return (stage + 1 < first_member.size() ? first_member[stage + 1] : total) - first_member[stage]; };
-        // (re)build stage i from its members' CURRENT settings; `fresh` avoids making the first set twice
-        auto build = [chain, first_member, n_members](std::size_t stage, const std::vector<std::shared_ptr<Stage>>* fresh) -> std::unique_ptr<Stage> {
-            const std::size_t m0 = first_member[stage];
-            const auto get = [&](std::size_t m) { return fresh ? (*fresh)[m] : std::static_pointer_cast<Stage>(chain[m]->make_device_stage()); };
-            if (n_members(stage) == 2) {
-                auto fir  = std::dynamic_pointer_cast<FirStage<std::complex<float>>>(get(m0));
-                auto spec = std::dynamic_pointer_cast<PowerSpectrumStage>(get(m0 + 1));
-                return std::make_unique<ChainStage>(fir->taps, spec->N, spec->window);
+        // member stages from the members' CURRENT settings, then fused: per-sample neighbours into one program or into the launch of the filter next to them,
+        // fir -> Decimator into the polyphase filter, fir_filter<complex<float>> -> PowerSpectrum into the fused chain kernel (fuse_stages)
+        const auto make_members = [chain](std::size_t first, std::size_t count) {
+            std::vector<std::unique_ptr<Stage>> made;
+            for (std::size_t m = first; m < first + count; ++m) {
+                auto st = std::static_pointer_cast<Stage>(chain[m]->make_device_stage());
+                if (!st) return std::vector<std::unique_ptr<Stage>>{};
+                made.push_back(std::make_unique<Holder>(std::move(st)));
             }
-            return std::make_unique<Holder>(get(m0));
+            return made;
         };
+        auto made = make_members(0, chain.size());
+        if (made.size() != chain.size()) continue; // a member without a device kernel: leave the chain to the per-block seam
+        auto groups = fuse_stages(std::move(made));
+        struct GroupInfo { std::size_t first, count, anchor; };
+        std::vector<GroupInfo>            info;
+        std::vector<DeviceRun::RunMember> members;
         std::vector<std::unique_ptr<Stage>> fused;
-        for (std::size_t st = 0; st < first_member.size(); ++st) fused.push_back(build(st, &made));
+        for (auto& grp : groups) {
+            info.push_back({grp.members.front(), grp.members.size(), grp.anchor});
+            for (std::size_t m : grp.members) members.push_back({chain[m], fused.size()});
+            fused.push_back(std::move(grp.stage));
+        }
+        // stage i again from its members' current settings.  Only absorbed neighbours changed: the live filter takes their new programs and keeps its state
+        // (a gain step by tag in front of a FIR: the history holds the old gain's samples, as on the host); otherwise the group is made anew
+        auto rebuild = [chain, info, make_members](std::size_t stage, const std::vector<bool>& dirty, Stage* live) -> std::unique_ptr<Stage> {
+            const GroupInfo& gi   = info[stage];
+            std::size_t      base = 0; // index of the group's first member in the run's member list (groups are contiguous and in order)
+            for (std::size_t k = 0; k < stage; ++k) base += info[k].count;
+            auto made = make_members(gi.first, gi.count);
+            if (made.size() != gi.count) throw std::runtime_error("device run: a member lost its device kernel");
+            const bool anchored = gi.anchor != static_cast<std::size_t>(-1) && gi.count > 1;
+            if (anchored && live && !dirty[base + (gi.anchor - gi.first)]) {
+                live->clear_absorbed();
+                bool ok = true;
+                for (std::size_t m = gi.anchor - gi.first; m-- > 0 && ok;) ok = made[m]->program() && live->absorb(*made[m]->program(), true);
+                for (std::size_t m = gi.anchor - gi.first + 1; m < gi.count && ok; ++m) ok = made[m]->program() && live->absorb(*made[m]->program(), false);
+                if (ok) return nullptr;
+            }
+            return fuse_to_one(std::move(made));
+        };
         if (run_edge_items) {
             (void)chain.front()->input_edges()[0]->ensure_capacity(run_edge_items);
             (void)chain.back()->output_edges()[0]->ensure_capacity(run_edge_items);
         }
         auto  run = std::make_unique<DeviceRun>(std::move(fused), chain.front()->input_edges()[0], chain.back()->output_edges()[0], chain.front()->compute_domain());
         auto* ref = run.get();
-        run->set_members(std::move(members), [build](std::size_t stage) { return build(stage, nullptr); });
+        run->set_members(std::move(members), std::move(rebuild));
         std::vector<std::unique_ptr<BlockModel>> kept;
         bool                                     placed = false;
         for (auto& bp : blocks) {

@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
         dump(out + (fused ? "_chain.bin" : "_chain_hann.bin"), sink._samples);
     }
     { // 3b. the planner finds the device chains by itself: (a) fir -> PowerSpectrum collapses into the fused kernel, (b) MultiplyConst -> fir_filter<float>
-      //     becomes a two-stage run on one stream, (c) a host block between two device blocks splits the chain
+      //     becomes ONE stage (the gain in the filter's launch), (c) a host block between two device blocks splits the chain
         Graph g;
         auto& src  = g.emplaceBlock<testing::VectorSource<std::complex<float>>>();
         src.values = x;
@@ -156,7 +156,7 @@ int main(int argc, char** argv) {
         std::printf("planner: %zu runs:", runs.size());
         for (auto* r : runs) std::printf(" [%s]", std::string(r->description()).c_str());
         std::printf("\n");
-        if (runs.size() != 2 || runs[0]->description() != "chain_fir_fft_mag2" || runs[1]->description() != "math_const -> fir_f32") ++errors;
+        if (runs.size() != 2 || runs[0]->description() != "chain_fir_fft_mag2" || runs[1]->description() != "fir_f32[pre: mul]") ++errors; // (the gain rides in the filter's launch)
         scheduler::Simple sched;
         sched.exchange(std::move(g));
         if (const auto r = sched.runAndWait(); !r) { std::cerr << "planned graph: " << r.error().message << "\n"; ++errors; }
@@ -410,7 +410,7 @@ int main(int argc, char** argv) {
             const property_map cfg{{"fftSize", std::int64_t(512)}, {"window", "Hamming"s}, {"outputInDb", true}};
             compare("FFT<float> 512 Hamming dB", run_one<BR, float, DataSet<float>>(cfg, xf, true, errors), run_one<BR, float, DataSet<float>>(cfg, xf, false, errors), xf.size() / 512);
         }
-        { // planner over resampling stages: MultiplyConst -> BasicDecimatingFilter(FIR, /4) -> Decimator(/3) -> iir_filter, one run, one stream
+        { // planner over resampling stages: MultiplyConst -> BasicDecimatingFilter(FIR, /4) -> Decimator(/3) -> iir_filter, one run, one stream (the gain in the filter's taps)
             std::vector<float> got[2];
             for (int dev = 1; dev >= 0; --dev) {
                 Graph g;
@@ -432,7 +432,7 @@ int main(int argc, char** argv) {
                     const auto runs = hip::plan(g, 2, 0); // (default-size edges on purpose: several launches, so that the pipelining shows)
                     the_run = runs.empty() ? nullptr : runs[0];
                     std::printf("planner (resampling): %zu run:%s%s\n", runs.size(), runs.empty() ? "" : " ", runs.empty() ? "" : std::string(runs[0]->description()).c_str());
-                    if (runs.size() != 1 || runs[0]->description() != "math_const -> basic_fir_decim -> decimator -> iir_f32" || runs[0]->out_count(12) != 1) ++errors;
+                    if (runs.size() != 1 || runs[0]->description() != "basic_fir_decim[pre: mul] -> decimator -> iir_f32" || runs[0]->out_count(12) != 1) ++errors;
                 }
                 scheduler::Simple sched;
                 sched.exchange(std::move(g));
@@ -440,7 +440,7 @@ int main(int argc, char** argv) {
                 got[dev] = sink._samples;
                 if (dev) { // work() only queues: chunk c + 1 is copied in while chunk c computes and chunk c - 1 is copied out
                     const std::size_t ov = the_run ? the_run->overlapped_chunks() : 0;
-                    std::printf("pipelined run: %zu of %zu launches queued while an earlier chunk was still in flight\n", ov, the_run ? the_run->launches() / 4 : 0);
+                    std::printf("pipelined run: %zu of %zu launches queued while an earlier chunk was still in flight\n", ov, the_run ? the_run->launches() / 3 : 0);
                     // (reported, not asserted: whether a chunk is still in flight when the next one is queued is a matter of timing on five small chunks; the
                     //  pipelining itself is measured by bench_host_feed: profiles/r02_host_feed.txt)
                 }
@@ -449,7 +449,7 @@ int main(int argc, char** argv) {
         }
     }
     { // 5b. merge API on the device: Merge<MultiplyConst, FeedbackMerge<Adder, MultiplyConst>> (the reference benchmark's IIR low-pass) is ONE first-order
-      //     section for the scan kernel; a Merge of two unrelated blocks is a two-stage block with its intermediate in HBM
+      //     section for the scan kernel; a Merge of a gain and a filter is the filter with the gain in its taps (5c: every other fusable pair)
         using blocks::math::MultiplyConst;
         using IIRChain = gr::Merge<MultiplyConst<float>, "out", gr::FeedbackMerge<Adder<>, "out", MultiplyConst<float>, "out", "in2">, "in1">;
         std::vector<float> xs(400000);
@@ -487,6 +487,130 @@ int main(int argc, char** argv) {
         probe2.applySettings(cfg2);
         std::printf("merge MultiplyConst -> fir_filter on the device: stage '%s', max rel err %.3g%s\n", std::string(hip::Kernel<Two>::make_stage(probe2)->kind()).c_str(), e2, e2 <= 1e-5 ? "" : "  FAILED");
         if (!(e2 <= 1e-5)) ++errors;
+    }
+    { // 5c. kernel-level fusion, the run-time Merge<> (BlockMerging.hpp:126-240): adjacent per-sample blocks are ONE launch, and they ride in the launch of the
+      //     filter next to them -- no intermediate stream in HBM
+        using namespace blocks::math;
+        std::vector<float> xs(300000);
+        std::uint32_t      lcg = 7u;
+        for (auto& v : xs) { lcg = lcg * 1664525u + 1013904223u; v = static_cast<float>(static_cast<std::int32_t>(lcg >> 8) % 2001 - 1000) / 250.f; }
+        // (i) the reference's merged benchmark chains (core/benchmarks/bm_MergeApi.cpp:174: mult -> div -> add, and that ten times over): one program each,
+        //     bit-identical to the merged block on the host (the same IEEE operations in the same order)
+        using Chain1  = gr::Merge<MultiplyConst<float>, "out", gr::Merge<DivideConst<float>, "out", AddConst<float>, "in">, "in">;
+        using Chain2  = gr::Merge<Chain1, "out", Chain1, "in">;
+        using Chain4  = gr::Merge<Chain2, "out", Chain2, "in">;
+        using Chain8  = gr::Merge<Chain4, "out", Chain4, "in">;
+        using Chain10 = gr::Merge<Chain8, "out", Chain2, "in">;
+        for (const double value : {2.0, 3.0}) { // 2: the quotient is a product with 0.5, bit for bit; 3: a true division
+            const property_map cfg{{"value", value}}; // a flat key reaches every part that has such a setting
+            const auto d1 = run_one<Chain1, float, float>(cfg, xs, true, errors), h1 = run_one<Chain1, float, float>(cfg, xs, false, errors);
+            const auto d10 = run_one<Chain10, float, float>(cfg, xs, true, errors), h10 = run_one<Chain10, float, float>(cfg, xs, false, errors);
+            Chain1 p1;
+            Chain10 p10;
+            p1.applySettings(cfg);
+            p10.applySettings(cfg);
+            const auto s1 = hip::Kernel<Chain1>::make_stage(p1);
+            const auto s10 = hip::Kernel<Chain10>::make_stage(p10);
+            const bool same1 = d1.size() == h1.size() && std::memcmp(d1.data(), h1.data(), d1.size() * sizeof(float)) == 0;
+            const bool same10 = d10.size() == h10.size() && std::memcmp(d10.data(), h10.data(), d10.size() * sizeof(float)) == 0;
+            std::printf("merge mult->div->add (value %g) on the device: stage '%s', %s the host block; (mult->div->add)^10: stage '%s', %s\n", value, std::string(s1->kind()).c_str(),
+                        same1 ? "bit-identical to" : "DIFFERS from", std::string(s10->kind()).c_str(), same10 ? "bit-identical" : "DIFFERS");
+            if (!same1 || !same10 || s1->kind() != "ewise[mul,div,add]" || s10->kind() != "ewise[30 ops]") ++errors;
+        }
+        { // the integer chain wraps like the C++ blocks: bit-exact
+            using IChain = gr::Merge<MultiplyConst<std::int32_t>, "out", gr::Merge<DivideConst<std::int32_t>, "out", AddConst<std::int32_t>, "in">, "in">;
+            std::vector<std::int32_t> xi(100000);
+            for (auto& v : xi) { lcg = lcg * 1664525u + 1013904223u; v = static_cast<std::int32_t>(lcg); }
+            const property_map cfg{{"leftBlock.value", std::int64_t(77777)}, {"rightBlock.leftBlock.value", std::int64_t(-13)}, {"rightBlock.rightBlock.value", std::int64_t(2000000000)}};
+            const bool same = run_one<IChain, std::int32_t, std::int32_t>(cfg, xi, true, errors) == run_one<IChain, std::int32_t, std::int32_t>(cfg, xi, false, errors);
+            std::printf("merge mult->div->add <int32> on the device: %s the host block\n", same ? "bit-identical to" : "DIFFERS from");
+            if (!same) ++errors;
+        }
+        { // (ii) the same chain as three graph blocks: the planner makes ONE stage of them (one launch per chunk, 8 B of HBM traffic per sample instead of 24)
+            std::vector<float> got[2];
+            std::size_t        stages = 0, launches = 0;
+            std::string        desc;
+            for (int dev = 1; dev >= 0; --dev) {
+                Graph g;
+                const auto dom = [&](property_map m) { if (dev) m["compute_domain"] = "gpu:hip:0"s; return m; };
+                auto& src  = g.emplaceBlock<testing::VectorSource<float>>();
+                src.values = xs;
+                auto& mul  = g.emplaceBlock<MultiplyConst<float>>(dom({{"value", 3.0}}));
+                auto& div  = g.emplaceBlock<DivideConst<float>>(dom({{"value", 7.0}}));
+                auto& add  = g.emplaceBlock<AddConst<float>>(dom({{"value", -1.0}}));
+                auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+                if (!g.connect<"out", "in">(src, mul) || !g.connect<"out", "in">(mul, div) || !g.connect<"out", "in">(div, add) || !g.connect<"out", "in">(add, sink)) ++errors;
+                hip::DeviceRun* run = nullptr;
+                if (dev) {
+                    const auto runs = hip::plan(g);
+                    if (runs.size() != 1) { ++errors; break; }
+                    run    = runs[0];
+                    stages = run->stages().size();
+                    desc   = std::string(run->description());
+                }
+                scheduler::Simple sched;
+                sched.exchange(std::move(g));
+                if (const auto r = sched.runAndWait(); !r) { std::cerr << "fused math run: " << r.error().message << "\n"; ++errors; }
+                got[dev] = sink._samples;
+                if (run) launches = run->launches();
+            }
+            const bool same = got[1].size() == xs.size() && got[1] == got[0];
+            std::printf("planner (math chain): 1 run: %s  (%zu stage, %zu launch%s), output %s the host graph\n", desc.c_str(), stages, launches, launches == 1 ? "" : "es", same ? "bit-identical to" : "DIFFERS from");
+            if (stages != 1 || desc != "ewise[mul,div,add]" || !same) ++errors;
+        }
+        { // (iii) the channeliser: Rotator -> BasicDecimatingFilter<complex<float>> (designed real taps on complex data) -> PowerSpectrum.  The rotator is the
+          //       filter's load hook: two launches per chunk (filter, transform), and the only intermediate in HBM is the DECIMATED stream.  Checked against the oracle
+          //       by tests/test_host_cpp.py (the host Rotator accumulates its phase in float and drifts away from the closed form over a long stream)
+            Graph g;
+            auto& src  = g.emplaceBlock<testing::VectorSource<std::complex<float>>>({{"n_samples_max", std::int64_t(8 * 256 * 24)}});
+            src.values = x;
+            auto& rot  = g.emplaceBlock<Rotator<std::complex<float>>>({{"phase_increment", 0.3}, {"initial_phase", 0.25}, {"compute_domain", "gpu:hip:0"s}});
+            auto& bdf  = g.emplaceBlock<filter::BasicDecimatingFilter<std::complex<float>>>({{"filter_type", "FIR"s}, {"filter_order", std::int64_t(4)}, {"f_low", 40.0}, {"sample_rate", 1000.0},
+                                                                                             {"fir_design_method", "Hamming"s}, {"decimate", std::int64_t(8)}, {"compute_domain", "gpu:hip:0"s}});
+            auto& spec = g.emplaceBlock<blocks::fft::PowerSpectrum<std::complex<float>>>({{"fftSize", std::int64_t(256)}, {"window", "Hann"s}, {"compute_domain", "gpu:hip:0"s}});
+            auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+            if (!g.connect<"out", "in">(src, rot) || !g.connect<"out", "in">(rot, bdf) || !g.connect<"out", "in">(bdf, spec) || !g.connect<"out", "in">(spec, sink)) ++errors;
+            const auto runs = hip::plan(g);
+            scheduler::Simple sched;
+            sched.exchange(std::move(g));
+            if (const auto r = sched.runAndWait(); !r) { std::cerr << "channeliser: " << r.error().message << "\n"; ++errors; }
+            if (runs.size() == 1) {
+                std::printf("planner (channeliser): 1 run: %s  (%zu stages, %zu launches for %zu samples in)\n", std::string(runs[0]->description()).c_str(), runs[0]->stages().size(), runs[0]->launches(),
+                            std::size_t(8 * 256 * 24));
+                if (runs[0]->stages().size() != 2 || runs[0]->description() != "basic_fir_decim[pre: rot] -> power_spectrum_c32") ++errors;
+            } else ++errors;
+            if (sink._samples.size() != 256 * 24) ++errors;
+            dump(out + "_channeliser.bin", sink._samples);
+            dump(out + "_channeliser_taps.bin", bdf._design.taps);
+        }
+        { // (iv) fir_filter -> Decimator is the polyphase decimating FIR (only the kept outputs are computed), with the gain in front of it in its taps
+            std::vector<float> got[2];
+            std::string        desc;
+            for (int dev = 1; dev >= 0; --dev) {
+                Graph g;
+                const auto dom = [&](property_map m) { if (dev) m["compute_domain"] = "gpu:hip:0"s; return m; };
+                auto& src  = g.emplaceBlock<testing::VectorSource<float>>();
+                src.values = xs;
+                auto& mul  = g.emplaceBlock<MultiplyConst<float>>(dom({{"value", 0.5}}));
+                auto& fir  = g.emplaceBlock<filter::fir_filter<float>>(dom({{"b", std::vector<double>{0.1, 0.2, 0.4, 0.2, 0.1, 0.05, -0.05}}}));
+                auto& dec  = g.emplaceBlock<filter::Decimator<float>>(dom({{"decim", std::int64_t(5)}}));
+                auto& add  = g.emplaceBlock<AddConst<float>>(dom({{"value", 2.0}}));
+                auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+                if (!g.connect<"out", "in">(src, mul) || !g.connect<"out", "in">(mul, fir) || !g.connect<"out", "in">(fir, dec) || !g.connect<"out", "in">(dec, add) || !g.connect<"out", "in">(add, sink)) ++errors;
+                if (dev) {
+                    const auto runs = hip::plan(g);
+                    if (runs.size() != 1) { ++errors; break; }
+                    desc = std::string(runs[0]->description());
+                }
+                scheduler::Simple sched;
+                sched.exchange(std::move(g));
+                if (const auto r = sched.runAndWait(); !r) { std::cerr << "fir -> decimator: " << r.error().message << "\n"; ++errors; }
+                got[dev] = sink._samples;
+            }
+            const double e = got[1].size() == xs.size() / 5 ? max_rel(got[1], got[0]) : 1e30;
+            std::printf("planner (gain -> fir -> Decimator -> add): 1 run: %s, max rel err vs the host graph %.3g%s\n", desc.c_str(), e, e <= 1e-5 ? "" : "  FAILED");
+            if (!(e <= 1e-5) || desc != "fir_f32/5[pre: mul; post: add]") ++errors;
+        }
     }
     { // 5b. the multi-channel graph of BASELINE configs[4] in the C++ API: every channel its own planned device run (fir_filter -> PowerSpectrum fused), channel c on
       //     device c mod <devices> (one here; the runs set their device on every work() call), the fan-in combiner math::Add<float> with n_inputs = channels

@@ -327,6 +327,40 @@ int gr4hip_math_const(int op, int dtype, const void* d_in, void* d_out, size_t n
  * h_d_ins is a HOST array of n_inputs device pointers. */
 int gr4hip_math_nary(int op, int dtype, const void* const* h_d_ins, size_t n_inputs, void* d_out, size_t n, gr4hip_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------ fused runs of per-sample blocks
+ * The reference fuses adjacent blocks at compile time: Merge<A, "out", B, "in"> (core/include/gnuradio-4.0/BlockMerging.hpp:126-240) is ONE processOne() that
+ * carries the value through both parts in registers -- its published table (docs/USER_API_Connecting_Blocks.md:207-222) measures mult -> div -> add and that
+ * chain ten times over.  gr4hip_ewise is the same thing for chains known at run time: a PROGRAM of per-sample ops of one sample type --
+ *   gr4hip_ewise_append_const    MathOpImpl<T, op>::processOne (Math.hpp:38-56): value (op) constant, the semantics of gr4hip_math_const (integers promote, wrap and
+ *                                narrow like C++: bit-exact; float ops are single IEEE operations in program order, never contracted into fused multiply-adds)
+ *   gr4hip_ewise_append_rotator  Rotator<complex<float>>::processOne (Rotator.hpp:51-61) with the closed-form phase of GR4HIP_ROTATOR_CLOSED_FORM: sample k of the
+ *                                stream (counted from create / reset) is multiplied by exp(j (initial_phase + (k + 1) phase_increment)); C32 programs only
+ * -- that gr4hip_ewise_process runs as ONE launch with the values in registers: 2 sizeof(T) bytes of HBM traffic per sample whatever the number of ops.
+ * The same program can ride in the launch of a neighbouring filter as its load hook (prologue) or store hook (epilogue): gr4hip_fir_set_prologue / _epilogue below.
+ * A program holds no device state besides its op list; the stream position (what a rotator op's phase is a function of) is advanced by gr4hip_ewise_process. */
+typedef struct gr4hip_ewise gr4hip_ewise_t;
+int gr4hip_ewise_create(gr4hip_ewise_t** prog, int dtype);
+int gr4hip_ewise_append_const(gr4hip_ewise_t* prog, int op, const void* h_value); /* h_value: one host element of the program's dtype */
+int gr4hip_ewise_append_rotator(gr4hip_ewise_t* prog, float phase_increment, float initial_phase);
+int gr4hip_ewise_length(const gr4hip_ewise_t* prog, size_t* n_ops);
+int gr4hip_ewise_reset(gr4hip_ewise_t* prog); /* stream position back to 0: rotator ops restart from their initial phase */
+int gr4hip_ewise_position(const gr4hip_ewise_t* prog, uint64_t* samples);
+int gr4hip_ewise_process(gr4hip_ewise_t* prog, const void* d_in, void* d_out, size_t n, gr4hip_stream_t stream); /* in place (d_in == d_out) is allowed */
+int gr4hip_ewise_destroy(gr4hip_ewise_t* prog);
+/* Neighbours of a FIR filter in ITS launch.  prologue: applied to every input sample before the filter sees it (the history the filter carries is the history of
+ * the prologue's OUTPUT, zero before the first sample, exactly as if the blocks ran one after the other); epilogue: applied to every output sample before it is
+ * stored.  The program is copied (later changes to `prog` do not reach the filter); NULL or an empty program removes the hook.  dtype of the program == dtype of
+ * the filter.  How it is executed:
+ *   - a program that is nothing but real gains (MultiplyConst / DivideConst; complex constants with a zero imaginary part) is folded into the taps -- a FIR filter
+ *     is linear, fir(g x) == (g b) * x -- and costs nothing in any kernel (the rounding differs from the two-block form in the last bits: one float product per
+ *     tap instead of one per sample, same float32 level, same 1e-5 parity bar);
+ *   - anything else (AddConst / SubtractConst, complex gains, a rotator) runs as a load / store hook of the register-window kernel (any tap count, any
+ *     decimation, float or complex): one launch, no intermediate stream in HBM; the matrix-pipe and frequency-domain kernels are not used for that handle.
+ * A prologue replaced in mid-stream keeps the samples already in the filter's history as the OLD prologue produced them.  GR4HIP_UNSUPPORTED: the program's
+ * dtype does not match. */
+int gr4hip_fir_set_prologue(gr4hip_fir_t* fir, const gr4hip_ewise_t* prog);
+int gr4hip_fir_set_epilogue(gr4hip_fir_t* fir, const gr4hip_ewise_t* prog);
+
 /* Rotator<complex<float>>::processOne (blocks/math/.../Rotator.hpp:51-61): phase += inc (before the first sample),
  * single +-2pi wrap, y = x * (cos, sin); the accumulated phase is carried across calls.
  * Two evaluations of the phase (gr4hip_rotator_set_algo; both keep the same carried state, so they may be switched between calls):

@@ -143,7 +143,7 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
         t, _ = O.chain(b, x, N, wid, truth=True)
         assert len(got) == frames * N and rel(got, t) <= 1e-5, name
     # the planner's runs: fused chain with a Blackman-Harris window, and MultiplyConst -> fir_filter<float> | host AddConst | MultiplyConst
-    assert "planner: 2 runs: [chain_fir_fft_mag2] [math_const -> fir_f32]" in r.stdout
+    assert "planner: 2 runs: [chain_fir_fft_mag2] [fir_f32[pre: mul]]" in r.stdout  # the gain in front of the filter rides in its launch (folded into the taps)
     got = np.fromfile(tmp_path / "o_chain_planned_bh.bin", np.float32)
     t, _ = O.chain(b, x, N, [w.lower() for w in O.WINDOWS].index("blackmanharris"), truth=True)
     assert len(got) == frames * N and rel(got, t) <= 1e-5
@@ -163,7 +163,25 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     assert len(got) == frames * N and rel(got, t) <= 1e-5
     # merge API: the reference benchmark's FeedbackMerge IIR collapses into one first-order section of the scan kernel
     assert "merge IIR low-pass (FeedbackMerge) on the device: stage 'iir_f32'" in r.stdout
-    assert "merge MultiplyConst -> fir_filter on the device: stage 'math_const + fir_f32'" in r.stdout
+    assert "merge MultiplyConst -> fir_filter on the device: stage 'fir_f32[pre: mul]'" in r.stdout
+    # kernel-level fusion (the run-time Merge<>): the reference's merged benchmark chains are ONE program each, bit-identical to the merged block on the host ...
+    for value in (2, 3):
+        assert f"merge mult->div->add (value {value}) on the device: stage 'ewise[mul,div,add]', bit-identical to the host block; (mult->div->add)^10: stage 'ewise[30 ops]', bit-identical" in r.stdout
+    assert "merge mult->div->add <int32> on the device: bit-identical to the host block" in r.stdout
+    # ... three graph blocks are one stage, one launch per chunk; fir_filter -> Decimator is the polyphase decimating FIR with its neighbours absorbed
+    assert "planner (math chain): 1 run: ewise[mul,div,add]  (1 stage, 1 launch), output bit-identical to the host graph" in r.stdout
+    assert "planner (gain -> fir -> Decimator -> add): 1 run: fir_f32/5[pre: mul; post: add]" in r.stdout
+    # ... and the channeliser Rotator -> BasicDecimatingFilter<complex<float>> -> PowerSpectrum is two launches per chunk with only the decimated stream in HBM:
+    # the rotator is the filter's load hook.  Against the oracle: float64 rotator, float64 FIR on the rotator's float32 output, every 8th sample, 256-point Hann frames
+    assert "planner (channeliser): 1 run: basic_fir_decim[pre: rot] -> power_spectrum_c32  (2 stages, 2 launches" in r.stdout
+    ctaps = np.fromfile(tmp_path / "o_channeliser_taps.bin", np.float32)
+    nin = 8 * 256 * 24
+    xin = np.resize(x, nin)
+    rot, _ = O.rotator(xin.astype(np.complex128), float(np.float32(0.3)), float(np.float32(0.25)))
+    yd = O.fir(ctaps, rot.astype(np.complex64))[0][::8]
+    want, _ = O.chain(np.ones(1, np.float32), yd.astype(np.complex64), 256, 3, truth=True)
+    got = np.fromfile(tmp_path / "o_channeliser.bin", np.float32)
+    assert len(got) == 256 * 24 and rel(got, want) <= 1e-5
     assert "merge IIR low-pass (SplitMergeCombine feedback) on the device: stage 'iir_f32'" in r.stdout
     assert "SplitMergeCombine on the device: stage 'split(fir_f32 | math_const)'" in r.stdout
     assert "pipelined run:" in r.stdout and "pipelined run: 0 of" not in r.stdout  # copies and kernels of neighbouring chunks overlap
@@ -177,7 +195,7 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
         assert f"seam {what}" in r.stdout, what
     assert "FAILED" not in r.stdout
     assert "settings-by-tag on a lone device block (MultiplyConst value)" in r.stdout and "settings-by-tag on a lone device block (fir_filter taps, history kept)" in r.stdout
-    assert "planner (resampling): 1 run: math_const -> basic_fir_decim -> decimator -> iir_f32" in r.stdout
+    assert "planner (resampling): 1 run: basic_fir_decim[pre: mul] -> decimator -> iir_f32" in r.stdout
     # ... and BasicDecimatingFilter<float> (designed Hamming FIR / Chebyshev-1 IIR low-pass, order 4, 100 Hz at 1 kHz, decimate 5) against the oracle
     xin = np.fromfile(tmp_path / "o_basic_in.bin", np.float32)
     par = O.filter_params(order=4, fLow=100.0, fs=1000.0)
