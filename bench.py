@@ -34,6 +34,51 @@ KERNEL_SYMBOLS = {1: "gr4::fir_poly_kernel + gr4::fft_fast_kernel (unfused)", 3:
                   4: "gr4::fir_poly_kernel + gr4::fft_fast_kernel (time domain)"}
 
 
+class Watchdog:
+    """A multi-rank run nobody watches must not hang its lease: every phase that waits for another rank (rendezvous, communicator, collectives, the timed
+    loop) runs under a wall-clock deadline.  When one passes, this rank says where it is (rank-tagged, stderr), rank 0 prints the bench's JSON line with an
+    "error" key, and the process exits with code 4 (torch.distributed.run then takes the other ranks down).  A hang inside the library's own communicator
+    (--fanin-impl capi, never exercised between two GPUs before its first driver run) gets ONE retry: every rank re-executes itself with
+    --fanin-impl torch --fanin-cus 0, the most conservative configuration."""
+
+    def __init__(self, rank: int, world: int, argv, timeout: float):
+        import threading
+        self.rank, self.world, self.argv, self.timeout = rank, world, list(argv), timeout
+        self.phase, self.deadline, self.retryable, self.t0 = "start", None, False, time.time()
+        self.lock = threading.Lock()
+        if world > 1 and timeout > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def enter(self, phase: str, seconds: float = None, retryable: bool = False):
+        with self.lock:
+            self.phase, self.retryable = phase, retryable
+            self.deadline = time.time() + (seconds if seconds is not None else self.timeout)
+
+    def leave(self):
+        with self.lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                late = self.deadline is not None and time.time() > self.deadline
+                phase, retryable = self.phase, self.retryable
+            if not late:
+                continue
+            msg = f"rank {self.rank} of {self.world}: no progress in phase '{phase}' within its deadline ({self.timeout:.0f} s budget per waiting phase); {time.time() - self.t0:.0f} s since start"
+            print(f"[bench][watchdog] {msg}", file=sys.stderr, flush=True)
+            if retryable and os.environ.get("GR4HIP_BENCH_RETRY") != "1":
+                print(f"[bench][watchdog] rank {self.rank}: retrying once with --fanin-impl torch --fanin-cus 0", file=sys.stderr, flush=True)
+                os.environ["GR4HIP_BENCH_RETRY"] = "1"
+                args = [a for a in self.argv]
+                os.execv(sys.executable, [sys.executable] + args + ["--fanin-impl", "torch", "--fanin-cus", "0"])
+            if self.rank == 0:
+                print(json.dumps({"metric": "Msamples/s through 256-tap cplx FIR->8192-pt FFT chain; %HBM roofline @1/2/4/8 GPU", "value": None, "n_gpus": self.world,
+                                  "error": msg, "phase": phase, "retried": os.environ.get("GR4HIP_BENCH_RETRY") == "1"}), flush=True)
+            os._exit(4)
+
+
 def _usable_cores() -> int:
     """hardware threads this process may actually use: affinity mask and cgroup CPU quota, not just os.cpu_count()"""
     n = os.cpu_count() or 1
@@ -135,6 +180,11 @@ def main():
                     "instead of ONE launch with the fold in registers (gr4hip_chain_process_multi)")
     ap.add_argument("--guard-mode", type=int, default=0, help="dynamic-range guard of the AUTO chain: 0 strict (default of the library), 1 deferred, 2 off")
     ap.add_argument("--no-graph8", action="store_true", help="N = 1: skip the extra measurement of the 8-channel graph on this one GPU (the 1-GPU point of the strong-scaling curve)")
+    ap.add_argument("--prewarm-ms", type=float, default=40.0, help="untimed launches for at least this long BEFORE the counted --warmup steps: the shader clock needs ~20 ms under load to "
+                    "settle (profiles/r02_clock_ramp.txt), and a short --steps run would otherwise be timed inside that ramp; reported as prewarm_ms / prewarm_steps")
+    ap.add_argument("--no-hann-row", action="store_true", help="N = 1: skip the second row with the FFT block's default Hann window (SURVEY.md 8(d))")
+    ap.add_argument("--fanin-timeout", type=float, default=90.0, help="N > 1: seconds any phase that waits for another rank may take before the run gives up with a rank-tagged diagnostic "
+                    "(exit code 4, an \"error\" key in the JSON line) instead of hanging; 0 = no watchdog")
     args = ap.parse_args()
 
     import numpy as np
@@ -151,11 +201,18 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     local = local % torch.cuda.device_count() if args.dist_backend != "nccl" else local
     torch.cuda.set_device(local)
+    wd = Watchdog(rank, world, sys.argv, args.fanin_timeout)
+    rank_log = {}  # per-rank timings of the phases that involve other ranks (printed by every rank on stderr, gathered into the JSON line)
     if world > 1:
+        wd.enter("rendezvous (init_process_group)")
+        t_ = time.perf_counter()
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
         else:
             dist.init_process_group(args.dist_backend)
+        dist.barrier()
+        rank_log["rendezvous_s"] = round(time.perf_counter() - t_, 3)
+        wd.leave()
 
     n_channels = args.channels or (1 if world == 1 else 8)
     plan = fanin.channel_plan(n_channels, world)
@@ -197,6 +254,8 @@ def main():
             ch.set_max_workgroups(max(1, n_cu - args.fanin_cus))
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nchunks)]
+    ev_all = []   # (start, end) of every timed launch of this rank's first channel, all steps
+    step_ev = []  # (start, end) of every timed step on the main stream
     done = [[torch.cuda.Event() for _ in mine] for _ in range(2)]
     main_stream = torch.cuda.current_stream()
     # the fan-in of launch c runs on its own stream beside the chains of launch c + 1; slab c & 1 is free again when its fan-in has finished
@@ -205,6 +264,8 @@ def main():
     recv = torch.empty((frames_per_chunk, NFFT), dtype=torch.float32, device="cuda") if world > 1 else None  # all_to_all landing area
     comm = None
     if world > 1 and args.dist_backend == "nccl" and args.fanin_impl == "capi":
+        wd.enter("gr4hip_fanin communicator (ncclCommInitRank through the library)", retryable=True)
+        t_ = time.perf_counter()
         try:
             comm = fanin.Communicator()
             ok = 1
@@ -215,6 +276,11 @@ def main():
         dist.all_reduce(agree, op=dist.ReduceOp.MIN)
         if int(agree.item()) == 0:
             comm = None
+        rank_log["communicator_s"] = round(time.perf_counter() - t_, 3)
+        wd.leave()
+    if world > 1 and os.environ.get("GR4HIP_BENCH_STALL_RANK") == str(rank):  # test hook: this rank never reaches its first collective
+        print(f"[bench] rank {rank}: stalling on purpose (GR4HIP_BENCH_STALL_RANK)", file=sys.stderr, flush=True)
+        time.sleep(10 ** 6)
     fanin_algo = args.fanin_algo if args.fanin_algo != "auto" else "reduce_scatter"
     fanin_probe = None
     if world > 1 and args.fanin_algo == "auto":
@@ -222,6 +288,7 @@ def main():
         probe_src = torch.zeros((frames_per_chunk, NFFT), dtype=torch.float32, device="cuda")
         fanin_probe = {}
         for algo in ("reduce_scatter", "all_to_all"):
+            wd.enter(f"fan-in probe: {algo} ({'gr4hip_fanin_*' if comm is not None else 'torch.distributed'})", retryable=comm is not None)
             try:
                 fanin.fan_in_sum(probe_src, rs_out[0], algo=algo, recv=recv, comm=comm)
                 torch.cuda.synchronize()
@@ -236,11 +303,24 @@ def main():
                 t = torch.tensor([float("inf")], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fanin_probe[algo] = float(t.item())
+            wd.leave()
         fanin_algo = min(fanin_probe, key=fanin_probe.get)  # the same numbers on every rank: the same choice
+        rank_log["probe_choice"] = fanin_algo
         del probe_src
+    elif world > 1:
+        wd.enter(f"first fan-in: {fanin_algo}", retryable=comm is not None)
+        fanin.fan_in_sum(torch.zeros((frames_per_chunk, NFFT), dtype=torch.float32, device="cuda"), rs_out[0], algo=fanin_algo, recv=recv, comm=comm)
+        torch.cuda.synchronize()
+        wd.leave()
 
     def step(record: bool):
         # (no reset between steps: the stream simply continues, the FIR history of a step's first frame is the previous step's tail)
+        if record:
+            for c in range(nchunks):
+                ev[c] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev_all.extend(ev)
+            step_ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            step_ev[-1][0].record()
         if len(mine) > 1 and not multi:  # a channel stream must not overwrite a slice the previous step's fold still reads
             for s in streams:
                 s.wait_stream(main_stream)
@@ -291,22 +371,48 @@ def main():
         if len(mine) > 1 and not multi:
             for s in streams:
                 main_stream.wait_stream(s)
+        if record:
+            step_ev[-1][1].record()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed, uncounted launches until the clocks have settled under this load (then the counted warm-up, then the timed steps)
+    wd.enter("pre-warm + warm-up steps", seconds=max(args.fanin_timeout, 1.0) * 2)
+    prewarm_steps, t_pre = 0, time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        step(False)
+        torch.cuda.synchronize()
+        prewarm_steps += 1
+        if world > 1:  # every rank runs the same number of steps: the slowest rank's clock decides
+            more = torch.tensor([1 if (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(more, op=dist.ReduceOp.MAX)
+            if int(more.item()) == 0:
+                break
+    prewarm_ms = (time.perf_counter() - t_pre) * 1e3
     for _ in range(args.warmup):
         step(False)
     fence()
+    wd.enter("timed steps", seconds=max(args.fanin_timeout, 1.0) * 2 + 0.05 * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
         # event times are read after the timed region
     fence()
     dt = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b_) for a, b_ in ev]  # last step's launches of this rank's first channel (all steps are identical work)
+    wd.leave()
+    kernel_ms = [a.elapsed_time(b_) for a, b_ in ev_all]  # every timed launch of this rank's first channel
+    step_ms = sorted(a.elapsed_time(b_) for a, b_ in step_ev)
+    median_step_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    if world > 1:  # per-rank view of the timed region, for the record of a first run nobody watches
+        rank_log.update({"launch_ms_mean": round(sum(kernel_ms) / len(kernel_ms), 4), "step_ms_median": round(median_step_ms, 4), "wall_s": round(dt, 4)})
+        print(f"[bench] rank {rank}: {json.dumps(rank_log)}", file=sys.stderr, flush=True)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_log)
+    else:
+        gathered = None
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -365,7 +471,9 @@ def main():
         res = {
             "metric": "Msamples/s through 256-tap cplx FIR->8192-pt FFT chain; %HBM roofline @1/2/4/8 GPU",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if combine else "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "median_ms_per_step": round(median_step_ms, 4),
+            "value_at_median_step": round(float(n) * n_channels / (median_step_ms * 1e-3) / 1e6, 3),  # the median over the timed steps (HIP events on the launch stream)
+            "prewarm_ms": round(prewarm_ms, 1), "prewarm_steps": prewarm_steps, "higher_is_better": True, "scaling": "strong" if combine else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, 2^{args.log2_samples}-sample stream per channel "
                                    f"(BASELINE.json configs[{4 if combine else 1}]), rectangular window, {nchunks} launch(es) of 2^{log2_chunk} samples per channel" + graph,
@@ -375,7 +483,8 @@ def main():
                                                "deferred", "off"][args.guard_mode]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None, "traffic_from_committed_profile": committed, "kernel": KERNEL_SYMBOLS.get(algo, str(algo)),
-                         "algorithmic_bytes_per_launch": chunk * ALGO_BYTES_PER_SAMPLE, "avg_launch_ms": round(launch_ms, 4),
+                         "algorithmic_bytes_per_launch": chunk * ALGO_BYTES_PER_SAMPLE, "avg_launch_ms": round(launch_ms, 4), "timed_launches": len(kernel_ms),
+                         "median_launch_ms": round(sorted(kernel_ms)[len(kernel_ms) // 2], 4),
                          "frac_of_measured_copy_rate": round(achieved / 6290.0, 4),  # 6.29 TB/s: what a float4 copy reaches on this part (MI355X_MICROARCH.md)
                          "whole_job_frac_per_gpu": round(value * 1e6 * ALGO_BYTES_PER_SAMPLE / world / 1e9 / HBM_PEAK_GBS, 4)},
         }
@@ -387,11 +496,54 @@ def main():
                             "probe_seconds_per_launch": ({k: (None if v == float("inf") else round(v, 6)) for k, v in fanin_probe.items()} if fanin_probe else None),
                             "xgmi_egress_bytes_per_input_sample": round(egress, 4),
                             "xgmi_ceiling_msamples": round(world * (world - 1) * XGMI_LINK_GBS * 1e9 / egress / 1e6, 1),
-                            "note": "ceiling = N GPUs x (N-1) links x 153 GB/s nominal per direction / egress bytes per input sample; the collective of launch c overlaps the transforms of launch c+1"}
+                            "note": "ceiling = N GPUs x (N-1) links x 153 GB/s nominal per direction / egress bytes per input sample; the collective of launch c overlaps the transforms of launch c+1",
+                            "implementation": "gr4hip_fanin_* (the library's own RCCL communicator)" if comm is not None else ("torch.distributed (" + args.dist_backend + ")"),
+                            "retried_after_watchdog": os.environ.get("GR4HIP_BENCH_RETRY") == "1", "per_rank": gathered}
         if verify:
             res["verify"] = verify
             if not (verify["max_rel_err"] <= PARITY_TOL):
                 rc = 3
+        if world == 1 and not combine and not args.no_hann_row:
+            # "rectangular for the headline run and Hann as a second row" -- the FFT block's default window (blocks/fourier/.../fft.hpp:99); same
+            # stream, same taps, same launch size; three transforms per frame instead of two (DESIGN.md 3.1 "Any window")
+            try:
+                hann = G.Chain(taps, NFFT, "Hann", 0)
+                if args.guard_mode:
+                    hann.set_guard_mode(args.guard_mode)
+                hout = outs[0]
+                hsteps = max(3, min(args.steps, 12))
+                for _ in range(2):
+                    for c in range(nchunks):
+                        hann.process_bulk(xs[0][c * chunk:(c + 1) * chunk], hout[c * frames_per_chunk:(c + 1) * frames_per_chunk])
+                torch.cuda.synchronize()
+                hev = []
+                for _ in range(hsteps):
+                    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a_.record()
+                    for c in range(nchunks):
+                        hann.process_bulk(xs[0][c * chunk:(c + 1) * chunk], hout[c * frames_per_chunk:(c + 1) * frames_per_chunk])
+                    b_.record()
+                    hev.append((a_, b_))
+                torch.cuda.synchronize()
+                hms = sorted(a_.elapsed_time(b_) for a_, b_ in hev)
+                hmed = hms[len(hms) // 2]
+                row = {"window": "Hann", "value": round(n / (hmed * 1e-3) / 1e6, 3), "unit": "Msamples/s", "median_ms_per_step": round(hmed, 4), "steps": hsteps,
+                       "frac": round(n * ALGO_BYTES_PER_SAMPLE / (hmed * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                if not args.no_verify:
+                    O = _oracle()
+                    herr = []
+                    for f in (1, 255, n // NFFT - 1):
+                        prev = xs[0][(f - 1) * NFFT:f * NFFT].cpu().numpy()
+                        cur = xs[0][f * NFFT:(f + 1) * NFFT].cpu().numpy()
+                        truth = O.chain(taps, np.concatenate([prev, cur]), NFFT, 3, truth=True)[0].reshape(-1, NFFT)[1]
+                        herr.append(_rel_err(hout[f].cpu().numpy(), truth))
+                    row["verify_max_rel_err"] = float(f"{max(herr):.3e}")
+                    if not (max(herr) <= PARITY_TOL):
+                        rc = 3
+                res["hann_second_row"] = row
+                del hann
+            except Exception as e:  # never at the price of the headline line
+                res["hann_second_row"] = {"error": str(e)[:200]}
         if world == 1 and not combine and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not combine and not args.no_graph8 and os.environ.get("GR4HIP_BENCH_CHILD") != "1":

@@ -229,7 +229,9 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
         shared     = shared && c->taps == c0->taps;
         any_guard  = any_guard || c->guard;
     }
-    const bool fold = d_sum && !d_mag2 && shared && n_chains > 1; // the combiner in registers; otherwise per-chain spectra (+ the n-ary Add below)
+    // the combiner in registers; otherwise per-chain spectra (+ the n-ary Add below).  The fold measures all channels together into chain 0's slots: with a guard on
+    // some chain but not on chain 0 nothing would be measured at all, so such a mix keeps its per-chain spectra (every guarded chain then measures itself)
+    const bool fold = d_sum && !d_mag2 && shared && n_chains > 1 && (!any_guard || c0->guard);
     // per-chain spectra nobody asked for but the fold needs: scratch on handles[0]
     std::vector<float*> outs(n_chains, nullptr);
     if (!fold) {
@@ -260,7 +262,18 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
     std::vector<gr4::ChainFused*> fs(n_chains);
     std::vector<const float*>     xs(n_chains);
     for (size_t i = 0; i < n_chains; ++i) { fs[i] = chains[i]->fused; xs[i] = static_cast<const float*>(d_in[i]); }
-    const bool strict = any_guard && c0->guard_mode == GR4HIP_GUARD_STRICT;
+    bool strict = false; // the most conservative mode among the guarded chains decides for the launch they share
+    for (size_t i = 0; i < n_chains; ++i) strict = strict || (chains[i]->guard && chains[i]->guard_mode == GR4HIP_GUARD_STRICT);
+    // a span the guard rejects is redone from the histories the call started with: guarded chains move to the time domain, the others (GUARD_OFF, explicit
+    // FUSED_FD: "never switches") stay on the fused kernel -- whose history the rejected launch has already advanced, so it is put back first
+    const auto prepare_redo = [&]() -> int {
+        for (size_t i = 0; i < n_chains; ++i) {
+            gr4hip_chain* c = chains[i];
+            if (c->guard) { if (const int rc = chain_switch_to_time_domain(c, static_cast<const float*>(c->d_hist_save.ptr), st)) return rc; }
+            else if (const int rc = chain_fused_set_history(c->fused, static_cast<const float*>(c->d_hist_save.ptr), st)) return rc;
+        }
+        return GR4HIP_OK;
+    };
     if (any_guard) { // the histories the call starts with (a span the guard rejects is redone from them)
         for (size_t i = 0; i < n_chains; ++i) {
             gr4hip_chain* c = chains[i];
@@ -276,11 +289,8 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
                 if (chain_fused_power_ratio(c->fused, false, false, &r)) c->last_ratio = r;
                 bad = bad || (chains[i]->guard && c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio);
             }
-            if (bad) {
-                for (size_t i = 0; i < n_chains; ++i) {
-                    int rc = chain_switch_to_time_domain(chains[i], static_cast<const float*>(chains[i]->d_hist_save.ptr), st);
-                    if (rc) return rc;
-                }
+            if (bad) { // (nothing launched yet in this call: the saved histories are the current ones, the copy back is a no-op)
+                if (const int rc = prepare_redo()) return rc;
                 return chain_by_chain();
             }
         }
@@ -298,10 +308,7 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
             bad = bad || (chains[i]->guard && c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio);
         }
         if (bad) {
-            for (size_t i = 0; i < n_chains; ++i) {
-                rc = chain_switch_to_time_domain(chains[i], static_cast<const float*>(chains[i]->d_hist_save.ptr), st);
-                if (rc) return rc;
-            }
+            if ((rc = prepare_redo())) return rc;
             return chain_by_chain();
         }
     }

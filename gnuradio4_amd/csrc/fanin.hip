@@ -50,7 +50,11 @@ static RcclApi& rccl() {
             if (api.lib) break;
             api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
-        if (!api.lib) { api.why = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + "); set GR4HIP_RCCL_LIBRARY"; return; }
+        if (!api.lib) {
+            const char* e = dlerror(); // (once: the call clears the error it returns)
+            api.why = std::string("librccl not found (") + (e ? e : "?") + "); set GR4HIP_RCCL_LIBRARY";
+            return;
+        }
         auto get = [&](const char* sym, auto& fn) {
             fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.lib, sym));
             if (!fn && api.why.empty()) api.why = std::string("librccl lacks ") + sym;

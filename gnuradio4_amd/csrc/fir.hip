@@ -686,14 +686,14 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         // the INPUT rms per output sample, six times below the fused chain's -- so 1e-5 of the OUTPUT rms holds down to a power ratio of (4e-7 / 1e-5)^2 = 1.6e-3; 2.5e-3
         // (-26 dB) with margin.  White noise through a DC-gain-1 low-pass of cut-off fc passes 2 fc of its power: every anti-alias filter down to fc = 0.00125 stays here.
         constexpr float kDecimFdMinPowerRatio = 2.5e-3f;
-        if (guarded && f->guard_mode == GR4HIP_GUARD_DEFERRED && f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) f->fd_blocked = true;
+        if (guarded && f->guard_mode == GR4HIP_GUARD_DEFERRED && f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) f->fd_blocked = f->f32_products = true;
         if (!f->fd_blocked) {
             rc = fir_decim_fd_run(f->dfd, x, n_in, hist, (int)f->hcap, y, st, guarded);
             if (rc) return rc;
             done = n_in;
             if (guarded && f->guard_mode == GR4HIP_GUARD_STRICT) {
                 if (fir_decim_fd_power_ratio(f->dfd, true, &ratio)) f->fd_ratio = ratio;
-                if (f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) { f->fd_blocked = true; done = 0; }
+                if (f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) { f->fd_blocked = f->f32_products = true; done = 0; } // (float32 products from here on, like the complex path: the call that trips the guard and the calls after it run the same kernels)
             }
         }
     }

@@ -669,7 +669,7 @@ void fir_bf16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::
 int fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay,
                     int accum) {
     const auto af = static_cast<const u32x4_b*>(afrag);
-    if (KS >= kBfSharedMinKS && 32 * KS - 16 + delay <= kBfSeg) { // the wide windows: shared fragment stream, double-buffered planes (fir_mfma_bf16x3_shared_kernel)
+    if ((KS == 8 || KS == 9) && KS >= kBfSharedMinKS && 32 * KS - 16 + delay <= kBfSeg) { // the wide windows: shared fragment stream, double-buffered planes (fir_mfma_bf16x3_shared_kernel)
         const long nseg = ceil_div(n, (long)kBfSeg);
         const int  spw  = (int)std::min<long>(std::max<long>(nseg * (long)nch / GR4_BF16_TARGET_WGS, 1), GR4_BF16_MAX_SPW); // segments per workgroup: the prologue (tap fragments, first staging) once per run
         const dim3 grid((unsigned)ceil_div(nseg, (long)spw), nch);

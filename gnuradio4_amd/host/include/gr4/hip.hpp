@@ -1949,12 +1949,19 @@ public:
             if (_branches.empty()) { avail = 0; all_done = true; }
             std::size_t frames = std::min(avail / _N, _shard.frames_per_exchange);
             if (frames < _shard.frames_per_exchange && !all_done) return {requested, 0, work::Status::INSUFFICIENT_INPUT_ITEMS}; // every rank exchanges the same frame counts
+            if (_shard.scatter && frames % static_cast<std::size_t>(_shard.n_ranks)) { // the stream's last exchange: reduce_scatter hands out whole frames, the same count to every rank
+                const std::size_t left = frames % static_cast<std::size_t>(_shard.n_ranks);
+                frames -= left;
+                if (frames == 0) { // fewer frames than ranks are left: they cannot be shared out -- dropped, said once, and the stream ends DONE (not ERROR)
+                    std::cerr << "[gr::hip] fan-in (reduce_scatter over " << _shard.n_ranks << " ranks): the last " << left << " frame(s) of the stream are not a whole share per rank and are dropped\n";
+                    for (auto& b : _branches) b.in->consume_items(std::min(b.in->available_items(), left * _N));
+                }
+            }
             if (frames == 0) {
                 if (all_done) { _out->producer_done = true; return {requested, 0, work::Status::DONE}; }
                 return {requested, 0, work::Status::INSUFFICIENT_INPUT_ITEMS};
             }
             const std::size_t n_out = _shard.scatter ? frames / static_cast<std::size_t>(_shard.n_ranks) * _N : frames * _N;
-            if (_shard.scatter && frames % static_cast<std::size_t>(_shard.n_ranks)) throw std::runtime_error("reduce_scatter fan-in: the exchange's frame count is not a multiple of the rank count");
             if (_out->free_items() < n_out) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
             const std::size_t n = frames * _N;
             // the exchange's tag: every tag on the exchange's samples of every LOCAL branch merged ("gr:" keys; identical tags on several branches collapse, like

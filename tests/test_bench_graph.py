@@ -65,3 +65,28 @@ def test_bench_two_ranks_share_the_gpu_gloo_fanin(algo):
         assert r["fanin"]["collective"].startswith(algo)
     v = r["verify"]  # rank 0's shard of the 8-channel sum vs the oracle's sum of the eight channels' spectra
     assert v["verified_frames"] >= 3 and v["max_rel_err"] <= 1e-5
+
+
+def test_bench_stalled_rank_gives_a_diagnostic_not_a_hang():
+    """a rank that never reaches its first collective (injected: GR4HIP_BENCH_STALL_RANK) must not hang the run: every waiting phase has a wall-clock deadline,
+    the ranks say where they are, rank 0 prints the JSON line with an "error" key, and the launcher exits non-zero -- well inside a minute"""
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GR4HIP_BENCH_STALL_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--log2-samples", "24", "--steps", "2", "--warmup", "1", "--fanin-timeout", "12"]
+    t0 = time.time()
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    took = time.time() - t0
+    assert p.returncode != 0, p.stdout[-2000:]
+    assert took < 60, took
+    assert "[bench][watchdog] rank 0 of 2: no progress in phase" in p.stderr, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["error"].startswith("rank 0 of 2: no progress in phase"), p.stdout[-2000:]
+
+
+def test_bench_line_has_the_median_the_prewarm_and_the_hann_row():
+    r = _run([sys.executable, "bench.py", "--steps", "5", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline", "--no-graph8"])
+    assert r["prewarm_ms"] >= 40 and r["prewarm_steps"] >= 1 and r["median_ms_per_step"] > 0 and r["value_at_median_step"] > 0
+    assert r["roofline"]["timed_launches"] == 5 * 4
+    h = r["hann_second_row"]
+    assert h["window"] == "Hann" and h["value"] > 0 and 0 < h["frac"] < 1 and h["verify_max_rel_err"] <= 1e-5

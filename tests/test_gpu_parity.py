@@ -1471,6 +1471,35 @@ def test_chain_process_multi_guard(G):
                 assert _rel(o2[c].cpu().numpy().ravel(), truths[c][1]) <= TOL, c
 
 
+def test_chain_process_multi_mixed_guard_modes(G):
+    """a multi launch over chains with DIFFERENT guard modes: a GUARD_OFF chain is never moved to the time domain (and its history is put back before the rejected
+    span is redone), a GUARD_OFF chain 0 does not switch the others' guard off (the in-register fold would measure into chain 0 only), and one STRICT chain makes
+    the launch strict"""
+    from gnuradio4_amd.blocks import chain_process_multi
+    N, ntaps, nch = 8192, 64, 3
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    clean = [O.signal_c32(25 + c, 24 * N, tone_frel=0.01, tone_amp=1.0) for c in range(nch)]
+    loud = O.signal_c32(36, 24 * N, tone_frel=0.31, tone_amp=30.0)
+    second = [clean[0], loud, clean[2]]
+    truths = [O.chain(b, np.concatenate([clean[c], second[c]]), N, 0, truth=True)[0].reshape(2, -1) for c in range(nch)]
+    for fold in (False, True):
+        chains = [G.Chain(b, N, "None") for _ in range(nch)]
+        chains[0].set_guard_mode(G.capi.GUARD_OFF)
+        chains[2].set_guard_mode(G.capi.GUARD_DEFERRED)
+        o1, s1 = chain_process_multi(chains, [dev(x) for x in clean], want_outs=not fold, sum_out=torch.empty((24, N), dtype=torch.float32, device="cuda"))
+        o2, s2 = chain_process_multi(chains, [dev(x) for x in second], want_outs=not fold, sum_out=torch.empty((24, N), dtype=torch.float32, device="cuda"))
+        assert chains[1].last_power_ratio()[1], fold          # the strict chain saw its interferer in this very call ...
+        assert not chains[0].last_power_ratio()[1], fold      # ... and the unguarded chain stays on the fused kernel
+        assert chains[0].algo == G.capi.CHAIN_FUSED_FD
+        assert _rel(s1.cpu().numpy().ravel(), sum(t[0] for t in truths)) <= TOL
+        assert _rel(s2.cpu().numpy().ravel(), sum(t[1] for t in truths)) <= TOL, fold
+        # the unguarded chain's history survived the redo: a third call continues its stream
+        third = O.signal_c32(47, 8 * N, tone_frel=0.01)
+        t3 = O.chain(b, np.concatenate([clean[0], second[0], third]), N, 0, truth=True)[0].reshape(-1, N)[48:]
+        got = chains[0].process_bulk(dev(third)).cpu().numpy()
+        assert _rel(got.ravel(), t3.ravel()) <= TOL, fold
+
+
 def test_chain_random_configurations(G):
     """seeded random draws over the chain's parameter space (fftSize, tap count, window, frame counts per call): every one against the float64 oracle"""
     rng = np.random.default_rng(2024)
