@@ -179,6 +179,20 @@ class iir_filter(_Handle):
     def reset(self):
         check((lib().gr4hip_iir64_reset if self._f64 else lib().gr4hip_iir_reset)(self._h), "iir_filter.reset")
 
+    def set_algo(self, algo: int):
+        """capi.IIR_AUTO (default: the parallel-in-time kernels unless the create-time self-test finds that float32 cannot carry this cascade's state through them),
+        capi.IIR_PARALLEL or capi.IIR_SEQUENTIAL_F32 (the reference's arithmetic in the requested form, one lane, sample by sample) -- include/gr4hip.h"""
+        if self._f64:
+            raise capi.Gr4HipError(capi.UNSUPPORTED, "iir_filter", "the float64 cascade has one evaluation")
+        check(lib().gr4hip_iir_set_algo(self._h, int(algo)), "iir_filter.set_algo")
+
+    @property
+    def algo_in_use(self):
+        """(evaluation in use, create-time error of the parallel kernels, of the sequential float32 form) -- errors as max |error| / output rms, < 0: not measured"""
+        a, ep, es = C.c_int(0), C.c_float(0), C.c_float(0)
+        check(lib().gr4hip_iir_get_algo(self._h, C.byref(a), C.byref(ep), C.byref(es)), "iir_filter.get_algo")
+        return a.value, ep.value, es.value
+
     def status(self):
         """synchronise the current stream and raise if an earlier launch of this handle reported a look-back time-out (include/gr4hip.h)"""
         if not self._f64:

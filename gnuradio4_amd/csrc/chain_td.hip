@@ -32,6 +32,9 @@ void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vect
 int  make_window(int window, float* w, size_t n, float beta);                                                               // runtime.hip
 
 using td_f32x4 = __attribute__((ext_vector_type(4))) float;
+#ifndef GR4_TD_EIGHT_TERMS
+#define GR4_TD_EIGHT_TERMS 1
+#endif
 using td_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using td_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using td_f32x2  = __attribute__((ext_vector_type(2))) float;
@@ -168,6 +171,11 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
                     d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
                     d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
+#if GR4_TD_EIGHT_TERMS // + ml, lm: the products are then exact to ~2^-31 -- below a float32 product's own 2^-25.  This chain has no dynamic-range guard (AUTO takes it for
+                    //   <= 64 taps): under a rejected interferer 50 dB above the output the six-term form measured 3 x the float32 CPU sum's error (profiles/r03_fuzz_summary.txt)
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bl, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bm, d, 0, 0, 0);
+#endif
                 };
                 six(q0, cr0, dr0);
                 six(q0 + 3 * PL, ci0, di0);

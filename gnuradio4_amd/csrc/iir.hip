@@ -784,6 +784,98 @@ __global__ __launch_bounds__(kIirBS, 4) void iir_seq_kernel(IirSeqArgs a, IirCoe
     }
 }
 
+// ------------------------------------------------------------------------------------------------ sequential float32 kernel (GR4HIP_IIR_SEQUENTIAL_F32)
+// The reference's own arithmetic, form by form (detail::computeFilter, FilterTool.hpp:116-158): one lane walks the cascade sample by sample with the section's
+// input / output histories in registers, float32 operations in source order (no fused multiply-adds) -- slow (one dependent chain), and exactly as close to
+// float64 as the block on the host.  For cascades whose state the parallel-in-time evaluation cannot carry in float32 (ill-conditioned narrow-band designs of
+// high order: profiles/r03_fuzz_summary.txt) and for callers who chose a form for its noise behaviour.
+constexpr int kIirSeqMaxSec = 8, kIirSeqMaxOrd = 4, kIirSeqChunk = 4096;
+struct IirSeqF32Coef {
+    float b[kIirSeqMaxSec][kIirSeqMaxOrd + 1], a[kIirSeqMaxSec][kIirSeqMaxOrd + 1]; // zero padded
+    int   nsec, nb, na, form;                                                        // nb / na: coefficient counts per section (na == 1: no feedback)
+};
+// one section, one sample; ih / oh: input / output history, newest first (what push_front + cbegin() give upstream)
+template <typename T>
+__host__ __device__ inline T iir_form_step(int form, const float* b, const float* a, int nb, int na, T (&ih)[kIirSeqMaxOrd + 1], T (&oh)[kIirSeqMaxOrd + 1], T x) {
+#pragma clang fp contract(off)
+    const auto push = [](T (&h)[kIirSeqMaxOrd + 1], T v) {
+#pragma unroll
+        for (int j = kIirSeqMaxOrd; j > 0; --j) h[j] = h[j - 1];
+        h[0] = v;
+    };
+    const auto dot = [](const float* c, int first, int count, const T (&h)[kIirSeqMaxOrd + 1]) { // sum_{k = first}^{count - 1} c[k] h[k - first]
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k <= kIirSeqMaxOrd; ++k)
+            if (k >= first && k < count) acc = acc + (T)c[k] * h[k - first];
+        return acc;
+    };
+    if (form == GR4HIP_DF_I) {
+        push(ih, x);
+        const T o = dot(b, 0, nb, ih) - dot(a, 1, na, oh);
+        push(oh, o);
+        return o;
+    }
+    if (form == GR4HIP_DF_II) {
+        if (na > 1) {
+            const T w = x - dot(a, 1, na, ih);
+            push(ih, w);
+        } else {
+            push(ih, x);
+        }
+        return dot(b, 0, nb, ih);
+    }
+    if (form == GR4HIP_DF_I_TRANSPOSED) {
+        const T v0 = x - dot(a, 1, na, oh);
+        push(oh, v0);
+        return dot(b, 0, nb, oh);
+    }
+    const T o = (T)b[0] * x + dot(b, 1, nb, ih) - dot(a, 1, na, oh); // DF_II_TRANSPOSED as the reference writes it
+    push(ih, x);
+    push(oh, o);
+    return o;
+}
+
+__global__ __launch_bounds__(64) void iir_sequential_kernel(const float* __restrict__ x, float* __restrict__ y, long n, IirSeqF32Coef c, float* __restrict__ state /*[nsec][2][kIirSeqMaxOrd + 1]*/) {
+    __shared__ float buf[kIirSeqChunk];
+    const int lane = threadIdx.x;
+    float     ih[kIirSeqMaxSec][kIirSeqMaxOrd + 1], oh[kIirSeqMaxSec][kIirSeqMaxOrd + 1];
+#pragma unroll
+    for (int s = 0; s < kIirSeqMaxSec; ++s)
+#pragma unroll
+        for (int j = 0; j <= kIirSeqMaxOrd; ++j) {
+            ih[s][j] = (lane == 0 && s < c.nsec) ? state[(s * 2 + 0) * (kIirSeqMaxOrd + 1) + j] : 0.f;
+            oh[s][j] = (lane == 0 && s < c.nsec) ? state[(s * 2 + 1) * (kIirSeqMaxOrd + 1) + j] : 0.f;
+        }
+    for (long base = 0; base < n; base += kIirSeqChunk) {
+        const int cnt = (int)(n - base < kIirSeqChunk ? n - base : kIirSeqChunk);
+        for (int i = lane; i < cnt; i += 64) buf[i] = x[base + i];
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = 0; i < cnt; ++i) {
+                float v = buf[i];
+#pragma unroll
+                for (int s = 0; s < kIirSeqMaxSec; ++s)
+                    if (s < c.nsec) v = iir_form_step<float>(c.form, c.b[s], c.a[s], c.nb, c.na, ih[s], oh[s], v);
+                buf[i] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < cnt; i += 64) y[base + i] = buf[i];
+        __syncthreads();
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < kIirSeqMaxSec; ++s)
+#pragma unroll
+            for (int j = 0; j <= kIirSeqMaxOrd; ++j)
+                if (s < c.nsec) {
+                    state[(s * 2 + 0) * (kIirSeqMaxOrd + 1) + j] = ih[s][j];
+                    state[(s * 2 + 1) * (kIirSeqMaxOrd + 1) + j] = oh[s][j];
+                }
+    }
+}
+
 } // namespace gr4
 
 using namespace gr4;
@@ -805,6 +897,12 @@ struct gr4hip_iir {
     // as one 16-state scan 69 Gsamples/s, as 4 + 4 biquads 230)
     gr4hip_iir*         part[2] = {nullptr, nullptr};
     DeviceBuffer        d_mid;
+    // the cascade as given (top-level handle): what GR4HIP_IIR_SEQUENTIAL_F32 walks, and what the create-time self-test of GR4HIP_IIR_AUTO compares against
+    IirSeqF32Coef       seq{};
+    DeviceBuffer        d_seq_state;
+    int                 algo = GR4HIP_IIR_AUTO, algo_in_use = GR4HIP_IIR_PARALLEL;
+    float               selftest_parallel = -1.f, selftest_f32 = -1.f; // create-time errors (max |.| / output rms against float64) of the parallel kernels and of the sequential float32 form
+    bool                top = true;
     ~gr4hip_iir() {
         if (h_err) (void)hipHostFree(h_err);
         delete part[0];
@@ -965,7 +1063,33 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
 
 extern "C" {
 
+static int iir_create_impl(gr4hip_iir_t** out, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na, bool top);
+static int iir_selftest(gr4hip_iir* f);
+static int iir_process_parallel(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream);
+
 int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na) {
+    return iir_create_impl(out, form, nsections, h_b, nb, h_a, na, true);
+}
+
+// the top-level handle keeps the cascade as given (for the sequential float32 kernel and the create-time self-test)
+static int iir_finish_top(gr4hip_iir* f, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na) {
+    f->top      = true;
+    f->seq      = IirSeqF32Coef{};
+    f->seq.nsec = (int)nsections;
+    f->seq.nb   = (int)nb;
+    f->seq.na   = (int)na;
+    f->seq.form = form;
+    for (size_t s = 0; s < nsections; ++s) {
+        for (size_t j = 0; j < nb; ++j) f->seq.b[s][j] = h_b[s * nb + j];
+        for (size_t j = 0; j < na; ++j) f->seq.a[s][j] = h_a[s * na + j];
+    }
+    int rc = f->d_seq_state.ensure((size_t)kIirSeqMaxSec * 2 * (kIirSeqMaxOrd + 1) * sizeof(float));
+    if (rc) return rc;
+    GR4_HIP_TRY(hipMemset(f->d_seq_state.ptr, 0, f->d_seq_state.bytes));
+    return iir_selftest(f);
+}
+
+static int iir_create_impl(gr4hip_iir_t** out, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na, bool top) {
     GR4_REQUIRE(out, "iir: null output handle");
     GR4_REQUIRE(form >= GR4HIP_DF_I && form <= GR4HIP_DF_II_TRANSPOSED, "iir: unknown form %d", form);
     GR4_REQUIRE(nsections >= 1 && h_b && h_a && nb >= 1 && na >= 1, "iir: need >= 1 section and non-empty b, a");
@@ -981,8 +1105,10 @@ int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const floa
     f->ord  = ord;
     if (nsections * ord > 8 && !dev_switch(kDevIirNoSplit)) { // two cascades of <= 8 state values (GR4HIP_IIR_NO_SPLIT: the 16-state kernels, which the tests compare)
         const size_t k = 8 / ord;
-        int rc = gr4hip_iir_create(&f->part[0], form, k, h_b, nb, h_a, na);
-        if (!rc) rc = gr4hip_iir_create(&f->part[1], form, nsections - k, h_b + k * nb, nb, h_a + k * na, na);
+        int rc = iir_create_impl(&f->part[0], form, k, h_b, nb, h_a, na, false);
+        if (!rc) rc = iir_create_impl(&f->part[1], form, nsections - k, h_b + k * nb, nb, h_a + k * na, na, false);
+        f->top = top;
+        if (!rc && top) rc = iir_finish_top(f, form, nsections, h_b, nb, h_a, na);
         if (rc) { delete f; return rc; }
         *out = f;
         return GR4HIP_OK;
@@ -1048,9 +1174,58 @@ int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const floa
         if (!rc) { hipError_t e = hipMemcpy(f->d_tab.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     }
     if (rc) { delete f; return rc; }
+    f->top = false; // (reset below must not touch the sequential state before it exists)
     rc = gr4hip_iir_reset(f);
+    if (!rc && top) rc = iir_finish_top(f, form, nsections, h_b, nb, h_a, na);
     if (rc) { delete f; return rc; }
+    f->top = top;
     *out = f;
+    return GR4HIP_OK;
+}
+
+// GR4HIP_IIR_AUTO: is float32 enough to carry this cascade's state through the parallel-in-time kernels?  Measured, not predicted: a three-tile noise vector through
+// the kernels this handle would use, against the same cascade in float64 and in the reference's sequential float32 arithmetic (requested form) on the host.  More
+// than 1e-5 of the output rms AND more than ten times the sequential float32 error: the handle runs GR4HIP_IIR_SEQUENTIAL_F32 instead.
+static int iir_selftest(gr4hip_iir* f) {
+    f->algo_in_use = GR4HIP_IIR_PARALLEL;
+    if (f->algo == GR4HIP_IIR_SEQUENTIAL_F32) { f->algo_in_use = GR4HIP_IIR_SEQUENTIAL_F32; return GR4HIP_OK; }
+    if (f->algo == GR4HIP_IIR_PARALLEL) return GR4HIP_OK;
+    const long         n = 3L * kIirBS * kIirL + 777;
+    std::vector<float> x((size_t)n), y((size_t)n);
+    uint32_t           lcg = 12345u;
+    for (auto& v : x) { lcg = lcg * 1664525u + 1013904223u; v = (float)((int32_t)lcg) * (1.0f / 2147483648.0f); }
+    DeviceBuffer dx, dy;
+    int          rc = dx.ensure((size_t)n * sizeof(float));
+    if (!rc) rc = dy.ensure((size_t)n * sizeof(float));
+    if (rc) return rc;
+    GR4_HIP_TRY(hipMemcpy(dx.ptr, x.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    rc = iir_process_parallel(f, static_cast<const float*>(dx.ptr), (size_t)n, static_cast<float*>(dy.ptr), nullptr);
+    if (rc) return rc;
+    GR4_HIP_TRY(hipMemcpy(y.data(), dy.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    f->top = false;
+    rc     = gr4hip_iir_reset(f); // the stream starts from zero state
+    f->top = true;
+    if (rc) return rc;
+    const IirSeqF32Coef& c = f->seq;
+    double ih64[kIirSeqMaxSec][kIirSeqMaxOrd + 1] = {}, oh64[kIirSeqMaxSec][kIirSeqMaxOrd + 1] = {};
+    float  ih32[kIirSeqMaxSec][kIirSeqMaxOrd + 1] = {}, oh32[kIirSeqMaxSec][kIirSeqMaxOrd + 1] = {};
+    double e_par = 0, e_f32 = 0, pw = 0;
+    for (long i = 0; i < n; ++i) {
+        double v64 = x[(size_t)i];
+        float  v32 = x[(size_t)i];
+        for (int s = 0; s < c.nsec; ++s) {
+            v64 = iir_form_step<double>(GR4HIP_DF_II_TRANSPOSED, c.b[s], c.a[s], c.nb, c.na, ih64[s], oh64[s], v64); // (float64: any form; the transposed one carries the least state noise)
+            v32 = iir_form_step<float>(c.form, c.b[s], c.a[s], c.nb, c.na, ih32[s], oh32[s], v32);
+        }
+        pw += v64 * v64;
+        e_par = std::max(e_par, std::fabs((double)y[(size_t)i] - v64));
+        e_f32 = std::max(e_f32, std::fabs((double)v32 - v64));
+    }
+    const double rms = std::sqrt(pw / (double)n);
+    if (!(rms > 0.0) || !std::isfinite(rms)) return GR4HIP_OK; // nothing to judge (all-zero response, or an unstable filter: no arithmetic makes that one right)
+    f->selftest_parallel = (float)(e_par / rms);
+    f->selftest_f32      = (float)(e_f32 / rms);
+    if (!(e_par / rms <= 1e-5) && !(e_par <= 10.0 * e_f32)) f->algo_in_use = GR4HIP_IIR_SEQUENTIAL_F32;
     return GR4HIP_OK;
 }
 
@@ -1066,6 +1241,7 @@ static int iir_take_error(gr4hip_iir* f, const char* where) {
 
 int gr4hip_iir_reset(gr4hip_iir_t* f) {
     GR4_REQUIRE(f, "iir_reset: null handle");
+    if (f->top && f->d_seq_state.ptr) GR4_HIP_TRY(hipMemset(f->d_seq_state.ptr, 0, f->d_seq_state.bytes));
     if (f->part[0]) { int rc = gr4hip_iir_reset(f->part[0]); return rc ? rc : gr4hip_iir_reset(f->part[1]); }
     for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(f->d_state[k].ptr, 0, kIirMaxM * sizeof(float))); // (hipMemset synchronises: every earlier launch has finished)
     f->cur = 0;
@@ -1079,20 +1255,51 @@ int gr4hip_iir_status(gr4hip_iir_t* f, gr4hip_stream_t stream) {
     return iir_take_error(f, "iir_status");
 }
 
+int gr4hip_iir_set_algo(gr4hip_iir_t* f, int algo) {
+    GR4_REQUIRE(f && f->top, "iir_set_algo: null handle");
+    GR4_REQUIRE(algo >= GR4HIP_IIR_AUTO && algo <= GR4HIP_IIR_SEQUENTIAL_F32, "iir_set_algo: unknown algo %d", algo);
+    f->algo = algo;
+    // the two evaluations keep different state (DF-II delay lines of the scan / the form's input and output histories): the filter restarts from zero state
+    int rc = gr4hip_iir_reset(f);
+    if (rc) return rc;
+    return iir_selftest(f);
+}
+
+int gr4hip_iir_get_algo(const gr4hip_iir_t* f, int* algo_in_use, float* selftest_parallel, float* selftest_sequential_f32) {
+    GR4_REQUIRE(f && algo_in_use, "iir_get_algo: null argument");
+    *algo_in_use = f->algo_in_use;
+    if (selftest_parallel) *selftest_parallel = f->selftest_parallel;
+    if (selftest_sequential_f32) *selftest_sequential_f32 = f->selftest_f32;
+    return GR4HIP_OK;
+}
+
 int gr4hip_iir_process(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream) {
     GR4_REQUIRE(f, "iir_process: null handle");
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "iir_process: null device pointer");
+    if (f->top && f->algo_in_use == GR4HIP_IIR_SEQUENTIAL_F32) {
+        hipLaunchKernelGGL(iir_sequential_kernel, dim3(1), dim3(64), 0, as_stream(stream), d_in, d_out, (long)n, f->seq, static_cast<float*>(f->d_seq_state.ptr));
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
+    return iir_process_parallel(f, d_in, n, d_out, stream);
+}
+
+} // extern "C"
+
+static int iir_process_parallel(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream) {
     if (f->part[0]) {
         int rc = f->d_mid.ensure(n * sizeof(float));
-        if (!rc) rc = gr4hip_iir_process(f->part[0], d_in, n, static_cast<float*>(f->d_mid.ptr), stream);
-        return rc ? rc : gr4hip_iir_process(f->part[1], static_cast<const float*>(f->d_mid.ptr), n, d_out, stream);
+        if (!rc) rc = iir_process_parallel(f->part[0], d_in, n, static_cast<float*>(f->d_mid.ptr), stream);
+        return rc ? rc : iir_process_parallel(f->part[1], static_cast<const float*>(f->d_mid.ptr), n, d_out, stream);
     }
     hipStream_t st = as_stream(stream);
     const long  ln = (long)n;
     if (f->ord == 2) return f->nsec == 2 ? iir_run<2, 2>(f, d_in, d_out, ln, st) : f->nsec == 4 ? iir_run<2, 4>(f, d_in, d_out, ln, st) : iir_run<2, 8>(f, d_in, d_out, ln, st);
     return f->nsec == 1 ? iir_run<4, 1>(f, d_in, d_out, ln, st) : f->nsec == 2 ? iir_run<4, 2>(f, d_in, d_out, ln, st) : iir_run<4, 4>(f, d_in, d_out, ln, st);
 }
+
+extern "C" {
 
 int gr4hip_iir_destroy(gr4hip_iir_t* f) { delete f; return GR4HIP_OK; }
 

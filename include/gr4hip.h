@@ -18,6 +18,14 @@
  *   - state that the reference keeps in block members (HistoryBuffer, _accumulated_phase, twiddles, windows)
  *     lives in opaque handles created/destroyed by *_create / *_destroy.
  *   - one handle is driven by one thread at a time (Scheduler.hpp:1938-1951: job lists are disjoint).
+ *   - PARITY CONTRACT (stated here once; tests/test_gpu_parity.py::_rel is this formula and every float test uses it): integer, byte and copy results are
+ *     bit-exact.  A float32 result y against the float64 evaluation t of the same blocks on the same input satisfies
+ *         max_k |y_k - t_k| / max(|t_k|, rms(t)) <= 1e-5
+ *     -- the relative error of every value above the rms level of the OUTPUT, the rms-normalised absolute error of every value below it (point-wise relative
+ *     error is meaningless at spectral zeros; an all-rms normalisation would ask for better than float32 epsilon on the dominant bin of a quadratic output).
+ *     Where the reference's own float32 arithmetic cannot meet that bound (a rejected signal far above the output, an ill-conditioned IIR cascade), the bound is
+ *     the reference's float32 error on the same input, and the entry points below say which mechanism keeps the device there (dynamic-range guard, eight-term
+ *     products, GR4HIP_IIR_SEQUENTIAL_F32).
  */
 #ifndef GR4HIP_H
 #define GR4HIP_H
@@ -203,6 +211,19 @@ int gr4hip_iir_create(gr4hip_iir_t** iir, int form, size_t nsections, const floa
 int gr4hip_iir_reset(gr4hip_iir_t* iir);
 int gr4hip_iir_process(gr4hip_iir_t* iir, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream);
 int gr4hip_iir_status(gr4hip_iir_t* iir, gr4hip_stream_t stream);
+/* How the cascade is evaluated (per handle; changing it restarts the filter from zero state):
+ *   GR4HIP_IIR_PARALLEL        the parallel-in-time kernels described above (direct form II whatever `form` says).
+ *   GR4HIP_IIR_SEQUENTIAL_F32  the reference's own arithmetic: one lane walks the cascade sample by sample in the REQUESTED form (detail::computeFilter,
+ *                              FilterTool.hpp:116-158: DF_I / DF_II / DF_I_TRANSPOSED / DF_II_TRANSPOSED with their own input / output histories), float32
+ *                              operations in source order.  ~10 Msamples/s; as close to float64 as the block on the host, form for form.
+ *   GR4HIP_IIR_AUTO (default)  PARALLEL unless float32 cannot carry this cascade's state through the scan: gr4hip_iir_create measures it -- a three-tile noise vector
+ *                              through the kernels the handle would use, against float64 and against the sequential float32 form on the host -- and selects
+ *                              SEQUENTIAL_F32 when the parallel result is off by more than 1e-5 of the output rms AND by more than ten times the sequential float32
+ *                              error (ill-conditioned narrow-band cascades of high order: an order-16, fc = 0.016 Butterworth measured 7.8e-2 against 7.0e-3).
+ * gr4hip_iir_get_algo reports the evaluation in use and the two create-time errors (max |error| / output rms; < 0: not measured). */
+typedef enum { GR4HIP_IIR_AUTO = 0, GR4HIP_IIR_PARALLEL = 1, GR4HIP_IIR_SEQUENTIAL_F32 = 2 } gr4hip_iir_algo;
+int gr4hip_iir_set_algo(gr4hip_iir_t* iir, int algo);
+int gr4hip_iir_get_algo(const gr4hip_iir_t* iir, int* algo_in_use, float* selftest_parallel, float* selftest_sequential_f32);
 int gr4hip_iir_destroy(gr4hip_iir_t* iir);
 
 /* ------------------------------------------------------------------------------------------------ a5 (host-side design)
