@@ -6,14 +6,23 @@
 #include <bit>
 #include <vector>
 
+#include <span>
+
 namespace gr {
-template <typename T>
+// HistoryBuffer<T, N>: N == std::dynamic_extent (default) takes its capacity at run time, a fixed N at compile time (HistoryBuffer.hpp:67: the Section of
+// FilterTool.hpp:187 uses the two-parameter form)
+template <typename T, std::size_t N = std::dynamic_extent>
 class HistoryBuffer {
     std::vector<T> _d;
     std::size_t    _cap, _head = 0, _size = 0;
 
 public:
-    explicit HistoryBuffer(std::size_t capacity = 32) : _d(2 * std::bit_ceil(std::max<std::size_t>(capacity, 1)), T{}), _cap(std::bit_ceil(std::max<std::size_t>(capacity, 1))) {}
+    using value_type = T;
+    HistoryBuffer() requires(N != std::dynamic_extent) : _d(2 * std::bit_ceil(N), T{}), _cap(std::bit_ceil(N)) {}
+    explicit HistoryBuffer(std::size_t capacity) requires(N == std::dynamic_extent)
+        : _d(2 * std::bit_ceil(std::max<std::size_t>(capacity, 1)), T{}), _cap(std::bit_ceil(std::max<std::size_t>(capacity, 1))) {
+        if (capacity == 0) throw std::out_of_range("capacity is zero");
+    }
     // the storage is mirrored ([0, cap) == [cap, 2 cap)): the newest-first window [head, head + cap) is always contiguous, as upstream
     void push_front(const T& v) noexcept {
         _head          = (_head + _cap - 1) & (_cap - 1);
@@ -29,6 +38,8 @@ public:
     [[nodiscard]] auto end() const noexcept { return begin() + static_cast<std::ptrdiff_t>(_cap); }
     [[nodiscard]] auto cbegin() const noexcept { return begin(); }
     [[nodiscard]] auto cend() const noexcept { return end(); }
-    void reset(T v = T{}) noexcept { std::fill(_d.begin(), _d.end(), v); _size = 0; _head = 0; }
+    void reset(T v = T{}) noexcept { std::fill(_d.begin(), _d.end(), v); _size = 0; _head = 0; } // HistoryBuffer.hpp: back to the empty state, storage kept
+    [[nodiscard]] const T& front() const noexcept { return _d[_head]; }
+    [[nodiscard]] const T& back() const noexcept { return _d[_head + (_size ? _size - 1 : 0)]; }
 };
 } // namespace gr

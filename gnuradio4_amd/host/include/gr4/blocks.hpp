@@ -268,7 +268,7 @@ struct fir_filter : Block<fir_filter<T>> {
     using tap_type = std::conditional_t<detail::is_complex<T>::value, float, T>;
     PortIn<T>             in;
     PortOut<T>            out;
-    std::vector<tap_type> b{tap_type(1)};
+    Tensor<tap_type>      b{tap_type(1)}; // feedforward coefficients: the reference's settings type (time_domain_filter.hpp:32); a std::vector in a property_map is accepted
     std::vector<T>        _history = std::vector<T>(32, T{}); // newest first, like HistoryBuffer{32}
     GR_MAKE_REFLECTABLE(fir_filter, in, out, b);
 
@@ -295,7 +295,7 @@ template <typename T, IIRForm form = IIRForm::DF_II>
 struct iir_filter : Block<iir_filter<T, form>> {
     PortIn<T>      in;
     PortOut<T>     out;
-    std::vector<T> b{T(1)}, a{T(1)};
+    Tensor<T>      b{T(1)}, a{T(1)}; // time_domain_filter.hpp:73-74
     std::vector<T> _x = std::vector<T>(32, T{}), _y = std::vector<T>(32, T{});
     GR_MAKE_REFLECTABLE(iir_filter, in, out, b, a);
 
@@ -303,7 +303,7 @@ struct iir_filter : Block<iir_filter<T, form>> {
         std::move_backward(h.begin(), h.end() - 1, h.end());
         h[0] = v;
     }
-    static T dot(const std::vector<T>& c, std::size_t first, const std::vector<T>& h) {
+    static T dot(const Tensor<T>& c, std::size_t first, const std::vector<T>& h) {
         T acc{};
         for (std::size_t k = first; k < c.size(); ++k) acc += c[k] * h[k - first];
         return acc;

@@ -46,6 +46,17 @@ string format(string_view f, const Args&... args) {
 
 namespace gr {
 namespace meta {
+using gr::fixed_string; // gr::meta::fixed_string (meta/utils.hpp:133): a structural compile-time string, deducible from a literal
+template <typename T>
+struct is_std_array_type : std::false_type {};
+template <typename T, std::size_t N>
+struct is_std_array_type<std::array<T, N>> : std::true_type {};
+template <typename T>
+concept vector_type = gr::detail::is_vector<std::remove_cv_t<T>>::value;
+template <typename T>
+concept array_type = is_std_array_type<std::remove_cv_t<T>>::value;
+template <typename T, typename V = void>
+concept array_or_vector_type = (vector_type<T> || array_type<T>) && (std::same_as<V, void> || std::same_as<typename T::value_type, V>); // meta/utils.hpp:700
 template <typename T>
 inline constexpr bool always_false = false;
 template <typename T>

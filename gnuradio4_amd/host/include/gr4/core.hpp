@@ -80,6 +80,54 @@ public:
     [[nodiscard]] const Error& error() const { return *_e; }
 };
 
+// ---------------------------------------------------------------------------------------------- gr::Tensor<T> (core/include/gnuradio-4.0/Tensor.hpp)
+// The settings type of the reference's filter blocks (fir_filter::b, iir_filter::b / a: Tensor<T>, blocks/filter/.../time_domain_filter.hpp:32, 73-74).  The
+// dynamic-extents managed form, row-major, as far as block code uses it: construction from values / a vector / extents, size / rank / extents, element and
+// iterator access over the flat storage, comparison.  (Views, static extents and the mdspan bridge of the reference type are not part of the hot path.)
+template <typename T>
+struct Tensor {
+    using value_type = T;
+    std::vector<T>           _data;
+    std::vector<std::size_t> _extents{0};
+
+    Tensor() = default;
+    Tensor(std::initializer_list<T> values) : _data(values), _extents{values.size()} {}                 // a rank-1 tensor of these values: Tensor<T> b{T{1}}
+    Tensor(const std::vector<T>& values) : _data(values), _extents{values.size()} {}                    // NOLINT: a vector is a rank-1 tensor
+    Tensor(std::vector<T>&& values) : _data(std::move(values)), _extents{_data.size()} {}               // NOLINT
+    template <std::input_iterator It>
+    Tensor(It first, It last) : _data(first, last), _extents{_data.size()} {}
+    static Tensor with_extents(std::vector<std::size_t> extents, T fill = T{}) {
+        Tensor t;
+        std::size_t n = 1;
+        for (auto e : extents) n *= e;
+        t._data.assign(n, fill);
+        t._extents = std::move(extents);
+        return t;
+    }
+    Tensor& operator=(const std::vector<T>& values) { _data = values; _extents = {values.size()}; return *this; }
+    Tensor& operator=(std::initializer_list<T> values) { _data = values; _extents = {values.size()}; return *this; }
+    operator const std::vector<T>&() const noexcept { return _data; } // NOLINT: flat storage, for code that takes the std::vector spelling of the setting
+
+    [[nodiscard]] std::size_t size() const noexcept { return _data.size(); }
+    [[nodiscard]] bool        empty() const noexcept { return _data.empty(); }
+    [[nodiscard]] std::size_t rank() const noexcept { return _extents.size(); }
+    [[nodiscard]] std::size_t extent(std::size_t d) const { return _extents.at(d); }
+    [[nodiscard]] std::span<const std::size_t> extents() const noexcept { return _extents; }
+    [[nodiscard]] T*          data() noexcept { return _data.data(); }
+    [[nodiscard]] const T*    data() const noexcept { return _data.data(); }
+    [[nodiscard]] T&          operator[](std::size_t i) noexcept { return _data[i]; }
+    [[nodiscard]] const T&    operator[](std::size_t i) const noexcept { return _data[i]; }
+    [[nodiscard]] auto begin() noexcept { return _data.begin(); }
+    [[nodiscard]] auto end() noexcept { return _data.end(); }
+    [[nodiscard]] auto begin() const noexcept { return _data.begin(); }
+    [[nodiscard]] auto end() const noexcept { return _data.end(); }
+    [[nodiscard]] auto cbegin() const noexcept { return _data.cbegin(); }
+    [[nodiscard]] auto cend() const noexcept { return _data.cend(); }
+    void resize(std::size_t n, T fill = T{}) { _data.resize(n, fill); _extents = {n}; }
+    void assign(std::size_t n, T fill) { _data.assign(n, fill); _extents = {n}; }
+    [[nodiscard]] friend bool operator==(const Tensor& a, const Tensor& b) { return a._extents == b._extents && a._data == b._data; }
+};
+
 // ---------------------------------------------------------------------------------------------- property_map (settings payload)
 struct property_map;
 using pmt_base = std::variant<bool, std::int64_t, std::uint64_t, double, float, std::string, std::complex<float>, std::complex<double>, std::vector<float>,
@@ -91,6 +139,10 @@ struct pmt : pmt_base {
     pmt() = default;
     pmt(const property_map& nested);
     pmt(property_map&& nested);
+    // a Tensor<T> setting travels as its flat values (the reference's property_map holds the tensor itself; the std::vector spelling stays accepted wherever a
+    // Tensor<T> member is set)
+    pmt(const Tensor<float>& t) : pmt_base(std::vector<float>(t.begin(), t.end())) {}
+    pmt(const Tensor<double>& t) : pmt_base(std::vector<double>(t.begin(), t.end())) {}
     [[nodiscard]] const property_map* get_if_map() const noexcept {
         const auto* p = std::get_if<std::shared_ptr<const property_map>>(static_cast<const pmt_base*>(this));
         return p ? p->get() : nullptr;
@@ -124,6 +176,10 @@ template <typename T>
 struct is_complex : std::false_type {};
 template <typename T>
 struct is_complex<std::complex<T>> : std::true_type {};
+template <typename T>
+struct is_tensor : std::false_type {};
+template <typename T>
+struct is_tensor<Tensor<T>> : std::true_type {};
 
 // conversion of a property value to the member's type (arithmetic <-> arithmetic, vector<float|double> <-> vector<T>, string, enum by integer)
 template <typename T>
@@ -151,6 +207,14 @@ bool assign_from(T& dst, const pmt& v) {
             } else if constexpr (is_complex<T>::value && is_complex<X>::value) {
                 dst = T(static_cast<typename T::value_type>(x.real()), static_cast<typename T::value_type>(x.imag()));
                 return true;
+            } else if constexpr (is_tensor<T>::value && is_vector<X>::value) { // Tensor<T> settings take the vector<float | double | int64> spellings
+                if constexpr (std::is_arithmetic_v<typename T::value_type> && std::is_arithmetic_v<typename X::value_type>) {
+                    dst.assign(x.size(), {});
+                    for (std::size_t i = 0; i < x.size(); ++i) dst[i] = static_cast<typename T::value_type>(x[i]);
+                    return true;
+                } else {
+                    return false;
+                }
             } else if constexpr (is_vector<T>::value && is_vector<X>::value) {
                 if constexpr (std::is_arithmetic_v<typename T::value_type> && std::is_arithmetic_v<typename X::value_type>) {
                     dst.assign(x.size(), {});

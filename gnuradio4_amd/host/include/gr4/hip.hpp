@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cctype>
@@ -50,6 +51,9 @@ struct Options {
     // measured output / input power falls below the threshold is redone in the time domain before the stage's enqueue returns -- the enqueue then waits for its own
     // launch), GR4HIP_GUARD_DEFERRED (enqueues stay asynchronous, the switch lags by one chunk) or GR4HIP_GUARD_OFF (include/gr4hip.h)
     int guard_mode = GR4HIP_GUARD_STRICT;
+    // A sharded graph's exchange (FanInRun) waits for other ranks: seconds one exchange may take before the run gives up with a rank-tagged message and
+    // work::Status::ERROR instead of hanging its process (a peer that died or never joined); <= 0: wait for ever
+    double collective_timeout_s = 120.0;
 };
 inline Options& options() { static Options o; return o; }
 
@@ -1911,6 +1915,8 @@ class FanInRun final : public BlockModel {
     DevBuf                          _d_partial{false}, _d_sum{false}, _h_out{true};
     std::string                     _name;
     std::size_t                     _launches = 0, _exchanges = 0, _tags_forwarded = 0;
+    gr4hip_event_t                  _ev = nullptr;
+    bool                            _stalled = false; // an exchange timed out: the stream is abandoned (never synchronised again)
 
 public:
     FanInRun(std::vector<std::pair<std::shared_ptr<EdgeBufferBase>, std::vector<float>>> local_branches, std::shared_ptr<EdgeBufferBase> out, std::size_t fftSize, int window,
@@ -1927,7 +1933,9 @@ public:
         _name = "fan_in[" + std::to_string(_branches.size()) + " of " + std::to_string(n_total) + " channels on gpu:hip:" + std::to_string(_domain.index) + "]";
     }
     ~FanInRun() override {
+        if (_stalled) return; // a collective that never completes still owns the stream and the buffers it was queued with: leaked on purpose, the process is going down
         for (auto& b : _branches) gr4hip_chain_destroy(b.chain);
+        if (_ev) gr4hip_event_destroy(_ev);
         if (_s) gr4hip_stream_destroy(_s);
     }
     [[nodiscard]] std::size_t local_channels() const { return _branches.size(); }
@@ -2012,6 +2020,22 @@ public:
             void* direct = _out->memory() == pinned_resource() ? _out->reserve_items(n_out) : nullptr; // a page-locked output edge takes the result copy in its own storage
             held_reserved = direct ? n_out : 0;
             check(gr4hip_memcpy_d2h(direct ? direct : _h_out.ensure(n_out * 4), result, n_out * 4, _s), "d2h");
+            if (_shard.comm && options().collective_timeout_s > 0) { // the exchange involves other processes: bounded wait, then a diagnostic instead of a hung rank
+                if (!_ev) check(gr4hip_event_create(&_ev), "gr4hip_event_create");
+                check(gr4hip_event_record(_ev, _s), "event record");
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int done = 0;;) {
+                    check(gr4hip_event_query(_ev, &done), "event query");
+                    if (done) break;
+                    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (waited > options().collective_timeout_s) {
+                        _stalled = true; // (the stream still holds the collective: nothing more is queued on it, the destructor does not wait for it)
+                        throw std::runtime_error("fan-in exchange " + std::to_string(_exchanges) + " of rank " + std::to_string(_shard.rank) + " / " + std::to_string(_shard.n_ranks) +
+                                                 " did not complete within " + std::to_string(static_cast<int>(options().collective_timeout_s)) + " s (a peer that never joined the collective?)");
+                    }
+                    std::this_thread::sleep_for(waited < 0.01 ? std::chrono::microseconds(20) : std::chrono::microseconds(500));
+                }
+            }
             check(gr4hip_stream_synchronize(_s), "stream synchronize");
             for (auto& b : _branches)
                 if (b.n_lent) { b.in->consume_items(b.n_lent); b.n_lent = 0; }
@@ -2022,6 +2046,7 @@ public:
             return {requested, n_out, work::Status::OK};
         } catch (const std::exception& e) {
             std::cerr << "[gr::hip] fan-in run failed: " << e.what() << "\n";
+            if (_stalled) return {requested, 0, work::Status::ERROR}; // (nothing can be taken back from a stream that does not drain)
             (void)gr4hip_stream_synchronize(_s); // nothing of the failed exchange may still read a lent span
             for (auto& b : _branches)
                 if (b.n_lent) { b.in->unlend_items(b.n_lent); b.n_lent = 0; }

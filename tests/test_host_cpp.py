@@ -59,6 +59,42 @@ def test_reference_block_headers_compile_unmodified(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="container-only: needs the reference tree where it lies (nothing of it travels)")
+def test_reference_algorithm_headers_compile_unmodified(tmp_path, golden):
+    """the reference's algorithm/fourier/window.hpp and fft_common.hpp, included from /root/reference as they are, compile against this host layer (gr4/compat.hpp
+    carries gr::meta::fixed_string and gr::meta::array_or_vector_type for them) and reproduce what the reference's own test holds for them
+    (qa_algorithm_fourier.cpp:145-180: the N = 8 array of every window, the numpy.unwrap vector) -- and they agree with the oracle's restatement and with the
+    library's host-side window::create (gr4hip_window_create), i.e. the restatements are checked against the reference's own code, not only against its test vectors"""
+    import ctypes as C
+    import numpy as np
+    import oracle_lib as O
+    exe = tmp_path / "test_reference_algorithm_dropin"
+    cmd = ["g++", "-std=c++20", "-w", "-O1", "-I" + os.path.join(ROOT, "gnuradio4_amd", "host", "include"), "-I" + os.path.join(REFERENCE, "algorithm", "include"),
+           "-I" + os.path.join(REFERENCE, "third_party", "magic_enum"), os.path.join(ROOT, "gnuradio4_amd", "host", "tests", "test_reference_algorithm_dropin.cpp"), "-o", str(exe)]
+    c = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stderr[-4000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "reference algorithm drop-in: done (window.hpp, fft_common.hpp unmodified)" in r.stdout and "FAILED" not in r.stdout, r.stdout + r.stderr
+    rows = {ln.split()[0] + (" " + ln.split()[1] if ln.startswith("window ") else ""): ln for ln in r.stdout.splitlines()}
+    vals = lambda key, skip: np.array([float(v) for v in rows[key].split()[skip:]])
+    from gnuradio4_amd import capi
+    for wid, name in enumerate(O.WINDOWS):
+        got = vals(f"window {wid}", 2)
+        np.testing.assert_allclose(got, golden["window_n8"][name], atol=2e-6, err_msg=name)           # the vectors the reference's test holds
+        np.testing.assert_allclose(got, O.window(wid, 8, np.float32), rtol=0, atol=1e-7, err_msg=name)  # the oracle's restatement against the reference's code
+        w = np.empty(8, np.float32)
+        assert capi.lib().gr4hip_window_create(wid, w.ctypes.data, 8, C.c_float(1.6)) == 0
+        np.testing.assert_allclose(got, w, rtol=0, atol=1e-7, err_msg=name)                               # the library's host-side window::create
+    assert rows["typenames"].split(" ", 1)[1] == "[" + ", ".join(O.WINDOWS) + "]"
+    np.testing.assert_allclose(vals("unwrap", 1), golden["unwrap"]["expected"], atol=1e-7)
+    spec = np.array([1, -2j, -3 + 3j, 0.5 + 0.25j, 0, 2 - 1j, -1 - 1j, 4], np.complex64)
+    np.testing.assert_allclose(vals("magnitude_shifted", 1), O.magnitude(spec, shift=True), rtol=1e-6)
+    np.testing.assert_allclose(vals("magnitude_half_db", 1), O.magnitude(spec, half=True, in_db=True), rtol=1e-6)
+    np.testing.assert_allclose(vals("phase_deg_unwrapped_shifted", 1), O.phase(spec, in_deg=True, unwrap=True, shift=True), rtol=1e-5, atol=1e-4)
+    src = open(os.path.join(ROOT, "gnuradio4_amd", "host", "tests", "test_reference_algorithm_dropin.cpp")).read()
+    assert "#include <gnuradio-4.0/algorithm/fourier/window.hpp>" in src and "bessel_i0" not in src  # only #included, never copied
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="container-only: needs the reference tree where it lies (nothing of it travels)")
 def test_hbm_ring_models_the_reference_bufferlike_concept():
     """the reference's own BufferLike / BufferReaderLike / BufferWriterLike concepts (core/include/gnuradio-4.0/Buffer.hpp:78-102, included
     unmodified from /root/reference; std-only header) hold for gr::hip::CircularBuffer<T> (static_asserts in host/tests/test_reference_bufferlike.cpp)"""
