@@ -186,6 +186,16 @@ bool ewise_as_real_gain(const gr4hip_ewise* p, double* gain) {
     *gain = g;
     return true;
 }
+// (library-internal) a program as its own launch on values of `dtype`: hooks of kernels that run it in front of / behind themselves
+int ewise_run(const EwiseHook& prog, int dtype, const void* in, void* out, long n, hipStream_t st) {
+    if (n <= 0 || prog.n_ops <= 0) return GR4HIP_OK;
+    switch (dtype) {
+    case GR4HIP_F32: return ewise_launch<float>(in, out, n, prog, st);
+    case GR4HIP_C32: return ewise_launch<float2>(in, out, n, prog, st);
+    case GR4HIP_F64: return ewise_launch<double>(in, out, n, prog, st);
+    default: set_error("ewise_run: dtype %d", dtype); return GR4HIP_INVALID_ARGUMENT;
+    }
+}
 gr4hip_ewise* ewise_clone(const gr4hip_ewise* p) { // a private copy of the op list (its own device buffer, position 0)
     auto* q = new (std::nothrow) gr4hip_ewise();
     if (q) { q->dtype = p->dtype; q->user = p->user; }

@@ -211,4 +211,5 @@ namespace gr4 {
 int           ewise_device_ops(gr4hip_ewise* p, EwiseHook* hook); // uploads on first use after a change; hook->pos = p->pos
 bool          ewise_as_real_gain(const gr4hip_ewise* p, double* gain);
 gr4hip_ewise* ewise_clone(const gr4hip_ewise* p);
+int           ewise_run(const EwiseHook& prog, int dtype, const void* in, void* out, long n, hipStream_t st);
 } // namespace gr4

@@ -4,7 +4,18 @@
 
 namespace gr4 {
 
+#if GR4_CMUL_PK // experiment (round 4, VERDICT #3 i): the complex product as two packed instructions with operand-select / negate modifiers instead of 2 mul + 2 fma
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    typedef float cm_f2 __attribute__((ext_vector_type(2)));
+    cm_f2       t, r;
+    const cm_f2 x = {a.x, a.y}, w = {b.x, b.y};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(x), "v"(w));          // {-a.y b.y, a.y b.x}
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(w), "v"(t));       // {a.x b.x, a.x b.y} + t
+    return make_float2(r[0], r[1]);
+}
+#else
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
+#endif
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 mulmi(float2 a) { return make_float2(a.y, -a.x); }

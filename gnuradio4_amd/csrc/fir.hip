@@ -19,13 +19,14 @@ namespace gr4 {
 
 // x: n_in samples; hist: the last `hcap` input samples before x (oldest first); tp: [D][Qpad] phase-major taps
 // (tp[p][q] = b[q*D + p], zero padded); y: n_out samples, y[m] = sum_k b[k] x[m*D - k].
-// HOOK: the filter's per-sample neighbours ride in this launch (ewise.hpp).  `pre` is applied to every input sample on its way into LDS -- x and the history
-// alike are RAW samples; a sample with absolute stream index pre.pos + i below pre_origin entered the history under an earlier prologue (or is the zero initial
-// history) and is taken as it lies -- `post` to every output sample before its store (post.pos = absolute index of y[0]).
+// HOOK: the filter's per-sample neighbours ride in this launch (ewise.hpp).  `pre` is applied to every sample of x on its way into LDS (pre.pos = absolute
+// stream index of x[0]); the carried history holds what the prologue made of earlier samples and is taken as it lies (the next history this launch writes is
+// made of prologue OUTPUTS too) -- exactly the filter's memory when the blocks run one after the other; `post` is applied to every output sample before its
+// store (post.pos = absolute index of y[0]).
 template <int S, int BS, bool HOOK>
 __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ x, const float* __restrict__ hist, const float* __restrict__ tp,
                                                        float* __restrict__ y, long n_in, long n_out, int hcap, int D, int G, float* __restrict__ new_hist,
-                                                       EwiseHook pre, long pre_origin, EwiseHook post) {
+                                                       EwiseHook pre, EwiseHook post) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R  = kFirR;
     constexpr int E  = 4 / S;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
                     const long ii = i + c;
                     t[c] = (ii >= 0) ? (ii < n_in ? x[ii] : 0.f) : (ii >= -(long)hcap ? hist[hcap + ii] : 0.f);
                     if constexpr (HOOK)
-                        if (ii < n_in && ii >= -(long)hcap && pre.pos + ii >= pre_origin) t[c] = ewise_hook1<float>(t[c], pre, ii);
+                        if (ii >= 0 && ii < n_in) t[c] = ewise_hook1<float>(t[c], pre, ii);
                 }
                 v = make_float4(t[0], t[1], t[2], t[3]);
             }
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
                     const float* p  = (ii >= 0) ? (ii < n_in ? x + 2 * ii : nullptr) : (ii >= -(long)hcap ? hist + 2 * (hcap + ii) : nullptr);
                     float2       q  = p ? make_float2(p[0], p[1]) : make_float2(0.f, 0.f);
                     if constexpr (HOOK)
-                        if (p && pre.pos + ii >= pre_origin) q = ewise_hook1<float2>(q, pre, ii);
+                        if (p && ii >= 0) q = ewise_hook1<float2>(q, pre, ii);
                     t[2 * c]     = q.x;
                     t[2 * c + 1] = q.y;
                 }
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
             const float* src = (i >= 0) ? (i < n_in ? x + S * i : nullptr) : (i >= -(long)hcap ? hist + S * (hcap + i) : nullptr);
             float*       dst = xl + (size_t)p * Lf + (size_t)jl * S;
             if constexpr (HOOK) {
-                if (src && pre.pos + i >= pre_origin) {
+                if (src && i >= 0) {
                     if constexpr (S == 1) dst[0] = ewise_hook1<float>(src[0], pre, i);
                     else { const float2 q = ewise_hook1<float2>(make_float2(src[0], src[1]), pre, i); dst[0] = q.x; dst[S - 1] = q.y; }
                     continue;
@@ -165,9 +166,21 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
     // a span served by this launch alone: workgroup 0 also writes the block's next history (the other half of the ping-pong pair; nobody reads it in this
     // launch), which saves the separate update launch -- a scheduler's 4 Ki .. 64 Ki-sample work() chunks cost launches, not arithmetic
     if (new_hist != nullptr && blockIdx.x == 0) {
-        for (int t = tid; t < hcap * S; t += BS) {
-            const long h = t / S, c = t % S, i = n_in - hcap + h;
-            new_hist[t]  = (i >= 0) ? x[i * S + c] : hist[(hcap + i) * S + c];
+        if constexpr (HOOK) { // the next history is made of what the prologue produces
+            for (int h = tid; h < hcap; h += BS) {
+                const long i = n_in - hcap + h;
+                if constexpr (S == 1) new_hist[h] = i >= 0 ? ewise_hook1<float>(x[i], pre, i) : hist[hcap + i];
+                else {
+                    const float2 q = i >= 0 ? ewise_hook1<float2>(make_float2(x[2 * i], x[2 * i + 1]), pre, i) : make_float2(hist[2 * (hcap + i)], hist[2 * (hcap + i) + 1]);
+                    new_hist[2 * h]     = q.x;
+                    new_hist[2 * h + 1] = q.y;
+                }
+            }
+        } else {
+            for (int t = tid; t < hcap * S; t += BS) {
+                const long h = t / S, c = t % S, i = n_in - hcap + h;
+                new_hist[t]  = (i >= 0) ? x[i * S + c] : hist[(hcap + i) * S + c];
+            }
         }
     }
 }
@@ -182,13 +195,10 @@ __global__ void fir_hist_update_kernel(const float* __restrict__ x, const float*
     new_hist[t]  = (i >= 0) ? x[i * S + c] : old_hist[(hcap + i) * S + c];
 }
 
-// a prologue is replaced in mid-stream: the samples already in the history become what the OLD prologue made of them (hist[h] has absolute index pos - hcap + h)
-template <typename V>
-__global__ void fir_hist_cook_kernel(V* __restrict__ hist, int hcap, EwiseHook pre /*pos = index of the next input sample*/, long pre_origin) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= hcap) return;
-    const long i = (long)h - hcap;
-    if (pre.pos + i >= pre_origin && pre.pos + i >= 0) hist[h] = ewise_hook1<V>(hist[h], pre, i);
+// the stored history changes its meaning (a prologue gain moves into or out of the taps): every sample times `factor`
+__global__ void fir_hist_scale_kernel(float* __restrict__ hist, int nfloats, float factor) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nfloats) hist[t] *= factor;
 }
 
 template <typename V>
@@ -280,8 +290,10 @@ struct gr4hip_fir {
     double             pre_gain = 1.0, post_gain = 1.0;
     double             folded = 1.0;   // the gain the device tap tables currently carry: `taps` = folded x `user_taps`
     std::vector<float> user_taps;      // the block's setting `b` as given
-    long               pos = 0;        // input samples consumed since create / reset / a history replacement
-    long               pre_origin = 0; // history samples with an absolute index below this are what an EARLIER prologue produced (or the zero initial history)
+    long               pos = 0;        // input samples consumed since create / reset: the absolute index a rotator op's phase is a function of
+    double             hist_gain = 1.0; // the stored history times this = what the prologue made of those samples (a folded prologue gain keeps RAW samples in the
+                                        // history -- the taps carry the gain --, a hooked prologue keeps its outputs there: 1)
+    DeviceBuffer       d_pre;          // long spans of filters that take a matrix-pipe kernel: the prologue's output (one element-wise launch in front of it)
     ~gr4hip_fir() { delete pre; delete post; }
 };
 
@@ -312,7 +324,7 @@ static int fir_alloc_hist(gr4hip_fir* f) {
     return GR4HIP_OK;
 }
 
-struct FirHooks { EwiseHook pre, post; long pre_origin = 0; bool any = false; };
+struct FirHooks { EwiseHook pre, post; bool any = false; };
 
 template <int S, int BS, bool HOOK>
 static int fir_launch_h(const gr4hip_fir* f, const float* x, const float* hist, float* y, long n_in, long n_out, size_t lds, hipStream_t st, float* new_hist, const FirHooks& hk) {
@@ -321,7 +333,7 @@ static int fir_launch_h(const gr4hip_fir* f, const float* x, const float* hist, 
     const long TOs  = BS * kFirR / S;
     const long grid = ceil_div(n_out, TOs);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, st, x, hist, (const float*)f->d_taps.ptr, y, n_in, n_out,
-                       (int)f->hcap, (int)f->decim, f->G, new_hist, hk.pre, hk.pre_origin, hk.post);
+                       (int)f->hcap, (int)f->decim, f->G, new_hist, hk.pre, hk.post);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
@@ -347,14 +359,24 @@ static int fir_apply_gain(gr4hip_fir* f, double gain) {
     fir_invalidate_tables(f);
     return fir_upload_taps(f);
 }
-// what this call does with the neighbours: gains ride in the taps (a prologue's only once no sample an earlier prologue produced is left in the history), the
-// rest as hooks of the register-window kernel
+// the stored history follows a change of its meaning: hist_gain -> g (a prologue gain that moves into or out of the taps)
+static int fir_rescale_history(gr4hip_fir* f, double g) {
+    if (g == f->hist_gain) return GR4HIP_OK;
+    if (f->pos > 0) {
+        GR4_HIP_TRY(hipDeviceSynchronize()); // (a settings change, not a per-call operation: everything queued on the handle finishes first)
+        const int nf = (int)(f->hcap * f->S);
+        hipLaunchKernelGGL(fir_hist_scale_kernel, dim3((unsigned)ceil_div(nf, 256)), dim3(256), 0, nullptr, (float*)f->d_hist[f->cur].ptr, nf, (float)(f->hist_gain / g));
+        GR4_LAUNCH_CHECK();
+        GR4_HIP_TRY(hipDeviceSynchronize());
+    }
+    f->hist_gain = g;
+    return GR4HIP_OK;
+}
+// what this call does with the neighbours: gains ride in the taps, the rest are hooks (or, in front of / behind a matrix-pipe kernel, element-wise launches)
 static int fir_prepare_hooks(gr4hip_fir* f, FirHooks* hk) {
-    const bool fold_pre  = f->pre && f->pre_is_gain && (f->pre_origin == 0 || f->pos - f->pre_origin >= (long)f->hcap);
-    const bool fold_post = f->post && f->post_is_gain;
-    const double want    = (fold_pre ? f->pre_gain : 1.0) * (fold_post ? f->post_gain : 1.0);
+    const bool   fold_pre = f->pre && f->pre_is_gain, fold_post = f->post && f->post_is_gain;
+    const double want     = (fold_pre ? f->pre_gain : 1.0) * (fold_post ? f->post_gain : 1.0);
     if (want != f->folded) { if (const int rc = fir_apply_gain(f, want)) return rc; }
-    hk->pre_origin = f->pre_origin;
     if (f->pre && !fold_pre) {
         f->pre->pos = f->pos;
         if (const int rc = ewise_device_ops(f->pre, &hk->pre)) return rc;
@@ -366,21 +388,6 @@ static int fir_prepare_hooks(gr4hip_fir* f, FirHooks* hk) {
     hk->any = hk->pre.n_ops > 0 || hk->post.n_ops > 0;
     return GR4HIP_OK;
 }
-// (set_prologue in mid-stream) the history becomes what the outgoing prologue made of it
-static int fir_cook_history(gr4hip_fir* f) {
-    if (!f->pre || f->pos == 0) return GR4HIP_OK;
-    EwiseHook h;
-    f->pre->pos = f->pos;
-    if (const int rc = ewise_device_ops(f->pre, &h)) return rc;
-    if (h.n_ops == 0) return GR4HIP_OK;
-    GR4_HIP_TRY(hipDeviceSynchronize()); // (a settings change, not a per-call operation: everything queued on the handle finishes first)
-    const unsigned grid = (unsigned)ceil_div(f->hcap, (size_t)256);
-    if (f->S == 2) hipLaunchKernelGGL(fir_hist_cook_kernel<float2>, dim3(grid), dim3(256), 0, nullptr, (float2*)f->d_hist[f->cur].ptr, (int)f->hcap, h, f->pre_origin);
-    else hipLaunchKernelGGL(fir_hist_cook_kernel<float>, dim3(grid), dim3(256), 0, nullptr, (float*)f->d_hist[f->cur].ptr, (int)f->hcap, h, f->pre_origin);
-    GR4_LAUNCH_CHECK();
-    GR4_HIP_TRY(hipDeviceSynchronize());
-    return GR4HIP_OK;
-}
 static int fir_set_hook(gr4hip_fir* f, const gr4hip_ewise_t* prog, bool prologue) {
     GR4_REQUIRE(f, "fir_set_%s: null handle", prologue ? "prologue" : "epilogue");
     if (prog && prog->dtype != f->dtype) { set_error("fir_set_%s: the program's dtype %d is not the filter's (%d)", prologue ? "prologue" : "epilogue", prog->dtype, f->dtype); return GR4HIP_UNSUPPORTED; }
@@ -390,11 +397,15 @@ static int fir_set_hook(gr4hip_fir* f, const gr4hip_ewise_t* prog, bool prologue
         GR4_REQUIRE(copy, "out of host memory");
     }
     if (prologue) {
-        if (const int rc = fir_cook_history(f)) { delete copy; return rc; }
+        // the history keeps what the OUTGOING prologue made of the samples in it (the filter's memory when the blocks run one after the other): with a hooked
+        // prologue it holds those outputs already, with a folded gain it holds raw samples and is brought to the new prologue's convention here
+        double     g       = 1.0;
+        const bool is_gain = copy && ewise_as_real_gain(copy, &g);
+        if (const int rc = fir_rescale_history(f, is_gain ? g : 1.0)) { delete copy; return rc; }
         delete f->pre;
         f->pre         = copy;
-        f->pre_origin  = f->pos;
-        f->pre_is_gain = copy && ewise_as_real_gain(copy, &f->pre_gain);
+        f->pre_is_gain = is_gain;
+        f->pre_gain    = is_gain ? g : 1.0;
     } else {
         delete f->post;
         f->post         = copy;
@@ -437,7 +448,6 @@ int gr4hip_fir_set_taps(gr4hip_fir_t* f, const float* h_taps, size_t ntaps) {
     if (rc) return rc;
     if (ntaps > f->hcap) { // the reference replaces the HistoryBuffer (history is lost) only when it must grow
         f->hcap = bit_ceil_sz(ntaps);
-        f->pre_origin = f->pos; // (the new history is all zeros: nothing in it is a raw sample)
         return fir_alloc_hist(f);
     }
     return GR4HIP_OK;
@@ -448,7 +458,7 @@ int gr4hip_fir_reset(gr4hip_fir_t* f) {
     f->fd_probed = f->fd_blocked = false;
     f->f32_products = f->f32_user;
     f->fd_ratio  = -1.f;
-    f->pos = f->pre_origin = 0;
+    f->pos = 0;
     return fir_alloc_hist(f);
 }
 
@@ -472,6 +482,8 @@ int gr4hip_fir_set_guard_mode(gr4hip_fir_t* f, int mode) {
 // the three-term bf16 kernels are off for this handle (GR4HIP_FIR_EXACT_F32: IEEE float32 multiply-add, the reference's Inf / NaN behaviour) or for the process (developer switch)
 static bool no_bf16x3(const gr4hip_fir_t* f) { return f->algo == GR4HIP_FIR_EXACT_F32 || f->f32_products || dev_switch(kDevFirNoBf16x3); }
 
+static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, gr4hip_stream_t stream, const FirHooks& hk);
+
 int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
     GR4_REQUIRE(f, "fir_process: null handle");
     GR4_REQUIRE(n_in % f->decim == 0, "fir_process: n_in=%zu is not a multiple of decim=%zu", n_in, f->decim);
@@ -479,11 +491,40 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     if (n_out_p) *n_out_p = n_out;
     if (n_in == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "fir_process: null device pointer");
+    FirHooks hk;
+    if (f->pre || f->post || f->folded != 1.0) { if (const int rc = fir_prepare_hooks(f, &hk)) return rc; }
+    // Neighbours that do not fold into the taps are load / store hooks of the register-window kernel.  Where a plain filter of this shape takes a matrix-pipe or
+    // frequency-domain kernel instead (more than 32 taps on a long span, the float decimators), that kernel is worth more than the saved pass: add -> 256-tap FIR
+    // measured 165 Gsamples/s hooked against 277 as an element-wise launch + the bf16 kernel.  There the program runs as ONE element-wise launch in front of
+    // (behind) the filter's own -- same results, same history (the filter sees, and remembers, the prologue's output); everything else stays one launch.
+    // (where the crossover lies, float, 2^27 samples: add -> 64 taps 432 hooked / 347 as two launches; -> 256 taps 165 / 258; the register-window kernel is FP32-bound
+    // from ~48 taps per output on, the element-wise launch costs one pass at ~740 Gsamples/s)
+    const size_t per_out    = ceil_div(f->ntaps, f->decim); // taps per computed output
+    const bool   fast_shape = f->algo == GR4HIP_FIR_AUTO && ((f->decim == 1 && f->ntaps > (f->S == 2 ? (size_t)64 : (size_t)96) && f->ntaps <= (f->S == 2 ? (size_t)256 : (size_t)1024) && n_in >= kMfmaMinSamples) ||
+                                                               (f->S == 1 && f->decim >= 2 && per_out > 12 && n_out >= ((size_t)1 << 14)));
+    if (hk.any && fast_shape) {
+        hipStream_t st  = as_stream(stream);
+        const void* src = d_in;
+        if (hk.pre.n_ops > 0) {
+            if (const int rc = f->d_pre.ensure(n_in * f->S * sizeof(float))) return rc;
+            if (const int rc = ewise_run(hk.pre, f->dtype, d_in, f->d_pre.ptr, (long)n_in, st)) return rc;
+            src = f->d_pre.ptr;
+        }
+        FirHooks none;
+        if (const int rc = fir_process_core(f, src, n_in, d_out, stream, none)) return rc;
+        if (hk.post.n_ops > 0) return ewise_run(hk.post, f->dtype, d_out, d_out, (long)n_out, st);
+        return GR4HIP_OK;
+    }
+    return fir_process_core(f, d_in, n_in, d_out, stream, hk);
+}
+
+} // extern "C"
+
+static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, gr4hip_stream_t stream, const FirHooks& hk) {
+    const size_t n_out = n_in / f->decim;
     hipStream_t  st   = as_stream(stream);
     const float* x    = static_cast<const float*>(d_in);
     float*       y    = static_cast<float*>(d_out);
-    FirHooks     hk;
-    if (f->pre || f->post || f->folded != 1.0) { if (const int rc = fir_prepare_hooks(f, &hk)) return rc; }
     const bool   plain = !hk.any;
     const int    algo  = plain ? f->algo : (int)GR4HIP_FIR_EXACT_F32; // (EXACT_F32 == "the register-window kernel only") // hooks run in the register-window kernel only: the matrix-pipe and frequency-domain kernels below are for plain filters
     const float* hist = (const float*)f->d_hist[f->cur].ptr;
@@ -773,8 +814,6 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     f->pos += (long)n_in;
     return GR4HIP_OK;
 }
-
-} // extern "C"
 
 // (library-internal, chain.hip) make `d_last256` -- the 256 complex samples in front of the next input sample -- this filter's history: the fused chain
 // hands its stream over to the direct-form kernels when the dynamic-range guard switches algorithms

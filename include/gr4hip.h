@@ -375,10 +375,14 @@ int gr4hip_ewise_destroy(gr4hip_ewise_t* prog);
  *   - a program that is nothing but real gains (MultiplyConst / DivideConst; complex constants with a zero imaginary part) is folded into the taps -- a FIR filter
  *     is linear, fir(g x) == (g b) * x -- and costs nothing in any kernel (the rounding differs from the two-block form in the last bits: one float product per
  *     tap instead of one per sample, same float32 level, same 1e-5 parity bar);
- *   - anything else (AddConst / SubtractConst, complex gains, a rotator) runs as a load / store hook of the register-window kernel (any tap count, any
- *     decimation, float or complex): one launch, no intermediate stream in HBM; the matrix-pipe and frequency-domain kernels are not used for that handle.
- * A prologue replaced in mid-stream keeps the samples already in the filter's history as the OLD prologue produced them.  GR4HIP_UNSUPPORTED: the program's
- * dtype does not match. */
+ *   - anything else (AddConst / SubtractConst, complex gains, a rotator) is a load / store hook of the register-window kernel (any tap count, any decimation, float
+ *     or complex): one launch, no intermediate stream in HBM.  Exception, by measurement: where a plain filter of the same shape takes a matrix-pipe or
+ *     frequency-domain kernel AND the register-window kernel is far behind it (more than 96 taps -- 64 for complex -- on a span of >= 2^16 samples, float decimators with
+ *     more than 12 taps per output on long spans), that kernel is worth more than the saved pass
+ *     (add -> 256-tap FIR: 165 Gsamples/s hooked, 277 as an element-wise launch + the bf16 kernel), and the program runs as ONE element-wise launch in front of
+ *     (behind) the filter's own inside this call: same results, same carried history.
+ * The history the filter carries is always what the prologue in force made of the samples -- also when the prologue is replaced in mid-stream: the samples already in
+ * the filter's memory keep the OLD program's values, exactly as when the blocks run one after the other.  GR4HIP_UNSUPPORTED: the program's dtype does not match. */
 int gr4hip_fir_set_prologue(gr4hip_fir_t* fir, const gr4hip_ewise_t* prog);
 int gr4hip_fir_set_epilogue(gr4hip_fir_t* fir, const gr4hip_ewise_t* prog);
 
