@@ -339,6 +339,10 @@ class FFT(_Handle):
         check(lib().gr4hip_fft_spectrum(self._h, x.data_ptr(), frames, out.data_ptr(), _stream()), "FFT.spectrum")
         return out
 
+    def set_epilogue(self, prog: Optional["Merged"]):
+        """float blocks BEHIND the power spectrum (normalisation, an offset) in the transform's launch: applied to every |X|^2 of mag2() (gr4hip_fft_set_epilogue)"""
+        check(lib().gr4hip_fft_set_epilogue(self._h, prog._h if prog is not None else None), "FFT.set_epilogue")
+
     def mag2(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x, frames = self._frames(x)
         if out is None:
@@ -506,6 +510,17 @@ class Merged(_Handle):
         v = C.c_uint64(0)
         check(lib().gr4hip_ewise_position(self._h, C.byref(v)), "Merged.position")
         return v.value
+
+    def decimate(self, x: torch.Tensor, decim: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Decimator<T> with this program's blocks behind it in ONE launch: out[m] = program(x[m * decim]) (gr4hip_ewise_decimate)"""
+        x = _dev(x, "Merged.decimate")
+        if x.dtype != self.dtype:
+            raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Merged", f"expected {self.dtype}, got {x.dtype}")
+        n_out = -(-x.numel() // int(decim))
+        if out is None:
+            out = torch.empty(n_out, dtype=self.dtype, device=x.device)
+        check(lib().gr4hip_ewise_decimate(self._h, x.data_ptr(), x.numel(), int(decim), out.data_ptr(), None, _stream()), "Merged.decimate")
+        return out
 
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "Merged")

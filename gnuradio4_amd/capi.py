@@ -106,6 +106,7 @@ SIGNATURES = {
     "gr4hip_fft_process": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gr4hip_fft_spectrum": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "gr4hip_fft_mag2": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "gr4hip_fft_set_epilogue": (_i, [_vp, _vp]),
     "gr4hip_fft_destroy": (_i, [_vp]),
     "gr4hip_fft_plan": (_i, [_sz, _pi, _vp, _pi]),
     "gr4hip_window_create": (_i, [_i, _vp, _sz, _f]),
@@ -137,6 +138,7 @@ SIGNATURES = {
     "gr4hip_ewise_reset": (_i, [_vp]),
     "gr4hip_ewise_position": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "gr4hip_ewise_process": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "gr4hip_ewise_decimate": (_i, [_vp, _vp, _sz, _sz, _vp, _psz, _vp]),
     "gr4hip_ewise_destroy": (_i, [_vp]),
     "gr4hip_fir_set_prologue": (_i, [_vp, _vp]),
     "gr4hip_fir_set_epilogue": (_i, [_vp, _vp]),

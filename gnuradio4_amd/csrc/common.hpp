@@ -28,6 +28,7 @@ enum DevSwitch {
     kDevRotatorWalk,          // GR4HIP_ROTATOR_WALK
     kDevChain16,              // GR4HIP_CHAIN16
     kDevFftSmoothRuntime,     // GR4HIP_FFT_SMOOTH_RUNTIME: the run-time mixed-radix kernel also for sizes that have a compile-time plan
+    kDevEwiseNoDivRcp,        // GR4HIP_EWISE_NO_DIV_RCP: element-wise programs divide by a float constant with the general quotient (the tests compare it with the reciprocal form)
     kDevSwitchCount
 };
 int dev_switch(DevSwitch s);

@@ -55,6 +55,17 @@ __global__ __launch_bounds__(256) void ewise_kernel(const T* __restrict__ in, T*
     }
 }
 
+// Decimator<T> (time_domain_filter.hpp:234-244: keep the samples with i % decim == 0) with the per-sample blocks behind it in the same launch: only the kept samples
+// are read at all.  (Memoryless blocks in FRONT of a Decimator commute with it -- f(x)[m D] == f(x[m D]) -- so the planner moves them behind and they land here too.)
+template <typename T>
+__global__ __launch_bounds__(256) void ewise_decimate_kernel(const T* __restrict__ in, T* __restrict__ out, long n_out, long decim, EwiseHook prog) {
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < n_out; m += (long)gridDim.x * blockDim.x) {
+        T e[1] = {in[m * decim]};
+        ewise_apply<T, 1>(e, prog.ops, prog.n_ops, prog.has_div, [&](int) { return prog.pos + m; });
+        out[m] = e[0];
+    }
+}
+
 template <typename T>
 static int ewise_launch(const void* in, void* out, long n, const EwiseHook& prog, hipStream_t st) {
     constexpr long VE = 16 / sizeof(T), SL = ew_slab<T>();
@@ -94,7 +105,21 @@ static void compile_float(gr4hip_ewise* p) {
         o.kind = kEwAffine;
         std::memcpy(o.u.raw, &m, sizeof(F));
         std::memcpy(o.u.raw + 8, &a, sizeof(F));
-        if (c) { o.flags = kEwFlagDiv; std::memcpy(o.u.raw + 16, c, sizeof(F)); p->has_div = 1; }
+        if (c) {
+            o.flags = kEwFlagDiv;
+            std::memcpy(o.u.raw + 16, c, sizeof(F));
+            p->has_div = 1;
+            if constexpr (std::is_same_v<F, float>) { // a constant divisor in a safe range: the device multiplies by its correctly rounded reciprocal and corrects (ewise.hpp)
+                uint32_t bits;
+                std::memcpy(&bits, c, 4);
+                const float ac = std::fabs(*c);
+                if (ac >= 0x1p-40f && ac <= 0x1p40f && (bits & 0x7fffffu) != 0x7fffffu && !dev_switch(kDevEwiseNoDivRcp)) {
+                    const float y = 1.0f / *c; // IEEE division on the host: correctly rounded
+                    o.flags |= kEwFlagDivRcp;
+                    std::memcpy(o.u.raw + 20, &y, 4);
+                }
+            }
+        }
         p->ops.push_back(o);
         m = F(1); a = -F(0); have_m = have_a = false;
     };
@@ -289,6 +314,31 @@ int gr4hip_ewise_process(gr4hip_ewise_t* p, const void* d_in, void* d_out, size_
     }
     if (rc) return rc;
     p->pos += (long)n;
+    return GR4HIP_OK;
+}
+
+int gr4hip_ewise_decimate(gr4hip_ewise_t* p, const void* d_in, size_t n_in, size_t decim, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
+    GR4_REQUIRE(p, "ewise_decimate: null handle");
+    GR4_REQUIRE(decim >= 1, "ewise_decimate: decim must be >= 1");
+    const size_t n_out = ceil_div(n_in, decim); // i % decim == 0 for i in [0, n_in)
+    if (n_out_p) *n_out_p = n_out;
+    if (n_out == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out, "ewise_decimate: null device pointer");
+    EwiseHook prog;
+    int       rc = ewise_device_ops(p, &prog);
+    if (rc) return rc;
+    hipStream_t    st   = as_stream(stream);
+    const unsigned grid = (unsigned)std::min<size_t>(ceil_div(n_out, (size_t)256), 8192);
+#define GR4_EWD(ID, T) case ID: hipLaunchKernelGGL(ewise_decimate_kernel<T>, dim3(grid), dim3(256), 0, st, static_cast<const T*>(d_in), static_cast<T*>(d_out), (long)n_out, (long)decim, prog); break
+    switch (p->dtype) {
+        GR4_EWD(GR4HIP_U8, uint8_t); GR4_EWD(GR4HIP_U16, uint16_t); GR4_EWD(GR4HIP_U32, uint32_t); GR4_EWD(GR4HIP_U64, uint64_t);
+        GR4_EWD(GR4HIP_I8, int8_t); GR4_EWD(GR4HIP_I16, int16_t); GR4_EWD(GR4HIP_I32, int32_t); GR4_EWD(GR4HIP_I64, int64_t);
+        GR4_EWD(GR4HIP_F32, float); GR4_EWD(GR4HIP_F64, double); GR4_EWD(GR4HIP_C32, float2);
+    default: hipLaunchKernelGGL(ewise_decimate_kernel<double2>, dim3(grid), dim3(256), 0, st, static_cast<const double2*>(d_in), static_cast<double2*>(d_out), (long)n_out, (long)decim, prog); break;
+    }
+#undef GR4_EWD
+    GR4_LAUNCH_CHECK();
+    p->pos += (long)n_out;
     return GR4HIP_OK;
 }
 

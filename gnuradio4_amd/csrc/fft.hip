@@ -376,6 +376,7 @@ struct gr4hip_fft {
     Pow2Engine   eng;  // the power-of-two transform both are built on (kind 1: of N points, kind 2: of M points)
     DeviceBuffer d_chirp, d_chirpF, d_scratchA, d_scratchB;
     gr4::ChainFused* pipe = nullptr; // N = 8192 complex, |X|^2 only: the persistent frame pipeline of chain_fused.hip (built on first use)
+    gr4hip_ewise*    post = nullptr; // gr4hip_fft_set_epilogue: float blocks behind |X|^2, in the transform's launch
     ~gr4hip_fft();
 };
 
@@ -718,21 +719,40 @@ int gr4hip_fft_spectrum(gr4hip_fft_t* f, const void* d_in, size_t n_frames, floa
     return fft_run(f, d_in, n_frames, o, nullptr, nullptr, stream);
 }
 
-gr4hip_fft::~gr4hip_fft() { if (pipe) gr4::chain_fused_destroy(pipe); }
+gr4hip_fft::~gr4hip_fft() { if (pipe) gr4::chain_fused_destroy(pipe); delete post; }
+
+int gr4hip_fft_set_epilogue(gr4hip_fft_t* f, const gr4hip_ewise_t* prog) {
+    GR4_REQUIRE(f, "fft_set_epilogue: null handle");
+    if (prog && prog->dtype != GR4HIP_F32) { set_error("fft_set_epilogue: |X|^2 is a float stream, the program's dtype is %d", prog->dtype); return GR4HIP_UNSUPPORTED; }
+    gr4hip_ewise* copy = nullptr;
+    if (prog && !prog->user.empty()) {
+        copy = ewise_clone(prog);
+        GR4_REQUIRE(copy, "out of host memory");
+    }
+    delete f->post;
+    f->post = copy;
+    return GR4HIP_OK;
+}
 
 int gr4hip_fft_mag2(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float* d_mag2, gr4hip_stream_t stream) {
     GR4_REQUIRE(d_mag2 || n_frames == 0, "fft_mag2: null output");
     GR4_REQUIRE(f, "fft_mag2: null handle");
+    EwiseHook post;
+    if (f->post) { if (const int rc = ewise_device_ops(f->post, &post)) return rc; }
     // 8192-point complex frames, >= one frame per CU: the frame pipeline of the fused chain kernel without its filter (LDS-DMA prefetch of the next
     // frame during the transform of this one); everything else goes to the FFT block kernels
     if (fft_on_frame_pipeline(f, n_frames)) {
         int rc = fft_pipe(f);
         if (rc) return rc;
         const bool windowed = f->window != GR4HIP_WIN_NONE && f->window != GR4HIP_WIN_RECTANGULAR;
-        return gr4::chain_fused_fft_mag2(f->pipe, static_cast<const float*>(d_in), n_frames, d_mag2, windowed ? static_cast<const float*>(f->d_window.ptr) : nullptr, as_stream(stream));
+        rc = gr4::chain_fused_fft_mag2(f->pipe, static_cast<const float*>(d_in), n_frames, d_mag2, windowed ? static_cast<const float*>(f->d_window.ptr) : nullptr, as_stream(stream));
+        // (the frame pipeline has no store hook: an epilogue is one element-wise launch over its output, in place)
+        if (!rc && post.n_ops > 0) rc = ewise_run(post, GR4HIP_F32, d_mag2, d_mag2, (long)(n_frames * f->N), as_stream(stream));
+        return rc;
     }
     FftOutputs o{};
-    o.mag2 = d_mag2;
+    o.mag2      = d_mag2;
+    o.mag2_post = post; // every kernel of this file stores |X|^2 through emit_bin or the fast kernel's register epilogue: the program rides in the transform's launch
     return fft_run(f, d_in, n_frames, o, nullptr, nullptr, stream);
 }
 

@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fft_radix.hpp"
+#include "ewise.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -33,6 +34,7 @@ struct FftOutputs {
     float* mag2;      // natural order
     float* ranges;    // fast kernels only: [frames][4][2] {min, max} of magnitude, phase, Re, Im (fft.hpp:229-232); null = not requested
     int    in_db, in_deg, real_input;
+    EwiseHook mag2_post; // per-sample float blocks behind a PowerSpectrum (MultiplyConst / AddConst ...: gr4hip_fft_set_epilogue): applied to |X|^2 before its store
 };
 
 // every requested output of one natural-order bin k of one frame (fft.hpp:164-166, fft_common.hpp:20-56, 91-123)
@@ -40,7 +42,11 @@ __device__ __forceinline__ void emit_bin(const FftOutputs& out, long frame, int 
     const int half = N / 2;
     const int nout = out.real_input ? half : N;
     if (out.spectrum) reinterpret_cast<float2*>(out.spectrum)[frame * N + k] = X;
-    if (out.mag2) out.mag2[frame * N + k] = fmaf(X.x, X.x, X.y * X.y);
+    if (out.mag2) {
+        float m = fmaf(X.x, X.x, X.y * X.y);
+        if (out.mag2_post.n_ops > 0) m = ewise_hook1<float>(m, out.mag2_post, frame * N + k);
+        out.mag2[frame * N + k] = m;
+    }
     if (out.real_input) {
         if (k >= half) {
             if (out.re) out.re[frame * half + (k - half)] = X.x;
@@ -291,8 +297,12 @@ __global__ __launch_bounds__(512, 4) void fft_fast_kernel(const float* __restric
         }
         if (out.mag2) {
             const rsrc_t r = make_rsrc(out.mag2 + f0 * N, nlive * N * 4u);
+            float m[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) buf_store_f(r, fmaf(X[j].x, X[j].x, X[j].y * X[j].y), eN * 4, j * ST * 4);
+            for (int j = 0; j < 16; ++j) m[j] = fmaf(X[j].x, X[j].x, X[j].y * X[j].y);
+            if (out.mag2_post.n_ops > 0) ewise_apply<float, 16>(m, out.mag2_post.ops, out.mag2_post.n_ops, out.mag2_post.has_div, [](int) { return 0L; }); // (float programs have no index-dependent op)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) buf_store_f(r, m[j], eN * 4, j * ST * 4);
         }
         if (!out.real_input) { // N bins; magnitude and phase are fftshift-ed (bin k -> (k + N/2) mod N), Re/Im natural
             if (out.re) {

@@ -304,12 +304,29 @@ struct PowerSpectrumStage final : Stage {
     gr4hip_fft_t* h = nullptr;
     std::size_t   N;
     int           window;
+    EwiseProgram  post; // float blocks behind |X|^2 (normalisation, an offset): in the transform's launch (gr4hip_fft_set_epilogue)
+    std::string   _kind = "power_spectrum_c32";
     PowerSpectrumStage(std::size_t fftSize, int win) : N(fftSize), window(win) {
         in_bytes = 8; out_bytes = 4; in_chunk = out_chunk = fftSize;
+        post.dtype = GR4HIP_F32;
         check(gr4hip_fft_create(&h, GR4HIP_C32, fftSize, win, 0), "gr4hip_fft_create");
     }
     ~PowerSpectrumStage() override { gr4hip_fft_destroy(h); }
-    std::string_view kind() const override { return "power_spectrum_c32"; }
+    std::string_view kind() const override { return _kind; }
+    void apply() {
+        gr4hip_ewise_t* prog = post.empty() ? nullptr : post.make();
+        const int       rc   = gr4hip_fft_set_epilogue(h, prog);
+        if (prog) gr4hip_ewise_destroy(prog);
+        check(rc, "gr4hip_fft_set_epilogue");
+        _kind = post.empty() ? "power_spectrum_c32" : "power_spectrum_c32[post: " + post.describe() + "]";
+    }
+    bool absorb(const EwiseProgram& p, bool before) override {
+        if (before || p.dtype != GR4HIP_F32) return false;
+        post.append(p);
+        apply();
+        return true;
+    }
+    void clear_absorbed() override { if (!post.empty()) { post.ops.clear(); apply(); } }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
         *n_out = (n / N) * N;
         return gr4hip_fft_mag2(h, in, n / N, static_cast<float*>(out), s);
@@ -437,10 +454,31 @@ struct IirStage final : Stage {
 
 template <typename T>
 struct DecimatorStage final : Stage {
-    std::size_t decim;
-    explicit DecimatorStage(std::size_t d) : decim(std::max<std::size_t>(1, d)) { in_bytes = out_bytes = sizeof(T); in_chunk = decim; out_chunk = 1; }
-    std::string_view kind() const override { return "decimator"; }
-    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override { return gr4hip_decimate(dtype_of<T>(), in, n, decim, out, n_out, s); }
+    std::size_t      decim;
+    EwiseProgram     absorbed; // per-sample blocks around the decimator, all applied BEHIND it (memoryless blocks commute with dropping samples): one launch
+    gr4hip_ewise_t*  h = nullptr;
+    std::string      _kind = "decimator";
+    explicit DecimatorStage(std::size_t d) : decim(std::max<std::size_t>(1, d)) { in_bytes = out_bytes = sizeof(T); in_chunk = decim; out_chunk = 1; absorbed.dtype = dtype_of<T>(); }
+    ~DecimatorStage() override { if (h) gr4hip_ewise_destroy(h); }
+    std::string_view kind() const override { return _kind; }
+    void refresh() {
+        if (h) gr4hip_ewise_destroy(h);
+        h     = absorbed.empty() ? nullptr : absorbed.make();
+        _kind = absorbed.empty() ? "decimator" : "decimator[post: " + absorbed.describe() + "]";
+    }
+    bool absorb(const EwiseProgram& p, bool before) override {
+        if (p.dtype != dtype_of<T>()) return false;
+        for (const auto& o : p.ops)
+            if (before && o.kind == EwiseProgram::kRotator) return false; // a rotator's phase counts samples: it does not commute with dropping them
+        if (before) absorbed.prepend(p); else absorbed.append(p);
+        refresh();
+        return true;
+    }
+    void clear_absorbed() override { if (!absorbed.empty()) { absorbed.ops.clear(); refresh(); } }
+    int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
+        if (h) return gr4hip_ewise_decimate(h, in, n, decim, out, n_out, s);
+        return gr4hip_decimate(dtype_of<T>(), in, n, decim, out, n_out, s);
+    }
 };
 
 // interpolating FIR: polyphase kernel, n_out = n L
@@ -786,6 +824,7 @@ inline std::unique_ptr<Stage> fuse_fir_decimator(Stage& a, Stage& b) {
     if (!fir || !dec || fir->decim != 1 || dec->decim < 2 || !fir->absorbed.post.empty()) return nullptr;
     auto fused = std::make_unique<FirStage<T>>(fir->taps, dec->decim);
     if (!fir->absorbed.pre.empty() && !fused->absorb(fir->absorbed.pre, true)) return nullptr;
+    if (!dec->absorbed.empty() && !fused->absorb(dec->absorbed, false)) return nullptr; // what the decimator had taken in rides behind the decimating filter
     return fused;
 }
 inline std::unique_ptr<Stage> fuse_pair(Stage& a, Stage& b); // defined below ChainStage's users
@@ -980,7 +1019,7 @@ inline std::unique_ptr<Stage> fuse_pair(Stage& a, Stage& b) {
     if (auto f = fuse_fir_decimator<std::complex<float>>(a, b)) return f;
     auto* fir  = dynamic_cast<FirStage<std::complex<float>>*>(a.self());
     auto* spec = dynamic_cast<PowerSpectrumStage*>(b.self());
-    if (fir && spec && fir->decim == 1 && fir->absorbed.post.empty()) { // the fused FIR -> FFT -> |.|^2 kernel; a gain in front of the filter rides in its taps
+    if (fir && spec && fir->decim == 1 && fir->absorbed.post.empty() && spec->post.empty()) { // the fused FIR -> FFT -> |.|^2 kernel; a gain in front of the filter rides in its taps
         double g = 1.0;
         if (!fir->absorbed.pre.empty() && !AbsorbedPrograms::real_gain(fir->absorbed.pre, &g)) return nullptr;
         std::vector<float> taps(fir->taps.size());

@@ -611,6 +611,47 @@ int main(int argc, char** argv) {
             std::printf("planner (gain -> fir -> Decimator -> add): 1 run: %s, max rel err vs the host graph %.3g%s\n", desc.c_str(), e, e <= 1e-5 ? "" : "  FAILED");
             if (!(e <= 1e-5) || desc != "fir_f32/5[pre: mul; post: add]") ++errors;
         }
+        { // (v) per-sample blocks around a Decimator ride behind it in its launch (they commute with dropping samples); float blocks behind a PowerSpectrum ride in the
+          //     transform's launch.  Against the same graphs on the host
+            std::vector<std::int32_t> xi(90001);
+            for (auto& v : xi) { lcg = lcg * 1664525u + 1013904223u; v = static_cast<std::int32_t>(lcg >> 4); }
+            std::vector<std::int32_t> gi[2];
+            std::vector<float>        gs[2];
+            std::string               d1, d2;
+            for (int dev = 1; dev >= 0; --dev) {
+                Graph g;
+                const auto dom = [&](property_map m) { if (dev) m["compute_domain"] = "gpu:hip:0"s; return m; };
+                auto& src  = g.emplaceBlock<testing::VectorSource<std::int32_t>>();
+                src.values = xi;
+                auto& add  = g.emplaceBlock<AddConst<std::int32_t>>(dom({{"value", std::int64_t(12345)}}));
+                auto& dec  = g.emplaceBlock<filter::Decimator<std::int32_t>>(dom({{"decim", std::int64_t(7)}}));
+                auto& mul  = g.emplaceBlock<MultiplyConst<std::int32_t>>(dom({{"value", std::int64_t(-3)}}));
+                auto& sink = g.emplaceBlock<testing::VectorSink<std::int32_t>>();
+                auto& csrc = g.emplaceBlock<testing::VectorSource<std::complex<float>>>({{"n_samples_max", std::int64_t(40 * 256)}});
+                csrc.values = x;
+                auto& spec = g.emplaceBlock<blocks::fft::PowerSpectrum<std::complex<float>>>(dom({{"fftSize", std::int64_t(256)}, {"window", "Hann"s}}));
+                auto& nrm  = g.emplaceBlock<DivideConst<float>>(dom({{"value", 65536.0}}));
+                auto& off  = g.emplaceBlock<AddConst<float>>(dom({{"value", 0.5}}));
+                auto& ssnk = g.emplaceBlock<testing::VectorSink<float>>();
+                if (!g.connect<"out", "in">(src, add) || !g.connect<"out", "in">(add, dec) || !g.connect<"out", "in">(dec, mul) || !g.connect<"out", "in">(mul, sink) ||
+                    !g.connect<"out", "in">(csrc, spec) || !g.connect<"out", "in">(spec, nrm) || !g.connect<"out", "in">(nrm, off) || !g.connect<"out", "in">(off, ssnk)) ++errors;
+                if (dev) {
+                    const auto runs = hip::plan(g);
+                    if (runs.size() != 2) { ++errors; break; }
+                    d1 = std::string(runs[0]->description());
+                    d2 = std::string(runs[1]->description());
+                }
+                scheduler::Simple sched;
+                sched.exchange(std::move(g));
+                if (const auto r = sched.runAndWait(); !r) { std::cerr << "decimator / spectrum hooks: " << r.error().message << "\n"; ++errors; }
+                gi[dev] = sink._samples;
+                gs[dev] = ssnk._samples;
+            }
+            const double e = gs[1].size() == 40 * 256 && gs[0].size() == gs[1].size() ? max_rel(gs[1], gs[0]) : 1e30;
+            std::printf("planner (blocks around a Decimator, behind a PowerSpectrum): [%s] %s the host graph; [%s] max rel err %.3g%s\n", d1.c_str(), gi[1] == gi[0] && !gi[1].empty() ? "bit-identical to" : "DIFFERS from",
+                        d2.c_str(), e, e <= 1e-5 ? "" : "  FAILED");
+            if (gi[1] != gi[0] || gi[1].size() != xi.size() / 7 /* whole decimation groups: input_chunk_size = decim */ || !(e <= 1e-5) || d1 != "decimator[post: add,mul]" || d2 != "power_spectrum_c32[post: div,add]") ++errors;
+        }
     }
     { // 5b. the multi-channel graph of BASELINE configs[4] in the C++ API: every channel its own planned device run (fir_filter -> PowerSpectrum fused), channel c on
       //     device c mod <devices> (one here; the runs set their device on every work() call), the fan-in combiner math::Add<float> with n_inputs = channels

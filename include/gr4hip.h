@@ -86,6 +86,7 @@ typedef enum { /* how the FIR->FFT->mag2 chain is executed */
                               inputs whose out-of-band content dwarfs the filtered output (see gr4hip_fir_set_algo), and where the dynamic-range guard sends a stream */
 } gr4hip_chain_algo_t;
 
+typedef struct gr4hip_ewise gr4hip_ewise_t; /* a run of per-sample blocks (gr4hip_ewise_* below) */
 typedef void* gr4hip_stream_t; /* hipStream_t */
 typedef void* gr4hip_event_t;  /* hipEvent_t  */
 
@@ -97,7 +98,7 @@ const char* gr4hip_last_error(void); /* thread-local text of the last failure */
  * Nothing here changes the meaning of a call -- choices that do (exact float32 FIR arithmetic, the rotator's phase recurrence, the chain's algorithm and
  * guard) are per-handle settings: gr4hip_fir_set_algo, gr4hip_rotator_set_algo, gr4hip_chain_create / gr4hip_chain_set_guard_mode.
  * Names: GR4HIP_FIR_NO_BF16X3, GR4HIP_FIR_NO_DECIM_FD, GR4HIP_IIR_THREE_PASS, GR4HIP_IIR_LOOKBACK, GR4HIP_IIR_NO_SPLIT, GR4HIP_FFT_BLUESTEIN_PIPELINE,
- * GR4HIP_FFT_NO_PIPELINE, GR4HIP_ROTATOR_LEAP, GR4HIP_ROTATOR_WALK, GR4HIP_CHAIN16, GR4HIP_FFT_SMOOTH_RUNTIME. */
+ * GR4HIP_FFT_NO_PIPELINE, GR4HIP_ROTATOR_LEAP, GR4HIP_ROTATOR_WALK, GR4HIP_CHAIN16, GR4HIP_FFT_SMOOTH_RUNTIME, GR4HIP_EWISE_NO_DIV_RCP. */
 int gr4hip_developer_switch(const char* name, int value);
 const char* gr4hip_status_string(int status);
 int         gr4hip_device_count(int* count);
@@ -260,6 +261,10 @@ int gr4hip_fft_process(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, flo
 int gr4hip_fft_spectrum(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, float* d_spectrum, gr4hip_stream_t stream);
 /* |X[k]|^2 in natural bin order: mag2[(k + N/2) % N] == (magnitude_block[k] * N/2)^2 */
 int gr4hip_fft_mag2(gr4hip_fft_t* fft, const void* d_in, size_t n_frames, float* d_mag2, gr4hip_stream_t stream);
+/* Per-sample float blocks BEHIND a power spectrum (MultiplyConst / DivideConst / AddConst / SubtractConst<float> on the |X|^2 stream: normalisation, an offset) in the
+ * transform's launch: the program (gr4hip_ewise_t of dtype F32, copied; NULL or empty removes it) is applied to every |X|^2 value of gr4hip_fft_mag2 before its store --
+ * natively in every transform kernel of the FFT block (one launch); the 8192-point frame pipeline runs it as one element-wise launch over its output inside the call. */
+int gr4hip_fft_set_epilogue(gr4hip_fft_t* fft, const gr4hip_ewise_t* f32_prog);
 int gr4hip_fft_destroy(gr4hip_fft_t* fft);
 /* Which device path a size takes (host-only, no device needed): kind 0 = power of two <= 8192 (one kernel), 3 = {2,3,5}-smooth <= 8192 (mixed-radix passes in one
  * launch: the sizes SimdFFT::canProcessSize takes with radix-3 / radix-5 passes, SimdFFT.hpp:348-375; radices[0 .. n_passes) is the run-time plan, <= 15 passes of
@@ -359,7 +364,6 @@ int gr4hip_math_nary(int op, int dtype, const void* const* h_d_ins, size_t n_inp
  * -- that gr4hip_ewise_process runs as ONE launch with the values in registers: 2 sizeof(T) bytes of HBM traffic per sample whatever the number of ops.
  * The same program can ride in the launch of a neighbouring filter as its load hook (prologue) or store hook (epilogue): gr4hip_fir_set_prologue / _epilogue below.
  * A program holds no device state besides its op list; the stream position (what a rotator op's phase is a function of) is advanced by gr4hip_ewise_process. */
-typedef struct gr4hip_ewise gr4hip_ewise_t;
 int gr4hip_ewise_create(gr4hip_ewise_t** prog, int dtype);
 int gr4hip_ewise_append_const(gr4hip_ewise_t* prog, int op, const void* h_value); /* h_value: one host element of the program's dtype */
 int gr4hip_ewise_append_rotator(gr4hip_ewise_t* prog, float phase_increment, float initial_phase);
@@ -367,6 +371,10 @@ int gr4hip_ewise_length(const gr4hip_ewise_t* prog, size_t* n_ops);
 int gr4hip_ewise_reset(gr4hip_ewise_t* prog); /* stream position back to 0: rotator ops restart from their initial phase */
 int gr4hip_ewise_position(const gr4hip_ewise_t* prog, uint64_t* samples);
 int gr4hip_ewise_process(gr4hip_ewise_t* prog, const void* d_in, void* d_out, size_t n, gr4hip_stream_t stream); /* in place (d_in == d_out) is allowed */
+/* gr::filter::Decimator<T> (time_domain_filter.hpp:234-244) with the program's blocks BEHIND it in one launch: d_out[m] = program(d_in[m * decim]), m < ceil(n_in / decim);
+ * only the kept samples are read.  The stream position (rotator phase) counts OUTPUT samples.  Memoryless blocks in front of a Decimator commute with it, so a planner
+ * that finds const blocks on either side of one hands them all to this call. */
+int gr4hip_ewise_decimate(gr4hip_ewise_t* prog, const void* d_in, size_t n_in, size_t decim, void* d_out, size_t* n_out, gr4hip_stream_t stream);
 int gr4hip_ewise_destroy(gr4hip_ewise_t* prog);
 /* Neighbours of a FIR filter in ITS launch.  prologue: applied to every input sample before the filter sees it (the history the filter carries is the history of
  * the prologue's OUTPUT, zero before the first sample, exactly as if the blocks ran one after the other); epilogue: applied to every output sample before it is

@@ -217,3 +217,65 @@ def test_fir_hook_dtype_mismatch_is_refused(G):
     with pytest.raises(G.capi.Gr4HipError) as e:
         f.set_prologue(G.Merged(torch.complex64, [("Rotator", 0.1)]))
     assert e.value.status == G.capi.UNSUPPORTED
+
+
+def test_decimator_takes_the_blocks_behind_it(G):
+    """Decimator<T> + per-sample blocks in one launch (only the kept samples are read): bit-exact for an integer type, a rotator behind the decimator counts OUTPUT samples"""
+    rng = np.random.default_rng(3)
+    x = _rand(5, 100_001, rng)
+    ops = [("Multiply", np.int16(7)), ("Add", np.int16(-300)), ("Divide", np.int16(3))]
+    for decim in (1, 3, 8, 100):
+        want = _chain_on_cpu(5, np.ascontiguousarray(x[::decim]), ops)
+        got = G.Merged(torch.int16, ops).decimate(dev(x), decim).cpu().numpy()
+        assert np.array_equal(got, want), decim
+    xc = O.signal_c32(3, 80_000)
+    m = G.Merged(torch.complex64, [("Rotator", 0.25, 0.5), ("Multiply", 2.0)])
+    got = np.concatenate([m.decimate(dev(xc[:40_000]), 8).cpu().numpy(), m.decimate(dev(xc[40_000:]), 8).cpu().numpy()])
+    rot, _ = O.rotator(xc[::8].astype(np.complex128), float(np.float32(0.25)), float(np.float32(0.5)))
+    assert np.max(np.abs(got - 2.0 * rot)) <= 1e-5 * np.max(np.abs(rot))
+
+
+@pytest.mark.parametrize("N,frames", [(1024, 40), (256, 33), (1000, 12), (6, 50), (8192, 300), (16384, 3), (1009, 4)])
+def test_power_spectrum_takes_the_blocks_behind_it(G, N, frames):
+    """float blocks behind a power spectrum -- |X|^2 / N^2 + offset -- ride in the transform's launch (gr4hip_fft_set_epilogue): every kernel family of the FFT block
+    (fast power-of-two, mixed-radix, small block kernel, the 8192-point frame pipeline, four-step, chirp), against the separate blocks on the same output"""
+    x = O.signal_c32(N, N * frames)
+    ops = [("Divide", float(N) * N), ("Multiply", 3.0), ("Add", 0.125)]
+    plain = G.FFT(N, "Hann").mag2(dev(x))
+    want = G.Merged(torch.float32, ops).process_bulk(plain.reshape(-1)).cpu().numpy()
+    f = G.FFT(N, "Hann")
+    f.set_epilogue(G.Merged(torch.float32, ops))
+    got = f.mag2(dev(x)).cpu().numpy().ravel()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # the same float operations on the same |X|^2
+    f.set_epilogue(None)
+    assert torch.equal(f.mag2(dev(x)), plain)
+    with pytest.raises(G.capi.Gr4HipError):
+        f.set_epilogue(G.Merged(torch.complex64, [("Add", 1)]))
+
+
+def test_division_by_a_constant_is_the_ieee_quotient_for_every_float(G):
+    """DivideConst<float> inside a merged program multiplies by the correctly rounded reciprocal and corrects with two fused multiply-adds (three operations instead of
+    the general quotient's eleven).  That this IS the IEEE quotient is not argued but checked: ALL 2^32 float bit patterns (zeros, subnormals, infinities, NaNs included)
+    through both forms, for constants across the admitted range, compared bit for bit on the device"""
+    consts = [3.0, 0.7, 10.0, 0.1, -1.5, 1.25, 7.0e-9, 9.87654e11, 1.0000001, 0.99999994, 3.4028235e-12, 12345.678, float(np.float32(2.0) ** -40), float(np.float32(2.0) ** 40)]
+    chunk = 1 << 28
+    base = torch.arange(chunk, dtype=torch.int64, device="cuda")
+    for c in consts:
+        fast = G.Merged(torch.float32, [("Divide", c)])
+        G.capi.developer_switch("GR4HIP_EWISE_NO_DIV_RCP", 1)
+        try:
+            slow = G.Merged(torch.float32, [("Divide", c)])
+            slow.process_bulk(torch.zeros(8, device="cuda"))  # (the program is compiled at its first launch: with the switch set)
+        finally:
+            G.capi.developer_switch("GR4HIP_EWISE_NO_DIV_RCP", 0)
+        fast.process_bulk(torch.zeros(8, device="cuda"))
+        for k in range(16):
+            bits = (base + k * chunk).to(torch.int32) if k < 8 else (base + k * chunk - (1 << 32)).to(torch.int32)
+            x = bits.view(torch.float32)
+            a, b = fast.process_bulk(x), slow.process_bulk(x)
+            same = a.view(torch.int32) == b.view(torch.int32)
+            if not bool(same.all()):
+                bad = (~same).nonzero()[:4].ravel().tolist()
+                raise AssertionError((c, k, [(float(x[i]), float(a[i]), float(b[i])) for i in bad]))
+        want = (np.float32(1.2345) / np.float32(c))
+        assert fast.process_bulk(torch.full((4,), 1.2345, device="cuda"))[0].item() == want

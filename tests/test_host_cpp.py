@@ -207,6 +207,7 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     # ... three graph blocks are one stage, one launch per chunk; fir_filter -> Decimator is the polyphase decimating FIR with its neighbours absorbed
     assert "planner (math chain): 1 run: ewise[mul,div,add]  (1 stage, 1 launch), output bit-identical to the host graph" in r.stdout
     assert "planner (gain -> fir -> Decimator -> add): 1 run: fir_f32/5[pre: mul; post: add]" in r.stdout
+    assert "planner (blocks around a Decimator, behind a PowerSpectrum): [decimator[post: add,mul]] bit-identical to the host graph; [power_spectrum_c32[post: div,add]] max rel err" in r.stdout
     # ... and the channeliser Rotator -> BasicDecimatingFilter<complex<float>> -> PowerSpectrum is two launches per chunk with only the decimated stream in HBM:
     # the rotator is the filter's load hook.  Against the oracle: float64 rotator, float64 FIR on the rotator's float32 output, every 8th sample, 256-point Hann frames
     assert "planner (channeliser): 1 run: basic_fir_decim[pre: rot] -> power_spectrum_c32  (2 stages, 2 launches" in r.stdout
