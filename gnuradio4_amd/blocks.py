@@ -209,6 +209,20 @@ class iir_filter(_Handle):
         return out
 
 
+def fir_iir_process(fir: "fir_filter", iir: "iir_filter", x: torch.Tensor, out: Optional[torch.Tensor] = None, mode: int = 0) -> torch.Tensor:
+    """BasicDecimatingFilter (FIR) -> IIR cascade in one call (gr4hip_fir_iir_process, BASELINE configs[2]).  mode capi.FIR_IIR_ONE_LAUNCH: the cascade as the
+    frequency-domain decimator's store epilogue where both qualify -- one launch, no decimated stream in HBM; FIR_IIR_TWO_LAUNCHES; FIR_IIR_AUTO (0): the faster one
+    as measured (two launches).  Both handles keep their own state"""
+    x = _dev(x, "fir_iir_process")
+    if x.dtype != torch.float32 or fir.dtype != torch.float32 or iir.dtype != torch.float32:
+        raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "fir_iir_process", "float32 stream, filter and cascade")
+    n_out = x.numel() // fir.decimate
+    if out is None:
+        out = torch.empty(n_out, dtype=torch.float32, device=x.device)
+    check(lib().gr4hip_fir_iir_process(fir._h, iir._h, x.data_ptr(), x.numel(), out.data_ptr(), None, int(mode), _stream()), "fir_iir_process")
+    return out
+
+
 def design_fir(filter_response: int, order: int, f_low: float, f_high: float, sample_rate: float, window="Kaiser", gain=1.0,
                attenuation_db=40.0, beta=1.6) -> np.ndarray:
     """fir::designFilter<float> (FilterTool.hpp:1006-1071) through the library's host-side restatement."""

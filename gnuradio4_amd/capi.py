@@ -21,6 +21,7 @@ GUARD_STRICT, GUARD_DEFERRED, GUARD_OFF = range(3)
 FIR_AUTO, FIR_TIME_DOMAIN, FIR_EXACT_F32, FIR_TIME_DOMAIN_F32 = range(4)
 ROTATOR_CLOSED_FORM, ROTATOR_RECURRENCE = range(2)
 IIR_AUTO, IIR_PARALLEL, IIR_SEQUENTIAL_F32 = range(3)
+FIR_IIR_AUTO, FIR_IIR_ONE_LAUNCH, FIR_IIR_TWO_LAUNCHES = range(3)
 SYNTH_MIX = 0xd1b54a32d192ed03  # group g of a synth stream: Xoshiro256pp(seed ^ SYNTH_MIX * (g + 1)) (include/gr4hip.h)
 
 
@@ -99,6 +100,7 @@ SIGNATURES = {
     "gr4hip_iir_set_algo": (_i, [_vp, _i]),
     "gr4hip_iir_get_algo": (_i, [_vp, _pi, _pf, _pf]),
     "gr4hip_iir_destroy": (_i, [_vp]),
+    "gr4hip_fir_iir_process": (_i, [_vp, _vp, _vp, _sz, _vp, _psz, _i, _vp]),
     "gr4hip_filter_params_default": (_i, [_vp]),
     "gr4hip_fir_design": (_i, [_i, _vp, _i, _vp, _sz, _psz]),
     "gr4hip_iir_design": (_i, [_i, _vp, _i, _vp, _vp, _sz, _psz]),

@@ -222,7 +222,8 @@ struct FirDecimFd;
 int  fir_decim_fd_supported(size_t ntaps, size_t decim);
 int  fir_decim_fd_create(FirDecimFd** out, const float* taps, size_t ntaps);
 void fir_decim_fd_destroy(FirDecimFd* c);
-int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st, bool measure);
+struct DecimFdIir { const float* tab; int nsec; const float* state_in; float* state_out; int warm_blocks; };
+int  fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st, bool measure, const DecimFdIir* iir = nullptr);
 int  fir_decim_fd_power_ratio(FirDecimFd* c, bool wait, float* ratio);
 
 // fir_batched.hip: block-Toeplitz FIR on the f32 MFMA units (real, <= 256 taps)
@@ -293,6 +294,7 @@ struct gr4hip_fir {
     long               pos = 0;        // input samples consumed since create / reset: the absolute index a rotator op's phase is a function of
     double             hist_gain = 1.0; // the stored history times this = what the prologue made of those samples (a folded prologue gain keeps RAW samples in the
                                         // history -- the taps carry the gain --, a hooked prologue keeps its outputs there: 1)
+    DeviceBuffer       d_mid;          // gr4hip_fir_iir_process, two-launch path: the decimated stream between the filter and the cascade
     DeviceBuffer       d_pre;          // long spans of filters that take a matrix-pipe kernel: the prologue's output (one element-wise launch in front of it)
     ~gr4hip_fir() { delete pre; delete post; }
 };
@@ -812,6 +814,66 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     }
     f->cur ^= 1;
     f->pos += (long)n_in;
+    return GR4HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decimating FIR -> IIR cascade (BASELINE configs[2])
+int  gr4hip_internal_iir_fusable(gr4hip_iir_t* f, const float** d_tab, int* nsec, const float** d_state_in, float** d_state_out, int* warm_blocks); // iir.hip
+void gr4hip_internal_iir_commit(gr4hip_iir_t* f);
+
+extern "C" int gr4hip_fir_iir_process(gr4hip_fir_t* f, gr4hip_iir_t* iir, const float* d_in, size_t n_in, float* d_out, size_t* n_out_p, int mode, gr4hip_stream_t stream) {
+    GR4_REQUIRE(f && iir, "fir_iir_process: null handle");
+    GR4_REQUIRE(mode >= GR4HIP_FIR_IIR_AUTO && mode <= GR4HIP_FIR_IIR_TWO_LAUNCHES, "fir_iir_process: unknown mode %d", mode);
+    GR4_REQUIRE(f->dtype == GR4HIP_F32, "fir_iir_process: a float filter in front of the float cascade");
+    GR4_REQUIRE(n_in % f->decim == 0, "fir_iir_process: n_in=%zu is not a multiple of decim=%zu", n_in, f->decim);
+    const size_t n_out = n_in / f->decim;
+    if (n_out_p) *n_out_p = n_out;
+    if (n_in == 0) return GR4HIP_OK;
+    GR4_REQUIRE(d_in && d_out, "fir_iir_process: null device pointer");
+    hipStream_t  st = as_stream(stream);
+    const auto two_launches = [&](const float* x, size_t n, float* y) -> int { // the decimated stream through HBM (f->d_pre as scratch)
+        if (const int rc = f->d_mid.ensure(std::max<size_t>(n / f->decim, 1) * sizeof(float))) return rc;
+        float* mid = static_cast<float*>(f->d_mid.ptr);
+        if (const int rc = gr4hip_fir_process(f, x, n, mid, nullptr, stream)) return rc;
+        return gr4hip_iir_process(iir, mid, n / f->decim, y, stream);
+    };
+    constexpr size_t kHop = 7168, kMinBlocks = 64;
+    const float*     tab = nullptr;
+    const float*     st_in = nullptr;
+    float*           st_out = nullptr;
+    int              nsec = 0, warm = 0;
+    const size_t     whole = n_in / kHop * kHop;
+    const bool       fusable = mode == GR4HIP_FIR_IIR_ONE_LAUNCH && f->S == 1 && f->decim == 8 && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked && !f->pre && !f->post && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 &&
+                         whole >= kMinBlocks * kHop && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0 && !dev_switch(kDevFirNoDecimFd) &&
+                         gr4hip_internal_iir_fusable(iir, &tab, &nsec, &st_in, &st_out, &warm);
+    if (!fusable) return two_launches(d_in, n_in, d_out);
+    int rc = GR4HIP_OK;
+    if (!f->dfd) rc = fir_decim_fd_create(&f->dfd, f->taps.data(), f->ntaps);
+    if (rc) return rc;
+    // the decimator's dynamic-range guard as in gr4hip_fir_process: its own measurement decides (strict: before this call returns -- nothing of the launch is kept, the
+    // cascade's state included), a finished earlier launch decides (deferred)
+    constexpr float kDecimFdMinPowerRatio = 2.5e-3f;
+    const bool      guarded = f->guard_mode != GR4HIP_GUARD_OFF && f->ntaps > 1;
+    float           ratio;
+    if (guarded && fir_decim_fd_power_ratio(f->dfd, false, &ratio)) f->fd_ratio = ratio;
+    if (guarded && f->guard_mode == GR4HIP_GUARD_DEFERRED && f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) { f->fd_blocked = f->f32_products = true; return two_launches(d_in, n_in, d_out); }
+    const float*     hist = (const float*)f->d_hist[f->cur].ptr;
+    const DecimFdIir fuse{tab, nsec, st_in, st_out, warm};
+    rc = fir_decim_fd_run(f->dfd, d_in, whole, hist, (int)f->hcap, d_out, st, guarded, &fuse);
+    if (rc) return rc;
+    if (guarded && f->guard_mode == GR4HIP_GUARD_STRICT) {
+        if (fir_decim_fd_power_ratio(f->dfd, true, &ratio)) f->fd_ratio = ratio;
+        if (f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) { f->fd_blocked = f->f32_products = true; return two_launches(d_in, n_in, d_out); } // (neither handle has moved)
+    }
+    gr4hip_internal_iir_commit(iir);
+    {   // the filter's history moves behind the whole blocks
+        const long tot = (long)f->hcap;
+        hipLaunchKernelGGL(fir_hist_update_kernel, dim3((unsigned)ceil_div(tot, 256L)), dim3(256), 0, st, d_in, hist, (float*)f->d_hist[f->cur ^ 1].ptr, (long)whole, (int)f->hcap, 1);
+        GR4_LAUNCH_CHECK();
+        f->cur ^= 1;
+        f->pos += (long)whole;
+    }
+    if (whole < n_in) return two_launches(d_in + whole, n_in - whole, d_out + whole / 8); // what is left of the span (< one block): the polyphase kernel and the cascade's own
     return GR4HIP_OK;
 }
 

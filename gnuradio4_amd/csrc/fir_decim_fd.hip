@@ -62,8 +62,90 @@ struct DecimFdArgs {
     float*        pw_host; // page-locked, device-mapped {in, out, sequence number}: written by the last workgroup to finish
     unsigned      pw_seq;
     float         pw_thr;  // a block whose output power is below pw_thr x its input power marks the launch (word 33 of pw, word 3 of pw_host)
+    // fir_decim_fd_kernel<true>: the biquad cascade behind the decimator (Filter<float>::processOne over the sections, FilterTool.hpp:244-246) in the SAME launch --
+    // BASELINE configs[2] without the decimated stream in HBM.  y then receives the cascade's output.
+    const float*  iir;           // [iir_nsec][32]: b0 b1 b2 a1 a2 - - - | P_k (k < 5): A^(14 2^k), row-major 2 x 2, A = [[-a1, -a2], [1, 0]] (the section's state transition)
+    const float*  iir_state;     // [4][2]: the cascade's direct-form-II delay lines (w[n-1], w[n-2]) in front of the span
+    float*        iir_state_out; // ... behind it (written by the workgroup that owns the span's last block)
+    int           iir_nsec, run_blocks, warm_blocks; // contiguous blocks per workgroup; blocks every run but the first starts early from zero state (the cascade's memory fades: ||Phi_896^warm|| <= 1e-8)
 };
+constexpr int kDfLdsIir = kDfLdsAll + 896 * 4 + 8 * 4; // + the block's decimated samples on their way from the final pass (lanes 0 .. 127) to the cascade's wave
+static_assert(2 * kDfLdsIir <= 160 * 1024, "two workgroups per CU, with the cascade");
 
+// ---- the cascade on one block: 896 samples, ONE wave, lane l owns samples 14 l .. 14 l + 13 (in registers, filtered in place section by section).
+// Per section: a run from zero state (lane 0: from the carried state) gives every chunk's end state; a Kogge-Stone scan inside each row of 16 lanes (DPP row
+// shifts, the 2 x 2 powers A^(14 2^k) as uniform multipliers), the four row totals chained in scalar registers, and A^(14 (j + 1)) W_row by binary powers give
+// every chunk's TRUE end state; shifted one lane up it is the next chunk's start state, from which the chunk is run again, now with outputs.
+template <int CTRL>
+__device__ __forceinline__ float decim_dpp(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ float decim_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+typedef const __attribute__((address_space(4))) float* decim_ctab_t;
+// (z0, z1): every chunk's end state from zero state (lane 0: from the carried state) -> every chunk's TRUE start state (c0, c1)
+__device__ __forceinline__ void decim_iir_scan(decim_ctab_t tab, float z0, float z1, float T0, float T1, int lane, float& c0, float& c1) {
+    const auto mul = [&](int k, float u0, float u1, float& r0, float& r1) { // (r0, r1) += P_k (u0, u1)
+        const float p00 = tab[8 + 4 * k], p01 = tab[9 + 4 * k], p10 = tab[10 + 4 * k], p11 = tab[11 + 4 * k];
+        r0 = fmaf(p00, u0, fmaf(p01, u1, r0));
+        r1 = fmaf(p10, u0, fmaf(p11, u1, r1));
+    };
+    float s0 = z0, s1 = z1;
+    { const float u0 = decim_dpp<0x111>(s0), u1 = decim_dpp<0x111>(s1); mul(0, u0, u1, s0, s1); } // row_shr:1 (lanes at a row's start read 0)
+    { const float u0 = decim_dpp<0x112>(s0), u1 = decim_dpp<0x112>(s1); mul(1, u0, u1, s0, s1); } // row_shr:2
+    { const float u0 = decim_dpp<0x114>(s0), u1 = decim_dpp<0x114>(s1); mul(2, u0, u1, s0, s1); } // row_shr:4
+    { const float u0 = decim_dpp<0x118>(s0), u1 = decim_dpp<0x118>(s1); mul(3, u0, u1, s0, s1); } // row_shr:8
+    // state at the start of row r from the rows before it: W_0 = 0, W_{r+1} = A^(14 16) W_r + (row r's total, at its lane 15)
+    float w0 = 0.f, w1 = 0.f, W0 = 0.f, W1 = 0.f;
+    const int row = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float n0 = decim_lane(s0, 16 * r + 15), n1 = decim_lane(s1, 16 * r + 15);
+        mul(4, w0, w1, n0, n1);
+        w0 = n0;
+        w1 = n1;
+        if (row == r + 1) { W0 = w0; W1 = w1; }
+    }
+    // + A^(14 (j + 1)) W, j = lane in row: the binary powers of j + 1 (1 .. 16)
+    const int j1 = (lane & 15) + 1;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float h0 = 0.f, h1 = 0.f;
+        mul(k, W0, W1, h0, h1);
+        if ((j1 >> k) & 1) { W0 = h0; W1 = h1; }
+    }
+    s0 += W0;
+    s1 += W1;
+    // the chunk's start state: the end state of the chunk before it (wave_shr:1; lane 0: the carried state)
+    c0 = decim_dpp<0x138>(s0);
+    c1 = decim_dpp<0x138>(s1);
+    if (lane == 0) { c0 = T0; c1 = T1; }
+}
+// the chunk's run from zero state (lane 0: from the carried state Ts): end state
+__device__ __forceinline__ void decim_iir_first(const float (&x)[14], decim_ctab_t tab, const float* Ts, int lane, float& z0, float& z1) {
+    const float a1 = tab[3], a2 = tab[4];
+    z0 = lane == 0 ? Ts[0] : 0.f;
+    z1 = lane == 0 ? Ts[1] : 0.f;
+#pragma unroll
+    for (int n = 0; n < 14; ++n) {
+        const float w = fmaf(-a2, z1, fmaf(-a1, z0, x[n]));
+        z1            = z0;
+        z0            = w;
+    }
+}
+// section `tab` on the chunk, in place: end state from zero state, scan, the run proper
+__device__ __forceinline__ void decim_iir_section(float (&x)[14], decim_ctab_t tab, float* Ts, int lane) {
+    const float a1 = tab[3], a2 = tab[4];
+    float       z0, z1, c0, c1;
+    decim_iir_first(x, tab, Ts, lane, z0, z1);
+    decim_iir_scan(tab, z0, z1, Ts[0], Ts[1], lane, c0, c1);
+    const float b0 = tab[0], b1 = tab[1], b2 = tab[2];
+#pragma unroll
+    for (int n = 0; n < 14; ++n) {
+        const float w = fmaf(-a2, c1, fmaf(-a1, c0, x[n]));
+        x[n]          = fmaf(b2, c1, fmaf(b1, c0, b0 * w));
+        c1            = c0;
+        c0            = w;
+    }
+    if (lane == 63) { Ts[0] = c0; Ts[1] = c1; } // the block's end state: what the next block starts from (one wave, LDS in program order)
+}
 __device__ __forceinline__ void ifft8(float2 (&v)[8]) { // inverse DFT-8: the forward butterfly on (im, re)
     float2 t[8];
 #pragma unroll
@@ -107,6 +189,7 @@ __device__ __forceinline__ float decim_wave_total_lane63(float v) {
     return v;
 }
 
+template <bool IIR>
 __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_df[]; // the ONLY LDS object
     const int t0   = threadIdx.x;
@@ -122,7 +205,40 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
     }
     const float2 bI1 = a.twI1[lane0 & 15], bI2 = a.twI2[t0 & 127];
     const unsigned lds_L = __builtin_amdgcn_readfirstlane(lds_off(smem_df));
-    long blk = blockIdx.x;
+    long blk = blockIdx.x, blk_end = a.n_blocks, emit0 = 0;
+    // IIR: a contiguous run of blocks per workgroup (the cascade's state is carried from block to block in the cascade wave's registers); every run but the
+    // span's first starts warm_blocks early from zero state, those blocks advance the state only
+    float  yc[14];  // the cascade wave's samples of the block before this one
+    float* Yl = reinterpret_cast<float*>(smem_df + kDfLdsAll);
+    float* Tl = Yl + 896; // [4][2] the cascade's carried state, per section (LDS: touched by the cascade wave only)
+    long   pblk = -1; // block whose decimated samples sit in Yl
+    if constexpr (IIR) {
+        emit0 = (long)blockIdx.x * a.run_blocks;
+        if (emit0 >= a.n_blocks) return;
+        blk     = emit0 - a.warm_blocks < 0 ? 0 : emit0 - a.warm_blocks;
+        blk_end = emit0 + a.run_blocks < a.n_blocks ? emit0 + a.run_blocks : a.n_blocks;
+        if (wave == 7 && lane0 < 8) Tl[lane0] = blk == 0 ? a.iir_state[lane0] : 0.f;
+    }
+    const decim_ctab_t itab = (decim_ctab_t)(uintptr_t)a.iir;
+    // the cascade on the block in Yl: sections [s_lo, s_hi) (wave 7; between two of the block loop's barriers each)
+    const auto cascade = [&](int s_lo, int s_hi, int lane) {
+#ifdef GR4_DFIIR_NOCASCADE // (timing only: what the fused launch costs without the cascade's arithmetic)
+        return;
+#endif
+#pragma unroll 1
+        for (int s = s_lo; s < s_hi && s < a.iir_nsec; ++s) decim_iir_section(yc, itab + 32 * s, Tl + 2 * s, lane);
+    };
+    const auto cascade_load = [&](int lane) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { const float2 v = *reinterpret_cast<const float2*>(Yl + 14 * lane + 2 * i); yc[2 * i] = v.x; yc[2 * i + 1] = v.y; }
+    };
+    const auto cascade_store = [&](int lane) {
+        if (pblk >= emit0) {
+            float* yo = a.y + pblk * (kDfHop / 8) + 14 * lane;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) *reinterpret_cast<float2*>(yo + 2 * i) = make_float2(yc[2 * i], yc[2 * i + 1]);
+        }
+    };
     float pw_in = 0.f, pw_out = 0.f;
     // every block's own verdict: the workgroup's sum of out - thr * in.  A lane keeps the block's share until the next block's top barrier, the waves' totals (DPP network)
     // meet in 16 words of LDS behind the image, wave 0 collects the sum of the block before -- no barrier of its own
@@ -131,8 +247,8 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
     if (threadIdx.x < 16) Gv[threadIdx.x] = 0.f;
     int   iter  = 0;
     if (blk < a.n_blocks) decim_dma(a, blk, lds_L, wave, lane0);
-    for (; blk < a.n_blocks; blk += gridDim.x, ++iter) {
-        const bool measure = a.pw != nullptr && blk != a.tail_blk; // wave-uniform; EVERY block: one the guard does not look at is one it cannot vouch for
+    for (; blk < blk_end; blk += IIR ? 1 : gridDim.x, ++iter) {
+        const bool measure = a.pw != nullptr && blk != a.tail_blk && (!IIR || blk >= emit0); // wave-uniform; EVERY block (once): one the guard does not look at is one it cannot vouch for
         float      blk_in  = 0.f;
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
@@ -168,7 +284,7 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) *reinterpret_cast<float2*>(smem_df + kDfOffW + q * kDfRS + 8 * t) = u[q];
         G16_LDS_BARRIER(); // #1: the landing buffer is free
-        const long bn = (blk + gridDim.x < a.n_blocks) ? blk + gridDim.x : blk; // (last iteration re-reads its own block: no divergent paths around the DMA)
+        const long bn = IIR ? (blk + 1 < blk_end ? blk + 1 : blk) : (blk + gridDim.x < a.n_blocks) ? blk + gridDim.x : blk; // (last iteration re-reads its own block: no divergent paths around the DMA)
         decim_dma(a, bn, lds_L, wave, l);
         // ---- phase 1: wave q: Z[8 k' + q], 512 points on its own
         float2 v[8];
@@ -198,6 +314,19 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
             GF[kk + 64] = g1;
         }
         G16_LDS_BARRIER(); // #2: all eight G_q are in place
+        if constexpr (IIR) { // wave 7 is idle from here to the top of the loop (inverse transforms: waves 0, 1; final pass: lanes 0 .. 127): the block before this one
+#ifdef GR4_DFIIR_PIPE_TIMING // (timing only, results are garbage: three waves, GR4_DFIIR_PIPE_TIMING sections each per block -- is there room for a pipeline of waves?)
+            if (wave >= 5 && pblk >= 0) {
+                cascade_load(l);
+                cascade(0, 1, l);
+            }
+#else
+            if (wave == 7 && pblk >= 0) { // goes through the cascade meanwhile, half of it before barrier #3 ...
+                cascade_load(l);
+                cascade(0, 2, l);
+            }
+#endif
+        }
         // ---- the eight 128-point inverse transforms F_q[i''] = sum_k' G_q[k'] W_128^{-k' i''}: waves 0 and 1, one transform per 16-lane group (8 points a lane),
         //      so that every lane of the two waves works (one transform per wave on 16 of its 64 lanes cost four times the issue slots)
         if (wave < 2) {
@@ -240,7 +369,20 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
 #pragma unroll
             for (int bp = 0; bp < 8; ++bp) Gq[a1p + 8 * (2 * bp + hh)] = v[bp];
         }
-        G16_LDS_BARRIER(); // #3: every F_q is in place
+        G16_LDS_BARRIER(); // #3: every F_q is in place (IIR: and wave 7 has taken the previous block out of Yl)
+        if constexpr (IIR) {
+#ifdef GR4_DFIIR_PIPE_TIMING
+            if (wave >= 5 && pblk >= 0) {
+                if (GR4_DFIIR_PIPE_TIMING > 1) cascade(1, 2, l);
+                if (wave == 7) cascade_store(l);
+            }
+#else
+            if (wave == 7 && pblk >= 0) { // ... and half of it behind
+                cascade(2, 4, l);
+                cascade_store(l);
+            }
+#endif
+        }
         // ---- final pass across the waves: y[i'' + 128 a] = Re( sum_q W_1024^{-q i''} F_q[i''] W_8^{-q a} ), lanes 0..127
         if (t < 128) {
             const float2* F = reinterpret_cast<const float2*>(smem_df + kDfOffF) + t;
@@ -251,9 +393,14 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
             // valid outputs: i' = i'' + 128 a >= 128, i.e. a = 1..7 -> y[blk * 896 + i' - 128]
             float*    yo    = a.y + blk * (kDfHop / 8) + t;
             const int valid = blk == a.tail_blk ? a.tail_out : kDfHop / 8;
+            if constexpr (IIR) { // the decimated samples stay on chip: to the cascade wave through LDS (read after the next barrier)
 #pragma unroll
-            for (int aa = 1; aa < 8; ++aa)
-                if (t + 128 * (aa - 1) < valid) yo[128 * (aa - 1)] = v[aa].x;
+                for (int aa = 1; aa < 8; ++aa) Yl[t + 128 * (aa - 1)] = v[aa].x;
+            } else {
+#pragma unroll
+                for (int aa = 1; aa < 8; ++aa)
+                    if (t + 128 * (aa - 1) < valid) yo[128 * (aa - 1)] = v[aa].x;
+            }
             if (measure) {
                 float blk_out = 0.f;
 #pragma unroll
@@ -261,6 +408,25 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
                 pw_out += blk_out;
                 pw_dprev = fmaf(-a.pw_thr, blk_in, blk_out);
             }
+        }
+        if constexpr (IIR) {
+            pblk = blk;
+            // the cross-pass twiddles are needed again only behind the next top barrier: fetched anew here (L2), so that their 16 registers are free while the
+            // cascade wave holds its 14 samples (laundered pointer: the loads must not be hoisted back out of the loop)
+            const float2* p = a.twX + t0 * 8;
+            asm volatile("" : "+v"(p));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) twX[k] = p[k];
+        }
+    }
+    if constexpr (IIR) { // the run's last block: its samples are in Yl behind the final pass
+        G16_LDS_BARRIER();
+        if (wave == 7 && pblk >= 0) {
+            const int l = threadIdx.x & 63;
+            cascade_load(l);
+            cascade(0, 4, l);
+            cascade_store(l);
+            if (blk_end == a.n_blocks && l < 8) a.iir_state_out[l] = Tl[l]; // the state behind the span
         }
     }
     if (a.pw != nullptr) { // one pair of atomics per wave, spread over 16 slots
@@ -303,6 +469,7 @@ __global__ __launch_bounds__(kDfT, 4) void fir_decim_fd_kernel(DecimFdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+struct DecimFdIir { const float* tab; int nsec; const float* state_in; float* state_out; int warm_blocks; }; // (device pointers; fir.hip fills it from the IIR handle)
 struct FirDecimFd {
     DeviceBuffer d_twX, d_tw1, d_tw2, d_R, d_twI1, d_twI2, d_hist1024, d_stage, d_pw;
     float*       h_pw = nullptr;     // page-locked, device-mapped {in, out, sequence number} of the last measured launch that has finished
@@ -392,8 +559,10 @@ __global__ __launch_bounds__(256) void decim_fd_prepare_kernel(const float* __re
 
 // d_hist: the filter's history (hcap samples in front of d_in); n_in input samples (a multiple of 8): floor(n_in / 7168) whole blocks and, if anything is left, one partial block
 // measure: this launch samples input and output power (dynamic-range guard, fir.hip); fir_decim_fd_power_ratio hands the result out
-int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st, bool measure) {
+// iir != null: whole blocks only (n_in a multiple of 7168), the biquad cascade rides in the launch and d_out receives ITS output (fir_decim_fd_kernel<true>)
+int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float* d_hist, int hcap, float* d_out, hipStream_t st, bool measure, const DecimFdIir* iir) {
     const size_t full = n_in / kDfHop, rest = n_in - full * kDfHop;
+    GR4_REQUIRE(!iir || rest == 0, "fir_decim_fd: the fused cascade takes whole blocks");
     int          rc   = c->d_hist1024.ensure(kDfV * sizeof(float));
     if (!rc && rest) rc = c->d_stage.ensure(kDfN * sizeof(float));
     if (rc) return rc;
@@ -428,11 +597,21 @@ int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float*
     GR4_REQUIRE(n_cu != 0, "fir_decim_fd: cannot query the current device");
     if (first) {
         n_cu = -n_cu;
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_fd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDfLdsAll));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_fd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDfLdsAll));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_fd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDfLdsIir));
         per_device.done(dev, n_cu);
     }
+    if (iir) { // contiguous runs: as many as there are workgroup slots, none shorter than its own warm-up
+        const size_t slots = (size_t)2 * n_cu;
+        const size_t run   = std::max<size_t>(ceil_div(n_blocks, slots), (size_t)std::max(iir->warm_blocks, 1));
+        a.iir = iir->tab; a.iir_nsec = iir->nsec; a.iir_state = iir->state_in; a.iir_state_out = iir->state_out;
+        a.run_blocks = (int)run; a.warm_blocks = iir->warm_blocks;
+        hipLaunchKernelGGL(fir_decim_fd_kernel<true>, dim3((unsigned)ceil_div(n_blocks, run)), dim3(kDfT), kDfLdsIir, st, a);
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
     const unsigned grid = (unsigned)std::min<size_t>(n_blocks, (size_t)2 * n_cu);
-    hipLaunchKernelGGL(fir_decim_fd_kernel, dim3(grid), dim3(kDfT), kDfLdsAll, st, a);
+    hipLaunchKernelGGL(fir_decim_fd_kernel<false>, dim3(grid), dim3(kDfT), kDfLdsAll, st, a);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

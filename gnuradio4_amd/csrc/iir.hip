@@ -900,6 +900,8 @@ struct gr4hip_iir {
     // the cascade as given (top-level handle): what GR4HIP_IIR_SEQUENTIAL_F32 walks, and what the create-time self-test of GR4HIP_IIR_AUTO compares against
     IirSeqF32Coef       seq{};
     DeviceBuffer        d_seq_state;
+    DeviceBuffer        d_fuse_tab;       // the cascade as the decimator's fused launch reads it (fir_decim_fd.hip: 32 floats per section), built on first use
+    int                 fuse_warm = -1;   // blocks of 896 samples after which the cascade has forgotten its start state (||Phi_896^w|| <= 1e-8); 0: it does not within 4
     int                 algo = GR4HIP_IIR_AUTO, algo_in_use = GR4HIP_IIR_PARALLEL;
     float               selftest_parallel = -1.f, selftest_f32 = -1.f; // create-time errors (max |.| / output rms against float64) of the parallel kernels and of the sequential float32 form
     bool                top = true;
@@ -1298,6 +1300,50 @@ static int iir_process_parallel(gr4hip_iir_t* f, const float* d_in, size_t n, fl
     if (f->ord == 2) return f->nsec == 2 ? iir_run<2, 2>(f, d_in, d_out, ln, st) : f->nsec == 4 ? iir_run<2, 4>(f, d_in, d_out, ln, st) : iir_run<2, 8>(f, d_in, d_out, ln, st);
     return f->nsec == 1 ? iir_run<4, 1>(f, d_in, d_out, ln, st) : f->nsec == 2 ? iir_run<4, 2>(f, d_in, d_out, ln, st) : iir_run<4, 4>(f, d_in, d_out, ln, st);
 }
+
+// (library-internal, fir.hip: gr4hip_fir_iir_process) what the frequency-domain decimator needs to run this cascade as its store epilogue: up to four biquads on the
+// parallel-in-time path, the per-section tables (coefficients + the 2 x 2 powers A^(14 2^k) of its chunk scan), the carried direct-form-II state (read from the
+// current slot, written to the other: gr4hip_internal_iir_commit makes it current once the launch is known to stand) and the warm-up in blocks of 896 samples.
+// Returns 0 when the cascade does not qualify (the caller keeps the two launches).
+int gr4hip_internal_iir_fusable(gr4hip_iir* f, const float** d_tab, int* nsec, const float** d_state_in, float** d_state_out, int* warm_blocks) {
+    if (!f || !f->top || f->part[0] || f->ord != 2 || f->algo_in_use != GR4HIP_IIR_PARALLEL || f->seq.nsec < 1 || f->seq.nsec > 4 || f->seq.nb > 3 || f->seq.na > 3) return 0;
+    if (f->fuse_warm < 0) {
+        f->fuse_warm = 0;
+        std::vector<double> P = host_phi(f, 896), Pw = P;
+        const int           M = f->M;
+        for (int w = 1; w <= 4; ++w) {
+            double nrm = 0;
+            for (int i = 0; i < M; ++i) { double r = 0; for (int j = 0; j < M; ++j) r += std::fabs(Pw[i * M + j]); nrm = std::max(nrm, r); }
+            if (nrm <= 1e-8) { f->fuse_warm = w; break; }
+            std::vector<double> nx((size_t)M * M, 0.0);
+            for (int i = 0; i < M; ++i)
+                for (int k = 0; k < M; ++k)
+                    for (int j = 0; j < M; ++j) nx[i * M + j] += Pw[i * M + k] * P[k * M + j];
+            Pw = nx;
+        }
+        std::vector<float> tab((size_t)32 * f->seq.nsec, 0.f);
+        for (int s = 0; s < f->seq.nsec; ++s) {
+            float* t = tab.data() + 32 * s;
+            t[0] = f->seq.b[s][0]; t[1] = f->seq.b[s][1]; t[2] = f->seq.b[s][2]; t[3] = f->seq.a[s][1]; t[4] = f->seq.a[s][2];
+            double A[4] = {-(double)t[3], -(double)t[4], 1.0, 0.0}, R[4] = {1, 0, 0, 1};
+            const auto mm = [](const double* x, const double* y, double* o) { const double r[4] = {x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3], x[2] * y[0] + x[3] * y[2], x[2] * y[1] + x[3] * y[3]}; std::memcpy(o, r, sizeof(r)); };
+            for (int i = 0; i < 14; ++i) mm(R, A, R); // A^14: one chunk
+            for (int k = 0; k < 5; ++k) {
+                for (int i = 0; i < 4; ++i) t[8 + 4 * k + i] = (float)R[i];
+                mm(R, R, R);
+            }
+        }
+        if (f->d_fuse_tab.ensure(tab.size() * sizeof(float)) != GR4HIP_OK || hipMemcpy(f->d_fuse_tab.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) f->fuse_warm = 0;
+    }
+    if (f->fuse_warm <= 0) return 0;
+    *d_tab       = static_cast<const float*>(f->d_fuse_tab.ptr);
+    *nsec        = f->seq.nsec;
+    *d_state_in  = static_cast<const float*>(f->d_state[f->cur].ptr);
+    *d_state_out = static_cast<float*>(f->d_state[f->cur ^ 1].ptr);
+    *warm_blocks = f->fuse_warm;
+    return 1;
+}
+void gr4hip_internal_iir_commit(gr4hip_iir* f) { f->cur ^= 1; }
 
 extern "C" {
 

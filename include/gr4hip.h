@@ -227,6 +227,21 @@ int gr4hip_iir_set_algo(gr4hip_iir_t* iir, int algo);
 int gr4hip_iir_get_algo(const gr4hip_iir_t* iir, int* algo_in_use, float* selftest_parallel, float* selftest_sequential_f32);
 int gr4hip_iir_destroy(gr4hip_iir_t* iir);
 
+/* BasicDecimatingFilter (FIR design) -> BasicFilter (IIR design), BASELINE.json configs[2]: the decimating processBulk loop (time_domain_filter.hpp:190-204) feeding
+ * Filter<float>::processOne over the sections (FilterTool.hpp:244-246).  One call for both handles; each keeps its own state (history, delay lines) exactly as if
+ * gr4hip_fir_process and gr4hip_iir_process were called one after the other, and the two may be mixed freely with those calls.
+ * mode GR4HIP_FIR_IIR_ONE_LAUNCH: when the filter takes the frequency-domain decimator (float, decimate by 8, <= 1024 taps, a span of >= 64 blocks of 7168 samples) and
+ * the cascade is up to four biquads on the parallel path whose memory fades within four blocks, the cascade runs as the decimator's STORE EPILOGUE: one launch, the
+ * decimated stream never reaches HBM (4.5 instead of 5.5 bytes per input sample) -- contiguous block runs per workgroup, the cascade's state carried in one wave,
+ * every run but the first warmed up over the blocks in front of it (state error <= 1e-8); anything else runs as the two launches.
+ * mode GR4HIP_FIR_IIR_TWO_LAUNCHES: the decimated stream through a scratch buffer of the filter handle.
+ * mode GR4HIP_FIR_IIR_AUTO: the faster of the two as measured on MI355X -- the two launches (the decimator is bound by vector-instruction issue, not by HBM: the
+ * cascade's instructions cost the same inside its launch as in their own, and the contiguous runs cost the decimator another 10 %; DESIGN.md 7 has the numbers).
+ * ONE_LAUNCH is for a caller that shares HBM bandwidth with other streams and prefers the smaller traffic.
+ * The decimator's dynamic-range guard works as in gr4hip_fir_process (a rejected span is redone on the polyphase kernels + the cascade's own, from untouched states). */
+typedef enum { GR4HIP_FIR_IIR_AUTO = 0, GR4HIP_FIR_IIR_ONE_LAUNCH = 1, GR4HIP_FIR_IIR_TWO_LAUNCHES = 2 } gr4hip_fir_iir_mode;
+int gr4hip_fir_iir_process(gr4hip_fir_t* fir, gr4hip_iir_t* iir, const float* d_in, size_t n_in, float* d_out, size_t* n_out, int mode, gr4hip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ a5 (host-side design)
  * BasicFilterProto<float>::designFilter (time_domain_filter.hpp:163-182): FIR by window method
  * (fir::designFilter<float>, FilterTool.hpp:964-1071; tap count from Kaiser's estimate :985-1004) or IIR biquad

@@ -30,6 +30,19 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.fixture
+def devsw(G):
+    """developer switches of the library (gr4hip_developer_switch: which of two kernels serves a call), restored when the test ends"""
+    used = set()
+
+    def set_(name, value=1):
+        used.add(name)
+        G.capi.developer_switch(name, value)
+    yield set_
+    for name in used:
+        G.capi.developer_switch(name, 0)
+
+
 def _rel(got, truth):
     got = np.asarray(got).astype(np.complex128 if np.iscomplexobj(got) else np.float64).ravel()
     truth = np.asarray(truth).ravel()
@@ -279,3 +292,43 @@ def test_division_by_a_constant_is_the_ieee_quotient_for_every_float(G):
                 raise AssertionError((c, k, [(float(x[i]), float(a[i]), float(b[i])) for i in bad]))
         want = (np.float32(1.2345) / np.float32(c))
         assert fast.process_bulk(torch.full((4,), 1.2345, device="cuda"))[0].item() == want
+
+
+def _lowpass(ntaps, fc):
+    k = np.arange(ntaps, dtype=np.float64)
+    t = np.hamming(ntaps) * 2 * fc * np.sinc(2 * fc * (k - (ntaps - 1) / 2.0))
+    return (t / t.sum()).astype(np.float32)
+
+
+@pytest.mark.parametrize("order,nblocks,extra", [(8, 200, 0), (8, 1500, 4321 * 8), (4, 777, 8), (2, 64, 7160), (6, 3000, 0)])
+def test_decimating_fir_and_iir_cascade_in_one_launch(G, order, nblocks, extra):
+    """BASELINE configs[2] (decimate-by-8 1024-tap FIR -> biquad cascade) through gr4hip_fir_iir_process: the cascade as the frequency-domain decimator's store epilogue
+    (one launch: contiguous block runs per workgroup, the state carried in one wave, warm-up blocks in front of every run) against the float64 oracle AND against the
+    same call with the decimated stream in HBM; the handles' states are interchangeable with the separate calls (a second span continues the stream either way)"""
+    import gnuradio4_amd.blocks as B
+    n = nblocks * 7168 + extra
+    x = O.signal_f32(order + nblocks, n)
+    taps = _lowpass(1024, 0.05)
+    b, a = B.design_iir(G.capi.LOWPASS, order, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    secs = O.make_sections([(bb, aa) for bb, aa in zip(b, a)])
+    yd, _ = O.fir_decim(taps, x, 8)
+    truth = O.iir_cascade(secs, yd.astype(np.float32), O.DF_II, f64=True)
+    # (the oracle's cascade takes float32 input: the decimated stream as the filter block hands it on -- rounded to float32 -- as on the device)
+    cut = (n // 2) // 8 * 8
+    res = {}
+    for mode, m in (("fused", G.capi.FIR_IIR_ONE_LAUNCH), ("two", G.capi.FIR_IIR_TWO_LAUNCHES), ("auto", G.capi.FIR_IIR_AUTO)):
+        fir, iir = G.fir_filter(taps, torch.float32, decimate=8), G.iir_filter(b, a)
+        xd = dev(x)
+        y = torch.cat([B.fir_iir_process(fir, iir, xd[:cut], mode=m), B.fir_iir_process(fir, iir, xd[cut:], mode=m)])
+        res[mode] = y.cpu().numpy()
+        assert len(res[mode]) == n // 8
+        assert _rel(res[mode], truth) <= 1e-5, (mode, order, nblocks)
+    assert _rel(res["fused"], res["two"].astype(np.float64)) <= 1e-5  # (each is within 1e-5 of float64: different float32 roundings of the same cascade)
+    # mixed with the separate calls on the same handles: first half fused, second half as gr4hip_fir_process + gr4hip_iir_process
+    fir, iir = G.fir_filter(taps, torch.float32, decimate=8), G.iir_filter(b, a)
+    xd = dev(x)
+    y1 = B.fir_iir_process(fir, iir, xd[:cut], mode=G.capi.FIR_IIR_ONE_LAUNCH)
+    y2 = iir.process_bulk(fir.process_bulk(xd[cut:]))
+    assert _rel(torch.cat([y1, y2]).cpu().numpy(), truth) <= 1e-5
+    with pytest.raises(G.capi.Gr4HipError):
+        B.fir_iir_process(fir, iir, xd[:cut], mode=7)
