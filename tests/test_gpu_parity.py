@@ -1720,6 +1720,17 @@ def test_configs2_full_size_properties(G):
     ti = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)]), tf.astype(np.float32), O.DF_II, f64=True)
     got = yo[m0 // 8:m0 // 8 + 40000].cpu().numpy()
     assert _rel(got, ti[-40000:]) <= TOL
+    # the same stream through gr4hip_fir_iir_process: the cascade as the decimator's store epilogue (ONE launch for the whole blocks, the decimated stream never in HBM),
+    # in two calls cut inside the span; and the library's own choice (AUTO)
+    rms = float(yo.double().pow(2).mean().sqrt())
+    for mode in (G.capi.FIR_IIR_ONE_LAUNCH, G.capi.FIR_IIR_AUTO):
+        fir.reset(); iir.reset()
+        cut = (1 << 26) + 8 * 4321
+        y1 = torch.cat([G.blocks.fir_iir_process(fir, iir, x[:cut], mode=mode), G.blocks.fir_iir_process(fir, iir, x[cut:], mode=mode)])
+        assert y1.numel() == n // 8
+        assert float((y1 - yo).abs().max()) <= 2e-5 * rms, (mode, float((y1 - yo).abs().max()) / rms)
+        assert _rel(y1[m0 // 8:m0 // 8 + 40000].cpu().numpy(), ti[-40000:]) <= TOL
+        del y1
 
 
 def test_configs3_full_size_properties(G):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turn gpurun_out/prof_<tag>/ (rocprofv3 outputs) into the committed text summaries under profiles/.
-usage: summarize_profiles.py <tag> <kernel-substring>"""
+usage: summarize_profiles.py <tag> <kernel-name-for-the-file> [<kernel-substring to match, default: the name>]"""
 import collections
 import csv
 import glob
@@ -9,6 +9,7 @@ import sqlite3
 import sys
 
 tag, kern = sys.argv[1], sys.argv[2]
+match = sys.argv[3] if len(sys.argv) > 3 else kern  # (bench.py also launches the Hann instantiation: chain_fd_kernel<1, 13>)
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 lines = []
@@ -18,20 +19,20 @@ lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-ba
 lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'%':>6}  kernel")
 for name, calls, total, avg, pct in rows:
     lines.append(f"{calls:7d} {total:12.1f} {avg:10.2f} {pct:6.2f}  {name}")
-durs = [(e - b) / 1e3 for b, e in db.execute("select start, end from kernels where name like ? order by start", (f"%{kern}%",)).fetchall()]
+durs = [(e - b) / 1e3 for b, e in db.execute("select start, end from kernels where name like ? order by start", (f"%{match}%",)).fetchall()]
 if durs:
     sd = sorted(durs)
     lines.append("")
-    lines.append(f"# per-dispatch durations of '{kern}' in launch order (us): the clocks ramp over the first ~20 launches after the idle gap, the")
+    lines.append(f"# per-dispatch durations of '{match}' in launch order (us): the clocks ramp over the first ~20 launches after the idle gap, the")
     lines.append(f"# steady-state tail is what bench.py's HIP events report for the last timed step (roofline.avg_launch_ms)")
     lines.append("#   " + " ".join(f"{d:.0f}" for d in durs))
     lines.append(f"#   min {sd[0]:.1f}  median {sd[len(sd)//2]:.1f}  max {sd[-1]:.1f}  mean of last 4 {sum(durs[-4:])/4:.1f}")
 lines.append("")
 lines.append(f"# rocprofv3 --pmc <counters> (separate passes, counters only) -- python bench.py --steps 1 --warmup 1 --log2-samples 28 --no-cpu-baseline")
-lines.append(f"# per-dispatch means for kernels matching '{kern}' (one dispatch = one launch of 2^28 samples)")
+lines.append(f"# per-dispatch means for kernels matching '{match}' (one dispatch = one launch of 2^28 samples)")
 for f in sorted(glob.glob(os.path.join(src, "pmc_*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
-    rows_k = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+    rows_k = [r for r in csv.DictReader(open(f)) if match in r["Kernel_Name"]]
     full = max((int(r["Grid_Size"]) for r in rows_k), default=0)  # the guard's probe launch (first call of a stream: 8 frames) is a dispatch too: full-size launches only
     for r in rows_k:
         if int(r["Grid_Size"]) == full:
