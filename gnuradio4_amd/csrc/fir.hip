@@ -234,8 +234,9 @@ void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
-void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af);
-int  fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist);
+void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af, bool cplx);
+int  fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist,
+                           const EwiseHook* pre, const EwiseHook* post, bool cplx);
 int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
@@ -484,6 +485,27 @@ int gr4hip_fir_set_guard_mode(gr4hip_fir_t* f, int mode) {
 // the three-term bf16 kernels are off for this handle (GR4HIP_FIR_EXACT_F32: IEEE float32 multiply-add, the reference's Inf / NaN behaviour) or for the process (developer switch)
 static bool no_bf16x3(const gr4hip_fir_t* f) { return f->algo == GR4HIP_FIR_EXACT_F32 || f->f32_products || dev_switch(kDevFirNoBf16x3); }
 
+// does this call take the band-form bf16 decimators (fir_bf16.hip)?  Builds their fragments on first use.
+static bool fir_decim_bf16_ready(gr4hip_fir_t* f, size_t n_in, const void* d_in, const void* d_out, int* rc) {
+    *rc = GR4HIP_OK;
+    if (!(f->decim >= (f->S == 1 ? (size_t)2 : (size_t)3) && f->decim <= (f->S == 1 ? (size_t)12 : (size_t)16) && n_in / f->decim >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
+          ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !no_bf16x3(f)))
+        return false;
+    if (f->bdKS == 0) {
+        std::vector<unsigned short> af;
+        int                         ks = 0;
+        fir_decim_bf16_make_afrag(f->taps.data(), f->ntaps, f->decim, &ks, &f->bdHb, &af, f->S == 2);
+        if (ks == 0 || (f->S == 1 && f->decim == 8 && ks > 9 && f->ntaps <= 1024)) f->bdKS = -1; // the window does not fit -- or decimate-by-8 with a long window, where the
+                                                                                                  // frequency-domain kernel is faster (762 against 305 G input samples/s at 1024 taps)
+        else {
+            *rc = f->d_bdfrag.ensure(af.size() * sizeof(unsigned short));
+            if (!*rc) { hipError_t e = hipMemcpy(f->d_bdfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); *rc = GR4HIP_RUNTIME_ERROR; } }
+            if (*rc) return false;
+            f->bdKS = ks;
+        }
+    }
+    return f->bdKS > 0;
+}
 static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, gr4hip_stream_t stream, const FirHooks& hk);
 
 int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
@@ -504,7 +526,10 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     const size_t per_out    = ceil_div(f->ntaps, f->decim); // taps per computed output
     const bool   fast_shape = f->algo == GR4HIP_FIR_AUTO && ((f->decim == 1 && f->ntaps > (f->S == 2 ? (size_t)64 : (size_t)96) && f->ntaps <= (f->S == 2 ? (size_t)256 : (size_t)1024) && n_in >= kMfmaMinSamples) ||
                                                                (f->S == 1 && f->decim >= 2 && per_out > 12 && n_out >= ((size_t)1 << 14)));
-    if (hk.any && fast_shape) {
+    int        brc  = GR4HIP_OK;
+    const bool band = hk.any && fir_decim_bf16_ready(f, n_in, d_in, d_out, &brc); // (those kernels carry the hooks themselves)
+    if (brc) return brc;
+    if (hk.any && fast_shape && !band) {
         hipStream_t st  = as_stream(stream);
         const void* src = d_in;
         if (hk.pre.n_ops > 0) {
@@ -686,28 +711,20 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     }
     // float, decimate by 2 .. 12 with a window of <= 1152 samples (taps - 1 + 15 D), long 16-byte-aligned span: the band form with three-term bf16 products
     // (fir_bf16.hip; windows beyond 288 samples with the K-steps split over the four waves)
-    if (done == 0 && f->S == 1 && f->decim >= 2 && f->decim <= 12 && n_out >= (1u << 14) && algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
-        ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !no_bf16x3(f) && plain) {
+    // complex<float> (real taps), decimate by 3 .. 16: the same kernels on the interleaved stream read as floats (fir_decim_bf16_make_afrag: the rows of a tile
+    // alternate between the re and im phases of the window) -- the register-window kernel below stages a decimator's samples one by one (decimate by 8, 64 taps:
+    // 171 G input samples/s against 483 here; by 16: 97 against 445; by 2 it is ahead: 389 / 307 against 348 / 252 at 16 / 64 taps)
+    // These kernels take the neighbours' programs themselves (load hook where the samples are split into bf16 planes, store hook on the output tile).
+    if (done == 0) {
         int rc = GR4HIP_OK;
-        if (f->bdKS == 0) {
-            std::vector<unsigned short> af;
-            int                         ks = 0;
-            fir_decim_bf16_make_afrag(f->taps.data(), f->ntaps, f->decim, &ks, &f->bdHb, &af);
-            if (ks == 0 || (f->decim == 8 && ks > 9 && f->ntaps <= 1024)) f->bdKS = -1; // the window does not fit -- or decimate-by-8 with a long window, where the
-                                                                                          // frequency-domain kernel is faster (762 against 305 G input samples/s at 1024 taps): the kernels below
-            else {
-                rc = f->d_bdfrag.ensure(af.size() * sizeof(unsigned short));
-                if (!rc) { hipError_t e = hipMemcpy(f->d_bdfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
-                if (rc) return rc;
-                f->bdKS = ks;
-            }
-        }
-        if (f->bdKS > 0) {
+        if (fir_decim_bf16_ready(f, n_in, d_in, d_out, &rc)) {
             float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
-            rc = fir_decim_bf16_launch(f->bdKS, (int)f->decim, f->bdHb, x, (long)n_in, hist, (int)f->hcap, f->d_bdfrag.ptr, y, (long)n_out, st, nh);
+            rc = fir_decim_bf16_launch(f->bdKS, (int)f->decim, f->bdHb, x, (long)(n_in * f->S), hist, (int)(f->hcap * f->S), f->d_bdfrag.ptr, y, (long)(n_out * f->S), st, nh,
+                                       hk.pre.n_ops > 0 ? &hk.pre : nullptr, hk.post.n_ops > 0 ? &hk.post : nullptr, f->S == 2);
             if (rc == GR4HIP_OK) { done = n_in; mfma_wrote_hist = true; }
-            else if (rc != GR4HIP_UNSUPPORTED) return rc;
-        }
+            else if (rc == GR4HIP_UNSUPPORTED) f->bdKS = -1; // (the staged segment does not fit: do not ask again)
+            else return rc;
+        } else if (rc) return rc;
     }
     // float, decimate by 8, <= 1024 taps, long 16-byte-aligned span: overlap-save blocks of 8192 samples in the frequency domain (~35 lane-operations per
     // input sample instead of 2 K / 8 flop: HBM / power-bound instead of FP32-bound); a partial last block rides in the same launch

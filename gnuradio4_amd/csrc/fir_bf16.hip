@@ -30,6 +30,7 @@
 // 163-164 against 168 Gsamples/s at 256 taps, 175 against 179 at 224: it is at the same power cap with two streams' worth of MFMAs per sample, and stays as it is.)
 #include "common.hpp"
 #include "buffer_ops.hpp"
+#include "ewise.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -430,14 +431,65 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_c32_kernel(const float2* 
     }
 }
 
+// ---- the neighbours of a decimator in its launch (gr4hip_fir_set_prologue / _epilogue; fir.hip): a program applied to the samples on their way into the bf16 planes
+// (positions are FLOAT indices of the stream as the kernel sees it; cplx: two floats per sample, programs of complex<float> items) and to the outputs before the store
+struct BdHooks { EwiseHook pre, post; int cplx = 0; };
+__device__ __forceinline__ float4 bd_hook4(float4 v, const EwiseHook& h, int cplx, long fi /*float index of v.x: a multiple of 4*/) {
+    if (cplx) {
+        float2 e[2] = {make_float2(v.x, v.y), make_float2(v.z, v.w)};
+        ewise_hook<float2, 2>(e, h, fi >> 1);
+        return make_float4(e[0].x, e[0].y, e[1].x, e[1].y);
+    }
+    float e[4] = {v.x, v.y, v.z, v.w};
+    ewise_hook<float, 4>(e, h, fi);
+    return make_float4(e[0], e[1], e[2], e[3]);
+}
+// four staged floats at stream float index fi (a multiple of 4) of the span's first segment: history in front of position 0 (as it lies: it holds what the prologue
+// produced), the prologue on the samples of this span
+template <bool HOOK>
+__device__ __forceinline__ float4 bd_stage_slow(const float* __restrict__ x, const float* __restrict__ hist, int Kh, long n_in, long fi, const BdHooks& hk) {
+    float t[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const long i = fi + c;
+        t[c]         = i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f);
+    }
+    float4 v = make_float4(t[0], t[1], t[2], t[3]);
+    if constexpr (HOOK) {
+        if (hk.pre.n_ops > 0) {
+            const float4 w = bd_hook4(v, hk.pre, hk.cplx, fi); // (fi, Kh and n_in are even for complex streams: a pair never straddles position 0)
+            if (fi >= 0) v = w;
+            else if (fi + 2 >= 0) { v.z = w.z; v.w = w.w; if (!hk.cplx && fi + 1 >= 0) v.y = w.y; }
+            else if (!hk.cplx && fi + 3 >= 0) v.w = w.w;
+        }
+    }
+    return v;
+}
+template <bool HOOK>
+__device__ __forceinline__ void bd_new_hist(const float* __restrict__ x, const float* __restrict__ hist, int Kh, long n_in, float* __restrict__ new_hist, int tid, const BdHooks& hk) {
+    if constexpr (HOOK) {
+        if (hk.pre.n_ops > 0) { // Kh is a multiple of 4 floats for every filter that reaches these kernels with a prologue (fir.hip: hcap is a power of two >= 4)
+            for (int h = 4 * tid; h < Kh; h += 4 * 256) {
+                const float4 v = bd_stage_slow<true>(x, hist, Kh, n_in, n_in - Kh + h, hk);
+                new_hist[h] = v.x; new_hist[h + 1] = v.y; new_hist[h + 2] = v.z; new_hist[h + 3] = v.w;
+            }
+            return;
+        }
+    }
+    for (int h = tid; h < Kh; h += 256) {
+        const long i = n_in - Kh + h;
+        new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+    }
+}
+
 // Decimating fir_filter<float> with short polyphase branches (decimation 2 .. 9, window Hb + 15 D + 1 <= 288 samples): the band form of fir_decim_band_kernel
 // (samples in stream order, A[j][u] = b[Hb + j D - u]: the decimation sits in the A operand) with the three-term products -- the polyphase kernel on the f32 MFMA
 // is bound by that instruction (D = 2, 256 taps: 306 G input samples/s).  1024 outputs (1024 D inputs) per segment, one tile per wave, one accumulator per term.
 constexpr int kBdSegOut = 1024, kBdMaxNL4 = 10;
-template <int KS>
+template <int KS, bool HOOK>
 __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh, const u32x4_b* __restrict__ afrag,
                                                                 float* __restrict__ y, long n_out, long n_in, int D, int Hb /*a multiple of 4: samples in front of a block*/,
-                                                                float* __restrict__ new_hist) {
+                                                                float* __restrict__ new_hist, BdHooks hk) {
     extern __shared__ __attribute__((aligned(16))) unsigned short bpl[]; // [3][PL]
     const int NS = 16 * D * 63 + 32 * KS, PL = NS + 8; // staged samples per segment: the last block's window ends 16 D 63 + 32 KS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
@@ -473,18 +525,13 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < kBdMaxNL4; ++u) {
                 const int q = tid + 256 * u;
-                if (q < NS / 4) put4(q, nxt[u]);
+                if (q < NS / 4) {
+                    if constexpr (HOOK) { if (hk.pre.n_ops > 0) nxt[u] = bd_hook4(nxt[u], hk.pre, hk.cplx, in0 + 4L * q); }
+                    put4(q, nxt[u]);
+                }
             }
         } else { // the first segment of the span reads the carried history in front of x
-            for (int q = tid; q < NS / 4; q += 256) {
-                float t[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const long i = in0 + 4L * q + c;
-                    t[c]         = i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f);
-                }
-                put4(q, make_float4(t[0], t[1], t[2], t[3]));
-            }
+            for (int q = tid; q < NS / 4; q += 256) put4(q, bd_stage_slow<HOOK>(x, hist, Kh, n_in, in0 + 4L * q, hk));
         }
         __syncthreads();
         if (sg + 1 < slast) load_next(in_start(sg + 1)); // (>= 0: sg + 1 >= 1)
@@ -506,27 +553,26 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
         float      v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (c0[r] + (c1[r] + c2[r])) + ((c3[r] + c4[r]) + c5[r]);
+        if constexpr (HOOK) {
+            if (hk.post.n_ops > 0) { const float4 w = bd_hook4(make_float4(v[0], v[1], v[2], v[3]), hk.post, hk.cplx, o); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
+        }
         if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
         else
             for (int r = 0; r < 4; ++r)
                 if (o + r < n_out) y[o + r] = v[r];
         __syncthreads();
     }
-    if (new_hist != nullptr && blockIdx.x == 0) {
-        for (int h = tid; h < Kh; h += 256) {
-            const long i = n_in - Kh + h;
-            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
-        }
-    }
+    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK>(x, hist, Kh, n_in, new_hist, tid, hk);
 }
 
 // The same with LONG windows (taps - 1 + 15 D + 1 <= 1152 samples: BASELINE configs[2]'s decimate-by-8 1024-tap filter, decimation 10 .. 32 with K ~ 32 D): the four
 // waves of a workgroup split the K-steps -- each holds the fragments of its quarter (<= 9 steps) -- and their partial tiles are summed through LDS.  Two tiles
 // (512 outputs, 512 D inputs + the window) per segment, twelve accumulators per wave.
 constexpr int kBsTiles = 2, kBsSegOut = 256 * kBsTiles, kBsMaxNL4 = 20;
-template <int KSW, int NL4> // K-steps of 32 per wave (the window is 128 KSW samples); float4 loads a lane holds for the next segment
+template <int KSW, int NL4, bool HOOK> // K-steps of 32 per wave (the window is 128 KSW samples); float4 loads a lane holds for the next segment
 __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh, const u32x4_b* __restrict__ afrag /*[3][4 KSW][64]*/,
-                                                                       float* __restrict__ y, long n_out, long n_in, int D, int Hb, float* __restrict__ new_hist, int spw /*segments per workgroup*/) {
+                                                                       float* __restrict__ y, long n_out, long n_in, int D, int Hb, float* __restrict__ new_hist, int spw /*segments per workgroup*/,
+                                                                       BdHooks hk) {
     extern __shared__ __attribute__((aligned(16))) unsigned short bpl[]; // [3][PL] bf16 planes, then the partial tiles [4 waves][kBsTiles][64 lanes][4] floats
     constexpr int KS = 4 * KSW;
     const int NS = 16 * D * (16 * kBsTiles - 1) + 32 * KS, PL = NS + 8;
@@ -564,18 +610,13 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
 #pragma unroll
             for (int u = 0; u < NL4; ++u) {
                 const int q = tid + 256 * u;
-                if (q < NS / 4) put4(q, nxt[u]);
+                if (q < NS / 4) {
+                    if constexpr (HOOK) { if (hk.pre.n_ops > 0) nxt[u] = bd_hook4(nxt[u], hk.pre, hk.cplx, in0 + 4L * q); }
+                    put4(q, nxt[u]);
+                }
             }
         } else {
-            for (int q = tid; q < NS / 4; q += 256) {
-                float t[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const long i = in0 + 4L * q + c;
-                    t[c]         = i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f);
-                }
-                put4(q, make_float4(t[0], t[1], t[2], t[3]));
-            }
+            for (int q = tid; q < NS / 4; q += 256) put4(q, bd_stage_slow<HOOK>(x, hist, Kh, n_in, in0 + 4L * q, hk));
         }
         __syncthreads();
         if (sg + 1 < slast) load_next(in_start(sg + 1));
@@ -608,18 +649,22 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
         for (int tl = 0; tl < kBsTiles; ++tl) {
             const int  o = tid, ln = (o >> 4) + 16 * ((o & 15) >> 2), r = o & 3;
             const long m = sg * kBsSegOut + 256 * tl + o;
-            if (m < n_out)
-                y[m] = (part[((0 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((1 * kBsTiles + tl) * 64 + ln) * 4 + r]) +
-                       (part[((2 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((3 * kBsTiles + tl) * 64 + ln) * 4 + r]);
+            float      val = (part[((0 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((1 * kBsTiles + tl) * 64 + ln) * 4 + r]) +
+                             (part[((2 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((3 * kBsTiles + tl) * 64 + ln) * 4 + r]);
+            if constexpr (HOOK) {
+                if (hk.post.n_ops > 0) {
+                    if (hk.cplx) { // lanes 2 i and 2 i + 1 hold one complex output: both evaluate the program on it, each keeps its component
+                        const float other = __shfl_xor(val, 1);
+                        const float2 w    = ewise_hook1<float2>((tid & 1) ? make_float2(other, val) : make_float2(val, other), hk.post, m >> 1);
+                        val               = (tid & 1) ? w.y : w.x;
+                    } else val = ewise_hook1<float>(val, hk.post, m);
+                }
+            }
+            if (m < n_out) y[m] = val;
         }
         __syncthreads(); // (the partial tiles and the planes are reused by the next segment)
     }
-    if (new_hist != nullptr && blockIdx.x == 0) {
-        for (int h = tid; h < Kh; h += 256) {
-            const long i = n_in - Kh + h;
-            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
-        }
-    }
+    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK>(x, hist, Kh, n_in, new_hist, tid, hk);
 }
 
 static unsigned short host_bf_rne(float f) {
@@ -719,9 +764,13 @@ int fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int K
 
 // band-form fragments of a decimator: [3][KS][64][8], element t of lane l at K-step ks = tap-plane value b_p[Hb + (l & 15) D - (32 ks + 8 (l >> 4) + t)]
 // Returns KS = 0 when the window Hb + 15 D + 1 does not fit 1152 samples (KS <= 9: one wave holds all fragments; 12 .. 36: split over the four waves).
-void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af) {
-    const int Hb = (int)((ntaps - 1 + 3) / 4 * 4);
-    int       KS = ((Hb + 15 * (int)D + 1 + 31) / 32 * 32) / 32;
+// cplx: complex<float> samples x real taps on the SAME kernels, the interleaved stream read as 2 n floats: float output o = 2 m + c (component c of output m) is
+// sum_k b[k] xf[2 (m D - k) + c], i.e. row j of a tile (16 float outputs = 8 complex ones, 16 D floats of input further on per tile, exactly the float case) sits
+// s_j = 2 D (j >> 1) + (j & 1) floats into the window and sees tap k at window position Hb + s_j - 2 k: A[j][u] = b[(Hb + s_j - u) / 2] where that is even, else 0.
+// Half of the matrix pipe's work multiplies zeros; the pipe has that to spare (the kernels are bound by the stream), the VALU polyphase kernel it replaces is not close.
+void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af, bool cplx) {
+    const int Hb = (int)(((cplx ? 2 : 1) * (ntaps - 1) + 3) / 4 * 4);
+    int       KS = ((Hb + (cplx ? 14 * (int)D + 1 : 15 * (int)D) + 1 + 31) / 32 * 32) / 32;
     *KS_out = 0;
     *Hb_out = Hb;
     if (KS > 9) KS = (KS + 3) / 4 * 4; // split over the four waves (fir_decim_bf16x3_splitk_kernel): a multiple of 4, <= 36
@@ -742,14 +791,25 @@ void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* K
         for (int ks = 0; ks < KS; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int t = 0; t < 8; ++t) {
-                    const long k = (long)Hb + (long)(l & 15) * (long)D - (32 * ks + 8 * (l >> 4) + t);
+                    const int j = l & 15;
+                    long      k = (long)Hb + (cplx ? 2L * (long)D * (j >> 1) + (j & 1) : (long)j * (long)D) - (32 * ks + 8 * (l >> 4) + t);
+                    if (cplx) k = (k & 1) ? -1 : k / 2;
                     if (k >= 0 && (size_t)k < ntaps) (*af)[(((size_t)p * KS + ks) * 64 + l) * 8 + t] = pl[p][(size_t)k];
                 }
     *KS_out = KS;
 }
 
 // y[m] = sum_k b[k] x[m D - k], m < n_out; hist[h] = x[-Kh + h]; x and y 16-byte aligned
-int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist) {
+// pre / post: programs for the samples on their way in / the outputs on their way out (null: none); cplx: the stream is complex<float> read as floats (the programs'
+// positions are sample indices)
+int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist,
+                          const EwiseHook* pre, const EwiseHook* post, bool cplx) {
+    BdHooks hk;
+    if (pre) hk.pre = *pre;
+    if (post) hk.post = *post;
+    hk.cplx = cplx ? 1 : 0;
+    const bool hooked = hk.pre.n_ops > 0 || hk.post.n_ops > 0;
+    if (hooked && (Kh % 4) != 0) return GR4HIP_UNSUPPORTED;
     if (KS > 9) { // long window: the waves split the K-steps
         const int    NS   = 16 * D * (16 * kBsTiles - 1) + 32 * KS, PL = NS + 8;
         const size_t lds  = (size_t)(3 * PL + (3 * PL & 1)) * sizeof(unsigned short) + (size_t)4 * kBsTiles * 64 * 4 * sizeof(float);
@@ -761,9 +821,10 @@ int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, cons
         const auto af   = static_cast<const u32x4_b*>(afrag);
 #define GR4_BS_CASE(K)                                                                                                                     \
     case K: {                                                                                                                              \
-        auto kern = small ? fir_decim_bf16x3_splitk_kernel<K, 6> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4>;                           \
+        auto kern = hooked ? (small ? fir_decim_bf16x3_splitk_kernel<K, 6, true> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4, true>)     \
+                           : (small ? fir_decim_bf16x3_splitk_kernel<K, 6, false> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4, false>);  \
         if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, af, y, n_out, n_in, D, Hb, new_hist, spw);                         \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, af, y, n_out, n_in, D, Hb, new_hist, spw, hk);                     \
     } break
         switch (KS / 4) {
             GR4_BS_CASE(3);
@@ -786,9 +847,9 @@ int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, cons
     const auto af = static_cast<const u32x4_b*>(afrag);
 #define GR4_BD_CASE(K)                                                                                                                     \
     case K: {                                                                                                                              \
-        auto kern = fir_decim_bf16x3_kernel<K>;                                                                                            \
+        auto kern = hooked ? fir_decim_bf16x3_kernel<K, true> : fir_decim_bf16x3_kernel<K, false>;                                         \
         if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, af, y, n_out, n_in, D, Hb, new_hist);                              \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, af, y, n_out, n_in, D, Hb, new_hist, hk);                          \
     } break
     switch (KS) {
         GR4_BD_CASE(1);

@@ -174,10 +174,11 @@ def _fir64(b, x, decim=1):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("ntaps,decim", [(45, 1), (200, 1), (64, 4), (1024, 8), (31, 3)])
+@pytest.mark.parametrize("ntaps,decim", [(45, 1), (200, 1), (64, 4), (1024, 8), (31, 3), (200, 16), (100, 8), (520, 8), (80, 10), (64, 2), (300, 5)])
 def test_fir_takes_its_neighbours_into_its_launch(G, cplx, ntaps, decim):
     """per-sample blocks in front of and behind a FIR filter, executed by the filter's kernel: gains folded into the taps, adds / complex gains / a rotator as
-    load and store hooks; streamed in ragged calls (the carried history is the prologue's output); against float64 of the chain of separate blocks"""
+    load and store hooks -- of the register-window kernel, or of the band-form matrix-pipe decimators (decimation 2 .. 12 float, 3 .. 16 complex, long spans) where the
+    samples are split into bf16 planes; streamed in ragged calls (the carried history is the prologue's output); against float64 of the chain of separate blocks"""
     n = 12 * 8192 * decim if not cplx else 6 * 8192 * decim
     x = O.signal_c32(4, n) if cplx else O.signal_f32(4, n)
     b = O.design_taps_hamming_lowpass(ntaps, 0.1)

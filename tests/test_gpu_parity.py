@@ -229,6 +229,27 @@ def test_fir_decimating_long_input_mfma(G, decim, ntaps):
     assert _rel(y, truth) <= TOL
 
 
+@pytest.mark.parametrize("decim,ntaps", [(8, 64), (8, 87), (8, 88), (8, 256), (8, 520), (2, 16), (2, 130), (2, 1), (3, 100), (4, 128), (4, 33), (5, 91), (7, 33), (10, 80), (12, 200),
+                                         (16, 64), (16, 256), (16, 460), (16, 1), (16, 600), (17, 64)])
+def test_fir_complex_decimating_long_input_matrix_pipe(G, decim, ntaps):
+    """complex<float> samples x real taps, decimate by 2 .. 16, >= 2^14 outputs per span: the float decimator's band-form kernels (three-term bf16 products) on the
+    interleaved stream read as floats -- the rows of a tile alternate between the re and im phases of the window; shapes beyond their windows (and decimation 17)
+    stay on the register-window kernel.  Against the float64 oracle, across calls that switch kernels"""
+    rng = np.random.default_rng(1000 * ntaps + decim)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    cuts = [0, 40 * decim, (40 + 20_003) * decim, (40 + 20_003 + 7) * decim, (40 + 20_003 + 7 + 16_384) * decim, (40 + 20_003 + 7 + 16_384 + 33_000) * decim]
+    x = O.signal_c32(17, cuts[-1])
+    truth = O.fir(b, x, acc64=True)[0][::decim]
+    f = G.fir_filter(b, torch.complex64, decimate=decim)
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        xin = torch.empty(hi - lo + 2, dtype=torch.complex64, device="cuda")[2:]  # 16-byte aligned start
+        xin.copy_(torch.from_numpy(x[lo:hi]))
+        parts.append(f.process_bulk(xin).cpu().numpy())
+    y = np.concatenate(parts)
+    assert y.shape == truth.shape and _rel(y, truth) <= TOL
+
+
 @pytest.mark.parametrize("ntaps", [1024, 1000, 513, 129, 8, 1])
 def test_fir_decimate_by_8_frequency_domain(G, ntaps, devsw):
     """BASELINE configs[2]'s filter: decimate by 8, <= 1024 taps, spans of >= 64 blocks of 7168 samples take the overlap-save kernel (csrc/fir_decim_fd.hip:
