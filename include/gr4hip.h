@@ -399,7 +399,8 @@ int gr4hip_ewise_destroy(gr4hip_ewise_t* prog);
  *     is linear, fir(g x) == (g b) * x -- and costs nothing in any kernel (the rounding differs from the two-block form in the last bits: one float product per
  *     tap instead of one per sample, same float32 level, same 1e-5 parity bar);
  *   - anything else (AddConst / SubtractConst, complex gains, a rotator) is a load / store hook of the register-window kernel (any tap count, any decimation, float
- *     or complex): one launch, no intermediate stream in HBM.  Exception, by measurement: where a plain filter of the same shape takes a matrix-pipe or
+ *     or complex) or of the band-form matrix-pipe decimators (float: decimation 2 .. 12, complex: 3 .. 16, windows they hold, spans of >= 2^14 outputs): one launch, no
+ *     intermediate stream in HBM.  Exception, by measurement: where a plain filter of the same shape takes a matrix-pipe or
  *     frequency-domain kernel AND the register-window kernel is far behind it (more than 96 taps -- 64 for complex -- on a span of >= 2^16 samples, float decimators with
  *     more than 12 taps per output on long spans), that kernel is worth more than the saved pass
  *     (add -> 256-tap FIR: 165 Gsamples/s hooked, 277 as an element-wise launch + the bf16 kernel), and the program runs as ONE element-wise launch in front of
