@@ -461,19 +461,34 @@ class FirBatched(_Handle):
         return out[:, :x.shape[1]]
 
 
-def math_const(op, x: torch.Tensor, value) -> torch.Tensor:
-    """MathOpImpl<T,op>::processOne (Math.hpp:38-56): AddConst / SubtractConst / MultiplyConst / DivideConst."""
+def _uncertain_id(t: torch.Tensor, who: str) -> int:
+    """gr::UncertainValue<float | double> streams are float tensors of shape [n, 2]: rows of {value, uncertainty} (meta/.../UncertainValue.hpp:34-40)"""
+    if t.dim() != 2 or t.shape[1] != 2 or t.dtype not in (torch.float32, torch.float64):
+        raise capi.Gr4HipError(capi.INVALID_ARGUMENT, who, "UncertainValue streams are float32 / float64 tensors of shape [n, 2]")
+    return capi.UF32 if t.dtype == torch.float32 else capi.UF64
+
+
+def math_const(op, x: torch.Tensor, value, uncertain: bool = False) -> torch.Tensor:
+    """MathOpImpl<T,op>::processOne (Math.hpp:38-56): AddConst / SubtractConst / MultiplyConst / DivideConst.
+    uncertain: T = UncertainValue<float | double> -- x of shape [n, 2], value = (value, uncertainty)."""
     x = _dev(x, "math_const")
-    did = _DTYPE_ID[x.dtype]
-    v = np.array([value]).astype(_NP_DTYPE[did])
+    if uncertain:
+        did = _uncertain_id(x, "math_const")
+        v = np.asarray(value, np.float32 if did == capi.UF32 else np.float64).reshape(2)
+        n = x.shape[0]
+    else:
+        did = _DTYPE_ID[x.dtype]
+        v = np.array([value]).astype(_NP_DTYPE[did])
+        n = x.numel()
     out = torch.empty_like(x)
-    check(lib().gr4hip_math_const(_OPS.get(op, op), did, x.data_ptr(), out.data_ptr(), x.numel(), v.ctypes.data, _stream()), "math_const")
+    check(lib().gr4hip_math_const(_OPS.get(op, op), did, x.data_ptr(), out.data_ptr(), n, v.ctypes.data, _stream()), "math_const")
     return out
 
 
-def math_nary(op, inputs: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def math_nary(op, inputs: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None, uncertain: bool = False) -> torch.Tensor:
     """MathOpMultiPortImpl<T,op>::processBulk (Math.hpp:100-107): Add / Subtract / Multiply / Divide over n_inputs.
-    `out` (optional): a contiguous device tensor of the inputs' dtype and length that receives the result."""
+    `out` (optional): a contiguous device tensor of the inputs' dtype and length that receives the result.
+    uncertain: T = UncertainValue<float | double>, every stream of shape [n, 2]."""
     ins = [_dev(t, "math_nary") for t in inputs]
     if not 1 <= len(ins) <= 32:
         raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "math_nary", "n_inputs must be in [1, 32] (Math.hpp:90)")
@@ -484,7 +499,8 @@ def math_nary(op, inputs: Sequence[torch.Tensor], out: Optional[torch.Tensor] = 
         out = torch.empty_like(ins[0])
     elif not out.is_cuda or not out.is_contiguous() or out.dtype != ins[0].dtype or out.numel() != ins[0].numel():
         raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "math_nary", "out must be a contiguous device tensor of the inputs' dtype and length")
-    check(lib().gr4hip_math_nary(_OPS.get(op, op), _DTYPE_ID[ins[0].dtype], ptrs, len(ins), out.data_ptr(), out.numel(), _stream()), "math_nary")
+    did = _uncertain_id(ins[0], "math_nary") if uncertain else _DTYPE_ID[ins[0].dtype]
+    check(lib().gr4hip_math_nary(_OPS.get(op, op), did, ptrs, len(ins), out.data_ptr(), ins[0].shape[0] if uncertain else out.numel(), _stream()), "math_nary")
     return out
 
 

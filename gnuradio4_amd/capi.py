@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libgr4hip.so")
 
 OK, DONE, INSUFFICIENT_INPUT, INSUFFICIENT_OUTPUT = 0, -1, -2, -3
 ERROR, INVALID_ARGUMENT, RUNTIME_ERROR, UNSUPPORTED, NO_DEVICE = -100, -101, -102, -103, -104
-U8, U16, U32, U64, I8, I16, I32, I64, F32, F64, C32, C64 = range(12)
+U8, U16, U32, U64, I8, I16, I32, I64, F32, F64, C32, C64, UF32, UF64 = range(14)  # UF32 / UF64: gr::UncertainValue<float | double>, {value, uncertainty} pairs
 ADD, SUB, MUL, DIV = range(4)
 DF_I, DF_II, DF_I_TRANSPOSED, DF_II_TRANSPOSED = range(4)
 WINDOWS = ["None", "Rectangular", "Hamming", "Hann", "HannExp", "Blackman", "Nuttall", "BlackmanHarris",

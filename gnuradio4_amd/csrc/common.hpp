@@ -62,8 +62,8 @@ int dev_switch(DevSwitch s);
 inline hipStream_t as_stream(gr4hip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline size_t dtype_size(int dtype) {
-    static const size_t s[12] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 8, 16};
-    return (dtype >= 0 && dtype < 12) ? s[dtype] : 0;
+    static const size_t s[14] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 8, 16, 8, 16};
+    return (dtype >= 0 && dtype < 14) ? s[dtype] : 0;
 }
 
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }

@@ -233,6 +233,10 @@ extern "C" {
 int gr4hip_ewise_create(gr4hip_ewise_t** out, int dtype) {
     GR4_REQUIRE(out, "ewise: null output handle");
     GR4_REQUIRE(dtype_size(dtype), "ewise: unknown dtype %d", dtype);
+    if (dtype == GR4HIP_UF32 || dtype == GR4HIP_UF64) { // (value + uncertainty pairs: the math entry points take them, one launch per block)
+        set_error("ewise: programs of UncertainValue elements are not implemented");
+        return GR4HIP_UNSUPPORTED;
+    }
     auto* p = new (std::nothrow) gr4hip_ewise();
     GR4_REQUIRE(p, "out of host memory");
     p->dtype = dtype;

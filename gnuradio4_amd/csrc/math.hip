@@ -47,9 +47,25 @@ __device__ __forceinline__ F2 apply_cop(F2 a, F2 b) {
     return r;
 }
 
+// gr::UncertainValue<float | double> (meta/.../UncertainValue.hpp:34-40): {value, uncertainty}; both operands uncertain, real value types: the reference's operators
+// (:121-250) propagate uncorrelated errors -- one IEEE operation per source operation on the value, std::hypot for the combination
+template <typename F> struct UVal { F v, u; };
+__device__ __forceinline__ float  u_hypot(float a, float b) { return hypotf(a, b); }
+__device__ __forceinline__ double u_hypot(double a, double b) { return hypot(a, b); }
+template <typename F, int OP>
+__device__ __forceinline__ UVal<F> apply_uop(UVal<F> a, UVal<F> b) {
+#pragma clang fp contract(off)
+    if constexpr (OP == GR4HIP_ADD) return {a.v + b.v, u_hypot(a.u, b.u)};                                  // :121-133
+    else if constexpr (OP == GR4HIP_SUB) return {a.v - b.v, u_hypot(a.u, b.u)};                             // :159-171
+    else if constexpr (OP == GR4HIP_MUL) return {a.v * b.v, u_hypot(a.v * b.u, b.v * a.u)};                 // :192-204
+    else return {a.v / b.v, u_hypot(a.u / b.v, b.u * a.v / (b.v * b.v))};                                   // :221-243
+}
+
 template <typename T, int OP>
 __device__ __forceinline__ T apply_any(T a, T b) {
     if constexpr (std::is_same_v<T, float2> || std::is_same_v<T, double2>) return apply_cop<T, OP>(a, b);
+    else if constexpr (std::is_same_v<T, UVal<float>>) return apply_uop<float, OP>(a, b);
+    else if constexpr (std::is_same_v<T, UVal<double>>) return apply_uop<double, OP>(a, b);
     else return apply_op<T, OP>(a, b);
 }
 
@@ -147,6 +163,8 @@ static int math_dispatch(int op, int dtype, const NaryPtrs& ins, int n_inputs, c
         GR4_CASE(GR4HIP_F64, double)
         GR4_CASE(GR4HIP_C32, float2)
         GR4_CASE(GR4HIP_C64, double2)
+        GR4_CASE(GR4HIP_UF32, UVal<float>)
+        GR4_CASE(GR4HIP_UF64, UVal<double>)
     default: set_error("math: unknown dtype %d", dtype); return GR4HIP_INVALID_ARGUMENT;
     }
 #undef GR4_CASE

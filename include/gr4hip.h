@@ -53,7 +53,12 @@ typedef enum {
 
 typedef enum { /* element types of the reference's block registrations (Math.hpp:25-28, time_domain_filter.hpp:20,213) */
     GR4HIP_U8 = 0, GR4HIP_U16, GR4HIP_U32, GR4HIP_U64, GR4HIP_I8, GR4HIP_I16, GR4HIP_I32, GR4HIP_I64,
-    GR4HIP_F32, GR4HIP_F64, GR4HIP_C32, GR4HIP_C64
+    GR4HIP_F32, GR4HIP_F64, GR4HIP_C32, GR4HIP_C64,
+    /* gr::UncertainValue<float | double> (meta/.../UncertainValue.hpp:34): an element is the pair {value, uncertainty}, 8 / 16 bytes, laid out like the struct.
+     * Taken by the math blocks (gr4hip_math_const / gr4hip_math_nary: both operands carry an uncertainty, uncorrelated propagation as the reference's operators
+     * write it, UncertainValue.hpp:121-250: a +- b -> hypot(ua, ub); a * b -> hypot(a ub, b ua); a / b -> hypot(ua / b, ub a / b^2)), by gr4hip_decimate and the
+     * ring buffers (any element size).  Not a filter / transform sample type here. */
+    GR4HIP_UF32, GR4HIP_UF64
 } gr4hip_dtype;
 
 typedef enum { GR4HIP_ADD = 0, GR4HIP_SUB, GR4HIP_MUL, GR4HIP_DIV } gr4hip_op; /* std::plus/minus/multiplies/divides */

@@ -776,8 +776,8 @@ void gr4o_chain_c32_truth(const float* b, size_t ntaps, float* hist, size_t N, i
  * Signed overflow is computed through the unsigned type (two's complement wrap) to stay defined in C.
  * ---------------------------------------------------------------------------------------------- */
 size_t gr4o_dtype_size(int dtype) {
-    static const size_t s[12] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 8, 16};
-    return (dtype >= 0 && dtype < 12) ? s[dtype] : 0;
+    static const size_t s[14] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 8, 16, 8, 16};
+    return (dtype >= 0 && dtype < 14) ? s[dtype] : 0;
 }
 
 #define INT_OP(TYPE, UTYPE)                                                      \
@@ -805,6 +805,32 @@ static double op_double(int op, double a, double b) { return op == GR4O_ADD ? a 
 static float complex op_c32(int op, float complex a, float complex b) { return op == GR4O_ADD ? a + b : op == GR4O_SUB ? a - b : op == GR4O_MUL ? a * b : a / b; }
 static double complex op_c64(int op, double complex a, double complex b) { return op == GR4O_ADD ? a + b : op == GR4O_SUB ? a - b : op == GR4O_MUL ? a * b : a / b; }
 
+/* gr::UncertainValue<float | double> (meta/include/gnuradio-4.0/meta/UncertainValue.hpp:34-40): {value, uncertainty}.  MathOpImpl<UncertainValue<T>, op> applies
+ * op()(a, value) with BOTH operands uncertain and a real value type: the "both ValueType[T,U] are arithmetic uncertainties" branches of operator+ (:121-133),
+ * operator- (:159-171), operator* (:192-204) and operator/ (:221-243): uncorrelated propagation, std::hypot for the combination, every product and quotient in T. */
+typedef struct { float v, u; } gr4o_uf32;
+typedef struct { double v, u; } gr4o_uf64;
+static gr4o_uf32 op_uf32(int op, gr4o_uf32 a, gr4o_uf32 b) {
+    gr4o_uf32 r;
+    switch (op) {
+    case GR4O_ADD: r.v = a.v + b.v; r.u = hypotf(a.u, b.u); break;
+    case GR4O_SUB: r.v = a.v - b.v; r.u = hypotf(a.u, b.u); break;
+    case GR4O_MUL: r.v = a.v * b.v; r.u = hypotf(a.v * b.u, b.v * a.u); break;
+    default: r.v = a.v / b.v; r.u = hypotf(a.u / b.v, b.u * a.v / (b.v * b.v)); break;
+    }
+    return r;
+}
+static gr4o_uf64 op_uf64(int op, gr4o_uf64 a, gr4o_uf64 b) {
+    gr4o_uf64 r;
+    switch (op) {
+    case GR4O_ADD: r.v = a.v + b.v; r.u = hypot(a.u, b.u); break;
+    case GR4O_SUB: r.v = a.v - b.v; r.u = hypot(a.u, b.u); break;
+    case GR4O_MUL: r.v = a.v * b.v; r.u = hypot(a.v * b.u, b.v * a.u); break;
+    default: r.v = a.v / b.v; r.u = hypot(a.u / b.v, b.u * a.v / (b.v * b.v)); break;
+    }
+    return r;
+}
+
 #define APPLY(TYPE, FN)                                                                           \
     do {                                                                                          \
         const TYPE* a_ = (const TYPE*)a; const TYPE* b_ = (const TYPE*)b; TYPE* o_ = (TYPE*)out;    \
@@ -826,6 +852,8 @@ static int math_binary(int op, int dtype, const void* a, const void* b, int b_st
     case GR4O_F64: APPLY(double, op_double); break;
     case GR4O_C32: APPLY(float complex, op_c32); break;
     case GR4O_C64: APPLY(double complex, op_c64); break;
+    case GR4O_UF32: APPLY(gr4o_uf32, op_uf32); break;
+    case GR4O_UF64: APPLY(gr4o_uf64, op_uf64); break;
     default: return -1;
     }
     return 0;

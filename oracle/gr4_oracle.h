@@ -133,7 +133,7 @@ void gr4o_chain_c32_truth(const float* b, size_t ntaps, float* hist, size_t N, i
 
 /* ---- a11/a12: math blocks (blocks/math/.../Math.hpp:38-56, 100-107) ----
  * dtype ids: 0 u8,1 u16,2 u32,3 u64,4 i8,5 i16,6 i32,7 i64,8 f32,9 f64,10 c32,11 c64. op: 0 add,1 sub,2 mul,3 div */
-enum { GR4O_U8 = 0, GR4O_U16, GR4O_U32, GR4O_U64, GR4O_I8, GR4O_I16, GR4O_I32, GR4O_I64, GR4O_F32, GR4O_F64, GR4O_C32, GR4O_C64 };
+enum { GR4O_U8 = 0, GR4O_U16, GR4O_U32, GR4O_U64, GR4O_I8, GR4O_I16, GR4O_I32, GR4O_I64, GR4O_F32, GR4O_F64, GR4O_C32, GR4O_C64, GR4O_UF32, GR4O_UF64 /* UncertainValue<float|double>: {value, uncertainty} pairs */ };
 enum { GR4O_ADD = 0, GR4O_SUB, GR4O_MUL, GR4O_DIV };
 size_t gr4o_dtype_size(int dtype);
 int    gr4o_math_const(int op, int dtype, const void* in, void* out, size_t n, const void* value);

@@ -14,9 +14,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-U8, U16, U32, U64, I8, I16, I32, I64, F32, F64, C32, C64 = range(12)
+U8, U16, U32, U64, I8, I16, I32, I64, F32, F64, C32, C64, UF32, UF64 = range(14)
 NP_DTYPES = [np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16, np.int32, np.int64,
-             np.float32, np.float64, np.complex64, np.complex128]
+             np.float32, np.float64, np.complex64, np.complex128,
+             np.float32, np.float64]  # UF32 / UF64 (gr::UncertainValue<float | double>): arrays of shape [n, 2] = {value, uncertainty} rows
 ADD, SUB, MUL, DIV = range(4)
 DF_I, DF_II, DF_I_T, DF_II_T = range(4)
 LOWPASS, HIGHPASS, BANDPASS, BANDSTOP = range(4)

@@ -1818,6 +1818,45 @@ def test_math_parity(G, dtype_id, opname):
         np.testing.assert_allclose(got, want, rtol=3e-6 if dtype_id in (8, 10) else 1e-14)
 
 
+@pytest.mark.parametrize("dtype_id", [O.UF32, O.UF64])
+@pytest.mark.parametrize("opname", ["Add", "Subtract", "Multiply", "Divide"])
+def test_math_uncertain_value_parity(G, golden, dtype_id, opname):
+    """MathOpImpl / MathOpMultiPortImpl<gr::UncertainValue<float | double>> (Math.hpp:25-28, 68-71; the operators of meta/.../UncertainValue.hpp:121-250): streams of
+    {value, uncertainty} pairs, uncorrelated propagation; against the oracle (pinned on qa_UncertainValue.cpp's known answers) and those known answers themselves.
+    Values are one IEEE operation each -> bit-exact; uncertainties go through hypot (1 ulp between libraries)"""
+    rng = np.random.default_rng(dtype_id * 11 + _OPS[opname])
+    op, dt = _OPS[opname], O.NP_DTYPES[dtype_id]
+    tol = 4e-7 if dt == np.float32 else 1e-15
+    n = 100_003
+    def rand():
+        v = rng.uniform(0.5, 4.0, n) * rng.choice([-1.0, 1.0], n)
+        return np.stack([v, rng.uniform(0.0, 0.5, n)], axis=1).astype(dt)
+    ins = [rand() for _ in range(3)]
+    for k in (1, 2, 3):
+        got = G.math_nary(opname, [dev(a) for a in ins[:k]], uncertain=True).cpu().numpy()
+        want = O.math_nary(op, dtype_id, ins[:k])
+        assert got.shape == (n, 2)
+        assert np.array_equal(got[:, 0], want[:, 0]), (opname, k)
+        np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=tol * k)
+    value = (float(dt(1.75)), float(dt(0.125)))
+    got = G.math_const(opname, dev(ins[0]), value, uncertain=True).cpu().numpy()
+    want = O.math_const(op, dtype_id, ins[0], value)
+    assert np.array_equal(got[:, 0], want[:, 0])
+    np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=tol)
+    c = golden["uncertain_value"][opname]
+    np.testing.assert_allclose(G.math_const(opname, dev(np.array([c["a"]], dt)), c["b"], uncertain=True).cpu().numpy(), np.array([c["out"]], dt), rtol=tol)
+    np.testing.assert_allclose(G.math_nary(opname, [dev(np.array([c["a"]], dt)), dev(np.array([c["b"]], dt))], uncertain=True).cpu().numpy(), np.array([c["out"]], dt), rtol=tol)
+    # a span that starts anywhere (8- / 16-byte elements in a ring): scalar head and tail around the 16-byte body, and an odd element count
+    for off in (1, 3):
+        buf = torch.empty((n + 4, 2), dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda")
+        buf[off:off + n].copy_(dev(ins[0]))
+        got2 = G.math_const(opname, buf[off:off + n], value, uncertain=True).cpu().numpy()
+        assert np.array_equal(got2, got)
+    assert G.math_nary("Add", [dev(np.zeros((0, 2), dt))], uncertain=True).numel() == 0
+    with pytest.raises(G.capi.Gr4HipError):  # merged programs of UncertainValue elements: refused (UNSUPPORTED), the caller keeps one launch per block
+        G.capi.check(G.capi.lib().gr4hip_ewise_create(C.byref(C.c_void_p()), dtype_id), "ewise_create")
+
+
 def test_tiny_and_empty_spans_every_block(G):
     """work() hands a block whatever the upstream produced: 0, 1, 2 ... samples per call must stream exactly like one long call (state carried)"""
     sizes = [0, 1, 2, 3, 7, 0, 31, 33, 255, 257, 1, 1000]

@@ -341,6 +341,22 @@ def test_math_const_golden(golden, dtype_id):
         assert O.math_const(op, dtype_id, np.array([g["x"]], dt), 1)[0] == {"Add": 5, "Subtract": 3, "Multiply": 4, "Divide": 4}[name]
 
 
+@pytest.mark.parametrize("dtype_id", [O.UF32, O.UF64])
+def test_math_uncertain_value_golden(golden, dtype_id):
+    """MathOpImpl / MathOpMultiPortImpl on gr::UncertainValue<float | double> (Math.hpp:25-28, 68-71): the reference's own known answers for its operators
+    (meta/test/qa_UncertainValue.cpp), as a const op and as a two-input op"""
+    g = golden["uncertain_value"]
+    dt = O.NP_DTYPES[dtype_id]
+    for name, op in _OPS.items():
+        c = g[name]
+        a, b, want = np.array([c["a"]], dt), np.array([c["b"]], dt), np.array([c["out"]], dt)
+        np.testing.assert_allclose(O.math_const(op, dtype_id, a, c["b"]), want, rtol=2e-7 if dt == np.float32 else 1e-15)
+        np.testing.assert_allclose(O.math_nary(op, dtype_id, [a, b]), want, rtol=2e-7 if dt == np.float32 else 1e-15)
+    # three inputs fold from the left like std::transform over the ports (Math.hpp:100-107): ((a + b) + c)
+    a, b, c = (np.array([[1.0, 3.0]], dt), np.array([[2.0, 4.0]], dt), np.array([[3.0, 12.0]], dt))
+    np.testing.assert_allclose(O.math_nary(O.ADD, dtype_id, [a, b, c]), np.array([[6.0, 13.0]], dt), rtol=1e-6)
+
+
 def test_math_integer_wraparound():
     x = np.array([250, 3, 255], np.uint8)
     assert np.array_equal(O.math_const(O.ADD, O.U8, x, 10), np.array([4, 13, 9], np.uint8))
