@@ -59,6 +59,15 @@ template <typename T, typename V = void>
 concept array_or_vector_type = (vector_type<T> || array_type<T>) && (std::same_as<V, void> || std::same_as<typename T::value_type, V>); // meta/utils.hpp:700
 template <typename T>
 inline constexpr bool always_false = false;
+// is_instantiation_of<T, Template> (meta/utils.hpp): T is Template<...> of type arguments
+namespace compat_inst {
+template <typename T, template <typename...> class Template>
+struct test : std::false_type {};
+template <template <typename...> class Template, typename... Args>
+struct test<Template<Args...>, Template> : std::true_type {};
+} // namespace compat_inst
+template <typename T, template <typename...> class Template>
+concept is_instantiation_of = compat_inst::test<std::remove_cvref_t<T>, Template>::value;
 template <typename T>
 concept complex_like = detail::is_complex<std::remove_cvref_t<T>>::value;
 // the scalar behind a sample type (meta/utils.hpp): complex<T> -> T
@@ -75,12 +84,10 @@ concept t_or_simd = std::same_as<V, T>;
 template <typename V, typename... T>
 concept any_simd = false;
 } // namespace meta
+#ifndef GR4_COMPAT_NO_UNCERTAIN_VALUE // (gr::UncertainValue<T> itself: gr4/core.hpp; a unit that includes the reference's own UncertainValue.hpp gets both names from there)
 template <typename T>
 concept arithmetic_or_complex_like = std::is_arithmetic_v<T> || meta::complex_like<T>;
-template <typename T>
-struct UncertainValue; // (value + uncertainty: named in registration lists only; not instantiated by this layer)
-template <typename T>
-concept UncertainValueLike = false;
+#endif
 
 struct exception : std::runtime_error { // gr::exception (reporting.hpp): message + source location upstream
     using std::runtime_error::runtime_error;

@@ -128,6 +128,55 @@ struct Tensor {
     [[nodiscard]] friend bool operator==(const Tensor& a, const Tensor& b) { return a._extents == b._extents && a._data == b._data; }
 };
 
+// ---------------------------------------------------------------------------------------------- UncertainValue<T> (meta/include/gnuradio-4.0/meta/UncertainValue.hpp)
+// A value with its standard uncertainty; the sample type of two of the fourteen math-block registrations (Math.hpp:25-28, 68-71).  Real value types here
+// (float, double).  Arithmetic between two uncertain values propagates UNCORRELATED errors (UncertainValue.hpp:121-250): sums and differences combine the
+// uncertainties in quadrature, products and quotients the partial derivatives times the operands' uncertainties; a plain number as one operand has none.
+// (GR4_COMPAT_NO_UNCERTAIN_VALUE: a translation unit that includes the REFERENCE's own UncertainValue.hpp against this layer defines it first.)
+#ifndef GR4_COMPAT_NO_UNCERTAIN_VALUE
+template <typename T>
+struct UncertainValue {
+    using value_type = T;
+    T value{};
+    T uncertainty{};
+    constexpr UncertainValue() = default;
+    constexpr UncertainValue(T v, T u = T{}) noexcept : value(v), uncertainty(u) {}
+    friend constexpr bool operator==(const UncertainValue&, const UncertainValue&) = default;
+};
+namespace detail {
+template <typename T>
+struct is_uncertain : std::false_type {};
+template <typename T>
+struct is_uncertain<UncertainValue<T>> : std::true_type {};
+} // namespace detail
+template <typename T>
+concept UncertainValueLike = detail::is_uncertain<std::remove_cvref_t<T>>::value;
+
+template <std::floating_point T>
+[[nodiscard]] inline UncertainValue<T> operator+(const UncertainValue<T>& a, const UncertainValue<T>& b) noexcept { return {a.value + b.value, std::hypot(a.uncertainty, b.uncertainty)}; }
+template <std::floating_point T>
+[[nodiscard]] inline UncertainValue<T> operator-(const UncertainValue<T>& a, const UncertainValue<T>& b) noexcept { return {a.value - b.value, std::hypot(a.uncertainty, b.uncertainty)}; }
+template <std::floating_point T>
+[[nodiscard]] inline UncertainValue<T> operator*(const UncertainValue<T>& a, const UncertainValue<T>& b) noexcept { return {a.value * b.value, std::hypot(a.value * b.uncertainty, b.value * a.uncertainty)}; }
+template <std::floating_point T>
+[[nodiscard]] inline UncertainValue<T> operator/(const UncertainValue<T>& a, const UncertainValue<T>& b) noexcept {
+    return {a.value / b.value, std::hypot(a.uncertainty / b.value, b.uncertainty * a.value / (b.value * b.value))};
+}
+// one operand exact
+template <std::floating_point T> [[nodiscard]] constexpr UncertainValue<T> operator+(const UncertainValue<T>& a, T b) noexcept { return {a.value + b, a.uncertainty}; }
+template <std::floating_point T> [[nodiscard]] constexpr UncertainValue<T> operator+(T a, const UncertainValue<T>& b) noexcept { return {a + b.value, b.uncertainty}; }
+template <std::floating_point T> [[nodiscard]] constexpr UncertainValue<T> operator-(const UncertainValue<T>& a, T b) noexcept { return {a.value - b, a.uncertainty}; }
+template <std::floating_point T> [[nodiscard]] constexpr UncertainValue<T> operator-(T a, const UncertainValue<T>& b) noexcept { return {a - b.value, b.uncertainty}; }
+template <std::floating_point T> [[nodiscard]] constexpr UncertainValue<T> operator*(const UncertainValue<T>& a, T b) noexcept { return {a.value * b, a.uncertainty * b}; }
+template <std::floating_point T> [[nodiscard]] constexpr UncertainValue<T> operator*(T a, const UncertainValue<T>& b) noexcept { return {a * b.value, a * b.uncertainty}; }
+template <std::floating_point T> [[nodiscard]] inline UncertainValue<T> operator/(const UncertainValue<T>& a, T b) noexcept { return {a.value / b, a.uncertainty / std::abs(b)}; }
+template <std::floating_point T> [[nodiscard]] inline UncertainValue<T> operator/(T a, const UncertainValue<T>& b) noexcept { return {a / b.value, b.uncertainty * std::abs(a) / (b.value * b.value)}; }
+template <std::floating_point T> [[nodiscard]] constexpr UncertainValue<T> operator-(const UncertainValue<T>& a) noexcept { return {-a.value, a.uncertainty}; }
+// gr::value / gr::uncertainty (UncertainValue.hpp:79-97): the parts of an uncertain value; a plain number is its own value and has no uncertainty
+template <typename T> [[nodiscard]] constexpr auto value(const T& v) noexcept { if constexpr (UncertainValueLike<T>) return v.value; else return v; }
+template <typename T> [[nodiscard]] constexpr auto uncertainty(const T& v) noexcept { if constexpr (UncertainValueLike<T>) return v.uncertainty; else return T{}; }
+#endif
+
 // ---------------------------------------------------------------------------------------------- property_map (settings payload)
 struct property_map;
 using pmt_base = std::variant<bool, std::int64_t, std::uint64_t, double, float, std::string, std::complex<float>, std::complex<double>, std::vector<float>,
@@ -201,6 +250,19 @@ bool assign_from(T& dst, const pmt& v) {
             } else if constexpr (std::is_arithmetic_v<T> && std::is_arithmetic_v<X>) {
                 dst = static_cast<T>(x);
                 return true;
+#ifndef GR4_COMPAT_NO_UNCERTAIN_VALUE
+            } else if constexpr (is_uncertain<T>::value && std::is_arithmetic_v<X>) { // a plain number: no uncertainty
+                dst = T(static_cast<typename T::value_type>(x));
+                return true;
+            } else if constexpr (is_uncertain<T>::value && is_vector<X>::value) { // {value, uncertainty}
+                if constexpr (std::is_arithmetic_v<typename X::value_type>) {
+                    if (x.size() != 2) return false;
+                    dst = T(static_cast<typename T::value_type>(x[0]), static_cast<typename T::value_type>(x[1]));
+                    return true;
+                } else {
+                    return false;
+                }
+#endif
             } else if constexpr (is_complex<T>::value && std::is_arithmetic_v<X>) {
                 dst = T(static_cast<typename T::value_type>(x), 0);
                 return true;

@@ -360,7 +360,9 @@ constexpr int dtype_of() { // gr4hip_dtype of a sample type
     else if constexpr (std::is_same_v<T, std::int8_t>) return GR4HIP_I8; else if constexpr (std::is_same_v<T, std::int16_t>) return GR4HIP_I16;
     else if constexpr (std::is_same_v<T, std::int32_t>) return GR4HIP_I32; else if constexpr (std::is_same_v<T, std::int64_t>) return GR4HIP_I64;
     else if constexpr (std::is_same_v<T, float>) return GR4HIP_F32; else if constexpr (std::is_same_v<T, double>) return GR4HIP_F64;
-    else if constexpr (std::is_same_v<T, std::complex<float>>) return GR4HIP_C32; else return GR4HIP_C64;
+    else if constexpr (std::is_same_v<T, std::complex<float>>) return GR4HIP_C32; else if constexpr (std::is_same_v<T, std::complex<double>>) return GR4HIP_C64;
+    else if constexpr (std::is_same_v<T, gr::UncertainValue<float>>) return GR4HIP_UF32; // {value, uncertainty}: the struct's layout is the device's element
+    else { static_assert(std::is_same_v<T, gr::UncertainValue<double>>, "no gr4hip_dtype for this sample type"); return GR4HIP_UF64; }
 }
 
 template <typename T, int OP>
@@ -377,7 +379,9 @@ struct MathConstStage final : Stage {
     }
     std::string_view kind() const override { return "math_const"; }
     static constexpr int dtype() { return dtype_of<T>(); }
-    const EwiseProgram*  program() const override { return &prog; }
+    const EwiseProgram*  program() const override { // (UncertainValue elements: one launch per block, gr4hip_ewise_create refuses them)
+        if constexpr (gr::UncertainValueLike<T>) return nullptr; else return &prog;
+    }
     int enqueue(const void* in, std::size_t n, void* out, std::size_t* n_out, gr4hip_stream_t s) override {
         *n_out = n;
         return gr4hip_math_const(OP, dtype(), in, out, n, &value, s);

@@ -50,9 +50,28 @@ void math_suite() { // vectors of qa_Math.cpp:59-121 (integer-valued rows)
     DivideConst<T> d;   d.applySettings({{"value", std::int64_t(2)}}); EXPECT(d.processOne(T(4)) == T(2));
 }
 
+// gr::UncertainValue<float | double>, two of the fourteen registered math types (Math.hpp:25-28, 68-71): the reference's known answers for its operators
+// (meta/test/qa_UncertainValue.cpp:35-42, 98-102, 148-152, 190-194) through the const blocks and the multi-port blocks
+template <typename F>
+void uncertain_suite() {
+    using namespace gr::blocks::math;
+    using U = gr::UncertainValue<F>;
+    const auto near = [](U got, F v, F u) { return std::abs(got.value - v) <= F(1e-6) * std::abs(v) && std::abs(got.uncertainty - u) <= F(1e-6) * std::abs(u); };
+    AddConst<U> a;      a.applySettings({{"value", std::vector<double>{20.0, 4.0}}}); EXPECT(near(a.processOne(U{10, 3}), 30, 5));
+    SubtractConst<U> s; s.applySettings({{"value", std::vector<double>{10.0, 4.0}}}); EXPECT(near(s.processOne(U{20, 3}), 10, 5));
+    MultiplyConst<U> m; m.applySettings({{"value", std::vector<double>{3.0, 0.5}}});  EXPECT(near(m.processOne(U{4, F(0.5)}), 12, F(2.5)));
+    DivideConst<U> d;   d.applySettings({{"value", std::vector<double>{4.0, 0.5}}});  EXPECT(near(d.processOne(U{16, 2}), 4, F(0.70710678118654752)));
+    MultiplyConst<U> one;                                                             EXPECT(near(one.processOne(U{4, F(0.5)}), 4, F(0.5))); // default value 1 (no uncertainty)
+    one.applySettings({{"value", 3.0}});                                              EXPECT(near(one.processOne(U{4, F(0.5)}), 12, F(1.5))); // a plain number: exact
+    math_case<U, Add<U>>({{U{10, 3}, U{1, 0}}, {U{20, 4}, U{2, 0}}}, {U{30, 5}, U{3, 0}});
+    math_case<U, Multiply<U>>({{U{4, F(0.5)}}, {U{3, F(0.5)}}}, {U{12, F(2.5)}});
+    EXPECT(gr::value(U{3, 1}) == F(3) && gr::uncertainty(U{3, 1}) == F(1) && gr::uncertainty(F(42)) == F(0) && !gr::UncertainValueLike<F> && gr::UncertainValueLike<U>);
+}
+
 int main(int argc, char** argv) {
     // ---- math blocks through Graph + Scheduler for the integer and float types
     math_suite<std::uint8_t>(); math_suite<std::int16_t>(); math_suite<std::int32_t>(); math_suite<std::uint64_t>(); math_suite<float>(); math_suite<double>();
+    uncertain_suite<float>(); uncertain_suite<double>();
 
     // ---- connect(): errors are returned, not thrown (docs/USER_API_Connecting_Blocks.md "Error handling")
     {

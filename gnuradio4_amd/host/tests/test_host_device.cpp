@@ -379,6 +379,53 @@ int main(int argc, char** argv) {
                 if (!dev) report("Add<int32> n_inputs = 3", keep[0] == keep[1] && keep[0].size() == 150000 ? 0.0 : 1.0, 0.0);
             }
         }
+        { // gr::UncertainValue<float | double> samples ({value, uncertainty}; Math.hpp:25-28, 68-71): DivideConst and a three-input Multiply, device against the host body
+            const auto run_u = [&]<typename U>(bool dev, bool nary, U) {
+                using F = typename U::value_type;
+                std::vector<U> s(120001);
+                for (std::size_t i = 0; i < s.size(); ++i) s[i] = U{F(1.5) + F(0.001) * F(i % 997) * (i % 2 ? F(1) : F(-1)), F(0.01) * F(1 + i % 13)};
+                Graph g;
+                auto& sink = g.emplaceBlock<testing::VectorSink<U>>();
+                if (nary) {
+                    auto& mul = g.emplaceBlock<blocks::math::Multiply<U>>(dev ? property_map{{"n_inputs", std::int64_t(3)}, {"compute_domain", "gpu:hip:0"s}} : property_map{{"n_inputs", std::int64_t(3)}});
+                    for (std::size_t i = 0; i < 3; ++i) {
+                        auto& src  = g.emplaceBlock<testing::VectorSource<U>>();
+                        src.values.assign(s.begin() + static_cast<std::ptrdiff_t>(i * 7), s.begin() + static_cast<std::ptrdiff_t>(i * 7 + 100000));
+                        if (!g.connect(src, "out"s, mul, "in#"s + std::to_string(i))) ++errors;
+                    }
+                    g.template connect<"out", "in">(mul, sink);
+                    scheduler::Simple sched;
+                    sched.exchange(std::move(g));
+                    if (!sched.runAndWait()) ++errors;
+                    if (dev && !mul._device_state) ++errors;
+                    if (dev) hip::release(mul);
+                } else {
+                    auto& src  = g.emplaceBlock<testing::VectorSource<U>>();
+                    src.values = s;
+                    auto& div  = g.emplaceBlock<blocks::math::DivideConst<U>>(dev ? property_map{{"value", std::vector<double>{4.0, 0.5}}, {"compute_domain", "gpu:hip:0"s}} : property_map{{"value", std::vector<double>{4.0, 0.5}}});
+                    g.template connect<"out", "in">(src, div);
+                    g.template connect<"out", "in">(div, sink);
+                    scheduler::Simple sched;
+                    sched.exchange(std::move(g));
+                    if (!sched.runAndWait()) ++errors;
+                    if (dev && !div._device_state) ++errors;
+                    if (dev) hip::release(div);
+                }
+                return sink._samples;
+            };
+            const auto cmp_u = [&](const char* what, const auto& d, const auto& h, std::size_t n, double tol) {
+                double worst = d.size() == n && h.size() == n ? 0.0 : 1e30;
+                for (std::size_t i = 0; i < n && worst < 1e29; ++i) {
+                    if (d[i].value != h[i].value) worst = 1e30; // one IEEE operation per source operation: identical
+                    worst = std::max(worst, std::abs(double(d[i].uncertainty) - double(h[i].uncertainty)) / std::abs(double(h[i].uncertainty)));
+                }
+                report(what, worst, tol);
+            };
+            cmp_u("DivideConst<UncertainValue<float>>", run_u(true, false, gr::UncertainValue<float>{}), run_u(false, false, gr::UncertainValue<float>{}), 120001, 4e-7);
+            cmp_u("DivideConst<UncertainValue<double>>", run_u(true, false, gr::UncertainValue<double>{}), run_u(false, false, gr::UncertainValue<double>{}), 120001, 1e-15);
+            cmp_u("Multiply<UncertainValue<float>> n_inputs = 3", run_u(true, true, gr::UncertainValue<float>{}), run_u(false, true, gr::UncertainValue<float>{}), 100000, 1e-6);
+            cmp_u("Multiply<UncertainValue<double>> n_inputs = 3", run_u(true, true, gr::UncertainValue<double>{}), run_u(false, true, gr::UncertainValue<double>{}), 100000, 1e-15);
+        }
         { // the FFT block: DataSets from the device equal the host body's (values to 1e-5 of the frame scale, identical descriptive part)
             std::vector<std::complex<float>> xc(1000 * 3 + 5);
             for (std::size_t i = 0; i < xc.size(); ++i) xc[i] = std::complex<float>(xf[2 * i], xf[2 * i + 1]) + std::polar(1.f, static_cast<float>(2 * std::numbers::pi * 0.1 * double(i % 1000)));

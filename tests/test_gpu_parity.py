@@ -4,6 +4,7 @@ integer / byte / copy work; for float32 FIR / IIR / FFT  max_k |gpu_k - truth_k|
 (BASELINE.json north_star: "<= 1e-5 rel"; relative above the rms level of the output, rms-normalised below it: point-wise relative error is
 meaningless near spectral zeros)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1846,6 +1847,13 @@ def test_math_uncertain_value_parity(G, golden, dtype_id, opname):
     c = golden["uncertain_value"][opname]
     np.testing.assert_allclose(G.math_const(opname, dev(np.array([c["a"]], dt)), c["b"], uncertain=True).cpu().numpy(), np.array([c["out"]], dt), rtol=tol)
     np.testing.assert_allclose(G.math_nary(opname, [dev(np.array([c["a"]], dt)), dev(np.array([c["b"]], dt))], uncertain=True).cpu().numpy(), np.array([c["out"]], dt), rtol=tol)
+    # ... and what the reference's own UncertainValue.hpp computes (fixture generated by running it: tests/golden/make_uncertain_fixture.py)
+    fx = np.load(os.path.join(O.ROOT, "tests", "golden", "uncertain_value_ops.npz"))["f32" if dtype_id == O.UF32 else "f64"]
+    k = ["Add", "Subtract", "Multiply", "Divide"].index(opname)
+    fa, fb, fw = np.ascontiguousarray(fx[:, 0:2]), np.ascontiguousarray(fx[:, 2:4]), fx[:, 4 + 2 * k:6 + 2 * k]
+    fg = G.math_nary(opname, [dev(fa), dev(fb)], uncertain=True).cpu().numpy()
+    assert np.array_equal(fg[:, 0], fw[:, 0])
+    np.testing.assert_allclose(fg[:, 1], fw[:, 1], rtol=tol, atol=0)
     # a span that starts anywhere (8- / 16-byte elements in a ring): scalar head and tail around the 16-byte body, and an odd element count
     for off in (1, 3):
         buf = torch.empty((n + 4, 2), dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda")

@@ -95,6 +95,26 @@ def test_reference_algorithm_headers_compile_unmodified(tmp_path, golden):
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="container-only: needs the reference tree where it lies (nothing of it travels)")
+def test_reference_uncertain_value_header_compiles_unmodified_and_pins_the_fixture():
+    """the reference's meta/UncertainValue.hpp, included from /root/reference as it is, compiles against this host layer (its <gnuradio-4.0/meta/utils.hpp> is the
+    layer's forwarding header) -- its operators on 2304 operand pairs per type ARE the committed fixture tests/golden/uncertain_value_ops.npz (which the oracle and
+    the device are compared with, tests/test_oracle_golden.py / test_gpu_parity.py), and the layer's own gr::UncertainValue gives the same numbers bit for bit"""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("make_uncertain_fixture", os.path.join(ROOT, "tests", "golden", "make_uncertain_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref, own = mod.table(True), mod.table(False)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "uncertain_value_ops.npz"))
+    for k in ("f32", "f64"):
+        assert ref[k].shape == (2304, 12)
+        assert np.array_equal(ref[k], fx[k].astype(np.float64)), k   # the fixture is what the reference's code computes
+        assert np.array_equal(own[k], ref[k]), k                      # the layer's type: the same arithmetic
+    src = open(os.path.join(ROOT, "gnuradio4_amd", "host", "tests", "test_reference_uncertain_value.cpp")).read()
+    assert "#include REF_UNCERTAIN_HPP" in src and "hypot" not in src  # only #included, never copied
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="container-only: needs the reference tree where it lies (nothing of it travels)")
 def test_hbm_ring_models_the_reference_bufferlike_concept():
     """the reference's own BufferLike / BufferReaderLike / BufferWriterLike concepts (core/include/gnuradio-4.0/Buffer.hpp:78-102, included
     unmodified from /root/reference; std-only header) hold for gr::hip::CircularBuffer<T> (static_asserts in host/tests/test_reference_bufferlike.cpp)"""

@@ -1,6 +1,7 @@
 """The CPU oracle pinned against the reference's own golden vectors / known-answer tests
 and against the reference itself (oracle/_ref/libgr4ref.so, built from the reference's rng headers)."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -355,6 +356,19 @@ def test_math_uncertain_value_golden(golden, dtype_id):
     # three inputs fold from the left like std::transform over the ports (Math.hpp:100-107): ((a + b) + c)
     a, b, c = (np.array([[1.0, 3.0]], dt), np.array([[2.0, 4.0]], dt), np.array([[3.0, 12.0]], dt))
     np.testing.assert_allclose(O.math_nary(O.ADD, dtype_id, [a, b, c]), np.array([[6.0, 13.0]], dt), rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype_id", [O.UF32, O.UF64])
+def test_math_uncertain_value_fixture_from_the_reference_header(dtype_id):
+    """tests/golden/uncertain_value_ops.npz holds what the reference's own meta/UncertainValue.hpp computes for 2304 operand pairs per type (generated by
+    tests/golden/make_uncertain_fixture.py, re-checked against the reference in the container by tests/test_host_cpp.py): the oracle's restatement gives the same"""
+    fx = np.load(os.path.join(O.ROOT, "tests", "golden", "uncertain_value_ops.npz"))["f32" if dtype_id == O.UF32 else "f64"]
+    a, b = np.ascontiguousarray(fx[:, 0:2]), np.ascontiguousarray(fx[:, 2:4])
+    for k, op in enumerate((O.ADD, O.SUB, O.MUL, O.DIV)):
+        want = fx[:, 4 + 2 * k:6 + 2 * k]
+        got = O.math_nary(op, dtype_id, [a, b])
+        assert np.array_equal(got[:, 0], want[:, 0]), op
+        np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=2e-7 if dtype_id == O.UF32 else 4e-16, atol=0)
 
 
 def test_math_integer_wraparound():
