@@ -113,6 +113,11 @@ class fir_filter(_Handle):
         multiply-add only: the reference's Inf / NaN behaviour) -- include/gr4hip.h"""
         check(lib().gr4hip_fir_set_algo(self._h, int(algo)), "fir_filter.set_algo")
 
+    def set_guard_mode(self, mode: int):
+        """capi.GUARD_STRICT (default) / GUARD_DEFERRED / GUARD_OFF: the dynamic-range guard of the frequency-domain kernels, and (OFF) of the f16 direct
+        form's per-segment verdict -- gr4hip_fir_set_guard_mode, include/gr4hip.h"""
+        check(lib().gr4hip_fir_set_guard_mode(self._h, int(mode)), "fir_filter.set_guard_mode")
+
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "fir_filter")
         if x.dtype != self.dtype:

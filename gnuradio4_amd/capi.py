@@ -18,7 +18,7 @@ WINDOWS = ["None", "Rectangular", "Hamming", "Hann", "HannExp", "Blackman", "Nut
 FFT_OUTPUT_IN_DB, FFT_OUTPUT_IN_DEG, FFT_UNWRAP_PHASE = 1, 2, 4
 CHAIN_AUTO, CHAIN_UNFUSED, CHAIN_FUSED_TD, CHAIN_FUSED_FD, CHAIN_TIME_DOMAIN = range(5)
 GUARD_STRICT, GUARD_DEFERRED, GUARD_OFF = range(3)
-FIR_AUTO, FIR_TIME_DOMAIN, FIR_EXACT_F32, FIR_TIME_DOMAIN_F32 = range(4)
+FIR_AUTO, FIR_TIME_DOMAIN, FIR_EXACT_F32, FIR_TIME_DOMAIN_F32, FIR_TIME_DOMAIN_BF16X3 = range(5)
 ROTATOR_CLOSED_FORM, ROTATOR_RECURRENCE = range(2)
 IIR_AUTO, IIR_PARALLEL, IIR_SEQUENTIAL_F32 = range(3)
 FIR_IIR_AUTO, FIR_IIR_ONE_LAUNCH, FIR_IIR_TWO_LAUNCHES = range(3)

@@ -233,6 +233,8 @@ int  fir_mfma_c32_launch(int KS, const float* x, long n, const float* hist, cons
 void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_out, std::vector<float>* row);
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
+bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
+int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int nprod, int guard);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af, bool cplx);
 int  fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist,
@@ -267,6 +269,7 @@ struct gr4hip_fir {
     int                cur = 0;
     int                algo = GR4HIP_FIR_AUTO; // gr4hip_fir_set_algo
     bool               f32_user = false;       // (what gr4hip_fir_set_algo asked for: a reset re-arms the guard and goes back to it)
+    bool               bf16_user = false;      // GR4HIP_FIR_TIME_DOMAIN_BF16X3: the three-term bf16 products where the default would take the two-term f16 ones
     bool               f32_products = false;   // GR4HIP_FIR_TIME_DOMAIN_F32, or a stream the dynamic-range guard has moved: no three-term bf16 products (the f32 matrix-pipe kernels instead)
     int                guard_mode = GR4HIP_GUARD_STRICT; // gr4hip_fir_set_guard_mode
     gr4::ChainFused*   fd  = nullptr; // complex, decim 1, ntaps <= 256: frequency-domain plan (created on first use)
@@ -279,6 +282,10 @@ struct gr4hip_fir {
     int                bandKp = 0;
     DeviceBuffer       d_bfrag;       // float / complex, 65 .. 256 taps (float: slices of 256 up to 2048): the three bf16 tap-fragment tables of fir_mfma_bf16x3_kernel (built on first use)
     int                bfKS = 0;
+    DeviceBuffer       d_hfrag;       // float, 33 .. 256 taps and the 256-tap slices of 384 .. 1024: the two-term f16 tables of fir_mfma_f16x2_kernel (fir_f16.hip; built on first use)
+    int                hfKS = 0;      // < 0: taps that form cannot carry
+    std::vector<size_t> hf_off;       // per slice: offset into d_hfrag (in 16-bit units) ...
+    std::vector<int>    hf_ks;        // ... and window size
     DeviceBuffer       d_bdfrag;      // float, decim 2 .. 9, short branches: band-form bf16 fragments (fir_decim_bf16x3_kernel)
     int                bdKS = 0, bdHb = 0; // bdKS < 0: the window does not fit that kernel
     std::vector<size_t> bf_off;       // per slice: offset into d_bfrag (in bf16 elements) ...
@@ -352,6 +359,7 @@ static void fir_invalidate_tables(gr4hip_fir* f) {
     f->mKS = 0;
     f->bandKp = 0;
     f->bfKS = 0;
+    f->hfKS = 0;
     f->bdKS = 0;
 }
 // `taps` = gain x `user_taps` (float64 product, rounded once), uploaded
@@ -470,9 +478,10 @@ int gr4hip_fir_set_epilogue(gr4hip_fir_t* f, const gr4hip_ewise_t* prog) { retur
 
 int gr4hip_fir_set_algo(gr4hip_fir_t* f, int algo) {
     GR4_REQUIRE(f, "fir_set_algo: null handle");
-    GR4_REQUIRE(algo >= GR4HIP_FIR_AUTO && algo <= GR4HIP_FIR_TIME_DOMAIN_F32, "fir_set_algo: unknown algo %d", algo);
-    f->algo         = algo == GR4HIP_FIR_TIME_DOMAIN_F32 ? (int)GR4HIP_FIR_TIME_DOMAIN : algo;
+    GR4_REQUIRE(algo >= GR4HIP_FIR_AUTO && algo <= GR4HIP_FIR_TIME_DOMAIN_BF16X3, "fir_set_algo: unknown algo %d", algo);
+    f->algo         = algo == GR4HIP_FIR_TIME_DOMAIN_F32 ? (int)GR4HIP_FIR_TIME_DOMAIN : (algo == GR4HIP_FIR_TIME_DOMAIN_BF16X3 ? (f->S == 2 ? (int)GR4HIP_FIR_TIME_DOMAIN : (int)GR4HIP_FIR_AUTO) : algo); // (float filters take their matrix-pipe kernels under AUTO)
     f->f32_products = f->f32_user = algo == GR4HIP_FIR_TIME_DOMAIN_F32;
+    f->bf16_user    = algo == GR4HIP_FIR_TIME_DOMAIN_BF16X3;
     return GR4HIP_OK;
 }
 int gr4hip_fir_set_guard_mode(gr4hip_fir_t* f, int mode) {
@@ -656,6 +665,41 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // (384 .. 1024 taps: slices of 256 taps, each a pass over the input delayed by 256 p samples that adds to y: 512 taps 115 instead of 90 Gsamples/s on the
     // register-window kernel, 1024 taps 50.5 instead of 47; below 384 and above 1024 taps the extra passes cost more than they save -- measured)
     if (f->S == 1 && f->decim == 1 && f->ntaps > 32 && (f->ntaps <= 256 || (f->ntaps >= 384 && f->ntaps <= 1024)) && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+        algo == GR4HIP_FIR_AUTO && !no_bf16x3(f) && !f->bf16_user && !dev_switch(kDevFirNoF16x2) && f->hfKS >= 0 && plain) {
+        // ... on the f16 matrix pipe with two-term splits under a per-segment block exponent (fir_f16.hip): three products per tap instead of six
+        int          rc = GR4HIP_OK;
+        const size_t nslice = ceil_div(f->ntaps, (size_t)256);
+        if (f->hfKS == 0) {
+            std::vector<unsigned short> all;
+            bool                        ok = true;
+            f->hf_off.assign(nslice, 0);
+            f->hf_ks.assign(nslice, 0);
+            for (size_t p = 0; p < nslice && ok; ++p) {
+                std::vector<unsigned short> af;
+                const size_t                len = std::min<size_t>(256, f->ntaps - 256 * p);
+                ok = fir_f16_make_afrag(f->taps.data() + 256 * p, len, &f->hf_ks[p], &af, 1, 0);
+                f->hf_off[p] = all.size();
+                all.insert(all.end(), af.begin(), af.end());
+            }
+            if (!ok) f->hfKS = -1;
+            else {
+                rc = f->d_hfrag.ensure(all.size() * sizeof(unsigned short));
+                if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (rc) return rc;
+                f->hfKS = f->hf_ks[0];
+            }
+        }
+        if (f->hfKS > 0) {
+            float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
+            for (size_t p = 0; p < nslice && !rc; ++p)
+                rc = fir_f16_launch(f->hf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_hfrag.ptr + f->hf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0, dev_switch(kDevFirF16Products) == 4 ? 4 : 3,
+                                    nslice == 1 && f->guard_mode != GR4HIP_GUARD_OFF /*every segment judges its own output / input power (fir_f16.hip); the slices of a long filter see partial sums*/);
+            if (rc) return rc;
+            done = n_in;
+            mfma_wrote_hist = true;
+        }
+    }
+    if (done == 0 && f->S == 1 && f->decim == 1 && f->ntaps > 32 && (f->ntaps <= 256 || (f->ntaps >= 384 && f->ntaps <= 1024)) && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
         algo == GR4HIP_FIR_AUTO && !no_bf16x3(f) && plain) {
         int          rc = GR4HIP_OK;
         const size_t nslice = ceil_div(f->ntaps, (size_t)256);

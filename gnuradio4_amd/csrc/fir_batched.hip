@@ -475,6 +475,8 @@ using namespace gr4;
 namespace gr4 {
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_bf16.hip
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
+bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
+int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int nprod, int guard);
 }
 struct gr4hip_fir_batched {
     size_t       nch = 0, ntaps = 0;
@@ -483,6 +485,8 @@ struct gr4hip_fir_batched {
     int          cur = 0;
     DeviceBuffer d_bfrag; // > 64 taps: per-channel three-term bf16 tap fragments (fir_bf16.hip)
     int          bfKS = 0;
+    DeviceBuffer d_hfrag; // > 32 taps: per-channel two-term f16 tables (fir_f16.hip) -- the default on long spans
+    int          hfKS = 0;
 };
 
 extern "C" {
@@ -504,6 +508,13 @@ int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, cons
         fir_bf16_make_afrag(h_taps, ntaps, &f->bfKS, &bf, nchannels, 0);
         rc = f->d_bfrag.ensure(bf.size() * sizeof(unsigned short));
         if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, bf.data(), bf.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+    }
+    if (!rc && ntaps >= kBfMinTaps && ntaps > 32) {
+        std::vector<unsigned short> hf;
+        if (fir_f16_make_afrag(h_taps, ntaps, &f->hfKS, &hf, nchannels, 0)) {
+            rc = f->d_hfrag.ensure(hf.size() * sizeof(unsigned short));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, hf.data(), hf.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+        } else f->hfKS = 0;
     }
     for (int k = 0; k < 2 && !rc; ++k) rc = f->d_hist[k].ensure(nchannels * f->Kp * sizeof(float));
     if (!rc) rc = gr4hip_fir_batched_reset(f);
@@ -527,7 +538,9 @@ int gr4hip_fir_batched_process(gr4hip_fir_batched_t* f, const float* d_in, size_
     hipStream_t st = as_stream(stream);
     const float *hist = (const float*)f->d_hist[f->cur].ptr, *af = (const float*)f->d_afrag.ptr;
     int rc;
-    if (f->bfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3)) // three-term bf16 form (fir_bf16.hip): same history layout
+    if (f->hfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2)) // two-term f16 form (fir_f16.hip): same history layout
+        rc = fir_f16_launch(f->hfKS, d_in, (long)n, hist, f->Kp, f->d_hfrag.ptr, d_out, st, nullptr, (long)in_stride, (long)out_stride, (unsigned)f->nch, 0, 0, dev_switch(kDevFirF16Products) == 4 ? 4 : 3, 1);
+    else if (f->bfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3)) // three-term bf16 form (fir_bf16.hip): same history layout
         rc = fir_bf16_launch(f->bfKS, d_in, (long)n, hist, f->Kp, f->d_bfrag.ptr, d_out, st, nullptr, (long)in_stride, (long)out_stride, (unsigned)f->nch, 0, 0);
     else
         rc = fir_mfma_launch(f->KS, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n, (unsigned)f->nch, st, nullptr);

@@ -1,0 +1,461 @@
+// fir_f16.hip -- fir_filter<float> (33 .. 256 taps, slices of longer filters, the batched many-channel FIR) on the f16 matrix pipe: two-term splits under a
+// per-segment block exponent, three products per tap instead of fir_bf16.hip's six.
+//
+// fir_bf16.hip holds the package at its 1400 W cap with the shader clock at 1.73 - 1.77 GHz: six dense bf16 MFMAs per K-step are the price of float32 accuracy on a
+// pipe whose terms carry 8 significant bits.  An f16 term carries 11: x = (x1 + x2 / 2^11) / s with x1 = f16(x s), x2 = f16((x s - x1) 2^11) is exact to 2^-22 |x|
+// (typically 2^-24), and with the taps split the same way the three products x1 b1, x1 b2, x2 b1 carry everything above 2^-22 of a product -- the parity bar is
+// 1e-5 = 2^-16.6.  Half the matrix-pipe work of the bf16 form, two planes instead of three in LDS.
+//
+// What f16 does not have is float32's exponent range, so each segment of 4096 outputs (its 4096 + Hb staged samples) carries ONE block exponent: s is the power
+// of two that puts the segment's largest magnitude in [2^14, 2^15); the residual plane is scaled by another 2^11, so its quantisation floor (f16 subnormals,
+// 2^-24) sits 2^-49 below the segment's largest sample.  The statistics (largest magnitude, and the smallest non-zero per-lane maximum as the level of the
+// ordinary samples) are taken from the registers the segment is prefetched into, one segment ahead of the split, through eight LDS words -- no extra barrier.
+// A segment that holds a non-finite sample, or whose largest sample is more than 2^28 above that ordinary level (a glitch of 1e30 beside unit-power samples),
+// is not given to the f16 pipe at all: the workgroup evaluates its 4096 outputs with float32 products on the f32 matrix pipe (slow_segment below) -- or, when the
+// sample is not finite, as plain float32 sums one output at a time: the reference's +-Inf / NaN on exactly the ntaps outputs whose window holds it.
+//
+// The kernel also judges its own accuracy.  The error of this form is relative to the PRODUCTS (~1.3e-7 rms of sqrt(sum b^2) x rms(x)), like float32's own rounding
+// but four times larger, so it only shows against the OUTPUT when the filter removes nearly everything it is given.  Every segment's output power is compared
+// with its input power: P_y < 2^-12 (sum b^2) P_x -- more than 36 dB of the staged power rejected beyond what white noise would lose -- and the segment is
+// evaluated again on the float32 path, at the end of the workgroup's run of segments (`guard`; off for the slices of long filters, whose launches see partial sums).
+// So a stream whose rejected part is far above what passes costs the float32 path's rate on exactly the segments where that is so, and has the reference's
+// float32 error there (include/gr4hip.h, "PARITY CONTRACT").
+//
+// Same output-to-tile map, fragment stream, double-buffered planes and prefetch as fir_mfma_bf16x3_shared_kernel (fir_bf16.hip), for every window width KS = 3 .. 9.
+#include "common.hpp"
+#include "buffer_ops.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace gr4 {
+
+using f16x8_h = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2_h = __attribute__((ext_vector_type(2))) _Float16;
+using f32x4_h = __attribute__((ext_vector_type(4))) float;
+using f32x2_h = __attribute__((ext_vector_type(2))) float;
+using u32x4_h = __attribute__((ext_vector_type(4))) unsigned;
+
+#ifndef GR4_F16_WG_PER_CU
+#define GR4_F16_WG_PER_CU 2
+#endif
+#ifndef GR4_F16_TARGET_WGS
+#define GR4_F16_TARGET_WGS 512
+#define GR4_F16_MAX_SPW 128
+#endif
+constexpr int kHfSeg      = 4096;
+constexpr int kHfMaxRange = 28; // a segment whose largest sample is more than 2^28 above its ordinary level takes the float32 path
+
+// channel block of the table fir_f16_make_afrag writes, in 16-bit units: [2 planes][KS][64 lanes][8] f16 fragments, 8 units of header {float 1 / t, int ntaps, float 2^-12 sum b^2, -},
+// 32 KS float taps (the float32 path's)
+__host__ __device__ constexpr int hf_block_units(int KS) { return KS * 1024 + 8 + KS * 64; }
+
+// two samples -> their two f16 terms under the block scale s (a power of two: x s is exact); the residual is exact in float32 and enters its plane times 2^11
+__device__ __forceinline__ void hf_split2(float x0, float x1, float s, unsigned& h, unsigned& l) {
+    const f32x2_h v  = {x0 * s, x1 * s};
+    const f16x2_h hh = __builtin_convertvector(v, f16x2_h);
+    const f32x2_h r  = (v - __builtin_convertvector(hh, f32x2_h)) * 2048.f;
+    const f16x2_h ll = __builtin_convertvector(r, f16x2_h);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+// wave-wide reductions on the DPP network (four row steps) + four scalar reads: every lane returns the wave's value.  (Six ds_bpermute steps per statistic were a
+// dependent chain of ~600 cycles in front of the segment's barrier: 8 % of the kernel.)
+template <typename Op>
+__device__ __forceinline__ unsigned hf_wave_reduce_u32(unsigned v, Op op) {
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));  // quad_perm [1, 0, 3, 2]
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));  // quad_perm [2, 3, 0, 1]
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false)); // row_half_mirror
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false)); // row_mirror: every lane holds its row of 16
+    const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16), r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float hf_wave_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int KS, int NPROD> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block; NPROD = 3 (x1 b1, x1 b2, x2 b1) or 4 (+ x2 b2)
+__global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(const float* __restrict__ x0, const float* __restrict__ hist0 /*the Kh samples in front of x*/, int Kh,
+                                                                                const unsigned short* __restrict__ blk0 /*[channels] blocks of hf_block_units(KS)*/, float* __restrict__ y0, long n,
+                                                                                float* __restrict__ new_hist, long in_stride, long out_stride /*channel blockIdx.y*/,
+                                                                                int delay /*this pass filters x delayed by `delay` samples ...*/, int accum /*... and adds to y (slices of long filters)*/,
+                                                                                int seg_per_wg, int guard /*judge every segment's output / input power (see the header)*/) {
+    const float*          x     = x0 + (long)blockIdx.y * in_stride;
+    const float*          hist  = hist0 + (long)blockIdx.y * Kh;
+    const unsigned short* blk   = blk0 + (long)blockIdx.y * hf_block_units(KS);
+    const u32x4_h*        afrag = reinterpret_cast<const u32x4_h*>(blk);
+    const float           inv_t = *reinterpret_cast<const float*>(blk + KS * 1024);
+    const int             ntaps = *reinterpret_cast<const int*>(blk + KS * 1024 + 2);
+    const float           gthr  = *reinterpret_cast<const float*>(blk + KS * 1024 + 4);
+    const float*          tapsf = reinterpret_cast<const float*>(blk + KS * 1024 + 8);
+    float*                y     = y0 + (long)blockIdx.y * out_stride;
+    constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kHfSeg + Hb; // staged samples per segment (a multiple of 16)
+    constexpr int PL  = NS + 8 * (NS / 256) + 16;               // f16 elements per plane: one 16-byte chunk of padding per 256 samples (see P below)
+    constexpr int NL4 = (NS / 4 + 255) / 256;                   // float4 loads a lane holds for the next segment
+    constexpr int NM  = KS + 3;                                 // fragments of a wave's stream
+    __shared__ __attribute__((aligned(16))) unsigned short pls[2][2 * PL];
+    __shared__ __attribute__((aligned(16))) unsigned stat[2][12]; // per data segment parity: the four waves' largest magnitude bits, smallest non-zero lane maxima, sums of squares
+    __shared__ __attribute__((aligned(16))) float    ystat[2][4]; // per computed segment parity: the four waves' output powers
+    __shared__ unsigned char noted[GR4_F16_MAX_SPW];              // per segment of this workgroup's run: 1 = again with float32 products, 2 = again as plain float32 sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    auto P = [](int s_) { return s_ + 8 * (s_ >> 8); };
+
+    u32x4_h a[2][KS]; // A fragments of the two tap planes
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[p][ks] = afrag[(p * KS + ks) * 64 + lane];
+
+    auto xs = [&](long i) -> float { return i >= 0 ? (i < n ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f); }; // the stream: carried history in front of x, zeros past the end
+    float4 nxa[NL4], nxb[NL4];
+    auto   load_next = [&](float4 (&nxt)[NL4], long seg0) { // seg0 >= kHfSeg >= Hb + delay: nothing below 0; past the end of the span / of the segment the range check returns 0
+        const long   i0   = seg0 - Hb - delay;
+        const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
+        const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto load_general = [&](float4 (&nxt)[NL4], long seg0) { // the first segment of the span: sample by sample
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int q = tid + 256 * u;
+            float     t[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q < NS / 4)
+                for (int c = 0; c < 4; ++c) t[c] = xs(seg0 + 4L * q + c - Hb - delay);
+            nxt[u] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    };
+    // statistics of the registers of one staged segment -> stat[slot]; read back (after a barrier) by block_scale
+    auto put_stats = [&](const float4 (&v)[NL4], int slot) {
+        unsigned mx = 0;
+        float    px = 0.f;
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const unsigned b0 = __float_as_uint(v[u].x) & 0x7fffffffu, b1 = __float_as_uint(v[u].y) & 0x7fffffffu, b2 = __float_as_uint(v[u].z) & 0x7fffffffu, b3 = __float_as_uint(v[u].w) & 0x7fffffffu;
+            mx = max(max(mx, b0), max(b1, max(b2, b3)));
+            px = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, fmaf(v[u].w, v[u].w, px))));
+        }
+        unsigned mn = mx ? mx : 0xffffffffu;
+        mx = hf_wave_reduce_u32(mx, [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
+        mn = hf_wave_reduce_u32(mn, [](unsigned a_, unsigned b_) { return a_ < b_ ? a_ : b_; });
+        px = hf_wave_sum(px);
+        if (lane == 0) { stat[slot][wave] = mx; stat[slot][4 + wave] = mn; stat[slot][8 + wave] = __float_as_uint(px); }
+    };
+    auto put_ypower = [&](float py, int slot) {
+        py = hf_wave_sum(py);
+        if (lane == 0) ystat[slot][wave] = py;
+    };
+    // -> scale s (its inverse in inv_s), and whether the segment must take the float32 path
+    auto block_scale = [&](int slot, float& s, float& inv_s, float& px) -> int { // 0: the f16 pipe; 1: float32 products (the spread); 2: plain float32 sums (a non-finite sample)
+        const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[slot][0]), n4 = *reinterpret_cast<const uint4*>(&stat[slot][4]), p4 = *reinterpret_cast<const uint4*>(&stat[slot][8]);
+        px = (__uint_as_float(p4.x) + __uint_as_float(p4.y)) + (__uint_as_float(p4.z) + __uint_as_float(p4.w));
+        const unsigned mx = __builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))), mn = __builtin_amdgcn_readfirstlane(min(min(n4.x, n4.y), min(n4.z, n4.w)));
+        const int  e  = (int)(mx >> 23), el = (int)(mn >> 23);
+        const int  slow = e == 255 ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0);
+        const int  ec = e < 15 ? 15 : (e > 254 ? 254 : e);
+        s     = __uint_as_float((unsigned)(268 - ec) << 23); // largest magnitude -> [2^14, 2^15)
+        inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
+        return slow;
+    };
+    auto put4e = [&](unsigned short* pl, int e, float4 v, float s) {
+        unsigned h0, l0, h1, l1;
+        hf_split2(v.x, v.y, s, h0, l0);
+        hf_split2(v.z, v.w, s, h1, l1);
+        *reinterpret_cast<uint2*>(pl + e)      = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(pl + PL + e) = make_uint2(l0, l1);
+    };
+    auto put_next = [&](unsigned short* pl, int u, const float4& v, float s) { // branch-free (it sits between MFMAs): lanes past the staged range write into the spare elements behind each plane
+        const int q = tid + 256 * u;
+        put4e(pl, (256 * (u + 1) <= NS / 4 || q < NS / 4) ? P(4 * q) : PL - 16 + 4 * (lane & 3), v, s);
+    };
+    const long nseg = (n + kHfSeg - 1) / kHfSeg, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
+    if (sfirst >= slast) return; // (whole workgroups only: no barrier is skipped by part of one)
+    if (tid < GR4_F16_MAX_SPW) noted[tid] = 0;
+    const int tb = (wave >> 1) + 8 * (wave & 1); // waves 0, 1: the even tiles from 0 / 8; waves 2, 3: the odd tiles from 1 / 9
+    const int sb = 256 * col + 16 * tb + 8 * kq;
+    // the float32 path: one segment's outputs as float32 products on the f32 matrix pipe (v_mfma_f32_16x16x4_f32: every product and partial sum an IEEE float32
+    // operation, the sums block-wise).  `stage` is a plane buffer nobody needs at that moment (4520 floats): the segment's NS raw samples go there, 4 floats
+    // of padding per 256 (lane (col, kq) reads word 256 col + 16 t + 4 k4 + kq: 64 different banks), the tap operand comes from the float taps of the table.
+    // Same tile map as the f16 path; about the rate of the library's f32 matrix-pipe FIR kernel while it runs.  Called by the whole workgroup.
+    auto slow_segment = [&](long sg, unsigned short* stage16) {
+        float*     stg  = reinterpret_cast<float*>(stage16);
+        const long seg0 = sg * kHfSeg;
+        auto       Pf   = [](int i) { return i + 4 * (i >> 8); };
+        if (sg > 0) load_next(nxa, seg0); // (the prefetch registers are free by now)
+        else load_general(nxa, 0);
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int q = tid + 256 * u;
+            if (256 * (u + 1) <= NS / 4 || q < NS / 4) *reinterpret_cast<float4*>(stg + Pf(4 * q)) = nxa[u]; // (4 consecutive samples never straddle a pad: pads sit at multiples of 256)
+        }
+        float* tz = reinterpret_cast<float*>(stage16 == pls[0] ? pls[1] : pls[0]); // the taps with Kw zeros either side: tz[Kw + k] = b[k]
+        for (int i = tid; i < 2 * Kw; i += 256) tz[i] = (i >= Kw && i - Kw < ntaps) ? tapsf[i - Kw] : 0.f;
+        __syncthreads();
+        f32x4_h acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+        const float* ta = tz + Kw + Hb + col - kq; // the tap operand of K-step k4: A[row = col][k = kq] = b[Hb + col - (4 k4 + kq)]
+        for (int k0 = 0; k0 < Kw / 4; k0 += 8) {   // (Kw / 4 = 8 KS; chunks of eight K-steps keep 40 LDS reads in flight without hoisting all 360 of them into registers)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int   k4 = k0 + kk;
+                const float av = ta[-4 * k4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, stg[Pf(256 * col + 16 * (tb + 2 * j) + 4 * k4 + kq)], acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long o = seg0 + 256L * col + 16 * (tb + 2 * j) + 4 * kq;
+            if (o + 3 < n) {
+                float4 w = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+                if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w; }
+                *reinterpret_cast<float4*>(y + o) = w;
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + acc[j][r];
+            }
+        }
+        __syncthreads(); // (the buffer is staged again by the next noted segment)
+    };
+    // a segment that holds a non-finite sample: plain float32 sums from global memory, one output at a time -- the reference's classes (+Inf, -Inf, NaN) on exactly the
+    // ntaps outputs whose window holds the sample (the matrix pipe would multiply it with the zero padding of the tap operand).  Very slow; such samples are not ordinary data.
+    auto exact_segment = [&](long sg) {
+        for (int r = 0; r < kHfSeg / 256; ++r) {
+            const long o = sg * kHfSeg + tid + 256 * r;
+            if (o >= n) break;
+            float acc = 0.f;
+            for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs(o - delay - k), acc);
+            y[o] = (accum ? y[o] : 0.f) + acc;
+        }
+    };
+    // segments for the float32 path are only NOTED while the run is under way (a byte per segment of the run in LDS: masks in scalar registers spilled) and evaluated behind it, when
+    // the tap fragments and the prefetch registers are dead -- inside the loop the call would sit on 110 live registers and spill them into the f16 loop
+    auto note = [&](long sg, bool exact) {
+        if (tid == 0) noted[sg - sfirst] = exact ? 2 : 1;
+    };
+    // the guard's verdict on segment sg (its output powers are in ystat[sg & 1], a barrier ago): rejected -> again on the float32 path
+    auto judge = [&](long sg, float px) {
+        const float4 p4 = *reinterpret_cast<const float4*>(&ystat[sg & 1][0]);
+        const float  py = (p4.x + p4.y) + (p4.z + p4.w);
+        if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, false);
+    };
+    float s_cur, inv_cur, px_cur, px_prev = 0.f;
+    int   slow_cur;
+    {
+        if (sfirst > 0) load_next(nxa, sfirst * kHfSeg);
+        else load_general(nxa, 0);
+        put_stats(nxa, (int)(sfirst & 1));
+        __syncthreads();
+        slow_cur = block_scale((int)(sfirst & 1), s_cur, inv_cur, px_cur);
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) put_next(pls[0], u, nxa[u], s_cur);
+        load_next(nxa, (sfirst + 1) * kHfSeg); // (past the end of the span: empty loads)
+        put_stats(nxa, (int)((sfirst + 1) & 1));
+        __syncthreads();
+    }
+    // one segment: MFMAs on `pl`; `cur` (the segment behind it, requested a segment ago, statistics in stat[(sg + 1) & 1]) goes into `plo` meanwhile; the segment behind THAT
+    // is requested into `oth` first and its statistics are left in stat[sg & 1] before the barrier
+    auto segment = [&](long sg, const unsigned short* pl, unsigned short* plo, float4 (&cur)[NL4], float4 (&oth)[NL4]) {
+        const long seg0 = sg * kHfSeg;
+        float      s_nx, inv_nx, px_nx;
+        const int  slow_nx = block_scale((int)((sg + 1) & 1), s_nx, inv_nx, px_nx);
+        load_next(oth, seg0 + 2 * kHfSeg);
+        if (guard && sg > sfirst) judge(sg - 1, px_prev);
+        float py = 0.f;
+        if (!slow_cur) {
+            f32x4_h c[4], d[4], e4[NPROD == 4 ? 4 : 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+            if constexpr (NPROD == 4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e4[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const unsigned short* q  = pl + P(sb + 32 * m);
+                const f16x8_h         b1 = *reinterpret_cast<const f16x8_h*>(q), b2 = *reinterpret_cast<const f16x8_h*>(q + PL);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ks = m - j;
+                    if (ks < 0 || ks >= KS) continue;
+                    const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a[1][ks]);
+                    c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[j], 0, 0, 0);
+                    d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, d[j], 0, 0, 0);
+                    d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, d[j], 0, 0, 0);
+                    if constexpr (NPROD == 4) e4[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, e4[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < NL4; ++u) // the next segment's samples are split and written into the other buffer beside the MFMAs, spread over the stream
+                    if (u * NM / NL4 == m) put_next(plo, u, cur[u], s_nx);
+            }
+            // D[row = 4 kq + r][col]: y[seg0 + 256 col + 16 t + 4 kq + r]; the small terms are added to the large ones last, then the two block scales come off (powers of two)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long o = seg0 + 256L * col + 16 * (tb + 2 * j) + 4 * kq;
+                float      v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = d[j][r];
+                    if constexpr (NPROD == 4) t += e4[j][r] * (1.f / 2048.f);
+                    v[r] = ((c[j][r] + t * (1.f / 2048.f)) * inv_t) * inv_cur;
+                    py   = fmaf(v[r], v[r], py);
+                }
+                if (o + 3 < n) {
+                    float4 w = make_float4(v[0], v[1], v[2], v[3]);
+                    if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w; }
+                    *reinterpret_cast<float4*>(y + o) = w;
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + v[r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) put_next(plo, u, cur[u], s_nx);
+            note(sg, slow_cur == 2);
+            py = __builtin_inff(); // (nothing to judge)
+        }
+        put_stats(oth, (int)(sg & 1));
+        put_ypower(py, (int)(sg & 1));
+        s_cur    = s_nx;
+        inv_cur  = inv_nx;
+        slow_cur = slow_nx;
+        px_prev  = px_cur;
+        px_cur   = px_nx;
+        __syncthreads(); // the other buffer and the statistics are complete, and every wave is done with this buffer before the segment after the next overwrites it
+    };
+    for (long sg = sfirst; sg < slast; sg += 2) {
+        segment(sg, pls[0], pls[1], nxa, nxb);
+        if (sg + 1 < slast) segment(sg + 1, pls[1], pls[0], nxb, nxa);
+    }
+    if (guard) judge(slast - 1, px_prev);
+    __syncthreads();
+    for (int i = 0; i < seg_per_wg; ++i) { // (uniform: every lane reads the same bytes)
+        const int kind = noted[i];
+        if (kind == 1) {
+            __builtin_amdgcn_s_waitcnt(0); // this wave's stores have landed (and everybody's, behind slow_segment's first barrier) before other lanes write the same outputs
+            slow_segment(sfirst + i, pls[0]);
+        } else if (kind == 2) exact_segment(sfirst + i);
+    }
+    if (new_hist != nullptr && blockIdx.x == 0 && blockIdx.y == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+        }
+    }
+}
+
+static unsigned short host_f16_rne(float f) { // float -> IEEE binary16, round to nearest even (subnormals kept)
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    const unsigned short sign = (unsigned short)((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (unsigned short)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (u >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u); // >= 65520 rounds to infinity
+    if (u < 0x38800000u) {                                         // below 2^-14: a multiple of 2^-24
+        float a;
+        std::memcpy(&a, &u, 4);
+        return (unsigned short)(sign | (unsigned)std::nearbyint(a * 16777216.f));
+    }
+    unsigned       h   = (((u >> 23) - 112u) << 10) | ((u & 0x7fffffu) >> 13);
+    const unsigned rem = u & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (unsigned short)(sign | h);
+}
+static float host_f16_to_f(unsigned short h) {
+    const int   e = (h >> 10) & 31, m = h & 1023;
+    const float v = e == 0 ? std::ldexp((float)m, -24) : (e == 31 ? (m ? NAN : INFINITY) : std::ldexp((float)(1024 + m), e - 25));
+    return (h & 0x8000) ? -v : v;
+}
+
+// the table the kernel reads: per channel a block of hf_block_units(KS) 16-bit units (see there).  Fragment (plane p, K-step ks, lane l, element t) = tap-plane value
+// b_p[Hb + (l & 15) - (32 ks + 8 (l >> 4) + t)], b_1 = f16(b t), b_2 = f16((b t - b_1) 2^11), t = the power of two that puts the channel's largest tap in [2^14, 2^15).
+// false: taps this form cannot carry (non-finite) -- the caller keeps its other kernels
+bool fir_f16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks) {
+    const int KS = force_ks ? force_ks : std::max(3, (int)((ntaps - 1 + 16 + 31) / 32)), Hb = 32 * KS - 16;
+    if (KS < 3 || KS > 9 || (size_t)Hb + 1 < ntaps) return false;
+    const size_t units = (size_t)hf_block_units(KS);
+    af->assign(nch * units, 0);
+    for (size_t c = 0; c < nch; ++c) {
+        const float*    taps = taps_all + c * ntaps;
+        unsigned short* blk  = af->data() + c * units;
+        unsigned        mx   = 0;
+        for (size_t k = 0; k < ntaps; ++k) {
+            unsigned u;
+            std::memcpy(&u, &taps[k], 4);
+            mx = std::max(mx, u & 0x7fffffffu);
+        }
+        if (mx >= 0x7f800000u) return false;
+        const int      e  = std::min(std::max((int)(mx >> 23), 15), 254);
+        const unsigned tb = (unsigned)(268 - e) << 23, ib = (unsigned)(e - 14) << 23;
+        float          t, inv_t;
+        std::memcpy(&t, &tb, 4);
+        std::memcpy(&inv_t, &ib, 4);
+        std::vector<unsigned short> pl[2];
+        for (auto& v : pl) v.assign(ntaps, 0);
+        for (size_t k = 0; k < ntaps; ++k) {
+            const float          b = taps[k] * t;
+            const unsigned short h = host_f16_rne(b);
+            pl[0][k] = h;
+            pl[1][k] = host_f16_rne((b - host_f16_to_f(h)) * 2048.f);
+        }
+        for (int p = 0; p < 2; ++p)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int l = 0; l < 64; ++l)
+                    for (int tt = 0; tt < 8; ++tt) {
+                        const int k = Hb + (l & 15) - (32 * ks + 8 * (l >> 4) + tt);
+                        if (k >= 0 && (size_t)k < ntaps) blk[(((size_t)p * KS + ks) * 64 + l) * 8 + tt] = pl[p][k];
+                    }
+        const int nt = (int)ntaps;
+        double    h2 = 0;
+        for (size_t k = 0; k < ntaps; ++k) h2 += (double)taps[k] * taps[k];
+        const float gthr = (float)(h2 / 4096.0);
+        std::memcpy(blk + KS * 1024, &inv_t, 4);
+        std::memcpy(blk + KS * 1024 + 2, &nt, 4);
+        std::memcpy(blk + KS * 1024 + 4, &gthr, 4);
+        std::memcpy(blk + KS * 1024 + 8, taps, ntaps * sizeof(float));
+    }
+    *KS_out = KS;
+    return true;
+}
+
+// y[i] = sum_k b[k] x[i - delay - k] (+ y[i] when accum), i < n; hist = the Kh samples in front of x; x and y 16-byte aligned, strides multiples of 4
+int fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum,
+                   int nprod, int guard) {
+    if (KS < 3 || KS > 9 || 32 * KS - 16 + delay > kHfSeg) return GR4HIP_UNSUPPORTED;
+    const auto tb   = static_cast<const unsigned short*>(table);
+    const long nseg = ceil_div(n, (long)kHfSeg);
+    const int  spw  = (int)std::min<long>(std::max<long>(nseg * (long)nch / GR4_F16_TARGET_WGS, 1), GR4_F16_MAX_SPW); // segments per workgroup: the prologue (tap fragments, first staging) once per run
+    const dim3 grid((unsigned)ceil_div(nseg, (long)spw), nch);
+#define GR4_HF_CASE(K)                                                                                                                                                     \
+    case K:                                                                                                                                                                \
+        if (nprod == 4) hipLaunchKernelGGL((fir_mfma_f16x2_kernel<K, 4>), grid, dim3(256), 0, st, x, hist, Kh, tb, y, n, new_hist, in_stride, out_stride, delay, accum, spw, guard); \
+        else hipLaunchKernelGGL((fir_mfma_f16x2_kernel<K, 3>), grid, dim3(256), 0, st, x, hist, Kh, tb, y, n, new_hist, in_stride, out_stride, delay, accum, spw, guard);            \
+        break
+    switch (KS) {
+        GR4_HF_CASE(3);
+        GR4_HF_CASE(4);
+        GR4_HF_CASE(5);
+        GR4_HF_CASE(6);
+        GR4_HF_CASE(7);
+        GR4_HF_CASE(8);
+        GR4_HF_CASE(9);
+    default: return GR4HIP_UNSUPPORTED;
+    }
+#undef GR4_HF_CASE
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+} // namespace gr4

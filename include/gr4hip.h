@@ -177,7 +177,7 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
  * reference's sequential float32 sum -- 7e-6 of the output where a rejected signal 50 dB above it leaves the float32 CPU form at 3e-5 and the three-term bf16
  * products at 1e-4), 33 .. 256 taps at about a third of the bf16 kernels' rate; Inf / NaN reach as described above.  It is where the dynamic-range guard sends
  * a stream (FIR_AUTO's fast convolution, the chain): the regime that made it fall back is the one in which the product precision shows. */
-typedef enum { GR4HIP_FIR_AUTO = 0, GR4HIP_FIR_TIME_DOMAIN = 1, GR4HIP_FIR_EXACT_F32 = 2, GR4HIP_FIR_TIME_DOMAIN_F32 = 3 } gr4hip_fir_algo;
+typedef enum { GR4HIP_FIR_AUTO = 0, GR4HIP_FIR_TIME_DOMAIN = 1, GR4HIP_FIR_EXACT_F32 = 2, GR4HIP_FIR_TIME_DOMAIN_F32 = 3, GR4HIP_FIR_TIME_DOMAIN_BF16X3 = 4 } gr4hip_fir_algo;
 int gr4hip_fir_set_algo(gr4hip_fir_t* fir, int algo);
 int gr4hip_fir_set_guard_mode(gr4hip_fir_t* fir, int mode); /* gr4hip_guard_mode (below), for FIR_AUTO's fast convolution of long complex spans; default GR4HIP_GUARD_STRICT */
 int gr4hip_fir_process(gr4hip_fir_t* fir, const void* d_in, size_t n_in, void* d_out, size_t* n_out, gr4hip_stream_t stream);

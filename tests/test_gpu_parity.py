@@ -184,6 +184,7 @@ def test_fir_float_bf16_three_term_kernel(G, ntaps, devsw):
     x = (O.signal_f32(91, n, tone_frel=0.31, tone_amp=30.0)).astype(np.float32)
     truth, _ = O.fir(b, x)
     f = G.fir_filter(b, torch.float32)
+    f.set_algo(G.capi.FIR_TIME_DOMAIN_BF16X3)  # (the default takes the two-term f16 kernel since round 4: test_fir_float_f16_two_term_kernel)
     cuts = [0, 120_000, 120_004, 121_000, n]
 
     def run(flt):
@@ -207,11 +208,112 @@ def test_fir_float_bf16_three_term_kernel(G, ntaps, devsw):
     tr, _ = O.fir(br, xr)
     xin = torch.empty(100_004, dtype=torch.float32, device="cuda")[4:]
     xin.copy_(torch.from_numpy(xr))
-    e_bf = _rel(G.fir_filter(br, torch.float32).process_bulk(xin).cpu().numpy(), tr)
+    fbf = G.fir_filter(br, torch.float32)
+    fbf.set_algo(G.capi.FIR_TIME_DOMAIN_BF16X3)
+    e_bf = _rel(fbf.process_bulk(xin).cpu().numpy(), tr)
     devsw("GR4HIP_FIR_NO_BF16X3", 1)
     e_32 = _rel(G.fir_filter(br, torch.float32).process_bulk(xin).cpu().numpy(), tr)
     devsw("GR4HIP_FIR_NO_BF16X3", 0)
     assert e_bf <= 3e-6 and e_bf <= 3 * e_32 + 1e-7, (e_bf, e_32)
+
+
+def _dev16(x):
+    t = torch.empty(x.size + 4, dtype=torch.float32, device="cuda")[4:]  # 16-byte aligned start
+    t.copy_(torch.from_numpy(x))
+    return t
+
+
+@pytest.mark.parametrize("ntaps", [33, 65, 81, 113, 146, 200, 256, 400, 1024])
+def test_fir_float_f16_two_term_kernel(G, ntaps, devsw):
+    """fir_filter<float>, 33 .. 256 taps (and the 256-tap slices of 384 .. 1024), long aligned spans -- the default since round 4: samples and taps as two f16
+    terms each under a per-segment block exponent, three products per tap on the f16 matrix pipe (fir_f16.hip).  Against the float64 oracle at the same bar as
+    every float32 path, also when the filter removes a tone 30 dB above what passes and across ragged calls; on white noise through a random filter no
+    worse than twice the three-term bf16 kernel; and whatever the level of the stream (1e-30 .. 1e30: the block exponent)."""
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    n = 300_000
+    x = (O.signal_f32(91, n, tone_frel=0.31, tone_amp=30.0)).astype(np.float32)
+    truth, _ = O.fir(b, x)
+    cuts = [0, 120_000, 120_004, 121_000, n]
+
+    def run(flt, xx):
+        return np.concatenate([flt.process_bulk(_dev16(xx[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    y = run(G.fir_filter(b, torch.float32), x)
+    assert _rel(y, truth) <= TOL
+    devsw("GR4HIP_FIR_NO_F16X2", 1)
+    ybf = run(G.fir_filter(b, torch.float32), x)
+    devsw("GR4HIP_FIR_NO_F16X2", 0)
+    assert not np.array_equal(y, ybf)  # (two different kernels did run)
+    for scale in (1e-30, 1e30):  # a power-of-ten level far from 1: every segment finds its own exponent
+        xs_ = (x.astype(np.float64) * scale).astype(np.float32)
+        ts, _ = O.fir(b, xs_)
+        assert _rel(run(G.fir_filter(b, torch.float32), xs_), ts) <= TOL
+    rng = np.random.default_rng(ntaps)
+    br = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    xr = O.signal_f32(92, 100_000, tone_amp=0.0)
+    tr, _ = O.fir(br, xr)
+    e_hf = _rel(G.fir_filter(br, torch.float32).process_bulk(_dev16(xr)).cpu().numpy(), tr)
+    fbf = G.fir_filter(br, torch.float32)
+    fbf.set_algo(G.capi.FIR_TIME_DOMAIN_BF16X3)
+    e_bf = _rel(fbf.process_bulk(_dev16(xr)).cpu().numpy(), tr)
+    assert e_hf <= 3e-6 and e_hf <= 2 * e_bf + 1e-7, (e_hf, e_bf)
+
+
+@pytest.mark.parametrize("ntaps", [64, 200, 256])
+def test_fir_f16_kernel_judges_its_own_segments(G, ntaps):
+    """a rejected tone 50 dB above the noise that passes: the error of ANY split-product form is relative to the products and shows against the output (the
+    three-term bf16 kernel: ~1e-4, the two-term f16 products by themselves: ~2e-4; the reference's own float32 sum: ~3e-5).  The f16 kernel compares every
+    segment's output power with its input power and evaluates a segment that rejects more than 36 dB of it again as float32 sums -- the default stays at the
+    reference's float32 error (include/gr4hip.h, PARITY CONTRACT); gr4hip_fir_set_guard_mode(GUARD_OFF) shows what it would be without.  Segments of ordinary
+    input inside the same stream are not redone (the verdict is per segment): the stream's second half is plain noise and stays on the matrix pipe."""
+    n = 1 << 18
+    b = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    x = (O.signal_f32(7, n, tone_amp=0.0) * 0.05).astype(np.float32)
+    t = np.arange(n // 2)
+    x[: n // 2] += (316.0 * np.cos(2 * np.pi * 0.31 * t)).astype(np.float32)
+    truth, _ = O.fir(b, x)
+    half = slice(ntaps, n // 2 - 4096), slice(n // 2 + 8192, n)
+
+    def err(y, sl):
+        return _rel(y[sl], truth[sl])
+    y = G.fir_filter(b, torch.float32).process_bulk(_dev16(x)).cpu().numpy()
+    off = G.fir_filter(b, torch.float32)
+    off.set_guard_mode(G.capi.GUARD_OFF)
+    yo = off.process_bulk(_dev16(x)).cpu().numpy()
+    ex = G.fir_filter(b, torch.float32)
+    ex.set_algo(G.capi.FIR_EXACT_F32)
+    ye = ex.process_bulk(_dev16(x)).cpu().numpy()
+    assert err(yo, half[0]) > 3e-5                       # the products by themselves, under the interferer
+    assert err(y, half[0]) <= 1.5 * err(ye, half[0]) + 1e-6  # judged and redone: the float32 sum's error
+    assert err(y, half[1]) <= TOL and np.array_equal(y[half[1]], yo[half[1]])  # ordinary segments: the matrix-pipe result, untouched
+
+
+def test_fir_f16_kernel_outliers_and_non_finite_samples(G):
+    """the block exponent's blind spot, closed: a finite glitch of 1e30 (and one of 3.4e38, an Inf, a NaN) among unit-power samples would push a whole segment's
+    ordinary samples below the f16 planes' floor -- the kernel sees the spread (largest magnitude against the smallest per-lane maximum) and gives such a
+    segment to the float32 path: the classes and the reach of the non-finite values are the reference's (exactly ntaps outputs), and every other output of the
+    stream is inside the parity bar"""
+    n, ntaps = 300_000, 200
+    b = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    x = O.signal_f32(7, n)
+    pos = {"glitch": 30_001, "inf": 90_003, "nan": 150_005, "big": 210_007}
+    x[pos["glitch"]] = 1e30
+    x[pos["inf"]] = -np.inf
+    x[pos["nan"]] = np.nan
+    x[pos["big"]] = 3.4e38
+    truth, _ = O.fir(b, x)
+    with np.errstate(over="ignore", invalid="ignore"):
+        t32 = truth.astype(np.float32)
+    xc = x.copy()
+    xc[list(pos.values())] = 0
+    rms = float(np.sqrt(np.mean(O.fir(b, xc)[0] ** 2)))
+    y = G.fir_filter(b, torch.float32).process_bulk(_dev16(x)).cpu().numpy()
+    assert np.array_equal(np.isnan(y), np.isnan(t32)) and np.array_equal(np.isposinf(y), np.isposinf(t32)) and np.array_equal(np.isneginf(y), np.isneginf(t32))
+    ok = np.isfinite(t32)
+    near = np.zeros(n, bool)
+    for m in (pos["glitch"], pos["big"]):
+        near[m: m + ntaps] = True
+    assert float(np.max(np.abs(y[ok & ~near] - truth[ok & ~near]) / np.maximum(np.abs(truth[ok & ~near]), rms))) <= TOL  # the ordinary outputs, at THEIR level
+    assert float(np.max(np.abs(y[ok & near] - truth[ok & near]) / np.maximum(np.abs(truth[ok & near]), 1e-3 * np.abs(truth[ok & near]).max()))) <= TOL  # under the glitches: relative to them
 
 
 @pytest.mark.parametrize("decim,ntaps", [(8, 1024), (2, 64), (3, 600), (4, 100), (10, 1000), (5, 91), (16, 4096), (16, 512), (16, 33), (32, 1024), (32, 7), (64, 2048), (64, 100), (64, 1),
@@ -1437,6 +1539,12 @@ def test_fir_non_finite_samples(G, cplx, ntaps):
     assert tol(y, ~tbad) <= TOL
     # --- default algorithm
     y = G.fir_filter(b, dt).process_bulk(_aligned16(x)).cpu().numpy()
+    if not cplx:  # float, since round 4: the two-term f16 kernel gives a segment with such a sample to its float32 path -- the reference's classes and reach, exactly
+        assert np.array_equal(np.isnan(y), np.isnan(t32)) and np.array_equal(np.isposinf(y), np.isposinf(t32)) and np.array_equal(np.isneginf(y), np.isneginf(t32))
+        assert tol(y, ~tbad) <= TOL
+        f = G.fir_filter(b, dt)
+        f.set_algo(G.capi.FIR_TIME_DOMAIN_BF16X3)  # the three-term bf16 kernel, per handle: what the text above says
+        y = f.process_bulk(_aligned16(x)).cpu().numpy()
     ybad = ~np.isfinite(y)
     assert not np.any(tbad & ~ybad)                                         # nothing the reference makes non-finite comes out finite
     allowed = np.zeros(n, bool)
