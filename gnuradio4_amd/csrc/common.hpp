@@ -30,7 +30,6 @@ enum DevSwitch {
     kDevFftSmoothRuntime,     // GR4HIP_FFT_SMOOTH_RUNTIME: the run-time mixed-radix kernel also for sizes that have a compile-time plan
     kDevEwiseNoDivRcp,        // GR4HIP_EWISE_NO_DIV_RCP: element-wise programs divide by a float constant with the general quotient (the tests compare it with the reciprocal form)
     kDevFirNoF16x2,           // GR4HIP_FIR_NO_F16X2: the three-term bf16 FIR kernels where the default takes the two-term f16 ones (per handle: GR4HIP_FIR_TIME_DOMAIN_BF16X3)
-    kDevFirF16Products,       // GR4HIP_FIR_F16_PRODUCTS=4: the f16 kernels keep the fourth product x2 b2 (measurement only)
     kDevSwitchCount
 };
 int dev_switch(DevSwitch s);

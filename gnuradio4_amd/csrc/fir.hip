@@ -234,7 +234,7 @@ void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
-int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int nprod, int guard);
+int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af, bool cplx);
 int  fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist,
@@ -692,8 +692,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         if (f->hfKS > 0) {
             float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
             for (size_t p = 0; p < nslice && !rc; ++p)
-                rc = fir_f16_launch(f->hf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_hfrag.ptr + f->hf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0, dev_switch(kDevFirF16Products) == 4 ? 4 : 3,
-                                    nslice == 1 && f->guard_mode != GR4HIP_GUARD_OFF /*every segment judges its own output / input power (fir_f16.hip); the slices of a long filter see partial sums*/);
+                rc = fir_f16_launch(f->hf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_hfrag.ptr + f->hf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0, nslice == 1 && f->guard_mode != GR4HIP_GUARD_OFF /*every segment judges its own output / input power (fir_f16.hip); the slices of a long filter see partial sums*/);
             if (rc) return rc;
             done = n_in;
             mfma_wrote_hist = true;

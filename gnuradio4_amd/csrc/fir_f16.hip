@@ -4,7 +4,9 @@
 // fir_bf16.hip holds the package at its 1400 W cap with the shader clock at 1.73 - 1.77 GHz: six dense bf16 MFMAs per K-step are the price of float32 accuracy on a
 // pipe whose terms carry 8 significant bits.  An f16 term carries 11: x = (x1 + x2 / 2^11) / s with x1 = f16(x s), x2 = f16((x s - x1) 2^11) is exact to 2^-22 |x|
 // (typically 2^-24), and with the taps split the same way the three products x1 b1, x1 b2, x2 b1 carry everything above 2^-22 of a product -- the parity bar is
-// 1e-5 = 2^-16.6.  Half the matrix-pipe work of the bf16 form, two planes instead of three in LDS.
+// 1e-5 = 2^-16.6.  Half the matrix-pipe work of the bf16 form, two planes instead of three in LDS.  (The fourth product x2 b2 was measured and dropped: 256 taps
+// 526 -> 453 Gsamples/s for an error of 1.4e-4 instead of 1.8e-4 of the output under a rejected tone 50 dB above it -- the representation of x and b in 22 bits is
+// what is left either way, and that regime is the guard's below.)
 //
 // What f16 does not have is float32's exponent range, so each segment of 4096 outputs (its 4096 + Hb staged samples) carries ONE block exponent: s is the power
 // of two that puts the segment's largest magnitude in [2^14, 2^15); the residual plane is scaled by another 2^11, so its quantisation floor (f16 subnormals,
@@ -20,6 +22,9 @@
 // evaluated again on the float32 path, at the end of the workgroup's run of segments (`guard`; off for the slices of long filters, whose launches see partial sums).
 // So a stream whose rejected part is far above what passes costs the float32 path's rate on exactly the segments where that is so, and has the reference's
 // float32 error there (include/gr4hip.h, "PARITY CONTRACT").
+//
+// (Measured and dropped: the outputs through LDS as whole 1 KiB rows one segment later instead of 64-byte pieces straight from the accumulators -- 256 taps 499 -> 488,
+// 64 taps 623 -> 626 Gsamples/s on one box: the store pattern is not what these launches wait for.)
 //
 // Same output-to-tile map, fragment stream, double-buffered planes and prefetch as fir_mfma_bf16x3_shared_kernel (fir_bf16.hip), for every window width KS = 3 .. 9.
 #include "common.hpp"
@@ -82,7 +87,7 @@ __device__ __forceinline__ float hf_wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
-template <int KS, int NPROD> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block; NPROD = 3 (x1 b1, x1 b2, x2 b1) or 4 (+ x2 b2)
+template <int KS> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block
 __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(const float* __restrict__ x0, const float* __restrict__ hist0 /*the Kh samples in front of x*/, int Kh,
                                                                                 const unsigned short* __restrict__ blk0 /*[channels] blocks of hf_block_units(KS)*/, float* __restrict__ y0, long n,
                                                                                 float* __restrict__ new_hist, long in_stride, long out_stride /*channel blockIdx.y*/,
@@ -138,14 +143,13 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     };
     // statistics of the registers of one staged segment -> stat[slot]; read back (after a barrier) by block_scale
     auto put_stats = [&](const float4 (&v)[NL4], int slot) {
-        unsigned mx = 0;
-        float    px = 0.f;
+        float mf = 0.f, px = 0.f; // largest magnitude (v_max3_f32 on |.|: a NaN is passed over, an Inf stays) and the power (NaN if a NaN is among the samples)
 #pragma unroll
         for (int u = 0; u < NL4; ++u) {
-            const unsigned b0 = __float_as_uint(v[u].x) & 0x7fffffffu, b1 = __float_as_uint(v[u].y) & 0x7fffffffu, b2 = __float_as_uint(v[u].z) & 0x7fffffffu, b3 = __float_as_uint(v[u].w) & 0x7fffffffu;
-            mx = max(max(mx, b0), max(b1, max(b2, b3)));
+            mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fabsf(v[u].x)), __builtin_fmaxf(__builtin_fabsf(v[u].y), __builtin_fmaxf(__builtin_fabsf(v[u].z), __builtin_fabsf(v[u].w))));
             px = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, fmaf(v[u].w, v[u].w, px))));
         }
+        unsigned mx = __float_as_uint(mf);
         unsigned mn = mx ? mx : 0xffffffffu;
         mx = hf_wave_reduce_u32(mx, [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
         mn = hf_wave_reduce_u32(mn, [](unsigned a_, unsigned b_) { return a_ < b_ ? a_ : b_; });
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         px = (__uint_as_float(p4.x) + __uint_as_float(p4.y)) + (__uint_as_float(p4.z) + __uint_as_float(p4.w));
         const unsigned mx = __builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))), mn = __builtin_amdgcn_readfirstlane(min(min(n4.x, n4.y), min(n4.z, n4.w)));
         const int  e  = (int)(mx >> 23), el = (int)(mn >> 23);
-        const int  slow = e == 255 ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0);
+        const int  slow = (e == 255 || px != px) ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0); // (px = +Inf without an Inf sample: squares above 3.4e38 -- the guard
+                                                                                                                  //  cannot judge such a segment and sends it to the float32 products)
         const int  ec = e < 15 ? 15 : (e > 254 ? 254 : e);
         s     = __uint_as_float((unsigned)(268 - ec) << 23); // largest magnitude -> [2^14, 2^15)
         inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
@@ -275,12 +280,9 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         if (guard && sg > sfirst) judge(sg - 1, px_prev);
         float py = 0.f;
         if (!slow_cur) {
-            f32x4_h c[4], d[4], e4[NPROD == 4 ? 4 : 1];
+            f32x4_h c[4], d[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
-            if constexpr (NPROD == 4)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e4[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const unsigned short* q  = pl + P(sb + 32 * m);
@@ -293,31 +295,41 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
                     c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[j], 0, 0, 0);
                     d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, d[j], 0, 0, 0);
                     d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, d[j], 0, 0, 0);
-                    if constexpr (NPROD == 4) e4[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, e4[j], 0, 0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < NL4; ++u) // the next segment's samples are split and written into the other buffer beside the MFMAs, spread over the stream
                     if (u * NM / NL4 == m) put_next(plo, u, cur[u], s_nx);
             }
-            // D[row = 4 kq + r][col]: y[seg0 + 256 col + 16 t + 4 kq + r]; the small terms are added to the large ones last, then the two block scales come off (powers of two)
+            // D[row = 4 kq + r][col]: y[seg0 + 256 col + 16 t + 4 kq + r]; the small terms are added to the large ones last, then the two block scales come off (powers of two:
+            // as ONE factor when their product is a normal float -- every stream but those within 2^6 of float32's limits)
+            const int   ek  = (int)((__float_as_uint(inv_t) >> 23) & 255) + (int)((__float_as_uint(inv_cur) >> 23) & 255) - 254;
+            const bool  one = ek > -120 && ek < 120;
+            const float k1 = one ? inv_t * inv_cur : inv_t, k2 = one ? 1.f : inv_cur, kd = k1 * (1.f / 2048.f);
+            const bool  full = seg0 + kHfSeg <= n && !accum; // whole segments leave through a buffer descriptor (no 64-bit address per store)
+            const rsrc_t ry  = make_rsrc(y + seg0, full ? kHfSeg * 4u : 0u);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const long o = seg0 + 256L * col + 16 * (tb + 2 * j) + 4 * kq;
-                float      v[4];
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float t = d[j][r];
-                    if constexpr (NPROD == 4) t += e4[j][r] * (1.f / 2048.f);
-                    v[r] = ((c[j][r] + t * (1.f / 2048.f)) * inv_t) * inv_cur;
-                    py   = fmaf(v[r], v[r], py);
+                    v[r] = fmaf(d[j][r], kd, c[j][r] * k1);
+                    if (!one) v[r] *= k2;
+                    py = fmaf(v[r], v[r], py);
                 }
-                if (o + 3 < n) {
-                    float4 w = make_float4(v[0], v[1], v[2], v[3]);
-                    if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w; }
-                    *reinterpret_cast<float4*>(y + o) = w;
+                const int oo = 256 * col + 16 * (tb + 2 * j) + 4 * kq;
+                if (full) {
+                    const u32x4_h w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(w, ry, oo * 4, 0, 0);
                 } else {
-                    for (int r = 0; r < 4; ++r)
-                        if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + v[r];
+                    const long o = seg0 + oo;
+                    if (o + 3 < n) {
+                        float4 w = make_float4(v[0], v[1], v[2], v[3]);
+                        if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w; }
+                        *reinterpret_cast<float4*>(y + o) = w;
+                    } else {
+                        for (int r = 0; r < 4; ++r)
+                            if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + v[r];
+                    }
                 }
             }
         } else {
@@ -432,17 +444,14 @@ bool fir_f16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::v
 
 // y[i] = sum_k b[k] x[i - delay - k] (+ y[i] when accum), i < n; hist = the Kh samples in front of x; x and y 16-byte aligned, strides multiples of 4
 int fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum,
-                   int nprod, int guard) {
+                   int guard) {
     if (KS < 3 || KS > 9 || 32 * KS - 16 + delay > kHfSeg) return GR4HIP_UNSUPPORTED;
     const auto tb   = static_cast<const unsigned short*>(table);
     const long nseg = ceil_div(n, (long)kHfSeg);
-    const int  spw  = (int)std::min<long>(std::max<long>(nseg * (long)nch / GR4_F16_TARGET_WGS, 1), GR4_F16_MAX_SPW); // segments per workgroup: the prologue (tap fragments, first staging) once per run
+    const long wgs  = KS <= 5 ? 2 * GR4_F16_TARGET_WGS : GR4_F16_TARGET_WGS; // (narrow windows: shorter runs measured +3 % -- 64 taps 620 -> 642 Gsamples/s --, wide ones -1 %)
+    const int  spw  = (int)std::min<long>(std::max<long>(nseg * (long)nch / wgs, 1), GR4_F16_MAX_SPW); // segments per workgroup: the prologue (tap fragments, first staging) once per run
     const dim3 grid((unsigned)ceil_div(nseg, (long)spw), nch);
-#define GR4_HF_CASE(K)                                                                                                                                                     \
-    case K:                                                                                                                                                                \
-        if (nprod == 4) hipLaunchKernelGGL((fir_mfma_f16x2_kernel<K, 4>), grid, dim3(256), 0, st, x, hist, Kh, tb, y, n, new_hist, in_stride, out_stride, delay, accum, spw, guard); \
-        else hipLaunchKernelGGL((fir_mfma_f16x2_kernel<K, 3>), grid, dim3(256), 0, st, x, hist, Kh, tb, y, n, new_hist, in_stride, out_stride, delay, accum, spw, guard);            \
-        break
+#define GR4_HF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_f16x2_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, tb, y, n, new_hist, in_stride, out_stride, delay, accum, spw, guard); break
     switch (KS) {
         GR4_HF_CASE(3);
         GR4_HF_CASE(4);

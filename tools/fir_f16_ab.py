@@ -1,5 +1,5 @@
 """developer tool: the two-term f16 FIR kernels (fir_f16.hip) against the three-term bf16 ones (fir_bf16.hip) on one box -- error against the float64 oracle
-and rate, float FIR over tap counts and BASELINE configs[3]; GR4HIP_FIR_F16_PRODUCTS=4 keeps the fourth product (x2 b2)."""
+and rate, float FIR over tap counts and BASELINE configs[3]."""
 import sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, torch
@@ -14,8 +14,7 @@ def rel(got, truth):
     return float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), rms)))
 
 
-MODES = [("bf16x3", {"GR4HIP_FIR_NO_F16X2": 1}), ("f16x2/3", {"GR4HIP_FIR_NO_F16X2": 0, "GR4HIP_FIR_F16_PRODUCTS": 3}), ("f16x2/3 unguarded", {"GR4HIP_FIR_NO_F16X2": 0, "GR4HIP_FIR_F16_PRODUCTS": 3}),
-         ("f16x2/4", {"GR4HIP_FIR_NO_F16X2": 0, "GR4HIP_FIR_F16_PRODUCTS": 4})]
+MODES = [("bf16x3", {"GR4HIP_FIR_NO_F16X2": 1}), ("f16x2", {"GR4HIP_FIR_NO_F16X2": 0}), ("f16x2 unguarded", {"GR4HIP_FIR_NO_F16X2": 0})]
 
 
 def mode(m):
