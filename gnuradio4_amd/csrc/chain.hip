@@ -126,7 +126,10 @@ static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, 
     std::vector<float>& taps = c->taps;
     int rc = GR4HIP_OK;
     // the kernel pair with float32 products (GR4HIP_FIR_TIME_DOMAIN_F32), at every fft size: the regime that trips the guard -- a rejected signal far above the
-    // output -- is the one in which the three-term bf16 products of chain_td_kernel / the default direct form measure 3 .. 16 x a float32 sum's error
+    // output -- is the one in which the three-term bf16 products of chain_td_kernel / the split-product direct forms measure 3 .. 16 x a float32 sum's error.
+    // (Round 4 tried the two-term f16 direct form here, whose own guard redoes the segments that reject more than 36 dB of their power: the pair went from 97 to
+    // ~160 Gsamples/s, but between the two thresholds -- 14 .. 36 dB rejected -- its error, small against the filtered samples, is a function of the rejected tone and
+    // the transform behind it gathers it into a few bins: 4 of the chain guard tests failed the bar there.  The float32 products stay.)
     if (!c->fir) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, taps.data(), taps.size(), 1);
         if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN_F32);

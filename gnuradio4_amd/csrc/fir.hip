@@ -234,6 +234,7 @@ void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
+int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard);
 int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af, bool cplx);
@@ -619,8 +620,30 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // complex<float>, no decimation, 33..256 taps, whatever the fast convolution did not take (GR4HIP_FIR_TIME_DOMAIN, a stream the dynamic-range guard has
     // moved to the direct form, or both): the same block-Toeplitz product on the re and im planes of the interleaved samples (fir_mfma_c32_kernel)
     // (16-byte-aligned input too: the three-term bf16 form of the same product, fir_bf16.hip)
+    // ... since round 4 on the f16 matrix pipe with two-term splits under a per-segment block exponent (fir_f16.hip): half the products, and every segment judges its
+    // own output / input power -- so a stream the fast convolution's guard has handed over stays here (the segments that need float32 products get them inside the launch)
+    if (f->S == 2 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y + done * 2) | reinterpret_cast<uintptr_t>(x + done * 2)) & 15) == 0 &&
+        algo != GR4HIP_FIR_EXACT_F32 && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && f->hfKS >= 0 && plain) {
+        int rc = GR4HIP_OK;
+        if (f->hfKS == 0) {
+            std::vector<unsigned short> af;
+            if (!fir_f16_make_afrag(f->taps.data(), f->ntaps, &f->hfKS, &af, 1, 0)) f->hfKS = -1;
+            else {
+                rc = f->d_hfrag.ensure(af.size() * sizeof(unsigned short));
+                if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (rc) { f->hfKS = 0; return rc; }
+            }
+        }
+        if (f->hfKS > 0) {
+            float* nh = done == 0 ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
+            rc = fir_f16_c32_launch(f->hfKS, x + done * 2, (long)(n_in - done), hist, (int)f->hcap, f->d_hfrag.ptr, y + done * 2, st, nh, f->guard_mode != GR4HIP_GUARD_OFF);
+            if (rc) return rc;
+            done = n_in;
+            mfma_wrote_hist = nh != nullptr;
+        }
+    }
     static const size_t kCBfMinTaps = [] { const char* e = std::getenv("GR4HIP_CFIR_BF16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // developer knob: 65 puts 33..64 taps back on the f32 MFMA (measured 5-8 % slower: 299-316 against 322-333 Gsamples/s); below 33 taps the register-window kernel is ahead up to 27 taps and within 3 % from there (tools/cfir_bf16_threshold.py)
-    if (f->S == 2 && f->decim == 1 && f->ntaps >= kCBfMinTaps && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y + done * 2) | reinterpret_cast<uintptr_t>(x + done * 2)) & 15) == 0 &&
+    if (done < n_in && f->S == 2 && f->decim == 1 && f->ntaps >= kCBfMinTaps && f->ntaps <= 256 && n_in - done >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y + done * 2) | reinterpret_cast<uintptr_t>(x + done * 2)) & 15) == 0 &&
         !no_bf16x3(f) && plain) {
         int rc = GR4HIP_OK;
         if (f->bfKS == 0) {

@@ -314,9 +314,11 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
                 for (int r = 0; r < 4; ++r) {
                     v[r] = fmaf(d[j][r], kd, c[j][r] * k1);
                     if (!one) v[r] *= k2;
-                    py = fmaf(v[r], v[r], py);
                 }
                 const int oo = 256 * col + 16 * (tb + 2 * j) + 4 * kq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) // the guard's output power: the outputs of the span only (past its end the staged zeros make the filter ring: not what it passes)
+                    if (seg0 + kHfSeg <= n || seg0 + oo + r < n) py = fmaf(v[r], v[r], py);
                 if (full) {
                     const u32x4_h w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                     __builtin_amdgcn_raw_buffer_store_b128(w, ry, oo * 4, 0, 0);
@@ -361,6 +363,284 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         } else if (kind == 2) exact_segment(sfirst + i);
     }
     if (new_hist != nullptr && blockIdx.x == 0 && blockIdx.y == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+        }
+    }
+}
+
+// fir_filter<complex<float>> (real taps on interleaved {re, im} samples) on the same scheme: the two components are two real streams under the same taps and ONE block
+// exponent -- four planes (re / im x the two terms), 2048 complex outputs per segment (16 columns of 128, eight tiles per column), a wave walks the fragment stream of
+// its two tiles (tb, tb + 2) once per component: four accumulator pairs in flight as in the float kernel.  D leaves re-interleaved, 32 bytes per lane.  The guard, the
+// float32 products for judged / outlier segments and the plain sums for non-finite samples are the float kernel's, on both components.  hist: the Kh complex samples in
+// front of x.
+constexpr int kHfSegC = 2048;
+
+template <int KS>
+__global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_kernel(const float2* __restrict__ x, const float2* __restrict__ hist /*the Kh samples in front of x*/, int Kh,
+                                                                                    const unsigned short* __restrict__ blk /*one block of hf_block_units(KS)*/, float2* __restrict__ y, long n,
+                                                                                    float2* __restrict__ new_hist, int seg_per_wg, int guard) {
+    const u32x4_h* afrag = reinterpret_cast<const u32x4_h*>(blk);
+    const float    inv_t = *reinterpret_cast<const float*>(blk + KS * 1024);
+    const int      ntaps = *reinterpret_cast<const int*>(blk + KS * 1024 + 2);
+    const float    gthr  = *reinterpret_cast<const float*>(blk + KS * 1024 + 4);
+    const float*   tapsf = reinterpret_cast<const float*>(blk + KS * 1024 + 8);
+    constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kHfSegC + Hb; // staged complex samples per segment (a multiple of 16)
+    constexpr int PL  = NS + 8 * (NS / 128 + 1) + 16;            // f16 elements per plane: one 16-byte chunk of padding per 128 samples (the columns are 128 samples apart)
+    constexpr int NL4 = (NS / 2 + 255) / 256;                    // float4 loads (two complex samples each) a lane holds for the next segment
+    constexpr int NM  = KS + 1;                                  // fragments of a wave's stream (two tiles, one K-step apart)
+    __shared__ __attribute__((aligned(16))) unsigned short pls[2][4 * PL]; // planes re1, re2, im1, im2
+    __shared__ __attribute__((aligned(16))) unsigned stat[2][12];
+    __shared__ __attribute__((aligned(16))) float    ystat[2][4];
+    __shared__ unsigned char noted[GR4_F16_MAX_SPW];
+    static_assert(4 * PL * 2 >= (2 * (NS + 4 * (NS / 128 + 1))) * 4, "the float32 path stages both components of a segment in one plane buffer");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    auto P = [](int s_) { return s_ + 8 * (s_ >> 7); };
+
+    u32x4_h a[2][KS];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[p][ks] = afrag[(p * KS + ks) * 64 + lane];
+
+    auto xs = [&](long i) -> float2 { return i >= 0 ? (i < n ? x[i] : make_float2(0.f, 0.f)) : (i >= -(long)Kh ? hist[Kh + i] : make_float2(0.f, 0.f)); };
+    float4 nxa[NL4], nxb[NL4];
+    auto   load_next = [&](float4 (&nxt)[NL4], long seg0) { // seg0 >= kHfSegC >= Hb
+        const long   i0   = seg0 - Hb;
+        const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
+        const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 8 : 0));
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto load_general = [&](float4 (&nxt)[NL4], long seg0) {
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int q = tid + 256 * u;
+            float2    t0 = make_float2(0.f, 0.f), t1 = t0;
+            if (q < NS / 2) { t0 = xs(seg0 + 2L * q - Hb); t1 = xs(seg0 + 2L * q + 1 - Hb); }
+            nxt[u] = make_float4(t0.x, t0.y, t1.x, t1.y);
+        }
+    };
+    auto put_stats = [&](const float4 (&v)[NL4], int slot) {
+        float mf = 0.f, px = 0.f;
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fabsf(v[u].x)), __builtin_fmaxf(__builtin_fabsf(v[u].y), __builtin_fmaxf(__builtin_fabsf(v[u].z), __builtin_fabsf(v[u].w))));
+            px = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, fmaf(v[u].w, v[u].w, px))));
+        }
+        unsigned mx = __float_as_uint(mf);
+        unsigned mn = mx ? mx : 0xffffffffu;
+        mx = hf_wave_reduce_u32(mx, [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
+        mn = hf_wave_reduce_u32(mn, [](unsigned a_, unsigned b_) { return a_ < b_ ? a_ : b_; });
+        px = hf_wave_sum(px);
+        if (lane == 0) { stat[slot][wave] = mx; stat[slot][4 + wave] = mn; stat[slot][8 + wave] = __float_as_uint(px); }
+    };
+    auto put_ypower = [&](float py, int slot) {
+        py = hf_wave_sum(py);
+        if (lane == 0) ystat[slot][wave] = py;
+    };
+    auto block_scale = [&](int slot, float& s, float& inv_s, float& px) -> int {
+        const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[slot][0]), n4 = *reinterpret_cast<const uint4*>(&stat[slot][4]), p4 = *reinterpret_cast<const uint4*>(&stat[slot][8]);
+        px = (__uint_as_float(p4.x) + __uint_as_float(p4.y)) + (__uint_as_float(p4.z) + __uint_as_float(p4.w));
+        const unsigned mx = __builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))), mn = __builtin_amdgcn_readfirstlane(min(min(n4.x, n4.y), min(n4.z, n4.w)));
+        const int e = (int)(mx >> 23), el = (int)(mn >> 23);
+        const int slow = (e == 255 || px != px) ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0);
+        const int ec = e < 15 ? 15 : (e > 254 ? 254 : e);
+        s     = __uint_as_float((unsigned)(268 - ec) << 23);
+        inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
+        return slow;
+    };
+    // two complex samples {re0, im0, re1, im1} -> elements e, e + 1 of the four planes
+    auto put2e = [&](unsigned short* pl, int e, float4 v, float s) {
+        unsigned rh, rl, ih, il;
+        hf_split2(v.x, v.z, s, rh, rl);
+        hf_split2(v.y, v.w, s, ih, il);
+        *reinterpret_cast<unsigned*>(pl + e)          = rh;
+        *reinterpret_cast<unsigned*>(pl + PL + e)     = rl;
+        *reinterpret_cast<unsigned*>(pl + 2 * PL + e) = ih;
+        *reinterpret_cast<unsigned*>(pl + 3 * PL + e) = il;
+    };
+    auto put_next = [&](unsigned short* pl, int u, const float4& v, float s) { // branch-free: lanes past the staged range write into the spare elements behind each plane
+        const int q = tid + 256 * u;
+        put2e(pl, (256 * (u + 1) <= NS / 2 || q < NS / 2) ? P(2 * q) : PL - 16 + 2 * (lane & 7), v, s);
+    };
+    const int tb = (wave >> 1) + 4 * (wave & 1); // waves 0, 1: tiles {0, 2} / {4, 6}; waves 2, 3: tiles {1, 3} / {5, 7}
+    const int sb = 128 * col + 16 * tb + 8 * kq;
+    // the float32 path (see the float kernel): both components staged as float32 in one plane buffer, the taps in the other
+    auto slow_segment = [&](long sg, unsigned short* stage16) {
+        constexpr int SF = NS + 4 * (NS / 128 + 1); // floats per component: 4 floats of padding per 128 (lane (col, kq) reads word 128 col + 16 t + 4 k4 + kq: 64 different banks)
+        float*     stg  = reinterpret_cast<float*>(stage16);
+        const long seg0 = sg * kHfSegC;
+        auto       Pf   = [](int i) { return i + 4 * (i >> 7); };
+        if (sg > 0) load_next(nxa, seg0);
+        else load_general(nxa, 0);
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int q = tid + 256 * u;
+            if (256 * (u + 1) <= NS / 2 || q < NS / 2) {
+                *reinterpret_cast<float2*>(stg + Pf(2 * q))      = make_float2(nxa[u].x, nxa[u].z);
+                *reinterpret_cast<float2*>(stg + SF + Pf(2 * q)) = make_float2(nxa[u].y, nxa[u].w);
+            }
+        }
+        float* tz = reinterpret_cast<float*>(stage16 == pls[0] ? pls[1] : pls[0]);
+        for (int i = tid; i < 2 * Kw; i += 256) tz[i] = (i >= Kw && i - Kw < ntaps) ? tapsf[i - Kw] : 0.f;
+        __syncthreads();
+        f32x4_h acc[4]; // (tile 0 re, tile 0 im, tile 1 re, tile 1 im)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+        const float* ta = tz + Kw + Hb + col - kq;
+        for (int k0 = 0; k0 < Kw / 4; k0 += 8) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int   k4 = k0 + kk;
+                const float av = ta[-4 * k4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, stg[(j & 1) * SF + Pf(128 * col + 16 * (tb + 2 * (j >> 1)) + 4 * k4 + kq)], acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const long o = seg0 + 128L * col + 16 * (tb + 2 * jj) + 4 * kq;
+            for (int r = 0; r < 4; ++r)
+                if (o + r < n) y[o + r] = make_float2(acc[2 * jj][r], acc[2 * jj + 1][r]);
+        }
+        __syncthreads();
+    };
+    auto exact_segment = [&](long sg) { // a non-finite sample: plain float32 sums, the reference's classes on exactly the ntaps outputs whose window holds it
+        for (int r = 0; r < kHfSegC / 256; ++r) {
+            const long o = sg * kHfSegC + tid + 256 * r;
+            if (o >= n) break;
+            float ar = 0.f, ai = 0.f;
+            for (int k = 0; k < ntaps; ++k) {
+                const float2 v = xs(o - k);
+                ar = fmaf(tapsf[k], v.x, ar);
+                ai = fmaf(tapsf[k], v.y, ai);
+            }
+            y[o] = make_float2(ar, ai);
+        }
+    };
+    const long nseg = (n + kHfSegC - 1) / kHfSegC, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
+    if (sfirst >= slast) return;
+    if (tid < GR4_F16_MAX_SPW) noted[tid] = 0;
+    auto note = [&](long sg, bool exact) {
+        if (tid == 0) noted[sg - sfirst] = exact ? 2 : 1;
+    };
+    auto judge = [&](long sg, float px) {
+        const float4 p4 = *reinterpret_cast<const float4*>(&ystat[sg & 1][0]);
+        const float  py = (p4.x + p4.y) + (p4.z + p4.w);
+        if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, false);
+    };
+    float s_cur, inv_cur, px_cur, px_prev = 0.f;
+    int   slow_cur;
+    {
+        if (sfirst > 0) load_next(nxa, sfirst * kHfSegC);
+        else load_general(nxa, 0);
+        put_stats(nxa, (int)(sfirst & 1));
+        __syncthreads();
+        slow_cur = block_scale((int)(sfirst & 1), s_cur, inv_cur, px_cur);
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) put_next(pls[0], u, nxa[u], s_cur);
+        load_next(nxa, (sfirst + 1) * kHfSegC);
+        put_stats(nxa, (int)((sfirst + 1) & 1));
+        __syncthreads();
+    }
+    auto segment = [&](long sg, const unsigned short* pl, unsigned short* plo, float4 (&cur)[NL4], float4 (&oth)[NL4]) {
+        const long seg0 = sg * kHfSegC;
+        float      s_nx, inv_nx, px_nx;
+        const int  slow_nx = block_scale((int)((sg + 1) & 1), s_nx, inv_nx, px_nx);
+        load_next(oth, seg0 + 2 * kHfSegC);
+        if (guard && sg > sfirst) judge(sg - 1, px_prev);
+        float py = 0.f;
+        if (!slow_cur) {
+            f32x4_h c[4], d[4]; // index 2 tile + component
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const unsigned short* q = pl + P(sb + 32 * m);
+                f16x8_h               b1[2], b2[2];
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    b1[cp] = *reinterpret_cast<const f16x8_h*>(q + 2 * cp * PL);
+                    b2[cp] = *reinterpret_cast<const f16x8_h*>(q + (2 * cp + 1) * PL);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int ks = m - jj;
+                    if (ks < 0 || ks >= KS) continue;
+                    const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a[1][ks]);
+#pragma unroll
+                    for (int cp = 0; cp < 2; ++cp) {
+                        c[2 * jj + cp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[cp], c[2 * jj + cp], 0, 0, 0);
+                        d[2 * jj + cp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2[cp], d[2 * jj + cp], 0, 0, 0);
+                        d[2 * jj + cp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1[cp], d[2 * jj + cp], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NL4; ++u)
+                    if (u * NM / NL4 == m) put_next(plo, u, cur[u], s_nx);
+            }
+            const int   ek  = (int)((__float_as_uint(inv_t) >> 23) & 255) + (int)((__float_as_uint(inv_cur) >> 23) & 255) - 254;
+            const bool  one = ek > -120 && ek < 120;
+            const float k1 = one ? inv_t * inv_cur : inv_t, k2 = one ? 1.f : inv_cur, kd = k1 * (1.f / 2048.f);
+            const bool   full = seg0 + kHfSegC <= n;
+            const rsrc_t ry   = make_rsrc(y + seg0, full ? kHfSegC * 8u : 0u);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                float vr[4], vi[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vr[r] = fmaf(d[2 * jj][r], kd, c[2 * jj][r] * k1);
+                    vi[r] = fmaf(d[2 * jj + 1][r], kd, c[2 * jj + 1][r] * k1);
+                    if (!one) { vr[r] *= k2; vi[r] *= k2; }
+                }
+                const int oo = 128 * col + 16 * (tb + 2 * jj) + 4 * kq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) // (the outputs of the span only)
+                    if (full || seg0 + oo + r < n) py = fmaf(vr[r], vr[r], fmaf(vi[r], vi[r], py));
+                if (full) {
+                    const u32x4_h w0 = {__float_as_uint(vr[0]), __float_as_uint(vi[0]), __float_as_uint(vr[1]), __float_as_uint(vi[1])};
+                    const u32x4_h w1 = {__float_as_uint(vr[2]), __float_as_uint(vi[2]), __float_as_uint(vr[3]), __float_as_uint(vi[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(w0, ry, oo * 8, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(w1, ry, oo * 8 + 16, 0, 0);
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (seg0 + oo + r < n) y[seg0 + oo + r] = make_float2(vr[r], vi[r]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) put_next(plo, u, cur[u], s_nx);
+            note(sg, slow_cur == 2);
+            py = __builtin_inff();
+        }
+        put_stats(oth, (int)(sg & 1));
+        put_ypower(py, (int)(sg & 1));
+        s_cur    = s_nx;
+        inv_cur  = inv_nx;
+        slow_cur = slow_nx;
+        px_prev  = px_cur;
+        px_cur   = px_nx;
+        __syncthreads();
+    };
+    for (long sg = sfirst; sg < slast; sg += 2) {
+        segment(sg, pls[0], pls[1], nxa, nxb);
+        if (sg + 1 < slast) segment(sg + 1, pls[1], pls[0], nxb, nxa);
+    }
+    if (guard) judge(slast - 1, px_prev);
+    __syncthreads();
+    for (int i = 0; i < seg_per_wg; ++i) {
+        const int kind = noted[i];
+        if (kind == 1) {
+            __builtin_amdgcn_s_waitcnt(0);
+            slow_segment(sfirst + i, pls[0]);
+        } else if (kind == 2) exact_segment(sfirst + i);
+    }
+    if (new_hist != nullptr && blockIdx.x == 0) {
         for (int h = tid; h < Kh; h += 256) {
             const long i = n - Kh + h;
             new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
@@ -463,6 +743,31 @@ int fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, co
     default: return GR4HIP_UNSUPPORTED;
     }
 #undef GR4_HF_CASE
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+// the same on complex samples (real taps); hist = the Kh complex samples in front of x; x and y 16-byte aligned; `table` from fir_f16_make_afrag (one channel)
+int fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard) {
+    if (KS < 3 || KS > 9) return GR4HIP_UNSUPPORTED;
+    const auto tb   = static_cast<const unsigned short*>(table);
+    const auto xc   = reinterpret_cast<const float2*>(x), hc = reinterpret_cast<const float2*>(hist);
+    const auto yc   = reinterpret_cast<float2*>(y), nh = reinterpret_cast<float2*>(new_hist);
+    const long nseg = ceil_div(n, (long)kHfSegC);
+    const int  spw  = (int)std::min<long>(std::max<long>(nseg / GR4_F16_TARGET_WGS, 1), GR4_F16_MAX_SPW);
+    const dim3 grid((unsigned)ceil_div(nseg, (long)spw));
+#define GR4_HFC_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_f16x2_c32_kernel<K>, grid, dim3(256), 0, st, xc, hc, Kh, tb, yc, n, nh, spw, guard); break
+    switch (KS) {
+        GR4_HFC_CASE(3);
+        GR4_HFC_CASE(4);
+        GR4_HFC_CASE(5);
+        GR4_HFC_CASE(6);
+        GR4_HFC_CASE(7);
+        GR4_HFC_CASE(8);
+        GR4_HFC_CASE(9);
+    default: return GR4HIP_UNSUPPORTED;
+    }
+#undef GR4_HFC_CASE
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

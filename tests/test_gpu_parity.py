@@ -316,6 +316,58 @@ def test_fir_f16_kernel_outliers_and_non_finite_samples(G):
     assert float(np.max(np.abs(y[ok & near] - truth[ok & near]) / np.maximum(np.abs(truth[ok & near]), 1e-3 * np.abs(truth[ok & near]).max()))) <= TOL  # under the glitches: relative to them
 
 
+def _dev16c(x):
+    t = torch.empty(x.size + 2, dtype=torch.complex64, device="cuda")[2:]  # 16-byte aligned start
+    t.copy_(torch.from_numpy(x))
+    return t
+
+
+@pytest.mark.parametrize("ntaps", [33, 64, 97, 200, 256])
+def test_fir_complex_f16_two_term_kernel(G, ntaps, devsw):
+    """fir_filter<complex<float>>, 33 .. 256 taps, the direct form on long aligned spans (GR4HIP_FIR_TIME_DOMAIN; the default up to 96 taps) -- since round 4 the
+    two-term f16 kernel on both components under one block exponent (fir_f16.hip): the float64 oracle's bar with a rejected tone 30 dB above what passes, across
+    ragged calls, at any level of the stream; a rejected tone 50 dB above the noise is judged per segment and redone with float32 products (the error of the
+    float32 kernel, where the products by themselves -- guard off -- are an order of magnitude above it)"""
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    n = 200_000
+    x = O.signal_c32(91, n, tone_frel=0.31, tone_amp=30.0)
+    truth, _ = O.fir(b, x)
+    cuts = [0, 90_000, 90_002, 91_000, n]
+
+    def make(algo=None, guard=None):
+        f = G.fir_filter(b, torch.complex64)
+        f.set_algo(G.capi.FIR_TIME_DOMAIN if algo is None else algo)
+        if guard is not None:
+            f.set_guard_mode(guard)
+        return f
+
+    def run(flt, xx):
+        return np.concatenate([flt.process_bulk(_dev16c(xx[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    y = run(make(), x)
+    assert _rel(y, truth) <= TOL
+    ybf = run(make(G.capi.FIR_TIME_DOMAIN_BF16X3), x)
+    assert _rel(ybf, truth) <= TOL and not np.array_equal(y, ybf)  # (two different kernels did run)
+    for scale in (1e-30, 1e30):
+        xs_ = (x.astype(np.complex128) * scale).astype(np.complex64)
+        ts, _ = O.fir(b, xs_)
+        assert _rel(run(make(), xs_), ts) <= TOL
+    # a rejected tone 50 dB above the noise
+    bw = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    xi = (O.signal_c32(7, n, tone_amp=0.0) * 0.05).astype(np.complex64)
+    xi += (316.0 * np.exp(2j * np.pi * 0.31 * np.arange(n))).astype(np.complex64)
+    ti, _ = O.fir(bw, xi)
+    sl = slice(ntaps, n)
+
+    def go(algo=None, guard=None):
+        f = G.fir_filter(bw, torch.complex64)
+        f.set_algo(G.capi.FIR_TIME_DOMAIN if algo is None else algo)
+        if guard is not None:
+            f.set_guard_mode(guard)
+        return _rel(f.process_bulk(_dev16c(xi)).cpu().numpy()[sl], ti[sl])
+    e_def, e_off, e_32 = go(), go(guard=G.capi.GUARD_OFF), go(G.capi.FIR_TIME_DOMAIN_F32)
+    assert e_off > 3e-5 and e_def <= 1.5 * e_32 + 1e-6, (e_def, e_off, e_32)
+
+
 @pytest.mark.parametrize("decim,ntaps", [(8, 1024), (2, 64), (3, 600), (4, 100), (10, 1000), (5, 91), (16, 4096), (16, 512), (16, 33), (32, 1024), (32, 7), (64, 2048), (64, 100), (64, 1),
                                          (11, 352), (12, 384), (20, 333), (24, 100), (25, 800), (48, 1536), (100, 1000), (96, 1536),
                                          (2, 256), (2, 258), (2, 17), (3, 243), (4, 228), (5, 213), (7, 100), (9, 152), (9, 153), (6, 1)])
@@ -1539,8 +1591,10 @@ def test_fir_non_finite_samples(G, cplx, ntaps):
     assert tol(y, ~tbad) <= TOL
     # --- default algorithm
     y = G.fir_filter(b, dt).process_bulk(_aligned16(x)).cpu().numpy()
-    if not cplx:  # float, since round 4: the two-term f16 kernel gives a segment with such a sample to its float32 path -- the reference's classes and reach, exactly
-        assert np.array_equal(np.isnan(y), np.isnan(t32)) and np.array_equal(np.isposinf(y), np.isposinf(t32)) and np.array_equal(np.isneginf(y), np.isneginf(t32))
+    if True:  # since round 4: the two-term f16 kernels (float and complex) give a segment with such a sample to their float32 paths -- the reference's classes and reach, exactly
+        for part in ((np.real, np.imag) if cplx else (np.asarray,)):
+            yp, tp = part(y), part(t32)
+            assert np.array_equal(np.isnan(yp), np.isnan(tp)) and np.array_equal(np.isposinf(yp), np.isposinf(tp)) and np.array_equal(np.isneginf(yp), np.isneginf(tp))
         assert tol(y, ~tbad) <= TOL
         f = G.fir_filter(b, dt)
         f.set_algo(G.capi.FIR_TIME_DOMAIN_BF16X3)  # the three-term bf16 kernel, per handle: what the text above says
