@@ -571,7 +571,12 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
     // (<= 96 taps: the direct form is faster -- write-bound 300 .. 356 Gsamples/s up to 64 taps, 311 .. 275 at 65 .. 96 taps on the bf16 matrix pipe, against
     // the fast convolution's 248 at every tap count, tools/cfir_taps_sweep.py -- and has no dynamic-range floor; 128 taps: 220, 256 taps: 151)
-    if (f->S == 2 && f->decim == 1 && f->ntaps > 96 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && algo == GR4HIP_FIR_AUTO && !f->fd_blocked) {
+    // (round 4: the direct form on the f16 matrix pipe -- further down -- is as fast at 256 taps and faster below (129 taps 288 against 241, 192 taps 255 against 242,
+    // 256 taps 237 against 240 Gsamples/s, tools/cfir_taps_sweep.py), its error is relative to the output, a non-finite sample reaches ntaps outputs instead of an
+    // 8192-sample block and the call stays asynchronous: the fast convolution is left with the spans that kernel does not take -- unaligned ones)
+    const bool f16c = f->S == 2 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 256 && n_in >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
+                      algo != GR4HIP_FIR_EXACT_F32 && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && f->hfKS >= 0 && plain;
+    if (f->S == 2 && f->decim == 1 && f->ntaps > 96 && f->ntaps <= 256 && n_in >= kFdMinFrames * kFdFrame && algo == GR4HIP_FIR_AUTO && !f->fd_blocked && !f16c) {
         int rc = GR4HIP_OK;
         if (!f->fd) {
             rc = chain_fused_create(&f->fd, f->taps.data(), f->ntaps, kFdFrame, GR4HIP_WIN_NONE, GR4HIP_CHAIN_FUSED_FD);

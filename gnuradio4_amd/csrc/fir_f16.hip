@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
             const int   ek  = (int)((__float_as_uint(inv_t) >> 23) & 255) + (int)((__float_as_uint(inv_cur) >> 23) & 255) - 254;
             const bool  one = ek > -120 && ek < 120;
             const float k1 = one ? inv_t * inv_cur : inv_t, k2 = one ? 1.f : inv_cur, kd = k1 * (1.f / 2048.f);
-            const bool  full = seg0 + kHfSeg <= n && !accum; // whole segments leave through a buffer descriptor (no 64-bit address per store)
+            const bool  whole = seg0 + kHfSeg <= n, full = whole && !accum; // whole segments leave through a buffer descriptor (no 64-bit address per store)
             const rsrc_t ry  = make_rsrc(y + seg0, full ? kHfSeg * 4u : 0u);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -316,9 +316,11 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
                     if (!one) v[r] *= k2;
                 }
                 const int oo = 256 * col + 16 * (tb + 2 * j) + 4 * kq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) // the guard's output power: the outputs of the span only (past its end the staged zeros make the filter ring: not what it passes)
-                    if (seg0 + kHfSeg <= n || seg0 + oo + r < n) py = fmaf(v[r], v[r], py);
+                // the guard's output power: the outputs of the span only (past its end the staged zeros make the filter ring: not what it passes)
+                if (whole) py = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], py))));
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (seg0 + oo + r < n) py = fmaf(v[r], v[r], py);
                 if (full) {
                     const u32x4_h w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                     __builtin_amdgcn_raw_buffer_store_b128(w, ry, oo * 4, 0, 0);
@@ -599,9 +601,12 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
                     if (!one) { vr[r] *= k2; vi[r] *= k2; }
                 }
                 const int oo = 128 * col + 16 * (tb + 2 * jj) + 4 * kq;
+                if (full) { // (the guard's output power: the outputs of the span only)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) // (the outputs of the span only)
-                    if (full || seg0 + oo + r < n) py = fmaf(vr[r], vr[r], fmaf(vi[r], vi[r], py));
+                    for (int r = 0; r < 4; ++r) py = fmaf(vr[r], vr[r], fmaf(vi[r], vi[r], py));
+                } else
+                    for (int r = 0; r < 4; ++r)
+                        if (seg0 + oo + r < n) py = fmaf(vr[r], vr[r], fmaf(vi[r], vi[r], py));
                 if (full) {
                     const u32x4_h w0 = {__float_as_uint(vr[0]), __float_as_uint(vi[0]), __float_as_uint(vr[1]), __float_as_uint(vi[1])};
                     const u32x4_h w1 = {__float_as_uint(vr[2]), __float_as_uint(vi[2]), __float_as_uint(vr[3]), __float_as_uint(vi[3])};

@@ -146,12 +146,16 @@ int gr4hip_ring_size(const gr4hip_ring_t* ring, size_t* bytes);
  * dtype F32 (registered) or C32 (complex data x real taps).  decim > 1 gives the
  * BasicFilterProto decimating processBulk (:190-204): output m == y[m*decim]; n_in must be a multiple of decim
  * (the reference guarantees it through input_chunk_size = decimate, :166-168). */
-/* Non-finite and near-FLT_MAX samples (pinned by tests/test_gpu_parity.py::test_fir_non_finite_samples / test_chain_non_finite_samples).  The reference's
- * transform_reduce gives +-Inf / NaN on exactly the ntaps outputs whose window contains such a sample.  With the default algorithm:
- *  - 33 .. 256 taps (float and complex; float also 384 .. 1024) on long 16-byte-aligned spans evaluate the products with samples and taps split into three
- *    bf16 terms each (float32 accuracy, same 1e-5 parity bar): every output the reference makes non-finite is non-finite here too, as NaN (not +-Inf); the
- *    reach is the kernel's 32-sample-granular window -- at most 15 outputs earlier and 46 later than the reference's; a finite sample above bf16's largest
- *    value, 3.39e38, counts as infinite;
+/* Non-finite and near-FLT_MAX samples (pinned by tests/test_gpu_parity.py::test_fir_non_finite_samples / test_fir_f16_kernel_outliers_and_non_finite_samples /
+ * test_chain_non_finite_samples).  The reference's transform_reduce gives +-Inf / NaN on exactly the ntaps outputs whose window contains such a sample.  With the
+ * default algorithm:
+ *  - 33 .. 256 taps (float and complex; float also 384 .. 1024) on long 16-byte-aligned spans evaluate the products on the f16 matrix pipe, samples and taps split
+ *    into two f16 terms under a block exponent per segment of 4096 (complex: 2048) outputs (csrc/fir_f16.hip; same 1e-5 parity bar).  A segment that holds a
+ *    non-finite sample is evaluated as plain float32 sums instead: the reference's classes (+Inf, -Inf, NaN) on exactly its outputs; a finite outlier more than
+ *    2^28 above the segment's ordinary level (1e30 or 3.4e38 beside unit-power samples) sends its segment to float32 products on the f32 matrix pipe, so the
+ *    samples beside it keep their accuracy.  (GR4HIP_FIR_TIME_DOMAIN_BF16X3, the three-term bf16 kernels of rounds 2-3: every output the reference makes
+ *    non-finite is non-finite, as NaN, the reach is the kernel's 32-sample-granular window -- at most 15 outputs earlier and 46 later than the reference's --,
+ *    and a finite sample above bf16's largest value, 3.39e38, counts as infinite.)
  *  - complex data, 97 .. 256 taps, spans of >= 64 x 8192 samples take a fast-convolution kernel: a non-finite sample reaches every output of its 8192-sample
  *    block (and of the next block when it lies within the block's last 255 samples) instead of the next ntaps outputs.
  * gr4hip_fir_set_algo(GR4HIP_FIR_EXACT_F32) selects, per handle, kernels whose classes (+Inf, -Inf, NaN) and reach are the reference's exactly. */
@@ -165,10 +169,17 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
 /* FIR_AUTO carries the same dynamic-range guard as GR4HIP_CHAIN_AUTO (gr4hip_chain_last_power_ratio below): the first fast convolution of a stream is probed
  * on eight frames, later ones are watched through the powers every launch measures (every frame judged by itself), and below an output / input power ratio of
  * 0.04 the direct form takes over. */
-/* Accuracy of the bf16 three-term direct form (GR4HIP_FIR_TIME_DOMAIN and the default for 33 .. 256 taps): the six products kept carry everything above 2^-23 of
- * a product, a correctly rounded float32 product 2^-25.  On ordinary input the error against float64 is that of a float32 sum (~2e-7); when a rejected
- * out-of-band signal 50 dB above the output dominates the partial sums it measures 3 .. 12 x the float32 CPU form's (profiles/r03_fuzz_summary.txt) -- both are
- * then above 1e-5 of the output.  GR4HIP_FIR_EXACT_F32 is the float32 arithmetic itself. */
+/* Accuracy of the direct form on the matrix pipes (the default for 33 .. 256 taps, float 384 .. 1024; GR4HIP_FIR_TIME_DOMAIN for complex data).  Round 4: two-term
+ * f16 splits, three products per tap (x1 b1, x1 b2, x2 b1: everything above 2^-22 of a product; a correctly rounded float32 product carries 2^-25).  On ordinary
+ * input the error against float64 is that of a float32 sum (3e-7 .. 6e-7, below the three-term bf16 kernel's).  The error is relative to the PRODUCTS, so it shows
+ * against the OUTPUT when the filter removes nearly all it is given -- and the kernel judges that itself: every segment's output power P_y is compared with its
+ * input power P_x, and a segment with P_y < 2^-12 (sum b^2) P_x (36 dB more rejected than white noise would lose; the products by themselves are then at
+ * <= 3e-6 of the output) is evaluated again inside the launch with float32 products on the f32 matrix pipe: under a rejected tone 50 dB above the output the default
+ * is at the float32 kernels' error (3e-5 .. 4e-5 -- the reference's own float32 sum is there too), the products alone at 2e-4, the three-term bf16 kernel
+ * (GR4HIP_FIR_TIME_DOMAIN_BF16X3: no guard) at 5e-5 .. 1e-4.  gr4hip_fir_set_guard_mode(GR4HIP_GUARD_OFF) switches the verdict off; the 256-tap slices of longer
+ * float filters run without it (their launches see partial sums).  A stream in which every segment is rejected runs at 109 (256 taps) .. 264 (64 taps) Gsamples/s. */
+/* GR4HIP_FIR_TIME_DOMAIN_BF16X3: the three-term bf16 products of rounds 2-3 (six products per tap, everything above 2^-23 of a product, float32's exponent range
+ * without a block exponent, no guard) where the default takes the f16 kernels; for complex data also "direct form" like GR4HIP_FIR_TIME_DOMAIN. */
 /* GR4HIP_FIR_EXACT_F32: every product and sum in IEEE float32 (no frequency-domain kernels, no bf16 splits): the kernels whose arithmetic is the reference's
  * transform_reduce (time_domain_filter.hpp:44-47) term for term up to the order of the additions -- an infinite or NaN input sample reaches exactly the
  * ntaps outputs whose window contains it, as +-Inf / NaN (tests/test_gpu_parity.py::test_fir_non_finite_samples pins this and what the default algorithm
@@ -179,7 +190,7 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
  * a stream (FIR_AUTO's fast convolution, the chain): the regime that made it fall back is the one in which the product precision shows. */
 typedef enum { GR4HIP_FIR_AUTO = 0, GR4HIP_FIR_TIME_DOMAIN = 1, GR4HIP_FIR_EXACT_F32 = 2, GR4HIP_FIR_TIME_DOMAIN_F32 = 3, GR4HIP_FIR_TIME_DOMAIN_BF16X3 = 4 } gr4hip_fir_algo;
 int gr4hip_fir_set_algo(gr4hip_fir_t* fir, int algo);
-int gr4hip_fir_set_guard_mode(gr4hip_fir_t* fir, int mode); /* gr4hip_guard_mode (below), for FIR_AUTO's fast convolution of long complex spans; default GR4HIP_GUARD_STRICT */
+int gr4hip_fir_set_guard_mode(gr4hip_fir_t* fir, int mode); /* gr4hip_guard_mode (below), for FIR_AUTO's fast convolution of long complex spans and (GUARD_OFF) the f16 direct form's per-segment verdict; default GR4HIP_GUARD_STRICT */
 int gr4hip_fir_process(gr4hip_fir_t* fir, const void* d_in, size_t n_in, void* d_out, size_t* n_out, gr4hip_stream_t stream);
 int gr4hip_fir_destroy(gr4hip_fir_t* fir);
 
@@ -465,7 +476,9 @@ int gr4hip_rotator64_destroy(gr4hip_rotator64_t* rot);
 
 /* ------------------------------------------------------------------------------------------------ batched FIR (configs[3])
  * nchannels independent fir_filter<float> instances, per-channel taps h_taps[c][k], channel-major samples
- * d_in[c * in_stride + n]; evaluated as a block-Toeplitz contraction on the f32 MFMA units. */
+ * d_in[c * in_stride + n]; evaluated as a block-Toeplitz contraction on the matrix pipe: more than 32 taps on spans of >= 32768 samples per channel with two-term
+ * f16 splits under a per-segment block exponent (csrc/fir_f16.hip: three products per tap, every segment judged, see gr4hip_fir_set_algo above), otherwise with
+ * float32 products on the f32 MFMA units. */
 typedef struct gr4hip_fir_batched gr4hip_fir_batched_t;
 int gr4hip_fir_batched_create(gr4hip_fir_batched_t** fb, size_t nchannels, const float* h_taps, size_t ntaps);
 int gr4hip_fir_batched_reset(gr4hip_fir_batched_t* fb);

@@ -458,23 +458,29 @@ def test_fir_random_span_sizes_switch_kernels(G, kind):
 
 
 @pytest.mark.parametrize("ntaps", [256, 129, 97, 91, 65, 33, 2])
-def test_fir_complex_long_input_fast_convolution(G, ntaps):
+def test_fir_complex_long_input_fast_convolution(G, ntaps, devsw):
     """complex<float>, 97 .. 256 taps, >= 64 frames of 8192: whole frames take the frequency-domain kernel, the rest the direct form;
-    history crosses both boundaries (<= 96 taps: the same spans stay on the direct form -- write-bound up to 64 taps, bf16 matrix pipe above -- which is faster there)"""
+    history crosses both boundaries (<= 96 taps: the same spans stay on the direct form, which is faster there).  Since round 4 the default for 16-byte-aligned spans
+    is the direct form on the f16 matrix pipe at every tap count (as fast, error relative to the output): the fast convolution serves the spans that kernel does not
+    take -- the 8-byte-aligned one below -- and is run on the aligned spans here through the developer switch"""
     rng = np.random.default_rng(ntaps)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
     n = 3000 + (70 * 8192 + 77) + 5 + 64 * 8192
     x = O.signal_c32(5, n)
     truth, _ = O.fir(b, x)
-    f = G.fir_filter(b, torch.complex64)
     cuts = [0, 3000, 3000 + 70 * 8192 + 77, 3000 + 70 * 8192 + 77 + 5, n]  # direct | FD + remainder | direct | FD exactly 64 frames
-    parts = []
-    for lo, hi in zip(cuts[:-1], cuts[1:]):
-        xin = torch.empty(hi - lo + 2, dtype=torch.complex64, device="cuda")[2:]  # 16-byte aligned start
-        xin.copy_(torch.from_numpy(x[lo:hi]))
-        parts.append(f.process_bulk(xin).cpu().numpy())
-    y = np.concatenate(parts)
-    assert _rel(y, truth) <= TOL
+    ys = []
+    for no_f16 in (1, 0):
+        devsw("GR4HIP_FIR_NO_F16X2", no_f16)
+        f = G.fir_filter(b, torch.complex64)
+        parts = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            xin = torch.empty(hi - lo + 2, dtype=torch.complex64, device="cuda")[2:]  # 16-byte aligned start
+            xin.copy_(torch.from_numpy(x[lo:hi]))
+            parts.append(f.process_bulk(xin).cpu().numpy())
+        ys.append(np.concatenate(parts))
+        assert _rel(ys[-1], truth) <= TOL
+    assert not np.array_equal(ys[0], ys[1])  # (the fast convolution, then the f16 direct form)
     # an input span that is only 8-byte aligned (e.g. an odd ring-buffer position) gives the same answer
     f2 = G.fir_filter(b, torch.complex64)
     xin = torch.empty(n + 1, dtype=torch.complex64, device="cuda")[1:]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Secondary configurations of BASELINE.json (parity-test cases, not the bench line): timings on one MI355X.
   configs[2]: polyphase decimating FIR (decim 8, 1024 taps) + IIR biquad x4 cascade      (float stream)
-  configs[3]: batched 64-channel x 256-tap FIR on the matrix pipe (three-term bf16 splits, float32 accuracy)
+  configs[3]: batched 64-channel x 256-tap FIR on the matrix pipe (two-term f16 splits under a block exponent since round 4; the three-term bf16 kernel beside it)
   plus the stand-alone blocks (math, FFT block, fir_filter) for the roofline table in DESIGN.md
 usage: bench_configs.py [--json out.json]"""
 import json
@@ -62,10 +62,17 @@ rng = np.random.default_rng(0)
 fb = G.FirBatched(np.stack([lowpass(ntaps, 0.05 + 0.005 * c) for c in range(nch)]))
 yb = torch.empty_like(xb)
 t = timeit(lambda: fb.process_bulk(xb, yb))
-res["configs[3] 64 ch x 256-tap FIR (bf16 matrix pipe, three-term splits)"] = {"Msamples/s (all channels)": round(nch * n / t / 1e6, 1), "ms": round(t * 1e3, 3), "alg_GB/s": round(nch * n * 8 / t / 1e9, 1),
+res["configs[3] 64 ch x 256-tap FIR (f16 matrix pipe, two-term splits under a block exponent)"] = {"Msamples/s (all channels)": round(nch * n / t / 1e6, 1), "ms": round(t * 1e3, 3), "alg_GB/s": round(nch * n * 8 / t / 1e9, 1),
                                                "hbm_frac": round(nch * n * 8 / t / 8e12, 3), "float32_equivalent_TFLOP/s": round(nch * n * 512 / t / 1e12, 1),
-                                               "executed_bf16_TFLOP/s": round(nch * n * 6 * 2 * 288 / t / 1e12, 1), "bf16_mfma_peak_frac": round(nch * n * 6 * 2 * 288 / t / 2.5e15, 3),
-                                               "note": "six bf16 MFMAs per 32-sample K-step of the 288-sample window (fir_bf16.hip); the f32 MFMA kernel (GR4HIP_FIR_NO_BF16X3=1) ran this at 251 Gsamples/s = 87 % of the f32 matrix peak"}
+                                               "executed_f16_TFLOP/s": round(nch * n * 3 * 2 * 288 / t / 1e12, 1), "f16_mfma_peak_frac": round(nch * n * 3 * 2 * 288 / t / 2.5e15, 3),
+                                               "note": "three f16 MFMAs per 32-sample K-step of the 288-sample window (fir_f16.hip, round 4), every segment judged in the kernel; the three-term bf16 kernel (six MFMAs, GR4HIP_FIR_NO_F16X2=1) is the row below, the f32 MFMA kernel (GR4HIP_FIR_NO_BF16X3=1) ran this at 251 Gsamples/s"}
+capi.developer_switch("GR4HIP_FIR_NO_F16X2", 1)
+fb3 = G.FirBatched(np.stack([lowpass(ntaps, 0.05 + 0.005 * c) for c in range(nch)]))
+t = timeit(lambda: fb3.process_bulk(xb, yb))
+capi.developer_switch("GR4HIP_FIR_NO_F16X2", 0)
+res["configs[3] on the three-term bf16 kernel (rounds 2-3)"] = {"Msamples/s (all channels)": round(nch * n / t / 1e6, 1), "ms": round(t * 1e3, 3), "hbm_frac": round(nch * n * 8 / t / 8e12, 3),
+                                                               "executed_bf16_TFLOP/s": round(nch * n * 6 * 2 * 288 / t / 1e12, 1)}
+del fb3
 # the same work on the VALU kernel (one fir_filter at a time)
 f1 = G.fir_filter(lowpass(ntaps, 0.05), torch.float32)
 x1 = xb.reshape(-1)  # one long real stream
