@@ -163,7 +163,8 @@ typedef struct gr4hip_fir gr4hip_fir_t;
 int gr4hip_fir_create(gr4hip_fir_t** fir, int dtype, const float* h_taps, size_t ntaps, size_t decim);
 int gr4hip_fir_set_taps(gr4hip_fir_t* fir, const float* h_taps, size_t ntaps); /* settingsChanged (:38-42): history is kept */
 int gr4hip_fir_reset(gr4hip_fir_t* fir);
-/* GR4HIP_FIR_AUTO (default): long complex spans take the fast-convolution kernel.  Its float32 error floor is ~2e-6 of the INPUT rms per output sample
+/* GR4HIP_FIR_AUTO (default): since round 4 complex data with 33 .. 256 taps takes the f16 direct form on 16-byte-aligned spans (error relative to the output, see
+ * below); long complex spans that are only 8-byte aligned (97 .. 256 taps) take the fast-convolution kernel.  Its float32 error floor is ~2e-6 of the INPUT rms per output sample
  * (three transforms' worth of rounding), the direct form's ~2e-7: when out-of-band signals that the filter removes are much stronger than what it
  * passes, GR4HIP_FIR_TIME_DOMAIN keeps the error relative to the OUTPUT inside the 1e-5 parity bar (the reference's own arithmetic, 1024 flop/sample). */
 /* FIR_AUTO carries the same dynamic-range guard as GR4HIP_CHAIN_AUTO (gr4hip_chain_last_power_ratio below): the first fast convolution of a stream is probed
