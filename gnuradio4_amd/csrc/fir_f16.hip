@@ -10,15 +10,18 @@
 //
 // What f16 does not have is float32's exponent range, so each segment of 4096 outputs (its 4096 + Hb staged samples) carries ONE block exponent: s is the power
 // of two that puts the segment's largest magnitude in [2^14, 2^15); the residual plane is scaled by another 2^11, so its quantisation floor (f16 subnormals,
-// 2^-24) sits 2^-49 below the segment's largest sample.  The statistics (largest magnitude, and the smallest non-zero per-lane maximum as the level of the
-// ordinary samples) are taken from the registers the segment is prefetched into, one segment ahead of the split, through eight LDS words -- no extra barrier.
-// A segment that holds a non-finite sample, or whose largest sample is more than 2^28 above that ordinary level (a glitch of 1e30 beside unit-power samples),
+// 2^-24) sits 2^-49 below the segment's largest sample.  The statistics (largest magnitude, and the quietest group of four consecutive samples as the level of
+// the ordinary samples) are taken from the registers the segment is prefetched into, one segment ahead of the split, through eight LDS words -- no extra barrier.
+// A segment that holds a non-finite sample, or whose largest sample is more than 2^28 above that ordinary level (a glitch of 1e30 beside unit-power samples, a
+// burst that ends inside the segment and leaves a floor 170 dB below it),
 // is not given to the f16 pipe at all: the workgroup evaluates its 4096 outputs with float32 products on the f32 matrix pipe (slow_segment below) -- or, when the
 // sample is not finite, as plain float32 sums one output at a time: the reference's +-Inf / NaN on exactly the ntaps outputs whose window holds it.
 //
 // The kernel also judges its own accuracy.  The error of this form is relative to the PRODUCTS (~1.3e-7 rms of sqrt(sum b^2) x rms(x)), like float32's own rounding
 // but four times larger, so it only shows against the OUTPUT when the filter removes nearly everything it is given.  Every segment's output power is compared
-// with its input power: P_y < 2^-12 (sum b^2) P_x -- more than 36 dB of the staged power rejected beyond what white noise would lose -- and the segment is
+// with its input power -- P_y as sixteen times the power of the QUIETEST of the segment's sixteen output columns (256 outputs each), so that a start-up transient or
+// the edge of a burst somewhere in the segment does not hide that the rest of it is all rejection: P_y < 2^-12 (sum b^2) P_x -- more than 36 dB of the staged power
+// rejected beyond what white noise would lose -- and the segment is
 // evaluated again on the float32 path, at the end of the workgroup's run of segments (`guard`; off for the slices of long filters, whose launches see partial sums).
 // So a stream whose rejected part is far above what passes costs the float32 path's rate on exactly the segments where that is so, and has the reference's
 // float32 error there (include/gr4hip.h, "PARITY CONTRACT").
@@ -87,6 +90,22 @@ __device__ __forceinline__ float hf_wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// the sum over the four lanes (col, kq = 0 .. 3) that hold one output column, on every one of them: v_permlane16_swap / v_permlane32_swap (gfx950) of a value with itself
+// put the even rows beside the odd ones / the lower half beside the upper one
+__device__ __forceinline__ float hf_column_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v            = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// the smallest value of a row of 16 lanes, on every lane of the row
+__device__ __forceinline__ float hf_row_min(float v) {
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    return __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
+}
+
 template <int KS> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block
 __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(const float* __restrict__ x0, const float* __restrict__ hist0 /*the Kh samples in front of x*/, int Kh,
                                                                                 const unsigned short* __restrict__ blk0 /*[channels] blocks of hf_block_units(KS)*/, float* __restrict__ y0, long n,
@@ -107,8 +126,8 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     constexpr int NL4 = (NS / 4 + 255) / 256;                   // float4 loads a lane holds for the next segment
     constexpr int NM  = KS + 3;                                 // fragments of a wave's stream
     __shared__ __attribute__((aligned(16))) unsigned short pls[2][2 * PL];
-    __shared__ __attribute__((aligned(16))) unsigned stat[2][12]; // per data segment parity: the four waves' largest magnitude bits, smallest non-zero lane maxima, sums of squares
-    __shared__ __attribute__((aligned(16))) float    ystat[2][4]; // per computed segment parity: the four waves' output powers
+    __shared__ __attribute__((aligned(16))) unsigned stat[2][12]; // per data segment parity: the four waves' largest magnitude bits, quietest non-zero groups of four, sums of squares
+    __shared__ __attribute__((aligned(16))) float    ystat[2][4][16]; // per computed segment parity: the four waves' output powers per column of 256 outputs
     __shared__ unsigned char noted[GR4_F16_MAX_SPW];              // per segment of this workgroup's run: 1 = again with float32 products, 2 = again as plain float32 sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
     auto P = [](int s_) { return s_ + 8 * (s_ >> 8); };
@@ -144,21 +163,24 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     // statistics of the registers of one staged segment -> stat[slot]; read back (after a barrier) by block_scale
     auto put_stats = [&](const float4 (&v)[NL4], int slot) {
         float mf = 0.f, px = 0.f; // largest magnitude (v_max3_f32 on |.|: a NaN is passed over, an Inf stays) and the power (NaN if a NaN is among the samples)
+        unsigned mn = 0xffffffffu; // the quietest group of four consecutive values that is not all zeros: the level of the ordinary samples, local in TIME (a level that
+                                   // drops in the middle of a segment is seen, not only an isolated outlier)
 #pragma unroll
         for (int u = 0; u < NL4; ++u) {
-            mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fabsf(v[u].x)), __builtin_fmaxf(__builtin_fabsf(v[u].y), __builtin_fmaxf(__builtin_fabsf(v[u].z), __builtin_fabsf(v[u].w))));
+            const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[u].x), __builtin_fabsf(v[u].y)), __builtin_fmaxf(__builtin_fabsf(v[u].z), __builtin_fabsf(v[u].w)));
+            mf = __builtin_fmaxf(mf, m4);
+            mn = min(mn, __float_as_uint(m4) - 1u); // (0 - 1 wraps to the largest value: groups of zeros are passed over; one unit on the others is nothing against 2^28)
             px = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, fmaf(v[u].w, v[u].w, px))));
         }
         unsigned mx = __float_as_uint(mf);
-        unsigned mn = mx ? mx : 0xffffffffu;
         mx = hf_wave_reduce_u32(mx, [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
         mn = hf_wave_reduce_u32(mn, [](unsigned a_, unsigned b_) { return a_ < b_ ? a_ : b_; });
         px = hf_wave_sum(px);
         if (lane == 0) { stat[slot][wave] = mx; stat[slot][4 + wave] = mn; stat[slot][8 + wave] = __float_as_uint(px); }
     };
-    auto put_ypower = [&](float py, int slot) {
-        py = hf_wave_sum(py);
-        if (lane == 0) ystat[slot][wave] = py;
+    auto put_ypower = [&](float py, int slot) { // (a lane's tiles all lie in its column `col`)
+        py = hf_column_sum(py);
+        if (lane < 16) ystat[slot][wave][lane] = py;
     };
     // -> scale s (its inverse in inv_s), and whether the segment must take the float32 path
     auto block_scale = [&](int slot, float& s, float& inv_s, float& px) -> int { // 0: the f16 pipe; 1: float32 products (the spread); 2: plain float32 sums (a non-finite sample)
@@ -252,8 +274,9 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     };
     // the guard's verdict on segment sg (its output powers are in ystat[sg & 1], a barrier ago): rejected -> again on the float32 path
     auto judge = [&](long sg, float px) {
-        const float4 p4 = *reinterpret_cast<const float4*>(&ystat[sg & 1][0]);
-        const float  py = (p4.x + p4.y) + (p4.z + p4.w);
+        const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
+        const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
+                                                // segment does not hide that the rest of it is all rejection
         if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, false);
     };
     float s_cur, inv_cur, px_cur, px_prev = 0.f;
@@ -342,6 +365,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
             note(sg, slow_cur == 2);
             py = __builtin_inff(); // (nothing to judge)
         }
+        if (seg0 + 256L * col >= n) py = __builtin_inff(); // (a column past the end of the span)
         put_stats(oth, (int)(sg & 1));
         put_ypower(py, (int)(sg & 1));
         s_cur    = s_nx;
@@ -394,7 +418,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
     constexpr int NM  = KS + 1;                                  // fragments of a wave's stream (two tiles, one K-step apart)
     __shared__ __attribute__((aligned(16))) unsigned short pls[2][4 * PL]; // planes re1, re2, im1, im2
     __shared__ __attribute__((aligned(16))) unsigned stat[2][12];
-    __shared__ __attribute__((aligned(16))) float    ystat[2][4];
+    __shared__ __attribute__((aligned(16))) float    ystat[2][4][16]; // (per column of 128 outputs)
     __shared__ unsigned char noted[GR4_F16_MAX_SPW];
     static_assert(4 * PL * 2 >= (2 * (NS + 4 * (NS / 128 + 1))) * 4, "the float32 path stages both components of a segment in one plane buffer");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
@@ -428,22 +452,25 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         }
     };
     auto put_stats = [&](const float4 (&v)[NL4], int slot) {
-        float mf = 0.f, px = 0.f;
+        float mf = 0.f, px = 0.f; // largest magnitude (v_max3_f32 on |.|: a NaN is passed over, an Inf stays) and the power (NaN if a NaN is among the samples)
+        unsigned mn = 0xffffffffu; // the quietest group of four consecutive values that is not all zeros: the level of the ordinary samples, local in TIME (a level that
+                                   // drops in the middle of a segment is seen, not only an isolated outlier)
 #pragma unroll
         for (int u = 0; u < NL4; ++u) {
-            mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fabsf(v[u].x)), __builtin_fmaxf(__builtin_fabsf(v[u].y), __builtin_fmaxf(__builtin_fabsf(v[u].z), __builtin_fabsf(v[u].w))));
+            const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[u].x), __builtin_fabsf(v[u].y)), __builtin_fmaxf(__builtin_fabsf(v[u].z), __builtin_fabsf(v[u].w)));
+            mf = __builtin_fmaxf(mf, m4);
+            mn = min(mn, __float_as_uint(m4) - 1u); // (0 - 1 wraps to the largest value: groups of zeros are passed over; one unit on the others is nothing against 2^28)
             px = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, fmaf(v[u].w, v[u].w, px))));
         }
         unsigned mx = __float_as_uint(mf);
-        unsigned mn = mx ? mx : 0xffffffffu;
         mx = hf_wave_reduce_u32(mx, [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
         mn = hf_wave_reduce_u32(mn, [](unsigned a_, unsigned b_) { return a_ < b_ ? a_ : b_; });
         px = hf_wave_sum(px);
         if (lane == 0) { stat[slot][wave] = mx; stat[slot][4 + wave] = mn; stat[slot][8 + wave] = __float_as_uint(px); }
     };
-    auto put_ypower = [&](float py, int slot) {
-        py = hf_wave_sum(py);
-        if (lane == 0) ystat[slot][wave] = py;
+    auto put_ypower = [&](float py, int slot) { // (a lane's tiles all lie in its column `col`)
+        py = hf_column_sum(py);
+        if (lane < 16) ystat[slot][wave][lane] = py;
     };
     auto block_scale = [&](int slot, float& s, float& inv_s, float& px) -> int {
         const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[slot][0]), n4 = *reinterpret_cast<const uint4*>(&stat[slot][4]), p4 = *reinterpret_cast<const uint4*>(&stat[slot][8]);
@@ -532,8 +559,9 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         if (tid == 0) noted[sg - sfirst] = exact ? 2 : 1;
     };
     auto judge = [&](long sg, float px) {
-        const float4 p4 = *reinterpret_cast<const float4*>(&ystat[sg & 1][0]);
-        const float  py = (p4.x + p4.y) + (p4.z + p4.w);
+        const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
+        const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
+                                                // segment does not hide that the rest of it is all rejection
         if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, false);
     };
     float s_cur, inv_cur, px_cur, px_prev = 0.f;
@@ -623,6 +651,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
             note(sg, slow_cur == 2);
             py = __builtin_inff();
         }
+        if (seg0 + 128L * col >= n) py = __builtin_inff(); // (a column past the end of the span)
         put_stats(oth, (int)(sg & 1));
         put_ypower(py, (int)(sg & 1));
         s_cur    = s_nx;

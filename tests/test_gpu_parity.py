@@ -480,7 +480,7 @@ def test_fir_complex_long_input_fast_convolution(G, ntaps, devsw):
             parts.append(f.process_bulk(xin).cpu().numpy())
         ys.append(np.concatenate(parts))
         assert _rel(ys[-1], truth) <= TOL
-    assert not np.array_equal(ys[0], ys[1])  # (the fast convolution, then the f16 direct form)
+    assert ntaps <= 32 or not np.array_equal(ys[0], ys[1])  # (the fast convolution / the bf16 direct form, then the f16 direct form; <= 32 taps: the register-window kernel both times)
     # an input span that is only 8-byte aligned (e.g. an odd ring-buffer position) gives the same answer
     f2 = G.fir_filter(b, torch.complex64)
     xin = torch.empty(n + 1, dtype=torch.complex64, device="cuda")[1:]
