@@ -158,6 +158,83 @@ def oracle_frame(O, taps, x_dev, f):
     return out.reshape(-1, NFFT)[1]
 
 
+def secondary_configs(G, verify):
+    """BASELINE.json configs[2] and configs[3] on this GPU: steady-state rates (back-to-back launches between two events, medians over rounds), each output checked against
+    the oracle on a sampled stretch.  Not the headline metric: rows beside it, so that the driver's record carries them."""
+    import numpy as np
+    import torch
+    from gnuradio4_amd import capi
+
+    def lowpass(ntaps, fc):
+        k = np.arange(ntaps, dtype=np.float64)
+        t = np.hamming(ntaps) * 2 * fc * np.sinc(2 * fc * (k - (ntaps - 1) / 2.0))
+        return (t / t.sum()).astype(np.float32)
+
+    def rate(fn, reps, rounds=5):
+        fn()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(rounds):
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            for _ in range(reps):
+                fn()
+            b_.record()
+            b_.synchronize()
+            ms.append(a_.elapsed_time(b_) / reps)
+        return sorted(ms)[len(ms) // 2]
+
+    out = {}
+    O = _oracle() if verify else None
+    # configs[3]: 64 channels x 256 taps (csrc/fir_f16.hip: two-term f16 splits under a block exponent on the f16 matrix pipe, every segment judged)
+    nch, ntaps, n = 64, 256, 1 << 22
+    taps = np.stack([lowpass(ntaps, 0.05 + 0.005 * c) for c in range(nch)])
+    xb = torch.stack([G.synth_f32(n, seed=42 + c) for c in range(nch)])
+    yb = torch.empty_like(xb)
+    fb = G.FirBatched(taps)
+    ms = rate(lambda: fb.process_bulk(xb, yb), 20)
+    row = {"workload": "64 channels x 256-tap float FIR x 2^22 samples (BASELINE.json configs[3]), csrc/fir_f16.hip", "value": round(nch * n / (ms * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+           "ms_per_launch": round(ms, 4), "bytes_per_sample": 8, "hbm_frac": round(nch * n * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "float32_equivalent_TFLOP/s": round(nch * n * 2 * ntaps / (ms * 1e-3) / 1e12, 1), "executed_f16_TFLOP/s": round(nch * n * 3 * 2 * 288 / (ms * 1e-3) / 1e12, 1)}
+    if verify:
+        fb2 = G.FirBatched(taps)  # (a fresh history: the timed handle has seen the span many times)
+        fb2.process_bulk(xb, yb)
+        errs = []
+        for c in (0, 37, 63):
+            m = 3 * 4096 + 100
+            truth, _ = O.fir(taps[c], xb[c, :m].cpu().numpy())
+            errs.append(_rel_err(yb[c, :m].cpu().numpy(), truth))
+        row["verify_max_rel_err"] = float(f"{max(errs):.3e}")
+    out["configs[3]"] = row
+    del xb, yb, fb
+    # configs[2]: decimate-by-8 1024-tap FIR + Butterworth order 8 (4 biquads) at the decimated rate, gr4hip_fir_process -> gr4hip_iir_process
+    n2 = 1 << 27
+    x = G.synth_f32(n2, seed=42)
+    b1024 = lowpass(1024, 0.05)
+    fir = G.fir_filter(b1024, torch.float32, decimate=8)
+    bi, ai = G.blocks.design_iir(capi.LOWPASS, 8, 0.05, float("nan"), 1.0, capi.BUTTERWORTH)
+    iir = G.iir_filter(bi, ai)
+    yd = torch.empty(n2 // 8, dtype=torch.float32, device="cuda")
+    yo = torch.empty_like(yd)
+
+    def both():
+        fir.process_bulk(x, yd)
+        iir.process_bulk(yd, yo)
+    ms = rate(both, 20)
+    row = {"workload": "decimate-by-8 1024-tap float FIR + 4 biquads x 2^27 input samples (BASELINE.json configs[2]), two launches", "value": round(n2 / (ms * 1e-3) / 1e6, 1),
+           "unit": "Msamples/s (input rate)", "ms_per_pass": round(ms, 4), "bytes_per_input_sample": 5.5, "hbm_frac": round(n2 * 5.5 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if verify:
+        fir2, iir2 = G.fir_filter(b1024, torch.float32, decimate=8), G.iir_filter(bi, ai)
+        fir2.process_bulk(x, yd)
+        iir2.process_bulk(yd, yo)
+        m = 8 * 20000
+        td, _ = O.fir_decim(b1024, x[:m].cpu().numpy(), 8)
+        ti = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)]), td.astype(np.float32), O.DF_II, f64=True)
+        row["verify_max_rel_err"] = float(f"{max(_rel_err(yd[: m // 8].cpu().numpy(), td), _rel_err(yo[: m // 8].cpu().numpy(), ti)):.3e}")
+    out["configs[2]"] = row
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +259,7 @@ def main():
     ap.add_argument("--no-graph8", action="store_true", help="N = 1: skip the extra measurement of the 8-channel graph on this one GPU (the 1-GPU point of the strong-scaling curve)")
     ap.add_argument("--prewarm-ms", type=float, default=40.0, help="untimed launches for at least this long BEFORE the counted --warmup steps: the shader clock needs ~20 ms under load to "
                     "settle (profiles/r02_clock_ramp.txt), and a short --steps run would otherwise be timed inside that ramp; reported as prewarm_ms / prewarm_steps")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the rows of BASELINE.json configs[2] and configs[3] (a second or two each, after the headline)")
     ap.add_argument("--no-hann-row", action="store_true", help="N = 1: skip the second row with the FFT block's default Hann window (SURVEY.md 8(d))")
     ap.add_argument("--fanin-timeout", type=float, default=90.0, help="N > 1: seconds any phase that waits for another rank may take before the run gives up with a rank-tagged diagnostic "
                     "(exit code 4, an \"error\" key in the JSON line) instead of hanging; 0 = no watchdog")
@@ -544,6 +622,13 @@ def main():
                 del hann
             except Exception as e:  # never at the price of the headline line
                 res["hann_second_row"] = {"error": str(e)[:200]}
+        if world == 1 and not combine and not args.no_secondary and os.environ.get("GR4HIP_BENCH_CHILD") != "1":
+            try:
+                res["secondary_configs"] = secondary_configs(G, not args.no_verify)
+                if any(isinstance(v, dict) and v.get("verify_max_rel_err", 0.0) > PARITY_TOL for v in res["secondary_configs"].values()):
+                    rc = 3
+            except Exception as e:  # never at the price of the headline line
+                res["secondary_configs"] = {"error": str(e)[:200]}
         if world == 1 and not combine and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not combine and not args.no_graph8 and os.environ.get("GR4HIP_BENCH_CHILD") != "1":

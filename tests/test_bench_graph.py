@@ -84,9 +84,12 @@ def test_bench_stalled_rank_gives_a_diagnostic_not_a_hang():
     assert len(lines) == 1 and json.loads(lines[0])["error"].startswith("rank 0 of 2: no progress in phase"), p.stdout[-2000:]
 
 
-def test_bench_line_has_the_median_the_prewarm_and_the_hann_row():
+def test_bench_line_has_the_median_the_prewarm_the_hann_row_and_the_secondary_configs():
     r = _run([sys.executable, "bench.py", "--steps", "5", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline", "--no-graph8"])
     assert r["prewarm_ms"] >= 40 and r["prewarm_steps"] >= 1 and r["median_ms_per_step"] > 0 and r["value_at_median_step"] > 0
     assert r["roofline"]["timed_launches"] == 5 * 4
     h = r["hann_second_row"]
     assert h["window"] == "Hann" and h["value"] > 0 and 0 < h["frac"] < 1 and h["verify_max_rel_err"] <= 1e-5
+    sc = r["secondary_configs"]  # BASELINE.json configs[2] and configs[3] beside the headline, each checked against the oracle
+    for k in ("configs[2]", "configs[3]"):
+        assert sc[k]["value"] > 0 and 0 < sc[k]["hbm_frac"] < 1 and sc[k]["verify_max_rel_err"] <= 1e-5, sc[k]
