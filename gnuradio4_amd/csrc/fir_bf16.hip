@@ -545,9 +545,11 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c1, 0, 0, 0);
             c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c2, 0, 0, 0);
+#ifndef GR4_T_BD_THREE // timing only (wrong results): what three products instead of six would give this kernel
             c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c3, 0, 0, 0);
             c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c4, 0, 0, 0);
             c5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c5, 0, 0, 0);
+#endif
         }
         const long o = sg * kBdSegOut + 16L * (16 * wave + col) + 4 * kq; // D[row = 4 kq + r][col]
         float      v[4];
