@@ -21,10 +21,12 @@
 // but four times larger, so it only shows against the OUTPUT when the filter removes nearly everything it is given.  Every segment's output power is compared
 // with its input power -- P_y as sixteen times the power of the QUIETEST of the segment's sixteen output columns (256 outputs each), so that a start-up transient or
 // the edge of a burst somewhere in the segment does not hide that the rest of it is all rejection: P_y < 2^-12 (sum b^2) P_x -- more than 36 dB of the staged power
-// rejected beyond what white noise would lose -- and the segment is
-// evaluated again on the float32 path, at the end of the workgroup's run of segments (`guard`; off for the slices of long filters, whose launches see partial sums).
-// So a stream whose rejected part is far above what passes costs the float32 path's rate on exactly the segments where that is so, and has the reference's
-// float32 error there (include/gr4hip.h, "PARITY CONTRACT").
+// rejected beyond what white noise would lose -- and the segment is evaluated again at the end of the workgroup's run of segments (`guard`; off for the slices of long
+// filters, whose launches see partial sums) with THREE f16 terms per factor -- 33 bits, the float32 values themselves; the six products of order <= 2, each exact to 2^-33,
+// in the same float32 accumulators: float32 products at twice the first evaluation's matrix-pipe time (redo_segment; the f32 matrix pipe would take five times).  So a
+// stream whose rejected part is far above what passes costs three evaluations' worth on exactly the segments where that is so (256 taps: 166 instead of 515 Gsamples/s
+// when EVERY segment is rejected), and has float32 products there: measured 3.2e-5 .. 3.6e-5 under a tone 50 dB above the output, the f32 kernels' 3.4e-5 .. 4.0e-5, the
+// reference's sequential float32 sum 6.8e-5 .. 7.3e-5 (include/gr4hip.h, "PARITY CONTRACT").
 //
 // (Measured and dropped: the outputs through LDS as whole 1 KiB rows one segment later instead of 64-byte pieces straight from the accumulators -- 256 taps 499 -> 488,
 // 64 taps 623 -> 626 Gsamples/s on one box: the store pattern is not what these launches wait for.)
@@ -55,9 +57,9 @@ using u32x4_h = __attribute__((ext_vector_type(4))) unsigned;
 constexpr int kHfSeg      = 4096;
 constexpr int kHfMaxRange = 28; // a segment whose largest sample is more than 2^28 above its ordinary level takes the float32 path
 
-// channel block of the table fir_f16_make_afrag writes, in 16-bit units: [2 planes][KS][64 lanes][8] f16 fragments, 8 units of header {float 1 / t, int ntaps, float 2^-12 sum b^2, -},
+// channel block of the table fir_f16_make_afrag writes, in 16-bit units: [3 planes][KS][64 lanes][8] f16 fragments (the third plane: the judged segments' second evaluation), 8 units of header {float 1 / t, int ntaps, float 2^-12 sum b^2, -},
 // 32 KS float taps (the float32 path's)
-__host__ __device__ constexpr int hf_block_units(int KS) { return KS * 1024 + 8 + KS * 64; }
+__host__ __device__ constexpr int hf_block_units(int KS) { return KS * 1536 + 8 + KS * 64; }
 
 // two samples -> their two f16 terms under the block scale s (a power of two: x s is exact); the residual is exact in float32 and enters its plane times 2^11
 __device__ __forceinline__ void hf_split2(float x0, float x1, float s, unsigned& h, unsigned& l) {
@@ -106,6 +108,19 @@ __device__ __forceinline__ float hf_row_min(float v) {
     return __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
 }
 
+// the same into THREE terms (33 bits: a float32 value exactly, while the block exponent holds): the second evaluation of a segment the guard has rejected
+__device__ __forceinline__ void hf_split2x3(float x0, float x1, float s, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2_h v  = {x0 * s, x1 * s};
+    const f16x2_h hh = __builtin_convertvector(v, f16x2_h);
+    const f32x2_h r1 = (v - __builtin_convertvector(hh, f32x2_h)) * 2048.f;
+    const f16x2_h mm = __builtin_convertvector(r1, f16x2_h);
+    const f32x2_h r2 = (r1 - __builtin_convertvector(mm, f32x2_h)) * 2048.f;
+    const f16x2_h ll = __builtin_convertvector(r2, f16x2_h);
+    h = __builtin_bit_cast(unsigned, hh);
+    m = __builtin_bit_cast(unsigned, mm);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
 template <int KS> // K-steps of 32: window Kw = 32 KS, Hb = Kw - 16 samples in front of a 16-output block
 __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(const float* __restrict__ x0, const float* __restrict__ hist0 /*the Kh samples in front of x*/, int Kh,
                                                                                 const unsigned short* __restrict__ blk0 /*[channels] blocks of hf_block_units(KS)*/, float* __restrict__ y0, long n,
@@ -116,10 +131,10 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     const float*          hist  = hist0 + (long)blockIdx.y * Kh;
     const unsigned short* blk   = blk0 + (long)blockIdx.y * hf_block_units(KS);
     const u32x4_h*        afrag = reinterpret_cast<const u32x4_h*>(blk);
-    const float           inv_t = *reinterpret_cast<const float*>(blk + KS * 1024);
-    const int             ntaps = *reinterpret_cast<const int*>(blk + KS * 1024 + 2);
-    const float           gthr  = *reinterpret_cast<const float*>(blk + KS * 1024 + 4);
-    const float*          tapsf = reinterpret_cast<const float*>(blk + KS * 1024 + 8);
+    const float           inv_t = *reinterpret_cast<const float*>(blk + KS * 1536);
+    const int             ntaps = *reinterpret_cast<const int*>(blk + KS * 1536 + 2);
+    const float           gthr  = *reinterpret_cast<const float*>(blk + KS * 1536 + 4);
+    const float*          tapsf = reinterpret_cast<const float*>(blk + KS * 1536 + 8);
     float*                y     = y0 + (long)blockIdx.y * out_stride;
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kHfSeg + Hb; // staged samples per segment (a multiple of 16)
     constexpr int PL  = NS + 8 * (NS / 256) + 16;               // f16 elements per plane: one 16-byte chunk of padding per 256 samples (see P below)
@@ -128,7 +143,8 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short pls[2][2 * PL];
     __shared__ __attribute__((aligned(16))) unsigned stat[2][12]; // per data segment parity: the four waves' largest magnitude bits, quietest non-zero groups of four, sums of squares
     __shared__ __attribute__((aligned(16))) float    ystat[2][4][16]; // per computed segment parity: the four waves' output powers per column of 256 outputs
-    __shared__ unsigned char noted[GR4_F16_MAX_SPW];              // per segment of this workgroup's run: 1 = again with float32 products, 2 = again as plain float32 sums
+    __shared__ unsigned char noted[GR4_F16_MAX_SPW];              // per segment of this workgroup's run: what `note` says
+    static_assert(2 * PL * 2 >= (NS + 4 * (NS / 256 + 1)) * 4 && 2 * PL * 2 >= 2 * Kw * 4, "the float32 path stages a segment's raw samples in one plane buffer and the padded taps in the other");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
     auto P = [](int s_) { return s_ + 8 * (s_ >> 8); };
 
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     const int tb = (wave >> 1) + 8 * (wave & 1); // waves 0, 1: the even tiles from 0 / 8; waves 2, 3: the odd tiles from 1 / 9
     const int sb = 256 * col + 16 * tb + 8 * kq;
     // the float32 path: one segment's outputs as float32 products on the f32 matrix pipe (v_mfma_f32_16x16x4_f32: every product and partial sum an IEEE float32
-    // operation, the sums block-wise).  `stage` is a plane buffer nobody needs at that moment (4520 floats): the segment's NS raw samples go there, 4 floats
+    // operation, the sums block-wise).  `stage` is a plane buffer nobody needs at that moment: the segment's NS raw samples go there, 4 floats
     // of padding per 256 (lane (col, kq) reads word 256 col + 16 t + 4 k4 + kq: 64 different banks), the tap operand comes from the float taps of the table.
     // Same tile map as the f16 path; about the rate of the library's f32 matrix-pipe FIR kernel while it runs.  Called by the whole workgroup.
     auto slow_segment = [&](long sg, unsigned short* stage16) {
@@ -267,17 +283,88 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
             y[o] = (accum ? y[o] : 0.f) + acc;
         }
     };
-    // segments for the float32 path are only NOTED while the run is under way (a byte per segment of the run in LDS: masks in scalar registers spilled) and evaluated behind it, when
-    // the tap fragments and the prefetch registers are dead -- inside the loop the call would sit on 110 live registers and spill them into the f16 loop
-    auto note = [&](long sg, bool exact) {
-        if (tid == 0) noted[sg - sfirst] = exact ? 2 : 1;
+    // a segment the guard has rejected, again: samples and taps as THREE f16 terms (33 bits: the float32 values themselves), the six products of order <= 2 -- every product
+    // exact to 2^-33, the sums the matrix pipe's float32 accumulators: float32 products at twice the f16 path's matrix-pipe time (the f32 pipe: 5 times).  The planes of both
+    // buffers are free behind the run (terms 1, 2 in the first, term 3 in the second), the third tap plane comes from the table.  Same tile map, same way out.
+    auto redo_segment = [&](long sg) {
+        const long seg0 = sg * kHfSeg;
+        u32x4_h    a3[3][KS];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a3[p][ks] = afrag[(p * KS + ks) * 64 + lane];
+        if (sg > 0) load_next(nxa, seg0);
+        else load_general(nxa, 0);
+        float mf = 0.f;
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fmaxf(__builtin_fabsf(nxa[u].x), __builtin_fabsf(nxa[u].y))), __builtin_fmaxf(__builtin_fabsf(nxa[u].z), __builtin_fabsf(nxa[u].w)));
+        const unsigned mw = hf_wave_reduce_u32(__float_as_uint(mf), [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
+        if (lane == 0) stat[0][wave] = mw;
+        __syncthreads();
+        const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[0][0]);
+        const int   e  = (int)(__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))) >> 23), ec = e < 15 ? 15 : (e > 254 ? 254 : e);
+        const float s = __uint_as_float((unsigned)(268 - ec) << 23), inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int q = tid + 256 * u;
+            if (256 * (u + 1) <= NS / 4 || q < NS / 4) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                hf_split2x3(nxa[u].x, nxa[u].y, s, h0, m0, l0);
+                hf_split2x3(nxa[u].z, nxa[u].w, s, h1, m1, l1);
+                *reinterpret_cast<uint2*>(pls[0] + P(4 * q))      = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(pls[0] + PL + P(4 * q)) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(pls[1] + P(4 * q))      = make_uint2(l0, l1);
+            }
+        }
+        __syncthreads();
+        f32x4_h c[4], d[4], g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = d[j] = g[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int     qo = P(sb + 32 * m);
+            const f16x8_h b1 = *reinterpret_cast<const f16x8_h*>(pls[0] + qo), b2 = *reinterpret_cast<const f16x8_h*>(pls[0] + PL + qo), b3 = *reinterpret_cast<const f16x8_h*>(pls[1] + qo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ks = m - j;
+                if (ks < 0 || ks >= KS) continue;
+                const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a3[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a3[1][ks]), a3_ = __builtin_bit_cast(f16x8_h, a3[2][ks]);
+                c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[j], 0, 0, 0);
+                d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, d[j], 0, 0, 0);
+                g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b3, g[j], 0, 0, 0);
+                d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, d[j], 0, 0, 0);
+                g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, g[j], 0, 0, 0);
+                g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3_, b1, g[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long o = seg0 + 256L * col + 16 * (tb + 2 * j) + 4 * kq;
+            float      v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((c[j][r] + (d[j][r] + g[j][r] * (1.f / 2048.f)) * (1.f / 2048.f)) * inv_t) * inv_s;
+            if (o + 3 < n) {
+                float4 w = make_float4(v[0], v[1], v[2], v[3]);
+                if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w; }
+                *reinterpret_cast<float4*>(y + o) = w;
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + v[r];
+            }
+        }
+        __syncthreads(); // (the planes are staged again by the next noted segment)
+    };
+    // segments for the second evaluation are only NOTED while the run is under way (a byte per segment of the run in LDS: masks in scalar registers spilled) and evaluated behind
+    // it, when the tap fragments and the prefetch registers are dead -- inside the loop the call would sit on 110 live registers and spill them into the f16 loop
+    auto note = [&](long sg, int kind) { // 1: float32 products on the f32 pipe (the spread); 2: plain float32 sums (a non-finite sample); 3: three-term f16 products (the guard)
+        if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
     };
     // the guard's verdict on segment sg (its output powers are in ystat[sg & 1], a barrier ago): rejected -> again on the float32 path
     auto judge = [&](long sg, float px) {
         const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
         const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
                                                 // segment does not hide that the rest of it is all rejection
-        if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, false);
+        if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, 3);
     };
     float s_cur, inv_cur, px_cur, px_prev = 0.f;
     int   slow_cur;
@@ -362,7 +449,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         } else {
 #pragma unroll
             for (int u = 0; u < NL4; ++u) put_next(plo, u, cur[u], s_nx);
-            note(sg, slow_cur == 2);
+            note(sg, slow_cur);
             py = __builtin_inff(); // (nothing to judge)
         }
         if (seg0 + 256L * col >= n) py = __builtin_inff(); // (a column past the end of the span)
@@ -383,10 +470,11 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     __syncthreads();
     for (int i = 0; i < seg_per_wg; ++i) { // (uniform: every lane reads the same bytes)
         const int kind = noted[i];
-        if (kind == 1) {
-            __builtin_amdgcn_s_waitcnt(0); // this wave's stores have landed (and everybody's, behind slow_segment's first barrier) before other lanes write the same outputs
-            slow_segment(sfirst + i, pls[0]);
-        } else if (kind == 2) exact_segment(sfirst + i);
+        if (kind == 3) {
+            __builtin_amdgcn_s_waitcnt(0); // this wave's stores of the first evaluation have landed (and everybody's, behind redo_segment's first barrier) before other lanes write the same outputs
+            redo_segment(sfirst + i);
+        } else if (kind == 1) slow_segment(sfirst + i, pls[0]);
+        else if (kind == 2) exact_segment(sfirst + i);
     }
     if (new_hist != nullptr && blockIdx.x == 0 && blockIdx.y == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
         for (int h = tid; h < Kh; h += 256) {
@@ -408,10 +496,10 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
                                                                                     const unsigned short* __restrict__ blk /*one block of hf_block_units(KS)*/, float2* __restrict__ y, long n,
                                                                                     float2* __restrict__ new_hist, int seg_per_wg, int guard) {
     const u32x4_h* afrag = reinterpret_cast<const u32x4_h*>(blk);
-    const float    inv_t = *reinterpret_cast<const float*>(blk + KS * 1024);
-    const int      ntaps = *reinterpret_cast<const int*>(blk + KS * 1024 + 2);
-    const float    gthr  = *reinterpret_cast<const float*>(blk + KS * 1024 + 4);
-    const float*   tapsf = reinterpret_cast<const float*>(blk + KS * 1024 + 8);
+    const float    inv_t = *reinterpret_cast<const float*>(blk + KS * 1536);
+    const int      ntaps = *reinterpret_cast<const int*>(blk + KS * 1536 + 2);
+    const float    gthr  = *reinterpret_cast<const float*>(blk + KS * 1536 + 4);
+    const float*   tapsf = reinterpret_cast<const float*>(blk + KS * 1536 + 8);
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kHfSegC + Hb; // staged complex samples per segment (a multiple of 16)
     constexpr int PL  = NS + 8 * (NS / 128 + 1) + 16;            // f16 elements per plane: one 16-byte chunk of padding per 128 samples (the columns are 128 samples apart)
     constexpr int NL4 = (NS / 2 + 255) / 256;                    // float4 loads (two complex samples each) a lane holds for the next segment
@@ -555,14 +643,91 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
     const long nseg = (n + kHfSegC - 1) / kHfSegC, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
     if (sfirst >= slast) return;
     if (tid < GR4_F16_MAX_SPW) noted[tid] = 0;
-    auto note = [&](long sg, bool exact) {
-        if (tid == 0) noted[sg - sfirst] = exact ? 2 : 1;
+    // a segment the guard has rejected, again with three-term f16 products (see the float kernel): terms 1, 2 of both components in the first buffer's four planes, term 3
+    // in the second buffer's first two
+    auto redo_segment = [&](long sg) {
+        const long seg0 = sg * kHfSegC;
+        u32x4_h    a3[3][KS];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a3[p][ks] = afrag[(p * KS + ks) * 64 + lane];
+        if (sg > 0) load_next(nxa, seg0);
+        else load_general(nxa, 0);
+        float mf = 0.f;
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fmaxf(__builtin_fabsf(nxa[u].x), __builtin_fabsf(nxa[u].y))), __builtin_fmaxf(__builtin_fabsf(nxa[u].z), __builtin_fabsf(nxa[u].w)));
+        const unsigned mw = hf_wave_reduce_u32(__float_as_uint(mf), [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
+        if (lane == 0) stat[0][wave] = mw;
+        __syncthreads();
+        const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[0][0]);
+        const int   e  = (int)(__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))) >> 23), ec = e < 15 ? 15 : (e > 254 ? 254 : e);
+        const float s = __uint_as_float((unsigned)(268 - ec) << 23), inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int q = tid + 256 * u;
+            if (256 * (u + 1) <= NS / 2 || q < NS / 2) {
+                unsigned rh, rm, rl, ih, im, il;
+                hf_split2x3(nxa[u].x, nxa[u].z, s, rh, rm, rl);
+                hf_split2x3(nxa[u].y, nxa[u].w, s, ih, im, il);
+                const int e2 = P(2 * q);
+                *reinterpret_cast<unsigned*>(pls[0] + e2)          = rh;
+                *reinterpret_cast<unsigned*>(pls[0] + PL + e2)     = rm;
+                *reinterpret_cast<unsigned*>(pls[0] + 2 * PL + e2) = ih;
+                *reinterpret_cast<unsigned*>(pls[0] + 3 * PL + e2) = im;
+                *reinterpret_cast<unsigned*>(pls[1] + e2)          = rl;
+                *reinterpret_cast<unsigned*>(pls[1] + PL + e2)     = il;
+            }
+        }
+        __syncthreads();
+        f32x4_h c[4], d[4], g[4]; // index 2 tile + component
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = d[j] = g[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int qo = P(sb + 32 * m);
+            f16x8_h   b1[2], b2[2], b3[2];
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                b1[cp] = *reinterpret_cast<const f16x8_h*>(pls[0] + 2 * cp * PL + qo);
+                b2[cp] = *reinterpret_cast<const f16x8_h*>(pls[0] + (2 * cp + 1) * PL + qo);
+                b3[cp] = *reinterpret_cast<const f16x8_h*>(pls[1] + cp * PL + qo);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int ks = m - jj;
+                if (ks < 0 || ks >= KS) continue;
+                const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a3[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a3[1][ks]), a3_ = __builtin_bit_cast(f16x8_h, a3[2][ks]);
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    const int j = 2 * jj + cp;
+                    c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[cp], c[j], 0, 0, 0);
+                    d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2[cp], d[j], 0, 0, 0);
+                    g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b3[cp], g[j], 0, 0, 0);
+                    d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1[cp], d[j], 0, 0, 0);
+                    g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2[cp], g[j], 0, 0, 0);
+                    g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3_, b1[cp], g[j], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const long o = seg0 + 128L * col + 16 * (tb + 2 * jj) + 4 * kq;
+            for (int r = 0; r < 4; ++r)
+                if (o + r < n)
+                    y[o + r] = make_float2(((c[2 * jj][r] + (d[2 * jj][r] + g[2 * jj][r] * (1.f / 2048.f)) * (1.f / 2048.f)) * inv_t) * inv_s,
+                                           ((c[2 * jj + 1][r] + (d[2 * jj + 1][r] + g[2 * jj + 1][r] * (1.f / 2048.f)) * (1.f / 2048.f)) * inv_t) * inv_s);
+        }
+        __syncthreads();
+    };
+    auto note = [&](long sg, int kind) { // 1: float32 products on the f32 pipe (the spread); 2: plain float32 sums (a non-finite sample); 3: three-term f16 products (the guard)
+        if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
     };
     auto judge = [&](long sg, float px) {
         const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
         const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
                                                 // segment does not hide that the rest of it is all rejection
-        if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, false);
+        if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, 3);
     };
     float s_cur, inv_cur, px_cur, px_prev = 0.f;
     int   slow_cur;
@@ -648,7 +813,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         } else {
 #pragma unroll
             for (int u = 0; u < NL4; ++u) put_next(plo, u, cur[u], s_nx);
-            note(sg, slow_cur == 2);
+            note(sg, slow_cur);
             py = __builtin_inff();
         }
         if (seg0 + 128L * col >= n) py = __builtin_inff(); // (a column past the end of the span)
@@ -669,10 +834,11 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
     __syncthreads();
     for (int i = 0; i < seg_per_wg; ++i) {
         const int kind = noted[i];
-        if (kind == 1) {
+        if (kind == 3) {
             __builtin_amdgcn_s_waitcnt(0);
-            slow_segment(sfirst + i, pls[0]);
-        } else if (kind == 2) exact_segment(sfirst + i);
+            redo_segment(sfirst + i);
+        } else if (kind == 1) slow_segment(sfirst + i, pls[0]);
+        else if (kind == 2) exact_segment(sfirst + i);
     }
     if (new_hist != nullptr && blockIdx.x == 0) {
         for (int h = tid; h < Kh; h += 256) {
@@ -728,15 +894,18 @@ bool fir_f16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::v
         float          t, inv_t;
         std::memcpy(&t, &tb, 4);
         std::memcpy(&inv_t, &ib, 4);
-        std::vector<unsigned short> pl[2];
+        std::vector<unsigned short> pl[3];
         for (auto& v : pl) v.assign(ntaps, 0);
         for (size_t k = 0; k < ntaps; ++k) {
-            const float          b = taps[k] * t;
-            const unsigned short h = host_f16_rne(b);
+            const float          b  = taps[k] * t;
+            const unsigned short h  = host_f16_rne(b);
+            const float          r1 = (b - host_f16_to_f(h)) * 2048.f; // (exact in float32)
+            const unsigned short m  = host_f16_rne(r1);
             pl[0][k] = h;
-            pl[1][k] = host_f16_rne((b - host_f16_to_f(h)) * 2048.f);
+            pl[1][k] = m;
+            pl[2][k] = host_f16_rne((r1 - host_f16_to_f(m)) * 2048.f);
         }
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 3; ++p)
             for (int ks = 0; ks < KS; ++ks)
                 for (int l = 0; l < 64; ++l)
                     for (int tt = 0; tt < 8; ++tt) {
@@ -747,10 +916,10 @@ bool fir_f16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::v
         double    h2 = 0;
         for (size_t k = 0; k < ntaps; ++k) h2 += (double)taps[k] * taps[k];
         const float gthr = (float)(h2 / 4096.0);
-        std::memcpy(blk + KS * 1024, &inv_t, 4);
-        std::memcpy(blk + KS * 1024 + 2, &nt, 4);
-        std::memcpy(blk + KS * 1024 + 4, &gthr, 4);
-        std::memcpy(blk + KS * 1024 + 8, taps, ntaps * sizeof(float));
+        std::memcpy(blk + KS * 1536, &inv_t, 4);
+        std::memcpy(blk + KS * 1536 + 2, &nt, 4);
+        std::memcpy(blk + KS * 1536 + 4, &gthr, 4);
+        std::memcpy(blk + KS * 1536 + 8, taps, ntaps * sizeof(float));
     }
     *KS_out = KS;
     return true;

@@ -152,7 +152,7 @@ int gr4hip_ring_size(const gr4hip_ring_t* ring, size_t* bytes);
  *  - 33 .. 256 taps (float and complex; float also 384 .. 1024) on long 16-byte-aligned spans evaluate the products on the f16 matrix pipe, samples and taps split
  *    into two f16 terms under a block exponent per segment of 4096 (complex: 2048) outputs (csrc/fir_f16.hip; same 1e-5 parity bar).  A segment that holds a
  *    non-finite sample is evaluated as plain float32 sums instead: the reference's classes (+Inf, -Inf, NaN) on exactly its outputs; a finite outlier more than
- *    2^28 above the segment's ordinary level (1e30 or 3.4e38 beside unit-power samples) sends its segment to float32 products on the f32 matrix pipe, so the
+ *    2^28 above the segment's ordinary level (1e30 or 3.4e38 beside unit-power samples, a burst that ends inside the segment) sends its segment to float32 products on the f32 matrix pipe, so the
  *    samples beside it keep their accuracy.  (GR4HIP_FIR_TIME_DOMAIN_BF16X3, the three-term bf16 kernels of rounds 2-3: every output the reference makes
  *    non-finite is non-finite, as NaN, the reach is the kernel's 32-sample-granular window -- at most 15 outputs earlier and 46 later than the reference's --,
  *    and a finite sample above bf16's largest value, 3.39e38, counts as infinite.)
@@ -175,10 +175,11 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
  * input the error against float64 is that of a float32 sum (3e-7 .. 6e-7, below the three-term bf16 kernel's).  The error is relative to the PRODUCTS, so it shows
  * against the OUTPUT when the filter removes nearly all it is given -- and the kernel judges that itself: every segment's output power P_y is compared with its
  * input power P_x, and a segment with P_y < 2^-12 (sum b^2) P_x (36 dB more rejected than white noise would lose; the products by themselves are then at
- * <= 3e-6 of the output) is evaluated again inside the launch with float32 products on the f32 matrix pipe: under a rejected tone 50 dB above the output the default
- * is at the float32 kernels' error (3e-5 .. 4e-5 -- the reference's own float32 sum is there too), the products alone at 2e-4, the three-term bf16 kernel
+ * <= 3e-6 of the output) is evaluated again inside the launch with THREE f16 terms per factor (33 bits: the float32 values themselves; six products per tap, each exact to 2^-33, summed in the
+ * matrix pipe's float32 accumulators -- float32 products at twice the matrix-pipe time): under a rejected tone 50 dB above the output the default is at 3e-5 .. 4e-5,
+ * the float32 kernels' own error on that input and half the reference's sequential float32 sum's (7e-5), the products alone at 2e-4, the three-term bf16 kernel
  * (GR4HIP_FIR_TIME_DOMAIN_BF16X3: no guard) at 5e-5 .. 1e-4.  gr4hip_fir_set_guard_mode(GR4HIP_GUARD_OFF) switches the verdict off; the 256-tap slices of longer
- * float filters run without it (their launches see partial sums).  A stream in which every segment is rejected runs at 109 (256 taps) .. 264 (64 taps) Gsamples/s. */
+ * float filters run without it (their launches see partial sums).  A stream in which every segment is rejected runs both evaluations: 166 (256 taps) .. 325 (64 taps) Gsamples/s. */
 /* GR4HIP_FIR_TIME_DOMAIN_BF16X3: the three-term bf16 products of rounds 2-3 (six products per tap, everything above 2^-23 of a product, float32's exponent range
  * without a block exponent, no guard) where the default takes the f16 kernels; for complex data also "direct form" like GR4HIP_FIR_TIME_DOMAIN. */
 /* GR4HIP_FIR_EXACT_F32: every product and sum in IEEE float32 (no frequency-domain kernels, no bf16 splits): the kernels whose arithmetic is the reference's
