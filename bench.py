@@ -158,6 +158,42 @@ def oracle_frame(O, taps, x_dev, f):
     return out.reshape(-1, NFFT)[1]
 
 
+def live_traffic(kernel_symbol, log2_samples, log2_chunk):
+    """HBM bytes per launch of the headline kernel from the PMC counters, as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
+    counter-only rocprofv3 passes (they do not fit one pass; no trace domains beside them), FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of 16-byte-per-lane
+    streaming reads -- this kernel's LDS-DMA -- at 64 bytes), per full-size dispatch.  Each pass is a short child run of this script at the same launch size.
+    None when rocprofv3 is not there or a pass fails: the line then quotes the committed profile's figure only."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    match = kernel_symbol.split("gr4::")[-1].split("<")[0] + "<" + kernel_symbol.split("<")[-1].split(",")[0]  # chain_fd_kernel<0 (the Hann row's instantiation is <1, ...>)
+    kib = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="gr4pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", ctr, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+               "--log2-samples", str(log2_samples), "--log2-chunk", str(log2_chunk), "--no-cpu-baseline", "--no-graph8", "--no-hann-row", "--no-secondary", "--no-verify", "--no-live-traffic"]
+        try:
+            subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "GR4HIP_BENCH_CHILD": "1"})
+            rows = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                rows += [r for r in csv.DictReader(open(f)) if match in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            full = max((int(r["Grid_Size"]) for r in rows), default=0)  # (the guard's probe of a stream's first call is a dispatch of the same kernel on eight frames)
+            vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == full]
+            if not vals:
+                return None, f"no {ctr} rows for {match}"
+            kib[ctr] = sum(vals) / len(vals)
+        except Exception as e:
+            return None, f"{ctr} pass failed: {str(e)[:120]}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024), (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate counter-only passes over short runs of this script at the same "
+                                                                      f"launch size: FETCH_SIZE {kib['FETCH_SIZE']:.0f} KiB x 2 (gfx950 16-byte/lane correction) + WRITE_SIZE {kib['WRITE_SIZE']:.0f} KiB per dispatch")
+
+
 def secondary_configs(G, verify):
     """BASELINE.json configs[2] and configs[3] on this GPU: steady-state rates (back-to-back launches between two events, medians over rounds), each output checked against
     the oracle on a sampled stretch.  Not the headline metric: rows beside it, so that the driver's record carries them."""
@@ -259,6 +295,8 @@ def main():
     ap.add_argument("--no-graph8", action="store_true", help="N = 1: skip the extra measurement of the 8-channel graph on this one GPU (the 1-GPU point of the strong-scaling curve)")
     ap.add_argument("--prewarm-ms", type=float, default=40.0, help="untimed launches for at least this long BEFORE the counted --warmup steps: the shader clock needs ~20 ms under load to "
                     "settle (profiles/r02_clock_ramp.txt), and a short --steps run would otherwise be timed inside that ramp; reported as prewarm_ms / prewarm_steps")
+    ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: do not collect roofline.traffic (two short child runs of this script under rocprofv3 --pmc FETCH_SIZE / "
+                                                                   "--pmc WRITE_SIZE, counters only, after the headline); traffic stays null and the committed profile's figure is quoted")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the rows of BASELINE.json configs[2] and configs[3] (a second or two each, after the headline)")
     ap.add_argument("--no-hann-row", action="store_true", help="N = 1: skip the second row with the FFT block's default Hann window (SURVEY.md 8(d))")
     ap.add_argument("--fanin-timeout", type=float, default=90.0, help="N > 1: seconds any phase that waits for another rank may take before the run gives up with a rank-tagged diagnostic "
@@ -622,6 +660,15 @@ def main():
                 del hann
             except Exception as e:  # never at the price of the headline line
                 res["hann_second_row"] = {"error": str(e)[:200]}
+        if world == 1 and not combine and not args.no_live_traffic and os.environ.get("GR4HIP_BENCH_CHILD") != "1":
+            try:
+                tb, how = live_traffic(KERNEL_SYMBOLS.get(algo, ""), args.log2_samples, log2_chunk)
+                res["roofline"]["traffic"] = tb
+                res["roofline"]["traffic_how"] = how
+                if tb:
+                    res["roofline"]["traffic_over_algorithmic"] = round(tb / (chunk * ALGO_BYTES_PER_SAMPLE), 4)
+            except Exception as e:  # never at the price of the headline line
+                res["roofline"]["traffic_how"] = f"not collected: {str(e)[:160]}"
         if world == 1 and not combine and not args.no_secondary and os.environ.get("GR4HIP_BENCH_CHILD") != "1":
             try:
                 res["secondary_configs"] = secondary_configs(G, not args.no_verify)

@@ -30,7 +30,7 @@ def _run(cmd, timeout=900):
 
 
 def test_bench_single_channel_self_check():
-    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline", "--no-graph8"])
+    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline", "--no-graph8", "--no-live-traffic", "--no-secondary"])
     assert r["n_gpus"] == 1 and r["config"]["channels"] == 1 and r["scaling"] == "weak"
     assert r["roofline"]["kernel"] == "gr4::chain_fd_kernel<0, 13>"
     v = r["verify"]
@@ -39,7 +39,7 @@ def test_bench_single_channel_self_check():
 
 def test_bench_single_channel_line_carries_the_one_gpu_point_of_the_graph():
     """the N = 1 line also reports the 8-channel graph on this one GPU (own process, after the headline): the origin of the strong-scaling curve"""
-    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline"])
+    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline", "--no-live-traffic", "--no-secondary"])
     g8 = r["eight_channel_graph_on_one_gpu"]
     assert "error" not in g8 and g8["value"] > 0 and g8["verify"]["max_rel_err"] <= 1e-5 and r["config"]["channels"] == 1
 
@@ -93,3 +93,11 @@ def test_bench_line_has_the_median_the_prewarm_the_hann_row_and_the_secondary_co
     sc = r["secondary_configs"]  # BASELINE.json configs[2] and configs[3] beside the headline, each checked against the oracle
     for k in ("configs[2]", "configs[3]"):
         assert sc[k]["value"] > 0 and 0 < sc[k]["hbm_frac"] < 1 and sc[k]["verify_max_rel_err"] <= 1e-5, sc[k]
+    # roofline.traffic: measured live where rocprofv3 is there (two counter-only child passes), null otherwise.  At this test's small launches (2^24 samples) the per-workgroup
+    # tables (H, twiddles, taps: ~25 MB over 256 workgroups) are 11 % on top of the 201 MB of samples; at the headline's 2^30-sample launch the ratio is 1.02
+    rf = r["roofline"]
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert rf["traffic"] and 0.95 <= rf["traffic_over_algorithmic"] <= 1.20, (rf.get("traffic"), rf.get("traffic_how"))
+    else:
+        assert rf["traffic"] is None
