@@ -24,8 +24,8 @@
 // rejected beyond what white noise would lose -- and the segment is evaluated again at the end of the workgroup's run of segments (`guard`; off for the slices of long
 // filters, whose launches see partial sums) with THREE f16 terms per factor -- 33 bits, the float32 values themselves; the six products of order <= 2, each exact to 2^-33,
 // in the same float32 accumulators: float32 products at twice the first evaluation's matrix-pipe time (redo_segment; the f32 matrix pipe would take five times).  So a
-// stream whose rejected part is far above what passes costs three evaluations' worth on exactly the segments where that is so (256 taps: 166 instead of 515 Gsamples/s
-// when EVERY segment is rejected), and has float32 products there: measured 3.2e-5 .. 3.6e-5 under a tone 50 dB above the output, the f32 kernels' 3.4e-5 .. 4.0e-5, the
+// stream whose rejected part is far above what passes costs three evaluations' worth on exactly the segments where that is so (256 taps: 190 instead of 515 Gsamples/s
+// when EVERY segment is rejected -- after two rejections in a row a workgroup skips the first evaluation but for every eighth segment), and has float32 products there: measured 3.2e-5 .. 3.6e-5 under a tone 50 dB above the output, the f32 kernels' 3.4e-5 .. 4.0e-5, the
 // reference's sequential float32 sum 6.8e-5 .. 7.3e-5 (include/gr4hip.h, "PARITY CONTRACT").
 //
 // (Measured and dropped: the outputs through LDS as whole 1 KiB rows one segment later instead of 64-byte pieces straight from the accumulators -- 256 taps 499 -> 488,
@@ -359,12 +359,17 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     auto note = [&](long sg, int kind) { // 1: float32 products on the f32 pipe (the spread); 2: plain float32 sums (a non-finite sample); 3: three-term f16 products (the guard)
         if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
     };
-    // the guard's verdict on segment sg (its output powers are in ystat[sg & 1], a barrier ago): rejected -> again on the float32 path
+    // the guard's verdict on segment sg (its output powers are in ystat[sg & 1], a barrier ago): rejected -> noted for the second evaluation.  After two rejections in a row the
+    // first evaluation of the following segments is skipped (they are noted unseen) but for every eighth, which probes whether the stream has changed: a stream that is all
+    // rejection costs the second evaluation and an eighth of the first, not both
+    int  streak = 0;
     auto judge = [&](long sg, float px) {
         const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
         const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
                                                 // segment does not hide that the rest of it is all rejection
-        if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, 3);
+        const int rej = __builtin_amdgcn_readfirstlane((int)(py < gthr * px)), known = __builtin_amdgcn_readfirstlane((int)(py < __builtin_inff())); // (Inf: nothing was judged)
+        if (rej) note(sg, 3);
+        if (known) streak = rej ? streak + 1 : 0;
     };
     float s_cur, inv_cur, px_cur, px_prev = 0.f;
     int   slow_cur;
@@ -388,8 +393,9 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         const int  slow_nx = block_scale((int)((sg + 1) & 1), s_nx, inv_nx, px_nx);
         load_next(oth, seg0 + 2 * kHfSeg);
         if (guard && sg > sfirst) judge(sg - 1, px_prev);
+        const bool skip = guard && streak >= 2 && (sg & 7) != 0;
         float py = 0.f;
-        if (!slow_cur) {
+        if (!slow_cur && !skip) {
             f32x4_h c[4], d[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         } else {
 #pragma unroll
             for (int u = 0; u < NL4; ++u) put_next(plo, u, cur[u], s_nx);
-            note(sg, slow_cur);
+            note(sg, slow_cur ? slow_cur : 3);
             py = __builtin_inff(); // (nothing to judge)
         }
         if (seg0 + 256L * col >= n) py = __builtin_inff(); // (a column past the end of the span)
@@ -723,11 +729,14 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
     auto note = [&](long sg, int kind) { // 1: float32 products on the f32 pipe (the spread); 2: plain float32 sums (a non-finite sample); 3: three-term f16 products (the guard)
         if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
     };
+    int  streak = 0; // (see the float kernel)
     auto judge = [&](long sg, float px) {
         const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
         const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
                                                 // segment does not hide that the rest of it is all rejection
-        if (__builtin_amdgcn_readfirstlane((int)(py < gthr * px))) note(sg, 3);
+        const int rej = __builtin_amdgcn_readfirstlane((int)(py < gthr * px)), known = __builtin_amdgcn_readfirstlane((int)(py < __builtin_inff())); // (Inf: nothing was judged)
+        if (rej) note(sg, 3);
+        if (known) streak = rej ? streak + 1 : 0;
     };
     float s_cur, inv_cur, px_cur, px_prev = 0.f;
     int   slow_cur;
@@ -749,8 +758,9 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         const int  slow_nx = block_scale((int)((sg + 1) & 1), s_nx, inv_nx, px_nx);
         load_next(oth, seg0 + 2 * kHfSegC);
         if (guard && sg > sfirst) judge(sg - 1, px_prev);
+        const bool skip = guard && streak >= 2 && (sg & 7) != 0;
         float py = 0.f;
-        if (!slow_cur) {
+        if (!slow_cur && !skip) {
             f32x4_h c[4], d[4]; // index 2 tile + component
 #pragma unroll
             for (int j = 0; j < 4; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
@@ -813,7 +823,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         } else {
 #pragma unroll
             for (int u = 0; u < NL4; ++u) put_next(plo, u, cur[u], s_nx);
-            note(sg, slow_cur);
+            note(sg, slow_cur ? slow_cur : 3);
             py = __builtin_inff();
         }
         if (seg0 + 128L * col >= n) py = __builtin_inff(); // (a column past the end of the span)

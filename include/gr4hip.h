@@ -179,7 +179,8 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
  * matrix pipe's float32 accumulators -- float32 products at twice the matrix-pipe time): under a rejected tone 50 dB above the output the default is at 3e-5 .. 4e-5,
  * the float32 kernels' own error on that input and half the reference's sequential float32 sum's (7e-5), the products alone at 2e-4, the three-term bf16 kernel
  * (GR4HIP_FIR_TIME_DOMAIN_BF16X3: no guard) at 5e-5 .. 1e-4.  gr4hip_fir_set_guard_mode(GR4HIP_GUARD_OFF) switches the verdict off; the 256-tap slices of longer
- * float filters run without it (their launches see partial sums).  A stream in which every segment is rejected runs both evaluations: 166 (256 taps) .. 325 (64 taps) Gsamples/s. */
+ * float filters run without it (their launches see partial sums).  After two rejections in a row a workgroup skips the first evaluation of the segments that follow but for every eighth (a probe): a stream in which every segment is rejected runs at
+ * 190 (256 taps) .. 376 (64 taps) Gsamples/s. */
 /* GR4HIP_FIR_TIME_DOMAIN_BF16X3: the three-term bf16 products of rounds 2-3 (six products per tap, everything above 2^-23 of a product, float32's exponent range
  * without a block exponent, no guard) where the default takes the f16 kernels; for complex data also "direct form" like GR4HIP_FIR_TIME_DOMAIN. */
 /* GR4HIP_FIR_EXACT_F32: every product and sum in IEEE float32 (no frequency-domain kernels, no bf16 splits): the kernels whose arithmetic is the reference's
