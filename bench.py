@@ -170,6 +170,8 @@ def live_traffic(kernel_symbol, log2_samples, log2_chunk):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ):
+        return None, "this run is itself being profiled: no counter passes nested inside a trace"
     match = kernel_symbol.split("gr4::")[-1].split("<")[0] + "<" + kernel_symbol.split("<")[-1].split(",")[0]  # chain_fd_kernel<0 (the Hann row's instantiation is <1, ...>)
     kib = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
