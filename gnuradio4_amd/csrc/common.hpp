@@ -30,6 +30,7 @@ enum DevSwitch {
     kDevFftSmoothRuntime,     // GR4HIP_FFT_SMOOTH_RUNTIME: the run-time mixed-radix kernel also for sizes that have a compile-time plan
     kDevEwiseNoDivRcp,        // GR4HIP_EWISE_NO_DIV_RCP: element-wise programs divide by a float constant with the general quotient (the tests compare it with the reciprocal form)
     kDevFirNoF16x2,           // GR4HIP_FIR_NO_F16X2: the three-term bf16 FIR kernels where the default takes the two-term f16 ones (per handle: GR4HIP_FIR_TIME_DOMAIN_BF16X3)
+    kDevFirNoDecimF16,        // GR4HIP_FIR_NO_DECIM_F16: the frequency-domain decimate-by-8 kernel where the default takes the f16 band-form one (fir_decim_f16.hip)
     kDevSwitchCount
 };
 int dev_switch(DevSwitch s);

@@ -234,6 +234,8 @@ void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
+bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab); // fir_decim_f16.hip
+int  fir_decim_f16_launch(int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard);
 int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard);
 int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
@@ -285,6 +287,8 @@ struct gr4hip_fir {
     int                bfKS = 0;
     DeviceBuffer       d_hfrag;       // float, 33 .. 256 taps and the 256-tap slices of 384 .. 1024: the two-term f16 tables of fir_mfma_f16x2_kernel (fir_f16.hip; built on first use)
     int                hfKS = 0;      // < 0: taps that form cannot carry
+    DeviceBuffer       d_dhtab;       // float, decimate by 8, 169 .. 1025 taps: the table of fir_decim8_f16x2_kernel (fir_decim_f16.hip; built on first use)
+    int                dhKQ = 0;      // < 0: a shape that kernel does not carry
     std::vector<size_t> hf_off;       // per slice: offset into d_hfrag (in 16-bit units) ...
     std::vector<int>    hf_ks;        // ... and window size
     DeviceBuffer       d_bdfrag;      // float, decim 2 .. 9, short branches: band-form bf16 fragments (fir_decim_bf16x3_kernel)
@@ -361,6 +365,7 @@ static void fir_invalidate_tables(gr4hip_fir* f) {
     f->bandKp = 0;
     f->bfKS = 0;
     f->hfKS = 0;
+    f->dhKQ = 0;
     f->bdKS = 0;
 }
 // `taps` = gain x `user_taps` (float64 product, rounded once), uploaded
@@ -779,6 +784,28 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         if (rc) return rc;
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
+    }
+    // float, decimate by 8, 169 .. 1025 taps (BASELINE configs[2]), long 16-byte-aligned span: the band form on the f16 matrix pipe, two-term splits under a per-segment block
+    // exponent, the K-steps split over the four waves, every segment judged and the rejected ones evaluated again with float32 products inside the launch (fir_decim_f16.hip)
+    // -- its error is relative to the output, so it needs no host-side guard and the call stays asynchronous
+    if (done == 0 && f->S == 1 && f->decim == 8 && f->ntaps > 168 && f->ntaps <= 1025 && n_in >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+        algo == GR4HIP_FIR_AUTO && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && !dev_switch(kDevFirNoDecimF16) && f->dhKQ >= 0 && plain) {
+        int rc = GR4HIP_OK;
+        if (f->dhKQ == 0) {
+            std::vector<unsigned short> tab;
+            if (!fir_decim_f16_make_table(f->taps.data(), f->ntaps, f->decim, &f->dhKQ, &tab)) f->dhKQ = -1;
+            else {
+                rc = f->d_dhtab.ensure(tab.size() * sizeof(unsigned short));
+                if (!rc) { hipError_t e = hipMemcpy(f->d_dhtab.ptr, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (rc) { f->dhKQ = 0; return rc; }
+            }
+        }
+        if (f->dhKQ > 0) {
+            rc = fir_decim_f16_launch(f->dhKQ, x, (long)n_in, hist, (int)f->hcap, f->d_dhtab.ptr, y, (long)n_out, st, (float*)f->d_hist[f->cur ^ 1].ptr, f->guard_mode != GR4HIP_GUARD_OFF);
+            if (rc) return rc;
+            done = n_in;
+            mfma_wrote_hist = true;
+        }
     }
     // float, decimate by 2 .. 12 with a window of <= 1152 samples (taps - 1 + 15 D), long 16-byte-aligned span: the band form with three-term bf16 products
     // (fir_bf16.hip; windows beyond 288 samples with the K-steps split over the four waves)

@@ -1,0 +1,362 @@
+// fir_decim_f16.hip -- BasicDecimatingFilter<float>, decimate by 8, up to 1025 taps (BASELINE configs[2]), on the f16 matrix pipe: the band form of the contraction
+//
+//     y[m] = sum_k b[k] x[8 m - k]:   D[j][c] = sum_u A[j][u] B[u][c],   A[j][u] = b[Hb + 8 j - u],   B[u][c] = staged[base(tile) + u],   u < 128 KQ
+//
+// (samples in stream order, the decimation in the tap operand: a tile of 16 outputs sees a window of Hb + 121 <= 128 KQ samples, the next tile starts 128 samples on) with
+// fir_f16.hip's arithmetic -- samples and taps as two f16 terms under a per-segment block exponent, three products per tap -- and its safeguards: every segment's statistics
+// (largest magnitude, quietest group of four, power) decide its block scale and whether it is given to the f16 pipe at all, every segment's output power is judged against
+// its input power, and a rejected segment is evaluated again with three-term f16 products (float32 products) at the end of the workgroup's run.
+//
+// What the bf16 split-K kernel of fir_bf16.hip paid for (305 G input samples/s at 1024 taps): six products, three planes, two tiles per segment.  Here the K-steps are split
+// over the four waves of a workgroup as there -- a wave keeps the tap fragments of its quarter (KQ K-steps: 72 registers at KQ = 9) -- but a segment is 1024 outputs
+// = 64 tiles (16 columns of 64 outputs, four tile rows), a wave runs its K quarter for ALL four tile rows, and because tile rows sit exactly four K-steps apart it walks ONE
+// sample-fragment stream of KQ + 12 fragments for the 4 KQ K-steps it evaluates (a third of the LDS operand reads).  The four partial tiles meet in LDS; thread (w', lane)
+// sums tile row w' and takes it out.  108 f16 MFMAs per wave and 8192 input samples: half the matrix-pipe work per input sample of the 256-tap FIR of fir_f16.hip.
+#include "common.hpp"
+#include "buffer_ops.hpp"
+#include "fir_f16_common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace gr4 {
+
+constexpr int kDhSegOut = 1024, kDhD = 8, kDhSegIn = kDhSegOut * kDhD, kDhMaxSpw = 64;
+
+// the table fir_decim_f16_make_table writes, in 16-bit units: [4 waves][3 planes][KQ][64 lanes][8] f16 fragments, 8 units of header {float 1 / t, int ntaps, float guard
+// threshold, -}, 1040 float taps
+__host__ __device__ constexpr int dh_frag_units(int KQ) { return 4 * 3 * KQ * 512; }
+__host__ __device__ constexpr int dh_table_units(int KQ) { return dh_frag_units(KQ) + 8 + 2 * 1040; }
+
+// the matrix-pipe evaluation of a staged segment with NT terms per factor (2: three products; 3: the six products of order <= 2 = float32 products): this wave's K quarter
+// for the four tile rows, its partial tiles to `part`
+template <int KQ, int NT, int PL>
+__device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const unsigned short* __restrict__ pls, float (*__restrict__ part)[4][64][4], int wave, int lane) {
+    constexpr int NM = KQ + 12;
+    const int col = lane & 15, kq = lane >> 4;
+    auto      P   = [](int s_) { return s_ + 8 * (s_ >> 9); };
+    f32x4_h   c[4], d[4], g[NT == 3 ? 4 : 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NT == 3)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+    const int sb = 512 * col + 32 * KQ * wave + 8 * kq;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int     qo = P(sb + 32 * m);
+        const f16x8_h b1 = *reinterpret_cast<const f16x8_h*>(pls + qo), b2 = *reinterpret_cast<const f16x8_h*>(pls + PL + qo);
+        f16x8_h       b3 = b1;
+        if constexpr (NT == 3) b3 = *reinterpret_cast<const f16x8_h*>(pls + 2 * PL + qo);
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr) {
+            const int ks = m - 4 * tr;
+            if (ks < 0 || ks >= KQ) continue;
+            const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a[1][ks]);
+            c[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[tr], 0, 0, 0);
+            d[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, d[tr], 0, 0, 0);
+            d[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, d[tr], 0, 0, 0);
+            if constexpr (NT == 3) {
+                const f16x8_h a3 = __builtin_bit_cast(f16x8_h, a[2][ks]);
+                g[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b3, g[tr], 0, 0, 0);
+                g[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, g[tr], 0, 0, 0);
+                g[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3, b1, g[tr], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int tr = 0; tr < 4; ++tr) {
+        float4 w;
+        if constexpr (NT == 3)
+            w = make_float4(c[tr][0] + (d[tr][0] + g[tr][0] * (1.f / 2048.f)) * (1.f / 2048.f), c[tr][1] + (d[tr][1] + g[tr][1] * (1.f / 2048.f)) * (1.f / 2048.f),
+                            c[tr][2] + (d[tr][2] + g[tr][2] * (1.f / 2048.f)) * (1.f / 2048.f), c[tr][3] + (d[tr][3] + g[tr][3] * (1.f / 2048.f)) * (1.f / 2048.f));
+        else
+            w = make_float4(c[tr][0] + d[tr][0] * (1.f / 2048.f), c[tr][1] + d[tr][1] * (1.f / 2048.f), c[tr][2] + d[tr][2] * (1.f / 2048.f), c[tr][3] + d[tr][3] * (1.f / 2048.f));
+        *reinterpret_cast<float4*>(&part[wave][tr][lane][0]) = w;
+    }
+}
+
+template <int KQ> // K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 128 samples in front of a tile's first output
+__global__ __launch_bounds__(256, 2) void fir_decim8_f16x2_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh,
+                                                                  const unsigned short* __restrict__ tab, float* __restrict__ y, long n_out, long n_in,
+                                                                  float* __restrict__ new_hist, int guard, int seg_per_wg /*<= kDhMaxSpw*/) {
+    constexpr int Hb = 128 * KQ - 128, NS = kDhSegIn + Hb; // staged samples per segment (a multiple of 128)
+    constexpr int PL  = NS + 8 * (NS / 512 + 1) + 16;      // f16 elements per plane: one 16-byte chunk of padding per 512 samples (the 16 columns of a fragment read are 512 samples apart)
+    constexpr int NL4 = (NS / 4 + 255) / 256;              // float4 loads a lane holds for the next segment
+    constexpr int NM  = KQ + 12;                           // fragments of a wave's stream
+    const u32x4_h* afrag = reinterpret_cast<const u32x4_h*>(tab);
+    const float    inv_t = *reinterpret_cast<const float*>(tab + dh_frag_units(KQ));
+    const int      ntaps = *reinterpret_cast<const int*>(tab + dh_frag_units(KQ) + 2);
+    const float    gthr  = *reinterpret_cast<const float*>(tab + dh_frag_units(KQ) + 4);
+    const float*   tapsf = reinterpret_cast<const float*>(tab + dh_frag_units(KQ) + 8);
+    extern __shared__ __attribute__((aligned(16))) unsigned short pls[]; // [3][PL]: planes x1, x2 (x3: the second evaluation)
+    __shared__ __attribute__((aligned(16))) float          part[4][4][64][4]; // [K quarter = wave][tile row][lane][row within the lane's four]
+    __shared__ __attribute__((aligned(16))) unsigned       stat[12];
+    __shared__ __attribute__((aligned(16))) float          ystat[4][16]; // the four tile rows' output powers per column of 64 outputs
+    __shared__ unsigned char                               noted[kDhMaxSpw];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    auto P = [](int s_) { return s_ + 8 * (s_ >> 9); };
+
+    auto xs = [&](long i) __attribute__((always_inline)) -> float { return i >= 0 ? (i < n_in ? x[i] : 0.f) : (i >= -(long)Kh ? hist[Kh + i] : 0.f); };
+    float4 nxt[NL4];
+    auto   load_next = [&](long sg) __attribute__((always_inline)) { // sg >= 1: nothing below 0
+        const long   i0   = sg * kDhSegIn - Hb;
+        const long   nrec = n_in - i0 < (long)NS ? n_in - i0 : (long)NS;
+        const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto load_general = [&](long sg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int q = tid + 256 * u;
+            const long i0 = sg * kDhSegIn - Hb + 4L * q;
+            nxt[u] = q < NS / 4 ? make_float4(xs(i0), xs(i0 + 1), xs(i0 + 2), xs(i0 + 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto load_seg = [&](long sg) __attribute__((always_inline)) {
+        if (sg > 0) load_next(sg);
+        else load_general(0);
+    };
+    auto put_stats = [&]() __attribute__((always_inline)) {
+        float    mf = 0.f, px = 0.f;
+        unsigned mn = 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nxt[u].x), __builtin_fabsf(nxt[u].y)), __builtin_fmaxf(__builtin_fabsf(nxt[u].z), __builtin_fabsf(nxt[u].w)));
+            mf = __builtin_fmaxf(mf, m4);
+            mn = min(mn, __float_as_uint(m4) - 1u);
+            px = fmaf(nxt[u].x, nxt[u].x, fmaf(nxt[u].y, nxt[u].y, fmaf(nxt[u].z, nxt[u].z, fmaf(nxt[u].w, nxt[u].w, px))));
+        }
+        unsigned mx = __float_as_uint(mf);
+        mx = hf_wave_reduce_u32(mx, [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
+        mn = hf_wave_reduce_u32(mn, [](unsigned a_, unsigned b_) { return a_ < b_ ? a_ : b_; });
+        px = hf_wave_sum(px);
+        if (lane == 0) { stat[wave] = mx; stat[4 + wave] = mn; stat[8 + wave] = __float_as_uint(px); }
+    };
+    auto block_scale = [&](float& s, float& inv_s, float& px) __attribute__((always_inline)) -> int { // 0: the f16 pipe; 1: the spread; 2: a non-finite sample
+        const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[0]), n4 = *reinterpret_cast<const uint4*>(&stat[4]), p4 = *reinterpret_cast<const uint4*>(&stat[8]);
+        px = (__uint_as_float(p4.x) + __uint_as_float(p4.y)) + (__uint_as_float(p4.z) + __uint_as_float(p4.w));
+        const unsigned mx = __builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))), mn = __builtin_amdgcn_readfirstlane(min(min(n4.x, n4.y), min(n4.z, n4.w)));
+        const int e = (int)(mx >> 23), el = (int)(mn >> 23);
+        const int slow = (e == 255 || px != px) ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0);
+        const int ec = e < 15 ? 15 : (e > 254 ? 254 : e);
+        s     = __uint_as_float((unsigned)(268 - ec) << 23);
+        inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
+        return slow;
+    };
+    // thread (w', lane) takes tile row w' out: the four K quarters' partial tiles summed in a fixed order, the block scales off, y[seg + 64 col + 16 w' + 4 kq + r]
+    auto take_out = [&](long sg, float k, float& py) __attribute__((always_inline)) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((part[0][wave][lane][r] + part[1][wave][lane][r]) + (part[2][wave][lane][r] + part[3][wave][lane][r])) * k;
+        const long o = sg * kDhSegOut + 64L * col + 16 * wave + 4 * kq;
+        if (o + 3 < n_out) {
+            *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            py = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], py))));
+        } else {
+            for (int r = 0; r < 4; ++r)
+                if (o + r < n_out) { y[o + r] = v[r]; py = fmaf(v[r], v[r], py); }
+        }
+    };
+    // plain float32 sums from global memory, one output at a time: a segment with a non-finite sample (the reference's classes on exactly its outputs) or with a spread
+    // beyond the block exponent's reach.  Very slow; such samples are not ordinary data.
+    auto exact_segment = [&](long sg) __attribute__((always_inline)) {
+        for (int r = 0; r < kDhSegOut / 256; ++r) {
+            const long m = sg * kDhSegOut + tid + 256 * r;
+            if (m >= n_out) break;
+            float acc = 0.f;
+            for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs(8 * m - k), acc);
+            y[m] = acc;
+        }
+    };
+    // the matrix-pipe evaluation of the staged segment with NT terms per factor (2: three products; 3: the six products of order <= 2 = float32 products)
+    u32x4_h a[3][KQ]; // this wave's quarter of the tap fragments: planes 0, 1 from the start, plane 2 for the second evaluation
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks) a[p][ks] = afrag[((wave * 3 + p) * KQ + ks) * 64 + lane];
+    // the guard (fir_f16.hip): sixteen times the power of the QUIETEST of the segment's sixteen output columns, at the input rate, against 2^-12 (sum b^2) x the input power
+    auto rejected = [&](float px) __attribute__((always_inline)) -> bool {
+        const float pc = (ystat[0][col] + ystat[1][col]) + (ystat[2][col] + ystat[3][col]);
+        return __builtin_amdgcn_readfirstlane((int)(16.f * hf_row_min(pc) * (float)kDhD < gthr * px)) != 0;
+    };
+    const long nseg = (n_out + kDhSegOut - 1) / kDhSegOut, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
+    if (sfirst >= slast) return;
+    if (tid < kDhMaxSpw) noted[tid] = 0;
+    {
+        load_seg(sfirst);
+        float px_prev = 0.f;
+        int   kind_prev = -1; // (nothing to judge yet)
+        for (long sg = sfirst; sg < slast; ++sg) {
+            put_stats();
+            __syncthreads(); // the statistics are complete; every wave is done with the planes, the partial tiles and the verdict words of the segment before
+            float     s, inv_s, px;
+            const int kind = block_scale(s, inv_s, px);
+            if (guard && kind_prev == 0 && rejected(px_prev) && tid == 0) noted[sg - 1 - sfirst] = 3; // the verdict on the segment before (its output powers: a barrier ago)
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) {
+                const int q = tid + 256 * u;
+                if (256 * (u + 1) <= NS / 4 || q < NS / 4) {
+                    unsigned h0, l0, h1, l1;
+                    hf_split2(nxt[u].x, nxt[u].y, s, h0, l0);
+                    hf_split2(nxt[u].z, nxt[u].w, s, h1, l1);
+                    *reinterpret_cast<uint2*>(pls + P(4 * q))      = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(pls + PL + P(4 * q)) = make_uint2(l0, l1);
+                }
+            }
+            if (sg + 1 < slast) load_next(sg + 1);
+            __syncthreads();
+            if (kind == 0) dh_contract<KQ, 2, PL>(a, pls, part, wave, lane);
+            else if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
+            __syncthreads();
+            float py = 0.f;
+            if (kind == 0) take_out(sg, inv_t * inv_s, py);
+            if (kind != 0 || sg * kDhSegOut + 64L * col >= n_out) py = __builtin_inff(); // (nothing to judge; a column past the end of the span)
+            py = hf_column_sum(py);
+            if (lane < 16) ystat[wave][lane] = py;
+            px_prev   = px;
+            kind_prev = kind;
+        }
+        __syncthreads();
+        if (guard && kind_prev == 0 && rejected(px_prev) && tid == 0) noted[slast - 1 - sfirst] = 3;
+    }
+    __syncthreads();
+    bool any3 = false;
+    for (int i = 0; i < seg_per_wg; ++i) any3 |= noted[i] == 3;
+    if (any3) { // the second evaluation of the segments the guard rejected: three f16 terms per factor, the six products of order <= 2 (float32 products)
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks) a[2][ks] = afrag[((wave * 3 + 2) * KQ + ks) * 64 + lane];
+        __builtin_amdgcn_s_waitcnt(0); // this wave's stores of the first evaluation have landed (and everybody's, behind the next barrier) before other lanes write the same outputs
+        for (int i = 0; i < seg_per_wg; ++i) {
+            if (noted[i] != 3) continue;
+            const long sg = sfirst + i;
+            load_seg(sg);
+            float mf = 0.f;
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fmaxf(__builtin_fabsf(nxt[u].x), __builtin_fabsf(nxt[u].y))), __builtin_fmaxf(__builtin_fabsf(nxt[u].z), __builtin_fabsf(nxt[u].w)));
+            const unsigned mw = hf_wave_reduce_u32(__float_as_uint(mf), [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
+            if (lane == 0) stat[wave] = mw;
+            __syncthreads();
+            const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[0]);
+            const int   e  = (int)(__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))) >> 23), ec = e < 15 ? 15 : (e > 254 ? 254 : e);
+            const float s = __uint_as_float((unsigned)(268 - ec) << 23), inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) {
+                const int q = tid + 256 * u;
+                if (256 * (u + 1) <= NS / 4 || q < NS / 4) {
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    hf_split2x3(nxt[u].x, nxt[u].y, s, h0, m0, l0);
+                    hf_split2x3(nxt[u].z, nxt[u].w, s, h1, m1, l1);
+                    *reinterpret_cast<uint2*>(pls + P(4 * q))          = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(pls + PL + P(4 * q))     = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(pls + 2 * PL + P(4 * q)) = make_uint2(l0, l1);
+                }
+            }
+            __syncthreads();
+            dh_contract<KQ, 3, PL>(a, pls, part, wave, lane);
+            __syncthreads();
+            float py = 0.f;
+            take_out(sg, inv_t * inv_s, py);
+            __syncthreads();
+        }
+    }
+    for (int i = 0; i < seg_per_wg; ++i)
+        if (noted[i] == 1 || noted[i] == 2) exact_segment(sfirst + i);
+    if (new_hist != nullptr && blockIdx.x == 0) {
+        for (int h = tid; h < Kh; h += 256) {
+            const long i = n_in - Kh + h;
+            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
+        }
+    }
+}
+
+// the table of fir_decim8_f16x2_kernel<KQ> (see dh_table_units): fragment (wave w, plane p, K-step ks, lane l, element t) = tap-plane value
+// b_p[Hb + 8 (l & 15) - (32 (KQ w + ks) + 8 (l >> 4) + t)]; planes as fir_f16_make_afrag's.  false: taps or a shape this kernel does not carry
+bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab) {
+    if (D != (size_t)kDhD || ntaps < 2 || ntaps > 1025) return false;
+    int KQ = 0;
+    for (int k : {3, 5, 7, 9})
+        if ((size_t)(128 * k - 127) >= ntaps) { KQ = k; break; }
+    if (!KQ) return false;
+    const int Hb = 128 * KQ - 128;
+    unsigned  mx = 0;
+    for (size_t k = 0; k < ntaps; ++k) {
+        unsigned u;
+        std::memcpy(&u, &taps[k], 4);
+        mx = std::max(mx, u & 0x7fffffffu);
+    }
+    if (mx >= 0x7f800000u) return false;
+    const int      e  = std::min(std::max((int)(mx >> 23), 15), 254);
+    const unsigned tb = (unsigned)(268 - e) << 23, ib = (unsigned)(e - 14) << 23;
+    float          t, inv_t;
+    std::memcpy(&t, &tb, 4);
+    std::memcpy(&inv_t, &ib, 4);
+    std::vector<unsigned short> pl[3];
+    for (auto& v : pl) v.assign(ntaps, 0);
+    double h2 = 0;
+    for (size_t k = 0; k < ntaps; ++k) {
+        const float          b  = taps[k] * t;
+        const unsigned short h  = host_f16_rne(b);
+        const float          r1 = (b - host_f16_to_f(h)) * 2048.f;
+        const unsigned short m  = host_f16_rne(r1);
+        pl[0][k] = h;
+        pl[1][k] = m;
+        pl[2][k] = host_f16_rne((r1 - host_f16_to_f(m)) * 2048.f);
+        h2 += (double)taps[k] * taps[k];
+    }
+    tab->assign((size_t)dh_table_units(KQ), 0);
+    for (int w = 0; w < 4; ++w)
+        for (int p = 0; p < 3; ++p)
+            for (int ks = 0; ks < KQ; ++ks)
+                for (int l = 0; l < 64; ++l)
+                    for (int tt = 0; tt < 8; ++tt) {
+                        const long k = (long)Hb + 8 * (l & 15) - (32 * (KQ * w + ks) + 8 * (l >> 4) + tt);
+                        if (k >= 0 && (size_t)k < ntaps) (*tab)[((((size_t)w * 3 + p) * KQ + ks) * 64 + l) * 8 + tt] = pl[p][(size_t)k];
+                    }
+    unsigned short* hd   = tab->data() + dh_frag_units(KQ);
+    const int       nt   = (int)ntaps;
+    const float     gthr = (float)(h2 / 4096.0); // P_y D < 2^-12 (sum b^2) P_x: 36 dB more rejected than white noise would lose (fir_f16.hip)
+    std::memcpy(hd, &inv_t, 4);
+    std::memcpy(hd + 2, &nt, 4);
+    std::memcpy(hd + 4, &gthr, 4);
+    std::memcpy(hd + 8, taps, ntaps * sizeof(float));
+    *KQ_out = KQ;
+    return true;
+}
+
+// y[m] = sum_k b[k] x[8 m - k], m < n_out = n_in / 8; hist[h] = x[-Kh + h]; x and y 16-byte aligned
+int fir_decim_f16_launch(int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard) {
+    const auto tb = static_cast<const unsigned short*>(table);
+    static const int kSpwEnv = [] { const char* e = std::getenv("GR4HIP_DH_SPW"); return e ? std::atoi(e) : 0; }(); // developer knob
+    static const int kWgsEnv = [] { const char* e = std::getenv("GR4HIP_DH_WGS"); return e ? std::atoi(e) : 0; }();
+    const long nseg = ceil_div(n_out, (long)kDhSegOut);
+    const int  spw  = kSpwEnv ? kSpwEnv : (int)std::min<long>(std::max<long>(nseg / (kWgsEnv ? kWgsEnv : 512), 4), 32); // segments per workgroup: the tap fragments and the first staging once per run (2^27 inputs: 4 / 8 / 16 / 32 / 64 segments measured 739 / 758 / 777 / 788 / 520 G at 1024 taps)
+    const dim3 grid((unsigned)ceil_div(nseg, (long)spw));
+#define GR4_DH_CASE(K)                                                                                                                                                   \
+    case K: {                                                                                                                                                            \
+        constexpr int    NS  = kDhSegIn + 128 * K - 128;                                                                                                                  \
+        constexpr size_t lds = (size_t)3 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                      \
+        static bool      set = false; /* (idempotent: a race sets it twice) */                                                                                            \
+        if (!set) { GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim8_f16x2_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; } \
+        hipLaunchKernelGGL(fir_decim8_f16x2_kernel<K>, grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw);                                   \
+    } break
+    switch (KQ) {
+        GR4_DH_CASE(3);
+        GR4_DH_CASE(5);
+        GR4_DH_CASE(7);
+        GR4_DH_CASE(9);
+    default: return GR4HIP_UNSUPPORTED;
+    }
+#undef GR4_DH_CASE
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+} // namespace gr4

@@ -405,6 +405,62 @@ def test_fir_complex_decimating_long_input_matrix_pipe(G, decim, ntaps):
     assert y.shape == truth.shape and _rel(y, truth) <= TOL
 
 
+@pytest.mark.parametrize("ntaps", [169, 257, 258, 513, 514, 769, 770, 1024, 1025])
+def test_fir_decimate_by_8_f16_band_kernel(G, ntaps, devsw):
+    """BasicDecimatingFilter<float>, decimate by 8, 169 .. 1025 taps, long aligned spans -- the default since late round 4: the band form on the f16 matrix pipe
+    (fir_decim_f16.hip; the window sizes 3 / 5 / 7 / 9 K-steps per wave at their edges).  The float64 oracle's bar across ragged calls and at any level of the stream
+    (the per-segment block exponent); a glitch of 1e30 and an Inf among ordinary samples (such segments are evaluated as float32 sums: the reference's classes on exactly
+    the outputs whose window holds the sample, every other output at its own level); a rejected tone 50 dB above the output: judged per segment and evaluated again with
+    three-term f16 products -- the error of the float32 polyphase kernels, where the two-term products alone (guard off) are several times above it"""
+    rng = np.random.default_rng(ntaps)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 8 * 60_000
+    cuts = [0, 8 * 20_001, 8 * 20_001 + 8 * 17_000, n]
+    x = O.signal_f32(31, n)
+
+    def run(xx, taps=b, guard=None):
+        f = G.fir_filter(taps, torch.float32, decimate=8)
+        if guard is not None:
+            f.set_guard_mode(guard)
+        return np.concatenate([f.process_bulk(dev(xx[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    truth, _ = O.fir_decim(b, x, 8)
+    y = run(x)
+    assert y.shape == truth.shape and _rel(y, truth) <= TOL
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 1)
+    assert not np.array_equal(y, run(x))  # (another kernel without it)
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
+    for scale in (1e-30, 1e30):
+        xs_ = (x.astype(np.float64) * scale).astype(np.float32)
+        ts, _ = O.fir_decim(b, xs_, 8)
+        assert _rel(run(xs_), ts) <= TOL
+    # outliers and a non-finite sample
+    xo = x.copy()
+    xo[100_003], xo[300_005] = 1e30, np.inf
+    to, _ = O.fir_decim(b, xo, 8)
+    with np.errstate(over="ignore", invalid="ignore"):
+        t32 = to.astype(np.float32)
+    yo = run(xo)
+    assert np.array_equal(np.isnan(yo), np.isnan(t32)) and np.array_equal(np.isposinf(yo), np.isposinf(t32)) and np.array_equal(np.isneginf(yo), np.isneginf(t32))
+    ok = np.isfinite(t32)
+    near = np.zeros(len(to), bool)
+    near[100_003 // 8: (100_003 + ntaps) // 8 + 1] = True
+    rms = float(np.sqrt(np.mean(truth ** 2)))
+    assert float(np.max(np.abs(yo[ok & ~near] - to[ok & ~near]) / np.maximum(np.abs(to[ok & ~near]), rms))) <= TOL
+    assert float(np.max(np.abs(yo[ok & near] - to[ok & near]) / np.maximum(np.abs(to[ok & near]), 1e-3 * np.abs(to[ok & near]).max()))) <= TOL
+    # a rejected tone 50 dB above the noise through an anti-alias low-pass
+    bl = O.design_taps_hamming_lowpass(ntaps, 0.05)
+    xi = (O.signal_f32(7, n, tone_amp=0.0) * 0.05 + 316.0 * np.cos(2 * np.pi * 0.31 * np.arange(n))).astype(np.float32)
+    ti, _ = O.fir_decim(bl, xi, 8)
+    sl = slice(ntaps, None)
+    e_def, e_off = _rel(run(xi, bl)[sl], ti[sl]), _rel(run(xi, bl, G.capi.GUARD_OFF)[sl], ti[sl])
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 1)
+    devsw("GR4HIP_FIR_NO_DECIM_FD", 1)
+    e_poly = _rel(run(xi, bl)[sl], ti[sl])  # the float32 polyphase kernels
+    devsw("GR4HIP_FIR_NO_DECIM_FD", 0)
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
+    assert e_off > 1.5 * e_def and e_def <= 2.0 * e_poly + 1e-6, (e_def, e_off, e_poly)
+
+
 @pytest.mark.parametrize("ntaps", [1024, 1000, 513, 129, 8, 1])
 def test_fir_decimate_by_8_frequency_domain(G, ntaps, devsw):
     """BASELINE configs[2]'s filter: decimate by 8, <= 1024 taps, spans of >= 64 blocks of 7168 samples take the overlap-save kernel (csrc/fir_decim_fd.hip:
@@ -416,15 +472,22 @@ def test_fir_decimate_by_8_frequency_domain(G, ntaps, devsw):
     cuts = [0, 64 * blk + 8 * 37, 64 * blk + 8 * 37 + 8 * 5, 2 * (64 * blk) + 8 * 100, 2 * (64 * blk) + 8 * 100 + 70 * blk]
     x = O.signal_f32(31, cuts[-1])
     truth, _ = O.fir_decim(b, x, 8)
-    f = G.fir_filter(b, torch.float32, decimate=8)
-    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    def run():
+        f = G.fir_filter(b, torch.float32, decimate=8)
+        return np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    y16 = run()  # the default since late round 4: 169 .. 1025 taps on the f16 band-form kernel (fir_decim_f16.hip), the rest as below
+    assert y16.shape == truth.shape and _rel(y16, truth) <= TOL
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 1)  # the frequency-domain kernel
+    y = run()
     assert y.shape == truth.shape and _rel(y, truth) <= TOL
+    assert (ntaps <= 168) == np.array_equal(y, y16)  # (two different kernels did run where the f16 one applies)
     devsw("GR4HIP_FIR_NO_DECIM_FD", 1)  # developer switch: the polyphase (MFMA / VALU) kernels on the same stream
-    f2 = G.fir_filter(b, torch.float32, decimate=8)
-    y2 = np.concatenate([f2.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    y2 = run()
     devsw("GR4HIP_FIR_NO_DECIM_FD", 0)
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
     assert _rel(y2, truth) <= TOL
     assert _rel(y, truth) <= _rel(y2, truth) + 2e-6  # as accurate as the direct form, to 1/5 of the tolerance
+    assert _rel(y16, truth) <= _rel(y2, truth) + 2e-6
 
 
 @pytest.mark.parametrize("kind", ["float", "complex", "decim"])
@@ -1474,14 +1537,20 @@ def test_fir_decimate_by_8_dynamic_range_guard(G, devsw):
         f = G.fir_filter(b, torch.float32, decimate=D)
         y = f.process_bulk(dev(x)).cpu().numpy()
         assert _rel(y, truth) <= TOL, name
+        # (late round 4: the default above is the f16 band-form kernel of fir_decim_f16.hip, whose error is relative to the output and which judges its own segments;
+        # the frequency-domain kernel and its host-side guard stay behind GR4HIP_FIR_NO_DECIM_F16 -- and are what the rest of this test is about)
+        devsw("GR4HIP_FIR_NO_DECIM_F16", 1)
+        f1 = G.fir_filter(b, torch.float32, decimate=D)
+        assert _rel(f1.process_bulk(dev(x)).cpu().numpy(), truth) <= TOL, name
         # what the guard is for: the same span forced through the frequency-domain kernel
         f2 = G.fir_filter(b, torch.float32, decimate=D)
         G.capi.check(G.capi.lib().gr4hip_fir_set_guard_mode(f2._h, G.capi.GUARD_OFF), "guard off")
         e_fd = _rel(f2.process_bulk(dev(x)).cpu().numpy(), truth)
+        devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
         assert (e_fd > TOL) == expect_switch, (name, e_fd)
 
 
-def test_guard_sees_every_frame_and_block(G):
+def test_guard_sees_every_frame_and_block(G, devsw):
     """an interferer that sets in near the END of a long call -- where one workgroup has long left its first frame behind -- or only for a few frames is seen:
     the kernels judge every frame / block by itself (workgroup-wide sums of output - threshold x input power), not a sample of them, and not the launch's totals,
     which such a short event barely moves.  Strict guard: the span is redone before the call returns, every output inside the bar."""
@@ -1507,10 +1576,13 @@ def test_guard_sees_every_frame_and_block(G):
     xq = O.signal_f32(41, n, tone_frel=0.01, tone_amp=1.0, noise_amp=0.05)
     xq[-3 * 7168:] += (100.0 * np.cos(2 * np.pi * 0.31 * np.arange(3 * 7168))).astype(np.float32)
     truth, _ = O.fir_decim(bd, xq, D)
+    assert _rel(G.fir_filter(bd, torch.float32, decimate=D).process_bulk(dev(xq)).cpu().numpy(), truth) <= TOL  # (the default: the f16 band-form kernel)
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 1)
     assert _rel(G.fir_filter(bd, torch.float32, decimate=D).process_bulk(dev(xq)).cpu().numpy(), truth) <= TOL
     f2 = G.fir_filter(bd, torch.float32, decimate=D)
     G.capi.check(G.capi.lib().gr4hip_fir_set_guard_mode(f2._h, G.capi.GUARD_OFF), "guard off")
     assert _rel(f2.process_bulk(dev(xq)).cpu().numpy(), truth) > TOL  # (what the guard was for)
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
 
 
 def test_guard_destination_multiplies_in_float32(G):
@@ -1902,8 +1974,11 @@ def test_configs2_full_size_properties(G):
     assert float((yo - yo2).abs().max()) <= 2e-5 * float(yo.double().pow(2).mean().sqrt()), float((yo - yo2).abs().max()) / float(yo.double().pow(2).mean().sqrt())
     del yd2, yo2
     fir.reset(); iir.reset()
-    y3 = iir.process_bulk(fir.process_bulk(-4 * x))  # linearity of the pair (a power of two: every product and sum scales exactly)
-    assert float((y3 + 4 * yo).abs().max()) <= 1e-6 * float((4 * yo).double().pow(2).mean().sqrt())
+    y3 = iir.process_bulk(fir.process_bulk(4 * x))  # linearity of the pair (a power of two: every product and sum scales exactly -- the f16 decimator's block exponent moves with it)
+    assert float((y3 - 4 * yo).abs().max()) <= 1e-6 * float((4 * yo).double().pow(2).mean().sqrt())
+    fir.reset(); iir.reset()
+    y3 = iir.process_bulk(fir.process_bulk(-4 * x))  # (a sign flip is not exact on the matrix pipe: its accumulators do not round symmetrically -- 8e-7 of the rms measured)
+    assert float((y3 + 4 * yo).abs().max()) <= 1e-5 * float((4 * yo).double().pow(2).mean().sqrt())
     del y3
     ones = torch.ones(1 << 22, dtype=torch.float32, device="cuda")  # DC gain 1 x Butterworth DC gain 1
     fir.reset(); iir.reset()
