@@ -46,8 +46,8 @@ res["configs[2] decim-8 1024-tap FIR + 4 biquads"] = {
     "Msamples/s (input rate, both kernels)": round(n / (t_fir + t_iir) / 1e6, 1), "fir_ms": round(t_fir * 1e3, 3), "iir_ms": round(t_iir * 1e3, 3),
     "fir_Msamples/s (input)": round(n / t_fir / 1e6, 1), "alg_GB/s": round(n * 5.5 / (t_fir + t_iir) / 1e9, 1), "hbm_frac": round(n * 5.5 / (t_fir + t_iir) / 8e12, 3),
     "fir_direct_form_equivalent_TFLOP/s": round(n / 8 * 2048 / t_fir / 1e12, 1),
-    "note": "5.5 B/input sample: 4 in + 0.5 decimated stream written + 0.5 read + 0.5 out; the FIR runs as 8192-sample overlap-save blocks in the frequency domain "
-            "(csrc/fir_decim_fd.hip), the polyphase MFMA kernel it replaces is FP32-bound at 256 flop/input sample"}
+    "note": "5.5 B/input sample: 4 in + 0.5 decimated stream written + 0.5 read + 0.5 out; since late round 4 the FIR runs in band form on the f16 matrix pipe "
+            "(csrc/fir_decim_f16.hip); the frequency-domain kernel of rounds 1-3 (GR4HIP_FIR_NO_DECIM_F16=1) ran this at 530"}
 capi.developer_switch("GR4HIP_FIR_NO_DECIM_FD", 1)
 fir_p = G.fir_filter(lowpass(1024, 0.05), torch.float32, decimate=8)
 t_firp = timeit(lambda: fir_p.process_bulk(x, yd))
