@@ -20,7 +20,10 @@ constexpr int kHfMaxRange = 28; // a segment whose largest sample is more than 2
 __device__ __forceinline__ void hf_split2(float x0, float x1, float s, unsigned& h, unsigned& l) {
     const f32x2_h v  = {x0 * s, x1 * s};
     const f16x2_h hh = __builtin_convertvector(v, f16x2_h);
-    const f32x2_h r  = (v - __builtin_convertvector(hh, f32x2_h)) * 2048.f;
+    // (x s - hh) 2^11 as ONE mixed-precision multiply-add per sample on the f16 term itself (v_fma_mix_f32; exact: the result is representable) -- measured + 1.5 % on the
+    // decimator against converting hh back and subtracting
+    const float   s2 = s * 2048.f;
+    const f32x2_h r  = {__builtin_fmaf((float)hh[0], -2048.f, x0 * s2), __builtin_fmaf((float)hh[1], -2048.f, x1 * s2)};
     const f16x2_h ll = __builtin_convertvector(r, f16x2_h);
     h = __builtin_bit_cast(unsigned, hh);
     l = __builtin_bit_cast(unsigned, ll);
@@ -67,9 +70,10 @@ __device__ __forceinline__ float hf_row_min(float v) {
 __device__ __forceinline__ void hf_split2x3(float x0, float x1, float s, unsigned& h, unsigned& m, unsigned& l) {
     const f32x2_h v  = {x0 * s, x1 * s};
     const f16x2_h hh = __builtin_convertvector(v, f16x2_h);
-    const f32x2_h r1 = (v - __builtin_convertvector(hh, f32x2_h)) * 2048.f;
+    const float   s2 = s * 2048.f;
+    const f32x2_h r1 = {__builtin_fmaf((float)hh[0], -2048.f, x0 * s2), __builtin_fmaf((float)hh[1], -2048.f, x1 * s2)};
     const f16x2_h mm = __builtin_convertvector(r1, f16x2_h);
-    const f32x2_h r2 = (r1 - __builtin_convertvector(mm, f32x2_h)) * 2048.f;
+    const f32x2_h r2 = {__builtin_fmaf((float)mm[0], -2048.f, r1[0] * 2048.f), __builtin_fmaf((float)mm[1], -2048.f, r1[1] * 2048.f)};
     const f16x2_h ll = __builtin_convertvector(r2, f16x2_h);
     h = __builtin_bit_cast(unsigned, hh);
     m = __builtin_bit_cast(unsigned, mm);
