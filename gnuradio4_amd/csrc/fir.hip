@@ -785,10 +785,11 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
-    // float, decimate by 8, 169 .. 1025 taps (BASELINE configs[2]), long 16-byte-aligned span: the band form on the f16 matrix pipe, two-term splits under a per-segment block
+    // float, decimate by 8, 97 .. 1025 taps (BASELINE configs[2]), long 16-byte-aligned span: the band form on the f16 matrix pipe, two-term splits under a per-segment block
     // exponent, the K-steps split over the four waves, every segment judged and the rejected ones evaluated again with float32 products inside the launch (fir_decim_f16.hip)
     // -- its error is relative to the output, so it needs no host-side guard and the call stays asynchronous
-    if (done == 0 && f->S == 1 && f->decim == 8 && f->ntaps > 168 && f->ntaps <= 1025 && n_in >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+    static const size_t kDhMinTaps = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)97; }(); // developer knob.  Measured (G input samples/s, bf16 band kernel / this one): 64 taps 1037 / 998, 100 taps 984 / 999, 128 taps 963 / 998, 168 taps 595 / 999
+    if (done == 0 && f->S == 1 && f->decim == 8 && f->ntaps >= kDhMinTaps && f->ntaps <= 1025 && n_in >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
         algo == GR4HIP_FIR_AUTO && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && !dev_switch(kDevFirNoDecimF16) && f->dhKQ >= 0 && plain) {
         int rc = GR4HIP_OK;
         if (f->dhKQ == 0) {

