@@ -343,8 +343,7 @@ int fir_decim_f16_launch(int KQ, const float* x, long n_in, const float* hist, i
     case K: {                                                                                                                                                            \
         constexpr int    NS  = kDhSegIn + 128 * K - 128;                                                                                                                  \
         constexpr size_t lds = (size_t)3 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                      \
-        static bool      set = false; /* (idempotent: a race sets it twice) */                                                                                            \
-        if (!set) { GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim8_f16x2_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; } \
+        if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim8_f16x2_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per call: the attribute is per device) */ \
         hipLaunchKernelGGL(fir_decim8_f16x2_kernel<K>, grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw);                                   \
     } break
     switch (KQ) {
