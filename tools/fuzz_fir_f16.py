@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""developer tool: the f16 FIR kernels (csrc/fir_f16.hip: block exponent per segment, per-segment guard, float32 paths) against float64 -- random tap counts, float / complex,
+"""developer tool: the f16 FIR kernels (csrc/fir_f16.hip, and for a third of the float cases the decimate-by-8 kernel of fir_decim_f16.hip: block exponent per segment,
+per-segment guard, float32 paths) against float64 -- random tap counts, float / complex,
 ragged and unaligned calls, stream levels 1e-30 .. 1e30, levels that jump by up to 1e12 from stretch to stretch, zero and denormal stretches, sparse outliers up to 1e30,
 Inf / NaN samples, rejected tones up to 60 dB above the noise.  The error is judged block by block (4096 outputs) against the level the LOCAL input gives the products:
 |y - truth| <= 1e-5 max(|truth|, sqrt(sum b^2) rms(x over the block, the taps in front of it and a segment either side)); under a rejected tone against 3 x the error of
@@ -31,14 +32,15 @@ def run(f, x, cuts, cplx, misalign):
     return np.concatenate(parts)
 
 
-def local_err(y, truth, x, taps):
+def local_err(y, truth, x, taps, D=1):
     """max over blocks of 4096 outputs of |y - truth| / max(|truth|, local product level): the level of sqrt(sum b^2) x over the block, the taps in front of it and one
     kernel segment either side (the kernel's segments start at the CALL's first sample, not on the block grid); float32's own resolution (denormals) as a floor"""
     nt = len(taps); g = float(np.sqrt(np.sum(taps.astype(np.float64) ** 2)))
     x2 = np.abs(x.astype(np.complex128 if np.iscomplexobj(x) else np.float64)) ** 2
     worst, where = 0.0, -1
-    for s in range(0, len(y), 4096):
-        e = min(s + 4096, len(y)); lo = max(0, s - nt - 4096 - 32); hi = min(len(y), e + 4096)
+    B = 4096 // D if D == 1 else 1024  # (the decimator's segments are 1024 outputs)
+    for s in range(0, len(y), B):
+        e = min(s + B, len(y)); lo = max(0, D * (s - B) - nt - 32); hi = min(len(x), D * (e + B))
         lvl = g * np.sqrt(float(np.sum(x2[lo:hi])) / max(hi - lo, 1))  # (summed per window: a running sum loses the quiet stretches behind a loud one)
         den = np.maximum(np.maximum(np.abs(truth[s:e]), lvl), 1e-38)
         q = np.abs(y[s:e] - truth[s:e]) / den
@@ -58,8 +60,11 @@ def fir64(taps, x):
 
 while time.time() - t0 < secs:
     cplx = bool(rng.integers(0, 2))
-    nt = int(rng.choice([33, 40, 64, 65, 81, 82, 100, 128, 129, 200, 224, 255, 256] + ([] if cplx else [384, 512, 777, 1024])))
+    dec8 = (not cplx) and rng.integers(0, 3) == 0  # BasicDecimatingFilter<float>, decimate by 8: fir_decim_f16.hip
+    nt = int(rng.choice([97, 100, 168, 200, 257, 258, 400, 513, 514, 700, 769, 770, 1000, 1024, 1025])) if dec8 else int(rng.choice([33, 40, 64, 65, 81, 82, 100, 128, 129, 200, 224, 255, 256] + ([] if cplx else [384, 512, 777, 1024])))
     n = int(rng.integers(1 << 16, 1 << 19)) + int(rng.integers(0, 5000))
+    if dec8:
+        n = (int(rng.integers(1 << 18, 1 << 20)) + int(rng.integers(0, 5000))) // 8 * 8
     kind = str(rng.choice(["plain", "level", "jumps", "holes", "outliers", "nonfinite", "tone"]))
     kinds[kind] = kinds.get(kind, 0) + 1
     taps = (rng.standard_normal(nt) * np.hamming(nt) * 10.0 ** rng.uniform(-3, 1)).astype(np.float32)
@@ -92,38 +97,45 @@ while time.time() - t0 < secs:
     if kind == "nonfinite":
         for a in rng.integers(0, n, size=int(rng.integers(1, 4))):
             x[a] = [np.inf, -np.inf, np.nan][int(rng.integers(0, 3))]
-    ncut = int(rng.integers(0, 3)); al = 2 if cplx else 4
+    ncut = int(rng.integers(0, 3)); al = 32 if dec8 else (2 if cplx else 4)
     cuts = sorted(set([0, n] + [int(c) // al * al for c in rng.integers(0, n, size=ncut)]))
     misalign = bool(rng.integers(0, 8) == 0)
     truth = fir64(taps, x)
-    f = G.fir_filter(taps, torch.complex64 if cplx else torch.float32)
+    D = 8 if dec8 else 1
+    truth = truth[::D]
+    f = G.fir_filter(taps, torch.complex64 if cplx else torch.float32, decimate=D)
     if cplx:
         f.set_algo(capi.FIR_TIME_DOMAIN)
     y = run(f, x, cuts, cplx, misalign)
-    tag = f"{kind} cplx={cplx} taps={nt} n={n} cuts={cuts} misalign={misalign}"
+    tag = f"{kind} cplx={cplx} dec8={dec8} taps={nt} n={n} cuts={cuts} misalign={misalign}"
     if kind == "nonfinite":
         with np.errstate(all="ignore"):
             t32 = truth.astype(dt)
         bad = ~np.isfinite(t32)
         ok = True
-        if misalign or nt > 256 or min(b - a for a, b in zip(cuts[:-1], cuts[1:])) < (1 << 16):  # other kernels (short calls: the register-window kernel's padded taps): a superset of the reference's non-finite outputs
+        if misalign or (nt > 256 and not dec8) or min(b - a for a, b in zip(cuts[:-1], cuts[1:])) < ((1 << 17) if dec8 else (1 << 16)):  # other kernels (short calls: the register-window kernel's padded taps): a superset of the reference's non-finite outputs
             ok = not np.any(bad & np.isfinite(y))
         else:
             for part in ((np.real, np.imag) if cplx else (np.asarray,)):
                 ok &= np.array_equal(np.isnan(part(y)), np.isnan(part(t32))) and np.array_equal(np.isposinf(part(y)), np.isposinf(part(t32))) and np.array_equal(np.isneginf(part(y)), np.isneginf(part(t32)))
         good = np.isfinite(t32) & np.isfinite(y)
         xz = np.where(np.isfinite(x), x, 0).astype(dt)
-        r, w = local_err(np.where(good, y, 0), np.where(good, truth, 0), xz, taps) if ok else (1.0, -1)
+        r, w = local_err(np.where(good, y, 0), np.where(good, truth, 0), xz, taps, D) if ok else (1.0, -1)
         tag += f" classes_ok={ok} nonfinite_at={np.flatnonzero(~np.isfinite(x))[:4]} worst_at={w}"
     elif kind == "tone":
-        ye = O.fir(taps, x, acc64=False)[0]  # the reference's own float32 arithmetic: the sequential sum of transform_reduce (oracle restatement, test infrastructure)
+        if dec8:  # the decimator: against the library's float32 polyphase kernels on the same calls (their block-wise sums are what a decimator's float32 products give here)
+            capi.developer_switch("GR4HIP_FIR_NO_DECIM_F16", 1); capi.developer_switch("GR4HIP_FIR_NO_DECIM_FD", 1)
+            ye = run(G.fir_filter(taps, torch.float32, decimate=8), x, cuts, cplx, misalign)
+            capi.developer_switch("GR4HIP_FIR_NO_DECIM_F16", 0); capi.developer_switch("GR4HIP_FIR_NO_DECIM_FD", 0)
+        else:
+            ye = O.fir(taps, x, acc64=False)[0]  # the reference's own float32 arithmetic: the sequential sum of transform_reduce (oracle restatement, test infrastructure)
         rms = float(np.sqrt(np.mean(np.abs(truth[nt:]) ** 2)))
         e = float(np.max(np.abs(y[nt:] - truth[nt:]) / np.maximum(np.abs(truth[nt:]), rms))); e32 = float(np.max(np.abs(ye[nt:] - truth[nt:]) / np.maximum(np.abs(truth[nt:]), rms)))
-        r = 0.0 if e <= max(1e-5, (3.0 if nt <= 256 else 12.0) * e32) else e  # (the 256-tap slices of longer filters run unjudged: partial sums)
+        r = 0.0 if e <= max(1e-5, (3.0 if (nt <= 256 or dec8) else 12.0) * e32) else e  # (the 256-tap slices of longer filters run unjudged: partial sums)
         tag += f" amp={amp:.0f} err={e:.2e} reference_f32={e32:.2e}"
     else:
-        r, w = local_err(y, truth, x, taps)
-        tag += f" worst_at={w} y={y[w]:.6g} truth={truth[w]:.6g} |x| around: {np.abs(x[max(0, w - 300):w + 1]).max():.3g} / segment max {np.abs(x[max(0, w - 4400):w + 4400]).max():.3g}"
+        r, w = local_err(y, truth, x, taps, D)
+        tag += f" worst_at={w} y={y[w]:.6g} truth={truth[w]:.6g} |x| around: {np.abs(x[max(0, D * w - 300):D * w + 1]).max():.3g} / segment max {np.abs(x[max(0, D * w - 4400 * D):D * w + 4400 * D]).max():.3g}"
     cases += 1; worst = max(worst, r)
     if r > 1e-5:
         fails += 1; kfail[kind] = kfail.get(kind, 0) + 1
