@@ -399,6 +399,7 @@ int main(int argc, char** argv) {
                     if (!sched.runAndWait()) ++errors;
                     if (dev && !mul._device_state) ++errors;
                     if (dev) hip::release(mul);
+                    return sink._samples; // (copied while the scheduler still owns the graph: behind this block the sink is gone)
                 } else {
                     auto& src  = g.emplaceBlock<testing::VectorSource<U>>();
                     src.values = s;
@@ -410,13 +411,20 @@ int main(int argc, char** argv) {
                     if (!sched.runAndWait()) ++errors;
                     if (dev && !div._device_state) ++errors;
                     if (dev) hip::release(div);
+                    return sink._samples; // (a copy taken after the scheduler's destructor read freed memory: its first 32 bytes were the allocator's now and then)
                 }
-                return sink._samples;
             };
             const auto cmp_u = [&](const char* what, const auto& d, const auto& h, std::size_t n, double tol) {
                 double worst = d.size() == n && h.size() == n ? 0.0 : 1e30;
                 for (std::size_t i = 0; i < n && worst < 1e29; ++i) {
-                    if (d[i].value != h[i].value) worst = 1e30; // one IEEE operation per source operation: identical
+                    if (d[i].value != h[i].value) {
+                        worst = 1e30; // one IEEE operation per source operation: identical
+                        std::size_t bad = 0, last = i;
+                        for (std::size_t k = i; k < n; ++k)
+                            if (d[k].value != h[k].value) { ++bad; last = k; }
+                        std::printf("  %s: first differing element %zu (device {%g, %g}, host {%g, %g}), %zu differ, the last one %zu\n", what, i, double(d[i].value), double(d[i].uncertainty), double(h[i].value),
+                                    double(h[i].uncertainty), bad, last);
+                    }
                     worst = std::max(worst, std::abs(double(d[i].uncertainty) - double(h[i].uncertainty)) / std::abs(double(h[i].uncertainty)));
                 }
                 report(what, worst, tol);
