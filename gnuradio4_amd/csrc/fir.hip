@@ -235,7 +235,7 @@ void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vect
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
 bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab); // fir_decim_f16.hip
-int  fir_decim_f16_launch(int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard);
+int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard);
 int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard);
 int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
@@ -789,7 +789,8 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // exponent, the K-steps split over the four waves, every segment judged and the rejected ones evaluated again with float32 products inside the launch (fir_decim_f16.hip)
     // -- its error is relative to the output, so it needs no host-side guard and the call stays asynchronous
     static const size_t kDhMinTaps = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)97; }(); // developer knob.  Measured (G input samples/s, bf16 band kernel / this one): 64 taps 1037 / 998, 100 taps 984 / 999, 128 taps 963 / 998, 168 taps 595 / 999
-    if (done == 0 && f->S == 1 && f->decim == 8 && f->ntaps >= kDhMinTaps && f->ntaps <= 1025 && n_in >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+    static const size_t kDhMinTapsWide = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_WIDE"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // (decimate by 16 / 32)
+    if (done == 0 && f->S == 1 && ((f->decim == 8 && f->ntaps >= kDhMinTaps) || ((f->decim == 16 || f->decim == 32) && f->ntaps >= kDhMinTapsWide)) && f->ntaps <= 1025 && n_in >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
         algo == GR4HIP_FIR_AUTO && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && !dev_switch(kDevFirNoDecimF16) && f->dhKQ >= 0 && plain) {
         int rc = GR4HIP_OK;
         if (f->dhKQ == 0) {
@@ -802,7 +803,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             }
         }
         if (f->dhKQ > 0) {
-            rc = fir_decim_f16_launch(f->dhKQ, x, (long)n_in, hist, (int)f->hcap, f->d_dhtab.ptr, y, (long)n_out, st, (float*)f->d_hist[f->cur ^ 1].ptr, f->guard_mode != GR4HIP_GUARD_OFF);
+            rc = fir_decim_f16_launch((int)f->decim, f->dhKQ, x, (long)n_in, hist, (int)f->hcap, f->d_dhtab.ptr, y, (long)n_out, st, (float*)f->d_hist[f->cur ^ 1].ptr, f->guard_mode != GR4HIP_GUARD_OFF);
             if (rc) return rc;
             done = n_in;
             mfma_wrote_hist = true;

@@ -1,6 +1,7 @@
-// fir_decim_f16.hip -- BasicDecimatingFilter<float>, decimate by 8, up to 1025 taps (BASELINE configs[2]), on the f16 matrix pipe: the band form of the contraction
+// fir_decim_f16.hip -- BasicDecimatingFilter<float>, decimate by D = 8 (up to 1025 taps: BASELINE configs[2]), 16 (897) or 32 (641), on the f16 matrix pipe: the band form of the
+// contraction (written out below for D = 8; a segment is 8192 input samples whatever D: 16 columns of 512 samples, 32 / D tile rows per column, D / 2 K-steps apart)
 //
-//     y[m] = sum_k b[k] x[8 m - k]:   D[j][c] = sum_u A[j][u] B[u][c],   A[j][u] = b[Hb + 8 j - u],   B[u][c] = staged[base(tile) + u],   u < 128 KQ
+//     y[m] = sum_k b[k] x[D m - k]:   D[j][c] = sum_u A[j][u] B[u][c],   A[j][u] = b[Hb + D j - u],   B[u][c] = staged[base(tile) + u],   u < 128 KQ
 //
 // (samples in stream order, the decimation in the tap operand: a tile of 16 outputs sees a window of Hb + 121 <= 128 KQ samples, the next tile starts 128 samples on) with
 // fir_f16.hip's arithmetic -- samples and taps as two f16 terms under a per-segment block exponent, three products per tap -- and its safeguards: every segment's statistics
@@ -24,7 +25,7 @@
 
 namespace gr4 {
 
-constexpr int kDhSegOut = 1024, kDhD = 8, kDhSegIn = kDhSegOut * kDhD, kDhMaxSpw = 64;
+constexpr int kDhSegIn = 8192, kDhMaxSpw = 64; // a segment: 8192 input samples = 8192 / D outputs = 16 columns of 512 samples, 32 / D tile rows per column (D = 8, 16, 32)
 
 // the table fir_decim_f16_make_table writes, in 16-bit units: [4 waves][3 planes][KQ][64 lanes][8] f16 fragments, 8 units of header {float 1 / t, int ntaps, float guard
 // threshold, -}, 1040 float taps
@@ -33,17 +34,17 @@ __host__ __device__ constexpr int dh_table_units(int KQ) { return dh_frag_units(
 
 // the matrix-pipe evaluation of a staged segment with NT terms per factor (2: three products; 3: the six products of order <= 2 = float32 products): this wave's K quarter
 // for the four tile rows, its partial tiles to `part`
-template <int KQ, int NT, int PL>
-__device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const unsigned short* __restrict__ pls, float (*__restrict__ part)[4][64][4], int wave, int lane) {
-    constexpr int NM = KQ + 12;
+template <int D, int KQ, int NT, int PL>
+__device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const unsigned short* __restrict__ pls, float (*__restrict__ part)[32 / D][64][4], int wave, int lane) {
+    constexpr int TR = 32 / D, TS = D / 2, NM = KQ + TS * (TR - 1); // tile rows per column, K-steps between them (16 D samples), fragments of the stream
     const int col = lane & 15, kq = lane >> 4;
     auto      P   = [](int s_) { return s_ + 8 * (s_ >> 9); };
-    f32x4_h   c[4], d[4], g[NT == 3 ? 4 : 1];
+    f32x4_h   c[TR], d[TR], g[NT == 3 ? TR : 1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TR; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
     if constexpr (NT == 3)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TR; ++j) g[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
     const int sb = 512 * col + 32 * KQ * wave + 8 * kq;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
@@ -52,8 +53,8 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const uns
         f16x8_h       b3 = b1;
         if constexpr (NT == 3) b3 = *reinterpret_cast<const f16x8_h*>(pls + 2 * PL + qo);
 #pragma unroll
-        for (int tr = 0; tr < 4; ++tr) {
-            const int ks = m - 4 * tr;
+        for (int tr = 0; tr < TR; ++tr) {
+            const int ks = m - TS * tr;
             if (ks < 0 || ks >= KQ) continue;
             const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a[1][ks]);
             c[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[tr], 0, 0, 0);
@@ -68,7 +69,7 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const uns
         }
     }
 #pragma unroll
-    for (int tr = 0; tr < 4; ++tr) {
+    for (int tr = 0; tr < TR; ++tr) {
         float4 w;
         if constexpr (NT == 3)
             w = make_float4(c[tr][0] + (d[tr][0] + g[tr][0] * (1.f / 2048.f)) * (1.f / 2048.f), c[tr][1] + (d[tr][1] + g[tr][1] * (1.f / 2048.f)) * (1.f / 2048.f),
@@ -79,21 +80,21 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const uns
     }
 }
 
-template <int KQ> // K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 128 samples in front of a tile's first output
-__global__ __launch_bounds__(256, 2) void fir_decim8_f16x2_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh,
+template <int D, int KQ> // decimation 8 / 16 / 32; K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 16 D samples in front of a tile's first output
+__global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh,
                                                                   const unsigned short* __restrict__ tab, float* __restrict__ y, long n_out, long n_in,
                                                                   float* __restrict__ new_hist, int guard, int seg_per_wg /*<= kDhMaxSpw*/) {
-    constexpr int Hb = 128 * KQ - 128, NS = kDhSegIn + Hb; // staged samples per segment (a multiple of 128)
+    constexpr int TR = 32 / D, SO = kDhSegIn / D, Hb = 128 * KQ - 16 * D, NS = kDhSegIn + Hb; // tile rows per column, outputs per segment, staged samples per segment (a multiple of 128)
+    static_assert(Hb > 0, "the window must hold a tile's 16 D input samples");
     constexpr int PL  = NS + 8 * (NS / 512 + 1) + 16;      // f16 elements per plane: one 16-byte chunk of padding per 512 samples (the 16 columns of a fragment read are 512 samples apart)
     constexpr int NL4 = (NS / 4 + 255) / 256;              // float4 loads a lane holds for the next segment
-    constexpr int NM  = KQ + 12;                           // fragments of a wave's stream
     const u32x4_h* afrag = reinterpret_cast<const u32x4_h*>(tab);
     const float    inv_t = *reinterpret_cast<const float*>(tab + dh_frag_units(KQ));
     const int      ntaps = *reinterpret_cast<const int*>(tab + dh_frag_units(KQ) + 2);
     const float    gthr  = *reinterpret_cast<const float*>(tab + dh_frag_units(KQ) + 4);
     const float*   tapsf = reinterpret_cast<const float*>(tab + dh_frag_units(KQ) + 8);
     extern __shared__ __attribute__((aligned(16))) unsigned short pls[]; // [3][PL]: planes x1, x2 (x3: the second evaluation)
-    __shared__ __attribute__((aligned(16))) float          part[4][4][64][4]; // [K quarter = wave][tile row][lane][row within the lane's four]
+    __shared__ __attribute__((aligned(16))) float          part[4][TR][64][4]; // [K quarter = wave][tile row][lane][row within the lane's four]
     __shared__ __attribute__((aligned(16))) unsigned       stat[12];
     __shared__ __attribute__((aligned(16))) float          ystat[4][16]; // the four tile rows' output powers per column of 64 outputs
     __shared__ unsigned char                               noted[kDhMaxSpw];
@@ -151,12 +152,13 @@ __global__ __launch_bounds__(256, 2) void fir_decim8_f16x2_kernel(const float* _
         inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
         return slow;
     };
-    // thread (w', lane) takes tile row w' out: the four K quarters' partial tiles summed in a fixed order, the block scales off, y[seg + 64 col + 16 w' + 4 kq + r]
+    // thread (w', lane) takes tile row w' out: the four K quarters' partial tiles summed in a fixed order, the block scales off, y[seg + 16 TR col + 16 w' + 4 kq + r]
     auto take_out = [&](long sg, float k, float& py) __attribute__((always_inline)) {
+        if (wave >= TR) return; // (thread (w', lane) takes tile row w': D = 16 / 32 have two / one of them)
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = ((part[0][wave][lane][r] + part[1][wave][lane][r]) + (part[2][wave][lane][r] + part[3][wave][lane][r])) * k;
-        const long o = sg * kDhSegOut + 64L * col + 16 * wave + 4 * kq;
+        const long o = sg * SO + (long)(16 * TR) * col + 16 * wave + 4 * kq;
         if (o + 3 < n_out) {
             *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
             py = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], py))));
@@ -168,11 +170,12 @@ __global__ __launch_bounds__(256, 2) void fir_decim8_f16x2_kernel(const float* _
     // plain float32 sums from global memory, one output at a time: a segment with a non-finite sample (the reference's classes on exactly its outputs) or with a spread
     // beyond the block exponent's reach.  Very slow; such samples are not ordinary data.
     auto exact_segment = [&](long sg) __attribute__((always_inline)) {
-        for (int r = 0; r < kDhSegOut / 256; ++r) {
-            const long m = sg * kDhSegOut + tid + 256 * r;
-            if (m >= n_out) break;
+        for (int r = 0; r < (SO + 255) / 256; ++r) {
+            const int j = tid + 256 * r;
+            const long m = sg * SO + j;
+            if (j >= SO || m >= n_out) break;
             float acc = 0.f;
-            for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs(8 * m - k), acc);
+            for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs((long)D * m - k), acc);
             y[m] = acc;
         }
     };
@@ -185,9 +188,9 @@ __global__ __launch_bounds__(256, 2) void fir_decim8_f16x2_kernel(const float* _
     // the guard (fir_f16.hip): sixteen times the power of the QUIETEST of the segment's sixteen output columns, at the input rate, against 2^-12 (sum b^2) x the input power
     auto rejected = [&](float px) __attribute__((always_inline)) -> bool {
         const float pc = (ystat[0][col] + ystat[1][col]) + (ystat[2][col] + ystat[3][col]);
-        return __builtin_amdgcn_readfirstlane((int)(16.f * hf_row_min(pc) * (float)kDhD < gthr * px)) != 0;
+        return __builtin_amdgcn_readfirstlane((int)(16.f * hf_row_min(pc) * (float)D < gthr * px)) != 0;
     };
-    const long nseg = (n_out + kDhSegOut - 1) / kDhSegOut, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
+    const long nseg = (n_out + SO - 1) / SO, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
     if (sfirst >= slast) return;
     if (tid < kDhMaxSpw) noted[tid] = 0;
     {
@@ -213,12 +216,13 @@ __global__ __launch_bounds__(256, 2) void fir_decim8_f16x2_kernel(const float* _
             }
             if (sg + 1 < slast) load_next(sg + 1);
             __syncthreads();
-            if (kind == 0) dh_contract<KQ, 2, PL>(a, pls, part, wave, lane);
+            if (kind == 0) dh_contract<D, KQ, 2, PL>(a, pls, part, wave, lane);
             else if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
             __syncthreads();
             float py = 0.f;
             if (kind == 0) take_out(sg, inv_t * inv_s, py);
-            if (kind != 0 || sg * kDhSegOut + 64L * col >= n_out) py = __builtin_inff(); // (nothing to judge; a column past the end of the span)
+            if (wave >= TR) py = 0.f;                                                                  // (no tile row of its own: nothing to add to the columns' sums)
+            else if (kind != 0 || sg * SO + (long)(16 * TR) * col >= n_out) py = __builtin_inff(); // (nothing to judge; a column past the end of the span)
             py = hf_column_sum(py);
             if (lane < 16) ystat[wave][lane] = py;
             px_prev   = px;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim8_f16x2_kernel(const float* _
                 }
             }
             __syncthreads();
-            dh_contract<KQ, 3, PL>(a, pls, part, wave, lane);
+            dh_contract<D, KQ, 3, PL>(a, pls, part, wave, lane);
             __syncthreads();
             float py = 0.f;
             take_out(sg, inv_t * inv_s, py);
@@ -280,12 +284,12 @@ __global__ __launch_bounds__(256, 2) void fir_decim8_f16x2_kernel(const float* _
 // the table of fir_decim8_f16x2_kernel<KQ> (see dh_table_units): fragment (wave w, plane p, K-step ks, lane l, element t) = tap-plane value
 // b_p[Hb + 8 (l & 15) - (32 (KQ w + ks) + 8 (l >> 4) + t)]; planes as fir_f16_make_afrag's.  false: taps or a shape this kernel does not carry
 bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab) {
-    if (D != (size_t)kDhD || ntaps < 2 || ntaps > 1025) return false;
+    if ((D != 8 && D != 16 && D != 32) || ntaps < 2) return false;
     int KQ = 0;
     for (int k : {3, 5, 7, 9})
-        if ((size_t)(128 * k - 127) >= ntaps) { KQ = k; break; }
+        if (128 * k > 16 * (int)D && (size_t)(128 * k - 16 * (int)D + 1) >= ntaps) { KQ = k; break; } // Hb = 128 KQ - 16 D >= taps - 1
     if (!KQ) return false;
-    const int Hb = 128 * KQ - 128;
+    const int Hb = 128 * KQ - 16 * (int)D;
     unsigned  mx = 0;
     for (size_t k = 0; k < ntaps; ++k) {
         unsigned u;
@@ -317,7 +321,7 @@ bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ
             for (int ks = 0; ks < KQ; ++ks)
                 for (int l = 0; l < 64; ++l)
                     for (int tt = 0; tt < 8; ++tt) {
-                        const long k = (long)Hb + 8 * (l & 15) - (32 * (KQ * w + ks) + 8 * (l >> 4) + tt);
+                        const long k = (long)Hb + (long)D * (l & 15) - (32 * (KQ * w + ks) + 8 * (l >> 4) + tt);
                         if (k >= 0 && (size_t)k < ntaps) (*tab)[((((size_t)w * 3 + p) * KQ + ks) * 64 + l) * 8 + tt] = pl[p][(size_t)k];
                     }
     unsigned short* hd   = tab->data() + dh_frag_units(KQ);
@@ -331,20 +335,21 @@ bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ
     return true;
 }
 
-// y[m] = sum_k b[k] x[8 m - k], m < n_out = n_in / 8; hist[h] = x[-Kh + h]; x and y 16-byte aligned
-int fir_decim_f16_launch(int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard) {
-    const auto tb = static_cast<const unsigned short*>(table);
+// y[m] = sum_k b[k] x[D m - k], m < n_out = n_in / D, D = 8 / 16 / 32; hist[h] = x[-Kh + h]; x and y 16-byte aligned
+template <int D>
+static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float* hist, int Kh, const unsigned short* tb, float* y, long n_out, hipStream_t st, float* new_hist, int guard) {
     static const int kSpwEnv = [] { const char* e = std::getenv("GR4HIP_DH_SPW"); return e ? std::atoi(e) : 0; }(); // developer knob
-    static const int kWgsEnv = [] { const char* e = std::getenv("GR4HIP_DH_WGS"); return e ? std::atoi(e) : 0; }();
-    const long nseg = ceil_div(n_out, (long)kDhSegOut);
-    const int  spw  = kSpwEnv ? kSpwEnv : (int)std::min<long>(std::max<long>(nseg / (kWgsEnv ? kWgsEnv : 512), 4), 32); // segments per workgroup: the tap fragments and the first staging once per run (2^27 inputs: 4 / 8 / 16 / 32 / 64 segments measured 739 / 758 / 777 / 788 / 520 G at 1024 taps)
+    const long nseg = ceil_div(n_out, (long)(kDhSegIn / D));
+    const int  spw  = kSpwEnv ? kSpwEnv : (int)std::min<long>(std::max<long>(nseg / 512, 4), 32); // segments per workgroup: the tap fragments and the first staging once per run (2^27 inputs, D = 8: 4 / 8 / 16 / 32 / 64 segments measured 739 / 758 / 777 / 788 / 520 G at 1024 taps)
     const dim3 grid((unsigned)ceil_div(nseg, (long)spw));
 #define GR4_DH_CASE(K)                                                                                                                                                   \
     case K: {                                                                                                                                                            \
-        constexpr int    NS  = kDhSegIn + 128 * K - 128;                                                                                                                  \
-        constexpr size_t lds = (size_t)3 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                      \
-        if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim8_f16x2_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per call: the attribute is per device) */ \
-        hipLaunchKernelGGL(fir_decim8_f16x2_kernel<K>, grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw);                                   \
+        if constexpr (128 * K > 16 * D) {                                                                                                                                \
+            constexpr int    NS  = kDhSegIn + 128 * K - 16 * D;                                                                                                          \
+            constexpr size_t lds = (size_t)3 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                  \
+            if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_f16x2_kernel<D, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per call: the attribute is per device) */ \
+            hipLaunchKernelGGL((fir_decim_f16x2_kernel<D, K>), grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw);                            \
+        } else return GR4HIP_UNSUPPORTED;                                                                                                                                \
     } break
     switch (KQ) {
         GR4_DH_CASE(3);
@@ -356,6 +361,15 @@ int fir_decim_f16_launch(int KQ, const float* x, long n_in, const float* hist, i
 #undef GR4_DH_CASE
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
+}
+int fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard) {
+    const auto tb = static_cast<const unsigned short*>(table);
+    switch (D) {
+    case 8: return fir_decim_f16_launch_d<8>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard);
+    case 16: return fir_decim_f16_launch_d<16>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard);
+    case 32: return fir_decim_f16_launch_d<32>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard);
+    default: return GR4HIP_UNSUPPORTED;
+    }
 }
 
 } // namespace gr4

@@ -405,25 +405,26 @@ def test_fir_complex_decimating_long_input_matrix_pipe(G, decim, ntaps):
     assert y.shape == truth.shape and _rel(y, truth) <= TOL
 
 
-@pytest.mark.parametrize("ntaps", [97, 169, 257, 258, 513, 514, 769, 770, 1024, 1025])
-def test_fir_decimate_by_8_f16_band_kernel(G, ntaps, devsw):
-    """BasicDecimatingFilter<float>, decimate by 8, 97 .. 1025 taps, long aligned spans -- the default since late round 4: the band form on the f16 matrix pipe
+@pytest.mark.parametrize("D,ntaps", [(8, 97), (8, 169), (8, 257), (8, 258), (8, 513), (8, 514), (8, 769), (8, 770), (8, 1024), (8, 1025),
+                                     (16, 33), (16, 129), (16, 130), (16, 385), (16, 386), (16, 897), (32, 64), (32, 129), (32, 130), (32, 641)])
+def test_fir_decimate_by_8_16_32_f16_band_kernel(G, D, ntaps, devsw):
+    """BasicDecimatingFilter<float>, decimate by 8 (97 .. 1025 taps), 16 (33 .. 897) and 32 (33 .. 641), long aligned spans -- the default since late round 4: the band form on the f16 matrix pipe
     (fir_decim_f16.hip; the window sizes 3 / 5 / 7 / 9 K-steps per wave at their edges).  The float64 oracle's bar across ragged calls and at any level of the stream
     (the per-segment block exponent); a glitch of 1e30 and an Inf among ordinary samples (such segments are evaluated as float32 sums: the reference's classes on exactly
     the outputs whose window holds the sample, every other output at its own level); a rejected tone 50 dB above the output: judged per segment and evaluated again with
     three-term f16 products -- within 3 x the error of the float32 polyphase kernels, where the two-term products alone (guard off) are several times above it"""
     rng = np.random.default_rng(ntaps)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
-    n = 8 * 60_000
-    cuts = [0, 8 * 20_001, 8 * 20_001 + 8 * 17_000, n]
+    n = D * 4 * 15_000
+    cuts = [0, D * 4 * 5_001, D * 4 * 5_001 + D * 4 * 4_250, n]  # (calls of >= 2^17 samples, 16-byte aligned)
     x = O.signal_f32(31, n)
 
     def run(xx, taps=b, guard=None):
-        f = G.fir_filter(taps, torch.float32, decimate=8)
+        f = G.fir_filter(taps, torch.float32, decimate=D)
         if guard is not None:
             f.set_guard_mode(guard)
         return np.concatenate([f.process_bulk(dev(xx[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
-    truth, _ = O.fir_decim(b, x, 8)
+    truth, _ = O.fir_decim(b, x, D)
     y = run(x)
     assert y.shape == truth.shape and _rel(y, truth) <= TOL
     devsw("GR4HIP_FIR_NO_DECIM_F16", 1)
@@ -431,27 +432,27 @@ def test_fir_decimate_by_8_f16_band_kernel(G, ntaps, devsw):
     devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
     for scale in (1e-30, 1e30):
         xs_ = (x.astype(np.float64) * scale).astype(np.float32)
-        ts, _ = O.fir_decim(b, xs_, 8)
+        ts, _ = O.fir_decim(b, xs_, D)
         assert _rel(run(xs_), ts) <= TOL
     # outliers and a non-finite sample
     xo = x.copy()
     xo[100_003], xo[300_005] = 1e30, np.inf
-    to, _ = O.fir_decim(b, xo, 8)
+    to, _ = O.fir_decim(b, xo, D)
     with np.errstate(over="ignore", invalid="ignore"):
         t32 = to.astype(np.float32)
     yo = run(xo)
     assert np.array_equal(np.isnan(yo), np.isnan(t32)) and np.array_equal(np.isposinf(yo), np.isposinf(t32)) and np.array_equal(np.isneginf(yo), np.isneginf(t32))
     ok = np.isfinite(t32)
     near = np.zeros(len(to), bool)
-    near[100_003 // 8: (100_003 + ntaps) // 8 + 1] = True
+    near[100_003 // D: (100_003 + ntaps) // D + 1] = True
     rms = float(np.sqrt(np.mean(truth ** 2)))
     assert float(np.max(np.abs(yo[ok & ~near] - to[ok & ~near]) / np.maximum(np.abs(to[ok & ~near]), rms))) <= TOL
     assert float(np.max(np.abs(yo[ok & near] - to[ok & near]) / np.maximum(np.abs(to[ok & near]), 1e-3 * np.abs(to[ok & near]).max()))) <= TOL
     # a rejected tone 50 dB above the noise through an anti-alias low-pass
-    bl = O.design_taps_hamming_lowpass(ntaps, 0.05)
+    bl = O.design_taps_hamming_lowpass(ntaps, 0.4 / D)
     xi = (O.signal_f32(7, n, tone_amp=0.0) * 0.05 + 316.0 * np.cos(2 * np.pi * 0.31 * np.arange(n))).astype(np.float32)
-    ti, _ = O.fir_decim(bl, xi, 8)
-    sl = slice(ntaps, None)
+    ti, _ = O.fir_decim(bl, xi, D)
+    sl = slice(ntaps // D + 1, None)
     e_def, e_off = _rel(run(xi, bl)[sl], ti[sl]), _rel(run(xi, bl, G.capi.GUARD_OFF)[sl], ti[sl])
     devsw("GR4HIP_FIR_NO_DECIM_F16", 1)
     devsw("GR4HIP_FIR_NO_DECIM_FD", 1)

@@ -61,10 +61,11 @@ def fir64(taps, x):
 while time.time() - t0 < secs:
     cplx = bool(rng.integers(0, 2))
     dec8 = (not cplx) and rng.integers(0, 3) == 0  # BasicDecimatingFilter<float>, decimate by 8: fir_decim_f16.hip
-    nt = int(rng.choice([97, 100, 168, 200, 257, 258, 400, 513, 514, 700, 769, 770, 1000, 1024, 1025])) if dec8 else int(rng.choice([33, 40, 64, 65, 81, 82, 100, 128, 129, 200, 224, 255, 256] + ([] if cplx else [384, 512, 777, 1024])))
+    DD = int(rng.choice([8, 16, 32])) if dec8 else 1  # the decimation of the dec8 cases: 8, 16 or 32
+    nt = int(rng.choice({8: [97, 100, 168, 200, 257, 258, 400, 513, 514, 700, 769, 770, 1000, 1024, 1025], 16: [33, 64, 129, 130, 300, 385, 386, 641, 642, 897], 32: [33, 64, 129, 130, 385, 386, 641]}[DD])) if dec8 else int(rng.choice([33, 40, 64, 65, 81, 82, 100, 128, 129, 200, 224, 255, 256] + ([] if cplx else [384, 512, 777, 1024])))
     n = int(rng.integers(1 << 16, 1 << 19)) + int(rng.integers(0, 5000))
     if dec8:
-        n = (int(rng.integers(1 << 18, 1 << 20)) + int(rng.integers(0, 5000))) // 8 * 8
+        n = (int(rng.integers(1 << 18, 1 << 20)) + int(rng.integers(0, 5000))) // DD * DD
     kind = str(rng.choice(["plain", "level", "jumps", "holes", "outliers", "nonfinite", "tone"]))
     kinds[kind] = kinds.get(kind, 0) + 1
     taps = (rng.standard_normal(nt) * np.hamming(nt) * 10.0 ** rng.uniform(-3, 1)).astype(np.float32)
@@ -97,17 +98,17 @@ while time.time() - t0 < secs:
     if kind == "nonfinite":
         for a in rng.integers(0, n, size=int(rng.integers(1, 4))):
             x[a] = [np.inf, -np.inf, np.nan][int(rng.integers(0, 3))]
-    ncut = int(rng.integers(0, 3)); al = 32 if dec8 else (2 if cplx else 4)
+    ncut = int(rng.integers(0, 3)); al = 4 * DD if dec8 else (2 if cplx else 4)
     cuts = sorted(set([0, n] + [int(c) // al * al for c in rng.integers(0, n, size=ncut)]))
     misalign = bool(rng.integers(0, 8) == 0)
     truth = fir64(taps, x)
-    D = 8 if dec8 else 1
+    D = DD
     truth = truth[::D]
     f = G.fir_filter(taps, torch.complex64 if cplx else torch.float32, decimate=D)
     if cplx:
         f.set_algo(capi.FIR_TIME_DOMAIN)
     y = run(f, x, cuts, cplx, misalign)
-    tag = f"{kind} cplx={cplx} dec8={dec8} taps={nt} n={n} cuts={cuts} misalign={misalign}"
+    tag = f"{kind} cplx={cplx} decim={DD} taps={nt} n={n} cuts={cuts} misalign={misalign}"
     if kind == "nonfinite":
         with np.errstate(all="ignore"):
             t32 = truth.astype(dt)
@@ -125,7 +126,7 @@ while time.time() - t0 < secs:
     elif kind == "tone":
         if dec8:  # the decimator: against the library's float32 polyphase kernels on the same calls (their block-wise sums are what a decimator's float32 products give here)
             capi.developer_switch("GR4HIP_FIR_NO_DECIM_F16", 1); capi.developer_switch("GR4HIP_FIR_NO_DECIM_FD", 1)
-            ye = run(G.fir_filter(taps, torch.float32, decimate=8), x, cuts, cplx, misalign)
+            ye = run(G.fir_filter(taps, torch.float32, decimate=D), x, cuts, cplx, misalign)
             capi.developer_switch("GR4HIP_FIR_NO_DECIM_F16", 0); capi.developer_switch("GR4HIP_FIR_NO_DECIM_FD", 0)
         else:
             ye = O.fir(taps, x, acc64=False)[0]  # the reference's own float32 arithmetic: the sequential sum of transform_reduce (oracle restatement, test infrastructure)
