@@ -596,6 +596,26 @@ def test_fir_settings_changed_keeps_history(G):
     assert _rel(y1, t1) <= TOL and _rel(y2, t2[2000:]) <= TOL
 
 
+def test_f16_kernels_follow_a_settings_change_in_mid_stream(G):
+    """settingsChanged (time_domain_filter.hpp:38-42) between two long calls: the f16 matrix-pipe kernels rebuild their tap tables (fragments, block exponent of the taps,
+    guard threshold, the float taps of their float32 paths) and keep the history -- float FIR, complex FIR, decimate-by-8"""
+    rng = np.random.default_rng(11)
+    n = 8 * 40_000
+    for cplx, decim, k1, k2 in ((False, 1, 200, 256), (True, 1, 100, 128), (False, 8, 900, 1024)):
+        x = (O.signal_c32 if cplx else O.signal_f32)(9, n)
+        b1, b2 = (rng.standard_normal(k1) / np.sqrt(k1)).astype(np.float32), (rng.standard_normal(k2) / np.sqrt(k2)).astype(np.float32)
+        f = G.fir_filter(b1, torch.complex64 if cplx else torch.float32, decimate=decim)
+        if cplx:
+            f.set_algo(G.capi.FIR_TIME_DOMAIN)
+        h = n // 2
+        y1 = f.process_bulk(dev(x[:h])).cpu().numpy()
+        f.settings_changed(b2)  # k2 <= bit_ceil(k1): history survives
+        y2 = f.process_bulk(dev(x[h:])).cpu().numpy()
+        fd = (lambda bb, xx: O.fir_decim(bb, xx, decim)[0]) if decim > 1 else (lambda bb, xx: O.fir(bb, xx)[0])
+        t1, t2 = fd(b1, x[:h]), fd(b2, x)
+        assert _rel(y1, t1) <= TOL and _rel(y2, t2[h // decim:]) <= TOL, (cplx, decim)
+
+
 @pytest.mark.parametrize("decim,ntaps", [(2, 33), (5, 91), (8, 1024), (10, 64), (64, 512)])
 def test_decimating_fir_parity(G, decim, ntaps):
     rng = np.random.default_rng(decim)
