@@ -234,8 +234,8 @@ void fir_decim_band_make_row(const float* taps, size_t ntaps, size_t D, int* Kp_
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks);
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
-bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab); // fir_decim_f16.hip
-int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard);
+bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab, bool cplx); // fir_decim_f16.hip
+int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, int cplx);
 int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard);
 int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
@@ -790,12 +790,16 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // -- its error is relative to the output, so it needs no host-side guard and the call stays asynchronous
     static const size_t kDhMinTaps = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)97; }(); // developer knob.  Measured (G input samples/s, bf16 band kernel / this one): 64 taps 1037 / 998, 100 taps 984 / 999, 128 taps 963 / 998, 168 taps 595 / 999
     static const size_t kDhMinTapsWide = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_WIDE"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // (decimate by 16 / 32)
-    if (done == 0 && f->S == 1 && ((f->decim == 8 && f->ntaps >= kDhMinTaps) || ((f->decim == 16 || f->decim == 32) && f->ntaps >= kDhMinTapsWide)) && f->ntaps <= 1025 && n_in >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+    // complex<float> (real taps), decimate by 16 / 32 from 33 taps, by 8 from 97 (nothing hooked in): the same kernel on the interleaved stream read as floats, the
+    // interleaving in the tap table (2 taps - 1 <= the window's reach: up to 513 / 449 / 321 taps at D = 8 / 16 / 32)
+    static const size_t kDhMinTapsC8 = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_C8"); return e ? (size_t)std::atoi(e) : (size_t)97; }(); // (complex, decimate by 8, G input samples/s bf16 band kernel / this one: 32 taps 539 / 519, 64 taps 494 / 500, 128 taps 373 / 499, 256 taps 260 / 470; developer knob)
+    if (done == 0 && ((f->S == 1 && ((f->decim == 8 && f->ntaps >= kDhMinTaps) || ((f->decim == 16 || f->decim == 32) && f->ntaps >= kDhMinTapsWide))) ||
+                      (f->S == 2 && (((f->decim == 16 || f->decim == 32) && f->ntaps >= kDhMinTapsWide) || (f->decim == 8 && f->ntaps >= kDhMinTapsC8)))) && f->ntaps <= 1025 && n_in * f->S >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
         algo == GR4HIP_FIR_AUTO && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && !dev_switch(kDevFirNoDecimF16) && f->dhKQ >= 0 && plain) {
         int rc = GR4HIP_OK;
         if (f->dhKQ == 0) {
             std::vector<unsigned short> tab;
-            if (!fir_decim_f16_make_table(f->taps.data(), f->ntaps, f->decim, &f->dhKQ, &tab)) f->dhKQ = -1;
+            if (!fir_decim_f16_make_table(f->taps.data(), f->ntaps, f->decim, &f->dhKQ, &tab, f->S == 2)) f->dhKQ = -1;
             else {
                 rc = f->d_dhtab.ensure(tab.size() * sizeof(unsigned short));
                 if (!rc) { hipError_t e = hipMemcpy(f->d_dhtab.ptr, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
@@ -803,7 +807,8 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             }
         }
         if (f->dhKQ > 0) {
-            rc = fir_decim_f16_launch((int)f->decim, f->dhKQ, x, (long)n_in, hist, (int)f->hcap, f->d_dhtab.ptr, y, (long)n_out, st, (float*)f->d_hist[f->cur ^ 1].ptr, f->guard_mode != GR4HIP_GUARD_OFF);
+            rc = fir_decim_f16_launch((int)f->decim, f->dhKQ, x, (long)(n_in * f->S), hist, (int)(f->hcap * f->S), f->d_dhtab.ptr, y, (long)(n_out * f->S), st, (float*)f->d_hist[f->cur ^ 1].ptr,
+                                      f->guard_mode != GR4HIP_GUARD_OFF, f->S == 2);
             if (rc) return rc;
             done = n_in;
             mfma_wrote_hist = true;

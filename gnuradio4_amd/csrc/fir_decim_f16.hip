@@ -83,7 +83,8 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const uns
 template <int D, int KQ> // decimation 8 / 16 / 32; K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 16 D samples in front of a tile's first output
 __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh,
                                                                   const unsigned short* __restrict__ tab, float* __restrict__ y, long n_out, long n_in,
-                                                                  float* __restrict__ new_hist, int guard, int seg_per_wg /*<= kDhMaxSpw*/) {
+                                                                  float* __restrict__ new_hist, int guard, int seg_per_wg /*<= kDhMaxSpw*/,
+                                                                 int cplx /*the streams are complex<float> read as floats (n_in, n_out, Kh in floats; D complex samples in per complex sample out): the tap table carries the interleaving*/) {
     constexpr int TR = 32 / D, SO = kDhSegIn / D, Hb = 128 * KQ - 16 * D, NS = kDhSegIn + Hb; // tile rows per column, outputs per segment, staged samples per segment (a multiple of 128)
     static_assert(Hb > 0, "the window must hold a tile's 16 D input samples");
     constexpr int PL  = NS + 8 * (NS / 512 + 1) + 16;      // f16 elements per plane: one 16-byte chunk of padding per 512 samples (the 16 columns of a fragment read are 512 samples apart)
@@ -175,7 +176,11 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
             const long m = sg * SO + j;
             if (j >= SO || m >= n_out) break;
             float acc = 0.f;
-            for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs((long)D * m - k), acc);
+            if (cplx) { // float m = component (m & 1) of complex output m >> 1
+                for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs(2 * ((long)D * (m >> 1) - k) + (m & 1)), acc);
+            } else {
+                for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs((long)D * m - k), acc);
+            }
             y[m] = acc;
         }
     };
@@ -283,11 +288,14 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
 
 // the table of fir_decim8_f16x2_kernel<KQ> (see dh_table_units): fragment (wave w, plane p, K-step ks, lane l, element t) = tap-plane value
 // b_p[Hb + 8 (l & 15) - (32 (KQ w + ks) + 8 (l >> 4) + t)]; planes as fir_f16_make_afrag's.  false: taps or a shape this kernel does not carry
-bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab) {
+// cplx: complex<float> streams read as floats (fir_bf16.hip's scheme): row j of a tile -- 16 float outputs = 8 complex ones, 16 D floats of input further on per tile, exactly
+// the float geometry -- sits s_j = 2 D (j >> 1) + (j & 1) floats into the window and sees tap k at window position Hb + s_j - 2 k: A[j][u] = b[(Hb + s_j - u) / 2] where that is
+// even, else 0 (half of the matrix pipe's work multiplies zeros; the launches are bound by the stream)
+bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab, bool cplx) {
     if ((D != 8 && D != 16 && D != 32) || ntaps < 2) return false;
     int KQ = 0;
     for (int k : {3, 5, 7, 9})
-        if (128 * k > 16 * (int)D && (size_t)(128 * k - 16 * (int)D + 1) >= ntaps) { KQ = k; break; } // Hb = 128 KQ - 16 D >= taps - 1
+        if (128 * k > 16 * (int)D && (size_t)(128 * k - 16 * (int)D + 1) >= (cplx ? 2 * ntaps - 1 : ntaps)) { KQ = k; break; } // Hb = 128 KQ - 16 D >= taps - 1 (complex: 2 (taps - 1))
     if (!KQ) return false;
     const int Hb = 128 * KQ - 16 * (int)D;
     unsigned  mx = 0;
@@ -321,7 +329,9 @@ bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ
             for (int ks = 0; ks < KQ; ++ks)
                 for (int l = 0; l < 64; ++l)
                     for (int tt = 0; tt < 8; ++tt) {
-                        const long k = (long)Hb + (long)D * (l & 15) - (32 * (KQ * w + ks) + 8 * (l >> 4) + tt);
+                        const int j = l & 15;
+                        long      k = (long)Hb + (cplx ? 2L * (long)D * (j >> 1) + (j & 1) : (long)D * j) - (32 * (KQ * w + ks) + 8 * (l >> 4) + tt);
+                        if (cplx) k = (k & 1) ? -1 : k / 2;
                         if (k >= 0 && (size_t)k < ntaps) (*tab)[((((size_t)w * 3 + p) * KQ + ks) * 64 + l) * 8 + tt] = pl[p][(size_t)k];
                     }
     unsigned short* hd   = tab->data() + dh_frag_units(KQ);
@@ -337,7 +347,7 @@ bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ
 
 // y[m] = sum_k b[k] x[D m - k], m < n_out = n_in / D, D = 8 / 16 / 32; hist[h] = x[-Kh + h]; x and y 16-byte aligned
 template <int D>
-static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float* hist, int Kh, const unsigned short* tb, float* y, long n_out, hipStream_t st, float* new_hist, int guard) {
+static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float* hist, int Kh, const unsigned short* tb, float* y, long n_out, hipStream_t st, float* new_hist, int guard, int cplx) {
     static const int kSpwEnv = [] { const char* e = std::getenv("GR4HIP_DH_SPW"); return e ? std::atoi(e) : 0; }(); // developer knob
     const long nseg = ceil_div(n_out, (long)(kDhSegIn / D));
     const int  spw  = kSpwEnv ? kSpwEnv : (int)std::min<long>(std::max<long>(nseg / 512, 4), 32); // segments per workgroup: the tap fragments and the first staging once per run (2^27 inputs, D = 8: 4 / 8 / 16 / 32 / 64 segments measured 739 / 758 / 777 / 788 / 520 G at 1024 taps)
@@ -348,7 +358,7 @@ static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float
             constexpr int    NS  = kDhSegIn + 128 * K - 16 * D;                                                                                                          \
             constexpr size_t lds = (size_t)3 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                  \
             if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_f16x2_kernel<D, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per call: the attribute is per device) */ \
-            hipLaunchKernelGGL((fir_decim_f16x2_kernel<D, K>), grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw);                            \
+            hipLaunchKernelGGL((fir_decim_f16x2_kernel<D, K>), grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw, cplx);                      \
         } else return GR4HIP_UNSUPPORTED;                                                                                                                                \
     } break
     switch (KQ) {
@@ -362,12 +372,13 @@ static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
-int fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard) {
+// cplx: x, y, hist are complex<float> streams passed as floats: n_in, n_out, Kh count FLOATS, D is the decimation of the complex stream
+int fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, int cplx) {
     const auto tb = static_cast<const unsigned short*>(table);
     switch (D) {
-    case 8: return fir_decim_f16_launch_d<8>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard);
-    case 16: return fir_decim_f16_launch_d<16>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard);
-    case 32: return fir_decim_f16_launch_d<32>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard);
+    case 8: return fir_decim_f16_launch_d<8>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, cplx);
+    case 16: return fir_decim_f16_launch_d<16>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, cplx);
+    case 32: return fir_decim_f16_launch_d<32>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, cplx);
     default: return GR4HIP_UNSUPPORTED;
     }
 }

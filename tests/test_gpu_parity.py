@@ -385,11 +385,12 @@ def test_fir_decimating_long_input_mfma(G, decim, ntaps):
 
 
 @pytest.mark.parametrize("decim,ntaps", [(8, 64), (8, 87), (8, 88), (8, 256), (8, 520), (2, 16), (2, 130), (2, 1), (3, 100), (4, 128), (4, 33), (5, 91), (7, 33), (10, 80), (12, 200),
-                                         (16, 64), (16, 256), (16, 460), (16, 1), (16, 600), (17, 64)])
+                                         (16, 64), (16, 256), (16, 460), (16, 1), (16, 600), (17, 64), (16, 33), (16, 449), (16, 450), (32, 64), (32, 256), (32, 321), (32, 322)])
 def test_fir_complex_decimating_long_input_matrix_pipe(G, decim, ntaps):
     """complex<float> samples x real taps, decimate by 2 .. 16, >= 2^14 outputs per span: the float decimator's band-form kernels (three-term bf16 products) on the
     interleaved stream read as floats -- the rows of a tile alternate between the re and im phases of the window; shapes beyond their windows (and decimation 17)
-    stay on the register-window kernel.  Against the float64 oracle, across calls that switch kernels"""
+    stay on the register-window kernel.  Since late round 4 decimation 16 / 32 (33 .. 449 / 321 taps) and 8 (97 .. 513 taps) take the f16 band-form kernel of
+    fir_decim_f16.hip the same way (the interleaving in its tap table).  Against the float64 oracle, across calls that switch kernels"""
     rng = np.random.default_rng(1000 * ntaps + decim)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
     cuts = [0, 40 * decim, (40 + 20_003) * decim, (40 + 20_003 + 7) * decim, (40 + 20_003 + 7 + 16_384) * decim, (40 + 20_003 + 7 + 16_384 + 33_000) * decim]
