@@ -463,6 +463,70 @@ def test_fir_decimate_by_8_16_32_f16_band_kernel(G, D, ntaps, devsw):
     assert e_off > 1.5 * e_def and e_def <= 3.0 * e_poly + 1e-6, (e_def, e_off, e_poly)  # (measured 1.0 .. 2.1 x: the matrix pipe's float32 sums of 32-product groups)
 
 
+@pytest.mark.parametrize("D,ntaps", [(8, 97), (8, 256), (8, 513), (16, 33), (16, 200), (16, 449), (32, 64), (32, 321)])
+def test_fir_complex_decimate_f16_band_kernel_levels_outliers_and_rejected_tone(G, D, ntaps, devsw):
+    """BasicDecimatingFilter<complex<float>> with real taps on the f16 band-form kernel (the interleaved stream read as floats, the interleaving in the tap table): the float64
+    oracle's bar at any level of the stream; a glitch of 1e30 in a re and an Inf in an im component -- the reference's classes on exactly the outputs (and the components) whose
+    window holds the sample, the other component of the same outputs finite and at its own level (real taps never mix the two); a rejected tone 50 dB above the output
+    evaluated again inside the kernel"""
+    rng = np.random.default_rng(ntaps + D)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = D * 4 * 12_000
+    cuts = [0, D * 4 * 4_001, D * 4 * 4_001 + D * 4 * 4_250, n]
+    x = O.signal_c32(37, n)
+
+    def oracle(taps, xx):  # (real taps never mix the components: the float oracle on each)
+        xx = xx.astype(np.complex128)
+        re, im = O.fir_decim(taps, xx.real.astype(np.float32), D)[0], O.fir_decim(taps, xx.imag.astype(np.float32), D)[0]
+        out = np.empty(len(re), np.complex128)  # (not re + 1j * im: 0 x Inf)
+        out.real, out.imag = re, im
+        return out
+
+    def run(xx, taps=b, guard=None):
+        f = G.fir_filter(taps, torch.complex64, decimate=D)
+        if guard is not None:
+            f.set_guard_mode(guard)
+        return np.concatenate([f.process_bulk(dev(xx[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    truth = oracle(b, x)
+    y = run(x)
+    assert y.shape == truth.shape and _rel(y, truth) <= TOL
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 1)
+    assert not np.array_equal(y, run(x))  # (another kernel without it)
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
+    for scale in (1e-30, 1e30):
+        xs_ = (x.astype(np.complex128) * scale).astype(np.complex64)
+        ts = oracle(b, xs_)
+        assert _rel(run(xs_), ts) <= TOL
+    xo = x.copy()
+    xo[100_003] = complex(1e30, xo[100_003].imag)
+    xo[300_005] = complex(xo[300_005].real, np.inf)
+    to = oracle(b, xo)
+    yo = run(xo)
+    rms = float(np.sqrt(np.mean(np.abs(truth) ** 2)))
+    for part in (np.real, np.imag):
+        with np.errstate(over="ignore", invalid="ignore"):
+            t32 = part(to).astype(np.float32)
+        yp, tp = part(yo), part(to)
+        assert np.array_equal(np.isnan(yp), np.isnan(t32)) and np.array_equal(np.isposinf(yp), np.isposinf(t32)) and np.array_equal(np.isneginf(yp), np.isneginf(t32))
+        ok = np.isfinite(t32)
+        near = np.zeros(len(to), bool)
+        if part is np.real:
+            near[100_003 // D: (100_003 + ntaps) // D + 1] = True
+        assert float(np.max(np.abs(yp[ok & ~near] - tp[ok & ~near]) / np.maximum(np.abs(tp[ok & ~near]), rms))) <= TOL
+        if near.any():
+            assert float(np.max(np.abs(yp[ok & near] - tp[ok & near]) / np.maximum(np.abs(tp[ok & near]), 1e-3 * np.abs(tp[ok & near]).max()))) <= TOL
+    assert np.isfinite(np.imag(yo)[100_003 // D: (100_003 + ntaps) // D + 1]).all() and np.isfinite(np.real(yo)[300_005 // D: (300_005 + ntaps) // D + 1]).all()
+    bl = O.design_taps_hamming_lowpass(ntaps, 0.4 / D)
+    xi = (O.signal_c32(7, n, tone_amp=0.0) * 0.05 + 316.0 * np.exp(2j * np.pi * 0.31 * np.arange(n))).astype(np.complex64)
+    ti = oracle(bl, xi)
+    sl = slice(ntaps // D + 1, None)
+    e_def, e_off = _rel(run(xi, bl)[sl], ti[sl]), _rel(run(xi, bl, G.capi.GUARD_OFF)[sl], ti[sl])
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 1)
+    e_bf = _rel(run(xi, bl)[sl], ti[sl])  # the bf16 band kernels with their guard (float32 products on a rejected span)
+    devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
+    assert e_off > 1.5 * e_def and e_def <= 3.0 * e_bf + 1e-6, (e_def, e_off, e_bf)
+
+
 @pytest.mark.parametrize("ntaps", [1024, 1000, 513, 129, 8, 1])
 def test_fir_decimate_by_8_frequency_domain(G, ntaps, devsw):
     """BASELINE configs[2]'s filter: decimate by 8, <= 1024 taps, spans of >= 64 blocks of 7168 samples take the overlap-save kernel (csrc/fir_decim_fd.hip:
