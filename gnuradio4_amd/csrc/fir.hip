@@ -792,7 +792,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     static const size_t kDhMinTapsWide = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_WIDE"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // (decimate by 16 / 32)
     // complex<float> (real taps), decimate by 16 / 32 from 33 taps, by 8 from 97 (nothing hooked in): the same kernel on the interleaved stream read as floats, the
     // interleaving in the tap table (2 taps - 1 <= the window's reach: up to 513 / 449 / 321 taps at D = 8 / 16 / 32)
-    static const size_t kDhMinTapsC8 = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_C8"); return e ? (size_t)std::atoi(e) : (size_t)97; }(); // (complex, decimate by 8, G input samples/s bf16 band kernel / this one: 32 taps 539 / 519, 64 taps 494 / 500, 128 taps 373 / 499, 256 taps 260 / 470; developer knob)
+    static const size_t kDhMinTapsC8 = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_C8"); return e ? (size_t)std::atoi(e) : (size_t)64; }(); // (complex, decimate by 8, G input samples/s bf16 band kernel / this one over three boxes: 32 taps 517 .. 539 / 519 .. 538, 64 taps 484 .. 494 / 500 .. 535, 128 taps 373 / 499, 256 taps 260 / 470; developer knob)
     if (done == 0 && ((f->S == 1 && ((f->decim == 8 && f->ntaps >= kDhMinTaps) || ((f->decim == 16 || f->decim == 32) && f->ntaps >= kDhMinTapsWide))) ||
                       (f->S == 2 && (((f->decim == 16 || f->decim == 32) && f->ntaps >= kDhMinTapsWide) || (f->decim == 8 && f->ntaps >= kDhMinTapsC8)))) && f->ntaps <= 1025 && n_in * f->S >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
         algo == GR4HIP_FIR_AUTO && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && !dev_switch(kDevFirNoDecimF16) && f->dhKQ >= 0 && plain) {

@@ -146,7 +146,7 @@ int gr4hip_ring_size(const gr4hip_ring_t* ring, size_t* bytes);
  * dtype F32 (registered) or C32 (complex data x real taps).  decim > 1 gives the
  * BasicFilterProto decimating processBulk (:190-204): output m == y[m*decim]; n_in must be a multiple of decim
  * (the reference guarantees it through input_chunk_size = decimate, :166-168). */
-/* Decimate by 8 with 97 .. 1025 taps (float, long 16-byte-aligned spans: BASELINE configs[2]'s filter), by 16 with 33 .. 897 and by 32 with 33 .. 641 taps (complex data: by 8 with 97 .. 513, by 16 with 33 .. 449, by 32 with 33 .. 321 taps) run since late round 4 on the f16 matrix pipe with the arithmetic and
+/* Decimate by 8 with 97 .. 1025 taps (float, long 16-byte-aligned spans: BASELINE configs[2]'s filter), by 16 with 33 .. 897 and by 32 with 33 .. 641 taps (complex data: by 8 with 64 .. 513, by 16 with 33 .. 449, by 32 with 33 .. 321 taps) run since late round 4 on the f16 matrix pipe with the arithmetic and
  * the safeguards described below for the non-decimating filters (csrc/fir_decim_f16.hip: block exponent per segment of 1024 outputs, per-segment verdict, second evaluation with
  * three-term f16 products, float32 sums for segments with a non-finite sample or a spread beyond 2^28): error relative to the OUTPUT, the call asynchronous.  The
  * frequency-domain kernel of rounds 1-3 (error floor relative to the input, strict host-side guard) is what GR4HIP_FIR_IIR_ONE_LAUNCH fuses the cascade into. */
