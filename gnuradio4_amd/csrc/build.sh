@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libgr4hip.so
-SRCS="runtime.hip fir.hip fir_interp.hip fir_decim_fd.hip fft.hip fft_fast_pk.hip math.hip ewise.hip iir.hip chain.hip chain_fused.hip chain_td.hip chain16.hip fir_batched.hip fir_bf16.hip fir_f16.hip fir_decim_f16.hip design.hip f64.hip fanin.hip"
+SRCS="runtime.hip fir.hip fir_interp.hip fir_decim_fd.hip fft.hip fft_fast_pk.hip math.hip ewise.hip iir.hip chain.hip chain_fused.hip chain_td.hip chain16.hip fir_batched.hip fir_bf16.hip fir_f16.hip fir_decim_f16.hip fir_exact.hip design.hip f64.hip fanin.hip"
 mkdir -p ../../build/obj
 OBJS=""
 pids=()

@@ -235,13 +235,17 @@ void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vect
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
 bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab, bool cplx); // fir_decim_f16.hip
-int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, int cplx);
-int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard);
-int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard);
+int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx);
+int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard, unsigned char* flags);
+int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard,
+                    unsigned char* flags, long flags_stride, float gthr);
+// fir_exact.hip: the marked outputs of y[o] = sum_k b[k] x[D o - k] again on the FP64 matrix pipe (flags: one byte per 2^seg_shift outputs; null: every output)
+int  fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const float* d_taps, int ntaps, int D, int cplx, float* y, long n_out, const unsigned char* flags, int seg_shift,
+                      const unsigned* gate, hipStream_t st, unsigned nch = 1, long in_stride = 0, long out_stride = 0, long taps_stride = 0, long flags_stride = 0);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af, bool cplx);
 int  fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist,
-                           const EwiseHook* pre, const EwiseHook* post, bool cplx);
+                           const EwiseHook* pre, const EwiseHook* post, bool cplx, unsigned char* flags, float gthr, int* seg_out);
 int  fir_decim_band_launch(int D, int Kp, const float* x, const float* hist, int hcap, const float* row, float* y, long n_out, long n_in, hipStream_t st);
 void fir_mfma_make_afrag_decim(const float* taps, size_t ntaps, size_t D, int* Kp_out, int* KS_out, std::vector<float>* af_out);
 int  fir_mfma_decim_launch(int KS, int D, const float* x, const float* hist, const float* afrag, float* y, long n_out, hipStream_t st);
@@ -257,6 +261,11 @@ __global__ void fir_hist_widen_kernel(const T* __restrict__ hist, int hcap, T* _
 using namespace gr4;
 
 constexpr size_t kFdFrame     = 8192;
+// the per-segment guard of the split-product kernels (fir_f16.hip, fir_decim_f16.hip, fir_bf16.hip's decimators): a segment is marked for the second evaluation when its output
+// power is below this x (sum b^2) x its input power -- 21 dB more rejected than white noise would lose.  Where it comes from: the two-term f16 products' error is ~1.3e-7 rms of
+// the PRODUCTS' level sqrt(sum b^2) rms(x), its largest values ~4 x that; at an output 2^-3.5 = 1 / 11.3 of that level they reach 6e-6 of the output -- inside the 1e-5 bar with
+// margin (measured with tools/tone_ratio.py: at the 36 dB threshold of round 4 unmarked segments reached 4.4e-5).  The tables of fir_f16.hip / fir_decim_f16.hip carry the same number.
+constexpr double kGuardSegmentRatio = 1.0 / 128.0;
 constexpr size_t kMfmaMinSamples = 1 << 16;
 constexpr size_t kFdMinFrames = 64; // below this the direct-form kernel is as fast (the persistent FD grid wants >= 1 frame per CU)
 
@@ -268,6 +277,8 @@ struct gr4hip_fir {
     std::vector<float> taps;
     int                G = 0;      // tap groups per phase
     DeviceBuffer       d_taps;     // [D][Qpad]
+    DeviceBuffer       d_tapsf;    // the taps as they are (what fir_exact_kernel multiplies with)
+    DeviceBuffer       d_flags;    // one byte per segment of the f16 matrix-pipe kernels' last launch: the segments fir_exact_kernel evaluates again behind it
     DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
     int                cur = 0;
     int                algo = GR4HIP_FIR_AUTO; // gr4hip_fir_set_algo
@@ -325,6 +336,9 @@ static int fir_upload_taps(gr4hip_fir* f) {
     int rc = f->d_taps.ensure(tp.size() * sizeof(float));
     if (rc) return rc;
     GR4_HIP_TRY(hipMemcpy(f->d_taps.ptr, tp.data(), tp.size() * sizeof(float), hipMemcpyHostToDevice));
+    rc = f->d_tapsf.ensure(K * sizeof(float));
+    if (rc) return rc;
+    GR4_HIP_TRY(hipMemcpy(f->d_tapsf.ptr, f->taps.data(), K * sizeof(float), hipMemcpyHostToDevice));
     return GR4HIP_OK;
 }
 
@@ -646,7 +660,12 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         }
         if (f->hfKS > 0) {
             float* nh = done == 0 ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
-            rc = fir_f16_c32_launch(f->hfKS, x + done * 2, (long)(n_in - done), hist, (int)f->hcap, f->d_hfrag.ptr, y + done * 2, st, nh, f->guard_mode != GR4HIP_GUARD_OFF);
+            const long nrem = (long)(n_in - done);
+            rc = f->d_flags.ensure((size_t)ceil_div(nrem, 2048L));
+            if (rc) return rc;
+            rc = fir_f16_c32_launch(f->hfKS, x + done * 2, nrem, hist, (int)f->hcap, f->d_hfrag.ptr, y + done * 2, st, nh, f->guard_mode != GR4HIP_GUARD_OFF, (unsigned char*)f->d_flags.ptr);
+            if (rc) return rc;
+            rc = fir_exact_launch(x + done * 2, nrem, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, 1, 1, y + done * 2, nrem, (const unsigned char*)f->d_flags.ptr, 11, nullptr, st); // the marked segments again, on the FP64 matrix pipe
             if (rc) return rc;
             done = n_in;
             mfma_wrote_hist = nh != nullptr;
@@ -724,8 +743,18 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         }
         if (f->hfKS > 0) {
             float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
+            rc = f->d_flags.ensure(ceil_div(n_in, (size_t)4096));
+            if (rc) return rc;
+            // every segment judges its own output / input power (fir_f16.hip); of a long filter's slices the LAST one does, on the sums it leaves in y (the whole filter's
+            // outputs) against the whole filter's threshold.  Marked segments -- rejected, or with samples the block exponent cannot carry in ANY slice -- are evaluated
+            // again with all the taps on the FP64 matrix pipe (fir_exact.hip)
+            double h2 = 0;
+            for (float b : f->taps) h2 += (double)b * b;
             for (size_t p = 0; p < nslice && !rc; ++p)
-                rc = fir_f16_launch(f->hf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_hfrag.ptr + f->hf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0, nslice == 1 && f->guard_mode != GR4HIP_GUARD_OFF /*every segment judges its own output / input power (fir_f16.hip); the slices of a long filter see partial sums*/);
+                rc = fir_f16_launch(f->hf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_hfrag.ptr + f->hf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0,
+                                    p + 1 == nslice && f->guard_mode != GR4HIP_GUARD_OFF, (unsigned char*)f->d_flags.ptr, 0, nslice > 1 ? (float)(h2 * kGuardSegmentRatio) : 0.f);
+            if (rc) return rc;
+            rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, 1, 0, y, (long)n_in, (const unsigned char*)f->d_flags.ptr, 12, nullptr, st);
             if (rc) return rc;
             done = n_in;
             mfma_wrote_hist = true;
@@ -807,8 +836,15 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             }
         }
         if (f->dhKQ > 0) {
+            const long segf = 8192 / (long)f->decim; // the kernel's segment: 8192 input floats = this many output floats
+            rc = f->d_flags.ensure((size_t)ceil_div((long)(n_out * f->S), segf));
+            if (rc) return rc;
             rc = fir_decim_f16_launch((int)f->decim, f->dhKQ, x, (long)(n_in * f->S), hist, (int)(f->hcap * f->S), f->d_dhtab.ptr, y, (long)(n_out * f->S), st, (float*)f->d_hist[f->cur ^ 1].ptr,
-                                      f->guard_mode != GR4HIP_GUARD_OFF, f->S == 2);
+                                      f->guard_mode != GR4HIP_GUARD_OFF, (unsigned char*)f->d_flags.ptr, f->S == 2);
+            if (rc) return rc;
+            // the marked segments again on the FP64 matrix pipe (fir_exact.hip; in samples: a complex segment is half as many outputs)
+            rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, f->S == 2, y, (long)n_out, (const unsigned char*)f->d_flags.ptr,
+                                  ilog2((size_t)(segf / f->S)), nullptr, st);
             if (rc) return rc;
             done = n_in;
             mfma_wrote_hist = true;
@@ -824,8 +860,19 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         int rc = GR4HIP_OK;
         if (fir_decim_bf16_ready(f, n_in, d_in, d_out, &rc)) {
             float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
+            // every segment judges its own output / input power (the three-term products' error is relative to the products); the marked ones are evaluated again on the
+            // FP64 matrix pipe behind the launch (fir_exact.hip).  Hooked launches are not judged: the second evaluation reads the raw stream
+            const bool judged = f->guard_mode != GR4HIP_GUARD_OFF && hk.pre.n_ops == 0 && hk.post.n_ops == 0 && f->ntaps > 1;
+            int        seg_out = 0;
+            if (judged) { rc = f->d_flags.ensure((size_t)ceil_div((long)(n_out * f->S), 512L)); if (rc) return rc; }
+            double h2 = 0;
+            for (float b : f->taps) h2 += (double)b * b;
             rc = fir_decim_bf16_launch(f->bdKS, (int)f->decim, f->bdHb, x, (long)(n_in * f->S), hist, (int)(f->hcap * f->S), f->d_bdfrag.ptr, y, (long)(n_out * f->S), st, nh,
-                                       hk.pre.n_ops > 0 ? &hk.pre : nullptr, hk.post.n_ops > 0 ? &hk.post : nullptr, f->S == 2);
+                                       hk.pre.n_ops > 0 ? &hk.pre : nullptr, hk.post.n_ops > 0 ? &hk.post : nullptr, f->S == 2, judged ? (unsigned char*)f->d_flags.ptr : nullptr,
+                                       (float)(h2 * kGuardSegmentRatio), &seg_out);
+            if (rc == GR4HIP_OK && judged)
+                rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, f->S == 2, y, (long)n_out, (const unsigned char*)f->d_flags.ptr,
+                                      ilog2((size_t)(seg_out / f->S)), nullptr, st);
             if (rc == GR4HIP_OK) { done = n_in; mfma_wrote_hist = true; }
             else if (rc == GR4HIP_UNSUPPORTED) f->bdKS = -1; // (the staged segment does not fit: do not ask again)
             else return rc;

@@ -476,7 +476,10 @@ namespace gr4 {
 void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_bf16.hip
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
-int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard);
+int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard,
+                    unsigned char* flags, long flags_stride, float gthr);
+int  fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const float* d_taps, int ntaps, int D, int cplx, float* y, long n_out, const unsigned char* flags, int seg_shift,
+                      const unsigned* gate, hipStream_t st, unsigned nch, long in_stride, long out_stride, long taps_stride, long flags_stride); // fir_exact.hip
 }
 struct gr4hip_fir_batched {
     size_t       nch = 0, ntaps = 0;
@@ -487,6 +490,7 @@ struct gr4hip_fir_batched {
     int          bfKS = 0;
     DeviceBuffer d_hfrag; // > 32 taps: per-channel two-term f16 tables (fir_f16.hip) -- the default on long spans
     int          hfKS = 0;
+    DeviceBuffer d_tapsf, d_flags; // the taps as they are and one byte per channel and segment: what fir_exact_kernel evaluates again behind the f16 launch
 };
 
 extern "C" {
@@ -515,6 +519,10 @@ int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, cons
             rc = f->d_hfrag.ensure(hf.size() * sizeof(unsigned short));
             if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, hf.data(), hf.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
         } else f->hfKS = 0;
+        if (!rc && f->hfKS) {
+            rc = f->d_tapsf.ensure(nchannels * ntaps * sizeof(float));
+            if (!rc) { hipError_t e = hipMemcpy(f->d_tapsf.ptr, h_taps, nchannels * ntaps * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+        }
     }
     for (int k = 0; k < 2 && !rc; ++k) rc = f->d_hist[k].ensure(nchannels * f->Kp * sizeof(float));
     if (!rc) rc = gr4hip_fir_batched_reset(f);
@@ -538,9 +546,13 @@ int gr4hip_fir_batched_process(gr4hip_fir_batched_t* f, const float* d_in, size_
     hipStream_t st = as_stream(stream);
     const float *hist = (const float*)f->d_hist[f->cur].ptr, *af = (const float*)f->d_afrag.ptr;
     int rc;
-    if (f->hfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2)) // two-term f16 form (fir_f16.hip): same history layout
-        rc = fir_f16_launch(f->hfKS, d_in, (long)n, hist, f->Kp, f->d_hfrag.ptr, d_out, st, nullptr, (long)in_stride, (long)out_stride, (unsigned)f->nch, 0, 0, 1);
-    else if (f->bfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3)) // three-term bf16 form (fir_bf16.hip): same history layout
+    if (f->hfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2)) { // two-term f16 form (fir_f16.hip): same history layout
+        const long nsegs = (long)ceil_div(n, (size_t)4096);
+        rc = f->d_flags.ensure((size_t)nsegs * f->nch);
+        if (!rc) rc = fir_f16_launch(f->hfKS, d_in, (long)n, hist, f->Kp, f->d_hfrag.ptr, d_out, st, nullptr, (long)in_stride, (long)out_stride, (unsigned)f->nch, 0, 0, 1, (unsigned char*)f->d_flags.ptr, nsegs, 0.f);
+        if (!rc) rc = fir_exact_launch(d_in, (long)n, hist, f->Kp, (const float*)f->d_tapsf.ptr, (int)f->ntaps, 1, 0, d_out, (long)n, (const unsigned char*)f->d_flags.ptr, 12, nullptr, st, (unsigned)f->nch,
+                                       (long)in_stride, (long)out_stride, (long)f->ntaps, nsegs); // the marked segments again on the FP64 matrix pipe
+    } else if (f->bfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3)) // three-term bf16 form (fir_bf16.hip): same history layout
         rc = fir_bf16_launch(f->bfKS, d_in, (long)n, hist, f->Kp, f->d_bfrag.ptr, d_out, st, nullptr, (long)in_stride, (long)out_stride, (unsigned)f->nch, 0, 0);
     else
         rc = fir_mfma_launch(f->KS, d_in, (long)in_stride, hist, af, d_out, (long)out_stride, (long)n, (unsigned)f->nch, st, nullptr);

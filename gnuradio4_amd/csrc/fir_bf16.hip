@@ -31,6 +31,7 @@
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "ewise.hpp"
+#include "fir_f16_common.hpp" // (hf_wave_sum)
 
 #include <algorithm>
 #include <cstring>
@@ -433,7 +434,22 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_c32_kernel(const float2* 
 
 // ---- the neighbours of a decimator in its launch (gr4hip_fir_set_prologue / _epilogue; fir.hip): a program applied to the samples on their way into the bf16 planes
 // (positions are FLOAT indices of the stream as the kernel sees it; cplx: two floats per sample, programs of complex<float> items) and to the outputs before the store
-struct BdHooks { EwiseHook pre, post; int cplx = 0; };
+struct BdHooks {
+    EwiseHook pre, post;
+    int       cplx = 0;
+    // the guard (fir_f16.hip's, per segment): the three-term products' error is relative to the PRODUCTS, so a segment whose output power is below gthr x its staged input
+    // power -- more than 21 dB rejected beyond what white noise would lose -- is MARKED in flags[segment], and fir_exact_kernel (fir_exact.hip), launched behind this
+    // kernel, evaluates it again on the FP64 matrix pipe.  flags == nullptr: nobody judges (hooked launches: the second evaluation reads the raw stream)
+    float          gthr  = 0.f;
+    unsigned char* flags = nullptr;
+};
+// the judge's two sums of a segment: every wave leaves its part in st[0 .. 3] (input) / st[4 .. 7] (output); after the segment's last barrier thread 0 decides.  The
+// quietest wave's outputs count as the segment's (a start-up transient in one quarter of it does not hide that the rest is all rejection)
+__device__ __forceinline__ void bd_judge(const float* st, const BdHooks& hk, long sg, int D) {
+    const float px = (st[0] + st[1]) + (st[2] + st[3]);
+    const float py = 4.f * __builtin_fminf(__builtin_fminf(st[4], st[5]), __builtin_fminf(st[6], st[7]));
+    hk.flags[sg]   = (py * (float)D < hk.gthr * px) ? 3 : 0; // (a NaN power compares false: unmarked -- the non-finite classes are these kernels' own)
+}
 __device__ __forceinline__ float4 bd_hook4(float4 v, const EwiseHook& h, int cplx, long fi /*float index of v.x: a multiple of 4*/) {
     if (cplx) {
         float2 e[2] = {make_float2(v.x, v.y), make_float2(v.z, v.w)};
@@ -491,6 +507,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
                                                                 float* __restrict__ y, long n_out, long n_in, int D, int Hb /*a multiple of 4: samples in front of a block*/,
                                                                 float* __restrict__ new_hist, BdHooks hk) {
     extern __shared__ __attribute__((aligned(16))) unsigned short bpl[]; // [3][PL]
+    __shared__ float jst[2][8]; // the judge's sums, by segment parity
     const int NS = 16 * D * 63 + 32 * KS, PL = NS + 8; // staged samples per segment: the last block's window ends 16 D 63 + 32 KS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
     u32x4_b   a[3][KS];
@@ -521,6 +538,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
     if (sfirst < slast && in_start(sfirst) >= 0) load_next(in_start(sfirst));
     for (long sg = sfirst; sg < slast; ++sg) {
         const long in0 = in_start(sg);
+        float      pxl = 0.f;
         if (in0 >= 0) {
 #pragma unroll
             for (int u = 0; u < kBdMaxNL4; ++u) {
@@ -528,10 +546,19 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
                 if (q < NS / 4) {
                     if constexpr (HOOK) { if (hk.pre.n_ops > 0) nxt[u] = bd_hook4(nxt[u], hk.pre, hk.cplx, in0 + 4L * q); }
                     put4(q, nxt[u]);
+                    pxl = fmaf(nxt[u].x, nxt[u].x, fmaf(nxt[u].y, nxt[u].y, fmaf(nxt[u].z, nxt[u].z, fmaf(nxt[u].w, nxt[u].w, pxl))));
                 }
             }
         } else { // the first segment of the span reads the carried history in front of x
-            for (int q = tid; q < NS / 4; q += 256) put4(q, bd_stage_slow<HOOK>(x, hist, Kh, n_in, in0 + 4L * q, hk));
+            for (int q = tid; q < NS / 4; q += 256) {
+                const float4 v = bd_stage_slow<HOOK>(x, hist, Kh, n_in, in0 + 4L * q, hk);
+                put4(q, v);
+                pxl = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, pxl))));
+            }
+        }
+        if (hk.flags != nullptr) {
+            pxl = hf_wave_sum(pxl);
+            if (lane == 0) jst[sg & 1][wave] = pxl;
         }
         __syncthreads();
         if (sg + 1 < slast) load_next(in_start(sg + 1)); // (>= 0: sg + 1 >= 1)
@@ -562,7 +589,15 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
         else
             for (int r = 0; r < 4; ++r)
                 if (o + r < n_out) y[o + r] = v[r];
+        if (hk.flags != nullptr) { // (unhooked launches only: v is the filter's output)
+            float pyl = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pyl = o + r < n_out ? fmaf(v[r], v[r], pyl) : pyl;
+            pyl = hf_wave_sum(pyl);
+            if (lane == 0) jst[sg & 1][4 + wave] = sg * kBdSegOut + 256L * wave < n_out ? pyl : __builtin_inff(); // (a wave past the end of the span: nothing to judge)
+        }
         __syncthreads();
+        if (hk.flags != nullptr && tid == 0) bd_judge(jst[sg & 1], hk, sg, D);
     }
     if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK>(x, hist, Kh, n_in, new_hist, tid, hk);
 }
@@ -576,6 +611,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
                                                                        float* __restrict__ y, long n_out, long n_in, int D, int Hb, float* __restrict__ new_hist, int spw /*segments per workgroup*/,
                                                                        BdHooks hk) {
     extern __shared__ __attribute__((aligned(16))) unsigned short bpl[]; // [3][PL] bf16 planes, then the partial tiles [4 waves][kBsTiles][64 lanes][4] floats
+    __shared__ float jst[2][8]; // the judge's sums, by segment parity
     constexpr int KS = 4 * KSW;
     const int NS = 16 * D * (16 * kBsTiles - 1) + 32 * KS, PL = NS + 8;
     float*    part = reinterpret_cast<float*>(bpl + 3 * PL + (3 * PL & 1));
@@ -608,6 +644,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
     if (sfirst < slast && in_start(sfirst) >= 0) load_next(in_start(sfirst));
     for (long sg = sfirst; sg < slast; ++sg) {
         const long in0 = in_start(sg);
+        float      pxl = 0.f, pyl = 0.f;
         if (in0 >= 0) {
 #pragma unroll
             for (int u = 0; u < NL4; ++u) {
@@ -615,10 +652,19 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
                 if (q < NS / 4) {
                     if constexpr (HOOK) { if (hk.pre.n_ops > 0) nxt[u] = bd_hook4(nxt[u], hk.pre, hk.cplx, in0 + 4L * q); }
                     put4(q, nxt[u]);
+                    pxl = fmaf(nxt[u].x, nxt[u].x, fmaf(nxt[u].y, nxt[u].y, fmaf(nxt[u].z, nxt[u].z, fmaf(nxt[u].w, nxt[u].w, pxl))));
                 }
             }
         } else {
-            for (int q = tid; q < NS / 4; q += 256) put4(q, bd_stage_slow<HOOK>(x, hist, Kh, n_in, in0 + 4L * q, hk));
+            for (int q = tid; q < NS / 4; q += 256) {
+                const float4 v = bd_stage_slow<HOOK>(x, hist, Kh, n_in, in0 + 4L * q, hk);
+                put4(q, v);
+                pxl = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, pxl))));
+            }
+        }
+        if (hk.flags != nullptr) {
+            pxl = hf_wave_sum(pxl);
+            if (lane == 0) jst[sg & 1][wave] = pxl;
         }
         __syncthreads();
         if (sg + 1 < slast) load_next(in_start(sg + 1));
@@ -662,9 +708,14 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
                     } else val = ewise_hook1<float>(val, hk.post, m);
                 }
             }
-            if (m < n_out) y[m] = val;
+            if (m < n_out) { y[m] = val; pyl = fmaf(val, val, pyl); }
+        }
+        if (hk.flags != nullptr) { // (unhooked launches only: val is the filter's output; a wave's 64 threads hold outputs 64 w .. 64 w + 63 of both tiles)
+            pyl = hf_wave_sum(pyl);
+            if (lane == 0) jst[sg & 1][4 + wave] = sg * kBsSegOut + 64L * wave < n_out ? pyl : __builtin_inff();
         }
         __syncthreads(); // (the partial tiles and the planes are reused by the next segment)
+        if (hk.flags != nullptr && tid == 0) bd_judge(jst[sg & 1], hk, sg, D);
     }
     if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK>(x, hist, Kh, n_in, new_hist, tid, hk);
 }
@@ -804,13 +855,17 @@ void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* K
 // y[m] = sum_k b[k] x[m D - k], m < n_out; hist[h] = x[-Kh + h]; x and y 16-byte aligned
 // pre / post: programs for the samples on their way in / the outputs on their way out (null: none); cplx: the stream is complex<float> read as floats (the programs'
 // positions are sample indices)
+// flags (optional, unhooked launches): one byte per segment -- *seg_out outputs (floats, as n_out counts): 512 for the split-K kernel (KS > 9), else 1024 -- the segments whose
+// output power is below gthr x their input power: fir_exact_launch evaluates them again behind this launch
 int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist,
-                          const EwiseHook* pre, const EwiseHook* post, bool cplx) {
+                          const EwiseHook* pre, const EwiseHook* post, bool cplx, unsigned char* flags, float gthr, int* seg_out) {
     BdHooks hk;
     if (pre) hk.pre = *pre;
     if (post) hk.post = *post;
     hk.cplx = cplx ? 1 : 0;
     const bool hooked = hk.pre.n_ops > 0 || hk.post.n_ops > 0;
+    if (!hooked && flags != nullptr && gthr > 0.f) { hk.flags = flags; hk.gthr = gthr; }
+    if (seg_out) *seg_out = KS > 9 ? kBsSegOut : kBdSegOut;
     if (hooked && (Kh % 4) != 0) return GR4HIP_UNSUPPORTED;
     if (KS > 9) { // long window: the waves split the K-steps
         const int    NS   = 16 * D * (16 * kBsTiles - 1) + 32 * KS, PL = NS + 8;

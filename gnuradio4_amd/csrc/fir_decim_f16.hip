@@ -25,33 +25,27 @@
 
 namespace gr4 {
 
-constexpr int kDhSegIn = 8192, kDhMaxSpw = 64; // a segment: 8192 input samples = 8192 / D outputs = 16 columns of 512 samples, 32 / D tile rows per column (D = 8, 16, 32)
+constexpr int kDhSegIn = 8192; // a segment: 8192 input samples = 8192 / D outputs = 16 columns of 512 samples, 32 / D tile rows per column (D = 8, 16, 32)
 
 // the table fir_decim_f16_make_table writes, in 16-bit units: [4 waves][3 planes][KQ][64 lanes][8] f16 fragments, 8 units of header {float 1 / t, int ntaps, float guard
 // threshold, -}, 1040 float taps
 __host__ __device__ constexpr int dh_frag_units(int KQ) { return 4 * 3 * KQ * 512; }
 __host__ __device__ constexpr int dh_table_units(int KQ) { return dh_frag_units(KQ) + 8 + 2 * 1040; }
 
-// the matrix-pipe evaluation of a staged segment with NT terms per factor (2: three products; 3: the six products of order <= 2 = float32 products): this wave's K quarter
-// for the four tile rows, its partial tiles to `part`
-template <int D, int KQ, int NT, int PL>
-__device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const unsigned short* __restrict__ pls, float (*__restrict__ part)[32 / D][64][4], int wave, int lane) {
+// the matrix-pipe evaluation of a staged segment (two terms per factor, three products): this wave's K quarter for the tile rows, its partial tiles to `part`
+template <int D, int KQ, int PL>
+__device__ __forceinline__ void dh_contract(const u32x4_h (&a)[2][KQ], const unsigned short* __restrict__ pls, float (*__restrict__ part)[32 / D][64][4], int wave, int lane) {
     constexpr int TR = 32 / D, TS = D / 2, NM = KQ + TS * (TR - 1); // tile rows per column, K-steps between them (16 D samples), fragments of the stream
     const int col = lane & 15, kq = lane >> 4;
     auto      P   = [](int s_) { return s_ + 8 * (s_ >> 9); };
-    f32x4_h   c[TR], d[TR], g[NT == 3 ? TR : 1];
+    f32x4_h   c[TR], d[TR];
 #pragma unroll
     for (int j = 0; j < TR; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
-    if constexpr (NT == 3)
-#pragma unroll
-        for (int j = 0; j < TR; ++j) g[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
     const int sb = 512 * col + 32 * KQ * wave + 8 * kq;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         const int     qo = P(sb + 32 * m);
         const f16x8_h b1 = *reinterpret_cast<const f16x8_h*>(pls + qo), b2 = *reinterpret_cast<const f16x8_h*>(pls + PL + qo);
-        f16x8_h       b3 = b1;
-        if constexpr (NT == 3) b3 = *reinterpret_cast<const f16x8_h*>(pls + 2 * PL + qo);
 #pragma unroll
         for (int tr = 0; tr < TR; ++tr) {
             const int ks = m - TS * tr;
@@ -60,30 +54,19 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[3][KQ], const uns
             c[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[tr], 0, 0, 0);
             d[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, d[tr], 0, 0, 0);
             d[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, d[tr], 0, 0, 0);
-            if constexpr (NT == 3) {
-                const f16x8_h a3 = __builtin_bit_cast(f16x8_h, a[2][ks]);
-                g[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b3, g[tr], 0, 0, 0);
-                g[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, g[tr], 0, 0, 0);
-                g[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3, b1, g[tr], 0, 0, 0);
-            }
         }
     }
 #pragma unroll
-    for (int tr = 0; tr < TR; ++tr) {
-        float4 w;
-        if constexpr (NT == 3)
-            w = make_float4(c[tr][0] + (d[tr][0] + g[tr][0] * (1.f / 2048.f)) * (1.f / 2048.f), c[tr][1] + (d[tr][1] + g[tr][1] * (1.f / 2048.f)) * (1.f / 2048.f),
-                            c[tr][2] + (d[tr][2] + g[tr][2] * (1.f / 2048.f)) * (1.f / 2048.f), c[tr][3] + (d[tr][3] + g[tr][3] * (1.f / 2048.f)) * (1.f / 2048.f));
-        else
-            w = make_float4(c[tr][0] + d[tr][0] * (1.f / 2048.f), c[tr][1] + d[tr][1] * (1.f / 2048.f), c[tr][2] + d[tr][2] * (1.f / 2048.f), c[tr][3] + d[tr][3] * (1.f / 2048.f));
-        *reinterpret_cast<float4*>(&part[wave][tr][lane][0]) = w;
-    }
+    for (int tr = 0; tr < TR; ++tr)
+        *reinterpret_cast<float4*>(&part[wave][tr][lane][0]) =
+            make_float4(c[tr][0] + d[tr][0] * (1.f / 2048.f), c[tr][1] + d[tr][1] * (1.f / 2048.f), c[tr][2] + d[tr][2] * (1.f / 2048.f), c[tr][3] + d[tr][3] * (1.f / 2048.f));
 }
 
 template <int D, int KQ> // decimation 8 / 16 / 32; K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 16 D samples in front of a tile's first output
 __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh,
                                                                   const unsigned short* __restrict__ tab, float* __restrict__ y, long n_out, long n_in,
                                                                   float* __restrict__ new_hist, int guard, int seg_per_wg /*<= kDhMaxSpw*/,
+                                                                 unsigned char* __restrict__ flags /*one byte per segment: what fir_exact_kernel evaluates again behind this launch*/,
                                                                  int cplx /*the streams are complex<float> read as floats (n_in, n_out, Kh in floats; D complex samples in per complex sample out): the tap table carries the interleaving*/) {
     constexpr int TR = 32 / D, SO = kDhSegIn / D, Hb = 128 * KQ - 16 * D, NS = kDhSegIn + Hb; // tile rows per column, outputs per segment, staged samples per segment (a multiple of 128)
     static_assert(Hb > 0, "the window must hold a tile's 16 D input samples");
@@ -91,14 +74,11 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
     constexpr int NL4 = (NS / 4 + 255) / 256;              // float4 loads a lane holds for the next segment
     const u32x4_h* afrag = reinterpret_cast<const u32x4_h*>(tab);
     const float    inv_t = *reinterpret_cast<const float*>(tab + dh_frag_units(KQ));
-    const int      ntaps = *reinterpret_cast<const int*>(tab + dh_frag_units(KQ) + 2);
     const float    gthr  = *reinterpret_cast<const float*>(tab + dh_frag_units(KQ) + 4);
-    const float*   tapsf = reinterpret_cast<const float*>(tab + dh_frag_units(KQ) + 8);
-    extern __shared__ __attribute__((aligned(16))) unsigned short pls[]; // [3][PL]: planes x1, x2 (x3: the second evaluation)
+    extern __shared__ __attribute__((aligned(16))) unsigned short pls[]; // [2][PL]: planes x1, x2
     __shared__ __attribute__((aligned(16))) float          part[4][TR][64][4]; // [K quarter = wave][tile row][lane][row within the lane's four]
     __shared__ __attribute__((aligned(16))) unsigned       stat[12];
     __shared__ __attribute__((aligned(16))) float          ystat[4][16]; // the four tile rows' output powers per column of 64 outputs
-    __shared__ unsigned char                               noted[kDhMaxSpw];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
     auto P = [](int s_) { return s_ + 8 * (s_ >> 9); };
 
@@ -168,24 +148,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
                 if (o + r < n_out) { y[o + r] = v[r]; py = fmaf(v[r], v[r], py); }
         }
     };
-    // plain float32 sums from global memory, one output at a time: a segment with a non-finite sample (the reference's classes on exactly its outputs) or with a spread
-    // beyond the block exponent's reach.  Very slow; such samples are not ordinary data.
-    auto exact_segment = [&](long sg) __attribute__((always_inline)) {
-        for (int r = 0; r < (SO + 255) / 256; ++r) {
-            const int j = tid + 256 * r;
-            const long m = sg * SO + j;
-            if (j >= SO || m >= n_out) break;
-            float acc = 0.f;
-            if (cplx) { // float m = component (m & 1) of complex output m >> 1
-                for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs(2 * ((long)D * (m >> 1) - k) + (m & 1)), acc);
-            } else {
-                for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs((long)D * m - k), acc);
-            }
-            y[m] = acc;
-        }
-    };
-    // the matrix-pipe evaluation of the staged segment with NT terms per factor (2: three products; 3: the six products of order <= 2 = float32 products)
-    u32x4_h a[3][KQ]; // this wave's quarter of the tap fragments: planes 0, 1 from the start, plane 2 for the second evaluation
+    u32x4_h a[2][KQ]; // this wave's quarter of the tap fragments (planes 0, 1 of the table's three)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -197,7 +160,8 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
     };
     const long nseg = (n_out + SO - 1) / SO, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
     if (sfirst >= slast) return;
-    if (tid < kDhMaxSpw) noted[tid] = 0;
+    if (tid < slast - sfirst) flags[sfirst + tid] = 0; // segments this kernel cannot vouch for are MARKED (1: spread beyond the block exponent; 2: a non-finite sample; 3: rejected
+                                                       // by the guard); fir_exact_kernel (fir_exact.hip), launched behind this one, evaluates them again on the FP64 matrix pipe
     {
         load_seg(sfirst);
         float px_prev = 0.f;
@@ -207,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
             __syncthreads(); // the statistics are complete; every wave is done with the planes, the partial tiles and the verdict words of the segment before
             float     s, inv_s, px;
             const int kind = block_scale(s, inv_s, px);
-            if (guard && kind_prev == 0 && rejected(px_prev) && tid == 0) noted[sg - 1 - sfirst] = 3; // the verdict on the segment before (its output powers: a barrier ago)
+            if (guard && kind_prev == 0 && rejected(px_prev) && tid == 0) flags[sg - 1] = 3; // the verdict on the segment before (its output powers: a barrier ago)
 #pragma unroll
             for (int u = 0; u < NL4; ++u) {
                 const int q = tid + 256 * u;
@@ -221,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
             }
             if (sg + 1 < slast) load_next(sg + 1);
             __syncthreads();
-            if (kind == 0) dh_contract<D, KQ, 2, PL>(a, pls, part, wave, lane);
-            else if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
+            if (kind == 0) dh_contract<D, KQ, PL>(a, pls, part, wave, lane);
+            else if (tid == 0) flags[sg] = (unsigned char)kind;
             __syncthreads();
             float py = 0.f;
             if (kind == 0) take_out(sg, inv_t * inv_s, py);
@@ -234,50 +198,8 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
             kind_prev = kind;
         }
         __syncthreads();
-        if (guard && kind_prev == 0 && rejected(px_prev) && tid == 0) noted[slast - 1 - sfirst] = 3;
+        if (guard && kind_prev == 0 && rejected(px_prev) && tid == 0) flags[slast - 1] = 3;
     }
-    __syncthreads();
-    bool any3 = false;
-    for (int i = 0; i < seg_per_wg; ++i) any3 |= noted[i] == 3;
-    if (any3) { // the second evaluation of the segments the guard rejected: three f16 terms per factor, the six products of order <= 2 (float32 products)
-#pragma unroll
-        for (int ks = 0; ks < KQ; ++ks) a[2][ks] = afrag[((wave * 3 + 2) * KQ + ks) * 64 + lane];
-        __builtin_amdgcn_s_waitcnt(0); // this wave's stores of the first evaluation have landed (and everybody's, behind the next barrier) before other lanes write the same outputs
-        for (int i = 0; i < seg_per_wg; ++i) {
-            if (noted[i] != 3) continue;
-            const long sg = sfirst + i;
-            load_seg(sg);
-            float mf = 0.f;
-#pragma unroll
-            for (int u = 0; u < NL4; ++u) mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fmaxf(__builtin_fabsf(nxt[u].x), __builtin_fabsf(nxt[u].y))), __builtin_fmaxf(__builtin_fabsf(nxt[u].z), __builtin_fabsf(nxt[u].w)));
-            const unsigned mw = hf_wave_reduce_u32(__float_as_uint(mf), [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
-            if (lane == 0) stat[wave] = mw;
-            __syncthreads();
-            const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[0]);
-            const int   e  = (int)(__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))) >> 23), ec = e < 15 ? 15 : (e > 254 ? 254 : e);
-            const float s = __uint_as_float((unsigned)(268 - ec) << 23), inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
-#pragma unroll
-            for (int u = 0; u < NL4; ++u) {
-                const int q = tid + 256 * u;
-                if (256 * (u + 1) <= NS / 4 || q < NS / 4) {
-                    unsigned h0, m0, l0, h1, m1, l1;
-                    hf_split2x3(nxt[u].x, nxt[u].y, s, h0, m0, l0);
-                    hf_split2x3(nxt[u].z, nxt[u].w, s, h1, m1, l1);
-                    *reinterpret_cast<uint2*>(pls + P(4 * q))          = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(pls + PL + P(4 * q))     = make_uint2(m0, m1);
-                    *reinterpret_cast<uint2*>(pls + 2 * PL + P(4 * q)) = make_uint2(l0, l1);
-                }
-            }
-            __syncthreads();
-            dh_contract<D, KQ, 3, PL>(a, pls, part, wave, lane);
-            __syncthreads();
-            float py = 0.f;
-            take_out(sg, inv_t * inv_s, py);
-            __syncthreads();
-        }
-    }
-    for (int i = 0; i < seg_per_wg; ++i)
-        if (noted[i] == 1 || noted[i] == 2) exact_segment(sfirst + i);
     if (new_hist != nullptr && blockIdx.x == 0) {
         for (int h = tid; h < Kh; h += 256) {
             const long i = n_in - Kh + h;
@@ -336,7 +258,7 @@ bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ
                     }
     unsigned short* hd   = tab->data() + dh_frag_units(KQ);
     const int       nt   = (int)ntaps;
-    const float     gthr = (float)(h2 / 4096.0); // P_y D < 2^-12 (sum b^2) P_x: 36 dB more rejected than white noise would lose (fir_f16.hip)
+    const float     gthr = (float)(h2 / 128.0); // P_y D < 2^-7 (sum b^2) P_x: 21 dB more rejected than white noise would lose (fir.hip, kGuardSegmentRatio)
     std::memcpy(hd, &inv_t, 4);
     std::memcpy(hd + 2, &nt, 4);
     std::memcpy(hd + 4, &gthr, 4);
@@ -347,7 +269,7 @@ bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ
 
 // y[m] = sum_k b[k] x[D m - k], m < n_out = n_in / D, D = 8 / 16 / 32; hist[h] = x[-Kh + h]; x and y 16-byte aligned
 template <int D>
-static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float* hist, int Kh, const unsigned short* tb, float* y, long n_out, hipStream_t st, float* new_hist, int guard, int cplx) {
+static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float* hist, int Kh, const unsigned short* tb, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx) {
     static const int kSpwEnv = [] { const char* e = std::getenv("GR4HIP_DH_SPW"); return e ? std::atoi(e) : 0; }(); // developer knob
     const long nseg = ceil_div(n_out, (long)(kDhSegIn / D));
     const int  spw  = kSpwEnv ? kSpwEnv : (int)std::min<long>(std::max<long>(nseg / 512, 4), 32); // segments per workgroup: the tap fragments and the first staging once per run (2^27 inputs, D = 8: 4 / 8 / 16 / 32 / 64 segments measured 739 / 758 / 777 / 788 / 520 G at 1024 taps)
@@ -356,9 +278,9 @@ static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float
     case K: {                                                                                                                                                            \
         if constexpr (128 * K > 16 * D) {                                                                                                                                \
             constexpr int    NS  = kDhSegIn + 128 * K - 16 * D;                                                                                                          \
-            constexpr size_t lds = (size_t)3 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                  \
+            constexpr size_t lds = (size_t)2 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                  \
             if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_f16x2_kernel<D, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per call: the attribute is per device) */ \
-            hipLaunchKernelGGL((fir_decim_f16x2_kernel<D, K>), grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw, cplx);                      \
+            hipLaunchKernelGGL((fir_decim_f16x2_kernel<D, K>), grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw, flags, cplx);                      \
         } else return GR4HIP_UNSUPPORTED;                                                                                                                                \
     } break
     switch (KQ) {
@@ -373,12 +295,13 @@ static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float
     return GR4HIP_OK;
 }
 // cplx: x, y, hist are complex<float> streams passed as floats: n_in, n_out, Kh count FLOATS, D is the decimation of the complex stream
-int fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, int cplx) {
+// flags: ceil(n_out / (8192 / D)) bytes: the segments (8192 / D outputs, counted as n_out is) fir_exact_launch evaluates again behind this launch
+int fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx) {
     const auto tb = static_cast<const unsigned short*>(table);
     switch (D) {
-    case 8: return fir_decim_f16_launch_d<8>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, cplx);
-    case 16: return fir_decim_f16_launch_d<16>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, cplx);
-    case 32: return fir_decim_f16_launch_d<32>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, cplx);
+    case 8: return fir_decim_f16_launch_d<8>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx);
+    case 16: return fir_decim_f16_launch_d<16>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx);
+    case 32: return fir_decim_f16_launch_d<32>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx);
     default: return GR4HIP_UNSUPPORTED;
     }
 }

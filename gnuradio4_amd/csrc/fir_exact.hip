@@ -1,0 +1,179 @@
+// fir_exact.hip -- the second evaluation of the matrix-pipe FIR / decimator kernels, as ONE kernel behind all of them:  y[o] = sum_k b[k] x[D o - k]  on the FP64 matrix
+// pipe (v_mfma_f64_16x16x4_f64: every float32 x float32 product exact in float64, the sums in float64, ONE rounding to float32 at the end).
+//
+// Why it exists.  The split-product kernels (fir_f16.hip, fir_decim_f16.hip; the fused chain of chain_fused.hip) carry an error that is relative to the PRODUCTS -- like the
+// reference's own float32 sum (time_domain_filter.hpp:44-47), but a few times larger -- so it shows against the OUTPUT only when the filter removes nearly everything it is
+// given.  Those kernels judge every segment themselves (output power against input power) and mark the ones they cannot vouch for; the marked segments are evaluated again
+// HERE, with an error far below the reference's float32 arithmetic whatever the signal (2^-53 of the partial sums instead of 2^-24): the parity contract's second clause
+// (include/gr4hip.h, "PARITY CONTRACT") holds with a factor of ONE and a wide margin, with no per-shape exceptions.  Until round 5 every kernel family carried its own second
+// evaluation inside its main kernel (three-term f16 products, float32 matrix-pipe sums): 110 live registers spilled around them, and their float32 accumulation measured
+// 1 .. 3.3 x the reference's error depending on the shape.
+//
+// One kernel for every family because the contraction is the same band form for all of them:
+//
+//     D[j][c] = sum_u A[j][u] B[u][c],   A[j][u] = b[Hb + D j - u],   B[u][c] = staged[D (256 t + 16 c) + u],   u < Kw = Hb + 15 D + 1
+//
+// -- a tile is 16 consecutive outputs (rows j) of 16 columns c that lie 16 outputs apart: ONE tile row = 256 consecutive outputs, its input window 256 D + Kw samples.  The
+// samples are staged as raw float32 (LDS, 4 floats of padding per 16 D: the 64 lanes of a B read hit 64 different banks for every D), the taps as a zero-padded float32 array;
+// both operands are converted to float64 on the way into the matrix pipe (one v_cvt_f64_f32 each per 64-cycle MFMA).  A workgroup's unit is 1024 outputs (float: four tile
+// rows, one per wave) or 512 complex outputs (real taps never mix the components: they are staged as two real streams, wave = component x tile row).
+//
+// Which outputs: `flags` holds one byte per segment of the caller's main kernel (2^seg_shift outputs): non-zero = evaluate again (the main kernels write 1: outlier spread,
+// 2: a non-finite sample, 3: rejected by the guard); null = every output (the fused chain's guard, gated by the launch's verdict word `gate`).  A unit none of whose segments is
+// marked costs its workgroup a few byte loads.  A unit whose staged window holds a non-finite sample is evaluated as plain float32 sums in the reference's order instead, one
+// output at a time (0 x Inf in the zero part of the tap operand would spread the NaN to outputs whose window does not hold the sample; the classes +Inf / -Inf / NaN and their
+// reach -- exactly ntaps outputs -- are the reference's).
+//
+// Rate when EVERY segment is marked: the FP64 matrix pipe's 78.6 TFLOP/s = 16 multiply-adds per cycle and SIMD: 256 taps -> ~120 Gsamples/s (float), ~60 (complex); a
+// decimator by 8 with 1024 taps ~230 G input samples/s.  That is the price of a stream that is all rejection; ordinary streams never come here.
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace gr4 {
+
+using f64x4_e = __attribute__((ext_vector_type(4))) double;
+
+struct FirExactArgs {
+    const float*         x;          // the span: n_in samples per channel (complex: interleaved {re, im}), channel ch at x + ch * in_stride floats
+    const float*         hist;       // the Kh samples in front of x (channel ch at hist + ch * Kh samples); older samples read as zero
+    const float*         taps;       // float32 taps, channel ch at taps + ch * taps_stride
+    float*               y;          // n_out outputs per channel, channel ch at y + ch * out_stride floats
+    const unsigned char* flags;      // one byte per 2^seg_shift outputs (channel ch at flags + ch * flags_stride), or null: every output
+    const unsigned*      gate;       // optional: the kernel does nothing unless *gate != 0
+    long                 n_in, n_out, in_stride, out_stride, taps_stride, flags_stride;
+    int                  Kh, ntaps, D, cplx, seg_shift;
+    int                  Hb, Kw;     // samples in front of a tile's first output that its window holds (>= ntaps - 1), window length Hb + 15 D + 1 (a multiple of 16)
+    unsigned             div16D;     // ceil(2^32 / (16 D)): i / (16 D) = (i * div16D) >> 32 for the indices that occur
+    long                 n_units;
+};
+
+constexpr int kExUnit = 1024; // outputs (floats) per unit: 4 tile rows; complex: 512 outputs x 2 components
+
+__global__ __launch_bounds__(256, 1) void fir_exact_kernel(FirExactArgs a) {
+    if (a.gate != nullptr && __builtin_nontemporal_load(a.gate) == 0u) return;
+    extern __shared__ __attribute__((aligned(16))) float ex_smem[];
+    __shared__ int bad;
+    const int ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    const int NC = a.cplx ? 2 : 1, UO = kExUnit / NC, D = a.D, Hb = a.Hb, Kw = a.Kw; // components, outputs per component and unit
+    const float*         x     = a.x + (long)ch * a.in_stride;
+    const float*         hist  = a.hist + (long)ch * a.Kh * NC;
+    const float*         taps  = a.taps + (long)ch * a.taps_stride;
+    float*               y     = a.y + (long)ch * a.out_stride;
+    const unsigned char* flags = a.flags ? a.flags + (long)ch * a.flags_stride : nullptr;
+    const int L  = D * (UO - 1) + Hb + 1;                                  // staged samples per component
+    auto      ph = [&](int i) { return i + 4 * (int)(((unsigned long long)(unsigned)i * a.div16D) >> 32); }; // LDS position of staged sample i
+    const int Lp = ph(L - 1) + 4;
+    float*    tz = ex_smem;                    // tz[15 D + k] = b[k], zeros either side: k = Hb + D j - u runs over -15 D .. Kw - 1
+    float*    sg = ex_smem + ((Kw + 15 * D + 3) & ~3); // [NC][Lp]
+    auto xs = [&](long i, int c) -> float { // sample i of the stream, component c: history in front of x, zeros before that and past the end
+        if (i >= 0) return i < a.n_in ? x[i * NC + c] : 0.f;
+        return i >= -(long)a.Kh ? hist[((long)a.Kh + i) * NC + c] : 0.f;
+    };
+    for (int i = tid; i < Kw + 15 * D; i += 256) {
+        const int k = i - 15 * D;
+        tz[i]       = (k >= 0 && k < a.ntaps) ? taps[k] : 0.f;
+    }
+    const int comp = a.cplx ? (wave & 1) : 0, tr = a.cplx ? (wave >> 1) : wave; // this wave's component and tile row
+    for (long u = blockIdx.x; u < a.n_units; u += gridDim.x) {
+        const long ou = u * UO; // first output of the unit
+        bool       any = flags == nullptr;
+        if (!any) {
+            const long last = (ou + UO - 1 < a.n_out ? ou + UO - 1 : a.n_out - 1) >> a.seg_shift;
+            for (long s = ou >> a.seg_shift; s <= last; ++s) any = any || flags[s] != 0; // (uniform: every lane reads the same bytes)
+        }
+        if (!any) continue;
+        __syncthreads(); // (the previous unit's readers are done with the staged samples)
+        if (tid == 0) bad = 0;
+        __syncthreads();
+        const long s0 = (long)D * ou - Hb;
+        int        nf = 0;
+        for (int i = tid; i < L; i += 256) {
+            const int p = ph(i);
+            for (int c = 0; c < NC; ++c) {
+                const float v = xs(s0 + i, c);
+                nf |= (int)!(__builtin_fabsf(v) <= 3.4028234663852886e38f);
+                sg[c * Lp + p] = v;
+            }
+        }
+        if (nf) bad = 1;
+        __syncthreads();
+        auto marked = [&](long o) -> bool { return o < a.n_out && (flags == nullptr || flags[o >> a.seg_shift] != 0); };
+        if (bad) { // a non-finite sample in the window: plain float32 sums in the reference's order
+            for (int r = tid; r < UO; r += 256) {
+                const long o = ou + r;
+                if (!marked(o)) continue;
+                for (int c = 0; c < NC; ++c) {
+                    float     acc = 0.f;
+                    const int b0  = D * r + Hb;
+                    for (int k = 0; k < a.ntaps; ++k) acc = fmaf(tz[15 * D + k], sg[c * Lp + ph(b0 - k)], acc);
+                    y[o * NC + c] = acc;
+                }
+            }
+            continue;
+        }
+        if ((long)ou + 256L * tr >= a.n_out) continue; // (whole waves; no barrier below)
+        // this wave's tile row: B[u][c] = staged[D (256 tr + 16 c) + u], A[j][u] = tz[15 D + Hb + D j - u]
+        const float* sb = sg + comp * Lp + D * (256 * tr + 16 * col) + 4 * (16 * tr + col) + kq;
+        const float* ta = tz + 15 * D + Hb + D * col - kq;
+        f64x4_e      acc = {0., 0., 0., 0.};
+        const int    nk = Kw / 4, blk = 4 * D; // K-steps of 4; a pad of 4 floats every 16 D samples = every 4 D steps
+        for (int k0 = 0, pad = 0; k0 < nk; k0 += blk, pad += 4) {
+            const int kend = k0 + blk < nk ? k0 + blk : nk;
+            for (int k4 = k0; k4 < kend; k4 += 4) { // (Kw is a multiple of 16: whole groups of four K-steps)
+                float av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { av[q] = ta[-4 * (k4 + q)]; bv[q] = sb[4 * (k4 + q) + pad]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[q], (double)bv[q], acc, 0, 0, 0);
+            }
+        }
+        // D[row = kq + 4 r][col]: output ou + 256 tr + 16 col + kq + 4 r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long o = ou + 256L * tr + 16 * col + kq + 4 * r;
+            if (marked(o)) y[o * NC + comp] = (float)acc[r];
+        }
+    }
+}
+
+// Hb, Kw of the band form for (ntaps, D); false when the staged unit does not fit the CU's 160 KiB of LDS
+bool fir_exact_shape(int ntaps, int D, int cplx, int* Hb, int* Kw, size_t* lds_bytes) {
+    if (ntaps < 1 || D < 1 || D > 64) return false;
+    const int kw = (ntaps + 15 * D + 15) & ~15, hb = kw - 15 * D - 1, NC = cplx ? 2 : 1, UO = kExUnit / NC;
+    const long L  = (long)D * (UO - 1) + hb + 1, Lp = (L - 1) + 4 * ((L - 1) / (16 * D)) + 4;
+    const size_t bytes = (size_t)(((kw + 15 * D + 3) & ~3) + NC * Lp) * sizeof(float);
+    if (Hb) *Hb = hb;
+    if (Kw) *Kw = kw;
+    if (lds_bytes) *lds_bytes = bytes;
+    return bytes <= 158 * 1024;
+}
+
+// evaluates the marked outputs (flags == nullptr: all of them) of  y[o] = sum_k b[k] x[D o - k],  o < n_out.  Sizes in samples (float, or complex when cplx); strides in floats.
+int fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const float* d_taps, int ntaps, int D, int cplx, float* y, long n_out, const unsigned char* flags, int seg_shift,
+                     const unsigned* gate, hipStream_t st, unsigned nch = 1, long in_stride = 0, long out_stride = 0, long taps_stride = 0, long flags_stride = 0) {
+    FirExactArgs a{};
+    size_t       lds = 0;
+    if (!fir_exact_shape(ntaps, D, cplx, &a.Hb, &a.Kw, &lds)) return GR4HIP_UNSUPPORTED;
+    if (n_out <= 0) return GR4HIP_OK;
+    static PerDevice pd;
+    bool             first = false;
+    int              dev = 0, n_cu = pd.current(&first, &dev);
+    if (first) {
+        if (n_cu == 0) { set_error("fir_exact: no device"); return GR4HIP_NO_DEVICE; }
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        n_cu = -n_cu;
+        pd.done(dev, n_cu);
+    }
+    a.x = x; a.hist = hist; a.taps = d_taps; a.y = y; a.flags = flags; a.gate = gate;
+    a.n_in = n_in; a.n_out = n_out; a.in_stride = in_stride; a.out_stride = out_stride; a.taps_stride = taps_stride; a.flags_stride = flags_stride;
+    a.Kh = Kh; a.ntaps = ntaps; a.D = D; a.cplx = cplx; a.seg_shift = seg_shift;
+    a.div16D  = (unsigned)(((1ull << 32) + 16ull * D - 1) / (16ull * D));
+    a.n_units = ceil_div(n_out, (long)(kExUnit / (cplx ? 2 : 1)));
+    const unsigned gx = (unsigned)std::min<long>(a.n_units, std::max<long>(1, (long)n_cu * 4 / (long)nch));
+    hipLaunchKernelGGL(fir_exact_kernel, dim3(gx, nch), dim3(256), lds, st, a);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+} // namespace gr4

@@ -60,16 +60,17 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
                                                                                 const unsigned short* __restrict__ blk0 /*[channels] blocks of hf_block_units(KS)*/, float* __restrict__ y0, long n,
                                                                                 float* __restrict__ new_hist, long in_stride, long out_stride /*channel blockIdx.y*/,
                                                                                 int delay /*this pass filters x delayed by `delay` samples ...*/, int accum /*... and adds to y (slices of long filters)*/,
-                                                                                int seg_per_wg, int guard /*judge every segment's output / input power (see the header)*/) {
+                                                                                int seg_per_wg, int guard /*judge every segment's output / input power (see the header)*/,
+                                                                                unsigned char* __restrict__ flags0 /*one byte per segment: what fir_exact_kernel evaluates again behind this launch*/, long flags_stride,
+                                                                                float gthr_arg /*> 0: the guard's threshold instead of the table's (the last slice of a long filter judges the whole filter's sum)*/) {
     const float*          x     = x0 + (long)blockIdx.y * in_stride;
     const float*          hist  = hist0 + (long)blockIdx.y * Kh;
     const unsigned short* blk   = blk0 + (long)blockIdx.y * hf_block_units(KS);
     const u32x4_h*        afrag = reinterpret_cast<const u32x4_h*>(blk);
     const float           inv_t = *reinterpret_cast<const float*>(blk + KS * 1536);
-    const int             ntaps = *reinterpret_cast<const int*>(blk + KS * 1536 + 2);
-    const float           gthr  = *reinterpret_cast<const float*>(blk + KS * 1536 + 4);
-    const float*          tapsf = reinterpret_cast<const float*>(blk + KS * 1536 + 8);
+    const float           gthr  = gthr_arg > 0.f ? gthr_arg : *reinterpret_cast<const float*>(blk + KS * 1536 + 4);
     float*                y     = y0 + (long)blockIdx.y * out_stride;
+    unsigned char*        flags = flags0 + (long)blockIdx.y * flags_stride;
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kHfSeg + Hb; // staged samples per segment (a multiple of 16)
     constexpr int PL  = NS + 8 * (NS / 256) + 16;               // f16 elements per plane: one 16-byte chunk of padding per 256 samples (see P below)
     constexpr int NL4 = (NS / 4 + 255) / 256;                   // float4 loads a lane holds for the next segment
@@ -77,8 +78,6 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short pls[2][2 * PL];
     __shared__ __attribute__((aligned(16))) unsigned stat[2][12]; // per data segment parity: the four waves' largest magnitude bits, quietest non-zero groups of four, sums of squares
     __shared__ __attribute__((aligned(16))) float    ystat[2][4][16]; // per computed segment parity: the four waves' output powers per column of 256 outputs
-    __shared__ unsigned char noted[GR4_F16_MAX_SPW];              // per segment of this workgroup's run: what `note` says
-    static_assert(2 * PL * 2 >= (NS + 4 * (NS / 256 + 1)) * 4 && 2 * PL * 2 >= 2 * Kw * 4, "the float32 path stages a segment's raw samples in one plane buffer and the padded taps in the other");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
     auto P = [](int s_) { return s_ + 8 * (s_ >> 8); };
 
@@ -158,140 +157,14 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
     };
     const long nseg = (n + kHfSeg - 1) / kHfSeg, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
     if (sfirst >= slast) return; // (whole workgroups only: no barrier is skipped by part of one)
-    if (tid < GR4_F16_MAX_SPW) noted[tid] = 0;
+    if (!accum && tid < slast - sfirst) flags[sfirst + tid] = 0; // (a later slice of a long filter adds its marks to the earlier ones'; the barriers below order this store before any mark)
     const int tb = (wave >> 1) + 8 * (wave & 1); // waves 0, 1: the even tiles from 0 / 8; waves 2, 3: the odd tiles from 1 / 9
     const int sb = 256 * col + 16 * tb + 8 * kq;
-    // the float32 path: one segment's outputs as float32 products on the f32 matrix pipe (v_mfma_f32_16x16x4_f32: every product and partial sum an IEEE float32
-    // operation, the sums block-wise).  `stage` is a plane buffer nobody needs at that moment: the segment's NS raw samples go there, 4 floats
-    // of padding per 256 (lane (col, kq) reads word 256 col + 16 t + 4 k4 + kq: 64 different banks), the tap operand comes from the float taps of the table.
-    // Same tile map as the f16 path; about the rate of the library's f32 matrix-pipe FIR kernel while it runs.  Called by the whole workgroup.
-    auto slow_segment = [&](long sg, unsigned short* stage16) {
-        float*     stg  = reinterpret_cast<float*>(stage16);
-        const long seg0 = sg * kHfSeg;
-        auto       Pf   = [](int i) { return i + 4 * (i >> 8); };
-        if (sg > 0) load_next(nxa, seg0); // (the prefetch registers are free by now)
-        else load_general(nxa, 0);
-#pragma unroll
-        for (int u = 0; u < NL4; ++u) {
-            const int q = tid + 256 * u;
-            if (256 * (u + 1) <= NS / 4 || q < NS / 4) *reinterpret_cast<float4*>(stg + Pf(4 * q)) = nxa[u]; // (4 consecutive samples never straddle a pad: pads sit at multiples of 256)
-        }
-        float* tz = reinterpret_cast<float*>(stage16 == pls[0] ? pls[1] : pls[0]); // the taps with Kw zeros either side: tz[Kw + k] = b[k]
-        for (int i = tid; i < 2 * Kw; i += 256) tz[i] = (i >= Kw && i - Kw < ntaps) ? tapsf[i - Kw] : 0.f;
-        __syncthreads();
-        f32x4_h acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
-        const float* ta = tz + Kw + Hb + col - kq; // the tap operand of K-step k4: A[row = col][k = kq] = b[Hb + col - (4 k4 + kq)]
-        for (int k0 = 0; k0 < Kw / 4; k0 += 8) {   // (Kw / 4 = 8 KS; chunks of eight K-steps keep 40 LDS reads in flight without hoisting all 360 of them into registers)
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const int   k4 = k0 + kk;
-                const float av = ta[-4 * k4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, stg[Pf(256 * col + 16 * (tb + 2 * j) + 4 * k4 + kq)], acc[j], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long o = seg0 + 256L * col + 16 * (tb + 2 * j) + 4 * kq;
-            if (o + 3 < n) {
-                float4 w = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-                if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w; }
-                *reinterpret_cast<float4*>(y + o) = w;
-            } else {
-                for (int r = 0; r < 4; ++r)
-                    if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + acc[j][r];
-            }
-        }
-        __syncthreads(); // (the buffer is staged again by the next noted segment)
-    };
-    // a segment that holds a non-finite sample: plain float32 sums from global memory, one output at a time -- the reference's classes (+Inf, -Inf, NaN) on exactly the
-    // ntaps outputs whose window holds the sample (the matrix pipe would multiply it with the zero padding of the tap operand).  Very slow; such samples are not ordinary data.
-    auto exact_segment = [&](long sg) {
-        for (int r = 0; r < kHfSeg / 256; ++r) {
-            const long o = sg * kHfSeg + tid + 256 * r;
-            if (o >= n) break;
-            float acc = 0.f;
-            for (int k = 0; k < ntaps; ++k) acc = fmaf(tapsf[k], xs(o - delay - k), acc);
-            y[o] = (accum ? y[o] : 0.f) + acc;
-        }
-    };
-    // a segment the guard has rejected, again: samples and taps as THREE f16 terms (33 bits: the float32 values themselves), the six products of order <= 2 -- every product
-    // exact to 2^-33, the sums the matrix pipe's float32 accumulators: float32 products at twice the f16 path's matrix-pipe time (the f32 pipe: 5 times).  The planes of both
-    // buffers are free behind the run (terms 1, 2 in the first, term 3 in the second), the third tap plane comes from the table.  Same tile map, same way out.
-    auto redo_segment = [&](long sg) {
-        const long seg0 = sg * kHfSeg;
-        u32x4_h    a3[3][KS];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a3[p][ks] = afrag[(p * KS + ks) * 64 + lane];
-        if (sg > 0) load_next(nxa, seg0);
-        else load_general(nxa, 0);
-        float mf = 0.f;
-#pragma unroll
-        for (int u = 0; u < NL4; ++u) mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fmaxf(__builtin_fabsf(nxa[u].x), __builtin_fabsf(nxa[u].y))), __builtin_fmaxf(__builtin_fabsf(nxa[u].z), __builtin_fabsf(nxa[u].w)));
-        const unsigned mw = hf_wave_reduce_u32(__float_as_uint(mf), [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
-        if (lane == 0) stat[0][wave] = mw;
-        __syncthreads();
-        const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[0][0]);
-        const int   e  = (int)(__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))) >> 23), ec = e < 15 ? 15 : (e > 254 ? 254 : e);
-        const float s = __uint_as_float((unsigned)(268 - ec) << 23), inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
-#pragma unroll
-        for (int u = 0; u < NL4; ++u) {
-            const int q = tid + 256 * u;
-            if (256 * (u + 1) <= NS / 4 || q < NS / 4) {
-                unsigned h0, m0, l0, h1, m1, l1;
-                hf_split2x3(nxa[u].x, nxa[u].y, s, h0, m0, l0);
-                hf_split2x3(nxa[u].z, nxa[u].w, s, h1, m1, l1);
-                *reinterpret_cast<uint2*>(pls[0] + P(4 * q))      = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(pls[0] + PL + P(4 * q)) = make_uint2(m0, m1);
-                *reinterpret_cast<uint2*>(pls[1] + P(4 * q))      = make_uint2(l0, l1);
-            }
-        }
-        __syncthreads();
-        f32x4_h c[4], d[4], g[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = d[j] = g[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const int     qo = P(sb + 32 * m);
-            const f16x8_h b1 = *reinterpret_cast<const f16x8_h*>(pls[0] + qo), b2 = *reinterpret_cast<const f16x8_h*>(pls[0] + PL + qo), b3 = *reinterpret_cast<const f16x8_h*>(pls[1] + qo);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ks = m - j;
-                if (ks < 0 || ks >= KS) continue;
-                const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a3[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a3[1][ks]), a3_ = __builtin_bit_cast(f16x8_h, a3[2][ks]);
-                c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[j], 0, 0, 0);
-                d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, d[j], 0, 0, 0);
-                g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b3, g[j], 0, 0, 0);
-                d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, d[j], 0, 0, 0);
-                g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, g[j], 0, 0, 0);
-                g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3_, b1, g[j], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long o = seg0 + 256L * col + 16 * (tb + 2 * j) + 4 * kq;
-            float      v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = ((c[j][r] + (d[j][r] + g[j][r] * (1.f / 2048.f)) * (1.f / 2048.f)) * inv_t) * inv_s;
-            if (o + 3 < n) {
-                float4 w = make_float4(v[0], v[1], v[2], v[3]);
-                if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w; }
-                *reinterpret_cast<float4*>(y + o) = w;
-            } else {
-                for (int r = 0; r < 4; ++r)
-                    if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + v[r];
-            }
-        }
-        __syncthreads(); // (the planes are staged again by the next noted segment)
-    };
-    // segments for the second evaluation are only NOTED while the run is under way (a byte per segment of the run in LDS: masks in scalar registers spilled) and evaluated behind
-    // it, when the tap fragments and the prefetch registers are dead -- inside the loop the call would sit on 110 live registers and spill them into the f16 loop
-    auto note = [&](long sg, int kind) { // 1: float32 products on the f32 pipe (the spread); 2: plain float32 sums (a non-finite sample); 3: three-term f16 products (the guard)
-        if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
+    // segments this kernel cannot vouch for are only MARKED (a byte per segment in `flags`): fir_exact_kernel (fir_exact.hip), launched behind this one, evaluates their
+    // outputs again on the FP64 matrix pipe.  (Until round 5 the second evaluation sat in this kernel behind the run: three more code paths, and their 110 live registers
+    // spilled around the f16 loop.)
+    auto note = [&](long sg, int kind) { // 1: the spread of the segment's samples is beyond the block exponent; 2: a non-finite sample; 3: rejected by the guard
+        if (tid == 0) flags[sg] = (unsigned char)(accum ? (flags[sg] | kind) : kind);
     };
     // the guard's verdict on segment sg (its output powers are in ystat[sg & 1], a barrier ago): rejected -> noted for the second evaluation.  After two rejections in a row the
     // first evaluation of the following segments is skipped (they are noted unseen) but for every eighth, which probes whether the stream has changed: a stream that is all
@@ -366,12 +239,10 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
                     if (!one) v[r] *= k2;
                 }
                 const int oo = 256 * col + 16 * (tb + 2 * j) + 4 * kq;
-                // the guard's output power: the outputs of the span only (past its end the staged zeros make the filter ring: not what it passes)
-                if (whole) py = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], py))));
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (seg0 + oo + r < n) py = fmaf(v[r], v[r], py);
+                // the guard's output power: the outputs of the span only (past its end the staged zeros make the filter ring: not what it passes); the slices of a long
+                // filter: of the sums this launch leaves in y (the last slice's are the filter's outputs)
                 if (full) {
+                    py = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], py))));
                     const u32x4_h w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                     __builtin_amdgcn_raw_buffer_store_b128(w, ry, oo * 4, 0, 0);
                 } else {
@@ -379,10 +250,15 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
                     if (o + 3 < n) {
                         float4 w = make_float4(v[0], v[1], v[2], v[3]);
                         if (accum) { const float4 p = *reinterpret_cast<const float4*>(y + o); w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w; }
+                        py = fmaf(w.x, w.x, fmaf(w.y, w.y, fmaf(w.z, w.z, fmaf(w.w, w.w, py))));
                         *reinterpret_cast<float4*>(y + o) = w;
                     } else {
                         for (int r = 0; r < 4; ++r)
-                            if (o + r < n) y[o + r] = (accum ? y[o + r] : 0.f) + v[r];
+                            if (o + r < n) {
+                                const float w = (accum ? y[o + r] : 0.f) + v[r];
+                                py   = fmaf(w, w, py);
+                                y[o + r] = w;
+                            }
                     }
                 }
             }
@@ -407,15 +283,6 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         if (sg + 1 < slast) segment(sg + 1, pls[1], pls[0], nxb, nxa);
     }
     if (guard) judge(slast - 1, px_prev);
-    __syncthreads();
-    for (int i = 0; i < seg_per_wg; ++i) { // (uniform: every lane reads the same bytes)
-        const int kind = noted[i];
-        if (kind == 3) {
-            __builtin_amdgcn_s_waitcnt(0); // this wave's stores of the first evaluation have landed (and everybody's, behind redo_segment's first barrier) before other lanes write the same outputs
-            redo_segment(sfirst + i);
-        } else if (kind == 1) slow_segment(sfirst + i, pls[0]);
-        else if (kind == 2) exact_segment(sfirst + i);
-    }
     if (new_hist != nullptr && blockIdx.x == 0 && blockIdx.y == 0) { // the other half of the caller's ping-pong pair: nobody reads it in this launch
         for (int h = tid; h < Kh; h += 256) {
             const long i = n - Kh + h;
@@ -434,12 +301,11 @@ constexpr int kHfSegC = 2048;
 template <int KS>
 __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_kernel(const float2* __restrict__ x, const float2* __restrict__ hist /*the Kh samples in front of x*/, int Kh,
                                                                                     const unsigned short* __restrict__ blk /*one block of hf_block_units(KS)*/, float2* __restrict__ y, long n,
-                                                                                    float2* __restrict__ new_hist, int seg_per_wg, int guard) {
+                                                                                    float2* __restrict__ new_hist, int seg_per_wg, int guard,
+                                                                                    unsigned char* __restrict__ flags /*one byte per segment: what fir_exact_kernel evaluates again behind this launch*/) {
     const u32x4_h* afrag = reinterpret_cast<const u32x4_h*>(blk);
     const float    inv_t = *reinterpret_cast<const float*>(blk + KS * 1536);
-    const int      ntaps = *reinterpret_cast<const int*>(blk + KS * 1536 + 2);
     const float    gthr  = *reinterpret_cast<const float*>(blk + KS * 1536 + 4);
-    const float*   tapsf = reinterpret_cast<const float*>(blk + KS * 1536 + 8);
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kHfSegC + Hb; // staged complex samples per segment (a multiple of 16)
     constexpr int PL  = NS + 8 * (NS / 128 + 1) + 16;            // f16 elements per plane: one 16-byte chunk of padding per 128 samples (the columns are 128 samples apart)
     constexpr int NL4 = (NS / 2 + 255) / 256;                    // float4 loads (two complex samples each) a lane holds for the next segment
@@ -447,8 +313,6 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
     __shared__ __attribute__((aligned(16))) unsigned short pls[2][4 * PL]; // planes re1, re2, im1, im2
     __shared__ __attribute__((aligned(16))) unsigned stat[2][12];
     __shared__ __attribute__((aligned(16))) float    ystat[2][4][16]; // (per column of 128 outputs)
-    __shared__ unsigned char noted[GR4_F16_MAX_SPW];
-    static_assert(4 * PL * 2 >= (2 * (NS + 4 * (NS / 128 + 1))) * 4, "the float32 path stages both components of a segment in one plane buffer");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
     auto P = [](int s_) { return s_ + 8 * (s_ >> 7); };
 
@@ -527,141 +391,11 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
     };
     const int tb = (wave >> 1) + 4 * (wave & 1); // waves 0, 1: tiles {0, 2} / {4, 6}; waves 2, 3: tiles {1, 3} / {5, 7}
     const int sb = 128 * col + 16 * tb + 8 * kq;
-    // the float32 path (see the float kernel): both components staged as float32 in one plane buffer, the taps in the other
-    auto slow_segment = [&](long sg, unsigned short* stage16) {
-        constexpr int SF = NS + 4 * (NS / 128 + 1); // floats per component: 4 floats of padding per 128 (lane (col, kq) reads word 128 col + 16 t + 4 k4 + kq: 64 different banks)
-        float*     stg  = reinterpret_cast<float*>(stage16);
-        const long seg0 = sg * kHfSegC;
-        auto       Pf   = [](int i) { return i + 4 * (i >> 7); };
-        if (sg > 0) load_next(nxa, seg0);
-        else load_general(nxa, 0);
-#pragma unroll
-        for (int u = 0; u < NL4; ++u) {
-            const int q = tid + 256 * u;
-            if (256 * (u + 1) <= NS / 2 || q < NS / 2) {
-                *reinterpret_cast<float2*>(stg + Pf(2 * q))      = make_float2(nxa[u].x, nxa[u].z);
-                *reinterpret_cast<float2*>(stg + SF + Pf(2 * q)) = make_float2(nxa[u].y, nxa[u].w);
-            }
-        }
-        float* tz = reinterpret_cast<float*>(stage16 == pls[0] ? pls[1] : pls[0]);
-        for (int i = tid; i < 2 * Kw; i += 256) tz[i] = (i >= Kw && i - Kw < ntaps) ? tapsf[i - Kw] : 0.f;
-        __syncthreads();
-        f32x4_h acc[4]; // (tile 0 re, tile 0 im, tile 1 re, tile 1 im)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
-        const float* ta = tz + Kw + Hb + col - kq;
-        for (int k0 = 0; k0 < Kw / 4; k0 += 8) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const int   k4 = k0 + kk;
-                const float av = ta[-4 * k4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, stg[(j & 1) * SF + Pf(128 * col + 16 * (tb + 2 * (j >> 1)) + 4 * k4 + kq)], acc[j], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const long o = seg0 + 128L * col + 16 * (tb + 2 * jj) + 4 * kq;
-            for (int r = 0; r < 4; ++r)
-                if (o + r < n) y[o + r] = make_float2(acc[2 * jj][r], acc[2 * jj + 1][r]);
-        }
-        __syncthreads();
-    };
-    auto exact_segment = [&](long sg) { // a non-finite sample: plain float32 sums, the reference's classes on exactly the ntaps outputs whose window holds it
-        for (int r = 0; r < kHfSegC / 256; ++r) {
-            const long o = sg * kHfSegC + tid + 256 * r;
-            if (o >= n) break;
-            float ar = 0.f, ai = 0.f;
-            for (int k = 0; k < ntaps; ++k) {
-                const float2 v = xs(o - k);
-                ar = fmaf(tapsf[k], v.x, ar);
-                ai = fmaf(tapsf[k], v.y, ai);
-            }
-            y[o] = make_float2(ar, ai);
-        }
-    };
     const long nseg = (n + kHfSegC - 1) / kHfSegC, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
     if (sfirst >= slast) return;
-    if (tid < GR4_F16_MAX_SPW) noted[tid] = 0;
-    // a segment the guard has rejected, again with three-term f16 products (see the float kernel): terms 1, 2 of both components in the first buffer's four planes, term 3
-    // in the second buffer's first two
-    auto redo_segment = [&](long sg) {
-        const long seg0 = sg * kHfSegC;
-        u32x4_h    a3[3][KS];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a3[p][ks] = afrag[(p * KS + ks) * 64 + lane];
-        if (sg > 0) load_next(nxa, seg0);
-        else load_general(nxa, 0);
-        float mf = 0.f;
-#pragma unroll
-        for (int u = 0; u < NL4; ++u) mf = __builtin_fmaxf(__builtin_fmaxf(mf, __builtin_fmaxf(__builtin_fabsf(nxa[u].x), __builtin_fabsf(nxa[u].y))), __builtin_fmaxf(__builtin_fabsf(nxa[u].z), __builtin_fabsf(nxa[u].w)));
-        const unsigned mw = hf_wave_reduce_u32(__float_as_uint(mf), [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
-        if (lane == 0) stat[0][wave] = mw;
-        __syncthreads();
-        const uint4 m4 = *reinterpret_cast<const uint4*>(&stat[0][0]);
-        const int   e  = (int)(__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))) >> 23), ec = e < 15 ? 15 : (e > 254 ? 254 : e);
-        const float s = __uint_as_float((unsigned)(268 - ec) << 23), inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
-#pragma unroll
-        for (int u = 0; u < NL4; ++u) {
-            const int q = tid + 256 * u;
-            if (256 * (u + 1) <= NS / 2 || q < NS / 2) {
-                unsigned rh, rm, rl, ih, im, il;
-                hf_split2x3(nxa[u].x, nxa[u].z, s, rh, rm, rl);
-                hf_split2x3(nxa[u].y, nxa[u].w, s, ih, im, il);
-                const int e2 = P(2 * q);
-                *reinterpret_cast<unsigned*>(pls[0] + e2)          = rh;
-                *reinterpret_cast<unsigned*>(pls[0] + PL + e2)     = rm;
-                *reinterpret_cast<unsigned*>(pls[0] + 2 * PL + e2) = ih;
-                *reinterpret_cast<unsigned*>(pls[0] + 3 * PL + e2) = im;
-                *reinterpret_cast<unsigned*>(pls[1] + e2)          = rl;
-                *reinterpret_cast<unsigned*>(pls[1] + PL + e2)     = il;
-            }
-        }
-        __syncthreads();
-        f32x4_h c[4], d[4], g[4]; // index 2 tile + component
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = d[j] = g[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const int qo = P(sb + 32 * m);
-            f16x8_h   b1[2], b2[2], b3[2];
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
-                b1[cp] = *reinterpret_cast<const f16x8_h*>(pls[0] + 2 * cp * PL + qo);
-                b2[cp] = *reinterpret_cast<const f16x8_h*>(pls[0] + (2 * cp + 1) * PL + qo);
-                b3[cp] = *reinterpret_cast<const f16x8_h*>(pls[1] + cp * PL + qo);
-            }
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int ks = m - jj;
-                if (ks < 0 || ks >= KS) continue;
-                const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a3[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a3[1][ks]), a3_ = __builtin_bit_cast(f16x8_h, a3[2][ks]);
-#pragma unroll
-                for (int cp = 0; cp < 2; ++cp) {
-                    const int j = 2 * jj + cp;
-                    c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[cp], c[j], 0, 0, 0);
-                    d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2[cp], d[j], 0, 0, 0);
-                    g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b3[cp], g[j], 0, 0, 0);
-                    d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1[cp], d[j], 0, 0, 0);
-                    g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2[cp], g[j], 0, 0, 0);
-                    g[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3_, b1[cp], g[j], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const long o = seg0 + 128L * col + 16 * (tb + 2 * jj) + 4 * kq;
-            for (int r = 0; r < 4; ++r)
-                if (o + r < n)
-                    y[o + r] = make_float2(((c[2 * jj][r] + (d[2 * jj][r] + g[2 * jj][r] * (1.f / 2048.f)) * (1.f / 2048.f)) * inv_t) * inv_s,
-                                           ((c[2 * jj + 1][r] + (d[2 * jj + 1][r] + g[2 * jj + 1][r] * (1.f / 2048.f)) * (1.f / 2048.f)) * inv_t) * inv_s);
-        }
-        __syncthreads();
-    };
-    auto note = [&](long sg, int kind) { // 1: float32 products on the f32 pipe (the spread); 2: plain float32 sums (a non-finite sample); 3: three-term f16 products (the guard)
-        if (tid == 0) noted[sg - sfirst] = (unsigned char)kind;
+    if (tid < slast - sfirst) flags[sfirst + tid] = 0; // (the barriers below order this store before any mark)
+    auto note = [&](long sg, int kind) { // 1: the spread is beyond the block exponent; 2: a non-finite sample; 3: rejected by the guard -> fir_exact_kernel behind this launch
+        if (tid == 0) flags[sg] = (unsigned char)kind;
     };
     int  streak = 0; // (see the float kernel)
     auto judge = [&](long sg, float px) {
@@ -775,15 +509,6 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         if (sg + 1 < slast) segment(sg + 1, pls[1], pls[0], nxb, nxa);
     }
     if (guard) judge(slast - 1, px_prev);
-    __syncthreads();
-    for (int i = 0; i < seg_per_wg; ++i) {
-        const int kind = noted[i];
-        if (kind == 3) {
-            __builtin_amdgcn_s_waitcnt(0);
-            redo_segment(sfirst + i);
-        } else if (kind == 1) slow_segment(sfirst + i, pls[0]);
-        else if (kind == 2) exact_segment(sfirst + i);
-    }
     if (new_hist != nullptr && blockIdx.x == 0) {
         for (int h = tid; h < Kh; h += 256) {
             const long i = n - Kh + h;
@@ -836,7 +561,7 @@ bool fir_f16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::v
         const int nt = (int)ntaps;
         double    h2 = 0;
         for (size_t k = 0; k < ntaps; ++k) h2 += (double)taps[k] * taps[k];
-        const float gthr = (float)(h2 / 4096.0);
+        const float gthr = (float)(h2 / 128.0); // (fir.hip, kGuardSegmentRatio)
         std::memcpy(blk + KS * 1536, &inv_t, 4);
         std::memcpy(blk + KS * 1536 + 2, &nt, 4);
         std::memcpy(blk + KS * 1536 + 4, &gthr, 4);
@@ -847,15 +572,16 @@ bool fir_f16_make_afrag(const float* taps_all, size_t ntaps, int* KS_out, std::v
 }
 
 // y[i] = sum_k b[k] x[i - delay - k] (+ y[i] when accum), i < n; hist = the Kh samples in front of x; x and y 16-byte aligned, strides multiples of 4
+// flags: nch x ceil(n / 4096) bytes (channel c at flags + c * flags_stride): the segments fir_exact_launch evaluates again behind the (last) launch
 int fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum,
-                   int guard) {
+                   int guard, unsigned char* flags, long flags_stride, float gthr) {
     if (KS < 3 || KS > 9 || 32 * KS - 16 + delay > kHfSeg) return GR4HIP_UNSUPPORTED;
     const auto tb   = static_cast<const unsigned short*>(table);
     const long nseg = ceil_div(n, (long)kHfSeg);
     const long wgs  = KS <= 5 ? 2 * GR4_F16_TARGET_WGS : GR4_F16_TARGET_WGS; // (narrow windows: shorter runs measured +3 % -- 64 taps 620 -> 642 Gsamples/s --, wide ones -1 %)
     const int  spw  = (int)std::min<long>(std::max<long>(nseg * (long)nch / wgs, 1), GR4_F16_MAX_SPW); // segments per workgroup: the prologue (tap fragments, first staging) once per run
     const dim3 grid((unsigned)ceil_div(nseg, (long)spw), nch);
-#define GR4_HF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_f16x2_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, tb, y, n, new_hist, in_stride, out_stride, delay, accum, spw, guard); break
+#define GR4_HF_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_f16x2_kernel<K>, grid, dim3(256), 0, st, x, hist, Kh, tb, y, n, new_hist, in_stride, out_stride, delay, accum, spw, guard, flags, flags_stride, gthr); break
     switch (KS) {
         GR4_HF_CASE(3);
         GR4_HF_CASE(4);
@@ -872,7 +598,7 @@ int fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, co
 }
 
 // the same on complex samples (real taps); hist = the Kh complex samples in front of x; x and y 16-byte aligned; `table` from fir_f16_make_afrag (one channel)
-int fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard) {
+int fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard, unsigned char* flags /*ceil(n / 2048) bytes*/) {
     if (KS < 3 || KS > 9) return GR4HIP_UNSUPPORTED;
     const auto tb   = static_cast<const unsigned short*>(table);
     const auto xc   = reinterpret_cast<const float2*>(x), hc = reinterpret_cast<const float2*>(hist);
@@ -880,7 +606,7 @@ int fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh
     const long nseg = ceil_div(n, (long)kHfSegC);
     const int  spw  = (int)std::min<long>(std::max<long>(nseg / GR4_F16_TARGET_WGS, 1), GR4_F16_MAX_SPW);
     const dim3 grid((unsigned)ceil_div(nseg, (long)spw));
-#define GR4_HFC_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_f16x2_c32_kernel<K>, grid, dim3(256), 0, st, xc, hc, Kh, tb, yc, n, nh, spw, guard); break
+#define GR4_HFC_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_f16x2_c32_kernel<K>, grid, dim3(256), 0, st, xc, hc, Kh, tb, yc, n, nh, spw, guard, flags); break
     switch (KS) {
         GR4_HFC_CASE(3);
         GR4_HFC_CASE(4);
