@@ -12,8 +12,10 @@
 // Long spans leave this kernel: float 33..256 taps and polyphase decimators go to the MFMA kernels of fir_batched.hip, complex <= 256 taps
 // to the frequency-domain kernel of chain_fused.hip (gr4hip_fir_process below decides).
 #include "common.hpp"
+#include "fir_exact.hpp"
 #include "ewise.hpp"
 #include "fir_window.hpp"
+#include "fir_f16_common.hpp" // (hf_wave_sum)
 
 namespace gr4 {
 
@@ -23,11 +25,17 @@ namespace gr4 {
 // stream index of x[0]); the carried history holds what the prologue made of earlier samples and is taken as it lies (the next history this launch writes is
 // made of prologue OUTPUTS too) -- exactly the filter's memory when the blocks run one after the other; `post` is applied to every output sample before its
 // store (post.pos = absolute index of y[0]).
+// gthr > 0: the workgroup judges its own outputs like the matrix-pipe kernels do (fir_f16.hip): output power (of its quietest wave) below gthr x the power of the samples it
+// was given = the filter removes nearly everything, where ANY float32 sum -- this one phase by phase, the reference's tap by tap -- shows its rounding against the output
+// (measured, complex decimate-by-2, tone near fs / 2: 12 x the reference order's error).  Such a workgroup evaluates its outputs again from the samples it has staged, with
+// float64 products and sums (one rounding at the end): no second launch, hooks included (the staged samples are the prologue's outputs).  Non-finite power either side
+// compares false: those outputs keep the float32 sums and with them the reference's classes.
 template <int S, int BS, bool HOOK>
 __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ x, const float* __restrict__ hist, const float* __restrict__ tp,
                                                        float* __restrict__ y, long n_in, long n_out, int hcap, int D, int G, float* __restrict__ new_hist,
-                                                       EwiseHook pre, EwiseHook post) {
+                                                       EwiseHook pre, EwiseHook post, float gthr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float judge_red[2 * (BS / 64)];
     constexpr int R  = kFirR;
     constexpr int E  = 4 / S;
     const int     Lf = BS * R + 4 * G; // floats per phase row
@@ -140,6 +148,42 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
         }
     }
 
+    if (gthr > 0.f) {
+        float px = 0.f, py = 0.f;
+        for (int p = 0; p < D; ++p) { // the samples this lane's outputs sit on: every staged sample of the workgroup's own span exactly once
+            const float4 a = *reinterpret_cast<const float4*>(xl + (size_t)p * Lf + c0), b = *reinterpret_cast<const float4*>(xl + (size_t)p * Lf + c0 + 4);
+            px += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) py = fmaf(acc[r], acc[r], py);
+        px = hf_wave_sum(px);
+        py = hf_wave_sum(py);
+        if ((tid & 63) == 0) { judge_red[tid >> 6] = px; judge_red[BS / 64 + (tid >> 6)] = py; }
+        __syncthreads();
+        px = 0.f;
+        py = judge_red[BS / 64];
+#pragma unroll
+        for (int w = 0; w < BS / 64; ++w) { px += judge_red[w]; py = fminf(py, judge_red[BS / 64 + w]); } // (fminf drops a NaN: the test below sees it through px, or the wave's outputs are NaN anyway)
+        bool finite = true;
+#pragma unroll
+        for (int w = 0; w < BS / 64; ++w) finite = finite && judge_red[BS / 64 + w] < 3.0e38f;
+        if (finite && py * (float)(BS / 64) * (float)D < gthr * px) { // (uniform over the workgroup)
+            double a64[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a64[r] = 0.0;
+            for (int p = 0; p < D; ++p) {
+                const float* row = xl + (size_t)p * Lf + c0;
+                const float* tg  = bl + (size_t)p * Qp;
+                for (int q = 0; q < Qp; ++q) { // tap b[q D + p] meets the phase-p sample q places back
+                    const double t = (double)tg[q];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) a64[r] = __builtin_fma(t, (double)row[r - q * S], a64[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = (float)a64[r];
+        }
+    }
     const long of    = M0 * S + (long)tid * R; // first output float of this lane
     const long nf    = n_out * S;
     if constexpr (HOOK) {
@@ -239,9 +283,6 @@ int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float*
 int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard, unsigned char* flags);
 int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard,
                     unsigned char* flags, long flags_stride, float gthr);
-// fir_exact.hip: the marked outputs of y[o] = sum_k b[k] x[D o - k] again on the FP64 matrix pipe (flags: one byte per 2^seg_shift outputs; null: every output)
-int  fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const float* d_taps, int ntaps, int D, int cplx, float* y, long n_out, const unsigned char* flags, int seg_shift,
-                      const unsigned* gate, hipStream_t st, unsigned nch = 1, long in_stride = 0, long out_stride = 0, long taps_stride = 0, long flags_stride = 0);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
 void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* KS_out, int* Hb_out, std::vector<unsigned short>* af, bool cplx);
 int  fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist,
@@ -278,6 +319,7 @@ struct gr4hip_fir {
     int                G = 0;      // tap groups per phase
     DeviceBuffer       d_taps;     // [D][Qpad]
     DeviceBuffer       d_tapsf;    // the taps as they are (what fir_exact_kernel multiplies with)
+    double             tap_power = 0; // sum b^2 of `taps` (the guard's thresholds are multiples of it)
     DeviceBuffer       d_flags;    // one byte per segment of the f16 matrix-pipe kernels' last launch: the segments fir_exact_kernel evaluates again behind it
     DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
     int                cur = 0;
@@ -338,6 +380,8 @@ static int fir_upload_taps(gr4hip_fir* f) {
     GR4_HIP_TRY(hipMemcpy(f->d_taps.ptr, tp.data(), tp.size() * sizeof(float), hipMemcpyHostToDevice));
     rc = f->d_tapsf.ensure(K * sizeof(float));
     if (rc) return rc;
+    f->tap_power = 0;
+    for (float b : f->taps) f->tap_power += (double)b * b;
     GR4_HIP_TRY(hipMemcpy(f->d_tapsf.ptr, f->taps.data(), K * sizeof(float), hipMemcpyHostToDevice));
     return GR4HIP_OK;
 }
@@ -362,7 +406,7 @@ static int fir_launch_h(const gr4hip_fir* f, const float* x, const float* hist, 
     const long TOs  = BS * kFirR / S;
     const long grid = ceil_div(n_out, TOs);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, st, x, hist, (const float*)f->d_taps.ptr, y, n_in, n_out,
-                       (int)f->hcap, (int)f->decim, f->G, new_hist, hk.pre, hk.post);
+                       (int)f->hcap, (int)f->decim, f->G, new_hist, hk.pre, hk.post, f->guard_mode != GR4HIP_GUARD_OFF && f->ntaps > 1 ? (float)(f->tap_power * kGuardSegmentRatio) : 0.f);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
@@ -586,6 +630,10 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     const float* hist = (const float*)f->d_hist[f->cur].ptr;
     size_t       done = 0; // samples already produced by the frequency-domain path
     bool         mfma_wrote_hist = false;
+    // a kernel that does not judge its own segments (the float32 matrix-pipe forms, the three-term bf16 direct forms) notes here where its part of the span starts and which
+    // samples lie in front of it: fir_judge_kernel + fir_exact_kernel follow it at the end of the call (every kernel of this file answers to the same guard)
+    size_t       unj_from = SIZE_MAX;
+    const float* unj_hist = nullptr;
     // complex<float>, no decimation, <= 256 taps, long input: whole 8192-sample frames go through the fused FFT -> xH -> inverse
     // kernel (2 transforms per frame instead of 1024 flop per sample); the direct-form kernel finishes the remainder
     // (<= 96 taps: the direct form is faster -- write-bound 300 .. 356 Gsamples/s up to 64 taps, 311 .. 275 at 65 .. 96 taps on the bf16 matrix pipe, against
@@ -685,6 +733,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         float* nh = done == 0 ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
         rc = fir_bf16_c32_launch(f->bfKS, x + done * 2, (long)(n_in - done), hist, (int)f->hcap, f->d_bfrag.ptr, y + done * 2, st, nh);
         if (rc) return rc;
+        unj_from = done; unj_hist = hist;
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
@@ -709,6 +758,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         float* nh = (done == 0 && (int)f->hcap == f->mKp) ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
         rc = fir_mfma_c32_launch(f->mKS, x + done * 2, (long)(n_in - done), hk, (const float*)f->d_afrag.ptr, y + done * 2, st, nh);
         if (rc) return rc;
+        unj_from = done; unj_hist = hist;
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
@@ -748,8 +798,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             // every segment judges its own output / input power (fir_f16.hip); of a long filter's slices the LAST one does, on the sums it leaves in y (the whole filter's
             // outputs) against the whole filter's threshold.  Marked segments -- rejected, or with samples the block exponent cannot carry in ANY slice -- are evaluated
             // again with all the taps on the FP64 matrix pipe (fir_exact.hip)
-            double h2 = 0;
-            for (float b : f->taps) h2 += (double)b * b;
+            const double h2 = f->tap_power;
             for (size_t p = 0; p < nslice && !rc; ++p)
                 rc = fir_f16_launch(f->hf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_hfrag.ptr + f->hf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0,
                                     p + 1 == nslice && f->guard_mode != GR4HIP_GUARD_OFF, (unsigned char*)f->d_flags.ptr, 0, nslice > 1 ? (float)(h2 * kGuardSegmentRatio) : 0.f);
@@ -784,6 +833,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         for (size_t p = 0; p < nslice && !rc; ++p)
             rc = fir_bf16_launch(f->bf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_bfrag.ptr + f->bf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0);
         if (rc) return rc;
+        unj_from = 0; unj_hist = hist;
         done = n_in;
         mfma_wrote_hist = true;
     }
@@ -811,6 +861,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         float* nh = (int)f->hcap == f->mKp ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
         rc = fir_mfma_launch(f->mKS, x, (long)n_in, hk, (const float*)f->d_afrag.ptr, y, (long)((n_in + 3) & ~(size_t)3), (long)n_in, 1, st, nh);
         if (rc) return rc;
+        unj_from = 0; unj_hist = hist;
         done = n_in;
         mfma_wrote_hist = nh != nullptr;
     }
@@ -861,18 +912,17 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         if (fir_decim_bf16_ready(f, n_in, d_in, d_out, &rc)) {
             float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
             // every segment judges its own output / input power (the three-term products' error is relative to the products); the marked ones are evaluated again on the
-            // FP64 matrix pipe behind the launch (fir_exact.hip).  Hooked launches are not judged: the second evaluation reads the raw stream
-            const bool judged = f->guard_mode != GR4HIP_GUARD_OFF && hk.pre.n_ops == 0 && hk.post.n_ops == 0 && f->ntaps > 1;
+            // FP64 matrix pipe behind the launch (fir_exact.hip), which runs the launch's load / store programs too
+            const bool judged = f->guard_mode != GR4HIP_GUARD_OFF && f->ntaps > 1;
             int        seg_out = 0;
             if (judged) { rc = f->d_flags.ensure((size_t)ceil_div((long)(n_out * f->S), 512L)); if (rc) return rc; }
-            double h2 = 0;
-            for (float b : f->taps) h2 += (double)b * b;
+            const double h2 = f->tap_power;
             rc = fir_decim_bf16_launch(f->bdKS, (int)f->decim, f->bdHb, x, (long)(n_in * f->S), hist, (int)(f->hcap * f->S), f->d_bdfrag.ptr, y, (long)(n_out * f->S), st, nh,
                                        hk.pre.n_ops > 0 ? &hk.pre : nullptr, hk.post.n_ops > 0 ? &hk.post : nullptr, f->S == 2, judged ? (unsigned char*)f->d_flags.ptr : nullptr,
                                        (float)(h2 * kGuardSegmentRatio), &seg_out);
             if (rc == GR4HIP_OK && judged)
                 rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, f->S == 2, y, (long)n_out, (const unsigned char*)f->d_flags.ptr,
-                                      ilog2((size_t)(seg_out / f->S)), nullptr, st);
+                                      ilog2((size_t)(seg_out / f->S)), nullptr, st, 1, 0, 0, 0, 0, &hk.pre, &hk.post);
             if (rc == GR4HIP_OK) { done = n_in; mfma_wrote_hist = true; }
             else if (rc == GR4HIP_UNSUPPORTED) f->bdKS = -1; // (the staged segment does not fit: do not ask again)
             else return rc;
@@ -921,7 +971,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             if (rc) { f->bandKp = 0; return rc; }
         }
         rc = fir_decim_band_launch((int)f->decim, f->bandKp, x, hist, (int)f->hcap, (const float*)f->d_band.ptr, y, (long)n_out, (long)n_in, st);
-        if (rc == GR4HIP_OK) done = n_in;
+        if (rc == GR4HIP_OK) { done = n_in; unj_from = 0; unj_hist = hist; }
         else if (rc != GR4HIP_UNSUPPORTED) return rc; // UNSUPPORTED: the tile does not fit the LDS, keep the kernels below
     }
     // float polyphase decimator with >= 16 taps per phase and a long span: the same contraction with the D phase products summed in
@@ -943,7 +993,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         hipLaunchKernelGGL(fir_hist_widen_kernel<float>, dim3((unsigned)ceil_div(hl, 256)), dim3(256), 0, st, hist + (f->hcap - hu), hu, (float*)f->d_hist256.ptr, hl);
         GR4_LAUNCH_CHECK();
         rc = fir_mfma_decim_launch(f->mKS, (int)f->decim, x, (const float*)f->d_hist256.ptr, (const float*)f->d_afrag.ptr, y, (long)n_out, st);
-        if (rc == GR4HIP_OK) done = n_in;
+        if (rc == GR4HIP_OK) { done = n_in; unj_from = 0; unj_hist = hist; }
         else if (rc != GR4HIP_UNSUPPORTED) return rc; // UNSUPPORTED: the de-interleaved segment does not fit the LDS, keep the VALU kernel
     }
     const int E  = 4 / f->S;
@@ -972,9 +1022,24 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             if (rb) { f->bandKp = 0; return rb; }
         }
         rc = fir_decim_band_launch((int)f->decim, f->bandKp, x, hist, (int)f->hcap, (const float*)f->d_band.ptr, y, (long)n_out, (long)n_in, st);
+        if (rc == GR4HIP_OK) { unj_from = 0; unj_hist = hist; }
     }
     if (rc == GR4HIP_UNSUPPORTED) { set_error("fir_process: ntaps=%zu decim=%zu does not fit the LDS tiling", f->ntaps, f->decim); return rc; }
     if (rc) return rc;
+    if (unj_from != SIZE_MAX && f->guard_mode != GR4HIP_GUARD_OFF && f->ntaps > 1) {
+        const long ni = (long)(n_in - unj_from), no = ni / (long)f->decim;
+        const int  shift = f->S == 2 ? 10 : 11;
+        const float* xr = x + unj_from * f->S;
+        float*       yr = y + (unj_from / f->decim) * f->S;
+        if (no > 0) {
+            rc = f->d_flags.ensure((size_t)ceil_div(no, 1L << shift));
+            if (rc) return rc;
+            rc = fir_judge_launch(xr, ni, yr, no, (int)f->decim, f->S == 2, shift, (float)(f->tap_power * kGuardSegmentRatio), (unsigned char*)f->d_flags.ptr, st);
+            if (rc) return rc;
+            rc = fir_exact_launch(xr, ni, unj_hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, f->S == 2, yr, no, (const unsigned char*)f->d_flags.ptr, shift, nullptr, st);
+            if (rc && rc != GR4HIP_UNSUPPORTED) return rc; // (UNSUPPORTED: decimation x taps beyond what the second evaluation stages -- the float32 sums stand)
+        }
+    }
     if (!hist_written) {
         const long tot = (long)f->hcap * f->S;
         hipLaunchKernelGGL(fir_hist_update_kernel, dim3((unsigned)ceil_div(tot, 256L)), dim3(256), 0, st, static_cast<const float*>(d_in),

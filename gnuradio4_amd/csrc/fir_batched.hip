@@ -10,6 +10,7 @@
 // is one conflict-free ds_read_b32 per MFMA from the staged (18/16-padded) input segment, D leaves as fully coalesced float4 stores.
 // Bound: MFMA f32 (157.3 TFLOP/s): 2*(Kp+16) flop per output sample.
 #include "common.hpp"
+#include "fir_exact.hpp"
 #include "buffer_ops.hpp"
 
 #include <cstdlib>
@@ -478,8 +479,6 @@ int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, 
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
 int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard,
                     unsigned char* flags, long flags_stride, float gthr);
-int  fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const float* d_taps, int ntaps, int D, int cplx, float* y, long n_out, const unsigned char* flags, int seg_shift,
-                      const unsigned* gate, hipStream_t st, unsigned nch, long in_stride, long out_stride, long taps_stride, long flags_stride); // fir_exact.hip
 }
 struct gr4hip_fir_batched {
     size_t       nch = 0, ntaps = 0;

@@ -439,7 +439,8 @@ struct BdHooks {
     int       cplx = 0;
     // the guard (fir_f16.hip's, per segment): the three-term products' error is relative to the PRODUCTS, so a segment whose output power is below gthr x its staged input
     // power -- more than 21 dB rejected beyond what white noise would lose -- is MARKED in flags[segment], and fir_exact_kernel (fir_exact.hip), launched behind this
-    // kernel, evaluates it again on the FP64 matrix pipe.  flags == nullptr: nobody judges (hooked launches: the second evaluation reads the raw stream)
+    // kernel, evaluates it again on the FP64 matrix pipe (hooked launches: the powers are those of the prologue's output and of the filter's, and the second evaluation
+    // runs the same programs).  flags == nullptr: nobody judges
     float          gthr  = 0.f;
     unsigned char* flags = nullptr;
 };
@@ -582,6 +583,9 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
         float      v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (c0[r] + (c1[r] + c2[r])) + ((c3[r] + c4[r]) + c5[r]);
+        float pyl = 0.f; // (the filter's output, in front of the store program)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pyl = o + r < n_out ? fmaf(v[r], v[r], pyl) : pyl;
         if constexpr (HOOK) {
             if (hk.post.n_ops > 0) { const float4 w = bd_hook4(make_float4(v[0], v[1], v[2], v[3]), hk.post, hk.cplx, o); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
         }
@@ -589,10 +593,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
         else
             for (int r = 0; r < 4; ++r)
                 if (o + r < n_out) y[o + r] = v[r];
-        if (hk.flags != nullptr) { // (unhooked launches only: v is the filter's output)
-            float pyl = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pyl = o + r < n_out ? fmaf(v[r], v[r], pyl) : pyl;
+        if (hk.flags != nullptr) {
             pyl = hf_wave_sum(pyl);
             if (lane == 0) jst[sg & 1][4 + wave] = sg * kBdSegOut + 256L * wave < n_out ? pyl : __builtin_inff(); // (a wave past the end of the span: nothing to judge)
         }
@@ -699,6 +700,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
             const long m = sg * kBsSegOut + 256 * tl + o;
             float      val = (part[((0 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((1 * kBsTiles + tl) * 64 + ln) * 4 + r]) +
                              (part[((2 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((3 * kBsTiles + tl) * 64 + ln) * 4 + r]);
+            if (m < n_out) pyl = fmaf(val, val, pyl); // (the filter's output, in front of the store program)
             if constexpr (HOOK) {
                 if (hk.post.n_ops > 0) {
                     if (hk.cplx) { // lanes 2 i and 2 i + 1 hold one complex output: both evaluate the program on it, each keeps its component
@@ -708,9 +710,9 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
                     } else val = ewise_hook1<float>(val, hk.post, m);
                 }
             }
-            if (m < n_out) { y[m] = val; pyl = fmaf(val, val, pyl); }
+            if (m < n_out) y[m] = val;
         }
-        if (hk.flags != nullptr) { // (unhooked launches only: val is the filter's output; a wave's 64 threads hold outputs 64 w .. 64 w + 63 of both tiles)
+        if (hk.flags != nullptr) { // (a wave's 64 threads hold outputs 64 w .. 64 w + 63 of both tiles)
             pyl = hf_wave_sum(pyl);
             if (lane == 0) jst[sg & 1][4 + wave] = sg * kBsSegOut + 64L * wave < n_out ? pyl : __builtin_inff();
         }
@@ -855,7 +857,7 @@ void fir_decim_bf16_make_afrag(const float* taps, size_t ntaps, size_t D, int* K
 // y[m] = sum_k b[k] x[m D - k], m < n_out; hist[h] = x[-Kh + h]; x and y 16-byte aligned
 // pre / post: programs for the samples on their way in / the outputs on their way out (null: none); cplx: the stream is complex<float> read as floats (the programs'
 // positions are sample indices)
-// flags (optional, unhooked launches): one byte per segment -- *seg_out outputs (floats, as n_out counts): 512 for the split-K kernel (KS > 9), else 1024 -- the segments whose
+// flags (optional): one byte per segment -- *seg_out outputs (floats, as n_out counts): 512 for the split-K kernel (KS > 9), else 1024 -- the segments whose
 // output power is below gthr x their input power: fir_exact_launch evaluates them again behind this launch
 int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, const float* hist, int Kh, const void* afrag, float* y, long n_out, hipStream_t st, float* new_hist,
                           const EwiseHook* pre, const EwiseHook* post, bool cplx, unsigned char* flags, float gthr, int* seg_out) {
@@ -864,7 +866,7 @@ int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, cons
     if (post) hk.post = *post;
     hk.cplx = cplx ? 1 : 0;
     const bool hooked = hk.pre.n_ops > 0 || hk.post.n_ops > 0;
-    if (!hooked && flags != nullptr && gthr > 0.f) { hk.flags = flags; hk.gthr = gthr; }
+    if (flags != nullptr && gthr > 0.f) { hk.flags = flags; hk.gthr = gthr; }
     if (seg_out) *seg_out = KS > 9 ? kBsSegOut : kBdSegOut;
     if (hooked && (Kh % 4) != 0) return GR4HIP_UNSUPPORTED;
     if (KS > 9) { // long window: the waves split the K-steps

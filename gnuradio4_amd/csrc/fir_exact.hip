@@ -27,6 +27,9 @@
 // Rate when EVERY segment is marked: the FP64 matrix pipe's 78.6 TFLOP/s = 16 multiply-adds per cycle and SIMD: 256 taps -> ~120 Gsamples/s (float), ~60 (complex); a
 // decimator by 8 with 1024 taps ~230 G input samples/s.  That is the price of a stream that is all rejection; ordinary streams never come here.
 #include "common.hpp"
+#include "ewise.hpp"
+#include "fir_exact.hpp"
+#include "fir_f16_common.hpp" // (hf_wave_sum)
 
 #include <algorithm>
 
@@ -46,10 +49,12 @@ struct FirExactArgs {
     int                  Hb, Kw;     // samples in front of a tile's first output that its window holds (>= ntaps - 1), window length Hb + 15 D + 1 (a multiple of 16)
     unsigned             div16D;     // ceil(2^32 / (16 D)): i / (16 D) = (i * div16D) >> 32 for the indices that occur
     long                 n_units;
+    EwiseHook            pre, post;  // HOOK: the main kernel's load / store programs (the stored history holds prologue OUTPUTS already: only samples of x are mapped)
 };
 
 constexpr int kExUnit = 1024; // outputs (floats) per unit: 4 tile rows; complex: 512 outputs x 2 components
 
+template <bool HOOK>
 __global__ __launch_bounds__(256, 1) void fir_exact_kernel(FirExactArgs a) {
     if (a.gate != nullptr && __builtin_nontemporal_load(a.gate) == 0u) return;
     extern __shared__ __attribute__((aligned(16))) float ex_smem[];
@@ -67,8 +72,27 @@ __global__ __launch_bounds__(256, 1) void fir_exact_kernel(FirExactArgs a) {
     float*    tz = ex_smem;                    // tz[15 D + k] = b[k], zeros either side: k = Hb + D j - u runs over -15 D .. Kw - 1
     float*    sg = ex_smem + ((Kw + 15 * D + 3) & ~3); // [NC][Lp]
     auto xs = [&](long i, int c) -> float { // sample i of the stream, component c: history in front of x, zeros before that and past the end
-        if (i >= 0) return i < a.n_in ? x[i * NC + c] : 0.f;
+        if (i >= 0) {
+            if (i >= a.n_in) return 0.f;
+            if constexpr (HOOK) {
+                if (a.pre.n_ops > 0) {
+                    if (NC == 1) return ewise_hook1<float>(x[i], a.pre, i);
+                    const float2 q = ewise_hook1<float2>(make_float2(x[2 * i], x[2 * i + 1]), a.pre, i);
+                    return c ? q.y : q.x;
+                }
+            }
+            return x[i * NC + c];
+        }
         return i >= -(long)a.Kh ? hist[((long)a.Kh + i) * NC + c] : 0.f;
+    };
+    auto put = [&](long o, int c, float v, float v_other) { // output o, component c (complex: v_other = the other component, for a hooked store)
+        if constexpr (HOOK) {
+            if (a.post.n_ops > 0) {
+                if (NC == 1) v = ewise_hook1<float>(v, a.post, o);
+                else { const float2 q = ewise_hook1<float2>(c ? make_float2(v_other, v) : make_float2(v, v_other), a.post, o); v = c ? q.y : q.x; }
+            }
+        }
+        y[o * NC + c] = v;
     };
     for (int i = tid; i < Kw + 15 * D; i += 256) {
         const int k = i - 15 * D;
@@ -103,16 +127,16 @@ __global__ __launch_bounds__(256, 1) void fir_exact_kernel(FirExactArgs a) {
             for (int r = tid; r < UO; r += 256) {
                 const long o = ou + r;
                 if (!marked(o)) continue;
-                for (int c = 0; c < NC; ++c) {
-                    float     acc = 0.f;
-                    const int b0  = D * r + Hb;
-                    for (int k = 0; k < a.ntaps; ++k) acc = fmaf(tz[15 * D + k], sg[c * Lp + ph(b0 - k)], acc);
-                    y[o * NC + c] = acc;
-                }
+                float     acc[2] = {0.f, 0.f};
+                const int b0     = D * r + Hb;
+                for (int c = 0; c < NC; ++c)
+                    for (int k = 0; k < a.ntaps; ++k) acc[c] = fmaf(tz[15 * D + k], sg[c * Lp + ph(b0 - k)], acc[c]);
+                for (int c = 0; c < NC; ++c) put(o, c, acc[c], acc[c ^ 1]);
             }
             continue;
         }
-        if ((long)ou + 256L * tr >= a.n_out) continue; // (whole waves; no barrier below)
+        const bool swap = HOOK && NC == 2 && a.post.n_ops > 0; // a complex store program wants both components of an output: they sit in the neighbouring wave, exchanged through LDS
+        if (!swap && (long)ou + 256L * tr >= a.n_out) continue; // (whole waves; no barrier below)
         // this wave's tile row: B[u][c] = staged[D (256 tr + 16 c) + u], A[j][u] = tz[15 D + Hb + D j - u]
         const float* sb = sg + comp * Lp + D * (256 * tr + 16 * col) + 4 * (16 * tr + col) + kq;
         const float* ta = tz + 15 * D + Hb + D * col - kq;
@@ -129,10 +153,21 @@ __global__ __launch_bounds__(256, 1) void fir_exact_kernel(FirExactArgs a) {
             }
         }
         // D[row = kq + 4 r][col]: output ou + 256 tr + 16 col + kq + 4 r
+        float other[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (HOOK) {
+            if (swap) {
+                float* ox = sg + NC * Lp; // [4 waves][4][64]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ox[(wave * 4 + r) * 64 + lane] = (float)acc[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) other[r] = ox[((wave ^ 1) * 4 + r) * 64 + lane];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long o = ou + 256L * tr + 16 * col + kq + 4 * r;
-            if (marked(o)) y[o * NC + comp] = (float)acc[r];
+            if (marked(o)) put(o, comp, (float)acc[r], other[r]);
         }
     }
 }
@@ -142,7 +177,7 @@ bool fir_exact_shape(int ntaps, int D, int cplx, int* Hb, int* Kw, size_t* lds_b
     if (ntaps < 1 || D < 1 || D > 64) return false;
     const int kw = (ntaps + 15 * D + 15) & ~15, hb = kw - 15 * D - 1, NC = cplx ? 2 : 1, UO = kExUnit / NC;
     const long L  = (long)D * (UO - 1) + hb + 1, Lp = (L - 1) + 4 * ((L - 1) / (16 * D)) + 4;
-    const size_t bytes = (size_t)(((kw + 15 * D + 3) & ~3) + NC * Lp) * sizeof(float);
+    const size_t bytes = (size_t)(((kw + 15 * D + 3) & ~3) + NC * Lp + (cplx ? 1024 : 0)) * sizeof(float); // (+ the hooked complex store's exchange rows)
     if (Hb) *Hb = hb;
     if (Kw) *Kw = kw;
     if (lds_bytes) *lds_bytes = bytes;
@@ -151,7 +186,7 @@ bool fir_exact_shape(int ntaps, int D, int cplx, int* Hb, int* Kw, size_t* lds_b
 
 // evaluates the marked outputs (flags == nullptr: all of them) of  y[o] = sum_k b[k] x[D o - k],  o < n_out.  Sizes in samples (float, or complex when cplx); strides in floats.
 int fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const float* d_taps, int ntaps, int D, int cplx, float* y, long n_out, const unsigned char* flags, int seg_shift,
-                     const unsigned* gate, hipStream_t st, unsigned nch = 1, long in_stride = 0, long out_stride = 0, long taps_stride = 0, long flags_stride = 0) {
+                     const unsigned* gate, hipStream_t st, unsigned nch, long in_stride, long out_stride, long taps_stride, long flags_stride, const EwiseHook* pre, const EwiseHook* post) {
     FirExactArgs a{};
     size_t       lds = 0;
     if (!fir_exact_shape(ntaps, D, cplx, &a.Hb, &a.Kw, &lds)) return GR4HIP_UNSUPPORTED;
@@ -161,7 +196,8 @@ int fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const
     int              dev = 0, n_cu = pd.current(&first, &dev);
     if (first) {
         if (n_cu == 0) { set_error("fir_exact: no device"); return GR4HIP_NO_DEVICE; }
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_exact_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_exact_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         n_cu = -n_cu;
         pd.done(dev, n_cu);
     }
@@ -171,7 +207,51 @@ int fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const
     a.div16D  = (unsigned)(((1ull << 32) + 16ull * D - 1) / (16ull * D));
     a.n_units = ceil_div(n_out, (long)(kExUnit / (cplx ? 2 : 1)));
     const unsigned gx = (unsigned)std::min<long>(a.n_units, std::max<long>(1, (long)n_cu * 4 / (long)nch));
-    hipLaunchKernelGGL(fir_exact_kernel, dim3(gx, nch), dim3(256), lds, st, a);
+    const bool hooked = (pre && pre->n_ops > 0) || (post && post->n_ops > 0);
+    if (hooked) {
+        if (pre) a.pre = *pre;
+        if (post) a.post = *post;
+        hipLaunchKernelGGL(fir_exact_kernel<true>, dim3(gx, nch), dim3(256), lds, st, a);
+    } else hipLaunchKernelGGL(fir_exact_kernel<false>, dim3(gx, nch), dim3(256), lds, st, a);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
+// ---- the verdict for kernels that do not judge themselves (the float32 matrix-pipe forms, the three-term bf16 direct forms): one byte per 2^seg_shift outputs, non-zero where the
+// outputs' power (of the segment's quietest quarter) is below gthr x the power of the D x as many samples in front of them.  One pass over x and y; non-finite power either
+// side leaves the segment unmarked (the main kernel's classes stand).
+__global__ __launch_bounds__(256) void fir_judge_kernel(const float* __restrict__ x, long nxf, const float* __restrict__ y, long nyf, int D, int segf, float gthr, unsigned char* __restrict__ flags, long nseg) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = segf / 4; // a wave's quarter: q output floats, q D input floats
+    for (long sgi = blockIdx.x; sgi < nseg; sgi += gridDim.x) {
+        const long y0 = sgi * segf + (long)wave * q, x0 = y0 * D;
+        float      px = 0.f, py = 0.f;
+        for (long i = y0 + lane; i < y0 + q && i < nyf; i += 64) { const float v = y[i]; py = fmaf(v, v, py); }
+        for (long i = x0 + lane; i < x0 + (long)q * D && i < nxf; i += 64) { const float v = x[i]; px = fmaf(v, v, px); }
+        px = hf_wave_sum(px);
+        py = hf_wave_sum(py);
+        __syncthreads();
+        if (lane == 0) { red[wave] = px; red[4 + wave] = py; }
+        __syncthreads();
+        if (tid == 0) {
+            const float pxs = (red[0] + red[1]) + (red[2] + red[3]);
+            float       pym = red[4];
+            bool        fin = true;
+            for (int w = 0; w < 4; ++w) {
+                const bool present = sgi * segf + (long)w * q < nyf; // (the stream's last segment: quarters past its end do not vote)
+                if (!present) continue;
+                fin = fin && red[4 + w] < 3.0e38f;
+                pym = fminf(pym, red[4 + w]);
+            }
+            flags[sgi] = (fin && pxs < 3.0e38f && pym * 4.f * (float)D < gthr * pxs) ? 3 : 0;
+        }
+    }
+}
+int fir_judge_launch(const float* x, long n_in, const float* y, long n_out, int D, int cplx, int seg_shift, float gthr, unsigned char* flags, hipStream_t st) {
+    const int  NC = cplx ? 2 : 1, segf = NC << seg_shift;
+    const long nseg = ceil_div(n_out, 1L << seg_shift);
+    if (nseg <= 0) return GR4HIP_OK;
+    hipLaunchKernelGGL(fir_judge_kernel, dim3((unsigned)std::min<long>(nseg, 256 * 16)), dim3(256), 0, st, x, n_in * NC, y, n_out * NC, D, segf, gthr, flags, nseg);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

@@ -207,6 +207,36 @@ def test_fir_takes_its_neighbours_into_its_launch(G, cplx, ntaps, decim):
         assert _rel(got, truth) <= 1e-5, (pre, post)
 
 
+@pytest.mark.parametrize("cplx,ntaps,decim", [(False, 64, 4), (True, 64, 4), (True, 200, 10), (False, 300, 5), (False, 48, 3), (True, 40, 2)])
+def test_hooked_fir_answers_to_the_guard(G, cplx, ntaps, decim):
+    """a filter that carries its neighbours as load / store programs under a rejected tone 76 dB above what passes: the band-form decimators judge the prologue's OUTPUT
+    against the filter's, the second evaluation (fir_exact_kernel<true>) runs the same programs; the register-window kernel redoes a rejected workgroup from the samples
+    it staged.  The programs here are exact in float32 (x 1j; + 0.75 on samples of a 2^-10 grid), so what is measured is the filter's arithmetic: within the float64 bar,
+    or within the error of the reference's float32 sum (oracle, reference order) on the prologue's output where float32 cannot reach it"""
+    rng = np.random.default_rng(ntaps)
+    n = decim * 4 * 30_000
+    b = O.design_taps_hamming_lowpass(ntaps, 0.4 / decim)
+    ph = 2 * np.pi * 0.31 * np.arange(n)
+    x = 0.05 * (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)) + 316.0 * (np.exp(1j * ph) if cplx else np.cos(ph))
+    x = (np.round(x * 1024) / 1024).astype(np.complex64 if cplx else np.float32)
+    dt = torch.complex64 if cplx else torch.float32
+    pre, post = ([("Multiply", 1j)], [("Multiply", -1j)]) if cplx else ([("Add", 0.75)], [("Subtract", 0.25)])
+    mid = _program_on_cpu64(x, pre)
+    assert np.array_equal(mid, mid.astype(x.dtype))  # (exact in float32)
+    truth = _program_on_cpu64(_fir64(b, mid, decim), post)
+    ref32 = _program_on_cpu64(O.fir(b, mid.astype(x.dtype), acc64=False)[0][::decim], post)
+    f = G.fir_filter(b, dt, decimate=decim)
+    f.set_prologue(G.Merged(dt, pre))
+    f.set_epilogue(G.Merged(dt, post))
+    xd = dev(x)
+    cuts = [0, (n // decim // 3) * decim, n]
+    got = np.concatenate([f.process_bulk(xd[a:b_]).cpu().numpy() for a, b_ in zip(cuts[:-1], cuts[1:])])
+    sl = slice(ntaps // decim + 1, None)
+    e, e_ref = _rel(got[sl], truth[sl]), _rel(ref32[sl], truth[sl])
+    assert e <= max(1e-5, e_ref), (e, e_ref)
+
+
+
 def test_fir_prologue_replaced_in_mid_stream(G):
     """a gain step in front of a filter (settings-by-tag on the MultiplyConst of MultiplyConst -> fir_filter): the samples already in the filter's history keep
     the OLD gain, exactly as when the two blocks run one after the other; the same for a hook (AddConst) replaced by another"""

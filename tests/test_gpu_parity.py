@@ -247,10 +247,15 @@ def test_fir_float_f16_two_term_kernel(G, ntaps, devsw):
         return np.concatenate([flt.process_bulk(_dev16(xx[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
     y = run(G.fir_filter(b, torch.float32), x)
     assert _rel(y, truth) <= TOL
+    def unguarded():  # (under the guard both kernels hand this stream's segments to the second evaluation: the same float64 sums)
+        f = G.fir_filter(b, torch.float32)
+        f.set_guard_mode(G.capi.GUARD_OFF)
+        return run(f, x)
+    yhf = unguarded()
     devsw("GR4HIP_FIR_NO_F16X2", 1)
-    ybf = run(G.fir_filter(b, torch.float32), x)
+    ybf = unguarded()
     devsw("GR4HIP_FIR_NO_F16X2", 0)
-    assert not np.array_equal(y, ybf)  # (two different kernels did run)
+    assert not np.array_equal(yhf, ybf)  # (two different kernels did run)
     for scale in (1e-30, 1e30):  # a power-of-ten level far from 1: every segment finds its own exponent
         xs_ = (x.astype(np.float64) * scale).astype(np.float32)
         ts, _ = O.fir(b, xs_)
@@ -374,7 +379,9 @@ def test_fir_complex_f16_two_term_kernel(G, ntaps, devsw):
     y = run(make(), x)
     assert _rel(y, truth) <= TOL
     ybf = run(make(G.capi.FIR_TIME_DOMAIN_BF16X3), x)
-    assert _rel(ybf, truth) <= TOL and not np.array_equal(y, ybf)  # (two different kernels did run)
+    assert _rel(ybf, truth) <= TOL
+    # (under the guard both kernels hand this stream's segments to the same second evaluation; with the guard off each shows its own products)
+    assert not np.array_equal(run(make(guard=G.capi.GUARD_OFF), x), run(make(G.capi.FIR_TIME_DOMAIN_BF16X3, G.capi.GUARD_OFF), x))  # (two different kernels did run)
     for scale in (1e-30, 1e30):
         xs_ = (x.astype(np.complex128) * scale).astype(np.complex64)
         ts, _ = O.fir(b, xs_)
@@ -432,6 +439,46 @@ def test_fir_complex_decimating_long_input_matrix_pipe(G, decim, ntaps):
         parts.append(f.process_bulk(xin).cpu().numpy())
     y = np.concatenate(parts)
     assert y.shape == truth.shape and _rel(y, truth) <= TOL
+
+
+
+@pytest.mark.parametrize("cplx,D,ntaps,algo,short", [
+    (True, 2, 300, "FIR_AUTO", False),            # the register-window kernel (fir_poly_kernel): the phase-by-phase float32 sum measured 12 x the reference's order on this shape
+    (True, 2, 256, "FIR_EXACT_F32", False),
+    (False, 3, 64, "FIR_AUTO", True),             # spans below the matrix-pipe kernels' sizes: the register-window kernel at every shape
+    (False, 1, 32, "FIR_AUTO", False),
+    (True, 1, 48, "FIR_AUTO", True),
+    (False, 10, 256, "FIR_AUTO", False),          # float32 matrix-pipe forms (fir_decim_band_kernel / fir_mfma_decim_kernel): fir_judge_kernel + fir_exact_kernel behind them
+    (False, 10, 100, "FIR_AUTO", False),
+    (True, 10, 64, "FIR_AUTO", False),
+    (False, 12, 300, "FIR_AUTO", False),
+    (False, 1, 200, "FIR_TIME_DOMAIN_F32", False),   # the float32 / three-term bf16 direct forms a caller names
+    (False, 1, 200, "FIR_TIME_DOMAIN_BF16X3", False),
+    (True, 1, 200, "FIR_TIME_DOMAIN_F32", False),
+    (True, 1, 128, "FIR_TIME_DOMAIN_BF16X3", False),
+    (False, 1, 700, "FIR_TIME_DOMAIN_BF16X3", False),
+    (False, 5, 300, "FIR_AUTO", False), (True, 4, 256, "FIR_AUTO", False), (True, 5, 256, "FIR_AUTO", False),  # three-term bf16 band forms (judged inside the kernel)
+])
+def test_fir_every_kernel_answers_to_the_guard(G, cplx, D, ntaps, algo, short):
+    """the parity contract's second clause for EVERY kernel gr4hip_fir_process can take, not only the split-product ones: a rejected tone 36 .. 70 dB above what passes.
+    Each kernel judges its segments (or fir_judge_kernel does behind it) and the marked ones are evaluated again with float64 products and sums (fir_exact.hip; inside the
+    workgroup for the register-window kernel): the result is within the float64 oracle's bar, or -- where even that is out of float32's reach -- within the error of the
+    reference's own float32 sum in the reference's order (oracle: gr4o_fir_f32 / _c32), factor ONE"""
+    rng = np.random.default_rng(ntaps + D)
+    n = (D * 4 * 1_000) if short else (D * 4 * 40_000 if D > 1 else 1 << 18)
+    b = O.design_taps_hamming_lowpass(ntaps, 0.4 / D if D > 1 else 0.05)
+    for amp, fq in ((3.0, 0.27), (300.0, 0.44), (30.0, 0.31)):
+        ph = 2 * np.pi * fq * np.arange(n)
+        x = 0.05 * (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)) + amp * (np.exp(1j * ph) if cplx else np.cos(ph))
+        x = x.astype(np.complex64 if cplx else np.float32)
+        truth = O.fir(b, x)[0][::D]
+        f = G.fir_filter(b, torch.complex64 if cplx else torch.float32, decimate=D)
+        f.set_algo(getattr(G.capi, algo))
+        cuts = [0, (n // D // 3) * D, n]  # two calls: the second starts from a carried history
+        y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+        sl = slice(ntaps // D + 1, None)
+        e, e_ref = _rel(y[sl], truth[sl]), _ref32_err(b, x, truth, sl, D)
+        assert e <= max(TOL, e_ref), (amp, fq, e, e_ref)
 
 
 @pytest.mark.parametrize("D,ntaps", [(8, 97), (8, 169), (8, 257), (8, 258), (8, 513), (8, 514), (8, 769), (8, 770), (8, 1024), (8, 1025),
@@ -1710,10 +1757,14 @@ def test_guard_destination_multiplies_in_float32(G):
     assert _rel(G.Chain(b, N, "None", G.capi.CHAIN_TIME_DOMAIN).process_bulk(dev(x)).cpu().numpy().ravel(), truth) <= TOL
     # the FIR alone: float32 products against the default three-term bf16 ones, both against float64
     yt, _ = O.fir(b, x)                                           # (float64 accumulation)
-    f32 = G.fir_filter(b, torch.complex64); f32.set_algo(G.capi.FIR_TIME_DOMAIN_F32)
-    fbf = G.fir_filter(b, torch.complex64); fbf.set_algo(G.capi.FIR_TIME_DOMAIN_BF16X3)
+    # (guard off: the products by themselves.  Under the guard -- since round 5 every kernel answers to it -- both hand these segments to the float64 second evaluation)
+    f32 = G.fir_filter(b, torch.complex64); f32.set_algo(G.capi.FIR_TIME_DOMAIN_F32); f32.set_guard_mode(G.capi.GUARD_OFF)
+    fbf = G.fir_filter(b, torch.complex64); fbf.set_algo(G.capi.FIR_TIME_DOMAIN_BF16X3); fbf.set_guard_mode(G.capi.GUARD_OFF)
     e32, ebf = _rel(f32.process_bulk(dev(x)).cpu().numpy(), yt), _rel(fbf.process_bulk(dev(x)).cpu().numpy(), yt)
     assert e32 <= TOL and e32 < 0.5 * ebf, (e32, ebf)
+    for algo in (G.capi.FIR_TIME_DOMAIN_F32, G.capi.FIR_TIME_DOMAIN_BF16X3):
+        fg = G.fir_filter(b, torch.complex64); fg.set_algo(algo)
+        assert _rel(fg.process_bulk(dev(x)).cpu().numpy(), yt) <= 1e-6
     # since round 4 the direct form proper (GR4HIP_FIR_TIME_DOMAIN) is the f16 kernel that judges every segment and evaluates the rejected ones again with three-term
     # f16 products (float32 products): as close as the float32 kernel
     fhf = G.fir_filter(b, torch.complex64); fhf.set_algo(G.capi.FIR_TIME_DOMAIN)
