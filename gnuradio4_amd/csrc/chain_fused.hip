@@ -213,7 +213,11 @@ __device__ __forceinline__ void dma_tail(const float2* __restrict__ src, float2*
 
 // workgroup barriers that do NOT drain the vector-memory counter: an LDS-DMA for the next frame stays in flight across them
 // (__syncthreads() would emit s_waitcnt vmcnt(0) while a DMA is pending and serialise the prefetch with this frame's work)
+#if defined(GR4_T_NOBAR) // developer timing build (results are wrong): the in-frame barriers without the s_barrier = the bound of hiding every in-frame barrier wait behind other work
+#define GR4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
 #define GR4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 #define GR4_FULL_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // pass A on an image already in LDS, in place (the second and third transforms of the windowed kernel)
@@ -653,7 +657,11 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
             passB_compute_store(S, w, twBr, cb, kb);
 #endif
             GR4_STAMP(10);
+#if defined(GR4_T_NOB5) // developer timing build (results are wrong): E's exchange without its barrier = the bound of an E transform with one exchange fewer
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
             GR4_LDS_BARRIER(); // #5
+#endif
             GR4_STAMP(11);
             passC(S, w, twCr, t);
             GR4_PIN(w);

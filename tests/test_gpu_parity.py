@@ -2112,6 +2112,31 @@ def test_bench_size_launch_properties(G):
         assert _rel(whole[f].cpu().numpy(), truth.reshape(-1, N)[f - lo]) <= TOL, f
 
 
+@pytest.mark.parametrize("order,fc", [(8, 0.022), (6, 0.021), (8, 0.031)])
+def test_fir_iir_narrow_butterworth_against_the_float32_cascade(G, order, fc):
+    """profiles/r04_fuzz_summary.txt: decimate-by-8 FIR -> Butterworth order 6 / 8 at cut-off <= 0.031 fs came out at 1.0e-5 .. 2.1e-5 in every mode of
+    gr4hip_fir_iir_process -- the float32 floor of the cascade's state, not the device's.  Pinned here with the contract's second clause: the bound is the error of
+    the reference's own float32 cascade (oracle: gr4o_iir_cascade_f32, iir_filter<float, DF_II> section by section) on the same decimated stream, factor ONE"""
+    import gnuradio4_amd.blocks as B
+    rng = np.random.default_rng(order)
+    n = 200 * 7168 + 8 * 123
+    nt = 1000
+    k = np.arange(nt); t = np.hamming(nt) * np.sinc(0.1 * (k - (nt - 1) / 2)); taps = (t / t.sum()).astype(np.float32)
+    b, a = B.design_iir(G.capi.LOWPASS, order, fc, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    x = rng.standard_normal(n).astype(np.float32)
+    mid = O.fir_decim(taps, x, 8)[0].astype(np.float32)  # what the decimator hands the cascade (float64 sums, rounded once)
+    secs = O.make_sections([(bb, aa) for bb, aa in zip(np.asarray(b, np.float32).reshape(-1, 3), np.asarray(a, np.float32).reshape(-1, 3))])
+    truth = O.iir_cascade(secs, mid, 3, f64=True)
+    e_ref = min(_rel(O.iir_cascade(secs, mid, form, f64=False), truth) for form in (O.DF_I, O.DF_II))  # (the better of the reference's two default-able forms)
+    cut = (n // 8 // 3) * 8
+    for mode in (G.capi.FIR_IIR_AUTO, G.capi.FIR_IIR_ONE_LAUNCH, G.capi.FIR_IIR_TWO_LAUNCHES):
+        fir, iir = G.fir_filter(taps, torch.float32, decimate=8), G.iir_filter(b, a)
+        xd = dev(x)
+        y = np.concatenate([B.fir_iir_process(fir, iir, xd[:cut], mode=mode).cpu().numpy(), B.fir_iir_process(fir, iir, xd[cut:], mode=mode).cpu().numpy()])
+        e = _rel(y, truth)
+        assert e <= max(TOL, e_ref), (mode, e, e_ref)
+
+
 def test_configs2_full_size_properties(G):
     """BASELINE configs[2] at bench size (2^27 input samples: frequency-domain decimator + sequential-run IIR): chunking invariance over calls that take
     different kernels, linearity, DC gain of the decimated stream, and the float64 oracle on a slice deep inside the span"""
