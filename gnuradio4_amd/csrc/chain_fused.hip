@@ -645,6 +645,29 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
 #pragma unroll
             for (int q = 0; q < 16; ++q) pend[q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y);
             if (false) {
+#elif defined(GR4_T_EINTERP) // developer timing build (results are wrong): E read off a 4 x oversampled 1024-point grid through a 5-tap kernel (the grid's own small transform taken as free,
+                             // one barrier standing in for it) = the bound of replacing E's two radix-16 passes by an interpolation
+            GR4_LDS_BARRIER();
+            {
+                float cf[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) cf[j] = twCr[1 + j].x; // (stand-ins for the kernel's five coefficients of this lane's fractional position t & 7)
+                const float2* Sg = S + (t >> 3); // (the grid padded by its own first points: no wrap-around arithmetic, every read an immediate offset from one base)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float2    Eq   = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const float2 g = Sg[64 * q + j];
+                        Eq.x = fmaf(cf[j], g.x, Eq.x);
+                        Eq.y = fmaf(cf[j], g.y, Eq.y);
+                    }
+                    const float2 Xq = X[perm16(q)];
+                    const float2 Y  = make_float2(fmaf(Hr[q].x, Xq.x, fmaf(-Hr[q].y, Xq.y, Eq.x)), fmaf(Hr[q].x, Xq.y, fmaf(Hr[q].y, Xq.x, Eq.y)));
+                    pend[q] = fmaf(Y.x, Y.x, Y.y * Y.y);
+                }
+            }
+            if (false) {
 #else
             {
 #endif
