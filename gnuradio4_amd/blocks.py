@@ -408,8 +408,8 @@ class Chain(_Handle):
         return out
 
     def set_guard_mode(self, mode: int):
-        """capi.GUARD_STRICT (default: a span below the power-ratio threshold is redone in the time domain before the call returns; the call is
-        synchronous), GUARD_DEFERRED (asynchronous calls, the switch lags one call) or GUARD_OFF (include/gr4hip.h)"""
+        """capi.GUARD_STRICT (default: the frames a launch marks are evaluated again in the time domain by a launch enqueued behind it; asynchronous),
+        GUARD_DEFERRED (no second evaluation: the call that measures the drop is published from the fused kernel, the switch lags one call) or GUARD_OFF (include/gr4hip.h)"""
         check(lib().gr4hip_chain_set_guard_mode(self._h, int(mode)), "Chain.set_guard_mode")
 
 

@@ -17,6 +17,7 @@ bool chain_fused_multi_capable(const ChainFused* c);
 void chain_fused_destroy(ChainFused* c);
 void chain_fused_set_max_workgroups(ChainFused* c, unsigned n);
 void chain_fused_set_measure(ChainFused* c, bool on);
+void chain_fused_set_redo(ChainFused* c, bool on); // measured launches mark their frames one by one and chain_redo_kernel follows them
 int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio);
 const float* chain_fused_history(const ChainFused* c);
 int  chain_fused_set_history(ChainFused* c, const float* d_hist256, hipStream_t st);
@@ -132,7 +133,9 @@ static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, 
     // the transform behind it gathers it into a few bins: 4 of the chain guard tests failed the bar there.  The float32 products stay.)
     if (!c->fir) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, taps.data(), taps.size(), 1);
-        if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN_F32);
+        if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN); // (round 5: the direct form's own kernels -- every one of them judges its segments at 21 dB and hands the marked ones to
+                                                                            // the float64 second evaluation, fir_exact.hip; until then this was GR4HIP_FIR_TIME_DOMAIN_F32, because the split-product kernels' own
+                                                                            // guard started at 36 dB and 4 chain tests failed between the two thresholds)
         if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, c->N, c->window, 0);
     }
     if (!rc) rc = gr4hip_internal_fir_load_history(c->fir, d_hist256, st);
@@ -155,23 +158,22 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
         if (c->use_td) return chain_time_domain(c, d_in, frames, d_mag2, stream);
         float ratio;
         if (c->guard_mode == GR4HIP_GUARD_STRICT) {
-            // nothing out of tolerance is ever published: the span runs on the fused kernel, its measurement is awaited, and a span that fell below the
-            // threshold is redone by the direct-form kernels from the history the call started with -- before the call returns.  (The call therefore
-            // returns when the launch has finished; GR4HIP_GUARD_DEFERRED keeps it asynchronous at the price of one call of latency in the switch.)
-            int rc = c->d_hist_save.ensure(256 * 2 * sizeof(float));
-            if (rc) return rc;
-            GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-            rc = chain_fused_process(c->fused, x, frames, d_mag2, st);
-            if (rc) return rc;
-            if (chain_fused_power_ratio(c->fused, true, false, &ratio)) c->last_ratio = ratio;
-            c->probed = true;
+            // nothing out of tolerance is ever published, and nobody waits: the fused kernel marks the frames whose output power fell below the threshold, and
+            // chain_redo_kernel -- enqueued behind it on the same stream -- evaluates exactly those frames again in the time domain (float64 products) over the
+            // fused results.  The call returns when both launches are enqueued ("user code must not block in work()", docs/USER_API_advanced_work.md).  Until
+            // round 5 the call spun on a mapped word until its launch had ended and redid the whole span on the time-domain kernel pair.
+            // The measurement of an EARLIER launch, when it has arrived, still moves a stream that rejects most of its input to the time-domain kernels for good
+            // (they are the faster way through such a stream than fused kernel + second evaluation of every frame) -- without waiting for anything.
+            if (chain_fused_power_ratio(c->fused, false, false, &ratio)) c->last_ratio = ratio;
             if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) {
-                rc = chain_switch_to_time_domain(c, static_cast<const float*>(c->d_hist_save.ptr), st);
+                int rc = chain_switch_to_time_domain(c, chain_fused_history(c->fused), st);
                 if (rc) return rc;
                 return chain_time_domain(c, d_in, frames, d_mag2, stream);
             }
-            return GR4HIP_OK;
+            chain_fused_set_redo(c->fused, true);
+            return chain_fused_process(c->fused, x, frames, d_mag2, st);
         }
+        chain_fused_set_redo(c->fused, false);
         if (chain_fused_power_ratio(c->fused, false, false, &ratio)) c->last_ratio = ratio; // an earlier launch has finished: no waiting
         size_t done = 0;
         if (!c->probed) { // first call after create / reset: the first blocks synchronously, before the rest of the span is committed to an algorithm

@@ -68,6 +68,8 @@ struct ChainFdArgs {
     unsigned      pw_seq;
     unsigned      pw_mask; // 0: every frame is measured
     float         pw_thr; // a frame whose sampled output power is below pw_thr x its sampled input power marks the launch (word 33 of pw, word 3 of pw_host)
+    unsigned char* fflags; // optional, one byte per frame (8192-sample block): non-zero = that frame fell below the threshold -- chain_redo_kernel, launched behind this
+                           // kernel, evaluates exactly those frames again in the time domain (float64 products): the guard without the host
     unsigned long long* dbg; // GR4_FD_TIMING only
 };
 // several channels in ONE launch (gr4hip_chain_process_multi, kModeMag2 only).  fold_ch > 1: every workgroup takes frame f of ALL channels in turn (same taps:
@@ -430,12 +432,17 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                     if ((threadIdx.x & 63) == 63) Gv[8 * (iter & 1) + (threadIdx.x >> 6)] = wt;
                     if (threadIdx.x < 64) {
                         const float4 g0 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1)), g1 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1) + 4);
-                        pw_dmin = fminf(pw_dmin, ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w)));
+                        const float fsum = ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w)); // the frame two iterations back
+                        pw_dmin = fminf(pw_dmin, fsum);
+                        if constexpr (!MULTI) { if (a.fflags != nullptr && threadIdx.x == 0 && iter >= 2) a.fflags[f - 2 * fstride] = fsum < 0.f ? 1 : 0; }
                     }
                 } else { // the windowed kernels fill their 160 KiB to the byte: two words of global scratch per workgroup, L2 atomics
                     pw_dmin = fminf(pw_dmin, pw_pend);
                     if ((threadIdx.x & 63) == 63) atomicAdd(pw_slot + (iter & 1), wt);
-                    if (threadIdx.x == 0) pw_pend = atomicExch(pw_slot + ((iter + 1) & 1), 0.f); // the frame before that: every wave's share arrived before the barrier above
+                    if (threadIdx.x == 0) {
+                        pw_pend = atomicExch(pw_slot + ((iter + 1) & 1), 0.f); // the frame before that: every wave's share arrived before the barrier above
+                        if constexpr (!MULTI) { if (a.fflags != nullptr && iter >= 2) a.fflags[f - 2 * fstride] = pw_pend < 0.f ? 1 : 0; }
+                    }
                 }
             }
         }
@@ -833,14 +840,22 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
             }
             __syncthreads();
             if (threadIdx.x == 0) {
+                float s0 = 0.f, s1 = 0.f; // the verdict sums by parity of the iteration that filed them: parity iter & 1 = the last frame, the other = the one before it
                 if constexpr (!WIN) {
                     const float* Gv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + kLdsEbfBytes);
-                    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                     for (int w = 0; w < 8; ++w) { s0 += Gv[w]; s1 += Gv[8 + w]; }
                     pw_dmin = fminf(pw_dmin, fminf(s0, s1));
                 } else {
-                    pw_dmin = fminf(fminf(pw_dmin, pw_pend), fminf(atomicExch(pw_slot, 0.f), atomicExch(pw_slot + 1, 0.f))); // (the slots are zero again for the next launch)
+                    s0 = atomicExch(pw_slot, 0.f); s1 = atomicExch(pw_slot + 1, 0.f); // (the slots are zero again for the next launch)
+                    pw_dmin = fminf(fminf(pw_dmin, pw_pend), fminf(s0, s1));
+                }
+                if constexpr (!MULTI) {
+                    if (a.fflags != nullptr) { // (f has moved one stride past the workgroup's last frame)
+                        const float last = (iter & 1) ? s1 : s0, before = (iter & 1) ? s0 : s1;
+                        if (iter >= 1) a.fflags[f - fstride] = last < 0.f ? 1 : 0;
+                        if (iter >= 2) a.fflags[f - 2 * fstride] = before < 0.f ? 1 : 0;
+                    }
                 }
                 if (pw_dmin < 0.f) atomicOr(reinterpret_cast<unsigned*>(a.pw + 33), 1u);
                 float si = 0.f, so = 0.f;
@@ -879,6 +894,117 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
 }
 template <int MODE, int LOG2NF = 13>
 __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) { chain_fd_body<MODE, LOG2NF, false>(a, nullptr); }
+
+// ---- the guard's second evaluation, on the device: the frames chain_fd_kernel marked in a.fflags (output power below the threshold x input power: the fast
+// convolution's error, relative to the INPUT, shows against such an output) again with the filter in the TIME domain -- y_f = sum_k b[k] x[n - k] on the FP64 matrix
+// pipe (the band form of fir_exact.hip: float32 x float32 products exact, float64 sums, one rounding), x window, the frame transform of this file from LDS, |.|^2 over
+// the fused kernel's output.  Launched behind every guarded launch; a workgroup whose frames are unmarked reads their flag bytes and leaves (an ordinary stream costs
+// one near-empty launch).  No host in the loop: gr4hip_chain_process returns when both launches are enqueued (until round 5 it waited for the verdict and redid the
+// whole span on the time-domain kernel pair).  A frame whose staged window holds a non-finite sample keeps the fused kernel's result.
+// LDS: the frame image S (kSLen float2) + the staged window as two padded float planes (8192 + 256 samples each, 4 floats of padding per 16) + the tap row.
+constexpr int kRdHb = 256, kRdKw = 272, kRdL = kN + kRdHb, kRdLp = kRdL + 4 * (kRdL / 16) + 4;
+constexpr size_t kRdLdsBytes = (size_t)kSLen * sizeof(float2) + (size_t)(2 * kRdLp + kRdKw + 16) * sizeof(float);
+static_assert(kRdLdsBytes <= 160 * 1024, "LDS budget of one CU");
+template <int MODE, int LOG2NF = 13>
+__global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int ntaps) {
+    constexpr bool WIN = MODE != kModeMag2, SMALL = MODE == kModeWinSmall;
+    using f64x4_r = __attribute__((ext_vector_type(4))) double;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2* S  = smem;
+    float*  sg = reinterpret_cast<float*>(smem + kSLen); // [2][kRdLp]
+    float*  tz = sg + 2 * kRdLp;                         // tz[15 + k] = b[k], zeros either side
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, kq = lane >> 4;
+    auto ph = [](int i) { return i + 4 * (i >> 4); };
+    {   // an ordinary stream marks nothing: every lane looks at its share of this workgroup's flag bytes at once, and the workgroup leaves (measured: a lane that walks its
+        // 512 bytes one dependent load after the other costs the headline launch 0.35 ms)
+        int any = 0;
+        for (long f = (long)blockIdx.x + (long)t * gridDim.x; f < a.n_frames; f += (long)kT * gridDim.x) any |= a.fflags[f];
+        if (!__syncthreads_or(any)) return;
+    }
+    for (int i = t; i < kRdKw + 15; i += kT) { const int k = i - 15; tz[i] = (k >= 0 && k < ntaps) ? a.taps[k] : 0.f; }
+    const int   n0 = t >> 1, par = t & 1;
+    const float sgn = par ? -1.f : 1.f;
+    const int   cb = lane & 15;
+    const int   kb = 2 * wave + (kq >> 1) + 16 * (kq & 1);
+    float2 twBr[16], twCr[16], twA[16];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) { twBr[r] = a.twB[r * 32 + kb]; twCr[r] = a.twC[r * 512 + t]; }
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) twA[k1] = (t & 1) ? w32(k1) : make_float2(1.f, 0.f);
+    constexpr int NF = 1 << (SMALL ? LOG2NF : 8), TF = NF / 16, NPF = NF + NF / 32;
+    float2        sw2a = make_float2(1.f, 0.f), sw2b = sw2a, sw3 = sw2a, sw3sq = sw2a;
+    if constexpr (SMALL) {
+        const int tt = t % TF;
+        sw2a  = a.twS[(tt & 15) * (NF / 256)];
+        sw2b  = a.twS[2 * (tt & 15) * (NF / 256)];
+        sw3   = a.twS[tt & 255];
+        sw3sq = a.twS[(2 * (tt & 255)) & (NF - 1)];
+    }
+    const int comp = wave & 1;
+    for (long f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
+        if (a.fflags[f] == 0) continue; // (uniform)
+        __syncthreads();                // the previous frame's readers are done with S and the planes
+        int nf = 0;
+        for (int i = t; i < kRdL; i += kT) {
+            const long   sidx = f * kN - kRdHb + i;
+            const float2 v = sidx >= 0 ? a.x[sidx] : a.hist[256 + sidx];
+            nf |= (int)!(__builtin_fabsf(v.x) <= 3.4028234663852886e38f) | (int)!(__builtin_fabsf(v.y) <= 3.4028234663852886e38f);
+            sg[ph(i)]         = v.x;
+            sg[kRdLp + ph(i)] = v.y;
+        }
+        if (__syncthreads_or(nf)) continue;
+        // ---- y_f on the FP64 matrix pipe: wave = component x (tile rows (wave >> 1) + 4 i); a tile row = 256 consecutive outputs, D[row = kq + 4 r][col] = output 256 tr + 16 col + kq + 4 r
+        for (int i = 0; i < 8; ++i) {
+            const int    tr = (wave >> 1) + 4 * i;
+            const float* sb = sg + comp * kRdLp + (256 * tr + 16 * col) + 4 * (16 * tr + col) + kq;
+            const float* ta = tz + 15 + kRdHb + col - kq;
+            f64x4_r      acc = {0., 0., 0., 0.};
+            for (int k0 = 0, pad = 0; k0 < kRdKw / 4; k0 += 4, pad += 4) { // a pad of 4 floats every 16 samples = every 4 K-steps of 4
+                float av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { av[q] = ta[-4 * (k0 + q)]; bv[q] = sb[4 * (k0 + q) + pad]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[q], (double)bv[q], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 256 * tr + 16 * col + kq + 4 * r;
+                float     v = (float)acc[r];
+                if constexpr (WIN) v *= a.win[o] * (float)kN; // (the table holds window / N for the fused kernel's unnormalised inverse transform)
+                if constexpr (SMALL) reinterpret_cast<float*>(S)[2 * ((o >> LOG2NF) * NPF + (o & (NF - 1)) + ((o & (NF - 1)) >> 5)) + comp] = v;
+                else reinterpret_cast<float*>(S)[2 * addrA(o >> 8, o & 255) + comp] = v;
+            }
+        }
+        __syncthreads();
+        float* out = a.out + f * kN;
+        if constexpr (SMALL) {
+            auto PF = [](int i) { return i + (i >> 5); };
+            const int fl = t / TF, tt = t % TF;
+            float2*   fb = S + fl * NPF;
+            float2    v[16], Xs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fb[PF(tt + r * TF)];
+            __syncthreads();
+            float2 b2a = sw2a, b2b = sw2b, b3 = sw3, b3sq = sw3sq;
+            asm volatile("" : "+v"(b2a.x), "+v"(b2a.y), "+v"(b2b.x), "+v"(b2b.y), "+v"(b3.x), "+v"(b3.y), "+v"(b3sq.x), "+v"(b3sq.y));
+            fft_small_passes<LOG2NF>(v, fb, tt, b2a, b2b, b3, b3sq, Xs, [] { __syncthreads(); });
+#pragma unroll
+            for (int j = 0; j < 16; ++j) out[(t / TF) * NF + t % TF + j * TF] = fmaf(Xs[j].x, Xs[j].x, Xs[j].y * Xs[j].y);
+        } else {
+            passA_inplace(S, twA, par, n0, sgn);
+            __syncthreads();
+            float2 w[16], X[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
+            __syncthreads();
+            passB_compute_store(S, w, twBr, cb, kb);
+            __syncthreads();
+            passC(S, X, twCr, t);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) out[t + 512 * q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y);
+        }
+    }
+}
 __global__ __launch_bounds__(kT, 2) void chain_fd_multi_kernel(ChainFdArgs a, ChainFdMulti m) { chain_fd_body<kModeMag2, 13, true>(a, &m); }
 
 
@@ -910,6 +1036,8 @@ struct ChainFused {
     unsigned     pw_seen  = 0;         // sequence number of the last measurement handed out
     hipStream_t  pw_stream = nullptr;  // stream of the last measured launch
     float        win_gain = 1.f;       // mean w[n]^2 of the window the measured output carries (1: none)
+    bool         redo     = false;     // measured launches also mark their frames one by one and chain_redo_kernel follows them (chain.hip, GR4HIP_GUARD_STRICT)
+    DeviceBuffer d_fflags;             // one byte per frame of the last launch
     ~ChainFused() {
         if (c16) chain16_destroy(c16);
         if (h_pw) (void)hipHostFree(h_pw);
@@ -1075,6 +1203,11 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         a.pw_host = c->d_hpw;
         a.pw_seq  = c->pw_seq;
         a.pw_thr  = kGuardFrameThreshold * (fir_mode ? 1.f : (float)(c->small_log2n ? (1 << c->small_log2n) : kN) * c->win_gain); // (the scale chain_fused_power_ratio takes out)
+        if (c->redo && !fir_mode) {
+            rc = c->d_fflags.ensure(n_frames);
+            if (rc) return rc;
+            a.fflags = static_cast<unsigned char*>(c->d_fflags.ptr);
+        }
     }
 #ifdef GR4_FD_TIMING
     if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
@@ -1105,6 +1238,13 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fd_kernel<kModeWinSmall, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
         per_device.done(dev, n_cu);
     }
     const size_t   wgs  = c->max_wg ? std::min<size_t>(c->max_wg, (size_t)n_cu) : (size_t)n_cu;
@@ -1122,6 +1262,21 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     else if (c->windowed) hipLaunchKernelGGL(chain_fd_kernel<kModeWinMag2>, dim3(grid), dim3(kT), lds, st, a);
     else hipLaunchKernelGGL(chain_fd_kernel<kModeMag2>, dim3(grid), dim3(kT), lds, st, a);
     GR4_LAUNCH_CHECK();
+    if (a.fflags != nullptr) { // the marked frames again in the time domain, behind the launch that marked them
+        const unsigned rg = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu);
+        const int      nt = (int)c->ntaps;
+        switch (c->small_log2n) {
+        case 8: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 8>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+        case 9: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 9>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+        case 10: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 10>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+        case 11: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 11>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+        case 12: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 12>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+        default:
+            if (c->windowed) hipLaunchKernelGGL(chain_redo_kernel<kModeWinMag2>, dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt);
+            else hipLaunchKernelGGL(chain_redo_kernel<kModeMag2>, dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt);
+        }
+        GR4_LAUNCH_CHECK();
+    }
     // carry the last 256 input samples for the next call's first frame (stream-ordered after the kernel's reads)
     if (carry_hist) GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
     return GR4HIP_OK;
@@ -1237,6 +1392,7 @@ void chain_fused_destroy(ChainFused* c) { delete c; }
 // dynamic-range guard: sampled power ratio (output / input, window gain taken out) of the most recent measured launch.
 // wait: synchronise on that launch; otherwise only report it when it has already finished.  Returns 1 with *ratio set, 0 if nothing (new) is available.
 void chain_fused_set_measure(ChainFused* c, bool on) { c->measure = on; }
+void chain_fused_set_redo(ChainFused* c, bool on) { c->redo = on; }
 int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio) {
     if (!c->h_pw || c->pw_seq == c->pw_read) return 0;
     volatile unsigned* seqw = reinterpret_cast<volatile unsigned*>(c->h_pw) + 2; // sequence number of the launch whose pair the word holds

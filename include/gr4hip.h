@@ -24,8 +24,12 @@
  *     -- the relative error of every value above the rms level of the OUTPUT, the rms-normalised absolute error of every value below it (point-wise relative
  *     error is meaningless at spectral zeros; an all-rms normalisation would ask for better than float32 epsilon on the dominant bin of a quadratic output).
  *     Where the reference's own float32 arithmetic cannot meet that bound (a rejected signal far above the output, an ill-conditioned IIR cascade), the bound is
- *     the reference's float32 error on the same input, and the entry points below say which mechanism keeps the device there (dynamic-range guard, eight-term
- *     products, GR4HIP_IIR_SEQUENTIAL_F32).
+ *     the reference's float32 error on the same input -- the error of its sums evaluated in float32 in ITS order (time_domain_filter.hpp:44-47, iir section by
+ *     section) against float64 -- with a factor of ONE, at every shape (tests and fuzzers compare with the oracle's restatement of exactly that arithmetic, never
+ *     with another device kernel).  What keeps the device there: every FIR / decimator kernel answers to one guard -- a segment whose output power is more than
+ *     21 dB below what white noise of its input power would pass is evaluated again with float64 products and sums (fir_exact.hip; error ~6e-8 of the output
+ *     whatever the signal) --, the fused chain marks such frames and evaluates them again in the time domain behind its launch, and an ill-conditioned IIR
+ *     cascade runs on GR4HIP_IIR_SEQUENTIAL_F32.
  */
 #ifndef GR4HIP_H
 #define GR4HIP_H
@@ -174,27 +178,26 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
 /* FIR_AUTO carries the same dynamic-range guard as GR4HIP_CHAIN_AUTO (gr4hip_chain_last_power_ratio below): the first fast convolution of a stream is probed
  * on eight frames, later ones are watched through the powers every launch measures (every frame judged by itself), and below an output / input power ratio of
  * 0.04 the direct form takes over. */
-/* Accuracy of the direct form on the matrix pipes (the default for 33 .. 256 taps, float 384 .. 1024; GR4HIP_FIR_TIME_DOMAIN for complex data).  Round 4: two-term
- * f16 splits, three products per tap (x1 b1, x1 b2, x2 b1: everything above 2^-22 of a product; a correctly rounded float32 product carries 2^-25).  On ordinary
- * input the error against float64 is that of a float32 sum (3e-7 .. 6e-7, below the three-term bf16 kernel's).  The error is relative to the PRODUCTS, so it shows
- * against the OUTPUT when the filter removes nearly all it is given -- and the kernel judges that itself: every segment's output power P_y is compared with its
- * input power P_x, and a segment with P_y < 2^-12 (sum b^2) P_x (36 dB more rejected than white noise would lose; the products by themselves are then at
- * <= 3e-6 of the output) is evaluated again inside the launch with THREE f16 terms per factor (33 bits: the float32 values themselves; six products per tap, each exact to 2^-33, summed in the
- * matrix pipe's float32 accumulators -- float32 products at twice the matrix-pipe time): under a rejected tone 50 dB above the output the default is at 3e-5 .. 4e-5,
- * the float32 kernels' own error on that input and half the reference's sequential float32 sum's (7e-5), the products alone at 2e-4, the three-term bf16 kernel
- * (GR4HIP_FIR_TIME_DOMAIN_BF16X3: no guard) at 5e-5 .. 1e-4.  gr4hip_fir_set_guard_mode(GR4HIP_GUARD_OFF) switches the verdict off; the 256-tap slices of longer
- * float filters run without it (their launches see partial sums).  After two rejections in a row a workgroup skips the first evaluation of the segments that follow but for every eighth (a probe): a stream in which every segment is rejected runs at
- * 190 (256 taps) .. 376 (64 taps) Gsamples/s. */
+/* Accuracy of the direct form on the matrix pipes (the default for 33 .. 1024 taps and the decimators; GR4HIP_FIR_TIME_DOMAIN for complex data).  Two-term f16
+ * splits under a per-segment block exponent, three products per tap (everything above 2^-22 of a product; a correctly rounded float32 product carries 2^-25): on
+ * ordinary input the error against float64 is that of a float32 sum (3e-7 .. 6e-7).  The error is relative to the PRODUCTS, so it shows against the OUTPUT when the
+ * filter removes nearly all it is given -- like the reference's own float32 sum, whatever its order.  ONE guard for every kernel gr4hip_fir_process can take (round 5):
+ * each segment's output power P_y is compared with its input power P_x, and a segment with D P_y < (sum b^2 / 128) P_x (21 dB more rejected than white noise would lose;
+ * the split products are then at <= 6e-6 of the output) is marked and evaluated again with float64 products and sums, rounded once -- by fir_exact_kernel on the FP64
+ * matrix pipe behind the launch (same stream, no host), inside the workgroup for the register-window kernel, with the filter's load / store programs applied where it
+ * carries any.  Result: within 1e-5 of float64 on every stream tools/tone_ratio.py, tools/fuzz_fir_f16.py and the tests could construct (rejected tones up to 70 dB
+ * above what passes: 6e-8), where the reference's float32 sum itself is at 1e-5 .. 1e-3.  A stream in which EVERY segment is marked runs at the FP64 matrix pipe's
+ * rate (256 taps: ~100 Gsamples/s float, ~50 complex).  gr4hip_fir_set_guard_mode(GR4HIP_GUARD_OFF) switches the verdict off (the kernels' own products).
+ * Non-finite samples: a segment whose window holds one keeps the main kernel's float32 sums (the reference's classes and reach). */
 /* GR4HIP_FIR_TIME_DOMAIN_BF16X3: the three-term bf16 products of rounds 2-3 (six products per tap, everything above 2^-23 of a product, float32's exponent range
- * without a block exponent, no guard) where the default takes the f16 kernels; for complex data also "direct form" like GR4HIP_FIR_TIME_DOMAIN. */
+ * without a block exponent; judged like every kernel) where the default takes the f16 kernels; for complex data also "direct form" like GR4HIP_FIR_TIME_DOMAIN. */
 /* GR4HIP_FIR_EXACT_F32: every product and sum in IEEE float32 (no frequency-domain kernels, no bf16 splits): the kernels whose arithmetic is the reference's
  * transform_reduce (time_domain_filter.hpp:44-47) term for term up to the order of the additions -- an infinite or NaN input sample reaches exactly the
  * ntaps outputs whose window contains it, as +-Inf / NaN (tests/test_gpu_parity.py::test_fir_non_finite_samples pins this and what the default algorithm
  * does instead).  Slower for 33 .. 1024 taps (the f32 MFMA / register-window kernels: DESIGN.md 3.2, 3.6). */
 /* GR4HIP_FIR_TIME_DOMAIN_F32: the direct form with float32 products on the f32 matrix pipe (block-wise float32 sums: at least as close to float64 as the
  * reference's sequential float32 sum -- 7e-6 of the output where a rejected signal 50 dB above it leaves the float32 CPU form at 3e-5 and the three-term bf16
- * products at 1e-4), 33 .. 256 taps at about a third of the bf16 kernels' rate; Inf / NaN reach as described above.  It is where the dynamic-range guard sends
- * a stream (FIR_AUTO's fast convolution, the chain): the regime that made it fall back is the one in which the product precision shows. */
+ * products at 1e-4), 33 .. 256 taps at about a third of the bf16 kernels' rate; Inf / NaN reach as described above.  Judged like every kernel (above). */
 typedef enum { GR4HIP_FIR_AUTO = 0, GR4HIP_FIR_TIME_DOMAIN = 1, GR4HIP_FIR_EXACT_F32 = 2, GR4HIP_FIR_TIME_DOMAIN_F32 = 3, GR4HIP_FIR_TIME_DOMAIN_BF16X3 = 4 } gr4hip_fir_algo;
 int gr4hip_fir_set_algo(gr4hip_fir_t* fir, int algo);
 int gr4hip_fir_set_guard_mode(gr4hip_fir_t* fir, int mode); /* gr4hip_guard_mode (below), for FIR_AUTO's fast convolution of long complex spans and (GUARD_OFF) the f16 direct form's per-segment verdict; default GR4HIP_GUARD_STRICT */
@@ -327,15 +330,18 @@ int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
  * input power (power ratio >= 0.04) and miss it when a strong out-of-band signal is removed.  Every fused launch of an AUTO chain therefore measures input and
  * output power of EVERY frame (all of its samples and bins; a frame whose own ratio is below the threshold marks the launch, whatever the launch's totals say:
  * an interferer that sets in for the last few frames of a long span is seen); what happens with the measurement is the handle's guard mode (gr4hip_chain_set_guard_mode below; default STRICT: the
- * call that measures a ratio below 0.04 redoes its span with the direct-form kernels -- the reference's arithmetic, history handed over -- before it returns,
- * and the chain stays there until gr4hip_chain_reset).  Explicit GR4HIP_CHAIN_FUSED_FD never measures nor switches.  This call waits for the last measured
+ * frames a launch marks are evaluated again in the time domain by a second launch enqueued behind it, and a later call that finds a launch-wide ratio below 0.04 moves
+ * the stream to the direct-form kernels -- history handed over -- where it stays until gr4hip_chain_reset).  Explicit GR4HIP_CHAIN_FUSED_FD never measures nor switches.  This call waits for the last measured
  * launch and returns its ratio (< 0: nothing measured yet; the launch's totals -- or half the threshold when they are above it but one frame by itself was not)
  * and whether the chain now runs in the time domain. */
 int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time_domain, gr4hip_stream_t stream);
 /* What the guard does with its measurement (per handle; GR4HIP_CHAIN_AUTO chains on the fused frequency-domain kernel only, a no-op elsewhere):
- *   GR4HIP_GUARD_STRICT (default): every call awaits the measurement of its OWN launch and redoes a span that fell below the threshold with the direct-form
- *     kernels, from the history the call started with, before it returns: nothing out of tolerance is ever handed out.  The price: gr4hip_chain_process
- *     returns when its launch has finished (one host synchronisation per call) instead of when it is queued.
+ *   GR4HIP_GUARD_STRICT (default): nothing out of tolerance is ever handed out, and nobody waits.  The fused kernel writes one verdict byte per frame; chain_redo_kernel,
+ *     enqueued behind it on the same stream, evaluates exactly the marked frames again -- y = sum b[k] x[n - k] on the FP64 matrix pipe, window, frame transform,
+ *     |.|^2 over the fused result (an ordinary stream costs one near-empty launch, ~5 us).  gr4hip_chain_process returns when both launches are queued ("user code
+ *     must not block in work()", docs/USER_API_advanced_work.md).  The measurement of an EARLIER launch, once it has arrived, moves a stream that rejects most of its
+ *     input to the direct-form kernels for good (the faster way through such a stream) -- read without waiting.  Several chains in one call
+ *     (gr4hip_chain_process_multi) still await their shared launch.
  *   GR4HIP_GUARD_DEFERRED: calls stay asynchronous.  The first call after create / reset probes its first 8 blocks synchronously; later calls read the finished
  *     measurements of EARLIER launches, so the call in which a strong out-of-band signal first appears is published from the fused kernel (error floor
  *     ~2e-6 of the input rms) and the switch happens from the next call on.

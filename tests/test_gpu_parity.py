@@ -1577,11 +1577,12 @@ def test_chain_dynamic_range_and_the_time_domain_algo(G):
         if algo == G.capi.CHAIN_AUTO:
             assert _rel(got, truth) <= TOL  # every frame, the probed first ones included
             ratio, td = ch.last_power_ratio()
-            assert td and 0 <= ratio < 0.04, (ratio, td)
-            # ... and it stays there across calls (history handed over), until reset
+            assert not td and 0 <= ratio < 0.04, (ratio, td)  # (the call's marked frames were evaluated again on the device, behind the fused launch: nobody waited, nothing switched yet)
+            # ... the next call finds that measurement and moves the stream to the time-domain kernels (history handed over), where it stays until reset
             x2 = O.signal_c32(78, 4 * N, tone_frel=0.31, tone_amp=30.0)
             t2, _ = O.chain(b, np.concatenate([x, x2]), N, 3, truth=True)
             assert _rel(ch.process_bulk(dev(x2)).cpu().numpy().ravel(), t2[frames * N:]) <= TOL
+            assert ch.last_power_ratio()[1]
     assert errs[G.capi.CHAIN_TIME_DOMAIN] <= TOL and errs[G.capi.CHAIN_AUTO] <= TOL
     assert errs[G.capi.CHAIN_FUSED_FD] > TOL > errs[G.capi.CHAIN_TIME_DOMAIN]  # the price of the fused kernel on this input ...
     # ... and its bound: amplitude errors stay below 4e-6 of the input rms: |d mag2| <= 2 |Y| dY + dY^2 with dY = 4e-6 in_rms sqrt(N sum w^2)
@@ -1598,6 +1599,50 @@ def test_chain_dynamic_range_and_the_time_domain_algo(G):
     fa = G.fir_filter(b, torch.complex64)
     got = np.concatenate([fa.process_bulk(dev(xp[: 70 * N])).cpu().numpy(), fa.process_bulk(dev(xp[70 * N:])).cpu().numpy()])
     assert np.max(np.abs(got - yp)) <= 4e-6 * float(np.sqrt(np.mean(np.abs(xp) ** 2))) and _rel(got, yp) <= TOL
+
+
+def test_chain_strict_guard_does_not_wait_for_its_launch(G):
+    """GR4HIP_GUARD_STRICT without the host: gr4hip_chain_process returns while its launch is still running (an event recorded behind the call has not completed
+    when the call is back), two guarded chains on two streams overlap, and a stream whose every frame is marked still meets the bar -- the second evaluation
+    (chain_redo_kernel) rides the same stream.  docs/USER_API_advanced_work.md: user code must not block in work()"""
+    N, ntaps = 8192, 256
+    b = O.design_taps_hamming_lowpass(ntaps, 0.05)
+    frames = 1 << 14                                        # 2^27 samples: ~0.4 ms of kernel
+    x = G.synth_c32(frames * N, seed=3)
+    out = torch.empty(frames * N, dtype=torch.float32, device="cuda")
+    ch = G.Chain(b, N, "None")
+    assert ch.algo == G.capi.CHAIN_FUSED_FD
+    ch.process_bulk(x, out); torch.cuda.synchronize()       # (warm: tables, first-launch costs)
+    pending = 0
+    for _ in range(5):
+        ev = torch.cuda.Event()
+        ch.process_bulk(x, out)
+        ev.record()
+        pending += 0 if ev.query() else 1
+        torch.cuda.synchronize()
+    assert pending >= 4, pending                            # the call came back before its kernels were through
+    # two handles, two streams: both launches in flight together (each call returns at once, so the second is enqueued while the first runs)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    c1, c2 = G.Chain(b, N, "None"), G.Chain(b, N, "None")
+    o1, o2 = torch.empty_like(out), torch.empty_like(out)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        c1.process_bulk(x, o1); e1 = torch.cuda.Event(); e1.record()
+    with torch.cuda.stream(s2):
+        c2.process_bulk(x, o2); e2 = torch.cuda.Event(); e2.record()
+    assert not e1.query() or not e2.query()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    # every frame marked: the result is the time-domain evaluation's
+    n2 = 64 * N
+    loud = O.signal_c32(6, n2, tone_frel=0.31, tone_amp=300.0)
+    bl = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    truth, _ = O.chain(bl, loud, N, 0, truth=True)
+    for window, wid in (("None", 0), ("Hann", 3)):
+        tw, _ = O.chain(bl, loud, N, wid, truth=True)
+        cg = G.Chain(bl, N, window)
+        assert cg.algo == G.capi.CHAIN_FUSED_FD
+        assert _rel(cg.process_bulk(dev(loud)).cpu().numpy().ravel(), tw) <= TOL, window
 
 
 def test_chain_guard_hands_small_fft_sizes_to_the_fused_time_domain_kernel(G):
@@ -1620,7 +1665,7 @@ def test_chain_guard_hands_small_fft_sizes_to_the_fused_time_domain_kernel(G):
 
 def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
     """the guard of CHAIN_AUTO: pass-band input never leaves the fused kernel; an interferer that appears in a LATER call is found by that call's own
-    measurement.  GUARD_STRICT (default): the call redoes its span in the time domain before it returns -- EVERY call meets the bar.  GUARD_DEFERRED: the call
+    measurement.  GUARD_STRICT (default): the frames the fused kernel marks are evaluated again in the time domain by a launch enqueued behind it -- EVERY call meets the bar, no call waits.  GUARD_DEFERRED: the call
     that measures the drop is published from the fused kernel (its floor: ~2e-6 of the input rms, as include/gr4hip.h says) and the next call has switched."""
     N, ntaps = 8192, 64
     b = O.design_taps_hamming_lowpass(ntaps, 0.02)
@@ -1633,9 +1678,9 @@ def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
     parts = [ch.process_bulk(dev(clean)).cpu().numpy().ravel()]
     r, td = ch.last_power_ratio()
     assert not td and r > 0.04
-    parts.append(ch.process_bulk(dev(loud)).cpu().numpy().ravel())     # measured below the threshold -> redone in the time domain inside the call
+    parts.append(ch.process_bulk(dev(loud)).cpu().numpy().ravel())     # every frame measured below the threshold -> evaluated again in the time domain behind the fused launch (chain_redo_kernel)
     r, td = ch.last_power_ratio()
-    assert 0 <= r < 0.04 and td
+    assert 0 <= r < 0.04 and not td                                    # (the stream moves with the NEXT call, which finds this measurement without waiting for it)
     parts.append(ch.process_bulk(dev(loud)).cpu().numpy().ravel())
     assert ch.last_power_ratio()[1]
     assert _rel(parts[0], t[0]) <= TOL and _rel(parts[1], t[1]) <= TOL and _rel(parts[2], t[2]) <= TOL
@@ -1643,7 +1688,7 @@ def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
     ch.reset()
     mixed = np.concatenate([clean[: 20 * N], loud[: 20 * N]])
     tm, _ = O.chain(b, mixed, N, 0, truth=True)
-    assert _rel(ch.process_bulk(dev(mixed)).cpu().numpy().ravel(), tm) <= TOL and ch.last_power_ratio()[1]
+    assert _rel(ch.process_bulk(dev(mixed)).cpu().numpy().ravel(), tm) <= TOL and not ch.last_power_ratio()[1]  # (frame by frame: only the marked ones)
     # GUARD_DEFERRED: asynchronous calls, the switch lags by one call
     cd = G.Chain(b, N, "None")
     cd.set_guard_mode(G.capi.GUARD_DEFERRED)
@@ -1709,7 +1754,7 @@ def test_fir_decimate_by_8_dynamic_range_guard(G, devsw):
 def test_guard_sees_every_frame_and_block(G, devsw):
     """an interferer that sets in near the END of a long call -- where one workgroup has long left its first frame behind -- or only for a few frames is seen:
     the kernels judge every frame / block by itself (workgroup-wide sums of output - threshold x input power), not a sample of them, and not the launch's totals,
-    which such a short event barely moves.  Strict guard: the span is redone before the call returns, every output inside the bar."""
+    which such a short event barely moves.  Strict guard: the marked frames are evaluated again behind the launch (chain_redo_kernel), every output inside the bar."""
     N, ntaps = 8192, 100
     b = O.design_taps_hamming_lowpass(ntaps, 0.05)
     frames = 700                                                  # 256 workgroups: frames 512 .. 699 are every workgroup's third iteration
@@ -1723,7 +1768,7 @@ def test_guard_sees_every_frame_and_block(G, devsw):
         assert ch.algo == G.capi.CHAIN_FUSED_FD
         got = ch.process_bulk(dev(xi)).cpu().numpy().ravel()
         r, td = ch.last_power_ratio()
-        assert td and r < 0.04, (first, count, r)                 # the launch-wide ratio alone is ~0.3: one frame below the threshold marks the launch
+        assert not td and r < 0.04, (first, count, r)             # the launch-wide ratio alone is ~0.3: one frame below the threshold marks the launch (and chain_redo_kernel evaluates the marked frames again)
         assert _rel(got, truth) <= TOL, (first, count)
     # the frequency-domain decimator: a blocker in the last 3 of 700 blocks
     D, nt = 8, 1024
@@ -1753,7 +1798,7 @@ def test_guard_destination_multiplies_in_float32(G):
     truth, _ = O.chain(b, x, N, 0, truth=True)
     ch = G.Chain(b, N, "None")                                   # AUTO: the guard trips on the first call and redoes it
     got = ch.process_bulk(dev(x)).cpu().numpy().ravel()
-    assert ch.last_power_ratio()[1] and _rel(got, truth) <= TOL
+    assert 0 <= ch.last_power_ratio()[0] < 0.04 and _rel(got, truth) <= TOL
     assert _rel(G.Chain(b, N, "None", G.capi.CHAIN_TIME_DOMAIN).process_bulk(dev(x)).cpu().numpy().ravel(), truth) <= TOL
     # the FIR alone: float32 products against the default three-term bf16 ones, both against float64
     yt, _ = O.fir(b, x)                                           # (float64 accumulation)
