@@ -94,6 +94,16 @@ __global__ __launch_bounds__(256, 1) void fir_exact_kernel(FirExactArgs a) {
         }
         y[o * NC + c] = v;
     };
+    if (flags != nullptr) { // an ordinary stream marks nothing: every lane looks at its share of the workgroup's flag bytes at once and the workgroup leaves (a lane that walks
+                            // them one dependent load after the other cost configs[3] 50 us of its 520)
+        const long nseg = ((a.n_out - 1) >> a.seg_shift) + 1;
+        int        any  = 0;
+        for (long u = (long)blockIdx.x + (long)tid * gridDim.x; u < a.n_units; u += 256L * gridDim.x) {
+            const long s0 = (u * UO) >> a.seg_shift, s1 = ((u + 1) * UO - 1) >> a.seg_shift;
+            for (long sgi = s0; sgi <= s1 && sgi < nseg; ++sgi) any |= flags[sgi];
+        }
+        if (!__syncthreads_or(any)) return;
+    }
     for (int i = tid; i < Kw + 15 * D; i += 256) {
         const int k = i - 15 * D;
         tz[i]       = (k >= 0 && k < a.ntaps) ? taps[k] : 0.f;
