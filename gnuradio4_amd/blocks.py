@@ -44,6 +44,16 @@ def _dev(x: torch.Tensor, what: str) -> torch.Tensor:
     return x.resolve_conj().contiguous()  # materialise lazy conj views: the kernels read raw memory
 
 
+def _out(out: Optional[torch.Tensor], numel: int, dtype, x: torch.Tensor, what: str, shape=None) -> torch.Tensor:
+    """the tensor a kernel writes: allocated here, or the caller's -- which must be a contiguous device tensor of the result's dtype with room for it (the kernels
+    write raw memory: an undersized or host tensor would be an out-of-bounds device write)"""
+    if out is None:
+        return torch.empty(shape if shape is not None else numel, dtype=dtype, device=x.device)
+    if not isinstance(out, torch.Tensor) or not out.is_cuda or out.device != x.device or not out.is_contiguous() or out.dtype != dtype or out.numel() < numel:
+        raise capi.Gr4HipError(capi.INVALID_ARGUMENT, what, f"out must be a contiguous tensor on the input's device, dtype {dtype}, at least {numel} elements")
+    return out
+
+
 def _window_id(window) -> int:
     if isinstance(window, str):
         names = [w.lower() for w in capi.WINDOWS]
@@ -123,8 +133,7 @@ class fir_filter(_Handle):
         if x.dtype != self.dtype:
             raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "fir_filter", f"expected {self.dtype}, got {x.dtype}")
         n_out = x.numel() // self.decimate
-        if out is None:
-            out = torch.empty(n_out, dtype=self.dtype, device=x.device)
+        out = _out(out, n_out, self.dtype, x, "fir_filter.process")
         fn = lib().gr4hip_fir64_process if self._f64 else lib().gr4hip_fir_process
         check(fn(self._h, x.data_ptr(), x.numel(), out.data_ptr(), None, _stream()), "fir_filter.process")
         return out
@@ -154,8 +163,7 @@ class fir_interpolator(_Handle):
         x = _dev(x, "fir_interpolator")
         if x.dtype != self.dtype:
             raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "fir_interpolator", f"expected {self.dtype}, got {x.dtype}")
-        if out is None:
-            out = torch.empty(x.numel() * self.interpolate, dtype=self.dtype, device=x.device)
+        out = _out(out, x.numel() * self.interpolate, self.dtype, x, "fir_interpolator.process")
         check(lib().gr4hip_fir_interp_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), None, _stream()), "fir_interpolator.process")
         return out
 
@@ -207,8 +215,7 @@ class iir_filter(_Handle):
         x = _dev(x, "iir_filter")
         if x.dtype != self.dtype:
             raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "iir_filter", f"expected {self.dtype}, got {x.dtype}")
-        if out is None:
-            out = torch.empty_like(x)
+        out = _out(out, x.numel(), x.dtype, x, "iir_filter.process")
         fn = lib().gr4hip_iir64_process if self._f64 else lib().gr4hip_iir_process
         check(fn(self._h, x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "iir_filter.process")
         return out
@@ -222,8 +229,7 @@ def fir_iir_process(fir: "fir_filter", iir: "iir_filter", x: torch.Tensor, out: 
     if x.dtype != torch.float32 or fir.dtype != torch.float32 or iir.dtype != torch.float32:
         raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "fir_iir_process", "float32 stream, filter and cascade")
     n_out = x.numel() // fir.decimate
-    if out is None:
-        out = torch.empty(n_out, dtype=torch.float32, device=x.device)
+    out = _out(out, n_out, torch.float32, x, "fir_iir_process")
     check(lib().gr4hip_fir_iir_process(fir._h, iir._h, x.data_ptr(), x.numel(), out.data_ptr(), None, int(mode), _stream()), "fir_iir_process")
     return out
 
@@ -353,8 +359,7 @@ class FFT(_Handle):
 
     def spectrum(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x, frames = self._frames(x)
-        if out is None:
-            out = torch.empty((frames, self.fftSize), dtype=torch.complex64, device=x.device)
+        out = _out(out, frames * self.fftSize, torch.complex64, x, "FFT.spectrum", (frames, self.fftSize))
         check(lib().gr4hip_fft_spectrum(self._h, x.data_ptr(), frames, out.data_ptr(), _stream()), "FFT.spectrum")
         return out
 
@@ -364,8 +369,7 @@ class FFT(_Handle):
 
     def mag2(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x, frames = self._frames(x)
-        if out is None:
-            out = torch.empty((frames, self.fftSize), dtype=torch.float32, device=x.device)
+        out = _out(out, frames * self.fftSize, torch.float32, x, "FFT.mag2", (frames, self.fftSize))
         check(lib().gr4hip_fft_mag2(self._h, x.data_ptr(), frames, out.data_ptr(), _stream()), "FFT.mag2")
         return out
 
@@ -401,8 +405,7 @@ class Chain(_Handle):
         if x.dtype != torch.complex64:
             raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Chain", "input must be complex64")
         frames = x.numel() // self.fftSize
-        if out is None:
-            out = torch.empty((frames, self.fftSize), dtype=torch.float32, device=x.device)
+        out = _out(out, frames * self.fftSize, torch.float32, x, "Chain.process", (frames, self.fftSize))
         nf = C.c_size_t(0)
         check(lib().gr4hip_chain_process(self._h, x.data_ptr(), x.numel(), out.data_ptr(), C.byref(nf), _stream()), "Chain.process")
         return out
@@ -552,8 +555,7 @@ class Merged(_Handle):
         if x.dtype != self.dtype:
             raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Merged", f"expected {self.dtype}, got {x.dtype}")
         n_out = -(-x.numel() // int(decim))
-        if out is None:
-            out = torch.empty(n_out, dtype=self.dtype, device=x.device)
+        out = _out(out, n_out, self.dtype, x, "Merged.decimate")
         check(lib().gr4hip_ewise_decimate(self._h, x.data_ptr(), x.numel(), int(decim), out.data_ptr(), None, _stream()), "Merged.decimate")
         return out
 
@@ -561,8 +563,7 @@ class Merged(_Handle):
         x = _dev(x, "Merged")
         if x.dtype != self.dtype:
             raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Merged", f"expected {self.dtype}, got {x.dtype}")
-        if out is None:
-            out = torch.empty_like(x)
+        out = _out(out, x.numel(), x.dtype, x, "Merged.process")
         check(lib().gr4hip_ewise_process(self._h, x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "Merged.process")
         return out
 
@@ -618,8 +619,7 @@ class Rotator(_Handle):
         x = _dev(x, "Rotator")
         if x.dtype != self.dtype:
             raise capi.Gr4HipError(capi.INVALID_ARGUMENT, "Rotator", f"expected {self.dtype}, got {x.dtype}")
-        if out is None:
-            out = torch.empty_like(x)
+        out = _out(out, x.numel(), x.dtype, x, "Rotator.process")
         fn = lib().gr4hip_rotator64_process if self._f64 else lib().gr4hip_rotator_process
         check(fn(self._h, x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "Rotator.process")
         return out

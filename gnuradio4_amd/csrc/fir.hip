@@ -1077,6 +1077,11 @@ extern "C" int gr4hip_fir_iir_process(gr4hip_fir_t* f, gr4hip_iir_t* iir, const 
     float*           st_out = nullptr;
     int              nsec = 0, warm = 0;
     const size_t     whole = n_in / kHop * kHop;
+    if (f->folded != 1.0 && !f->pre && !f->post) { // (a gain prologue / epilogue that was taken off again left its factor in the taps on this path: gr4hip_fir_process undoes it
+                                                   // through fir_prepare_hooks, the fused launch below never came by there)
+        FirHooks hk0;
+        if (const int rc = fir_prepare_hooks(f, &hk0)) return rc;
+    }
     const bool       fusable = mode == GR4HIP_FIR_IIR_ONE_LAUNCH && f->S == 1 && f->decim == 8 && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked && !f->pre && !f->post && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 &&
                          whole >= kMinBlocks * kHop && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0 && !dev_switch(kDevFirNoDecimFd) &&
                          gr4hip_internal_iir_fusable(iir, &tab, &nsec, &st_in, &st_out, &warm);

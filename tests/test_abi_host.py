@@ -164,3 +164,22 @@ def test_developer_switch_names():
     L = capi.lib()
     assert L.gr4hip_developer_switch(b"GR4HIP_FFT_SMOOTH_RUNTIME", 1) == 0 and L.gr4hip_developer_switch(b"GR4HIP_FFT_SMOOTH_RUNTIME", 0) == 0
     assert L.gr4hip_developer_switch(b"GR4HIP_NO_SUCH_SWITCH", 1) < 0 and b"unknown switch" in L.gr4hip_last_error()
+
+
+def test_no_kernel_of_the_shipped_library_spills_vector_registers():
+    """the second-evaluation loops of the f16 FIR kernels spilled (26 .. 82 VGPRs, 108 .. 300 B of scratch) while DESIGN.md said they did not.
+    Round 5 moved every second evaluation out of the main kernels (fir_exact.hip); this reads the AMDGPU metadata notes of the code objects inside the shipped
+    libgr4hip.so (tools/kernel_resources.py, llvm-readelf --notes; no GPU needed): no FIR / decimator / chain kernel keeps anything in scratch memory.
+    Known, listed here so the list cannot grow unseen: chain_td_kernel<9, 11 / 12> (2 VGPRs, 12 B, outside their loops), fir_decim_fd_kernel<true> (the opt-in one-launch
+    decimator + cascade: 8 VGPRs), iir_pass_b<16> (the 16-state scan of cascades with more than 8 states: 71 VGPRs)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = kr.kernels()
+    assert len(ks) > 300
+    accepted = ("chain_td_kernel<9, 11>", "chain_td_kernel<9, 12>", "fir_decim_fd_kernel<true>", "iir_pass_b<16>")
+    bad = [(k["demangled"][:80], k["vspill"], k["scratch"]) for k in ks if (k["vspill"] or k["scratch"]) and not any(a in k["demangled"] for a in accepted)]
+    assert not bad, bad
+    for fam in ("fir_mfma_f16x2_kernel", "fir_mfma_f16x2_c32_kernel", "fir_decim_f16x2_kernel", "fir_exact_kernel", "chain_fd_kernel", "chain_redo_kernel", "fir_poly_kernel"):
+        assert any(fam in k["demangled"] for k in ks), fam

@@ -61,6 +61,26 @@ def devsw(G):
 
 
 # ------------------------------------------------------------------ plumbing
+def test_caller_supplied_output_tensors_are_checked(G):
+    """an undersized, host-side, strided or wrongly typed `out` handed to a kernel is an out-of-bounds device write -- every entry point of the host layer
+    that takes one refuses it (INVALID_ARGUMENT) before anything is launched"""
+    x = G.synth_f32(4096, seed=1)
+    b = O.design_taps_hamming_lowpass(31, 0.1)
+    f = G.fir_filter(b, torch.float32, decimate=4)
+    good = torch.empty(1024, dtype=torch.float32, device="cuda")
+    assert f.process_bulk(x, good) is good
+    for bad in (torch.empty(1023, dtype=torch.float32, device="cuda"), torch.empty(1024, dtype=torch.float32), torch.empty(1024, dtype=torch.float64, device="cuda"),
+                torch.empty(2048, dtype=torch.float32, device="cuda")[::2]):
+        with pytest.raises(G.capi.Gr4HipError):
+            f.process_bulk(x, bad)
+        with pytest.raises(G.capi.Gr4HipError):
+            G.Merged(torch.float32, [("Add", 1.0)]).decimate(x, 4, bad)
+    with pytest.raises(G.capi.Gr4HipError):
+        G.Merged(torch.float32, [("Add", 1.0)]).process_bulk(x, torch.empty(4095, dtype=torch.float32, device="cuda"))
+    with pytest.raises(G.capi.Gr4HipError):
+        G.FFT(256, "None").mag2(G.synth_c32(1024), torch.empty(1023, dtype=torch.float32, device="cuda"))
+
+
 def test_native_library_is_loaded_and_shares_torch_runtime(G):
     L = G.capi.lib()
     n = C.c_int(0)
