@@ -229,6 +229,27 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
     }
 }
 
+// the shape no tiled kernel takes (decimation x taps beyond every LDS tiling, e.g. complex data decimated by 100): one output per lane, the reference's sum term for term
+// (time_domain_filter.hpp:44-47 -- taps ascending, float32 fma), samples through the caches.  Slow and always there.
+template <int S>
+__global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restrict__ x, const float* __restrict__ hist, int hcap, const float* __restrict__ b, int ntaps, long D,
+                                                          float* __restrict__ y, long n_out, long n_in) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_out) return;
+    float acc[S];
+#pragma unroll
+    for (int c = 0; c < S; ++c) acc[c] = 0.f;
+    for (int k = 0; k < ntaps; ++k) {
+        const long   i = m * D - k;
+        const float* p = i >= 0 ? (i < n_in ? x + i * S : nullptr) : (i >= -(long)hcap ? hist + ((long)hcap + i) * S : nullptr);
+        if (p == nullptr) continue;
+#pragma unroll
+        for (int c = 0; c < S; ++c) acc[c] = fmaf(b[k], p[c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < S; ++c) y[m * S + c] = acc[c];
+}
+
 // new_hist[h] = virtual_input[n_in - hcap + h]  (virtual_input(i<0) = old_hist[hcap + i])
 __global__ void fir_hist_update_kernel(const float* __restrict__ x, const float* __restrict__ old_hist, float* __restrict__ new_hist, long n_in,
                                        int hcap, int S) {
@@ -602,7 +623,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     int        brc  = GR4HIP_OK;
     const bool band = hk.any && fir_decim_bf16_ready(f, n_in, d_in, d_out, &brc); // (those kernels carry the hooks themselves)
     if (brc) return brc;
-    if (hk.any && fast_shape && !band) {
+    auto around = [&]() -> int { // the programs as element-wise launches in front of / behind the plain filter
         hipStream_t st  = as_stream(stream);
         const void* src = d_in;
         if (hk.pre.n_ops > 0) {
@@ -614,8 +635,13 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
         if (const int rc = fir_process_core(f, src, n_in, d_out, stream, none)) return rc;
         if (hk.post.n_ops > 0) return ewise_run(hk.post, f->dtype, d_out, d_out, (long)n_out, st);
         return GR4HIP_OK;
-    }
-    return fir_process_core(f, d_in, n_in, d_out, stream, hk);
+    };
+    if (hk.any && fast_shape && !band) return around();
+    const int rc = fir_process_core(f, d_in, n_in, d_out, stream, hk);
+    //  a hooked decimator whose phase rows do not fit the register-window kernel's LDS at any workgroup size (decimation ~100 with few taps) -- the one kernel
+    // that carries hooks there -- is served like the fast shapes: nothing has been launched or moved when the core says UNSUPPORTED
+    if (rc == GR4HIP_UNSUPPORTED && hk.any) return around();
+    return rc;
 }
 
 } // extern "C"
@@ -1023,6 +1049,13 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         }
         rc = fir_decim_band_launch((int)f->decim, f->bandKp, x, hist, (int)f->hcap, (const float*)f->d_band.ptr, y, (long)n_out, (long)n_in, st);
         if (rc == GR4HIP_OK) { unj_from = 0; unj_hist = hist; }
+    }
+    if (rc == GR4HIP_UNSUPPORTED && done == 0 && plain) { // no tiling fits: the one-output-per-lane kernel (the guard's second evaluation follows it where that one fits)
+        const unsigned g = (unsigned)ceil_div((long)n_out, 256L);
+        if (f->S == 1) hipLaunchKernelGGL(fir_generic_kernel<1>, dim3(g), dim3(256), 0, st, x, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (long)f->decim, y, (long)n_out, (long)n_in);
+        else hipLaunchKernelGGL(fir_generic_kernel<2>, dim3(g), dim3(256), 0, st, x, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (long)f->decim, y, (long)n_out, (long)n_in);
+        GR4_LAUNCH_CHECK();
+        rc = GR4HIP_OK; unj_from = 0; unj_hist = hist;
     }
     if (rc == GR4HIP_UNSUPPORTED) { set_error("fir_process: ntaps=%zu decim=%zu does not fit the LDS tiling", f->ntaps, f->decim); return rc; }
     if (rc) return rc;

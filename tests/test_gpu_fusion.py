@@ -174,7 +174,7 @@ def _fir64(b, x, decim=1):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("ntaps,decim", [(45, 1), (200, 1), (64, 4), (1024, 8), (31, 3), (200, 16), (100, 8), (520, 8), (80, 10), (64, 2), (300, 5)])
+@pytest.mark.parametrize("ntaps,decim", [(45, 1), (200, 1), (64, 4), (1024, 8), (31, 3), (200, 16), (100, 8), (520, 8), (80, 10), (64, 2), (300, 5), (40, 100)])
 def test_fir_takes_its_neighbours_into_its_launch(G, cplx, ntaps, decim):
     """per-sample blocks in front of and behind a FIR filter, executed by the filter's kernel: gains folded into the taps, adds / complex gains / a rotator as
     load and store hooks -- of the register-window kernel, or of the band-form matrix-pipe decimators (decimation 2 .. 12 float, 3 .. 16 complex, long spans) where the

@@ -462,6 +462,22 @@ def test_fir_complex_decimating_long_input_matrix_pipe(G, decim, ntaps):
 
 
 
+@pytest.mark.parametrize("cplx,D,ntaps", [(True, 100, 40), (True, 128, 1000), (False, 200, 500), (False, 1000, 3), (True, 1000, 1), (False, 129, 4000)])
+def test_fir_shapes_beyond_every_tiling(G, cplx, D, ntaps):
+    """BasicDecimatingFilter takes any `decimate` a user types (time_domain_filter.hpp:190-204): decimation x taps beyond every LDS tiling of the tiled kernels
+    (complex data decimated by 100, float by more than 128) -- until round 5 GR4HIP_UNSUPPORTED -- runs on the one-output-per-lane kernel, the reference's sum term for
+    term; ragged calls carry the history"""
+    rng = np.random.default_rng(D + ntaps)
+    b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = D * 3000
+    x = O.signal_c32(3, n) if cplx else O.signal_f32(3, n)
+    truth = O.fir(b, x)[0][::D]
+    f = G.fir_filter(b, torch.complex64 if cplx else torch.float32, decimate=D)
+    cuts = [0, D * 7, D * 1000, n]
+    y = np.concatenate([f.process_bulk(dev(x[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert y.shape == truth.shape and _rel(y, truth) <= TOL
+
+
 @pytest.mark.parametrize("cplx,D,ntaps,algo,short", [
     (True, 2, 300, "FIR_AUTO", False),            # the register-window kernel (fir_poly_kernel): the phase-by-phase float32 sum measured 12 x the reference's order on this shape
     (True, 2, 256, "FIR_EXACT_F32", False),
