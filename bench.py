@@ -132,7 +132,8 @@ def cpu_baseline(target_seconds: float = 12.0):
             list(ex.map(lambda c: O.chain(b, xs[c % len(xs)], NFFT, 0, truth=False, L=L), range(ncore)))
         dta = time.perf_counter() - t0
         res["all_cores"] = {"value": round(ncore * per * NFFT / dta / 1e6, 3), "unit": "Msamples/s", "cores": ncore,
-                            "sample": f"{ncore} independent chains x {per} frames, one per hardware thread"}
+                            "sample": f"{ncore} independent chains x {per} frames, one per usable hardware thread: {ncore} of the host's {os.cpu_count()} threads (this process's affinity mask); "
+                                      f"the whole host's one-chain-per-thread ceiling is about {os.cpu_count() / max(ncore, 1):.0f} x this value"}
     except Exception as e:  # the single-core number above is the contract; this one is context
         res["all_cores"] = {"error": str(e)}
     return res
@@ -234,6 +235,17 @@ def secondary_configs(G, verify):
     row = {"workload": "64 channels x 256-tap float FIR x 2^22 samples (BASELINE.json configs[3]), csrc/fir_f16.hip", "value": round(nch * n / (ms * 1e-3) / 1e6, 1), "unit": "Msamples/s",
            "ms_per_launch": round(ms, 4), "bytes_per_sample": 8, "hbm_frac": round(nch * n * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "float32_equivalent_TFLOP/s": round(nch * n * 2 * ntaps / (ms * 1e-3) / 1e12, 1), "executed_f16_TFLOP/s": round(nch * n * 3 * 2 * 288 / (ms * 1e-3) / 1e12, 1)}
+    row["arithmetic"] = "f16x2 (two-term f16 splits under a per-segment block exponent: 22-bit products, float32 accumulation; segments that reject > 21 dB again in float64)"
+    try:  # the 24-bit form beside it: three-term bf16 products (csrc/fir_bf16.hip) on the same launch
+        capi.developer_switch("GR4HIP_FIR_NO_F16X2", 1)
+        fb3 = G.FirBatched(taps)
+        ms3 = rate(lambda: fb3.process_bulk(xb, yb), 20)
+        row["bf16x3_24bit_products_msamples"] = round(nch * n / (ms3 * 1e-3) / 1e6, 1)
+        del fb3
+    except Exception as e:
+        row["bf16x3_24bit_products_msamples"] = str(e)[:120]
+    finally:
+        capi.developer_switch("GR4HIP_FIR_NO_F16X2", 0)
     if verify:
         fb2 = G.FirBatched(taps)  # (a fresh history: the timed handle has seen the span many times)
         fb2.process_bulk(xb, yb)
@@ -261,6 +273,21 @@ def secondary_configs(G, verify):
     ms = rate(both, 20)
     row = {"workload": "decimate-by-8 1024-tap float FIR (csrc/fir_decim_f16.hip) + 4 biquads x 2^27 input samples (BASELINE.json configs[2]), two launches", "value": round(n2 / (ms * 1e-3) / 1e6, 1),
            "unit": "Msamples/s (input rate)", "ms_per_pass": round(ms, 4), "bytes_per_input_sample": 5.5, "hbm_frac": round(n2 * 5.5 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    row["arithmetic"] = "decimator: f16x2 (22-bit products, float32 accumulation; segments that reject > 21 dB again in float64); cascade: float32, exact parallel-in-time scan"
+    try:  # the 24-bit forms beside it: the frequency-domain decimator (float32 transforms) -- what decimate-by-8 at 1024 taps takes without the f16 kernel
+        capi.developer_switch("GR4HIP_FIR_NO_DECIM_F16", 1)
+        fir3, iir3 = G.fir_filter(b1024, torch.float32, decimate=8), G.iir_filter(bi, ai)
+
+        def both3():
+            fir3.process_bulk(x, yd)
+            iir3.process_bulk(yd, yo)
+        ms3 = rate(both3, 20)
+        row["f32_frequency_domain_decimator_msamples"] = round(n2 / (ms3 * 1e-3) / 1e6, 1)
+        del fir3, iir3
+    except Exception as e:
+        row["f32_frequency_domain_decimator_msamples"] = str(e)[:120]
+    finally:
+        capi.developer_switch("GR4HIP_FIR_NO_DECIM_F16", 0)
     if verify:
         fir2, iir2 = G.fir_filter(b1024, torch.float32, decimate=8), G.iir_filter(bi, ai)
         fir2.process_bulk(x, yd)
@@ -593,6 +620,7 @@ def main():
             "value_at_median_step": round(float(n) * n_channels / (median_step_ms * 1e-3) / 1e6, 3),  # the median over the timed steps (HIP events on the launch stream)
             "prewarm_ms": round(prewarm_ms, 1), "prewarm_steps": prewarm_steps, "higher_is_better": True, "scaling": "strong" if combine else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": "f32 (float32 butterflies and twiddles; the 255-sample correction FIR on three-term bf16 products, 24 bits; marked frames again in float64)",
             "config": {"workload": f"complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, 2^{args.log2_samples}-sample stream per channel "
                                    f"(BASELINE.json configs[{4 if combine else 1}]), rectangular window, {nchunks} launch(es) of 2^{log2_chunk} samples per channel" + graph,
                        "chain_algo": KERNEL_SYMBOLS.get(algo, str(algo)), "channels": n_channels,

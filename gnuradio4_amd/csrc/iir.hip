@@ -13,6 +13,9 @@
 // Bound: FP32 FMA latency chains, 2 recurrence passes per sample (DESIGN.md "iir_cascade").
 #include "common.hpp"
 
+#include <map>
+#include <mutex>
+
 #include <cmath>
 #include <cstdlib>
 
@@ -1067,6 +1070,9 @@ extern "C" {
 
 static int iir_create_impl(gr4hip_iir_t** out, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na, bool top);
 static int iir_selftest(gr4hip_iir* f);
+struct IirVerdict { int algo; float e_par, e_f32; };
+static std::map<std::vector<float>, IirVerdict> g_selftest; // (the errors are ratios to the output rms: a gain on the numerators leaves them as they are)
+static std::mutex                               g_selftest_mu;
 static int iir_process_parallel(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream);
 
 int gr4hip_iir_create(gr4hip_iir_t** out, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na) {
@@ -1192,6 +1198,26 @@ static int iir_selftest(gr4hip_iir* f) {
     f->algo_in_use = GR4HIP_IIR_PARALLEL;
     if (f->algo == GR4HIP_IIR_SEQUENTIAL_F32) { f->algo_in_use = GR4HIP_IIR_SEQUENTIAL_F32; return GR4HIP_OK; }
     if (f->algo == GR4HIP_IIR_PARALLEL) return GR4HIP_OK;
+    //  the verdict belongs to the cascade, not to the handle: one test per coefficient set and process.  A gain on a numerator does not change the conditioning
+    // (every section's numerator enters the key divided by its largest coefficient), so the planner's regain -- a new handle per absorbed or cleared gain -- finds it here
+    // instead of another upload / launch / download / host simulation with two device synchronisations.
+    std::vector<float> key;
+    {
+        const IirSeqF32Coef& c = f->seq;
+        key = {(float)c.form, (float)c.nsec, (float)c.nb, (float)c.na};
+        for (int s_ = 0; s_ < c.nsec; ++s_) {
+            float mx = 0.f;
+            for (int j = 0; j < c.nb; ++j) mx = std::max(mx, std::fabs(c.b[s_][j]));
+            for (int j = 0; j < c.nb; ++j) key.push_back(mx > 0.f ? c.b[s_][j] / mx : 0.f);
+            for (int j = 0; j < c.na; ++j) key.push_back(c.a[s_][j]);
+        }
+        std::lock_guard<std::mutex> lk(g_selftest_mu);
+        const auto it = g_selftest.find(key);
+        if (it != g_selftest.end()) {
+            f->algo_in_use = it->second.algo; f->selftest_parallel = it->second.e_par; f->selftest_f32 = it->second.e_f32;
+            return GR4HIP_OK;
+        }
+    }
     const long         n = 3L * kIirBS * kIirL + 777;
     std::vector<float> x((size_t)n), y((size_t)n);
     uint32_t           lcg = 12345u;
@@ -1228,6 +1254,10 @@ static int iir_selftest(gr4hip_iir* f) {
     f->selftest_parallel = (float)(e_par / rms);
     f->selftest_f32      = (float)(e_f32 / rms);
     if (!(e_par / rms <= 1e-5) && !(e_par <= 10.0 * e_f32)) f->algo_in_use = GR4HIP_IIR_SEQUENTIAL_F32;
+    {
+        std::lock_guard<std::mutex> lk(g_selftest_mu);
+        g_selftest[key] = IirVerdict{f->algo_in_use, f->selftest_parallel, f->selftest_f32};
+    }
     return GR4HIP_OK;
 }
 
