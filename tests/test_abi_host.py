@@ -2,6 +2,7 @@
 entry points (window, filter design, status/error plumbing) agree with the oracle.  No compute calls need a GPU here."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -183,3 +184,13 @@ def test_no_kernel_of_the_shipped_library_spills_vector_registers():
     assert not bad, bad
     for fam in ("fir_mfma_f16x2_kernel", "fir_mfma_f16x2_c32_kernel", "fir_decim_f16x2_kernel", "fir_exact_kernel", "chain_fd_kernel", "chain_redo_kernel", "fir_poly_kernel"):
         assert any(fam in k["demangled"] for k in ks), fam
+
+
+def test_kernel_table_is_current():
+    """KERNELS.md (the per-kernel register / LDS / spill table DESIGN.md points to) is generated from the shipped library by tools/regen_kernel_table.sh: the committed
+    file must be what the built libgr4hip.so says (a hand-written table had gone stale)"""
+    import subprocess
+    want = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--md"], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    have = open(os.path.join(ROOT, "KERNELS.md")).read().strip().splitlines()
+    assert have[-len(want):] == want, "run tools/regen_kernel_table.sh"
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 40 * 1024
