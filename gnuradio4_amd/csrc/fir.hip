@@ -341,6 +341,7 @@ struct gr4hip_fir {
     DeviceBuffer       d_taps;     // [D][Qpad]
     DeviceBuffer       d_tapsf;    // the taps as they are (what fir_exact_kernel multiplies with)
     double             tap_power = 0; // sum b^2 of `taps` (the guard's thresholds are multiples of it)
+    DeviceBuffer       d_flags_fd; // the same for the frequency-domain kernels' spans (judged behind their launch at their own thresholds)
     DeviceBuffer       d_flags;    // one byte per segment of the f16 matrix-pipe kernels' last launch: the segments fir_exact_kernel evaluates again behind it
     DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
     int                cur = 0;
@@ -683,14 +684,21 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         float        ratio;
         const bool   guarded = f->ntaps > 1 && f->guard_mode != GR4HIP_GUARD_OFF;
         if (guarded && f->guard_mode == GR4HIP_GUARD_STRICT) {
-            // the whole span on the fast convolution, its own measurement awaited: below the threshold the direct form redoes it before the call returns
-            rc = chain_fused_fir(f->fd, x, (const float*)f->d_hist256.ptr, frames, y, st);
-            if (rc) return rc;
-            if (chain_fused_power_ratio(f->fd, true, true, &ratio)) f->fd_ratio = ratio;
+            // (round 5: nobody waits) the whole span on the fast convolution; every 8192-sample frame is judged behind it at the fast convolution's own threshold -- output power
+            // below 0.04 x input power: its error floor, ~2e-6 of the INPUT rms, would show against such an output -- and the marked frames are evaluated again with float64
+            // products (fir_judge_kernel + fir_exact_kernel on the same stream).  The measurement of an EARLIER launch, when it has arrived, moves a stream that rejects most of
+            // its input to the direct form for good.
+            if (chain_fused_power_ratio(f->fd, false, true, &ratio)) f->fd_ratio = ratio;
             f->fd_probed = true;
-            if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) f->fd_blocked = f->f32_products = true; // (the direct form the guard falls back to multiplies in float32: under the rejected signal that made it fall back the three-term bf16 products measure 3 .. 16 x a float32 sum's error)
+            if (f->fd_ratio >= 0.f && f->fd_ratio < 0.04f) f->fd_blocked = f->f32_products = true;
             else {
-                done = frames * kFdFrame;
+                const long nfd = (long)(frames * kFdFrame);
+                rc = chain_fused_fir(f->fd, x, (const float*)f->d_hist256.ptr, frames, y, st);
+                if (!rc) rc = f->d_flags_fd.ensure(frames);
+                if (!rc) rc = fir_judge_launch(x, nfd, y, nfd, 1, 1, 13, 0.04f, (unsigned char*)f->d_flags_fd.ptr, st);
+                if (!rc) rc = fir_exact_launch(x, nfd, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, 1, 1, y, nfd, (const unsigned char*)f->d_flags_fd.ptr, 13, nullptr, st);
+                if (rc) return rc;
+                done = (size_t)nfd;
                 hist = x + (done - f->hcap) * 2;
             }
         } else {
@@ -974,14 +982,16 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         // the INPUT rms per output sample, six times below the fused chain's -- so 1e-5 of the OUTPUT rms holds down to a power ratio of (4e-7 / 1e-5)^2 = 1.6e-3; 2.5e-3
         // (-26 dB) with margin.  White noise through a DC-gain-1 low-pass of cut-off fc passes 2 fc of its power: every anti-alias filter down to fc = 0.00125 stays here.
         constexpr float kDecimFdMinPowerRatio = 2.5e-3f;
-        if (guarded && f->guard_mode == GR4HIP_GUARD_DEFERRED && f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) f->fd_blocked = f->f32_products = true;
+        if (guarded && f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) f->fd_blocked = f->f32_products = true; // (an earlier launch's measurement, read without waiting)
         if (!f->fd_blocked) {
             rc = fir_decim_fd_run(f->dfd, x, n_in, hist, (int)f->hcap, y, st, guarded);
             if (rc) return rc;
             done = n_in;
-            if (guarded && f->guard_mode == GR4HIP_GUARD_STRICT) {
-                if (fir_decim_fd_power_ratio(f->dfd, true, &ratio)) f->fd_ratio = ratio;
-                if (f->fd_ratio >= 0.f && f->fd_ratio < kDecimFdMinPowerRatio) { f->fd_blocked = f->f32_products = true; done = 0; } // (float32 products from here on, like the complex path: the call that trips the guard and the calls after it run the same kernels)
+            if (guarded && f->guard_mode == GR4HIP_GUARD_STRICT) { // (round 5: nobody waits) segments of 2048 outputs judged behind the launch at this kernel's threshold, the marked ones again in float64
+                rc = f->d_flags_fd.ensure((size_t)ceil_div((long)n_out, 2048L));
+                if (!rc) rc = fir_judge_launch(x, (long)n_in, y, (long)n_out, (int)f->decim, 0, 11, kDecimFdMinPowerRatio, (unsigned char*)f->d_flags_fd.ptr, st);
+                if (!rc) rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, 0, y, (long)n_out, (const unsigned char*)f->d_flags_fd.ptr, 11, nullptr, st);
+                if (rc && rc != GR4HIP_UNSUPPORTED) return rc;
             }
         }
     }

@@ -1787,6 +1787,32 @@ def test_fir_decimate_by_8_dynamic_range_guard(G, devsw):
         assert (e_fd > TOL) == expect_switch, (name, e_fd)
 
 
+def test_complex_fast_convolution_guard_without_the_host(G):
+    """fir_filter<complex<float>>, 97 .. 256 taps, on a long span that is only 8-byte aligned: the fast-convolution kernel (chain_fd_kernel<kModeFir>) -- whose error floor is
+    relative to the INPUT.  Round 5: its strict guard judges every 8192-sample frame behind the launch (fir_judge_kernel at the 0.04 threshold) and fir_exact_kernel
+    evaluates the marked frames again; the call does not wait, a blocker in a few frames of a long call is seen, ordinary input keeps the fast convolution's result"""
+    ntaps = 200
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    n = 100 * 8192
+    base = torch.empty(n + 3, dtype=torch.complex64, device="cuda")
+
+    def run(x, guard=None):
+        t = base[3:]  # 24 bytes past a 256-byte boundary: 8-byte aligned only
+        assert t.data_ptr() % 16 == 8
+        t.copy_(torch.from_numpy(x))
+        f = G.fir_filter(b, torch.complex64)
+        if guard is not None:
+            f.set_guard_mode(guard)
+        return f.process_bulk(t).cpu().numpy()
+    quiet = O.signal_c32(5, n, tone_frel=0.005, tone_amp=1.0)
+    loud = quiet.copy()
+    loud[60 * 8192:63 * 8192] += (300.0 * np.exp(2j * np.pi * 0.31 * np.arange(3 * 8192))).astype(np.complex64)
+    for x, tripped in ((quiet, False), (loud, True)):
+        truth = O.fir(b, x)[0]
+        assert _rel(run(x), truth) <= TOL
+        assert (_rel(run(x, G.capi.GUARD_OFF), truth) > TOL) == tripped  # (what the guard is for)
+
+
 def test_guard_sees_every_frame_and_block(G, devsw):
     """an interferer that sets in near the END of a long call -- where one workgroup has long left its first frame behind -- or only for a few frames is seen:
     the kernels judge every frame / block by itself (workgroup-wide sums of output - threshold x input power), not a sample of them, and not the launch's totals,
