@@ -1047,7 +1047,7 @@ struct BlockWrapper final : BlockModel {
                     e = p.buffer;
                 } else {
                     // the port already feeds a reader: this connection is a fan-out -- a mirror buffer of its own for the new reader
-                    if constexpr (P::kGpu) e = nullptr; // (GPU-domain edges: one reader per ring in this layer)
+                    if constexpr (P::kGpu) e = p.buffer->add_reader(); // GPU-domain edges: another read cursor on the SAME ring in HBM (hip.hpp DeviceEdgeBuffer: no copy)
                     else e = p.buffer->add_mirror(std::max<std::size_t>(min_size, 65536), mr ? mr : std::pmr::get_default_resource());
                 }
             }

@@ -1280,17 +1280,43 @@ public:
 // hands out hold DEVICE pointers, contiguous across the wrap.  Host code must not dereference them; blocks with GPU ports pass them to
 // kernels.  Crossing between the domains takes an explicit converter block, H2D<T> / D2H<T> below (core/README.md:87-110): the cost of the
 // transfer is a visible node of the graph, and everything between the two converters stays in HBM.
+// Fan-out (round 5): the reference's edges are one writer -> N readers on ONE buffer (CircularBuffer.hpp:880-946, Graph.hpp:595-690).  A second connection from a
+// GPU-domain output port gets a VIEW of the same ring -- its own read cursor (new_reader()), no storage, no copy: a device graph with a tee (spectrum + recorder behind
+// one filter) reads the filtered samples twice from the same HBM pages, and the writer's free space is what the slowest reader leaves (the ring's min over its cursors).
+// The CPU-domain edges of this layer tee by copying into a mirror buffer (core.hpp); here that would be a device-to-device copy per published span.
 template <typename T>
 struct DeviceEdgeBuffer final : EdgeBufferBase {
     CircularBuffer<T>                  ring;
     typename CircularBuffer<T>::Writer w;
     typename CircularBuffer<T>::Reader r;
+    bool                               is_view = false;                 // a further reader of another edge's ring: reads only
+    std::vector<std::shared_ptr<DeviceEdgeBuffer<T>>> views;            // the further readers of THIS edge's ring
     explicit DeviceEdgeBuffer(std::size_t min_elements) : ring(min_elements), w(ring.new_writer()), r(ring.new_reader()) {}
+    struct view_of {};
+    DeviceEdgeBuffer(DeviceEdgeBuffer& primary, view_of) : ring(primary.w.buffer()), w(ring.new_writer()), r(ring.new_reader()), is_view(true) {
+        upstream  = &primary;
+        read_pos  = primary.write_pos; // (a new reader starts at the write position: CircularBuffer.hpp semantics)
+        write_pos = primary.write_pos;
+    }
+    [[nodiscard]] std::shared_ptr<DeviceEdgeBuffer<T>> add_reader() {
+        auto v = std::make_shared<DeviceEdgeBuffer<T>>(*this, view_of{});
+        views.push_back(v);
+        mirror_bases.push_back(v); // (tags published on this edge reach every reader's side channel)
+        return v;
+    }
     [[nodiscard]] std::size_t        available() const noexcept { return r.available(); }
-    [[nodiscard]] std::size_t        free_space() const noexcept { return w.available(); }
+    [[nodiscard]] std::size_t        free_space() const noexcept { return is_view ? 0 : w.available(); }
     [[nodiscard]] std::span<const T> read_span(std::size_t n) const { return r.get(n); }
-    [[nodiscard]] std::span<T>       write_span(std::size_t n) { return w.reserve(n); }
-    void                             publish(std::size_t n) { w.publish(n); advanceWrite(n); }
+    [[nodiscard]] std::span<T>       write_span(std::size_t n) {
+        if (is_view) throw std::logic_error("DeviceEdgeBuffer: a reader's view of a ring cannot be written");
+        return w.reserve(n);
+    }
+    void                             publish(std::size_t n) {
+        if (is_view) throw std::logic_error("DeviceEdgeBuffer: a reader's view of a ring cannot be written");
+        w.publish(n);
+        advanceWrite(n);
+        for (auto& v : views) v->advanceWrite(n);
+    }
     void                             consume(std::size_t n) { (void)r.consume(n); advanceRead(n); }
     [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
     [[nodiscard]] std::size_t available_items() const noexcept override { return available(); }

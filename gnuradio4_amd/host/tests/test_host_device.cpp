@@ -244,6 +244,33 @@ int main(int argc, char** argv) {
         dump(out + "_gpu_ports_hann.bin", sink._samples);
     }
 
+    { // 3d. a tee on a GPU-DOMAIN edge (round 5): fir.out (GPU port) feeds the spectrum block (GPU port) AND a D2H converter -> both readers hold their own cursor on the
+      //     SAME ring in HBM (one writer -> N readers, CircularBuffer.hpp:880-946): no copy of the filtered stream, the writer waits for the slower of the two
+        Graph g;
+        auto& src  = g.emplaceBlock<testing::VectorSource<std::complex<float>>>();
+        src.values = x;
+        auto& h2d  = g.emplaceBlock<hip::H2D<std::complex<float>>>();
+        auto& fir  = g.emplaceBlock<hip::OnDevice<filter::fir_filter<std::complex<float>>>>({{"b", tapsd}, {"name", "fir@gpu"s}});
+        auto& spec = g.emplaceBlock<hip::OnDevice<blocks::fft::PowerSpectrum<std::complex<float>>>>({{"fftSize", std::int64_t(N)}, {"window", "None"s}});
+        auto& d2hs = g.emplaceBlock<hip::D2H<float>>();
+        auto& d2hf = g.emplaceBlock<hip::D2H<std::complex<float>>>();
+        auto& s1   = g.emplaceBlock<testing::VectorSink<float>>();
+        auto& s2   = g.emplaceBlock<testing::VectorSink<std::complex<float>>>();
+        bool  wired = g.connect<"out", "in">(src, h2d).has_value() && g.connect<"out", "in">(h2d, fir).has_value() && g.connect<"out", "in">(fir, spec).has_value() &&
+                     g.connect<"out", "in">(fir, d2hf).has_value() /* the second reader of fir.out */ && g.connect<"out", "in">(spec, d2hs).has_value() &&
+                     g.connect<"out", "in">(d2hs, s1).has_value() && g.connect<"out", "in">(d2hf, s2).has_value();
+        if (!wired) ++errors;
+        const bool   same_ring = wired && fir.out.buffer && fir.out.buffer->views.size() == 1 && d2hf.in.buffer && d2hf.in.buffer->is_view &&
+                               d2hf.in.buffer->read_span(0).data() == fir.out.buffer->read_span(0).data();
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        if (const auto r = sched.runAndWait(); !r) { std::cerr << "gpu-domain tee: " << r.error().message << "\n"; ++errors; }
+        std::printf("gpu-domain tee: %s, %zu spectra samples, %zu filtered samples\n", same_ring ? "2 readers on one ring in HBM" : "NOT one ring", s1._samples.size(), s2._samples.size());
+        if (!same_ring || s1._samples.size() != (x.size() / N) * N || s2._samples.size() != x.size()) ++errors;
+        dump(out + "_gpu_tee_fir.bin", s2._samples);
+        dump(out + "_gpu_tee_spec.bin", s1._samples);
+    }
+
     { // 4. the GPU-resident BufferLike ring: spans that wrap the physical end stay contiguous; two readers, back-pressure
         hip::CircularBuffer<float> ring(1 << 16);
         auto                       w = ring.new_writer();

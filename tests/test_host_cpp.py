@@ -207,6 +207,13 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     xin = np.resize(np.array([1.0, -2.0, 3.0, 0.5, 0.25], np.float64), 200000) * 2.0
     want = (np.convolve(xin, [0.5, 0.25, 0.25])[:200000] + 1.0) * 3.0
     assert len(pf) == 200000 and np.max(np.abs(pf - want)) <= 1e-5
+    # a tee on a GPU-domain edge: two read cursors on ONE ring in HBM (CircularBuffer.hpp:880-946: one writer -> N readers), no copy; both streams match the oracle
+    assert "gpu-domain tee: 2 readers on one ring in HBM" in r.stdout
+    gt = np.fromfile(tmp_path / "o_gpu_tee_fir.bin", np.complex64)
+    assert len(gt) == len(x) and rel(gt, truth) <= 1e-5
+    gs = np.fromfile(tmp_path / "o_gpu_tee_spec.bin", np.float32)
+    t0, _ = O.chain(b, x, N, 0, truth=True)
+    assert len(gs) == frames * N and rel(gs, t0) <= 1e-5
     # a tee behind a device block: nothing fused across it, both readers complete, the filtered stream equals the oracle's
     assert "tee'd device edge: 0 fused runs" in r.stdout
     tee = np.fromfile(tmp_path / "o_tee_fir.bin", np.complex64)
