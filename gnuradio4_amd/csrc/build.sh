@@ -10,7 +10,7 @@ pids=()
 for s in $SRCS; do
   o=../../build/obj/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.hpp -nt "$o" ] || [ fir_window.hpp -nt "$o" ] || [ fft_radix.hpp -nt "$o" ] || [ buffer_ops.hpp -nt "$o" ] || [ fft_kernels.hpp -nt "$o" ] || [ fft_smooth.hpp -nt "$o" ] || [ fft_smooth_sizes.inc -nt "$o" ] || [ wave16_common.hpp -nt "$o" ] || [ ewise.hpp -nt "$o" ] || [ fir_f16_common.hpp -nt "$o" ] || [ build.sh -nt "$o" ] || [ ../../include/gr4hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.hpp -nt "$o" ] || [ fir_window.hpp -nt "$o" ] || [ fft_radix.hpp -nt "$o" ] || [ buffer_ops.hpp -nt "$o" ] || [ fft_kernels.hpp -nt "$o" ] || [ fft_smooth.hpp -nt "$o" ] || [ fft_smooth_sizes.inc -nt "$o" ] || [ wave16_common.hpp -nt "$o" ] || [ ewise.hpp -nt "$o" ] || [ fir_band_hooks.hpp -nt "$o" ] || [ fir_exact.hpp -nt "$o" ] || [ fir_f16_common.hpp -nt "$o" ] || [ build.sh -nt "$o" ] || [ ../../include/gr4hip.h -nt "$o" ]; then
     # hipcc's SLP vectoriser turns float math into v_pk_*_f32 on register pairs it assembles with v_mov: measured slower on every kernel
     # of this library (fused chain -12 %, register-window FIR -32 %) except the two FFT sizes in fft_fast_pk.hip
     SLP=-fno-slp-vectorize

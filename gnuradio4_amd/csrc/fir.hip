@@ -300,7 +300,8 @@ void fir_bf16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vect
 int  fir_bf16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum);
 bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
 bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab, bool cplx); // fir_decim_f16.hip
-int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx);
+int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx,
+                          const EwiseHook* pre, const EwiseHook* post);
 int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard, unsigned char* flags);
 int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard,
                     unsigned char* flags, long flags_stride, float gthr);
@@ -581,6 +582,20 @@ int gr4hip_fir_set_guard_mode(gr4hip_fir_t* f, int mode) {
 static bool no_bf16x3(const gr4hip_fir_t* f) { return f->algo == GR4HIP_FIR_EXACT_F32 || f->f32_products || dev_switch(kDevFirNoBf16x3); }
 
 // does this call take the band-form bf16 decimators (fir_bf16.hip)?  Builds their fragments on first use.
+// does the f16 band-form decimator (fir_decim_f16.hip: D = 4 / 8 / 16 / 32, two-term f16 products, carries the filter's programs since round 5) take this call?
+static bool fir_decim_f16_shape(const gr4hip_fir_t* f, size_t n_in, const void* d_in, const void* d_out, bool hooked) {
+    if (hooked && f->decim == 4 && (f->S == 2 ? 2 * f->ntaps - 1 : f->ntaps) > 577) return false; // (decimate by 4 with more than five K-steps per wave AND programs: 256 registers do not hold it without spills; the bf16 band kernel takes it)
+    // developer knobs.  Measured (G input samples/s, bf16 band kernel / this one), float decimate by 8: 64 taps 1037 / 998, 100 taps 984 / 999, 128 taps 963 / 998
+    static const size_t kMin8   = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)97; }();
+    static const size_t kMinW   = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_WIDE"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // (decimate by 16 / 32)
+    static const size_t kMinC8  = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_C8"); return e ? (size_t)std::atoi(e) : (size_t)64; }();   // (complex, decimate by 8)
+    static const size_t kMin4   = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_D4"); return e ? (size_t)std::atoi(e) : (size_t)33; }();   // (decimate by 4, float and complex: round 5)
+    const size_t D = f->decim;
+    const bool   taps_ok = (f->S == 1 && ((D == 8 && f->ntaps >= kMin8) || ((D == 16 || D == 32) && f->ntaps >= kMinW) || (D == 4 && f->ntaps >= kMin4))) ||
+                         (f->S == 2 && (((D == 16 || D == 32) && f->ntaps >= kMinW) || (D == 8 && f->ntaps >= kMinC8) || (D == 4 && f->ntaps >= kMin4)));
+    return taps_ok && f->ntaps <= 1025 && n_in * f->S >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && f->algo == GR4HIP_FIR_AUTO && !f->f32_user &&
+           !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && !dev_switch(kDevFirNoDecimF16) && f->dhKQ >= 0;
+}
 static bool fir_decim_bf16_ready(gr4hip_fir_t* f, size_t n_in, const void* d_in, const void* d_out, int* rc) {
     *rc = GR4HIP_OK;
     if (!(f->decim >= (f->S == 1 ? (size_t)2 : (size_t)3) && f->decim <= (f->S == 1 ? (size_t)12 : (size_t)16) && n_in / f->decim >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
@@ -622,7 +637,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     const bool   fast_shape = f->algo == GR4HIP_FIR_AUTO && ((f->decim == 1 && f->ntaps > (f->S == 2 ? (size_t)64 : (size_t)96) && f->ntaps <= (f->S == 2 ? (size_t)256 : (size_t)1024) && n_in >= kMfmaMinSamples) ||
                                                                (f->S == 1 && f->decim >= 2 && per_out > 12 && n_out >= ((size_t)1 << 14)));
     int        brc  = GR4HIP_OK;
-    const bool band = hk.any && fir_decim_bf16_ready(f, n_in, d_in, d_out, &brc); // (those kernels carry the hooks themselves)
+    const bool band = hk.any && (fir_decim_f16_shape(f, n_in, d_in, d_out, true) || fir_decim_bf16_ready(f, n_in, d_in, d_out, &brc)); // (those kernels carry the hooks themselves)
     if (brc) return brc;
     auto around = [&]() -> int { // the programs as element-wise launches in front of / behind the plain filter
         hipStream_t st  = as_stream(stream);
@@ -902,14 +917,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // float, decimate by 8, 97 .. 1025 taps (BASELINE configs[2]), long 16-byte-aligned span: the band form on the f16 matrix pipe, two-term splits under a per-segment block
     // exponent, the K-steps split over the four waves, every segment judged and the rejected ones evaluated again with float32 products inside the launch (fir_decim_f16.hip)
     // -- its error is relative to the output, so it needs no host-side guard and the call stays asynchronous
-    static const size_t kDhMinTaps = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)97; }(); // developer knob.  Measured (G input samples/s, bf16 band kernel / this one): 64 taps 1037 / 998, 100 taps 984 / 999, 128 taps 963 / 998, 168 taps 595 / 999
-    static const size_t kDhMinTapsWide = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_WIDE"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // (decimate by 16 / 32)
-    // complex<float> (real taps), decimate by 16 / 32 from 33 taps, by 8 from 97 (nothing hooked in): the same kernel on the interleaved stream read as floats, the
-    // interleaving in the tap table (2 taps - 1 <= the window's reach: up to 513 / 449 / 321 taps at D = 8 / 16 / 32)
-    static const size_t kDhMinTapsC8 = [] { const char* e = std::getenv("GR4HIP_FIR_DECIM_F16_MIN_TAPS_C8"); return e ? (size_t)std::atoi(e) : (size_t)64; }(); // (complex, decimate by 8, G input samples/s bf16 band kernel / this one over three boxes: 32 taps 517 .. 539 / 519 .. 538, 64 taps 484 .. 494 / 500 .. 535, 128 taps 373 / 499, 256 taps 260 / 470; developer knob)
-    if (done == 0 && ((f->S == 1 && ((f->decim == 8 && f->ntaps >= kDhMinTaps) || ((f->decim == 16 || f->decim == 32) && f->ntaps >= kDhMinTapsWide))) ||
-                      (f->S == 2 && (((f->decim == 16 || f->decim == 32) && f->ntaps >= kDhMinTapsWide) || (f->decim == 8 && f->ntaps >= kDhMinTapsC8)))) && f->ntaps <= 1025 && n_in * f->S >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
-        algo == GR4HIP_FIR_AUTO && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && !dev_switch(kDevFirNoDecimF16) && f->dhKQ >= 0 && plain) {
+    if (done == 0 && fir_decim_f16_shape(f, n_in, d_in, d_out, hk.any)) { // (hooked calls too: the kernel carries the programs, fir_exact_kernel<true> runs them again on marked segments)
         int rc = GR4HIP_OK;
         if (f->dhKQ == 0) {
             std::vector<unsigned short> tab;
@@ -925,11 +933,11 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             rc = f->d_flags.ensure((size_t)ceil_div((long)(n_out * f->S), segf));
             if (rc) return rc;
             rc = fir_decim_f16_launch((int)f->decim, f->dhKQ, x, (long)(n_in * f->S), hist, (int)(f->hcap * f->S), f->d_dhtab.ptr, y, (long)(n_out * f->S), st, (float*)f->d_hist[f->cur ^ 1].ptr,
-                                      f->guard_mode != GR4HIP_GUARD_OFF, (unsigned char*)f->d_flags.ptr, f->S == 2);
+                                      f->guard_mode != GR4HIP_GUARD_OFF, (unsigned char*)f->d_flags.ptr, f->S == 2, &hk.pre, &hk.post);
             if (rc) return rc;
             // the marked segments again on the FP64 matrix pipe (fir_exact.hip; in samples: a complex segment is half as many outputs)
             rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, f->S == 2, y, (long)n_out, (const unsigned char*)f->d_flags.ptr,
-                                  ilog2((size_t)(segf / f->S)), nullptr, st);
+                                  ilog2((size_t)(segf / f->S)), nullptr, st, 1, 0, 0, 0, 0, &hk.pre, &hk.post);
             if (rc) return rc;
             done = n_in;
             mfma_wrote_hist = true;

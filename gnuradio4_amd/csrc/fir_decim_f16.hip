@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fir_f16_common.hpp"
+#include "fir_band_hooks.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -25,7 +26,7 @@
 
 namespace gr4 {
 
-constexpr int kDhSegIn = 8192; // a segment: 8192 input samples = 8192 / D outputs = 16 columns of 512 samples, 32 / D tile rows per column (D = 8, 16, 32)
+constexpr int kDhSegIn = 8192; // a segment: 8192 input samples = 8192 / D outputs = 16 columns of 512 samples, 32 / D tile rows per column (D = 4, 8, 16, 32)
 
 // the table fir_decim_f16_make_table writes, in 16-bit units: [4 waves][3 planes][KQ][64 lanes][8] f16 fragments, 8 units of header {float 1 / t, int ntaps, float guard
 // threshold, -}, 1040 float taps
@@ -62,12 +63,16 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[2][KQ], const uns
             make_float4(c[tr][0] + d[tr][0] * (1.f / 2048.f), c[tr][1] + d[tr][1] * (1.f / 2048.f), c[tr][2] + d[tr][2] * (1.f / 2048.f), c[tr][3] + d[tr][3] * (1.f / 2048.f));
 }
 
-template <int D, int KQ> // decimation 8 / 16 / 32; K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 16 D samples in front of a tile's first output
+// HOOK (round 5): the filter's per-sample neighbours ride in this launch like in the bf16 band kernels (fir_band_hooks.hpp): `hk.pre` on every sample of x on its way into
+// the statistics and the f16 planes (the carried history holds prologue OUTPUTS and is taken as it lies; the next history this launch writes is made of them too), `hk.post`
+// on every output before its store (the verdict's output power is the FILTER's, in front of it).  The channeliser -- rotator -> decimate-by-8 complex FIR -- is this shape.
+template <int D, int KQ, bool HOOK> // decimation 4 / 8 / 16 / 32; K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 16 D samples in front of a tile's first output
 __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh,
                                                                   const unsigned short* __restrict__ tab, float* __restrict__ y, long n_out, long n_in,
                                                                   float* __restrict__ new_hist, int guard, int seg_per_wg /*<= kDhMaxSpw*/,
                                                                  unsigned char* __restrict__ flags /*one byte per segment: what fir_exact_kernel evaluates again behind this launch*/,
-                                                                 int cplx /*the streams are complex<float> read as floats (n_in, n_out, Kh in floats; D complex samples in per complex sample out): the tap table carries the interleaving*/) {
+                                                                 int cplx /*the streams are complex<float> read as floats (n_in, n_out, Kh in floats; D complex samples in per complex sample out): the tap table carries the interleaving*/,
+                                                                 BdHooks hk) {
     constexpr int TR = 32 / D, SO = kDhSegIn / D, Hb = 128 * KQ - 16 * D, NS = kDhSegIn + Hb; // tile rows per column, outputs per segment, staged samples per segment (a multiple of 128)
     static_assert(Hb > 0, "the window must hold a tile's 16 D input samples");
     constexpr int PL  = NS + 8 * (NS / 512 + 1) + 16;      // f16 elements per plane: one 16-byte chunk of padding per 512 samples (the 16 columns of a fragment read are 512 samples apart)
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) unsigned short pls[]; // [2][PL]: planes x1, x2
     __shared__ __attribute__((aligned(16))) float          part[4][TR][64][4]; // [K quarter = wave][tile row][lane][row within the lane's four]
     __shared__ __attribute__((aligned(16))) unsigned       stat[12];
-    __shared__ __attribute__((aligned(16))) float          ystat[4][16]; // the four tile rows' output powers per column of 64 outputs
+    __shared__ __attribute__((aligned(16))) float          ystat[4][16]; // per wave: the output powers of the tile rows it takes out, per column
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
     auto P = [](int s_) { return s_ + 8 * (s_ >> 9); };
 
@@ -105,6 +110,30 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
     auto load_seg = [&](long sg) __attribute__((always_inline)) {
         if (sg > 0) load_next(sg);
         else load_general(0);
+    };
+    auto hook_loaded = [&](long sg) __attribute__((always_inline)) { // the prologue on the samples of x among the loaded ones (sg = 0: the history in front of them stays as it lies)
+        if constexpr (HOOK) {
+            if (hk.pre.n_ops > 0) {
+#pragma unroll
+                for (int u = 0; u < NL4; ++u) {
+                    const int  q  = tid + 256 * u;
+                    const long fi = sg * kDhSegIn - Hb + 4L * q;
+                    if (q < NS / 4 && fi + 3 >= 0 && fi < n_in) {
+                        const float4 w = bd_hook4(nxt[u], hk.pre, cplx, fi); // (fi, Kh and n_in are even for complex streams: a pair never straddles position 0)
+                        float4       v = nxt[u];
+                        if (fi >= 0) v = w;
+                        else if (fi + 2 >= 0) { v.z = w.z; v.w = w.w; if (!cplx && fi + 1 >= 0) v.y = w.y; }
+                        else if (!cplx) v.w = w.w;
+                        if (fi + 3 >= n_in) { // (the span's end inside this chunk: zeros stay zeros)
+                            if (fi + 1 >= n_in) v.y = 0.f;
+                            if (fi + 2 >= n_in) v.z = 0.f;
+                            v.w = 0.f;
+                        }
+                        nxt[u] = v;
+                    }
+                }
+            }
+        }
     };
     auto put_stats = [&]() __attribute__((always_inline)) {
         float    mf = 0.f, px = 0.f;
@@ -135,17 +164,24 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
     };
     // thread (w', lane) takes tile row w' out: the four K quarters' partial tiles summed in a fixed order, the block scales off, y[seg + 16 TR col + 16 w' + 4 kq + r]
     auto take_out = [&](long sg, float k, float& py) __attribute__((always_inline)) {
-        if (wave >= TR) return; // (thread (w', lane) takes tile row w': D = 16 / 32 have two / one of them)
-        float v[4];
+        // thread (w', lane) takes tile rows w', w' + 4, ... out (D = 4: two each; D = 16 / 32 have two / one tile row: the other waves take nothing)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = ((part[0][wave][lane][r] + part[1][wave][lane][r]) + (part[2][wave][lane][r] + part[3][wave][lane][r])) * k;
-        const long o = sg * SO + (long)(16 * TR) * col + 16 * wave + 4 * kq;
-        if (o + 3 < n_out) {
-            *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
-            py = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], py))));
-        } else {
+        for (int tr = wave; tr < TR; tr += 4) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((part[0][tr][lane][r] + part[1][tr][lane][r]) + (part[2][tr][lane][r] + part[3][tr][lane][r])) * k;
+            const long o = sg * SO + (long)(16 * TR) * col + 16 * tr + 4 * kq;
+#pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (o + r < n_out) { y[o + r] = v[r]; py = fmaf(v[r], v[r], py); }
+                if (o + r < n_out) py = fmaf(v[r], v[r], py); // (the filter's output, in front of the store program)
+            if constexpr (HOOK) {
+                if (hk.post.n_ops > 0) { const float4 w = bd_hook4(make_float4(v[0], v[1], v[2], v[3]), hk.post, cplx, o); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
+            }
+            if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+                for (int r = 0; r < 4; ++r)
+                    if (o + r < n_out) y[o + r] = v[r];
+            }
         }
     };
     u32x4_h a[2][KQ]; // this wave's quarter of the tap fragments (planes 0, 1 of the table's three)
@@ -155,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
         for (int ks = 0; ks < KQ; ++ks) a[p][ks] = afrag[((wave * 3 + p) * KQ + ks) * 64 + lane];
     // the guard (fir_f16.hip): sixteen times the power of the QUIETEST of the segment's sixteen output columns, at the input rate, against 2^-12 (sum b^2) x the input power
     auto rejected = [&](float px) __attribute__((always_inline)) -> bool {
-        const float pc = (ystat[0][col] + ystat[1][col]) + (ystat[2][col] + ystat[3][col]);
+        const float pc = (ystat[0][col] + ystat[1][col]) + (ystat[2][col] + ystat[3][col]); // (a wave's entry is the sum over the tile rows it took out)
         return __builtin_amdgcn_readfirstlane((int)(16.f * hf_row_min(pc) * (float)D < gthr * px)) != 0;
     };
     const long nseg = (n_out + SO - 1) / SO, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
@@ -167,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
         float px_prev = 0.f;
         int   kind_prev = -1; // (nothing to judge yet)
         for (long sg = sfirst; sg < slast; ++sg) {
+            hook_loaded(sg);
             put_stats();
             __syncthreads(); // the statistics are complete; every wave is done with the planes, the partial tiles and the verdict words of the segment before
             float     s, inv_s, px;
@@ -200,12 +237,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
         __syncthreads();
         if (guard && kind_prev == 0 && rejected(px_prev) && tid == 0) flags[slast - 1] = 3;
     }
-    if (new_hist != nullptr && blockIdx.x == 0) {
-        for (int h = tid; h < Kh; h += 256) {
-            const long i = n_in - Kh + h;
-            new_hist[h]  = i >= 0 ? x[i] : hist[Kh + i];
-        }
-    }
+    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK>(x, hist, Kh, n_in, new_hist, tid, hk);
 }
 
 // the table of fir_decim8_f16x2_kernel<KQ> (see dh_table_units): fragment (wave w, plane p, K-step ks, lane l, element t) = tap-plane value
@@ -214,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
 // the float geometry -- sits s_j = 2 D (j >> 1) + (j & 1) floats into the window and sees tap k at window position Hb + s_j - 2 k: A[j][u] = b[(Hb + s_j - u) / 2] where that is
 // even, else 0 (half of the matrix pipe's work multiplies zeros; the launches are bound by the stream)
 bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab, bool cplx) {
-    if ((D != 8 && D != 16 && D != 32) || ntaps < 2) return false;
+    if ((D != 4 && D != 8 && D != 16 && D != 32) || ntaps < 2) return false;
     int KQ = 0;
     for (int k : {3, 5, 7, 9})
         if (128 * k > 16 * (int)D && (size_t)(128 * k - 16 * (int)D + 1) >= (cplx ? 2 * ntaps - 1 : ntaps)) { KQ = k; break; } // Hb = 128 KQ - 16 D >= taps - 1 (complex: 2 (taps - 1))
@@ -267,9 +299,12 @@ bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ
     return true;
 }
 
-// y[m] = sum_k b[k] x[D m - k], m < n_out = n_in / D, D = 8 / 16 / 32; hist[h] = x[-Kh + h]; x and y 16-byte aligned
+// y[m] = sum_k b[k] x[D m - k], m < n_out = n_in / D, D = 4 / 8 / 16 / 32; hist[h] = x[-Kh + h]; x and y 16-byte aligned
 template <int D>
-static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float* hist, int Kh, const unsigned short* tb, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx) {
+static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float* hist, int Kh, const unsigned short* tb, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx,
+                                  const BdHooks& hk) {
+    const bool hooked = hk.pre.n_ops > 0 || hk.post.n_ops > 0;
+    if (hooked && ((Kh % 4) != 0 || (D == 4 && KQ > 5))) return GR4HIP_UNSUPPORTED; // (fir.hip does not send these shapes here)
     static const int kSpwEnv = [] { const char* e = std::getenv("GR4HIP_DH_SPW"); return e ? std::atoi(e) : 0; }(); // developer knob
     const long nseg = ceil_div(n_out, (long)(kDhSegIn / D));
     const int  spw  = kSpwEnv ? kSpwEnv : (int)std::min<long>(std::max<long>(nseg / 512, 4), 32); // segments per workgroup: the tap fragments and the first staging once per run (2^27 inputs, D = 8: 4 / 8 / 16 / 32 / 64 segments measured 739 / 758 / 777 / 788 / 520 G at 1024 taps)
@@ -279,8 +314,10 @@ static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float
         if constexpr (128 * K > 16 * D) {                                                                                                                                \
             constexpr int    NS  = kDhSegIn + 128 * K - 16 * D;                                                                                                          \
             constexpr size_t lds = (size_t)2 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                  \
-            if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decim_f16x2_kernel<D, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per call: the attribute is per device) */ \
-            hipLaunchKernelGGL((fir_decim_f16x2_kernel<D, K>), grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw, flags, cplx);                      \
+            constexpr bool kHookFits = !(D == 4 && K > 5); /* (the hooked D = 4 kernels with 7 / 9 K-steps per wave would spill: never instantiated) */                           \
+            auto kern = (hooked && kHookFits) ? fir_decim_f16x2_kernel<D, K, kHookFits> : fir_decim_f16x2_kernel<D, K, false>;                                                                \
+            if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per call: the attribute is per device) */ \
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw, flags, cplx, hk);                                   \
         } else return GR4HIP_UNSUPPORTED;                                                                                                                                \
     } break
     switch (KQ) {
@@ -296,12 +333,19 @@ static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float
 }
 // cplx: x, y, hist are complex<float> streams passed as floats: n_in, n_out, Kh count FLOATS, D is the decimation of the complex stream
 // flags: ceil(n_out / (8192 / D)) bytes: the segments (8192 / D outputs, counted as n_out is) fir_exact_launch evaluates again behind this launch
-int fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx) {
+// pre / post (optional): the filter's load / store programs (positions: sample indices of x[0] / y[0])
+int fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx,
+                         const EwiseHook* pre, const EwiseHook* post) {
     const auto tb = static_cast<const unsigned short*>(table);
+    BdHooks    hk;
+    if (pre) hk.pre = *pre;
+    if (post) hk.post = *post;
+    hk.cplx = cplx;
     switch (D) {
-    case 8: return fir_decim_f16_launch_d<8>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx);
-    case 16: return fir_decim_f16_launch_d<16>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx);
-    case 32: return fir_decim_f16_launch_d<32>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx);
+    case 4: return fir_decim_f16_launch_d<4>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx, hk);
+    case 8: return fir_decim_f16_launch_d<8>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx, hk);
+    case 16: return fir_decim_f16_launch_d<16>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx, hk);
+    case 32: return fir_decim_f16_launch_d<32>(KQ, x, n_in, hist, Kh, tb, y, n_out, st, new_hist, guard, flags, cplx, hk);
     default: return GR4HIP_UNSUPPORTED;
     }
 }

@@ -518,7 +518,8 @@ def test_fir_every_kernel_answers_to_the_guard(G, cplx, D, ntaps, algo, short):
 
 
 @pytest.mark.parametrize("D,ntaps", [(8, 97), (8, 169), (8, 257), (8, 258), (8, 513), (8, 514), (8, 769), (8, 770), (8, 1024), (8, 1025),
-                                     (16, 33), (16, 129), (16, 130), (16, 385), (16, 386), (16, 897), (32, 64), (32, 129), (32, 130), (32, 641)])
+                                     (16, 33), (16, 129), (16, 130), (16, 385), (16, 386), (16, 897), (32, 64), (32, 129), (32, 130), (32, 641),
+                                     (4, 33), (4, 64), (4, 321), (4, 322), (4, 577), (4, 578), (4, 1025)])  # (round 5: decimate by 4 on the same kernel, eight tile rows per column)
 def test_fir_decimate_by_8_16_32_f16_band_kernel(G, D, ntaps, devsw):
     """BasicDecimatingFilter<float>, decimate by 8 (97 .. 1025 taps), 16 (33 .. 897) and 32 (33 .. 641), long aligned spans -- the default since late round 4: the band form on the f16 matrix pipe
     (fir_decim_f16.hip; the window sizes 3 / 5 / 7 / 9 K-steps per wave at their edges).  The float64 oracle's bar across ragged calls and at any level of the stream
@@ -528,8 +529,9 @@ def test_fir_decimate_by_8_16_32_f16_band_kernel(G, D, ntaps, devsw):
     are several times above it"""
     rng = np.random.default_rng(ntaps)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
-    n = D * 4 * 15_000
-    cuts = [0, D * 4 * 5_001, D * 4 * 5_001 + D * 4 * 4_250, n]  # (calls of >= 2^17 samples, 16-byte aligned)
+    U = D * 4 * max(1, 8 // D)  # (decimate by 4: twice as many outputs, so that every call still is >= 2^17 samples)
+    n = U * 15_000
+    cuts = [0, U * 5_001, U * 5_001 + U * 4_250, n]  # (calls of >= 2^17 samples, 16-byte aligned)
     x = O.signal_f32(31, n)
 
     def run(xx, taps=b, guard=None):
@@ -571,7 +573,7 @@ def test_fir_decimate_by_8_16_32_f16_band_kernel(G, D, ntaps, devsw):
     assert e_off > 1.5 * e_def and e_def <= max(TOL, e_ref) and e_def <= 1e-6, (e_def, e_off, e_ref)  # the contract's bound, factor one
 
 
-@pytest.mark.parametrize("D,ntaps", [(8, 64), (8, 97), (8, 256), (8, 513), (16, 33), (16, 200), (16, 449), (32, 64), (32, 321)])
+@pytest.mark.parametrize("D,ntaps", [(8, 64), (8, 97), (8, 256), (8, 513), (16, 33), (16, 200), (16, 449), (32, 64), (32, 321), (4, 33), (4, 161), (4, 162), (4, 289), (4, 513)])
 def test_fir_complex_decimate_f16_band_kernel_levels_outliers_and_rejected_tone(G, D, ntaps, devsw):
     """BasicDecimatingFilter<complex<float>> with real taps on the f16 band-form kernel (the interleaved stream read as floats, the interleaving in the tap table): the float64
     oracle's bar at any level of the stream; a glitch of 1e30 in a re and an Inf in an im component -- the reference's classes on exactly the outputs (and the components) whose
@@ -579,8 +581,9 @@ def test_fir_complex_decimate_f16_band_kernel_levels_outliers_and_rejected_tone(
     evaluated again inside the kernel"""
     rng = np.random.default_rng(ntaps + D)
     b = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
-    n = D * 4 * 12_000
-    cuts = [0, D * 4 * 4_001, D * 4 * 4_001 + D * 4 * 4_250, n]
+    U = D * 4 * max(1, 8 // D)
+    n = U * 12_000
+    cuts = [0, U * 4_001, U * 4_001 + U * 4_250, n]
     x = O.signal_c32(37, n)
 
     def oracle(taps, xx):  # (real taps never mix the components: the float oracle on each)
