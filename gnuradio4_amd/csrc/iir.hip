@@ -688,8 +688,12 @@ __global__ __launch_bounds__(kIirBS, 4) void iir_seq_kernel(IirSeqArgs a, IirCoe
 #pragma unroll
             for (int j = 0; j < ORD; ++j) st[s][j] = 0.f;
         float* row = tile + c * (kIirL + 1);
+#if defined(GR4_T_IIR_NOZS) // developer timing build (results are wrong): no zero-state run = the bound of moving it to the matrix pipe
+        st[0][0] = row[0];
+#else
 #pragma unroll 4
         for (int i = 0; i < kIirL; ++i) (void)iir_step<ORD, NSEC>(coef, st, row[i]);
+#endif
         float e[MP], ex[MP];
 #pragma unroll
         for (int s = 0; s < NSEC; ++s)
