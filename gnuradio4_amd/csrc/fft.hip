@@ -150,6 +150,80 @@ __global__ __launch_bounds__(256) void fft_emit_kernel(const float2* __restrict_
     emit_bin(out, frame0 + f, N, k, B[f * N + (long)(k % n1) * (N / n1) + k / n1]);
 }
 
+// (1b, round 5) N = 65536 = 256 x 256 in TWO kernels, 32 B of HBM traffic per point instead of the 48 of the three-kernel pipeline above (bm_fft.cpp:44-58 times this size):
+//       n = 256 n1 + n2, k = k1 + 256 k2:   X[k1 + 256 k2] = sum_{n2} W_256^{n2 k2} ( W_N^{n2 k1} sum_{n1} x[256 n1 + n2] W_256^{n1 k1} )
+//     fft_64k_cols_kernel: a workgroup takes 16 neighbouring columns n2 of a frame (every row of them is one 128-byte segment), window, the 256-point transform down each
+//                          column (16 lanes x 16 points, radix 16 x 16, one exchange through LDS), x W_N^{n2 k1}, A[f][k1][n2] (128-byte segments again)
+//     fft_64k_rows_kernel: a workgroup takes 16 neighbouring rows k1 of A (2 KiB each), the 256-point transform along each, a transposition through LDS so that 16
+//                          consecutive lanes hold 16 consecutive bins k1 + 256 k2, every requested output
+// W_256^j is read as W_N^{256 j} from the one twiddle table of the size.
+__device__ __forceinline__ void fft256_by_16_lanes(float2 (&v)[16], float2* S /*this transform's 16 x 17 exchange rows*/, int t, const float2* w256 /*W_256^j, in LDS*/) {
+    fft16<1>(v); // over r: Y_t[q] at slot perm16(q)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float2 y = v[perm16(q)];
+        if (q > 0) y = cmul(y, w256[(t * q) & 255]); // W_256^{t q}
+        S[q * 17 + t] = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) v[tt] = S[t * 17 + tt]; // lane q = t gathers Y_tt[q]
+    fft16<1>(v); // over t: X[q + 16 p] at slot perm16(p)
+}
+__global__ __launch_bounds__(256) void fft_64k_cols_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ twG /*W_N^{n2 k1} at [k1][n2]*/,
+                                                            const float2* __restrict__ tw4096, float2* __restrict__ A, int real_input) {
+    __shared__ float2 S[16 * 16 * 17];
+    __shared__ float2 w256[256];
+    w256[threadIdx.x] = tw4096[16 * threadIdx.x]; // W_256^j = W_4096^{16 j}
+    constexpr int N = 65536;
+    const long    f = blockIdx.x >> 4;
+    const int     cb = blockIdx.x & 15, col = threadIdx.x & 15, t = threadIdx.x >> 4, n2 = 16 * cb + col;
+    float2        v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int  n1 = t + 16 * r;
+        const long i  = f * N + 256L * n1 + n2;
+        float2     x  = real_input ? make_float2(in[i], 0.f) : reinterpret_cast<const float2*>(in)[i];
+        if (window) { const float w = window[256 * n1 + n2]; x.x *= w; x.y *= w; }
+        v[r] = x;
+    }
+    __syncthreads();
+    fft256_by_16_lanes(v, S + col * 16 * 17, t, w256);
+    // W_N^{n2 k1} from a table laid out [k1][n2]: the 16 lanes of a column group read 128 consecutive bytes, like the samples.  (Measured: the same values gathered from the
+    // linear table W_N^j -- one random 8-byte read per point -- 95 Gsamples/s; as W_N^{n2 t} x W_4096^{n2 p}, two rounded factors -- 150, but 1.2e-5 on the strong-tone test
+    // signal where one exact factor gives 8e-6.)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int k1 = t + 16 * p;
+        A[(f * 256 + k1) * 256 + n2] = cmul(v[perm16(p)], twG[k1 * 256 + n2]);
+    }
+}
+__global__ __launch_bounds__(256) void fft_64k_rows_kernel(const float2* __restrict__ A, const float2* __restrict__ tw4096, FftOutputs out, long frame0) {
+    __shared__ float2 S[16 * 16 * 17];
+    __shared__ float2 w256[256];
+    w256[threadIdx.x] = tw4096[16 * threadIdx.x];
+    constexpr int N = 65536;
+    const long    f = blockIdx.x >> 4;
+    const int     rb = blockIdx.x & 15, row = threadIdx.x >> 4, t = threadIdx.x & 15;
+    const float2* a = A + (f * 256 + 16 * rb + row) * 256;
+    float2        v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = a[t + 16 * r];
+    __syncthreads();
+    fft256_by_16_lanes(v, S + row * 16 * 17, t, w256);
+    __syncthreads(); // every transform has read its exchange rows: S is free for the transposition
+    // X[k2 = t + 16 p] of row k1 = 16 rb + row -> O[k2][row]; then lane l emits bins (16 rb + (l & 15)) + 256 k2, k2 = (l >> 4) + 16 i: 16 consecutive lanes = 16 consecutive bins
+#pragma unroll
+    for (int p = 0; p < 16; ++p) S[(t + 16 * p) * 17 + row] = v[perm16(p)];
+    __syncthreads();
+    const int rr = threadIdx.x & 15, k2b = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k2 = k2b + 16 * i;
+        emit_bin(out, frame0 + f, N, 16 * rb + rr + 256 * k2, S[k2 * 17 + rr]);
+    }
+}
+
 // N1 = 32 .. 256 (N = 2^17 .. 2^20): the column transforms no longer fit a lane's registers.  They run as ordinary N1-point frames of the block
 // kernels, between two transpositions done in 32 x 32 tiles through LDS (reads and writes both in 256-byte rows):
 //   gather:  x[f][n1][n2] (window applied) -> Xt[f][n2][n1]        cols: N1-point transforms of the 4096 rows of Xt -> Yt[f][n2][k1]
@@ -359,6 +433,7 @@ struct Pow2Engine {
     int          n1 = 0; // 0: single launch
     FftPlanDev   plan{}, plan_cols{};
     DeviceBuffer tw /*W_M^j*/, tw_rows /*W_4096^j*/, tw_cols /*W_N1^j, N1 > 16*/, s0, s1;
+    DeviceBuffer tw_grid; // M = 65536: W_M^{n2 k1} as a table [k1][n2] (256 x 256): the column kernel reads it in the same 128-byte segments as the samples
 };
 constexpr size_t kFftMaxPow2 = size_t(1) << 20;      // largest power-of-two transform (N1 = 256)
 constexpr long   kFftBatchElems = 1L << 25;          // multi-kernel paths: complex elements per scratch buffer (256 MiB); longer inputs run in batches of frames
@@ -453,6 +528,17 @@ static int engine_create(Pow2Engine* e, size_t M) {
     if (M <= 8192) return fft_build_plan(M, &e->plan);
     e->n1 = (int)(M / 4096);
     rc    = fft_upload_twiddles(4096, &e->tw_rows);
+    if (!rc && M == 65536) {
+        std::vector<float> g((size_t)2 * 65536);
+        for (int k1 = 0; k1 < 256; ++k1)
+            for (int n2 = 0; n2 < 256; ++n2) {
+                const double ang = -2.0 * M_PI * (double)((k1 * n2) & 65535) / 65536.0;
+                g[2 * ((size_t)k1 * 256 + n2)]     = (float)std::cos(ang);
+                g[2 * ((size_t)k1 * 256 + n2) + 1] = (float)std::sin(ang);
+            }
+        rc = e->tw_grid.ensure(g.size() * sizeof(float));
+        if (!rc) GR4_HIP_TRY(hipMemcpy(e->tw_grid.ptr, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (!rc && e->n1 > 16) {
         rc = fft_build_plan((size_t)e->n1, &e->plan_cols);
         if (!rc) rc = fft_upload_twiddles((size_t)e->n1, &e->tw_cols);
@@ -476,6 +562,14 @@ static int engine_run(Pow2Engine* e, const float* d_in, const float* window, con
     float2*    s1  = static_cast<float2*>(e->s1.ptr);
     const auto twN = static_cast<const float2*>(e->tw.ptr);
     FftOutputs spec{};
+    if (M == 65536 && !dev_switch(kDevFftFourStep64k)) { // 256 x 256 in two kernels (32 B of HBM traffic per point instead of 48)
+        const auto tw4096 = static_cast<const float2*>(e->tw_rows.ptr);
+        hipLaunchKernelGGL(fft_64k_cols_kernel, dim3((unsigned)(n_frames * 16)), dim3(256), 0, st, d_in, window, static_cast<const float2*>(e->tw_grid.ptr), tw4096, s0, fin.real_input);
+        GR4_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fft_64k_rows_kernel, dim3((unsigned)(n_frames * 16)), dim3(256), 0, st, (const float2*)s0, tw4096, fin, frame0);
+        GR4_LAUNCH_CHECK();
+        return GR4HIP_OK;
+    }
     if (n1 <= 16) {
         const dim3 grid((unsigned)ceil_div(n_frames * 4096L, 256L));
         if (n1 == 4) hipLaunchKernelGGL(fft_big_cols_kernel<4>, grid, dim3(256), 0, st, d_in, window, twN, s0, n_frames, fin.real_input);

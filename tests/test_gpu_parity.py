@@ -1295,6 +1295,19 @@ def test_fft_large_power_of_two(G, N):
         assert _rel(got[f], truth) <= tol
     if N == 16384:
         assert _rel(O.dft64(x[:N]), np.fft.fft(x[:N].astype(np.complex128))) <= 1e-9
+    if N == 65536:  # round 5: 256 x 256 in two kernels (32 B of HBM traffic per point); the three-kernel four-step pipeline behind the developer switch gives the same spectra
+        G.capi.developer_switch("GR4HIP_FFT_FOUR_STEP_64K", 1)
+        old = G.FFT(N, "None").spectrum(dev(x)).cpu().numpy()
+        G.capi.developer_switch("GR4HIP_FFT_FOUR_STEP_64K", 0)
+        assert not np.array_equal(old, got) and _rel(old[0], np.fft.fft(x[:N].astype(np.complex128))) <= tol  # (two different kernels did run)
+        xr = O.signal_f32(5, 3 * N)  # real input, Hamming window, the DataSet outputs through the same two kernels: the same values as the four-step pipeline's to rounding
+        new_out = G.FFT(N, "Hamming", dtype=torch.float32).process_bulk(dev(xr), ranges=False)
+        G.capi.developer_switch("GR4HIP_FFT_FOUR_STEP_64K", 1)
+        old_out = G.FFT(N, "Hamming", dtype=torch.float32).process_bulk(dev(xr), ranges=False)
+        G.capi.developer_switch("GR4HIP_FFT_FOUR_STEP_64K", 0)
+        for key in ("magnitude", "re", "im"):
+            a_, b_ = new_out[key].cpu().numpy(), old_out[key].cpu().numpy()
+            assert a_.shape == b_.shape and _rel(a_, b_.astype(np.float64)) <= TOL, key
     m2 = G.FFT(N, "Hann").mag2(dev(x)).cpu().numpy()
     w = O.window(3, N)
     t2 = np.abs(np.fft.fft(x[:N].astype(np.complex128) * w)) ** 2
