@@ -5,7 +5,9 @@ import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
 from scipy.signal import lfilter, get_window
+sys.path.insert(0, "tests")
 import gnuradio4_amd as G
+import oracle_lib as O
 from gnuradio4_amd import capi
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -41,12 +43,15 @@ while time.time() - t0 < secs:
     r = float(np.max(np.abs(got - truth) / np.maximum(truth, rms)))
     # what float32 arithmetic itself leaves (the reference's direct-form sum in float32, transform in float64): a rejected interferer 50 dB above the output puts
     # the rounding of its products -- relative to the INPUT -- well above 1e-5 of the output, on the CPU as on the device
-    y32 = lfilter(taps, np.float32([1.0]), x).astype(np.complex64).reshape(frames, N)
+    y32 = O.fir(taps, x, acc64=False)[0].reshape(frames, N)  # (the oracle's restatement of time_domain_filter.hpp:44-47 in float32, in the reference's order)
     t32 = np.abs(np.fft.fft(y32.astype(np.complex128) * (w if win != "None" else 1.0), axis=1)) ** 2
     r32 = float(np.max(np.abs(t32 - truth) / np.maximum(truth, rms)))
     ratio, td = ch.last_power_ratio() if hasattr(ch, "last_power_ratio") else (None, None)
     switched += 1 if td else 0
     cases += 1; worst = max(worst, r)
-    if r > 2e-5 + 8 * r32: print("FAIL", f"N={N} taps={nt} win={win} frames={frames} cuts={cuts}", r, "float32 direct form:", r32, flush=True)  # (mag2 doubles the relative error of the amplitude: 2 x 1e-5)
-    worst_excess = max(globals().get("worst_excess", 0.0), r - 8 * r32)
-print(f"{cases} cases in {time.time() - t0:.0f} s ({switched} ended on the time-domain kernels), worst relative error of |Y|^2 {worst:.3g}, worst excess over 8 x the float32 direct form (the bf16 three-term direct form under a rejected +50 dB interferer measures up to 6.5 x) {worst_excess:.3g} (bar 2e-5)")
+    # the contract (include/gr4hip.h): 1e-5 of the output, or the reference's own float32 error where that is larger -- factor ONE
+    if r > max(1e-5, r32):
+        fails = globals().get("fails", 0) + 1
+        if fails <= 12: print("FAIL", f"N={N} taps={nt} win={win} frames={frames} cuts={cuts} ratio={ratio}", r, "reference float32 FIR:", r32, flush=True)
+    worst_excess = max(globals().get("worst_excess", 0.0), r - max(1e-5, r32))
+print(f"{cases} cases in {time.time() - t0:.0f} s ({switched} ended on the time-domain kernels), {globals().get('fails', 0)} above max(1e-5, the reference's float32 error), worst relative error of |Y|^2 {worst:.3g}, worst excess over the bar {globals().get('worst_excess', 0.0):.3g}")

@@ -87,9 +87,9 @@ while time.time() - t0 < secs:
         truth = signal.sosfilt(sos, mid)
         r = rel(y, truth); tag = f"fir_iir mode={mode} order={order} fc={fc:.3f} n={n} cut={cut} taps={nt}"; key = f"fir_iir_mode{mode}"
         if r > 1e-5:  # the contract's second clause: the reference's own float32 cascade on the same decimated stream (oracle restatement, test infrastructure), factor ONE
-            secs = O.make_sections([(bb, aa) for bb, aa in zip(np.asarray(b, np.float32).reshape(-1, 3), np.asarray(a, np.float32).reshape(-1, 3))])
-            t64 = O.iir_cascade(secs, mid.astype(np.float32), 3, f64=True)
-            e_ref = min(rel(O.iir_cascade(secs, mid.astype(np.float32), form, f64=False), t64) for form in (O.DF_I, O.DF_II))
+            sections = O.make_sections([(bb, aa) for bb, aa in zip(np.asarray(b, np.float32).reshape(-1, 3), np.asarray(a, np.float32).reshape(-1, 3))])
+            t64 = O.iir_cascade(sections, mid.astype(np.float32), 3, f64=True)
+            e_ref = min(rel(O.iir_cascade(sections, mid.astype(np.float32), form, f64=False), t64) for form in (O.DF_I, O.DF_II))
             tag += f" reference_f32={e_ref:.2e}"
             if r <= e_ref: r = 0.0
     cases += 1
