@@ -70,6 +70,10 @@ struct ChainFdArgs {
     float         pw_thr; // a frame whose sampled output power is below pw_thr x its sampled input power marks the launch (word 33 of pw, word 3 of pw_host)
     unsigned char* fflags; // optional, one byte per frame (8192-sample block): non-zero = that frame fell below the threshold -- chain_redo_kernel, launched behind this
                            // kernel, evaluates exactly those frames again in the time domain (float64 products): the guard without the host
+    // chain_redo_kernel only (0 = the fused kernel's own conventions):
+    int            redo_hist_len; // samples `hist` holds in front of x (0: 256)
+    int            redo_flags_per_block; // flag bytes per 8192-sample block (0: 1; the fused time-domain kernel judges 4096-sample segments: 2)
+    long           redo_n;        // samples of the span (0: n_frames whole blocks); a partial last block reads zeros behind it and writes only what the span holds
     unsigned long long* dbg; // GR4_FD_TIMING only
 };
 // several channels in ONE launch (gr4hip_chain_process_multi, kModeMag2 only).  fold_ch > 1: every workgroup takes frame f of ALL channels in turn (same taps:
@@ -915,10 +919,17 @@ __global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int nt
     float*  tz = sg + 2 * kRdLp;                         // tz[15 + k] = b[k], zeros either side
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, kq = lane >> 4;
     auto ph = [](int i) { return i + 4 * (i >> 4); };
+    const int  fpb    = a.redo_flags_per_block > 0 ? a.redo_flags_per_block : 1, hlen = a.redo_hist_len > 0 ? a.redo_hist_len : 256;
+    const long n_span = a.redo_n > 0 ? a.redo_n : a.n_frames * kN, n_flags = (n_span + kN / fpb - 1) / (kN / fpb);
+    const auto marked = [&](long f) { // any flag byte of block f
+        int m = 0;
+        for (long b = f * fpb; b < (f + 1) * fpb && b < n_flags; ++b) m |= a.fflags[b];
+        return m;
+    };
     {   // an ordinary stream marks nothing: every lane looks at its share of this workgroup's flag bytes at once, and the workgroup leaves (measured: a lane that walks its
         // 512 bytes one dependent load after the other costs the headline launch 0.35 ms)
         int any = 0;
-        for (long f = (long)blockIdx.x + (long)t * gridDim.x; f < a.n_frames; f += (long)kT * gridDim.x) any |= a.fflags[f];
+        for (long f = (long)blockIdx.x + (long)t * gridDim.x; f < a.n_frames; f += (long)kT * gridDim.x) any |= marked(f);
         if (!__syncthreads_or(any)) return;
     }
     for (int i = t; i < kRdKw + 15; i += kT) { const int k = i - 15; tz[i] = (k >= 0 && k < ntaps) ? a.taps[k] : 0.f; }
@@ -942,12 +953,12 @@ __global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int nt
     }
     const int comp = wave & 1;
     for (long f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
-        if (a.fflags[f] == 0) continue; // (uniform)
-        __syncthreads();                // the previous frame's readers are done with S and the planes
+        if (marked(f) == 0) continue; // (uniform)
+        __syncthreads();              // the previous frame's readers are done with S and the planes
         int nf = 0;
         for (int i = t; i < kRdL; i += kT) {
             const long   sidx = f * kN - kRdHb + i;
-            const float2 v = sidx >= 0 ? a.x[sidx] : a.hist[256 + sidx];
+            const float2 v = sidx >= 0 ? (sidx < n_span ? a.x[sidx] : make_float2(0.f, 0.f)) : (sidx >= -(long)hlen ? a.hist[hlen + sidx] : make_float2(0.f, 0.f));
             nf |= (int)!(__builtin_fabsf(v.x) <= 3.4028234663852886e38f) | (int)!(__builtin_fabsf(v.y) <= 3.4028234663852886e38f);
             sg[ph(i)]         = v.x;
             sg[kRdLp + ph(i)] = v.y;
@@ -989,7 +1000,10 @@ __global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int nt
             asm volatile("" : "+v"(b2a.x), "+v"(b2a.y), "+v"(b2b.x), "+v"(b2b.y), "+v"(b3.x), "+v"(b3.y), "+v"(b3sq.x), "+v"(b3sq.y));
             fft_small_passes<LOG2NF>(v, fb, tt, b2a, b2b, b3, b3sq, Xs, [] { __syncthreads(); });
 #pragma unroll
-            for (int j = 0; j < 16; ++j) out[(t / TF) * NF + t % TF + j * TF] = fmaf(Xs[j].x, Xs[j].x, Xs[j].y * Xs[j].y);
+            for (int j = 0; j < 16; ++j) {
+                const int off = (t / TF) * NF + t % TF + j * TF;
+                if (f * kN + off < n_span) out[off] = fmaf(Xs[j].x, Xs[j].x, Xs[j].y * Xs[j].y);
+            }
         } else {
             passA_inplace(S, twA, par, n0, sgn);
             __syncthreads();
@@ -1393,6 +1407,54 @@ void chain_fused_destroy(ChainFused* c) { delete c; }
 // wait: synchronise on that launch; otherwise only report it when it has already finished.  Returns 1 with *ratio set, 0 if nothing (new) is available.
 void chain_fused_set_measure(ChainFused* c, bool on) { c->measure = on; }
 void chain_fused_set_redo(ChainFused* c, bool on) { c->redo = on; }
+
+// (chain.hip) the second evaluation for ANOTHER kernel's launch -- the fused time-domain chain (chain_td.hip), which judges 4096-sample segments: the blocks of the span
+// d_in[0 .. n_samples) that hold a marked segment again with float64 products, over d_out.  `c` supplies the tables (taps, window, twiddles) of the same chain
+// configuration; d_hist: the hist_len samples in front of d_in.
+int chain_fused_redo(ChainFused* c, const float* d_in, const float* d_hist, int hist_len, size_t n_samples, float* d_out, const unsigned char* d_flags, int flags_per_block, hipStream_t st) {
+    if (n_samples == 0) return GR4HIP_OK;
+    ChainFdArgs a{};
+    a.x    = reinterpret_cast<const float2*>(d_in);
+    a.hist = reinterpret_cast<const float2*>(d_hist);
+    a.twB  = static_cast<const float2*>(c->d_twB.ptr);
+    a.twC  = static_cast<const float2*>(c->d_twC.ptr);
+    a.taps = static_cast<const float*>(c->d_taps.ptr);
+    a.win  = static_cast<const float*>(c->d_win.ptr);
+    a.twS  = static_cast<const float2*>(c->d_twS.ptr);
+    a.out  = d_out;
+    a.n_frames = (long)ceil_div(n_samples, (size_t)kN);
+    a.fflags   = const_cast<unsigned char*>(d_flags);
+    a.redo_hist_len = hist_len; a.redo_flags_per_block = flags_per_block; a.redo_n = (long)n_samples;
+    static PerDevice per_device;
+    bool             first = false;
+    int              dev = -1, n_cu = per_device.current(&first, &dev);
+    GR4_REQUIRE(n_cu != 0, "fused chain: cannot query the current device");
+    if (first) {
+        n_cu = -n_cu;
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_kernel<kModeWinSmall, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+        per_device.done(dev, n_cu);
+    }
+    const unsigned rg = (unsigned)std::min<size_t>((size_t)a.n_frames, (size_t)n_cu);
+    const int      nt = (int)c->ntaps;
+    switch (c->small_log2n) {
+    case 8: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 8>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    case 9: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 9>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    case 10: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 10>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    case 11: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 11>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    case 12: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 12>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    default:
+        if (c->windowed) hipLaunchKernelGGL(chain_redo_kernel<kModeWinMag2>, dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt);
+        else hipLaunchKernelGGL(chain_redo_kernel<kModeMag2>, dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt);
+    }
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
 int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio) {
     if (!c->h_pw || c->pw_seq == c->pw_read) return 0;
     volatile unsigned* seqw = reinterpret_cast<volatile unsigned*>(c->h_pw) + 2; // sequence number of the launch whose pair the word holds

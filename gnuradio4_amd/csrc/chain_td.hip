@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fft_radix.hpp"
+#include "fir_f16_common.hpp" // (hf_wave_sum)
 
 #include <cmath>
 
@@ -70,13 +71,16 @@ template <int KS /*K-steps of 32: window 32 KS, Hb = 32 KS - 16 samples in front
 __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(const float2* __restrict__ x, const float2* __restrict__ hist /*the Kh samples in front of x*/, int Kh,
                                                         const td_u32x4* __restrict__ afrag /*[3 planes][KS][64 lanes]: 8 bf16 each (fir_bf16_make_afrag)*/,
                                                         const float* __restrict__ win /*[N] or null*/, const float2* __restrict__ tw /*W_N^j*/, float* __restrict__ out,
-                                                        long n /*samples: whole frames*/, float2* __restrict__ new_hist) {
+                                                        long n /*samples: whole frames*/, float2* __restrict__ new_hist,
+                                                        float gthr /*> 0: the FIR guard of fir.hip -- a segment whose FILTER output carries less than gthr x the power of its samples is marked*/,
+                                                        unsigned char* __restrict__ flags /*one byte per 4096-sample segment: chain_redo_kernel (chain_fused.hip) evaluates the marked ones again*/) {
     constexpr int Hb = 32 * KS - 16, NS = kTdSeg + Hb, N = 1 << LOG2N, T = N / 16, NP = N + N / 32;
     constexpr int PL  = NS + 8;                         // bf16 elements per plane
     constexpr int NL4 = (NS / 2 + 255) / 256;          // float4 loads (two complex samples each) per lane and segment
     constexpr int R3  = N / 256;                       // third pass radix (1: none)
     constexpr int B3  = R3 > 1 ? 16 / R3 : 1, NB3 = N / (R3 > 1 ? R3 : 1);
     extern __shared__ __attribute__((aligned(16))) float td_sm[];
+    __shared__ float jred[8]; // the judge's wave sums: input power, output power
     unsigned short* pl = reinterpret_cast<unsigned short*>(td_sm); // [6][PL] staged samples: re h, m, l, im h, m, l ...
     float2*         fb = reinterpret_cast<float2*>(td_sm);         // ... then, in the same place, the segment's frames [4096 / N][NP]
     auto    P  = [](int i) { return i + (i >> 5); };
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
     const long n_frames = n >> LOG2N;
     for (long sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
         const long seg0 = sg * kTdSeg;
+        float      pxl  = 0.f; // this lane's share of the segment's input power (its own 4096 samples, not the history in front of them)
         if (sg > 0) { // (no register prefetch of the next segment: with several workgroups per CU another one always has work)
             const long   i0   = seg0 - Hb; // seg0 >= kTdSeg > Hb: nothing below 0; past the end of the span / of the segment the range check returns 0
             const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
@@ -122,7 +127,10 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
 #pragma unroll
             for (int u = 0; u < NL4; ++u) {
                 const int q = tid + 256 * u;
-                if (q < NS / 2) put2(q, nxt[u]);
+                if (q < NS / 2) {
+                    put2(q, nxt[u]);
+                    if (2 * q >= Hb) pxl = fmaf(nxt[u].x, nxt[u].x, fmaf(nxt[u].y, nxt[u].y, fmaf(nxt[u].z, nxt[u].z, fmaf(nxt[u].w, nxt[u].w, pxl)))); // (Hb is even: a pair never straddles the segment's start)
+                }
             }
         } else {
             for (int q = tid; q < NS / 2; q += 256) { // the first segment of the span reads the carried history in front of x
@@ -133,6 +141,7 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
                     t2[c]        = i >= 0 ? (i < n ? x[i] : make_float2(0.f, 0.f)) : (i >= -(long)Kh ? hist[Kh + i] : make_float2(0.f, 0.f));
                 }
                 put2(q, make_float4(t2[0].x, t2[0].y, t2[1].x, t2[1].y));
+                if (2 * q >= Hb) pxl = fmaf(t2[0].x, t2[0].x, fmaf(t2[0].y, t2[0].y, fmaf(t2[1].x, t2[1].x, fmaf(t2[1].y, t2[1].y, pxl))));
             }
         }
         GR4_TD_BARRIER();
@@ -191,7 +200,22 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
                 acr[2 * pp + 1][r] = cr1[r] + dr1[r]; aci[2 * pp + 1][r] = ci1[r] + di1[r];
             }
         }
+        if (gthr > 0.f) { // the filter's output power (in front of the window), the quietest wave's counting for the segment like in the band kernels
+            float pyl = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pyl = fmaf(acr[q][r], acr[q][r], fmaf(aci[q][r], aci[q][r], pyl)); // (outputs past the span's end: the filter's ringing over zeros -- a few taps' worth in the last segment)
+            pxl = hf_wave_sum(pxl);
+            pyl = hf_wave_sum(pyl);
+            if (lane == 0) { jred[wave] = pxl; jred[4 + wave] = seg0 + 1024L * wave < n ? pyl : __builtin_inff(); } // (a wave past the end of the span: nothing to judge)
+        }
         GR4_TD_BARRIER(); // every wave is done with the staged samples: the frame buffer takes their place
+        if (gthr > 0.f && tid == 0) {
+            const float px = (jred[0] + jred[1]) + (jred[2] + jred[3]);
+            const float py = 4.f * __builtin_fminf(__builtin_fminf(jred[4], jred[5]), __builtin_fminf(jred[6], jred[7]));
+            flags[sg] = (py < gthr * px) ? 3 : 0; // (a NaN power compares false: unmarked)
+        }
         // D[row = 4 kq + r][col] of tile q: sample 16 (16 (4 wave + q) + col) + 4 kq + r of the segment; x window -> frame buffer (natural order)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -294,6 +318,8 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
 // sched_group_barrier does not finish on a 272-MFMA region.)
 
 struct ChainTd {
+    float        gthr = 0.f;      // (sum b^2) / 128: the FIR guard's threshold (fir.hip kGuardSegmentRatio); chain_td_process passes it unless the guard is off
+    DeviceBuffer d_flags;         // one byte per 4096-sample segment of the last launch
     size_t       ntaps = 0, N = 0;
     int          KS = 0, Kp = 0, log2n = 0;
     bool         windowed = false;
@@ -317,6 +343,11 @@ int chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_s
     GR4_REQUIRE(c, "out of host memory");
     c->ntaps = ntaps;
     c->N     = fft_size;
+    {
+        double h2 = 0;
+        for (size_t k = 0; k < ntaps; ++k) h2 += (double)taps[k] * taps[k];
+        c->gthr = (float)(h2 / 128.0);
+    }
     (void)hipGetDevice(&c->dev);
     c->log2n = (int)ilog2(fft_size);
     std::vector<unsigned short> af;
@@ -366,7 +397,7 @@ int chain_td_set_history256(ChainTd* c, const float* d_hist256, hipStream_t st) 
 }
 
 template <int KS>
-static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
+static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st, bool judged) {
     constexpr int NS = kTdSeg + 32 * KS - 16, PL = NS + 8;
     const size_t  lds = std::max((size_t)6 * PL * sizeof(unsigned short), (size_t)(kTdSeg + kTdSeg / 32) * sizeof(float2)); // six bf16 planes of staged samples, then the frames
     const long    n   = (long)(n_frames * c->N), nseg = ceil_div(n, (long)kTdSeg);
@@ -379,12 +410,18 @@ static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_ma
     const auto    af = static_cast<const td_u32x4*>(c->d_afrag.ptr);
     const float*  wn = c->windowed ? static_cast<const float*>(c->d_win.ptr) : nullptr;
     const auto    tw = static_cast<const float2*>(c->d_tw.ptr);
+    const float   gthr = judged && c->ntaps > 1 ? c->gthr : 0.f;
+    unsigned char* fl  = nullptr;
+    if (gthr > 0.f) {
+        if (const int rc = c->d_flags.ensure((size_t)nseg)) return rc;
+        fl = static_cast<unsigned char*>(c->d_flags.ptr);
+    }
 #define GR4_TD_CASE(L2)                                                                                                                    \
     case L2: {                                                                                                                             \
         auto kern = chain_td_kernel<KS, L2>;                                                                                               \
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
         const dim3 grid((unsigned)std::min<long>(nseg, (long)n_cu * td_waves<KS, L2>()));                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, xc, hc, c->Kp, af, wn, tw, d_mag2, n, nh);                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, xc, hc, c->Kp, af, wn, tw, d_mag2, n, nh, gthr, fl);                       \
     } break
     switch (c->log2n) {
         GR4_TD_CASE(8);
@@ -400,14 +437,17 @@ static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_ma
     return GR4HIP_OK;
 }
 
-int chain_td_process(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
+// judged: every 4096-sample segment's filter output power is compared with its input power and the verdict left in chain_td_flags() -- one byte per segment; the caller
+// (chain.hip) enqueues chain_fused_redo behind this launch with the history this call STARTED from (chain_td_history before the call)
+int chain_td_process(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st, bool judged) {
     if (n_frames == 0) return GR4HIP_OK;
     GR4_REQUIRE((uintptr_t)d_in % 8 == 0 && (uintptr_t)d_mag2 % 4 == 0, "fused time-domain chain: misaligned device pointer");
     switch (c->KS) {
-    case 3: return td_launch<3>(c, d_in, n_frames, d_mag2, st);
-    case 5: return td_launch<5>(c, d_in, n_frames, d_mag2, st);
-    default: return td_launch<9>(c, d_in, n_frames, d_mag2, st);
+    case 3: return td_launch<3>(c, d_in, n_frames, d_mag2, st, judged);
+    case 5: return td_launch<5>(c, d_in, n_frames, d_mag2, st, judged);
+    default: return td_launch<9>(c, d_in, n_frames, d_mag2, st, judged);
     }
 }
+const unsigned char* chain_td_flags(const ChainTd* c) { return static_cast<const unsigned char*>(c->d_flags.ptr); }
 
 } // namespace gr4

@@ -1697,6 +1697,40 @@ def test_chain_strict_guard_does_not_wait_for_its_launch(G):
         assert _rel(cg.process_bulk(dev(loud)).cpu().numpy().ravel(), tw) <= TOL, window
 
 
+@pytest.mark.parametrize("N,ntaps,window,wid", [(4096, 64, "None", 0), (2048, 64, "Hann", 3), (256, 33, "BlackmanHarris", 7), (1024, 17, "Hamming", 2)])
+def test_fused_time_domain_chain_answers_to_the_guard(G, N, ntaps, window, wid):
+    """CHAIN_AUTO with <= 64 taps at fft sizes <= 4096 runs the fused time-domain kernel (chain_td.hip: the filter as float32 sums in the matrix pipe's order).  tools/fuzz_chain.py
+    against the oracle's reference-order float32 FIR found it at up to 4.6 x that sum's error under a rejected interferer; since round 5 the kernel marks the 4096-sample
+    segments whose filter output carries less than (sum b^2 / 128) x their input power and chain_redo_kernel evaluates the blocks that hold one again with float64 products
+    behind the launch: within the float64 bar, or within the reference's own float32 error -- factor ONE.  An interferer that sets in mid-stream, ragged calls, a span that
+    is not a whole number of 8192-sample blocks"""
+    rng = np.random.default_rng(N + ntaps)
+    frames = (3 * 8192 + 4096) // N * 4 + 1 if N < 4096 else 13
+    n = frames * N
+    b = O.design_taps_hamming_lowpass(ntaps, 0.05)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    start = n // 3 + 17
+    x[start:] += (300.0 * np.exp(2j * np.pi * 0.41 * np.arange(n - start))).astype(np.complex64)
+    truth, _ = O.chain(b, x, N, wid, truth=True)
+    y32 = O.fir(b, x, acc64=False)[0].reshape(frames, N)
+    w = O.window(wid, N).astype(np.float64) if wid else 1.0
+    t32 = (np.abs(np.fft.fft(y32.astype(np.complex128) * w, axis=1)) ** 2).ravel()
+    ch = G.Chain(b, N, window)
+    assert ch.algo == G.capi.CHAIN_FUSED_TD
+    cuts = [0, frames // 4, frames // 4 + 1, frames]
+    got = np.concatenate([ch.process_bulk(dev(x[a * N:c * N])).cpu().numpy().ravel() for a, c in zip(cuts[:-1], cuts[1:])])
+
+    def rel_frames(a, t):  # the chain's metric: per frame
+        a, t = a.reshape(frames, N), t.reshape(frames, N)
+        rms = np.sqrt(np.mean(t ** 2, axis=1, keepdims=True))
+        return float(np.max(np.abs(a - t) / np.maximum(t, rms)))
+    e, e_ref = rel_frames(got, truth), rel_frames(t32, truth)
+    assert e <= max(TOL, e_ref), (e, e_ref)
+    off = G.Chain(b, N, window)
+    off.set_guard_mode(G.capi.GUARD_OFF)
+    assert rel_frames(off.process_bulk(dev(x)).cpu().numpy().ravel(), truth) > e  # (what the second evaluation is for)
+
+
 def test_chain_guard_hands_small_fft_sizes_to_the_fused_time_domain_kernel(G):
     """fftSize <= 4096 with more than 64 taps: CHAIN_AUTO starts on the fused fast convolution; a stream whose filter removes most of the input is handed
     (history included) to the fused time-domain kernel -- one launch, the reference's arithmetic -- and meets the bar relative to the OUTPUT"""
