@@ -625,7 +625,7 @@ def main():
                                    f"(BASELINE.json configs[{4 if combine else 1}]), rectangular window, {nchunks} launch(es) of 2^{log2_chunk} samples per channel" + graph,
                        "chain_algo": KERNEL_SYMBOLS.get(algo, str(algo)), "channels": n_channels,
                        "parallelism": f"{n_channels} independent channel(s), {per_gpu} per GPU",
-                       "dynamic_range_guard": ["strict: every frame measured and judged inside the kernel, a span below the threshold redone before the call returns (library default)",
+                       "dynamic_range_guard": ["strict: every frame measured and judged inside the kernel, the marked frames evaluated again in the time domain by a launch enqueued behind it; no host wait (library default)",
                                                "deferred", "off"][args.guard_mode]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None, "traffic_from_committed_profile": committed, "kernel": KERNEL_SYMBOLS.get(algo, str(algo)),
