@@ -652,6 +652,7 @@ struct IirSeqArgs {
     float*       state_out;
     long         tiles_per_wg;
     int          warm_tiles;
+    int          warm_chunks; // warm_tiles == 1: the last this many 32-sample chunks of the warm-up tile are enough (a multiple of 32, <= 256)
 };
 
 template <int ORD, int NSEC>
@@ -679,7 +680,26 @@ __global__ __launch_bounds__(kIirBS, 4) void iir_seq_kernel(IirSeqArgs a, IirCoe
     for (long b = tb; b < t1; ++b) {
         const bool emit = b >= t0; // warm-up tiles only advance the state
         const long base = b * kIirBS * kIirL;
-        iir_stage_tile(tile, a.x, base, a.n);
+        // (round 5) a warm-up tile exists to leave the state at its END, and the filter has forgotten everything older than warm_chunks chunks by then (||Phi_L^wc|| <= 1e-8):
+        // only the tile's last wc chunks are read from HBM and run -- the lanes in front of them keep the zero state (for Butterworth-8 at fc = 0.05 that is 32 chunks of
+        // 256: an eighth of the tile's traffic and of its zero-state instructions; a run of two tiles per workgroup paid 3 reads and 3 zero-state passes for 2 tiles)
+        const int  first = emit ? 0 : kIirBS - a.warm_chunks; // first chunk (lane) of the tile that takes part
+        if (first == 0) iir_stage_tile(tile, a.x, base, a.n);
+        else if (base + (long)kIirBS * kIirL <= a.n && (reinterpret_cast<uintptr_t>(a.x + base) & 15) == 0) { // (first is a multiple of 32 chunks = 4 of the lane's 8 float4 slots... slot q covers chunks 32 q .. 32 q + 31)
+#pragma unroll
+            for (int q = 0; q < kIirL / 4; ++q) {
+                if (32 * q < first) continue; // (uniform)
+                const float4 v = reinterpret_cast<const float4*>(a.x + base)[q * kIirBS + threadIdx.x];
+                const int    s_ = 4 * (q * kIirBS + threadIdx.x);
+                float*       d = tile + (s_ / kIirL) * (kIirL + 1) + (s_ % kIirL);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int s_ = first * kIirL + threadIdx.x; s_ < kIirBS * kIirL; s_ += kIirBS) {
+                const long i = base + s_;
+                tile[(s_ / kIirL) * (kIirL + 1) + (s_ % kIirL)] = i < a.n ? a.x[i] : 0.f;
+            }
+        }
         __syncthreads();
         // ---- 1. zero-state run and in-wave scan
         float st[NSEC][ORD];
@@ -688,12 +708,10 @@ __global__ __launch_bounds__(kIirBS, 4) void iir_seq_kernel(IirSeqArgs a, IirCoe
 #pragma unroll
             for (int j = 0; j < ORD; ++j) st[s][j] = 0.f;
         float* row = tile + c * (kIirL + 1);
-#if defined(GR4_T_IIR_NOZS) // developer timing build (results are wrong): no zero-state run = the bound of moving it to the matrix pipe
-        st[0][0] = row[0];
-#else
+        if (c >= first) {
 #pragma unroll 4
-        for (int i = 0; i < kIirL; ++i) (void)iir_step<ORD, NSEC>(coef, st, row[i]);
-#endif
+            for (int i = 0; i < kIirL; ++i) (void)iir_step<ORD, NSEC>(coef, st, row[i]);
+        }
         float e[MP], ex[MP];
 #pragma unroll
         for (int s = 0; s < NSEC; ++s)
@@ -897,6 +915,7 @@ struct gr4hip_iir {
     DeviceBuffer        d_zc, d_zb, d_tb;
     DeviceBuffer        d_tab;            // one-pass tables: Phi_L^r [16], Phi_L^{16a} [16], Phi_B^l [65]  (M <= 8)
     DeviceBuffer        d_stz;            // one-pass block status words: [nblocks][M] x 2 (+ ticket)
+    int                 warm_chunks = 256; // ... and, when one tile is enough, how many of its last 32-sample chunks are (a multiple of 32)
     int                 warm_tiles = 0;   // segment-sequential kernel: warm-up tiles that make a run's unknown start state irrelevant (0: memory does not fade fast enough)
     unsigned*           h_err = nullptr;  // page-locked, device-visible: a look-back that timed out (never observed) is reported by the next call, loudly
     // more than 8 state values (5 .. 8 biquads, 3 .. 4 sections of order 4): two cascades of <= 8 state values run one behind the other through a scratch
@@ -987,6 +1006,7 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
             a.state_out = static_cast<float*>(f->d_state[f->cur ^ 1].ptr);
             a.tiles_per_wg = per;
             a.warm_tiles   = f->warm_tiles;
+            a.warm_chunks  = f->warm_tiles == 1 ? f->warm_chunks : kIirBS;
             hipLaunchKernelGGL((iir_seq_kernel<ORD, NSEC>), dim3((unsigned)ceil_div(nblocks, per)), dim3(kIirBS), 0, st, a, cf);
             GR4_LAUNCH_CHECK();
             f->cur ^= 1;
@@ -1180,6 +1200,16 @@ static int iir_create_impl(gr4hip_iir_t** out, int form, size_t nsections, const
                 for (int i = 0; i < M; ++i) { double r = 0; for (int j = 0; j < M; ++j) r += std::fabs(Pw[i * M + j]); nrm = std::max(nrm, r); }
                 if (nrm <= 1e-8) { f->warm_tiles = w; break; }
                 Pw = mul(Pw, Pw);
+            }
+            f->warm_chunks = kIirBS;
+            if (f->warm_tiles == 1) { // one tile is enough: are its last 32 / 64 / 128 chunks?
+                std::vector<double> Pc = mul(PL16, PL16); // Phi_L^32
+                for (int wc = 32; wc < kIirBS; wc *= 2) {
+                    double nrm = 0;
+                    for (int i = 0; i < M; ++i) { double r = 0; for (int j = 0; j < M; ++j) r += std::fabs(Pc[i * M + j]); nrm = std::max(nrm, r); }
+                    if (nrm <= 1e-8) { f->warm_chunks = wc; break; }
+                    Pc = mul(Pc, Pc);
+                }
             }
         }
         rc = f->d_tab.ensure(tab.size() * sizeof(float));
