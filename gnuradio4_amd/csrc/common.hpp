@@ -31,6 +31,7 @@ enum DevSwitch {
     kDevEwiseNoDivRcp,        // GR4HIP_EWISE_NO_DIV_RCP: element-wise programs divide by a float constant with the general quotient (the tests compare it with the reciprocal form)
     kDevFirNoF16x2,           // GR4HIP_FIR_NO_F16X2: the three-term bf16 FIR kernels where the default takes the two-term f16 ones (per handle: GR4HIP_FIR_TIME_DOMAIN_BF16X3)
     kDevFirNoDecimF16,        // GR4HIP_FIR_NO_DECIM_F16: the frequency-domain decimate-by-8 kernel where the default takes the f16 band-form one (fir_decim_f16.hip)
+    kDevFftBluesteinGeneric,  // GR4HIP_FFT_BLUESTEIN_GENERIC: the chirp convolution on the run-time radix-8 passes (one frame per workgroup) instead of the compile-time 16 x 16 x R3 plan
     kDevFftFourStep64k,       // GR4HIP_FFT_FOUR_STEP_64K: 65536-point transforms through the three-kernel four-step pipeline instead of the two-kernel 256 x 256 form
     kDevSwitchCount
 };

@@ -349,6 +349,58 @@ __global__ void bluestein_fused_kernel(const float* __restrict__ in, const float
     }
 }
 
+// (round 5) the same chirp convolution on the compile-time 16 x 16 x R3 plan of the power-of-two kernels (fft_small_passes, fft_radix.hpp): 16 points per lane, M / 16 lanes
+// per frame, 512 / (M / 16) frames per workgroup.  The two M-point transforms run register to register -- lane t's outputs of the first, bins t + j M / 16, ARE its inputs of
+// the second -- so the frame only crosses LDS inside the transforms' own exchanges (the generic radix-8 passes above: four exchanges per transform at M = 2048, each through
+// a full round trip).  bm_fft.cpp:44 times N = 1009: 58 -> see profiles/r05_bm_fft.txt.
+template <int LOG2M>
+__global__ __launch_bounds__(512) void bluestein_fast_kernel(const float* __restrict__ in, const float* __restrict__ window, const float2* __restrict__ cconj, const float2* __restrict__ Bf,
+                                                             const float2* __restrict__ tw /*W_M^j*/, FftOutputs out, int N, long n_frames) {
+    constexpr int M = 1 << LOG2M, TF = M / 16, FPB = 512 / TF, NPF = M + M / 32;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int  fl = threadIdx.x / TF, tt = threadIdx.x % TF;
+    const long frame = (long)blockIdx.x * FPB + fl;
+    const bool live  = frame < n_frames;
+    float2*    fb    = lds + (size_t)fl * NPF;
+    const float2 sw2a = tw[(tt & 15) * (M / 256)], sw2b = tw[2 * (tt & 15) * (M / 256)], sw3 = tw[tt & 255], sw3sq = tw[(2 * (tt & 255)) & (M - 1)];
+    float2 v[16], X[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = tt + r * TF;
+        float2    x = make_float2(0.f, 0.f);
+        if (live && i < N) {
+            const long g = frame * (long)N + i;
+            x            = out.real_input ? make_float2(in[g], 0.f) : reinterpret_cast<const float2*>(in)[g];
+            if (window) { const float w = window[i]; x.x *= w; x.y *= w; }
+            x = cmulf(x, cconj[i]);
+        }
+        v[r] = x;
+    }
+    fft_small_passes<LOG2M>(v, fb, tt, sw2a, sw2b, sw3, sw3sq, X, [] { __syncthreads(); });
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float2 p = cmulf(X[j], Bf[tt + j * TF]);
+        v[j]           = make_float2(p.x, -p.y);
+    }
+    fft_small_passes<LOG2M>(v, fb, tt, sw2a, sw2b, sw3, sw3sq, X, [] { __syncthreads(); });
+    if (!live) return;
+    const float sc = 1.f / (float)M;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = tt + j * TF;
+        if (k < N) emit_bin(out, frame, N, k, cmulf(make_float2(X[j].x * sc, -X[j].y * sc), cconj[k]));
+    }
+}
+template <int LOG2M>
+static int bluestein_fast_launch(const float* d_in, const float* win, const float2* cconj, const float2* Bf, const float2* tw, const FftOutputs& o, int N, long n_frames, hipStream_t st) {
+    constexpr int    M = 1 << LOG2M, FPB = 512 / (M / 16);
+    constexpr size_t lds = (size_t)FPB * (M + M / 32) * sizeof(float2);
+    GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bluestein_fast_kernel<LOG2M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(bluestein_fast_kernel<LOG2M>, dim3((unsigned)ceil_div(n_frames, (long)FPB)), dim3(512), lds, st, d_in, win, cconj, Bf, tw, o, N, n_frames);
+    GR4_LAUNCH_CHECK();
+    return GR4HIP_OK;
+}
+
 // fft_common.hpp:71-89 unwrapPhase + :113-120 (deg, shift).  One workgroup per frame; wrap counts are integers, so a
 // parallel prefix sum of the per-bin jump decisions reproduces the sequential loop.
 __global__ void unwrap_kernel(const float* __restrict__ raw, float* __restrict__ out, int nout, int in_deg, int shift) {
@@ -706,6 +758,16 @@ static int fft_run_multi(gr4hip_fft_t* f, const float* d_in, long n_frames, cons
     const float* win    = static_cast<const float*>(f->d_window.ptr);
     const long   batch  = std::max(1L, kFftBatchElems / M);
     const long   in_per = o.real_input ? N : 2 * N; // floats per input frame
+    if (f->kind == 2 && M >= 256 && M <= 4096 && !dev_switch(kDevFftBluesteinPipeline) && !dev_switch(kDevFftBluesteinGeneric)) { // the compile-time 16 x 16 x R3 plan, register to register
+        const auto cc = static_cast<const float2*>(f->d_chirp.ptr), bf = static_cast<const float2*>(f->d_chirpF.ptr), tw = static_cast<const float2*>(f->d_tw.ptr);
+        switch (M) {
+        case 256: return bluestein_fast_launch<8>(d_in, win, cc, bf, tw, o, (int)N, n_frames, st);
+        case 512: return bluestein_fast_launch<9>(d_in, win, cc, bf, tw, o, (int)N, n_frames, st);
+        case 1024: return bluestein_fast_launch<10>(d_in, win, cc, bf, tw, o, (int)N, n_frames, st);
+        case 2048: return bluestein_fast_launch<11>(d_in, win, cc, bf, tw, o, (int)N, n_frames, st);
+        default: return bluestein_fast_launch<12>(d_in, win, cc, bf, tw, o, (int)N, n_frames, st);
+        }
+    }
     if (f->kind == 2 && M <= 8192 && !dev_switch(kDevFftBluesteinPipeline)) { // (developer switch: the five-kernel pipeline, which the tests compare)
         const size_t lds = (size_t)f->plan.fpb * M * sizeof(float2);
         if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bluestein_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

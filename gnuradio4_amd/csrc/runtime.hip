@@ -12,7 +12,7 @@ namespace gr4 {
 static thread_local char g_err[512] = "";
 
 static const char* const kDevNames[kDevSwitchCount] = {"GR4HIP_FIR_NO_BF16X3", "GR4HIP_FIR_NO_DECIM_FD", "GR4HIP_IIR_THREE_PASS", "GR4HIP_IIR_LOOKBACK", "GR4HIP_IIR_NO_SPLIT",
-                                                       "GR4HIP_FFT_BLUESTEIN_PIPELINE", "GR4HIP_FFT_NO_PIPELINE", "GR4HIP_ROTATOR_LEAP", "GR4HIP_ROTATOR_WALK", "GR4HIP_CHAIN16", "GR4HIP_FFT_SMOOTH_RUNTIME", "GR4HIP_EWISE_NO_DIV_RCP", "GR4HIP_FIR_NO_F16X2", "GR4HIP_FIR_NO_DECIM_F16", "GR4HIP_FFT_FOUR_STEP_64K"};
+                                                       "GR4HIP_FFT_BLUESTEIN_PIPELINE", "GR4HIP_FFT_NO_PIPELINE", "GR4HIP_ROTATOR_LEAP", "GR4HIP_ROTATOR_WALK", "GR4HIP_CHAIN16", "GR4HIP_FFT_SMOOTH_RUNTIME", "GR4HIP_EWISE_NO_DIV_RCP", "GR4HIP_FIR_NO_F16X2", "GR4HIP_FIR_NO_DECIM_F16", "GR4HIP_FFT_BLUESTEIN_GENERIC", "GR4HIP_FFT_FOUR_STEP_64K"};
 struct DevTable {
     std::atomic<int> v[kDevSwitchCount];
     DevTable() {

@@ -1162,10 +1162,11 @@ def test_fft_spectrum_frame_pipeline(G, window, devsw):
         assert _rel(got[f].cpu().numpy(), O.dft64(fr)) <= TOL, f
 
 
-@pytest.mark.parametrize("N", [3, 5, 12, 100, 1000, 1009, 3000, 4095])
+@pytest.mark.parametrize("N", [3, 5, 12, 100, 131, 257, 521, 1000, 1009, 2039, 3000, 4095])
 def test_fft_any_size_bluestein(G, N):
-    """sizes that are not a power of two (the reference's Bluestein branch, algorithm/.../fourier/fft.hpp:353-381), <= 4096"""
-    frames = 3
+    """sizes that are not a power of two (the reference's Bluestein branch, algorithm/.../fourier/fft.hpp:353-381), <= 4096.  Round 5: chirp lengths M = 256 .. 4096 run the two
+    M-point transforms on the compile-time 16 x 16 x R3 plan, register to register (bluestein_fast_kernel); the run-time radix-8 form stays behind a developer switch"""
+    frames = 7 if N > 64 else 3  # (not a whole number of workgroups' frames)
     x = O.signal_c32(N, frames * N)
     F = G.FFT(N, "Hann")
     w = O.window(3, N)
@@ -1176,6 +1177,11 @@ def test_fft_any_size_bluestein(G, N):
     out = F.process_bulk(dev(x))
     mag, ph, re, im = O.fft_block_truth(x[:N], 3)
     assert _rel(out["magnitude"][0].cpu().numpy(), mag) <= TOL and _rel(out["re"][0].cpu().numpy(), re) <= TOL
+    if N in (131, 257, 521, 1009, 2039):  # (M = 512 .. 4096: the same spectra from the generic form, from another kernel)
+        G.capi.developer_switch("GR4HIP_FFT_BLUESTEIN_GENERIC", 1)
+        old = G.FFT(N, "Hann").spectrum(dev(x)).cpu().numpy()
+        G.capi.developer_switch("GR4HIP_FFT_BLUESTEIN_GENERIC", 0)
+        assert not np.array_equal(old, got) and _rel(old, got.astype(np.complex128)) <= TOL
 
 
 @pytest.mark.parametrize("N", [6, 12, 15, 45, 100, 243, 360, 1000, 1536, 1920, 3000, 3125, 3750, 4000, 6000, 6561, 7680, 7776, 8000])
