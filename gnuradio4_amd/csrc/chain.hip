@@ -12,7 +12,7 @@ struct ChainFused;
 int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
 int  chain_fused_reset(ChainFused* c);
 int  chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st);
-int  chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps, const float* const* d_in, size_t n_frames, float* const* d_out, float* d_sum, hipStream_t st);
+int  chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps, const float* const* d_in, size_t n_frames, float* const* d_out, float* d_sum, hipStream_t st, bool redo);
 bool chain_fused_multi_capable(const ChainFused* c);
 void chain_fused_destroy(ChainFused* c);
 void chain_fused_set_max_workgroups(ChainFused* c, unsigned n);
@@ -306,7 +306,7 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
             if (rc) return rc;
             GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
-        if (!strict) { // deferred: a finished earlier launch decides for this one
+        { // a finished earlier launch decides for this one, without waiting (strict: the frames THIS launch marks are evaluated again on the device behind it)
             bool bad = false;
             for (size_t i = 0; i < n_chains; ++i) {
                 float r;
@@ -320,23 +320,12 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
             }
         }
     }
-    int rc = chain_fused_process_multi(fs.data(), n_chains, shared, xs.data(), frames, fold ? nullptr : outs.data(), fold ? d_sum : nullptr, st);
+    // (round 5) strict: nobody waits -- the launch writes a verdict byte per frame (the fold: a frame is marked when any channel's share of it fell below the threshold) and
+    // the second evaluation rides the same stream (chain_redo_kernel per chain, chain_redo_fold_kernel for the fold); until round 5 the call awaited its launch's
+    // measurement and redid the whole span chain by chain on the host's say-so
+    int rc = chain_fused_process_multi(fs.data(), n_chains, shared, xs.data(), frames, fold ? nullptr : outs.data(), fold ? d_sum : nullptr, st, strict);
     if (rc) return rc;
-    if (strict) { // await the measurement(s) of this launch; redo the span in the time domain if it fell below the threshold
-        bool bad = false;
-        for (size_t i = 0; i < n_chains; ++i) {
-            gr4hip_chain* c = chains[fold ? 0 : i]; // (the fold measures all channels together, into chain 0's slots: the ratio that matters for the delivered sum)
-            float r;
-            if (chain_fused_power_ratio(c->fused, true, false, &r)) c->last_ratio = r;
-            chains[i]->probed = true;
-            chains[i]->last_ratio = c->last_ratio;
-            bad = bad || (chains[i]->guard && c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio);
-        }
-        if (bad) {
-            if ((rc = prepare_redo())) return rc;
-            return chain_by_chain();
-        }
-    }
+    for (size_t i = 0; i < n_chains; ++i) chains[i]->probed = true;
     if (!fold && d_sum) {
         std::vector<const void*> ins(outs.begin(), outs.end());
         return gr4hip_math_nary(GR4HIP_ADD, GR4HIP_F32, ins.data(), n_chains, d_sum, frames * c0->N, stream);

@@ -97,6 +97,8 @@ struct ChainFdMulti {
     float*        pws[kMaxMulti];
     float*        pw_hosts[kMaxMulti];
     unsigned      pw_seqs[kMaxMulti];
+    unsigned char* fflags[kMaxMulti]; // fold_ch == 1: every channel's own verdict bytes (one per frame; null: not judged).  The fold's are ChainFdArgs::fflags: a frame is
+                                      // marked when ANY channel's share of it fell below the threshold (set-only: the host zeroes the bytes in front of the launch)
 };
 
 // pass-A layout: rows 0..15 at r * kRowA, rows 16..31 shifted by 16 float2 (32 banks).  A ds_read/write_b64 is served in two groups of 32
@@ -291,6 +293,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
         } else { // this workgroup belongs to ONE channel: its pointers take the place of the single-channel arguments
             const int c = (int)(blockIdx.x % (unsigned)mc->n_ch);
             a.x = mc->xs[c]; a.hist = mc->hists[c]; a.H = mc->Hs[c]; a.efrag = mc->efrags[c]; a.out = mc->outs[c]; a.pw = mc->pws[c]; a.pw_host = mc->pw_hosts[c]; a.pw_seq = mc->pw_seqs[c];
+            a.fflags = mc->fflags[c];
             fstart = blockIdx.x / (unsigned)mc->n_ch;
             fstride = gridDim.x / (unsigned)mc->n_ch;
             gslot = (unsigned)fstart; gcount = (unsigned)fstride;
@@ -397,7 +400,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
     [[maybe_unused]] int fiter = 0; // frames this workgroup has finished (MULTI: an item is one channel of a frame)
 #pragma unroll
     for (int q = 0; q < 16; ++q) pend[q] = pendi[q] = 0.f;
-    long fprev = -1;
+    long fprev = -1, fh1 = -1, fh2 = -1;
     long f   = fstart;
     int  cur = 0, ch = 0; // ch: channel of the current work item (MULTI with shared taps: frame f of channels 0 .. C - 1 in turn)
 #if defined(GR4_PRIO_YOUNG)
@@ -438,14 +441,17 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                         const float4 g0 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1)), g1 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1) + 4);
                         const float fsum = ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w)); // the frame two iterations back
                         pw_dmin = fminf(pw_dmin, fsum);
-                        if constexpr (!MULTI) { if (a.fflags != nullptr && threadIdx.x == 0 && iter >= 2) a.fflags[f - 2 * fstride] = fsum < 0.f ? 1 : 0; }
+                        if (a.fflags != nullptr && threadIdx.x == 0 && fh2 >= 0) {
+                            if constexpr (MULTI) { if (fsum < 0.f) a.fflags[fh2] = 1; } // (several work items per frame: set-only)
+                            else a.fflags[fh2] = fsum < 0.f ? 1 : 0;
+                        }
                     }
                 } else { // the windowed kernels fill their 160 KiB to the byte: two words of global scratch per workgroup, L2 atomics
                     pw_dmin = fminf(pw_dmin, pw_pend);
                     if ((threadIdx.x & 63) == 63) atomicAdd(pw_slot + (iter & 1), wt);
                     if (threadIdx.x == 0) {
                         pw_pend = atomicExch(pw_slot + ((iter + 1) & 1), 0.f); // the frame before that: every wave's share arrived before the barrier above
-                        if constexpr (!MULTI) { if (a.fflags != nullptr && iter >= 2) a.fflags[f - 2 * fstride] = pw_pend < 0.f ? 1 : 0; }
+                        if (a.fflags != nullptr && fh2 >= 0) a.fflags[fh2] = pw_pend < 0.f ? 1 : 0; // (the windowed modes are single-channel)
                     }
                 }
             }
@@ -811,6 +817,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                 pw_dprev = fmaf(-a.pw_thr, fr_in, fr_out); // (summed over the wave at the top of the next iteration: the DPP sequence here costs the compiler ten spills)
             }
         }
+        fh2 = fh1; fh1 = f; // (the frames of the last two work items: whose verdict sums thread 0 meets one / two iterations later)
         fprev = f;
         if constexpr (MULTI) { // the fold is complete after the last channel; the other work items store nothing
             if (ch != C - 1) fprev = -1;
@@ -854,11 +861,14 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                     s0 = atomicExch(pw_slot, 0.f); s1 = atomicExch(pw_slot + 1, 0.f); // (the slots are zero again for the next launch)
                     pw_dmin = fminf(fminf(pw_dmin, pw_pend), fminf(s0, s1));
                 }
-                if constexpr (!MULTI) {
-                    if (a.fflags != nullptr) { // (f has moved one stride past the workgroup's last frame)
-                        const float last = (iter & 1) ? s1 : s0, before = (iter & 1) ? s0 : s1;
-                        if (iter >= 1) a.fflags[f - fstride] = last < 0.f ? 1 : 0;
-                        if (iter >= 2) a.fflags[f - 2 * fstride] = before < 0.f ? 1 : 0;
+                if (a.fflags != nullptr) { // the last two work items: fh1 the last, fh2 the one before it
+                    const float last = (iter & 1) ? s1 : s0, before = (iter & 1) ? s0 : s1;
+                    if constexpr (MULTI) {
+                        if (fh1 >= 0 && last < 0.f) a.fflags[fh1] = 1;
+                        if (fh2 >= 0 && before < 0.f) a.fflags[fh2] = 1;
+                    } else {
+                        if (fh1 >= 0) a.fflags[fh1] = last < 0.f ? 1 : 0;
+                        if (fh2 >= 0) a.fflags[fh2] = before < 0.f ? 1 : 0;
                     }
                 }
                 if (pw_dmin < 0.f) atomicOr(reinterpret_cast<unsigned*>(a.pw + 33), 1u);
@@ -909,9 +919,13 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_kernel(ChainFdArgs a) { chain_
 constexpr int kRdHb = 256, kRdKw = 272, kRdL = kN + kRdHb, kRdLp = kRdL + 4 * (kRdL / 16) + 4;
 constexpr size_t kRdLdsBytes = (size_t)kSLen * sizeof(float2) + (size_t)(2 * kRdLp + kRdKw + 16) * sizeof(float);
 static_assert(kRdLdsBytes <= 160 * 1024, "LDS budget of one CU");
-template <int MODE, int LOG2NF = 13>
-__global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int ntaps) {
+// FOLD: several channels of a launch that kept only sum_c |FFT(fir(x_c))|^2 (gr4hip_chain_process_multi with shared taps): a marked frame is evaluated again for EVERY channel
+// (mc->xs / mc->hists), the fold kept in registers as the fused kernel keeps it (math::Add's left fold over the inputs); a non-finite sample in any channel's window leaves the
+// frame as it is.
+template <int MODE, int LOG2NF, bool FOLD>
+__device__ __forceinline__ void chain_redo_body(ChainFdArgs& a, int ntaps, const ChainFdMulti* mc) {
     constexpr bool WIN = MODE != kModeMag2, SMALL = MODE == kModeWinSmall;
+    static_assert(!FOLD || MODE == kModeMag2, "the fold: 8192-point rectangular-window chains only");
     using f64x4_r = __attribute__((ext_vector_type(4))) double;
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2* S  = smem;
@@ -952,18 +966,25 @@ __global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int nt
         sw3sq = a.twS[(2 * (tt & 255)) & (NF - 1)];
     }
     const int comp = wave & 1;
+    const int C = FOLD ? mc->n_ch : 1;
     for (long f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
         if (marked(f) == 0) continue; // (uniform)
+        [[maybe_unused]] float accm[16]; // FOLD: the running sum over the channels, bins t + 512 q
+        [[maybe_unused]] bool  spoilt = false;
+      for (int ch = 0; ch < C; ++ch) {
+        const float2* xc = a.x;
+        const float2* hc = a.hist;
+        if constexpr (FOLD) { xc = mc->xs[ch]; hc = mc->hists[ch]; }
         __syncthreads();              // the previous frame's readers are done with S and the planes
         int nf = 0;
         for (int i = t; i < kRdL; i += kT) {
             const long   sidx = f * kN - kRdHb + i;
-            const float2 v = sidx >= 0 ? (sidx < n_span ? a.x[sidx] : make_float2(0.f, 0.f)) : (sidx >= -(long)hlen ? a.hist[hlen + sidx] : make_float2(0.f, 0.f));
+            const float2 v = sidx >= 0 ? (sidx < n_span ? xc[sidx] : make_float2(0.f, 0.f)) : (sidx >= -(long)hlen ? hc[hlen + sidx] : make_float2(0.f, 0.f));
             nf |= (int)!(__builtin_fabsf(v.x) <= 3.4028234663852886e38f) | (int)!(__builtin_fabsf(v.y) <= 3.4028234663852886e38f);
             sg[ph(i)]         = v.x;
             sg[kRdLp + ph(i)] = v.y;
         }
-        if (__syncthreads_or(nf)) continue;
+        if (__syncthreads_or(nf)) { spoilt = true; break; } // (uniform; single channel: the fused kernel's result stands)
         // ---- y_f on the FP64 matrix pipe: wave = component x (tile rows (wave >> 1) + 4 i); a tile row = 256 consecutive outputs, D[row = kq + 4 r][col] = output 256 tr + 16 col + kq + 4 r
         for (int i = 0; i < 8; ++i) {
             const int    tr = (wave >> 1) + 4 * i;
@@ -1014,11 +1035,30 @@ __global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int nt
             passB_compute_store(S, w, twBr, cb, kb);
             __syncthreads();
             passC(S, X, twCr, t);
+            if constexpr (FOLD) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) out[t + 512 * q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y);
+                for (int q = 0; q < 16; ++q) {
+                    const float m2 = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y);
+                    accm[q] = ch == 0 ? m2 : accm[q] + m2;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) out[t + 512 * q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y);
+            }
+        }
+      } // channels
+        if constexpr (FOLD) {
+            if (!spoilt) {
+                float* out = a.out + f * kN;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) out[t + 512 * q] = accm[q];
+            }
         }
     }
 }
+template <int MODE, int LOG2NF = 13>
+__global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int ntaps) { chain_redo_body<MODE, LOG2NF, false>(a, ntaps, nullptr); }
+__global__ __launch_bounds__(kT, 1) void chain_redo_fold_kernel(ChainFdArgs a, ChainFdMulti m, int ntaps) { chain_redo_body<kModeMag2, 13, true>(a, ntaps, &m); }
 __global__ __launch_bounds__(kT, 2) void chain_fd_multi_kernel(ChainFdArgs a, ChainFdMulti m) { chain_fd_body<kModeMag2, 13, true>(a, &m); }
 
 
@@ -1338,7 +1378,9 @@ int chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, si
 //   d_sum != nullptr (needs shared_taps): only the combiner output sum_i |FFT(fir(x_i))|^2 is written (math::Add's left fold, kept in registers);
 //   otherwise d_out[i] receives chain i's spectra and workgroup b works for chain b mod n.
 // The guard's powers: with the fold, of all channels together into chain 0's slots (the ratio that matters for the delivered sum); otherwise per chain.
-int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps, const float* const* d_in, size_t n_frames, float* const* d_out, float* d_sum, hipStream_t st) {
+int chain_fused_redo(ChainFused* c, const float* d_in, const float* d_hist, int hist_len, size_t n_samples, float* d_out, const unsigned char* d_flags, int flags_per_block, hipStream_t st);
+// redo: the measured chains' frames are marked one by one and evaluated again in the time domain behind the launch (chain_redo_kernel per chain; the fold: chain_redo_fold_kernel)
+int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps, const float* const* d_in, size_t n_frames, float* const* d_out, float* d_sum, hipStream_t st, bool redo) {
     GR4_REQUIRE(n >= 1 && n <= (size_t)kMaxMulti, "chain multi: 1 .. %d chains per launch", kMaxMulti);
     const bool fold = d_sum != nullptr;
     GR4_REQUIRE(!fold || shared_taps, "chain multi: the in-register fold needs identical taps on every chain");
@@ -1372,9 +1414,15 @@ int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps,
             m.pws[i] = static_cast<float*>(c->d_pw.ptr);
             m.pw_hosts[i] = c->d_hpw;
             m.pw_seqs[i] = c->pw_seq;
+            if (redo) { // (set-only in the kernel: zeroed here)
+                rc = c->d_fflags.ensure(n_frames);
+                if (rc) return rc;
+                GR4_HIP_TRY(hipMemsetAsync(c->d_fflags.ptr, 0, n_frames, st));
+                m.fflags[i] = static_cast<unsigned char*>(c->d_fflags.ptr);
+            }
         }
     }
-    if (fold) { a.pw = m.pws[0]; a.pw_host = m.pw_hosts[0]; a.pw_seq = m.pw_seqs[0]; }
+    if (fold) { a.pw = m.pws[0]; a.pw_host = m.pw_hosts[0]; a.pw_seq = m.pw_seqs[0]; a.fflags = m.fflags[0]; }
     a.pw_thr = kGuardFrameThreshold * (float)kN; // (8192-point rectangular-window chains only: window gain 1)
     constexpr size_t lds = (size_t)kLdsEbfBytes + 64; // = lds_ebf of chain_fused_run
     static PerDevice per_device;
@@ -1396,6 +1444,21 @@ int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps,
     }
     hipLaunchKernelGGL(chain_fd_multi_kernel, dim3(grid), dim3(kT), lds, st, a, m);
     GR4_LAUNCH_CHECK();
+    if (redo) { // the marked frames again in the time domain, from the histories the call started with (the carry below is stream-ordered behind these launches)
+        if (fold) {
+            if (a.fflags != nullptr) {
+                if (first) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_redo_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRdLdsBytes));
+                hipLaunchKernelGGL(chain_redo_fold_kernel, dim3((unsigned)std::min<size_t>(n_frames, (size_t)n_cu)), dim3(kT), kRdLdsBytes, st, a, m, (int)c0->ntaps);
+                GR4_LAUNCH_CHECK();
+            }
+        } else {
+            for (size_t i = 0; i < n; ++i)
+                if (m.fflags[i] != nullptr) {
+                    const int rc = chain_fused_redo(cs[i], d_in[i], static_cast<const float*>(cs[i]->d_hist.ptr), 256, n_frames * (size_t)kN, d_out[i], m.fflags[i], 1, st);
+                    if (rc) return rc;
+                }
+        }
+    }
     for (size_t i = 0; i < n; ++i) // carry every chain's last 256 input samples (stream-ordered after the kernel's reads)
         GR4_HIP_TRY(hipMemcpyAsync(cs[i]->d_hist.ptr, m.xs[i] + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
     return GR4HIP_OK;

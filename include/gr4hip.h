@@ -341,7 +341,8 @@ int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time
  *     |.|^2 over the fused result (an ordinary stream costs one near-empty launch, ~5 us).  gr4hip_chain_process returns when both launches are queued ("user code
  *     must not block in work()", docs/USER_API_advanced_work.md).  The measurement of an EARLIER launch, once it has arrived, moves a stream that rejects most of its
  *     input to the direct-form kernels for good (the faster way through such a stream) -- read without waiting.  Several chains in one call
- *     (gr4hip_chain_process_multi) still await their shared launch.
+ *     (gr4hip_chain_process_multi) work the same way: per-channel verdict bytes and one chain_redo_kernel per channel, or -- the fold -- a frame marked when ANY
+ *     channel's share of it fell below the threshold and chain_redo_fold_kernel, which evaluates every channel of a marked frame again and keeps the sum in registers.
  *   GR4HIP_GUARD_DEFERRED: calls stay asynchronous.  The first call after create / reset probes its first 8 blocks synchronously; later calls read the finished
  *     measurements of EARLIER launches, so the call in which a strong out-of-band signal first appears is published from the fused kernel (error floor
  *     ~2e-6 of the input rms) and the switch happens from the next call on.

@@ -2105,26 +2105,31 @@ def test_chain_process_multi_one_launch(G):
 
 
 def test_chain_process_multi_guard(G):
-    """the dynamic-range guard inside the multi launch: an interferer on ONE channel (own-taps mode: per-channel measurement; fold mode: the summed powers,
-    dominated by the loud channel) sends the call's span through the time-domain kernels before it returns (GUARD_STRICT)"""
+    """the dynamic-range guard inside the multi launch: an interferer on ONE channel (own-taps mode: per-channel verdicts; fold mode: a frame is marked when any channel's
+    share of it fell below the threshold).  GUARD_STRICT since round 5: the marked frames are evaluated again on the device behind the launch (chain_redo_kernel per
+    channel, chain_redo_fold_kernel for the fold: every channel of a marked frame again, the sum kept in registers) -- the call does not wait; the NEXT call finds the
+    measurement and moves the guarded chains to the time-domain kernels"""
     from gnuradio4_amd.blocks import chain_process_multi
     N, ntaps, nch = 8192, 64, 3
     b = O.design_taps_hamming_lowpass(ntaps, 0.02)
     clean = [O.signal_c32(5 + c, 24 * N, tone_frel=0.01, tone_amp=1.0) for c in range(nch)]
     loud = O.signal_c32(16, 24 * N, tone_frel=0.31, tone_amp=30.0)
     second = [clean[0], loud, clean[2]]
-    truths = [O.chain(b, np.concatenate([clean[c], second[c]]), N, 0, truth=True)[0].reshape(2, -1) for c in range(nch)]
+    truths = [O.chain(b, np.concatenate([clean[c], second[c], second[c]]), N, 0, truth=True)[0].reshape(3, -1) for c in range(nch)]
     for fold in (False, True):
         chains = [G.Chain(b, N, "None") for _ in range(nch)]
         o1, s1 = chain_process_multi(chains, [dev(x) for x in clean], want_outs=not fold, sum_out=torch.empty((24, N), dtype=torch.float32, device="cuda"))
         assert not any(c.last_power_ratio()[1] for c in chains)
         o2, s2 = chain_process_multi(chains, [dev(x) for x in second], want_outs=not fold, sum_out=torch.empty((24, N), dtype=torch.float32, device="cuda"))
-        assert chains[1].last_power_ratio()[1], fold
         assert _rel(s1.cpu().numpy().ravel(), sum(t[0] for t in truths)) <= TOL
-        assert _rel(s2.cpu().numpy().ravel(), sum(t[1] for t in truths)) <= TOL, fold
+        assert _rel(s2.cpu().numpy().ravel(), sum(t[1] for t in truths)) <= TOL, fold  # (the marked frames were evaluated again behind the launch)
         if not fold:
             for c in range(nch):
                 assert _rel(o2[c].cpu().numpy().ravel(), truths[c][1]) <= TOL, c
+        assert not chains[1].last_power_ratio()[1], fold                                  # (nothing has moved yet: nobody waited for the measurement)
+        o3, s3 = chain_process_multi(chains, [dev(x) for x in second], want_outs=not fold, sum_out=torch.empty((24, N), dtype=torch.float32, device="cuda"))
+        assert chains[1].last_power_ratio()[1], fold                                      # the third call found it: the guarded chains run in the time domain from here on
+        assert _rel(s3.cpu().numpy().ravel(), sum(t[2] for t in truths)) <= TOL, fold
 
 
 def test_chain_process_multi_mixed_guard_modes(G):
@@ -2137,21 +2142,24 @@ def test_chain_process_multi_mixed_guard_modes(G):
     clean = [O.signal_c32(25 + c, 24 * N, tone_frel=0.01, tone_amp=1.0) for c in range(nch)]
     loud = O.signal_c32(36, 24 * N, tone_frel=0.31, tone_amp=30.0)
     second = [clean[0], loud, clean[2]]
-    truths = [O.chain(b, np.concatenate([clean[c], second[c]]), N, 0, truth=True)[0].reshape(2, -1) for c in range(nch)]
+    truths = [O.chain(b, np.concatenate([clean[c], second[c], second[c]]), N, 0, truth=True)[0].reshape(3, -1) for c in range(nch)]
     for fold in (False, True):
         chains = [G.Chain(b, N, "None") for _ in range(nch)]
         chains[0].set_guard_mode(G.capi.GUARD_OFF)
         chains[2].set_guard_mode(G.capi.GUARD_DEFERRED)
         o1, s1 = chain_process_multi(chains, [dev(x) for x in clean], want_outs=not fold, sum_out=torch.empty((24, N), dtype=torch.float32, device="cuda"))
         o2, s2 = chain_process_multi(chains, [dev(x) for x in second], want_outs=not fold, sum_out=torch.empty((24, N), dtype=torch.float32, device="cuda"))
-        assert chains[1].last_power_ratio()[1], fold          # the strict chain saw its interferer in this very call ...
+        assert _rel(s1.cpu().numpy().ravel(), sum(t[0] for t in truths)) <= TOL
+        assert _rel(s2.cpu().numpy().ravel(), sum(t[1] for t in truths)) <= TOL, fold  # the strict chain's marked frames were evaluated again behind the launch ...
+        assert not chains[1].last_power_ratio()[1], fold      # ... nobody waited, nothing has moved yet
+        o3, s3 = chain_process_multi(chains, [dev(x) for x in second], want_outs=not fold, sum_out=torch.empty((24, N), dtype=torch.float32, device="cuda"))
+        assert chains[1].last_power_ratio()[1], fold          # the next call found the measurement: the strict chain runs in the time domain ...
         assert not chains[0].last_power_ratio()[1], fold      # ... and the unguarded chain stays on the fused kernel
         assert chains[0].algo == G.capi.CHAIN_FUSED_FD
-        assert _rel(s1.cpu().numpy().ravel(), sum(t[0] for t in truths)) <= TOL
-        assert _rel(s2.cpu().numpy().ravel(), sum(t[1] for t in truths)) <= TOL, fold
-        # the unguarded chain's history survived the redo: a third call continues its stream
+        assert _rel(s3.cpu().numpy().ravel(), sum(t[2] for t in truths)) <= TOL, fold
+        # the unguarded chain's history survived the move: a further call continues its stream
         third = O.signal_c32(47, 8 * N, tone_frel=0.01)
-        t3 = O.chain(b, np.concatenate([clean[0], second[0], third]), N, 0, truth=True)[0].reshape(-1, N)[48:]
+        t3 = O.chain(b, np.concatenate([clean[0], second[0], second[0], third]), N, 0, truth=True)[0].reshape(-1, N)[72:]
         got = chains[0].process_bulk(dev(third)).cpu().numpy()
         assert _rel(got.ravel(), t3.ravel()) <= TOL, fold
 
