@@ -5,7 +5,9 @@ import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
 from scipy.signal import lfilter, sosfilt, butter, cheby1, upfirdn
+sys.path.insert(0, "tests")
 import gnuradio4_amd as G
+import oracle_lib as O
 from gnuradio4_amd import capi
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -26,10 +28,12 @@ while time.time() - t0 < secs:
         x = rng.standard_normal(n).astype(np.float32)
         f = G.iir_filter(sos[:, :3], sos[:, 3:])
         y = np.concatenate([f.process_bulk(torch.from_numpy(x[a:b]).cuda()).cpu().numpy() for a, b in cuts_of(n, 1)])
-        truth = sosfilt(sos, x.astype(np.float64))
-        y32 = x.copy()  # the same cascade section by section in float32 on the CPU (direct form II transposed): what float32 state rounding alone leaves
-        for sec in sos.astype(np.float32): y32 = lfilter(sec[:3], sec[3:], y32).astype(np.float32)
-        r = rel(y, truth); r32 = rel(y32, truth); tag = f"iir order={order} fc={fc:.3f} n={n} (float32 cpu {r32:.1e})"; bar = 2e-5 + 10 * r32
+        # truth: the SAME float32 coefficients the block holds, float64 arithmetic (the oracle's cascade); the contract's bound: the reference's own float32 cascade -- its
+        # default form section by section (oracle: gr4o_iir_cascade_f32) -- factor ONE
+        secs_ = O.make_sections([(bb, aa) for bb, aa in zip(sos[:, :3].astype(np.float32), sos[:, 3:].astype(np.float32))])
+        truth = O.iir_cascade(secs_, x, 3, f64=True)
+        r = rel(y, truth); r32 = min(rel(O.iir_cascade(secs_, x, form, f64=False), truth) for form in (O.DF_I, O.DF_II))
+        tag = f"iir order={order} fc={fc:.3f} n={n} (reference float32 cascade {r32:.1e})"; bar = max(1e-5, r32)
     elif kind == 1:  # decimating FIR
         D = int(rng.integers(2, 17)); nt = int(rng.choice([16, 64, 100, 256, 320, 500, 1024]))
         taps = (rng.standard_normal(nt) * np.hamming(nt) / np.sqrt(nt)).astype(np.float32)
