@@ -24,8 +24,8 @@
 // output at a time (0 x Inf in the zero part of the tap operand would spread the NaN to outputs whose window does not hold the sample; the classes +Inf / -Inf / NaN and their
 // reach -- exactly ntaps outputs -- are the reference's).
 //
-// Rate when EVERY segment is marked: the FP64 matrix pipe's 78.6 TFLOP/s = 16 multiply-adds per cycle and SIMD: 256 taps -> ~120 Gsamples/s (float), ~60 (complex); a
-// decimator by 8 with 1024 taps ~230 G input samples/s.  That is the price of a stream that is all rejection; ordinary streams never come here.
+// Rate when EVERY segment is marked (measured, profiles/r05_rejected_stream_rates.txt; main kernel + this one): float 256 taps 264 Gsamples/s (518 unmarked), complex 143
+// (178), decimate by 8 with 1024 taps 417 G input samples/s (749).  That is the price of a stream that is all rejection; ordinary streams never come here.
 #include "common.hpp"
 #include "ewise.hpp"
 #include "fir_exact.hpp"
