@@ -990,14 +990,18 @@ __device__ __forceinline__ void chain_redo_body(ChainFdArgs& a, int ntaps, const
             const int    tr = (wave >> 1) + 4 * i;
             const float* sb = sg + comp * kRdLp + (256 * tr + 16 * col) + 4 * (16 * tr + col) + kq;
             const float* ta = tz + 15 + kRdHb + col - kq;
-            f64x4_r      acc = {0., 0., 0., 0.};
+            f64x4_r      acc = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.}; // (two accumulators over alternating K-steps: one dependent chain per wave leaves the pipe idle for its latency)
             for (int k0 = 0, pad = 0; k0 < kRdKw / 4; k0 += 4, pad += 4) { // a pad of 4 floats every 16 samples = every 4 K-steps of 4
                 float av[4], bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { av[q] = ta[-4 * (k0 + q)]; bv[q] = sb[4 * (k0 + q) + pad]; }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[q], (double)bv[q], acc, 0, 0, 0);
+                acc  = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[0], (double)bv[0], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[1], (double)bv[1], acc1, 0, 0, 0);
+                acc  = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[2], (double)bv[2], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[3], (double)bv[3], acc1, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = 256 * tr + 16 * col + kq + 4 * r;

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void fir_exact_kernel(FirExactArgs a) {
         // this wave's tile row: B[u][c] = staged[D (256 tr + 16 c) + u], A[j][u] = tz[15 D + Hb + D j - u]
         const float* sb = sg + comp * Lp + D * (256 * tr + 16 * col) + 4 * (16 * tr + col) + kq;
         const float* ta = tz + 15 * D + Hb + D * col - kq;
-        f64x4_e      acc = {0., 0., 0., 0.};
+        f64x4_e      acc = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.}; // two accumulators over alternating K-steps: a single chain of dependent MFMAs leaves the pipe idle for its latency
         const int    nk = Kw / 4, blk = 4 * D; // K-steps of 4; a pad of 4 floats every 16 D samples = every 4 D steps
         for (int k0 = 0, pad = 0; k0 < nk; k0 += blk, pad += 4) {
             const int kend = k0 + blk < nk ? k0 + blk : nk;
@@ -158,10 +158,14 @@ __global__ __launch_bounds__(256, 1) void fir_exact_kernel(FirExactArgs a) {
                 float av[4], bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { av[q] = ta[-4 * (k4 + q)]; bv[q] = sb[4 * (k4 + q) + pad]; }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[q], (double)bv[q], acc, 0, 0, 0);
+                acc  = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[0], (double)bv[0], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[1], (double)bv[1], acc1, 0, 0, 0);
+                acc  = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[2], (double)bv[2], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[3], (double)bv[3], acc1, 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
         // D[row = kq + 4 r][col]: output ou + 256 tr + 16 col + kq + 4 r
         float other[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (HOOK) {
