@@ -46,6 +46,8 @@ SIGNATURES = {
     "gr4hip_free": (_i, [_vp]),
     "gr4hip_malloc_host": (_i, [_pvp, _sz]),
     "gr4hip_free_host": (_i, [_vp]),
+    "gr4hip_host_ring_create": (_i, [_pvp, _sz]),
+    "gr4hip_host_ring_destroy": (_i, [_vp, _sz]),
     "gr4hip_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
     "gr4hip_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "gr4hip_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),

@@ -1,6 +1,10 @@
 // runtime.hip -- error state, device/memory/stream/event helpers and the VMM double-mapped ring of libgr4hip.
 #include "common.hpp"
 
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <cstdlib>
 
@@ -145,6 +149,29 @@ int gr4hip_malloc(void** d_ptr, size_t bytes) { GR4_REQUIRE(d_ptr, "d_ptr is nul
 int gr4hip_free(void* d_ptr) { if (d_ptr) GR4_HIP_TRY(hipFree(d_ptr)); return GR4HIP_OK; }
 int gr4hip_malloc_host(void** h_ptr, size_t bytes) { GR4_REQUIRE(h_ptr, "h_ptr is null"); GR4_HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault)); return GR4HIP_OK; }
 int gr4hip_free_host(void* h_ptr) { if (h_ptr) GR4_HIP_TRY(hipHostFree(h_ptr)); return GR4HIP_OK; }
+int gr4hip_host_ring_create(void** base_out, size_t bytes) {
+    GR4_REQUIRE(base_out, "host_ring_create: null output");
+    const long page = sysconf(_SC_PAGESIZE);
+    GR4_REQUIRE(bytes > 0 && page > 0 && bytes % (size_t)page == 0, "host_ring_create: %zu bytes is not a multiple of the page size", bytes);
+    const int fd = (int)syscall(SYS_memfd_create, "gr4hip_host_ring", 1u /*MFD_CLOEXEC*/);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { if (fd >= 0) close(fd); set_error("host_ring_create: memfd of %zu bytes failed", bytes); return GR4HIP_RUNTIME_ERROR; }
+    char* base = static_cast<char*>(mmap(nullptr, 2 * bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0)); // the address range, then the same pages into both halves
+    bool  ok   = base != MAP_FAILED;
+    ok = ok && mmap(base, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, 0) != MAP_FAILED;
+    ok = ok && mmap(base + bytes, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, 0) != MAP_FAILED;
+    close(fd);
+    if (!ok) { if (base != MAP_FAILED) munmap(base, 2 * bytes); set_error("host_ring_create: double mapping of %zu bytes failed", bytes); return GR4HIP_RUNTIME_ERROR; }
+    const hipError_t e = hipHostRegister(base, 2 * bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); munmap(base, 2 * bytes); set_error("host_ring_create: hipHostRegister failed: %s", hipGetErrorString(e)); return GR4HIP_RUNTIME_ERROR; }
+    *base_out = base;
+    return GR4HIP_OK;
+}
+int gr4hip_host_ring_destroy(void* base, size_t bytes) {
+    if (!base) return GR4HIP_OK;
+    (void)hipHostUnregister(base);
+    munmap(base, 2 * bytes);
+    return GR4HIP_OK;
+}
 int gr4hip_memcpy_h2d(void* d, const void* h, size_t bytes, gr4hip_stream_t s) { if (bytes) GR4_HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, as_stream(s))); return GR4HIP_OK; }
 int gr4hip_memcpy_d2h(void* h, const void* d, size_t bytes, gr4hip_stream_t s) { if (bytes) GR4_HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, as_stream(s))); return GR4HIP_OK; }
 int gr4hip_memcpy_d2d(void* dd, const void* ds, size_t bytes, gr4hip_stream_t s) { if (bytes) GR4_HIP_TRY(hipMemcpyAsync(dd, ds, bytes, hipMemcpyDeviceToDevice, as_stream(s))); return GR4HIP_OK; }

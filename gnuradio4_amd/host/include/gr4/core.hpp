@@ -482,13 +482,45 @@ struct EdgeBufferBase {
     [[nodiscard]] virtual std::size_t capacity_items() const noexcept { return 0; }
     virtual void                      write_items(const void* src, std::size_t n) = 0; // copy + publish
 };
+// A memory resource that can also hand out RINGS: `bytes` of storage mapped twice back to back (base[i] and base[i + bytes] are the same byte) -- the reference's
+// double-mapped CircularBuffer (CircularBuffer.hpp:75-172) as an allocation mode.  The "hip" provider's page-locked resource is one (hip.hpp): an edge made of such a
+// ring never moves samples to its front, and the copy engines read spans that wrap its end in place.
+struct RingResource {
+    virtual ~RingResource() = default;
+    [[nodiscard]] virtual void* ring_allocate(std::size_t bytes) = 0; // nullptr: no ring of this size (the caller takes ordinary storage)
+    virtual void                ring_deallocate(void* base, std::size_t bytes) = 0;
+};
 template <typename T>
 struct EdgeBuffer final : EdgeBufferBase {
     std::pmr::vector<T> data; // storage from the edge's memory resource (Graph.hpp:738-775): default heap, or e.g. the "hip" provider's pinned pages
+    // ring mode (round 5): the resource is a RingResource and capacity * sizeof(T) is a whole number of pages -- `capacity` items mapped twice; head / tail count on for ever,
+    // item i lives at ring[i % capacity] and every span of up to `capacity` items is contiguous.  Linear mode (everything else): 2 x capacity items, compacted when drained.
+    T*                         ring = nullptr;
+    std::pmr::memory_resource* mr_  = nullptr;
     std::size_t         head = 0, tail = 0, capacity;
     std::size_t         lent = 0, reserved = 0; // items handed out for in-place reading (from head) / writing (from tail) that are still in flight
-    explicit EdgeBuffer(std::size_t cap = 65536, std::pmr::memory_resource* mr = std::pmr::get_default_resource()) : data(2 * cap, mr), capacity(cap) {} // default edge size: Graph.hpp:102
-    [[nodiscard]] std::pmr::memory_resource* resource() const { return data.get_allocator().resource(); }
+    explicit EdgeBuffer(std::size_t cap = 65536, std::pmr::memory_resource* mr = std::pmr::get_default_resource()) : data(mr), mr_(mr), capacity(cap) { allocate(cap); } // default edge size: Graph.hpp:102
+    EdgeBuffer(const EdgeBuffer&)            = delete;
+    EdgeBuffer& operator=(const EdgeBuffer&) = delete;
+    ~EdgeBuffer() override { release_ring(); }
+    void release_ring() {
+        if (ring) dynamic_cast<RingResource*>(mr_)->ring_deallocate(ring, capacity * sizeof(T));
+        ring = nullptr;
+    }
+    void allocate(std::size_t cap) {
+        release_ring();
+        capacity = cap;
+        if constexpr (std::is_trivially_copyable_v<T>) {
+            if (auto* rr = dynamic_cast<RingResource*>(mr_)) ring = static_cast<T*>(rr->ring_allocate(cap * sizeof(T)));
+        }
+        if (ring) { data.clear(); data.shrink_to_fit(); std::memset(static_cast<void*>(ring), 0, cap * sizeof(T)); }
+        else data.assign(2 * cap, T{});
+    }
+    [[nodiscard]] bool        is_ring() const noexcept { return ring != nullptr; }
+    [[nodiscard]] T*          base() noexcept { return ring ? ring : data.data(); }
+    [[nodiscard]] const T*    base() const noexcept { return ring ? ring : data.data(); }
+    [[nodiscard]] std::size_t at(std::size_t pos) const noexcept { return ring ? pos % capacity : pos; } // storage index of stream position `pos`
+    [[nodiscard]] std::pmr::memory_resource* resource() const { return mr_; }
     std::vector<std::shared_ptr<EdgeBuffer<T>>> mirrors; // see EdgeBufferBase::upstream
     std::shared_ptr<EdgeBuffer<T>> add_mirror(std::size_t cap, std::pmr::memory_resource* mr) {
         auto m      = std::make_shared<EdgeBuffer<T>>(cap, mr);
@@ -500,17 +532,18 @@ struct EdgeBuffer final : EdgeBufferBase {
     [[nodiscard]] std::size_t available() const noexcept { return tail - head; }
     [[nodiscard]] std::size_t free_space() const noexcept {
         std::size_t f = capacity - std::min(capacity, available() + reserved);
-        if (lent || reserved) f = std::min(f, data.size() - tail - reserved); // the storage stays where it is while a neighbour reads or writes it in place
+        if (!ring && (lent || reserved)) f = std::min(f, data.size() - tail - reserved); // the storage stays where it is while a neighbour reads or writes it in place (a ring never moves)
         for (const auto& m : mirrors) f = std::min(f, m->free_space());
         return f;
     }
-    std::span<const T>        read_span(std::size_t n) const { return {data.data() + head, n}; }
-    void compact() { // move the unread part to the front (amortised O(1) per sample)
+    std::span<const T>        read_span(std::size_t n) const { return {base() + at(head), n}; }
+    void compact() { // (linear mode) move the unread part to the front (amortised O(1) per sample)
         std::move(data.begin() + static_cast<std::ptrdiff_t>(head), data.begin() + static_cast<std::ptrdiff_t>(tail), data.begin());
         tail -= head;
         head = 0;
     }
     std::span<T>              write_span(std::size_t n) {
+        if (ring) return {ring + at(tail + reserved), n}; // (n <= free_space() <= capacity: contiguous through the second mapping)
         if (tail + reserved + n > data.size()) {
             if (lent || reserved) throw std::logic_error("EdgeBuffer::write_span: beyond free_space() while spans are lent or reserved");
             compact();
@@ -520,7 +553,7 @@ struct EdgeBuffer final : EdgeBufferBase {
     void publish(std::size_t n) noexcept {
         for (auto& m : mirrors) { // the tee: every further reader gets its copy
             auto dst = m->write_span(n);
-            std::copy_n(data.data() + tail, n, dst.data());
+            std::copy_n(base() + at(tail), n, dst.data());
             m->publish(n);
         }
         tail += n;
@@ -529,7 +562,7 @@ struct EdgeBuffer final : EdgeBufferBase {
     void consume(std::size_t n) noexcept {
         head += n;
         advanceRead(n);
-        if (head == tail && !lent && !reserved) head = tail = 0; // drained: the next span starts at the front again, nothing to move
+        if (!ring && head == tail && !lent && !reserved) head = tail = 0; // (linear mode) drained: the next span starts at the front again, nothing to move
     }
     [[nodiscard]] std::size_t elem_bytes() const noexcept override { return sizeof(T); }
     [[nodiscard]] std::size_t available_items() const noexcept override { return available() - lent; }
@@ -541,7 +574,7 @@ struct EdgeBuffer final : EdgeBufferBase {
     }
     [[nodiscard]] const void* lend_items(std::size_t n) override {
         if (lent + n > available()) return nullptr;
-        const T* p = data.data() + head + lent;
+        const T* p = base() + at(head + lent);
         lent += n;
         return p;
     }
@@ -566,8 +599,7 @@ struct EdgeBuffer final : EdgeBufferBase {
     bool ensure_capacity(std::size_t n) override {
         if (n <= capacity) return true;
         if (available() || lent || reserved || !mirrors.empty() || upstream) return false;
-        data.assign(2 * n, T{});
-        capacity = n;
+        allocate(n);
         head = tail = 0;
         return true;
     }

@@ -167,7 +167,17 @@ struct DevBuf {
 // Edge storage for EdgeParameters{.domain = "gpu:hip[:i]"} on CPU-domain ports: page-locked host memory.  The samples stay addressable by the
 // host blocks on both ends of the edge, and the copy engines read them in place -- gr::hip::H2D skips its staging copy for such an edge.
 // (Edges between GPU-domain ports do not go through a memory_resource at all: DeviceEdgeBuffer below owns a VMM double mapping in HBM.)
-class PinnedResource final : public std::pmr::memory_resource {
+class PinnedResource final : public std::pmr::memory_resource, public RingResource {
+public:
+    // (round 5) edges of this provider are page-locked RINGS where their size allows (gr4hip_host_ring_create: memfd + two mappings + hipHostRegister): a span that wraps
+    // the end is contiguous, the copy engine takes it in place, nothing is ever moved to the front of the edge
+    [[nodiscard]] void* ring_allocate(std::size_t bytes) override {
+        void* p = nullptr;
+        return (bytes % 4096 == 0 && gr4hip_host_ring_create(&p, bytes) == GR4HIP_OK) ? p : nullptr;
+    }
+    void ring_deallocate(void* base, std::size_t bytes) override { gr4hip_host_ring_destroy(base, bytes); }
+
+private:
     void* do_allocate(std::size_t bytes, std::size_t align) override {
         void* p = nullptr;
         if (align > 4096 || gr4hip_malloc_host(&p, std::max<std::size_t>(bytes, 1)) != GR4HIP_OK) throw std::bad_alloc();

@@ -25,7 +25,7 @@ struct DmaSource : Block<DmaSource<T>> {
     std::size_t _produced = 0;
     GR_MAKE_REFLECTABLE(DmaSource, out, n_samples_max);
     void fill() { // once, before the clock starts
-        for (std::size_t i = 0; i < out.buffer->data.size(); ++i) out.buffer->data[i] = {static_cast<float>(i % 17) - 8.f, static_cast<float>(i % 5)};
+        for (std::size_t i = 0, nfill = out.buffer->is_ring() ? out.buffer->capacity : out.buffer->data.size(); i < nfill; ++i) out.buffer->base()[i] = {static_cast<float>(i % 17) - 8.f, static_cast<float>(i % 5)};
     }
     work::Result customWork(std::size_t requested) {
         if (_produced >= n_samples_max) return {requested, 0, work::Status::DONE};

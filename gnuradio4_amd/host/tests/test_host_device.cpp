@@ -271,6 +271,32 @@ int main(int argc, char** argv) {
         dump(out + "_gpu_tee_spec.bin", s1._samples);
     }
 
+    { // 3e. the page-locked host edge as a RING (round 5; north star: "pinned hipMemcpyAsync into a GPU-resident double-mapped CircularBuffer"): a CPU-domain edge of the
+      //     "hip" provider at the reference's default 65536 items is `capacity` items mapped twice (gr4hip_host_ring_create); 20 x its capacity streams through
+      //     src -> [ring edge] -> H2D -> [HBM ring] -> D2H -> [ring edge] -> sink: both host edges wrap many times, nothing is moved to their front, every sample arrives
+        hip::register_provider();
+        Graph g;
+        std::vector<float> ramp(20 * 65536 + 123);
+        for (std::size_t i = 0; i < ramp.size(); ++i) ramp[i] = static_cast<float>(static_cast<std::int32_t>((i * 2654435761u) >> 8) % 100003);
+        auto& src  = g.emplaceBlock<testing::VectorSource<float>>();
+        src.values = ramp;
+        auto& h2d  = g.emplaceBlock<hip::H2D<float>>();
+        auto& d2h  = g.emplaceBlock<hip::D2H<float>>();
+        auto& sink = g.emplaceBlock<testing::VectorSink<float>>();
+        bool  wired = g.connect<"out", "in">(src, h2d, EdgeParameters{.domain = "gpu:hip:0"}).has_value() && g.connect<"out", "in">(h2d, d2h).has_value() &&
+                     g.connect<"out", "in">(d2h, sink, EdgeParameters{.domain = "gpu:hip:0"}).has_value();
+        if (!wired) ++errors;
+        const bool rings = wired && h2d.in.buffer->is_ring() && d2h.out.buffer->is_ring() && h2d.in.buffer->capacity == 65536 &&
+                           h2d.in.buffer->base()[5] == h2d.in.buffer->base()[5 + 65536]; // (the second mapping IS the first)
+        scheduler::Simple sched;
+        sched.exchange(std::move(g));
+        if (const auto r = sched.runAndWait(); !r) { std::cerr << "host ring edge: " << r.error().message << "\n"; ++errors; }
+        const bool same = sink._samples == ramp;
+        std::printf("host ring edge: %s, %zu samples through 65536-item edges (%zu wraps), %s, %zu bytes staged by H2D\n", rings ? "page-locked double-mapped rings" : "NOT rings", ramp.size(),
+                    ramp.size() / 65536, same ? "every sample arrived" : "DATA MISMATCH", h2d._staged_bytes);
+        if (!rings || !same || h2d._staged_bytes != 0) ++errors;
+    }
+
     { // 4. the GPU-resident BufferLike ring: spans that wrap the physical end stay contiguous; two readers, back-pressure
         hip::CircularBuffer<float> ring(1 << 16);
         auto                       w = ring.new_writer();

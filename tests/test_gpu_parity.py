@@ -61,6 +61,31 @@ def devsw(G):
 
 
 # ------------------------------------------------------------------ plumbing
+def test_host_ring_is_double_mapped_and_page_locked(G):
+    """gr4hip_host_ring_create: `bytes` of page-locked host storage mapped twice back to back (the reference's double-mapped CircularBuffer, CircularBuffer.hpp:75-172, on the
+    host side of the link): base[i] and base[i + bytes] are the same byte, a span across the physical end is one contiguous source for the copy engine"""
+    import ctypes as C
+    L = G.capi.lib()
+    nbytes = 1 << 20
+    base = C.c_void_p()
+    G.capi.check(L.gr4hip_host_ring_create(C.byref(base), nbytes), "host_ring_create")
+    try:
+        a = np.ctypeslib.as_array((C.c_uint32 * (2 * nbytes // 4)).from_address(base.value))
+        a[: nbytes // 4] = (np.arange(nbytes // 4, dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+        assert np.array_equal(a[: nbytes // 4], a[nbytes // 4:])          # the second mapping IS the first
+        a[nbytes // 4 + 7] = 42
+        assert a[7] == 42
+        d = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda")
+        start = nbytes // 4 - 1000                                         # a span that wraps the physical end, read in place by the copy engine
+        G.capi.check(L.gr4hip_memcpy_h2d(d.data_ptr(), base.value + 4 * start, nbytes, None), "h2d")
+        G.capi.check(L.gr4hip_stream_synchronize(None), "sync")
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), a[start:start + nbytes // 4])
+        with pytest.raises(G.capi.Gr4HipError):
+            G.capi.check(L.gr4hip_host_ring_create(C.byref(C.c_void_p()), 1000), "not a whole number of pages")
+    finally:
+        G.capi.check(L.gr4hip_host_ring_destroy(base, nbytes), "host_ring_destroy")
+
+
 def test_caller_supplied_output_tensors_are_checked(G):
     """an undersized, host-side, strided or wrongly typed `out` handed to a kernel is an out-of-bounds device write -- every entry point of the host layer
     that takes one refuses it (INVALID_ARGUMENT) before anything is launched"""

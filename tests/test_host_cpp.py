@@ -207,6 +207,8 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     xin = np.resize(np.array([1.0, -2.0, 3.0, 0.5, 0.25], np.float64), 200000) * 2.0
     want = (np.convolve(xin, [0.5, 0.25, 0.25])[:200000] + 1.0) * 3.0
     assert len(pf) == 200000 and np.max(np.abs(pf - want)) <= 1e-5
+    # the page-locked host edge is a double-mapped RING (CircularBuffer.hpp:75-172 on the host side of the link): 20 x its capacity through it, nothing moved, nothing staged
+    assert "host ring edge: page-locked double-mapped rings" in r.stdout and "every sample arrived, 0 bytes staged" in r.stdout
     # a tee on a GPU-domain edge: two read cursors on ONE ring in HBM (CircularBuffer.hpp:880-946: one writer -> N readers), no copy; both streams match the oracle
     assert "gpu-domain tee: 2 readers on one ring in HBM" in r.stdout
     gt = np.fromfile(tmp_path / "o_gpu_tee_fir.bin", np.complex64)
