@@ -1975,27 +1975,72 @@ struct Shard {
     gr4hip_fanin_t* comm = nullptr;      // null with n_ranks == 1: no collective at all; non-null: the collective runs even on one rank
     bool            scatter = false;     // true: every rank publishes only its 1 / n_ranks of each exchange's frames (reduce_scatter) instead of the whole sum
     std::size_t     frames_per_exchange = 0; // 0: as many frames as the branches' input edges hold (plan_sharded's run_edge_items / fftSize): an exchange then drains the edges,
-                                             // which never have to move unread samples to make room (64-frame exchanges on 4 Mi-sample edges: 2.5 instead of 6.4 Gsamples/s host-fed)
+                                             // which never have to move unread samples to make room (host-fed, 4 Mi-sample edges: 6.0 Gsamples/s drained per exchange; 64-frame exchanges 5.7 with the two-slab pipeline, 2.5 before it)
 };
 
 class FanInRun final : public BlockModel {
     struct Branch {
         std::shared_ptr<EdgeBufferBase> in;
         gr4hip_chain_t*                 chain = nullptr;
-        DevBuf                          d_in{false}, h_in{true};
-        std::size_t                     n_lent = 0; // items of the input edge the copy engine is reading in place
     };
-    std::deque<Branch>              _branches; // (a Branch owns device buffers: it never moves)
+    // One exchange in flight (round 5: TWO of them, the pipeline bench.py has had since round 3).  Its samples are copied on the copy stream, the ONE launch of all
+    // local channels runs on the compute stream behind that copy, the collective and the copy of the sum run on the exchange stream behind the launch: the exchange of
+    // launch c runs beside launch c + 1 (and beside the host's refill of the input edges), the host waits only for the copy of its OWN input spans before it hands them
+    // back, and for the oldest exchange when both slabs are taken.
+    struct Slab {
+        std::deque<DevBuf> d_in, h_in; // per local branch
+        DevBuf             d_partial{false}, d_sum{false}, h_out{true};
+        gr4hip_event_t     ev_in = nullptr, ev_launch = nullptr, ev_done = nullptr;
+        std::size_t        n_out = 0, exchange = 0;
+        void*              direct = nullptr; // the output edge's own (page-locked) storage, reserved in order
+        property_map       fwd;
+        bool               busy = false;
+    };
+    std::deque<Branch>              _branches;
     std::shared_ptr<EdgeBufferBase> _out;
     Shard                           _shard;
     std::size_t                     _N, _n_total;
     ComputeDomain                   _domain;
-    gr4hip_stream_t                 _s = nullptr;
-    DevBuf                          _d_partial{false}, _d_sum{false}, _h_out{true};
+    gr4hip_stream_t                 _s = nullptr, _s_copy = nullptr, _s_exchange = nullptr;
+    static constexpr std::size_t    kSlabs = 2;
+    std::array<Slab, kSlabs>        _slabs;
+    std::size_t                     _oldest = 0, _in_flight = 0, _pending_staged = 0; // _pending_staged: output items of exchanges in flight that will be COPIED into the output edge
     std::string                     _name;
-    std::size_t                     _launches = 0, _exchanges = 0, _tags_forwarded = 0;
-    gr4hip_event_t                  _ev = nullptr;
-    bool                            _stalled = false; // an exchange timed out: the stream is abandoned (never synchronised again)
+    std::size_t                     _launches = 0, _exchanges = 0, _tags_forwarded = 0, _overlapped = 0;
+    bool                            _stalled = false; // an exchange timed out: the streams are abandoned (never synchronised again)
+
+    // waits for `ev`; with a communicator the wait is bounded (other processes are involved): a diagnostic instead of a hung rank
+    void wait_bounded(gr4hip_event_t ev, std::size_t exchange) {
+        if (!_shard.comm || options().collective_timeout_s <= 0) { check(gr4hip_event_synchronize(ev), "event synchronize"); return; }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int done = 0;;) {
+            check(gr4hip_event_query(ev, &done), "event query");
+            if (done) return;
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > options().collective_timeout_s) {
+                _stalled = true; // (the streams still hold the collective: nothing more is queued on them, the destructor does not wait for them)
+                throw std::runtime_error("fan-in exchange " + std::to_string(exchange) + " of rank " + std::to_string(_shard.rank) + " / " + std::to_string(_shard.n_ranks) +
+                                         " did not complete within " + std::to_string(static_cast<int>(options().collective_timeout_s)) + " s (a peer that never joined the collective?)");
+            }
+            std::this_thread::sleep_for(waited < 0.01 ? std::chrono::microseconds(20) : std::chrono::microseconds(500));
+        }
+    }
+    // the oldest exchange has completed: its frames (and its tag) appear on the output edge
+    std::size_t retire() {
+        Slab& sl = _slabs[_oldest];
+        if (!sl.fwd.empty()) { _out->publishTag(sl.fwd, 0); ++_tags_forwarded; sl.fwd.clear(); }
+        if (sl.direct) _out->publish_reserved(sl.n_out);
+        else {
+            _pending_staged -= sl.n_out;
+            if (void* dst = sl.n_out * 4 >= (std::size_t(2) << 20) ? _out->reserve_items(sl.n_out) : nullptr) { CopyPool::instance().copy(dst, sl.h_out.p, sl.n_out * 4); _out->publish_reserved(sl.n_out); } // large exchange into a pageable edge: the copy threads share it
+            else _out->write_items(sl.h_out.p, sl.n_out);
+        }
+        sl.busy   = false;
+        sl.direct = nullptr;
+        _oldest   = (_oldest + 1) % kSlabs;
+        --_in_flight;
+        return sl.n_out;
+    }
 
 public:
     FanInRun(std::vector<std::pair<std::shared_ptr<EdgeBufferBase>, std::vector<float>>> local_branches, std::shared_ptr<EdgeBufferBase> out, std::size_t fftSize, int window,
@@ -2003,30 +2048,55 @@ public:
         : _out(std::move(out)), _shard(shard), _N(fftSize), _n_total(n_total), _domain(std::move(domain)) {
         check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
         check(gr4hip_stream_create(&_s), "gr4hip_stream_create");
+        check(gr4hip_stream_create(&_s_copy), "gr4hip_stream_create");
+        check(gr4hip_stream_create(&_s_exchange), "gr4hip_stream_create");
         for (auto& [edge, taps] : local_branches) {
             _branches.emplace_back();
             _branches.back().in = std::move(edge);
             check(gr4hip_chain_create(&_branches.back().chain, taps.data(), taps.size(), fftSize, window, GR4HIP_CHAIN_AUTO), "gr4hip_chain_create");
             check(gr4hip_chain_set_guard_mode(_branches.back().chain, options().guard_mode), "gr4hip_chain_set_guard_mode");
         }
+        for (auto& sl : _slabs) {
+            for (std::size_t c = 0; c < _branches.size(); ++c) { sl.d_in.emplace_back(false); sl.h_in.emplace_back(true); }
+            check(gr4hip_event_create(&sl.ev_in), "gr4hip_event_create");
+            check(gr4hip_event_create(&sl.ev_launch), "gr4hip_event_create");
+            check(gr4hip_event_create(&sl.ev_done), "gr4hip_event_create");
+        }
         _name = "fan_in[" + std::to_string(_branches.size()) + " of " + std::to_string(n_total) + " channels on gpu:hip:" + std::to_string(_domain.index) + "]";
     }
     ~FanInRun() override {
-        if (_stalled) return; // a collective that never completes still owns the stream and the buffers it was queued with: leaked on purpose, the process is going down
+        if (_stalled) return; // a collective that never completes still owns the streams and the buffers it was queued with: leaked on purpose, the process is going down
+        for (gr4hip_stream_t s : {_s_copy, _s, _s_exchange})
+            if (s) (void)gr4hip_stream_synchronize(s);
         for (auto& b : _branches) gr4hip_chain_destroy(b.chain);
-        if (_ev) gr4hip_event_destroy(_ev);
-        if (_s) gr4hip_stream_destroy(_s);
+        for (auto& sl : _slabs)
+            for (gr4hip_event_t e : {sl.ev_in, sl.ev_launch, sl.ev_done})
+                if (e) gr4hip_event_destroy(e);
+        for (gr4hip_stream_t s : {_s_copy, _s, _s_exchange})
+            if (s) gr4hip_stream_destroy(s);
     }
     [[nodiscard]] std::size_t local_channels() const { return _branches.size(); }
     [[nodiscard]] std::size_t launches() const { return _launches; }   // device launches of the branch kernels: ONE per exchange whatever the channel count
     [[nodiscard]] std::size_t exchanges() const { return _exchanges; } // collectives queued
+    [[nodiscard]] std::size_t overlapped() const { return _overlapped; } // launches queued while an earlier exchange was still in flight
     [[nodiscard]] std::size_t tags_forwarded() const { return _tags_forwarded; }
     [[nodiscard]] std::size_t frames_per_exchange() const { return _shard.frames_per_exchange; }
 
     work::Result work(std::size_t requested) override {
-        std::size_t held_reserved = 0;
+        std::vector<std::size_t> lent_from; // branches whose input edge the copy engine is reading in place (spans lent in this call and not yet handed back)
+        std::size_t              lent_n = 0;
+        Slab*       queued   = nullptr;
         try {
             check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
+            std::size_t published = 0;
+            // (1) exchanges that have completed appear on the output edge, in order; nobody waits here
+            while (_in_flight) {
+                int done = 0;
+                check(gr4hip_event_query(_slabs[_oldest].ev_done, &done), "event query");
+                if (!done) break;
+                published += retire();
+            }
+            // (2) the next exchange, if a slab is free and the edges hold it
             bool        all_done = true;
             std::size_t avail    = std::numeric_limits<std::size_t>::max();
             for (auto& b : _branches) {
@@ -2035,8 +2105,8 @@ public:
             }
             if (_branches.empty()) { avail = 0; all_done = true; }
             std::size_t frames = std::min(avail / _N, _shard.frames_per_exchange);
-            if (frames < _shard.frames_per_exchange && !all_done) return {requested, 0, work::Status::INSUFFICIENT_INPUT_ITEMS}; // every rank exchanges the same frame counts
-            if (_shard.scatter && frames % static_cast<std::size_t>(_shard.n_ranks)) { // the stream's last exchange: reduce_scatter hands out whole frames, the same count to every rank
+            if (frames < _shard.frames_per_exchange && !all_done) frames = 0; // every rank exchanges the same frame counts: wait for a whole exchange
+            if (frames && _shard.scatter && frames % static_cast<std::size_t>(_shard.n_ranks)) { // the stream's last exchange: reduce_scatter hands out whole frames, the same count to every rank
                 const std::size_t left = frames % static_cast<std::size_t>(_shard.n_ranks);
                 frames -= left;
                 if (frames == 0) { // fewer frames than ranks are left: they cannot be shared out -- dropped, said once, and the stream ends DONE (not ERROR)
@@ -2044,92 +2114,98 @@ public:
                     for (auto& b : _branches) b.in->consume_items(std::min(b.in->available_items(), left * _N));
                 }
             }
-            if (frames == 0) {
-                if (all_done) { _out->producer_done = true; return {requested, 0, work::Status::DONE}; }
-                return {requested, 0, work::Status::INSUFFICIENT_INPUT_ITEMS};
-            }
             const std::size_t n_out = _shard.scatter ? frames / static_cast<std::size_t>(_shard.n_ranks) * _N : frames * _N;
-            if (_out->free_items() < n_out) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
-            const std::size_t n = frames * _N;
-            // the exchange's tag: every tag on the exchange's samples of every LOCAL branch merged ("gr:" keys; identical tags on several branches collapse, like
-            // the merged input tag of an n-ary block, Block.hpp:1511-1530), published on the first output sample; gr:sample_rate follows the run's rate change
-            // (1 : 1, or 1 / n_ranks of the frames in scatter mode).  Tags of branches that live on other ranks stay on those ranks.
-            property_map fwd;
-            for (auto& b : _branches)
-                for (const auto& [key, value] : b.in->mergedTags(n)) {
-                    if (!std::string_view(key).starts_with(GR_TAG_PREFIX)) continue;
-                    const float* rate = _shard.scatter && tag::settingsKey(key) == tag::SAMPLE_RATE ? std::get_if<float>(&value) : nullptr;
-                    if (rate) fwd.insert_or_assign(key, *rate / static_cast<float>(_shard.n_ranks));
-                    else fwd.insert_or_assign(key, value);
-                }
-            // samples of every local branch land in HBM (pinned staging, one stream: the copies of branch c + 1 run behind those of branch c)
-            std::vector<gr4hip_chain_t*> chains;
-            std::vector<const void*>     ins;
-            for (auto& b : _branches) {
-                const void* lent = b.in->lend_items(n);
-                if (lent && b.in->memory() == pinned_resource()) { // page-locked edge ("hip" provider): the copy engine reads the edge in place; the span goes back below
-                    check(gr4hip_memcpy_h2d(b.d_in.ensure(n * 8), lent, n * 8, _s), "h2d");
-                    b.n_lent = n;
-                } else {
-                    if (lent) { // pageable edge: staged through page-locked memory by the copy threads
-                        CopyPool::instance().copy(b.h_in.ensure(n * 8), lent, n * 8);
-                        b.in->consume_items(n);
+            const bool        room  = _out->free_items() >= n_out + _pending_staged;
+            if (frames && room && _in_flight < kSlabs) {
+                Slab&             sl = _slabs[(_oldest + _in_flight) % kSlabs];
+                const std::size_t n  = frames * _N;
+                queued               = &sl;
+                sl.n_out             = n_out;
+                sl.direct            = nullptr;
+                lent_n               = n;
+                // the exchange's tag: every tag on the exchange's samples of every LOCAL branch merged ("gr:" keys; identical tags on several branches collapse, like
+                // the merged input tag of an n-ary block, Block.hpp:1511-1530), published on the first output sample; gr:sample_rate follows the run's rate change
+                // (1 : 1, or 1 / n_ranks of the frames in scatter mode).  Tags of branches that live on other ranks stay on those ranks.
+                sl.fwd.clear();
+                for (auto& b : _branches)
+                    for (const auto& [key, value] : b.in->mergedTags(n)) {
+                        if (!std::string_view(key).starts_with(GR_TAG_PREFIX)) continue;
+                        const float* rate = _shard.scatter && tag::settingsKey(key) == tag::SAMPLE_RATE ? std::get_if<float>(&value) : nullptr;
+                        if (rate) sl.fwd.insert_or_assign(key, *rate / static_cast<float>(_shard.n_ranks));
+                        else sl.fwd.insert_or_assign(key, value);
+                    }
+                // samples of every local branch land in HBM on the copy stream (the copies of branch c + 1 behind those of branch c), beside the launch before this one
+                std::vector<gr4hip_chain_t*> chains;
+                std::vector<const void*>     ins;
+                for (std::size_t c = 0; c < _branches.size(); ++c) {
+                    auto&       b    = _branches[c];
+                    const void* lent = b.in->lend_items(n);
+                    if (lent && b.in->memory() == pinned_resource()) { // page-locked edge ("hip" provider): the copy engine reads the edge in place; the span goes back below
+                        lent_from.push_back(c);
+                        check(gr4hip_memcpy_h2d(sl.d_in[c].ensure(n * 8), lent, n * 8, _s_copy), "h2d");
                     } else {
-                        b.in->read_items(b.h_in.ensure(n * 8), n);
+                        if (lent) { // pageable edge: staged through the slab's page-locked memory by the copy threads
+                            CopyPool::instance().copy(sl.h_in[c].ensure(n * 8), lent, n * 8);
+                            b.in->consume_items(n);
+                        } else {
+                            b.in->read_items(sl.h_in[c].ensure(n * 8), n);
+                        }
+                        check(gr4hip_memcpy_h2d(sl.d_in[c].ensure(n * 8), sl.h_in[c].p, n * 8, _s_copy), "h2d");
                     }
-                    check(gr4hip_memcpy_h2d(b.d_in.ensure(n * 8), b.h_in.p, n * 8, _s), "h2d");
+                    chains.push_back(b.chain);
+                    ins.push_back(sl.d_in[c].p);
                 }
-                chains.push_back(b.chain);
-                ins.push_back(b.d_in.p);
-            }
-            // ONE launch for all local channels, the local part of math::Add as its store epilogue
-            std::size_t got = 0;
-            check(gr4hip_chain_process_multi(chains.data(), chains.size(), ins.data(), n, nullptr, static_cast<float*>(_d_partial.ensure(n * 4)), &got, _s), "gr4hip_chain_process_multi");
-            ++_launches;
-            const float* result = static_cast<const float*>(_d_partial.p);
-            if (_shard.comm) { // the combiner's inputs that live on other devices: one collective per exchange
-                float* sum = static_cast<float*>(_d_sum.ensure(n_out * 4));
-                if (_shard.scatter) check(gr4hip_fanin_reduce_scatter_sum_f32(_shard.comm, result, sum, n_out, _s), "gr4hip_fanin_reduce_scatter_sum_f32");
-                else check(gr4hip_fanin_all_reduce_sum_f32(_shard.comm, result, sum, n_out, _s), "gr4hip_fanin_all_reduce_sum_f32");
-                result = sum;
-                ++_exchanges;
-            } else if (_shard.n_ranks != 1) {
-                throw std::runtime_error("sharded graph without a communicator");
-            }
-            void* direct = _out->memory() == pinned_resource() ? _out->reserve_items(n_out) : nullptr; // a page-locked output edge takes the result copy in its own storage
-            held_reserved = direct ? n_out : 0;
-            check(gr4hip_memcpy_d2h(direct ? direct : _h_out.ensure(n_out * 4), result, n_out * 4, _s), "d2h");
-            if (_shard.comm && options().collective_timeout_s > 0) { // the exchange involves other processes: bounded wait, then a diagnostic instead of a hung rank
-                if (!_ev) check(gr4hip_event_create(&_ev), "gr4hip_event_create");
-                check(gr4hip_event_record(_ev, _s), "event record");
-                const auto t0 = std::chrono::steady_clock::now();
-                for (int done = 0;;) {
-                    check(gr4hip_event_query(_ev, &done), "event query");
-                    if (done) break;
-                    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                    if (waited > options().collective_timeout_s) {
-                        _stalled = true; // (the stream still holds the collective: nothing more is queued on it, the destructor does not wait for it)
-                        throw std::runtime_error("fan-in exchange " + std::to_string(_exchanges) + " of rank " + std::to_string(_shard.rank) + " / " + std::to_string(_shard.n_ranks) +
-                                                 " did not complete within " + std::to_string(static_cast<int>(options().collective_timeout_s)) + " s (a peer that never joined the collective?)");
-                    }
-                    std::this_thread::sleep_for(waited < 0.01 ? std::chrono::microseconds(20) : std::chrono::microseconds(500));
+                check(gr4hip_event_record(sl.ev_in, _s_copy), "event record");
+                check(gr4hip_stream_wait_event(_s, sl.ev_in), "stream wait");
+                // ONE launch for all local channels, the local part of math::Add as its store epilogue
+                std::size_t got = 0;
+                check(gr4hip_chain_process_multi(chains.data(), chains.size(), ins.data(), n, nullptr, static_cast<float*>(sl.d_partial.ensure(n * 4)), &got, _s), "gr4hip_chain_process_multi");
+                ++_launches;
+                if (_in_flight) ++_overlapped;
+                check(gr4hip_event_record(sl.ev_launch, _s), "event record");
+                check(gr4hip_stream_wait_event(_s_exchange, sl.ev_launch), "stream wait");
+                const float* result = static_cast<const float*>(sl.d_partial.p);
+                if (_shard.comm) { // the combiner's inputs that live on other devices: one collective per exchange, beside the NEXT launch
+                    float* sum = static_cast<float*>(sl.d_sum.ensure(n_out * 4));
+                    if (_shard.scatter) check(gr4hip_fanin_reduce_scatter_sum_f32(_shard.comm, result, sum, n_out, _s_exchange), "gr4hip_fanin_reduce_scatter_sum_f32");
+                    else check(gr4hip_fanin_all_reduce_sum_f32(_shard.comm, result, sum, n_out, _s_exchange), "gr4hip_fanin_all_reduce_sum_f32");
+                    result = sum;
+                    ++_exchanges;
+                } else if (_shard.n_ranks != 1) {
+                    throw std::runtime_error("sharded graph without a communicator");
                 }
+                sl.direct = _out->memory() == pinned_resource() ? _out->reserve_items(n_out) : nullptr; // a page-locked output edge takes the result copy in its own storage
+                check(gr4hip_memcpy_d2h(sl.direct ? sl.direct : sl.h_out.ensure(n_out * 4), result, n_out * 4, _s_exchange), "d2h");
+                check(gr4hip_event_record(sl.ev_done, _s_exchange), "event record");
+                sl.exchange = _exchanges;
+                sl.busy     = true;
+                if (!sl.direct) _pending_staged += n_out;
+                ++_in_flight;
+                queued = nullptr; // (from here on the slab is the pipeline's: a failure below is the run's failure, handled as a whole)
+                // the input spans go back as soon as the copy engine has read them (the launch and the exchange are still running): the sources refill beside the device
+                if (!lent_from.empty()) check(gr4hip_event_synchronize(sl.ev_in), "event synchronize");
+                for (const std::size_t c : lent_from) _branches[c].in->consume_items(n);
+                lent_from.clear();
+                return {requested, published + n, work::Status::OK};
             }
-            check(gr4hip_stream_synchronize(_s), "stream synchronize");
-            for (auto& b : _branches)
-                if (b.n_lent) { b.in->consume_items(b.n_lent); b.n_lent = 0; }
-            if (!fwd.empty()) { _out->publishTag(fwd, 0); ++_tags_forwarded; }
-            if (direct) { _out->publish_reserved(n_out); held_reserved = 0; }
-            else if (void* dst = n_out * 4 >= (std::size_t(2) << 20) ? _out->reserve_items(n_out) : nullptr) { CopyPool::instance().copy(dst, _h_out.p, n_out * 4); _out->publish_reserved(n_out); } // large exchange into a pageable edge: the copy threads share it
-            else _out->write_items(_h_out.p, n_out);
-            return {requested, n_out, work::Status::OK};
+            if (published) return {requested, published, work::Status::OK};
+            // (3) nothing could be queued and nothing had completed: the oldest exchange is what everybody is waiting for
+            if (_in_flight) {
+                wait_bounded(_slabs[_oldest].ev_done, _slabs[_oldest].exchange);
+                return {requested, retire(), work::Status::OK};
+            }
+            if (frames && !room) return {requested, 0, work::Status::INSUFFICIENT_OUTPUT_ITEMS};
+            if (all_done) { _out->producer_done = true; return {requested, 0, work::Status::DONE}; }
+            return {requested, 0, work::Status::INSUFFICIENT_INPUT_ITEMS};
         } catch (const std::exception& e) {
             std::cerr << "[gr::hip] fan-in run failed: " << e.what() << "\n";
-            if (_stalled) return {requested, 0, work::Status::ERROR}; // (nothing can be taken back from a stream that does not drain)
-            (void)gr4hip_stream_synchronize(_s); // nothing of the failed exchange may still read a lent span
-            for (auto& b : _branches)
-                if (b.n_lent) { b.in->unlend_items(b.n_lent); b.n_lent = 0; }
-            if (held_reserved) _out->unreserve_items(held_reserved);
+            if (_stalled) return {requested, 0, work::Status::ERROR}; // (nothing can be taken back from streams that do not drain)
+            for (gr4hip_stream_t s : {_s_copy, _s, _s_exchange}) (void)gr4hip_stream_synchronize(s); // nothing of the failed exchange may still read a lent span
+            for (const std::size_t c : lent_from) _branches[c].in->unlend_items(lent_n);
+            std::size_t held = queued && queued->direct ? queued->n_out : 0;
+            for (auto& sl : _slabs)
+                if (sl.busy && sl.direct) held += sl.n_out;
+            if (held) _out->unreserve_items(held);
             return {requested, 0, work::Status::ERROR};
         }
     }

@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
     if (const auto r = sched.runAndWait(); !r) { std::fprintf(stderr, "%s\n", r.error().message.c_str()); return 3; }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double in = double(C) * double(sink._count);
-    std::printf("host-fed fan-in (%s, %s edges, %zu frames per exchange): %zu output samples, %zu channels in %.3f s = %.1f Msamples/s aggregate (%.2f GB/s in + %.2f GB/s out over PCIe); %zu launches\n",
-                std::string(run->name()).c_str(), mode.c_str(), run->frames_per_exchange(), sink._count, C, dt, in / dt / 1e6, in * 8 / dt / 1e9, double(sink._count) * 4 / dt / 1e9, run->launches());
+    std::printf("host-fed fan-in (%s, %s edges, %zu frames per exchange): %zu output samples, %zu channels in %.3f s = %.1f Msamples/s aggregate (%.2f GB/s in + %.2f GB/s out over PCIe); %zu launches, %zu of them queued beside the exchange before\n",
+                std::string(run->name()).c_str(), mode.c_str(), run->frames_per_exchange(), sink._count, C, dt, in / dt / 1e6, in * 8 / dt / 1e9, double(sink._count) * 4 / dt / 1e9, run->launches(), run->overlapped());
     return sink._count == (n / N) * N ? 0 : 1;
 }

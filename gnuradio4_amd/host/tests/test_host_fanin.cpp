@@ -87,8 +87,9 @@ int main(int argc, char** argv) {
         sched.exchange(std::move(b.g));
         if (const auto r = sched.runAndWait(); !r) { std::cerr << "sharded graph: " << r.error().message << "\n"; return 3; }
         const std::size_t frames = x.size() / N, want_launches = (frames + 3) / 4;
-        std::printf("run (variant %d): %zu outputs, %zu launches, %zu collectives\n", variant, b.sink->_samples.size(), run->launches(), run->exchanges());
+        std::printf("run (variant %d): %zu outputs, %zu launches (%zu queued beside an exchange still in flight), %zu collectives\n", variant, b.sink->_samples.size(), run->launches(), run->overlapped(), run->exchanges());
         if (b.sink->_samples.size() != frames * N || run->launches() != want_launches || run->exchanges() != want_launches) ++errors;
+        if (want_launches > 2 && run->overlapped() == 0) { std::printf("run (variant %d): no launch was ever queued beside the exchange before it\n", variant); ++errors; } // the two-slab pipeline
         { // tags cross the run like one n-ary block: channel 2's rate tag on sample 0, channel 1's trigger at the start of the exchange it fell into, "gr:" keys only
             const auto& tg = b.sink->_tags;
             const bool ok = C < 3 || (run->tags_forwarded() == 2 && tg.size() == 2 && tg[0].index == 0 && tg[0].map.count("gr:sample_rate") && std::get<float>(tg[0].map.at("gr:sample_rate")) == 2.0e6f &&
