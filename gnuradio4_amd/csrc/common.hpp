@@ -1,5 +1,6 @@
 // common.hpp -- shared helpers of libgr4hip (gfx950 only; no CUDA/compat paths).
 #pragma once
+#include <cmath>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -73,6 +74,25 @@ inline size_t dtype_size(int dtype) {
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline int  ilog2(size_t n) { int l = 0; while ((size_t(1) << l) < n) ++l; return l; }
 template <typename T> inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+// A rotator's phase in TURNS as a 64-bit binary fraction (units of 2^-64 turn): sums and products modulo 2^64 ARE the reduction modulo one turn, so
+// phase(k) = p0 + k inc is exact however long the stream and however it is associated -- p0 + k inc at once, or the phase of the sample before plus inc: every kernel
+// that evaluates a rotator (math.hip, the element-wise programs, the decimators that carry one as their load program) lands on the same 64 bits.  The increment itself
+// is rounded to 2^-64 turn once (exact for |inc| >= 2^-11 turn; below that 2^-65 turn per sample: 3e-8 turn after 2^40 samples).
+inline unsigned long long turns_fix(double turns) {
+    const double f = turns - std::floor(turns); // [0, 1]
+    return f >= 0.0 && f < 1.0 ? (unsigned long long)(f * 18446744073709551616.0) : 0ull; // (1.0: a tiny negative argument; not finite: the callers mark those)
+}
+inline double fix_turns(unsigned long long p) { return (double)p * (1.0 / 18446744073709551616.0); }
+#ifdef __HIPCC__
+// exp(j 2 pi phase): the top 32 bits as a signed fraction of a turn in [-0.5, 0.5) -> float (24 bits: 2^-26 turn), then the hardware sine / cosine, which take turns
+// (max |error| 1.25e-7 on [-0.5, 0.5), tools/ubench/native_sincos_accuracy.hip)
+__device__ __forceinline__ void rotor_at(unsigned long long phase, float& cs, float& sn) {
+    const float tf = (float)(int)(unsigned)(phase >> 32) * 0x1p-32f;
+    sn = __builtin_amdgcn_sinf(tf);
+    cs = __builtin_amdgcn_cosf(tf);
+}
+#endif
 
 // Per-device one-time set-up (function attributes are per device; a process may drive several GPUs through gr4hip_set_device).
 // current(&first, &dev): CU count of the calling thread's current device (0: query failed).  The first time a table sees a device it returns

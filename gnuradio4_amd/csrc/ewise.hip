@@ -193,6 +193,9 @@ int ewise_device_ops(gr4hip_ewise* p, EwiseHook* hook) {
     hook->n_ops   = (int)p->ops.size();
     hook->has_div = p->has_div;
     hook->pos     = p->pos;
+    hook->rotor_only = p->dtype == GR4HIP_C32 && p->ops.size() == 1 && p->ops[0].kind == kEwRotate && !(p->ops[0].flags & kEwFlagNan);
+    hook->rot_p0     = hook->rotor_only ? p->ops[0].u.q[0] : 0;
+    hook->rot_inc    = hook->rotor_only ? p->ops[0].u.q[1] : 0;
     return GR4HIP_OK;
 }
 // (library-internal) a program that is nothing but real gains -- MultiplyConst / DivideConst on float, or on complex<float> with a real value: its product, in float64.
@@ -261,11 +264,12 @@ int gr4hip_ewise_append_rotator(gr4hip_ewise_t* p, float phase_increment, float 
     GR4_REQUIRE(phase_increment == phase_increment && initial_phase == initial_phase, "ewise_append_rotator: NaN phase (the stand-alone rotator's recurrence reproduces the reference there)");
     EwiseOp      o{};
     const double two_pi = 6.283185307179586476925286766559;
-    const double inc_t = (double)phase_increment / two_pi, inc20 = inc_t * 1048576.0;
-    o.kind   = kEwRotate;
-    o.u.d[0] = (double)initial_phase / two_pi;
-    o.u.d[1] = inc_t - std::floor(inc_t);
-    o.u.d[2] = inc20 - std::floor(inc20);
+    const double ph_t = (double)initial_phase / two_pi, inc_t = (double)phase_increment / two_pi;
+    o.kind = kEwRotate;
+    if (std::isfinite(ph_t) && std::isfinite(inc_t)) {
+        o.u.q[0] = turns_fix(ph_t);
+        o.u.q[1] = turns_fix(inc_t);
+    } else o.flags = kEwFlagNan;
     p->user.push_back(o);
     p->dirty = true;
     return GR4HIP_OK;

@@ -25,13 +25,13 @@
 namespace gr4 {
 
 enum : int { kEwAdd = GR4HIP_ADD, kEwSub = GR4HIP_SUB, kEwMul = GR4HIP_MUL, kEwDiv = GR4HIP_DIV, kEwRotate = 4, kEwAffine = 5 };
-enum : int { kEwFlagDiv = 1, kEwFlagDivRcp = 2 }; // kEwFlagDivRcp (float): the correctly rounded reciprocal of c sits behind c (raw + 20)
+enum : int { kEwFlagDiv = 1, kEwFlagDivRcp = 2, kEwFlagNan = 4 }; // kEwFlagDivRcp (float): the correctly rounded reciprocal of c sits behind c (raw + 20)
 
 struct alignas(16) EwiseOp { // 32 bytes
     int kind, flags;
     union {
         unsigned char raw[24]; // kEwAffine: m at 0, a at 8, c at 16 (each one T); complex ops: the constant at 0
-        double        d[3];    // kEwRotate: {phase0 in turns, frac(inc in turns), frac(2^20 inc in turns)}
+        unsigned long long q[3]; // kEwRotate: {phase0, increment} as 64-bit fractions of a turn (common.hpp: turns_fix); flags = kEwFlagNan: a non-finite phase or increment
     } u;
 };
 // programs are read through the scalar cache (uniform address, constant address space): one s_load per item and wave, no vector registers
@@ -51,6 +51,10 @@ struct EwiseHook { // a program attached to another kernel's load or store: pos 
     int       n_ops   = 0;
     int       has_div = 0; // some item of a real-typed program carries a division
     long      pos     = 0;
+    // the program is ONE finite rotator on complex<float> (a down-converter's mixer: the channeliser's front end): its constants ride in the hook itself, and a kernel
+    // that knows the order in which it touches samples steps the phase by integer additions (bit-identical to walking the program: the phase is exact modulo 2^64)
+    int                rotor_only = 0;
+    unsigned long long rot_p0 = 0, rot_inc = 0;
 };
 
 template <typename T> struct EwWide { using type = uint32_t; }; // +, -, * modulo 2^32 (then narrowed): what promotion to int, the operation and the narrowing give
@@ -98,18 +102,18 @@ __device__ __forceinline__ T ew_cconst(T a, T b) { // std::complex arithmetic on
     return r;
 }
 
-// exp(j 2 pi (ph0 + k inc)) with k = absolute sample index + 1, evaluated like rotator_closed_kernel (math.hip): float64 turns, the product split at 2^20 so that
-// the argument of the reduction stays exact however long the stream
-__device__ __forceinline__ void ew_rotor(const EwiseOp& op, long k, float& cs, float& sn) {
-    double t = fma((double)(k & 0xfffff), op.u.d[1], op.u.d[0]);
-    t        = fma((double)(k >> 20), op.u.d[2], t);
-    t -= rint(t); // [-0.5, 0.5] turns
-    // v_sin_f32 / v_cos_f32 take their argument in turns: max |error| 1.25e-7 over 2^28 arguments of [-0.5, 0.5) (tools/ubench/native_sincos_accuracy.hip) against 1.56e-7
-    // for sincosf(float(2 pi t)), which rounds the radians first -- and two instructions instead of ~50 (a rotator as the load hook of a matrix-pipe decimator is
-    // bound by exactly these)
-    const float tf = (float)t;
-    sn = __builtin_amdgcn_sinf(tf);
-    cs = __builtin_amdgcn_cosf(tf);
+// exp(j 2 pi (ph0 + k inc)) with k = absolute sample index + 1, the arithmetic of rotator_closed_kernel (math.hip): the phase as a 64-bit fraction of a turn, exact
+// modulo one turn (common.hpp: turns_fix, rotor_at).  A rotator as the load hook of a matrix-pipe decimator is bound by exactly this: one 64-bit product per CALL (the
+// first element), two integer additions per further element (their index differences are compile-time constants in every kernel: the products are scalar).
+__device__ __forceinline__ unsigned long long ew_rotor_phase(const EwiseOp& op, long k) { return op.u.q[0] + (unsigned long long)k * op.u.q[1]; }
+__device__ __forceinline__ void ew_rotor(const EwiseOp& op, unsigned long long phase, float& cs, float& sn) {
+#ifdef GR4_T_ROTOR_TRIVIAL // timing-only build: what a hooked launch costs without the rotor's arithmetic (wrong results)
+    cs = __builtin_bit_cast(float, (int)phase & 0x3f800000);
+    sn = (float)op.flags;
+    return;
+#endif
+    rotor_at(phase, cs, sn);
+    if (op.flags & kEwFlagNan) cs = sn = __builtin_nanf(""); // (uniform)
 }
 
 // apply the whole program to NE values held by this lane; index(j) = absolute stream index of element j (rotator ops only)
@@ -196,11 +200,13 @@ __device__ __forceinline__ void ewise_apply(T (&e)[NE], EwiseProg ops, int n_ops
                 break;
             default:
                 if constexpr (std::is_same_v<T, float2>) {
+                    const long               i0  = index(0);
+                    const unsigned long long ph0 = ew_rotor_phase(cur, i0 + 1);
 #pragma unroll
                     for (int j = 0; j < NE; ++j) {
 #pragma clang fp contract(off)
                         float cs, sn;
-                        ew_rotor(cur, index(j) + 1, cs, sn);
+                        ew_rotor(cur, ph0 + (unsigned long long)(index(j) - i0) * cur.u.q[1], cs, sn);
                         const float2 x = e[j];
                         e[j] = make_float2(x.x * cs - x.y * sn, x.x * sn + x.y * cs);
                     }

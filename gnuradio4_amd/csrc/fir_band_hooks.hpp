@@ -34,6 +34,28 @@ __device__ __forceinline__ float4 bd_hook4(float4 v, const EwiseHook& h, int cpl
     ewise_hook<float, 4>(e, h, fi);
     return make_float4(e[0], e[1], e[2], e[3]);
 }
+// The load program is ONE rotator on a complex stream and nothing rides on the store (EwiseHook::rotor_only: rotator -> decimating FIR, a down-converter): a lane's
+// float4 number u of a segment holds the complex samples (in0 + 4 (tid + 256 u)) / 2 and the one behind it -- the first phase from one 64-bit product per segment,
+// every further one by integer additions, bit-identical to walking the program (common.hpp: the phase is exact modulo 2^64).  Samples past the span's end are zeros and
+// stay zeros under a finite rotor.
+struct BdRotor {
+    unsigned long long ph, step, inc;
+};
+__device__ __forceinline__ BdRotor bd_rotor_start(const EwiseHook& h, long in0 /*float index of the segment's first staged float: even*/, int tid) {
+    BdRotor r;
+    r.inc  = h.rot_inc;
+    r.step = 512ull * h.rot_inc;
+    r.ph   = h.rot_p0 + (unsigned long long)(h.pos + 1 + in0 / 2) * h.rot_inc + (unsigned long long)(2 * tid) * h.rot_inc;
+    return r;
+}
+__device__ __forceinline__ float4 bd_rotor_next(float4 v, BdRotor& r) { // the lane's next float4 (256 float4s further on)
+#pragma clang fp contract(off)
+    float c0, s0, c1, s1;
+    rotor_at(r.ph, c0, s0);
+    rotor_at(r.ph + r.inc, c1, s1);
+    r.ph += r.step;
+    return make_float4(v.x * c0 - v.y * s0, v.x * s0 + v.y * c0, v.z * c1 - v.w * s1, v.z * s1 + v.w * c1);
+}
 // four staged floats at stream float index fi (a multiple of 4) of the span's first segment: history in front of position 0 (as it lies: it holds what the prologue
 // produced), the prologue on the samples of this span
 template <bool HOOK>

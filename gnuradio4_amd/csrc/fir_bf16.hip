@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void fir_mfma_bf16x3_c32_kernel(const float2* 
 // (samples in stream order, A[j][u] = b[Hb + j D - u]: the decimation sits in the A operand) with the three-term products -- the polyphase kernel on the f32 MFMA
 // is bound by that instruction (D = 2, 256 taps: 306 G input samples/s).  1024 outputs (1024 D inputs) per segment, one tile per wave, one accumulator per term.
 constexpr int kBdSegOut = 1024, kBdMaxNL4 = 10;
-template <int KS, bool HOOK>
+template <int KS, int HOOK> // HOOK 1: the filter's load / store programs walked per sample; 2: the load program is one rotator on a complex stream (fir_band_hooks.hpp: BdRotor)
 __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh, const u32x4_b* __restrict__ afrag,
                                                                 float* __restrict__ y, long n_out, long n_in, int D, int Hb /*a multiple of 4: samples in front of a block*/,
                                                                 float* __restrict__ new_hist, BdHooks hk) {
@@ -476,18 +476,21 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
         const long in0 = in_start(sg);
         float      pxl = 0.f;
         if (in0 >= 0) {
+            [[maybe_unused]] BdRotor rot;
+            if constexpr (HOOK == 2) rot = bd_rotor_start(hk.pre, in0, tid);
 #pragma unroll
             for (int u = 0; u < kBdMaxNL4; ++u) {
                 const int q = tid + 256 * u;
                 if (q < NS / 4) {
-                    if constexpr (HOOK) { if (hk.pre.n_ops > 0) nxt[u] = bd_hook4(nxt[u], hk.pre, hk.cplx, in0 + 4L * q); }
+                    if constexpr (HOOK == 2) nxt[u] = bd_rotor_next(nxt[u], rot);
+                    if constexpr (HOOK == 1) { if (hk.pre.n_ops > 0) nxt[u] = bd_hook4(nxt[u], hk.pre, hk.cplx, in0 + 4L * q); }
                     put4(q, nxt[u]);
                     pxl = fmaf(nxt[u].x, nxt[u].x, fmaf(nxt[u].y, nxt[u].y, fmaf(nxt[u].z, nxt[u].z, fmaf(nxt[u].w, nxt[u].w, pxl))));
                 }
             }
         } else { // the first segment of the span reads the carried history in front of x
             for (int q = tid; q < NS / 4; q += 256) {
-                const float4 v = bd_stage_slow<HOOK>(x, hist, Kh, n_in, in0 + 4L * q, hk);
+                const float4 v = bd_stage_slow<HOOK != 0>(x, hist, Kh, n_in, in0 + 4L * q, hk);
                 put4(q, v);
                 pxl = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, pxl))));
             }
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
         float pyl = 0.f; // (the filter's output, in front of the store program)
 #pragma unroll
         for (int r = 0; r < 4; ++r) pyl = o + r < n_out ? fmaf(v[r], v[r], pyl) : pyl;
-        if constexpr (HOOK) {
+        if constexpr (HOOK == 1) {
             if (hk.post.n_ops > 0) { const float4 w = bd_hook4(make_float4(v[0], v[1], v[2], v[3]), hk.post, hk.cplx, o); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
         }
         if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -535,14 +538,14 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_kernel(const float* __re
         __syncthreads();
         if (hk.flags != nullptr && tid == 0) bd_judge(jst[sg & 1], hk, sg, D);
     }
-    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK>(x, hist, Kh, n_in, new_hist, tid, hk);
+    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK != 0>(x, hist, Kh, n_in, new_hist, tid, hk);
 }
 
 // The same with LONG windows (taps - 1 + 15 D + 1 <= 1152 samples: BASELINE configs[2]'s decimate-by-8 1024-tap filter, decimation 10 .. 32 with K ~ 32 D): the four
 // waves of a workgroup split the K-steps -- each holds the fragments of its quarter (<= 9 steps) -- and their partial tiles are summed through LDS.  Two tiles
 // (512 outputs, 512 D inputs + the window) per segment, twelve accumulators per wave.
 constexpr int kBsTiles = 2, kBsSegOut = 256 * kBsTiles, kBsMaxNL4 = 20;
-template <int KSW, int NL4, bool HOOK> // K-steps of 32 per wave (the window is 128 KSW samples); float4 loads a lane holds for the next segment
+template <int KSW, int NL4, int HOOK> // K-steps of 32 per wave (the window is 128 KSW samples); float4 loads a lane holds for the next segment
 __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh, const u32x4_b* __restrict__ afrag /*[3][4 KSW][64]*/,
                                                                        float* __restrict__ y, long n_out, long n_in, int D, int Hb, float* __restrict__ new_hist, int spw /*segments per workgroup*/,
                                                                        BdHooks hk) {
@@ -582,18 +585,21 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
         const long in0 = in_start(sg);
         float      pxl = 0.f, pyl = 0.f;
         if (in0 >= 0) {
+            [[maybe_unused]] BdRotor rot;
+            if constexpr (HOOK == 2) rot = bd_rotor_start(hk.pre, in0, tid);
 #pragma unroll
             for (int u = 0; u < NL4; ++u) {
                 const int q = tid + 256 * u;
                 if (q < NS / 4) {
-                    if constexpr (HOOK) { if (hk.pre.n_ops > 0) nxt[u] = bd_hook4(nxt[u], hk.pre, hk.cplx, in0 + 4L * q); }
+                    if constexpr (HOOK == 2) nxt[u] = bd_rotor_next(nxt[u], rot);
+                    if constexpr (HOOK == 1) { if (hk.pre.n_ops > 0) nxt[u] = bd_hook4(nxt[u], hk.pre, hk.cplx, in0 + 4L * q); }
                     put4(q, nxt[u]);
                     pxl = fmaf(nxt[u].x, nxt[u].x, fmaf(nxt[u].y, nxt[u].y, fmaf(nxt[u].z, nxt[u].z, fmaf(nxt[u].w, nxt[u].w, pxl))));
                 }
             }
         } else {
             for (int q = tid; q < NS / 4; q += 256) {
-                const float4 v = bd_stage_slow<HOOK>(x, hist, Kh, n_in, in0 + 4L * q, hk);
+                const float4 v = bd_stage_slow<HOOK != 0>(x, hist, Kh, n_in, in0 + 4L * q, hk);
                 put4(q, v);
                 pxl = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, pxl))));
             }
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
             float      val = (part[((0 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((1 * kBsTiles + tl) * 64 + ln) * 4 + r]) +
                              (part[((2 * kBsTiles + tl) * 64 + ln) * 4 + r] + part[((3 * kBsTiles + tl) * 64 + ln) * 4 + r]);
             if (m < n_out) pyl = fmaf(val, val, pyl); // (the filter's output, in front of the store program)
-            if constexpr (HOOK) {
+            if constexpr (HOOK == 1) {
                 if (hk.post.n_ops > 0) {
                     if (hk.cplx) { // lanes 2 i and 2 i + 1 hold one complex output: both evaluate the program on it, each keeps its component
                         const float other = __shfl_xor(val, 1);
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(256) void fir_decim_bf16x3_splitk_kernel(const floa
         __syncthreads(); // (the partial tiles and the planes are reused by the next segment)
         if (hk.flags != nullptr && tid == 0) bd_judge(jst[sg & 1], hk, sg, D);
     }
-    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK>(x, hist, Kh, n_in, new_hist, tid, hk);
+    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK != 0>(x, hist, Kh, n_in, new_hist, tid, hk);
 }
 
 static unsigned short host_bf_rne(float f) {
@@ -804,6 +810,7 @@ int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, cons
     if (flags != nullptr && gthr > 0.f) { hk.flags = flags; hk.gthr = gthr; }
     if (seg_out) *seg_out = KS > 9 ? kBsSegOut : kBdSegOut;
     if (hooked && (Kh % 4) != 0) return GR4HIP_UNSUPPORTED;
+    const bool ddc = cplx && hk.pre.rotor_only && hk.pre.n_ops == 1 && hk.post.n_ops == 0; // rotator -> decimator: the phase stepped in integers (BdRotor)
     if (KS > 9) { // long window: the waves split the K-steps
         const int    NS   = 16 * D * (16 * kBsTiles - 1) + 32 * KS, PL = NS + 8;
         const size_t lds  = (size_t)(3 * PL + (3 * PL & 1)) * sizeof(unsigned short) + (size_t)4 * kBsTiles * 64 * 4 * sizeof(float);
@@ -815,8 +822,9 @@ int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, cons
         const auto af   = static_cast<const u32x4_b*>(afrag);
 #define GR4_BS_CASE(K)                                                                                                                     \
     case K: {                                                                                                                              \
-        auto kern = hooked ? (small ? fir_decim_bf16x3_splitk_kernel<K, 6, true> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4, true>)     \
-                           : (small ? fir_decim_bf16x3_splitk_kernel<K, 6, false> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4, false>);  \
+        auto kern = ddc    ? (small ? fir_decim_bf16x3_splitk_kernel<K, 6, 2> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4, 2>)           \
+                    : hooked ? (small ? fir_decim_bf16x3_splitk_kernel<K, 6, 1> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4, 1>)         \
+                             : (small ? fir_decim_bf16x3_splitk_kernel<K, 6, 0> : fir_decim_bf16x3_splitk_kernel<K, kBsMaxNL4, 0>);        \
         if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, af, y, n_out, n_in, D, Hb, new_hist, spw, hk);                     \
     } break
@@ -841,7 +849,7 @@ int fir_decim_bf16_launch(int KS, int D, int Hb, const float* x, long n_in, cons
     const auto af = static_cast<const u32x4_b*>(afrag);
 #define GR4_BD_CASE(K)                                                                                                                     \
     case K: {                                                                                                                              \
-        auto kern = hooked ? fir_decim_bf16x3_kernel<K, true> : fir_decim_bf16x3_kernel<K, false>;                                         \
+        auto kern = ddc ? fir_decim_bf16x3_kernel<K, 2> : (hooked ? fir_decim_bf16x3_kernel<K, 1> : fir_decim_bf16x3_kernel<K, 0>);        \
         if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, af, y, n_out, n_in, D, Hb, new_hist, hk);                          \
     } break

@@ -66,7 +66,9 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[2][KQ], const uns
 // HOOK (round 5): the filter's per-sample neighbours ride in this launch like in the bf16 band kernels (fir_band_hooks.hpp): `hk.pre` on every sample of x on its way into
 // the statistics and the f16 planes (the carried history holds prologue OUTPUTS and is taken as it lies; the next history this launch writes is made of them too), `hk.post`
 // on every output before its store (the verdict's output power is the FILTER's, in front of it).  The channeliser -- rotator -> decimate-by-8 complex FIR -- is this shape.
-template <int D, int KQ, bool HOOK> // decimation 4 / 8 / 16 / 32; K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 16 D samples in front of a tile's first output
+// HOOK == 2 (round 5): the load program is ONE rotator on a complex stream and there is no store program -- rotator -> decimating FIR, a down-converter -- : no program walk,
+// the phase of a lane's first sample from one 64-bit product per segment, every further one by an integer addition (ewise.hpp: bit-identical to HOOK == 1).
+template <int D, int KQ, int HOOK> // decimation 4 / 8 / 16 / 32; K-steps of 32 per wave: window 128 KQ samples, Hb = 128 KQ - 16 D samples in front of a tile's first output
 __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __restrict__ x, const float* __restrict__ hist /*hist[h] = x[-Kh + h]*/, int Kh,
                                                                   const unsigned short* __restrict__ tab, float* __restrict__ y, long n_out, long n_in,
                                                                   float* __restrict__ new_hist, int guard, int seg_per_wg /*<= kDhMaxSpw*/,
@@ -112,7 +114,22 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
         else load_general(0);
     };
     auto hook_loaded = [&](long sg) __attribute__((always_inline)) { // the prologue on the samples of x among the loaded ones (sg = 0: the history in front of them stays as it lies)
-        if constexpr (HOOK) {
+        if constexpr (HOOK == 2) {
+            // nxt[u] = complex samples kc, kc + 1 with kc = (sg kDhSegIn - Hb) / 2 + 2 (tid + 256 u) of this span: rotor index pos + kc + 1.  Samples past the span's end are
+            // zeros and stay zeros under a finite rotor; the history in front of position 0 (sg == 0 only) stays as it lies
+            BdRotor rot = bd_rotor_start(hk.pre, sg * kDhSegIn - Hb, tid);
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) {
+                const float4 v = nxt[u];
+                float4       w = bd_rotor_next(v, rot);
+                if (sg == 0) {
+                    const long fi = 4L * (tid + 256 * u) - Hb;
+                    if (fi < 0) { w.x = v.x; w.y = v.y; }
+                    if (fi + 2 < 0) { w.z = v.z; w.w = v.w; }
+                }
+                nxt[u] = w;
+            }
+        } else if constexpr (HOOK == 1) {
             if (hk.pre.n_ops > 0) {
 #pragma unroll
                 for (int u = 0; u < NL4; ++u) {
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (o + r < n_out) py = fmaf(v[r], v[r], py); // (the filter's output, in front of the store program)
-            if constexpr (HOOK) {
+            if constexpr (HOOK == 1) {
                 if (hk.post.n_ops > 0) { const float4 w = bd_hook4(make_float4(v[0], v[1], v[2], v[3]), hk.post, cplx, o); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
             }
             if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -237,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
         __syncthreads();
         if (guard && kind_prev == 0 && rejected(px_prev) && tid == 0) flags[slast - 1] = 3;
     }
-    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK>(x, hist, Kh, n_in, new_hist, tid, hk);
+    if (new_hist != nullptr && blockIdx.x == 0) bd_new_hist<HOOK != 0>(x, hist, Kh, n_in, new_hist, tid, hk);
 }
 
 // the table of fir_decim8_f16x2_kernel<KQ> (see dh_table_units): fragment (wave w, plane p, K-step ks, lane l, element t) = tap-plane value
@@ -304,7 +321,8 @@ template <int D>
 static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float* hist, int Kh, const unsigned short* tb, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx,
                                   const BdHooks& hk) {
     const bool hooked = hk.pre.n_ops > 0 || hk.post.n_ops > 0;
-    if (hooked && ((Kh % 4) != 0 || (D == 4 && KQ > 5))) return GR4HIP_UNSUPPORTED; // (fir.hip does not send these shapes here)
+    const bool ddc    = cplx && hk.pre.rotor_only && hk.pre.n_ops == 1 && hk.post.n_ops == 0 && (Kh % 4) == 0; // rotator -> decimator: the phase stepped in integers
+    if (hooked && !ddc && ((Kh % 4) != 0 || (D == 4 && KQ > 5))) return GR4HIP_UNSUPPORTED; // (fir.hip does not send these shapes here)
     static const int kSpwEnv = [] { const char* e = std::getenv("GR4HIP_DH_SPW"); return e ? std::atoi(e) : 0; }(); // developer knob
     const long nseg = ceil_div(n_out, (long)(kDhSegIn / D));
     const int  spw  = kSpwEnv ? kSpwEnv : (int)std::min<long>(std::max<long>(nseg / 512, 4), 32); // segments per workgroup: the tap fragments and the first staging once per run (2^27 inputs, D = 8: 4 / 8 / 16 / 32 / 64 segments measured 739 / 758 / 777 / 788 / 520 G at 1024 taps)
@@ -315,7 +333,7 @@ static int fir_decim_f16_launch_d(int KQ, const float* x, long n_in, const float
             constexpr int    NS  = kDhSegIn + 128 * K - 16 * D;                                                                                                          \
             constexpr size_t lds = (size_t)2 * (NS + 8 * (NS / 512 + 1) + 16) * sizeof(unsigned short);                                                                  \
             constexpr bool kHookFits = !(D == 4 && K > 5); /* (the hooked D = 4 kernels with 7 / 9 K-steps per wave would spill: never instantiated) */                           \
-            auto kern = (hooked && kHookFits) ? fir_decim_f16x2_kernel<D, K, kHookFits> : fir_decim_f16x2_kernel<D, K, false>;                                                                \
+            auto kern = ddc ? fir_decim_f16x2_kernel<D, K, 2> : ((hooked && kHookFits) ? fir_decim_f16x2_kernel<D, K, kHookFits ? 1 : 0> : fir_decim_f16x2_kernel<D, K, 0>);              \
             if (lds > 48 * 1024) GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* (per call: the attribute is per device) */ \
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, hist, Kh, tb, y, n_out, n_in, new_hist, guard, spw, flags, cplx, hk);                                   \
         } else return GR4HIP_UNSUPPORTED;                                                                                                                                \

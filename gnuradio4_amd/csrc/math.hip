@@ -309,20 +309,19 @@ __global__ __launch_bounds__(256) void rotator_apply_kernel(const float2* __rest
     }
 }
 
-// Closed-form phase (GR4HIP_ROTATOR_CLOSED_FORM): sample i of a call sees phase = carried + (i + 1) inc, evaluated in float64 turns and reduced
-// exactly: k inc = (k >> 20) (2^20 inc) + (k & 0xfffff) inc with both factors' fractional parts taken first, so the argument of the final fract() stays
-// below 2^21 turns (2^-32 turn resolution) however long the span.  One pass, 16 B per sample: HBM-bound.  The float recurrence of the reference
-// drifts ~1e-7 rad per step away from this value (the walker above reproduces that drift bit for bit); this one is the float64 oracle's phase.
+// Closed-form phase (GR4HIP_ROTATOR_CLOSED_FORM): sample i of a call sees phase = carried + (i + 1) inc, with phases and the increment as 64-bit fractions of a
+// turn (common.hpp: turns_fix): the sum modulo 2^64 IS the reduction modulo one turn, exact however long the span (round 5; until then float64 turns with the
+// product split at 2^20: four float64 operations and three conversions per sample where this takes three integer ones).  One pass, 16 B per sample: HBM-bound.
+// The float recurrence of the reference drifts ~1e-7 rad per step away from this value (the walker above reproduces that drift bit for bit); this one is the
+// float64 oracle's phase.
 template <bool V4> // V4: 16-byte accesses (both spans 16-byte aligned); otherwise one 8-byte sample per lane (a ring span may start at any element)
-__global__ __launch_bounds__(256) void rotator_closed_kernel(const float4* __restrict__ x, float4* __restrict__ y, double ph0_t /*carried phase in turns: float64, kept by the handle*/,
-                                                             double inc_t, double inc_t20, long n) {
+__global__ __launch_bounds__(256) void rotator_closed_kernel(const float4* __restrict__ x, float4* __restrict__ y, unsigned long long ph0 /*carried phase: a 64-bit fraction of a turn, kept by the handle*/,
+                                                             unsigned long long inc, int bad /*a non-finite carried phase: NaN out*/, long n) {
     const long   pairs  = (n + 1) / 2;
     auto         rot    = [&](long k, float re, float im, float& ore, float& oim) { // k = sample index + 1
-        double t = fma((double)(k & 0xfffff), inc_t, ph0_t);
-        t        = fma((double)(k >> 20), inc_t20, t);
-        t -= rint(t); // [-0.5, 0.5] turns
-        const float tf = (float)t; // the hardware sine / cosine take turns (max |error| 1.25e-7 on [-0.5, 0.5), tools/ubench/native_sincos_accuracy.hip; ewise.hpp: ew_rotor is the same arithmetic)
-        const float sn = __builtin_amdgcn_sinf(tf), cs = __builtin_amdgcn_cosf(tf);
+        float cs, sn;
+        rotor_at(ph0 + (unsigned long long)k * inc, cs, sn); // (ewise.hpp: ew_rotor is the same arithmetic)
+        if (bad) cs = sn = __builtin_nanf("");
         ore = re * cs - im * sn;
         oim = re * sn + im * cs;
     };
@@ -424,8 +423,9 @@ struct gr4hip_rotator {
     float        inc  = 0.f;
     int          algo = GR4HIP_ROTATOR_CLOSED_FORM;
     int          cur  = 0; // state slot in use
-    double       ph_t = 0.0; // closed form: the carried phase in TURNS, float64, advanced on the host (inc is a host constant: nothing to read back, and no
-                             // rounding to float between calls -- one float per call is a 2.4e-7 rad random walk, beyond 1e-5 after a few thousand small calls)
+    unsigned long long ph_fix = 0; // closed form: the carried phase as a 64-bit fraction of a turn, advanced on the host (inc is a host constant: nothing to read back,
+                                   // and no rounding between calls -- one float per call is a 2.4e-7 rad random walk, beyond 1e-5 after a few thousand small calls)
+    bool               ph_bad = false; // a non-finite initial phase: NaN out
     DeviceBuffer d_state; // recurrence: _accumulated_phase as the reference's float
     DeviceBuffer d_ckpt;
     float*       state() const { return static_cast<float*>(d_state.ptr) + cur; }
@@ -470,7 +470,8 @@ int gr4hip_rotator_create(gr4hip_rotator_t** out, float phase_increment, float i
 int gr4hip_rotator_reset(gr4hip_rotator_t* r, float initial_phase) {
     GR4_REQUIRE(r, "rotator: null handle");
     GR4_HIP_TRY(hipMemcpy(r->state(), &initial_phase, sizeof(float), hipMemcpyHostToDevice));
-    r->ph_t = (double)initial_phase / 6.283185307179586476925286766559;
+    r->ph_bad = !std::isfinite(initial_phase);
+    r->ph_fix = r->ph_bad ? 0 : turns_fix((double)initial_phase / 6.283185307179586476925286766559);
     return GR4HIP_OK;
 }
 
@@ -481,12 +482,13 @@ int gr4hip_rotator_set_algo(gr4hip_rotator_t* r, int algo) {
     // the carried phase changes hands (rare: a settings change, not a per-call operation): everything queued on the handle finishes first
     GR4_HIP_TRY(hipDeviceSynchronize());
     if (algo == GR4HIP_ROTATOR_RECURRENCE) {
-        const float ph = (float)((r->ph_t - std::floor(r->ph_t)) * 6.283185307179586476925286766559);
+        const float ph = r->ph_bad ? std::nanf("") : (float)(fix_turns(r->ph_fix) * 6.283185307179586476925286766559);
         GR4_HIP_TRY(hipMemcpy(r->state(), &ph, sizeof(float), hipMemcpyHostToDevice));
     } else {
         float ph = 0.f;
         GR4_HIP_TRY(hipMemcpy(&ph, r->state(), sizeof(float), hipMemcpyDeviceToHost));
-        r->ph_t = (double)ph / 6.283185307179586476925286766559;
+        r->ph_bad = !std::isfinite(ph);
+        r->ph_fix = r->ph_bad ? 0 : turns_fix((double)ph / 6.283185307179586476925286766559);
     }
     r->algo = algo;
     return GR4HIP_OK;
@@ -497,18 +499,15 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "rotator: null device pointer");
     hipStream_t  st      = as_stream(stream);
-    if (r->algo == GR4HIP_ROTATOR_CLOSED_FORM && r->inc == r->inc) { // (a NaN increment takes the recurrence: NaN in, NaN out, like the reference)
-        const double inc_t = (double)r->inc / 6.283185307179586476925286766559, inc20 = inc_t * 1048576.0;
+    if (r->algo == GR4HIP_ROTATOR_CLOSED_FORM && std::isfinite(r->inc)) { // (a NaN / infinite increment takes the recurrence: NaN out, like the reference)
+        const unsigned long long inc = turns_fix((double)r->inc / 6.283185307179586476925286766559);
         const bool   v4    = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
         const size_t items = v4 ? (n + 1) / 2 : n;
         const unsigned grid = (unsigned)std::min<size_t>(ceil_div(items, (size_t)256), (size_t)1 << 20);
-        const double f1 = inc_t - std::floor(inc_t), f20 = inc20 - std::floor(inc20);
-        if (v4) hipLaunchKernelGGL(rotator_closed_kernel<true>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->ph_t, f1, f20, (long)n);
-        else hipLaunchKernelGGL(rotator_closed_kernel<false>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->ph_t, f1, f20, (long)n);
+        if (v4) hipLaunchKernelGGL(rotator_closed_kernel<true>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->ph_fix, inc, (int)r->ph_bad, (long)n);
+        else hipLaunchKernelGGL(rotator_closed_kernel<false>, dim3(grid), dim3(256), 0, st, (const float4*)d_in, (float4*)d_out, r->ph_fix, inc, (int)r->ph_bad, (long)n);
         GR4_LAUNCH_CHECK();
-        double t = std::fma((double)(n & 0xfffff), f1, r->ph_t); // the phase the next call starts from, in [0, 1) turns
-        t        = std::fma((double)(n >> 20), f20, t);
-        r->ph_t  = t - std::floor(t);
+        r->ph_fix += (unsigned long long)n * inc; // the phase the next call starts from (modulo one turn, exactly)
         return GR4HIP_OK;
     }
     // the reference's float recurrence, bit for bit
@@ -530,8 +529,8 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
 
 int gr4hip_rotator_phase(gr4hip_rotator_t* r, float* phase, gr4hip_stream_t stream) {
     GR4_REQUIRE(r && phase, "rotator_phase: null argument");
-    if (r->algo == GR4HIP_ROTATOR_CLOSED_FORM && r->inc == r->inc) { // known on the host: the phase behind everything queued so far
-        *phase = (float)((r->ph_t - std::floor(r->ph_t)) * 6.283185307179586476925286766559);
+    if (r->algo == GR4HIP_ROTATOR_CLOSED_FORM && std::isfinite(r->inc)) { // known on the host: the phase behind everything queued so far
+        *phase = r->ph_bad ? std::nanf("") : (float)(fix_turns(r->ph_fix) * 6.283185307179586476925286766559);
         return GR4HIP_OK;
     }
     GR4_HIP_TRY(hipMemcpyAsync(phase, r->state(), sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));

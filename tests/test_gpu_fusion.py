@@ -237,6 +237,28 @@ def test_hooked_fir_answers_to_the_guard(G, cplx, ntaps, decim):
 
 
 
+@pytest.mark.parametrize("ntaps,decim", [(64, 8), (128, 4), (520, 4), (64, 16), (100, 32), (80, 10), (300, 5), (700, 8)])
+def test_down_converter_steps_the_rotor_in_integers(G, ntaps, decim):
+    """rotator -> decimating complex FIR (a down-converter: the channeliser's front end): the band-form decimators recognise a load program that is ONE rotator and step
+    its phase -- a 64-bit fraction of a turn -- by integer additions instead of walking the program per sample (fir_band_hooks.hpp: BdRotor).  The phase is exact modulo
+    2^64 either way, so the launch must be BIT-identical to the same filter with the program walked (a second op, + 0, keeps it off the special path), in ragged calls
+    whose history is the rotor's output; and it answers to the float64 oracle"""
+    n = 8 * 8192 * decim
+    x = O.signal_c32(7, n)
+    b = O.design_taps_hamming_lowpass(ntaps, 0.4 / decim)
+    xd = dev(x)
+    for inc, ph0 in ((0.3, 0.25), (-2.9, 1.0), (1e-4, -0.5)):
+        truth = _fir64(b, _program_on_cpu64(x, [("Rotator", inc, ph0)]), decim)
+        outs = []
+        for prog in ([("Rotator", inc, ph0)], [("Rotator", inc, ph0), ("Add", 0.0)]):
+            f = G.fir_filter(b, torch.complex64, decimate=decim)
+            f.set_prologue(G.Merged(torch.complex64, prog))
+            cuts = [0, 2 * decim, 1001 * decim, (n // decim // 2) * decim, n]
+            outs.append(torch.cat([f.process_bulk(xd[a:b_]) for a, b_ in zip(cuts[:-1], cuts[1:])]))
+        assert bool((outs[0] == outs[1]).all()), (inc, ph0)
+        assert _rel(outs[0].cpu().numpy(), truth) <= 1e-5, (inc, ph0)
+
+
 def test_fir_prologue_replaced_in_mid_stream(G):
     """a gain step in front of a filter (settings-by-tag on the MultiplyConst of MultiplyConst -> fir_filter): the samples already in the filter's history keep
     the OLD gain, exactly as when the two blocks run one after the other; the same for a hook (AddConst) replaced by another"""
