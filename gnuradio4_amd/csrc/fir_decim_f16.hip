@@ -52,9 +52,13 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[2][KQ], const uns
             const int ks = m - TS * tr;
             if (ks < 0 || ks >= KQ) continue;
             const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a[1][ks]);
+#ifdef GR4_T_DH_NOMFMA // timing-only builds (tools/ab_dh.sh, profiles/r05_decim_bounds.txt): the operand reads without the products
+            asm volatile("" ::"v"(a1), "v"(a2), "v"(b1), "v"(b2));
+#else
             c[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[tr], 0, 0, 0);
             d[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, d[tr], 0, 0, 0);
             d[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, d[tr], 0, 0, 0);
+#endif
         }
     }
 #pragma unroll
@@ -221,7 +225,9 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
         int   kind_prev = -1; // (nothing to judge yet)
         for (long sg = sfirst; sg < slast; ++sg) {
             hook_loaded(sg);
+#ifndef GR4_T_DH_NOSTATS // timing-only: whatever the statistics words hold
             put_stats();
+#endif
             __syncthreads(); // the statistics are complete; every wave is done with the planes, the partial tiles and the verdict words of the segment before
             float     s, inv_s, px;
             const int kind = block_scale(s, inv_s, px);
@@ -231,19 +237,33 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
                 const int q = tid + 256 * u;
                 if (256 * (u + 1) <= NS / 4 || q < NS / 4) {
                     unsigned h0, l0, h1, l1;
+#ifdef GR4_T_DH_NOSPLIT // timing-only: the samples' bits
+                    h0 = __float_as_uint(nxt[u].x), l0 = __float_as_uint(nxt[u].y), h1 = __float_as_uint(nxt[u].z), l1 = __float_as_uint(nxt[u].w);
+#else
                     hf_split2(nxt[u].x, nxt[u].y, s, h0, l0);
                     hf_split2(nxt[u].z, nxt[u].w, s, h1, l1);
+#endif
                     *reinterpret_cast<uint2*>(pls + P(4 * q))      = make_uint2(h0, h1);
                     *reinterpret_cast<uint2*>(pls + PL + P(4 * q)) = make_uint2(l0, l1);
                 }
             }
+#ifndef GR4_T_DH_NOLOAD // timing-only: every segment is the run's first again
             if (sg + 1 < slast) load_next(sg + 1);
+#endif
             __syncthreads();
+#ifdef GR4_T_DH_NOCONTRACT // timing-only: no operand reads, no products, no partial tiles
+            if (kind == 0 && n_out < 0) dh_contract<D, KQ, PL>(a, pls, part, wave, lane);
+#else
             if (kind == 0) dh_contract<D, KQ, PL>(a, pls, part, wave, lane);
+#endif
             else if (tid == 0) flags[sg] = (unsigned char)kind;
             __syncthreads();
             float py = 0.f;
+#ifdef GR4_T_DH_NOOUT // timing-only: nothing leaves
+            if (kind == 0 && n_out < 0) take_out(sg, inv_t * inv_s, py);
+#else
             if (kind == 0) take_out(sg, inv_t * inv_s, py);
+#endif
             if (wave >= TR) py = 0.f;                                                                  // (no tile row of its own: nothing to add to the columns' sums)
             else if (kind != 0 || sg * SO + (long)(16 * TR) * col >= n_out) py = __builtin_inff(); // (nothing to judge; a column past the end of the span)
             py = hf_column_sum(py);

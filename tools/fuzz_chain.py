@@ -22,6 +22,7 @@ while time.time() - t0 < secs:
     n = frames * N
     taps = lowpass(nt, float(rng.choice([0.02, 0.05, 0.2])))
     x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    start = -N
     if rng.random() < 0.6:  # an interferer far outside the pass band, 20 .. 50 dB above the noise, from a random sample on
         start = int(rng.integers(0, n)); amp = 10 ** (float(rng.uniform(20, 50)) / 20)
         x[start:] += (amp * np.exp(2j * np.pi * 0.41 * np.arange(n - start))).astype(np.complex64)
@@ -52,6 +53,10 @@ while time.time() - t0 < secs:
     # the contract (include/gr4hip.h): 1e-5 of the output, or the reference's own float32 error where that is larger -- factor ONE
     if r > max(1e-5, r32):
         fails = globals().get("fails", 0) + 1
-        if fails <= 12: print("FAIL", f"N={N} taps={nt} win={win} frames={frames} cuts={cuts} ratio={ratio}", r, "reference float32 FIR:", r32, flush=True)
+        if fails <= 12:
+            e = np.abs(got - truth) / np.maximum(truth, rms)
+            fr = int(np.unravel_index(e.argmax(), e.shape)[0])
+            p_in = float(np.mean(np.abs(x.reshape(frames, N)[fr].astype(np.complex128)) ** 2)); p_out = float(truth[fr].sum() / (N * N * np.mean(w * w if win != "None" else 1.0)))
+            print("FAIL", f"N={N} taps={nt} win={win} frames={frames} cuts={cuts} ratio={ratio} worst frame {fr} (its own output / input power {p_out / p_in:.4g}; interferer from sample {locals().get('start', -1) / N:.3f} frames)", r, "reference float32 FIR:", r32, flush=True)
     worst_excess = max(globals().get("worst_excess", 0.0), r - max(1e-5, r32))
 print(f"{cases} cases in {time.time() - t0:.0f} s ({switched} ended on the time-domain kernels), {globals().get('fails', 0)} above max(1e-5, the reference's float32 error), worst relative error of |Y|^2 {worst:.3g}, worst excess over the bar {globals().get('worst_excess', 0.0):.3g}")
