@@ -210,19 +210,35 @@ def secondary_configs(G, verify):
         return (t / t.sum()).astype(np.float32)
 
     def rate(fn, reps, rounds=5):
+        """median ms per call over `rounds` groups of back-to-back calls (>= 30 ms each) between events, with NO host synchronisation between the groups and >= 60 ms of
+        back-to-back calls in front: the first ~20 ms after a host sync run at a sagged clock (profiles/r02_clock_ramp.txt; the headline's own pre-warm exists for the same
+        reason).  Until round 5 this synchronised after every group of 20 calls (4 - 10 ms), which under-reported these rows by ~10 % against tools/_timing.py's steady()."""
+        import time
         fn()
         torch.cuda.synchronize()
-        ms = []
-        for _ in range(rounds):
-            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a_.record()
-            for _ in range(reps):
+        t0, k = time.perf_counter(), 0
+        while True:
+            fn()
+            k += 1
+            if k % 4 == 0:
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0 >= 0.06:
+                    break
+        per = (time.perf_counter() - t0) / k
+        n = max(reps, int(0.03 / max(per, 1e-6)))
+        for _ in range(max(4, int(0.02 / max(per, 1e-6)))):  # the syncs above let the clock sag again: run up, no sync from here on
+            fn()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(rounds + 1)]
+        ev[0].record()
+        for r in range(rounds):
+            for _ in range(n):
                 fn()
-            b_.record()
-            b_.synchronize()
-            ms.append(a_.elapsed_time(b_) / reps)
+            ev[r + 1].record()
+        ev[-1].synchronize()
+        ms = [ev[r].elapsed_time(ev[r + 1]) / n for r in range(rounds)]
         return sorted(ms)[len(ms) // 2]
 
+    TIMING_NOTE = "steady state: >= 60 ms of back-to-back launches in front, median of 5 groups of >= 30 ms between events, no host sync between the groups (until round 5: a sync per 20 launches, ~10 % lower)"
     out = {}
     O = _oracle() if verify else None
     # configs[3]: 64 channels x 256 taps (csrc/fir_f16.hip: two-term f16 splits under a block exponent on the f16 matrix pipe, every segment judged)
@@ -236,6 +252,7 @@ def secondary_configs(G, verify):
            "ms_per_launch": round(ms, 4), "bytes_per_sample": 8, "hbm_frac": round(nch * n * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "float32_equivalent_TFLOP/s": round(nch * n * 2 * ntaps / (ms * 1e-3) / 1e12, 1), "executed_f16_TFLOP/s": round(nch * n * 3 * 2 * 288 / (ms * 1e-3) / 1e12, 1)}
     row["arithmetic"] = "f16x2 (two-term f16 splits under a per-segment block exponent: 22-bit products, float32 accumulation; segments that reject > 21 dB again in float64)"
+    row["timing"] = TIMING_NOTE
     try:  # the 24-bit form beside it: three-term bf16 products (csrc/fir_bf16.hip) on the same launch
         capi.developer_switch("GR4HIP_FIR_NO_F16X2", 1)
         fb3 = G.FirBatched(taps)
@@ -274,6 +291,7 @@ def secondary_configs(G, verify):
     row = {"workload": "decimate-by-8 1024-tap float FIR (csrc/fir_decim_f16.hip) + 4 biquads x 2^27 input samples (BASELINE.json configs[2]), two launches", "value": round(n2 / (ms * 1e-3) / 1e6, 1),
            "unit": "Msamples/s (input rate)", "ms_per_pass": round(ms, 4), "bytes_per_input_sample": 5.5, "hbm_frac": round(n2 * 5.5 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     row["arithmetic"] = "decimator: f16x2 (22-bit products, float32 accumulation; segments that reject > 21 dB again in float64); cascade: float32, exact parallel-in-time scan"
+    row["timing"] = TIMING_NOTE
     try:  # the 24-bit forms beside it: the frequency-domain decimator (float32 transforms) -- what decimate-by-8 at 1024 taps takes without the f16 kernel
         capi.developer_switch("GR4HIP_FIR_NO_DECIM_F16", 1)
         fir3, iir3 = G.fir_filter(b1024, torch.float32, decimate=8), G.iir_filter(bi, ai)

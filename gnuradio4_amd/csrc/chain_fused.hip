@@ -85,7 +85,8 @@ struct ChainFdArgs {
 #endif
 constexpr int   kLdsEbfBytes = (2 * kSLen + 512 + 256) * 8 + 4 * 2 * 256 * 4 + 6 * 512 * 2; // LDS of the non-windowed filter modes (= lds_ebf of chain_fused_run); the 16 verdict words follow it
 constexpr int   kPwFrameSlots = 40, kPwMaxWorkgroups = 2048; // ChainFdArgs::pw: words 0 .. 35 as before, then two words per workgroup for the frames' verdicts
-constexpr float kGuardFrameThreshold = 0.04f; // the guard's output / input power threshold (chain.hip, fir.hip), applied to every frame by itself inside the kernel
+constexpr float kGuardFirFrameThreshold = 0.04f; // the FIR-only fast convolution (fir.hip): its output is y itself, not |Y|^2
+constexpr float kGuardFrameThreshold = 0.08f; // the guard's output / input power threshold (chain.hip, fir.hip), applied to every frame by itself inside the kernel
 constexpr int kMaxMulti = 16;
 struct ChainFdMulti {
     int           n_ch, fold_ch;
@@ -1260,7 +1261,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         a.pw      = static_cast<float*>(c->d_pw.ptr);
         a.pw_host = c->d_hpw;
         a.pw_seq  = c->pw_seq;
-        a.pw_thr  = kGuardFrameThreshold * (fir_mode ? 1.f : (float)(c->small_log2n ? (1 << c->small_log2n) : kN) * c->win_gain); // (the scale chain_fused_power_ratio takes out)
+        a.pw_thr  = fir_mode ? kGuardFirFrameThreshold : kGuardFrameThreshold * (float)(c->small_log2n ? (1 << c->small_log2n) : kN) * c->win_gain; // (the scale chain_fused_power_ratio takes out)
         if (c->redo && !fir_mode) {
             rc = c->d_fflags.ensure(n_frames);
             if (rc) return rc;
@@ -1548,7 +1549,8 @@ int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* r
     *ratio = in > 0 ? (float)(out / (in * (fir_output ? 1.0 : nfft * c->win_gain))) : 1.f;
     // the launch-wide ratio can hide a frame: an interferer that arrives late in a long span barely moves the sums.  Every frame is judged by itself in the kernel
     // (a quarter of its points, per wave); a launch with ONE frame below the threshold reports below the threshold
-    if (reinterpret_cast<volatile unsigned*>(c->h_pw)[3] != 0u && *ratio >= kGuardFrameThreshold) *ratio = 0.5f * kGuardFrameThreshold;
+    const float thr = fir_output ? kGuardFirFrameThreshold : kGuardFrameThreshold;
+    if (reinterpret_cast<volatile unsigned*>(c->h_pw)[3] != 0u && *ratio >= thr) *ratio = 0.5f * thr;
     return 1;
 }
 const float* chain_fused_history(const ChainFused* c) { return static_cast<const float*>(c->d_hist.ptr); } // the 256 samples before the next call's first frame

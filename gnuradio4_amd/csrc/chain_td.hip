@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
 // sched_group_barrier does not finish on a 272-MFMA region.)
 
 struct ChainTd {
-    float        gthr = 0.f;      // (sum b^2) / 128: the FIR guard's threshold (fir.hip kGuardSegmentRatio); chain_td_process passes it unless the guard is off
+    float        gthr = 0.f;      // (sum b^2) / 32: the FIR guard (fir.hip kGuardSegmentRatio) 6 dB earlier; chain_td_process passes it unless the guard is off
     DeviceBuffer d_flags;         // one byte per 4096-sample segment of the last launch
     size_t       ntaps = 0, N = 0;
     int          KS = 0, Kp = 0, log2n = 0;
@@ -346,7 +346,7 @@ int chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_s
     {
         double h2 = 0;
         for (size_t k = 0; k < ntaps; ++k) h2 += (double)taps[k] * taps[k];
-        c->gthr = (float)(h2 / 128.0);
+        c->gthr = (float)(h2 / 32.0); // (the FIR guard of fir.hip is at 1 / 128: this kernel squares the filter output behind its transform, which doubles the split products' relative error -- chain.hip kChainPairGuardRatio)
     }
     (void)hipGetDevice(&c->dev);
     c->log2n = (int)ilog2(fft_size);

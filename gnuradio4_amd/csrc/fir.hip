@@ -342,6 +342,7 @@ struct gr4hip_fir {
     DeviceBuffer       d_taps;     // [D][Qpad]
     DeviceBuffer       d_tapsf;    // the taps as they are (what fir_exact_kernel multiplies with)
     double             tap_power = 0; // sum b^2 of `taps` (the guard's thresholds are multiples of it)
+    double             guard_ratio = kGuardSegmentRatio; // (library-internal callers may tighten it: the chain's kernel pair squares this filter's output -- chain.hip)
     DeviceBuffer       d_flags_fd; // the same for the frequency-domain kernels' spans (judged behind their launch at their own thresholds)
     DeviceBuffer       d_flags;    // one byte per segment of the f16 matrix-pipe kernels' last launch: the segments fir_exact_kernel evaluates again behind it
     DeviceBuffer       d_hist[2];  // ping-pong history (hcap samples each)
@@ -429,7 +430,7 @@ static int fir_launch_h(const gr4hip_fir* f, const float* x, const float* hist, 
     const long TOs  = BS * kFirR / S;
     const long grid = ceil_div(n_out, TOs);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BS), lds, st, x, hist, (const float*)f->d_taps.ptr, y, n_in, n_out,
-                       (int)f->hcap, (int)f->decim, f->G, new_hist, hk.pre, hk.post, f->guard_mode != GR4HIP_GUARD_OFF && f->ntaps > 1 ? (float)(f->tap_power * kGuardSegmentRatio) : 0.f);
+                       (int)f->hcap, (int)f->decim, f->G, new_hist, hk.pre, hk.post, f->guard_mode != GR4HIP_GUARD_OFF && f->ntaps > 1 ? (float)(f->tap_power * f->guard_ratio) : 0.f);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
@@ -750,6 +751,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             std::vector<unsigned short> af;
             if (!fir_f16_make_afrag(f->taps.data(), f->ntaps, &f->hfKS, &af, 1, 0)) f->hfKS = -1;
             else {
+                if (f->guard_ratio != kGuardSegmentRatio) { const float g = (float)(f->tap_power * f->guard_ratio); std::memcpy(af.data() + (size_t)f->hfKS * 1536 + 4, &g, 4); } // (the table's header: fir_f16_make_afrag)
                 rc = f->d_hfrag.ensure(af.size() * sizeof(unsigned short));
                 if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
                 if (rc) { f->hfKS = 0; return rc; }
@@ -850,7 +852,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             const double h2 = f->tap_power;
             for (size_t p = 0; p < nslice && !rc; ++p)
                 rc = fir_f16_launch(f->hf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_hfrag.ptr + f->hf_off[p], y, st, p == 0 ? nh : nullptr, 0, 0, 1, (int)(256 * p), p > 0,
-                                    p + 1 == nslice && f->guard_mode != GR4HIP_GUARD_OFF, (unsigned char*)f->d_flags.ptr, 0, nslice > 1 ? (float)(h2 * kGuardSegmentRatio) : 0.f);
+                                    p + 1 == nslice && f->guard_mode != GR4HIP_GUARD_OFF, (unsigned char*)f->d_flags.ptr, 0, (nslice > 1 || f->guard_ratio != kGuardSegmentRatio) ? (float)(h2 * f->guard_ratio) : 0.f);
             if (rc) return rc;
             rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, 1, 0, y, (long)n_in, (const unsigned char*)f->d_flags.ptr, 12, nullptr, st);
             if (rc) return rc;
@@ -961,7 +963,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             const double h2 = f->tap_power;
             rc = fir_decim_bf16_launch(f->bdKS, (int)f->decim, f->bdHb, x, (long)(n_in * f->S), hist, (int)(f->hcap * f->S), f->d_bdfrag.ptr, y, (long)(n_out * f->S), st, nh,
                                        hk.pre.n_ops > 0 ? &hk.pre : nullptr, hk.post.n_ops > 0 ? &hk.post : nullptr, f->S == 2, judged ? (unsigned char*)f->d_flags.ptr : nullptr,
-                                       (float)(h2 * kGuardSegmentRatio), &seg_out);
+                                       (float)(h2 * f->guard_ratio), &seg_out);
             if (rc == GR4HIP_OK && judged)
                 rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, f->S == 2, y, (long)n_out, (const unsigned char*)f->d_flags.ptr,
                                       ilog2((size_t)(seg_out / f->S)), nullptr, st, 1, 0, 0, 0, 0, &hk.pre, &hk.post);
@@ -1085,7 +1087,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         if (no > 0) {
             rc = f->d_flags.ensure((size_t)ceil_div(no, 1L << shift));
             if (rc) return rc;
-            rc = fir_judge_launch(xr, ni, yr, no, (int)f->decim, f->S == 2, shift, (float)(f->tap_power * kGuardSegmentRatio), (unsigned char*)f->d_flags.ptr, st);
+            rc = fir_judge_launch(xr, ni, yr, no, (int)f->decim, f->S == 2, shift, (float)(f->tap_power * f->guard_ratio), (unsigned char*)f->d_flags.ptr, st);
             if (rc) return rc;
             rc = fir_exact_launch(xr, ni, unj_hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, f->S == 2, yr, no, (const unsigned char*)f->d_flags.ptr, shift, nullptr, st);
             if (rc && rc != GR4HIP_UNSUPPORTED) return rc; // (UNSUPPORTED: decimation x taps beyond what the second evaluation stages -- the float32 sums stand)
@@ -1169,6 +1171,13 @@ extern "C" int gr4hip_fir_iir_process(gr4hip_fir_t* f, gr4hip_iir_t* iir, const 
 
 // (library-internal, chain.hip) make `d_last256` -- the 256 complex samples in front of the next input sample -- this filter's history: the fused chain
 // hands its stream over to the direct-form kernels when the dynamic-range guard switches algorithms
+// (library-internal, chain.hip) the per-segment guard's threshold as a multiple of (sum b^2): before the first call (the matrix-pipe kernels' tables carry it).  Non-decimating filters only
+int gr4hip_internal_fir_set_guard_ratio(gr4hip_fir_t* f, double ratio) {
+    GR4_REQUIRE(f && f->decim == 1 && ratio > 0 && ratio <= 1.0, "fir_set_guard_ratio: a non-decimating filter and a ratio in (0, 1] expected");
+    f->guard_ratio = ratio;
+    if (f->hfKS > 0) f->hfKS = 0; // (a table built already is built again with the new threshold)
+    return GR4HIP_OK;
+}
 int gr4hip_internal_fir_load_history(gr4hip_fir_t* f, const float* d_last256, hipStream_t st) {
     GR4_REQUIRE(f && f->S == 2 && f->hcap <= 256, "fir_load_history: complex filter with <= 256 samples of history expected");
     GR4_HIP_TRY(hipMemcpyAsync(f->d_hist[f->cur].ptr, d_last256 + (256 - f->hcap) * 2, f->hcap * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -1660,7 +1660,7 @@ def test_chain_dynamic_range_and_the_time_domain_algo(G):
         if algo == G.capi.CHAIN_AUTO:
             assert _rel(got, truth) <= TOL  # every frame, the probed first ones included
             ratio, td = ch.last_power_ratio()
-            assert not td and 0 <= ratio < 0.04, (ratio, td)  # (the call's marked frames were evaluated again on the device, behind the fused launch: nobody waited, nothing switched yet)
+            assert not td and 0 <= ratio < 0.08, (ratio, td)  # (the call's marked frames were evaluated again on the device, behind the fused launch: nobody waited, nothing switched yet)
             # ... the next call finds that measurement and moves the stream to the time-domain kernels (history handed over), where it stays until reset
             x2 = O.signal_c32(78, 4 * N, tone_frel=0.31, tone_amp=30.0)
             t2, _ = O.chain(b, np.concatenate([x, x2]), N, 3, truth=True)
@@ -1774,7 +1774,7 @@ def test_chain_guard_hands_small_fft_sizes_to_the_fused_time_domain_kernel(G):
     cut = 650 * N
     got = np.concatenate([ch.process_bulk(dev(x[:cut])).cpu().numpy().ravel(), ch.process_bulk(dev(x[cut:])).cpu().numpy().ravel()])
     ratio, td = ch.last_power_ratio()
-    assert td and 0 <= ratio < 0.04, (ratio, td)
+    assert td and 0 <= ratio < 0.08, (ratio, td)
     assert _rel(got, truth) <= TOL
     fd = G.Chain(b, N, "Hann", G.capi.CHAIN_FUSED_FD).process_bulk(dev(x)).cpu().numpy().ravel()
     assert _rel(fd, truth) > TOL  # what the guard is for
@@ -1794,10 +1794,10 @@ def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
     assert ch.algo == G.capi.CHAIN_FUSED_FD
     parts = [ch.process_bulk(dev(clean)).cpu().numpy().ravel()]
     r, td = ch.last_power_ratio()
-    assert not td and r > 0.04
+    assert not td and r > 0.08
     parts.append(ch.process_bulk(dev(loud)).cpu().numpy().ravel())     # every frame measured below the threshold -> evaluated again in the time domain behind the fused launch (chain_redo_kernel)
     r, td = ch.last_power_ratio()
-    assert 0 <= r < 0.04 and not td                                    # (the stream moves with the NEXT call, which finds this measurement without waiting for it)
+    assert 0 <= r < 0.08 and not td                                    # (the stream moves with the NEXT call, which finds this measurement without waiting for it)
     parts.append(ch.process_bulk(dev(loud)).cpu().numpy().ravel())
     assert ch.last_power_ratio()[1]
     assert _rel(parts[0], t[0]) <= TOL and _rel(parts[1], t[1]) <= TOL and _rel(parts[2], t[2]) <= TOL
@@ -1812,7 +1812,7 @@ def test_chain_guard_switches_mid_stream_and_not_on_ordinary_input(G):
     pd = [cd.process_bulk(dev(clean)).cpu().numpy().ravel()]
     pd.append(cd.process_bulk(dev(loud)).cpu().numpy().ravel())        # still fused: this call is the one that measures the drop
     r, td = cd.last_power_ratio()
-    assert 0 <= r < 0.04 and not td
+    assert 0 <= r < 0.08 and not td
     pd.append(cd.process_bulk(dev(loud)).cpu().numpy().ravel())        # switched before this call, history carried over
     assert cd.last_power_ratio()[1]
     assert _rel(pd[0], t[0]) <= TOL and _rel(pd[2], t[2]) <= TOL
@@ -1911,7 +1911,7 @@ def test_guard_sees_every_frame_and_block(G, devsw):
         assert ch.algo == G.capi.CHAIN_FUSED_FD
         got = ch.process_bulk(dev(xi)).cpu().numpy().ravel()
         r, td = ch.last_power_ratio()
-        assert not td and r < 0.04, (first, count, r)             # the launch-wide ratio alone is ~0.3: one frame below the threshold marks the launch (and chain_redo_kernel evaluates the marked frames again)
+        assert not td and r < 0.08, (first, count, r)             # the launch-wide ratio alone is ~0.3: one frame below the threshold marks the launch (and chain_redo_kernel evaluates the marked frames again)
         assert _rel(got, truth) <= TOL, (first, count)
     # the frequency-domain decimator: a blocker in the last 3 of 700 blocks
     D, nt = 8, 1024
@@ -1929,6 +1929,36 @@ def test_guard_sees_every_frame_and_block(G, devsw):
     devsw("GR4HIP_FIR_NO_DECIM_F16", 0)
 
 
+def test_chain_kernel_pair_squares_its_filter_output(G):
+    """round 5 (tools/fuzz_chain.py 120 41, case 828; tools/dbg_chain_case828.py): a 65-tap / fc 0.02 filter in front of a BlackmanHarris 8192-point transform, a tone ~20 dB
+    above the noise far outside the pass band: the frames sit 33 dB below their input -- 19 dB more than white noise loses, 2 dB short of the FIR guard's 21 dB -- so the
+    kernel pair's filter (two-term f16 products) left them unmarked at ~5e-6 of the OUTPUT, and |Y|^2 doubles that: 1.015e-5 where the reference's float32 chain is at 6e-7.
+    The pair's filter and the fused time-domain kernel now mark 6 dB earlier (chain.hip kChainPairGuardRatio).  Per-frame metric, as the fuzzer's."""
+    from scipy.signal import lfilter
+    N, ntaps, frames, on = 8192, 65, 20, 4
+    k = np.arange(ntaps)
+    b = np.hamming(ntaps) * 0.04 * np.sinc(0.04 * (k - (ntaps - 1) / 2))
+    b = (b / b.sum()).astype(np.float32)
+    rng = np.random.default_rng(828)
+    noise = (rng.standard_normal(frames * N) + 1j * rng.standard_normal(frames * N)).astype(np.complex64)
+    tone = np.exp(2j * np.pi * 0.41 * np.arange((frames - on) * N))
+    w = O.window(7, N, np.float32).astype(np.float64)
+    worst = 0.0
+    for db in (19.5, 20.0, 20.48, 21.0, 21.5, 22.0):
+        x = noise.copy()
+        x[on * N:] += (10 ** (db / 20) * tone).astype(np.complex64)
+        y = lfilter(b.astype(np.float64), [1.0], x.astype(np.complex128)).reshape(frames, N) * w
+        truth = np.abs(np.fft.fft(y, axis=1)) ** 2
+        rms = np.sqrt(np.mean(truth ** 2, axis=1, keepdims=True))
+        for algo in (G.capi.CHAIN_UNFUSED, G.capi.CHAIN_AUTO):
+            ch = G.Chain(b, N, "BlackmanHarris", algo)
+            got = np.concatenate([ch.process_bulk(dev(x[:on * N])).cpu().numpy(), ch.process_bulk(dev(x[on * N:])).cpu().numpy()]).reshape(frames, N)
+            worst = max(worst, float(np.max(np.abs(got - truth) / np.maximum(truth, rms))))
+    # measured: 1.04e-6 (the reference's float32 chain: 6 - 8e-7); with the FIR guard's own 21 dB threshold (developer build -DGR4_T_PAIR_GUARD_128) 8.3e-6 on this data and 1.015e-5 on the
+    # fuzzer's -- so the pin is well inside the bar, not at it
+    assert worst <= 3e-6, worst
+
+
 def test_guard_destination_multiplies_in_float32(G):
     """where the guard sends a stream -- a rejected signal far above the output -- is where product precision shows: the three-term bf16 products keep everything
     above 2^-23 of a product (3 .. 16 x the error of a float32 sum there), so the guard's destination and GR4HIP_CHAIN_TIME_DOMAIN run the direct form with
@@ -1941,7 +1971,7 @@ def test_guard_destination_multiplies_in_float32(G):
     truth, _ = O.chain(b, x, N, 0, truth=True)
     ch = G.Chain(b, N, "None")                                   # AUTO: the guard trips on the first call and redoes it
     got = ch.process_bulk(dev(x)).cpu().numpy().ravel()
-    assert 0 <= ch.last_power_ratio()[0] < 0.04 and _rel(got, truth) <= TOL
+    assert 0 <= ch.last_power_ratio()[0] < 0.08 and _rel(got, truth) <= TOL
     assert _rel(G.Chain(b, N, "None", G.capi.CHAIN_TIME_DOMAIN).process_bulk(dev(x)).cpu().numpy().ravel(), truth) <= TOL
     # the FIR alone: float32 products against the default three-term bf16 ones, both against float64
     yt, _ = O.fir(b, x)                                           # (float64 accumulation)
@@ -2094,7 +2124,7 @@ def test_chain_process_multi_one_launch(G):
         f0 += k
     assert _rel(np.concatenate(got), tsum) <= TOL
     r, td = chains[0].last_power_ratio()
-    assert not td and r > 0.04
+    assert not td and r > 0.08
     # the same handles go on one by one: the histories the multi launch left behind are the right ones
     x_more = [O.signal_c32(90 + c, 2 * N) for c in range(nch)]
     for c in range(nch):
