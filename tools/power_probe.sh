@@ -24,6 +24,8 @@ elif cfg == "iir4":
     x = G.synth_f32(2 * n, seed=42); y = torch.empty_like(x); f = G.iir_filter(b, a); run = lambda: f.process_bulk(x, y); units = 2 * n
 elif cfg == "decim8":
     x = G.synth_f32(2 * n, seed=42); y = torch.empty(2 * n // 8, dtype=torch.float32, device="cuda"); f = G.fir_filter(lowpass(1024), torch.float32, decimate=8); run = lambda: f.process_bulk(x, y); units = 2 * n
+elif cfg == "decim8off":  # (the guard off: for the timing-only builds of tools/ab_dh.sh, whose outputs are garbage)
+    x = G.synth_f32(2 * n, seed=42); y = torch.empty(2 * n // 8, dtype=torch.float32, device="cuda"); f = G.fir_filter(lowpass(1024), torch.float32, decimate=8); f.set_guard_mode(capi.GUARD_OFF); run = lambda: f.process_bulk(x, y); units = 2 * n
 elif cfg == "rotator":
     x = G.synth_c32(n); y = torch.empty_like(x); f = G.Rotator(phase_increment=0.37); run = lambda: f.process_bulk(x, out=y); units = n
 elif cfg.startswith("chain"):  # chain<taps>_<fftSize>_<window>[_fd]: GR4HIP_CHAIN_AUTO (or the fused fast convolution with _fd)
