@@ -23,6 +23,14 @@
 // (the radix-32 pass pairs neighbouring lanes through DPP).  The next frame streams into a second LDS buffer by LDS-DMA while the
 // current one is transformed; e comes from the MFMA units.  Exchange layouts are padded (rows of 272 / 513 float2) so that all
 // ds_read_b64 / ds_write_b64 are bank-conflict-free.  DESIGN.md 3.1 has the phase table, the measurements and what was tried.
+// (round 5) the frame pipeline's HBM accesses are streaming: the samples come in once through the LDS-DMA and the results leave once -- both marked nt.  A/B on one box, alternated
+// (profiles/r05_headline_bounds.txt): stores alone +0.5 %, loads alone +0.5 %, both +1.3 / +1.4 %.  Developer builds override the two macros on the command line.
+#ifndef GR4_BUF_STORE_AUX
+#define GR4_BUF_STORE_AUX 2
+#endif
+#ifndef GR4_DMA_MODS
+#define GR4_DMA_MODS " nt"
+#endif
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fft_radix.hpp"
@@ -195,7 +203,7 @@ __device__ __forceinline__ void pin16(float2 (&v)[16]) {
 __device__ __forceinline__ void dma_1k(const void* gsrc_lane, unsigned lds_byte_addr) {
     unsigned keep;
     lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr); // provably wave-uniform for the "s" constraint
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" GR4_DMA_MODS "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc_lane), "s"(lds_byte_addr)
                  : "memory");

@@ -13,6 +13,12 @@
 // = 64 tiles (16 columns of 64 outputs, four tile rows), a wave runs its K quarter for ALL four tile rows, and because tile rows sit exactly four K-steps apart it walks ONE
 // sample-fragment stream of KQ + 12 fragments for the 4 KQ K-steps it evaluates (a third of the LDS operand reads).  The four partial tiles meet in LDS; thread (w', lane)
 // sums tile row w' and takes it out.  108 f16 MFMAs per wave and 8192 input samples: half the matrix-pipe work per input sample of the 256-tap FIR of fir_f16.hip.
+#ifndef GR4_DH_LOAD_AUX // cache policy of the sample loads (2 = nt) / result stores: developer builds override; profiles/r05_streaming_hints.txt
+#define GR4_DH_LOAD_AUX 0
+#endif
+#ifndef GR4_DH_STORE_NT
+#define GR4_DH_STORE_NT 0
+#endif
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fir_f16_common.hpp"
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
         const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
 #pragma unroll
         for (int u = 0; u < NL4; ++u) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, GR4_DH_LOAD_AUX);
             nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
@@ -198,7 +204,13 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
             if constexpr (HOOK == 1) {
                 if (hk.post.n_ops > 0) { const float4 w = bd_hook4(make_float4(v[0], v[1], v[2], v[3]), hk.post, cplx, o); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
             }
-            if (o + 3 < n_out) *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (o + 3 < n_out) {
+#if GR4_DH_STORE_NT
+                __builtin_nontemporal_store(f32x4_h{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4_h*>(y + o));
+#else
+                *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
+            }
             else {
                 for (int r = 0; r < 4; ++r)
                     if (o + r < n_out) y[o + r] = v[r];

@@ -32,6 +32,12 @@
 // 64 taps 623 -> 626 Gsamples/s on one box: the store pattern is not what these launches wait for.)
 //
 // Same output-to-tile map, fragment stream, double-buffered planes and prefetch as fir_mfma_bf16x3_shared_kernel (fir_bf16.hip), for every window width KS = 3 .. 9.
+#ifndef GR4_HF_LOAD_AUX // cache policy of the sample loads / result stores (2 = nt, streaming): developer builds override; profiles/r05_streaming_hints.txt
+#define GR4_HF_LOAD_AUX 0
+#endif
+#ifndef GR4_HF_STORE_AUX
+#define GR4_HF_STORE_AUX 0
+#endif
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fir_f16_common.hpp"
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 4 : 0));
 #pragma unroll
         for (int u = 0; u < NL4; ++u) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, GR4_HF_LOAD_AUX);
             nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
                 if (full) {
                     py = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], py))));
                     const u32x4_h w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(w, ry, oo * 4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, ry, oo * 4, 0, GR4_HF_STORE_AUX);
                 } else {
                     const long o = seg0 + oo;
                     if (o + 3 < n) {
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 8 : 0));
 #pragma unroll
         for (int u = 0; u < NL4; ++u) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, GR4_HF_LOAD_AUX);
             nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
@@ -481,8 +487,8 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
                 if (full) {
                     const u32x4_h w0 = {__float_as_uint(vr[0]), __float_as_uint(vi[0]), __float_as_uint(vr[1]), __float_as_uint(vi[1])};
                     const u32x4_h w1 = {__float_as_uint(vr[2]), __float_as_uint(vi[2]), __float_as_uint(vr[3]), __float_as_uint(vi[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(w0, ry, oo * 8, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(w1, ry, oo * 8 + 16, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(w0, ry, oo * 8, 0, GR4_HF_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(w1, ry, oo * 8 + 16, 0, GR4_HF_STORE_AUX);
                 } else {
                     for (int r = 0; r < 4; ++r)
                         if (seg0 + oo + r < n) y[seg0 + oo + r] = make_float2(vr[r], vi[r]);
