@@ -7,6 +7,14 @@
 // launch instead of one frame per work() call.  One workgroup owns whole frames: the frame is read from HBM once
 // (window fused into the load), all passes run in LDS, and every requested output is written once, coalesced.
 // The fused FIR->FFT->mag2 kernels live in chain_fused.hip.
+// (round 5) the transforms' frames come in once and their results leave once: streaming (nt) hints on both (buffer_ops.hpp).  A/B on one box, alternated, 2^27 points per launch
+// (profiles/r05_streaming_hints.txt): N = 512 / 1024 mag2 472 - 479 -> 498 - 510 Gsamples/s (+ 4 ... + 7 %), spectrum 360 / 355 -> 367 - 374 / 355 - 375.
+#ifndef GR4_BUF_STORE_AUX
+#define GR4_BUF_STORE_AUX 2
+#endif
+#ifndef GR4_BUF_LOAD_AUX
+#define GR4_BUF_LOAD_AUX 2
+#endif
 #include "fft_kernels.hpp"
 #include "fft_smooth.hpp"
 

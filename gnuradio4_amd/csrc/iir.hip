@@ -99,12 +99,20 @@ __device__ __forceinline__ void iir_block_scan(float* sv, const float* pl /*LDS 
 
 // HBM -> LDS tile [chunk][L + 1]: all eight 16-byte loads of a lane are in flight before the first LDS write (a load-per-iteration
 // loop pays the full memory latency 32 times per block)
-__device__ __forceinline__ void iir_stage_tile(float* tile, const float* __restrict__ x, long base, long n) {
+using iir_f32x4 = __attribute__((ext_vector_type(4))) float;
+// nt (uniform): streaming hints on the tile's loads / stores -- a span that cannot stay in the 256 MB of memory-side cache anyway (profiles/r05_streaming_hints.txt: 4 biquads
+// on 2^26 / 2^27 samples + 3.5 %, 1-pole + 3 / + 6 %; on 2^24 samples, which a back-to-back loop re-reads from that cache, - 6 %: the host sets it from the span's size)
+__device__ __forceinline__ void iir_stage_tile(float* tile, const float* __restrict__ x, long base, long n, bool nt = false) {
     constexpr int kV = kIirL / 4; // float4 per lane
     if (base + (long)kIirBS * kIirL <= n && (reinterpret_cast<uintptr_t>(x + base) & 15) == 0) {
         float4 v[kV];
+        if (nt) {
 #pragma unroll
-        for (int q = 0; q < kV; ++q) v[q] = reinterpret_cast<const float4*>(x + base)[q * kIirBS + threadIdx.x];
+            for (int q = 0; q < kV; ++q) { const iir_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const iir_f32x4*>(x + base) + (q * kIirBS + threadIdx.x)); v[q] = make_float4(t[0], t[1], t[2], t[3]); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kV; ++q) v[q] = reinterpret_cast<const float4*>(x + base)[q * kIirBS + threadIdx.x];
+        }
 #pragma unroll
         for (int q = 0; q < kV; ++q) {
             const int s = 4 * (q * kIirBS + threadIdx.x);
@@ -118,14 +126,15 @@ __device__ __forceinline__ void iir_stage_tile(float* tile, const float* __restr
         }
     }
 }
-__device__ __forceinline__ void iir_unstage_tile(const float* tile, float* __restrict__ y, long base, long n) {
+__device__ __forceinline__ void iir_unstage_tile(const float* tile, float* __restrict__ y, long base, long n, bool nt = false) {
     constexpr int kV = kIirL / 4;
     if (base + (long)kIirBS * kIirL <= n && (reinterpret_cast<uintptr_t>(y + base) & 15) == 0) {
 #pragma unroll
         for (int q = 0; q < kV; ++q) {
             const int    s = 4 * (q * kIirBS + threadIdx.x);
             const float* d = tile + (s / kIirL) * (kIirL + 1) + (s % kIirL);
-            reinterpret_cast<float4*>(y + base)[q * kIirBS + threadIdx.x] = make_float4(d[0], d[1], d[2], d[3]);
+            if (nt) __builtin_nontemporal_store(iir_f32x4{d[0], d[1], d[2], d[3]}, reinterpret_cast<iir_f32x4*>(y + base) + (q * kIirBS + threadIdx.x));
+            else reinterpret_cast<float4*>(y + base)[q * kIirBS + threadIdx.x] = make_float4(d[0], d[1], d[2], d[3]);
         }
     } else {
         for (int s = threadIdx.x; s < kIirBS * kIirL; s += kIirBS) {
@@ -653,6 +662,7 @@ struct IirSeqArgs {
     long         tiles_per_wg;
     int          warm_tiles;
     int          warm_chunks; // warm_tiles == 1: the last this many 32-sample chunks of the warm-up tile are enough (a multiple of 32, <= 256)
+    int          nt;          // streaming hints on the tiles' loads and stores (spans beyond the memory-side cache)
 };
 
 template <int ORD, int NSEC>
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(kIirBS, 4) void iir_seq_kernel(IirSeqArgs a, IirCoe
         // only the tile's last wc chunks are read from HBM and run -- the lanes in front of them keep the zero state (for Butterworth-8 at fc = 0.05 that is 32 chunks of
         // 256: an eighth of the tile's traffic and of its zero-state instructions; a run of two tiles per workgroup paid 3 reads and 3 zero-state passes for 2 tiles)
         const int  first = emit ? 0 : kIirBS - a.warm_chunks; // first chunk (lane) of the tile that takes part
-        if (first == 0) iir_stage_tile(tile, a.x, base, a.n);
+        if (first == 0) iir_stage_tile(tile, a.x, base, a.n, a.nt != 0);
         else if (base + (long)kIirBS * kIirL <= a.n && (reinterpret_cast<uintptr_t>(a.x + base) & 15) == 0) { // (first is a multiple of 32 chunks = 4 of the lane's 8 float4 slots... slot q covers chunks 32 q .. 32 q + 31)
 #pragma unroll
             for (int q = 0; q < kIirL / 4; ++q) {
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(kIirBS, 4) void iir_seq_kernel(IirSeqArgs a, IirCoe
                 for (int j = 0; j < ORD; ++j) a.state_out[s * ORD + j] = st[s][j];
         }
         __syncthreads();
-        iir_unstage_tile(tile, a.y, base, a.n);
+        iir_unstage_tile(tile, a.y, base, a.n, a.nt != 0);
         __syncthreads(); // the tile is staged again at the top
     }
 }
@@ -1007,6 +1017,7 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
             a.tiles_per_wg = per;
             a.warm_tiles   = f->warm_tiles;
             a.warm_chunks  = f->warm_tiles == 1 ? f->warm_chunks : kIirBS;
+            a.nt           = (size_t)n * 2 * sizeof(float) > ((size_t)192 << 20); // input + output beyond what the 256 MB memory-side cache would keep
             hipLaunchKernelGGL((iir_seq_kernel<ORD, NSEC>), dim3((unsigned)ceil_div(nblocks, per)), dim3(kIirBS), 0, st, a, cf);
             GR4_LAUNCH_CHECK();
             f->cur ^= 1;
