@@ -20,6 +20,12 @@
 //   FFT      16 points per lane, fftSize / 16 lanes per frame: Stockham 16 x 16 x (fftSize / 256), the plan of fft_fast_kernel with its first pass fed
 //            from LDS instead of HBM; |X|^2 straight from registers (lane t holds bins t + j fftSize / 16: coalesced)
 // The frame buffer takes the place of the staged samples: LDS 38 KB -> four workgroups per CU, whose phases interleave on the two pipes.  HBM traffic: 8 B in + 4 B out per sample.  Bound: MFMA f32 (2 * 2 * (Kp + 16) flop per sample).
+#ifndef GR4_TD_LOAD_AUX // cache policy of the sample loads (2 = nt) / the spectrum stores: developer builds override; profiles/r05_streaming_hints.txt
+#define GR4_TD_LOAD_AUX 0
+#endif
+#ifndef GR4_TD_STORE_NT
+#define GR4_TD_STORE_NT 0
+#endif
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fft_radix.hpp"
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
             float4       nxt[NL4];
 #pragma unroll
             for (int u = 0; u < NL4; ++u) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 256 * u * 16, GR4_TD_LOAD_AUX);
                 nxt[u]       = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
 #pragma unroll
@@ -238,7 +244,13 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
         {
             const long frame = (seg0 >> LOG2N) + fl;
             if (frame < n_frames)
-                for (int j = 0; j < 16; ++j) out[frame * N + t + j * T] = fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
+                for (int j = 0; j < 16; ++j) {
+#if GR4_TD_STORE_NT
+                    __builtin_nontemporal_store(fmaf(v[j].x, v[j].x, v[j].y * v[j].y), &out[frame * N + t + j * T]);
+#else
+                    out[frame * N + t + j * T] = fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
+#endif
+                }
             GR4_TD_BARRIER(); continue;
         }
 #endif

@@ -1,5 +1,12 @@
 // fft_fast_pk.hip -- the fft_fast_kernel instantiations that are FASTER with hipcc's SLP vectoriser (packed f32 math): N = 256 and 8192.
 // build.sh compiles this file without -fno-slp-vectorize; see fft_kernels.hpp.
+// (round 5) streaming (nt) hints on the frames' loads and the results' stores, like fft.hip (profiles/r05_streaming_hints.txt: N = 256 |X|^2 442 - 456 -> 472 - 481 Gsamples/s)
+#ifndef GR4_BUF_STORE_AUX
+#define GR4_BUF_STORE_AUX 2
+#endif
+#ifndef GR4_BUF_LOAD_AUX
+#define GR4_BUF_LOAD_AUX 2
+#endif
 #include "fft_kernels.hpp"
 
 namespace gr4 {
