@@ -1041,6 +1041,20 @@ def test_iir_cascade_parity(G, order, design):
     assert _rel(y, truth) <= 2 * _rel(cpu32, truth) + 2e-6
 
 
+def test_iir_span_beyond_the_memory_side_cache(G):
+    """round 5: a span whose input + output exceed 192 MB takes the tiles' loads and stores with streaming (nt) hints (IirSeqArgs::nt, profiles/r05_streaming_hints.txt): the same
+    arithmetic -- the whole 2^25-sample span against the float64 oracle, and its state handed to a second call of ragged length"""
+    import gnuradio4_amd.blocks as B
+    b, a = B.design_iir(0, 8, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
+    n1, n2 = (1 << 25) + 4096 * 3 + 7, 70_001
+    x = O.signal_f32(7, n1 + n2)
+    truth = O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(b, a)]), x, O.DF_II, f64=True)
+    f = G.iir_filter(b, a)
+    y = np.concatenate([f.process_bulk(dev(x[:n1])).cpu().numpy(), f.process_bulk(dev(x[n1:])).cpu().numpy()])
+    assert _rel(y, truth) <= TOL
+    f.status()
+
+
 def test_iir_status_is_clean_after_long_streams(G):
     """gr4hip_iir_status: where a caller synchronises anyway; a look-back time-out (never observed) would surface here instead of on the next call"""
     bi, ai = G.blocks.design_iir(G.capi.LOWPASS, 8, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
