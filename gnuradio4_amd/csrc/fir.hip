@@ -751,7 +751,8 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             std::vector<unsigned short> af;
             if (!fir_f16_make_afrag(f->taps.data(), f->ntaps, &f->hfKS, &af, 1, 0)) f->hfKS = -1;
             else {
-                if (f->guard_ratio != kGuardSegmentRatio) { const float g = (float)(f->tap_power * f->guard_ratio); std::memcpy(af.data() + (size_t)f->hfKS * 1536 + 4, &g, 4); } // (the table's header: fir_f16_make_afrag)
+                if (f->guard_ratio != kGuardSegmentRatio) { const float g = (float)(f->tap_power * f->guard_ratio); std::memcpy(af.data() + (size_t)f->hfKS * 1536 + 6, &g, 4); } // (the table's header, fir_f16_make_afrag: the tighter
+                // threshold goes on the segment's WHOLE output power; the quietest-column statistic keeps its 21 dB -- at 15 dB it dips below on narrow-band noise alone: 1 % pass band, half of all segments marked)
                 rc = f->d_hfrag.ensure(af.size() * sizeof(unsigned short));
                 if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
                 if (rc) { f->hfKS = 0; return rc; }

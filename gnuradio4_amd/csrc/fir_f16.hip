@@ -312,6 +312,8 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
     const u32x4_h* afrag = reinterpret_cast<const u32x4_h*>(blk);
     const float    inv_t = *reinterpret_cast<const float*>(blk + KS * 1536);
     const float    gthr  = *reinterpret_cast<const float*>(blk + KS * 1536 + 4);
+    const float    gthr_all = *reinterpret_cast<const float*>(blk + KS * 1536 + 6); // (0 unless a library-internal caller set it -- fir.hip, gr4hip_internal_fir_set_guard_ratio: a second, tighter
+                                                                                       // threshold on the segment's WHOLE output power, a statistic that does not dip on narrow-band noise as the quietest column does)
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kHfSegC + Hb; // staged complex samples per segment (a multiple of 16)
     constexpr int PL  = NS + 8 * (NS / 128 + 1) + 16;            // f16 elements per plane: one 16-byte chunk of padding per 128 samples (the columns are 128 samples apart)
     constexpr int NL4 = (NS / 2 + 255) / 256;                    // float4 loads (two complex samples each) a lane holds for the next segment
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
         const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
                                                 // segment does not hide that the rest of it is all rejection
-        const int rej = __builtin_amdgcn_readfirstlane((int)(py < gthr * px)), known = __builtin_amdgcn_readfirstlane((int)(py < __builtin_inff())); // (Inf: nothing was judged)
+        const int rej = __builtin_amdgcn_readfirstlane((int)(py < gthr * px || hf_row_sum(pc) < gthr_all * px)), known = __builtin_amdgcn_readfirstlane((int)(py < __builtin_inff())); // (Inf: nothing was judged)
         if (rej) note(sg, 3);
         if (known) streak = rej ? streak + 1 : 0;
     };

@@ -66,6 +66,14 @@ __device__ __forceinline__ float hf_row_min(float v) {
     return __builtin_fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
 }
 
+// the sum of a row of 16 lanes, on every lane of the row
+__device__ __forceinline__ float hf_row_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+}
+
 // the same into THREE terms (33 bits: a float32 value exactly, while the block exponent holds): the second evaluation of a segment the guard has rejected
 __device__ __forceinline__ void hf_split2x3(float x0, float x1, float s, unsigned& h, unsigned& m, unsigned& l) {
     const f32x2_h v  = {x0 * s, x1 * s};
