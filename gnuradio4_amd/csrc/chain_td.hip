@@ -220,7 +220,10 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
         if (gthr > 0.f && tid == 0) {
             const float px = (jred[0] + jred[1]) + (jred[2] + jred[3]);
             const float py = 4.f * __builtin_fminf(__builtin_fminf(jred[4], jred[5]), __builtin_fminf(jred[6], jred[7]));
-            flags[sg] = (py < gthr * px) ? 3 : 0; // (a NaN power compares false: unmarked)
+            // two verdicts: the quietest wave's quarter at the FIR guard's 21 dB, the whole segment 6 dB earlier (this kernel squares the filter output behind its transform, which doubles
+            // the split products' relative error -- chain.hip kChainPairGuardRatio; the quietest-part statistic at 15 dB dips below on narrow-band noise alone)
+            const float pa = (jred[4] + jred[5]) + (jred[6] + jred[7]);
+            flags[sg] = (py < gthr * px || pa < 4.f * gthr * px) ? 3 : 0; // (a NaN power compares false: unmarked)
         }
         // D[row = 4 kq + r][col] of tile q: sample 16 (16 (4 wave + q) + col) + 4 kq + r of the segment; x window -> frame buffer (natural order)
 #pragma unroll
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256, (td_waves<KS, LOG2N>())) void chain_td_kernel(
 // sched_group_barrier does not finish on a 272-MFMA region.)
 
 struct ChainTd {
-    float        gthr = 0.f;      // (sum b^2) / 32: the FIR guard (fir.hip kGuardSegmentRatio) 6 dB earlier; chain_td_process passes it unless the guard is off
+    float        gthr = 0.f;      // (sum b^2) / 128: the FIR guard (fir.hip kGuardSegmentRatio); the kernel judges the whole segment at 4 x this as well; chain_td_process passes it unless the guard is off
     DeviceBuffer d_flags;         // one byte per 4096-sample segment of the last launch
     size_t       ntaps = 0, N = 0;
     int          KS = 0, Kp = 0, log2n = 0;
@@ -358,7 +361,7 @@ int chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_s
     {
         double h2 = 0;
         for (size_t k = 0; k < ntaps; ++k) h2 += (double)taps[k] * taps[k];
-        c->gthr = (float)(h2 / 32.0); // (the FIR guard of fir.hip is at 1 / 128: this kernel squares the filter output behind its transform, which doubles the split products' relative error -- chain.hip kChainPairGuardRatio)
+        c->gthr = (float)(h2 / 128.0); // (the kernel's second verdict is at 4 x this -- see there; until the round's last day this was h2 / 32 on the quietest-wave statistic alone) // (the FIR guard of fir.hip is at 1 / 128: this kernel squares the filter output behind its transform, which doubles the split products' relative error -- chain.hip kChainPairGuardRatio)
     }
     (void)hipGetDevice(&c->dev);
     c->log2n = (int)ilog2(fft_size);
