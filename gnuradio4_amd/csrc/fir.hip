@@ -1088,7 +1088,8 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
         if (no > 0) {
             rc = f->d_flags.ensure((size_t)ceil_div(no, 1L << shift));
             if (rc) return rc;
-            rc = fir_judge_launch(xr, ni, yr, no, (int)f->decim, f->S == 2, shift, (float)(f->tap_power * f->guard_ratio), (unsigned char*)f->d_flags.ptr, st);
+            rc = fir_judge_launch(xr, ni, yr, no, (int)f->decim, f->S == 2, shift, (float)(f->tap_power * kGuardSegmentRatio), (unsigned char*)f->d_flags.ptr, st,
+                                  f->guard_ratio != kGuardSegmentRatio ? (float)(f->tap_power * f->guard_ratio) : 0.f); // (a tighter ratio: on the segment's whole output power -- the quietest quarter dips on narrow-band noise)
             if (rc) return rc;
             rc = fir_exact_launch(xr, ni, unj_hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, (int)f->decim, f->S == 2, yr, no, (const unsigned char*)f->d_flags.ptr, shift, nullptr, st);
             if (rc && rc != GR4HIP_UNSUPPORTED) return rc; // (UNSUPPORTED: decimation x taps beyond what the second evaluation stages -- the float32 sums stand)

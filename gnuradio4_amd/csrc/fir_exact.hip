@@ -234,7 +234,7 @@ int fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const
 // ---- the verdict for kernels that do not judge themselves (the float32 matrix-pipe forms, the three-term bf16 direct forms): one byte per 2^seg_shift outputs, non-zero where the
 // outputs' power (of the segment's quietest quarter) is below gthr x the power of the D x as many samples in front of them.  One pass over x and y; non-finite power either
 // side leaves the segment unmarked (the main kernel's classes stand).
-__global__ __launch_bounds__(256) void fir_judge_kernel(const float* __restrict__ x, long nxf, const float* __restrict__ y, long nyf, int D, int segf, float gthr, unsigned char* __restrict__ flags, long nseg) {
+__global__ __launch_bounds__(256) void fir_judge_kernel(const float* __restrict__ x, long nxf, const float* __restrict__ y, long nyf, int D, int segf, float gthr, float gthr_all, unsigned char* __restrict__ flags, long nseg) {
     __shared__ float red[8];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = segf / 4; // a wave's quarter: q output floats, q D input floats
     for (long sgi = blockIdx.x; sgi < nseg; sgi += gridDim.x) {
@@ -249,23 +249,24 @@ __global__ __launch_bounds__(256) void fir_judge_kernel(const float* __restrict_
         __syncthreads();
         if (tid == 0) {
             const float pxs = (red[0] + red[1]) + (red[2] + red[3]);
-            float       pym = red[4];
+            float       pym = red[4], pya = 0.f;
             bool        fin = true;
             for (int w = 0; w < 4; ++w) {
                 const bool present = sgi * segf + (long)w * q < nyf; // (the stream's last segment: quarters past its end do not vote)
                 if (!present) continue;
                 fin = fin && red[4 + w] < 3.0e38f;
                 pym = fminf(pym, red[4 + w]);
+                pya += red[4 + w];
             }
-            flags[sgi] = (fin && pxs < 3.0e38f && pym * 4.f * (float)D < gthr * pxs) ? 3 : 0;
+            flags[sgi] = (fin && pxs < 3.0e38f && (pym * 4.f * (float)D < gthr * pxs || pya * (float)D < gthr_all * pxs)) ? 3 : 0; // (pya over the quarters present: the stream's last segment is judged a little early, never late)
         }
     }
 }
-int fir_judge_launch(const float* x, long n_in, const float* y, long n_out, int D, int cplx, int seg_shift, float gthr, unsigned char* flags, hipStream_t st) {
+int fir_judge_launch(const float* x, long n_in, const float* y, long n_out, int D, int cplx, int seg_shift, float gthr, unsigned char* flags, hipStream_t st, float gthr_all) {
     const int  NC = cplx ? 2 : 1, segf = NC << seg_shift;
     const long nseg = ceil_div(n_out, 1L << seg_shift);
     if (nseg <= 0) return GR4HIP_OK;
-    hipLaunchKernelGGL(fir_judge_kernel, dim3((unsigned)std::min<long>(nseg, 256 * 16)), dim3(256), 0, st, x, n_in * NC, y, n_out * NC, D, segf, gthr, flags, nseg);
+    hipLaunchKernelGGL(fir_judge_kernel, dim3((unsigned)std::min<long>(nseg, 256 * 16)), dim3(256), 0, st, x, n_in * NC, y, n_out * NC, D, segf, gthr, gthr_all, flags, nseg);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }

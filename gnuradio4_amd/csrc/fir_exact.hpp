@@ -13,6 +13,7 @@ int fir_exact_launch(const float* x, long n_in, const float* hist, int Kh, const
                      const unsigned* gate, hipStream_t st, unsigned nch = 1, long in_stride = 0, long out_stride = 0, long taps_stride = 0, long flags_stride = 0, const EwiseHook* pre = nullptr,
                      const EwiseHook* post = nullptr);
 // the verdict for a kernel that does not judge itself: flags[s] != 0 where the 2^seg_shift outputs of segment s carry less than gthr x the power of the samples in front of them
-int fir_judge_launch(const float* x, long n_in, const float* y, long n_out, int D, int cplx, int seg_shift, float gthr, unsigned char* flags, hipStream_t st);
+// gthr_all > 0: a second verdict on the segment's WHOLE output power (the chain's kernel pair: chain.hip kChainPairGuardRatio)
+int fir_judge_launch(const float* x, long n_in, const float* y, long n_out, int D, int cplx, int seg_shift, float gthr, unsigned char* flags, hipStream_t st, float gthr_all = 0.f);
 
 } // namespace gr4
