@@ -302,7 +302,7 @@ bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vecto
 bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ_out, std::vector<unsigned short>* tab, bool cplx); // fir_decim_f16.hip
 int  fir_decim_f16_launch(int D, int KQ, const float* x, long n_in, const float* hist, int Kh, const void* table, float* y, long n_out, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int cplx,
                           const EwiseHook* pre, const EwiseHook* post);
-int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard, unsigned char* flags);
+int  fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard, unsigned char* flags, int delay = 0, int accum = 0, float gthr = 0.f);
 int  fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, long in_stride, long out_stride, unsigned nch, int delay, int accum, int guard,
                     unsigned char* flags, long flags_stride, float gthr);
 int  fir_bf16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* afrag, float* y, hipStream_t st, float* new_hist);
@@ -769,6 +769,49 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             if (rc) return rc;
             done = n_in;
             mfma_wrote_hist = nh != nullptr;
+        }
+    }
+    // (round 5) complex, 257 .. 1024 taps: slices of 256 taps on the same kernel, each a pass over the input delayed by 256 p samples that adds to y (the float path's scheme below;
+    // until then these filters took the f32 matrix pipe at its peak: 512 taps 36 Gsamples/s, 1024 taps 17).  The last slice judges the sums against the whole filter's threshold;
+    // marked segments again with all the taps on the FP64 matrix pipe.
+    if (f->S == 2 && f->decim == 1 && f->ntaps > 256 && f->ntaps <= 1024 && done == 0 && n_in >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
+        algo == GR4HIP_FIR_AUTO && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && f->hfKS >= 0 && plain) {
+        int          rc = GR4HIP_OK;
+        const size_t nslice = ceil_div(f->ntaps, (size_t)256);
+        if (f->hfKS == 0) {
+            std::vector<unsigned short> all;
+            bool                        ok = true;
+            f->hf_off.assign(nslice, 0);
+            f->hf_ks.assign(nslice, 0);
+            for (size_t p = 0; p < nslice && ok; ++p) {
+                std::vector<unsigned short> af;
+                const size_t                len = std::min<size_t>(256, f->ntaps - 256 * p);
+                const int                   nat = std::max(3, (int)((len - 1 + 16 + 31) / 32));
+                ok = fir_f16_make_afrag(f->taps.data() + 256 * p, len, &f->hf_ks[p], &af, 1, nat == 8 ? 9 : 0); // (the sliced kernel at 8 K-steps would keep two registers in scratch: such a slice runs the 9-step kernel on zero-padded taps)
+                f->hf_off[p] = all.size();
+                all.insert(all.end(), af.begin(), af.end());
+            }
+            if (!ok) f->hfKS = -1;
+            else {
+                rc = f->d_hfrag.ensure(all.size() * sizeof(unsigned short));
+                if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (rc) return rc;
+                f->hfKS = f->hf_ks[0];
+            }
+        }
+        if (f->hfKS > 0) {
+            float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
+            rc = f->d_flags.ensure((size_t)ceil_div((long)n_in, 2048L));
+            if (rc) return rc;
+            const bool judged = f->guard_mode != GR4HIP_GUARD_OFF;
+            for (size_t p = 0; p < nslice && !rc; ++p)
+                rc = fir_f16_c32_launch(f->hf_ks[p], x, (long)n_in, hist, (int)f->hcap, (const unsigned short*)f->d_hfrag.ptr + f->hf_off[p], y, st, p == 0 ? nh : nullptr, p + 1 == nslice && judged,
+                                        (unsigned char*)f->d_flags.ptr, (int)(256 * p), p > 0, (float)(f->tap_power * kGuardSegmentRatio));
+            if (rc) return rc;
+            rc = fir_exact_launch(x, (long)n_in, hist, (int)f->hcap, (const float*)f->d_tapsf.ptr, (int)f->ntaps, 1, 1, y, (long)n_in, (const unsigned char*)f->d_flags.ptr, 11, nullptr, st);
+            if (rc) return rc;
+            done = n_in;
+            mfma_wrote_hist = true;
         }
     }
     static const size_t kCBfMinTaps = [] { const char* e = std::getenv("GR4HIP_CFIR_BF16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // developer knob: 65 puts 33..64 taps back on the f32 MFMA (measured 5-8 % slower: 299-316 against 322-333 Gsamples/s); below 33 taps the register-window kernel is ahead up to 27 taps and within 3 % from there (tools/cfir_bf16_threshold.py)

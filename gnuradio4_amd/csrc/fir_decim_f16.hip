@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
         const unsigned mx = __builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))), mn = __builtin_amdgcn_readfirstlane(min(min(n4.x, n4.y), min(n4.z, n4.w)));
         const int e = (int)(mx >> 23), el = (int)(mn >> 23);
         const int slow = (e == 255 || px != px) ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0);
+        if (slow == 0 && mx != 0u && (e < 127 - 60 || e > 127 + 60)) px = -1.f; // the powers are sums of SQUARES: with the largest sample outside [2^-60, 2^60] they leave float32's range (0 or Inf)
+                                                                                   // and the guard cannot judge -- judge() hands such a segment to the second evaluation as if it were rejected
         const int ec = e < 15 ? 15 : (e > 254 ? 254 : e);
         s     = __uint_as_float((unsigned)(268 - ec) << 23);
         inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void fir_decim_f16x2_kernel(const float* __
     // the guard (fir_f16.hip): sixteen times the power of the QUIETEST of the segment's sixteen output columns, at the input rate, against 2^-12 (sum b^2) x the input power
     auto rejected = [&](float px) __attribute__((always_inline)) -> bool {
         const float pc = (ystat[0][col] + ystat[1][col]) + (ystat[2][col] + ystat[3][col]); // (a wave's entry is the sum over the tile rows it took out)
-        return __builtin_amdgcn_readfirstlane((int)(16.f * hf_row_min(pc) * (float)D < gthr * px)) != 0;
+        return __builtin_amdgcn_readfirstlane((int)(px < 0.f || 16.f * hf_row_min(pc) * (float)D < gthr * px)) != 0; // (px < 0: block_scale could not form the power)
     };
     const long nseg = (n_out + SO - 1) / SO, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
     if (sfirst >= slast) return;

@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         px = (__uint_as_float(p4.x) + __uint_as_float(p4.y)) + (__uint_as_float(p4.z) + __uint_as_float(p4.w));
         const unsigned mx = __builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))), mn = __builtin_amdgcn_readfirstlane(min(min(n4.x, n4.y), min(n4.z, n4.w)));
         const int  e  = (int)(mx >> 23), el = (int)(mn >> 23);
-        const int  slow = (e == 255 || px != px) ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0); // (px = +Inf without an Inf sample: squares above 3.4e38 -- the guard
+        const int  slow = (e == 255 || px != px) ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0); // (px = +Inf without an Inf sample: squares above 3.4e38 -- see px = -1 below: the guard
                                                                                                                   //  cannot judge such a segment and sends it to the float32 products)
+        if (slow == 0 && mx != 0u && (e < 127 - 60 || e > 127 + 60)) px = -1.f; // the powers are sums of SQUARES: with the largest sample outside [2^-60, 2^60] they leave float32's range (0 or Inf)
+                                                                                   // and the guard cannot judge -- judge() hands such a segment to the second evaluation as if it were rejected
         const int  ec = e < 15 ? 15 : (e > 254 ? 254 : e);
         s     = __uint_as_float((unsigned)(268 - ec) << 23); // largest magnitude -> [2^14, 2^15)
         inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
         const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
         const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
                                                 // segment does not hide that the rest of it is all rejection
-        const int rej = __builtin_amdgcn_readfirstlane((int)(py < gthr * px)), known = __builtin_amdgcn_readfirstlane((int)(py < __builtin_inff())); // (Inf: nothing was judged)
+        const int rej = __builtin_amdgcn_readfirstlane((int)(px < 0.f || py < gthr * px)), known = __builtin_amdgcn_readfirstlane((int)(py < __builtin_inff())); // (Inf: nothing was judged)
         if (rej) note(sg, 3);
         if (known) streak = rej ? streak + 1 : 0;
     };
@@ -304,14 +306,19 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_kernel(
 // front of x.
 constexpr int kHfSegC = 2048;
 
-template <int KS>
+// SL (round 5): a SLICE of a longer filter, as in the float kernel -- this pass filters x delayed by `delay` samples and, with `accum`, adds to what is in y; only the last slice
+// judges (the sums it leaves in y, against the whole filter's threshold gthr_arg).  A template switch so that the 33 .. 256-tap kernels stay as they are (252 .. 256 registers at KS = 9).
+template <int KS, bool SL = false>
 __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_kernel(const float2* __restrict__ x, const float2* __restrict__ hist /*the Kh samples in front of x*/, int Kh,
                                                                                     const unsigned short* __restrict__ blk /*one block of hf_block_units(KS)*/, float2* __restrict__ y, long n,
                                                                                     float2* __restrict__ new_hist, int seg_per_wg, int guard,
-                                                                                    unsigned char* __restrict__ flags /*one byte per segment: what fir_exact_kernel evaluates again behind this launch*/) {
+                                                                                    unsigned char* __restrict__ flags /*one byte per segment: what fir_exact_kernel evaluates again behind this launch*/,
+                                                                                    int delay_arg, int accum_arg, float gthr_arg) {
+    const int delay = SL ? delay_arg : 0;
+    const bool accum = SL && accum_arg != 0;
     const u32x4_h* afrag = reinterpret_cast<const u32x4_h*>(blk);
     const float    inv_t = *reinterpret_cast<const float*>(blk + KS * 1536);
-    const float    gthr  = *reinterpret_cast<const float*>(blk + KS * 1536 + 4);
+    const float    gthr  = (SL && gthr_arg > 0.f) ? gthr_arg : *reinterpret_cast<const float*>(blk + KS * 1536 + 4);
     const float    gthr_all = *reinterpret_cast<const float*>(blk + KS * 1536 + 6); // (0 unless a library-internal caller set it -- fir.hip, gr4hip_internal_fir_set_guard_ratio: a second, tighter
                                                                                        // threshold on the segment's WHOLE output power, a statistic that does not dip on narrow-band noise as the quietest column does)
     constexpr int Kw = 32 * KS, Hb = Kw - 16, NS = kHfSegC + Hb; // staged complex samples per segment (a multiple of 16)
@@ -332,8 +339,8 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
 
     auto xs = [&](long i) -> float2 { return i >= 0 ? (i < n ? x[i] : make_float2(0.f, 0.f)) : (i >= -(long)Kh ? hist[Kh + i] : make_float2(0.f, 0.f)); };
     float4 nxa[NL4], nxb[NL4];
-    auto   load_next = [&](float4 (&nxt)[NL4], long seg0) { // seg0 >= kHfSegC >= Hb
-        const long   i0   = seg0 - Hb;
+    auto   load_next = [&](float4 (&nxt)[NL4], long seg0) { // seg0 >= kHfSegC >= Hb + delay
+        const long   i0   = seg0 - Hb - delay;
         const long   nrec = n - i0 < (long)NS ? n - i0 : (long)NS;
         const rsrc_t r    = make_rsrc(x + i0, (unsigned)(nrec > 0 ? nrec * 8 : 0));
 #pragma unroll
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         for (int u = 0; u < NL4; ++u) {
             const int q = tid + 256 * u;
             float2    t0 = make_float2(0.f, 0.f), t1 = t0;
-            if (q < NS / 2) { t0 = xs(seg0 + 2L * q - Hb); t1 = xs(seg0 + 2L * q + 1 - Hb); }
+            if (q < NS / 2) { t0 = xs(seg0 + 2L * q - Hb - delay); t1 = xs(seg0 + 2L * q + 1 - Hb - delay); }
             nxt[u] = make_float4(t0.x, t0.y, t1.x, t1.y);
         }
     };
@@ -378,6 +385,8 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
         const unsigned mx = __builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))), mn = __builtin_amdgcn_readfirstlane(min(min(n4.x, n4.y), min(n4.z, n4.w)));
         const int e = (int)(mx >> 23), el = (int)(mn >> 23);
         const int slow = (e == 255 || px != px) ? 2 : ((mn != 0xffffffffu && e - el > kHfMaxRange) ? 1 : 0);
+        if (slow == 0 && mx != 0u && (e < 127 - 60 || e > 127 + 60)) px = -1.f; // the powers are sums of SQUARES: with the largest sample outside [2^-60, 2^60] they leave float32's range (0 or Inf)
+                                                                                   // and the guard cannot judge -- judge() hands such a segment to the second evaluation as if it were rejected
         const int ec = e < 15 ? 15 : (e > 254 ? 254 : e);
         s     = __uint_as_float((unsigned)(268 - ec) << 23);
         inv_s = __uint_as_float((unsigned)(ec - 14) << 23);
@@ -401,16 +410,16 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
     const int sb = 128 * col + 16 * tb + 8 * kq;
     const long nseg = (n + kHfSegC - 1) / kHfSegC, sfirst = (long)blockIdx.x * seg_per_wg, slast = sfirst + seg_per_wg < nseg ? sfirst + seg_per_wg : nseg;
     if (sfirst >= slast) return;
-    if (tid < slast - sfirst) flags[sfirst + tid] = 0; // (the barriers below order this store before any mark)
+    if (!accum && tid < slast - sfirst) flags[sfirst + tid] = 0; // (the barriers below order this store before any mark; a later slice adds its marks to the earlier ones')
     auto note = [&](long sg, int kind) { // 1: the spread is beyond the block exponent; 2: a non-finite sample; 3: rejected by the guard -> fir_exact_kernel behind this launch
-        if (tid == 0) flags[sg] = (unsigned char)kind;
+        if (tid == 0) flags[sg] = (unsigned char)(accum ? (flags[sg] | kind) : kind);
     };
     int  streak = 0; // (see the float kernel)
     auto judge = [&](long sg, float px) {
         const float pc = (ystat[sg & 1][0][col] + ystat[sg & 1][1][col]) + (ystat[sg & 1][2][col] + ystat[sg & 1][3][col]); // this lane's column, over the four waves' tiles
         const float py = 16.f * hf_row_min(pc); // the QUIETEST of the sixteen columns, as a segment's worth: a start-up transient or the edge of a burst in one part of the
                                                 // segment does not hide that the rest of it is all rejection
-        const int rej = __builtin_amdgcn_readfirstlane((int)(py < gthr * px || hf_row_sum(pc) < gthr_all * px)), known = __builtin_amdgcn_readfirstlane((int)(py < __builtin_inff())); // (Inf: nothing was judged)
+        const int rej = __builtin_amdgcn_readfirstlane((int)(px < 0.f || py < gthr * px || hf_row_sum(pc) < gthr_all * px)), known = __builtin_amdgcn_readfirstlane((int)(py < __builtin_inff())); // (Inf: nothing was judged)
         if (rej) note(sg, 3);
         if (known) streak = rej ? streak + 1 : 0;
     };
@@ -480,6 +489,18 @@ __global__ __launch_bounds__(256, GR4_F16_WG_PER_CU) void fir_mfma_f16x2_c32_ker
                     if (!one) { vr[r] *= k2; vi[r] *= k2; }
                 }
                 const int oo = 128 * col + 16 * (tb + 2 * jj) + 4 * kq;
+                if constexpr (SL) {
+                    if (accum) { // the earlier slices' sums (the guard's output power below is the power of the SUM)
+                        if (full) {
+                            const auto p0 = __builtin_amdgcn_raw_buffer_load_b128(ry, oo * 8, 0, 0), p1 = __builtin_amdgcn_raw_buffer_load_b128(ry, oo * 8 + 16, 0, 0);
+                            vr[0] += __uint_as_float(p0[0]); vi[0] += __uint_as_float(p0[1]); vr[1] += __uint_as_float(p0[2]); vi[1] += __uint_as_float(p0[3]);
+                            vr[2] += __uint_as_float(p1[0]); vi[2] += __uint_as_float(p1[1]); vr[3] += __uint_as_float(p1[2]); vi[3] += __uint_as_float(p1[3]);
+                        } else {
+                            for (int r = 0; r < 4; ++r)
+                                if (seg0 + oo + r < n) { const float2 pv = y[seg0 + oo + r]; vr[r] += pv.x; vi[r] += pv.y; }
+                        }
+                    }
+                }
                 if (full) { // (the guard's output power: the outputs of the span only)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) py = fmaf(vr[r], vr[r], fmaf(vi[r], vi[r], py));
@@ -606,22 +627,29 @@ int fir_f16_launch(int KS, const float* x, long n, const float* hist, int Kh, co
 }
 
 // the same on complex samples (real taps); hist = the Kh complex samples in front of x; x and y 16-byte aligned; `table` from fir_f16_make_afrag (one channel)
-int fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard, unsigned char* flags /*ceil(n / 2048) bytes*/) {
-    if (KS < 3 || KS > 9) return GR4HIP_UNSUPPORTED;
+// delay / accum / gthr: a slice of a longer filter (y[i] (+)= sum_k b[k] x[i - delay - k]; gthr > 0: the whole filter's threshold, judged on the sums this pass leaves)
+int fir_f16_c32_launch(int KS, const float* x, long n, const float* hist, int Kh, const void* table, float* y, hipStream_t st, float* new_hist, int guard, unsigned char* flags /*ceil(n / 2048) bytes*/,
+                       int delay, int accum, float gthr) {
+    if (KS < 3 || KS > 9 || 32 * KS - 16 + delay > kHfSegC) return GR4HIP_UNSUPPORTED;
+    const bool sl = delay != 0 || accum != 0 || gthr > 0.f;
     const auto tb   = static_cast<const unsigned short*>(table);
     const auto xc   = reinterpret_cast<const float2*>(x), hc = reinterpret_cast<const float2*>(hist);
     const auto yc   = reinterpret_cast<float2*>(y), nh = reinterpret_cast<float2*>(new_hist);
     const long nseg = ceil_div(n, (long)kHfSegC);
     const int  spw  = (int)std::min<long>(std::max<long>(nseg / GR4_F16_TARGET_WGS, 1), GR4_F16_MAX_SPW);
     const dim3 grid((unsigned)ceil_div(nseg, (long)spw));
-#define GR4_HFC_CASE(K) case K: hipLaunchKernelGGL(fir_mfma_f16x2_c32_kernel<K>, grid, dim3(256), 0, st, xc, hc, Kh, tb, yc, n, nh, spw, guard, flags); break
+#define GR4_HFC_CASE(K) case K: if (sl) hipLaunchKernelGGL((fir_mfma_f16x2_c32_kernel<K, true>), grid, dim3(256), 0, st, xc, hc, Kh, tb, yc, n, nh, spw, guard, flags, delay, accum, gthr); \
+                                else hipLaunchKernelGGL((fir_mfma_f16x2_c32_kernel<K, false>), grid, dim3(256), 0, st, xc, hc, Kh, tb, yc, n, nh, spw, guard, flags, 0, 0, 0.f); break
     switch (KS) {
         GR4_HFC_CASE(3);
         GR4_HFC_CASE(4);
         GR4_HFC_CASE(5);
         GR4_HFC_CASE(6);
         GR4_HFC_CASE(7);
-        GR4_HFC_CASE(8);
+    case 8: // (no sliced instantiation: it would keep two registers in scratch -- fir.hip gives such a slice the 9-step kernel on zero-padded taps)
+        if (sl) return GR4HIP_UNSUPPORTED;
+        hipLaunchKernelGGL((fir_mfma_f16x2_c32_kernel<8, false>), grid, dim3(256), 0, st, xc, hc, Kh, tb, yc, n, nh, spw, guard, flags, 0, 0, 0.f);
+        break;
         GR4_HFC_CASE(9);
     default: return GR4HIP_UNSUPPORTED;
     }

@@ -448,6 +448,41 @@ def test_fir_complex_f16_two_term_kernel(G, ntaps, devsw):
     assert e_off > 3e-5 and e_def <= max(TOL, e_ref) and e_def <= 1e-6, (e_def, e_off, e_ref)  # the contract's bound (the reference's float32 sum), factor one
 
 
+@pytest.mark.parametrize("ntaps", [257, 300, 480, 496, 512, 777, 1000, 1024])
+def test_fir_complex_long_filters_as_slices_on_the_f16_kernel(G, ntaps):
+    """round 5: fir_filter<complex<float>> with 257 .. 1024 taps on long aligned spans = slices of 256 taps on the two-term f16 kernel, each a pass over the input delayed by 256 p
+    samples that adds to y (until then: the f32 matrix pipe at its peak, 36 Gsamples/s at 512 taps); the last slice judges the SUMS against the whole filter's threshold and the marked
+    segments are evaluated again with all the taps in float64.  Ragged calls (short ones take the other kernels: the history is one), any level of the stream, a rejected tone 30 dB
+    above what passes, and one 50 dB above the noise against the reference's float32 sum (factor one).  480 / 496 taps: a last slice of 224 / 240 taps is the 8-K-step shape,
+    which runs the 9-step kernel on zero-padded taps."""
+    b = O.design_taps_hamming_lowpass(ntaps, 0.02)
+    n = 400_000
+    x = O.signal_c32(91, n, tone_frel=0.31, tone_amp=30.0)
+    truth, _ = O.fir(b, x)
+    cuts = [0, 150_000, 150_002, 151_000, n]
+
+    def run(flt, xx):
+        return np.concatenate([flt.process_bulk(_dev16c(xx[lo:hi])).cpu().numpy() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert _rel(run(G.fir_filter(b, torch.complex64), x), truth) <= TOL
+    for scale in (1e-30, 1e30):
+        xs_ = (x.astype(np.complex128) * scale).astype(np.complex64)
+        ts, _ = O.fir(b, xs_)
+        assert _rel(run(G.fir_filter(b, torch.complex64), xs_), ts) <= TOL
+    bw = O.design_taps_hamming_lowpass(ntaps, 0.1)
+    xi = (O.signal_c32(7, n, tone_amp=0.0) * 0.05).astype(np.complex64)
+    xi += (316.0 * np.exp(2j * np.pi * 0.31 * np.arange(n))).astype(np.complex64)
+    ti, _ = O.fir(bw, xi)
+    sl = slice(ntaps, n)
+    f = G.fir_filter(bw, torch.complex64)
+    e_def = _rel(f.process_bulk(_dev16c(xi)).cpu().numpy()[sl], ti[sl])
+    assert e_def <= max(TOL, _ref32_err(bw, xi, ti, sl)) and e_def <= 2e-6, e_def
+    xn = x.copy(); xn[250_000] = np.nan + 0j; xn[300_000] = np.inf  # non-finite samples: the segments that hold one are evaluated again as plain sums
+    got = G.fir_filter(b, torch.complex64).process_bulk(_dev16c(xn)).cpu().numpy()
+    tn, _ = O.fir(b, xn)
+    fin = np.isfinite(tn)
+    assert np.array_equal(np.isfinite(got), fin) and _rel(got[fin], tn[fin]) <= TOL
+
+
 @pytest.mark.parametrize("decim,ntaps", [(8, 1024), (2, 64), (3, 600), (4, 100), (10, 1000), (5, 91), (16, 4096), (16, 512), (16, 33), (32, 1024), (32, 7), (64, 2048), (64, 100), (64, 1),
                                          (11, 352), (12, 384), (20, 333), (24, 100), (25, 800), (48, 1536), (100, 1000), (96, 1536),
                                          (2, 256), (2, 258), (2, 17), (3, 243), (4, 228), (5, 213), (7, 100), (9, 152), (9, 153), (6, 1)])
