@@ -775,7 +775,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // until then these filters took the f32 matrix pipe at its peak: 512 taps 36 Gsamples/s, 1024 taps 17).  The last slice judges the sums against the whole filter's threshold;
     // marked segments again with all the taps on the FP64 matrix pipe.
     if (f->S == 2 && f->decim == 1 && f->ntaps > 256 && f->ntaps <= 1024 && done == 0 && n_in >= kMfmaMinSamples / 2 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
-        algo == GR4HIP_FIR_AUTO && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && f->hfKS >= 0 && plain) {
+        algo != GR4HIP_FIR_EXACT_F32 && !f->f32_user && !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && f->hfKS >= 0 && plain) {
         int          rc = GR4HIP_OK;
         const size_t nslice = ceil_div(f->ntaps, (size_t)256);
         if (f->hfKS == 0) {
