@@ -1,3 +1,4 @@
+"""developer tool: the chain's kernel pair (GR4HIP_CHAIN_UNFUSED, 256 taps / 8192-point frames) a few times at two cut-offs, for a rocprofv3 kernel trace (which kernels, how long each)"""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
