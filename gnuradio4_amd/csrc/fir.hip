@@ -788,6 +788,8 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
                 const size_t                len = std::min<size_t>(256, f->ntaps - 256 * p);
                 const int                   nat = std::max(3, (int)((len - 1 + 16 + 31) / 32));
                 ok = fir_f16_make_afrag(f->taps.data() + 256 * p, len, &f->hf_ks[p], &af, 1, nat == 8 ? 9 : 0); // (the sliced kernel at 8 K-steps would keep two registers in scratch: such a slice runs the 9-step kernel on zero-padded taps)
+                if (ok && p + 1 == nslice && f->guard_ratio != kGuardSegmentRatio) { const float g = (float)(f->tap_power * f->guard_ratio); std::memcpy(af.data() + (size_t)f->hf_ks[p] * 1536 + 6, &g, 4); } // (the judging slice carries the
+                // library-internal caller's second verdict on the whole output power, like the one-pass table above)
                 f->hf_off[p] = all.size();
                 all.insert(all.end(), af.begin(), af.end());
             }
