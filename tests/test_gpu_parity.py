@@ -316,7 +316,7 @@ def test_fir_float_f16_two_term_kernel(G, ntaps, devsw):
     assert e_hf <= 3e-6 and e_hf <= 2 * e_bf + 1e-7, (e_hf, e_bf)
 
 
-@pytest.mark.parametrize("ntaps", [384, 777, 1024])
+@pytest.mark.parametrize("ntaps", [257, 300, 383, 384, 777, 1024, 1100, 2048])
 def test_fir_f16_slices_of_a_long_filter_are_judged_on_their_sum(G, ntaps):
     """fir_filter<float> with 384 .. 1024 taps runs as 256-tap slices that add into y; a slice sees partial sums, so until round 5 these ran unjudged (2e-4 of the
     output under a tone 50 dB above it: worse than the reference's float32 sum).  The LAST slice judges the sums it leaves in y -- the whole filter's outputs -- and marked
@@ -448,7 +448,7 @@ def test_fir_complex_f16_two_term_kernel(G, ntaps, devsw):
     assert e_off > 3e-5 and e_def <= max(TOL, e_ref) and e_def <= 1e-6, (e_def, e_off, e_ref)  # the contract's bound (the reference's float32 sum), factor one
 
 
-@pytest.mark.parametrize("ntaps", [257, 300, 480, 496, 512, 777, 1000, 1024])
+@pytest.mark.parametrize("ntaps", [257, 300, 480, 496, 512, 777, 1000, 1024, 1500, 1792])
 def test_fir_complex_long_filters_as_slices_on_the_f16_kernel(G, ntaps):
     """round 5: fir_filter<complex<float>> with 257 .. 1024 taps on long aligned spans = slices of 256 taps on the two-term f16 kernel, each a pass over the input delayed by 256 p
     samples that adds to y (until then: the f32 matrix pipe at its peak, 36 Gsamples/s at 512 taps); the last slice judges the SUMS against the whole filter's threshold and the marked

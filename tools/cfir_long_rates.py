@@ -8,7 +8,7 @@ from _timing import steady
 def lowpass(nt, fc):
     k = np.arange(nt); t = np.hamming(nt) * 2 * fc * np.sinc(2 * fc * (k - (nt - 1) / 2)); return (t / t.sum()).astype(np.float32)
 x = G.synth_c32(1 << 26, seed=1); y = torch.empty_like(x)
-for nt in (256, 257, 384, 512, 768, 1024):
+for nt in (256, 257, 384, 512, 768, 1024, 1280, 1792, 1800):
     row = []
     for sw in (0, 1):
         capi.developer_switch("GR4HIP_FIR_NO_F16X2", sw)
