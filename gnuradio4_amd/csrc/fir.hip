@@ -863,7 +863,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // (fir_bf16.hip: float32 accuracy, 2.4 times less matrix-pipe time than the f32 MFMA -- HBM-bound instead of MFMA-bound)
     // (384 .. 1024 taps: slices of 256 taps, each a pass over the input delayed by 256 p samples that adds to y: 512 taps 115 instead of 90 Gsamples/s on the
     // register-window kernel, 1024 taps 50.5 instead of 47; below 384 and above 1024 taps the extra passes cost more than they save -- measured)
-    if (f->S == 1 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 2048 /* (round 5's last day: 257 .. 383 and 1025 .. 2048 taps as slices too -- the three-term bf16 slices they were measured against in round 3 are not what they compete with any more: 257 / 300 / 383 taps 167 / 148 / 119 Gsamples/s on the other kernels, 1100 taps 44) */ && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
+    if (f->S == 1 && f->decim == 1 && f->ntaps > 32 && f->ntaps <= 3840 /* (fifteen slices: a slice's window and its delay must fit the kernel's 4096-sample segment; round 5's last day: 257 .. 383 and 1025 .. 3840 taps as slices too -- the three-term bf16 slices they were measured against in round 3 are not what they compete with any more: 257 / 300 / 383 taps 167 / 148 / 119 Gsamples/s on the other kernels, 1100 taps 44) */ && n_in >= kMfmaMinSamples && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 &&
         algo == GR4HIP_FIR_AUTO && !no_bf16x3(f) && !f->bf16_user && !dev_switch(kDevFirNoF16x2) && f->hfKS >= 0 && plain) {
         // ... on the f16 matrix pipe with two-term splits under a per-segment block exponent (fir_f16.hip): three products per tap instead of six
         int          rc = GR4HIP_OK;

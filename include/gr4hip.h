@@ -164,7 +164,7 @@ int gr4hip_ring_size(const gr4hip_ring_t* ring, size_t* bytes);
 /* Non-finite and near-FLT_MAX samples (pinned by tests/test_gpu_parity.py::test_fir_non_finite_samples / test_fir_f16_kernel_outliers_and_non_finite_samples /
  * test_chain_non_finite_samples).  The reference's transform_reduce gives +-Inf / NaN on exactly the ntaps outputs whose window contains such a sample.  With the
  * default algorithm:
- *  - 33 .. 256 taps (float and complex; as slices of 256 taps that add into y: float up to 2048, complex up to 1792 taps) on long 16-byte-aligned spans evaluate the products on the f16 matrix pipe, samples and taps split
+ *  - 33 .. 256 taps (float and complex; as slices of 256 taps that add into y: float up to 3840, complex up to 1792 taps) on long 16-byte-aligned spans evaluate the products on the f16 matrix pipe, samples and taps split
  *    into two f16 terms under a block exponent per segment of 4096 (complex: 2048) outputs (csrc/fir_f16.hip; same 1e-5 parity bar).  A segment that holds a
  *    non-finite sample is evaluated as plain float32 sums instead: the reference's classes (+Inf, -Inf, NaN) on exactly its outputs; a finite outlier more than
  *    2^28 above the segment's ordinary level (1e30 or 3.4e38 beside unit-power samples, a burst that ends inside the segment) sends its segment to float32 products on the f32 matrix pipe, so the
@@ -185,7 +185,7 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
 /* FIR_AUTO carries the same dynamic-range guard as GR4HIP_CHAIN_AUTO (gr4hip_chain_last_power_ratio below): the first fast convolution of a stream is probed
  * on eight frames, later ones are watched through the powers every launch measures (every frame judged by itself), and below an output / input power ratio of
  * 0.04 the direct form takes over. */
-/* Accuracy of the direct form on the matrix pipes (the default for 33 .. 2048 taps -- complex: .. 1792 -- and the decimators; GR4HIP_FIR_TIME_DOMAIN for complex data).  Two-term f16
+/* Accuracy of the direct form on the matrix pipes (the default for 33 .. 3840 taps -- complex: .. 1792 -- and the decimators; GR4HIP_FIR_TIME_DOMAIN for complex data).  Two-term f16
  * splits under a per-segment block exponent, three products per tap (everything above 2^-22 of a product; a correctly rounded float32 product carries 2^-25): on
  * ordinary input the error against float64 is that of a float32 sum (3e-7 .. 6e-7).  The error is relative to the PRODUCTS, so it shows against the OUTPUT when the
  * filter removes nearly all it is given -- like the reference's own float32 sum, whatever its order.  ONE guard for every kernel gr4hip_fir_process can take (round 5):

@@ -316,7 +316,7 @@ def test_fir_float_f16_two_term_kernel(G, ntaps, devsw):
     assert e_hf <= 3e-6 and e_hf <= 2 * e_bf + 1e-7, (e_hf, e_bf)
 
 
-@pytest.mark.parametrize("ntaps", [257, 300, 383, 384, 777, 1024, 1100, 2048])
+@pytest.mark.parametrize("ntaps", [257, 300, 383, 384, 777, 1024, 1100, 2048, 3000, 3840])
 def test_fir_f16_slices_of_a_long_filter_are_judged_on_their_sum(G, ntaps):
     """fir_filter<float> with 384 .. 1024 taps runs as 256-tap slices that add into y; a slice sees partial sums, so until round 5 these ran unjudged (2e-4 of the
     output under a tone 50 dB above it: worse than the reference's float32 sum).  The LAST slice judges the sums it leaves in y -- the whole filter's outputs -- and marked
