@@ -615,6 +615,14 @@ class Rotator(_Handle):
         check(lib().gr4hip_rotator_set_algo(self._h, ids[algo]), "Rotator.set_algo")
         self.algo = algo
 
+    def settings_changed(self, initial_phase: float = 0.0):
+        """settingsChanged (Rotator.hpp:40-49): _accumulated_phase = initial_phase.  Host-side note; the device word (recurrence) is stored on the next call's stream."""
+        if self._f64:
+            check(lib().gr4hip_rotator64_reset(self._h, float(initial_phase)), "Rotator.reset")
+        else:
+            check(lib().gr4hip_rotator_reset(self._h, float(np.float32(initial_phase))), "Rotator.reset")
+        self.initial_phase = initial_phase
+
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "Rotator")
         if x.dtype != self.dtype:

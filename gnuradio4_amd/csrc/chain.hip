@@ -19,7 +19,7 @@ void chain_fused_set_max_workgroups(ChainFused* c, unsigned n);
 void chain_fused_set_measure(ChainFused* c, bool on);
 void chain_fused_set_redo(ChainFused* c, bool on); // measured launches mark their frames one by one and chain_redo_kernel follows them
 int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio);
-const float* chain_fused_history(const ChainFused* c);
+const float* chain_fused_history(ChainFused* c, hipStream_t st); // (applies a pending reset on `st` first; null: that failed)
 int  chain_fused_set_history(ChainFused* c, const float* d_hist256, hipStream_t st);
 struct ChainTd;
 int  chain_td_supported(size_t ntaps, size_t fft_size, int window);
@@ -27,7 +27,7 @@ int  chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_
 int  chain_td_reset(ChainTd* c);
 int  chain_td_process(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st, bool judged);
 const unsigned char* chain_td_flags(const ChainTd* c);
-const float* chain_td_history(const ChainTd* c, int* Kp);
+const float* chain_td_history(ChainTd* c, int* Kp, hipStream_t st);
 int  chain_fused_redo(ChainFused* c, const float* d_in, const float* d_hist, int hist_len, size_t n_samples, float* d_out, const unsigned char* d_flags, int flags_per_block, hipStream_t st);
 int  chain_td_set_history256(ChainTd* c, const float* d_hist256, hipStream_t st);
 void chain_td_destroy(ChainTd* c);
@@ -137,7 +137,8 @@ static int chain_td_run(gr4hip_chain* c, const void* d_in, size_t frames, float*
         if (const int rc = chain_fused_create(&c->td_redo, c->taps.data(), c->taps.size(), c->N, c->window, GR4HIP_CHAIN_FUSED_FD)) return rc;
     }
     int          Kp   = 0;
-    const float* hist = chain_td_history(c->td, &Kp); // the samples in front of THIS call (the launch writes the other half of the pair)
+    const float* hist = chain_td_history(c->td, &Kp, st); // the samples in front of THIS call (the launch writes the other half of the pair)
+    if (!hist) return GR4HIP_RUNTIME_ERROR;
     int rc = chain_td_process(c->td, static_cast<const float*>(d_in), frames, d_mag2, st, judged);
     if (!rc && judged) rc = chain_fused_redo(c->td_redo, static_cast<const float*>(d_in), hist, Kp, frames * c->N, d_mag2, chain_td_flags(c->td), 2, st);
     return rc;
@@ -160,6 +161,7 @@ static int chain_time_domain(gr4hip_chain* c, const void* d_in, size_t frames, f
 static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, hipStream_t st) {
     std::vector<float>& taps = c->taps;
     int rc = GR4HIP_OK;
+    if (!d_hist256) return GR4HIP_RUNTIME_ERROR; // (chain_fused_history could not enqueue the pending reset: the error text is set)
     // the kernel pair with float32 products (GR4HIP_FIR_TIME_DOMAIN_F32), at every fft size: the regime that trips the guard -- a rejected signal far above the
     // output -- is the one in which the three-term bf16 products of chain_td_kernel / the split-product direct forms measure 3 .. 16 x a float32 sum's error.
     // (Round 4 tried the two-term f16 direct form here, whose own guard redoes the segments that reject more than 36 dB of their power: the pair went from 97 to
@@ -201,7 +203,7 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
             // (they are the faster way through such a stream than fused kernel + second evaluation of every frame) -- without waiting for anything.
             if (chain_fused_power_ratio(c->fused, false, false, &ratio)) c->last_ratio = ratio;
             if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) {
-                int rc = chain_switch_to_time_domain(c, chain_fused_history(c->fused), st);
+                int rc = chain_switch_to_time_domain(c, chain_fused_history(c->fused, st), st);
                 if (rc) return rc;
                 return chain_time_domain(c, d_in, frames, d_mag2, stream);
             }
@@ -214,7 +216,7 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
         if (!c->probed) { // first call after create / reset: the first blocks synchronously, before the rest of the span is committed to an algorithm
             int rc = c->d_hist_save.ensure(256 * 2 * sizeof(float));
             if (rc) return rc;
-            GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused, st), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
             const size_t probe = std::min(frames, kGuardProbeFrames * per);
             rc = chain_fused_process(c->fused, x, probe, d_mag2, st);
             if (rc) return rc;
@@ -227,7 +229,7 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
                 return chain_time_domain(c, d_in, frames, d_mag2, stream);
             }
         } else if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) { // an earlier call ran into the regime: switch before this one
-            int rc = chain_switch_to_time_domain(c, chain_fused_history(c->fused), st);
+            int rc = chain_switch_to_time_domain(c, chain_fused_history(c->fused, st), st);
             if (rc) return rc;
             return chain_time_domain(c, d_in, frames, d_mag2, stream);
         }
@@ -319,7 +321,7 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
             gr4hip_chain* c = chains[i];
             int rc = c->d_hist_save.ensure(256 * 2 * sizeof(float));
             if (rc) return rc;
-            GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            GR4_HIP_TRY(hipMemcpyAsync(c->d_hist_save.ptr, chain_fused_history(c->fused, st), 256 * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
         { // a finished earlier launch decides for this one, without waiting (strict: the frames THIS launch marks are evaluated again on the device behind it)
             bool bad = false;

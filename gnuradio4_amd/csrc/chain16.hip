@@ -321,7 +321,7 @@ template <typename T>
 static int upload16(DeviceBuffer& b, const std::vector<T>& h) {
     int rc = b.ensure(h.size() * sizeof(T));
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(b.ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    GR4_HIP_TRY(upload_fresh(b.ptr, h.data(), h.size() * sizeof(T)));
     return GR4HIP_OK;
 }
 

@@ -1104,6 +1104,8 @@ struct ChainFused {
     hipStream_t  pw_stream = nullptr;  // stream of the last measured launch
     float        win_gain = 1.f;       // mean w[n]^2 of the window the measured output carries (1: none)
     bool         redo     = false;     // measured launches also mark their frames one by one and chain_redo_kernel follows them (chain.hip, GR4HIP_GUARD_STRICT)
+    bool         zero_hist = true;     // reset asked for (or nothing has run yet): the carried history is zeroed on the stream of the next call that reads it (common.hpp, the stream rule)
+    unsigned     pw_floor = 0;         // measurements of launches up to this one belong to the stream before the last reset
     DeviceBuffer d_fflags;             // one byte per frame of the last launch
     ~ChainFused() {
         if (c16) chain16_destroy(c16);
@@ -1121,7 +1123,7 @@ template <typename T>
 static int upload(DeviceBuffer& b, const std::vector<T>& h) {
     int rc = b.ensure(h.size() * sizeof(T));
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(b.ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    GR4_HIP_TRY(upload_fresh(b.ptr, h.data(), h.size() * sizeof(T)));
     return GR4HIP_OK;
 }
 
@@ -1211,8 +1213,19 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
     return GR4HIP_OK;
 }
 
+// Block::reset() runs on the block's worker between two work() calls (Block.hpp:606, 1296): here it is a host-side note, and the history is zeroed ON THE STREAM of
+// the next call that reads it -- behind whatever that stream still has in flight for this handle (the carry of the launch before, chain_fused_run)
 int chain_fused_reset(ChainFused* c) {
-    GR4_HIP_TRY(hipMemset(c->d_hist.ptr, 0, 256 * sizeof(float2)));
+    c->zero_hist = true;
+    c->pw_floor  = c->pw_seq; // what launches of the old stream measured decides nothing for the new one
+    return GR4HIP_OK;
+}
+// the carried history as the next call must see it, in stream order
+static int history_on(ChainFused* c, hipStream_t st) {
+    if (c->zero_hist) {
+        GR4_HIP_TRY(hipMemsetAsync(c->d_hist.ptr, 0, 256 * sizeof(float2), st));
+        c->zero_hist = false;
+    }
     return GR4HIP_OK;
 }
 
@@ -1222,7 +1235,7 @@ static int arm_measure(ChainFused* c, hipStream_t st) {
         constexpr size_t words = kPwFrameSlots + 2 * kPwMaxWorkgroups; // 16 {in, out} slots, the done counter, the flag word, two verdict words per workgroup
         int rc = c->d_pw.ensure(words * sizeof(float));
         if (rc) return rc;
-        GR4_HIP_TRY(hipMemset(c->d_pw.ptr, 0, words * sizeof(float)));
+        GR4_HIP_TRY(hipMemsetAsync(c->d_pw.ptr, 0, words * sizeof(float), st)); // (in front of the first measured launch, on its stream)
         GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 4 * sizeof(float), hipHostMallocMapped));
         std::memset(c->h_pw, 0, 4 * sizeof(float));
         GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_hpw), c->h_pw, 0));
@@ -1236,6 +1249,7 @@ static int arm_measure(ChainFused* c, hipStream_t st) {
 // the output is the filtered stream itself (complex) instead of |FFT|^2
 static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist256, size_t n_frames, float* d_out, hipStream_t st, bool fir_mode, bool carry_hist,
                            bool fft_only = false, const float* fft_window = nullptr, bool fft_spectrum = false) {
+    if (!hist256) { if (const int rc = history_on(c, st)) return rc; }
     {
         const int use16 = dev_switch(kDevChain16);
         const bool plain_chain = !fir_mode && !fft_only && !c->windowed && c->small_log2n == 0;
@@ -1402,6 +1416,7 @@ int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps,
     ChainFdArgs  a{};
     ChainFdMulti m{};
     ChainFused*  c0 = cs[0];
+    for (size_t i = 0; i < n; ++i) { if (const int rc = history_on(cs[i], st)) return rc; }
     a.x = reinterpret_cast<const float2*>(d_in[0]);
     a.hist = static_cast<const float2*>(c0->d_hist.ptr);
     a.H = static_cast<const float2*>(c0->d_H.ptr);
@@ -1532,7 +1547,7 @@ int chain_fused_redo(ChainFused* c, const float* d_in, const float* d_hist, int 
     return GR4HIP_OK;
 }
 int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio) {
-    if (!c->h_pw || c->pw_seq == c->pw_read) return 0;
+    if (!c->h_pw || c->pw_seq == c->pw_read || c->pw_seq == c->pw_floor) return 0;
     volatile unsigned* seqw = reinterpret_cast<volatile unsigned*>(c->h_pw) + 2; // sequence number of the launch whose pair the word holds
     if (wait) { // spin on the mapped word the launch's last workgroup writes; every 4096 polls check that the stream has not simply failed / finished without it
         for (unsigned long spins = 1; *seqw != c->pw_seq; ++spins) {
@@ -1545,7 +1560,7 @@ int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* r
         }
     }
     const unsigned long long word = *reinterpret_cast<volatile unsigned long long*>(c->h_pw); // {in, out} of the most recent finished launch, stored whole
-    if (!wait && *seqw == c->pw_seen) return 0;                                                 // nothing new has arrived
+    if (!wait && (*seqw == c->pw_seen || (int)(*seqw - c->pw_floor) <= 0)) return 0;            // nothing new has arrived (or only from before the last reset)
     c->pw_seen = *seqw;
     c->pw_word = word;
     c->pw_read = c->pw_seq; // (with wait: exactly; without: at least one newer launch has reported)
@@ -1561,8 +1576,10 @@ int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* r
     if (reinterpret_cast<volatile unsigned*>(c->h_pw)[3] != 0u && *ratio >= thr) *ratio = 0.5f * thr;
     return 1;
 }
-const float* chain_fused_history(const ChainFused* c) { return static_cast<const float*>(c->d_hist.ptr); } // the 256 samples before the next call's first frame
+// the 256 samples before the next call's first frame, valid for work enqueued on `st` behind this call (null: the pending zeroing could not be enqueued)
+const float* chain_fused_history(ChainFused* c, hipStream_t st) { return history_on(c, st) ? nullptr : static_cast<const float*>(c->d_hist.ptr); }
 int chain_fused_set_history(ChainFused* c, const float* d_hist256, hipStream_t st) {
+    c->zero_hist = false;
     GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, d_hist256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
     return GR4HIP_OK;
 }

@@ -340,15 +340,22 @@ struct ChainTd {
     bool         windowed = false;
     DeviceBuffer d_afrag, d_win, d_tw, d_hist[2];
     int          cur = 0, dev = 0;
+    bool         zero_hist = true; // reset asked for (or nothing has run yet): d_hist[cur] is zeroed on the stream of the next call that reads it (common.hpp, the stream rule)
 };
 
 int chain_td_supported(size_t ntaps, size_t fft_size, int window) {
     return is_pow2(fft_size) && fft_size >= 256 && fft_size <= 4096 && ntaps >= 1 && ntaps <= 256 && window >= GR4HIP_WIN_NONE && window <= GR4HIP_WIN_KAISER;
 }
 
-int chain_td_reset(ChainTd* c) {
-    for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(c->d_hist[k].ptr, 0, (size_t)c->Kp * sizeof(float2)));
-    c->cur = 0;
+int chain_td_reset(ChainTd* c) { // host-side note only: a launch still in flight may be writing d_hist[cur] (its `new_hist`); the zeroing goes behind it on the next call's stream
+    c->zero_hist = true;
+    return GR4HIP_OK;
+}
+static int td_history_on(ChainTd* c, hipStream_t st) {
+    if (c->zero_hist) {
+        GR4_HIP_TRY(hipMemsetAsync(c->d_hist[c->cur].ptr, 0, (size_t)c->Kp * sizeof(float2), st));
+        c->zero_hist = false;
+    }
     return GR4HIP_OK;
 }
 
@@ -372,7 +379,7 @@ int chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_s
     auto up = [](DeviceBuffer& b, const void* p, size_t bytes) -> int {
         int rc = b.ensure(bytes);
         if (rc) return rc;
-        GR4_HIP_TRY(hipMemcpy(b.ptr, p, bytes, hipMemcpyHostToDevice));
+        GR4_HIP_TRY(upload_fresh(b.ptr, p, bytes));
         return GR4HIP_OK;
     };
     int rc = up(c->d_afrag, af.data(), af.size() * sizeof(unsigned short));
@@ -400,13 +407,15 @@ int chain_td_create(ChainTd** out, const float* taps, size_t ntaps, size_t fft_s
 
 void chain_td_destroy(ChainTd* c) { delete c; }
 
-// the carried history: the last Kp complex samples of the stream, hist[h] = x[-Kp + h] of the next call
-const float* chain_td_history(const ChainTd* c, int* Kp) {
+// the carried history: the last Kp complex samples of the stream, hist[h] = x[-Kp + h] of the next call; valid for work enqueued on `st` behind this call
+// (null: a pending reset could not be enqueued)
+const float* chain_td_history(ChainTd* c, int* Kp, hipStream_t st) {
     if (Kp) *Kp = c->Kp;
-    return static_cast<const float*>(c->d_hist[c->cur].ptr);
+    return td_history_on(c, st) ? nullptr : static_cast<const float*>(c->d_hist[c->cur].ptr);
 }
 // start from the 256 complex samples in front of the next call (the fused frequency-domain kernel's convention)
 int chain_td_set_history256(ChainTd* c, const float* d_hist256, hipStream_t st) {
+    c->zero_hist = false;
     GR4_HIP_TRY(hipMemcpyAsync(c->d_hist[c->cur].ptr, d_hist256 + 2 * (256 - c->Kp), (size_t)c->Kp * sizeof(float2), hipMemcpyDeviceToDevice, st));
     return GR4HIP_OK;
 }
@@ -457,6 +466,7 @@ static int td_launch(ChainTd* c, const float* d_in, size_t n_frames, float* d_ma
 int chain_td_process(ChainTd* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st, bool judged) {
     if (n_frames == 0) return GR4HIP_OK;
     GR4_REQUIRE((uintptr_t)d_in % 8 == 0 && (uintptr_t)d_mag2 % 4 == 0, "fused time-domain chain: misaligned device pointer");
+    if (const int rc = td_history_on(c, st)) return rc;
     switch (c->KS) {
     case 3: return td_launch<3>(c, d_in, n_frames, d_mag2, st, judged);
     case 5: return td_launch<5>(c, d_in, n_frames, d_mag2, st, judged);

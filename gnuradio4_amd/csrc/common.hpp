@@ -78,11 +78,14 @@ template <typename T> inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 // A rotator's phase in TURNS as a 64-bit binary fraction (units of 2^-64 turn): sums and products modulo 2^64 ARE the reduction modulo one turn, so
 // phase(k) = p0 + k inc is exact however long the stream and however it is associated -- p0 + k inc at once, or the phase of the sample before plus inc: every kernel
 // that evaluates a rotator (math.hip, the element-wise programs, the decimators that carry one as their load program) lands on the same 64 bits.  The increment itself
-// is rounded to 2^-64 turn once (exact for |inc| >= 2^-11 turn; below that 2^-65 turn per sample: 3e-8 turn after 2^40 samples).
-inline unsigned long long turns_fix(double turns) {
-    const double f = turns - std::floor(turns); // [0, 1]
-    return f >= 0.0 && f < 1.0 ? (unsigned long long)(f * 18446744073709551616.0) : 0ull; // (1.0: a tiny negative argument; not finite: the callers mark those)
+// is rounded to 2^-64 turn once, whatever its sign (exact for |inc| >= 2^-11 turn; below that 2^-65 turn per sample: 3e-8 turn after 2^40 samples).
+inline unsigned long long turns_fix_pos(double turns) { // turns >= 0
+    const double f = turns - std::floor(turns); // [0, 1)
+    return f >= 0.0 && f < 1.0 ? (unsigned long long)(f * 18446744073709551616.0) : 0ull; // (not finite: the callers mark those)
 }
+//  a negative argument is converted by magnitude and negated modulo 2^64: `turns - floor(turns)` = 1 - |turns| would round a small negative increment to
+// 2^-53 turn (5e-17 per sample: 3.5e-5 rad after 1e11 samples at -1e-4 rad / sample) where the positive one of the same size keeps 2^-64
+inline unsigned long long turns_fix(double turns) { return turns < 0.0 ? 0ull - turns_fix_pos(-turns) : turns_fix_pos(turns); }
 inline double fix_turns(unsigned long long p) { return (double)p * (1.0 / 18446744073709551616.0); }
 #ifdef __HIPCC__
 // exp(j 2 pi phase): the top 32 bits as a signed fraction of a turn in [-0.5, 0.5) -> float (24 bits: 2^-26 turn), then the hardware sine / cosine, which take turns
@@ -131,6 +134,19 @@ struct DeviceBuffer {
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
     ~DeviceBuffer() { release(); }
 };
+
+// THE STREAM RULE (include/gr4hip.h "Lifecycle calls").  A handle's device state is written in exactly two ways:
+//   (i)  upload_fresh(): a blocking copy into a buffer NO LAUNCH HAS SEEN YET -- the tables *_create builds, and tables built on first use inside a process call
+//        (a new DeviceBuffer, or one whose ensure() has just replaced it: hipFree waits for the device).  Complete when it returns, so visible to work enqueued
+//        afterwards on any stream.
+//   (ii) work enqueued on the stream of a process call: hipMemsetAsync / hipMemcpyAsync / kernels on `st`.
+// reset / set_taps / set_prologue / set_algo never touch the device: they note what the state has to become (zero_hist, taps_dirty, ...) and the next process
+// call applies it on ITS stream, in front of its own launches and therefore behind everything that stream still has in flight for the handle.  That is the
+// reference's contract -- reset() / settingsChanged() run on the block's worker between two work() calls (Block.hpp:606, 916-917, 1296; Scheduler.hpp:1938-1951) --
+// without a device-wide wait, and it holds on hipStreamNonBlocking streams, which the NULL stream does not order against (round 5's race: a NULL-stream hipMemset
+// of the carried history overtaken by the previous launch's carry).  A host-to-device hipMemcpyAsync from pageable memory returns when the source has been
+// consumed (the runtime stages it), so host vectors may be locals.  tests/test_abi_host.py greps for bare hipMemset( / hipMemcpy( in this directory.
+inline hipError_t upload_fresh(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
 
 // host-side restatement of gr::algorithm::window::create<float> (algorithm/.../fourier/window.hpp:69-183)
 int make_window(int type, float* w, size_t n, float beta);

@@ -181,12 +181,12 @@ static void ewise_compile(gr4hip_ewise* p) {
 
 namespace gr4 {
 // (library-internal) the device copy of a program, uploaded on first use after a change
-int ewise_device_ops(gr4hip_ewise* p, EwiseHook* hook) {
+int ewise_device_ops(gr4hip_ewise* p, EwiseHook* hook, hipStream_t st) {
     if (p->dirty) ewise_compile(p);
     if (p->dirty && !p->ops.empty()) {
         int rc = p->d_ops.ensure(p->ops.size() * sizeof(EwiseOp));
         if (rc) return rc;
-        GR4_HIP_TRY(hipMemcpy(p->d_ops.ptr, p->ops.data(), p->ops.size() * sizeof(EwiseOp), hipMemcpyHostToDevice));
+        GR4_HIP_TRY(hipMemcpyAsync(p->d_ops.ptr, p->ops.data(), p->ops.size() * sizeof(EwiseOp), hipMemcpyHostToDevice, st)); // (behind the launches `st` still has in flight with the old program)
     }
     p->dirty      = false;
     hook->ops     = p->ops.empty() ? nullptr : as_prog(p->d_ops.ptr);
@@ -298,7 +298,7 @@ int gr4hip_ewise_process(gr4hip_ewise_t* p, const void* d_in, void* d_out, size_
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "ewise_process: null device pointer");
     EwiseHook prog;
-    int       rc = ewise_device_ops(p, &prog);
+    int       rc = ewise_device_ops(p, &prog, as_stream(stream));
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
     if (prog.n_ops == 0) { // the empty program is the copy block
@@ -333,7 +333,7 @@ int gr4hip_ewise_decimate(gr4hip_ewise_t* p, const void* d_in, size_t n_in, size
     if (n_out == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "ewise_decimate: null device pointer");
     EwiseHook prog;
-    int       rc = ewise_device_ops(p, &prog);
+    int       rc = ewise_device_ops(p, &prog, as_stream(stream));
     if (rc) return rc;
     hipStream_t    st   = as_stream(stream);
     const unsigned grid = (unsigned)std::min<size_t>(ceil_div(n_out, (size_t)256), 8192);

@@ -243,7 +243,7 @@ struct gr4hip_ewise {
     long                      pos   = 0; // samples processed since create / reset: the absolute index a rotator op's phase is a function of
 };
 namespace gr4 {
-int           ewise_device_ops(gr4hip_ewise* p, EwiseHook* hook); // uploads on first use after a change; hook->pos = p->pos
+int           ewise_device_ops(gr4hip_ewise* p, EwiseHook* hook, hipStream_t st); // uploads on first use after a change, on `st` (the stream of the launch that will run it); hook->pos = p->pos
 bool          ewise_as_real_gain(const gr4hip_ewise* p, double* gain);
 gr4hip_ewise* ewise_clone(const gr4hip_ewise* p);
 int           ewise_run(const EwiseHook& prog, int dtype, const void* in, void* out, long n, hipStream_t st);

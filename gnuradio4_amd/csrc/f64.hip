@@ -578,12 +578,16 @@ struct gr4hip_fir64 {
     size_t              decim = 1, hcap = 32;
     DeviceBuffer        d_taps, d_hist[2], d_trow; // d_trow: zero-padded tap row of the matrix-pipe kernel
     int                 cur = 0;
+    // the stream rule (common.hpp): create / reset / set_taps only note what the device state has to become; fir64_state_on() enqueues it on the stream of the next call
+    std::vector<double> row_host;
+    bool                taps_dirty = false, zero_hist = true;
 };
 struct gr4hip_iir64 {
     Iir64Desc    d{};
     int          mp = 0;
     DeviceBuffer d_phiPow, d_phiL, d_phiB, d_state[2], d_P, d_Z, d_T;
     int          cur = 0;
+    bool         zero_state = true; // create / reset note it, the next call zeroes the state pair on its own stream
 };
 struct gr4hip_fft64 {
     size_t       N = 0;
@@ -599,27 +603,39 @@ static size_t bit_ceil_sz(size_t v) { size_t p = 1; while (p < v) p <<= 1; retur
 
 static int fir64_upload(gr4hip_fir64* f, const double* taps, size_t ntaps, bool keep_history) {
     const size_t hcap = std::max<size_t>(32, bit_ceil_sz(ntaps)); // HistoryBuffer{32}, grown by settingsChanged (time_domain_filter.hpp:36-42)
-    int          rc   = f->d_taps.ensure(ntaps * sizeof(double));
+    int          rc   = f->d_taps.ensure(ntaps * sizeof(double)); // (growing frees the old table: hipFree waits for the device)
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(f->d_taps.ptr, taps, ntaps * sizeof(double), hipMemcpyHostToDevice));
     { // fir64_mfma_kernel: row[16 + q] = b[q], zero elsewhere
-        const size_t        Kp = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : ntaps <= 256 ? 256 : (ntaps + 63) / 64 * 64;
-        std::vector<double> row(Kp + 32, 0.0);
+        const size_t         Kp = ntaps <= 64 ? 64 : ntaps <= 128 ? 128 : ntaps <= 256 ? 256 : (ntaps + 63) / 64 * 64;
+        std::vector<double>& row = f->row_host;
+        row.assign(Kp + 32, 0.0);
         for (size_t q = 0; q < ntaps; ++q) row[16 + q] = taps[q];
         rc = f->d_trow.ensure(row.size() * sizeof(double));
         if (rc) return rc;
-        GR4_HIP_TRY(hipMemcpy(f->d_trow.ptr, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (!keep_history || hcap != f->hcap || !f->d_hist[0].ptr) { // a history that has to grow starts empty, as upstream's replaced HistoryBuffer does
         for (auto& h : f->d_hist) {
             rc = h.ensure(hcap * sizeof(double));
             if (rc) return rc;
-            GR4_HIP_TRY(hipMemset(h.ptr, 0, hcap * sizeof(double)));
         }
-        f->cur = 0;
+        f->zero_hist = true;
     }
     f->hcap = hcap;
     f->taps.assign(taps, taps + ntaps);
+    f->taps_dirty = true; // uploaded by fir64_state_on, on the stream of the next call
+    return GR4HIP_OK;
+}
+// pending tap upload / zeroing of the carried history, onto the stream of the call about to be enqueued: behind this handle's earlier launches on it, in front of the next
+static int fir64_state_on(gr4hip_fir64* f, hipStream_t st) {
+    if (f->taps_dirty) {
+        GR4_HIP_TRY(hipMemcpyAsync(f->d_taps.ptr, f->taps.data(), f->taps.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        GR4_HIP_TRY(hipMemcpyAsync(f->d_trow.ptr, f->row_host.data(), f->row_host.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        f->taps_dirty = false;
+    }
+    if (f->zero_hist) {
+        GR4_HIP_TRY(hipMemsetAsync(f->d_hist[f->cur].ptr, 0, f->hcap * sizeof(double), st));
+        f->zero_hist = false;
+    }
     return GR4HIP_OK;
 }
 
@@ -645,7 +661,7 @@ int gr4hip_fir64_set_taps(gr4hip_fir64_t* f, const double* h_taps, size_t ntaps)
 }
 int gr4hip_fir64_reset(gr4hip_fir64_t* f) {
     GR4_REQUIRE(f, "fir64_reset: null handle");
-    for (auto& h : f->d_hist) GR4_HIP_TRY(hipMemset(h.ptr, 0, f->hcap * sizeof(double)));
+    f->zero_hist = true;
     return GR4HIP_OK;
 }
 int gr4hip_fir64_process(gr4hip_fir64_t* f, const double* d_in, size_t n_in, double* d_out, size_t* n_out_p, gr4hip_stream_t stream) {
@@ -656,6 +672,7 @@ int gr4hip_fir64_process(gr4hip_fir64_t* f, const double* d_in, size_t n_in, dou
     if (n_in == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "fir64_process: null device pointer");
     hipStream_t st = as_stream(stream);
+    if (const int rc = fir64_state_on(f, st)) return rc;
     const int   K = (int)f->taps.size(), D = (int)f->decim;
     if (D == 1 && K > 16 && n_in >= 32768 && (uintptr_t)d_out % 16 == 0 && f->d_trow.ptr) { // matrix-pipe form; writes the next history itself
         const int    Kp = K <= 64 ? 64 : K <= 128 ? 128 : K <= 256 ? 256 : (K + 63) / 64 * 64, NPAD = (kF64Seg + Kp) / 16 * 18;
@@ -770,18 +787,16 @@ int gr4hip_iir64_create(gr4hip_iir64_t** out, int form, size_t nsections, const 
     for (auto& s : f->d_state)
         if (!rc) rc = s.ensure(kI64MP * sizeof(double));
     if (rc) { delete f; return rc; }
-    hipError_t e = hipMemcpy(f->d_phiPow.ptr, pow2.data(), pow2.size() * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(f->d_phiL.ptr, powl.data(), powl.size() * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(f->d_phiB.ptr, phiB.data(), phiB.size() * sizeof(double), hipMemcpyHostToDevice);
-    for (auto& s : f->d_state)
-        if (e == hipSuccess) e = hipMemset(s.ptr, 0, kI64MP * sizeof(double));
+    hipError_t e = upload_fresh(f->d_phiPow.ptr, pow2.data(), pow2.size() * sizeof(double));
+    if (e == hipSuccess) e = upload_fresh(f->d_phiL.ptr, powl.data(), powl.size() * sizeof(double));
+    if (e == hipSuccess) e = upload_fresh(f->d_phiB.ptr, phiB.data(), phiB.size() * sizeof(double));
     if (e != hipSuccess) { delete f; set_error("iir64: upload failed: %s", hipGetErrorString(e)); return GR4HIP_RUNTIME_ERROR; }
     *out = f;
     return GR4HIP_OK;
 }
 int gr4hip_iir64_reset(gr4hip_iir64_t* f) {
     GR4_REQUIRE(f, "iir64_reset: null handle");
-    for (auto& s : f->d_state) GR4_HIP_TRY(hipMemset(s.ptr, 0, kI64MP * sizeof(double)));
+    f->zero_state = true;
     return GR4HIP_OK;
 }
 int gr4hip_iir64_process(gr4hip_iir64_t* f, const double* d_in, size_t n, double* d_out, gr4hip_stream_t stream) {
@@ -789,6 +804,10 @@ int gr4hip_iir64_process(gr4hip_iir64_t* f, const double* d_in, size_t n, double
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "iir64_process: null device pointer");
     hipStream_t st    = as_stream(stream);
+    if (f->zero_state) { // a pending reset: onto this call's stream, in front of its launches
+        for (auto& s : f->d_state) GR4_HIP_TRY(hipMemsetAsync(s.ptr, 0, kI64MP * sizeof(double), st));
+        f->zero_state = false;
+    }
     const long  tiles = (long)ceil_div(n, (size_t)kI64BS * kI64L);
     const int   mp    = f->mp;
     int         rc    = f->d_P.ensure((size_t)tiles * kI64BS * mp * sizeof(double));
@@ -834,10 +853,10 @@ int gr4hip_fft64_create(gr4hip_fft64_t** out, size_t fft_size, int window, int f
         std::vector<double> w(fft_size);
         rc = make_window64(window, w.data(), fft_size, 1.6);
         if (!rc) rc = f->d_win.ensure(fft_size * sizeof(double));
-        if (!rc && hipMemcpy(f->d_win.ptr, w.data(), fft_size * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("fft64: window upload failed"); rc = GR4HIP_RUNTIME_ERROR; }
+        if (!rc && upload_fresh(f->d_win.ptr, w.data(), fft_size * sizeof(double)) != hipSuccess) { set_error("fft64: window upload failed"); rc = GR4HIP_RUNTIME_ERROR; }
         f->windowed = true;
     }
-    if (!rc && hipMemcpy(f->d_tw.ptr, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("fft64: twiddle upload failed"); rc = GR4HIP_RUNTIME_ERROR; }
+    if (!rc && upload_fresh(f->d_tw.ptr, tw.data(), tw.size() * sizeof(double)) != hipSuccess) { set_error("fft64: twiddle upload failed"); rc = GR4HIP_RUNTIME_ERROR; }
     if (rc) { delete f; return rc; }
     *out = f;
     return GR4HIP_OK;

@@ -403,7 +403,14 @@ template <int LOG2M>
 static int bluestein_fast_launch(const float* d_in, const float* win, const float2* cconj, const float2* Bf, const float2* tw, const FftOutputs& o, int N, long n_frames, hipStream_t st) {
     constexpr int    M = 1 << LOG2M, FPB = 512 / (M / 16);
     constexpr size_t lds = (size_t)FPB * (M + M / 32) * sizeof(float2);
-    GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bluestein_fast_kernel<LOG2M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static PerDevice per_device; //  the LDS opt-in once per device and instantiation, not a driver call on every launch
+    bool             first = false;
+    int              dev = -1, n_cu = per_device.current(&first, &dev);
+    GR4_REQUIRE(n_cu != 0, "fft: cannot query the current device");
+    if (first) {
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bluestein_fast_kernel<LOG2M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        per_device.done(dev, -n_cu);
+    }
     hipLaunchKernelGGL(bluestein_fast_kernel<LOG2M>, dim3((unsigned)ceil_div(n_frames, (long)FPB)), dim3(512), lds, st, d_in, win, cconj, Bf, tw, o, N, n_frames);
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
@@ -546,7 +553,7 @@ int fft_upload_twiddles(size_t N, DeviceBuffer* buf) {
     }
     int rc = buf->ensure(tw.size() * sizeof(float));
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(buf->ptr, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    GR4_HIP_TRY(upload_fresh(buf->ptr, tw.data(), tw.size() * sizeof(float)));
     return GR4HIP_OK;
 }
 
@@ -597,7 +604,7 @@ static int engine_create(Pow2Engine* e, size_t M) {
                 g[2 * ((size_t)k1 * 256 + n2) + 1] = (float)std::sin(ang);
             }
         rc = e->tw_grid.ensure(g.size() * sizeof(float));
-        if (!rc) GR4_HIP_TRY(hipMemcpy(e->tw_grid.ptr, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (!rc) GR4_HIP_TRY(upload_fresh(e->tw_grid.ptr, g.data(), g.size() * sizeof(float)));
     }
     if (!rc && e->n1 > 16) {
         rc = fft_build_plan((size_t)e->n1, &e->plan_cols);
@@ -696,7 +703,7 @@ int gr4hip_fft_create(gr4hip_fft_t** out, int in_dtype, size_t fft_size, int win
         std::vector<float> w(fft_size);
         rc = make_window(window, w.data(), fft_size, 1.6f); // fft.hpp:141: create(_window, _windowType) -> default beta
         if (!rc) rc = f->d_window.ensure(fft_size * sizeof(float));
-        if (!rc) { hipError_t e = hipMemcpy(f->d_window.ptr, w.data(), fft_size * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("window upload: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+        if (!rc) { hipError_t e = upload_fresh(f->d_window.ptr, w.data(), fft_size * sizeof(float)); if (e != hipSuccess) { set_error("window upload: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     }
     if (rc) { delete f; return rc; }
     *out = f;
@@ -754,8 +761,8 @@ static int fft_upload_bluestein(size_t N, size_t M, DeviceBuffer* d_cconj, Devic
     int rc = d_cconj->ensure(cc.size() * sizeof(float));
     if (!rc) rc = d_Bf->ensure(bf.size() * sizeof(float));
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(d_cconj->ptr, cc.data(), cc.size() * sizeof(float), hipMemcpyHostToDevice));
-    GR4_HIP_TRY(hipMemcpy(d_Bf->ptr, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+    GR4_HIP_TRY(upload_fresh(d_cconj->ptr, cc.data(), cc.size() * sizeof(float)));
+    GR4_HIP_TRY(upload_fresh(d_Bf->ptr, bf.data(), bf.size() * sizeof(float)));
     return GR4HIP_OK;
 }
 
@@ -902,7 +909,7 @@ int gr4hip_fft_mag2(gr4hip_fft_t* f, const void* d_in, size_t n_frames, float* d
     GR4_REQUIRE(d_mag2 || n_frames == 0, "fft_mag2: null output");
     GR4_REQUIRE(f, "fft_mag2: null handle");
     EwiseHook post;
-    if (f->post) { if (const int rc = ewise_device_ops(f->post, &post)) return rc; }
+    if (f->post) { if (const int rc = ewise_device_ops(f->post, &post, as_stream(stream))) return rc; }
     // 8192-point complex frames, >= one frame per CU: the frame pipeline of the fused chain kernel without its filter (LDS-DMA prefetch of the next
     // frame during the transform of this one); everything else goes to the FFT block kernels
     if (fft_on_frame_pipeline(f, n_frames)) {

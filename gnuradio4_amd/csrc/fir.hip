@@ -155,19 +155,29 @@ __global__ __launch_bounds__(BS) void fir_poly_kernel(const float* __restrict__ 
             px += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r) py = fmaf(acc[r], acc[r], py);
+        for (int r = 0; r < R; ++r)
+            if (M0 * S + (long)tid * R + r < n_out * S) py = fmaf(acc[r], acc[r], py); // (outputs past the span do not exist: the filter's transient into the zero-staged samples behind a truncated tone is not output power)
         px = hf_wave_sum(px);
         py = hf_wave_sum(py);
         if ((tid & 63) == 0) { judge_red[tid >> 6] = px; judge_red[BS / 64 + (tid >> 6)] = py; }
         __syncthreads();
+        //  only waves whose 64 R outputs all exist vote: a wave past n_out sees zero-staged samples, its output power is 0 and the quietest-wave
+        // statistic sent the last workgroup of EVERY call -- and every call shorter than 3/4 of a workgroup -- through the float64 loop.  A workgroup without one
+        // complete wave (a span shorter than 64 R outputs) is judged on wave 0 alone, whose input sum counts the real samples only.
         px = 0.f;
-        py = judge_red[BS / 64];
-#pragma unroll
-        for (int w = 0; w < BS / 64; ++w) { px += judge_red[w]; py = fminf(py, judge_red[BS / 64 + w]); } // (fminf drops a NaN: the test below sees it through px, or the wave's outputs are NaN anyway)
+        py = 3.4e38f;
+        int  nc = 0;
         bool finite = true;
 #pragma unroll
-        for (int w = 0; w < BS / 64; ++w) finite = finite && judge_red[BS / 64 + w] < 3.0e38f;
-        if (finite && py * (float)(BS / 64) * (float)D < gthr * px) { // (uniform over the workgroup)
+        for (int w = 0; w < BS / 64; ++w)
+            if (M0 * S + (long)(w + 1) * 64 * R <= n_out * S) {
+                ++nc;
+                px += judge_red[w];
+                py = fminf(py, judge_red[BS / 64 + w]); // (fminf drops a NaN: the test below sees it through px, or the wave's outputs are NaN anyway)
+                finite = finite && judge_red[BS / 64 + w] < 3.0e38f;
+            }
+        if (nc == 0) { nc = 1; px = judge_red[0]; py = judge_red[BS / 64]; finite = py < 3.0e38f; }
+        if (finite && py * (float)nc * (float)D < gthr * px) { // (uniform over the workgroup)
             double a64[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) a64[r] = 0.0;
@@ -386,6 +396,12 @@ struct gr4hip_fir {
                                         // history -- the taps carry the gain --, a hooked prologue keeps its outputs there: 1)
     DeviceBuffer       d_mid;          // gr4hip_fir_iir_process, two-launch path: the decimated stream between the filter and the cascade
     DeviceBuffer       d_pre;          // long spans of filters that take a matrix-pipe kernel: the prologue's output (one element-wise launch in front of it)
+    // the stream rule (common.hpp): create / reset / set_taps / set_prologue only note what the device state has to become; fir_state_on() enqueues it on the stream of
+    // the next call that needs it, behind whatever that stream still has in flight for this handle
+    std::vector<float> tp_host;        // d_taps' image ([D][Qpad]) as fir_upload_taps laid it out
+    bool               taps_dirty = false; // d_taps / d_tapsf do not hold tp_host / taps yet
+    bool               zero_hist  = true;  // d_hist[cur] is to be zeroed (create, reset, a history that had to grow)
+    double             hist_rescale = 1.0; // d_hist[cur] is to be multiplied by this (a prologue gain that moved into or out of the taps)
     ~gr4hip_fir() { delete pre; delete post; }
 };
 
@@ -397,16 +413,16 @@ static int fir_upload_taps(gr4hip_fir* f) {
     const size_t Q = ceil_div(K, D);
     f->G           = (int)ceil_div(Q, (size_t)E);
     const size_t Qp = (size_t)f->G * E;
-    std::vector<float> tp(D * Qp, 0.f);
+    std::vector<float>& tp = f->tp_host;
+    tp.assign(D * Qp, 0.f);
     for (size_t k = 0; k < K; ++k) tp[(k % D) * Qp + (k / D)] = f->taps[k];
-    int rc = f->d_taps.ensure(tp.size() * sizeof(float));
+    int rc = f->d_taps.ensure(tp.size() * sizeof(float)); // (growing frees the old table: hipFree waits for the device, nothing in flight loses its taps)
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(f->d_taps.ptr, tp.data(), tp.size() * sizeof(float), hipMemcpyHostToDevice));
     rc = f->d_tapsf.ensure(K * sizeof(float));
     if (rc) return rc;
     f->tap_power = 0;
     for (float b : f->taps) f->tap_power += (double)b * b;
-    GR4_HIP_TRY(hipMemcpy(f->d_tapsf.ptr, f->taps.data(), K * sizeof(float), hipMemcpyHostToDevice));
+    f->taps_dirty = true; // uploaded by fir_state_on, on the stream of the next call
     return GR4HIP_OK;
 }
 
@@ -415,9 +431,31 @@ static int fir_alloc_hist(gr4hip_fir* f) {
     for (int k = 0; k < 2; ++k) {
         int rc = f->d_hist[k].ensure(bytes);
         if (rc) return rc;
-        GR4_HIP_TRY(hipMemset(f->d_hist[k].ptr, 0, bytes));
     }
-    f->cur = 0;
+    f->zero_hist    = true; // zeroed by fir_state_on, on the stream of the next call (a launch still in flight may be writing either half of the pair)
+    f->hist_rescale = 1.0;
+    return GR4HIP_OK;
+}
+// The handle's device state as the call about to be enqueued on `st` must see it: pending tap upload, pending zeroing / rescaling of the carried history.
+// Everything goes onto `st`, so it is ordered behind the earlier launches of this handle on that stream (Block.hpp:606, 916-917: reset() / settingsChanged() run
+// between two work() calls of the block's own worker) and in front of the launch that follows.
+static int fir_state_on(gr4hip_fir* f, hipStream_t st) {
+    if (f->taps_dirty) {
+        GR4_HIP_TRY(hipMemcpyAsync(f->d_taps.ptr, f->tp_host.data(), f->tp_host.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        GR4_HIP_TRY(hipMemcpyAsync(f->d_tapsf.ptr, f->taps.data(), f->ntaps * sizeof(float), hipMemcpyHostToDevice, st));
+        f->taps_dirty = false;
+    }
+    if (f->zero_hist) {
+        GR4_HIP_TRY(hipMemsetAsync(f->d_hist[f->cur].ptr, 0, f->hcap * f->S * sizeof(float), st));
+        f->zero_hist    = false;
+        f->hist_rescale = 1.0;
+    }
+    if (f->hist_rescale != 1.0) {
+        const int nf = (int)(f->hcap * f->S);
+        hipLaunchKernelGGL(fir_hist_scale_kernel, dim3((unsigned)ceil_div(nf, 256)), dim3(256), 0, st, (float*)f->d_hist[f->cur].ptr, nf, (float)f->hist_rescale);
+        GR4_LAUNCH_CHECK();
+        f->hist_rescale = 1.0;
+    }
     return GR4HIP_OK;
 }
 
@@ -461,28 +499,22 @@ static int fir_apply_gain(gr4hip_fir* f, double gain) {
 // the stored history follows a change of its meaning: hist_gain -> g (a prologue gain that moves into or out of the taps)
 static int fir_rescale_history(gr4hip_fir* f, double g) {
     if (g == f->hist_gain) return GR4HIP_OK;
-    if (f->pos > 0) {
-        GR4_HIP_TRY(hipDeviceSynchronize()); // (a settings change, not a per-call operation: everything queued on the handle finishes first)
-        const int nf = (int)(f->hcap * f->S);
-        hipLaunchKernelGGL(fir_hist_scale_kernel, dim3((unsigned)ceil_div(nf, 256)), dim3(256), 0, nullptr, (float*)f->d_hist[f->cur].ptr, nf, (float)(f->hist_gain / g));
-        GR4_LAUNCH_CHECK();
-        GR4_HIP_TRY(hipDeviceSynchronize());
-    }
+    if (f->pos > 0) f->hist_rescale *= f->hist_gain / g; // applied by fir_state_on on the next call's stream (in float64 until then: two changes in a row round once)
     f->hist_gain = g;
     return GR4HIP_OK;
 }
 // what this call does with the neighbours: gains ride in the taps, the rest are hooks (or, in front of / behind a matrix-pipe kernel, element-wise launches)
-static int fir_prepare_hooks(gr4hip_fir* f, FirHooks* hk) {
+static int fir_prepare_hooks(gr4hip_fir* f, FirHooks* hk, hipStream_t st) {
     const bool   fold_pre = f->pre && f->pre_is_gain, fold_post = f->post && f->post_is_gain;
     const double want     = (fold_pre ? f->pre_gain : 1.0) * (fold_post ? f->post_gain : 1.0);
     if (want != f->folded) { if (const int rc = fir_apply_gain(f, want)) return rc; }
     if (f->pre && !fold_pre) {
         f->pre->pos = f->pos;
-        if (const int rc = ewise_device_ops(f->pre, &hk->pre)) return rc;
+        if (const int rc = ewise_device_ops(f->pre, &hk->pre, st)) return rc;
     }
     if (f->post && !fold_post) {
         f->post->pos = f->pos / (long)f->decim;
-        if (const int rc = ewise_device_ops(f->post, &hk->post)) return rc;
+        if (const int rc = ewise_device_ops(f->post, &hk->post, st)) return rc;
     }
     hk->any = hk->pre.n_ops > 0 || hk->post.n_ops > 0;
     return GR4HIP_OK;
@@ -597,7 +629,7 @@ static bool fir_decim_f16_shape(const gr4hip_fir_t* f, size_t n_in, const void* 
     return taps_ok && f->ntaps <= 1025 && n_in * f->S >= (1u << 17) && ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && f->algo == GR4HIP_FIR_AUTO && !f->f32_user &&
            !f->bf16_user && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2) && !dev_switch(kDevFirNoDecimF16) && f->dhKQ >= 0;
 }
-static bool fir_decim_bf16_ready(gr4hip_fir_t* f, size_t n_in, const void* d_in, const void* d_out, int* rc) {
+static bool fir_decim_bf16_ready(gr4hip_fir_t* f, size_t n_in, const void* d_in, const void* d_out, int* rc, hipStream_t st) {
     *rc = GR4HIP_OK;
     if (!(f->decim >= (f->S == 1 ? (size_t)2 : (size_t)3) && f->decim <= (f->S == 1 ? (size_t)12 : (size_t)16) && n_in / f->decim >= (1u << 14) && f->algo == GR4HIP_FIR_AUTO && f->bdKS >= 0 &&
           ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_in)) & 15) == 0 && !no_bf16x3(f)))
@@ -610,7 +642,7 @@ static bool fir_decim_bf16_ready(gr4hip_fir_t* f, size_t n_in, const void* d_in,
                                                                                                   // frequency-domain kernel is faster (762 against 305 G input samples/s at 1024 taps)
         else {
             *rc = f->d_bdfrag.ensure(af.size() * sizeof(unsigned short));
-            if (!*rc) { hipError_t e = hipMemcpy(f->d_bdfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); *rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!*rc) { hipError_t e = hipMemcpyAsync(f->d_bdfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); *rc = GR4HIP_RUNTIME_ERROR; } }
             if (*rc) return false;
             f->bdKS = ks;
         }
@@ -627,7 +659,8 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     if (n_in == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "fir_process: null device pointer");
     FirHooks hk;
-    if (f->pre || f->post || f->folded != 1.0) { if (const int rc = fir_prepare_hooks(f, &hk)) return rc; }
+    if (f->pre || f->post || f->folded != 1.0) { if (const int rc = fir_prepare_hooks(f, &hk, as_stream(stream))) return rc; }
+    if (const int rc = fir_state_on(f, as_stream(stream))) return rc; // pending reset / tap upload / history rescale: onto this call's stream, in front of its launches
     // Neighbours that do not fold into the taps are load / store hooks of the register-window kernel.  Where a plain filter of this shape takes a matrix-pipe or
     // frequency-domain kernel instead (more than 32 taps on a long span, the float decimators), that kernel is worth more than the saved pass: add -> 256-tap FIR
     // measured 165 Gsamples/s hooked against 277 as an element-wise launch + the bf16 kernel.  There the program runs as ONE element-wise launch in front of
@@ -638,7 +671,7 @@ int gr4hip_fir_process(gr4hip_fir_t* f, const void* d_in, size_t n_in, void* d_o
     const bool   fast_shape = f->algo == GR4HIP_FIR_AUTO && ((f->decim == 1 && f->ntaps > (f->S == 2 ? (size_t)64 : (size_t)96) && f->ntaps <= (f->S == 2 ? (size_t)256 : (size_t)1024) && n_in >= kMfmaMinSamples) ||
                                                                (f->S == 1 && f->decim >= 2 && per_out > 12 && n_out >= ((size_t)1 << 14)));
     int        brc  = GR4HIP_OK;
-    const bool band = hk.any && (fir_decim_f16_shape(f, n_in, d_in, d_out, true) || fir_decim_bf16_ready(f, n_in, d_in, d_out, &brc)); // (those kernels carry the hooks themselves)
+    const bool band = hk.any && (fir_decim_f16_shape(f, n_in, d_in, d_out, true) || fir_decim_bf16_ready(f, n_in, d_in, d_out, &brc, as_stream(stream))); // (those kernels carry the hooks themselves)
     if (brc) return brc;
     auto around = [&]() -> int { // the programs as element-wise launches in front of / behind the plain filter
         hipStream_t st  = as_stream(stream);
@@ -754,7 +787,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
                 if (f->guard_ratio != kGuardSegmentRatio) { const float g = (float)(f->tap_power * f->guard_ratio); std::memcpy(af.data() + (size_t)f->hfKS * 1536 + 6, &g, 4); } // (the table's header, fir_f16_make_afrag: the tighter
                 // threshold goes on the segment's WHOLE output power; the quietest-column statistic keeps its 21 dB -- at 15 dB it dips below on narrow-band noise alone: 1 % pass band, half of all segments marked)
                 rc = f->d_hfrag.ensure(af.size() * sizeof(unsigned short));
-                if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (!rc) { hipError_t e = hipMemcpyAsync(f->d_hfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
                 if (rc) { f->hfKS = 0; return rc; }
             }
         }
@@ -796,7 +829,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             if (!ok) f->hfKS = -1;
             else {
                 rc = f->d_hfrag.ensure(all.size() * sizeof(unsigned short));
-                if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (!rc) { hipError_t e = hipMemcpyAsync(f->d_hfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
                 if (rc) return rc;
                 f->hfKS = f->hf_ks[0];
             }
@@ -824,7 +857,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             std::vector<unsigned short> af;
             fir_bf16_make_afrag(f->taps.data(), f->ntaps, &f->bfKS, &af, 1, 0);
             rc = f->d_bfrag.ensure(af.size() * sizeof(unsigned short));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!rc) { hipError_t e = hipMemcpyAsync(f->d_bfrag.ptr, af.data(), af.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->bfKS = 0; return rc; }
         }
         float* nh = done == 0 ? (float*)f->d_hist[f->cur ^ 1].ptr : nullptr;
@@ -841,7 +874,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             std::vector<float> af;
             fir_mfma_make_afrag(f->taps.data(), f->ntaps, 1, &f->mKp, &f->mKS, &af);
             rc = f->d_afrag.ensure(af.size() * sizeof(float));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!rc) { hipError_t e = hipMemcpyAsync(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->mKS = 0; return rc; }
         }
         const float* hk = hist; // (hcap = bit_ceil(ntaps) is Kp for 33 .. 256 taps: read in place; a span served by this launch alone also gets its next history from it)
@@ -883,7 +916,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             if (!ok) f->hfKS = -1;
             else {
                 rc = f->d_hfrag.ensure(all.size() * sizeof(unsigned short));
-                if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (!rc) { hipError_t e = hipMemcpyAsync(f->d_hfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
                 if (rc) return rc;
                 f->hfKS = f->hf_ks[0];
             }
@@ -922,7 +955,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
                 all.insert(all.end(), af.begin(), af.end());
             }
             rc = f->d_bfrag.ensure(all.size() * sizeof(unsigned short));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!rc) { hipError_t e = hipMemcpyAsync(f->d_bfrag.ptr, all.data(), all.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) return rc;
             f->bfKS = f->bf_ks[0];
         }
@@ -942,7 +975,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             std::vector<float> af;
             fir_mfma_make_afrag(f->taps.data(), f->ntaps, 1, &f->mKp, &f->mKS, &af);
             rc = f->d_afrag.ensure(af.size() * sizeof(float));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!rc) { hipError_t e = hipMemcpyAsync(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->mKS = 0; return rc; }
         }
         // hcap = bit_ceil(ntaps) IS Kp for 33 .. 256 taps: the block's history is read as it lies, and the launch writes the next one (one launch per call
@@ -972,7 +1005,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             if (!fir_decim_f16_make_table(f->taps.data(), f->ntaps, f->decim, &f->dhKQ, &tab, f->S == 2)) f->dhKQ = -1;
             else {
                 rc = f->d_dhtab.ensure(tab.size() * sizeof(unsigned short));
-                if (!rc) { hipError_t e = hipMemcpy(f->d_dhtab.ptr, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+                if (!rc) { hipError_t e = hipMemcpyAsync(f->d_dhtab.ptr, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
                 if (rc) { f->dhKQ = 0; return rc; }
             }
         }
@@ -999,7 +1032,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
     // These kernels take the neighbours' programs themselves (load hook where the samples are split into bf16 planes, store hook on the output tile).
     if (done == 0) {
         int rc = GR4HIP_OK;
-        if (fir_decim_bf16_ready(f, n_in, d_in, d_out, &rc)) {
+        if (fir_decim_bf16_ready(f, n_in, d_in, d_out, &rc, st)) {
             float* nh = (float*)f->d_hist[f->cur ^ 1].ptr;
             // every segment judges its own output / input power (the three-term products' error is relative to the products); the marked ones are evaluated again on the
             // FP64 matrix pipe behind the launch (fir_exact.hip), which runs the launch's load / store programs too
@@ -1059,7 +1092,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             std::vector<float> row;
             fir_decim_band_make_row(f->taps.data(), f->ntaps, f->decim, &f->bandKp, &row);
             rc = f->d_band.ensure(row.size() * sizeof(float));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_band.ptr, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!rc) { hipError_t e = hipMemcpyAsync(f->d_band.ptr, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->bandKp = 0; return rc; }
         }
         rc = fir_decim_band_launch((int)f->decim, f->bandKp, x, hist, (int)f->hcap, (const float*)f->d_band.ptr, y, (long)n_out, (long)n_in, st);
@@ -1075,7 +1108,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             std::vector<float> af;
             fir_mfma_make_afrag_decim(f->taps.data(), f->ntaps, f->decim, &f->mKp, &f->mKS, &af);
             rc = f->d_afrag.ensure(af.size() * sizeof(float));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!rc) { hipError_t e = hipMemcpyAsync(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
             if (rc) { f->mKS = 0; return rc; }
         }
         const int hl = f->mKp * (int)f->decim; // history the kernel wants: Kp D samples
@@ -1110,7 +1143,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
             std::vector<float> row;
             fir_decim_band_make_row(f->taps.data(), f->ntaps, f->decim, &f->bandKp, &row);
             int rb = f->d_band.ensure(row.size() * sizeof(float));
-            if (!rb) { hipError_t e = hipMemcpy(f->d_band.ptr, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rb = GR4HIP_RUNTIME_ERROR; } }
+            if (!rb) { hipError_t e = hipMemcpyAsync(f->d_band.ptr, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice, st); if (e != hipSuccess) { set_error("fir: upload failed: %s", hipGetErrorString(e)); rb = GR4HIP_RUNTIME_ERROR; } }
             if (rb) { f->bandKp = 0; return rb; }
         }
         rc = fir_decim_band_launch((int)f->decim, f->bandKp, x, hist, (int)f->hcap, (const float*)f->d_band.ptr, y, (long)n_out, (long)n_in, st);
@@ -1152,7 +1185,7 @@ static int fir_process_core(gr4hip_fir_t* f, const void* d_in, size_t n_in, void
 }
 
 // ------------------------------------------------------------------------------------------------ decimating FIR -> IIR cascade (BASELINE configs[2])
-int  gr4hip_internal_iir_fusable(gr4hip_iir_t* f, const float** d_tab, int* nsec, const float** d_state_in, float** d_state_out, int* warm_blocks); // iir.hip
+int  gr4hip_internal_iir_fusable(gr4hip_iir_t* f, const float** d_tab, int* nsec, const float** d_state_in, float** d_state_out, int* warm_blocks, hipStream_t st); // iir.hip
 void gr4hip_internal_iir_commit(gr4hip_iir_t* f);
 
 extern "C" int gr4hip_fir_iir_process(gr4hip_fir_t* f, gr4hip_iir_t* iir, const float* d_in, size_t n_in, float* d_out, size_t* n_out_p, int mode, gr4hip_stream_t stream) {
@@ -1180,11 +1213,12 @@ extern "C" int gr4hip_fir_iir_process(gr4hip_fir_t* f, gr4hip_iir_t* iir, const 
     if (f->folded != 1.0 && !f->pre && !f->post) { // (a gain prologue / epilogue that was taken off again left its factor in the taps on this path: gr4hip_fir_process undoes it
                                                    // through fir_prepare_hooks, the fused launch below never came by there)
         FirHooks hk0;
-        if (const int rc = fir_prepare_hooks(f, &hk0)) return rc;
+        if (const int rc = fir_prepare_hooks(f, &hk0, st)) return rc;
     }
+    if (const int rc = fir_state_on(f, st)) return rc;
     const bool       fusable = mode == GR4HIP_FIR_IIR_ONE_LAUNCH && f->S == 1 && f->decim == 8 && f->algo == GR4HIP_FIR_AUTO && !f->fd_blocked && !f->pre && !f->post && fir_decim_fd_supported(f->ntaps, f->decim) && f->ntaps <= 1024 &&
                          whole >= kMinBlocks * kHop && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0 && !dev_switch(kDevFirNoDecimFd) &&
-                         gr4hip_internal_iir_fusable(iir, &tab, &nsec, &st_in, &st_out, &warm);
+                         gr4hip_internal_iir_fusable(iir, &tab, &nsec, &st_in, &st_out, &warm, st);
     if (!fusable) return two_launches(d_in, n_in, d_out);
     int rc = GR4HIP_OK;
     if (!f->dfd) rc = fir_decim_fd_create(&f->dfd, f->taps.data(), f->ntaps);
@@ -1227,6 +1261,8 @@ int gr4hip_internal_fir_set_guard_ratio(gr4hip_fir_t* f, double ratio) {
 }
 int gr4hip_internal_fir_load_history(gr4hip_fir_t* f, const float* d_last256, hipStream_t st) {
     GR4_REQUIRE(f && f->S == 2 && f->hcap <= 256, "fir_load_history: complex filter with <= 256 samples of history expected");
+    f->zero_hist    = false; // (what was pending for the history is superseded; the taps go up with the next call)
+    f->hist_rescale = 1.0;
     GR4_HIP_TRY(hipMemcpyAsync(f->d_hist[f->cur].ptr, d_last256 + (256 - f->hcap) * 2, f->hcap * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
     return GR4HIP_OK;
 }

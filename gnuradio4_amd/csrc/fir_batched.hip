@@ -490,6 +490,7 @@ struct gr4hip_fir_batched {
     DeviceBuffer d_hfrag; // > 32 taps: per-channel two-term f16 tables (fir_f16.hip) -- the default on long spans
     int          hfKS = 0;
     DeviceBuffer d_tapsf, d_flags; // the taps as they are and one byte per channel and segment: what fir_exact_kernel evaluates again behind the f16 launch
+    bool         zero_hist = true; // the stream rule (common.hpp): create / reset note it, the next call zeroes d_hist[cur] on its own stream
 };
 
 extern "C" {
@@ -504,23 +505,23 @@ int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, cons
     std::vector<float> af;
     fir_mfma_make_afrag(h_taps, ntaps, nchannels, &f->Kp, &f->KS, &af);
     int rc = f->d_afrag.ensure(af.size() * sizeof(float));
-    if (!rc) { hipError_t e = hipMemcpy(f->d_afrag.ptr, af.data(), af.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+    if (!rc) { hipError_t e = upload_fresh(f->d_afrag.ptr, af.data(), af.size() * sizeof(float)); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     static const size_t kBfMinTaps = [] { const char* e = std::getenv("GR4HIP_FIR_BATCHED_BF16_MIN_TAPS"); return e ? (size_t)std::atoi(e) : (size_t)33; }(); // developer knob
     if (!rc && ntaps >= kBfMinTaps && ntaps > 32) {
         std::vector<unsigned short> bf;
         fir_bf16_make_afrag(h_taps, ntaps, &f->bfKS, &bf, nchannels, 0);
         rc = f->d_bfrag.ensure(bf.size() * sizeof(unsigned short));
-        if (!rc) { hipError_t e = hipMemcpy(f->d_bfrag.ptr, bf.data(), bf.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+        if (!rc) { hipError_t e = upload_fresh(f->d_bfrag.ptr, bf.data(), bf.size() * sizeof(unsigned short)); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     }
     if (!rc && ntaps >= kBfMinTaps && ntaps > 32) {
         std::vector<unsigned short> hf;
         if (fir_f16_make_afrag(h_taps, ntaps, &f->hfKS, &hf, nchannels, 0)) {
             rc = f->d_hfrag.ensure(hf.size() * sizeof(unsigned short));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_hfrag.ptr, hf.data(), hf.size() * sizeof(unsigned short), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!rc) { hipError_t e = upload_fresh(f->d_hfrag.ptr, hf.data(), hf.size() * sizeof(unsigned short)); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
         } else f->hfKS = 0;
         if (!rc && f->hfKS) {
             rc = f->d_tapsf.ensure(nchannels * ntaps * sizeof(float));
-            if (!rc) { hipError_t e = hipMemcpy(f->d_tapsf.ptr, h_taps, nchannels * ntaps * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+            if (!rc) { hipError_t e = upload_fresh(f->d_tapsf.ptr, h_taps, nchannels * ntaps * sizeof(float)); if (e != hipSuccess) { set_error("fir_batched: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
         }
     }
     for (int k = 0; k < 2 && !rc; ++k) rc = f->d_hist[k].ensure(nchannels * f->Kp * sizeof(float));
@@ -532,8 +533,7 @@ int gr4hip_fir_batched_create(gr4hip_fir_batched_t** out, size_t nchannels, cons
 
 int gr4hip_fir_batched_reset(gr4hip_fir_batched_t* f) {
     GR4_REQUIRE(f, "fir_batched_reset: null handle");
-    for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(f->d_hist[k].ptr, 0, f->nch * f->Kp * sizeof(float)));
-    f->cur = 0;
+    f->zero_hist = true; // (a launch still in flight on the caller's stream may be writing the other half of the pair: the zeroing goes behind it, on the next call's stream)
     return GR4HIP_OK;
 }
 
@@ -543,6 +543,10 @@ int gr4hip_fir_batched_process(gr4hip_fir_batched_t* f, const float* d_in, size_
     GR4_REQUIRE(d_in && d_out && in_stride >= n && out_stride >= n, "fir_batched_process: null pointer or stride shorter than n");
     GR4_REQUIRE(((uintptr_t)d_out % 16 == 0) && (out_stride % 4 == 0), "fir_batched_process: output must be 16-byte aligned with a stride multiple of 4");
     hipStream_t st = as_stream(stream);
+    if (f->zero_hist) {
+        GR4_HIP_TRY(hipMemsetAsync(f->d_hist[f->cur].ptr, 0, f->nch * f->Kp * sizeof(float), st));
+        f->zero_hist = false;
+    }
     const float *hist = (const float*)f->d_hist[f->cur].ptr, *af = (const float*)f->d_afrag.ptr;
     int rc;
     if (f->hfKS && n >= 32768 && (uintptr_t)d_in % 16 == 0 && in_stride % 4 == 0 && !dev_switch(kDevFirNoBf16x3) && !dev_switch(kDevFirNoF16x2)) { // two-term f16 form (fir_f16.hip): same history layout

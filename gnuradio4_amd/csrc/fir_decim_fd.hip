@@ -490,7 +490,7 @@ template <typename T>
 static int upload_df(DeviceBuffer& b, const std::vector<T>& h) {
     int rc = b.ensure(h.size() * sizeof(T));
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(b.ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    GR4_HIP_TRY(upload_fresh(b.ptr, h.data(), h.size() * sizeof(T)));
     return GR4HIP_OK;
 }
 
@@ -580,7 +580,7 @@ int fir_decim_fd_run(FirDecimFd* c, const float* d_in, size_t n_in, const float*
         if (!c->h_pw) {
             rc = c->d_pw.ensure(36 * sizeof(float));
             if (rc) return rc;
-            GR4_HIP_TRY(hipMemset(c->d_pw.ptr, 0, 36 * sizeof(float)));
+            GR4_HIP_TRY(hipMemsetAsync(c->d_pw.ptr, 0, 36 * sizeof(float), st)); // (in front of the first measured launch, on its stream)
             GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 4 * sizeof(float), hipHostMallocMapped));
             std::memset(c->h_pw, 0, 4 * sizeof(float));
             GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_hpw), c->h_pw, 0));

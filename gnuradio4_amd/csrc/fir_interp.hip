@@ -265,6 +265,9 @@ struct gr4hip_fir_interp {
     std::vector<float> taps;
     DeviceBuffer       d_taps, d_hist[2], d_row; // d_row: zero-padded natural-order tap row of the matrix-pipe kernel
     int                cur = 0, KS = 0, G = 1;   // KS = 0: no matrix-pipe form for this (L, K)
+    // the stream rule (common.hpp): create / reset / set_taps only note what the device state has to become; ip_state_on() enqueues it on the stream of the next call
+    std::vector<float> t_host, row_host; // images of d_taps / d_row as ip_upload laid them out
+    bool               taps_dirty = false, zero_hist = true;
 };
 
 constexpr size_t kIpMfmaMinOut = 32768; // shorter spans: the register-window kernel (fewer, smaller workgroups)
@@ -274,11 +277,13 @@ static size_t ip_bit_ceil(size_t v) { size_t p = 1; while (p < v) p <<= 1; retur
 
 static int ip_upload(gr4hip_fir_interp* f) {
     f->Kp = ceil_div(f->ntaps, f->L);
-    std::vector<float> t(f->Kp * f->L, 0.f);
+    std::vector<float>& t = f->t_host;
+    t.assign(f->Kp * f->L, 0.f);
     for (size_t k = 0; k < f->ntaps; ++k) t[(k / f->L) * f->L + (k % f->L)] = (float)f->L * f->taps[k]; // branch p = k % L, step q = k / L, gain L
-    int rc = f->d_taps.ensure(t.size() * sizeof(float));
+    int rc = f->d_taps.ensure(t.size() * sizeof(float)); // (growing frees the old table: hipFree waits for the device)
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(f->d_taps.ptr, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    f->taps_dirty = true; // uploaded by ip_state_on, on the stream of the next call
+    f->row_host.clear();
     f->KS = 0;
     const bool pow2 = f->L == 2 || f->L == 4 || f->L == 8 || f->L == 16;
     if (pow2 || f->L == 7 || f->L > 8) { // fir_interp_mfma_kernel: window of 4 KS >= Kp - 1 + G samples per block; (L = 3, 5, 6 fill 3 .. 6 of the 16 rows
@@ -288,11 +293,11 @@ static int ip_upload(gr4hip_fir_interp* f) {
         if (G == 8) KS += KS & 1; // the window start Hq = 4 KS - G is a whole number of G-sample blocks
         f->G = (int)G;
         if (KS <= (size_t)kIpMaxKS && 4 * KS * f->L <= 16384) { // (tap row of <= 64 KB in LDS)
-            std::vector<float> row(16 + 4 * KS * f->L, 0.f);
+            std::vector<float>& row = f->row_host;
+            row.assign(16 + 4 * KS * f->L, 0.f);
             for (size_t k = 0; k < f->ntaps; ++k) row[16 + k] = (float)f->L * f->taps[k];
             rc = f->d_row.ensure(row.size() * sizeof(float));
             if (rc) return rc;
-            GR4_HIP_TRY(hipMemcpy(f->d_row.ptr, row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice));
             f->KS = (int)KS;
         }
     }
@@ -327,9 +332,21 @@ static int ip_alloc_hist(gr4hip_fir_interp* f) {
     for (int k = 0; k < 2; ++k) {
         int rc = f->d_hist[k].ensure(bytes);
         if (rc) return rc;
-        GR4_HIP_TRY(hipMemset(f->d_hist[k].ptr, 0, bytes));
     }
-    f->cur = 0;
+    f->zero_hist = true; // zeroed by ip_state_on, on the stream of the next call (a launch still in flight may be writing either half of the pair)
+    return GR4HIP_OK;
+}
+// pending tap upload / zeroing of the carried history, onto the stream of the call about to be enqueued: behind this handle's earlier launches on it, in front of the next
+static int ip_state_on(gr4hip_fir_interp* f, hipStream_t st) {
+    if (f->taps_dirty) {
+        GR4_HIP_TRY(hipMemcpyAsync(f->d_taps.ptr, f->t_host.data(), f->t_host.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        if (!f->row_host.empty()) GR4_HIP_TRY(hipMemcpyAsync(f->d_row.ptr, f->row_host.data(), f->row_host.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        f->taps_dirty = false;
+    }
+    if (f->zero_hist) {
+        GR4_HIP_TRY(hipMemsetAsync(f->d_hist[f->cur].ptr, 0, f->hcap * f->S * sizeof(float), st));
+        f->zero_hist = false;
+    }
     return GR4HIP_OK;
 }
 
@@ -414,6 +431,7 @@ int gr4hip_fir_interp_process(gr4hip_fir_interp_t* f, const void* d_in, size_t n
     if (n_in == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "fir_interp_process: null device pointer");
     hipStream_t st = as_stream(stream);
+    if (const int rc = ip_state_on(f, st)) return rc;
     if (f->KS > 0 && n_in * f->L >= kIpMfmaMinOut && (uintptr_t)d_out % 16 == 0 && (uintptr_t)d_in % (4 * f->S) == 0 && !ip_env_no_mfma()) { // matrix-pipe form; writes the next history itself
         float* nh = static_cast<float*>(f->d_hist[f->cur ^ 1].ptr);
         int    rc = f->S == 1 ? ip_mfma_dispatch<1>(f, d_in, d_out, (long)n_in, st, nh) : ip_mfma_dispatch<2>(f, d_in, d_out, (long)n_in, st, nh);

@@ -941,6 +941,8 @@ struct gr4hip_iir {
     int                 algo = GR4HIP_IIR_AUTO, algo_in_use = GR4HIP_IIR_PARALLEL;
     float               selftest_parallel = -1.f, selftest_f32 = -1.f; // create-time errors (max |.| / output rms against float64) of the parallel kernels and of the sequential float32 form
     bool                top = true;
+    // the stream rule (common.hpp): create / reset / set_algo only note that the state is to be zeroed; iir_state_on() enqueues it on the stream of the next call
+    bool                zero_state = true, zero_seq = true;
     ~gr4hip_iir() {
         if (h_err) (void)hipHostFree(h_err);
         delete part[0];
@@ -1105,8 +1107,10 @@ extern "C" {
 
 static int iir_create_impl(gr4hip_iir_t** out, int form, size_t nsections, const float* h_b, size_t nb, const float* h_a, size_t na, bool top);
 static int iir_selftest(gr4hip_iir* f);
+static int iir_state_on(gr4hip_iir* f, hipStream_t st);
 struct IirVerdict { int algo; float e_par, e_f32; };
-static std::map<std::vector<float>, IirVerdict> g_selftest; // (the errors are ratios to the output rms: a gain on the numerators leaves them as they are)
+static std::map<std::vector<uint32_t>, IirVerdict> g_selftest; // keyed on bit patterns (a strict weak order whatever the values) + the device; bounded (kSelftestCacheMax)
+constexpr size_t                                  kSelftestCacheMax = 4096; // (the errors are ratios to the output rms: a gain on the numerators leaves them as they are)
 static std::mutex                               g_selftest_mu;
 static int iir_process_parallel(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_out, gr4hip_stream_t stream);
 
@@ -1128,7 +1132,7 @@ static int iir_finish_top(gr4hip_iir* f, int form, size_t nsections, const float
     }
     int rc = f->d_seq_state.ensure((size_t)kIirSeqMaxSec * 2 * (kIirSeqMaxOrd + 1) * sizeof(float));
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemset(f->d_seq_state.ptr, 0, f->d_seq_state.bytes));
+    f->zero_seq = true;
     return iir_selftest(f);
 }
 
@@ -1177,7 +1181,7 @@ static int iir_create_impl(gr4hip_iir_t** out, int form, size_t nsections, const
         Pk = mat_square(Pk, f->M);
     }
     int rc = f->d_phi.ensure(phi.size() * sizeof(float));
-    if (!rc) { hipError_t e = hipMemcpy(f->d_phi.ptr, phi.data(), phi.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+    if (!rc) { hipError_t e = upload_fresh(f->d_phi.ptr, phi.data(), phi.size() * sizeof(float)); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     for (int k = 0; k < 2 && !rc; ++k) rc = f->d_state[k].ensure(kIirMaxM * sizeof(float));
     if (!rc && f->M <= 8) { // tables of the single-pass kernel, all powers in double
         const int M = f->M;
@@ -1224,7 +1228,7 @@ static int iir_create_impl(gr4hip_iir_t** out, int form, size_t nsections, const
             }
         }
         rc = f->d_tab.ensure(tab.size() * sizeof(float));
-        if (!rc) { hipError_t e = hipMemcpy(f->d_tab.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
+        if (!rc) { hipError_t e = upload_fresh(f->d_tab.ptr, tab.data(), tab.size() * sizeof(float)); if (e != hipSuccess) { set_error("iir: upload failed: %s", hipGetErrorString(e)); rc = GR4HIP_RUNTIME_ERROR; } }
     }
     if (rc) { delete f; return rc; }
     f->top = false; // (reset below must not touch the sequential state before it exists)
@@ -1246,16 +1250,23 @@ static int iir_selftest(gr4hip_iir* f) {
     //  the verdict belongs to the cascade, not to the handle: one test per coefficient set and process.  A gain on a numerator does not change the conditioning
     // (every section's numerator enters the key divided by its largest coefficient), so the planner's regain -- a new handle per absorbed or cleared gain -- finds it here
     // instead of another upload / launch / download / host simulation with two device synchronisations.
-    std::vector<float> key;
+    std::vector<uint32_t> key;
+    bool                  cacheable = true; //  non-finite coefficients are not cached: there is nothing to learn from them twice
     {
         const IirSeqF32Coef& c = f->seq;
-        key = {(float)c.form, (float)c.nsec, (float)c.nb, (float)c.na};
+        int                  dev = 0;
+        (void)hipGetDevice(&dev);
+        key = {(uint32_t)c.form, (uint32_t)c.nsec, (uint32_t)c.nb, (uint32_t)c.na, (uint32_t)dev,
+               (uint32_t)((dev_switch(kDevIirThreePass) ? 1 : 0) | (dev_switch(kDevIirLookback) ? 2 : 0) | (dev_switch(kDevIirNoSplit) ? 4 : 0))};
+        const auto put = [&](float v) { uint32_t u; std::memcpy(&u, &v, 4); key.push_back(u); cacheable = cacheable && std::isfinite(v); };
         for (int s_ = 0; s_ < c.nsec; ++s_) {
             float mx = 0.f;
             for (int j = 0; j < c.nb; ++j) mx = std::max(mx, std::fabs(c.b[s_][j]));
-            for (int j = 0; j < c.nb; ++j) key.push_back(mx > 0.f ? c.b[s_][j] / mx : 0.f);
-            for (int j = 0; j < c.na; ++j) key.push_back(c.a[s_][j]);
+            for (int j = 0; j < c.nb; ++j) put(mx > 0.f ? c.b[s_][j] / mx : 0.f);
+            for (int j = 0; j < c.na; ++j) put(c.a[s_][j]);
         }
+    }
+    if (cacheable) {
         std::lock_guard<std::mutex> lk(g_selftest_mu);
         const auto it = g_selftest.find(key);
         if (it != g_selftest.end()) {
@@ -1263,6 +1274,9 @@ static int iir_selftest(gr4hip_iir* f) {
             return GR4HIP_OK;
         }
     }
+    // the test drives the handle's own state on the NULL stream: whatever a caller's streams still have in flight for this handle (gr4hip_iir_set_algo in
+    // mid-stream) finishes first -- a settings change that measures something is a blocking call anyway (upload, launch, download, host simulation)
+    GR4_HIP_TRY(hipDeviceSynchronize());
     const long         n = 3L * kIirBS * kIirL + 777;
     std::vector<float> x((size_t)n), y((size_t)n);
     uint32_t           lcg = 12345u;
@@ -1271,8 +1285,9 @@ static int iir_selftest(gr4hip_iir* f) {
     int          rc = dx.ensure((size_t)n * sizeof(float));
     if (!rc) rc = dy.ensure((size_t)n * sizeof(float));
     if (rc) return rc;
-    GR4_HIP_TRY(hipMemcpy(dx.ptr, x.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    rc = iir_process_parallel(f, static_cast<const float*>(dx.ptr), (size_t)n, static_cast<float*>(dy.ptr), nullptr);
+    GR4_HIP_TRY(upload_fresh(dx.ptr, x.data(), (size_t)n * sizeof(float)));
+    rc = iir_state_on(f, nullptr);
+    if (!rc) rc = iir_process_parallel(f, static_cast<const float*>(dx.ptr), (size_t)n, static_cast<float*>(dy.ptr), nullptr);
     if (rc) return rc;
     GR4_HIP_TRY(hipMemcpy(y.data(), dy.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     f->top = false;
@@ -1299,8 +1314,9 @@ static int iir_selftest(gr4hip_iir* f) {
     f->selftest_parallel = (float)(e_par / rms);
     f->selftest_f32      = (float)(e_f32 / rms);
     if (!(e_par / rms <= 1e-5) && !(e_par <= 10.0 * e_f32)) f->algo_in_use = GR4HIP_IIR_SEQUENTIAL_F32;
-    {
+    if (cacheable) {
         std::lock_guard<std::mutex> lk(g_selftest_mu);
+        if (g_selftest.size() >= kSelftestCacheMax) g_selftest.clear();
         g_selftest[key] = IirVerdict{f->algo_in_use, f->selftest_parallel, f->selftest_f32};
     }
     return GR4HIP_OK;
@@ -1316,13 +1332,26 @@ static int iir_take_error(gr4hip_iir* f, const char* where) {
     return GR4HIP_OK;
 }
 
+// Block::reset() between two work() calls (Block.hpp:606, 1296): a host-side note; the state is zeroed on the stream of the next call, behind the launches that
+// stream still has in flight for this handle (they write the other half of the state pair)
 int gr4hip_iir_reset(gr4hip_iir_t* f) {
     GR4_REQUIRE(f, "iir_reset: null handle");
-    if (f->top && f->d_seq_state.ptr) GR4_HIP_TRY(hipMemset(f->d_seq_state.ptr, 0, f->d_seq_state.bytes));
+    if (f->top) f->zero_seq = true;
     if (f->part[0]) { int rc = gr4hip_iir_reset(f->part[0]); return rc ? rc : gr4hip_iir_reset(f->part[1]); }
-    for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemset(f->d_state[k].ptr, 0, kIirMaxM * sizeof(float))); // (hipMemset synchronises: every earlier launch has finished)
-    f->cur = 0;
+    f->zero_state = true;
     return iir_take_error(f, "iir_reset");
+}
+static int iir_state_on(gr4hip_iir* f, hipStream_t st) {
+    if (f->top && f->zero_seq && f->d_seq_state.ptr) {
+        GR4_HIP_TRY(hipMemsetAsync(f->d_seq_state.ptr, 0, f->d_seq_state.bytes, st));
+        f->zero_seq = false;
+    }
+    if (f->part[0]) { int rc = iir_state_on(f->part[0], st); return rc ? rc : iir_state_on(f->part[1], st); }
+    if (f->zero_state) {
+        for (int k = 0; k < 2; ++k) GR4_HIP_TRY(hipMemsetAsync(f->d_state[k].ptr, 0, kIirMaxM * sizeof(float), st));
+        f->zero_state = false;
+    }
+    return GR4HIP_OK;
 }
 
 int gr4hip_iir_status(gr4hip_iir_t* f, gr4hip_stream_t stream) {
@@ -1354,6 +1383,7 @@ int gr4hip_iir_process(gr4hip_iir_t* f, const float* d_in, size_t n, float* d_ou
     GR4_REQUIRE(f, "iir_process: null handle");
     if (n == 0) return GR4HIP_OK;
     GR4_REQUIRE(d_in && d_out, "iir_process: null device pointer");
+    if (const int rc = iir_state_on(f, as_stream(stream))) return rc; // a pending reset: onto this call's stream, in front of its launches
     if (f->top && f->algo_in_use == GR4HIP_IIR_SEQUENTIAL_F32) {
         hipLaunchKernelGGL(iir_sequential_kernel, dim3(1), dim3(64), 0, as_stream(stream), d_in, d_out, (long)n, f->seq, static_cast<float*>(f->d_seq_state.ptr));
         GR4_LAUNCH_CHECK();
@@ -1380,7 +1410,7 @@ static int iir_process_parallel(gr4hip_iir_t* f, const float* d_in, size_t n, fl
 // parallel-in-time path, the per-section tables (coefficients + the 2 x 2 powers A^(14 2^k) of its chunk scan), the carried direct-form-II state (read from the
 // current slot, written to the other: gr4hip_internal_iir_commit makes it current once the launch is known to stand) and the warm-up in blocks of 896 samples.
 // Returns 0 when the cascade does not qualify (the caller keeps the two launches).
-int gr4hip_internal_iir_fusable(gr4hip_iir* f, const float** d_tab, int* nsec, const float** d_state_in, float** d_state_out, int* warm_blocks) {
+int gr4hip_internal_iir_fusable(gr4hip_iir* f, const float** d_tab, int* nsec, const float** d_state_in, float** d_state_out, int* warm_blocks, hipStream_t st) {
     if (!f || !f->top || f->part[0] || f->ord != 2 || f->algo_in_use != GR4HIP_IIR_PARALLEL || f->seq.nsec < 1 || f->seq.nsec > 4 || f->seq.nb > 3 || f->seq.na > 3) return 0;
     if (f->fuse_warm < 0) {
         f->fuse_warm = 0;
@@ -1408,9 +1438,10 @@ int gr4hip_internal_iir_fusable(gr4hip_iir* f, const float** d_tab, int* nsec, c
                 mm(R, R, R);
             }
         }
-        if (f->d_fuse_tab.ensure(tab.size() * sizeof(float)) != GR4HIP_OK || hipMemcpy(f->d_fuse_tab.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) f->fuse_warm = 0;
+        if (f->d_fuse_tab.ensure(tab.size() * sizeof(float)) != GR4HIP_OK || upload_fresh(f->d_fuse_tab.ptr, tab.data(), tab.size() * sizeof(float)) != hipSuccess) f->fuse_warm = 0;
     }
     if (f->fuse_warm <= 0) return 0;
+    if (iir_state_on(f, st)) return 0; // (a pending reset goes in front of the launch that reads the state)
     *d_tab       = static_cast<const float*>(f->d_fuse_tab.ptr);
     *nsec        = f->seq.nsec;
     *d_state_in  = static_cast<const float*>(f->d_state[f->cur].ptr);

@@ -429,7 +429,13 @@ struct gr4hip_rotator {
     DeviceBuffer d_state; // recurrence: _accumulated_phase as the reference's float
     DeviceBuffer d_ckpt;
     float*       state() const { return static_cast<float*>(d_state.ptr) + cur; }
+    // the stream rule (common.hpp): create / reset / set_algo note the phase the device word has to hold; the next call of the recurrence stores it on its own stream
+    bool         store_pending = false;
+    float        store_value   = 0.f;
 };
+namespace gr4 {
+__global__ void rotator_store_phase_kernel(float* state, float value) { *state = value; }
+}
 
 extern "C" {
 
@@ -469,7 +475,8 @@ int gr4hip_rotator_create(gr4hip_rotator_t** out, float phase_increment, float i
 
 int gr4hip_rotator_reset(gr4hip_rotator_t* r, float initial_phase) {
     GR4_REQUIRE(r, "rotator: null handle");
-    GR4_HIP_TRY(hipMemcpy(r->state(), &initial_phase, sizeof(float), hipMemcpyHostToDevice));
+    r->store_pending = true; // (a launch of the recurrence still in flight on the caller's stream updates the word: the new value goes behind it, on the next call's stream)
+    r->store_value   = initial_phase;
     r->ph_bad = !std::isfinite(initial_phase);
     r->ph_fix = r->ph_bad ? 0 : turns_fix((double)initial_phase / 6.283185307179586476925286766559);
     return GR4HIP_OK;
@@ -479,14 +486,17 @@ int gr4hip_rotator_set_algo(gr4hip_rotator_t* r, int algo) {
     GR4_REQUIRE(r, "rotator: null handle");
     GR4_REQUIRE(algo == GR4HIP_ROTATOR_CLOSED_FORM || algo == GR4HIP_ROTATOR_RECURRENCE, "rotator_set_algo: unknown algo %d", algo);
     if (algo == r->algo) return GR4HIP_OK;
-    // the carried phase changes hands (rare: a settings change, not a per-call operation): everything queued on the handle finishes first
-    GR4_HIP_TRY(hipDeviceSynchronize());
-    if (algo == GR4HIP_ROTATOR_RECURRENCE) {
-        const float ph = r->ph_bad ? std::nanf("") : (float)(fix_turns(r->ph_fix) * 6.283185307179586476925286766559);
-        GR4_HIP_TRY(hipMemcpy(r->state(), &ph, sizeof(float), hipMemcpyHostToDevice));
-    } else {
-        float ph = 0.f;
-        GR4_HIP_TRY(hipMemcpy(&ph, r->state(), sizeof(float), hipMemcpyDeviceToHost));
+    // the carried phase changes hands (rare: a settings change, not a per-call operation)
+    if (algo == GR4HIP_ROTATOR_RECURRENCE) { // host -> device: stored in front of the next call, on its stream
+        r->store_pending = true;
+        r->store_value   = r->ph_bad ? std::nanf("") : (float)(fix_turns(r->ph_fix) * 6.283185307179586476925286766559);
+    } else { // device -> host: everything queued on the handle, on whatever stream, finishes first
+        float ph = r->store_value;
+        if (!r->store_pending) {
+            GR4_HIP_TRY(hipDeviceSynchronize());
+            GR4_HIP_TRY(hipMemcpyAsync(&ph, r->state(), sizeof(float), hipMemcpyDeviceToHost, nullptr));
+            GR4_HIP_TRY(hipStreamSynchronize(nullptr));
+        }
         r->ph_bad = !std::isfinite(ph);
         r->ph_fix = r->ph_bad ? 0 : turns_fix((double)ph / 6.283185307179586476925286766559);
     }
@@ -511,6 +521,11 @@ int gr4hip_rotator_process(gr4hip_rotator_t* r, const void* d_in, void* d_out, s
         return GR4HIP_OK;
     }
     // the reference's float recurrence, bit for bit
+    if (r->store_pending) {
+        hipLaunchKernelGGL(rotator_store_phase_kernel, dim3(1), dim3(1), 0, st, r->state(), r->store_value);
+        GR4_LAUNCH_CHECK();
+        r->store_pending = false;
+    }
     const size_t nchunks = ceil_div(n, (size_t)kRotChunk);
     int          rc      = r->d_ckpt.ensure(nchunks * sizeof(float));
     if (rc) return rc;
@@ -533,6 +548,7 @@ int gr4hip_rotator_phase(gr4hip_rotator_t* r, float* phase, gr4hip_stream_t stre
         *phase = r->ph_bad ? std::nanf("") : (float)(fix_turns(r->ph_fix) * 6.283185307179586476925286766559);
         return GR4HIP_OK;
     }
+    if (r->store_pending) { *phase = r->store_value; return GR4HIP_OK; } // (reset since the last call: the word on the device is not it yet)
     GR4_HIP_TRY(hipMemcpyAsync(phase, r->state(), sizeof(float), hipMemcpyDeviceToHost, as_stream(stream)));
     GR4_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     return GR4HIP_OK;

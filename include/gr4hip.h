@@ -17,6 +17,16 @@
  *   - complex samples are interleaved {re, im}; dtype ids are gr4hip_dtype.
  *   - state that the reference keeps in block members (HistoryBuffer, _accumulated_phase, twiddles, windows)
  *     lives in opaque handles created/destroyed by *_create / *_destroy.
+ *   - LIFECYCLE CALLS ARE STREAM-ORDERED WITH THE DATA.  *_reset, *_set_taps, gr4hip_fir_set_prologue / _epilogue, *_set_algo and *_set_guard_mode return at once
+ *     and never touch device memory: they note what the handle's device state has to become, and the NEXT *_process call on the handle applies it on the stream
+ *     IT is given (hipMemsetAsync / hipMemcpyAsync / a small kernel), in front of its own launches -- hence behind every launch that stream still has in flight
+ *     for the handle.  This is the reference's contract: reset() and settingsChanged() run on the block's own worker between two work() calls
+ *     (Block.hpp:606, 916-917, 1296; one worker per job list, Scheduler.hpp:1938-1951), so they are ordered with the block's samples by construction.  It holds
+ *     on hipStreamNonBlocking streams (gr4hip_stream_create makes those), which the NULL stream does not order against, and needs no device-wide wait.  A caller
+ *     that moves a handle from one stream to another orders the two streams itself (gr4hip_event_record + gr4hip_stream_wait_event), as it must for the carried
+ *     history anyway.  After a settings change the first process call may hold the HOST until that stream has drained: the new tables go up from pageable memory,
+ *     stream-ordered.  Calls that hand a device value back to the host (gr4hip_rotator_phase under the recurrence, gr4hip_iir_status; gr4hip_iir_set_algo and
+ *     gr4hip_rotator_set_algo when they have to measure or read something) wait for what they need and say so.  *_create uploads block and are complete on return.
  *   - one handle is driven by one thread at a time (Scheduler.hpp:1938-1951: job lists are disjoint).
  *   - PARITY CONTRACT (stated here once; tests/test_gpu_parity.py::_rel is this formula and every float test uses it): integer, byte and copy results are
  *     bit-exact.  A float32 result y against the float64 evaluation t of the same blocks on the same input satisfies

@@ -48,6 +48,32 @@ def test_no_oracle_or_reference_in_product():
     assert not bad, bad
 
 
+def test_lifecycle_calls_never_touch_the_device_outside_a_stream():
+    """the stream rule (csrc/common.hpp, include/gr4hip.h "LIFECYCLE CALLS ARE STREAM-ORDERED WITH THE DATA"): in the kernel library a handle's device state is
+    written by upload_fresh() into a buffer no launch has seen, or by work enqueued on the stream of a process call -- never by a NULL-stream hipMemset / blocking
+    hipMemcpy (round 5's race: gr4hip_chain_reset's hipMemset overtaken by the previous launch's carry on a non-blocking stream).  What is left of either name:
+    upload_fresh itself, the create-time self-test's download, and developer-build timing dumps."""
+    src = os.path.join(ROOT, "gnuradio4_amd", "csrc")
+    allowed = {("common.hpp", "upload_fresh"), ("iir.hip", "hipMemcpy(y.data(), dy.ptr"), ("iir.hip", "a.dbgc"), ("chain_fused.hip", "gr4::g_dbg"), ("chain16.hip", "gr4::g_dbg16")}
+    bad = []
+    for f in sorted(os.listdir(src)):
+        if not f.endswith((".hip", ".hpp")):
+            continue
+        for n, line in enumerate(open(os.path.join(src, f), errors="replace"), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bhipMemset\(|\bhipMemcpy\(|\bhipMemcpyToSymbol\(", code) and not any(f == af and tok in line for af, tok in allowed):
+                bad.append(f"{f}:{n}: {line.strip()[:100]}")
+    assert not bad, "\n".join(bad)
+    # every mutator is a host-side note: no HIP call at all between its braces (the device work is in *_state_on / history_on, which take the stream)
+    for f, fn in (("chain_fused.hip", "int chain_fused_reset(ChainFused* c) {"), ("chain_td.hip", "int chain_td_reset(ChainTd* c) {"), ("fir_batched.hip", "int gr4hip_fir_batched_reset("),
+                  ("iir.hip", "int gr4hip_iir_reset(gr4hip_iir_t* f) {"), ("fir.hip", "int gr4hip_fir_reset(gr4hip_fir_t* f) {"), ("math.hip", "int gr4hip_rotator_reset("),
+                  ("f64.hip", "int gr4hip_fir64_reset("), ("f64.hip", "int gr4hip_iir64_reset("), ("fir_interp.hip", "int gr4hip_fir_interp_reset(")):
+        t = open(os.path.join(src, f), errors="replace").read()
+        i = t.index(fn)
+        body = t[i:t.index("\n}\n", i)]
+        assert not re.search(r"\bhip[A-Z]\w*\(", body), (f, fn, body)
+
+
 def test_status_strings_and_errors(L):
     assert L.gr4hip_status_string(0) == b"OK"
     assert L.gr4hip_status_string(-2) == b"INSUFFICIENT_INPUT_ITEMS"
