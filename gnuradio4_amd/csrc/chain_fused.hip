@@ -1109,7 +1109,7 @@ struct ChainFused {
     DeviceBuffer d_fflags;             // one byte per frame of the last launch
     ~ChainFused() {
         if (c16) chain16_destroy(c16);
-        if (h_pw) (void)hipHostFree(h_pw);
+        if (h_pw) hip_quiet(hipHostFree(h_pw));
     }
 };
 
@@ -1589,7 +1589,7 @@ void chain_fused_set_max_workgroups(ChainFused* c, unsigned n) { c->max_wg = n; 
 } // namespace gr4
 extern "C" int gr4hip_dbg_fd_timing(unsigned long long* h_out, size_t n_frames) { // developer-only, not part of the ABI
     if (!gr4::g_dbg) return GR4HIP_ERROR;
-    (void)hipDeviceSynchronize();
+    hip_quiet(hipDeviceSynchronize());
     return hipMemcpy(h_out, gr4::g_dbg, n_frames * 8 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? GR4HIP_OK : GR4HIP_RUNTIME_ERROR;
 }
 namespace gr4 {

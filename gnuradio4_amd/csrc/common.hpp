@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -63,6 +64,11 @@ int dev_switch(DevSwitch s);
             return GR4HIP_RUNTIME_ERROR;                                                        \
         }                                                                                       \
     } while (0)
+
+// A HIP call whose failure the caller can do nothing about (frees in destructors): the runtime's last-error word is sticky since ROCm 7 -- an ignored failure
+// stays there until somebody calls hipGetLastError, and that somebody is GR4_LAUNCH_CHECK behind an innocent launch (round 6: hipHostUnregister of a ring with a copy
+// still in flight -> "kernel launch failed: unknown error" in the next gr4hip_iir_create, one run in two).  So: ignored means cleared.
+inline hipError_t hip_quiet(hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e; }
 
 inline hipStream_t as_stream(gr4hip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -124,14 +130,14 @@ struct DeviceBuffer {
     size_t bytes = 0;
     int    ensure(size_t need) {
         if (need <= bytes) return GR4HIP_OK;
-        if (ptr) (void)hipFree(ptr);
+        if (ptr) hip_quiet(hipFree(ptr));
         ptr   = nullptr;
         bytes = 0;
         GR4_HIP_TRY(hipMalloc(&ptr, need));
         bytes = need;
         return GR4HIP_OK;
     }
-    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+    void release() { if (ptr) hip_quiet(hipFree(ptr)); ptr = nullptr; bytes = 0; }
     ~DeviceBuffer() { release(); }
 };
 

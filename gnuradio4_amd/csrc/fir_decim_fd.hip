@@ -477,7 +477,7 @@ struct FirDecimFd {
     unsigned     pw_seq = 0, pw_seen = 0;
     hipStream_t  pw_stream = nullptr;
     ~FirDecimFd() {
-        if (h_pw) (void)hipHostFree(h_pw);
+        if (h_pw) hip_quiet(hipHostFree(h_pw));
     }
 };
 

@@ -944,7 +944,7 @@ struct gr4hip_iir {
     // the stream rule (common.hpp): create / reset / set_algo only note that the state is to be zeroed; iir_state_on() enqueues it on the stream of the next call
     bool                zero_state = true, zero_seq = true;
     ~gr4hip_iir() {
-        if (h_err) (void)hipHostFree(h_err);
+        if (h_err) hip_quiet(hipHostFree(h_err));
         delete part[0];
         delete part[1];
     }
@@ -1069,7 +1069,7 @@ static int iir_run(gr4hip_iir* f, const float* x, float* y, long n, hipStream_t 
 #ifdef GR4_IIR_TIMING
             {
                 std::vector<unsigned long long> h(16 * nblocks);
-                (void)hipStreamSynchronize(st);
+                hip_quiet(hipStreamSynchronize(st));
                 (void)hipMemcpy(h.data(), a.dbgc, h.size() * 8, hipMemcpyDeviceToHost);
                 FILE* fp = fopen("/tmp/iir_stamps.txt", "w");
                 for (long i = 0; i < nblocks; ++i) { for (int k = 0; k < 16; ++k) fprintf(fp, "%llu ", h[i * 16 + k]); fprintf(fp, "\n"); }

@@ -87,7 +87,7 @@ def _np(t):
 
 # ---------------------------------------------------------------------------------------------------------------- reset behind a held stream, per handle type
 @pytest.mark.parametrize("ntaps,n,cplx,decim", [(31, 8192, False, 1), (200, 1 << 17, False, 1), (1000, 1 << 17, False, 1), (256, 1 << 17, True, 1), (64, 1 << 16, True, 1),
-                                                (1024, 1 << 18, False, 8), (80, 1 << 18, True, 4), (48, 1 << 17, False, 5)])
+                                                (1024, 1 << 18, False, 8), (80, 1 << 18, True, 4), (48, 131070, False, 5)])
 def test_fir_reset_is_ordered_behind_the_launch_in_flight(G, ntaps, n, cplx, decim):
     """fir_filter (register-window, f16 matrix-pipe, sliced, complex, decimating kernels): process(x1) | reset | process(x2) queued behind a held stream == two fresh filters"""
     b = O.design_taps_hamming_lowpass(ntaps, 0.1 / decim)
