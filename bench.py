@@ -318,6 +318,59 @@ def secondary_configs(G, verify):
     return out
 
 
+def _compact_line(res: dict, detail_file: str) -> dict:
+    """THE line rank 0 prints (the driver keeps 2 000 characters of tail and only the key NAMES of nested rows): every contract key, the secondary rows as
+    top-level NUMBERS right behind `value`, short strings, < 2 000 characters.  Everything else -- the prose, per-row timing notes, per-rank logs -- goes to `detail_file`."""
+    def g(d, *ks, default=None):
+        for k in ks:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+    line = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step") if k in res}
+    if "error" in res:
+        line["error"] = res["error"]
+    sc = res.get("secondary_configs") or {}
+    rows = {  # Msamples/s and fraction of 8 TB/s (algorithmic bytes), each checked against the float64 oracle in this run (max relative error beside it)
+        "hann_msamples": g(res, "hann_second_row", "value"), "hann_frac": g(res, "hann_second_row", "frac"), "hann_err": g(res, "hann_second_row", "verify_max_rel_err"),
+        "guard_in_stream_msamples": g(res, "guard_tripped_row", "in_stream_msamples"), "guard_settled_msamples": g(res, "guard_tripped_row", "settled_msamples"),
+        "guard_err": g(res, "guard_tripped_row", "in_stream_verify_max_rel_err"),
+        "configs2_msamples": g(sc, "configs[2]", "value"), "configs2_frac": g(sc, "configs[2]", "hbm_frac"), "configs2_err": g(sc, "configs[2]", "verify_max_rel_err"),
+        "configs3_msamples": g(sc, "configs[3]", "value"), "configs3_frac": g(sc, "configs[3]", "hbm_frac"), "configs3_err": g(sc, "configs[3]", "verify_max_rel_err"),
+        "graph8_msamples": g(res, "eight_channel_graph_on_one_gpu", "value"), "graph8_err": g(res, "eight_channel_graph_on_one_gpu", "verify", "max_rel_err"),
+        "host_feed_msamples": g(res, "host_feed_row", "value"),
+    }
+    line.update({k: v for k, v in rows.items() if v is not None})
+    for k in ("median_ms_per_step", "value_at_median_step", "prewarm_ms", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        if k in res:
+            line[k] = res[k]
+    cfg = res.get("config") or {}
+    line["config"] = {"workload": f"configs[{4 if cfg.get('channels', 1) > 1 else 1}]: complex<float> {NTAPS}-tap FIR -> {NFFT}-pt FFT -> mag2, rectangular window, "
+                                  + cfg.get("workload", "").split("rectangular window, ")[-1].split(";")[0],
+                      "chain_algo": cfg.get("chain_algo"), "channels": cfg.get("channels"), "parallelism": cfg.get("parallelism"),
+                      "guard": (cfg.get("dynamic_range_guard") or "").split(":")[0]}
+    rf = res.get("roofline") or {}
+    line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "algorithmic_bytes_per_launch",
+                                          "avg_launch_ms", "median_launch_ms", "timed_launches") if k in rf}
+    if "verify" in res:
+        line["verify"] = {k: res["verify"][k] for k in ("verified_frames", "max_rel_err", "tolerance") if k in res["verify"]}
+    cb = res.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": (cb.get("sample") or "").split(" (")[0], "all_cores_value": g(cb, "all_cores", "value"), "all_cores": g(cb, "all_cores", "cores")}
+    if "fanin" in res:
+        line["fanin"] = {k: res["fanin"][k] for k in ("collective", "xgmi_ceiling_msamples", "probe_seconds_per_launch", "implementation") if k in res["fanin"]}
+    if detail_file:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_file)), exist_ok=True)
+            with open(detail_file, "w") as f:
+                json.dump(res, f, indent=1)
+            line["detail_file"] = os.path.relpath(detail_file, ROOT) if os.path.abspath(detail_file).startswith(ROOT) else detail_file
+        except OSError:
+            pass
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +388,8 @@ def main():
                     "communicator the C++ engine uses; torch.distributed only ships its id) or through torch.distributed's own communicator")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check of the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail-file", default=None, help="where rank 0 writes the long form of the result (every row with its workload text, timing notes, per-rank logs); "
+                                                        "default gpurun_out/bench_detail.json under the repo root; '' = nowhere.  The printed line stays under 2 000 characters")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of sampled output frames")
     ap.add_argument("--no-multi", action="store_true", help="several channels per GPU: one kernel per channel on its own stream + a separate math::Add fold (round 2's shape) "
                     "instead of ONE launch with the fold in registers (gr4hip_chain_process_multi)")
@@ -782,7 +837,10 @@ def main():
                                                          "steps": g8["steps"], "verify": g8.get("verify"), "workload": g8["config"]["workload"]}
             except Exception as e:  # never at the price of the headline line
                 res["eight_channel_graph_on_one_gpu"] = {"error": str(e)[:200]}
-        print(json.dumps(res), flush=True)
+        detail = args.detail_file
+        if detail is None:
+            detail = "" if os.environ.get("GR4HIP_BENCH_CHILD") == "1" else os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        print(json.dumps(_compact_line(res, detail)), flush=True)
     if world > 1:
         dist.destroy_process_group()
     sys.exit(rc)

@@ -2206,6 +2206,10 @@ public:
             for (auto& sl : _slabs)
                 if (sl.busy && sl.direct) held += sl.n_out;
             if (held) _out->unreserve_items(held);
+            //  the pipeline starts over: nothing that was in flight is published later -- its reservations are gone, a retire() after this error would
+            // publish storage that is no longer reserved
+            for (auto& sl : _slabs) { sl.busy = false; sl.direct = nullptr; sl.fwd.clear(); }
+            _in_flight = 0; _pending_staged = 0; _oldest = 0;
             return {requested, 0, work::Status::ERROR};
         }
     }

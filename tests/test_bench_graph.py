@@ -26,7 +26,16 @@ def _run(cmd, timeout=900):
     assert p.returncode == 0, f"{' '.join(cmd)}\nrc={p.returncode}\n{p.stdout[-3000:]}\n{p.stderr[-3000:]}"
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
-    return json.loads(lines[0])
+    assert len(lines[0]) < 2000, len(lines[0])  # the driver's record keeps 2 000 characters of tail: the whole line fits
+    r = json.loads(lines[0])
+    if "detail_file" in r:  # the long form (rows with their workload text and timing notes): the tests below read both through one dict, the printed line's keys on top
+        d = json.load(open(os.path.join(ROOT, r["detail_file"])))
+        for k, v in d.items():
+            if isinstance(v, dict) and isinstance(r.get(k), dict):
+                r[k] = {**v, **r[k]}
+            else:
+                r.setdefault(k, v)
+    return r
 
 
 def test_bench_single_channel_self_check():
@@ -88,6 +97,7 @@ def test_bench_line_has_the_median_the_prewarm_the_hann_row_and_the_secondary_co
     r = _run([sys.executable, "bench.py", "--steps", "5", "--warmup", "1", "--log2-samples", "26", "--log2-chunk", "24", "--no-cpu-baseline", "--no-graph8"])
     assert r["prewarm_ms"] >= 40 and r["prewarm_steps"] >= 1 and r["median_ms_per_step"] > 0 and r["value_at_median_step"] > 0
     assert r["roofline"]["timed_launches"] == 5 * 4
+    assert r["hann_msamples"] > 0 and r["configs2_msamples"] > 0 and r["configs3_msamples"] > 0 and r["guard_settled_msamples"] > 0  # the rows as top-level numbers of the printed line
     h = r["hann_second_row"]
     assert h["window"] == "Hann" and h["value"] > 0 and 0 < h["frac"] < 1 and h["verify_max_rel_err"] <= 1e-5
     sc = r["secondary_configs"]  # BASELINE.json configs[2] and configs[3] beside the headline, each checked against the oracle

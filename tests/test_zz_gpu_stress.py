@@ -156,17 +156,17 @@ def test_fir_interpolator_reset_is_ordered(G, interp, ntaps, cplx):
     assert _rel(_np(y1), t1) <= TOL and _rel(_np(y2), t2) <= TOL
 
 
-@pytest.mark.parametrize("order,algo", [(4, "auto"), (8, "auto"), (16, "auto"), (8, "sequential")])
+@pytest.mark.parametrize("order,algo", [(4, "auto"), (8, "auto"), (12, "auto"), (8, "sequential")])
 def test_iir_reset_is_ordered_behind_the_launch_in_flight(G, order, algo):
     """iir cascades (2 / 4 / 8 biquads: the one-pass scan, the split cascade) and GR4HIP_IIR_SEQUENTIAL_F32: the state pair is zeroed on the call's stream"""
-    bi, ai = G.blocks.design_iir(G.capi.LOWPASS, order, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
-    sec = O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)])
+    bi, ai = G.blocks.design_iir(G.capi.LOWPASS, order, 0.1 if order > 8 else 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)  # (12: six biquads = the split cascade)
+    sec = lambda: O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)])  # (the oracle's sections carry their state: a fresh cascade per span)
     n = (1 << 20) + 77 if algo == "auto" else 50_000
     x1, x2 = O.signal_f32(41, n), O.signal_f32(42, n // 2)
     f = G.iir_filter(bi, ai)
     if algo == "sequential":
         f.set_algo(G.capi.IIR_SEQUENTIAL_F32)
-    t1, t2 = O.iir_cascade(sec, x1, O.DF_II, f64=True), O.iir_cascade(sec, x2, O.DF_II, f64=True)
+    t1, t2 = O.iir_cascade(sec(), x1, O.DF_II, f64=True), O.iir_cascade(sec(), x2, O.DF_II, f64=True)
     d1, d2 = dev(x1), dev(x2)
     with _Hostile() as h:
         y1 = f.process_bulk(d1)
@@ -174,7 +174,7 @@ def test_iir_reset_is_ordered_behind_the_launch_in_flight(G, order, algo):
         y2 = f.process_bulk(d2)
         h.queued()
     if algo == "sequential":  # the reference's float32 arithmetic in its order: bit for bit
-        assert np.array_equal(_np(y1), O.iir_cascade(sec, x1, O.DF_II, f64=False)) and np.array_equal(_np(y2), O.iir_cascade(sec, x2, O.DF_II, f64=False))
+        assert np.array_equal(_np(y1), O.iir_cascade(sec(), x1, O.DF_II, f64=False)) and np.array_equal(_np(y2), O.iir_cascade(sec(), x2, O.DF_II, f64=False))
     else:
         assert _rel(_np(y1), t1) <= TOL and _rel(_np(y2), t2) <= TOL
     f.status()
@@ -278,9 +278,8 @@ def test_decimator_and_cascade_in_one_launch_reset_is_ordered(G):
     ntaps, n = 1024, 7168 * 80
     b = O.design_taps_hamming_lowpass(ntaps, 0.05)
     bi, ai = G.blocks.design_iir(G.capi.LOWPASS, 8, 0.05, float("nan"), 1.0, G.capi.BUTTERWORTH)
-    sec = O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)])
     x1, x2 = O.signal_f32(91, n), O.signal_f32(92, n)
-    truth = [O.iir_cascade(sec, O.fir_decim(b, x, 8)[0].astype(np.float32), O.DF_II, f64=True) for x in (x1, x2)]
+    truth = [O.iir_cascade(O.make_sections([(bb, aa) for bb, aa in zip(bi, ai)]), O.fir_decim(b, x, 8)[0].astype(np.float32), O.DF_II, f64=True) for x in (x1, x2)]
     f, q = G.fir_filter(b, torch.float32, decimate=8), G.iir_filter(bi, ai)
     f.set_guard_mode(G.capi.GUARD_DEFERRED)  # (strict waits for its own measurement on this path: a different contract, tested in test_gpu_parity.py)
     d1, d2 = dev(x1), dev(x2)
