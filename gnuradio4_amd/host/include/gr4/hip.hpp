@@ -54,6 +54,9 @@ struct Options {
     // A sharded graph's exchange (FanInRun) waits for other ranks: seconds one exchange may take before the run gives up with a rank-tagged message and
     // work::Status::ERROR instead of hanging its process (a peer that died or never joined); <= 0: wait for ever
     double collective_timeout_s = 120.0;
+    // A device run whose input edge is smaller than a launch is worth (the reference's default: 65 536 items, Graph.hpp:102) gathers the edge's contents in its device
+    // ring and launches over ~2^20 items at a time (DeviceRun "batching"); false: one launch per edge-full, round 5's behaviour (0.8 Gsamples/s host-fed at 2^16-item edges)
+    bool batch_small_edges = true;
 };
 inline Options& options() { static Options o; return o; }
 
@@ -1466,8 +1469,13 @@ class DeviceRun final : public BlockModel {
     struct Slot {
         DevBuf         h_in{true}, h_out{true}, d_out;
         gr4hip_event_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
-        std::size_t    n_out = 0, n_lent = 0; // n_lent: input items the copy engine reads in the edge's own storage, released when in_done has fired
+        std::size_t    n_out = 0;
+        std::size_t    seq = 0;               // position of the chunk in the stream of chunks (the lent pieces name their chunk by it)
         void*          direct = nullptr;      // the result copy lands in the output edge's own (page-locked) storage: published in place
+        bool           piecewise = false;     // a batching run's chunk: its result leaves in pieces (retire_pieces)
+        const void*    d_res = nullptr;       // ... from here (the last stage's output), out_off items of it published so far,
+        std::size_t    out_off = 0, piece_n = 0; // piece_n items on their way into the output edge's storage
+        bool           staged = false, copied = false; // the whole result is (on its way) in h_out; its copy has landed
         bool           busy = false;
         bool           launched = false;      // false: the chunk's samples are on their way into the ring (or there), its kernels are not queued yet
         const void*    d_src = nullptr;       // where the chunk sits in the ring
@@ -1475,6 +1483,14 @@ class DeviceRun final : public BlockModel {
         property_map   fwd; // tags to publish at the first output sample of this chunk
     };
     std::array<Slot, kDepth> _slots;
+    struct Piece { gr4hip_event_t ev; std::size_t n; std::size_t seq; }; // an input span the copy engine is reading in the edge's own storage: ev fires when it has landed
+    std::deque<Piece>           _lent;
+    std::vector<gr4hip_event_t> _ev_free, _ev_all;
+    std::size_t                 _next_seq = 0, _launched_seq = 0; // chunks numbered in queue order; every chunk below _launched_seq has its kernels queued
+    // batching: an input edge that holds less than a launch is worth -- the reference's default 65 536 items (Graph.hpp:102) -- is drained piece by piece
+    // into the device ring and the kernels are launched over ~2^20 items at a time; the result leaves piece by piece as the output edge takes it
+    bool                        _batching = false;
+    std::size_t                 _batch_items = std::size_t(1) << 20;
     std::size_t     _inplace_chunks = 0, _direct_chunks = 0; // chunks copied straight out of a page-locked input edge / straight into a page-locked output edge
     std::size_t     _q_head = 0, _q_count = 0, _pending_out = 0, _overlapped = 0; // FIFO of busy slots; output items not yet published; chunks queued while another was in flight
     DevBuf          _d_a, _d_b;
@@ -1516,6 +1532,8 @@ public:
         check(gr4hip_ring_create(&_ring, (kDepth + 1) * chunk_items * _in_bytes), "gr4hip_ring_create");
         check(gr4hip_ring_base(_ring, &_ring_base), "ring base");
         check(gr4hip_ring_size(_ring, &_ring_bytes), "ring size");
+        _batch_items = std::min(_batch_items, chunk_items);
+        _batching    = in->capacity_items() > 0 && in->capacity_items() < _batch_items && options().batch_small_edges;
     }
     ~DeviceRun() override {
         for (gr4hip_stream_t st : {_s_in, _s_k, _s_out})
@@ -1524,6 +1542,7 @@ public:
         for (auto& sl : _slots)
             for (gr4hip_event_t ev : {sl.in_done, sl.k_done, sl.out_done})
                 if (ev) gr4hip_event_destroy(ev);
+        for (gr4hip_event_t ev : _ev_all) gr4hip_event_destroy(ev);
         if (_ring) gr4hip_ring_destroy(_ring);
         for (gr4hip_stream_t st : {_s_in, _s_k, _s_out})
             if (st) gr4hip_stream_destroy(st);
@@ -1531,36 +1550,44 @@ public:
     [[nodiscard]] std::size_t overlapped_chunks() const { return _overlapped; }
     [[nodiscard]] std::size_t inplace_chunks() const { return _inplace_chunks; }
     [[nodiscard]] std::size_t direct_chunks() const { return _direct_chunks; }
-    // the oldest input span still lent out: wait for its copy and give it back; returns the items released (0: nothing is lent)
+    // ---- input spans lent to the copy engine (pieces, oldest first).  A piece goes back to the edge when its copy has landed and -- edges that hold whole chunks --
+    // its chunk's kernels are queued (a chunk whose launch fails goes back to the edge whole); a batching run (below) gives it back as soon as the copy has landed:
+    // the edge is smaller than the batch, the samples wait for their launch in the device ring
+    [[nodiscard]] bool releasable(const Piece& pc) const { return _batching || pc.seq < _launched_seq; }
+    // the oldest piece still lent: wait for its copy and give it back; returns the items released (0: nothing that may go back is lent)
     std::size_t release_oldest_input() {
-        for (std::size_t i = 0; i < _q_count; ++i) {
-            Slot& sl = _slots[(_q_head + i) % kDepth];
-            if (!sl.launched) break; // a chunk keeps its input until its kernels are queued: one whose launch fails goes back to the edge whole
-            if (sl.n_lent == 0) continue;
-            check(gr4hip_event_synchronize(sl.in_done), "event sync");
-            const std::size_t n = sl.n_lent;
-            _in_edge->consume_items(n);
-            sl.n_lent = 0;
-            return n;
-        }
-        return 0;
+        if (_lent.empty() || !releasable(_lent.front())) return 0;
+        const Piece pc = _lent.front();
+        check(gr4hip_event_synchronize(pc.ev), "event sync");
+        _in_edge->consume_items(pc.n);
+        _ev_free.push_back(pc.ev);
+        _lent.pop_front();
+        return pc.n;
     }
-    // input spans lent to the copy engine go back to the edge, oldest first, as their copies land (wait: block until all have)
-    void release_inputs(bool wait) {
+    // lent pieces go back to the edge, oldest first, as their copies land (wait: block until all have)
+    std::size_t release_inputs(bool wait) { // returns the items that went back
+        std::size_t freed = 0;
         if (wait) launch_pending(0); // (everything lent is to go back: the chunks that hold spans run first)
-        for (std::size_t i = 0; i < _q_count; ++i) {
-            Slot& sl = _slots[(_q_head + i) % kDepth];
-            if (!sl.launched) break;
-            if (sl.n_lent == 0) continue;
-            if (wait) check(gr4hip_event_synchronize(sl.in_done), "event sync");
+        while (!_lent.empty() && releasable(_lent.front())) {
+            const Piece pc = _lent.front();
+            if (wait) check(gr4hip_event_synchronize(pc.ev), "event sync");
             else {
                 int done = 0;
-                check(gr4hip_event_query(sl.in_done, &done), "event query");
-                if (!done) return;
+                check(gr4hip_event_query(pc.ev, &done), "event query");
+                if (!done) return freed;
             }
-            _in_edge->consume_items(sl.n_lent);
-            sl.n_lent = 0;
+            _in_edge->consume_items(pc.n);
+            _ev_free.push_back(pc.ev);
+            _lent.pop_front();
+            freed += pc.n;
         }
+        return freed;
+    }
+    gr4hip_event_t piece_event() {
+        if (_ev_free.empty()) { gr4hip_event_t ev = nullptr; check(gr4hip_event_create(&ev), "gr4hip_event_create"); _ev_all.push_back(ev); return ev; }
+        gr4hip_event_t ev = _ev_free.back();
+        _ev_free.pop_back();
+        return ev;
     }
     // rate bookkeeping (Resampling<>, Block.hpp:1576-1636, across the whole run): walking back from the last stage, `need` is the count a
     // stage's output must be a multiple of; it produces out_chunk per in_chunk
@@ -1582,11 +1609,10 @@ public:
     const std::vector<std::unique_ptr<Stage>>& stages() const { return _stages; }
 
     // the kernels and the result copy of a chunk whose samples are on their way into the ring.  Ingest and launch are separate steps: work() queues the copy of
-    // chunk c + 1 BEFORE it launches chunk c, so that the link stays busy while a stage's enqueue waits for its own launch (the strict dynamic-range guard of the
-    // chain: the call returns when the launch has finished) -- with both in one step the copy engine idled for a kernel time per chunk (host-fed 5.4 Gsamples/s
-    // under the strict guard where the deferred one gave 6.1)
+    // chunk c + 1 BEFORE it launches chunk c, so that the link stays busy while a stage's enqueue is busy.  A batching run's result goes out piece by piece (retire):
+    // only the wait for the kernels is queued on the result stream here
     void launch(Slot& sl) {
-        check(gr4hip_stream_wait_event(_s_k, sl.in_done), "stream wait");
+        check(gr4hip_stream_wait_event(_s_k, sl.in_done), "stream wait"); // (in_done: recorded behind the chunk's LAST piece)
         const void* cur = sl.d_src;
         std::size_t cnt = sl.n_in;
         for (std::size_t i = 0; i < _stages.size(); ++i) { // stages run back-to-back on the kernel stream; intermediates stay in HBM
@@ -1602,15 +1628,71 @@ public:
         if (cnt != sl.n_out) throw std::runtime_error("device run: a chunk produced an unexpected number of samples");
         check(gr4hip_event_record(sl.k_done, _s_k), "event record");
         check(gr4hip_stream_wait_event(_s_out, sl.k_done), "stream wait");
-        check(gr4hip_memcpy_d2h(sl.direct ? sl.direct : sl.h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _s_out), "d2h");
-        check(gr4hip_event_record(sl.out_done, _s_out), "event record");
-        sl.launched = true;
+        sl.d_res = cur;
+        if (!sl.piecewise || _out_edge->memory() != pinned_resource()) { // the whole result in one copy: into the reserved span of a page-locked edge, or into the slot's own page-locked buffer
+            check(gr4hip_memcpy_d2h(sl.direct ? sl.direct : sl.h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _s_out), "d2h");
+            check(gr4hip_event_record(sl.out_done, _s_out), "event record");
+            sl.staged = !sl.direct;
+        }
+        sl.launched   = true;
+        _launched_seq = sl.seq + 1;
     }
     // launches every ingested chunk except the newest `keep` ones, oldest first
     void launch_pending(std::size_t keep) {
         for (std::size_t i = 0; i + keep < _q_count; ++i) {
             Slot& sl = _slots[(_q_head + i) % kDepth];
             if (!sl.launched) launch(sl);
+        }
+    }
+    void finish_slot(Slot& sl) {
+        sl.direct = nullptr;
+        sl.busy = sl.launched = sl.staged = false;
+        sl.out_off = sl.piece_n = 0;
+        sl.fwd.clear();
+        _q_head = (_q_head + 1) % kDepth;
+        --_q_count;
+    }
+    // a batching run's oldest chunk: its result leaves in pieces of at most half the output edge -- straight into the edge's page-locked storage where there is room (the sink
+    // drains one half while the copy engine fills the other), or out of the slot's staging buffer into an ordinary edge.  Publishes what has landed, queues the next piece, never
+    // waits for room in the edge (the sink runs on this thread).  only_if_done: never waits for a copy either.
+    std::size_t retire_pieces(Slot& sl, bool only_if_done) {
+        std::size_t       pub  = 0;
+        const bool        pin  = _out_edge->memory() == pinned_resource();
+        const std::size_t half = std::max<std::size_t>(_out_edge->capacity_items() / 2, 1);
+        for (;;) {
+            if (sl.piece_n || (sl.staged && sl.out_off == 0 && !sl.copied)) { // a copy in flight: the piece (page-locked edge) or the whole result (staging buffer)
+                if (only_if_done) {
+                    int done = 0;
+                    check(gr4hip_event_query(sl.out_done, &done), "event query");
+                    if (!done) return pub;
+                } else {
+                    check(gr4hip_event_synchronize(sl.out_done), "event sync");
+                }
+                sl.copied = true;
+                if (sl.piece_n) {
+                    if (sl.out_off == 0 && !sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
+                    _out_edge->publish_reserved(sl.piece_n);
+                    sl.out_off += sl.piece_n;
+                    pub += sl.piece_n;
+                    sl.piece_n = 0;
+                }
+            }
+            if (sl.out_off == sl.n_out) { finish_slot(sl); return pub; }
+            std::size_t n = std::min({sl.n_out - sl.out_off, half, _out_edge->free_items()});
+            if (n == 0) return pub; // the edge is full: the sink's turn
+            if (pin) {
+                void* dst = _out_edge->reserve_items(n);
+                if (!dst) return pub;
+                check(gr4hip_memcpy_d2h(dst, static_cast<const char*>(sl.d_res) + sl.out_off * _out_bytes, n * _out_bytes, _s_out), "d2h");
+                check(gr4hip_event_record(sl.out_done, _s_out), "event record");
+                sl.piece_n = n;
+                ++_direct_chunks;
+            } else {
+                if (sl.out_off == 0 && !sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
+                _write(static_cast<const char*>(sl.h_out.p) + sl.out_off * _out_bytes, n);
+                sl.out_off += n;
+                pub += n;
+            }
         }
     }
 
@@ -1622,6 +1704,7 @@ public:
             if (only_if_done) return 0;
             launch(sl);
         }
+        if (sl.piecewise) return retire_pieces(sl, only_if_done);
         if (only_if_done) {
             int done = 0;
             check(gr4hip_event_query(sl.out_done, &done), "event query");
@@ -1629,7 +1712,11 @@ public:
         } else {
             check(gr4hip_event_synchronize(sl.out_done), "event sync");
         }
-        if (sl.n_lent) { _in_edge->consume_items(sl.n_lent); sl.n_lent = 0; } // the result has landed, so has the input (slots retire oldest first)
+        while (!_lent.empty() && _lent.front().seq <= sl.seq) { // the result has landed, so has the input (slots retire oldest first)
+            _in_edge->consume_items(_lent.front().n);
+            _ev_free.push_back(_lent.front().ev);
+            _lent.pop_front();
+        }
         if (!sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
         const std::size_t n = sl.n_out;
         if (sl.direct) _out_edge->publish_reserved(n);
@@ -1639,12 +1726,19 @@ public:
             else _write(sl.h_out.p, n);
             _pending_out -= n;
         }
-        sl.direct = nullptr;
-        sl.busy = sl.launched = false;
-        sl.fwd.clear();
-        _q_head = (_q_head + 1) % kDepth;
-        --_q_count;
+        finish_slot(sl);
         return n;
+    }
+    // everything queued leaves (a stage is about to be replaced, tags are about to be read relative to the read position).  false: the output edge is full and the
+    // sink has to run first -- only a batching run can be stuck like that (a chunk-per-slot run never queues more than the output edge takes)
+    bool drain(std::size_t& published) {
+        while (_q_count) {
+            const std::size_t before = _q_count;
+            const std::size_t r      = retire(false);
+            published += r;
+            if (_q_count == before && r == 0) return false;
+        }
+        return true;
     }
 
     work::Result work(std::size_t requested) override {
@@ -1653,7 +1747,11 @@ public:
             check(gr4hip_set_device(_domain.index), "gr4hip_set_device"); // runs on several devices share the scheduler thread: the current device is per call
             std::size_t published = 0;
             while (const std::size_t r = retire(true)) published += r; // whatever has finished since the last call
-            release_inputs(!_in_edge->tags.empty()); // tags are addressed relative to the read position: with tags around, every lent span is returned first
+            if (_batching && !_in_edge->tags.empty() && _q_count) { // tags around: a batching run goes chunk by chunk (nothing in flight while settings may change)
+                launch_pending(0);
+                if (!drain(published)) return {requested, published, published ? work::Status::OK : work::Status::INSUFFICIENT_OUTPUT_ITEMS};
+            }
+            const std::size_t freed_now = release_inputs(!_in_edge->tags.empty()); // tags are addressed relative to the read position: with tags around, every lent span is returned first
             // the launch's tag: the one on its first sample -- launches end where the next tag starts -- or, when a whole input chunk (a frame, a
             // decimation group) has to span tags, all of them merged (Block.hpp:1511-1530).  Settings-by-tag for the member blocks first (only the
             // stages of members that changed are rebuilt, the others keep their state), then forwarded across the whole run like across one block:
@@ -1665,7 +1763,7 @@ public:
                     for (std::size_t m = 0; m < _members.size(); ++m)
                         if (_members[m].block->apply_tag_settings(map)) dirty[_members[m].stage] = changed[m] = true;
                     if (std::find(dirty.begin(), dirty.end(), true) == dirty.end()) return;
-                    while (_q_count) published += retire(false); // a stage is replaced: nothing of the old one may be in flight
+                    while (_q_count) published += retire(false); // a stage is replaced: nothing of the old one may be in flight (a batching run has drained above)
                     for (std::size_t i = 0; i < _stages.size(); ++i)
                         if (dirty[i] && _rebuild) {
                             if (auto fresh = _rebuild(i, changed, _stages[i].get())) _stages[i] = std::move(fresh);
@@ -1688,20 +1786,51 @@ public:
                     else fwd.insert_or_assign(key, value);
                 }
             }
-            if (_q_count == kDepth) published += retire(false); // all slots queued: wait for the oldest
-            std::size_t n = std::min({_avail(), requested, _ring_bytes / _in_bytes / (kDepth + 1)}); // kDepth chunks in flight never wrap onto each other in the ring
+            // ---- a batching run (the input edge holds less than a launch is worth: the reference's default 65 536-item edges, Graph.hpp:102): the piece that has arrived joins
+            // the newest chunk while that one is not launched, carries no tag of its own and is short of the batch size -- one launch per ~2^20 items instead of one per edge-full
+            const std::size_t batch_items = std::max(_batch_items / _in_chunk, std::size_t(1)) * _in_chunk;
+            Slot* open = nullptr;
+            if (_batching && _q_count && fwd.empty()) {
+                Slot& newest = _slots[(_q_head + _q_count - 1) % kDepth];
+                if (!newest.launched && newest.n_in < batch_items) open = &newest;
+            }
+            if (!open && _q_count == kDepth) {
+                published += retire(false); // all slots queued: wait for the oldest
+                if (_q_count == kDepth) return {requested, published, published ? work::Status::OK : work::Status::INSUFFICIENT_OUTPUT_ITEMS}; // (batching: the sink has to make room first)
+            }
+            std::size_t n = std::min({_avail(), requested, _batching ? (open ? batch_items - open->n_in : batch_items) : _ring_bytes / _in_bytes / (kDepth + 1)}); // kDepth chunks in flight never wrap onto each other in the ring
             n = std::min(n, std::max(_in_edge->samplesUntilNextTag(), _in_chunk)); // a launch ends where the next tag starts (Block.hpp:1511-1530): tags sit on launch boundaries
-            const std::size_t space = _space() - std::min(_space(), _pending_out);  // the output edge minus what queued chunks will publish (reserved spans are already off it)
-            n = std::min(n / _in_chunk, space / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
+            if (_batching) {
+                // half the edge per piece: the source refills one half while the copy engine reads the other
+                if (_in_edge->capacity_items() / 2 >= _in_chunk) n = std::min(n, _in_edge->capacity_items() / 2);
+                n = n / _in_chunk * _in_chunk;
+            } else {
+                const std::size_t space = _space() - std::min(_space(), _pending_out);  // the output edge minus what queued chunks will publish (reserved spans are already off it)
+                n = std::min(n / _in_chunk, space / std::max<std::size_t>(1, _out_per_chunk)) * _in_chunk; // whole chunks that also fit the output edge
+            }
             if (n == 0) {
-                launch_pending(0); // nothing new to copy: whatever has been ingested runs now
-                if (_q_count) { // nothing new to queue
-                    // input lent to the copy engine is what keeps a small edge full: give the oldest such span back as soon as ITS copy has landed and let the
-                    // source refill the edge while the kernels and the result copy of that chunk still run (waiting for the whole chunk here serialised
-                    // source, copies and kernels on a default 64 Ki-sample edge: 0.73 -> 2 Gsamples/s host-fed); otherwise publish the oldest chunk
-                    if (const std::size_t freed = release_oldest_input()) return {requested, std::max(published, freed), work::Status::OK}; // (progress: the source can write again)
-                    published += retire(false);
-                    return {requested, published, work::Status::OK};
+                if (_batching) {
+                    if (freed_now) return {requested, std::max(published, freed_now), work::Status::OK}; // a piece has just gone back: the source writes into its place while the next one is on the link
+                    // nothing new has arrived.  A lent piece is what keeps a small edge full: it goes back as soon as ITS copy has landed and the source runs; with nothing
+                    // lent the input has run dry for now -- what has been gathered is launched (a slow source is served chunk by chunk, a fast one in full batches)
+                    if (const std::size_t freed = release_oldest_input()) return {requested, std::max(published, freed), work::Status::OK};
+                    launch_pending(0);
+                    if (_q_count) {
+                        const std::size_t r = retire(false);
+                        published += r;
+                        if (r) return {requested, published, work::Status::OK};
+                        if (published) return {requested, published, work::Status::OK};
+                        return {requested, 0, _avail() < _in_chunk && !_in_edge->done() && _out_edge->free_items() ? work::Status::INSUFFICIENT_INPUT_ITEMS : work::Status::INSUFFICIENT_OUTPUT_ITEMS};
+                    }
+                } else {
+                    launch_pending(0); // nothing new to copy: whatever has been ingested runs now
+                    if (_q_count) { // nothing new to queue
+                        // input lent to the copy engine is what keeps a small edge full: give the oldest such span back as soon as ITS copy has landed and let the
+                        // source refill the edge while the kernels and the result copy of that chunk still run; otherwise publish the oldest chunk
+                        if (const std::size_t freed = release_oldest_input()) return {requested, std::max(published, freed), work::Status::OK}; // (progress: the source can write again)
+                        published += retire(false);
+                        return {requested, published, work::Status::OK};
+                    }
                 }
                 if (published) return {requested, published, work::Status::OK};
                 if (_avail() < _in_chunk && _in_edge->done()) {
@@ -1711,9 +1840,9 @@ public:
                 return {requested, 0, _avail() < _in_chunk ? work::Status::INSUFFICIENT_INPUT_ITEMS : work::Status::INSUFFICIENT_OUTPUT_ITEMS};
             }
             // a page-locked output edge ("hip" provider) takes the result copy in its own storage; at the end of the storage the edge must compact
-            // first, which it only does with nothing in flight
+            // first, which it only does with nothing in flight.  (A batching run's results leave piece by piece: retire_pieces)
             void* direct = nullptr;
-            if (_out_edge->memory() == pinned_resource()) {
+            if (!_batching && _out_edge->memory() == pinned_resource()) {
                 const std::size_t n_res = out_count(n);
                 direct = _out_edge->reserve_items(n_res);
                 if (!direct && _q_count) {
@@ -1722,40 +1851,62 @@ public:
                 }
                 if (direct) held_reserved = n_res;
             }
-            Slot& sl = _slots[(_q_head + _q_count) % kDepth];
-            if (_q_count) ++_overlapped;
+            const bool fresh = open == nullptr;
+            Slot& sl = fresh ? _slots[(_q_head + _q_count) % kDepth] : *open;
+            if (fresh && _q_count) ++_overlapped;
+            if (fresh) sl.seq = _next_seq++;
             // samples land in HBM: pinned staging -> hipMemcpyAsync -> the double-mapped ring (a wrapping span stays contiguous)
             char*       d_in    = static_cast<char*>(_ring_base) + _ring_wr;
             const void* lent = _in_edge->lend_items(n);
             if (lent) held_lent = n;
             if (lent && _in_edge->memory() == pinned_resource()) { // page-locked storage ("hip" provider): the copy engine reads the edge in place;
                 check(gr4hip_memcpy_h2d(d_in, lent, n * _in_bytes, _s_in), "h2d"); // the span goes back to the edge once the copy has landed (release_inputs)
-                check(gr4hip_event_record(sl.in_done, _s_in), "event record");
-                sl.n_lent = n;
+                gr4hip_event_t ev = piece_event();
+                check(gr4hip_event_record(ev, _s_in), "event record");
+                _lent.push_back({ev, n, sl.seq});
                 ++_inplace_chunks;
             } else {
-                if (lent) { // pageable edge: staged through page-locked memory by the copy threads; the span stays lent until the chunk's copy has landed, like an
-                    CopyPool::instance().copy(sl.h_in.ensure(n * _in_bytes), lent, n * _in_bytes); // in-place one -- a chunk whose launch fails goes back to the edge whole
-                    sl.n_lent = n;
+                // pageable edge: staged through page-locked memory (the copy threads share a large piece).  A chunk-per-slot run keeps the span lent until the chunk is launched,
+                // like an in-place one -- a chunk whose launch fails goes back to the edge whole; a batching run hands it back at once (the staging buffer has it)
+                const std::size_t off = fresh ? 0 : sl.n_in * _in_bytes;
+                char*             stage = static_cast<char*>(sl.h_in.ensure((_batching ? batch_items : n) * _in_bytes)) + off;
+                if (lent) {
+                    CopyPool::instance().copy(stage, lent, n * _in_bytes);
+                    if (_batching) _in_edge->consume_items(n);
+                    else {
+                        gr4hip_event_t ev = piece_event();
+                        check(gr4hip_memcpy_h2d(d_in, stage, n * _in_bytes, _s_in), "h2d");
+                        check(gr4hip_event_record(ev, _s_in), "event record");
+                        _lent.push_back({ev, n, sl.seq});
+                        stage = nullptr;
+                    }
                 } else {
-                    _read(sl.h_in.ensure(n * _in_bytes), n);
+                    _read(stage, n);
                 }
-                check(gr4hip_memcpy_h2d(d_in, sl.h_in.p, n * _in_bytes, _s_in), "h2d");
-                check(gr4hip_event_record(sl.in_done, _s_in), "event record");
+                if (stage) check(gr4hip_memcpy_h2d(d_in, stage, n * _in_bytes, _s_in), "h2d");
             }
+            check(gr4hip_event_record(sl.in_done, _s_in), "event record"); // (behind the chunk's newest piece: what the kernel stream waits for)
             _ring_wr = (_ring_wr + n * _in_bytes) % _ring_bytes;
-            sl.d_src    = d_in;
-            sl.n_in     = n;
-            sl.n_out    = out_count(n);
-            sl.busy     = true;
-            sl.launched = false;
-            sl.direct   = direct;
-            sl.fwd      = std::move(fwd);
+            if (fresh) {
+                sl.d_src     = d_in;
+                sl.n_in      = n;
+                sl.busy      = true;
+                sl.launched  = false;
+                sl.staged = sl.copied = false;
+                sl.out_off = sl.piece_n = 0;
+                sl.piecewise = _batching;
+                sl.direct    = direct;
+                sl.fwd       = std::move(fwd);
+                ++_q_count;
+            } else {
+                sl.n_in += n;
+            }
+            sl.n_out = out_count(sl.n_in);
             if (direct) ++_direct_chunks;
-            else _pending_out += sl.n_out;
-            ++_q_count;
+            else if (!_batching) _pending_out += sl.n_out;
             held_lent = held_reserved = 0; // (the slot owns the spans from here on)
             launch_pending(1);             // the chunk before this one: its kernels go out while this chunk's copy is on the link
+            if (_batching && sl.n_in >= batch_items) launch_pending(0); // a full batch does not wait for the next piece
             return {requested, n, work::Status::OK};
         } catch (const std::exception& e) {
             std::cerr << "[gr::hip] device run failed: " << e.what() << "\n";
@@ -1767,17 +1918,23 @@ public:
                 (void)gr4hip_stream_synchronize(_s_in);
                 (void)gr4hip_stream_synchronize(_s_k);
                 (void)gr4hip_stream_synchronize(_s_out);
-                if (held_lent) _in_edge->unlend_items(held_lent);
+                if (held_lent) {
+                    if (!_lent.empty() && _lent.back().n == held_lent && _lent.back().seq + 1 == _next_seq) { _ev_free.push_back(_lent.back().ev); _lent.pop_back(); } // (the piece of the call that failed)
+                    _in_edge->unlend_items(held_lent);
+                }
                 if (held_reserved) _out_edge->unreserve_items(held_reserved);
-                while (_q_count && !_slots[(_q_head + _q_count - 1) % kDepth].launched) { // ingested chunks whose launch failed (or never happened): the newest entries of the queue
+                // ingested chunks whose launch failed (or never happened) are the newest entries of the queue.  A chunk-per-slot run hands their spans back (newest first) and
+                // forgets them; a batching run has given the spans back already -- the samples are in the device ring: the chunk stays queued and is launched again by the next call
+                while (!_batching && _q_count && !_slots[(_q_head + _q_count - 1) % kDepth].launched) {
                     Slot& sl = _slots[(_q_head + _q_count - 1) % kDepth];
-                    if (sl.n_lent) { _in_edge->unlend_items(sl.n_lent); sl.n_lent = 0; }
+                    while (!_lent.empty() && _lent.back().seq == sl.seq) { _in_edge->unlend_items(_lent.back().n); _ev_free.push_back(_lent.back().ev); _lent.pop_back(); }
                     if (sl.direct) _out_edge->unreserve_items(sl.n_out);
                     else _pending_out -= std::min(_pending_out, sl.n_out);
                     sl.direct = nullptr;
                     sl.busy   = false;
                     sl.fwd.clear();
                     --_q_count;
+                    _ring_wr = static_cast<std::size_t>(static_cast<const char*>(sl.d_src) - static_cast<const char*>(_ring_base)) % _ring_bytes; // (the ring takes the next chunk where this one began)
                 }
             }
             return {requested, 0, work::Status::ERROR};

@@ -193,7 +193,7 @@ int main(int argc, char** argv) {
         const bool same   = staged.size() == 96 * N && in_place == staged;
         std::printf("page-locked edges: %zu launches, %zu chunks read in place, %zu written in place, %zu overlapped, output %s the staged run\n", launches, inplace, direct, overlapped,
                     same ? "equals" : "DIFFERS from");
-        if (!same || launches < 2 || inplace != launches || direct != launches) ++errors; // (chunks this small finish before the next one is queued: overlap is bench_host_feed's subject)
+        if (!same || launches < 1 || inplace < launches || direct < launches) ++errors; // (round 6: edges this small are gathered in the device ring -- several pieces read and written in place per launch)
     }
     { // 3b'. a tee'd device edge: fir.out feeds the spectrum block AND a host sink -> the planner must not fuse across it (the filtered samples have to
       //      reach the host edge); both readers see every sample
