@@ -55,6 +55,7 @@ SIGNATURES = {
     "gr4hip_stream_create": (_i, [_pvp]),
     "gr4hip_stream_destroy": (_i, [_vp]),
     "gr4hip_stream_synchronize": (_i, [_vp]),
+    "gr4hip_stream_query": (_i, [_vp, C.POINTER(C.c_int)]),
     "gr4hip_event_create": (_i, [_pvp]),
     "gr4hip_event_destroy": (_i, [_vp]),
     "gr4hip_event_record": (_i, [_vp, _vp]),

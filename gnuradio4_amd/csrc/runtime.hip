@@ -183,6 +183,14 @@ int gr4hip_memset(void* d, int v, size_t bytes, gr4hip_stream_t s) { if (bytes) 
 int gr4hip_stream_create(gr4hip_stream_t* s) { GR4_REQUIRE(s, "stream is null"); hipStream_t st; GR4_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); *s = st; return GR4HIP_OK; }
 int gr4hip_stream_destroy(gr4hip_stream_t s) { if (s) GR4_HIP_TRY(hipStreamDestroy(as_stream(s))); return GR4HIP_OK; }
 int gr4hip_stream_synchronize(gr4hip_stream_t s) { GR4_HIP_TRY(hipStreamSynchronize(as_stream(s))); return GR4HIP_OK; }
+int gr4hip_stream_query(gr4hip_stream_t s, int* idle) {
+    GR4_REQUIRE(idle, "idle is null");
+    hipError_t e = hipStreamQuery(as_stream(s));
+    if (e == hipSuccess) { *idle = 1; return GR4HIP_OK; }
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); *idle = 0; return GR4HIP_OK; }
+    set_error("hipStreamQuery failed: %s", hipGetErrorString(e));
+    return GR4HIP_RUNTIME_ERROR;
+}
 int gr4hip_event_create(gr4hip_event_t* ev) { GR4_REQUIRE(ev, "ev is null"); hipEvent_t e; GR4_HIP_TRY(hipEventCreate(&e)); *ev = e; return GR4HIP_OK; }
 int gr4hip_event_destroy(gr4hip_event_t ev) { if (ev) GR4_HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return GR4HIP_OK; }
 int gr4hip_event_record(gr4hip_event_t ev, gr4hip_stream_t s) { GR4_HIP_TRY(hipEventRecord((hipEvent_t)ev, as_stream(s))); return GR4HIP_OK; }

@@ -1465,16 +1465,22 @@ class DeviceRun final : public BlockModel {
     // chunk c - 1 run beside the kernels of chunk c.  work() only queues; a chunk's output is published -- and the cursors move -- when its last
     // event has fired (Block.hpp:1989-2026: publish after the work is done), in queue order.
     gr4hip_stream_t _s_in = nullptr, _s_k = nullptr, _s_out = nullptr;
+    // a batching run alternates its pieces between two copy streams per direction: a copy of a few hundred KB costs the engine ~10 us of fixed time whatever its size
+    // (measured: 256 KiB pieces back to back on ONE stream 14.2 us each = 18.6 GB/s, tools/dbg/api_costs.py) -- two in flight hide it
+    gr4hip_stream_t _s_in2 = nullptr, _s_out2 = nullptr;
+    std::size_t     _piece_no = 0, _opiece_no = 0;
     static constexpr std::size_t kDepth = 3;
     struct Slot {
         DevBuf         h_in{true}, h_out{true}, d_out;
-        gr4hip_event_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
+        gr4hip_event_t in_done = nullptr, k_done = nullptr, out_done = nullptr, in_done2 = nullptr, out_done2 = nullptr;
         std::size_t    n_out = 0;
         std::size_t    seq = 0;               // position of the chunk in the stream of chunks (the lent pieces name their chunk by it)
         void*          direct = nullptr;      // the result copy lands in the output edge's own (page-locked) storage: published in place
         bool           piecewise = false;     // a batching run's chunk: its result leaves in pieces (retire_pieces)
         const void*    d_res = nullptr;       // ... from here (the last stage's output), out_off items of it published so far,
-        std::size_t    out_off = 0, piece_n = 0; // piece_n items on their way into the output edge's storage
+        std::size_t    out_off = 0, q_off = 0;   // q_off: items queued for their copy so far (published + on their way)
+        std::size_t    piece_n[2] = {0, 0};      // up to two pieces on their way into the output edge's storage, oldest first ...
+        int            piece_s[2] = {0, 0}, pieces = 0; // ... and the result stream each is on
         bool           staged = false, copied = false; // the whole result is (on its way) in h_out; its copy has landed
         bool           busy = false;
         bool           launched = false;      // false: the chunk's samples are on their way into the ring (or there), its kernels are not queued yet
@@ -1483,14 +1489,14 @@ class DeviceRun final : public BlockModel {
         property_map   fwd; // tags to publish at the first output sample of this chunk
     };
     std::array<Slot, kDepth> _slots;
-    struct Piece { gr4hip_event_t ev; std::size_t n; std::size_t seq; }; // an input span the copy engine is reading in the edge's own storage: ev fires when it has landed
+    struct Piece { gr4hip_event_t ev; std::size_t n; std::size_t seq; gr4hip_stream_t st = nullptr; }; // an input span the copy engine is reading in the edge's own storage: it has landed when ev has fired -- or (a batching run: no event, a record costs 2.7 us) when its copy stream is idle
     std::deque<Piece>           _lent;
     std::vector<gr4hip_event_t> _ev_free, _ev_all;
     std::size_t                 _next_seq = 0, _launched_seq = 0; // chunks numbered in queue order; every chunk below _launched_seq has its kernels queued
     // batching: an input edge that holds less than a launch is worth -- the reference's default 65 536 items (Graph.hpp:102) -- is drained piece by piece
     // into the device ring and the kernels are launched over ~2^20 items at a time; the result leaves piece by piece as the output edge takes it
     bool                        _batching = false;
-    std::size_t                 _batch_items = std::size_t(1) << 20;
+    std::size_t                 _batch_items = std::size_t(1) << 21;
     std::size_t     _inplace_chunks = 0, _direct_chunks = 0; // chunks copied straight out of a page-locked input edge / straight into a page-locked output edge
     std::size_t     _q_head = 0, _q_count = 0, _pending_out = 0, _overlapped = 0; // FIFO of busy slots; output items not yet published; chunks queued while another was in flight
     DevBuf          _d_a, _d_b;
@@ -1523,9 +1529,9 @@ public:
         for (auto& s : _stages) _desc += std::string(_desc.empty() ? "" : " -> ") + std::string(s->kind());
         recompute_rates();
         check(gr4hip_set_device(_domain.index), "gr4hip_set_device");
-        for (gr4hip_stream_t* st : {&_s_in, &_s_k, &_s_out}) check(gr4hip_stream_create(st), "gr4hip_stream_create");
+        for (gr4hip_stream_t* st : {&_s_in, &_s_k, &_s_out, &_s_in2, &_s_out2}) check(gr4hip_stream_create(st), "gr4hip_stream_create");
         for (auto& sl : _slots)
-            for (gr4hip_event_t* ev : {&sl.in_done, &sl.k_done, &sl.out_done}) check(gr4hip_event_create(ev), "gr4hip_event_create");
+            for (gr4hip_event_t* ev : {&sl.in_done, &sl.k_done, &sl.out_done, &sl.in_done2, &sl.out_done2}) check(gr4hip_event_create(ev), "gr4hip_event_create");
         // GPU-resident double-mapped input ring: kDepth + 1 chunks.  A chunk is a quarter of what the input edge holds (so that the source refills the edge while
         // chunks are in flight), between 2^21 and 2^23 items: fewer, larger copies and launches per sample
         const std::size_t chunk_items = in->memory() == pinned_resource() ? std::clamp<std::size_t>(in->capacity_items() / 4, std::size_t(1) << 21, std::size_t(1) << 23) : std::size_t(1) << 21; // (edges that are staged by host copies overlap better in small chunks)
@@ -1533,18 +1539,18 @@ public:
         check(gr4hip_ring_base(_ring, &_ring_base), "ring base");
         check(gr4hip_ring_size(_ring, &_ring_bytes), "ring size");
         _batch_items = std::min(_batch_items, chunk_items);
-        _batching    = in->capacity_items() > 0 && in->capacity_items() < _batch_items && options().batch_small_edges;
+        _batching    = in->capacity_items() > 0 && in->capacity_items() <= _batch_items && options().batch_small_edges;
     }
     ~DeviceRun() override {
-        for (gr4hip_stream_t st : {_s_in, _s_k, _s_out})
+        for (gr4hip_stream_t st : {_s_in, _s_in2, _s_k, _s_out, _s_out2})
             if (st) gr4hip_stream_synchronize(st); // nothing may be in flight when the stages and buffers go
         _stages.clear();
         for (auto& sl : _slots)
-            for (gr4hip_event_t ev : {sl.in_done, sl.k_done, sl.out_done})
+            for (gr4hip_event_t ev : {sl.in_done, sl.k_done, sl.out_done, sl.in_done2, sl.out_done2})
                 if (ev) gr4hip_event_destroy(ev);
         for (gr4hip_event_t ev : _ev_all) gr4hip_event_destroy(ev);
         if (_ring) gr4hip_ring_destroy(_ring);
-        for (gr4hip_stream_t st : {_s_in, _s_k, _s_out})
+        for (gr4hip_stream_t st : {_s_in, _s_in2, _s_k, _s_out, _s_out2})
             if (st) gr4hip_stream_destroy(st);
     }
     [[nodiscard]] std::size_t overlapped_chunks() const { return _overlapped; }
@@ -1554,13 +1560,20 @@ public:
     // its chunk's kernels are queued (a chunk whose launch fails goes back to the edge whole); a batching run (below) gives it back as soon as the copy has landed:
     // the edge is smaller than the batch, the samples wait for their launch in the device ring
     [[nodiscard]] bool releasable(const Piece& pc) const { return _batching || pc.seq < _launched_seq; }
+    bool piece_landed(const Piece& pc, bool wait) {
+        if (wait) { check(pc.ev ? gr4hip_event_synchronize(pc.ev) : gr4hip_stream_synchronize(pc.st), "sync"); return true; }
+        int done = 0;
+        check(pc.ev ? gr4hip_event_query(pc.ev, &done) : gr4hip_stream_query(pc.st, &done), "query");
+        return done != 0;
+    }
+    void piece_gone(const Piece& pc) { if (pc.ev) _ev_free.push_back(pc.ev); }
     // the oldest piece still lent: wait for its copy and give it back; returns the items released (0: nothing that may go back is lent)
     std::size_t release_oldest_input() {
         if (_lent.empty() || !releasable(_lent.front())) return 0;
         const Piece pc = _lent.front();
-        check(gr4hip_event_synchronize(pc.ev), "event sync");
+        piece_landed(pc, true);
         _in_edge->consume_items(pc.n);
-        _ev_free.push_back(pc.ev);
+        piece_gone(pc);
         _lent.pop_front();
         return pc.n;
     }
@@ -1570,14 +1583,9 @@ public:
         if (wait) launch_pending(0); // (everything lent is to go back: the chunks that hold spans run first)
         while (!_lent.empty() && releasable(_lent.front())) {
             const Piece pc = _lent.front();
-            if (wait) check(gr4hip_event_synchronize(pc.ev), "event sync");
-            else {
-                int done = 0;
-                check(gr4hip_event_query(pc.ev, &done), "event query");
-                if (!done) return freed;
-            }
+            if (!piece_landed(pc, wait)) return freed;
             _in_edge->consume_items(pc.n);
-            _ev_free.push_back(pc.ev);
+            piece_gone(pc);
             _lent.pop_front();
             freed += pc.n;
         }
@@ -1612,7 +1620,12 @@ public:
     // chunk c + 1 BEFORE it launches chunk c, so that the link stays busy while a stage's enqueue is busy.  A batching run's result goes out piece by piece (retire):
     // only the wait for the kernels is queued on the result stream here
     void launch(Slot& sl) {
-        check(gr4hip_stream_wait_event(_s_k, sl.in_done), "stream wait"); // (in_done: recorded behind the chunk's LAST piece)
+        if (sl.piecewise) { // a batch: its pieces went over both copy streams; the events go behind the newest piece of each (pieces of the NEXT batch may sit in front of them: small)
+            check(gr4hip_event_record(sl.in_done, _s_in), "event record");
+            check(gr4hip_event_record(sl.in_done2, _s_in2), "event record");
+            check(gr4hip_stream_wait_event(_s_k, sl.in_done2), "stream wait");
+        }
+        check(gr4hip_stream_wait_event(_s_k, sl.in_done), "stream wait");
         const void* cur = sl.d_src;
         std::size_t cnt = sl.n_in;
         for (std::size_t i = 0; i < _stages.size(); ++i) { // stages run back-to-back on the kernel stream; intermediates stay in HBM
@@ -1628,6 +1641,7 @@ public:
         if (cnt != sl.n_out) throw std::runtime_error("device run: a chunk produced an unexpected number of samples");
         check(gr4hip_event_record(sl.k_done, _s_k), "event record");
         check(gr4hip_stream_wait_event(_s_out, sl.k_done), "stream wait");
+        if (sl.piecewise) check(gr4hip_stream_wait_event(_s_out2, sl.k_done), "stream wait");
         sl.d_res = cur;
         if (!sl.piecewise || _out_edge->memory() != pinned_resource()) { // the whole result in one copy: into the reserved span of a page-locked edge, or into the slot's own page-locked buffer
             check(gr4hip_memcpy_d2h(sl.direct ? sl.direct : sl.h_out.ensure(cnt * _out_bytes), cur, cnt * _out_bytes, _s_out), "d2h");
@@ -1647,7 +1661,8 @@ public:
     void finish_slot(Slot& sl) {
         sl.direct = nullptr;
         sl.busy = sl.launched = sl.staged = false;
-        sl.out_off = sl.piece_n = 0;
+        sl.out_off = sl.q_off = 0;
+        sl.pieces = 0;
         sl.fwd.clear();
         _q_head = (_q_head + 1) % kDepth;
         --_q_count;
@@ -1658,41 +1673,61 @@ public:
     std::size_t retire_pieces(Slot& sl, bool only_if_done) {
         std::size_t       pub  = 0;
         const bool        pin  = _out_edge->memory() == pinned_resource();
-        const std::size_t half = std::max<std::size_t>(_out_edge->capacity_items() / 2, 1);
+        static const int opiece_div = [] { const char* e = std::getenv("GR4HIP_RUN_OPIECE_DIV"); return e ? std::max(1, std::atoi(e)) : 1; }(); // developer knob (2: half the edge per piece -- measured slower at every edge size: the copy engine spends ~10 us per operation whatever its size, one operation at a time per direction)
+        const std::size_t half = std::max<std::size_t>(_out_edge->capacity_items() / opiece_div, 1);
+        const auto landed = [&](gr4hip_event_t ev) {
+            if (!only_if_done) { check(gr4hip_event_synchronize(ev), "event sync"); return true; }
+            int done = 0;
+            check(gr4hip_event_query(ev, &done), "event query");
+            return done != 0;
+        };
+        const auto idle = [&](gr4hip_stream_t st) { // a piece has landed when the result stream it is on has nothing left to do (one piece per stream in flight)
+            if (!only_if_done) { check(gr4hip_stream_synchronize(st), "stream sync"); return true; }
+            int done = 0;
+            check(gr4hip_stream_query(st, &done), "stream query");
+            return done != 0;
+        };
         for (;;) {
-            if (sl.piece_n || (sl.staged && sl.out_off == 0 && !sl.copied)) { // a copy in flight: the piece (page-locked edge) or the whole result (staging buffer)
-                if (only_if_done) {
-                    int done = 0;
-                    check(gr4hip_event_query(sl.out_done, &done), "event query");
-                    if (!done) return pub;
-                } else {
-                    check(gr4hip_event_synchronize(sl.out_done), "event sync");
-                }
+            if (sl.staged && !sl.copied) { // the whole result on its way into the slot's staging buffer
+                if (!landed(sl.out_done)) return pub;
                 sl.copied = true;
-                if (sl.piece_n) {
-                    if (sl.out_off == 0 && !sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
-                    _out_edge->publish_reserved(sl.piece_n);
-                    sl.out_off += sl.piece_n;
-                    pub += sl.piece_n;
-                    sl.piece_n = 0;
-                }
+            }
+            while (sl.pieces) { // pieces that have landed appear on the edge, in order
+                if (!idle(sl.piece_s[0] ? _s_out2 : _s_out)) break;
+                if (sl.out_off == 0 && !sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
+                _out_edge->publish_reserved(sl.piece_n[0]);
+                sl.out_off += sl.piece_n[0];
+                pub += sl.piece_n[0];
+                sl.piece_n[0] = sl.piece_n[1]; sl.piece_s[0] = sl.piece_s[1];
+                --sl.pieces;
             }
             if (sl.out_off == sl.n_out) { finish_slot(sl); return pub; }
-            std::size_t n = std::min({sl.n_out - sl.out_off, half, _out_edge->free_items()});
-            if (n == 0) return pub; // the edge is full: the sink's turn
+            bool queued = false;
             if (pin) {
-                void* dst = _out_edge->reserve_items(n);
-                if (!dst) return pub;
-                check(gr4hip_memcpy_d2h(dst, static_cast<const char*>(sl.d_res) + sl.out_off * _out_bytes, n * _out_bytes, _s_out), "d2h");
-                check(gr4hip_event_record(sl.out_done, _s_out), "event record");
-                sl.piece_n = n;
-                ++_direct_chunks;
+                while (sl.pieces < 2 && sl.q_off < sl.n_out) {
+                    if (sl.pieces == 1 && sl.piece_s[0] == (int)(_opiece_no & 1)) ++_opiece_no; // (the stream the piece in flight is NOT on: one piece per stream)
+                    const std::size_t n = std::min({sl.n_out - sl.q_off, half, _out_edge->free_items()});
+                    void* dst = n ? _out_edge->reserve_items(n) : nullptr;
+                    if (!dst) break; // the edge is full: the sink's turn
+                    const int which = (int)(_opiece_no++ & 1);
+                    check(gr4hip_memcpy_d2h(dst, static_cast<const char*>(sl.d_res) + sl.q_off * _out_bytes, n * _out_bytes, which ? _s_out2 : _s_out), "d2h");
+                    sl.piece_n[sl.pieces] = n; sl.piece_s[sl.pieces] = which;
+                    ++sl.pieces;
+                    sl.q_off += n;
+                    ++_direct_chunks;
+                    queued = true;
+                }
             } else {
-                if (sl.out_off == 0 && !sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
-                _write(static_cast<const char*>(sl.h_out.p) + sl.out_off * _out_bytes, n);
-                sl.out_off += n;
-                pub += n;
+                const std::size_t n = std::min(sl.n_out - sl.out_off, _out_edge->free_items());
+                if (n) {
+                    if (sl.out_off == 0 && !sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
+                    _write(static_cast<const char*>(sl.h_out.p) + sl.out_off * _out_bytes, n);
+                    sl.out_off += n; sl.q_off = sl.out_off;
+                    pub += n;
+                    if (sl.out_off == sl.n_out) { finish_slot(sl); return pub; }
+                }
             }
+            if (only_if_done || (!sl.pieces && !queued)) return pub; // nothing more can happen without the sink (or without waiting)
         }
     }
 
@@ -1714,7 +1749,7 @@ public:
         }
         while (!_lent.empty() && _lent.front().seq <= sl.seq) { // the result has landed, so has the input (slots retire oldest first)
             _in_edge->consume_items(_lent.front().n);
-            _ev_free.push_back(_lent.front().ev);
+            piece_gone(_lent.front());
             _lent.pop_front();
         }
         if (!sl.fwd.empty()) { _out_edge->publishTag(sl.fwd, 0); ++_tags_forwarded; }
@@ -1802,7 +1837,8 @@ public:
             n = std::min(n, std::max(_in_edge->samplesUntilNextTag(), _in_chunk)); // a launch ends where the next tag starts (Block.hpp:1511-1530): tags sit on launch boundaries
             if (_batching) {
                 // half the edge per piece: the source refills one half while the copy engine reads the other
-                if (_in_edge->capacity_items() / 2 >= _in_chunk) n = std::min(n, _in_edge->capacity_items() / 2);
+                static const int piece_div = [] { const char* e = std::getenv("GR4HIP_RUN_PIECE_DIV"); return e ? std::max(1, std::atoi(e)) : 1; }(); // developer knob (2: half the edge per piece -- measured slower at every edge size: the copy engine spends ~10 us per operation whatever its size, one operation at a time per direction)
+                if (_in_edge->capacity_items() / piece_div >= _in_chunk) n = std::min(n, _in_edge->capacity_items() / piece_div);
                 n = n / _in_chunk * _in_chunk;
             } else {
                 const std::size_t space = _space() - std::min(_space(), _pending_out);  // the output edge minus what queued chunks will publish (reserved spans are already off it)
@@ -1860,10 +1896,14 @@ public:
             const void* lent = _in_edge->lend_items(n);
             if (lent) held_lent = n;
             if (lent && _in_edge->memory() == pinned_resource()) { // page-locked storage ("hip" provider): the copy engine reads the edge in place;
-                check(gr4hip_memcpy_h2d(d_in, lent, n * _in_bytes, _s_in), "h2d"); // the span goes back to the edge once the copy has landed (release_inputs)
-                gr4hip_event_t ev = piece_event();
-                check(gr4hip_event_record(ev, _s_in), "event record");
-                _lent.push_back({ev, n, sl.seq});
+                gr4hip_stream_t sin = _batching && (_piece_no++ & 1) ? _s_in2 : _s_in;
+                check(gr4hip_memcpy_h2d(d_in, lent, n * _in_bytes, sin), "h2d"); // the span goes back to the edge once the copy has landed (release_inputs)
+                if (_batching) _lent.push_back({nullptr, n, sl.seq, sin});
+                else {
+                    gr4hip_event_t ev = piece_event();
+                    check(gr4hip_event_record(ev, sin), "event record");
+                    _lent.push_back({ev, n, sl.seq});
+                }
                 ++_inplace_chunks;
             } else {
                 // pageable edge: staged through page-locked memory (the copy threads share a large piece).  A chunk-per-slot run keeps the span lent until the chunk is launched,
@@ -1885,7 +1925,7 @@ public:
                 }
                 if (stage) check(gr4hip_memcpy_h2d(d_in, stage, n * _in_bytes, _s_in), "h2d");
             }
-            check(gr4hip_event_record(sl.in_done, _s_in), "event record"); // (behind the chunk's newest piece: what the kernel stream waits for)
+            if (!_batching) check(gr4hip_event_record(sl.in_done, _s_in), "event record"); // what the kernel stream waits for (a batch: recorded when it is launched, behind its last piece)
             _ring_wr = (_ring_wr + n * _in_bytes) % _ring_bytes;
             if (fresh) {
                 sl.d_src     = d_in;
@@ -1893,7 +1933,8 @@ public:
                 sl.busy      = true;
                 sl.launched  = false;
                 sl.staged = sl.copied = false;
-                sl.out_off = sl.piece_n = 0;
+                sl.out_off = sl.q_off = 0;
+                sl.pieces    = 0;
                 sl.piecewise = _batching;
                 sl.direct    = direct;
                 sl.fwd       = std::move(fwd);
@@ -1915,11 +1956,9 @@ public:
             bool unlaunched = false;
             for (std::size_t i = 0; i < _q_count; ++i) unlaunched = unlaunched || !_slots[(_q_head + i) % kDepth].launched;
             if (held_lent || held_reserved || unlaunched) {
-                (void)gr4hip_stream_synchronize(_s_in);
-                (void)gr4hip_stream_synchronize(_s_k);
-                (void)gr4hip_stream_synchronize(_s_out);
+                for (gr4hip_stream_t st : {_s_in, _s_in2, _s_k, _s_out, _s_out2}) (void)gr4hip_stream_synchronize(st);
                 if (held_lent) {
-                    if (!_lent.empty() && _lent.back().n == held_lent && _lent.back().seq + 1 == _next_seq) { _ev_free.push_back(_lent.back().ev); _lent.pop_back(); } // (the piece of the call that failed)
+                    if (!_lent.empty() && _lent.back().n == held_lent && _lent.back().seq + 1 == _next_seq) { piece_gone(_lent.back()); _lent.pop_back(); } // (the piece of the call that failed)
                     _in_edge->unlend_items(held_lent);
                 }
                 if (held_reserved) _out_edge->unreserve_items(held_reserved);
@@ -1927,7 +1966,7 @@ public:
                 // forgets them; a batching run has given the spans back already -- the samples are in the device ring: the chunk stays queued and is launched again by the next call
                 while (!_batching && _q_count && !_slots[(_q_head + _q_count - 1) % kDepth].launched) {
                     Slot& sl = _slots[(_q_head + _q_count - 1) % kDepth];
-                    while (!_lent.empty() && _lent.back().seq == sl.seq) { _in_edge->unlend_items(_lent.back().n); _ev_free.push_back(_lent.back().ev); _lent.pop_back(); }
+                    while (!_lent.empty() && _lent.back().seq == sl.seq) { _in_edge->unlend_items(_lent.back().n); piece_gone(_lent.back()); _lent.pop_back(); }
                     if (sl.direct) _out_edge->unreserve_items(sl.n_out);
                     else _pending_out -= std::min(_pending_out, sl.n_out);
                     sl.direct = nullptr;

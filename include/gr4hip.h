@@ -144,6 +144,7 @@ int gr4hip_memset(void* d_dst, int value, size_t bytes, gr4hip_stream_t stream);
 int gr4hip_stream_create(gr4hip_stream_t* stream);
 int gr4hip_stream_destroy(gr4hip_stream_t stream);
 int gr4hip_stream_synchronize(gr4hip_stream_t stream);
+int gr4hip_stream_query(gr4hip_stream_t stream, int* idle); /* *idle = 1: everything queued on the stream has finished (hipStreamQuery; never waits) -- one call instead of an event record + query per copy for a caller that keeps one copy in flight per stream (gr::hip::DeviceRun's pieces) */
 int gr4hip_event_create(gr4hip_event_t* ev);
 int gr4hip_event_destroy(gr4hip_event_t ev);
 int gr4hip_event_record(gr4hip_event_t ev, gr4hip_stream_t stream);

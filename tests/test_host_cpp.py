@@ -250,7 +250,7 @@ def test_device_graphs_match_oracle(host_bins, tmp_path, N, ntaps):
     assert len(got) == 256 * 24 and rel(got, want) <= 1e-5
     assert "merge IIR low-pass (SplitMergeCombine feedback) on the device: stage 'iir_f32'" in r.stdout
     assert "SplitMergeCombine on the device: stage 'split(fir_f32 | math_const)'" in r.stdout
-    assert "pipelined run:" in r.stdout and "pipelined run: 0 of" not in r.stdout  # copies and kernels of neighbouring chunks overlap
+    assert "pipelined run:" in r.stdout  # (round 6: default-size edges are gathered in the device ring -- this short stream is ONE launch; the overlap of copies and kernels is bench_host_feed's subject)
     # tags through a fused device run
     assert "tags through the device run: 2 forwarded, 1 stage rebuilt" in r.stdout
     assert "tags: device run forwarded {0: 250 Hz, 10000: 250 Hz + gr:value}, host graph the same" in r.stdout
