@@ -16,9 +16,12 @@ lines = []
 db = sqlite3.connect(os.path.join(src, "trace_results.db"))
 rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
 lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (round tag {tag}; durations in microseconds)")
-lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'%':>6}  kernel")
+lines.append("# median_us is the figure to read: avg_us mixes dispatches of different launch sizes (the guard row's short launches, the 2^28-sample counter passes) into one mean (VERDICT r05)")
+lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'median_us':>10} {'%':>6}  kernel")
 for name, calls, total, avg, pct in rows:
-    lines.append(f"{calls:7d} {total:12.1f} {avg:10.2f} {pct:6.2f}  {name}")
+    ds = sorted((e - b) / 1e3 for b, e in db.execute("select start, end from kernels where name = ?", (name,)).fetchall())
+    med = ds[len(ds) // 2] if ds else float("nan")
+    lines.append(f"{calls:7d} {total:12.1f} {avg:10.2f} {med:10.2f} {pct:6.2f}  {name[:150]}")
 durs = [(e - b) / 1e3 for b, e in db.execute("select start, end from kernels where name like ? order by start", (f"%{match}%",)).fetchall()]
 if durs:
     sd = sorted(durs)
