@@ -5,13 +5,15 @@
 // GR4HIP_CHAIN_FUSED_TD (chain_td.hip): one launch, direct-form filter on the matrix pipe + one transform per frame, fft_size 256...4096, <= 256 taps;
 //   AUTO picks it for <= 64 taps (faster than the fast convolution there).  The dynamic-range guard sends a stream to the kernel pair with float32 products.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace gr4 {
 int chain_fused_supported(size_t ntaps, size_t fft_size, int window, int algo);
 struct ChainFused;
 int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
 int  chain_fused_reset(ChainFused* c);
-int  chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st);
+int  chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st, bool td = false); // td: every frame in the time domain (chain_td16_kernel + float64 behind it)
+bool chain_fused_has_td(const ChainFused* c);
 int  chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps, const float* const* d_in, size_t n_frames, float* const* d_out, float* d_sum, hipStream_t st, bool redo);
 bool chain_fused_multi_capable(const ChainFused* c);
 void chain_fused_destroy(ChainFused* c);
@@ -66,6 +68,7 @@ struct gr4hip_chain {
     // read the finished measurements of earlier ones without waiting.  Below the threshold the handle switches to the direct-form kernels (the
     // reference's own arithmetic) from the call that finds out onwards, until reset.
     bool            guard = false, probed = false, use_td = false;
+    bool            td_fused = false;  // use_td: the fused handle's own time-domain form (chain_td16_kernel + float64 behind it, round 6) instead of the kernel pair
     int             guard_mode = GR4HIP_GUARD_STRICT;
     float           last_ratio = -1.f; // most recent measured power ratio (< 0: none yet)
     DeviceBuffer    d_hist_save;
@@ -120,7 +123,7 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
 
 int gr4hip_chain_reset(gr4hip_chain_t* c) {
     GR4_REQUIRE(c, "chain_reset: null handle");
-    c->probed = c->use_td = false;
+    c->probed = c->use_td = c->td_fused = false;
     c->last_ratio = -1.f;
     if (c->fused && c->fir) { int rc = gr4hip_fir_reset(c->fir); if (rc) return rc; }
     if (c->td) { int rc = chain_td_reset(c->td); if (rc || !c->fused) return rc; }
@@ -149,6 +152,7 @@ static int chain_td_run(gr4hip_chain* c, const void* d_in, size_t frames, float*
 // Gsamples/s at 256 taps, 167 instead of 179 at 64: two grids that each fill the chip take turns anyway, and the extra launches cost.)
 static int chain_time_domain(gr4hip_chain* c, const void* d_in, size_t frames, float* d_mag2, gr4hip_stream_t stream) {
     if (c->td) return chain_td_run(c, d_in, frames, d_mag2, stream); // one launch where the size allows
+    if (c->td_fused) return chain_fused_process(c->fused, static_cast<const float*>(d_in), frames, d_mag2, as_stream(stream), true); // filter -> window -> transform in one kernel, frame by frame
     const size_t n  = frames * c->N;
     int          rc = c->d_y.ensure(n * 2 * sizeof(float));
     if (rc) return rc;
@@ -162,6 +166,17 @@ static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, 
     std::vector<float>& taps = c->taps;
     int rc = GR4HIP_OK;
     if (!d_hist256) return GR4HIP_RUNTIME_ERROR; // (chain_fused_history could not enqueue the pending reset: the error text is set)
+    // round 6: the fused handle has the chain in the time domain itself (chain_td16_kernel: the filter on the f16 matrix pipe, the window and ONE transform per frame from LDS,
+    // float64 behind it for the frames that are beyond 22-bit products): no intermediate stream in HBM, the same arithmetic as the frames a fused launch marks.
+    // Measured (profiles/r06_chain_td16.txt): as the destination of a WHOLE stream the one kernel runs 135 / 124 Gsamples/s (rectangular / Hann) where the kernel pair -- the same
+    // filter arithmetic with two workgroups per CU interleaving their staging and their products, then the FFT kernel -- runs 141 - 150 / 137 - 149, so the pair stays the
+    // destination and the one-kernel form is a developer switch; where it pays is behind a fused launch, on the frames that launch marks (chain_fused.hip: 31 -> 85 Gsamples/s)
+    static const bool fused_td = std::getenv("GR4HIP_CHAIN_TD_FUSED") != nullptr;
+    if (c->fused && !c->td && fused_td && chain_fused_has_td(c->fused)) {
+        if (d_hist256 != chain_fused_history(c->fused, st)) { if (const int rc2 = chain_fused_set_history(c->fused, d_hist256, st)) return rc2; }
+        c->td_fused = c->use_td = true;
+        return GR4HIP_OK;
+    }
     // the kernel pair with float32 products (GR4HIP_FIR_TIME_DOMAIN_F32), at every fft size: the regime that trips the guard -- a rejected signal far above the
     // output -- is the one in which the three-term bf16 products of chain_td_kernel / the split-product direct forms measure 3 .. 16 x a float32 sum's error.
     // (Round 4 tried the two-term f16 direct form here, whose own guard redoes the segments that reject more than 36 dB of their power: the pair went from 97 to

@@ -408,7 +408,7 @@ int chain16_run(Chain16* c, const float* d_in, const float* d_hist256, size_t n_
 #ifdef GR4_C16_TIMING
 extern "C" int gr4hip_dbg_c16_timing(unsigned long long* h_out, size_t n_frames) { // developer-only, not part of the ABI
     if (!gr4::g_dbg16) return GR4HIP_ERROR;
-    hip_quiet(hipDeviceSynchronize());
+    gr4::hip_quiet(hipDeviceSynchronize());
     return hipMemcpy(h_out, gr4::g_dbg16, n_frames * 16 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? GR4HIP_OK : GR4HIP_RUNTIME_ERROR;
 }
 #endif

@@ -34,6 +34,7 @@
 #include "common.hpp"
 #include "buffer_ops.hpp"
 #include "fft_radix.hpp"
+#include "fir_f16_common.hpp"
 
 #include <cmath>
 #include <complex>
@@ -82,6 +83,10 @@ struct ChainFdArgs {
     int            redo_hist_len; // samples `hist` holds in front of x (0: 256)
     int            redo_flags_per_block; // flag bytes per 8192-sample block (0: 1; the fused time-domain kernel judges 4096-sample segments: 2)
     long           redo_n;        // samples of the span (0: n_frames whole blocks); a partial last block reads zeros behind it and writes only what the span holds
+    int            redo_min_flag; // chain_redo_kernel takes the blocks whose flag byte is >= this (0: any marked block).  2: chain_td16_kernel has been over the marked frames
+                                  // first and left a 2 on the ones whose filter output lies too far below their input for its 22-bit products
+    const unsigned short* hfrag;  // chain_td16_kernel: the filter's two-term f16 tap table (fir_f16_make_afrag at KS = 9: fragments + {1 / t, ntaps, sum b^2 / 128, -} + the taps)
+    float          td16_thr;      // ... and the fraction of (sum b^2) x the staged input power below which a frame's filter output is left to the float64 evaluation
     unsigned long long* dbg; // GR4_FD_TIMING only
 };
 // several channels in ONE launch (gr4hip_chain_process_multi, kModeMag2 only).  fold_ch > 1: every workgroup takes frame f of ALL channels in turn (same taps:
@@ -94,6 +99,8 @@ struct ChainFdArgs {
 constexpr int   kLdsEbfBytes = (2 * kSLen + 512 + 256) * 8 + 4 * 2 * 256 * 4 + 6 * 512 * 2; // LDS of the non-windowed filter modes (= lds_ebf of chain_fused_run); the 16 verdict words follow it
 constexpr int   kPwFrameSlots = 40, kPwMaxWorkgroups = 2048; // ChainFdArgs::pw: words 0 .. 35 as before, then two words per workgroup for the frames' verdicts
 constexpr float kGuardFirFrameThreshold = 0.04f; // the FIR-only fast convolution (fir.hip): its output is y itself, not |Y|^2
+constexpr float kTd16GuardRatio = 1.0f / 32.0f; // chain_td16_kernel leaves a frame to the float64 evaluation when its filter output carries less than this x (sum b^2) x its input power: 15 dB below what
+                                                // white noise would pass, where the 22-bit products' error (~1.3e-7 rms of the products' level, its peaks 4 x that) reaches 6e-6 of |Y|^2 (chain.hip kChainPairGuardRatio)
 constexpr float kGuardFrameThreshold = 0.08f; // the guard's output / input power threshold (chain.hip, fir.hip), applied to every frame by itself inside the kernel
 constexpr int kMaxMulti = 16;
 struct ChainFdMulti {
@@ -944,9 +951,10 @@ __device__ __forceinline__ void chain_redo_body(ChainFdArgs& a, int ntaps, const
     auto ph = [](int i) { return i + 4 * (i >> 4); };
     const int  fpb    = a.redo_flags_per_block > 0 ? a.redo_flags_per_block : 1, hlen = a.redo_hist_len > 0 ? a.redo_hist_len : 256;
     const long n_span = a.redo_n > 0 ? a.redo_n : a.n_frames * kN, n_flags = (n_span + kN / fpb - 1) / (kN / fpb);
-    const auto marked = [&](long f) { // any flag byte of block f
+    const int  min_flag = a.redo_min_flag > 0 ? a.redo_min_flag : 1;
+    const auto marked = [&](long f) { // any flag byte of block f (at or above the level this launch answers to)
         int m = 0;
-        for (long b = f * fpb; b < (f + 1) * fpb && b < n_flags; ++b) m |= a.fflags[b];
+        for (long b = f * fpb; b < (f + 1) * fpb && b < n_flags; ++b) m |= (int)(a.fflags[b] >= min_flag);
         return m;
     };
     {   // an ordinary stream marks nothing: every lane looks at its share of this workgroup's flag bytes at once, and the workgroup leaves (measured: a lane that walks its
@@ -1069,6 +1077,293 @@ __device__ __forceinline__ void chain_redo_body(ChainFdArgs& a, int ntaps, const
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// chain_td16_kernel (round 6): the chain in the TIME domain at the headline shape -- <= 256 taps, 8192-sample blocks, any window, fftSize 256 .. 8192 -- for the frames the
+// fused fast convolution has marked (flag byte 1), or for every frame of a stream the guard has moved (the host sets every byte to 1):
+//     y = sum_k b[k] x[n - k] on the f16 matrix pipe (two-term splits under ONE block exponent per frame, three products per tap: fir_f16.hip's arithmetic and tile map,
+//     four 2048-output segments per frame, two per half of the workgroup)  ->  x window  ->  the frame transform of this file from LDS  ->  |.|^2.
+// Its products carry 22 bits: the error is ~1.3e-7 of the PRODUCTS' level sqrt(sum b^2) rms(x) -- relative to the filtered output while the filter passes what white noise
+// would pass, which is exactly the stream the fast convolution (error relative to the INPUT) cannot serve: a narrow channel filter over wide-band noise.  A frame whose
+// filter output lies more than 15 dB below that level (a strong rejected interferer; chain.hip kChainPairGuardRatio) gets flag 2 and is left to chain_redo_kernel's float64
+// products behind this launch, like a frame with a non-finite or absurdly ranged sample.  Until round 6 EVERY marked frame took the float64 evaluation: 31 Gsamples/s on a
+// stream that marks all of them (34 = 45 % of the FP64 matrix pipe's peak).
+constexpr int kT16KS = 9, kT16Kw = 32 * kT16KS, kT16Hb = kT16Kw - 16;                     // window of 288 samples: Hb = 272 in front of a 16-output tile
+constexpr int kT16NS = kN + kT16Hb;                                                         // staged complex samples per frame
+constexpr int kT16PL = kT16NS + 8 * (kT16NS / 128 + 1) + 16;                                // f16 elements per plane (16 bytes of padding per 128 samples)
+constexpr int kT16NL4 = (kT16NS / 2 + kT - 1) / kT;                                         // float4 (two complex samples) a lane stages
+constexpr size_t kT16LdsBytes = (size_t)kSLen * sizeof(float2) + (size_t)4 * kT16PL * sizeof(unsigned short) + 64 * sizeof(float);
+static_assert(kT16LdsBytes <= 160 * 1024, "LDS budget of one CU");
+static_assert(kT16NS % 16 == 0, "whole 16-sample groups");
+
+#ifdef GR4_FD_TIMING
+#define GR4_T16_STAMP(i, fr)                                                                          \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        if ((threadIdx.x & 63) == 0 && a.dbg) a.dbg[((fr) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define GR4_T16_STAMP(i, fr) do { } while (0)
+#endif
+template <int MODE, int LOG2NF>
+__device__ __forceinline__ void chain_td16_body(ChainFdArgs& a) {
+    constexpr bool WIN = MODE != kModeMag2, SMALL = MODE == kModeWinSmall;
+    constexpr int  KS = kT16KS, Hb = kT16Hb, NS = kT16NS, PL = kT16PL, NL4 = kT16NL4, NM = KS + 1;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2*         S   = smem;
+    unsigned short* pls = reinterpret_cast<unsigned short*>(smem + kSLen); // planes re1, re2, im1, im2
+    unsigned*       st  = reinterpret_cast<unsigned*>(pls + 4 * PL);       // [0..7] largest magnitude per wave, [8..15] quietest group, [16..23] input power, [24..31] output power
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, kq = lane >> 4;
+    auto P = [](int s_) { return s_ + 8 * (s_ >> 7); };
+    {   // nothing marked (the ordinary stream): leave at once -- every lane looks at its share of the flag bytes
+        int any = 0;
+        for (long f = (long)blockIdx.x + (long)t * gridDim.x; f < a.n_frames; f += (long)kT * gridDim.x) any |= (int)(a.fflags[f] == 1);
+        if (!__syncthreads_or(any)) return;
+    }
+    const unsigned short* blk   = a.hfrag;
+    const u32x4_h*        afrag = reinterpret_cast<const u32x4_h*>(blk);
+    const float           inv_t = *reinterpret_cast<const float*>(blk + KS * 1536);
+    const float           h2_128 = *reinterpret_cast<const float*>(blk + KS * 1536 + 4); // sum b^2 / 128
+    const float           gthr  = h2_128 * 128.f * a.td16_thr;
+    // transform tables (as chain_redo_kernel)
+    const int   n0 = t >> 1, par = t & 1;
+    const float sgn = par ? -1.f : 1.f;
+    const int   cb = lane & 15;
+    const int   kb = 2 * wave + (kq >> 1) + 16 * (kq & 1);
+    constexpr int NF = 1 << (SMALL ? LOG2NF : 8), TF = NF / 16, NPF = NF + NF / 32;
+    const long  n_span = a.n_frames * kN;
+    const int   hlen = 256;
+    // this workgroup's next frame marked 1 at or behind f (uniform)
+    const auto next_marked = [&](long f) {
+        while (f < a.n_frames && a.fflags[f] != 1) f += gridDim.x;
+        return f;
+    };
+    // NS samples from x[f N - Hb ...] into registers (the 256 samples of carried history in front of the span, zeros further back: they meet zero taps)
+    float4 v4[NL4];
+    const auto load_frame = [&](long f) {
+        if (f > 0) { // (uniform) the staged range starts inside the span: one buffer descriptor, no per-lane address or bound (a read behind the span's end returns zeros)
+            const long   i0   = f * kN - Hb;
+            const long   nrec = n_span - i0 < (long)NS ? n_span - i0 : (long)NS;
+            const rsrc_t r    = make_rsrc(a.x + i0, (unsigned)(nrec * 8));
+#pragma unroll
+            for (int u = 0; u < NL4; ++u) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, t * 16, kT * u * 16, 0);
+                v4[u]        = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+            return;
+        }
+        // the span's first frame: the 256 samples of carried history in front of it, zeros further back.  Two descriptors, no branch: a lane's pair lies in the span, in the
+        // history or in front of both, and a buffer read outside its descriptor (a negative offset is a huge unsigned one) returns zeros -- so the two reads are added
+        const long   nrec = n_span < (long)kN ? n_span : (long)kN;
+        const rsrc_t rx = make_rsrc(a.x, (unsigned)(nrec * 8)), rh = make_rsrc(a.hist, (unsigned)(hlen * 8));
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int  i  = 2 * (t + kT * u) - Hb; // (even, like Hb and the history's length: a pair never straddles a boundary)
+            const auto vx = __builtin_amdgcn_raw_buffer_load_b128(rx, i * 8, 0, 0), vh = __builtin_amdgcn_raw_buffer_load_b128(rh, (hlen + i) * 8, 0, 0);
+            v4[u] = make_float4(__uint_as_float(vx[0] | vh[0]), __uint_as_float(vx[1] | vh[1]), __uint_as_float(vx[2] | vh[2]), __uint_as_float(vx[3] | vh[3]));
+        }
+    };
+    long f = next_marked(blockIdx.x);
+    if (f < a.n_frames) load_frame(f);
+    for (; f < a.n_frames;) {
+        const long fnext = next_marked(f + gridDim.x);
+        __syncthreads();                // the previous frame's readers are done with S, the planes and the statistics
+        GR4_T16_STAMP(0, f);
+        // ---- statistics of the staged samples (one block exponent per frame)
+        float  mf = 0.f, px = 0.f;
+        unsigned mn = 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const float4 s = v4[u];
+            const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s.x), __builtin_fabsf(s.y)), __builtin_fmaxf(__builtin_fabsf(s.z), __builtin_fabsf(s.w)));
+            mf = __builtin_fmaxf(mf, m4);
+            mn = min(mn, __float_as_uint(m4) - 1u);
+            px = fmaf(s.x, s.x, fmaf(s.y, s.y, fmaf(s.z, s.z, fmaf(s.w, s.w, px))));
+        }
+        {
+            unsigned mx = __float_as_uint(mf);
+            mx = hf_wave_reduce_u32(mx, [](unsigned a_, unsigned b_) { return a_ > b_ ? a_ : b_; });
+            mn = hf_wave_reduce_u32(mn, [](unsigned a_, unsigned b_) { return a_ < b_ ? a_ : b_; });
+            px = hf_wave_sum(px);
+            if (lane == 0) { st[wave] = mx; st[8 + wave] = mn; st[16 + wave] = __float_as_uint(px); }
+        }
+        __syncthreads();
+        GR4_T16_STAMP(1, f);
+        unsigned mx = 0, mq = 0xffffffffu;
+        px = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { mx = max(mx, st[w]); mq = min(mq, st[8 + w]); px += __uint_as_float(st[16 + w]); }
+        const int e = (int)(mx >> 23), el = (int)(mq >> 23);
+        // a non-finite sample, a spread beyond what one block exponent carries, powers outside float32's range: the float64 evaluation's frame (it leaves a non-finite one as the fused kernel wrote it)
+        const bool hard = e == 255 || px != px || (mq != 0xffffffffu && e - el > kHfMaxRange) || (mx != 0u && (e < 127 - 60 || e > 127 + 60));
+        if (hard) { if (t == 0) a.fflags[f] = 2; f = fnext; if (f < a.n_frames) load_frame(f); continue; } // (uniform)
+        const int   ec = e < 15 ? 15 : (e > 254 ? 254 : e);
+        const float s_cur = __uint_as_float((unsigned)(268 - ec) << 23), inv_cur = __uint_as_float((unsigned)(ec - 14) << 23);
+#pragma unroll
+        for (int u = 0; u < NL4; ++u) {
+            const int q = t + kT * u;
+            unsigned rh, rl, ih, il;
+            hf_split2(v4[u].x, v4[u].z, s_cur, rh, rl);
+            hf_split2(v4[u].y, v4[u].w, s_cur, ih, il);
+            const int el_ = q < NS / 2 ? P(2 * q) : PL - 16 + 2 * (lane & 7); // (lanes past the staged range: the spare elements behind each plane)
+            *reinterpret_cast<unsigned*>(pls + el_)          = rh;
+            *reinterpret_cast<unsigned*>(pls + PL + el_)     = rl;
+            *reinterpret_cast<unsigned*>(pls + 2 * PL + el_) = ih;
+            *reinterpret_cast<unsigned*>(pls + 3 * PL + el_) = il;
+        }
+        __syncthreads();
+        const long fcur = f;
+        GR4_T16_STAMP(2, fcur);
+        // ---- y on the f16 matrix pipe, x window, into the transform's image
+        u32x4_h        af[2][KS];
+        const u32x4_h* afp = afrag;
+        asm volatile("" : "+s"(afp)); // (the fragments are the same for every frame: loaded here, per frame, so that their 72 registers are free during the transform -- hoisted out of the
+                                      // frame loop they pushed the kernel into scratch)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) af[p][ks] = afp[(p * KS + ks) * 64 + lane];
+        const int   ek  = (int)((__float_as_uint(inv_t) >> 23) & 255) + (int)((__float_as_uint(inv_cur) >> 23) & 255) - 254;
+        const bool  one = ek > -120 && ek < 120;
+        const float k1 = one ? inv_t * inv_cur : inv_t, k2 = one ? 1.f : inv_cur, kd = k1 * (1.f / 2048.f);
+        float py = 0.f;
+#ifndef GR4_T16_NT
+#define GR4_T16_NT 2   // tiles of a 128-output column per wave: 2 (fir_f16.hip's map: four waves per 2048-output segment, two passes over the frame) or 4 (two waves per segment, one pass)
+#endif
+#ifndef GR4_T16_PIPE
+#define GR4_T16_PIPE 0 // 1: the sample fragments of step m + 1 are read before the products of step m are issued
+#endif
+        // Measured (profiles/r06_chain_td16.txt; settled stream, Gsamples/s rectangular / Hann): NT 2 144 / 131; NT 2 + PIPE 149 / 120; NT 4 + PIPE 126 / 94.  One stream of sample
+        // fragments serves a wave's NT tiles (tile jj meets fragment m at K-step m - jj), so NT 4 reads 40 % less LDS per product and PIPE hides the reads' queueing behind the
+        // wave's own products -- the products' phase does shrink (16.8k -> 14.5k -> 13.4k cycles per frame) -- but 64 accumulator + 72 tap-fragment + 32 sample-fragment registers
+        // at 256 per lane put the staging and the transform into scratch, which costs more than the products gain.
+        constexpr int NT = GR4_T16_NT, NMS = KS + NT - 1;
+#pragma unroll 1
+        for (int pass = 0; pass < 4 / NT; ++pass) {
+            const int sg  = NT == 4 ? wave >> 1 : (wave >> 2) + 2 * pass;
+            const int tb2 = NT == 4 ? wave & 1 : ((wave & 3) >> 1) + 4 * (wave & 1); // NT 2: waves 0, 1 of a group: tiles {0, 2} / {4, 6}; waves 2, 3: tiles {1, 3} / {5, 7}
+            const int sb  = 2048 * sg + 128 * col + 16 * tb2 + 8 * kq;
+            f32x4_h c[2 * NT], d[2 * NT]; // index 2 tile + component
+#pragma unroll
+            for (int j = 0; j < 2 * NT; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+            f16x8_h bq[2][4];
+            const auto frag = [&](int m, f16x8_h (&b)[4]) {
+                const unsigned short* q = pls + P(sb + 32 * m);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b[k] = *reinterpret_cast<const f16x8_h*>(q + k * PL); // re1, re2, im1, im2
+            };
+#ifndef GR4_T16_NOFIR
+            if (GR4_T16_PIPE) frag(0, bq[0]);
+#pragma unroll
+            for (int m = 0; m < NMS; ++m) {
+                if (GR4_T16_PIPE) {
+                    if (m + 1 < NMS) frag(m + 1, bq[(m + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else frag(m, bq[m & 1]);
+                const f16x8_h b1[2] = {bq[m & 1][0], bq[m & 1][2]}, b2[2] = {bq[m & 1][1], bq[m & 1][3]};
+#pragma unroll
+                for (int jj = 0; jj < NT; ++jj) {
+                    const int ks = m - jj;
+                    if (ks < 0 || ks >= KS) continue;
+                    const f16x8_h a1 = __builtin_bit_cast(f16x8_h, af[0][ks]), a2 = __builtin_bit_cast(f16x8_h, af[1][ks]);
+#pragma unroll
+                    for (int cp = 0; cp < 2; ++cp) {
+                        c[2 * jj + cp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[cp], c[2 * jj + cp], 0, 0, 0);
+                        d[2 * jj + cp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2[cp], d[2 * jj + cp], 0, 0, 0);
+                        d[2 * jj + cp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1[cp], d[2 * jj + cp], 0, 0, 0);
+                    }
+                }
+            }
+#endif
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float vr = fmaf(d[2 * jj][r], kd, c[2 * jj][r] * k1), vi = fmaf(d[2 * jj + 1][r], kd, c[2 * jj + 1][r] * k1);
+                    if (!one) { vr *= k2; vi *= k2; }
+                    py = fmaf(vr, vr, fmaf(vi, vi, py));
+                    const int o = 2048 * sg + 128 * col + 16 * (tb2 + 2 * jj) + 4 * kq + r;
+                    if constexpr (WIN) { const float w = a.win[o] * (float)kN; vr *= w; vi *= w; } // (the table holds window / N for the fused kernel's unnormalised inverse transform)
+                    if constexpr (SMALL) S[(o >> LOG2NF) * NPF + (o & (NF - 1)) + ((o & (NF - 1)) >> 5)] = make_float2(vr, vi);
+                    else S[addrA(o >> 8, o & 255)] = make_float2(vr, vi);
+                }
+            }
+        }
+        GR4_T16_STAMP(3, fcur);
+        py = hf_wave_sum(py);
+        if (lane == 0) st[24 + wave] = __float_as_uint(py);
+        f = fnext;
+        __syncthreads();
+        GR4_T16_STAMP(4, fcur);
+        py = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) py += __uint_as_float(st[24 + w]);
+#ifdef GR4_T16_NOFFT // timing-only build: no transform, no result
+        if (py != 12345.f) { if (f < a.n_frames) load_frame(f); continue; }
+#endif
+        if (!(py >= gthr * px)) { if (t == 0) a.fflags[fcur] = 2; if (f < a.n_frames) load_frame(f); continue; } // (uniform) the filter removes too much of what it is given for 22-bit products: float64 behind this launch
+        // ---- the frame transform and |.|^2 (chain_redo_kernel's)
+        float* out = a.out + fcur * kN;
+        if constexpr (SMALL) {
+            float2 sw2a, sw2b, sw3, sw3sq;
+            {
+                const int     tt  = t % TF;
+                const float2* tws = a.twS;
+                asm volatile("" : "+s"(tws)); // (per frame, like the fragments)
+                sw2a  = tws[(tt & 15) * (NF / 256)];
+                sw2b  = tws[2 * (tt & 15) * (NF / 256)];
+                sw3   = tws[tt & 255];
+                sw3sq = tws[(2 * (tt & 255)) & (NF - 1)];
+            }
+            auto PF = [](int i) { return i + (i >> 5); };
+            const int fl = t / TF, tt = t % TF;
+            float2*   fb = S + fl * NPF;
+            float2    v[16], Xs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fb[PF(tt + r * TF)];
+            __syncthreads();
+            fft_small_passes<LOG2NF>(v, fb, tt, sw2a, sw2b, sw3, sw3sq, Xs, [] { __syncthreads(); });
+            if (f < a.n_frames) load_frame(f); // the next frame's samples are on their way while this one's spectra leave
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int off = (t / TF) * NF + t % TF + j * TF;
+                out[off] = fmaf(Xs[j].x, Xs[j].x, Xs[j].y * Xs[j].y);
+            }
+        } else {
+            float2 twA[16];
+            int    odd = t & 1;
+            asm volatile("" : "+v"(odd)); // (per frame, like the fragments: 32 registers)
+#pragma unroll
+            for (int k1_ = 0; k1_ < 16; ++k1_) twA[k1_] = odd ? w32(k1_) : make_float2(1.f, 0.f);
+            passA_inplace(S, twA, par, n0, sgn);
+            __syncthreads();
+            GR4_T16_STAMP(5, fcur);
+            if (f < a.n_frames) load_frame(f); // the next frame's samples are on their way during passes B and C (~3 us); behind pass A, whose 32 twiddle registers are free again
+            float2 w[16], X[16], twr[16];
+            const float2 *twb = a.twB, *twc = a.twC;
+            asm volatile("" : "+s"(twb), "+s"(twc)); // (per frame, like the fragments)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = S[addrA(kb, cb + 16 * r)];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) twr[r] = twb[r * 32 + kb];
+            __syncthreads();
+            passB_compute_store(S, w, twr, cb, kb);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) twr[r] = twc[r * 512 + t];
+            __syncthreads();
+            GR4_T16_STAMP(6, fcur);
+            passC(S, X, twr, t);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) out[t + 512 * q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y);
+            GR4_T16_STAMP(7, fcur);
+        }
+    }
+}
+template <int MODE, int LOG2NF = 13>
+__global__ __launch_bounds__(kT, 1) void chain_td16_kernel(ChainFdArgs a) { chain_td16_body<MODE, LOG2NF>(a); }
+
 template <int MODE, int LOG2NF = 13>
 __global__ __launch_bounds__(kT, 1) void chain_redo_kernel(ChainFdArgs a, int ntaps) { chain_redo_body<MODE, LOG2NF, false>(a, ntaps, nullptr); }
 __global__ __launch_bounds__(kT, 1) void chain_redo_fold_kernel(ChainFdArgs a, ChainFdMulti m, int ntaps) { chain_redo_body<kModeMag2, 13, true>(a, ntaps, &m); }
@@ -1076,6 +1371,7 @@ __global__ __launch_bounds__(kT, 2) void chain_fd_multi_kernel(ChainFdArgs a, Ch
 
 
 int chain_fused_reset(struct ChainFused* c);
+bool fir_f16_make_afrag(const float* taps, size_t ntaps, int* KS_out, std::vector<unsigned short>* af, size_t nch, int force_ks); // fir_f16.hip
 // chain16.hip: the 16-wave kernel for the rectangular-window modes (|FFT(fir(x))|^2 and |FFT(x)|^2 at 8192 points)
 struct Chain16;
 int  chain16_create(Chain16** out, const float* H, const float* taps256);
@@ -1107,6 +1403,8 @@ struct ChainFused {
     bool         zero_hist = true;     // reset asked for (or nothing has run yet): the carried history is zeroed on the stream of the next call that reads it (common.hpp, the stream rule)
     unsigned     pw_floor = 0;         // measurements of launches up to this one belong to the stream before the last reset
     DeviceBuffer d_fflags;             // one byte per frame of the last launch
+    DeviceBuffer d_hfrag;              // the two-term f16 tap table of chain_td16_kernel (null: taps that form cannot carry -- the float64 evaluation takes every marked frame)
+    bool         td16 = false;
     ~ChainFused() {
         if (c16) chain16_destroy(c16);
         if (h_pw) hip_quiet(hipHostFree(h_pw));
@@ -1183,6 +1481,12 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
                         }
         rc = upload(c->d_efrag, ef);
     }
+    if (!rc) { // chain_td16_kernel's table (round 6): the same taps as two f16 terms, fragments of a 288-sample window
+        std::vector<unsigned short> hf;
+        int                         ks = 0;
+        static const bool off = std::getenv("GR4HIP_CHAIN_NO_TD16") != nullptr; // developer switch: every marked frame on the float64 evaluation, round 5's behaviour
+        if (!off && fir_f16_make_afrag(taps, ntaps, &ks, &hf, 1, kT16KS) && ks == kT16KS) { rc = upload(c->d_hfrag, hf); c->td16 = !rc; }
+    }
     if (!rc && fft_size == (size_t)kN) rc = chain16_create(&c->c16, H.data(), hp.data());
     c->small_log2n = fft_size == (size_t)kN ? 0 : (int)ilog2(fft_size);
     c->windowed    = c->small_log2n != 0 || (window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR);
@@ -1242,6 +1546,56 @@ static int arm_measure(ChainFused* c, hipStream_t st) {
     }
     ++c->pw_seq;
     c->pw_stream = st;
+    return GR4HIP_OK;
+}
+
+// the launches that follow a launch which has marked frames in a.fflags (same stream): chain_td16_kernel over the frames marked 1 (22-bit products on the f16 matrix pipe;
+// it leaves a 2 on the frames that are beyond it), then chain_redo_kernel (float64 products) over what is left -- every marked frame when the taps have no f16 table
+static int second_evaluations(ChainFused* c, ChainFdArgs a, size_t n_frames, hipStream_t st) {
+    static PerDevice per_device;
+    bool             first = false;
+    int              dev = -1, n = per_device.current(&first, &dev);
+    GR4_REQUIRE(n != 0, "fused chain: cannot query the current device");
+    const int n_cu = n < 0 ? -n : n;
+    if (first) {
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
+        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
+        per_device.done(dev, -n);
+    }
+    const unsigned rg = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu);
+    const int      nt = (int)c->ntaps;
+    if (c->td16) {
+        a.hfrag    = static_cast<const unsigned short*>(c->d_hfrag.ptr);
+        a.td16_thr = kTd16GuardRatio;
+        switch (c->small_log2n) {
+        case 8: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 8>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
+        case 9: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 9>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
+        case 10: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 10>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
+        case 11: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 11>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
+        case 12: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 12>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
+        default:
+            if (c->windowed) hipLaunchKernelGGL(chain_td16_kernel<kModeWinMag2>, dim3(rg), dim3(kT), kT16LdsBytes, st, a);
+            else hipLaunchKernelGGL(chain_td16_kernel<kModeMag2>, dim3(rg), dim3(kT), kT16LdsBytes, st, a);
+        }
+        GR4_LAUNCH_CHECK();
+        a.redo_min_flag = 2;
+    }
+    switch (c->small_log2n) {
+    case 8: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 8>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    case 9: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 9>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    case 10: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 10>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    case 11: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 11>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    case 12: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 12>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
+    default:
+        if (c->windowed) hipLaunchKernelGGL(chain_redo_kernel<kModeWinMag2>, dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt);
+        else hipLaunchKernelGGL(chain_redo_kernel<kModeMag2>, dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt);
+    }
+    GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
 
@@ -1344,19 +1698,7 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     else hipLaunchKernelGGL(chain_fd_kernel<kModeMag2>, dim3(grid), dim3(kT), lds, st, a);
     GR4_LAUNCH_CHECK();
     if (a.fflags != nullptr) { // the marked frames again in the time domain, behind the launch that marked them
-        const unsigned rg = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu);
-        const int      nt = (int)c->ntaps;
-        switch (c->small_log2n) {
-        case 8: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 8>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
-        case 9: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 9>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
-        case 10: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 10>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
-        case 11: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 11>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
-        case 12: hipLaunchKernelGGL((chain_redo_kernel<kModeWinSmall, 12>), dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt); break;
-        default:
-            if (c->windowed) hipLaunchKernelGGL(chain_redo_kernel<kModeWinMag2>, dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt);
-            else hipLaunchKernelGGL(chain_redo_kernel<kModeMag2>, dim3(rg), dim3(kT), kRdLdsBytes, st, a, nt);
-        }
-        GR4_LAUNCH_CHECK();
+        if (const int rc = second_evaluations(c, a, n_frames, st)) return rc;
     }
     // carry the last 256 input samples for the next call's first frame (stream-ordered after the kernel's reads)
     if (carry_hist) GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_frames * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
@@ -1365,19 +1707,50 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
 
 // n_frames counts FFT frames of the plan's fftSize.  At fftSize < 8192 whole 8192-sample blocks go through the kernel directly; the frames
 // behind the last whole block (< 8192 samples) are copied into a zero-padded staging block, transformed, and only their spectra copied out.
-int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
-    if (c->small_log2n == 0) return chain_fused_run(c, d_in, nullptr, n_frames, d_mag2, st, false, true);
+// n_blocks 8192-sample blocks entirely in the time domain (a stream the dynamic-range guard has moved there): every block's flag byte is set to 1 and the second evaluations
+// run as behind a fused launch that had marked them all -- chain_td16_kernel, then chain_redo_kernel on what that one leaves (float64)
+static int chain_fused_td_run(ChainFused* c, const float* d_in, size_t n_blocks, float* d_out, hipStream_t st, bool carry_hist) {
+    if (!c->td16) { set_error("fused chain: no time-domain form for these taps"); return GR4HIP_UNSUPPORTED; }
+    if (const int rc = history_on(c, st)) return rc;
+    if (const int rc = c->d_fflags.ensure(n_blocks)) return rc;
+    GR4_HIP_TRY(hipMemsetAsync(c->d_fflags.ptr, 1, n_blocks, st));
+    ChainFdArgs a{};
+    a.x        = reinterpret_cast<const float2*>(d_in);
+    a.hist     = static_cast<const float2*>(c->d_hist.ptr);
+    a.twB      = static_cast<const float2*>(c->d_twB.ptr);
+    a.twC      = static_cast<const float2*>(c->d_twC.ptr);
+    a.taps     = static_cast<const float*>(c->d_taps.ptr);
+    a.win      = static_cast<const float*>(c->d_win.ptr);
+    a.twS      = static_cast<const float2*>(c->d_twS.ptr);
+    a.out      = d_out;
+    a.n_frames = (long)n_blocks;
+    a.fflags   = static_cast<unsigned char*>(c->d_fflags.ptr);
+#ifdef GR4_FD_TIMING
+    if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
+    if (n_blocks * 8 * 16 * 8 <= ((size_t)1 << 26)) a.dbg = g_dbg;
+#endif
+    if (const int rc = second_evaluations(c, a, n_blocks, st)) return rc;
+    if (carry_hist) GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_blocks * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    return GR4HIP_OK;
+}
+bool chain_fused_has_td(const ChainFused* c) { return c->td16; }
+
+int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st, bool td) {
+    const auto run = [&](const float* in, size_t blocks, float* out, bool carry) {
+        return td ? chain_fused_td_run(c, in, blocks, out, st, carry) : chain_fused_run(c, in, nullptr, blocks, out, st, false, carry);
+    };
+    if (c->small_log2n == 0) return run(d_in, n_frames, d_mag2, true);
     const size_t nf = (size_t)1 << c->small_log2n, per_block = kN / nf;
     const size_t blocks = n_frames / per_block, rem = n_frames % per_block; // rem fft-frames = rem * nf samples (>= 256 each)
     if (blocks) {
-        int rc = chain_fused_run(c, d_in, nullptr, blocks, d_mag2, st, false, true);
+        int rc = run(d_in, blocks, d_mag2, true);
         if (rc) return rc;
     }
     if (rem) {
         const float* tail = d_in + blocks * (size_t)kN * 2;
         GR4_HIP_TRY(hipMemsetAsync(c->d_stage_in.ptr, 0, kN * sizeof(float2), st));
         GR4_HIP_TRY(hipMemcpyAsync(c->d_stage_in.ptr, tail, rem * nf * sizeof(float2), hipMemcpyDeviceToDevice, st));
-        int rc = chain_fused_run(c, static_cast<const float*>(c->d_stage_in.ptr), nullptr, 1, static_cast<float*>(c->d_stage_out.ptr), st, false, false);
+        int rc = run(static_cast<const float*>(c->d_stage_in.ptr), 1, static_cast<float*>(c->d_stage_out.ptr), false);
         if (rc) return rc;
         GR4_HIP_TRY(hipMemcpyAsync(d_mag2 + blocks * (size_t)kN, c->d_stage_out.ptr, rem * nf * sizeof(float), hipMemcpyDeviceToDevice, st));
         // history for the next call: the last 256 REAL input samples (rem * nf >= 256)
@@ -1589,7 +1962,7 @@ void chain_fused_set_max_workgroups(ChainFused* c, unsigned n) { c->max_wg = n; 
 } // namespace gr4
 extern "C" int gr4hip_dbg_fd_timing(unsigned long long* h_out, size_t n_frames) { // developer-only, not part of the ABI
     if (!gr4::g_dbg) return GR4HIP_ERROR;
-    hip_quiet(hipDeviceSynchronize());
+    gr4::hip_quiet(hipDeviceSynchronize());
     return hipMemcpy(h_out, gr4::g_dbg, n_frames * 8 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? GR4HIP_OK : GR4HIP_RUNTIME_ERROR;
 }
 namespace gr4 {

@@ -68,7 +68,7 @@ int dev_switch(DevSwitch s);
 // A HIP call whose failure the caller can do nothing about (frees in destructors): the runtime's last-error word is sticky since ROCm 7 -- an ignored failure
 // stays there until somebody calls hipGetLastError, and that somebody is GR4_LAUNCH_CHECK behind an innocent launch (round 6: hipHostUnregister of a ring with a copy
 // still in flight -> "kernel launch failed: unknown error" in the next gr4hip_iir_create, one run in two).  So: ignored means cleared.
-inline hipError_t hip_quiet(hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e; }
+inline void hip_quiet(hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); }
 
 inline hipStream_t as_stream(gr4hip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

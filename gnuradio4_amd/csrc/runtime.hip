@@ -171,7 +171,8 @@ int gr4hip_host_ring_destroy(void* base, size_t bytes) {
     // a copy engine may still be reading or writing these pages (the last chunks of an edge): unregistering under it fails ("unknown error", observed one run in two of
     // the host engine's test) and leaves the pages pinned.  Everything queued on the device finishes first -- this is a teardown call.
     hip_quiet(hipDeviceSynchronize());
-    const hipError_t e = hip_quiet(hipHostUnregister(base));
+    const hipError_t e = hipHostUnregister(base);
+    hip_quiet(e);
     munmap(base, 2 * bytes);
     if (e != hipSuccess) { set_error("host_ring_destroy: hipHostUnregister failed: %s", hipGetErrorString(e)); return GR4HIP_RUNTIME_ERROR; }
     return GR4HIP_OK;

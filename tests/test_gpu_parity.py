@@ -1749,6 +1749,31 @@ def test_chain_every_frame_marked_meets_the_bar(G):
         assert _rel(cg.process_bulk(dev(loud)).cpu().numpy().ravel(), tw) <= TOL, window
 
 
+@pytest.mark.parametrize("N,ntaps,window,wid,fc,amp,f0", [(8192, 256, "None", 0, 0.005, 1.0, 0.1), (8192, 256, "Hann", 3, 0.005, 1.0, 0.1), (8192, 129, "Kaiser", 11, 0.01, 0.0, 0.1),
+                                                       (1024, 200, "Hamming", 2, 0.005, 1.0, 0.1), (256, 100, "BlackmanHarris", 7, 0.004, 3.0, 0.2), (4096, 256, "None", 0, 0.008, 0.5, 0.3),
+                                                       (8192, 256, "None", 0, 0.02, 300.0, 0.31), (8192, 256, "Hann", 3, 0.02, 30.0, 0.31), (2048, 77, "Hann", 3, 0.02, 1000.0, 0.4)])
+def test_chain_marked_frames_on_the_f16_pipe_then_float64(G, N, ntaps, window, wid, fc, amp, f0):
+    """round 6: the frames a fused launch marks (output / input power below 0.08: the fast convolution's error, relative to the INPUT, would show) are evaluated again by
+    chain_td16_kernel -- filter on the f16 matrix pipe (22-bit products under one block exponent per frame), window, one transform from LDS -- and only the frames whose filter
+    output lies more than 15 dB below what white noise would pass (flag 2: the loud rejected tones of the last three cases) by chain_redo_kernel's float64 products behind it.
+    A narrow channel filter over wide-band noise (every frame marked), all windows' code paths (8192 rectangular / windowed, fftSize < 8192), ragged calls, the call after the
+    stream has moved to the time domain for good: all against the float64 oracle at the contract's bar"""
+    b = O.design_taps_hamming_lowpass(ntaps, fc)
+    n = 21 * 8192
+    x = O.signal_c32(5, n, tone_frel=f0, tone_amp=amp)
+    truth, _ = O.chain(b, x, N, wid, truth=True)
+    ch = G.Chain(b, N, window)
+    assert ch.algo == G.capi.CHAIN_FUSED_FD
+    d = dev(x)
+    cuts = [0, 8192 * 5, 8192 * 5 + N * (8192 // N // 2 + 1), 8192 * 13, n]  # (a cut inside an 8192-sample block when fftSize < 8192: the staged tail)
+    got = np.concatenate([ch.process_bulk(d[lo:hi]).cpu().numpy().ravel() for lo, hi in zip(cuts[:-1], cuts[1:])])
+    assert _rel(got, truth) <= TOL
+    ratio, moved = ch.last_power_ratio()
+    assert 0 <= ratio < 0.08 and moved  # (the later calls ran in the time domain; the first one in-stream)
+    ch.reset()
+    assert _rel(ch.process_bulk(d).cpu().numpy().ravel(), truth) <= TOL  # the whole span in-stream: fused launch + the second evaluations, one call
+
+
 @pytest.mark.parametrize("N,ntaps,window,wid", [(4096, 64, "None", 0), (2048, 64, "Hann", 3), (256, 33, "BlackmanHarris", 7), (1024, 17, "Hamming", 2)])
 def test_fused_time_domain_chain_answers_to_the_guard(G, N, ntaps, window, wid):
     """CHAIN_AUTO with <= 64 taps at fft sizes <= 4096 runs the fused time-domain kernel (chain_td.hip: the filter as float32 sums in the matrix pipe's order).  tools/fuzz_chain.py
