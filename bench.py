@@ -765,8 +765,8 @@ def main():
                 res["hann_second_row"] = {"error": str(e)[:200]}
         if world == 1 and not combine and not args.no_hann_row and not args.guard_mode:
             # what the strict guard costs a stream it trips on EVERY frame: the same samples through a 256-tap low-pass that passes 1 % of their power (-20 dB: below the
-            # guard's 4 % threshold).  "in_stream": the fused launch marks every frame and chain_redo_kernel, enqueued behind it, evaluates them all again in the time domain
-            # (float64 products) -- what a call costs before the stream has moved; "settled": a later call has found the measurement and moved the stream to the time-domain
+            # guard's 8 % threshold).  "in_stream": the fused launch marks every frame and chain_td16_kernel, enqueued behind it, evaluates them all again in the time domain
+            # (22-bit products on the f16 matrix pipe; float64 for the frames that one leaves) -- what a call costs before the stream has moved; "settled": a later call has found the measurement and moved the stream to the time-domain
             # kernel pair for good.  Neither waits for the host (DESIGN.md 3.1 "the guard without the host").
             try:
                 ng = min(n, 1 << 27)
@@ -788,7 +788,7 @@ def main():
                     return sorted(ts_)[len(ts_) // 2]
                 t_in = _timed(True)
                 row = {"taps": "256-tap Hamming low-pass, cut-off 0.005 fs (passes 1 % of the stream's power)", "samples": ng,
-                       "in_stream_msamples": round(ng / (t_in * 1e-3) / 1e6, 1), "in_stream_note": "fused launch + chain_redo_kernel on every frame, one stream, no host wait"}
+                       "in_stream_msamples": round(ng / (t_in * 1e-3) / 1e6, 1), "in_stream_note": "fused launch + the second evaluation of every frame behind it (chain_td16_kernel on the f16 matrix pipe, float64 for what that leaves), one stream, no host wait"}
                 if not args.no_verify:
                     O = _oracle()
                     f = 77
@@ -821,6 +821,22 @@ def main():
                     rc = 3
             except Exception as e:  # never at the price of the headline line
                 res["secondary_configs"] = {"error": str(e)[:200]}
+        if world == 1 and not combine and not args.no_secondary and os.environ.get("GR4HIP_BENCH_CHILD") != "1":
+            # the PCIe-inclusive rate (never `value`): the same chain host-fed through the C++ engine (gnuradio4_amd/host: Graph::connect, hip::plan, scheduler::Simple on one host thread)
+            # between page-locked edges of the REFERENCE'S DEFAULT SIZE, 65 536 items (Graph.hpp:102) -- VERDICT r05 item 5 -- and of 2^24 items (what the link gives)
+            try:
+                import re as _re
+                import subprocess
+                exe = os.path.join(ROOT, "build", "host", "bench_host_feed")
+                row = {"workload": "DmaSource -> fir_filter<complex<float>> 256 taps -> PowerSpectrum 8192 -> NullSink, 2^29 samples, page-locked edges, one host thread"}
+                for key, edge in (("value", "16"), ("edges_2^24_msamples", "24")):
+                    out = subprocess.run([exe, "29", str(NFFT), str(NTAPS), "dma", edge], capture_output=True, text=True, timeout=120).stdout
+                    m = _re.search(r"= ([0-9.]+) Msamples/s", out)
+                    row[key] = float(m.group(1)) if m else None
+                row["unit"], row["edge_items"] = "Msamples/s", 65536
+                res["host_feed_row"] = row
+            except Exception as e:  # never at the price of the headline line
+                res["host_feed_row"] = {"error": str(e)[:200]}
         if world == 1 and not combine and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not combine and not args.no_graph8 and os.environ.get("GR4HIP_BENCH_CHILD") != "1":

@@ -98,6 +98,7 @@ def test_bench_line_has_the_median_the_prewarm_the_hann_row_and_the_secondary_co
     assert r["prewarm_ms"] >= 40 and r["prewarm_steps"] >= 1 and r["median_ms_per_step"] > 0 and r["value_at_median_step"] > 0
     assert r["roofline"]["timed_launches"] == 5 * 4
     assert r["hann_msamples"] > 0 and r["configs2_msamples"] > 0 and r["configs3_msamples"] > 0 and r["guard_settled_msamples"] > 0  # the rows as top-level numbers of the printed line
+    assert r["host_feed_msamples"] > 0  # the chain host-fed through the C++ engine at the reference's default 65 536-item edges (PCIe-inclusive: never `value`)
     h = r["hann_second_row"]
     assert h["window"] == "Hann" and h["value"] > 0 and 0 < h["frac"] < 1 and h["verify_max_rel_err"] <= 1e-5
     sc = r["secondary_configs"]  # BASELINE.json configs[2] and configs[3] beside the headline, each checked against the oracle
