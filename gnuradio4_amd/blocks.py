@@ -400,6 +400,12 @@ class Chain(_Handle):
         check(lib().gr4hip_chain_last_power_ratio(self._h, C.byref(r), C.byref(td), _stream()), "Chain.last_power_ratio")
         return r.value, bool(td.value)
 
+    def last_guard_fractions(self):
+        """(fraction of the last measured launch's frames the fused kernel marked or -1, fraction of all frames since create / reset that ended in float64)"""
+        m, f = C.c_float(0), C.c_float(0)
+        check(lib().gr4hip_chain_last_guard_fractions(self._h, C.byref(m), C.byref(f), _stream()), "Chain.last_guard_fractions")
+        return m.value, f.value
+
     def process_bulk(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev(x, "Chain")
         if x.dtype != torch.complex64:

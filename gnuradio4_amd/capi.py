@@ -121,6 +121,7 @@ SIGNATURES = {
     "gr4hip_chain_process": (_i, [_vp, _vp, _sz, _vp, _psz, _vp]),
     "gr4hip_chain_get_algo": (_i, [_vp, _pi]),
     "gr4hip_chain_last_power_ratio": (_i, [_vp, _pf, _pi, _vp]),
+    "gr4hip_chain_last_guard_fractions": (_i, [_vp, _pf, _pf, _vp]),
     "gr4hip_chain_set_max_workgroups": (_i, [_vp, C.c_uint]),
     "gr4hip_chain_set_guard_mode": (_i, [_vp, _i]),
     "gr4hip_fir_set_guard_mode": (_i, [_vp, _i]),

@@ -12,15 +12,14 @@ int chain_fused_supported(size_t ntaps, size_t fft_size, int window, int algo);
 struct ChainFused;
 int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
 int  chain_fused_reset(ChainFused* c);
-int  chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st, bool td = false); // td: every frame in the time domain (chain_td16_kernel + float64 behind it)
-bool chain_fused_has_td(const ChainFused* c);
+int  chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st);
 int  chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps, const float* const* d_in, size_t n_frames, float* const* d_out, float* d_sum, hipStream_t st, bool redo);
 bool chain_fused_multi_capable(const ChainFused* c);
 void chain_fused_destroy(ChainFused* c);
 void chain_fused_set_max_workgroups(ChainFused* c, unsigned n);
 void chain_fused_set_measure(ChainFused* c, bool on);
 void chain_fused_set_redo(ChainFused* c, bool on); // measured launches mark their frames one by one and chain_redo_kernel follows them
-int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio);
+int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio, float* marked_fraction = nullptr, float* float64_fraction = nullptr);
 const float* chain_fused_history(ChainFused* c, hipStream_t st); // (applies a pending reset on `st` first; null: that failed)
 int  chain_fused_set_history(ChainFused* c, const float* d_hist256, hipStream_t st);
 struct ChainTd;
@@ -68,13 +67,23 @@ struct gr4hip_chain {
     // read the finished measurements of earlier ones without waiting.  Below the threshold the handle switches to the direct-form kernels (the
     // reference's own arithmetic) from the call that finds out onwards, until reset.
     bool            guard = false, probed = false, use_td = false;
-    bool            td_fused = false;  // use_td: the fused handle's own time-domain form (chain_td16_kernel + float64 behind it, round 6) instead of the kernel pair
     int             guard_mode = GR4HIP_GUARD_STRICT;
     float           last_ratio = -1.f; // most recent measured power ratio (< 0: none yet)
+    float           last_marked = -1.f; // ... the fraction of that launch's frames the kernel marked (< 0: none yet) ...
+    float           last_f64 = 0.f;     // ... and the fraction of all frames since create / reset that took the float64 evaluation: what a strict stream is moved on
     DeviceBuffer    d_hist_save;
     DeviceBuffer    d_multi;           // gr4hip_chain_process_multi on handles[0]: per-chain spectra when only their sum was asked for and one launch cannot fold them
 };
-constexpr float  kGuardMinPowerRatio = 0.08f;
+// (round 6: the power ratio is reported, no longer decided on -- a frame is judged on the fourth-moment statistic of chain_fused.hip, kGuardR4Max)
+// When does a stream move to the time-domain kernel pair (float32 products: 69 Gsamples/s) for good?  Strict guard: the marked frames are evaluated again behind their launch anyway;
+// a frame that chain_td16_kernel settles costs 1 / 333 + 1 / 113 ns per sample (85 Gsamples/s if every frame is marked: faster than the pair), a frame that goes on to float64
+// 1 / 34 more -- the pair is the faster way from one float64 frame in ten on.  Deferred guard: nothing is evaluated again -- one marked frame moves the stream, as before.
+constexpr float  kGuardMoveFloat64Fraction = 0.1f;
+static bool chain_should_move(const gr4hip_chain* c) { return c->guard_mode == GR4HIP_GUARD_STRICT ? c->last_f64 > kGuardMoveFloat64Fraction : c->last_marked > 0.f; }
+static void chain_note_measurement(gr4hip_chain* c, gr4::ChainFused* f, bool wait) {
+    float r, m, f64;
+    if (chain_fused_power_ratio(f, wait, false, &r, &m, &f64)) { c->last_ratio = r; c->last_marked = m; c->last_f64 = f64; }
+}
 constexpr size_t kGuardProbeFrames   = 8; // in units of 8192-sample blocks
 constexpr size_t kTdAutoMaxTaps      = 64; // AUTO: up to here the fused time-domain kernel beats the fused fast convolution (tools/chain_modes_rates.py)
 
@@ -123,8 +132,9 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
 
 int gr4hip_chain_reset(gr4hip_chain_t* c) {
     GR4_REQUIRE(c, "chain_reset: null handle");
-    c->probed = c->use_td = c->td_fused = false;
-    c->last_ratio = -1.f;
+    c->probed = c->use_td = false;
+    c->last_ratio = c->last_marked = -1.f;
+    c->last_f64 = 0.f;
     if (c->fused && c->fir) { int rc = gr4hip_fir_reset(c->fir); if (rc) return rc; }
     if (c->td) { int rc = chain_td_reset(c->td); if (rc || !c->fused) return rc; }
     return c->fused ? chain_fused_reset(c->fused) : gr4hip_fir_reset(c->fir);
@@ -152,7 +162,6 @@ static int chain_td_run(gr4hip_chain* c, const void* d_in, size_t frames, float*
 // Gsamples/s at 256 taps, 167 instead of 179 at 64: two grids that each fill the chip take turns anyway, and the extra launches cost.)
 static int chain_time_domain(gr4hip_chain* c, const void* d_in, size_t frames, float* d_mag2, gr4hip_stream_t stream) {
     if (c->td) return chain_td_run(c, d_in, frames, d_mag2, stream); // one launch where the size allows
-    if (c->td_fused) return chain_fused_process(c->fused, static_cast<const float*>(d_in), frames, d_mag2, as_stream(stream), true); // filter -> window -> transform in one kernel, frame by frame
     const size_t n  = frames * c->N;
     int          rc = c->d_y.ensure(n * 2 * sizeof(float));
     if (rc) return rc;
@@ -166,17 +175,6 @@ static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, 
     std::vector<float>& taps = c->taps;
     int rc = GR4HIP_OK;
     if (!d_hist256) return GR4HIP_RUNTIME_ERROR; // (chain_fused_history could not enqueue the pending reset: the error text is set)
-    // round 6: the fused handle has the chain in the time domain itself (chain_td16_kernel: the filter on the f16 matrix pipe, the window and ONE transform per frame from LDS,
-    // float64 behind it for the frames that are beyond 22-bit products): no intermediate stream in HBM, the same arithmetic as the frames a fused launch marks.
-    // Measured (profiles/r06_chain_td16.txt): as the destination of a WHOLE stream the one kernel runs 135 / 124 Gsamples/s (rectangular / Hann) where the kernel pair -- the same
-    // filter arithmetic with two workgroups per CU interleaving their staging and their products, then the FFT kernel -- runs 141 - 150 / 137 - 149, so the pair stays the
-    // destination and the one-kernel form is a developer switch; where it pays is behind a fused launch, on the frames that launch marks (chain_fused.hip: 31 -> 85 Gsamples/s)
-    static const bool fused_td = std::getenv("GR4HIP_CHAIN_TD_FUSED") != nullptr;
-    if (c->fused && !c->td && fused_td && chain_fused_has_td(c->fused)) {
-        if (d_hist256 != chain_fused_history(c->fused, st)) { if (const int rc2 = chain_fused_set_history(c->fused, d_hist256, st)) return rc2; }
-        c->td_fused = c->use_td = true;
-        return GR4HIP_OK;
-    }
     // the kernel pair with float32 products (GR4HIP_FIR_TIME_DOMAIN_F32), at every fft size: the regime that trips the guard -- a rejected signal far above the
     // output -- is the one in which the three-term bf16 products of chain_td_kernel / the split-product direct forms measure 3 .. 16 x a float32 sum's error.
     // (Round 4 tried the two-term f16 direct form here, whose own guard redoes the segments that reject more than 36 dB of their power: the pair went from 97 to
@@ -184,9 +182,11 @@ static int chain_switch_to_time_domain(gr4hip_chain* c, const float* d_hist256, 
     // the transform behind it gathers it into a few bins: 4 of the chain guard tests failed the bar there.  The float32 products stay.)
     if (!c->fir) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, taps.data(), taps.size(), 1);
-        if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN); // (round 5: the direct form's own kernels -- every one of them judges its segments at 21 dB and hands the marked ones to
-                                                                            // the float64 second evaluation, fir_exact.hip; until then this was GR4HIP_FIR_TIME_DOMAIN_F32, because the split-product kernels' own
-                                                                            // guard started at 36 dB and 4 chain tests failed between the two thresholds)
+        // float32 PRODUCTS (the f32 matrix pipe: the reference's own arithmetic) -- round 4's choice, again since round 6.  Round 5 took the two-term f16 direct form with its
+        // per-segment guard here (140 instead of 69 Gsamples/s); tools/fuzz_chain.py "wide" (round 6: interferers from -5 dB, anywhere outside the pass band) found what a power
+        // statistic cannot see: the 22-bit products' error is COHERENT on a tone -- its residue behind the filter is off by 2^-22 sum|b| / |H(f)| of itself --, and the transform
+        // gathers it into the one bin where the metric looks: 1.2e-5 at a residue that reaches the rms level of the output spectrum 26 dB or more down.
+        if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN_F32);
         if (!rc) rc = gr4hip_internal_fir_set_guard_ratio(c->fir, kChainPairGuardRatio);
         if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, c->N, c->window, 0);
     }
@@ -208,7 +208,6 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
         const float* x   = static_cast<const float*>(d_in);
         const size_t per = c->N < 8192 ? 8192 / c->N : 1; // fft frames per 8192-sample block
         if (c->use_td) return chain_time_domain(c, d_in, frames, d_mag2, stream);
-        float ratio;
         if (c->guard_mode == GR4HIP_GUARD_STRICT) {
             // nothing out of tolerance is ever published, and nobody waits: the fused kernel marks the frames whose output power fell below the threshold, and
             // chain_redo_kernel -- enqueued behind it on the same stream -- evaluates exactly those frames again in the time domain (float64 products) over the
@@ -216,8 +215,8 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
             // round 5 the call spun on a mapped word until its launch had ended and redid the whole span on the time-domain kernel pair.
             // The measurement of an EARLIER launch, when it has arrived, still moves a stream that rejects most of its input to the time-domain kernels for good
             // (they are the faster way through such a stream than fused kernel + second evaluation of every frame) -- without waiting for anything.
-            if (chain_fused_power_ratio(c->fused, false, false, &ratio)) c->last_ratio = ratio;
-            if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) {
+            chain_note_measurement(c, c->fused, false);
+            if (chain_should_move(c)) {
                 int rc = chain_switch_to_time_domain(c, chain_fused_history(c->fused, st), st);
                 if (rc) return rc;
                 return chain_time_domain(c, d_in, frames, d_mag2, stream);
@@ -226,7 +225,7 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
             return chain_fused_process(c->fused, x, frames, d_mag2, st);
         }
         chain_fused_set_redo(c->fused, false);
-        if (chain_fused_power_ratio(c->fused, false, false, &ratio)) c->last_ratio = ratio; // an earlier launch has finished: no waiting
+        chain_note_measurement(c, c->fused, false); // an earlier launch has finished: no waiting
         size_t done = 0;
         if (!c->probed) { // first call after create / reset: the first blocks synchronously, before the rest of the span is committed to an algorithm
             int rc = c->d_hist_save.ensure(256 * 2 * sizeof(float));
@@ -235,15 +234,15 @@ int gr4hip_chain_process(gr4hip_chain_t* c, const void* d_in, size_t n_samples, 
             const size_t probe = std::min(frames, kGuardProbeFrames * per);
             rc = chain_fused_process(c->fused, x, probe, d_mag2, st);
             if (rc) return rc;
-            if (chain_fused_power_ratio(c->fused, true, false, &ratio)) c->last_ratio = ratio;
+            chain_note_measurement(c, c->fused, true);
             c->probed = true;
             done      = probe;
-            if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) { // redo the probed frames too, from the history the call started with
+            if (chain_should_move(c)) { // redo the probed frames too, from the history the call started with
                 rc = chain_switch_to_time_domain(c, static_cast<const float*>(c->d_hist_save.ptr), st);
                 if (rc) return rc;
                 return chain_time_domain(c, d_in, frames, d_mag2, stream);
             }
-        } else if (c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio) { // an earlier call ran into the regime: switch before this one
+        } else if (chain_should_move(c)) { // an earlier call ran into the regime: switch before this one
             int rc = chain_switch_to_time_domain(c, chain_fused_history(c->fused, st), st);
             if (rc) return rc;
             return chain_time_domain(c, d_in, frames, d_mag2, stream);
@@ -341,10 +340,9 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
         { // a finished earlier launch decides for this one, without waiting (strict: the frames THIS launch marks are evaluated again on the device behind it)
             bool bad = false;
             for (size_t i = 0; i < n_chains; ++i) {
-                float r;
                 gr4hip_chain* c = chains[fold ? 0 : i];
-                if (chain_fused_power_ratio(c->fused, false, false, &r)) c->last_ratio = r;
-                bad = bad || (chains[i]->guard && c->last_ratio >= 0.f && c->last_ratio < kGuardMinPowerRatio);
+                chain_note_measurement(c, c->fused, false);
+                bad = bad || (chains[i]->guard && chain_should_move(c));
             }
             if (bad) { // (nothing launched yet in this call: the saved histories are the current ones, the copy back is a no-op)
                 if (const int rc = prepare_redo()) return rc;
@@ -368,10 +366,18 @@ int gr4hip_chain_process_multi(gr4hip_chain_t* const* chains, size_t n_chains, c
 int gr4hip_chain_last_power_ratio(gr4hip_chain_t* c, float* ratio, int* time_domain, gr4hip_stream_t stream) {
     GR4_REQUIRE(c && ratio, "chain_last_power_ratio: null argument");
     (void)stream;
-    float r;
-    if (c->fused && c->guard && chain_fused_power_ratio(c->fused, true, false, &r)) c->last_ratio = r; // waits for the last measured launch
+    if (c->fused && c->guard) chain_note_measurement(c, c->fused, true); // waits for the last measured launch
     *ratio = c->last_ratio;
     if (time_domain) *time_domain = c->use_td ? 1 : 0;
+    return GR4HIP_OK;
+}
+
+int gr4hip_chain_last_guard_fractions(gr4hip_chain_t* c, float* marked, float* float64, gr4hip_stream_t stream) {
+    GR4_REQUIRE(c && marked && float64, "chain_last_guard_fractions: null argument");
+    (void)stream;
+    if (c->fused && c->guard) chain_note_measurement(c, c->fused, true); // waits for the last measured launch
+    *marked  = c->last_marked;
+    *float64 = c->last_f64;
     return GR4HIP_OK;
 }
 

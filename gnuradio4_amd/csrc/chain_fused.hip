@@ -76,7 +76,10 @@ struct ChainFdArgs {
     float*        pw_host; // page-locked {in, out}: written with one 8-byte store by the last workgroup to finish (no extra stream operation per launch)
     unsigned      pw_seq;
     unsigned      pw_mask; // 0: every frame is measured
-    float         pw_thr; // a frame whose sampled output power is below pw_thr x its sampled input power marks the launch (word 33 of pw, word 3 of pw_host)
+    float         pw_thr; // kModeFir: a frame whose output power is below pw_thr x its input power marks the launch (word 33 of pw, word 3 of pw_host)
+    int           no_tier; // the frames this launch marks go straight to the float64 evaluation (counted as such)
+    float         pw_c5i; // ... or when  sum_k |Y_k|^4  <  pw_c5i x (peak component of X)^4  -- see kGuardPeakMax
+    float         pw_c4;  // the |.|^2 modes (round 6): a frame is marked when  pw_c4 x sum_k |Y_k|^4  <  (sum_n |x_n|^2)^2  -- see kGuardR4Max
     unsigned char* fflags; // optional, one byte per frame (8192-sample block): non-zero = that frame fell below the threshold -- chain_redo_kernel, launched behind this
                            // kernel, evaluates exactly those frames again in the time domain (float64 products): the guard without the host
     // chain_redo_kernel only (0 = the fused kernel's own conventions):
@@ -96,11 +99,29 @@ struct ChainFdArgs {
 #ifndef GR4_PW_IN_STEP
 #define GR4_PW_IN_STEP 1 // every input sample of every frame (a lane's samples t + 512 m are 512-sample stripes of the frame: a subset of m is blind to a burst in the others)
 #endif
-constexpr int   kLdsEbfBytes = (2 * kSLen + 512 + 256) * 8 + 4 * 2 * 256 * 4 + 6 * 512 * 2; // LDS of the non-windowed filter modes (= lds_ebf of chain_fused_run); the 16 verdict words follow it
+constexpr int   kLdsEbfBytes = (2 * kSLen + 512 + 256) * 8 + 4 * 2 * 256 * 4 + 6 * 512 * 2; // LDS of the non-windowed filter modes (= lds_ebf of chain_fused_run); the verdict words (kGvBytes) follow it
+constexpr int   kGvW = 24, kGvBytes = 2 * kGvW * 4; // verdict words per parity of the frame: eight wave totals of sum |Y|^4, of the input power, eight wave maxima of the input spectrum's peak
 constexpr int   kPwFrameSlots = 40, kPwMaxWorkgroups = 2048; // ChainFdArgs::pw: words 0 .. 35 as before, then two words per workgroup for the frames' verdicts
 constexpr float kGuardFirFrameThreshold = 0.04f; // the FIR-only fast convolution (fir.hip): its output is y itself, not |Y|^2
+constexpr float kTd16Agree = 5.0e-6f;  // chain_td16_kernel stores its spectrum only where it agrees with the fused launch's this closely in every bin (see there)
 constexpr float kTd16GuardRatio = 1.0f / 32.0f; // chain_td16_kernel leaves a frame to the float64 evaluation when its filter output carries less than this x (sum b^2) x its input power: 15 dB below what
                                                 // white noise would pass, where the 22-bit products' error (~1.3e-7 rms of the products' level, its peaks 4 x that) reaches 6e-6 of |Y|^2 (chain.hip kChainPairGuardRatio)
+// Round 6: what a |.|^2 frame is judged on.  The fast convolution's error is K eps-sized relative to the INPUT's level per bin, the parity metric normalises by max(|truth_k|,
+// rms_k(truth)) with truth = |Y_k|^2 -- so the error shows as  K sqrt(R4),  R4 = w2 nf mean|x|^2 / rms_k(|Y_k|^2)  (the input's per-bin power over the rms of the OUTPUT mag2
+// spectrum; w2 = mean window^2, nf = fftSize), not as a function of the power ratio P_out / P_in: a 1 %-pass-band channel filter over wide-band noise (ratio 0.01, R4 = 7: error
+// 1.3e-6) is as accurate as a wide one, a tone 10 dB above the noise that the filter rejects (ratio 0.009, R4 = 25: 7e-6) is not.  Measured K = err / sqrt(R4) over rectangular /
+// Hann / Blackman-Harris / Kaiser frames of 256 .. 8192 points, 33 .. 256 taps, rejected tones 0 .. 60 dB above the noise (tools/dbg/fd_error_vs_statistic2.py): <= 1.3e-6 for
+// R4 <= 100, <= 2.7e-6 anywhere below R4 = 1e4.  Frames with R4 > 8 are marked (2.7e-6 sqrt(8) = 7.6e-6 < 1e-5).  Until round 6 the power ratio < 0.08 marked them: every frame
+// of every filter that passes less than 8 % of white noise (R4 = 2.4 .. 3), three times earlier than needed.
+constexpr float kGuardR4Max = 8.0f;
+// The second condition (round 6, found by tools/fuzz_chain.py's wide mode): a float32 transform leaves IMAGES of a strong line -- rounding errors of c eps |X_peak|, c ~ 1.2, at the
+// bins N/2 (3N/4, 9N/16 ...: the last radix-16 pass) away from it.  Any float32 FFT has them; the reference's sits behind its filter, ours in front: a line the filter takes down
+// by 10 .. 30 dB (in its transition band, or a 2-tap average's single null) still dominates the output's rms, R4 is small, and the image lands in the pass band at full gain next
+// to bins of |Y_k|^2 ~ rms: error 2 c eps wg |X_peak| / sqrt(rms).  Measured over the fuzzer's six cases (tools/dbg/case2.py): err <= 1.4e-7 sqrt(T), T = wg^2 |X_peak|^2 /
+// rms_k(|Y_k|^2) (wg = mean window), 1.06 .. 1.3e-5 at T = 7e3 .. 3e4.  The kernel takes the peak as the largest |Re| / |Im| of the frame's X (one v_max3 per bin; within
+// [1/sqrt2, 1] of |X_peak|) and marks T' = 2 wg^2 peak^2 / rms > kGuardPeakMax, T <= T' <= 2 T: every frame with T >= 2000 (error past 6.3e-6) is marked.  White noise has
+// T' = 13 .. 20 R4 (<= 160 where R4 passes), a line IN the pass band ~ sqrt(N) / |H|^2: neither comes near.
+constexpr float kGuardPeakMax = 2000.0f;
 constexpr float kGuardFrameThreshold = 0.08f; // the guard's output / input power threshold (chain.hip, fir.hip), applied to every frame by itself inside the kernel
 constexpr int kMaxMulti = 16;
 struct ChainFdMulti {
@@ -289,6 +310,30 @@ __device__ __forceinline__ float wave_total_lane63(float v) {
     return v;
 }
 
+// maximum of v (>= 0) over the wave, same network: lands in lane 63.  On the bit patterns (floats >= 0 order as unsigned integers): fmaxf would canonicalise every operand
+// (a v_max_f32 x, x each) and keep the DPP move apart from the maximum
+__device__ __forceinline__ float wave_max_lane63(float vf) {
+    unsigned v = __float_as_uint(vf);
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+    return __uint_as_float(v);
+}
+// max(acc, |x|, |y|) in one instruction (fmaxf(fabsf()) costs three: the compiler canonicalises each operand first)
+__device__ __forceinline__ float max3_abs(float acc, float x, float y) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(acc) : "v"(x), "v"(y));
+    return acc;
+}
+// the largest of eight floats >= 0 (two float4 of LDS), on their bit patterns
+__device__ __forceinline__ float max8_nonneg(const float4& a, const float4& b) {
+    const unsigned m0 = max(max(__float_as_uint(a.x), __float_as_uint(a.y)), max(__float_as_uint(a.z), __float_as_uint(a.w)));
+    const unsigned m1 = max(max(__float_as_uint(b.x), __float_as_uint(b.y)), max(__float_as_uint(b.z), __float_as_uint(b.w)));
+    return __uint_as_float(max(m0, m1));
+}
+
 template <int MODE, int LOG2NF, bool MULTI>
 __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti* mc) {
     constexpr bool WIN   = MODE == kModeWinMag2 || MODE == kModeWinSmall; // y_f is needed in the time domain and multiplied by a.win
@@ -325,7 +370,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
     float2* el = T1 + 256;                           // 256: e[n]
     float*  P  = reinterpret_cast<float*>(el + 256); // [4 K quarters][re, im][256]: partial e; WIN: followed by the pass-B twiddle table [16][32]
     if constexpr (!WIN && !FFTONLY) { // the frames' verdict words (dynamic-range guard) start at zero; the first frame's top barrier comes before anyone reads them
-        if (threadIdx.x < 16) reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + kLdsEbfBytes)[threadIdx.x] = 0.f;
+        if (threadIdx.x < 2 * kGvW) reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + kLdsEbfBytes)[threadIdx.x] = 0.f;
     }
     constexpr bool EBFW = GR4_E_BF16 && GR4_E_BF16_WIN && WIN;                  // windowed modes: the table keeps rows 1 .. 15 only (row 0 is never read), which is the 256 bytes the bf16 planes need
     float*  Dre = P + 4 * 2 * 256 + (WIN ? (EBFW ? 960 : 1024) : 0);                  // kDPad: Dz[s] = d[s - 1] (1 <= s <= 255), zero elsewhere (s <= 511); planar, one pad
@@ -408,10 +453,18 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
     // ... and every frame's own verdict: the sum over the WORKGROUP of out - thr * in (a wave alone will not do: its bins are 64-bin windows 2048 apart, and a narrow
     // pass band lands in the windows of two or three waves).  Each wave adds its total into one of two words of global scratch (L2 atomics, no LDS: the windowed
     // kernels have none to spare, and no barrier of their own: the frame's top barrier orders them), thread 0 collects the sum of the frame before two iterations later.
-    float  pw_dprev = 0.f;  // this lane's out - thr * in of the frame before
+    float  pw_dprev = 0.f;  // this lane's out - thr * in of the frame before (kModeFir) / its sum of |Y_k|^4 (the |.|^2 modes)
+    [[maybe_unused]] float pw_iprev = 0.f; // the |.|^2 modes: this lane's share of the frame's input power
+    [[maybe_unused]] float pw_kprev = 0.f; // the |.|^2 modes: the largest |Re| / |Im| among this lane's bins of the frame's input spectrum
+    [[maybe_unused]] float pw_pend_i = 0.f;
     float  pw_pend = 0.f;   // thread 0: the workgroup sum requested an iteration ago
     float  pw_dmin = 0.f;   // thread 0: the smallest workgroup sum so far (negative: a frame fell below the threshold by itself)
-    float* pw_slot = a.pw != nullptr ? a.pw + kPwFrameSlots + 2 * blockIdx.x : nullptr;
+    unsigned pw_nmark = 0;  // thread 0: how many of this workgroup's frames (MULTI: work items) were marked
+    float* pw_slot = a.pw != nullptr ? a.pw + kPwFrameSlots + 6 * blockIdx.x : nullptr;
+    constexpr bool Q4 = MODE != kModeFir; // judged on the fourth-moment statistic
+    // the frame's verdict from its two workgroup sums: negative = marked (a sum that left float32's range marks too)
+    // (sa: sum of |Y_k|^4, sb: input power, sk: peak component of the input spectrum -- the two conditions of kGuardR4Max / kGuardPeakMax)
+    const auto verdict = [&](float sa, float sb, float sk) { return Q4 ? ((sa < 3.0e38f) ? fminf(fmaf(sa, a.pw_c4, -sb * sb), fmaf(-(sk * sk) * (sk * sk), a.pw_c5i, sa)) : -1.f) : sa; };
     int   iter = 0;
     [[maybe_unused]] int fiter = 0; // frames this workgroup has finished (MULTI: an item is one channel of a frame)
 #pragma unroll
@@ -442,7 +495,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
         const int   kb = 2 * wave + (kq >> 1) + 16 * (kq & 1);
         float2* S  = cur ? B1 : B0;
         float2* Sn = cur ? B0 : B1;
-        [[maybe_unused]] float m2sum = 0.f;
+        [[maybe_unused]] float m2sum = 0.f, m4sum = 0.f;
         const float2* Tc = cur ? T1 : T0;
         GR4_STAMP(0);
         GR4_FULL_BARRIER(); // T: this frame's image has landed (vmcnt(0) + barrier); everything of the previous frame is dead
@@ -450,13 +503,21 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
         if constexpr (!FFTONLY) {
             if (a.pw != nullptr) {
                 const float wt = wave_total_lane63(pw_dprev); // the frame before this one
-                if constexpr (!WIN) { // 64 bytes of LDS behind the image: wave totals of frame i - 1 in, the sum of frame i - 2 out (wave 0); the frame's own barriers order them
+                [[maybe_unused]] float wti = 0.f, wtk = 0.f;
+                if constexpr (Q4) { wti = wave_total_lane63(pw_iprev); wtk = wave_max_lane63(pw_kprev); }
+                if constexpr (!WIN) { // 192 bytes of LDS behind the image: wave totals of frame i - 1 in, the sums of frame i - 2 out (wave 0); the frame's own barriers order them
                     float* Gv = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + kLdsEbfBytes);
-                    if ((threadIdx.x & 63) == 63) Gv[8 * (iter & 1) + (threadIdx.x >> 6)] = wt;
+                    if ((threadIdx.x & 63) == 63) { Gv[kGvW * (iter & 1) + (threadIdx.x >> 6)] = wt; if constexpr (Q4) { Gv[kGvW * (iter & 1) + 8 + (threadIdx.x >> 6)] = wti; Gv[kGvW * (iter & 1) + 16 + (threadIdx.x >> 6)] = wtk; } }
                     if (threadIdx.x < 64) {
-                        const float4 g0 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1)), g1 = *reinterpret_cast<const float4*>(Gv + 8 * ((iter + 1) & 1) + 4);
-                        const float fsum = ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w)); // the frame two iterations back
+                        const float4 g0 = *reinterpret_cast<const float4*>(Gv + kGvW * ((iter + 1) & 1)), g1 = *reinterpret_cast<const float4*>(Gv + kGvW * ((iter + 1) & 1) + 4);
+                        float fsum = ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w)); // the frame two iterations back
+                        if constexpr (Q4) {
+                            const float4 h0 = *reinterpret_cast<const float4*>(Gv + kGvW * ((iter + 1) & 1) + 8), h1 = *reinterpret_cast<const float4*>(Gv + kGvW * ((iter + 1) & 1) + 12);
+                            const float4 k0 = *reinterpret_cast<const float4*>(Gv + kGvW * ((iter + 1) & 1) + 16), k1 = *reinterpret_cast<const float4*>(Gv + kGvW * ((iter + 1) & 1) + 20);
+                            fsum = verdict(fsum, ((h0.x + h0.y) + (h0.z + h0.w)) + ((h1.x + h1.y) + (h1.z + h1.w)), max8_nonneg(k0, k1));
+                        }
                         pw_dmin = fminf(pw_dmin, fsum);
+                        pw_nmark += (unsigned)(fsum < 0.f);
                         if (a.fflags != nullptr && threadIdx.x == 0 && fh2 >= 0) {
                             if constexpr (MULTI) { if (fsum < 0.f) a.fflags[fh2] = 1; } // (several work items per frame: set-only)
                             else a.fflags[fh2] = fsum < 0.f ? 1 : 0;
@@ -464,9 +525,11 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                     }
                 } else { // the windowed kernels fill their 160 KiB to the byte: two words of global scratch per workgroup, L2 atomics
                     pw_dmin = fminf(pw_dmin, pw_pend);
-                    if ((threadIdx.x & 63) == 63) atomicAdd(pw_slot + (iter & 1), wt);
+                    pw_nmark += (unsigned)(pw_pend < 0.f);
+                    if ((threadIdx.x & 63) == 63) { atomicAdd(pw_slot + (iter & 1), wt); if constexpr (Q4) { atomicAdd(pw_slot + 2 + (iter & 1), wti); atomicMax(reinterpret_cast<unsigned*>(pw_slot) + 4 + (iter & 1), __float_as_uint(wtk)); } } // (floats >= 0 order as their bit patterns)
                     if (threadIdx.x == 0) {
                         pw_pend = atomicExch(pw_slot + ((iter + 1) & 1), 0.f); // the frame before that: every wave's share arrived before the barrier above
+                        if constexpr (Q4) { const float si2 = atomicExch(pw_slot + 2 + ((iter + 1) & 1), 0.f); pw_pend = verdict(pw_pend, si2, __uint_as_float(atomicExch(reinterpret_cast<unsigned*>(pw_slot) + 4 + ((iter + 1) & 1), 0u))); } // (a slot nothing was filed in holds zeros: verdict 0, not marked)
                         if (a.fflags != nullptr && fh2 >= 0) a.fflags[fh2] = pw_pend < 0.f ? 1 : 0; // (the windowed modes are single-channel)
                     }
                 }
@@ -512,10 +575,12 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                 for (int m = 0; m < 16; ++m) v[m] = make_float2(v[m].x * wA[m], v[m].y * wA[m]);
             }
             if constexpr (!FFTONLY) {
-                if (measure) { // x[t + 512 m], m = 0, 8: an eighth of the frame's samples, spread over all of it (1024 per workgroup)
-                    float s = 0.f;
+                if (measure) { // every input sample of the frame (GR4_PW_IN_STEP 1), re and im in one v_pk_fma_f32: the lane's samples sit in the register pairs ds_read_b64 filled
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-                    for (int m = 0; m < 16; m += GR4_PW_IN_STEP) s = fmaf(v[m].x, v[m].x, fmaf(v[m].y, v[m].y, s));
+                    for (int m = 0; m < 16; m += GR4_PW_IN_STEP) { const f32x2 vm = {v[m].x, v[m].y}; s2 = __builtin_elementwise_fma(vm, vm, s2); }
+                    const float s = s2.x + s2.y;
                     fr_in = (float)GR4_PW_IN_STEP * s;
                     pw_in += fr_in;
                 }
@@ -658,6 +723,13 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
         float2 X[16];
         passC(S, X, twCr, t);
         GR4_DRAIN(6);
+        [[maybe_unused]] float fr_pk = 0.f; // the largest component of this lane's sixteen bins of X: the frame's peak, for the guard's second condition
+        if constexpr (Q4 && !FFTONLY) {
+            if (measure) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) fr_pk = max3_abs(fr_pk, X[q].x, X[q].y);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if constexpr (!FFTONLY && !(GR4_FMA_COMBINE && MODE == kModeMag2)) X[perm16(q)] = cmul(Hr[q], X[perm16(q)]); // (headline mode: H enters in the combine, as one fma chain onto E)
@@ -732,7 +804,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                 const float2 Y = cadd(X[perm16(q)], w[perm16(q)]);
 #endif
                 const float m2 = fmaf(Y.x, Y.x, Y.y * Y.y);
-                if constexpr (MULTI) m2sum += m2; // (the guard's output power of THIS work item: pend carries the running fold)
+                if constexpr (MULTI) { m2sum += m2; m4sum = fmaf(m2, m2, m4sum); } // (the guard's output sums of THIS work item: pend carries the running fold)
                 pend[q] = (MULTI && ch > 0) ? pend[q] + m2 : m2; // out[t + 512 q], stored during the next frame (MULTI: math::Add's left fold over the channels)
             }
             }
@@ -823,14 +895,28 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
         if constexpr (!FFTONLY) {
             if (measure) { // ALL of the lane's outputs: its sixteen bins t + 512 q are a comb over the whole spectrum, any subset of q is not (a low-pass sits in q = 0 and 15)
                 float fr_out = MULTI ? m2sum : 0.f;
-                if constexpr (!MULTI) {
+                [[maybe_unused]] float fr_o4 = MULTI ? m4sum : 0.f; // sum of |Y_k|^4 over this lane's bins
+                if constexpr (!MULTI && !Q4) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) fr_out += MODE == kModeFir ? fmaf(pend[q], pend[q], pendi[q] * pendi[q]) : pend[q];
+                    for (int q = 0; q < 16; ++q) fr_out += fmaf(pend[q], pend[q], pendi[q] * pendi[q]);
+                }
+                if constexpr (!MULTI && Q4) { // two bins per instruction (v_pk_fma_f32 / v_pk_add_f32)
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    f32x2 a4 = {0.f, 0.f}, a2 = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const f32x2 pq = {pend[q], pend[q + 1]};
+                        a4 = __builtin_elementwise_fma(pq, pq, a4);
+                        a2 += pq;
+                    }
+                    fr_o4  = a4.x + a4.y;
+                    fr_out = a2.x + a2.y;
                 }
                 pw_out += fr_out;
                 // the frame's own verdict, per wave (1024 of its points): the wave's sum of out - thr * in on the DPP network (it lands in lane 63; the other lanes keep
                 // partial sums nobody reads), its minimum over the frames kept per lane -- no LDS, no barrier, no branch
-                pw_dprev = fmaf(-a.pw_thr, fr_in, fr_out); // (summed over the wave at the top of the next iteration: the DPP sequence here costs the compiler ten spills)
+                if constexpr (Q4) { pw_dprev = fr_o4; pw_iprev = fr_in; pw_kprev = fr_pk; }
+                else pw_dprev = fmaf(-a.pw_thr, fr_in, fr_out); // (summed over the wave at the top of the next iteration: the DPP sequence here costs the compiler ten spills)
             }
         }
         fh2 = fh1; fh1 = f; // (the frames of the last two work items: whose verdict sums thread 0 meets one / two iterations later)
@@ -854,10 +940,13 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
             }
             {   // the last two frames' verdicts
                 const float wt = wave_total_lane63(pw_dprev);
+                [[maybe_unused]] float wti = 0.f, wtk = 0.f;
+                if constexpr (Q4) { wti = wave_total_lane63(pw_iprev); wtk = wave_max_lane63(pw_kprev); }
                 if constexpr (!WIN) {
-                    if ((threadIdx.x & 63) == 63) reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + kLdsEbfBytes)[8 * (iter & 1) + (threadIdx.x >> 6)] = wt;
+                    float* Gv = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + kLdsEbfBytes);
+                    if ((threadIdx.x & 63) == 63) { Gv[kGvW * (iter & 1) + (threadIdx.x >> 6)] = wt; if constexpr (Q4) { Gv[kGvW * (iter & 1) + 8 + (threadIdx.x >> 6)] = wti; Gv[kGvW * (iter & 1) + 16 + (threadIdx.x >> 6)] = wtk; } }
                 } else {
-                    if ((threadIdx.x & 63) == 63) atomicAdd(pw_slot + (iter & 1), wt);
+                    if ((threadIdx.x & 63) == 63) { atomicAdd(pw_slot + (iter & 1), wt); if constexpr (Q4) { atomicAdd(pw_slot + 2 + (iter & 1), wti); atomicMax(reinterpret_cast<unsigned*>(pw_slot) + 4 + (iter & 1), __float_as_uint(wtk)); } }
                 }
             }
             __syncthreads(); // (P below is not a DMA target; every lane is past its last use of it)
@@ -871,11 +960,25 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                 if constexpr (!WIN) {
                     const float* Gv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + kLdsEbfBytes);
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) { s0 += Gv[w]; s1 += Gv[8 + w]; }
+                    for (int w = 0; w < 8; ++w) { s0 += Gv[w]; s1 += Gv[kGvW + w]; }
+                    if constexpr (Q4) {
+                        float i0 = 0.f, i1 = 0.f, k0 = 0.f, k1 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) { i0 += Gv[8 + w]; i1 += Gv[kGvW + 8 + w]; k0 = __uint_as_float(max(__float_as_uint(k0), __float_as_uint(Gv[16 + w]))); k1 = __uint_as_float(max(__float_as_uint(k1), __float_as_uint(Gv[kGvW + 16 + w]))); }
+                        s0 = verdict(s0, i0, k0); // (a slot nothing was filed in holds zeros: verdict 0, not marked)
+                        s1 = verdict(s1, i1, k1);
+                    }
                     pw_dmin = fminf(pw_dmin, fminf(s0, s1));
+                    pw_nmark += (unsigned)(s0 < 0.f) + (unsigned)(s1 < 0.f);
                 } else {
                     s0 = atomicExch(pw_slot, 0.f); s1 = atomicExch(pw_slot + 1, 0.f); // (the slots are zero again for the next launch)
+                    if constexpr (Q4) {
+                        const float i0 = atomicExch(pw_slot + 2, 0.f), i1 = atomicExch(pw_slot + 3, 0.f);
+                        s0 = verdict(s0, i0, __uint_as_float(atomicExch(reinterpret_cast<unsigned*>(pw_slot) + 4, 0u)));
+                        s1 = verdict(s1, i1, __uint_as_float(atomicExch(reinterpret_cast<unsigned*>(pw_slot) + 5, 0u)));
+                    }
                     pw_dmin = fminf(fminf(pw_dmin, pw_pend), fminf(s0, s1));
+                    pw_nmark += (unsigned)(pw_pend < 0.f) + (unsigned)(s0 < 0.f) + (unsigned)(s1 < 0.f);
                 }
                 if (a.fflags != nullptr) { // the last two work items: fh1 the last, fh2 the one before it
                     const float last = (iter & 1) ? s1 : s0, before = (iter & 1) ? s0 : s1;
@@ -887,7 +990,7 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                         if (fh2 >= 0) a.fflags[fh2] = before < 0.f ? 1 : 0;
                     }
                 }
-                if (pw_dmin < 0.f) atomicOr(reinterpret_cast<unsigned*>(a.pw + 33), 1u);
+                if (pw_dmin < 0.f) atomicAdd(reinterpret_cast<unsigned*>(a.pw + 33), pw_nmark ? pw_nmark : 1u); // (word 33: how many frames of this launch were marked)
                 float si = 0.f, so = 0.f;
 #pragma unroll
                 for (int w = 0; w < kT / 64; ++w) { si += P[2 * w]; so += P[2 * w + 1]; }
@@ -901,7 +1004,9 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
                     float tin = 0.f, tout = 0.f;
                     for (int k = 0; k < 16; ++k) { tin += atomicExch(a.pw + 2 * k, 0.f); tout += atomicExch(a.pw + 2 * k + 1, 0.f); }
                     atomicExch(done, 0u);
-                    reinterpret_cast<volatile unsigned*>(a.pw_host)[3] = atomicExch(reinterpret_cast<unsigned*>(a.pw + 33), 0u); // a frame of this launch fell below the threshold
+                    const unsigned nm = atomicExch(reinterpret_cast<unsigned*>(a.pw + 33), 0u);
+                    reinterpret_cast<volatile unsigned*>(a.pw_host)[3] = nm; // how many frames of this launch were marked
+                    if (a.no_tier && nm) atomicAdd_system(reinterpret_cast<unsigned*>(a.pw_host) + 4, nm); // no 22-bit tier behind this launch: every one of them is a float64 frame (the running total chain_td16_kernel adds to otherwise)
                     // ONE 8-byte store: the pair arrives whole; then, behind a system-scope fence, the launch's sequence number -- what a waiting host spins on
                     // (a few microseconds after the last workgroup instead of a stream synchronisation's wake-up)
                     *reinterpret_cast<volatile unsigned long long*>(a.pw_host) = (unsigned long long)__float_as_uint(tin) | ((unsigned long long)__float_as_uint(tout) << 32);
@@ -1110,7 +1215,7 @@ static_assert(kT16NS % 16 == 0, "whole 16-sample groups");
 template <int MODE, int LOG2NF>
 __device__ __forceinline__ void chain_td16_body(ChainFdArgs& a) {
     constexpr bool WIN = MODE != kModeMag2, SMALL = MODE == kModeWinSmall;
-    constexpr int  KS = kT16KS, Hb = kT16Hb, NS = kT16NS, PL = kT16PL, NL4 = kT16NL4, NM = KS + 1;
+    constexpr int  KS = kT16KS, Hb = kT16Hb, NS = kT16NS, PL = kT16PL, NL4 = kT16NL4;
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2*         S   = smem;
     unsigned short* pls = reinterpret_cast<unsigned short*>(smem + kSLen); // planes re1, re2, im1, im2
@@ -1165,6 +1270,7 @@ __device__ __forceinline__ void chain_td16_body(ChainFdArgs& a) {
             v4[u] = make_float4(__uint_as_float(vx[0] | vh[0]), __uint_as_float(vx[1] | vh[1]), __uint_as_float(vx[2] | vh[2]), __uint_as_float(vx[3] | vh[3]));
         }
     };
+    unsigned n_esc = 0; // frames this workgroup left to the float64 evaluation
     long f = next_marked(blockIdx.x);
     if (f < a.n_frames) load_frame(f);
     for (; f < a.n_frames;) {
@@ -1198,7 +1304,7 @@ __device__ __forceinline__ void chain_td16_body(ChainFdArgs& a) {
         const int e = (int)(mx >> 23), el = (int)(mq >> 23);
         // a non-finite sample, a spread beyond what one block exponent carries, powers outside float32's range: the float64 evaluation's frame (it leaves a non-finite one as the fused kernel wrote it)
         const bool hard = e == 255 || px != px || (mq != 0xffffffffu && e - el > kHfMaxRange) || (mx != 0u && (e < 127 - 60 || e > 127 + 60));
-        if (hard) { if (t == 0) a.fflags[f] = 2; f = fnext; if (f < a.n_frames) load_frame(f); continue; } // (uniform)
+        if (hard) { if (t == 0) a.fflags[f] = 2; ++n_esc; f = fnext; if (f < a.n_frames) load_frame(f); continue; } // (uniform)
         const int   ec = e < 15 ? 15 : (e > 254 ? 254 : e);
         const float s_cur = __uint_as_float((unsigned)(268 - ec) << 23), inv_cur = __uint_as_float((unsigned)(ec - 14) << 23);
 #pragma unroll
@@ -1303,7 +1409,7 @@ __device__ __forceinline__ void chain_td16_body(ChainFdArgs& a) {
 #ifdef GR4_T16_NOFFT // timing-only build: no transform, no result
         if (py != 12345.f) { if (f < a.n_frames) load_frame(f); continue; }
 #endif
-        if (!(py >= gthr * px)) { if (t == 0) a.fflags[fcur] = 2; if (f < a.n_frames) load_frame(f); continue; } // (uniform) the filter removes too much of what it is given for 22-bit products: float64 behind this launch
+        if (!(py >= gthr * px)) { if (t == 0) a.fflags[fcur] = 2; ++n_esc; if (f < a.n_frames) load_frame(f); continue; } // (uniform) the filter removes too much of what it is given for 22-bit products: float64 behind this launch
         // ---- the frame transform and |.|^2 (chain_redo_kernel's)
         float* out = a.out + fcur * kN;
         if constexpr (SMALL) {
@@ -1355,11 +1461,35 @@ __device__ __forceinline__ void chain_td16_body(ChainFdArgs& a) {
             __syncthreads();
             GR4_T16_STAMP(6, fcur);
             passC(S, X, twr, t);
+            // ---- the second opinion: this frame's spectrum from the fused launch is still in `out`.  The two evaluations err in different ways -- the fast convolution by K sqrt(R4)
+            // spread over the bins, the 22-bit products COHERENTLY where a tone is rejected (its residue is off by 2^-22 sum|b| / |H(f)| of itself: 4.7e-5 measured on a 17-tap filter
+            // 51 dB down, tools/fuzz_chain.py wide) -- so where they agree within kTd16Agree of max(value, rms of the frame's |Y|^2) in EVERY bin both are right and this one is stored;
+            // where they do not, nobody knows which, and the frame goes to the float64 evaluation
+            float m2[16], s4 = 0.f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) out[t + 512 * q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y);
+            for (int q = 0; q < 16; ++q) { m2[q] = fmaf(X[perm16(q)].x, X[perm16(q)].x, X[perm16(q)].y * X[perm16(q)].y); s4 = fmaf(m2[q], m2[q], s4); }
+            s4 = hf_wave_sum(s4);
+            if (lane == 0) st[32 + wave] = __float_as_uint(s4);
+            __syncthreads();
+            s4 = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < 8; ++w_) s4 += __uint_as_float(st[32 + w_]);
+            const float l2 = __builtin_sqrtf(s4 * (1.f / (float)kN)); // rms_k |Y_k|^2
+            int bad = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float fd = out[t + 512 * q];
+                bad |= (int)!(__builtin_fabsf(m2[q] - fd) <= kTd16Agree * __builtin_fmaxf(__builtin_fmaxf(m2[q], fd), l2)); // (a NaN anywhere: not agreed)
+            }
+            if (__syncthreads_or(bad)) { if (t == 0) a.fflags[fcur] = 2; ++n_esc; continue; } // (uniform)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) out[t + 512 * q] = m2[q];
             GR4_T16_STAMP(7, fcur);
         }
     }
+    // how many frames went on to the float64 evaluation: a running total in the page-locked word behind the launch's measurement (the host decides with it whether the stream is
+    // better off on the time-domain kernel pair: chain.hip)
+    if (t == 0 && n_esc && a.pw_host != nullptr) atomicAdd_system(reinterpret_cast<unsigned*>(a.pw_host) + 4, n_esc);
 }
 template <int MODE, int LOG2NF = 13>
 __global__ __launch_bounds__(kT, 1) void chain_td16_kernel(ChainFdArgs a) { chain_td16_body<MODE, LOG2NF>(a); }
@@ -1399,9 +1529,13 @@ struct ChainFused {
     unsigned     pw_seen  = 0;         // sequence number of the last measurement handed out
     hipStream_t  pw_stream = nullptr;  // stream of the last measured launch
     float        win_gain = 1.f;       // mean w[n]^2 of the window the measured output carries (1: none)
+    float        win_mean = 1.f;       // mean w[n] (what a line keeps of its height)
     bool         redo     = false;     // measured launches also mark their frames one by one and chain_redo_kernel follows them (chain.hip, GR4HIP_GUARD_STRICT)
     bool         zero_hist = true;     // reset asked for (or nothing has run yet): the carried history is zeroed on the stream of the next call that reads it (common.hpp, the stream rule)
     unsigned     pw_floor = 0;         // measurements of launches up to this one belong to the stream before the last reset
+    size_t       pw_items = 0;         // frames (x channels of a folded launch) the last measured launch judged
+    size_t       judged = 0;           // frames judged since create / reset ...
+    unsigned     f64_floor = 0;        // the running total of word 4 (frames that went on to float64) at the last reset
     DeviceBuffer d_fflags;             // one byte per frame of the last launch
     DeviceBuffer d_hfrag;              // the two-term f16 tap table of chain_td16_kernel (null: taps that form cannot carry -- the float64 evaluation takes every marked frame)
     bool         td16 = false;
@@ -1494,9 +1628,10 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
         std::vector<float> w(fft_size, 1.f), wt(kN);
         if (window != GR4HIP_WIN_NONE && window != GR4HIP_WIN_RECTANGULAR) rc = make_window(window, w.data(), fft_size, 1.6f); // fft.hpp:141: default beta
         for (int n = 0; n < kN; ++n) wt[n] = w[n % fft_size] * (1.0f / (float)kN);
-        double g = 0;
-        for (size_t n = 0; n < fft_size; ++n) g += (double)w[n] * w[n];
+        double g = 0, g1 = 0;
+        for (size_t n = 0; n < fft_size; ++n) { g += (double)w[n] * w[n]; g1 += (double)w[n]; }
         c->win_gain = (float)(g / (double)fft_size);
+        c->win_mean = (float)(g1 / (double)fft_size);
         if (!rc) rc = upload(c->d_win, wt);
     }
     if (!rc && c->small_log2n) {
@@ -1522,6 +1657,8 @@ int chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t
 int chain_fused_reset(ChainFused* c) {
     c->zero_hist = true;
     c->pw_floor  = c->pw_seq; // what launches of the old stream measured decides nothing for the new one
+    c->judged = 0;
+    if (c->h_pw) c->f64_floor = reinterpret_cast<volatile unsigned*>(c->h_pw)[4];
     return GR4HIP_OK;
 }
 // the carried history as the next call must see it, in stream order
@@ -1536,12 +1673,12 @@ static int history_on(ChainFused* c, hipStream_t st) {
 // dynamic-range guard: this launch of `c` is a measured one (accumulators and the mapped result word exist from the first time on)
 static int arm_measure(ChainFused* c, hipStream_t st) {
     if (!c->h_pw) {
-        constexpr size_t words = kPwFrameSlots + 2 * kPwMaxWorkgroups; // 16 {in, out} slots, the done counter, the flag word, two verdict words per workgroup
+        constexpr size_t words = kPwFrameSlots + 6 * kPwMaxWorkgroups; // 16 {in, out} slots, the done counter, the flag word, four verdict words per workgroup
         int rc = c->d_pw.ensure(words * sizeof(float));
         if (rc) return rc;
         GR4_HIP_TRY(hipMemsetAsync(c->d_pw.ptr, 0, words * sizeof(float), st)); // (in front of the first measured launch, on its stream)
-        GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 4 * sizeof(float), hipHostMallocMapped));
-        std::memset(c->h_pw, 0, 4 * sizeof(float));
+        GR4_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_pw), 8 * sizeof(float), hipHostMallocMapped)); // {in, out, sequence number, frames marked, frames left to float64 (running total), -, -, -}
+        std::memset(c->h_pw, 0, 8 * sizeof(float));
         GR4_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_hpw), c->h_pw, 0));
     }
     ++c->pw_seq;
@@ -1560,28 +1697,15 @@ static int second_evaluations(ChainFused* c, ChainFdArgs a, size_t n_frames, hip
     if (first) {
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
         GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinMag2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
-        GR4_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_td16_kernel<kModeWinSmall, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kT16LdsBytes));
         per_device.done(dev, -n);
     }
     const unsigned rg = (unsigned)std::min<size_t>(n_frames, (size_t)n_cu);
     const int      nt = (int)c->ntaps;
-    if (c->td16) {
+    if (c->td16 && c->small_log2n == 0) { // (frames of fewer than 8192 points: float64 for every marked block -- the agreement test below is per 8192-point spectrum)
         a.hfrag    = static_cast<const unsigned short*>(c->d_hfrag.ptr);
         a.td16_thr = kTd16GuardRatio;
-        switch (c->small_log2n) {
-        case 8: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 8>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
-        case 9: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 9>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
-        case 10: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 10>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
-        case 11: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 11>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
-        case 12: hipLaunchKernelGGL((chain_td16_kernel<kModeWinSmall, 12>), dim3(rg), dim3(kT), kT16LdsBytes, st, a); break;
-        default:
-            if (c->windowed) hipLaunchKernelGGL(chain_td16_kernel<kModeWinMag2>, dim3(rg), dim3(kT), kT16LdsBytes, st, a);
-            else hipLaunchKernelGGL(chain_td16_kernel<kModeMag2>, dim3(rg), dim3(kT), kT16LdsBytes, st, a);
-        }
+        if (c->windowed) hipLaunchKernelGGL(chain_td16_kernel<kModeWinMag2>, dim3(rg), dim3(kT), kT16LdsBytes, st, a);
+        else hipLaunchKernelGGL(chain_td16_kernel<kModeMag2>, dim3(rg), dim3(kT), kT16LdsBytes, st, a);
         GR4_LAUNCH_CHECK();
         a.redo_min_flag = 2;
     }
@@ -1634,10 +1758,20 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     if (measure) {
         int rc = arm_measure(c, st);
         if (rc) return rc;
+        c->pw_items = n_frames;
+        c->judged += n_frames;
         a.pw      = static_cast<float*>(c->d_pw.ptr);
         a.pw_host = c->d_hpw;
         a.pw_seq  = c->pw_seq;
         a.pw_thr  = fir_mode ? kGuardFirFrameThreshold : kGuardFrameThreshold * (float)(c->small_log2n ? (1 << c->small_log2n) : kN) * c->win_gain; // (the scale chain_fused_power_ratio takes out)
+        {   // R4 = scale S_in / (sqrt(8192) sqrt(S4)), scale = nf w2 (sums over one 8192-sample block): marked when R4 > kGuardR4Max  <=>  S4 R4max^2 8192 / scale^2 < S_in^2
+            const double scale = (double)(c->small_log2n ? (1 << c->small_log2n) : kN) * (double)c->win_gain;
+            a.pw_c4 = (float)((double)kGuardR4Max * kGuardR4Max * (double)kN / (scale * scale));
+            // T' = 2 wg^2 (peak nf / 8192)^2 / sqrt(S4 / 8192) > Tmax  <=>  S4 < peak^4 x 4 wg^4 nf^4 / (Tmax^2 8192^3)   (peak: of the 8192-point X of the block)
+            const double nfr = (double)(c->small_log2n ? (1 << c->small_log2n) : kN) / (double)kN, wg2 = (double)c->win_mean * c->win_mean;
+            a.pw_c5i = (float)(4.0 * wg2 * wg2 * nfr * nfr * nfr * nfr * (double)kN / ((double)kGuardPeakMax * kGuardPeakMax));
+            a.no_tier = (c->td16 && c->small_log2n == 0) ? 0 : 1; // (second_evaluations: chain_td16_kernel first, where the taps have an f16 table and the frames 8192 points)
+        }
         if (c->redo && !fir_mode) {
             rc = c->d_fflags.ensure(n_frames);
             if (rc) return rc;
@@ -1651,8 +1785,8 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
     // two frame buffers, two tails, e | partial tiles (+ WIN: pass-B twiddle table), planar padded d, taps
     constexpr size_t lds_base = (size_t)(2 * kSLen + 512 + 256) * sizeof(float2) + (size_t)(4 * 2 * 256 + 2 * kDPad + 272) * sizeof(float);
     constexpr size_t lds_win  = lds_base + ((GR4_E_BF16 && GR4_E_BF16_WIN) ? 960 * sizeof(float) + 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 1024 * sizeof(float)); // = 160 KiB exactly with the bf16 planes
-    constexpr size_t lds_ebf  = lds_base + (GR4_E_BF16 ? 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 0) + 64; // non-windowed filter modes: six bf16 planes of Dz instead of Dre / Dim / hl, + the 16 verdict words
-    static_assert(!GR4_E_BF16 || lds_ebf == (size_t)kLdsEbfBytes + 64, "the kernel's verdict words sit behind the image");
+    constexpr size_t lds_ebf  = lds_base + (GR4_E_BF16 ? 6 * 512 * sizeof(unsigned short) - (2 * kDPad + 272) * sizeof(float) : 0) + kGvBytes; // non-windowed filter modes: six bf16 planes of Dz instead of Dre / Dim / hl, + the verdict words
+    static_assert(!GR4_E_BF16 || lds_ebf == (size_t)kLdsEbfBytes + kGvBytes, "the kernel's verdict words sit behind the image");
     static_assert(lds_win <= 160 * 1024 && lds_ebf <= 160 * 1024, "LDS budget of one CU");
     const size_t lds  = (c->windowed && !fir_mode && !fft_only) ? lds_win : (fft_only ? lds_base : lds_ebf);
     static PerDevice per_device; // LDS opt-in and CU count, once per device this process uses
@@ -1707,38 +1841,8 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
 
 // n_frames counts FFT frames of the plan's fftSize.  At fftSize < 8192 whole 8192-sample blocks go through the kernel directly; the frames
 // behind the last whole block (< 8192 samples) are copied into a zero-padded staging block, transformed, and only their spectra copied out.
-// n_blocks 8192-sample blocks entirely in the time domain (a stream the dynamic-range guard has moved there): every block's flag byte is set to 1 and the second evaluations
-// run as behind a fused launch that had marked them all -- chain_td16_kernel, then chain_redo_kernel on what that one leaves (float64)
-static int chain_fused_td_run(ChainFused* c, const float* d_in, size_t n_blocks, float* d_out, hipStream_t st, bool carry_hist) {
-    if (!c->td16) { set_error("fused chain: no time-domain form for these taps"); return GR4HIP_UNSUPPORTED; }
-    if (const int rc = history_on(c, st)) return rc;
-    if (const int rc = c->d_fflags.ensure(n_blocks)) return rc;
-    GR4_HIP_TRY(hipMemsetAsync(c->d_fflags.ptr, 1, n_blocks, st));
-    ChainFdArgs a{};
-    a.x        = reinterpret_cast<const float2*>(d_in);
-    a.hist     = static_cast<const float2*>(c->d_hist.ptr);
-    a.twB      = static_cast<const float2*>(c->d_twB.ptr);
-    a.twC      = static_cast<const float2*>(c->d_twC.ptr);
-    a.taps     = static_cast<const float*>(c->d_taps.ptr);
-    a.win      = static_cast<const float*>(c->d_win.ptr);
-    a.twS      = static_cast<const float2*>(c->d_twS.ptr);
-    a.out      = d_out;
-    a.n_frames = (long)n_blocks;
-    a.fflags   = static_cast<unsigned char*>(c->d_fflags.ptr);
-#ifdef GR4_FD_TIMING
-    if (!g_dbg) GR4_HIP_TRY(hipMalloc(&g_dbg, (size_t)1 << 26));
-    if (n_blocks * 8 * 16 * 8 <= ((size_t)1 << 26)) a.dbg = g_dbg;
-#endif
-    if (const int rc = second_evaluations(c, a, n_blocks, st)) return rc;
-    if (carry_hist) GR4_HIP_TRY(hipMemcpyAsync(c->d_hist.ptr, a.x + n_blocks * (size_t)kN - 256, 256 * sizeof(float2), hipMemcpyDeviceToDevice, st));
-    return GR4HIP_OK;
-}
-bool chain_fused_has_td(const ChainFused* c) { return c->td16; }
-
-int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st, bool td) {
-    const auto run = [&](const float* in, size_t blocks, float* out, bool carry) {
-        return td ? chain_fused_td_run(c, in, blocks, out, st, carry) : chain_fused_run(c, in, nullptr, blocks, out, st, false, carry);
-    };
+int chain_fused_process(ChainFused* c, const float* d_in, size_t n_frames, float* d_mag2, hipStream_t st) {
+    const auto run = [&](const float* in, size_t blocks, float* out, bool carry) { return chain_fused_run(c, in, nullptr, blocks, out, st, false, carry); };
     if (c->small_log2n == 0) return run(d_in, n_frames, d_mag2, true);
     const size_t nf = (size_t)1 << c->small_log2n, per_block = kN / nf;
     const size_t blocks = n_frames / per_block, rem = n_frames % per_block; // rem fft-frames = rem * nf samples (>= 256 each)
@@ -1812,6 +1916,8 @@ int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps,
         if (measure) {
             int rc = arm_measure(c, st);
             if (rc) return rc;
+            c->pw_items = fold ? n_frames * n : n_frames;
+            c->judged += c->pw_items;
             m.pws[i] = static_cast<float*>(c->d_pw.ptr);
             m.pw_hosts[i] = c->d_hpw;
             m.pw_seqs[i] = c->pw_seq;
@@ -1825,7 +1931,10 @@ int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps,
     }
     if (fold) { a.pw = m.pws[0]; a.pw_host = m.pw_hosts[0]; a.pw_seq = m.pw_seqs[0]; a.fflags = m.fflags[0]; }
     a.pw_thr = kGuardFrameThreshold * (float)kN; // (8192-point rectangular-window chains only: window gain 1)
-    constexpr size_t lds = (size_t)kLdsEbfBytes + 64; // = lds_ebf of chain_fused_run
+    a.pw_c4  = kGuardR4Max * kGuardR4Max / (float)kN;
+    a.pw_c5i = 4.0f * (float)kN / (kGuardPeakMax * kGuardPeakMax);
+    a.no_tier = 1; // (the multi launch's marked frames go to chain_redo_kernel / chain_redo_fold_kernel)
+    constexpr size_t lds = (size_t)kLdsEbfBytes + kGvBytes; // = lds_ebf of chain_fused_run
     static PerDevice per_device;
     bool             first = false;
     int              dev = -1, n_cu = per_device.current(&first, &dev);
@@ -1919,7 +2028,7 @@ int chain_fused_redo(ChainFused* c, const float* d_in, const float* d_hist, int 
     GR4_LAUNCH_CHECK();
     return GR4HIP_OK;
 }
-int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio) {
+int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio, float* marked_fraction, float* float64_fraction) {
     if (!c->h_pw || c->pw_seq == c->pw_read || c->pw_seq == c->pw_floor) return 0;
     volatile unsigned* seqw = reinterpret_cast<volatile unsigned*>(c->h_pw) + 2; // sequence number of the launch whose pair the word holds
     if (wait) { // spin on the mapped word the launch's last workgroup writes; every 4096 polls check that the stream has not simply failed / finished without it
@@ -1945,8 +2054,15 @@ int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* r
     *ratio = in > 0 ? (float)(out / (in * (fir_output ? 1.0 : nfft * c->win_gain))) : 1.f;
     // the launch-wide ratio can hide a frame: an interferer that arrives late in a long span barely moves the sums.  Every frame is judged by itself in the kernel
     // (a quarter of its points, per wave); a launch with ONE frame below the threshold reports below the threshold
-    const float thr = fir_output ? kGuardFirFrameThreshold : kGuardFrameThreshold;
-    if (reinterpret_cast<volatile unsigned*>(c->h_pw)[3] != 0u && *ratio >= thr) *ratio = 0.5f * thr;
+    const unsigned n_marked = reinterpret_cast<volatile unsigned*>(c->h_pw)[3];
+    if (float64_fraction) { // of the frames judged since the last reset, how many took the float64 evaluation (as far as the kernels' running totals have arrived)
+        const size_t n64 = (size_t)(reinterpret_cast<volatile unsigned*>(c->h_pw)[4] - c->f64_floor); // (chain_td16_kernel's escalations; the marked frames of launches without that tier)
+        *float64_fraction = c->judged ? std::min(1.f, (float)n64 / (float)c->judged) : 0.f;
+    }
+    if (marked_fraction) *marked_fraction = c->pw_items ? std::min(1.f, (float)n_marked / (float)c->pw_items) : (n_marked ? 1.f : 0.f);
+    // kModeFir (y itself is the output): the launch reports below the threshold as soon as ONE frame is.  The |.|^2 modes (round 6) report the power ratio as it is: what their
+    // frames are judged on is the fourth-moment statistic (kGuardR4Max), and what the caller decides on is the fraction of frames that were marked
+    if (fir_output && n_marked != 0u && *ratio >= kGuardFirFrameThreshold) *ratio = 0.5f * kGuardFirFrameThreshold;
     return 1;
 }
 // the 256 samples before the next call's first frame, valid for work enqueued on `st` behind this call (null: the pending zeroing could not be enqueued)

@@ -289,7 +289,7 @@ struct ChainFused;
 int  chain_fused_create(ChainFused** out, const float* taps, size_t ntaps, size_t fft_size, int window, int algo);
 int  chain_fused_fir(ChainFused* c, const float* d_in, const float* d_hist256, size_t n_frames, float* d_y, hipStream_t st);
 void chain_fused_set_measure(ChainFused* c, bool on);
-int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio);
+int  chain_fused_power_ratio(ChainFused* c, bool wait, bool fir_output, float* ratio, float* marked_fraction = nullptr, float* float64_fraction = nullptr);
 void chain_fused_destroy(ChainFused* c);
 
 // fir_decim_fd.hip: decimate-by-8 real FIR (<= 1024 taps) as overlap-save blocks in the frequency domain

@@ -343,17 +343,22 @@ int gr4hip_chain_reset(gr4hip_chain_t* chain);
 int gr4hip_chain_process(gr4hip_chain_t* chain, const void* d_in_c32, size_t n_samples, float* d_mag2, size_t* n_frames,
                          gr4hip_stream_t stream);
 int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
-/* Dynamic-range guard of GR4HIP_CHAIN_AUTO.  The fused kernels filter in the frequency domain and carry the float32 rounding of their transforms: an error
- * floor of ~2e-6 of the INPUT rms per output sample (measured worst case 1.3e-6).  The parity bar is 1e-5 of the OUTPUT and |Y|^2 doubles the relative error of Y, so they meet it
- * while the filter passes at least -11 dB of the input power (power ratio >= 0.08; 0.04 until round 5, when the chain fuzzer found frames just above it at 1.02 - 1.29e-5)
- * and miss it when a strong out-of-band signal is removed.  Every fused launch of an AUTO chain therefore measures input and
- * output power of EVERY frame (all of its samples and bins; a frame whose own ratio is below the threshold marks the launch, whatever the launch's totals say:
- * an interferer that sets in for the last few frames of a long span is seen); what happens with the measurement is the handle's guard mode (gr4hip_chain_set_guard_mode below; default STRICT: the
- * frames a launch marks are evaluated again in the time domain by a second launch enqueued behind it, and a later call that finds a launch-wide ratio below 0.08 moves
- * the stream to the direct-form kernels -- history handed over -- where it stays until gr4hip_chain_reset).  Explicit GR4HIP_CHAIN_FUSED_FD never measures nor switches.  This call waits for the last measured
- * launch and returns its ratio (< 0: nothing measured yet; the launch's totals -- or half the threshold when they are above it but one frame by itself was not)
- * and whether the chain now runs in the time domain. */
+/* Dynamic-range guard of GR4HIP_CHAIN_AUTO.  The fused kernels filter in the frequency domain and carry the float32 rounding of their transforms, which is sized by the
+ * frame's INPUT, while the parity bar (1e-5 of max(|Y_k|^2, rms_k |Y_k|^2)) is sized by its OUTPUT.  Every fused launch of an AUTO chain therefore judges EVERY frame (all of its
+ * samples and bins) on two statistics (round 6; chain_fused.hip kGuardR4Max / kGuardPeakMax have the measurements):
+ *   R4 = w2 nf mean|x|^2 / rms_k |Y_k|^2 > 8     the spread error, K sqrt(R4) with K <= 2.7e-6: wide-band input the filter removes most of (a 1 %-pass-band filter over white
+ *                                                noise has R4 = 6 .. 13, a 4 % one 3 .. 5), or a rejected interferer;
+ *   T' = 2 wg^2 peak(X)^2 / rms_k |Y_k|^2 > 2000  the images a float32 transform leaves of a strong line (1.2 eps of it, half a transform away): a line the filter takes down by
+ *                                                10 .. 30 dB that still dominates the output.
+ * (Until round 6 the test was output / input power < 0.08, which marked every frame of every narrow filter -- three times earlier than needed -- and missed the second case.)
+ * What happens with the verdicts is the handle's guard mode (gr4hip_chain_set_guard_mode below; default STRICT: the frames a launch marks are evaluated again in the time domain
+ * by launches enqueued behind it -- on the f16 matrix pipe where that agrees with the fused result, in float64 where it does not -- and a stream in which more than a tenth of
+ * all frames end in float64 moves to the direct-form kernels, history handed over, where it stays until gr4hip_chain_reset).  Explicit GR4HIP_CHAIN_FUSED_FD never measures nor
+ * switches.  gr4hip_chain_last_power_ratio waits for the last measured launch and returns its output / input power (window gain taken out; < 0: nothing measured yet --
+ * informative since round 6) and whether the chain now runs in the time domain; gr4hip_chain_last_guard_fractions the fraction of that launch's frames the kernel marked
+ * (< 0: nothing measured yet) and the fraction of all frames since create / reset that went on to float64. */
 int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time_domain, gr4hip_stream_t stream);
+int gr4hip_chain_last_guard_fractions(gr4hip_chain_t* chain, float* marked, float* float64, gr4hip_stream_t stream);
 /* What the guard does with its measurement (per handle; GR4HIP_CHAIN_AUTO chains on the fused frequency-domain kernel only, a no-op elsewhere):
  *   GR4HIP_GUARD_STRICT (default): nothing out of tolerance is ever handed out, and nobody waits.  The fused kernel writes one verdict byte per frame; chain_redo_kernel,
  *     enqueued behind it on the same stream, evaluates exactly the marked frames again -- y = sum b[k] x[n - k] on the FP64 matrix pipe, window, frame transform,

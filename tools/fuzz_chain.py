@@ -20,12 +20,19 @@ while time.time() - t0 < secs:
     win = str(rng.choice(["None", "Hann", "Hamming", "BlackmanHarris"]))
     frames = int(rng.integers(20, 400)) if N >= 2048 else int(rng.integers(100, 3000))
     n = frames * N
-    taps = lowpass(nt, float(rng.choice([0.02, 0.05, 0.2])))
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"  # round 6 (the fourth-moment guard): narrower filters, interferers from -5 dB, anywhere outside the pass band, sometimes a second one, sometimes a burst
+    fc = float(rng.choice([0.0025, 0.005, 0.01, 0.02, 0.05, 0.2] if wide else [0.02, 0.05, 0.2]))
+    taps = lowpass(nt, fc)
     x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    if wide and rng.random() < 0.3: x *= np.float32(10 ** float(rng.uniform(-3, 3)))  # the stream's level
     start = -N
-    if rng.random() < 0.6:  # an interferer far outside the pass band, 20 .. 50 dB above the noise, from a random sample on
-        start = int(rng.integers(0, n)); amp = 10 ** (float(rng.uniform(20, 50)) / 20)
-        x[start:] += (amp * np.exp(2j * np.pi * 0.41 * np.arange(n - start))).astype(np.complex64)
+    if rng.random() < (0.75 if wide else 0.6):  # an interferer far outside the pass band, 20 .. 50 dB above the noise, from a random sample on
+        start = int(rng.integers(0, n)); amp = 10 ** (float(rng.uniform(-5 if wide else 20, 50)) / 20) * float(np.sqrt(np.mean(np.abs(x[:4096]) ** 2) / 2))
+        f_int = float(rng.uniform(min(0.45, fc + 2.0 / nt + 0.01), 0.49)) * (1 if rng.random() < 0.5 else -1) if wide else 0.41
+        stop = n if (not wide or rng.random() < 0.7) else min(n, start + int(rng.integers(100, 4 * N)))
+        x[start:stop] += (amp * np.exp(2j * np.pi * f_int * np.arange(stop - start))).astype(np.complex64)
+        if wide and rng.random() < 0.3:
+            x += (float(rng.uniform(0.3, 30)) * np.exp(2j * np.pi * float(rng.uniform(-0.49, 0.49)) * np.arange(n))).astype(np.complex64)  # a second tone anywhere, in or out of band
     ch = G.Chain(taps, N, win, capi.CHAIN_AUTO)
     cuts = sorted(set([0, frames] + [int(c) for c in rng.integers(0, frames, size=int(rng.integers(0, 4)))]))
     parts = [ch.process_bulk(torch.from_numpy(x[a * N:b * N]).cuda()).cpu().numpy() for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
@@ -53,6 +60,8 @@ while time.time() - t0 < secs:
     # the contract (include/gr4hip.h): 1e-5 of the output, or the reference's own float32 error where that is larger -- factor ONE
     if r > max(1e-5, r32):
         fails = globals().get("fails", 0) + 1
+        if len(sys.argv) > 4:  # dump the failing case for tools/dbg/fuzz_case.py
+            np.savez(f"{sys.argv[4]}_{fails}.npz", x=x, taps=taps, N=N, win=win, cuts=np.array(cuts), frames=frames)
         if fails <= 12:
             e = np.abs(got - truth) / np.maximum(truth, rms)
             fr = int(np.unravel_index(e.argmax(), e.shape)[0])
