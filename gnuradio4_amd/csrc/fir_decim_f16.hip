@@ -48,6 +48,15 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[2][KQ], const uns
     f32x4_h   c[TR], d[TR];
 #pragma unroll
     for (int j = 0; j < TR; ++j) c[j] = d[j] = f32x4_h{0.f, 0.f, 0.f, 0.f};
+#ifdef GR4_T_DH_MFMA32 // timing-only build (results are wrong; profiles/r06_decim_floor.txt): the products of two tile rows as ONE 32 x 32 x 16 instruction on the same operand
+                       // registers -- half the matrix instructions and operand reads for the same multiply-adds = the bound of a kernel re-tiled for 32 x 32 x 16
+    using f32x16_h = __attribute__((ext_vector_type(16))) float;
+    f32x16_h c32[(TR + 1) / 2], d32[(TR + 1) / 2];
+#pragma unroll
+    for (int j = 0; j < (TR + 1) / 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c32[j][e] = d32[j][e] = 0.f;
+#endif
     const int sb = 512 * col + 32 * KQ * wave + 8 * kq;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
@@ -60,6 +69,14 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[2][KQ], const uns
             const f16x8_h a1 = __builtin_bit_cast(f16x8_h, a[0][ks]), a2 = __builtin_bit_cast(f16x8_h, a[1][ks]);
 #ifdef GR4_T_DH_NOMFMA // timing-only builds (tools/ab_dh.sh, profiles/r05_decim_bounds.txt): the operand reads without the products
             asm volatile("" ::"v"(a1), "v"(a2), "v"(b1), "v"(b2));
+#elif defined(GR4_T_DH_MFMA32)
+            if ((tr & 1) == 0) {
+                c32[tr >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, c32[tr >> 1], 0, 0, 0);
+                d32[tr >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, d32[tr >> 1], 0, 0, 0);
+                d32[tr >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, d32[tr >> 1], 0, 0, 0);
+            } else {
+                asm volatile("" ::"v"(a1), "v"(a2)); // (the odd tile rows' tap fragments stay live: a re-tiled kernel holds as many)
+            }
 #else
             c[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c[tr], 0, 0, 0);
             d[tr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, d[tr], 0, 0, 0);
@@ -67,6 +84,12 @@ __device__ __forceinline__ void dh_contract(const u32x4_h (&a)[2][KQ], const uns
 #endif
         }
     }
+#ifdef GR4_T_DH_MFMA32
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { c[tr][e] = c32[tr >> 1][8 * (tr & 1) + e] + c32[tr >> 1][8 * (tr & 1) + 4 + e]; d[tr][e] = d32[tr >> 1][8 * (tr & 1) + e] + d32[tr >> 1][8 * (tr & 1) + 4 + e]; }
+#endif
 #pragma unroll
     for (int tr = 0; tr < TR; ++tr)
         *reinterpret_cast<float4*>(&part[wave][tr][lane][0]) =
