@@ -78,8 +78,8 @@ struct ChainFdArgs {
     unsigned      pw_mask; // 0: every frame is measured
     float         pw_thr; // kModeFir: a frame whose output power is below pw_thr x its input power marks the launch (word 33 of pw, word 3 of pw_host)
     int           no_tier; // the frames this launch marks go straight to the float64 evaluation (counted as such)
-    float         pw_c5i; // ... or when  sum_k |Y_k|^4  <  pw_c5i x (peak component of X)^4  -- see kGuardPeakMax
-    float         pw_c4;  // the |.|^2 modes (round 6): a frame is marked when  pw_c4 x sum_k |Y_k|^4  <  (sum_n |x_n|^2)^2  -- see kGuardR4Max
+    float         pw_c5i; // ... pw_c5i x (peak component of X)^2  -- see kGuardPeakMax
+    float         pw_c4;  // the |.|^2 modes (round 6): a frame is marked when  sqrt(sum_k |Y_k|^4)  <  pw_c4 x sum_n |x_n|^2 + ...  -- see kGuardR4Max
     unsigned char* fflags; // optional, one byte per frame (8192-sample block): non-zero = that frame fell below the threshold -- chain_redo_kernel, launched behind this
                            // kernel, evaluates exactly those frames again in the time domain (float64 products): the guard without the host
     // chain_redo_kernel only (0 = the fused kernel's own conventions):
@@ -108,12 +108,14 @@ constexpr float kTd16GuardRatio = 1.0f / 32.0f; // chain_td16_kernel leaves a fr
                                                 // white noise would pass, where the 22-bit products' error (~1.3e-7 rms of the products' level, its peaks 4 x that) reaches 6e-6 of |Y|^2 (chain.hip kChainPairGuardRatio)
 // Round 6: what a |.|^2 frame is judged on.  The fast convolution's error is K eps-sized relative to the INPUT's level per bin, the parity metric normalises by max(|truth_k|,
 // rms_k(truth)) with truth = |Y_k|^2 -- so the error shows as  K sqrt(R4),  R4 = w2 nf mean|x|^2 / rms_k(|Y_k|^2)  (the input's per-bin power over the rms of the OUTPUT mag2
-// spectrum; w2 = mean window^2, nf = fftSize), not as a function of the power ratio P_out / P_in: a 1 %-pass-band channel filter over wide-band noise (ratio 0.01, R4 = 7: error
-// 1.3e-6) is as accurate as a wide one, a tone 10 dB above the noise that the filter rejects (ratio 0.009, R4 = 25: 7e-6) is not.  Measured K = err / sqrt(R4) over rectangular /
-// Hann / Blackman-Harris / Kaiser frames of 256 .. 8192 points, 33 .. 256 taps, rejected tones 0 .. 60 dB above the noise (tools/dbg/fd_error_vs_statistic2.py): <= 1.3e-6 for
-// R4 <= 100, <= 2.7e-6 anywhere below R4 = 1e4.  Frames with R4 > 8 are marked (2.7e-6 sqrt(8) = 7.6e-6 < 1e-5).  Until round 6 the power ratio < 0.08 marked them: every frame
-// of every filter that passes less than 8 % of white noise (R4 = 2.4 .. 3), three times earlier than needed.
-constexpr float kGuardR4Max = 8.0f;
+// spectrum; w2 = mean window^2, nf = fftSize), not as a function of the power ratio P_out / P_in: a 1 %-pass-band channel filter over wide-band noise (ratio 0.008, R4 = 6 .. 13:
+// error 2.5e-6) is as accurate as a wide one.  Measured per frame with the guard off (tools/dbg/r4_threshold.py: 256 / 129 / 64 taps, cut-offs 0.0025 .. 0.015, rectangular /
+// Hann / Blackman-Harris, white noise alone and beside a wide-band neighbour 0 .. 24 dB stronger, steady and in bursts; 90 000 frames; frames the second statistic below marks
+// left out): K <= 1.1e-6 everywhere, worst error 3.3e-6 below R4 = 20, 4.8e-6 below 24, 5.3e-6 below 32.  The two statistics' errors add in power, so a frame is marked when
+// R4 / kGuardR4Max + T' / kGuardPeakMax > 1: at most max(1.1e-6 sqrt(20), 1.4e-7 sqrt(2000)) = 6.3e-6 on the boundary (white noise carries T' = 13 .. 20 R4: marked from R4 = 16.7).  (Lines -- a rejected tone -- reach
+// K = 2.7e-6 through the images of the transform: the second statistic's.)  Until round 6 the power ratio < 0.08 marked them: every frame of every filter that passes less
+// than 8 % of white noise (R4 = 2.4 .. 3), where nothing needed fixing.
+constexpr float kGuardR4Max = 20.0f;
 // The second condition (round 6, found by tools/fuzz_chain.py's wide mode): a float32 transform leaves IMAGES of a strong line -- rounding errors of c eps |X_peak|, c ~ 1.2, at the
 // bins N/2 (3N/4, 9N/16 ...: the last radix-16 pass) away from it.  Any float32 FFT has them; the reference's sits behind its filter, ours in front: a line the filter takes down
 // by 10 .. 30 dB (in its transition band, or a 2-tap average's single null) still dominates the output's rms, R4 is small, and the image lands in the pass band at full gain next
@@ -122,6 +124,10 @@ constexpr float kGuardR4Max = 8.0f;
 // [1/sqrt2, 1] of |X_peak|) and marks T' = 2 wg^2 peak^2 / rms > kGuardPeakMax, T <= T' <= 2 T: every frame with T >= 2000 (error past 6.3e-6) is marked.  White noise has
 // T' = 13 .. 20 R4 (<= 160 where R4 passes), a line IN the pass band ~ sqrt(N) / |H|^2: neither comes near.
 constexpr float kGuardPeakMax = 2000.0f;
+// fftSize < 8192: the kernel judges 8192-sample BLOCKS (its fast convolution's unit), the metric frames -- a frame shorter than the filter's memory can be 20 dB quieter than its
+// block (a 256-point frame behind a 256-tap filter at cut-off 0.0025: the wide fuzzer's 7.7e-6 at block R4 = 13), and a line that sets in late in a block is a smaller peak of the
+// block's transform than of its last frames'.  Tighter limits there (R4 at round 6's first, fuzz-validated setting): err / sqrt(T) reaches 2.7e-7 at 256 points.
+constexpr float kGuardR4MaxSmall = 8.0f, kGuardPeakMaxSmall = 600.0f;
 constexpr float kGuardFrameThreshold = 0.08f; // the guard's output / input power threshold (chain.hip, fir.hip), applied to every frame by itself inside the kernel
 constexpr int kMaxMulti = 16;
 struct ChainFdMulti {
@@ -464,7 +470,8 @@ __device__ __forceinline__ void chain_fd_body(ChainFdArgs& a, const ChainFdMulti
     constexpr bool Q4 = MODE != kModeFir; // judged on the fourth-moment statistic
     // the frame's verdict from its two workgroup sums: negative = marked (a sum that left float32's range marks too)
     // (sa: sum of |Y_k|^4, sb: input power, sk: peak component of the input spectrum -- the two conditions of kGuardR4Max / kGuardPeakMax)
-    const auto verdict = [&](float sa, float sb, float sk) { return Q4 ? ((sa < 3.0e38f) ? fminf(fmaf(sa, a.pw_c4, -sb * sb), fmaf(-(sk * sk) * (sk * sk), a.pw_c5i, sa)) : -1.f) : sa; };
+    // R4 / kGuardR4Max + T' / kGuardPeakMax > 1 (the two errors add in power):  sqrt(S4) < pw_c4 x S_in + pw_c5i x peak^2  (an overflow on the right marks; so does a sum on the left that left float32's range)
+    const auto verdict = [&](float sa, float sb, float sk) { return Q4 ? ((sa < 3.0e38f) ? __builtin_sqrtf(sa) - fmaf(sb, a.pw_c4, (sk * sk) * a.pw_c5i) : -1.f) : sa; };
     int   iter = 0;
     [[maybe_unused]] int fiter = 0; // frames this workgroup has finished (MULTI: an item is one channel of a frame)
 #pragma unroll
@@ -1764,12 +1771,13 @@ static int chain_fused_run(ChainFused* c, const float* d_in, const float* hist25
         a.pw_host = c->d_hpw;
         a.pw_seq  = c->pw_seq;
         a.pw_thr  = fir_mode ? kGuardFirFrameThreshold : kGuardFrameThreshold * (float)(c->small_log2n ? (1 << c->small_log2n) : kN) * c->win_gain; // (the scale chain_fused_power_ratio takes out)
-        {   // R4 = scale S_in / (sqrt(8192) sqrt(S4)), scale = nf w2 (sums over one 8192-sample block): marked when R4 > kGuardR4Max  <=>  S4 R4max^2 8192 / scale^2 < S_in^2
+        {   // R4 = scale S_in / (sqrt(8192) sqrt(S4)), scale = nf w2 (sums over one 8192-sample block); marked when R4 / kGuardR4Max + T' / kGuardPeakMax > 1
             const double scale = (double)(c->small_log2n ? (1 << c->small_log2n) : kN) * (double)c->win_gain;
-            a.pw_c4 = (float)((double)kGuardR4Max * kGuardR4Max * (double)kN / (scale * scale));
+            const double r4max = c->small_log2n ? kGuardR4MaxSmall : kGuardR4Max, tmax = c->small_log2n ? kGuardPeakMaxSmall : kGuardPeakMax;
+            a.pw_c4 = (float)(scale / (std::sqrt((double)kN) * r4max)); // R4 / R4max = pw_c4 S_in / sqrt(S4)
             // T' = 2 wg^2 (peak nf / 8192)^2 / sqrt(S4 / 8192) > Tmax  <=>  S4 < peak^4 x 4 wg^4 nf^4 / (Tmax^2 8192^3)   (peak: of the 8192-point X of the block)
             const double nfr = (double)(c->small_log2n ? (1 << c->small_log2n) : kN) / (double)kN, wg2 = (double)c->win_mean * c->win_mean;
-            a.pw_c5i = (float)(4.0 * wg2 * wg2 * nfr * nfr * nfr * nfr * (double)kN / ((double)kGuardPeakMax * kGuardPeakMax));
+            a.pw_c5i = (float)(2.0 * wg2 * nfr * nfr * std::sqrt((double)kN) / tmax); // T' / Tmax = pw_c5i peak^2 / sqrt(S4)
             a.no_tier = (c->td16 && c->small_log2n == 0) ? 0 : 1; // (second_evaluations: chain_td16_kernel first, where the taps have an f16 table and the frames 8192 points)
         }
         if (c->redo && !fir_mode) {
@@ -1931,8 +1939,8 @@ int chain_fused_process_multi(ChainFused* const* cs, size_t n, bool shared_taps,
     }
     if (fold) { a.pw = m.pws[0]; a.pw_host = m.pw_hosts[0]; a.pw_seq = m.pw_seqs[0]; a.fflags = m.fflags[0]; }
     a.pw_thr = kGuardFrameThreshold * (float)kN; // (8192-point rectangular-window chains only: window gain 1)
-    a.pw_c4  = kGuardR4Max * kGuardR4Max / (float)kN;
-    a.pw_c5i = 4.0f * (float)kN / (kGuardPeakMax * kGuardPeakMax);
+    a.pw_c4  = std::sqrt((float)kN) / kGuardR4Max;
+    a.pw_c5i = 2.0f * std::sqrt((float)kN) / kGuardPeakMax;
     a.no_tier = 1; // (the multi launch's marked frames go to chain_redo_kernel / chain_redo_fold_kernel)
     constexpr size_t lds = (size_t)kLdsEbfBytes + kGvBytes; // = lds_ebf of chain_fused_run
     static PerDevice per_device;

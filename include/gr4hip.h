@@ -346,11 +346,12 @@ int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
 /* Dynamic-range guard of GR4HIP_CHAIN_AUTO.  The fused kernels filter in the frequency domain and carry the float32 rounding of their transforms, which is sized by the
  * frame's INPUT, while the parity bar (1e-5 of max(|Y_k|^2, rms_k |Y_k|^2)) is sized by its OUTPUT.  Every fused launch of an AUTO chain therefore judges EVERY frame (all of its
  * samples and bins) on two statistics (round 6; chain_fused.hip kGuardR4Max / kGuardPeakMax have the measurements):
- *   R4 = w2 nf mean|x|^2 / rms_k |Y_k|^2 > 8     the spread error, K sqrt(R4) with K <= 2.7e-6: wide-band input the filter removes most of (a 1 %-pass-band filter over white
- *                                                noise has R4 = 6 .. 13, a 4 % one 3 .. 5), or a rejected interferer;
- *   T' = 2 wg^2 peak(X)^2 / rms_k |Y_k|^2 > 2000  the images a float32 transform leaves of a strong line (1.2 eps of it, half a transform away): a line the filter takes down by
- *                                                10 .. 30 dB that still dominates the output.
- * (Until round 6 the test was output / input power < 0.08, which marked every frame of every narrow filter -- three times earlier than needed -- and missed the second case.)
+ *   R4 = w2 nf mean|x|^2 / rms_k |Y_k|^2          the spread error, K sqrt(R4) with K <= 1.1e-6 on noise-like input: wide-band input the filter removes most of (a 1 %-pass-band
+ *                                                filter over white noise has R4 = 6 .. 13, a 4 % one 3 .. 5, a wide-band neighbour 20 dB up ~50);
+ *   T' = 2 wg^2 peak(X)^2 / rms_k |Y_k|^2         the images a float32 transform leaves of a strong line (1.2 eps of it, half a transform away): a line the filter takes down by
+ *                                                10 dB or more that still dominates the output, error <= 1.4e-7 sqrt(T');
+ * a frame is marked when R4 / 20 + T' / 2000 > 1 (the errors add in power: <= 6.3e-6 on the boundary; fftSize < 8192, judged per 8192-sample block: R4 / 8 + T' / 600).
+ * (Until round 6 the test was output / input power < 0.08, which marked every frame of every narrow filter where nothing needed fixing, and missed the second case.)
  * What happens with the verdicts is the handle's guard mode (gr4hip_chain_set_guard_mode below; default STRICT: the frames a launch marks are evaluated again in the time domain
  * by launches enqueued behind it -- on the f16 matrix pipe where that agrees with the fused result, in float64 where it does not -- and a stream in which more than a tenth of
  * all frames end in float64 moves to the direct-form kernels, history handed over, where it stays until gr4hip_chain_reset).  Explicit GR4HIP_CHAIN_FUSED_FD never measures nor

@@ -1749,15 +1749,43 @@ def test_chain_every_frame_marked_meets_the_bar(G):
         assert _rel(cg.process_bulk(dev(loud)).cpu().numpy().ravel(), tw) <= TOL, window
 
 
+@pytest.mark.parametrize("window,wid", [("None", 0), ("Hann", 3)])
+def test_chain_guard_judges_frames_on_what_the_error_depends_on(G, window, wid):
+    """round 6: the guard's two statistics (include/gr4hip.h, chain_fused.hip kGuardR4Max / kGuardPeakMax).  (1) A 1 %-pass-band channel filter over wide-band noise ALONE
+    (output / input power 0.008: every frame marked until round 6) has R4 = 6 .. 13 of 20 (a frame in forty goes over under the Hann window): not marked, the fused launch alone meets the bar.  (2) The same noise beside
+    a wide-band neighbour 20 dB stronger outside the pass band: R4 ~ 50, every frame marked, evaluated again behind the launch.  (3) A line the filter only dents -- a 2-tap
+    average over noise + a tone near fs / 2, 20 dB down at the output but still its strongest component (the wide fuzzer's case: the transform's image of the line lands in the
+    pass band; output / input power 0.15, R4 = 1.9, never marked by either earlier test): marked by the line statistic."""
+    N, frames = 8192, 40
+    n = frames * N
+    rng = np.random.default_rng(77)
+    noise = O.signal_c32(31, n, tone_amp=0.0)
+    b = O.design_taps_hamming_lowpass(256, 0.005)
+    v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    V = np.fft.fft(v); V[np.abs(np.fft.fftfreq(n) - 0.3) > 0.05] = 0
+    v = np.fft.ifft(V); v *= 10.0 * np.sqrt(np.mean(np.abs(noise) ** 2) / np.mean(np.abs(v) ** 2))
+    k = np.arange(n)
+    cases = ((b, noise, 0.0, 0.1), (b, (noise + v).astype(np.complex64), 1.0, 1.0),
+             (np.array([0.5, 0.5], np.float32), (noise + 1.7 * np.sqrt(np.mean(np.abs(noise) ** 2)) * np.exp(2j * np.pi * 0.5326 * k)).astype(np.complex64), 1.0, 1.0))
+    for taps, x, lo, hi in cases:
+        truth, _ = O.chain(taps, x, N, wid, truth=True)
+        ch = G.Chain(taps, N, window)
+        assert ch.algo == G.capi.CHAIN_FUSED_FD
+        got = ch.process_bulk(dev(x)).cpu().numpy().ravel()
+        marked, f64 = ch.last_guard_fractions()
+        assert lo <= marked <= hi, (len(taps), marked)
+        assert _rel(got, truth) <= TOL, (len(taps), marked, f64)
+
+
 @pytest.mark.parametrize("N,ntaps,window,wid,fc,amp,f0", [(8192, 256, "None", 0, 0.005, 1.0, 0.1), (8192, 256, "Hann", 3, 0.005, 1.0, 0.1), (8192, 129, "Kaiser", 11, 0.01, 0.0, 0.1),
                                                        (1024, 200, "Hamming", 2, 0.005, 1.0, 0.1), (256, 100, "BlackmanHarris", 7, 0.004, 3.0, 0.2), (4096, 256, "None", 0, 0.008, 0.5, 0.3),
                                                        (8192, 256, "None", 0, 0.02, 300.0, 0.31), (8192, 256, "Hann", 3, 0.02, 30.0, 0.31), (2048, 77, "Hann", 3, 0.02, 1000.0, 0.4)])
 def test_chain_marked_frames_on_the_f16_pipe_then_float64(G, N, ntaps, window, wid, fc, amp, f0):
-    """round 6: the frames a fused launch marks (fourth-moment statistic R4 > 8 or a dominant line the filter only dents: the fast convolution's error, sized by the INPUT, would
+    """round 6: the frames a fused launch marks (fourth-moment statistic and line statistic, R4 / 20 + T' / 2000 > 1: the fast convolution's error, sized by the INPUT, would
     show) are evaluated again by chain_td16_kernel at 8192 points -- filter on the f16 matrix pipe (22-bit products under one block exponent per frame), window, one transform
     from LDS, stored where it agrees with the fused result in every bin -- and what that leaves (the loud rejected tones of the last three cases; every marked frame at
     fftSize < 8192) by chain_redo_kernel's float64 products behind it.  A stream in which more than a tenth of the frames end in float64 moves to the time-domain kernel pair.
-    A narrow channel filter over wide-band noise (every frame marked, none in float64: the stream stays), all windows' code paths (8192 rectangular / windowed, fftSize < 8192),
+    A narrow channel filter removing a tone at the noise's level (every frame marked, none in float64: the stream stays), all windows' code paths (8192 rectangular / windowed, fftSize < 8192),
     ragged calls, the call after the stream has moved: all against the float64 oracle at the contract's bar"""
     b = O.design_taps_hamming_lowpass(ntaps, fc)
     n = 21 * 8192

@@ -67,5 +67,13 @@ while time.time() - t0 < secs:
             fr = int(np.unravel_index(e.argmax(), e.shape)[0])
             p_in = float(np.mean(np.abs(x.reshape(frames, N)[fr].astype(np.complex128)) ** 2)); p_out = float(truth[fr].sum() / (N * N * np.mean(w * w if win != "None" else 1.0)))
             print("FAIL", f"N={N} taps={nt} win={win} frames={frames} cuts={cuts} ratio={ratio} worst frame {fr} (its own output / input power {p_out / p_in:.4g}; interferer from sample {locals().get('start', -1) / N:.3f} frames)", r, "reference float32 FIR:", r32, flush=True)
+    elif r > 6e-6 and globals().get("nears", 0) < 12:  # inside the bar but close: which tier answered, and what the guard's two statistics say about the frame
+        nears = globals().get("nears", 0) + 1
+        e = np.abs(got - truth) / np.maximum(truth, rms)
+        fr = int(np.unravel_index(e.argmax(), e.shape)[0])
+        xf = x.reshape(frames, N)[fr].astype(np.complex128); X = np.fft.fft(xf)
+        w2_, wg_ = (float(np.mean(w * w)), float(np.mean(w))) if win != "None" else (1.0, 1.0)
+        r4 = w2_ * N * float(np.mean(np.abs(xf) ** 2)) / float(rms[fr, 0]); tp = 2 * wg_ ** 2 * float(max(np.abs(X.real).max(), np.abs(X.imag).max())) ** 2 / float(rms[fr, 0])
+        print("NEAR", f"N={N} taps={nt} fc={fc} win={win} frames={frames} cuts={cuts} moved={td} worst frame {fr}: err {r:.3g} (reference float32 FIR {r32:.3g}) R4 {r4:.3g} T' {tp:.4g} -> R4/20 + T'/2000 = {r4 / 20 + tp / 2000:.3g}; interferer from frame {locals().get('start', -1) / N:.2f}", flush=True)
     worst_excess = max(globals().get("worst_excess", 0.0), r - max(1e-5, r32))
 print(f"{cases} cases in {time.time() - t0:.0f} s ({switched} ended on the time-domain kernels), {globals().get('fails', 0)} above max(1e-5, the reference's float32 error), worst relative error of |Y|^2 {worst:.3g}, worst excess over the bar {globals().get('worst_excess', 0.0):.3g}")
