@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """developer tool: random chain configurations (taps, fft size, window, call boundaries, an out-of-band interferer switched on somewhere in the stream, guard strict)
 against float64 numpy (lfilter -> window -> fft -> |.|^2).  usage: fuzz_chain.py [seconds = 120] [seed = 0]"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
 from scipy.signal import lfilter, get_window
@@ -17,6 +17,8 @@ def lowpass(nt, fc):
 t0 = time.time(); cases = 0; worst = 0.0; switched = 0
 while time.time() - t0 < secs:
     N = int(2 ** rng.integers(8, 14)); nt = int(rng.choice([2, 17, 64, 65, 100, 200, 256]))
+    if os.environ.get("FUZZ_N"): N = int(rng.choice([int(v) for v in os.environ["FUZZ_N"].split(",")]))        # e.g. FUZZ_N=16384,1000 FUZZ_TAPS=17,65,300: the shapes CHAIN_AUTO serves with the kernel pair
+    if os.environ.get("FUZZ_TAPS"): nt = int(rng.choice([int(v) for v in os.environ["FUZZ_TAPS"].split(",")]))
     win = str(rng.choice(["None", "Hann", "Hamming", "BlackmanHarris"]))
     frames = int(rng.integers(20, 400)) if N >= 2048 else int(rng.integers(100, 3000))
     n = frames * N
