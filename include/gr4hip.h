@@ -361,13 +361,14 @@ int gr4hip_chain_get_algo(const gr4hip_chain_t* chain, int* algo_in_use);
 int gr4hip_chain_last_power_ratio(gr4hip_chain_t* chain, float* ratio, int* time_domain, gr4hip_stream_t stream);
 int gr4hip_chain_last_guard_fractions(gr4hip_chain_t* chain, float* marked, float* float64, gr4hip_stream_t stream);
 /* What the guard does with its measurement (per handle; GR4HIP_CHAIN_AUTO chains on the fused frequency-domain kernel only, a no-op elsewhere):
- *   GR4HIP_GUARD_STRICT (default): nothing out of tolerance is ever handed out, and nobody waits.  The fused kernel writes one verdict byte per frame; chain_redo_kernel,
- *     enqueued behind it on the same stream, evaluates exactly the marked frames again -- y = sum b[k] x[n - k] on the FP64 matrix pipe, window, frame transform,
- *     |.|^2 over the fused result (an ordinary stream costs one near-empty launch, ~5 us).  gr4hip_chain_process returns when both launches are queued ("user code
- *     must not block in work()", docs/USER_API_advanced_work.md).  The measurement of an EARLIER launch, once it has arrived, moves a stream that rejects most of its
- *     input to the direct-form kernels for good (the faster way through such a stream) -- read without waiting.  Several chains in one call
+ *   GR4HIP_GUARD_STRICT (default): nothing out of tolerance is ever handed out, and nobody waits.  The fused kernel writes one verdict byte per frame; chain_td16_kernel
+ *     (8192-point frames: the filter with 22-bit products on the f16 matrix pipe, window, frame transform; stored where it agrees with the fused result in every bin)
+ *     and chain_redo_kernel (what that leaves: y = sum b[k] x[n - k] on the FP64 matrix pipe, window, frame transform, |.|^2 over the fused result), enqueued behind it
+ *     on the same stream, evaluate exactly the marked frames again (an ordinary stream costs two near-empty launches, ~5 us each).  gr4hip_chain_process returns when
+ *     the launches are queued ("user code must not block in work()", docs/USER_API_advanced_work.md).  The counts of EARLIER launches, once they have arrived, move a
+ *     stream in which more than a tenth of all frames ended in float64 to the direct-form kernels for good -- read without waiting.  Several chains in one call
  *     (gr4hip_chain_process_multi) work the same way: per-channel verdict bytes and one chain_redo_kernel per channel, or -- the fold -- a frame marked when ANY
- *     channel's share of it fell below the threshold and chain_redo_fold_kernel, which evaluates every channel of a marked frame again and keeps the sum in registers.
+ *     channel's share of it is and chain_redo_fold_kernel, which evaluates every channel of a marked frame again and keeps the sum in registers.
  *   GR4HIP_GUARD_DEFERRED: calls stay asynchronous.  The first call after create / reset probes its first 8 blocks synchronously; later calls read the finished
  *     measurements of EARLIER launches, so the call in which a strong out-of-band signal first appears is published from the fused kernel (error floor
  *     ~2e-6 of the input rms) and the switch happens from the next call on.
