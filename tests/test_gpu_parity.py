@@ -1777,6 +1777,23 @@ def test_chain_guard_judges_frames_on_what_the_error_depends_on(G, window, wid):
         assert _rel(got, truth) <= TOL, (len(taps), marked, f64)
 
 
+@pytest.mark.parametrize("level", [1e-17, 1e-12, 1e9, 1e12])
+def test_chain_guard_at_extreme_stream_levels(G, level):
+    """the guard's statistic sums fourth powers: beyond samples of ~3e7 (or below ~1e-12 .. 1e-17) sum |Y_k|^4 leaves float32's range and nothing can be judged -- such frames are
+    marked wholesale and evaluated again behind the launch (a sum of 0 or Inf marks): the bar holds at every level float32 can carry the spectrum at"""
+    N, frames = 8192, 12
+    b = O.design_taps_hamming_lowpass(256, 0.02)
+    x = (O.signal_c32(14, frames * N, tone_frel=0.31, tone_amp=3.0).astype(np.complex128) * level).astype(np.complex64)
+    for window, wid in (("None", 0), ("Hann", 3)):
+        truth, _ = O.chain(b, x, N, wid, truth=True)
+        ch = G.Chain(b, N, window)
+        got = ch.process_bulk(dev(x)).cpu().numpy().ravel()
+        marked, f64 = ch.last_guard_fractions()
+        assert _rel(got, truth) <= TOL, (window, marked, f64)
+        if level >= 1e9 or level <= 1e-17:
+            assert marked == 1.0
+
+
 @pytest.mark.parametrize("N,ntaps,window,wid,fc,amp,f0", [(8192, 256, "None", 0, 0.005, 1.0, 0.1), (8192, 256, "Hann", 3, 0.005, 1.0, 0.1), (8192, 129, "Kaiser", 11, 0.01, 0.0, 0.1),
                                                        (1024, 200, "Hamming", 2, 0.005, 1.0, 0.1), (256, 100, "BlackmanHarris", 7, 0.004, 3.0, 0.2), (4096, 256, "None", 0, 0.008, 0.5, 0.3),
                                                        (8192, 256, "None", 0, 0.02, 300.0, 0.31), (8192, 256, "Hann", 3, 0.02, 30.0, 0.31), (2048, 77, "Hann", 3, 0.02, 1000.0, 0.4)])
