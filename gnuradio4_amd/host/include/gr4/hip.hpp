@@ -47,9 +47,9 @@ struct Options {
     // the drift of the reference's float accumulator (beyond 1e-5 of the CPU block's own output after ~10^3 .. 10^5 samples).  true = the reference's float
     // recurrence itself, bit-identical to the block on the host (a sequential walk: far slower; include/gr4hip.h, gr4hip_rotator_set_algo).
     bool rotator_reference_recurrence = false;
-    // Dynamic-range guard of the frequency-domain kernels (fused chain, long complex FIR spans, decimate-by-8 FIR): GR4HIP_GUARD_STRICT (default: a span whose
-    // measured output / input power falls below the threshold is redone in the time domain before the stage's enqueue returns -- the enqueue then waits for its own
-    // launch), GR4HIP_GUARD_DEFERRED (enqueues stay asynchronous, the switch lags by one chunk) or GR4HIP_GUARD_OFF (include/gr4hip.h)
+    // Dynamic-range guard of the frequency-domain kernels (fused chain, long complex FIR spans, decimate-by-8 FIR): GR4HIP_GUARD_STRICT (default: the frames /
+    // segments a launch marks are evaluated again in the time domain by launches enqueued behind it on the same stream -- nobody waits, since round 5),
+    // GR4HIP_GUARD_DEFERRED (enqueues stay asynchronous, the switch lags by one chunk) or GR4HIP_GUARD_OFF (include/gr4hip.h)
     int guard_mode = GR4HIP_GUARD_STRICT;
     // A sharded graph's exchange (FanInRun) waits for other ranks: seconds one exchange may take before the run gives up with a rank-tagged message and
     // work::Status::ERROR instead of hanging its process (a peer that died or never joined); <= 0: wait for ever
