@@ -116,7 +116,13 @@ int gr4hip_chain_create(gr4hip_chain_t** out, const float* h_taps, size_t ntaps,
     int rc;
     if (use == GR4HIP_CHAIN_UNFUSED || use == GR4HIP_CHAIN_TIME_DOMAIN) {
         rc = gr4hip_fir_create(&c->fir, GR4HIP_C32, h_taps, ntaps, 1);
-        if (!rc && use == GR4HIP_CHAIN_TIME_DOMAIN) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN_F32); // "the reference's own arithmetic": float32 products
+        // float32 PRODUCTS for both (round 6's last day; until then GR4HIP_CHAIN_UNFUSED -- what GR4HIP_CHAIN_AUTO takes at fft sizes beyond 8192, other than powers of two, or
+        // past 256 taps -- ran the two-term f16 direct form under its two power verdicts).  A power statistic cannot see what the transform behind the filter does with the 22-bit
+        // products' error: it is COHERENT on a tone (its residue behind the filter is off by up to 2^-22 sum|b| / |H(f)| of itself), and the transform gathers it into the one bin
+        // where the metric looks.  tools/dbg/pair_coherent.py -- 65 taps, a tone 15 dB above the noise removed by ~60 dB, 16384 points: 28 of 2 400 streams at 1.0 .. 4.2e-5, the
+        // reference's float32 sum at 6e-7.  fir_filter by itself keeps the f16 kernels: its metric is the time-domain sample against the output's rms, where that error is 1e-6.
+        // (Measured instead: the f16 kernels with EVERY segment evaluated again in float64 behind them -- 27 Gsamples/s at 256 taps x 16384 points against 44 on float32 products.)
+        if (!rc) rc = gr4hip_fir_set_algo(c->fir, GR4HIP_FIR_TIME_DOMAIN_F32);
         if (!rc) rc = gr4hip_internal_fir_set_guard_ratio(c->fir, kChainPairGuardRatio);
         if (!rc) rc = gr4hip_fft_create(&c->fft, GR4HIP_C32, fft_size, window, 0);
     } else if (use == GR4HIP_CHAIN_FUSED_TD) {

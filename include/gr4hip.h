@@ -97,7 +97,10 @@ enum { /* FFT block output options (blocks/fourier/.../fft.hpp:103-105) */
 
 typedef enum { /* how the FIR->FFT->mag2 chain is executed */
     GR4HIP_CHAIN_AUTO = 0,
-    GR4HIP_CHAIN_UNFUSED,  /* fir kernel -> HBM -> fft+mag2 kernel (any window, any size the FFT block supports) */
+    GR4HIP_CHAIN_UNFUSED,  /* fir kernel -> HBM -> fft+mag2 kernel (any window, any size the FFT block supports: what AUTO takes beyond 8192 points, at sizes that are no power of two
+                              and past 256 taps).  Since round 6 the filter runs on float32 products here too (= GR4HIP_CHAIN_TIME_DOMAIN): the 22-bit products of the f16 direct form err
+                              COHERENTLY on a tone, and the transform behind the filter gathers that into one bin -- up to 4e-5 of |Y|^2 where a tone 15 dB above the noise is removed by
+                              60 dB (tools/dbg/pair_coherent.py), which no power statistic of the filter can see.  44 Gsamples/s at 256 taps x 16384 points (130 on the f16 form) */
     GR4HIP_CHAIN_FUSED_TD, /* one launch: direct-form FIR on the matrix pipe -> window -> FFT -> mag2 (fft_size 256 .. 4096, <= 256 taps); AUTO takes it for <= 64 taps */
     GR4HIP_CHAIN_FUSED_FD, /* one launch, frequency-domain FIR (circular convolution + exact tail correction) + FFT + mag2;
                               fft_size 256 ... 8192 (power of two), <= 256 taps, any window */

@@ -1777,6 +1777,32 @@ def test_chain_guard_judges_frames_on_what_the_error_depends_on(G, window, wid):
         assert _rel(got, truth) <= TOL, (len(taps), marked, f64)
 
 
+def test_chain_kernel_pair_under_a_removed_tone(G):
+    """fft sizes beyond 8192 (CHAIN_AUTO -> the kernel pair: FIR kernel -> HBM -> FFT kernel): a tone 15 dB above the noise that a 65-tap filter removes by ~60 dB leaves a
+    residue at the level of the output spectrum's rms.  The two-term f16 direct form's 22-bit products err coherently on the tone and the transform gathers that into the
+    residue's bin: 1.0 .. 4.2e-5 in ~1 % of such streams until round 6's last day (tools/dbg/pair_coherent.py), where the reference's float32 sum is at 6e-7.  The pair's
+    filter runs on float32 products since: inside the bar, or inside the reference's own float32 error -- factor ONE"""
+    N, frames = 16384, 6
+    n = frames * N
+    b = O.design_taps_hamming_lowpass(65, 0.05)
+    rng = np.random.default_rng(12)
+    H = np.abs(np.fft.fft(b.astype(np.float64), 65536))
+    worst = 0.0
+    for trial in range(24):
+        f0 = float(rng.uniform(0.11, 0.18)); amp = float(rng.uniform(5.0, 7.0))
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n) + amp * np.exp(2j * np.pi * (f0 * np.arange(n) + rng.random()))).astype(np.complex64)
+        truth, _ = O.chain(b, x, N, 0, truth=True)
+        ch = G.Chain(b, N, "None")
+        assert ch.algo == G.capi.CHAIN_UNFUSED
+        got = ch.process_bulk(dev(x)).cpu().numpy().ravel()
+        y32 = O.fir(b, x, acc64=False)[0].reshape(frames, N)
+        t32 = (np.abs(np.fft.fft(y32.astype(np.complex128), axis=1)) ** 2).ravel()
+        e, e32 = _rel(got, truth), _rel(t32, truth)
+        assert e <= max(TOL, e32), (trial, f0, amp, e, e32)
+        worst = max(worst, e)
+    assert worst <= 5e-6, worst  # (measured 1.4e-6; the f16 form reached 4e-5)
+
+
 @pytest.mark.parametrize("level", [1e-17, 1e-12, 1e9, 1e12])
 def test_chain_guard_at_extreme_stream_levels(G, level):
     """the guard's statistic sums fourth powers: beyond samples of ~3e7 (or below ~1e-12 .. 1e-17) sum |Y_k|^4 leaves float32's range and nothing can be judged -- such frames are
