@@ -364,7 +364,10 @@ bool fir_decim_f16_make_table(const float* taps, size_t ntaps, size_t D, int* KQ
                     }
     unsigned short* hd   = tab->data() + dh_frag_units(KQ);
     const int       nt   = (int)ntaps;
-    const float     gthr = (float)(h2 / 128.0); // P_y D < 2^-7 (sum b^2) P_x: 21 dB more rejected than white noise would lose (fir.hip, kGuardSegmentRatio)
+    // P_y D < 2^-6 (sum b^2) P_x: 18 dB more rejected than white noise would lose.  (2^-7 -- fir.hip's kGuardSegmentRatio -- until round 6's last day: the 22-bit products' error is
+    // coherent on a tone, and a tone in the transition band of a long decimating filter, 18 .. 21 dB above what passes, left 7.9 / 9.4e-6 of the output's rms at decimation 8 / 16 in
+    // 1 300 targeted streams, tools/dbg/fir_coherent.py: inside the bar, too close to it.  3 dB earlier: a factor 1.4 on that error.)
+    const float     gthr = (float)(h2 / 64.0);
     std::memcpy(hd, &inv_t, 4);
     std::memcpy(hd + 2, &nt, 4);
     std::memcpy(hd + 4, &gthr, 4);

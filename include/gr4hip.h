@@ -204,7 +204,7 @@ int gr4hip_fir_reset(gr4hip_fir_t* fir);
  * ordinary input the error against float64 is that of a float32 sum (3e-7 .. 6e-7).  The error is relative to the PRODUCTS, so it shows against the OUTPUT when the
  * filter removes nearly all it is given -- like the reference's own float32 sum, whatever its order.  ONE guard for every kernel gr4hip_fir_process can take (round 5):
  * each segment's output power P_y is compared with its input power P_x, and a segment with D P_y < (sum b^2 / 128) P_x (21 dB more rejected than white noise would lose;
- * the split products are then at <= 6e-6 of the output) is marked and evaluated again with float64 products and sums, rounded once -- by fir_exact_kernel on the FP64
+ * the split products are then at <= 6e-6 of the output; the f16 decimators mark at sum b^2 / 64 since round 6: a tone in a long filter's transition band left 9e-6) is marked and evaluated again with float64 products and sums, rounded once -- by fir_exact_kernel on the FP64
  * matrix pipe behind the launch (same stream, no host), inside the workgroup for the register-window kernel, with the filter's load / store programs applied where it
  * carries any.  Result: within 1e-5 of float64 on every stream tools/tone_ratio.py, tools/fuzz_fir_f16.py and the tests could construct (rejected tones up to 70 dB
  * above what passes: 6e-8), where the reference's float32 sum itself is at 1e-5 .. 1e-3.  A stream in which EVERY segment is marked runs at the FP64 matrix pipe's
